@@ -1,0 +1,202 @@
+"""ctypes binding of the CPU parity oracle (oracle/oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product package never imports this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+c_int = ctypes.c_int
+c_i32 = ctypes.c_int32
+c_dbl = ctypes.c_double
+c_flt = ctypes.c_float
+P = ctypes.c_void_p
+
+
+def build(force=False):
+    """Compile oracle.c with the committed Makefile (gcc only)."""
+    src = os.path.join(_HERE, "oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(
+        os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "oracle.h"))
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "clean", "all"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(P) if a is not None else None
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def dcsrmv(kid, base, alpha, m, nnz, val, col, row, x, beta, y, nthreads=0):
+    """y <- alpha*A*x + beta*y with the reference's dispatch rule; returns (status, y)."""
+    val, col, row, x = _f64(val), _i32(col), _i32(row), _f64(x)
+    y = _f64(y).copy()
+    L = lib()
+    if nthreads and nthreads > 0:
+        st = L.orc_dcsrmv_omp(c_int(kid), c_int(base), c_dbl(alpha), c_i32(m), c_i32(nnz), _p(val),
+                              _p(col), _p(row), _p(x), c_dbl(beta), _p(y), c_int(nthreads))
+    else:
+        st = L.orc_dcsrmv(c_int(kid), c_int(base), c_dbl(alpha), c_i32(m), c_i32(nnz), _p(val),
+                          _p(col), _p(row), _p(x), c_dbl(beta), _p(y))
+    return st, y
+
+
+def dcsrmv_order(order, base, alpha, m, val, col, row, x, beta, y):
+    """order in {'ref','lane4','lane8'}: one specific reference kernel."""
+    fn = {"ref": "orc_dcsrmv_ref", "lane4": "orc_dcsrmv_lane4", "lane8": "orc_dcsrmv_lane8"}[order]
+    val, col, row, x = _f64(val), _i32(col), _i32(row), _f64(x)
+    y = _f64(y).copy()
+    st = getattr(lib(), fn)(c_int(base), c_dbl(alpha), c_i32(m), _p(val), _p(col), _p(row), _p(x),
+                            c_dbl(beta), _p(y))
+    return st, y
+
+
+def scsrmv(order, base, alpha, m, val, col, row, x, beta, y):
+    fn = {"ref": "orc_scsrmv_ref", "lane8": "orc_scsrmv_lane8"}[order]
+    val, col, row, x = _f32(val), _i32(col), _i32(row), _f32(x)
+    y = _f32(y).copy()
+    st = getattr(lib(), fn)(c_int(base), c_flt(alpha), c_i32(m), _p(val), _p(col), _p(row), _p(x),
+                            c_flt(beta), _p(y))
+    return st, y
+
+
+def dcsrmvt(base, alpha, m, n, val, col, row, x, beta, y):
+    val, col, row, x = _f64(val), _i32(col), _i32(row), _f64(x)
+    y = _f64(y).copy()
+    st = lib().orc_dcsrmvt(c_int(base), c_dbl(alpha), c_i32(m), c_i32(n), _p(val), _p(col), _p(row),
+                           _p(x), c_dbl(beta), _p(y))
+    return st, y
+
+
+def max_threads():
+    return int(lib().orc_max_threads())
+
+
+def dtrsv(kind, alpha, m, base, a, icol, ilrow, ilend, b, unit, incb=1, incx=1, x0=None):
+    """kind in {'l','lt','u','ut'}; ilend = idiag (l, lt) or iurow (u, ut)."""
+    a, icol, ilrow, ilend, b = _f64(a), _i32(icol), _i32(ilrow), _i32(ilend), _f64(b)
+    x = np.zeros(max(1, (m - 1) * incx + 1), dtype=np.float64) if x0 is None else _f64(x0).copy()
+    fn = getattr(lib(), "orc_dtrsv_" + kind)
+    st = fn(c_dbl(alpha), c_i32(m), c_int(base), _p(a), _p(icol), _p(ilrow), _p(ilend), _p(b),
+            c_i32(incb), _p(x), c_i32(incx), c_int(1 if unit else 0))
+    return st, x
+
+
+def dcsrmm(order, alpha, base, val, col, row, m, B, n, ldb, beta, C, ldc):
+    """order: 'row' or 'col' (the two reference kernels)."""
+    val, col, row, B = _f64(val), _i32(col), _i32(row), _f64(B)
+    C = _f64(C).copy()
+    fn = lib().orc_dcsrmm_row if order == "row" else lib().orc_dcsrmm_col
+    st = fn(c_dbl(alpha), c_int(base), _p(val), _p(col), _p(row), c_i32(m), _p(B), c_i32(n),
+            c_i32(ldb), c_dbl(beta), _p(C), c_i32(ldc))
+    return st, C
+
+
+def dscale_dense(order, C, m, n, ld, beta):
+    C = _f64(C).copy()
+    st = lib().orc_dscale_dense(c_int(1 if order == "col" else 0), _p(C), c_i32(m), c_i32(n),
+                                c_i32(ld), c_dbl(beta))
+    return st, C
+
+
+def mat_check(maj, mind, nnz, ptr, ind, val, shape, base):
+    ptr, ind, val = _i32(ptr), _i32(ind), _f64(val)
+    sort, fd = c_int(0), c_int(0)
+    st = lib().orc_mat_check(c_i32(maj), c_i32(mind), c_i32(nnz), _p(ptr), _p(ind), _p(val),
+                             c_int(shape), c_int(base), ctypes.byref(sort), ctypes.byref(fd))
+    return st, sort.value, bool(fd.value)
+
+
+def csr_indices(m, base, ptr, ind):
+    ptr, ind = _i32(ptr), _i32(ind)
+    idiag = np.zeros(max(m, 1), dtype=np.int32)
+    iurow = np.zeros(max(m, 1), dtype=np.int32)
+    st = lib().orc_csr_indices(c_i32(m), c_int(base), _p(ptr), _p(ind), _p(idiag), _p(iurow))
+    return st, idiag[:m], iurow[:m]
+
+
+def dcsr_optimize(m, n, nnz, base, ptr, ind, val):
+    """Returns dict(status, ptr, ind, val, idiag, iurow, is_internal, fulldiag, base)."""
+    ptr, ind, val = _i32(ptr), _i32(ind), _f64(val)
+    cap = nnz + min(m, n) + 1
+    optr = np.zeros(m + 1, dtype=np.int32)
+    oind = np.zeros(cap, dtype=np.int32)
+    oval = np.zeros(cap, dtype=np.float64)
+    idiag = np.zeros(max(m, 1), dtype=np.int32)
+    iurow = np.zeros(max(m, 1), dtype=np.int32)
+    onnz, internal, fd = c_i32(0), c_int(0), c_int(0)
+    st = lib().orc_dcsr_optimize(c_i32(m), c_i32(n), c_i32(nnz), c_int(base), _p(ptr), _p(ind),
+                                 _p(val), _p(optr), _p(oind), _p(oval), ctypes.byref(onnz),
+                                 _p(idiag), _p(iurow), ctypes.byref(internal), ctypes.byref(fd))
+    if st == 0 and not internal.value:
+        optr, oind, oval, obase = ptr, ind[:nnz], val[:nnz], base
+    else:
+        oind, oval, obase = oind[: onnz.value], oval[: onnz.value], 0
+    return dict(status=st, ptr=optr, ind=oind, val=oval, idiag=idiag[:m], iurow=iurow[:m],
+                is_internal=bool(internal.value), fulldiag=bool(fd.value), base=obase)
+
+
+def dcsr2csc(m, n, nnz, base_csr, base_csc, row_ptr, col_ind, val):
+    row_ptr, col_ind, val = _i32(row_ptr), _i32(col_ind), _f64(val)
+    ri = np.zeros(max(nnz, 1), dtype=np.int32)
+    cp = np.zeros(n + 1, dtype=np.int32)
+    cv = np.zeros(max(nnz, 1), dtype=np.float64)
+    st = lib().orc_dcsr2csc(c_i32(m), c_i32(n), c_i32(nnz), c_int(base_csr), c_int(base_csc),
+                            _p(row_ptr), _p(col_ind), _p(val), _p(ri), _p(cp), _p(cv))
+    return st, cp, ri[:nnz], cv[:nnz]
+
+
+def dilu0(n, base, row_ptr, col_ind, val):
+    row_ptr, col_ind = _i32(row_ptr), _i32(col_ind)
+    val = _f64(val).copy()
+    diag = np.zeros(max(n, 1), dtype=np.int32)
+    st = lib().orc_dilu0(c_i32(n), c_int(base), _p(diag), _p(val), _p(row_ptr), _p(col_ind))
+    return st, val, diag[:n]
+
+
+def dcsr2m(m, n, base_a, ptr_a, ind_a, val_a, base_b, ptr_b, ind_b, val_b):
+    """C = A*B (general CSR x CSR); C is 0-based, columns in first-touch order."""
+    ptr_a, ind_a, val_a = _i32(ptr_a), _i32(ind_a), _f64(val_a)
+    ptr_b, ind_b, val_b = _i32(ptr_b), _i32(ind_b), _f64(val_b)
+    ptr_c = np.zeros(m + 1, dtype=np.int32)
+    nnz_c = c_i32(0)
+    st = lib().orc_csr2m_nnz(c_i32(m), c_i32(n), c_int(base_a), _p(ptr_a), _p(ind_a), c_int(base_b),
+                             _p(ptr_b), _p(ind_b), _p(ptr_c), ctypes.byref(nnz_c))
+    if st != 0:
+        return st, None, None, None
+    ind_c = np.zeros(max(nnz_c.value, 1), dtype=np.int32)
+    val_c = np.zeros(max(nnz_c.value, 1), dtype=np.float64)
+    st = lib().orc_dcsr2m_fill(c_i32(m), c_i32(n), c_int(base_a), _p(ptr_a), _p(ind_a), _p(val_a),
+                               c_int(base_b), _p(ptr_b), _p(ind_b), _p(val_b), _p(ptr_c), _p(ind_c),
+                               _p(val_c))
+    return st, ptr_c, ind_c[: nnz_c.value], val_c[: nnz_c.value]

@@ -1,0 +1,867 @@
+/*
+ * oracle.c -- CPU restatement of the AOCL-Sparse CSR SpMV / TRSV / csrmm / clean-CSR path.
+ * TEST INFRASTRUCTURE ONLY (see oracle.h).  Parity pinned on the reference's own
+ * known-answer vectors (tests/golden/); the reference library is unbuildable here.
+ *
+ * Floating point: the reference is compiled with -ffp-contract=fast (CMakeLists.txt:190)
+ * for FMA-capable x86, so every "acc += a*b" below is an explicit fma(); this file is
+ * compiled with -ffp-contract=off so nothing else is contracted behind our back.
+ */
+#include "oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------ */
+/* SpMV row kernels.  Each computes one row's dot product in the reference's order.      */
+/* ------------------------------------------------------------------------------------ */
+
+/* csrmv_kr.hpp:493-496: result += val[j]*x[col[j]] left to right. */
+static inline double row_ref_d(const double *val, const oint *col, const double *x, oint s,
+                               oint e, int base)
+{
+    double r = 0.0;
+    for(oint j = s; j < e; j++)
+        r = fma(val[j - base], x[col[j - base] - base], r);
+    return r;
+}
+
+static inline float row_ref_s(const float *val, const oint *col, const float *x, oint s,
+                              oint e, int base)
+{
+    float r = 0.0f;
+    for(oint j = s; j < e; j++)
+        r = fmaf(val[j - base], x[col[j - base] - base], r);
+    return r;
+}
+
+/* csrmv_kr.hpp:974-1020: 4 lanes FMA over the first floor(n/4)*4 entries, hadd
+ * (l0+l1)+(l2+l3), then the scalar tail continues on the reduced value. */
+static inline double row_lane4_d(const double *val, const oint *col, const double *x, oint s,
+                                 oint e, int base)
+{
+    oint   n    = e - s;
+    oint   krem = n % 4;
+    double l[4] = {0.0, 0.0, 0.0, 0.0};
+    double r    = 0.0;
+    oint   j;
+    for(j = s; j < e - krem; j += 4)
+        for(int k = 0; k < 4; k++)
+            l[k] = fma(val[j + k - base], x[col[j + k - base] - base], l[k]);
+    if(n / 4)
+        r = (l[0] + l[1]) + (l[2] + l[3]);
+    for(j = e - krem; j < e; j++)
+        r = fma(val[j - base], x[col[j - base] - base], r);
+    return r;
+}
+
+/* csrmv_avx512.cpp:64-113: 8 lanes; v[k] = l[k]+l[k+4]; (v0+v1)+(v2+v3); scalar tail. */
+static inline double row_lane8_d(const double *val, const oint *col, const double *x, oint s,
+                                 oint e, int base)
+{
+    oint   n    = e - s;
+    oint   krem = n % 8;
+    double l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double r    = 0.0;
+    oint   j;
+    for(j = s; j < e - krem; j += 8)
+        for(int k = 0; k < 8; k++)
+            l[k] = fma(val[j + k - base], x[col[j + k - base] - base], l[k]);
+    if(n / 8)
+    {
+        double v0 = l[0] + l[4], v1 = l[1] + l[5], v2 = l[2] + l[6], v3 = l[3] + l[7];
+        r = (v0 + v1) + (v2 + v3);
+    }
+    for(j = e - krem; j < e; j++)
+        r = fma(val[j - base], x[col[j - base] - base], r);
+    return r;
+}
+
+/* csrmv_kr.hpp:766-812: float, 8 lanes; ((x0+x4)+(x2+x6)) + ((x1+x5)+(x3+x7)); tail. */
+static inline float row_lane8_s(const float *val, const oint *col, const float *x, oint s,
+                                oint e, int base)
+{
+    oint  n    = e - s;
+    oint  krem = n % 8;
+    float l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float r    = 0.0f;
+    oint  j;
+    for(j = s; j < e - krem; j += 8)
+        for(int k = 0; k < 8; k++)
+            l[k] = fmaf(val[j + k - base], x[col[j + k - base] - base], l[k]);
+    if(n / 8)
+    {
+        float q0 = l[0] + l[4], q1 = l[1] + l[5], q2 = l[2] + l[6], q3 = l[3] + l[7];
+        float d0 = q0 + q2, d1 = q1 + q3;
+        r = d0 + d1;
+    }
+    for(j = e - krem; j < e; j++)
+        r = fmaf(val[j - base], x[col[j - base] - base], r);
+    return r;
+}
+
+/* csrmv_kr.hpp:497-509: if(alpha!=1) r=alpha*r; if(beta!=0) r += beta*y (contracted). */
+static inline double finish_d(double r, double alpha, double beta, const double *yi)
+{
+    if(alpha != 1.0)
+        r = alpha * r;
+    if(beta != 0.0)
+        r = fma(beta, *yi, r);
+    return r;
+}
+
+static inline float finish_s(float r, float alpha, float beta, const float *yi)
+{
+    if(alpha != 1.0f)
+        r = alpha * r;
+    if(beta != 0.0f)
+        r = fmaf(beta, *yi, r);
+    return r;
+}
+
+#define DEF_DCSRMV(NAME, ROWFN)                                                              \
+    int NAME(int base, double alpha, oint m, const double *val, const oint *col,             \
+             const oint *row, const double *x, double beta, double *y)                       \
+    {                                                                                        \
+        for(oint i = 0; i < m; i++)                                                          \
+            y[i] = finish_d(ROWFN(val, col, x, row[i], row[i + 1], base), alpha, beta, &y[i]); \
+        return ORC_SUCCESS;                                                                  \
+    }
+
+DEF_DCSRMV(orc_dcsrmv_ref, row_ref_d)
+DEF_DCSRMV(orc_dcsrmv_lane4, row_lane4_d)
+DEF_DCSRMV(orc_dcsrmv_lane8, row_lane8_d)
+
+int orc_scsrmv_ref(int base, float alpha, oint m, const float *val, const oint *col,
+                   const oint *row, const float *x, float beta, float *y)
+{
+    for(oint i = 0; i < m; i++)
+        y[i] = finish_s(row_ref_s(val, col, x, row[i], row[i + 1], base), alpha, beta, &y[i]);
+    return ORC_SUCCESS;
+}
+
+int orc_scsrmv_lane8(int base, float alpha, oint m, const float *val, const oint *col,
+                     const oint *row, const float *x, float beta, float *y)
+{
+    for(oint i = 0; i < m; i++)
+        y[i] = finish_s(row_lane8_s(val, col, x, row[i], row[i + 1], base), alpha, beta, &y[i]);
+    return ORC_SUCCESS;
+}
+
+/* csrmv.hpp:322-355: the KAT has kid 0 (ref), 1 and 2 (AVX2), 3 (AVX-512); nnz<=10*m
+ * overrides kid to 0; auto (kid<0) resolves to the AVX-512 kernel on an AVX-512 host. */
+static int resolve_kid(int kid, oint m, oint nnz)
+{
+    if((long long)nnz <= 10LL * (long long)m)
+        return 0;
+    if(kid < 0)
+        return 3;
+    return kid;
+}
+
+int orc_dcsrmv(int kid, int base, double alpha, oint m, oint nnz, const double *val,
+               const oint *col, const oint *row, const double *x, double beta, double *y)
+{
+    switch(resolve_kid(kid, m, nnz))
+    {
+    case 0:
+        return orc_dcsrmv_ref(base, alpha, m, val, col, row, x, beta, y);
+    case 1:
+    case 2:
+        return orc_dcsrmv_lane4(base, alpha, m, val, col, row, x, beta, y);
+    case 3:
+        return orc_dcsrmv_lane8(base, alpha, m, val, col, row, x, beta, y);
+    default:
+        return ORC_INVALID_KID;
+    }
+}
+
+int orc_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+int orc_dcsrmv_omp(int kid, int base, double alpha, oint m, oint nnz, const double *val,
+                   const oint *col, const oint *row, const double *x, double beta, double *y,
+                   int nthreads)
+{
+    int k = resolve_kid(kid, m, nnz);
+    if(k > 3)
+        return ORC_INVALID_KID;
+    if(nthreads < 1)
+        nthreads = 1;
+    /* csrmv_kr.hpp:483-488: omp parallel for over rows (static schedule). */
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+#endif
+    for(oint i = 0; i < m; i++)
+    {
+        double r;
+        if(k == 0)
+            r = row_ref_d(val, col, x, row[i], row[i + 1], base);
+        else if(k == 3)
+            r = row_lane8_d(val, col, x, row[i], row[i + 1], base);
+        else
+            r = row_lane4_d(val, col, x, row[i], row[i + 1], base);
+        y[i] = finish_d(r, alpha, beta, &y[i]);
+    }
+    return ORC_SUCCESS;
+}
+
+/* csrmv_kt.cpp:96-214 with one thread: scale y (beta==0 writes zeros, beta==1 untouched),
+ * then row by row y[col] += val * (alpha*x[i]).  The vector body multiplies then adds
+ * (kt_mul_p then +=, :184-193); the tail "y += aval*alpha*x[i]" is contracted to an fma of
+ * (aval*alpha) and x[i] (:195-199).  With one thread there is no merge step. */
+int orc_dcsrmvt(int base, double alpha, oint m, oint n, const double *val, const oint *col,
+                const oint *row, const double *x, double beta, double *y)
+{
+    if(beta == 0.0)
+        for(oint i = 0; i < n; i++)
+            y[i] = 0.0;
+    else if(beta != 1.0)
+        for(oint i = 0; i < n; i++)
+            y[i] = beta * y[i];
+    /* the OpenMP build accumulates into a zeroed per-thread buffer and merges it into y
+     * afterwards (:150-160, :203-210); with one thread that is buf then y += buf. */
+    double *buf = (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double));
+    if(!buf)
+        return ORC_MEMORY_ERROR;
+    const oint tsz = 8; /* b512 doubles on an AVX-512 host */
+    for(oint i = 0; i < m; i++)
+    {
+        oint   s = row[i], e = row[i + 1];
+        oint   krem = (e - s) % tsz;
+        double ax   = alpha * x[i];
+        oint   j;
+        for(j = s; j < e - krem; j++)
+            buf[col[j - base] - base] += val[j - base] * ax;
+        for(j = e - krem; j < e; j++)
+            buf[col[j - base] - base]
+                = fma(val[j - base] * alpha, x[i], buf[col[j - base] - base]);
+    }
+    for(oint i = 0; i < n; i++)
+        y[i] += buf[i];
+    free(buf);
+    return ORC_SUCCESS;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* TRSV reference kernels, trsv_kr.hpp:38-222.  "xi -= a*x" contracts to fma(-a, x, xi). */
+/* ------------------------------------------------------------------------------------ */
+#define DEF_TRSV(T, SUF, FMA)                                                                \
+    int orc_##SUF##trsv_l(T alpha, oint m, int base, const T *a, const oint *icol,           \
+                          const oint *ilrow, const oint *idiag, const T *b, oint incb, T *x, \
+                          oint incx, int unit)                                               \
+    {                                                                                        \
+        for(oint i = 0; i < m; i++)                                                          \
+        {                                                                                    \
+            T xi = alpha * b[(size_t)i * incb];                                              \
+            for(oint idx = ilrow[i]; idx < idiag[i]; idx++)                                  \
+                xi = FMA(-a[idx - base], x[(size_t)(icol[idx - base] - base) * incx], xi);   \
+            if(!unit)                                                                        \
+                xi /= a[idiag[i] - base];                                                    \
+            x[(size_t)i * incx] = xi;                                                        \
+        }                                                                                    \
+        return ORC_SUCCESS;                                                                  \
+    }                                                                                        \
+    int orc_##SUF##trsv_u(T alpha, oint m, int base, const T *a, const oint *icol,           \
+                          const oint *ilrow, const oint *iurow, const T *b, oint incb, T *x, \
+                          oint incx, int unit)                                               \
+    {                                                                                        \
+        for(oint i = m - 1; i >= 0; i--)                                                     \
+        {                                                                                    \
+            T xi = alpha * b[(size_t)i * incb];                                              \
+            for(oint idx = iurow[i]; idx <= ilrow[i + 1] - 1; idx++)                         \
+                xi = FMA(-a[idx - base], x[(size_t)(icol[idx - base] - base) * incx], xi);   \
+            if(!unit)                                                                        \
+                xi /= a[iurow[i] - 1 - base];                                                \
+            x[(size_t)i * incx] = xi;                                                        \
+        }                                                                                    \
+        return ORC_SUCCESS;                                                                  \
+    }
+
+DEF_TRSV(double, d, fma)
+DEF_TRSV(float, s, fmaf)
+
+/* trsv_kr.hpp:101-120: x = alpha*b; for i = m-1..0: x[i] /= d; x[col] -= a*x[i]. */
+int orc_dtrsv_lt(double alpha, oint m, int base, const double *a, const oint *icol,
+                 const oint *ilrow, const oint *idiag, const double *b, oint incb, double *x,
+                 oint incx, int unit)
+{
+    for(oint i = 0; i < m; i++)
+        x[(size_t)i * incx] = alpha * b[(size_t)i * incb];
+    for(oint i = m - 1; i >= 0; i--)
+    {
+        if(!unit)
+            x[(size_t)i * incx] /= a[idiag[i] - base];
+        double xi = x[(size_t)i * incx];
+        for(oint idx = ilrow[i]; idx < idiag[i]; idx++)
+        {
+            size_t c = (size_t)(icol[idx - base] - base) * incx;
+            x[c]     = fma(-a[idx - base], xi, x[c]);
+        }
+    }
+    return ORC_SUCCESS;
+}
+
+/* trsv_kr.hpp:196-221: x = alpha*b; for i = 0..m-1: x[i] /= d; x[col] -= a*x[i]. */
+int orc_dtrsv_ut(double alpha, oint m, int base, const double *a, const oint *icol,
+                 const oint *ilrow, const oint *iurow, const double *b, oint incb, double *x,
+                 oint incx, int unit)
+{
+    for(oint i = 0; i < m; i++)
+        x[(size_t)i * incx] = alpha * b[(size_t)i * incb];
+    for(oint i = 0; i < m; i++)
+    {
+        if(!unit)
+            x[(size_t)i * incx] /= a[iurow[i] - 1 - base];
+        double xi = x[(size_t)i * incx];
+        for(oint idx = iurow[i]; idx <= ilrow[i + 1] - 1; idx++)
+        {
+            size_t c = (size_t)(icol[idx - base] - base) * incx;
+            x[c]     = fma(-a[idx - base], xi, x[c]);
+        }
+    }
+    return ORC_SUCCESS;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* csrmm reference kernels, csrmm.hpp:36-144.                                            */
+/* ------------------------------------------------------------------------------------ */
+
+/* csrmm.hpp:69-85: sum = aval*B + sum (fma chain); C = (beta*C) + (alpha*sum), which the
+ * compiler contracts to fma(beta, C, alpha*sum). */
+int orc_dcsrmm_col(double alpha, int base, const double *val, const oint *col,
+                   const oint *row, oint m, const double *B, oint n, oint ldb, double beta,
+                   double *C, oint ldc)
+{
+    for(oint j = 0; j < n; j++)
+        for(oint i = 0; i < m; i++)
+        {
+            double sum = 0.0;
+            for(oint k = row[i]; k < row[i + 1]; k++)
+                sum = fma(val[k - base], B[(size_t)(col[k - base] - base) + (size_t)j * ldb], sum);
+            size_t ic = (size_t)i + (size_t)j * ldc;
+            C[ic]     = fma(beta, C[ic], alpha * sum);
+        }
+    return ORC_SUCCESS;
+}
+
+/* csrmm.hpp:123-139: C_row *= beta; then per nnz in CSR order C += (aval*B)*alpha,
+ * contracted to fma(aval*B, alpha, C). */
+int orc_dcsrmm_row(double alpha, int base, const double *val, const oint *col,
+                   const oint *row, oint m, const double *B, oint n, oint ldb, double beta,
+                   double *C, oint ldc)
+{
+    for(oint i = 0; i < m; i++)
+    {
+        double *c = C + (size_t)i * ldc;
+        for(oint k = 0; k < n; k++)
+            c[k] = c[k] * beta;
+        for(oint j = row[i]; j < row[i + 1]; j++)
+        {
+            const double *brow = B + (size_t)(col[j - base] - base) * ldb;
+            double        av   = val[j - base];
+            for(oint k = 0; k < n; k++)
+                c[k] = fma(av * brow[k], alpha, c[k]);
+        }
+    }
+    return ORC_SUCCESS;
+}
+
+/* csrmm.hpp:361-427: beta==0 writes exact zeros, otherwise C *= beta. */
+int orc_dscale_dense(int order, double *C, oint m, oint n, oint ld, double beta)
+{
+    oint outer = order == 1 ? n : m;
+    oint inner = order == 1 ? m : n;
+    for(oint o = 0; o < outer; o++)
+        for(oint i = 0; i < inner; i++)
+        {
+            size_t idx = (size_t)o * ld + i;
+            C[idx]     = beta == 0.0 ? 0.0 : C[idx] * beta;
+        }
+    return ORC_SUCCESS;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* clean-CSR path                                                                        */
+/* ------------------------------------------------------------------------------------ */
+
+/* csr_util.cpp:124-279 */
+int orc_mat_check(oint maj, oint mind, oint nnz, const oint *ptr, const oint *ind,
+                  const void *val, int shape, int base, int *sort_out, int *fulldiag_out)
+{
+    if(!ptr || !ind || !val)
+        return ORC_INVALID_POINTER;
+    if(mind < 0 || maj < 0 || nnz < 0)
+        return ORC_INVALID_SIZE;
+    if(ptr[0] - base != 0)
+        return ORC_INVALID_VALUE;
+    if(ptr[maj] - base != nnz)
+        return ORC_INVALID_VALUE;
+    for(oint i = 1; i <= maj; i++)
+        if(ptr[i - 1] > ptr[i])
+            return ORC_INVALID_VALUE;
+
+    int  sort     = ORC_FULLY_SORTED;
+    int  fulldiag = 1;
+    oint jmin = 0, jmax = mind - 1;
+    for(oint i = 0; i < maj; i++)
+    {
+        oint idxend = ptr[i + 1] - base, idxstart = ptr[i] - base;
+        if(shape == 1)
+        {
+            jmin = 0;
+            jmax = i;
+        }
+        else if(shape == 2)
+        {
+            jmin = i;
+            jmax = mind - 1;
+        }
+        int  diagonal = 0, upper = 0;
+        oint prev = -1;
+        for(oint idx = idxstart; idx < idxend; idx++)
+        {
+            oint j = ind[idx] - base;
+            if(j < jmin || j > jmax)
+                return ORC_INVALID_INDEX_VALUE;
+            if(sort != ORC_UNSORTED)
+            {
+                if(prev > j)
+                    sort = ORC_PARTIALLY_SORTED;
+                else
+                    prev = j;
+                if((j <= i && upper) || (j < i && diagonal))
+                    sort = ORC_UNSORTED;
+            }
+            if(j > i)
+                upper = 1;
+            else if(j == i)
+            {
+                if(diagonal)
+                    return ORC_INVALID_VALUE;
+                diagonal = 1;
+            }
+        }
+        if(!diagonal && i < mind)
+            fulldiag = 0;
+    }
+    *sort_out     = sort;
+    *fulldiag_out = fulldiag;
+    return ORC_SUCCESS;
+}
+
+/* csr_util.cpp:290-364 */
+int orc_check_sort_diag(oint m, oint n, int base, const oint *ptr, const oint *ind,
+                        int *sorted, int *fulldiag)
+{
+    *sorted   = 0;
+    *fulldiag = 0;
+    if(m < 0 || n < 0)
+        return ORC_INVALID_SIZE;
+    if(!ptr || !ind)
+        return ORC_INVALID_POINTER;
+    *sorted   = 1;
+    *fulldiag = 1;
+    for(oint i = 0; i < m; i++)
+    {
+        int  lower = 1, found = 0;
+        oint idxend = ptr[i + 1] - base;
+        for(oint idx = ptr[i] - base; idx < idxend; idx++)
+        {
+            oint j = ind[idx] - base;
+            if(j == i)
+            {
+                if(found)
+                    return ORC_INVALID_VALUE;
+                found   = 1;
+                *sorted = lower;
+                lower   = 0;
+            }
+            else
+            {
+                if(lower)
+                    lower = j < i;
+                else
+                    *sorted = *sorted && (j > i);
+            }
+            if(!*sorted)
+            {
+                *fulldiag = 0;
+                return ORC_SUCCESS;
+            }
+        }
+        if(!found && i < n)
+            *fulldiag = 0;
+        if(!*sorted)
+        {
+            *fulldiag = 0;
+            return ORC_SUCCESS;
+        }
+    }
+    return ORC_SUCCESS;
+}
+
+/* csr_util.cpp:389-458 */
+int orc_csr_indices(oint m, int base, const oint *ptr, const oint *ind, oint *idiag,
+                    oint *iurow)
+{
+    if(m < 0)
+        return ORC_INVALID_SIZE;
+    if(!ptr || !ind || !idiag || !iurow)
+        return ORC_INVALID_POINTER;
+    for(oint i = 0; i < m; i++)
+    {
+        int  found  = 0;
+        oint idxend = ptr[i + 1] - base;
+        for(oint idx = ptr[i] - base; idx < idxend; idx++)
+        {
+            oint j = ind[idx] - base;
+            if(j >= i)
+            {
+                oint adj = idx + base;
+                idiag[i] = adj;
+                iurow[i] = j == i ? adj + 1 : adj;
+                found    = 1;
+                break;
+            }
+        }
+        if(!found)
+        {
+            idiag[i] = idxend + base;
+            iurow[i] = idxend + base;
+        }
+    }
+    return ORC_SUCCESS;
+}
+
+/* csr_util.hpp:100-159: per-row sort of (index,value) by index.  The reference sorts a
+ * permutation with std::sort and a "<=" comparator, so the relative order of duplicate
+ * column indices is implementation-defined; rows without duplicates have a unique result,
+ * which is what this stable insertion/merge sort produces. */
+typedef struct
+{
+    oint   c;
+    double v;
+} cv_t;
+
+static int cv_cmp(const void *a, const void *b)
+{
+    oint ca = ((const cv_t *)a)->c, cb = ((const cv_t *)b)->c;
+    return (ca > cb) - (ca < cb);
+}
+
+/* csr_util.hpp:765-967 */
+int orc_dcsr_optimize(oint m, oint n, oint nnz, int base, const oint *ptr, const oint *ind,
+                      const double *val, oint *optr, oint *oind, double *oval, oint *onnz,
+                      oint *idiag, oint *iurow, int *is_internal, int *fulldiag_out)
+{
+    int sort, fd, sorted, fulldiag;
+    int st = orc_mat_check(m, n, nnz, ptr, ind, val, 0, base, &sort, &fd);
+    if(st != ORC_SUCCESS)
+        return st;
+    st = orc_check_sort_diag(m, n, base, ptr, ind, &sorted, &fulldiag);
+    if(st != ORC_SUCCESS)
+        return ORC_INTERNAL_ERROR;
+    if(sorted && fulldiag)
+    {
+        /* user's memory is used as is (base preserved) */
+        *is_internal  = 0;
+        *onnz         = nnz;
+        *fulldiag_out = fulldiag;
+        return orc_csr_indices(m, base, ptr, ind, idiag, iurow);
+    }
+    *is_internal = 1;
+    /* 0-based copy (:893-902) */
+    oint   *tptr = (oint *)malloc(sizeof(oint) * ((size_t)m + 1));
+    oint   *tind = (oint *)malloc(sizeof(oint) * ((size_t)nnz + 1));
+    double *tval = (double *)malloc(sizeof(double) * ((size_t)nnz + 1));
+    if(!tptr || !tind || !tval)
+    {
+        free(tptr);
+        free(tind);
+        free(tval);
+        return ORC_MEMORY_ERROR;
+    }
+    for(oint i = 0; i <= m; i++)
+        tptr[i] = ptr[i] - base;
+    for(oint i = 0; i < nnz; i++)
+    {
+        tind[i] = ind[i] - base;
+        tval[i] = val[i];
+    }
+    if(!sorted)
+    {
+        /* aoclsparse_sort_idx_val (:904-916) then re-check (:918-924) */
+        oint  maxrow = 0;
+        for(oint i = 0; i < m; i++)
+            if(tptr[i + 1] - tptr[i] > maxrow)
+                maxrow = tptr[i + 1] - tptr[i];
+        cv_t *buf = (cv_t *)malloc(sizeof(cv_t) * ((size_t)maxrow + 1));
+        if(!buf)
+        {
+            free(tptr);
+            free(tind);
+            free(tval);
+            return ORC_MEMORY_ERROR;
+        }
+        for(oint i = 0; i < m; i++)
+        {
+            oint s = tptr[i], len = tptr[i + 1] - tptr[i];
+            for(oint k = 0; k < len; k++)
+            {
+                buf[k].c = tind[s + k];
+                buf[k].v = tval[s + k];
+            }
+            qsort(buf, (size_t)len, sizeof(cv_t), cv_cmp);
+            for(oint k = 0; k < len; k++)
+            {
+                tind[s + k] = buf[k].c;
+                tval[s + k] = buf[k].v;
+            }
+        }
+        free(buf);
+        st = orc_check_sort_diag(m, n, 0, tptr, tind, &sorted, &fulldiag);
+        if(st != ORC_SUCCESS)
+        {
+            free(tptr);
+            free(tind);
+            free(tval);
+            return st;
+        }
+    }
+    oint newnnz = nnz;
+    if(!fulldiag)
+    {
+        /* aoclsparse_csr_csc_fill_diag (csr_util.hpp:167-279): insert explicit zeros for
+         * missing diagonals of rows i < n, keeping each row sorted. */
+        oint w = 0;
+        for(oint i = 0; i < m; i++)
+        {
+            oint s = tptr[i], e = tptr[i + 1];
+            optr[i] = w;
+            int placed = (i >= n); /* rows beyond n have no diagonal */
+            for(oint idx = s; idx < e; idx++)
+            {
+                oint j = tind[idx];
+                if(!placed && j >= i)
+                {
+                    if(j != i)
+                    {
+                        oind[w] = i;
+                        oval[w] = 0.0;
+                        w++;
+                    }
+                    placed = 1;
+                }
+                oind[w] = j;
+                oval[w] = tval[idx];
+                w++;
+            }
+            if(!placed)
+            {
+                oind[w] = i;
+                oval[w] = 0.0;
+                w++;
+            }
+        }
+        optr[m] = w;
+        newnnz  = w;
+    }
+    else
+    {
+        memcpy(optr, tptr, sizeof(oint) * ((size_t)m + 1));
+        memcpy(oind, tind, sizeof(oint) * (size_t)nnz);
+        memcpy(oval, tval, sizeof(double) * (size_t)nnz);
+    }
+    free(tptr);
+    free(tind);
+    free(tval);
+    *onnz         = newnnz;
+    *fulldiag_out = fulldiag;
+    return orc_csr_indices(m, 0, optr, oind, idiag, iurow);
+}
+
+/* convert.hpp:552-655: counting-sort transpose, stable in row order. */
+int orc_dcsr2csc(oint m, oint n, oint nnz, int base_csr, int base_csc, const oint *row_ptr,
+                 const oint *col_ind, const double *val, oint *csc_row_ind, oint *csc_col_ptr,
+                 double *csc_val)
+{
+    if(m < 0 || n < 0 || nnz < 0)
+        return ORC_INVALID_SIZE;
+    if(m == 0 || n == 0 || nnz == 0)
+    {
+        for(oint i = 0; i < n + 1; i++)
+            csc_col_ptr[i] = base_csc;
+        return ORC_SUCCESS;
+    }
+    if((base_csr != 0 && base_csr != 1) || (base_csc != 0 && base_csc != 1))
+        return ORC_INVALID_VALUE;
+    if(!val || !row_ptr || !col_ind || !csc_val || !csc_row_ind || !csc_col_ptr)
+        return ORC_INVALID_POINTER;
+    for(oint i = 0; i < n + 1; i++)
+        csc_col_ptr[i] = 0;
+    for(oint i = 0; i < nnz; i++)
+        ++csc_col_ptr[col_ind[i] - base_csr + 1];
+    for(oint i = 0; i < n; i++)
+        csc_col_ptr[i + 1] += csc_col_ptr[i];
+    for(oint i = 0; i < m; i++)
+        for(oint j = row_ptr[i] - base_csr; j < row_ptr[i + 1] - base_csr; j++)
+        {
+            oint c           = col_ind[j] - base_csr;
+            oint idx         = csc_col_ptr[c];
+            csc_row_ind[idx] = i + base_csc;
+            csc_val[idx]     = val[j];
+            ++csc_col_ptr[c];
+        }
+    for(oint i = n; i > 0; i--)
+        csc_col_ptr[i] = csc_col_ptr[i - 1] + base_csc;
+    csc_col_ptr[0] = base_csc;
+    return ORC_SUCCESS;
+}
+
+/* ilu0.hpp:35-107: IKJ ILU(0) in place; lu_diag_ptr[i] = 0-based position of the diagonal.
+ * Restated with the reference's mapper convention (a stored position of 0 means "absent",
+ * :83-86), so the entry at array position 0 is never updated -- kept for fidelity. */
+int orc_dilu0(oint n, int base, oint *lu_diag_ptr, double *val, const oint *row_ptr,
+              const oint *col_ind)
+{
+    oint *mapper = (oint *)calloc((size_t)(n > 0 ? n : 1), sizeof(oint));
+    if(!mapper)
+        return ORC_MEMORY_ERROR;
+    for(oint i = 0; i < n; i++)
+    {
+        oint j1 = row_ptr[i] - base, j2 = row_ptr[i + 1] - base, j, k = -1;
+        for(j = j1; j < j2; j++)
+            mapper[col_ind[j] - base] = j;
+        for(j = j1; j < j2; j++)
+        {
+            k = col_ind[j] - base;
+            if(k >= i)
+                break;
+            double d = val[lu_diag_ptr[k]];
+            if(fabs(d) <= 2.220446049250313e-16) /* aoclsparse_is_nearzero */
+            {
+                free(mapper);
+                return ORC_NUMERICAL_ERROR;
+            }
+            val[j] = val[j] / d;
+            for(oint jj = lu_diag_ptr[k] + 1; jj < row_ptr[k + 1] - base; jj++)
+            {
+                oint jw = mapper[col_ind[jj] - base];
+                if(jw != 0)
+                    val[jw] = fma(-val[j], val[jj], val[jw]);
+            }
+        }
+        lu_diag_ptr[i] = j;
+        if(j >= j2 || k != i || fabs(val[j]) <= 2.220446049250313e-16)
+        {
+            free(mapper);
+            return ORC_NUMERICAL_ERROR;
+        }
+        for(oint mn = j1; mn < j2; mn++)
+            mapper[col_ind[mn] - base] = 0;
+    }
+    free(mapper);
+    return ORC_SUCCESS;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* sp2m = two-stage Gustavson, csr2m.cpp:46-302 (count) and :310-543 (finalize).         */
+/* ------------------------------------------------------------------------------------ */
+int orc_csr2m_nnz(oint m, oint n, int base_a, const oint *ptr_a, const oint *ind_a,
+                  int base_b, const oint *ptr_b, const oint *ind_b, oint *ptr_c, oint *nnz_c)
+{
+    if(!ptr_a || !ind_a || !ptr_b || !ind_b)
+        return ORC_INVALID_POINTER;
+    oint *mark = (oint *)malloc(sizeof(oint) * ((size_t)n + 1));
+    if(!mark)
+        return ORC_MEMORY_ERROR;
+    for(oint i = 0; i < n; i++)
+        mark[i] = -1;
+    long long total = 0;
+    ptr_c[0]        = 0;
+    for(oint i = 0; i < m; i++)
+    {
+        oint cnt = 0;
+        for(oint j = ptr_a[i] - base_a; j < ptr_a[i + 1] - base_a; j++)
+        {
+            oint ca = ind_a[j] - base_a;
+            for(oint k = ptr_b[ca] - base_b; k < ptr_b[ca + 1] - base_b; k++)
+            {
+                oint cb = ind_b[k] - base_b;
+                if(mark[cb] != i)
+                {
+                    mark[cb] = i;
+                    cnt++;
+                }
+            }
+        }
+        total += cnt;
+        ptr_c[i + 1] = (oint)total;
+    }
+    free(mark);
+    if(total > 2147483647LL)
+        return ORC_INVALID_SIZE;
+    *nnz_c = (oint)total;
+    return ORC_SUCCESS;
+}
+
+int orc_dcsr2m_fill(oint m, oint n, int base_a, const oint *ptr_a, const oint *ind_a,
+                    const double *val_a, int base_b, const oint *ptr_b, const oint *ind_b,
+                    const double *val_b, const oint *ptr_c, oint *ind_c, double *val_c)
+{
+    oint   *aidx = (oint *)malloc(sizeof(oint) * ((size_t)n + 1));
+    double *asum = (double *)malloc(sizeof(double) * ((size_t)n + 1));
+    if(!aidx || !asum)
+    {
+        free(aidx);
+        free(asum);
+        return ORC_MEMORY_ERROR;
+    }
+    for(oint i = 0; i < n; i++)
+    {
+        aidx[i] = -1;
+        asum[i] = 0.0;
+    }
+    int st = ORC_SUCCESS;
+    for(oint i = 0; i < m; i++)
+    {
+        oint w = ptr_c[i];
+        for(oint j = ptr_a[i] - base_a; j < ptr_a[i + 1] - base_a; j++)
+        {
+            oint   ca = ind_a[j] - base_a;
+            double va = val_a[j];
+            for(oint k = ptr_b[ca] - base_b; k < ptr_b[ca + 1] - base_b; k++)
+            {
+                oint cb = ind_b[k] - base_b;
+                if(aidx[cb] != i)
+                {
+                    ind_c[w] = cb; /* first-touch order, csr2m.cpp:489-496 */
+                    aidx[cb] = i;
+                    asum[cb] = va * val_b[k];
+                    w++;
+                }
+                else
+                    asum[cb] = fma(va, val_b[k], asum[cb]); /* :498, contracted */
+            }
+        }
+        if(w != ptr_c[i + 1])
+            st = ORC_INTERNAL_ERROR;
+        else
+            for(w = ptr_c[i]; w < ptr_c[i + 1]; w++)
+                val_c[w] = asum[ind_c[w]];
+    }
+    free(aidx);
+    free(asum);
+    return st;
+}

@@ -1,0 +1,155 @@
+/*
+ * oracle.h -- CPU restatement of the AOCL-Sparse hot path (TEST INFRASTRUCTURE ONLY).
+ *
+ * This is the parity oracle: plain C99, scalar loops with explicit fma() wherever the
+ * reference (built with -ffp-contract=fast, CMakeLists.txt:190) contracts a*b+c.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ * The product library (aocl-sparse_amd/) never links, loads or calls anything here.
+ *
+ * Pinning: the reference library itself is UNBUILDABLE in this image without stand-ins
+ * (it needs the absent AOCL-Utils header Au/Cpuid/X86Cpu.hh, library/src/include/
+ * aoclsparse_context.hpp:38, and the cmake-generated aoclsparse_version.h,
+ * library/include/aoclsparse.h:61), so oracle/_ref does not exist.  The oracle is
+ * pinned instead against the known-answer vectors the reference's own unit tests
+ * hold for this path (the JSON files under tests/golden, produced by tests/golden/make_fixtures.py).
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference/library/src unless noted).  Status codes follow
+ * library/include/aoclsparse_types.h:304-324.
+ */
+#ifndef ORACLE_H_
+#define ORACLE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t oint; /* aoclsparse_int in the LP64 build (aoclsparse_types.h:54-58) */
+
+enum
+{
+    ORC_SUCCESS             = 0,
+    ORC_NOT_IMPLEMENTED     = 1,
+    ORC_INVALID_POINTER     = 2,
+    ORC_INVALID_SIZE        = 3,
+    ORC_INTERNAL_ERROR      = 4,
+    ORC_INVALID_VALUE       = 5,
+    ORC_INVALID_INDEX_VALUE = 6,
+    ORC_WRONG_TYPE          = 9,
+    ORC_MEMORY_ERROR        = 10,
+    ORC_NUMERICAL_ERROR     = 11,
+    ORC_INVALID_KID         = 14
+};
+
+/* sort classes, aoclsparse_types.h:376-384 */
+enum
+{
+    ORC_UNKNOWN_SORT     = 0,
+    ORC_FULLY_SORTED     = 1,
+    ORC_PARTIALLY_SORTED = 2,
+    ORC_UNSORTED         = 3
+};
+
+/* ---- SpMV, y = alpha*A*x + beta*y, general non-transposed CSR ---------------------- */
+/* level2/aoclsparse_csrmv_kr.hpp:448-513 (ref_csrmv_gn): scalar left-to-right FMA chain. */
+int orc_dcsrmv_ref(int base, double alpha, oint m, const double *val, const oint *col,
+                   const oint *row, const double *x, double beta, double *y);
+int orc_scsrmv_ref(int base, float alpha, oint m, const float *val, const oint *col,
+                   const oint *row, const float *x, float beta, float *y);
+/* level2/aoclsparse_csrmv_kr.hpp:949-1040 (AVX2, 4 lanes, kid 1/2). */
+int orc_dcsrmv_lane4(int base, double alpha, oint m, const double *val, const oint *col,
+                     const oint *row, const double *x, double beta, double *y);
+/* level2/aoclsparse_csrmv_avx512.cpp:36-134 (AVX-512, 8 lanes, kid 3). */
+int orc_dcsrmv_lane8(int base, double alpha, oint m, const double *val, const oint *col,
+                     const oint *row, const double *x, double beta, double *y);
+/* level2/aoclsparse_csrmv_kr.hpp:734-831 (float, AVX2 8 lanes; the only float gn kernel). */
+int orc_scsrmv_lane8(int base, float alpha, oint m, const float *val, const oint *col,
+                     const oint *row, const float *x, float beta, float *y);
+/* Dispatch rule of level2/aoclsparse_csrmv.hpp:322-355: nnz<=10*m forces kid 0;
+ * kid<0 (auto) on an AVX-512 host resolves to kid 3.  Returns ORC_INVALID_KID for kid>3. */
+int orc_dcsrmv(int kid, int base, double alpha, oint m, oint nnz, const double *val,
+               const oint *col, const oint *row, const double *x, double beta, double *y);
+/* Transposed SpMV, single-thread order of level2/aoclsparse_csrmv_kt.cpp:96-214 with one
+ * thread (y scaled first, then y[col] += val*(alpha*x[i]) row by row). */
+int orc_dcsrmvt(int base, double alpha, oint m, oint n, const double *val, const oint *col,
+                const oint *row, const double *x, double beta, double *y);
+/* OpenMP static-row version of orc_dcsrmv (same per-row arithmetic); CPU baseline leg. */
+int orc_dcsrmv_omp(int kid, int base, double alpha, oint m, oint nnz, const double *val,
+                   const oint *col, const oint *row, const double *x, double beta, double *y,
+                   int nthreads);
+int orc_max_threads(void);
+
+/* ---- TRSV, level2/aoclsparse_trsv_kr.hpp:38-222 ------------------------------------- */
+/* ilend = idiag for the L kernels, iurow for the U kernels (trsv.cpp:381-400). */
+int orc_dtrsv_l(double alpha, oint m, int base, const double *a, const oint *icol,
+                const oint *ilrow, const oint *idiag, const double *b, oint incb, double *x,
+                oint incx, int unit);
+int orc_dtrsv_lt(double alpha, oint m, int base, const double *a, const oint *icol,
+                 const oint *ilrow, const oint *idiag, const double *b, oint incb, double *x,
+                 oint incx, int unit);
+int orc_dtrsv_u(double alpha, oint m, int base, const double *a, const oint *icol,
+                const oint *ilrow, const oint *iurow, const double *b, oint incb, double *x,
+                oint incx, int unit);
+int orc_dtrsv_ut(double alpha, oint m, int base, const double *a, const oint *icol,
+                 const oint *ilrow, const oint *iurow, const double *b, oint incb, double *x,
+                 oint incx, int unit);
+int orc_strsv_l(float alpha, oint m, int base, const float *a, const oint *icol,
+                const oint *ilrow, const oint *idiag, const float *b, oint incb, float *x,
+                oint incx, int unit);
+int orc_strsv_u(float alpha, oint m, int base, const float *a, const oint *icol,
+                const oint *ilrow, const oint *iurow, const float *b, oint incb, float *x,
+                oint incx, int unit);
+
+/* ---- csrmm, C = alpha*A*B + beta*C, level3/aoclsparse_csrmm.hpp:36-144, 361-427 ------ */
+int orc_dcsrmm_col(double alpha, int base, const double *val, const oint *col,
+                   const oint *row, oint m, const double *B, oint n, oint ldb, double beta,
+                   double *C, oint ldc);
+int orc_dcsrmm_row(double alpha, int base, const double *val, const oint *col,
+                   const oint *row, oint m, const double *B, oint n, oint ldb, double beta,
+                   double *C, oint ldc);
+/* order: 0 row-major, 1 column-major (aoclsparse_types.h:289-293). */
+int orc_dscale_dense(int order, double *C, oint m, oint n, oint ld, double beta);
+
+/* ---- clean-CSR / analysis path, analysis/aoclsparse_csr_util.{cpp,hpp} --------------- */
+/* csr_util.cpp:124-279; shape: 0 general, 1 lower, 2 upper. */
+int orc_mat_check(oint maj, oint mind, oint nnz, const oint *ptr, const oint *ind,
+                  const void *val, int shape, int base, int *sort, int *fulldiag);
+/* csr_util.cpp:290-364 */
+int orc_check_sort_diag(oint m, oint n, int base, const oint *ptr, const oint *ind,
+                        int *sorted, int *fulldiag);
+/* csr_util.cpp:389-458; idiag/iurow (length m) are written in the matrix's base. */
+int orc_csr_indices(oint m, int base, const oint *ptr, const oint *ind, oint *idiag,
+                    oint *iurow);
+/* csr_util.hpp:765-967.  Builds the clean CSR.  If the input is already group-sorted with a
+ * full diagonal, *is_internal=0 and optr/oind/oval are NOT written (the reference aliases
+ * the user's arrays, base preserved).  Otherwise a 0-based sorted, diagonal-filled copy is
+ * written; buffers must hold m+1 / nnz+min(m,n) / nnz+min(m,n) entries.  *onnz = new nnz.
+ * idiag/iurow (length m) always written.  *fulldiag_out = A->opt_csr_full_diag. */
+int orc_dcsr_optimize(oint m, oint n, oint nnz, int base, const oint *ptr, const oint *ind,
+                      const double *val, oint *optr, oint *oind, double *oval, oint *onnz,
+                      oint *idiag, oint *iurow, int *is_internal, int *fulldiag_out);
+/* conversion/aoclsparse_convert.hpp:552-655 */
+int orc_dcsr2csc(oint m, oint n, oint nnz, int base_csr, int base_csc, const oint *row_ptr,
+                 const oint *col_ind, const double *val, oint *csc_row_ind, oint *csc_col_ptr,
+                 double *csc_val);
+
+/* ---- ILU(0), solvers/aoclsparse_ilu0.hpp:35-107 (test-input generator for TRSV) ------ */
+int orc_dilu0(oint n, int base, oint *lu_diag_ptr, double *val, const oint *row_ptr,
+              const oint *col_ind);
+
+/* ---- sp2m (C = A*B, both general CSR), level3/aoclsparse_csr2m.cpp:46-543 ------------ */
+/* stage 1: row_ptr_C (0-based, length m+1).  Returns nnz_C in *nnz_c. */
+int orc_csr2m_nnz(oint m, oint n, int base_a, const oint *ptr_a, const oint *ind_a,
+                  int base_b, const oint *ptr_b, const oint *ind_b, oint *ptr_c,
+                  oint *nnz_c);
+/* stage 2: fills ind_c/val_c in the reference's first-touch column order. */
+int orc_dcsr2m_fill(oint m, oint n, int base_a, const oint *ptr_a, const oint *ind_a,
+                    const double *val_a, int base_b, const oint *ptr_b, const oint *ind_b,
+                    const double *val_b, const oint *ptr_c, oint *ind_c, double *val_c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/reference_kats.json: the known-answer vectors the reference's own
+unit tests hold for the CSR SpMV / clean-CSR / TRSV / csrmm path.
+
+The small cases are re-typed here as data (matrix, right-hand side, expected result), each with
+the reference file:line it comes from.  The N25 TRSV system (565 non-zeros, 16 right-hand
+sides) is extracted numerically from the reference's fixture database when /root/reference is
+present (this container only); the committed JSON is what the tests read, so nothing under
+tests/ touches /root/reference at run time.
+
+Run:  python tests/golden/make_fixtures.py        (rewrites reference_kats.json)
+"""
+import json
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/tests/unit_tests"
+
+out = {"_about": "known-answer vectors re-typed/extracted from amd/aocl-sparse v5.3.2 unit tests; "
+                 "data only (inputs + expected outputs)"}
+
+# ------------------------------------------------------------------------------------------
+# SpMV: tests/unit_tests/csrmv_tests.cpp:185-220 (base-1 KAT), tests/examples/sample_spmv_c.c:50-59
+# ------------------------------------------------------------------------------------------
+out["csrmv"] = [
+    dict(name="N5_base0", src="tests/examples/sample_spmv_c.c:50-59", base=0, m=5, n=5,
+         row_ptr=[0, 2, 3, 4, 7, 8], col_ind=[0, 3, 1, 2, 1, 3, 4, 4], val=[1, 2, 3, 4, 5, 6, 7, 8],
+         x=[1, 2, 3, 4, 5], alpha=1.0, beta=0.0, y0=[0, 0, 0, 0, 0], y_gold=[9, 6, 12, 69, 40]),
+    dict(name="N5_base1", src="tests/unit_tests/csrmv_tests.cpp:185-220", base=1, m=5, n=5,
+         row_ptr=[1, 3, 4, 5, 8, 9], col_ind=[1, 4, 2, 3, 2, 4, 5, 5], val=[1, 2, 3, 4, 5, 6, 7, 8],
+         x=[1, 2, 3, 4, 5], alpha=1.0, beta=0.0, y0=[0, 0, 0, 0, 0], y_gold=[9, 6, 12, 69, 40]),
+]
+
+# ------------------------------------------------------------------------------------------
+# clean CSR after optimize: inputs tests/unit_tests/common_data_utils.h:609-760,
+# expected tests/unit_tests/hint_tests.cpp:75-170 (all base 0, double)
+# ------------------------------------------------------------------------------------------
+N10_in_col = [9, 4, 6, 3, 8, 6, 0, 6, 4, 6, 7, 1, 2, 9, 3, 8, 5, 0, 6, 2, 1,
+              5, 3, 8, 3, 8, 5, 1, 4, 8, 5, 9, 1, 4, 8, 5, 4, 6, 6, 2, 3, 7]
+N10_in_val = [5.91, 5.95, 7.95, 0.83, 5.48, 6.75, 0.01, 4.78, 9.20, 3.40, 2.26, 3.01, 8.34, 6.82,
+              7.40, 1.12, 3.31, 4.96, 2.66, 1.77, 5.28, 8.95, 3.09, 2.37, 4.48, 2.92, 1.46, 6.17,
+              8.77, 9.96, 7.19, 9.61, 6.48, 4.95, 6.76, 8.87, 5.07, 3.58, 2.09, 8.66, 6.77, 3.69]
+N10_out_col = [0, 4, 6, 9, 1, 3, 6, 8, 0, 2, 6, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 1, 2, 3, 4,
+               5, 6, 8, 3, 5, 8, 1, 4, 5, 6, 8, 1, 4, 5, 7, 8, 9, 4, 6, 8, 2, 3, 6, 7, 9]
+N10_out_val = [0, 5.95, 7.95, 5.91, 0, 0.83, 6.75, 5.48, 0.01, 0, 4.78, 4.96, 3.01,
+               8.34, 7.4, 9.2, 3.31, 3.4, 2.26, 1.12, 6.82, 5.28, 1.77, 3.09, 0, 8.95,
+               2.66, 2.37, 4.48, 1.46, 2.92, 6.17, 8.77, 7.19, 0, 9.96, 6.48, 4.95, 8.87,
+               0, 6.76, 9.61, 5.07, 3.58, 0, 8.66, 6.77, 2.09, 3.69, 0]
+out["clean_csr"] = [
+    dict(name="N5_full_sorted", m=5, n=5,
+         row_ptr=[0, 2, 3, 4, 7, 8], col_ind=[0, 3, 1, 2, 1, 3, 4, 4], val=[1, 2, 3, 4, 5, 6, 7, 8],
+         exp=dict(icrow=[0, 2, 3, 4, 7, 8], icol=[0, 3, 1, 2, 1, 3, 4, 4],
+                  aval=[1, 2, 3, 4, 5, 6, 7, 8], idiag=[0, 2, 3, 5, 7], iurow=[1, 3, 4, 6, 8],
+                  is_internal=False)),
+    dict(name="N5_full_unsorted", m=5, n=5,
+         row_ptr=[0, 2, 3, 4, 7, 8], col_ind=[3, 0, 1, 2, 3, 1, 4, 4], val=[2, 1, 3, 4, 6, 5, 7, 8],
+         exp=dict(icrow=[0, 2, 3, 4, 7, 8], icol=[0, 3, 1, 2, 1, 3, 4, 4],
+                  aval=[1, 2, 3, 4, 5, 6, 7, 8], idiag=[0, 2, 3, 5, 7], iurow=[1, 3, 4, 6, 8],
+                  is_internal=True)),
+    dict(name="N59_partial_sort", m=5, n=5,
+         row_ptr=[0, 2, 3, 4, 8, 9], col_ind=[0, 3, 1, 2, 2, 1, 3, 4, 4],
+         val=[1, 2, 3, 4, 9, 5, 6, 7, 8],
+         exp=dict(icrow=[0, 2, 3, 4, 8, 9], icol=[0, 3, 1, 2, 2, 1, 3, 4, 4],
+                  aval=[1, 2, 3, 4, 9, 5, 6, 7, 8], idiag=[0, 2, 3, 6, 8], iurow=[1, 3, 4, 7, 9],
+                  is_internal=False)),
+    dict(name="N5_1_hole", m=5, n=5,
+         row_ptr=[0, 2, 3, 4, 6, 7], col_ind=[3, 0, 1, 2, 1, 4, 4], val=[2, 1, 3, 4, 5, 7, 8],
+         exp=dict(icrow=[0, 2, 3, 4, 7, 8], icol=[0, 3, 1, 2, 1, 3, 4, 4],
+                  aval=[1, 2, 3, 4, 5, 0, 7, 8], idiag=[0, 2, 3, 5, 7], iurow=[1, 3, 4, 6, 8],
+                  is_internal=True)),
+    dict(name="N5_empty_rows", m=5, n=5,
+         row_ptr=[0, 2, 2, 3, 5, 5], col_ind=[3, 0, 2, 1, 4], val=[2, 1, 4, 5, 7],
+         exp=dict(icrow=[0, 2, 3, 4, 7, 8], icol=[0, 3, 1, 2, 1, 3, 4, 4],
+                  aval=[1, 2, 0, 4, 5, 0, 7, 0], idiag=[0, 2, 3, 5, 7], iurow=[1, 3, 4, 6, 8],
+                  is_internal=True)),
+    dict(name="N10_random", m=10, n=10,
+         row_ptr=[0, 3, 6, 8, 18, 24, 27, 31, 36, 38, 42], col_ind=N10_in_col, val=N10_in_val,
+         exp=dict(icrow=[0, 4, 8, 11, 21, 28, 31, 36, 42, 45, 50], icol=N10_out_col,
+                  aval=N10_out_val, idiag=[0, 4, 9, 14, 24, 29, 34, 39, 44, 49],
+                  iurow=[1, 5, 10, 15, 25, 30, 35, 40, 45, 50], is_internal=True)),
+    dict(name="M5_rect_N7", m=5, n=7,
+         row_ptr=[0, 3, 5, 6, 10, 13], col_ind=[0, 3, 5, 1, 5, 2, 1, 3, 4, 6, 4, 5, 6],
+         val=[1, 2, 1, 3, 2, 4, 5, 6, 7, 3, 8, 4, 5],
+         exp=dict(icrow=[0, 3, 5, 6, 10, 13], icol=[0, 3, 5, 1, 5, 2, 1, 3, 4, 6, 4, 5, 6],
+                  aval=[1, 2, 1, 3, 2, 4, 5, 6, 7, 3, 8, 4, 5], idiag=[0, 3, 5, 7, 10],
+                  iurow=[1, 4, 6, 8, 11], is_internal=False)),
+    dict(name="M5_rect_N7_2holes", m=5, n=7,
+         row_ptr=[0, 3, 5, 5, 9, 11], col_ind=[0, 3, 5, 1, 5, 1, 3, 4, 6, 5, 6],
+         val=[1, 2, 1, 3, 2, 5, 6, 7, 3, 4, 5],
+         exp=dict(icrow=[0, 3, 5, 6, 10, 13], icol=[0, 3, 5, 1, 5, 2, 1, 3, 4, 6, 4, 5, 6],
+                  aval=[1, 2, 1, 3, 2, 0, 5, 6, 7, 3, 0, 4, 5], idiag=[0, 3, 5, 7, 10],
+                  iurow=[1, 4, 6, 8, 11], is_internal=True)),
+    dict(name="M7_rect_N5", m=7, n=5,
+         row_ptr=[0, 2, 3, 4, 7, 8, 10, 12], col_ind=[0, 3, 1, 2, 1, 3, 4, 4, 1, 2, 0, 3],
+         val=[1, 2, 3, 4, 5, 6, 7, 8, 1, 2, 3, 4],
+         exp=dict(icrow=[0, 2, 3, 4, 7, 8, 10, 12], icol=[0, 3, 1, 2, 1, 3, 4, 4, 1, 2, 0, 3],
+                  aval=[1, 2, 3, 4, 5, 6, 7, 8, 1, 2, 3, 4], idiag=[0, 2, 3, 5, 7],
+                  iurow=[1, 3, 4, 6, 8], is_internal=False)),
+    dict(name="M7_rect_N5_2holes", m=7, n=5,
+         row_ptr=[0, 2, 3, 3, 6, 6, 8, 10], col_ind=[0, 3, 1, 3, 1, 4, 1, 2, 0, 3],
+         val=[1, 2, 3, 6, 5, 7, 1, 2, 3, 4],
+         exp=dict(icrow=[0, 2, 3, 4, 7, 8, 10, 12], icol=[0, 3, 1, 2, 1, 3, 4, 4, 1, 2, 0, 3],
+                  aval=[1, 2, 3, 0, 5, 6, 7, 0, 1, 2, 3, 4], idiag=[0, 2, 3, 5, 7],
+                  iurow=[1, 3, 4, 6, 8], is_internal=True)),
+]
+for c in out["clean_csr"]:
+    c["src"] = "tests/unit_tests/common_data_utils.h:609-760 + hint_tests.cpp:75-170"
+
+# ------------------------------------------------------------------------------------------
+# TRSV known answers (real double).  variants: (label, fill, trans, unit)
+# D7: common_data_utils.h:1373-1543;  S7: :1545-1801;  N25: :1803-2305
+# xref in the JSON is already multiplied by alpha (the reference does the same, :1541, :1768).
+# ------------------------------------------------------------------------------------------
+VARIANTS = [("Lx", "lower", "n", False), ("LL_Ix", "lower", "n", True),
+            ("LTx", "lower", "t", False), ("LL_ITx", "lower", "t", True),
+            ("Ux", "upper", "n", False), ("UU_Ix", "upper", "n", True),
+            ("UTx", "upper", "t", False), ("UU_ITx", "upper", "t", True)]
+
+trsv = []
+d7 = dict(m=7, row_ptr=[0, 1, 2, 3, 4, 5, 6, 7], col_ind=[0, 1, 2, 3, 4, 5, 6],
+          val=[-2, -4, 3, 5, -7, 9, 4], b=[1, -2, 8, 5, -1, 11, 3], alpha=-9.845233)
+for lab, fill, tr, unit in VARIANTS:
+    xs = [1, -2, 8, 5, -1, 11, 3] if unit else [-0.5, 0.5, 8.0 / 3.0, 1.0, 1.0 / 7.0, 11.0 / 9.0, 0.75]
+    trsv.append(dict(name="D7_" + lab + "_aB", src="tests/unit_tests/common_data_utils.h:1373-1543",
+                     fill=fill, trans=tr, unit=unit, xref=[d7["alpha"] * v for v in xs], **d7))
+
+s7 = dict(m=7, row_ptr=[0, 5, 10, 15, 21, 26, 30, 34],
+          col_ind=[0, 1, 4, 5, 6, 0, 1, 2, 3, 5, 1, 2, 3, 4, 6, 0, 2,
+                   3, 4, 5, 6, 1, 2, 3, 4, 5, 0, 2, 3, 5, 2, 3, 4, 6],
+          val=[-2, 1, 3, 7, -1, 2, -4, 1, 2, 4, 6, -2, 9, 1, 9, -9, 1, -2, 1, 1, 1,
+               8, 2, 1, -2, 2, 8, 4, 3, 7, 3, 6, 9, 2],
+          b=[1, -2, 0, 2, -1, 0, 3], alpha=1.3334)
+s7x = {"Lx": [-0.5, 0.25, 0.75, 1.625, 3.0625, -0.553571428571, -18.28125],
+       "LL_Ix": [1, -4, 24, -13, -4, -65, 45],
+       "LTx": [2.03125, 34.59375, 13.0625, 7.125, 7.25, 0, 1.5],
+       "LL_ITx": [85, 12, 35, 12, -28, 0, 3],
+       "Ux": [0.625, 2.25, 7.0, 0.0, 0.5, 0.0, 1.5],
+       "UU_Ix": [-17, 24, -26, 0, -1, 0, 3],
+       "UTx": [-5.0e-1, 3.75e-1, 1.875e-1, 2.1875e-1, -4.6875e-2, 2.6785714e-1, 2.96875e-1],
+       "UU_ITx": [1, -3, 3, -19, 12, 0, -4]}
+for lab, fill, tr, unit in VARIANTS:
+    trsv.append(dict(name="S7_" + lab + "_aB", src="tests/unit_tests/common_data_utils.h:1545-1801",
+                     fill=fill, trans=tr, unit=unit, xref=[s7["alpha"] * v for v in s7x[lab]], **s7))
+
+
+def _nums(txt):
+    txt = re.sub(r"\(T\)", "", txt)
+    return [float(t) for t in re.findall(r"[-+]?\d+\.?\d*(?:[eE][-+]?\d+)?", txt)]
+
+
+def extract_n25():
+    """Numeric extraction of the N25 system from the reference's fixture database."""
+    src = open(os.path.join(REF, "common_data_utils.h")).read()
+    lo = src.index("case N25_Lx_aB: // large m test set")
+    hi = src.index("case A_nullptr:", lo)
+    blk = src[lo:hi]
+    res = {}
+    for lab, _, _, _ in VARIANTS:
+        key = "case N25_%s_aB:" % lab
+        # second occurrence = the inner switch (first is the outer case list)
+        p = [m.start() for m in re.finditer(re.escape(key), blk)][-1]
+        q = blk.index("if constexpr(!cplx)", p)
+        a = blk.index("{", q)
+        z = blk.index("};", a)
+        b = _nums(blk[a + 1:z])
+        assert len(b) == 25, (lab, len(b))
+        res[lab] = b
+    p2 = blk.index("START PART 2")
+
+    def arr(name):
+        a = blk.index(name + " = {", p2) if (name + " = {") in blk[p2:] else blk.index(name + "  = {", p2)
+        a = blk.index("{", a)
+        z = blk.index("};", a)
+        return _nums(blk[a + 1:z])
+
+    icrow = [int(v) for v in arr("icrowa")]
+    icol = [int(v) for v in arr("icola")]
+    aval = arr("aval")
+    assert len(icrow) == 26 and len(icol) == 565 and len(aval) == 565, (len(icrow), len(icol), len(aval))
+    return icrow, icol, aval, res
+
+
+n25_path = os.path.join(HERE, "reference_kats.json")
+if os.path.isdir(REF):
+    icrow, icol, aval, bmap = extract_n25()
+    for lab, fill, tr, unit in VARIANTS:
+        trsv.append(dict(name="N25_" + lab + "_aB", src="tests/unit_tests/common_data_utils.h:1803-2305",
+                         fill=fill, trans=tr, unit=unit, m=25, row_ptr=icrow, col_ind=icol, val=aval,
+                         b=bmap[lab], alpha=2.0, xref=[3.0] * 25))
+else:  # keep what the committed file already has
+    old = json.load(open(n25_path))
+    trsv += [t for t in old["trsv"] if t["name"].startswith("N25_")]
+out["trsv"] = trsv
+# absolute tolerance the reference applies to these systems: expected_precision(10) =
+# 10*sqrt(2*eps) (library/src/extra/aoclsparse_utils.hpp:556-580, trsv_tests.cpp:174-186)
+out["trsv_abs_tol"] = 10.0 * (2.0 * 2.220446049250313e-16) ** 0.5
+
+# ------------------------------------------------------------------------------------------
+# csrmm known answers, tests/unit_tests/csrmm_tests.cpp:99-325 (ids 0, 1, 3; op = none; base 0)
+# dense operands are packed (ld = leading dimension of the stated order).
+# ------------------------------------------------------------------------------------------
+B1 = [1.0, -2.0, 3.0, 4.0, 5.0, -6.0, 1.0, -2.0, 3.0, 4.0, 5.0, -6.0, 1.0,
+      -2.0, 3.0, 4.0, 5.0, -6.0, 1.0, -2.0, 3.0, 4.0, 5.0, -6.0, 10]
+out["csrmm"] = [
+    dict(name="id0_alpha0", src="tests/unit_tests/csrmm_tests.cpp:99-163", m=3, k=3, n=3,
+         row_ptr=[0, 2, 3, 4], col_ind=[1, 2, 0, 2], val=[42.0, 0.2, 4.6, -8], alpha=0.0, beta=-3.2,
+         B=[-1.0, -2.7, 3.0, 4.5, 5.8, -6.0, 1.0, -2.0, 3.0],
+         C=[1.0, -2.0, 3.0, 4.0, 5.0, -6.0, 1.0, -2.0, 3.0],
+         C_exp_col=[-3.2, 6.4, -9.6, -12.8, -16, 19.2, -3.2, 6.4, -9.6],
+         C_exp_row=[-3.2, 6.4, -9.6, -12.8, -16, 19.2, -3.2, 6.4, -9.6]),
+    dict(name="id1_5x5", src="tests/unit_tests/csrmm_tests.cpp:164-217", m=5, k=5, n=5,
+         row_ptr=[0, 2, 3, 4, 5, 8], col_ind=[1, 3, 1, 4, 2, 2, 3, 4],
+         val=[42.0, 2, 4, 8, 10, 12, 14, 16], alpha=3.0, beta=2.5, B=B1, C=B1,
+         C_exp_col=[-225.5, -29, 127.5, 100, 528.5, 129, 14.5, 91, -52.5, 256,
+                    -755.5, -87, 74.5, 25, 103.5, 646, 72.5, -63, -177.5, -275,
+                    475.5, 58, 252.5, 135, 433],
+         C_exp_row=[-729.5, 151, -280.5, 394, 504.5, -87, 14.5, -29, 43.5, 58,
+                    84.5, 81, 122.5, -149, 247.5, 160, -167.5, 15, -57.5, 85,
+                    499.5, 196, 36.5, -333, 529],
+         C_exp_col_T=[2.5, 97, 307.5, 226, 324.5, -15, -741.5, 229, 139.5, 154,
+                      12.5, 543, 50.5, 151, 175.5, 10, 576.5, -57, -57.5, -245,
+                      7.5, 436, 192.5, 423, 625],
+         C_exp_row_T=[2.5, -5, 7.5, 10, 12.5, 39, -237.5, 349, 547.5, 688,
+                      240.5, 279, 2.5, -191, 307.5, 142, 168.5, 213, -225.5, 445,
+                      271.5, 58, 276.5, -351, 577]),
+    dict(name="id3_4x3", src="tests/unit_tests/csrmm_tests.cpp:292-324", m=4, k=3, n=2,
+         row_ptr=[0, 0, 1, 2, 3], col_ind=[0, 1, 2], val=[2, 4, 8], alpha=-4.5, beta=11.0,
+         B=[3.0, 7.0, 3.0, 1.0, 5.0, 2.0], C=[0.0] * 8,
+         C_exp_col=[0, -27, -126, -108, 0, -9, -90, -72],
+         C_exp_row=[0, 0, -27, -63, -54, -18, -180, -72]),
+]
+
+with open(n25_path, "w") as f:
+    json.dump(out, f, indent=None, separators=(",", ":"))
+    f.write("\n")
+print("wrote", n25_path, os.path.getsize(n25_path), "bytes;",
+      len(out["trsv"]), "trsv systems")

@@ -1,0 +1,259 @@
+"""Pin the CPU oracle (oracle/oracle.c) against the reference's own known-answer vectors
+(tests/golden/reference_kats.json; provenance in tests/golden/make_fixtures.py)."""
+import numpy as np
+import pytest
+
+import oracle
+
+EPS = np.finfo(np.float64).eps
+
+
+def test_csrmv_kat(kats):
+    # tests/unit_tests/csrmv_tests.cpp:185-220, tests/examples/sample_spmv_c.c:50-59
+    for c in kats["csrmv"]:
+        nnz = len(c["val"])
+        for kid in (-1, 0, 1, 2, 3):
+            st, y = oracle.dcsrmv(kid, c["base"], c["alpha"], c["m"], nnz, c["val"], c["col_ind"],
+                                  c["row_ptr"], c["x"], c["beta"], c["y0"])
+            assert st == 0
+            assert np.array_equal(y, np.array(c["y_gold"], dtype=np.float64)), (c["name"], kid)
+        for order in ("ref", "lane4", "lane8"):
+            st, y = oracle.dcsrmv_order(order, c["base"], c["alpha"], c["m"], c["val"], c["col_ind"],
+                                        c["row_ptr"], c["x"], c["beta"], c["y0"])
+            assert st == 0 and np.array_equal(y, np.array(c["y_gold"], dtype=np.float64))
+
+
+def test_csrmv_beta0_ignores_nan_in_y(kats):
+    # csrmv_kr.hpp:504-509: y is not read when beta == 0 (mv_tests.cpp:1858-2290)
+    c = kats["csrmv"][0]
+    y0 = np.full(c["m"], np.nan)
+    st, y = oracle.dcsrmv(-1, 0, 1.0, c["m"], 8, c["val"], c["col_ind"], c["row_ptr"], c["x"], 0.0, y0)
+    assert st == 0 and np.array_equal(y, np.array(c["y_gold"], dtype=np.float64))
+
+
+def test_clean_csr_kat(kats):
+    # tests/unit_tests/hint_tests.cpp:75-170: clean CSR must be integer-exact
+    for c in kats["clean_csr"]:
+        nnz = len(c["val"])
+        r = oracle.dcsr_optimize(c["m"], c["n"], nnz, 0, c["row_ptr"], c["col_ind"], c["val"])
+        e = c["exp"]
+        assert r["status"] == 0, c["name"]
+        assert r["is_internal"] == e["is_internal"], c["name"]
+        assert np.array_equal(r["ptr"], e["icrow"]), c["name"]
+        assert np.array_equal(r["ind"], e["icol"]), c["name"]
+        assert np.array_equal(r["val"], np.array(e["aval"], dtype=np.float64)), c["name"]
+        dim = min(c["m"], c["n"])
+        assert np.array_equal(r["idiag"][:dim], e["idiag"]), c["name"]
+        assert np.array_equal(r["iurow"][:dim], e["iurow"]), c["name"]
+
+
+def _solve(kats_case, base):
+    c = kats_case
+    m = c["m"]
+    ptr = np.array(c["row_ptr"], dtype=np.int32) + base
+    ind = np.array(c["col_ind"], dtype=np.int32) + base
+    val = np.array(c["val"], dtype=np.float64)
+    r = oracle.dcsr_optimize(m, m, len(val), base, ptr, ind, val)
+    assert r["status"] == 0
+    kind = {("lower", "n"): "l", ("lower", "t"): "lt", ("upper", "n"): "u", ("upper", "t"): "ut"}[
+        (c["fill"], c["trans"])]
+    ilend = r["idiag"] if c["fill"] == "lower" else r["iurow"]
+    st, x = oracle.dtrsv(kind, c["alpha"], m, r["base"], r["val"], r["ind"], r["ptr"], ilend,
+                         c["b"], c["unit"])
+    assert st == 0
+    return x
+
+
+def test_trsv_kat(kats):
+    # tests/unit_tests/common_data_utils.h:1373-2305 via trsv_tests.cpp:279-318
+    tol = kats["trsv_abs_tol"]
+    assert len(kats["trsv"]) == 24
+    for c in kats["trsv"]:
+        for base in (0, 1):
+            x = _solve(c, base)
+            err = np.max(np.abs(x - np.array(c["xref"])))
+            assert err <= tol, (c["name"], base, err)
+
+
+def test_trsv_strided(kats):
+    c = [t for t in kats["trsv"] if t["name"] == "S7_Lx_aB"][0]
+    m = c["m"]
+    r = oracle.dcsr_optimize(m, m, len(c["val"]), 0, c["row_ptr"], c["col_ind"], c["val"])
+    incb, incx = 3, 2
+    b = np.zeros(m * incb)
+    b[::incb] = c["b"]
+    st, x = oracle.dtrsv("l", c["alpha"], m, 0, r["val"], r["ind"], r["ptr"], r["idiag"], b,
+                         c["unit"], incb=incb, incx=incx)
+    assert st == 0
+    assert np.max(np.abs(x[::incx][:m] - np.array(c["xref"]))) <= kats["trsv_abs_tol"]
+
+
+def test_csrmm_kat(kats):
+    # tests/unit_tests/csrmm_tests.cpp:99-325
+    for c in kats["csrmm"]:
+        m, k, n = c["m"], c["k"], c["n"]
+        for order, ldb, ldc, key in (("col", k, m, "C_exp_col"), ("row", n, n, "C_exp_row")):
+            if c["alpha"] == 0.0:
+                st, C = oracle.dscale_dense(order, c["C"], m, n, ldc, c["beta"])
+            else:
+                st, C = oracle.dcsrmm(order, c["alpha"], 0, c["val"], c["col_ind"], c["row_ptr"], m,
+                                      c["B"], n, ldb, c["beta"], c["C"], ldc)
+            assert st == 0
+            exp = np.array(c[key], dtype=np.float64)
+            assert np.allclose(C[: m * n], exp, rtol=1e-13, atol=1e-12), (c["name"], order)
+
+
+def test_csrmm_transpose_kat_via_csr2csc(kats):
+    # op = transpose KATs (csrmm_tests.cpp:190-215): the reference transposes A with csr2csc and
+    # runs the same kernels (csrmm.hpp:737-771).
+    c = [t for t in kats["csrmm"] if t["name"] == "id1_5x5"][0]
+    m, k, n = c["m"], c["k"], c["n"]
+    st, cp, ri, cv = oracle.dcsr2csc(m, k, len(c["val"]), 0, 0, c["row_ptr"], c["col_ind"], c["val"])
+    assert st == 0
+    for order, ld, key in (("col", 5, "C_exp_col_T"), ("row", 5, "C_exp_row_T")):
+        st, C = oracle.dcsrmm(order, c["alpha"], 0, cv, ri, cp, k, c["B"], n, ld, c["beta"], c["C"], ld)
+        assert st == 0
+        assert np.allclose(C, np.array(c[key]), rtol=1e-13, atol=1e-12), order
+
+
+def _rand_csr(rng, m, n, row_nnz, base=0):
+    ptr = [0]
+    ind, val = [], []
+    for i in range(m):
+        k = int(row_nnz(i))
+        cols = np.sort(rng.choice(n, size=min(k, n), replace=False))
+        ind += list(cols)
+        val += list(rng.uniform(-1, 1, size=len(cols)))
+        ptr.append(len(ind))
+    return (np.array(ptr, np.int32) + base, np.array(ind, np.int32) + base,
+            np.array(val, np.float64))
+
+
+def test_csrmv_orders_within_forward_error_bound():
+    """All three reference orders agree within c*eps*sum|a_ij x_j|."""
+    rng = np.random.default_rng(69069)
+    m = n = 600
+    ptr, ind, val = _rand_csr(rng, m, n, lambda i: rng.integers(0, 90))
+    x = rng.uniform(-1, 1, n)
+    y0 = rng.uniform(-1, 1, m)
+    ref = None
+    absrow = np.zeros(m)
+    for i in range(m):
+        s, e = ptr[i], ptr[i + 1]
+        absrow[i] = np.sum(np.abs(val[s:e] * x[ind[s:e]]))
+    exact = np.array([np.sum(val[ptr[i]:ptr[i + 1]].astype(np.longdouble)
+                             * x[ind[ptr[i]:ptr[i + 1]]].astype(np.longdouble)) for i in range(m)])
+    for order in ("ref", "lane4", "lane8"):
+        st, y = oracle.dcsrmv_order(order, 0, 1.0, m, val, ind, ptr, x, 0.0, y0)
+        assert st == 0
+        rowlen = np.diff(ptr)
+        bound = (rowlen + 2) * EPS * absrow + 1e-300
+        assert np.all(np.abs(y - exact.astype(np.float64)) <= bound), order
+        ref = y if ref is None else ref
+    # base-1 gives bitwise the same result as base-0
+    st, y1 = oracle.dcsrmv_order("lane8", 1, 1.0, m, val, ind + 1, ptr + 1, x, 0.0, y0)
+    st, y0_ = oracle.dcsrmv_order("lane8", 0, 1.0, m, val, ind, ptr, x, 0.0, y0)
+    assert np.array_equal(y1, y0_)
+
+
+def test_dispatch_rule_and_kid():
+    # csrmv.hpp:332-333: nnz <= 10*m forces the scalar kernel whatever kid says
+    rng = np.random.default_rng(1)
+    m = n = 200
+    ptr, ind, val = _rand_csr(rng, m, n, lambda i: 9)
+    x = rng.uniform(-1, 1, n)
+    st, ya = oracle.dcsrmv(3, 0, 1.0, m, len(val), val, ind, ptr, x, 0.0, np.zeros(m))
+    st, yr = oracle.dcsrmv_order("ref", 0, 1.0, m, val, ind, ptr, x, 0.0, np.zeros(m))
+    assert np.array_equal(ya, yr)
+    ptr, ind, val = _rand_csr(rng, m, n, lambda i: 40)
+    st, ya = oracle.dcsrmv(-1, 0, 1.0, m, len(val), val, ind, ptr, x, 0.0, np.zeros(m))
+    st, y8 = oracle.dcsrmv_order("lane8", 0, 1.0, m, val, ind, ptr, x, 0.0, np.zeros(m))
+    assert np.array_equal(ya, y8)
+    st, _ = oracle.dcsrmv(4, 0, 1.0, m, len(val), val, ind, ptr, x, 0.0, np.zeros(m))
+    assert st == 14  # aoclsparse_status_invalid_kid
+    # OpenMP leg computes the same bits
+    st, yo = oracle.dcsrmv(-1, 0, 2.5, m, len(val), val, ind, ptr, x, 0.5, np.ones(m), nthreads=2)
+    st, ys = oracle.dcsrmv(-1, 0, 2.5, m, len(val), val, ind, ptr, x, 0.5, np.ones(m))
+    assert np.array_equal(yo, ys)
+
+
+def test_transposed_spmv_matches_dense():
+    rng = np.random.default_rng(5)
+    m, n = 70, 50
+    ptr, ind, val = _rand_csr(rng, m, n, lambda i: rng.integers(0, 20))
+    A = np.zeros((m, n))
+    for i in range(m):
+        A[i, ind[ptr[i]:ptr[i + 1]]] = val[ptr[i]:ptr[i + 1]]
+    x = rng.uniform(-1, 1, m)
+    y0 = rng.uniform(-1, 1, n)
+    st, y = oracle.dcsrmvt(0, 5.1, m, n, val, ind, ptr, x, 3.2, y0)
+    assert st == 0 and np.allclose(y, 5.1 * A.T @ x + 3.2 * y0, rtol=1e-13, atol=1e-13)
+
+
+def test_mat_check_classes():
+    # csr_util.cpp:124-279
+    st, sort, fd = oracle.mat_check(5, 5, 8, [0, 2, 3, 4, 7, 8], [0, 3, 1, 2, 1, 3, 4, 4], [1.0] * 8, 0, 0)
+    assert (st, sort, fd) == (0, 1, True)
+    st, sort, fd = oracle.mat_check(5, 5, 8, [0, 2, 3, 4, 7, 8], [3, 0, 1, 2, 3, 1, 4, 4], [1.0] * 8, 0, 0)
+    assert (st, sort, fd) == (0, 3, True)
+    st, sort, fd = oracle.mat_check(5, 5, 9, [0, 2, 3, 4, 8, 9], [0, 3, 1, 2, 2, 1, 3, 4, 4], [1.0] * 9, 0, 0)
+    assert (st, sort, fd) == (0, 2, True)
+    # out-of-range column -> invalid_index_value; duplicate diagonal -> invalid_value
+    assert oracle.mat_check(2, 2, 2, [0, 1, 2], [0, 2], [1.0, 1.0], 0, 0)[0] == 6
+    assert oracle.mat_check(2, 2, 3, [0, 2, 3], [0, 0, 1], [1.0] * 3, 0, 0)[0] == 5
+    assert oracle.mat_check(2, 2, 2, [1, 1, 2], [0, 1], [1.0] * 2, 0, 0)[0] == 5  # ptr[0] != base
+
+
+def test_ilu0_and_trsv_roundtrip():
+    """ILU(0) of a 5-pt Laplacian: L*U reproduces A on A's pattern; L solve has tiny residual."""
+    g = 12
+    m = g * g
+    rows, cols, vals = [], [], []
+    ptr = [0]
+    for r in range(m):
+        i, j = divmod(r, g)
+        for c, v in ((r - g, -1.0), (r - 1, -1.0), (r, 4.0), (r + 1, -1.0), (r + g, -1.0)):
+            if c < 0 or c >= m or (c == r - 1 and j == 0) or (c == r + 1 and j == g - 1):
+                continue
+            cols.append(c)
+            vals.append(v)
+        ptr.append(len(cols))
+    st, lu, diag = oracle.dilu0(m, 0, ptr, cols, vals)
+    assert st == 0
+    L = np.eye(m)
+    U = np.zeros((m, m))
+    A = np.zeros((m, m))
+    for r in range(m):
+        for p in range(ptr[r], ptr[r + 1]):
+            A[r, cols[p]] = vals[p]
+            if cols[p] < r:
+                L[r, cols[p]] = lu[p]
+            else:
+                U[r, cols[p]] = lu[p]
+    P = (A != 0)
+    assert np.allclose((L @ U)[P], A[P], atol=1e-12)
+    r = oracle.dcsr_optimize(m, m, len(cols), 0, ptr, cols, lu)
+    assert not r["is_internal"]
+    b = L @ np.ones(m)
+    st, x = oracle.dtrsv("l", 1.0, m, 0, lu, cols, ptr, r["idiag"], b, True)
+    assert st == 0 and np.max(np.abs(x - 1.0)) < 1e-13
+
+
+def test_sp2m_matches_dense():
+    rng = np.random.default_rng(11)
+    m, k, n = 40, 30, 50
+    pa, ia, va = _rand_csr(rng, m, k, lambda i: rng.integers(0, 8))
+    pb, ib, vb = _rand_csr(rng, k, n, lambda i: rng.integers(0, 8), base=1)
+    st, pc, ic, vc = oracle.dcsr2m(m, n, 0, pa, ia, va, 1, pb, ib, vb)
+    assert st == 0
+    A = np.zeros((m, k))
+    B = np.zeros((k, n))
+    for i in range(m):
+        A[i, ia[pa[i]:pa[i + 1]]] = va[pa[i]:pa[i + 1]]
+    for i in range(k):
+        B[i, ib[pb[i] - 1:pb[i + 1] - 1] - 1] = vb[pb[i] - 1:pb[i + 1] - 1]
+    C = np.zeros((m, n))
+    for i in range(m):
+        assert len(set(ic[pc[i]:pc[i + 1]])) == pc[i + 1] - pc[i]
+        C[i, ic[pc[i]:pc[i + 1]]] = vc[pc[i]:pc[i + 1]]
+    assert np.allclose(C, A @ B, atol=1e-13)
