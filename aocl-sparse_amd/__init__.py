@@ -1,0 +1,305 @@
+"""ctypes view of libaoclsparse_mi355.so -- the C-ABI drop-in for the aoclsparse_* hot path.
+
+The directory name carries a hyphen (repo contract), so import it through
+``__graft_entry__.load_package()`` (importlib by path, module name ``aocl_sparse_amd``).
+
+This module holds NO arithmetic: it declares the C signatures of include/aoclsparse.h and
+include/aoclsparse_mi355.h and a few numpy/torch conveniences for tests and bench.py.  If the shared
+library has not been built it raises -- there is no Python or CPU fallback for the product path.
+"""
+import ctypes
+import os
+from ctypes import POINTER, byref, c_bool, c_char_p, c_double, c_float, c_int, c_int32, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libaoclsparse_mi355.so")
+INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
+
+# enum values of include/aoclsparse.h
+OP_NONE, OP_TRANSPOSE, OP_CONJ_TRANSPOSE = 111, 112, 113
+BASE_ZERO, BASE_ONE = 0, 1
+TYPE_GENERAL, TYPE_SYMMETRIC, TYPE_HERMITIAN, TYPE_TRIANGULAR = 0, 1, 2, 3
+DIAG_NON_UNIT, DIAG_UNIT, DIAG_ZERO = 0, 1, 2
+FILL_LOWER, FILL_UPPER = 0, 1
+ORDER_ROW, ORDER_COLUMN = 0, 1
+STAGE_NNZ_COUNT, STAGE_FINALIZE, STAGE_FULL = 0, 1, 2
+MEM_MINIMAL, MEM_UNRESTRICTED = 0, 1
+PTR_AUTO, PTR_HOST, PTR_DEVICE = 0, 1, 2
+
+STATUS = {
+    0: "success", 1: "not_implemented", 2: "invalid_pointer", 3: "invalid_size", 4: "internal_error",
+    5: "invalid_value", 6: "invalid_index_value", 7: "maxit", 8: "user_stop", 9: "wrong_type",
+    10: "memory_error", 11: "numerical_error", 12: "invalid_operation", 13: "unsorted_input",
+    14: "invalid_kid",
+}
+
+
+class SpmvInfo(ctypes.Structure):
+    _fields_ = [("kernel", c_int32), ("order", c_int32), ("row_blocks", c_int32),
+                ("long_rows", c_int32), ("max_row_nnz", c_int32), ("device_resident", c_int32)]
+
+
+# every exported symbol of include/*.h: name -> (restype, argtypes)
+_I = c_int32
+_P = c_void_p
+SIGNATURES = {
+    # auxiliary
+    "aoclsparse_get_version": (c_char_p, []),
+    "aoclsparse_enable_instructions": (c_int, [c_char_p]),
+    "aoclsparse_debug_get": (c_int, [c_char_p, POINTER(_I), c_char_p, POINTER(c_bool), c_char_p]),
+    "aoclsparse_is_avx512_build": (_I, []),
+    "aoclsparse_create_mat_descr": (c_int, [POINTER(_P)]),
+    "aoclsparse_copy_mat_descr": (c_int, [_P, _P]),
+    "aoclsparse_destroy_mat_descr": (c_int, [_P]),
+    "aoclsparse_set_mat_index_base": (c_int, [_P, c_int]),
+    "aoclsparse_get_mat_index_base": (c_int, [_P]),
+    "aoclsparse_set_mat_type": (c_int, [_P, c_int]),
+    "aoclsparse_get_mat_type": (c_int, [_P]),
+    "aoclsparse_set_mat_fill_mode": (c_int, [_P, c_int]),
+    "aoclsparse_get_mat_fill_mode": (c_int, [_P]),
+    "aoclsparse_set_mat_diag_type": (c_int, [_P, c_int]),
+    "aoclsparse_get_mat_diag_type": (c_int, [_P]),
+    "aoclsparse_create_scsr": (c_int, [POINTER(_P), c_int, _I, _I, _I, _P, _P, _P]),
+    "aoclsparse_create_dcsr": (c_int, [POINTER(_P), c_int, _I, _I, _I, _P, _P, _P]),
+    "aoclsparse_export_scsr": (c_int, [_P, POINTER(c_int), POINTER(_I), POINTER(_I), POINTER(_I),
+                                       POINTER(_P), POINTER(_P), POINTER(_P)]),
+    "aoclsparse_export_dcsr": (c_int, [_P, POINTER(c_int), POINTER(_I), POINTER(_I), POINTER(_I),
+                                       POINTER(_P), POINTER(_P), POINTER(_P)]),
+    "aoclsparse_destroy": (c_int, [POINTER(_P)]),
+    # analysis
+    "aoclsparse_optimize": (c_int, [_P]),
+    "aoclsparse_set_mv_hint": (c_int, [_P, c_int, _P, _I]),
+    "aoclsparse_set_mv_hint_kid": (c_int, [_P, c_int, _P, _I, _I]),
+    "aoclsparse_set_sv_hint": (c_int, [_P, c_int, _P, _I]),
+    "aoclsparse_set_mm_hint": (c_int, [_P, c_int, _P, _I]),
+    "aoclsparse_set_2m_hint": (c_int, [_P, c_int, _P, _I]),
+    "aoclsparse_set_memory_hint": (c_int, [_P, c_int]),
+    # level 2
+    "aoclsparse_scsrmv": (c_int, [c_int, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "aoclsparse_dcsrmv": (c_int, [c_int, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "aoclsparse_smv": (c_int, [c_int, _P, _P, _P, _P, _P, _P]),
+    "aoclsparse_dmv": (c_int, [c_int, _P, _P, _P, _P, _P, _P]),
+    "aoclsparse_strsv": (c_int, [c_int, c_float, _P, _P, _P, _P]),
+    "aoclsparse_dtrsv": (c_int, [c_int, c_double, _P, _P, _P, _P]),
+    "aoclsparse_strsv_kid": (c_int, [c_int, c_float, _P, _P, _P, _P, _I]),
+    "aoclsparse_dtrsv_kid": (c_int, [c_int, c_double, _P, _P, _P, _P, _I]),
+    "aoclsparse_strsv_strided": (c_int, [c_int, c_float, _P, _P, _P, _I, _P, _I]),
+    "aoclsparse_dtrsv_strided": (c_int, [c_int, c_double, _P, _P, _P, _I, _P, _I]),
+    # level 3
+    "aoclsparse_scsrmm": (c_int, [c_int, c_float, _P, _P, c_int, _P, _I, _I, c_float, _P, _I]),
+    "aoclsparse_dcsrmm": (c_int, [c_int, c_double, _P, _P, c_int, _P, _I, _I, c_double, _P, _I]),
+    "aoclsparse_scsrmm_kid": (c_int, [c_int, c_float, _P, _P, c_int, _P, _I, _I, c_float, _P, _I, _I]),
+    "aoclsparse_dcsrmm_kid": (c_int, [c_int, c_double, _P, _P, c_int, _P, _I, _I, c_double, _P, _I, _I]),
+    "aoclsparse_sp2m": (c_int, [c_int, _P, _P, c_int, _P, _P, c_int, POINTER(_P)]),
+    "aoclsparse_spmm": (c_int, [c_int, _P, _P, POINTER(_P)]),
+    "aoclsparse_dcsr2m": (c_int, [c_int, _P, _P, c_int, _P, _P, c_int, POINTER(_P)]),
+    "aoclsparse_scsr2m": (c_int, [c_int, _P, _P, c_int, _P, _P, c_int, POINTER(_P)]),
+    # include/aoclsparse_mi355.h
+    "aoclsparse_mi355_set_pointer_mode": (c_int, [c_int]),
+    "aoclsparse_mi355_set_stream": (c_int, [_P]),
+    "aoclsparse_mi355_get_stream": (_P, []),
+    "aoclsparse_mi355_synchronize": (c_int, []),
+    "aoclsparse_mi355_device_info": (c_int, [POINTER(_I), POINTER(_I), c_char_p]),
+    "aoclsparse_mi355_timer_start": (c_int, []),
+    "aoclsparse_mi355_timer_stop": (c_int, [POINTER(c_float)]),
+    "aoclsparse_mi355_export_diag": (c_int, [_P, POINTER(_P), POINTER(_P), POINTER(_I)]),
+    "aoclsparse_mi355_get_spmv_info": (c_int, [_P, c_int, POINTER(SpmvInfo)]),
+    "aoclsparse_mi355_get_trsv_levels": (c_int, [_P, c_int, c_int, POINTER(_I)]),
+    "aoclsparse_mi355_invalidate": (c_int, [_P]),
+    "mi355_csrmv_plan_bound": (_I, [_I, _I]),
+    "mi355_csrmv_plan_host": (_I, [_I, _I, _P, _P]),
+    "mi355_dcsrmv": (c_int, [_P, _I, _I, _I, c_double, _I, _P, _P, _P, _P, _I, _P, c_double, _P]),
+    "mi355_scsrmv": (c_int, [_P, _I, _I, _I, c_float, _I, _P, _P, _P, _P, _I, _P, c_float, _P]),
+    "mi355_dcsrmm": (c_int, [_P, _I, _I, c_double, _I, _I, _P, _P, _P, _P, _I, _I, c_double, _P, _I]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once) and attach the signatures.  Raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libaoclsparse_mi355.so is not built (%s): run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` -- the HIP library is the product, there is no fallback" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here = symbol declared in include/ but not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    """numpy array / torch tensor / int / None -> c_void_p"""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return c_void_p(a)
+    if hasattr(a, "data_ptr"):  # torch tensor (host or device)
+        return c_void_p(a.data_ptr())
+    return c_void_p(a.ctypes.data)
+
+
+class Descr:
+    """aoclsparse_mat_descr wrapper."""
+
+    def __init__(self, base=0, mtype=TYPE_GENERAL, fill=FILL_LOWER, diag=DIAG_NON_UNIT):
+        self.h = c_void_p()
+        st = lib().aoclsparse_create_mat_descr(byref(self.h))
+        assert st == 0, STATUS[st]
+        L = lib()
+        assert L.aoclsparse_set_mat_index_base(self.h, base) == 0
+        assert L.aoclsparse_set_mat_type(self.h, mtype) == 0
+        assert L.aoclsparse_set_mat_fill_mode(self.h, fill) == 0
+        assert L.aoclsparse_set_mat_diag_type(self.h, diag) == 0
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().aoclsparse_destroy_mat_descr(self.h)
+                self.h = c_void_p()
+        except Exception:
+            pass
+
+
+class Matrix:
+    """aoclsparse_matrix wrapper; keeps the aliased numpy arrays alive (the library does not copy)."""
+
+    def __init__(self, base, m, n, row_ptr, col_ind, val):
+        import numpy as np
+
+        self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+        self.col_ind = np.ascontiguousarray(col_ind, dtype=np.int32)
+        self.val = np.ascontiguousarray(val)
+        assert self.val.dtype in (np.float64, np.float32)
+        self.double = self.val.dtype == np.float64
+        self.m, self.n, self.nnz, self.base = m, n, int(self.row_ptr[m]) - base if len(self.row_ptr) > m else 0, base
+        self.h = c_void_p()
+        fn = lib().aoclsparse_create_dcsr if self.double else lib().aoclsparse_create_scsr
+        self.status = fn(byref(self.h), base, m, n, self.nnz, _ptr(self.row_ptr), _ptr(self.col_ind),
+                         _ptr(self.val))
+
+    def destroy(self):
+        if self.h:
+            lib().aoclsparse_destroy(byref(self.h))
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    def export(self):
+        """-> dict(base, m, n, nnz, row_ptr, col_ind, val) copies of aoclsparse_export_?csr."""
+        import numpy as np
+
+        base, m, n, nnz = c_int(), c_int32(), c_int32(), c_int32()
+        rp, ci, v = c_void_p(), c_void_p(), c_void_p()
+        fn = lib().aoclsparse_export_dcsr if self.double else lib().aoclsparse_export_scsr
+        st = fn(self.h, byref(base), byref(m), byref(n), byref(nnz), byref(rp), byref(ci), byref(v))
+        if st != 0:
+            return dict(status=st)
+        ct = c_double if self.double else c_float
+        row_ptr = np.ctypeslib.as_array(ctypes.cast(rp, POINTER(c_int32)), (m.value + 1,)).copy()
+        col = np.ctypeslib.as_array(ctypes.cast(ci, POINTER(c_int32)), (max(nnz.value, 1),))[: nnz.value].copy()
+        val = np.ctypeslib.as_array(ctypes.cast(v, POINTER(ct)), (max(nnz.value, 1),))[: nnz.value].copy()
+        return dict(status=0, base=base.value, m=m.value, n=n.value, nnz=nnz.value, row_ptr=row_ptr,
+                    col_ind=col, val=val, aliased=(rp.value == self.row_ptr.ctypes.data))
+
+    def export_diag(self):
+        import numpy as np
+
+        d, u, internal = c_void_p(), c_void_p(), c_int32()
+        st = lib().aoclsparse_mi355_export_diag(self.h, byref(d), byref(u), byref(internal))
+        if st != 0:
+            return dict(status=st)
+        k = max(self.m, 1)
+        idiag = np.ctypeslib.as_array(ctypes.cast(d, POINTER(c_int32)), (k,))[: self.m].copy()
+        iurow = np.ctypeslib.as_array(ctypes.cast(u, POINTER(c_int32)), (k,))[: self.m].copy()
+        return dict(status=0, idiag=idiag, iurow=iurow, is_internal=bool(internal.value))
+
+    def spmv_info(self, op=OP_NONE):
+        info = SpmvInfo()
+        st = lib().aoclsparse_mi355_get_spmv_info(self.h, op, byref(info))
+        assert st == 0
+        return info
+
+    def trsv_levels(self, fill, op=OP_NONE):
+        lv = c_int32(-2)
+        assert lib().aoclsparse_mi355_get_trsv_levels(self.h, fill, op, byref(lv)) == 0
+        return lv.value
+
+
+def scalar(v, double=True):
+    return (c_double if double else c_float)(v)
+
+
+def dmv(op, alpha, A, descr, x, beta, y):
+    a, b = c_double(alpha), c_double(beta)
+    return lib().aoclsparse_dmv(op, byref(a), A.h, descr.h, _ptr(x), byref(b), _ptr(y))
+
+
+def smv(op, alpha, A, descr, x, beta, y):
+    a, b = c_float(alpha), c_float(beta)
+    return lib().aoclsparse_smv(op, byref(a), A.h, descr.h, _ptr(x), byref(b), _ptr(y))
+
+
+def dcsrmv(op, alpha, m, n, nnz, val, col, row, descr, x, beta, y):
+    a, b = c_double(alpha), c_double(beta)
+    return lib().aoclsparse_dcsrmv(op, byref(a), m, n, nnz, _ptr(val), _ptr(col), _ptr(row), descr.h,
+                                   _ptr(x), byref(b), _ptr(y))
+
+
+def scsrmv(op, alpha, m, n, nnz, val, col, row, descr, x, beta, y):
+    a, b = c_float(alpha), c_float(beta)
+    return lib().aoclsparse_scsrmv(op, byref(a), m, n, nnz, _ptr(val), _ptr(col), _ptr(row), descr.h,
+                                   _ptr(x), byref(b), _ptr(y))
+
+
+def dtrsv(op, alpha, A, descr, b, x, kid=None, incb=None, incx=None):
+    L = lib()
+    if incb is not None or incx is not None:
+        return L.aoclsparse_dtrsv_strided(op, alpha, A.h, descr.h, _ptr(b), incb or 1, _ptr(x), incx or 1)
+    if kid is None:
+        return L.aoclsparse_dtrsv(op, alpha, A.h, descr.h, _ptr(b), _ptr(x))
+    return L.aoclsparse_dtrsv_kid(op, alpha, A.h, descr.h, _ptr(b), _ptr(x), kid)
+
+
+def strsv(op, alpha, A, descr, b, x, kid=None):
+    L = lib()
+    if kid is None:
+        return L.aoclsparse_strsv(op, alpha, A.h, descr.h, _ptr(b), _ptr(x))
+    return L.aoclsparse_strsv_kid(op, alpha, A.h, descr.h, _ptr(b), _ptr(x), kid)
+
+
+def dcsrmm(op, alpha, A, descr, order, B, n, ldb, beta, C, ldc, kid=None):
+    L = lib()
+    if kid is None:
+        return L.aoclsparse_dcsrmm(op, alpha, A.h, descr.h, order, _ptr(B), n, ldb, beta, _ptr(C), ldc)
+    return L.aoclsparse_dcsrmm_kid(op, alpha, A.h, descr.h, order, _ptr(B), n, ldb, beta, _ptr(C), ldc, kid)
+
+
+def scsrmm(op, alpha, A, descr, order, B, n, ldb, beta, C, ldc):
+    return lib().aoclsparse_scsrmm(op, alpha, A.h, descr.h, order, _ptr(B), n, ldb, beta, _ptr(C), ldc)
+
+
+def device_info():
+    dev, cus = c_int32(-1), c_int32(0)
+    name = ctypes.create_string_buffer(256)
+    st = lib().aoclsparse_mi355_device_info(byref(dev), byref(cus), name)
+    return st, dev.value, cus.value, name.value.decode()
+
+
+def timer_start():
+    return lib().aoclsparse_mi355_timer_start()
+
+
+def timer_stop():
+    ms = c_float(0)
+    st = lib().aoclsparse_mi355_timer_stop(byref(ms))
+    assert st == 0, STATUS[st]
+    return ms.value

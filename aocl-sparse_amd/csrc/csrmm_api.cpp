@@ -1,0 +1,168 @@
+// csrmm_api.cpp -- aoclsparse_?csrmm(_kid): checks of level3/aoclsparse_csrmm.hpp:448-618, then the
+// HIP kernels of csrmm_kernels.hip on the device-resident CSR (A^T copy for op != none).
+#include "internal.hpp"
+
+using namespace mi355;
+
+namespace
+{
+
+template <typename T>
+aoclsparse_status stage_dense(Runtime &rt, int slot, const T *host, aoclsparse_int outer, aoclsparse_int ld,
+                              bool copy, void **dev, size_t *bytes)
+{
+    *bytes               = sizeof(T) * (size_t)outer * (size_t)ld;
+    aoclsparse_status st = rt.staging(slot, *bytes, dev);
+    if(st != aoclsparse_status_success)
+        return st;
+    if(copy && *bytes)
+        MI355_HIP_TRY(hipMemcpyAsync(*dev, host, *bytes, hipMemcpyHostToDevice, rt.stream()));
+    return aoclsparse_status_success;
+}
+
+template <typename T>
+aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclsparse_matrix A,
+                          const aoclsparse_mat_descr descr, aoclsparse_order order, const T *B,
+                          aoclsparse_int n, aoclsparse_int ldb, const T beta, T *C, aoclsparse_int ldc,
+                          aoclsparse_int kid, aoclsparse_matrix_data_type vt)
+{
+    if(!A || !B || !C || !descr)
+        return aoclsparse_status_invalid_pointer;
+    if(A->input_format != aoclsparse_csr_mat)
+        return aoclsparse_status_not_implemented;
+    if(op != aoclsparse_operation_none && op != aoclsparse_operation_transpose
+       && op != aoclsparse_operation_conjugate_transpose)
+        return aoclsparse_status_invalid_value;
+    if(descr->type != aoclsparse_matrix_type_general && descr->type != aoclsparse_matrix_type_symmetric
+       && descr->type != aoclsparse_matrix_type_hermitian)
+        return aoclsparse_status_not_implemented;
+    if((descr->type == aoclsparse_matrix_type_symmetric || descr->type == aoclsparse_matrix_type_hermitian)
+       && A->m != A->n)
+        return aoclsparse_status_invalid_size;
+    if(order != aoclsparse_order_row && order != aoclsparse_order_column)
+        return aoclsparse_status_invalid_value;
+    if(A->val_type != vt)
+        return aoclsparse_status_wrong_type;
+    if(descr->base != A->base)
+        return aoclsparse_status_invalid_value;
+
+    const aoclsparse_int m = A->m, k = A->n;
+    if(m < 0 || n < 0 || k < 0)
+        return aoclsparse_status_invalid_size;
+    if(m == 0 || n == 0 || k == 0)
+        return aoclsparse_status_success;
+    if(alpha == T(0) && beta == T(1))
+        return aoclsparse_status_success;
+    if(!A->user.val || !A->user.ptr || !A->user.ind)
+        return aoclsparse_status_invalid_pointer;
+
+    const bool           tr     = op != aoclsparse_operation_none;
+    const bool           colmaj = order == aoclsparse_order_column;
+    const aoclsparse_int b_rows = tr ? m : k; // rows of B
+    const aoclsparse_int m_c    = tr ? k : m; // rows of C
+    const aoclsparse_int chk_b  = colmaj ? b_rows : n;
+    const aoclsparse_int chk_c  = colmaj ? m_c : n;
+    if(ldb < (chk_b > 1 ? chk_b : 1))
+        return aoclsparse_status_invalid_size;
+    if(ldc < (chk_c > 1 ? chk_c : 1))
+        return aoclsparse_status_invalid_size;
+    // LP64 index range of dim*ld (csrmm.hpp:592-611)
+    const long long c_outer = colmaj ? n : m_c, b_outer = colmaj ? n : b_rows;
+    if(c_outer * (long long)ldc > 2147483647LL || b_outer * (long long)ldb > 2147483647LL)
+        return aoclsparse_status_invalid_size;
+    if(kid > 3) // KATs of csrmm.hpp:776-837 hold kernels 0..3
+        return aoclsparse_status_invalid_kid;
+
+    Runtime          &rt = Runtime::get();
+    aoclsparse_status st = rt.init();
+    if(st != aoclsparse_status_success)
+        return st;
+    std::unique_lock<std::recursive_mutex> sl(rt.stage_lock, std::defer_lock);
+    if(rt.pointer_mode != aoclsparse_mi355_pointer_device)
+        sl.lock();
+
+    const bool bdev = rt.is_device_pointer(B), cdev = rt.is_device_pointer(C);
+    void      *dB = const_cast<T *>(B), *dC = C;
+    size_t     bbytes = 0, cbytes = 0;
+    if(!cdev)
+    {
+        st = stage_dense<T>(rt, 4, C, (aoclsparse_int)c_outer, ldc, true, &dC, &cbytes);
+        if(st != aoclsparse_status_success)
+            return st;
+    }
+    auto finish = [&]() -> aoclsparse_status {
+        if(!cdev)
+        {
+            MI355_HIP_TRY(hipMemcpyAsync(C, dC, cbytes, hipMemcpyDeviceToHost, rt.stream()));
+            MI355_HIP_TRY(hipStreamSynchronize(rt.stream()));
+        }
+        return aoclsparse_status_success;
+    };
+
+    if(alpha == T(0))
+    {
+        // csrmm.hpp:614-618
+        st = launch_scale_dense<T>(rt.stream(), order, static_cast<T *>(dC), m_c, n, ldc, beta);
+        return st == aoclsparse_status_success ? finish() : st;
+    }
+    if(descr->type != aoclsparse_matrix_type_general)
+        return aoclsparse_status_not_implemented; // symmetric csrmm: next wave
+
+    if(!bdev)
+    {
+        st = stage_dense<T>(rt, 3, B, (aoclsparse_int)b_outer, ldb, true, &dB, &bbytes);
+        if(st != aoclsparse_status_success)
+            return st;
+    }
+    DeviceCsr *d = nullptr;
+    SpmvPlan  *p = nullptr;
+    st           = ensure_spmv(const_cast<aoclsparse_matrix>(A), tr, d, p);
+    if(st != aoclsparse_status_success)
+        return st;
+    {
+        std::shared_lock<std::shared_mutex> r(A->guard);
+        st = launch_csrmm<T>(rt.stream(), order, d->base, alpha, d->m, d->n, d->val.as<T>(),
+                             d->ind.as<aoclsparse_int>(), d->ptr.as<aoclsparse_int>(), static_cast<const T *>(dB),
+                             n, ldb, beta, static_cast<T *>(dC), ldc);
+    }
+    return st == aoclsparse_status_success ? finish() : st;
+}
+
+} // namespace
+
+extern "C" {
+
+aoclsparse_status aoclsparse_dcsrmm(aoclsparse_operation op, const double alpha, const aoclsparse_matrix A,
+                                    const aoclsparse_mat_descr descr, aoclsparse_order order, const double *B,
+                                    aoclsparse_int n, aoclsparse_int ldb, const double beta, double *C,
+                                    aoclsparse_int ldc)
+{
+    return csrmm_t<double>(op, alpha, A, descr, order, B, n, ldb, beta, C, ldc, -1, aoclsparse_dmat);
+}
+
+aoclsparse_status aoclsparse_scsrmm(aoclsparse_operation op, const float alpha, const aoclsparse_matrix A,
+                                    const aoclsparse_mat_descr descr, aoclsparse_order order, const float *B,
+                                    aoclsparse_int n, aoclsparse_int ldb, const float beta, float *C,
+                                    aoclsparse_int ldc)
+{
+    return csrmm_t<float>(op, alpha, A, descr, order, B, n, ldb, beta, C, ldc, -1, aoclsparse_smat);
+}
+
+aoclsparse_status aoclsparse_dcsrmm_kid(aoclsparse_operation op, const double alpha, const aoclsparse_matrix A,
+                                        const aoclsparse_mat_descr descr, aoclsparse_order order,
+                                        const double *B, aoclsparse_int n, aoclsparse_int ldb,
+                                        const double beta, double *C, aoclsparse_int ldc,
+                                        const aoclsparse_int kid)
+{
+    return csrmm_t<double>(op, alpha, A, descr, order, B, n, ldb, beta, C, ldc, kid, aoclsparse_dmat);
+}
+
+aoclsparse_status aoclsparse_scsrmm_kid(aoclsparse_operation op, const float alpha, const aoclsparse_matrix A,
+                                        const aoclsparse_mat_descr descr, aoclsparse_order order,
+                                        const float *B, aoclsparse_int n, aoclsparse_int ldb, const float beta,
+                                        float *C, aoclsparse_int ldc, const aoclsparse_int kid)
+{
+    return csrmm_t<float>(op, alpha, A, descr, order, B, n, ldb, beta, C, ldc, kid, aoclsparse_smat);
+}
+
+} // extern "C"

@@ -1,0 +1,294 @@
+// internal.hpp -- object model of the MI355X engine behind the aoclsparse_* C ABI.
+//
+// Host side keeps the reference's semantics (handles alias the user's CSR arrays, clean CSR
+// with idiag/iurow, hint list, status codes); everything a kernel touches lives in HBM in the
+// DeviceCsr mirrors below.  Layout rationale is in DESIGN.md.
+#pragma once
+
+#include "aoclsparse.h"
+#include "aoclsparse_mi355.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <shared_mutex>
+#include <vector>
+
+// ---- descriptor (library/src/include/aoclsparse_descr.h:37-47) --------------------------
+struct _aoclsparse_mat_descr
+{
+    aoclsparse_matrix_type type      = aoclsparse_matrix_type_general;
+    aoclsparse_fill_mode   fill_mode = aoclsparse_fill_mode_lower;
+    aoclsparse_diag_type   diag_type = aoclsparse_diag_type_non_unit;
+    aoclsparse_index_base  base      = aoclsparse_index_base_zero;
+};
+
+namespace mi355
+{
+
+// ---- status helpers ----------------------------------------------------------------------
+#define MI355_HIP_TRY(expr)                                   \
+    do                                                        \
+    {                                                         \
+        hipError_t e__ = (expr);                              \
+        if(e__ != hipSuccess)                                 \
+            return ::mi355::map_hip_error(e__);               \
+    } while(0)
+
+aoclsparse_status map_hip_error(hipError_t e);
+
+// ---- hinted actions (library/src/include/aoclsparse_mat_structures.hpp:36-68) -------------
+enum hinted_action
+{
+    action_none = 0,
+    action_mv,
+    action_sv,
+    action_mm,
+    action_2m,
+    action_ilu0,
+    action_sm,
+    action_dotmv,
+    action_symgs,
+    action_sorv,
+    action_syrk,
+    action_max
+};
+
+// descriptor+operation id; same enumeration idea as include/aoclsparse_mtx_dispatcher.hpp:41-74
+// restricted to what real types can produce (conjugate == plain for real data).
+enum class doid : int
+{
+    gn = 0, // general, no-trans
+    gt, // general, transpose
+    sl, // symmetric lower / upper (transpose is the same operation)
+    su,
+    tln, // triangular lower/upper x none/transpose
+    tlt,
+    tun,
+    tut,
+    len
+};
+
+doid get_doid(const _aoclsparse_mat_descr *d, aoclsparse_operation op);
+
+struct Hint
+{
+    hinted_action          act;
+    doid                   id;
+    aoclsparse_operation   trans;
+    aoclsparse_matrix_type type;
+    aoclsparse_fill_mode   fill;
+    aoclsparse_int         nop;
+    aoclsparse_int         kid;
+    bool                   optimized = false;
+};
+
+// ---- device memory -------------------------------------------------------------------------
+struct DeviceBuffer
+{
+    void  *ptr   = nullptr;
+    size_t bytes = 0;
+    DeviceBuffer() = default;
+    DeviceBuffer(const DeviceBuffer &)            = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    ~DeviceBuffer();
+    aoclsparse_status alloc(size_t nbytes);
+    aoclsparse_status upload(const void *host, size_t nbytes, hipStream_t s); // alloc + H2D
+    void              release();
+    template <typename T>
+    T *as() const
+    {
+        return static_cast<T *>(ptr);
+    }
+};
+
+// CSR arrays resident in HBM, always 4/8-byte element arrays in the SAME base as the host
+// copy they mirror (kernels subtract base at load time).
+struct DeviceCsr
+{
+    aoclsparse_int m = 0, n = 0, nnz = 0, base = 0;
+    DeviceBuffer   ptr, ind, val;
+    bool           valid = false;
+};
+
+// SpMV execution plan (CSR-Adaptive row blocks), see spmv_kernels.hip
+struct SpmvPlan
+{
+    aoclsparse_int nblocks     = 0;
+    aoclsparse_int long_rows   = 0;
+    aoclsparse_int max_row_nnz = 0;
+    DeviceBuffer   rowblocks;
+    bool           valid = false;
+};
+
+// TRSV plan of one (triangle, op) pair: the row-form structure the kernels walk plus the level sets
+// (rows sorted by dependency level), see trsv_kernels.hip / trsv_api.cpp
+struct TrsvPlan
+{
+    aoclsparse_int              nlevels = -1;
+    aoclsparse_int              max_width = 0; // widest level
+    std::vector<aoclsparse_int> level_ptr; // host, nlevels+1
+    DeviceBuffer                rowmap; // device, m rows in level order
+    // entries of row i: positions [rs[i], re[i]) of ind/val (positions and indices in `base`)
+    const aoclsparse_int *rs = nullptr, *re = nullptr, *ind = nullptr;
+    const void           *val = nullptr;
+    int                   base    = 0;
+    bool                  reverse = false; // walk a row right-to-left (L^T column sweep order)
+    DeviceBuffer          own_ptr, own_ind, own_val; // transposed strict triangle (lt / ut)
+    bool                  valid = false;
+};
+
+// host CSR view; owned==true when the library allocated the arrays (clean copy / transpose)
+struct HostCsr
+{
+    aoclsparse_int        m = 0, n = 0, nnz = 0;
+    aoclsparse_index_base base  = aoclsparse_index_base_zero;
+    aoclsparse_int       *ptr   = nullptr;
+    aoclsparse_int       *ind   = nullptr;
+    void                 *val   = nullptr;
+    aoclsparse_int       *idiag = nullptr; // owned whenever non-null
+    aoclsparse_int       *iurow = nullptr;
+    bool                  owned        = false;
+    bool                  is_optimized = false;
+    ~HostCsr();
+};
+
+} // namespace mi355
+
+// ---- matrix handle (library/src/include/aoclsparse_mat_structures.hpp:774-859) -------------
+struct _aoclsparse_matrix
+{
+    aoclsparse_int                m = 0, n = 0, nnz = 0;
+    aoclsparse_index_base         base         = aoclsparse_index_base_zero;
+    aoclsparse_matrix_data_type   val_type     = aoclsparse_dmat;
+    aoclsparse_matrix_format_type input_format = aoclsparse_csr_mat;
+    int                           sort         = 0; // aoclsparse_matrix_sort
+    bool                          fulldiag     = false;
+    aoclsparse_memory_usage       mem_policy   = aoclsparse_memory_usage_unrestricted;
+    bool                          optimized    = false;
+    bool                          opt_csr_full_diag = false;
+
+    mi355::HostCsr                  user; // aliases the caller's arrays
+    std::unique_ptr<mi355::HostCsr> opt_copy; // clean copy when the user arrays are not clean
+    mi355::HostCsr                 *opt = nullptr; // clean CSR: &user or opt_copy.get()
+    std::unique_ptr<mi355::HostCsr> trans; // A^T of the user CSR (built for gt hints / first use)
+
+    std::vector<mi355::Hint> hints; // newest first (csr_util.cpp:47-100 prepends)
+
+    // device side; guarded by `guard` (executors take it shared, builders exclusive)
+    mi355::DeviceCsr dev_user, dev_opt, dev_trans;
+    mi355::DeviceBuffer dev_opt_idiag, dev_opt_iurow;
+    mi355::SpmvPlan  plan_user, plan_trans;
+    mi355::TrsvPlan  trsv_plan[4]; // index: (upper?2:0) + (transpose?1:0)
+    mi355::DeviceBuffer dev_diag; // diagonal values of the clean CSR (length min(m,n))
+    mi355::DeviceBuffer trsv_scratch; // ticket + timeout words of the sync-free solve
+
+    // sp2m stage-1 state (C handles own their arrays)
+    bool owns_user_arrays = false;
+
+    mutable std::shared_mutex guard;
+};
+
+namespace mi355
+{
+
+// ---- runtime (one process per GPU; uses the current HIP device) ----------------------------
+class Runtime
+{
+public:
+    static Runtime &get();
+    aoclsparse_status init(); // lazy; internal_error when no device
+    hipStream_t       stream() const
+    {
+        return stream_;
+    }
+    void set_stream(hipStream_t s)
+    {
+        stream_ = s;
+    }
+    aoclsparse_mi355_pointer_mode pointer_mode = aoclsparse_mi355_pointer_auto;
+    // true when p is memory the device can dereference (device or managed allocation)
+    bool is_device_pointer(const void *p);
+    int  device = -1, cus = 0;
+    char name[256] = {0};
+    // scratch staging buffers for host-pointer calls (grown on demand, reused)
+    aoclsparse_status staging(int slot, size_t bytes, void **out);
+    hipEvent_t        ev0 = nullptr, ev1 = nullptr;
+    std::mutex        lock;
+    std::recursive_mutex stage_lock; // serialises calls that stage host buffers
+
+private:
+    bool         inited_ = false;
+    aoclsparse_status init_status_ = aoclsparse_status_success;
+    hipStream_t  stream_ = nullptr;
+    DeviceBuffer stage_[6];
+};
+
+// ---- host analysis (matrix.cpp) --------------------------------------------------------------
+aoclsparse_status mat_check(aoclsparse_int maj, aoclsparse_int mind, aoclsparse_int nnz,
+                            const aoclsparse_int *ptr, const aoclsparse_int *ind, const void *val,
+                            int shape, aoclsparse_index_base base, int &sort, bool &fulldiag);
+aoclsparse_status check_sort_diag(aoclsparse_int m, aoclsparse_int n, aoclsparse_index_base base,
+                                  const aoclsparse_int *ptr, const aoclsparse_int *ind, bool &sorted,
+                                  bool &fulldiag);
+aoclsparse_status csr_indices(aoclsparse_int m, aoclsparse_index_base base,
+                              const aoclsparse_int *ptr, const aoclsparse_int *ind,
+                              aoclsparse_int **idiag, aoclsparse_int **iurow);
+// builds A->opt (clean CSR + idiag/iurow) if absent; thread-safe (double-checked)
+aoclsparse_status csr_optimize(aoclsparse_matrix A);
+// builds A->trans (host transpose of the user CSR, 0-based) if absent
+aoclsparse_status build_transpose(aoclsparse_matrix A);
+
+// ---- device mirrors / plans ---------------------------------------------------------------------
+size_t            val_size(aoclsparse_matrix_data_type t);
+aoclsparse_status upload_csr(const HostCsr &h, size_t vsize, DeviceCsr &d);
+aoclsparse_status ensure_spmv(aoclsparse_matrix A, bool transposed, DeviceCsr *&dcsr,
+                              SpmvPlan *&plan);
+// clean CSR on the device + level sets of one triangle (trsv_api.cpp)
+aoclsparse_status ensure_trsv(aoclsparse_matrix A, bool upper, bool transposed);
+aoclsparse_status build_spmv_plan(aoclsparse_int m, aoclsparse_index_base base,
+                                  const aoclsparse_int *row_ptr_host, SpmvPlan &plan);
+
+// ---- kernel launchers (HIP translation units) --------------------------------------------------
+// order: 0 scalar, 1 lane4, 2 lane8
+template <typename T>
+aoclsparse_status launch_csrmv(hipStream_t s, int order, bool strict, int base, T alpha,
+                               aoclsparse_int m, const T *val, const aoclsparse_int *col,
+                               const aoclsparse_int *row_ptr, const aoclsparse_int *rowblocks,
+                               aoclsparse_int nblocks, const T *x, T beta, T *y);
+template <typename T>
+aoclsparse_status launch_scale(hipStream_t s, T *y, aoclsparse_int n, T beta);
+template <typename T>
+aoclsparse_status launch_strided_gather(hipStream_t s, const T *src, aoclsparse_int inc,
+                                        aoclsparse_int n, T *dst);
+template <typename T>
+aoclsparse_status launch_strided_scatter(hipStream_t s, const T *src, aoclsparse_int n, T *dst,
+                                         aoclsparse_int inc);
+
+// TRSV in row form (trsv_kernels.hip).  schedule 0: one launch per level; 1: sync-free single launch.
+template <typename T>
+aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool reverse, bool unit, int base, T alpha,
+                              aoclsparse_int m, const aoclsparse_int *rs, const aoclsparse_int *re,
+                              const aoclsparse_int *ind, const T *val, const T *diag,
+                              const TrsvPlan &plan, const T *b, T *x, unsigned int *scratch);
+
+template <typename T>
+aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, T alpha,
+                               aoclsparse_int m, aoclsparse_int k, const T *val,
+                               const aoclsparse_int *col, const aoclsparse_int *row_ptr, const T *B,
+                               aoclsparse_int n, aoclsparse_int ldb, T beta, T *C,
+                               aoclsparse_int ldc);
+template <typename T>
+aoclsparse_status launch_scale_dense(hipStream_t s, aoclsparse_order order, T *C, aoclsparse_int m,
+                                     aoclsparse_int n, aoclsparse_int ld, T beta);
+
+// SpMV plan constants shared by host planner and kernels
+constexpr int SPMV_BLOCK   = 256; // threads per workgroup (4 wavefronts)
+constexpr int SPMV_TILE    = 2048; // non-zeros staged in LDS per workgroup (val+x: 32 KiB fp64)
+constexpr int SPMV_MAXROWS = 512; // rows per stream block (2 per thread)
+
+} // namespace mi355

@@ -1,0 +1,771 @@
+// matrix.cpp -- descriptor + handle lifecycle, clean-CSR analysis, hints/optimize, device mirrors.
+//
+// Behaviour follows the reference (cited per function, paths relative to
+// /root/reference/library/src); the data layout behind the opaque handles is our own.
+#include "internal.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+using namespace mi355;
+
+namespace mi355
+{
+
+doid get_doid(const _aoclsparse_mat_descr *d, aoclsparse_operation op)
+{
+    // include/aoclsparse_mtx_dispatcher.hpp:79-143 for real types (conjugate == transpose)
+    const bool tr = op != aoclsparse_operation_none;
+    switch(d->type)
+    {
+    case aoclsparse_matrix_type_general:
+        return tr ? doid::gt : doid::gn;
+    case aoclsparse_matrix_type_symmetric:
+    case aoclsparse_matrix_type_hermitian:
+        return d->fill_mode == aoclsparse_fill_mode_lower ? doid::sl : doid::su;
+    case aoclsparse_matrix_type_triangular:
+        if(d->fill_mode == aoclsparse_fill_mode_lower)
+            return tr ? doid::tlt : doid::tln;
+        return tr ? doid::tut : doid::tun;
+    }
+    return doid::len;
+}
+
+// ---- validity / sort class / full diagonal: analysis/aoclsparse_csr_util.cpp:124-279 ---------
+aoclsparse_status mat_check(aoclsparse_int maj, aoclsparse_int mind, aoclsparse_int nnz,
+                            const aoclsparse_int *ptr, const aoclsparse_int *ind, const void *val,
+                            int shape, aoclsparse_index_base base, int &sort, bool &fulldiag)
+{
+    if(!ptr || !ind || !val)
+        return aoclsparse_status_invalid_pointer;
+    if(mind < 0 || maj < 0 || nnz < 0)
+        return aoclsparse_status_invalid_size;
+    if(ptr[0] != base || ptr[maj] - base != nnz)
+        return aoclsparse_status_invalid_value;
+    for(aoclsparse_int i = 0; i < maj; i++)
+        if(ptr[i] > ptr[i + 1])
+            return aoclsparse_status_invalid_value;
+
+    int  cls  = 1; // fully sorted until proven otherwise
+    bool full = true;
+    for(aoclsparse_int i = 0; i < maj; i++)
+    {
+        const aoclsparse_int lo = shape == 2 ? i : 0;
+        const aoclsparse_int hi = shape == 1 ? i : mind - 1;
+        bool           seen_diag = false, seen_upper = false;
+        aoclsparse_int prev = -1;
+        for(aoclsparse_int p = ptr[i] - base; p < ptr[i + 1] - base; p++)
+        {
+            const aoclsparse_int j = ind[p] - base;
+            if(j < lo || j > hi)
+                return aoclsparse_status_invalid_index_value;
+            if(cls != 3)
+            {
+                if(prev > j)
+                    cls = 2; // order inside a group broken: partially sorted
+                else
+                    prev = j;
+                if((j <= i && seen_upper) || (j < i && seen_diag))
+                    cls = 3; // L | D | U group order broken: unsorted
+            }
+            if(j > i)
+                seen_upper = true;
+            else if(j == i)
+            {
+                if(seen_diag)
+                    return aoclsparse_status_invalid_value; // duplicate diagonal
+                seen_diag = true;
+            }
+        }
+        if(!seen_diag && i < mind)
+            full = false;
+    }
+    sort     = cls;
+    fulldiag = full;
+    return aoclsparse_status_success;
+}
+
+// ---- group order (L | D | U) + diagonal presence: csr_util.cpp:290-364 -------------------------
+aoclsparse_status check_sort_diag(aoclsparse_int m, aoclsparse_int n, aoclsparse_index_base base,
+                                  const aoclsparse_int *ptr, const aoclsparse_int *ind, bool &sorted,
+                                  bool &fulldiag)
+{
+    sorted = fulldiag = false;
+    if(m < 0 || n < 0)
+        return aoclsparse_status_invalid_size;
+    if(!ptr || !ind)
+        return aoclsparse_status_invalid_pointer;
+    sorted = fulldiag = true;
+    for(aoclsparse_int i = 0; i < m; i++)
+    {
+        bool in_lower = true, have_diag = false;
+        for(aoclsparse_int p = ptr[i] - base; p < ptr[i + 1] - base; p++)
+        {
+            const aoclsparse_int j = ind[p] - base;
+            if(j == i)
+            {
+                if(have_diag)
+                    return aoclsparse_status_invalid_value;
+                have_diag = true;
+                sorted    = in_lower;
+                in_lower  = false;
+            }
+            else if(in_lower)
+                in_lower = j < i;
+            else
+                sorted = sorted && j > i;
+            if(!sorted)
+            {
+                fulldiag = false;
+                return aoclsparse_status_success;
+            }
+        }
+        if(!have_diag && i < n)
+            fulldiag = false;
+    }
+    return aoclsparse_status_success;
+}
+
+// ---- idiag / iurow in the matrix's base: csr_util.cpp:389-458 ----------------------------------
+aoclsparse_status csr_indices(aoclsparse_int m, aoclsparse_index_base base,
+                              const aoclsparse_int *ptr, const aoclsparse_int *ind,
+                              aoclsparse_int **idiag, aoclsparse_int **iurow)
+{
+    if(m < 0)
+        return aoclsparse_status_invalid_size;
+    if(!ptr || !ind || !idiag || !iurow)
+        return aoclsparse_status_invalid_pointer;
+    aoclsparse_int *d = new(std::nothrow) aoclsparse_int[m > 0 ? m : 1];
+    aoclsparse_int *u = new(std::nothrow) aoclsparse_int[m > 0 ? m : 1];
+    if(!d || !u)
+    {
+        delete[] d;
+        delete[] u;
+        return aoclsparse_status_memory_error;
+    }
+    for(aoclsparse_int i = 0; i < m; i++)
+    {
+        const aoclsparse_int e = ptr[i + 1] - base;
+        aoclsparse_int       p = ptr[i] - base;
+        while(p < e && ind[p] - base < i)
+            p++;
+        // p: first entry at or right of the diagonal (or row end); positions keep the base
+        d[i] = p + base;
+        u[i] = (p < e && ind[p] - base == i) ? p + base + 1 : p + base;
+    }
+    *idiag = d;
+    *iurow = u;
+    return aoclsparse_status_success;
+}
+
+template <typename T>
+static aoclsparse_status make_clean_copy(aoclsparse_matrix A, bool sorted, bool &fulldiag,
+                                         std::unique_ptr<HostCsr> &out)
+{
+    // csr_util.hpp:875-951: 0-based copy, per-row sort (csr_util.hpp:100-159), explicit zero
+    // diagonals for rows i < n (csr_util.hpp:167-279).
+    const HostCsr       &u    = A->user;
+    const aoclsparse_int m    = u.m, n = u.n, nnz = A->nnz, b = u.base;
+    const T             *uval = static_cast<const T *>(u.val);
+    std::vector<aoclsparse_int> tptr(m + 1), tind(nnz);
+    std::vector<T>              tval(nnz);
+    for(aoclsparse_int i = 0; i <= m; i++)
+        tptr[i] = u.ptr[i] - b;
+    for(aoclsparse_int p = 0; p < nnz; p++)
+    {
+        tind[p] = u.ind[p] - b;
+        tval[p] = uval[p];
+    }
+    if(!sorted)
+    {
+        std::vector<aoclsparse_int> perm;
+        for(aoclsparse_int i = 0; i < m; i++)
+        {
+            const aoclsparse_int s = tptr[i], len = tptr[i + 1] - s;
+            perm.resize(len);
+            std::iota(perm.begin(), perm.end(), 0);
+            std::stable_sort(perm.begin(), perm.end(), [&](aoclsparse_int a, aoclsparse_int c) {
+                return u.ind[s + a] < u.ind[s + c];
+            });
+            for(aoclsparse_int k = 0; k < len; k++)
+            {
+                tind[s + k] = u.ind[s + perm[k]] - b;
+                tval[s + k] = uval[s + perm[k]];
+            }
+        }
+        bool              s2;
+        aoclsparse_status st = check_sort_diag(m, n, aoclsparse_index_base_zero, tptr.data(),
+                                               tind.data(), s2, fulldiag);
+        if(st != aoclsparse_status_success)
+            return st;
+    }
+    aoclsparse_int missing = 0;
+    if(!fulldiag)
+        for(aoclsparse_int i = 0; i < std::min(m, n); i++)
+        {
+            bool have = false;
+            for(aoclsparse_int p = tptr[i]; p < tptr[i + 1] && !have; p++)
+                have = tind[p] == i;
+            missing += !have;
+        }
+    std::unique_ptr<HostCsr> c(new HostCsr);
+    c->m = m, c->n = n, c->nnz = nnz + missing, c->base = aoclsparse_index_base_zero;
+    c->owned = true;
+    c->ptr   = new aoclsparse_int[m + 1];
+    c->ind   = new aoclsparse_int[c->nnz > 0 ? c->nnz : 1];
+    c->val   = ::operator new(sizeof(T) * (c->nnz > 0 ? c->nnz : 1));
+    T             *cval = static_cast<T *>(c->val);
+    aoclsparse_int w    = 0;
+    for(aoclsparse_int i = 0; i < m; i++)
+    {
+        c->ptr[i]   = w;
+        bool placed = fulldiag || i >= n;
+        for(aoclsparse_int p = tptr[i]; p < tptr[i + 1]; p++)
+        {
+            if(!placed && tind[p] >= i)
+            {
+                if(tind[p] != i)
+                {
+                    c->ind[w] = i;
+                    cval[w++] = T(0);
+                }
+                placed = true;
+            }
+            c->ind[w] = tind[p];
+            cval[w++] = tval[p];
+        }
+        if(!placed)
+        {
+            c->ind[w] = i;
+            cval[w++] = T(0);
+        }
+    }
+    c->ptr[m] = w;
+    c->nnz    = w;
+    out       = std::move(c);
+    return aoclsparse_status_success;
+}
+
+// ---- clean CSR, analysis/aoclsparse_csr_util.hpp:765-967 -----------------------------------------
+aoclsparse_status csr_optimize(aoclsparse_matrix A)
+{
+    if(!A)
+        return aoclsparse_status_invalid_pointer;
+    {
+        std::shared_lock<std::shared_mutex> r(A->guard);
+        if(A->opt)
+            return aoclsparse_status_success;
+    }
+    std::unique_lock<std::shared_mutex> w(A->guard);
+    if(A->opt)
+        return aoclsparse_status_success;
+    HostCsr &u = A->user;
+    if(!u.ptr || !u.ind || !u.val)
+        return aoclsparse_status_invalid_pointer;
+    try
+    {
+        aoclsparse_status st
+            = mat_check(u.m, u.n, A->nnz, u.ptr, u.ind, u.val, 0, u.base, A->sort, A->fulldiag);
+        if(st != aoclsparse_status_success)
+            return st;
+        bool sorted, fulldiag;
+        st = check_sort_diag(u.m, u.n, u.base, u.ptr, u.ind, sorted, fulldiag);
+        if(st != aoclsparse_status_success)
+            return aoclsparse_status_internal_error;
+        if(sorted && fulldiag)
+        {
+            // already clean: keep using the caller's memory, only add idiag / iurow
+            st = csr_indices(u.m, u.base, u.ptr, u.ind, &u.idiag, &u.iurow);
+            if(st != aoclsparse_status_success)
+                return st;
+            u.is_optimized = true;
+            A->opt         = &u;
+        }
+        else
+        {
+            std::unique_ptr<HostCsr> c;
+            st = A->val_type == aoclsparse_smat ? make_clean_copy<float>(A, sorted, fulldiag, c)
+                                                : make_clean_copy<double>(A, sorted, fulldiag, c);
+            if(st != aoclsparse_status_success)
+                return st;
+            st = csr_indices(c->m, c->base, c->ptr, c->ind, &c->idiag, &c->iurow);
+            if(st != aoclsparse_status_success)
+                return st;
+            c->is_optimized = true;
+            A->opt_copy     = std::move(c);
+            A->opt          = A->opt_copy.get();
+        }
+        A->opt_csr_full_diag = fulldiag;
+        A->optimized         = true;
+    }
+    catch(const std::bad_alloc &)
+    {
+        return aoclsparse_status_memory_error;
+    }
+    return aoclsparse_status_success;
+}
+
+// ---- transpose of the user CSR, conversion/aoclsparse_convert.hpp:552-655 (counting sort) ---------
+template <typename T>
+static void transpose_into(const HostCsr &u, aoclsparse_int nnz, HostCsr &t)
+{
+    const aoclsparse_int m = u.m, n = u.n, b = u.base;
+    const T             *uv = static_cast<const T *>(u.val);
+    T                   *tv = static_cast<T *>(t.val);
+    std::fill(t.ptr, t.ptr + n + 1, 0);
+    for(aoclsparse_int p = 0; p < nnz; p++)
+        t.ptr[u.ind[p] - b + 1]++;
+    for(aoclsparse_int j = 0; j < n; j++)
+        t.ptr[j + 1] += t.ptr[j];
+    std::vector<aoclsparse_int> next(t.ptr, t.ptr + n);
+    for(aoclsparse_int i = 0; i < m; i++)
+        for(aoclsparse_int p = u.ptr[i] - b; p < u.ptr[i + 1] - b; p++)
+        {
+            const aoclsparse_int q = next[u.ind[p] - b]++;
+            t.ind[q]               = i;
+            tv[q]                  = uv[p];
+        }
+}
+
+aoclsparse_status build_transpose(aoclsparse_matrix A)
+{
+    {
+        std::shared_lock<std::shared_mutex> r(A->guard);
+        if(A->trans)
+            return aoclsparse_status_success;
+    }
+    std::unique_lock<std::shared_mutex> w(A->guard);
+    if(A->trans)
+        return aoclsparse_status_success;
+    try
+    {
+        std::unique_ptr<HostCsr> t(new HostCsr);
+        const size_t             vs = val_size(A->val_type);
+        t->m = A->n, t->n = A->m, t->nnz = A->nnz, t->base = aoclsparse_index_base_zero;
+        t->owned = true;
+        t->ptr   = new aoclsparse_int[t->m + 1];
+        t->ind   = new aoclsparse_int[A->nnz > 0 ? A->nnz : 1];
+        t->val   = ::operator new(vs * (A->nnz > 0 ? A->nnz : 1));
+        if(A->val_type == aoclsparse_smat)
+            transpose_into<float>(A->user, A->nnz, *t);
+        else
+            transpose_into<double>(A->user, A->nnz, *t);
+        A->trans = std::move(t);
+    }
+    catch(const std::bad_alloc &)
+    {
+        return aoclsparse_status_memory_error;
+    }
+    return aoclsparse_status_success;
+}
+
+// ---- device mirrors ---------------------------------------------------------------------------------
+aoclsparse_status upload_csr(const HostCsr &h, size_t vsize, DeviceCsr &d)
+{
+    Runtime          &rt = Runtime::get();
+    const aoclsparse_int nnz = h.ptr[h.m] - h.base;
+    aoclsparse_status st = d.ptr.upload(h.ptr, sizeof(aoclsparse_int) * (size_t)(h.m + 1), rt.stream());
+    if(st == aoclsparse_status_success)
+        st = d.ind.upload(h.ind, sizeof(aoclsparse_int) * (size_t)nnz, rt.stream());
+    if(st == aoclsparse_status_success)
+        st = d.val.upload(h.val, vsize * (size_t)nnz, rt.stream());
+    if(st != aoclsparse_status_success)
+        return st;
+    d.m = h.m, d.n = h.n, d.nnz = nnz, d.base = h.base;
+    d.valid = true;
+    return aoclsparse_status_success;
+}
+
+// CSR-Adaptive row blocks (host, O(m)): consecutive rows are packed into a block while their
+// non-zeros fit one LDS tile (SPMV_TILE) and the row count stays <= SPMV_MAXROWS; a row longer
+// than a tile gets a block of its own.  rowblocks[b]..rowblocks[b+1] = rows of block b.
+static aoclsparse_int plan_rows(aoclsparse_int m, aoclsparse_index_base base,
+                                const aoclsparse_int *row_ptr, aoclsparse_int *rb,
+                                aoclsparse_int *long_rows, aoclsparse_int *max_row)
+{
+    aoclsparse_int nb = 0, lr = 0, mx = 0, i = 0;
+    rb[0] = 0;
+    while(i < m)
+    {
+        const aoclsparse_int start = row_ptr[i] - base;
+        aoclsparse_int       j     = i;
+        while(j < m && j - i < SPMV_MAXROWS && (row_ptr[j + 1] - base) - start <= SPMV_TILE)
+            j++;
+        if(j == i) // single row longer than a tile
+        {
+            j = i + 1;
+            lr++;
+        }
+        for(aoclsparse_int r = i; r < j; r++)
+            mx = std::max(mx, row_ptr[r + 1] - row_ptr[r]);
+        rb[++nb] = j;
+        i        = j;
+    }
+    if(long_rows)
+        *long_rows = lr;
+    if(max_row)
+        *max_row = mx;
+    return nb;
+}
+
+aoclsparse_status build_spmv_plan(aoclsparse_int m, aoclsparse_index_base base,
+                                  const aoclsparse_int *row_ptr_host, SpmvPlan &plan)
+{
+    try
+    {
+        std::vector<aoclsparse_int> rb((size_t)m + 2);
+        plan.nblocks = plan_rows(m, base, row_ptr_host, rb.data(), &plan.long_rows, &plan.max_row_nnz);
+        aoclsparse_status st = plan.rowblocks.upload(
+            rb.data(), sizeof(aoclsparse_int) * (size_t)(plan.nblocks + 1), Runtime::get().stream());
+        if(st != aoclsparse_status_success)
+            return st;
+        plan.valid = true;
+    }
+    catch(const std::bad_alloc &)
+    {
+        return aoclsparse_status_memory_error;
+    }
+    return aoclsparse_status_success;
+}
+
+aoclsparse_status ensure_spmv(aoclsparse_matrix A, bool transposed, DeviceCsr *&dcsr, SpmvPlan *&plan)
+{
+    dcsr = transposed ? &A->dev_trans : &A->dev_user;
+    plan = transposed ? &A->plan_trans : &A->plan_user;
+    {
+        std::shared_lock<std::shared_mutex> r(A->guard);
+        if(dcsr->valid && plan->valid)
+            return aoclsparse_status_success;
+    }
+    if(transposed)
+    {
+        aoclsparse_status st = build_transpose(A);
+        if(st != aoclsparse_status_success)
+            return st;
+    }
+    std::unique_lock<std::shared_mutex> w(A->guard);
+    const HostCsr                      &h = transposed ? *A->trans : A->user;
+    if(!dcsr->valid)
+    {
+        aoclsparse_status st = upload_csr(h, val_size(A->val_type), *dcsr);
+        if(st != aoclsparse_status_success)
+            return st;
+    }
+    if(!plan->valid)
+    {
+        aoclsparse_status st = build_spmv_plan(h.m, h.base, h.ptr, *plan);
+        if(st != aoclsparse_status_success)
+            return st;
+    }
+    return aoclsparse_status_success;
+}
+
+} // namespace mi355
+
+// =====================================================================================================
+extern "C" {
+
+aoclsparse_int mi355_csrmv_plan_bound(aoclsparse_int m, aoclsparse_int /*nnz*/)
+{
+    return m + 2;
+}
+
+aoclsparse_int mi355_csrmv_plan_host(aoclsparse_int m, aoclsparse_int base,
+                                     const aoclsparse_int *row_ptr_host, aoclsparse_int *rowblocks_host)
+{
+    if(m < 0 || !row_ptr_host || !rowblocks_host || (base != 0 && base != 1))
+        return -1;
+    return plan_rows(m, (aoclsparse_index_base)base, row_ptr_host, rowblocks_host, nullptr, nullptr);
+}
+
+// ---- descriptor: extra/aoclsparse_auxiliary.cpp:191-360 -------------------------------------------------
+aoclsparse_status aoclsparse_create_mat_descr(aoclsparse_mat_descr *descr)
+{
+    if(!descr)
+        return aoclsparse_status_invalid_pointer;
+    *descr = new(std::nothrow) _aoclsparse_mat_descr;
+    return *descr ? aoclsparse_status_success : aoclsparse_status_memory_error;
+}
+
+aoclsparse_status aoclsparse_copy_mat_descr(aoclsparse_mat_descr dest, const aoclsparse_mat_descr src)
+{
+    if(!dest || !src)
+        return aoclsparse_status_invalid_pointer;
+    *dest = *src;
+    return aoclsparse_status_success;
+}
+
+aoclsparse_status aoclsparse_destroy_mat_descr(aoclsparse_mat_descr descr)
+{
+    delete descr; // NULL is a no-op success (:238-246)
+    return aoclsparse_status_success;
+}
+
+aoclsparse_status aoclsparse_set_mat_index_base(aoclsparse_mat_descr descr, aoclsparse_index_base base)
+{
+    if(!descr)
+        return aoclsparse_status_invalid_pointer;
+    if(base != aoclsparse_index_base_zero && base != aoclsparse_index_base_one)
+        return aoclsparse_status_invalid_value;
+    descr->base = base;
+    return aoclsparse_status_success;
+}
+
+aoclsparse_index_base aoclsparse_get_mat_index_base(const aoclsparse_mat_descr descr)
+{
+    return descr ? descr->base : aoclsparse_index_base_zero;
+}
+
+aoclsparse_status aoclsparse_set_mat_type(aoclsparse_mat_descr descr, aoclsparse_matrix_type type)
+{
+    if(!descr)
+        return aoclsparse_status_invalid_pointer;
+    if(type != aoclsparse_matrix_type_general && type != aoclsparse_matrix_type_symmetric
+       && type != aoclsparse_matrix_type_hermitian && type != aoclsparse_matrix_type_triangular)
+        return aoclsparse_status_invalid_value;
+    descr->type = type;
+    return aoclsparse_status_success;
+}
+
+aoclsparse_matrix_type aoclsparse_get_mat_type(const aoclsparse_mat_descr descr)
+{
+    return descr ? descr->type : aoclsparse_matrix_type_general;
+}
+
+aoclsparse_status aoclsparse_set_mat_fill_mode(aoclsparse_mat_descr descr, aoclsparse_fill_mode fill_mode)
+{
+    if(!descr)
+        return aoclsparse_status_invalid_pointer;
+    if(fill_mode != aoclsparse_fill_mode_lower && fill_mode != aoclsparse_fill_mode_upper)
+        return aoclsparse_status_invalid_value;
+    descr->fill_mode = fill_mode;
+    return aoclsparse_status_success;
+}
+
+aoclsparse_fill_mode aoclsparse_get_mat_fill_mode(const aoclsparse_mat_descr descr)
+{
+    return descr ? descr->fill_mode : aoclsparse_fill_mode_lower;
+}
+
+aoclsparse_status aoclsparse_set_mat_diag_type(aoclsparse_mat_descr descr, aoclsparse_diag_type diag_type)
+{
+    if(!descr)
+        return aoclsparse_status_invalid_pointer;
+    if(diag_type != aoclsparse_diag_type_unit && diag_type != aoclsparse_diag_type_non_unit
+       && diag_type != aoclsparse_diag_type_zero)
+        return aoclsparse_status_invalid_value;
+    descr->diag_type = diag_type;
+    return aoclsparse_status_success;
+}
+
+aoclsparse_diag_type aoclsparse_get_mat_diag_type(const aoclsparse_mat_descr descr)
+{
+    return descr ? descr->diag_type : aoclsparse_diag_type_non_unit;
+}
+
+// ---- create / destroy / export: create/aoclsparse_create.cpp:34-97, auxiliary.cpp:657-671, 1303-1353 ---
+static aoclsparse_status create_csr(aoclsparse_matrix *mat, aoclsparse_index_base base,
+                                    aoclsparse_int M, aoclsparse_int N, aoclsparse_int nnz,
+                                    aoclsparse_int *row_ptr, aoclsparse_int *col_idx, void *val,
+                                    aoclsparse_matrix_data_type vt)
+{
+    if(!mat)
+        return aoclsparse_status_invalid_pointer;
+    *mat = nullptr;
+    int               sort     = 0;
+    bool              fulldiag = false;
+    aoclsparse_status st = mat_check(M, N, nnz, row_ptr, col_idx, val, 0, base, sort, fulldiag);
+    if(st != aoclsparse_status_success)
+        return st;
+    _aoclsparse_matrix *A = new(std::nothrow) _aoclsparse_matrix;
+    if(!A)
+        return aoclsparse_status_memory_error;
+    A->m = M, A->n = N, A->nnz = nnz, A->base = base, A->val_type = vt;
+    A->sort = sort, A->fulldiag = fulldiag;
+    A->user.m = M, A->user.n = N, A->user.nnz = nnz, A->user.base = base;
+    A->user.ptr = row_ptr, A->user.ind = col_idx, A->user.val = val;
+    A->user.owned = false;
+    *mat          = A;
+    return aoclsparse_status_success;
+}
+
+aoclsparse_status aoclsparse_create_dcsr(aoclsparse_matrix *mat, aoclsparse_index_base base,
+                                         aoclsparse_int M, aoclsparse_int N, aoclsparse_int nnz,
+                                         aoclsparse_int *row_ptr, aoclsparse_int *col_idx, double *val)
+{
+    return create_csr(mat, base, M, N, nnz, row_ptr, col_idx, val, aoclsparse_dmat);
+}
+
+aoclsparse_status aoclsparse_create_scsr(aoclsparse_matrix *mat, aoclsparse_index_base base,
+                                         aoclsparse_int M, aoclsparse_int N, aoclsparse_int nnz,
+                                         aoclsparse_int *row_ptr, aoclsparse_int *col_idx, float *val)
+{
+    return create_csr(mat, base, M, N, nnz, row_ptr, col_idx, val, aoclsparse_smat);
+}
+
+aoclsparse_status aoclsparse_destroy(aoclsparse_matrix *mat)
+{
+    if(!mat)
+        return aoclsparse_status_success; // :657-671 accepts NULL
+    if(*mat)
+    {
+        if((*mat)->owns_user_arrays)
+            (*mat)->user.owned = true; // sp2m results: the handle owns its CSR
+        delete *mat;
+        *mat = nullptr;
+    }
+    return aoclsparse_status_success;
+}
+
+} // extern "C"
+
+template <typename T>
+static aoclsparse_status export_csr(const aoclsparse_matrix mat, aoclsparse_index_base *base,
+                                    aoclsparse_int *m, aoclsparse_int *n, aoclsparse_int *nnz,
+                                    aoclsparse_int **row_ptr, aoclsparse_int **col_ind, T **val,
+                                    aoclsparse_matrix_data_type vt)
+{
+    if(!mat || !base || !m || !n || !nnz || !row_ptr || !col_ind || !val)
+        return aoclsparse_status_invalid_pointer;
+    if(mat->val_type != vt)
+        return aoclsparse_status_wrong_type;
+    std::shared_lock<std::shared_mutex> r(mat->guard);
+    const HostCsr *c = mat->opt ? mat->opt : &mat->user; // optimized CSR preferred (:1326-1347)
+    if(!c->ptr || !c->ind || !c->val)
+        return aoclsparse_status_invalid_value;
+    *row_ptr = c->ptr;
+    *col_ind = c->ind;
+    *val     = static_cast<T *>(c->val);
+    *nnz     = c->ptr[mat->m] - c->base;
+    *base    = c->base;
+    *m       = mat->m;
+    *n       = mat->n;
+    return aoclsparse_status_success;
+}
+
+extern "C" {
+
+aoclsparse_status aoclsparse_export_dcsr(const aoclsparse_matrix mat, aoclsparse_index_base *base,
+                                         aoclsparse_int *m, aoclsparse_int *n, aoclsparse_int *nnz,
+                                         aoclsparse_int **row_ptr, aoclsparse_int **col_ind, double **val)
+{
+    return export_csr<double>(mat, base, m, n, nnz, row_ptr, col_ind, val, aoclsparse_dmat);
+}
+
+aoclsparse_status aoclsparse_export_scsr(const aoclsparse_matrix mat, aoclsparse_index_base *base,
+                                         aoclsparse_int *m, aoclsparse_int *n, aoclsparse_int *nnz,
+                                         aoclsparse_int **row_ptr, aoclsparse_int **col_ind, float **val)
+{
+    return export_csr<float>(mat, base, m, n, nnz, row_ptr, col_ind, val, aoclsparse_smat);
+}
+
+aoclsparse_status aoclsparse_mi355_export_diag(const aoclsparse_matrix A, aoclsparse_int **idiag,
+                                               aoclsparse_int **iurow, aoclsparse_int *is_internal)
+{
+    if(!A || !idiag || !iurow)
+        return aoclsparse_status_invalid_pointer;
+    std::shared_lock<std::shared_mutex> r(A->guard);
+    if(!A->opt)
+        return aoclsparse_status_invalid_operation;
+    *idiag = A->opt->idiag;
+    *iurow = A->opt->iurow;
+    if(is_internal)
+        *is_internal = A->opt != &A->user;
+    return aoclsparse_status_success;
+}
+
+aoclsparse_status aoclsparse_mi355_invalidate(aoclsparse_matrix A)
+{
+    if(!A)
+        return aoclsparse_status_invalid_pointer;
+    std::unique_lock<std::shared_mutex> w(A->guard);
+    A->dev_user.valid = A->dev_opt.valid = A->dev_trans.valid = false;
+    A->plan_user.valid = A->plan_trans.valid = false;
+    for(auto &p : A->trsv_plan)
+        p.valid = false, p.nlevels = -1;
+    A->trans.reset();
+    return aoclsparse_status_success;
+}
+
+// ---- hints: analysis/aoclsparse_analysis.cpp:568-747 -----------------------------------------------------
+static aoclsparse_status set_hint(aoclsparse_matrix mat, hinted_action act, aoclsparse_operation trans,
+                                  const aoclsparse_mat_descr descr, aoclsparse_int ncalls,
+                                  aoclsparse_int kid = -1)
+{
+    if(!mat || !mat->user.ptr || !descr)
+        return aoclsparse_status_invalid_pointer;
+    if(descr->base != aoclsparse_index_base_zero && descr->base != aoclsparse_index_base_one)
+        return aoclsparse_status_invalid_value;
+    if(descr->base != mat->base) // is_descr_matching, mat_structures.hpp:808-814
+        return aoclsparse_status_invalid_value;
+    if(trans != aoclsparse_operation_none && trans != aoclsparse_operation_transpose
+       && trans != aoclsparse_operation_conjugate_transpose)
+        return aoclsparse_status_invalid_value;
+    if(descr->fill_mode != aoclsparse_fill_mode_lower && descr->fill_mode != aoclsparse_fill_mode_upper)
+        return aoclsparse_status_invalid_value;
+    if(descr->diag_type != aoclsparse_diag_type_non_unit && descr->diag_type != aoclsparse_diag_type_unit
+       && descr->diag_type != aoclsparse_diag_type_zero)
+        return aoclsparse_status_invalid_value;
+    if(descr->type != aoclsparse_matrix_type_general && descr->type != aoclsparse_matrix_type_symmetric
+       && descr->type != aoclsparse_matrix_type_triangular && descr->type != aoclsparse_matrix_type_hermitian)
+        return aoclsparse_status_invalid_value;
+    if(ncalls < 0 || (ncalls == 0 && kid == -1))
+        return aoclsparse_status_invalid_value;
+    if(act <= action_none || act >= action_max)
+        return aoclsparse_status_invalid_operation;
+    try
+    {
+        Hint h{act, get_doid(descr, trans), trans, descr->type, descr->fill_mode, ncalls, kid, false};
+        mat->hints.insert(mat->hints.begin(), h); // newest first
+    }
+    catch(const std::bad_alloc &)
+    {
+        return aoclsparse_status_memory_error;
+    }
+    return aoclsparse_status_success;
+}
+
+aoclsparse_status aoclsparse_set_mv_hint(aoclsparse_matrix mat, aoclsparse_operation trans,
+                                         const aoclsparse_mat_descr descr, aoclsparse_int n)
+{
+    return set_hint(mat, action_mv, trans, descr, n);
+}
+
+aoclsparse_status aoclsparse_set_mv_hint_kid(aoclsparse_matrix mat, aoclsparse_operation trans,
+                                             const aoclsparse_mat_descr descr, aoclsparse_int n,
+                                             aoclsparse_int kid)
+{
+    return set_hint(mat, action_mv, trans, descr, n, kid);
+}
+
+aoclsparse_status aoclsparse_set_sv_hint(aoclsparse_matrix mat, aoclsparse_operation trans,
+                                         const aoclsparse_mat_descr descr, aoclsparse_int n)
+{
+    return set_hint(mat, action_sv, trans, descr, n);
+}
+
+aoclsparse_status aoclsparse_set_mm_hint(aoclsparse_matrix mat, aoclsparse_operation trans,
+                                         const aoclsparse_mat_descr descr, aoclsparse_int n)
+{
+    return set_hint(mat, action_mm, trans, descr, n);
+}
+
+aoclsparse_status aoclsparse_set_2m_hint(aoclsparse_matrix mat, aoclsparse_operation trans,
+                                         const aoclsparse_mat_descr descr, aoclsparse_int n)
+{
+    return set_hint(mat, action_2m, trans, descr, n);
+}
+
+aoclsparse_status aoclsparse_set_memory_hint(aoclsparse_matrix mat, const aoclsparse_memory_usage policy)
+{
+    // analysis.cpp:725-747
+    if(!mat)
+        return aoclsparse_status_invalid_pointer;
+    if(policy != aoclsparse_memory_usage_minimal && policy != aoclsparse_memory_usage_unrestricted)
+        return aoclsparse_status_invalid_value;
+    mat->mem_policy = policy;
+    return aoclsparse_status_success;
+}
+
+} // extern "C"

@@ -1,0 +1,86 @@
+// optimize.cpp -- aoclsparse_optimize: the inspector step.
+//
+// Hint bookkeeping follows analysis/aoclsparse_analysis.cpp:426-566 of the reference (which hints
+// count as "mv only", when the clean CSR is built, idempotence).  What an optimisation PRODUCES is
+// MI355X-specific: instead of CPU formats (br4 / ELL-hybrid / blocked CSR) the matrix is made
+// resident in HBM and the execution plans of the hinted operations are built once:
+//   mv  hint -> device CSR (+ A^T copy for a transposed hint) + CSR-Adaptive row blocks
+//   sv  hint -> clean CSR, idiag/iurow, level sets of the hinted triangle, device copies
+//   mm / 2m  -> clean CSR + device CSR
+#include "internal.hpp"
+
+using namespace mi355;
+
+extern "C" aoclsparse_status aoclsparse_optimize(aoclsparse_matrix A)
+{
+    if(!A)
+        return aoclsparse_status_invalid_pointer;
+    if(A->m < 0 || A->n < 0 || A->nnz < 0)
+        return aoclsparse_status_invalid_size;
+    if(!A->user.ptr || !A->user.ind || !A->user.val)
+        return aoclsparse_status_invalid_pointer;
+
+    // classify pending hints (analysis.cpp:484-508)
+    bool           all_done = true;
+    aoclsparse_int mv_count = 0, other = 0, sum = 0;
+    for(Hint &h : A->hints)
+    {
+        if(h.optimized)
+            continue;
+        all_done = false;
+        if((h.act == action_mv || h.act == action_dotmv) && h.trans == aoclsparse_operation_none
+           && h.type == aoclsparse_matrix_type_general && A->val_type == aoclsparse_dmat && h.nop > 0)
+            mv_count++;
+        else
+            other++;
+        sum++;
+    }
+    if(all_done) // also the no-hint case: analysis.cpp:509-511 returns before doing anything
+        return aoclsparse_status_success;
+
+    aoclsparse_status st = aoclsparse_status_success;
+    if(other || sum == 0)
+    {
+        st = csr_optimize(A); // clean CSR (analysis.cpp:513-553)
+        if(st != aoclsparse_status_success)
+            return st;
+    }
+
+    // Device residency + plans.  A box without a GPU (the CPU-only test tier) still completes the
+    // host analysis above; device work is attempted only when a device exists and is skipped for
+    // aoclsparse_memory_usage_minimal, which forbids copies of the matrix (analysis.cpp:446).
+    Runtime &rt = Runtime::get();
+    if(A->mem_policy == aoclsparse_memory_usage_unrestricted && A->m > 0 && A->n > 0 && A->nnz > 0
+       && rt.init() == aoclsparse_status_success)
+    {
+        for(Hint &h : A->hints)
+        {
+            if(h.optimized)
+                continue;
+            if(h.act == action_mv && h.type == aoclsparse_matrix_type_general)
+            {
+                DeviceCsr *d = nullptr;
+                SpmvPlan  *p = nullptr;
+                st = ensure_spmv(A, h.trans != aoclsparse_operation_none, d, p);
+            }
+            else if(h.act == action_sv
+                    && (h.type == aoclsparse_matrix_type_triangular
+                        || h.type == aoclsparse_matrix_type_symmetric))
+            {
+                st = ensure_trsv(A, h.fill == aoclsparse_fill_mode_upper,
+                                 h.trans != aoclsparse_operation_none);
+            }
+            else if(h.act == action_mm || h.act == action_2m)
+            {
+                DeviceCsr *d = nullptr;
+                SpmvPlan  *p = nullptr;
+                st = ensure_spmv(A, false, d, p);
+            }
+            if(st != aoclsparse_status_success)
+                return st;
+        }
+    }
+    for(Hint &h : A->hints)
+        h.optimized = true;
+    return aoclsparse_status_success;
+}

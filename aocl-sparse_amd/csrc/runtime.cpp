@@ -1,0 +1,280 @@
+// runtime.cpp -- device context, pointer classification, staging buffers, misc. entry points.
+#include "internal.hpp"
+
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace mi355
+{
+
+aoclsparse_status map_hip_error(hipError_t e)
+{
+    // hipError_t -> memory_error / internal_error; never throw across the ABI
+    if(e == hipSuccess)
+        return aoclsparse_status_success;
+    (void)hipGetLastError();
+    if(e == hipErrorOutOfMemory)
+        return aoclsparse_status_memory_error;
+    return aoclsparse_status_internal_error;
+}
+
+DeviceBuffer::~DeviceBuffer()
+{
+    release();
+}
+
+void DeviceBuffer::release()
+{
+    if(ptr)
+        (void)hipFree(ptr);
+    ptr   = nullptr;
+    bytes = 0;
+}
+
+aoclsparse_status DeviceBuffer::alloc(size_t nbytes)
+{
+    if(nbytes <= bytes && ptr)
+        return aoclsparse_status_success;
+    release();
+    size_t want = nbytes ? nbytes : 8;
+    MI355_HIP_TRY(hipMalloc(&ptr, want));
+    bytes = want;
+    return aoclsparse_status_success;
+}
+
+aoclsparse_status DeviceBuffer::upload(const void *host, size_t nbytes, hipStream_t s)
+{
+    aoclsparse_status st = alloc(nbytes);
+    if(st != aoclsparse_status_success)
+        return st;
+    if(nbytes)
+    {
+        MI355_HIP_TRY(hipMemcpyAsync(ptr, host, nbytes, hipMemcpyHostToDevice, s));
+        MI355_HIP_TRY(hipStreamSynchronize(s)); // host arrays are pageable: complete before return
+    }
+    return aoclsparse_status_success;
+}
+
+HostCsr::~HostCsr()
+{
+    if(owned)
+    {
+        delete[] ptr;
+        delete[] ind;
+        ::operator delete(val);
+    }
+    delete[] idiag;
+    delete[] iurow;
+}
+
+Runtime &Runtime::get()
+{
+    static Runtime r;
+    return r;
+}
+
+aoclsparse_status Runtime::init()
+{
+    if(inited_)
+        return init_status_;
+    std::lock_guard<std::mutex> g(lock);
+    if(inited_)
+        return init_status_;
+    int        count = 0;
+    hipError_t e     = hipGetDeviceCount(&count);
+    if(e != hipSuccess || count <= 0)
+    {
+        (void)hipGetLastError();
+        // the HIP path is the product: fail loudly, there is no CPU fallback
+        std::fprintf(stderr,
+                     "aoclsparse(mi355): no HIP device available (%s); this library has no CPU "
+                     "fallback\n",
+                     e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        init_status_ = aoclsparse_status_internal_error;
+        inited_      = true;
+        return init_status_;
+    }
+    // one process per GPU: honour an explicit ordinal, else keep the caller's current device
+    if(const char *env = std::getenv("AOCLSPARSE_MI355_DEVICE"))
+    {
+        int d = std::atoi(env);
+        if(d >= 0 && d < count)
+            (void)hipSetDevice(d);
+    }
+    (void)hipGetDevice(&device);
+    hipDeviceProp_t prop;
+    if(hipGetDeviceProperties(&prop, device) == hipSuccess)
+    {
+        cus = prop.multiProcessorCount;
+        std::snprintf(name, sizeof(name), "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if(hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess)
+        init_status_ = aoclsparse_status_internal_error;
+    inited_ = true;
+    return init_status_;
+}
+
+bool Runtime::is_device_pointer(const void *p)
+{
+    if(pointer_mode == aoclsparse_mi355_pointer_device)
+        return true;
+    if(pointer_mode == aoclsparse_mi355_pointer_host)
+        return false;
+    hipPointerAttribute_t attr;
+    hipError_t            e = hipPointerGetAttributes(&attr, p);
+    if(e != hipSuccess)
+    {
+        (void)hipGetLastError(); // plain malloc'ed memory is "invalid value": host
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged
+           || attr.type == hipMemoryTypeUnified;
+}
+
+aoclsparse_status Runtime::staging(int slot, size_t bytes, void **out)
+{
+    aoclsparse_status st = stage_[slot].alloc(bytes);
+    *out                 = stage_[slot].ptr;
+    return st;
+}
+
+size_t val_size(aoclsparse_matrix_data_type t)
+{
+    return t == aoclsparse_smat ? sizeof(float) : sizeof(double);
+}
+
+} // namespace mi355
+
+using namespace mi355;
+
+extern "C" {
+
+aoclsparse_status aoclsparse_mi355_set_pointer_mode(aoclsparse_mi355_pointer_mode mode)
+{
+    if(mode != aoclsparse_mi355_pointer_auto && mode != aoclsparse_mi355_pointer_host
+       && mode != aoclsparse_mi355_pointer_device)
+        return aoclsparse_status_invalid_value;
+    Runtime::get().pointer_mode = mode;
+    return aoclsparse_status_success;
+}
+
+aoclsparse_status aoclsparse_mi355_set_stream(void *hip_stream)
+{
+    aoclsparse_status st = Runtime::get().init();
+    if(st != aoclsparse_status_success)
+        return st;
+    Runtime::get().set_stream(static_cast<hipStream_t>(hip_stream));
+    return aoclsparse_status_success;
+}
+
+void *aoclsparse_mi355_get_stream(void)
+{
+    return Runtime::get().stream();
+}
+
+aoclsparse_status aoclsparse_mi355_synchronize(void)
+{
+    aoclsparse_status st = Runtime::get().init();
+    if(st != aoclsparse_status_success)
+        return st;
+    MI355_HIP_TRY(hipStreamSynchronize(Runtime::get().stream()));
+    return aoclsparse_status_success;
+}
+
+aoclsparse_status
+    aoclsparse_mi355_device_info(aoclsparse_int *device, aoclsparse_int *compute_units, char name[256])
+{
+    Runtime          &rt = Runtime::get();
+    aoclsparse_status st = rt.init();
+    if(st != aoclsparse_status_success)
+        return st;
+    if(device)
+        *device = rt.device;
+    if(compute_units)
+        *compute_units = rt.cus;
+    if(name)
+        std::memcpy(name, rt.name, 256);
+    return aoclsparse_status_success;
+}
+
+aoclsparse_status aoclsparse_mi355_timer_start(void)
+{
+    Runtime          &rt = Runtime::get();
+    aoclsparse_status st = rt.init();
+    if(st != aoclsparse_status_success)
+        return st;
+    MI355_HIP_TRY(hipEventRecord(rt.ev0, rt.stream()));
+    return aoclsparse_status_success;
+}
+
+aoclsparse_status aoclsparse_mi355_timer_stop(float *elapsed_ms)
+{
+    Runtime &rt = Runtime::get();
+    if(!elapsed_ms)
+        return aoclsparse_status_invalid_pointer;
+    aoclsparse_status st = rt.init();
+    if(st != aoclsparse_status_success)
+        return st;
+    MI355_HIP_TRY(hipEventRecord(rt.ev1, rt.stream()));
+    MI355_HIP_TRY(hipEventSynchronize(rt.ev1));
+    MI355_HIP_TRY(hipEventElapsedTime(elapsed_ms, rt.ev0, rt.ev1));
+    return aoclsparse_status_success;
+}
+
+// ---- version / context shims (library/src/extra/aoclsparse_auxiliary.cpp:56-173, 1433) --------
+const char *aoclsparse_get_version(void)
+{
+    return "AOCL-Sparse 5.3.2 compatible; MI355X-native engine r1 (gfx950)";
+}
+
+// The ISA preference selects CPU kernels in the reference; here it is accepted and recorded so
+// callers that set it keep working.  Valid tokens: context.hpp:182-213.
+static char g_isa[16] = "ENV";
+
+aoclsparse_status aoclsparse_enable_instructions(const char isa_preference[])
+{
+    if(!isa_preference)
+        return aoclsparse_status_invalid_pointer;
+    static const char *ok[] = {"ENV", "GENERIC", "AVX2", "AVX512", ""};
+    char               up[16];
+    size_t             n = std::strlen(isa_preference);
+    if(n >= sizeof(up))
+        return aoclsparse_status_invalid_value;
+    for(size_t i = 0; i <= n; i++)
+        up[i] = (char)std::toupper((unsigned char)isa_preference[i]);
+    for(const char *t : ok)
+        if(std::strcmp(t, up) == 0)
+        {
+            std::strcpy(g_isa, up[0] ? up : "ENV");
+            return aoclsparse_status_success;
+        }
+    return aoclsparse_status_invalid_value;
+}
+
+aoclsparse_status aoclsparse_debug_get(char            isa_preference[],
+                                       aoclsparse_int *num_threads,
+                                       char            tl_isa_preference[],
+                                       bool           *is_isa_updated,
+                                       char            arch[])
+{
+    if(isa_preference)
+        std::strcpy(isa_preference, g_isa);
+    if(tl_isa_preference)
+        std::strcpy(tl_isa_preference, g_isa);
+    if(num_threads)
+        *num_threads = 1;
+    if(is_isa_updated)
+        *is_isa_updated = false;
+    if(arch)
+        std::strcpy(arch, "GFX950");
+    return aoclsparse_status_success;
+}
+
+aoclsparse_int aoclsparse_is_avx512_build(void)
+{
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,432 @@
+// spmv_api.cpp -- aoclsparse_?csrmv (raw arrays) and aoclsparse_?mv (handle) on the HIP engine.
+//
+// Argument checks and their order follow level2/aoclsparse_csrmv.hpp:61-103 and
+// level2/aoclsparse_mv.cpp:55-121 of the reference; kernel choice follows csrmv.hpp:322-355
+// (nnz <= 10*m -> scalar order, kid 1/2 -> 4-lane order, kid 3 / auto -> 8-lane order).
+#include "internal.hpp"
+
+#include <cstring>
+#include <vector>
+
+using namespace mi355;
+
+namespace
+{
+
+// A host or device array made addressable by the GPU for one call.
+struct Arg
+{
+    void       *dev   = nullptr;
+    void       *host  = nullptr;
+    size_t      bytes = 0;
+    bool        staged = false;
+    aoclsparse_status in(Runtime &rt, int slot, const void *p, size_t nbytes, bool is_dev, bool copy)
+    {
+        bytes = nbytes;
+        if(is_dev)
+        {
+            dev = const_cast<void *>(p);
+            return aoclsparse_status_success;
+        }
+        staged = true;
+        host   = const_cast<void *>(p);
+        aoclsparse_status st = rt.staging(slot, nbytes, &dev);
+        if(st != aoclsparse_status_success)
+            return st;
+        if(copy && nbytes)
+            MI355_HIP_TRY(hipMemcpyAsync(dev, p, nbytes, hipMemcpyHostToDevice, rt.stream()));
+        return aoclsparse_status_success;
+    }
+    aoclsparse_status out(Runtime &rt)
+    {
+        if(staged && bytes)
+            MI355_HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, rt.stream()));
+        return aoclsparse_status_success;
+    }
+};
+
+inline bool valid_op(aoclsparse_operation op)
+{
+    return op == aoclsparse_operation_none || op == aoclsparse_operation_transpose
+           || op == aoclsparse_operation_conjugate_transpose;
+}
+inline bool valid_base(int b)
+{
+    return b == aoclsparse_index_base_zero || b == aoclsparse_index_base_one;
+}
+inline bool valid_type(int t)
+{
+    return t >= aoclsparse_matrix_type_general && t <= aoclsparse_matrix_type_triangular;
+}
+
+// csrmv.hpp:322-355.  Returns the summation order (0 scalar, 1 lane4, 2 lane8) and whether the
+// caller pinned a kernel (strict order also for rows longer than a tile).
+template <typename T>
+aoclsparse_status resolve_order(aoclsparse_int kid, aoclsparse_int m, aoclsparse_int nnz,
+                                aoclsparse_int max_row_nnz, int &order, bool &strict)
+{
+    strict = kid >= 0;
+    if constexpr(sizeof(T) == 4)
+    {
+        order = 2; // the only float kernel for general/no-trans is the 8-lane one (:317-321)
+    }
+    else
+    {
+        if((long long)nnz <= 10LL * (long long)m)
+            kid = 0;
+        if(kid < 0 || kid == 3)
+            order = 2;
+        else if(kid == 0)
+            order = 0;
+        else if(kid == 1 || kid == 2)
+            order = 1;
+        else
+            return aoclsparse_status_invalid_kid;
+    }
+    // a lane-grouped kernel on rows shorter than the lane count IS the scalar chain (the vector
+    // loop never runs): use one lane per row, same bits, no idle lanes
+    if((order == 2 && max_row_nnz < 8) || (order == 1 && max_row_nnz < 4))
+        order = 0;
+    return aoclsparse_status_success;
+}
+
+template <typename T>
+aoclsparse_status run_on_device_csr(Runtime &rt, aoclsparse_int kid, const DeviceCsr &d,
+                                    const SpmvPlan &plan, T alpha, const T *x, T beta, T *y,
+                                    aoclsparse_int nx, aoclsparse_int ny)
+{
+    int               order;
+    bool              strict;
+    aoclsparse_status st = resolve_order<T>(kid, d.m, d.nnz, plan.max_row_nnz, order, strict);
+    if(st != aoclsparse_status_success)
+        return st;
+    const bool xdev = rt.is_device_pointer(x), ydev = rt.is_device_pointer(y);
+    Arg        ax, ay;
+    st = ax.in(rt, 3, x, sizeof(T) * (size_t)nx, xdev, true);
+    if(st != aoclsparse_status_success)
+        return st;
+    st = ay.in(rt, 4, y, sizeof(T) * (size_t)ny, ydev, beta != T(0));
+    if(st != aoclsparse_status_success)
+        return st;
+    st = launch_csrmv<T>(rt.stream(), order, strict, d.base, alpha, d.m, d.val.as<T>(),
+                         d.ind.as<aoclsparse_int>(), d.ptr.as<aoclsparse_int>(),
+                         plan.rowblocks.as<aoclsparse_int>(), plan.nblocks, static_cast<const T *>(ax.dev),
+                         beta, static_cast<T *>(ay.dev));
+    if(st != aoclsparse_status_success)
+        return st;
+    st = ay.out(rt);
+    if(st != aoclsparse_status_success)
+        return st;
+    if(ay.staged) // host-pointer semantics: result visible on return
+        MI355_HIP_TRY(hipStreamSynchronize(rt.stream()));
+    return aoclsparse_status_success;
+}
+
+template <typename T>
+aoclsparse_status scale_y(Runtime &rt, T *y, aoclsparse_int n, T beta)
+{
+    if(n <= 0)
+        return aoclsparse_status_success;
+    const bool ydev = rt.is_device_pointer(y);
+    Arg        ay;
+    aoclsparse_status st = ay.in(rt, 4, y, sizeof(T) * (size_t)n, ydev, beta != T(0));
+    if(st != aoclsparse_status_success)
+        return st;
+    st = launch_scale<T>(rt.stream(), static_cast<T *>(ay.dev), n, beta);
+    if(st != aoclsparse_status_success)
+        return st;
+    st = ay.out(rt);
+    if(st == aoclsparse_status_success && ay.staged)
+        MI355_HIP_TRY(hipStreamSynchronize(rt.stream()));
+    return st;
+}
+
+// ---- handle path ---------------------------------------------------------------------------------
+template <typename T>
+aoclsparse_status mv_t(aoclsparse_operation op, const T *alpha, aoclsparse_matrix A,
+                       const aoclsparse_mat_descr descr, const T *x, const T *beta, T *y,
+                       aoclsparse_matrix_data_type vt)
+{
+    if(!alpha || !beta || !A || !descr || !x || !y)
+        return aoclsparse_status_invalid_pointer;
+    if(!A->user.ptr)
+        return aoclsparse_status_invalid_pointer;
+    if(descr->base != A->base)
+        return aoclsparse_status_invalid_value;
+    if(!valid_op(op))
+        return aoclsparse_status_invalid_value;
+    if(A->val_type != vt)
+        return aoclsparse_status_wrong_type;
+    if(!valid_type(descr->type))
+        return aoclsparse_status_invalid_value;
+    if((descr->type == aoclsparse_matrix_type_symmetric || descr->type == aoclsparse_matrix_type_hermitian)
+       && A->m != A->n)
+        return aoclsparse_status_invalid_size;
+    if(op == aoclsparse_operation_conjugate_transpose)
+        op = aoclsparse_operation_transpose;
+    if(descr->type == aoclsparse_matrix_type_hermitian)
+        return aoclsparse_status_not_implemented;
+
+    Runtime          &rt = Runtime::get();
+    aoclsparse_status st = rt.init();
+    if(st != aoclsparse_status_success)
+        return st;
+    std::unique_lock<std::recursive_mutex> sl(rt.stage_lock, std::defer_lock);
+    if(rt.pointer_mode != aoclsparse_mi355_pointer_device)
+        sl.lock();
+
+    // mv.cpp:116-121: empty matrix still scales y
+    if(A->m == 0 || A->n == 0 || (A->nnz == 0 && descr->type == aoclsparse_matrix_type_general))
+        return scale_y<T>(rt, y, op == aoclsparse_operation_none ? A->m : A->n, *beta);
+
+    if(descr->type != aoclsparse_matrix_type_general)
+        return aoclsparse_status_not_implemented; // symmetric / triangular SpMV: next wave
+
+    const doid     id  = get_doid(descr, op);
+    aoclsparse_int kid = -1; // magic_box.hpp:34-53: first hint with matching action + doid
+    for(const Hint &h : A->hints)
+        if(h.act == action_mv && h.id == id)
+        {
+            kid = h.kid;
+            break;
+        }
+    const bool tr   = op != aoclsparse_operation_none;
+    DeviceCsr *dcsr = nullptr;
+    SpmvPlan  *plan = nullptr;
+    st              = ensure_spmv(A, tr, dcsr, plan);
+    if(st != aoclsparse_status_success)
+        return st;
+    std::shared_lock<std::shared_mutex> r(A->guard);
+    return run_on_device_csr<T>(rt, kid, *dcsr, *plan, *alpha, x, *beta, y, tr ? A->m : A->n,
+                                tr ? A->n : A->m);
+}
+
+// ---- raw-array path --------------------------------------------------------------------------------
+// Plans for device-resident raw arrays are cached on (row_ptr address, m, nnz, base): the one-shot
+// API has no handle to hang an analysis on ("raw csrmv").
+struct RawPlan
+{
+    const void    *key = nullptr;
+    aoclsparse_int m = -1, nnz = -1, base = -1;
+    SpmvPlan       plan;
+};
+constexpr int RAW_CACHE = 8;
+RawPlan       g_raw[RAW_CACHE];
+int           g_raw_next = 0;
+
+template <typename T>
+aoclsparse_status csrmv_t(aoclsparse_operation trans, const T *alpha, aoclsparse_int m,
+                          aoclsparse_int n, aoclsparse_int nnz, const T *val,
+                          const aoclsparse_int *col, const aoclsparse_int *row,
+                          const aoclsparse_mat_descr descr, const T *x, const T *beta, T *y,
+                          aoclsparse_matrix_data_type vt)
+{
+    // csrmv.hpp:61-103, same order
+    if(!alpha || !beta)
+        return aoclsparse_status_invalid_pointer;
+    if(!descr)
+        return aoclsparse_status_invalid_pointer;
+    if(!valid_base(descr->base))
+        return aoclsparse_status_invalid_value;
+    if(!valid_type(descr->type))
+        return aoclsparse_status_invalid_value;
+    if(!valid_op(trans))
+        return aoclsparse_status_invalid_value;
+    if(descr->type != aoclsparse_matrix_type_general && descr->type != aoclsparse_matrix_type_symmetric)
+        return aoclsparse_status_not_implemented;
+    if(descr->type == aoclsparse_matrix_type_symmetric && m != n)
+        return aoclsparse_status_invalid_size;
+    if(m < 0 || n < 0 || nnz < 0)
+        return aoclsparse_status_invalid_size;
+    if(!val || !row || !col || !x || !y)
+        return aoclsparse_status_invalid_pointer;
+    if(descr->type == aoclsparse_matrix_type_symmetric)
+        return aoclsparse_status_not_implemented; // next wave
+
+    Runtime          &rt = Runtime::get();
+    aoclsparse_status st = rt.init();
+    if(st != aoclsparse_status_success)
+        return st;
+    std::unique_lock<std::recursive_mutex> sl(rt.stage_lock, std::defer_lock);
+    if(rt.pointer_mode != aoclsparse_mi355_pointer_device)
+        sl.lock();
+    const bool tr = trans != aoclsparse_operation_none;
+    const bool mdev = rt.is_device_pointer(row);
+
+    if(tr)
+    {
+        // transposed one-shot call: gather the CSR on the host, transpose there, run as a handle
+        std::vector<aoclsparse_int> hrow, hcol;
+        std::vector<T>              hval;
+        const aoclsparse_int       *prow = row, *pcol = col;
+        const T                    *pval = val;
+        try
+        {
+            if(mdev)
+            {
+                hrow.resize((size_t)m + 1), hcol.resize(nnz), hval.resize(nnz);
+                MI355_HIP_TRY(hipMemcpy(hrow.data(), row, sizeof(aoclsparse_int) * ((size_t)m + 1),
+                                        hipMemcpyDeviceToHost));
+                MI355_HIP_TRY(hipMemcpy(hcol.data(), col, sizeof(aoclsparse_int) * (size_t)nnz,
+                                        hipMemcpyDeviceToHost));
+                MI355_HIP_TRY(hipMemcpy(hval.data(), val, sizeof(T) * (size_t)nnz, hipMemcpyDeviceToHost));
+                prow = hrow.data(), pcol = hcol.data(), pval = hval.data();
+            }
+        }
+        catch(const std::bad_alloc &)
+        {
+            return aoclsparse_status_memory_error;
+        }
+        _aoclsparse_matrix tmp;
+        tmp.m = m, tmp.n = n, tmp.nnz = nnz, tmp.base = descr->base, tmp.val_type = vt;
+        tmp.user.m = m, tmp.user.n = n, tmp.user.nnz = nnz, tmp.user.base = descr->base;
+        tmp.user.ptr = const_cast<aoclsparse_int *>(prow);
+        tmp.user.ind = const_cast<aoclsparse_int *>(pcol);
+        tmp.user.val = const_cast<T *>(pval);
+        if(m == 0 || n == 0 || nnz == 0)
+            return scale_y<T>(rt, y, n, *beta);
+        DeviceCsr *dcsr = nullptr;
+        SpmvPlan  *plan = nullptr;
+        st              = ensure_spmv(&tmp, true, dcsr, plan);
+        if(st != aoclsparse_status_success)
+            return st;
+        st = run_on_device_csr<T>(rt, -1, *dcsr, *plan, *alpha, x, *beta, y, m, n);
+        if(st == aoclsparse_status_success) // tmp's device buffers die with it: drain first
+            MI355_HIP_TRY(hipStreamSynchronize(rt.stream()));
+        return st;
+    }
+
+    if(m == 0)
+        return aoclsparse_status_success;
+
+    // non-transposed: make the three CSR arrays device-addressable
+    Arg aval, acol, arow;
+    st = arow.in(rt, 2, row, sizeof(aoclsparse_int) * ((size_t)m + 1), mdev, true);
+    if(st == aoclsparse_status_success)
+        st = acol.in(rt, 1, col, sizeof(aoclsparse_int) * (size_t)nnz, rt.is_device_pointer(col), true);
+    if(st == aoclsparse_status_success)
+        st = aval.in(rt, 0, val, sizeof(T) * (size_t)nnz, rt.is_device_pointer(val), true);
+    if(st != aoclsparse_status_success)
+        return st;
+
+    SpmvPlan  local;
+    SpmvPlan *plan = &local;
+    try
+    {
+        if(mdev)
+        {
+            std::lock_guard<std::mutex> g(rt.lock);
+            RawPlan                    *hit = nullptr;
+            for(auto &e : g_raw)
+                if(e.key == row && e.m == m && e.nnz == nnz && e.base == descr->base && e.plan.valid)
+                    hit = &e;
+            if(!hit)
+            {
+                std::vector<aoclsparse_int> hrow((size_t)m + 1);
+                MI355_HIP_TRY(hipMemcpy(hrow.data(), row, sizeof(aoclsparse_int) * ((size_t)m + 1),
+                                        hipMemcpyDeviceToHost));
+                hit             = &g_raw[g_raw_next];
+                g_raw_next      = (g_raw_next + 1) % RAW_CACHE;
+                hit->plan.valid = false;
+                st              = build_spmv_plan(m, descr->base, hrow.data(), hit->plan);
+                if(st != aoclsparse_status_success)
+                    return st;
+                hit->key = row, hit->m = m, hit->nnz = nnz, hit->base = descr->base;
+            }
+            plan = &hit->plan;
+        }
+        else
+        {
+            st = build_spmv_plan(m, descr->base, row, local);
+            if(st != aoclsparse_status_success)
+                return st;
+        }
+    }
+    catch(const std::bad_alloc &)
+    {
+        return aoclsparse_status_memory_error;
+    }
+
+    DeviceCsr view; // non-owning view for the shared launcher
+    view.m = m, view.n = n, view.nnz = nnz, view.base = descr->base;
+    view.ptr.ptr = arow.dev, view.ind.ptr = acol.dev, view.val.ptr = aval.dev;
+    st = run_on_device_csr<T>(rt, -1, view, *plan, *alpha, x, *beta, y, n, m);
+    view.ptr.ptr = view.ind.ptr = view.val.ptr = nullptr; // not ours to free
+    if(st == aoclsparse_status_success && plan == &local)
+        MI355_HIP_TRY(hipStreamSynchronize(rt.stream())); // local plan buffer is freed on return
+    return st;
+}
+
+} // namespace
+
+extern "C" {
+
+aoclsparse_status aoclsparse_dcsrmv(aoclsparse_operation trans, const double *alpha, aoclsparse_int m,
+                                    aoclsparse_int n, aoclsparse_int nnz, const double *csr_val,
+                                    const aoclsparse_int *csr_col_ind, const aoclsparse_int *csr_row_ptr,
+                                    const aoclsparse_mat_descr descr, const double *x, const double *beta,
+                                    double *y)
+{
+    return csrmv_t<double>(trans, alpha, m, n, nnz, csr_val, csr_col_ind, csr_row_ptr, descr, x, beta, y,
+                           aoclsparse_dmat);
+}
+
+aoclsparse_status aoclsparse_scsrmv(aoclsparse_operation trans, const float *alpha, aoclsparse_int m,
+                                    aoclsparse_int n, aoclsparse_int nnz, const float *csr_val,
+                                    const aoclsparse_int *csr_col_ind, const aoclsparse_int *csr_row_ptr,
+                                    const aoclsparse_mat_descr descr, const float *x, const float *beta,
+                                    float *y)
+{
+    return csrmv_t<float>(trans, alpha, m, n, nnz, csr_val, csr_col_ind, csr_row_ptr, descr, x, beta, y,
+                          aoclsparse_smat);
+}
+
+aoclsparse_status aoclsparse_dmv(aoclsparse_operation op, const double *alpha, aoclsparse_matrix A,
+                                 const aoclsparse_mat_descr descr, const double *x, const double *beta,
+                                 double *y)
+{
+    return mv_t<double>(op, alpha, A, descr, x, beta, y, aoclsparse_dmat);
+}
+
+aoclsparse_status aoclsparse_smv(aoclsparse_operation op, const float *alpha, aoclsparse_matrix A,
+                                 const aoclsparse_mat_descr descr, const float *x, const float *beta,
+                                 float *y)
+{
+    return mv_t<float>(op, alpha, A, descr, x, beta, y, aoclsparse_smat);
+}
+
+aoclsparse_status aoclsparse_mi355_get_spmv_info(const aoclsparse_matrix A, aoclsparse_operation op,
+                                                 aoclsparse_mi355_spmv_info *info)
+{
+    if(!A || !info)
+        return aoclsparse_status_invalid_pointer;
+    std::shared_lock<std::shared_mutex> r(A->guard);
+    const bool                          tr = op != aoclsparse_operation_none;
+    const SpmvPlan                     &p  = tr ? A->plan_trans : A->plan_user;
+    const DeviceCsr                    &d  = tr ? A->dev_trans : A->dev_user;
+    std::memset(info, 0, sizeof(*info));
+    info->device_resident = d.valid;
+    if(!p.valid)
+        return aoclsparse_status_success;
+    info->kernel      = 1;
+    info->row_blocks  = p.nblocks;
+    info->long_rows   = p.long_rows;
+    info->max_row_nnz = p.max_row_nnz;
+    aoclsparse_int kid = -1;
+    for(const Hint &h : A->hints)
+        if(h.act == action_mv && h.id == (tr ? doid::gt : doid::gn))
+        {
+            kid = h.kid;
+            break;
+        }
+    int  order  = 0;
+    bool strict = false;
+    if(A->val_type == aoclsparse_smat)
+        resolve_order<float>(kid, d.m, d.nnz, p.max_row_nnz, order, strict);
+    else
+        resolve_order<double>(kid, d.m, d.nnz, p.max_row_nnz, order, strict);
+    info->order = order;
+    return aoclsparse_status_success;
+}
+
+} // extern "C"

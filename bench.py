@@ -1,0 +1,307 @@
+#!/usr/bin/env python3
+"""bench.py -- CSR SpMV fp64 (aoclsparse_dmv through the C ABI) on N MI355X, one process per GPU.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the
+driver starts it with torch.distributed.run, one rank per GPU.  Prints ONE JSON line on rank 0.
+
+  step      = one aoclsparse_dmv (alpha=1, beta=0) over the whole matrix, x and y resident in HBM.
+  workload  = 5-point Laplacian, BASELINE.json configs[1] scaled from its 100x100 grid (795 KB,
+              launch-latency bound: reported in the "l100" object) to a 4096x4096 grid (m=16.8 M,
+              nnz=83.9 M, 1.34 GB of algorithmic bytes > the 256 MiB Infinity Cache), as BASELINE.md
+              section 3 row 2 prescribes for the roofline claim.
+  value     = whole-job GFLOP/s = N * K * 2*nnz / max-over-ranks(time)   (SpMV does not shard: N
+              independent replicas, "scaling": "weak"; DESIGN.md section "multi-GPU").
+  roofline  = algorithmic bytes of one launch / average kernel time (hipEvents on the library's
+              stream around the K back-to-back launches) against 8 TB/s HBM3E.
+  cpu_baseline = the CPU oracle (oracle/, a port of the reference's ref_csrmv_gn order) on this box's
+              host cores, a bounded number of passes over the same matrix.
+  csrmm     = supplementary: aoclsparse csrmm kernel, 1M x 1M Laplacian times a dense B with 256
+              columns, B/C column-sharded over the N ranks (A broadcast from rank 0 over RCCL).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+# ---- pure helpers (unit-tested on CPU with gloo, tests/test_bench_dist_cpu.py) -------------------
+def spmv_bytes(m, n, nnz, beta_nonzero=False):
+    """Reference byte model, tests/include/aoclsparse_gbyte.hpp:39-45."""
+    return (m + 1 + nnz) * 4 + (m + n + nnz) * 8 + (8 * m if beta_nonzero else 0)
+
+
+def csrmm_bytes(m, k, nnz, ncols, beta_nonzero=False):
+    """Dense-correct csrmm byte count."""
+    return (m + 1 + nnz) * 4 + nnz * 8 + 8 * ncols * (k + m * (2 if beta_nonzero else 1))
+
+
+def column_shard(ncols, world, rank):
+    """Contiguous column slab [j0, j1) of rank `rank` (block distribution, remainder to low ranks)."""
+    q, r = divmod(ncols, world)
+    j0 = rank * q + min(rank, r)
+    return j0, j0 + q + (1 if rank < r else 0)
+
+
+def reduce_scalar(value, op, dist=None, device="cpu"):
+    """max / sum of a python float over all ranks (identity when not distributed)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    import torch
+
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def job_throughput(units_this_rank, seconds_this_rank, dist=None, device="cpu"):
+    """(sum of units over ranks) / (max of time over ranks) -- the whole-job figure."""
+    tmax = reduce_scalar(seconds_this_rank, "max", dist, device)
+    usum = reduce_scalar(units_this_rank, "sum", dist, device)
+    return usum / tmax, tmax
+
+
+# ---- the benchmark ------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--grid", type=int, default=4096, help="Laplacian grid edge of the headline workload")
+    ap.add_argument("--cpu-passes", type=int, default=0, help="CPU baseline passes (0 = ~10 s worth)")
+    ap.add_argument("--mm-grid", type=int, default=1000, help="csrmm: A = Laplacian on grid^2")
+    ap.add_argument("--mm-cols", type=int, default=256)
+    ap.add_argument("--no-csrmm", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import __graft_entry__ as entry
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus or world == 1, "WORLD_SIZE must match --gpus"
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the product has no CPU path"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    pkg = entry.load_package()
+    L = pkg.lib()
+    st, dev_id, cus, dev_name = pkg.device_info()
+    assert st == 0, "HIP runtime failed to initialise"
+    L.aoclsparse_mi355_set_pointer_mode(pkg.PTR_DEVICE)  # every vector below lives in HBM
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---------------- headline: scaled 5-pt Laplacian dmv ----------------
+    g = args.grid
+    m, row_ptr, col_ind, val = entry.laplace5(g)
+    nnz = int(len(val))
+    A = pkg.Matrix(0, m, m, row_ptr, col_ind, val)
+    assert A.status == 0
+    descr = pkg.Descr()
+    assert L.aoclsparse_set_mv_hint(A.h, pkg.OP_NONE, descr.h, args.steps + args.warmup) == 0
+    assert L.aoclsparse_optimize(A.h) == 0  # uploads CSR to HBM + builds the row-block plan
+    info = A.spmv_info()
+    xh = np.sin(0.01 * np.arange(m))
+    x = torch.from_numpy(xh).to(device)
+    y = torch.zeros(m, dtype=torch.float64, device=device)
+
+    def step():
+        s = pkg.dmv(pkg.OP_NONE, 1.0, A, descr, x, 0.0, y)
+        assert s == 0, pkg.STATUS[s]
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    pkg.timer_start()
+    for _ in range(args.steps):
+        step()
+    kernel_ms_total = pkg.timer_stop()  # hipEvent pair on the launch stream; also drains it
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    flops = 2.0 * nnz
+    abytes = spmv_bytes(m, m, nnz)
+    gflops, tmax = job_throughput(args.steps * flops / 1e9, elapsed, dist if world > 1 else None, device)
+    kernel_ms = kernel_ms_total / args.steps
+    achieved = abytes / (kernel_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "CSR SpMV fp64 GFLOP/s + achieved-HBM-GB/s %roofline",
+        "value": round(gflops, 3),
+        "unit": "GFLOP/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(tmax / args.steps * 1e3, 6),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "aoclsparse_dmv, 5-pt Laplacian grid %dx%d (m=%d, nnz=%d), alpha=1 beta=0; "
+                        "BASELINE configs[1] scaled past the 256 MiB Infinity Cache" % (g, g, m, nnz),
+            "kernel": "csr-adaptive stream, order %d (reference ref_csrmv_gn order), %d row blocks"
+                      % (info.order, info.row_blocks),
+            "parallelism": "replicas x%d" % world,
+            "device": dev_name,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": round(achieved, 2),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None,
+            "algorithmic_bytes_per_launch": abytes,
+            "kernel_ms": round(kernel_ms, 6),
+        },
+    }
+
+    if rank == 0:
+        # ---- parity of the timed configuration against the oracle (checker, not timed) ----
+        import oracle
+
+        so, yref = oracle.dcsrmv(-1, 0, 1.0, m, nnz, val, col_ind, row_ptr, xh, 0.0, np.zeros(1),
+                                 nthreads=oracle.max_threads()) if False else (0, None)
+        yd = y.cpu().numpy()
+        so, yref = oracle.dcsrmv(-1, 0, 1.0, m, nnz, val, col_ind, row_ptr, xh, 0.0, np.zeros(m),
+                                 nthreads=oracle.max_threads())
+        out["parity"] = {"vs": "oracle ref_csrmv_gn order", "bit_exact": bool(np.array_equal(yd, yref)),
+                         "max_abs_diff": float(np.max(np.abs(yd - yref)))}
+
+        # ---- literal configs[1]: L100 (10k x 10k), launch-latency bound ----
+        m1, rp1, ci1, v1 = entry.laplace5(100)
+        A1 = pkg.Matrix(0, m1, m1, rp1, ci1, v1)
+        assert L.aoclsparse_set_mv_hint(A1.h, pkg.OP_NONE, descr.h, 1000) == 0 and L.aoclsparse_optimize(A1.h) == 0
+        x1 = torch.from_numpy(np.sin(0.01 * np.arange(m1))).to(device)
+        y1 = torch.zeros(m1, dtype=torch.float64, device=device)
+        for _ in range(50):
+            pkg.dmv(pkg.OP_NONE, 1.0, A1, descr, x1, 0.0, y1)
+        torch.cuda.synchronize()
+        reps = 2000
+        pkg.timer_start()
+        for _ in range(reps):
+            pkg.dmv(pkg.OP_NONE, 1.0, A1, descr, x1, 0.0, y1)
+        us = pkg.timer_stop() * 1e3 / reps
+        b1 = spmv_bytes(m1, m1, len(v1))
+        out["l100"] = {"workload": "BASELINE configs[1] literal: 10k x 10k 5-pt Laplacian, nnz=%d" % len(v1),
+                       "us_per_call": round(us, 3), "gflops": round(2.0 * len(v1) / us / 1e3, 3),
+                       "gbs": round(b1 / us / 1e3, 2), "algorithmic_bytes": b1,
+                       "note": "795 KB problem: bound by launch latency, not HBM"}
+
+        # ---- CPU baseline: the oracle on this box's host cores, bounded sample ----
+        if not args.no_cpu:
+            nthr = oracle.max_threads()
+            yc = np.zeros(m)
+            t = time.perf_counter()
+            oracle.dcsrmv(-1, 0, 1.0, m, nnz, val, col_ind, row_ptr, xh, 0.0, yc, nthreads=nthr)
+            one = time.perf_counter() - t
+            passes = args.cpu_passes or max(3, min(200, int(10.0 / max(one, 1e-3))))
+            t = time.perf_counter()
+            for _ in range(passes):
+                oracle.dcsrmv(-1, 0, 1.0, m, nnz, val, col_ind, row_ptr, xh, 0.0, yc, nthreads=nthr)
+            dt = (time.perf_counter() - t) / passes
+            out["cpu_baseline"] = {"value": round(flops / dt / 1e9, 3), "unit": "GFLOP/s", "cores": nthr,
+                                   "kind": "port",
+                                   "sample": "%d passes of the same %dx%d-grid Laplacian SpMV with the oracle "
+                                             "(ref_csrmv_gn order, OpenMP static rows, %d threads; includes one "
+                                             "8*m-byte y copy per pass in the ctypes wrapper)" % (passes, g, g, nthr),
+                                   "gbs": round(abytes / dt / 1e9, 2), "host_cpus": os.cpu_count()}
+        else:
+            out["cpu_baseline"] = None
+
+    # ---------------- supplementary: column-sharded csrmm ----------------
+    if not args.no_csrmm:
+        out_mm = run_csrmm(args, pkg, entry, torch, dist, np, world, rank, device, barrier)
+        if rank == 0:
+            out["csrmm"] = out_mm
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_csrmm(args, pkg, entry, torch, dist, np, world, rank, device, barrier):
+    """C = A*B, A = 5-pt Laplacian (m = mm_grid^2), B dense with mm_cols columns, column-major so a
+    rank's slab B[:, j0:j1] is contiguous.  A is broadcast from rank 0 (RCCL); B/C stay sharded: no
+    data-path collective.  Uses the thin device-pointer ABI (mi355_dcsrmm)."""
+    L = pkg.lib()
+    gm = args.mm_grid
+    m = gm * gm
+    t_b = 0.0
+    if rank == 0:
+        _, rp, ci, v = entry.laplace5(gm)
+        meta = torch.tensor([len(v)], dtype=torch.int64, device=device)
+    else:
+        meta = torch.zeros(1, dtype=torch.int64, device=device)
+    if world > 1:
+        dist.broadcast(meta, 0)
+    nnz = int(meta.item())
+    if rank == 0:
+        d_rp, d_ci, d_v = (torch.from_numpy(a).to(device) for a in (rp, ci, v))
+    else:
+        d_rp = torch.empty(m + 1, dtype=torch.int32, device=device)
+        d_ci = torch.empty(nnz, dtype=torch.int32, device=device)
+        d_v = torch.empty(nnz, dtype=torch.float64, device=device)
+    if world > 1:
+        barrier()
+        t = time.perf_counter()
+        for tns in (d_rp, d_ci, d_v):
+            dist.broadcast(tns, 0)
+        torch.cuda.synchronize()
+        t_b = time.perf_counter() - t
+    j0, j1 = column_shard(args.mm_cols, world, rank)
+    nloc = j1 - j0
+    gen = torch.Generator(device=device)
+    gen.manual_seed(777 + j0)
+    B = torch.rand(nloc * m, dtype=torch.float64, device=device, generator=gen) * 2.0 - 1.0
+    C = torch.zeros(nloc * m, dtype=torch.float64, device=device)
+
+    def mm():
+        s = L.mi355_dcsrmm(None, pkg.ORDER_COLUMN, 0, 1.0, m, m, pkg._ptr(d_v), pkg._ptr(d_ci), pkg._ptr(d_rp),
+                           pkg._ptr(B), nloc, m, 0.0, pkg._ptr(C), m)
+        assert s == 0
+
+    reps = 10
+    for _ in range(2):
+        mm()
+    barrier()
+    t = time.perf_counter()
+    for _ in range(reps):
+        mm()
+    barrier()
+    dt = (time.perf_counter() - t) / reps
+    tmax = reduce_scalar(dt, "max", dist if world > 1 else None, device)
+    checksum = reduce_scalar(float(C.sum().item()), "sum", dist if world > 1 else None, device)
+    total_bytes = csrmm_bytes(m, m, nnz, args.mm_cols) + (world - 1) * ((m + 1 + nnz) * 4 + nnz * 8)
+    return {"workload": "mi355_dcsrmm, A = 5-pt Laplacian %dx%d grid (nnz=%d), B %d x %d fp64 column-major, "
+                        "beta=0, columns sharded over %d rank(s)" % (gm, gm, nnz, m, args.mm_cols, world),
+            "ms": round(tmax * 1e3, 4), "gflops": round(2.0 * nnz * args.mm_cols / tmax / 1e9, 2),
+            "gbs_algorithmic": round(total_bytes / tmax / 1e9, 2), "cols_per_rank": nloc,
+            "a_broadcast_ms": round(t_b * 1e3, 3), "checksum": checksum}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,394 @@
+/*
+ * aoclsparse.h -- C ABI of the MI355X-native CSR SpMV / SpMM / TRSV engine.
+ *
+ * Drop-in boundary: every declaration below has the same name, argument order, argument
+ * meaning, enum values and status codes as the AOCL-Sparse (v5.3.2) entry point it
+ * replaces; the reference declaration is cited as file:line relative to the reference's
+ * library/include/.  Only the hot path named in DESIGN.md is provided (LP64:
+ * aoclsparse_int is int32).  Pointers may be host pointers (reference semantics: staged
+ * over PCIe, synchronous) or device pointers of the current HIP device (extension:
+ * stream-ordered, see aoclsparse_mi355.h).
+ */
+#ifndef AOCLSPARSE_H_
+#define AOCLSPARSE_H_
+
+#include <stdbool.h>
+#include <stdint.h>
+
+#if defined(__GNUC__)
+#define DLL_PUBLIC __attribute__((visibility("default")))
+#else
+#define DLL_PUBLIC
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- types: aoclsparse_types.h ---------------------------------------------------- */
+typedef int32_t aoclsparse_int; /* :54-58 (LP64 build) */
+
+typedef struct aoclsparse_float_complex_ /* :77-87 */
+{
+    float real, imag;
+} aoclsparse_float_complex;
+typedef struct aoclsparse_double_complex_ /* :89-99 */
+{
+    double real, imag;
+} aoclsparse_double_complex;
+
+typedef struct _aoclsparse_mat_descr *aoclsparse_mat_descr; /* :114 */
+typedef struct _aoclsparse_matrix    *aoclsparse_matrix; /* :140 */
+
+typedef enum aoclsparse_operation_ /* :151-156 */
+{
+    aoclsparse_operation_none                = 111,
+    aoclsparse_operation_transpose           = 112,
+    aoclsparse_operation_conjugate_transpose = 113
+} aoclsparse_operation;
+
+typedef enum aoclsparse_index_base_ /* :162-166 */
+{
+    aoclsparse_index_base_zero = 0,
+    aoclsparse_index_base_one  = 1
+} aoclsparse_index_base;
+
+typedef enum aoclsparse_matrix_type_ /* :172-185 */
+{
+    aoclsparse_matrix_type_general    = 0,
+    aoclsparse_matrix_type_symmetric  = 1,
+    aoclsparse_matrix_type_hermitian  = 2,
+    aoclsparse_matrix_type_triangular = 3
+} aoclsparse_matrix_type;
+
+typedef enum aoclsparse_matrix_data_type_ /* :191-197 */
+{
+    aoclsparse_dmat = 0,
+    aoclsparse_smat = 1,
+    aoclsparse_cmat = 2,
+    aoclsparse_zmat = 3
+} aoclsparse_matrix_data_type;
+
+typedef enum aoclsparse_matrix_format_type_ /* :214-239; only csr is produced here */
+{
+    aoclsparse_csr_mat           = 0,
+    aoclsparse_ell_mat           = 1,
+    aoclsparse_ellt_mat          = 2,
+    aoclsparse_ellt_csr_hyb_mat  = 3,
+    aoclsparse_ell_csr_hyb_mat   = 4,
+    aoclsparse_dia_mat           = 5,
+    aoclsparse_csr_mat_br4       = 6,
+    aoclsparse_coo_mat           = 7,
+    aoclsparse_tcsr_mat          = 8,
+    aoclsparse_blkcsr_mat        = 9,
+    aoclsparse_bsr_mat           = 10,
+    aoclsparse_uninitialized_mat = 11
+} aoclsparse_matrix_format_type;
+
+typedef enum aoclsparse_diag_type_ /* :248-257 */
+{
+    aoclsparse_diag_type_non_unit = 0,
+    aoclsparse_diag_type_unit     = 1,
+    aoclsparse_diag_type_zero     = 2
+} aoclsparse_diag_type;
+
+typedef enum aoclsparse_fill_mode_ /* :266-270 */
+{
+    aoclsparse_fill_mode_lower = 0,
+    aoclsparse_fill_mode_upper = 1
+} aoclsparse_fill_mode;
+
+typedef enum aoclsparse_order_ /* :289-293 */
+{
+    aoclsparse_order_row    = 0,
+    aoclsparse_order_column = 1
+} aoclsparse_order;
+
+typedef enum aoclsparse_status_ /* :304-324 */
+{
+    aoclsparse_status_success             = 0,
+    aoclsparse_status_not_implemented     = 1,
+    aoclsparse_status_invalid_pointer     = 2,
+    aoclsparse_status_invalid_size        = 3,
+    aoclsparse_status_internal_error      = 4,
+    aoclsparse_status_invalid_value       = 5,
+    aoclsparse_status_invalid_index_value = 6,
+    aoclsparse_status_maxit               = 7,
+    aoclsparse_status_user_stop           = 8,
+    aoclsparse_status_wrong_type          = 9,
+    aoclsparse_status_memory_error        = 10,
+    aoclsparse_status_numerical_error     = 11,
+    aoclsparse_status_invalid_operation   = 12,
+    aoclsparse_status_unsorted_input      = 13,
+    aoclsparse_status_invalid_kid         = 14
+} aoclsparse_status;
+
+typedef enum aoclsparse_request_ /* :335-347 */
+{
+    aoclsparse_stage_nnz_count        = 0,
+    aoclsparse_stage_finalize         = 1,
+    aoclsparse_stage_full_computation = 2
+} aoclsparse_request;
+
+typedef enum aoclsparse_memory_usage_ /* :369-374 */
+{
+    aoclsparse_memory_usage_minimal      = 0,
+    aoclsparse_memory_usage_unrestricted = 1
+} aoclsparse_memory_usage;
+
+/* ---- auxiliary: aoclsparse_auxiliary.h -------------------------------------------- */
+DLL_PUBLIC const char *aoclsparse_get_version(void); /* :47 */
+DLL_PUBLIC aoclsparse_status aoclsparse_enable_instructions(const char isa_preference[]); /* :89 */
+DLL_PUBLIC aoclsparse_status aoclsparse_debug_get(char            isa_preference[], /* :110-114 */
+                                                  aoclsparse_int *num_threads,
+                                                  char            tl_isa_preference[],
+                                                  bool           *is_isa_updated,
+                                                  char            arch[]);
+DLL_PUBLIC aoclsparse_int aoclsparse_is_avx512_build(void); /* :1123 */
+
+DLL_PUBLIC aoclsparse_status aoclsparse_create_mat_descr(aoclsparse_mat_descr *descr); /* :131 */
+DLL_PUBLIC aoclsparse_status aoclsparse_copy_mat_descr(aoclsparse_mat_descr       dest, /* :148 */
+                                                       const aoclsparse_mat_descr src);
+DLL_PUBLIC aoclsparse_status aoclsparse_destroy_mat_descr(aoclsparse_mat_descr descr); /* :165 */
+DLL_PUBLIC aoclsparse_status aoclsparse_set_mat_index_base(aoclsparse_mat_descr  descr, /* :184 */
+                                                           aoclsparse_index_base base);
+DLL_PUBLIC aoclsparse_index_base aoclsparse_get_mat_index_base(const aoclsparse_mat_descr descr);
+DLL_PUBLIC aoclsparse_status aoclsparse_set_mat_type(aoclsparse_mat_descr   descr, /* :222 */
+                                                     aoclsparse_matrix_type type);
+DLL_PUBLIC aoclsparse_matrix_type aoclsparse_get_mat_type(const aoclsparse_mat_descr descr);
+DLL_PUBLIC aoclsparse_status aoclsparse_set_mat_fill_mode(aoclsparse_mat_descr descr, /* :258 */
+                                                          aoclsparse_fill_mode fill_mode);
+DLL_PUBLIC aoclsparse_fill_mode aoclsparse_get_mat_fill_mode(const aoclsparse_mat_descr descr);
+DLL_PUBLIC aoclsparse_status aoclsparse_set_mat_diag_type(aoclsparse_mat_descr descr, /* :293 */
+                                                          aoclsparse_diag_type diag_type);
+DLL_PUBLIC aoclsparse_diag_type aoclsparse_get_mat_diag_type(const aoclsparse_mat_descr descr);
+
+/* The arrays are aliased, not copied (:364-370); they must outlive the handle. */
+DLL_PUBLIC aoclsparse_status aoclsparse_create_scsr(aoclsparse_matrix    *mat, /* :400-407 */
+                                                    aoclsparse_index_base base,
+                                                    aoclsparse_int        M,
+                                                    aoclsparse_int        N,
+                                                    aoclsparse_int        nnz,
+                                                    aoclsparse_int       *row_ptr,
+                                                    aoclsparse_int       *col_idx,
+                                                    float                *val);
+DLL_PUBLIC aoclsparse_status aoclsparse_create_dcsr(aoclsparse_matrix    *mat, /* :410-417 */
+                                                    aoclsparse_index_base base,
+                                                    aoclsparse_int        M,
+                                                    aoclsparse_int        N,
+                                                    aoclsparse_int        nnz,
+                                                    aoclsparse_int       *row_ptr,
+                                                    aoclsparse_int       *col_idx,
+                                                    double               *val);
+/* Returns internal pointers (no copy), the optimized CSR if one exists. */
+DLL_PUBLIC aoclsparse_status aoclsparse_export_scsr(const aoclsparse_matrix mat, /* :786-793 */
+                                                    aoclsparse_index_base  *base,
+                                                    aoclsparse_int         *m,
+                                                    aoclsparse_int         *n,
+                                                    aoclsparse_int         *nnz,
+                                                    aoclsparse_int        **row_ptr,
+                                                    aoclsparse_int        **col_ind,
+                                                    float                 **val);
+DLL_PUBLIC aoclsparse_status aoclsparse_export_dcsr(const aoclsparse_matrix mat, /* :795-802 */
+                                                    aoclsparse_index_base  *base,
+                                                    aoclsparse_int         *m,
+                                                    aoclsparse_int         *n,
+                                                    aoclsparse_int         *nnz,
+                                                    aoclsparse_int        **row_ptr,
+                                                    aoclsparse_int        **col_ind,
+                                                    double                **val);
+DLL_PUBLIC aoclsparse_status aoclsparse_destroy(aoclsparse_matrix *mat); /* :836 */
+
+/* ---- analysis: aoclsparse_analysis.h ----------------------------------------------- */
+DLL_PUBLIC aoclsparse_status aoclsparse_optimize(aoclsparse_matrix mat); /* :56 */
+DLL_PUBLIC aoclsparse_status aoclsparse_set_mv_hint(aoclsparse_matrix          mat, /* :88-92 */
+                                                    aoclsparse_operation       trans,
+                                                    const aoclsparse_mat_descr descr,
+                                                    aoclsparse_int expected_no_of_calls);
+DLL_PUBLIC aoclsparse_status aoclsparse_set_mv_hint_kid(aoclsparse_matrix          mat,
+                                                        aoclsparse_operation       trans,
+                                                        const aoclsparse_mat_descr descr,
+                                                        aoclsparse_int expected_no_of_calls,
+                                                        aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_set_sv_hint(aoclsparse_matrix          mat,
+                                                    aoclsparse_operation       trans,
+                                                    const aoclsparse_mat_descr descr,
+                                                    aoclsparse_int expected_no_of_calls);
+DLL_PUBLIC aoclsparse_status aoclsparse_set_mm_hint(aoclsparse_matrix          mat,
+                                                    aoclsparse_operation       trans,
+                                                    const aoclsparse_mat_descr descr,
+                                                    aoclsparse_int expected_no_of_calls);
+DLL_PUBLIC aoclsparse_status aoclsparse_set_2m_hint(aoclsparse_matrix          mat,
+                                                    aoclsparse_operation       trans,
+                                                    const aoclsparse_mat_descr descr,
+                                                    aoclsparse_int expected_no_of_calls);
+DLL_PUBLIC aoclsparse_status aoclsparse_set_memory_hint(aoclsparse_matrix             mat,
+                                                        const aoclsparse_memory_usage policy);
+
+/* ---- level 2: aoclsparse_functions.h ----------------------------------------------- */
+/* y = alpha*op(A)*x + beta*y on raw CSR arrays; scalars BY POINTER (:695-721). */
+DLL_PUBLIC aoclsparse_status aoclsparse_scsrmv(aoclsparse_operation       trans,
+                                               const float               *alpha,
+                                               aoclsparse_int             m,
+                                               aoclsparse_int             n,
+                                               aoclsparse_int             nnz,
+                                               const float               *csr_val,
+                                               const aoclsparse_int      *csr_col_ind,
+                                               const aoclsparse_int      *csr_row_ptr,
+                                               const aoclsparse_mat_descr descr,
+                                               const float               *x,
+                                               const float               *beta,
+                                               float                     *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_dcsrmv(aoclsparse_operation       trans,
+                                               const double              *alpha,
+                                               aoclsparse_int             m,
+                                               aoclsparse_int             n,
+                                               aoclsparse_int             nnz,
+                                               const double              *csr_val,
+                                               const aoclsparse_int      *csr_col_ind,
+                                               const aoclsparse_int      *csr_row_ptr,
+                                               const aoclsparse_mat_descr descr,
+                                               const double              *x,
+                                               const double              *beta,
+                                               double                    *y);
+/* Inspector-executor SpMV on a handle (:1298-1313). */
+DLL_PUBLIC aoclsparse_status aoclsparse_smv(aoclsparse_operation       op,
+                                            const float               *alpha,
+                                            aoclsparse_matrix          A,
+                                            const aoclsparse_mat_descr descr,
+                                            const float               *x,
+                                            const float               *beta,
+                                            float                     *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_dmv(aoclsparse_operation       op,
+                                            const double              *alpha,
+                                            aoclsparse_matrix          A,
+                                            const aoclsparse_mat_descr descr,
+                                            const double              *x,
+                                            const double              *beta,
+                                            double                    *y);
+/* op(A)*x = alpha*b on the triangle fill_mode selects; alpha BY VALUE (:1525-1539). */
+DLL_PUBLIC aoclsparse_status aoclsparse_strsv(aoclsparse_operation       trans,
+                                              const float                alpha,
+                                              aoclsparse_matrix          A,
+                                              const aoclsparse_mat_descr descr,
+                                              const float               *b,
+                                              float                     *x);
+DLL_PUBLIC aoclsparse_status aoclsparse_dtrsv(aoclsparse_operation       trans,
+                                              const double               alpha,
+                                              aoclsparse_matrix          A,
+                                              const aoclsparse_mat_descr descr,
+                                              const double              *b,
+                                              double                    *x);
+DLL_PUBLIC aoclsparse_status aoclsparse_strsv_kid(aoclsparse_operation       trans, /* :1602-1618 */
+                                                  const float                alpha,
+                                                  aoclsparse_matrix          A,
+                                                  const aoclsparse_mat_descr descr,
+                                                  const float               *b,
+                                                  float                     *x,
+                                                  aoclsparse_int             kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_dtrsv_kid(aoclsparse_operation       trans,
+                                                  const double               alpha,
+                                                  aoclsparse_matrix          A,
+                                                  const aoclsparse_mat_descr descr,
+                                                  const double              *b,
+                                                  double                    *x,
+                                                  aoclsparse_int             kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_strsv_strided(aoclsparse_operation       trans, /* :1647-1665 */
+                                                      const float                alpha,
+                                                      aoclsparse_matrix          A,
+                                                      const aoclsparse_mat_descr descr,
+                                                      const float               *b,
+                                                      const aoclsparse_int       incb,
+                                                      float                     *x,
+                                                      const aoclsparse_int       incx);
+DLL_PUBLIC aoclsparse_status aoclsparse_dtrsv_strided(aoclsparse_operation       trans,
+                                                      const double               alpha,
+                                                      aoclsparse_matrix          A,
+                                                      const aoclsparse_mat_descr descr,
+                                                      const double              *b,
+                                                      const aoclsparse_int       incb,
+                                                      double                    *x,
+                                                      const aoclsparse_int       incx);
+
+/* ---- level 3 ------------------------------------------------------------------------ */
+/* C = alpha*op(A)*B + beta*C, dense B/C in the stated order; alpha, beta BY VALUE (:2487-2511). */
+DLL_PUBLIC aoclsparse_status aoclsparse_scsrmm(aoclsparse_operation       op,
+                                               const float                alpha,
+                                               const aoclsparse_matrix    A,
+                                               const aoclsparse_mat_descr descr,
+                                               aoclsparse_order           order,
+                                               const float               *B,
+                                               aoclsparse_int             n,
+                                               aoclsparse_int             ldb,
+                                               const float                beta,
+                                               float                     *C,
+                                               aoclsparse_int             ldc);
+DLL_PUBLIC aoclsparse_status aoclsparse_dcsrmm(aoclsparse_operation       op,
+                                               const double               alpha,
+                                               const aoclsparse_matrix    A,
+                                               const aoclsparse_mat_descr descr,
+                                               aoclsparse_order           order,
+                                               const double              *B,
+                                               aoclsparse_int             n,
+                                               aoclsparse_int             ldb,
+                                               const double               beta,
+                                               double                    *C,
+                                               aoclsparse_int             ldc);
+DLL_PUBLIC aoclsparse_status aoclsparse_scsrmm_kid(aoclsparse_operation       op, /* :3426-3452 */
+                                                   const float                alpha,
+                                                   const aoclsparse_matrix    A,
+                                                   const aoclsparse_mat_descr descr,
+                                                   aoclsparse_order           order,
+                                                   const float               *B,
+                                                   aoclsparse_int             n,
+                                                   aoclsparse_int             ldb,
+                                                   const float                beta,
+                                                   float                     *C,
+                                                   aoclsparse_int             ldc,
+                                                   const aoclsparse_int       kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_dcsrmm_kid(aoclsparse_operation       op,
+                                                   const double               alpha,
+                                                   const aoclsparse_matrix    A,
+                                                   const aoclsparse_mat_descr descr,
+                                                   aoclsparse_order           order,
+                                                   const double              *B,
+                                                   aoclsparse_int             n,
+                                                   aoclsparse_int             ldb,
+                                                   const double               beta,
+                                                   double                    *C,
+                                                   aoclsparse_int             ldc,
+                                                   const aoclsparse_int       kid);
+/* C = op(A)*op(B), sparse result allocated by the library (:2202-2209, :2258-2261, :2795-2813). */
+DLL_PUBLIC aoclsparse_status aoclsparse_sp2m(aoclsparse_operation       opA,
+                                             const aoclsparse_mat_descr descrA,
+                                             const aoclsparse_matrix    A,
+                                             aoclsparse_operation       opB,
+                                             const aoclsparse_mat_descr descrB,
+                                             const aoclsparse_matrix    B,
+                                             const aoclsparse_request   request,
+                                             aoclsparse_matrix         *C);
+DLL_PUBLIC aoclsparse_status aoclsparse_spmm(aoclsparse_operation    opA,
+                                             const aoclsparse_matrix A,
+                                             const aoclsparse_matrix B,
+                                             aoclsparse_matrix      *C);
+DLL_PUBLIC aoclsparse_status aoclsparse_dcsr2m(aoclsparse_operation       trans_A,
+                                               const aoclsparse_mat_descr descrA,
+                                               const aoclsparse_matrix    csrA,
+                                               aoclsparse_operation       trans_B,
+                                               const aoclsparse_mat_descr descrB,
+                                               const aoclsparse_matrix    csrB,
+                                               const aoclsparse_request   request,
+                                               aoclsparse_matrix         *csrC);
+DLL_PUBLIC aoclsparse_status aoclsparse_scsr2m(aoclsparse_operation       trans_A,
+                                               const aoclsparse_mat_descr descrA,
+                                               const aoclsparse_matrix    csrA,
+                                               aoclsparse_operation       trans_B,
+                                               const aoclsparse_mat_descr descrB,
+                                               const aoclsparse_matrix    csrB,
+                                               const aoclsparse_request   request,
+                                               aoclsparse_matrix         *csrC);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AOCLSPARSE_H_ */

@@ -1,0 +1,125 @@
+/*
+ * aoclsparse_mi355.h -- MI355X-specific additions next to the aoclsparse_* drop-in ABI.
+ *
+ * Nothing here exists in the reference (a CPU library has no device boundary).  Two groups:
+ *   1. aoclsparse_mi355_*: runtime control and introspection of a handle's device plan.
+ *   2. mi355_*: the thin HIP C-ABI the host layer itself calls -- plain device pointers,
+ *      sizes and a hipStream_t (passed as void*), no handles, asynchronous.  These are the
+ *      entry points a benchmark or a solver that keeps x/y resident in HBM binds directly.
+ */
+#ifndef AOCLSPARSE_MI355_H_
+#define AOCLSPARSE_MI355_H_
+
+#include "aoclsparse.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- runtime control ------------------------------------------------------------------ */
+typedef enum aoclsparse_mi355_pointer_mode_
+{
+    aoclsparse_mi355_pointer_auto   = 0, /* classify x/y/B/C per call (hipPointerGetAttributes) */
+    aoclsparse_mi355_pointer_host   = 1, /* reference semantics: host pointers, staged, synchronous */
+    aoclsparse_mi355_pointer_device = 2 /* device pointers, stream-ordered, no query */
+} aoclsparse_mi355_pointer_mode;
+
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_set_pointer_mode(aoclsparse_mi355_pointer_mode mode);
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_set_stream(void *hip_stream);
+DLL_PUBLIC void             *aoclsparse_mi355_get_stream(void);
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_synchronize(void);
+/* device ordinal in use, CU count and name; status internal_error when no HIP device exists */
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_device_info(aoclsparse_int *device,
+                                                          aoclsparse_int *compute_units,
+                                                          char            name[256]);
+/* hipEvent pair on the library's stream: start, run work, stop -> elapsed milliseconds */
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_timer_start(void);
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_timer_stop(float *elapsed_ms);
+
+/* ---- introspection of a handle --------------------------------------------------------- */
+/* idiag / iurow of the clean CSR (host arrays owned by the handle, length m, matrix base);
+ * the counterpart of the reference-internal csr::idiag / csr::iurow the unit tests inspect
+ * (tests/unit_tests/hint_tests.cpp:172-192).  Requires a prior optimize/trsv. */
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_export_diag(const aoclsparse_matrix A,
+                                                          aoclsparse_int        **idiag,
+                                                          aoclsparse_int        **iurow,
+                                                          aoclsparse_int         *is_internal);
+typedef struct aoclsparse_mi355_spmv_info_
+{
+    aoclsparse_int kernel; /* 0 none yet, 1 csr-adaptive stream, 2 merge-path */
+    aoclsparse_int order; /* 0 scalar chain (kid 0), 1 4-lane (kid 1/2), 2 8-lane (kid 3) */
+    aoclsparse_int row_blocks; /* workgroups per launch */
+    aoclsparse_int long_rows; /* rows longer than one LDS tile */
+    aoclsparse_int max_row_nnz;
+    aoclsparse_int device_resident; /* 1 once the CSR arrays are in HBM */
+} aoclsparse_mi355_spmv_info;
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_get_spmv_info(const aoclsparse_matrix     A,
+                                                            aoclsparse_operation        op,
+                                                            aoclsparse_mi355_spmv_info *info);
+/* number of dependency levels of the triangle a trsv with (fill, op) walks; -1 before analysis */
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_get_trsv_levels(const aoclsparse_matrix A,
+                                                              aoclsparse_fill_mode    fill,
+                                                              aoclsparse_operation    op,
+                                                              aoclsparse_int         *levels);
+/* drop every device-side copy/plan of the handle (call after mutating the aliased arrays) */
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_invalidate(aoclsparse_matrix A);
+
+/* ---- thin HIP C-ABI: device pointers, explicit stream ---------------------------------- */
+/* Row-block table for mi355_?csrmv: rowblocks must hold mi355_csrmv_plan_bound(m, nnz)
+ * ints; built on the HOST from a host row_ptr.  Returns the number of blocks, <0 on error. */
+DLL_PUBLIC aoclsparse_int mi355_csrmv_plan_bound(aoclsparse_int m, aoclsparse_int nnz);
+DLL_PUBLIC aoclsparse_int mi355_csrmv_plan_host(aoclsparse_int        m,
+                                                aoclsparse_int        base,
+                                                const aoclsparse_int *row_ptr_host,
+                                                aoclsparse_int       *rowblocks_host);
+/* y = alpha*A*x + beta*y; order: 0 scalar chain, 1 4-lane, 2 8-lane (reference kid 0 / 1,2 / 3);
+ * strict != 0 keeps the reference order for rows longer than one LDS tile too. */
+DLL_PUBLIC aoclsparse_status mi355_dcsrmv(void                 *stream,
+                                          aoclsparse_int        order,
+                                          aoclsparse_int        strict,
+                                          aoclsparse_int        base,
+                                          double                alpha,
+                                          aoclsparse_int        m,
+                                          const double         *val,
+                                          const aoclsparse_int *col,
+                                          const aoclsparse_int *row_ptr,
+                                          const aoclsparse_int *rowblocks,
+                                          aoclsparse_int        nblocks,
+                                          const double         *x,
+                                          double                beta,
+                                          double               *y);
+DLL_PUBLIC aoclsparse_status mi355_scsrmv(void                 *stream,
+                                          aoclsparse_int        order,
+                                          aoclsparse_int        strict,
+                                          aoclsparse_int        base,
+                                          float                 alpha,
+                                          aoclsparse_int        m,
+                                          const float          *val,
+                                          const aoclsparse_int *col,
+                                          const aoclsparse_int *row_ptr,
+                                          const aoclsparse_int *rowblocks,
+                                          aoclsparse_int        nblocks,
+                                          const float          *x,
+                                          float                 beta,
+                                          float                *y);
+/* C = alpha*A*B + beta*C (op none), dense B/C device pointers; order as aoclsparse_order. */
+DLL_PUBLIC aoclsparse_status mi355_dcsrmm(void                 *stream,
+                                          aoclsparse_int        order,
+                                          aoclsparse_int        base,
+                                          double                alpha,
+                                          aoclsparse_int        m,
+                                          aoclsparse_int        k,
+                                          const double         *val,
+                                          const aoclsparse_int *col,
+                                          const aoclsparse_int *row_ptr,
+                                          const double         *B,
+                                          aoclsparse_int        n,
+                                          aoclsparse_int        ldb,
+                                          double                beta,
+                                          double               *C,
+                                          aoclsparse_int        ldc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AOCLSPARSE_MI355_H_ */

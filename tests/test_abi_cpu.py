@@ -1,0 +1,273 @@
+"""CPU tier: the C-ABI library loads, exports every symbol include/*.h declares, and its host-side
+logic (descriptor, create/validate, hints, optimize -> clean CSR, status codes) matches the reference's
+behaviour and the oracle.  No compute entry point is exercised here (needs a GPU)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+from util import ROOT, pkg, random_csr
+
+P = pkg()
+L = P.lib()
+
+
+def _declared_symbols():
+    names = []
+    for h in ("aoclsparse.h", "aoclsparse_mi355.h"):
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        src = re.sub(r"#define DLL_PUBLIC.*", "", src)
+        for m in re.finditer(r"DLL_PUBLIC\s+[^;(]*?\b(\w+)\s*\(", src):
+            names.append(m.group(1))
+    return names
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    names = _declared_symbols()
+    assert len(names) >= 60
+    out = subprocess.check_output(["nm", "-D", "--defined-only", P.LIB_PATH], text=True)
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    for n in names:
+        assert n in exported, "declared in include/ but not exported: " + n
+        assert n in P.SIGNATURES, "no ctypes signature for " + n
+    # nothing but the C ABI leaks out (library built with -fvisibility=hidden)
+    leaked = [s for s in exported if not (s.startswith("aoclsparse_") or s.startswith("mi355_"))]
+    assert not leaked, leaked
+
+
+def test_product_does_not_reference_the_oracle():
+    out = subprocess.check_output(["nm", "-D", P.LIB_PATH], text=True)
+    assert "orc_" not in out
+    ldd = subprocess.check_output(["ldd", P.LIB_PATH], text=True)
+    assert "liboracle" not in ldd and "amdhip64" in ldd
+    for root, _, files in os.walk(os.path.join(ROOT, "aocl-sparse_amd")):
+        for f in files:
+            if f.endswith((".cpp", ".hip", ".hpp", ".py")):
+                txt = open(os.path.join(root, f)).read()
+                assert "import oracle" not in txt and "liboracle" not in txt, f
+
+
+def test_version_and_context_shims():
+    assert b"5.3.2" in L.aoclsparse_get_version()
+    assert L.aoclsparse_is_avx512_build() == 0
+    assert L.aoclsparse_enable_instructions(b"AVX2") == 0
+    assert L.aoclsparse_enable_instructions(b"bogus") == 5
+    assert L.aoclsparse_enable_instructions(None) == 2
+
+
+def test_descriptor_api():
+    # library/src/extra/aoclsparse_auxiliary.cpp:191-360
+    d = ctypes.c_void_p()
+    assert L.aoclsparse_create_mat_descr(None) == 2
+    assert L.aoclsparse_create_mat_descr(ctypes.byref(d)) == 0
+    assert L.aoclsparse_get_mat_index_base(d) == 0 and L.aoclsparse_get_mat_type(d) == 0
+    assert L.aoclsparse_get_mat_fill_mode(d) == 0 and L.aoclsparse_get_mat_diag_type(d) == 0
+    assert L.aoclsparse_set_mat_index_base(d, 1) == 0 and L.aoclsparse_get_mat_index_base(d) == 1
+    assert L.aoclsparse_set_mat_index_base(d, 2) == 5
+    assert L.aoclsparse_set_mat_type(d, 3) == 0 and L.aoclsparse_get_mat_type(d) == 3
+    assert L.aoclsparse_set_mat_type(d, 4) == 5
+    assert L.aoclsparse_set_mat_fill_mode(d, 1) == 0 and L.aoclsparse_set_mat_fill_mode(d, 2) == 5
+    assert L.aoclsparse_set_mat_diag_type(d, 2) == 0 and L.aoclsparse_set_mat_diag_type(d, 3) == 5
+    assert L.aoclsparse_set_mat_type(None, 0) == 2
+    assert L.aoclsparse_get_mat_type(None) == 0 and L.aoclsparse_get_mat_diag_type(None) == 0
+    d2 = ctypes.c_void_p()
+    assert L.aoclsparse_create_mat_descr(ctypes.byref(d2)) == 0
+    assert L.aoclsparse_copy_mat_descr(d2, d) == 0 and L.aoclsparse_get_mat_type(d2) == 3
+    assert L.aoclsparse_copy_mat_descr(None, d) == 2 and L.aoclsparse_copy_mat_descr(d2, None) == 2
+    assert L.aoclsparse_destroy_mat_descr(d) == 0 and L.aoclsparse_destroy_mat_descr(d2) == 0
+    assert L.aoclsparse_destroy_mat_descr(None) == 0
+
+
+def test_create_validation_matches_oracle():
+    # create/aoclsparse_create.cpp:34-97 -> aoclsparse_mat_check_internal
+    cases = [
+        (5, 5, [0, 2, 3, 4, 7, 8], [0, 3, 1, 2, 1, 3, 4, 4], 0),
+        (2, 2, [0, 1, 2], [0, 2], 0),          # column out of range
+        (2, 2, [0, 2, 3], [0, 0, 1], 0),       # duplicate diagonal
+        (2, 2, [1, 1, 2], [0, 1], 0),          # ptr[0] != base
+        (2, 2, [0, 2, 1], [0, 1], 0),          # decreasing ptr / ptr[m] != nnz
+        (3, 3, [1, 2, 3, 4], [1, 2, 3], 1),    # base one, fine
+    ]
+    for m, n, rp, ci, base in cases:
+        nnz = len(ci)
+        v = np.ones(max(nnz, 1))
+        A = P.Matrix(base, m, n, rp, ci, v[:nnz] if nnz else v)
+        A.nnz = nnz
+        h = ctypes.c_void_p()
+        st = L.aoclsparse_create_dcsr(ctypes.byref(h), base, m, n, nnz, P._ptr(A.row_ptr), P._ptr(A.col_ind),
+                                      P._ptr(A.val))
+        so, _, _ = oracle.mat_check(m, n, nnz, rp, ci, v, 0, base)
+        assert st == so, (rp, ci, st, so)
+        if st == 0:
+            assert L.aoclsparse_destroy(ctypes.byref(h)) == 0 and not h.value
+    h = ctypes.c_void_p()
+    assert L.aoclsparse_create_dcsr(None, 0, 1, 1, 1, None, None, None) == 2
+    assert L.aoclsparse_create_dcsr(ctypes.byref(h), 0, 1, 1, 1, None, None, None) == 2
+    a = np.zeros(2, np.int32)
+    assert L.aoclsparse_create_dcsr(ctypes.byref(h), 0, -1, 1, 0, P._ptr(a), P._ptr(a), P._ptr(a)) == 3
+    assert L.aoclsparse_destroy(None) == 0
+
+
+def test_optimize_produces_reference_clean_csr(kats):
+    # tests/unit_tests/hint_tests.cpp:75-170 via aoclsparse_set_sv_hint + aoclsparse_optimize
+    for c in kats["clean_csr"]:
+        A = P.Matrix(0, c["m"], c["n"], c["row_ptr"], c["col_ind"], np.array(c["val"], np.float64))
+        assert A.status == 0, c["name"]
+        d = P.Descr(mtype=P.TYPE_TRIANGULAR)
+        assert L.aoclsparse_set_sv_hint(A.h, P.OP_NONE, d.h, 1) == 0
+        assert L.aoclsparse_optimize(A.h) == 0, c["name"]
+        e, g = A.export(), A.export_diag()
+        x = c["exp"]
+        assert e["status"] == 0 and g["status"] == 0
+        assert np.array_equal(e["row_ptr"], x["icrow"]), c["name"]
+        assert np.array_equal(e["col_ind"], x["icol"]), c["name"]
+        assert np.array_equal(e["val"], np.array(x["aval"], np.float64)), c["name"]
+        dim = min(c["m"], c["n"])
+        assert np.array_equal(g["idiag"][:dim], x["idiag"]), c["name"]
+        assert np.array_equal(g["iurow"][:dim], x["iurow"]), c["name"]
+        assert g["is_internal"] == x["is_internal"] and e["aliased"] == (not x["is_internal"])
+
+
+@pytest.mark.parametrize("base", [0, 1])
+def test_optimize_random_matches_oracle_bit_exact(base):
+    rp, ci, v = random_csr(7 + base, 300, 280, lambda r, i: r.integers(0, 12), base=base, sort=False)
+    # knock out some diagonals / keep others so fill-in paths are exercised
+    A = P.Matrix(base, 300, 280, rp, ci, v)
+    assert A.status == 0
+    d = P.Descr(base=base, mtype=P.TYPE_TRIANGULAR)
+    assert L.aoclsparse_set_sv_hint(A.h, P.OP_NONE, d.h, 3) == 0
+    assert L.aoclsparse_optimize(A.h) == 0
+    e, g = A.export(), A.export_diag()
+    o = oracle.dcsr_optimize(300, 280, len(v), base, rp, ci, v)
+    assert o["status"] == 0 and e["base"] == o["base"]
+    assert np.array_equal(e["row_ptr"], o["ptr"]) and np.array_equal(e["col_ind"], o["ind"])
+    assert np.array_equal(e["val"], o["val"])
+    assert np.array_equal(g["idiag"], o["idiag"]) and np.array_equal(g["iurow"], o["iurow"])
+    assert g["is_internal"] == o["is_internal"]
+
+
+def test_export_before_optimize_returns_user_arrays():
+    rp, ci, v = random_csr(3, 20, 20, lambda r, i: 3)
+    A = P.Matrix(0, 20, 20, rp, ci, v)
+    e = A.export()
+    assert e["status"] == 0 and e["aliased"] and e["nnz"] == len(v)
+    assert A.export_diag()["status"] == 12  # invalid_operation: no clean CSR yet
+    As = P.Matrix(0, 20, 20, rp, ci, v.astype(np.float32))
+    base, m, n, nnz = ctypes.c_int(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    a, b, c = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    st = L.aoclsparse_export_dcsr(As.h, ctypes.byref(base), ctypes.byref(m), ctypes.byref(n),
+                                  ctypes.byref(nnz), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+    assert st == 9  # wrong_type
+    assert L.aoclsparse_export_dcsr(None, None, None, None, None, None, None, None) == 2
+
+
+def test_hint_validation():
+    # analysis/aoclsparse_analysis.cpp:568-625, tests/unit_tests/hint_tests.cpp:253-357
+    rp, ci, v = random_csr(1, 10, 10, lambda r, i: 2)
+    A = P.Matrix(0, 10, 10, rp, ci, v)
+    d = P.Descr()
+    assert L.aoclsparse_set_mv_hint(None, P.OP_NONE, d.h, 1) == 2
+    assert L.aoclsparse_set_mv_hint(A.h, P.OP_NONE, None, 1) == 2
+    assert L.aoclsparse_set_mv_hint(A.h, 114, d.h, 1) == 5
+    assert L.aoclsparse_set_mv_hint(A.h, P.OP_NONE, d.h, -1) == 5
+    assert L.aoclsparse_set_mv_hint(A.h, P.OP_NONE, d.h, 0) == 5          # nop == 0 needs a kid
+    assert L.aoclsparse_set_mv_hint_kid(A.h, P.OP_NONE, d.h, 0, 2) == 0
+    d1 = P.Descr(base=1)
+    assert L.aoclsparse_set_mv_hint(A.h, P.OP_NONE, d1.h, 1) == 5         # base mismatch
+    for fn in (L.aoclsparse_set_sv_hint, L.aoclsparse_set_mm_hint, L.aoclsparse_set_2m_hint):
+        assert fn(A.h, P.OP_TRANSPOSE, d.h, 7) == 0
+    assert L.aoclsparse_set_memory_hint(A.h, P.MEM_MINIMAL) == 0
+    assert L.aoclsparse_set_memory_hint(A.h, 7) == 5
+    assert L.aoclsparse_set_memory_hint(None, 0) == 2
+    assert L.aoclsparse_optimize(None) == 2
+    assert L.aoclsparse_optimize(A.h) == 0  # minimal memory: host analysis only, no device copies
+
+
+def test_argument_checks_that_precede_any_device_work():
+    """Status codes pinned by csrmv_tests.cpp:33-183, mv_tests.cpp:56-341, trsv_tests.cpp negative
+    cases and csrmm_tests.cpp:1833-1995; all of them return before the GPU is touched."""
+    rp, ci, v = random_csr(2, 6, 6, lambda r, i: 2)
+    nnz = len(v)
+    x, y = np.ones(6), np.zeros(6)
+    d = P.Descr()
+    one, zero = ctypes.c_double(1.0), ctypes.c_double(0.0)
+    f = L.aoclsparse_dcsrmv
+    args = lambda **k: [k.get("op", 111), k.get("alpha", ctypes.byref(one)), k.get("m", 6), k.get("n", 6),
+                        k.get("nnz", nnz), k.get("val", P._ptr(v)), k.get("col", P._ptr(ci)),
+                        k.get("row", P._ptr(rp)), k.get("descr", d.h), k.get("x", P._ptr(x)),
+                        k.get("beta", ctypes.byref(zero)), k.get("y", P._ptr(y))]
+    assert f(*args(alpha=None)) == 2 and f(*args(beta=None)) == 2 and f(*args(descr=None)) == 2
+    assert f(*args(op=114)) == 5
+    assert f(*args(m=-1)) == 3 and f(*args(n=-1)) == 3 and f(*args(nnz=-1)) == 3
+    for k in ("val", "col", "row", "x", "y"):
+        assert f(*args(**{k: None})) == 2
+    dt = P.Descr(mtype=P.TYPE_TRIANGULAR)
+    assert f(*args(descr=dt.h)) == 1           # only general + symmetric (csrmv.hpp:83-88)
+    ds = P.Descr(mtype=P.TYPE_SYMMETRIC)
+    assert f(*args(descr=ds.h, m=5)) == 3      # symmetric must be square
+    A = P.Matrix(0, 6, 6, rp, ci, v)
+    g = L.aoclsparse_dmv
+    assert g(111, None, A.h, d.h, P._ptr(x), ctypes.byref(zero), P._ptr(y)) == 2
+    assert g(111, ctypes.byref(one), None, d.h, P._ptr(x), ctypes.byref(zero), P._ptr(y)) == 2
+    assert g(111, ctypes.byref(one), A.h, None, P._ptr(x), ctypes.byref(zero), P._ptr(y)) == 2
+    assert g(111, ctypes.byref(one), A.h, d.h, None, ctypes.byref(zero), P._ptr(y)) == 2
+    assert g(114, ctypes.byref(one), A.h, d.h, P._ptr(x), ctypes.byref(zero), P._ptr(y)) == 5
+    d1 = P.Descr(base=1)
+    assert g(111, ctypes.byref(one), A.h, d1.h, P._ptr(x), ctypes.byref(zero), P._ptr(y)) == 5
+    assert L.aoclsparse_smv(111, ctypes.byref(one), A.h, d.h, P._ptr(x), ctypes.byref(zero), P._ptr(y)) == 9
+    # trsv (trsv.cpp:59-113)
+    t = L.aoclsparse_dtrsv
+    assert t(111, 1.0, None, dt.h, P._ptr(x), P._ptr(y)) == 2
+    assert t(111, 1.0, A.h, dt.h, None, P._ptr(y)) == 2
+    assert t(111, 1.0, A.h, d.h, P._ptr(x), P._ptr(y)) == 5        # general type is invalid for trsv
+    dz = P.Descr(mtype=P.TYPE_TRIANGULAR, diag=P.DIAG_ZERO)
+    assert t(111, 1.0, A.h, dz.h, P._ptr(x), P._ptr(y)) == 5
+    assert L.aoclsparse_strsv(111, 1.0, A.h, dt.h, P._ptr(x), P._ptr(y)) == 9
+    assert L.aoclsparse_dtrsv_strided(111, 1.0, A.h, dt.h, P._ptr(x), 0, P._ptr(y), 1) == 5
+    R = P.Matrix(0, 6, 7, rp, ci, v)
+    assert t(111, 1.0, R.h, dt.h, P._ptr(x), P._ptr(y)) == 5       # not square
+    # a matrix without a full diagonal cannot be solved with a non-unit diagonal (trsv.cpp:133-137)
+    H = P.Matrix(0, 3, 3, [0, 1, 1, 2], [0, 2], np.ones(2))
+    assert t(111, 1.0, H.h, dt.h, P._ptr(x), P._ptr(y)) == 5
+    assert L.aoclsparse_dtrsv_kid(111, 1.0, A.h, P.Descr(mtype=3, diag=P.DIAG_UNIT).h, P._ptr(x), P._ptr(y), 4) == 14
+    # csrmm (csrmm.hpp:448-611)
+    B, C = np.ones(36), np.zeros(36)
+    mm = L.aoclsparse_dcsrmm
+    assert mm(111, 1.0, None, d.h, 0, P._ptr(B), 6, 6, 0.0, P._ptr(C), 6) == 2
+    assert mm(111, 1.0, A.h, d.h, 0, None, 6, 6, 0.0, P._ptr(C), 6) == 2
+    assert mm(114, 1.0, A.h, d.h, 0, P._ptr(B), 6, 6, 0.0, P._ptr(C), 6) == 5
+    assert mm(111, 1.0, A.h, d.h, 2, P._ptr(B), 6, 6, 0.0, P._ptr(C), 6) == 5
+    assert mm(111, 1.0, A.h, dt.h, 0, P._ptr(B), 6, 6, 0.0, P._ptr(C), 6) == 1
+    assert mm(111, 1.0, A.h, d.h, 0, P._ptr(B), 6, 5, 0.0, P._ptr(C), 6) == 3   # ldb too small
+    assert mm(111, 1.0, A.h, d.h, 1, P._ptr(B), 6, 6, 0.0, P._ptr(C), 5) == 3   # ldc too small
+    assert mm(111, 1.0, A.h, d.h, 0, P._ptr(B), -1, 6, 0.0, P._ptr(C), 6) == 3
+    assert mm(111, 0.0, A.h, d.h, 0, P._ptr(B), 6, 6, 1.0, P._ptr(C), 6) == 0   # alpha=0,beta=1: no-op
+    assert mm(111, 1.0, A.h, d.h, 0, P._ptr(B), 0, 6, 0.0, P._ptr(C), 6) == 0   # n == 0 quick return
+    assert L.aoclsparse_scsrmm(111, 1.0, A.h, d.h, 0, P._ptr(B), 6, 6, 0.0, P._ptr(C), 6) == 9
+    assert mm(111, 1.0, A.h, d.h, 0, P._ptr(B), 6, 2 ** 30, 0.0, P._ptr(C), 6) == 3  # dim*ld overflows int32
+    # sp2m family: checks run, product itself not implemented in round 1
+    Cc = ctypes.c_void_p()
+    assert L.aoclsparse_sp2m(111, d.h, A.h, 111, d.h, None, 2, ctypes.byref(Cc)) == 2
+    assert L.aoclsparse_sp2m(111, d.h, A.h, 111, d.h, R.h, 2, ctypes.byref(Cc)) == 1
+    assert L.aoclsparse_sp2m(111, d.h, R.h, 111, d.h, A.h, 2, ctypes.byref(Cc)) == 3  # 6x7 times 6x6
+
+
+def test_row_block_planner_properties():
+    """mi355_csrmv_plan_host: blocks tile [0,m) with whole rows, <= TILE nnz unless a single long row."""
+    rp, ci, v = random_csr(5, 3000, 3000, lambda r, i: 5000 if i % 701 == 3 else r.integers(0, 30))
+    m = 3000
+    rb = np.zeros(L.mi355_csrmv_plan_bound(m, len(v)), dtype=np.int32)
+    nb = L.mi355_csrmv_plan_host(m, 0, P._ptr(rp), P._ptr(rb))
+    assert nb > 0 and rb[0] == 0 and rb[nb] == m
+    rb = rb[: nb + 1]
+    assert np.all(np.diff(rb) > 0)
+    cnt = rp[rb[1:]].astype(np.int64) - rp[rb[:-1]]
+    rows = np.diff(rb)
+    assert np.all((cnt <= 2048) | (rows == 1)) and np.all(rows <= 512)
+    assert np.sum((cnt > 2048)) == 5
+    assert L.mi355_csrmv_plan_host(-1, 0, P._ptr(rp), P._ptr(rb)) < 0

@@ -1,0 +1,508 @@
+"""GPU tier (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs.  fp results of SpMV and TRSV must be BIT-IDENTICAL to the reference order the oracle
+restates (GPU fma == x86 fma); where the schedule legitimately differs (long rows in auto mode,
+transposed SpMV, csrmm row-major) the componentwise forward-error bound of SURVEY.md section 8d is
+asserted with the constant written here."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle
+from util import (EPS32, EPS64, abs_row_sums, laplace5, pkg, powerlaw_rows, random_csr,
+                  triangular_system)
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+P = pkg()
+L = P.lib()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    assert torch.cuda.is_available(), "GPU tests need a GPU (no CPU fallback exists)"
+    st, d, cus, name = P.device_info()
+    assert st == 0 and cus > 0
+    yield
+    L.aoclsparse_mi355_set_pointer_mode(P.PTR_AUTO)
+
+
+def run_dmv(A, d, x, y0, alpha, beta, op=P.OP_NONE, on_device=True):
+    if on_device:
+        xd, yd = dev(x), dev(y0)
+        st = P.dmv(op, alpha, A, d, xd, beta, yd)
+        torch.cuda.synchronize()
+        return st, yd.cpu().numpy()
+    y = y0.copy()
+    st = P.dmv(op, alpha, A, d, x, beta, y)
+    return st, y
+
+
+# --------------------------------------------------------------------------------------------------
+# SpMV
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("base", [0, 1])
+@pytest.mark.parametrize("alpha,beta", [(1.0, 0.0), (5.1, 3.2), (-0.3, 1.0)])
+def test_l100_dmv_bit_exact(base, alpha, beta):
+    """BASELINE config 1/2: 10k x 10k 5-pt Laplacian; the reference runs ref_csrmv_gn (nnz <= 10 m)."""
+    m, rp, ci, v = laplace5(100, base=base)
+    v = v * np.random.default_rng(3).uniform(0.5, 1.5, len(v))  # inexact products
+    x = np.sin(0.01 * np.arange(m))
+    y0 = np.random.default_rng(4).uniform(-1, 1, m)
+    A = P.Matrix(base, m, m, rp, ci, v)
+    d = P.Descr(base=base)
+    assert L.aoclsparse_set_mv_hint(A.h, P.OP_NONE, d.h, 10) == 0 and L.aoclsparse_optimize(A.h) == 0
+    info = A.spmv_info()
+    assert info.kernel == 1 and info.order == 0 and info.device_resident == 1 and info.long_rows == 0
+    for on_device in (True, False):
+        st, y = run_dmv(A, d, x, y0, alpha, beta, on_device=on_device)
+        assert st == 0
+        so, yr = oracle.dcsrmv(-1, base, alpha, m, len(v), v, ci, rp, x, beta, y0)
+        assert so == 0 and np.array_equal(y, yr)
+
+
+def test_beta_zero_overwrites_nan_y():
+    m, rp, ci, v = laplace5(30)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    d = P.Descr()
+    x = np.ones(m)
+    st, y = run_dmv(A, d, x, np.full(m, np.nan), 1.0, 0.0)
+    so, yr = oracle.dcsrmv(-1, 0, 1.0, m, len(v), v, ci, rp, x, 0.0, np.zeros(m))
+    assert st == 0 and np.array_equal(y, yr)
+
+
+@pytest.mark.parametrize("kid,order", [(0, "ref"), (1, "lane4"), (2, "lane4"), (3, "lane8"), (-1, "lane8")])
+def test_kid_selects_reference_order_bit_exact(kid, order):
+    """nnz > 10 m: kid 0/1/2/3 = ref / AVX2 / AVX2 / AVX-512 summation orders (csrmv.hpp:338-343)."""
+    m = n = 3000
+    rp, ci, v = random_csr(11, m, n, lambda r, i: r.integers(0, 90))
+    assert len(v) > 10 * m
+    x = np.random.default_rng(5).uniform(-1, 1, n)
+    y0 = np.random.default_rng(6).uniform(-1, 1, m)
+    A = P.Matrix(0, m, n, rp, ci, v)
+    d = P.Descr()
+    if kid >= 0:
+        assert L.aoclsparse_set_mv_hint_kid(A.h, P.OP_NONE, d.h, 0, kid) == 0
+    st, y = run_dmv(A, d, x, y0, 2.5, -0.5)
+    assert st == 0
+    so, yr = oracle.dcsrmv_order(order, 0, 2.5, m, v, ci, rp, x, -0.5, y0)
+    assert np.array_equal(y, yr), np.max(np.abs(y - yr))
+    so, ya = oracle.dcsrmv(kid, 0, 2.5, m, len(v), v, ci, rp, x, -0.5, y0)
+    assert np.array_equal(y, ya)
+
+
+def test_invalid_kid():
+    rp, ci, v = random_csr(12, 50, 50, lambda r, i: 20)
+    A = P.Matrix(0, 50, 50, rp, ci, v)
+    d = P.Descr()
+    assert L.aoclsparse_set_mv_hint_kid(A.h, P.OP_NONE, d.h, 1, 7) == 0
+    st, _ = run_dmv(A, d, np.ones(50), np.zeros(50), 1.0, 0.0)
+    assert st == 14
+
+
+def test_power_law_rows_with_long_rows_strict_and_auto():
+    """scircuit / webbase-like: mean ~6, a few rows far longer than one LDS tile (2048)."""
+    m = n = 40000
+    rp, ci, v = random_csr(21, m, n, lambda r, i: 9000 if i in (17, 20011) else (
+        2500 if i == 33333 else powerlaw_rows(6, 400)(r, i)))
+    assert len(v) <= 10 * m
+    x = np.random.default_rng(7).uniform(-1, 1, n)
+    y0 = np.zeros(m)
+    d = P.Descr()
+    # auto: rows that fit a tile are bit-exact, long rows within the componentwise bound
+    A = P.Matrix(0, m, n, rp, ci, v)
+    st, y = run_dmv(A, d, x, y0, 1.0, 0.0)
+    assert st == 0 and A.spmv_info().long_rows == 3
+    so, yr = oracle.dcsrmv(-1, 0, 1.0, m, len(v), v, ci, rp, x, 0.0, y0)
+    lens = np.diff(rp)
+    short = lens <= 2048
+    assert np.array_equal(y[short], yr[short])
+    scale = abs_row_sums(rp, ci, v, x)
+    c = 2 * np.ceil(np.log2(np.maximum(lens, 2))) + 4 + lens / 256.0  # tree + 256 partial chains
+    assert np.all(np.abs(y - yr) <= c * EPS64 * scale + 1e-300)
+    # pinned kernel (kid 0): strict reference order for every row, long ones included
+    B = P.Matrix(0, m, n, rp, ci, v)
+    assert L.aoclsparse_set_mv_hint_kid(B.h, P.OP_NONE, d.h, 0, 0) == 0
+    st, ys = run_dmv(B, d, x, y0, 1.0, 0.0)
+    assert st == 0 and np.array_equal(ys, yr)
+
+
+@pytest.mark.parametrize("kid,order", [(3, "lane8"), (1, "lane4")])
+def test_long_rows_strict_lane_orders(kid, order):
+    m, n = 300, 60000
+    rp, ci, v = random_csr(22, m, n, lambda r, i: 10000 + i if i % 100 == 7 else r.integers(20, 60))
+    x = np.random.default_rng(8).uniform(-1, 1, n)
+    A = P.Matrix(0, m, n, rp, ci, v)
+    d = P.Descr()
+    assert L.aoclsparse_set_mv_hint_kid(A.h, P.OP_NONE, d.h, 0, kid) == 0
+    st, y = run_dmv(A, d, x, np.zeros(m), 1.0, 0.0)
+    so, yr = oracle.dcsrmv_order(order, 0, 1.0, m, v, ci, rp, x, 0.0, np.zeros(m))
+    assert st == 0 and np.array_equal(y, yr)
+
+
+def test_empty_rows_rectangular_and_unsorted_columns():
+    m, n = 5000, 777
+    rp, ci, v = random_csr(23, m, n, lambda r, i: 0 if i % 3 == 0 else r.integers(1, 25), base=1, sort=False)
+    x = np.random.default_rng(9).uniform(-1, 1, n)
+    y0 = np.random.default_rng(10).uniform(-1, 1, m)
+    A = P.Matrix(1, m, n, rp, ci, v)
+    d = P.Descr(base=1)
+    st, y = run_dmv(A, d, x, y0, 0.7, 0.0)
+    so, yr = oracle.dcsrmv(-1, 1, 0.7, m, len(v), v, ci, rp, x, 0.0, y0)
+    assert st == 0 and np.array_equal(y, yr)
+    assert np.all(y[::3] == 0.0)
+
+
+def test_empty_matrix_scales_y():
+    # mv.cpp:116-121
+    A = P.Matrix(0, 4, 4, [0, 0, 0, 0, 0], np.zeros(1, np.int32), np.zeros(1))
+    A2 = P.Matrix(0, 4, 4, np.zeros(5, np.int32), np.zeros(0, np.int32), np.zeros(0))
+    d = P.Descr()
+    st, y = run_dmv(A2, d, np.ones(4), np.arange(4.0), 3.0, 2.0)
+    assert st == 0 and np.array_equal(y, 2.0 * np.arange(4.0))
+    st, y = run_dmv(A2, d, np.ones(4), np.full(4, np.nan), 3.0, 0.0, on_device=False)
+    assert st == 0 and np.array_equal(y, np.zeros(4))
+
+
+def test_float_smv_bit_exact():
+    """float general SpMV always runs the 8-lane AVX2 kernel (csrmv.hpp:317-321)."""
+    for seed, rl in ((31, lambda r, i: r.integers(0, 70)), (32, lambda r, i: r.integers(0, 7))):
+        m = n = 2500
+        rp, ci, v = random_csr(seed, m, n, rl, dtype=np.float32)
+        x = np.random.default_rng(1).uniform(-1, 1, n).astype(np.float32)
+        y0 = np.random.default_rng(2).uniform(-1, 1, m).astype(np.float32)
+        A = P.Matrix(0, m, n, rp, ci, v)
+        d = P.Descr()
+        xd, yd = dev(x), dev(y0)
+        st = P.smv(P.OP_NONE, 1.5, A, d, xd, 0.25, yd)
+        torch.cuda.synchronize()
+        so, yr = oracle.scsrmv("lane8", 0, 1.5, m, v, ci, rp, x, 0.25, y0)
+        assert st == 0 and np.array_equal(yd.cpu().numpy(), yr)
+        y = y0.copy()
+        st = P.scsrmv(P.OP_NONE, 1.5, m, n, len(v), v, ci, rp, d, x, 0.25, y)
+        assert st == 0 and np.array_equal(y, yr)
+
+
+def test_raw_dcsrmv_host_and_device_pointers():
+    m, rp, ci, v = laplace5(64)
+    x = np.random.default_rng(1).uniform(-1, 1, m)
+    y0 = np.random.default_rng(2).uniform(-1, 1, m)
+    d = P.Descr()
+    so, yr = oracle.dcsrmv(-1, 0, 1.0, m, len(v), v, ci, rp, x, 0.5, y0)
+    y = y0.copy()
+    assert P.dcsrmv(P.OP_NONE, 1.0, m, m, len(v), v, ci, rp, d, x, 0.5, y) == 0
+    assert np.array_equal(y, yr)
+    vd, cd, rd, xd, yd = dev(v), dev(ci), dev(rp), dev(x), dev(y0)
+    for _ in range(2):  # second call hits the cached row-block plan
+        yd.copy_(torch.from_numpy(y0))
+        assert P.dcsrmv(P.OP_NONE, 1.0, m, m, len(v), vd, cd, rd, d, xd, 0.5, yd) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(yd.cpu().numpy(), yr)
+    # thin HIP C-ABI with an explicit host-built plan
+    rb = np.zeros(L.mi355_csrmv_plan_bound(m, len(v)), dtype=np.int32)
+    nb = L.mi355_csrmv_plan_host(m, 0, P._ptr(rp), P._ptr(rb))
+    rbd = dev(rb)
+    yd.copy_(torch.from_numpy(y0))
+    st = L.mi355_dcsrmv(None, 0, 0, 0, 1.0, m, P._ptr(vd), P._ptr(cd), P._ptr(rd), P._ptr(rbd), nb,
+                        P._ptr(xd), 0.5, P._ptr(yd))
+    torch.cuda.synchronize()
+    assert st == 0 and np.array_equal(yd.cpu().numpy(), yr)
+
+
+@pytest.mark.parametrize("op", [P.OP_TRANSPOSE, P.OP_CONJ_TRANSPOSE])
+def test_transposed_spmv_within_bound(op):
+    """csrmvt_kt's result depends on the CPU thread count (per-thread buffers); parity is the
+    componentwise bound |dy| <= (len+4) eps sum|a x||alpha| + 2 eps |beta y| against the 1-thread order."""
+    m, n = 4000, 3000
+    rp, ci, v = random_csr(41, m, n, lambda r, i: r.integers(0, 30))
+    x = np.random.default_rng(3).uniform(-1, 1, m)
+    y0 = np.random.default_rng(4).uniform(-1, 1, n)
+    A = P.Matrix(0, m, n, rp, ci, v)
+    d = P.Descr()
+    assert L.aoclsparse_set_mv_hint(A.h, op, d.h, 5) == 0 and L.aoclsparse_optimize(A.h) == 0
+    assert A.spmv_info(op).device_resident == 1
+    st, y = run_dmv(A, d, x, y0, 5.1, 3.2, op=op)
+    so, yr = oracle.dcsrmvt(0, 5.1, m, n, v, ci, rp, x, 3.2, y0)
+    assert st == 0 and so == 0
+    st2, cp, ri, cv = oracle.dcsr2csc(m, n, len(v), 0, 0, rp, ci, v)
+    scale = abs_row_sums(cp, ri, cv, x) * 5.1
+    lens = np.diff(cp)
+    assert np.all(np.abs(y - yr) <= (lens + 4) * EPS64 * scale + 2 * EPS64 * np.abs(3.2 * y0) + 1e-300)
+    yh = y0.copy()
+    assert P.dcsrmv(op, 5.1, m, n, len(v), v, ci, rp, d, x, 3.2, yh) == 0
+    assert np.array_equal(yh, y)
+
+
+def test_large_laplacian_linearity_and_checksum():
+    """Full-size property check (grid 2048^2, 21 M nnz): A*1 has a known closed form and SpMV is linear."""
+    g = 2048
+    m, rp, ci, v = laplace5(g)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    d = P.Descr()
+    assert L.aoclsparse_set_mv_hint(A.h, P.OP_NONE, d.h, 100) == 0 and L.aoclsparse_optimize(A.h) == 0
+    ones = torch.ones(m, dtype=torch.float64, device="cuda")
+    y = torch.empty_like(ones)
+    assert P.dmv(P.OP_NONE, 1.0, A, d, ones, 0.0, y) == 0
+    torch.cuda.synchronize()
+    deg = np.diff(rp) - 1
+    assert np.array_equal(y.cpu().numpy(), 4.0 - deg)  # exact in fp64
+    x1 = torch.rand(m, dtype=torch.float64, device="cuda")
+    y1, y2 = torch.empty_like(x1), torch.empty_like(x1)
+    assert P.dmv(P.OP_NONE, 1.0, A, d, x1, 0.0, y1) == 0
+    assert P.dmv(P.OP_NONE, 1.0, A, d, 2.0 * x1, 0.0, y2) == 0  # scaling by 2 is exact
+    torch.cuda.synchronize()
+    assert torch.equal(y2, 2.0 * y1)
+    # spot-check 100k rows against the oracle
+    xs = x1.cpu().numpy()
+    so, yr = oracle.dcsrmv(-1, 0, 1.0, m, len(v), v, ci, rp, xs, 0.0, np.zeros(m))
+    assert np.array_equal(y1.cpu().numpy(), yr)
+
+
+# --------------------------------------------------------------------------------------------------
+# TRSV
+# --------------------------------------------------------------------------------------------------
+KIND = {("lower", "n"): "l", ("lower", "t"): "lt", ("upper", "n"): "u", ("upper", "t"): "ut"}
+
+
+def oracle_trsv(base, m, rp, ci, v, fill, trans, unit, alpha, b):
+    o = oracle.dcsr_optimize(m, m, len(v), base, rp, ci, v)
+    assert o["status"] == 0
+    ilend = o["idiag"] if fill == "lower" else o["iurow"]
+    st, x = oracle.dtrsv(KIND[(fill, trans)], alpha, m, o["base"], o["val"], o["ind"], o["ptr"], ilend, b, unit)
+    assert st == 0
+    return x
+
+
+@pytest.mark.parametrize("kid", [None, 0, 1, 3])
+def test_trsv_reference_kats(kats, kid):
+    """D7 / S7 / N25 systems of the reference's unit tests (trsv_tests.cpp:279-318), every schedule,
+    both index bases, triangular and symmetric descriptors, host and device vectors."""
+    tol = kats["trsv_abs_tol"]
+    for c in kats["trsv"]:
+        for base in (0, 1):
+            m = c["m"]
+            rp = np.array(c["row_ptr"], np.int32) + base
+            ci = np.array(c["col_ind"], np.int32) + base
+            v = np.array(c["val"], np.float64)
+            b = np.array(c["b"], np.float64)
+            A = P.Matrix(base, m, m, rp, ci, v)
+            mt = P.TYPE_TRIANGULAR if base == 0 else P.TYPE_SYMMETRIC
+            d = P.Descr(base=base, mtype=mt, fill=P.FILL_LOWER if c["fill"] == "lower" else P.FILL_UPPER,
+                        diag=P.DIAG_UNIT if c["unit"] else P.DIAG_NON_UNIT)
+            op = P.OP_NONE if c["trans"] == "n" else P.OP_TRANSPOSE
+            x = np.zeros(m)
+            st = P.dtrsv(op, c["alpha"], A, d, b, x, kid=kid)
+            assert st == 0, (c["name"], base, kid, P.STATUS[st])
+            assert np.max(np.abs(x - np.array(c["xref"]))) <= tol, (c["name"], base, kid)
+            xr = oracle_trsv(base, m, rp, ci, v, c["fill"], c["trans"], c["unit"], c["alpha"], b)
+            assert np.array_equal(x, xr), (c["name"], base, kid)
+            bd, xd = dev(b), torch.zeros(m, dtype=torch.float64, device="cuda")
+            assert P.dtrsv(op, c["alpha"], A, d, bd, xd, kid=kid) == 0
+            torch.cuda.synchronize()
+            assert np.array_equal(xd.cpu().numpy(), xr)
+
+
+@pytest.mark.parametrize("fill,trans,unit", [("lower", "n", False), ("lower", "n", True), ("lower", "t", False),
+                                             ("upper", "n", False), ("upper", "t", True), ("upper", "t", False)])
+@pytest.mark.parametrize("kid", [0, 2])
+def test_trsv_random_bit_exact(fill, trans, unit, kid):
+    m = 20000
+    rp, ci, v = triangular_system(51, m, 6, band=300)
+    b = np.random.default_rng(5).uniform(-1, 1, m)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    d = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=P.FILL_LOWER if fill == "lower" else P.FILL_UPPER,
+                diag=P.DIAG_UNIT if unit else P.DIAG_NON_UNIT)
+    op = P.OP_NONE if trans == "n" else P.OP_TRANSPOSE
+    assert L.aoclsparse_set_sv_hint(A.h, op, d.h, 3) == 0 and L.aoclsparse_optimize(A.h) == 0
+    lv = A.trsv_levels(P.FILL_LOWER if fill == "lower" else P.FILL_UPPER, op)
+    assert 1 < lv < m
+    bd, xd = dev(b), torch.zeros(m, dtype=torch.float64, device="cuda")
+    st = P.dtrsv(op, 1.3, A, d, bd, xd, kid=kid)
+    torch.cuda.synchronize()
+    xr = oracle_trsv(0, m, rp, ci, v, fill, trans, unit, 1.3, b)
+    assert st == 0 and np.array_equal(xd.cpu().numpy(), xr)
+
+
+def test_trsv_unsorted_input_with_missing_diagonals_unit():
+    """optimize must sort + insert zero diagonals (hint_tests.cpp N5_1_hole); unit-diag solve works."""
+    m = 3000
+    rp, ci, v = random_csr(61, m, m, lambda r, i: r.integers(0, 9), sort=False)
+    b = np.random.default_rng(6).uniform(-1, 1, m)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    d = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=P.FILL_LOWER, diag=P.DIAG_UNIT)
+    x = np.zeros(m)
+    assert P.dtrsv(P.OP_NONE, 1.0, A, d, b, x) == 0
+    xr = oracle_trsv(0, m, rp, ci, v, "lower", "n", True, 1.0, b)
+    assert np.array_equal(x, xr)
+    dn = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=P.FILL_LOWER, diag=P.DIAG_NON_UNIT)
+    assert P.dtrsv(P.OP_NONE, 1.0, A, dn, b, x) == 5  # not full rank: invalid_value (trsv.cpp:133-137)
+
+
+def test_trsv_strided_and_float():
+    m = 4000
+    rp, ci, v = triangular_system(71, m, 4, band=50)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    d = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=P.FILL_UPPER)
+    rng = np.random.default_rng(7)
+    incb, incx = 3, 2
+    b = rng.uniform(-1, 1, m * incb)
+    x = np.full(m * incx, 7.0)
+    assert P.dtrsv(P.OP_NONE, 0.9, A, d, b, x, incb=incb, incx=incx) == 0
+    xr = oracle_trsv(0, m, rp, ci, v, "upper", "n", False, 0.9, b[::incb][:m].copy())
+    assert np.array_equal(x[::incx][:m], xr) and np.all(x[1::incx] == 7.0)
+    bd, xd = dev(b), dev(np.full(m * incx, 7.0))
+    assert P.dtrsv(P.OP_NONE, 0.9, A, d, bd, xd, incb=incb, incx=incx) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(xd.cpu().numpy(), x)
+    # float: same recurrence in fp32 (oracle orc_strsv_l)
+    vf = v.astype(np.float32)
+    Af = P.Matrix(0, m, m, rp, ci, vf)
+    dl = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=P.FILL_LOWER)
+    bf = rng.uniform(-1, 1, m).astype(np.float32)
+    xf = np.zeros(m, np.float32)
+    assert P.strsv(P.OP_NONE, 1.0, Af, dl, bf, xf) == 0
+    o = oracle.dcsr_optimize(m, m, len(v), 0, rp, ci, v)
+    xo = np.zeros(m, np.float32)
+    st = oracle.lib().orc_strsv_l(ctypes.c_float(1.0), m, 0, P._ptr(vf), P._ptr(ci), P._ptr(rp),
+                                  P._ptr(o["idiag"]), P._ptr(bf), 1, P._ptr(xo), 1, 0)
+    assert st == 0 and np.array_equal(xf, xo)
+
+
+def test_trsv_ilu0_laplacian_residual():
+    """BASELINE config 5 in miniature: unit-lower ILU(0) factor of a 2-D Laplacian (grid 300^2):
+    2g-1 dependency levels, b = L*1 so x* = 1; residual and bit-parity with the serial CPU solve."""
+    g = 300
+    m, rp, ci, v = laplace5(g)
+    st, lu, diag = oracle.dilu0(m, 0, rp, ci, v)
+    assert st == 0
+    A = P.Matrix(0, m, m, rp, ci, lu)
+    d = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=P.FILL_LOWER, diag=P.DIAG_UNIT)
+    assert L.aoclsparse_set_sv_hint(A.h, P.OP_NONE, d.h, 10) == 0 and L.aoclsparse_optimize(A.h) == 0
+    assert A.trsv_levels(P.FILL_LOWER) == 2 * g - 1
+    o = oracle.dcsr_optimize(m, m, len(lu), 0, rp, ci, lu)
+    # b = L * 1 computed with the oracle's strict-lower rows
+    b = np.ones(m)
+    low = np.zeros(m)
+    for i in range(m):
+        low[i] = lu[rp[i]:o["idiag"][i]].sum()
+    b = b + low
+    for kid in (0, 1, None):
+        xd = torch.zeros(m, dtype=torch.float64, device="cuda")
+        assert P.dtrsv(P.OP_NONE, 1.0, A, d, dev(b), xd, kid=kid) == 0
+        torch.cuda.synchronize()
+        x = xd.cpu().numpy()
+        st, xr = oracle.dtrsv("l", 1.0, m, 0, lu, ci, rp, o["idiag"], b, True)
+        assert np.array_equal(x, xr)
+        assert np.max(np.abs(x - 1.0)) < 1e-12
+
+
+# --------------------------------------------------------------------------------------------------
+# csrmm
+# --------------------------------------------------------------------------------------------------
+def test_csrmm_reference_kats(kats):
+    for c in kats["csrmm"]:
+        m, k, n = c["m"], c["k"], c["n"]
+        A = P.Matrix(0, m, k, c["row_ptr"], c["col_ind"], np.array(c["val"], np.float64))
+        d = P.Descr()
+        for order, ldb, ldc, key in ((P.ORDER_COLUMN, k, m, "C_exp_col"), (P.ORDER_ROW, n, n, "C_exp_row")):
+            B, C = np.array(c["B"], np.float64), np.array(c["C"], np.float64)
+            assert P.dcsrmm(P.OP_NONE, c["alpha"], A, d, order, B, n, ldb, c["beta"], C, ldc) == 0
+            assert np.allclose(C[: m * n], np.array(c[key]), rtol=1e-13, atol=1e-12), (c["name"], order)
+    c = [t for t in kats["csrmm"] if t["name"] == "id1_5x5"][0]
+    A = P.Matrix(0, 5, 5, c["row_ptr"], c["col_ind"], np.array(c["val"], np.float64))
+    d = P.Descr()
+    for order, key in ((P.ORDER_COLUMN, "C_exp_col_T"), (P.ORDER_ROW, "C_exp_row_T")):
+        B, C = np.array(c["B"], np.float64), np.array(c["C"], np.float64)
+        assert P.dcsrmm(P.OP_TRANSPOSE, c["alpha"], A, d, order, B, 5, 5, c["beta"], C, 5) == 0
+        assert np.allclose(C, np.array(c[key]), rtol=1e-13, atol=1e-12)
+
+
+@pytest.mark.parametrize("n", [1, 7, 32, 256])
+@pytest.mark.parametrize("alpha,beta", [(1.0, 0.0), (3.0, -2.0)])
+def test_csrmm_random_vs_oracle(n, alpha, beta):
+    """Column-major: bit-identical to csrmm_col_major_ref's order.  Row-major: the same per-element
+    arithmetic is used (dot then fma(beta,C,alpha*dot)), so it equals the col-major oracle bitwise and
+    sits within (len+3) eps sum|a b||alpha| + 2 eps |beta c| of csrmm_row_major_ref."""
+    m, k = 3000, 2500
+    rp, ci, v = random_csr(81, m, k, lambda r, i: r.integers(0, 14), base=1)
+    rng = np.random.default_rng(777)
+    A = P.Matrix(1, m, k, rp, ci, v)
+    d = P.Descr(base=1)
+    assert L.aoclsparse_set_mm_hint(A.h, P.OP_NONE, d.h, 2) == 0 and L.aoclsparse_optimize(A.h) == 0
+    ldb, ldc = k + 3, m + 5
+    B = rng.uniform(-1, 1, ldb * n)
+    C0 = rng.uniform(-1, 1, ldc * n)
+    Cd = dev(C0)
+    assert P.dcsrmm(P.OP_NONE, alpha, A, d, P.ORDER_COLUMN, dev(B), n, ldb, beta, Cd, ldc) == 0
+    torch.cuda.synchronize()
+    so, Cr = oracle.dcsrmm("col", alpha, 1, v, ci, rp, m, B, n, ldb, beta, C0, ldc)
+    assert np.array_equal(Cd.cpu().numpy(), Cr)
+    # row-major, host pointers
+    ldb, ldc = n + 2, n + 4
+    Br = rng.uniform(-1, 1, k * ldb)
+    Cr0 = rng.uniform(-1, 1, m * ldc)
+    Ch = Cr0.copy()
+    assert P.dcsrmm(P.OP_NONE, alpha, A, d, P.ORDER_ROW, Br, n, ldb, beta, Ch, ldc) == 0
+    so, Cref = oracle.dcsrmm("row", alpha, 1, v, ci, rp, m, Br, n, ldb, beta, Cr0, ldc)
+    Bm, Cm = Br.reshape(k, ldb)[:, :n], Cr0.reshape(m, ldc)[:, :n]
+    Av = np.abs(v)
+    scale = np.zeros((m, n))
+    for i in range(m):
+        s, e = rp[i] - 1, rp[i + 1] - 1
+        if e > s:
+            scale[i] = Av[s:e] @ np.abs(Bm[ci[s:e] - 1])
+    lens = np.diff(rp)[:, None]
+    diff = np.abs(Ch.reshape(m, ldc)[:, :n] - Cref.reshape(m, ldc)[:, :n])
+    assert np.all(diff <= (lens + 3) * EPS64 * scale * abs(alpha) + 2 * EPS64 * np.abs(beta * Cm) + 1e-300)
+    assert np.array_equal(Ch.reshape(m, ldc)[:, n:], Cr0.reshape(m, ldc)[:, n:])  # padding untouched
+
+
+def test_csrmm_alpha_zero_and_transpose():
+    m, k, n = 500, 400, 16
+    rp, ci, v = random_csr(91, m, k, lambda r, i: r.integers(0, 9))
+    A = P.Matrix(0, m, k, rp, ci, v)
+    d = P.Descr()
+    rng = np.random.default_rng(1)
+    C0 = rng.uniform(-1, 1, m * n)
+    C = C0.copy()
+    assert P.dcsrmm(P.OP_NONE, 0.0, A, d, P.ORDER_ROW, np.ones(k * n), n, n, 0.0, C, n) == 0
+    assert np.all(C == 0.0)
+    C = C0.copy()
+    C[3] = np.nan
+    assert P.dcsrmm(P.OP_NONE, 0.0, A, d, P.ORDER_ROW, np.ones(k * n), n, n, 0.0, C, n) == 0
+    assert np.all(C == 0.0)  # scale_dense_matrix writes exact zeros (csrmm.hpp:366-393)
+    # op = transpose: C (k x n) = A^T B (m x n)
+    B = rng.uniform(-1, 1, m * n)
+    Ct = rng.uniform(-1, 1, k * n)
+    Ch = Ct.copy()
+    assert P.dcsrmm(P.OP_TRANSPOSE, 2.0, A, d, P.ORDER_ROW, B, n, n, 0.5, Ch, n) == 0
+    st, cp, ri, cv = oracle.dcsr2csc(m, k, len(v), 0, 0, rp, ci, v)
+    so, Cref = oracle.dcsrmm("col", 2.0, 0, cv, ri, cp, k, np.ascontiguousarray(B.reshape(m, n).T).ravel(), n, m, 0.5,
+                             np.ascontiguousarray(Ct.reshape(k, n).T).ravel(), k)
+    assert np.array_equal(Ch.reshape(k, n), Cref.reshape(n, k).T)
+
+
+def test_csrmm_column_shards_compose():
+    """Multi-GPU contract: C[:, J] depends only on A and B[:, J]; shards are independent."""
+    g = 200
+    m, rp, ci, v = laplace5(g)
+    n, shards = 64, 4
+    rng = np.random.default_rng(777)
+    B = rng.uniform(-1, 1, (n, m))  # column-major storage: B[j] is column j
+    A = P.Matrix(0, m, m, rp, ci, v)
+    d = P.Descr()
+    full = torch.zeros(n * m, dtype=torch.float64, device="cuda")
+    assert P.dcsrmm(P.OP_NONE, 1.0, A, d, P.ORDER_COLUMN, dev(B.ravel()), n, m, 0.0, full, m) == 0
+    w = n // shards
+    parts = []
+    for s in range(shards):
+        Cs = torch.zeros(w * m, dtype=torch.float64, device="cuda")
+        assert P.dcsrmm(P.OP_NONE, 1.0, A, d, P.ORDER_COLUMN, dev(B[s * w:(s + 1) * w].ravel()), w, m, 0.0, Cs, m) == 0
+        parts.append(Cs)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat(parts), full)
