@@ -35,7 +35,7 @@ STATUS = {
 
 
 class SpmvInfo(ctypes.Structure):
-    _fields_ = [("kernel", c_int32), ("order", c_int32), ("row_blocks", c_int32),
+    _fields_ = [("kernel", c_int32), ("order", c_int32), ("row_blocks", c_int32), ("tile", c_int32),
                 ("long_rows", c_int32), ("max_row_nnz", c_int32), ("device_resident", c_int32)]
 
 
@@ -107,9 +107,9 @@ SIGNATURES = {
     "aoclsparse_mi355_get_trsv_levels": (c_int, [_P, c_int, c_int, POINTER(_I)]),
     "aoclsparse_mi355_invalidate": (c_int, [_P]),
     "mi355_csrmv_plan_bound": (_I, [_I, _I]),
-    "mi355_csrmv_plan_host": (_I, [_I, _I, _P, _P]),
-    "mi355_dcsrmv": (c_int, [_P, _I, _I, _I, c_double, _I, _P, _P, _P, _P, _I, _P, c_double, _P]),
-    "mi355_scsrmv": (c_int, [_P, _I, _I, _I, c_float, _I, _P, _P, _P, _P, _I, _P, c_float, _P]),
+    "mi355_csrmv_plan_host": (_I, [_I, _I, _I, _P, _P]),
+    "mi355_dcsrmv": (c_int, [_P, _I, _I, _I, _I, c_double, _I, _P, _P, _P, _P, _I, _P, c_double, _P]),
+    "mi355_scsrmv": (c_int, [_P, _I, _I, _I, _I, c_float, _I, _P, _P, _P, _P, _I, _P, c_float, _P]),
     "mi355_dcsrmm": (c_int, [_P, _I, _I, c_double, _I, _I, _P, _P, _P, _P, _I, _I, c_double, _P, _I]),
 }
 

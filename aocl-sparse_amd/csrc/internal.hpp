@@ -121,7 +121,8 @@ struct SpmvPlan
     aoclsparse_int nblocks     = 0;
     aoclsparse_int long_rows   = 0;
     aoclsparse_int max_row_nnz = 0;
-    DeviceBuffer   rowblocks;
+    aoclsparse_int tile        = 0; // LDS tile (non-zeros per row block): 1024 or 2048
+    DeviceBuffer   rowblocks; // nblocks+1 entries {first row, first non-zero (0-based)}
     bool           valid = false;
 };
 
@@ -250,15 +251,15 @@ aoclsparse_status ensure_spmv(aoclsparse_matrix A, bool transposed, DeviceCsr *&
                               SpmvPlan *&plan);
 // clean CSR on the device + level sets of one triangle (trsv_api.cpp)
 aoclsparse_status ensure_trsv(aoclsparse_matrix A, bool upper, bool transposed);
-aoclsparse_status build_spmv_plan(aoclsparse_int m, aoclsparse_index_base base,
+aoclsparse_status build_spmv_plan(aoclsparse_int m, aoclsparse_int nnz, aoclsparse_index_base base,
                                   const aoclsparse_int *row_ptr_host, SpmvPlan &plan);
 
 // ---- kernel launchers (HIP translation units) --------------------------------------------------
 // order: 0 scalar, 1 lane4, 2 lane8
 template <typename T>
-aoclsparse_status launch_csrmv(hipStream_t s, int order, bool strict, int base, T alpha,
+aoclsparse_status launch_csrmv(hipStream_t s, int order, bool strict, int tile, int base, T alpha,
                                aoclsparse_int m, const T *val, const aoclsparse_int *col,
-                               const aoclsparse_int *row_ptr, const aoclsparse_int *rowblocks,
+                               const aoclsparse_int *row_ptr, const aoclsparse_int *blocks,
                                aoclsparse_int nblocks, const T *x, T beta, T *y);
 template <typename T>
 aoclsparse_status launch_scale(hipStream_t s, T *y, aoclsparse_int n, T beta);
@@ -287,8 +288,11 @@ aoclsparse_status launch_scale_dense(hipStream_t s, aoclsparse_order order, T *C
                                      aoclsparse_int n, aoclsparse_int ld, T beta);
 
 // SpMV plan constants shared by host planner and kernels
-constexpr int SPMV_BLOCK   = 256; // threads per workgroup (4 wavefronts)
-constexpr int SPMV_TILE    = 2048; // non-zeros staged in LDS per workgroup (val+x: 32 KiB fp64)
-constexpr int SPMV_MAXROWS = 512; // rows per stream block (2 per thread)
+// LDS tile = non-zeros staged per workgroup: 512 (128 threads), 1024 or 2048 (256 threads);
+// rows per stream block (their row_ptr slice is kept in LDS)
+constexpr int spmv_maxrows(int tile)
+{
+    return tile / 2 < 512 ? tile / 2 : 512;
+}
 
 } // namespace mi355

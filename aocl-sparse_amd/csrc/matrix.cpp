@@ -5,6 +5,7 @@
 #include "internal.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -378,19 +379,18 @@ aoclsparse_status upload_csr(const HostCsr &h, size_t vsize, DeviceCsr &d)
 }
 
 // CSR-Adaptive row blocks (host, O(m)): consecutive rows are packed into a block while their
-// non-zeros fit one LDS tile (SPMV_TILE) and the row count stays <= SPMV_MAXROWS; a row longer
-// than a tile gets a block of its own.  rowblocks[b]..rowblocks[b+1] = rows of block b.
-static aoclsparse_int plan_rows(aoclsparse_int m, aoclsparse_index_base base,
-                                const aoclsparse_int *row_ptr, aoclsparse_int *rb,
+// non-zeros fit one LDS tile and the row count stays <= spmv_maxrows(tile); a row longer than a tile gets a
+// block of its own.  Entry b = {first row, first non-zero (0-based)}; entry nb closes the last block.
+static aoclsparse_int plan_rows(aoclsparse_int m, aoclsparse_index_base base, aoclsparse_int tile,
+                                const aoclsparse_int *row_ptr, aoclsparse_int *blocks,
                                 aoclsparse_int *long_rows, aoclsparse_int *max_row)
 {
     aoclsparse_int nb = 0, lr = 0, mx = 0, i = 0;
-    rb[0] = 0;
     while(i < m)
     {
         const aoclsparse_int start = row_ptr[i] - base;
         aoclsparse_int       j     = i;
-        while(j < m && j - i < SPMV_MAXROWS && (row_ptr[j + 1] - base) - start <= SPMV_TILE)
+        while(j < m && j - i < spmv_maxrows(tile) && (row_ptr[j + 1] - base) - start <= tile)
             j++;
         if(j == i) // single row longer than a tile
         {
@@ -399,9 +399,13 @@ static aoclsparse_int plan_rows(aoclsparse_int m, aoclsparse_index_base base,
         }
         for(aoclsparse_int r = i; r < j; r++)
             mx = std::max(mx, row_ptr[r + 1] - row_ptr[r]);
-        rb[++nb] = j;
-        i        = j;
+        blocks[2 * nb]     = i;
+        blocks[2 * nb + 1] = start;
+        nb++;
+        i = j;
     }
+    blocks[2 * nb]     = m;
+    blocks[2 * nb + 1] = row_ptr[m] - base;
     if(long_rows)
         *long_rows = lr;
     if(max_row)
@@ -409,15 +413,31 @@ static aoclsparse_int plan_rows(aoclsparse_int m, aoclsparse_index_base base,
     return nb;
 }
 
-aoclsparse_status build_spmv_plan(aoclsparse_int m, aoclsparse_index_base base,
+static aoclsparse_int choose_tile(aoclsparse_int /*m*/, aoclsparse_int /*nnz*/)
+{
+    // 1024: 18 KiB of LDS per workgroup -> 8 workgroups (32 wavefronts) per CU hide the
+    // load -> gather -> reduce latency chain better than 4 fatter ones (measured)
+    // tuning knobs (read when a plan is built): AOCLSPARSE_MI355_SPMV_TILE=1024|2048,
+    // AOCLSPARSE_MI355_XCD_ORDER=1 enables the XCD-contiguous block order (encoded as tile|1;
+    // measured slower than the plain order on the Laplacian, so off by default)
+    const char *e      = std::getenv("AOCLSPARSE_MI355_SPMV_TILE");
+    const int   forced = e ? std::atoi(e) : 0;
+    const char *x      = std::getenv("AOCLSPARSE_MI355_XCD_ORDER");
+    const int   xcd    = (x && std::atoi(x) != 0) ? 1 : 0;
+    return (forced == 2048 || forced == 1024 || forced == 512 ? forced : 1024) | xcd;
+}
+
+aoclsparse_status build_spmv_plan(aoclsparse_int m, aoclsparse_int nnz, aoclsparse_index_base base,
                                   const aoclsparse_int *row_ptr_host, SpmvPlan &plan)
 {
     try
     {
-        std::vector<aoclsparse_int> rb((size_t)m + 2);
-        plan.nblocks = plan_rows(m, base, row_ptr_host, rb.data(), &plan.long_rows, &plan.max_row_nnz);
+        std::vector<aoclsparse_int> blk(2 * ((size_t)m + 2));
+        plan.tile    = choose_tile(m, nnz);
+        plan.nblocks = plan_rows(m, base, plan.tile & ~1, row_ptr_host, blk.data(), &plan.long_rows,
+                                 &plan.max_row_nnz);
         aoclsparse_status st = plan.rowblocks.upload(
-            rb.data(), sizeof(aoclsparse_int) * (size_t)(plan.nblocks + 1), Runtime::get().stream());
+            blk.data(), sizeof(aoclsparse_int) * 2 * (size_t)(plan.nblocks + 1), Runtime::get().stream());
         if(st != aoclsparse_status_success)
             return st;
         plan.valid = true;
@@ -454,7 +474,7 @@ aoclsparse_status ensure_spmv(aoclsparse_matrix A, bool transposed, DeviceCsr *&
     }
     if(!plan->valid)
     {
-        aoclsparse_status st = build_spmv_plan(h.m, h.base, h.ptr, *plan);
+        aoclsparse_status st = build_spmv_plan(h.m, h.ptr[h.m] - h.base, h.base, h.ptr, *plan);
         if(st != aoclsparse_status_success)
             return st;
     }
@@ -468,15 +488,15 @@ extern "C" {
 
 aoclsparse_int mi355_csrmv_plan_bound(aoclsparse_int m, aoclsparse_int /*nnz*/)
 {
-    return m + 2;
+    return 2 * (m + 2);
 }
 
-aoclsparse_int mi355_csrmv_plan_host(aoclsparse_int m, aoclsparse_int base,
-                                     const aoclsparse_int *row_ptr_host, aoclsparse_int *rowblocks_host)
+aoclsparse_int mi355_csrmv_plan_host(aoclsparse_int m, aoclsparse_int base, aoclsparse_int tile,
+                                     const aoclsparse_int *row_ptr_host, aoclsparse_int *blocks_host)
 {
-    if(m < 0 || !row_ptr_host || !rowblocks_host || (base != 0 && base != 1))
+    if(m < 0 || !row_ptr_host || !blocks_host || (base != 0 && base != 1) || (tile != 512 && tile != 1024 && tile != 2048))
         return -1;
-    return plan_rows(m, (aoclsparse_index_base)base, row_ptr_host, rowblocks_host, nullptr, nullptr);
+    return plan_rows(m, (aoclsparse_index_base)base, tile, row_ptr_host, blocks_host, nullptr, nullptr);
 }
 
 // ---- descriptor: extra/aoclsparse_auxiliary.cpp:191-360 -------------------------------------------------

@@ -108,7 +108,7 @@ aoclsparse_status run_on_device_csr(Runtime &rt, aoclsparse_int kid, const Devic
     st = ay.in(rt, 4, y, sizeof(T) * (size_t)ny, ydev, beta != T(0));
     if(st != aoclsparse_status_success)
         return st;
-    st = launch_csrmv<T>(rt.stream(), order, strict, d.base, alpha, d.m, d.val.as<T>(),
+    st = launch_csrmv<T>(rt.stream(), order, strict, plan.tile, d.base, alpha, d.m, d.val.as<T>(),
                          d.ind.as<aoclsparse_int>(), d.ptr.as<aoclsparse_int>(),
                          plan.rowblocks.as<aoclsparse_int>(), plan.nblocks, static_cast<const T *>(ax.dev),
                          beta, static_cast<T *>(ay.dev));
@@ -328,7 +328,7 @@ aoclsparse_status csrmv_t(aoclsparse_operation trans, const T *alpha, aoclsparse
                 hit             = &g_raw[g_raw_next];
                 g_raw_next      = (g_raw_next + 1) % RAW_CACHE;
                 hit->plan.valid = false;
-                st              = build_spmv_plan(m, descr->base, hrow.data(), hit->plan);
+                st              = build_spmv_plan(m, nnz, descr->base, hrow.data(), hit->plan);
                 if(st != aoclsparse_status_success)
                     return st;
                 hit->key = row, hit->m = m, hit->nnz = nnz, hit->base = descr->base;
@@ -337,7 +337,7 @@ aoclsparse_status csrmv_t(aoclsparse_operation trans, const T *alpha, aoclsparse
         }
         else
         {
-            st = build_spmv_plan(m, descr->base, row, local);
+            st = build_spmv_plan(m, nnz, descr->base, row, local);
             if(st != aoclsparse_status_success)
                 return st;
         }
@@ -410,6 +410,7 @@ aoclsparse_status aoclsparse_mi355_get_spmv_info(const aoclsparse_matrix A, aocl
         return aoclsparse_status_success;
     info->kernel      = 1;
     info->row_blocks  = p.nblocks;
+    info->tile        = p.tile & ~1;
     info->long_rows   = p.long_rows;
     info->max_row_nnz = p.max_row_nnz;
     aoclsparse_int kid = -1;

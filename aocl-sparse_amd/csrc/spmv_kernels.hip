@@ -1,20 +1,25 @@
 // spmv_kernels.hip -- CSR-Adaptive SpMV for gfx950 (wave64, 256 CUs / 8 XCDs, 160 KiB LDS per CU).
 //
 // One workgroup (256 threads = 4 wavefronts) owns one ROW BLOCK: consecutive whole rows whose
-// non-zeros fit one LDS tile (SPMV_TILE = 2048).  Phase 1 streams val[] / col_ind[] of the block
-// with fully coalesced loads, gathers x[col] (L2 / Infinity-Cache hits) and parks {val, x} in LDS.
-// Phase 2 reduces each row out of LDS in EXACTLY the summation order of the reference CPU kernel
-// the reference would dispatch:
-//   order 0: one lane per row, left-to-right FMA chain     = ref_csrmv_gn        (csrmv_kr.hpp:448-513)
-//   order 1: 4 lanes per row, j mod 4, (l0+l1)+(l2+l3), tail = ..._vectorized_avx2 (csrmv_kr.hpp:949-1040)
-//   order 2: 8 lanes per row, j mod 8, AVX-512 tree, tail    = ..._vectorized_avx512 (csrmv_avx512.cpp:36-134)
-//            (float: the AVX2 8-lane tree of csrmv_kr.hpp:734-831)
+// non-zeros fit one LDS tile (TILE = 1024 or 2048, chosen per matrix by the planner).  The plan
+// entry of a block is {first row, first non-zero}, so a workgroup knows its row range AND its
+// non-zero range after one small cached load.
+//   phase 1: the block's val[] / col_ind[] are streamed with coalesced 16-byte / 8-byte loads (two
+//            non-zeros per lane), x[col] is gathered (L2 / Infinity-Cache hits) and {val, x} are
+//            parked in LDS; the block's row_ptr slice is loaded in the same breath into LDS.
+//   phase 2: every row is reduced out of LDS in EXACTLY the summation order of the CPU kernel the
+//            reference would dispatch:
+//     order 0: one lane per row, left-to-right FMA chain      = ref_csrmv_gn         (csrmv_kr.hpp:448-513)
+//     order 1: 4 lanes per row, j mod 4, (l0+l1)+(l2+l3), tail = ..._vectorized_avx2  (csrmv_kr.hpp:949-1040)
+//     order 2: 8 lanes per row, j mod 8, AVX-512 tree, tail    = ..._vectorized_avx512 (csrmv_avx512.cpp:36-134)
+//              (float: the AVX2 8-lane tree of csrmv_kr.hpp:734-831)
 // so y is bit-identical to that CPU kernel (GPU fma == x86 vfmadd).  A row longer than a tile gets a
-// workgroup of its own: STRICT keeps the reference order (tiles through LDS, owner lanes chain),
+// workgroup of its own: `strict` keeps the reference order (tiles through LDS, owner lanes chain),
 // otherwise a wavefront tree is used (documented componentwise bound).
 //
 // HBM traffic per launch = the algorithmic bytes: val 8 B + col 4 B per nnz, row_ptr 4 B + y 8 B per
-// row, x 8 B per column once (re-reads are cache hits).  Roofline: HBM (AI ~ 0.16 flop/B).
+// row, x 8 B per column once (re-reads are cache hits), + 8 B per row block of plan.
+// Roofline: HBM (AI ~ 0.16 flop/B).
 #include "internal.hpp"
 
 #include <hip/hip_runtime.h>
@@ -71,8 +76,21 @@ struct lanes_of
     static constexpr int value = ORDER == 0 ? 1 : (ORDER == 1 ? 4 : 8);
 };
 
-// workgroup-wide sum (any order) for the non-strict long-row path
 template <typename T>
+struct pair_of;
+template <>
+struct pair_of<double>
+{
+    using type = double2;
+};
+template <>
+struct pair_of<float>
+{
+    using type = float2;
+};
+
+// workgroup-wide sum (any order) for the non-strict long-row path
+template <typename T, int BLOCK>
 __device__ __forceinline__ T block_sum(T v, T *scratch)
 {
     for(int off = 32; off > 0; off >>= 1)
@@ -83,61 +101,122 @@ __device__ __forceinline__ T block_sum(T v, T *scratch)
     __syncthreads();
     T r = T(0);
     if(threadIdx.x == 0)
-        for(int w = 0; w < SPMV_BLOCK / 64; w++)
+        for(int w = 0; w < BLOCK / 64; w++)
             r += scratch[w];
     return r;
 }
 
-template <typename T, int ORDER, bool STRICT>
-__global__ __launch_bounds__(SPMV_BLOCK) void csr_adaptive_kernel(const aoclsparse_int *__restrict__ rowblocks,
+// flags: bit0 strict long rows, bit1 16-byte-aligned val / 8-byte-aligned col (pair loads allowed),
+//        bit2 XCD-contiguous block order
+template <typename T, int ORDER, int TILE, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restrict__ blocks,
                                                                   const aoclsparse_int *__restrict__ row_ptr,
                                                                   const aoclsparse_int *__restrict__ col,
                                                                   const T *__restrict__ val,
                                                                   const T *__restrict__ x,
                                                                   T *__restrict__ y,
-                                                                  T              alpha,
-                                                                  T              beta,
-                                                                  int            base,
-                                                                  int            nblocks,
-                                                                  int            chunk)
+                                                                  T   alpha,
+                                                                  T   beta,
+                                                                  int base,
+                                                                  int nblocks,
+                                                                  int chunk,
+                                                                  int flags)
 {
-    __shared__ T s_val[SPMV_TILE];
-    __shared__ T s_x[SPMV_TILE];
+    constexpr int MAXROWS = spmv_maxrows(TILE); // planner guarantees rows <= MAXROWS
+    __shared__ T              s_val[TILE + 4];
+    __shared__ T              s_x[TILE + 4];
+    __shared__ aoclsparse_int s_row[MAXROWS + 1];
+    using P2          = typename pair_of<T>::type;
     constexpr int L   = lanes_of<ORDER>::value;
     const int     tid = threadIdx.x;
     // XCD-aware order: workgroups with equal blockIdx%8 share an XCD (one L2); give each XCD a
     // contiguous eighth of the row blocks so its x windows stay in its own L2.
-    const int b = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    const int b = (flags & 4) ? (blockIdx.x & 7) * chunk + (blockIdx.x >> 3) : (int)blockIdx.x;
     if(b >= nblocks)
         return;
-    const int r0  = rowblocks[b];
-    const int r1  = rowblocks[b + 1];
-    const int p0  = row_ptr[r0] - base;
-    const int cnt = (row_ptr[r1] - base) - p0;
+    const int2 e0 = blocks[b], e1 = blocks[b + 1];
+    const int  r0 = e0.x, p0 = e0.y;
+    const int  nrows = e1.x - r0;
+    const int  cnt   = e1.y - p0;
 
-    if(cnt <= SPMV_TILE)
+    if(cnt <= TILE)
     {
-        // ---- phase 1: coalesced stream of the block's non-zeros into LDS ------------------------
-#pragma unroll
-        for(int k = 0; k < SPMV_TILE / SPMV_BLOCK; k++)
+        // ---- phase 1: coalesced stream of the block into LDS ----------------------------------------
+        // window start rounded down to 4 non-zeros when the arrays allow 16-byte loads (flags bit1):
+        // the <= 3 extra leading entries belong to the previous row and are never reduced
+        const int w0   = (flags & 2) ? (p0 & ~3) : p0;
+        const int cntw = cnt + (p0 - w0);
+        for(int i = tid; i <= nrows; i += BLOCK)
+            s_row[i] = row_ptr[r0 + i] - base - w0;
+        if(flags & 2)
         {
-            const int i = tid + k * SPMV_BLOCK;
-            if(i < cnt)
+#pragma unroll
+            for(int k = 0; k < TILE / (4 * BLOCK); k++)
             {
-                const T   v = val[p0 + i];
-                const int c = col[p0 + i] - base;
-                s_val[i]    = v;
-                s_x[i]      = x[c];
+                const int i = 4 * (tid + k * BLOCK);
+                if(i + 3 < cntw)
+                {
+                    const int4 c = *reinterpret_cast<const int4 *>(col + w0 + i);
+                    if constexpr(sizeof(T) == 8)
+                    {
+                        const P2 va = *reinterpret_cast<const P2 *>(val + w0 + i);
+                        const P2 vb = *reinterpret_cast<const P2 *>(val + w0 + i + 2);
+                        s_val[i]     = va.x;
+                        s_val[i + 1] = va.y;
+                        s_val[i + 2] = vb.x;
+                        s_val[i + 3] = vb.y;
+                    }
+                    else
+                    {
+                        const float4 vq = *reinterpret_cast<const float4 *>(val + w0 + i);
+                        s_val[i]     = vq.x;
+                        s_val[i + 1] = vq.y;
+                        s_val[i + 2] = vq.z;
+                        s_val[i + 3] = vq.w;
+                    }
+                    s_x[i]     = x[c.x - base];
+                    s_x[i + 1] = x[c.y - base];
+                    s_x[i + 2] = x[c.z - base];
+                    s_x[i + 3] = x[c.w - base];
+                }
+                else
+                {
+                    for(int q = i; q < cntw && q < i + 4; q++)
+                    {
+                        s_val[q] = val[w0 + q];
+                        s_x[q]   = x[col[w0 + q] - base];
+                    }
+                }
+            }
+            // the window shift can push a full tile up to 3 entries past index TILE-1
+            if(tid < 3 && TILE + tid < cntw)
+            {
+                s_val[TILE + tid] = val[w0 + TILE + tid];
+                s_x[TILE + tid]   = x[col[w0 + TILE + tid] - base];
+            }
+        }
+        else
+        {
+#pragma unroll
+            for(int k = 0; k < TILE / BLOCK; k++)
+            {
+                const int i = tid + k * BLOCK;
+                if(i < cntw)
+                {
+                    s_val[i] = val[w0 + i];
+                    s_x[i]   = x[col[w0 + i] - base];
+                }
             }
         }
         __syncthreads();
-        // ---- phase 2: per-row reduction in the reference order --------------------------------------
+        // ---- phase 2: per-row reduction in the reference order -----------------------------------------
         const int grp  = tid / L;
         const int lane = tid % L;
-        for(int r = r0 + grp; r < r1; r += SPMV_BLOCK / L)
+        for(int rr = grp; rr < nrows; rr += BLOCK / L)
         {
-            const int s = row_ptr[r] - base - p0;
-            const int e = row_ptr[r + 1] - base - p0;
+            const int s   = s_row[rr];
+            const int e   = s_row[rr + 1];
+            const int r   = r0 + rr;
             T         acc = T(0);
             if constexpr(L == 1)
             {
@@ -164,20 +243,20 @@ __global__ __launch_bounds__(SPMV_BLOCK) void csr_adaptive_kernel(const aoclspar
     }
     else
     {
-        // ---- long row: this workgroup owns the single row r0 ------------------------------------------
+        // ---- long row: this workgroup owns the single row r0 ---------------------------------------------
         const int n = cnt;
-        if constexpr(STRICT)
+        if(flags & 1)
         {
             const int nfull = n & ~(L - 1);
             T         acc   = T(0);
-            for(int t0 = 0; t0 < nfull; t0 += SPMV_TILE)
+            for(int t0 = 0; t0 < nfull; t0 += TILE)
             {
-                const int tn = min(SPMV_TILE, nfull - t0);
+                const int tn = min(TILE, nfull - t0);
                 __syncthreads();
 #pragma unroll
-                for(int k = 0; k < SPMV_TILE / SPMV_BLOCK; k++)
+                for(int k = 0; k < TILE / BLOCK; k++)
                 {
-                    const int i = tid + k * SPMV_BLOCK;
+                    const int i = tid + k * BLOCK;
                     if(i < tn)
                     {
                         s_val[i] = val[p0 + t0 + i];
@@ -208,9 +287,9 @@ __global__ __launch_bounds__(SPMV_BLOCK) void csr_adaptive_kernel(const aoclspar
         {
             // wavefront tree: same flops, order differs (bound stated in DESIGN.md / tests)
             T acc = T(0);
-            for(int j = tid; j < n; j += SPMV_BLOCK)
+            for(int j = tid; j < n; j += BLOCK)
                 acc = dev_fma(val[p0 + j], x[col[p0 + j] - base], acc);
-            T res = block_sum(acc, s_val);
+            T res = block_sum<T, BLOCK>(acc, s_val);
             if(tid == 0)
                 y[r0] = finish(res, alpha, beta, &y[r0]);
         }
@@ -242,43 +321,60 @@ __global__ void scatter_strided_kernel(const T *src, aoclsparse_int n, T *dst, a
         dst[(size_t)i * inc] = src[i];
 }
 
-template <typename T, int ORDER, bool STRICT>
-static void launch_inst(hipStream_t s, int base, T alpha, const T *val, const aoclsparse_int *col,
-                        const aoclsparse_int *row_ptr, const aoclsparse_int *rowblocks,
-                        aoclsparse_int nblocks, const T *x, T beta, T *y)
+template <typename T, int ORDER, int TILE, int BLOCK>
+static void launch_inst(hipStream_t s, int flags, int base, T alpha, const T *val, const aoclsparse_int *col,
+                        const aoclsparse_int *row_ptr, const aoclsparse_int *blocks, aoclsparse_int nblocks,
+                        const T *x, T beta, T *y)
 {
     const int chunk = (nblocks + 7) / 8;
-    hipLaunchKernelGGL((csr_adaptive_kernel<T, ORDER, STRICT>), dim3(chunk * 8), dim3(SPMV_BLOCK), 0, s,
-                       rowblocks, row_ptr, col, val, x, y, alpha, beta, base, (int)nblocks, chunk);
+    const int grid  = (flags & 4) ? chunk * 8 : (int)nblocks;
+    hipLaunchKernelGGL((csr_adaptive_kernel<T, ORDER, TILE, BLOCK>), dim3(grid), dim3(BLOCK), 0, s,
+                       reinterpret_cast<const int2 *>(blocks), row_ptr, col, val, x, y, alpha, beta, base,
+                       (int)nblocks, chunk, flags);
 }
 
+// tile: 512 (128-thread workgroups), 1024 or 2048 (256 threads); bit0 set = XCD-contiguous block order
 template <typename T>
-aoclsparse_status launch_csrmv(hipStream_t s, int order, bool strict, int base, T alpha,
+aoclsparse_status launch_csrmv(hipStream_t s, int order, bool strict, int tile, int base, T alpha,
                                aoclsparse_int m, const T *val, const aoclsparse_int *col,
-                               const aoclsparse_int *row_ptr, const aoclsparse_int *rowblocks,
+                               const aoclsparse_int *row_ptr, const aoclsparse_int *blocks,
                                aoclsparse_int nblocks, const T *x, T beta, T *y)
 {
     if(m <= 0 || nblocks <= 0)
         return aoclsparse_status_success;
-#define MI355_CASE(O, S)                                                                            \
-    launch_inst<T, O, S>(s, base, alpha, val, col, row_ptr, rowblocks, nblocks, x, beta, y);        \
+    const bool xcd = (tile & 1) != 0;
+    tile &= ~1;
+    int flags = strict ? 1 : 0;
+    if(reinterpret_cast<uintptr_t>(val) % 16 == 0 && reinterpret_cast<uintptr_t>(col) % 16 == 0)
+        flags |= 2;
+    if(xcd)
+        flags |= 4;
+    const int tsel = tile == 512 ? 0 : (tile == 1024 ? 1 : (tile == 2048 ? 2 : -1));
+    if(tsel < 0 || order < 0 || order > 2)
+        return aoclsparse_status_invalid_kid;
+#define MI355_CASE(O, TL, BL)                                                                                 \
+    launch_inst<T, O, TL, BL>(s, flags, base, alpha, val, col, row_ptr, blocks, nblocks, x, beta, y);         \
     break
-    switch(order * 2 + (strict ? 1 : 0))
+    switch(order * 3 + tsel)
     {
     case 0:
-        MI355_CASE(0, false);
+        MI355_CASE(0, 512, 128);
     case 1:
-        MI355_CASE(0, true);
+        MI355_CASE(0, 1024, 256);
     case 2:
-        MI355_CASE(1, false);
+        MI355_CASE(0, 2048, 256);
     case 3:
-        MI355_CASE(1, true);
+        MI355_CASE(1, 512, 128);
     case 4:
-        MI355_CASE(2, false);
+        MI355_CASE(1, 1024, 256);
     case 5:
-        MI355_CASE(2, true);
-    default:
-        return aoclsparse_status_invalid_kid;
+        MI355_CASE(1, 2048, 256);
+    case 6:
+        MI355_CASE(2, 512, 128);
+    case 7:
+        MI355_CASE(2, 1024, 256);
+    case 8:
+        MI355_CASE(2, 2048, 256);
     }
 #undef MI355_CASE
     MI355_HIP_TRY(hipGetLastError());
@@ -318,7 +414,7 @@ aoclsparse_status launch_strided_scatter(hipStream_t s, const T *src, aoclsparse
 }
 
 #define MI355_INSTANTIATE(T)                                                                                   \
-    template aoclsparse_status launch_csrmv<T>(hipStream_t, int, bool, int, T, aoclsparse_int, const T *,      \
+    template aoclsparse_status launch_csrmv<T>(hipStream_t, int, bool, int, int, T, aoclsparse_int, const T *, \
                                                const aoclsparse_int *, const aoclsparse_int *,                  \
                                                const aoclsparse_int *, aoclsparse_int, const T *, T, T *);      \
     template aoclsparse_status launch_scale<T>(hipStream_t, T *, aoclsparse_int, T);                           \
@@ -335,34 +431,36 @@ using namespace mi355;
 
 extern "C" {
 
-aoclsparse_status mi355_dcsrmv(void *stream, aoclsparse_int order, aoclsparse_int strict, aoclsparse_int base,
-                               double alpha, aoclsparse_int m, const double *val, const aoclsparse_int *col,
-                               const aoclsparse_int *row_ptr, const aoclsparse_int *rowblocks,
-                               aoclsparse_int nblocks, const double *x, double beta, double *y)
+aoclsparse_status mi355_dcsrmv(void *stream, aoclsparse_int order, aoclsparse_int strict, aoclsparse_int tile,
+                               aoclsparse_int base, double alpha, aoclsparse_int m, const double *val,
+                               const aoclsparse_int *col, const aoclsparse_int *row_ptr,
+                               const aoclsparse_int *blocks, aoclsparse_int nblocks, const double *x,
+                               double beta, double *y)
 {
-    if(!val || !col || !row_ptr || !rowblocks || !x || !y)
+    if(!val || !col || !row_ptr || !blocks || !x || !y)
         return aoclsparse_status_invalid_pointer;
     if(m < 0 || nblocks < 0)
         return aoclsparse_status_invalid_size;
-    if(base != 0 && base != 1)
+    if((base != 0 && base != 1) || (tile != 512 && tile != 1024 && tile != 2048))
         return aoclsparse_status_invalid_value;
-    return launch_csrmv<double>((hipStream_t)stream, order, strict != 0, base, alpha, m, val, col, row_ptr,
-                                rowblocks, nblocks, x, beta, y);
+    return launch_csrmv<double>((hipStream_t)stream, order, strict != 0, tile, base, alpha, m, val, col, row_ptr,
+                                blocks, nblocks, x, beta, y);
 }
 
-aoclsparse_status mi355_scsrmv(void *stream, aoclsparse_int order, aoclsparse_int strict, aoclsparse_int base,
-                               float alpha, aoclsparse_int m, const float *val, const aoclsparse_int *col,
-                               const aoclsparse_int *row_ptr, const aoclsparse_int *rowblocks,
-                               aoclsparse_int nblocks, const float *x, float beta, float *y)
+aoclsparse_status mi355_scsrmv(void *stream, aoclsparse_int order, aoclsparse_int strict, aoclsparse_int tile,
+                               aoclsparse_int base, float alpha, aoclsparse_int m, const float *val,
+                               const aoclsparse_int *col, const aoclsparse_int *row_ptr,
+                               const aoclsparse_int *blocks, aoclsparse_int nblocks, const float *x, float beta,
+                               float *y)
 {
-    if(!val || !col || !row_ptr || !rowblocks || !x || !y)
+    if(!val || !col || !row_ptr || !blocks || !x || !y)
         return aoclsparse_status_invalid_pointer;
     if(m < 0 || nblocks < 0)
         return aoclsparse_status_invalid_size;
-    if(base != 0 && base != 1)
+    if((base != 0 && base != 1) || (tile != 512 && tile != 1024 && tile != 2048))
         return aoclsparse_status_invalid_value;
-    return launch_csrmv<float>((hipStream_t)stream, order, strict != 0, base, alpha, m, val, col, row_ptr,
-                               rowblocks, nblocks, x, beta, y);
+    return launch_csrmv<float>((hipStream_t)stream, order, strict != 0, tile, base, alpha, m, val, col, row_ptr,
+                               blocks, nblocks, x, beta, y);
 }
 
 } // extern "C"

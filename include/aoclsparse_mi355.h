@@ -49,6 +49,7 @@ typedef struct aoclsparse_mi355_spmv_info_
     aoclsparse_int kernel; /* 0 none yet, 1 csr-adaptive stream, 2 merge-path */
     aoclsparse_int order; /* 0 scalar chain (kid 0), 1 4-lane (kid 1/2), 2 8-lane (kid 3) */
     aoclsparse_int row_blocks; /* workgroups per launch */
+    aoclsparse_int tile; /* non-zeros staged in LDS per workgroup */
     aoclsparse_int long_rows; /* rows longer than one LDS tile */
     aoclsparse_int max_row_nnz;
     aoclsparse_int device_resident; /* 1 once the CSR arrays are in HBM */
@@ -65,25 +66,30 @@ DLL_PUBLIC aoclsparse_status aoclsparse_mi355_get_trsv_levels(const aoclsparse_m
 DLL_PUBLIC aoclsparse_status aoclsparse_mi355_invalidate(aoclsparse_matrix A);
 
 /* ---- thin HIP C-ABI: device pointers, explicit stream ---------------------------------- */
-/* Row-block table for mi355_?csrmv: rowblocks must hold mi355_csrmv_plan_bound(m, nnz)
- * ints; built on the HOST from a host row_ptr.  Returns the number of blocks, <0 on error. */
+/* Row-block table for mi355_?csrmv, built on the HOST from a host row_ptr: nblocks+1 entries
+ * {first row, first non-zero (0-based)}, i.e. 2*(nblocks+1) ints; blocks_host must hold
+ * mi355_csrmv_plan_bound(m, nnz) ints.  tile = non-zeros staged in LDS per workgroup: 512, 1024 or 2048.
+ * Returns the number of blocks, <0 on error. */
 DLL_PUBLIC aoclsparse_int mi355_csrmv_plan_bound(aoclsparse_int m, aoclsparse_int nnz);
 DLL_PUBLIC aoclsparse_int mi355_csrmv_plan_host(aoclsparse_int        m,
                                                 aoclsparse_int        base,
+                                                aoclsparse_int        tile,
                                                 const aoclsparse_int *row_ptr_host,
-                                                aoclsparse_int       *rowblocks_host);
+                                                aoclsparse_int       *blocks_host);
 /* y = alpha*A*x + beta*y; order: 0 scalar chain, 1 4-lane, 2 8-lane (reference kid 0 / 1,2 / 3);
- * strict != 0 keeps the reference order for rows longer than one LDS tile too. */
+ * strict != 0 keeps the reference order for rows longer than one LDS tile too; tile must be the
+ * value the plan was built with; blocks is the DEVICE copy of the plan. */
 DLL_PUBLIC aoclsparse_status mi355_dcsrmv(void                 *stream,
                                           aoclsparse_int        order,
                                           aoclsparse_int        strict,
+                                          aoclsparse_int        tile,
                                           aoclsparse_int        base,
                                           double                alpha,
                                           aoclsparse_int        m,
                                           const double         *val,
                                           const aoclsparse_int *col,
                                           const aoclsparse_int *row_ptr,
-                                          const aoclsparse_int *rowblocks,
+                                          const aoclsparse_int *blocks,
                                           aoclsparse_int        nblocks,
                                           const double         *x,
                                           double                beta,
@@ -91,13 +97,14 @@ DLL_PUBLIC aoclsparse_status mi355_dcsrmv(void                 *stream,
 DLL_PUBLIC aoclsparse_status mi355_scsrmv(void                 *stream,
                                           aoclsparse_int        order,
                                           aoclsparse_int        strict,
+                                          aoclsparse_int        tile,
                                           aoclsparse_int        base,
                                           float                 alpha,
                                           aoclsparse_int        m,
                                           const float          *val,
                                           const aoclsparse_int *col,
                                           const aoclsparse_int *row_ptr,
-                                          const aoclsparse_int *rowblocks,
+                                          const aoclsparse_int *blocks,
                                           aoclsparse_int        nblocks,
                                           const float          *x,
                                           float                 beta,

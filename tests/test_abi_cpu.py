@@ -258,16 +258,24 @@ def test_argument_checks_that_precede_any_device_work():
 
 
 def test_row_block_planner_properties():
-    """mi355_csrmv_plan_host: blocks tile [0,m) with whole rows, <= TILE nnz unless a single long row."""
+    """mi355_csrmv_plan_host: blocks tile [0,m) with whole rows, <= tile nnz unless a single long row."""
     rp, ci, v = random_csr(5, 3000, 3000, lambda r, i: 5000 if i % 701 == 3 else r.integers(0, 30))
     m = 3000
-    rb = np.zeros(L.mi355_csrmv_plan_bound(m, len(v)), dtype=np.int32)
-    nb = L.mi355_csrmv_plan_host(m, 0, P._ptr(rp), P._ptr(rb))
-    assert nb > 0 and rb[0] == 0 and rb[nb] == m
-    rb = rb[: nb + 1]
-    assert np.all(np.diff(rb) > 0)
-    cnt = rp[rb[1:]].astype(np.int64) - rp[rb[:-1]]
-    rows = np.diff(rb)
-    assert np.all((cnt <= 2048) | (rows == 1)) and np.all(rows <= 512)
-    assert np.sum((cnt > 2048)) == 5
-    assert L.mi355_csrmv_plan_host(-1, 0, P._ptr(rp), P._ptr(rb)) < 0
+    for tile in (512, 1024, 2048):
+        blk = np.zeros(L.mi355_csrmv_plan_bound(m, len(v)), dtype=np.int32)
+        nb = L.mi355_csrmv_plan_host(m, 0, tile, P._ptr(rp), P._ptr(blk))
+        assert nb > 0
+        blk = blk[: 2 * (nb + 1)].reshape(nb + 1, 2)
+        rows, pos = blk[:, 0], blk[:, 1]
+        assert rows[0] == 0 and rows[nb] == m and pos[0] == 0 and pos[nb] == len(v)
+        assert np.all(np.diff(rows) > 0) and np.array_equal(pos, rp[rows])
+        cnt, nr = np.diff(pos), np.diff(rows)
+        assert np.all((cnt <= tile) | (nr == 1)) and np.all(nr <= min(512, tile // 2))
+        assert np.sum(cnt > tile) == 5
+    assert L.mi355_csrmv_plan_host(-1, 0, 1024, P._ptr(rp), P._ptr(blk)) < 0
+    assert L.mi355_csrmv_plan_host(m, 0, 256, P._ptr(rp), P._ptr(blk)) < 0
+    # base-1 row_ptr gives the same 0-based plan
+    b1 = np.zeros(L.mi355_csrmv_plan_bound(m, len(v)), dtype=np.int32)
+    rp1 = (rp + 1).astype(np.int32)
+    nb1 = L.mi355_csrmv_plan_host(m, 1, 2048, P._ptr(rp1), P._ptr(b1))
+    assert nb1 == nb and np.array_equal(b1[: 2 * (nb + 1)].reshape(nb + 1, 2), blk)

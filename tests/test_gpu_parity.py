@@ -120,7 +120,7 @@ def test_power_law_rows_with_long_rows_strict_and_auto():
     assert st == 0 and A.spmv_info().long_rows == 3
     so, yr = oracle.dcsrmv(-1, 0, 1.0, m, len(v), v, ci, rp, x, 0.0, y0)
     lens = np.diff(rp)
-    short = lens <= 2048
+    short = lens <= A.spmv_info().tile
     assert np.array_equal(y[short], yr[short])
     scale = abs_row_sums(rp, ci, v, x)
     c = 2 * np.ceil(np.log2(np.maximum(lens, 2))) + 4 + lens / 256.0  # tree + 256 partial chains
@@ -204,12 +204,20 @@ def test_raw_dcsrmv_host_and_device_pointers():
         torch.cuda.synchronize()
         assert np.array_equal(yd.cpu().numpy(), yr)
     # thin HIP C-ABI with an explicit host-built plan
-    rb = np.zeros(L.mi355_csrmv_plan_bound(m, len(v)), dtype=np.int32)
-    nb = L.mi355_csrmv_plan_host(m, 0, P._ptr(rp), P._ptr(rb))
-    rbd = dev(rb)
+    for tile in (512, 1024, 2048):
+        rb = np.zeros(L.mi355_csrmv_plan_bound(m, len(v)), dtype=np.int32)
+        nb = L.mi355_csrmv_plan_host(m, 0, tile, P._ptr(rp), P._ptr(rb))
+        rbd = dev(rb)
+        yd.copy_(torch.from_numpy(y0))
+        st = L.mi355_dcsrmv(None, 0, 0, tile, 0, 1.0, m, P._ptr(vd), P._ptr(cd), P._ptr(rd), P._ptr(rbd), nb,
+                            P._ptr(xd), 0.5, P._ptr(yd))
+        torch.cuda.synchronize()
+        assert st == 0 and np.array_equal(yd.cpu().numpy(), yr)
+    # arrays that are only 8-byte aligned take the scalar-load path of the kernel
+    vo, co = dev(np.concatenate([[0.0], v])), dev(np.concatenate([[0], ci]).astype(np.int32))
     yd.copy_(torch.from_numpy(y0))
-    st = L.mi355_dcsrmv(None, 0, 0, 0, 1.0, m, P._ptr(vd), P._ptr(cd), P._ptr(rd), P._ptr(rbd), nb,
-                        P._ptr(xd), 0.5, P._ptr(yd))
+    st = L.mi355_dcsrmv(None, 0, 0, 2048, 0, 1.0, m, vo.data_ptr() + 8, co.data_ptr() + 4, P._ptr(rd),
+                        P._ptr(rbd), nb, P._ptr(xd), 0.5, P._ptr(yd))
     torch.cuda.synchronize()
     assert st == 0 and np.array_equal(yd.cpu().numpy(), yr)
 
