@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--mm-cols", type=int, default=256)
     ap.add_argument("--no-csrmm", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-l100", action="store_true")
     args = ap.parse_args()
 
     import numpy as np
@@ -182,8 +183,6 @@ def main():
         # ---- parity of the timed configuration against the oracle (checker, not timed) ----
         import oracle
 
-        so, yref = oracle.dcsrmv(-1, 0, 1.0, m, nnz, val, col_ind, row_ptr, xh, 0.0, np.zeros(1),
-                                 nthreads=oracle.max_threads()) if False else (0, None)
         yd = y.cpu().numpy()
         so, yref = oracle.dcsrmv(-1, 0, 1.0, m, nnz, val, col_ind, row_ptr, xh, 0.0, np.zeros(m),
                                  nthreads=oracle.max_threads())
@@ -191,43 +190,58 @@ def main():
                          "max_abs_diff": float(np.max(np.abs(yd - yref)))}
 
         # ---- literal configs[1]: L100 (10k x 10k), launch-latency bound ----
-        m1, rp1, ci1, v1 = entry.laplace5(100)
-        A1 = pkg.Matrix(0, m1, m1, rp1, ci1, v1)
-        assert L.aoclsparse_set_mv_hint(A1.h, pkg.OP_NONE, descr.h, 1000) == 0 and L.aoclsparse_optimize(A1.h) == 0
-        x1 = torch.from_numpy(np.sin(0.01 * np.arange(m1))).to(device)
-        y1 = torch.zeros(m1, dtype=torch.float64, device=device)
-        for _ in range(50):
-            pkg.dmv(pkg.OP_NONE, 1.0, A1, descr, x1, 0.0, y1)
-        torch.cuda.synchronize()
-        reps = 2000
-        pkg.timer_start()
-        for _ in range(reps):
-            pkg.dmv(pkg.OP_NONE, 1.0, A1, descr, x1, 0.0, y1)
-        us = pkg.timer_stop() * 1e3 / reps
-        b1 = spmv_bytes(m1, m1, len(v1))
-        out["l100"] = {"workload": "BASELINE configs[1] literal: 10k x 10k 5-pt Laplacian, nnz=%d" % len(v1),
-                       "us_per_call": round(us, 3), "gflops": round(2.0 * len(v1) / us / 1e3, 3),
-                       "gbs": round(b1 / us / 1e3, 2), "algorithmic_bytes": b1,
-                       "note": "795 KB problem: bound by launch latency, not HBM"}
+        if not args.no_l100:
+            m1, rp1, ci1, v1 = entry.laplace5(100)
+            A1 = pkg.Matrix(0, m1, m1, rp1, ci1, v1)
+            assert L.aoclsparse_set_mv_hint(A1.h, pkg.OP_NONE, descr.h, 1000) == 0
+            assert L.aoclsparse_optimize(A1.h) == 0
+            x1 = torch.from_numpy(np.sin(0.01 * np.arange(m1))).to(device)
+            y1 = torch.zeros(m1, dtype=torch.float64, device=device)
+            for _ in range(50):
+                pkg.dmv(pkg.OP_NONE, 1.0, A1, descr, x1, 0.0, y1)
+            torch.cuda.synchronize()
+            reps = 2000
+            pkg.timer_start()
+            for _ in range(reps):
+                pkg.dmv(pkg.OP_NONE, 1.0, A1, descr, x1, 0.0, y1)
+            us = pkg.timer_stop() * 1e3 / reps
+            b1 = spmv_bytes(m1, m1, len(v1))
+            so, yr1 = oracle.dcsrmv(-1, 0, 1.0, m1, len(v1), v1, ci1, rp1, x1.cpu().numpy(), 0.0, np.zeros(m1))
+            out["l100"] = {"workload": "BASELINE configs[1] literal: 10k x 10k 5-pt Laplacian, nnz=%d" % len(v1),
+                           "us_per_call": round(us, 3), "gflops": round(2.0 * len(v1) / us / 1e3, 3),
+                           "gbs": round(b1 / us / 1e3, 2), "algorithmic_bytes": b1,
+                           "bit_exact": bool(np.array_equal(y1.cpu().numpy(), yr1)),
+                           "note": "795 KB problem: bound by launch latency, not HBM"}
 
         # ---- CPU baseline: the oracle on this box's host cores, bounded sample ----
         if not args.no_cpu:
-            nthr = oracle.max_threads()
+            # thread sweep on a bounded sample: the reference's OpenMP row split is not guaranteed to
+            # scale on a big host, so the best thread count found is the one reported
             yc = np.zeros(m)
-            t = time.perf_counter()
-            oracle.dcsrmv(-1, 0, 1.0, m, nnz, val, col_ind, row_ptr, xh, 0.0, yc, nthreads=nthr)
-            one = time.perf_counter() - t
-            passes = args.cpu_passes or max(3, min(200, int(10.0 / max(one, 1e-3))))
+            best = None
+            cand = sorted({1, 8, 16, 32, 64, oracle.max_threads()})
+            cand = [c for c in cand if c <= oracle.max_threads()]
+            for nthr in cand:
+                oracle.dcsrmv_inplace(-1, 0, 1.0, m, nnz, val, col_ind, row_ptr, xh, 0.0, yc, nthreads=nthr)
+                t = time.perf_counter()
+                for _ in range(3):
+                    oracle.dcsrmv_inplace(-1, 0, 1.0, m, nnz, val, col_ind, row_ptr, xh, 0.0, yc, nthreads=nthr)
+                one = (time.perf_counter() - t) / 3
+                if best is None or one < best[1]:
+                    best = (nthr, one)
+            nthr, one = best
+            passes = args.cpu_passes or max(5, min(300, int(8.0 / max(one, 1e-4))))
             t = time.perf_counter()
             for _ in range(passes):
-                oracle.dcsrmv(-1, 0, 1.0, m, nnz, val, col_ind, row_ptr, xh, 0.0, yc, nthreads=nthr)
+                oracle.dcsrmv_inplace(-1, 0, 1.0, m, nnz, val, col_ind, row_ptr, xh, 0.0, yc, nthreads=nthr)
             dt = (time.perf_counter() - t) / passes
             out["cpu_baseline"] = {"value": round(flops / dt / 1e9, 3), "unit": "GFLOP/s", "cores": nthr,
                                    "kind": "port",
                                    "sample": "%d passes of the same %dx%d-grid Laplacian SpMV with the oracle "
-                                             "(ref_csrmv_gn order, OpenMP static rows, %d threads; includes one "
-                                             "8*m-byte y copy per pass in the ctypes wrapper)" % (passes, g, g, nthr),
-                                   "gbs": round(abytes / dt / 1e9, 2), "host_cpus": os.cpu_count()}
+                                             "(ref_csrmv_gn order, OpenMP static rows; best of a %s-thread sweep "
+                                             "= %d threads)" % (passes, g, g, "/".join(map(str, cand)), nthr),
+                                   "gbs": round(abytes / dt / 1e9, 2), "host_cpus": os.cpu_count(),
+                                   "bit_exact_vs_gpu": bool(np.array_equal(yc, yd))}
         else:
             out["cpu_baseline"] = None
 

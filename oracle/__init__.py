@@ -71,6 +71,13 @@ def dcsrmv(kid, base, alpha, m, nnz, val, col, row, x, beta, y, nthreads=0):
     return st, y
 
 
+def dcsrmv_inplace(kid, base, alpha, m, nnz, val, col, row, x, beta, y, nthreads=1):
+    """Timing leg: arrays must already be contiguous numpy arrays of the right dtype; y is updated in
+    place (no copies inside the timed call)."""
+    return lib().orc_dcsrmv_omp(c_int(kid), c_int(base), c_dbl(alpha), c_i32(m), c_i32(nnz), _p(val), _p(col),
+                                _p(row), _p(x), c_dbl(beta), _p(y), c_int(nthreads))
+
+
 def dcsrmv_order(order, base, alpha, m, val, col, row, x, beta, y):
     """order in {'ref','lane4','lane8'}: one specific reference kernel."""
     fn = {"ref": "orc_dcsrmv_ref", "lane4": "orc_dcsrmv_lane4", "lane8": "orc_dcsrmv_lane8"}[order]
