@@ -146,6 +146,15 @@ def main():
     kernel_ms = kernel_ms_total / args.steps
     achieved = abytes / (kernel_ms * 1e-3) / 1e9
 
+    traffic, traffic_src = None, None
+    try:  # PMC counters cannot be read from inside the run: use the committed rocprofv3 measurement
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        if pmc.get("grid") == g:
+            traffic, traffic_src = pmc["traffic_bytes_per_launch"], "profiles/pmc_traffic.json"
+    except (OSError, ValueError, KeyError):
+        pass
+
     out = {
         "metric": "CSR SpMV fp64 GFLOP/s + achieved-HBM-GB/s %roofline",
         "value": round(gflops, 3),
@@ -173,7 +182,8 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": abytes,
             "kernel_ms": round(kernel_ms, 6),
         },
