@@ -126,21 +126,26 @@ struct SpmvPlan
     bool           valid = false;
 };
 
-// TRSV plan of one (triangle, op) pair: the row-form structure the kernels walk plus the level sets
-// (rows sorted by dependency level), see trsv_kernels.hip / trsv_api.cpp
+// TRSV plan of one (triangle, op) pair (trsv_api.cpp / trsv_kernels.hip): the strict triangle
+// re-laid out in LEVEL ORDER.  Position k holds row rowmap[k]; its entries sit at
+// [pptr[k], pptr[k+1]) of pind/pval already in the order the reference's chain consumes them, so
+// a level is one contiguous slab of HBM and every kernel walks forward.
+struct TrsvSegment
+{
+    aoclsparse_int l0, l1; // levels [l0, l1)
+    bool           narrow; // true: one single-workgroup launch loops over the levels
+};
 struct TrsvPlan
 {
-    aoclsparse_int              nlevels = -1;
+    aoclsparse_int              nlevels   = -1;
     aoclsparse_int              max_width = 0; // widest level
+    aoclsparse_int              launches  = 0; // kernel launches of the hybrid schedule
     std::vector<aoclsparse_int> level_ptr; // host, nlevels+1
-    DeviceBuffer                rowmap; // device, m rows in level order
-    // entries of row i: positions [rs[i], re[i]) of ind/val (positions and indices in `base`)
-    const aoclsparse_int *rs = nullptr, *re = nullptr, *ind = nullptr;
-    const void           *val = nullptr;
-    int                   base    = 0;
-    bool                  reverse = false; // walk a row right-to-left (L^T column sweep order)
-    DeviceBuffer          own_ptr, own_ind, own_val; // transposed strict triangle (lt / ut)
-    bool                  valid = false;
+    std::vector<TrsvSegment>    segments; // hybrid schedule
+    DeviceBuffer                rowmap, levels; // device: m rows in level order; level_ptr copy
+    DeviceBuffer                pptr, pind, pval; // device: level-ordered strict triangle; pind = positions
+    DeviceBuffer                xp; // device workspace: solution in level order (stream-ordered reuse)
+    bool                        valid = false;
 };
 
 // host CSR view; owned==true when the library allocated the arrays (clean copy / transpose)
@@ -181,8 +186,7 @@ struct _aoclsparse_matrix
     std::vector<mi355::Hint> hints; // newest first (csr_util.cpp:47-100 prepends)
 
     // device side; guarded by `guard` (executors take it shared, builders exclusive)
-    mi355::DeviceCsr dev_user, dev_opt, dev_trans;
-    mi355::DeviceBuffer dev_opt_idiag, dev_opt_iurow;
+    mi355::DeviceCsr dev_user, dev_trans;
     mi355::SpmvPlan  plan_user, plan_trans;
     mi355::TrsvPlan  trsv_plan[4]; // index: (upper?2:0) + (transpose?1:0)
     mi355::DeviceBuffer dev_diag; // diagonal values of the clean CSR (length min(m,n))
@@ -270,12 +274,13 @@ template <typename T>
 aoclsparse_status launch_strided_scatter(hipStream_t s, const T *src, aoclsparse_int n, T *dst,
                                          aoclsparse_int inc);
 
-// TRSV in row form (trsv_kernels.hip).  schedule 0: one launch per level; 1: sync-free single launch.
+// TRSV on the level-ordered layout (trsv_kernels.hip).
+// schedule 0: one launch per level; 1: hybrid (narrow level runs inside one workgroup); 2: sync-free.
+constexpr int TRSV_NARROW = 1024; // a level this narrow is solved by one workgroup (one row per lane)
 template <typename T>
-aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool reverse, bool unit, int base, T alpha,
-                              aoclsparse_int m, const aoclsparse_int *rs, const aoclsparse_int *re,
-                              const aoclsparse_int *ind, const T *val, const T *diag,
-                              const TrsvPlan &plan, const T *b, T *x, unsigned int *scratch);
+aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, aoclsparse_int m,
+                              const TrsvPlan &plan, const T *diag, const T *b, T *x,
+                              unsigned int *scratch);
 
 template <typename T>
 aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, T alpha,

@@ -700,7 +700,7 @@ aoclsparse_status aoclsparse_mi355_invalidate(aoclsparse_matrix A)
     if(!A)
         return aoclsparse_status_invalid_pointer;
     std::unique_lock<std::shared_mutex> w(A->guard);
-    A->dev_user.valid = A->dev_opt.valid = A->dev_trans.valid = false;
+    A->dev_user.valid = A->dev_trans.valid = false;
     A->plan_user.valid = A->plan_trans.valid = false;
     for(auto &p : A->trsv_plan)
         p.valid = false, p.nlevels = -1;

@@ -14,19 +14,79 @@ using namespace mi355;
 namespace mi355
 {
 
+// Host view of the strict triangle one (fill, op) variant walks: row i depends on the rows listed in
+// [ptr[i], ptr[i+1]) of ind (0-based), val in the order the reference's chain applies them.
+template <typename T>
+struct Triangle
+{
+    std::vector<aoclsparse_int> ptr, ind;
+    std::vector<T>              val;
+    bool                        descending = false; // solve order m-1..0 (dependencies point to larger rows)
+};
+
+template <typename T>
+static void build_triangle(const HostCsr &c, bool upper, bool transposed, Triangle<T> &t)
+{
+    const aoclsparse_int  m = c.m, b = c.base;
+    const aoclsparse_int *s = upper ? c.iurow : c.ptr; // strict triangle of row i: [s[i], e[i]) in base b
+    const aoclsparse_int *e = upper ? c.ptr + 1 : c.idiag;
+    const T              *v = static_cast<const T *>(c.val);
+    t.ptr.assign((size_t)m + 1, 0);
+    if(!transposed)
+    {
+        // L: rows ascending, entries left to right (ref_trsv_l); U: rows descending (ref_trsv_u)
+        for(aoclsparse_int i = 0; i < m; i++)
+            t.ptr[i + 1] = t.ptr[i] + (e[i] - s[i]);
+        t.ind.resize((size_t)std::max(t.ptr[m], 1));
+        t.val.resize((size_t)std::max(t.ptr[m], 1));
+        for(aoclsparse_int i = 0; i < m; i++)
+            for(aoclsparse_int p = s[i] - b, q = t.ptr[i]; p < e[i] - b; p++, q++)
+            {
+                t.ind[q] = c.ind[p] - b;
+                t.val[q] = v[p];
+            }
+        t.descending = upper;
+        return;
+    }
+    // transposed solves are column sweeps (ref_trsv_lth / _uth): x_c receives a_ic * x_i from every
+    // stored (i, c).  Row form on the transposed triangle: row c lists the i's.  L^T: sweep i = m-1..0,
+    // so x_c is updated in DESCENDING i; U^T: i = 0..m-1, ascending.
+    for(aoclsparse_int i = 0; i < m; i++)
+        for(aoclsparse_int p = s[i] - b; p < e[i] - b; p++)
+            t.ptr[c.ind[p] - b + 1]++;
+    for(aoclsparse_int j = 0; j < m; j++)
+        t.ptr[j + 1] += t.ptr[j];
+    t.ind.resize((size_t)std::max(t.ptr[m], 1));
+    t.val.resize((size_t)std::max(t.ptr[m], 1));
+    std::vector<aoclsparse_int> next(t.ptr.begin(), t.ptr.end() - 1);
+    const bool                  desc_fill = !upper; // L^T: fill from the largest source row down
+    for(aoclsparse_int ii = 0; ii < m; ii++)
+    {
+        const aoclsparse_int i = desc_fill ? m - 1 - ii : ii;
+        for(aoclsparse_int p = s[i] - b; p < e[i] - b; p++)
+        {
+            const aoclsparse_int q = next[c.ind[p] - b]++;
+            t.ind[q]               = i;
+            t.val[q]               = v[p];
+        }
+    }
+    t.descending = !upper; // L^T is upper triangular: x_c needs x_i, i > c
+}
+
 // level[i] = 1 + max level of the rows row i depends on; rows bucketed by level (counting sort,
-// ascending row index inside a level).
-static aoclsparse_status level_sets(aoclsparse_int m, const aoclsparse_int *rs, const aoclsparse_int *re,
-                                    const aoclsparse_int *ind, int base, bool descending, TrsvPlan &plan)
+// ascending row index inside a level); then the triangle is re-laid out in that order and the hybrid
+// schedule (runs of narrow levels vs. wide levels) is derived.
+template <typename T>
+static aoclsparse_status build_levels(aoclsparse_int m, const Triangle<T> &t, TrsvPlan &plan)
 {
     std::vector<aoclsparse_int> level((size_t)m, 0);
     aoclsparse_int              nlev = 0;
-    for(aoclsparse_int t = 0; t < m; t++)
+    for(aoclsparse_int k = 0; k < m; k++)
     {
-        const aoclsparse_int i  = descending ? m - 1 - t : t;
+        const aoclsparse_int i  = t.descending ? m - 1 - k : k;
         aoclsparse_int       lv = 0;
-        for(aoclsparse_int p = rs[i] - base; p < re[i] - base; p++)
-            lv = std::max(lv, level[ind[p] - base] + 1);
+        for(aoclsparse_int p = t.ptr[i]; p < t.ptr[i + 1]; p++)
+            lv = std::max(lv, level[t.ind[p]] + 1);
         level[i] = lv;
         nlev     = std::max(nlev, lv + 1);
     }
@@ -44,43 +104,56 @@ static aoclsparse_status level_sets(aoclsparse_int m, const aoclsparse_int *rs, 
     for(aoclsparse_int i = 0; i < m; i++)
         rowmap[next[level[i]]++] = i;
     plan.nlevels = nlev;
-    return plan.rowmap.upload(rowmap.data(), sizeof(aoclsparse_int) * (size_t)m, Runtime::get().stream());
+
+    // level-ordered copy of the triangle; dependencies are rewritten as POSITIONS in that order
+    std::vector<aoclsparse_int> pos((size_t)m);
+    for(aoclsparse_int k = 0; k < m; k++)
+        pos[rowmap[k]] = k;
+    std::vector<aoclsparse_int> pptr((size_t)m + 1, 0), pind(t.ind.size());
+    std::vector<T>              pval(t.val.size());
+    for(aoclsparse_int k = 0; k < m; k++)
+    {
+        const aoclsparse_int i = rowmap[k], len = t.ptr[i + 1] - t.ptr[i];
+        pptr[k + 1]            = pptr[k] + len;
+        for(aoclsparse_int j = 0; j < len; j++)
+            pind[pptr[k] + j] = pos[t.ind[t.ptr[i] + j]];
+        std::copy(t.val.begin() + t.ptr[i], t.val.begin() + t.ptr[i + 1], pval.begin() + pptr[k]);
+    }
+    // hybrid schedule
+    plan.segments.clear();
+    plan.launches = 0;
+    for(aoclsparse_int l = 0; l < nlev;)
+    {
+        const bool     narrow = plan.level_ptr[l + 1] - plan.level_ptr[l] <= TRSV_NARROW;
+        aoclsparse_int e      = l + 1;
+        while(e < nlev && ((plan.level_ptr[e + 1] - plan.level_ptr[e] <= TRSV_NARROW) == narrow))
+            e++;
+        // a lone narrow level between wide ones is cheaper as an ordinary launch
+        plan.segments.push_back({l, e, narrow && e - l > 1});
+        plan.launches += (narrow && e - l > 1) ? 1 : e - l;
+        l = e;
+    }
+    hipStream_t       st = Runtime::get().stream();
+    aoclsparse_status rc = plan.rowmap.upload(rowmap.data(), sizeof(aoclsparse_int) * (size_t)m, st);
+    if(rc == aoclsparse_status_success)
+        rc = plan.levels.upload(plan.level_ptr.data(), sizeof(aoclsparse_int) * ((size_t)nlev + 1), st);
+    if(rc == aoclsparse_status_success)
+        rc = plan.pptr.upload(pptr.data(), sizeof(aoclsparse_int) * ((size_t)m + 1), st);
+    if(rc == aoclsparse_status_success)
+        rc = plan.pind.upload(pind.data(), sizeof(aoclsparse_int) * pind.size(), st);
+    if(rc == aoclsparse_status_success)
+        rc = plan.pval.upload(pval.data(), sizeof(T) * pval.size(), st);
+    if(rc == aoclsparse_status_success)
+        rc = plan.xp.alloc(sizeof(T) * (size_t)std::max(m, 1));
+    return rc;
 }
 
 template <typename T>
-static aoclsparse_status build_transposed_triangle(const HostCsr &c, bool upper, TrsvPlan &plan,
-                                                   std::vector<aoclsparse_int> &tptr,
-                                                   std::vector<aoclsparse_int> &tind)
+static aoclsparse_status build_plan_t(const HostCsr &c, bool upper, bool transposed, TrsvPlan &plan)
 {
-    // strict triangle of the clean CSR, transposed by counting sort (stable: ascending source row)
-    const aoclsparse_int  m = c.m, b = c.base;
-    const aoclsparse_int *s = upper ? c.iurow : c.ptr; // positions in base b
-    const aoclsparse_int *e = upper ? c.ptr + 1 : c.idiag;
-    const T              *v = static_cast<const T *>(c.val);
-    tptr.assign((size_t)m + 1, 0);
-    for(aoclsparse_int i = 0; i < m; i++)
-        for(aoclsparse_int p = s[i] - b; p < e[i] - b; p++)
-            tptr[c.ind[p] - b + 1]++;
-    for(aoclsparse_int j = 0; j < m; j++)
-        tptr[j + 1] += tptr[j];
-    const aoclsparse_int tnnz = tptr[m];
-    tind.assign((size_t)std::max(tnnz, 1), 0);
-    std::vector<T>              tval((size_t)std::max(tnnz, 1));
-    std::vector<aoclsparse_int> next(tptr.begin(), tptr.end() - 1);
-    for(aoclsparse_int i = 0; i < m; i++)
-        for(aoclsparse_int p = s[i] - b; p < e[i] - b; p++)
-        {
-            const aoclsparse_int q = next[c.ind[p] - b]++;
-            tind[q]                = i;
-            tval[q]                = v[p];
-        }
-    hipStream_t       st = Runtime::get().stream();
-    aoclsparse_status rc = plan.own_ptr.upload(tptr.data(), sizeof(aoclsparse_int) * ((size_t)m + 1), st);
-    if(rc == aoclsparse_status_success)
-        rc = plan.own_ind.upload(tind.data(), sizeof(aoclsparse_int) * (size_t)tnnz, st);
-    if(rc == aoclsparse_status_success)
-        rc = plan.own_val.upload(tval.data(), sizeof(T) * (size_t)tnnz, st);
-    return rc;
+    Triangle<T> t;
+    build_triangle<T>(c, upper, transposed, t);
+    return build_levels<T>(c.m, t, plan);
 }
 
 aoclsparse_status ensure_trsv(aoclsparse_matrix A, bool upper, bool transposed)
@@ -97,62 +170,28 @@ aoclsparse_status ensure_trsv(aoclsparse_matrix A, bool upper, bool transposed)
     std::unique_lock<std::shared_mutex> w(A->guard);
     if(plan.valid)
         return aoclsparse_status_success;
-    const HostCsr &c  = *A->opt;
-    const size_t   vs = val_size(A->val_type);
-    const aoclsparse_int m = c.m;
-    Runtime       &rt = Runtime::get();
+    const HostCsr       &c  = *A->opt;
+    const size_t         vs = val_size(A->val_type);
+    const aoclsparse_int m  = c.m;
+    Runtime             &rt = Runtime::get();
     try
     {
-        if(!A->dev_opt.valid)
+        if(!A->dev_diag.ptr)
         {
-            st = upload_csr(c, vs, A->dev_opt);
-            if(st == aoclsparse_status_success)
-                st = A->dev_opt_idiag.upload(c.idiag, sizeof(aoclsparse_int) * (size_t)m, rt.stream());
-            if(st == aoclsparse_status_success)
-                st = A->dev_opt_iurow.upload(c.iurow, sizeof(aoclsparse_int) * (size_t)m, rt.stream());
-            if(st != aoclsparse_status_success)
-                return st;
             // diagonal values (only read for non-unit solves, which require a full diagonal)
             std::vector<char> dv(vs * (size_t)std::max(m, 1), 0);
             for(aoclsparse_int i = 0; i < std::min(c.m, c.n); i++)
                 if(c.iurow[i] == c.idiag[i] + 1)
-                    std::memcpy(&dv[vs * (size_t)i], static_cast<const char *>(c.val) + vs * (size_t)(c.idiag[i] - c.base),
-                                vs);
+                    std::memcpy(&dv[vs * (size_t)i],
+                                static_cast<const char *>(c.val) + vs * (size_t)(c.idiag[i] - c.base), vs);
             st = A->dev_diag.upload(dv.data(), vs * (size_t)m, rt.stream());
+            if(st == aoclsparse_status_success)
+                st = A->trsv_scratch.alloc(2 * sizeof(unsigned int));
             if(st != aoclsparse_status_success)
                 return st;
         }
-        st = A->trsv_scratch.alloc(2 * sizeof(unsigned int));
-        if(st != aoclsparse_status_success)
-            return st;
-        if(!transposed)
-        {
-            plan.rs   = upper ? A->dev_opt_iurow.as<aoclsparse_int>() : A->dev_opt.ptr.as<aoclsparse_int>();
-            plan.re   = upper ? A->dev_opt.ptr.as<aoclsparse_int>() + 1 : A->dev_opt_idiag.as<aoclsparse_int>();
-            plan.ind  = A->dev_opt.ind.as<aoclsparse_int>();
-            plan.val  = A->dev_opt.val.ptr;
-            plan.base = c.base;
-            plan.reverse = false;
-            // L: row i depends on smaller rows (ascending sweep); U: on larger rows (descending)
-            st = level_sets(m, upper ? c.iurow : c.ptr, upper ? c.ptr + 1 : c.idiag, c.ind, c.base, upper, plan);
-        }
-        else
-        {
-            std::vector<aoclsparse_int> tptr, tind;
-            st = A->val_type == aoclsparse_smat ? build_transposed_triangle<float>(c, upper, plan, tptr, tind)
-                                                : build_transposed_triangle<double>(c, upper, plan, tptr, tind);
-            if(st != aoclsparse_status_success)
-                return st;
-            plan.rs   = plan.own_ptr.as<aoclsparse_int>();
-            plan.re   = plan.own_ptr.as<aoclsparse_int>() + 1;
-            plan.ind  = plan.own_ind.as<aoclsparse_int>();
-            plan.val  = plan.own_val.ptr;
-            plan.base = 0;
-            // L^T is upper triangular: x_c needs x_i for i > c, applied in DESCENDING i
-            // (ref_trsv_lth sweeps i = m-1..0); U^T is lower triangular, ascending.
-            plan.reverse = !upper;
-            st = level_sets(m, tptr.data(), tptr.data() + 1, tind.data(), 0, !upper, plan);
-        }
+        st = A->val_type == aoclsparse_smat ? build_plan_t<float>(c, upper, transposed, plan)
+                                            : build_plan_t<double>(c, upper, transposed, plan);
         if(st != aoclsparse_status_success)
             return st;
         plan.valid = true;
@@ -232,9 +271,11 @@ aoclsparse_status trsv_t(aoclsparse_operation trans, const T alpha, aoclsparse_m
     std::shared_lock<std::shared_mutex> r(A->guard);
     const TrsvPlan                     &plan = A->trsv_plan[(upper ? 2 : 0) + (tr ? 1 : 0)];
 
-    // schedule: kid 0 = one launch per level, kid 1..3 = sync-free single launch;
-    // auto: per-level launches while the DAG is shallow, sync-free once launches would dominate
-    const int schedule = kid == 0 ? 0 : (kid > 0 ? 1 : (plan.nlevels <= 48 ? 0 : 1));
+    // schedule (all three give the same bits): kid 0 = one launch per level, kid 1/2 = hybrid (narrow
+    // level runs inside one workgroup), kid 3 = sync-free single launch.  auto: a shallow DAG of wide
+    // levels is cheapest as plain launches; otherwise sync-free, which measured fastest on both the
+    // 2-D Laplacian and the shell-like ILU(0) factors (profiles/r1).
+    const int schedule = kid == 0 ? 0 : (kid == 3 ? 2 : (kid > 0 ? 1 : (plan.nlevels <= 32 ? 0 : 2)));
 
     const bool bdev = rt.is_device_pointer(b), xdev = rt.is_device_pointer(x);
     const T   *db   = nullptr;
@@ -278,8 +319,7 @@ aoclsparse_status trsv_t(aoclsparse_operation trans, const T alpha, aoclsparse_m
             return st;
         dx = static_cast<T *>(tmp);
     }
-    st = launch_trsv<T>(rt.stream(), schedule, plan.reverse, unit, plan.base, alpha, m, plan.rs, plan.re,
-                        plan.ind, static_cast<const T *>(plan.val), A->dev_diag.as<T>(), plan, db, dx,
+    st = launch_trsv<T>(rt.stream(), schedule, unit, alpha, m, plan, A->dev_diag.as<T>(), db, dx,
                         A->trsv_scratch.as<unsigned int>());
     if(st != aoclsparse_status_success)
         return st;
@@ -301,11 +341,11 @@ aoclsparse_status trsv_t(aoclsparse_operation trans, const T alpha, aoclsparse_m
         if(st != aoclsparse_status_success)
             return st;
     }
-    if(!xdev || schedule == 1)
+    if(!xdev || schedule == 2)
     {
         // host semantics, and the sync-free path reports a (never expected) spin timeout
         MI355_HIP_TRY(hipStreamSynchronize(rt.stream()));
-        if(schedule == 1)
+        if(schedule == 2)
         {
             unsigned int words[2] = {0, 0};
             MI355_HIP_TRY(hipMemcpy(words, A->trsv_scratch.ptr, sizeof(words), hipMemcpyDeviceToHost));

@@ -3,26 +3,29 @@
 // The reference solves row by row on one core (level2/aoclsparse_trsv_kr.hpp:38-222); the
 // dependency DAG of the triangle is the only thing that orders rows, so rows of one LEVEL (all
 // dependencies in earlier levels) are solved concurrently here.  Every row is still reduced by ONE
-// lane as the reference's chain  xi = alpha*b_i; xi = fma(-a_ij, x_j, xi) in storage order; xi /= d
-// so x is bit-identical to ref_trsv_l / _u / _lth / _uth (kid 0) whatever the schedule.
+// lane as the reference's chain  xi = alpha*b_i; xi = fma(-a_ij, x_j, xi) in the reference's order;
+// xi /= d, so x is bit-identical to ref_trsv_l / _u / _lth / _uth (kid 0) whatever the schedule.
 //
-// All four variants run as a "row form" on a per-variant structure (trsv_api.cpp):
-//   L, U   : rows of the clean CSR, entries [rs[i], re[i]) left to right
-//   L^T    : rows of the transposed strict lower triangle, entries right to left (the column sweep
-//            of ref_trsv_lth updates x_c in DESCENDING i)
-//   U^T    : rows of the transposed strict upper triangle, left to right
+// Data layout (built once per (fill, op) by trsv_api.cpp): the strict triangle re-laid out in level
+// order.  Position k holds row rowmap[k]; its entries are [pptr[k], pptr[k+1]) of pind (POSITION of the
+// row depended on) / pval, stored in chain order (L: left to right; U: left to right; L^T: descending source row, as the column sweep of
+// ref_trsv_lth applies them; U^T: ascending).  A level is a contiguous slab, so per-level traffic is
+// streaming and the next level can be prefetched before the current one has been published.
 //
-// Two schedules:
-//   level launches (kid 0): one launch per level over rowmap[level_ptr[l] .. level_ptr[l+1]).
-//   sync-free      (kid>=1, auto for deep DAGs): ONE launch; rows are taken in level order and a
-//       lane polls x[col] until it is no longer the NOT-READY tag.  x doubles as the flag (one
-//       naturally aligned 8-byte agent-scope store per row), the data-tagged hand-off of
-//       MI355X_MICROARCH.md ("handoff-1to1"): relaxed agent-scope atomics = sc1 loads/stores that
-//       bypass the non-coherent per-CU L1.  Logical block ids come from an atomic ticket, so a block
-//       only ever waits on rows owned by blocks that already started: no dependence on dispatch order.
+// Schedules:
+//   0  one launch per level (rows of a level spread over the whole chip).
+//   1  hybrid (default): runs of NARROW levels (<= 1024 rows each) execute inside ONE 1024-lane
+//      workgroup that walks the levels with a workgroup barrier between them, exchanging x through an
+//      LDS ring, instead of paying a ~3.5 us kernel boundary per level; wide levels get a chip-wide
+//      launch each.
+//   2  sync-free: ONE launch; rows are taken in level order and a lane polls x[col] until it is no
+//      longer the NOT-READY tag.  x doubles as the flag (one naturally aligned 8-byte agent-scope store
+//      per row): the data-tagged hand-off of MI355X_MICROARCH.md ("handoff-1to1"); relaxed agent-scope
+//      atomics = sc1 loads/stores that bypass the non-coherent per-CU L1.  Logical block ids come from
+//      an atomic ticket, so a block only waits on rows of blocks that already started.
 //
-// Traffic per solve = algorithmic bytes (12 B per stored entry of the triangle + 4+4+8+8+8 B per
-// row); bound: latency of the dependency chain (levels x ~1 us), not HBM.
+// Algorithmic bytes per solve: 12 B per stored entry of the triangle + (4+4+8+8+8) B per row.  Bound:
+// the dependency chain (levels x per-level latency), not HBM, unless levels are tens of thousands wide.
 #include "internal.hpp"
 
 #include <hip/hip_runtime.h>
@@ -63,38 +66,173 @@ __global__ void trsv_fill_tag_kernel(T *x, aoclsparse_int m)
         reinterpret_cast<B *>(x)[i] = tag<T>::value;
 }
 
-// one level: rows rowmap[first .. first+count)
-template <typename T, bool REVERSE>
-__global__ void trsv_level_kernel(const aoclsparse_int *__restrict__ rowmap, aoclsparse_int first,
-                                  aoclsparse_int count, const aoclsparse_int *__restrict__ rs,
-                                  const aoclsparse_int *__restrict__ re,
-                                  const aoclsparse_int *__restrict__ ind, const T *__restrict__ val,
-                                  const T *__restrict__ diag, const T *__restrict__ b, T *x, T alpha,
-                                  int unit, int base)
+// All kernels work in LEVEL-ORDER ("position") space: xp[k] = x[rowmap[k]], and pind[] holds the
+// POSITION of the row an entry depends on, always smaller than the position of the row it belongs to.
+// Results are written twice: xp[k] (what later rows read) and x[rowmap[k]] (what the caller gets).
+
+// ---- schedule 0 / wide levels: positions [first, first+count) -------------------------------------------
+template <typename T>
+__global__ void trsv_level_kernel(aoclsparse_int first, aoclsparse_int count,
+                                  const aoclsparse_int *__restrict__ rowmap,
+                                  const aoclsparse_int *__restrict__ pptr,
+                                  const aoclsparse_int *__restrict__ pind, const T *__restrict__ pval,
+                                  const T *__restrict__ diag, const T *__restrict__ b, T *xp, T *x, T alpha,
+                                  int unit)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if(k >= count)
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= count)
         return;
-    const int i  = rowmap[first + k];
+    const int k  = first + t;
+    const int i  = rowmap[k];
     T         xi = alpha * b[i];
-    const int s = rs[i] - base, e = re[i] - base;
-    if constexpr(!REVERSE)
-        for(int p = s; p < e; p++)
-            xi = neg_fma(val[p], x[ind[p] - base], xi);
-    else
-        for(int p = e - 1; p >= s; p--)
-            xi = neg_fma(val[p], x[ind[p] - base], xi);
+    const int s = pptr[k], e = pptr[k + 1];
+    for(int p = s; p < e; p++)
+        xi = neg_fma(pval[p], xp[pind[p]], xi);
     if(!unit)
         xi /= diag[i];
-    x[i] = xi;
+    xp[k] = xi;
+    x[i]  = xi;
 }
 
-template <typename T, bool REVERSE>
+// ---- schedule 1, narrow runs: one workgroup walks levels [l0, l1), one lane per row ----------------------
+// The run's recent solutions live in an LDS ring of TRSV_RING positions, so a dependency on a recent
+// level costs an LDS read (~100 ns) instead of a global round trip, and the level barrier is a bare
+// s_barrier behind an LDS-only wait: global loads of the NEXT levels' matrix data (three-stage software
+// pipeline: level bounds -> row id / entry range -> rhs, diagonal, first TRSV_PF entries) stay in flight
+// across barriers.  Dependencies older than the ring are read from xp in global memory; this workgroup
+// wrote them itself (same CU, so its L1 is coherent for them) at least TRSV_RING-TRSV_NARROW positions
+// ago, and a full vmcnt(0) drain every TRSV_DRAIN levels bounds how long such a store can be pending.
+constexpr int TRSV_PF    = 8;
+constexpr int TRSV_RING  = 8192; // positions kept in LDS (64 KiB fp64)
+constexpr int TRSV_DRAIN = 4; // levels between full memory drains (< (RING-NARROW)/NARROW)
+
+template <typename T>
+__global__ __launch_bounds__(TRSV_NARROW) void trsv_multilevel_kernel(
+    aoclsparse_int l0, aoclsparse_int l1, const aoclsparse_int *__restrict__ levels,
+    const aoclsparse_int *__restrict__ rowmap, const aoclsparse_int *__restrict__ pptr,
+    const aoclsparse_int *__restrict__ pind, const T *__restrict__ pval, const T *__restrict__ diag,
+    const T *__restrict__ b, T *xp, T *x, T alpha, int unit)
+{
+    __shared__ T ring[TRSV_RING];
+    const int    tid = threadIdx.x;
+    auto stage_a = [&](int l) -> int {
+        if(l >= l1)
+            return -1;
+        const int first = levels[l], cnt = levels[l + 1] - first;
+        return tid < cnt ? first + tid : -1;
+    };
+    const int run_first = levels[l0]; // positions before this were solved by earlier launches
+    int       kA = stage_a(l0 + 2);
+    int       kB = stage_a(l0 + 1);
+    int       kC = stage_a(l0);
+    int       iB = -1, sB = 0, eB = 0;
+    if(kB >= 0)
+    {
+        iB = rowmap[kB];
+        sB = pptr[kB];
+        eB = pptr[kB + 1];
+    }
+    int iC = -1, sC = 0, eC = 0;
+    T   rhs = T(0), dg = T(1);
+    T   pv[TRSV_PF];
+    int pc[TRSV_PF];
+    if(kC >= 0)
+    {
+        iC  = rowmap[kC];
+        sC  = pptr[kC];
+        eC  = pptr[kC + 1];
+        rhs = alpha * b[iC];
+        if(!unit)
+            dg = diag[iC];
+#pragma unroll
+        for(int j = 0; j < TRSV_PF; j++)
+            if(sC + j < eC)
+            {
+                pv[j] = pval[sC + j];
+                pc[j] = pind[sC + j];
+            }
+    }
+    for(int l = l0; l < l1; l++)
+    {
+        const int lfirst = levels[l];
+        // positions >= lo are valid in the ring while this level is being written
+        const int lo = max(run_first, lfirst - TRSV_RING + TRSV_NARROW);
+        const int ci = iC, ck = kC, cs = sC, ce = eC;
+        T         xi = rhs;
+        const T   cd = dg;
+        T         cv[TRSV_PF];
+        int       cc[TRSV_PF];
+#pragma unroll
+        for(int j = 0; j < TRSV_PF; j++)
+        {
+            cv[j] = pv[j];
+            cc[j] = pc[j];
+        }
+        // ---- prefetch batch for the next levels (independent global loads) ----
+        const int kA2 = stage_a(l + 3);
+        int       iB2 = -1, sB2 = 0, eB2 = 0;
+        if(kA >= 0)
+        {
+            iB2 = rowmap[kA];
+            sB2 = pptr[kA];
+            eB2 = pptr[kA + 1];
+        }
+        kC = kB, iC = iB, sC = sB, eC = eB;
+        if(iC >= 0)
+        {
+            rhs = alpha * b[iC];
+            if(!unit)
+                dg = diag[iC];
+#pragma unroll
+            for(int j = 0; j < TRSV_PF; j++)
+                if(sC + j < eC)
+                {
+                    pv[j] = pval[sC + j];
+                    pc[j] = pind[sC + j];
+                }
+        }
+        kB = kA, iB = iB2, sB = sB2, eB = eB2;
+        kA = kA2;
+        // ---- solve my row of level l ----
+        if(ci >= 0)
+        {
+#pragma unroll
+            for(int j = 0; j < TRSV_PF; j++)
+                if(cs + j < ce)
+                {
+                    const int q  = cc[j];
+                    const T   xv = q >= lo ? ring[q & (TRSV_RING - 1)] : xp[q];
+                    xi           = neg_fma(cv[j], xv, xi);
+                }
+            for(int p = cs + TRSV_PF; p < ce; p++)
+            {
+                const int q  = pind[p];
+                const T   xv = q >= lo ? ring[q & (TRSV_RING - 1)] : xp[q];
+                xi           = neg_fma(pval[p], xv, xi);
+            }
+            if(!unit)
+                xi /= cd;
+            ring[ck & (TRSV_RING - 1)] = xi;
+            xp[ck]                     = xi;
+            x[ci]                      = xi;
+        }
+        if(((l - l0) % TRSV_DRAIN) == TRSV_DRAIN - 1)
+            __syncthreads(); // full drain: every xp store older than this is visible to the workgroup
+        else
+        {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); // LDS writes only
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        }
+    }
+}
+
+// ---- schedule 2: sync-free -------------------------------------------------------------------------------------
+template <typename T>
 __global__ __launch_bounds__(256) void trsv_syncfree_kernel(
-    const aoclsparse_int *__restrict__ rowmap, aoclsparse_int m, const aoclsparse_int *__restrict__ rs,
-    const aoclsparse_int *__restrict__ re, const aoclsparse_int *__restrict__ ind,
-    const T *__restrict__ val, const T *__restrict__ diag, const T *__restrict__ b, T *x, T alpha,
-    int unit, int base, unsigned int *ticket, unsigned int *timeout_flag)
+    aoclsparse_int m, const aoclsparse_int *__restrict__ rowmap, const aoclsparse_int *__restrict__ pptr,
+    const aoclsparse_int *__restrict__ pind, const T *__restrict__ pval, const T *__restrict__ diag,
+    const T *__restrict__ b, T *xp, T *x, T alpha, int unit, unsigned int *ticket, unsigned int *timeout_flag)
 {
     using B = typename tag<T>::bits;
     __shared__ unsigned int s_bid;
@@ -106,98 +244,98 @@ __global__ __launch_bounds__(256) void trsv_syncfree_kernel(
         return;
     const int i  = rowmap[k];
     T         xi = alpha * b[i];
-    const int s = rs[i] - base, e = re[i] - base;
-    int       p    = REVERSE ? e - 1 : s;
-    const int pend = REVERSE ? s - 1 : e;
-    const int step = REVERSE ? -1 : 1;
-    B        *xb   = reinterpret_cast<B *>(x);
+    int       p  = pptr[k];
+    const int pe = pptr[k + 1];
+    B        *xb = reinterpret_cast<B *>(xp);
     bool      done = false;
     // every lane keeps iterating until ITS row is published: a lane may wait on a row owned by
     // another lane of the same wavefront, so the store must happen inside the loop
     unsigned int spins = 0;
     while(!done)
     {
-        if(p != pend)
+        if(p != pe)
         {
-            const int c    = ind[p] - base;
-            const B   bits = __hip_atomic_load(&xb[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const B bits = __hip_atomic_load(&xb[pind[p]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if(bits != tag<T>::value)
             {
                 T xv;
                 __builtin_memcpy(&xv, &bits, sizeof(T));
-                xi = neg_fma(val[p], xv, xi);
-                p += step;
+                xi = neg_fma(pval[p], xv, xi);
+                p++;
                 spins = 0;
             }
             else if(++spins > (1u << 24))
             {
                 // never expected: bail out instead of hanging the GPU, host reports internal_error
                 atomicExch(timeout_flag, 1u);
-                p = pend;
+                p = pe;
             }
             else
                 __builtin_amdgcn_s_sleep(1);
         }
-        if(p == pend)
+        if(p == pe)
         {
             if(!unit)
                 xi /= diag[i];
             B out;
             __builtin_memcpy(&out, &xi, sizeof(T));
-            __hip_atomic_store(&xb[i], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&xb[k], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            x[i] = xi;
             done = true;
         }
     }
 }
 
 template <typename T>
-aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool reverse, bool unit, int base, T alpha,
-                              aoclsparse_int m, const aoclsparse_int *rs, const aoclsparse_int *re,
-                              const aoclsparse_int *ind, const T *val, const T *diag,
-                              const TrsvPlan &plan, const T *b, T *x, unsigned int *scratch)
+aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, aoclsparse_int m,
+                              const TrsvPlan &plan, const T *diag, const T *b, T *x, unsigned int *scratch)
 {
     if(m <= 0)
         return aoclsparse_status_success;
     const aoclsparse_int *rowmap = plan.rowmap.as<aoclsparse_int>();
+    const aoclsparse_int *pptr   = plan.pptr.as<aoclsparse_int>();
+    const aoclsparse_int *pind   = plan.pind.as<aoclsparse_int>();
+    const T              *pval   = plan.pval.as<T>();
+    T                    *xp     = plan.xp.as<T>();
+    auto level_launch = [&](aoclsparse_int l) {
+        const aoclsparse_int first = plan.level_ptr[l], count = plan.level_ptr[l + 1] - first;
+        const int            bs = count >= 256 ? 256 : 64;
+        hipLaunchKernelGGL((trsv_level_kernel<T>), dim3((count + bs - 1) / bs), dim3(bs), 0, s, first, count,
+                           rowmap, pptr, pind, pval, diag, b, xp, x, alpha, (int)unit);
+    };
     if(schedule == 0)
     {
         for(aoclsparse_int l = 0; l < plan.nlevels; l++)
-        {
-            const aoclsparse_int first = plan.level_ptr[l], count = plan.level_ptr[l + 1] - first;
-            const int            bs = count >= 256 ? 256 : 64;
-            if(reverse)
-                hipLaunchKernelGGL((trsv_level_kernel<T, true>), dim3((count + bs - 1) / bs), dim3(bs), 0, s,
-                                   rowmap, first, count, rs, re, ind, val, diag, b, x, alpha, (int)unit, base);
-            else
-                hipLaunchKernelGGL((trsv_level_kernel<T, false>), dim3((count + bs - 1) / bs), dim3(bs), 0,
-                                   s, rowmap, first, count, rs, re, ind, val, diag, b, x, alpha, (int)unit,
-                                   base);
-        }
-        MI355_HIP_TRY(hipGetLastError());
-        return aoclsparse_status_success;
+            level_launch(l);
     }
-    // sync-free: tag x, reset ticket + timeout word, one launch
-    MI355_HIP_TRY(hipMemsetAsync(scratch, 0, 2 * sizeof(unsigned int), s));
-    hipLaunchKernelGGL((trsv_fill_tag_kernel<T>), dim3((m + 255) / 256), dim3(256), 0, s, x, m);
-    const int bs = 256;
-    if(reverse)
-        hipLaunchKernelGGL((trsv_syncfree_kernel<T, true>), dim3((m + bs - 1) / bs), dim3(bs), 0, s, rowmap,
-                           m, rs, re, ind, val, diag, b, x, alpha, (int)unit, base, scratch, scratch + 1);
+    else if(schedule == 1)
+    {
+        for(const TrsvSegment &g : plan.segments)
+        {
+            if(g.narrow)
+                hipLaunchKernelGGL((trsv_multilevel_kernel<T>), dim3(1), dim3(TRSV_NARROW), 0, s, g.l0, g.l1,
+                                   plan.levels.as<aoclsparse_int>(), rowmap, pptr, pind, pval, diag, b, xp, x,
+                                   alpha, (int)unit);
+            else
+                for(aoclsparse_int l = g.l0; l < g.l1; l++)
+                    level_launch(l);
+        }
+    }
     else
-        hipLaunchKernelGGL((trsv_syncfree_kernel<T, false>), dim3((m + bs - 1) / bs), dim3(bs), 0, s,
-                           rowmap, m, rs, re, ind, val, diag, b, x, alpha, (int)unit, base, scratch,
-                           scratch + 1);
+    {
+        // sync-free: tag xp, reset ticket + timeout word, one launch
+        MI355_HIP_TRY(hipMemsetAsync(scratch, 0, 2 * sizeof(unsigned int), s));
+        hipLaunchKernelGGL((trsv_fill_tag_kernel<T>), dim3((m + 255) / 256), dim3(256), 0, s, xp, m);
+        hipLaunchKernelGGL((trsv_syncfree_kernel<T>), dim3((m + 255) / 256), dim3(256), 0, s, m, rowmap, pptr,
+                           pind, pval, diag, b, xp, x, alpha, (int)unit, scratch, scratch + 1);
+    }
     MI355_HIP_TRY(hipGetLastError());
     return aoclsparse_status_success;
 }
 
-template aoclsparse_status launch_trsv<double>(hipStream_t, int, bool, bool, int, double, aoclsparse_int,
-                                               const aoclsparse_int *, const aoclsparse_int *,
-                                               const aoclsparse_int *, const double *, const double *,
-                                               const TrsvPlan &, const double *, double *, unsigned int *);
-template aoclsparse_status launch_trsv<float>(hipStream_t, int, bool, bool, int, float, aoclsparse_int,
-                                              const aoclsparse_int *, const aoclsparse_int *,
-                                              const aoclsparse_int *, const float *, const float *,
-                                              const TrsvPlan &, const float *, float *, unsigned int *);
+template aoclsparse_status launch_trsv<double>(hipStream_t, int, bool, double, aoclsparse_int, const TrsvPlan &,
+                                               const double *, const double *, double *, unsigned int *);
+template aoclsparse_status launch_trsv<float>(hipStream_t, int, bool, float, aoclsparse_int, const TrsvPlan &,
+                                              const float *, const float *, float *, unsigned int *);
 
 } // namespace mi355

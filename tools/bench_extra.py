@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the driver's bench line): SuiteSparse stand-ins (BASELINE config 3),
+csrmm layouts (config 4), level-scheduled TRSV on ILU(0) factors (config 5), and the PCIe-inclusive
+host-pointer SpMV rate.  Every result is checked against the CPU oracle.  One JSON object per line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import __graft_entry__ as entry  # noqa: E402
+import oracle  # noqa: E402
+import standins  # noqa: E402
+from bench import csrmm_bytes, spmv_bytes  # noqa: E402
+
+pkg = entry.load_package()
+L = pkg.lib()
+ap = argparse.ArgumentParser()
+ap.add_argument("--what", default="spmv,csrmm,trsv,pcie")
+ap.add_argument("--small", action="store_true", help="skip the two 50-120 M nnz stand-ins")
+args = ap.parse_args()
+what = set(args.what.split(","))
+dev = torch.device("cuda", 0)
+
+
+def emit(**kw):
+    print(json.dumps(kw), flush=True)
+
+
+def time_calls(fn, reps, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    pkg.timer_start()
+    for _ in range(reps):
+        fn()
+    return pkg.timer_stop() / reps
+
+
+d0 = pkg.Descr()
+
+if "spmv" in what:
+    L.aoclsparse_mi355_set_pointer_mode(pkg.PTR_DEVICE)
+    names = ["circuit-like", "web-like"] + ([] if args.small else ["shell-like", "flan-like"])
+    for name in names:
+        m, rp, ci, v = standins.ALL[name]()
+        nnz = len(v)
+        A = pkg.Matrix(0, m, m, rp, ci, v)
+        assert L.aoclsparse_set_mv_hint(A.h, pkg.OP_NONE, d0.h, 100) == 0 and L.aoclsparse_optimize(A.h) == 0
+        info = A.spmv_info()
+        xh = np.random.default_rng(1).uniform(-1, 1, m)
+        x = torch.from_numpy(xh).to(dev)
+        y = torch.zeros(m, dtype=torch.float64, device=dev)
+        ms = time_calls(lambda: pkg.dmv(pkg.OP_NONE, 1.0, A, d0, x, 0.0, y), 50)
+        so, yr = oracle.dcsrmv(-1, 0, 1.0, m, nnz, v, ci, rp, xh, 0.0, np.zeros(m), nthreads=oracle.max_threads())
+        yd = y.cpu().numpy()
+        lens = np.diff(rp)
+        short = lens <= info.tile
+        b = spmv_bytes(m, m, nnz)
+        emit(kind="spmv", matrix=name + " (stand-in)", m=m, nnz=nnz, order=info.order, tile=info.tile,
+             row_blocks=info.row_blocks, long_rows=info.long_rows, max_row=int(lens.max()), ms=round(ms, 5),
+             gflops=round(2 * nnz / ms / 1e6, 2), gbs=round(b / ms / 1e6, 1), frac_of_8TBs=round(b / ms / 1e6 / 8000, 4),
+             bit_exact_rows_within_tile=bool(np.array_equal(yd[short], yr[short])),
+             max_abs_diff_long_rows=float(np.max(np.abs(yd - yr))))
+        del A, x, y
+
+if "csrmm" in what:
+    L.aoclsparse_mi355_set_pointer_mode(pkg.PTR_DEVICE)
+    g = 1000
+    m, rp, ci, v = entry.laplace5(g)
+    nnz = len(v)
+    A = pkg.Matrix(0, m, m, rp, ci, v)
+    assert L.aoclsparse_set_mm_hint(A.h, pkg.OP_NONE, d0.h, 10) == 0 and L.aoclsparse_optimize(A.h) == 0
+    for n in (256, 32):
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(777)
+        B = torch.rand(m * n, dtype=torch.float64, device=dev, generator=gen) * 2 - 1
+        C = torch.zeros(m * n, dtype=torch.float64, device=dev)
+        for order, ldb, ldc, nm in ((pkg.ORDER_ROW, n, n, "row-major"), (pkg.ORDER_COLUMN, m, m, "column-major")):
+            for beta in (0.0, -2.0):
+                ms = time_calls(lambda: pkg.dcsrmm(pkg.OP_NONE, 1.0, A, d0, order, B, n, ldb, beta, C, ldc), 10, 2)
+                b = csrmm_bytes(m, m, nnz, n, beta != 0.0)
+                emit(kind="csrmm", A="5-pt Laplacian grid 1000^2 (nnz=%d)" % nnz, n=n, layout=nm, beta=beta,
+                     ms=round(ms, 4), gflops=round(2.0 * nnz * n / ms / 1e6, 1), gbs=round(b / ms / 1e6, 1),
+                     frac_of_8TBs=round(b / ms / 1e6 / 8000, 4))
+        # parity sample: 64 columns' worth against the oracle (col-major, beta = 0)
+        C.zero_()
+        pkg.dcsrmm(pkg.OP_NONE, 1.0, A, d0, pkg.ORDER_COLUMN, B, n, m, 0.0, C, m)
+        torch.cuda.synchronize()
+        ns = min(n, 8)
+        so, Cr = oracle.dcsrmm("col", 1.0, 0, v, ci, rp, m, B[: ns * m].cpu().numpy(), ns, m, 0.0, np.zeros(ns * m), m)
+        emit(kind="csrmm-parity", n=n, cols_checked=ns, bit_exact=bool(np.array_equal(C[: ns * m].cpu().numpy(), Cr)))
+        del B, C
+
+if "trsv" in what:
+    L.aoclsparse_mi355_set_pointer_mode(pkg.PTR_DEVICE)
+    cases = [("ILU(0) of 5-pt Laplacian grid 1000^2", lambda: entry.laplace5(1000))]
+    if not args.small:
+        cases.append(("ILU(0) of shell-like stand-in (af_shell10-like)", standins.shell_like))
+    for title, gen in cases:
+        m, rp, ci, v = gen()
+        t = time.time()
+        st, lu, dg = oracle.dilu0(m, 0, rp, ci, v)
+        t_ilu = time.time() - t
+        assert st == 0, st
+        A = pkg.Matrix(0, m, m, rp, ci, lu)
+        dl = pkg.Descr(mtype=pkg.TYPE_TRIANGULAR, fill=pkg.FILL_LOWER, diag=pkg.DIAG_UNIT)
+        t = time.time()
+        assert L.aoclsparse_set_sv_hint(A.h, pkg.OP_NONE, dl.h, 100) == 0 and L.aoclsparse_optimize(A.h) == 0
+        t_opt = time.time() - t
+        lv = A.trsv_levels(pkg.FILL_LOWER)
+        o = oracle.dcsr_optimize(m, m, len(lu), 0, rp, ci, lu)
+        nnz_l = int(np.sum(o["idiag"] - rp[:-1]))
+        bh = np.random.default_rng(2).uniform(-1, 1, m)
+        t = time.time()
+        st, xr = oracle.dtrsv("l", 1.0, m, 0, lu, ci, rp, o["idiag"], bh, True)
+        t_cpu = time.time() - t
+        bdev = torch.from_numpy(bh).to(dev)
+        xdev = torch.zeros(m, dtype=torch.float64, device=dev)
+        abytes = (m + 1 + nnz_l) * 4 + (2 * m + nnz_l) * 8
+        for kid, nm in ((0, "one launch per level"), (1, "hybrid: narrow level runs in one workgroup"),
+                        (3, "sync-free single launch")):
+            if kid != 1 and lv > 100000:
+                continue  # hundreds of thousands of launches / hops: minutes
+            reps = 3 if kid != 1 and lv > 500 else 10
+            ms = time_calls(lambda: pkg.dtrsv(pkg.OP_NONE, 1.0, A, dl, bdev, xdev, kid=kid), reps, 1)
+            torch.cuda.synchronize()
+            xg = xdev.cpu().numpy()
+            emit(kind="trsv", system=title, m=m, nnz_strict_lower=nnz_l, levels=lv, schedule=nm, ms=round(ms, 4),
+                 gflops=round((2.0 * nnz_l + m) / ms / 1e6, 2), gbs=round(abytes / ms / 1e6, 1),
+                 cpu_serial_ms=round(t_cpu * 1e3, 2), bit_exact_vs_cpu=bool(np.array_equal(xg, xr)),
+                 analysis_s=round(t_opt, 2), ilu0_cpu_s=round(t_ilu, 2))
+        del A
+
+if "pcie" in what:
+    L.aoclsparse_mi355_set_pointer_mode(pkg.PTR_AUTO)
+    g = 4096
+    m, rp, ci, v = entry.laplace5(g)
+    nnz = len(v)
+    A = pkg.Matrix(0, m, m, rp, ci, v)
+    assert L.aoclsparse_set_mv_hint(A.h, pkg.OP_NONE, d0.h, 10) == 0 and L.aoclsparse_optimize(A.h) == 0
+    xh = np.sin(0.01 * np.arange(m))
+    yh = np.zeros(m)
+    pkg.dmv(pkg.OP_NONE, 1.0, A, d0, xh, 0.0, yh)
+    t = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        pkg.dmv(pkg.OP_NONE, 1.0, A, d0, xh, 0.0, yh)
+    dt = (time.perf_counter() - t) / reps
+    emit(kind="pcie-inclusive", workload="aoclsparse_dmv, HOST x and y (pageable), grid 4096^2 Laplacian resident in HBM",
+         ms=round(dt * 1e3, 3), gflops=round(2.0 * nnz / dt / 1e9, 2),
+         note="x H2D + y D2H of 134 MB each per call dominate; kernel itself ~0.25 ms")
+    # one-shot raw API with everything on the host: the matrix crosses PCIe every call
+    yh2 = np.zeros(m)
+    pkg.dcsrmv(pkg.OP_NONE, 1.0, m, m, nnz, v, ci, rp, d0, xh, 0.0, yh2)
+    t = time.perf_counter()
+    pkg.dcsrmv(pkg.OP_NONE, 1.0, m, m, nnz, v, ci, rp, d0, xh, 0.0, yh2)
+    dt = time.perf_counter() - t
+    emit(kind="pcie-inclusive", workload="aoclsparse_dcsrmv, ALL arrays on the host (matrix re-sent every call)",
+         ms=round(dt * 1e3, 3), gflops=round(2.0 * nnz / dt / 1e9, 2), equal_to_handle_path=bool(np.array_equal(yh, yh2)))

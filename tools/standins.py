@@ -1,0 +1,96 @@
+"""Seeded structural stand-ins for the SuiteSparse matrices BASELINE.json config 3 names (the .mtx files
+are neither in the reference tree nor reachable from the GPU box: SURVEY.md section 8d).  numpy only,
+vectorised; every generator returns (m, row_ptr, col_ind, val) with 0-based sorted, duplicate-free rows
+and a full diagonal.  Results obtained on them are labelled "stand-in" wherever they are reported."""
+import numpy as np
+
+
+def _to_csr(n, rows, cols, seed):
+    key = np.unique(rows.astype(np.int64) * n + cols.astype(np.int64))
+    r = (key // n).astype(np.int64)
+    c = (key % n).astype(np.int32)
+    row_ptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(row_ptr, r + 1, 1)
+    row_ptr = np.cumsum(row_ptr)
+    rng = np.random.default_rng(seed)
+    val = rng.uniform(-1.0, 1.0, size=len(c))
+    val[c == r] = rng.uniform(4.0, 8.0, size=int(np.sum(c == r)))
+    return n, row_ptr.astype(np.int32), c, val
+
+
+def _powerlaw_lengths(rng, n, mean, maxlen, alpha):
+    ln = (rng.pareto(alpha, size=n) + 1.0)
+    ln = ln * (mean / ln.mean())
+    return np.clip(np.rint(ln), 1, maxlen).astype(np.int64)
+
+
+def circuit_like(n=170998, seed=101):
+    """scircuit-like: n=170,998, ~5.6 nnz/row, power-law rows (max ~353), 20 % near-diagonal."""
+    rng = np.random.default_rng(seed)
+    ln = _powerlaw_lengths(rng, n, 4.7, 353, 1.6)
+    ln[rng.integers(0, n, 3)] = 353
+    rows = np.repeat(np.arange(n), ln)
+    near = rng.random(len(rows)) < 0.2
+    cols = rng.integers(0, n, len(rows))
+    cols[near] = np.clip(rows[near] + rng.integers(-30, 31, int(near.sum())), 0, n - 1)
+    rows = np.concatenate([rows, np.arange(n)])
+    cols = np.concatenate([cols, np.arange(n)])
+    return _to_csr(n, rows, cols, seed + 1)
+
+
+def web_like(n=1000005, seed=202):
+    """webbase-1M-like: n=1,000,005, ~3.1 nnz/row, a few rows of ~4,700, Zipf-distributed columns."""
+    rng = np.random.default_rng(seed)
+    ln = _powerlaw_lengths(rng, n, 2.2, 4700, 1.3)
+    ln[rng.integers(0, n, 4)] = 4700
+    rows = np.repeat(np.arange(n), ln)
+    cols = (rng.zipf(1.3, len(rows)) - 1) % n
+    mix = rng.random(len(rows)) < 0.5
+    cols[mix] = rng.integers(0, n, int(mix.sum()))
+    rows = np.concatenate([rows, np.arange(n)])
+    cols = np.concatenate([cols, np.arange(n)])
+    return _to_csr(n, rows, cols, seed + 1)
+
+
+def shell_like(n=1508065, seed=303, width=600):
+    """af_shell10-like: n=1,508,065, 5 dofs per node of a structured shell mesh `width` nodes wide; node
+    (i, j) couples to (i, j+-1), (i+-1, j) and the (i-1, j-1) / (i+1, j+1) diagonal: 7 dense 5x5 blocks,
+    ~35 nnz/row, very uniform.  No coupling across the ends of a mesh row."""
+    nb = n // 5
+    n = nb * 5
+    bi = np.arange(nb, dtype=np.int64)
+    j = bi % width
+    offs = np.array([-width - 1, -width, -1, 0, 1, width, width + 1], dtype=np.int64)
+    dj = np.array([-1, 0, -1, 0, 1, 0, 1], dtype=np.int64)
+    bc = bi[:, None] + offs[None, :]
+    jj = j[:, None] + dj[None, :]
+    ok = (bc >= 0) & (bc < nb) & (jj >= 0) & (jj < width)
+    brow = np.repeat(bi, ok.sum(axis=1))
+    bcol = bc[ok]
+    rows = (brow[:, None, None] * 5 + np.arange(5)[None, :, None] + np.zeros((1, 1, 5), np.int64)).ravel()
+    cols = (bcol[:, None, None] * 5 + np.zeros((1, 5, 1), np.int64) + np.arange(5)[None, None, :]).ravel()
+    return _to_csr(n, rows, cols, seed)
+
+
+def flan_like(nx=81, ny=80, nz=80, seed=404):
+    """Flan_1565-like: 3-D 27-point stencil with 3 dofs per node, n = 3*nx*ny*nz = 1,555,200, ~75/row."""
+    nodes = nx * ny * nz
+    idx = np.arange(nodes, dtype=np.int64)
+    ix, iy, iz = idx // (ny * nz), (idx // nz) % ny, idx % nz
+    rows_l, cols_l = [], []
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dz in (-1, 0, 1):
+                ok = ((ix + dx >= 0) & (ix + dx < nx) & (iy + dy >= 0) & (iy + dy < ny)
+                      & (iz + dz >= 0) & (iz + dz < nz))
+                nb = (ix + dx) * (ny * nz) + (iy + dy) * nz + (iz + dz)
+                rows_l.append(idx[ok])
+                cols_l.append(nb[ok])
+    nr = np.concatenate(rows_l)
+    nc = np.concatenate(cols_l)
+    rows = (nr[:, None, None] * 3 + np.arange(3)[None, :, None] + np.zeros((1, 1, 3), np.int64)).ravel()
+    cols = (nc[:, None, None] * 3 + np.zeros((1, 3, 1), np.int64) + np.arange(3)[None, None, :]).ravel()
+    return _to_csr(3 * nodes, rows, cols, seed)
+
+
+ALL = {"circuit-like": circuit_like, "web-like": web_like, "shell-like": shell_like, "flan-like": flan_like}
