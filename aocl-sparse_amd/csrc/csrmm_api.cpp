@@ -105,8 +105,8 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
         st = launch_scale_dense<T>(rt.stream(), order, static_cast<T *>(dC), m_c, n, ldc, beta);
         return st == aoclsparse_status_success ? finish() : st;
     }
-    if(descr->type != aoclsparse_matrix_type_general)
-        return aoclsparse_status_not_implemented; // symmetric csrmm: next wave
+    if(descr->type == aoclsparse_matrix_type_hermitian)
+        return aoclsparse_status_not_implemented; // real types: hermitian csrmm is not offered
 
     if(!bdev)
     {
@@ -116,7 +116,19 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
     }
     DeviceCsr *d = nullptr;
     SpmvPlan  *p = nullptr;
-    st           = ensure_spmv(const_cast<aoclsparse_matrix>(A), tr, d, p);
+    if(descr->type == aoclsparse_matrix_type_symmetric)
+    {
+        // csrmm.hpp:667-718 runs serial *_sym_ref kernels on one triangle; here the symmetric
+        // operator is materialised once (derived.cpp) and the general kernels are used
+        Derived *dv = nullptr;
+        st = ensure_derived(const_cast<aoclsparse_matrix>(A), descr->type, descr->fill_mode, descr->diag_type,
+                            false, dv);
+        if(st != aoclsparse_status_success)
+            return st;
+        d = &dv->dev;
+    }
+    else
+        st = ensure_spmv(const_cast<aoclsparse_matrix>(A), tr, d, p);
     if(st != aoclsparse_status_success)
         return st;
     {

@@ -9,8 +9,8 @@
 // stencil would give an MFMA are >90 % zeros, so reshaping to GEMM only adds traffic.
 //   row-major  : one lane owns 2 adjacent columns of one C row (16-B loads/stores); the B rows a
 //                sparse row touches are contiguous 8*n-byte streams; val/col are wave-uniform loads.
-//   column-major: one lane owns one row and a tile of 16 columns held in registers, so A is re-read
-//                n/16 times (from L2 once the first pass has pulled it in) and C is written coalesced.
+//   column-major: one lane owns one row, keeps its first 8 entries in registers and sweeps 64
+//                columns, so A is read n/64 times and every B / C access is coalesced across rows.
 // Algorithmic bytes: (m+1+nnz)*4 + nnz*8 + 8*n*(k + m*(1+[beta!=0]))  (BASELINE.md section 2).
 #include "internal.hpp"
 
@@ -88,7 +88,58 @@ __global__ __launch_bounds__(256) void csrmm_row_kernel(int base, T alpha, aocls
     }
 }
 
-constexpr int CM_TILE = 16; // columns per lane in the column-major kernel
+// row-major, n >= 128: one WAVEFRONT per (row, 128-column chunk).  The row index is wave-uniform
+// (readfirstlane), so row_ptr / val / col_ind come through the scalar cache and the vector memory
+// pipe carries only the B rows (16 B per lane) and the C row.  Four non-zeros are issued per step.
+template <typename T>
+__global__ __launch_bounds__(256) void csrmm_row_wave_kernel(int base, T alpha, aoclsparse_int m,
+                                                             const T *__restrict__ val,
+                                                             const aoclsparse_int *__restrict__ col,
+                                                             const aoclsparse_int *__restrict__ row_ptr,
+                                                             const T *__restrict__ B, aoclsparse_int n,
+                                                             aoclsparse_int ldb, T beta, T *__restrict__ C,
+                                                             aoclsparse_int ldc)
+{
+    using V       = typename vec2<T>::type;
+    const int w   = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i   = blockIdx.x * 4 + w;
+    const int j   = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
+    if(i >= m || j >= n)
+        return;
+    const int s = row_ptr[i] - base, e = row_ptr[i + 1] - base;
+    T         a0 = T(0), a1 = T(0);
+    const T  *Bj = B + j;
+    int       p  = s;
+    for(; p + 4 <= e; p += 4)
+    {
+        const T v0 = val[p], v1 = val[p + 1], v2 = val[p + 2], v3 = val[p + 3];
+        const V b0 = *reinterpret_cast<const V *>(Bj + (size_t)(col[p] - base) * ldb);
+        const V b1 = *reinterpret_cast<const V *>(Bj + (size_t)(col[p + 1] - base) * ldb);
+        const V b2 = *reinterpret_cast<const V *>(Bj + (size_t)(col[p + 2] - base) * ldb);
+        const V b3 = *reinterpret_cast<const V *>(Bj + (size_t)(col[p + 3] - base) * ldb);
+        a0 = mm_fma(v0, b0.x, a0), a1 = mm_fma(v0, b0.y, a1);
+        a0 = mm_fma(v1, b1.x, a0), a1 = mm_fma(v1, b1.y, a1);
+        a0 = mm_fma(v2, b2.x, a0), a1 = mm_fma(v2, b2.y, a1);
+        a0 = mm_fma(v3, b3.x, a0), a1 = mm_fma(v3, b3.y, a1);
+    }
+    for(; p < e; p++)
+    {
+        const T v0 = val[p];
+        const V b0 = *reinterpret_cast<const V *>(Bj + (size_t)(col[p] - base) * ldb);
+        a0 = mm_fma(v0, b0.x, a0), a1 = mm_fma(v0, b0.y, a1);
+    }
+    V *cp = reinterpret_cast<V *>(C + (size_t)i * ldc + j);
+    V  c  = *cp;
+    c.x   = mm_fma(beta, c.x, alpha * a0);
+    c.y   = mm_fma(beta, c.y, alpha * a1);
+    *cp   = c;
+}
+
+// column-major: one lane owns one row; the first CM_K entries of the row are kept in registers and the
+// lane sweeps CM_COLS columns, so A is read n/CM_COLS times (once for a 32..64-column shard) and every
+// B / C access is coalesced across the 64 rows of a wavefront.
+constexpr int CM_K    = 8;
+constexpr int CM_COLS = 64;
 
 template <typename T>
 __global__ __launch_bounds__(256) void csrmm_col_kernel(int base, T alpha, aoclsparse_int m,
@@ -102,48 +153,35 @@ __global__ __launch_bounds__(256) void csrmm_col_kernel(int base, T alpha, aocls
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if(i >= m)
         return;
-    const int j0 = blockIdx.y * CM_TILE;
-    const int nj = min(CM_TILE, n - j0);
+    const int j0 = blockIdx.y * CM_COLS;
+    const int j1 = min(n, j0 + CM_COLS);
     const int s = row_ptr[i] - base, e = row_ptr[i + 1] - base;
-    T         acc[CM_TILE];
+    T         v[CM_K];
+    int       c[CM_K];
 #pragma unroll
-    for(int jj = 0; jj < CM_TILE; jj++)
-        acc[jj] = T(0);
-    if(nj == CM_TILE)
+    for(int k = 0; k < CM_K; k++)
     {
-        for(int p = s; p < e; p++)
+        v[k] = T(0);
+        c[k] = 0;
+        if(s + k < e)
         {
-            const T  a  = val[p];
-            const T *bp = B + (size_t)(col[p] - base) + (size_t)j0 * ldb;
-#pragma unroll
-            for(int jj = 0; jj < CM_TILE; jj++)
-                acc[jj] = mm_fma(a, bp[(size_t)jj * ldb], acc[jj]);
-        }
-#pragma unroll
-        for(int jj = 0; jj < CM_TILE; jj++)
-        {
-            T *cp = C + (size_t)i + (size_t)(j0 + jj) * ldc;
-            *cp   = mm_fma(beta, *cp, alpha * acc[jj]);
+            v[k] = val[s + k];
+            c[k] = col[s + k] - base;
         }
     }
-    else
+    const int len = e - s;
+    for(int j = j0; j < j1; j++)
     {
-        for(int p = s; p < e; p++)
-        {
-            const T  a  = val[p];
-            const T *bp = B + (size_t)(col[p] - base) + (size_t)j0 * ldb;
+        const T *Bj  = B + (size_t)j * ldb;
+        T        acc = T(0);
 #pragma unroll
-            for(int jj = 0; jj < CM_TILE; jj++)
-                if(jj < nj)
-                    acc[jj] = mm_fma(a, bp[(size_t)jj * ldb], acc[jj]);
-        }
-#pragma unroll
-        for(int jj = 0; jj < CM_TILE; jj++)
-            if(jj < nj)
-            {
-                T *cp = C + (size_t)i + (size_t)(j0 + jj) * ldc;
-                *cp   = mm_fma(beta, *cp, alpha * acc[jj]);
-            }
+        for(int k = 0; k < CM_K; k++)
+            if(k < len)
+                acc = mm_fma(v[k], Bj[c[k]], acc);
+        for(int p = s + CM_K; p < e; p++)
+            acc = mm_fma(val[p], Bj[col[p] - base], acc);
+        T *cp = C + (size_t)i + (size_t)j * ldc;
+        *cp   = mm_fma(beta, *cp, alpha * acc);
     }
 }
 
@@ -185,7 +223,10 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
         const int tx    = lanes >= 128 ? 128 : pow2_at_least(lanes);
         const int ty    = 256 / tx;
         dim3      block(tx, ty), grid((m + ty - 1) / ty, (lanes + tx - 1) / tx);
-        if(vec)
+        if(vec && n >= 128)
+            hipLaunchKernelGGL((csrmm_row_wave_kernel<T>), dim3((m + 3) / 4, (n + 127) / 128), dim3(256), 0, s,
+                               base, alpha, m, val, col, row_ptr, B, n, ldb, beta, C, ldc);
+        else if(vec)
             hipLaunchKernelGGL((csrmm_row_kernel<T, true>), grid, block, 0, s, base, alpha, m, val, col, row_ptr,
                                B, n, ldb, beta, C, ldc);
         else
@@ -194,7 +235,7 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
     }
     else
     {
-        dim3 block(256), grid((m + 255) / 256, (n + CM_TILE - 1) / CM_TILE);
+        dim3 block(256), grid((m + 255) / 256, (n + CM_COLS - 1) / CM_COLS);
         hipLaunchKernelGGL((csrmm_col_kernel<T>), grid, block, 0, s, base, alpha, m, val, col, row_ptr, B, n,
                            ldb, beta, C, ldc);
     }

@@ -163,6 +163,16 @@ struct HostCsr
     ~HostCsr();
 };
 
+// A general CSR derived from the clean CSR so that the general kernels can serve a symmetric or
+// triangular descriptor: key = (type, fill, diag, transposed).
+struct Derived
+{
+    int       type = 0, fill = 0, diag = 0, trans = 0;
+    HostCsr   host; // owned, 0-based, sorted rows
+    DeviceCsr dev;
+    SpmvPlan  plan;
+};
+
 } // namespace mi355
 
 // ---- matrix handle (library/src/include/aoclsparse_mat_structures.hpp:774-859) -------------
@@ -191,6 +201,10 @@ struct _aoclsparse_matrix
     mi355::TrsvPlan  trsv_plan[4]; // index: (upper?2:0) + (transpose?1:0)
     mi355::DeviceBuffer dev_diag; // diagonal values of the clean CSR (length min(m,n))
     mi355::DeviceBuffer trsv_scratch; // ticket + timeout words of the sync-free solve
+
+    // matrices derived from the clean CSR for non-general descriptors (symmetric expansion,
+    // triangular slices), built on first use: see derived.cpp
+    std::vector<std::unique_ptr<mi355::Derived>> derived;
 
     // sp2m stage-1 state (C handles own their arrays)
     bool owns_user_arrays = false;
@@ -253,6 +267,9 @@ size_t            val_size(aoclsparse_matrix_data_type t);
 aoclsparse_status upload_csr(const HostCsr &h, size_t vsize, DeviceCsr &d);
 aoclsparse_status ensure_spmv(aoclsparse_matrix A, bool transposed, DeviceCsr *&dcsr,
                               SpmvPlan *&plan);
+// symmetric expansion / triangular slice of the clean CSR as a general device CSR (derived.cpp)
+aoclsparse_status ensure_derived(aoclsparse_matrix A, aoclsparse_matrix_type type, aoclsparse_fill_mode fill,
+                                 aoclsparse_diag_type diag, bool transposed, Derived *&out);
 // clean CSR on the device + level sets of one triangle (trsv_api.cpp)
 aoclsparse_status ensure_trsv(aoclsparse_matrix A, bool upper, bool transposed);
 aoclsparse_status build_spmv_plan(aoclsparse_int m, aoclsparse_int nnz, aoclsparse_index_base base,

@@ -5,6 +5,7 @@
 // (nnz <= 10*m -> scalar order, kid 1/2 -> 4-lane order, kid 3 / auto -> 8-lane order).
 #include "internal.hpp"
 
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -179,9 +180,6 @@ aoclsparse_status mv_t(aoclsparse_operation op, const T *alpha, aoclsparse_matri
     if(A->m == 0 || A->n == 0 || (A->nnz == 0 && descr->type == aoclsparse_matrix_type_general))
         return scale_y<T>(rt, y, op == aoclsparse_operation_none ? A->m : A->n, *beta);
 
-    if(descr->type != aoclsparse_matrix_type_general)
-        return aoclsparse_status_not_implemented; // symmetric / triangular SpMV: next wave
-
     const doid     id  = get_doid(descr, op);
     aoclsparse_int kid = -1; // magic_box.hpp:34-53: first hint with matching action + doid
     for(const Hint &h : A->hints)
@@ -193,12 +191,25 @@ aoclsparse_status mv_t(aoclsparse_operation op, const T *alpha, aoclsparse_matri
     const bool tr   = op != aoclsparse_operation_none;
     DeviceCsr *dcsr = nullptr;
     SpmvPlan  *plan = nullptr;
-    st              = ensure_spmv(A, tr, dcsr, plan);
-    if(st != aoclsparse_status_success)
-        return st;
+    if(descr->type != aoclsparse_matrix_type_general)
+    {
+        // symmetric / triangular operator: general CSR derived from the clean CSR (derived.cpp); the
+        // reference optimises the CSR on the fly here too (mv.cpp:134-149)
+        Derived *dv = nullptr;
+        st          = ensure_derived(A, descr->type, descr->fill_mode, descr->diag_type, tr, dv);
+        if(st != aoclsparse_status_success)
+            return st;
+        dcsr = &dv->dev;
+        plan = &dv->plan;
+    }
+    else
+    {
+        st = ensure_spmv(A, tr, dcsr, plan);
+        if(st != aoclsparse_status_success)
+            return st;
+    }
     std::shared_lock<std::shared_mutex> r(A->guard);
-    return run_on_device_csr<T>(rt, kid, *dcsr, *plan, *alpha, x, *beta, y, tr ? A->m : A->n,
-                                tr ? A->n : A->m);
+    return run_on_device_csr<T>(rt, kid, *dcsr, *plan, *alpha, x, *beta, y, dcsr->n, dcsr->m);
 }
 
 // ---- raw-array path --------------------------------------------------------------------------------
@@ -240,9 +251,6 @@ aoclsparse_status csrmv_t(aoclsparse_operation trans, const T *alpha, aoclsparse
         return aoclsparse_status_invalid_size;
     if(!val || !row || !col || !x || !y)
         return aoclsparse_status_invalid_pointer;
-    if(descr->type == aoclsparse_matrix_type_symmetric)
-        return aoclsparse_status_not_implemented; // next wave
-
     Runtime          &rt = Runtime::get();
     aoclsparse_status st = rt.init();
     if(st != aoclsparse_status_success)
@@ -252,6 +260,80 @@ aoclsparse_status csrmv_t(aoclsparse_operation trans, const T *alpha, aoclsparse
         sl.lock();
     const bool tr = trans != aoclsparse_operation_none;
     const bool mdev = rt.is_device_pointer(row);
+
+    if(descr->type == aoclsparse_matrix_type_symmetric)
+    {
+        // aoclsparse_csrmv_symm (csrmv_kr.hpp:41-92): the arrays hold ONE triangle; every stored
+        // entry except a diagonal sitting LAST in its row is applied as the pair (i,c),(c,i); op is
+        // irrelevant for a symmetric operator.  One-shot path: expand on the host, run general.
+        if(m == 0)
+            return aoclsparse_status_success;
+        std::vector<aoclsparse_int> hrow, hcol;
+        std::vector<T>              hval;
+        const aoclsparse_int       *prow = row, *pcol = col;
+        const T                    *pval = val;
+        const int                   b    = descr->base;
+        try
+        {
+            if(mdev)
+            {
+                hrow.resize((size_t)m + 1), hcol.resize(nnz), hval.resize(nnz);
+                MI355_HIP_TRY(hipMemcpy(hrow.data(), row, sizeof(aoclsparse_int) * ((size_t)m + 1),
+                                        hipMemcpyDeviceToHost));
+                MI355_HIP_TRY(hipMemcpy(hcol.data(), col, sizeof(aoclsparse_int) * (size_t)nnz,
+                                        hipMemcpyDeviceToHost));
+                MI355_HIP_TRY(hipMemcpy(hval.data(), val, sizeof(T) * (size_t)nnz, hipMemcpyDeviceToHost));
+                prow = hrow.data(), pcol = hcol.data(), pval = hval.data();
+            }
+            std::vector<aoclsparse_int> eptr((size_t)m + 1, 0);
+            auto                        last_is_diag = [&](aoclsparse_int i) {
+                return prow[i + 1] > prow[i] && pcol[prow[i + 1] - b - 1] - b == i;
+            };
+            for(aoclsparse_int i = 0; i < m; i++)
+            {
+                const aoclsparse_int ld = last_is_diag(i) ? 1 : 0;
+                eptr[i + 1] += prow[i + 1] - prow[i]; // the row itself (diagonal included once)
+                for(aoclsparse_int p = prow[i] - b; p < prow[i + 1] - b - ld; p++)
+                    eptr[pcol[p] - b + 1]++; // mirrored entry
+            }
+            for(aoclsparse_int i = 0; i < m; i++)
+                eptr[i + 1] += eptr[i];
+            const aoclsparse_int        ennz = eptr[m];
+            std::vector<aoclsparse_int> eind((size_t)std::max(ennz, 1)), next(eptr.begin(), eptr.end() - 1);
+            std::vector<T>              eval((size_t)std::max(ennz, 1));
+            for(aoclsparse_int i = 0; i < m; i++)
+            {
+                const aoclsparse_int ld = last_is_diag(i) ? 1 : 0;
+                for(aoclsparse_int p = prow[i] - b; p < prow[i + 1] - b; p++)
+                {
+                    aoclsparse_int q = next[i]++;
+                    eind[q] = pcol[p] - b, eval[q] = pval[p];
+                    if(p < prow[i + 1] - b - ld)
+                    {
+                        q       = next[pcol[p] - b]++;
+                        eind[q] = i, eval[q] = pval[p];
+                    }
+                }
+            }
+            _aoclsparse_matrix tmp;
+            tmp.m = m, tmp.n = m, tmp.nnz = ennz, tmp.base = aoclsparse_index_base_zero, tmp.val_type = vt;
+            tmp.user.m = m, tmp.user.n = m, tmp.user.nnz = ennz, tmp.user.base = aoclsparse_index_base_zero;
+            tmp.user.ptr = eptr.data(), tmp.user.ind = eind.data(), tmp.user.val = eval.data();
+            DeviceCsr *dcsr = nullptr;
+            SpmvPlan  *plan = nullptr;
+            st              = ensure_spmv(&tmp, false, dcsr, plan);
+            if(st != aoclsparse_status_success)
+                return st;
+            st = run_on_device_csr<T>(rt, -1, *dcsr, *plan, *alpha, x, *beta, y, m, m);
+            if(st == aoclsparse_status_success)
+                MI355_HIP_TRY(hipStreamSynchronize(rt.stream()));
+            return st;
+        }
+        catch(const std::bad_alloc &)
+        {
+            return aoclsparse_status_memory_error;
+        }
+    }
 
     if(tr)
     {

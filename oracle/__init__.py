@@ -105,6 +105,31 @@ def dcsrmvt(base, alpha, m, n, val, col, row, x, beta, y):
     return st, y
 
 
+def dcsrmv_symm_raw(base, alpha, m, val, col, row, x, beta, y):
+    val, col, row, x = _f64(val), _i32(col), _i32(row), _f64(x)
+    y = _f64(y).copy()
+    st = lib().orc_dcsrmv_symm_raw(c_int(base), c_dbl(alpha), c_i32(m), _p(val), _p(col), _p(row), _p(x),
+                                   c_dbl(beta), _p(y))
+    return st, y
+
+
+def dcsrmv_special(kind, base, alpha, m, n, diag, fill, val, col, ptr, idiag, iurow, x, beta, y):
+    """kind: 'symm' | 'tri' | 'tri_t' on the clean CSR (+ idiag/iurow); fill 0/1, diag 0/1/2."""
+    val, col, ptr, idiag, iurow, x = _f64(val), _i32(col), _i32(ptr), _i32(idiag), _i32(iurow), _f64(x)
+    y = _f64(y).copy()
+    L = lib()
+    if kind == "symm":
+        st = L.orc_dcsrmv_symm(c_int(base), c_dbl(alpha), c_i32(m), c_int(diag), c_int(fill), _p(val), _p(col),
+                               _p(ptr), _p(idiag), _p(iurow), _p(x), c_dbl(beta), _p(y))
+    elif kind == "tri":
+        st = L.orc_dcsrmv_tri(c_int(base), c_dbl(alpha), c_i32(m), c_int(diag), c_int(fill), _p(val), _p(col),
+                              _p(ptr), _p(idiag), _p(iurow), _p(x), c_dbl(beta), _p(y))
+    else:
+        st = L.orc_dcsrmv_tri_t(c_int(base), c_dbl(alpha), c_i32(m), c_i32(n), c_int(diag), c_int(fill), _p(val),
+                                _p(col), _p(ptr), _p(idiag), _p(iurow), _p(x), c_dbl(beta), _p(y))
+    return st, y
+
+
 def max_threads():
     return int(lib().orc_max_threads())
 

@@ -254,6 +254,132 @@ int orc_dcsrmvt(int base, double alpha, oint m, oint n, const double *val, const
 }
 
 /* ------------------------------------------------------------------------------------ */
+/* Symmetric / triangular SpMV reference kernels.                                        */
+/* ------------------------------------------------------------------------------------ */
+static void scale_y_d(double *y, oint n, double beta)
+{
+    if(beta == 0.0)
+        for(oint i = 0; i < n; i++)
+            y[i] = 0.0;
+    else if(beta != 1.0)
+        for(oint i = 0; i < n; i++)
+            y[i] = beta * y[i];
+}
+
+/* csrmv_kr.hpp:41-92 (aoclsparse_csrmv_symm, the raw-array csrmv with a symmetric descriptor):
+ * every stored entry except a diagonal in LAST position of its row is applied twice. */
+int orc_dcsrmv_symm_raw(int base, double alpha, oint m, const double *val, const oint *col,
+                        const oint *row, const double *x, double beta, double *y)
+{
+    scale_y_d(y, m, beta);
+    for(oint i = 0; i < m; i++)
+    {
+        oint didx = row[i + 1] - base - 1;
+        int  last = (row[i + 1] > row[i]) && (col[didx] - base == i); /* reference reads col[-1] on empty rows */
+        if(last)
+            y[i] = fma(alpha * val[didx], x[i], y[i]); /* last*alpha*val*x[i], contracted */
+        oint end = row[i + 1] - base - last;
+        for(oint j = row[i] - base; j < end; j++)
+        {
+            oint c = col[j] - base;
+            y[i]   = fma(alpha * val[j], x[c], y[i]);
+            y[c]   = fma(alpha * val[j], x[i], y[c]);
+        }
+    }
+    return ORC_SUCCESS;
+}
+
+/* csrmv_kr.hpp:107-186 (aoclsparse_csrmv_symm_internal) on the clean CSR: fill 0 lower / 1 upper,
+ * diag 0 non_unit / 1 unit / 2 zero; istart/iend select the strict triangle via idiag / iurow. */
+int orc_dcsrmv_symm(int base, double alpha, oint m, int diag, int fill, const double *val,
+                    const oint *col, const oint *ptr, const oint *idiag, const oint *iurow,
+                    const double *x, double beta, double *y)
+{
+    scale_y_d(y, m, beta);
+    for(oint i = 0; i < m; i++)
+    {
+        oint   s = fill == 0 ? ptr[i] : iurow[i], e = fill == 0 ? idiag[i] : ptr[i + 1];
+        double xv = x[i], sum = 0.0;
+        for(oint j = s; j < e; j++)
+        {
+            oint   c = col[j - base] - base;
+            double v = alpha * val[j - base];
+            sum      = fma(v, x[c], sum);
+            y[c]     = fma(v, xv, y[c]);
+        }
+        if(diag == 0)
+            sum = fma(alpha * val[idiag[i] - base], xv, sum);
+        else if(diag == 1)
+            sum = fma(alpha, xv, sum);
+        y[i] += sum;
+    }
+    return ORC_SUCCESS;
+}
+
+/* csrmv_kr.hpp:658-728 (ref_csrmv_tri): rows [rs[i], re[i]) of the clean CSR, i.e. strict triangle
+ * plus the stored diagonal; unit/zero diag drop the stored diagonal, unit adds x[i]. */
+int orc_dcsrmv_tri(int base, double alpha, oint m, int diag, int fill, const double *val,
+                   const oint *col, const oint *ptr, const oint *idiag, const oint *iurow,
+                   const double *x, double beta, double *y)
+{
+    (void)iurow;
+    scale_y_d(y, m, beta);
+    for(oint i = 0; i < m; i++)
+    {
+        /* lower: [ptr[i], iurow[i]) ; upper: [idiag[i], ptr[i+1]) (csrmv.hpp:110-123) */
+        oint rs = fill == 0 ? ptr[i] : idiag[i], re = fill == 0 ? iurow[i] : ptr[i + 1];
+        int  so = 0, eo = 0;
+        if(diag != 0)
+        {
+            if(fill == 0)
+                eo = -1;
+            else
+                so = 1;
+        }
+        double r = 0.0;
+        if(so && diag == 1)
+            r += x[i];
+        for(oint j = rs + so; j < re + eo; j++)
+            r = fma(val[j - base], x[col[j - base] - base], r);
+        if(eo && diag == 1)
+            r += x[i];
+        y[i] = fma(alpha, r, y[i]);
+    }
+    return ORC_SUCCESS;
+}
+
+/* csrmv_kr.hpp:577-649 (ref_csrmv_tri_th): transposed triangular SpMV, column sweep. */
+int orc_dcsrmv_tri_t(int base, double alpha, oint m, oint n, int diag, int fill, const double *val,
+                     const oint *col, const oint *ptr, const oint *idiag, const oint *iurow,
+                     const double *x, double beta, double *y)
+{
+    scale_y_d(y, n, beta);
+    for(oint i = 0; i < m; i++)
+    {
+        oint rs = fill == 0 ? ptr[i] : idiag[i], re = fill == 0 ? iurow[i] : ptr[i + 1];
+        int  so = 0, eo = 0;
+        if(diag != 0)
+        {
+            if(fill == 0)
+                eo = -1;
+            else
+                so = 1;
+        }
+        double axi = alpha * x[i];
+        if(so && diag == 1)
+            y[i] += axi;
+        for(oint j = rs + so; j < re + eo; j++)
+        {
+            oint c = col[j - base] - base;
+            y[c]   = fma(val[j - base], axi, y[c]);
+        }
+        if(eo && diag == 1)
+            y[i] += axi;
+    }
+    return ORC_SUCCESS;
+}
+
+/* ------------------------------------------------------------------------------------ */
 /* TRSV reference kernels, trsv_kr.hpp:38-222.  "xi -= a*x" contracts to fma(-a, x, xi). */
 /* ------------------------------------------------------------------------------------ */
 #define DEF_TRSV(T, SUF, FMA)                                                                \

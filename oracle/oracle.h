@@ -75,6 +75,20 @@ int orc_dcsrmv(int kid, int base, double alpha, oint m, oint nnz, const double *
  * thread (y scaled first, then y[col] += val*(alpha*x[i]) row by row). */
 int orc_dcsrmvt(int base, double alpha, oint m, oint n, const double *val, const oint *col,
                 const oint *row, const double *x, double beta, double *y);
+/* Symmetric / triangular SpMV of the reference (serial kernels):
+ * csrmv_kr.hpp:41-92 (raw csrmv, symmetric descriptor), :107-186 (clean CSR, symmetric),
+ * :658-728 (triangular), :577-649 (triangular transposed).  fill 0 lower/1 upper; diag 0/1/2. */
+int orc_dcsrmv_symm_raw(int base, double alpha, oint m, const double *val, const oint *col,
+                        const oint *row, const double *x, double beta, double *y);
+int orc_dcsrmv_symm(int base, double alpha, oint m, int diag, int fill, const double *val,
+                    const oint *col, const oint *ptr, const oint *idiag, const oint *iurow,
+                    const double *x, double beta, double *y);
+int orc_dcsrmv_tri(int base, double alpha, oint m, int diag, int fill, const double *val,
+                   const oint *col, const oint *ptr, const oint *idiag, const oint *iurow,
+                   const double *x, double beta, double *y);
+int orc_dcsrmv_tri_t(int base, double alpha, oint m, oint n, int diag, int fill, const double *val,
+                     const oint *col, const oint *ptr, const oint *idiag, const oint *iurow,
+                     const double *x, double beta, double *y);
 /* OpenMP static-row version of orc_dcsrmv (same per-row arithmetic); CPU baseline leg. */
 int orc_dcsrmv_omp(int kid, int base, double alpha, oint m, oint nnz, const double *val,
                    const oint *col, const oint *row, const double *x, double beta, double *y,

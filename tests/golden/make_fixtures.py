@@ -32,6 +32,23 @@ out["csrmv"] = [
          x=[1, 2, 3, 4, 5], alpha=1.0, beta=0.0, y0=[0, 0, 0, 0, 0], y_gold=[9, 6, 12, 69, 40]),
 ]
 
+# symmetric raw csrmv: tests/unit_tests/csrmv_tests.cpp:288-352.  The test compares against its own
+# dense-free reference (ref_csrmvsym); the matrix and x are small integers, so y_gold below is the exact
+# symmetric product (L + D + L^T) x, computed here in integer arithmetic.
+_sr = [0, 1, 2, 5, 6, 8, 11, 15, 18]
+_sc = [0, 1, 0, 1, 2, 3, 1, 4, 0, 4, 5, 0, 3, 4, 6, 2, 5, 7]
+_sv = [19, 10, 1, 8, 11, 13, 2, 11, 2, 1, 9, 7, 9, 5, 12, 5, 5, 9]
+_sx = [1, 2, 3, 4, 5, 6, 7, 8]
+_sy = [0] * 8
+for _i in range(8):
+    for _p in range(_sr[_i], _sr[_i + 1]):
+        _sy[_i] += _sv[_p] * _sx[_sc[_p]]
+        if _sc[_p] != _i:
+            _sy[_sc[_p]] += _sv[_p] * _sx[_i]
+out["csrmv_sym"] = [dict(name="S8_lower", src="tests/unit_tests/csrmv_tests.cpp:288-352", base=0, m=8,
+                         fill="lower", row_ptr=_sr, col_ind=_sc, val=_sv, x=_sx, alpha=1.0, beta=0.0,
+                         y_gold=_sy)]
+
 # ------------------------------------------------------------------------------------------
 # clean CSR after optimize: inputs tests/unit_tests/common_data_utils.h:609-760,
 # expected tests/unit_tests/hint_tests.cpp:75-170 (all base 0, double)

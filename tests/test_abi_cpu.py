@@ -207,7 +207,7 @@ def test_argument_checks_that_precede_any_device_work():
     for k in ("val", "col", "row", "x", "y"):
         assert f(*args(**{k: None})) == 2
     dt = P.Descr(mtype=P.TYPE_TRIANGULAR)
-    assert f(*args(descr=dt.h)) == 1           # only general + symmetric (csrmv.hpp:83-88)
+    assert f(*args(descr=dt.h)) == 1           # raw csrmv: only general + symmetric (csrmv.hpp:83-88)
     ds = P.Descr(mtype=P.TYPE_SYMMETRIC)
     assert f(*args(descr=ds.h, m=5)) == 3      # symmetric must be square
     A = P.Matrix(0, 6, 6, rp, ci, v)

@@ -514,3 +514,83 @@ def test_csrmm_column_shards_compose():
         parts.append(Cs)
     torch.cuda.synchronize()
     assert torch.equal(torch.cat(parts), full)
+
+
+# --------------------------------------------------------------------------------------------------
+# symmetric / triangular descriptors (derived general CSR on the device, csrc/derived.cpp)
+# --------------------------------------------------------------------------------------------------
+def _dense(m, n, rp, ci, v, base=0):
+    A = np.zeros((m, n))
+    for i in range(m):
+        A[i, ci[rp[i] - base:rp[i + 1] - base] - base] = v[rp[i] - base:rp[i + 1] - base]
+    return A
+
+
+def test_symmetric_raw_csrmv_kat(kats):
+    """csrmv_tests.cpp:288-352: one stored triangle, symmetric descriptor, op = transpose, y = NaN, beta = 0."""
+    c = kats["csrmv_sym"][0]
+    m = c["m"]
+    rp, ci, v = np.array(c["row_ptr"], np.int32), np.array(c["col_ind"], np.int32), np.array(c["val"], np.float64)
+    x = np.array(c["x"], np.float64)
+    d = P.Descr(mtype=P.TYPE_SYMMETRIC, fill=P.FILL_LOWER)
+    for op in (P.OP_NONE, P.OP_TRANSPOSE):
+        y = np.full(m, np.nan)
+        assert P.dcsrmv(op, c["alpha"], m, m, len(v), v, ci, rp, d, x, c["beta"], y) == 0
+        assert np.array_equal(y, np.array(c["y_gold"], np.float64))
+    so, yo = oracle.dcsrmv_symm_raw(0, 1.0, m, v, ci, rp, x, 0.0, np.zeros(m))
+    assert np.array_equal(yo, np.array(c["y_gold"], np.float64))
+
+
+@pytest.mark.parametrize("fill", [P.FILL_LOWER, P.FILL_UPPER])
+@pytest.mark.parametrize("diag", [P.DIAG_NON_UNIT, P.DIAG_UNIT, P.DIAG_ZERO])
+def test_symmetric_and_triangular_dmv(fill, diag):
+    """Against the serial reference kernels restated in the oracle (csrmv_kr.hpp:107-186, 577-728) within
+    |dy| <= (len+6) eps (|alpha| sum|a x| + |beta y|); the operators are also checked against a dense
+    construction so that the expansion itself (which triangle, which diagonal) is pinned exactly."""
+    m = 1500
+    rp, ci, v = random_csr(101 + fill + 2 * diag, m, m, lambda r, i: r.integers(0, 16), sort=False)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    rng = np.random.default_rng(9)
+    x, y0 = rng.uniform(-1, 1, m), rng.uniform(-1, 1, m)
+    alpha, beta = 1.7, -0.4
+    o = oracle.dcsr_optimize(m, m, len(v), 0, rp, ci, v)
+    D = _dense(m, m, o["ptr"], o["ind"], o["val"])
+    tri = np.tril(D, -1) if fill == P.FILL_LOWER else np.triu(D, 1)
+    dg = np.diag(np.diag(D)) if diag == P.DIAG_NON_UNIT else (np.eye(m) if diag == P.DIAG_UNIT else 0.0)
+    absx = np.abs(x)
+    for mtype, ops in ((P.TYPE_SYMMETRIC, (P.OP_NONE, P.OP_TRANSPOSE)), (P.TYPE_TRIANGULAR, (P.OP_NONE, P.OP_TRANSPOSE))):
+        d = P.Descr(mtype=mtype, fill=fill, diag=diag)
+        for op in ops:
+            st, y = run_dmv(A, d, x, y0, alpha, beta, op=op)
+            assert st == 0, (mtype, op, P.STATUS[st])
+            if mtype == P.TYPE_SYMMETRIC:
+                M = tri + tri.T + dg
+                so, yo = oracle.dcsrmv_special("symm", o["base"], alpha, m, m, diag, fill, o["val"], o["ind"],
+                                               o["ptr"], o["idiag"], o["iurow"], x, beta, y0)
+            else:
+                M = tri + dg if op == P.OP_NONE else (tri + dg).T
+                so, yo = oracle.dcsrmv_special("tri" if op == P.OP_NONE else "tri_t", o["base"], alpha, m, m, diag,
+                                               fill, o["val"], o["ind"], o["ptr"], o["idiag"], o["iurow"], x, beta, y0)
+            assert so == 0
+            lens = (M != 0).sum(axis=1)
+            bound = (lens + 6) * EPS64 * (abs(alpha) * (np.abs(M) @ absx) + np.abs(beta * y0)) + 1e-300
+            assert np.all(np.abs(y - yo) <= bound), (mtype, op, np.max(np.abs(y - yo) / bound))
+            assert np.all(np.abs(y - (alpha * (M @ x) + beta * y0)) <= 4 * bound)
+
+
+def test_symmetric_csrmm():
+    """csrmm.hpp:667-718 (serial *_sym_ref kernels): C = alpha*(L+D+L^T)*B + beta*C."""
+    m, n = 800, 24
+    rp, ci, v = random_csr(131, m, m, lambda r, i: r.integers(0, 12))
+    A = P.Matrix(0, m, m, rp, ci, v)
+    d = P.Descr(mtype=P.TYPE_SYMMETRIC, fill=P.FILL_UPPER)
+    rng = np.random.default_rng(3)
+    B, C0 = rng.uniform(-1, 1, m * n), rng.uniform(-1, 1, m * n)
+    C = C0.copy()
+    assert P.dcsrmm(P.OP_NONE, 2.0, A, d, P.ORDER_ROW, B, n, n, 0.5, C, n) == 0
+    o = oracle.dcsr_optimize(m, m, len(v), 0, rp, ci, v)
+    D = _dense(m, m, o["ptr"], o["ind"], o["val"])
+    M = np.triu(D, 1) + np.triu(D, 1).T + np.diag(np.diag(D))
+    ref = 2.0 * (M @ B.reshape(m, n)) + 0.5 * C0.reshape(m, n)
+    scale = 2.0 * (np.abs(M) @ np.abs(B.reshape(m, n))) + np.abs(0.5 * C0.reshape(m, n))
+    assert np.all(np.abs(C.reshape(m, n) - ref) <= 40 * EPS64 * scale + 1e-300)
