@@ -1,46 +1,327 @@
-// sp2m_api.cpp -- aoclsparse_sp2m / aoclsparse_spmm / aoclsparse_?csr2m entry points.
+// sp2m_api.cpp -- aoclsparse_sp2m / aoclsparse_spmm / aoclsparse_?csr2m: C = op(A) * op(B), sparse result.
 //
-// Argument checks follow level3/aoclsparse_csr2m.cpp:592-740 of the reference.  The sparse x sparse
-// product itself (two-stage Gustavson, csr2m.cpp:46-543) has no HIP kernel yet: rather than ship a CPU
-// loop inside the GPU product, valid requests return aoclsparse_status_not_implemented (DESIGN.md,
-// "open rows").  The oracle restates the algorithm (oracle.c: orc_csr2m_nnz / orc_dcsr2m_fill).
+// Driver logic follows level3/aoclsparse_csr2m.cpp:592-861 of the reference: argument checks in the
+// same order, empty-product quick return that still allocates an empty C, op handling (A^T / B^T by an
+// explicit counting-sort transpose, A^T B^T as (B A)^T with the product transposed back at finalize),
+// the two-stage request protocol (stage_nnz_count allocates C and fills row_ptr; stage_finalize fills
+// col_ind / val of that same C; full_computation does both), C always 0-based.  The product itself runs
+// on the GPU (spgemm_kernels.hip); C's arrays are host arrays owned by the new handle, like any handle
+// created by aoclsparse_create_?csr, so export / destroy work unchanged.
 #include "internal.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
 
 using namespace mi355;
 
+namespace mi355
+{
+template <typename T>
+aoclsparse_status launch_spgemm(hipStream_t s, bool fill, aoclsparse_int m, int base_a,
+                                const aoclsparse_int *ptr_a, const aoclsparse_int *ind_a, const T *val_a,
+                                int base_b, const aoclsparse_int *ptr_b, const aoclsparse_int *ind_b,
+                                const T *val_b, const long long *slab_off, int *slab_idx, T *slab_val,
+                                const aoclsparse_int *ptr_c, aoclsparse_int *cnt_or_ind_c, T *val_c);
+}
+
 namespace
 {
-aoclsparse_status sp2m_checks(aoclsparse_operation opA, const aoclsparse_mat_descr descrA,
-                              const aoclsparse_matrix A, aoclsparse_operation opB,
-                              const aoclsparse_mat_descr descrB, const aoclsparse_matrix B,
-                              const aoclsparse_request request, aoclsparse_matrix *C)
+
+// host CSR operand, either a view of a handle's user arrays or an owned transpose
+template <typename T>
+struct Operand
 {
-    if(!A || !B || !C || !descrA || !descrB)
+    aoclsparse_int              m = 0, n = 0, nnz = 0, base = 0;
+    const aoclsparse_int       *ptr = nullptr, *ind = nullptr;
+    const T                    *val = nullptr;
+    std::vector<aoclsparse_int> optr, oind;
+    std::vector<T>              oval;
+};
+
+template <typename T>
+void view_of(const aoclsparse_matrix A, Operand<T> &o)
+{
+    o.m = A->m, o.n = A->n, o.nnz = A->nnz, o.base = A->base;
+    o.ptr = A->user.ptr, o.ind = A->user.ind, o.val = static_cast<const T *>(A->user.val);
+}
+
+// conversion/aoclsparse_convert.hpp:552-655 with equal in/out bases (csr2m.cpp:771-781)
+template <typename T>
+void transpose_of(const Operand<T> &a, Operand<T> &t)
+{
+    const aoclsparse_int b = a.base;
+    t.m = a.n, t.n = a.m, t.nnz = a.nnz, t.base = b;
+    t.optr.assign((size_t)t.m + 1, 0);
+    t.oind.resize((size_t)std::max(a.nnz, 1));
+    t.oval.resize((size_t)std::max(a.nnz, 1));
+    for(aoclsparse_int p = 0; p < a.nnz; p++)
+        t.optr[a.ind[p] - b + 1]++;
+    for(aoclsparse_int j = 0; j < t.m; j++)
+        t.optr[j + 1] += t.optr[j];
+    std::vector<aoclsparse_int> next(t.optr.begin(), t.optr.end() - 1);
+    for(aoclsparse_int i = 0; i < a.m; i++)
+        for(aoclsparse_int p = a.ptr[i] - b; p < a.ptr[i + 1] - b; p++)
+        {
+            const aoclsparse_int q = next[a.ind[p] - b]++;
+            t.oind[q]              = i + b;
+            t.oval[q]              = a.val[p];
+        }
+    for(aoclsparse_int j = 0; j <= t.m; j++)
+        t.optr[j] += b;
+    t.ptr = t.optr.data(), t.ind = t.oind.data(), t.val = t.oval.data();
+}
+
+aoclsparse_status new_result(aoclsparse_matrix *C, aoclsparse_int m, aoclsparse_int n, aoclsparse_int nnz,
+                             aoclsparse_matrix_data_type vt, const aoclsparse_int *row_ptr)
+{
+    _aoclsparse_matrix *c = new(std::nothrow) _aoclsparse_matrix;
+    if(!c)
+        return aoclsparse_status_memory_error;
+    const size_t vs = val_size(vt);
+    c->m = m, c->n = n, c->nnz = nnz, c->base = aoclsparse_index_base_zero, c->val_type = vt;
+    c->user.m = m, c->user.n = n, c->user.nnz = nnz, c->user.base = aoclsparse_index_base_zero;
+    c->user.ptr = new(std::nothrow) aoclsparse_int[(size_t)m + 1];
+    c->user.ind = new(std::nothrow) aoclsparse_int[(size_t)std::max(nnz, 1)];
+    c->user.val = ::operator new(vs * (size_t)std::max(nnz, 1), std::nothrow);
+    c->user.owned = true; // freed by the handle
+    c->owns_user_arrays = true;
+    if(!c->user.ptr || !c->user.ind || !c->user.val)
+    {
+        delete c;
+        return aoclsparse_status_memory_error;
+    }
+    if(row_ptr)
+        std::memcpy(c->user.ptr, row_ptr, sizeof(aoclsparse_int) * ((size_t)m + 1));
+    else
+        std::fill(c->user.ptr, c->user.ptr + m + 1, 0);
+    *C = c;
+    return aoclsparse_status_success;
+}
+
+template <typename T>
+aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr descrA, const aoclsparse_matrix A,
+                         aoclsparse_operation opB, const aoclsparse_mat_descr descrB, const aoclsparse_matrix B,
+                         aoclsparse_request request, aoclsparse_matrix *C, aoclsparse_matrix_data_type vt)
+{
+    if(!descrA || !descrB)
         return aoclsparse_status_invalid_pointer;
+    if(!A || !B || !C)
+        return aoclsparse_status_invalid_pointer;
+    if(request != aoclsparse_stage_finalize)
+        *C = nullptr;
+    if(A->input_format != aoclsparse_csr_mat || B->input_format != aoclsparse_csr_mat)
+        return aoclsparse_status_not_implemented;
+    if(A->val_type != vt || B->val_type != vt)
+        return aoclsparse_status_wrong_type;
     if(!A->user.ptr || !B->user.ptr)
         return aoclsparse_status_invalid_pointer;
-    if(A->val_type != B->val_type)
-        return aoclsparse_status_wrong_type;
-    if(descrA->base != A->base || descrB->base != B->base)
+    auto valid_base = [](int b) { return b == 0 || b == 1; };
+    if(!valid_base(descrA->base) || !valid_base(descrB->base))
         return aoclsparse_status_invalid_value;
-    auto valid_op = [](aoclsparse_operation o) {
-        return o == aoclsparse_operation_none || o == aoclsparse_operation_transpose
-               || o == aoclsparse_operation_conjugate_transpose;
-    };
-    if(!valid_op(opA) || !valid_op(opB))
-        return aoclsparse_status_invalid_value;
-    if(request != aoclsparse_stage_nnz_count && request != aoclsparse_stage_finalize
-       && request != aoclsparse_stage_full_computation)
+    if(A->base != descrA->base || B->base != descrB->base)
         return aoclsparse_status_invalid_value;
     if(descrA->type != aoclsparse_matrix_type_general || descrB->type != aoclsparse_matrix_type_general)
         return aoclsparse_status_not_implemented;
-    // inner dimensions of op(A) * op(B)
-    const aoclsparse_int ka = opA == aoclsparse_operation_none ? A->n : A->m;
-    const aoclsparse_int kb = opB == aoclsparse_operation_none ? B->m : B->n;
-    if(ka != kb)
+    auto is_tr = [](aoclsparse_operation o, bool &ok) {
+        ok = o == aoclsparse_operation_none || o == aoclsparse_operation_transpose
+             || o == aoclsparse_operation_conjugate_transpose;
+        return o != aoclsparse_operation_none;
+    };
+    bool       okA, okB;
+    const bool trA = is_tr(opA, okA), trB = is_tr(opB, okB);
+    if(!okA || !okB)
+        return aoclsparse_status_invalid_value;
+    const aoclsparse_int m_a = trA ? A->n : A->m, n_a = trA ? A->m : A->n;
+    const aoclsparse_int m_b = trB ? B->n : B->m, n_b = trB ? B->m : B->n;
+    if(n_a != m_b)
         return aoclsparse_status_invalid_size;
+    if(request != aoclsparse_stage_nnz_count && request != aoclsparse_stage_finalize
+       && request != aoclsparse_stage_full_computation)
+        return aoclsparse_status_invalid_value;
+    if(m_a == 0 || n_a == 0 || n_b == 0 || A->nnz == 0 || B->nnz == 0)
+    {
+        if(*C == nullptr) // csr2m.cpp:705-735: valid empty result
+            return new_result(C, m_a, n_b, 0, vt, nullptr);
+        return aoclsparse_status_success;
+    }
+
+    Runtime          &rt = Runtime::get();
+    aoclsparse_status st = rt.init();
+    if(st != aoclsparse_status_success)
+        return st;
+    std::lock_guard<std::recursive_mutex> sl(rt.stage_lock);
+    try
+    {
+        // operands in computation orientation (csr2m.cpp:743-830)
+        const int  opflag = (trA ? 1 : 0) | (trB ? 2 : 0);
+        Operand<T> va, vb, ta, tb;
+        view_of<T>(A, va);
+        view_of<T>(B, vb);
+        const Operand<T> *X = &va, *Y = &vb;
+        if(opflag == 3)
+            X = &vb, Y = &va; // (B A)^T
+        else
+        {
+            if(trA)
+            {
+                transpose_of<T>(va, ta);
+                X = &ta;
+            }
+            if(trB)
+            {
+                transpose_of<T>(vb, tb);
+                Y = &tb;
+            }
+        }
+        const aoclsparse_int m = X->m, n = Y->n; // product D = X * Y is m x n
+
+        // upper bound of every row's list; rows above the LDS capacity get a slice of a global slab
+        // (offset table: off[i+1]-off[i] = upper bound for such rows, 0 for rows that use LDS)
+        std::vector<long long> off((size_t)m + 1, 0);
+        for(aoclsparse_int i = 0; i < m; i++)
+        {
+            long long ub = 0;
+            for(aoclsparse_int p = X->ptr[i] - X->base; p < X->ptr[i + 1] - X->base; p++)
+            {
+                const aoclsparse_int c = X->ind[p] - X->base;
+                ub += Y->ptr[c + 1] - Y->ptr[c];
+            }
+            off[i + 1] = off[i] + (ub > 1024 ? ub : 0);
+        }
+        const long long slab_total = off[m];
+        DeviceBuffer d_xp, d_xi, d_xv, d_yp, d_yi, d_yv, d_off, d_slab_i, d_slab_v, d_cnt, d_cptr, d_ci, d_cv;
+        hipStream_t  s = rt.stream();
+        const bool   count = request != aoclsparse_stage_finalize, fill = request != aoclsparse_stage_nnz_count;
+        st = d_xp.upload(X->ptr, sizeof(aoclsparse_int) * ((size_t)X->m + 1), s);
+        if(st == aoclsparse_status_success)
+            st = d_xi.upload(X->ind, sizeof(aoclsparse_int) * (size_t)X->nnz, s);
+        if(st == aoclsparse_status_success)
+            st = d_yp.upload(Y->ptr, sizeof(aoclsparse_int) * ((size_t)Y->m + 1), s);
+        if(st == aoclsparse_status_success)
+            st = d_yi.upload(Y->ind, sizeof(aoclsparse_int) * (size_t)Y->nnz, s);
+        if(st == aoclsparse_status_success)
+            st = d_off.upload(off.data(), sizeof(long long) * ((size_t)m + 1), s);
+        if(st == aoclsparse_status_success)
+            st = d_slab_i.alloc(sizeof(int) * (size_t)std::max<long long>(slab_total, 1));
+        if(st != aoclsparse_status_success)
+            return st;
+
+        if(count)
+        {
+            st = d_cnt.alloc(sizeof(aoclsparse_int) * (size_t)m);
+            if(st != aoclsparse_status_success)
+                return st;
+            st = launch_spgemm<T>(s, false, m, X->base, d_xp.as<aoclsparse_int>(), d_xi.as<aoclsparse_int>(),
+                                  nullptr, Y->base, d_yp.as<aoclsparse_int>(), d_yi.as<aoclsparse_int>(), nullptr,
+                                  d_off.as<long long>(), d_slab_i.as<int>(), nullptr, nullptr,
+                                  d_cnt.as<aoclsparse_int>(), nullptr);
+            if(st != aoclsparse_status_success)
+                return st;
+            std::vector<aoclsparse_int> cptr((size_t)m + 1, 0);
+            MI355_HIP_TRY(hipMemcpyAsync(cptr.data() + 1, d_cnt.ptr, sizeof(aoclsparse_int) * (size_t)m,
+                                         hipMemcpyDeviceToHost, s));
+            MI355_HIP_TRY(hipStreamSynchronize(s));
+            long long run = 0; // 64-bit prefix sum, overflow -> invalid_size (csr2m.cpp:221-236)
+            for(aoclsparse_int i = 1; i <= m; i++)
+            {
+                run += cptr[i];
+                cptr[i] = (aoclsparse_int)run;
+            }
+            if(run > 2147483647LL)
+                return aoclsparse_status_invalid_size;
+            const aoclsparse_int nnz_c = (aoclsparse_int)run;
+            if(opflag == 3)
+            {
+                // C is n x m; keep D's row_ptr in the handle's transposed-product scratch until finalize
+                st = new_result(C, n, m, nnz_c, vt, nullptr);
+                if(st != aoclsparse_status_success)
+                    return st;
+                (*C)->trans.reset(new HostCsr);
+                HostCsr &d = *(*C)->trans;
+                d.m = m, d.n = n, d.nnz = nnz_c, d.base = aoclsparse_index_base_zero, d.owned = true;
+                d.ptr = new aoclsparse_int[(size_t)m + 1];
+                d.ind = new aoclsparse_int[(size_t)std::max(nnz_c, 1)];
+                d.val = ::operator new(sizeof(T) * (size_t)std::max(nnz_c, 1));
+                std::memcpy(d.ptr, cptr.data(), sizeof(aoclsparse_int) * ((size_t)m + 1));
+            }
+            else
+            {
+                st = new_result(C, m, n, nnz_c, vt, cptr.data());
+                if(st != aoclsparse_status_success)
+                    return st;
+            }
+        }
+        if(fill)
+        {
+            if(*C == nullptr)
+                return aoclsparse_status_invalid_pointer;
+            _aoclsparse_matrix *c = *C;
+            if(c->val_type != vt || !c->owns_user_arrays)
+                return aoclsparse_status_invalid_pointer;
+            HostCsr *d = opflag == 3 ? c->trans.get() : &c->user; // where the product D lands
+            if(!d || !d->ptr || !d->ind || !d->val)
+                return aoclsparse_status_invalid_pointer;
+            if(d->m != m || d->n != n)
+                return aoclsparse_status_invalid_size; // csr2m.cpp:397-399
+            const aoclsparse_int nnz_c = d->ptr[m];
+            st = d_xv.upload(X->val, sizeof(T) * (size_t)X->nnz, s);
+            if(st == aoclsparse_status_success)
+                st = d_yv.upload(Y->val, sizeof(T) * (size_t)Y->nnz, s);
+            if(st == aoclsparse_status_success)
+                st = d_slab_v.alloc(sizeof(T) * (size_t)std::max<long long>(slab_total, 1));
+            if(st == aoclsparse_status_success)
+                st = d_cptr.upload(d->ptr, sizeof(aoclsparse_int) * ((size_t)m + 1), s);
+            if(st == aoclsparse_status_success)
+                st = d_ci.alloc(sizeof(aoclsparse_int) * (size_t)std::max(nnz_c, 1));
+            if(st == aoclsparse_status_success)
+                st = d_cv.alloc(sizeof(T) * (size_t)std::max(nnz_c, 1));
+            if(st != aoclsparse_status_success)
+                return st;
+            st = launch_spgemm<T>(s, true, m, X->base, d_xp.as<aoclsparse_int>(), d_xi.as<aoclsparse_int>(),
+                                  d_xv.as<T>(), Y->base, d_yp.as<aoclsparse_int>(), d_yi.as<aoclsparse_int>(),
+                                  d_yv.as<T>(), d_off.as<long long>(), d_slab_i.as<int>(), d_slab_v.as<T>(),
+                                  d_cptr.as<aoclsparse_int>(), d_ci.as<aoclsparse_int>(), d_cv.as<T>());
+            if(st != aoclsparse_status_success)
+                return st;
+            MI355_HIP_TRY(hipMemcpyAsync(d->ind, d_ci.ptr, sizeof(aoclsparse_int) * (size_t)nnz_c,
+                                         hipMemcpyDeviceToHost, s));
+            MI355_HIP_TRY(hipMemcpyAsync(d->val, d_cv.ptr, sizeof(T) * (size_t)nnz_c, hipMemcpyDeviceToHost, s));
+            MI355_HIP_TRY(hipStreamSynchronize(s));
+            if(opflag == 3)
+            {
+                // C = D^T by the reference's counting-sort transpose (csr2m.cpp:520-538)
+                Operand<T> dv, dt;
+                dv.m = m, dv.n = n, dv.nnz = nnz_c, dv.base = 0;
+                dv.ptr = d->ptr, dv.ind = d->ind, dv.val = static_cast<const T *>(d->val);
+                transpose_of<T>(dv, dt);
+                std::memcpy(c->user.ptr, dt.optr.data(), sizeof(aoclsparse_int) * ((size_t)n + 1));
+                std::memcpy(c->user.ind, dt.oind.data(), sizeof(aoclsparse_int) * (size_t)nnz_c);
+                std::memcpy(c->user.val, dt.oval.data(), sizeof(T) * (size_t)nnz_c);
+            }
+        }
+    }
+    catch(const std::bad_alloc &)
+    {
+        return aoclsparse_status_memory_error;
+    }
+    return aoclsparse_status_success;
+}
+
+aoclsparse_status sp2m_any(aoclsparse_operation opA, const aoclsparse_mat_descr descrA, const aoclsparse_matrix A,
+                           aoclsparse_operation opB, const aoclsparse_mat_descr descrB, const aoclsparse_matrix B,
+                           aoclsparse_request request, aoclsparse_matrix *C)
+{
+    // level3/aoclsparse_sp2m.cpp:27-50 dispatches on A's value type
+    if(!A || !B || !C || !descrA || !descrB)
+        return aoclsparse_status_invalid_pointer;
+    if(A->val_type == aoclsparse_dmat)
+        return sp2m_t<double>(opA, descrA, A, opB, descrB, B, request, C, aoclsparse_dmat);
+    if(A->val_type == aoclsparse_smat)
+        return sp2m_t<float>(opA, descrA, A, opB, descrB, B, request, C, aoclsparse_smat);
     return aoclsparse_status_not_implemented;
 }
+
 } // namespace
 
 extern "C" {
@@ -50,7 +331,7 @@ aoclsparse_status aoclsparse_sp2m(aoclsparse_operation opA, const aoclsparse_mat
                                   const aoclsparse_mat_descr descrB, const aoclsparse_matrix B,
                                   const aoclsparse_request request, aoclsparse_matrix *C)
 {
-    return sp2m_checks(opA, descrA, A, opB, descrB, B, request, C);
+    return sp2m_any(opA, descrA, A, opB, descrB, B, request, C);
 }
 
 aoclsparse_status aoclsparse_spmm(aoclsparse_operation opA, const aoclsparse_matrix A,
@@ -62,7 +343,7 @@ aoclsparse_status aoclsparse_spmm(aoclsparse_operation opA, const aoclsparse_mat
     _aoclsparse_mat_descr dA, dB;
     dA.base = A->base;
     dB.base = B->base;
-    return sp2m_checks(opA, &dA, A, aoclsparse_operation_none, &dB, B, aoclsparse_stage_full_computation, C);
+    return sp2m_any(opA, &dA, A, aoclsparse_operation_none, &dB, B, aoclsparse_stage_full_computation, C);
 }
 
 aoclsparse_status aoclsparse_dcsr2m(aoclsparse_operation trans_A, const aoclsparse_mat_descr descrA,
@@ -70,9 +351,9 @@ aoclsparse_status aoclsparse_dcsr2m(aoclsparse_operation trans_A, const aoclspar
                                     const aoclsparse_mat_descr descrB, const aoclsparse_matrix csrB,
                                     const aoclsparse_request request, aoclsparse_matrix *csrC)
 {
-    if(csrA && csrA->val_type != aoclsparse_dmat)
-        return aoclsparse_status_wrong_type;
-    return sp2m_checks(trans_A, descrA, csrA, trans_B, descrB, csrB, request, csrC);
+    if(!descrA || !descrB || !csrA || !csrB || !csrC)
+        return aoclsparse_status_invalid_pointer;
+    return sp2m_t<double>(trans_A, descrA, csrA, trans_B, descrB, csrB, request, csrC, aoclsparse_dmat);
 }
 
 aoclsparse_status aoclsparse_scsr2m(aoclsparse_operation trans_A, const aoclsparse_mat_descr descrA,
@@ -80,9 +361,9 @@ aoclsparse_status aoclsparse_scsr2m(aoclsparse_operation trans_A, const aoclspar
                                     const aoclsparse_mat_descr descrB, const aoclsparse_matrix csrB,
                                     const aoclsparse_request request, aoclsparse_matrix *csrC)
 {
-    if(csrA && csrA->val_type != aoclsparse_smat)
-        return aoclsparse_status_wrong_type;
-    return sp2m_checks(trans_A, descrA, csrA, trans_B, descrB, csrB, request, csrC);
+    if(!descrA || !descrB || !csrA || !csrB || !csrC)
+        return aoclsparse_status_invalid_pointer;
+    return sp2m_t<float>(trans_A, descrA, csrA, trans_B, descrB, csrB, request, csrC, aoclsparse_smat);
 }
 
 } // extern "C"

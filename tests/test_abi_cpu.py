@@ -250,11 +250,28 @@ def test_argument_checks_that_precede_any_device_work():
     assert mm(111, 1.0, A.h, d.h, 0, P._ptr(B), 0, 6, 0.0, P._ptr(C), 6) == 0   # n == 0 quick return
     assert L.aoclsparse_scsrmm(111, 1.0, A.h, d.h, 0, P._ptr(B), 6, 6, 0.0, P._ptr(C), 6) == 9
     assert mm(111, 1.0, A.h, d.h, 0, P._ptr(B), 6, 2 ** 30, 0.0, P._ptr(C), 6) == 3  # dim*ld overflows int32
-    # sp2m family: checks run, product itself not implemented in round 1
+    # sp2m family (csr2m.cpp:592-740): checks first; a valid product needs the GPU
     Cc = ctypes.c_void_p()
     assert L.aoclsparse_sp2m(111, d.h, A.h, 111, d.h, None, 2, ctypes.byref(Cc)) == 2
-    assert L.aoclsparse_sp2m(111, d.h, A.h, 111, d.h, R.h, 2, ctypes.byref(Cc)) == 1
+    assert L.aoclsparse_sp2m(111, None, A.h, 111, d.h, A.h, 2, ctypes.byref(Cc)) == 2
     assert L.aoclsparse_sp2m(111, d.h, R.h, 111, d.h, A.h, 2, ctypes.byref(Cc)) == 3  # 6x7 times 6x6
+    assert L.aoclsparse_sp2m(114, d.h, A.h, 111, d.h, A.h, 2, ctypes.byref(Cc)) == 5
+    assert L.aoclsparse_sp2m(111, d1.h, A.h, 111, d.h, A.h, 2, ctypes.byref(Cc)) == 5  # base mismatch
+    assert L.aoclsparse_sp2m(111, dt.h, A.h, 111, d.h, A.h, 2, ctypes.byref(Cc)) == 1  # general only
+    assert L.aoclsparse_scsr2m(111, d.h, A.h, 111, d.h, A.h, 2, ctypes.byref(Cc)) == 9
+    assert L.aoclsparse_sp2m(111, d.h, A.h, 111, d.h, R.h, 2, ctypes.byref(Cc)) in (0, 4)  # 4: no HIP device here
+    # empty product: an empty C is still allocated (csr2m.cpp:705-735), no device needed
+    E = P.Matrix(0, 6, 6, np.zeros(7, np.int32), np.zeros(1, np.int32), np.zeros(1))
+    E.nnz = 0
+    Eh = ctypes.c_void_p()
+    assert L.aoclsparse_create_dcsr(ctypes.byref(Eh), 0, 6, 6, 0, P._ptr(E.row_ptr), P._ptr(E.col_ind), P._ptr(E.val)) == 0
+    assert L.aoclsparse_sp2m(111, d.h, Eh, 111, d.h, A.h, 2, ctypes.byref(Cc)) == 0 and Cc.value
+    base, mm_, nn_, nz = ctypes.c_int(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    a, b, c = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    assert L.aoclsparse_export_dcsr(Cc, ctypes.byref(base), ctypes.byref(mm_), ctypes.byref(nn_), ctypes.byref(nz),
+                                    ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) == 0
+    assert (mm_.value, nn_.value, nz.value, base.value) == (6, 6, 0, 0)
+    assert L.aoclsparse_destroy(ctypes.byref(Cc)) == 0 and L.aoclsparse_destroy(ctypes.byref(Eh)) == 0
 
 
 def test_row_block_planner_properties():

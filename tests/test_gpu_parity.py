@@ -594,3 +594,111 @@ def test_symmetric_csrmm():
     ref = 2.0 * (M @ B.reshape(m, n)) + 0.5 * C0.reshape(m, n)
     scale = 2.0 * (np.abs(M) @ np.abs(B.reshape(m, n))) + np.abs(0.5 * C0.reshape(m, n))
     assert np.all(np.abs(C.reshape(m, n) - ref) <= 40 * EPS64 * scale + 1e-300)
+
+
+# --------------------------------------------------------------------------------------------------
+# sp2m / spmm / csr2m (spgemm_kernels.hip): structure AND values bit-identical to the reference's
+# two-stage Gustavson (first-touch column order, accumulation in visit order)
+# --------------------------------------------------------------------------------------------------
+def _export(h, double=True):
+    base, m, n, nnz = ctypes.c_int(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    rp, ci, v = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    fn = L.aoclsparse_export_dcsr if double else L.aoclsparse_export_scsr
+    st = fn(h, ctypes.byref(base), ctypes.byref(m), ctypes.byref(n), ctypes.byref(nnz), ctypes.byref(rp),
+            ctypes.byref(ci), ctypes.byref(v))
+    assert st == 0
+    ct = ctypes.c_double if double else ctypes.c_float
+    k = max(nnz.value, 1)
+    row = np.ctypeslib.as_array(ctypes.cast(rp, ctypes.POINTER(ctypes.c_int32)), (m.value + 1,)).copy()
+    col = np.ctypeslib.as_array(ctypes.cast(ci, ctypes.POINTER(ctypes.c_int32)), (k,))[: nnz.value].copy()
+    val = np.ctypeslib.as_array(ctypes.cast(v, ctypes.POINTER(ct)), (k,))[: nnz.value].copy()
+    return base.value, m.value, n.value, nnz.value, row, col, val
+
+
+@pytest.mark.parametrize("base_a,base_b", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_sp2m_bit_exact_vs_oracle(base_a, base_b):
+    m, k, n = 3000, 2500, 2800
+    pa, ia, va = random_csr(201, m, k, lambda r, i: r.integers(0, 9), base=base_a)
+    pb, ib, vb = random_csr(202, k, n, lambda r, i: r.integers(0, 9), base=base_b)
+    A, B = P.Matrix(base_a, m, k, pa, ia, va), P.Matrix(base_b, k, n, pb, ib, vb)
+    dA, dB = P.Descr(base=base_a), P.Descr(base=base_b)
+    so, pc, ic, vc = oracle.dcsr2m(m, n, base_a, pa, ia, va, base_b, pb, ib, vb)
+    assert so == 0
+    # full computation
+    C = ctypes.c_void_p()
+    assert L.aoclsparse_sp2m(P.OP_NONE, dA.h, A.h, P.OP_NONE, dB.h, B.h, P.STAGE_FULL, ctypes.byref(C)) == 0
+    b, cm, cn, cz, row, col, val = _export(C)
+    assert (b, cm, cn, cz) == (0, m, n, len(ic))
+    assert np.array_equal(row, pc) and np.array_equal(col, ic) and np.array_equal(val, vc)
+    assert L.aoclsparse_destroy(ctypes.byref(C)) == 0
+    # two-stage protocol: count allocates + fills row_ptr, finalize fills the same handle
+    C = ctypes.c_void_p()
+    assert L.aoclsparse_dcsr2m(P.OP_NONE, dA.h, A.h, P.OP_NONE, dB.h, B.h, P.STAGE_NNZ_COUNT, ctypes.byref(C)) == 0
+    h0 = C.value
+    b, cm, cn, cz, row, _, _ = _export(C)
+    assert cz == len(ic) and np.array_equal(row, pc)
+    assert L.aoclsparse_dcsr2m(P.OP_NONE, dA.h, A.h, P.OP_NONE, dB.h, B.h, P.STAGE_FINALIZE, ctypes.byref(C)) == 0
+    assert C.value == h0
+    _, _, _, _, row, col, val = _export(C)
+    assert np.array_equal(col, ic) and np.array_equal(val, vc)
+    assert L.aoclsparse_destroy(ctypes.byref(C)) == 0
+
+
+def test_sp2m_transposes_and_long_rows():
+    """op(A), op(B) in {N, T}; one operand row long enough (upper bound > 1024) for the global-slab path."""
+    m, k, n = 400, 350, 500
+    pa, ia, va = random_csr(211, m, k, lambda r, i: 300 if i == 7 else r.integers(0, 7))
+    pb, ib, vb = random_csr(212, k, n, lambda r, i: r.integers(0, 12))
+    A, B = P.Matrix(0, m, k, pa, ia, va), P.Matrix(0, k, n, pb, ib, vb)
+    d = P.Descr()
+    DA, DB = _dense(m, k, pa, ia, va), _dense(k, n, pb, ib, vb)
+    so, pc, ic, vc = oracle.dcsr2m(m, n, 0, pa, ia, va, 0, pb, ib, vb)
+    C = ctypes.c_void_p()
+    assert L.aoclsparse_spmm(P.OP_NONE, A.h, B.h, ctypes.byref(C)) == 0
+    _, _, _, cz, row, col, val = _export(C)
+    assert np.array_equal(row, pc) and np.array_equal(col, ic) and np.array_equal(val, vc)
+    assert np.max(np.diff(pc)) > 0 and (pa[8] - pa[7]) == 300
+    L.aoclsparse_destroy(ctypes.byref(C))
+    # A^T * B2, A * B3^T, A^T * B4^T against dense products and the oracle on explicit transposes
+    st, tp, ti, tv = oracle.dcsr2csc(m, k, len(va), 0, 0, pa, ia, va)  # A^T as CSR (k x m)
+    pb2, ib2, vb2 = random_csr(213, m, n, lambda r, i: r.integers(0, 10))
+    B2 = P.Matrix(0, m, n, pb2, ib2, vb2)
+    assert L.aoclsparse_sp2m(P.OP_TRANSPOSE, d.h, A.h, P.OP_NONE, d.h, B2.h, P.STAGE_FULL, ctypes.byref(C)) == 0
+    _, cm, cn, cz, row, col, val = _export(C)
+    so, pc, ic, vc = oracle.dcsr2m(k, n, 0, tp, ti, tv, 0, pb2, ib2, vb2)
+    assert (cm, cn) == (k, n) and np.array_equal(row, pc) and np.array_equal(col, ic) and np.array_equal(val, vc)
+    L.aoclsparse_destroy(ctypes.byref(C))
+    pb3, ib3, vb3 = random_csr(214, n, k, lambda r, i: r.integers(0, 10))
+    B3 = P.Matrix(0, n, k, pb3, ib3, vb3)
+    assert L.aoclsparse_sp2m(P.OP_NONE, d.h, A.h, P.OP_TRANSPOSE, d.h, B3.h, P.STAGE_FULL, ctypes.byref(C)) == 0
+    _, cm, cn, cz, row, col, val = _export(C)
+    assert (cm, cn) == (m, n)
+    assert np.allclose(_dense(cm, cn, row, col, val), DA @ _dense(n, k, pb3, ib3, vb3).T, atol=1e-12)
+    L.aoclsparse_destroy(ctypes.byref(C))
+    pb4, ib4, vb4 = random_csr(215, n, m, lambda r, i: r.integers(0, 10))
+    B4 = P.Matrix(0, n, m, pb4, ib4, vb4)
+    assert L.aoclsparse_sp2m(P.OP_TRANSPOSE, d.h, A.h, P.OP_TRANSPOSE, d.h, B4.h, P.STAGE_FULL, ctypes.byref(C)) == 0
+    _, cm, cn, cz, row, col, val = _export(C)
+    assert (cm, cn) == (k, n)
+    assert np.allclose(_dense(cm, cn, row, col, val), DA.T @ _dense(n, m, pb4, ib4, vb4).T, atol=1e-12)
+    assert all(np.all(np.diff(col[row[i]:row[i + 1]]) > 0) for i in range(cm))  # transposed back: sorted rows
+    L.aoclsparse_destroy(ctypes.byref(C))
+
+
+def test_sp2m_laplacian_squared_and_float():
+    """A*A on L100 has 128,004 non-zeros."""
+    m, rp, ci, v = laplace5(100)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    d = P.Descr()
+    C = ctypes.c_void_p()
+    assert L.aoclsparse_sp2m(P.OP_NONE, d.h, A.h, P.OP_NONE, d.h, A.h, P.STAGE_FULL, ctypes.byref(C)) == 0
+    _, cm, cn, cz, row, col, val = _export(C)
+    assert cz == 128004
+    so, pc, ic, vc = oracle.dcsr2m(m, m, 0, rp, ci, v, 0, rp, ci, v)
+    assert np.array_equal(row, pc) and np.array_equal(col, ic) and np.array_equal(val, vc)
+    L.aoclsparse_destroy(ctypes.byref(C))
+    Af = P.Matrix(0, m, m, rp, ci, v.astype(np.float32))
+    assert L.aoclsparse_scsr2m(P.OP_NONE, d.h, Af.h, P.OP_NONE, d.h, Af.h, P.STAGE_FULL, ctypes.byref(C)) == 0
+    _, _, _, cz, row, col, val = _export(C, double=False)
+    assert cz == 128004 and np.array_equal(col, ic) and np.array_equal(val, vc.astype(np.float32))
+    L.aoclsparse_destroy(ctypes.byref(C))
