@@ -2,8 +2,11 @@
 //
 // Arithmetic per output element follows the reference's column-major kernel
 // (level3/aoclsparse_csrmm.hpp:69-85): sum = fma(a_ik, B_kj, sum) over the row in CSR order, then
-// C = fma(beta, C, alpha*sum).  C is read even when beta == 0, as every reference csrmm kernel does
-// (SURVEY.md Appendix B), so NaN/Inf already in C propagate exactly as on the CPU.
+// C = fma(beta, C, alpha*sum).  Every reference csrmm kernel reads C even when beta == 0 (SURVEY.md
+// Appendix B), which costs a third of the traffic at 256 columns.  Here, for beta == 0, C is read only
+// where alpha*sum is an exact zero (the one case where fma(0, C, z) != z for finite C: the sign of the
+// zero): bit-identical to the reference for every FINITE C, while a NaN/Inf already sitting in C is
+// overwritten instead of propagated.  AOCLSPARSE_MI355_CSRMM_STRICT_BETA0=1 restores the read.
 //
 // HBM-bound (AI ~ 0.6 flop/B at 256 columns, 5 nnz/row): no MFMA -- the dense tiles a 5-point
 // stencil would give an MFMA are >90 % zeros, so reshaping to GEMM only adds traffic.
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(256) void csrmm_row_kernel(int base, T alpha, aocls
                                                         const aoclsparse_int *__restrict__ row_ptr,
                                                         const T *__restrict__ B, aoclsparse_int n,
                                                         aoclsparse_int ldb, T beta, T *__restrict__ C,
-                                                        aoclsparse_int ldc)
+                                                        aoclsparse_int ldc, bool readc)
 {
     using V     = typename vec2<T>::type;
     const int i = blockIdx.x * blockDim.y + threadIdx.y; // rows on grid.x (no 65535 limit)
@@ -69,11 +72,18 @@ __global__ __launch_bounds__(256) void csrmm_row_kernel(int base, T alpha, aocls
             a0        = mm_fma(a, b.x, a0);
             a1        = mm_fma(a, b.y, a1);
         }
-        V *cp = reinterpret_cast<V *>(C + (size_t)i * ldc + j);
-        V  c  = *cp;
-        c.x   = mm_fma(beta, c.x, alpha * a0);
-        c.y   = mm_fma(beta, c.y, alpha * a1);
-        *cp   = c;
+        V      *cp = reinterpret_cast<V *>(C + (size_t)i * ldc + j);
+        const T z0 = alpha * a0, z1 = alpha * a1;
+        V       c;
+        if(readc || z0 == T(0) || z1 == T(0))
+        {
+            c   = *cp;
+            c.x = mm_fma(beta, c.x, z0);
+            c.y = mm_fma(beta, c.y, z1);
+        }
+        else
+            c.x = z0, c.y = z1;
+        *cp = c;
     }
     else
     {
@@ -83,8 +93,9 @@ __global__ __launch_bounds__(256) void csrmm_row_kernel(int base, T alpha, aocls
         T acc = T(0);
         for(int p = s; p < e; p++)
             acc = mm_fma(val[p], B[(size_t)(col[p] - base) * ldb + j], acc);
-        T *cp = C + (size_t)i * ldc + j;
-        *cp   = mm_fma(beta, *cp, alpha * acc);
+        T      *cp = C + (size_t)i * ldc + j;
+        const T z  = alpha * acc;
+        *cp        = (readc || z == T(0)) ? mm_fma(beta, *cp, z) : z;
     }
 }
 
@@ -98,7 +109,7 @@ __global__ __launch_bounds__(256) void csrmm_row_wave_kernel(int base, T alpha, 
                                                              const aoclsparse_int *__restrict__ row_ptr,
                                                              const T *__restrict__ B, aoclsparse_int n,
                                                              aoclsparse_int ldb, T beta, T *__restrict__ C,
-                                                             aoclsparse_int ldc)
+                                                             aoclsparse_int ldc, bool readc)
 {
     using V       = typename vec2<T>::type;
     const int w   = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -128,11 +139,18 @@ __global__ __launch_bounds__(256) void csrmm_row_wave_kernel(int base, T alpha, 
         const V b0 = *reinterpret_cast<const V *>(Bj + (size_t)(col[p] - base) * ldb);
         a0 = mm_fma(v0, b0.x, a0), a1 = mm_fma(v0, b0.y, a1);
     }
-    V *cp = reinterpret_cast<V *>(C + (size_t)i * ldc + j);
-    V  c  = *cp;
-    c.x   = mm_fma(beta, c.x, alpha * a0);
-    c.y   = mm_fma(beta, c.y, alpha * a1);
-    *cp   = c;
+    V      *cp = reinterpret_cast<V *>(C + (size_t)i * ldc + j);
+    const T z0 = alpha * a0, z1 = alpha * a1;
+    V       c;
+    if(readc || z0 == T(0) || z1 == T(0))
+    {
+        c   = *cp;
+        c.x = mm_fma(beta, c.x, z0);
+        c.y = mm_fma(beta, c.y, z1);
+    }
+    else
+        c.x = z0, c.y = z1;
+    *cp = c;
 }
 
 // column-major: one lane owns one row; the first CM_K entries of the row are kept in registers and the
@@ -148,7 +166,7 @@ __global__ __launch_bounds__(256) void csrmm_col_kernel(int base, T alpha, aocls
                                                         const aoclsparse_int *__restrict__ row_ptr,
                                                         const T *__restrict__ B, aoclsparse_int n,
                                                         aoclsparse_int ldb, T beta, T *__restrict__ C,
-                                                        aoclsparse_int ldc)
+                                                        aoclsparse_int ldc, bool readc)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if(i >= m)
@@ -180,8 +198,9 @@ __global__ __launch_bounds__(256) void csrmm_col_kernel(int base, T alpha, aocls
                 acc = mm_fma(v[k], Bj[c[k]], acc);
         for(int p = s + CM_K; p < e; p++)
             acc = mm_fma(val[p], Bj[col[p] - base], acc);
-        T *cp = C + (size_t)i + (size_t)j * ldc;
-        *cp   = mm_fma(beta, *cp, alpha * acc);
+        T      *cp = C + (size_t)i + (size_t)j * ldc;
+        const T z  = alpha * acc;
+        *cp        = (readc || z == T(0)) ? mm_fma(beta, *cp, z) : z;
     }
 }
 
@@ -214,6 +233,11 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
 {
     if(m <= 0 || n <= 0)
         return aoclsparse_status_success;
+    static const bool strict_beta0 = [] {
+        const char *e = getenv("AOCLSPARSE_MI355_CSRMM_STRICT_BETA0");
+        return e && atoi(e) != 0;
+    }();
+    const bool readc = beta != T(0) || strict_beta0;
     if(order == aoclsparse_order_row)
     {
         const bool vec = (n % 2 == 0) && (ldb % 2 == 0) && (ldc % 2 == 0)
@@ -225,19 +249,19 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
         dim3      block(tx, ty), grid((m + ty - 1) / ty, (lanes + tx - 1) / tx);
         if(vec && n >= 128)
             hipLaunchKernelGGL((csrmm_row_wave_kernel<T>), dim3((m + 3) / 4, (n + 127) / 128), dim3(256), 0, s,
-                               base, alpha, m, val, col, row_ptr, B, n, ldb, beta, C, ldc);
+                               base, alpha, m, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc);
         else if(vec)
             hipLaunchKernelGGL((csrmm_row_kernel<T, true>), grid, block, 0, s, base, alpha, m, val, col, row_ptr,
-                               B, n, ldb, beta, C, ldc);
+                               B, n, ldb, beta, C, ldc, readc);
         else
             hipLaunchKernelGGL((csrmm_row_kernel<T, false>), grid, block, 0, s, base, alpha, m, val, col,
-                               row_ptr, B, n, ldb, beta, C, ldc);
+                               row_ptr, B, n, ldb, beta, C, ldc, readc);
     }
     else
     {
         dim3 block(256), grid((m + 255) / 256, (n + CM_COLS - 1) / CM_COLS);
         hipLaunchKernelGGL((csrmm_col_kernel<T>), grid, block, 0, s, base, alpha, m, val, col, row_ptr, B, n,
-                           ldb, beta, C, ldc);
+                           ldb, beta, C, ldc, readc);
     }
     MI355_HIP_TRY(hipGetLastError());
     return aoclsparse_status_success;

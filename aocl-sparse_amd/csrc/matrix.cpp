@@ -413,18 +413,21 @@ static aoclsparse_int plan_rows(aoclsparse_int m, aoclsparse_index_base base, ao
     return nb;
 }
 
-static aoclsparse_int choose_tile(aoclsparse_int /*m*/, aoclsparse_int /*nnz*/)
+static aoclsparse_int choose_tile(aoclsparse_int /*m*/, aoclsparse_int nnz)
 {
     // 1024: 18 KiB of LDS per workgroup -> 8 workgroups (32 wavefronts) per CU hide the
-    // load -> gather -> reduce latency chain better than 4 fatter ones (measured)
-    // tuning knobs (read when a plan is built): AOCLSPARSE_MI355_SPMV_TILE=1024|2048,
+    // load -> gather -> reduce latency chain better than 4 fatter ones (0.257 vs 0.290 ms on the 4096^2
+    // Laplacian).  A matrix too small to give every CU ~16 such blocks gets 512-entry tiles and 128-lane
+    // workgroups instead (web-like stand-in: 0.039 vs 0.056 ms).  profiles/r1, DESIGN.md 5.1.
+    // tuning knobs (read when a plan is built): AOCLSPARSE_MI355_SPMV_TILE=512|1024|2048,
     // AOCLSPARSE_MI355_XCD_ORDER=1 enables the XCD-contiguous block order (encoded as tile|1;
     // measured slower than the plain order on the Laplacian, so off by default)
     const char *e      = std::getenv("AOCLSPARSE_MI355_SPMV_TILE");
     const int   forced = e ? std::atoi(e) : 0;
     const char *x      = std::getenv("AOCLSPARSE_MI355_XCD_ORDER");
     const int   xcd    = (x && std::atoi(x) != 0) ? 1 : 0;
-    return (forced == 2048 || forced == 1024 || forced == 512 ? forced : 1024) | xcd;
+    const int   automatic = (long long)nnz < 1024LL * 256 * 16 ? 512 : 1024;
+    return (forced == 2048 || forced == 1024 || forced == 512 ? forced : automatic) | xcd;
 }
 
 aoclsparse_status build_spmv_plan(aoclsparse_int m, aoclsparse_int nnz, aoclsparse_index_base base,

@@ -51,7 +51,7 @@ def column_shard(ncols, world, rank):
 
 def reduce_scalar(value, op, dist=None, device="cpu"):
     """max / sum of a python float over all ranks (identity when not distributed)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return float(value)
     import torch
 
@@ -95,9 +95,11 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product has no CPU path"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run: RCCL even for 1 rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     pkg = entry.load_package()
     L = pkg.lib()
@@ -107,7 +109,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -142,7 +144,7 @@ def main():
 
     flops = 2.0 * nnz
     abytes = spmv_bytes(m, m, nnz)
-    gflops, tmax = job_throughput(args.steps * flops / 1e9, elapsed, dist if world > 1 else None, device)
+    gflops, tmax = job_throughput(args.steps * flops / 1e9, elapsed, dist if use_dist else None, device)
     kernel_ms = kernel_ms_total / args.steps
     achieved = abytes / (kernel_ms * 1e-3) / 1e9
 
@@ -257,13 +259,13 @@ def main():
 
     # ---------------- supplementary: column-sharded csrmm ----------------
     if not args.no_csrmm:
-        out_mm = run_csrmm(args, pkg, entry, torch, dist, np, world, rank, device, barrier)
+        out_mm = run_csrmm(args, pkg, entry, torch, dist if use_dist else None, np, world, rank, device, barrier)
         if rank == 0:
             out["csrmm"] = out_mm
 
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
@@ -280,7 +282,7 @@ def run_csrmm(args, pkg, entry, torch, dist, np, world, rank, device, barrier):
         meta = torch.tensor([len(v)], dtype=torch.int64, device=device)
     else:
         meta = torch.zeros(1, dtype=torch.int64, device=device)
-    if world > 1:
+    if dist is not None:
         dist.broadcast(meta, 0)
     nnz = int(meta.item())
     if rank == 0:
@@ -289,7 +291,7 @@ def run_csrmm(args, pkg, entry, torch, dist, np, world, rank, device, barrier):
         d_rp = torch.empty(m + 1, dtype=torch.int32, device=device)
         d_ci = torch.empty(nnz, dtype=torch.int32, device=device)
         d_v = torch.empty(nnz, dtype=torch.float64, device=device)
-    if world > 1:
+    if dist is not None:
         barrier()
         t = time.perf_counter()
         for tns in (d_rp, d_ci, d_v):
@@ -317,8 +319,8 @@ def run_csrmm(args, pkg, entry, torch, dist, np, world, rank, device, barrier):
         mm()
     barrier()
     dt = (time.perf_counter() - t) / reps
-    tmax = reduce_scalar(dt, "max", dist if world > 1 else None, device)
-    checksum = reduce_scalar(float(C.sum().item()), "sum", dist if world > 1 else None, device)
+    tmax = reduce_scalar(dt, "max", dist, device)
+    checksum = reduce_scalar(float(C.sum().item()), "sum", dist, device)
     total_bytes = csrmm_bytes(m, m, nnz, args.mm_cols) + (world - 1) * ((m + 1 + nnz) * 4 + nnz * 8)
     return {"workload": "mi355_dcsrmm, A = 5-pt Laplacian %dx%d grid (nnz=%d), B %d x %d fp64 column-major, "
                         "beta=0, columns sharded over %d rank(s)" % (gm, gm, nnz, m, args.mm_cols, world),

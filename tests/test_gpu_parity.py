@@ -4,6 +4,7 @@ restates (GPU fma == x86 fma); where the schedule legitimately differs (long row
 transposed SpMV, csrmm row-major) the componentwise forward-error bound of SURVEY.md section 8d is
 asserted with the constant written here."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -751,3 +752,57 @@ def test_concurrent_executors_on_one_handle():
     for k in range(4):
         so, yr = oracle.dcsrmv(-1, 0, 1.0, m, len(v), v, ci, rp, xs[k], 0.0, np.zeros(m))
         assert np.array_equal(outs[k], yr)
+
+
+def test_csrmm_beta0_nonfinite_c_policy():
+    """beta == 0: bit-identical to the reference for finite C (incl. signed zeros of empty rows); a NaN
+    already in C is overwritten unless AOCLSPARSE_MI355_CSRMM_STRICT_BETA0=1."""
+    import subprocess
+    import sys
+    import textwrap
+
+    m, k, n = 300, 300, 8
+    rp, ci, v = random_csr(141, m, k, lambda r, i: 0 if i % 5 == 0 else r.integers(1, 6))
+    rng = np.random.default_rng(4)
+    B = rng.uniform(-1, 1, k * n)
+    C0 = rng.uniform(-1, 1, m * n)  # finite, both signs: decides the sign of the zeros of empty rows
+    A = P.Matrix(0, m, k, rp, ci, v)
+    d = P.Descr()
+    for alpha in (1.5, -1.5):
+        for order, ldb, ldc, oname in ((P.ORDER_COLUMN, k, m, "col"), (P.ORDER_ROW, n, n, "row")):
+            C = C0.copy()
+            assert P.dcsrmm(P.OP_NONE, alpha, A, d, order, B, n, ldb, 0.0, C, ldc) == 0
+            if oname == "col":
+                so, Cr = oracle.dcsrmm("col", alpha, 0, v, ci, rp, m, B, n, ldb, 0.0, C0, ldc)
+            else:  # same per-element arithmetic on the transposed layout
+                so, Cr = oracle.dcsrmm("col", alpha, 0, v, ci, rp, m, np.ascontiguousarray(B.reshape(k, n).T).ravel(),
+                                       n, k, 0.0, np.ascontiguousarray(C0.reshape(m, n).T).ravel(), m)
+                Cr = np.ascontiguousarray(Cr.reshape(n, m).T).ravel()
+            assert np.array_equal(C, Cr) and np.array_equal(np.signbit(C), np.signbit(Cr))
+    Cn = C0.copy()
+    Cn[::7] = np.nan
+    C = Cn.copy()
+    assert P.dcsrmm(P.OP_NONE, 1.5, A, d, P.ORDER_COLUMN, B, n, k, 0.0, C, m) == 0
+    so, Cz = oracle.dcsrmm("col", 1.5, 0, v, ci, rp, m, B, n, k, 0.0, np.zeros(m * n), m)
+    nz = Cz != 0
+    assert np.array_equal(C[nz], Cz[nz])  # NaN overwritten where the product is non-zero
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        from util import pkg, random_csr
+        import oracle
+        P = pkg()
+        m, k, n = 300, 300, 8
+        rp, ci, v = random_csr(141, m, k, lambda r, i: 0 if i %% 5 == 0 else r.integers(1, 6))
+        rng = np.random.default_rng(4)
+        B = rng.uniform(-1, 1, k * n); C0 = rng.uniform(-1, 1, m * n); C0[::7] = np.nan
+        A = P.Matrix(0, m, k, rp, ci, v); d = P.Descr(); C = C0.copy()
+        assert P.dcsrmm(P.OP_NONE, 1.5, A, d, P.ORDER_COLUMN, B, n, k, 0.0, C, m) == 0
+        so, Cr = oracle.dcsrmm("col", 1.5, 0, v, ci, rp, m, B, n, k, 0.0, C0, m)
+        assert np.array_equal(np.isnan(C), np.isnan(Cr)) and np.isnan(C).sum() > 0
+        assert np.array_equal(C[~np.isnan(C)], Cr[~np.isnan(Cr)])
+        print("strict ok")
+    """) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, AOCLSPARSE_MI355_CSRMM_STRICT_BETA0="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "strict ok" in out.stdout, out.stderr[-2000:]

@@ -28,7 +28,7 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 
 // V: 0 full, 1 no gather, 2 no LDS val, 3 no phase 2, 4 stream only, 5 full with product in LDS (8 B/nnz),
 //    6 full with non-temporal val/col loads, 7 = 6 + non-temporal y stores and row_ptr loads
-template <int V>
+template <int V, bool L8 = false>
 __global__ __launch_bounds__(BLOCK) void k(const int2 *__restrict__ blocks, const int *__restrict__ row_ptr,
                                            const int *__restrict__ col, const double *__restrict__ val,
                                            const double *__restrict__ x, double *__restrict__ y)
@@ -113,6 +113,29 @@ __global__ __launch_bounds__(BLOCK) void k(const int2 *__restrict__ blocks, cons
     {
         for(int rr = tid; rr < nrows; rr += BLOCK)
             y[r0 + rr] = s_x[rr] + sink;
+        return;
+    }
+    if(L8)
+    {
+        const int grp = tid >> 3, lane = tid & 7;
+        for(int rr = grp; rr < nrows; rr += BLOCK / 8)
+        {
+            const int s = s_row[rr], e = s_row[rr + 1];
+            const int nfull = (e - s) & ~7;
+            double    acc = 0;
+            for(int j = s + lane; j < s + nfull; j += 8)
+                acc = fma(s_val[j], s_x[j], acc);
+            double vq = acc + __shfl_down(acc, 4, 8);
+            double t = vq + __shfl_down(vq, 1, 8);
+            double res = t + __shfl_down(t, 2, 8);
+            if(lane == 0)
+            {
+                if(nfull == 0) res = 0;
+                for(int j = s + nfull; j < e; j++)
+                    res = fma(s_val[j], s_x[j], res);
+                y[r0 + rr] = res;
+            }
+        }
         return;
     }
     for(int rr = tid; rr < nrows; rr += BLOCK)
@@ -245,11 +268,30 @@ __global__ __launch_bounds__(BLOCK) void k3(const int2 *__restrict__ blocks, int
 int main(int argc, char **argv)
 {
     const int g = argc > 1 ? atoi(argv[1]) : 4096;
-    const long long m = (long long)g * g;
+    const int K = argc > 2 ? atoi(argv[2]) : 5; // K > 5: uniform rows of K entries in groups of 5 columns
+    const long long m = K > 5 ? (long long)g * 400 : (long long)g * g;
     std::vector<int> rp(m + 1), ci;
     std::vector<double> v;
-    ci.reserve(5 * m), v.reserve(5 * m);
+    ci.reserve((size_t)K * m), v.reserve((size_t)K * m);
     rp[0] = 0;
+    if(K > 5)
+    {
+        const int ngrp = K / 5;
+        for(long long r = 0; r < m; r++)
+        {
+            for(int gq = 0; gq < ngrp; gq++)
+            {
+                const long long basec = r - r % 5 + (long long)(gq - ngrp / 2) * 3005;
+                for(int q = 0; q < 5; q++)
+                {
+                    const long long c = basec + q;
+                    if(c >= 0 && c < m) ci.push_back((int)c), v.push_back(0.37 + 1e-3 * q);
+                }
+            }
+            rp[r + 1] = (int)ci.size();
+        }
+    }
+    else
     for(long long r = 0; r < m; r++)
     {
         const long long i = r / g, j = r % g;
@@ -276,7 +318,16 @@ int main(int argc, char **argv)
     for(long long r = 0; r < m; r++)
     {
         double a = 0;
-        for(int p = rp[r]; p < rp[r + 1]; p++) a = fma(v[p], x[ci[p]], a);
+        if(K > 10)
+        {
+            double l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const int n = rp[r + 1] - rp[r], nf = n & ~7;
+            for(int p = 0; p < nf; p++) l[p & 7] = fma(v[rp[r] + p], x[ci[rp[r] + p]], l[p & 7]);
+            if(nf) a = ((l[0] + l[4]) + (l[1] + l[5])) + ((l[2] + l[6]) + (l[3] + l[7]));
+            for(int p = rp[r] + nf; p < rp[r + 1]; p++) a = fma(v[p], x[ci[p]], a);
+        }
+        else
+            for(int p = rp[r]; p < rp[r + 1]; p++) a = fma(v[p], x[ci[p]], a);
         yref[r] = a;
     }
     int *d_rp, *d_ci, *d_blk;
@@ -300,7 +351,8 @@ int main(int argc, char **argv)
         const int2 *B = (const int2 *)d_blk;
         switch(variant)
         {
-        case 0: hipLaunchKernelGGL(k<0>, dim3(nb), dim3(BLOCK), 0, 0, B, d_rp, d_ci, d_v, d_x, d_y); break;
+        case 0: if(K > 10) hipLaunchKernelGGL((k<0, true>), dim3(nb), dim3(BLOCK), 0, 0, B, d_rp, d_ci, d_v, d_x, d_y);
+                else hipLaunchKernelGGL(k<0>, dim3(nb), dim3(BLOCK), 0, 0, B, d_rp, d_ci, d_v, d_x, d_y); break;
         case 1: hipLaunchKernelGGL(k<1>, dim3(nb), dim3(BLOCK), 0, 0, B, d_rp, d_ci, d_v, d_x, d_y); break;
         case 2: hipLaunchKernelGGL(k<2>, dim3(nb), dim3(BLOCK), 0, 0, B, d_rp, d_ci, d_v, d_x, d_y); break;
         case 3: hipLaunchKernelGGL(k<3>, dim3(nb), dim3(BLOCK), 0, 0, B, d_rp, d_ci, d_v, d_x, d_y); break;
@@ -327,12 +379,12 @@ int main(int argc, char **argv)
             CHECK(hipEventElapsedTime(&ms, e0, e1));
             best[q] = std::min(best[q], (double)ms / 20);
         }
-    run(11);
+    run(0);
     std::vector<double> y(m);
     CHECK(hipMemcpy(y.data(), d_y, m * 8, hipMemcpyDeviceToHost));
     long long bad = 0;
     for(long long r = 0; r < m; r++) bad += y[r] != yref[r];
-    printf("grid %d: m=%lld nnz=%lld blocks=%d, full variant mismatches vs host fma chain: %lld\n", g, m, nnz, nb, bad);
+    printf("grid %d K %d: m=%lld nnz=%lld blocks=%d, full variant mismatches vs host fma chain: %lld\n", g, K, m, nnz, nb, bad);
     for(int q = 0; q < 13; q++)
         printf("V%d %-34s %.4f ms  %.0f GB/s (algorithmic bytes)\n", q, names[q], best[q], abytes / best[q] / 1e6);
     return 0;
