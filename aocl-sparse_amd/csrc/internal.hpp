@@ -140,6 +140,7 @@ struct TrsvPlan
     aoclsparse_int              nlevels   = -1;
     aoclsparse_int              max_width = 0; // widest level
     aoclsparse_int              launches  = 0; // kernel launches of the hybrid schedule
+    aoclsparse_int              nnz_tri   = 0; // entries of the strict triangle
     std::vector<aoclsparse_int> level_ptr; // host, nlevels+1
     std::vector<TrsvSegment>    segments; // hybrid schedule
     DeviceBuffer                rowmap, levels; // device: m rows in level order; level_ptr copy

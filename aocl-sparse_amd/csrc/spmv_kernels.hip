@@ -231,7 +231,24 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restr
             T         acc = T(0);
             if constexpr(L == 1)
             {
-                for(int j = s; j < e; j++)
+                // same left-to-right chain, but the LDS reads of 8 entries are issued together so that a
+                // long row pays the LDS latency once per 8 entries instead of once per entry
+                int j = s;
+                if(e - s >= 16) // short rows (the common case) skip the batched path entirely
+                    for(; j + 8 <= e; j += 8)
+                    {
+                        T a[8], b[8];
+#pragma unroll
+                        for(int q = 0; q < 8; q++)
+                        {
+                            a[q] = s_val[j + q];
+                            b[q] = s_x[j + q];
+                        }
+#pragma unroll
+                        for(int q = 0; q < 8; q++)
+                            acc = dev_fma(a[q], b[q], acc);
+                    }
+                for(; j < e; j++)
                     acc = dev_fma(s_val[j], s_x[j], acc);
                 store_y(&y[r], finish(acc, alpha, beta, &y[r]), flags);
             }

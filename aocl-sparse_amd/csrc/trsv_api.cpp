@@ -104,6 +104,7 @@ static aoclsparse_status build_levels(aoclsparse_int m, const Triangle<T> &t, Tr
     for(aoclsparse_int i = 0; i < m; i++)
         rowmap[next[level[i]]++] = i;
     plan.nlevels = nlev;
+    plan.nnz_tri = t.ptr[m];
 
     // level-ordered copy of the triangle; dependencies are rewritten as POSITIONS in that order
     std::vector<aoclsparse_int> pos((size_t)m);
