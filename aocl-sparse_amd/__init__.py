@@ -66,6 +66,11 @@ SIGNATURES = {
     "aoclsparse_export_dcsr": (c_int, [_P, POINTER(c_int), POINTER(_I), POINTER(_I), POINTER(_I),
                                        POINTER(_P), POINTER(_P), POINTER(_P)]),
     "aoclsparse_destroy": (c_int, [POINTER(_P)]),
+    "aoclsparse_sset_value": (c_int, [_P, _I, _I, c_float]),
+    "aoclsparse_dset_value": (c_int, [_P, _I, _I, c_double]),
+    "aoclsparse_supdate_values": (c_int, [_P, _I, _P]),
+    "aoclsparse_dupdate_values": (c_int, [_P, _I, _P]),
+    "aoclsparse_copy": (c_int, [_P, _P, POINTER(_P)]),
     # analysis
     "aoclsparse_optimize": (c_int, [_P]),
     "aoclsparse_set_mv_hint": (c_int, [_P, c_int, _P, _I]),
@@ -79,6 +84,8 @@ SIGNATURES = {
     "aoclsparse_dcsrmv": (c_int, [c_int, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "aoclsparse_smv": (c_int, [c_int, _P, _P, _P, _P, _P, _P]),
     "aoclsparse_dmv": (c_int, [c_int, _P, _P, _P, _P, _P, _P]),
+    "aoclsparse_sdotmv": (c_int, [c_int, c_float, _P, _P, _P, c_float, _P, _P]),
+    "aoclsparse_ddotmv": (c_int, [c_int, c_double, _P, _P, _P, c_double, _P, _P]),
     "aoclsparse_strsv": (c_int, [c_int, c_float, _P, _P, _P, _P]),
     "aoclsparse_dtrsv": (c_int, [c_int, c_double, _P, _P, _P, _P]),
     "aoclsparse_strsv_kid": (c_int, [c_int, c_float, _P, _P, _P, _P, _I]),
@@ -86,6 +93,10 @@ SIGNATURES = {
     "aoclsparse_strsv_strided": (c_int, [c_int, c_float, _P, _P, _P, _I, _P, _I]),
     "aoclsparse_dtrsv_strided": (c_int, [c_int, c_double, _P, _P, _P, _I, _P, _I]),
     # level 3
+    "aoclsparse_strsm": (c_int, [c_int, c_float, _P, _P, c_int, _P, _I, _I, _P, _I]),
+    "aoclsparse_dtrsm": (c_int, [c_int, c_double, _P, _P, c_int, _P, _I, _I, _P, _I]),
+    "aoclsparse_strsm_kid": (c_int, [c_int, c_float, _P, _P, c_int, _P, _I, _I, _P, _I, _I]),
+    "aoclsparse_dtrsm_kid": (c_int, [c_int, c_double, _P, _P, c_int, _P, _I, _I, _P, _I, _I]),
     "aoclsparse_scsrmm": (c_int, [c_int, c_float, _P, _P, c_int, _P, _I, _I, c_float, _P, _I]),
     "aoclsparse_dcsrmm": (c_int, [c_int, c_double, _P, _P, c_int, _P, _I, _I, c_double, _P, _I]),
     "aoclsparse_scsrmm_kid": (c_int, [c_int, c_float, _P, _P, c_int, _P, _I, _I, c_float, _P, _I, _I]),

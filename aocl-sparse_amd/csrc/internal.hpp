@@ -145,7 +145,6 @@ struct TrsvPlan
     std::vector<TrsvSegment>    segments; // hybrid schedule
     DeviceBuffer                rowmap, levels; // device: m rows in level order; level_ptr copy
     DeviceBuffer                pptr, pind, pval; // device: level-ordered strict triangle; pind = positions
-    DeviceBuffer                xp; // device workspace: solution in level order (stream-ordered reuse)
     bool                        valid = false;
 };
 
@@ -201,7 +200,8 @@ struct _aoclsparse_matrix
     mi355::SpmvPlan  plan_user, plan_trans;
     mi355::TrsvPlan  trsv_plan[4]; // index: (upper?2:0) + (transpose?1:0)
     mi355::DeviceBuffer dev_diag; // diagonal values of the clean CSR (length min(m,n))
-    mi355::DeviceBuffer trsv_scratch; // ticket + timeout words of the sync-free solve
+    mi355::DeviceBuffer trsv_scratch; // ticket (one per right-hand side) + timeout words of the sync-free solve
+    mi355::DeviceBuffer trsv_xp; // solution(s) in level order, m x nrhs (stream-ordered reuse)
 
     // matrices derived from the clean CSR for non-general descriptors (symmetric expansion,
     // triangular slices), built on first use: see derived.cpp
@@ -245,7 +245,7 @@ private:
     bool         inited_ = false;
     aoclsparse_status init_status_ = aoclsparse_status_success;
     hipStream_t  stream_ = nullptr;
-    DeviceBuffer stage_[6];
+    DeviceBuffer stage_[8];
 };
 
 // ---- host analysis (matrix.cpp) --------------------------------------------------------------
@@ -285,6 +285,9 @@ aoclsparse_status launch_csrmv(hipStream_t s, int order, bool strict, int tile, 
                                aoclsparse_int nblocks, const T *x, T beta, T *y);
 template <typename T>
 aoclsparse_status launch_scale(hipStream_t s, T *y, aoclsparse_int n, T beta);
+// d = x . y; partial must hold 1024 elements (spmv_kernels.hip)
+template <typename T>
+aoclsparse_status launch_dot(hipStream_t s, aoclsparse_int n, const T *x, const T *y, T *partial, T *d);
 template <typename T>
 aoclsparse_status launch_strided_gather(hipStream_t s, const T *src, aoclsparse_int inc,
                                         aoclsparse_int n, T *dst);
@@ -297,8 +300,9 @@ aoclsparse_status launch_strided_scatter(hipStream_t s, const T *src, aoclsparse
 constexpr int TRSV_NARROW = 1024; // a level this narrow is solved by one workgroup (one row per lane)
 template <typename T>
 aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, aoclsparse_int m,
-                              const TrsvPlan &plan, const T *diag, const T *b, T *x,
-                              unsigned int *scratch);
+                              const TrsvPlan &plan, const T *diag, const T *b, T *x, T *xp,
+                              unsigned int *scratch, aoclsparse_int nrhs, long long b_off, aoclsparse_int incb,
+                              long long x_off, aoclsparse_int incx);
 
 template <typename T>
 aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, T alpha,

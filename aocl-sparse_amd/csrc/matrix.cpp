@@ -711,6 +711,127 @@ aoclsparse_status aoclsparse_mi355_invalidate(aoclsparse_matrix A)
     return aoclsparse_status_success;
 }
 
+} // extern "C"
+
+// ---- value mutation + copy: extra/aoclsparse_auxiliary.hpp:216-270, 388-470; auxiliary.cpp:775-835 -------
+// The reference writes into the FIRST representation (the caller's arrays, which the handle aliases) and
+// deletes every derived copy.  Same here, device mirrors included: they are rebuilt lazily.
+static void drop_derived_state(aoclsparse_matrix A)
+{
+    if(A->opt != &A->user)
+    {
+        A->opt_copy.reset();
+        A->opt       = nullptr;
+        A->optimized = false;
+    }
+    A->trans.reset();
+    A->derived.clear();
+    A->dev_user.valid = A->dev_trans.valid = false; // row-block plans stay valid: structure is unchanged
+    A->dev_diag.release();
+    for(auto &p : A->trsv_plan)
+        p.valid = false, p.nlevels = -1;
+}
+
+template <typename T>
+static aoclsparse_status set_value(aoclsparse_matrix A, aoclsparse_int row_idx, aoclsparse_int col_idx, T val,
+                                   aoclsparse_matrix_data_type vt)
+{
+    if(!A || !A->user.ptr || !A->user.ind || !A->user.val)
+        return aoclsparse_status_invalid_pointer;
+    const aoclsparse_int b = A->base;
+    if(A->m + b <= row_idx || row_idx < b || A->n + b <= col_idx || col_idx < b)
+        return aoclsparse_status_invalid_value;
+    if(A->val_type != vt)
+        return aoclsparse_status_wrong_type;
+    std::unique_lock<std::shared_mutex> w(A->guard);
+    const aoclsparse_int                r = row_idx - b;
+    for(aoclsparse_int p = A->user.ptr[r] - b; p < A->user.ptr[r + 1] - b; p++)
+        if(A->user.ind[p] == col_idx)
+        {
+            static_cast<T *>(A->user.val)[p] = val;
+            drop_derived_state(A);
+            return aoclsparse_status_success;
+        }
+    return aoclsparse_status_invalid_index_value;
+}
+
+template <typename T>
+static aoclsparse_status update_values(aoclsparse_matrix A, aoclsparse_int len, T *val, aoclsparse_matrix_data_type vt)
+{
+    if(!A || !val || !A->user.ptr)
+        return aoclsparse_status_invalid_pointer;
+    if(len != A->nnz)
+        return aoclsparse_status_invalid_size;
+    if(A->val_type != vt)
+        return aoclsparse_status_wrong_type;
+    if(!A->user.val)
+        return aoclsparse_status_invalid_pointer;
+    std::unique_lock<std::shared_mutex> w(A->guard);
+    std::memcpy(A->user.val, val, sizeof(T) * (size_t)len);
+    drop_derived_state(A);
+    return aoclsparse_status_success;
+}
+
+extern "C" {
+
+aoclsparse_status aoclsparse_dset_value(aoclsparse_matrix A, aoclsparse_int row_idx, aoclsparse_int col_idx, double val)
+{
+    return set_value<double>(A, row_idx, col_idx, val, aoclsparse_dmat);
+}
+aoclsparse_status aoclsparse_sset_value(aoclsparse_matrix A, aoclsparse_int row_idx, aoclsparse_int col_idx, float val)
+{
+    return set_value<float>(A, row_idx, col_idx, val, aoclsparse_smat);
+}
+aoclsparse_status aoclsparse_dupdate_values(aoclsparse_matrix A, aoclsparse_int len, double *val)
+{
+    return update_values<double>(A, len, val, aoclsparse_dmat);
+}
+aoclsparse_status aoclsparse_supdate_values(aoclsparse_matrix A, aoclsparse_int len, float *val)
+{
+    return update_values<float>(A, len, val, aoclsparse_smat);
+}
+
+aoclsparse_status aoclsparse_copy(const aoclsparse_matrix src, const aoclsparse_mat_descr /*descr*/,
+                                  aoclsparse_matrix *dest)
+{
+    if(!src || !dest)
+        return aoclsparse_status_invalid_pointer;
+    if(src->m < 0 || src->n < 0 || src->nnz < 0)
+        return aoclsparse_status_invalid_size;
+    if(src == *dest)
+        return aoclsparse_status_invalid_pointer;
+    if(src->val_type != aoclsparse_dmat && src->val_type != aoclsparse_smat)
+        return aoclsparse_status_wrong_type;
+    if(!src->user.ptr || !src->user.ind || !src->user.val)
+        return aoclsparse_status_invalid_pointer;
+    _aoclsparse_matrix *c = new(std::nothrow) _aoclsparse_matrix;
+    if(!c)
+        return aoclsparse_status_memory_error;
+    const size_t         vs  = val_size(src->val_type);
+    const aoclsparse_int nnz = src->nnz;
+    c->m = src->m, c->n = src->n, c->nnz = nnz, c->base = src->base, c->val_type = src->val_type;
+    c->sort = src->sort, c->fulldiag = src->fulldiag;
+    c->user.m = src->m, c->user.n = src->n, c->user.nnz = nnz, c->user.base = src->base;
+    c->user.ptr = new(std::nothrow) aoclsparse_int[(size_t)src->m + 1];
+    c->user.ind = new(std::nothrow) aoclsparse_int[(size_t)std::max(nnz, 1)];
+    c->user.val = ::operator new(vs * (size_t)std::max(nnz, 1), std::nothrow);
+    c->user.owned = true, c->owns_user_arrays = true; // deep copy: the new handle owns its arrays
+    if(!c->user.ptr || !c->user.ind || !c->user.val)
+    {
+        delete c;
+        return aoclsparse_status_memory_error;
+    }
+    std::memcpy(c->user.ptr, src->user.ptr, sizeof(aoclsparse_int) * ((size_t)src->m + 1));
+    std::memcpy(c->user.ind, src->user.ind, sizeof(aoclsparse_int) * (size_t)nnz);
+    std::memcpy(c->user.val, src->user.val, vs * (size_t)nnz);
+    *dest = c;
+    return aoclsparse_status_success;
+}
+
+} // extern "C"
+
+extern "C" {
+
 // ---- hints: analysis/aoclsparse_analysis.cpp:568-747 -----------------------------------------------------
 static aoclsparse_status set_hint(aoclsparse_matrix mat, hinted_action act, aoclsparse_operation trans,
                                   const aoclsparse_mat_descr descr, aoclsparse_int ncalls,

@@ -439,9 +439,61 @@ aoclsparse_status csrmv_t(aoclsparse_operation trans, const T *alpha, aoclsparse
     return st;
 }
 
+// level2/aoclsparse_dotmv.hpp:31-70: y = alpha*op(A)*x + beta*y, then d = x . y over min(m, n) entries
+template <typename T>
+aoclsparse_status dotmv_t(aoclsparse_operation op, T alpha, aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                          const T *x, T beta, T *y, T *d, aoclsparse_matrix_data_type vt)
+{
+    if(!d || !A)
+        return aoclsparse_status_invalid_pointer;
+    Runtime &rt = Runtime::get();
+    // keep y on the device between the two steps when the caller's y is a host array
+    aoclsparse_status st = mv_t<T>(op, &alpha, A, descr, x, &beta, y, vt);
+    if(st != aoclsparse_status_success)
+        return st;
+    std::lock_guard<std::recursive_mutex> sl(rt.stage_lock);
+    const aoclsparse_int                  n = std::min(A->m, A->n);
+    const bool xdev = rt.is_device_pointer(x), ydev = rt.is_device_pointer(y), ddev = rt.is_device_pointer(d);
+    Arg        ax, ay;
+    st = ax.in(rt, 3, x, sizeof(T) * (size_t)n, xdev, true);
+    if(st == aoclsparse_status_success)
+        st = ay.in(rt, 4, y, sizeof(T) * (size_t)n, ydev, true);
+    void *part = nullptr, *dd = d;
+    if(st == aoclsparse_status_success)
+        st = rt.staging(6, sizeof(T) * 1024, &part);
+    if(st == aoclsparse_status_success && !ddev)
+        st = rt.staging(7, sizeof(T), &dd);
+    if(st != aoclsparse_status_success)
+        return st;
+    st = launch_dot<T>(rt.stream(), n, static_cast<const T *>(ax.dev), static_cast<const T *>(ay.dev),
+                       static_cast<T *>(part), static_cast<T *>(dd));
+    if(st != aoclsparse_status_success)
+        return st;
+    if(!ddev)
+    {
+        MI355_HIP_TRY(hipMemcpyAsync(d, dd, sizeof(T), hipMemcpyDeviceToHost, rt.stream()));
+        MI355_HIP_TRY(hipStreamSynchronize(rt.stream()));
+    }
+    return aoclsparse_status_success;
+}
+
 } // namespace
 
 extern "C" {
+
+aoclsparse_status aoclsparse_ddotmv(const aoclsparse_operation op, const double alpha, aoclsparse_matrix A,
+                                    const aoclsparse_mat_descr descr, const double *x, const double beta,
+                                    double *y, double *d)
+{
+    return dotmv_t<double>(op, alpha, A, descr, x, beta, y, d, aoclsparse_dmat);
+}
+
+aoclsparse_status aoclsparse_sdotmv(const aoclsparse_operation op, const float alpha, aoclsparse_matrix A,
+                                    const aoclsparse_mat_descr descr, const float *x, const float beta, float *y,
+                                    float *d)
+{
+    return dotmv_t<float>(op, alpha, A, descr, x, beta, y, d, aoclsparse_smat);
+}
 
 aoclsparse_status aoclsparse_dcsrmv(aoclsparse_operation trans, const double *alpha, aoclsparse_int m,
                                     aoclsparse_int n, aoclsparse_int nnz, const double *csr_val,

@@ -24,6 +24,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 namespace mi355
 {
 
@@ -349,6 +351,51 @@ __global__ void scatter_strided_kernel(const T *src, aoclsparse_int n, T *dst, a
         dst[(size_t)i * inc] = src[i];
 }
 
+// d = sum_i x[i]*y[i] for ?dotmv (level2/aoclsparse_dotmv.hpp:47-70): fixed two-stage tree, so the result
+// is deterministic (the reference's KT kernel sums SIMD lanes; parity is a tolerance)
+constexpr int DOT_BLOCKS = 1024;
+template <typename T>
+__global__ __launch_bounds__(256) void dot_partial_kernel(const T *__restrict__ x, const T *__restrict__ y,
+                                                          aoclsparse_int n, T *partial)
+{
+    __shared__ T sh[4];
+    T            acc = T(0);
+    for(long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        acc = dev_fma(x[i], y[i], acc);
+    for(int off = 32; off > 0; off >>= 1)
+        acc += __shfl_down(acc, off, 64);
+    if((threadIdx.x & 63) == 0)
+        sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if(threadIdx.x == 0)
+        partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void dot_final_kernel(const T *__restrict__ partial, int count, T *d)
+{
+    __shared__ T sh[4];
+    T            acc = T(0);
+    for(int i = threadIdx.x; i < count; i += 256)
+        acc += partial[i];
+    for(int off = 32; off > 0; off >>= 1)
+        acc += __shfl_down(acc, off, 64);
+    if((threadIdx.x & 63) == 0)
+        sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if(threadIdx.x == 0)
+        *d = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+template <typename T>
+aoclsparse_status launch_dot(hipStream_t s, aoclsparse_int n, const T *x, const T *y, T *partial, T *d)
+{
+    const int blocks = n <= 0 ? 1 : (int)std::min<long long>(DOT_BLOCKS, ((long long)n + 255) / 256);
+    hipLaunchKernelGGL((dot_partial_kernel<T>), dim3(blocks), dim3(256), 0, s, x, y, n, partial);
+    hipLaunchKernelGGL((dot_final_kernel<T>), dim3(1), dim3(256), 0, s, partial, blocks, d);
+    MI355_HIP_TRY(hipGetLastError());
+    return aoclsparse_status_success;
+}
+
 template <typename T, int ORDER, int TILE, int BLOCK>
 static void launch_inst(hipStream_t s, int flags, int base, T alpha, const T *val, const aoclsparse_int *col,
                         const aoclsparse_int *row_ptr, const aoclsparse_int *blocks, aoclsparse_int nblocks,
@@ -448,6 +495,7 @@ aoclsparse_status launch_strided_scatter(hipStream_t s, const T *src, aoclsparse
                                                const aoclsparse_int *, const aoclsparse_int *,                  \
                                                const aoclsparse_int *, aoclsparse_int, const T *, T, T *);      \
     template aoclsparse_status launch_scale<T>(hipStream_t, T *, aoclsparse_int, T);                           \
+    template aoclsparse_status launch_dot<T>(hipStream_t, aoclsparse_int, const T *, const T *, T *, T *);     \
     template aoclsparse_status launch_strided_gather<T>(hipStream_t, const T *, aoclsparse_int,                 \
                                                         aoclsparse_int, T *);                                   \
     template aoclsparse_status launch_strided_scatter<T>(hipStream_t, const T *, aoclsparse_int, T *,           \

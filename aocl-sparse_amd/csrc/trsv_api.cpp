@@ -144,8 +144,6 @@ static aoclsparse_status build_levels(aoclsparse_int m, const Triangle<T> &t, Tr
         rc = plan.pind.upload(pind.data(), sizeof(aoclsparse_int) * pind.size(), st);
     if(rc == aoclsparse_status_success)
         rc = plan.pval.upload(pval.data(), sizeof(T) * pval.size(), st);
-    if(rc == aoclsparse_status_success)
-        rc = plan.xp.alloc(sizeof(T) * (size_t)std::max(m, 1));
     return rc;
 }
 
@@ -186,8 +184,6 @@ aoclsparse_status ensure_trsv(aoclsparse_matrix A, bool upper, bool transposed)
                     std::memcpy(&dv[vs * (size_t)i],
                                 static_cast<const char *>(c.val) + vs * (size_t)(c.idiag[i] - c.base), vs);
             st = A->dev_diag.upload(dv.data(), vs * (size_t)m, rt.stream());
-            if(st == aoclsparse_status_success)
-                st = A->trsv_scratch.alloc(2 * sizeof(unsigned int));
             if(st != aoclsparse_status_success)
                 return st;
         }
@@ -208,6 +204,87 @@ aoclsparse_status ensure_trsv(aoclsparse_matrix A, bool upper, bool transposed)
 
 namespace
 {
+
+// Shared tail of trsv / trsm: plan lookup, schedule choice, staging of host operands, launch.
+// b / x describe nrhs right-hand sides: column c at b + c*b_off (element stride incb), likewise x.
+// span_b / span_x = number of elements of the caller's arrays that the strided views cover.
+template <typename T>
+aoclsparse_status solve_core(aoclsparse_operation trans, T alpha, aoclsparse_matrix A,
+                             const aoclsparse_mat_descr descr, aoclsparse_int kid, const T *b, T *x,
+                             aoclsparse_int nrhs, long long b_off, aoclsparse_int incb, size_t span_b,
+                             long long x_off, aoclsparse_int incx, size_t span_x, bool x_partial)
+{
+    const aoclsparse_int m  = A->m;
+    Runtime             &rt = Runtime::get();
+    aoclsparse_status    st = rt.init();
+    if(st != aoclsparse_status_success)
+        return st;
+    const bool upper = descr->fill_mode == aoclsparse_fill_mode_upper;
+    const bool tr    = trans != aoclsparse_operation_none;
+    const bool unit  = descr->diag_type == aoclsparse_diag_type_unit;
+    st               = ensure_trsv(A, upper, tr);
+    if(st != aoclsparse_status_success)
+        return st;
+    // solves on one handle share its workspaces: serialise their enqueue (kernels are stream-ordered)
+    std::lock_guard<std::recursive_mutex> sl(rt.stage_lock);
+    std::shared_lock<std::shared_mutex>   r(A->guard);
+    const TrsvPlan                       &plan = A->trsv_plan[(upper ? 2 : 0) + (tr ? 1 : 0)];
+
+    // schedule (all three give the same bits): kid 0 = one launch per level, kid 1/2 = hybrid (narrow
+    // level runs inside one workgroup), kid 3 = sync-free single launch.  auto: a shallow DAG of wide
+    // levels is cheapest as plain launches; otherwise sync-free, which measured fastest on both the
+    // 2-D Laplacian and the shell-like ILU(0) factors (profiles/r1, DESIGN.md).
+    const int schedule = kid == 0 ? 0 : (kid == 3 ? 2 : (kid > 0 ? 1 : (plan.nlevels <= 32 ? 0 : 2)));
+
+    st = A->trsv_xp.alloc(sizeof(T) * (size_t)m * (size_t)nrhs);
+    if(st == aoclsparse_status_success)
+        st = A->trsv_scratch.alloc(sizeof(unsigned int) * ((size_t)nrhs + 1));
+    if(st != aoclsparse_status_success)
+        return st;
+
+    const bool bdev = rt.is_device_pointer(b), xdev = rt.is_device_pointer(x);
+    const T   *db   = b;
+    T         *dx   = x;
+    void      *tmp  = nullptr;
+    if(!bdev)
+    {
+        st = rt.staging(0, sizeof(T) * span_b, &tmp);
+        if(st != aoclsparse_status_success)
+            return st;
+        MI355_HIP_TRY(hipMemcpyAsync(tmp, b, sizeof(T) * span_b, hipMemcpyHostToDevice, rt.stream()));
+        db = static_cast<const T *>(tmp);
+    }
+    if(!xdev)
+    {
+        st = rt.staging(2, sizeof(T) * span_x, &tmp);
+        if(st != aoclsparse_status_success)
+            return st;
+        if(x_partial) // strided / padded x: the untouched slots must survive the round trip
+            MI355_HIP_TRY(hipMemcpyAsync(tmp, x, sizeof(T) * span_x, hipMemcpyHostToDevice, rt.stream()));
+        dx = static_cast<T *>(tmp);
+    }
+    st = launch_trsv<T>(rt.stream(), schedule, unit, alpha, m, plan, A->dev_diag.as<T>(), db, dx,
+                        A->trsv_xp.as<T>(), A->trsv_scratch.as<unsigned int>(), nrhs, b_off, incb, x_off, incx);
+    if(st != aoclsparse_status_success)
+        return st;
+    if(!xdev)
+        MI355_HIP_TRY(hipMemcpyAsync(x, dx, sizeof(T) * span_x, hipMemcpyDeviceToHost, rt.stream()));
+    const bool syncfree = schedule == 2 || (schedule == 1 && (nrhs != 1 || incb != 1 || incx != 1));
+    if(!xdev || syncfree)
+    {
+        // host semantics, and the sync-free path reports a (never expected) spin timeout
+        MI355_HIP_TRY(hipStreamSynchronize(rt.stream()));
+        if(syncfree)
+        {
+            unsigned int word = 0;
+            MI355_HIP_TRY(hipMemcpy(&word, A->trsv_scratch.as<unsigned int>() + nrhs, sizeof(word),
+                                    hipMemcpyDeviceToHost));
+            if(word)
+                return aoclsparse_status_internal_error;
+        }
+    }
+    return aoclsparse_status_success;
+}
 
 template <typename T>
 aoclsparse_status trsv_t(aoclsparse_operation trans, const T alpha, aoclsparse_matrix A,
@@ -246,8 +323,7 @@ aoclsparse_status trsv_t(aoclsparse_operation trans, const T alpha, aoclsparse_m
     aoclsparse_status st = csr_optimize(A);
     if(st != aoclsparse_status_success)
         return st;
-    const bool unit = descr->diag_type == aoclsparse_diag_type_unit;
-    if(!A->opt_csr_full_diag && !unit)
+    if(!A->opt_csr_full_diag && descr->diag_type != aoclsparse_diag_type_unit)
         return aoclsparse_status_invalid_value;
     // KAT of trsv.cpp:315-376 has kernels 0..3 per doid
     if(kid > 3)
@@ -255,107 +331,73 @@ aoclsparse_status trsv_t(aoclsparse_operation trans, const T alpha, aoclsparse_m
     // (m-1)*inc must not overflow, trsv.cpp:407-411
     if((long long)(m - 1) * incb > 2147483647LL || (long long)(m - 1) * incx > 2147483647LL)
         return aoclsparse_status_invalid_size;
+    return solve_core<T>(trans, alpha, A, descr, kid, b, x, 1, 0, incb, (size_t)(m - 1) * incb + 1, 0, incx,
+                         (size_t)(m - 1) * incx + 1, incx != 1);
+}
 
-    Runtime &rt = Runtime::get();
-    st          = rt.init();
+// level3/aoclsparse_trsm.hpp:40-160: X = alpha * inv(op(A)) * B column by column.  The reference loops
+// aoclsparse::trsv over the n columns (OpenMP over columns); here all columns run in ONE launch (the
+// level structure is shared, blockIdx.y is the column), each bit-identical to the single-RHS solve.
+template <typename T>
+aoclsparse_status trsm_t(aoclsparse_operation trans, const T alpha, aoclsparse_matrix A,
+                         const aoclsparse_mat_descr descr, aoclsparse_order order, const T *B, aoclsparse_int n,
+                         aoclsparse_int ldb, T *X, aoclsparse_int ldx, aoclsparse_int kid,
+                         aoclsparse_matrix_data_type vt)
+{
+    if(!A || !X || !B || !descr)
+        return aoclsparse_status_invalid_pointer;
+    if(!A->user.ptr)
+        return aoclsparse_status_invalid_pointer;
+    if(descr->base != A->base)
+        return aoclsparse_status_invalid_value;
+    if(A->input_format != aoclsparse_csr_mat)
+        return aoclsparse_status_not_implemented;
+    const aoclsparse_int m = A->m;
+    if(m < 0 || A->nnz < 0 || n < 0)
+        return aoclsparse_status_invalid_size;
+    if(m == 0 || A->n == 0 || A->nnz == 0 || n == 0)
+        return aoclsparse_status_success;
+    if(m != A->n)
+        return aoclsparse_status_invalid_size;
+    if(ldb < 0 || ldx < 0)
+        return aoclsparse_status_invalid_size;
+    if(descr->base != aoclsparse_index_base_zero && descr->base != aoclsparse_index_base_one)
+        return aoclsparse_status_invalid_value;
+    if(trans != aoclsparse_operation_none && trans != aoclsparse_operation_transpose
+       && trans != aoclsparse_operation_conjugate_transpose)
+        return aoclsparse_status_invalid_value;
+    if(descr->type != aoclsparse_matrix_type_symmetric && descr->type != aoclsparse_matrix_type_triangular)
+        return aoclsparse_status_invalid_value;
+    if(descr->fill_mode != aoclsparse_fill_mode_lower && descr->fill_mode != aoclsparse_fill_mode_upper)
+        return aoclsparse_status_not_implemented;
+    if(A->val_type != vt)
+        return aoclsparse_status_wrong_type;
+    aoclsparse_status st = csr_optimize(A);
     if(st != aoclsparse_status_success)
         return st;
-    std::unique_lock<std::recursive_mutex> sl(rt.stage_lock, std::defer_lock);
-    if(rt.pointer_mode != aoclsparse_mi355_pointer_device)
-        sl.lock();
-
-    const bool upper = descr->fill_mode == aoclsparse_fill_mode_upper;
-    const bool tr    = trans != aoclsparse_operation_none;
-    st               = ensure_trsv(A, upper, tr);
-    if(st != aoclsparse_status_success)
-        return st;
-    std::shared_lock<std::shared_mutex> r(A->guard);
-    const TrsvPlan                     &plan = A->trsv_plan[(upper ? 2 : 0) + (tr ? 1 : 0)];
-
-    // schedule (all three give the same bits): kid 0 = one launch per level, kid 1/2 = hybrid (narrow
-    // level runs inside one workgroup), kid 3 = sync-free single launch.  auto: a shallow DAG of wide
-    // levels is cheapest as plain launches; otherwise sync-free, which measured fastest on both the
-    // 2-D Laplacian and the shell-like ILU(0) factors (profiles/r1, DESIGN.md).
-    const int schedule = kid == 0 ? 0 : (kid == 3 ? 2 : (kid > 0 ? 1 : (plan.nlevels <= 32 ? 0 : 2)));
-
-    const bool bdev = rt.is_device_pointer(b), xdev = rt.is_device_pointer(x);
-    const T   *db   = nullptr;
-    T         *dx   = nullptr;
-    void      *tmp  = nullptr;
-    const size_t nb = (size_t)(m - 1) * incb + 1, nx = (size_t)(m - 1) * incx + 1;
-    // b: contiguous device vector
-    if(bdev && incb == 1)
-        db = b;
+    aoclsparse_int incb, incx;
+    long long      b_off, x_off;
+    if(order == aoclsparse_order_row)
+        incb = ldb, incx = ldx, b_off = 1, x_off = 1;
+    else if(order == aoclsparse_order_column)
+        incb = 1, incx = 1, b_off = ldb, x_off = ldx;
     else
-    {
-        st = rt.staging(0, sizeof(T) * (size_t)m, &tmp);
-        if(st != aoclsparse_status_success)
-            return st;
-        T *cb = static_cast<T *>(tmp);
-        if(bdev)
-            st = launch_strided_gather<T>(rt.stream(), b, incb, m, cb);
-        else if(incb == 1)
-            MI355_HIP_TRY(hipMemcpyAsync(cb, b, sizeof(T) * (size_t)m, hipMemcpyHostToDevice, rt.stream()));
-        else
-        {
-            void *raw = nullptr;
-            st        = rt.staging(1, sizeof(T) * nb, &raw);
-            if(st != aoclsparse_status_success)
-                return st;
-            MI355_HIP_TRY(hipMemcpyAsync(raw, b, sizeof(T) * nb, hipMemcpyHostToDevice, rt.stream()));
-            st = launch_strided_gather<T>(rt.stream(), static_cast<const T *>(raw), incb, m, cb);
-        }
-        if(st != aoclsparse_status_success)
-            return st;
-        db = cb;
-    }
-    // x: contiguous device vector the kernels write
-    const bool xdirect = xdev && incx == 1;
-    if(xdirect)
-        dx = x;
-    else
-    {
-        st = rt.staging(2, sizeof(T) * (size_t)m, &tmp);
-        if(st != aoclsparse_status_success)
-            return st;
-        dx = static_cast<T *>(tmp);
-    }
-    st = launch_trsv<T>(rt.stream(), schedule, unit, alpha, m, plan, A->dev_diag.as<T>(), db, dx,
-                        A->trsv_scratch.as<unsigned int>());
-    if(st != aoclsparse_status_success)
-        return st;
-    if(!xdirect)
-    {
-        if(xdev)
-            st = launch_strided_scatter<T>(rt.stream(), dx, m, x, incx);
-        else if(incx == 1)
-            MI355_HIP_TRY(hipMemcpyAsync(x, dx, sizeof(T) * (size_t)m, hipMemcpyDeviceToHost, rt.stream()));
-        else
-        {
-            // strided host x: only the strided slots may change -> read back compact, scatter on host
-            std::vector<T> hx((size_t)m);
-            MI355_HIP_TRY(hipMemcpyAsync(hx.data(), dx, sizeof(T) * (size_t)m, hipMemcpyDeviceToHost, rt.stream()));
-            MI355_HIP_TRY(hipStreamSynchronize(rt.stream()));
-            for(aoclsparse_int i = 0; i < m; i++)
-                x[(size_t)i * incx] = hx[i];
-        }
-        if(st != aoclsparse_status_success)
-            return st;
-    }
-    if(!xdev || schedule == 2)
-    {
-        // host semantics, and the sync-free path reports a (never expected) spin timeout
-        MI355_HIP_TRY(hipStreamSynchronize(rt.stream()));
-        if(schedule == 2)
-        {
-            unsigned int words[2] = {0, 0};
-            MI355_HIP_TRY(hipMemcpy(words, A->trsv_scratch.ptr, sizeof(words), hipMemcpyDeviceToHost));
-            if(words[1])
-                return aoclsparse_status_internal_error;
-        }
-    }
-    (void)nx;
-    return aoclsparse_status_success;
+        return aoclsparse_status_invalid_value;
+    if((long long)n * b_off > 2147483647LL || (long long)n * x_off > 2147483647LL)
+        return aoclsparse_status_invalid_size;
+    // what every per-column trsv of the reference checks (trsv.cpp:72-137)
+    if(incb <= 0 || incx <= 0 || descr->diag_type == aoclsparse_diag_type_zero)
+        return aoclsparse_status_invalid_value;
+    if(!A->opt_csr_full_diag && descr->diag_type != aoclsparse_diag_type_unit)
+        return aoclsparse_status_invalid_value;
+    if(kid > 3)
+        return aoclsparse_status_invalid_kid;
+    const size_t span_b = (size_t)(m - 1) * incb + (size_t)(n - 1) * b_off + 1;
+    const size_t span_x = (size_t)(m - 1) * incx + (size_t)(n - 1) * x_off + 1;
+    if(span_b > 2147483647ULL || span_x > 2147483647ULL)
+        return aoclsparse_status_invalid_size;
+    const bool dense_x = order == aoclsparse_order_row ? ldx == n : ldx == m;
+    return solve_core<T>(trans, alpha, A, descr, kid, B, X, n, b_off, incb, span_b, x_off, incx, span_x, !dense_x);
 }
 
 } // namespace
@@ -400,6 +442,36 @@ aoclsparse_status aoclsparse_strsv_strided(aoclsparse_operation trans, const flo
                                            const aoclsparse_int incb, float *x, const aoclsparse_int incx)
 {
     return trsv_t<float>(trans, alpha, A, descr, b, incb, x, incx, -1, aoclsparse_smat);
+}
+
+aoclsparse_status aoclsparse_dtrsm(const aoclsparse_operation trans, const double alpha, aoclsparse_matrix A,
+                                   const aoclsparse_mat_descr descr, aoclsparse_order order, const double *B,
+                                   aoclsparse_int n, aoclsparse_int ldb, double *X, aoclsparse_int ldx)
+{
+    return trsm_t<double>(trans, alpha, A, descr, order, B, n, ldb, X, ldx, -1, aoclsparse_dmat);
+}
+
+aoclsparse_status aoclsparse_strsm(const aoclsparse_operation trans, const float alpha, aoclsparse_matrix A,
+                                   const aoclsparse_mat_descr descr, aoclsparse_order order, const float *B,
+                                   aoclsparse_int n, aoclsparse_int ldb, float *X, aoclsparse_int ldx)
+{
+    return trsm_t<float>(trans, alpha, A, descr, order, B, n, ldb, X, ldx, -1, aoclsparse_smat);
+}
+
+aoclsparse_status aoclsparse_dtrsm_kid(const aoclsparse_operation trans, const double alpha, aoclsparse_matrix A,
+                                       const aoclsparse_mat_descr descr, aoclsparse_order order, const double *B,
+                                       aoclsparse_int n, aoclsparse_int ldb, double *X, aoclsparse_int ldx,
+                                       const aoclsparse_int kid)
+{
+    return trsm_t<double>(trans, alpha, A, descr, order, B, n, ldb, X, ldx, kid, aoclsparse_dmat);
+}
+
+aoclsparse_status aoclsparse_strsm_kid(const aoclsparse_operation trans, const float alpha, aoclsparse_matrix A,
+                                       const aoclsparse_mat_descr descr, aoclsparse_order order, const float *B,
+                                       aoclsparse_int n, aoclsparse_int ldb, float *X, aoclsparse_int ldx,
+                                       const aoclsparse_int kid)
+{
+    return trsm_t<float>(trans, alpha, A, descr, order, B, n, ldb, X, ldx, kid, aoclsparse_smat);
 }
 
 aoclsparse_status aoclsparse_mi355_get_trsv_levels(const aoclsparse_matrix A, aoclsparse_fill_mode fill,

@@ -58,10 +58,10 @@ __device__ __forceinline__ float neg_fma(float a, float b, float c)
 }
 
 template <typename T>
-__global__ void trsv_fill_tag_kernel(T *x, aoclsparse_int m)
+__global__ void trsv_fill_tag_kernel(T *x, long long m)
 {
-    using B     = typename tag<T>::bits;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    using B           = typename tag<T>::bits;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if(i < m)
         reinterpret_cast<B *>(x)[i] = tag<T>::value;
 }
@@ -71,27 +71,40 @@ __global__ void trsv_fill_tag_kernel(T *x, aoclsparse_int m)
 // Results are written twice: xp[k] (what later rows read) and x[rowmap[k]] (what the caller gets).
 
 // ---- schedule 0 / wide levels: positions [first, first+count) -------------------------------------------
+// Right-hand-side geometry shared by the kernels: column c of a multi-RHS solve (aoclsparse_?trsm loops
+// trsv over the columns, level3/aoclsparse_trsm.hpp:150-158) lives at b + c*b_off with element stride
+// incb, its solution at x + c*x_off with stride incx; blockIdx.y selects the column.  trsv is nrhs = 1.
+struct RhsGeom
+{
+    long long b_off, x_off;
+    int       incb, incx;
+};
+
 template <typename T>
-__global__ void trsv_level_kernel(aoclsparse_int first, aoclsparse_int count,
+__global__ void trsv_level_kernel(aoclsparse_int first, aoclsparse_int count, aoclsparse_int m,
                                   const aoclsparse_int *__restrict__ rowmap,
                                   const aoclsparse_int *__restrict__ pptr,
                                   const aoclsparse_int *__restrict__ pind, const T *__restrict__ pval,
                                   const T *__restrict__ diag, const T *__restrict__ b, T *xp, T *x, T alpha,
-                                  int unit)
+                                  int unit, RhsGeom g)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if(t >= count)
         return;
+    const int c = blockIdx.y;
+    b += c * g.b_off;
+    x += c * g.x_off;
+    xp += (size_t)c * m;
     const int k  = first + t;
     const int i  = rowmap[k];
-    T         xi = alpha * b[i];
+    T         xi = alpha * b[(size_t)i * g.incb];
     const int s = pptr[k], e = pptr[k + 1];
     for(int p = s; p < e; p++)
         xi = neg_fma(pval[p], xp[pind[p]], xi);
     if(!unit)
         xi /= diag[i];
-    xp[k] = xi;
-    x[i]  = xi;
+    xp[k]                  = xi;
+    x[(size_t)i * g.incx] = xi;
 }
 
 // ---- schedule 1, narrow runs: one workgroup walks levels [l0, l1), one lane per row ----------------------
@@ -239,11 +252,17 @@ template <typename T, int TRSV_SF_BLOCK, int TRSV_SF_PF>
 __global__ __launch_bounds__(TRSV_SF_BLOCK) void trsv_syncfree_kernel(
     aoclsparse_int m, const aoclsparse_int *__restrict__ rowmap, const aoclsparse_int *__restrict__ pptr,
     const aoclsparse_int *__restrict__ pind, const T *__restrict__ pval, const T *__restrict__ diag,
-    const T *__restrict__ b, T *xp, T *x, T alpha, int unit, unsigned int *ticket, unsigned int *timeout_flag)
+    const T *__restrict__ b, T *xp, T *x, T alpha, int unit, unsigned int *ticket, unsigned int *timeout_flag,
+    RhsGeom g)
 {
     using B = typename tag<T>::bits;
     __shared__ unsigned int s_bid;
     __shared__ B            s_x[TRSV_SF_BLOCK];
+    const int c = blockIdx.y; // right-hand side; every column has its own ticket counter and xp slab
+    b += c * g.b_off;
+    x += c * g.x_off;
+    xp += (size_t)c * m;
+    ticket += c;
     // the first TRSV_SF_PF entries of each row, [entry][lane] so that a wavefront reads one bank row;
     // without this every entry of a row is a dependent global load on the critical path of its level
     __shared__ T   s_ev[TRSV_SF_PF][TRSV_SF_BLOCK];
@@ -267,7 +286,7 @@ __global__ __launch_bounds__(TRSV_SF_BLOCK) void trsv_syncfree_kernel(
             s_ev[j][tid] = pval[p0 + j];
             s_ec[j][tid] = pind[p0 + j];
         }
-    T    xi = alpha * b[i];
+    T    xi = alpha * b[(size_t)i * g.incb];
     T    dg = T(1);
     if(!unit)
         dg = diag[i];
@@ -314,28 +333,38 @@ __global__ __launch_bounds__(TRSV_SF_BLOCK) void trsv_syncfree_kernel(
             __builtin_memcpy(&out, &xi, sizeof(T));
             __hip_atomic_store(&s_x[tid], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_store(&xb[k], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            x[i] = xi;
+            x[(size_t)i * g.incx] = xi;
             done = true;
         }
     }
 }
 
+// scratch: nrhs ticket words followed by one timeout word (zeroed here for the sync-free schedule)
 template <typename T>
 aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, aoclsparse_int m,
-                              const TrsvPlan &plan, const T *diag, const T *b, T *x, unsigned int *scratch)
+                              const TrsvPlan &plan, const T *diag, const T *b, T *x, T *xp, unsigned int *scratch,
+                              aoclsparse_int nrhs, long long b_off, aoclsparse_int incb, long long x_off,
+                              aoclsparse_int incx)
 {
-    if(m <= 0)
+    if(m <= 0 || nrhs <= 0)
         return aoclsparse_status_success;
     const aoclsparse_int *rowmap = plan.rowmap.as<aoclsparse_int>();
     const aoclsparse_int *pptr   = plan.pptr.as<aoclsparse_int>();
     const aoclsparse_int *pind   = plan.pind.as<aoclsparse_int>();
     const T              *pval   = plan.pval.as<T>();
-    T                    *xp     = plan.xp.as<T>();
+    const RhsGeom         g{b_off, x_off, incb, incx};
+    if(schedule == 1 && (nrhs != 1 || incb != 1 || incx != 1))
+        schedule = 2; // the single-workgroup runs of the hybrid schedule are single-RHS, unit stride
     auto level_launch = [&](aoclsparse_int l) {
         const aoclsparse_int first = plan.level_ptr[l], count = plan.level_ptr[l + 1] - first;
         const int            bs = count >= 256 ? 256 : 64;
-        hipLaunchKernelGGL((trsv_level_kernel<T>), dim3((count + bs - 1) / bs), dim3(bs), 0, s, first, count,
-                           rowmap, pptr, pind, pval, diag, b, xp, x, alpha, (int)unit);
+        for(aoclsparse_int c0 = 0; c0 < nrhs; c0 += 65535)
+        {
+            const int nc = nrhs - c0 < 65535 ? nrhs - c0 : 65535;
+            hipLaunchKernelGGL((trsv_level_kernel<T>), dim3((count + bs - 1) / bs, nc), dim3(bs), 0, s, first, count,
+                               m, rowmap, pptr, pind, pval, diag, b + c0 * b_off, xp + (size_t)c0 * m, x + c0 * x_off,
+                               alpha, (int)unit, g);
+        }
     };
     if(schedule == 0)
     {
@@ -344,36 +373,47 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
     }
     else if(schedule == 1)
     {
-        for(const TrsvSegment &g : plan.segments)
+        for(const TrsvSegment &sg : plan.segments)
         {
-            if(g.narrow)
-                hipLaunchKernelGGL((trsv_multilevel_kernel<T>), dim3(1), dim3(TRSV_NARROW), 0, s, g.l0, g.l1,
-                                   plan.levels.as<aoclsparse_int>(), rowmap, pptr, pind, pval, diag, b, xp, x,
-                                   alpha, (int)unit);
+            if(sg.narrow)
+                hipLaunchKernelGGL((trsv_multilevel_kernel<T>), dim3(1), dim3(TRSV_NARROW), 0, s, sg.l0, sg.l1,
+                                   plan.levels.as<aoclsparse_int>(), rowmap, pptr, pind, pval, diag, b, xp, x, alpha,
+                                   (int)unit);
             else
-                for(aoclsparse_int l = g.l0; l < g.l1; l++)
+                for(aoclsparse_int l = sg.l0; l < sg.l1; l++)
                     level_launch(l);
         }
     }
     else
     {
-        // sync-free: tag xp, reset ticket + timeout word, one launch
-        MI355_HIP_TRY(hipMemsetAsync(scratch, 0, 2 * sizeof(unsigned int), s));
-        hipLaunchKernelGGL((trsv_fill_tag_kernel<T>), dim3((m + 255) / 256), dim3(256), 0, s, xp, m);
-        if((long long)plan.nnz_tri > 10LL * m)
-            hipLaunchKernelGGL((trsv_syncfree_kernel<T, 512, 20>), dim3((m + 511) / 512), dim3(512), 0, s, m, rowmap,
-                               pptr, pind, pval, diag, b, xp, x, alpha, (int)unit, scratch, scratch + 1);
-        else
-            hipLaunchKernelGGL((trsv_syncfree_kernel<T, 1024, 12>), dim3((m + 1023) / 1024), dim3(1024), 0, s, m,
-                               rowmap, pptr, pind, pval, diag, b, xp, x, alpha, (int)unit, scratch, scratch + 1);
+        // sync-free: tag xp, reset tickets + timeout word, one launch over all right-hand sides
+        MI355_HIP_TRY(hipMemsetAsync(scratch, 0, ((size_t)nrhs + 1) * sizeof(unsigned int), s));
+        const long long total = (long long)m * nrhs;
+        hipLaunchKernelGGL((trsv_fill_tag_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xp,
+                           total);
+        unsigned int *tmo = scratch + nrhs;
+        for(aoclsparse_int c0 = 0; c0 < nrhs; c0 += 65535)
+        {
+            const int nc = nrhs - c0 < 65535 ? nrhs - c0 : 65535;
+            if((long long)plan.nnz_tri > 10LL * m)
+                hipLaunchKernelGGL((trsv_syncfree_kernel<T, 512, 20>), dim3((m + 511) / 512, nc), dim3(512), 0, s, m,
+                                   rowmap, pptr, pind, pval, diag, b + c0 * b_off, xp + (size_t)c0 * m, x + c0 * x_off,
+                                   alpha, (int)unit, scratch + c0, tmo, g);
+            else
+                hipLaunchKernelGGL((trsv_syncfree_kernel<T, 1024, 12>), dim3((m + 1023) / 1024, nc), dim3(1024), 0, s,
+                                   m, rowmap, pptr, pind, pval, diag, b + c0 * b_off, xp + (size_t)c0 * m,
+                                   x + c0 * x_off, alpha, (int)unit, scratch + c0, tmo, g);
+        }
     }
     MI355_HIP_TRY(hipGetLastError());
     return aoclsparse_status_success;
 }
 
 template aoclsparse_status launch_trsv<double>(hipStream_t, int, bool, double, aoclsparse_int, const TrsvPlan &,
-                                               const double *, const double *, double *, unsigned int *);
+                                               const double *, const double *, double *, double *, unsigned int *,
+                                               aoclsparse_int, long long, aoclsparse_int, long long, aoclsparse_int);
 template aoclsparse_status launch_trsv<float>(hipStream_t, int, bool, float, aoclsparse_int, const TrsvPlan &,
-                                              const float *, const float *, float *, unsigned int *);
+                                              const float *, const float *, float *, float *, unsigned int *,
+                                              aoclsparse_int, long long, aoclsparse_int, long long, aoclsparse_int);
 
 } // namespace mi355

@@ -198,6 +198,21 @@ DLL_PUBLIC aoclsparse_status aoclsparse_export_dcsr(const aoclsparse_matrix mat,
                                                     aoclsparse_int        **col_ind,
                                                     double                **val);
 DLL_PUBLIC aoclsparse_status aoclsparse_destroy(aoclsparse_matrix *mat); /* :836 */
+/* Value mutation writes through to the aliased user arrays and drops every derived / device copy
+ * (:340-356, :735-746); aoclsparse_copy makes a deep copy that owns its arrays (:1010-1012). */
+DLL_PUBLIC aoclsparse_status aoclsparse_sset_value(aoclsparse_matrix A,
+                                                   aoclsparse_int    row_idx,
+                                                   aoclsparse_int    col_idx,
+                                                   float             val);
+DLL_PUBLIC aoclsparse_status aoclsparse_dset_value(aoclsparse_matrix A,
+                                                   aoclsparse_int    row_idx,
+                                                   aoclsparse_int    col_idx,
+                                                   double            val);
+DLL_PUBLIC aoclsparse_status aoclsparse_supdate_values(aoclsparse_matrix A, aoclsparse_int len, float *val);
+DLL_PUBLIC aoclsparse_status aoclsparse_dupdate_values(aoclsparse_matrix A, aoclsparse_int len, double *val);
+DLL_PUBLIC aoclsparse_status aoclsparse_copy(const aoclsparse_matrix    src,
+                                             const aoclsparse_mat_descr descr,
+                                             aoclsparse_matrix         *dest);
 
 /* ---- analysis: aoclsparse_analysis.h ----------------------------------------------- */
 DLL_PUBLIC aoclsparse_status aoclsparse_optimize(aoclsparse_matrix mat); /* :56 */
@@ -266,6 +281,23 @@ DLL_PUBLIC aoclsparse_status aoclsparse_dmv(aoclsparse_operation       op,
                                             const double              *x,
                                             const double              *beta,
                                             double                    *y);
+/* y = alpha*op(A)*x + beta*y and d = x.y over min(m,n) entries; scalars BY VALUE (:1782-1801). */
+DLL_PUBLIC aoclsparse_status aoclsparse_sdotmv(const aoclsparse_operation op,
+                                               const float                alpha,
+                                               aoclsparse_matrix          A,
+                                               const aoclsparse_mat_descr descr,
+                                               const float               *x,
+                                               const float                beta,
+                                               float                     *y,
+                                               float                     *d);
+DLL_PUBLIC aoclsparse_status aoclsparse_ddotmv(const aoclsparse_operation op,
+                                               const double               alpha,
+                                               aoclsparse_matrix          A,
+                                               const aoclsparse_mat_descr descr,
+                                               const double              *x,
+                                               const double               beta,
+                                               double                    *y,
+                                               double                    *d);
 /* op(A)*x = alpha*b on the triangle fill_mode selects; alpha BY VALUE (:1525-1539). */
 DLL_PUBLIC aoclsparse_status aoclsparse_strsv(aoclsparse_operation       trans,
                                               const float                alpha,
@@ -311,6 +343,49 @@ DLL_PUBLIC aoclsparse_status aoclsparse_dtrsv_strided(aoclsparse_operation      
                                                       const aoclsparse_int       incx);
 
 /* ---- level 3 ------------------------------------------------------------------------ */
+/* op(A)*X = alpha*B for n right-hand sides (dense B, X in the stated order) (:1968-2101). */
+DLL_PUBLIC aoclsparse_status aoclsparse_strsm(const aoclsparse_operation trans,
+                                              const float                alpha,
+                                              aoclsparse_matrix          A,
+                                              const aoclsparse_mat_descr descr,
+                                              aoclsparse_order           order,
+                                              const float               *B,
+                                              aoclsparse_int             n,
+                                              aoclsparse_int             ldb,
+                                              float                     *X,
+                                              aoclsparse_int             ldx);
+DLL_PUBLIC aoclsparse_status aoclsparse_dtrsm(const aoclsparse_operation trans,
+                                              const double               alpha,
+                                              aoclsparse_matrix          A,
+                                              const aoclsparse_mat_descr descr,
+                                              aoclsparse_order           order,
+                                              const double              *B,
+                                              aoclsparse_int             n,
+                                              aoclsparse_int             ldb,
+                                              double                    *X,
+                                              aoclsparse_int             ldx);
+DLL_PUBLIC aoclsparse_status aoclsparse_strsm_kid(const aoclsparse_operation trans,
+                                                  const float                alpha,
+                                                  aoclsparse_matrix          A,
+                                                  const aoclsparse_mat_descr descr,
+                                                  aoclsparse_order           order,
+                                                  const float               *B,
+                                                  aoclsparse_int             n,
+                                                  aoclsparse_int             ldb,
+                                                  float                     *X,
+                                                  aoclsparse_int             ldx,
+                                                  const aoclsparse_int       kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_dtrsm_kid(const aoclsparse_operation trans,
+                                                  const double               alpha,
+                                                  aoclsparse_matrix          A,
+                                                  const aoclsparse_mat_descr descr,
+                                                  aoclsparse_order           order,
+                                                  const double              *B,
+                                                  aoclsparse_int             n,
+                                                  aoclsparse_int             ldb,
+                                                  double                    *X,
+                                                  aoclsparse_int             ldx,
+                                                  const aoclsparse_int       kid);
 /* C = alpha*op(A)*B + beta*C, dense B/C in the stated order; alpha, beta BY VALUE (:2487-2511). */
 DLL_PUBLIC aoclsparse_status aoclsparse_scsrmm(aoclsparse_operation       op,
                                                const float                alpha,

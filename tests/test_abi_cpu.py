@@ -296,3 +296,51 @@ def test_row_block_planner_properties():
     rp1 = (rp + 1).astype(np.int32)
     nb1 = L.mi355_csrmv_plan_host(m, 1, 2048, P._ptr(rp1), P._ptr(b1))
     assert nb1 == nb and np.array_equal(b1[: 2 * (nb + 1)].reshape(nb + 1, 2), blk)
+
+
+def test_value_mutation_and_copy_host_semantics():
+    """aoclsparse_?set_value / ?update_values / copy (auxiliary.hpp:216-270, 388-470; auxiliary.cpp:775-835):
+    writes go through to the aliased user arrays, the clean copy is dropped, copy is deep."""
+    rp = np.array([0, 2, 3, 4, 6, 7], np.int32)
+    ci = np.array([3, 0, 1, 2, 1, 4, 4], np.int32)  # N5_1_hole: unsorted + a missing diagonal
+    v = np.array([2, 1, 3, 4, 5, 7, 8], np.float64)
+    A = P.Matrix(0, 5, 5, rp, ci, v)
+    d = P.Descr(mtype=P.TYPE_TRIANGULAR)
+    assert L.aoclsparse_set_sv_hint(A.h, P.OP_NONE, d.h, 1) == 0 and L.aoclsparse_optimize(A.h) == 0
+    assert A.export()["nnz"] == 8  # clean copy with the inserted zero diagonal
+    assert L.aoclsparse_dset_value(A.h, 3, 1, -5.5) == 0
+    assert A.val[4] == -5.5  # user's array was written
+    e = A.export()
+    assert e["aliased"] and e["nnz"] == 7  # clean copy dropped, user arrays exported again
+    assert L.aoclsparse_dset_value(A.h, 3, 3, 1.0) == 6   # (3,3) is not stored: invalid_index_value
+    assert L.aoclsparse_dset_value(A.h, 5, 0, 1.0) == 5 and L.aoclsparse_dset_value(A.h, 0, -1, 1.0) == 5
+    assert L.aoclsparse_sset_value(A.h, 0, 0, 1.0) == 9 and L.aoclsparse_dset_value(None, 0, 0, 1.0) == 2
+    nv = np.arange(1.0, 8.0)
+    assert L.aoclsparse_dupdate_values(A.h, 7, P._ptr(nv)) == 0 and np.array_equal(A.val, nv)
+    assert L.aoclsparse_dupdate_values(A.h, 6, P._ptr(nv)) == 3 and L.aoclsparse_dupdate_values(A.h, 7, None) == 2
+    assert L.aoclsparse_optimize(A.h) == 0  # hints were already consumed: no-op, like the reference
+    C = ctypes.c_void_p()
+    assert L.aoclsparse_copy(A.h, d.h, ctypes.byref(C)) == 0 and C.value and C.value != A.h.value
+    base, m, n, nnz = ctypes.c_int(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    a, b, c = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    assert L.aoclsparse_export_dcsr(C, ctypes.byref(base), ctypes.byref(m), ctypes.byref(n), ctypes.byref(nnz),
+                                    ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) == 0
+    assert a.value != A.row_ptr.ctypes.data and nnz.value == 7
+    cv = np.ctypeslib.as_array(ctypes.cast(c, ctypes.POINTER(ctypes.c_double)), (7,)).copy()
+    assert np.array_equal(cv, nv)
+    assert L.aoclsparse_copy(None, d.h, ctypes.byref(C)) == 2
+    assert L.aoclsparse_destroy(ctypes.byref(C)) == 0
+    # trsm / dotmv argument checks (trsm.hpp:54-140, dotmv.hpp:42-46)
+    x, y = np.ones(5), np.zeros(5)
+    assert L.aoclsparse_ddotmv(111, 1.0, A.h, d.h, P._ptr(x), 0.0, P._ptr(y), None) == 2
+    assert L.aoclsparse_ddotmv(111, 1.0, None, d.h, P._ptr(x), 0.0, P._ptr(y), P._ptr(y)) == 2
+    Bm, Xm = np.ones(10), np.zeros(10)
+    t = L.aoclsparse_dtrsm
+    assert t(111, 1.0, None, d.h, 0, P._ptr(Bm), 2, 2, P._ptr(Xm), 2) == 2
+    assert t(111, 1.0, A.h, P.Descr().h, 0, P._ptr(Bm), 2, 2, P._ptr(Xm), 2) == 5   # general type
+    assert t(111, 1.0, A.h, d.h, 0, P._ptr(Bm), -1, 2, P._ptr(Xm), 2) == 3
+    assert t(111, 1.0, A.h, d.h, 0, P._ptr(Bm), 0, 2, P._ptr(Xm), 2) == 0           # n == 0 quick return
+    assert t(111, 1.0, A.h, d.h, 2, P._ptr(Bm), 2, 2, P._ptr(Xm), 2) == 5           # bad order
+    assert t(114, 1.0, A.h, d.h, 0, P._ptr(Bm), 2, 2, P._ptr(Xm), 2) == 5
+    assert t(111, 1.0, A.h, d.h, 0, P._ptr(Bm), 2, 2, P._ptr(Xm), 2) == 5           # missing diagonal, non-unit
+    assert L.aoclsparse_strsm(111, 1.0, A.h, d.h, 0, P._ptr(Bm), 2, 2, P._ptr(Xm), 2) == 9

@@ -806,3 +806,89 @@ def test_csrmm_beta0_nonfinite_c_policy():
     env = dict(os.environ, AOCLSPARSE_MI355_CSRMM_STRICT_BETA0="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "strict ok" in out.stdout, out.stderr[-2000:]
+
+
+# --------------------------------------------------------------------------------------------------
+# "next" rows of SURVEY 8f: trsm, dotmv, value mutation
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("order", [P.ORDER_ROW, P.ORDER_COLUMN])
+@pytest.mark.parametrize("kid", [None, 0, 3])
+def test_trsm_equals_trsv_per_column(order, kid):
+    """level3/aoclsparse_trsm.hpp:150-158: trsm IS a loop of trsv over the columns -> each column must be
+    bit-identical to the serial reference solve of that column."""
+    m, n = 6000, 7
+    rp, ci, v = triangular_system(161, m, 5, band=200)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    rng = np.random.default_rng(6)
+    for fill, trans, unit in (("lower", "n", False), ("upper", "t", True)):
+        d = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=P.FILL_LOWER if fill == "lower" else P.FILL_UPPER,
+                    diag=P.DIAG_UNIT if unit else P.DIAG_NON_UNIT)
+        op = P.OP_NONE if trans == "n" else P.OP_TRANSPOSE
+        if order == P.ORDER_ROW:
+            ldb, ldx = n + 2, n + 1
+            Bm, Xm = rng.uniform(-1, 1, (m, ldb)), np.full((m, ldx), 9.0)
+            cols_b = [Bm[:, j].copy() for j in range(n)]
+        else:
+            ldb, ldx = m + 3, m
+            Bm, Xm = rng.uniform(-1, 1, (n, ldb)), np.full((n, ldx), 9.0)
+            cols_b = [Bm[j, :m].copy() for j in range(n)]
+        fn = L.aoclsparse_dtrsm if kid is None else L.aoclsparse_dtrsm_kid
+        args = [op, 0.7, A.h, d.h, order, P._ptr(Bm), n, ldb, P._ptr(Xm), ldx] + ([] if kid is None else [kid])
+        assert fn(*args) == 0
+        Xd = dev(np.full_like(Xm, 9.0))
+        args[5], args[8] = P._ptr(dev(Bm)), P._ptr(Xd)
+        assert fn(*args) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(Xd.cpu().numpy(), Xm)
+        for j in range(n):
+            xr = oracle_trsv(0, m, rp, ci, v, fill, trans, unit, 0.7, cols_b[j])
+            got = Xm[:, j] if order == P.ORDER_ROW else Xm[j, :m]
+            assert np.array_equal(got, xr), (order, kid, fill, j)
+        if order == P.ORDER_ROW:
+            assert np.all(Xm[:, n:] == 9.0)  # padding untouched
+
+
+def test_dotmv():
+    m, n = 3000, 2600
+    rp, ci, v = random_csr(171, m, n, lambda r, i: r.integers(0, 12))
+    A = P.Matrix(0, m, n, rp, ci, v)
+    d = P.Descr()
+    rng = np.random.default_rng(8)
+    x, y0 = rng.uniform(-1, 1, n), rng.uniform(-1, 1, m)
+    y, dot = y0.copy(), np.zeros(1)
+    assert L.aoclsparse_ddotmv(P.OP_NONE, 1.3, A.h, d.h, P._ptr(x), -0.2, P._ptr(y), P._ptr(dot)) == 0
+    so, yr = oracle.dcsrmv(-1, 0, 1.3, m, len(v), v, ci, rp, x, -0.2, y0)
+    assert np.array_equal(y, yr)
+    k = min(m, n)
+    ref = float(np.dot(x[:k].astype(np.longdouble), yr[:k].astype(np.longdouble)))
+    assert abs(dot[0] - ref) <= 2 * k * EPS64 * float(np.dot(np.abs(x[:k]), np.abs(yr[:k])))
+    xd, yd, dd = dev(x), dev(y0), torch.zeros(1, dtype=torch.float64, device="cuda")
+    assert L.aoclsparse_ddotmv(P.OP_NONE, 1.3, A.h, d.h, P._ptr(xd), -0.2, P._ptr(yd), P._ptr(dd)) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(yd.cpu().numpy(), yr) and dd.item() == dot[0]  # deterministic tree
+
+
+def test_set_value_and_update_values_refresh_the_device_copy():
+    m, rp, ci, v = laplace5(40)
+    v = v.copy()
+    A = P.Matrix(0, m, m, rp, ci, v)
+    d = P.Descr()
+    x = np.random.default_rng(3).uniform(-1, 1, m)
+    st, y1 = run_dmv(A, d, x, np.zeros(m), 1.0, 0.0)
+    assert L.aoclsparse_dset_value(A.h, 7, 7, 123.5) == 0
+    st, y2 = run_dmv(A, d, x, np.zeros(m), 1.0, 0.0)
+    so, yr = oracle.dcsrmv(-1, 0, 1.0, m, len(v), A.val, ci, rp, x, 0.0, np.zeros(m))
+    assert np.array_equal(y2, yr) and y2[7] != y1[7]
+    nv = np.random.default_rng(4).uniform(-1, 1, len(v))
+    assert L.aoclsparse_dupdate_values(A.h, len(v), P._ptr(nv)) == 0
+    st, y3 = run_dmv(A, d, x, np.zeros(m), 1.0, 0.0)
+    so, yr = oracle.dcsrmv(-1, 0, 1.0, m, len(v), nv, ci, rp, x, 0.0, np.zeros(m))
+    assert np.array_equal(y3, yr)
+    # the triangular solve plan is rebuilt from the new values too
+    dt = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=P.FILL_LOWER, diag=P.DIAG_UNIT)
+    b, xs = np.ones(m), np.zeros(m)
+    assert P.dtrsv(P.OP_NONE, 1.0, A, dt, b, xs) == 0
+    assert L.aoclsparse_dset_value(A.h, 50, 49, 0.25) == 0
+    xs2 = np.zeros(m)
+    assert P.dtrsv(P.OP_NONE, 1.0, A, dt, b, xs2) == 0
+    assert np.array_equal(xs2, oracle_trsv(0, m, rp, ci, A.val, "lower", "n", True, 1.0, b)) and not np.array_equal(xs, xs2)
