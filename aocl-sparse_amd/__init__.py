@@ -97,6 +97,21 @@ SIGNATURES = {
     "aoclsparse_dtrsm": (c_int, [c_int, c_double, _P, _P, c_int, _P, _I, _I, _P, _I]),
     "aoclsparse_strsm_kid": (c_int, [c_int, c_float, _P, _P, c_int, _P, _I, _I, _P, _I, _I]),
     "aoclsparse_dtrsm_kid": (c_int, [c_int, c_double, _P, _P, c_int, _P, _I, _I, _P, _I, _I]),
+    "aoclsparse_ssymgs": (c_int, [c_int, _P, _P, c_float, _P, _P]),
+    "aoclsparse_dsymgs": (c_int, [c_int, _P, _P, c_double, _P, _P]),
+    "aoclsparse_ssymgs_kid": (c_int, [c_int, _P, _P, c_float, _P, _P, _I]),
+    "aoclsparse_dsymgs_kid": (c_int, [c_int, _P, _P, c_double, _P, _P, _I]),
+    "aoclsparse_ssymgs_mv": (c_int, [c_int, _P, _P, c_float, _P, _P, _P]),
+    "aoclsparse_dsymgs_mv": (c_int, [c_int, _P, _P, c_double, _P, _P, _P]),
+    "aoclsparse_ssymgs_mv_kid": (c_int, [c_int, _P, _P, c_float, _P, _P, _P, _I]),
+    "aoclsparse_dsymgs_mv_kid": (c_int, [c_int, _P, _P, c_double, _P, _P, _P, _I]),
+    "aoclsparse_silu_smoother": (c_int, [c_int, _P, _P, POINTER(_P), _P, _P, _P]),
+    "aoclsparse_dilu_smoother": (c_int, [c_int, _P, _P, POINTER(_P), _P, _P, _P]),
+    "aoclsparse_set_dotmv_hint": (c_int, [_P, c_int, _P, _I]),
+    "aoclsparse_set_lu_smoother_hint": (c_int, [_P, c_int, _P, _I]),
+    "aoclsparse_set_sm_hint": (c_int, [_P, c_int, _P, c_int, _I]),
+    "aoclsparse_set_symgs_hint": (c_int, [_P, c_int, _P, _I]),
+    "aoclsparse_set_sorv_hint": (c_int, [_P, _P, c_int, _I]),
     "aoclsparse_scsrmm": (c_int, [c_int, c_float, _P, _P, c_int, _P, _I, _I, c_float, _P, _I]),
     "aoclsparse_dcsrmm": (c_int, [c_int, c_double, _P, _P, c_int, _P, _I, _I, c_double, _P, _I]),
     "aoclsparse_scsrmm_kid": (c_int, [c_int, c_float, _P, _P, c_int, _P, _I, _I, c_float, _P, _I, _I]),

@@ -50,11 +50,13 @@ enum hinted_action
     action_mm,
     action_2m,
     action_ilu0,
-    action_sm,
+    action_sm_row,
+    action_sm_col,
     action_dotmv,
     action_symgs,
-    action_sorv,
-    action_syrk,
+    action_sorv_forward,
+    action_sorv_backward,
+    action_sorv_symm,
     action_max
 };
 
@@ -210,6 +212,14 @@ struct _aoclsparse_matrix
     // sp2m stage-1 state (C handles own their arrays)
     bool owns_user_arrays = false;
 
+    // composite solvers (solvers_api.cpp): vector workspaces in HBM, and the ILU(0) factors
+    // (solvers/aoclsparse_ilu.hpp:94-104, analysis.cpp:390-425): values on the user's pattern, kept
+    // on the host for *precond_csr_val and mirrored by a factor handle whose TRSV plans do the solves
+    mi355::DeviceBuffer work[6];
+    bool                ilu_ready = false, ilu_factorized = false;
+    void               *ilu_val = nullptr; // nnz values, library-owned (malloc)
+    aoclsparse_matrix   ilu_factor = nullptr; // aliases user.ptr / user.ind / ilu_val
+
     mutable std::shared_mutex guard;
 };
 
@@ -248,6 +258,17 @@ private:
     DeviceBuffer stage_[8];
 };
 
+// While one of these is alive on a thread, every pointer handed to the executors by that thread is
+// taken as device memory: composite routines (symgs, ilu smoother, iterative solvers) chain the
+// executors on their own HBM workspaces whatever pointer mode the caller selected.
+struct DeviceScope
+{
+    DeviceScope();
+    ~DeviceScope();
+    DeviceScope(const DeviceScope &)            = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
+
 // ---- host analysis (matrix.cpp) --------------------------------------------------------------
 aoclsparse_status mat_check(aoclsparse_int maj, aoclsparse_int mind, aoclsparse_int nnz,
                             const aoclsparse_int *ptr, const aoclsparse_int *ind, const void *val,
@@ -260,6 +281,8 @@ aoclsparse_status csr_indices(aoclsparse_int m, aoclsparse_index_base base,
                               aoclsparse_int **idiag, aoclsparse_int **iurow);
 // builds A->opt (clean CSR + idiag/iurow) if absent; thread-safe (double-checked)
 aoclsparse_status csr_optimize(aoclsparse_matrix A);
+// allocates the ILU(0) value array as a copy of A's values (solvers_api.cpp; analysis.cpp:390-425)
+aoclsparse_status ilu_prepare(aoclsparse_matrix A);
 // builds A->trans (host transpose of the user CSR, 0-based) if absent
 aoclsparse_status build_transpose(aoclsparse_matrix A);
 
@@ -285,6 +308,9 @@ aoclsparse_status launch_csrmv(hipStream_t s, int order, bool strict, int tile, 
                                aoclsparse_int nblocks, const T *x, T beta, T *y);
 template <typename T>
 aoclsparse_status launch_scale(hipStream_t s, T *y, aoclsparse_int n, T beta);
+// w = a*x + b*y elementwise (w may alias x or y); a == 1, b == -1 is an exact subtraction
+template <typename T>
+aoclsparse_status launch_waxpby(hipStream_t s, aoclsparse_int n, T a, const T *x, T b, const T *y, T *w);
 // d = x . y; partial must hold 1024 elements (spmv_kernels.hip)
 template <typename T>
 aoclsparse_status launch_dot(hipStream_t s, aoclsparse_int n, const T *x, const T *y, T *partial, T *d);

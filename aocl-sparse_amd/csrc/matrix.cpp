@@ -635,6 +635,9 @@ aoclsparse_status aoclsparse_destroy(aoclsparse_matrix *mat)
     {
         if((*mat)->owns_user_arrays)
             (*mat)->user.owned = true; // sp2m results: the handle owns its CSR
+        if((*mat)->ilu_factor)
+            aoclsparse_destroy(&(*mat)->ilu_factor); // aliases ptr/ind/ilu_val: frees only its own plans
+        std::free((*mat)->ilu_val);
         delete *mat;
         *mat = nullptr;
     }
@@ -899,6 +902,44 @@ aoclsparse_status aoclsparse_set_2m_hint(aoclsparse_matrix mat, aoclsparse_opera
                                          const aoclsparse_mat_descr descr, aoclsparse_int n)
 {
     return set_hint(mat, action_2m, trans, descr, n);
+}
+
+aoclsparse_status aoclsparse_set_dotmv_hint(aoclsparse_matrix mat, aoclsparse_operation trans,
+                                            const aoclsparse_mat_descr descr, aoclsparse_int n)
+{
+    return set_hint(mat, action_dotmv, trans, descr, n);
+}
+
+aoclsparse_status aoclsparse_set_lu_smoother_hint(aoclsparse_matrix mat, aoclsparse_operation trans,
+                                                  const aoclsparse_mat_descr descr, aoclsparse_int n)
+{
+    return set_hint(mat, action_ilu0, trans, descr, n);
+}
+
+aoclsparse_status aoclsparse_set_sm_hint(aoclsparse_matrix mat, aoclsparse_operation trans,
+                                         const aoclsparse_mat_descr descr, const aoclsparse_order order,
+                                         aoclsparse_int n)
+{
+    if(order != aoclsparse_order_row && order != aoclsparse_order_column) // analysis.cpp:686-689
+        return aoclsparse_status_invalid_value;
+    return set_hint(mat, order == aoclsparse_order_row ? action_sm_row : action_sm_col, trans, descr, n);
+}
+
+aoclsparse_status aoclsparse_set_symgs_hint(aoclsparse_matrix mat, aoclsparse_operation trans,
+                                            const aoclsparse_mat_descr descr, aoclsparse_int n)
+{
+    return set_hint(mat, action_symgs, trans, descr, n);
+}
+
+aoclsparse_status aoclsparse_set_sorv_hint(aoclsparse_matrix mat, const aoclsparse_mat_descr descr,
+                                           const aoclsparse_sor_type type, const aoclsparse_int n)
+{
+    if(type != aoclsparse_sor_forward && type != aoclsparse_sor_backward && type != aoclsparse_sor_symmetric)
+        return aoclsparse_status_invalid_value; // analysis.cpp:713-717
+    const hinted_action act = type == aoclsparse_sor_forward    ? action_sorv_forward
+                              : type == aoclsparse_sor_backward ? action_sorv_backward
+                                                                : action_sorv_symm;
+    return set_hint(mat, act, aoclsparse_operation_none, descr, n);
 }
 
 aoclsparse_status aoclsparse_set_memory_hint(aoclsparse_matrix mat, const aoclsparse_memory_usage policy)

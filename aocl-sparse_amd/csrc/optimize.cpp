@@ -31,6 +31,8 @@ extern "C" aoclsparse_status aoclsparse_optimize(aoclsparse_matrix A)
         if((h.act == action_mv || h.act == action_dotmv) && h.trans == aoclsparse_operation_none
            && h.type == aoclsparse_matrix_type_general && A->val_type == aoclsparse_dmat && h.nop > 0)
             mv_count++; // would select optimize_mv in the reference; here every mv hint gets a plan
+        else if((h.act == action_ilu0 || h.act == action_symgs) && h.nop > 0)
+            ; // counted apart (analysis.cpp:499-502): neither asks for the clean CSR
         else
             other++;
         sum++;
@@ -46,6 +48,15 @@ extern "C" aoclsparse_status aoclsparse_optimize(aoclsparse_matrix A)
         if(st != aoclsparse_status_success)
             return st;
     }
+
+    // analysis.cpp:555-564: an ILU hint makes optimize allocate the factor's value array
+    for(Hint &h : A->hints)
+        if(!h.optimized && h.act == action_ilu0)
+        {
+            st = ilu_prepare(A);
+            if(st != aoclsparse_status_success)
+                return st;
+        }
 
     // Device residency + plans.  A box without a GPU (the CPU-only test tier) still completes the
     // host analysis above; device work is attempted only when a device exists and is skipped for
@@ -64,7 +75,7 @@ extern "C" aoclsparse_status aoclsparse_optimize(aoclsparse_matrix A)
                 SpmvPlan  *p = nullptr;
                 st = ensure_spmv(A, h.trans != aoclsparse_operation_none, d, p);
             }
-            else if(h.act == action_sv
+            else if((h.act == action_sv || h.act == action_sm_row || h.act == action_sm_col)
                     && (h.type == aoclsparse_matrix_type_triangular
                         || h.type == aoclsparse_matrix_type_symmetric))
             {

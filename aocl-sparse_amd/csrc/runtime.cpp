@@ -116,8 +116,20 @@ aoclsparse_status Runtime::init()
     return init_status_;
 }
 
+thread_local int tl_device_scope = 0;
+DeviceScope::DeviceScope()
+{
+    ++tl_device_scope;
+}
+DeviceScope::~DeviceScope()
+{
+    --tl_device_scope;
+}
+
 bool Runtime::is_device_pointer(const void *p)
 {
+    if(tl_device_scope > 0) // a composite routine calling the executors on its own device buffers
+        return true;
     if(pointer_mode == aoclsparse_mi355_pointer_device)
         return true;
     if(pointer_mode == aoclsparse_mi355_pointer_host)

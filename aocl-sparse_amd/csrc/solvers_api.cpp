@@ -1,0 +1,425 @@
+// solvers_api.cpp -- composite routines on top of the SpMV / TRSV executors: symmetric Gauss-Seidel
+// (aoclsparse_?symgs, ?symgs_mv) and the ILU(0) smoother (aoclsparse_?ilu_smoother).
+//
+// Both keep every intermediate vector in HBM: host operands are staged once on entry, the executors are
+// chained on the library stream under a DeviceScope, and only the results travel back.
+//   symgs : solvers/aoclsparse_symgs.hpp:62-258 (algorithm), :264-394 (checks)
+//   ilu   : solvers/aoclsparse_ilu.hpp:33-139, solvers/aoclsparse_ilu0.hpp:34-199, analysis.cpp:390-425
+#include "internal.hpp"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+using namespace mi355;
+
+namespace
+{
+
+// typed access to the public executors (the composites are written once for float and double)
+inline aoclsparse_status exec_mv(aoclsparse_operation op, const double *alpha, aoclsparse_matrix A,
+                                 const aoclsparse_mat_descr d, const double *x, const double *beta, double *y)
+{
+    return aoclsparse_dmv(op, alpha, A, d, x, beta, y);
+}
+inline aoclsparse_status exec_mv(aoclsparse_operation op, const float *alpha, aoclsparse_matrix A,
+                                 const aoclsparse_mat_descr d, const float *x, const float *beta, float *y)
+{
+    return aoclsparse_smv(op, alpha, A, d, x, beta, y);
+}
+inline aoclsparse_status exec_trsv(aoclsparse_operation op, double alpha, aoclsparse_matrix A,
+                                   const aoclsparse_mat_descr d, const double *b, double *x, aoclsparse_int kid)
+{
+    return aoclsparse_dtrsv_kid(op, alpha, A, d, b, x, kid);
+}
+inline aoclsparse_status exec_trsv(aoclsparse_operation op, float alpha, aoclsparse_matrix A,
+                                   const aoclsparse_mat_descr d, const float *b, float *x, aoclsparse_int kid)
+{
+    return aoclsparse_strsv_kid(op, alpha, A, d, b, x, kid);
+}
+inline aoclsparse_status create_csr(aoclsparse_matrix *M, aoclsparse_index_base b, aoclsparse_int m, aoclsparse_int n,
+                                    aoclsparse_int nnz, aoclsparse_int *p, aoclsparse_int *c, double *v)
+{
+    return aoclsparse_create_dcsr(M, b, m, n, nnz, p, c, v);
+}
+inline aoclsparse_status create_csr(aoclsparse_matrix *M, aoclsparse_index_base b, aoclsparse_int m, aoclsparse_int n,
+                                    aoclsparse_int nnz, aoclsparse_int *p, aoclsparse_int *c, float *v)
+{
+    return aoclsparse_create_scsr(M, b, m, n, nnz, p, c, v);
+}
+
+// A caller's vector made device-resident for the duration of one composite call.
+template <typename T>
+struct Vec
+{
+    T    *dev  = nullptr;
+    T    *host = nullptr;
+    bool  staged = false;
+    aoclsparse_status in(Runtime &rt, DeviceBuffer &buf, const T *p, aoclsparse_int n, bool copy)
+    {
+        if(rt.is_device_pointer(p))
+        {
+            dev = const_cast<T *>(p);
+            return aoclsparse_status_success;
+        }
+        staged = true;
+        host   = const_cast<T *>(p);
+        aoclsparse_status st = buf.alloc(sizeof(T) * (size_t)n);
+        if(st != aoclsparse_status_success)
+            return st;
+        dev = buf.as<T>();
+        if(copy)
+            MI355_HIP_TRY(hipMemcpyAsync(dev, p, sizeof(T) * (size_t)n, hipMemcpyHostToDevice, rt.stream()));
+        return aoclsparse_status_success;
+    }
+    aoclsparse_status out(Runtime &rt, aoclsparse_int n)
+    {
+        if(staged)
+            MI355_HIP_TRY(hipMemcpyAsync(host, dev, sizeof(T) * (size_t)n, hipMemcpyDeviceToHost, rt.stream()));
+        return aoclsparse_status_success;
+    }
+};
+
+#define MI355_TRY(expr)                          \
+    do                                           \
+    {                                            \
+        aoclsparse_status st__ = (expr);         \
+        if(st__ != aoclsparse_status_success)    \
+            return st__;                         \
+    } while(0)
+
+// ---- symmetric Gauss-Seidel ------------------------------------------------------------------------
+template <typename T>
+aoclsparse_status symgs_t(aoclsparse_operation trans, aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                          const T alpha, const T *b, T *x, T *y, aoclsparse_int kid, bool fuse_mv,
+                          aoclsparse_matrix_data_type vt)
+{
+    // symgs.hpp:276-352, same order
+    if(!x || !b)
+        return aoclsparse_status_invalid_pointer;
+    if(fuse_mv && !y)
+        return aoclsparse_status_invalid_pointer;
+    if(!A || !descr)
+        return aoclsparse_status_invalid_pointer;
+    if(!A->user.ptr)
+        return aoclsparse_status_invalid_pointer;
+    if(descr->base != A->base)
+        return aoclsparse_status_invalid_value;
+    if(A->input_format != aoclsparse_csr_mat)
+        return aoclsparse_status_not_implemented;
+    if(descr->base != aoclsparse_index_base_zero && descr->base != aoclsparse_index_base_one)
+        return aoclsparse_status_invalid_value;
+    if(trans != aoclsparse_operation_none && trans != aoclsparse_operation_transpose
+       && trans != aoclsparse_operation_conjugate_transpose)
+        return aoclsparse_status_invalid_value;
+    if(descr->fill_mode != aoclsparse_fill_mode_lower && descr->fill_mode != aoclsparse_fill_mode_upper)
+        return aoclsparse_status_invalid_value;
+    if(descr->diag_type == aoclsparse_diag_type_unit)
+        return aoclsparse_status_not_implemented;
+    if(descr->type == aoclsparse_matrix_type_general && trans == aoclsparse_operation_conjugate_transpose)
+        return aoclsparse_status_not_implemented;
+    if(descr->type != aoclsparse_matrix_type_symmetric && descr->type != aoclsparse_matrix_type_triangular
+       && descr->type != aoclsparse_matrix_type_general && descr->type != aoclsparse_matrix_type_hermitian)
+        return aoclsparse_status_invalid_value;
+    if(A->m < 0 || A->nnz < 0 || A->n < 0)
+        return aoclsparse_status_invalid_size;
+    if(A->m == 0 || A->n == 0 || A->nnz == 0)
+        return aoclsparse_status_success;
+    if(A->m != A->n)
+        return aoclsparse_status_invalid_size;
+    if(A->val_type != vt)
+        return aoclsparse_status_wrong_type;
+    MI355_TRY(csr_optimize(A));
+    if(!A->opt_csr_full_diag) // unit diagonals were refused above
+        return aoclsparse_status_invalid_value;
+    (void)kid; // symgs.hpp:354-381: every kid runs the reference composition
+
+    Runtime &rt = Runtime::get();
+    MI355_TRY(rt.init());
+    std::lock_guard<std::recursive_mutex> sl(rt.stage_lock); // the handle's workspaces are shared
+    const aoclsparse_int m = A->m;
+    Vec<T>               vb, vx, vy;
+    MI355_TRY(vb.in(rt, A->work[2], b, m, true));
+    MI355_TRY(vx.in(rt, A->work[3], x, m, true)); // x carries the initial guess
+    if(fuse_mv)
+        MI355_TRY(vy.in(rt, A->work[4], y, m, false));
+    const T one = T(1), zero = T(0);
+    {
+        DeviceScope scope;
+        if(descr->type == aoclsparse_matrix_type_triangular)
+        {
+            // symgs.hpp:128-149: a single solve with the given triangle (+ the product)
+            MI355_TRY(exec_trsv(trans, one, A, descr, vb.dev, vx.dev, -1));
+            if(fuse_mv)
+                MI355_TRY(exec_mv(trans, &one, A, descr, vx.dev, &zero, vy.dev));
+        }
+        else
+        {
+            MI355_TRY(A->work[0].alloc(sizeof(T) * (size_t)m));
+            MI355_TRY(A->work[1].alloc(sizeof(T) * (size_t)m));
+            T *r = A->work[0].as<T>(), *q = A->work[1].as<T>();
+            // which stored triangle plays L and which U, and under which operation (symgs.hpp:151-190)
+            aoclsparse_operation u_trans = aoclsparse_operation_transpose, l_trans = aoclsparse_operation_none;
+            aoclsparse_fill_mode u_fill = aoclsparse_fill_mode_lower, l_fill = aoclsparse_fill_mode_lower;
+            if(descr->type == aoclsparse_matrix_type_hermitian)
+                u_trans = aoclsparse_operation_conjugate_transpose;
+            if(descr->type == aoclsparse_matrix_type_symmetric && descr->fill_mode == aoclsparse_fill_mode_upper)
+            {
+                u_fill = l_fill = aoclsparse_fill_mode_upper;
+                u_trans = aoclsparse_operation_none, l_trans = aoclsparse_operation_transpose;
+            }
+            else if(descr->type == aoclsparse_matrix_type_general && trans == aoclsparse_operation_none)
+            {
+                u_trans = l_trans = aoclsparse_operation_none;
+                u_fill            = aoclsparse_fill_mode_upper;
+            }
+            else if(descr->type == aoclsparse_matrix_type_general && trans == aoclsparse_operation_transpose)
+            {
+                u_trans = l_trans = aoclsparse_operation_transpose;
+                l_fill = aoclsparse_fill_mode_upper, u_fill = aoclsparse_fill_mode_lower;
+            }
+            else if(descr->type == aoclsparse_matrix_type_hermitian && descr->fill_mode == aoclsparse_fill_mode_upper)
+            {
+                u_fill = l_fill = aoclsparse_fill_mode_upper;
+                u_trans = aoclsparse_operation_none, l_trans = aoclsparse_operation_conjugate_transpose;
+            }
+            _aoclsparse_mat_descr d = *descr;
+            d.type                  = aoclsparse_matrix_type_triangular;
+            auto with = [&](aoclsparse_fill_mode f, aoclsparse_diag_type dt) {
+                d.fill_mode = f, d.diag_type = dt;
+                return &d;
+            };
+            // 1: (L + D) x1 = b - alpha U x0
+            MI355_TRY(exec_mv(u_trans, &alpha, A, with(u_fill, aoclsparse_diag_type_zero), vx.dev, &zero, q));
+            MI355_TRY(launch_waxpby<T>(rt.stream(), m, one, vb.dev, T(-1), q, r));
+            MI355_TRY(exec_trsv(l_trans, one, A, with(l_fill, aoclsparse_diag_type_non_unit), r, q, -1));
+            // 2: (U + D) x = b - L x1
+            MI355_TRY(exec_mv(l_trans, &one, A, with(l_fill, aoclsparse_diag_type_zero), q, &zero, r));
+            MI355_TRY(launch_waxpby<T>(rt.stream(), m, one, vb.dev, T(-1), r, q));
+            MI355_TRY(exec_trsv(u_trans, one, A, with(u_fill, aoclsparse_diag_type_non_unit), q, vx.dev, -1));
+            // 3: y = op(A) x
+            if(fuse_mv)
+                MI355_TRY(exec_mv(trans, &one, A, descr, vx.dev, &zero, vy.dev));
+        }
+    }
+    MI355_TRY(vx.out(rt, m));
+    if(fuse_mv)
+        MI355_TRY(vy.out(rt, m));
+    if(vx.staged || vy.staged)
+        MI355_HIP_TRY(hipStreamSynchronize(rt.stream()));
+    return aoclsparse_status_success;
+}
+
+// ---- ILU(0) ------------------------------------------------------------------------------------------
+template <typename T>
+bool near_zero(T v)
+{
+    // aoclsparse_is_nearzero, extra/aoclsparse_utils.hpp:598-613: |v| <= 1e-2 * 2 * macheps
+    return std::fabs(v) <= T(1e-2) * T(2) * std::numeric_limits<T>::epsilon();
+}
+
+// IKJ factorisation on the user's pattern, in place in `val` (ilu0.hpp:34-111).  Host, serial: it runs
+// once per handle; the per-iteration work -- the two triangular solves -- is what runs on the GPU.
+template <typename T>
+aoclsparse_status ilu0_factorize(aoclsparse_int n, aoclsparse_int base, const aoclsparse_int *ptr,
+                                 const aoclsparse_int *ind, T *val)
+{
+    std::vector<aoclsparse_int> where, diag;
+    try
+    {
+        where.assign((size_t)n, 0);
+        diag.assign((size_t)n, 0);
+    }
+    catch(const std::bad_alloc &)
+    {
+        return aoclsparse_status_memory_error;
+    }
+    for(aoclsparse_int i = 0; i < n; i++)
+    {
+        const aoclsparse_int s = ptr[i] - base, e = ptr[i + 1] - base;
+        for(aoclsparse_int j = s; j < e; j++)
+            where[ind[j] - base] = j;
+        aoclsparse_int j = s, k = -1;
+        for(; j < e; j++)
+        {
+            k = ind[j] - base;
+            if(k >= i)
+                break;
+            const T pivot = val[diag[k]];
+            if(near_zero(pivot))
+                return aoclsparse_status_numerical_error;
+            val[j] = val[j] / pivot;
+            for(aoclsparse_int jj = diag[k] + 1; jj < ptr[k + 1] - base; jj++)
+            {
+                const aoclsparse_int w = where[ind[jj] - base];
+                if(w != 0) // position 0 doubles as "absent" in the reference's map (:78-82)
+                    val[w] = std::fma(-val[j], val[jj], val[w]);
+            }
+        }
+        diag[i] = j;
+        if(j >= e || k != i || near_zero(val[j]))
+            return aoclsparse_status_numerical_error;
+        for(aoclsparse_int q = s; q < e; q++)
+            where[ind[q] - base] = 0;
+    }
+    return aoclsparse_status_success;
+}
+
+template <typename T>
+aoclsparse_status ilu_smoother_t(aoclsparse_operation op, aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                 T **precond_csr_val, T *x, const T *b, aoclsparse_matrix_data_type vt)
+{
+    // ilu.hpp:43-98, same order
+    if(!descr || !A)
+        return aoclsparse_status_invalid_pointer;
+    if(!x || !b || !precond_csr_val)
+        return aoclsparse_status_invalid_pointer;
+    if(!A->user.ptr)
+        return aoclsparse_status_invalid_pointer;
+    if(descr->base != A->base)
+        return aoclsparse_status_invalid_value;
+    if(op != aoclsparse_operation_none)
+        return aoclsparse_status_not_implemented;
+    if(A->input_format != aoclsparse_csr_mat)
+        return aoclsparse_status_not_implemented;
+    if(descr->type != aoclsparse_matrix_type_general)
+        return aoclsparse_status_not_implemented;
+    if(A->sort != 1 && A->sort != 2) // fully or partially sorted (aoclsparse_matrix_sort)
+        return aoclsparse_status_unsorted_input;
+    if(!A->fulldiag)
+        return aoclsparse_status_numerical_error;
+    if(A->val_type != vt)
+        return aoclsparse_status_wrong_type;
+    if(A->m < 0 || A->n < 0 || A->m != A->n)
+        return aoclsparse_status_invalid_size;
+    if(A->m == 0 || A->n == 0)
+        return aoclsparse_status_success;
+    MI355_TRY(ilu_prepare(A));
+
+    Runtime &rt = Runtime::get();
+    MI355_TRY(rt.init());
+    std::lock_guard<std::recursive_mutex> sl(rt.stage_lock);
+    *precond_csr_val = nullptr;
+    if(!A->ilu_factorized)
+    {
+        MI355_TRY(ilu0_factorize<T>(A->n, A->base, A->user.ptr, A->user.ind, static_cast<T *>(A->ilu_val)));
+        // the factors as a matrix of their own: its level-scheduled TRSV plans are the smoother's solves
+        MI355_TRY(create_csr(&A->ilu_factor, A->base, A->m, A->n, A->nnz, A->user.ptr, A->user.ind,
+                             static_cast<T *>(A->ilu_val)));
+        A->ilu_factorized = true;
+    }
+    *precond_csr_val = static_cast<T *>(A->ilu_val);
+
+    const aoclsparse_int m = A->m;
+    Vec<T>               vb, vx;
+    MI355_TRY(vb.in(rt, A->work[2], b, m, true));
+    MI355_TRY(vx.in(rt, A->work[3], x, m, false));
+    MI355_TRY(A->work[0].alloc(sizeof(T) * (size_t)m));
+    {
+        // ilu0.hpp:113-156: L y = b with the unit lower factor, then U x = y
+        DeviceScope           scope;
+        _aoclsparse_mat_descr d = *descr;
+        d.type                  = aoclsparse_matrix_type_triangular;
+        d.fill_mode = aoclsparse_fill_mode_lower, d.diag_type = aoclsparse_diag_type_unit;
+        MI355_TRY(exec_trsv(aoclsparse_operation_none, T(1), A->ilu_factor, &d, vb.dev, A->work[0].as<T>(), -1));
+        d.fill_mode = aoclsparse_fill_mode_upper, d.diag_type = aoclsparse_diag_type_non_unit;
+        MI355_TRY(exec_trsv(aoclsparse_operation_none, T(1), A->ilu_factor, &d, A->work[0].as<T>(), vx.dev, -1));
+    }
+    MI355_TRY(vx.out(rt, m));
+    if(vx.staged)
+        MI355_HIP_TRY(hipStreamSynchronize(rt.stream()));
+    return aoclsparse_status_success;
+}
+
+} // namespace
+
+namespace mi355
+{
+
+// analysis.cpp:390-425 (aoclsparse_optimize_ilu): the factor values start as a copy of A's values
+aoclsparse_status ilu_prepare(aoclsparse_matrix A)
+{
+    if(!A)
+        return aoclsparse_status_invalid_pointer;
+    if(!A->user.val)
+        return aoclsparse_status_invalid_pointer;
+    if(A->ilu_ready)
+        return aoclsparse_status_success;
+    const size_t bytes = val_size(A->val_type) * (size_t)A->nnz;
+    A->ilu_val         = std::malloc(bytes ? bytes : 1);
+    if(!A->ilu_val)
+        return aoclsparse_status_memory_error;
+    std::memcpy(A->ilu_val, A->user.val, bytes);
+    A->ilu_ready = true;
+    return aoclsparse_status_success;
+}
+
+} // namespace mi355
+
+extern "C" {
+
+aoclsparse_status aoclsparse_dsymgs(aoclsparse_operation trans, aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                    const double alpha, const double *b, double *x)
+{
+    return symgs_t<double>(trans, A, descr, alpha, b, x, nullptr, -1, false, aoclsparse_dmat);
+}
+aoclsparse_status aoclsparse_ssymgs(aoclsparse_operation trans, aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                    const float alpha, const float *b, float *x)
+{
+    return symgs_t<float>(trans, A, descr, alpha, b, x, nullptr, -1, false, aoclsparse_smat);
+}
+aoclsparse_status aoclsparse_dsymgs_kid(aoclsparse_operation trans, aoclsparse_matrix A,
+                                        const aoclsparse_mat_descr descr, const double alpha, const double *b,
+                                        double *x, const aoclsparse_int kid)
+{
+    return symgs_t<double>(trans, A, descr, alpha, b, x, nullptr, kid, false, aoclsparse_dmat);
+}
+aoclsparse_status aoclsparse_ssymgs_kid(aoclsparse_operation trans, aoclsparse_matrix A,
+                                        const aoclsparse_mat_descr descr, const float alpha, const float *b, float *x,
+                                        const aoclsparse_int kid)
+{
+    return symgs_t<float>(trans, A, descr, alpha, b, x, nullptr, kid, false, aoclsparse_smat);
+}
+aoclsparse_status aoclsparse_dsymgs_mv(aoclsparse_operation trans, aoclsparse_matrix A,
+                                       const aoclsparse_mat_descr descr, const double alpha, const double *b,
+                                       double *x, double *y)
+{
+    return symgs_t<double>(trans, A, descr, alpha, b, x, y, -1, true, aoclsparse_dmat);
+}
+aoclsparse_status aoclsparse_ssymgs_mv(aoclsparse_operation trans, aoclsparse_matrix A,
+                                       const aoclsparse_mat_descr descr, const float alpha, const float *b, float *x,
+                                       float *y)
+{
+    return symgs_t<float>(trans, A, descr, alpha, b, x, y, -1, true, aoclsparse_smat);
+}
+aoclsparse_status aoclsparse_dsymgs_mv_kid(aoclsparse_operation trans, aoclsparse_matrix A,
+                                           const aoclsparse_mat_descr descr, const double alpha, const double *b,
+                                           double *x, double *y, const aoclsparse_int kid)
+{
+    return symgs_t<double>(trans, A, descr, alpha, b, x, y, kid, true, aoclsparse_dmat);
+}
+aoclsparse_status aoclsparse_ssymgs_mv_kid(aoclsparse_operation trans, aoclsparse_matrix A,
+                                           const aoclsparse_mat_descr descr, const float alpha, const float *b,
+                                           float *x, float *y, const aoclsparse_int kid)
+{
+    return symgs_t<float>(trans, A, descr, alpha, b, x, y, kid, true, aoclsparse_smat);
+}
+
+aoclsparse_status aoclsparse_dilu_smoother(aoclsparse_operation op, aoclsparse_matrix A,
+                                           const aoclsparse_mat_descr descr, double **precond_csr_val,
+                                           const double *approx_inv_diag, double *x, const double *b)
+{
+    (void)approx_inv_diag; // unused by the reference as well (solvers/aoclsparse_ilu.cpp:43-52)
+    return ilu_smoother_t<double>(op, A, descr, precond_csr_val, x, b, aoclsparse_dmat);
+}
+aoclsparse_status aoclsparse_silu_smoother(aoclsparse_operation op, aoclsparse_matrix A,
+                                           const aoclsparse_mat_descr descr, float **precond_csr_val,
+                                           const float *approx_inv_diag, float *x, const float *b)
+{
+    (void)approx_inv_diag;
+    return ilu_smoother_t<float>(op, A, descr, precond_csr_val, x, b, aoclsparse_smat);
+}
+
+} // extern "C"

@@ -459,6 +459,24 @@ aoclsparse_status launch_csrmv(hipStream_t s, int order, bool strict, int tile, 
 }
 
 template <typename T>
+__global__ void waxpby_kernel(aoclsparse_int n, T a, const T *x, T b, const T *y, T *w)
+{
+    const aoclsparse_int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n)
+        w[i] = a * x[i] + b * y[i]; // built with -ffp-contract=off: two products, one sum
+}
+
+template <typename T>
+aoclsparse_status launch_waxpby(hipStream_t s, aoclsparse_int n, T a, const T *x, T b, const T *y, T *w)
+{
+    if(n <= 0)
+        return aoclsparse_status_success;
+    hipLaunchKernelGGL((waxpby_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, s, n, a, x, b, y, w);
+    MI355_HIP_TRY(hipGetLastError());
+    return aoclsparse_status_success;
+}
+
+template <typename T>
 aoclsparse_status launch_scale(hipStream_t s, T *y, aoclsparse_int n, T beta)
 {
     if(n <= 0)
@@ -495,6 +513,7 @@ aoclsparse_status launch_strided_scatter(hipStream_t s, const T *src, aoclsparse
                                                const aoclsparse_int *, const aoclsparse_int *,                  \
                                                const aoclsparse_int *, aoclsparse_int, const T *, T, T *);      \
     template aoclsparse_status launch_scale<T>(hipStream_t, T *, aoclsparse_int, T);                           \
+    template aoclsparse_status launch_waxpby<T>(hipStream_t, aoclsparse_int, T, const T *, T, const T *, T *); \
     template aoclsparse_status launch_dot<T>(hipStream_t, aoclsparse_int, const T *, const T *, T *, T *);     \
     template aoclsparse_status launch_strided_gather<T>(hipStream_t, const T *, aoclsparse_int,                 \
                                                         aoclsparse_int, T *);                                   \

@@ -104,6 +104,13 @@ typedef enum aoclsparse_order_ /* :289-293 */
     aoclsparse_order_column = 1
 } aoclsparse_order;
 
+typedef enum aoclsparse_sor_type_ /* :356-361 */
+{
+    aoclsparse_sor_forward   = 0,
+    aoclsparse_sor_backward  = 1,
+    aoclsparse_sor_symmetric = 2
+} aoclsparse_sor_type;
+
 typedef enum aoclsparse_status_ /* :304-324 */
 {
     aoclsparse_status_success             = 0,
@@ -237,6 +244,28 @@ DLL_PUBLIC aoclsparse_status aoclsparse_set_2m_hint(aoclsparse_matrix          m
                                                     aoclsparse_operation       trans,
                                                     const aoclsparse_mat_descr descr,
                                                     aoclsparse_int expected_no_of_calls);
+/* aoclsparse_analysis.h: the remaining hint setters record the action in the same list. */
+DLL_PUBLIC aoclsparse_status aoclsparse_set_dotmv_hint(aoclsparse_matrix          mat,
+                                                       aoclsparse_operation       trans,
+                                                       const aoclsparse_mat_descr descr,
+                                                       aoclsparse_int expected_no_of_calls);
+DLL_PUBLIC aoclsparse_status aoclsparse_set_lu_smoother_hint(aoclsparse_matrix          mat,
+                                                             aoclsparse_operation       trans,
+                                                             const aoclsparse_mat_descr descr,
+                                                             aoclsparse_int expected_no_of_calls);
+DLL_PUBLIC aoclsparse_status aoclsparse_set_sm_hint(aoclsparse_matrix          mat,
+                                                    aoclsparse_operation       trans,
+                                                    const aoclsparse_mat_descr descr,
+                                                    const aoclsparse_order     order,
+                                                    aoclsparse_int             expected_no_of_calls);
+DLL_PUBLIC aoclsparse_status aoclsparse_set_symgs_hint(aoclsparse_matrix          mat,
+                                                       aoclsparse_operation       trans,
+                                                       const aoclsparse_mat_descr descr,
+                                                       aoclsparse_int expected_no_of_calls);
+DLL_PUBLIC aoclsparse_status aoclsparse_set_sorv_hint(aoclsparse_matrix          mat,
+                                                      const aoclsparse_mat_descr descr,
+                                                      const aoclsparse_sor_type  type,
+                                                      const aoclsparse_int expected_no_of_calls);
 DLL_PUBLIC aoclsparse_status aoclsparse_set_memory_hint(aoclsparse_matrix             mat,
                                                         const aoclsparse_memory_usage policy);
 
@@ -386,6 +415,45 @@ DLL_PUBLIC aoclsparse_status aoclsparse_dtrsm_kid(const aoclsparse_operation tra
                                                   double                    *X,
                                                   aoclsparse_int             ldx,
                                                   const aoclsparse_int       kid);
+/* ---- composite solvers kept device-resident (aoclsparse_solvers.h) -----------------------------
+ * Symmetric Gauss-Seidel sweep (:824-1070): x holds the initial guess on entry; ?symgs_mv also returns
+ * y = op(A) x.  ILU(0) smoother (:1136-1151): factorises once per handle, then x = U^-1 L^-1 b;
+ * *precond_csr_val points at the library-owned factor values (host), approx_inv_diag is unused. */
+DLL_PUBLIC aoclsparse_status aoclsparse_ssymgs(aoclsparse_operation trans, aoclsparse_matrix A,
+                                               const aoclsparse_mat_descr descr, const float alpha,
+                                               const float *b, float *x);
+DLL_PUBLIC aoclsparse_status aoclsparse_dsymgs(aoclsparse_operation trans, aoclsparse_matrix A,
+                                               const aoclsparse_mat_descr descr, const double alpha,
+                                               const double *b, double *x);
+DLL_PUBLIC aoclsparse_status aoclsparse_ssymgs_kid(aoclsparse_operation trans, aoclsparse_matrix A,
+                                                   const aoclsparse_mat_descr descr, const float alpha,
+                                                   const float *b, float *x, const aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_dsymgs_kid(aoclsparse_operation trans, aoclsparse_matrix A,
+                                                   const aoclsparse_mat_descr descr, const double alpha,
+                                                   const double *b, double *x, const aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_ssymgs_mv(aoclsparse_operation trans, aoclsparse_matrix A,
+                                                  const aoclsparse_mat_descr descr, const float alpha,
+                                                  const float *b, float *x, float *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_dsymgs_mv(aoclsparse_operation trans, aoclsparse_matrix A,
+                                                  const aoclsparse_mat_descr descr, const double alpha,
+                                                  const double *b, double *x, double *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_ssymgs_mv_kid(aoclsparse_operation trans, aoclsparse_matrix A,
+                                                      const aoclsparse_mat_descr descr, const float alpha,
+                                                      const float *b, float *x, float *y,
+                                                      const aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_dsymgs_mv_kid(aoclsparse_operation trans, aoclsparse_matrix A,
+                                                      const aoclsparse_mat_descr descr, const double alpha,
+                                                      const double *b, double *x, double *y,
+                                                      const aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_silu_smoother(aoclsparse_operation op, aoclsparse_matrix A,
+                                                      const aoclsparse_mat_descr descr,
+                                                      float **precond_csr_val, const float *approx_inv_diag,
+                                                      float *x, const float *b);
+DLL_PUBLIC aoclsparse_status aoclsparse_dilu_smoother(aoclsparse_operation op, aoclsparse_matrix A,
+                                                      const aoclsparse_mat_descr descr,
+                                                      double **precond_csr_val, const double *approx_inv_diag,
+                                                      double *x, const double *b);
+
 /* C = alpha*op(A)*B + beta*C, dense B/C in the stated order; alpha, beta BY VALUE (:2487-2511). */
 DLL_PUBLIC aoclsparse_status aoclsparse_scsrmm(aoclsparse_operation       op,
                                                const float                alpha,

@@ -216,6 +216,23 @@ def dilu0(n, base, row_ptr, col_ind, val):
     return st, val, diag[:n]
 
 
+def dilu_solve(n, base, lu_diag_ptr, val, row_ptr, col_ind, b):
+    """x = U^-1 L^-1 b with the ILU(0) factors (values `val` on the pattern row_ptr/col_ind)."""
+    val, row_ptr, col_ind, b, lu = _f64(val), _i32(row_ptr), _i32(col_ind), _f64(b), _i32(lu_diag_ptr)
+    x = np.zeros(n, dtype=np.float64)
+    st = lib().orc_dilu_solve(c_i32(n), c_int(base), _p(lu), _p(val), _p(row_ptr), _p(col_ind), _p(x), _p(b))
+    return st, x
+
+
+def dsymgs(mtype, fill, trans, base, alpha, m, val, col, ptr, idiag, iurow, b, x0):
+    """One symmetric Gauss-Seidel sweep on the clean CSR; mtype 0 general / 1 symmetric / 3 triangular."""
+    val, col, ptr, idiag, iurow, b = _f64(val), _i32(col), _i32(ptr), _i32(idiag), _i32(iurow), _f64(b)
+    x = _f64(x0).copy()
+    st = lib().orc_dsymgs(c_int(mtype), c_int(fill), c_int(trans), c_int(base), c_dbl(alpha), c_i32(m), _p(val),
+                          _p(col), _p(ptr), _p(idiag), _p(iurow), _p(b), _p(x), None, c_int(0))
+    return st, x
+
+
 def dcsr2m(m, n, base_a, ptr_a, ind_a, val_a, base_b, ptr_b, ind_b, val_b):
     """C = A*B (general CSR x CSR); C is 0-based, columns in first-touch order."""
     ptr_a, ind_a, val_a = _i32(ptr_a), _i32(ind_a), _f64(val_a)

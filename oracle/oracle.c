@@ -875,7 +875,7 @@ int orc_dilu0(oint n, int base, oint *lu_diag_ptr, double *val, const oint *row_
             if(k >= i)
                 break;
             double d = val[lu_diag_ptr[k]];
-            if(fabs(d) <= 2.220446049250313e-16) /* aoclsparse_is_nearzero */
+            if(fabs(d) <= 1e-2 * 2.0 * 2.220446049250313e-16) /* aoclsparse_is_nearzero, extra/aoclsparse_utils.hpp:598-613 */
             {
                 free(mapper);
                 return ORC_NUMERICAL_ERROR;
@@ -889,7 +889,7 @@ int orc_dilu0(oint n, int base, oint *lu_diag_ptr, double *val, const oint *row_
             }
         }
         lu_diag_ptr[i] = j;
-        if(j >= j2 || k != i || fabs(val[j]) <= 2.220446049250313e-16)
+        if(j >= j2 || k != i || fabs(val[j]) <= 1e-2 * 2.0 * 2.220446049250313e-16)
         {
             free(mapper);
             return ORC_NUMERICAL_ERROR;
@@ -898,6 +898,85 @@ int orc_dilu0(oint n, int base, oint *lu_diag_ptr, double *val, const oint *row_
             mapper[col_ind[mn] - base] = 0;
     }
     free(mapper);
+    return ORC_SUCCESS;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Symmetric Gauss-Seidel sweep, solvers/aoclsparse_symgs.hpp:62-258 (symgs_ref), built   */
+/* from the triangular SpMV and TRSV restatements above exactly as the reference chains   */
+/* aoclsparse::mv / aoclsparse::trsv on the clean CSR.  type: 0 general, 1 symmetric,     */
+/* 3 triangular; fill 0 lower / 1 upper; trans 0 none / 1 transpose.                      */
+/* ------------------------------------------------------------------------------------ */
+static int symgs_mv(int tr, int base, double alpha, oint m, int diag, int fill, const double *val,
+                    const oint *col, const oint *ptr, const oint *idiag, const oint *iurow,
+                    const double *x, double *y)
+{
+    /* beta = 0: the triangular kernels zero y first (csrmv_kr.hpp:535-542) */
+    return tr ? orc_dcsrmv_tri_t(base, alpha, m, m, diag, fill, val, col, ptr, idiag, iurow, x, 0.0, y)
+              : orc_dcsrmv_tri(base, alpha, m, diag, fill, val, col, ptr, idiag, iurow, x, 0.0, y);
+}
+static int symgs_sv(int tr, int fill, int base, oint m, const double *val, const oint *col,
+                    const oint *ptr, const oint *idiag, const oint *iurow, const double *b, double *x)
+{
+    if(fill == 0)
+        return tr ? orc_dtrsv_lt(1.0, m, base, val, col, ptr, idiag, b, 1, x, 1, 0)
+                  : orc_dtrsv_l(1.0, m, base, val, col, ptr, idiag, b, 1, x, 1, 0);
+    return tr ? orc_dtrsv_ut(1.0, m, base, val, col, ptr, iurow, b, 1, x, 1, 0)
+              : orc_dtrsv_u(1.0, m, base, val, col, ptr, iurow, b, 1, x, 1, 0);
+}
+int orc_dsymgs(int type, int fill, int trans, int base, double alpha, oint m, const double *val,
+               const oint *col, const oint *ptr, const oint *idiag, const oint *iurow,
+               const double *b, double *x, double *y, int fuse_mv)
+{
+    if(type == 3) /* :128-149 */
+        return symgs_sv(trans, fill, base, m, val, col, ptr, idiag, iurow, b, x);
+    int u_tr = 1, l_tr = 0, u_fill = 0, l_fill = 0; /* symmetric, lower stored (:151-163) */
+    if(type == 1 && fill == 1)
+        u_fill = l_fill = 1, u_tr = 0, l_tr = 1;
+    else if(type == 0 && trans == 0)
+        u_tr = l_tr = 0, u_fill = 1;
+    else if(type == 0 && trans == 1)
+        u_tr = l_tr = 1, l_fill = 1, u_fill = 0;
+    double *r = (double *)malloc(sizeof(double) * (size_t)(m > 0 ? m : 1));
+    double *q = (double *)malloc(sizeof(double) * (size_t)(m > 0 ? m : 1));
+    if(!r || !q)
+    {
+        free(r), free(q);
+        return ORC_MEMORY_ERROR;
+    }
+    symgs_mv(u_tr, base, alpha, m, 2, u_fill, val, col, ptr, idiag, iurow, x, q); /* q = alpha U x0 */
+    for(oint i = 0; i < m; i++)
+        r[i] = b[i] - q[i];
+    symgs_sv(l_tr, l_fill, base, m, val, col, ptr, idiag, iurow, r, q); /* (L+D) x1 = r */
+    symgs_mv(l_tr, base, 1.0, m, 2, l_fill, val, col, ptr, idiag, iurow, q, r); /* r = L x1 */
+    for(oint i = 0; i < m; i++)
+        q[i] = b[i] - r[i];
+    symgs_sv(u_tr, u_fill, base, m, val, col, ptr, idiag, iurow, q, x); /* (U+D) x = q */
+    free(r), free(q);
+    (void)y, (void)fuse_mv; /* the closing product is checked by the callers with orc_dcsrmv* */
+    return ORC_SUCCESS;
+}
+
+/* ILU(0) solve, solvers/aoclsparse_ilu0.hpp:113-156: L y = b (unit lower), U x = y; "sum - val*x"  */
+/* contracts to an FMA under the reference's -ffp-contract=fast.                                    */
+int orc_dilu_solve(oint n, int base, const oint *lu_diag_ptr, const double *val, const oint *row_ptr,
+                   const oint *col_ind, double *x, const double *b)
+{
+    for(oint i = 0; i < n; i++)
+    {
+        double sum = b[i];
+        for(oint k = row_ptr[i] - base; k < lu_diag_ptr[i]; k++)
+            sum = fma(-val[k], x[col_ind[k] - base], sum);
+        x[i] = sum;
+    }
+    for(oint i = n - 1; i >= 0; i--)
+    {
+        for(oint k = lu_diag_ptr[i] + 1; k < row_ptr[i + 1] - base; k++)
+            x[i] = fma(-val[k], x[col_ind[k] - base], x[i]);
+        double d = val[lu_diag_ptr[i]];
+        if(!(fabs(d) <= 1e-2 * 2.0 * 2.220446049250313e-16))
+            x[i] = x[i] / d;
+    }
     return ORC_SUCCESS;
 }
 

@@ -153,6 +153,16 @@ int orc_dcsr2csc(oint m, oint n, oint nnz, int base_csr, int base_csc, const oin
 int orc_dilu0(oint n, int base, oint *lu_diag_ptr, double *val, const oint *row_ptr,
               const oint *col_ind);
 
+/* solvers/aoclsparse_ilu0.hpp:113-156: x = U^-1 L^-1 b on the factors orc_dilu0 produced */
+int orc_dilu_solve(oint n, int base, const oint *lu_diag_ptr, const double *val, const oint *row_ptr,
+                   const oint *col_ind, double *x, const double *b);
+
+/* ---- symmetric Gauss-Seidel, solvers/aoclsparse_symgs.hpp:62-258 --------------------- */
+/* clean CSR + idiag/iurow; type 0 general / 1 symmetric / 3 triangular; x in: guess, out: sweep */
+int orc_dsymgs(int type, int fill, int trans, int base, double alpha, oint m, const double *val,
+               const oint *col, const oint *ptr, const oint *idiag, const oint *iurow,
+               const double *b, double *x, double *y, int fuse_mv);
+
 /* ---- sp2m (C = A*B, both general CSR), level3/aoclsparse_csr2m.cpp:46-543 ------------ */
 /* stage 1: row_ptr_C (0-based, length m+1).  Returns nnz_C in *nnz_c. */
 int orc_csr2m_nnz(oint m, oint n, int base_a, const oint *ptr_a, const oint *ind_a,

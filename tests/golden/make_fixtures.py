@@ -248,8 +248,68 @@ out["csrmm"] = [
          C_exp_row=[0, 0, -27, -63, -54, -18, -180, -72]),
 ]
 
+# ------------------------------------------------------------------------------------------
+# symmetric Gauss-Seidel: systems tests/unit_tests/common_data_utils.h:2673-3895, run by
+# tests/unit_tests/symgs_tests.cpp:380-455 (x0 = 1, one sweep unless iters says otherwise; the same
+# x_gold for both fill modes and both operations of the symmetric systems).  y_gold = A * x_gold as
+# held for the ?symgs_mv twin of each system.
+# ------------------------------------------------------------------------------------------
+def extract_symgs():
+    src = open(os.path.join(REF, "common_data_utils.h")).read()
+
+    def block(name, nxt):
+        lo = src.index("    case GS_%s:\n    case GS_MV_%s:" % (name, name))
+        return src[lo:src.index("    case %s:" % nxt, lo + 10)]
+
+    def real_arrays(blk, name):
+        """every `name = {...};` initialiser of the real-typed branches (no bcd( complex literals)"""
+        res = []
+        for m_ in re.finditer(r"\b%s\s*=\s*\{" % name, blk):
+            z = blk.index("};", m_.end())
+            body = blk[m_.end():z]
+            if "bcd(" not in body:
+                res.append(_nums(body))
+        return res
+
+    cases = []
+    for name, nxt, alpha, iters, lines in (("S7", "GS_TRIDIAG_M5", 1.0, 1, "2673-2813"),
+                                           ("TRIDIAG_M5", "GS_BLOCK_TRDIAG_S9", 1.0, 1, "2815-2932"),
+                                           ("BLOCK_TRDIAG_S9", "GS_CONVERGE_S4", 1.0, 1, "2934-3084"),
+                                           ("CONVERGE_S4", "GS_NONSYM_S4", 1.0, 8, "3086-3202"),
+                                           ("SYMM_ALPHA2_S9", "EXT_G5", 2.0, 1, "3743-3895")):
+        blk = block(name, nxt)
+        rp = [int(v) for v in real_arrays(blk, "icrowa")[0]]
+        ci = [int(v) for v in real_arrays(blk, "icola")[0]]
+        av = real_arrays(blk, "aval")[0]
+        x0 = real_arrays(blk, "x")[0]
+        b = real_arrays(blk, "b")[0]
+        xg = real_arrays(blk, "wcolxref")[0]
+        yg = real_arrays(blk, "xref")[0]
+        n = len(rp) - 1
+        assert len(ci) == rp[-1] == len(av) and len(b) == len(xg) == len(yg) == len(x0) == n, (name, n)
+        cases.append(dict(name="GS_" + name, src="tests/unit_tests/common_data_utils.h:" + lines, mtype="symmetric",
+                          m=n, row_ptr=rp, col_ind=ci, val=av, alpha=alpha, iters=iters, x0=x0, b=b,
+                          x_gold=xg, y_gold=yg))
+    return cases
+
+
+if os.path.isdir(REF):
+    symgs = extract_symgs()
+else:
+    symgs = [c for c in json.load(open(n25_path))["symgs"] if c["mtype"] == "symmetric"]
+# non-symmetric 4x4, general descriptor (common_data_utils.h:3204-3351): small integers, re-typed
+symgs.append(dict(name="GS_NONSYM_S4", src="tests/unit_tests/common_data_utils.h:3204-3351", mtype="general", m=4,
+                  row_ptr=[0, 4, 8, 12, 16], col_ind=[0, 1, 2, 3] * 4,
+                  val=[2, 1, 2, 1, 6, -6, 6, 12, 4, 3, 3, -3, 2, 2, -1, 1], alpha=1.0, iters=1, x0=[1.0] * 4,
+                  b=[6, 36, -1, 10],
+                  x_gold=dict(n=[-35, 35.333333333333336, 13.666666666666666, 13.333333333333332],
+                              t=[-406.16666666666669, 60.5, 53.333333333333336, 121]),
+                  y_gold=dict(n=[6, -180, -33, 0.3333333333333286],
+                              t=[6, -367.16666666666669, -410.33333333333337, 280.83333333333326])))
+out["symgs"] = symgs
+
 with open(n25_path, "w") as f:
     json.dump(out, f, indent=None, separators=(",", ":"))
     f.write("\n")
 print("wrote", n25_path, os.path.getsize(n25_path), "bytes;",
-      len(out["trsv"]), "trsv systems")
+      len(out["trsv"]), "trsv systems,", len(out["symgs"]), "symgs systems")

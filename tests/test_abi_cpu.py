@@ -344,3 +344,21 @@ def test_value_mutation_and_copy_host_semantics():
     assert t(114, 1.0, A.h, d.h, 0, P._ptr(Bm), 2, 2, P._ptr(Xm), 2) == 5
     assert t(111, 1.0, A.h, d.h, 0, P._ptr(Bm), 2, 2, P._ptr(Xm), 2) == 5           # missing diagonal, non-unit
     assert L.aoclsparse_strsm(111, 1.0, A.h, d.h, 0, P._ptr(Bm), 2, 2, P._ptr(Xm), 2) == 9
+
+
+def test_remaining_hint_setters_and_ilu_hint():
+    """analysis.cpp:644-731: dotmv / lu_smoother / sm / symgs / sorv hints share set_hint's checks; sm and sorv
+    validate their extra enum first."""
+    rp = np.array([0, 2, 3, 4, 7, 8], np.int32)
+    ci = np.array([0, 3, 1, 2, 1, 3, 4, 4], np.int32)
+    v = np.arange(1.0, 9.0)
+    A, d = P.Matrix(0, 5, 5, rp, ci, v), P.Descr()
+    assert L.aoclsparse_set_dotmv_hint(A.h, P.OP_NONE, d.h, 3) == 0
+    assert L.aoclsparse_set_symgs_hint(A.h, P.OP_NONE, d.h, 3) == 0
+    assert L.aoclsparse_set_lu_smoother_hint(A.h, P.OP_NONE, d.h, 3) == 0
+    assert L.aoclsparse_set_sm_hint(A.h, P.OP_NONE, d.h, P.ORDER_ROW, 3) == 0
+    assert L.aoclsparse_set_sm_hint(A.h, P.OP_NONE, d.h, 7, 3) == 5
+    assert L.aoclsparse_set_sorv_hint(A.h, d.h, 2, 3) == 0 and L.aoclsparse_set_sorv_hint(A.h, d.h, 3, 3) == 5
+    assert L.aoclsparse_set_symgs_hint(A.h, P.OP_NONE, d.h, -1) == 5
+    assert L.aoclsparse_set_dotmv_hint(None, P.OP_NONE, d.h, 1) == 2
+    assert L.aoclsparse_optimize(A.h) == 0

@@ -892,3 +892,101 @@ def test_set_value_and_update_values_refresh_the_device_copy():
     xs2 = np.zeros(m)
     assert P.dtrsv(P.OP_NONE, 1.0, A, dt, b, xs2) == 0
     assert np.array_equal(xs2, oracle_trsv(0, m, rp, ci, A.val, "lower", "n", True, 1.0, b)) and not np.array_equal(xs, xs2)
+
+
+def test_symgs_reference_kats(kats):
+    """symgs_tests.cpp:380-455: every system, fill mode, operation, index base; ?symgs and ?symgs_mv; host and
+    device vectors.  Tolerance = the reference's expected_precision(10)."""
+    tol = kats["trsv_abs_tol"]
+    mt = {"general": P.TYPE_GENERAL, "symmetric": P.TYPE_SYMMETRIC}
+    for c in kats["symgs"]:
+        m = c["m"]
+        for base in (0, 1):
+            rp = np.array(c["row_ptr"], np.int32) + base
+            ci = np.array(c["col_ind"], np.int32) + base
+            v = np.array(c["val"], np.float64)
+            b = np.array(c["b"], np.float64)
+            A = P.Matrix(base, m, m, rp, ci, v)
+            for fill in (P.FILL_LOWER, P.FILL_UPPER):
+                for ti, op in enumerate((P.OP_NONE, P.OP_TRANSPOSE)):
+                    d = P.Descr(base=base, mtype=mt[c["mtype"]], fill=fill)
+                    xg = c["x_gold"] if c["mtype"] == "symmetric" else c["x_gold"]["nt"[ti]]
+                    yg = c["y_gold"] if c["mtype"] == "symmetric" else c["y_gold"]["nt"[ti]]
+                    x, y = np.array(c["x0"], np.float64), np.zeros(m)
+                    for _ in range(c["iters"]):
+                        assert L.aoclsparse_dsymgs_mv(op, A.h, d.h, c["alpha"], P._ptr(b), P._ptr(x), P._ptr(y)) == 0
+                    assert np.all(np.abs(x - np.array(xg)) <= tol), (c["name"], base, fill, ti)
+                    assert np.all(np.abs(y - np.array(yg)) <= tol * max(1.0, np.abs(yg).max())), (c["name"], base, fill, ti)
+                    xd, bd = dev(np.array(c["x0"], np.float64)), dev(b)
+                    for _ in range(c["iters"]):
+                        assert L.aoclsparse_dsymgs_kid(op, A.h, d.h, c["alpha"], P._ptr(bd), P._ptr(xd), 0) == 0
+                    torch.cuda.synchronize()
+                    assert np.array_equal(xd.cpu().numpy(), x)
+
+
+@pytest.mark.parametrize("mtype", ["symmetric", "general"])
+def test_symgs_large_against_oracle(mtype):
+    """One sweep on a 2-D Laplacian-like SPD matrix with random off-diagonals; the TRSV stages are bit-exact,
+    the triangular products carry the SpMV bound, so compare within a small multiple of eps * scale."""
+    g = 70
+    m, rp, ci, v = laplace5(g)
+    rng = np.random.default_rng(17)
+    v = v.copy()
+    if mtype == "general":
+        v[v < 0] = rng.uniform(-1.0, -0.2, np.count_nonzero(v < 0))
+    A = P.Matrix(0, m, m, rp, ci, v)
+    b, x0 = rng.uniform(-1, 1, m), rng.uniform(-1, 1, m)
+    o = oracle.dcsr_optimize(m, m, len(v), 0, rp, ci, v)
+    for fill, ti in ((0, 0), (1, 0), (0, 1)):
+        d = P.Descr(mtype=P.TYPE_SYMMETRIC if mtype == "symmetric" else P.TYPE_GENERAL,
+                    fill=P.FILL_LOWER if fill == 0 else P.FILL_UPPER)
+        x = x0.copy()
+        assert L.aoclsparse_dsymgs((P.OP_NONE, P.OP_TRANSPOSE)[ti], A.h, d.h, 0.9, P._ptr(b), P._ptr(x)) == 0
+        st, xr = oracle.dsymgs(1 if mtype == "symmetric" else 0, fill, ti, 0, 0.9, m, o["val"], o["ind"], o["ptr"],
+                               o["idiag"], o["iurow"], b, x0)
+        assert st == 0
+        assert np.max(np.abs(x - xr)) <= 64 * EPS64 * max(1.0, np.abs(xr).max()), (fill, ti, np.max(np.abs(x - xr)))
+
+
+def test_symgs_and_ilu_argument_checks_on_gpu_box():
+    m, rp, ci, v = laplace5(6)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    b, x = np.ones(m), np.ones(m)
+    assert L.aoclsparse_dsymgs(P.OP_NONE, A.h, P.Descr(mtype=P.TYPE_SYMMETRIC, diag=P.DIAG_UNIT).h, 1.0, P._ptr(b), P._ptr(x)) == 1
+    assert L.aoclsparse_dsymgs(113, A.h, P.Descr().h, 1.0, P._ptr(b), P._ptr(x)) == 1  # general + conj. transpose
+    assert L.aoclsparse_dsymgs(P.OP_NONE, A.h, P.Descr(base=1).h, 1.0, P._ptr(b), P._ptr(x)) == 5
+    assert L.aoclsparse_ssymgs(P.OP_NONE, A.h, P.Descr().h, 1.0, P._ptr(b), P._ptr(x)) == 9
+    assert L.aoclsparse_dsymgs(P.OP_NONE, A.h, P.Descr().h, 1.0, None, P._ptr(x)) == 2
+    assert L.aoclsparse_dsymgs_mv(P.OP_NONE, A.h, P.Descr().h, 1.0, P._ptr(b), P._ptr(x), None) == 2
+
+
+@pytest.mark.parametrize("base", [0, 1])
+def test_ilu_smoother_matches_reference_factorisation_and_solve(base):
+    """ilu_tests.cpp drives aoclsparse_dilu_smoother on a handle with an LU-smoother hint: the factors returned
+    through precond_csr_val and the smoothed x must equal the serial IKJ factorisation + the two serial solves."""
+    g = 48
+    m, rp, ci, v = laplace5(g)
+    rng = np.random.default_rng(23)
+    v = v * rng.uniform(0.8, 1.2, len(v))
+    rp, ci = rp + base, ci + base
+    A = P.Matrix(base, m, m, rp, ci, v)
+    d = P.Descr(base=base)
+    assert L.aoclsparse_set_lu_smoother_hint(A.h, P.OP_NONE, d.h, 10) == 0 and L.aoclsparse_optimize(A.h) == 0
+    st, lu, diag = oracle.dilu0(m, base, rp, ci, v)
+    assert st == 0
+    pv = ctypes.c_void_p()
+    for it in range(2):  # second call reuses the factors
+        b, x = rng.uniform(-1, 1, m), np.zeros(m)
+        assert L.aoclsparse_dilu_smoother(P.OP_NONE, A.h, d.h, ctypes.byref(pv), None, P._ptr(x), P._ptr(b)) == 0
+        fac = np.ctypeslib.as_array(ctypes.cast(pv, ctypes.POINTER(ctypes.c_double)), (len(v),))
+        assert np.array_equal(fac, lu)
+        st, xr = oracle.dilu_solve(m, base, diag, lu, rp, ci, b)
+        assert st == 0 and np.array_equal(x, xr)
+        xd = torch.zeros(m, dtype=torch.float64, device="cuda")
+        assert L.aoclsparse_dilu_smoother(P.OP_NONE, A.h, d.h, ctypes.byref(pv), None, P._ptr(xd), P._ptr(dev(b))) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(xd.cpu().numpy(), xr)
+    assert np.array_equal(A.val, v)  # the user's values are never touched
+    assert L.aoclsparse_dilu_smoother(P.OP_TRANSPOSE, A.h, d.h, ctypes.byref(pv), None, P._ptr(x), P._ptr(b)) == 1
+    assert L.aoclsparse_dilu_smoother(P.OP_NONE, A.h, P.Descr(base=base, mtype=P.TYPE_SYMMETRIC).h, ctypes.byref(pv), None,
+                                      P._ptr(x), P._ptr(b)) == 1

@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 import oracle
+from util import laplace5
 
 EPS = np.finfo(np.float64).eps
 
@@ -257,3 +258,59 @@ def test_sp2m_matches_dense():
         assert len(set(ic[pc[i]:pc[i + 1]])) == pc[i + 1] - pc[i]
         C[i, ic[pc[i]:pc[i + 1]]] = vc[pc[i]:pc[i + 1]]
     assert np.allclose(C, A @ B, atol=1e-13)
+
+
+def _symgs_oracle(c, fill, trans, base=0, x0=None, iters=None):
+    m = c["m"]
+    rp = np.array(c["row_ptr"], np.int32) + base
+    ci = np.array(c["col_ind"], np.int32) + base
+    v = np.array(c["val"], np.float64)
+    o = oracle.dcsr_optimize(m, m, len(v), base, rp, ci, v)
+    assert o["status"] == 0 and o["fulldiag"]
+    x = np.array(c["x0"] if x0 is None else x0, np.float64)
+    mtype = {"general": 0, "symmetric": 1, "triangular": 3}[c["mtype"]]
+    for _ in range(c["iters"] if iters is None else iters):
+        st, x = oracle.dsymgs(mtype, fill, trans, o["base"], c["alpha"], m, o["val"], o["ind"], o["ptr"], o["idiag"],
+                              o["iurow"], np.array(c["b"], np.float64), x)
+        assert st == 0
+    return x
+
+
+def test_symgs_kat(kats):
+    """symgs_tests.cpp:380-455 on the systems of common_data_utils.h:2673-3895: the sweep and the closing
+    product, every (fill, op) the reference runs, within the reference's own tolerance
+    expected_precision(10) = 10*sqrt(2 eps) and, tighter, 1e-13 relative (the vectors carry 17 digits)."""
+    tol = kats["trsv_abs_tol"]
+    for c in kats["symgs"]:
+        m = c["m"]
+        rp, ci, v = np.array(c["row_ptr"], np.int32), np.array(c["col_ind"], np.int32), np.array(c["val"], np.float64)
+        for fill in (0, 1):
+            for trans in (0, 1):
+                x = _symgs_oracle(c, fill, trans, base=fill)  # both index bases along the way
+                xg = c["x_gold"] if c["mtype"] == "symmetric" else c["x_gold"]["nt"[trans]]
+                yg = c["y_gold"] if c["mtype"] == "symmetric" else c["y_gold"]["nt"[trans]]
+                xg, yg = np.array(xg, np.float64), np.array(yg, np.float64)
+                assert np.all(np.abs(x - xg) <= tol), (c["name"], fill, trans)
+                assert np.all(np.abs(x - xg) <= 1e-13 * np.maximum(1.0, np.abs(xg)).max() * 4), (c["name"], fill, trans)
+                if trans == 0 or c["mtype"] == "symmetric":
+                    so, y = oracle.dcsrmv(0, 0, 1.0, m, len(v), v, ci, rp, x, 0.0, np.zeros(m))
+                else:
+                    so, y = oracle.dcsrmvt(0, 1.0, m, m, v, ci, rp, x, 0.0, np.zeros(m))
+                assert np.all(np.abs(y - yg) <= tol * max(1.0, np.abs(yg).max())), (c["name"], fill, trans)
+
+
+def test_ilu_solve_inverts_the_factors():
+    m, rp, ci, v = laplace5(12)
+    st, lu, diag = oracle.dilu0(m, 0, rp, ci, v)
+    assert st == 0
+    b = np.random.default_rng(5).uniform(-1, 1, m)
+    st, x = oracle.dilu_solve(m, 0, diag, lu, rp, ci, b)
+    assert st == 0
+    Lm, Um = np.eye(m), np.zeros((m, m))
+    for i in range(m):
+        for p in range(rp[i], rp[i + 1]):
+            if ci[p] < i:
+                Lm[i, ci[p]] = lu[p]
+            else:
+                Um[i, ci[p]] = lu[p]
+    assert np.allclose(Lm @ (Um @ x), b, rtol=0, atol=1e-12)
