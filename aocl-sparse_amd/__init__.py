@@ -97,6 +97,20 @@ SIGNATURES = {
     "aoclsparse_dtrsm": (c_int, [c_int, c_double, _P, _P, c_int, _P, _I, _I, _P, _I]),
     "aoclsparse_strsm_kid": (c_int, [c_int, c_float, _P, _P, c_int, _P, _I, _I, _P, _I, _I]),
     "aoclsparse_dtrsm_kid": (c_int, [c_int, c_double, _P, _P, c_int, _P, _I, _I, _P, _I, _I]),
+    "aoclsparse_sellmv": (c_int, [c_int, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
+    "aoclsparse_dellmv": (c_int, [c_int, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
+    "aoclsparse_selltmv": (c_int, [c_int, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
+    "aoclsparse_delltmv": (c_int, [c_int, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
+    "aoclsparse_sellthybmv": (c_int, [c_int, _P, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "aoclsparse_dellthybmv": (c_int, [c_int, _P, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "aoclsparse_csr2ell_width": (c_int, [_I, _I, _P, _P]),
+    "aoclsparse_csr2ellthyb_width": (c_int, [_I, _I, _P, _P, _P]),
+    "aoclsparse_scsr2ell": (c_int, [_I, _P, _P, _P, _P, _P, _P, _I]),
+    "aoclsparse_dcsr2ell": (c_int, [_I, _P, _P, _P, _P, _P, _P, _I]),
+    "aoclsparse_scsr2ellt": (c_int, [_I, _P, _P, _P, _P, _P, _P, _I]),
+    "aoclsparse_dcsr2ellt": (c_int, [_I, _P, _P, _P, _P, _P, _P, _I]),
+    "aoclsparse_scsr2ellthyb": (c_int, [_I, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _I]),
+    "aoclsparse_dcsr2ellthyb": (c_int, [_I, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _I]),
     "aoclsparse_ssymgs": (c_int, [c_int, _P, _P, c_float, _P, _P]),
     "aoclsparse_dsymgs": (c_int, [c_int, _P, _P, c_double, _P, _P]),
     "aoclsparse_ssymgs_kid": (c_int, [c_int, _P, _P, c_float, _P, _P, _I]),

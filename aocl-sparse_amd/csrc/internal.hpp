@@ -255,7 +255,7 @@ private:
     bool         inited_ = false;
     aoclsparse_status init_status_ = aoclsparse_status_success;
     hipStream_t  stream_ = nullptr;
-    DeviceBuffer stage_[8];
+    DeviceBuffer stage_[16]; // 0-7: csrmv / mv / trsv / dotmv, 8-15: ELL family (ell_api.cpp)
 };
 
 // While one of these is alive on a thread, every pointer handed to the executors by that thread is
@@ -267,6 +267,37 @@ struct DeviceScope
     ~DeviceScope();
     DeviceScope(const DeviceScope &)            = delete;
     DeviceScope &operator=(const DeviceScope &) = delete;
+};
+
+// A host or device array made addressable by the GPU for one call of a raw-array entry point.
+struct StagedArg
+{
+    void  *dev = nullptr, *host = nullptr;
+    size_t bytes  = 0;
+    bool   staged = false;
+    aoclsparse_status in(Runtime &rt, int slot, const void *p, size_t nbytes, bool copy)
+    {
+        bytes = nbytes;
+        if(rt.is_device_pointer(p))
+        {
+            dev = const_cast<void *>(p);
+            return aoclsparse_status_success;
+        }
+        staged = true;
+        host   = const_cast<void *>(p);
+        aoclsparse_status st = rt.staging(slot, nbytes ? nbytes : 1, &dev);
+        if(st != aoclsparse_status_success)
+            return st;
+        if(copy && nbytes)
+            MI355_HIP_TRY(hipMemcpyAsync(dev, p, nbytes, hipMemcpyHostToDevice, rt.stream()));
+        return aoclsparse_status_success;
+    }
+    aoclsparse_status out(Runtime &rt)
+    {
+        if(staged && bytes)
+            MI355_HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, rt.stream()));
+        return aoclsparse_status_success;
+    }
 };
 
 // ---- host analysis (matrix.cpp) --------------------------------------------------------------
@@ -320,6 +351,24 @@ aoclsparse_status launch_strided_gather(hipStream_t s, const T *src, aoclsparse_
 template <typename T>
 aoclsparse_status launch_strided_scatter(hipStream_t s, const T *src, aoclsparse_int n, T *dst,
                                          aoclsparse_int inc);
+
+// ELL family (ell_kernels.hip).  ellmv: row-major ELL, padding = column -1, double in the reference's
+// 4-lane order (ellmv.hpp:90-208), float in its scalar order (:34-85).  elltmv: column-major ELL, one
+// FMA chain per row (:316-444).  csr_rows: the CSR part of ELLT-HYB, rows listed in `map`, 4-lane
+// order, beta term taken from ysrc[i] (:660-757).
+template <typename T>
+aoclsparse_status launch_ellmv(hipStream_t s, int base, T alpha, aoclsparse_int m, const T *val,
+                               const aoclsparse_int *col, aoclsparse_int width, const T *x, T beta, T *y);
+template <typename T>
+aoclsparse_status launch_elltmv(hipStream_t s, int base, T alpha, aoclsparse_int m, const T *val,
+                                const aoclsparse_int *col, aoclsparse_int width, const T *x, T beta, T *y);
+template <typename T>
+aoclsparse_status launch_csr_rows(hipStream_t s, int base, T alpha, aoclsparse_int nrows,
+                                  const aoclsparse_int *map, const T *val, const aoclsparse_int *col,
+                                  const aoclsparse_int *row_ptr, const T *x, T beta, const T *ysrc, T *y);
+template <typename T>
+aoclsparse_status launch_gather_rows(hipStream_t s, aoclsparse_int n, const aoclsparse_int *map, const T *src,
+                                     T *dst);
 
 // TRSV on the level-ordered layout (trsv_kernels.hip).
 // schedule 0: one launch per level; 1: hybrid (narrow level runs inside one workgroup); 2: sync-free.

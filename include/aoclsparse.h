@@ -415,6 +415,87 @@ DLL_PUBLIC aoclsparse_status aoclsparse_dtrsm_kid(const aoclsparse_operation tra
                                                   double                    *X,
                                                   aoclsparse_int             ldx,
                                                   const aoclsparse_int       kid);
+/* ---- ELL family: the formats the reference's optimize step stores, as raw-array products
+ * (aoclsparse_functions.h:789-885) and their CSR conversions (aoclsparse_convert.h).  Only general
+ * descriptors and op = none exist in the reference (anything else: not_implemented).  ELL is row-major
+ * with column -1 as padding; ELLT is column-major (ell[p*m + i]); ELLT-HYB = ELLT over all rows plus the
+ * rows listed in csr_row_idx_map (0-based) recomputed from the CSR arrays.  ?ellthybmv exists for double. */
+DLL_PUBLIC aoclsparse_status aoclsparse_sellmv(aoclsparse_operation trans, const float *alpha, aoclsparse_int m,
+                                               aoclsparse_int n, aoclsparse_int nnz, const float *ell_val,
+                                               const aoclsparse_int *ell_col_ind, aoclsparse_int ell_width,
+                                               const aoclsparse_mat_descr descr, const float *x,
+                                               const float *beta, float *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_dellmv(aoclsparse_operation trans, const double *alpha, aoclsparse_int m,
+                                               aoclsparse_int n, aoclsparse_int nnz, const double *ell_val,
+                                               const aoclsparse_int *ell_col_ind, aoclsparse_int ell_width,
+                                               const aoclsparse_mat_descr descr, const double *x,
+                                               const double *beta, double *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_selltmv(aoclsparse_operation trans, const float *alpha, aoclsparse_int m,
+                                                aoclsparse_int n, aoclsparse_int nnz, const float *ell_val,
+                                                const aoclsparse_int *ell_col_ind, aoclsparse_int ell_width,
+                                                const aoclsparse_mat_descr descr, const float *x,
+                                                const float *beta, float *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_delltmv(aoclsparse_operation trans, const double *alpha, aoclsparse_int m,
+                                                aoclsparse_int n, aoclsparse_int nnz, const double *ell_val,
+                                                const aoclsparse_int *ell_col_ind, aoclsparse_int ell_width,
+                                                const aoclsparse_mat_descr descr, const double *x,
+                                                const double *beta, double *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_sellthybmv(aoclsparse_operation trans, const float *alpha,
+                                                   aoclsparse_int m, aoclsparse_int n, aoclsparse_int nnz,
+                                                   const float *ell_val, const aoclsparse_int *ell_col_ind,
+                                                   aoclsparse_int ell_width, const aoclsparse_int ell_m,
+                                                   const float *csr_val, const aoclsparse_int *csr_row_ind,
+                                                   const aoclsparse_int *csr_col_ind, aoclsparse_int *row_idx_map,
+                                                   aoclsparse_int *csr_row_idx_map,
+                                                   const aoclsparse_mat_descr descr, const float *x,
+                                                   const float *beta, float *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_dellthybmv(aoclsparse_operation trans, const double *alpha,
+                                                   aoclsparse_int m, aoclsparse_int n, aoclsparse_int nnz,
+                                                   const double *ell_val, const aoclsparse_int *ell_col_ind,
+                                                   aoclsparse_int ell_width, const aoclsparse_int ell_m,
+                                                   const double *csr_val, const aoclsparse_int *csr_row_ind,
+                                                   const aoclsparse_int *csr_col_ind, aoclsparse_int *row_idx_map,
+                                                   aoclsparse_int *csr_row_idx_map,
+                                                   const aoclsparse_mat_descr descr, const double *x,
+                                                   const double *beta, double *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_csr2ell_width(aoclsparse_int m, aoclsparse_int nnz,
+                                                      const aoclsparse_int *csr_row_ptr, aoclsparse_int *ell_width);
+DLL_PUBLIC aoclsparse_status aoclsparse_csr2ellthyb_width(aoclsparse_int m, aoclsparse_int nnz,
+                                                          const aoclsparse_int *csr_row_ptr, aoclsparse_int *ell_m,
+                                                          aoclsparse_int *ell_width);
+DLL_PUBLIC aoclsparse_status aoclsparse_scsr2ell(aoclsparse_int m, const aoclsparse_mat_descr descr,
+                                                 const aoclsparse_int *csr_row_ptr,
+                                                 const aoclsparse_int *csr_col_ind, const float *csr_val,
+                                                 aoclsparse_int *ell_col_ind, float *ell_val,
+                                                 aoclsparse_int ell_width);
+DLL_PUBLIC aoclsparse_status aoclsparse_dcsr2ell(aoclsparse_int m, const aoclsparse_mat_descr descr,
+                                                 const aoclsparse_int *csr_row_ptr,
+                                                 const aoclsparse_int *csr_col_ind, const double *csr_val,
+                                                 aoclsparse_int *ell_col_ind, double *ell_val,
+                                                 aoclsparse_int ell_width);
+DLL_PUBLIC aoclsparse_status aoclsparse_scsr2ellt(aoclsparse_int m, const aoclsparse_mat_descr descr,
+                                                  const aoclsparse_int *csr_row_ptr,
+                                                  const aoclsparse_int *csr_col_ind, const float *csr_val,
+                                                  aoclsparse_int *ell_col_ind, float *ell_val,
+                                                  aoclsparse_int ell_width);
+DLL_PUBLIC aoclsparse_status aoclsparse_dcsr2ellt(aoclsparse_int m, const aoclsparse_mat_descr descr,
+                                                  const aoclsparse_int *csr_row_ptr,
+                                                  const aoclsparse_int *csr_col_ind, const double *csr_val,
+                                                  aoclsparse_int *ell_col_ind, double *ell_val,
+                                                  aoclsparse_int ell_width);
+DLL_PUBLIC aoclsparse_status aoclsparse_scsr2ellthyb(aoclsparse_int m, aoclsparse_index_base base,
+                                                     aoclsparse_int *ell_m, const aoclsparse_int *csr_row_ptr,
+                                                     const aoclsparse_int *csr_col_ind, const float *csr_val,
+                                                     aoclsparse_int *row_idx_map, aoclsparse_int *csr_row_idx_map,
+                                                     aoclsparse_int *ell_col_ind, float *ell_val,
+                                                     aoclsparse_int ell_width);
+DLL_PUBLIC aoclsparse_status aoclsparse_dcsr2ellthyb(aoclsparse_int m, aoclsparse_index_base base,
+                                                     aoclsparse_int *ell_m, const aoclsparse_int *csr_row_ptr,
+                                                     const aoclsparse_int *csr_col_ind, const double *csr_val,
+                                                     aoclsparse_int *row_idx_map, aoclsparse_int *csr_row_idx_map,
+                                                     aoclsparse_int *ell_col_ind, double *ell_val,
+                                                     aoclsparse_int ell_width);
+
 /* ---- composite solvers kept device-resident (aoclsparse_solvers.h) -----------------------------
  * Symmetric Gauss-Seidel sweep (:824-1070): x holds the initial guess on entry; ?symgs_mv also returns
  * y = op(A) x.  ILU(0) smoother (:1136-1151): factorises once per handle, then x = U^-1 L^-1 b;

@@ -233,6 +233,54 @@ def dsymgs(mtype, fill, trans, base, alpha, m, val, col, ptr, idiag, iurow, b, x
     return st, x
 
 
+def csr2ell(layout, m, base, row_ptr, col_ind, val):
+    """layout 'ell' | 'ellt' -> (width, ell_col, ell_val); 'hyb' -> (width, ell_m, map, ell_col, ell_val)."""
+    row_ptr, col_ind, val = _i32(row_ptr), _i32(col_ind), _f64(val)
+    L = lib()
+    w, em = c_i32(0), c_i32(0)
+    if layout == "hyb":
+        L.orc_csr2ellthyb_width(c_i32(m), c_i32(len(val)), _p(row_ptr), ctypes.byref(em), ctypes.byref(w))
+    else:
+        L.orc_csr2ell_width(c_i32(m), _p(row_ptr), ctypes.byref(w))
+    cells = max(1, m * w.value)
+    ec, ev = np.zeros(cells, np.int32), np.zeros(cells, np.float64)
+    if layout == "hyb":
+        mp = np.zeros(max(1, m - em.value), np.int32)
+        em2 = c_i32(0)
+        L.orc_dcsr2ellthyb(c_i32(m), c_int(base), ctypes.byref(em2), _p(row_ptr), _p(col_ind), _p(val), _p(mp), _p(ec),
+                           _p(ev), w)
+        assert em2.value == em.value
+        return w.value, em.value, mp[: m - em.value], ec[: m * w.value], ev[: m * w.value]
+    L.orc_dcsr2ell(c_int(1 if layout == "ellt" else 0), c_i32(m), c_int(base), _p(row_ptr), _p(col_ind), _p(val), _p(ec),
+                   _p(ev), w)
+    return w.value, ec[: m * w.value], ev[: m * w.value]
+
+
+def dellmv(layout, base, alpha, m, val, col, width, x, beta, y):
+    val, col, x = _f64(val), _i32(col), _f64(x)
+    y = _f64(y).copy()
+    fn = lib().orc_delltmv if layout == "ellt" else lib().orc_dellmv
+    st = fn(c_int(base), c_dbl(alpha), c_i32(m), _p(val), _p(col), c_i32(width), _p(x), c_dbl(beta), _p(y))
+    return st, y
+
+
+def sellmv(base, alpha, m, val, col, width, x, beta, y):
+    val, col, x = _f32(val), _i32(col), _f32(x)
+    y = _f32(y).copy()
+    st = lib().orc_sellmv(c_int(base), ctypes.c_float(alpha), c_i32(m), _p(val), _p(col), c_i32(width), _p(x),
+                          ctypes.c_float(beta), _p(y))
+    return st, y
+
+
+def dellthybmv(base, alpha, m, ell_val, ell_col, width, ell_m, csr_val, csr_row, csr_col, rmap, x, beta, y):
+    ell_val, ell_col, csr_val, csr_row, csr_col = _f64(ell_val), _i32(ell_col), _f64(csr_val), _i32(csr_row), _i32(csr_col)
+    rmap, x = _i32(rmap), _f64(x)
+    y = _f64(y).copy()
+    st = lib().orc_dellthybmv(c_int(base), c_dbl(alpha), c_i32(m), _p(ell_val), _p(ell_col), c_i32(width), c_i32(ell_m),
+                              _p(csr_val), _p(csr_row), _p(csr_col), _p(rmap), _p(x), c_dbl(beta), _p(y))
+    return st, y
+
+
 def dcsr2m(m, n, base_a, ptr_a, ind_a, val_a, base_b, ptr_b, ind_b, val_b):
     """C = A*B (general CSR x CSR); C is 0-based, columns in first-touch order."""
     ptr_a, ind_a, val_a = _i32(ptr_a), _i32(ind_a), _f64(val_a)

@@ -981,6 +981,193 @@ int orc_dilu_solve(oint n, int base, const oint *lu_diag_ptr, const double *val,
 }
 
 /* ------------------------------------------------------------------------------------ */
+/* ELL family, level2/aoclsparse_ellmv.hpp.  Padding of row-major ELL = column -1.        */
+/* ------------------------------------------------------------------------------------ */
+static double ell_finish_d(double r, double alpha, double beta, double y)
+{
+    if(alpha != 1.0)
+        r = alpha * r;
+    if(beta != 0.0)
+        r = fma(beta, y, r); /* "result += beta * y[i]" under -ffp-contract=fast */
+    return r;
+}
+/* aoclsparse_dellmv_avx2, ellmv.hpp:90-208: 4 lanes over full groups (a group whose 4th column is padding
+ * goes to the scalar tail), hadd reduction (l0+l1)+(l2+l3), scalar tail that stops at padding. */
+int orc_dellmv(int base, double alpha, oint m, const double *val, const oint *col, oint width,
+               const double *x, double beta, double *y)
+{
+    for(oint i = 0; i < m; i++)
+    {
+        const double *v = val + (size_t)i * width;
+        const oint   *c = col + (size_t)i * width;
+        oint          k_iter = width / 4, k_rem = width % 4, p = 0;
+        double        l[4] = {0, 0, 0, 0}, r = 0.0;
+        for(oint it = 0; it < k_iter; it++)
+        {
+            if(c[p + 3] - base < 0)
+            {
+                k_rem = 4;
+                break;
+            }
+            for(int q = 0; q < 4; q++)
+                l[q] = fma(v[p + q], x[c[p + q] - base], l[q]);
+            p += 4;
+        }
+        if(k_iter)
+            r = (l[0] + l[1]) + (l[2] + l[3]);
+        for(oint q = 0; q < k_rem; q++)
+        {
+            oint cc = c[p + q] - base;
+            if(cc < 0)
+                break;
+            r = fma(v[p + q], x[cc], r);
+        }
+        y[i] = ell_finish_d(r, alpha, beta, y[i]);
+    }
+    return ORC_SUCCESS;
+}
+/* aoclsparse_ellmv_ref<float>, ellmv.hpp:34-85 (what aoclsparse_sellmv runs) */
+int orc_sellmv(int base, float alpha, oint m, const float *val, const oint *col, oint width,
+               const float *x, float beta, float *y)
+{
+    for(oint i = 0; i < m; i++)
+    {
+        float r = 0.0f;
+        for(oint p = 0; p < width; p++)
+        {
+            oint cc = col[(size_t)i * width + p] - base;
+            if(cc < 0)
+                break;
+            r = fmaf(val[(size_t)i * width + p], x[cc], r);
+        }
+        if(alpha != 1.0f)
+            r = alpha * r;
+        if(beta != 0.0f)
+            r = fmaf(beta, y[i], r);
+        y[i] = r;
+    }
+    return ORC_SUCCESS;
+}
+/* aoclsparse_elltmv_avx2 / _ref, ellmv.hpp:316-444: one FMA chain per row over the column-major cells */
+int orc_delltmv(int base, double alpha, oint m, const double *val, const oint *col, oint width,
+                const double *x, double beta, double *y)
+{
+    for(oint j = 0; j < m; j++)
+    {
+        double r = 0.0;
+        for(oint i = 0; i < width; i++)
+            r = fma(val[(size_t)i * m + j], x[col[(size_t)i * m + j] - base], r);
+        y[j] = ell_finish_d(r, alpha, beta, y[j]);
+    }
+    return ORC_SUCCESS;
+}
+/* aoclsparse_ellthybmv_avx2, ellmv.hpp:554-757: ELLT pass over all rows, then the listed rows again
+ * from the CSR arrays in the 4-lane order, with the beta term taken from the ORIGINAL y. */
+int orc_dellthybmv(int base, double alpha, oint m, const double *ell_val, const oint *ell_col,
+                   oint width, oint ell_m, const double *csr_val, const oint *csr_row,
+                   const oint *csr_col, const oint *map, const double *x, double beta, double *y)
+{
+    oint    nlong = m - ell_m;
+    double *ytmp  = (double *)malloc(sizeof(double) * (size_t)(nlong > 0 ? nlong : 1));
+    if(!ytmp)
+        return ORC_MEMORY_ERROR;
+    for(oint i = 0; i < nlong; i++)
+        ytmp[i] = y[map[i]];
+    orc_delltmv(base, alpha, m, ell_val, ell_col, width, x, beta, y);
+    for(oint i = 0; i < nlong; i++)
+    {
+        oint   row = map[i], s = csr_row[row] - base, e = csr_row[row + 1] - base;
+        oint   full = (e - s) / 4 * 4;
+        double l[4] = {0, 0, 0, 0}, r = 0.0;
+        for(oint p = s; p < s + full; p++)
+            l[(p - s) & 3] = fma(csr_val[p], x[csr_col[p] - base], l[(p - s) & 3]);
+        if(full)
+            r = (l[0] + l[1]) + (l[2] + l[3]);
+        for(oint p = s + full; p < e; p++)
+            r = fma(csr_val[p], x[csr_col[p] - base], r);
+        y[row] = ell_finish_d(r, alpha, beta, ytmp[i]);
+    }
+    free(ytmp);
+    return ORC_SUCCESS;
+}
+/* conversion/aoclsparse_convert.hpp:41-107 (ELL), :110-175 (ELLT), :178-289 (ELLT-HYB) and
+ * conversion/aoclsparse_convert.cpp:311-412 (widths).  layout: 0 ELL, 1 ELLT. */
+int orc_csr2ell_width(oint m, const oint *row_ptr, oint *width)
+{
+    *width = 0;
+    for(oint i = 0; i < m; i++)
+        if(row_ptr[i + 1] - row_ptr[i] > *width)
+            *width = row_ptr[i + 1] - row_ptr[i];
+    return ORC_SUCCESS;
+}
+int orc_csr2ellthyb_width(oint m, oint nnz, const oint *row_ptr, oint *ell_m, oint *width)
+{
+    *width = 0, *ell_m = 0;
+    if(m == 0)
+        return ORC_SUCCESS;
+    oint mx = 0, mn = nnz, cmn = 0, cmx = 0, avg = nnz / m;
+    for(oint i = 0; i < m; i++)
+    {
+        oint len = row_ptr[i + 1] - row_ptr[i];
+        if(len > mx && len <= avg)
+            mx = len;
+        if(len < mn && len > avg)
+            mn = len;
+        if(len <= avg)
+            cmx++;
+        else
+            cmn++;
+    }
+    *width = cmx >= cmn ? mx : mn;
+    for(oint i = 0; i < m; i++)
+        if(row_ptr[i + 1] - row_ptr[i] <= *width)
+            (*ell_m)++;
+    return ORC_SUCCESS;
+}
+int orc_dcsr2ell(int layout, oint m, int base, const oint *row_ptr, const oint *col_ind,
+                 const double *val, oint *ell_col, double *ell_val, oint width)
+{
+    for(oint i = 0; i < m; i++)
+    {
+        oint s = row_ptr[i] - base, e = row_ptr[i + 1] - base, k = 0;
+        for(oint j = s; j < e; j++, k++)
+        {
+            size_t o   = layout ? (size_t)k * m + i : (size_t)i * width + k;
+            ell_col[o] = col_ind[j], ell_val[o] = val[j];
+        }
+        for(; k < width; k++)
+        {
+            size_t o   = layout ? (size_t)k * m + i : (size_t)i * width + k;
+            ell_col[o] = layout ? (e > s ? col_ind[e - 1] : base) : -1; /* empty row: see ell_api.cpp */
+            ell_val[o] = 0.0;
+        }
+    }
+    return ORC_SUCCESS;
+}
+int orc_dcsr2ellthyb(oint m, int base, oint *ell_m, const oint *row_ptr, const oint *col_ind,
+                     const double *val, oint *map, oint *ell_col, double *ell_val, oint width)
+{
+    oint nlong = 0;
+    *ell_m     = 0;
+    for(oint i = 0; i < m; i++)
+    {
+        oint s = row_ptr[i] - base, e = row_ptr[i + 1] - base, k = 0;
+        oint pad = e > s ? col_ind[e - 1] : base;
+        if(e - s > width)
+            map[nlong++] = i;
+        else
+        {
+            (*ell_m)++;
+            for(oint j = s; j < e; j++, k++)
+                ell_col[(size_t)k * m + i] = col_ind[j], ell_val[(size_t)k * m + i] = val[j];
+        }
+        for(; k < width; k++)
+            ell_col[(size_t)k * m + i] = pad, ell_val[(size_t)k * m + i] = 0.0;
+    }
+    return ORC_SUCCESS;
+}
+
+/* ------------------------------------------------------------------------------------ */
 /* sp2m = two-stage Gustavson, csr2m.cpp:46-302 (count) and :310-543 (finalize).         */
 /* ------------------------------------------------------------------------------------ */
 int orc_csr2m_nnz(oint m, oint n, int base_a, const oint *ptr_a, const oint *ind_a,

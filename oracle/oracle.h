@@ -163,6 +163,23 @@ int orc_dsymgs(int type, int fill, int trans, int base, double alpha, oint m, co
                const oint *col, const oint *ptr, const oint *idiag, const oint *iurow,
                const double *b, double *x, double *y, int fuse_mv);
 
+/* ---- ELL family, level2/aoclsparse_ellmv.hpp + conversion/aoclsparse_convert.{hpp,cpp} ----- */
+int orc_dellmv(int base, double alpha, oint m, const double *val, const oint *col, oint width,
+               const double *x, double beta, double *y);
+int orc_sellmv(int base, float alpha, oint m, const float *val, const oint *col, oint width,
+               const float *x, float beta, float *y);
+int orc_delltmv(int base, double alpha, oint m, const double *val, const oint *col, oint width,
+                const double *x, double beta, double *y);
+int orc_dellthybmv(int base, double alpha, oint m, const double *ell_val, const oint *ell_col,
+                   oint width, oint ell_m, const double *csr_val, const oint *csr_row,
+                   const oint *csr_col, const oint *map, const double *x, double beta, double *y);
+int orc_csr2ell_width(oint m, const oint *row_ptr, oint *width);
+int orc_csr2ellthyb_width(oint m, oint nnz, const oint *row_ptr, oint *ell_m, oint *width);
+int orc_dcsr2ell(int layout, oint m, int base, const oint *row_ptr, const oint *col_ind,
+                 const double *val, oint *ell_col, double *ell_val, oint width);
+int orc_dcsr2ellthyb(oint m, int base, oint *ell_m, const oint *row_ptr, const oint *col_ind,
+                     const double *val, oint *map, oint *ell_col, double *ell_val, oint width);
+
 /* ---- sp2m (C = A*B, both general CSR), level3/aoclsparse_csr2m.cpp:46-543 ------------ */
 /* stage 1: row_ptr_C (0-based, length m+1).  Returns nnz_C in *nnz_c. */
 int orc_csr2m_nnz(oint m, oint n, int base_a, const oint *ptr_a, const oint *ind_a,

@@ -308,6 +308,13 @@ symgs.append(dict(name="GS_NONSYM_S4", src="tests/unit_tests/common_data_utils.h
                               t=[6, -367.16666666666669, -410.33333333333337, 280.83333333333326])))
 out["symgs"] = symgs
 
+# ELL: tests/unit_tests/ellmv_tests.cpp:151-252 (3x3, one-based CSR converted with csr2ell, and the same
+# matrix given directly as one-based ELL with -1 padding)
+out["ell"] = [dict(name="M3_base1", src="tests/unit_tests/ellmv_tests.cpp:151-252", base=1, m=3, n=3,
+                   row_ptr=[1, 2, 3, 5], col_ind=[1, 2, 1, 3], val=[8.0, 5.0, 7.0, 7.0], x=[1.0, 2.0, 3.0],
+                   alpha=1.0, beta=0.0, ell_width=2, ell_col_ind=[1, -1, 2, -1, 1, 3],
+                   ell_val=[8.0, 0.0, 5.0, 0.0, 7.0, 7.0], y_gold=[8.0, 10.0, 28.0])]
+
 with open(n25_path, "w") as f:
     json.dump(out, f, indent=None, separators=(",", ":"))
     f.write("\n")

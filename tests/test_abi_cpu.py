@@ -362,3 +362,70 @@ def test_remaining_hint_setters_and_ilu_hint():
     assert L.aoclsparse_set_symgs_hint(A.h, P.OP_NONE, d.h, -1) == 5
     assert L.aoclsparse_set_dotmv_hint(None, P.OP_NONE, d.h, 1) == 2
     assert L.aoclsparse_optimize(A.h) == 0
+
+
+def _rand_rows(seed, m, n, maxlen):
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(0, maxlen, m)
+    lens[min(5, m - 1)] = 0
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ci = np.concatenate([np.sort(rng.choice(n, k, replace=False)) for k in lens] + [np.zeros(0, np.int64)]).astype(np.int32)
+    return rp, ci, rng.uniform(-1, 1, len(ci))
+
+
+@pytest.mark.parametrize("base", [0, 1])
+def test_ell_conversions_match_the_oracle(base, kats):
+    """conversion/aoclsparse_convert.{cpp,hpp}: widths, ELL (-1 padding), ELLT (last-column padding), ELLT-HYB
+    (row map, ell_m) -- int-exact against the restatement, which is pinned on ellmv_tests.cpp's 3x3."""
+    import oracle
+    m, n = 200, 180
+    rp, ci, v = _rand_rows(41, m, n, 19)
+    rp, ci = rp + base, ci + base
+    d = P.Descr(base=base)
+    w = ctypes.c_int32(-1)
+    assert L.aoclsparse_csr2ell_width(m, len(v), P._ptr(rp), ctypes.byref(w)) == 0
+    for layout, fn in (("ell", L.aoclsparse_dcsr2ell), ("ellt", L.aoclsparse_dcsr2ellt)):
+        wo, ec, ev = oracle.csr2ell(layout, m, base, rp, ci, v)
+        assert w.value == wo
+        gc, gv = np.full(m * wo, 77, np.int32), np.full(m * wo, 77.0)
+        assert fn(m, d.h, P._ptr(rp), P._ptr(ci), P._ptr(v), P._ptr(gc), P._ptr(gv), wo) == 0
+        assert np.array_equal(gc, ec) and np.array_equal(gv, ev)
+    wh, em = ctypes.c_int32(-1), ctypes.c_int32(-1)
+    assert L.aoclsparse_csr2ellthyb_width(m, len(v), P._ptr(rp), ctypes.byref(em), ctypes.byref(wh)) == 0
+    wo, emo, mp, hc, hv = oracle.csr2ell("hyb", m, base, rp, ci, v)
+    assert (wh.value, em.value) == (wo, emo)
+    gc, gv, gm, em2 = np.full(m * wo, 77, np.int32), np.full(m * wo, 77.0), np.full(m, -5, np.int32), ctypes.c_int32(0)
+    assert L.aoclsparse_dcsr2ellthyb(m, base, ctypes.byref(em2), P._ptr(rp), P._ptr(ci), P._ptr(v), None, P._ptr(gm),
+                                     P._ptr(gc), P._ptr(gv), wo) == 0
+    assert em2.value == emo and np.array_equal(gm[: m - emo], mp) and np.array_equal(gc, hc) and np.array_equal(gv, hv)
+    # the reference's own 3x3 (ellmv_tests.cpp:151-204)
+    c = kats["ell"][0]
+    rp3, ci3, v3 = np.array(c["row_ptr"], np.int32), np.array(c["col_ind"], np.int32), np.array(c["val"])
+    gc, gv = np.zeros(6, np.int32), np.zeros(6)
+    assert L.aoclsparse_dcsr2ell(3, P.Descr(base=1).h, P._ptr(rp3), P._ptr(ci3), P._ptr(v3), P._ptr(gc), P._ptr(gv), 2) == 0
+    assert list(gc) == c["ell_col_ind"] and list(gv) == c["ell_val"]
+    # argument checks
+    assert L.aoclsparse_csr2ell_width(-1, 0, P._ptr(rp), ctypes.byref(w)) == 3
+    assert L.aoclsparse_csr2ell_width(m, 0, None, ctypes.byref(w)) == 2
+    assert L.aoclsparse_dcsr2ell(m, d.h, None, P._ptr(ci), P._ptr(v), P._ptr(gc), P._ptr(gv), 3) == 2
+    assert L.aoclsparse_dcsr2ell(m, d.h, P._ptr(rp), P._ptr(ci), P._ptr(v), P._ptr(gc), P._ptr(gv), -1) == 3
+
+
+def test_ellmv_argument_checks():
+    """ellmv_tests.cpp:31-150: nullptr, wrong size, not implemented, invalid base, do-nothing."""
+    col, val = np.array([-1, 1], np.int32), np.array([0.0, 42.0])
+    x, y = np.array([1.0, -2.0, 3.0]), np.array([0.1, 0.2])
+    a, b = np.array([2.3]), np.array([11.2])
+    d = P.Descr()
+    for fn in (L.aoclsparse_dellmv, L.aoclsparse_delltmv):
+        args = lambda **k: [k.get("op", P.OP_NONE), P._ptr(a), k.get("m", 2), k.get("n", 3), 1, k.get("val", P._ptr(val)),
+                            k.get("col", P._ptr(col)), k.get("w", 1), k.get("d", d.h), k.get("x", P._ptr(x)), P._ptr(b),
+                            k.get("y", P._ptr(y))]
+        assert fn(*args(val=None)) == 2 and fn(*args(col=None)) == 2 and fn(*args(x=None)) == 2
+        assert fn(*args(y=None)) == 2 and fn(*args(d=None)) == 2
+        assert fn(*args(m=-1)) == 3 and fn(*args(n=-1)) == 3 and fn(*args(w=-1)) == 3
+        assert fn(*args(d=P.Descr(mtype=P.TYPE_SYMMETRIC).h)) == 1 and fn(*args(op=P.OP_TRANSPOSE)) == 1
+        bad = P.Descr()
+        L.aoclsparse_set_mat_index_base(bad.h, 2)
+        assert fn(*args(m=0, w=1)) == 3 and fn(*args(w=0)) == 0 and np.array_equal(y, [0.1, 0.2])
+    assert L.aoclsparse_sellthybmv(P.OP_NONE, None, 1, 1, 1, None, None, 1, 1, None, None, None, None, None, d.h, None, None, None) == 1

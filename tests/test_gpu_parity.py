@@ -990,3 +990,92 @@ def test_ilu_smoother_matches_reference_factorisation_and_solve(base):
     assert L.aoclsparse_dilu_smoother(P.OP_TRANSPOSE, A.h, d.h, ctypes.byref(pv), None, P._ptr(x), P._ptr(b)) == 1
     assert L.aoclsparse_dilu_smoother(P.OP_NONE, A.h, P.Descr(base=base, mtype=P.TYPE_SYMMETRIC).h, ctypes.byref(pv), None,
                                       P._ptr(x), P._ptr(b)) == 1
+
+
+# --------------------------------------------------------------------------------------------------
+# ELL family
+# --------------------------------------------------------------------------------------------------
+def _ell_rows(seed, m, n, maxlen, long_every=0):
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(0, maxlen, m)
+    lens[min(5, m - 1)] = 0
+    if long_every:
+        lens[::long_every] = rng.integers(3 * maxlen, 9 * maxlen, len(lens[::long_every]))
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ci = np.concatenate([np.sort(rng.choice(n, k, replace=False)) for k in lens]).astype(np.int32)
+    return rp, ci, rng.uniform(-1, 1, len(ci))
+
+
+def test_ellmv_reference_kat(kats):
+    c = kats["ell"][0]
+    d = P.Descr(base=c["base"])
+    col, val, x = np.array(c["ell_col_ind"], np.int32), np.array(c["ell_val"]), np.array(c["x"])
+    y, a, b = np.full(3, np.nan), np.array([c["alpha"]]), np.array([c["beta"]])
+    assert L.aoclsparse_dellmv(P.OP_NONE, P._ptr(a), 3, 3, 4, P._ptr(val), P._ptr(col), 2, d.h, P._ptr(x), P._ptr(b), P._ptr(y)) == 0
+    assert list(y) == c["y_gold"]
+    yf = np.full(3, np.nan, np.float32)
+    assert L.aoclsparse_sellmv(P.OP_NONE, P._ptr(a.astype(np.float32)), 3, 3, 4, P._ptr(val.astype(np.float32)), P._ptr(col), 2,
+                               d.h, P._ptr(x.astype(np.float32)), P._ptr(b.astype(np.float32)), P._ptr(yf)) == 0
+    assert list(yf) == c["y_gold"]
+
+
+@pytest.mark.parametrize("base", [0, 1])
+@pytest.mark.parametrize("alpha,beta", [(1.0, 0.0), (1.7, -0.3)])
+def test_ell_family_bit_exact(base, alpha, beta):
+    """?ellmv (4-lane order / scalar float), ?elltmv, dellthybmv against the restated reference kernels, host and
+    device arrays, both index bases; beta == 0 must not read y."""
+    m, n = 5000, 4700
+    rp, ci, v = _ell_rows(51, m, n, 23, long_every=97)
+    rp, ci = rp + base, ci + base
+    d = P.Descr(base=base)
+    rng = np.random.default_rng(52)
+    x = rng.uniform(-1, 1, n)
+    y0 = rng.uniform(-1, 1, m) if beta != 0.0 else np.full(m, np.nan)
+    a, b = np.array([alpha]), np.array([beta])
+    for layout, fn in (("ell", L.aoclsparse_dellmv), ("ellt", L.aoclsparse_delltmv)):
+        w, ec, ev = oracle.csr2ell(layout, m, base, rp, ci, v)
+        st, yr = oracle.dellmv(layout, base, alpha, m, ev, ec, w, x, beta, y0)
+        y = y0.copy()
+        assert fn(P.OP_NONE, P._ptr(a), m, n, len(v), P._ptr(ev), P._ptr(ec), w, d.h, P._ptr(x), P._ptr(b), P._ptr(y)) == 0
+        assert np.array_equal(y, yr), layout
+        yd, evd, ecd = dev(y0), dev(ev), dev(ec)
+        assert fn(P.OP_NONE, P._ptr(a), m, n, len(v), P._ptr(evd), P._ptr(ecd), w, d.h, P._ptr(dev(x)), P._ptr(b), P._ptr(yd)) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(yd.cpu().numpy(), yr), layout
+    w, em, mp, hc, hv = oracle.csr2ell("hyb", m, base, rp, ci, v)
+    assert 0 < len(mp) < m
+    st, yr = oracle.dellthybmv(base, alpha, m, hv, hc, w, em, v, rp, ci, mp, x, beta, y0)
+    y = y0.copy()
+    args = [P.OP_NONE, P._ptr(a), m, n, len(v), P._ptr(hv), P._ptr(hc), w, em, P._ptr(v), P._ptr(rp), P._ptr(ci), None, P._ptr(mp),
+            d.h, P._ptr(x), P._ptr(b), P._ptr(y)]
+    assert L.aoclsparse_dellthybmv(*args) == 0
+    assert np.array_equal(y, yr)
+    keep = [dev(t) for t in (hv, hc, v, rp, ci, mp, x, y0)]
+    for k, t in zip((5, 6, 9, 10, 11, 13, 15, 17), keep):
+        args[k] = P._ptr(t)
+    assert L.aoclsparse_dellthybmv(*args) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(keep[-1].cpu().numpy(), yr)
+    # float: scalar-order ELL and ELLT
+    vf, xf = v.astype(np.float32), x.astype(np.float32)
+    af, bf = a.astype(np.float32), b.astype(np.float32)
+    y0f = y0.astype(np.float32)
+    w, ec, ev = oracle.csr2ell("ell", m, base, rp, ci, vf.astype(np.float64))
+    st, yr = oracle.sellmv(base, float(af[0]), m, ev.astype(np.float32), ec, w, xf, float(bf[0]), y0f)
+    yf = y0f.copy()
+    assert L.aoclsparse_sellmv(P.OP_NONE, P._ptr(af), m, n, len(v), P._ptr(ev.astype(np.float32)), P._ptr(ec), w, d.h, P._ptr(xf),
+                               P._ptr(bf), P._ptr(yf)) == 0
+    assert np.array_equal(yf, yr)
+
+
+def test_ellt_all_rows_short_equals_csr_scalar_order():
+    """L100-like input: ELLT with one lane per row is the reference's scalar chain, so it must reproduce the CSR
+    scalar kernel bit for bit (padding contributes +0)."""
+    m, rp, ci, v = laplace5(100)
+    w, tc, tv = oracle.csr2ell("ellt", m, 0, rp, ci, v)
+    x = np.sin(0.01 * np.arange(m))
+    a, b, y = np.array([1.0]), np.array([0.0]), np.zeros(m)
+    assert L.aoclsparse_delltmv(P.OP_NONE, P._ptr(a), m, m, len(v), P._ptr(tv), P._ptr(tc), w, P.Descr().h, P._ptr(x), P._ptr(b),
+                                P._ptr(y)) == 0
+    so, yr = oracle.dcsrmv(0, 0, 1.0, m, len(v), v, ci, rp, x, 0.0, np.zeros(m))
+    assert np.array_equal(y, yr)

@@ -314,3 +314,48 @@ def test_ilu_solve_inverts_the_factors():
             else:
                 Um[i, ci[p]] = lu[p]
     assert np.allclose(Lm @ (Um @ x), b, rtol=0, atol=1e-12)
+
+
+def test_ell_kat_and_conversions(kats):
+    """ellmv_tests.cpp:151-252: csr2ell of the one-based 3x3 gives the -1 padded arrays the test also feeds
+    directly, and both give y_gold; ELLT and ELLT-HYB of the same matrix agree."""
+    c = kats["ell"][0]
+    m, base = c["m"], c["base"]
+    w, ec, ev = oracle.csr2ell("ell", m, base, c["row_ptr"], c["col_ind"], c["val"])
+    assert w == c["ell_width"] and list(ec) == c["ell_col_ind"] and list(ev) == c["ell_val"]
+    st, y = oracle.dellmv("ell", base, c["alpha"], m, ev, ec, w, c["x"], c["beta"], np.full(m, np.nan))
+    assert st == 0 and list(y) == c["y_gold"]
+    st, yf = oracle.sellmv(base, c["alpha"], m, ev, ec, w, c["x"], c["beta"], np.full(m, np.nan))
+    assert st == 0 and list(yf) == c["y_gold"]
+    w, tc, tv = oracle.csr2ell("ellt", m, base, c["row_ptr"], c["col_ind"], c["val"])
+    st, y = oracle.dellmv("ellt", base, c["alpha"], m, tv, tc, w, c["x"], c["beta"], np.full(m, np.nan))
+    assert st == 0 and list(y) == c["y_gold"]
+    w, em, mp, hc, hv = oracle.csr2ell("hyb", m, base, c["row_ptr"], c["col_ind"], c["val"])
+    assert (w, em, list(mp)) == (1, 2, [2])
+    st, y = oracle.dellthybmv(base, c["alpha"], m, hv, hc, w, em, c["val"], c["row_ptr"], c["col_ind"], mp, c["x"],
+                              c["beta"], np.full(m, np.nan))
+    assert st == 0 and list(y) == c["y_gold"]
+
+
+def test_ell_orders_against_csr_oracle():
+    rng = np.random.default_rng(31)
+    m, n = 300, 280
+    lens = rng.integers(0, 23, m)
+    lens[5] = 0
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ci = np.concatenate([np.sort(rng.choice(n, k, replace=False)) for k in lens]).astype(np.int32)
+    v = rng.uniform(-1, 1, len(ci))
+    x, y0 = rng.uniform(-1, 1, n), rng.uniform(-1, 1, m)
+    # row-major ELL in the 4-lane order == CSR 4-lane kernel on rows whose length is a multiple of 4 or < 4 ...
+    w, ec, ev = oracle.csr2ell("ell", m, 0, rp, ci, v)
+    st, ye = oracle.dellmv("ell", 0, 1.7, m, ev, ec, w, x, -0.3, y0)
+    st, yc = oracle.dcsrmv_order("lane4", 0, 1.7, m, v, ci, rp, x, -0.3, y0)
+    assert np.array_equal(ye, yc)  # ... and in fact on every row: both walk full groups then a scalar tail
+    w, tc, tv = oracle.csr2ell("ellt", m, 0, rp, ci, v)
+    st, yt = oracle.dellmv("ellt", 0, 1.7, m, tv, tc, w, x, -0.3, y0)
+    st, yr = oracle.dcsrmv_order("ref", 0, 1.7, m, v, ci, rp, x, -0.3, y0)
+    assert np.allclose(yt, yr, rtol=0, atol=1e-13)  # padding adds +0*x terms: same value unless -0/Inf
+    w, em, mp, hc, hv = oracle.csr2ell("hyb", m, 0, rp, ci, v)
+    assert em + len(mp) == m and np.all(lens[mp] > w) and np.count_nonzero(lens <= w) == em
+    st, yh = oracle.dellthybmv(0, 1.7, m, hv, hc, w, em, v, rp, ci, mp, x, -0.3, y0)
+    assert np.array_equal(yh[mp], yc[mp]) and np.allclose(yh, yr, rtol=0, atol=1e-13)
