@@ -117,6 +117,19 @@ struct DeviceCsr
     bool           valid = false;
 };
 
+// SELL-64 twin of a device CSR (sell_kernels.hip): built by aoclsparse_optimize for an mv hint when the
+// padding stays small; the handle's ?mv then runs on it instead of the CSR-Adaptive kernel.
+struct SellPlan
+{
+    aoclsparse_int nslices = 0;
+    long long      cells   = 0; // stored cells = sum over slices of 64 * (longest row of the slice)
+    DeviceBuffer   slice_ptr; // nslices+1 cell offsets (long long)
+    DeviceBuffer   val, col; // cells values / 0-based columns (-1 = padding)
+    DeviceBuffer   rowlen; // m row lengths (read by the 4- and 8-lane orders only)
+    bool           valid = false, tried = false;
+    bool           wanted = false; // optimize chose SELL: rebuilt lazily after the values change
+};
+
 // SpMV execution plan (CSR-Adaptive row blocks), see spmv_kernels.hip
 struct SpmvPlan
 {
@@ -126,6 +139,7 @@ struct SpmvPlan
     aoclsparse_int tile        = 0; // LDS tile (non-zeros per row block): 1024 or 2048
     DeviceBuffer   rowblocks; // nblocks+1 entries {first row, first non-zero (0-based)}
     bool           valid = false;
+    SellPlan       sell;
 };
 
 // TRSV plan of one (triangle, op) pair (trsv_api.cpp / trsv_kernels.hip): the strict triangle
@@ -327,6 +341,9 @@ aoclsparse_status ensure_derived(aoclsparse_matrix A, aoclsparse_matrix_type typ
                                  aoclsparse_diag_type diag, bool transposed, Derived *&out);
 // clean CSR on the device + level sets of one triangle (trsv_api.cpp)
 aoclsparse_status ensure_trsv(aoclsparse_matrix A, bool upper, bool transposed);
+// SELL-64 copy of d (row_ptr_host = the host row pointer d mirrors); leaves plan.sell.valid false when the
+// padding would exceed the budget (AOCLSPARSE_MI355_SELL=0 never, =1 always)
+aoclsparse_status build_sell(const aoclsparse_int *row_ptr_host, const DeviceCsr &d, size_t vsize, SpmvPlan &plan);
 aoclsparse_status build_spmv_plan(aoclsparse_int m, aoclsparse_int nnz, aoclsparse_index_base base,
                                   const aoclsparse_int *row_ptr_host, SpmvPlan &plan);
 
@@ -337,6 +354,14 @@ aoclsparse_status launch_csrmv(hipStream_t s, int order, bool strict, int tile, 
                                aoclsparse_int m, const T *val, const aoclsparse_int *col,
                                const aoclsparse_int *row_ptr, const aoclsparse_int *blocks,
                                aoclsparse_int nblocks, const T *x, T beta, T *y);
+template <typename T>
+aoclsparse_status launch_sell_fill(hipStream_t s, aoclsparse_int m, int base, const aoclsparse_int *row_ptr,
+                                   const aoclsparse_int *col, const T *val, aoclsparse_int nslices,
+                                   const long long *slice_ptr, T *sval, aoclsparse_int *scol, aoclsparse_int *rowlen);
+template <typename T>
+aoclsparse_status launch_sellmv(hipStream_t s, int order, T alpha, aoclsparse_int m, aoclsparse_int nslices,
+                                const long long *slice_ptr, const T *sval, const aoclsparse_int *scol,
+                                const aoclsparse_int *rowlen, const T *x, T beta, T *y);
 template <typename T>
 aoclsparse_status launch_scale(hipStream_t s, T *y, aoclsparse_int n, T beta);
 // w = a*x + b*y elementwise (w may alias x or y); a == 1, b == -1 is an exact subtraction

@@ -452,6 +452,66 @@ aoclsparse_status build_spmv_plan(aoclsparse_int m, aoclsparse_int nnz, aoclspar
     return aoclsparse_status_success;
 }
 
+aoclsparse_status build_sell(const aoclsparse_int *row_ptr_host, const DeviceCsr &d, size_t vsize, SpmvPlan &plan)
+{
+    SellPlan &sp = plan.sell;
+    if(sp.valid || sp.tried)
+        return aoclsparse_status_success;
+    sp.tried = true;
+    static const int mode = [] {
+        const char *e = getenv("AOCLSPARSE_MI355_SELL");
+        return e ? atoi(e) : -1;
+    }();
+    if(mode == 0 || d.m <= 0 || d.nnz <= 0 || !d.valid)
+        return aoclsparse_status_success;
+    const aoclsparse_int   m = d.m, nslices = (m + 63) / 64;
+    std::vector<long long> sptr;
+    try
+    {
+        sptr.resize((size_t)nslices + 1);
+    }
+    catch(const std::bad_alloc &)
+    {
+        return aoclsparse_status_memory_error;
+    }
+    sptr[0] = 0;
+    for(aoclsparse_int s = 0; s < nslices; s++)
+    {
+        aoclsparse_int w = 0;
+        for(aoclsparse_int i = s * 64; i < std::min<aoclsparse_int>(m, s * 64 + 64); i++)
+            w = std::max(w, row_ptr_host[i + 1] - row_ptr_host[i]);
+        sptr[s + 1] = sptr[s] + 64LL * w;
+    }
+    const long long cells = sptr[nslices];
+    // Padding budget: the SELL kernel moves 12 B per cell at ~0.78 of peak where CSR-Adaptive moves
+    // 12 B per non-zero + 4 B per row at ~0.66 (profiles/r1): SELL wins up to ~1.15 cells per non-zero.
+    if(mode != 1 && (double)cells > 1.15 * (double)d.nnz + 64.0)
+        return aoclsparse_status_success;
+    Runtime          &rt = Runtime::get();
+    aoclsparse_status st = sp.slice_ptr.upload(sptr.data(), sizeof(long long) * sptr.size(), rt.stream());
+    if(st == aoclsparse_status_success)
+        st = sp.val.alloc(vsize * (size_t)std::max<long long>(cells, 1));
+    if(st == aoclsparse_status_success)
+        st = sp.col.alloc(sizeof(aoclsparse_int) * (size_t)std::max<long long>(cells, 1));
+    if(st == aoclsparse_status_success)
+        st = sp.rowlen.alloc(sizeof(aoclsparse_int) * (size_t)m);
+    if(st != aoclsparse_status_success)
+        return st;
+    if(vsize == sizeof(float))
+        st = launch_sell_fill<float>(rt.stream(), m, d.base, d.ptr.as<aoclsparse_int>(), d.ind.as<aoclsparse_int>(),
+                                     d.val.as<float>(), nslices, sp.slice_ptr.as<long long>(), sp.val.as<float>(),
+                                     sp.col.as<aoclsparse_int>(), sp.rowlen.as<aoclsparse_int>());
+    else
+        st = launch_sell_fill<double>(rt.stream(), m, d.base, d.ptr.as<aoclsparse_int>(), d.ind.as<aoclsparse_int>(),
+                                      d.val.as<double>(), nslices, sp.slice_ptr.as<long long>(), sp.val.as<double>(),
+                                      sp.col.as<aoclsparse_int>(), sp.rowlen.as<aoclsparse_int>());
+    if(st != aoclsparse_status_success)
+        return st;
+    MI355_HIP_TRY(hipStreamSynchronize(rt.stream())); // sptr (host) is read by the upload until here
+    sp.nslices = nslices, sp.cells = cells, sp.valid = sp.wanted = true;
+    return aoclsparse_status_success;
+}
+
 aoclsparse_status ensure_spmv(aoclsparse_matrix A, bool transposed, DeviceCsr *&dcsr, SpmvPlan *&plan)
 {
     dcsr = transposed ? &A->dev_trans : &A->dev_user;
@@ -708,6 +768,8 @@ aoclsparse_status aoclsparse_mi355_invalidate(aoclsparse_matrix A)
     std::unique_lock<std::shared_mutex> w(A->guard);
     A->dev_user.valid = A->dev_trans.valid = false;
     A->plan_user.valid = A->plan_trans.valid = false;
+    A->plan_user.sell.valid = A->plan_user.sell.tried = false;
+    A->plan_trans.sell.valid = A->plan_trans.sell.tried = false;
     for(auto &p : A->trsv_plan)
         p.valid = false, p.nlevels = -1;
     A->trans.reset();
@@ -730,6 +792,8 @@ static void drop_derived_state(aoclsparse_matrix A)
     A->trans.reset();
     A->derived.clear();
     A->dev_user.valid = A->dev_trans.valid = false; // row-block plans stay valid: structure is unchanged
+    A->plan_user.sell.valid = A->plan_user.sell.tried = false; // the SELL copies hold values: rebuilt on optimize
+    A->plan_trans.sell.valid = A->plan_trans.sell.tried = false;
     A->dev_diag.release();
     for(auto &p : A->trsv_plan)
         p.valid = false, p.nlevels = -1;

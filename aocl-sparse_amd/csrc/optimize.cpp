@@ -74,6 +74,14 @@ extern "C" aoclsparse_status aoclsparse_optimize(aoclsparse_matrix A)
                 DeviceCsr *d = nullptr;
                 SpmvPlan  *p = nullptr;
                 st = ensure_spmv(A, h.trans != aoclsparse_operation_none, d, p);
+                if(st == aoclsparse_status_success && h.nop > 0)
+                {
+                    // the mv hint's format choice (analysis.cpp:146-382 picks br4 / ELLT-HYB / blocked CSR on
+                    // the CPU): a SELL-64 copy when its padding is small
+                    std::unique_lock<std::shared_mutex> w(A->guard);
+                    const HostCsr &hc = h.trans != aoclsparse_operation_none ? *A->trans : A->user;
+                    st                = build_sell(hc.ptr, *d, val_size(A->val_type), *p);
+                }
             }
             else if((h.act == action_sv || h.act == action_sm_row || h.act == action_sm_col)
                     && (h.type == aoclsparse_matrix_type_triangular

@@ -109,10 +109,16 @@ aoclsparse_status run_on_device_csr(Runtime &rt, aoclsparse_int kid, const Devic
     st = ay.in(rt, 4, y, sizeof(T) * (size_t)ny, ydev, beta != T(0));
     if(st != aoclsparse_status_success)
         return st;
-    st = launch_csrmv<T>(rt.stream(), order, strict, plan.tile, d.base, alpha, d.m, d.val.as<T>(),
-                         d.ind.as<aoclsparse_int>(), d.ptr.as<aoclsparse_int>(),
-                         plan.rowblocks.as<aoclsparse_int>(), plan.nblocks, static_cast<const T *>(ax.dev),
-                         beta, static_cast<T *>(ay.dev));
+    if(plan.sell.valid) // format chosen by optimize for an mv hint: every order is exact there
+        st = launch_sellmv<T>(rt.stream(), order, alpha, d.m, plan.sell.nslices, plan.sell.slice_ptr.as<long long>(),
+                              plan.sell.val.as<T>(), plan.sell.col.as<aoclsparse_int>(),
+                              plan.sell.rowlen.as<aoclsparse_int>(), static_cast<const T *>(ax.dev), beta,
+                              static_cast<T *>(ay.dev));
+    else
+        st = launch_csrmv<T>(rt.stream(), order, strict, plan.tile, d.base, alpha, d.m, d.val.as<T>(),
+                             d.ind.as<aoclsparse_int>(), d.ptr.as<aoclsparse_int>(),
+                             plan.rowblocks.as<aoclsparse_int>(), plan.nblocks, static_cast<const T *>(ax.dev),
+                             beta, static_cast<T *>(ay.dev));
     if(st != aoclsparse_status_success)
         return st;
     st = ay.out(rt);
@@ -207,6 +213,13 @@ aoclsparse_status mv_t(aoclsparse_operation op, const T *alpha, aoclsparse_matri
         st = ensure_spmv(A, tr, dcsr, plan);
         if(st != aoclsparse_status_success)
             return st;
+        if(plan->sell.wanted && !plan->sell.valid) // values changed since optimize built the SELL copy
+        {
+            std::unique_lock<std::shared_mutex> w(A->guard);
+            st = build_sell((tr ? *A->trans : A->user).ptr, *dcsr, val_size(A->val_type), *plan);
+            if(st != aoclsparse_status_success)
+                return st;
+        }
     }
     std::shared_lock<std::shared_mutex> r(A->guard);
     return run_on_device_csr<T>(rt, kid, *dcsr, *plan, *alpha, x, *beta, y, dcsr->n, dcsr->m);
@@ -542,8 +555,8 @@ aoclsparse_status aoclsparse_mi355_get_spmv_info(const aoclsparse_matrix A, aocl
     info->device_resident = d.valid;
     if(!p.valid)
         return aoclsparse_status_success;
-    info->kernel      = 1;
-    info->row_blocks  = p.nblocks;
+    info->kernel      = p.sell.valid ? 3 : 1;
+    info->row_blocks  = p.sell.valid ? (p.sell.nslices < 2048 ? p.sell.nslices : (p.sell.nslices + 3) / 4) : p.nblocks;
     info->tile        = p.tile & ~1;
     info->long_rows   = p.long_rows;
     info->max_row_nnz = p.max_row_nnz;

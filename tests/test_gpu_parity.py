@@ -59,7 +59,7 @@ def test_l100_dmv_bit_exact(base, alpha, beta):
     d = P.Descr(base=base)
     assert L.aoclsparse_set_mv_hint(A.h, P.OP_NONE, d.h, 10) == 0 and L.aoclsparse_optimize(A.h) == 0
     info = A.spmv_info()
-    assert info.kernel == 1 and info.order == 0 and info.device_resident == 1 and info.long_rows == 0
+    assert info.kernel == 3 and info.order == 0 and info.device_resident == 1 and info.long_rows == 0  # SELL-64
     for on_device in (True, False):
         st, y = run_dmv(A, d, x, y0, alpha, beta, on_device=on_device)
         assert st == 0
@@ -1079,3 +1079,100 @@ def test_ellt_all_rows_short_equals_csr_scalar_order():
                                 P._ptr(y)) == 0
     so, yr = oracle.dcsrmv(0, 0, 1.0, m, len(v), v, ci, rp, x, 0.0, np.zeros(m))
     assert np.array_equal(y, yr)
+
+
+# --------------------------------------------------------------------------------------------------
+# SELL-64: the format optimize builds for an mv hint
+# --------------------------------------------------------------------------------------------------
+def _hinted(base, m, n, rp, ci, v, kid=None, op=None):
+    A = P.Matrix(base, m, n, rp, ci, v)
+    d = P.Descr(base=base)
+    o = P.OP_NONE if op is None else op
+    if kid is None:
+        assert L.aoclsparse_set_mv_hint(A.h, o, d.h, 100) == 0
+    else:
+        assert L.aoclsparse_set_mv_hint_kid(A.h, o, d.h, 100, kid) == 0
+    assert L.aoclsparse_optimize(A.h) == 0
+    return A, d
+
+
+def test_sell_chosen_for_uniform_rows_and_bit_exact_scalar_order():
+    g = 300
+    m, rp, ci, v = laplace5(g)
+    A, d = _hinted(0, m, m, rp, ci, v)
+    assert A.spmv_info().kernel == 3
+    rng = np.random.default_rng(61)
+    x, y0 = rng.uniform(-1, 1, m), rng.uniform(-1, 1, m)
+    for alpha, beta in ((1.0, 0.0), (5.1, 3.2)):
+        st, y = run_dmv(A, d, x, y0 if beta else np.full(m, np.nan), alpha, beta)
+        so, yr = oracle.dcsrmv(-1, 0, alpha, m, len(v), v, ci, rp, x, beta, y0 if beta else np.zeros(m))
+        assert st == 0 and np.array_equal(y, yr)
+    # NaN / Inf in x only reach the rows that reference them (padding cells are skipped, not multiplied)
+    xb = x.copy()
+    xb[7], xb[g * 17 + 3] = np.nan, np.inf
+    st, y = run_dmv(A, d, xb, np.zeros(m), 1.0, 0.0)
+    so, yr = oracle.dcsrmv(-1, 0, 1.0, m, len(v), v, ci, rp, xb, 0.0, np.zeros(m))
+    assert np.array_equal(np.isnan(y), np.isnan(yr)) and np.array_equal(y[~np.isnan(yr)], yr[~np.isnan(yr)])
+
+
+@pytest.mark.parametrize("kid,order", [(None, "lane8"), (1, "lane4"), (3, "lane8"), (0, "ref")])
+@pytest.mark.parametrize("base", [0, 1])
+def test_sell_lane_orders_bit_exact(kid, order, base):
+    """nnz > 10 m: the reference runs its vector kernels; a SELL lane reproduces their order with 4 / 8 private
+    partial sums.  Rows of every length mod 8, empty rows, a last partial slice."""
+    m, n = 64 * 37 + 13, 3000
+    rng = np.random.default_rng(62)
+    lens = rng.integers(36, 41, m)  # padding stays under the 1.15 budget
+    lens[3], lens[100], lens[m - 1] = 0, 7, 25
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ci = np.concatenate([rng.choice(n, k, replace=False) for k in lens]).astype(np.int32)  # unsorted columns
+    v = rng.uniform(-1, 1, len(ci))
+    A, d = _hinted(base, m, n, rp + base, ci + base, v, kid=kid)
+    assert A.spmv_info().kernel == 3 and len(v) > 10 * m
+    x, y0 = rng.uniform(-1, 1, n), rng.uniform(-1, 1, m)
+    st, y = run_dmv(A, d, x, y0, -1.3, 0.7)
+    so, yr = oracle.dcsrmv_order(order, 0, -1.3, m, v, ci, rp, x, 0.7, y0)
+    assert st == 0 and np.array_equal(y, yr)
+
+
+def test_sell_float_transposed_and_value_refresh():
+    m, n = 2100, 1900
+    rp, ci, v = random_csr(63, m, n, lambda r, i: r.integers(12, 15))
+    vf = v.astype(np.float32)
+    A = P.Matrix(0, m, n, rp, ci, vf)
+    d = P.Descr()
+    assert L.aoclsparse_set_mv_hint(A.h, P.OP_NONE, d.h, 10) == 0 and L.aoclsparse_optimize(A.h) == 0
+    assert A.spmv_info().kernel == 3
+    x = np.random.default_rng(64).uniform(-1, 1, n).astype(np.float32)
+    y, a, b = np.zeros(m, np.float32), np.array([1.5], np.float32), np.array([0.0], np.float32)
+    assert L.aoclsparse_smv(P.OP_NONE, P._ptr(a), A.h, d.h, P._ptr(x), P._ptr(b), P._ptr(y)) == 0
+    so, yr = oracle.scsrmv("lane8", 0, 1.5, m, vf, ci, rp, x, 0.0, np.zeros(m, np.float32))
+    assert np.array_equal(y, yr)
+    # transposed hint: SELL of A^T (a structurally symmetric pattern keeps the rows of A^T uniform)
+    m2, rp2, ci2, v2 = laplace5(50)
+    vd = v2 * np.random.default_rng(69).uniform(0.5, 1.5, len(v2))
+    B = P.Matrix(0, m2, m2, rp2, ci2, vd)
+    assert L.aoclsparse_set_mv_hint(B.h, P.OP_TRANSPOSE, d.h, 10) == 0
+    assert L.aoclsparse_set_mv_hint(B.h, P.OP_NONE, d.h, 10) == 0 and L.aoclsparse_optimize(B.h) == 0
+    assert B.spmv_info(P.OP_TRANSPOSE).kernel == 3 and B.spmv_info().kernel == 3
+    xt = np.random.default_rng(65).uniform(-1, 1, m2)
+    st, yt = run_dmv(B, d, xt, np.zeros(m2), 1.0, 0.0, op=P.OP_TRANSPOSE)
+    dense = np.zeros((m2, m2))
+    for i in range(m2):
+        dense[i, ci2[rp2[i]:rp2[i + 1]]] = vd[rp2[i]:rp2[i + 1]]
+    assert st == 0 and np.allclose(yt, dense.T @ xt, rtol=0, atol=1e-12)
+    # values change -> the SELL copy is rebuilt on the next product
+    nv = np.random.default_rng(66).uniform(-1, 1, len(vd))
+    assert L.aoclsparse_dupdate_values(B.h, len(nv), P._ptr(nv)) == 0
+    assert B.spmv_info().kernel == 1  # dropped with the other derived copies ...
+    xs = np.random.default_rng(67).uniform(-1, 1, m2)
+    st, y2 = run_dmv(B, d, xs, np.zeros(m2), 1.0, 0.0)
+    so, yr = oracle.dcsrmv(-1, 0, 1.0, m2, len(nv), nv, ci2, rp2, xs, 0.0, np.zeros(m2))
+    assert st == 0 and np.array_equal(y2, yr) and B.spmv_info().kernel == 3  # ... and back on first use
+
+
+def test_sell_not_chosen_for_power_law_rows():
+    m = 20000
+    rp, ci, v = random_csr(68, m, m, powerlaw_rows(6, 9000))
+    A, d = _hinted(0, m, m, rp, ci, v)
+    assert A.spmv_info().kernel == 1
