@@ -556,8 +556,10 @@ aoclsparse_status aoclsparse_mi355_get_spmv_info(const aoclsparse_matrix A, aocl
     if(!p.valid)
         return aoclsparse_status_success;
     info->kernel      = p.sell.valid ? 3 : 1;
-    info->row_blocks  = p.sell.valid ? (p.sell.nslices < 2048 ? p.sell.nslices : (p.sell.nslices + 3) / 4) : p.nblocks;
+    info->row_blocks  = p.sell.valid ? (p.sell.nslices < 2048 ? p.sell.nslices : (p.sell.nslices + 1) / 2) : p.nblocks;
     info->tile        = p.tile & ~1;
+    info->sell_slices  = p.sell.valid ? p.sell.nslices : 0;
+    info->stored_cells = p.sell.valid ? p.sell.cells : 0;
     info->long_rows   = p.long_rows;
     info->max_row_nnz = p.max_row_nnz;
     aoclsparse_int kid = -1;

@@ -152,7 +152,7 @@ def main():
     try:  # PMC counters cannot be read from inside the run: use the committed rocprofv3 measurement
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pmc = json.load(f)
-        if pmc.get("grid") == g:
+        if pmc.get("grid") == g and pmc.get("kernel_id", 1) == info.kernel:
             traffic, traffic_src = pmc["traffic_bytes_per_launch"], "profiles/pmc_traffic.json"
     except (OSError, ValueError, KeyError):
         pass
@@ -173,8 +173,12 @@ def main():
         "config": {
             "workload": "aoclsparse_dmv, 5-pt Laplacian grid %dx%d (m=%d, nnz=%d), alpha=1 beta=0; "
                         "BASELINE configs[1] scaled past the 256 MiB Infinity Cache" % (g, g, m, nnz),
-            "kernel": "csr-adaptive stream, order %d (reference ref_csrmv_gn order), %d row blocks"
-                      % (info.order, info.row_blocks),
+            "kernel": ("SELL-64 built by aoclsparse_optimize for the mv hint (%d slices, %d cells = %.3f x nnz), "
+                       "order %d (reference ref_csrmv_gn order)"
+                       % (info.sell_slices, info.stored_cells, info.stored_cells / max(nnz, 1), info.order))
+                      if info.kernel == 3 else
+                      ("csr-adaptive stream, order %d (reference ref_csrmv_gn order), %d row blocks"
+                       % (info.order, info.row_blocks)),
             "parallelism": "replicas x%d" % world,
             "device": dev_name,
         },
@@ -187,6 +191,7 @@ def main():
             "traffic": traffic,
             "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": abytes,
+            "stored_format_bytes_per_launch": (info.stored_cells * 12 + 16 * m) if info.kernel == 3 else abytes,
             "kernel_ms": round(kernel_ms, 6),
         },
     }

@@ -63,7 +63,8 @@ if "spmv" in what:
         lens = np.diff(rp)
         short = lens <= info.tile
         b = spmv_bytes(m, m, nnz)
-        emit(kind="spmv", matrix=name + " (stand-in)", m=m, nnz=nnz, order=info.order, tile=info.tile,
+        emit(kind="spmv", matrix=name + " (stand-in)", m=m, nnz=nnz, kernel={1: "csr-adaptive", 3: "sell-64"}.get(info.kernel, info.kernel),
+             cells_per_nnz=round(info.stored_cells / nnz, 3) if info.kernel == 3 else None, order=info.order, tile=info.tile,
              row_blocks=info.row_blocks, long_rows=info.long_rows, max_row=int(lens.max()), ms=round(ms, 5),
              gflops=round(2 * nnz / ms / 1e6, 2), gbs=round(b / ms / 1e6, 1), frac_of_8TBs=round(b / ms / 1e6 / 8000, 4),
              bit_exact_rows_within_tile=bool(np.array_equal(yd[short], yr[short])),
