@@ -395,6 +395,31 @@ template <typename T>
 aoclsparse_status launch_gather_rows(hipStream_t s, aoclsparse_int n, const aoclsparse_int *map, const T *src,
                                      T *dst);
 
+// dense-vector steps of the iterative solvers (itsol_kernels.hip); `partial` holds
+// vec_reduce_scratch_elems(k) elements, reduction results land in device memory
+int vec_reduce_scratch_elems(int k);
+template <typename T>
+aoclsparse_status launch_cg_init(hipStream_t s, aoclsparse_int n, const T *b, const T *x, T *r, T *p);
+template <typename T>
+aoclsparse_status launch_vec_copy(hipStream_t s, aoclsparse_int n, const T *src, T *dst);
+template <typename T>
+aoclsparse_status launch_vec_add(hipStream_t s, aoclsparse_int n, const T *src, T *dst);
+template <typename T>
+aoclsparse_status launch_vec_mul(hipStream_t s, aoclsparse_int n, const T *src, T *dst);
+template <typename T>
+aoclsparse_status launch_vec_fill(hipStream_t s, aoclsparse_int n, T *dst, T value);
+template <typename T>
+aoclsparse_status launch_cg_direction(hipStream_t s, aoclsparse_int n, T beta, T *p, const T *z);
+template <typename T>
+aoclsparse_status launch_cg_step(hipStream_t s, aoclsparse_int n, T alpha, const T *p, const T *q, T *x, T *r,
+                                 T *partial, T *rr);
+template <typename T>
+aoclsparse_status launch_multidot(hipStream_t s, aoclsparse_int n, int k, const T *V, long long ld, const T *w,
+                                  T *partial, T *out);
+template <typename T>
+aoclsparse_status launch_lincomb(hipStream_t s, int sign, aoclsparse_int n, int k, const T *c, const T *V,
+                                 long long ld, T *w);
+
 // TRSV on the level-ordered layout (trsv_kernels.hip).
 // schedule 0: one launch per level; 1: hybrid (narrow level runs inside one workgroup); 2: sync-free.
 constexpr int TRSV_NARROW = 1024; // a level this narrow is solved by one workgroup (one row per lane)

@@ -535,6 +535,50 @@ DLL_PUBLIC aoclsparse_status aoclsparse_dilu_smoother(aoclsparse_operation op, a
                                                       double **precond_csr_val, const double *approx_inv_diag,
                                                       double *x, const double *b);
 
+/* ---- iterative solvers (aoclsparse_solvers.h:104-560): CG and restarted GMRES, options by name
+ * ("iterative method", "cg iteration limit", "cg rel tolerance", "cg abs tolerance", "cg preconditioner",
+ * "gmres iteration limit", "gmres rel tolerance", "gmres abs tolerance", "gmres preconditioner",
+ * "gmres restart iterations").  rinfo[0] = residual norm, rinfo[1] = ||b|| (GMRES: rtol*||b||), rinfo[30] =
+ * iterations.  The direct interface keeps every iterate in HBM; see DESIGN.md 5.8 for the RCI workspaces. */
+typedef struct _aoclsparse_itsol_handle *aoclsparse_itsol_handle;
+typedef enum aoclsparse_itsol_rci_job_ /* :115-133 */
+{
+    aoclsparse_rci_interrupt = -1,
+    aoclsparse_rci_stop      = 0,
+    aoclsparse_rci_start,
+    aoclsparse_rci_mv,
+    aoclsparse_rci_precond,
+    aoclsparse_rci_stopping_criterion
+} aoclsparse_itsol_rci_job;
+DLL_PUBLIC void              aoclsparse_itsol_handle_prn_options(aoclsparse_itsol_handle handle);
+DLL_PUBLIC aoclsparse_status aoclsparse_itsol_option_set(aoclsparse_itsol_handle handle, const char *option,
+                                                         const char *value);
+DLL_PUBLIC aoclsparse_status aoclsparse_itsol_d_init(aoclsparse_itsol_handle *handle);
+DLL_PUBLIC aoclsparse_status aoclsparse_itsol_s_init(aoclsparse_itsol_handle *handle);
+DLL_PUBLIC void              aoclsparse_itsol_destroy(aoclsparse_itsol_handle *handle);
+DLL_PUBLIC aoclsparse_status aoclsparse_itsol_d_rci_input(aoclsparse_itsol_handle handle, aoclsparse_int n,
+                                                          const double *b);
+DLL_PUBLIC aoclsparse_status aoclsparse_itsol_s_rci_input(aoclsparse_itsol_handle handle, aoclsparse_int n,
+                                                          const float *b);
+DLL_PUBLIC aoclsparse_status aoclsparse_itsol_d_rci_solve(aoclsparse_itsol_handle   handle,
+                                                          aoclsparse_itsol_rci_job *ircomm, double **u,
+                                                          double **v, double *x, double rinfo[100]);
+DLL_PUBLIC aoclsparse_status aoclsparse_itsol_s_rci_solve(aoclsparse_itsol_handle   handle,
+                                                          aoclsparse_itsol_rci_job *ircomm, float **u, float **v,
+                                                          float *x, float rinfo[100]);
+DLL_PUBLIC aoclsparse_status aoclsparse_itsol_d_solve(
+    aoclsparse_itsol_handle handle, aoclsparse_int n, aoclsparse_matrix mat, const aoclsparse_mat_descr descr,
+    const double *b, double *x, double rinfo[100],
+    aoclsparse_int precond(aoclsparse_int flag, aoclsparse_int n, const double *u, double *v, void *udata),
+    aoclsparse_int monit(aoclsparse_int n, const double *x, const double *r, double rinfo[100], void *udata),
+    void *udata);
+DLL_PUBLIC aoclsparse_status aoclsparse_itsol_s_solve(
+    aoclsparse_itsol_handle handle, aoclsparse_int n, aoclsparse_matrix mat, const aoclsparse_mat_descr descr,
+    const float *b, float *x, float rinfo[100],
+    aoclsparse_int precond(aoclsparse_int flag, aoclsparse_int n, const float *u, float *v, void *udata),
+    aoclsparse_int monit(aoclsparse_int n, const float *x, const float *r, float rinfo[100], void *udata),
+    void *udata);
+
 /* C = alpha*op(A)*B + beta*C, dense B/C in the stated order; alpha, beta BY VALUE (:2487-2511). */
 DLL_PUBLIC aoclsparse_status aoclsparse_scsrmm(aoclsparse_operation       op,
                                                const float                alpha,

@@ -281,6 +281,24 @@ def dellthybmv(base, alpha, m, ell_val, ell_col, width, ell_m, csr_val, csr_row,
     return st, y
 
 
+def dcg(n, base, ptr, col, val, idiag, iurow, b, x0, rtol, atol, maxit, precond):
+    """CG on a clean CSR holding the whole symmetric matrix; precond 0 none / 3 SymGS -> (status, x, rinfo)."""
+    ptr, col, val, idiag, iurow, b = _i32(ptr), _i32(col), _f64(val), _i32(idiag), _i32(iurow), _f64(b)
+    x, rinfo = _f64(x0).copy(), np.zeros(100)
+    st = lib().orc_dcg(c_i32(n), c_int(base), _p(ptr), _p(col), _p(val), _p(idiag), _p(iurow), _p(b), _p(x),
+                       c_dbl(rtol), c_dbl(atol), c_i32(maxit), c_int(precond), _p(rinfo))
+    return st, x, rinfo
+
+
+def dgmres(n, base, ptr, col, val, b, x0, restart, rtol, atol, maxit, precond):
+    """restarted GMRES; precond 0 none / 2 ILU0 -> (status, x, rinfo)."""
+    ptr, col, val, b = _i32(ptr), _i32(col), _f64(val), _f64(b)
+    x, rinfo = _f64(x0).copy(), np.zeros(100)
+    st = lib().orc_dgmres(c_i32(n), c_int(base), _p(ptr), _p(col), _p(val), _p(b), _p(x), c_i32(restart), c_dbl(rtol),
+                          c_dbl(atol), c_i32(maxit), c_int(precond), _p(rinfo))
+    return st, x, rinfo
+
+
 def dcsr2m(m, n, base_a, ptr_a, ind_a, val_a, base_b, ptr_b, ind_b, val_b):
     """C = A*B (general CSR x CSR); C is 0-based, columns in first-touch order."""
     ptr_a, ind_a, val_a = _i32(ptr_a), _i32(ind_a), _f64(val_a)

@@ -1168,6 +1168,245 @@ int orc_dcsr2ellthyb(oint m, int base, oint *ell_m, const oint *row_ptr, const o
 }
 
 /* ------------------------------------------------------------------------------------ */
+/* Iterative solvers, solvers/aoclsparse_itsol_functions.hpp: CG :632-875 (+ the built-in */
+/* SymGS preconditioner :390-479), restarted GMRES :910-1367 (+ ILU(0) preconditioner).   */
+/* The reference's level-1 steps are AOCL-BLAS calls (not vendored): plain loops here.    */
+/* A is a general clean CSR holding the whole (for CG: symmetric) matrix.                 */
+/* precond: CG 0 none / 3 SymGS; GMRES 0 none / 2 ILU0.  Returns the reference's status;   */
+/* rinfo[0] residual norm, rinfo[1] ||b|| (GMRES: rtol*||b||), rinfo[30] iterations.       */
+/* ------------------------------------------------------------------------------------ */
+static double orc_nrm2(oint n, const double *v)
+{
+    double s = 0.0;
+    for(oint i = 0; i < n; i++)
+        s += v[i] * v[i];
+    return sqrt(s);
+}
+static void orc_mv(oint n, int base, const oint *ptr, const oint *col, const double *val,
+                   const double *x, double *y)
+{
+    orc_dcsrmv_ref(base, 1.0, n, val, col, ptr, x, 0.0, y);
+}
+int orc_dcg(oint n, int base, const oint *ptr, const oint *col, const double *val,
+            const oint *idiag, const oint *iurow, const double *b, double *x, double rtol,
+            double atol, oint maxit, int precond, double *rinfo)
+{
+    const double tiny = 1e-2 * 2.0 * 2.220446049250313e-16;
+    double      *w    = (double *)calloc(5 * (size_t)(n > 0 ? n : 1), sizeof(double));
+    if(!w)
+        return ORC_MEMORY_ERROR;
+    double *r = w, *z = w + n, *p = w + 2 * (size_t)n, *q = w + 3 * (size_t)n, *y = w + 4 * (size_t)n;
+    int     status = ORC_SUCCESS;
+    for(int i = 0; i < 100; i++)
+        rinfo[i] = 0.0;
+    for(oint i = 0; i < n; i++)
+        r[i] = -b[i], p[i] = x[i];
+    double bnorm = orc_nrm2(n, b), brtol = rtol * bnorm;
+    rinfo[1]     = bnorm;
+    orc_mv(n, base, ptr, col, val, p, q);
+    for(oint i = 0; i < n; i++)
+        r[i] += q[i], p[i] = 0.0;
+    double rnorm = orc_nrm2(n, r), rz = 1.0;
+    rinfo[0]     = rnorm;
+    oint niter   = 0;
+    for(;;)
+    {
+        if((0.0 < atol && rnorm <= atol) || (0.0 < rtol && rnorm <= brtol))
+            break;
+        if(maxit > 0 && niter > maxit)
+        {
+            status = 7; /* aoclsparse_status_maxit */
+            break;
+        }
+        niter++;
+        rinfo[30] = (double)niter;
+        if(precond == 3)
+        {
+            /* (L+D) y = r ; y = D y ; (U+D) z = y */
+            orc_dtrsv_l(1.0, n, base, val, col, ptr, idiag, r, 1, y, 1, 0);
+            for(oint i = 0; i < n; i++)
+                y[i] *= val[idiag[i] - base];
+            orc_dtrsv_u(1.0, n, base, val, col, ptr, iurow, y, 1, z, 1, 0);
+        }
+        else
+            for(oint i = 0; i < n; i++)
+                z[i] = r[i];
+        double rz_new = 0.0;
+        for(oint i = 0; i < n; i++)
+            rz_new += r[i] * z[i];
+        if(rz <= tiny)
+        {
+            status = ORC_NUMERICAL_ERROR;
+            break;
+        }
+        double beta = rz_new / rz;
+        rz          = rz_new;
+        for(oint i = 0; i < n; i++)
+            p[i] = beta * p[i] - z[i];
+        orc_mv(n, base, ptr, col, val, p, q);
+        double pq = 0.0;
+        for(oint i = 0; i < n; i++)
+            pq += p[i] * q[i];
+        if(pq <= tiny)
+        {
+            status = ORC_NUMERICAL_ERROR;
+            break;
+        }
+        double alpha = rz / pq;
+        for(oint i = 0; i < n; i++)
+            x[i] += alpha * p[i], r[i] += alpha * q[i];
+        rnorm    = orc_nrm2(n, r);
+        rinfo[0] = rnorm;
+    }
+    free(w);
+    return status;
+}
+
+/* LAPACK 3.10 dlartg, unscaled branch (the values met here are far from the over/underflow limits) */
+static void orc_lartg(double f, double g, double *c, double *s, double *r)
+{
+    if(g == 0.0)
+        *c = 1.0, *s = 0.0, *r = f;
+    else if(f == 0.0)
+        *c = 0.0, *s = copysign(1.0, g), *r = fabs(g);
+    else
+    {
+        double d = sqrt(f * f + g * g);
+        *c = fabs(f) / d, *r = copysign(d, f), *s = g / *r;
+    }
+}
+int orc_dgmres(oint n, int base, const oint *ptr, const oint *col, const double *val,
+               const double *b, double *x, oint m, double rtol, double atol, oint maxit,
+               int precond, double *rinfo)
+{
+    const double tiny = 1e-2 * 2.0 * 2.220446049250313e-16;
+    size_t       nn = (size_t)(n > 0 ? n : 1), mm = (size_t)m;
+    double      *V = (double *)calloc((mm + 1) * nn, sizeof(double)), *Z = (double *)calloc((mm + 1) * nn, sizeof(double));
+    double      *h = (double *)calloc(mm * mm, sizeof(double)), *g = (double *)calloc(mm + 1, sizeof(double));
+    double      *c = (double *)calloc(mm, sizeof(double)), *s = (double *)calloc(mm, sizeof(double));
+    double      *lu = NULL;
+    oint        *ludiag = NULL;
+    int          status = ORC_SUCCESS;
+    if(!V || !Z || !h || !g || !c || !s)
+    {
+        status = ORC_MEMORY_ERROR;
+        goto done;
+    }
+    if(precond == 2)
+    {
+        oint nnz = ptr[n] - base;
+        lu       = (double *)malloc(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1));
+        ludiag   = (oint *)malloc(sizeof(oint) * nn);
+        if(!lu || !ludiag)
+        {
+            status = ORC_MEMORY_ERROR;
+            goto done;
+        }
+        memcpy(lu, val, sizeof(double) * (size_t)nnz);
+        status = orc_dilu0(n, base, ludiag, lu, ptr, col);
+        if(status != ORC_SUCCESS)
+            goto done;
+    }
+    oint niter = 0;
+    for(;;) /* one restart cycle per pass */
+    {
+        orc_mv(n, base, ptr, col, val, x, V);
+        double bnorm = orc_nrm2(n, b), brtol = rtol * bnorm;
+        rinfo[1]     = brtol;
+        if(fabs(atol) <= tiny && fabs(brtol) <= tiny)
+        {
+            status = 5; /* invalid_value */
+            goto done;
+        }
+        for(oint i = 0; i < n; i++)
+            V[i] = b[i] - V[i];
+        double rnorm = orc_nrm2(n, V);
+        g[0] = rnorm, rinfo[0] = rnorm;
+        if((0.0 < rnorm && (rnorm <= atol || rnorm <= brtol)) || rnorm == 0.0)
+        {
+            rinfo[30] = (double)niter;
+            goto done;
+        }
+        for(oint i = 0; i < n; i++)
+            V[i] *= 1.0 / rnorm;
+        oint j = 0;
+        for(; j < m; j++)
+        {
+            double *vj = V + (size_t)j * nn, *w = V + (size_t)(j + 1) * nn, *zj = Z + (size_t)j * nn;
+            if(precond == 2)
+                orc_dilu_solve(n, base, ludiag, lu, ptr, col, zj, vj);
+            orc_mv(n, base, ptr, col, val, precond ? zj : vj, w);
+            for(oint i = 0; i <= j; i++)
+            {
+                double d = 0.0;
+                for(oint k = 0; k < n; k++)
+                    d += w[k] * V[(size_t)i * nn + k];
+                h[(size_t)i * mm + j] = d;
+            }
+            for(oint k = 0; k < n; k++)
+            {
+                double hv = 0.0;
+                for(oint i = 0; i <= j; i++)
+                    hv += h[(size_t)i * mm + j] * V[(size_t)i * nn + k];
+                w[k] -= hv;
+            }
+            double hh = orc_nrm2(n, w);
+            if(hh < atol || hh < brtol)
+            {
+                niter += j + 1;
+                rinfo[30] = (double)niter, rinfo[0] = hh;
+                goto done;
+            }
+            for(oint k = 0; k < n; k++)
+                w[k] *= 1.0 / hh;
+            for(oint i = 0; i < j; i++)
+            {
+                double r1 = h[(size_t)i * mm + j], r2 = h[(size_t)(i + 1) * mm + j];
+                h[(size_t)i * mm + j]       = c[i] * r1 - s[i] * r2;
+                h[(size_t)(i + 1) * mm + j] = s[i] * r1 + c[i] * r2;
+            }
+            double rr = h[(size_t)j * mm + j];
+            orc_lartg(rr, -hh, &c[j], &s[j], &h[(size_t)j * mm + j]);
+            double g0 = g[j];
+            g[j] = c[j] * g0, g[j + 1] = s[j] * g0;
+            rinfo[0] = fabs(g[j]);
+        }
+        for(oint jj = m - 1; jj >= 0; jj--)
+        {
+            double yj = g[jj];
+            for(oint i = jj + 1; i < m; i++)
+                yj -= h[(size_t)jj * mm + i] * s[i];
+            if(fabs(h[(size_t)jj * mm + jj]) <= tiny)
+            {
+                status = ORC_NUMERICAL_ERROR;
+                goto done;
+            }
+            s[jj] = yj / h[(size_t)jj * mm + jj];
+        }
+        for(oint k = 0; k < n; k++)
+        {
+            double acc = 0.0;
+            for(oint t = 0; t < m; t++)
+                acc += (precond ? Z : V)[(size_t)t * nn + k] * s[t];
+            x[k] += acc;
+        }
+        rnorm = fabs(g[m]);
+        niter += m;
+        rinfo[30] = (double)niter, rinfo[0] = rnorm;
+        if((0.0 < atol && rnorm <= atol) || (0.0 < rnorm && rnorm <= brtol))
+            goto done;
+        if(maxit > 0 && niter >= maxit)
+        {
+            status = 7;
+            goto done;
+        }
+    }
+done:
+    free(V), free(Z), free(h), free(g), free(c), free(s), free(lu), free(ludiag);
+    return status;
+}
+
+/* ------------------------------------------------------------------------------------ */
 /* sp2m = two-stage Gustavson, csr2m.cpp:46-302 (count) and :310-543 (finalize).         */
 /* ------------------------------------------------------------------------------------ */
 int orc_csr2m_nnz(oint m, oint n, int base_a, const oint *ptr_a, const oint *ind_a,

@@ -180,6 +180,14 @@ int orc_dcsr2ell(int layout, oint m, int base, const oint *row_ptr, const oint *
 int orc_dcsr2ellthyb(oint m, int base, oint *ell_m, const oint *row_ptr, const oint *col_ind,
                      const double *val, oint *map, oint *ell_col, double *ell_val, oint width);
 
+/* ---- iterative solvers, solvers/aoclsparse_itsol_functions.hpp:632-1367 (level-1 steps as plain loops) */
+int orc_dcg(oint n, int base, const oint *ptr, const oint *col, const double *val,
+            const oint *idiag, const oint *iurow, const double *b, double *x, double rtol,
+            double atol, oint maxit, int precond, double *rinfo);
+int orc_dgmres(oint n, int base, const oint *ptr, const oint *col, const double *val,
+               const double *b, double *x, oint m, double rtol, double atol, oint maxit,
+               int precond, double *rinfo);
+
 /* ---- sp2m (C = A*B, both general CSR), level3/aoclsparse_csr2m.cpp:46-543 ------------ */
 /* stage 1: row_ptr_C (0-based, length m+1).  Returns nnz_C in *nnz_c. */
 int orc_csr2m_nnz(oint m, oint n, int base_a, const oint *ptr_a, const oint *ind_a,

@@ -308,6 +308,23 @@ symgs.append(dict(name="GS_NONSYM_S4", src="tests/unit_tests/common_data_utils.h
                               t=[6, -367.16666666666669, -410.33333333333337, 280.83333333333326])))
 out["symgs"] = symgs
 
+# iterative solvers: tests/examples/sample_itsol_d_cg.cpp:62-98 (8x8 SPD, lower triangle stored, x0 = 1, "CG Abs
+# Tolerance" 5e-6, "CG Preconditioner" SGS, b = A * expected) and tests/examples/sample_itsol_d_gmres.cpp:100-116
+# (cage4, 9x9 unsymmetric)
+out["itsol"] = dict(
+    cg=dict(src="tests/examples/sample_itsol_d_cg.cpp:62-98", n=8, row_ptr=[0, 1, 2, 5, 6, 8, 11, 15, 18],
+            col_ind=[0, 1, 0, 1, 2, 3, 1, 4, 0, 4, 5, 0, 3, 4, 6, 2, 5, 7],
+            val=[19, 10, 1, 8, 11, 13, 2, 11, 2, 1, 9, 7, 9, 5, 12, 5, 5, 9], x0=[1.0] * 8,
+            expected=[1.0, 0.0, 1.0, 0.0, 1.0, 0.0, 1.0, 0.0], abs_tol=5.0e-6, precond="SGS"),
+    gmres=dict(src="tests/examples/sample_itsol_d_gmres.cpp:100-116", n=9,
+               row_ptr=[0, 5, 10, 15, 20, 26, 32, 38, 44, 49],
+               col_ind=[0, 1, 3, 4, 7, 0, 1, 2, 4, 5, 1, 2, 3, 5, 6, 0, 2, 3, 6, 7, 0, 1, 4, 5, 6,
+                        8, 1, 2, 4, 5, 7, 8, 2, 3, 4, 6, 7, 8, 0, 3, 5, 6, 7, 8, 4, 5, 6, 7, 8],
+               val=[0.75, 0.14, 0.11, 0.14, 0.11, 0.08, 0.69, 0.11, 0.08, 0.11, 0.09, 0.67, 0.08,
+                    0.09, 0.08, 0.09, 0.14, 0.73, 0.14, 0.09, 0.04, 0.04, 0.54, 0.14, 0.11, 0.25,
+                    0.05, 0.05, 0.08, 0.45, 0.08, 0.15, 0.04, 0.04, 0.09, 0.47, 0.09, 0.18, 0.05,
+                    0.05, 0.14, 0.11, 0.55, 0.25, 0.08, 0.08, 0.09, 0.08, 0.17]))
+
 # ELL: tests/unit_tests/ellmv_tests.cpp:151-252 (3x3, one-based CSR converted with csr2ell, and the same
 # matrix given directly as one-based ELL with -1 padding)
 out["ell"] = [dict(name="M3_base1", src="tests/unit_tests/ellmv_tests.cpp:151-252", base=1, m=3, n=3,

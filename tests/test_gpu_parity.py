@@ -1176,3 +1176,205 @@ def test_sell_not_chosen_for_power_law_rows():
     rp, ci, v = random_csr(68, m, m, powerlaw_rows(6, 9000))
     A, d = _hinted(0, m, m, rp, ci, v)
     assert A.spmv_info().kernel == 1
+
+
+# --------------------------------------------------------------------------------------------------
+# iterative solvers
+# --------------------------------------------------------------------------------------------------
+
+def _sym_full_test(n, rp, ci, v):
+    rows = [[] for _ in range(n)]
+    for i in range(n):
+        for p in range(rp[i], rp[i + 1]):
+            rows[i].append((ci[p], v[p]))
+            if ci[p] != i:
+                rows[ci[p]].append((i, v[p]))
+    rows = [sorted(r) for r in rows]
+    frp = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    return frp, np.array([c for r in rows for c, _ in r], np.int32), np.array([a for r in rows for _, a in r], np.float64)
+
+
+def torch_from_ptr(ptr, n):
+    """float64 CUDA tensor aliasing n elements of device memory at `ptr` (RCI workspaces handed out by the library)."""
+    class _Holder:
+        pass
+    hld = _Holder()
+    hld.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+    return torch.as_tensor(hld, device="cuda")
+
+
+PRECOND_T = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_double),
+                             ctypes.POINTER(ctypes.c_double), ctypes.c_void_p)
+MONIT_T = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                           ctypes.POINTER(ctypes.c_double), ctypes.c_void_p)
+
+
+def _itsol(opts):
+    h = ctypes.c_void_p()
+    assert L.aoclsparse_itsol_d_init(ctypes.byref(h)) == 0
+    for k, v in opts.items():
+        assert L.aoclsparse_itsol_option_set(h, k.encode(), str(v).encode()) == 0, (k, v)
+    return h
+
+
+def _lower(n, rp, ci, v):
+    keep = np.concatenate([[p for p in range(rp[i], rp[i + 1]) if ci[p] <= i] for i in range(n)]).astype(np.int64)
+    lens = [np.count_nonzero(ci[rp[i]:rp[i + 1]] <= i) for i in range(n)]
+    return np.concatenate([[0], np.cumsum(lens)]).astype(np.int32), ci[keep].copy(), v[keep].copy()
+
+
+def test_itsol_cg_reference_example(kats):
+    """tests/examples/sample_itsol_d_cg.cpp: lower-stored 8x8 SPD system, SGS-preconditioned CG, host vectors."""
+    c = kats["itsol"]["cg"]
+    n = c["n"]
+    rp, ci, v = np.array(c["row_ptr"], np.int32), np.array(c["col_ind"], np.int32), np.array(c["val"], np.float64)
+    A = P.Matrix(0, n, n, rp, ci, v)
+    d = P.Descr(mtype=P.TYPE_SYMMETRIC, fill=P.FILL_LOWER)
+    xe, b = np.array(c["expected"]), np.zeros(n)
+    assert P.dmv(P.OP_NONE, 1.0, A, d, xe, 0.0, b) == 0
+    for pre in ("None", "SGS"):
+        h = _itsol({"CG Abs Tolerance": c["abs_tol"], "CG Preconditioner": pre})
+        x, rinfo = np.array(c["x0"]), np.zeros(100)
+        assert L.aoclsparse_itsol_d_solve(h, n, A.h, d.h, P._ptr(b), P._ptr(x), P._ptr(rinfo), None, None, None) == 0
+        assert np.max(np.abs(x - xe)) < 1e-5 and rinfo[0] <= c["abs_tol"] and 1 <= rinfo[30] <= 8
+        assert abs(rinfo[1] - np.linalg.norm(b)) <= 1e-12 * np.linalg.norm(b)
+        L.aoclsparse_itsol_destroy(ctypes.byref(h))
+        assert h.value is None
+
+
+@pytest.mark.parametrize("pre,code", [("None", 0), ("SymGS", 3)])
+def test_itsol_cg_laplacian_matches_restated_solver(pre, code):
+    """Same iteration count (+-1: different dot-product trees) and solution as the restated CPU solver; device
+    vectors stay in HBM for the whole solve."""
+    g = 64
+    n, rp, ci, v = laplace5(g)
+    lrp, lci, lv = _lower(n, rp, ci, v)
+    A = P.Matrix(0, n, n, lrp, lci, lv)
+    d = P.Descr(mtype=P.TYPE_SYMMETRIC, fill=P.FILL_LOWER)
+    rng = np.random.default_rng(71)
+    xe = rng.uniform(-1, 1, n)
+    so, b = oracle.dcsrmv(0, 0, 1.0, n, len(v), v, ci, rp, xe, 0.0, np.zeros(n))
+    o = oracle.dcsr_optimize(n, n, len(v), 0, rp, ci, v)
+    st, xo, ro = oracle.dcg(n, 0, o["ptr"], o["ind"], o["val"], o["idiag"], o["iurow"], b, np.zeros(n), 1e-9, 0.0, 500, code)
+    assert st == 0
+    h = _itsol({"CG Rel Tolerance": 1e-9, "CG Abs Tolerance": 0.0, "CG Preconditioner": pre, "CG Iteration Limit": 500})
+    xd, bd, rinfo = dev(np.zeros(n)), dev(b), np.zeros(100)
+    assert L.aoclsparse_itsol_d_solve(h, n, A.h, d.h, P._ptr(bd), P._ptr(xd), P._ptr(rinfo), None, None, None) == 0
+    x = xd.cpu().numpy()
+    assert abs(rinfo[30] - ro[30]) <= 1, (rinfo[30], ro[30])
+    assert np.max(np.abs(x - xe)) < 1e-6 and np.max(np.abs(x - xo)) < 1e-6
+    assert rinfo[0] <= 1e-9 * np.linalg.norm(b)
+    L.aoclsparse_itsol_destroy(ctypes.byref(h))
+
+
+def test_itsol_gmres_ilu0_and_plain():
+    """Unsymmetric, diagonally dominant system: restarted GMRES with and without the ILU(0) preconditioner against
+    the restated solver (iterations counted per completed restart cycle, as the reference does)."""
+    g = 40
+    n, rp, ci, v = laplace5(g)
+    v = v.copy()
+    rng = np.random.default_rng(72)
+    v[v < 0] = rng.uniform(-1.0, -0.3, np.count_nonzero(v < 0))
+    xe = rng.uniform(-1, 1, n)
+    so, b = oracle.dcsrmv(0, 0, 1.0, n, len(v), v, ci, rp, xe, 0.0, np.zeros(n))
+    A = P.Matrix(0, n, n, rp, ci, v)
+    d = P.Descr()
+    for pre, code in (("None", 0), ("ILU0", 2)):
+        st, xo, ro = oracle.dgmres(n, 0, rp, ci, v, b, np.ones(n), 20, 1e-10, 1e-12, 400, code)
+        h = _itsol({"iterative method": "GMRES", "gmres preconditioner": pre, "gmres restart iterations": 20,
+                    "gmres rel tolerance": 1e-10, "gmres abs tolerance": 1e-12, "gmres iteration limit": 400})
+        x, rinfo = np.ones(n), np.zeros(100)
+        sg = L.aoclsparse_itsol_d_solve(h, n, A.h, d.h, P._ptr(b), P._ptr(x), P._ptr(rinfo), None, None, None)
+        assert sg == st == 0, (pre, sg, st, rinfo[0], rinfo[30])
+        assert abs(rinfo[30] - ro[30]) <= 20 and np.max(np.abs(x - xe)) < 1e-7, (pre, rinfo[30], ro[30])
+        L.aoclsparse_itsol_destroy(ctypes.byref(h))
+
+
+def test_itsol_callbacks_limits_and_errors(kats):
+    c = kats["itsol"]["cg"]
+    n = c["n"]
+    rp, ci, v = np.array(c["row_ptr"], np.int32), np.array(c["col_ind"], np.int32), np.array(c["val"], np.float64)
+    A = P.Matrix(0, n, n, rp, ci, v)
+    d = P.Descr(mtype=P.TYPE_SYMMETRIC, fill=P.FILL_LOWER)
+    xe, b = np.array(c["expected"]), np.zeros(n)
+    assert P.dmv(P.OP_NONE, 1.0, A, d, xe, 0.0, b) == 0
+    diag = np.array([19, 10, 11, 13, 11, 9, 12, 9], np.float64)
+    calls = {"p": 0, "m": 0}
+
+    def jacobi(flag, nn, u, w, udata):
+        calls["p"] += 1
+        for i in range(nn):
+            w[i] = u[i] / diag[i]
+        return 0
+
+    def monit(nn, x, r, rinfo, udata):
+        calls["m"] += 1
+        assert abs(np.linalg.norm([r[i] for i in range(nn)]) - rinfo[0]) <= 1e-10 * max(1.0, rinfo[0])
+        return 0
+
+    h = _itsol({"CG Preconditioner": "User", "CG Abs Tolerance": 1e-9})
+    x, rinfo = np.ones(n), np.zeros(100)
+    pc, mc = PRECOND_T(jacobi), MONIT_T(monit)
+    assert L.aoclsparse_itsol_d_solve(h, n, A.h, d.h, P._ptr(b), P._ptr(x), P._ptr(rinfo), pc, mc, None) == 0
+    assert np.max(np.abs(x - xe)) < 1e-7 and calls["p"] == rinfo[30] and calls["m"] >= rinfo[30]
+    # user stop from the monitor (status 8), missing user preconditioner (2), iteration limit (7)
+    stop = MONIT_T(lambda nn, x, r, ri, u: 1 if ri[30] > 1 else 0)
+    x = np.ones(n)
+    assert L.aoclsparse_itsol_d_solve(h, n, A.h, d.h, P._ptr(b), P._ptr(x), P._ptr(rinfo), pc, stop, None) == 8
+    assert L.aoclsparse_itsol_d_solve(h, n, A.h, d.h, P._ptr(b), P._ptr(x), P._ptr(rinfo), None, None, None) == 2
+    L.aoclsparse_itsol_destroy(ctypes.byref(h))
+    h = _itsol({"CG Iteration Limit": 2, "CG Abs Tolerance": 1e-14, "CG Rel Tolerance": 0.0})
+    x = np.ones(n)
+    assert L.aoclsparse_itsol_d_solve(h, n, A.h, d.h, P._ptr(b), P._ptr(x), P._ptr(rinfo), None, None, None) == 7
+    assert rinfo[30] == 3  # the reference stops once niter > maxit
+    assert L.aoclsparse_itsol_d_solve(h, n, A.h, P.Descr().h, P._ptr(b), P._ptr(x), P._ptr(rinfo), None, None, None) == 5
+    assert L.aoclsparse_itsol_d_solve(h, n + 1, A.h, d.h, P._ptr(np.zeros(n + 1)), P._ptr(np.zeros(n + 1)), P._ptr(rinfo), None,
+                                      None, None) == 3
+    assert L.aoclsparse_itsol_s_solve(h, n, A.h, d.h, P._ptr(b), P._ptr(x), P._ptr(rinfo), None, None, None) == 9
+    L.aoclsparse_itsol_destroy(ctypes.byref(h))
+
+
+@pytest.mark.parametrize("device", [False, True])
+def test_itsol_rci_interfaces(device, kats):
+    """Reverse communication: the caller runs v = A u itself.  Host b -> pinned workspaces a host caller can read;
+    device b -> HBM workspaces and device pointers."""
+    c = kats["itsol"]["cg"]
+    n = c["n"]
+    rp, ci, v = _sym_full_test(n, c["row_ptr"], c["col_ind"], c["val"])
+    dense = np.zeros((n, n))
+    for i in range(n):
+        dense[i, ci[rp[i]:rp[i + 1]]] = v[rp[i]:rp[i + 1]]
+    xe = np.array(c["expected"])
+    b = dense @ xe
+    h = _itsol({"CG Abs Tolerance": 1e-10})
+    rinfo, ircomm = np.zeros(100), ctypes.c_int(1)
+    u, w = ctypes.c_void_p(), ctypes.c_void_p()
+    if device:
+        bd, xd = dev(b), dev(np.ones(n))
+        assert L.aoclsparse_itsol_d_rci_input(h, n, P._ptr(bd)) == 0
+        xarg = P._ptr(xd)
+    else:
+        x = np.ones(n)
+        assert L.aoclsparse_itsol_d_rci_input(h, n, P._ptr(b)) == 0
+        xarg = P._ptr(x)
+    Ad = dev(dense.reshape(-1))
+    steps = 0
+    while ircomm.value != 0 and steps < 200:
+        st = L.aoclsparse_itsol_d_rci_solve(h, ctypes.byref(ircomm), ctypes.byref(u), ctypes.byref(w), xarg, P._ptr(rinfo))
+        assert st == 0
+        steps += 1
+        if ircomm.value == 2:  # aoclsparse_rci_mv
+            if device:
+                assert L.aoclsparse_mi355_synchronize() == 0
+                uu = torch_from_ptr(u.value, n)
+                ww = torch_from_ptr(w.value, n)
+                ww.copy_(Ad.view(n, n) @ uu)
+                torch.cuda.synchronize()
+            else:
+                uu = np.ctypeslib.as_array(ctypes.cast(u, ctypes.POINTER(ctypes.c_double)), (n,))
+                ww = np.ctypeslib.as_array(ctypes.cast(w, ctypes.POINTER(ctypes.c_double)), (n,))
+                ww[:] = dense @ uu
+    assert ircomm.value == 0 and steps < 200
+    xs = xd.cpu().numpy() if device else x
+    assert np.max(np.abs(xs - xe)) < 1e-8 and rinfo[0] <= 1e-10
+    L.aoclsparse_itsol_destroy(ctypes.byref(h))

@@ -359,3 +359,39 @@ def test_ell_orders_against_csr_oracle():
     assert em + len(mp) == m and np.all(lens[mp] > w) and np.count_nonzero(lens <= w) == em
     st, yh = oracle.dellthybmv(0, 1.7, m, hv, hc, w, em, v, rp, ci, mp, x, -0.3, y0)
     assert np.array_equal(yh[mp], yc[mp]) and np.allclose(yh, yr, rtol=0, atol=1e-13)
+
+
+def _sym_full(n, rp, ci, v):
+    """lower-triangle CSR -> full symmetric CSR (sorted rows)"""
+    rows = [[] for _ in range(n)]
+    for i in range(n):
+        for p in range(rp[i], rp[i + 1]):
+            rows[i].append((ci[p], v[p]))
+            if ci[p] != i:
+                rows[ci[p]].append((i, v[p]))
+    rows = [sorted(r) for r in rows]
+    frp = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    return frp, np.array([c for r in rows for c, _ in r], np.int32), np.array([a for r in rows for _, a in r], np.float64)
+
+
+def test_itsol_examples(kats):
+    """sample_itsol_d_cg.cpp: CG + SGS on the 8x8 SPD system reaches `expected` within its 5e-6 absolute tolerance;
+    restarted GMRES (+ILU0) on cage4 reaches the 0.5 vector.  Pins the restated solvers on the reference's examples."""
+    c = kats["itsol"]["cg"]
+    n = c["n"]
+    rp, ci, v = _sym_full(n, c["row_ptr"], c["col_ind"], c["val"])
+    o = oracle.dcsr_optimize(n, n, len(v), 0, rp, ci, v)
+    xe = np.array(c["expected"])
+    so, b = oracle.dcsrmv(0, 0, 1.0, n, len(v), v, ci, rp, xe, 0.0, np.zeros(n))
+    for precond in (0, 3):
+        st, x, rinfo = oracle.dcg(n, 0, o["ptr"], o["ind"], o["val"], o["idiag"], o["iurow"], b, c["x0"], 4.2e-8,
+                                  c["abs_tol"], 500, precond)
+        assert st == 0 and rinfo[0] <= c["abs_tol"] and np.max(np.abs(x - xe)) < 1e-5 and 1 <= rinfo[30] <= 8
+    g = kats["itsol"]["gmres"]
+    n = g["n"]
+    rp, ci, v = np.array(g["row_ptr"], np.int32), np.array(g["col_ind"], np.int32), np.array(g["val"])
+    xe = np.full(n, 0.5)
+    so, b = oracle.dcsrmv(0, 0, 1.0, n, len(v), v, ci, rp, xe, 0.0, np.zeros(n))
+    for precond in (0, 2):
+        st, x, rinfo = oracle.dgmres(n, 0, rp, ci, v, b, np.ones(n), 7, 4.2e-8, 1e-10, 50, precond)
+        assert st == 0 and np.max(np.abs(x - xe)) < 1e-6, (precond, st, rinfo[0], rinfo[30])

@@ -22,7 +22,7 @@ from bench import csrmm_bytes, spmv_bytes  # noqa: E402
 pkg = entry.load_package()
 L = pkg.lib()
 ap = argparse.ArgumentParser()
-ap.add_argument("--what", default="spmv,csrmm,trsv,pcie")
+ap.add_argument("--what", default="spmv,csrmm,trsv,cg,pcie")
 ap.add_argument("--small", action="store_true", help="skip the two 50-120 M nnz stand-ins")
 args = ap.parse_args()
 what = set(args.what.split(","))
@@ -137,6 +137,49 @@ if "trsv" in what:
                  gflops=round((2.0 * nnz_l + m) / ms / 1e6, 2), gbs=round(abytes / ms / 1e6, 1),
                  cpu_serial_ms=round(t_cpu * 1e3, 2), bit_exact_vs_cpu=bool(np.array_equal(xg, xr)),
                  analysis_s=round(t_opt, 2), ilu0_cpu_s=round(t_ilu, 2))
+        del A
+
+if "cg" in what:
+    # device-resident CG (aoclsparse_itsol_d_solve): every iterate stays in HBM; 3 scalar read-backs per iteration
+    import ctypes
+    import time
+    L.aoclsparse_mi355_set_pointer_mode(pkg.PTR_AUTO)
+    for g, pre in ((2048, "None"), (1024, "SymGS")):
+        m, rp, ci, v = entry.laplace5(g)
+        keep = ci <= np.repeat(np.arange(m, dtype=np.int32), np.diff(rp))
+        lrp = np.concatenate([[0], np.cumsum(np.add.reduceat(keep.astype(np.int64), rp[:-1]))]).astype(np.int32)
+        lci, lv = ci[keep].copy(), v[keep].copy()
+        A = pkg.Matrix(0, m, m, lrp, lci, lv)
+        ds = pkg.Descr(mtype=pkg.TYPE_SYMMETRIC, fill=pkg.FILL_LOWER)
+        iters = 100
+        h = ctypes.c_void_p()
+        assert L.aoclsparse_itsol_d_init(ctypes.byref(h)) == 0
+        for k, val in (("CG Iteration Limit", iters - 1), ("CG Rel Tolerance", 0.0), ("CG Abs Tolerance", 1e-300),
+                       ("CG Preconditioner", pre)):
+            assert L.aoclsparse_itsol_option_set(h, k.encode(), str(val).encode()) == 0
+        xe = np.sin(0.001 * np.arange(m))
+        so, b = oracle.dcsrmv(0, 0, 1.0, m, len(v), v, ci, rp, xe, 0.0, np.zeros(m), nthreads=oracle.max_threads())
+        bd = torch.from_numpy(b).to(dev)
+        rinfo = np.zeros(100)
+        best = 1e30
+        for rep in range(3):  # first pass pays for the analysis (symmetric expansion, level sets)
+            xd = torch.zeros(m, dtype=torch.float64, device=dev)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            st = L.aoclsparse_itsol_d_solve(h, m, A.h, ds.h, pkg._ptr(bd), pkg._ptr(xd), pkg._ptr(rinfo), None, None, None)
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        assert st == 7 and rinfo[30] == iters, (st, rinfo[30])
+        o = oracle.dcsr_optimize(m, m, len(v), 0, rp, ci, v)
+        t0 = time.perf_counter()
+        so, xo, ro = oracle.dcg(m, 0, o["ptr"], o["ind"], o["val"], o["idiag"], o["iurow"], b, np.zeros(m), 0.0, 1e-300,
+                                9, 3 if pre == "SymGS" else 0)
+        cpu_ms_per_iter = (time.perf_counter() - t0) * 1e3 / max(ro[30], 1)
+        emit(kind="cg", system="5-pt Laplacian grid %d^2 (m=%d), lower triangle stored, symmetric descriptor" % (g, m),
+             preconditioner=pre, iterations=iters, ms_per_iteration=round(best * 1e3 / iters, 4),
+             residual_after=float(rinfo[0]), cpu_serial_ms_per_iteration=round(cpu_ms_per_iter, 2),
+             note="CPU = the restated reference loop, one thread (its level-1 steps are serial loops)")
+        L.aoclsparse_itsol_destroy(ctypes.byref(h))
         del A
 
 if "pcie" in what:
