@@ -141,6 +141,10 @@ aoclsparse_status ensure_derived(aoclsparse_matrix A, aoclsparse_matrix_type typ
         st = upload_csr(d->host, val_size(A->val_type), d->dev);
         if(st == aoclsparse_status_success)
             st = build_spmv_plan(d->host.m, d->host.nnz, d->host.base, d->host.ptr, d->plan);
+        // a derived operator exists because products with it were asked for: give it the SELL-64 twin too
+        // (when its padding is small); both kernels realise the same summation order on the derived rows
+        if(st == aoclsparse_status_success && A->mem_policy == aoclsparse_memory_usage_unrestricted)
+            st = build_sell(d->host.ptr, d->dev, val_size(A->val_type), d->plan);
         if(st != aoclsparse_status_success)
             return st;
         out = d.get();

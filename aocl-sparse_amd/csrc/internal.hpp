@@ -122,6 +122,7 @@ struct DeviceCsr
 struct SellPlan
 {
     aoclsparse_int nslices = 0;
+    int            pack    = 1; // 1: cell (p, lane) at 64 p + lane; 4: at 256 (p/4) + 4 lane + p%4
     long long      cells   = 0; // stored cells = sum over slices of 64 * (longest row of the slice)
     DeviceBuffer   slice_ptr; // nslices+1 cell offsets (long long)
     DeviceBuffer   val, col; // cells values / 0-based columns (-1 = padding)
@@ -355,11 +356,11 @@ aoclsparse_status launch_csrmv(hipStream_t s, int order, bool strict, int tile, 
                                const aoclsparse_int *row_ptr, const aoclsparse_int *blocks,
                                aoclsparse_int nblocks, const T *x, T beta, T *y);
 template <typename T>
-aoclsparse_status launch_sell_fill(hipStream_t s, aoclsparse_int m, int base, const aoclsparse_int *row_ptr,
+aoclsparse_status launch_sell_fill(hipStream_t s, int pack, aoclsparse_int m, int base, const aoclsparse_int *row_ptr,
                                    const aoclsparse_int *col, const T *val, aoclsparse_int nslices,
                                    const long long *slice_ptr, T *sval, aoclsparse_int *scol, aoclsparse_int *rowlen);
 template <typename T>
-aoclsparse_status launch_sellmv(hipStream_t s, int order, T alpha, aoclsparse_int m, aoclsparse_int nslices,
+aoclsparse_status launch_sellmv(hipStream_t s, int order, int pack, T alpha, aoclsparse_int m, aoclsparse_int nslices,
                                 const long long *slice_ptr, const T *sval, const aoclsparse_int *scol,
                                 const aoclsparse_int *rowlen, const T *x, T beta, T *y);
 template <typename T>

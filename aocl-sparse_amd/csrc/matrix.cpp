@@ -474,12 +474,20 @@ aoclsparse_status build_sell(const aoclsparse_int *row_ptr_host, const DeviceCsr
     {
         return aoclsparse_status_memory_error;
     }
+    // PACK 4 (four consecutive cells of a row adjacent, width rounded up to a multiple of 4) for long rows:
+    // contiguous 2 KB wavefront loads; PACK 1 otherwise (a 5-wide slice must not be padded to 8)
+    static const int pack_env = [] {
+        const char *e = getenv("AOCLSPARSE_MI355_SELL_PACK");
+        return e ? atoi(e) : 0;
+    }();
+    const int pack = pack_env == 1 || pack_env == 4 ? pack_env : ((long long)d.nnz >= 16LL * m ? 4 : 1);
     sptr[0] = 0;
     for(aoclsparse_int s = 0; s < nslices; s++)
     {
         aoclsparse_int w = 0;
         for(aoclsparse_int i = s * 64; i < std::min<aoclsparse_int>(m, s * 64 + 64); i++)
             w = std::max(w, row_ptr_host[i + 1] - row_ptr_host[i]);
+        w           = (w + pack - 1) / pack * pack;
         sptr[s + 1] = sptr[s] + 64LL * w;
     }
     const long long cells = sptr[nslices];
@@ -498,17 +506,17 @@ aoclsparse_status build_sell(const aoclsparse_int *row_ptr_host, const DeviceCsr
     if(st != aoclsparse_status_success)
         return st;
     if(vsize == sizeof(float))
-        st = launch_sell_fill<float>(rt.stream(), m, d.base, d.ptr.as<aoclsparse_int>(), d.ind.as<aoclsparse_int>(),
+        st = launch_sell_fill<float>(rt.stream(), pack, m, d.base, d.ptr.as<aoclsparse_int>(), d.ind.as<aoclsparse_int>(),
                                      d.val.as<float>(), nslices, sp.slice_ptr.as<long long>(), sp.val.as<float>(),
                                      sp.col.as<aoclsparse_int>(), sp.rowlen.as<aoclsparse_int>());
     else
-        st = launch_sell_fill<double>(rt.stream(), m, d.base, d.ptr.as<aoclsparse_int>(), d.ind.as<aoclsparse_int>(),
+        st = launch_sell_fill<double>(rt.stream(), pack, m, d.base, d.ptr.as<aoclsparse_int>(), d.ind.as<aoclsparse_int>(),
                                       d.val.as<double>(), nslices, sp.slice_ptr.as<long long>(), sp.val.as<double>(),
                                       sp.col.as<aoclsparse_int>(), sp.rowlen.as<aoclsparse_int>());
     if(st != aoclsparse_status_success)
         return st;
     MI355_HIP_TRY(hipStreamSynchronize(rt.stream())); // sptr (host) is read by the upload until here
-    sp.nslices = nslices, sp.cells = cells, sp.valid = sp.wanted = true;
+    sp.nslices = nslices, sp.cells = cells, sp.pack = pack, sp.valid = sp.wanted = true;
     return aoclsparse_status_success;
 }
 

@@ -3,8 +3,11 @@
 // The reference's optimize step re-stores a hinted matrix in the format its CPU kernels like best
 // (br4 / ELLT-HYB / blocked CSR, analysis.cpp:146-382).  The GPU analogue is sliced ELL with one slice
 // per 64-wide wavefront: slice s holds rows [64 s, 64 s + 64) column-major, cell (p, lane) at
-// slice_ptr[s] + 64 p + lane, padded to the slice's longest row (column -1, value 0).  Lane i of a wave
-// owns row i:
+// slice_ptr[s] + 64 p + lane, padded to the slice's longest row (column -1, value 0); matrices with >= 16
+// non-zeros per row keep four consecutive cells of a row adjacent instead (PACK 4: cell at
+// slice_ptr[s] + 256 (p/4) + 4 lane + p%4, width rounded up to a multiple of 4), so that a wavefront's load is
+// one contiguous 2 KB piece -- the in-flight slices of a long-row matrix are otherwise 512-byte accesses
+// strided by the slice size, which costs HBM page locality.  Lane i of a wave owns row i:
 //   * every val / col access is one coalesced line per wavefront instruction, no row_ptr, no LDS;
 //   * a lane walks its row front to back, so the reference's summation orders are reproduced exactly:
 //     order 0 is the scalar FMA chain (csrmv_kr.hpp:448-513); orders 1 / 2 keep 4 / 8 partial sums per
@@ -62,7 +65,15 @@ __device__ __forceinline__ T lanes_sum(const T (&l)[G])
         return ((l[0] + l[4]) + (l[2] + l[6])) + ((l[1] + l[5]) + (l[3] + l[7])); // csrmv_kr.hpp:788-806
 }
 
-template <typename T>
+// cell (p, lane) of a slice that starts at o0: PACK 1 -> o0 + 64 p + lane; PACK 4 -> four consecutive cells of a
+// row are adjacent: o0 + 256 (p / 4) + 4 lane + p % 4 (slice width is a multiple of 4 there)
+template <int PACK>
+__device__ __forceinline__ long long cell_of(int p, int lane)
+{
+    return PACK == 1 ? (long long)p * 64 + lane : (long long)(p >> 2) * 256 + lane * 4 + (p & 3);
+}
+
+template <typename T, int PACK>
 __global__ __launch_bounds__(256) void sell_fill_kernel(aoclsparse_int m, int base,
                                                         const aoclsparse_int *__restrict__ row_ptr,
                                                         const aoclsparse_int *__restrict__ col,
@@ -87,15 +98,66 @@ __global__ __launch_bounds__(256) void sell_fill_kernel(aoclsparse_int m, int ba
     }
     for(int p = 0; p < w; p++)
     {
-        const long long o = o0 + (long long)p * 64 + lane;
+        const long long o  = o0 + cell_of<PACK>(p, lane);
         const bool      in = p < len;
         sval[o]            = in ? val[b + p] : T(0);
         scol[o]            = in ? col[b + p] - base : -1;
     }
 }
 
+// four adjacent cells of one lane as vector loads (PACK 4): 32 B of values (16 B for float), 16 B of columns
+__device__ __forceinline__ void load4(const double *p, double (&o)[4])
+{
+    const double2 a = *reinterpret_cast<const double2 *>(p), b = *reinterpret_cast<const double2 *>(p + 2);
+    o[0] = a.x, o[1] = a.y, o[2] = b.x, o[3] = b.y;
+}
+__device__ __forceinline__ void load4(const float *p, float (&o)[4])
+{
+    const float4 a = *reinterpret_cast<const float4 *>(p);
+    o[0] = a.x, o[1] = a.y, o[2] = a.z, o[3] = a.w;
+}
+__device__ __forceinline__ void load4(const aoclsparse_int *p, int (&o)[4])
+{
+    const int4 a = *reinterpret_cast<const int4 *>(p);
+    o[0] = a.x, o[1] = a.y, o[2] = a.z, o[3] = a.w;
+}
+
+// loads the G cells p0 .. p0+G-1 of this lane (wave-uniform guards against the slice width w)
+template <typename T, int PACK, int G>
+__device__ __forceinline__ void load_step(const T *v, const aoclsparse_int *c, int p0, int w, T (&vv)[G], int (&cc)[G])
+{
+    if constexpr(PACK == 1)
+    {
+#pragma unroll
+        for(int q = 0; q < G; q++)
+        {
+            const bool ok = p0 + q < w;
+            vv[q]         = ok ? v[(p0 + q) * 64] : T(0);
+            cc[q]         = ok ? c[(p0 + q) * 64] : -1;
+        }
+    }
+    else
+    {
+#pragma unroll
+        for(int k = 0; k < G / 4; k++)
+        {
+            T   tv[4] = {T(0), T(0), T(0), T(0)};
+            int tc[4] = {-1, -1, -1, -1};
+            if(p0 + 4 * k < w) // w is a multiple of 4: the pack is whole or absent
+            {
+                const long long o = (long long)((p0 >> 2) + k) * 256;
+                load4(v + o, tv);
+                load4(c + o, tc);
+            }
+#pragma unroll
+            for(int q = 0; q < 4; q++)
+                vv[4 * k + q] = tv[q], cc[4 * k + q] = tc[q];
+        }
+    }
+}
+
 // WAVES slices per workgroup (1 for small matrices so that every slice gets its own CU)
-template <typename T, int ORDER, int WAVES>
+template <typename T, int ORDER, int WAVES, int PACK>
 __global__ __launch_bounds__(64 * WAVES) void sell_mv_kernel(aoclsparse_int m, aoclsparse_int nslices,
                                                              const long long *__restrict__ slice_ptr,
                                                              const T *__restrict__ sval,
@@ -110,14 +172,15 @@ __global__ __launch_bounds__(64 * WAVES) void sell_mv_kernel(aoclsparse_int m, a
         return;
     const long long       o0 = slice_ptr[s];
     const int             w  = (int)((slice_ptr[s + 1] - o0) >> 6);
-    const T              *v  = sval + o0 + lane;
-    const aoclsparse_int *c  = scol + o0 + lane;
+    const T              *v  = sval + o0 + lane * PACK;
+    const aoclsparse_int *c  = scol + o0 + lane * PACK;
     const int             i  = s * 64 + lane;
     T                     r  = T(0);
-    if constexpr(ORDER == 0)
+    if constexpr(ORDER == 0 && PACK == 1)
     {
-        // four independent line loads per step, then the gathers, then the chain.  Measured on the 4096^2
-        // Laplacian (w = 5): 0.218 ms; 8-wide or wave-uniform guarded steps 0.223-0.26 ms (profiles/r1)
+        // short rows (this is the layout of matrices with < 16 non-zeros per row): four independent line loads
+        // per step, then the gathers, then the chain.  Measured on the 4096^2 Laplacian (w = 5): 0.218 ms;
+        // 8-wide, guard-predicated or software-pipelined steps 0.223-0.26 ms (profiles/r1)
         int p = 0;
         for(; p + 4 <= w; p += 4)
         {
@@ -139,29 +202,39 @@ __global__ __launch_bounds__(64 * WAVES) void sell_mv_kernel(aoclsparse_int m, a
     }
     else
     {
-        constexpr int G    = ORDER == 1 ? 4 : 8;
-        const int     len  = i < m ? rowlen[i] : 0;
+        // Steps of G cells, software-pipelined: the lines of step k+1 are issued BEFORE the x gathers of step k,
+        // so a step costs one memory round trip instead of two (vmcnt retires in order: the gathers wait for
+        // the younger-issued lines too, but everything is in flight together).
+        constexpr int G    = ORDER == 2 ? 8 : 4;
+        const int     len  = (ORDER != 0 && i < m) ? rowlen[i] : 0;
         const int     full = len & ~(G - 1);
         T             l[G];
 #pragma unroll
         for(int q = 0; q < G; q++)
             l[q] = T(0);
         bool reduced = false;
+        T    vn[G];
+        int  cn[G];
+        load_step<T, PACK, G>(v, c, 0, w, vn, cn);
         for(int p0 = 0; p0 < w; p0 += G)
         {
             T   vv[G], xx[G];
             int cc[G];
 #pragma unroll
             for(int q = 0; q < G; q++)
-            {
-                const bool ok = p0 + q < w; // wave-uniform
-                vv[q]         = ok ? v[(p0 + q) * 64] : T(0);
-                cc[q]         = ok ? c[(p0 + q) * 64] : -1;
-            }
+                vv[q] = vn[q], cc[q] = cn[q];
+            if(p0 + G < w)
+                load_step<T, PACK, G>(v, c, p0 + G, w, vn, cn);
 #pragma unroll
             for(int q = 0; q < G; q++)
                 xx[q] = x[max(cc[q], 0)];
-            if(p0 < full)
+            if constexpr(ORDER == 0)
+            {
+#pragma unroll
+                for(int q = 0; q < G; q++)
+                    r = cc[q] >= 0 ? s_fma(vv[q], xx[q], r) : r;
+            }
+            else if(p0 < full)
             {
 #pragma unroll
                 for(int q = 0; q < G; q++)
@@ -177,14 +250,14 @@ __global__ __launch_bounds__(64 * WAVES) void sell_mv_kernel(aoclsparse_int m, a
                         r = s_fma(vv[q], xx[q], r);
             }
         }
-        if(!reduced)
+        if(ORDER != 0 && !reduced)
             r = lanes_sum<T, G>(l);
     }
     if(i < m)
         s_store(y + i, s_finish(r, alpha, beta, y + i), nt);
 }
 
-template <typename T, int ORDER>
+template <typename T, int ORDER, int PACK>
 void sell_launch(hipStream_t s, aoclsparse_int m, aoclsparse_int nslices, const long long *slice_ptr, const T *sval,
                  const aoclsparse_int *scol, const aoclsparse_int *rowlen, T alpha, const T *x, T beta, T *y)
 {
@@ -192,58 +265,69 @@ void sell_launch(hipStream_t s, aoclsparse_int m, aoclsparse_int nslices, const 
     // (swept on the headline workload: 1 / 2 / 4 / 8 slices per workgroup = 0.221 / 0.218 / 0.221 / 0.222 ms)
     const bool nt = (size_t)m * sizeof(T) > ((size_t)32 << 20);
     if(nslices < 2048)
-        hipLaunchKernelGGL((sell_mv_kernel<T, ORDER, 1>), dim3(nslices), dim3(64), 0, s, m, nslices, slice_ptr, sval,
-                           scol, rowlen, alpha, x, beta, y, nt);
+        hipLaunchKernelGGL((sell_mv_kernel<T, ORDER, 1, PACK>), dim3(nslices), dim3(64), 0, s, m, nslices, slice_ptr,
+                           sval, scol, rowlen, alpha, x, beta, y, nt);
     else
-        hipLaunchKernelGGL((sell_mv_kernel<T, ORDER, 2>), dim3((nslices + 1) / 2), dim3(128), 0, s, m, nslices,
+        hipLaunchKernelGGL((sell_mv_kernel<T, ORDER, 2, PACK>), dim3((nslices + 1) / 2), dim3(128), 0, s, m, nslices,
                            slice_ptr, sval, scol, rowlen, alpha, x, beta, y, nt);
 }
 
 } // namespace
 
 template <typename T>
-aoclsparse_status launch_sell_fill(hipStream_t s, aoclsparse_int m, int base, const aoclsparse_int *row_ptr,
+aoclsparse_status launch_sell_fill(hipStream_t s, int pack, aoclsparse_int m, int base, const aoclsparse_int *row_ptr,
                                    const aoclsparse_int *col, const T *val, aoclsparse_int nslices,
                                    const long long *slice_ptr, T *sval, aoclsparse_int *scol, aoclsparse_int *rowlen)
 {
     if(nslices <= 0)
         return aoclsparse_status_success;
-    hipLaunchKernelGGL((sell_fill_kernel<T>), dim3((nslices + 3) / 4), dim3(256), 0, s, m, base, row_ptr, col, val,
-                       nslices, slice_ptr, sval, scol, rowlen);
+    if(pack == 4)
+        hipLaunchKernelGGL((sell_fill_kernel<T, 4>), dim3((nslices + 3) / 4), dim3(256), 0, s, m, base, row_ptr, col,
+                           val, nslices, slice_ptr, sval, scol, rowlen);
+    else
+        hipLaunchKernelGGL((sell_fill_kernel<T, 1>), dim3((nslices + 3) / 4), dim3(256), 0, s, m, base, row_ptr, col,
+                           val, nslices, slice_ptr, sval, scol, rowlen);
     MI355_HIP_TRY(hipGetLastError());
     return aoclsparse_status_success;
 }
 
 template <typename T>
-aoclsparse_status launch_sellmv(hipStream_t s, int order, T alpha, aoclsparse_int m, aoclsparse_int nslices,
+aoclsparse_status launch_sellmv(hipStream_t s, int order, int pack, T alpha, aoclsparse_int m, aoclsparse_int nslices,
                                 const long long *slice_ptr, const T *sval, const aoclsparse_int *scol,
                                 const aoclsparse_int *rowlen, const T *x, T beta, T *y)
 {
     if(m <= 0 || nslices <= 0)
         return aoclsparse_status_success;
-    switch(order)
+    if(order < 0 || order > 2 || (pack != 1 && pack != 4))
+        return aoclsparse_status_invalid_kid;
+#define SELL_CASE(O, P)                                                                        \
+    sell_launch<T, O, P>(s, m, nslices, slice_ptr, sval, scol, rowlen, alpha, x, beta, y);   \
+    break
+    switch(order * 2 + (pack == 4 ? 1 : 0))
     {
     case 0:
-        sell_launch<T, 0>(s, m, nslices, slice_ptr, sval, scol, rowlen, alpha, x, beta, y);
-        break;
+        SELL_CASE(0, 1);
     case 1:
-        sell_launch<T, 1>(s, m, nslices, slice_ptr, sval, scol, rowlen, alpha, x, beta, y);
-        break;
+        SELL_CASE(0, 4);
     case 2:
-        sell_launch<T, 2>(s, m, nslices, slice_ptr, sval, scol, rowlen, alpha, x, beta, y);
-        break;
-    default:
-        return aoclsparse_status_invalid_kid;
+        SELL_CASE(1, 1);
+    case 3:
+        SELL_CASE(1, 4);
+    case 4:
+        SELL_CASE(2, 1);
+    case 5:
+        SELL_CASE(2, 4);
     }
+#undef SELL_CASE
     MI355_HIP_TRY(hipGetLastError());
     return aoclsparse_status_success;
 }
 
 #define MI355_SELL_INSTANTIATE(T)                                                                                     \
-    template aoclsparse_status launch_sell_fill<T>(hipStream_t, aoclsparse_int, int, const aoclsparse_int *,          \
+    template aoclsparse_status launch_sell_fill<T>(hipStream_t, int, aoclsparse_int, int, const aoclsparse_int *,     \
                                                    const aoclsparse_int *, const T *, aoclsparse_int,                 \
                                                    const long long *, T *, aoclsparse_int *, aoclsparse_int *);       \
-    template aoclsparse_status launch_sellmv<T>(hipStream_t, int, T, aoclsparse_int, aoclsparse_int,                  \
+    template aoclsparse_status launch_sellmv<T>(hipStream_t, int, int, T, aoclsparse_int, aoclsparse_int,             \
                                                 const long long *, const T *, const aoclsparse_int *,                 \
                                                 const aoclsparse_int *, const T *, T, T *);
 MI355_SELL_INSTANTIATE(double)

@@ -110,7 +110,7 @@ aoclsparse_status run_on_device_csr(Runtime &rt, aoclsparse_int kid, const Devic
     if(st != aoclsparse_status_success)
         return st;
     if(plan.sell.valid) // format chosen by optimize for an mv hint: every order is exact there
-        st = launch_sellmv<T>(rt.stream(), order, alpha, d.m, plan.sell.nslices, plan.sell.slice_ptr.as<long long>(),
+        st = launch_sellmv<T>(rt.stream(), order, plan.sell.pack, alpha, d.m, plan.sell.nslices, plan.sell.slice_ptr.as<long long>(),
                               plan.sell.val.as<T>(), plan.sell.col.as<aoclsparse_int>(),
                               plan.sell.rowlen.as<aoclsparse_int>(), static_cast<const T *>(ax.dev), beta,
                               static_cast<T *>(ay.dev));
