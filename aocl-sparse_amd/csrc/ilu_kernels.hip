@@ -1,0 +1,123 @@
+// ilu_kernels.hip -- level-scheduled ILU(0) factorisation on the user's CSR pattern, in place in a device
+// copy of the values.  Reference: solvers/aoclsparse_ilu0.hpp:34-111 (serial IKJ).
+//
+// Row i depends on the finished rows k < i of its own pattern, so rows are processed level by level (one
+// launch per dependency level, rows of a level in parallel), one wavefront per row:
+//   * the row's columns and values sit in LDS while it is eliminated (the wavefront both updates and re-reads
+//     them; LDS operations of one wave are ordered);
+//   * the k-loop walks the row's lower entries in stored order exactly like the reference; for each of them
+//     the 64 lanes take the entries of row k's upper part and apply  a_iw = fma(-l_ik, a_kw, a_iw)  to the
+//     matching position w of row i -- distinct entries of row k hit distinct positions, and the k steps are
+//     sequential, so every a_iw sees its updates in the reference's order: results are bit-identical;
+//   * a (near-)zero pivot or a row without its diagonal right after the lower part sets the error word.
+// One-time analysis work per handle; bound by the dependency chain (levels x launch latency), not by HBM.
+#include "internal.hpp"
+
+#include <hip/hip_runtime.h>
+
+namespace mi355
+{
+
+namespace
+{
+
+template <typename T>
+__device__ __forceinline__ bool ilu_near_zero(T v)
+{
+    // aoclsparse_is_nearzero, extra/aoclsparse_utils.hpp:598-613
+    return fabs((double)v) <= 1e-2 * 2.0 * (sizeof(T) == 8 ? 2.220446049250313e-16 : 1.1920928955078125e-07);
+}
+
+__device__ __forceinline__ double ilu_fma(double a, double b, double c)
+{
+    return fma(a, b, c);
+}
+__device__ __forceinline__ float ilu_fma(float a, float b, float c)
+{
+    return fmaf(a, b, c);
+}
+
+// one wavefront (= one workgroup) per row of the level; dynamic LDS: maxlen columns + maxlen values
+template <typename T>
+__global__ __launch_bounds__(64) void ilu0_level_kernel(int base, const aoclsparse_int *__restrict__ rows,
+                                                        const aoclsparse_int *__restrict__ row_ptr,
+                                                        const aoclsparse_int *__restrict__ col, T *val,
+                                                        aoclsparse_int *__restrict__ diag, int maxlen, int *error)
+{
+    extern __shared__ unsigned char smem[];
+    T              *sv   = reinterpret_cast<T *>(smem);
+    aoclsparse_int *sc   = reinterpret_cast<aoclsparse_int *>(smem + sizeof(T) * (size_t)maxlen);
+    const int       lane = threadIdx.x;
+    const int       i    = rows[blockIdx.x];
+    const int       s = row_ptr[i] - base, len = row_ptr[i + 1] - base - s;
+    for(int t = lane; t < len; t += 64)
+        sv[t] = val[s + t], sc[t] = col[s + t] - base;
+    __syncthreads(); // single-wave workgroup: an LDS fence
+    int  t = 0, k = -1;
+    bool bad = false;
+    for(; t < len; t++) // wave-uniform loop: every lane sees the same k, dk, pivot
+    {
+        k = sc[t];
+        if(k >= i)
+            break;
+        const int dk    = diag[k]; // written by an earlier level (earlier launch)
+        const T   pivot = val[dk];
+        if(ilu_near_zero(pivot))
+        {
+            bad = true;
+            break;
+        }
+        const T   lik = sv[t] / pivot;
+        const int ke  = row_ptr[k + 1] - base;
+        for(int j0 = dk + 1; j0 < ke; j0 += 64) // upper part of row k, 64 entries per round
+        {
+            const int  jj   = j0 + lane;
+            const bool have = jj < ke;
+            const int  c    = have ? col[jj] - base : -1;
+            const T    akw  = have ? val[jj] : T(0);
+            for(int w = 0; w < len; w++) // the reference's column -> position map, as a scan of the LDS row
+                if(have && sc[w] == c)
+                    sv[w] = ilu_fma(-lik, akw, sv[w]);
+        }
+        if(lane == 0)
+            sv[t] = lik;
+        __syncthreads();
+    }
+    if(!bad && (t >= len || k != i || ilu_near_zero(sv[t])))
+        bad = true; // no diagonal right after the lower part, or a (near-)zero pivot (:95-101)
+    if(bad)
+    {
+        if(lane == 0)
+            atomicExch(error, 1);
+        return;
+    }
+    if(lane == 0)
+        diag[i] = s + t;
+    for(int w = lane; w < len; w += 64)
+        val[s + w] = sv[w];
+}
+
+} // namespace
+
+template <typename T>
+aoclsparse_status launch_ilu0_level(hipStream_t s, int base, aoclsparse_int nrows, const aoclsparse_int *rows,
+                                    const aoclsparse_int *row_ptr, const aoclsparse_int *col, T *val,
+                                    aoclsparse_int *diag, int maxlen, int *error)
+{
+    if(nrows <= 0)
+        return aoclsparse_status_success;
+    const size_t lds = (sizeof(T) + sizeof(aoclsparse_int)) * (size_t)maxlen;
+    hipLaunchKernelGGL((ilu0_level_kernel<T>), dim3(nrows), dim3(64), lds, s, base, rows, row_ptr, col, val, diag,
+                       maxlen, error);
+    MI355_HIP_TRY(hipGetLastError());
+    return aoclsparse_status_success;
+}
+
+template aoclsparse_status launch_ilu0_level<double>(hipStream_t, int, aoclsparse_int, const aoclsparse_int *,
+                                                     const aoclsparse_int *, const aoclsparse_int *, double *,
+                                                     aoclsparse_int *, int, int *);
+template aoclsparse_status launch_ilu0_level<float>(hipStream_t, int, aoclsparse_int, const aoclsparse_int *,
+                                                    const aoclsparse_int *, const aoclsparse_int *, float *,
+                                                    aoclsparse_int *, int, int *);
+
+} // namespace mi355

@@ -396,6 +396,13 @@ template <typename T>
 aoclsparse_status launch_gather_rows(hipStream_t s, aoclsparse_int n, const aoclsparse_int *map, const T *src,
                                      T *dst);
 
+// one dependency level of the in-place ILU(0) factorisation (ilu_kernels.hip): rows[0..nrows) of the level,
+// diag[] = position of each finished row's diagonal, *error set on a bad pivot / missing diagonal
+template <typename T>
+aoclsparse_status launch_ilu0_level(hipStream_t s, int base, aoclsparse_int nrows, const aoclsparse_int *rows,
+                                    const aoclsparse_int *row_ptr, const aoclsparse_int *col, T *val,
+                                    aoclsparse_int *diag, int maxlen, int *error);
+
 // dense-vector steps of the iterative solvers (itsol_kernels.hip); `partial` holds
 // vec_reduce_scratch_elems(k) elements, reduction results land in device memory
 int vec_reduce_scratch_elems(int k);

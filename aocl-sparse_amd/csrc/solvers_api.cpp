@@ -220,51 +220,72 @@ bool near_zero(T v)
     return std::fabs(v) <= T(1e-2) * T(2) * std::numeric_limits<T>::epsilon();
 }
 
-// IKJ factorisation on the user's pattern, in place in `val` (ilu0.hpp:34-111).  Host, serial: it runs
-// once per handle; the per-iteration work -- the two triangular solves -- is what runs on the GPU.
+// ILU(0) on the user's pattern (ilu0.hpp:34-111), on the GPU: dependency levels of the strictly lower
+// pattern are computed on the host (integer work), then one launch per level eliminates the level's rows in
+// place in a device copy of the values (ilu_kernels.hip); the factors come back to `host_val` for
+// *precond_csr_val and for the factor handle.  Bit-identical to the serial IKJ loop.
 template <typename T>
-aoclsparse_status ilu0_factorize(aoclsparse_int n, aoclsparse_int base, const aoclsparse_int *ptr,
-                                 const aoclsparse_int *ind, T *val)
+aoclsparse_status ilu0_factorize(aoclsparse_matrix A, T *host_val)
 {
-    std::vector<aoclsparse_int> where, diag;
+    const aoclsparse_int  n = A->n, base = A->base, nnz = A->nnz;
+    const aoclsparse_int *ptr = A->user.ptr, *ind = A->user.ind;
+    std::vector<aoclsparse_int> level, order, lptr;
+    aoclsparse_int              nlev = 0, maxlen = 0;
     try
     {
-        where.assign((size_t)n, 0);
-        diag.assign((size_t)n, 0);
+        level.assign((size_t)n, 0);
+        for(aoclsparse_int i = 0; i < n; i++)
+        {
+            aoclsparse_int lv = 0;
+            for(aoclsparse_int j = ptr[i] - base; j < ptr[i + 1] - base; j++)
+            {
+                const aoclsparse_int k = ind[j] - base;
+                if(k >= i)
+                    break; // the k-loop of the reference stops at the first column >= i (:60-92)
+                lv = std::max(lv, level[k] + 1);
+            }
+            level[i] = lv;
+            nlev     = std::max(nlev, lv + 1);
+            maxlen   = std::max(maxlen, ptr[i + 1] - ptr[i]);
+        }
+        lptr.assign((size_t)nlev + 1, 0);
+        for(aoclsparse_int i = 0; i < n; i++)
+            lptr[level[i] + 1]++;
+        for(aoclsparse_int l = 0; l < nlev; l++)
+            lptr[l + 1] += lptr[l];
+        order.resize((size_t)n);
+        std::vector<aoclsparse_int> fill(lptr.begin(), lptr.end() - 1);
+        for(aoclsparse_int i = 0; i < n; i++)
+            order[fill[level[i]]++] = i;
     }
     catch(const std::bad_alloc &)
     {
         return aoclsparse_status_memory_error;
     }
-    for(aoclsparse_int i = 0; i < n; i++)
-    {
-        const aoclsparse_int s = ptr[i] - base, e = ptr[i + 1] - base;
-        for(aoclsparse_int j = s; j < e; j++)
-            where[ind[j] - base] = j;
-        aoclsparse_int j = s, k = -1;
-        for(; j < e; j++)
-        {
-            k = ind[j] - base;
-            if(k >= i)
-                break;
-            const T pivot = val[diag[k]];
-            if(near_zero(pivot))
-                return aoclsparse_status_numerical_error;
-            val[j] = val[j] / pivot;
-            for(aoclsparse_int jj = diag[k] + 1; jj < ptr[k + 1] - base; jj++)
-            {
-                const aoclsparse_int w = where[ind[jj] - base];
-                if(w != 0) // position 0 doubles as "absent" in the reference's map (:78-82)
-                    val[w] = std::fma(-val[j], val[jj], val[w]);
-            }
-        }
-        diag[i] = j;
-        if(j >= e || k != i || near_zero(val[j]))
-            return aoclsparse_status_numerical_error;
-        for(aoclsparse_int q = s; q < e; q++)
-            where[ind[q] - base] = 0;
-    }
-    return aoclsparse_status_success;
+    if((sizeof(T) + sizeof(aoclsparse_int)) * (size_t)maxlen > 60000) // one row must fit a workgroup's LDS
+        return aoclsparse_status_not_implemented;
+
+    Runtime &rt = Runtime::get();
+    DeviceCsr *dcsr = nullptr;
+    SpmvPlan  *plan = nullptr;
+    MI355_TRY(ensure_spmv(A, false, dcsr, plan)); // the pattern (and current values) in HBM
+    DeviceBuffer dval, ddiag, drows, derr;
+    MI355_TRY(dval.alloc(sizeof(T) * (size_t)std::max<aoclsparse_int>(nnz, 1)));
+    MI355_TRY(ddiag.alloc(sizeof(aoclsparse_int) * (size_t)n));
+    MI355_TRY(derr.alloc(sizeof(int)));
+    MI355_TRY(drows.upload(order.data(), sizeof(aoclsparse_int) * (size_t)n, rt.stream()));
+    // the factor starts from the values captured by ilu_prepare (the matrix at hint/optimize time)
+    MI355_HIP_TRY(hipMemcpyAsync(dval.ptr, host_val, sizeof(T) * (size_t)nnz, hipMemcpyHostToDevice, rt.stream()));
+    MI355_HIP_TRY(hipMemsetAsync(derr.ptr, 0, sizeof(int), rt.stream()));
+    for(aoclsparse_int l = 0; l < nlev; l++)
+        MI355_TRY(launch_ilu0_level<T>(rt.stream(), base, lptr[l + 1] - lptr[l], drows.as<aoclsparse_int>() + lptr[l],
+                                       dcsr->ptr.as<aoclsparse_int>(), dcsr->ind.as<aoclsparse_int>(), dval.as<T>(),
+                                       ddiag.as<aoclsparse_int>(), (int)maxlen, derr.as<int>()));
+    int err = 0;
+    MI355_HIP_TRY(hipMemcpyAsync(&err, derr.ptr, sizeof(int), hipMemcpyDeviceToHost, rt.stream()));
+    MI355_HIP_TRY(hipMemcpyAsync(host_val, dval.ptr, sizeof(T) * (size_t)nnz, hipMemcpyDeviceToHost, rt.stream()));
+    MI355_HIP_TRY(hipStreamSynchronize(rt.stream()));
+    return err ? aoclsparse_status_numerical_error : aoclsparse_status_success;
 }
 
 template <typename T>
@@ -304,7 +325,7 @@ aoclsparse_status ilu_smoother_t(aoclsparse_operation op, aoclsparse_matrix A, c
     *precond_csr_val = nullptr;
     if(!A->ilu_factorized)
     {
-        MI355_TRY(ilu0_factorize<T>(A->n, A->base, A->user.ptr, A->user.ind, static_cast<T *>(A->ilu_val)));
+        MI355_TRY(ilu0_factorize<T>(A, static_cast<T *>(A->ilu_val)));
         // the factors as a matrix of their own: its level-scheduled TRSV plans are the smoother's solves
         MI355_TRY(create_csr(&A->ilu_factor, A->base, A->m, A->n, A->nnz, A->user.ptr, A->user.ind,
                              static_cast<T *>(A->ilu_val)));

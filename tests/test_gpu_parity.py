@@ -1378,3 +1378,40 @@ def test_itsol_rci_interfaces(device, kats):
     xs = xd.cpu().numpy() if device else x
     assert np.max(np.abs(xs - xe)) < 1e-8 and rinfo[0] <= 1e-10
     L.aoclsparse_itsol_destroy(ctypes.byref(h))
+
+
+def test_ilu_factorisation_on_gpu_long_rows_partial_sort_and_bad_pivot():
+    """The level-scheduled factorisation equals the serial IKJ loop bit for bit also for rows longer than a
+    wavefront, for partially sorted rows (L | D | U groups, unsorted inside), and reports a vanishing pivot."""
+    rng = np.random.default_rng(81)
+    n = 600
+    dense = np.zeros((n, n))
+    for i in range(n):
+        cols = np.unique(np.clip(i + rng.integers(-150, 151, 90), 0, n - 1))
+        dense[i, cols] = rng.uniform(-1, 1, len(cols))
+        dense[i, i] = 40.0 + rng.uniform(0, 1)
+    rows = []
+    for i in range(n):
+        c = np.flatnonzero(dense[i])
+        lo, up = c[c < i], c[c > i]
+        rng.shuffle(lo), rng.shuffle(up)  # partially sorted: groups in order, unsorted inside
+        rows.append(np.concatenate([lo, [i], up]))
+    rp = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    ci = np.concatenate(rows).astype(np.int32)
+    v = np.array([dense[i, c] for i, r in enumerate(rows) for c in r])
+    assert np.diff(rp).max() > 64
+    A = P.Matrix(0, n, n, rp, ci, v)
+    d = P.Descr()
+    st, lu, diag = oracle.dilu0(n, 0, rp, ci, v)
+    assert st == 0
+    pv, b, x = ctypes.c_void_p(), rng.uniform(-1, 1, n), np.zeros(n)
+    assert L.aoclsparse_dilu_smoother(P.OP_NONE, A.h, d.h, ctypes.byref(pv), None, P._ptr(x), P._ptr(b)) == 0
+    fac = np.ctypeslib.as_array(ctypes.cast(pv, ctypes.POINTER(ctypes.c_double)), (len(v),))
+    assert np.array_equal(fac, lu)
+    st, xr = oracle.dilu_solve(n, 0, diag, lu, rp, ci, b)
+    assert np.array_equal(x, xr)
+    # a pivot that cancels exactly: [[1, 1], [1, 1]] -> u_11 = 0 -> numerical_error (11)
+    rp2, ci2, v2 = np.array([0, 2, 4], np.int32), np.array([0, 1, 0, 1], np.int32), np.array([1.0, 1.0, 1.0, 1.0])
+    B = P.Matrix(0, 2, 2, rp2, ci2, v2)
+    assert L.aoclsparse_dilu_smoother(P.OP_NONE, B.h, d.h, ctypes.byref(pv), None, P._ptr(np.zeros(2)), P._ptr(np.ones(2))) == 11
+    assert oracle.dilu0(2, 0, rp2, ci2, v2)[0] != 0
