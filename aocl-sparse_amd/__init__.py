@@ -98,6 +98,18 @@ SIGNATURES = {
     "aoclsparse_dtrsm": (c_int, [c_int, c_double, _P, _P, c_int, _P, _I, _I, _P, _I]),
     "aoclsparse_strsm_kid": (c_int, [c_int, c_float, _P, _P, c_int, _P, _I, _I, _P, _I, _I]),
     "aoclsparse_dtrsm_kid": (c_int, [c_int, c_double, _P, _P, c_int, _P, _I, _I, _P, _I, _I]),
+    "aoclsparse_create_scsc": (c_int, [POINTER(_P), c_int, _I, _I, _I, _P, _P, _P]),
+    "aoclsparse_create_dcsc": (c_int, [POINTER(_P), c_int, _I, _I, _I, _P, _P, _P]),
+    "aoclsparse_create_scoo": (c_int, [POINTER(_P), c_int, _I, _I, _I, _P, _P, _P]),
+    "aoclsparse_create_dcoo": (c_int, [POINTER(_P), c_int, _I, _I, _I, _P, _P, _P]),
+    "aoclsparse_export_scsc": (c_int, [_P, POINTER(c_int), POINTER(_I), POINTER(_I), POINTER(_I), POINTER(_P), POINTER(_P), POINTER(_P)]),
+    "aoclsparse_export_dcsc": (c_int, [_P, POINTER(c_int), POINTER(_I), POINTER(_I), POINTER(_I), POINTER(_P), POINTER(_P), POINTER(_P)]),
+    "aoclsparse_export_scoo": (c_int, [_P, POINTER(c_int), POINTER(_I), POINTER(_I), POINTER(_I), POINTER(_P), POINTER(_P), POINTER(_P)]),
+    "aoclsparse_export_dcoo": (c_int, [_P, POINTER(c_int), POINTER(_I), POINTER(_I), POINTER(_I), POINTER(_P), POINTER(_P), POINTER(_P)]),
+    "aoclsparse_convert_csr": (c_int, [_P, c_int, POINTER(_P)]),
+    "aoclsparse_order_mat": (c_int, [_P]),
+    "aoclsparse_scsr2csc": (c_int, [_I, _I, _I, _P, c_int, _P, _P, _P, _P, _P, _P]),
+    "aoclsparse_dcsr2csc": (c_int, [_I, _I, _I, _P, c_int, _P, _P, _P, _P, _P, _P]),
     "aoclsparse_sellmv": (c_int, [c_int, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
     "aoclsparse_dellmv": (c_int, [c_int, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
     "aoclsparse_selltmv": (c_int, [c_int, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P]),

@@ -227,6 +227,13 @@ struct _aoclsparse_matrix
     // sp2m stage-1 state (C handles own their arrays)
     bool owns_user_arrays = false;
 
+    // other input formats (formats_api.cpp): the caller's CSC arrays of a handle created from CSC (its CSR
+    // lives in `user`, owned), or the caller's COO arrays (input_format == aoclsparse_coo_mat, no CSR)
+    aoclsparse_int *csc_ptr = nullptr, *csc_ind = nullptr;
+    void           *csc_val = nullptr;
+    aoclsparse_int *coo_row = nullptr, *coo_col = nullptr;
+    void           *coo_val = nullptr;
+
     // composite solvers (solvers_api.cpp): vector workspaces in HBM, and the ILU(0) factors
     // (solvers/aoclsparse_ilu.hpp:94-104, analysis.cpp:390-425): values on the user's pattern, kept
     // on the host for *precond_csr_val and mirrored by a factor handle whose TRSV plans do the solves
@@ -327,6 +334,13 @@ aoclsparse_status csr_indices(aoclsparse_int m, aoclsparse_index_base base,
                               aoclsparse_int **idiag, aoclsparse_int **iurow);
 // builds A->opt (clean CSR + idiag/iurow) if absent; thread-safe (double-checked)
 aoclsparse_status csr_optimize(aoclsparse_matrix A);
+// forget every copy derived from the user's arrays (clean CSR, transposes, device mirrors, SELL, TRSV plans)
+void drop_derived_state(aoclsparse_matrix A);
+// value mutation on handles created from CSC / COO arrays (formats_api.cpp): the caller's arrays are the first
+// representation there; csc_refresh_csr rebuilds the handle's CSR values from the CSC arrays
+aoclsparse_status coo_set_value(aoclsparse_matrix A, aoclsparse_int row_idx, aoclsparse_int col_idx, const void *val);
+void              csc_set_value(aoclsparse_matrix A, aoclsparse_int row_idx, aoclsparse_int col_idx, const void *val);
+aoclsparse_status csc_refresh_csr(aoclsparse_matrix A);
 // allocates the ILU(0) value array as a copy of A's values (solvers_api.cpp; analysis.cpp:390-425)
 aoclsparse_status ilu_prepare(aoclsparse_matrix A);
 // builds A->trans (host transpose of the user CSR, 0-based) if absent

@@ -789,7 +789,9 @@ aoclsparse_status aoclsparse_mi355_invalidate(aoclsparse_matrix A)
 // ---- value mutation + copy: extra/aoclsparse_auxiliary.hpp:216-270, 388-470; auxiliary.cpp:775-835 -------
 // The reference writes into the FIRST representation (the caller's arrays, which the handle aliases) and
 // deletes every derived copy.  Same here, device mirrors included: they are rebuilt lazily.
-static void drop_derived_state(aoclsparse_matrix A)
+namespace mi355
+{
+void drop_derived_state(aoclsparse_matrix A)
 {
     if(A->opt != &A->user)
     {
@@ -806,12 +808,14 @@ static void drop_derived_state(aoclsparse_matrix A)
     for(auto &p : A->trsv_plan)
         p.valid = false, p.nlevels = -1;
 }
+} // namespace mi355
 
 template <typename T>
 static aoclsparse_status set_value(aoclsparse_matrix A, aoclsparse_int row_idx, aoclsparse_int col_idx, T val,
                                    aoclsparse_matrix_data_type vt)
 {
-    if(!A || !A->user.ptr || !A->user.ind || !A->user.val)
+    const bool coo = A && A->input_format == aoclsparse_coo_mat;
+    if(!A || (coo ? (!A->coo_row || !A->coo_col || !A->coo_val) : (!A->user.ptr || !A->user.ind || !A->user.val)))
         return aoclsparse_status_invalid_pointer;
     const aoclsparse_int b = A->base;
     if(A->m + b <= row_idx || row_idx < b || A->n + b <= col_idx || col_idx < b)
@@ -819,11 +823,15 @@ static aoclsparse_status set_value(aoclsparse_matrix A, aoclsparse_int row_idx, 
     if(A->val_type != vt)
         return aoclsparse_status_wrong_type;
     std::unique_lock<std::shared_mutex> w(A->guard);
-    const aoclsparse_int                r = row_idx - b;
+    if(coo)
+        return coo_set_value(A, row_idx, col_idx, &val);
+    const aoclsparse_int r = row_idx - b;
     for(aoclsparse_int p = A->user.ptr[r] - b; p < A->user.ptr[r + 1] - b; p++)
         if(A->user.ind[p] == col_idx)
         {
             static_cast<T *>(A->user.val)[p] = val;
+            if(A->csc_ptr)
+                csc_set_value(A, row_idx, col_idx, &val);
             drop_derived_state(A);
             return aoclsparse_status_success;
         }
@@ -833,16 +841,30 @@ static aoclsparse_status set_value(aoclsparse_matrix A, aoclsparse_int row_idx, 
 template <typename T>
 static aoclsparse_status update_values(aoclsparse_matrix A, aoclsparse_int len, T *val, aoclsparse_matrix_data_type vt)
 {
-    if(!A || !val || !A->user.ptr)
+    const bool coo = A && A->input_format == aoclsparse_coo_mat;
+    if(!A || !val || (coo ? !A->coo_val : !A->user.ptr))
         return aoclsparse_status_invalid_pointer;
     if(len != A->nnz)
         return aoclsparse_status_invalid_size;
     if(A->val_type != vt)
         return aoclsparse_status_wrong_type;
-    if(!A->user.val)
+    if(!coo && !A->user.val)
         return aoclsparse_status_invalid_pointer;
     std::unique_lock<std::shared_mutex> w(A->guard);
-    std::memcpy(A->user.val, val, sizeof(T) * (size_t)len);
+    if(coo) // the values follow the order of the caller's arrays (the first representation)
+    {
+        std::memcpy(A->coo_val, val, sizeof(T) * (size_t)len);
+        return aoclsparse_status_success;
+    }
+    if(A->csc_ptr)
+    {
+        std::memcpy(A->csc_val, val, sizeof(T) * (size_t)len);
+        aoclsparse_status st = csc_refresh_csr(A);
+        if(st != aoclsparse_status_success)
+            return st;
+    }
+    else
+        std::memcpy(A->user.val, val, sizeof(T) * (size_t)len);
     drop_derived_state(A);
     return aoclsparse_status_success;
 }

@@ -156,7 +156,7 @@ aoclsparse_status mv_t(aoclsparse_operation op, const T *alpha, aoclsparse_matri
 {
     if(!alpha || !beta || !A || !descr || !x || !y)
         return aoclsparse_status_invalid_pointer;
-    if(!A->user.ptr)
+    if(A->input_format == aoclsparse_csr_mat && !A->user.ptr)
         return aoclsparse_status_invalid_pointer;
     if(descr->base != A->base)
         return aoclsparse_status_invalid_value;
@@ -169,6 +169,8 @@ aoclsparse_status mv_t(aoclsparse_operation op, const T *alpha, aoclsparse_matri
     if((descr->type == aoclsparse_matrix_type_symmetric || descr->type == aoclsparse_matrix_type_hermitian)
        && A->m != A->n)
         return aoclsparse_status_invalid_size;
+    if(A->input_format != aoclsparse_csr_mat) // mv.cpp:96-97 (COO handles: convert with aoclsparse_convert_csr)
+        return aoclsparse_status_not_implemented;
     if(op == aoclsparse_operation_conjugate_transpose)
         op = aoclsparse_operation_transpose;
     if(descr->type == aoclsparse_matrix_type_hermitian)

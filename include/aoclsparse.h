@@ -415,6 +415,53 @@ DLL_PUBLIC aoclsparse_status aoclsparse_dtrsm_kid(const aoclsparse_operation tra
                                                   double                    *X,
                                                   aoclsparse_int             ldx,
                                                   const aoclsparse_int       kid);
+/* ---- other input formats and structure conversions (aoclsparse_auxiliary.h:674-1095, aoclsparse_convert.h:494-660).
+ * A CSC handle behaves like the CSR handle of the same matrix in every executor (its CSR is built at creation);
+ * a COO handle can be exported, mutated and converted (aoclsparse_convert_csr), executors return not_implemented. */
+DLL_PUBLIC aoclsparse_status aoclsparse_create_scsc(aoclsparse_matrix *mat, aoclsparse_index_base base,
+                                                    aoclsparse_int M, aoclsparse_int N, aoclsparse_int nnz,
+                                                    aoclsparse_int *col_ptr, aoclsparse_int *row_idx, float *val);
+DLL_PUBLIC aoclsparse_status aoclsparse_create_dcsc(aoclsparse_matrix *mat, aoclsparse_index_base base,
+                                                    aoclsparse_int M, aoclsparse_int N, aoclsparse_int nnz,
+                                                    aoclsparse_int *col_ptr, aoclsparse_int *row_idx, double *val);
+DLL_PUBLIC aoclsparse_status aoclsparse_create_scoo(aoclsparse_matrix *mat, const aoclsparse_index_base base,
+                                                    const aoclsparse_int M, const aoclsparse_int N,
+                                                    const aoclsparse_int nnz, aoclsparse_int *row_ind,
+                                                    aoclsparse_int *col_ind, float *val);
+DLL_PUBLIC aoclsparse_status aoclsparse_create_dcoo(aoclsparse_matrix *mat, const aoclsparse_index_base base,
+                                                    const aoclsparse_int M, const aoclsparse_int N,
+                                                    const aoclsparse_int nnz, aoclsparse_int *row_ind,
+                                                    aoclsparse_int *col_ind, double *val);
+DLL_PUBLIC aoclsparse_status aoclsparse_export_scsc(const aoclsparse_matrix mat, aoclsparse_index_base *base,
+                                                    aoclsparse_int *m, aoclsparse_int *n, aoclsparse_int *nnz,
+                                                    aoclsparse_int **col_ptr, aoclsparse_int **row_ind, float **val);
+DLL_PUBLIC aoclsparse_status aoclsparse_export_dcsc(const aoclsparse_matrix mat, aoclsparse_index_base *base,
+                                                    aoclsparse_int *m, aoclsparse_int *n, aoclsparse_int *nnz,
+                                                    aoclsparse_int **col_ptr, aoclsparse_int **row_ind, double **val);
+DLL_PUBLIC aoclsparse_status aoclsparse_export_scoo(const aoclsparse_matrix mat, aoclsparse_index_base *base,
+                                                    aoclsparse_int *m, aoclsparse_int *n, aoclsparse_int *nnz,
+                                                    aoclsparse_int **row_ptr, aoclsparse_int **col_ptr, float **val);
+DLL_PUBLIC aoclsparse_status aoclsparse_export_dcoo(const aoclsparse_matrix mat, aoclsparse_index_base *base,
+                                                    aoclsparse_int *m, aoclsparse_int *n, aoclsparse_int *nnz,
+                                                    aoclsparse_int **row_ptr, aoclsparse_int **col_ptr, double **val);
+/* new CSR handle (owning its arrays) holding op(src); src may be a CSR, CSC or COO handle */
+DLL_PUBLIC aoclsparse_status aoclsparse_convert_csr(const aoclsparse_matrix src_mat, const aoclsparse_operation op,
+                                                    aoclsparse_matrix *dest_mat);
+/* sort the indices (and values) of every row of the caller's arrays in place */
+DLL_PUBLIC aoclsparse_status aoclsparse_order_mat(aoclsparse_matrix mat);
+DLL_PUBLIC aoclsparse_status aoclsparse_scsr2csc(aoclsparse_int m, aoclsparse_int n, aoclsparse_int nnz,
+                                                 const aoclsparse_mat_descr descr, aoclsparse_index_base baseCSC,
+                                                 const aoclsparse_int *csr_row_ptr,
+                                                 const aoclsparse_int *csr_col_ind, const float *csr_val,
+                                                 aoclsparse_int *csc_row_ind, aoclsparse_int *csc_col_ptr,
+                                                 float *csc_val);
+DLL_PUBLIC aoclsparse_status aoclsparse_dcsr2csc(aoclsparse_int m, aoclsparse_int n, aoclsparse_int nnz,
+                                                 const aoclsparse_mat_descr descr, aoclsparse_index_base baseCSC,
+                                                 const aoclsparse_int *csr_row_ptr,
+                                                 const aoclsparse_int *csr_col_ind, const double *csr_val,
+                                                 aoclsparse_int *csc_row_ind, aoclsparse_int *csc_col_ptr,
+                                                 double *csc_val);
+
 /* ---- ELL family: the formats the reference's optimize step stores, as raw-array products
  * (aoclsparse_functions.h:789-885) and their CSR conversions (aoclsparse_convert.h).  Only general
  * descriptors and op = none exist in the reference (anything else: not_implemented).  ELL is row-major

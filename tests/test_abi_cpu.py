@@ -429,3 +429,79 @@ def test_ellmv_argument_checks():
         L.aoclsparse_set_mat_index_base(bad.h, 2)
         assert fn(*args(m=0, w=1)) == 3 and fn(*args(w=0)) == 0 and np.array_equal(y, [0.1, 0.2])
     assert L.aoclsparse_sellthybmv(P.OP_NONE, None, 1, 1, 1, None, None, 1, 1, None, None, None, None, None, d.h, None, None, None) == 1
+
+
+def test_csc_coo_handles_convert_order_and_csr2csc():
+    """formats either side of the path (aoclsparse_auxiliary.h:674-1095, aoclsparse_convert.h:494-660): all host
+    structure work, int-exact against the oracle's csr2csc restatement and a dense reconstruction."""
+    import oracle
+    rng = np.random.default_rng(91)
+    m, n = 23, 17
+    dense = (rng.uniform(size=(m, n)) < 0.3) * rng.uniform(-1, 1, (m, n))
+    dense[4, :] = 0.0
+    for base in (0, 1):
+        rows = [np.flatnonzero(dense[i]) for i in range(m)]
+        rp = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32) + base
+        ci = (np.concatenate(rows) + base).astype(np.int32)
+        v = np.concatenate([dense[i, r] for i, r in enumerate(rows)])
+        nnz = len(v)
+        # public csr2csc == the oracle's restatement
+        ri, cp, cv = np.zeros(nnz, np.int32), np.zeros(n + 1, np.int32), np.zeros(nnz)
+        d = P.Descr(base=base)
+        assert L.aoclsparse_dcsr2csc(m, n, nnz, d.h, 1 - base, P._ptr(rp), P._ptr(ci), P._ptr(v), P._ptr(ri), P._ptr(cp), P._ptr(cv)) == 0
+        o = oracle.dcsr2csc(m, n, nnz, base, 1 - base, rp, ci, v)
+        assert o[0] == 0 and np.array_equal(cp, o[1]) and np.array_equal(ri, o[2]) and np.array_equal(cv, o[3])
+        # CSC handle: exports the caller's arrays, behaves as the CSR of the same matrix
+        ri, cp, cv = ri - (1 - base) + base, cp - (1 - base) + base, cv.copy()
+        h = ctypes.c_void_p()
+        assert L.aoclsparse_create_dcsc(ctypes.byref(h), base, m, n, nnz, P._ptr(cp), P._ptr(ri), P._ptr(cv)) == 0
+        b_, m_, n_, z_ = ctypes.c_int(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        a1, a2, a3 = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        outs = (ctypes.byref(b_), ctypes.byref(m_), ctypes.byref(n_), ctypes.byref(z_), ctypes.byref(a1), ctypes.byref(a2), ctypes.byref(a3))
+        assert L.aoclsparse_export_dcsc(h, *outs) == 0
+        assert (a1.value, a2.value, a3.value) == (cp.ctypes.data, ri.ctypes.data, cv.ctypes.data) and (m_.value, n_.value) == (m, n)
+        assert L.aoclsparse_export_dcsr(h, *outs) == 0 and (b_.value, m_.value, n_.value, z_.value) == (base, m, n, nnz)
+        g_rp = np.ctypeslib.as_array(ctypes.cast(a1, ctypes.POINTER(ctypes.c_int32)), (m + 1,))
+        g_ci = np.ctypeslib.as_array(ctypes.cast(a2, ctypes.POINTER(ctypes.c_int32)), (nnz,))
+        g_v = np.ctypeslib.as_array(ctypes.cast(a3, ctypes.POINTER(ctypes.c_double)), (nnz,))
+        assert np.array_equal(g_rp, rp) and np.array_equal(g_ci, ci) and np.array_equal(g_v, v)
+        assert L.aoclsparse_dset_value(h, 2 + base, int(ci[rp[2] - base]), 9.5) == 0  # written to CSC and CSR
+        assert 9.5 in cv and g_v[rp[2] - base] == 9.5
+        assert L.aoclsparse_export_dcoo(h, *outs) == 5
+        L.aoclsparse_destroy(ctypes.byref(h))
+        # COO handle in shuffled order -> convert_csr (op none / transpose)
+        perm = rng.permutation(nnz)
+        cr = (np.repeat(np.arange(m), np.diff(rp)) + base).astype(np.int32)[perm]
+        cc, cval = ci[perm].copy(), v[perm].copy()
+        assert L.aoclsparse_create_dcoo(ctypes.byref(h), base, m, n, nnz, P._ptr(cr), P._ptr(cc), P._ptr(cval)) == 0
+        assert L.aoclsparse_export_dcoo(h, *outs) == 0 and a1.value == cr.ctypes.data
+        for op, mm, nn, ref in ((P.OP_NONE, m, n, dense), (P.OP_TRANSPOSE, n, m, dense.T)):
+            c = ctypes.c_void_p()
+            assert L.aoclsparse_convert_csr(h, op, ctypes.byref(c)) == 0
+            assert L.aoclsparse_order_mat(c) == 0  # rows hold the COO order: sort them
+            assert L.aoclsparse_export_dcsr(c, *outs) == 0 and (m_.value, n_.value, z_.value, b_.value) == (mm, nn, nnz, base)
+            q_rp = np.ctypeslib.as_array(ctypes.cast(a1, ctypes.POINTER(ctypes.c_int32)), (mm + 1,))
+            q_ci = np.ctypeslib.as_array(ctypes.cast(a2, ctypes.POINTER(ctypes.c_int32)), (nnz,))
+            q_v = np.ctypeslib.as_array(ctypes.cast(a3, ctypes.POINTER(ctypes.c_double)), (nnz,))
+            rebuilt = np.zeros((mm, nn))
+            for i in range(mm):
+                seg = slice(q_rp[i] - base, q_rp[i + 1] - base)
+                assert np.all(np.diff(q_ci[seg]) > 0)
+                rebuilt[i, q_ci[seg] - base] = q_v[seg]
+            assert np.array_equal(rebuilt, ref)
+            L.aoclsparse_destroy(ctypes.byref(c))
+        x, y, one, zero = np.ones(n), np.zeros(m), np.array([1.0]), np.array([0.0])
+        assert L.aoclsparse_dmv(P.OP_NONE, P._ptr(one), h, d.h, P._ptr(x), P._ptr(zero), P._ptr(y)) == 1  # COO: not_implemented
+        bad = cr.copy()
+        bad[0] = m + base
+        g = ctypes.c_void_p()
+        assert L.aoclsparse_create_dcoo(ctypes.byref(g), base, m, n, nnz, P._ptr(bad), P._ptr(cc), P._ptr(cval)) == 6
+        L.aoclsparse_destroy(ctypes.byref(h))
+    # order_mat on an unsorted CSR handle sorts the caller's arrays in place
+    rp = np.array([0, 2, 3, 4, 7, 8], np.int32)
+    ci = np.array([3, 0, 1, 2, 3, 1, 4, 4], np.int32)
+    v = np.array([2.0, 1, 3, 4, 6, 5, 7, 8])
+    A = P.Matrix(0, 5, 5, rp, ci, v)
+    assert L.aoclsparse_order_mat(A.h) == 0
+    assert list(ci) == [0, 3, 1, 2, 1, 3, 4, 4] and list(v) == [1, 2, 3, 4, 5, 6, 7, 8]
+    assert L.aoclsparse_order_mat(None) == 2

@@ -1415,3 +1415,39 @@ def test_ilu_factorisation_on_gpu_long_rows_partial_sort_and_bad_pivot():
     B = P.Matrix(0, 2, 2, rp2, ci2, v2)
     assert L.aoclsparse_dilu_smoother(P.OP_NONE, B.h, d.h, ctypes.byref(pv), None, P._ptr(np.zeros(2)), P._ptr(np.ones(2))) == 11
     assert oracle.dilu0(2, 0, rp2, ci2, v2)[0] != 0
+
+
+def test_csc_handle_and_converted_coo_run_the_path():
+    """A handle created from CSC arrays must behave as the CSR handle of the same matrix in dmv (N / T), trsv and
+    csrmm; a COO handle converted with aoclsparse_convert_csr likewise."""
+    m = 900
+    rp, ci, v = triangular_system(101, m, 6, band=60)
+    so, cp, ri, cv = oracle.dcsr2csc(m, m, len(v), 0, 0, rp, ci, v)
+    hc = ctypes.c_void_p()
+    assert L.aoclsparse_create_dcsc(ctypes.byref(hc), 0, m, m, len(v), P._ptr(cp), P._ptr(ri), P._ptr(cv)) == 0
+    rng = np.random.default_rng(102)
+    x, one, zero = rng.uniform(-1, 1, m), np.array([1.0]), np.array([0.0])
+    d = P.Descr()
+    for op, orc in ((P.OP_NONE, lambda: oracle.dcsrmv(-1, 0, 1.0, m, len(v), v, ci, rp, x, 0.0, np.zeros(m))[1]),
+                    (P.OP_TRANSPOSE, lambda: oracle.dcsrmvt(0, 1.0, m, m, v, ci, rp, x, 0.0, np.zeros(m))[1])):
+        y = np.zeros(m)
+        assert L.aoclsparse_dmv(op, P._ptr(one), hc, d.h, P._ptr(x), P._ptr(zero), P._ptr(y)) == 0
+        yr = orc()
+        assert np.array_equal(y, yr) if op == P.OP_NONE else np.allclose(y, yr, rtol=0, atol=1e-12)
+    dt = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=P.FILL_LOWER)
+    b, xs = rng.uniform(-1, 1, m), np.zeros(m)
+    assert L.aoclsparse_dtrsv(P.OP_NONE, 1.5, hc, dt.h, P._ptr(b), P._ptr(xs)) == 0
+    assert np.array_equal(xs, oracle_trsv(0, m, rp, ci, v, "lower", "n", False, 1.5, b))
+    L.aoclsparse_destroy(ctypes.byref(hc))
+    # COO (shuffled) -> CSR -> order_mat -> same product as the original CSR
+    perm = rng.permutation(len(v))
+    cr = np.repeat(np.arange(m, dtype=np.int32), np.diff(rp))[perm].copy()
+    cc, cval = ci[perm].copy(), v[perm].copy()
+    hcoo, hcsr = ctypes.c_void_p(), ctypes.c_void_p()
+    assert L.aoclsparse_create_dcoo(ctypes.byref(hcoo), 0, m, m, len(v), P._ptr(cr), P._ptr(cc), P._ptr(cval)) == 0
+    assert L.aoclsparse_convert_csr(hcoo, P.OP_NONE, ctypes.byref(hcsr)) == 0 and L.aoclsparse_order_mat(hcsr) == 0
+    y = np.zeros(m)
+    assert L.aoclsparse_dmv(P.OP_NONE, P._ptr(one), hcsr, d.h, P._ptr(x), P._ptr(zero), P._ptr(y)) == 0
+    so, yr = oracle.dcsrmv(-1, 0, 1.0, m, len(v), v, ci, rp, x, 0.0, np.zeros(m))
+    assert np.array_equal(y, yr)
+    L.aoclsparse_destroy(ctypes.byref(hcsr)), L.aoclsparse_destroy(ctypes.byref(hcoo))
