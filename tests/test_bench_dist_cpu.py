@@ -75,3 +75,20 @@ def test_job_throughput_world2_gloo():
 def test_single_rank_is_identity():
     assert bench.reduce_scalar(3.5, "max") == 3.5
     assert bench.job_throughput(10.0, 2.0) == (5.0, 2.0)
+
+
+def test_matrix_market_reader(tmp_path):
+    """tools/standins.read_mtx: coordinate real symmetric -> full sorted CSR (what the reference's harness does,
+    tests/include/aoclsparse_init.hpp:452-694)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import standins
+    p = tmp_path / "t.mtx"
+    p.write_text("%%MatrixMarket matrix coordinate real symmetric\n% c\n4 4 5\n1 1 2.0\n2 1 -1.0\n3 3 4.0\n4 2 0.5\n4 4 1.0\n")
+    m, n, rp, ci, v = standins.read_mtx(str(p))
+    assert (m, n) == (4, 4) and list(rp) == [0, 2, 4, 5, 7]
+    assert list(ci) == [0, 1, 0, 3, 2, 1, 3] and list(v) == [2.0, -1.0, -1.0, 0.5, 4.0, 0.5, 1.0]
+    q = tmp_path / "p.mtx"
+    q.write_text("%%MatrixMarket matrix coordinate pattern general\n2 3 2\n1 3\n2 1\n")
+    m, n, rp, ci, v = standins.read_mtx(str(q))
+    assert (m, n, list(rp), list(ci)) == (2, 3, [0, 1, 2], [2, 0]) and len(v) == 2

@@ -49,7 +49,7 @@ if "spmv" in what:
     L.aoclsparse_mi355_set_pointer_mode(pkg.PTR_DEVICE)
     names = ["circuit-like", "web-like"] + ([] if args.small else ["shell-like", "flan-like"])
     for name in names:
-        m, rp, ci, v = standins.ALL[name]()
+        label, m, rp, ci, v = standins.load(name)
         nnz = len(v)
         A = pkg.Matrix(0, m, m, rp, ci, v)
         assert L.aoclsparse_set_mv_hint(A.h, pkg.OP_NONE, d0.h, 100) == 0 and L.aoclsparse_optimize(A.h) == 0
@@ -63,7 +63,7 @@ if "spmv" in what:
         lens = np.diff(rp)
         short = lens <= info.tile
         b = spmv_bytes(m, m, nnz)
-        emit(kind="spmv", matrix=name + " (stand-in)", m=m, nnz=nnz, kernel={1: "csr-adaptive", 3: "sell-64"}.get(info.kernel, info.kernel),
+        emit(kind="spmv", matrix=label, m=m, nnz=nnz, kernel={1: "csr-adaptive", 3: "sell-64"}.get(info.kernel, info.kernel),
              cells_per_nnz=round(info.stored_cells / nnz, 3) if info.kernel == 3 else None, order=info.order, tile=info.tile,
              row_blocks=info.row_blocks, long_rows=info.long_rows, max_row=int(lens.max()), ms=round(ms, 5),
              gflops=round(2 * nnz / ms / 1e6, 2), gbs=round(b / ms / 1e6, 1), frac_of_8TBs=round(b / ms / 1e6 / 8000, 4),

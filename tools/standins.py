@@ -94,3 +94,55 @@ def flan_like(nx=81, ny=80, nz=80, seed=404):
 
 
 ALL = {"circuit-like": circuit_like, "web-like": web_like, "shell-like": shell_like, "flan-like": flan_like}
+
+
+# ---- MatrixMarket input (tests/include/aoclsparse_init.hpp:452-694 reads coordinate real / integer / pattern,
+# general or symmetric expanded to full) -------------------------------------------------------------------
+REAL_FILES = {"circuit-like": "scircuit.mtx", "web-like": "webbase-1M.mtx", "shell-like": "af_shell10.mtx",
+              "flan-like": "Flan_1565.mtx"}
+
+
+def read_mtx(path, seed=7):
+    """MatrixMarket coordinate file -> (m, n, row_ptr, col_ind, val), 0-based CSR with sorted rows.  Symmetric /
+    skew-symmetric / hermitian storage is expanded to the full matrix; pattern files get seeded random values;
+    duplicate entries are summed (as a coordinate assembly would)."""
+    with open(path, "rb") as f:
+        header = f.readline().decode().lower().split()
+        if len(header) < 5 or header[0] != "%%matrixmarket" or header[1] != "matrix" or header[2] != "coordinate":
+            raise ValueError("%s: only 'matrix coordinate' MatrixMarket files are supported" % path)
+        field, symm = header[3], header[4]
+        if field == "complex":
+            raise ValueError("%s: complex matrices are out of scope" % path)
+        line = f.readline()
+        while line.startswith(b"%") or not line.strip():
+            line = f.readline()
+        m, n, nnz = (int(t) for t in line.split()[:3])
+        data = np.loadtxt(f, ndmin=2) if nnz else np.zeros((0, 3))
+    r, c = data[:, 0].astype(np.int64) - 1, data[:, 1].astype(np.int64) - 1
+    v = np.random.default_rng(seed).uniform(-1, 1, len(r)) if field == "pattern" else data[:, 2].astype(np.float64)
+    if symm in ("symmetric", "hermitian", "skew-symmetric"):
+        off = r != c
+        r, c = np.concatenate([r, c[off]]), np.concatenate([c, r[off]])
+        v = np.concatenate([v, -v[off] if symm == "skew-symmetric" else v[off]])
+    key = r * n + c
+    order = np.argsort(key, kind="stable")
+    key, v = key[order], v[order]
+    uniq, start = np.unique(key, return_index=True)
+    v = np.add.reduceat(v, start) if len(v) else v
+    rows = (uniq // n).astype(np.int64)
+    row_ptr = np.zeros(m + 1, dtype=np.int64)
+    np.add.at(row_ptr, rows + 1, 1)
+    return m, n, np.cumsum(row_ptr).astype(np.int32), (uniq % n).astype(np.int32), v
+
+
+def load(name):
+    """(label, m, row_ptr, col_ind, val): the real SuiteSparse matrix when $MATRIX_DIR holds its .mtx file, else the
+    seeded stand-in (labelled as such)."""
+    import os
+    d = os.environ.get("MATRIX_DIR")
+    if d and os.path.isfile(os.path.join(d, REAL_FILES[name])):
+        m, n, rp, ci, v = read_mtx(os.path.join(d, REAL_FILES[name]))
+        assert m == n
+        return REAL_FILES[name], m, rp, ci, v
+    m, rp, ci, v = ALL[name]()
+    return name + " (stand-in)", m, rp, ci, v
