@@ -12,7 +12,8 @@ import os
 from ctypes import POINTER, byref, c_bool, c_char_p, c_double, c_float, c_int, c_int32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libaoclsparse_mi355.so")
+# AOCLSPARSE_MI355_LIB: load another build of the same library (e.g. a sanitizer build), never a different product
+LIB_PATH = os.environ.get("AOCLSPARSE_MI355_LIB") or os.path.join(_HERE, "lib", "libaoclsparse_mi355.so")
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 # enum values of include/aoclsparse.h
