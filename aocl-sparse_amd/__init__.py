@@ -35,6 +35,14 @@ STATUS = {
 }
 
 
+class CFloat(ctypes.Structure):
+    _fields_ = [("real", c_float), ("imag", c_float)]
+
+
+class CDouble(ctypes.Structure):
+    _fields_ = [("real", c_double), ("imag", c_double)]
+
+
 class SpmvInfo(ctypes.Structure):
     _fields_ = [("kernel", c_int32), ("order", c_int32), ("row_blocks", c_int32), ("tile", c_int32),
                 ("long_rows", c_int32), ("max_row_nnz", c_int32), ("device_resident", c_int32),
@@ -99,6 +107,16 @@ SIGNATURES = {
     "aoclsparse_dtrsm": (c_int, [c_int, c_double, _P, _P, c_int, _P, _I, _I, _P, _I]),
     "aoclsparse_strsm_kid": (c_int, [c_int, c_float, _P, _P, c_int, _P, _I, _I, _P, _I, _I]),
     "aoclsparse_dtrsm_kid": (c_int, [c_int, c_double, _P, _P, c_int, _P, _I, _I, _P, _I, _I]),
+    "aoclsparse_create_ccsr": (c_int, [POINTER(_P), c_int, _I, _I, _I, _P, _P, _P]),
+    "aoclsparse_create_zcsr": (c_int, [POINTER(_P), c_int, _I, _I, _I, _P, _P, _P]),
+    "aoclsparse_export_ccsr": (c_int, [_P, POINTER(c_int), POINTER(_I), POINTER(_I), POINTER(_I), POINTER(_P), POINTER(_P), POINTER(_P)]),
+    "aoclsparse_export_zcsr": (c_int, [_P, POINTER(c_int), POINTER(_I), POINTER(_I), POINTER(_I), POINTER(_P), POINTER(_P), POINTER(_P)]),
+    "aoclsparse_cset_value": (c_int, [_P, _I, _I, CFloat]),
+    "aoclsparse_zset_value": (c_int, [_P, _I, _I, CDouble]),
+    "aoclsparse_cupdate_values": (c_int, [_P, _I, _P]),
+    "aoclsparse_zupdate_values": (c_int, [_P, _I, _P]),
+    "aoclsparse_cmv": (c_int, [c_int, _P, _P, _P, _P, _P, _P]),
+    "aoclsparse_zmv": (c_int, [c_int, _P, _P, _P, _P, _P, _P]),
     "aoclsparse_create_scsc": (c_int, [POINTER(_P), c_int, _I, _I, _I, _P, _P, _P]),
     "aoclsparse_create_dcsc": (c_int, [POINTER(_P), c_int, _I, _I, _I, _P, _P, _P]),
     "aoclsparse_create_scoo": (c_int, [POINTER(_P), c_int, _I, _I, _I, _P, _P, _P]),

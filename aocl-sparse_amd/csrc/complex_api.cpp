@@ -1,0 +1,123 @@
+// complex_api.cpp -- aoclsparse_cmv / aoclsparse_zmv: y = alpha op(A) x + beta y for complex handles, every
+// descriptor type and operation the reference dispatches by doid (level2/aoclsparse_mv.cpp:41-349,
+// include/aoclsparse_mtx_dispatcher.hpp:41-353).
+//
+// The operator is always an ordinary CSR in HBM -- the user's CSR, its transpose, or an expansion / slice
+// derived from the clean CSR (derived.cpp; the mirrored half of a hermitian matrix is stored conjugated) --
+// and the conjugation that an operation adds on top is a flag of the kernel:
+//
+//   descriptor   op = N                 op = T                    op = H
+//   general      user                   transpose                 transpose, conj
+//   symmetric    expansion              expansion (A^T = A)       expansion, conj (A^H = conj A)
+//   hermitian    expansion              expansion, conj (A^T = conj A)   expansion (A^H = A)
+//   triangular   slice                  transposed slice          transposed slice, conj
+#include "internal.hpp"
+
+using namespace mi355;
+
+namespace
+{
+
+#define MI355_TRY(expr)                       \
+    do                                        \
+    {                                         \
+        aoclsparse_status st__ = (expr);      \
+        if(st__ != aoclsparse_status_success) \
+            return st__;                      \
+    } while(0)
+
+template <typename R>
+aoclsparse_status cmv_t(aoclsparse_operation op, const cplx<R> *alpha, aoclsparse_matrix A,
+                        const aoclsparse_mat_descr descr, const cplx<R> *x, const cplx<R> *beta, cplx<R> *y,
+                        aoclsparse_matrix_data_type vt)
+{
+    using C = cplx<R>;
+    // mv.cpp:55-97, same order
+    if(!alpha || !beta || !A || !descr || !x || !y)
+        return aoclsparse_status_invalid_pointer;
+    if(A->input_format == aoclsparse_csr_mat && !A->user.ptr)
+        return aoclsparse_status_invalid_pointer;
+    if(descr->base != A->base)
+        return aoclsparse_status_invalid_value;
+    if(op != aoclsparse_operation_none && op != aoclsparse_operation_transpose
+       && op != aoclsparse_operation_conjugate_transpose)
+        return aoclsparse_status_invalid_value;
+    if(A->val_type != vt)
+        return aoclsparse_status_wrong_type;
+    if(descr->type < aoclsparse_matrix_type_general || descr->type > aoclsparse_matrix_type_triangular)
+        return aoclsparse_status_invalid_value;
+    const bool sym  = descr->type == aoclsparse_matrix_type_symmetric;
+    const bool herm = descr->type == aoclsparse_matrix_type_hermitian;
+    if((sym || herm) && A->m != A->n)
+        return aoclsparse_status_invalid_size;
+    if(A->input_format != aoclsparse_csr_mat)
+        return aoclsparse_status_not_implemented;
+
+    Runtime &rt = Runtime::get();
+    MI355_TRY(rt.init());
+    std::lock_guard<std::recursive_mutex> sl(rt.stage_lock);
+    const bool                            tr = op != aoclsparse_operation_none;
+    if(A->m == 0 || A->n == 0 || (A->nnz == 0 && descr->type == aoclsparse_matrix_type_general))
+    {
+        const aoclsparse_int dim = tr ? A->n : A->m; // mv.cpp:116-121: an empty matrix still scales y
+        StagedArg            ay;
+        const bool           b0 = beta->re == R(0) && beta->im == R(0);
+        MI355_TRY(ay.in(rt, 4, y, sizeof(C) * (size_t)dim, !b0));
+        MI355_TRY(launch_cscale<R>(rt.stream(), static_cast<C *>(ay.dev), dim, *beta));
+        MI355_TRY(ay.out(rt));
+        if(ay.staged)
+            MI355_HIP_TRY(hipStreamSynchronize(rt.stream()));
+        return aoclsparse_status_success;
+    }
+
+    DeviceCsr *dcsr = nullptr;
+    bool       conj = false;
+    if(descr->type == aoclsparse_matrix_type_general)
+    {
+        SpmvPlan *plan = nullptr;
+        MI355_TRY(ensure_spmv(A, tr, dcsr, plan));
+        conj = op == aoclsparse_operation_conjugate_transpose;
+    }
+    else
+    {
+        Derived *dv = nullptr;
+        MI355_TRY(ensure_derived(A, descr->type, descr->fill_mode, descr->diag_type, tr, dv));
+        dcsr = &dv->dev;
+        conj = sym    ? op == aoclsparse_operation_conjugate_transpose
+               : herm ? op == aoclsparse_operation_transpose
+                      : op == aoclsparse_operation_conjugate_transpose;
+    }
+    std::shared_lock<std::shared_mutex> r(A->guard);
+    StagedArg                           ax, ay;
+    const bool                          b0 = beta->re == R(0) && beta->im == R(0);
+    MI355_TRY(ax.in(rt, 3, x, sizeof(C) * (size_t)dcsr->n, true));
+    MI355_TRY(ay.in(rt, 4, y, sizeof(C) * (size_t)dcsr->m, !b0));
+    MI355_TRY(launch_cspmv<R>(rt.stream(), dcsr->base, conj, *alpha, dcsr->m, dcsr->nnz, dcsr->val.as<C>(),
+                              dcsr->ind.as<aoclsparse_int>(), dcsr->ptr.as<aoclsparse_int>(),
+                              static_cast<const C *>(ax.dev), *beta, static_cast<C *>(ay.dev)));
+    MI355_TRY(ay.out(rt));
+    if(ay.staged)
+        MI355_HIP_TRY(hipStreamSynchronize(rt.stream()));
+    return aoclsparse_status_success;
+}
+
+} // namespace
+
+extern "C" {
+
+aoclsparse_status aoclsparse_cmv(aoclsparse_operation op, const aoclsparse_float_complex *alpha, aoclsparse_matrix A,
+                                 const aoclsparse_mat_descr descr, const aoclsparse_float_complex *x,
+                                 const aoclsparse_float_complex *beta, aoclsparse_float_complex *y)
+{
+    return cmv_t<float>(op, reinterpret_cast<const cfloat *>(alpha), A, descr, reinterpret_cast<const cfloat *>(x),
+                        reinterpret_cast<const cfloat *>(beta), reinterpret_cast<cfloat *>(y), aoclsparse_cmat);
+}
+aoclsparse_status aoclsparse_zmv(aoclsparse_operation op, const aoclsparse_double_complex *alpha, aoclsparse_matrix A,
+                                 const aoclsparse_mat_descr descr, const aoclsparse_double_complex *x,
+                                 const aoclsparse_double_complex *beta, aoclsparse_double_complex *y)
+{
+    return cmv_t<double>(op, reinterpret_cast<const cdouble *>(alpha), A, descr, reinterpret_cast<const cdouble *>(x),
+                         reinterpret_cast<const cdouble *>(beta), reinterpret_cast<cdouble *>(y), aoclsparse_zmat);
+}
+
+} // extern "C"

@@ -1,0 +1,143 @@
+// complex_kernels.hip -- SpMV for complex handles (aoclsparse_cmv / aoclsparse_zmv).
+//
+// One sub-wavefront group of G lanes per row (G = 4 .. 64 chosen from the mean row length): the lanes stride
+// over the row's entries with coalesced 8 / 16-byte value loads, keep one complex partial sum each and are
+// tree-reduced with shuffles; lane 0 applies alpha / beta.  `conj` multiplies by the conjugated matrix
+// value, which turns the stored transpose into the conjugate transpose and a symmetric / hermitian expansion
+// into its conjugate (op table in complex_api.cpp).  The reference computes these products with its
+// vectorised KT kernels (level2/aoclsparse_csrmv_kt.cpp:30-329) whose lane assignment is an x86 register
+// width: parity is the forward-error bound, not the bit pattern.  HBM-bound like the real kernels
+// (16 + 4 B per non-zero for double complex); not tuned further.
+#include "internal.hpp"
+
+#include <hip/hip_runtime.h>
+
+namespace mi355
+{
+
+namespace
+{
+
+template <typename R>
+__device__ __forceinline__ R c_fma(R a, R b, R c);
+template <>
+__device__ __forceinline__ double c_fma(double a, double b, double c)
+{
+    return fma(a, b, c);
+}
+template <>
+__device__ __forceinline__ float c_fma(float a, float b, float c)
+{
+    return fmaf(a, b, c);
+}
+
+// acc += a * b
+template <typename R>
+__device__ __forceinline__ void c_mac(cplx<R> &acc, cplx<R> a, cplx<R> b)
+{
+    acc.re = c_fma(a.re, b.re, acc.re);
+    acc.re = c_fma(-a.im, b.im, acc.re);
+    acc.im = c_fma(a.re, b.im, acc.im);
+    acc.im = c_fma(a.im, b.re, acc.im);
+}
+template <typename R>
+__device__ __forceinline__ cplx<R> c_mul(cplx<R> a, cplx<R> b)
+{
+    cplx<R> r(R(0), R(0));
+    c_mac(r, a, b);
+    return r;
+}
+
+template <typename R, int G>
+__global__ __launch_bounds__(256) void cspmv_kernel(int base, bool conj, cplx<R> alpha, aoclsparse_int m,
+                                                    const cplx<R> *__restrict__ val,
+                                                    const aoclsparse_int *__restrict__ col,
+                                                    const aoclsparse_int *__restrict__ row_ptr,
+                                                    const cplx<R> *__restrict__ x, cplx<R> beta,
+                                                    cplx<R> *__restrict__ y)
+{
+    const int lane = threadIdx.x % G;
+    const int row  = (int)(((long long)blockIdx.x * 256 + threadIdx.x) / G);
+    if(row >= m)
+        return; // whole groups leave together (256 % G == 0)
+    const int s = row_ptr[row] - base, e = row_ptr[row + 1] - base;
+    cplx<R>   acc(R(0), R(0));
+    for(int p = s + lane; p < e; p += G)
+    {
+        cplx<R> a = val[p];
+        if(conj)
+            a.im = -a.im;
+        c_mac(acc, a, x[col[p] - base]);
+    }
+#pragma unroll
+    for(int o = G / 2; o > 0; o >>= 1)
+    {
+        acc.re += __shfl_down(acc.re, o, G);
+        acc.im += __shfl_down(acc.im, o, G);
+    }
+    if(lane == 0)
+    {
+        cplx<R> r = acc;
+        if(!(alpha.re == R(1) && alpha.im == R(0)))
+            r = c_mul(alpha, acc);
+        if(!(beta.re == R(0) && beta.im == R(0))) // beta == 0 never reads y
+            c_mac(r, beta, y[row]);
+        y[row] = r;
+    }
+}
+
+template <typename R>
+__global__ void cscale_kernel(cplx<R> *y, aoclsparse_int n, cplx<R> beta)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n)
+        y[i] = (beta.re == R(0) && beta.im == R(0)) ? cplx<R>(R(0), R(0)) : c_mul(beta, y[i]);
+}
+
+} // namespace
+
+template <typename R>
+aoclsparse_status launch_cspmv(hipStream_t s, int base, bool conj, cplx<R> alpha, aoclsparse_int m, aoclsparse_int nnz,
+                               const cplx<R> *val, const aoclsparse_int *col, const aoclsparse_int *row_ptr,
+                               const cplx<R> *x, cplx<R> beta, cplx<R> *y)
+{
+    if(m <= 0)
+        return aoclsparse_status_success;
+    const long long mean = nnz / (long long)m;
+    auto            go   = [&](auto gtag) {
+        constexpr int G    = decltype(gtag)::value;
+        const long long nb = ((long long)m * G + 255) / 256;
+        hipLaunchKernelGGL((cspmv_kernel<R, G>), dim3((unsigned)nb), dim3(256), 0, s, base, conj, alpha, m, val, col,
+                           row_ptr, x, beta, y);
+    };
+    if(mean <= 6)
+        go(std::integral_constant<int, 4>{});
+    else if(mean <= 24)
+        go(std::integral_constant<int, 8>{});
+    else if(mean <= 96)
+        go(std::integral_constant<int, 16>{});
+    else
+        go(std::integral_constant<int, 64>{});
+    MI355_HIP_TRY(hipGetLastError());
+    return aoclsparse_status_success;
+}
+
+template <typename R>
+aoclsparse_status launch_cscale(hipStream_t s, cplx<R> *y, aoclsparse_int n, cplx<R> beta)
+{
+    if(n > 0)
+        hipLaunchKernelGGL((cscale_kernel<R>), dim3((n + 255) / 256), dim3(256), 0, s, y, n, beta);
+    MI355_HIP_TRY(hipGetLastError());
+    return aoclsparse_status_success;
+}
+
+template aoclsparse_status launch_cspmv<float>(hipStream_t, int, bool, cfloat, aoclsparse_int, aoclsparse_int,
+                                               const cfloat *, const aoclsparse_int *, const aoclsparse_int *,
+                                               const cfloat *, cfloat, cfloat *);
+template aoclsparse_status launch_cspmv<double>(hipStream_t, int, bool, cdouble, aoclsparse_int, aoclsparse_int,
+                                                const cdouble *, const aoclsparse_int *, const aoclsparse_int *,
+                                                const cdouble *, cdouble, cdouble *);
+template aoclsparse_status launch_cscale<float>(hipStream_t, cfloat *, aoclsparse_int, cfloat);
+template aoclsparse_status launch_cscale<double>(hipStream_t, cdouble *, aoclsparse_int, cdouble);
+
+} // namespace mi355

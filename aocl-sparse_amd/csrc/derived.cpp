@@ -66,6 +66,9 @@ static void build_derived(const HostCsr &c, aoclsparse_matrix_type type, bool up
     //   lower fill: [direct strict (cols < i)] [diag] [mirror (cols > i)]
     //   upper fill: [mirror (cols < i)] [diag] [direct strict (cols > i)]
     // Mirror entries of row i arrive in ascending source row when source rows are visited ascending.
+    // the mirrored half of a hermitian matrix is the conjugate of the stored one (identity for real types)
+    const bool herm = type == aoclsparse_matrix_type_hermitian;
+    auto       mir  = [&](T val) { return herm ? conj_of(val) : val; };
     auto put = [&](aoclsparse_int r, aoclsparse_int col, T val) {
         const aoclsparse_int q = next[r]++;
         out.ind[q]             = col;
@@ -86,7 +89,7 @@ static void build_derived(const HostCsr &c, aoclsparse_matrix_type type, bool up
             for(aoclsparse_int i = 0; i < m; i++)
                 for(aoclsparse_int p = s[i] - b; p < e[i] - b; p++)
                     if(c.ind[p] - b < rows)
-                        put(c.ind[p] - b, i, v[p]);
+                        put(c.ind[p] - b, i, mir(v[p]));
     }
     else
     {
@@ -95,7 +98,7 @@ static void build_derived(const HostCsr &c, aoclsparse_matrix_type type, bool up
             for(aoclsparse_int i = 0; i < m; i++)
                 for(aoclsparse_int p = s[i] - b; p < e[i] - b; p++)
                     if(c.ind[p] - b < rows)
-                        put(c.ind[p] - b, i, v[p]);
+                        put(c.ind[p] - b, i, mir(v[p]));
         for(aoclsparse_int i = 0; i < rows; i++)
         {
             if(i < dim && has_diag(i))
@@ -134,16 +137,17 @@ aoclsparse_status ensure_derived(aoclsparse_matrix A, aoclsparse_matrix_type typ
     {
         std::unique_ptr<Derived> d(new Derived);
         d->type = type, d->fill = fill, d->diag = diag, d->trans = transposed;
-        if(A->val_type == aoclsparse_smat)
-            build_derived<float>(*A->opt, type, fill == aoclsparse_fill_mode_upper, diag, transposed, d->host);
-        else
-            build_derived<double>(*A->opt, type, fill == aoclsparse_fill_mode_upper, diag, transposed, d->host);
+        dispatch_value_type(A->val_type, [&](auto tag) {
+            build_derived<decltype(tag)>(*A->opt, type, fill == aoclsparse_fill_mode_upper, diag, transposed, d->host);
+            return 0;
+        });
         st = upload_csr(d->host, val_size(A->val_type), d->dev);
         if(st == aoclsparse_status_success)
             st = build_spmv_plan(d->host.m, d->host.nnz, d->host.base, d->host.ptr, d->plan);
         // a derived operator exists because products with it were asked for: give it the SELL-64 twin too
         // (when its padding is small); both kernels realise the same summation order on the derived rows
-        if(st == aoclsparse_status_success && A->mem_policy == aoclsparse_memory_usage_unrestricted)
+        if(st == aoclsparse_status_success && A->mem_policy == aoclsparse_memory_usage_unrestricted
+           && !is_complex_type(A->val_type))
             st = build_sell(d->host.ptr, d->dev, val_size(A->val_type), d->plan);
         if(st != aoclsparse_status_success)
             return st;

@@ -377,6 +377,8 @@ aoclsparse_status aoclsparse_convert_csr(const aoclsparse_matrix src_mat, const 
         return aoclsparse_status_invalid_pointer;
     if(src_mat->input_format != aoclsparse_coo_mat && src_mat->input_format != aoclsparse_csr_mat)
         return aoclsparse_status_not_implemented;
+    if(is_complex_type(src_mat->val_type))
+        return aoclsparse_status_not_implemented; // complex handles: ?mv only
     return src_mat->val_type == aoclsparse_smat ? convert_csr<float>(src_mat, op, dest_mat, aoclsparse_smat)
                                                 : convert_csr<double>(src_mat, op, dest_mat, aoclsparse_dmat);
 }
@@ -393,6 +395,8 @@ aoclsparse_status aoclsparse_order_mat(aoclsparse_matrix mat)
         return aoclsparse_status_success;
     if(!mat->user.ptr || !mat->user.ind || !mat->user.val)
         return aoclsparse_status_invalid_pointer;
+    if(is_complex_type(mat->val_type))
+        return aoclsparse_status_not_implemented;
     std::unique_lock<std::shared_mutex> w(mat->guard);
     aoclsparse_status                   st;
     const bool                          f = mat->val_type == aoclsparse_smat;

@@ -41,6 +41,48 @@ namespace mi355
 
 aoclsparse_status map_hip_error(hipError_t e);
 
+// ---- complex values (aoclsparse_float_complex / aoclsparse_double_complex layout: {real, imag}) ---------
+template <typename R>
+struct cplx
+{
+    R re, im;
+    __host__ __device__ cplx() = default;
+    __host__ __device__ constexpr cplx(R r, R i = R(0))
+        : re(r)
+        , im(i)
+    {
+    }
+};
+using cfloat  = cplx<float>;
+using cdouble = cplx<double>;
+inline float  conj_of(float v) { return v; }
+inline double conj_of(double v) { return v; }
+template <typename R>
+inline cplx<R> conj_of(cplx<R> v)
+{
+    return cplx<R>(v.re, -v.im);
+}
+// f(T{}) with T = float / double / cfloat / cdouble for the handle's value type
+template <typename F>
+auto dispatch_value_type(aoclsparse_matrix_data_type t, F &&f)
+{
+    switch(t)
+    {
+    case aoclsparse_smat:
+        return f(float{});
+    case aoclsparse_cmat:
+        return f(cfloat{});
+    case aoclsparse_zmat:
+        return f(cdouble{});
+    default:
+        return f(double{});
+    }
+}
+inline bool is_complex_type(aoclsparse_matrix_data_type t)
+{
+    return t == aoclsparse_cmat || t == aoclsparse_zmat;
+}
+
 // ---- hinted actions (library/src/include/aoclsparse_mat_structures.hpp:36-68) -------------
 enum hinted_action
 {
@@ -391,6 +433,14 @@ aoclsparse_status launch_strided_gather(hipStream_t s, const T *src, aoclsparse_
 template <typename T>
 aoclsparse_status launch_strided_scatter(hipStream_t s, const T *src, aoclsparse_int n, T *dst,
                                          aoclsparse_int inc);
+
+// complex SpMV on a device CSR (complex_kernels.hip); conj multiplies by the conjugated matrix values
+template <typename R>
+aoclsparse_status launch_cspmv(hipStream_t s, int base, bool conj, cplx<R> alpha, aoclsparse_int m, aoclsparse_int nnz,
+                               const cplx<R> *val, const aoclsparse_int *col, const aoclsparse_int *row_ptr,
+                               const cplx<R> *x, cplx<R> beta, cplx<R> *y);
+template <typename R>
+aoclsparse_status launch_cscale(hipStream_t s, cplx<R> *y, aoclsparse_int n, cplx<R> beta);
 
 // ELL family (ell_kernels.hip).  ellmv: row-major ELL, padding = column -1, double in the reference's
 // 4-lane order (ellmv.hpp:90-208), float in its scalar order (:34-85).  elltmv: column-major ELL, one

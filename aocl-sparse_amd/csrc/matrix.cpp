@@ -286,8 +286,9 @@ aoclsparse_status csr_optimize(aoclsparse_matrix A)
         else
         {
             std::unique_ptr<HostCsr> c;
-            st = A->val_type == aoclsparse_smat ? make_clean_copy<float>(A, sorted, fulldiag, c)
-                                                : make_clean_copy<double>(A, sorted, fulldiag, c);
+            st = dispatch_value_type(A->val_type, [&](auto tag) {
+                return make_clean_copy<decltype(tag)>(A, sorted, fulldiag, c);
+            });
             if(st != aoclsparse_status_success)
                 return st;
             st = csr_indices(c->m, c->base, c->ptr, c->ind, &c->idiag, &c->iurow);
@@ -348,10 +349,10 @@ aoclsparse_status build_transpose(aoclsparse_matrix A)
         t->ptr   = new aoclsparse_int[t->m + 1];
         t->ind   = new aoclsparse_int[A->nnz > 0 ? A->nnz : 1];
         t->val   = ::operator new(vs * (A->nnz > 0 ? A->nnz : 1));
-        if(A->val_type == aoclsparse_smat)
-            transpose_into<float>(A->user, A->nnz, *t);
-        else
-            transpose_into<double>(A->user, A->nnz, *t);
+        dispatch_value_type(A->val_type, [&](auto tag) {
+            transpose_into<decltype(tag)>(A->user, A->nnz, *t);
+            return 0;
+        });
         A->trans = std::move(t);
     }
     catch(const std::bad_alloc &)
@@ -695,6 +696,22 @@ aoclsparse_status aoclsparse_create_scsr(aoclsparse_matrix *mat, aoclsparse_inde
     return create_csr(mat, base, M, N, nnz, row_ptr, col_idx, val, aoclsparse_smat);
 }
 
+aoclsparse_status aoclsparse_create_ccsr(aoclsparse_matrix *mat, aoclsparse_index_base base,
+                                         aoclsparse_int M, aoclsparse_int N, aoclsparse_int nnz,
+                                         aoclsparse_int *row_ptr, aoclsparse_int *col_idx,
+                                         aoclsparse_float_complex *val)
+{
+    return create_csr(mat, base, M, N, nnz, row_ptr, col_idx, val, aoclsparse_cmat);
+}
+
+aoclsparse_status aoclsparse_create_zcsr(aoclsparse_matrix *mat, aoclsparse_index_base base,
+                                         aoclsparse_int M, aoclsparse_int N, aoclsparse_int nnz,
+                                         aoclsparse_int *row_ptr, aoclsparse_int *col_idx,
+                                         aoclsparse_double_complex *val)
+{
+    return create_csr(mat, base, M, N, nnz, row_ptr, col_idx, val, aoclsparse_zmat);
+}
+
 aoclsparse_status aoclsparse_destroy(aoclsparse_matrix *mat)
 {
     if(!mat)
@@ -752,6 +769,22 @@ aoclsparse_status aoclsparse_export_scsr(const aoclsparse_matrix mat, aoclsparse
                                          aoclsparse_int **row_ptr, aoclsparse_int **col_ind, float **val)
 {
     return export_csr<float>(mat, base, m, n, nnz, row_ptr, col_ind, val, aoclsparse_smat);
+}
+
+aoclsparse_status aoclsparse_export_ccsr(const aoclsparse_matrix mat, aoclsparse_index_base *base,
+                                         aoclsparse_int *m, aoclsparse_int *n, aoclsparse_int *nnz,
+                                         aoclsparse_int **row_ptr, aoclsparse_int **col_ind,
+                                         aoclsparse_float_complex **val)
+{
+    return export_csr<aoclsparse_float_complex>(mat, base, m, n, nnz, row_ptr, col_ind, val, aoclsparse_cmat);
+}
+
+aoclsparse_status aoclsparse_export_zcsr(const aoclsparse_matrix mat, aoclsparse_index_base *base,
+                                         aoclsparse_int *m, aoclsparse_int *n, aoclsparse_int *nnz,
+                                         aoclsparse_int **row_ptr, aoclsparse_int **col_ind,
+                                         aoclsparse_double_complex **val)
+{
+    return export_csr<aoclsparse_double_complex>(mat, base, m, n, nnz, row_ptr, col_ind, val, aoclsparse_zmat);
 }
 
 aoclsparse_status aoclsparse_mi355_export_diag(const aoclsparse_matrix A, aoclsparse_int **idiag,
@@ -879,6 +912,24 @@ aoclsparse_status aoclsparse_sset_value(aoclsparse_matrix A, aoclsparse_int row_
 {
     return set_value<float>(A, row_idx, col_idx, val, aoclsparse_smat);
 }
+aoclsparse_status aoclsparse_cset_value(aoclsparse_matrix A, aoclsparse_int row_idx, aoclsparse_int col_idx,
+                                        aoclsparse_float_complex val)
+{
+    return set_value<aoclsparse_float_complex>(A, row_idx, col_idx, val, aoclsparse_cmat);
+}
+aoclsparse_status aoclsparse_zset_value(aoclsparse_matrix A, aoclsparse_int row_idx, aoclsparse_int col_idx,
+                                        aoclsparse_double_complex val)
+{
+    return set_value<aoclsparse_double_complex>(A, row_idx, col_idx, val, aoclsparse_zmat);
+}
+aoclsparse_status aoclsparse_cupdate_values(aoclsparse_matrix A, aoclsparse_int len, aoclsparse_float_complex *val)
+{
+    return update_values<aoclsparse_float_complex>(A, len, val, aoclsparse_cmat);
+}
+aoclsparse_status aoclsparse_zupdate_values(aoclsparse_matrix A, aoclsparse_int len, aoclsparse_double_complex *val)
+{
+    return update_values<aoclsparse_double_complex>(A, len, val, aoclsparse_zmat);
+}
 aoclsparse_status aoclsparse_dupdate_values(aoclsparse_matrix A, aoclsparse_int len, double *val)
 {
     return update_values<double>(A, len, val, aoclsparse_dmat);
@@ -897,7 +948,7 @@ aoclsparse_status aoclsparse_copy(const aoclsparse_matrix src, const aoclsparse_
         return aoclsparse_status_invalid_size;
     if(src == *dest)
         return aoclsparse_status_invalid_pointer;
-    if(src->val_type != aoclsparse_dmat && src->val_type != aoclsparse_smat)
+    if(src->val_type < aoclsparse_dmat || src->val_type > aoclsparse_zmat)
         return aoclsparse_status_wrong_type;
     if(!src->user.ptr || !src->user.ind || !src->user.val)
         return aoclsparse_status_invalid_pointer;

@@ -74,7 +74,7 @@ extern "C" aoclsparse_status aoclsparse_optimize(aoclsparse_matrix A)
                 DeviceCsr *d = nullptr;
                 SpmvPlan  *p = nullptr;
                 st = ensure_spmv(A, h.trans != aoclsparse_operation_none, d, p);
-                if(st == aoclsparse_status_success && h.nop > 0)
+                if(st == aoclsparse_status_success && h.nop > 0 && !is_complex_type(A->val_type))
                 {
                     // the mv hint's format choice (analysis.cpp:146-382 picks br4 / ELLT-HYB / blocked CSR on
                     // the CPU): a SELL-64 copy when its padding is small

@@ -154,7 +154,7 @@ aoclsparse_status Runtime::staging(int slot, size_t bytes, void **out)
 
 size_t val_size(aoclsparse_matrix_data_type t)
 {
-    return t == aoclsparse_smat ? sizeof(float) : sizeof(double);
+    return t == aoclsparse_smat ? sizeof(float) : (t == aoclsparse_zmat ? 2 * sizeof(double) : sizeof(double)); // cmat: 2 floats
 }
 
 } // namespace mi355

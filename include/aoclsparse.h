@@ -415,6 +415,43 @@ DLL_PUBLIC aoclsparse_status aoclsparse_dtrsm_kid(const aoclsparse_operation tra
                                                   double                    *X,
                                                   aoclsparse_int             ldx,
                                                   const aoclsparse_int       kid);
+/* ---- complex handles: creation, export, mutation and y = alpha op(A) x + beta y for every
+ * descriptor type (general / symmetric / hermitian / triangular) and operation (N / T / H)
+ * (aoclsparse_auxiliary.h:340-345,419-436,735-741,804-822; aoclsparse_functions.h:1280-1296).  Every other
+ * executor returns wrong_type for a complex handle. */
+DLL_PUBLIC aoclsparse_status aoclsparse_create_ccsr(aoclsparse_matrix *mat, aoclsparse_index_base base,
+                                                    aoclsparse_int M, aoclsparse_int N, aoclsparse_int nnz,
+                                                    aoclsparse_int *row_ptr, aoclsparse_int *col_idx,
+                                                    aoclsparse_float_complex *val);
+DLL_PUBLIC aoclsparse_status aoclsparse_create_zcsr(aoclsparse_matrix *mat, aoclsparse_index_base base,
+                                                    aoclsparse_int M, aoclsparse_int N, aoclsparse_int nnz,
+                                                    aoclsparse_int *row_ptr, aoclsparse_int *col_idx,
+                                                    aoclsparse_double_complex *val);
+DLL_PUBLIC aoclsparse_status aoclsparse_export_ccsr(const aoclsparse_matrix mat, aoclsparse_index_base *base,
+                                                    aoclsparse_int *m, aoclsparse_int *n, aoclsparse_int *nnz,
+                                                    aoclsparse_int **row_ptr, aoclsparse_int **col_ind,
+                                                    aoclsparse_float_complex **val);
+DLL_PUBLIC aoclsparse_status aoclsparse_export_zcsr(const aoclsparse_matrix mat, aoclsparse_index_base *base,
+                                                    aoclsparse_int *m, aoclsparse_int *n, aoclsparse_int *nnz,
+                                                    aoclsparse_int **row_ptr, aoclsparse_int **col_ind,
+                                                    aoclsparse_double_complex **val);
+DLL_PUBLIC aoclsparse_status aoclsparse_cset_value(aoclsparse_matrix A, aoclsparse_int row_idx,
+                                                   aoclsparse_int col_idx, aoclsparse_float_complex val);
+DLL_PUBLIC aoclsparse_status aoclsparse_zset_value(aoclsparse_matrix A, aoclsparse_int row_idx,
+                                                   aoclsparse_int col_idx, aoclsparse_double_complex val);
+DLL_PUBLIC aoclsparse_status aoclsparse_cupdate_values(aoclsparse_matrix A, aoclsparse_int len,
+                                                       aoclsparse_float_complex *val);
+DLL_PUBLIC aoclsparse_status aoclsparse_zupdate_values(aoclsparse_matrix A, aoclsparse_int len,
+                                                       aoclsparse_double_complex *val);
+DLL_PUBLIC aoclsparse_status aoclsparse_cmv(aoclsparse_operation op, const aoclsparse_float_complex *alpha,
+                                            aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                            const aoclsparse_float_complex *x,
+                                            const aoclsparse_float_complex *beta, aoclsparse_float_complex *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_zmv(aoclsparse_operation op, const aoclsparse_double_complex *alpha,
+                                            aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                            const aoclsparse_double_complex *x,
+                                            const aoclsparse_double_complex *beta, aoclsparse_double_complex *y);
+
 /* ---- other input formats and structure conversions (aoclsparse_auxiliary.h:674-1095, aoclsparse_convert.h:494-660).
  * A CSC handle behaves like the CSR handle of the same matrix in every executor (its CSR is built at creation);
  * a COO handle can be exported, mutated and converted (aoclsparse_convert_csr), executors return not_implemented. */

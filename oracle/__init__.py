@@ -299,6 +299,35 @@ def dgmres(n, base, ptr, col, val, b, x0, restart, rtol, atol, maxit, precond):
     return st, x, rinfo
 
 
+def zmv(op, mtype, fill, diag, base, alpha, m, n, ptr, ind, val, x, beta, y):
+    """Complex y = alpha op(M) x + beta y, M assembled from a CLEAN CSR (sorted, unique) the way the reference's
+    doid dispatch reads it (level2/aoclsparse_mv.cpp:41-349, csrmv_kr.hpp:41-444): mtype 'general' | 'symmetric'
+    | 'hermitian' | 'triangular'; fill 'lower' | 'upper'; diag 'non_unit' | 'unit' | 'zero'; op 'n' | 't' | 'h'.
+    numpy restatement (complex128 accumulate; also used for complex64 inputs with a float32 tolerance)."""
+    ptr, ind = np.asarray(ptr, np.int64) - base, np.asarray(ind, np.int64) - base
+    val, x, y = np.asarray(val, np.complex128), np.asarray(x, np.complex128), np.asarray(y, np.complex128)
+    rows = np.repeat(np.arange(m), np.diff(ptr))
+    M = np.zeros((m, n), np.complex128)
+    if mtype == "general":
+        np.add.at(M, (rows, ind), val)
+    else:
+        strict = (ind < rows) if fill == "lower" else (ind > rows)
+        np.add.at(M, (rows[strict], ind[strict]), val[strict])
+        if mtype == "symmetric":
+            M = M + M.T
+        elif mtype == "hermitian":
+            M = M + M.conj().T
+        k = min(m, n)
+        if diag == "unit":
+            M[np.arange(k), np.arange(k)] += 1.0
+        elif diag == "non_unit":
+            d = ind == rows
+            np.add.at(M, (rows[d], ind[d]), val[d])
+    Mo = {"n": M, "t": M.T, "h": M.conj().T}[op]
+    scale = np.abs(alpha) * (np.abs(Mo) @ np.abs(x)) + np.abs(beta) * np.abs(y)
+    return alpha * (Mo @ x) + (beta * y if beta != 0 else 0.0), scale
+
+
 def dcsr2m(m, n, base_a, ptr_a, ind_a, val_a, base_b, ptr_b, ind_b, val_b):
     """C = A*B (general CSR x CSR); C is 0-based, columns in first-touch order."""
     ptr_a, ind_a, val_a = _i32(ptr_a), _i32(ind_a), _f64(val_a)

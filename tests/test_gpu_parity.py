@@ -1451,3 +1451,97 @@ def test_csc_handle_and_converted_coo_run_the_path():
     so, yr = oracle.dcsrmv(-1, 0, 1.0, m, len(v), v, ci, rp, x, 0.0, np.zeros(m))
     assert np.array_equal(y, yr)
     L.aoclsparse_destroy(ctypes.byref(hcsr)), L.aoclsparse_destroy(ctypes.byref(hcoo))
+
+
+# --------------------------------------------------------------------------------------------------
+# complex handles
+# --------------------------------------------------------------------------------------------------
+def _cplx_matrix(seed, m, n, maxlen, dtype):
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(0, maxlen, m)
+    lens[min(3, m - 1)] = 0
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ci = np.concatenate([np.sort(rng.choice(n, k, replace=False)) for k in lens] + [np.zeros(0, np.int64)]).astype(np.int32)
+    v = (rng.uniform(-1, 1, len(ci)) + 1j * rng.uniform(-1, 1, len(ci))).astype(dtype)
+    return rp, ci, v
+
+
+@pytest.mark.parametrize("prec", ["z", "c"])
+def test_complex_mv_every_descriptor_and_operation(prec):
+    """aoclsparse_zmv / aoclsparse_cmv: general (rectangular), symmetric, hermitian, triangular x N / T / H x fill x
+    diag, both index bases, host and device vectors, within (len + 8) eps of the restated operator."""
+    dtype, rdtype, eps = (np.complex128, np.float64, EPS64) if prec == "z" else (np.complex64, np.float32, EPS32)
+    create = L.aoclsparse_create_zcsr if prec == "z" else L.aoclsparse_create_ccsr
+    mv = L.aoclsparse_zmv if prec == "z" else L.aoclsparse_cmv
+    rng = np.random.default_rng(111)
+    alpha, beta = np.array([0.7 - 0.4j], dtype), np.array([-0.3 + 0.2j], dtype)
+    ops = {"n": P.OP_NONE, "t": P.OP_TRANSPOSE, "h": P.OP_CONJ_TRANSPOSE}
+    for base in (0, 1):
+        for (m, n, cases) in ((700, 640, [("general", "lower", "non_unit")]),
+                              (600, 600, [(t, f, dg) for t in ("symmetric", "hermitian", "triangular") for f in ("lower", "upper")
+                                          for dg in (("non_unit", "unit") if f == "lower" else ("non_unit", "zero"))])):
+            rp, ci, v = _cplx_matrix(112 + base, m, n, 19, dtype)
+            if m == n:  # full diagonal so that every diag type is meaningful
+                dense = np.zeros((m, n), dtype)
+                for i in range(m):
+                    dense[i, ci[rp[i]:rp[i + 1]]] = v[rp[i]:rp[i + 1]]
+                    dense[i, i] = 3.0  # real: a hermitian matrix has a real diagonal
+                rows = [np.flatnonzero(dense[i]) for i in range(m)]
+                rp = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+                ci = np.concatenate(rows).astype(np.int32)
+                v = np.concatenate([dense[i, r] for i, r in enumerate(rows)]).astype(dtype)
+            rpb, cib = rp + base, ci + base
+            h = ctypes.c_void_p()
+            assert create(ctypes.byref(h), base, m, n, len(v), P._ptr(rpb), P._ptr(cib), P._ptr(v)) == 0
+            lens = np.diff(rp)
+            for mtype, fill, diag in cases:
+                d = P.Descr(base=base, mtype={"general": 0, "symmetric": 1, "hermitian": 2, "triangular": 3}[mtype],
+                            fill=P.FILL_LOWER if fill == "lower" else P.FILL_UPPER,
+                            diag={"non_unit": 0, "unit": 1, "zero": 2}[diag])
+                for opn, op in ops.items():
+                    nx, ny = (n, m) if opn == "n" or mtype != "general" else (m, n)
+                    x = (rng.uniform(-1, 1, nx) + 1j * rng.uniform(-1, 1, nx)).astype(dtype)
+                    y0 = (rng.uniform(-1, 1, ny) + 1j * rng.uniform(-1, 1, ny)).astype(dtype)
+                    yr, scale = oracle.zmv(opn, mtype, fill, diag, base, alpha[0], m, n, rpb, cib, v, x, beta[0], y0)
+                    y = y0.copy()
+                    assert mv(op, P._ptr(alpha), h, d.h, P._ptr(x), P._ptr(beta), P._ptr(y)) == 0, (mtype, opn)
+                    bound = (2 * lens.max() + 16) * eps * (scale + 1e-30)
+                    assert np.all(np.abs(y - yr) <= bound), (prec, base, mtype, fill, diag, opn, np.max(np.abs(y - yr) / bound))
+                    yd = dev(y0)
+                    assert mv(op, P._ptr(alpha), h, d.h, P._ptr(dev(x)), P._ptr(beta), P._ptr(yd)) == 0
+                    torch.cuda.synchronize()
+                    assert np.array_equal(yd.cpu().numpy(), y)
+            # beta = 0 must not read y
+            zero, x = np.zeros(1, dtype), (rng.uniform(-1, 1, n)).astype(dtype)
+            y = np.full(m, np.nan + 1j * np.nan, dtype)
+            assert mv(P.OP_NONE, P._ptr(alpha), h, P.Descr(base=base).h, P._ptr(x), P._ptr(zero), P._ptr(y)) == 0
+            assert not np.any(np.isnan(y))
+            L.aoclsparse_destroy(ctypes.byref(h))
+
+
+def test_complex_handle_plumbing_and_type_checks():
+    rp, ci, v = _cplx_matrix(113, 40, 40, 6, np.complex128)
+    h = ctypes.c_void_p()
+    assert L.aoclsparse_create_zcsr(ctypes.byref(h), 0, 40, 40, len(v), P._ptr(rp), P._ptr(ci), P._ptr(v)) == 0
+    b_, m_, n_, z_ = ctypes.c_int(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    a1, a2, a3 = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    outs = (ctypes.byref(b_), ctypes.byref(m_), ctypes.byref(n_), ctypes.byref(z_), ctypes.byref(a1), ctypes.byref(a2), ctypes.byref(a3))
+    assert L.aoclsparse_export_zcsr(h, *outs) == 0 and a3.value == v.ctypes.data and z_.value == len(v)
+    assert L.aoclsparse_export_dcsr(h, *outs) == 9 and L.aoclsparse_export_ccsr(h, *outs) == 9
+    r = int(np.flatnonzero(np.diff(rp))[0])
+    assert L.aoclsparse_zset_value(h, r, int(ci[rp[r]]), P.CDouble(2.5, -1.5)) == 0 and v[rp[r]] == 2.5 - 1.5j
+    nv = (np.arange(len(v)) + 1j).astype(np.complex128)
+    assert L.aoclsparse_zupdate_values(h, len(v), P._ptr(nv)) == 0 and np.array_equal(v, nv)
+    d, one = P.Descr(), np.ones(1)
+    x, y = np.ones(40), np.zeros(40)
+    assert L.aoclsparse_dmv(P.OP_NONE, P._ptr(one), h, d.h, P._ptr(x), P._ptr(one), P._ptr(y)) == 9  # wrong_type
+    assert L.aoclsparse_cmv(P.OP_NONE, P._ptr(one), h, d.h, P._ptr(x), P._ptr(one), P._ptr(y)) == 9
+    assert L.aoclsparse_set_mv_hint(h, P.OP_NONE, d.h, 5) == 0 and L.aoclsparse_optimize(h) == 0
+    c = ctypes.c_void_p()
+    assert L.aoclsparse_copy(h, d.h, ctypes.byref(c)) == 0
+    xz, yz, a = (np.ones(40) + 0j), np.zeros(40, np.complex128), np.ones(1, np.complex128)
+    y2 = yz.copy()
+    assert L.aoclsparse_zmv(P.OP_NONE, P._ptr(a), h, d.h, P._ptr(xz), P._ptr(np.zeros(1, np.complex128)), P._ptr(yz)) == 0
+    assert L.aoclsparse_zmv(P.OP_NONE, P._ptr(a), c, d.h, P._ptr(xz), P._ptr(np.zeros(1, np.complex128)), P._ptr(y2)) == 0
+    assert np.array_equal(yz, y2) and np.allclose(yz, np.add.reduceat(nv, rp[:-1].clip(max=len(nv) - 1)) * (np.diff(rp) > 0))
+    L.aoclsparse_destroy(ctypes.byref(c)), L.aoclsparse_destroy(ctypes.byref(h))

@@ -395,3 +395,17 @@ def test_itsol_examples(kats):
     for precond in (0, 2):
         st, x, rinfo = oracle.dgmres(n, 0, rp, ci, v, b, np.ones(n), 7, 4.2e-8, 1e-10, 50, precond)
         assert st == 0 and np.max(np.abs(x - xe)) < 1e-6, (precond, st, rinfo[0], rinfo[30])
+
+
+def test_complex_mv_restatement_on_a_hand_checked_hermitian_matrix():
+    """3x3 hermitian H = [[2, 1-i, 0], [1+i, 3, 2i], [0, -2i, 1]] stored as its lower triangle: H x, H^T x = conj(H) x
+    and H^H x = H x worked out by hand."""
+    ptr, ind = [0, 1, 3, 5], [0, 0, 1, 1, 2]
+    val = [2, 1 + 1j, 3, -2j, 1]
+    x = np.array([1, 1j, 2])
+    y, _ = oracle.zmv("n", "hermitian", "lower", "non_unit", 0, 1.0, 3, 3, ptr, ind, val, x, 0.0, np.zeros(3))
+    assert np.allclose(y, [2 + (1 - 1j) * 1j, (1 + 1j) + 3j + 4j, -2j * 1j + 2])
+    yt, _ = oracle.zmv("t", "hermitian", "lower", "non_unit", 0, 1.0, 3, 3, ptr, ind, val, x, 0.0, np.zeros(3))
+    assert np.allclose(yt, [2 + (1 + 1j) * 1j, (1 - 1j) + 3j - 4j, 2j * 1j + 2])
+    yh, _ = oracle.zmv("h", "hermitian", "lower", "non_unit", 0, 1.0, 3, 3, ptr, ind, val, x, 0.0, np.zeros(3))
+    assert np.allclose(yh, y)
