@@ -115,6 +115,10 @@ SIGNATURES = {
     "aoclsparse_zset_value": (c_int, [_P, _I, _I, CDouble]),
     "aoclsparse_cupdate_values": (c_int, [_P, _I, _P]),
     "aoclsparse_zupdate_values": (c_int, [_P, _I, _P]),
+    "aoclsparse_ccsrmm": (c_int, [c_int, CFloat, _P, _P, c_int, _P, _I, _I, CFloat, _P, _I]),
+    "aoclsparse_zcsrmm": (c_int, [c_int, CDouble, _P, _P, c_int, _P, _I, _I, CDouble, _P, _I]),
+    "aoclsparse_ccsrmm_kid": (c_int, [c_int, CFloat, _P, _P, c_int, _P, _I, _I, CFloat, _P, _I, _I]),
+    "aoclsparse_zcsrmm_kid": (c_int, [c_int, CDouble, _P, _P, c_int, _P, _I, _I, CDouble, _P, _I, _I]),
     "aoclsparse_cmv": (c_int, [c_int, _P, _P, _P, _P, _P, _P]),
     "aoclsparse_zmv": (c_int, [c_int, _P, _P, _P, _P, _P, _P]),
     "aoclsparse_create_scsc": (c_int, [POINTER(_P), c_int, _I, _I, _I, _P, _P, _P]),

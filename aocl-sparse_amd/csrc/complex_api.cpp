@@ -101,9 +101,139 @@ aoclsparse_status cmv_t(aoclsparse_operation op, const cplx<R> *alpha, aoclspars
     return aoclsparse_status_success;
 }
 
+// aoclsparse_{c,z}csrmm: checks as level3/aoclsparse_csrmm.hpp:429-640 (same order as csrmm_api.cpp), operator
+// choice as in cmv_t
+template <typename R>
+aoclsparse_status ccsrmm_t(aoclsparse_operation op, const cplx<R> alpha, const aoclsparse_matrix A,
+                           const aoclsparse_mat_descr descr, aoclsparse_order order, const cplx<R> *B, aoclsparse_int n,
+                           aoclsparse_int ldb, const cplx<R> beta, cplx<R> *C, aoclsparse_int ldc, aoclsparse_int kid,
+                           aoclsparse_matrix_data_type vt)
+{
+    using Cx = cplx<R>;
+    if(!A || !B || !C || !descr)
+        return aoclsparse_status_invalid_pointer;
+    if(A->input_format != aoclsparse_csr_mat)
+        return aoclsparse_status_not_implemented;
+    if(op != aoclsparse_operation_none && op != aoclsparse_operation_transpose
+       && op != aoclsparse_operation_conjugate_transpose)
+        return aoclsparse_status_invalid_value;
+    const bool sym = descr->type == aoclsparse_matrix_type_symmetric, herm = descr->type == aoclsparse_matrix_type_hermitian;
+    if(descr->type != aoclsparse_matrix_type_general && !sym && !herm)
+        return aoclsparse_status_not_implemented;
+    if((sym || herm) && A->m != A->n)
+        return aoclsparse_status_invalid_size;
+    if(order != aoclsparse_order_row && order != aoclsparse_order_column)
+        return aoclsparse_status_invalid_value;
+    if(A->val_type != vt)
+        return aoclsparse_status_wrong_type;
+    if(descr->base != A->base)
+        return aoclsparse_status_invalid_value;
+    const aoclsparse_int m = A->m, k = A->n;
+    if(m < 0 || n < 0 || k < 0)
+        return aoclsparse_status_invalid_size;
+    if(m == 0 || n == 0 || k == 0)
+        return aoclsparse_status_success;
+    const bool a0 = alpha.re == R(0) && alpha.im == R(0), b0 = beta.re == R(0) && beta.im == R(0);
+    if(a0 && beta.re == R(1) && beta.im == R(0))
+        return aoclsparse_status_success;
+    if(!A->user.val || !A->user.ptr || !A->user.ind)
+        return aoclsparse_status_invalid_pointer;
+    const bool           tr     = op != aoclsparse_operation_none;
+    const bool           colmaj = order == aoclsparse_order_column;
+    const aoclsparse_int b_rows = tr ? m : k, m_c = tr ? k : m;
+    const aoclsparse_int chk_b = colmaj ? b_rows : n, chk_c = colmaj ? m_c : n;
+    if(ldb < (chk_b > 1 ? chk_b : 1) || ldc < (chk_c > 1 ? chk_c : 1))
+        return aoclsparse_status_invalid_size;
+    const long long c_outer = colmaj ? n : m_c, b_outer = colmaj ? n : b_rows;
+    if(c_outer * (long long)ldc > 2147483647LL || b_outer * (long long)ldb > 2147483647LL)
+        return aoclsparse_status_invalid_size;
+    if(kid > 3)
+        return aoclsparse_status_invalid_kid;
+
+    Runtime &rt = Runtime::get();
+    MI355_TRY(rt.init());
+    std::lock_guard<std::recursive_mutex> sl(rt.stage_lock);
+    StagedArg                             aB, aC;
+    MI355_TRY(aC.in(rt, 4, C, sizeof(Cx) * (size_t)c_outer * (size_t)ldc, true)); // padding of ldc survives
+    auto finish = [&]() -> aoclsparse_status {
+        MI355_TRY(aC.out(rt));
+        if(aC.staged)
+            MI355_HIP_TRY(hipStreamSynchronize(rt.stream()));
+        return aoclsparse_status_success;
+    };
+    if(a0)
+    {
+        MI355_TRY(launch_cscale_dense<R>(rt.stream(), order, static_cast<Cx *>(aC.dev), m_c, n, ldc, beta));
+        return finish();
+    }
+    (void)b0;
+    MI355_TRY(aB.in(rt, 3, B, sizeof(Cx) * (size_t)b_outer * (size_t)ldb, true));
+    DeviceCsr *d    = nullptr;
+    bool       conj = false;
+    if(sym || herm)
+    {
+        Derived *dv = nullptr;
+        MI355_TRY(ensure_derived(const_cast<aoclsparse_matrix>(A), descr->type, descr->fill_mode, descr->diag_type,
+                                 false, dv));
+        d    = &dv->dev;
+        conj = sym ? op == aoclsparse_operation_conjugate_transpose : op == aoclsparse_operation_transpose;
+    }
+    else
+    {
+        SpmvPlan *p = nullptr;
+        MI355_TRY(ensure_spmv(const_cast<aoclsparse_matrix>(A), tr, d, p));
+        conj = op == aoclsparse_operation_conjugate_transpose;
+    }
+    {
+        std::shared_lock<std::shared_mutex> r(A->guard);
+        MI355_TRY(launch_ccsrmm<R>(rt.stream(), order, d->base, conj, alpha, d->m, d->val.as<Cx>(),
+                                   d->ind.as<aoclsparse_int>(), d->ptr.as<aoclsparse_int>(),
+                                   static_cast<const Cx *>(aB.dev), n, ldb, beta, static_cast<Cx *>(aC.dev), ldc));
+    }
+    return finish();
+}
+
 } // namespace
 
 extern "C" {
+
+aoclsparse_status aoclsparse_ccsrmm(aoclsparse_operation op, const aoclsparse_float_complex alpha,
+                                    const aoclsparse_matrix A, const aoclsparse_mat_descr descr, aoclsparse_order order,
+                                    const aoclsparse_float_complex *B, aoclsparse_int n, aoclsparse_int ldb,
+                                    const aoclsparse_float_complex beta, aoclsparse_float_complex *C, aoclsparse_int ldc)
+{
+    return ccsrmm_t<float>(op, cfloat(alpha.real, alpha.imag), A, descr, order, reinterpret_cast<const cfloat *>(B), n,
+                           ldb, cfloat(beta.real, beta.imag), reinterpret_cast<cfloat *>(C), ldc, -1, aoclsparse_cmat);
+}
+aoclsparse_status aoclsparse_zcsrmm(aoclsparse_operation op, const aoclsparse_double_complex alpha,
+                                    const aoclsparse_matrix A, const aoclsparse_mat_descr descr, aoclsparse_order order,
+                                    const aoclsparse_double_complex *B, aoclsparse_int n, aoclsparse_int ldb,
+                                    const aoclsparse_double_complex beta, aoclsparse_double_complex *C,
+                                    aoclsparse_int ldc)
+{
+    return ccsrmm_t<double>(op, cdouble(alpha.real, alpha.imag), A, descr, order, reinterpret_cast<const cdouble *>(B),
+                            n, ldb, cdouble(beta.real, beta.imag), reinterpret_cast<cdouble *>(C), ldc, -1,
+                            aoclsparse_zmat);
+}
+aoclsparse_status aoclsparse_ccsrmm_kid(aoclsparse_operation op, const aoclsparse_float_complex alpha,
+                                        const aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                        aoclsparse_order order, const aoclsparse_float_complex *B, aoclsparse_int n,
+                                        aoclsparse_int ldb, const aoclsparse_float_complex beta,
+                                        aoclsparse_float_complex *C, aoclsparse_int ldc, const aoclsparse_int kid)
+{
+    return ccsrmm_t<float>(op, cfloat(alpha.real, alpha.imag), A, descr, order, reinterpret_cast<const cfloat *>(B), n,
+                           ldb, cfloat(beta.real, beta.imag), reinterpret_cast<cfloat *>(C), ldc, kid, aoclsparse_cmat);
+}
+aoclsparse_status aoclsparse_zcsrmm_kid(aoclsparse_operation op, const aoclsparse_double_complex alpha,
+                                        const aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                        aoclsparse_order order, const aoclsparse_double_complex *B, aoclsparse_int n,
+                                        aoclsparse_int ldb, const aoclsparse_double_complex beta,
+                                        aoclsparse_double_complex *C, aoclsparse_int ldc, const aoclsparse_int kid)
+{
+    return ccsrmm_t<double>(op, cdouble(alpha.real, alpha.imag), A, descr, order, reinterpret_cast<const cdouble *>(B),
+                            n, ldb, cdouble(beta.real, beta.imag), reinterpret_cast<cdouble *>(C), ldc, kid,
+                            aoclsparse_zmat);
+}
 
 aoclsparse_status aoclsparse_cmv(aoclsparse_operation op, const aoclsparse_float_complex *alpha, aoclsparse_matrix A,
                                  const aoclsparse_mat_descr descr, const aoclsparse_float_complex *x,

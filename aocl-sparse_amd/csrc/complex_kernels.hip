@@ -12,6 +12,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 namespace mi355
 {
 
@@ -94,7 +96,100 @@ __global__ void cscale_kernel(cplx<R> *y, aoclsparse_int n, cplx<R> beta)
         y[i] = (beta.re == R(0) && beta.im == R(0)) ? cplx<R>(R(0), R(0)) : c_mul(beta, y[i]);
 }
 
+// C = alpha op(A) B + beta C, dense B / C row- or column-major: one lane per output element, lanes of a workgroup
+// along the contiguous direction of C (columns for row-major, rows for column-major).  beta == 0 does not read C.
+template <typename R, bool COLMAJ>
+__global__ __launch_bounds__(256) void ccsrmm_kernel(int base, bool conj, cplx<R> alpha, aoclsparse_int m,
+                                                     const cplx<R> *__restrict__ val,
+                                                     const aoclsparse_int *__restrict__ col,
+                                                     const aoclsparse_int *__restrict__ row_ptr,
+                                                     const cplx<R> *__restrict__ B, aoclsparse_int n,
+                                                     aoclsparse_int ldb, cplx<R> beta, cplx<R> *__restrict__ C,
+                                                     aoclsparse_int ldc)
+{
+    const int i = COLMAJ ? blockIdx.x * blockDim.x + threadIdx.x : blockIdx.x * blockDim.y + threadIdx.y;
+    const int j = COLMAJ ? blockIdx.y * blockDim.y + threadIdx.y : blockIdx.y * blockDim.x + threadIdx.x;
+    if(i >= m || j >= n)
+        return;
+    cplx<R> acc(R(0), R(0));
+    for(int p = row_ptr[i] - base; p < row_ptr[i + 1] - base; p++)
+    {
+        cplx<R> a = val[p];
+        if(conj)
+            a.im = -a.im;
+        const size_t k = (size_t)(col[p] - base);
+        c_mac(acc, a, COLMAJ ? B[k + (size_t)j * ldb] : B[k * ldb + j]);
+    }
+    cplx<R> *cp = COLMAJ ? C + i + (size_t)j * ldc : C + (size_t)i * ldc + j;
+    cplx<R>  r  = c_mul(alpha, acc);
+    if(!(beta.re == R(0) && beta.im == R(0)))
+        c_mac(r, beta, *cp);
+    *cp = r;
+}
+
+template <typename R, bool COLMAJ>
+__global__ void cscale_dense_kernel(cplx<R> *C, aoclsparse_int inner, aoclsparse_int outer, aoclsparse_int ld,
+                                    cplx<R> beta)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, o = blockIdx.y;
+    if(i < inner && o < outer)
+    {
+        cplx<R> *cp = C + (size_t)o * ld + i;
+        *cp         = (beta.re == R(0) && beta.im == R(0)) ? cplx<R>(R(0), R(0)) : c_mul(beta, *cp);
+    }
+}
+
 } // namespace
+
+template <typename R>
+aoclsparse_status launch_ccsrmm(hipStream_t s, aoclsparse_order order, int base, bool conj, cplx<R> alpha,
+                                aoclsparse_int m, const cplx<R> *val, const aoclsparse_int *col,
+                                const aoclsparse_int *row_ptr, const cplx<R> *B, aoclsparse_int n, aoclsparse_int ldb,
+                                cplx<R> beta, cplx<R> *C, aoclsparse_int ldc)
+{
+    if(m <= 0 || n <= 0)
+        return aoclsparse_status_success;
+    if(order == aoclsparse_order_column)
+    {
+        // rows on grid.x (no 65535 limit), columns on grid.y in chunks of 4 -> loop over y chunks if needed
+        for(aoclsparse_int j0 = 0; j0 < n; j0 += 65535 * 4)
+        {
+            const aoclsparse_int nj = std::min<aoclsparse_int>(n - j0, 65535 * 4);
+            hipLaunchKernelGGL((ccsrmm_kernel<R, true>), dim3((m + 63) / 64, (nj + 3) / 4), dim3(64, 4), 0, s, base,
+                               conj, alpha, m, val, col, row_ptr, B + (size_t)j0 * ldb, nj, ldb, beta,
+                               C + (size_t)j0 * ldc, ldc);
+        }
+    }
+    else
+    {
+        const int tx = n >= 64 ? 64 : (n >= 16 ? 16 : 4), ty = 256 / tx;
+        for(aoclsparse_int j0 = 0; j0 < n; j0 += 65535 * tx)
+        {
+            const aoclsparse_int nj = std::min<aoclsparse_int>(n - j0, 65535 * tx);
+            hipLaunchKernelGGL((ccsrmm_kernel<R, false>), dim3((m + ty - 1) / ty, (nj + tx - 1) / tx), dim3(tx, ty), 0,
+                               s, base, conj, alpha, m, val, col, row_ptr, B + j0, nj, ldb, beta, C + j0, ldc);
+        }
+    }
+    MI355_HIP_TRY(hipGetLastError());
+    return aoclsparse_status_success;
+}
+
+template <typename R>
+aoclsparse_status launch_cscale_dense(hipStream_t s, aoclsparse_order order, cplx<R> *C, aoclsparse_int m,
+                                      aoclsparse_int n, aoclsparse_int ld, cplx<R> beta)
+{
+    const aoclsparse_int inner = order == aoclsparse_order_column ? m : n, outer = order == aoclsparse_order_column ? n : m;
+    if(inner <= 0 || outer <= 0)
+        return aoclsparse_status_success;
+    for(aoclsparse_int o0 = 0; o0 < outer; o0 += 65535)
+    {
+        const aoclsparse_int no = std::min<aoclsparse_int>(outer - o0, 65535);
+        hipLaunchKernelGGL((cscale_dense_kernel<R, true>), dim3((inner + 255) / 256, no), dim3(256), 0, s,
+                           C + (size_t)o0 * ld, inner, no, ld, beta);
+    }
+    MI355_HIP_TRY(hipGetLastError());
+    return aoclsparse_status_success;
+}
 
 template <typename R>
 aoclsparse_status launch_cspmv(hipStream_t s, int base, bool conj, cplx<R> alpha, aoclsparse_int m, aoclsparse_int nnz,
@@ -137,6 +232,18 @@ template aoclsparse_status launch_cspmv<float>(hipStream_t, int, bool, cfloat, a
 template aoclsparse_status launch_cspmv<double>(hipStream_t, int, bool, cdouble, aoclsparse_int, aoclsparse_int,
                                                 const cdouble *, const aoclsparse_int *, const aoclsparse_int *,
                                                 const cdouble *, cdouble, cdouble *);
+template aoclsparse_status launch_ccsrmm<float>(hipStream_t, aoclsparse_order, int, bool, cfloat, aoclsparse_int,
+                                                const cfloat *, const aoclsparse_int *, const aoclsparse_int *,
+                                                const cfloat *, aoclsparse_int, aoclsparse_int, cfloat, cfloat *,
+                                                aoclsparse_int);
+template aoclsparse_status launch_ccsrmm<double>(hipStream_t, aoclsparse_order, int, bool, cdouble, aoclsparse_int,
+                                                 const cdouble *, const aoclsparse_int *, const aoclsparse_int *,
+                                                 const cdouble *, aoclsparse_int, aoclsparse_int, cdouble, cdouble *,
+                                                 aoclsparse_int);
+template aoclsparse_status launch_cscale_dense<float>(hipStream_t, aoclsparse_order, cfloat *, aoclsparse_int,
+                                                      aoclsparse_int, aoclsparse_int, cfloat);
+template aoclsparse_status launch_cscale_dense<double>(hipStream_t, aoclsparse_order, cdouble *, aoclsparse_int,
+                                                       aoclsparse_int, aoclsparse_int, cdouble);
 template aoclsparse_status launch_cscale<float>(hipStream_t, cfloat *, aoclsparse_int, cfloat);
 template aoclsparse_status launch_cscale<double>(hipStream_t, cdouble *, aoclsparse_int, cdouble);
 

@@ -441,6 +441,14 @@ aoclsparse_status launch_cspmv(hipStream_t s, int base, bool conj, cplx<R> alpha
                                const cplx<R> *x, cplx<R> beta, cplx<R> *y);
 template <typename R>
 aoclsparse_status launch_cscale(hipStream_t s, cplx<R> *y, aoclsparse_int n, cplx<R> beta);
+template <typename R>
+aoclsparse_status launch_ccsrmm(hipStream_t s, aoclsparse_order order, int base, bool conj, cplx<R> alpha,
+                                aoclsparse_int m, const cplx<R> *val, const aoclsparse_int *col,
+                                const aoclsparse_int *row_ptr, const cplx<R> *B, aoclsparse_int n, aoclsparse_int ldb,
+                                cplx<R> beta, cplx<R> *C, aoclsparse_int ldc);
+template <typename R>
+aoclsparse_status launch_cscale_dense(hipStream_t s, aoclsparse_order order, cplx<R> *C, aoclsparse_int m,
+                                      aoclsparse_int n, aoclsparse_int ld, cplx<R> beta);
 
 // ELL family (ell_kernels.hip).  ellmv: row-major ELL, padding = column -1, double in the reference's
 // 4-lane order (ellmv.hpp:90-208), float in its scalar order (:34-85).  elltmv: column-major ELL, one

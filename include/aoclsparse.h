@@ -451,6 +451,33 @@ DLL_PUBLIC aoclsparse_status aoclsparse_zmv(aoclsparse_operation op, const aocls
                                             aoclsparse_matrix A, const aoclsparse_mat_descr descr,
                                             const aoclsparse_double_complex *x,
                                             const aoclsparse_double_complex *beta, aoclsparse_double_complex *y);
+/* C = alpha op(A) B + beta C for complex handles (aoclsparse_functions.h:2461-2484, :3398-3425): general,
+ * symmetric and hermitian descriptors, alpha / beta BY VALUE */
+DLL_PUBLIC aoclsparse_status aoclsparse_ccsrmm(aoclsparse_operation op, const aoclsparse_float_complex alpha,
+                                               const aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                               aoclsparse_order order, const aoclsparse_float_complex *B,
+                                               aoclsparse_int n, aoclsparse_int ldb,
+                                               const aoclsparse_float_complex beta, aoclsparse_float_complex *C,
+                                               aoclsparse_int ldc);
+DLL_PUBLIC aoclsparse_status aoclsparse_zcsrmm(aoclsparse_operation op, const aoclsparse_double_complex alpha,
+                                               const aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                               aoclsparse_order order, const aoclsparse_double_complex *B,
+                                               aoclsparse_int n, aoclsparse_int ldb,
+                                               const aoclsparse_double_complex beta, aoclsparse_double_complex *C,
+                                               aoclsparse_int ldc);
+DLL_PUBLIC aoclsparse_status aoclsparse_ccsrmm_kid(aoclsparse_operation op, const aoclsparse_float_complex alpha,
+                                                   const aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                                   aoclsparse_order order, const aoclsparse_float_complex *B,
+                                                   aoclsparse_int n, aoclsparse_int ldb,
+                                                   const aoclsparse_float_complex beta, aoclsparse_float_complex *C,
+                                                   aoclsparse_int ldc, const aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_zcsrmm_kid(aoclsparse_operation op, const aoclsparse_double_complex alpha,
+                                                   const aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                                   aoclsparse_order order, const aoclsparse_double_complex *B,
+                                                   aoclsparse_int n, aoclsparse_int ldb,
+                                                   const aoclsparse_double_complex beta,
+                                                   aoclsparse_double_complex *C, aoclsparse_int ldc,
+                                                   const aoclsparse_int kid);
 
 /* ---- other input formats and structure conversions (aoclsparse_auxiliary.h:674-1095, aoclsparse_convert.h:494-660).
  * A CSC handle behaves like the CSR handle of the same matrix in every executor (its CSR is built at creation);
