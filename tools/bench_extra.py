@@ -22,7 +22,7 @@ from bench import csrmm_bytes, spmv_bytes  # noqa: E402
 pkg = entry.load_package()
 L = pkg.lib()
 ap = argparse.ArgumentParser()
-ap.add_argument("--what", default="spmv,csrmm,trsv,cg,pcie")
+ap.add_argument("--what", default="spmv,csrmm,trsv,cg,next,pcie")
 ap.add_argument("--small", action="store_true", help="skip the two 50-120 M nnz stand-ins")
 args = ap.parse_args()
 what = set(args.what.split(","))
@@ -181,6 +181,86 @@ if "cg" in what:
              note="CPU = the restated reference loop, one thread (its level-1 steps are serial loops)")
         L.aoclsparse_itsol_destroy(ctypes.byref(h))
         del A
+
+if "next" in what:
+    # the SURVEY 8f rows, one line each: same device-resident setting as the headline, parity stated per line
+    import ctypes
+    L.aoclsparse_mi355_set_pointer_mode(pkg.PTR_DEVICE)
+    g = 2048
+    m, rp, ci, v = entry.laplace5(g)
+    nnz = len(v)
+    rng = np.random.default_rng(5)
+    xh = rng.uniform(-1, 1, m)
+    xd = torch.from_numpy(xh).to(dev)
+    so, yref = oracle.dcsrmv(-1, 0, 1.0, m, nnz, v, ci, rp, xh, 0.0, np.zeros(m), nthreads=oracle.max_threads())
+    one, zero = np.array([1.0]), np.array([0.0])
+    # ELLT twin (device arrays)
+    w, tc, tv = oracle.csr2ell("ellt", m, 0, rp, ci, v)
+    tcd, tvd, yd = torch.from_numpy(tc).to(dev), torch.from_numpy(tv).to(dev), torch.zeros(m, dtype=torch.float64, device=dev)
+    fn = lambda: L.aoclsparse_delltmv(pkg.OP_NONE, pkg._ptr(one), m, m, nnz, pkg._ptr(tvd), pkg._ptr(tcd), w, d0.h, pkg._ptr(xd),
+                                     pkg._ptr(zero), pkg._ptr(yd))
+    ms = time_calls(fn, 30)
+    emit(kind="next", op="aoclsparse_delltmv (device arrays)", system="5-pt Laplacian grid %d^2" % g, ms=round(ms, 4),
+         gbs_ell_bytes=round((m * w * 12 + 16 * m) / ms / 1e6, 1), bit_exact_vs_csr_scalar_order=bool(np.array_equal(yd.cpu().numpy(), yref)))
+    # dotmv
+    A = pkg.Matrix(0, m, m, rp, ci, v)
+    assert L.aoclsparse_set_mv_hint(A.h, pkg.OP_NONE, d0.h, 10) == 0 and L.aoclsparse_optimize(A.h) == 0
+    dd = torch.zeros(1, dtype=torch.float64, device=dev)
+    ms = time_calls(lambda: L.aoclsparse_ddotmv(pkg.OP_NONE, 1.0, A.h, d0.h, pkg._ptr(xd), 0.0, pkg._ptr(yd), pkg._ptr(dd)), 30)
+    emit(kind="next", op="aoclsparse_ddotmv", system="5-pt Laplacian grid %d^2" % g, ms=round(ms, 4),
+         y_bit_exact=bool(np.array_equal(yd.cpu().numpy(), yref)), dot_rel_err=float(abs(dd.item() - np.dot(xh, yref)) / abs(np.dot(xh, yref))))
+    # complex SpMV (same pattern, complex values)
+    vz = (v + 1j * rng.uniform(-1, 1, nnz)).astype(np.complex128)
+    hz = ctypes.c_void_p()
+    assert L.aoclsparse_create_zcsr(ctypes.byref(hz), 0, m, m, nnz, pkg._ptr(rp), pkg._ptr(ci), pkg._ptr(vz)) == 0
+    xz = torch.from_numpy((xh + 1j * rng.uniform(-1, 1, m)).astype(np.complex128)).to(dev)
+    yz = torch.zeros(m, dtype=torch.complex128, device=dev)
+    oz, zz = np.ones(1, np.complex128), np.zeros(1, np.complex128)
+    ms = time_calls(lambda: L.aoclsparse_zmv(pkg.OP_NONE, pkg._ptr(oz), hz, d0.h, pkg._ptr(xz), pkg._ptr(zz), pkg._ptr(yz)), 30)
+    zb = (m + 1 + nnz) * 4 + (2 * m + nnz) * 16
+    emit(kind="next", op="aoclsparse_zmv", system="5-pt Laplacian grid %d^2, complex values" % g, ms=round(ms, 4),
+         gbs=round(zb / ms / 1e6, 1), frac_of_8TBs=round(zb / ms / 1e6 / 8000, 4))
+    L.aoclsparse_destroy(ctypes.byref(hz))
+    del A, tcd, tvd
+    # symgs, ilu smoother, trsm on the 1000^2 Laplacian
+    g = 1000
+    m, rp, ci, v = entry.laplace5(g)
+    A = pkg.Matrix(0, m, m, rp, ci, v)
+    ds = pkg.Descr(mtype=pkg.TYPE_SYMMETRIC, fill=pkg.FILL_LOWER)
+    bh, x0 = rng.uniform(-1, 1, m), rng.uniform(-1, 1, m)
+    bd, xs = torch.from_numpy(bh).to(dev), torch.from_numpy(x0).to(dev)
+    ms = time_calls(lambda: L.aoclsparse_dsymgs(pkg.OP_NONE, A.h, ds.h, 1.0, pkg._ptr(bd), pkg._ptr(xs)), 5, 1)
+    o = oracle.dcsr_optimize(m, m, len(v), 0, rp, ci, v)
+    t0 = time.time()
+    so, xr = oracle.dsymgs(1, 0, 0, 0, 1.0, m, o["val"], o["ind"], o["ptr"], o["idiag"], o["iurow"], bh, x0)
+    emit(kind="next", op="aoclsparse_dsymgs (one sweep)", system="5-pt Laplacian grid %d^2" % g, ms=round(ms, 3),
+         cpu_serial_ms=round((time.time() - t0) * 1e3, 2))
+    pv = ctypes.c_void_p()
+    xi = torch.zeros(m, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    assert L.aoclsparse_dilu_smoother(pkg.OP_NONE, A.h, d0.h, ctypes.byref(pv), None, pkg._ptr(xi), pkg._ptr(bd)) == 0
+    torch.cuda.synchronize()
+    t_first = time.time() - t0
+    ms = time_calls(lambda: L.aoclsparse_dilu_smoother(pkg.OP_NONE, A.h, d0.h, ctypes.byref(pv), None, pkg._ptr(xi), pkg._ptr(bd)), 5, 1)
+    t0 = time.time()
+    so, lu, dg = oracle.dilu0(m, 0, rp, ci, v)
+    t_fac = time.time() - t0
+    t0 = time.time()
+    so, xr = oracle.dilu_solve(m, 0, dg, lu, rp, ci, bh)
+    emit(kind="next", op="aoclsparse_dilu_smoother", system="5-pt Laplacian grid %d^2" % g,
+         first_call_s=round(t_first, 3), first_call_includes="GPU factorisation (1,999 levels) + level analysis of both factors",
+         apply_ms=round(ms, 3), cpu_factorise_s=round(t_fac, 3), cpu_apply_ms=round((time.time() - t0) * 1e3, 2),
+         x_bit_exact=bool(np.array_equal(xi.cpu().numpy(), xr)))
+    nr = 8
+    dl = pkg.Descr(mtype=pkg.TYPE_TRIANGULAR, fill=pkg.FILL_LOWER)
+    Bd = torch.from_numpy(rng.uniform(-1, 1, (m, nr))).to(dev).contiguous()
+    Xd = torch.zeros((m, nr), dtype=torch.float64, device=dev)
+    ms = time_calls(lambda: L.aoclsparse_dtrsm(pkg.OP_NONE, 1.0, A.h, dl.h, pkg.ORDER_ROW, pkg._ptr(Bd), nr, nr, pkg._ptr(Xd), nr), 5, 1)
+    ms1 = time_calls(lambda: pkg.dtrsv(pkg.OP_NONE, 1.0, A, dl, bd, xi), 5, 1)
+    emit(kind="next", op="aoclsparse_dtrsm, %d right-hand sides (row-major)" % nr, system="lower triangle of the 5-pt Laplacian grid %d^2" % g,
+         ms=round(ms, 3), one_trsv_ms=round(ms1, 3), note="all columns share each launch; the reference loops trsv per column")
+    del A
 
 if "pcie" in what:
     L.aoclsparse_mi355_set_pointer_mode(pkg.PTR_AUTO)
