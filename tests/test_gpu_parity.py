@@ -1605,3 +1605,63 @@ def test_complex_csrmm(prec):
                         pad = Cb[:, mc:] if colmaj else Cb[:, n:]
                         assert beta == 0 or np.all(pad == 7 + 7j)
         L.aoclsparse_destroy(ctypes.byref(h))
+
+
+# --------------------------------------------------------------------------------------------------
+# BASELINE configs 4 and 5 at full size, through size-independent properties
+# --------------------------------------------------------------------------------------------------
+def test_csrmm_full_config_properties():
+    """Config 4: A = 5-pt Laplacian on 1000^2 (1M x 1M), B 1M x 256 fp64.  A * ones has a closed form (exact in
+    fp64), the product is linear in B (scaling by 2 is exact), and four columns are checked against the oracle."""
+    g, n = 1000, 256
+    m, rp, ci, v = laplace5(g)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    d = P.Descr()
+    assert L.aoclsparse_set_mm_hint(A.h, P.OP_NONE, d.h, 10) == 0 and L.aoclsparse_optimize(A.h) == 0
+    deg = (np.diff(rp) - 1).astype(np.float64)
+    for order, ld in ((P.ORDER_ROW, n), (P.ORDER_COLUMN, m)):
+        B = torch.ones(m * n, dtype=torch.float64, device="cuda")
+        # (finite garbage, not NaN: an exactly-zero result still reads C to get the reference's sign of zero)
+        C = torch.full((m * n,), 7.0, dtype=torch.float64, device="cuda")
+        assert P.dcsrmm(P.OP_NONE, 1.0, A, d, order, B, n, ld, 0.0, C, ld) == 0
+        torch.cuda.synchronize()
+        Cm = C.view(m, n) if order == P.ORDER_ROW else C.view(n, m).t()
+        expect = torch.from_numpy(4.0 - deg).cuda()
+        assert torch.equal(Cm[:, 0], expect) and torch.equal(Cm[:, n - 1], expect) and torch.equal(Cm.sum(dim=1), expect * n)
+        del B, C, Cm
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    B = torch.rand(m * n, dtype=torch.float64, device="cuda", generator=gen)
+    C1, C2 = torch.zeros_like(B), torch.zeros_like(B)
+    assert P.dcsrmm(P.OP_NONE, 1.0, A, d, P.ORDER_COLUMN, B, n, m, 0.0, C1, m) == 0
+    assert P.dcsrmm(P.OP_NONE, 1.0, A, d, P.ORDER_COLUMN, 2.0 * B, n, m, 0.0, C2, m) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(C2, 2.0 * C1)
+    for j in (0, 1, 100, 255):
+        so, cr = oracle.dcsrmm("col", 1.0, 0, v, ci, rp, m, B[j * m:(j + 1) * m].cpu().numpy(), 1, m, 0.0, np.zeros(m), m)
+        assert np.array_equal(C1[j * m:(j + 1) * m].cpu().numpy(), cr)
+
+
+def test_trsv_full_config_properties():
+    """Config 5 in its Laplacian form: unit-lower ILU(0) factor of the 1000^2 grid (1M rows, 1,999 levels).  The
+    solve is bit-identical to the serial CPU solve and L x reproduces b to a few ulps of the row scale."""
+    g = 1000
+    m, rp, ci, v = laplace5(g)
+    st, lu, dg = oracle.dilu0(m, 0, rp, ci, v)
+    assert st == 0
+    A = P.Matrix(0, m, m, rp, ci, lu)
+    dl = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=P.FILL_LOWER, diag=P.DIAG_UNIT)
+    assert L.aoclsparse_set_sv_hint(A.h, P.OP_NONE, dl.h, 10) == 0 and L.aoclsparse_optimize(A.h) == 0
+    assert A.trsv_levels(P.FILL_LOWER) == 2 * g - 1
+    b = np.random.default_rng(6).uniform(-1, 1, m)
+    bd, xd = dev(b), torch.zeros(m, dtype=torch.float64, device="cuda")
+    assert P.dtrsv(P.OP_NONE, 1.0, A, dl, bd, xd) == 0
+    torch.cuda.synchronize()
+    x = xd.cpu().numpy()
+    assert np.array_equal(x, oracle_trsv(0, m, rp, ci, lu, "lower", "n", True, 1.0, b))
+    # residual through the triangular product of the same handle: (L + I) x = b
+    yd = torch.zeros(m, dtype=torch.float64, device="cuda")
+    assert P.dmv(P.OP_NONE, 1.0, A, dl, xd, 0.0, yd) == 0
+    torch.cuda.synchronize()
+    r = np.abs(yd.cpu().numpy() - b)
+    assert r.max() <= 16 * EPS64 * max(1.0, np.abs(x).max())
