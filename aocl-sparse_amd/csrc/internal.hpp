@@ -173,6 +173,17 @@ struct SellPlan
     bool           wanted = false; // optimize chose SELL: rebuilt lazily after the values change
 };
 
+// merge-path tiling of a device CSR (mergepath_kernels.hip): tile w starts at {row ends, non-zeros} =
+// starts[2w], starts[2w+1]; two carry records per tile
+constexpr int MP_ITEMS = 1024; // rows + non-zeros per workgroup
+struct MergePlan
+{
+    aoclsparse_int ntiles = 0;
+    DeviceBuffer   starts; // (ntiles + 1) x {i, j}
+    DeviceBuffer   carry_row, carry_val; // 2 * ntiles each
+    bool           valid = false, tried = false;
+};
+
 // SpMV execution plan (CSR-Adaptive row blocks), see spmv_kernels.hip
 struct SpmvPlan
 {
@@ -183,6 +194,7 @@ struct SpmvPlan
     DeviceBuffer   rowblocks; // nblocks+1 entries {first row, first non-zero (0-based)}
     bool           valid = false;
     SellPlan       sell;
+    MergePlan      merge;
 };
 
 // TRSV plan of one (triangle, op) pair (trsv_api.cpp / trsv_kernels.hip): the strict triangle
@@ -401,6 +413,9 @@ aoclsparse_status ensure_trsv(aoclsparse_matrix A, bool upper, bool transposed);
 // SELL-64 copy of d (row_ptr_host = the host row pointer d mirrors); leaves plan.sell.valid false when the
 // padding would exceed the budget (AOCLSPARSE_MI355_SELL=0 never, =1 always)
 aoclsparse_status build_sell(const aoclsparse_int *row_ptr_host, const DeviceCsr &d, size_t vsize, SpmvPlan &plan);
+// merge-path tiling (host binary searches over row_ptr_host); built only when AOCLSPARSE_MI355_SPMV_KERNEL=merge
+aoclsparse_status build_merge_plan(aoclsparse_int m, aoclsparse_int nnz, aoclsparse_index_base base,
+                                   const aoclsparse_int *row_ptr_host, size_t vsize, SpmvPlan &plan);
 aoclsparse_status build_spmv_plan(aoclsparse_int m, aoclsparse_int nnz, aoclsparse_index_base base,
                                   const aoclsparse_int *row_ptr_host, SpmvPlan &plan);
 
@@ -419,6 +434,10 @@ template <typename T>
 aoclsparse_status launch_sellmv(hipStream_t s, int order, int pack, T alpha, aoclsparse_int m, aoclsparse_int nslices,
                                 const long long *slice_ptr, const T *sval, const aoclsparse_int *scol,
                                 const aoclsparse_int *rowlen, const T *x, T beta, T *y);
+template <typename T>
+aoclsparse_status launch_mergepath(hipStream_t s, int base, T alpha, aoclsparse_int ntiles, const aoclsparse_int *starts,
+                                   const T *val, const aoclsparse_int *col, const aoclsparse_int *row_ptr, const T *x,
+                                   T beta, T *y, aoclsparse_int *carry_row, T *carry_val);
 template <typename T>
 aoclsparse_status launch_scale(hipStream_t s, T *y, aoclsparse_int n, T beta);
 // w = a*x + b*y elementwise (w may alias x or y); a == 1, b == -1 is an exact subtraction

@@ -521,6 +521,70 @@ aoclsparse_status build_sell(const aoclsparse_int *row_ptr_host, const DeviceCsr
     return aoclsparse_status_success;
 }
 
+// 0 auto, 1 CSR-Adaptive always, 2 merge-path whenever it can serve the request
+// (read at plan-build time, i.e. once per handle and operator)
+static int spmv_kernel_choice()
+{
+    const char *e = getenv("AOCLSPARSE_MI355_SPMV_KERNEL");
+    if(!e)
+        return 0;
+    return !strcmp(e, "merge") ? 2 : (!strcmp(e, "adaptive") ? 1 : 0);
+}
+
+aoclsparse_status build_merge_plan(aoclsparse_int m, aoclsparse_int nnz, aoclsparse_index_base base,
+                                   const aoclsparse_int *ptr, size_t vsize, SpmvPlan &plan)
+{
+    MergePlan &mp = plan.merge;
+    if(mp.valid || mp.tried)
+        return aoclsparse_status_success;
+    mp.tried = true;
+    const int choice = spmv_kernel_choice();
+    if(m <= 0 || nnz <= 0)
+        return aoclsparse_status_success;
+    // auto never selects it: measured on the MI355X it loses to the row-block kernel on both power-law stand-ins
+    // (44.2 vs 29.5 us web-like, 14.3 vs 11.4 us circuit-like -- DESIGN.md section 5.2), so it is opt-in
+    if(choice != 2)
+        return aoclsparse_status_success;
+    const long long             items  = (long long)m + nnz;
+    const aoclsparse_int        ntiles = (aoclsparse_int)((items + MP_ITEMS - 1) / MP_ITEMS);
+    std::vector<aoclsparse_int> st;
+    try
+    {
+        st.resize(2 * ((size_t)ntiles + 1));
+    }
+    catch(const std::bad_alloc &)
+    {
+        return aoclsparse_status_memory_error;
+    }
+    for(aoclsparse_int w = 0; w <= ntiles; w++)
+    {
+        // merge-path search on diagonal d: the largest i with (row end i-1) <= (d - i) consumed non-zeros
+        const long long d  = std::min<long long>((long long)w * MP_ITEMS, items);
+        long long       lo = std::max<long long>(0, d - nnz), hi = std::min<long long>(d, m);
+        while(lo < hi)
+        {
+            const long long mid = (lo + hi) / 2;
+            if((long long)(ptr[mid + 1] - base) <= d - mid - 1)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        st[2 * (size_t)w]     = (aoclsparse_int)lo;
+        st[2 * (size_t)w + 1] = (aoclsparse_int)(d - lo);
+    }
+    Runtime          &rt = Runtime::get();
+    aoclsparse_status s1 = mp.starts.upload(st.data(), sizeof(aoclsparse_int) * st.size(), rt.stream());
+    if(s1 == aoclsparse_status_success)
+        s1 = mp.carry_row.alloc(sizeof(aoclsparse_int) * 2 * (size_t)ntiles);
+    if(s1 == aoclsparse_status_success)
+        s1 = mp.carry_val.alloc(vsize * 2 * (size_t)ntiles);
+    if(s1 != aoclsparse_status_success)
+        return s1;
+    mp.ntiles = ntiles;
+    mp.valid  = true;
+    return aoclsparse_status_success;
+}
+
 aoclsparse_status ensure_spmv(aoclsparse_matrix A, bool transposed, DeviceCsr *&dcsr, SpmvPlan *&plan)
 {
     dcsr = transposed ? &A->dev_trans : &A->dev_user;
@@ -547,6 +611,12 @@ aoclsparse_status ensure_spmv(aoclsparse_matrix A, bool transposed, DeviceCsr *&
     if(!plan->valid)
     {
         aoclsparse_status st = build_spmv_plan(h.m, h.ptr[h.m] - h.base, h.base, h.ptr, *plan);
+        if(st != aoclsparse_status_success)
+            return st;
+    }
+    if(!is_complex_type(A->val_type))
+    {
+        aoclsparse_status st = build_merge_plan(h.m, h.ptr[h.m] - h.base, h.base, h.ptr, val_size(A->val_type), *plan);
         if(st != aoclsparse_status_success)
             return st;
     }

@@ -46,7 +46,7 @@ DLL_PUBLIC aoclsparse_status aoclsparse_mi355_export_diag(const aoclsparse_matri
                                                           aoclsparse_int         *is_internal);
 typedef struct aoclsparse_mi355_spmv_info_
 {
-    aoclsparse_int kernel; /* 0 none yet, 1 csr-adaptive stream, 3 SELL-64 (mv hint + optimize) */
+    aoclsparse_int kernel; /* 0 none yet, 1 csr-adaptive stream, 2 merge-path (scalar order, no pinned kid; else 1), 3 SELL-64 (mv hint + optimize) */
     aoclsparse_int order; /* 0 scalar chain (kid 0), 1 4-lane (kid 1/2), 2 8-lane (kid 3) */
     aoclsparse_int row_blocks; /* workgroups per launch */
     aoclsparse_int tile; /* non-zeros staged in LDS per workgroup */

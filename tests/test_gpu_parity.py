@@ -133,6 +133,90 @@ def test_power_law_rows_with_long_rows_strict_and_auto():
     assert st == 0 and np.array_equal(ys, yr)
 
 
+def _merge_cut_rows(rp, base, items=1024):
+    """rows cut by a merge-path tile boundary (tiles of `items` row-ends + non-zeros)."""
+    m = len(rp) - 1
+    end = rp[1:].astype(np.int64) - base
+    key = end + np.arange(m)  # strictly increasing: merge-path position of row end i
+    d = np.arange(0, m + end[-1] + items, items)
+    d = d[d <= m + end[-1]]
+    i = np.searchsorted(key, d, side="left")
+    j = d - i
+    ok = i < m
+    cut = np.zeros(m, dtype=bool)
+    ii = i[ok]
+    cut[ii[(rp[ii].astype(np.int64) - base) < j[ok]]] = True
+    return cut
+
+
+@pytest.fixture
+def merge_kernel():
+    os.environ["AOCLSPARSE_MI355_SPMV_KERNEL"] = "merge"
+    yield
+    del os.environ["AOCLSPARSE_MI355_SPMV_KERNEL"]
+
+
+@pytest.mark.parametrize("base", [0, 1])
+def test_merge_path_kernel_power_law(merge_kernel, base):
+    """merge-path tiles (AOCLSPARSE_MI355_SPMV_KERNEL=merge): rows inside one tile follow the reference's scalar
+    order bit for bit; a row cut by tile boundaries is the ordered sum of its pieces' chains -- bound
+    (pieces + len) * eps * sum|a||x|."""
+    m = n = 30000
+    rp, ci, v = random_csr(121, m, n, lambda r, i: 9000 if i in (0, 17, 20011) else (
+        2500 if i == m - 1 else (0 if i % 7 == 3 else powerlaw_rows(6, 400)(r, i))), base=base)
+    assert len(v) <= 10 * m
+    x = np.random.default_rng(7).uniform(-1, 1, n)
+    y0 = np.random.default_rng(8).uniform(-1, 1, m)
+    d = P.Descr(base=base)
+    A = P.Matrix(base, m, n, rp, ci, v)
+    for alpha, beta in ((1.0, 0.0), (-0.75, 1.5)):
+        st, y = run_dmv(A, d, x, y0, alpha, beta)
+        assert st == 0 and A.spmv_info().kernel == 2
+        so, yr = oracle.dcsrmv(-1, base, alpha, m, len(v), v, ci, rp, x, beta, y0)
+        cut = _merge_cut_rows(rp, base)
+        assert 3 <= cut.sum() < 200
+        assert np.array_equal(y[~cut], yr[~cut])
+        lens = np.diff(rp)
+        scale = abs(alpha) * abs_row_sums(rp, ci, v, x, base) + abs(beta * y0)
+        c = lens + lens / 1024.0 + 6
+        assert np.all(np.abs(y - yr) <= c * EPS64 * scale + 1e-300)
+    # a pinned kid keeps the strict order: served by the row-block kernel, cut rows included
+    B = P.Matrix(base, m, n, rp, ci, v)
+    assert L.aoclsparse_set_mv_hint_kid(B.h, P.OP_NONE, d.h, 0, 0) == 0
+    st, ys = run_dmv(B, d, x, y0, 1.0, 0.0)
+    so, yr = oracle.dcsrmv(-1, base, 1.0, m, len(v), v, ci, rp, x, 0.0, y0)
+    assert st == 0 and np.array_equal(ys, yr)
+
+
+def test_merge_path_kernel_edges(merge_kernel):
+    d = P.Descr()
+    # smaller than one tile; trailing and leading empty rows; one row spanning many tiles; rectangular
+    for seed, m, n, rl in ((1, 40, 60, lambda r, i: r.integers(0, 9)),
+                           (2, 5000, 300, lambda r, i: 0 if (i < 1100 or i > 3900) else r.integers(0, 12)),
+                           (3, 3000, 20000, lambda r, i: 15000 if i == 1500 else 1),
+                           (4, 1024, 1024, lambda r, i: 0)):
+        rp, ci, v = random_csr(seed, m, n, rl)
+        if len(v) == 0:
+            ci, v = np.zeros(1, np.int32), np.zeros(1)
+        x = np.random.default_rng(3).uniform(-1, 1, n)
+        y0 = np.random.default_rng(4).uniform(-1, 1, m)
+        A = P.Matrix(0, m, n, rp, ci, v)
+        st, y = run_dmv(A, d, x, y0, 2.0, 0.5)
+        so, yr = oracle.dcsrmv(-1, 0, 2.0, m, int(rp[-1]), v, ci, rp, x, 0.5, y0)
+        assert st == 0
+        cut = _merge_cut_rows(rp, 0) if rp[-1] > 0 else np.zeros(m, bool)
+        assert np.array_equal(y[~cut], yr[~cut])
+        scale = 2.0 * abs_row_sums(rp, ci, v, x) + abs(0.5 * y0)
+        assert np.all(np.abs(y - yr) <= (np.diff(rp) + 24) * EPS64 * scale + 1e-300)
+    # a wide matrix (nnz > 10 m) runs the lane orders: the row-block kernel serves it, bit-exact
+    rp, ci, v = random_csr(5, 2000, 2000, lambda r, i: r.integers(20, 40))
+    x = np.random.default_rng(3).uniform(-1, 1, 2000)
+    A = P.Matrix(0, 2000, 2000, rp, ci, v)
+    st, y = run_dmv(A, d, x, np.zeros(2000), 1.0, 0.0)
+    so, yr = oracle.dcsrmv(-1, 0, 1.0, 2000, len(v), v, ci, rp, x, 0.0, np.zeros(2000))
+    assert st == 0 and np.array_equal(y, yr)
+
+
 @pytest.mark.parametrize("kid,order", [(3, "lane8"), (1, "lane4")])
 def test_long_rows_strict_lane_orders(kid, order):
     m, n = 300, 60000

@@ -14,7 +14,7 @@ for name in sys.argv[1:] or ["web-like", "circuit-like"]:
     m, rp, ci, v = standins.ALL[name](); nnz = len(v)
     lens = np.diff(rp)
     x = torch.from_numpy(np.random.default_rng(1).uniform(-1, 1, m)).to(dev); y = torch.zeros(m, dtype=torch.float64, device=dev)
-    A = pkg.Matrix(0, m, m, rp, ci, v)
+    A = pkg.Matrix(0, m, m, rp, ci, v)  # AOCLSPARSE_MI355_SPMV_KERNEL=merge|adaptive picks the kernel
     assert L.aoclsparse_set_mv_hint(A.h, pkg.OP_NONE, d0.h, 100) == 0 and L.aoclsparse_optimize(A.h) == 0
     info = A.spmv_info()
     for _ in range(5): pkg.dmv(pkg.OP_NONE, 1.0, A, d0, x, 0.0, y)
