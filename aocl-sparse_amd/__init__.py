@@ -139,6 +139,9 @@ SIGNATURES = {
     "aoclsparse_delltmv": (c_int, [c_int, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
     "aoclsparse_sellthybmv": (c_int, [c_int, _P, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "aoclsparse_dellthybmv": (c_int, [c_int, _P, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "aoclsparse_dblkcsrmv": (c_int, [c_int, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I]),
+    "aoclsparse_opt_blksize": (_I, [_I, _I, c_int, _P, _P, _P]),
+    "aoclsparse_csr2blkcsr": (c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, c_int]),
     "aoclsparse_csr2ell_width": (c_int, [_I, _I, _P, _P]),
     "aoclsparse_csr2ellthyb_width": (c_int, [_I, _I, _P, _P, _P]),
     "aoclsparse_scsr2ell": (c_int, [_I, _P, _P, _P, _P, _P, _P, _I]),

@@ -331,7 +331,7 @@ private:
     bool         inited_ = false;
     aoclsparse_status init_status_ = aoclsparse_status_success;
     hipStream_t  stream_ = nullptr;
-    DeviceBuffer stage_[16]; // 0-7: csrmv / mv / trsv / dotmv, 8-15: ELL family (ell_api.cpp)
+    DeviceBuffer stage_[16]; // 0-7: csrmv / mv / trsv / dotmv, 8-15: ELL family and BLKCSR (ell_api.cpp, blk_api.cpp)
 };
 
 // While one of these is alive on a thread, every pointer handed to the executors by that thread is
@@ -434,6 +434,14 @@ template <typename T>
 aoclsparse_status launch_sellmv(hipStream_t s, int order, int pack, T alpha, aoclsparse_int m, aoclsparse_int nslices,
                                 const long long *slice_ptr, const T *sval, const aoclsparse_int *scol,
                                 const aoclsparse_int *rowlen, const T *x, T beta, T *y);
+// BLKCSR (blk_kernels.hip): value offset of every block (three small launches: per-chunk popcount scan, scan of
+// the chunk totals in part[], add), then the product
+constexpr int     BLK_PART_SHIFT = 10;
+aoclsparse_status launch_blk_valoff(hipStream_t s, aoclsparse_int nblk, int rows, const uint8_t *masks,
+                                    aoclsparse_int *valoff, aoclsparse_int *part);
+aoclsparse_status launch_blkcsrmv(hipStream_t s, int base, double alpha, aoclsparse_int m, int rows, const uint8_t *masks,
+                                  const double *val, const aoclsparse_int *col, const aoclsparse_int *row_ptr,
+                                  const aoclsparse_int *valoff, const double *x, double beta, double *y);
 template <typename T>
 aoclsparse_status launch_mergepath(hipStream_t s, int base, T alpha, aoclsparse_int ntiles, const aoclsparse_int *starts,
                                    const T *val, const aoclsparse_int *col, const aoclsparse_int *row_ptr, const T *x,

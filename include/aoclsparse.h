@@ -569,6 +569,24 @@ DLL_PUBLIC aoclsparse_status aoclsparse_dellthybmv(aoclsparse_operation trans, c
                                                    aoclsparse_int *csr_row_idx_map,
                                                    const aoclsparse_mat_descr descr, const double *x,
                                                    const double *beta, double *y);
+/* BLKCSR: 1/2/4 x 8 blocks with one bit mask per sub-row (reference: aoclsparse_functions.h:887-900,
+ * aoclsparse_convert.h:560-626; convert.cpp:36-310).  opt_blksize / csr2blkcsr are host routines. */
+DLL_PUBLIC aoclsparse_status aoclsparse_dblkcsrmv(aoclsparse_operation trans, const double *alpha,
+                                                  aoclsparse_int m, aoclsparse_int n, aoclsparse_int nnz,
+                                                  const uint8_t *masks, const double *blk_csr_val,
+                                                  const aoclsparse_int *blk_col_ind,
+                                                  const aoclsparse_int *blk_row_ptr,
+                                                  const aoclsparse_mat_descr descr, const double *x,
+                                                  const double *beta, double *y, aoclsparse_int nRowsblk);
+DLL_PUBLIC aoclsparse_int aoclsparse_opt_blksize(aoclsparse_int m, aoclsparse_int nnz, aoclsparse_index_base base,
+                                                 const aoclsparse_int *csr_row_ptr,
+                                                 const aoclsparse_int *csr_col_ind, aoclsparse_int *total_blks);
+DLL_PUBLIC aoclsparse_status aoclsparse_csr2blkcsr(aoclsparse_int m, aoclsparse_int n, aoclsparse_int nnz,
+                                                   const aoclsparse_int *csr_row_ptr,
+                                                   const aoclsparse_int *csr_col_ind, const double *csr_val,
+                                                   aoclsparse_int *blk_row_ptr, aoclsparse_int *blk_col_ind,
+                                                   double *blk_csr_val, uint8_t *masks, aoclsparse_int nRowsblk,
+                                                   aoclsparse_index_base base);
 DLL_PUBLIC aoclsparse_status aoclsparse_csr2ell_width(aoclsparse_int m, aoclsparse_int nnz,
                                                       const aoclsparse_int *csr_row_ptr, aoclsparse_int *ell_width);
 DLL_PUBLIC aoclsparse_status aoclsparse_csr2ellthyb_width(aoclsparse_int m, aoclsparse_int nnz,

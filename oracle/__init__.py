@@ -281,6 +281,39 @@ def dellthybmv(base, alpha, m, ell_val, ell_col, width, ell_m, csr_val, csr_row,
     return st, y
 
 
+def opt_blksize(m, nnz, base, row_ptr, col_ind):
+    """-> (rows_blk or 0, total blocks)"""
+    row_ptr, col_ind = _i32(row_ptr), _i32(col_ind)
+    tot = c_i32(0)
+    fn = lib().orc_opt_blksize
+    fn.restype = c_i32
+    r = fn(c_i32(m), c_i32(nnz), c_int(base), _p(row_ptr), _p(col_ind), ctypes.byref(tot))
+    return r, tot.value
+
+
+def csr2blkcsr(m, n, base, row_ptr, col_ind, val, rows_blk):
+    """-> (status, blk_row_ptr, blk_col_ind, blk_val, masks) trimmed to the blocks produced"""
+    row_ptr, col_ind, val = _i32(row_ptr), _i32(col_ind), _f64(val)
+    nnz = len(val)
+    brp = np.zeros(m + 1, np.int32)
+    bc = np.zeros(max(1, nnz), np.int32)
+    bv = np.zeros(nnz + rows_blk * 8, np.float64)
+    mk = np.zeros(max(1, nnz) * rows_blk + rows_blk * 8, np.uint8)
+    nb = c_i32(0)
+    st = lib().orc_dcsr2blkcsr(c_i32(m), c_i32(n), c_i32(nnz), _p(row_ptr), _p(col_ind), _p(val), _p(brp), _p(bc), _p(bv),
+                               _p(mk), c_i32(rows_blk), c_int(base), ctypes.byref(nb))
+    return st, brp, bc[: nb.value], bv[:nnz], mk[: nb.value * rows_blk]
+
+
+def dblkcsrmv(base, alpha, m, masks, blk_val, blk_col, blk_row_ptr, x, beta, y, rows_blk):
+    masks = np.ascontiguousarray(masks, dtype=np.uint8)
+    blk_val, blk_col, blk_row_ptr, x = _f64(blk_val), _i32(blk_col), _i32(blk_row_ptr), _f64(x)
+    y = _f64(y).copy()
+    st = lib().orc_dblkcsrmv(c_int(base), c_dbl(alpha), c_i32(m), _p(masks), _p(blk_val), _p(blk_col), _p(blk_row_ptr),
+                             _p(x), c_dbl(beta), _p(y), c_i32(rows_blk))
+    return st, y
+
+
 def dcg(n, base, ptr, col, val, idiag, iurow, b, x0, rtol, atol, maxit, precond):
     """CG on a clean CSR holding the whole symmetric matrix; precond 0 none / 3 SymGS -> (status, x, rinfo)."""
     ptr, col, val, idiag, iurow, b = _i32(ptr), _i32(col), _f64(val), _i32(idiag), _i32(iurow), _f64(b)

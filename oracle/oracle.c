@@ -1090,6 +1090,163 @@ int orc_dellthybmv(int base, double alpha, oint m, const double *ell_val, const 
     free(ytmp);
     return ORC_SUCCESS;
 }
+/* ---- BLKCSR ------------------------------------------------------------------------------------------
+ * walk of one row block, shared by the block count (convert.cpp:71-107) and the conversion (:214-283):
+ * every pass opens a window of 8 columns at the smallest unread column of the block's sub-rows and consumes
+ * every entry of every sub-row that falls inside it. */
+static oint blk_min_col(oint rows, oint i0, oint m, int base, const oint *row_ptr, const oint *col, const oint *pos)
+{
+    oint c = 0x7fffffff;
+    for(oint r = 0; r < rows && i0 + r < m; r++)
+        if(pos[r] < row_ptr[i0 + r + 1] - base && col[pos[r]] - base < c)
+            c = col[pos[r]] - base;
+    return c;
+}
+/* aoclsparse_opt_blksize, convert.cpp:36-147 */
+oint orc_opt_blksize(oint m, oint nnz, int base, const oint *row_ptr, const oint *col_ind, oint *total_blks)
+{
+    if(m <= 0 || nnz <= 0 || !row_ptr || !col_ind || !total_blks)
+        return 0;
+    static const oint factor[3] = {1, 2, 4};
+    oint   total[3];
+    double per[3], util[3], inc[2] = {0, 0};
+    double nnzpr = (double)nnz / m;
+    for(int f = 0; f < 3; f++)
+    {
+        oint rows = factor[f], blocks = 0;
+        for(oint i0 = 0; i0 < m; i0 += rows)
+        {
+            oint pos[4] = {0, 0, 0, 0};
+            for(oint r = 0; r < rows && i0 + r < m; r++)
+                pos[r] = row_ptr[i0 + r] - base;
+            for(;;)
+            {
+                oint c = blk_min_col(rows, i0, m, base, row_ptr, col_ind, pos);
+                if(c == 0x7fffffff)
+                    break;
+                for(oint r = 0; r < rows && i0 + r < m; r++)
+                    while(pos[r] < row_ptr[i0 + r + 1] - base && col_ind[pos[r]] - base < c + 8)
+                        pos[r]++;
+                blocks++;
+            }
+        }
+        total[f] = blocks;
+        if(blocks == 0)
+            return 0;
+        per[f]  = (double)nnz / (double)blocks;
+        util[f] = per[f] / ((double)rows * 8) * 100;
+        if((nnzpr < 30 && util[0] < 40) || (nnzpr > 30 && util[0] < 50))
+            return 0;
+        if(f)
+            inc[f - 1] = (per[f] - per[f - 1]) / per[f - 1] * 100;
+    }
+    /* the reference calls the INTEGER abs() on both differences (convert.cpp:128-129): they are truncated */
+    double d_blks = (double)abs((int)(inc[0] - inc[1]));
+    double d_util = (double)abs((int)(util[1] - util[2]));
+    if(util[2] > 24 && (d_blks < 12.5 || d_util < 12.5) && inc[1] > 51)
+    {
+        *total_blks = total[2];
+        return 4;
+    }
+    if(util[1] > 28)
+    {
+        *total_blks = total[1];
+        return 2;
+    }
+    return 0;
+}
+/* aoclsparse_csr2blkcsr, convert.cpp:149-310.  Values are appended sub-row by sub-row inside a block; a
+ * window that would run past column n is re-anchored at n-8 and its masks shifted left accordingly. */
+int orc_dcsr2blkcsr(oint m, oint n, oint nnz, const oint *row_ptr, const oint *col_ind, const double *val,
+                    oint *blk_row_ptr, oint *blk_col, double *blk_val, unsigned char *masks, oint rows,
+                    int base, oint *nblk)
+{
+    if(m < 0 || n < 8 || nnz < 0)
+        return ORC_INVALID_SIZE;
+    if(!row_ptr || !col_ind || !val || !blk_row_ptr || !blk_col || !blk_val || !masks)
+        return ORC_INVALID_POINTER;
+    if(rows != 1 && rows != 2 && rows != 4)
+        return ORC_INVALID_SIZE;
+    oint blocks = 0, nv = 0;
+    for(oint i0 = 0; i0 < m; i0 += rows)
+    {
+        oint pos[4] = {0, 0, 0, 0}, first = blocks;
+        for(oint r = 0; r < rows && i0 + r < m; r++)
+            pos[r] = row_ptr[i0 + r] - base;
+        for(;;)
+        {
+            oint c = blk_min_col(rows, i0, m, base, row_ptr, col_ind, pos);
+            if(c == 0x7fffffff)
+                break;
+            unsigned char mk[4] = {0, 0, 0, 0}, shifted[4] = {0, 0, 0, 0};
+            for(oint r = 0; r < rows && i0 + r < m; r++)
+                while(pos[r] < row_ptr[i0 + r + 1] - base && col_ind[pos[r]] - base < c + 8)
+                {
+                    blk_val[nv++] = val[pos[r]];
+                    mk[r] |= (unsigned char)(1u << (col_ind[pos[r]] - base - c));
+                    if(c + 8 > n)
+                        shifted[r] = (unsigned char)(mk[r] << (8 - (n - c)));
+                    pos[r]++;
+                }
+            const int past = c + 8 > n;
+            blk_col[blocks] = (past ? n - 8 : c) + base;
+            for(oint r = 0; r < rows; r++)
+                masks[(size_t)blocks * rows + r] = past ? shifted[r] : mk[r];
+            blocks++;
+        }
+        blk_row_ptr[i0] = first + base;
+        for(oint r = 1; r < rows && i0 + r < m; r++)
+            blk_row_ptr[i0 + r] = blocks + base;
+    }
+    blk_row_ptr[m] = blocks + base;
+    if(nblk)
+        *nblk = blocks;
+    return ORC_SUCCESS;
+}
+/* aoclsparse_blkcsrmv_{1,2,4}x8_vectorized_avx512, blkcsrmv_avx512.cpp:40-369: per sub-row eight lane
+ * accumulators (lane = column offset inside the window), one fmadd per block with zeros where the mask has no
+ * bit (so x is multiplied by 0 there, as the expand-load does), reduction lo4+hi4 -> hadd -> add, then
+ * sum = 0 + that, alpha if != 1, fma(beta, y, sum) if beta != 0.  Values are consumed in storage order. */
+int orc_dblkcsrmv(int base, double alpha, oint m, const unsigned char *masks, const double *blk_val,
+                  const oint *blk_col, const oint *blk_row_ptr, const double *x, double beta, double *y, oint rows)
+{
+    if(rows != 1 && rows != 2 && rows != 4)
+        return ORC_INVALID_SIZE;
+    size_t iv = 0;
+    for(oint i0 = 0; i0 < m; i0 += rows)
+    {
+        double acc[4][8];
+        for(int r = 0; r < 4; r++)
+            for(int l = 0; l < 8; l++)
+                acc[r][l] = 0.0;
+        for(oint b = blk_row_ptr[i0] - base; b < blk_row_ptr[i0 + 1] - base; b++)
+        {
+            const double *xw = x + (blk_col[b] - base);
+            for(oint r = 0; r < rows; r++)
+            {
+                unsigned mk = masks[(size_t)b * rows + r];
+                for(int l = 0; l < 8; l++)
+                {
+                    double v  = (mk >> l) & 1 ? blk_val[iv++] : 0.0;
+                    acc[r][l] = fma(v, xw[l], acc[r][l]);
+                }
+            }
+        }
+        for(oint r = 0; r < rows && i0 + r < m; r++)
+        {
+            double v0 = acc[r][0] + acc[r][4], v1 = acc[r][1] + acc[r][5];
+            double v2 = acc[r][2] + acc[r][6], v3 = acc[r][3] + acc[r][7];
+            double sum = 0.0;
+            sum += (v0 + v1) + (v2 + v3);
+            if(alpha != 1.0)
+                sum = alpha * sum;
+            if(beta != 0.0)
+                sum = fma(beta, y[i0 + r], sum);
+            y[i0 + r] = sum;
+        }
+    }
+    return ORC_SUCCESS;
+}
 /* conversion/aoclsparse_convert.hpp:41-107 (ELL), :110-175 (ELLT), :178-289 (ELLT-HYB) and
  * conversion/aoclsparse_convert.cpp:311-412 (widths).  layout: 0 ELL, 1 ELLT. */
 int orc_csr2ell_width(oint m, const oint *row_ptr, oint *width)

@@ -180,6 +180,17 @@ int orc_dcsr2ell(int layout, oint m, int base, const oint *row_ptr, const oint *
 int orc_dcsr2ellthyb(oint m, int base, oint *ell_m, const oint *row_ptr, const oint *col_ind,
                      const double *val, oint *map, oint *ell_col, double *ell_val, oint width);
 
+/* ---- BLKCSR (1/2/4 x 8 blocks + bit masks), conversion/aoclsparse_convert.cpp:36-310,
+ *      level2/aoclsparse_blkcsrmv_avx512.cpp:40-369 */
+oint orc_opt_blksize(oint m, oint nnz, int base, const oint *row_ptr, const oint *col_ind, oint *total_blks);
+/* returns the number of blocks in *nblk; outputs sized by the caller (blk_col >= nnz, masks >= nnz*rows_blk) */
+int orc_dcsr2blkcsr(oint m, oint n, oint nnz, const oint *row_ptr, const oint *col_ind, const double *val,
+                    oint *blk_row_ptr, oint *blk_col, double *blk_val, unsigned char *masks, oint rows_blk,
+                    int base, oint *nblk);
+int orc_dblkcsrmv(int base, double alpha, oint m, const unsigned char *masks, const double *blk_val,
+                  const oint *blk_col, const oint *blk_row_ptr, const double *x, double beta, double *y,
+                  oint rows_blk);
+
 /* ---- iterative solvers, solvers/aoclsparse_itsol_functions.hpp:632-1367 (level-1 steps as plain loops) */
 int orc_dcg(oint n, int base, const oint *ptr, const oint *col, const double *val,
             const oint *idiag, const oint *iurow, const double *b, double *x, double rtol,

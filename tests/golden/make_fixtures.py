@@ -332,6 +332,19 @@ out["ell"] = [dict(name="M3_base1", src="tests/unit_tests/ellmv_tests.cpp:151-25
                    alpha=1.0, beta=0.0, ell_width=2, ell_col_ind=[1, -1, 2, -1, 1, 3],
                    ell_val=[8.0, 0.0, 5.0, 0.0, 7.0, 7.0], y_gold=[8.0, 10.0, 28.0])]
 
+# BLKCSR: tests/unit_tests/blkcsrmv_tests.cpp:444-470 (block arrays given directly, one-based, 2x8 blocks),
+# :518-537 (one-based CSR through csr2blkcsr, rows_blk 1/2/4) and :656-676 (the same, zero-based)
+_blk_common = dict(m=6, n=8, nnz=14, x=[1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0], alpha=1.0, beta=0.0,
+                   val=[8.0, 2.0, 3.0, 3.0, 3.0, 6.0, 10.0, 9.0, 6.0, 2.0, 2.0, 3.0, 2.0, 6.0],
+                   y_gold=[8.0, 2.0, 0.0, 204.0, 23.0, 14.0])
+out["blkcsr"] = dict(
+    direct=dict(_blk_common, src="tests/unit_tests/blkcsrmv_tests.cpp:444-470", base=1, rows_blk=2,
+                blk_col_ind=[1, 1, 1], blk_row_ptr=[1, 2, 2, 3, 3, 4, 4], masks=[1, 1, 0, 255, 24, 3]),
+    csr=[dict(_blk_common, src="tests/unit_tests/blkcsrmv_tests.cpp:518-537", base=1,
+              row_ptr=[1, 2, 3, 3, 11, 13, 15], col_ind=[1, 1, 1, 2, 3, 4, 5, 6, 7, 8, 4, 5, 1, 2]),
+         dict(_blk_common, src="tests/unit_tests/blkcsrmv_tests.cpp:656-676", base=0,
+              row_ptr=[0, 1, 2, 2, 10, 12, 14], col_ind=[0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 3, 4, 0, 1])])
+
 with open(n25_path, "w") as f:
     json.dump(out, f, indent=None, separators=(",", ":"))
     f.write("\n")

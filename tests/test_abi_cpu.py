@@ -431,6 +431,91 @@ def test_ellmv_argument_checks():
     assert L.aoclsparse_sellthybmv(P.OP_NONE, None, 1, 1, 1, None, None, 1, 1, None, None, None, None, None, d.h, None, None, None) == 1
 
 
+def _blk_convert(m, n, base, rp, ci, v, rows):
+    nnz = len(v)
+    brp, bc = np.full(m + 1, -7, np.int32), np.full(max(1, nnz), -7, np.int32)
+    bv, mk = np.full(nnz + rows * 8, 77.0), np.full(max(1, nnz) * rows + rows * 8, 0xEE, np.uint8)
+    st = L.aoclsparse_csr2blkcsr(m, n, nnz, P._ptr(rp), P._ptr(ci), P._ptr(v), P._ptr(brp), P._ptr(bc), P._ptr(bv),
+                                 P._ptr(mk), rows, base)
+    return st, brp, bc, bv, mk
+
+
+@pytest.mark.parametrize("base", [0, 1])
+def test_blkcsr_conversion_and_block_size_match_the_oracle(base, kats):
+    """aoclsparse_csr2blkcsr / aoclsparse_opt_blksize (conversion/aoclsparse_convert.cpp:36-310) are host integer
+    routines: bit-exact against the restatement (pinned on blkcsrmv_tests.cpp's arrays), including windows
+    re-anchored at n-8 and row counts that are not a multiple of the block height."""
+    import oracle
+    from util import banded_rows
+    for seed, m, n, per in ((1, 203, 150, lambda r, i: 0 if i % 11 == 3 else 4 + (i * 5) % 17),
+                            (2, 61, 19, lambda r, i: 3 + i % 9), (3, 40, 8, lambda r, i: 1 + i % 8),
+                            (4, 300, 400, lambda r, i: 12 + i % 30)):
+        rp, ci, v = banded_rows(seed, m, n, per, base)
+        for rows in (1, 2, 4):
+            st, brp, bc, bv, mk = _blk_convert(m, n, base, rp, ci, v, rows)
+            so, obrp, obc, obv, omk = oracle.csr2blkcsr(m, n, base, rp, ci, v, rows)
+            assert st == so == 0
+            nb = len(obc)
+            assert np.array_equal(brp, obrp) and np.array_equal(bc[:nb], obc) and np.array_equal(bv[: len(v)], obv)
+            assert np.array_equal(mk[: nb * rows], omk)
+            assert np.all(bc[nb:] == -7) and np.all(bv[len(v):] == 77.0) and np.all(mk[nb * rows:] == 0xEE)
+        tot, oref = ctypes.c_int32(-1), oracle.opt_blksize(m, len(v), base, rp, ci)
+        r = L.aoclsparse_opt_blksize(m, len(v), base, P._ptr(rp), P._ptr(ci), ctypes.byref(tot))
+        assert r == oref[0] and (r == 0 or tot.value == oref[1])
+    # a dense-ish banded matrix makes the heuristic pick a blocked size at all
+    rp, ci, v = banded_rows(9, 400, 64, lambda r, i: 40, base)
+    tot, oref = ctypes.c_int32(-1), oracle.opt_blksize(400, len(v), base, rp, ci)
+    assert L.aoclsparse_opt_blksize(400, len(v), base, P._ptr(rp), P._ptr(ci), ctypes.byref(tot)) == oref[0] != 0
+    assert tot.value == oref[1]
+    # the reference's own arrays (blkcsrmv_tests.cpp:444-470 == csr2blkcsr of :518-537 with 2x8 blocks)
+    d, c = kats["blkcsr"]["direct"], kats["blkcsr"]["csr"][0]
+    st, brp, bc, bv, mk = _blk_convert(c["m"], c["n"], 1, np.array(c["row_ptr"], np.int32), np.array(c["col_ind"], np.int32),
+                                       np.array(c["val"]), 2)
+    assert st == 0 and list(brp) == d["blk_row_ptr"] and list(bc[:3]) == d["blk_col_ind"] and list(mk[:6]) == d["masks"]
+    assert list(bv[:14]) == d["val"]
+
+
+def test_blkcsr_argument_checks():
+    """blkcsrmv_tests.cpp:33-300 and :776-900: pointer / size / base / type checks, do-nothing sizes."""
+    val, col, ptr = np.array([3.0, 2.0, 1.0]), np.array([1], np.int32), np.array([0, 1, 1], np.int32)
+    x, y = np.arange(8.0), np.array([0.1, 0.2])
+    a, b, mk = np.array([2.3]), np.array([11.2]), np.array([100, 25], np.uint8)
+    d = P.Descr()
+    for rows in (1, 2, 4):
+        args = lambda **k: [k.get("op", P.OP_NONE), P._ptr(a), k.get("m", 2), k.get("n", 8), k.get("nnz", 3),
+                            k.get("mk", P._ptr(mk)), k.get("val", P._ptr(val)), k.get("col", P._ptr(col)),
+                            k.get("ptr", P._ptr(ptr)), k.get("d", d.h), k.get("x", P._ptr(x)), P._ptr(b), k.get("y", P._ptr(y)),
+                            k.get("rows", rows)]
+        fn = L.aoclsparse_dblkcsrmv
+        for name in ("mk", "val", "col", "ptr", "x", "y", "d"):
+            assert fn(*args(**{name: None})) == 2, name
+        assert fn(*args(m=-1)) == 3 and fn(*args(n=-1)) == 3 and fn(*args(n=7)) == 3 and fn(*args(nnz=-1)) == 3
+        assert fn(*args(m=0)) == 0 and fn(*args(nnz=0)) == 0 and np.array_equal(y, [0.1, 0.2])
+        assert fn(*args(op=P.OP_TRANSPOSE)) == 1 and fn(*args(d=P.Descr(mtype=P.TYPE_TRIANGULAR).h)) == 1
+        bad = P.Descr()
+        L.aoclsparse_set_mat_index_base(bad.h, 2)
+        assert L.aoclsparse_get_mat_index_base(bad.h) == 0  # the setter refuses it ...
+        ctypes.cast(bad.h, ctypes.POINTER(ctypes.c_int32))[3] = 2  # ... so write descr->base as blkcsrmv_tests.cpp:413 does
+        assert fn(*args(d=bad.h)) == 5
+    assert fn(*args(rows=-1)) == 3 and fn(*args(rows=5)) == 3
+    tot = ctypes.c_int32(0)
+    assert L.aoclsparse_opt_blksize(0, 3, 0, P._ptr(ptr), P._ptr(col), ctypes.byref(tot)) == 0
+    assert L.aoclsparse_opt_blksize(-1, 3, 0, P._ptr(ptr), P._ptr(col), ctypes.byref(tot)) == 0
+    assert L.aoclsparse_opt_blksize(2, -1, 0, P._ptr(ptr), P._ptr(col), ctypes.byref(tot)) == 0
+    assert L.aoclsparse_opt_blksize(2, 3, 0, None, P._ptr(col), ctypes.byref(tot)) == 0
+    assert L.aoclsparse_opt_blksize(2, 3, 0, P._ptr(ptr), None, ctypes.byref(tot)) == 0
+    assert L.aoclsparse_opt_blksize(2, 3, 0, P._ptr(ptr), P._ptr(col), None) == 0
+    out = [np.zeros(8, np.int32), np.zeros(8, np.int32), np.zeros(40), np.zeros(40, np.uint8)]
+    cv = lambda **k: [k.get("m", 2), k.get("n", 8), k.get("nnz", 1), k.get("ptr", P._ptr(ptr)), k.get("col", P._ptr(col)),
+                      k.get("val", P._ptr(val)), k.get("o0", P._ptr(out[0])), k.get("o1", P._ptr(out[1])),
+                      k.get("o2", P._ptr(out[2])), k.get("o3", P._ptr(out[3])), k.get("rows", 2), 0]
+    fn = L.aoclsparse_csr2blkcsr
+    assert fn(*cv()) == 0
+    for name in ("ptr", "col", "val", "o0", "o1", "o2", "o3"):
+        assert fn(*cv(**{name: None})) == 2, name
+    assert fn(*cv(m=-1)) == 3 and fn(*cv(n=7)) == 3 and fn(*cv(nnz=-1)) == 3 and fn(*cv(rows=3)) == 3 and fn(*cv(rows=0)) == 3
+
+
 def test_csc_coo_handles_convert_order_and_csr2csc():
     """formats either side of the path (aoclsparse_auxiliary.h:674-1095, aoclsparse_convert.h:494-660): all host
     structure work, int-exact against the oracle's csr2csc restatement and a dense reconstruction."""

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import oracle
-from util import (EPS32, EPS64, abs_row_sums, laplace5, pkg, powerlaw_rows, random_csr,
+from util import (EPS32, EPS64, abs_row_sums, banded_rows, laplace5, pkg, powerlaw_rows, random_csr,
                   triangular_system)
 
 pytestmark = pytest.mark.gpu
@@ -1150,6 +1150,75 @@ def test_ell_family_bit_exact(base, alpha, beta):
     assert L.aoclsparse_sellmv(P.OP_NONE, P._ptr(af), m, n, len(v), P._ptr(ev.astype(np.float32)), P._ptr(ec), w, d.h, P._ptr(xf),
                                P._ptr(bf), P._ptr(yf)) == 0
     assert np.array_equal(yf, yr)
+
+
+def _blkmv(base, alpha, beta, m, n, nnz, mk, bv, bc, brp, x, y, rows, on_device):
+    a, b, d = np.array([alpha]), np.array([beta]), P.Descr(base=base)
+    if on_device:
+        mk, bv, bc, brp, x, yd = dev(mk), dev(bv), dev(bc), dev(brp), dev(x), dev(y)
+        st = L.aoclsparse_dblkcsrmv(P.OP_NONE, P._ptr(a), m, n, nnz, P._ptr(mk), P._ptr(bv), P._ptr(bc), P._ptr(brp), d.h,
+                                    P._ptr(x), P._ptr(b), P._ptr(yd), rows)
+        torch.cuda.synchronize()
+        return st, yd.cpu().numpy()
+    y = y.copy()
+    st = L.aoclsparse_dblkcsrmv(P.OP_NONE, P._ptr(a), m, n, nnz, P._ptr(mk), P._ptr(bv), P._ptr(bc), P._ptr(brp), d.h, P._ptr(x),
+                                P._ptr(b), P._ptr(y), rows)
+    return st, y
+
+
+def test_blkcsrmv_reference_kats(kats):
+    """blkcsrmv_tests.cpp:444-470 (arrays fed directly) and :518-537 / :656-676 (through csr2blkcsr, 1/2/4 x 8)."""
+    c = kats["blkcsr"]["direct"]
+    st, y = _blkmv(c["base"], c["alpha"], c["beta"], c["m"], c["n"], c["nnz"], np.array(c["masks"], np.uint8), np.array(c["val"]),
+                   np.array(c["blk_col_ind"], np.int32), np.array(c["blk_row_ptr"], np.int32), np.array(c["x"]),
+                   np.full(c["m"], np.nan), c["rows_blk"], False)
+    assert st == 0 and list(y) == c["y_gold"]
+    for c in kats["blkcsr"]["csr"]:
+        for rows in (1, 2, 4):
+            so, brp, bc, bv, mk = oracle.csr2blkcsr(c["m"], c["n"], c["base"], c["row_ptr"], c["col_ind"], c["val"], rows)
+            for on_device in (False, True):
+                st, y = _blkmv(c["base"], c["alpha"], c["beta"], c["m"], c["n"], c["nnz"], mk, bv, bc, brp, np.array(c["x"]),
+                               np.full(c["m"], np.nan), rows, on_device)
+                assert st == 0 and list(y) == c["y_gold"]
+
+
+@pytest.mark.parametrize("base", [0, 1])
+@pytest.mark.parametrize("rows", [1, 2, 4])
+def test_blkcsrmv_bit_exact(base, rows):
+    """the 8 lanes of a row group are the 8 lanes of the reference's zmm accumulator: bit-identical to the restated
+    AVX-512 kernels (blkcsrmv_avx512.cpp:40-369) for any alpha/beta, row counts that are not a multiple of the block
+    height, empty rows, windows re-anchored at n-8, and more blocks than one scan chunk (1024)."""
+    for seed, m, n, per, alpha, beta in ((1, 3001, 2500, lambda r, i: 0 if i % 13 == 5 else 6 + (i * 7) % 40, 1.0, 0.0),
+                                         (2, 777, 21, lambda r, i: 2 + i % 15, -1.25, 0.5),
+                                         (3, 50, 8, lambda r, i: 1 + i % 8, 2.0, 1.0)):
+        rp, ci, v = banded_rows(seed, m, n, per, base)
+        so, brp, bc, bv, mk = oracle.csr2blkcsr(m, n, base, rp, ci, v, rows)
+        assert so == 0 and (seed != 1 or len(bc) > 2048)
+        rng = np.random.default_rng(seed)
+        x = rng.uniform(-1, 1, n)
+        y0 = rng.uniform(-1, 1, m) if beta != 0.0 else np.full(m, np.nan)
+        so, yr = oracle.dblkcsrmv(base, alpha, m, mk, bv, bc, brp, x, beta, y0, rows)
+        for on_device in (False, True):
+            st, y = _blkmv(base, alpha, beta, m, n, len(v), mk, bv, bc, brp, x, y0, rows, on_device)
+            assert st == 0 and np.array_equal(y, yr)
+        # and it is the same product as the CSR one up to the regrouping of each row's terms
+        so, yc = oracle.dcsrmv_order("ref", base, alpha, m, v, ci, rp, x, beta, np.nan_to_num(y0))
+        scale = abs(alpha) * abs_row_sums(rp, ci, v, x, base) + abs(beta * np.nan_to_num(y0))
+        assert np.all(np.abs(yr - yc) <= (np.diff(rp) + 4) * EPS64 * scale + 1e-300)
+
+
+def test_blkcsrmv_window_reads_x_like_the_expand_load():
+    """a lane whose mask bit is clear still multiplies x by 0 (the reference's zero-filled expand-load), so a NaN in
+    a column the window covers but the row does not own reaches y -- exactly as on the CPU."""
+    m, n = 6, 16
+    rp, ci, v = np.array([0, 2, 3, 3, 5, 6, 8], np.int32), np.array([0, 2, 9, 1, 4, 15, 3, 12], np.int32), np.arange(1.0, 9.0)
+    x = np.arange(1.0, 17.0)
+    x[1] = np.nan  # inside row 0's window [0, 8), not one of its columns
+    for rows in (1, 2, 4):
+        so, brp, bc, bv, mk = oracle.csr2blkcsr(m, n, 0, rp, ci, v, rows)
+        so, yr = oracle.dblkcsrmv(0, 1.0, m, mk, bv, bc, brp, x, 0.0, np.zeros(m), rows)
+        st, y = _blkmv(0, 1.0, 0.0, m, n, len(v), mk, bv, bc, brp, x, np.zeros(m), rows, True)
+        assert st == 0 and np.isnan(yr[0]) and np.array_equal(y, yr, equal_nan=True)
 
 
 def test_ellt_all_rows_short_equals_csr_scalar_order():

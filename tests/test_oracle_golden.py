@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import oracle
-from util import laplace5
+from util import banded_rows, laplace5
 
 EPS = np.finfo(np.float64).eps
 
@@ -359,6 +359,60 @@ def test_ell_orders_against_csr_oracle():
     assert em + len(mp) == m and np.all(lens[mp] > w) and np.count_nonzero(lens <= w) == em
     st, yh = oracle.dellthybmv(0, 1.7, m, hv, hc, w, em, v, rp, ci, mp, x, -0.3, y0)
     assert np.array_equal(yh[mp], yc[mp]) and np.allclose(yh, yr, rtol=0, atol=1e-13)
+
+
+def test_blkcsr_kats(kats):
+    """blkcsrmv_tests.cpp:444-470 (block arrays fed directly) and :518-537 / :656-676 (CSR through csr2blkcsr
+    for 1/2/4 x 8 blocks): every route gives y_gold, and the 2x8 conversion of the one-based CSR reproduces the
+    direct arrays of the first test."""
+    d = kats["blkcsr"]["direct"]
+    st, y = oracle.dblkcsrmv(d["base"], d["alpha"], d["m"], d["masks"], d["val"], d["blk_col_ind"], d["blk_row_ptr"],
+                             d["x"], d["beta"], np.full(d["m"], np.nan), d["rows_blk"])
+    assert st == 0 and list(y) == d["y_gold"]
+    for c in kats["blkcsr"]["csr"]:
+        for rows in (1, 2, 4):
+            st, brp, bc, bv, mk = oracle.csr2blkcsr(c["m"], c["n"], c["base"], c["row_ptr"], c["col_ind"], c["val"], rows)
+            assert st == 0
+            if rows == 2 and c["base"] == 1:
+                assert list(brp) == d["blk_row_ptr"] and list(bc) == d["blk_col_ind"] and list(mk) == d["masks"]
+                assert list(bv) == d["val"]
+            st, y = oracle.dblkcsrmv(c["base"], c["alpha"], c["m"], mk, bv, bc, brp, c["x"], c["beta"],
+                                     np.full(c["m"], np.nan), rows)
+            assert st == 0 and list(y) == c["y_gold"]
+    # error returns pinned by blkcsrmv_tests.cpp:776-900 (opt_blksize gives 0, csr2blkcsr the size code)
+    assert oracle.opt_blksize(0, 3, 0, [0, 1, 1], [1])[0] == 0 and oracle.opt_blksize(2, -1, 0, [0, 1, 1], [1])[0] == 0
+    assert oracle.csr2blkcsr(2, 7, 0, [0, 1, 1], [1], [3.0], 2)[0] == 3
+    assert oracle.csr2blkcsr(2, 8, 0, [0, 1, 1], [1], [3.0], 3)[0] == 3
+
+
+def test_blkcsr_structure_properties():
+    """conversion invariants on random banded matrices: every entry lands in exactly one block bit, windows stay
+    inside [0, n), popcounts add up to nnz, and the product equals the CSR product up to the 8-lane regrouping."""
+    for seed, base, n in ((1, 0, 64), (2, 1, 21), (3, 0, 8)):
+        m = 37
+        rp, ci, v = banded_rows(seed, m, n, lambda r, i: 0 if i % 9 == 4 else 3 + (i * 7) % 11, base)
+        x, y0 = np.random.default_rng(5).uniform(-1, 1, n), np.random.default_rng(6).uniform(-1, 1, m)
+        st, yr = oracle.dcsrmv_order("ref", base, 1.3, m, v, ci, rp, x, -0.4, y0)
+        for rows in (1, 2, 4):
+            st, brp, bc, bv, mk = oracle.csr2blkcsr(m, n, base, rp, ci, v, rows)
+            assert st == 0 and int(np.unpackbits(mk).sum()) == len(v)
+            assert np.all(bc - base >= 0) and np.all(bc - base + 8 <= n)
+            # rebuild (row, col, val) triples from the blocks and compare with the CSR
+            trip, iv = [], 0
+            for i0 in range(0, m, rows):
+                for b in range(brp[i0] - base, brp[i0 + 1] - base):
+                    for r in range(rows):
+                        for l in range(8):
+                            if mk[b * rows + r] >> l & 1:
+                                trip.append((i0 + r, bc[b] - base + l, bv[iv]))
+                                iv += 1
+            ref = [(i, ci[p] - base, v[p]) for i in range(m) for p in range(rp[i] - base, rp[i + 1] - base)]
+            assert sorted(trip) == sorted(ref)
+            st, y = oracle.dblkcsrmv(base, 1.3, m, mk, bv, bc, brp, x, -0.4, y0, rows)
+            assert st == 0 and np.allclose(y, yr, rtol=0, atol=1e-13)
+        r, tot = oracle.opt_blksize(m, len(v), base, rp, ci)
+        if r:
+            assert tot == len(oracle.csr2blkcsr(m, n, base, rp, ci, v, r)[2])
 
 
 def _sym_full(n, rp, ci, v):

@@ -79,3 +79,19 @@ def triangular_system(seed, m, avg_off, base=0, dtype=np.float64, band=None):
     rid = np.repeat(np.arange(m), lens)
     val[col == rid] = rng.uniform(2.0, 4.0, size=m) * rng.choice([-1.0, 1.0], size=m)
     return (row_ptr + base).astype(np.int32), (col + base).astype(np.int32), val.astype(dtype)
+
+
+def banded_rows(seed, m, n, per_row, base=0):
+    """rows made of short runs of neighbouring columns -- what BLKCSR is meant for"""
+    rng = np.random.default_rng(seed)
+    rp, ci = [0], []
+    for i in range(m):
+        cols, want = set(), min(n, int(per_row(rng, i)))
+        while len(cols) < want:
+            c0 = int(rng.integers(0, n))
+            cols.update(range(c0, min(n, c0 + int(rng.integers(1, 7)))))
+        cols = sorted(cols)[:want]
+        ci += cols
+        rp.append(len(ci))
+    v = rng.uniform(-1, 1, len(ci))
+    return np.array(rp, np.int32) + base, np.array(ci, np.int32) + base, v

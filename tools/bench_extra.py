@@ -202,6 +202,27 @@ if "next" in what:
     ms = time_calls(fn, 30)
     emit(kind="next", op="aoclsparse_delltmv (device arrays)", system="5-pt Laplacian grid %d^2" % g, ms=round(ms, 4),
          gbs_ell_bytes=round((m * w * 12 + 16 * m) / ms / 1e6, 1), bit_exact_vs_csr_scalar_order=bool(np.array_equal(yd.cpu().numpy(), yref)))
+    # BLKCSR twin on the blocked stand-in (conversion by the library's own host routine, product on device arrays)
+    import standins
+    bm, brp_, bci_, bv_ = standins.shell_like()
+    bnnz, tot = len(bv_), ctypes.c_int32(0)
+    rows_blk = L.aoclsparse_opt_blksize(bm, bnnz, 0, pkg._ptr(brp_), pkg._ptr(bci_), ctypes.byref(tot)) or 4
+    brp, bc = np.zeros(bm + 1, np.int32), np.zeros(bnnz, np.int32)
+    bv, mk = np.zeros(bnnz + 64), np.zeros(bnnz * rows_blk + 64, np.uint8)
+    assert L.aoclsparse_csr2blkcsr(bm, bm, bnnz, pkg._ptr(brp_), pkg._ptr(bci_), pkg._ptr(bv_), pkg._ptr(brp), pkg._ptr(bc), pkg._ptr(bv),
+                                   pkg._ptr(mk), rows_blk, 0) == 0
+    nb = int(brp[bm])
+    bx = rng.uniform(-1, 1, bm)
+    so, byref = oracle.dblkcsrmv(0, 1.0, bm, mk[: nb * rows_blk], bv[:bnnz], bc[:nb], brp, bx, 0.0, np.zeros(bm), rows_blk)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    mkd, bvd, bcd, brpd, bxd, byd = t(mk), t(bv), t(bc), t(brp), t(bx), torch.zeros(bm, dtype=torch.float64, device=dev)
+    fn = lambda: L.aoclsparse_dblkcsrmv(pkg.OP_NONE, pkg._ptr(one), bm, bm, bnnz, pkg._ptr(mkd), pkg._ptr(bvd), pkg._ptr(bcd),
+                                        pkg._ptr(brpd), d0.h, pkg._ptr(bxd), pkg._ptr(zero), pkg._ptr(byd), rows_blk)
+    ms = time_calls(fn, 30)
+    emit(kind="next", op="aoclsparse_dblkcsrmv %dx8 (device arrays)" % rows_blk,
+         system="shell-like stand-in m=%d nnz=%d blocks=%d" % (bm, bnnz, nb), ms=round(ms, 4),
+         gbs_blk_bytes=round((bnnz * 8 + nb * (4 + rows_blk) + 4 * bm + 16 * bm) / ms / 1e6, 1),
+         bit_exact_vs_avx512_order=bool(np.array_equal(byd.cpu().numpy(), byref)))
     # dotmv
     A = pkg.Matrix(0, m, m, rp, ci, v)
     assert L.aoclsparse_set_mv_hint(A.h, pkg.OP_NONE, d0.h, 10) == 0 and L.aoclsparse_optimize(A.h) == 0
