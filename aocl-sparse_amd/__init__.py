@@ -119,6 +119,18 @@ SIGNATURES = {
     "aoclsparse_zcsrmm": (c_int, [c_int, CDouble, _P, _P, c_int, _P, _I, _I, CDouble, _P, _I]),
     "aoclsparse_ccsrmm_kid": (c_int, [c_int, CFloat, _P, _P, c_int, _P, _I, _I, CFloat, _P, _I, _I]),
     "aoclsparse_zcsrmm_kid": (c_int, [c_int, CDouble, _P, _P, c_int, _P, _I, _I, CDouble, _P, _I, _I]),
+    "aoclsparse_ctrsv": (c_int, [c_int, CFloat, _P, _P, _P, _P]),
+    "aoclsparse_ctrsv_kid": (c_int, [c_int, CFloat, _P, _P, _P, _P, _I]),
+    "aoclsparse_ctrsv_strided": (c_int, [c_int, CFloat, _P, _P, _P, _I, _P, _I]),
+    "aoclsparse_ctrsm": (c_int, [c_int, CFloat, _P, _P, c_int, _P, _I, _I, _P, _I]),
+    "aoclsparse_ctrsm_kid": (c_int, [c_int, CFloat, _P, _P, c_int, _P, _I, _I, _P, _I, _I]),
+    "aoclsparse_ztrsv": (c_int, [c_int, CDouble, _P, _P, _P, _P]),
+    "aoclsparse_ztrsv_kid": (c_int, [c_int, CDouble, _P, _P, _P, _P, _I]),
+    "aoclsparse_ztrsv_strided": (c_int, [c_int, CDouble, _P, _P, _P, _I, _P, _I]),
+    "aoclsparse_ztrsm": (c_int, [c_int, CDouble, _P, _P, c_int, _P, _I, _I, _P, _I]),
+    "aoclsparse_ztrsm_kid": (c_int, [c_int, CDouble, _P, _P, c_int, _P, _I, _I, _P, _I, _I]),
+    "aoclsparse_scsrsv": (c_int, [c_int, _P, _I, _P, _P, _P, _P, _P, _P]),
+    "aoclsparse_dcsrsv": (c_int, [c_int, _P, _I, _P, _P, _P, _P, _P, _P]),
     "aoclsparse_cmv": (c_int, [c_int, _P, _P, _P, _P, _P, _P]),
     "aoclsparse_zmv": (c_int, [c_int, _P, _P, _P, _P, _P, _P]),
     "aoclsparse_create_scsc": (c_int, [POINTER(_P), c_int, _I, _I, _I, _P, _P, _P]),
@@ -129,6 +141,16 @@ SIGNATURES = {
     "aoclsparse_export_dcsc": (c_int, [_P, POINTER(c_int), POINTER(_I), POINTER(_I), POINTER(_I), POINTER(_P), POINTER(_P), POINTER(_P)]),
     "aoclsparse_export_scoo": (c_int, [_P, POINTER(c_int), POINTER(_I), POINTER(_I), POINTER(_I), POINTER(_P), POINTER(_P), POINTER(_P)]),
     "aoclsparse_export_dcoo": (c_int, [_P, POINTER(c_int), POINTER(_I), POINTER(_I), POINTER(_I), POINTER(_P), POINTER(_P), POINTER(_P)]),
+    "aoclsparse_create_ccsc": (c_int, [POINTER(_P), c_int, _I, _I, _I, _P, _P, _P]),
+    "aoclsparse_create_ccoo": (c_int, [POINTER(_P), c_int, _I, _I, _I, _P, _P, _P]),
+    "aoclsparse_export_ccsc": (c_int, [_P, POINTER(c_int), POINTER(_I), POINTER(_I), POINTER(_I), POINTER(_P), POINTER(_P), POINTER(_P)]),
+    "aoclsparse_export_ccoo": (c_int, [_P, POINTER(c_int), POINTER(_I), POINTER(_I), POINTER(_I), POINTER(_P), POINTER(_P), POINTER(_P)]),
+    "aoclsparse_ccsr2csc": (c_int, [_I, _I, _I, _P, c_int, _P, _P, _P, _P, _P, _P]),
+    "aoclsparse_create_zcsc": (c_int, [POINTER(_P), c_int, _I, _I, _I, _P, _P, _P]),
+    "aoclsparse_create_zcoo": (c_int, [POINTER(_P), c_int, _I, _I, _I, _P, _P, _P]),
+    "aoclsparse_export_zcsc": (c_int, [_P, POINTER(c_int), POINTER(_I), POINTER(_I), POINTER(_I), POINTER(_P), POINTER(_P), POINTER(_P)]),
+    "aoclsparse_export_zcoo": (c_int, [_P, POINTER(c_int), POINTER(_I), POINTER(_I), POINTER(_I), POINTER(_P), POINTER(_P), POINTER(_P)]),
+    "aoclsparse_zcsr2csc": (c_int, [_I, _I, _I, _P, c_int, _P, _P, _P, _P, _P, _P]),
     "aoclsparse_convert_csr": (c_int, [_P, c_int, POINTER(_P)]),
     "aoclsparse_order_mat": (c_int, [_P]),
     "aoclsparse_scsr2csc": (c_int, [_I, _I, _I, _P, c_int, _P, _P, _P, _P, _P, _P]),

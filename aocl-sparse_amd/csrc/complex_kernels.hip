@@ -139,6 +139,99 @@ __global__ void cscale_dense_kernel(cplx<R> *C, aoclsparse_int inner, aoclsparse
     }
 }
 
+
+// ---- complex triangular solve --------------------------------------------------------------------------
+// Same level-ordered layout as the real solve (trsv_kernels.hip: position k holds row rowmap[k], pind = positions,
+// entries in the reference's chain order).  One lane per row: xi = alpha*b_i; xi -= a_ij * x_j ...; xi /= d_i --
+// the order of ref_trsv_l / _u / _lth / _uth (level2/aoclsparse_trsv_kr.hpp:38-222) with complex operands.  The
+// reference's complex multiply / divide are whatever std::complex compiles to, so parity here is the forward-error
+// bound.  Column c of a multi-RHS solve (blockIdx.y) lives at b + c*b_off with element stride incb.
+struct CRhsGeom
+{
+    long long b_off, x_off;
+    int       incb, incx;
+};
+
+template <typename R>
+__device__ __forceinline__ cplx<R> ctrsv_row(int k, const aoclsparse_int *__restrict__ rowmap,
+                                             const aoclsparse_int *__restrict__ pptr,
+                                             const aoclsparse_int *__restrict__ pind, const cplx<R> *__restrict__ pval,
+                                             const cplx<R> *__restrict__ diag, const cplx<R> *__restrict__ b,
+                                             const cplx<R> *xp, cplx<R> alpha, int unit, int conj_diag, int incb, int &row)
+{
+    const int i = rowmap[k];
+    row         = i;
+    cplx<R> xi  = c_mul(alpha, b[(size_t)i * incb]);
+    for(int p = pptr[k], e = pptr[k + 1]; p < e; p++)
+    {
+        const cplx<R> a = pval[p], xj = xp[pind[p]];
+        c_mac(xi, cplx<R>(-a.re, -a.im), xj);
+    }
+    if(!unit)
+    {
+        cplx<R> d = diag[i];
+        if(conj_diag)
+            d.im = -d.im;
+        const R den = c_fma(d.re, d.re, d.im * d.im);
+        const R re  = c_fma(xi.re, d.re, xi.im * d.im) / den;
+        const R im  = c_fma(xi.im, d.re, -(xi.re * d.im)) / den;
+        xi          = cplx<R>(re, im);
+    }
+    return xi;
+}
+
+template <typename R>
+__global__ void ctrsv_level_kernel(aoclsparse_int first, aoclsparse_int count, aoclsparse_int m,
+                                   const aoclsparse_int *__restrict__ rowmap, const aoclsparse_int *__restrict__ pptr,
+                                   const aoclsparse_int *__restrict__ pind, const cplx<R> *__restrict__ pval,
+                                   const cplx<R> *__restrict__ diag, const cplx<R> *__restrict__ b, cplx<R> *xp,
+                                   cplx<R> *x, cplx<R> alpha, int unit, int conj_diag, CRhsGeom g)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= count)
+        return;
+    const int c = blockIdx.y;
+    b += c * g.b_off;
+    x += c * g.x_off;
+    xp += (size_t)c * m;
+    int           i;
+    const cplx<R> xi = ctrsv_row<R>(first + t, rowmap, pptr, pind, pval, diag, b, xp, alpha, unit, conj_diag, g.incb, i);
+    xp[first + t]         = xi;
+    x[(size_t)i * g.incx] = xi;
+}
+
+// a run of narrow levels [l0, l1) inside ONE workgroup (a lane per row, a workgroup barrier per level): what later
+// levels read was written by this workgroup, i.e. through this CU's own L1
+template <typename R>
+__global__ __launch_bounds__(1024) void ctrsv_run_kernel(aoclsparse_int l0, aoclsparse_int l1, aoclsparse_int m,
+                                                         const aoclsparse_int *__restrict__ levels,
+                                                         const aoclsparse_int *__restrict__ rowmap,
+                                                         const aoclsparse_int *__restrict__ pptr,
+                                                         const aoclsparse_int *__restrict__ pind,
+                                                         const cplx<R> *__restrict__ pval, const cplx<R> *__restrict__ diag,
+                                                         const cplx<R> *__restrict__ b, cplx<R> *xp, cplx<R> *x,
+                                                         cplx<R> alpha, int unit, int conj_diag, CRhsGeom g)
+{
+    const int c = blockIdx.y;
+    b += c * g.b_off;
+    x += c * g.x_off;
+    xp += (size_t)c * m;
+    for(int l = l0; l < l1; l++)
+    {
+        const int first = levels[l], count = levels[l + 1] - first;
+        if((int)threadIdx.x < count)
+        {
+            int           i;
+            const cplx<R> xi = ctrsv_row<R>(first + threadIdx.x, rowmap, pptr, pind, pval, diag, b, xp, alpha, unit,
+                                            conj_diag, g.incb, i);
+            xp[first + threadIdx.x] = xi;
+            x[(size_t)i * g.incx]   = xi;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 } // namespace
 
 template <typename R>
@@ -225,6 +318,52 @@ aoclsparse_status launch_cscale(hipStream_t s, cplx<R> *y, aoclsparse_int n, cpl
     MI355_HIP_TRY(hipGetLastError());
     return aoclsparse_status_success;
 }
+
+
+template <typename R>
+aoclsparse_status launch_ctrsv(hipStream_t s, bool unit, bool conj_diag, cplx<R> alpha, aoclsparse_int m,
+                               const TrsvPlan &plan, const cplx<R> *diag, const cplx<R> *b, cplx<R> *x, cplx<R> *xp,
+                               aoclsparse_int nrhs, long long b_off, aoclsparse_int incb, long long x_off,
+                               aoclsparse_int incx)
+{
+    if(m <= 0 || nrhs <= 0)
+        return aoclsparse_status_success;
+    const aoclsparse_int *rowmap = plan.rowmap.as<aoclsparse_int>(), *pptr = plan.pptr.as<aoclsparse_int>();
+    const aoclsparse_int *pind = plan.pind.as<aoclsparse_int>(), *levels = plan.levels.as<aoclsparse_int>();
+    const cplx<R>        *pval = plan.pval.as<cplx<R>>();
+    const CRhsGeom        g{b_off, x_off, incb, incx};
+    for(aoclsparse_int c0 = 0; c0 < nrhs; c0 += 65535)
+    {
+        const int nc = nrhs - c0 < 65535 ? nrhs - c0 : 65535;
+        for(const TrsvSegment &sg : plan.segments)
+        {
+            if(sg.narrow)
+            {
+                hipLaunchKernelGGL((ctrsv_run_kernel<R>), dim3(1, nc), dim3(TRSV_NARROW), 0, s, sg.l0, sg.l1, m, levels,
+                                   rowmap, pptr, pind, pval, diag, b + c0 * b_off, xp + (size_t)c0 * m, x + c0 * x_off,
+                                   alpha, (int)unit, (int)conj_diag, g);
+                continue;
+            }
+            for(aoclsparse_int l = sg.l0; l < sg.l1; l++)
+            {
+                const aoclsparse_int first = plan.level_ptr[l], count = plan.level_ptr[l + 1] - first;
+                const int            bs = count >= 256 ? 256 : 64;
+                hipLaunchKernelGGL((ctrsv_level_kernel<R>), dim3((count + bs - 1) / bs, nc), dim3(bs), 0, s, first,
+                                   count, m, rowmap, pptr, pind, pval, diag, b + c0 * b_off, xp + (size_t)c0 * m,
+                                   x + c0 * x_off, alpha, (int)unit, (int)conj_diag, g);
+            }
+        }
+    }
+    MI355_HIP_TRY(hipGetLastError());
+    return aoclsparse_status_success;
+}
+
+template aoclsparse_status launch_ctrsv<float>(hipStream_t, bool, bool, cfloat, aoclsparse_int, const TrsvPlan &,
+                                               const cfloat *, const cfloat *, cfloat *, cfloat *, aoclsparse_int,
+                                               long long, aoclsparse_int, long long, aoclsparse_int);
+template aoclsparse_status launch_ctrsv<double>(hipStream_t, bool, bool, cdouble, aoclsparse_int, const TrsvPlan &,
+                                                const cdouble *, const cdouble *, cdouble *, cdouble *, aoclsparse_int,
+                                                long long, aoclsparse_int, long long, aoclsparse_int);
 
 template aoclsparse_status launch_cspmv<float>(hipStream_t, int, bool, cfloat, aoclsparse_int, aoclsparse_int,
                                                const cfloat *, const aoclsparse_int *, const aoclsparse_int *,

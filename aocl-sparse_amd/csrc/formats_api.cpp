@@ -232,7 +232,10 @@ aoclsparse_status convert_csr(const aoclsparse_matrix src, aoclsparse_operation 
             return st;
         }
     }
-    // conjugation is the identity for real types; the reference leaves sort / fulldiag at their defaults
+    if(op == aoclsparse_operation_conjugate_transpose)
+        for(aoclsparse_int i = 0; i < src->nnz; i++)
+            dv[i] = conj_of(dv[i]); // identity for real types
+    // the reference leaves sort / fulldiag at their defaults
     // (aoclsparse_init_mat): unknown, so that ILU-type routines re-check; here they are computed
     bool sorted = false, fd = false;
     int  sort   = 0;
@@ -304,13 +307,11 @@ void csc_set_value(aoclsparse_matrix A, aoclsparse_int row_idx, aoclsparse_int c
 
 aoclsparse_status csc_refresh_csr(aoclsparse_matrix A)
 {
-    return A->val_type == aoclsparse_smat
-               ? csr2csc<float>(A->n, A->m, A->nnz, A->base, A->base, A->csc_ptr, A->csc_ind,
-                                static_cast<const float *>(A->csc_val), A->user.ind, A->user.ptr,
-                                static_cast<float *>(A->user.val))
-               : csr2csc<double>(A->n, A->m, A->nnz, A->base, A->base, A->csc_ptr, A->csc_ind,
-                                 static_cast<const double *>(A->csc_val), A->user.ind, A->user.ptr,
-                                 static_cast<double *>(A->user.val));
+    return dispatch_value_type(A->val_type, [&](auto tag) {
+        using T = decltype(tag);
+        return csr2csc<T>(A->n, A->m, A->nnz, A->base, A->base, A->csc_ptr, A->csc_ind, static_cast<const T *>(A->csc_val),
+                          A->user.ind, A->user.ptr, static_cast<T *>(A->user.val));
+    });
 }
 
 } // namespace mi355
@@ -340,6 +341,55 @@ aoclsparse_status aoclsparse_create_scoo(aoclsparse_matrix *mat, const aoclspars
                                          aoclsparse_int *row_ind, aoclsparse_int *col_ind, float *val)
 {
     return create_coo<float>(mat, base, M, N, nnz, row_ind, col_ind, val, aoclsparse_smat);
+}
+
+aoclsparse_status aoclsparse_create_ccsc(aoclsparse_matrix *mat, aoclsparse_index_base base, aoclsparse_int M,
+                                         aoclsparse_int N, aoclsparse_int nnz, aoclsparse_int *col_ptr,
+                                         aoclsparse_int *row_idx, aoclsparse_float_complex *val)
+{
+    return create_csc<cfloat>(mat, base, M, N, nnz, col_ptr, row_idx, reinterpret_cast<cfloat *>(val), aoclsparse_cmat);
+}
+aoclsparse_status aoclsparse_create_zcsc(aoclsparse_matrix *mat, aoclsparse_index_base base, aoclsparse_int M,
+                                         aoclsparse_int N, aoclsparse_int nnz, aoclsparse_int *col_ptr,
+                                         aoclsparse_int *row_idx, aoclsparse_double_complex *val)
+{
+    return create_csc<cdouble>(mat, base, M, N, nnz, col_ptr, row_idx, reinterpret_cast<cdouble *>(val), aoclsparse_zmat);
+}
+aoclsparse_status aoclsparse_create_ccoo(aoclsparse_matrix *mat, const aoclsparse_index_base base,
+                                         const aoclsparse_int M, const aoclsparse_int N, const aoclsparse_int nnz,
+                                         aoclsparse_int *row_ind, aoclsparse_int *col_ind, aoclsparse_float_complex *val)
+{
+    return create_coo<cfloat>(mat, base, M, N, nnz, row_ind, col_ind, reinterpret_cast<cfloat *>(val), aoclsparse_cmat);
+}
+aoclsparse_status aoclsparse_create_zcoo(aoclsparse_matrix *mat, const aoclsparse_index_base base,
+                                         const aoclsparse_int M, const aoclsparse_int N, const aoclsparse_int nnz,
+                                         aoclsparse_int *row_ind, aoclsparse_int *col_ind, aoclsparse_double_complex *val)
+{
+    return create_coo<cdouble>(mat, base, M, N, nnz, row_ind, col_ind, reinterpret_cast<cdouble *>(val), aoclsparse_zmat);
+}
+aoclsparse_status aoclsparse_export_ccsc(const aoclsparse_matrix mat, aoclsparse_index_base *base, aoclsparse_int *m,
+                                         aoclsparse_int *n, aoclsparse_int *nnz, aoclsparse_int **col_ptr,
+                                         aoclsparse_int **row_ind, aoclsparse_float_complex **val)
+{
+    return export_csc<cfloat>(mat, base, m, n, nnz, col_ptr, row_ind, reinterpret_cast<cfloat **>(val), aoclsparse_cmat);
+}
+aoclsparse_status aoclsparse_export_zcsc(const aoclsparse_matrix mat, aoclsparse_index_base *base, aoclsparse_int *m,
+                                         aoclsparse_int *n, aoclsparse_int *nnz, aoclsparse_int **col_ptr,
+                                         aoclsparse_int **row_ind, aoclsparse_double_complex **val)
+{
+    return export_csc<cdouble>(mat, base, m, n, nnz, col_ptr, row_ind, reinterpret_cast<cdouble **>(val), aoclsparse_zmat);
+}
+aoclsparse_status aoclsparse_export_ccoo(const aoclsparse_matrix mat, aoclsparse_index_base *base, aoclsparse_int *m,
+                                         aoclsparse_int *n, aoclsparse_int *nnz, aoclsparse_int **row_ptr,
+                                         aoclsparse_int **col_ptr, aoclsparse_float_complex **val)
+{
+    return export_coo<cfloat>(mat, base, m, n, nnz, row_ptr, col_ptr, reinterpret_cast<cfloat **>(val), aoclsparse_cmat);
+}
+aoclsparse_status aoclsparse_export_zcoo(const aoclsparse_matrix mat, aoclsparse_index_base *base, aoclsparse_int *m,
+                                         aoclsparse_int *n, aoclsparse_int *nnz, aoclsparse_int **row_ptr,
+                                         aoclsparse_int **col_ptr, aoclsparse_double_complex **val)
+{
+    return export_coo<cdouble>(mat, base, m, n, nnz, row_ptr, col_ptr, reinterpret_cast<cdouble **>(val), aoclsparse_zmat);
 }
 
 aoclsparse_status aoclsparse_export_dcsc(const aoclsparse_matrix mat, aoclsparse_index_base *base, aoclsparse_int *m,
@@ -377,10 +427,9 @@ aoclsparse_status aoclsparse_convert_csr(const aoclsparse_matrix src_mat, const 
         return aoclsparse_status_invalid_pointer;
     if(src_mat->input_format != aoclsparse_coo_mat && src_mat->input_format != aoclsparse_csr_mat)
         return aoclsparse_status_not_implemented;
-    if(is_complex_type(src_mat->val_type))
-        return aoclsparse_status_not_implemented; // complex handles: ?mv only
-    return src_mat->val_type == aoclsparse_smat ? convert_csr<float>(src_mat, op, dest_mat, aoclsparse_smat)
-                                                : convert_csr<double>(src_mat, op, dest_mat, aoclsparse_dmat);
+    return dispatch_value_type(src_mat->val_type, [&](auto tag) {
+        return convert_csr<decltype(tag)>(src_mat, op, dest_mat, src_mat->val_type);
+    });
 }
 
 aoclsparse_status aoclsparse_order_mat(aoclsparse_matrix mat)
@@ -395,20 +444,16 @@ aoclsparse_status aoclsparse_order_mat(aoclsparse_matrix mat)
         return aoclsparse_status_success;
     if(!mat->user.ptr || !mat->user.ind || !mat->user.val)
         return aoclsparse_status_invalid_pointer;
-    if(is_complex_type(mat->val_type))
-        return aoclsparse_status_not_implemented;
     std::unique_lock<std::shared_mutex> w(mat->guard);
-    aoclsparse_status                   st;
-    const bool                          f = mat->val_type == aoclsparse_smat;
-    if(mat->csc_ptr) // the caller's CSC arrays are "the first representation" there (auxiliary.cpp:1268-1294)
-    {
-        st = f ? sort_rows<float>(mat->n, mat->base, mat->csc_ptr, mat->csc_ind, static_cast<float *>(mat->csc_val))
-               : sort_rows<double>(mat->n, mat->base, mat->csc_ptr, mat->csc_ind, static_cast<double *>(mat->csc_val));
-        if(st != aoclsparse_status_success)
-            return st;
-    }
-    st = f ? sort_rows<float>(mat->m, mat->base, mat->user.ptr, mat->user.ind, static_cast<float *>(mat->user.val))
-           : sort_rows<double>(mat->m, mat->base, mat->user.ptr, mat->user.ind, static_cast<double *>(mat->user.val));
+    aoclsparse_status                   st = dispatch_value_type(mat->val_type, [&](auto tag) {
+        using T              = decltype(tag);
+        aoclsparse_status rc = aoclsparse_status_success;
+        if(mat->csc_ptr) // the caller's CSC arrays are "the first representation" there (auxiliary.cpp:1268-1294)
+            rc = sort_rows<T>(mat->n, mat->base, mat->csc_ptr, mat->csc_ind, static_cast<T *>(mat->csc_val));
+        if(rc == aoclsparse_status_success)
+            rc = sort_rows<T>(mat->m, mat->base, mat->user.ptr, mat->user.ind, static_cast<T *>(mat->user.val));
+        return rc;
+    });
     if(st != aoclsparse_status_success)
         return st;
     int  sort = 0;
@@ -441,6 +486,29 @@ aoclsparse_status aoclsparse_scsr2csc(aoclsparse_int m, aoclsparse_int n, aoclsp
         return aoclsparse_status_invalid_pointer;
     return csr2csc<float>(m, n, nnz, descr->base, baseCSC, csr_row_ptr, csr_col_ind, csr_val, csc_row_ind, csc_col_ptr,
                           csc_val);
+}
+aoclsparse_status aoclsparse_ccsr2csc(aoclsparse_int m, aoclsparse_int n, aoclsparse_int nnz,
+                                      const aoclsparse_mat_descr descr, aoclsparse_index_base baseCSC,
+                                      const aoclsparse_int *csr_row_ptr, const aoclsparse_int *csr_col_ind,
+                                      const aoclsparse_float_complex *csr_val, aoclsparse_int *csc_row_ind,
+                                      aoclsparse_int *csc_col_ptr, aoclsparse_float_complex *csc_val)
+{
+    if(!descr)
+        return aoclsparse_status_invalid_pointer;
+    return csr2csc<cfloat>(m, n, nnz, descr->base, baseCSC, csr_row_ptr, csr_col_ind, reinterpret_cast<const cfloat *>(csr_val),
+                           csc_row_ind, csc_col_ptr, reinterpret_cast<cfloat *>(csc_val));
+}
+aoclsparse_status aoclsparse_zcsr2csc(aoclsparse_int m, aoclsparse_int n, aoclsparse_int nnz,
+                                      const aoclsparse_mat_descr descr, aoclsparse_index_base baseCSC,
+                                      const aoclsparse_int *csr_row_ptr, const aoclsparse_int *csr_col_ind,
+                                      const aoclsparse_double_complex *csr_val, aoclsparse_int *csc_row_ind,
+                                      aoclsparse_int *csc_col_ptr, aoclsparse_double_complex *csc_val)
+{
+    if(!descr)
+        return aoclsparse_status_invalid_pointer;
+    return csr2csc<cdouble>(m, n, nnz, descr->base, baseCSC, csr_row_ptr, csr_col_ind,
+                            reinterpret_cast<const cdouble *>(csr_val), csc_row_ind, csc_col_ptr,
+                            reinterpret_cast<cdouble *>(csc_val));
 }
 
 } // extern "C"

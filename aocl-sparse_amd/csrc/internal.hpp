@@ -269,7 +269,7 @@ struct _aoclsparse_matrix
     // device side; guarded by `guard` (executors take it shared, builders exclusive)
     mi355::DeviceCsr dev_user, dev_trans;
     mi355::SpmvPlan  plan_user, plan_trans;
-    mi355::TrsvPlan  trsv_plan[4]; // index: (upper?2:0) + (transpose?1:0)
+    mi355::TrsvPlan  trsv_plan[6]; // index: (upper?2:0) + (transpose?1:0); complex op = H: 4 + (upper?1:0)
     mi355::DeviceBuffer dev_diag; // diagonal values of the clean CSR (length min(m,n))
     mi355::DeviceBuffer trsv_scratch; // ticket (one per right-hand side) + timeout words of the sync-free solve
     mi355::DeviceBuffer trsv_xp; // solution(s) in level order, m x nrhs (stream-ordered reuse)
@@ -409,7 +409,7 @@ aoclsparse_status ensure_spmv(aoclsparse_matrix A, bool transposed, DeviceCsr *&
 aoclsparse_status ensure_derived(aoclsparse_matrix A, aoclsparse_matrix_type type, aoclsparse_fill_mode fill,
                                  aoclsparse_diag_type diag, bool transposed, Derived *&out);
 // clean CSR on the device + level sets of one triangle (trsv_api.cpp)
-aoclsparse_status ensure_trsv(aoclsparse_matrix A, bool upper, bool transposed);
+aoclsparse_status ensure_trsv(aoclsparse_matrix A, bool upper, bool transposed, bool conj = false);
 // SELL-64 copy of d (row_ptr_host = the host row pointer d mirrors); leaves plan.sell.valid false when the
 // padding would exceed the budget (AOCLSPARSE_MI355_SELL=0 never, =1 always)
 aoclsparse_status build_sell(const aoclsparse_int *row_ptr_host, const DeviceCsr &d, size_t vsize, SpmvPlan &plan);
@@ -535,6 +535,14 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
                               const TrsvPlan &plan, const T *diag, const T *b, T *x, T *xp,
                               unsigned int *scratch, aoclsparse_int nrhs, long long b_off, aoclsparse_int incb,
                               long long x_off, aoclsparse_int incx);
+
+// complex triangular solve (complex_kernels.hip): the hybrid schedule of the plan (runs of narrow levels inside one
+// workgroup, one launch per wide level); conj_diag for op = H (the plan's values are stored conjugated)
+template <typename R>
+aoclsparse_status launch_ctrsv(hipStream_t s, bool unit, bool conj_diag, cplx<R> alpha, aoclsparse_int m,
+                               const TrsvPlan &plan, const cplx<R> *diag, const cplx<R> *b, cplx<R> *x, cplx<R> *xp,
+                               aoclsparse_int nrhs, long long b_off, aoclsparse_int incb, long long x_off,
+                               aoclsparse_int incx);
 
 template <typename T>
 aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, T alpha,

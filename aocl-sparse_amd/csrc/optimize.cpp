@@ -87,8 +87,8 @@ extern "C" aoclsparse_status aoclsparse_optimize(aoclsparse_matrix A)
                     && (h.type == aoclsparse_matrix_type_triangular
                         || h.type == aoclsparse_matrix_type_symmetric))
             {
-                st = ensure_trsv(A, h.fill == aoclsparse_fill_mode_upper,
-                                 h.trans != aoclsparse_operation_none);
+                st = ensure_trsv(A, h.fill == aoclsparse_fill_mode_upper, h.trans != aoclsparse_operation_none,
+                                 h.trans == aoclsparse_operation_conjugate_transpose);
             }
             else if(h.act == action_mm || h.act == action_2m)
             {

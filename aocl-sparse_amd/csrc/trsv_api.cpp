@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 
 using namespace mi355;
 
@@ -25,7 +26,7 @@ struct Triangle
 };
 
 template <typename T>
-static void build_triangle(const HostCsr &c, bool upper, bool transposed, Triangle<T> &t)
+static void build_triangle(const HostCsr &c, bool upper, bool transposed, bool conj, Triangle<T> &t)
 {
     const aoclsparse_int  m = c.m, b = c.base;
     const aoclsparse_int *s = upper ? c.iurow : c.ptr; // strict triangle of row i: [s[i], e[i]) in base b
@@ -71,6 +72,9 @@ static void build_triangle(const HostCsr &c, bool upper, bool transposed, Triang
         }
     }
     t.descending = !upper; // L^T is upper triangular: x_c needs x_i, i > c
+    if(conj) // op = H: the column sweep applies conj(a_ic) (ref_trsv_lth / _uth with the conjugating accessor)
+        for(auto &a : t.val)
+            a = conj_of(a);
 }
 
 // level[i] = 1 + max level of the rows row i depends on; rows bucketed by level (counting sort,
@@ -148,19 +152,20 @@ static aoclsparse_status build_levels(aoclsparse_int m, const Triangle<T> &t, Tr
 }
 
 template <typename T>
-static aoclsparse_status build_plan_t(const HostCsr &c, bool upper, bool transposed, TrsvPlan &plan)
+static aoclsparse_status build_plan_t(const HostCsr &c, bool upper, bool transposed, bool conj, TrsvPlan &plan)
 {
     Triangle<T> t;
-    build_triangle<T>(c, upper, transposed, t);
+    build_triangle<T>(c, upper, transposed, conj, t);
     return build_levels<T>(c.m, t, plan);
 }
 
-aoclsparse_status ensure_trsv(aoclsparse_matrix A, bool upper, bool transposed)
+aoclsparse_status ensure_trsv(aoclsparse_matrix A, bool upper, bool transposed, bool conj)
 {
+    conj = conj && transposed && is_complex_type(A->val_type);
     aoclsparse_status st = csr_optimize(A);
     if(st != aoclsparse_status_success)
         return st;
-    TrsvPlan &plan = A->trsv_plan[(upper ? 2 : 0) + (transposed ? 1 : 0)];
+    TrsvPlan &plan = A->trsv_plan[conj ? 4 + (upper ? 1 : 0) : (upper ? 2 : 0) + (transposed ? 1 : 0)];
     {
         std::shared_lock<std::shared_mutex> r(A->guard);
         if(plan.valid)
@@ -187,8 +192,9 @@ aoclsparse_status ensure_trsv(aoclsparse_matrix A, bool upper, bool transposed)
             if(st != aoclsparse_status_success)
                 return st;
         }
-        st = A->val_type == aoclsparse_smat ? build_plan_t<float>(c, upper, transposed, plan)
-                                            : build_plan_t<double>(c, upper, transposed, plan);
+        st = dispatch_value_type(A->val_type, [&](auto tag) {
+            return build_plan_t<decltype(tag)>(c, upper, transposed, conj, plan);
+        });
         if(st != aoclsparse_status_success)
             return st;
         plan.valid = true;
@@ -204,6 +210,14 @@ aoclsparse_status ensure_trsv(aoclsparse_matrix A, bool upper, bool transposed)
 
 namespace
 {
+
+#define MI355_TRY(expr)                       \
+    do                                        \
+    {                                         \
+        aoclsparse_status st__ = (expr);      \
+        if(st__ != aoclsparse_status_success) \
+            return st__;                      \
+    } while(0)
 
 // Shared tail of trsv / trsm: plan lookup, schedule choice, staging of host operands, launch.
 // b / x describe nrhs right-hand sides: column c at b + c*b_off (element stride incb), likewise x.
@@ -222,19 +236,22 @@ aoclsparse_status solve_core(aoclsparse_operation trans, T alpha, aoclsparse_mat
     const bool upper = descr->fill_mode == aoclsparse_fill_mode_upper;
     const bool tr    = trans != aoclsparse_operation_none;
     const bool unit  = descr->diag_type == aoclsparse_diag_type_unit;
-    st               = ensure_trsv(A, upper, tr);
+    constexpr bool is_cplx = !std::is_floating_point<T>::value;
+    const bool     conj    = is_cplx && trans == aoclsparse_operation_conjugate_transpose;
+    st                     = ensure_trsv(A, upper, tr, conj);
     if(st != aoclsparse_status_success)
         return st;
     // solves on one handle share its workspaces: serialise their enqueue (kernels are stream-ordered)
     std::lock_guard<std::recursive_mutex> sl(rt.stage_lock);
     std::shared_lock<std::shared_mutex>   r(A->guard);
-    const TrsvPlan                       &plan = A->trsv_plan[(upper ? 2 : 0) + (tr ? 1 : 0)];
+    const TrsvPlan &plan = A->trsv_plan[conj ? 4 + (upper ? 1 : 0) : (upper ? 2 : 0) + (tr ? 1 : 0)];
 
     // schedule (all three give the same bits): kid 0 = one launch per level, kid 1/2 = hybrid (narrow
     // level runs inside one workgroup), kid 3 = sync-free single launch.  auto: a shallow DAG of wide
     // levels is cheapest as plain launches; otherwise sync-free, which measured fastest on both the
     // 2-D Laplacian and the shell-like ILU(0) factors (profiles/r1).
-    const int schedule = kid == 0 ? 0 : (kid == 3 ? 2 : (kid > 0 ? 1 : (plan.nlevels <= 32 ? 0 : 2)));
+    // (complex handles always run the hybrid schedule: their 8 / 16-byte x cannot be the one-word ready flag)
+    const int schedule = is_cplx ? 1 : kid == 0 ? 0 : (kid == 3 ? 2 : (kid > 0 ? 1 : (plan.nlevels <= 32 ? 0 : 2)));
 
     st = A->trsv_xp.alloc(sizeof(T) * (size_t)m * (size_t)nrhs);
     if(st == aoclsparse_status_success)
@@ -263,13 +280,17 @@ aoclsparse_status solve_core(aoclsparse_operation trans, T alpha, aoclsparse_mat
             MI355_HIP_TRY(hipMemcpyAsync(tmp, x, sizeof(T) * span_x, hipMemcpyHostToDevice, rt.stream()));
         dx = static_cast<T *>(tmp);
     }
-    st = launch_trsv<T>(rt.stream(), schedule, unit, alpha, m, plan, A->dev_diag.as<T>(), db, dx,
-                        A->trsv_xp.as<T>(), A->trsv_scratch.as<unsigned int>(), nrhs, b_off, incb, x_off, incx);
+    if constexpr(is_cplx)
+        st = launch_ctrsv(rt.stream(), unit, conj, alpha, m, plan, A->dev_diag.as<T>(), db, dx, A->trsv_xp.as<T>(), nrhs,
+                          b_off, incb, x_off, incx);
+    else
+        st = launch_trsv<T>(rt.stream(), schedule, unit, alpha, m, plan, A->dev_diag.as<T>(), db, dx,
+                            A->trsv_xp.as<T>(), A->trsv_scratch.as<unsigned int>(), nrhs, b_off, incb, x_off, incx);
     if(st != aoclsparse_status_success)
         return st;
     if(!xdev)
         MI355_HIP_TRY(hipMemcpyAsync(x, dx, sizeof(T) * span_x, hipMemcpyDeviceToHost, rt.stream()));
-    const bool syncfree = schedule == 2 || (schedule == 1 && (nrhs != 1 || incb != 1 || incx != 1));
+    const bool syncfree = !is_cplx && (schedule == 2 || (schedule == 1 && (nrhs != 1 || incb != 1 || incx != 1)));
     if(!xdev || syncfree)
     {
         // host semantics, and the sync-free path reports a (never expected) spin timeout
@@ -400,9 +421,74 @@ aoclsparse_status trsm_t(aoclsparse_operation trans, const T alpha, aoclsparse_m
     return solve_core<T>(trans, alpha, A, descr, kid, B, X, n, b_off, incb, span_b, x_off, incx, span_x, !dense_x);
 }
 
+// aoclsparse_?csrsv (level2/aoclsparse_csrsv.hpp:28-190): the older raw-array solve, y = inv(T) * alpha * x with T the
+// lower / upper triangle of the CSR arrays chosen by descr->fill_mode.  Its row loop is the chain of ref_trsv_l / _u
+// (alpha*x_i, subtract in storage order, divide by the diagonal), so it is served by the TRSV path on a one-shot
+// handle over the caller's arrays (kid 0 order: bit-identical for sorted rows with a full diagonal).
+// Deviations, both on input the reference mishandles: rows are sorted by the clean-CSR step instead of being cut at
+// the first upper entry, and a missing diagonal of a non-unit solve is invalid_value instead of a division by a
+// stale entry.  Host arrays only (the analysis walks them).
+template <typename T>
+aoclsparse_status csrsv_t(aoclsparse_operation trans, const T *alpha, aoclsparse_int m, const T *csr_val,
+                          const aoclsparse_int *csr_col_ind, const aoclsparse_int *csr_row_ptr,
+                          const aoclsparse_mat_descr descr, const T *x, T *y)
+{
+    if(!csr_val || !csr_row_ptr || !csr_col_ind || !x || !y || !descr || !alpha)
+        return aoclsparse_status_invalid_pointer;
+    if(descr->base != aoclsparse_index_base_zero)
+        return aoclsparse_status_not_implemented;
+    if(descr->type != aoclsparse_matrix_type_general && descr->type != aoclsparse_matrix_type_symmetric)
+        return aoclsparse_status_not_implemented;
+    if(trans != aoclsparse_operation_none)
+        return aoclsparse_status_not_implemented;
+    if(m < 0)
+        return aoclsparse_status_invalid_size;
+    if(m == 0)
+        return aoclsparse_status_success;
+    Runtime &rt = Runtime::get();
+    MI355_TRY(rt.init());
+    if(rt.is_device_pointer(csr_row_ptr) || rt.is_device_pointer(csr_col_ind) || rt.is_device_pointer(csr_val))
+        return aoclsparse_status_not_implemented;
+    aoclsparse_matrix A  = nullptr;
+    aoclsparse_status st = std::is_same<T, float>::value
+                               ? aoclsparse_create_scsr(&A, descr->base, m, m, csr_row_ptr[m] - descr->base,
+                                                        const_cast<aoclsparse_int *>(csr_row_ptr),
+                                                        const_cast<aoclsparse_int *>(csr_col_ind),
+                                                        reinterpret_cast<float *>(const_cast<T *>(csr_val)))
+                               : aoclsparse_create_dcsr(&A, descr->base, m, m, csr_row_ptr[m] - descr->base,
+                                                        const_cast<aoclsparse_int *>(csr_row_ptr),
+                                                        const_cast<aoclsparse_int *>(csr_col_ind),
+                                                        reinterpret_cast<double *>(const_cast<T *>(csr_val)));
+    if(st != aoclsparse_status_success)
+        return st;
+    _aoclsparse_mat_descr tri = *descr;
+    tri.type                  = aoclsparse_matrix_type_triangular;
+    if(tri.fill_mode != aoclsparse_fill_mode_lower)
+        tri.fill_mode = aoclsparse_fill_mode_upper; // csrsv.hpp:77-86: anything but lower runs the upper solve
+    st = trsv_t<T>(aoclsparse_operation_none, *alpha, A, &tri, x, 1, y, 1, 0,
+                   std::is_same<T, float>::value ? aoclsparse_smat : aoclsparse_dmat);
+    aoclsparse_destroy(&A);
+    return st;
+}
+
 } // namespace
 
 extern "C" {
+
+aoclsparse_status aoclsparse_dcsrsv(aoclsparse_operation trans, const double *alpha, aoclsparse_int m,
+                                    const double *csr_val, const aoclsparse_int *csr_col_ind,
+                                    const aoclsparse_int *csr_row_ptr, const aoclsparse_mat_descr descr, const double *x,
+                                    double *y)
+{
+    return csrsv_t<double>(trans, alpha, m, csr_val, csr_col_ind, csr_row_ptr, descr, x, y);
+}
+aoclsparse_status aoclsparse_scsrsv(aoclsparse_operation trans, const float *alpha, aoclsparse_int m,
+                                    const float *csr_val, const aoclsparse_int *csr_col_ind,
+                                    const aoclsparse_int *csr_row_ptr, const aoclsparse_mat_descr descr, const float *x,
+                                    float *y)
+{
+    return csrsv_t<float>(trans, alpha, m, csr_val, csr_col_ind, csr_row_ptr, descr, x, y);
+}
 
 aoclsparse_status aoclsparse_dtrsv(aoclsparse_operation trans, const double alpha, aoclsparse_matrix A,
                                    const aoclsparse_mat_descr descr, const double *b, double *x)
@@ -474,14 +560,85 @@ aoclsparse_status aoclsparse_strsm_kid(const aoclsparse_operation trans, const f
     return trsm_t<float>(trans, alpha, A, descr, order, B, n, ldb, X, ldx, kid, aoclsparse_smat);
 }
 
+aoclsparse_status aoclsparse_ctrsv(aoclsparse_operation trans, const aoclsparse_float_complex alpha, aoclsparse_matrix A,
+                                   const aoclsparse_mat_descr descr, const aoclsparse_float_complex *b, aoclsparse_float_complex *x)
+{
+    return trsv_t<cfloat>(trans, cfloat(alpha.real, alpha.imag), A, descr, reinterpret_cast<const cfloat *>(b), 1,
+                         reinterpret_cast<cfloat *>(x), 1, -1, aoclsparse_cmat);
+}
+aoclsparse_status aoclsparse_ctrsv_kid(aoclsparse_operation trans, const aoclsparse_float_complex alpha, aoclsparse_matrix A,
+                                       const aoclsparse_mat_descr descr, const aoclsparse_float_complex *b, aoclsparse_float_complex *x, aoclsparse_int kid)
+{
+    return trsv_t<cfloat>(trans, cfloat(alpha.real, alpha.imag), A, descr, reinterpret_cast<const cfloat *>(b), 1,
+                         reinterpret_cast<cfloat *>(x), 1, kid, aoclsparse_cmat);
+}
+aoclsparse_status aoclsparse_ctrsv_strided(aoclsparse_operation trans, const aoclsparse_float_complex alpha, aoclsparse_matrix A,
+                                           const aoclsparse_mat_descr descr, const aoclsparse_float_complex *b, const aoclsparse_int incb,
+                                           aoclsparse_float_complex *x, const aoclsparse_int incx)
+{
+    return trsv_t<cfloat>(trans, cfloat(alpha.real, alpha.imag), A, descr, reinterpret_cast<const cfloat *>(b), incb,
+                         reinterpret_cast<cfloat *>(x), incx, -1, aoclsparse_cmat);
+}
+aoclsparse_status aoclsparse_ctrsm(const aoclsparse_operation trans, const aoclsparse_float_complex alpha, aoclsparse_matrix A,
+                                   const aoclsparse_mat_descr descr, aoclsparse_order order, const aoclsparse_float_complex *B,
+                                   aoclsparse_int n, aoclsparse_int ldb, aoclsparse_float_complex *X, aoclsparse_int ldx)
+{
+    return trsm_t<cfloat>(trans, cfloat(alpha.real, alpha.imag), A, descr, order, reinterpret_cast<const cfloat *>(B), n, ldb,
+                         reinterpret_cast<cfloat *>(X), ldx, -1, aoclsparse_cmat);
+}
+aoclsparse_status aoclsparse_ctrsm_kid(const aoclsparse_operation trans, const aoclsparse_float_complex alpha, aoclsparse_matrix A,
+                                       const aoclsparse_mat_descr descr, aoclsparse_order order, const aoclsparse_float_complex *B,
+                                       aoclsparse_int n, aoclsparse_int ldb, aoclsparse_float_complex *X, aoclsparse_int ldx,
+                                       const aoclsparse_int kid)
+{
+    return trsm_t<cfloat>(trans, cfloat(alpha.real, alpha.imag), A, descr, order, reinterpret_cast<const cfloat *>(B), n, ldb,
+                         reinterpret_cast<cfloat *>(X), ldx, kid, aoclsparse_cmat);
+}
+
+aoclsparse_status aoclsparse_ztrsv(aoclsparse_operation trans, const aoclsparse_double_complex alpha, aoclsparse_matrix A,
+                                   const aoclsparse_mat_descr descr, const aoclsparse_double_complex *b, aoclsparse_double_complex *x)
+{
+    return trsv_t<cdouble>(trans, cdouble(alpha.real, alpha.imag), A, descr, reinterpret_cast<const cdouble *>(b), 1,
+                         reinterpret_cast<cdouble *>(x), 1, -1, aoclsparse_zmat);
+}
+aoclsparse_status aoclsparse_ztrsv_kid(aoclsparse_operation trans, const aoclsparse_double_complex alpha, aoclsparse_matrix A,
+                                       const aoclsparse_mat_descr descr, const aoclsparse_double_complex *b, aoclsparse_double_complex *x, aoclsparse_int kid)
+{
+    return trsv_t<cdouble>(trans, cdouble(alpha.real, alpha.imag), A, descr, reinterpret_cast<const cdouble *>(b), 1,
+                         reinterpret_cast<cdouble *>(x), 1, kid, aoclsparse_zmat);
+}
+aoclsparse_status aoclsparse_ztrsv_strided(aoclsparse_operation trans, const aoclsparse_double_complex alpha, aoclsparse_matrix A,
+                                           const aoclsparse_mat_descr descr, const aoclsparse_double_complex *b, const aoclsparse_int incb,
+                                           aoclsparse_double_complex *x, const aoclsparse_int incx)
+{
+    return trsv_t<cdouble>(trans, cdouble(alpha.real, alpha.imag), A, descr, reinterpret_cast<const cdouble *>(b), incb,
+                         reinterpret_cast<cdouble *>(x), incx, -1, aoclsparse_zmat);
+}
+aoclsparse_status aoclsparse_ztrsm(const aoclsparse_operation trans, const aoclsparse_double_complex alpha, aoclsparse_matrix A,
+                                   const aoclsparse_mat_descr descr, aoclsparse_order order, const aoclsparse_double_complex *B,
+                                   aoclsparse_int n, aoclsparse_int ldb, aoclsparse_double_complex *X, aoclsparse_int ldx)
+{
+    return trsm_t<cdouble>(trans, cdouble(alpha.real, alpha.imag), A, descr, order, reinterpret_cast<const cdouble *>(B), n, ldb,
+                         reinterpret_cast<cdouble *>(X), ldx, -1, aoclsparse_zmat);
+}
+aoclsparse_status aoclsparse_ztrsm_kid(const aoclsparse_operation trans, const aoclsparse_double_complex alpha, aoclsparse_matrix A,
+                                       const aoclsparse_mat_descr descr, aoclsparse_order order, const aoclsparse_double_complex *B,
+                                       aoclsparse_int n, aoclsparse_int ldb, aoclsparse_double_complex *X, aoclsparse_int ldx,
+                                       const aoclsparse_int kid)
+{
+    return trsm_t<cdouble>(trans, cdouble(alpha.real, alpha.imag), A, descr, order, reinterpret_cast<const cdouble *>(B), n, ldb,
+                         reinterpret_cast<cdouble *>(X), ldx, kid, aoclsparse_zmat);
+}
+
 aoclsparse_status aoclsparse_mi355_get_trsv_levels(const aoclsparse_matrix A, aoclsparse_fill_mode fill,
                                                    aoclsparse_operation op, aoclsparse_int *levels)
 {
     if(!A || !levels)
         return aoclsparse_status_invalid_pointer;
     std::shared_lock<std::shared_mutex> r(A->guard);
-    const TrsvPlan &p = A->trsv_plan[(fill == aoclsparse_fill_mode_upper ? 2 : 0)
-                                     + (op != aoclsparse_operation_none ? 1 : 0)];
+    const bool      up = fill == aoclsparse_fill_mode_upper;
+    const bool      cj = op == aoclsparse_operation_conjugate_transpose && is_complex_type(A->val_type);
+    const TrsvPlan &p  = A->trsv_plan[cj ? 4 + (up ? 1 : 0) : (up ? 2 : 0) + (op != aoclsparse_operation_none ? 1 : 0)];
     *levels = p.valid ? p.nlevels : -1;
     return aoclsparse_status_success;
 }

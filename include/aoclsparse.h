@@ -479,6 +479,57 @@ DLL_PUBLIC aoclsparse_status aoclsparse_zcsrmm_kid(aoclsparse_operation op, cons
                                                    aoclsparse_double_complex *C, aoclsparse_int ldc,
                                                    const aoclsparse_int kid);
 
+/* raw-array triangular solve y = inv(T) * alpha * x, T = the triangle of the CSR arrays named by descr->fill_mode
+ * (aoclsparse_functions.h:1318-1402): zero-based, op = none, general / symmetric descriptor type, host arrays. */
+DLL_PUBLIC aoclsparse_status aoclsparse_scsrsv(aoclsparse_operation trans, const float *alpha, aoclsparse_int m,
+                                               const float *csr_val, const aoclsparse_int *csr_col_ind,
+                                               const aoclsparse_int *csr_row_ptr, const aoclsparse_mat_descr descr,
+                                               const float *x, float *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_dcsrsv(aoclsparse_operation trans, const double *alpha, aoclsparse_int m,
+                                               const double *csr_val, const aoclsparse_int *csr_col_ind,
+                                               const aoclsparse_int *csr_row_ptr, const aoclsparse_mat_descr descr,
+                                               const double *x, double *y);
+/* complex triangular solves (aoclsparse_functions.h:1541-1598,1620-1697,2620-2760): same checks and semantics as the
+ * real ones; op = conjugate_transpose conjugates the triangle.  kid is validated and otherwise ignored. */
+DLL_PUBLIC aoclsparse_status aoclsparse_ctrsv(aoclsparse_operation trans, const aoclsparse_float_complex alpha,
+                                               aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                               const aoclsparse_float_complex *b, aoclsparse_float_complex *x);
+DLL_PUBLIC aoclsparse_status aoclsparse_ctrsv_kid(aoclsparse_operation trans, const aoclsparse_float_complex alpha,
+                                                   aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                                   const aoclsparse_float_complex *b, aoclsparse_float_complex *x, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_ctrsv_strided(aoclsparse_operation trans, const aoclsparse_float_complex alpha,
+                                                       aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                                       const aoclsparse_float_complex *b, const aoclsparse_int incb,
+                                                       aoclsparse_float_complex *x, const aoclsparse_int incx);
+DLL_PUBLIC aoclsparse_status aoclsparse_ctrsm(const aoclsparse_operation trans, const aoclsparse_float_complex alpha,
+                                               aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                               aoclsparse_order order, const aoclsparse_float_complex *B, aoclsparse_int n,
+                                               aoclsparse_int ldb, aoclsparse_float_complex *X, aoclsparse_int ldx);
+DLL_PUBLIC aoclsparse_status aoclsparse_ctrsm_kid(const aoclsparse_operation trans, const aoclsparse_float_complex alpha,
+                                                   aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                                   aoclsparse_order order, const aoclsparse_float_complex *B, aoclsparse_int n,
+                                                   aoclsparse_int ldb, aoclsparse_float_complex *X, aoclsparse_int ldx,
+                                                   const aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_ztrsv(aoclsparse_operation trans, const aoclsparse_double_complex alpha,
+                                               aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                               const aoclsparse_double_complex *b, aoclsparse_double_complex *x);
+DLL_PUBLIC aoclsparse_status aoclsparse_ztrsv_kid(aoclsparse_operation trans, const aoclsparse_double_complex alpha,
+                                                   aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                                   const aoclsparse_double_complex *b, aoclsparse_double_complex *x, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_ztrsv_strided(aoclsparse_operation trans, const aoclsparse_double_complex alpha,
+                                                       aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                                       const aoclsparse_double_complex *b, const aoclsparse_int incb,
+                                                       aoclsparse_double_complex *x, const aoclsparse_int incx);
+DLL_PUBLIC aoclsparse_status aoclsparse_ztrsm(const aoclsparse_operation trans, const aoclsparse_double_complex alpha,
+                                               aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                               aoclsparse_order order, const aoclsparse_double_complex *B, aoclsparse_int n,
+                                               aoclsparse_int ldb, aoclsparse_double_complex *X, aoclsparse_int ldx);
+DLL_PUBLIC aoclsparse_status aoclsparse_ztrsm_kid(const aoclsparse_operation trans, const aoclsparse_double_complex alpha,
+                                                   aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                                   aoclsparse_order order, const aoclsparse_double_complex *B, aoclsparse_int n,
+                                                   aoclsparse_int ldb, aoclsparse_double_complex *X, aoclsparse_int ldx,
+                                                   const aoclsparse_int kid);
+
 /* ---- other input formats and structure conversions (aoclsparse_auxiliary.h:674-1095, aoclsparse_convert.h:494-660).
  * A CSC handle behaves like the CSR handle of the same matrix in every executor (its CSR is built at creation);
  * a COO handle can be exported, mutated and converted (aoclsparse_convert_csr), executors return not_implemented. */
@@ -525,6 +576,51 @@ DLL_PUBLIC aoclsparse_status aoclsparse_dcsr2csc(aoclsparse_int m, aoclsparse_in
                                                  const aoclsparse_int *csr_col_ind, const double *csr_val,
                                                  aoclsparse_int *csc_row_ind, aoclsparse_int *csc_col_ptr,
                                                  double *csc_val);
+/* complex twins of the above (aoclsparse_auxiliary.h:438-560,748-870; aoclsparse_convert.h:528-560) */
+DLL_PUBLIC aoclsparse_status aoclsparse_create_ccsc(aoclsparse_matrix *mat, aoclsparse_index_base base,
+                                                    aoclsparse_int M, aoclsparse_int N, aoclsparse_int nnz,
+                                                    aoclsparse_int *col_ptr, aoclsparse_int *row_idx,
+                                                    aoclsparse_float_complex *val);
+DLL_PUBLIC aoclsparse_status aoclsparse_create_ccoo(aoclsparse_matrix *mat, const aoclsparse_index_base base,
+                                                    const aoclsparse_int M, const aoclsparse_int N,
+                                                    const aoclsparse_int nnz, aoclsparse_int *row_ind,
+                                                    aoclsparse_int *col_ind, aoclsparse_float_complex *val);
+DLL_PUBLIC aoclsparse_status aoclsparse_export_ccsc(const aoclsparse_matrix mat, aoclsparse_index_base *base,
+                                                    aoclsparse_int *m, aoclsparse_int *n, aoclsparse_int *nnz,
+                                                    aoclsparse_int **col_ptr, aoclsparse_int **row_ind,
+                                                    aoclsparse_float_complex **val);
+DLL_PUBLIC aoclsparse_status aoclsparse_export_ccoo(const aoclsparse_matrix mat, aoclsparse_index_base *base,
+                                                    aoclsparse_int *m, aoclsparse_int *n, aoclsparse_int *nnz,
+                                                    aoclsparse_int **row_ptr, aoclsparse_int **col_ptr,
+                                                    aoclsparse_float_complex **val);
+DLL_PUBLIC aoclsparse_status aoclsparse_ccsr2csc(aoclsparse_int m, aoclsparse_int n, aoclsparse_int nnz,
+                                                 const aoclsparse_mat_descr descr, aoclsparse_index_base baseCSC,
+                                                 const aoclsparse_int *csr_row_ptr,
+                                                 const aoclsparse_int *csr_col_ind,
+                                                 const aoclsparse_float_complex *csr_val, aoclsparse_int *csc_row_ind,
+                                                 aoclsparse_int *csc_col_ptr, aoclsparse_float_complex *csc_val);
+DLL_PUBLIC aoclsparse_status aoclsparse_create_zcsc(aoclsparse_matrix *mat, aoclsparse_index_base base,
+                                                    aoclsparse_int M, aoclsparse_int N, aoclsparse_int nnz,
+                                                    aoclsparse_int *col_ptr, aoclsparse_int *row_idx,
+                                                    aoclsparse_double_complex *val);
+DLL_PUBLIC aoclsparse_status aoclsparse_create_zcoo(aoclsparse_matrix *mat, const aoclsparse_index_base base,
+                                                    const aoclsparse_int M, const aoclsparse_int N,
+                                                    const aoclsparse_int nnz, aoclsparse_int *row_ind,
+                                                    aoclsparse_int *col_ind, aoclsparse_double_complex *val);
+DLL_PUBLIC aoclsparse_status aoclsparse_export_zcsc(const aoclsparse_matrix mat, aoclsparse_index_base *base,
+                                                    aoclsparse_int *m, aoclsparse_int *n, aoclsparse_int *nnz,
+                                                    aoclsparse_int **col_ptr, aoclsparse_int **row_ind,
+                                                    aoclsparse_double_complex **val);
+DLL_PUBLIC aoclsparse_status aoclsparse_export_zcoo(const aoclsparse_matrix mat, aoclsparse_index_base *base,
+                                                    aoclsparse_int *m, aoclsparse_int *n, aoclsparse_int *nnz,
+                                                    aoclsparse_int **row_ptr, aoclsparse_int **col_ptr,
+                                                    aoclsparse_double_complex **val);
+DLL_PUBLIC aoclsparse_status aoclsparse_zcsr2csc(aoclsparse_int m, aoclsparse_int n, aoclsparse_int nnz,
+                                                 const aoclsparse_mat_descr descr, aoclsparse_index_base baseCSC,
+                                                 const aoclsparse_int *csr_row_ptr,
+                                                 const aoclsparse_int *csr_col_ind,
+                                                 const aoclsparse_double_complex *csr_val, aoclsparse_int *csc_row_ind,
+                                                 aoclsparse_int *csc_col_ptr, aoclsparse_double_complex *csc_val);
 
 /* ---- ELL family: the formats the reference's optimize step stores, as raw-array products
  * (aoclsparse_functions.h:789-885) and their CSR conversions (aoclsparse_convert.h).  Only general

@@ -281,6 +281,14 @@ def dellthybmv(base, alpha, m, ell_val, ell_col, width, ell_m, csr_val, csr_row,
     return st, y
 
 
+def dcsrsv(lower, unit, alpha, m, val, col, row_ptr, x):
+    val, col, row_ptr, x = _f64(val), _i32(col), _i32(row_ptr), _f64(x)
+    y = np.zeros(m)
+    st = lib().orc_dcsrsv(c_int(1 if lower else 0), c_int(1 if unit else 0), c_dbl(alpha), c_i32(m), _p(val), _p(col),
+                          _p(row_ptr), _p(x), _p(y))
+    return st, y
+
+
 def opt_blksize(m, nnz, base, row_ptr, col_ind):
     """-> (rows_blk or 0, total blocks)"""
     row_ptr, col_ind = _i32(row_ptr), _i32(col_ind)

@@ -1090,6 +1090,47 @@ int orc_dellthybmv(int base, double alpha, oint m, const double *ell_val, const 
     free(ytmp);
     return ORC_SUCCESS;
 }
+/* aoclsparse_csr_lsolve / _usolve, csrsv.hpp:88-187 (zero-based only, :47-51).  Lower: the row is walked left to
+ * right and CUT at the first entry on or right of the diagonal; upper: every entry right of the diagonal is applied.
+ * y -= a*y is contracted to an fma like every other chain; the diagonal used is the last one seen (diag_j persists
+ * across rows, as in the reference). */
+int orc_dcsrsv(int lower, int unit, double alpha, oint m, const double *val, const oint *col, const oint *row_ptr,
+               const double *x, double *y)
+{
+    oint diag_j = 0;
+    if(lower)
+        for(oint r = 0; r < m; r++)
+        {
+            double yr = alpha * x[r];
+            for(oint j = row_ptr[r]; j < row_ptr[r + 1]; j++)
+            {
+                if(col[j] < r)
+                    yr = fma(-val[j], y[col[j]], yr);
+                else
+                {
+                    if(!unit && col[j] == r)
+                        diag_j = j;
+                    break;
+                }
+            }
+            y[r] = unit ? yr : yr / val[diag_j];
+        }
+    else
+        for(oint r = m - 1; r >= 0; r--)
+        {
+            double yr = alpha * x[r];
+            for(oint j = row_ptr[r]; j < row_ptr[r + 1]; j++)
+            {
+                if(col[j] > r)
+                    yr = fma(-val[j], y[col[j]], yr);
+                if(!unit && col[j] == r)
+                    diag_j = j;
+            }
+            y[r] = unit ? yr : yr / val[diag_j];
+        }
+    return ORC_SUCCESS;
+}
+
 /* ---- BLKCSR ------------------------------------------------------------------------------------------
  * walk of one row block, shared by the block count (convert.cpp:71-107) and the conversion (:214-283):
  * every pass opens a window of 8 columns at the smallest unread column of the block's sub-rows and consumes

@@ -180,6 +180,11 @@ int orc_dcsr2ell(int layout, oint m, int base, const oint *row_ptr, const oint *
 int orc_dcsr2ellthyb(oint m, int base, oint *ell_m, const oint *row_ptr, const oint *col_ind,
                      const double *val, oint *map, oint *ell_col, double *ell_val, oint width);
 
+/* ---- aoclsparse_dcsrsv, level2/aoclsparse_csrsv.hpp:28-190 (no reference test holds vectors for it: cross-checked
+ *      against the pinned TRSV restatement on sorted full-diagonal inputs, where both walk the same chain) */
+int orc_dcsrsv(int lower, int unit, double alpha, oint m, const double *val, const oint *col, const oint *row_ptr,
+               const double *x, double *y);
+
 /* ---- BLKCSR (1/2/4 x 8 blocks + bit masks), conversion/aoclsparse_convert.cpp:36-310,
  *      level2/aoclsparse_blkcsrmv_avx512.cpp:40-369 */
 oint orc_opt_blksize(oint m, oint nnz, int base, const oint *row_ptr, const oint *col_ind, oint *total_blks);

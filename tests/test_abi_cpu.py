@@ -590,3 +590,83 @@ def test_csc_coo_handles_convert_order_and_csr2csc():
     assert L.aoclsparse_order_mat(A.h) == 0
     assert list(ci) == [0, 3, 1, 2, 1, 3, 4, 4] and list(v) == [1, 2, 3, 4, 5, 6, 7, 8]
     assert L.aoclsparse_order_mat(None) == 2
+
+
+@pytest.mark.parametrize("prec", ["c", "z"])
+def test_complex_csc_coo_convert_order_and_csr2csc(prec):
+    """complex twins of the format routines (aoclsparse_auxiliary.h:438-560, aoclsparse_convert.h:528-560): host structure
+    work checked against a dense reconstruction; aoclsparse_convert_csr with op = H conjugates."""
+    ct, rt, exp_csr = (np.complex64, np.float32, L.aoclsparse_export_ccsr) if prec == "c" else (np.complex128, np.float64, L.aoclsparse_export_zcsr)
+    fn = lambda stem: getattr(L, "aoclsparse_" + stem.replace("?", prec))
+    rng = np.random.default_rng(17)
+    m, n = 19, 13
+    dense = ((rng.uniform(size=(m, n)) < 0.35) * (rng.uniform(-1, 1, (m, n)) + 1j * rng.uniform(-1, 1, (m, n)))).astype(ct)
+    dense[3, :] = 0
+    for base in (0, 1):
+        rows = [np.flatnonzero(dense[i]) for i in range(m)]
+        rp = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32) + base
+        ci = (np.concatenate(rows) + base).astype(np.int32)
+        v = np.concatenate([dense[i, r] for i, r in enumerate(rows)]).astype(ct)
+        nnz = len(v)
+        d = P.Descr(base=base)
+        ri, cp, cv = np.zeros(nnz, np.int32), np.zeros(n + 1, np.int32), np.zeros(nnz, ct)
+        assert fn("?csr2csc")(m, n, nnz, d.h, base, P._ptr(rp), P._ptr(ci), P._ptr(v), P._ptr(ri), P._ptr(cp), P._ptr(cv)) == 0
+        back = np.zeros((m, n), ct)
+        for j in range(n):
+            seg = slice(cp[j] - base, cp[j + 1] - base)
+            assert np.all(np.diff(ri[seg]) > 0)
+            back[ri[seg] - base, j] = cv[seg]
+        assert np.array_equal(back, dense)
+        b_, m_, n_, z_ = ctypes.c_int(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        a1, a2, a3 = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        outs = (ctypes.byref(b_), ctypes.byref(m_), ctypes.byref(n_), ctypes.byref(z_), ctypes.byref(a1), ctypes.byref(a2), ctypes.byref(a3))
+
+        def csr_to_dense(h, mm, nn):
+            assert exp_csr(h, *outs) == 0 and (m_.value, n_.value, z_.value, b_.value) == (mm, nn, nnz, base)
+            q_rp = np.ctypeslib.as_array(ctypes.cast(a1, ctypes.POINTER(ctypes.c_int32)), (mm + 1,))
+            q_ci = np.ctypeslib.as_array(ctypes.cast(a2, ctypes.POINTER(ctypes.c_int32)), (nnz,))
+            q_v = np.ctypeslib.as_array(ctypes.cast(a3, ctypes.POINTER(ctypes.c_float if prec == "c" else ctypes.c_double)), (2 * nnz,))
+            q_v = q_v.view(ct)
+            out = np.zeros((mm, nn), ct)
+            for i in range(mm):
+                seg = slice(q_rp[i] - base, q_rp[i + 1] - base)
+                assert np.all(np.diff(q_ci[seg]) > 0)
+                out[i, q_ci[seg] - base] = q_v[seg]
+            return out
+
+        # CSC handle: its CSR is the same matrix; export_?csc hands back the caller's arrays
+        h = ctypes.c_void_p()
+        assert fn("create_?csc")(ctypes.byref(h), base, m, n, nnz, P._ptr(cp), P._ptr(ri), P._ptr(cv)) == 0
+        assert fn("export_?csc")(h, *outs) == 0 and (a1.value, a2.value, a3.value) == (cp.ctypes.data, ri.ctypes.data, cv.ctypes.data)
+        assert np.array_equal(csr_to_dense(h, m, n), dense)
+        wrong = L.aoclsparse_export_dcsc if prec == "z" else L.aoclsparse_export_zcsc
+        assert wrong(h, *outs) == 9  # aoclsparse_status_wrong_type
+        L.aoclsparse_destroy(ctypes.byref(h))
+        # COO handle in shuffled order -> convert_csr for the three operations
+        perm = rng.permutation(nnz)
+        cr = (np.repeat(np.arange(m), np.diff(rp)) + base).astype(np.int32)[perm]
+        cc, cval = ci[perm].copy(), v[perm].copy()
+        assert fn("create_?coo")(ctypes.byref(h), base, m, n, nnz, P._ptr(cr), P._ptr(cc), P._ptr(cval)) == 0
+        assert fn("export_?coo")(h, *outs) == 0 and a3.value == cval.ctypes.data
+        for op, mm, nn, ref in ((P.OP_NONE, m, n, dense), (P.OP_TRANSPOSE, n, m, dense.T), (P.OP_CONJ_TRANSPOSE, n, m, dense.conj().T)):
+            c = ctypes.c_void_p()
+            assert L.aoclsparse_convert_csr(h, op, ctypes.byref(c)) == 0
+            assert L.aoclsparse_order_mat(c) == 0
+            assert np.array_equal(csr_to_dense(c, mm, nn), ref)
+            L.aoclsparse_destroy(ctypes.byref(c))
+        L.aoclsparse_destroy(ctypes.byref(h))
+
+
+def test_csrsv_argument_checks():
+    """level2/aoclsparse_csrsv.hpp:38-75, in its order (all before any device work)."""
+    rp, ci, v = np.array([0, 1, 3], np.int32), np.array([0, 0, 1], np.int32), np.array([2.0, 1.0, 4.0])
+    x, y, a = np.array([1.0, 2.0]), np.zeros(2), np.array([1.0])
+    d = P.Descr()
+    args = lambda **k: [k.get("op", P.OP_NONE), k.get("a", P._ptr(a)), k.get("m", 2), k.get("val", P._ptr(v)), k.get("col", P._ptr(ci)),
+                        k.get("ptr", P._ptr(rp)), k.get("d", d.h), k.get("x", P._ptr(x)), k.get("y", P._ptr(y))]
+    fn = L.aoclsparse_dcsrsv
+    for name in ("a", "val", "col", "ptr", "d", "x", "y"):
+        assert fn(*args(**{name: None})) == 2, name
+    assert fn(*args(d=P.Descr(base=1).h)) == 1 and fn(*args(d=P.Descr(mtype=P.TYPE_TRIANGULAR).h)) == 1
+    assert fn(*args(op=P.OP_TRANSPOSE)) == 1 and fn(*args(m=-1)) == 3 and fn(*args(m=0)) == 0
+    assert L.aoclsparse_scsrsv(P.OP_NONE, None, 2, None, None, None, None, None, None) == 2

@@ -1700,6 +1700,141 @@ def test_complex_handle_plumbing_and_type_checks():
     L.aoclsparse_destroy(ctypes.byref(c)), L.aoclsparse_destroy(ctypes.byref(h))
 
 
+def test_csrsv_bit_exact():
+    """aoclsparse_?csrsv on sorted rows with a full diagonal: the chain of csrsv.hpp:88-187 bit for bit (lower / upper,
+    unit / non-unit, alpha), float within its own restated chain via the double check of structure."""
+    m = 3000
+    rp, ci, v = triangular_system(81, m, 6)
+    b = np.random.default_rng(4).uniform(-1, 1, m)
+    for lower in (True, False):
+        for unit in (False, True):
+            d = P.Descr(fill=P.FILL_LOWER if lower else P.FILL_UPPER, diag=P.DIAG_UNIT if unit else P.DIAG_NON_UNIT)
+            so, yr = oracle.dcsrsv(lower, unit, -1.3, m, v, ci, rp, b)
+            y, a = np.full(m, np.nan), np.array([-1.3])
+            assert L.aoclsparse_dcsrsv(P.OP_NONE, P._ptr(a), m, P._ptr(v), P._ptr(ci), P._ptr(rp), d.h, P._ptr(b), P._ptr(y)) == 0
+            assert np.array_equal(y, yr)
+    vf, bf, yf, af = v.astype(np.float32), b.astype(np.float32), np.zeros(m, np.float32), np.array([1.0], np.float32)
+    assert L.aoclsparse_scsrsv(P.OP_NONE, P._ptr(af), m, P._ptr(vf), P._ptr(ci), P._ptr(rp), P.Descr().h, P._ptr(bf), P._ptr(yf)) == 0
+    so, yr = oracle.dcsrsv(True, False, 1.0, m, vf.astype(np.float64), ci, rp, bf.astype(np.float64))
+    assert np.max(np.abs(yf - yr)) <= 64 * EPS32 * np.max(np.abs(yr))
+    # a missing diagonal in a non-unit solve is refused (the reference would divide by a stale entry)
+    rp2, ci2, v2 = np.array([0, 1, 2], np.int32), np.array([0, 0], np.int32), np.array([2.0, 1.0])
+    y2 = np.zeros(2)
+    assert L.aoclsparse_dcsrsv(P.OP_NONE, P._ptr(np.array([1.0])), 2, P._ptr(v2), P._ptr(ci2), P._ptr(rp2), P.Descr().h,
+                               P._ptr(np.ones(2)), P._ptr(y2)) == 5
+
+
+def _cplx_tri_system(seed, n, dtype, base):
+    """sorted complex CSR with a dominant full diagonal, ~8 entries per row on both sides of it"""
+    rng = np.random.default_rng(seed)
+    dense = np.zeros((n, n), np.complex128)
+    for i in range(n):
+        cols = rng.choice(n, size=min(n, 8), replace=False)
+        dense[i, cols] = rng.uniform(-0.5, 0.5, len(cols)) + 1j * rng.uniform(-0.5, 0.5, len(cols))
+        dense[i, i] = (3.0 + rng.uniform(0, 1)) * np.exp(1j * rng.uniform(0, 2 * np.pi))
+    dense = dense.astype(dtype)
+    rows = [np.flatnonzero(dense[i]) for i in range(n)]
+    rp = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32) + base
+    ci = (np.concatenate(rows) + base).astype(np.int32)
+    v = np.concatenate([dense[i, r] for i, r in enumerate(rows)]).astype(dtype)
+    return dense, rp, ci, v
+
+
+def _op_tri(dense, fill, diag, op):
+    T = np.tril(dense) if fill == "lower" else np.triu(dense)
+    if diag == "unit":
+        np.fill_diagonal(T, 1.0)
+    return {"n": T, "t": T.T, "h": T.conj().T}[op]
+
+
+@pytest.mark.parametrize("prec", ["z", "c"])
+def test_complex_trsv_trsm(prec):
+    """aoclsparse_{c,z}trsv(_kid)(_strided) and {c,z}trsm: L / U x N / T / H x unit / non-unit, both bases, host and
+    device operands, strides and padded leading dimensions, against a dense solve of the same triangle.  The reference's
+    complex arithmetic is std::complex (trsv_kr.hpp:38-222), so parity is normwise: 64 eps |x| for these
+    diagonally dominant systems."""
+    dtype, eps = (np.complex128, EPS64) if prec == "z" else (np.complex64, EPS32)
+    C = P.CDouble if prec == "z" else P.CFloat
+    fn = lambda stem: getattr(L, "aoclsparse_" + stem.replace("?", prec))
+    ops = {"n": P.OP_NONE, "t": P.OP_TRANSPOSE, "h": P.OP_CONJ_TRANSPOSE}
+    n = 500
+    rng = np.random.default_rng(5)
+    alpha = 0.8 - 0.6j
+    for base in (0, 1):
+        dense, rp, ci, v = _cplx_tri_system(31 + base, n, dtype, base)
+        h = ctypes.c_void_p()
+        assert fn("create_?csr")(ctypes.byref(h), base, n, n, len(v), P._ptr(rp), P._ptr(ci), P._ptr(v)) == 0
+        b = (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(dtype)
+        for fill in ("lower", "upper"):
+            for diag in ("non_unit", "unit"):
+                d = P.Descr(base=base, mtype=P.TYPE_TRIANGULAR, fill=P.FILL_LOWER if fill == "lower" else P.FILL_UPPER,
+                            diag=P.DIAG_UNIT if diag == "unit" else P.DIAG_NON_UNIT)
+                for op in "nth":
+                    M = _op_tri(dense.astype(np.complex128), fill, diag, op)
+                    xr = np.linalg.solve(M, alpha * b.astype(np.complex128))
+                    tol = 64 * eps * np.max(np.abs(xr))
+                    x = np.full(n, np.nan, dtype)
+                    assert fn("?trsv")(ops[op], C(alpha.real, alpha.imag), h, d.h, P._ptr(b), P._ptr(x)) == 0
+                    assert np.max(np.abs(x - xr)) <= tol, (fill, diag, op, np.max(np.abs(x - xr)), tol)
+                    xd = dev(np.zeros(n, dtype))
+                    assert fn("?trsv_kid")(ops[op], C(alpha.real, alpha.imag), h, d.h, P._ptr(dev(b)), P._ptr(xd), 3) == 0
+                    torch.cuda.synchronize()
+                    assert np.array_equal(xd.cpu().numpy(), x)  # one arithmetic whatever the operands' home
+            # strided, and multi-RHS in both layouts with padded leading dimensions (padding untouched)
+            d = P.Descr(base=base, mtype=P.TYPE_TRIANGULAR, fill=P.FILL_LOWER if fill == "lower" else P.FILL_UPPER)
+            xr = np.linalg.solve(_op_tri(dense.astype(np.complex128), fill, "non_unit", "h"), alpha * b.astype(np.complex128))
+            bs, xs = np.zeros(3 * n, dtype), np.full(2 * n, 7 + 7j, dtype)
+            bs[::3] = b
+            assert fn("?trsv_strided")(P.OP_CONJ_TRANSPOSE, C(alpha.real, alpha.imag), h, d.h, P._ptr(bs), 3, P._ptr(xs), 2) == 0
+            assert np.max(np.abs(xs[::2] - xr)) <= 64 * eps * np.max(np.abs(xr)) and np.all(xs[1::2] == 7 + 7j)
+            k = 5
+            Bm = (rng.uniform(-1, 1, (n, k)) + 1j * rng.uniform(-1, 1, (n, k))).astype(dtype)
+            Xr = np.linalg.solve(_op_tri(dense.astype(np.complex128), fill, "non_unit", "t"), alpha * Bm.astype(np.complex128))
+            for order, ldb, ldx in ((P.ORDER_ROW, k + 2, k + 1), (P.ORDER_COLUMN, n + 3, n + 4)):
+                if order == P.ORDER_ROW:
+                    Bb, Xb = np.zeros((n, ldb), dtype), np.full((n, ldx), 9 - 9j, dtype)
+                    Bb[:, :k] = Bm
+                else:
+                    Bb, Xb = np.zeros((k, ldb), dtype), np.full((k, ldx), 9 - 9j, dtype)
+                    Bb[:, :n] = Bm.T
+                assert fn("?trsm")(P.OP_TRANSPOSE, C(alpha.real, alpha.imag), h, d.h, order, P._ptr(Bb), k, ldb, P._ptr(Xb), ldx) == 0
+                got = Xb[:, :k] if order == P.ORDER_ROW else Xb[:, :n].T
+                pad = Xb[:, k:] if order == P.ORDER_ROW else Xb[:, n:]
+                assert np.max(np.abs(got - Xr)) <= 64 * eps * np.max(np.abs(Xr)) and np.all(pad == 9 - 9j)
+        # checks shared with the real solves (trsv.cpp:59-137)
+        dg = P.Descr(base=base)
+        assert fn("?trsv")(P.OP_NONE, C(1, 0), h, dg.h, P._ptr(b), P._ptr(x)) == 5  # general descriptor
+        wrong = L.aoclsparse_ctrsv if prec == "z" else L.aoclsparse_ztrsv
+        assert wrong(P.OP_NONE, (P.CFloat if prec == "z" else P.CDouble)(1, 0), h, d.h, P._ptr(b), P._ptr(x)) == 9
+        assert fn("?trsv_kid")(P.OP_NONE, C(1, 0), h, d.h, P._ptr(b), P._ptr(x), 4) == 14
+        L.aoclsparse_destroy(ctypes.byref(h))
+
+
+def test_complex_trsv_reference_h5_round_trip():
+    """trsv_tests.cpp:313-318 / common_data_utils.h:4349-4470: the 5x5 lower-stored complex matrix, xref = 1..5,
+    b = op(T) xref built by the test itself, x = solve -> xref.  All six (fill, op) cases; with fill = upper the same
+    arrays leave only the diagonal."""
+    rp = np.array([0, 1, 3, 5, 7, 11], np.int32)
+    ci = np.array([0, 0, 1, 1, 2, 2, 3, 0, 1, 2, 4], np.int32)
+    v = np.array([4 - 0j, 2 + 2j, 5 - 1j, 1 + 2j, 3 - 3j, 2 + 0.5j, 4 - 4j, 1 + 2j, 3 - 3j, 0 - 2j, 2 - 2j])
+    dense = np.zeros((5, 5), np.complex128)
+    for i in range(5):
+        dense[i, ci[rp[i]:rp[i + 1]]] = v[rp[i]:rp[i + 1]]
+    xref = np.arange(1.0, 6.0) + 0j
+    for base, fill, op in ((0, "lower", "n"), (0, "lower", "t"), (0, "lower", "h"), (1, "upper", "n"), (1, "upper", "t"), (1, "upper", "h")):
+        rpb, cib = rp + base, ci + base
+        h = ctypes.c_void_p()
+        assert L.aoclsparse_create_zcsr(ctypes.byref(h), base, 5, 5, 11, P._ptr(rpb), P._ptr(cib), P._ptr(v)) == 0
+        d = P.Descr(base=base, mtype=P.TYPE_TRIANGULAR, fill=P.FILL_LOWER if fill == "lower" else P.FILL_UPPER)
+        b = _op_tri(dense, fill, "non_unit", op) @ xref
+        x = np.zeros(5, np.complex128)
+        o = {"n": P.OP_NONE, "t": P.OP_TRANSPOSE, "h": P.OP_CONJ_TRANSPOSE}[op]
+        assert L.aoclsparse_ztrsv(o, P.CDouble(1, 0), h, d.h, P._ptr(b), P._ptr(x)) == 0
+        assert np.max(np.abs(x - xref)) <= 10 * np.sqrt(2 * EPS64)  # the reference's own acceptance (expected_precision)
+        assert np.max(np.abs(x - xref)) <= 32 * EPS64 * 5
+        L.aoclsparse_destroy(ctypes.byref(h))
+
+
 @pytest.mark.parametrize("prec", ["z", "c"])
 def test_complex_csrmm(prec):
     """aoclsparse_{c,z}csrmm: general (N / T / H, rectangular), symmetric and hermitian, both layouts with padded

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import oracle
-from util import banded_rows, laplace5
+from util import banded_rows, laplace5, triangular_system
 
 EPS = np.finfo(np.float64).eps
 
@@ -359,6 +359,22 @@ def test_ell_orders_against_csr_oracle():
     assert em + len(mp) == m and np.all(lens[mp] > w) and np.count_nonzero(lens <= w) == em
     st, yh = oracle.dellthybmv(0, 1.7, m, hv, hc, w, em, v, rp, ci, mp, x, -0.3, y0)
     assert np.array_equal(yh[mp], yc[mp]) and np.allclose(yh, yr, rtol=0, atol=1e-13)
+
+
+def test_csrsv_restatement_equals_the_pinned_trsv_chain():
+    """aoclsparse_csrsv.hpp:88-187 has no vectors in the reference's tests; on sorted rows with a full diagonal its loops
+    are the chains of ref_trsv_l / ref_trsv_u, which ARE pinned (trsv KATs): the two restatements must agree bitwise."""
+    m = 400
+    rp, ci, v = triangular_system(71, m, 5)
+    b = np.random.default_rng(3).uniform(-1, 1, m)
+    o = oracle.dcsr_optimize(m, m, len(v), 0, rp, ci, v)
+    assert o["status"] == 0
+    for lower in (True, False):
+        for unit in (False, True):
+            st, y = oracle.dcsrsv(lower, unit, 1.7, m, v, ci, rp, b)
+            st2, x = oracle.dtrsv("l" if lower else "u", 1.7, m, o["base"], o["val"], o["ind"], o["ptr"],
+                                  o["idiag"] if lower else o["iurow"], b, unit)
+            assert st == 0 and st2 == 0 and np.array_equal(y, x[:m])
 
 
 def test_blkcsr_kats(kats):

@@ -22,7 +22,7 @@ from bench import csrmm_bytes, spmv_bytes  # noqa: E402
 pkg = entry.load_package()
 L = pkg.lib()
 ap = argparse.ArgumentParser()
-ap.add_argument("--what", default="spmv,csrmm,trsv,cg,next,pcie")
+ap.add_argument("--what", default="spmv,csrmm,trsv,cg,next,setup,pcie")
 ap.add_argument("--small", action="store_true", help="skip the two 50-120 M nnz stand-ins")
 args = ap.parse_args()
 what = set(args.what.split(","))
@@ -282,6 +282,57 @@ if "next" in what:
     emit(kind="next", op="aoclsparse_dtrsm, %d right-hand sides (row-major)" % nr, system="lower triangle of the 5-pt Laplacian grid %d^2" % g,
          ms=round(ms, 3), one_trsv_ms=round(ms1, 3), note="all columns share each launch; the reference loops trsv per column")
     del A
+
+if "setup" in what:
+    # one-off costs on the path: optimize with an mv hint (clean-CSR checks on the host,
+    # upload, SELL-64 build on the GPU) and sp2m (A*A), each beside the restated CPU routine on this host
+    import ctypes
+    L.aoclsparse_mi355_set_pointer_mode(pkg.PTR_AUTO)
+    for g in (1000, 4096):
+        m, rp, ci, v = entry.laplace5(g)
+        nnz = len(v)
+        t = time.time()
+        A = pkg.Matrix(0, m, m, rp, ci, v)
+        t_create = time.time() - t
+        assert L.aoclsparse_set_mv_hint(A.h, pkg.OP_NONE, d0.h, 100) == 0
+        t = time.time()
+        assert L.aoclsparse_optimize(A.h) == 0
+        torch.cuda.synchronize()
+        t_opt = time.time() - t
+        x = np.ones(m)
+        y = np.zeros(m)
+        t = time.time()
+        assert pkg.dmv(pkg.OP_NONE, 1.0, A, d0, x, 0.0, y) == 0
+        t_first = time.time() - t
+        t = time.time()
+        o = oracle.dcsr_optimize(m, m, nnz, 0, rp, ci, v)
+        t_cpu = time.time() - t
+        emit(kind="setup", op="create + set_mv_hint + optimize", system="5-pt Laplacian grid %d^2 (nnz=%d)" % (g, nnz),
+             create_s=round(t_create, 4), optimize_s=round(t_opt, 4), first_mv_host_arrays_s=round(t_first, 4),
+             cpu_clean_csr_restatement_s=round(t_cpu, 4), spmv_calls_to_amortise=int(t_opt / 0.22e-3) if g == 4096 else None)
+        del A
+    for g in (300, 1000):
+        m, rp, ci, v = entry.laplace5(g)
+        A = pkg.Matrix(0, m, m, rp, ci, v)
+        C = ctypes.c_void_p()
+        assert L.aoclsparse_sp2m(pkg.OP_NONE, d0.h, A.h, pkg.OP_NONE, d0.h, A.h, pkg.STAGE_FULL, ctypes.byref(C)) == 0  # warm-up (uploads A)
+        L.aoclsparse_destroy(ctypes.byref(C))
+        best = 1e9
+        for _ in range(3):
+            t = time.time()
+            assert L.aoclsparse_sp2m(pkg.OP_NONE, d0.h, A.h, pkg.OP_NONE, d0.h, A.h, pkg.STAGE_FULL, ctypes.byref(C)) == 0
+            best = min(best, time.time() - t)
+            nb, cm, cn, cz = ctypes.c_int(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+            pr, pc_, pv = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+            assert L.aoclsparse_export_dcsr(C, ctypes.byref(nb), ctypes.byref(cm), ctypes.byref(cn), ctypes.byref(cz),
+                                            ctypes.byref(pr), ctypes.byref(pc_), ctypes.byref(pv)) == 0
+            L.aoclsparse_destroy(ctypes.byref(C))
+        t = time.time()
+        so, pcr, icr, vcr = oracle.dcsr2m(m, m, 0, rp, ci, v, 0, rp, ci, v)
+        t_cpu = time.time() - t
+        emit(kind="setup", op="aoclsparse_sp2m A*A (result returned as host CSR)", system="5-pt Laplacian grid %d^2" % g,
+             nnz_c=int(cz.value), s=round(best, 4), cpu_restatement_s=round(t_cpu, 4), same_nnz=bool(cz.value == len(icr)))
+        del A
 
 if "pcie" in what:
     L.aoclsparse_mi355_set_pointer_mode(pkg.PTR_AUTO)
