@@ -131,6 +131,8 @@ SIGNATURES = {
     "aoclsparse_ztrsm_kid": (c_int, [c_int, CDouble, _P, _P, c_int, _P, _I, _I, _P, _I, _I]),
     "aoclsparse_scsrsv": (c_int, [c_int, _P, _I, _P, _P, _P, _P, _P, _P]),
     "aoclsparse_dcsrsv": (c_int, [c_int, _P, _I, _P, _P, _P, _P, _P, _P]),
+    "aoclsparse_cdotmv": (c_int, [c_int, CFloat, _P, _P, _P, CFloat, _P, _P]),
+    "aoclsparse_zdotmv": (c_int, [c_int, CDouble, _P, _P, _P, CDouble, _P, _P]),
     "aoclsparse_cmv": (c_int, [c_int, _P, _P, _P, _P, _P, _P]),
     "aoclsparse_zmv": (c_int, [c_int, _P, _P, _P, _P, _P, _P]),
     "aoclsparse_create_scsc": (c_int, [POINTER(_P), c_int, _I, _I, _I, _P, _P, _P]),

@@ -13,6 +13,8 @@
 //   triangular   slice                  transposed slice          transposed slice, conj
 #include "internal.hpp"
 
+#include <algorithm>
+
 using namespace mi355;
 
 namespace
@@ -193,9 +195,59 @@ aoclsparse_status ccsrmm_t(aoclsparse_operation op, const cplx<R> alpha, const a
     return finish();
 }
 
+// aoclsparse_{c,z}dotmv (level2/aoclsparse_dotmv.hpp:31-60): y = alpha op(A) x + beta y, then the CONJUGATED dot
+// d = sum conj(x_i) y_i over min(m, n) entries (level1/aoclsparse_dense_dot.hpp:36-49)
+template <typename R>
+aoclsparse_status cdotmv_t(aoclsparse_operation op, cplx<R> alpha, aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                           const cplx<R> *x, cplx<R> beta, cplx<R> *y, cplx<R> *d, aoclsparse_matrix_data_type vt)
+{
+    using C = cplx<R>;
+    if(!d || !A)
+        return aoclsparse_status_invalid_pointer;
+    MI355_TRY(cmv_t<R>(op, &alpha, A, descr, x, &beta, y, vt));
+    Runtime                              &rt = Runtime::get();
+    std::lock_guard<std::recursive_mutex> sl(rt.stage_lock);
+    const aoclsparse_int                  n = std::min(A->m, A->n);
+    StagedArg                             ax, ay;
+    MI355_TRY(ax.in(rt, 3, x, sizeof(C) * (size_t)n, true));
+    MI355_TRY(ay.in(rt, 4, y, sizeof(C) * (size_t)n, true));
+    void      *part = nullptr, *dd = d;
+    const bool ddev = rt.is_device_pointer(d);
+    MI355_TRY(rt.staging(6, sizeof(C) * 1024, &part));
+    if(!ddev)
+        MI355_TRY(rt.staging(7, sizeof(C), &dd));
+    MI355_TRY(launch_cdot<R>(rt.stream(), n, static_cast<const C *>(ax.dev), static_cast<const C *>(ay.dev),
+                             static_cast<C *>(part), static_cast<C *>(dd)));
+    if(!ddev)
+    {
+        MI355_HIP_TRY(hipMemcpyAsync(d, dd, sizeof(C), hipMemcpyDeviceToHost, rt.stream()));
+        MI355_HIP_TRY(hipStreamSynchronize(rt.stream()));
+    }
+    return aoclsparse_status_success;
+}
+
 } // namespace
 
 extern "C" {
+
+aoclsparse_status aoclsparse_cdotmv(const aoclsparse_operation op, const aoclsparse_float_complex alpha,
+                                    aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                    const aoclsparse_float_complex *x, const aoclsparse_float_complex beta,
+                                    aoclsparse_float_complex *y, aoclsparse_float_complex *d)
+{
+    return cdotmv_t<float>(op, cfloat(alpha.real, alpha.imag), A, descr, reinterpret_cast<const cfloat *>(x),
+                           cfloat(beta.real, beta.imag), reinterpret_cast<cfloat *>(y), reinterpret_cast<cfloat *>(d),
+                           aoclsparse_cmat);
+}
+aoclsparse_status aoclsparse_zdotmv(const aoclsparse_operation op, const aoclsparse_double_complex alpha,
+                                    aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                    const aoclsparse_double_complex *x, const aoclsparse_double_complex beta,
+                                    aoclsparse_double_complex *y, aoclsparse_double_complex *d)
+{
+    return cdotmv_t<double>(op, cdouble(alpha.real, alpha.imag), A, descr, reinterpret_cast<const cdouble *>(x),
+                            cdouble(beta.real, beta.imag), reinterpret_cast<cdouble *>(y), reinterpret_cast<cdouble *>(d),
+                            aoclsparse_zmat);
+}
 
 aoclsparse_status aoclsparse_ccsrmm(aoclsparse_operation op, const aoclsparse_float_complex alpha,
                                     const aoclsparse_matrix A, const aoclsparse_mat_descr descr, aoclsparse_order order,

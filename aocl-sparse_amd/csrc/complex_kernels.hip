@@ -232,6 +232,49 @@ __global__ __launch_bounds__(1024) void ctrsv_run_kernel(aoclsparse_int l0, aocl
     }
 }
 
+
+// ---- conjugated dot product d = sum conj(x_i) * y_i (level1/aoclsparse_dense_dot.hpp:36-49), fixed two-stage tree
+constexpr int CDOT_BLOCKS = 1024;
+template <typename R>
+__device__ __forceinline__ cplx<R> cdot_block_reduce(cplx<R> acc, cplx<R> *sh)
+{
+    for(int off = 32; off > 0; off >>= 1)
+    {
+        acc.re += __shfl_down(acc.re, off, 64);
+        acc.im += __shfl_down(acc.im, off, 64);
+    }
+    if((threadIdx.x & 63) == 0)
+        sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    return cplx<R>((sh[0].re + sh[1].re) + (sh[2].re + sh[3].re), (sh[0].im + sh[1].im) + (sh[2].im + sh[3].im));
+}
+template <typename R>
+__global__ __launch_bounds__(256) void cdot_partial_kernel(const cplx<R> *__restrict__ x, const cplx<R> *__restrict__ y,
+                                                           aoclsparse_int n, cplx<R> *partial)
+{
+    __shared__ cplx<R> sh[4];
+    cplx<R>            acc(R(0), R(0));
+    for(long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    {
+        const cplx<R> a = x[i];
+        c_mac(acc, cplx<R>(a.re, -a.im), y[i]);
+    }
+    const cplx<R> r = cdot_block_reduce(acc, sh);
+    if(threadIdx.x == 0)
+        partial[blockIdx.x] = r;
+}
+template <typename R>
+__global__ __launch_bounds__(256) void cdot_final_kernel(const cplx<R> *__restrict__ partial, int count, cplx<R> *d)
+{
+    __shared__ cplx<R> sh[4];
+    cplx<R>            acc(R(0), R(0));
+    for(int i = threadIdx.x; i < count; i += 256)
+        acc.re += partial[i].re, acc.im += partial[i].im;
+    const cplx<R> r = cdot_block_reduce(acc, sh);
+    if(threadIdx.x == 0)
+        *d = r;
+}
+
 } // namespace
 
 template <typename R>
@@ -364,6 +407,20 @@ template aoclsparse_status launch_ctrsv<float>(hipStream_t, bool, bool, cfloat, 
 template aoclsparse_status launch_ctrsv<double>(hipStream_t, bool, bool, cdouble, aoclsparse_int, const TrsvPlan &,
                                                 const cdouble *, const cdouble *, cdouble *, cdouble *, aoclsparse_int,
                                                 long long, aoclsparse_int, long long, aoclsparse_int);
+
+template <typename R>
+aoclsparse_status launch_cdot(hipStream_t s, aoclsparse_int n, const cplx<R> *x, const cplx<R> *y, cplx<R> *partial,
+                              cplx<R> *d)
+{
+    const int blocks = n <= 0 ? 1 : (int)std::min<long long>(CDOT_BLOCKS, ((long long)n + 255) / 256);
+    hipLaunchKernelGGL((cdot_partial_kernel<R>), dim3(blocks), dim3(256), 0, s, x, y, n, partial);
+    hipLaunchKernelGGL((cdot_final_kernel<R>), dim3(1), dim3(256), 0, s, partial, blocks, d);
+    MI355_HIP_TRY(hipGetLastError());
+    return aoclsparse_status_success;
+}
+template aoclsparse_status launch_cdot<float>(hipStream_t, aoclsparse_int, const cfloat *, const cfloat *, cfloat *, cfloat *);
+template aoclsparse_status launch_cdot<double>(hipStream_t, aoclsparse_int, const cdouble *, const cdouble *, cdouble *,
+                                               cdouble *);
 
 template aoclsparse_status launch_cspmv<float>(hipStream_t, int, bool, cfloat, aoclsparse_int, aoclsparse_int,
                                                const cfloat *, const aoclsparse_int *, const aoclsparse_int *,

@@ -479,6 +479,16 @@ DLL_PUBLIC aoclsparse_status aoclsparse_zcsrmm_kid(aoclsparse_operation op, cons
                                                    aoclsparse_double_complex *C, aoclsparse_int ldc,
                                                    const aoclsparse_int kid);
 
+/* y = alpha op(A) x + beta y followed by the conjugated dot d = sum conj(x_i) y_i (aoclsparse_functions.h:1925-1990) */
+DLL_PUBLIC aoclsparse_status aoclsparse_cdotmv(const aoclsparse_operation op, const aoclsparse_float_complex alpha,
+                                               aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                               const aoclsparse_float_complex *x, const aoclsparse_float_complex beta,
+                                               aoclsparse_float_complex *y, aoclsparse_float_complex *d);
+DLL_PUBLIC aoclsparse_status aoclsparse_zdotmv(const aoclsparse_operation op, const aoclsparse_double_complex alpha,
+                                               aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                               const aoclsparse_double_complex *x,
+                                               const aoclsparse_double_complex beta, aoclsparse_double_complex *y,
+                                               aoclsparse_double_complex *d);
 /* raw-array triangular solve y = inv(T) * alpha * x, T = the triangle of the CSR arrays named by descr->fill_mode
  * (aoclsparse_functions.h:1318-1402): zero-based, op = none, general / symmetric descriptor type, host arrays. */
 DLL_PUBLIC aoclsparse_status aoclsparse_scsrsv(aoclsparse_operation trans, const float *alpha, aoclsparse_int m,

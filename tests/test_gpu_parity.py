@@ -1672,6 +1672,40 @@ def test_complex_mv_every_descriptor_and_operation(prec):
             L.aoclsparse_destroy(ctypes.byref(h))
 
 
+@pytest.mark.parametrize("prec", ["z", "c"])
+def test_complex_dotmv(prec):
+    """aoclsparse_{c,z}dotmv: y as ?mv (same kernel, same bits), d = sum conj(x_i) y_i over min(m, n) entries
+    (dense_dot.hpp:36-49) within 2k eps sum|x_i y_i| of numpy's vdot; host and device operands."""
+    dtype, eps = (np.complex128, EPS64) if prec == "z" else (np.complex64, EPS32)
+    C = P.CDouble if prec == "z" else P.CFloat
+    create = L.aoclsparse_create_zcsr if prec == "z" else L.aoclsparse_create_ccsr
+    mv, dotmv = (L.aoclsparse_zmv, L.aoclsparse_zdotmv) if prec == "z" else (L.aoclsparse_cmv, L.aoclsparse_cdotmv)
+    m, n = 900, 700
+    rp, ci, v = _cplx_matrix(131, m, n, 9, dtype)
+    h = ctypes.c_void_p()
+    assert create(ctypes.byref(h), 0, m, n, len(v), P._ptr(rp), P._ptr(ci), P._ptr(v)) == 0
+    d = P.Descr()
+    rng = np.random.default_rng(9)
+    alpha, beta = np.array([0.6 + 0.3j], dtype), np.array([-0.2 + 0.7j], dtype)
+    for op, nx, ny in ((P.OP_NONE, n, m), (P.OP_CONJ_TRANSPOSE, m, n)):
+        x = (rng.uniform(-1, 1, nx) + 1j * rng.uniform(-1, 1, nx)).astype(dtype)
+        y0 = (rng.uniform(-1, 1, ny) + 1j * rng.uniform(-1, 1, ny)).astype(dtype)
+        yr = y0.copy()
+        assert mv(op, P._ptr(alpha), h, d.h, P._ptr(x), P._ptr(beta), P._ptr(yr)) == 0
+        y, dot = y0.copy(), np.zeros(1, dtype)
+        assert dotmv(op, C(alpha[0].real, alpha[0].imag), h, d.h, P._ptr(x), C(beta[0].real, beta[0].imag), P._ptr(y), P._ptr(dot)) == 0
+        k = min(m, n)
+        ref = np.vdot(x[:k].astype(np.complex128), yr[:k].astype(np.complex128))
+        assert np.array_equal(y, yr)
+        assert abs(dot[0] - ref) <= 2 * k * eps * np.sum(np.abs(x[:k]) * np.abs(yr[:k]))
+        yd, dd = dev(y0), dev(np.zeros(1, dtype))
+        assert dotmv(op, C(alpha[0].real, alpha[0].imag), h, d.h, P._ptr(dev(x)), C(beta[0].real, beta[0].imag), P._ptr(yd), P._ptr(dd)) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(yd.cpu().numpy(), yr) and dd.cpu().numpy()[0] == dot[0]
+    assert dotmv(P.OP_NONE, C(1, 0), h, d.h, P._ptr(x), C(0, 0), P._ptr(y), None) == 2
+    L.aoclsparse_destroy(ctypes.byref(h))
+
+
 def test_complex_handle_plumbing_and_type_checks():
     rp, ci, v = _cplx_matrix(113, 40, 40, 6, np.complex128)
     h = ctypes.c_void_p()
