@@ -78,6 +78,7 @@ struct RhsGeom
 {
     long long b_off, x_off;
     int       incb, incx;
+    int       cols_fast; // sync-free kernel only: blockIdx.x = column
 };
 
 template <typename T>
@@ -258,7 +259,11 @@ __global__ __launch_bounds__(TRSV_SF_BLOCK) void trsv_syncfree_kernel(
     using B = typename tag<T>::bits;
     __shared__ unsigned int s_bid;
     __shared__ B            s_x[TRSV_SF_BLOCK];
-    const int c = blockIdx.y; // right-hand side; every column has its own ticket counter and xp slab
+    // right-hand side: every column has its own ticket counter and xp slab.  Columns are the FAST grid dimension
+    // (when the block count fits gridDim.y): the dispatcher then hands out the k-th workgroup of every column
+    // together, so the independent chains of a multi-RHS solve advance side by side instead of one column's
+    // waiting workgroups filling every CU before the next column starts.
+    const int c = g.cols_fast ? blockIdx.x : blockIdx.y;
     b += c * g.b_off;
     x += c * g.x_off;
     xp += (size_t)c * m;
@@ -352,7 +357,7 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
     const aoclsparse_int *pptr   = plan.pptr.as<aoclsparse_int>();
     const aoclsparse_int *pind   = plan.pind.as<aoclsparse_int>();
     const T              *pval   = plan.pval.as<T>();
-    const RhsGeom         g{b_off, x_off, incb, incx};
+    RhsGeom               g{b_off, x_off, incb, incx, 0};
     if(schedule == 1 && (nrhs != 1 || incb != 1 || incx != 1))
         schedule = 2; // the single-workgroup runs of the hybrid schedule are single-RHS, unit stride
     auto level_launch = [&](aoclsparse_int l) {
@@ -395,14 +400,18 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
         for(aoclsparse_int c0 = 0; c0 < nrhs; c0 += 65535)
         {
             const int nc = nrhs - c0 < 65535 ? nrhs - c0 : 65535;
-            if((long long)plan.nnz_tri > 10LL * m)
-                hipLaunchKernelGGL((trsv_syncfree_kernel<T, 512, 20>), dim3((m + 511) / 512, nc), dim3(512), 0, s, m,
-                                   rowmap, pptr, pind, pval, diag, b + c0 * b_off, xp + (size_t)c0 * m, x + c0 * x_off,
-                                   alpha, (int)unit, scratch + c0, tmo, g);
+            const bool     wide = (long long)plan.nnz_tri > 10LL * m;
+            const unsigned nblk = (unsigned)((m + (wide ? 511 : 1023)) / (wide ? 512 : 1024));
+            g.cols_fast         = nc > 1 && nblk <= 65535u;
+            const dim3 grid     = g.cols_fast ? dim3(nc, nblk) : dim3(nblk, nc);
+            if(wide)
+                hipLaunchKernelGGL((trsv_syncfree_kernel<T, 512, 20>), grid, dim3(512), 0, s, m, rowmap, pptr, pind, pval,
+                                   diag, b + c0 * b_off, xp + (size_t)c0 * m, x + c0 * x_off, alpha, (int)unit, scratch + c0,
+                                   tmo, g);
             else
-                hipLaunchKernelGGL((trsv_syncfree_kernel<T, 1024, 12>), dim3((m + 1023) / 1024, nc), dim3(1024), 0, s,
-                                   m, rowmap, pptr, pind, pval, diag, b + c0 * b_off, xp + (size_t)c0 * m,
-                                   x + c0 * x_off, alpha, (int)unit, scratch + c0, tmo, g);
+                hipLaunchKernelGGL((trsv_syncfree_kernel<T, 1024, 12>), grid, dim3(1024), 0, s, m, rowmap, pptr, pind,
+                                   pval, diag, b + c0 * b_off, xp + (size_t)c0 * m, x + c0 * x_off, alpha, (int)unit,
+                                   scratch + c0, tmo, g);
         }
     }
     MI355_HIP_TRY(hipGetLastError());

@@ -273,14 +273,16 @@ if "next" in what:
          first_call_s=round(t_first, 3), first_call_includes="GPU factorisation (1,999 levels) + level analysis of both factors",
          apply_ms=round(ms, 3), cpu_factorise_s=round(t_fac, 3), cpu_apply_ms=round((time.time() - t0) * 1e3, 2),
          x_bit_exact=bool(np.array_equal(xi.cpu().numpy(), xr)))
-    nr = 8
     dl = pkg.Descr(mtype=pkg.TYPE_TRIANGULAR, fill=pkg.FILL_LOWER)
-    Bd = torch.from_numpy(rng.uniform(-1, 1, (m, nr))).to(dev).contiguous()
-    Xd = torch.zeros((m, nr), dtype=torch.float64, device=dev)
-    ms = time_calls(lambda: L.aoclsparse_dtrsm(pkg.OP_NONE, 1.0, A.h, dl.h, pkg.ORDER_ROW, pkg._ptr(Bd), nr, nr, pkg._ptr(Xd), nr), 5, 1)
     ms1 = time_calls(lambda: pkg.dtrsv(pkg.OP_NONE, 1.0, A, dl, bd, xi), 5, 1)
-    emit(kind="next", op="aoclsparse_dtrsm, %d right-hand sides (row-major)" % nr, system="lower triangle of the 5-pt Laplacian grid %d^2" % g,
-         ms=round(ms, 3), one_trsv_ms=round(ms1, 3), note="all columns share each launch; the reference loops trsv per column")
+    for nr in (8, 64):
+        Bd = torch.from_numpy(rng.uniform(-1, 1, (m, nr))).to(dev).contiguous()
+        Xd = torch.zeros((m, nr), dtype=torch.float64, device=dev)
+        ms = time_calls(lambda: L.aoclsparse_dtrsm(pkg.OP_NONE, 1.0, A.h, dl.h, pkg.ORDER_ROW, pkg._ptr(Bd), nr, nr, pkg._ptr(Xd), nr), 5, 1)
+        emit(kind="next", op="aoclsparse_dtrsm, %d right-hand sides (row-major)" % nr, system="lower triangle of the 5-pt Laplacian grid %d^2" % g,
+             ms=round(ms, 3), one_trsv_ms=round(ms1, 3),
+             note="one launch, columns are the fast grid dimension so their chains advance together; the reference loops trsv per column")
+        del Bd, Xd
     del A
 
 if "setup" in what:
