@@ -540,6 +540,12 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
 template <typename R>
 aoclsparse_status launch_cdot(hipStream_t s, aoclsparse_int n, const cplx<R> *x, const cplx<R> *y, cplx<R> *partial,
                               cplx<R> *d);
+// spgemm (spgemm_kernels.hip): list entries per wavefront kept in LDS; rows whose upper bound exceeds it use a global slab
+template <typename T>
+constexpr int spgemm_lds_cap()
+{
+    return sizeof(T) > 8 ? 512 : 1024; // 4 waves x cap x (4 + sizeof(T)) bytes of static LDS <= 64 KB
+}
 // complex triangular solve (complex_kernels.hip): the hybrid schedule of the plan (runs of narrow levels inside one
 // workgroup, one launch per wide level); conj_diag for op = H (the plan's values are stored conjugated)
 template <typename R>

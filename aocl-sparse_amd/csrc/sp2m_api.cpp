@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 using namespace mi355;
@@ -22,7 +23,8 @@ aoclsparse_status launch_spgemm(hipStream_t s, bool fill, aoclsparse_int m, int 
                                 const aoclsparse_int *ptr_a, const aoclsparse_int *ind_a, const T *val_a,
                                 int base_b, const aoclsparse_int *ptr_b, const aoclsparse_int *ind_b,
                                 const T *val_b, const long long *slab_off, int *slab_idx, T *slab_val,
-                                const aoclsparse_int *ptr_c, aoclsparse_int *cnt_or_ind_c, T *val_c);
+                                const aoclsparse_int *ptr_c, aoclsparse_int *cnt_or_ind_c, T *val_c, bool conj_a,
+                                bool conj_b);
 }
 
 namespace
@@ -159,8 +161,15 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
         view_of<T>(A, va);
         view_of<T>(B, vb);
         const Operand<T> *X = &va, *Y = &vb;
+        // op = H on a complex operand: the values are conjugated as the kernel loads them (csr2m.cpp:748-835)
+        constexpr bool is_cplx = !std::is_floating_point<T>::value;
+        bool           conj_x = is_cplx && opA == aoclsparse_operation_conjugate_transpose;
+        bool           conj_y = is_cplx && opB == aoclsparse_operation_conjugate_transpose;
         if(opflag == 3)
+        {
             X = &vb, Y = &va; // (B A)^T
+            std::swap(conj_x, conj_y);
+        }
         else
         {
             if(trA)
@@ -187,7 +196,7 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
                 const aoclsparse_int c = X->ind[p] - X->base;
                 ub += Y->ptr[c + 1] - Y->ptr[c];
             }
-            off[i + 1] = off[i] + (ub > 1024 ? ub : 0);
+            off[i + 1] = off[i] + (ub > spgemm_lds_cap<T>() ? ub : 0);
         }
         const long long slab_total = off[m];
         DeviceBuffer d_xp, d_xi, d_xv, d_yp, d_yi, d_yv, d_off, d_slab_i, d_slab_v, d_cnt, d_cptr, d_ci, d_cv;
@@ -215,7 +224,7 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
             st = launch_spgemm<T>(s, false, m, X->base, d_xp.as<aoclsparse_int>(), d_xi.as<aoclsparse_int>(),
                                   nullptr, Y->base, d_yp.as<aoclsparse_int>(), d_yi.as<aoclsparse_int>(), nullptr,
                                   d_off.as<long long>(), d_slab_i.as<int>(), nullptr, nullptr,
-                                  d_cnt.as<aoclsparse_int>(), nullptr);
+                                  d_cnt.as<aoclsparse_int>(), nullptr, false, false);
             if(st != aoclsparse_status_success)
                 return st;
             std::vector<aoclsparse_int> cptr((size_t)m + 1, 0);
@@ -281,7 +290,7 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
             st = launch_spgemm<T>(s, true, m, X->base, d_xp.as<aoclsparse_int>(), d_xi.as<aoclsparse_int>(),
                                   d_xv.as<T>(), Y->base, d_yp.as<aoclsparse_int>(), d_yi.as<aoclsparse_int>(),
                                   d_yv.as<T>(), d_off.as<long long>(), d_slab_i.as<int>(), d_slab_v.as<T>(),
-                                  d_cptr.as<aoclsparse_int>(), d_ci.as<aoclsparse_int>(), d_cv.as<T>());
+                                  d_cptr.as<aoclsparse_int>(), d_ci.as<aoclsparse_int>(), d_cv.as<T>(), conj_x, conj_y);
             if(st != aoclsparse_status_success)
                 return st;
             MI355_HIP_TRY(hipMemcpyAsync(d->ind, d_ci.ptr, sizeof(aoclsparse_int) * (size_t)nnz_c,
@@ -319,6 +328,10 @@ aoclsparse_status sp2m_any(aoclsparse_operation opA, const aoclsparse_mat_descr 
         return sp2m_t<double>(opA, descrA, A, opB, descrB, B, request, C, aoclsparse_dmat);
     if(A->val_type == aoclsparse_smat)
         return sp2m_t<float>(opA, descrA, A, opB, descrB, B, request, C, aoclsparse_smat);
+    if(A->val_type == aoclsparse_zmat)
+        return sp2m_t<cdouble>(opA, descrA, A, opB, descrB, B, request, C, aoclsparse_zmat);
+    if(A->val_type == aoclsparse_cmat)
+        return sp2m_t<cfloat>(opA, descrA, A, opB, descrB, B, request, C, aoclsparse_cmat);
     return aoclsparse_status_not_implemented;
 }
 

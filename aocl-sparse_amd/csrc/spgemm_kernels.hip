@@ -25,7 +25,6 @@
 namespace mi355
 {
 
-constexpr int SPGEMM_LDS_CAP = 1024; // list entries per wavefront kept in LDS
 
 __device__ __forceinline__ double sp_fma(double a, double b, double c)
 {
@@ -34,6 +33,42 @@ __device__ __forceinline__ double sp_fma(double a, double b, double c)
 __device__ __forceinline__ float sp_fma(float a, float b, float c)
 {
     return fmaf(a, b, c);
+}
+// complex: the reference's std::complex multiply-add (csr2m.cpp:489-498 with T = std::complex); component-wise fma
+template <typename R>
+__device__ __forceinline__ cplx<R> sp_fma(cplx<R> a, cplx<R> b, cplx<R> c)
+{
+    c.re = sp_fma(a.re, b.re, c.re);
+    c.re = sp_fma(-a.im, b.im, c.re);
+    c.im = sp_fma(a.re, b.im, c.im);
+    c.im = sp_fma(a.im, b.re, c.im);
+    return c;
+}
+__device__ __forceinline__ double sp_mul(double a, double b)
+{
+    return a * b;
+}
+__device__ __forceinline__ float sp_mul(float a, float b)
+{
+    return a * b;
+}
+template <typename R>
+__device__ __forceinline__ cplx<R> sp_mul(cplx<R> a, cplx<R> b)
+{
+    return sp_fma(a, b, cplx<R>(R(0), R(0)));
+}
+__device__ __forceinline__ double sp_conj(double a, bool)
+{
+    return a;
+}
+__device__ __forceinline__ float sp_conj(float a, bool)
+{
+    return a;
+}
+template <typename R>
+__device__ __forceinline__ cplx<R> sp_conj(cplx<R> a, bool on)
+{
+    return on ? cplx<R>(a.re, -a.im) : a;
 }
 
 // position of c in list[0..len) or -1; wave-uniform result
@@ -60,8 +95,9 @@ __global__ __launch_bounds__(256) void spgemm_row_kernel(aoclsparse_int m, int b
                                                          const T *__restrict__ val_b,
                                                          const long long *__restrict__ slab_off, int *slab_idx,
                                                          T *slab_val, const aoclsparse_int *__restrict__ ptr_c,
-                                                         aoclsparse_int *cnt_or_ind_c, T *val_c)
+                                                         aoclsparse_int *cnt_or_ind_c, T *val_c, bool conj_a, bool conj_b)
 {
+    constexpr int  SPGEMM_LDS_CAP = spgemm_lds_cap<T>();
     __shared__ int s_idx[4][SPGEMM_LDS_CAP];
     __shared__ T   s_val[FILL ? 4 : 1][FILL ? SPGEMM_LDS_CAP : 1];
     const int      w    = threadIdx.x >> 6;
@@ -82,7 +118,7 @@ __global__ __launch_bounds__(256) void spgemm_row_kernel(aoclsparse_int m, int b
         const int ca = ind_a[j] - base_a;
         T         va = T(0);
         if constexpr(FILL)
-            va = val_a[j];
+            va = sp_conj(val_a[j], conj_a);
         for(int k = ptr_b[ca] - base_b; k < ptr_b[ca + 1] - base_b; k++)
         {
             const int c   = ind_b[k] - base_b;
@@ -93,14 +129,14 @@ __global__ __launch_bounds__(256) void spgemm_row_kernel(aoclsparse_int m, int b
                 {
                     list[len] = c; // first touch: new entry of C (csr2m.cpp:489-496)
                     if constexpr(FILL)
-                        acc[len] = va * val_b[k];
+                        acc[len] = sp_mul(va, sp_conj(val_b[k], conj_b));
                 }
                 len++;
             }
             else if constexpr(FILL)
             {
                 if(lane == 0)
-                    acc[pos] = sp_fma(va, val_b[k], acc[pos]); // csr2m.cpp:498, contracted
+                    acc[pos] = sp_fma(va, sp_conj(val_b[k], conj_b), acc[pos]); // csr2m.cpp:498, contracted
             }
             if(!in_lds)
                 __threadfence_block(); // lane 0's global store must be visible to the next compare
@@ -124,29 +160,30 @@ aoclsparse_status launch_spgemm(hipStream_t s, bool fill, aoclsparse_int m, int 
                                 const aoclsparse_int *ptr_a, const aoclsparse_int *ind_a, const T *val_a,
                                 int base_b, const aoclsparse_int *ptr_b, const aoclsparse_int *ind_b,
                                 const T *val_b, const long long *slab_off, int *slab_idx, T *slab_val,
-                                const aoclsparse_int *ptr_c, aoclsparse_int *cnt_or_ind_c, T *val_c)
+                                const aoclsparse_int *ptr_c, aoclsparse_int *cnt_or_ind_c, T *val_c, bool conj_a,
+                                bool conj_b)
 {
     if(m <= 0)
         return aoclsparse_status_success;
     dim3 grid((m + 3) / 4), block(256);
     if(fill)
         hipLaunchKernelGGL((spgemm_row_kernel<T, true>), grid, block, 0, s, m, base_a, ptr_a, ind_a, val_a, base_b,
-                           ptr_b, ind_b, val_b, slab_off, slab_idx, slab_val, ptr_c, cnt_or_ind_c, val_c);
+                           ptr_b, ind_b, val_b, slab_off, slab_idx, slab_val, ptr_c, cnt_or_ind_c, val_c, conj_a, conj_b);
     else
         hipLaunchKernelGGL((spgemm_row_kernel<T, false>), grid, block, 0, s, m, base_a, ptr_a, ind_a, val_a, base_b,
-                           ptr_b, ind_b, val_b, slab_off, slab_idx, slab_val, ptr_c, cnt_or_ind_c, val_c);
+                           ptr_b, ind_b, val_b, slab_off, slab_idx, slab_val, ptr_c, cnt_or_ind_c, val_c, conj_a, conj_b);
     MI355_HIP_TRY(hipGetLastError());
     return aoclsparse_status_success;
 }
 
-template aoclsparse_status launch_spgemm<double>(hipStream_t, bool, aoclsparse_int, int, const aoclsparse_int *,
-                                                 const aoclsparse_int *, const double *, int,
-                                                 const aoclsparse_int *, const aoclsparse_int *, const double *,
-                                                 const long long *, int *, double *, const aoclsparse_int *,
-                                                 aoclsparse_int *, double *);
-template aoclsparse_status launch_spgemm<float>(hipStream_t, bool, aoclsparse_int, int, const aoclsparse_int *,
-                                                const aoclsparse_int *, const float *, int, const aoclsparse_int *,
-                                                const aoclsparse_int *, const float *, const long long *, int *,
-                                                float *, const aoclsparse_int *, aoclsparse_int *, float *);
+#define MI355_SPGEMM_INST(T)                                                                                        \
+    template aoclsparse_status launch_spgemm<T>(hipStream_t, bool, aoclsparse_int, int, const aoclsparse_int *,     \
+                                                const aoclsparse_int *, const T *, int, const aoclsparse_int *,     \
+                                                const aoclsparse_int *, const T *, const long long *, int *, T *,   \
+                                                const aoclsparse_int *, aoclsparse_int *, T *, bool, bool);
+MI355_SPGEMM_INST(double)
+MI355_SPGEMM_INST(float)
+MI355_SPGEMM_INST(cdouble)
+MI355_SPGEMM_INST(cfloat)
 
 } // namespace mi355

@@ -1758,6 +1758,83 @@ def test_csrsv_bit_exact():
                                P._ptr(np.ones(2)), P._ptr(y2)) == 5
 
 
+@pytest.mark.parametrize("prec", ["z", "c"])
+def test_complex_sp2m(prec):
+    """aoclsparse_sp2m / aoclsparse_spmm on complex handles: the structure (row_ptr and the first-touch column order) is the
+    one the real product of the same patterns has -- bit-exact against the oracle -- and the values are within
+    (terms + 4) eps sum|a||b| of the dense product; op in {N, T, H} on either side conjugates as it transposes
+    (csr2m.cpp:743-835); one row long enough for the global-slab path; two-stage protocol."""
+    dtype, eps = (np.complex128, EPS64) if prec == "z" else (np.complex64, EPS32)
+    create = L.aoclsparse_create_zcsr if prec == "z" else L.aoclsparse_create_ccsr
+    exp = L.aoclsparse_export_zcsr if prec == "z" else L.aoclsparse_export_ccsr
+    rng = np.random.default_rng(77)
+
+    def mat(seed, m, n, rl):
+        rp, ci, vr = random_csr(seed, m, n, rl)
+        v = (vr + 1j * rng.uniform(-1, 1, len(vr))).astype(dtype)
+        h = ctypes.c_void_p()
+        assert create(ctypes.byref(h), 0, m, n, len(v), P._ptr(rp), P._ptr(ci), P._ptr(v)) == 0
+        D = np.zeros((m, n), np.complex128)
+        for i in range(m):
+            D[i, ci[rp[i]:rp[i + 1]]] = v[rp[i]:rp[i + 1]]
+        return h, (rp, ci, v, vr), D
+
+    def result(C):
+        b, m_, n_, z_ = ctypes.c_int(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        a1, a2, a3 = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        assert exp(C, ctypes.byref(b), ctypes.byref(m_), ctypes.byref(n_), ctypes.byref(z_), ctypes.byref(a1), ctypes.byref(a2), ctypes.byref(a3)) == 0
+        nz = z_.value
+        row = np.ctypeslib.as_array(ctypes.cast(a1, ctypes.POINTER(ctypes.c_int32)), (m_.value + 1,)).copy()
+        col = np.ctypeslib.as_array(ctypes.cast(a2, ctypes.POINTER(ctypes.c_int32)), (max(nz, 1),))[:nz].copy()
+        val = np.ctypeslib.as_array(ctypes.cast(a3, ctypes.POINTER(ctypes.c_float if prec == "c" else ctypes.c_double)), (2 * max(nz, 1),)).view(dtype)[:nz].copy()
+        D = np.zeros((m_.value, n_.value), np.complex128)
+        for i in range(m_.value):
+            assert len(set(col[row[i]:row[i + 1]])) == row[i + 1] - row[i]
+            D[i, col[row[i]:row[i + 1]]] = val[row[i]:row[i + 1]]
+        return b.value, row, col, D
+
+    m, k, n = 300, 260, 280
+    hA, (pa, ia, va, var), DA = mat(1, m, k, lambda r, i: 400 if i == 9 else r.integers(0, 8))
+    hB, (pb, ib, vb, vbr), DB = mat(2, k, n, lambda r, i: r.integers(0, 9))
+    d = P.Descr()
+    opv = {"n": P.OP_NONE, "t": P.OP_TRANSPOSE, "h": P.OP_CONJ_TRANSPOSE}
+    f = {"n": lambda X: X, "t": lambda X: X.T, "h": lambda X: X.conj().T}
+    # N * N: structure against the oracle on the real parts (same patterns), values against the dense product
+    C = ctypes.c_void_p()
+    assert L.aoclsparse_sp2m(P.OP_NONE, d.h, hA, P.OP_NONE, d.h, hB, P.STAGE_FULL, ctypes.byref(C)) == 0
+    b, row, col, D = result(C)
+    so, pc, ic, vc = oracle.dcsr2m(m, n, 0, pa, ia, var, 0, pb, ib, vbr)
+    assert b == 0 and np.array_equal(row, pc) and np.array_equal(col, ic)
+    bound = (np.abs(DA) @ np.abs(DB)) * (12 * eps) + 1e-300
+    assert np.all(np.abs(D - DA @ DB) <= bound)
+    L.aoclsparse_destroy(ctypes.byref(C))
+    # two-stage protocol gives the same handle and result
+    assert L.aoclsparse_sp2m(P.OP_NONE, d.h, hA, P.OP_NONE, d.h, hB, P.STAGE_NNZ_COUNT, ctypes.byref(C)) == 0
+    h0 = C.value
+    assert L.aoclsparse_sp2m(P.OP_NONE, d.h, hA, P.OP_NONE, d.h, hB, P.STAGE_FINALIZE, ctypes.byref(C)) == 0 and C.value == h0
+    assert np.array_equal(result(C)[3], D)
+    L.aoclsparse_destroy(ctypes.byref(C))
+    # every operation pair on conforming shapes
+    shapes = {"n": (m, k), "t": (k, m), "h": (k, m)}
+    for oa in "nth":
+        for ob in "nth":
+            ra, ca_ = shapes[oa]
+            h1, keep1, D1 = mat(10 + ord(oa), ra, ca_, lambda r, i: r.integers(0, 7))  # the handle aliases keep1's arrays
+            inner = k  # columns of op(A1) in every case
+            rb, cb = (inner, 90) if ob == "n" else (90, inner)
+            h2, keep2, D2 = mat(20 + ord(ob), rb, cb, lambda r, i: r.integers(0, 7))
+            assert L.aoclsparse_sp2m(opv[oa], d.h, h1, opv[ob], d.h, h2, P.STAGE_FULL, ctypes.byref(C)) == 0
+            _, _, _, Dc = result(C)
+            ref = f[oa](D1) @ f[ob](D2)
+            bound = (np.abs(f[oa](D1)) @ np.abs(f[ob](D2))) * (12 * eps) + 1e-300
+            assert Dc.shape == ref.shape and np.all(np.abs(Dc - ref) <= bound), (oa, ob)
+            L.aoclsparse_destroy(ctypes.byref(C)), L.aoclsparse_destroy(ctypes.byref(h1)), L.aoclsparse_destroy(ctypes.byref(h2))
+    # mixed value types are refused
+    hr = P.Matrix(0, k, n, pb, ib, vbr)
+    assert L.aoclsparse_sp2m(P.OP_NONE, d.h, hA, P.OP_NONE, d.h, hr.h, P.STAGE_FULL, ctypes.byref(C)) == 9
+    L.aoclsparse_destroy(ctypes.byref(hA)), L.aoclsparse_destroy(ctypes.byref(hB))
+
+
 def _cplx_tri_system(seed, n, dtype, base):
     """sorted complex CSR with a dominant full diagonal, ~8 entries per row on both sides of it"""
     rng = np.random.default_rng(seed)
