@@ -264,7 +264,10 @@ def main():
 
     # ---------------- supplementary: column-sharded csrmm ----------------
     if not args.no_csrmm:
-        out_mm = run_csrmm(args, pkg, entry, torch, dist if use_dist else None, np, world, rank, device, barrier)
+        try:
+            out_mm = run_csrmm(args, pkg, entry, torch, dist if use_dist else None, np, world, rank, device, barrier)
+        except Exception as e:  # the supplement must never cost the headline line
+            out_mm = {"error": "%s: %s" % (type(e).__name__, e)}
         if rank == 0:
             out["csrmm"] = out_mm
 
