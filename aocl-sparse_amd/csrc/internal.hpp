@@ -521,6 +521,9 @@ template <typename T>
 aoclsparse_status launch_cg_step(hipStream_t s, aoclsparse_int n, T alpha, const T *p, const T *q, T *x, T *r,
                                  T *partial, T *rr);
 template <typename T>
+aoclsparse_status launch_cg_step_dev(hipStream_t s, aoclsparse_int n, T rz, T tiny, const T *p, const T *q, T *x, T *r,
+                                     T *partial, T *out2);
+template <typename T>
 aoclsparse_status launch_multidot(hipStream_t s, aoclsparse_int n, int k, const T *V, long long ld, const T *w,
                                   T *partial, T *out);
 template <typename T>

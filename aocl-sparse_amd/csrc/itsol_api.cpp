@@ -295,6 +295,7 @@ struct Solver
     // CG (cg_data, aoclsparse_itsol_data.hpp:96-111)
     VBuf           r, z, p, q, y;
     T              alpha = 0, rz = 0, beta = 0, rnorm2 = 0, bnorm2 = 0, brtol = 0, rtol = 0, atol = 0;
+    T              rr_last = 0; // r.r of the current residual (what z.r is when there is no preconditioner)
     int            task = task_start;
     aoclsparse_int niter = 0, maxit = 0;
     int            precond = 0;
@@ -419,7 +420,8 @@ struct Solver
                 break;
             case task_init_res:
                 MI355_TRY(launch_vec_add<T>(st, n, q.as<T>(), r.as<T>()));
-                MI355_TRY(nrm2(rt, r.as<T>(), rnorm2));
+                MI355_TRY(dots(rt, 1, r.as<T>(), 0, r.as<T>(), &rr_last));
+                rnorm2 = std::sqrt(rr_last);
                 if(rnorm2 != rnorm2)
                 {
                     exit_status = aoclsparse_status_numerical_error;
@@ -455,9 +457,7 @@ struct Solver
                 niter++;
                 rinfo[RINFO_ITER] = (T)niter;
                 task              = task_compute_beta;
-                if(!precond)
-                    MI355_TRY(launch_vec_copy<T>(st, n, r.as<T>(), z.as<T>()));
-                else
+                if(precond) // (without one z = r: the copy of :790-797 is skipped, r itself is used)
                 {
                     *ircomm = aoclsparse_rci_precond;
                     *u = r.as<T>(), *vv = z.as<T>();
@@ -466,13 +466,14 @@ struct Solver
                 [[fallthrough]];
             case task_compute_beta:
             {
-                T rz_new = 0;
-                MI355_TRY(dots(rt, 1, z.as<T>(), 0, r.as<T>(), &rz_new));
+                T rz_new = rr_last; // z = r: z.r is the r.r the previous step already reduced (same summation order)
+                if(precond)
+                    MI355_TRY(dots(rt, 1, z.as<T>(), 0, r.as<T>(), &rz_new));
                 if(negative_or_near_zero(rz))
                     return aoclsparse_status_numerical_error;
                 beta = rz_new / rz;
                 rz   = rz_new;
-                MI355_TRY(launch_cg_direction<T>(st, n, beta, p.as<T>(), z.as<T>()));
+                MI355_TRY(launch_cg_direction<T>(st, n, beta, p.as<T>(), precond ? z.as<T>() : r.as<T>()));
                 *ircomm = aoclsparse_rci_mv;
                 task    = task_take_step;
                 *u = p.as<T>(), *vv = q.as<T>();
@@ -480,18 +481,19 @@ struct Solver
             }
             case task_take_step:
             {
-                T pq = 0;
-                MI355_TRY(dots(rt, 1, q.as<T>(), 0, p.as<T>(), &pq));
-                if(negative_or_near_zero(pq) || pq == T(0))
-                    return aoclsparse_status_numerical_error; // A is not positive definite
-                alpha = rz / pq;
-                MI355_TRY(red_partial.alloc(sizeof(T) * (size_t)vec_reduce_scratch_elems(1), false));
-                MI355_TRY(red_out.alloc(sizeof(T), false));
-                MI355_TRY(launch_cg_step<T>(st, n, alpha, p.as<T>(), q.as<T>(), x, r.as<T>(), red_partial.as<T>(),
-                                            red_out.as<T>()));
-                T rr = 0;
-                MI355_HIP_TRY(hipMemcpyAsync(&rr, red_out.ptr, sizeof(T), hipMemcpyDeviceToHost, st));
+                // p.q, alpha = rz / (p.q) and the step are queued back to back; the host waits once, for r.r and p.q
+                MI355_TRY(red_partial.alloc(sizeof(T) * (size_t)vec_reduce_scratch_elems(2), false));
+                MI355_TRY(red_out.alloc(sizeof(T) * 2, false));
+                MI355_TRY(launch_cg_step_dev<T>(st, n, rz, T(1e-2) * T(2) * std::numeric_limits<T>::epsilon(), p.as<T>(),
+                                                q.as<T>(), x, r.as<T>(), red_partial.as<T>(), red_out.as<T>()));
+                T two[2] = {0, 0};
+                MI355_HIP_TRY(hipMemcpyAsync(two, red_out.ptr, sizeof(T) * 2, hipMemcpyDeviceToHost, st));
                 MI355_HIP_TRY(hipStreamSynchronize(st));
+                const T rr = two[0], pq = two[1];
+                if(negative_or_near_zero(pq) || pq == T(0))
+                    return aoclsparse_status_numerical_error; // A is not positive definite (x, r left untouched)
+                alpha   = rz / pq;
+                rr_last = rr;
                 x_dirty = true;
                 rnorm2  = std::sqrt(rr);
                 if(rnorm2 != rnorm2)

@@ -91,6 +91,33 @@ __global__ __launch_bounds__(256) void cg_step_kernel(aoclsparse_int n, T alpha,
         partial[blockIdx.x] = s;
 }
 
+// the same step with alpha = rz / pq formed on the device from the p.q the previous launch left in *pq_dev, so the
+// host does not have to wait for that dot product; a p.q the reference refuses (<= 0.02 eps or 0, :815-822) makes
+// the step a no-op and the host reports the error after the one synchronisation of the iteration
+template <typename T>
+__global__ __launch_bounds__(256) void cg_step_dev_kernel(aoclsparse_int n, T rz, const T *__restrict__ pq_dev, T tiny,
+                                                           const T *p, const T *q, T *x, T *r, T *partial)
+{
+    __shared__ T sh[4];
+    const T      pq    = *pq_dev;
+    const T      alpha = (pq <= tiny || pq == T(0)) ? T(0) : rz / pq;
+    T            acc   = T(0);
+    for(aoclsparse_int i = blockIdx.x * 256 + threadIdx.x; i < n; i += (aoclsparse_int)gridDim.x * 256)
+    {
+        T xn = x[i], rn = r[i];
+        if(alpha != T(0))
+        {
+            xn   = v_fma(alpha, p[i], xn);
+            rn   = v_fma(alpha, q[i], rn);
+            x[i] = xn, r[i] = rn;
+        }
+        acc = v_fma(rn, rn, acc);
+    }
+    const T s = block_reduce_256(acc, sh);
+    if(threadIdx.x == 0)
+        partial[blockIdx.x] = s;
+}
+
 // partial[y][b] = sum_i w[i] * V[y*ld + i] over block b's elements
 template <typename T>
 __global__ __launch_bounds__(256) void multidot_kernel(aoclsparse_int n, const T *V, long long ld, const T *w,
@@ -205,6 +232,18 @@ aoclsparse_status launch_cg_step(hipStream_t s, aoclsparse_int n, T alpha, const
     hipLaunchKernelGGL((reduce_final_kernel<T>), dim3(1), dim3(256), 0, s, nb, partial, rr);
     MI355_VEC_DONE();
 }
+// out2[0] = r_new . r_new, out2[1] = p.q (both stay on the device; partial holds 2 * RED_BLOCKS elements)
+template <typename T>
+aoclsparse_status launch_cg_step_dev(hipStream_t s, aoclsparse_int n, T rz, T tiny, const T *p, const T *q, T *x, T *r,
+                                     T *partial, T *out2)
+{
+    const int nb = red_blocks(n);
+    hipLaunchKernelGGL((multidot_kernel<T>), dim3(nb, 1), dim3(256), 0, s, n, q, 0LL, p, partial + RED_BLOCKS);
+    hipLaunchKernelGGL((reduce_final_kernel<T>), dim3(1), dim3(256), 0, s, nb, partial + RED_BLOCKS, out2 + 1);
+    hipLaunchKernelGGL((cg_step_dev_kernel<T>), dim3(nb), dim3(256), 0, s, n, rz, out2 + 1, tiny, p, q, x, r, partial);
+    hipLaunchKernelGGL((reduce_final_kernel<T>), dim3(1), dim3(256), 0, s, nb, partial, out2);
+    MI355_VEC_DONE();
+}
 template <typename T>
 aoclsparse_status launch_multidot(hipStream_t s, aoclsparse_int n, int k, const T *V, long long ld, const T *w,
                                   T *partial, T *out)
@@ -239,6 +278,8 @@ aoclsparse_status launch_lincomb(hipStream_t s, int sign, aoclsparse_int n, int 
     template aoclsparse_status launch_cg_direction<T>(hipStream_t, aoclsparse_int, T, T *, const T *);              \
     template aoclsparse_status launch_cg_step<T>(hipStream_t, aoclsparse_int, T, const T *, const T *, T *, T *,    \
                                                  T *, T *);                                                         \
+    template aoclsparse_status launch_cg_step_dev<T>(hipStream_t, aoclsparse_int, T, T, const T *, const T *, T *,  \
+                                                     T *, T *, T *);                                                \
     template aoclsparse_status launch_multidot<T>(hipStream_t, aoclsparse_int, int, const T *, long long,           \
                                                   const T *, T *, T *);                                             \
     template aoclsparse_status launch_lincomb<T>(hipStream_t, int, aoclsparse_int, int, const T *, const T *,       \
