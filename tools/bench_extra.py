@@ -126,8 +126,8 @@ if "trsv" in what:
         xdev = torch.zeros(m, dtype=torch.float64, device=dev)
         abytes = (m + 1 + nnz_l) * 4 + (2 * m + nnz_l) * 8
         for kid, nm in ((0, "one launch per level"), (1, "hybrid: narrow level runs in one workgroup"),
-                        (3, "sync-free single launch")):
-            if kid != 1 and lv > 100000:
+                        (3, "sync-free single launch"), (-1, "auto (kid -1; AOCLSPARSE_MI355_TRSV_SCHEDULE=%s)" % os.environ.get("AOCLSPARSE_MI355_TRSV_SCHEDULE", "unset"))):
+            if kid not in (1, -1) and lv > 100000:
                 continue  # hundreds of thousands of launches / hops: minutes
             reps = 3 if kid != 1 and lv > 500 else 10
             ms = time_calls(lambda: pkg.dtrsv(pkg.OP_NONE, 1.0, A, dl, bdev, xdev, kid=kid), reps, 1)
