@@ -2,10 +2,16 @@
 // HIP kernels of csrmm_kernels.hip on the device-resident CSR (A^T copy for op != none).
 #include "internal.hpp"
 
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
 using namespace mi355;
 
 namespace
 {
+
+constexpr int CM_DETOUR_NNZ_PER_ROW = 8; // = the column kernel's register cache (CM_K)
 
 template <typename T>
 aoclsparse_status stage_dense(Runtime &rt, int slot, const T *host, aoclsparse_int outer, aoclsparse_int ld,
@@ -17,6 +23,52 @@ aoclsparse_status stage_dense(Runtime &rt, int slot, const T *host, aoclsparse_i
         return st;
     if(copy && *bytes)
         MI355_HIP_TRY(hipMemcpyAsync(*dev, host, *bytes, hipMemcpyHostToDevice, rt.stream()));
+    return aoclsparse_status_success;
+}
+
+// Row groups for the row-major kernel: maximal runs (<= CSRMM_GROUP) of consecutive rows whose column arrays are
+// equal entry for entry.  Kept only when they pay: at least 1.5 rows per group on average.
+aoclsparse_status build_mm_groups(const HostCsr &h, SpmvPlan &plan)
+{
+    MmGroups &g = plan.mm;
+    if(g.valid || g.tried)
+        return aoclsparse_status_success;
+    g.tried = true;
+    static const bool off = [] {
+        const char *e = getenv("AOCLSPARSE_MI355_CSRMM_GROUPS");
+        return e && atoi(e) == 0;
+    }();
+    if(off || h.m < 2)
+        return aoclsparse_status_success;
+    std::vector<aoclsparse_int> first;
+    try
+    {
+        first.reserve((size_t)h.m / 2 + 2);
+        aoclsparse_int i = 0;
+        while(i < h.m)
+        {
+            first.push_back(i);
+            const aoclsparse_int s = h.ptr[i] - h.base, len = h.ptr[i + 1] - h.base - s;
+            aoclsparse_int       e = i + 1;
+            while(e < h.m && e - i < CSRMM_GROUP && len > 0 && h.ptr[e + 1] - h.ptr[e] == len
+                  && !memcmp(h.ind + s, h.ind + (h.ptr[e] - h.base), sizeof(aoclsparse_int) * (size_t)len))
+                e++;
+            i = e;
+        }
+        first.push_back(h.m);
+    }
+    catch(const std::bad_alloc &)
+    {
+        return aoclsparse_status_memory_error;
+    }
+    const aoclsparse_int ng = (aoclsparse_int)first.size() - 1;
+    if((long long)h.m * 2 < (long long)ng * 3)
+        return aoclsparse_status_success;
+    aoclsparse_status st = g.first.upload(first.data(), sizeof(aoclsparse_int) * first.size(), Runtime::get().stream());
+    if(st != aoclsparse_status_success)
+        return st;
+    g.ngroups = ng;
+    g.valid   = true;
     return aoclsparse_status_success;
 }
 
@@ -131,11 +183,46 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
         st = ensure_spmv(const_cast<aoclsparse_matrix>(A), tr, d, p);
     if(st != aoclsparse_status_success)
         return st;
+    // Column-major operands with many columns and rows longer than the column kernel's register cache: that kernel
+    // would re-read A once per 4 columns (100 ms on the shell-like stand-in).  Detour: B and C are copied to packed
+    // row-major scratch, the row-major kernels run, C is copied back -- three streaming passes (~0.5 ms each per GB)
+    // instead; per element the arithmetic is the same chain, so the bits do not change.
+    const bool detour = colmaj && n >= 16 && (long long)d->nnz > (long long)CM_DETOUR_NNZ_PER_ROW * d->m;
+    if(p && (!colmaj || detour) && !p->mm.tried)
+    {
+        std::unique_lock<std::shared_mutex> w(A->guard);
+        st = build_mm_groups(tr ? *A->trans : A->user, *p);
+        if(st != aoclsparse_status_success)
+            return st;
+    }
     {
         std::shared_lock<std::shared_mutex> r(A->guard);
-        st = launch_csrmm<T>(rt.stream(), order, d->base, alpha, d->m, d->n, d->val.as<T>(),
-                             d->ind.as<aoclsparse_int>(), d->ptr.as<aoclsparse_int>(), static_cast<const T *>(dB),
-                             n, ldb, beta, static_cast<T *>(dC), ldc);
+        const bool                          grouped = p && p->mm.valid;
+        const aoclsparse_int               *grp = grouped ? p->mm.first.as<aoclsparse_int>() : nullptr;
+        const aoclsparse_int                ngrp = grouped ? p->mm.ngroups : 0;
+        if(detour)
+        {
+            if(!sl.owns_lock())
+                sl.lock(); // the scratch slots are shared
+            void *bt = nullptr, *ct = nullptr;
+            st = rt.staging(5, sizeof(T) * (size_t)b_rows * (size_t)n, &bt);
+            if(st == aoclsparse_status_success)
+                st = rt.staging(6, sizeof(T) * (size_t)m_c * (size_t)n, &ct);
+            if(st == aoclsparse_status_success)
+                st = launch_relayout<T>(rt.stream(), true, static_cast<const T *>(dB), static_cast<T *>(bt), b_rows, n, ldb);
+            if(st == aoclsparse_status_success)
+                st = launch_relayout<T>(rt.stream(), true, static_cast<const T *>(dC), static_cast<T *>(ct), m_c, n, ldc);
+            if(st == aoclsparse_status_success)
+                st = launch_csrmm<T>(rt.stream(), aoclsparse_order_row, d->base, alpha, d->m, d->n, d->val.as<T>(),
+                                     d->ind.as<aoclsparse_int>(), d->ptr.as<aoclsparse_int>(), static_cast<const T *>(bt),
+                                     n, n, beta, static_cast<T *>(ct), n, grp, ngrp);
+            if(st == aoclsparse_status_success)
+                st = launch_relayout<T>(rt.stream(), false, static_cast<const T *>(ct), static_cast<T *>(dC), m_c, n, ldc);
+        }
+        else
+            st = launch_csrmm<T>(rt.stream(), order, d->base, alpha, d->m, d->n, d->val.as<T>(),
+                                 d->ind.as<aoclsparse_int>(), d->ptr.as<aoclsparse_int>(), static_cast<const T *>(dB),
+                                 n, ldb, beta, static_cast<T *>(dC), ldc, colmaj ? nullptr : grp, colmaj ? 0 : ngrp);
     }
     return st == aoclsparse_status_success ? finish() : st;
 }

@@ -158,6 +158,111 @@ __global__ __launch_bounds__(256) void csrmm_row_wave_kernel(int base, T alpha, 
     *cp = c;
 }
 
+// row-major, n >= 128, ROW GROUPS: consecutive rows with the SAME column pattern (the dof rows of one node of a
+// finite-element matrix, the rows of a dense block) are solved by one wavefront per (group, 128-column chunk): every
+// B row the group touches is loaded once and used for all its rows, i.e. the L2 -> CU traffic that bounds the
+// row-per-wave kernel on matrices with tens of non-zeros per row drops by the group size.  This is the blocked-ELL
+// idea without the padding: a group IS a dense r x L block of A, read in place from the CSR arrays (row ii's k-th
+// entry sits at row_ptr[ii] + k for every row of the group).  Per output element the FMA chain is still the row in
+// CSR order, so the result equals the other kernels' bit for bit.  Groups are found once per handle on the host
+// (csrmm_api.cpp: build_mm_groups) and capped at CSRMM_GROUP rows.
+template <typename T>
+__global__ __launch_bounds__(256) void csrmm_rowgroup_kernel(int base, T alpha, aoclsparse_int ngroups,
+                                                             const aoclsparse_int *__restrict__ grp,
+                                                             const T *__restrict__ val,
+                                                             const aoclsparse_int *__restrict__ col,
+                                                             const aoclsparse_int *__restrict__ row_ptr,
+                                                             const T *__restrict__ B, aoclsparse_int n, aoclsparse_int ldb,
+                                                             T beta, T *__restrict__ C, aoclsparse_int ldc, bool readc,
+                                                             int xcd_chunk)
+{
+    using V      = typename vec2<T>::type;
+    const int w  = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int gi = bx * 4 + w;
+    const int j  = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
+    if(gi >= ngroups || j >= n)
+        return;
+    const int i0 = grp[gi], r = grp[gi + 1] - i0; // 1 <= r <= CSRMM_GROUP
+    const int s0 = row_ptr[i0] - base, len = row_ptr[i0 + 1] - base - s0;
+    int       so[CSRMM_GROUP]; // start of every row of the group (wave-uniform)
+#pragma unroll
+    for(int q = 0; q < CSRMM_GROUP; q++)
+        so[q] = q < r ? row_ptr[i0 + q] - base : s0;
+    T acc0[CSRMM_GROUP], acc1[CSRMM_GROUP];
+#pragma unroll
+    for(int q = 0; q < CSRMM_GROUP; q++)
+        acc0[q] = T(0), acc1[q] = T(0);
+    const T *Bj = B + j;
+    int      k  = 0;
+    for(; k + 8 <= len; k += 8) // eight B rows in flight per step
+    {
+        V b[8];
+#pragma unroll
+        for(int u = 0; u < 8; u++)
+            b[u] = *reinterpret_cast<const V *>(Bj + (size_t)(col[s0 + k + u] - base) * ldb);
+#pragma unroll
+        for(int q = 0; q < CSRMM_GROUP; q++)
+            if(q < r)
+            {
+                T a[8];
+#pragma unroll
+                for(int u = 0; u < 8; u++)
+                    a[u] = val[so[q] + k + u];
+#pragma unroll
+                for(int u = 0; u < 8; u++)
+                    acc0[q] = mm_fma(a[u], b[u].x, acc0[q]), acc1[q] = mm_fma(a[u], b[u].y, acc1[q]);
+            }
+    }
+    for(; k + 4 <= len; k += 4) // four B rows in flight per step
+    {
+        V b[4];
+#pragma unroll
+        for(int u = 0; u < 4; u++)
+            b[u] = *reinterpret_cast<const V *>(Bj + (size_t)(col[s0 + k + u] - base) * ldb);
+#pragma unroll
+        for(int q = 0; q < CSRMM_GROUP; q++)
+            if(q < r)
+            {
+                T a[4];
+#pragma unroll
+                for(int u = 0; u < 4; u++)
+                    a[u] = val[so[q] + k + u];
+#pragma unroll
+                for(int u = 0; u < 4; u++)
+                    acc0[q] = mm_fma(a[u], b[u].x, acc0[q]), acc1[q] = mm_fma(a[u], b[u].y, acc1[q]);
+            }
+    }
+    for(; k < len; k++)
+    {
+        const V b0 = *reinterpret_cast<const V *>(Bj + (size_t)(col[s0 + k] - base) * ldb);
+#pragma unroll
+        for(int q = 0; q < CSRMM_GROUP; q++)
+            if(q < r)
+            {
+                const T a0 = val[so[q] + k];
+                acc0[q] = mm_fma(a0, b0.x, acc0[q]), acc1[q] = mm_fma(a0, b0.y, acc1[q]);
+            }
+    }
+#pragma unroll
+    for(int q = 0; q < CSRMM_GROUP; q++)
+        if(q < r)
+        {
+            V      *cp = reinterpret_cast<V *>(C + (size_t)(i0 + q) * ldc + j);
+            const T z0 = alpha * acc0[q], z1 = alpha * acc1[q];
+            V       c;
+            if(readc || z0 == T(0) || z1 == T(0))
+            {
+                c   = *cp;
+                c.x = mm_fma(beta, c.x, z0);
+                c.y = mm_fma(beta, c.y, z1);
+            }
+            else
+                c.x = z0, c.y = z1;
+            *cp = c;
+        }
+}
+
 // column-major: one lane owns one row; the first CM_K entries of the row are kept in registers and the
 // lane sweeps CM_COLS columns, so A is read n/CM_COLS times (once for a 32..64-column shard) and every
 // B / C access is coalesced across the 64 rows of a wavefront.
@@ -241,6 +346,36 @@ __global__ __launch_bounds__(256) void csrmm_col_kernel(int base, T alpha, aocls
     }
 }
 
+// dense layout change for the column-major detour of csrmm_api.cpp: src is R x N with element (r, c) at
+// src[r*rs + c*cs]; dst gets it at dst[r*rd + c*cd].  64 x 64 tiles through LDS so that both sides move whole lines
+// (tile rows run along whichever index is contiguous on each side).
+template <typename T>
+__global__ __launch_bounds__(256) void relayout_kernel(const T *__restrict__ src, long long rs, long long cs, T *__restrict__ dst,
+                                                       long long rd, long long cd, aoclsparse_int R, aoclsparse_int N,
+                                                       bool src_rows_contig)
+{
+    __shared__ T tile[64][65];
+    const int    r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int    tx = threadIdx.x & 63, ty = threadIdx.x >> 6; // 64 x 4
+    // read: the contiguous source index varies with tx
+    for(int k = ty; k < 64; k += 4)
+    {
+        const int r = src_rows_contig ? r0 + tx : r0 + k;
+        const int c = src_rows_contig ? c0 + k : c0 + tx;
+        if(r < R && c < N)
+            tile[r - r0][c - c0] = src[(long long)r * rs + (long long)c * cs];
+    }
+    __syncthreads();
+    // write: the contiguous destination index is the other one
+    for(int k = ty; k < 64; k += 4)
+    {
+        const int r = src_rows_contig ? r0 + k : r0 + tx;
+        const int c = src_rows_contig ? c0 + tx : c0 + k;
+        if(r < R && c < N)
+            dst[(long long)r * rd + (long long)c * cd] = tile[r - r0][c - c0];
+    }
+}
+
 // level3/aoclsparse_csrmm.hpp:361-427: beta == 0 stores exact zeros, otherwise C *= beta
 template <typename T>
 __global__ void scale_dense_kernel(T *C, aoclsparse_int inner, aoclsparse_int outer, aoclsparse_int ld, T beta)
@@ -266,7 +401,8 @@ template <typename T>
 aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, T alpha, aoclsparse_int m,
                                aoclsparse_int /*k*/, const T *val, const aoclsparse_int *col,
                                const aoclsparse_int *row_ptr, const T *B, aoclsparse_int n,
-                               aoclsparse_int ldb, T beta, T *C, aoclsparse_int ldc)
+                               aoclsparse_int ldb, T beta, T *C, aoclsparse_int ldc, const aoclsparse_int *grp,
+                               aoclsparse_int ngroups)
 {
     if(m <= 0 || n <= 0)
         return aoclsparse_status_success;
@@ -294,7 +430,13 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
         const int lanes = vec ? n / 2 : n;
         const int tx    = lanes >= 128 ? 128 : pow2_at_least(lanes);
         const int ty    = 256 / tx;
-        if(vec && n >= 128)
+        if(vec && n >= 128 && grp && ngroups > 0)
+        {
+            const int gx = grid_x((ngroups + 3) / 4, chunk);
+            hipLaunchKernelGGL((csrmm_rowgroup_kernel<T>), dim3(gx, (n + 127) / 128), dim3(256), 0, s, base, alpha,
+                               ngroups, grp, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk);
+        }
+        else if(vec && n >= 128)
         {
             const int gx = grid_x((m + 3) / 4, chunk);
             hipLaunchKernelGGL((csrmm_row_wave_kernel<T>), dim3(gx, (n + 127) / 128), dim3(256), 0, s, base, alpha,
@@ -342,13 +484,33 @@ aoclsparse_status launch_scale_dense(hipStream_t s, aoclsparse_order order, T *C
     return aoclsparse_status_success;
 }
 
+
+// column-major (ld) <-> packed row-major (ld = N) copies of an R x N dense matrix
+template <typename T>
+aoclsparse_status launch_relayout(hipStream_t s, bool to_row_major, const T *src, T *dst, aoclsparse_int R, aoclsparse_int N,
+                                  aoclsparse_int ld)
+{
+    if(R <= 0 || N <= 0)
+        return aoclsparse_status_success;
+    const dim3 grid((R + 63) / 64, (N + 63) / 64), block(256);
+    if(to_row_major) // src column-major: rows contiguous
+        hipLaunchKernelGGL((relayout_kernel<T>), grid, block, 0, s, src, 1LL, (long long)ld, dst, (long long)N, 1LL, R, N, true);
+    else // src packed row-major: columns contiguous
+        hipLaunchKernelGGL((relayout_kernel<T>), grid, block, 0, s, src, (long long)N, 1LL, dst, 1LL, (long long)ld, R, N, false);
+    MI355_HIP_TRY(hipGetLastError());
+    return aoclsparse_status_success;
+}
+
 #define MI355_INST_MM(T)                                                                                     \
     template aoclsparse_status launch_csrmm<T>(hipStream_t, aoclsparse_order, int, T, aoclsparse_int,        \
                                                aoclsparse_int, const T *, const aoclsparse_int *,             \
                                                const aoclsparse_int *, const T *, aoclsparse_int,             \
-                                               aoclsparse_int, T, T *, aoclsparse_int);                       \
+                                               aoclsparse_int, T, T *, aoclsparse_int, const aoclsparse_int *, \
+                                               aoclsparse_int);                                               \
     template aoclsparse_status launch_scale_dense<T>(hipStream_t, aoclsparse_order, T *, aoclsparse_int,     \
-                                                     aoclsparse_int, aoclsparse_int, T);
+                                                     aoclsparse_int, aoclsparse_int, T);                     \
+    template aoclsparse_status launch_relayout<T>(hipStream_t, bool, const T *, T *, aoclsparse_int,         \
+                                                  aoclsparse_int, aoclsparse_int);
 MI355_INST_MM(double)
 MI355_INST_MM(float)
 
@@ -367,5 +529,5 @@ extern "C" aoclsparse_status mi355_dcsrmm(void *stream, aoclsparse_int order, ao
     if((order != aoclsparse_order_row && order != aoclsparse_order_column) || (base != 0 && base != 1))
         return aoclsparse_status_invalid_value;
     return mi355::launch_csrmm<double>((hipStream_t)stream, (aoclsparse_order)order, base, alpha, m, k, val, col,
-                                       row_ptr, B, n, ldb, beta, C, ldc);
+                                       row_ptr, B, n, ldb, beta, C, ldc, nullptr, 0);
 }

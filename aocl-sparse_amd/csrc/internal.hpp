@@ -173,6 +173,15 @@ struct SellPlan
     bool           wanted = false; // optimize chose SELL: rebuilt lazily after the values change
 };
 
+// csrmm row groups (csrmm_kernels.hip: csrmm_rowgroup_kernel): runs of consecutive rows with one column pattern
+constexpr int CSRMM_GROUP = 8; // rows per group at most
+struct MmGroups
+{
+    aoclsparse_int ngroups = 0;
+    DeviceBuffer   first; // ngroups + 1 row indices
+    bool           valid = false, tried = false;
+};
+
 // merge-path tiling of a device CSR (mergepath_kernels.hip): tile w starts at {row ends, non-zeros} =
 // starts[2w], starts[2w+1]; two carry records per tile
 constexpr int MP_ITEMS = 1024; // rows + non-zeros per workgroup
@@ -195,6 +204,7 @@ struct SpmvPlan
     bool           valid = false;
     SellPlan       sell;
     MergePlan      merge;
+    MmGroups       mm;
 };
 
 // TRSV plan of one (triangle, op) pair (trsv_api.cpp / trsv_kernels.hip): the strict triangle
@@ -562,7 +572,10 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
                                aoclsparse_int m, aoclsparse_int k, const T *val,
                                const aoclsparse_int *col, const aoclsparse_int *row_ptr, const T *B,
                                aoclsparse_int n, aoclsparse_int ldb, T beta, T *C,
-                               aoclsparse_int ldc);
+                               aoclsparse_int ldc, const aoclsparse_int *grp = nullptr, aoclsparse_int ngroups = 0);
+template <typename T>
+aoclsparse_status launch_relayout(hipStream_t s, bool to_row_major, const T *src, T *dst, aoclsparse_int R, aoclsparse_int N,
+                                  aoclsparse_int ld);
 template <typename T>
 aoclsparse_status launch_scale_dense(hipStream_t s, aoclsparse_order order, T *C, aoclsparse_int m,
                                      aoclsparse_int n, aoclsparse_int ld, T beta);

@@ -555,6 +555,55 @@ def test_csrmm_random_vs_oracle(n, alpha, beta):
     assert np.array_equal(Ch.reshape(m, ldc)[:, n:], Cr0.reshape(m, ldc)[:, n:])  # padding untouched
 
 
+@pytest.mark.parametrize("base", [0, 1])
+def test_csrmm_row_groups_block_structured(base):
+    """rows that share a column pattern (the dof rows of a node) are multiplied as one group per wavefront; per element
+    the chain is still the row in CSR order, so C equals the column-major kernel's (= csrmm_col_major_ref's) bits.
+    Groups of 1..11 rows (cap 8), a group cut by an empty row, 128 and 384 columns with padded leading dimensions."""
+    rng = np.random.default_rng(5)
+    nodes, k = 260, 1300
+    rows_p, rows_c = [0], []
+    for nd in range(nodes):
+        dof = 1 + nd % 11
+        cols = np.sort(rng.choice(k, size=3 + nd % 37, replace=False))
+        for r in range(dof):
+            if nd % 17 == 3 and r == 2:
+                rows_p.append(rows_p[-1])  # an empty row inside the node
+                continue
+            rows_c.append(cols)
+            rows_p.append(rows_p[-1] + len(cols))
+    m = len(rows_p) - 1
+    rp = np.array(rows_p, np.int32) + base
+    ci = (np.concatenate(rows_c) + base).astype(np.int32)
+    v = rng.uniform(-1, 1, len(ci))
+    A = P.Matrix(base, m, k, rp, ci, v)
+    d = P.Descr(base=base)
+    for n, alpha, beta in ((128, 1.0, 0.0), (384, -0.7, 1.3)):
+        ldb, ldc = n + 2, n + 6
+        Br, C0 = rng.uniform(-1, 1, k * ldb), rng.uniform(-1, 1, m * ldc)
+        Cd = dev(C0)
+        assert P.dcsrmm(P.OP_NONE, alpha, A, d, P.ORDER_ROW, dev(Br), n, ldb, beta, Cd, ldc) == 0
+        torch.cuda.synchronize()
+        info = A.spmv_info()
+        assert 0 < info.mm_groups < m / 1.5
+        # the column-major oracle on the transposed layouts gives the per-element reference bits
+        Bc = np.ascontiguousarray(Br.reshape(k, ldb)[:, :n].T).ravel()
+        Cc = np.ascontiguousarray(C0.reshape(m, ldc)[:, :n].T).ravel()
+        so, Cref = oracle.dcsrmm("col", alpha, base, v, ci, rp, m, Bc, n, k, beta, Cc, m)
+        got = Cd.cpu().numpy().reshape(m, ldc)
+        assert np.array_equal(got[:, :n], Cref.reshape(n, m).T)
+        assert np.array_equal(got[:, n:], C0.reshape(m, ldc)[:, n:])
+        # column-major operands with rows this long take the detour through the row-major kernels (relayout of B and
+        # C): same bits as csrmm_col_major_ref, leading-dimension padding untouched
+        ldb2, ldc2 = k + 5, m + 3
+        B2, C2 = rng.uniform(-1, 1, ldb2 * n), rng.uniform(-1, 1, ldc2 * n)
+        C2d = dev(C2)
+        assert P.dcsrmm(P.OP_NONE, alpha, A, d, P.ORDER_COLUMN, dev(B2), n, ldb2, beta, C2d, ldc2) == 0
+        torch.cuda.synchronize()
+        so, C2ref = oracle.dcsrmm("col", alpha, base, v, ci, rp, m, B2, n, ldb2, beta, C2, ldc2)
+        assert len(v) > 8 * m and np.array_equal(C2d.cpu().numpy(), C2ref)
+
+
 def test_csrmm_alpha_zero_and_transpose():
     m, k, n = 500, 400, 16
     rp, ci, v = random_csr(91, m, k, lambda r, i: r.integers(0, 9))
