@@ -133,6 +133,14 @@ SIGNATURES = {
     "aoclsparse_dcsrsv": (c_int, [c_int, _P, _I, _P, _P, _P, _P, _P, _P]),
     "aoclsparse_cdotmv": (c_int, [c_int, CFloat, _P, _P, _P, CFloat, _P, _P]),
     "aoclsparse_zdotmv": (c_int, [c_int, CDouble, _P, _P, _P, CDouble, _P, _P]),
+    "aoclsparse_csymgs": (c_int, [c_int, _P, _P, CFloat, _P, _P]),
+    "aoclsparse_csymgs_kid": (c_int, [c_int, _P, _P, CFloat, _P, _P, _I]),
+    "aoclsparse_csymgs_mv": (c_int, [c_int, _P, _P, CFloat, _P, _P, _P]),
+    "aoclsparse_csymgs_mv_kid": (c_int, [c_int, _P, _P, CFloat, _P, _P, _P, _I]),
+    "aoclsparse_zsymgs": (c_int, [c_int, _P, _P, CDouble, _P, _P]),
+    "aoclsparse_zsymgs_kid": (c_int, [c_int, _P, _P, CDouble, _P, _P, _I]),
+    "aoclsparse_zsymgs_mv": (c_int, [c_int, _P, _P, CDouble, _P, _P, _P]),
+    "aoclsparse_zsymgs_mv_kid": (c_int, [c_int, _P, _P, CDouble, _P, _P, _P, _I]),
     "aoclsparse_cmv": (c_int, [c_int, _P, _P, _P, _P, _P, _P]),
     "aoclsparse_zmv": (c_int, [c_int, _P, _P, _P, _P, _P, _P]),
     "aoclsparse_create_scsc": (c_int, [POINTER(_P), c_int, _I, _I, _I, _P, _P, _P]),

@@ -275,6 +275,16 @@ __global__ __launch_bounds__(256) void cdot_final_kernel(const cplx<R> *__restri
         *d = r;
 }
 
+
+// w = x - y (the residual updates of the complex symmetric Gauss-Seidel sweep)
+template <typename R>
+__global__ void cdiff_kernel(aoclsparse_int n, const cplx<R> *x, const cplx<R> *y, cplx<R> *w)
+{
+    const aoclsparse_int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n)
+        w[i] = cplx<R>(x[i].re - y[i].re, x[i].im - y[i].im);
+}
+
 } // namespace
 
 template <typename R>
@@ -421,6 +431,17 @@ aoclsparse_status launch_cdot(hipStream_t s, aoclsparse_int n, const cplx<R> *x,
 template aoclsparse_status launch_cdot<float>(hipStream_t, aoclsparse_int, const cfloat *, const cfloat *, cfloat *, cfloat *);
 template aoclsparse_status launch_cdot<double>(hipStream_t, aoclsparse_int, const cdouble *, const cdouble *, cdouble *,
                                                cdouble *);
+
+template <typename R>
+aoclsparse_status launch_cdiff(hipStream_t s, aoclsparse_int n, const cplx<R> *x, const cplx<R> *y, cplx<R> *w)
+{
+    if(n > 0)
+        hipLaunchKernelGGL((cdiff_kernel<R>), dim3((n + 255) / 256), dim3(256), 0, s, n, x, y, w);
+    MI355_HIP_TRY(hipGetLastError());
+    return aoclsparse_status_success;
+}
+template aoclsparse_status launch_cdiff<float>(hipStream_t, aoclsparse_int, const cfloat *, const cfloat *, cfloat *);
+template aoclsparse_status launch_cdiff<double>(hipStream_t, aoclsparse_int, const cdouble *, const cdouble *, cdouble *);
 
 template aoclsparse_status launch_cspmv<float>(hipStream_t, int, bool, cfloat, aoclsparse_int, aoclsparse_int,
                                                const cfloat *, const aoclsparse_int *, const aoclsparse_int *,

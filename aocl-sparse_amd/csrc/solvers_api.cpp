@@ -29,6 +29,50 @@ inline aoclsparse_status exec_mv(aoclsparse_operation op, const float *alpha, ao
 {
     return aoclsparse_smv(op, alpha, A, d, x, beta, y);
 }
+inline aoclsparse_status exec_mv(aoclsparse_operation op, const cdouble *alpha, aoclsparse_matrix A,
+                                 const aoclsparse_mat_descr d, const cdouble *x, const cdouble *beta, cdouble *y)
+{
+    return aoclsparse_zmv(op, reinterpret_cast<const aoclsparse_double_complex *>(alpha), A, d,
+                          reinterpret_cast<const aoclsparse_double_complex *>(x),
+                          reinterpret_cast<const aoclsparse_double_complex *>(beta),
+                          reinterpret_cast<aoclsparse_double_complex *>(y));
+}
+inline aoclsparse_status exec_mv(aoclsparse_operation op, const cfloat *alpha, aoclsparse_matrix A,
+                                 const aoclsparse_mat_descr d, const cfloat *x, const cfloat *beta, cfloat *y)
+{
+    return aoclsparse_cmv(op, reinterpret_cast<const aoclsparse_float_complex *>(alpha), A, d,
+                          reinterpret_cast<const aoclsparse_float_complex *>(x),
+                          reinterpret_cast<const aoclsparse_float_complex *>(beta),
+                          reinterpret_cast<aoclsparse_float_complex *>(y));
+}
+inline aoclsparse_status exec_trsv(aoclsparse_operation op, cdouble alpha, aoclsparse_matrix A,
+                                   const aoclsparse_mat_descr d, const cdouble *b, cdouble *x, aoclsparse_int kid)
+{
+    return aoclsparse_ztrsv_kid(op, aoclsparse_double_complex{alpha.re, alpha.im}, A, d,
+                                reinterpret_cast<const aoclsparse_double_complex *>(b),
+                                reinterpret_cast<aoclsparse_double_complex *>(x), kid);
+}
+inline aoclsparse_status exec_trsv(aoclsparse_operation op, cfloat alpha, aoclsparse_matrix A,
+                                   const aoclsparse_mat_descr d, const cfloat *b, cfloat *x, aoclsparse_int kid)
+{
+    return aoclsparse_ctrsv_kid(op, aoclsparse_float_complex{alpha.re, alpha.im}, A, d,
+                                reinterpret_cast<const aoclsparse_float_complex *>(b),
+                                reinterpret_cast<aoclsparse_float_complex *>(x), kid);
+}
+// w = x - y
+template <typename T>
+inline aoclsparse_status exec_diff(hipStream_t s, aoclsparse_int n, const T *x, const T *y, T *w)
+{
+    return launch_waxpby<T>(s, n, T(1), x, T(-1), y, w);
+}
+inline aoclsparse_status exec_diff(hipStream_t s, aoclsparse_int n, const cdouble *x, const cdouble *y, cdouble *w)
+{
+    return launch_cdiff<double>(s, n, x, y, w);
+}
+inline aoclsparse_status exec_diff(hipStream_t s, aoclsparse_int n, const cfloat *x, const cfloat *y, cfloat *w)
+{
+    return launch_cdiff<float>(s, n, x, y, w);
+}
 inline aoclsparse_status exec_trsv(aoclsparse_operation op, double alpha, aoclsparse_matrix A,
                                    const aoclsparse_mat_descr d, const double *b, double *x, aoclsparse_int kid)
 {
@@ -193,11 +237,11 @@ aoclsparse_status symgs_t(aoclsparse_operation trans, aoclsparse_matrix A, const
             };
             // 1: (L + D) x1 = b - alpha U x0
             MI355_TRY(exec_mv(u_trans, &alpha, A, with(u_fill, aoclsparse_diag_type_zero), vx.dev, &zero, q));
-            MI355_TRY(launch_waxpby<T>(rt.stream(), m, one, vb.dev, T(-1), q, r));
+            MI355_TRY(exec_diff(rt.stream(), m, vb.dev, q, r));
             MI355_TRY(exec_trsv(l_trans, one, A, with(l_fill, aoclsparse_diag_type_non_unit), r, q, -1));
             // 2: (U + D) x = b - L x1
             MI355_TRY(exec_mv(l_trans, &one, A, with(l_fill, aoclsparse_diag_type_zero), q, &zero, r));
-            MI355_TRY(launch_waxpby<T>(rt.stream(), m, one, vb.dev, T(-1), r, q));
+            MI355_TRY(exec_diff(rt.stream(), m, vb.dev, r, q));
             MI355_TRY(exec_trsv(u_trans, one, A, with(u_fill, aoclsparse_diag_type_non_unit), q, vx.dev, -1));
             // 3: y = op(A) x
             if(fuse_mv)
@@ -381,6 +425,60 @@ aoclsparse_status ilu_prepare(aoclsparse_matrix A)
 
 extern "C" {
 
+aoclsparse_status aoclsparse_csymgs(aoclsparse_operation trans, aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                    const aoclsparse_float_complex alpha, const aoclsparse_float_complex *b, aoclsparse_float_complex *x)
+{
+    return symgs_t<cfloat>(trans, A, descr, cfloat(alpha.real, alpha.imag), reinterpret_cast<const cfloat *>(b),
+                          reinterpret_cast<cfloat *>(x), nullptr, -1, false, aoclsparse_cmat);
+}
+aoclsparse_status aoclsparse_csymgs_kid(aoclsparse_operation trans, aoclsparse_matrix A,
+                                        const aoclsparse_mat_descr descr, const aoclsparse_float_complex alpha, const aoclsparse_float_complex *b, aoclsparse_float_complex *x,
+                                        const aoclsparse_int kid)
+{
+    return symgs_t<cfloat>(trans, A, descr, cfloat(alpha.real, alpha.imag), reinterpret_cast<const cfloat *>(b),
+                          reinterpret_cast<cfloat *>(x), nullptr, kid, false, aoclsparse_cmat);
+}
+aoclsparse_status aoclsparse_csymgs_mv(aoclsparse_operation trans, aoclsparse_matrix A,
+                                       const aoclsparse_mat_descr descr, const aoclsparse_float_complex alpha, const aoclsparse_float_complex *b, aoclsparse_float_complex *x,
+                                       aoclsparse_float_complex *y)
+{
+    return symgs_t<cfloat>(trans, A, descr, cfloat(alpha.real, alpha.imag), reinterpret_cast<const cfloat *>(b),
+                          reinterpret_cast<cfloat *>(x), reinterpret_cast<cfloat *>(y), -1, true, aoclsparse_cmat);
+}
+aoclsparse_status aoclsparse_csymgs_mv_kid(aoclsparse_operation trans, aoclsparse_matrix A,
+                                           const aoclsparse_mat_descr descr, const aoclsparse_float_complex alpha, const aoclsparse_float_complex *b, aoclsparse_float_complex *x,
+                                           aoclsparse_float_complex *y, const aoclsparse_int kid)
+{
+    return symgs_t<cfloat>(trans, A, descr, cfloat(alpha.real, alpha.imag), reinterpret_cast<const cfloat *>(b),
+                          reinterpret_cast<cfloat *>(x), reinterpret_cast<cfloat *>(y), kid, true, aoclsparse_cmat);
+}
+aoclsparse_status aoclsparse_zsymgs(aoclsparse_operation trans, aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                    const aoclsparse_double_complex alpha, const aoclsparse_double_complex *b, aoclsparse_double_complex *x)
+{
+    return symgs_t<cdouble>(trans, A, descr, cdouble(alpha.real, alpha.imag), reinterpret_cast<const cdouble *>(b),
+                          reinterpret_cast<cdouble *>(x), nullptr, -1, false, aoclsparse_zmat);
+}
+aoclsparse_status aoclsparse_zsymgs_kid(aoclsparse_operation trans, aoclsparse_matrix A,
+                                        const aoclsparse_mat_descr descr, const aoclsparse_double_complex alpha, const aoclsparse_double_complex *b, aoclsparse_double_complex *x,
+                                        const aoclsparse_int kid)
+{
+    return symgs_t<cdouble>(trans, A, descr, cdouble(alpha.real, alpha.imag), reinterpret_cast<const cdouble *>(b),
+                          reinterpret_cast<cdouble *>(x), nullptr, kid, false, aoclsparse_zmat);
+}
+aoclsparse_status aoclsparse_zsymgs_mv(aoclsparse_operation trans, aoclsparse_matrix A,
+                                       const aoclsparse_mat_descr descr, const aoclsparse_double_complex alpha, const aoclsparse_double_complex *b, aoclsparse_double_complex *x,
+                                       aoclsparse_double_complex *y)
+{
+    return symgs_t<cdouble>(trans, A, descr, cdouble(alpha.real, alpha.imag), reinterpret_cast<const cdouble *>(b),
+                          reinterpret_cast<cdouble *>(x), reinterpret_cast<cdouble *>(y), -1, true, aoclsparse_zmat);
+}
+aoclsparse_status aoclsparse_zsymgs_mv_kid(aoclsparse_operation trans, aoclsparse_matrix A,
+                                           const aoclsparse_mat_descr descr, const aoclsparse_double_complex alpha, const aoclsparse_double_complex *b, aoclsparse_double_complex *x,
+                                           aoclsparse_double_complex *y, const aoclsparse_int kid)
+{
+    return symgs_t<cdouble>(trans, A, descr, cdouble(alpha.real, alpha.imag), reinterpret_cast<const cdouble *>(b),
+                          reinterpret_cast<cdouble *>(x), reinterpret_cast<cdouble *>(y), kid, true, aoclsparse_zmat);
+}
 aoclsparse_status aoclsparse_dsymgs(aoclsparse_operation trans, aoclsparse_matrix A, const aoclsparse_mat_descr descr,
                                     const double alpha, const double *b, double *x)
 {

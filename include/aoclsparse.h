@@ -489,6 +489,32 @@ DLL_PUBLIC aoclsparse_status aoclsparse_zdotmv(const aoclsparse_operation op, co
                                                const aoclsparse_double_complex *x,
                                                const aoclsparse_double_complex beta, aoclsparse_double_complex *y,
                                                aoclsparse_double_complex *d);
+/* complex symmetric Gauss-Seidel sweeps (aoclsparse_solvers.h: aoclsparse_?symgs(_mv)(_kid)): same checks and
+ * composition as the real ones; a hermitian descriptor uses the conjugate transpose of the stored triangle. */
+DLL_PUBLIC aoclsparse_status aoclsparse_csymgs(aoclsparse_operation trans, aoclsparse_matrix A,
+                                                const aoclsparse_mat_descr descr, const aoclsparse_float_complex alpha,
+                                                const aoclsparse_float_complex *b, aoclsparse_float_complex *x);
+DLL_PUBLIC aoclsparse_status aoclsparse_csymgs_kid(aoclsparse_operation trans, aoclsparse_matrix A,
+                                                    const aoclsparse_mat_descr descr, const aoclsparse_float_complex alpha,
+                                                    const aoclsparse_float_complex *b, aoclsparse_float_complex *x, const aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_csymgs_mv(aoclsparse_operation trans, aoclsparse_matrix A,
+                                                   const aoclsparse_mat_descr descr, const aoclsparse_float_complex alpha,
+                                                   const aoclsparse_float_complex *b, aoclsparse_float_complex *x, aoclsparse_float_complex *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_csymgs_mv_kid(aoclsparse_operation trans, aoclsparse_matrix A,
+                                                       const aoclsparse_mat_descr descr, const aoclsparse_float_complex alpha,
+                                                       const aoclsparse_float_complex *b, aoclsparse_float_complex *x, aoclsparse_float_complex *y, const aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_zsymgs(aoclsparse_operation trans, aoclsparse_matrix A,
+                                                const aoclsparse_mat_descr descr, const aoclsparse_double_complex alpha,
+                                                const aoclsparse_double_complex *b, aoclsparse_double_complex *x);
+DLL_PUBLIC aoclsparse_status aoclsparse_zsymgs_kid(aoclsparse_operation trans, aoclsparse_matrix A,
+                                                    const aoclsparse_mat_descr descr, const aoclsparse_double_complex alpha,
+                                                    const aoclsparse_double_complex *b, aoclsparse_double_complex *x, const aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_zsymgs_mv(aoclsparse_operation trans, aoclsparse_matrix A,
+                                                   const aoclsparse_mat_descr descr, const aoclsparse_double_complex alpha,
+                                                   const aoclsparse_double_complex *b, aoclsparse_double_complex *x, aoclsparse_double_complex *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_zsymgs_mv_kid(aoclsparse_operation trans, aoclsparse_matrix A,
+                                                       const aoclsparse_mat_descr descr, const aoclsparse_double_complex alpha,
+                                                       const aoclsparse_double_complex *b, aoclsparse_double_complex *x, aoclsparse_double_complex *y, const aoclsparse_int kid);
 /* raw-array triangular solve y = inv(T) * alpha * x, T = the triangle of the CSR arrays named by descr->fill_mode
  * (aoclsparse_functions.h:1318-1402): zero-based, op = none, general / symmetric descriptor type, host arrays. */
 DLL_PUBLIC aoclsparse_status aoclsparse_scsrsv(aoclsparse_operation trans, const float *alpha, aoclsparse_int m,

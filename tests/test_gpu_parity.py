@@ -1970,6 +1970,51 @@ def test_complex_trsv_trsm(prec):
         L.aoclsparse_destroy(ctypes.byref(h))
 
 
+@pytest.mark.parametrize("prec", ["z", "c"])
+def test_complex_symgs(prec):
+    """aoclsparse_{c,z}symgs(_mv): the two triangular sweeps of symgs.hpp:62-258 restated with dense numpy operators --
+    general (N, T), symmetric and hermitian (both fills): x1 = (L+D)^-1 (b - alpha U x0), x = (U+D)^-1 (b - L x1),
+    y = op(A) x; within 256 eps of the restatement on diagonally dominant systems."""
+    dtype, eps = (np.complex128, EPS64) if prec == "z" else (np.complex64, EPS32)
+    C = P.CDouble if prec == "z" else P.CFloat
+    fn = lambda stem: getattr(L, "aoclsparse_" + stem.replace("?", prec))
+    n = 300
+    rng = np.random.default_rng(21)
+    dense, rp, ci, v = _cplx_tri_system(77, n, dtype, 0)
+    D = dense.astype(np.complex128)
+    h = ctypes.c_void_p()
+    assert fn("create_?csr")(ctypes.byref(h), 0, n, n, len(v), P._ptr(rp), P._ptr(ci), P._ptr(v)) == 0
+    b = (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(dtype)
+    x0 = (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(dtype)
+    alpha = 0.9 + 0.2j
+    sl, su, dg = np.tril(D, -1), np.triu(D, 1), np.diag(np.diag(D))
+    cases = [("general", "lower", P.OP_NONE, sl, su, D), ("general", "lower", P.OP_TRANSPOSE, su.T, sl.T, D.T),
+             ("symmetric", "lower", P.OP_NONE, sl, sl.T, sl + dg + sl.T), ("symmetric", "upper", P.OP_NONE, su.T, su, su + dg + su.T),
+             ("hermitian", "lower", P.OP_NONE, sl, sl.conj().T, sl + dg + sl.conj().T),
+             ("hermitian", "upper", P.OP_NONE, su.conj().T, su, su + dg + su.conj().T)]
+    types = {"general": P.TYPE_GENERAL, "symmetric": P.TYPE_SYMMETRIC, "hermitian": P.TYPE_HERMITIAN}
+    for tname, fill, op, Lm, Um, Afull in cases:
+        d = P.Descr(mtype=types[tname], fill=P.FILL_LOWER if fill == "lower" else P.FILL_UPPER)
+        # the sweep that runs on the conjugate transpose of the stored triangle sees conj(D) (trsv with op = H)
+        Dl = dg.conj() if (tname, fill) == ("hermitian", "upper") else dg
+        Du = dg.conj() if (tname, fill) == ("hermitian", "lower") else dg
+        x1 = np.linalg.solve(Lm + Dl, b.astype(np.complex128) - alpha * (Um @ x0.astype(np.complex128)))
+        xr = np.linalg.solve(Um + Du, b.astype(np.complex128) - Lm @ x1)
+        x, y = x0.copy(), np.zeros(n, dtype)
+        assert fn("?symgs_mv")(op, h, d.h, C(alpha.real, alpha.imag), P._ptr(b), P._ptr(x), P._ptr(y)) == 0
+        tol = 256 * eps * max(1.0, np.max(np.abs(xr)))
+        assert np.max(np.abs(x - xr)) <= tol, (tname, fill, op, np.max(np.abs(x - xr)), tol)
+        yr = Afull @ xr
+        assert np.max(np.abs(y - yr)) <= 256 * eps * max(1.0, np.max(np.abs(yr))) * 8, (tname, fill)
+        xd = dev(x0)
+        assert fn("?symgs")(op, h, d.h, C(alpha.real, alpha.imag), P._ptr(dev(b)), P._ptr(xd)) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(xd.cpu().numpy(), x)
+    dgen = P.Descr()
+    assert fn("?symgs")(P.OP_CONJ_TRANSPOSE, h, dgen.h, C(1, 0), P._ptr(b), P._ptr(x)) == 1  # symgs.hpp: not implemented
+    L.aoclsparse_destroy(ctypes.byref(h))
+
+
 def test_complex_trsv_reference_h5_round_trip():
     """trsv_tests.cpp:313-318 / common_data_utils.h:4349-4470: the 5x5 lower-stored complex matrix, xref = 1..5,
     b = op(T) xref built by the test itself, x = solve -> xref.  All six (fill, op) cases; with fill = upper the same
