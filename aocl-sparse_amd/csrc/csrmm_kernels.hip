@@ -263,6 +263,105 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup_kernel(int base, T alpha, 
         }
 }
 
+// narrower B (32 <= n < 128): LANES lanes (2 columns each) per group, 64 / LANES groups per wavefront; the group's
+// row_ptr / col / val loads are then per-lane loads of one address per sub-wave instead of scalar loads
+template <typename T, int LANES>
+__global__ __launch_bounds__(256) void csrmm_rowgroup_sub_kernel(int base, T alpha, aoclsparse_int ngroups,
+                                                             const aoclsparse_int *__restrict__ grp,
+                                                             const T *__restrict__ val,
+                                                             const aoclsparse_int *__restrict__ col,
+                                                             const aoclsparse_int *__restrict__ row_ptr,
+                                                             const T *__restrict__ B, aoclsparse_int n, aoclsparse_int ldb,
+                                                             T beta, T *__restrict__ C, aoclsparse_int ldc, bool readc,
+                                                             int xcd_chunk)
+{
+    using V      = typename vec2<T>::type;
+    const int bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int gi = bx * (256 / LANES) + (int)threadIdx.x / LANES;
+    const int j  = 2 * ((int)threadIdx.x % LANES) + 2 * LANES * (int)blockIdx.y;
+    if(gi >= ngroups || j >= n)
+        return;
+    const int i0 = grp[gi], r = grp[gi + 1] - i0; // 1 <= r <= CSRMM_GROUP
+    const int s0 = row_ptr[i0] - base, len = row_ptr[i0 + 1] - base - s0;
+    int       so[CSRMM_GROUP]; // start of every row of the group (wave-uniform)
+#pragma unroll
+    for(int q = 0; q < CSRMM_GROUP; q++)
+        so[q] = q < r ? row_ptr[i0 + q] - base : s0;
+    T acc0[CSRMM_GROUP], acc1[CSRMM_GROUP];
+#pragma unroll
+    for(int q = 0; q < CSRMM_GROUP; q++)
+        acc0[q] = T(0), acc1[q] = T(0);
+    const T *Bj = B + j;
+    int      k  = 0;
+    for(; k + 8 <= len; k += 8) // eight B rows in flight per step
+    {
+        V b[8];
+#pragma unroll
+        for(int u = 0; u < 8; u++)
+            b[u] = *reinterpret_cast<const V *>(Bj + (size_t)(col[s0 + k + u] - base) * ldb);
+#pragma unroll
+        for(int q = 0; q < CSRMM_GROUP; q++)
+            if(q < r)
+            {
+                T a[8];
+#pragma unroll
+                for(int u = 0; u < 8; u++)
+                    a[u] = val[so[q] + k + u];
+#pragma unroll
+                for(int u = 0; u < 8; u++)
+                    acc0[q] = mm_fma(a[u], b[u].x, acc0[q]), acc1[q] = mm_fma(a[u], b[u].y, acc1[q]);
+            }
+    }
+    for(; k + 4 <= len; k += 4) // four B rows in flight per step
+    {
+        V b[4];
+#pragma unroll
+        for(int u = 0; u < 4; u++)
+            b[u] = *reinterpret_cast<const V *>(Bj + (size_t)(col[s0 + k + u] - base) * ldb);
+#pragma unroll
+        for(int q = 0; q < CSRMM_GROUP; q++)
+            if(q < r)
+            {
+                T a[4];
+#pragma unroll
+                for(int u = 0; u < 4; u++)
+                    a[u] = val[so[q] + k + u];
+#pragma unroll
+                for(int u = 0; u < 4; u++)
+                    acc0[q] = mm_fma(a[u], b[u].x, acc0[q]), acc1[q] = mm_fma(a[u], b[u].y, acc1[q]);
+            }
+    }
+    for(; k < len; k++)
+    {
+        const V b0 = *reinterpret_cast<const V *>(Bj + (size_t)(col[s0 + k] - base) * ldb);
+#pragma unroll
+        for(int q = 0; q < CSRMM_GROUP; q++)
+            if(q < r)
+            {
+                const T a0 = val[so[q] + k];
+                acc0[q] = mm_fma(a0, b0.x, acc0[q]), acc1[q] = mm_fma(a0, b0.y, acc1[q]);
+            }
+    }
+#pragma unroll
+    for(int q = 0; q < CSRMM_GROUP; q++)
+        if(q < r)
+        {
+            V      *cp = reinterpret_cast<V *>(C + (size_t)(i0 + q) * ldc + j);
+            const T z0 = alpha * acc0[q], z1 = alpha * acc1[q];
+            V       c;
+            if(readc || z0 == T(0) || z1 == T(0))
+            {
+                c   = *cp;
+                c.x = mm_fma(beta, c.x, z0);
+                c.y = mm_fma(beta, c.y, z1);
+            }
+            else
+                c.x = z0, c.y = z1;
+            *cp = c;
+        }
+}
+
+
 // column-major: one lane owns one row; the first CM_K entries of the row are kept in registers and the
 // lane sweeps CM_COLS columns, so A is read n/CM_COLS times (once for a 32..64-column shard) and every
 // B / C access is coalesced across the 64 rows of a wavefront.
@@ -435,6 +534,21 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
             const int gx = grid_x((ngroups + 3) / 4, chunk);
             hipLaunchKernelGGL((csrmm_rowgroup_kernel<T>), dim3(gx, (n + 127) / 128), dim3(256), 0, s, base, alpha,
                                ngroups, grp, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk);
+        }
+        else if(vec && n >= 32 && grp && ngroups > 0)
+        {
+            if(n >= 64)
+            {
+                const int gx = grid_x((ngroups + 7) / 8, chunk);
+                hipLaunchKernelGGL((csrmm_rowgroup_sub_kernel<T, 32>), dim3(gx, (n + 63) / 64), dim3(256), 0, s, base, alpha,
+                                   ngroups, grp, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk);
+            }
+            else
+            {
+                const int gx = grid_x((ngroups + 15) / 16, chunk);
+                hipLaunchKernelGGL((csrmm_rowgroup_sub_kernel<T, 16>), dim3(gx, (n + 31) / 32), dim3(256), 0, s, base, alpha,
+                                   ngroups, grp, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk);
+            }
         }
         else if(vec && n >= 128)
         {

@@ -578,7 +578,7 @@ def test_csrmm_row_groups_block_structured(base):
     v = rng.uniform(-1, 1, len(ci))
     A = P.Matrix(base, m, k, rp, ci, v)
     d = P.Descr(base=base)
-    for n, alpha, beta in ((128, 1.0, 0.0), (384, -0.7, 1.3)):
+    for n, alpha, beta in ((128, 1.0, 0.0), (384, -0.7, 1.3), (32, 1.0, 0.0), (96, 2.0, -1.0)):
         ldb, ldc = n + 2, n + 6
         Br, C0 = rng.uniform(-1, 1, k * ldb), rng.uniform(-1, 1, m * ldc)
         Cd = dev(C0)
