@@ -185,6 +185,7 @@ struct MmGroups
 // merge-path tiling of a device CSR (mergepath_kernels.hip): tile w starts at {row ends, non-zeros} =
 // starts[2w], starts[2w+1]; two carry records per tile
 constexpr int MP_ITEMS = 1024; // rows + non-zeros per workgroup
+constexpr int SELL_PROMOTE_CALLS = 8; // an un-hinted handle gets its SELL-64 copy at this many products
 struct MergePlan
 {
     aoclsparse_int ntiles = 0;
@@ -205,6 +206,7 @@ struct SpmvPlan
     SellPlan       sell;
     MergePlan      merge;
     MmGroups       mm;
+    int            mv_calls = 0; // products served from this plan without a SELL copy (promotion counter)
 };
 
 // TRSV plan of one (triangle, op) pair (trsv_api.cpp / trsv_kernels.hip): the strict triangle

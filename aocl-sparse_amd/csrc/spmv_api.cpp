@@ -220,7 +220,13 @@ aoclsparse_status mv_t(aoclsparse_operation op, const T *alpha, aoclsparse_matri
         st = ensure_spmv(A, tr, dcsr, plan);
         if(st != aoclsparse_status_success)
             return st;
-        if(plan->sell.wanted && !plan->sell.valid) // values changed since optimize built the SELL copy
+        // A handle that keeps being multiplied without ever having been given an mv hint is promoted to the SELL-64
+        // copy an optimize would have built (same summation orders, same bits; the copy costs about three products).
+        // aoclsparse_memory_usage_minimal and AOCLSPARSE_MI355_SELL=0 forbid it.
+        const bool promote = !plan->sell.valid && !plan->sell.tried && !plan->merge.valid && !is_complex_type(A->val_type)
+                             && A->mem_policy == aoclsparse_memory_usage_unrestricted
+                             && ++plan->mv_calls >= SELL_PROMOTE_CALLS;
+        if(promote || (plan->sell.wanted && !plan->sell.valid)) // or: values changed since the SELL copy was built
         {
             std::unique_lock<std::shared_mutex> w(A->guard);
             st = build_sell((tr ? *A->trans : A->user).ptr, *dcsr, val_size(A->val_type), *plan);

@@ -217,6 +217,28 @@ def test_merge_path_kernel_edges(merge_kernel):
     assert st == 0 and np.array_equal(y, yr)
 
 
+def test_unhinted_handle_is_promoted_to_sell():
+    """no mv hint, no optimize: the first products run the row-block kernel; at the 8th the handle gets the SELL-64 copy
+    an optimize would have built -- every product has the same bits; memory_usage_minimal keeps the handle as it is."""
+    m, rp, ci, v = laplace5(300)
+    x = np.random.default_rng(5).uniform(-1, 1, m)
+    so, yr = oracle.dcsrmv(-1, 0, 1.0, m, len(v), v, ci, rp, x, 0.0, np.zeros(m))
+    d = P.Descr()
+    A = P.Matrix(0, m, m, rp, ci, v)
+    kernels = []
+    for _ in range(10):
+        st, y = run_dmv(A, d, x, np.zeros(m), 1.0, 0.0)
+        assert st == 0 and np.array_equal(y, yr)
+        kernels.append(A.spmv_info().kernel)
+    assert kernels[:7] == [1] * 7 and kernels[7:] == [3] * 3
+    Bm = P.Matrix(0, m, m, rp, ci, v)
+    assert L.aoclsparse_set_memory_hint(Bm.h, 0) == 0  # aoclsparse_memory_usage_minimal
+    for _ in range(10):
+        st, y = run_dmv(Bm, d, x, np.zeros(m), 1.0, 0.0)
+        assert st == 0 and np.array_equal(y, yr)
+    assert Bm.spmv_info().kernel == 1
+
+
 @pytest.mark.parametrize("kid,order", [(3, "lane8"), (1, "lane4")])
 def test_long_rows_strict_lane_orders(kid, order):
     m, n = 300, 60000
