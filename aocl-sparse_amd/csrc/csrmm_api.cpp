@@ -195,6 +195,8 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
         if(st != aoclsparse_status_success)
             return st;
     }
+    if(detour && !sl.owns_lock())
+        sl.lock(); // the scratch slots are shared; taken before the handle's guard, as everywhere else
     {
         std::shared_lock<std::shared_mutex> r(A->guard);
         const bool                          grouped = p && p->mm.valid;
@@ -202,8 +204,6 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
         const aoclsparse_int                ngrp = grouped ? p->mm.ngroups : 0;
         if(detour)
         {
-            if(!sl.owns_lock())
-                sl.lock(); // the scratch slots are shared
             void *bt = nullptr, *ct = nullptr;
             st = rt.staging(5, sizeof(T) * (size_t)b_rows * (size_t)n, &bt);
             if(st == aoclsparse_status_success)
