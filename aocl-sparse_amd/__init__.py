@@ -203,6 +203,8 @@ SIGNATURES = {
     "aoclsparse_dsymgs_mv_kid": (c_int, [c_int, _P, _P, c_double, _P, _P, _P, _I]),
     "aoclsparse_silu_smoother": (c_int, [c_int, _P, _P, POINTER(_P), _P, _P, _P]),
     "aoclsparse_dilu_smoother": (c_int, [c_int, _P, _P, POINTER(_P), _P, _P, _P]),
+    "aoclsparse_cilu_smoother": (c_int, [c_int, _P, _P, POINTER(_P), _P, _P, _P]),
+    "aoclsparse_zilu_smoother": (c_int, [c_int, _P, _P, POINTER(_P), _P, _P, _P]),
     "aoclsparse_set_dotmv_hint": (c_int, [_P, c_int, _P, _I]),
     "aoclsparse_set_lu_smoother_hint": (c_int, [_P, c_int, _P, _I]),
     "aoclsparse_set_sm_hint": (c_int, [_P, c_int, _P, c_int, _I]),

@@ -28,13 +28,44 @@ __device__ __forceinline__ bool ilu_near_zero(T v)
     return fabs((double)v) <= 1e-2 * 2.0 * (sizeof(T) == 8 ? 2.220446049250313e-16 : 1.1920928955078125e-07);
 }
 
-__device__ __forceinline__ double ilu_fma(double a, double b, double c)
+// s - l * a and a / b: one fma / one division for real types (the reference's contracted update, :80-87); for
+// complex types component-wise fmas and the textbook quotient (the reference runs std::complex arithmetic there, so
+// complex factors carry a tolerance instead of bit-equality)
+__device__ __forceinline__ double ilu_nfma(double l, double a, double s)
 {
-    return fma(a, b, c);
+    return fma(-l, a, s);
 }
-__device__ __forceinline__ float ilu_fma(float a, float b, float c)
+__device__ __forceinline__ float ilu_nfma(float l, float a, float s)
 {
-    return fmaf(a, b, c);
+    return fmaf(-l, a, s);
+}
+template <typename R>
+__device__ __forceinline__ cplx<R> ilu_nfma(cplx<R> l, cplx<R> a, cplx<R> s)
+{
+    s.re = ilu_nfma(l.re, a.re, s.re);
+    s.re = ilu_nfma(-l.im, a.im, s.re);
+    s.im = ilu_nfma(l.re, a.im, s.im);
+    s.im = ilu_nfma(l.im, a.re, s.im);
+    return s;
+}
+__device__ __forceinline__ double ilu_div(double a, double b)
+{
+    return a / b;
+}
+__device__ __forceinline__ float ilu_div(float a, float b)
+{
+    return a / b;
+}
+template <typename R>
+__device__ __forceinline__ cplx<R> ilu_div(cplx<R> a, cplx<R> b)
+{
+    const R den = b.re * b.re + b.im * b.im;
+    return cplx<R>((a.re * b.re + a.im * b.im) / den, (a.im * b.re - a.re * b.im) / den);
+}
+template <typename R>
+__device__ __forceinline__ bool ilu_near_zero(cplx<R> v)
+{
+    return hypot((double)v.re, (double)v.im) <= 1e-2 * 2.0 * (sizeof(R) == 8 ? 2.220446049250313e-16 : 1.1920928955078125e-07);
 }
 
 // one wavefront (= one workgroup) per row of the level; dynamic LDS: maxlen columns + maxlen values
@@ -67,17 +98,19 @@ __global__ __launch_bounds__(64) void ilu0_level_kernel(int base, const aoclspar
             bad = true;
             break;
         }
-        const T   lik = sv[t] / pivot;
+        const T   lik = ilu_div(sv[t], pivot);
         const int ke  = row_ptr[k + 1] - base;
         for(int j0 = dk + 1; j0 < ke; j0 += 64) // upper part of row k, 64 entries per round
         {
             const int  jj   = j0 + lane;
             const bool have = jj < ke;
             const int  c    = have ? col[jj] - base : -1;
-            const T    akw  = have ? val[jj] : T(0);
+            T          akw  = T(0);
+            if(have)
+                akw = val[jj];
             for(int w = 0; w < len; w++) // the reference's column -> position map, as a scan of the LDS row
                 if(have && sc[w] == c)
-                    sv[w] = ilu_fma(-lik, akw, sv[w]);
+                    sv[w] = ilu_nfma(lik, akw, sv[w]);
         }
         if(lane == 0)
             sv[t] = lik;
@@ -119,5 +152,11 @@ template aoclsparse_status launch_ilu0_level<double>(hipStream_t, int, aoclspars
 template aoclsparse_status launch_ilu0_level<float>(hipStream_t, int, aoclsparse_int, const aoclsparse_int *,
                                                     const aoclsparse_int *, const aoclsparse_int *, float *,
                                                     aoclsparse_int *, int, int *);
+template aoclsparse_status launch_ilu0_level<cdouble>(hipStream_t, int, aoclsparse_int, const aoclsparse_int *,
+                                                      const aoclsparse_int *, const aoclsparse_int *, cdouble *,
+                                                      aoclsparse_int *, int, int *);
+template aoclsparse_status launch_ilu0_level<cfloat>(hipStream_t, int, aoclsparse_int, const aoclsparse_int *,
+                                                     const aoclsparse_int *, const aoclsparse_int *, cfloat *,
+                                                     aoclsparse_int *, int, int *);
 
 } // namespace mi355

@@ -94,6 +94,17 @@ inline aoclsparse_status create_csr(aoclsparse_matrix *M, aoclsparse_index_base 
     return aoclsparse_create_scsr(M, b, m, n, nnz, p, c, v);
 }
 
+inline aoclsparse_status create_csr(aoclsparse_matrix *M, aoclsparse_index_base b, aoclsparse_int m, aoclsparse_int n,
+                                    aoclsparse_int nnz, aoclsparse_int *p, aoclsparse_int *c, cdouble *v)
+{
+    return aoclsparse_create_zcsr(M, b, m, n, nnz, p, c, reinterpret_cast<aoclsparse_double_complex *>(v));
+}
+inline aoclsparse_status create_csr(aoclsparse_matrix *M, aoclsparse_index_base b, aoclsparse_int m, aoclsparse_int n,
+                                    aoclsparse_int nnz, aoclsparse_int *p, aoclsparse_int *c, cfloat *v)
+{
+    return aoclsparse_create_ccsr(M, b, m, n, nnz, p, c, reinterpret_cast<aoclsparse_float_complex *>(v));
+}
+
 // A caller's vector made device-resident for the duration of one composite call.
 template <typename T>
 struct Vec
@@ -425,6 +436,20 @@ aoclsparse_status ilu_prepare(aoclsparse_matrix A)
 
 extern "C" {
 
+aoclsparse_status aoclsparse_cilu_smoother(aoclsparse_operation op, aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                           aoclsparse_float_complex **precond_csr_val, const aoclsparse_float_complex *approx_inv_diag, aoclsparse_float_complex *x, const aoclsparse_float_complex *b)
+{
+    (void)approx_inv_diag; // unused by the reference as well
+    return ilu_smoother_t<cfloat>(op, A, descr, reinterpret_cast<cfloat **>(precond_csr_val), reinterpret_cast<cfloat *>(x),
+                                 reinterpret_cast<const cfloat *>(b), aoclsparse_cmat);
+}
+aoclsparse_status aoclsparse_zilu_smoother(aoclsparse_operation op, aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                           aoclsparse_double_complex **precond_csr_val, const aoclsparse_double_complex *approx_inv_diag, aoclsparse_double_complex *x, const aoclsparse_double_complex *b)
+{
+    (void)approx_inv_diag; // unused by the reference as well
+    return ilu_smoother_t<cdouble>(op, A, descr, reinterpret_cast<cdouble **>(precond_csr_val), reinterpret_cast<cdouble *>(x),
+                                 reinterpret_cast<const cdouble *>(b), aoclsparse_zmat);
+}
 aoclsparse_status aoclsparse_csymgs(aoclsparse_operation trans, aoclsparse_matrix A, const aoclsparse_mat_descr descr,
                                     const aoclsparse_float_complex alpha, const aoclsparse_float_complex *b, aoclsparse_float_complex *x)
 {

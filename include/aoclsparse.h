@@ -795,6 +795,16 @@ DLL_PUBLIC aoclsparse_status aoclsparse_dilu_smoother(aoclsparse_operation op, a
                                                       const aoclsparse_mat_descr descr,
                                                       double **precond_csr_val, const double *approx_inv_diag,
                                                       double *x, const double *b);
+DLL_PUBLIC aoclsparse_status aoclsparse_cilu_smoother(aoclsparse_operation op, aoclsparse_matrix A,
+                                                      const aoclsparse_mat_descr descr,
+                                                      aoclsparse_float_complex **precond_csr_val,
+                                                      const aoclsparse_float_complex *approx_inv_diag,
+                                                      aoclsparse_float_complex *x, const aoclsparse_float_complex *b);
+DLL_PUBLIC aoclsparse_status aoclsparse_zilu_smoother(aoclsparse_operation op, aoclsparse_matrix A,
+                                                      const aoclsparse_mat_descr descr,
+                                                      aoclsparse_double_complex **precond_csr_val,
+                                                      const aoclsparse_double_complex *approx_inv_diag,
+                                                      aoclsparse_double_complex *x, const aoclsparse_double_complex *b);
 
 /* ---- iterative solvers (aoclsparse_solvers.h:104-560): CG and restarted GMRES, options by name
  * ("iterative method", "cg iteration limit", "cg rel tolerance", "cg abs tolerance", "cg preconditioner",

@@ -2037,6 +2037,50 @@ def test_complex_symgs(prec):
     L.aoclsparse_destroy(ctypes.byref(h))
 
 
+@pytest.mark.parametrize("prec", ["z", "c"])
+def test_complex_ilu_smoother(prec):
+    """aoclsparse_{c,z}ilu_smoother: ILU(0) on the pattern (ilu0.hpp:34-111, IKJ) restated with numpy complex arithmetic,
+    then L y = b (unit lower), U x = y; factors through *precond_csr_val and x within 64 eps of the restatement."""
+    dtype, eps = (np.complex128, EPS64) if prec == "z" else (np.complex64, EPS32)
+    fn = lambda stem: getattr(L, "aoclsparse_" + stem.replace("?", prec))
+    n = 400
+    dense, rp, ci, v = _cplx_tri_system(91, n, dtype, 0)
+    h = ctypes.c_void_p()
+    assert fn("create_?csr")(ctypes.byref(h), 0, n, n, len(v), P._ptr(rp), P._ptr(ci), P._ptr(v)) == 0
+    # restated factorisation on the pattern
+    lu = v.astype(np.complex128).copy()
+    pos = [dict((int(ci[p]), p) for p in range(rp[i], rp[i + 1])) for i in range(n)]
+    for i in range(n):
+        for p in range(rp[i], rp[i + 1]):
+            k = int(ci[p])
+            if k >= i:
+                break
+            lu[p] = lu[p] / lu[pos[k][k]]
+            for q in range(pos[k][k] + 1, rp[k + 1]):
+                w = pos[i].get(int(ci[q]))
+                if w is not None:
+                    lu[w] -= lu[p] * lu[q]
+    Lm, Um = np.eye(n, dtype=np.complex128), np.zeros((n, n), np.complex128)
+    for i in range(n):
+        for p in range(rp[i], rp[i + 1]):
+            (Lm if ci[p] < i else Um)[i, ci[p]] = lu[p]
+    rng = np.random.default_rng(3)
+    b = (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(dtype)
+    xr = np.linalg.solve(Um, np.linalg.solve(Lm, b.astype(np.complex128)))
+    d = P.Descr()
+    assert L.aoclsparse_set_lu_smoother_hint(h, P.OP_NONE, d.h, 1) == 0 and L.aoclsparse_optimize(h) == 0
+    x, pv = np.zeros(n, dtype), ctypes.c_void_p()
+    assert fn("?ilu_smoother")(P.OP_NONE, h, d.h, ctypes.byref(pv), None, P._ptr(x), P._ptr(b)) == 0
+    got = np.ctypeslib.as_array(ctypes.cast(pv, ctypes.POINTER(ctypes.c_float if prec == "c" else ctypes.c_double)), (2 * len(v),)).view(dtype)
+    assert np.max(np.abs(got - lu)) <= 64 * eps * np.max(np.abs(lu))
+    assert np.max(np.abs(x - xr)) <= 256 * eps * np.max(np.abs(xr))
+    x2 = dev(np.zeros(n, dtype))
+    assert fn("?ilu_smoother")(P.OP_NONE, h, d.h, ctypes.byref(pv), None, P._ptr(x2), P._ptr(dev(b))) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(x2.cpu().numpy(), x)
+    L.aoclsparse_destroy(ctypes.byref(h))
+
+
 def test_complex_trsv_reference_h5_round_trip():
     """trsv_tests.cpp:313-318 / common_data_utils.h:4349-4470: the 5x5 lower-stored complex matrix, xref = 1..5,
     b = op(T) xref built by the test itself, x = solve -> xref.  All six (fill, op) cases; with fill = upper the same
