@@ -1403,6 +1403,93 @@ def test_sell_not_chosen_for_power_law_rows():
 
 
 # --------------------------------------------------------------------------------------------------
+# randomised sweep: many small shapes through every general-N SpMV route, TRSV and csrmm
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_randomised_shapes_spmv_trsv_csrmm(seed):
+    """shapes no hand-written case targets: m not a multiple of 64 / 4, empty matrices' neighbours (1 row, 1 column),
+    rows of 0..200 entries, both bases, hinted / un-hinted / promoted handles, raw arrays, kid pins, alpha / beta specials.
+    SpMV and TRSV bit-exact against the oracle, csrmm bit-exact against the column-major oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    base = int(rng.integers(0, 2))
+    m = int(rng.choice([1, 2, 3, 63, 64, 65, 127, 200, 257, 1000, 2049, 4097]))
+    n = int(rng.choice([1, 2, 5, 64, 130, 999, 3000])) if seed % 3 else m
+    dens = rng.choice([0, 1, 3, 12, 40, 200])
+    rp, ci, v = random_csr(seed, m, n, lambda r, i: 0 if dens == 0 else min(n, int(r.integers(0, 2 * dens + 1))), base=base)
+    nnz = len(v)
+    if nnz == 0:
+        ci, v = np.zeros(1, np.int32) + base, np.zeros(1)
+    x, y0 = rng.uniform(-1, 1, n), rng.uniform(-1, 1, m)
+    d = P.Descr(base=base)
+    for alpha, beta in ((1.0, 0.0), (0.0, 1.0), (-1.5, 0.25), (1.0, 1.0)):
+        y0b = np.full(m, np.nan) if beta == 0.0 else y0
+        for kid in (-1, 0, 1, 3):
+            so, yr = oracle.dcsrmv(kid, base, alpha, m, nnz, v, ci, rp, x, beta, y0b)
+            # handle with hint (SELL when the padding allows), pinned kid where given
+            A = P.Matrix(base, m, n, rp, ci, v) if nnz else None
+            if A is not None:
+                if kid < 0:
+                    assert L.aoclsparse_set_mv_hint(A.h, P.OP_NONE, d.h, 10) == 0
+                else:
+                    assert L.aoclsparse_set_mv_hint_kid(A.h, P.OP_NONE, d.h, 10, kid) == 0
+                assert L.aoclsparse_optimize(A.h) == 0
+                st, y = run_dmv(A, d, x, y0b, alpha, beta)
+                lens = np.diff(rp)
+                exact = kid >= 0 or lens.max(initial=0) <= A.spmv_info().tile or A.spmv_info().kernel == 3
+                assert st == 0
+                if exact:
+                    assert np.array_equal(y, yr, equal_nan=True), (kid, alpha, beta)
+                else:
+                    assert np.allclose(y, yr, rtol=0, atol=1e-12)
+            if kid < 0:
+                # raw arrays (host pointers) and an un-hinted handle multiplied past its promotion
+                yh = y0b.copy()
+                st = P.dcsrmv(P.OP_NONE, alpha, m, n, nnz, v, ci, rp, d, x, beta, yh)
+                assert st == 0
+                if nnz and np.diff(rp).max(initial=0) <= 512:
+                    assert np.array_equal(yh, yr, equal_nan=True)
+                if nnz:
+                    Bu = P.Matrix(base, m, n, rp, ci, v)
+                    for _ in range(9):
+                        st, y = run_dmv(Bu, d, x, y0b, alpha, beta)
+                    assert st == 0 and (np.array_equal(y, yr, equal_nan=True) or np.diff(rp).max() > 512)
+    # csrmm against the column-major oracle, both layouts, a few widths
+    if nnz:
+        A = P.Matrix(base, m, n, rp, ci, v)
+        for ncol in (1, 7, 32, 130):
+            ldb, ldc = n + int(rng.integers(0, 3)), m + int(rng.integers(0, 3))
+            Bc, C0 = rng.uniform(-1, 1, ldb * ncol), rng.uniform(-1, 1, ldc * ncol)
+            so, Cr = oracle.dcsrmm("col", -0.5, base, v, ci, rp, m, Bc, ncol, ldb, 2.0, C0, ldc)
+            Cd = dev(C0)
+            assert P.dcsrmm(P.OP_NONE, -0.5, A, d, P.ORDER_COLUMN, dev(Bc), ncol, ldb, 2.0, Cd, ldc) == 0
+            torch.cuda.synchronize()
+            assert np.array_equal(Cd.cpu().numpy(), Cr), ("col", ncol)
+            ldb2, ldc2 = ncol + int(rng.integers(0, 3)), ncol + int(rng.integers(0, 3))
+            Br = np.zeros((n, ldb2)); Br[:, :ncol] = Bc.reshape(ncol, ldb)[:, :n].T
+            Cr0 = np.full((m, ldc2), 7.25); Cr0[:, :ncol] = C0.reshape(ncol, ldc)[:, :m].T
+            Cd = dev(Cr0.ravel())
+            assert P.dcsrmm(P.OP_NONE, -0.5, A, d, P.ORDER_ROW, dev(Br.ravel()), ncol, ldb2, 2.0, Cd, ldc2) == 0
+            torch.cuda.synchronize()
+            got = Cd.cpu().numpy().reshape(m, ldc2)
+            assert np.array_equal(got[:, :ncol], Cr.reshape(ncol, ldc)[:, :m].T) and np.all(got[:, ncol:] == 7.25), ("row", ncol)
+    # TRSV on a square system of the same size class
+    if m >= 2:
+        trp, tci, tv = triangular_system(seed, m, int(rng.integers(1, 6)), base=base)
+        T = P.Matrix(base, m, m, trp, tci, tv)
+        b = rng.uniform(-1, 1, m)
+        o = oracle.dcsr_optimize(m, m, len(tv), base, trp, tci, tv)
+        for fill, kind, ends in ((P.FILL_LOWER, "l", "idiag"), (P.FILL_UPPER, "u", "iurow")):
+            for unit in (False, True):
+                dt = P.Descr(base=base, mtype=P.TYPE_TRIANGULAR, fill=fill, diag=P.DIAG_UNIT if unit else P.DIAG_NON_UNIT)
+                so, xr = oracle.dtrsv(kind, 0.75, m, o["base"], o["val"], o["ind"], o["ptr"], o[ends], b, unit)
+                for kid in (-1, 0, 1, 3):
+                    xd = dev(np.zeros(m))
+                    assert P.dtrsv(P.OP_NONE, 0.75, T, dt, dev(b), xd, kid=kid) == 0
+                    torch.cuda.synchronize()
+                    assert np.array_equal(xd.cpu().numpy(), xr[:m]), (kind, unit, kid)
+
+
+# --------------------------------------------------------------------------------------------------
 # iterative solvers (SURVEY 8f rank 3)
 # --------------------------------------------------------------------------------------------------
 
