@@ -1489,6 +1489,68 @@ def test_randomised_shapes_spmv_trsv_csrmm(seed):
                     assert np.array_equal(xd.cpu().numpy(), xr[:m]), (kind, unit, kid)
 
 
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_randomised_shapes_transposes_float_sp2m_trsm(seed):
+    """second sweep: transposed / strided TRSV and trsm (bit-exact), float SpMV in its 8-lane order (bit-exact), transposed
+    and symmetric dmv (forward-error bound), sp2m on rectangular shapes down to one row (structure and values bit-exact)."""
+    rng = np.random.default_rng(2000 + seed)
+    base = seed % 2
+    m = int(rng.choice([1, 3, 64, 65, 300, 1025, 3000]))
+    n = int(rng.choice([1, 4, 70, 500, 2500]))
+    rp, ci, v = random_csr(100 + seed, m, n, lambda r, i: min(n, int(r.integers(0, 25))), base=base)
+    nnz, d = len(v), P.Descr(base=base)
+    if nnz:
+        # float, general N: the reference's 8-lane order
+        vf = v.astype(np.float32)
+        xf, yf0 = rng.uniform(-1, 1, n).astype(np.float32), rng.uniform(-1, 1, m).astype(np.float32)
+        Af = P.Matrix(base, m, n, rp, ci, vf)
+        so, yr = oracle.scsrmv("lane8", base, 0.5, m, vf, ci, rp, xf, -1.0, yf0)
+        yd = dev(yf0)
+        assert P.smv(P.OP_NONE, 0.5, Af, d, dev(xf), -1.0, yd) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(yd.cpu().numpy(), yr)
+        # double, transposed: bound against a dense product
+        A = P.Matrix(base, m, n, rp, ci, v)
+        D = _dense(m, n, rp, ci, v, base)
+        xt, yt0 = rng.uniform(-1, 1, m), rng.uniform(-1, 1, n)
+        st, yt = run_dmv(A, d, xt, yt0, 1.25, -0.5, op=P.OP_TRANSPOSE)
+        scale = 1.25 * (np.abs(D).T @ np.abs(xt)) + 0.5 * np.abs(yt0)
+        assert st == 0 and np.all(np.abs(yt - (1.25 * D.T @ xt - 0.5 * yt0)) <= (np.count_nonzero(D, axis=0) + 6) * EPS64 * scale + 1e-300)
+        # sp2m: A * B with B = n x k
+        k = int(rng.choice([1, 9, 400]))
+        pb, ib, vb = random_csr(300 + seed, n, k, lambda r, i: min(k, int(r.integers(0, 12))), base=1 - base)
+        if len(vb):
+            Bm = P.Matrix(1 - base, n, k, pb, ib, vb)
+            C = ctypes.c_void_p()
+            assert L.aoclsparse_sp2m(P.OP_NONE, d.h, A.h, P.OP_NONE, P.Descr(base=1 - base).h, Bm.h, P.STAGE_FULL, ctypes.byref(C)) == 0
+            _, cm, cn, cz, row, col, val = _export(C)
+            so, pc, ic, vc = oracle.dcsr2m(m, k, base, rp, ci, v, 1 - base, pb, ib, vb)
+            assert (cm, cn) == (m, k) and np.array_equal(row, pc) and np.array_equal(col, ic) and np.array_equal(val, vc)
+            L.aoclsparse_destroy(ctypes.byref(C))
+    # triangular solves: transposed, strided, and several right-hand sides
+    mt = int(rng.choice([2, 63, 130, 1500]))
+    trp, tci, tv = triangular_system(500 + seed, mt, int(rng.integers(1, 5)), base=base)
+    T = P.Matrix(base, mt, mt, trp, tci, tv)
+    b = rng.uniform(-1, 1, mt)
+    for fill in ("lower", "upper"):
+        for unit in (False, True):
+            dt = P.Descr(base=base, mtype=P.TYPE_TRIANGULAR, fill=P.FILL_LOWER if fill == "lower" else P.FILL_UPPER,
+                         diag=P.DIAG_UNIT if unit else P.DIAG_NON_UNIT)
+            xr = oracle_trsv(base, mt, trp, tci, tv, fill, "t", unit, -0.6, b)
+            for kid in (None, 0, 3):
+                x = np.zeros(mt)
+                assert P.dtrsv(P.OP_TRANSPOSE, -0.6, T, dt, b, x, kid=kid) == 0 and np.array_equal(x, xr[:mt])
+            bs, xs = np.zeros(2 * mt), np.full(3 * mt, 5.5)
+            bs[::2] = b
+            assert P.dtrsv(P.OP_TRANSPOSE, -0.6, T, dt, bs, xs, incb=2, incx=3) == 0
+            assert np.array_equal(xs[::3], xr[:mt]) and np.all(xs[1::3] == 5.5) and np.all(xs[2::3] == 5.5)
+            nr = int(rng.choice([1, 2, 9]))
+            Bm, Xm = rng.uniform(-1, 1, (mt, nr)), np.zeros((mt, nr))
+            assert L.aoclsparse_dtrsm(P.OP_NONE, 2.0, T.h, dt.h, P.ORDER_ROW, P._ptr(Bm), nr, nr, P._ptr(Xm), nr) == 0
+            for j in range(nr):
+                assert np.array_equal(Xm[:, j], oracle_trsv(base, mt, trp, tci, tv, fill, "n", unit, 2.0, Bm[:, j].copy())[:mt])
+
+
 # --------------------------------------------------------------------------------------------------
 # iterative solvers (SURVEY 8f rank 3)
 # --------------------------------------------------------------------------------------------------
