@@ -218,6 +218,116 @@ __global__ __launch_bounds__(64 * WAVES) void k5p(int m, const double *__restric
     }
 }
 
+// ks: a workgroup of 4 wavefronts owns R consecutive rows of one 128-column chunk.  The distinct B rows its rows touch
+// (<= UCAP) are loaded ONCE into LDS, each by one wavefront, and every row then takes its pieces from LDS: the
+// L2 -> CU traffic per row drops from len to (distinct rows)/R pieces.  Generic: the distinct set is found on the
+// fly (one wavefront, one column per lane, 64 rounds of readlane + ballot); rows longer than ML entries or a set larger
+// than UCAP make the workgroup fall back to direct loads.
+template <int R, int ML, int UCAP>
+__global__ __launch_bounds__(256) void ks(int m, const double *__restrict__ val, const int *__restrict__ col,
+                                          const int *__restrict__ row_ptr, const double *__restrict__ B, int n, double beta,
+                                          double *__restrict__ C, bool readc, int chunk)
+{
+    static_assert(R * ML <= 64, "one lane per (row, entry)");
+    __shared__ v2d tile[UCAP][64];
+    __shared__ int s_slot[R * ML];
+    __shared__ int s_ucol[UCAP];
+    __shared__ int s_nu;
+    const int w    = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int i0   = xcd_row(blockIdx.x, chunk) * R;
+    const int j    = 2 * lane + 128 * (int)blockIdx.y;
+    if(i0 >= m)
+        return;
+    const double *Bj = B + j;
+    // wave 0: one lane per (row, entry)
+    if(w == 0)
+    {
+        const int rr = lane / ML, kk = lane % ML, i = i0 + rr;
+        int       c  = -1;
+        bool      too_long = false;
+        if(i < m && rr < R)
+        {
+            const int s = row_ptr[i], e = row_ptr[i + 1];
+            if(kk < e - s)
+                c = col[s + kk];
+            too_long = e - s > ML;
+        }
+        const bool any_long = __ballot(too_long) != 0ull;
+        int        owner    = lane;
+        for(int u = 0; u < 64; u++)
+        {
+            const int cu = __builtin_amdgcn_readlane(c, u);
+            if(cu >= 0 && c == cu && owner == lane && lane > u)
+                owner = u;
+        }
+        const unsigned long long uniq = __ballot(c >= 0 && owner == lane);
+        const int                nu   = __popcll(uniq);
+        const int                myslot = __popcll(uniq & ((1ull << lane) - 1ull));
+        if(c >= 0 && owner == lane && myslot < UCAP)
+            s_ucol[myslot] = c;
+        // slot of my owner
+        const int oslot = __shfl(myslot, owner);
+        if(lane < R * ML)
+            s_slot[lane] = c >= 0 ? oslot : -1;
+        if(lane == 0)
+            s_nu = (any_long || nu > UCAP) ? -1 : nu;
+    }
+    __syncthreads();
+    const int nu = s_nu;
+    if(nu >= 0)
+    {
+        for(int u = w; u < nu; u += 4)
+            tile[u][lane] = *reinterpret_cast<const v2d *>(Bj + (size_t)s_ucol[u] * n);
+        __syncthreads();
+        for(int rr = w; rr < R; rr += 4)
+        {
+            const int i = i0 + rr;
+            if(i >= m)
+                break;
+            const int s = row_ptr[i], e = row_ptr[i + 1];
+            v2d       a = {0, 0};
+            for(int p = s; p < e; p++)
+            {
+                const double v0 = val[p];
+                const v2d    b0 = tile[s_slot[rr * ML + (p - s)]][lane];
+                a.x = fma(v0, b0.x, a.x), a.y = fma(v0, b0.y, a.y);
+            }
+            v2d *cp = reinterpret_cast<v2d *>(C + (size_t)i * n + j);
+            if(readc)
+            {
+                const v2d c = *cp;
+                a.x = fma(beta, c.x, a.x), a.y = fma(beta, c.y, a.y);
+            }
+            *cp = a;
+        }
+    }
+    else
+    {
+        for(int rr = w; rr < R; rr += 4)
+        {
+            const int i = i0 + rr;
+            if(i >= m)
+                break;
+            const int s = row_ptr[i], e = row_ptr[i + 1];
+            v2d       a = {0, 0};
+            for(int p = s; p < e; p++)
+            {
+                const double v0 = val[p];
+                const v2d    b0 = *reinterpret_cast<const v2d *>(Bj + (size_t)col[p] * n);
+                a.x = fma(v0, b0.x, a.x), a.y = fma(v0, b0.y, a.y);
+            }
+            v2d *cp = reinterpret_cast<v2d *>(C + (size_t)i * n + j);
+            if(readc)
+            {
+                const v2d c = *cp;
+                a.x = fma(beta, c.x, a.x), a.y = fma(beta, c.y, a.y);
+            }
+            *cp = a;
+        }
+    }
+}
+
 __global__ void kdiff(size_t n, const double *a, const double *b, unsigned long long *cnt)
 {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -260,8 +370,8 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     constexpr int NV = 10;
-    const char *names[NV] = {"k0 shipped shape", "kr RW=4  4 waves (generic)", "k5p RW=2 4 waves", "k5p RW=4 4 waves", "k5p RW=8 4 waves",
-                             "k5p RW=16 4 waves", "k5p RW=32 4 waves", "k5p RW=8 2 waves", "k5p RW=16 1 wave", "k5p RW=64 4 waves"};
+    const char *names[NV] = {"k0 shipped shape", "ks R=4 ML=8 U=16 (LDS)", "k5p RW=2 4 waves", "ks R=8 ML=8 U=32 (LDS)", "ks R=8 ML=8 U=28 (LDS)",
+                             "ks R=12 ML=5 U=40", "ks R=4 ML=16 U=16", "k5p RW=8 2 waves", "k5p RW=16 1 wave", "k5p RW=64 4 waves"};
     for(int pass = 0; pass < 2; pass++)
     {
         const bool   readc = pass == 1;
@@ -284,12 +394,12 @@ int main(int argc, char **argv)
                 switch(q)
                 {
                 case 0: gr = launch(4), ch = gr.x / 8; k0<<<gr, 256>>>(ARGS); break;
-                case 1: gr = launch(16), ch = gr.x / 8; kr<4, 8, 4><<<gr, 256>>>(ARGS); break;
+                case 1: gr = launch(4), ch = gr.x / 8; ks<4, 8, 16><<<gr, 256>>>(ARGS); break;
                 case 2: gr = launch(8), ch = gr.x / 8; k5p<2, 4><<<gr, 256>>>(ARGS); break;
-                case 3: gr = launch(16), ch = gr.x / 8; k5p<4, 4><<<gr, 256>>>(ARGS); break;
-                case 4: gr = launch(32), ch = gr.x / 8; k5p<8, 4><<<gr, 256>>>(ARGS); break;
-                case 5: gr = launch(64), ch = gr.x / 8; k5p<16, 4><<<gr, 256>>>(ARGS); break;
-                case 6: gr = launch(128), ch = gr.x / 8; k5p<32, 4><<<gr, 256>>>(ARGS); break;
+                case 3: gr = launch(8), ch = gr.x / 8; ks<8, 8, 32><<<gr, 256>>>(ARGS); break;
+                case 4: gr = launch(8), ch = gr.x / 8; ks<8, 8, 28><<<gr, 256>>>(ARGS); break;
+                case 5: gr = launch(12), ch = gr.x / 8; ks<12, 5, 40><<<gr, 256>>>(ARGS); break;
+                case 6: gr = launch(4), ch = gr.x / 8; ks<4, 16, 16><<<gr, 256>>>(ARGS); break;
                 case 7: gr = launch(16), ch = gr.x / 8; k5p<8, 2><<<gr, 128>>>(ARGS); break;
                 case 8: gr = launch(16), ch = gr.x / 8; k5p<16, 1><<<gr, 64>>>(ARGS); break;
                 default: gr = launch(256), ch = gr.x / 8; k5p<64, 4><<<gr, 256>>>(ARGS); break;
