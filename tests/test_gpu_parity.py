@@ -1403,6 +1403,26 @@ def test_sell_not_chosen_for_power_law_rows():
 
 
 # --------------------------------------------------------------------------------------------------
+# the reference's own example programs, compiled unchanged against this library (oracle/Makefile: samples)
+# --------------------------------------------------------------------------------------------------
+def test_reference_samples_run_unchanged():
+    """tests/examples/sample_*.c(pp) of the reference (spmv, csrmm, dotmv, symgs(_mv), trsm, trsv, CG / GMRES direct and RCI
+    in both precisions, csr2m, complex sp2m and symgs) are built where the reference tree exists and travel as binaries;
+    each checks its own result and must exit 0.  Skipped when they were not built."""
+    import glob
+    import subprocess
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bins = sorted(glob.glob(os.path.join(here, "oracle", "_ref", "samples", "sample_*")))
+    if not bins:
+        pytest.skip("oracle/_ref/samples not built (no reference tree at build time)")
+    for b in bins:
+        r = subprocess.run([b], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, (os.path.basename(b), r.stdout[-400:], r.stderr[-400:])
+    out = subprocess.run([os.path.join(here, "oracle", "_ref", "samples", "sample_spmv_c")], capture_output=True, text=True).stdout
+    assert "69.000000" in out and "40.000000" in out  # y of the sample's 5x5 product
+
+
+# --------------------------------------------------------------------------------------------------
 # randomised sweep: many small shapes through every general-N SpMV route, TRSV and csrmm
 # --------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("seed", list(range(24)))
