@@ -141,6 +141,10 @@ SIGNATURES = {
     "aoclsparse_zsymgs_kid": (c_int, [c_int, _P, _P, CDouble, _P, _P, _I]),
     "aoclsparse_zsymgs_mv": (c_int, [c_int, _P, _P, CDouble, _P, _P, _P]),
     "aoclsparse_zsymgs_mv_kid": (c_int, [c_int, _P, _P, CDouble, _P, _P, _P, _I]),
+    "aoclsparse_mi355_strsv_full": (c_int, [c_int, c_float, _P, _P, _P, _I, _P, _I, _I]),
+    "aoclsparse_mi355_dtrsv_full": (c_int, [c_int, c_double, _P, _P, _P, _I, _P, _I, _I]),
+    "aoclsparse_mi355_ctrsv_full": (c_int, [c_int, CFloat, _P, _P, _P, _I, _P, _I, _I]),
+    "aoclsparse_mi355_ztrsv_full": (c_int, [c_int, CDouble, _P, _P, _P, _I, _P, _I, _I]),
     "aoclsparse_cmv": (c_int, [c_int, _P, _P, _P, _P, _P, _P]),
     "aoclsparse_zmv": (c_int, [c_int, _P, _P, _P, _P, _P, _P]),
     "aoclsparse_create_scsc": (c_int, [POINTER(_P), c_int, _I, _I, _I, _P, _P, _P]),

@@ -630,6 +630,35 @@ aoclsparse_status aoclsparse_ztrsm_kid(const aoclsparse_operation trans, const a
                          reinterpret_cast<cdouble *>(X), ldx, kid, aoclsparse_zmat);
 }
 
+aoclsparse_status aoclsparse_mi355_strsv_full(aoclsparse_operation trans, float alpha, aoclsparse_matrix A,
+                                              const aoclsparse_mat_descr descr, const float *b, aoclsparse_int incb,
+                                              float *x, aoclsparse_int incx, aoclsparse_int kid)
+{
+    return trsv_t<float>(trans, alpha, A, descr, b, incb, x, incx, kid, aoclsparse_smat);
+}
+aoclsparse_status aoclsparse_mi355_dtrsv_full(aoclsparse_operation trans, double alpha, aoclsparse_matrix A,
+                                              const aoclsparse_mat_descr descr, const double *b, aoclsparse_int incb,
+                                              double *x, aoclsparse_int incx, aoclsparse_int kid)
+{
+    return trsv_t<double>(trans, alpha, A, descr, b, incb, x, incx, kid, aoclsparse_dmat);
+}
+aoclsparse_status aoclsparse_mi355_ctrsv_full(aoclsparse_operation trans, aoclsparse_float_complex alpha,
+                                              aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                              const aoclsparse_float_complex *b, aoclsparse_int incb,
+                                              aoclsparse_float_complex *x, aoclsparse_int incx, aoclsparse_int kid)
+{
+    return trsv_t<cfloat>(trans, cfloat(alpha.real, alpha.imag), A, descr, reinterpret_cast<const cfloat *>(b), incb,
+                          reinterpret_cast<cfloat *>(x), incx, kid, aoclsparse_cmat);
+}
+aoclsparse_status aoclsparse_mi355_ztrsv_full(aoclsparse_operation trans, aoclsparse_double_complex alpha,
+                                              aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                              const aoclsparse_double_complex *b, aoclsparse_int incb,
+                                              aoclsparse_double_complex *x, aoclsparse_int incx, aoclsparse_int kid)
+{
+    return trsv_t<cdouble>(trans, cdouble(alpha.real, alpha.imag), A, descr, reinterpret_cast<const cdouble *>(b), incb,
+                           reinterpret_cast<cdouble *>(x), incx, kid, aoclsparse_zmat);
+}
+
 aoclsparse_status aoclsparse_mi355_get_trsv_levels(const aoclsparse_matrix A, aoclsparse_fill_mode fill,
                                                    aoclsparse_operation op, aoclsparse_int *levels)
 {

@@ -68,6 +68,27 @@ DLL_PUBLIC aoclsparse_status aoclsparse_mi355_get_trsv_levels(const aoclsparse_m
 /* drop every device-side copy/plan of the handle (call after mutating the aliased arrays) */
 DLL_PUBLIC aoclsparse_status aoclsparse_mi355_invalidate(aoclsparse_matrix A);
 
+/* trsv with strides AND a kernel id in one call: what the reference offers only through its C++ template
+ * aoclsparse::trsv<T> (library/include/aoclsparse.hpp); include/aoclsparse.hpp forwards to these. */
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_strsv_full(aoclsparse_operation trans, float alpha, aoclsparse_matrix A,
+                                                         const aoclsparse_mat_descr descr, const float *b,
+                                                         aoclsparse_int incb, float *x, aoclsparse_int incx,
+                                                         aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_dtrsv_full(aoclsparse_operation trans, double alpha, aoclsparse_matrix A,
+                                                         const aoclsparse_mat_descr descr, const double *b,
+                                                         aoclsparse_int incb, double *x, aoclsparse_int incx,
+                                                         aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_ctrsv_full(aoclsparse_operation trans, aoclsparse_float_complex alpha,
+                                                         aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                                         const aoclsparse_float_complex *b, aoclsparse_int incb,
+                                                         aoclsparse_float_complex *x, aoclsparse_int incx,
+                                                         aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_ztrsv_full(aoclsparse_operation trans, aoclsparse_double_complex alpha,
+                                                         aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                                         const aoclsparse_double_complex *b, aoclsparse_int incb,
+                                                         aoclsparse_double_complex *x, aoclsparse_int incx,
+                                                         aoclsparse_int kid);
+
 /* ---- thin HIP C-ABI: device pointers, explicit stream ---------------------------------- */
 /* Row-block table for mi355_?csrmv, built on the HOST from a host row_ptr: nblocks+1 entries
  * {first row, first non-zero (0-based)}, i.e. 2*(nblocks+1) ints; blocks_host must hold

@@ -1407,7 +1407,7 @@ def test_sell_not_chosen_for_power_law_rows():
 # --------------------------------------------------------------------------------------------------
 def test_reference_samples_run_unchanged():
     """tests/examples/sample_*.c(pp) of the reference (spmv, csrmm, dotmv, symgs(_mv), trsm, trsv, CG / GMRES direct and RCI
-    in both precisions, csr2m, complex sp2m and symgs) are built where the reference tree exists and travel as binaries;
+    in both precisions, csr2m, complex sp2m and symgs, and the three C++-interface samples through include/aoclsparse.hpp) are built where the reference tree exists and travel as binaries;
     each checks its own result and must exit 0.  Skipped when they were not built."""
     import glob
     import subprocess
