@@ -1,13 +1,13 @@
 // blk_kernels.hip -- SpMV on the reference's BLKCSR storage (1/2/4 x 8 blocks + one bit mask per sub-row).
 //
 // The CPU kernels (level2/aoclsparse_blkcsrmv_avx512.cpp:40-369) walk the packed value array with a running
-// popcount.  Here the running count becomes data: blk_valoff_kernel turns the masks into the value offset of
-// every block (popcount + exclusive scan, two small launches), after which the blocks of a row are independent
-// loads.  blk_mv_kernel gives every matrix row a group of 8 lanes = the 8 lanes of the reference's zmm
+// popcount.  Here the running count becomes data: three small launches (per-chunk popcount scan, scan of the chunk
+// totals, add) turn the masks into the absolute value offset of every block, after which the blocks of a row are
+// independent loads.  blk_mv_kernel gives every matrix row a group of 8 lanes = the 8 lanes of the reference's zmm
 // accumulator: lane l owns column (window start + l), multiplies its value (or 0 where the mask has no bit,
 // as the expand-load does) with x and chains the FMAs block after block; the group then reduces lo4+hi4,
 // pairs, pairs -- the reference's extract/hadd/add -- so the result is bit-identical to the AVX-512 kernel.
-// Bound: HBM, 8 B/nnz values + (4 + rows_blk) B/block + the x windows.
+// Bound: HBM, 8 B/nnz values + (8 + rows_blk) B/block (column, value offset, masks) + the x windows.
 #include "internal.hpp"
 
 #include <hip/hip_runtime.h>
