@@ -188,6 +188,14 @@ SIGNATURES = {
     "aoclsparse_dcsr2ellthyb": (c_int, [_I, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _I]),
     "aoclsparse_itsol_handle_prn_options": (None, [_P]),
     "aoclsparse_itsol_option_set": (c_int, [_P, c_char_p, c_char_p]),
+    "aoclsparse_itsol_c_init": (c_int, [POINTER(_P)]),
+    "aoclsparse_itsol_c_rci_input": (c_int, [_P, _I, _P]),
+    "aoclsparse_itsol_c_rci_solve": (c_int, [_P, POINTER(c_int), POINTER(_P), POINTER(_P), _P, _P]),
+    "aoclsparse_itsol_c_solve": (c_int, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "aoclsparse_itsol_z_init": (c_int, [POINTER(_P)]),
+    "aoclsparse_itsol_z_rci_input": (c_int, [_P, _I, _P]),
+    "aoclsparse_itsol_z_rci_solve": (c_int, [_P, POINTER(c_int), POINTER(_P), POINTER(_P), _P, _P]),
+    "aoclsparse_itsol_z_solve": (c_int, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "aoclsparse_itsol_d_init": (c_int, [POINTER(_P)]),
     "aoclsparse_itsol_s_init": (c_int, [POINTER(_P)]),
     "aoclsparse_itsol_destroy": (None, [POINTER(_P)]),

@@ -250,14 +250,14 @@ __device__ __forceinline__ cplx<R> cdot_block_reduce(cplx<R> acc, cplx<R> *sh)
 }
 template <typename R>
 __global__ __launch_bounds__(256) void cdot_partial_kernel(const cplx<R> *__restrict__ x, const cplx<R> *__restrict__ y,
-                                                           aoclsparse_int n, cplx<R> *partial)
+                                                           aoclsparse_int n, cplx<R> *partial, bool conj_x)
 {
     __shared__ cplx<R> sh[4];
     cplx<R>            acc(R(0), R(0));
     for(long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
     {
         const cplx<R> a = x[i];
-        c_mac(acc, cplx<R>(a.re, -a.im), y[i]);
+        c_mac(acc, cplx<R>(a.re, conj_x ? -a.im : a.im), y[i]);
     }
     const cplx<R> r = cdot_block_reduce(acc, sh);
     if(threadIdx.x == 0)
@@ -283,6 +283,23 @@ __global__ void cdiff_kernel(aoclsparse_int n, const cplx<R> *x, const cplx<R> *
     const aoclsparse_int i = blockIdx.x * blockDim.x + threadIdx.x;
     if(i < n)
         w[i] = cplx<R>(x[i].re - y[i].re, x[i].im - y[i].im);
+}
+
+
+// w = a x + b y with complex scalars (the vector steps of the complex CG / GMRES; y may alias w, x may be null when a = 0)
+template <typename R>
+__global__ void caxpby_kernel(aoclsparse_int n, cplx<R> a, const cplx<R> *x, cplx<R> b, const cplx<R> *y, cplx<R> *w)
+{
+    const aoclsparse_int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n)
+    {
+        cplx<R> r(R(0), R(0));
+        if(x)
+            c_mac(r, a, x[i]);
+        if(y)
+            c_mac(r, b, y[i]);
+        w[i] = r;
+    }
 }
 
 } // namespace
@@ -420,17 +437,18 @@ template aoclsparse_status launch_ctrsv<double>(hipStream_t, bool, bool, cdouble
 
 template <typename R>
 aoclsparse_status launch_cdot(hipStream_t s, aoclsparse_int n, const cplx<R> *x, const cplx<R> *y, cplx<R> *partial,
-                              cplx<R> *d)
+                              cplx<R> *d, bool conj_x)
 {
     const int blocks = n <= 0 ? 1 : (int)std::min<long long>(CDOT_BLOCKS, ((long long)n + 255) / 256);
-    hipLaunchKernelGGL((cdot_partial_kernel<R>), dim3(blocks), dim3(256), 0, s, x, y, n, partial);
+    hipLaunchKernelGGL((cdot_partial_kernel<R>), dim3(blocks), dim3(256), 0, s, x, y, n, partial, conj_x);
     hipLaunchKernelGGL((cdot_final_kernel<R>), dim3(1), dim3(256), 0, s, partial, blocks, d);
     MI355_HIP_TRY(hipGetLastError());
     return aoclsparse_status_success;
 }
-template aoclsparse_status launch_cdot<float>(hipStream_t, aoclsparse_int, const cfloat *, const cfloat *, cfloat *, cfloat *);
+template aoclsparse_status launch_cdot<float>(hipStream_t, aoclsparse_int, const cfloat *, const cfloat *, cfloat *, cfloat *,
+                                              bool);
 template aoclsparse_status launch_cdot<double>(hipStream_t, aoclsparse_int, const cdouble *, const cdouble *, cdouble *,
-                                               cdouble *);
+                                               cdouble *, bool);
 
 template <typename R>
 aoclsparse_status launch_cdiff(hipStream_t s, aoclsparse_int n, const cplx<R> *x, const cplx<R> *y, cplx<R> *w)
@@ -442,6 +460,20 @@ aoclsparse_status launch_cdiff(hipStream_t s, aoclsparse_int n, const cplx<R> *x
 }
 template aoclsparse_status launch_cdiff<float>(hipStream_t, aoclsparse_int, const cfloat *, const cfloat *, cfloat *);
 template aoclsparse_status launch_cdiff<double>(hipStream_t, aoclsparse_int, const cdouble *, const cdouble *, cdouble *);
+
+template <typename R>
+aoclsparse_status launch_caxpby(hipStream_t s, aoclsparse_int n, cplx<R> a, const cplx<R> *x, cplx<R> b, const cplx<R> *y,
+                                cplx<R> *w)
+{
+    if(n > 0)
+        hipLaunchKernelGGL((caxpby_kernel<R>), dim3((n + 255) / 256), dim3(256), 0, s, n, a, x, b, y, w);
+    MI355_HIP_TRY(hipGetLastError());
+    return aoclsparse_status_success;
+}
+template aoclsparse_status launch_caxpby<float>(hipStream_t, aoclsparse_int, cfloat, const cfloat *, cfloat, const cfloat *,
+                                                cfloat *);
+template aoclsparse_status launch_caxpby<double>(hipStream_t, aoclsparse_int, cdouble, const cdouble *, cdouble,
+                                                 const cdouble *, cdouble *);
 
 template aoclsparse_status launch_cspmv<float>(hipStream_t, int, bool, cfloat, aoclsparse_int, aoclsparse_int,
                                                const cfloat *, const aoclsparse_int *, const aoclsparse_int *,

@@ -556,7 +556,10 @@ aoclsparse_status launch_cdiff(hipStream_t s, aoclsparse_int n, const cplx<R> *x
 // d = sum conj(x_i) y_i; partial holds 1024 elements
 template <typename R>
 aoclsparse_status launch_cdot(hipStream_t s, aoclsparse_int n, const cplx<R> *x, const cplx<R> *y, cplx<R> *partial,
-                              cplx<R> *d);
+                              cplx<R> *d, bool conj_x = true);
+template <typename R>
+aoclsparse_status launch_caxpby(hipStream_t s, aoclsparse_int n, cplx<R> a, const cplx<R> *x, cplx<R> b, const cplx<R> *y,
+                                cplx<R> *w);
 // spgemm (spgemm_kernels.hip): list entries per wavefront kept in LDS; rows whose upper bound exceeds it use a global slab
 template <typename T>
 constexpr int spgemm_lds_cap()

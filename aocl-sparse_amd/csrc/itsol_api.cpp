@@ -27,6 +27,7 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <complex>
 #include <string>
 #include <vector>
 
@@ -977,6 +978,651 @@ aoclsparse_status solve_direct(Solver<T> *S, aoclsparse_int n, aoclsparse_matrix
     return finish(exit_status);
 }
 
+// ==== complex handles (aoclsparse_itsol_{c,z}_*) ==========================================================
+// The same two state machines with complex vectors (itsol_functions.hpp is one template over T).  CG: the products
+// r.z and p.q are the UNCONJUGATED sums the reference forms (:786-812), i.e. the conjugate-orthogonal CG for complex
+// SYMMETRIC matrices; norms and tolerances are real (tolerance_t<T>).  GMRES deviates on purpose: the reference stores
+// h(i,j) = sum conj(w_k) v_i[k] (the conjugate of the Hessenberg entry, :1090-1099), rotates with a complex sine WITHOUT
+// the conjugation a unitary rotation needs (:1140-1146) and updates x with conj(V) (:1255-1262), which cancels only
+// when the Krylov data are real multiples of one complex number -- as in its own sample (A = (1 + 0.1i) A_real with
+// ILU(0)); restated literally it diverges on a general complex matrix.  Here h(i,j) = v_i^H w, the rotation is
+// [c s; -conj(s) c] from ?lartg on (h(j,j), |w|) and x += sum y_i v_i, which reproduces the reference wherever it
+// converges.  Vector steps are the generic complex kernels of complex_kernels.hip, one reduction read back per
+// scalar: correctness path, not tuned.  Preconditioners: none, user, ILU(0) for GMRES; the built-in
+// SymGS of CG is not offered for complex handles (not_implemented).
+template <typename R>
+void clartg(std::complex<R> f, std::complex<R> g, R &c, std::complex<R> &s, std::complex<R> &r)
+{
+    // LAPACK 3.10 zlartg (la_lartg.f90), unscaled branch; operands outside [rtmin, rtmax] are scaled by their
+    // largest component first
+    using Cs = std::complex<R>;
+    if(g == Cs(0))
+    {
+        c = R(1), s = Cs(0), r = f;
+        return;
+    }
+    const R g1 = std::max(std::fabs(g.real()), std::fabs(g.imag()));
+    if(f == Cs(0))
+    {
+        const Cs gs = g / g1;
+        const R  d  = std::sqrt(std::norm(gs));
+        c = R(0), s = std::conj(gs) / d, r = Cs(d * g1);
+        return;
+    }
+    const R  f1 = std::max(std::fabs(f.real()), std::fabs(f.imag()));
+    const R  safmin = std::numeric_limits<R>::min(), safmax = R(1) / safmin;
+    const R  rtmin = std::sqrt(safmin), rtmax = std::sqrt(safmax / 4);
+    R        u = R(1);
+    Cs       fs = f, gs = g;
+    if(!(f1 > rtmin && f1 < rtmax && g1 > rtmin && g1 < rtmax))
+    {
+        u  = std::min(safmax, std::max(safmin, std::max(f1, g1)));
+        fs = f / u, gs = g / u;
+    }
+    const R f2 = std::norm(fs), g2 = std::norm(gs), h2 = f2 + g2;
+    c          = std::sqrt(f2 / h2);
+    r          = (fs / c) * u;
+    s          = std::conj(gs) * (fs * (R(1) / std::sqrt(f2 * h2)));
+}
+
+template <typename R>
+struct CSolver
+{
+    using C  = cplx<R>;
+    using Cs = std::complex<R>;
+    aoclsparse_int n = 0;
+    bool           have_b = false, pinned = false, solving = false, x_dirty = false;
+    int            method = solver_cg, task = task_start, precond = 0;
+    Options        opts;
+    VBuf           b, xshadow, red_partial, red_out, r, z, p, q, v, zz;
+    Cs             alpha = 0, rz = 0, beta = 0;
+    R              rnorm2 = 0, bnorm2 = 0, brtol = 0, rtol = 0, atol = 0;
+    aoclsparse_int niter = 0, maxit = 0, j = 0, restart = 0;
+    std::vector<Cs> h, g, s;
+    std::vector<R>  c;
+
+    static C dev(Cs v)
+    {
+        return C(v.real(), v.imag());
+    }
+    void free_solver_data()
+    {
+        r.release(), z.release(), p.release(), q.release(), v.release(), zz.release();
+        h.clear(), g.clear(), s.clear(), c.clear();
+        task = task_start, niter = 0, j = 0;
+    }
+    aoclsparse_status dot(Runtime &rt, const C *x, const C *y, bool conj_x, Cs &out)
+    {
+        MI355_TRY(red_partial.alloc(sizeof(C) * 1024, false));
+        MI355_TRY(red_out.alloc(sizeof(C), false));
+        MI355_TRY(launch_cdot<R>(rt.stream(), n, x, y, red_partial.as<C>(), red_out.as<C>(), conj_x));
+        C hv(R(0), R(0));
+        MI355_HIP_TRY(hipMemcpyAsync(&hv, red_out.ptr, sizeof(C), hipMemcpyDeviceToHost, rt.stream()));
+        MI355_HIP_TRY(hipStreamSynchronize(rt.stream()));
+        out = Cs(hv.re, hv.im);
+        return aoclsparse_status_success;
+    }
+    aoclsparse_status nrm2(Runtime &rt, const C *x, R &out)
+    {
+        Cs d;
+        MI355_TRY(dot(rt, x, x, true, d));
+        out = std::sqrt(d.real());
+        return aoclsparse_status_success;
+    }
+    aoclsparse_status axpby(Runtime &rt, Cs a, const C *x, Cs bb, const C *y, C *w)
+    {
+        return launch_caxpby<R>(rt.stream(), n, dev(a), x, dev(bb), y, w);
+    }
+    aoclsparse_status init()
+    {
+        method = opts.reg["iterative method"].key;
+        const size_t nb = sizeof(C) * (size_t)n;
+        if(method == solver_cg)
+        {
+            MI355_TRY(r.alloc(nb, pinned));
+            MI355_TRY(z.alloc(nb, pinned));
+            MI355_TRY(p.alloc(nb, pinned));
+            MI355_TRY(q.alloc(nb, pinned));
+            task    = task_start;
+            precond = opts.reg["cg preconditioner"].key;
+            rtol = (R)opts.reg["cg rel tolerance"].rval, atol = (R)opts.reg["cg abs tolerance"].rval;
+            maxit = (aoclsparse_int)opts.reg["cg iteration limit"].ival;
+        }
+        else
+        {
+            if(v.ptr == nullptr)
+            {
+                restart           = (aoclsparse_int)opts.reg["gmres restart iterations"].ival;
+                const long long m = restart;
+                if((m + 1) * (long long)n > std::numeric_limits<aoclsparse_int>::max()
+                   || m * m > std::numeric_limits<aoclsparse_int>::max())
+                    return aoclsparse_status_invalid_size;
+                const size_t kb = nb * (size_t)(m + 1);
+                MI355_TRY(v.alloc(kb, pinned));
+                MI355_TRY(zz.alloc(kb, pinned));
+                MI355_HIP_TRY(hipMemset(v.ptr, 0, kb));
+                MI355_HIP_TRY(hipMemset(zz.ptr, 0, kb));
+                try
+                {
+                    h.assign((size_t)(m * m), Cs(0)), g.assign((size_t)m + 1, Cs(0));
+                    s.assign((size_t)m, Cs(0)), c.assign((size_t)m, R(0));
+                }
+                catch(const std::bad_alloc &)
+                {
+                    return aoclsparse_status_memory_error;
+                }
+                niter = 0, j = 0;
+            }
+            task    = task_gmres_start;
+            precond = opts.reg["gmres preconditioner"].key;
+            rtol = (R)opts.reg["gmres rel tolerance"].rval, atol = (R)opts.reg["gmres abs tolerance"].rval;
+            maxit = (aoclsparse_int)opts.reg["gmres iteration limit"].ival;
+        }
+        return aoclsparse_status_success;
+    }
+    static bool tiny(Cs v)
+    {
+        return std::abs(v) <= R(1e-2) * R(2) * std::numeric_limits<R>::epsilon();
+    }
+
+    aoclsparse_status cg_step(Runtime &rt, aoclsparse_itsol_rci_job *ircomm, C **u, C **vv, C *x, R *rinfo)
+    {
+        aoclsparse_status exit_status = aoclsparse_status_success;
+        C *rp = r.as<C>(), *zp = z.as<C>(), *pp = p.as<C>(), *qp = q.as<C>();
+        if(task != task_start && *ircomm == aoclsparse_rci_interrupt)
+        {
+            *ircomm = aoclsparse_rci_stop;
+            return aoclsparse_status_user_stop;
+        }
+        bool loop;
+        do
+        {
+            loop = false;
+            switch(task)
+            {
+            case task_start:
+                for(int i = 0; i < 100; i++)
+                    rinfo[i] = R(0);
+                niter = 0;
+                // r = -b, p = x (:676-686)
+                MI355_TRY(axpby(rt, Cs(-1), b.as<C>(), Cs(0), nullptr, rp));
+                MI355_TRY(axpby(rt, Cs(1), x, Cs(0), nullptr, pp));
+                MI355_TRY(nrm2(rt, b.as<C>(), bnorm2));
+                if(bnorm2 != bnorm2)
+                    return aoclsparse_status_invalid_value;
+                rinfo[RINFO_RHS_NORM] = bnorm2;
+                brtol                 = rtol * bnorm2;
+                *ircomm = aoclsparse_rci_mv, task = task_init_res;
+                *u = pp, *vv = qp;
+                break;
+            case task_init_res:
+                MI355_TRY(axpby(rt, Cs(1), rp, Cs(1), qp, rp));
+                MI355_TRY(nrm2(rt, rp, rnorm2));
+                if(rnorm2 != rnorm2)
+                {
+                    exit_status = aoclsparse_status_numerical_error;
+                    break;
+                }
+                rinfo[RINFO_RES_NORM] = rnorm2;
+                MI355_TRY(axpby(rt, Cs(0), nullptr, Cs(0), nullptr, pp));
+                rz   = Cs(1, 1); // sic (:723)
+                task = task_check_conv;
+                [[fallthrough]];
+            case task_check_conv:
+                *u = rp, *vv = nullptr;
+                if((R(0) < atol && rnorm2 <= atol) || (R(0) < rtol && rnorm2 <= brtol))
+                {
+                    *ircomm = aoclsparse_rci_stop;
+                    break;
+                }
+                if(maxit > 0 && niter > maxit)
+                {
+                    *ircomm = aoclsparse_rci_stop, exit_status = aoclsparse_status_maxit;
+                    break;
+                }
+                task = task_start_iter, *ircomm = aoclsparse_rci_stopping_criterion;
+                break;
+            case task_start_iter:
+                niter++;
+                rinfo[RINFO_ITER] = (R)niter;
+                task              = task_compute_beta;
+                if(precond)
+                {
+                    *ircomm = aoclsparse_rci_precond;
+                    *u = rp, *vv = zp;
+                    break;
+                }
+                MI355_TRY(axpby(rt, Cs(1), rp, Cs(0), nullptr, zp));
+                [[fallthrough]];
+            case task_compute_beta:
+            {
+                Cs rz_new;
+                MI355_TRY(dot(rt, rp, zp, false, rz_new));
+                if(tiny(rz))
+                    return aoclsparse_status_numerical_error;
+                beta = rz_new / rz, rz = rz_new;
+                MI355_TRY(axpby(rt, beta, pp, Cs(-1), zp, pp));
+                *ircomm = aoclsparse_rci_mv, task = task_take_step;
+                *u = pp, *vv = qp;
+                break;
+            }
+            case task_take_step:
+            {
+                Cs pq;
+                MI355_TRY(dot(rt, pp, qp, false, pq));
+                if(tiny(pq) || pq == Cs(0))
+                    return aoclsparse_status_numerical_error;
+                alpha = rz / pq;
+                MI355_TRY(axpby(rt, alpha, pp, Cs(1), x, x));
+                MI355_TRY(axpby(rt, alpha, qp, Cs(1), rp, rp));
+                x_dirty = true;
+                MI355_TRY(nrm2(rt, rp, rnorm2));
+                if(rnorm2 != rnorm2)
+                {
+                    exit_status = aoclsparse_status_numerical_error;
+                    break;
+                }
+                rinfo[RINFO_RES_NORM] = rnorm2;
+                loop = true, task = task_check_conv;
+                break;
+            }
+            default:
+                *ircomm = aoclsparse_rci_stop;
+                return aoclsparse_status_internal_error;
+            }
+        } while(loop);
+        return exit_status;
+    }
+
+    aoclsparse_status gmres_step(Runtime &rt, aoclsparse_itsol_rci_job *ircomm, C **io1, C **io2, C *x, R *rinfo)
+    {
+        aoclsparse_status    exit_status = aoclsparse_status_success;
+        const aoclsparse_int m           = restart;
+        const long long      ld          = n;
+        C                   *V = v.as<C>(), *Z = zz.as<C>();
+        if(task != task_gmres_start && *ircomm == aoclsparse_rci_interrupt)
+        {
+            *ircomm = aoclsparse_rci_stop;
+            return aoclsparse_status_user_stop;
+        }
+        bool loop;
+        do
+        {
+            loop = false;
+            switch(task)
+            {
+            case task_gmres_start:
+                *io1 = x, *io2 = V;
+                *ircomm = aoclsparse_rci_mv, task = task_gmres_init_res;
+                break;
+            case task_gmres_init_res:
+            {
+                MI355_TRY(nrm2(rt, b.as<C>(), bnorm2));
+                if(std::isnan(bnorm2))
+                    return aoclsparse_status_invalid_value;
+                brtol                 = rtol * bnorm2;
+                rinfo[RINFO_RHS_NORM] = brtol; // sic (:1004)
+                if(near_zero(atol) && near_zero(brtol))
+                {
+                    exit_status = aoclsparse_status_invalid_value, *ircomm = aoclsparse_rci_stop;
+                    break;
+                }
+                MI355_TRY(axpby(rt, Cs(1), b.as<C>(), Cs(-1), V, V)); // v0 = b - A x
+                R g0 = 0;
+                MI355_TRY(nrm2(rt, V, g0));
+                g[0] = Cs(g0, 0), rnorm2 = g0;
+                rinfo[RINFO_RES_NORM] = rnorm2;
+                if((R(0) < rnorm2 && rnorm2 <= atol) || (R(0) < rnorm2 && rnorm2 <= brtol) || rnorm2 == R(0))
+                {
+                    *ircomm = aoclsparse_rci_stop, rinfo[RINFO_ITER] = (R)niter;
+                    break;
+                }
+                MI355_TRY(axpby(rt, Cs(R(1) / rnorm2), V, Cs(0), nullptr, V));
+                task = task_gmres_init_precond;
+                if(!precond)
+                    loop = true;
+                else
+                {
+                    *ircomm = aoclsparse_rci_precond;
+                    *io1 = V + (long long)j * ld, *io2 = Z + (long long)j * ld;
+                }
+                break;
+            }
+            case task_gmres_init_precond:
+            case task_gmres_end_iter:
+                *io1 = (precond ? Z : V) + (long long)j * ld, *io2 = V + (long long)(j + 1) * ld;
+                *ircomm = aoclsparse_rci_mv, task = task_gmres_start_iter;
+                break;
+            case task_gmres_start_iter:
+            {
+                C *w = V + (long long)(j + 1) * ld;
+                for(aoclsparse_int i = 0; i <= j; i++) // all h(i,j) = v_i^H w from the unmodified w, then the update
+                    MI355_TRY(dot(rt, V + (long long)i * ld, w, true, h[(size_t)i * m + j]));
+                for(aoclsparse_int i = 0; i <= j; i++)
+                    MI355_TRY(axpby(rt, -h[(size_t)i * m + j], V + (long long)i * ld, Cs(1), w, w));
+                R hh = 0;
+                MI355_TRY(nrm2(rt, w, hh));
+                if(hh < atol || hh < brtol)
+                {
+                    niter += j + 1;
+                    rinfo[RINFO_ITER] = (R)niter, rinfo[RINFO_RES_NORM] = hh;
+                    *ircomm = aoclsparse_rci_stop;
+                    break;
+                }
+                MI355_TRY(axpby(rt, Cs(R(1) / hh), w, Cs(0), nullptr, w));
+                for(aoclsparse_int i = 0; i < j; i++)
+                {
+                    const Cs r1 = h[(size_t)i * m + j], r2 = h[(size_t)(i + 1) * m + j];
+                    h[(size_t)i * m + j]       = c[i] * r1 + s[i] * r2;
+                    h[(size_t)(i + 1) * m + j] = -std::conj(s[i]) * r1 + c[i] * r2;
+                }
+                const Cs rr = h[(size_t)j * m + j];
+                clartg<R>(rr, Cs(hh, 0), c[j], s[j], h[(size_t)j * m + j]);
+                const Cs g0 = g[j];
+                g[j] = c[j] * g0, g[j + 1] = -std::conj(s[j]) * g0;
+                rnorm2 = std::abs(g[j]); // sic (:1173)
+                rinfo[RINFO_ITER] = (R)niter, rinfo[RINFO_RES_NORM] = rnorm2;
+                j++;
+                if(j >= m)
+                {
+                    task = task_gmres_x_update, loop = true;
+                    break;
+                }
+                task = task_gmres_end_iter;
+                if(!precond)
+                    loop = true;
+                else
+                {
+                    *ircomm = aoclsparse_rci_precond;
+                    *io1 = V + (long long)j * ld, *io2 = Z + (long long)j * ld;
+                }
+                break;
+            }
+            case task_gmres_x_update:
+            {
+                for(aoclsparse_int jj = j - 1; jj >= 0; jj--)
+                {
+                    Cs yj = g[jj];
+                    for(aoclsparse_int i = jj + 1; i < j; i++)
+                        yj -= h[(size_t)jj * m + i] * s[i];
+                    const Cs diag = h[(size_t)jj * m + jj];
+                    if(tiny(diag))
+                    {
+                        exit_status = aoclsparse_status_numerical_error;
+                        break;
+                    }
+                    s[jj] = yj / diag;
+                }
+                if(exit_status != aoclsparse_status_success)
+                    break;
+                for(aoclsparse_int i = 0; i < m; i++) // x += sum y_i v_i (z_i with a preconditioner), :1213-1232
+                    MI355_TRY(axpby(rt, s[i], (precond ? Z : V) + (long long)i * ld, Cs(1), x, x));
+                x_dirty = true;
+                rnorm2  = std::abs(g[j]);
+                niter += j;
+                rinfo[RINFO_ITER] = (R)niter, rinfo[RINFO_RES_NORM] = rnorm2;
+                const bool below_abs = R(0) < atol && rnorm2 <= atol, below_rel = R(0) < rnorm2 && rnorm2 <= brtol;
+                const bool at_max    = maxit > 0 && niter >= maxit;
+                if(j >= m)
+                    j = 0;
+                *ircomm = aoclsparse_rci_stopping_criterion;
+                task    = (below_abs || below_rel || at_max) ? task_gmres_convergence_check : task_gmres_restart_cycle;
+                break;
+            }
+            case task_gmres_restart_cycle:
+                *io1 = x, *io2 = V;
+                *ircomm = aoclsparse_rci_mv, task = task_gmres_init_res;
+                break;
+            case task_gmres_convergence_check:
+                if((R(0) < atol && rnorm2 <= atol) || (R(0) < rnorm2 && rnorm2 <= brtol))
+                    *ircomm = aoclsparse_rci_stop;
+                else if(maxit > 0 && niter >= maxit)
+                    exit_status = aoclsparse_status_maxit, *ircomm = aoclsparse_rci_stop;
+                break;
+            default:
+                *ircomm = aoclsparse_rci_stop;
+                return aoclsparse_status_internal_error;
+            }
+        } while(loop);
+        return exit_status;
+    }
+
+    aoclsparse_status rci(Runtime &rt, aoclsparse_itsol_rci_job *ircomm, C **u, C **vv, C *x, R *rinfo)
+    {
+        aoclsparse_status st;
+        if(!solving)
+        {
+            st = init();
+            if(st != aoclsparse_status_success)
+            {
+                *ircomm = aoclsparse_rci_stop;
+                return st;
+            }
+            solving = true, opts.locked = true;
+        }
+        st = method == solver_cg ? cg_step(rt, ircomm, u, vv, x, rinfo) : gmres_step(rt, ircomm, u, vv, x, rinfo);
+        if(st != aoclsparse_status_success)
+            *ircomm = aoclsparse_rci_stop;
+        if(*ircomm == aoclsparse_rci_stop)
+            solving = false, opts.locked = false;
+        return st;
+    }
+};
+
+template <typename R>
+aoclsparse_status cset_rhs(CSolver<R> &S, aoclsparse_int n, const cplx<R> *b, bool force_device)
+{
+    if(n < 0)
+        return aoclsparse_status_invalid_value;
+    if(!b)
+        return aoclsparse_status_invalid_pointer;
+    Runtime &rt = Runtime::get();
+    MI355_TRY(rt.init());
+    S.free_solver_data();
+    S.pinned = !force_device && !rt.is_device_pointer(b);
+    S.n      = n;
+    MI355_TRY(S.b.alloc(sizeof(cplx<R>) * (size_t)n, S.pinned));
+    if(n > 0)
+        MI355_HIP_TRY(hipMemcpy(S.b.ptr, b, sizeof(cplx<R>) * (size_t)n, hipMemcpyDefault));
+    S.have_b = true, S.solving = false;
+    return aoclsparse_status_success;
+}
+
+template <typename R>
+aoclsparse_status crci_public(CSolver<R> *S, aoclsparse_itsol_rci_job *ircomm, cplx<R> **u, cplx<R> **v, cplx<R> *x,
+                              R *rinfo)
+{
+    using C = cplx<R>;
+    if(!ircomm)
+        return aoclsparse_status_invalid_pointer;
+    if(!S)
+    {
+        *ircomm = aoclsparse_rci_stop;
+        return aoclsparse_status_internal_error;
+    }
+    if(!u || !v || !x || !rinfo)
+    {
+        *ircomm = aoclsparse_rci_stop;
+        return aoclsparse_status_invalid_pointer;
+    }
+    if(!S->have_b)
+    {
+        *ircomm = aoclsparse_rci_stop;
+        return aoclsparse_status_invalid_pointer;
+    }
+    Runtime &rt = Runtime::get();
+    MI355_TRY(rt.init());
+    C *xd = x;
+    if(S->pinned)
+    {
+        const bool starting = !S->solving;
+        MI355_TRY(S->xshadow.alloc(sizeof(C) * (size_t)S->n, true));
+        xd = S->xshadow.template as<C>();
+        if(starting)
+            std::memcpy(xd, x, sizeof(C) * (size_t)S->n);
+    }
+    S->x_dirty                 = false;
+    const aoclsparse_status st = S->rci(rt, ircomm, u, v, xd, rinfo);
+    if(S->pinned)
+    {
+        (void)hipStreamSynchronize(rt.stream());
+        if(S->x_dirty)
+            std::memcpy(x, xd, sizeof(C) * (size_t)S->n);
+        if(*u == xd)
+            *u = x;
+    }
+    return st;
+}
+
+template <typename R>
+aoclsparse_status cexec_mv(aoclsparse_matrix A, const aoclsparse_mat_descr d, const cplx<R> *x, cplx<R> *y);
+template <>
+aoclsparse_status cexec_mv<double>(aoclsparse_matrix A, const aoclsparse_mat_descr d, const cdouble *x, cdouble *y)
+{
+    const aoclsparse_double_complex one{1.0, 0.0}, zero{0.0, 0.0};
+    return aoclsparse_zmv(aoclsparse_operation_none, &one, A, d, reinterpret_cast<const aoclsparse_double_complex *>(x), &zero,
+                          reinterpret_cast<aoclsparse_double_complex *>(y));
+}
+template <>
+aoclsparse_status cexec_mv<float>(aoclsparse_matrix A, const aoclsparse_mat_descr d, const cfloat *x, cfloat *y)
+{
+    const aoclsparse_float_complex one{1.0f, 0.0f}, zero{0.0f, 0.0f};
+    return aoclsparse_cmv(aoclsparse_operation_none, &one, A, d, reinterpret_cast<const aoclsparse_float_complex *>(x), &zero,
+                          reinterpret_cast<aoclsparse_float_complex *>(y));
+}
+inline aoclsparse_status cexec_ilu(aoclsparse_matrix A, const aoclsparse_mat_descr d, cdouble *x, const cdouble *b)
+{
+    aoclsparse_double_complex *f = nullptr;
+    return aoclsparse_zilu_smoother(aoclsparse_operation_none, A, d, &f, nullptr, reinterpret_cast<aoclsparse_double_complex *>(x),
+                                    reinterpret_cast<const aoclsparse_double_complex *>(b));
+}
+inline aoclsparse_status cexec_ilu(aoclsparse_matrix A, const aoclsparse_mat_descr d, cfloat *x, const cfloat *b)
+{
+    aoclsparse_float_complex *f = nullptr;
+    return aoclsparse_cilu_smoother(aoclsparse_operation_none, A, d, &f, nullptr, reinterpret_cast<aoclsparse_float_complex *>(x),
+                                    reinterpret_cast<const aoclsparse_float_complex *>(b));
+}
+
+// aoclsparse_itsol_solve for complex handles: the loop of solve_direct with complex operands.  PT is the public complex
+// struct of the callbacks (layout-identical to cplx<R>).
+template <typename R, typename PT>
+aoclsparse_status csolve_direct(CSolver<R> *S, aoclsparse_int n, aoclsparse_matrix mat, const aoclsparse_mat_descr descr,
+                                const cplx<R> *b, cplx<R> *x, R *rinfo,
+                                aoclsparse_int precond(aoclsparse_int, aoclsparse_int, const PT *, PT *, void *),
+                                aoclsparse_int monit(aoclsparse_int, const PT *, const PT *, R *, void *), void *udata,
+                                aoclsparse_matrix_data_type vt)
+{
+    using C = cplx<R>;
+    if(!S)
+        return aoclsparse_status_internal_error;
+    if(!x || !rinfo)
+        return aoclsparse_status_invalid_pointer;
+    for(int i = 0; i < 100; i++)
+        rinfo[i] = R(0);
+    MI355_TRY(cset_rhs(*S, n, b, true));
+    MI355_TRY(S->init());
+    if(!mat || !descr)
+        return aoclsparse_status_invalid_pointer;
+    if(mat->val_type != vt)
+        return aoclsparse_status_wrong_type;
+    MI355_TRY(csr_optimize(mat));
+    Runtime &rt = Runtime::get();
+    if(mat->m != n || mat->n != n)
+        return aoclsparse_status_invalid_size;
+    if(S->method == solver_cg)
+    {
+        if(descr->type != aoclsparse_matrix_type_symmetric || descr->fill_mode != aoclsparse_fill_mode_lower)
+            return aoclsparse_status_invalid_value;
+        if(S->precond == 3)
+            return aoclsparse_status_not_implemented; // built-in SymGS: real handles only
+    }
+    if(S->precond == 1 && !precond)
+        return aoclsparse_status_invalid_pointer;
+    std::lock_guard<std::recursive_mutex> sl(rt.stage_lock);
+    const bool xdev = rt.is_device_pointer(x);
+    C         *xd   = x;
+    if(!xdev)
+    {
+        MI355_TRY(S->xshadow.alloc(sizeof(C) * (size_t)n, false));
+        xd = S->xshadow.template as<C>();
+        MI355_HIP_TRY(hipMemcpy(xd, x, sizeof(C) * (size_t)n, hipMemcpyHostToDevice));
+    }
+    std::vector<C> hu, hv;
+    if(precond || monit)
+    {
+        try
+        {
+            hu.resize((size_t)n), hv.resize((size_t)n);
+        }
+        catch(const std::bad_alloc &)
+        {
+            return aoclsparse_status_memory_error;
+        }
+    }
+    auto to_host = [&](std::vector<C> &hh, const C *d) -> aoclsparse_status {
+        MI355_HIP_TRY(hipMemcpyAsync(hh.data(), d, sizeof(C) * (size_t)n, hipMemcpyDeviceToHost, rt.stream()));
+        MI355_HIP_TRY(hipStreamSynchronize(rt.stream()));
+        return aoclsparse_status_success;
+    };
+    S->solving = true, S->opts.locked = true;
+    aoclsparse_itsol_rci_job ircomm = aoclsparse_rci_start;
+    C                       *u = nullptr, *v = nullptr;
+    aoclsparse_status        exit_status = aoclsparse_status_success, st;
+    auto finish = [&](aoclsparse_status code) {
+        S->solving = false, S->opts.locked = false;
+        if(!xdev)
+            (void)hipMemcpy(x, xd, sizeof(C) * (size_t)n, hipMemcpyDeviceToHost);
+        return code;
+    };
+    DeviceScope scope;
+    while(ircomm != aoclsparse_rci_stop)
+    {
+        exit_status = S->rci(rt, &ircomm, &u, &v, xd, rinfo);
+        if(exit_status != aoclsparse_status_success && ircomm != aoclsparse_rci_stop)
+            return finish(exit_status);
+        switch(ircomm)
+        {
+        case aoclsparse_rci_mv:
+            if(cexec_mv<R>(mat, descr, u, v) != aoclsparse_status_success)
+                return finish(aoclsparse_status_internal_error);
+            break;
+        case aoclsparse_rci_precond:
+            if(S->precond == 1)
+            {
+                st = to_host(hu, u);
+                if(st != aoclsparse_status_success)
+                    return finish(st);
+                if(precond(0, n, reinterpret_cast<const PT *>(hu.data()), reinterpret_cast<PT *>(hv.data()), udata) != 0)
+                    ircomm = aoclsparse_rci_interrupt;
+                if(hipMemcpy(v, hv.data(), sizeof(C) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess)
+                    return finish(aoclsparse_status_internal_error);
+            }
+            else if(S->method == solver_gmres && S->precond == 2)
+                (void)cexec_ilu(mat, descr, v, u);
+            else if(S->axpby(rt, std::complex<R>(1), u, std::complex<R>(0), nullptr, v) != aoclsparse_status_success)
+                return finish(aoclsparse_status_internal_error);
+            break;
+        case aoclsparse_rci_stopping_criterion:
+            if(monit)
+            {
+                st = to_host(hu, xd);
+                if(st == aoclsparse_status_success && S->method == solver_cg)
+                    st = to_host(hv, S->r.template as<C>());
+                if(st != aoclsparse_status_success)
+                    return finish(st);
+                if(monit(n, reinterpret_cast<const PT *>(hu.data()),
+                         S->method == solver_cg ? reinterpret_cast<const PT *>(hv.data()) : nullptr, rinfo, udata)
+                   != 0)
+                    ircomm = aoclsparse_rci_interrupt;
+            }
+            break;
+        default:
+            break;
+        }
+    }
+    return finish(exit_status);
+}
+
 } // namespace
 
 struct _aoclsparse_itsol_handle
@@ -984,6 +1630,8 @@ struct _aoclsparse_itsol_handle
     aoclsparse_matrix_data_type type = aoclsparse_dmat;
     Solver<float>              *s    = nullptr;
     Solver<double>             *d    = nullptr;
+    CSolver<float>             *c    = nullptr;
+    CSolver<double>            *z    = nullptr;
 };
 
 extern "C" {
@@ -996,6 +1644,10 @@ void aoclsparse_itsol_handle_prn_options(aoclsparse_itsol_handle handle)
         handle->d->opts.print();
     else if(handle->type == aoclsparse_smat && handle->s)
         handle->s->opts.print();
+    else if(handle->type == aoclsparse_zmat && handle->z)
+        handle->z->opts.print();
+    else if(handle->type == aoclsparse_cmat && handle->c)
+        handle->c->opts.print();
 }
 
 aoclsparse_status aoclsparse_itsol_option_set(aoclsparse_itsol_handle handle, const char *option, const char *value)
@@ -1006,6 +1658,10 @@ aoclsparse_status aoclsparse_itsol_option_set(aoclsparse_itsol_handle handle, co
         return handle->d ? handle->d->opts.set(option, value) : aoclsparse_status_internal_error;
     if(handle->type == aoclsparse_smat)
         return handle->s ? handle->s->opts.set(option, value) : aoclsparse_status_internal_error;
+    if(handle->type == aoclsparse_zmat)
+        return handle->z ? handle->z->opts.set(option, value) : aoclsparse_status_internal_error;
+    if(handle->type == aoclsparse_cmat)
+        return handle->c ? handle->c->opts.set(option, value) : aoclsparse_status_internal_error;
     return aoclsparse_status_invalid_value;
 }
 
@@ -1015,6 +1671,8 @@ void aoclsparse_itsol_destroy(aoclsparse_itsol_handle *handle)
     {
         delete(*handle)->s;
         delete(*handle)->d;
+        delete(*handle)->c;
+        delete(*handle)->z;
         delete *handle;
         *handle = nullptr;
     }
@@ -1119,6 +1777,106 @@ aoclsparse_status aoclsparse_itsol_s_solve(
     if(handle->type != aoclsparse_smat)
         return aoclsparse_status_wrong_type;
     return solve_direct<float>(handle->s, n, mat, descr, b, x, rinfo, precond, monit, udata, aoclsparse_smat);
+}
+
+aoclsparse_status aoclsparse_itsol_z_init(aoclsparse_itsol_handle *handle)
+{
+    if(!handle)
+        return aoclsparse_status_invalid_pointer;
+    try
+    {
+        *handle         = new _aoclsparse_itsol_handle;
+        (*handle)->type = aoclsparse_zmat;
+        (*handle)->z    = new CSolver<double>;
+        register_options<double>((*handle)->z->opts);
+    }
+    catch(const std::bad_alloc &)
+    {
+        aoclsparse_itsol_destroy(handle);
+        return aoclsparse_status_memory_error;
+    }
+    return aoclsparse_status_success;
+}
+aoclsparse_status aoclsparse_itsol_z_rci_input(aoclsparse_itsol_handle handle, aoclsparse_int n, const aoclsparse_double_complex *b)
+{
+    if(!handle)
+        return aoclsparse_status_invalid_pointer;
+    if(handle->type != aoclsparse_zmat)
+        return aoclsparse_status_wrong_type;
+    return cset_rhs(*handle->z, n, reinterpret_cast<const cplx<double> *>(b), false);
+}
+aoclsparse_status aoclsparse_itsol_z_rci_solve(aoclsparse_itsol_handle handle, aoclsparse_itsol_rci_job *ircomm,
+                                               aoclsparse_double_complex **u, aoclsparse_double_complex **v, aoclsparse_double_complex *x, double rinfo[100])
+{
+    if(!handle)
+        return aoclsparse_status_invalid_pointer;
+    if(handle->type != aoclsparse_zmat)
+        return aoclsparse_status_wrong_type;
+    return crci_public(handle->z, ircomm, reinterpret_cast<cplx<double> **>(u), reinterpret_cast<cplx<double> **>(v),
+                       reinterpret_cast<cplx<double> *>(x), rinfo);
+}
+aoclsparse_status aoclsparse_itsol_z_solve(
+    aoclsparse_itsol_handle handle, aoclsparse_int n, aoclsparse_matrix mat, const aoclsparse_mat_descr descr,
+    const aoclsparse_double_complex *b, aoclsparse_double_complex *x, double rinfo[100],
+    aoclsparse_int precond(aoclsparse_int flag, aoclsparse_int n, const aoclsparse_double_complex *u, aoclsparse_double_complex *v, void *udata),
+    aoclsparse_int monit(aoclsparse_int n, const aoclsparse_double_complex *x, const aoclsparse_double_complex *r, double rinfo[100], void *udata), void *udata)
+{
+    if(!handle)
+        return aoclsparse_status_invalid_pointer;
+    if(handle->type != aoclsparse_zmat)
+        return aoclsparse_status_wrong_type;
+    return csolve_direct<double, aoclsparse_double_complex>(handle->z, n, mat, descr, reinterpret_cast<const cplx<double> *>(b),
+                                    reinterpret_cast<cplx<double> *>(x), rinfo, precond, monit, udata, aoclsparse_zmat);
+}
+
+aoclsparse_status aoclsparse_itsol_c_init(aoclsparse_itsol_handle *handle)
+{
+    if(!handle)
+        return aoclsparse_status_invalid_pointer;
+    try
+    {
+        *handle         = new _aoclsparse_itsol_handle;
+        (*handle)->type = aoclsparse_cmat;
+        (*handle)->c    = new CSolver<float>;
+        register_options<float>((*handle)->c->opts);
+    }
+    catch(const std::bad_alloc &)
+    {
+        aoclsparse_itsol_destroy(handle);
+        return aoclsparse_status_memory_error;
+    }
+    return aoclsparse_status_success;
+}
+aoclsparse_status aoclsparse_itsol_c_rci_input(aoclsparse_itsol_handle handle, aoclsparse_int n, const aoclsparse_float_complex *b)
+{
+    if(!handle)
+        return aoclsparse_status_invalid_pointer;
+    if(handle->type != aoclsparse_cmat)
+        return aoclsparse_status_wrong_type;
+    return cset_rhs(*handle->c, n, reinterpret_cast<const cplx<float> *>(b), false);
+}
+aoclsparse_status aoclsparse_itsol_c_rci_solve(aoclsparse_itsol_handle handle, aoclsparse_itsol_rci_job *ircomm,
+                                               aoclsparse_float_complex **u, aoclsparse_float_complex **v, aoclsparse_float_complex *x, float rinfo[100])
+{
+    if(!handle)
+        return aoclsparse_status_invalid_pointer;
+    if(handle->type != aoclsparse_cmat)
+        return aoclsparse_status_wrong_type;
+    return crci_public(handle->c, ircomm, reinterpret_cast<cplx<float> **>(u), reinterpret_cast<cplx<float> **>(v),
+                       reinterpret_cast<cplx<float> *>(x), rinfo);
+}
+aoclsparse_status aoclsparse_itsol_c_solve(
+    aoclsparse_itsol_handle handle, aoclsparse_int n, aoclsparse_matrix mat, const aoclsparse_mat_descr descr,
+    const aoclsparse_float_complex *b, aoclsparse_float_complex *x, float rinfo[100],
+    aoclsparse_int precond(aoclsparse_int flag, aoclsparse_int n, const aoclsparse_float_complex *u, aoclsparse_float_complex *v, void *udata),
+    aoclsparse_int monit(aoclsparse_int n, const aoclsparse_float_complex *x, const aoclsparse_float_complex *r, float rinfo[100], void *udata), void *udata)
+{
+    if(!handle)
+        return aoclsparse_status_invalid_pointer;
+    if(handle->type != aoclsparse_cmat)
+        return aoclsparse_status_wrong_type;
+    return csolve_direct<float, aoclsparse_float_complex>(handle->c, n, mat, descr, reinterpret_cast<const cplx<float> *>(b),
+                                    reinterpret_cast<cplx<float> *>(x), rinfo, precond, monit, udata, aoclsparse_cmat);
 }
 
 } // extern "C"

@@ -849,6 +849,31 @@ DLL_PUBLIC aoclsparse_status aoclsparse_itsol_s_solve(
     aoclsparse_int precond(aoclsparse_int flag, aoclsparse_int n, const float *u, float *v, void *udata),
     aoclsparse_int monit(aoclsparse_int n, const float *x, const float *r, float rinfo[100], void *udata),
     void *udata);
+/* complex handles (aoclsparse_solvers.h: aoclsparse_itsol_{c,z}_*): norms, tolerances and rinfo are real */
+DLL_PUBLIC aoclsparse_status aoclsparse_itsol_c_init(aoclsparse_itsol_handle *handle);
+DLL_PUBLIC aoclsparse_status aoclsparse_itsol_c_rci_input(aoclsparse_itsol_handle handle, aoclsparse_int n,
+                                                          const aoclsparse_float_complex *b);
+DLL_PUBLIC aoclsparse_status aoclsparse_itsol_c_rci_solve(aoclsparse_itsol_handle   handle,
+                                                          aoclsparse_itsol_rci_job *ircomm, aoclsparse_float_complex **u,
+                                                          aoclsparse_float_complex **v, aoclsparse_float_complex *x, float rinfo[100]);
+DLL_PUBLIC aoclsparse_status aoclsparse_itsol_c_solve(
+    aoclsparse_itsol_handle handle, aoclsparse_int n, aoclsparse_matrix mat, const aoclsparse_mat_descr descr,
+    const aoclsparse_float_complex *b, aoclsparse_float_complex *x, float rinfo[100],
+    aoclsparse_int precond(aoclsparse_int flag, aoclsparse_int n, const aoclsparse_float_complex *u, aoclsparse_float_complex *v, void *udata),
+    aoclsparse_int monit(aoclsparse_int n, const aoclsparse_float_complex *x, const aoclsparse_float_complex *r, float rinfo[100], void *udata),
+    void *udata);
+DLL_PUBLIC aoclsparse_status aoclsparse_itsol_z_init(aoclsparse_itsol_handle *handle);
+DLL_PUBLIC aoclsparse_status aoclsparse_itsol_z_rci_input(aoclsparse_itsol_handle handle, aoclsparse_int n,
+                                                          const aoclsparse_double_complex *b);
+DLL_PUBLIC aoclsparse_status aoclsparse_itsol_z_rci_solve(aoclsparse_itsol_handle   handle,
+                                                          aoclsparse_itsol_rci_job *ircomm, aoclsparse_double_complex **u,
+                                                          aoclsparse_double_complex **v, aoclsparse_double_complex *x, double rinfo[100]);
+DLL_PUBLIC aoclsparse_status aoclsparse_itsol_z_solve(
+    aoclsparse_itsol_handle handle, aoclsparse_int n, aoclsparse_matrix mat, const aoclsparse_mat_descr descr,
+    const aoclsparse_double_complex *b, aoclsparse_double_complex *x, double rinfo[100],
+    aoclsparse_int precond(aoclsparse_int flag, aoclsparse_int n, const aoclsparse_double_complex *u, aoclsparse_double_complex *v, void *udata),
+    aoclsparse_int monit(aoclsparse_int n, const aoclsparse_double_complex *x, const aoclsparse_double_complex *r, double rinfo[100], void *udata),
+    void *udata);
 
 /* C = alpha*op(A)*B + beta*C, dense B/C in the stated order; alpha, beta BY VALUE (:2487-2511). */
 DLL_PUBLIC aoclsparse_status aoclsparse_scsrmm(aoclsparse_operation       op,

@@ -385,3 +385,93 @@ def dcsr2m(m, n, base_a, ptr_a, ind_a, val_a, base_b, ptr_b, ind_b, val_b):
                                c_int(base_b), _p(ptr_b), _p(ind_b), _p(val_b), _p(ptr_c), _p(ind_c),
                                _p(val_c))
     return st, ptr_c, ind_c[: nnz_c.value], val_c[: nnz_c.value]
+
+
+# ---- complex CG / GMRES, numpy restatements of solvers/aoclsparse_itsol_functions.hpp:632-875 and :910-1367 for
+# T = std::complex (dense operator A; no preconditioner).  No reference vectors exist for them: parity unpinned, the
+# checks are exit status, iteration counts and the solver tolerances.
+def zcg(A, b, x0, rtol, atol, maxit):
+    """unconjugated products r.z and p.q, rz starts at (1, 1): the reference's complex CG.  -> (status, x, niter, rnorm)"""
+    A, b, x = np.asarray(A, np.complex128), np.asarray(b, np.complex128), np.asarray(x0, np.complex128).copy()
+    tiny = 0.02 * np.finfo(np.float64).eps
+    brtol = rtol * np.linalg.norm(b)
+    r = -b + A @ x
+    p = np.zeros_like(x)
+    rz, niter = 1 + 1j, 0
+    rn = np.linalg.norm(r)
+    while True:
+        if (0 < atol and rn <= atol) or (0 < rtol and rn <= brtol):
+            return 0, x, niter, rn
+        if maxit > 0 and niter > maxit:
+            return 7, x, niter, rn  # aoclsparse_status_maxit
+        niter += 1
+        z = r.copy()
+        rz_new = np.sum(r * z)
+        if abs(rz) <= tiny:
+            return 8, x, niter, rn
+        beta, rz = rz_new / rz, rz_new
+        p = beta * p - z
+        q = A @ p
+        pq = np.sum(p * q)
+        if abs(pq) <= tiny:
+            return 8, x, niter, rn
+        alpha = rz / pq
+        x = x + alpha * p
+        r = r + alpha * q
+        rn = np.linalg.norm(r)
+
+
+def zgmres(A, b, x0, m, rtol, atol, maxit):
+    """-> (status, x, niter, rnorm).  The reference's control flow (restart cycles, convergence tested at the end of a cycle,
+    early exit when the new direction vanishes) around the textbook complex Arnoldi / Givens steps: h(i,j) = v_i^H w,
+    rotation [c s; -conj(s) c] from ?lartg on (h(j,j), |w|).  (The reference's own complex variant omits conjugations and
+    diverges on general complex matrices; see itsol_api.cpp.)"""
+    A, b, x = np.asarray(A, np.complex128), np.asarray(b, np.complex128), np.asarray(x0, np.complex128).copy()
+    n, niter = len(b), 0
+    brtol = rtol * np.linalg.norm(b)
+    while True:
+        V = np.zeros((m + 1, n), np.complex128)
+        H = np.zeros((m, m), np.complex128)
+        g, s, c = np.zeros(m + 1, np.complex128), np.zeros(m, np.complex128), np.zeros(m)
+        V[0] = b - A @ x
+        rn = np.linalg.norm(V[0])
+        g[0] = rn
+        if (0 < rn <= atol) or (0 < rn <= brtol) or rn == 0:
+            return 0, x, niter, rn
+        V[0] /= rn
+        j = 0
+        while j < m:
+            w = A @ V[j]
+            for i in range(j + 1):
+                H[i, j] = np.sum(np.conj(V[i]) * w)
+            for i in range(j + 1):
+                w = w - H[i, j] * V[i]
+            hh = np.linalg.norm(w)
+            if hh < atol or hh < brtol:
+                return 0, x, niter + j + 1, hh
+            V[j + 1] = w / hh
+            for i in range(j):
+                r1, r2 = H[i, j], H[i + 1, j]
+                H[i, j], H[i + 1, j] = c[i] * r1 + s[i] * r2, -np.conj(s[i]) * r1 + c[i] * r2
+            f, gg = H[j, j], hh + 0j
+            if f == 0:
+                c[j], s[j], H[j, j] = 0.0, np.conj(gg) / abs(gg), abs(gg)
+            else:
+                f2, g2 = abs(f) ** 2, abs(gg) ** 2
+                c[j] = np.sqrt(f2 / (f2 + g2))
+                H[j, j] = f / c[j]
+                s[j] = np.conj(gg) * (f / np.sqrt(f2 * (f2 + g2)))
+            g0 = g[j]
+            g[j], g[j + 1] = c[j] * g0, -np.conj(s[j]) * g0
+            j += 1
+        y = np.zeros(m, np.complex128)
+        for jj in range(m - 1, -1, -1):
+            y[jj] = (g[jj] - np.sum(H[jj, jj + 1:m] * y[jj + 1:m])) / H[jj, jj]
+        x = x + y @ V[:m]
+        rn = abs(g[m])
+        niter += m
+        below = (0 < atol and rn <= atol) or (0 < rn <= brtol)
+        if below:
+            return 0, x, niter, rn
+        if maxit > 0 and niter >= maxit:
+            return 7, x, niter, rn

@@ -2250,6 +2250,91 @@ def test_complex_ilu_smoother(prec):
     L.aoclsparse_destroy(ctypes.byref(h))
 
 
+@pytest.mark.parametrize("prec", ["z", "c"])
+def test_complex_itsol_cg_and_gmres(prec):
+    """aoclsparse_itsol_{c,z}_solve / _rci_*: the reference's state machines over complex vectors.  CG (its unconjugated
+    form) on a complex SYMMETRIC diagonally dominant system, GMRES (restarted, also with the ILU(0) preconditioner) on a
+    general one; exit status, iteration count (CG +-1, GMRES same cycle) and solution against the numpy restatement, and
+    the RCI loop driven by hand gives the direct interface's bits."""
+    dtype, rdtype, eps = (np.complex128, np.float64, EPS64) if prec == "z" else (np.complex64, np.float32, EPS32)
+    fn = lambda stem: getattr(L, "aoclsparse_" + stem.replace("?", prec))
+    n = 200
+    rng = np.random.default_rng(8)
+    dense, rp, ci, v = _cplx_tri_system(55, n, dtype, 0)
+    # a spectrum in the right half plane (the generator's diagonal has random phases: eigenvalues all around the origin)
+    for i in range(n):
+        dgp = rp[i] + int(np.searchsorted(ci[rp[i]:rp[i + 1]], i))
+        v[dgp] = 4.0 + 0.5j * (1 + i % 3)
+        dense[i, i] = v[dgp]
+    D = dense.astype(np.complex128)
+    xs = (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex128)
+    tol = 1e-9 if prec == "z" else 2e-4
+
+    def handle(method, extra=()):
+        hdl = ctypes.c_void_p()
+        assert fn("itsol_?_init")(ctypes.byref(hdl)) == 0
+        for k, val in (("iterative method", method),) + tuple(extra):
+            assert L.aoclsparse_itsol_option_set(hdl, k.encode(), val.encode()) == 0
+        return hdl
+
+    # ---- GMRES on the general matrix
+    A = ctypes.c_void_p()
+    assert fn("create_?csr")(ctypes.byref(A), 0, n, n, len(v), P._ptr(rp), P._ptr(ci), P._ptr(v)) == 0
+    d = P.Descr()
+    b = (D @ xs).astype(dtype)
+    opts = (("gmres rel tolerance", str(tol)), ("gmres abs tolerance", "0"), ("gmres restart iterations", "15"),
+            ("gmres iteration limit", "300"))
+    st_r, xr, it_r, rn_r = oracle.zgmres(D, b.astype(np.complex128), np.zeros(n), 15, tol, 0.0, 300)
+    hdl = handle("gmres", opts)
+    x, rinfo = np.zeros(n, dtype), np.zeros(100, rdtype)
+    assert fn("itsol_?_solve")(hdl, n, A, d.h, P._ptr(b), P._ptr(x), P._ptr(rinfo), None, None, None) == st_r == 0
+    assert abs(int(rinfo[30]) - it_r) <= 15 and np.max(np.abs(x - xs)) <= 50 * tol * np.max(np.abs(xs))
+    # the same solve through the RCI interface, mv done by the caller with aoclsparse_?mv on the handed-out pointers
+    hdl2 = handle("gmres", opts)
+    assert fn("itsol_?_rci_input")(hdl2, n, P._ptr(b)) == 0
+    x2, rinfo2 = np.zeros(n, dtype), np.zeros(100, rdtype)
+    job, u, vv = ctypes.c_int(1), ctypes.c_void_p(), ctypes.c_void_p()  # aoclsparse_rci_start
+    one, zero = np.ones(1, dtype), np.zeros(1, dtype)
+    mv = fn("?mv")
+    for _ in range(5000):
+        st = fn("itsol_?_rci_solve")(hdl2, ctypes.byref(job), ctypes.byref(u), ctypes.byref(vv), P._ptr(x2), P._ptr(rinfo2))
+        assert st == 0
+        if job.value == 2:  # aoclsparse_rci_mv
+            assert mv(P.OP_NONE, P._ptr(one), A, d.h, u, P._ptr(zero), vv) == 0
+        elif job.value == 0:  # aoclsparse_rci_stop
+            break
+    assert job.value == 0 and np.array_equal(x2, x) and rinfo2[30] == rinfo[30]
+    # ILU(0)-preconditioned: converges in no more cycles than the plain solve
+    hdl3 = handle("gmres", opts + (("gmres preconditioner", "ilu0"),))
+    assert L.aoclsparse_set_lu_smoother_hint(A, P.OP_NONE, d.h, 1) == 0 and L.aoclsparse_optimize(A) == 0
+    x3, rinfo3 = np.zeros(n, dtype), np.zeros(100, rdtype)
+    assert fn("itsol_?_solve")(hdl3, n, A, d.h, P._ptr(b), P._ptr(x3), P._ptr(rinfo3), None, None, None) == 0
+    assert rinfo3[30] <= rinfo[30] and np.max(np.abs(x3 - xs)) <= 50 * tol * np.max(np.abs(xs))
+    for hh in (hdl, hdl2, hdl3):
+        L.aoclsparse_itsol_destroy(ctypes.byref(hh))
+    L.aoclsparse_destroy(ctypes.byref(A))
+    # ---- CG on the complex symmetric matrix S = tril + tril^T (lower triangle stored)
+    Ls = np.tril(D)
+    S = Ls + np.tril(D, -1).T
+    rows = [np.flatnonzero(Ls[i]) for i in range(n)]
+    lrp = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    lci = np.concatenate(rows).astype(np.int32)
+    lv = np.concatenate([Ls[i, r] for i, r in enumerate(rows)]).astype(dtype)
+    A = ctypes.c_void_p()
+    assert fn("create_?csr")(ctypes.byref(A), 0, n, n, len(lv), P._ptr(lrp), P._ptr(lci), P._ptr(lv)) == 0
+    ds = P.Descr(mtype=P.TYPE_SYMMETRIC, fill=P.FILL_LOWER)
+    b = (S @ xs).astype(dtype)
+    st_r, xr, it_r, rn_r = oracle.zcg(S, b.astype(np.complex128), np.zeros(n), tol, 0.0, 500)
+    hdl = handle("cg", (("cg rel tolerance", str(tol)), ("cg abs tolerance", "0"), ("cg iteration limit", "500")))
+    x, rinfo = np.zeros(n, dtype), np.zeros(100, rdtype)
+    assert fn("itsol_?_solve")(hdl, n, A, ds.h, P._ptr(b), P._ptr(x), P._ptr(rinfo), None, None, None) == st_r == 0
+    assert abs(int(rinfo[30]) - it_r) <= (1 if prec == "z" else 3) and np.max(np.abs(x - xs)) <= 200 * tol * np.max(np.abs(xs))
+    hdl4 = handle("cg", (("cg preconditioner", "symgs"),))
+    assert fn("itsol_?_solve")(hdl4, n, A, ds.h, P._ptr(b), P._ptr(x), P._ptr(rinfo), None, None, None) == 1  # not offered
+    L.aoclsparse_itsol_destroy(ctypes.byref(hdl)), L.aoclsparse_itsol_destroy(ctypes.byref(hdl4))
+    L.aoclsparse_destroy(ctypes.byref(A))
+
+
 def test_complex_trsv_reference_h5_round_trip():
     """trsv_tests.cpp:313-318 / common_data_utils.h:4349-4470: the 5x5 lower-stored complex matrix, xref = 1..5,
     b = op(T) xref built by the test itself, x = solve -> xref.  All six (fill, op) cases; with fill = upper the same
