@@ -302,6 +302,16 @@ __global__ void caxpby_kernel(aoclsparse_int n, cplx<R> a, const cplx<R> *x, cpl
     }
 }
 
+
+// y[i] *= d[i] (the diagonal scale between the two sweeps of the SymGS preconditioner)
+template <typename R>
+__global__ void cvec_mul_kernel(aoclsparse_int n, const cplx<R> *d, cplx<R> *y)
+{
+    const aoclsparse_int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n)
+        y[i] = c_mul(d[i], y[i]);
+}
+
 } // namespace
 
 template <typename R>
@@ -474,6 +484,17 @@ template aoclsparse_status launch_caxpby<float>(hipStream_t, aoclsparse_int, cfl
                                                 cfloat *);
 template aoclsparse_status launch_caxpby<double>(hipStream_t, aoclsparse_int, cdouble, const cdouble *, cdouble,
                                                  const cdouble *, cdouble *);
+
+template <typename R>
+aoclsparse_status launch_cvec_mul(hipStream_t s, aoclsparse_int n, const cplx<R> *d, cplx<R> *y)
+{
+    if(n > 0)
+        hipLaunchKernelGGL((cvec_mul_kernel<R>), dim3((n + 255) / 256), dim3(256), 0, s, n, d, y);
+    MI355_HIP_TRY(hipGetLastError());
+    return aoclsparse_status_success;
+}
+template aoclsparse_status launch_cvec_mul<float>(hipStream_t, aoclsparse_int, const cfloat *, cfloat *);
+template aoclsparse_status launch_cvec_mul<double>(hipStream_t, aoclsparse_int, const cdouble *, cdouble *);
 
 template aoclsparse_status launch_cspmv<float>(hipStream_t, int, bool, cfloat, aoclsparse_int, aoclsparse_int,
                                                const cfloat *, const aoclsparse_int *, const aoclsparse_int *,

@@ -552,6 +552,8 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
                               long long x_off, aoclsparse_int incx);
 
 template <typename R>
+aoclsparse_status launch_cvec_mul(hipStream_t s, aoclsparse_int n, const cplx<R> *d, cplx<R> *y);
+template <typename R>
 aoclsparse_status launch_cdiff(hipStream_t s, aoclsparse_int n, const cplx<R> *x, const cplx<R> *y, cplx<R> *w);
 // d = sum conj(x_i) y_i; partial holds 1024 elements
 template <typename R>

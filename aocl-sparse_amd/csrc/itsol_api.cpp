@@ -1034,7 +1034,7 @@ struct CSolver
     bool           have_b = false, pinned = false, solving = false, x_dirty = false;
     int            method = solver_cg, task = task_start, precond = 0;
     Options        opts;
-    VBuf           b, xshadow, red_partial, red_out, r, z, p, q, v, zz;
+    VBuf           b, xshadow, red_partial, red_out, r, z, p, q, v, zz, symgs_y;
     Cs             alpha = 0, rz = 0, beta = 0;
     R              rnorm2 = 0, bnorm2 = 0, brtol = 0, rtol = 0, atol = 0;
     aoclsparse_int niter = 0, maxit = 0, j = 0, restart = 0;
@@ -1503,6 +1503,40 @@ inline aoclsparse_status cexec_ilu(aoclsparse_matrix A, const aoclsparse_mat_des
                                     reinterpret_cast<const aoclsparse_float_complex *>(b));
 }
 
+inline aoclsparse_status cexec_trsv(aoclsparse_operation op, aoclsparse_matrix A, const aoclsparse_mat_descr d,
+                                    const cdouble *b, cdouble *x)
+{
+    return aoclsparse_ztrsv(op, aoclsparse_double_complex{1.0, 0.0}, A, d, reinterpret_cast<const aoclsparse_double_complex *>(b),
+                            reinterpret_cast<aoclsparse_double_complex *>(x));
+}
+inline aoclsparse_status cexec_trsv(aoclsparse_operation op, aoclsparse_matrix A, const aoclsparse_mat_descr d,
+                                    const cfloat *b, cfloat *x)
+{
+    return aoclsparse_ctrsv(op, aoclsparse_float_complex{1.0f, 0.0f}, A, d, reinterpret_cast<const aoclsparse_float_complex *>(b),
+                            reinterpret_cast<aoclsparse_float_complex *>(x));
+}
+// the built-in SymGS preconditioner of CG for complex handles: precond_symgs with complex solves and scale
+template <typename R>
+aoclsparse_status cprecond_symgs(Runtime &rt, aoclsparse_matrix A, const aoclsparse_mat_descr descr, const cplx<R> *r,
+                                 cplx<R> *y, cplx<R> *z)
+{
+    if(descr->type != aoclsparse_matrix_type_general && descr->type != aoclsparse_matrix_type_symmetric)
+        return aoclsparse_status_invalid_value;
+    if(descr->diag_type == aoclsparse_diag_type_zero)
+        return aoclsparse_status_invalid_value;
+    _aoclsparse_mat_descr d = *descr;
+    d.type                  = aoclsparse_matrix_type_triangular;
+    const bool lower_direct = descr->type == aoclsparse_matrix_type_general || descr->fill_mode == aoclsparse_fill_mode_lower;
+    d.fill_mode             = lower_direct ? aoclsparse_fill_mode_lower : aoclsparse_fill_mode_upper;
+    MI355_TRY(cexec_trsv(lower_direct ? aoclsparse_operation_none : aoclsparse_operation_transpose, A, &d, r, y));
+    if(descr->diag_type == aoclsparse_diag_type_non_unit)
+        MI355_TRY(launch_cvec_mul<R>(rt.stream(), A->m, A->dev_diag.as<cplx<R>>(), y));
+    const bool upper_direct = descr->type == aoclsparse_matrix_type_general || descr->fill_mode == aoclsparse_fill_mode_upper;
+    d.fill_mode             = upper_direct ? aoclsparse_fill_mode_upper : aoclsparse_fill_mode_lower;
+    MI355_TRY(cexec_trsv(upper_direct ? aoclsparse_operation_none : aoclsparse_operation_transpose, A, &d, y, z));
+    return aoclsparse_status_success;
+}
+
 // aoclsparse_itsol_solve for complex handles: the loop of solve_direct with complex operands.  PT is the public complex
 // struct of the callbacks (layout-identical to cplx<R>).
 template <typename R, typename PT>
@@ -1534,7 +1568,12 @@ aoclsparse_status csolve_direct(CSolver<R> *S, aoclsparse_int n, aoclsparse_matr
         if(descr->type != aoclsparse_matrix_type_symmetric || descr->fill_mode != aoclsparse_fill_mode_lower)
             return aoclsparse_status_invalid_value;
         if(S->precond == 3)
-            return aoclsparse_status_not_implemented; // built-in SymGS: real handles only
+        {
+            if((!mat->opt_csr_full_diag && descr->diag_type != aoclsparse_diag_type_unit)
+               || descr->diag_type == aoclsparse_diag_type_zero)
+                return aoclsparse_status_invalid_value;
+            MI355_TRY(S->symgs_y.alloc(sizeof(C) * (size_t)n, false));
+        }
     }
     if(S->precond == 1 && !precond)
         return aoclsparse_status_invalid_pointer;
@@ -1595,6 +1634,11 @@ aoclsparse_status csolve_direct(CSolver<R> *S, aoclsparse_int n, aoclsparse_matr
                 if(precond(0, n, reinterpret_cast<const PT *>(hu.data()), reinterpret_cast<PT *>(hv.data()), udata) != 0)
                     ircomm = aoclsparse_rci_interrupt;
                 if(hipMemcpy(v, hv.data(), sizeof(C) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess)
+                    return finish(aoclsparse_status_internal_error);
+            }
+            else if(S->method == solver_cg && S->precond == 3)
+            {
+                if(cprecond_symgs<R>(rt, mat, descr, u, S->symgs_y.template as<C>(), v) != aoclsparse_status_success)
                     return finish(aoclsparse_status_internal_error);
             }
             else if(S->method == solver_gmres && S->precond == 2)
