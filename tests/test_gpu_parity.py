@@ -1571,6 +1571,72 @@ def test_randomised_shapes_transposes_float_sp2m_trsm(seed):
                 assert np.array_equal(Xm[:, j], oracle_trsv(base, mt, trp, tci, tv, fill, "n", unit, 2.0, Bm[:, j].copy())[:mt])
 
 
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_randomised_shapes_complex(seed):
+    """third sweep, complex handles: zmv / cmv (general, N / T / H), zcsrmm (both layouts), ztrsv (L / U, N / T / H), zdotmv and
+    sp2m on random shapes down to 1 x 1, both bases, against dense numpy operators within forward-error bounds."""
+    rng = np.random.default_rng(3000 + seed)
+    base = seed % 2
+    m = int(rng.choice([1, 2, 63, 65, 300, 1100]))
+    n = int(rng.choice([1, 3, 64, 257, 900]))
+    rp, ci, vr = random_csr(700 + seed, m, n, lambda r, i: min(n, int(r.integers(0, 14))), base=base)
+    if len(vr) == 0:
+        return
+    for dtype, eps, pre in ((np.complex128, EPS64, "z"), (np.complex64, EPS32, "c")):
+        fn = lambda stem: getattr(L, "aoclsparse_" + stem.replace("?", pre))
+        C = P.CDouble if pre == "z" else P.CFloat
+        v = (vr + 1j * rng.uniform(-1, 1, len(vr))).astype(dtype)
+        D = np.zeros((m, n), np.complex128)
+        for i in range(m):
+            D[i, ci[rp[i] - base:rp[i + 1] - base] - base] = v[rp[i] - base:rp[i + 1] - base]
+        h = ctypes.c_void_p()
+        assert fn("create_?csr")(ctypes.byref(h), base, m, n, len(v), P._ptr(rp), P._ptr(ci), P._ptr(v)) == 0
+        d = P.Descr(base=base)
+        alpha, beta = np.array([0.7 - 0.2j], dtype), np.array([-0.4 + 0.3j], dtype)
+        for op, M in ((P.OP_NONE, D), (P.OP_TRANSPOSE, D.T), (P.OP_CONJ_TRANSPOSE, D.conj().T)):
+            x = (rng.uniform(-1, 1, M.shape[1]) + 1j * rng.uniform(-1, 1, M.shape[1])).astype(dtype)
+            y0 = (rng.uniform(-1, 1, M.shape[0]) + 1j * rng.uniform(-1, 1, M.shape[0])).astype(dtype)
+            y = y0.copy()
+            assert fn("?mv")(op, P._ptr(alpha), h, d.h, P._ptr(x), P._ptr(beta), P._ptr(y)) == 0
+            ref = alpha[0] * (M @ x.astype(np.complex128)) + beta[0] * y0
+            scale = abs(alpha[0]) * (np.abs(M) @ np.abs(x)) + abs(beta[0]) * np.abs(y0)
+            assert np.all(np.abs(y - ref) <= (2 * np.count_nonzero(M, axis=1) + 16) * eps * scale + 1e-30), (pre, op)
+            # csrmm, 5 columns, both layouts
+            k = 5
+            Bm = (rng.uniform(-1, 1, (M.shape[1], k)) + 1j * rng.uniform(-1, 1, (M.shape[1], k))).astype(dtype)
+            C0 = (rng.uniform(-1, 1, (M.shape[0], k)) + 1j * rng.uniform(-1, 1, (M.shape[0], k))).astype(dtype)
+            refm = alpha[0] * (M @ Bm.astype(np.complex128)) + beta[0] * C0
+            scm = abs(alpha[0]) * (np.abs(M) @ np.abs(Bm)) + abs(beta[0]) * np.abs(C0)
+            for order in (P.ORDER_ROW, P.ORDER_COLUMN):
+                Bb = np.ascontiguousarray(Bm if order == P.ORDER_ROW else Bm.T)
+                Cb = np.ascontiguousarray(C0 if order == P.ORDER_ROW else C0.T).copy()
+                ldb, ldc = (k, k) if order == P.ORDER_ROW else (M.shape[1], M.shape[0])
+                assert fn("?csrmm")(op, C(alpha[0].real, alpha[0].imag), h, d.h, order, P._ptr(Bb), k, ldb,
+                                    C(beta[0].real, beta[0].imag), P._ptr(Cb), ldc) == 0
+                got = Cb if order == P.ORDER_ROW else Cb.T
+                assert np.all(np.abs(got - refm) <= (2 * np.count_nonzero(M, axis=1)[:, None] + 80) * eps * scm + 1e-30), (pre, op, order)
+        L.aoclsparse_destroy(ctypes.byref(h))
+    # triangular solves and dotmv on a square diagonally dominant system
+    nt = int(rng.choice([2, 64, 65, 333]))
+    dense, trp, tci, tv = _cplx_tri_system(900 + seed, nt, np.complex128, base)
+    h = ctypes.c_void_p()
+    assert L.aoclsparse_create_zcsr(ctypes.byref(h), base, nt, nt, len(tv), P._ptr(trp), P._ptr(tci), P._ptr(tv)) == 0
+    b = rng.uniform(-1, 1, nt) + 1j * rng.uniform(-1, 1, nt)
+    for fill in ("lower", "upper"):
+        for op, nm in ((P.OP_NONE, "n"), (P.OP_TRANSPOSE, "t"), (P.OP_CONJ_TRANSPOSE, "h")):
+            dt = P.Descr(base=base, mtype=P.TYPE_TRIANGULAR, fill=P.FILL_LOWER if fill == "lower" else P.FILL_UPPER)
+            xr = np.linalg.solve(_op_tri(dense.astype(np.complex128), fill, "non_unit", nm), (0.5 + 0.5j) * b)
+            x = np.zeros(nt, np.complex128)
+            assert L.aoclsparse_ztrsv(op, P.CDouble(0.5, 0.5), h, dt.h, P._ptr(b), P._ptr(x)) == 0
+            assert np.max(np.abs(x - xr)) <= 64 * EPS64 * max(1.0, np.max(np.abs(xr)))
+    dg = P.Descr(base=base)
+    y, dot = np.zeros(nt, np.complex128), np.zeros(1, np.complex128)
+    assert L.aoclsparse_zdotmv(P.OP_NONE, P.CDouble(1, 0), h, dg.h, P._ptr(b), P.CDouble(0, 0), P._ptr(y), P._ptr(dot)) == 0
+    yr = dense.astype(np.complex128) @ b
+    assert np.max(np.abs(y - yr)) <= 64 * EPS64 * np.max(np.abs(yr)) and abs(dot[0] - np.vdot(b, yr)) <= 4 * nt * EPS64 * np.sum(np.abs(b) * np.abs(yr))
+    L.aoclsparse_destroy(ctypes.byref(h))
+
+
 # --------------------------------------------------------------------------------------------------
 # iterative solvers (SURVEY 8f rank 3)
 # --------------------------------------------------------------------------------------------------
