@@ -99,6 +99,28 @@ if "csrmm" in what:
         emit(kind="csrmm-parity", n=n, cols_checked=ns, bit_exact=bool(np.array_equal(C[: ns * m].cpu().numpy(), Cr)))
         del B, C
 
+if "csrmm" in what and not args.small:
+    # block-structured A (tens of non-zeros per row): the row-group kernel and the column-major detour
+    L.aoclsparse_mi355_set_pointer_mode(pkg.PTR_DEVICE)
+    for name, gen in (("shell-like (stand-in)", standins.shell_like), ("flan-like (stand-in)", standins.flan_like)):
+        m, rp, ci, v = gen()
+        nnz = len(v)
+        A = pkg.Matrix(0, m, m, rp, ci, v)
+        assert L.aoclsparse_set_mm_hint(A.h, pkg.OP_NONE, d0.h, 10) == 0 and L.aoclsparse_optimize(A.h) == 0
+        for n in (256, 32):
+            gen_t = torch.Generator(device=dev)
+            gen_t.manual_seed(7)
+            B = torch.rand(m * n, dtype=torch.float64, device=dev, generator=gen_t) * 2 - 1
+            C = torch.zeros(m * n, dtype=torch.float64, device=dev)
+            for order, ld, nm in ((pkg.ORDER_ROW, n, "row-major"), (pkg.ORDER_COLUMN, m, "column-major")):
+                ms = time_calls(lambda: pkg.dcsrmm(pkg.OP_NONE, 1.0, A, d0, order, B, n, ld, 0.0, C, ld), 5, 2)
+                b = csrmm_bytes(m, m, nnz, n, False)
+                emit(kind="csrmm", A="%s m=%d nnz=%d" % (name, m, nnz), n=n, layout=nm, beta=0.0, ms=round(ms, 4),
+                     row_groups=int(A.spmv_info().mm_groups), gflops=round(2.0 * nnz * n / ms / 1e6, 1),
+                     gbs=round(b / ms / 1e6, 1), frac_of_8TBs=round(b / ms / 1e6 / 8000, 4))
+            del B, C
+        del A
+
 if "trsv" in what:
     L.aoclsparse_mi355_set_pointer_mode(pkg.PTR_DEVICE)
     cases = [("ILU(0) of 5-pt Laplacian grid 1000^2", lambda: entry.laplace5(1000))]
