@@ -2,6 +2,7 @@
 // HIP kernels of csrmm_kernels.hip on the device-resident CSR (A^T copy for op != none).
 #include "internal.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -41,6 +42,7 @@ aoclsparse_status build_mm_groups(const HostCsr &h, SpmvPlan &plan)
     if(off || h.m < 2)
         return aoclsparse_status_success;
     std::vector<aoclsparse_int> first;
+    int                         max_rows = 1;
     try
     {
         first.reserve((size_t)h.m / 2 + 2);
@@ -53,6 +55,7 @@ aoclsparse_status build_mm_groups(const HostCsr &h, SpmvPlan &plan)
             while(e < h.m && e - i < CSRMM_GROUP && len > 0 && h.ptr[e + 1] - h.ptr[e] == len
                   && !memcmp(h.ind + s, h.ind + (h.ptr[e] - h.base), sizeof(aoclsparse_int) * (size_t)len))
                 e++;
+            max_rows = std::max(max_rows, (int)(e - i));
             i = e;
         }
         first.push_back(h.m);
@@ -67,7 +70,7 @@ aoclsparse_status build_mm_groups(const HostCsr &h, SpmvPlan &plan)
     aoclsparse_status st = g.first.upload(first.data(), sizeof(aoclsparse_int) * first.size(), Runtime::get().stream());
     if(st != aoclsparse_status_success)
         return st;
-    g.ngroups = ng;
+    g.ngroups = ng, g.max_rows = max_rows;
     g.valid   = true;
     return aoclsparse_status_success;
 }
@@ -215,14 +218,15 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
             if(st == aoclsparse_status_success)
                 st = launch_csrmm<T>(rt.stream(), aoclsparse_order_row, d->base, alpha, d->m, d->n, d->val.as<T>(),
                                      d->ind.as<aoclsparse_int>(), d->ptr.as<aoclsparse_int>(), static_cast<const T *>(bt),
-                                     n, n, beta, static_cast<T *>(ct), n, grp, ngrp);
+                                     n, n, beta, static_cast<T *>(ct), n, grp, ngrp, grouped ? p->mm.max_rows : 0);
             if(st == aoclsparse_status_success)
                 st = launch_relayout<T>(rt.stream(), false, static_cast<const T *>(ct), static_cast<T *>(dC), m_c, n, ldc);
         }
         else
             st = launch_csrmm<T>(rt.stream(), order, d->base, alpha, d->m, d->n, d->val.as<T>(),
                                  d->ind.as<aoclsparse_int>(), d->ptr.as<aoclsparse_int>(), static_cast<const T *>(dB),
-                                 n, ldb, beta, static_cast<T *>(dC), ldc, colmaj ? nullptr : grp, colmaj ? 0 : ngrp);
+                                 n, ldb, beta, static_cast<T *>(dC), ldc, colmaj ? nullptr : grp, colmaj ? 0 : ngrp,
+                                 grouped ? p->mm.max_rows : 0);
     }
     return st == aoclsparse_status_success ? finish() : st;
 }

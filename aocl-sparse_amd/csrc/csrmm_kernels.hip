@@ -19,6 +19,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace mi355
 {
 
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(256) void csrmm_row_wave_kernel(int base, T alpha, 
 // entry sits at row_ptr[ii] + k for every row of the group).  Per output element the FMA chain is still the row in
 // CSR order, so the result equals the other kernels' bit for bit.  Groups are found once per handle on the host
 // (csrmm_api.cpp: build_mm_groups) and capped at CSRMM_GROUP rows.
-template <typename T>
+template <typename T, int GR>
 __global__ __launch_bounds__(256) void csrmm_rowgroup_kernel(int base, T alpha, aoclsparse_int ngroups,
                                                              const aoclsparse_int *__restrict__ grp,
                                                              const T *__restrict__ val,
@@ -183,15 +185,15 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup_kernel(int base, T alpha, 
     const int j  = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
     if(gi >= ngroups || j >= n)
         return;
-    const int i0 = grp[gi], r = grp[gi + 1] - i0; // 1 <= r <= CSRMM_GROUP
+    const int i0 = grp[gi], r = grp[gi + 1] - i0; // 1 <= r <= GR
     const int s0 = row_ptr[i0] - base, len = row_ptr[i0 + 1] - base - s0;
-    int       so[CSRMM_GROUP]; // start of every row of the group (wave-uniform)
+    int       so[GR]; // start of every row of the group (wave-uniform)
 #pragma unroll
-    for(int q = 0; q < CSRMM_GROUP; q++)
+    for(int q = 0; q < GR; q++)
         so[q] = q < r ? row_ptr[i0 + q] - base : s0;
-    T acc0[CSRMM_GROUP], acc1[CSRMM_GROUP];
+    T acc0[GR], acc1[GR];
 #pragma unroll
-    for(int q = 0; q < CSRMM_GROUP; q++)
+    for(int q = 0; q < GR; q++)
         acc0[q] = T(0), acc1[q] = T(0);
     const T *Bj = B + j;
     int      k  = 0;
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup_kernel(int base, T alpha, 
         for(int u = 0; u < 8; u++)
             b[u] = *reinterpret_cast<const V *>(Bj + (size_t)(col[s0 + k + u] - base) * ldb);
 #pragma unroll
-        for(int q = 0; q < CSRMM_GROUP; q++)
+        for(int q = 0; q < GR; q++)
             if(q < r)
             {
                 T a[8];
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup_kernel(int base, T alpha, 
         for(int u = 0; u < 4; u++)
             b[u] = *reinterpret_cast<const V *>(Bj + (size_t)(col[s0 + k + u] - base) * ldb);
 #pragma unroll
-        for(int q = 0; q < CSRMM_GROUP; q++)
+        for(int q = 0; q < GR; q++)
             if(q < r)
             {
                 T a[4];
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup_kernel(int base, T alpha, 
     {
         const V b0 = *reinterpret_cast<const V *>(Bj + (size_t)(col[s0 + k] - base) * ldb);
 #pragma unroll
-        for(int q = 0; q < CSRMM_GROUP; q++)
+        for(int q = 0; q < GR; q++)
             if(q < r)
             {
                 const T a0 = val[so[q] + k];
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup_kernel(int base, T alpha, 
             }
     }
 #pragma unroll
-    for(int q = 0; q < CSRMM_GROUP; q++)
+    for(int q = 0; q < GR; q++)
         if(q < r)
         {
             V      *cp = reinterpret_cast<V *>(C + (size_t)(i0 + q) * ldc + j);
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup_kernel(int base, T alpha, 
 
 // narrower B (32 <= n < 128): LANES lanes (2 columns each) per group, 64 / LANES groups per wavefront; the group's
 // row_ptr / col / val loads are then per-lane loads of one address per sub-wave instead of scalar loads
-template <typename T, int LANES>
+template <typename T, int LANES, int GR>
 __global__ __launch_bounds__(256) void csrmm_rowgroup_sub_kernel(int base, T alpha, aoclsparse_int ngroups,
                                                              const aoclsparse_int *__restrict__ grp,
                                                              const T *__restrict__ val,
@@ -281,15 +283,15 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup_sub_kernel(int base, T alp
     const int j  = 2 * ((int)threadIdx.x % LANES) + 2 * LANES * (int)blockIdx.y;
     if(gi >= ngroups || j >= n)
         return;
-    const int i0 = grp[gi], r = grp[gi + 1] - i0; // 1 <= r <= CSRMM_GROUP
+    const int i0 = grp[gi], r = grp[gi + 1] - i0; // 1 <= r <= GR
     const int s0 = row_ptr[i0] - base, len = row_ptr[i0 + 1] - base - s0;
-    int       so[CSRMM_GROUP]; // start of every row of the group (wave-uniform)
+    int       so[GR]; // start of every row of the group (wave-uniform)
 #pragma unroll
-    for(int q = 0; q < CSRMM_GROUP; q++)
+    for(int q = 0; q < GR; q++)
         so[q] = q < r ? row_ptr[i0 + q] - base : s0;
-    T acc0[CSRMM_GROUP], acc1[CSRMM_GROUP];
+    T acc0[GR], acc1[GR];
 #pragma unroll
-    for(int q = 0; q < CSRMM_GROUP; q++)
+    for(int q = 0; q < GR; q++)
         acc0[q] = T(0), acc1[q] = T(0);
     const T *Bj = B + j;
     int      k  = 0;
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup_sub_kernel(int base, T alp
         for(int u = 0; u < 8; u++)
             b[u] = *reinterpret_cast<const V *>(Bj + (size_t)(col[s0 + k + u] - base) * ldb);
 #pragma unroll
-        for(int q = 0; q < CSRMM_GROUP; q++)
+        for(int q = 0; q < GR; q++)
             if(q < r)
             {
                 T a[8];
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup_sub_kernel(int base, T alp
         for(int u = 0; u < 4; u++)
             b[u] = *reinterpret_cast<const V *>(Bj + (size_t)(col[s0 + k + u] - base) * ldb);
 #pragma unroll
-        for(int q = 0; q < CSRMM_GROUP; q++)
+        for(int q = 0; q < GR; q++)
             if(q < r)
             {
                 T a[4];
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup_sub_kernel(int base, T alp
     {
         const V b0 = *reinterpret_cast<const V *>(Bj + (size_t)(col[s0 + k] - base) * ldb);
 #pragma unroll
-        for(int q = 0; q < CSRMM_GROUP; q++)
+        for(int q = 0; q < GR; q++)
             if(q < r)
             {
                 const T a0 = val[so[q] + k];
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup_sub_kernel(int base, T alp
             }
     }
 #pragma unroll
-    for(int q = 0; q < CSRMM_GROUP; q++)
+    for(int q = 0; q < GR; q++)
         if(q < r)
         {
             V      *cp = reinterpret_cast<V *>(C + (size_t)(i0 + q) * ldc + j);
@@ -501,7 +503,7 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
                                aoclsparse_int /*k*/, const T *val, const aoclsparse_int *col,
                                const aoclsparse_int *row_ptr, const T *B, aoclsparse_int n,
                                aoclsparse_int ldb, T beta, T *C, aoclsparse_int ldc, const aoclsparse_int *grp,
-                               aoclsparse_int ngroups)
+                               aoclsparse_int ngroups, int group_rows)
 {
     if(m <= 0 || n <= 0)
         return aoclsparse_status_success;
@@ -529,26 +531,36 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
         const int lanes = vec ? n / 2 : n;
         const int tx    = lanes >= 128 ? 128 : pow2_at_least(lanes);
         const int ty    = 256 / tx;
-        if(vec && n >= 128 && grp && ngroups > 0)
+        if(vec && n >= 32 && grp && ngroups > 0)
         {
-            const int gx = grid_x((ngroups + 3) / 4, chunk);
-            hipLaunchKernelGGL((csrmm_rowgroup_kernel<T>), dim3(gx, (n + 127) / 128), dim3(256), 0, s, base, alpha,
-                               ngroups, grp, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk);
-        }
-        else if(vec && n >= 32 && grp && ngroups > 0)
-        {
-            if(n >= 64)
-            {
-                const int gx = grid_x((ngroups + 7) / 8, chunk);
-                hipLaunchKernelGGL((csrmm_rowgroup_sub_kernel<T, 32>), dim3(gx, (n + 63) / 64), dim3(256), 0, s, base, alpha,
-                                   ngroups, grp, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk);
-            }
+            // accumulators are sized by the largest group the matrix actually has (2, 4 or 8 rows)
+            auto go = [&](auto gr_tag) {
+                constexpr int GR = decltype(gr_tag)::value;
+                if(n >= 128)
+                {
+                    const int gx = grid_x((ngroups + 3) / 4, chunk);
+                    hipLaunchKernelGGL((csrmm_rowgroup_kernel<T, GR>), dim3(gx, (n + 127) / 128), dim3(256), 0, s, base, alpha,
+                                       ngroups, grp, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk);
+                }
+                else if(n >= 64)
+                {
+                    const int gx = grid_x((ngroups + 7) / 8, chunk);
+                    hipLaunchKernelGGL((csrmm_rowgroup_sub_kernel<T, 32, GR>), dim3(gx, (n + 63) / 64), dim3(256), 0, s, base,
+                                       alpha, ngroups, grp, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk);
+                }
+                else
+                {
+                    const int gx = grid_x((ngroups + 15) / 16, chunk);
+                    hipLaunchKernelGGL((csrmm_rowgroup_sub_kernel<T, 16, GR>), dim3(gx, (n + 31) / 32), dim3(256), 0, s, base,
+                                       alpha, ngroups, grp, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk);
+                }
+            };
+            if(group_rows <= 2)
+                go(std::integral_constant<int, 2>{});
+            else if(group_rows <= 4)
+                go(std::integral_constant<int, 4>{});
             else
-            {
-                const int gx = grid_x((ngroups + 15) / 16, chunk);
-                hipLaunchKernelGGL((csrmm_rowgroup_sub_kernel<T, 16>), dim3(gx, (n + 31) / 32), dim3(256), 0, s, base, alpha,
-                                   ngroups, grp, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk);
-            }
+                go(std::integral_constant<int, CSRMM_GROUP>{});
         }
         else if(vec && n >= 128)
         {
@@ -620,7 +632,7 @@ aoclsparse_status launch_relayout(hipStream_t s, bool to_row_major, const T *src
                                                aoclsparse_int, const T *, const aoclsparse_int *,             \
                                                const aoclsparse_int *, const T *, aoclsparse_int,             \
                                                aoclsparse_int, T, T *, aoclsparse_int, const aoclsparse_int *, \
-                                               aoclsparse_int);                                               \
+                                               aoclsparse_int, int);                                          \
     template aoclsparse_status launch_scale_dense<T>(hipStream_t, aoclsparse_order, T *, aoclsparse_int,     \
                                                      aoclsparse_int, aoclsparse_int, T);                     \
     template aoclsparse_status launch_relayout<T>(hipStream_t, bool, const T *, T *, aoclsparse_int,         \
@@ -643,5 +655,5 @@ extern "C" aoclsparse_status mi355_dcsrmm(void *stream, aoclsparse_int order, ao
     if((order != aoclsparse_order_row && order != aoclsparse_order_column) || (base != 0 && base != 1))
         return aoclsparse_status_invalid_value;
     return mi355::launch_csrmm<double>((hipStream_t)stream, (aoclsparse_order)order, base, alpha, m, k, val, col,
-                                       row_ptr, B, n, ldb, beta, C, ldc, nullptr, 0);
+                                       row_ptr, B, n, ldb, beta, C, ldc, nullptr, 0, 0);
 }

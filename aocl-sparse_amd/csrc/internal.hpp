@@ -178,6 +178,7 @@ constexpr int CSRMM_GROUP = 8; // rows per group at most
 struct MmGroups
 {
     aoclsparse_int ngroups = 0;
+    int            max_rows = 0; // rows of the largest group
     DeviceBuffer   first; // ngroups + 1 row indices
     bool           valid = false, tried = false;
 };
@@ -581,7 +582,8 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
                                aoclsparse_int m, aoclsparse_int k, const T *val,
                                const aoclsparse_int *col, const aoclsparse_int *row_ptr, const T *B,
                                aoclsparse_int n, aoclsparse_int ldb, T beta, T *C,
-                               aoclsparse_int ldc, const aoclsparse_int *grp = nullptr, aoclsparse_int ngroups = 0);
+                               aoclsparse_int ldc, const aoclsparse_int *grp = nullptr, aoclsparse_int ngroups = 0,
+                               int group_rows = 0);
 template <typename T>
 aoclsparse_status launch_relayout(hipStream_t s, bool to_row_major, const T *src, T *dst, aoclsparse_int R, aoclsparse_int N,
                                   aoclsparse_int ld);
