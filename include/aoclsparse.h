@@ -417,8 +417,9 @@ DLL_PUBLIC aoclsparse_status aoclsparse_dtrsm_kid(const aoclsparse_operation tra
                                                   const aoclsparse_int       kid);
 /* ---- complex handles: creation, export, mutation and y = alpha op(A) x + beta y for every
  * descriptor type (general / symmetric / hermitian / triangular) and operation (N / T / H)
- * (aoclsparse_auxiliary.h:340-345,419-436,735-741,804-822; aoclsparse_functions.h:1280-1296).  Every other
- * executor returns wrong_type for a complex handle. */
+ * (aoclsparse_auxiliary.h:340-345,419-436,735-741,804-822; aoclsparse_functions.h:1280-1296).  The other complex
+ * executors (dotmv, csrmm, trsv / trsm, symgs, ilu_smoother, itsol, sp2m) are declared with their real twins below;
+ * an executor of one value type returns wrong_type for a handle of another. */
 DLL_PUBLIC aoclsparse_status aoclsparse_create_ccsr(aoclsparse_matrix *mat, aoclsparse_index_base base,
                                                     aoclsparse_int M, aoclsparse_int N, aoclsparse_int nnz,
                                                     aoclsparse_int *row_ptr, aoclsparse_int *col_idx,

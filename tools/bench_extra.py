@@ -162,7 +162,7 @@ if "trsv" in what:
         del A
 
 if "cg" in what:
-    # device-resident CG (aoclsparse_itsol_d_solve): every iterate stays in HBM; 3 scalar read-backs per iteration
+    # device-resident CG (aoclsparse_itsol_d_solve): every iterate stays in HBM; one host wait per iteration
     import ctypes
     import time
     L.aoclsparse_mi355_set_pointer_mode(pkg.PTR_AUTO)
