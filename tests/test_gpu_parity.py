@@ -1402,6 +1402,34 @@ def test_sell_not_chosen_for_power_law_rows():
     assert A.spmv_info().kernel == 1
 
 
+def test_user_stream_ordering():
+    """aoclsparse_mi355_set_stream: with device operands every executor is enqueued on the caller's HIP stream, ordered with
+    the caller's own work on it (a producer kernel before, a consumer after), and nothing runs on the null stream."""
+    m, rp, ci, v = laplace5(400)
+    A, d = _hinted(0, m, m, rp, ci, v)
+    x_h = np.random.default_rng(2).uniform(-1, 1, m)
+    so, yr = oracle.dcsrmv(-1, 0, 2.0, m, len(v), v, ci, rp, 3.0 * x_h, 0.0, np.zeros(m))
+    stream = torch.cuda.Stream()
+    old = L.aoclsparse_mi355_get_stream()
+    try:
+        assert L.aoclsparse_mi355_set_stream(ctypes.c_void_p(stream.cuda_stream)) == 0
+        L.aoclsparse_mi355_set_pointer_mode(P.PTR_DEVICE)
+        with torch.cuda.stream(stream):
+            xd = dev(x_h)
+            big = torch.ones(64 * 1024 * 1024, device="cuda")  # keep the stream busy ahead of the product
+            for _ in range(20):
+                big.mul_(1.0000001)
+            xd.mul_(3.0)  # producer on the same stream: the product must see 3 x
+            yd = torch.zeros(m, dtype=torch.float64, device="cuda")
+            assert P.dmv(P.OP_NONE, 2.0, A, d, xd, 0.0, yd) == 0
+            z = yd * 1.0  # consumer on the same stream
+        stream.synchronize()
+        assert np.array_equal(z.cpu().numpy(), yr)
+    finally:
+        L.aoclsparse_mi355_set_stream(ctypes.c_void_p(old))
+        L.aoclsparse_mi355_set_pointer_mode(P.PTR_AUTO)
+
+
 # --------------------------------------------------------------------------------------------------
 # the reference's own example programs, compiled unchanged against this library (oracle/Makefile: samples)
 # --------------------------------------------------------------------------------------------------
