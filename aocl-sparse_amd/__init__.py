@@ -230,6 +230,22 @@ SIGNATURES = {
     "aoclsparse_spmm": (c_int, [c_int, _P, _P, POINTER(_P)]),
     "aoclsparse_dcsr2m": (c_int, [c_int, _P, _P, c_int, _P, _P, c_int, POINTER(_P)]),
     "aoclsparse_scsr2m": (c_int, [c_int, _P, _P, c_int, _P, _P, c_int, POINTER(_P)]),
+    "aoclsparse_ssp2md": (c_int, [c_int, _P, _P, c_int, _P, _P, c_float, c_float, _P, c_int, _I]),
+    "aoclsparse_sspmmd": (c_int, [c_int, _P, _P, c_int, _P, _I]),
+    "aoclsparse_scsr2dense": (c_int, [_I, _I, _P, _P, _P, _P, _P, _I, c_int]),
+    "aoclsparse_sadd": (c_int, [c_int, _P, c_float, _P, POINTER(_P)]),
+    "aoclsparse_dsp2md": (c_int, [c_int, _P, _P, c_int, _P, _P, c_double, c_double, _P, c_int, _I]),
+    "aoclsparse_dspmmd": (c_int, [c_int, _P, _P, c_int, _P, _I]),
+    "aoclsparse_dcsr2dense": (c_int, [_I, _I, _P, _P, _P, _P, _P, _I, c_int]),
+    "aoclsparse_dadd": (c_int, [c_int, _P, c_double, _P, POINTER(_P)]),
+    "aoclsparse_csp2md": (c_int, [c_int, _P, _P, c_int, _P, _P, CFloat, CFloat, _P, c_int, _I]),
+    "aoclsparse_cspmmd": (c_int, [c_int, _P, _P, c_int, _P, _I]),
+    "aoclsparse_ccsr2dense": (c_int, [_I, _I, _P, _P, _P, _P, _P, _I, c_int]),
+    "aoclsparse_cadd": (c_int, [c_int, _P, CFloat, _P, POINTER(_P)]),
+    "aoclsparse_zsp2md": (c_int, [c_int, _P, _P, c_int, _P, _P, CDouble, CDouble, _P, c_int, _I]),
+    "aoclsparse_zspmmd": (c_int, [c_int, _P, _P, c_int, _P, _I]),
+    "aoclsparse_zcsr2dense": (c_int, [_I, _I, _P, _P, _P, _P, _P, _I, c_int]),
+    "aoclsparse_zadd": (c_int, [c_int, _P, CDouble, _P, POINTER(_P)]),
     # include/aoclsparse_mi355.h
     "aoclsparse_mi355_set_pointer_mode": (c_int, [c_int]),
     "aoclsparse_mi355_set_stream": (c_int, [_P]),

@@ -591,6 +591,29 @@ template <typename T>
 aoclsparse_status launch_scale_dense(hipStream_t s, aoclsparse_order order, T *C, aoclsparse_int m,
                                      aoclsparse_int n, aoclsparse_int ld, T beta);
 
+// sp2md_kernels.hip: dense-result product, CSR -> dense, sparse sum
+template <typename T>
+aoclsparse_status launch_dense_scale(hipStream_t s, T *C, aoclsparse_int inner, aoclsparse_int outer, long long ld,
+                                     T beta, bool zero);
+template <typename T>
+aoclsparse_status launch_sp2md(hipStream_t s, aoclsparse_int m, int base_a, const aoclsparse_int *ptr_a,
+                               const aoclsparse_int *ind_a, const T *val_a, bool conj_a, int base_b,
+                               const aoclsparse_int *ptr_b, const aoclsparse_int *ind_b, const T *val_b, bool conj_b,
+                               T alpha, T *C, long long rs, long long cs);
+template <typename T>
+aoclsparse_status launch_csr2dense(hipStream_t s, aoclsparse_int m, int base, const aoclsparse_int *ptr,
+                                   const aoclsparse_int *ind, const T *val, T *A, long long rs, long long cs, int mode,
+                                   int fill, int diag);
+template <typename T>
+aoclsparse_status launch_csradd(hipStream_t s, bool fill, aoclsparse_int m, int base_a, const aoclsparse_int *ptr_a,
+                                const aoclsparse_int *ind_a, const T *val_a, bool conj_a, T alpha, int base_b,
+                                const aoclsparse_int *ptr_b, const aoclsparse_int *ind_b, const T *val_b, int base_c,
+                                const aoclsparse_int *ptr_c, aoclsparse_int *cnt_or_ind_c, T *val_c);
+// a new handle that owns host CSR arrays (sp2m_api.cpp); row_ptr copied when given, else filled with `base`
+aoclsparse_status new_csr_result(aoclsparse_matrix *C, aoclsparse_int m, aoclsparse_int n, aoclsparse_int nnz,
+                                 aoclsparse_matrix_data_type vt, const aoclsparse_int *row_ptr,
+                                 aoclsparse_index_base base = aoclsparse_index_base_zero);
+
 // SpMV plan constants shared by host planner and kernels
 // LDS tile = non-zeros staged per workgroup: 512 (128 threads), 1024 or 2048 (256 threads);
 // rows per stream block (their row_ptr slice is kept in LDS)

@@ -25,6 +25,33 @@ aoclsparse_status launch_spgemm(hipStream_t s, bool fill, aoclsparse_int m, int 
                                 const T *val_b, const long long *slab_off, int *slab_idx, T *slab_val,
                                 const aoclsparse_int *ptr_c, aoclsparse_int *cnt_or_ind_c, T *val_c, bool conj_a,
                                 bool conj_b);
+
+aoclsparse_status new_csr_result(aoclsparse_matrix *C, aoclsparse_int m, aoclsparse_int n, aoclsparse_int nnz,
+                                 aoclsparse_matrix_data_type vt, const aoclsparse_int *row_ptr, aoclsparse_index_base base)
+{
+    _aoclsparse_matrix *c = new(std::nothrow) _aoclsparse_matrix;
+    if(!c)
+        return aoclsparse_status_memory_error;
+    const size_t vs = val_size(vt);
+    c->m = m, c->n = n, c->nnz = nnz, c->base = base, c->val_type = vt;
+    c->user.m = m, c->user.n = n, c->user.nnz = nnz, c->user.base = base;
+    c->user.ptr = new(std::nothrow) aoclsparse_int[(size_t)m + 1];
+    c->user.ind = new(std::nothrow) aoclsparse_int[(size_t)std::max(nnz, 1)];
+    c->user.val = ::operator new(vs * (size_t)std::max(nnz, 1), std::nothrow);
+    c->user.owned = true; // freed by the handle
+    c->owns_user_arrays = true;
+    if(!c->user.ptr || !c->user.ind || !c->user.val)
+    {
+        delete c;
+        return aoclsparse_status_memory_error;
+    }
+    if(row_ptr)
+        std::memcpy(c->user.ptr, row_ptr, sizeof(aoclsparse_int) * ((size_t)m + 1));
+    else
+        std::fill(c->user.ptr, c->user.ptr + m + 1, (aoclsparse_int)base);
+    *C = c;
+    return aoclsparse_status_success;
+}
 }
 
 namespace
@@ -74,33 +101,6 @@ void transpose_of(const Operand<T> &a, Operand<T> &t)
     t.ptr = t.optr.data(), t.ind = t.oind.data(), t.val = t.oval.data();
 }
 
-aoclsparse_status new_result(aoclsparse_matrix *C, aoclsparse_int m, aoclsparse_int n, aoclsparse_int nnz,
-                             aoclsparse_matrix_data_type vt, const aoclsparse_int *row_ptr)
-{
-    _aoclsparse_matrix *c = new(std::nothrow) _aoclsparse_matrix;
-    if(!c)
-        return aoclsparse_status_memory_error;
-    const size_t vs = val_size(vt);
-    c->m = m, c->n = n, c->nnz = nnz, c->base = aoclsparse_index_base_zero, c->val_type = vt;
-    c->user.m = m, c->user.n = n, c->user.nnz = nnz, c->user.base = aoclsparse_index_base_zero;
-    c->user.ptr = new(std::nothrow) aoclsparse_int[(size_t)m + 1];
-    c->user.ind = new(std::nothrow) aoclsparse_int[(size_t)std::max(nnz, 1)];
-    c->user.val = ::operator new(vs * (size_t)std::max(nnz, 1), std::nothrow);
-    c->user.owned = true; // freed by the handle
-    c->owns_user_arrays = true;
-    if(!c->user.ptr || !c->user.ind || !c->user.val)
-    {
-        delete c;
-        return aoclsparse_status_memory_error;
-    }
-    if(row_ptr)
-        std::memcpy(c->user.ptr, row_ptr, sizeof(aoclsparse_int) * ((size_t)m + 1));
-    else
-        std::fill(c->user.ptr, c->user.ptr + m + 1, 0);
-    *C = c;
-    return aoclsparse_status_success;
-}
-
 template <typename T>
 aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr descrA, const aoclsparse_matrix A,
                          aoclsparse_operation opB, const aoclsparse_mat_descr descrB, const aoclsparse_matrix B,
@@ -144,7 +144,7 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
     if(m_a == 0 || n_a == 0 || n_b == 0 || A->nnz == 0 || B->nnz == 0)
     {
         if(*C == nullptr) // csr2m.cpp:705-735: valid empty result
-            return new_result(C, m_a, n_b, 0, vt, nullptr);
+            return new_csr_result(C, m_a, n_b, 0, vt, nullptr);
         return aoclsparse_status_success;
     }
 
@@ -243,7 +243,7 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
             if(opflag == 3)
             {
                 // C is n x m; keep D's row_ptr in the handle's transposed-product scratch until finalize
-                st = new_result(C, n, m, nnz_c, vt, nullptr);
+                st = new_csr_result(C, n, m, nnz_c, vt, nullptr);
                 if(st != aoclsparse_status_success)
                     return st;
                 (*C)->trans.reset(new HostCsr);
@@ -256,7 +256,7 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
             }
             else
             {
-                st = new_result(C, m, n, nnz_c, vt, cptr.data());
+                st = new_csr_result(C, m, n, nnz_c, vt, cptr.data());
                 if(st != aoclsparse_status_success)
                     return st;
             }

@@ -953,6 +953,74 @@ DLL_PUBLIC aoclsparse_status aoclsparse_scsr2m(aoclsparse_operation       trans_
                                                const aoclsparse_request   request,
                                                aoclsparse_matrix         *csrC);
 
+/* ---- sparse x sparse with a dense result, CSR -> dense, sparse sum ------------------------------------------
+ * Replaces library/include/aoclsparse_functions.h:2546-2586 (?spmmd), :2674-2720 (?sp2md), :2856-2882 (?add) and
+ * library/include/aoclsparse_convert.h:566-610 (?csr2dense).  C / A may be host or device memory. */
+DLL_PUBLIC aoclsparse_status aoclsparse_ssp2md(const aoclsparse_operation opA, const aoclsparse_mat_descr descrA,
+                                               const aoclsparse_matrix A, const aoclsparse_operation opB,
+                                               const aoclsparse_mat_descr descrB, const aoclsparse_matrix B,
+                                               const float alpha, const float beta, float *C,
+                                               const aoclsparse_order layout, const aoclsparse_int ldc);
+DLL_PUBLIC aoclsparse_status aoclsparse_dsp2md(const aoclsparse_operation opA, const aoclsparse_mat_descr descrA,
+                                               const aoclsparse_matrix A, const aoclsparse_operation opB,
+                                               const aoclsparse_mat_descr descrB, const aoclsparse_matrix B,
+                                               const double alpha, const double beta, double *C,
+                                               const aoclsparse_order layout, const aoclsparse_int ldc);
+DLL_PUBLIC aoclsparse_status aoclsparse_csp2md(const aoclsparse_operation opA, const aoclsparse_mat_descr descrA,
+                                               const aoclsparse_matrix A, const aoclsparse_operation opB,
+                                               const aoclsparse_mat_descr descrB, const aoclsparse_matrix B,
+                                               const aoclsparse_float_complex alpha, const aoclsparse_float_complex beta, aoclsparse_float_complex *C,
+                                               const aoclsparse_order layout, const aoclsparse_int ldc);
+DLL_PUBLIC aoclsparse_status aoclsparse_zsp2md(const aoclsparse_operation opA, const aoclsparse_mat_descr descrA,
+                                               const aoclsparse_matrix A, const aoclsparse_operation opB,
+                                               const aoclsparse_mat_descr descrB, const aoclsparse_matrix B,
+                                               const aoclsparse_double_complex alpha, const aoclsparse_double_complex beta, aoclsparse_double_complex *C,
+                                               const aoclsparse_order layout, const aoclsparse_int ldc);
+DLL_PUBLIC aoclsparse_status aoclsparse_sspmmd(const aoclsparse_operation op, const aoclsparse_matrix A,
+                                               const aoclsparse_matrix B, const aoclsparse_order layout,
+                                               float *C, const aoclsparse_int ldc);
+DLL_PUBLIC aoclsparse_status aoclsparse_dspmmd(const aoclsparse_operation op, const aoclsparse_matrix A,
+                                               const aoclsparse_matrix B, const aoclsparse_order layout,
+                                               double *C, const aoclsparse_int ldc);
+DLL_PUBLIC aoclsparse_status aoclsparse_cspmmd(const aoclsparse_operation op, const aoclsparse_matrix A,
+                                               const aoclsparse_matrix B, const aoclsparse_order layout,
+                                               aoclsparse_float_complex *C, const aoclsparse_int ldc);
+DLL_PUBLIC aoclsparse_status aoclsparse_zspmmd(const aoclsparse_operation op, const aoclsparse_matrix A,
+                                               const aoclsparse_matrix B, const aoclsparse_order layout,
+                                               aoclsparse_double_complex *C, const aoclsparse_int ldc);
+DLL_PUBLIC aoclsparse_status aoclsparse_scsr2dense(aoclsparse_int m, aoclsparse_int n,
+                                                   const aoclsparse_mat_descr descr, const float *csr_val,
+                                                   const aoclsparse_int *csr_row_ptr,
+                                                   const aoclsparse_int *csr_col_ind, float *A,
+                                                   aoclsparse_int ld, aoclsparse_order order);
+DLL_PUBLIC aoclsparse_status aoclsparse_dcsr2dense(aoclsparse_int m, aoclsparse_int n,
+                                                   const aoclsparse_mat_descr descr, const double *csr_val,
+                                                   const aoclsparse_int *csr_row_ptr,
+                                                   const aoclsparse_int *csr_col_ind, double *A,
+                                                   aoclsparse_int ld, aoclsparse_order order);
+DLL_PUBLIC aoclsparse_status aoclsparse_ccsr2dense(aoclsparse_int m, aoclsparse_int n,
+                                                   const aoclsparse_mat_descr descr, const aoclsparse_float_complex *csr_val,
+                                                   const aoclsparse_int *csr_row_ptr,
+                                                   const aoclsparse_int *csr_col_ind, aoclsparse_float_complex *A,
+                                                   aoclsparse_int ld, aoclsparse_order order);
+DLL_PUBLIC aoclsparse_status aoclsparse_zcsr2dense(aoclsparse_int m, aoclsparse_int n,
+                                                   const aoclsparse_mat_descr descr, const aoclsparse_double_complex *csr_val,
+                                                   const aoclsparse_int *csr_row_ptr,
+                                                   const aoclsparse_int *csr_col_ind, aoclsparse_double_complex *A,
+                                                   aoclsparse_int ld, aoclsparse_order order);
+DLL_PUBLIC aoclsparse_status aoclsparse_sadd(const aoclsparse_operation op, const aoclsparse_matrix A,
+                                             const float alpha, const aoclsparse_matrix B,
+                                             aoclsparse_matrix *C);
+DLL_PUBLIC aoclsparse_status aoclsparse_dadd(const aoclsparse_operation op, const aoclsparse_matrix A,
+                                             const double alpha, const aoclsparse_matrix B,
+                                             aoclsparse_matrix *C);
+DLL_PUBLIC aoclsparse_status aoclsparse_cadd(const aoclsparse_operation op, const aoclsparse_matrix A,
+                                             const aoclsparse_float_complex alpha, const aoclsparse_matrix B,
+                                             aoclsparse_matrix *C);
+DLL_PUBLIC aoclsparse_status aoclsparse_zadd(const aoclsparse_operation op, const aoclsparse_matrix A,
+                                             const aoclsparse_double_complex alpha, const aoclsparse_matrix B,
+                                             aoclsparse_matrix *C);
+
 #ifdef __cplusplus
 }
 #endif

@@ -387,6 +387,58 @@ def dcsr2m(m, n, base_a, ptr_a, ind_a, val_a, base_b, ptr_b, ind_b, val_b):
     return st, ptr_c, ind_c[: nnz_c.value], val_c[: nnz_c.value]
 
 
+def _op_operand(m, n, base, ptr, ind, val, trans):
+    """The operand after op handling: the stable csr2csc transpose the reference's drivers build (same base)."""
+    ptr, ind, val = _i32(ptr), _i32(ind), _f64(val)
+    if not trans:
+        return m, n, ptr, ind, val
+    nnz = int(ptr[m] - base)
+    st, cp, ri, cv = dcsr2csc(m, n, nnz, base, base, ptr, ind, val)
+    assert st == 0
+    return n, m, cp, _i32(ri), _f64(cv)
+
+
+def dsp2md(a, trans_a, b, trans_b, alpha, beta, C, rowmajor, ldc):
+    """C = alpha*op(A)*op(B) + beta*C, dense C (level3/aoclsparse_sp2md.hpp:179-431).  a / b = (m, n, base, ptr, ind,
+    val); C is the flat outer x ldc storage.  Returns the updated copy."""
+    ma, na, pa, ia, va = _op_operand(*a, trans_a)
+    mb, nb, pb, ib, vb = _op_operand(*b, trans_b)
+    assert na == mb
+    C = np.array(C, dtype=np.float64).ravel().copy()
+    outer, inner = (ma, nb) if rowmajor else (nb, ma)
+    lib().orc_dsp2md_scale(c_i32(outer), c_i32(inner), c_i32(ldc), c_dbl(beta), _p(C))
+    if alpha != 0.0:
+        rs, cs = (ldc, 1) if rowmajor else (1, ldc)
+        lib().orc_dsp2md(c_i32(ma), c_int(a[2]), _p(pa), _p(ia), _p(va), c_int(b[2]), _p(pb), _p(ib), _p(vb),
+                         c_dbl(alpha), _p(C), ctypes.c_longlong(rs), ctypes.c_longlong(cs))
+    return C
+
+
+def dcsr2dense(m, n, base, ptr, ind, val, A, ld, colmajor, mode=0, fill=0, diag=0):
+    """conversion/aoclsparse_convert.hpp:658-929; A is the flat outer x ld storage (padding kept)."""
+    ptr, ind, val = _i32(ptr), _i32(ind), _f64(val)
+    A = np.array(A, dtype=np.float64).ravel().copy()
+    lib().orc_dcsr2dense(c_i32(m), c_i32(n), c_int(base), _p(ptr), _p(ind), _p(val), _p(A), c_i32(ld),
+                         c_int(1 if colmajor else 0), c_int(mode), c_int(fill), c_int(diag))
+    return A
+
+
+def dcsradd(a, trans_a, alpha, b):
+    """C = alpha*op(A) + B (level3/aoclsparse_csradd.hpp:283-532).  Returns (ptr, ind, val) in A's base."""
+    ma, na, pa, ia, va = _op_operand(*a, trans_a)
+    mb, nb, base_b, pb, ib, vb = b[0], b[1], b[2], _i32(b[3]), _i32(b[4]), _f64(b[5])
+    assert (ma, na) == (mb, nb)
+    cap = max(len(ia) + len(ib), 1)
+    pc = np.zeros(ma + 1, dtype=np.int32)
+    ic = np.zeros(cap, dtype=np.int32)
+    vc = np.zeros(cap, dtype=np.float64)
+    lib().orc_dcsradd.restype = c_i32
+    w = lib().orc_dcsradd(c_i32(ma), c_i32(na), c_int(a[2]), _p(pa), _p(ia), _p(va), c_dbl(alpha), c_int(base_b),
+                          _p(pb), _p(ib), _p(vb), _p(pc), _p(ic), _p(vc))
+    assert w >= 0
+    return pc, ic[:w], vc[:w]
+
+
 # ---- complex CG / GMRES, numpy restatements of solvers/aoclsparse_itsol_functions.hpp:632-875 and :910-1367 for
 # T = std::complex (dense operator A; no preconditioner).  No reference vectors exist for them: parity unpinned, the
 # checks are exit status, iteration counts and the solver tolerances.

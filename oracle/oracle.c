@@ -1694,3 +1694,121 @@ int orc_dcsr2m_fill(oint m, oint n, int base_a, const oint *ptr_a, const oint *i
     free(asum);
     return st;
 }
+
+
+/* ---- sparse x sparse with a dense result: level3/aoclsparse_sp2md.hpp:40-168 ---------------------------------
+ * (A, B) are the operands AFTER op handling (the driver transposes with the stable csr2csc, :286-347); rs / cs are
+ * the element strides of a row / column step of C, so both layout kernels (:40-99 column, :101-168 row) are this
+ * one loop nest.  C(i,c) += (alpha*a) * b, contracted. */
+void orc_dsp2md(oint m, int base_a, const oint *ptr_a, const oint *ind_a, const double *val_a, int base_b,
+                const oint *ptr_b, const oint *ind_b, const double *val_b, double alpha, double *C, long long rs,
+                long long cs)
+{
+    for(oint i = 0; i < m; i++)
+        for(oint j = ptr_a[i] - base_a; j < ptr_a[i + 1] - base_a; j++)
+        {
+            const double v  = alpha * val_a[j];
+            const oint   ca = ind_a[j] - base_a;
+            for(oint k = ptr_b[ca] - base_b; k < ptr_b[ca + 1] - base_b; k++)
+            {
+                double *p = C + (long long)i * rs + (long long)(ind_b[k] - base_b) * cs;
+                *p        = fma(v, val_b[k], *p);
+            }
+        }
+}
+
+/* sp2md.hpp:362-379 / :407-420: beta == 0 stores zeros, beta == 1 leaves C alone, otherwise C *= beta */
+void orc_dsp2md_scale(oint outer, oint inner, oint ld, double beta, double *C)
+{
+    if(beta == 1.0)
+        return;
+    for(oint o = 0; o < outer; o++)
+        for(oint i = 0; i < inner; i++)
+            C[(size_t)o * ld + i] = beta == 0.0 ? 0.0 : beta * C[(size_t)o * ld + i];
+}
+
+/* ---- CSR -> dense: conversion/aoclsparse_convert.hpp:658-929 ---------------------------------------------------
+ * mode 0 general, 1 symmetric, 2 hermitian, 3 triangular; fill 0 lower / 1 upper; diag 0 non-unit, 1 unit, 2 zero.
+ * The reference's column-major symmetric branch addresses through row*ld for the diagonal and both mirrors
+ * (:770-806); with rs/cs strides that is this same walk. */
+void orc_dcsr2dense(oint m, oint n, int base, const oint *ptr, const oint *ind, const double *val, double *A,
+                    oint ld, int colmajor, int mode, int fill, int diag)
+{
+    const long long rs = colmajor ? 1 : ld, cs = colmajor ? ld : 1;
+    for(oint r = 0; r < m; r++)
+        for(oint c = 0; c < n; c++)
+            A[r * rs + c * cs] = 0.0;
+    for(oint r = 0; r < m; r++)
+    {
+        if(mode != 0 && diag == 1)
+            A[r * rs + r * cs] = 1.0;
+        else if(mode != 0 && diag == 2)
+            A[r * rs + r * cs] = 0.0;
+        for(oint at = ptr[r] - base; at < ptr[r + 1] - base; at++)
+        {
+            const oint c = ind[at] - base;
+            if(mode == 0)
+                A[r * rs + c * cs] = val[at];
+            else if(c == r)
+            {
+                if(diag == 0)
+                    A[r * rs + c * cs] = val[at];
+            }
+            else if((fill == 0 && c < r) || (fill == 1 && c > r))
+            {
+                A[r * rs + c * cs] = val[at];
+                if(mode == 1 || mode == 2)
+                    A[c * rs + r * cs] = val[at];
+            }
+        }
+    }
+}
+
+/* ---- C = alpha*A + B: level3/aoclsparse_csradd.hpp:137-281, single-thread branch ------------------------------
+ * A is the operand after op handling.  Row i of C: every entry of A's row (scaled), then B's entries whose column is
+ * new, in B's order; the others are added onto the recorded slot.  C's indices carry A's base.  ptr_c has m+1
+ * entries, ind_c / val_c room for nnz_a + nnz_b.  Returns nnz(C). */
+oint orc_dcsradd(oint m, oint n, int base_a, const oint *ptr_a, const oint *ind_a, const double *val_a, double alpha,
+                 int base_b, const oint *ptr_b, const oint *ind_b, const double *val_b, oint *ptr_c, oint *ind_c,
+                 double *val_c)
+{
+    oint *mark = (oint *)malloc(sizeof(oint) * ((size_t)n + 2));
+    oint *rec  = (oint *)malloc(sizeof(oint) * ((size_t)n + 2));
+    if(!mark || !rec)
+    {
+        free(mark);
+        free(rec);
+        return -1;
+    }
+    for(oint i = 0; i < n + 2; i++)
+        mark[i] = rec[i] = -1;
+    oint w   = 0;
+    ptr_c[0] = base_a;
+    for(oint i = 0; i < m; i++)
+    {
+        for(oint j = ptr_a[i] - base_a; j < ptr_a[i + 1] - base_a; j++)
+        {
+            const oint c = ind_a[j]; /* with A's base in place, :245 */
+            mark[c]      = i;
+            rec[c]       = w;
+            ind_c[w]     = c;
+            val_c[w++]   = alpha * val_a[j];
+        }
+        for(oint j = ptr_b[i] - base_b; j < ptr_b[i + 1] - base_b; j++)
+        {
+            const oint c = ind_b[j] - base_b + base_a;
+            if(mark[c] != i)
+            {
+                ind_c[w]   = c;
+                val_c[w++] = val_b[j];
+                mark[c]    = i;
+            }
+            else
+                val_c[rec[c]] += val_b[j];
+        }
+        ptr_c[i + 1] = w + base_a;
+    }
+    free(mark);
+    free(rec);
+    return w;
+}

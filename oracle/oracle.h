@@ -214,6 +214,17 @@ int orc_dcsr2m_fill(oint m, oint n, int base_a, const oint *ptr_a, const oint *i
                     const double *val_a, int base_b, const oint *ptr_b, const oint *ind_b,
                     const double *val_b, const oint *ptr_c, oint *ind_c, double *val_c);
 
+/* dense-result product, CSR -> dense, sparse sum (sp2md.hpp, convert.hpp:658-929, csradd.hpp) */
+void orc_dsp2md(oint m, int base_a, const oint *ptr_a, const oint *ind_a, const double *val_a, int base_b,
+                const oint *ptr_b, const oint *ind_b, const double *val_b, double alpha, double *C, long long rs,
+                long long cs);
+void orc_dsp2md_scale(oint outer, oint inner, oint ld, double beta, double *C);
+void orc_dcsr2dense(oint m, oint n, int base, const oint *ptr, const oint *ind, const double *val, double *A,
+                    oint ld, int colmajor, int mode, int fill, int diag);
+oint orc_dcsradd(oint m, oint n, int base_a, const oint *ptr_a, const oint *ind_a, const double *val_a, double alpha,
+                 int base_b, const oint *ptr_b, const oint *ind_b, const double *val_b, oint *ptr_c, oint *ind_c,
+                 double *val_c);
+
 #ifdef __cplusplus
 }
 #endif

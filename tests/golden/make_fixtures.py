@@ -345,6 +345,23 @@ out["blkcsr"] = dict(
          dict(_blk_common, src="tests/unit_tests/blkcsrmv_tests.cpp:656-676", base=0,
               row_ptr=[0, 1, 2, 2, 10, 12, 14], col_ind=[0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 3, 4, 0, 1])])
 
+# ------------------------------------------------------------------------------------------
+# Dense-result product and CSR -> dense: tests/unit_tests/spmmd_tests.cpp:130-157 (real 3x3 case: C = A*B and
+# C = A^T*B, row-major 3x3) and tests/unit_tests/conversion_tests.cpp:211-252 (5x5, 16 non-zeros; row-major,
+# column-major, and row-major with ld = 8 whose padding stays 0)
+# ------------------------------------------------------------------------------------------
+out["spmmd"] = dict(src="tests/unit_tests/spmmd_tests.cpp:130-157", m=3, k=3, n=3,
+                    a=dict(row_ptr=[0, 2, 3, 6], col_ind=[0, 2, 2, 0, 1, 2], val=[1, 2, 3, 4, 5, 6]),
+                    b=dict(row_ptr=[0, 2, 3, 4], col_ind=[0, 1, 2, 1], val=[1, 2, 3, 4]),
+                    c_none=[1, 10, 0, 0, 12, 0, 4, 32, 15], c_trans=[1, 18, 0, 0, 20, 0, 2, 28, 9])
+out["csr2dense"] = dict(src="tests/unit_tests/conversion_tests.cpp:211-252", m=5, n=5,
+                        row_ptr=[0, 3, 6, 10, 12, 16], col_ind=[0, 1, 4, 1, 2, 4, 0, 1, 2, 3, 2, 3, 0, 1, 2, 4],
+                        val=[1, 1, 4, 2, 4, 1, 2, 1, 8, 2, 4, 1, 3, 6, 2, 1],
+                        rowmajor=[1, 1, 0, 0, 4, 0, 2, 4, 0, 1, 2, 1, 8, 2, 0, 0, 0, 4, 1, 0, 3, 6, 2, 0, 1],
+                        colmajor=[1, 0, 2, 0, 3, 1, 2, 1, 0, 6, 0, 4, 8, 4, 2, 0, 0, 2, 1, 0, 4, 1, 0, 0, 1],
+                        rowmajor_ld8=[1, 1, 0, 0, 4, 0, 0, 0, 0, 2, 4, 0, 1, 0, 0, 0, 2, 1, 8, 2,
+                                      0, 0, 0, 0, 0, 0, 4, 1, 0, 0, 0, 0, 3, 6, 2, 0, 1, 0, 0, 0])
+
 with open(n25_path, "w") as f:
     json.dump(out, f, indent=None, separators=(",", ":"))
     f.write("\n")

@@ -670,3 +670,55 @@ def test_csrsv_argument_checks():
     assert fn(*args(d=P.Descr(base=1).h)) == 1 and fn(*args(d=P.Descr(mtype=P.TYPE_TRIANGULAR).h)) == 1
     assert fn(*args(op=P.OP_TRANSPOSE)) == 1 and fn(*args(m=-1)) == 3 and fn(*args(m=0)) == 0
     assert L.aoclsparse_scsrsv(P.OP_NONE, None, 2, None, None, None, None, None, None) == 2
+
+
+def test_dense_result_and_add_argument_checks():
+    """sp2md.hpp:192-276, spmmd.cpp:47-55, convert.hpp:669-727, csradd.hpp:289-312: every check that precedes the
+    computation, in the reference's order; an empty sum still yields a valid empty handle (csradd.hpp:163-177)."""
+    rp, ci, v = np.array([0, 1, 3], np.int32), np.array([0, 0, 1], np.int32), np.array([2.0, 1.0, 4.0])
+    A, Af = P.Matrix(0, 2, 2, rp, ci, v), P.Matrix(0, 2, 2, rp, ci, v.astype(np.float32))
+    W = P.Matrix(0, 2, 3, rp, np.array([0, 0, 2], np.int32), v)
+    d, ds, d1 = P.Descr(), P.Descr(mtype=P.TYPE_SYMMETRIC), P.Descr(base=1)
+    C = np.zeros(6)
+    f = L.aoclsparse_dsp2md
+    N, T, ROW, COL = P.OP_NONE, P.OP_TRANSPOSE, P.ORDER_ROW, P.ORDER_COLUMN
+    assert f(N, None, A.h, N, d.h, A.h, 1.0, 0.0, P._ptr(C), ROW, 2) == 2
+    assert f(N, ds.h, A.h, N, d.h, A.h, 1.0, 0.0, P._ptr(C), ROW, 2) == 1
+    assert f(N, d.h, A.h, N, d.h, A.h, 1.0, 0.0, P._ptr(C), 7, 2) == 5
+    assert f(N, d.h, None, N, d.h, A.h, 1.0, 0.0, P._ptr(C), ROW, 2) == 2
+    assert f(N, d.h, A.h, N, d.h, A.h, 1.0, 0.0, None, ROW, 2) == 2
+    assert f(N, d.h, A.h, N, d.h, Af.h, 1.0, 0.0, P._ptr(C), ROW, 2) == 9
+    assert f(N, d.h, W.h, N, d.h, A.h, 1.0, 0.0, P._ptr(C), ROW, 3) == 3  # 2x3 * 2x2
+    assert f(T, d.h, W.h, N, d.h, A.h, 1.0, 0.0, P._ptr(C), ROW, 1) == 3  # ldc < n
+    assert f(T, d.h, W.h, N, d.h, A.h, 1.0, 0.0, P._ptr(C), COL, 2) == 3  # ldc < rows of C (3)
+    assert f(N, d1.h, A.h, N, d.h, A.h, 1.0, 0.0, P._ptr(C), ROW, 2) == 5  # descriptor base != matrix base
+    assert L.aoclsparse_dspmmd(N, None, A.h, ROW, P._ptr(C), 2) == 2
+    assert L.aoclsparse_dspmmd(N, A.h, Af.h, ROW, P._ptr(C), 2) == 9
+    assert L.aoclsparse_sspmmd(N, Af.h, Af.h, 9, P._ptr(C), 2) == 5
+    g = L.aoclsparse_dcsr2dense
+    D = np.zeros(4)
+    assert g(2, 2, None, P._ptr(v), P._ptr(rp), P._ptr(ci), P._ptr(D), 2, ROW) == 2
+    assert g(2, 2, P.Descr(mtype=P.TYPE_TRIANGULAR).h, P._ptr(v), P._ptr(rp), P._ptr(ci), P._ptr(D), 2, COL) == 1
+    assert g(2, 2, P.Descr(mtype=P.TYPE_HERMITIAN).h, P._ptr(v), P._ptr(rp), P._ptr(ci), P._ptr(D), 2, COL) == 1
+    assert g(-1, 2, d.h, P._ptr(v), P._ptr(rp), P._ptr(ci), P._ptr(D), 2, ROW) == 3
+    assert g(0, 2, d.h, None, None, None, None, 2, ROW) == 0
+    for k in range(4):
+        a = [P._ptr(v), P._ptr(rp), P._ptr(ci), P._ptr(D)]
+        a[k] = None
+        assert g(2, 2, d.h, a[0], a[1], a[2], a[3], 2, ROW) == 2
+    assert g(2, 2, d.h, P._ptr(v), P._ptr(rp), P._ptr(ci), P._ptr(D), 2 ** 31 - 1, ROW) == 3
+    h = L.aoclsparse_dadd
+    out = ctypes.c_void_p()
+    assert h(N, None, 1.0, A.h, ctypes.byref(out)) == 2 and h(N, A.h, 1.0, A.h, None) == 2
+    assert h(N, A.h, 1.0, Af.h, ctypes.byref(out)) == 9
+    assert h(N, A.h, 1.0, W.h, ctypes.byref(out)) == 3 and h(T, W.h, 1.0, W.h, ctypes.byref(out)) == 3
+    e0 = np.array([1, 1, 1], np.int32)
+    E = P.Matrix(1, 2, 2, e0, np.zeros(1, np.int32), np.zeros(1))
+    assert h(N, E.h, 1.0, E.h, ctypes.byref(out)) == 0 and out.value
+    base, m, n, nnz = ctypes.c_int(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    p0, p1, p2 = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    assert L.aoclsparse_export_dcsr(out, ctypes.byref(base), ctypes.byref(m), ctypes.byref(n), ctypes.byref(nnz),
+                                    ctypes.byref(p0), ctypes.byref(p1), ctypes.byref(p2)) == 0
+    assert (base.value, m.value, n.value, nnz.value) == (1, 2, 2, 0)
+    assert list(np.ctypeslib.as_array(ctypes.cast(p0, ctypes.POINTER(ctypes.c_int32)), (3,))) == [1, 1, 1]
+    assert L.aoclsparse_destroy(ctypes.byref(out)) == 0

@@ -2575,3 +2575,245 @@ def test_trsv_full_config_properties():
     torch.cuda.synchronize()
     r = np.abs(yd.cpu().numpy() - b)
     assert r.max() <= 16 * EPS64 * max(1.0, np.abs(x).max())
+
+
+# --------------------------------------------------------------------------------------------------
+# sparse x sparse with a dense result, CSR -> dense, sparse sum (sp2md.hpp, spmmd.cpp, convert.hpp:658-929, csradd.hpp)
+# --------------------------------------------------------------------------------------------------
+def test_spmmd_and_csr2dense_reference_kats(kats):
+    """spmmd_tests.cpp:130-157 and conversion_tests.cpp:211-252 through the C ABI."""
+    k = kats["spmmd"]
+    for ba in (0, 1):
+        for bb in (0, 1):
+            A = P.Matrix(ba, 3, 3, np.array(k["a"]["row_ptr"], np.int32) + ba, np.array(k["a"]["col_ind"], np.int32) + ba,
+                         np.array(k["a"]["val"], np.float64))
+            B = P.Matrix(bb, 3, 3, np.array(k["b"]["row_ptr"], np.int32) + bb, np.array(k["b"]["col_ind"], np.int32) + bb,
+                         np.array(k["b"]["val"], np.float64))
+            for op, gold in ((P.OP_NONE, k["c_none"]), (P.OP_TRANSPOSE, k["c_trans"]), (P.OP_CONJ_TRANSPOSE, k["c_trans"])):
+                G = np.array(gold, np.float64).reshape(3, 3)
+                C = np.full(9, np.nan)
+                assert L.aoclsparse_dspmmd(op, A.h, B.h, P.ORDER_ROW, P._ptr(C), 3) == 0
+                assert np.array_equal(C.reshape(3, 3), G)
+                C = np.full(15, 7.0)
+                assert L.aoclsparse_dspmmd(op, A.h, B.h, P.ORDER_COLUMN, P._ptr(C), 5) == 0
+                assert np.array_equal(C.reshape(3, 5)[:, :3].T, G) and np.all(C.reshape(3, 5)[:, 3:] == 7.0)
+    k = kats["csr2dense"]
+    rp, ci, v = np.array(k["row_ptr"], np.int32), np.array(k["col_ind"], np.int32), np.array(k["val"], np.float64)
+    d = P.Descr()
+    for gold, ld, order in ((k["rowmajor"], 5, P.ORDER_ROW), (k["colmajor"], 5, P.ORDER_COLUMN), (k["rowmajor_ld8"], 8, P.ORDER_ROW)):
+        D = np.zeros(5 * ld) if ld == 8 else np.full(25, -1.0)
+        assert L.aoclsparse_dcsr2dense(5, 5, d.h, P._ptr(v), P._ptr(rp), P._ptr(ci), P._ptr(D), ld, order) == 0
+        assert np.array_equal(D, np.array(gold, np.float64))
+    D, d1 = np.full(25, -1.0), P.Descr(base=1)
+    rp1, ci1 = rp + 1, ci + 1
+    assert L.aoclsparse_dcsr2dense(5, 5, d1.h, P._ptr(v), P._ptr(rp1), P._ptr(ci1), P._ptr(D), 5, P.ORDER_ROW) == 0
+    assert np.array_equal(D, np.array(k["rowmajor"], np.float64))
+    Df = np.full(25, -1.0, np.float32)
+    vf = v.astype(np.float32)
+    assert L.aoclsparse_scsr2dense(5, 5, d.h, P._ptr(vf), P._ptr(rp), P._ptr(ci), P._ptr(Df), 5, P.ORDER_COLUMN) == 0
+    assert np.array_equal(Df, np.array(k["colmajor"], np.float32))
+
+
+@pytest.mark.parametrize("base_a,base_b", [(0, 0), (1, 0), (0, 1)])
+def test_sp2md_bit_exact_vs_oracle(base_a, base_b):
+    """Every (opA, opB) in {N, T}^2, both layouts, padded ldc, alpha / beta incl. 0 and 1: the dense result carries the
+    reference's per-element chain (unsorted operand rows; one long row of A)."""
+    m, k, n = 700, 520, 610
+    pa, ia, va = random_csr(401, m, k, lambda r, i: 300 if i == 5 else r.integers(0, 9), base=base_a, sort=False)
+    pb, ib, vb = random_csr(402, k, n, lambda r, i: r.integers(0, 80) if i % 50 == 0 else r.integers(0, 9), base=base_b, sort=False)
+    pbt, ibt, vbt = random_csr(403, n, k, lambda r, i: r.integers(0, 9), base=base_b, sort=False)  # for op(B) = T
+    pa2, ia2, va2 = random_csr(404, k, m, lambda r, i: r.integers(0, 9), base=base_a, sort=False)  # for op(A) = T
+    A, B = P.Matrix(base_a, m, k, pa, ia, va), P.Matrix(base_b, k, n, pb, ib, vb)
+    Bt, A2 = P.Matrix(base_b, n, k, pbt, ibt, vbt), P.Matrix(base_a, k, m, pa2, ia2, va2)
+    dA, dB = P.Descr(base=base_a), P.Descr(base=base_b)
+    a, b, bt, a2 = (m, k, base_a, pa, ia, va), (k, n, base_b, pb, ib, vb), (n, k, base_b, pbt, ibt, vbt), (k, m, base_a, pa2, ia2, va2)
+    rng = np.random.default_rng(9)
+    cases = [(A, a, False, B, b, False), (A2, a2, True, B, b, False), (A, a, False, Bt, bt, True), (A2, a2, True, Bt, bt, True)]
+    for (HA, ta, trA, HB, tb, trB) in cases:
+        for rowmaj, pad in ((True, 0), (False, 0), (True, 3), (False, 5)):
+            for alpha, beta in ((1.0, 0.0), (-1.25, 0.5), (2.0, 1.0), (0.0, 3.0)):
+                ldc = (n if rowmaj else m) + pad
+                outer = m if rowmaj else n
+                C0 = rng.uniform(-1, 1, outer * ldc)
+                if beta == 0.0:
+                    C0.reshape(outer, ldc)[:, :ldc - pad] = np.nan  # never read
+                want = oracle.dsp2md(ta, trA, tb, trB, alpha, beta, C0, rowmaj, ldc)
+                C = C0.copy()
+                st = L.aoclsparse_dsp2md(P.OP_TRANSPOSE if trA else P.OP_NONE, dA.h, HA.h, P.OP_TRANSPOSE if trB else P.OP_NONE,
+                                         dB.h, HB.h, alpha, beta, P._ptr(C), P.ORDER_ROW if rowmaj else P.ORDER_COLUMN, ldc)
+                assert st == 0 and np.array_equal(C, want), (trA, trB, rowmaj, pad, alpha, beta)
+    # device-resident result
+    import torch
+    Cd = torch.zeros(m * n, dtype=torch.float64, device="cuda")
+    assert L.aoclsparse_dspmmd(P.OP_NONE, A.h, B.h, P.ORDER_ROW, ctypes.c_void_p(Cd.data_ptr()), n) == 0
+    assert np.array_equal(Cd.cpu().numpy(), oracle.dsp2md(a, False, b, False, 1.0, 0.0, np.zeros(m * n), True, n))
+
+
+@pytest.mark.parametrize("prec", ["s", "c", "z"])
+def test_sp2md_float_and_complex(prec):
+    """fp32 and complex sp2md / spmmd: within (terms + 4) eps sum|a||b| of the dense product for every op pair (H
+    conjugates as it transposes, sp2md.hpp:281-347); tolerance: 16 eps * (|alpha| |A||B| + |beta C|)."""
+    m, k, n = 150, 130, 140
+    rng = np.random.default_rng(31)
+    cplx = prec != "s"
+    dtype = {"s": np.float32, "c": np.complex64, "z": np.complex128}[prec]
+    eps = EPS64 if prec == "z" else EPS32
+    create = getattr(L, f"aoclsparse_create_{prec}csr")
+    S = {"s": ctypes.c_float, "c": P.CFloat, "z": P.CDouble}[prec]
+    sc = (lambda z: S(z.real, z.imag)) if cplx else (lambda z: S(z))
+
+    def mat(seed, r, c):
+        rp, ci, vr = random_csr(seed, r, c, lambda g, i: g.integers(0, 9), sort=False)
+        v = (vr + (1j * rng.uniform(-1, 1, len(vr)) if cplx else 0)).astype(dtype)
+        h = ctypes.c_void_p()
+        assert create(ctypes.byref(h), 0, r, c, len(v), P._ptr(rp), P._ptr(ci), P._ptr(v)) == 0
+        D = np.zeros((r, c), np.complex128 if cplx else np.float64)
+        for i in range(r):
+            D[i, ci[rp[i]:rp[i + 1]]] = v[rp[i]:rp[i + 1]]
+        return h, D, (rp, ci, v)
+
+    f = {P.OP_NONE: lambda X: X, P.OP_TRANSPOSE: lambda X: X.T, P.OP_CONJ_TRANSPOSE: lambda X: X.conj().T}
+    d = P.Descr()
+    keep = []
+    alpha, beta = (0.75 - 0.5j, -0.25 + 1.0j) if cplx else (0.75, -0.25)
+    for opA in f:
+        for opB in f:
+            hA, DA, ka = mat(1, *((m, k) if opA == P.OP_NONE else (k, m)))
+            hB, DB, kb = mat(2, *((k, n) if opB == P.OP_NONE else (n, k)))
+            keep += [ka, kb]
+            for rowmaj in (True, False):
+                C0 = (rng.uniform(-1, 1, (m, n)) + (1j * rng.uniform(-1, 1, (m, n)) if cplx else 0)).astype(dtype)
+                C = np.ascontiguousarray(C0 if rowmaj else C0.T).copy()
+                st = getattr(L, f"aoclsparse_{prec}sp2md")(opA, d.h, hA, opB, d.h, hB, sc(alpha), sc(beta), P._ptr(C),
+                                                           P.ORDER_ROW if rowmaj else P.ORDER_COLUMN, n if rowmaj else m)
+                got = C if rowmaj else C.T
+                want = alpha * (f[opA](DA) @ f[opB](DB)) + beta * C0
+                bound = 16 * eps * (abs(alpha) * (np.abs(f[opA](DA)) @ np.abs(f[opB](DB))) + abs(beta) * np.abs(C0)) + 1e-30
+                assert st == 0 and np.all(np.abs(got - want) <= bound), (opA, opB, rowmaj)
+            if opB == P.OP_NONE:
+                C = np.full((m, n), np.nan, dtype)
+                assert getattr(L, f"aoclsparse_{prec}spmmd")(opA, hA, hB, P.ORDER_ROW, P._ptr(C), n) == 0
+                assert np.all(np.abs(C - f[opA](DA) @ DB) <= 16 * eps * (np.abs(f[opA](DA)) @ np.abs(DB)) + 1e-30)
+            L.aoclsparse_destroy(ctypes.byref(hA))
+            L.aoclsparse_destroy(ctypes.byref(hB))
+
+
+def test_csr2dense_all_descriptors_vs_oracle():
+    """General / symmetric / hermitian / triangular, both fills, the three diagonal kinds, both layouts where the
+    reference offers them, padded ld, device-resident arrays; complex hermitian mirrors conjugate."""
+    import torch
+    m = 333
+    for base in (0, 1):
+        rp, ci, v = random_csr(501, m, m, lambda r, i: r.integers(0, 12), base=base, sort=False)
+        for mode, mtype in ((0, P.TYPE_GENERAL), (1, P.TYPE_SYMMETRIC), (3, P.TYPE_TRIANGULAR)):
+            for fill in (0, 1):
+                for diag in (0, 1, 2):
+                    for colmaj in (False, True):
+                        if colmaj and mode == 3:
+                            continue
+                        d = P.Descr(base=base, mtype=mtype, fill=fill, diag=diag)
+                        ld = m + 2
+                        D0 = np.random.default_rng(3).uniform(-1, 1, m * ld)
+                        want = oracle.dcsr2dense(m, m, base, rp, ci, v, D0, ld, colmaj, mode, fill, diag)
+                        D = D0.copy()
+                        st = L.aoclsparse_dcsr2dense(m, m, d.h, P._ptr(v), P._ptr(rp), P._ptr(ci), P._ptr(D), ld,
+                                                     P.ORDER_COLUMN if colmaj else P.ORDER_ROW)
+                        assert st == 0 and np.array_equal(D, want), (base, mode, fill, diag, colmaj)
+    # rectangular general, device-resident CSR and dense arrays
+    rp, ci, v = random_csr(502, 400, 250, lambda r, i: r.integers(0, 30), sort=False)
+    t = [torch.from_numpy(x).cuda() for x in (v, rp, ci)]
+    Dd = torch.full((400 * 250,), -1.0, dtype=torch.float64, device="cuda")
+    assert L.aoclsparse_dcsr2dense(400, 250, P.Descr().h, *[ctypes.c_void_p(x.data_ptr()) for x in t],
+                                   ctypes.c_void_p(Dd.data_ptr()), 250, P.ORDER_ROW) == 0
+    assert np.array_equal(Dd.cpu().numpy().reshape(400, 250), _dense(400, 250, rp, ci, v))
+    # complex hermitian from the lower triangle
+    rp, ci, vr = random_csr(503, 90, 90, lambda r, i: r.integers(1, 9))
+    vz = (vr + 1j * np.random.default_rng(4).uniform(-1, 1, len(vr))).astype(np.complex128)
+    Dz = np.zeros((90, 90), np.complex128)
+    d = P.Descr(mtype=P.TYPE_HERMITIAN, fill=0, diag=0)
+    assert L.aoclsparse_zcsr2dense(90, 90, d.h, P._ptr(vz), P._ptr(rp), P._ptr(ci), P._ptr(Dz), 90, P.ORDER_ROW) == 0
+    F = np.zeros((90, 90), np.complex128)
+    for i in range(90):
+        F[i, ci[rp[i]:rp[i + 1]]] = vz[rp[i]:rp[i + 1]]
+    lo = np.tril(F, -1)
+    assert np.array_equal(Dz, lo + lo.conj().T + np.diag(np.diag(F)))
+
+
+@pytest.mark.parametrize("base_a,base_b", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_add_bit_exact_vs_oracle(base_a, base_b):
+    """C = alpha*op(A) + B: row_ptr / col_ind (A's row, then B's new columns in B's order, A's base) and values are the
+    reference's, bit for bit; op = N and T; rows longer than a wavefront; alpha = 0 keeps A's pattern."""
+    m, n = 2500, 2100
+    pa, ia, va = random_csr(601, m, n, lambda r, i: 200 if i == 3 else r.integers(0, 10), base=base_a, sort=False)
+    pb, ib, vb = random_csr(602, m, n, lambda r, i: 150 if i in (3, 4) else r.integers(0, 10), base=base_b, sort=False)
+    pt, it, vt = random_csr(603, n, m, lambda r, i: r.integers(0, 10), base=base_a, sort=False)
+    A, B, At = P.Matrix(base_a, m, n, pa, ia, va), P.Matrix(base_b, m, n, pb, ib, vb), P.Matrix(base_a, n, m, pt, it, vt)
+    for H, ta, op, alpha in ((A, (m, n, base_a, pa, ia, va), P.OP_NONE, -1.75), (At, (n, m, base_a, pt, it, vt), P.OP_TRANSPOSE, 0.3),
+                             (A, (m, n, base_a, pa, ia, va), P.OP_NONE, 0.0)):
+        pc, ic, vc = oracle.dcsradd(ta, op != P.OP_NONE, alpha, (m, n, base_b, pb, ib, vb))
+        C = ctypes.c_void_p()
+        assert L.aoclsparse_dadd(op, H.h, alpha, B.h, ctypes.byref(C)) == 0
+        b, cm, cn, cz, row, col, val = _export(C)
+        assert (b, cm, cn, cz) == (base_a, m, n, len(ic))
+        assert np.array_equal(row, pc) and np.array_equal(col, ic) and np.array_equal(val, vc)
+        # the sum is an ordinary handle: it multiplies
+        x = np.random.default_rng(8).uniform(-1, 1, n)
+        y = np.zeros(m)
+        dC = P.Descr(base=base_a)
+        one, zero = ctypes.c_double(1.0), ctypes.c_double(0.0)
+        assert L.aoclsparse_dmv(P.OP_NONE, ctypes.byref(one), C, dC.h, P._ptr(x), ctypes.byref(zero), P._ptr(y)) == 0
+        so, yr = oracle.dcsrmv(-1, base_a, 1.0, m, len(vc), vc, ic, pc, x, 0.0, np.zeros(m))
+        assert np.array_equal(y, yr)
+        assert L.aoclsparse_destroy(ctypes.byref(C)) == 0
+    # fp32 and complex (conjugate transpose) against the dense sum
+    Af, Bf = P.Matrix(base_a, m, n, pa, ia, va.astype(np.float32)), P.Matrix(base_b, m, n, pb, ib, vb.astype(np.float32))
+    C = ctypes.c_void_p()
+    assert L.aoclsparse_sadd(P.OP_NONE, Af.h, 0.5, Bf.h, ctypes.byref(C)) == 0
+    _, _, _, cz, row, col, val = _export(C, double=False)
+    pc, ic, vc = oracle.dcsradd((m, n, base_a, pa, ia, va), False, 0.5, (m, n, base_b, pb, ib, vb))
+    assert np.array_equal(row, pc) and np.array_equal(col, ic)
+    assert np.allclose(val, vc, rtol=4 * EPS32, atol=4 * EPS32)
+    L.aoclsparse_destroy(ctypes.byref(C))
+    vz, wz = (vt + 1j * vt[::-1]).astype(np.complex128), (vb - 0.5j * vb).astype(np.complex128)
+    hz, hw = ctypes.c_void_p(), ctypes.c_void_p()
+    assert L.aoclsparse_create_zcsr(ctypes.byref(hz), base_a, n, m, len(vz), P._ptr(pt), P._ptr(it), P._ptr(vz)) == 0
+    assert L.aoclsparse_create_zcsr(ctypes.byref(hw), base_b, m, n, len(wz), P._ptr(pb), P._ptr(ib), P._ptr(wz)) == 0
+    assert L.aoclsparse_zadd(P.OP_CONJ_TRANSPOSE, hz, P.CDouble(0.5, -2.0), hw, ctypes.byref(C)) == 0
+    bz, mz, nz, zz = ctypes.c_int(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    a1, a2, a3 = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    assert L.aoclsparse_export_zcsr(C, ctypes.byref(bz), ctypes.byref(mz), ctypes.byref(nz), ctypes.byref(zz), ctypes.byref(a1),
+                                    ctypes.byref(a2), ctypes.byref(a3)) == 0
+    row = np.ctypeslib.as_array(ctypes.cast(a1, ctypes.POINTER(ctypes.c_int32)), (m + 1,)) - base_a
+    col = np.ctypeslib.as_array(ctypes.cast(a2, ctypes.POINTER(ctypes.c_int32)), (zz.value,)) - base_a
+    val = np.ctypeslib.as_array(ctypes.cast(a3, ctypes.POINTER(ctypes.c_double)), (2 * zz.value,)).view(np.complex128)
+    got = np.zeros((m, n), np.complex128)
+    for i in range(m):
+        got[i, col[row[i]:row[i + 1]]] = val[row[i]:row[i + 1]]
+    Z = np.zeros((n, m), np.complex128)
+    for i in range(n):
+        Z[i, it[pt[i] - base_a:pt[i + 1] - base_a] - base_a] = vz[pt[i] - base_a:pt[i + 1] - base_a]
+    Wd = np.zeros((m, n), np.complex128)
+    for i in range(m):
+        Wd[i, ib[pb[i] - base_b:pb[i + 1] - base_b] - base_b] = wz[pb[i] - base_b:pb[i + 1] - base_b]
+    assert (mz.value, nz.value, bz.value) == (m, n, base_a)
+    assert np.allclose(got, (0.5 - 2.0j) * Z.conj().T + Wd, rtol=0, atol=8 * EPS64)
+    for h in (C, hz, hw):
+        L.aoclsparse_destroy(ctypes.byref(h))
+
+
+def test_spmmd_full_size_property_on_the_device():
+    """L64^2 (4096 x 4096, dense result 134 MB, device-resident): (A*A) 1 equals A (A 1) -- integer-valued, so exactly --
+    and the result is symmetric; a second call reuses the handles' device copies and gives the same bits."""
+    import torch
+    m, rp, ci, v = laplace5(64)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    Cd = torch.full((m * m,), float("nan"), dtype=torch.float64, device="cuda")
+    assert L.aoclsparse_dspmmd(P.OP_NONE, A.h, A.h, P.ORDER_COLUMN, ctypes.c_void_p(Cd.data_ptr()), m) == 0
+    C = Cd.view(m, m)
+    one = np.ones(m)
+    so, y1 = oracle.dcsrmv(-1, 0, 1.0, m, len(v), v, ci, rp, one, 0.0, np.zeros(m))
+    so, y2 = oracle.dcsrmv(-1, 0, 1.0, m, len(v), v, ci, rp, y1, 0.0, np.zeros(m))
+    assert np.array_equal(C.sum(dim=0).cpu().numpy(), y2) and bool(torch.equal(C, C.t()))
+    C2 = torch.zeros_like(Cd)
+    assert L.aoclsparse_dspmmd(P.OP_TRANSPOSE, A.h, A.h, P.ORDER_ROW, ctypes.c_void_p(C2.data_ptr()), m) == 0
+    assert bool(torch.equal(C2, Cd))

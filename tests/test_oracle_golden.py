@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import oracle
-from util import banded_rows, laplace5, triangular_system
+from util import banded_rows, laplace5, random_csr, triangular_system
 
 EPS = np.finfo(np.float64).eps
 
@@ -479,3 +479,78 @@ def test_complex_mv_restatement_on_a_hand_checked_hermitian_matrix():
     assert np.allclose(yt, [2 + (1 + 1j) * 1j, (1 - 1j) + 3j - 4j, 2j * 1j + 2])
     yh, _ = oracle.zmv("h", "hermitian", "lower", "non_unit", 0, 1.0, 3, 3, ptr, ind, val, x, 0.0, np.zeros(3))
     assert np.allclose(yh, y)
+
+
+# --------------------------------------------------------------------------------------------------
+# dense-result product, CSR -> dense, sparse sum (sp2md.hpp, convert.hpp:658-929, csradd.hpp)
+# --------------------------------------------------------------------------------------------------
+def _scipy_csr(m, n, base, ptr, ind, val):
+    import scipy.sparse as sp
+    return sp.csr_matrix((np.asarray(val), np.asarray(ind) - base, np.asarray(ptr) - base), shape=(m, n))
+
+
+def test_spmmd_and_csr2dense_kats(kats):
+    """The reference's own vectors: spmmd_tests.cpp:130-157 and conversion_tests.cpp:211-252."""
+    k = kats["spmmd"]
+    for base_a in (0, 1):
+        for base_b in (0, 1):
+            a = (3, 3, base_a, np.array(k["a"]["row_ptr"]) + base_a, np.array(k["a"]["col_ind"]) + base_a, k["a"]["val"])
+            b = (3, 3, base_b, np.array(k["b"]["row_ptr"]) + base_b, np.array(k["b"]["col_ind"]) + base_b, k["b"]["val"])
+            for trans, gold in ((False, k["c_none"]), (True, k["c_trans"])):
+                G = np.array(gold, dtype=np.float64).reshape(3, 3)
+                c = oracle.dsp2md(a, trans, b, False, 1.0, 0.0, np.full(9, np.nan), True, 3)
+                assert np.array_equal(c.reshape(3, 3), G)
+                c = oracle.dsp2md(a, trans, b, False, 1.0, 0.0, np.full(12, 7.0), False, 4)  # column-major, ldc 4
+                assert np.array_equal(c.reshape(3, 4)[:, :3].T, G) and np.all(c.reshape(3, 4)[:, 3] == 7.0)
+    k = kats["csr2dense"]
+    args = (5, 5, 0, k["row_ptr"], k["col_ind"], k["val"])
+    assert np.array_equal(oracle.dcsr2dense(*args, np.full(25, -1.0), 5, False), k["rowmajor"])
+    assert np.array_equal(oracle.dcsr2dense(*args, np.full(25, -1.0), 5, True), k["colmajor"])
+    assert np.array_equal(oracle.dcsr2dense(*args, np.zeros(40), 8, False), k["rowmajor_ld8"])
+    one = (5, 5, 1, np.array(k["row_ptr"]) + 1, np.array(k["col_ind"]) + 1, k["val"])
+    assert np.array_equal(oracle.dcsr2dense(*one, np.full(25, -1.0), 5, False), k["rowmajor"])
+
+
+def test_dense_result_restatements_against_scipy():
+    """Independent cross-check of the three restatements on random unsorted operands (scipy is not the reference:
+    it pins the mathematics, the KATs above pin the layout conventions)."""
+    m, k, n = 60, 45, 50
+    for base_a, base_b in ((0, 0), (1, 0), (0, 1)):
+        pa, ia, va = random_csr(11, m, k, lambda r, i: r.integers(0, 9), base=base_a, sort=False)
+        pb, ib, vb = random_csr(12, k, n, lambda r, i: r.integers(0, 9), base=base_b, sort=False)
+        pt, it, vt = random_csr(13, m, n, lambda r, i: r.integers(0, 9), base=base_b, sort=False)
+        A, B, Bt = _scipy_csr(m, k, base_a, pa, ia, va), _scipy_csr(k, n, base_b, pb, ib, vb), _scipy_csr(m, n, base_b, pt, it, vt)
+        c0 = np.random.default_rng(5).uniform(-1, 1, m * n)
+        c = oracle.dsp2md((m, k, base_a, pa, ia, va), False, (k, n, base_b, pb, ib, vb), False, 1.5, -0.5, c0, True, n)
+        assert np.allclose(c.reshape(m, n), 1.5 * (A @ B).toarray() - 0.5 * c0.reshape(m, n), atol=1e-13)
+        c0 = np.random.default_rng(6).uniform(-1, 1, k * n)
+        c = oracle.dsp2md((m, k, base_a, pa, ia, va), True, (m, n, base_b, pt, it, vt), False, 2.0, 1.0, c0, False, k)
+        assert np.allclose(c.reshape(n, k).T, 2.0 * (A.T @ Bt).toarray() + c0.reshape(n, k).T, atol=1e-13)
+        c = oracle.dsp2md((m, k, base_a, pa, ia, va), False, (n, k, base_b, *random_csr(14, n, k, lambda r, i: 4, base=base_b)),
+                          True, 1.0, 0.0, np.zeros(m * n), True, n)
+        B3 = _scipy_csr(n, k, base_b, *random_csr(14, n, k, lambda r, i: 4, base=base_b))
+        assert np.allclose(c.reshape(m, n), (A @ B3.T).toarray(), atol=1e-13)
+        # sparse sum: structure = A's row then B's new columns in order; values exact against scipy's sum
+        pb2, ib2, vb2 = random_csr(15, m, k, lambda r, i: r.integers(0, 9), base=base_b, sort=False)
+        pc, ic, vc = oracle.dcsradd((m, k, base_a, pa, ia, va), False, 0.75, (m, k, base_b, pb2, ib2, vb2))
+        S = 0.75 * A + _scipy_csr(m, k, base_b, pb2, ib2, vb2)
+        assert pc[0] == base_a and np.allclose(_scipy_csr(m, k, base_a, pc, ic, vc).toarray(), S.toarray(), atol=1e-15)
+        for i in range(m):
+            row = ic[pc[i] - base_a:pc[i + 1] - base_a]
+            la = pa[i + 1] - pa[i]
+            assert np.array_equal(row[:la], ia[pa[i] - base_a:pa[i + 1] - base_a]) and len(set(row)) == len(row)
+        pc, ic, vc = oracle.dcsradd((k, m, base_a, *random_csr(16, k, m, lambda r, i: 5, base=base_a)), True, -2.0,
+                                    (m, k, base_b, pb2, ib2, vb2))
+        At = _scipy_csr(k, m, base_a, *random_csr(16, k, m, lambda r, i: 5, base=base_a))
+        assert np.allclose(_scipy_csr(m, k, base_a, pc, ic, vc).toarray(),
+                           (-2.0 * At.T + _scipy_csr(m, k, base_b, pb2, ib2, vb2)).toarray(), atol=1e-15)
+        # csr2dense variants: symmetric / triangular from one triangle, unit / zero diagonal
+        ps, is_, vs = random_csr(17, m, m, lambda r, i: r.integers(1, 9), base=base_a, sort=False)
+        D = _scipy_csr(m, m, base_a, ps, is_, vs).toarray()
+        lo, up = np.tril(D, -1), np.triu(D, 1)
+        got = oracle.dcsr2dense(m, m, base_a, ps, is_, vs, np.zeros(m * m), m, False, 1, 0, 0).reshape(m, m)
+        assert np.array_equal(got, lo + lo.T + np.diag(np.diag(D)))
+        got = oracle.dcsr2dense(m, m, base_a, ps, is_, vs, np.zeros(m * m), m, True, 1, 1, 1).reshape(m, m)
+        assert np.array_equal(got, up + up.T + np.eye(m))
+        got = oracle.dcsr2dense(m, m, base_a, ps, is_, vs, np.zeros(m * m), m, False, 3, 1, 2).reshape(m, m)
+        assert np.array_equal(got, up)
