@@ -614,6 +614,19 @@ aoclsparse_status new_csr_result(aoclsparse_matrix *C, aoclsparse_int m, aoclspa
                                  aoclsparse_matrix_data_type vt, const aoclsparse_int *row_ptr,
                                  aoclsparse_index_base base = aoclsparse_index_base_zero);
 
+// level1_kernels.hip: sparse-vector operations
+constexpr int L1_DOT_PARTIALS = 1024;
+template <typename T>
+aoclsparse_status launch_axpyi(hipStream_t s, aoclsparse_int nnz, T a, const T *x, const aoclsparse_int *indx, T *y);
+template <typename T>
+aoclsparse_status launch_gather_scatter(hipStream_t s, aoclsparse_int nnz, T *x, const aoclsparse_int *indx,
+                                        long long stride, T *y, int mode);
+template <typename T>
+aoclsparse_status launch_roti(hipStream_t s, aoclsparse_int nnz, T *x, const aoclsparse_int *indx, T *y, T c, T sn);
+template <typename T>
+aoclsparse_status launch_doti(hipStream_t s, aoclsparse_int nnz, const T *x, const aoclsparse_int *indx, const T *y,
+                              bool conj, T *partial, T *out);
+
 // SpMV plan constants shared by host planner and kernels
 // LDS tile = non-zeros staged per workgroup: 512 (128 threads), 1024 or 2048 (256 threads);
 // rows per stream block (their row_ptr slice is kept in LDS)

@@ -1021,6 +1021,75 @@ DLL_PUBLIC aoclsparse_status aoclsparse_zadd(const aoclsparse_operation op, cons
                                              const aoclsparse_double_complex alpha, const aoclsparse_matrix B,
                                              aoclsparse_matrix *C);
 
+/* ---- level 1: compressed sparse vector (x, indx) against a dense vector y -----------------------------------------
+ * Replaces library/include/aoclsparse_functions.h:83-99 (?axpyi), :141-151 / :190-200 (?dotci / ?dotui), :236-246
+ * (?doti), :295-312 (?sctr), :344-357 (?sctrs), :416-430 (?roti), :492-505 (?gthr), :558-572 (?gthrz), :612-626 (?gthrs)
+ * and the _kid twins at :3220-3395.  Vectors may be host or device memory. */
+DLL_PUBLIC aoclsparse_status aoclsparse_saxpyi(const aoclsparse_int nnz, const float a, const float *x, const aoclsparse_int *indx, float *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_daxpyi(const aoclsparse_int nnz, const double a, const double *x, const aoclsparse_int *indx, double *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_caxpyi(const aoclsparse_int nnz, const void *a, const void *x, const aoclsparse_int *indx, void *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_zaxpyi(const aoclsparse_int nnz, const void *a, const void *x, const aoclsparse_int *indx, void *y);
+DLL_PUBLIC float aoclsparse_sdoti(const aoclsparse_int nnz, const float *x, const aoclsparse_int *indx, const float *y);
+DLL_PUBLIC double aoclsparse_ddoti(const aoclsparse_int nnz, const double *x, const aoclsparse_int *indx, const double *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_cdotci(const aoclsparse_int nnz, const void *x, const aoclsparse_int *indx, const void *y, void *dot);
+DLL_PUBLIC aoclsparse_status aoclsparse_cdotui(const aoclsparse_int nnz, const void *x, const aoclsparse_int *indx, const void *y, void *dot);
+DLL_PUBLIC aoclsparse_status aoclsparse_zdotci(const aoclsparse_int nnz, const void *x, const aoclsparse_int *indx, const void *y, void *dot);
+DLL_PUBLIC aoclsparse_status aoclsparse_zdotui(const aoclsparse_int nnz, const void *x, const aoclsparse_int *indx, const void *y, void *dot);
+DLL_PUBLIC aoclsparse_status aoclsparse_sgthr(aoclsparse_int nnz, const float *y, float *x, const aoclsparse_int *indx);
+DLL_PUBLIC aoclsparse_status aoclsparse_dgthr(aoclsparse_int nnz, const double *y, double *x, const aoclsparse_int *indx);
+DLL_PUBLIC aoclsparse_status aoclsparse_cgthr(aoclsparse_int nnz, const void *y, void *x, const aoclsparse_int *indx);
+DLL_PUBLIC aoclsparse_status aoclsparse_zgthr(aoclsparse_int nnz, const void *y, void *x, const aoclsparse_int *indx);
+DLL_PUBLIC aoclsparse_status aoclsparse_sgthrz(aoclsparse_int nnz, float *y, float *x, const aoclsparse_int *indx);
+DLL_PUBLIC aoclsparse_status aoclsparse_dgthrz(aoclsparse_int nnz, double *y, double *x, const aoclsparse_int *indx);
+DLL_PUBLIC aoclsparse_status aoclsparse_cgthrz(aoclsparse_int nnz, void *y, void *x, const aoclsparse_int *indx);
+DLL_PUBLIC aoclsparse_status aoclsparse_zgthrz(aoclsparse_int nnz, void *y, void *x, const aoclsparse_int *indx);
+DLL_PUBLIC aoclsparse_status aoclsparse_sgthrs(aoclsparse_int nnz, const float *y, float *x, aoclsparse_int stride);
+DLL_PUBLIC aoclsparse_status aoclsparse_dgthrs(aoclsparse_int nnz, const double *y, double *x, aoclsparse_int stride);
+DLL_PUBLIC aoclsparse_status aoclsparse_cgthrs(aoclsparse_int nnz, const void *y, void *x, aoclsparse_int stride);
+DLL_PUBLIC aoclsparse_status aoclsparse_zgthrs(aoclsparse_int nnz, const void *y, void *x, aoclsparse_int stride);
+DLL_PUBLIC aoclsparse_status aoclsparse_ssctr(const aoclsparse_int nnz, const float *x, const aoclsparse_int *indx, float *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_dsctr(const aoclsparse_int nnz, const double *x, const aoclsparse_int *indx, double *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_csctr(const aoclsparse_int nnz, const void *x, const aoclsparse_int *indx, void *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_zsctr(const aoclsparse_int nnz, const void *x, const aoclsparse_int *indx, void *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_ssctrs(const aoclsparse_int nnz, const float *x, aoclsparse_int stride, float *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_dsctrs(const aoclsparse_int nnz, const double *x, aoclsparse_int stride, double *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_csctrs(const aoclsparse_int nnz, const void *x, aoclsparse_int stride, void *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_zsctrs(const aoclsparse_int nnz, const void *x, aoclsparse_int stride, void *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_sroti(const aoclsparse_int nnz, float *x, const aoclsparse_int *indx, float *y, const float c, const float s);
+DLL_PUBLIC aoclsparse_status aoclsparse_droti(const aoclsparse_int nnz, double *x, const aoclsparse_int *indx, double *y, const double c, const double s);
+DLL_PUBLIC aoclsparse_status aoclsparse_saxpyi_kid(const aoclsparse_int nnz, const float a, const float *x, const aoclsparse_int *indx, float *y, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_daxpyi_kid(const aoclsparse_int nnz, const double a, const double *x, const aoclsparse_int *indx, double *y, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_caxpyi_kid(const aoclsparse_int nnz, const void *a, const void *x, const aoclsparse_int *indx, void *y, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_zaxpyi_kid(const aoclsparse_int nnz, const void *a, const void *x, const aoclsparse_int *indx, void *y, aoclsparse_int kid);
+DLL_PUBLIC float aoclsparse_sdoti_kid(const aoclsparse_int nnz, const float *x, const aoclsparse_int *indx, const float *y, aoclsparse_int kid);
+DLL_PUBLIC double aoclsparse_ddoti_kid(const aoclsparse_int nnz, const double *x, const aoclsparse_int *indx, const double *y, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_cdotci_kid(const aoclsparse_int nnz, const void *x, const aoclsparse_int *indx, const void *y, void *dot, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_cdotui_kid(const aoclsparse_int nnz, const void *x, const aoclsparse_int *indx, const void *y, void *dot, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_zdotci_kid(const aoclsparse_int nnz, const void *x, const aoclsparse_int *indx, const void *y, void *dot, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_zdotui_kid(const aoclsparse_int nnz, const void *x, const aoclsparse_int *indx, const void *y, void *dot, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_sgthr_kid(aoclsparse_int nnz, const float *y, float *x, const aoclsparse_int *indx, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_dgthr_kid(aoclsparse_int nnz, const double *y, double *x, const aoclsparse_int *indx, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_cgthr_kid(aoclsparse_int nnz, const void *y, void *x, const aoclsparse_int *indx, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_zgthr_kid(aoclsparse_int nnz, const void *y, void *x, const aoclsparse_int *indx, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_sgthrz_kid(aoclsparse_int nnz, float *y, float *x, const aoclsparse_int *indx, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_dgthrz_kid(aoclsparse_int nnz, double *y, double *x, const aoclsparse_int *indx, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_cgthrz_kid(aoclsparse_int nnz, void *y, void *x, const aoclsparse_int *indx, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_zgthrz_kid(aoclsparse_int nnz, void *y, void *x, const aoclsparse_int *indx, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_sgthrs_kid(aoclsparse_int nnz, const float *y, float *x, aoclsparse_int stride, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_dgthrs_kid(aoclsparse_int nnz, const double *y, double *x, aoclsparse_int stride, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_cgthrs_kid(aoclsparse_int nnz, const void *y, void *x, aoclsparse_int stride, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_zgthrs_kid(aoclsparse_int nnz, const void *y, void *x, aoclsparse_int stride, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_ssctr_kid(const aoclsparse_int nnz, const float *x, const aoclsparse_int *indx, float *y, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_dsctr_kid(const aoclsparse_int nnz, const double *x, const aoclsparse_int *indx, double *y, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_csctr_kid(const aoclsparse_int nnz, const void *x, const aoclsparse_int *indx, void *y, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_zsctr_kid(const aoclsparse_int nnz, const void *x, const aoclsparse_int *indx, void *y, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_ssctrs_kid(const aoclsparse_int nnz, const float *x, aoclsparse_int stride, float *y, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_dsctrs_kid(const aoclsparse_int nnz, const double *x, aoclsparse_int stride, double *y, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_csctrs_kid(const aoclsparse_int nnz, const void *x, aoclsparse_int stride, void *y, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_zsctrs_kid(const aoclsparse_int nnz, const void *x, aoclsparse_int stride, void *y, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_sroti_kid(const aoclsparse_int nnz, float *x, const aoclsparse_int *indx, float *y, const float c, const float s, aoclsparse_int kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_droti_kid(const aoclsparse_int nnz, double *x, const aoclsparse_int *indx, double *y, const double c, const double s, aoclsparse_int kid);
+
 #ifdef __cplusplus
 }
 #endif

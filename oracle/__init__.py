@@ -439,6 +439,41 @@ def dcsradd(a, trans_a, alpha, b):
     return pc, ic[:w], vc[:w]
 
 
+def daxpyi(a, x, indx, y):
+    """y[indx] += a*x (level1/aoclsparse_axpyi.hpp:35-50).  Returns (status, y)."""
+    x, indx, y = _f64(x), _i32(indx), _f64(y).copy()
+    st = lib().orc_daxpyi(c_i32(len(indx)), c_dbl(a), _p(x), _p(indx), _p(y))
+    return st, y
+
+
+def ddoti(x, indx, y):
+    x, indx, y = _f64(x), _i32(indx), _f64(y)
+    lib().orc_ddoti.restype = c_dbl
+    return lib().orc_ddoti(c_i32(len(indx)), _p(x), _p(indx), _p(y))
+
+
+def droti(x, indx, y, c, s):
+    x, indx, y = _f64(x).copy(), _i32(indx), _f64(y).copy()
+    st = lib().orc_droti(c_i32(len(indx)), _p(x), _p(indx), _p(y), c_dbl(c), c_dbl(s))
+    return st, x, y
+
+
+def gthr(y, indx, zero=False):
+    """x = y[indx]; gthrz also clears those entries (level1/aoclsparse_gthr.hpp:33-62).  Returns (x, y)."""
+    y = np.array(y).copy()
+    x = y[np.asarray(indx)].copy()
+    if zero:
+        y[np.asarray(indx)] = 0
+    return x, y
+
+
+def sctr(x, indx, y):
+    """y[indx] = x (level1/aoclsparse_sctr.hpp:34-53)."""
+    y = np.array(y).copy()
+    y[np.asarray(indx)] = np.asarray(x)[: len(indx)]
+    return y
+
+
 # ---- complex CG / GMRES, numpy restatements of solvers/aoclsparse_itsol_functions.hpp:632-875 and :910-1367 for
 # T = std::complex (dense operator A; no preconditioner).  No reference vectors exist for them: parity unpinned, the
 # checks are exit status, iteration counts and the solver tolerances.

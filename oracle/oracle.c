@@ -1812,3 +1812,38 @@ oint orc_dcsradd(oint m, oint n, int base_a, const oint *ptr_a, const oint *ind_
     free(rec);
     return w;
 }
+
+
+/* ---- level 1: level1/aoclsparse_axpyi.hpp:35-50, aoclsparse_dot.hpp:33-61, aoclsparse_roti.hpp:36-55 (reference
+ * kernels, kid 0).  Return 6 (invalid_index_value) at the first negative index, entries before it already applied. */
+int orc_daxpyi(oint nnz, double a, const double *x, const oint *indx, double *y)
+{
+    for(oint i = 0; i < nnz; i++)
+    {
+        if(indx[i] < 0)
+            return 6;
+        y[indx[i]] = fma(a, x[i], y[indx[i]]);
+    }
+    return ORC_SUCCESS;
+}
+
+double orc_ddoti(oint nnz, const double *x, const oint *indx, const double *y)
+{
+    double dot = 0.0;
+    for(oint i = 0; i < nnz; i++)
+        dot = fma(x[i], y[indx[i]], dot);
+    return dot;
+}
+
+int orc_droti(oint nnz, double *x, const oint *indx, double *y, double c, double s)
+{
+    for(oint i = 0; i < nnz; i++)
+    {
+        if(indx[i] < 0)
+            return 6;
+        const double t = x[i], u = y[indx[i]];
+        x[i]           = fma(c, t, s * u);
+        y[indx[i]]     = fma(c, u, -(s * t));
+    }
+    return ORC_SUCCESS;
+}

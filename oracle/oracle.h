@@ -225,6 +225,11 @@ oint orc_dcsradd(oint m, oint n, int base_a, const oint *ptr_a, const oint *ind_
                  int base_b, const oint *ptr_b, const oint *ind_b, const double *val_b, oint *ptr_c, oint *ind_c,
                  double *val_c);
 
+/* level 1 (reference kernels of level1/aoclsparse_axpyi.hpp, aoclsparse_dot.hpp, aoclsparse_roti.hpp) */
+int    orc_daxpyi(oint nnz, double a, const double *x, const oint *indx, double *y);
+double orc_ddoti(oint nnz, const double *x, const oint *indx, const double *y);
+int    orc_droti(oint nnz, double *x, const oint *indx, double *y, double c, double s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -362,6 +362,31 @@ out["csr2dense"] = dict(src="tests/unit_tests/conversion_tests.cpp:211-252", m=5
                         rowmajor_ld8=[1, 1, 0, 0, 4, 0, 0, 0, 0, 2, 4, 0, 1, 0, 0, 0, 2, 1, 8, 2,
                                       0, 0, 0, 0, 0, 0, 4, 1, 0, 0, 0, 0, 3, 6, 2, 0, 1, 0, 0, 0])
 
+# ------------------------------------------------------------------------------------------
+# Level 1 (real types): tests/unit_tests/axpyi_tests.cpp:78-88, roti_tests.cpp:50-99, dotp_tests.cpp:44,64-69,
+# gthr_tests.cpp:42-43,66-71, sctr_tests.cpp:71-84
+# ------------------------------------------------------------------------------------------
+out["level1"] = dict(
+    axpyi=dict(src="tests/unit_tests/axpyi_tests.cpp:78-88", a=30, x=[1, 2, 3, 4], indx=[3, 6, 8, 0],
+               y=[31, 0, 0, 0, 0, 0, 0, 0, 7], y_nnz4=[151, 0, 0, 30, 0, 0, 60, 0, 97], y_nnz2=[31, 0, 0, 30, 0, 0, 60, 0, 7]),
+    roti=[dict(src="tests/unit_tests/roti_tests.cpp:50-99", c=c, s=s_, indx=ix, x=x, y=y, x_exp=xe, y_exp=ye) for c, s_, ix, x, y, xe, ye in [
+        (-2, 2, [0, 3, 6], [1, 4, 8], [1, 0, 0, 4, 0, 0, 8], [0, 0, 0], [-4, 0, 0, -16, 0, 0, -32]),
+        (-4.5, 3.5, [0, 3, 6], [1, 4, 8], [1, 0, 0, 4, 0, 0, 8], [-1, -4, -8], [-8, 0, 0, -32, 0, 0, -64]),
+        (-4.5, 3.5, [0, 3, 6], [4.75, -2.5, 7], [4.75, 0, 0, -2.5, 0, 0, 7], [-4.75, 2.5, -7], [-38, 0, 0, 20, 0, 0, -56]),
+        (-4.5, 3.5, [0, 3, 6, 7, 9], [-0.75, 4, -9.5, 46, 1.25], [-0.75, 0, 0, 4, 0, 0, -9.5, 46, 0, 1.25],
+         [0.75, -4, 9.5, -46, -1.25], [6, 0, 0, -32, 0, 0, 76, -368, 0, -10]),
+        (2, 2, [0, 3, 6, 7, 9], [-0.75, 4, -9.5, 46, 1.25], [-0.75, 0, 0, 4, 0, 0, -9.5, 46, 0, 1.25],
+         [-3, 16, -38, 184, 5], [0, 0, 0, 0, 0, 0, 0, 0, 0, 0])]],
+    doti=dict(src="tests/unit_tests/dotp_tests.cpp:44,64-69", indx=[6, 1, 4, 20, 2, 3, 7, 8, 10, 12, 13, 15, 16, 18, 0, 14, 5, 11],
+              x=[1, 0, 3, 4, 0, 0, 7, 8, 0, 10, 0, 12, 0, 0, 15, 16, 0, 18],
+              y=[-4.7, 2, -1.3, 5, 4, 3, 1, 6, -7, 12, -3, 0.5, 4.5, 3.5, 15, 2, 8, 2, 9, 10, 6.25], dot=271.5),
+    gthr=dict(src="tests/unit_tests/gthr_tests.cpp:42-43,66-71", indx=[0, 3, 5, 1, 7, 12, 2, 6, 8, 9, 10, 11, 4, 13, 15, 16, 14, 18],
+              y=list(range(1, 23)), x_exp=[1, 4, 6, 2, 8, 13, 3, 7, 9, 10, 11, 12, 5, 14, 16, 17, 15, 19],
+              y_gthrz=[0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 18, 0, 20, 21, 22]),
+    sctr=dict(src="tests/unit_tests/sctr_tests.cpp:71-84", indx=[1, 5, 13, 14, 6, 8, 9, 3, 7, 2, 10, 0, 15, 12, 4, 11, 16],
+              x=list(range(1, 18)), y_nnz17=[12, 1, 10, 8, 15, 2, 5, 9, 6, 7, 11, 16, 14, 3, 4, 13, 17],
+              y_nnz10=[0, 1, 10, 8, 0, 2, 5, 9, 6, 7, 0, 0, 0, 3, 4, 0, 0]))
+
 with open(n25_path, "w") as f:
     json.dump(out, f, indent=None, separators=(",", ":"))
     f.write("\n")

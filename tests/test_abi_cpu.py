@@ -722,3 +722,32 @@ def test_dense_result_and_add_argument_checks():
     assert (base.value, m.value, n.value, nnz.value) == (1, 2, 2, 0)
     assert list(np.ctypeslib.as_array(ctypes.cast(p0, ctypes.POINTER(ctypes.c_int32)), (3,))) == [1, 1, 1]
     assert L.aoclsparse_destroy(ctypes.byref(out)) == 0
+
+
+def test_level1_argument_checks():
+    """Every check of the level-1 dispatchers that precedes the computation, in the reference's order
+    (axpyi.hpp:70-85, dot.hpp:74-86, gthr.hpp:73-104, sctr.hpp:65-88, roti.hpp:70-83)."""
+    x, y, ix = np.array([1.0, 2.0]), np.zeros(4), np.array([0, 3], np.int32)
+    X, Y, IX = P._ptr(x), P._ptr(y), P._ptr(ix)
+    assert L.aoclsparse_daxpyi(2, 1.0, None, IX, Y) == 2 and L.aoclsparse_daxpyi(-1, 1.0, None, IX, Y) == 2
+    assert L.aoclsparse_daxpyi(0, 1.0, X, IX, Y) == 0 and L.aoclsparse_daxpyi(-1, 1.0, X, IX, Y) == 3
+    assert L.aoclsparse_daxpyi_kid(2, 1.0, X, IX, Y, 4) == 14
+    a = np.array([1.0 + 0j])
+    assert L.aoclsparse_zaxpyi(2, None, X, IX, Y) == 2 and L.aoclsparse_zaxpyi(0, P._ptr(a), X, IX, Y) == 0
+    dot = np.array([7.0 + 7.0j])
+    assert L.aoclsparse_zdotci(2, X, IX, Y, None) == 2
+    assert L.aoclsparse_zdotui(0, X, IX, Y, P._ptr(dot)) == 3 and dot[0] == 0  # dot.hpp:78-82: cleared
+    assert L.aoclsparse_zdotci(2, None, IX, Y, P._ptr(dot)) == 2 and L.aoclsparse_cdotui_kid(2, X, IX, Y, P._ptr(dot), 9) == 14
+    assert L.aoclsparse_ddoti(0, X, IX, Y) == 0.0 and L.aoclsparse_sdoti(-3, None, None, None) == 0.0
+    for f in (L.aoclsparse_dgthr, L.aoclsparse_dgthrz, L.aoclsparse_sgthr, L.aoclsparse_zgthrz):
+        assert f(-1, Y, X, IX) == 3 and f(0, None, None, None) == 0
+        assert f(2, None, X, IX) == 2 and f(2, Y, None, IX) == 2 and f(2, Y, X, None) == 2
+    assert L.aoclsparse_dgthrs(2, Y, X, -1) == 3 and L.aoclsparse_dgthrs(2, None, X, 1) == 2
+    assert L.aoclsparse_dgthr_kid(2, Y, X, IX, 4) == 14
+    for f in (L.aoclsparse_dsctr, L.aoclsparse_csctr):
+        assert f(2, None, IX, Y) == 2 and f(2, X, IX, None) == 2 and f(0, X, IX, Y) == 0
+        assert f(-1, X, IX, Y) == 3 and f(2, X, None, Y) == 2
+    assert L.aoclsparse_dsctrs(2, X, 0, Y) == 3 and L.aoclsparse_dsctrs(2, X, -2, Y) == 3 and L.aoclsparse_dsctrs(0, X, 0, Y) == 0
+    assert L.aoclsparse_ssctrs_kid(2, X, 1, Y, 5) == 14
+    assert L.aoclsparse_droti(2, None, IX, Y, 1.0, 0.0) == 2 and L.aoclsparse_droti(0, X, IX, Y, 1.0, 0.0) == 0
+    assert L.aoclsparse_droti(-2, X, IX, Y, 1.0, 0.0) == 3 and L.aoclsparse_sroti_kid(2, X, IX, Y, 1.0, 0.0, 4) == 14

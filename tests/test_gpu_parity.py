@@ -2817,3 +2817,120 @@ def test_spmmd_full_size_property_on_the_device():
     C2 = torch.zeros_like(Cd)
     assert L.aoclsparse_dspmmd(P.OP_TRANSPOSE, A.h, A.h, P.ORDER_ROW, ctypes.c_void_p(C2.data_ptr()), m) == 0
     assert bool(torch.equal(C2, Cd))
+
+
+# --------------------------------------------------------------------------------------------------
+# level 1: compressed sparse vector against a dense vector (level1/aoclsparse_{axpyi,dot,gthr,sctr,roti}.hpp)
+# --------------------------------------------------------------------------------------------------
+def test_level1_reference_kats(kats):
+    """axpyi_tests.cpp:78-88, roti_tests.cpp:50-99, dotp_tests.cpp:64-69, gthr_tests.cpp:66-71, sctr_tests.cpp:71-84
+    through the C ABI with host vectors, double and float."""
+    k = kats["level1"]
+    for dt, p, eps in ((np.float64, "d", EPS64), (np.float32, "s", EPS32)):
+        a = k["axpyi"]
+        for nnz, gold in ((4, a["y_nnz4"]), (2, a["y_nnz2"])):
+            x, ix, y = np.array(a["x"], dt), np.array(a["indx"], np.int32), np.array(a["y"], dt)
+            assert getattr(L, f"aoclsparse_{p}axpyi")(nnz, a["a"], P._ptr(x), P._ptr(ix), P._ptr(y)) == 0
+            assert np.array_equal(y, np.array(gold, dt))
+        for r in k["roti"]:
+            x, ix, y = np.array(r["x"], dt), np.array(r["indx"], np.int32), np.array(r["y"], dt)
+            assert getattr(L, f"aoclsparse_{p}roti")(len(ix), P._ptr(x), P._ptr(ix), P._ptr(y), r["c"], r["s"]) == 0
+            assert np.array_equal(x, np.array(r["x_exp"], dt)) and np.array_equal(y, np.array(r["y_exp"], dt))
+        d = k["doti"]
+        x, ix, y = np.array(d["x"], dt), np.array(d["indx"], np.int32), np.array(d["y"], dt)
+        got = getattr(L, f"aoclsparse_{p}doti")(len(ix), P._ptr(x), P._ptr(ix), P._ptr(y))
+        assert abs(got - d["dot"]) <= 64 * eps * np.sum(np.abs(x * y[ix]))
+        g = k["gthr"]
+        ix = np.array(g["indx"], np.int32)
+        for fn, ygold in (("gthr", g["y"]), ("gthrz", g["y_gthrz"])):
+            y, x = np.array(g["y"], dt), np.full(len(ix), -1, dt)
+            assert getattr(L, f"aoclsparse_{p}{fn}")(len(ix), P._ptr(y), P._ptr(x), P._ptr(ix)) == 0
+            assert np.array_equal(x, np.array(g["x_exp"], dt)) and np.array_equal(y, np.array(ygold, dt))
+        s = k["sctr"]
+        for nnz, gold in ((17, s["y_nnz17"]), (10, s["y_nnz10"])):
+            x, ix, y = np.array(s["x"], dt), np.array(s["indx"], np.int32), np.zeros(17, dt)
+            assert getattr(L, f"aoclsparse_{p}sctr")(nnz, P._ptr(x), P._ptr(ix), P._ptr(y)) == 0
+            assert np.array_equal(y, np.array(gold, dt))
+    y = np.arange(12, dtype=np.float64)
+    assert L.aoclsparse_daxpyi(3, 1.0, P._ptr(np.ones(3)), P._ptr(np.array([1, -2, 3], np.int32)), P._ptr(y)) == 6
+    assert np.array_equal(y, np.arange(12))  # nothing is modified when an index is negative
+
+
+def test_level1_large_host_and_device_vectors():
+    """2 M entries into an 8 M vector: axpyi bit-exact against the oracle (one contracted multiply-add per entry),
+    gather / scatter / strided forms exact, roti against the oracle's contraction, dot products within
+    n eps sum|x y| of the serial sum; host vectors and device vectors; complex twins against numpy."""
+    import torch
+    n, nnz = 1 << 23, 1 << 21
+    rng = np.random.default_rng(71)
+    ix = rng.permutation(n)[:nnz].astype(np.int32)
+    x, y = rng.uniform(-1, 1, nnz), rng.uniform(-1, 1, n)
+    st, yr = oracle.daxpyi(0.3, x, ix, y)
+    y1 = y.copy()
+    assert L.aoclsparse_daxpyi(nnz, 0.3, P._ptr(x), P._ptr(ix), P._ptr(y1)) == 0 and np.array_equal(y1, yr)
+    xd, ixd, yd = dev(x), torch.from_numpy(ix).cuda(), dev(y)
+    dp = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert L.aoclsparse_daxpyi_kid(nnz, 0.3, dp(xd), dp(ixd), dp(yd), 3) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(yd.cpu().numpy(), yr)
+    # dot: device vectors, result by value; host vectors
+    ref = oracle.ddoti(x, ix, y)
+    bound = nnz * EPS64 * np.sum(np.abs(x * y[ix]))
+    assert abs(L.aoclsparse_ddoti(nnz, dp(xd), dp(ixd), dp(dev(y))) - ref) <= bound
+    assert abs(L.aoclsparse_ddoti_kid(nnz, P._ptr(x), P._ptr(ix), P._ptr(y), 0) - ref) <= bound
+    assert L.aoclsparse_ddoti(nnz, dp(xd), dp(ixd), dp(dev(y))) == L.aoclsparse_ddoti(nnz, P._ptr(x), P._ptr(ix), P._ptr(y))
+    # gather, gather-and-zero, strided gather / scatter, scatter
+    xg = np.zeros(nnz)
+    assert L.aoclsparse_dgthr(nnz, P._ptr(y), P._ptr(xg), P._ptr(ix)) == 0 and np.array_equal(xg, y[ix])
+    y2, xg = y.copy(), np.zeros(nnz)
+    assert L.aoclsparse_dgthrz(nnz, P._ptr(y2), P._ptr(xg), P._ptr(ix)) == 0
+    yz = y.copy()
+    yz[ix] = 0
+    assert np.array_equal(xg, y[ix]) and np.array_equal(y2, yz)
+    xs = np.zeros(nnz)
+    assert L.aoclsparse_dgthrs(nnz, P._ptr(y), P._ptr(xs), 3) == 0 and np.array_equal(xs, y[0:3 * nnz:3])
+    y3 = y.copy()
+    assert L.aoclsparse_dsctrs(nnz, P._ptr(x), 4, P._ptr(y3)) == 0
+    yw = y.copy()
+    yw[0:4 * nnz:4] = x
+    assert np.array_equal(y3, yw)
+    y4d = dev(y)
+    assert L.aoclsparse_dsctr(nnz, dp(xd), dp(ixd), dp(y4d)) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(y4d.cpu().numpy(), oracle.sctr(x, ix, y))
+    # Givens rotation
+    st, xr, yr2 = oracle.droti(x, ix, y, 0.6, -0.8)
+    x5, y5 = x.copy(), y.copy()
+    assert L.aoclsparse_droti(nnz, P._ptr(x5), P._ptr(ix), P._ptr(y5), 0.6, -0.8) == 0
+    assert np.array_equal(x5, xr) and np.array_equal(y5, yr2)
+    # float and complex twins
+    xf, yf = x.astype(np.float32), y.astype(np.float32)
+    y6 = yf.copy()
+    assert L.aoclsparse_saxpyi(nnz, 0.3, P._ptr(xf), P._ptr(ix), P._ptr(y6)) == 0
+    want = yf.copy()
+    want[ix] = (np.float32(0.3) * xf.astype(np.float64) + yf[ix].astype(np.float64)).astype(np.float32)  # exact product, one rounding
+    assert np.array_equal(y6, want)
+    m = 1 << 16
+    iz = rng.permutation(1 << 18)[:m].astype(np.int32)
+    xz = (rng.uniform(-1, 1, m) + 1j * rng.uniform(-1, 1, m)).astype(np.complex128)
+    yz = (rng.uniform(-1, 1, 1 << 18) + 1j * rng.uniform(-1, 1, 1 << 18)).astype(np.complex128)
+    az = np.array([0.5 - 1.5j])
+    y7 = yz.copy()
+    assert L.aoclsparse_zaxpyi(m, P._ptr(az), P._ptr(xz), P._ptr(iz), P._ptr(y7)) == 0
+    w7 = yz.copy()
+    w7[iz] += az[0] * xz
+    assert np.allclose(y7, w7, rtol=0, atol=8 * EPS64)
+    dot = np.zeros(1, np.complex128)
+    assert L.aoclsparse_zdotci(m, P._ptr(xz), P._ptr(iz), P._ptr(yz), P._ptr(dot)) == 0
+    assert abs(dot[0] - np.sum(np.conj(xz) * yz[iz])) <= m * EPS64 * np.sum(np.abs(xz * yz[iz]))
+    assert L.aoclsparse_zdotui(m, P._ptr(xz), P._ptr(iz), P._ptr(yz), P._ptr(dot)) == 0
+    assert abs(dot[0] - np.sum(xz * yz[iz])) <= m * EPS64 * np.sum(np.abs(xz * yz[iz]))
+    xc, yc = xz.astype(np.complex64), yz.astype(np.complex64)
+    dotc = np.zeros(1, np.complex64)
+    assert L.aoclsparse_cdotci(m, P._ptr(xc), P._ptr(iz), P._ptr(yc), P._ptr(dotc)) == 0
+    assert abs(dotc[0] - np.sum(np.conj(xz) * yz[iz])) <= 4 * m * EPS32 * np.sum(np.abs(xz * yz[iz]))
+    xo = np.zeros(m, np.complex128)
+    y8 = yz.copy()
+    assert L.aoclsparse_zgthrz(m, P._ptr(y8), P._ptr(xo), P._ptr(iz)) == 0 and np.array_equal(xo, yz[iz]) and np.all(y8[iz] == 0)
+    y9 = np.zeros(1 << 18, np.complex64)
+    assert L.aoclsparse_csctr(m, P._ptr(xc), P._ptr(iz), P._ptr(y9)) == 0 and np.array_equal(y9[iz], xc)

@@ -554,3 +554,27 @@ def test_dense_result_restatements_against_scipy():
         assert np.array_equal(got, up + up.T + np.eye(m))
         got = oracle.dcsr2dense(m, m, base_a, ps, is_, vs, np.zeros(m * m), m, False, 3, 1, 2).reshape(m, m)
         assert np.array_equal(got, up)
+
+
+def test_level1_kats(kats):
+    """axpyi_tests.cpp:78-88, roti_tests.cpp:50-99, dotp_tests.cpp:64-69, gthr_tests.cpp:66-71, sctr_tests.cpp:71-84."""
+    k = kats["level1"]
+    a = k["axpyi"]
+    for nnz, gold in ((4, a["y_nnz4"]), (2, a["y_nnz2"])):
+        st, y = oracle.daxpyi(a["a"], a["x"][:nnz], a["indx"][:nnz], a["y"])
+        assert st == 0 and np.array_equal(y, gold)
+    st, y = oracle.daxpyi(2.0, [1.0, 1.0, 1.0], [1, -1, 2], np.zeros(4))
+    assert st == 6 and np.array_equal(y, [0, 2, 0, 0])  # entries before the bad index are applied
+    for r in k["roti"]:
+        st, x, y = oracle.droti(r["x"], r["indx"], r["y"], r["c"], r["s"])
+        assert st == 0 and np.array_equal(x, r["x_exp"]) and np.array_equal(y, r["y_exp"])
+    d = k["doti"]
+    assert abs(oracle.ddoti(d["x"], d["indx"], d["y"]) - d["dot"]) <= 64 * EPS * 271.5
+    g = k["gthr"]
+    x, y = oracle.gthr(np.array(g["y"], np.float64), g["indx"])
+    assert np.array_equal(x, g["x_exp"]) and np.array_equal(y, g["y"])
+    x, y = oracle.gthr(np.array(g["y"], np.float64), g["indx"], zero=True)
+    assert np.array_equal(x, g["x_exp"]) and np.array_equal(y, g["y_gthrz"])
+    s = k["sctr"]
+    assert np.array_equal(oracle.sctr(s["x"], s["indx"], np.zeros(17)), s["y_nnz17"])
+    assert np.array_equal(oracle.sctr(s["x"], s["indx"][:10], np.zeros(17)), s["y_nnz10"])
