@@ -310,6 +310,20 @@ SIGNATURES = {
     "aoclsparse_zgthrs_kid": (c_int, [_I, _P, _P, _I, _I]),
     "aoclsparse_zsctr_kid": (c_int, [_I, _P, _P, _P, _I]),
     "aoclsparse_zsctrs_kid": (c_int, [_I, _P, _I, _P, _I]),
+    "aoclsparse_csr2dia_ndiag": (c_int, [_I, _I, _P, _I, _P, _P, _P]),
+    "aoclsparse_csr2bsr_nnz": (c_int, [_I, _I, _P, _P, _P, _I, _P, _P]),
+    "aoclsparse_scsr2dia": (c_int, [_I, _I, _P, _P, _P, _P, _I, _P, _P]),
+    "aoclsparse_sdiamv": (c_int, [c_int, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
+    "aoclsparse_sdiamv_kid": (c_int, [c_int, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I]),
+    "aoclsparse_sbsrmv": (c_int, [c_int, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "aoclsparse_dcsr2dia": (c_int, [_I, _I, _P, _P, _P, _P, _I, _P, _P]),
+    "aoclsparse_ddiamv": (c_int, [c_int, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
+    "aoclsparse_ddiamv_kid": (c_int, [c_int, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I]),
+    "aoclsparse_dbsrmv": (c_int, [c_int, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "aoclsparse_scsr2bsr": (c_int, [_I, _I, _P, c_int, _P, _P, _P, _I, _P, _P, _P]),
+    "aoclsparse_dcsr2bsr": (c_int, [_I, _I, _P, c_int, _P, _P, _P, _I, _P, _P, _P]),
+    "aoclsparse_ccsr2bsr": (c_int, [_I, _I, _P, c_int, _P, _P, _P, _I, _P, _P, _P]),
+    "aoclsparse_zcsr2bsr": (c_int, [_I, _I, _P, c_int, _P, _P, _P, _I, _P, _P, _P]),
     # include/aoclsparse_mi355.h
     "aoclsparse_mi355_set_pointer_mode": (c_int, [c_int]),
     "aoclsparse_mi355_set_stream": (c_int, [_P]),

@@ -1090,6 +1090,72 @@ DLL_PUBLIC aoclsparse_status aoclsparse_zsctrs_kid(const aoclsparse_int nnz, con
 DLL_PUBLIC aoclsparse_status aoclsparse_sroti_kid(const aoclsparse_int nnz, float *x, const aoclsparse_int *indx, float *y, const float c, const float s, aoclsparse_int kid);
 DLL_PUBLIC aoclsparse_status aoclsparse_droti_kid(const aoclsparse_int nnz, double *x, const aoclsparse_int *indx, double *y, const double c, const double s, aoclsparse_int kid);
 
+/* ---- DIA and BSR raw-array formats -----------------------------------------------------------------------------
+ * Replaces library/include/aoclsparse_convert.h:215-221 (csr2dia_ndiag), :266-285 (?csr2dia), :324-331 (csr2bsr_nnz),
+ * :380-430 (?csr2bsr) and library/include/aoclsparse_functions.h:1040-1106 (?diamv, ?diamv_kid), ?bsrmv.
+ * Conversions work on host arrays; the products accept host or device arrays. */
+DLL_PUBLIC aoclsparse_status aoclsparse_csr2dia_ndiag(aoclsparse_int m, aoclsparse_int n, const aoclsparse_mat_descr descr,
+                                                      aoclsparse_int nnz, const aoclsparse_int *csr_row_ptr,
+                                                      const aoclsparse_int *csr_col_ind, aoclsparse_int *dia_num_diag);
+DLL_PUBLIC aoclsparse_status aoclsparse_csr2bsr_nnz(aoclsparse_int m, aoclsparse_int n, const aoclsparse_mat_descr descr,
+                                                    const aoclsparse_int *csr_row_ptr, const aoclsparse_int *csr_col_ind,
+                                                    aoclsparse_int block_dim, aoclsparse_int *bsr_row_ptr,
+                                                    aoclsparse_int *bsr_nnz);
+DLL_PUBLIC aoclsparse_status aoclsparse_scsr2dia(aoclsparse_int m, aoclsparse_int n, const aoclsparse_mat_descr descr,
+                                               const aoclsparse_int *csr_row_ptr, const aoclsparse_int *csr_col_ind,
+                                               const float *csr_val, aoclsparse_int dia_num_diag,
+                                               aoclsparse_int *dia_offset, float *dia_val);
+DLL_PUBLIC aoclsparse_status aoclsparse_sdiamv(aoclsparse_operation trans, const float *alpha, aoclsparse_int m,
+                                             aoclsparse_int n, aoclsparse_int nnz, const float *dia_val,
+                                             const aoclsparse_int *dia_offset, aoclsparse_int dia_num_diag,
+                                             const aoclsparse_mat_descr descr, const float *x, const float *beta, float *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_sdiamv_kid(aoclsparse_operation trans, const float *alpha, aoclsparse_int m,
+                                                 aoclsparse_int n, aoclsparse_int nnz, const float *dia_val,
+                                                 const aoclsparse_int *dia_offset, aoclsparse_int dia_num_diag,
+                                                 const aoclsparse_mat_descr descr, const float *x, const float *beta,
+                                                 float *y, aoclsparse_int diamv_mode, aoclsparse_int diamv_kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_sbsrmv(aoclsparse_operation trans, const float *alpha, aoclsparse_int mb,
+                                             aoclsparse_int nb, aoclsparse_int bsr_dim, const float *bsr_val,
+                                             const aoclsparse_int *bsr_col_ind, const aoclsparse_int *bsr_row_ptr,
+                                             const aoclsparse_mat_descr descr, const float *x, const float *beta, float *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_dcsr2dia(aoclsparse_int m, aoclsparse_int n, const aoclsparse_mat_descr descr,
+                                               const aoclsparse_int *csr_row_ptr, const aoclsparse_int *csr_col_ind,
+                                               const double *csr_val, aoclsparse_int dia_num_diag,
+                                               aoclsparse_int *dia_offset, double *dia_val);
+DLL_PUBLIC aoclsparse_status aoclsparse_ddiamv(aoclsparse_operation trans, const double *alpha, aoclsparse_int m,
+                                             aoclsparse_int n, aoclsparse_int nnz, const double *dia_val,
+                                             const aoclsparse_int *dia_offset, aoclsparse_int dia_num_diag,
+                                             const aoclsparse_mat_descr descr, const double *x, const double *beta, double *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_ddiamv_kid(aoclsparse_operation trans, const double *alpha, aoclsparse_int m,
+                                                 aoclsparse_int n, aoclsparse_int nnz, const double *dia_val,
+                                                 const aoclsparse_int *dia_offset, aoclsparse_int dia_num_diag,
+                                                 const aoclsparse_mat_descr descr, const double *x, const double *beta,
+                                                 double *y, aoclsparse_int diamv_mode, aoclsparse_int diamv_kid);
+DLL_PUBLIC aoclsparse_status aoclsparse_dbsrmv(aoclsparse_operation trans, const double *alpha, aoclsparse_int mb,
+                                             aoclsparse_int nb, aoclsparse_int bsr_dim, const double *bsr_val,
+                                             const aoclsparse_int *bsr_col_ind, const aoclsparse_int *bsr_row_ptr,
+                                             const aoclsparse_mat_descr descr, const double *x, const double *beta, double *y);
+DLL_PUBLIC aoclsparse_status aoclsparse_scsr2bsr(aoclsparse_int m, aoclsparse_int n, const aoclsparse_mat_descr descr,
+                                               const aoclsparse_order block_order, const float *csr_val,
+                                               const aoclsparse_int *csr_row_ptr, const aoclsparse_int *csr_col_ind,
+                                               aoclsparse_int block_dim, float *bsr_val, aoclsparse_int *bsr_row_ptr,
+                                               aoclsparse_int *bsr_col_ind);
+DLL_PUBLIC aoclsparse_status aoclsparse_dcsr2bsr(aoclsparse_int m, aoclsparse_int n, const aoclsparse_mat_descr descr,
+                                               const aoclsparse_order block_order, const double *csr_val,
+                                               const aoclsparse_int *csr_row_ptr, const aoclsparse_int *csr_col_ind,
+                                               aoclsparse_int block_dim, double *bsr_val, aoclsparse_int *bsr_row_ptr,
+                                               aoclsparse_int *bsr_col_ind);
+DLL_PUBLIC aoclsparse_status aoclsparse_ccsr2bsr(aoclsparse_int m, aoclsparse_int n, const aoclsparse_mat_descr descr,
+                                               const aoclsparse_order block_order, const aoclsparse_float_complex *csr_val,
+                                               const aoclsparse_int *csr_row_ptr, const aoclsparse_int *csr_col_ind,
+                                               aoclsparse_int block_dim, aoclsparse_float_complex *bsr_val, aoclsparse_int *bsr_row_ptr,
+                                               aoclsparse_int *bsr_col_ind);
+DLL_PUBLIC aoclsparse_status aoclsparse_zcsr2bsr(aoclsparse_int m, aoclsparse_int n, const aoclsparse_mat_descr descr,
+                                               const aoclsparse_order block_order, const aoclsparse_double_complex *csr_val,
+                                               const aoclsparse_int *csr_row_ptr, const aoclsparse_int *csr_col_ind,
+                                               aoclsparse_int block_dim, aoclsparse_double_complex *bsr_val, aoclsparse_int *bsr_row_ptr,
+                                               aoclsparse_int *bsr_col_ind);
+
 #ifdef __cplusplus
 }
 #endif

@@ -474,6 +474,47 @@ def sctr(x, indx, y):
     return y
 
 
+def csr2dia(m, n, base, ptr, ind, val):
+    """(ndiag, dia_offset, dia_val[m*ndiag]) -- convert.cpp:510-566, convert.hpp:291-387."""
+    ptr, ind, val = _i32(ptr), _i32(ind), _f64(val)
+    lib().orc_csr2dia_ndiag.restype = c_i32
+    nd = lib().orc_csr2dia_ndiag(c_i32(m), c_i32(n), c_int(base), _p(ptr), _p(ind))
+    off = np.zeros(max(nd, 1), dtype=np.int32)
+    dv = np.zeros(max(nd * m, 1), dtype=np.float64)
+    st = lib().orc_dcsr2dia(c_i32(m), c_i32(n), c_int(base), _p(ptr), _p(ind), _p(val), c_i32(nd), _p(off), _p(dv))
+    assert st == 0
+    return nd, off[:nd], dv[: nd * m]
+
+
+def ddiamv(alpha, m, n, dia_val, dia_offset, x, beta, y):
+    dia_val, dia_offset, x, y = _f64(dia_val), _i32(dia_offset), _f64(x), _f64(y).copy()
+    lib().orc_ddiamv(c_dbl(alpha), c_i32(m), c_i32(n), _p(dia_val), _p(dia_offset), c_i32(len(dia_offset)), _p(x),
+                     c_dbl(beta), _p(y))
+    return y
+
+
+def csr2bsr(m, n, base, ptr, ind, val, dim, rowmajor):
+    """(bsr_row_ptr, bsr_col_ind, bsr_val) -- convert.cpp:596-729, convert.hpp:389-551."""
+    ptr, ind, val = _i32(ptr), _i32(ind), _f64(val)
+    mb = (m + dim - 1) // dim
+    bp = np.zeros(mb + 1, dtype=np.int32)
+    lib().orc_csr2bsr_nnz.restype = c_i32
+    nb = lib().orc_csr2bsr_nnz(c_i32(m), c_i32(n), c_int(base), _p(ptr), _p(ind), c_i32(dim), _p(bp))
+    assert nb >= 0
+    bi = np.zeros(max(nb, 1), dtype=np.int32)
+    bv = np.zeros(max(nb * dim * dim, 1), dtype=np.float64)
+    st = lib().orc_dcsr2bsr(c_i32(m), c_i32(n), c_int(base), c_int(1 if rowmajor else 0), _p(val), _p(ptr), _p(ind),
+                            c_i32(dim), _p(bv), _p(bp), _p(bi))
+    assert st == 0
+    return bp, bi[:nb], bv[: nb * dim * dim]
+
+
+def dbsrmv(alpha, mb, dim, base, val, col, ptr, x, beta, y):
+    val, col, ptr, x, y = _f64(val), _i32(col), _i32(ptr), _f64(x), _f64(y).copy()
+    lib().orc_dbsrmv(c_dbl(alpha), c_i32(mb), c_i32(dim), c_int(base), _p(val), _p(col), _p(ptr), _p(x), c_dbl(beta), _p(y))
+    return y
+
+
 # ---- complex CG / GMRES, numpy restatements of solvers/aoclsparse_itsol_functions.hpp:632-875 and :910-1367 for
 # T = std::complex (dense operator A; no preconditioner).  No reference vectors exist for them: parity unpinned, the
 # checks are exit status, iteration counts and the solver tolerances.

@@ -1847,3 +1847,184 @@ int orc_droti(oint nnz, double *x, const oint *indx, double *y, double c, double
     }
     return ORC_SUCCESS;
 }
+
+
+/* ---- DIA: conversion/aoclsparse_convert.cpp:510-566, conversion/aoclsparse_convert.hpp:291-387,
+ * level2/aoclsparse_diamv.hpp:34-70 (reference kernel) -------------------------------------------------------- */
+oint orc_csr2dia_ndiag(oint m, oint n, int base, const oint *ptr, const oint *ind)
+{
+    char *seen = (char *)calloc((size_t)m + (size_t)n + 1, 1);
+    oint  cnt  = 0;
+    if(!seen)
+        return -1;
+    for(oint i = 0; i < m; i++)
+        for(oint j = ptr[i] - base; j < ptr[i + 1] - base; j++)
+        {
+            const oint off = ind[j] - base - i + m;
+            if(!seen[off])
+            {
+                seen[off] = 1;
+                cnt++;
+            }
+        }
+    free(seen);
+    return cnt;
+}
+
+/* dia_val must come in zero-filled (m * ndiag): the reference only writes the stored entries (:372-383) */
+int orc_dcsr2dia(oint m, oint n, int base, const oint *ptr, const oint *ind, const double *val, oint ndiag,
+                 oint *dia_offset, double *dia_val)
+{
+    oint *rank = (oint *)calloc((size_t)m + (size_t)n + 1, sizeof(oint));
+    if(!rank)
+        return ORC_MEMORY_ERROR;
+    for(oint i = 0; i < m; i++)
+        for(oint j = ptr[i] - base; j < ptr[i + 1] - base; j++)
+            rank[ind[j] - base - i + m] = 1;
+    oint d = 0;
+    for(oint k = 0; k < m + n; k++)
+        if(rank[k])
+        {
+            rank[k] = d;
+            if(d < ndiag)
+                dia_offset[d] = k - m;
+            d++;
+        }
+    for(oint i = 0; i < m; i++)
+        for(oint j = ptr[i] - base; j < ptr[i + 1] - base; j++)
+            dia_val[i + (size_t)m * rank[ind[j] - base - i + m]] = val[j];
+    free(rank);
+    return ORC_SUCCESS;
+}
+
+void orc_ddiamv(double alpha, oint m, oint n, const double *dia_val, const oint *dia_offset, oint ndiag,
+                const double *x, double beta, double *y)
+{
+    if(beta == 0.0)
+        for(oint i = 0; i < m; i++)
+            y[i] = 0.0;
+    else if(beta != 1.0)
+        for(oint i = 0; i < m; i++)
+            y[i] = beta * y[i];
+    for(oint d = 0; d < ndiag; d++)
+    {
+        const oint off = dia_offset[d];
+        const oint i0 = off < 0 ? -off : 0, j0 = off > 0 ? off : 0;
+        const oint cnt = (m - i0) < (n - j0) ? (m - i0) : (n - j0);
+        for(oint j = 0; j < cnt; j++)
+            y[i0 + j] = fma(alpha * dia_val[i0 + (size_t)d * m + j], x[j + j0], y[i0 + j]);
+    }
+}
+
+/* ---- BSR: conversion/aoclsparse_convert.cpp:596-729, conversion/aoclsparse_convert.hpp:389-551,
+ * level2/aoclsparse_bsrmv_kr.hpp:30-94 with aoclsparse_bsrmv_bldr.hpp:47-161 ----------------------------------- */
+oint orc_csr2bsr_nnz(oint m, oint n, int base, const oint *ptr, const oint *ind, oint dim, oint *bsr_ptr)
+{
+    const oint mb = (m + dim - 1) / dim, nb = (n + dim - 1) / dim;
+    char      *hit = (char *)calloc((size_t)nb + 1, 1);
+    oint      *undo = (oint *)malloc(sizeof(oint) * ((size_t)nb + 1));
+    if(!hit || !undo)
+    {
+        free(hit);
+        free(undo);
+        return -1;
+    }
+    bsr_ptr[0] = base;
+    for(oint bi = 0; bi < mb; bi++)
+    {
+        oint k = 0;
+        for(oint i = 0; i < dim && bi * dim + i < m; i++)
+            for(oint j = ptr[bi * dim + i] - base; j < ptr[bi * dim + i + 1] - base; j++)
+            {
+                const oint bc = (ind[j] - base) / dim;
+                if(!hit[bc])
+                {
+                    hit[bc]   = 1;
+                    undo[k++] = bc;
+                }
+            }
+        bsr_ptr[bi + 1] = bsr_ptr[bi] + k;
+        while(k > 0)
+            hit[undo[--k]] = 0;
+    }
+    free(hit);
+    free(undo);
+    return bsr_ptr[mb] - base;
+}
+
+/* bsr_val must come in zero-filled; rowmajor: element (i,j) of a block at i*dim+j, else i+j*dim */
+int orc_dcsr2bsr(oint m, oint n, int base, int rowmajor, const double *val, const oint *ptr, const oint *ind, oint dim,
+                 double *bsr_val, const oint *bsr_ptr, oint *bsr_ind)
+{
+    const oint   mb = (m + dim - 1) / dim, nb = (n + dim - 1) / dim;
+    const size_t sq = (size_t)dim * dim;
+    long long   *at = (long long *)malloc(sizeof(long long) * ((size_t)nb + 1));
+    double      *sw = (double *)malloc(sizeof(double) * sq);
+    if(!at || !sw)
+    {
+        free(at);
+        free(sw);
+        return ORC_MEMORY_ERROR;
+    }
+    for(oint k = 0; k < nb; k++)
+        at[k] = -1;
+    for(oint bi = 0; bi < mb; bi++)
+    {
+        oint w = bsr_ptr[bi] - base;
+        for(oint i = 0; i < dim && bi * dim + i < m; i++)
+            for(oint p = ptr[bi * dim + i] - base; p < ptr[bi * dim + i + 1] - base; p++)
+            {
+                const oint c = ind[p] - base, bc = c / dim, j = c % dim;
+                if(at[bc] < 0)
+                {
+                    at[bc]       = (long long)w * (long long)sq;
+                    bsr_ind[w++] = bc + base;
+                }
+                bsr_val[at[bc] + (rowmajor ? (size_t)i * dim + j : (size_t)i + (size_t)j * dim)] = val[p];
+            }
+        for(oint k = bsr_ptr[bi] - base; k < bsr_ptr[bi + 1] - base; k++)
+            at[bsr_ind[k] - base] = -1;
+    }
+    /* the reference's bubble sort of every block row by block column (:518-544) */
+    for(oint bi = 0; bi < mb; bi++)
+    {
+        const oint b = bsr_ptr[bi] - base, e = bsr_ptr[bi + 1] - base;
+        for(oint pass = b; pass < e; pass++)
+            for(oint k = b; k < e - 1; k++)
+                if(bsr_ind[k] > bsr_ind[k + 1])
+                {
+                    memcpy(sw, bsr_val + sq * k, sizeof(double) * sq);
+                    memcpy(bsr_val + sq * k, bsr_val + sq * (k + 1), sizeof(double) * sq);
+                    memcpy(bsr_val + sq * (k + 1), sw, sizeof(double) * sq);
+                    const oint t   = bsr_ind[k];
+                    bsr_ind[k]     = bsr_ind[k + 1];
+                    bsr_ind[k + 1] = t;
+                }
+    }
+    free(at);
+    free(sw);
+    return ORC_SUCCESS;
+}
+
+void orc_dbsrmv(double alpha, oint mb, oint dim, int base, const double *val, const oint *col, const oint *ptr,
+                const double *x, double beta, double *y)
+{
+    const size_t sq = (size_t)dim * dim;
+    for(oint ai = 0; ai < mb; ai++)
+        for(oint bi = 0; bi < dim; bi++)
+        {
+            double sum = 0.0;
+            for(oint aj = ptr[ai] - base; aj < ptr[ai + 1] - base; aj++)
+            {
+                const double *v  = val + sq * aj + bi;
+                const double *xp = x + (size_t)dim * (col[aj] - base);
+                for(oint bj = 0; bj < dim; bj++)
+                    sum = fma(v[(size_t)dim * bj], xp[bj], sum);
+            }
+            if(alpha != 1.0)
+                sum = sum * alpha;
+            if(beta != 0.0)
+                sum = fma(beta, y[(size_t)ai * dim + bi], sum);
+            y[(size_t)ai * dim + bi] = sum;
+        }
+}

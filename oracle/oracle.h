@@ -230,6 +230,18 @@ int    orc_daxpyi(oint nnz, double a, const double *x, const oint *indx, double 
 double orc_ddoti(oint nnz, const double *x, const oint *indx, const double *y);
 int    orc_droti(oint nnz, double *x, const oint *indx, double *y, double c, double s);
 
+/* DIA and BSR raw-array formats (convert.cpp:510-729, convert.hpp:291-551, diamv.hpp:34-70, bsrmv_kr.hpp:30-94) */
+oint orc_csr2dia_ndiag(oint m, oint n, int base, const oint *ptr, const oint *ind);
+int  orc_dcsr2dia(oint m, oint n, int base, const oint *ptr, const oint *ind, const double *val, oint ndiag,
+                  oint *dia_offset, double *dia_val);
+void orc_ddiamv(double alpha, oint m, oint n, const double *dia_val, const oint *dia_offset, oint ndiag,
+                const double *x, double beta, double *y);
+oint orc_csr2bsr_nnz(oint m, oint n, int base, const oint *ptr, const oint *ind, oint dim, oint *bsr_ptr);
+int  orc_dcsr2bsr(oint m, oint n, int base, int rowmajor, const double *val, const oint *ptr, const oint *ind, oint dim,
+                  double *bsr_val, const oint *bsr_ptr, oint *bsr_ind);
+void orc_dbsrmv(double alpha, oint mb, oint dim, int base, const double *val, const oint *col, const oint *ptr,
+                const double *x, double beta, double *y);
+
 #ifdef __cplusplus
 }
 #endif

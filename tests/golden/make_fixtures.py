@@ -387,6 +387,14 @@ out["level1"] = dict(
               x=list(range(1, 18)), y_nnz17=[12, 1, 10, 8, 15, 2, 5, 9, 6, 7, 11, 16, 14, 3, 4, 13, 17],
               y_nnz10=[0, 1, 10, 8, 0, 2, 5, 9, 6, 7, 0, 0, 0, 3, 4, 0, 0]))
 
+# ------------------------------------------------------------------------------------------
+# DIA / BSR: tests/unit_tests/diamv_tests.cpp:137-197 (one-based CSR -> DIA -> diamv) and
+# tests/unit_tests/bsrmv_tests.cpp:40-101 (zero-based CSR -> BSR, block 2, column-major blocks -> bsrmv; y padded to 6)
+# ------------------------------------------------------------------------------------------
+out["dia_bsr"] = dict(src="tests/unit_tests/diamv_tests.cpp:137-197, bsrmv_tests.cpp:40-101", m=5, n=5,
+                      row_ptr=[0, 1, 2, 4, 6, 7], col_ind=[0, 1, 1, 2, 0, 3, 3], val=[6, 1, 2, 3, 5, 1, 10],
+                      x=[1, 2, 3, 4, 5, 6], y_gold=[6, 2, 13, 9, 40, 0], bsr_dim=2)
+
 with open(n25_path, "w") as f:
     json.dump(out, f, indent=None, separators=(",", ":"))
     f.write("\n")

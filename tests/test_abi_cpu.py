@@ -751,3 +751,66 @@ def test_level1_argument_checks():
     assert L.aoclsparse_ssctrs_kid(2, X, 1, Y, 5) == 14
     assert L.aoclsparse_droti(2, None, IX, Y, 1.0, 0.0) == 2 and L.aoclsparse_droti(0, X, IX, Y, 1.0, 0.0) == 0
     assert L.aoclsparse_droti(-2, X, IX, Y, 1.0, 0.0) == 3 and L.aoclsparse_sroti_kid(2, X, IX, Y, 1.0, 0.0, 4) == 14
+
+
+@pytest.mark.parametrize("base", [0, 1])
+def test_dia_bsr_conversions_match_the_oracle(base, kats):
+    """aoclsparse_csr2dia_ndiag / ?csr2dia / csr2bsr_nnz / ?csr2bsr are host routines: bit-exact against the oracle
+    (and through it the reference's vectors), plus their argument checks (convert.cpp:518-531, :605-637,
+    convert.hpp:301-334, :401-440) and those of ?diamv / ?bsrmv that precede any device work."""
+    m, n = 203, 167
+    rp, ci, v = random_csr(95, m, n, lambda r, i: r.integers(0, 9), base=base, sort=False)
+    d = P.Descr(base=base)
+    nd = ctypes.c_int32(-1)
+    assert L.aoclsparse_csr2dia_ndiag(m, n, d.h, len(v), P._ptr(rp), P._ptr(ci), ctypes.byref(nd)) == 0
+    ond, ooff, odv = oracle.csr2dia(m, n, base, rp, ci, v)
+    off, dv = np.zeros(nd.value, np.int32), np.zeros(nd.value * m)
+    assert nd.value == ond
+    assert L.aoclsparse_dcsr2dia(m, n, d.h, P._ptr(rp), P._ptr(ci), P._ptr(v), nd.value, P._ptr(off), P._ptr(dv)) == 0
+    assert np.array_equal(off, ooff) and np.array_equal(dv, odv)
+    vf, dvf = v.astype(np.float32), np.zeros(nd.value * m, np.float32)
+    assert L.aoclsparse_scsr2dia(m, n, d.h, P._ptr(rp), P._ptr(ci), P._ptr(vf), nd.value, P._ptr(off), P._ptr(dvf)) == 0
+    assert np.array_equal(dvf, odv.astype(np.float32))
+    for dim in (1, 2, 5, 8):
+        for order, rowmajor in ((P.ORDER_ROW, True), (P.ORDER_COLUMN, False)):
+            mb = (m + dim - 1) // dim
+            bp, nnzb = np.zeros(mb + 1, np.int32), ctypes.c_int32(-1)
+            assert L.aoclsparse_csr2bsr_nnz(m, n, d.h, P._ptr(rp), P._ptr(ci), dim, P._ptr(bp), ctypes.byref(nnzb)) == 0
+            obp, obi, obv = oracle.csr2bsr(m, n, base, rp, ci, v, dim, rowmajor)
+            assert nnzb.value == len(obi) and np.array_equal(bp, obp)
+            bi, bv = np.zeros(nnzb.value, np.int32), np.zeros(nnzb.value * dim * dim)
+            assert L.aoclsparse_dcsr2bsr(m, n, d.h, order, P._ptr(v), P._ptr(rp), P._ptr(ci), dim, P._ptr(bv), P._ptr(bp), P._ptr(bi)) == 0
+            assert np.array_equal(bi, obi) and np.array_equal(bv, obv)
+            vz, bz = (v + 2j * v).astype(np.complex128), np.zeros(nnzb.value * dim * dim, np.complex128)
+            assert L.aoclsparse_zcsr2bsr(m, n, d.h, order, P._ptr(vz), P._ptr(rp), P._ptr(ci), dim, P._ptr(bz), P._ptr(bp), P._ptr(bi)) == 0
+            assert np.array_equal(bz, obv + 2j * obv)
+    # argument checks
+    assert L.aoclsparse_csr2dia_ndiag(-1, n, d.h, 1, P._ptr(rp), P._ptr(ci), ctypes.byref(nd)) == 3
+    assert L.aoclsparse_csr2dia_ndiag(m, n, d.h, 1, P._ptr(rp), P._ptr(ci), None) == 2
+    assert L.aoclsparse_csr2dia_ndiag(m, n, d.h, 1, None, P._ptr(ci), ctypes.byref(nd)) == 2
+    assert L.aoclsparse_dcsr2dia(m, n, d.h, P._ptr(rp), P._ptr(ci), P._ptr(v), -1, P._ptr(off), P._ptr(dv)) == 3
+    assert L.aoclsparse_dcsr2dia(m, n, d.h, P._ptr(rp), P._ptr(ci), P._ptr(v), 0, None, None) == 0
+    assert L.aoclsparse_dcsr2dia(m, n, d.h, P._ptr(rp), P._ptr(ci), None, 3, P._ptr(off), P._ptr(dv)) == 2
+    bp, nnzb = np.zeros(m + 1, np.int32), ctypes.c_int32(-1)
+    assert L.aoclsparse_csr2bsr_nnz(m, n, d.h, P._ptr(rp), P._ptr(ci), 0, P._ptr(bp), ctypes.byref(nnzb)) == 3
+    assert L.aoclsparse_csr2bsr_nnz(m, n, d.h, P._ptr(rp), None, 2, P._ptr(bp), ctypes.byref(nnzb)) == 2
+    assert L.aoclsparse_csr2bsr_nnz(0, n, d.h, P._ptr(rp), P._ptr(ci), 2, P._ptr(bp), ctypes.byref(nnzb)) == 0 and nnzb.value == 0
+    assert L.aoclsparse_dcsr2bsr(m, n, d.h, P.ORDER_ROW, P._ptr(v), P._ptr(rp), P._ptr(ci), 0, P._ptr(v), P._ptr(bp), P._ptr(bp)) == 5
+    assert L.aoclsparse_dcsr2bsr(m, n, d.h, P.ORDER_ROW, None, P._ptr(rp), P._ptr(ci), 2, P._ptr(v), P._ptr(bp), P._ptr(bp)) == 2
+    a, b, x, y = ctypes.c_double(1.0), ctypes.c_double(0.0), np.zeros(n), np.zeros(m)
+    A, B = ctypes.byref(a), ctypes.byref(b)
+    f = L.aoclsparse_ddiamv
+    assert f(P.OP_NONE, None, m, n, 0, P._ptr(dv), P._ptr(off), 1, d.h, P._ptr(x), B, P._ptr(y)) == 2
+    assert f(P.OP_NONE, A, m, n, 0, P._ptr(dv), P._ptr(off), 1, None, P._ptr(x), B, P._ptr(y)) == 2
+    assert f(P.OP_TRANSPOSE, A, m, n, 0, P._ptr(dv), P._ptr(off), 1, d.h, P._ptr(x), B, P._ptr(y)) == 1
+    assert f(P.OP_NONE, A, m, n, 0, P._ptr(dv), P._ptr(off), 1, P.Descr(base=base, mtype=P.TYPE_SYMMETRIC).h, P._ptr(x), B, P._ptr(y)) == 1
+    assert f(P.OP_NONE, A, m, n, 0, P._ptr(dv), P._ptr(off), -1, d.h, P._ptr(x), B, P._ptr(y)) == 3
+    assert f(P.OP_NONE, A, 0, n, 0, P._ptr(dv), P._ptr(off), 1, d.h, P._ptr(x), B, P._ptr(y)) == 0
+    assert L.aoclsparse_ddiamv_kid(P.OP_NONE, A, m, n, 0, P._ptr(dv), P._ptr(off), 1, d.h, P._ptr(x), B, P._ptr(y), 0, 4) == 14
+    g = L.aoclsparse_dbsrmv
+    assert g(P.OP_NONE, None, 2, 2, 2, P._ptr(v), P._ptr(ci), P._ptr(rp), d.h, P._ptr(x), B, P._ptr(y)) == 2
+    assert g(P.OP_NONE, A, 2, 2, 2, P._ptr(v), P._ptr(ci), P._ptr(rp), None, P._ptr(x), B, P._ptr(y)) == 2
+    assert g(P.OP_TRANSPOSE, A, 2, 2, 2, P._ptr(v), P._ptr(ci), P._ptr(rp), d.h, P._ptr(x), B, P._ptr(y)) == 1
+    assert g(P.OP_NONE, A, 2, 2, 0, P._ptr(v), P._ptr(ci), P._ptr(rp), d.h, P._ptr(x), B, P._ptr(y)) == 3
+    assert g(P.OP_NONE, A, 0, 2, 2, None, None, None, d.h, None, B, None) == 0
+    assert g(P.OP_NONE, A, 2, 2, 2, None, P._ptr(ci), P._ptr(rp), d.h, P._ptr(x), B, P._ptr(y)) == 2

@@ -2934,3 +2934,95 @@ def test_level1_large_host_and_device_vectors():
     assert L.aoclsparse_zgthrz(m, P._ptr(y8), P._ptr(xo), P._ptr(iz)) == 0 and np.array_equal(xo, yz[iz]) and np.all(y8[iz] == 0)
     y9 = np.zeros(1 << 18, np.complex64)
     assert L.aoclsparse_csctr(m, P._ptr(xc), P._ptr(iz), P._ptr(y9)) == 0 and np.array_equal(y9[iz], xc)
+
+
+# --------------------------------------------------------------------------------------------------
+# DIA and BSR products (level2/aoclsparse_diamv.hpp:34-70, level2/aoclsparse_bsrmv_kr.hpp:30-154)
+# --------------------------------------------------------------------------------------------------
+def test_diamv_bsrmv_reference_kat(kats):
+    """diamv_tests.cpp:137-197 and bsrmv_tests.cpp:40-101: CSR -> DIA / BSR through the library's converters, then the
+    product; host arrays, beta = 0 with NaN in y."""
+    k = kats["dia_bsr"]
+    for base in (0, 1):
+        rp, ci, v = np.array(k["row_ptr"], np.int32) + base, np.array(k["col_ind"], np.int32) + base, np.array(k["val"], np.float64)
+        d = P.Descr(base=base)
+        nd = ctypes.c_int32()
+        assert L.aoclsparse_csr2dia_ndiag(5, 5, d.h, 7, P._ptr(rp), P._ptr(ci), ctypes.byref(nd)) == 0 and nd.value == 3
+        off, dv = np.zeros(3, np.int32), np.zeros(15)
+        assert L.aoclsparse_dcsr2dia(5, 5, d.h, P._ptr(rp), P._ptr(ci), P._ptr(v), 3, P._ptr(off), P._ptr(dv)) == 0
+        a, b = ctypes.c_double(1.0), ctypes.c_double(0.0)
+        x, y = np.array(k["x"][:5], np.float64), np.full(5, np.nan)
+        assert L.aoclsparse_ddiamv(P.OP_NONE, ctypes.byref(a), 5, 5, 7, P._ptr(dv), P._ptr(off), 3, d.h, P._ptr(x), ctypes.byref(b), P._ptr(y)) == 0
+        assert np.array_equal(y, k["y_gold"][:5])
+        bp, nnzb = np.zeros(4, np.int32), ctypes.c_int32()
+        assert L.aoclsparse_csr2bsr_nnz(5, 5, d.h, P._ptr(rp), P._ptr(ci), 2, P._ptr(bp), ctypes.byref(nnzb)) == 0 and nnzb.value == 4
+        bi, bv = np.zeros(4, np.int32), np.zeros(16)
+        assert L.aoclsparse_dcsr2bsr(5, 5, d.h, P.ORDER_COLUMN, P._ptr(v), P._ptr(rp), P._ptr(ci), 2, P._ptr(bv), P._ptr(bp), P._ptr(bi)) == 0
+        x, y = np.array(k["x"], np.float64), np.full(6, np.nan)
+        assert L.aoclsparse_dbsrmv(P.OP_NONE, ctypes.byref(a), 3, 3, 2, P._ptr(bv), P._ptr(bi), P._ptr(bp), d.h, P._ptr(x), ctypes.byref(b), P._ptr(y)) == 0
+        assert np.array_equal(y, k["y_gold"])
+
+
+@pytest.mark.parametrize("base", [0, 1])
+def test_diamv_bsrmv_bit_exact_vs_oracle(base):
+    """Banded and random matrices, rectangular, (alpha, beta) incl. 1 / 0, every block size the reference has a kernel
+    for (2..8, 16) and two it serves by the general loop (1, 11); host and device arrays; fp32 against fp64 with an
+    n eps bound.  One lane per scalar row keeps the reference kernel's chain: bit-identical."""
+    import torch
+    dp = lambda t: ctypes.c_void_p(t.data_ptr())
+    for (m, n, rl, seed) in ((5000, 4300, lambda r, i: r.integers(0, 12), 1), (3000, 3000, None, 2)):
+        rp, ci, v = (random_csr(seed, m, n, rl, base=base, sort=False) if seed == 1 else _banded(m, 7, base))
+        d = P.Descr(base=base)
+        rng = np.random.default_rng(seed)
+        nd, off, dv = oracle.csr2dia(m, n, base, rp, ci, v)
+        if nd * m < 40_000_000:
+            x, y0 = rng.uniform(-1, 1, n), rng.uniform(-1, 1, m)
+            for alpha, beta in ((1.0, 0.0), (-0.75, 1.0), (2.5, -0.5)):
+                a, b = ctypes.c_double(alpha), ctypes.c_double(beta)
+                want = oracle.ddiamv(alpha, m, n, dv, off, x, beta, y0)
+                y = y0.copy() if beta != 0 else np.full(m, np.nan)
+                assert L.aoclsparse_ddiamv(P.OP_NONE, ctypes.byref(a), m, n, len(v), P._ptr(dv), P._ptr(off), nd, d.h, P._ptr(x), ctypes.byref(b), P._ptr(y)) == 0
+                assert np.array_equal(y, want), (m, alpha, beta)
+                t = [torch.from_numpy(z).cuda() for z in (dv, off, x, y0.copy())]
+                assert L.aoclsparse_ddiamv_kid(P.OP_NONE, ctypes.byref(a), m, n, len(v), dp(t[0]), dp(t[1]), nd, d.h, dp(t[2]), ctypes.byref(b), dp(t[3]), 0, 0) == 0
+                torch.cuda.synchronize()
+                assert np.array_equal(t[3].cpu().numpy(), want)
+            af, bf = ctypes.c_float(2.5), ctypes.c_float(-0.5)
+            yf = y0.astype(np.float32)
+            assert L.aoclsparse_sdiamv(P.OP_NONE, ctypes.byref(af), m, n, len(v), P._ptr(dv.astype(np.float32)), P._ptr(off), nd, d.h,
+                                       P._ptr(x.astype(np.float32)), ctypes.byref(bf), P._ptr(yf)) == 0
+            scale = 2.5 * np.abs(oracle.ddiamv(1.0, m, n, np.abs(dv), off, np.abs(x), 0.0, y0)) + np.abs(y0)
+            assert np.all(np.abs(yf - oracle.ddiamv(2.5, m, n, dv, off, x, -0.5, y0)) <= (nd + 4) * EPS32 * scale + 1e-30)
+        for dim in (1, 2, 3, 4, 5, 6, 7, 8, 11, 16):
+            mb, nb = (m + dim - 1) // dim, (n + dim - 1) // dim
+            bp, bi, bv = oracle.csr2bsr(m, n, base, rp, ci, v, dim, False)
+            x, y0 = rng.uniform(-1, 1, nb * dim), rng.uniform(-1, 1, mb * dim)
+            for alpha, beta in ((1.0, 0.0), (-0.75, 1.0), (2.5, -0.5)):
+                a, b = ctypes.c_double(alpha), ctypes.c_double(beta)
+                want = oracle.dbsrmv(alpha, mb, dim, base, bv, bi, bp, x, beta, y0)
+                y = y0.copy() if beta != 0 else np.full(mb * dim, np.nan)
+                assert L.aoclsparse_dbsrmv(P.OP_NONE, ctypes.byref(a), mb, nb, dim, P._ptr(bv), P._ptr(bi), P._ptr(bp), d.h, P._ptr(x), ctypes.byref(b), P._ptr(y)) == 0
+                assert np.array_equal(y, want), (m, dim, alpha, beta)
+            t = [torch.from_numpy(z).cuda() for z in (bv, bi, bp, x, y0.copy())]
+            assert L.aoclsparse_dbsrmv(P.OP_NONE, ctypes.byref(a), mb, nb, dim, dp(t[0]), dp(t[1]), dp(t[2]), d.h, dp(t[3]), ctypes.byref(b), dp(t[4])) == 0
+            torch.cuda.synchronize()
+            assert np.array_equal(t[4].cpu().numpy(), want)
+        bp, bi, bv = oracle.csr2bsr(m, n, base, rp, ci, v, 4, False)
+        mb, nb = (m + 3) // 4, (n + 3) // 4
+        x, y0 = rng.uniform(-1, 1, nb * 4), rng.uniform(-1, 1, mb * 4)
+        af, bf = ctypes.c_float(2.5), ctypes.c_float(-0.5)
+        yf = y0.astype(np.float32)
+        assert L.aoclsparse_sbsrmv(P.OP_NONE, ctypes.byref(af), mb, nb, 4, P._ptr(bv.astype(np.float32)), P._ptr(bi), P._ptr(bp), d.h,
+                                   P._ptr(x.astype(np.float32)), ctypes.byref(bf), P._ptr(yf)) == 0
+        scale = 2.5 * oracle.dbsrmv(1.0, mb, 4, base, np.abs(bv), bi, bp, np.abs(x), 0.0, y0) + np.abs(y0)
+        assert np.all(np.abs(yf - oracle.dbsrmv(2.5, mb, 4, base, bv, bi, bp, x, -0.5, y0)) <= 64 * EPS32 * scale + 1e-30)
+
+
+def _banded(m, half, base):
+    """m x m band of half-width `half` (2*half+1 diagonals), rows sorted."""
+    rows = [np.arange(max(0, i - half), min(m, i + half + 1)) for i in range(m)]
+    rp = np.zeros(m + 1, np.int64)
+    rp[1:] = np.cumsum([len(r) for r in rows])
+    ci = np.concatenate(rows)
+    v = np.random.default_rng(12).uniform(-1, 1, len(ci))
+    return (rp + base).astype(np.int32), (ci + base).astype(np.int32), v

@@ -486,7 +486,7 @@ def test_complex_mv_restatement_on_a_hand_checked_hermitian_matrix():
 # --------------------------------------------------------------------------------------------------
 def _scipy_csr(m, n, base, ptr, ind, val):
     import scipy.sparse as sp
-    return sp.csr_matrix((np.asarray(val), np.asarray(ind) - base, np.asarray(ptr) - base), shape=(m, n))
+    return sp.csr_matrix((np.array(val, dtype=np.float64), np.asarray(ind) - base, np.asarray(ptr) - base), shape=(m, n))  # copies: scipy sorts in place
 
 
 def test_spmmd_and_csr2dense_kats(kats):
@@ -578,3 +578,39 @@ def test_level1_kats(kats):
     s = k["sctr"]
     assert np.array_equal(oracle.sctr(s["x"], s["indx"], np.zeros(17)), s["y_nnz17"])
     assert np.array_equal(oracle.sctr(s["x"], s["indx"][:10], np.zeros(17)), s["y_nnz10"])
+
+
+def test_dia_bsr_kats_and_properties(kats):
+    """diamv_tests.cpp:137-197 / bsrmv_tests.cpp:40-101, and the two formats against the pinned CSR SpMV oracle on random
+    matrices (same matrix, different storage: the products agree to a few ulp of sum|a x|)."""
+    k = kats["dia_bsr"]
+    for base in (0, 1):
+        rp, ci = np.array(k["row_ptr"]) + base, np.array(k["col_ind"]) + base
+        nd, off, dv = oracle.csr2dia(5, 5, base, rp, ci, k["val"])
+        assert nd == 3 and list(off) == [-3, -1, 0]
+        assert np.array_equal(oracle.ddiamv(1.0, 5, 5, dv, off, k["x"][:5], 0.0, np.full(5, np.nan)), k["y_gold"][:5])
+        for rowmajor in (False, True):
+            bp, bi, bv = oracle.csr2bsr(5, 5, base, rp, ci, k["val"], 2, rowmajor)
+            assert list(bp - base) == [0, 1, 3, 4] and list(bi - base) == [0, 0, 1, 1]
+            if not rowmajor:
+                assert np.array_equal(oracle.dbsrmv(1.0, 3, 2, base, bv, bi, bp, k["x"], 0.0, np.full(6, np.nan)), k["y_gold"])
+        blk = oracle.csr2bsr(5, 5, base, rp, ci, k["val"], 2, True)[2].reshape(-1, 2, 2)
+        assert np.array_equal(blk[0], [[6, 0], [0, 1]]) and np.array_equal(blk[1], [[0, 2], [5, 0]])
+    m, n = 301, 257
+    for base in (0, 1):
+        rp, ci, v = random_csr(91, m, n, lambda r, i: r.integers(0, 9), base=base, sort=False)
+        x, y0 = np.random.default_rng(1).uniform(-1, 1, n + 8), np.random.default_rng(2).uniform(-1, 1, m + 8)
+        so, yr = oracle.dcsrmv(0, base, 1.5, m, len(v), v, ci, rp, x[:n], -0.5, y0[:m])
+        scale = np.abs(_scipy_csr(m, n, base, rp, ci, v)) @ np.abs(x[:n]) * 1.5 + 0.5 * np.abs(y0[:m])
+        nd, off, dv = oracle.csr2dia(m, n, base, rp, ci, v)
+        assert nd == len(np.unique((ci - base) - np.repeat(np.arange(m), np.diff(rp)))) and np.all(np.diff(off) > 0)
+        assert np.all(np.abs(oracle.ddiamv(1.5, m, n, dv, off, x[:n], -0.5, y0[:m]) - yr) <= 16 * EPS * scale + 1e-300)
+        for dim in (2, 3, 7, 16):
+            mb, nb = (m + dim - 1) // dim, (n + dim - 1) // dim
+            bp, bi, bv = oracle.csr2bsr(m, n, base, rp, ci, v, dim, False)
+            assert all(np.all(np.diff(bi[bp[r] - base:bp[r + 1] - base]) > 0) for r in range(mb))
+            xx, yy = np.zeros(nb * dim), np.zeros(mb * dim)
+            xx[:n], yy[:m] = x[:n], y0[:m]
+            got = oracle.dbsrmv(1.5, mb, dim, base, bv, bi, bp, xx, -0.5, yy)
+            assert np.all(np.abs(got[:m] - yr) <= 16 * EPS * scale + 1e-300) and np.all(got[m:] == 0)
+            assert np.count_nonzero(bv) == len(v)
