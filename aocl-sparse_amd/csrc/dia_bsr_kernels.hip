@@ -39,13 +39,16 @@ __global__ __launch_bounds__(256) void diamv_kernel(T alpha, aoclsparse_int m, a
     y[i] = acc;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void bsrmv_kernel(T alpha, aoclsparse_int mb, aoclsparse_int dim, int base,
+// DIM > 0: block size known at compile time (the sizes the reference has dedicated kernels for, bsrmv.cpp:120-136), so
+// the loads of one block are all in flight before its multiply-add chain starts; DIM == 0: any size.
+template <typename T, int DIM>
+__global__ __launch_bounds__(256) void bsrmv_kernel(T alpha, aoclsparse_int mb, aoclsparse_int dim_rt, int base,
                                                     const T *__restrict__ val, const aoclsparse_int *__restrict__ col,
                                                     const aoclsparse_int *__restrict__ row_ptr, const T *__restrict__ x,
                                                     T beta, T *__restrict__ y)
 {
-    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; // scalar row
+    const aoclsparse_int dim = DIM > 0 ? DIM : dim_rt;
+    const long long      r = (long long)blockIdx.x * blockDim.x + threadIdx.x; // scalar row
     if(r >= (long long)mb * dim)
         return;
     const aoclsparse_int ai = (aoclsparse_int)(r / dim), bi = (aoclsparse_int)(r % dim);
@@ -55,8 +58,19 @@ __global__ __launch_bounds__(256) void bsrmv_kernel(T alpha, aoclsparse_int mb, 
     {
         const T *v  = val + sq * aj + bi;
         const T *xp = x + (size_t)dim * (col[aj] - base);
-        for(aoclsparse_int bj = 0; bj < dim; bj++)
-            sum = b_fma(v[(size_t)dim * bj], xp[bj], sum);
+        if constexpr(DIM > 0)
+        {
+            T a[DIM], b[DIM];
+#pragma unroll
+            for(int bj = 0; bj < DIM; bj++)
+                a[bj] = v[DIM * bj], b[bj] = xp[bj];
+#pragma unroll
+            for(int bj = 0; bj < DIM; bj++)
+                sum = b_fma(a[bj], b[bj], sum);
+        }
+        else
+            for(aoclsparse_int bj = 0; bj < dim; bj++)
+                sum = b_fma(v[(size_t)dim * bj], xp[bj], sum);
     }
     if(alpha != T(1))
         sum = sum * alpha;
@@ -84,8 +98,25 @@ aoclsparse_status launch_bsrmv(hipStream_t s, T alpha, aoclsparse_int mb, aoclsp
     const long long rows = (long long)mb * dim;
     if(rows <= 0)
         return aoclsparse_status_success;
-    hipLaunchKernelGGL((bsrmv_kernel<T>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, alpha, mb, dim, base, val,
-                       col, row_ptr, x, beta, y);
+    const dim3 grid((unsigned)((rows + 255) / 256)), block(256);
+#define MI355_BSR_CASE(D)                                                                                              \
+    case D:                                                                                                            \
+        hipLaunchKernelGGL((bsrmv_kernel<T, D>), grid, block, 0, s, alpha, mb, dim, base, val, col, row_ptr, x, beta, y); \
+        break;
+    switch(dim)
+    {
+        MI355_BSR_CASE(2)
+        MI355_BSR_CASE(3)
+        MI355_BSR_CASE(4)
+        MI355_BSR_CASE(5)
+        MI355_BSR_CASE(6)
+        MI355_BSR_CASE(7)
+        MI355_BSR_CASE(8)
+        MI355_BSR_CASE(16)
+    default:
+        hipLaunchKernelGGL((bsrmv_kernel<T, 0>), grid, block, 0, s, alpha, mb, dim, base, val, col, row_ptr, x, beta, y);
+    }
+#undef MI355_BSR_CASE
     MI355_HIP_TRY(hipGetLastError());
     return aoclsparse_status_success;
 }

@@ -22,7 +22,7 @@ from bench import csrmm_bytes, spmv_bytes  # noqa: E402
 pkg = entry.load_package()
 L = pkg.lib()
 ap = argparse.ArgumentParser()
-ap.add_argument("--what", default="spmv,csrmm,trsv,cg,next,setup,pcie")
+ap.add_argument("--what", default="spmv,csrmm,trsv,cg,next,wider,setup,pcie")
 ap.add_argument("--small", action="store_true", help="skip the two 50-120 M nnz stand-ins")
 args = ap.parse_args()
 what = set(args.what.split(","))
@@ -306,6 +306,98 @@ if "next" in what:
              note="one launch, columns are the fast grid dimension so their chains advance together; the reference loops trsv per column")
         del Bd, Xd
     del A
+
+if "wider" in what:
+    # routines beyond SURVEY 8(f): DIA / BSR products, dense-result sparse product, sparse sum, CSR -> dense, level 1
+    import ctypes
+    L.aoclsparse_mi355_set_pointer_mode(pkg.PTR_DEVICE)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    one, zero = ctypes.c_double(1.0), ctypes.c_double(0.0)
+    g = 4096
+    m, rp, ci, v = entry.laplace5(g)
+    nnz = len(v)
+    rng = np.random.default_rng(5)
+    xh = rng.uniform(-1, 1, m)
+    so, yref = oracle.dcsrmv(0, 0, 1.0, m, nnz, v, ci, rp, xh, 0.0, np.zeros(m), nthreads=oracle.max_threads())
+    # DIA: 5 diagonals, no index array at all
+    nd = ctypes.c_int32()
+    assert L.aoclsparse_mi355_set_pointer_mode(pkg.PTR_HOST) == 0
+    assert L.aoclsparse_csr2dia_ndiag(m, m, d0.h, nnz, pkg._ptr(rp), pkg._ptr(ci), ctypes.byref(nd)) == 0
+    off, dv = np.zeros(nd.value, np.int32), np.zeros(nd.value * m)
+    t0 = time.perf_counter()
+    assert L.aoclsparse_dcsr2dia(m, m, d0.h, pkg._ptr(rp), pkg._ptr(ci), pkg._ptr(v), nd.value, pkg._ptr(off), pkg._ptr(dv)) == 0
+    conv_s = time.perf_counter() - t0
+    assert L.aoclsparse_mi355_set_pointer_mode(pkg.PTR_DEVICE) == 0
+    dvd, offd, xd, yd = t(dv), t(off), t(xh), torch.zeros(m, dtype=torch.float64, device=dev)
+    fn = lambda: L.aoclsparse_ddiamv(pkg.OP_NONE, ctypes.byref(one), m, m, nnz, pkg._ptr(dvd), pkg._ptr(offd), nd.value, d0.h,
+                                     pkg._ptr(xd), ctypes.byref(zero), pkg._ptr(yd))
+    ms = time_calls(fn, 50)
+    db = nd.value * m * 8 + nd.value * 4 + 16 * m
+    emit(kind="wider", op="aoclsparse_ddiamv (device arrays)", system="5-pt Laplacian grid %d^2, %d diagonals" % (g, nd.value),
+         ms=round(ms, 4), dia_bytes=db, gbs=round(db / ms / 1e6, 1), frac_of_8TBs=round(db / ms / 1e6 / 8000, 4),
+         gflops=round(2 * nnz / ms / 1e6, 1), csr2dia_host_s=round(conv_s, 3),
+         equals_csr_oracle=bool(np.array_equal(yd.cpu().numpy(), yref)))
+    # BSR 4x4 on a block-structured matrix: the Laplacian pattern on a (g/2)^2 grid with dense 4x4 blocks
+    gb = 1024
+    mb, brp, bci, _ = entry.laplace5(gb)
+    nblk, dim = len(bci), 4
+    bv = rng.uniform(-1, 1, nblk * dim * dim)
+    bx = rng.uniform(-1, 1, mb * dim)
+    want = oracle.dbsrmv(1.0, mb, dim, 0, bv, bci, brp, bx, 0.0, np.zeros(mb * dim))
+    bvd, bcd, bpd, bxd, byd = t(bv), t(bci), t(brp), t(bx), torch.zeros(mb * dim, dtype=torch.float64, device=dev)
+    fn = lambda: L.aoclsparse_dbsrmv(pkg.OP_NONE, ctypes.byref(one), mb, mb, dim, pkg._ptr(bvd), pkg._ptr(bcd), pkg._ptr(bpd), d0.h,
+                                     pkg._ptr(bxd), ctypes.byref(zero), pkg._ptr(byd))
+    ms = time_calls(fn, 50)
+    bb = nblk * (dim * dim * 8 + 4) + (mb + 1) * 4 + 16 * mb * dim
+    emit(kind="wider", op="aoclsparse_dbsrmv 4x4 (device arrays)", system="5-pt block pattern grid %d^2, %d blocks" % (gb, nblk),
+         ms=round(ms, 4), bsr_bytes=bb, gbs=round(bb / ms / 1e6, 1), frac_of_8TBs=round(bb / ms / 1e6 / 8000, 4),
+         gflops=round(2 * nblk * dim * dim / ms / 1e6, 1), bit_exact=bool(np.array_equal(byd.cpu().numpy(), want)))
+    # dense-result product, sparse sum, CSR -> dense on the 100^2 .. 1000^2 Laplacians
+    m2, rp2, ci2, v2 = entry.laplace5(100)
+    A2 = pkg.Matrix(0, m2, m2, rp2, ci2, v2)
+    Cd = torch.zeros(m2 * m2, dtype=torch.float64, device=dev)
+    fn = lambda: L.aoclsparse_dspmmd(pkg.OP_NONE, A2.h, A2.h, pkg.ORDER_ROW, pkg._ptr(Cd), m2)
+    ms = time_calls(fn, 20)
+    want = oracle.dsp2md((m2, m2, 0, rp2, ci2, v2), False, (m2, m2, 0, rp2, ci2, v2), False, 1.0, 0.0, np.zeros(m2 * m2), True, m2)
+    emit(kind="wider", op="aoclsparse_dspmmd (dense C on device)", system="L100 x L100 -> dense 10000^2 (0.8 GB)", ms=round(ms, 4),
+         c_fill_gbs=round(m2 * m2 * 8 / ms / 1e6, 1), bit_exact=bool(np.array_equal(Cd.cpu().numpy(), want)))
+    Dd = torch.zeros(m2 * m2, dtype=torch.float64, device=dev)
+    vd2, rpd2, cid2 = t(v2), t(rp2), t(ci2)
+    fn = lambda: L.aoclsparse_dcsr2dense(m2, m2, d0.h, pkg._ptr(vd2), pkg._ptr(rpd2), pkg._ptr(cid2), pkg._ptr(Dd), m2, pkg.ORDER_ROW)
+    ms = time_calls(fn, 20)
+    emit(kind="wider", op="aoclsparse_dcsr2dense (device arrays)", system="L100 -> dense 10000^2 (0.8 GB)", ms=round(ms, 4),
+         fill_gbs=round(m2 * m2 * 8 / ms / 1e6, 1))
+    del Cd, Dd
+    m3, rp3, ci3, v3 = entry.laplace5(1000)
+    A3 = pkg.Matrix(0, m3, m3, rp3, ci3, v3)
+    B3 = pkg.Matrix(0, m3, m3, rp3, ci3, rng.uniform(-1, 1, len(v3)))
+    L.aoclsparse_mi355_set_pointer_mode(pkg.PTR_AUTO)
+    C = ctypes.c_void_p()
+    t0 = time.perf_counter()
+    assert L.aoclsparse_dadd(pkg.OP_TRANSPOSE, A3.h, 0.5, B3.h, ctypes.byref(C)) == 0
+    first = time.perf_counter() - t0
+    L.aoclsparse_destroy(ctypes.byref(C))
+    t0 = time.perf_counter()
+    assert L.aoclsparse_dadd(pkg.OP_TRANSPOSE, A3.h, 0.5, B3.h, ctypes.byref(C)) == 0
+    again = time.perf_counter() - t0
+    L.aoclsparse_destroy(ctypes.byref(C))
+    emit(kind="wider", op="aoclsparse_dadd op=T (host result handle)", system="L1000 (5 M nnz) + same pattern", first_call_s=round(first, 3),
+         repeat_call_s=round(again, 3), note="repeat reuses the handles' device copies; the result arrays return to the host")
+    # level 1: 16 M entries into a 64 M vector, device arrays
+    L.aoclsparse_mi355_set_pointer_mode(pkg.PTR_DEVICE)
+    n1, z1 = 1 << 26, 1 << 24
+    ix = torch.randperm(n1, device=dev)[:z1].to(torch.int32)
+    x1, y1 = torch.rand(z1, dtype=torch.float64, device=dev), torch.rand(n1, dtype=torch.float64, device=dev)
+    ms = time_calls(lambda: L.aoclsparse_daxpyi(z1, 0.5, pkg._ptr(x1), pkg._ptr(ix), pkg._ptr(y1)), 20)
+    emit(kind="wider", op="aoclsparse_daxpyi (device arrays)", system="16 M random entries of a 64 M vector", ms=round(ms, 4),
+         gbs_algorithmic=round(z1 * 28 / ms / 1e6, 1), gbs_sectors=round(z1 * (12 + 64) / ms / 1e6, 1))
+    ms = time_calls(lambda: L.aoclsparse_dgthr(z1, pkg._ptr(y1), pkg._ptr(x1), pkg._ptr(ix)), 20)
+    emit(kind="wider", op="aoclsparse_dgthr (device arrays)", system="16 M random entries of a 64 M vector", ms=round(ms, 4),
+         gbs_algorithmic=round(z1 * 20 / ms / 1e6, 1), gbs_sectors=round(z1 * (12 + 32) / ms / 1e6, 1))
+    ms = time_calls(lambda: L.aoclsparse_ddoti(z1, pkg._ptr(x1), pkg._ptr(ix), pkg._ptr(y1)), 20)
+    emit(kind="wider", op="aoclsparse_ddoti (device arrays, result by value)", system="16 M random entries of a 64 M vector",
+         ms=round(ms, 4), gbs_algorithmic=round(z1 * 20 / ms / 1e6, 1))
+    L.aoclsparse_mi355_set_pointer_mode(pkg.PTR_AUTO)
 
 if "setup" in what:
     # one-off costs on the path: optimize with an mv hint (clean-CSR checks on the host,
