@@ -1435,7 +1435,7 @@ def test_user_stream_ordering():
 # --------------------------------------------------------------------------------------------------
 def test_reference_samples_run_unchanged():
     """tests/examples/sample_*.c(pp) of the reference (spmv, csrmm, dotmv, symgs(_mv), trsm, trsv, CG / GMRES direct and RCI
-    in both precisions, csr2m, complex sp2m and symgs, and the three C++-interface samples through include/aoclsparse.hpp) are built where the reference tree exists and travel as binaries;
+    in both precisions, csr2m, complex sp2m, symgs(_mv), trsm and gthr, axpyi, dotp, roti, sctr, sp2md, spmmd, and the three C++-interface samples through include/aoclsparse.hpp) are built where the reference tree exists and travel as binaries;
     each checks its own result and must exit 0.  Skipped when they were not built."""
     import glob
     import subprocess
