@@ -324,6 +324,10 @@ SIGNATURES = {
     "aoclsparse_dcsr2bsr": (c_int, [_I, _I, _P, c_int, _P, _P, _P, _I, _P, _P, _P]),
     "aoclsparse_ccsr2bsr": (c_int, [_I, _I, _P, c_int, _P, _P, _P, _I, _P, _P, _P]),
     "aoclsparse_zcsr2bsr": (c_int, [_I, _I, _P, c_int, _P, _P, _P, _I, _P, _P, _P]),
+    "aoclsparse_ssorv": (c_int, [c_int, _P, _P, c_float, c_float, _P, _P]),
+    "aoclsparse_dsorv": (c_int, [c_int, _P, _P, c_double, c_double, _P, _P]),
+    "aoclsparse_csorv": (c_int, [c_int, _P, _P, CFloat, CFloat, _P, _P]),
+    "aoclsparse_zsorv": (c_int, [c_int, _P, _P, CDouble, CDouble, _P, _P]),
     # include/aoclsparse_mi355.h
     "aoclsparse_mi355_set_pointer_mode": (c_int, [c_int]),
     "aoclsparse_mi355_set_stream": (c_int, [_P]),

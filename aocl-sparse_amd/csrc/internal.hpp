@@ -627,6 +627,12 @@ template <typename T>
 aoclsparse_status launch_doti(hipStream_t s, aoclsparse_int nnz, const T *x, const aoclsparse_int *indx, const T *y,
                               bool conj, T *partial, T *out);
 
+// sorv_kernels.hip: one level of the forward SOR sweep
+template <typename T>
+aoclsparse_status launch_sorv_level(hipStream_t s, const aoclsparse_int *rows, aoclsparse_int count, int base,
+                                    const aoclsparse_int *ptr, const aoclsparse_int *ind, const T *val, T omega, T *x,
+                                    const T *xold, const T *b);
+
 // SpMV plan constants shared by host planner and kernels
 // LDS tile = non-zeros staged per workgroup: 512 (128 threads), 1024 or 2048 (256 threads);
 // rows per stream block (their row_ptr slice is kept in LDS)

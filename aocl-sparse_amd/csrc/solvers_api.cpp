@@ -145,6 +145,87 @@ struct Vec
             return st__;                         \
     } while(0)
 
+// ---- forward SOR sweep (solvers/aoclsparse_sorv.hpp:116-227) ------------------------------------------------------
+// sorv.hpp:32-75: every row holds exactly one diagonal entry and it is non-zero
+template <typename T>
+bool sorv_full_diag(const HostCsr &h)
+{
+    const T *v = static_cast<const T *>(h.val);
+    for(aoclsparse_int i = 0; i < h.m; i++)
+    {
+        bool found = false;
+        for(aoclsparse_int j = h.ptr[i] - h.base; j < h.ptr[i + 1] - h.base; j++)
+            if(h.ind[j] - h.base == i)
+            {
+                if(found || v[j] == T(0))
+                    return false;
+                found = true;
+            }
+        if(!found)
+            return false;
+    }
+    return true;
+}
+
+template <typename T>
+aoclsparse_status sorv_t(aoclsparse_sor_type sor_type, const aoclsparse_mat_descr descr, aoclsparse_matrix A, T omega,
+                         T alpha, T *x, const T *b, aoclsparse_matrix_data_type vt)
+{
+    if(!A || !descr || !x || !b)
+        return aoclsparse_status_invalid_pointer;
+    if(!A->user.ptr && A->input_format == aoclsparse_csr_mat)
+        return aoclsparse_status_invalid_pointer;
+    if(descr->base != A->base)
+        return aoclsparse_status_invalid_value;
+    if(A->m != A->n)
+        return aoclsparse_status_invalid_size;
+    if(A->m == 0)
+        return aoclsparse_status_success;
+    if(A->m < 0 || A->nnz < 0)
+        return aoclsparse_status_invalid_value;
+    if(A->input_format != aoclsparse_csr_mat || descr->type != aoclsparse_matrix_type_general)
+        return aoclsparse_status_not_implemented;
+    if(A->val_type != vt)
+        return aoclsparse_status_wrong_type;
+    if(sor_type != aoclsparse_sor_forward)
+        return sor_type == aoclsparse_sor_backward || sor_type == aoclsparse_sor_symmetric
+                   ? aoclsparse_status_not_implemented
+                   : aoclsparse_status_invalid_value;
+    if(!sorv_full_diag<T>(A->user))
+        return aoclsparse_status_invalid_value;
+
+    Runtime &rt = Runtime::get();
+    MI355_TRY(rt.init());
+    std::lock_guard<std::recursive_mutex> sl(rt.stage_lock); // the handle's workspaces are shared
+    const aoclsparse_int m = A->m;
+    // level sets of the strict lower triangle (the solve's analysis) and the user's CSR in HBM
+    MI355_TRY(ensure_trsv(A, false, false));
+    DeviceCsr *d = nullptr;
+    SpmvPlan  *p = nullptr;
+    MI355_TRY(ensure_spmv(A, false, d, p));
+    Vec<T> vb, vx;
+    MI355_TRY(vb.in(rt, A->work[2], b, m, true));
+    MI355_TRY(vx.in(rt, A->work[3], x, m, true));
+    MI355_TRY(A->work[0].alloc(sizeof(T) * (size_t)m));
+    hipStream_t s = rt.stream();
+    // x = alpha * x (exact zeros for alpha == 0, sorv.hpp:212-222), snapshot, then level by level
+    MI355_TRY(launch_dense_scale<T>(s, vx.dev, m, 1, m, alpha, alpha == T(0)));
+    MI355_HIP_TRY(hipMemcpyAsync(A->work[0].ptr, vx.dev, sizeof(T) * (size_t)m, hipMemcpyDeviceToDevice, s));
+    {
+        std::shared_lock<std::shared_mutex> r(A->guard);
+        const TrsvPlan                     &tp = A->trsv_plan[0];
+        const aoclsparse_int               *rows = tp.rowmap.as<aoclsparse_int>();
+        for(aoclsparse_int l = 0; l < tp.nlevels; l++)
+            MI355_TRY(launch_sorv_level<T>(s, rows + tp.level_ptr[l], tp.level_ptr[l + 1] - tp.level_ptr[l], d->base,
+                                           d->ptr.as<aoclsparse_int>(), d->ind.as<aoclsparse_int>(), d->val.as<T>(), omega,
+                                           vx.dev, A->work[0].as<T>(), vb.dev));
+    }
+    MI355_TRY(vx.out(rt, m));
+    if(vx.staged)
+        MI355_HIP_TRY(hipStreamSynchronize(s));
+    return aoclsparse_status_success;
+}
+
 // ---- symmetric Gauss-Seidel ------------------------------------------------------------------------
 template <typename T>
 aoclsparse_status symgs_t(aoclsparse_operation trans, aoclsparse_matrix A, const aoclsparse_mat_descr descr,
@@ -564,6 +645,31 @@ aoclsparse_status aoclsparse_silu_smoother(aoclsparse_operation op, aoclsparse_m
 {
     (void)approx_inv_diag;
     return ilu_smoother_t<float>(op, A, descr, precond_csr_val, x, b, aoclsparse_smat);
+}
+
+
+aoclsparse_status aoclsparse_dsorv(aoclsparse_sor_type sor_type, const aoclsparse_mat_descr descr, const aoclsparse_matrix A,
+                                   double omega, double alpha, double *x, const double *b)
+{
+    return sorv_t<double>(sor_type, descr, A, omega, alpha, x, b, aoclsparse_dmat);
+}
+aoclsparse_status aoclsparse_ssorv(aoclsparse_sor_type sor_type, const aoclsparse_mat_descr descr, const aoclsparse_matrix A,
+                                   float omega, float alpha, float *x, const float *b)
+{
+    return sorv_t<float>(sor_type, descr, A, omega, alpha, x, b, aoclsparse_smat);
+}
+// sorv.hpp:128-131: the complex types are not implemented in the reference either
+aoclsparse_status aoclsparse_csorv(aoclsparse_sor_type, const aoclsparse_mat_descr, const aoclsparse_matrix,
+                                   aoclsparse_float_complex, aoclsparse_float_complex, aoclsparse_float_complex *,
+                                   const aoclsparse_float_complex *)
+{
+    return aoclsparse_status_not_implemented;
+}
+aoclsparse_status aoclsparse_zsorv(aoclsparse_sor_type, const aoclsparse_mat_descr, const aoclsparse_matrix,
+                                   aoclsparse_double_complex, aoclsparse_double_complex, aoclsparse_double_complex *,
+                                   const aoclsparse_double_complex *)
+{
+    return aoclsparse_status_not_implemented;
 }
 
 } // extern "C"

@@ -1156,6 +1156,21 @@ DLL_PUBLIC aoclsparse_status aoclsparse_zcsr2bsr(aoclsparse_int m, aoclsparse_in
                                                aoclsparse_int block_dim, aoclsparse_double_complex *bsr_val, aoclsparse_int *bsr_row_ptr,
                                                aoclsparse_int *bsr_col_ind);
 
+/* ---- forward SOR sweep: replaces library/include/aoclsparse_solvers.h:640-682 (backward / symmetric and the complex
+ * types return not_implemented, as in the reference) */
+DLL_PUBLIC aoclsparse_status aoclsparse_ssorv(aoclsparse_sor_type sor_type, const aoclsparse_mat_descr descr,
+                                            const aoclsparse_matrix A, float omega, float alpha,
+                                            float *x, const float *b);
+DLL_PUBLIC aoclsparse_status aoclsparse_dsorv(aoclsparse_sor_type sor_type, const aoclsparse_mat_descr descr,
+                                            const aoclsparse_matrix A, double omega, double alpha,
+                                            double *x, const double *b);
+DLL_PUBLIC aoclsparse_status aoclsparse_csorv(aoclsparse_sor_type sor_type, const aoclsparse_mat_descr descr,
+                                            const aoclsparse_matrix A, aoclsparse_float_complex omega, aoclsparse_float_complex alpha,
+                                            aoclsparse_float_complex *x, const aoclsparse_float_complex *b);
+DLL_PUBLIC aoclsparse_status aoclsparse_zsorv(aoclsparse_sor_type sor_type, const aoclsparse_mat_descr descr,
+                                            const aoclsparse_matrix A, aoclsparse_double_complex omega, aoclsparse_double_complex alpha,
+                                            aoclsparse_double_complex *x, const aoclsparse_double_complex *b);
+
 #ifdef __cplusplus
 }
 #endif

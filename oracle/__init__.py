@@ -515,6 +515,13 @@ def dbsrmv(alpha, mb, dim, base, val, col, ptr, x, beta, y):
     return y
 
 
+def dsorv(n, base, ptr, ind, val, omega, alpha, x, b):
+    """One forward SOR sweep (solvers/aoclsparse_sorv.hpp:78-113); returns (status, x)."""
+    ptr, ind, val, x, b = _i32(ptr), _i32(ind), _f64(val), _f64(x).copy(), _f64(b)
+    st = lib().orc_dsorv(c_i32(n), c_int(base), _p(ptr), _p(ind), _p(val), c_dbl(omega), c_dbl(alpha), _p(x), _p(b))
+    return st, x
+
+
 # ---- complex CG / GMRES, numpy restatements of solvers/aoclsparse_itsol_functions.hpp:632-875 and :910-1367 for
 # T = std::complex (dense operator A; no preconditioner).  No reference vectors exist for them: parity unpinned, the
 # checks are exit status, iteration counts and the solver tolerances.

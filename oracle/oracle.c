@@ -2028,3 +2028,40 @@ void orc_dbsrmv(double alpha, oint mb, oint dim, int base, const double *val, co
             y[(size_t)ai * dim + bi] = sum;
         }
 }
+
+
+/* ---- forward SOR sweep: solvers/aoclsparse_sorv.hpp:78-113 and :212-226 (x = alpha*x first; exact zeros for
+ * alpha == 0).  Returns 5 (invalid_value) when a row lacks a single non-zero diagonal entry (:32-75). */
+int orc_dsorv(oint n, int base, const oint *ptr, const oint *ind, const double *val, double omega, double alpha,
+              double *x, const double *b)
+{
+    for(oint i = 0; i < n; i++)
+    {
+        int found = 0;
+        for(oint j = ptr[i] - base; j < ptr[i + 1] - base; j++)
+            if(ind[j] - base == i)
+            {
+                if(found || val[j] == 0.0)
+                    return ORC_INVALID_VALUE;
+                found = 1;
+            }
+        if(!found)
+            return ORC_INVALID_VALUE;
+    }
+    for(oint i = 0; i < n; i++)
+        x[i] = alpha != 0.0 ? alpha * x[i] : 0.0;
+    for(oint i = 0; i < n; i++)
+    {
+        double axi = 0.0, d = 1.0;
+        for(oint j = ptr[i] - base; j < ptr[i + 1] - base; j++)
+        {
+            const oint c = ind[j] - base;
+            if(c != i)
+                axi = fma(val[j], x[c], axi);
+            else
+                d = val[j];
+        }
+        x[i] = fma(omega, (b[i] - axi) / d - x[i], x[i]);
+    }
+    return ORC_SUCCESS;
+}

@@ -242,6 +242,10 @@ int  orc_dcsr2bsr(oint m, oint n, int base, int rowmajor, const double *val, con
 void orc_dbsrmv(double alpha, oint mb, oint dim, int base, const double *val, const oint *col, const oint *ptr,
                 const double *x, double beta, double *y);
 
+/* forward SOR sweep (solvers/aoclsparse_sorv.hpp:78-113, :212-226) */
+int orc_dsorv(oint n, int base, const oint *ptr, const oint *ind, const double *val, double omega, double alpha,
+              double *x, const double *b);
+
 #ifdef __cplusplus
 }
 #endif

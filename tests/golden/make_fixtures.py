@@ -395,6 +395,23 @@ out["dia_bsr"] = dict(src="tests/unit_tests/diamv_tests.cpp:137-197, bsrmv_tests
                       row_ptr=[0, 1, 2, 4, 6, 7], col_ind=[0, 1, 1, 2, 0, 3, 3], val=[6, 1, 2, 3, 5, 1, 10],
                       x=[1, 2, 3, 4, 5, 6], y_gold=[6, 2, 13, 9, 40, 0], bsr_dim=2)
 
+# ------------------------------------------------------------------------------------------
+# Forward SOR sweep: tests/unit_tests/sorv_tests.cpp:366-414 (octave-generated x after 1 and 10 sweeps, and with
+# alpha = 0 applied to the 10-sweep iterate) and tests/examples/sample_dsorv.cpp:51-61
+# ------------------------------------------------------------------------------------------
+out["sorv"] = [
+    dict(src="tests/unit_tests/sorv_tests.cpp:366-414", n=4, row_ptr=[0, 3, 7, 10, 13], col_ind=[0, 1, 2, 0, 1, 2, 3, 1, 2, 3, 0, 2, 3],
+         val=[4.0, -1.0, -6.0, -5.0, -4.0, 10.0, 8.0, 9.0, 4.0, -2.0, 1.0, -7.0, 5.0], b=[2.0, 21.0, -12.0, -6.0],
+         x0=[1.0, -0.5, -2.0, 3.7], omega=0.5,
+         x_iter1=[-0.8125, -1.1671874999999998, -0.26191406249999982, 1.14791015625],
+         x_iter10=[2.8668745958572917, -2.0001324279196497, 1.9725100983350874, 0.97782651833978285],
+         x_iter10_then_alpha0=[0.25, -2.78125, 1.62890625, 0.51523437500000002]),
+    dict(src="tests/examples/sample_dsorv.cpp:51-61", n=4, row_ptr=[0, 2, 5, 6, 10], col_ind=[0, 1, 0, 1, 2, 2, 1, 3, 2, 0],
+         val=[111.1, 2.345, 3.12, 9.87, -56.2, -39.678, 76.9, -25.106, -903.40, 32.0987],
+         b=[157.5045, -489.033, -321.3918, -7433.72955], x0=[1, -41, 5.7, 0.341], omega=0.5,
+         x_iter1=[1.6415369036903691, -29.305197322163828, 6.9000000000000004, -19.757185084519875]),
+]
+
 with open(n25_path, "w") as f:
     json.dump(out, f, indent=None, separators=(",", ":"))
     f.write("\n")

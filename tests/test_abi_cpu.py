@@ -814,3 +814,22 @@ def test_dia_bsr_conversions_match_the_oracle(base, kats):
     assert g(P.OP_NONE, A, 2, 2, 0, P._ptr(v), P._ptr(ci), P._ptr(rp), d.h, P._ptr(x), B, P._ptr(y)) == 3
     assert g(P.OP_NONE, A, 0, 2, 2, None, None, None, d.h, None, B, None) == 0
     assert g(P.OP_NONE, A, 2, 2, 2, None, P._ptr(ci), P._ptr(rp), d.h, P._ptr(x), B, P._ptr(y)) == 2
+
+
+def test_sorv_argument_checks():
+    """solvers/aoclsparse_sorv.hpp:126-210, in its order; everything up to the diagonal check happens on the host."""
+    rp, ci, v = np.array([0, 2, 3], np.int32), np.array([0, 1, 1], np.int32), np.array([2.0, 1.0, 4.0])
+    A, d, x, b = P.Matrix(0, 2, 2, rp, ci, v), P.Descr(), np.zeros(2), np.ones(2)
+    f = L.aoclsparse_dsorv
+    assert f(0, d.h, None, 1.0, 1.0, P._ptr(x), P._ptr(b)) == 2 and f(0, None, A.h, 1.0, 1.0, P._ptr(x), P._ptr(b)) == 2
+    assert f(0, d.h, A.h, 1.0, 1.0, None, P._ptr(b)) == 2 and f(0, d.h, A.h, 1.0, 1.0, P._ptr(x), None) == 2
+    assert f(0, P.Descr(base=1).h, A.h, 1.0, 1.0, P._ptr(x), P._ptr(b)) == 5
+    W = P.Matrix(0, 2, 3, rp, ci, v)
+    assert f(0, d.h, W.h, 1.0, 1.0, P._ptr(x), P._ptr(b)) == 3
+    assert f(0, P.Descr(mtype=P.TYPE_SYMMETRIC).h, A.h, 1.0, 1.0, P._ptr(x), P._ptr(b)) == 1
+    assert L.aoclsparse_ssorv(0, d.h, A.h, 1.0, 1.0, P._ptr(x), P._ptr(b)) == 9
+    assert f(1, d.h, A.h, 1.0, 1.0, P._ptr(x), P._ptr(b)) == 1 and f(2, d.h, A.h, 1.0, 1.0, P._ptr(x), P._ptr(b)) == 1
+    assert f(7, d.h, A.h, 1.0, 1.0, P._ptr(x), P._ptr(b)) == 5
+    Z = P.Matrix(0, 2, 2, rp, np.array([0, 1, 0], np.int32), v)  # second row without a diagonal
+    assert f(0, d.h, Z.h, 1.0, 1.0, P._ptr(x), P._ptr(b)) == 5
+    assert L.aoclsparse_zsorv(0, d.h, A.h, P.CDouble(1, 0), P.CDouble(1, 0), P._ptr(x), P._ptr(b)) == 1

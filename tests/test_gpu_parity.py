@@ -3026,3 +3026,66 @@ def _banded(m, half, base):
     ci = np.concatenate(rows)
     v = np.random.default_rng(12).uniform(-1, 1, len(ci))
     return (rp + base).astype(np.int32), (ci + base).astype(np.int32), v
+
+
+# --------------------------------------------------------------------------------------------------
+# forward SOR sweep (solvers/aoclsparse_sorv.hpp)
+# --------------------------------------------------------------------------------------------------
+def test_sorv_kats_and_bit_exact_sweeps(kats):
+    """The reference's vectors (sorv_tests.cpp:366-414, sample_dsorv.cpp) within its tolerance, and level-scheduled
+    sweeps on large matrices -- structurally unsymmetric, rows unsorted, both bases, host and device vectors -- bit-identical
+    to the serial restatement; repeated sweeps converge on a diagonally dominant system."""
+    import torch
+    tol = 10 * np.sqrt(2 * EPS64)
+    for k in kats["sorv"]:
+        rp, ci, v = np.array(k["row_ptr"], np.int32), np.array(k["col_ind"], np.int32), np.array(k["val"], np.float64)
+        A, d = P.Matrix(0, k["n"], k["n"], rp, ci, v), P.Descr()
+        x, b = np.array(k["x0"], np.float64), np.array(k["b"], np.float64)
+        assert L.aoclsparse_dsorv(0, d.h, A.h, k["omega"], 1.0, P._ptr(x), P._ptr(b)) == 0
+        assert np.allclose(x, k["x_iter1"], rtol=tol, atol=tol)
+        if "x_iter10" in k:
+            for _ in range(9):
+                assert L.aoclsparse_dsorv(0, d.h, A.h, k["omega"], 1.0, P._ptr(x), P._ptr(b)) == 0
+            assert np.allclose(x, k["x_iter10"], rtol=tol, atol=tol)
+            assert L.aoclsparse_dsorv(0, d.h, A.h, k["omega"], 0.0, P._ptr(x), P._ptr(b)) == 0
+            assert np.allclose(x, k["x_iter10_then_alpha0"], rtol=tol, atol=tol)
+    for base in (0, 1):
+        n = 6000
+        rp, ci, v = random_csr(700 + base, n, n, lambda r, i: r.integers(0, 9), base=base, sort=False)
+        # add a dominant diagonal where missing / replace where present: rebuild rows with exactly one diagonal entry
+        rows = []
+        for i in range(n):
+            c, w = ci[rp[i] - base:rp[i + 1] - base] - base, v[rp[i] - base:rp[i + 1] - base]
+            keep = c != i
+            c, w = np.append(c[keep], i), np.append(w[keep], 10.0 + i % 3)
+            perm = np.random.default_rng(i).permutation(len(c))
+            rows.append((c[perm], w[perm]))
+        rp2 = np.zeros(n + 1, np.int64)
+        rp2[1:] = np.cumsum([len(c) for c, _ in rows])
+        ci2 = (np.concatenate([c for c, _ in rows]) + base).astype(np.int32)
+        v2 = np.concatenate([w for _, w in rows])
+        rp2 = (rp2 + base).astype(np.int32)
+        A, d = P.Matrix(base, n, n, rp2, ci2, v2), P.Descr(base=base)
+        rng = np.random.default_rng(3)
+        x0, b = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+        for omega, alpha in ((1.0, 1.0), (0.7, -0.5), (1.3, 0.0)):
+            st, want = oracle.dsorv(n, base, rp2, ci2, v2, omega, alpha, x0, b)
+            x = x0.copy()
+            assert st == 0 and L.aoclsparse_dsorv(0, d.h, A.h, omega, alpha, P._ptr(x), P._ptr(b)) == 0
+            assert np.array_equal(x, want), (base, omega, alpha)
+            xd, bd = dev(x0), dev(b)
+            assert L.aoclsparse_dsorv(0, d.h, A.h, omega, alpha, ctypes.c_void_p(xd.data_ptr()), ctypes.c_void_p(bd.data_ptr())) == 0
+            torch.cuda.synchronize()
+            assert np.array_equal(xd.cpu().numpy(), want)
+        x = np.zeros(n)
+        for _ in range(25):
+            assert L.aoclsparse_dsorv(0, d.h, A.h, 1.0, 1.0, P._ptr(x), P._ptr(b)) == 0
+        D = np.zeros((n, n))
+        for i in range(n):
+            D[i, ci2[rp2[i] - base:rp2[i + 1] - base] - base] = v2[rp2[i] - base:rp2[i + 1] - base]
+        assert np.linalg.norm(D @ x - b) <= 1e-10 * np.linalg.norm(b)
+        xf, bf = x0.astype(np.float32), b.astype(np.float32)
+        Af = P.Matrix(base, n, n, rp2, ci2, v2.astype(np.float32))
+        assert L.aoclsparse_ssorv(0, d.h, Af.h, 0.7, 1.0, P._ptr(xf), P._ptr(bf)) == 0
+        st, want = oracle.dsorv(n, base, rp2, ci2, v2, 0.7, 1.0, x0, b)
+        assert np.allclose(xf, want, rtol=0, atol=64 * EPS32 * max(1.0, np.abs(want).max()))

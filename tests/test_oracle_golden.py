@@ -614,3 +614,21 @@ def test_dia_bsr_kats_and_properties(kats):
             got = oracle.dbsrmv(1.5, mb, dim, base, bv, bi, bp, xx, -0.5, yy)
             assert np.all(np.abs(got[:m] - yr) <= 16 * EPS * scale + 1e-300) and np.all(got[m:] == 0)
             assert np.count_nonzero(bv) == len(v)
+
+
+def test_sorv_kats(kats):
+    """sorv_tests.cpp:366-414 (1 and 10 sweeps, alpha = 0) and sample_dsorv.cpp:51-61, tolerance of the reference's own
+    check (10 * sqrt(2 eps) relative)."""
+    tol = 10 * np.sqrt(2 * EPS)
+    for k in kats["sorv"]:
+        x = np.array(k["x0"], np.float64)
+        st, x = oracle.dsorv(k["n"], 0, k["row_ptr"], k["col_ind"], k["val"], k["omega"], 1.0, x, k["b"])
+        assert st == 0 and np.allclose(x, k["x_iter1"], rtol=tol, atol=tol)
+        if "x_iter10" in k:
+            for _ in range(9):
+                st, x = oracle.dsorv(k["n"], 0, k["row_ptr"], k["col_ind"], k["val"], k["omega"], 1.0, x, k["b"])
+            assert np.allclose(x, k["x_iter10"], rtol=tol, atol=tol)
+            st, x = oracle.dsorv(k["n"], 0, k["row_ptr"], k["col_ind"], k["val"], k["omega"], 0.0, x, k["b"])
+            assert np.allclose(x, k["x_iter10_then_alpha0"], rtol=tol, atol=tol)
+    st, _ = oracle.dsorv(2, 0, [0, 1, 2], [0, 0], [1.0, 1.0], 1.0, 1.0, np.zeros(2), np.zeros(2))
+    assert st == 5  # second row has no diagonal
