@@ -336,6 +336,11 @@ SIGNATURES = {
     "aoclsparse_mi355_device_info": (c_int, [POINTER(_I), POINTER(_I), c_char_p]),
     "aoclsparse_mi355_timer_start": (c_int, []),
     "aoclsparse_mi355_timer_stop": (c_int, [POINTER(c_float)]),
+    "aoclsparse_mi355_timer_mark": (c_int, []),
+    "aoclsparse_mi355_timer_laps": (c_int, [POINTER(c_float), _I, POINTER(_I)]),
+    "aoclsparse_mi355_column_shard": (c_int, [_I, _I, _I, POINTER(_I), POINTER(_I)]),
+    "aoclsparse_mi355_dcsrmm_shard": (c_int, [c_int, c_double, _P, _P, c_int, _P, _I, _I, c_double, _P, _I, _I, _I]),
+    "aoclsparse_mi355_scsrmm_shard": (c_int, [c_int, c_float, _P, _P, c_int, _P, _I, _I, c_float, _P, _I, _I, _I]),
     "aoclsparse_mi355_export_diag": (c_int, [_P, POINTER(_P), POINTER(_P), POINTER(_I)]),
     "aoclsparse_mi355_get_spmv_info": (c_int, [_P, c_int, POINTER(SpmvInfo)]),
     "aoclsparse_mi355_get_trsv_levels": (c_int, [_P, c_int, c_int, POINTER(_I)]),
@@ -537,3 +542,31 @@ def timer_stop():
     st = lib().aoclsparse_mi355_timer_stop(byref(ms))
     assert st == 0, STATUS[st]
     return ms.value
+
+
+def timer_mark():
+    st = lib().aoclsparse_mi355_timer_mark()
+    assert st == 0, STATUS[st]
+
+
+def timer_laps(capacity=65536):
+    """-> list of elapsed milliseconds between consecutive timer_mark() calls (waits for the last one)."""
+    buf = (c_float * capacity)()
+    cnt = c_int32(0)
+    st = lib().aoclsparse_mi355_timer_laps(buf, capacity, byref(cnt))
+    assert st == 0, STATUS[st]
+    return [buf[i] for i in range(min(cnt.value, capacity))]
+
+
+def column_shard(ncols, world, rank):
+    """[j0, j1) of rank `rank`: the reference's per-thread column split (csrmm_kt.cpp:68-82) with ranks for threads."""
+    j0, j1 = c_int32(0), c_int32(0)
+    st = lib().aoclsparse_mi355_column_shard(ncols, world, rank, byref(j0), byref(j1))
+    if st != 0:
+        raise ValueError("column_shard(%d, %d, %d): %s" % (ncols, world, rank, STATUS[st]))
+    return j0.value, j1.value
+
+
+def dcsrmm_shard(op, alpha, A, descr, order, B, n, ldb, beta, C, ldc, world, rank):
+    return lib().aoclsparse_mi355_dcsrmm_shard(op, alpha, A.h, descr.h, order, _ptr(B), n, ldb, beta, _ptr(C), ldc,
+                                               world, rank)

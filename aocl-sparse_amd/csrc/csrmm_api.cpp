@@ -15,10 +15,12 @@ namespace
 constexpr int CM_DETOUR_NNZ_PER_ROW = 8; // = the column kernel's register cache (CM_K)
 
 template <typename T>
-aoclsparse_status stage_dense(Runtime &rt, int slot, const T *host, aoclsparse_int outer, aoclsparse_int ld,
-                              bool copy, void **dev, size_t *bytes)
+aoclsparse_status stage_dense(Runtime &rt, int slot, const T *host, aoclsparse_int outer, aoclsparse_int inner,
+                              aoclsparse_int ld, bool copy, void **dev, size_t *bytes)
 {
-    *bytes               = sizeof(T) * (size_t)outer * (size_t)ld;
+    // exact extent of a strided dense matrix: the last row / column carries no ld padding (BLAS convention), and a
+    // column shard of a row-major matrix starts j0 elements into its first row
+    *bytes               = outer > 0 ? sizeof(T) * ((size_t)(outer - 1) * (size_t)ld + (size_t)inner) : 0;
     aoclsparse_status st = rt.staging(slot, *bytes, dev);
     if(st != aoclsparse_status_success)
         return st;
@@ -141,7 +143,7 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
     size_t     bbytes = 0, cbytes = 0;
     if(!cdev)
     {
-        st = stage_dense<T>(rt, 4, C, (aoclsparse_int)c_outer, ldc, true, &dC, &cbytes);
+        st = stage_dense<T>(rt, 4, C, (aoclsparse_int)c_outer, colmaj ? m_c : n, ldc, true, &dC, &cbytes);
         if(st != aoclsparse_status_success)
             return st;
     }
@@ -165,7 +167,7 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
 
     if(!bdev)
     {
-        st = stage_dense<T>(rt, 3, B, (aoclsparse_int)b_outer, ldb, true, &dB, &bbytes);
+        st = stage_dense<T>(rt, 3, B, (aoclsparse_int)b_outer, colmaj ? b_rows : n, ldb, true, &dB, &bbytes);
         if(st != aoclsparse_status_success)
             return st;
     }
@@ -266,6 +268,72 @@ aoclsparse_status aoclsparse_scsrmm_kid(aoclsparse_operation op, const float alp
                                         float *C, aoclsparse_int ldc, const aoclsparse_int kid)
 {
     return csrmm_t<float>(op, alpha, A, descr, order, B, n, ldb, beta, C, ldc, kid, aoclsparse_smat);
+}
+
+} // extern "C"
+
+// ---- column shards (multi-GPU: one process per GPU owns columns [j0, j1) of B and C) --------------------------------
+// The reference splits B's columns over its worker threads inside the library (level3/aoclsparse_csrmm_kt.cpp:68-82:
+// start = n*t/T rounded up to a multiple of the 4-column block, capped at n).  Here the "thread" is a rank: the same
+// rule gives rank `rank` of `world` its slab, and *_shard computes exactly that slab of C from the FULL B / C arrays
+// the caller passes (no communication: C[:, J] depends only on A and B[:, J]).
+static aoclsparse_int shard_edge(aoclsparse_int n, aoclsparse_int world, aoclsparse_int t)
+{
+    long long e = (long long)n * t / world;
+    if(e % 4)
+        e += 4 - e % 4;
+    return (aoclsparse_int)std::min<long long>(e, n);
+}
+
+template <typename T>
+static aoclsparse_status csrmm_shard_t(aoclsparse_operation op, const T alpha, const aoclsparse_matrix A,
+                                       const aoclsparse_mat_descr descr, aoclsparse_order order, const T *B,
+                                       aoclsparse_int n, aoclsparse_int ldb, const T beta, T *C, aoclsparse_int ldc,
+                                       aoclsparse_int world, aoclsparse_int rank, aoclsparse_matrix_data_type vt)
+{
+    if(world < 1 || rank < 0 || rank >= world || n < 0)
+        return aoclsparse_status_invalid_value;
+    if(!B || !C)
+        return aoclsparse_status_invalid_pointer;
+    if(order != aoclsparse_order_row && order != aoclsparse_order_column)
+        return aoclsparse_status_invalid_value;
+    const aoclsparse_int j0 = shard_edge(n, world, rank), j1 = shard_edge(n, world, rank + 1);
+    if(j1 <= j0)
+        return aoclsparse_status_success; // more ranks than 4-column blocks: this rank owns nothing
+    const size_t ob = order == aoclsparse_order_column ? (size_t)j0 * (size_t)ldb : (size_t)j0;
+    const size_t oc = order == aoclsparse_order_column ? (size_t)j0 * (size_t)ldc : (size_t)j0;
+    return csrmm_t<T>(op, alpha, A, descr, order, B + ob, j1 - j0, ldb, beta, C + oc, ldc, -1, vt);
+}
+
+extern "C" {
+
+aoclsparse_status aoclsparse_mi355_column_shard(aoclsparse_int n, aoclsparse_int world, aoclsparse_int rank,
+                                                aoclsparse_int *j0, aoclsparse_int *j1)
+{
+    if(!j0 || !j1)
+        return aoclsparse_status_invalid_pointer;
+    if(world < 1 || rank < 0 || rank >= world || n < 0)
+        return aoclsparse_status_invalid_value;
+    *j0 = shard_edge(n, world, rank);
+    *j1 = shard_edge(n, world, rank + 1);
+    return aoclsparse_status_success;
+}
+
+aoclsparse_status aoclsparse_mi355_dcsrmm_shard(aoclsparse_operation op, const double alpha, const aoclsparse_matrix A,
+                                                const aoclsparse_mat_descr descr, aoclsparse_order order,
+                                                const double *B, aoclsparse_int n, aoclsparse_int ldb,
+                                                const double beta, double *C, aoclsparse_int ldc,
+                                                aoclsparse_int world, aoclsparse_int rank)
+{
+    return csrmm_shard_t<double>(op, alpha, A, descr, order, B, n, ldb, beta, C, ldc, world, rank, aoclsparse_dmat);
+}
+
+aoclsparse_status aoclsparse_mi355_scsrmm_shard(aoclsparse_operation op, const float alpha, const aoclsparse_matrix A,
+                                                const aoclsparse_mat_descr descr, aoclsparse_order order,
+                                                const float *B, aoclsparse_int n, aoclsparse_int ldb, const float beta,
+                                                float *C, aoclsparse_int ldc, aoclsparse_int world, aoclsparse_int rank)
+{
+    return csrmm_shard_t<float>(op, alpha, A, descr, order, B, n, ldb, beta, C, ldc, world, rank, aoclsparse_smat);
 }
 
 } // extern "C"

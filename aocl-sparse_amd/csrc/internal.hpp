@@ -10,6 +10,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
 #include <cstddef>
 #include <cstdint>
 #include <memory>
@@ -320,7 +321,8 @@ class Runtime
 {
 public:
     static Runtime &get();
-    aoclsparse_status init(); // lazy; internal_error when no device
+    aoclsparse_status init(); // lazy; internal_error when no device; binds the calling thread to `device`
+    void              bind_thread();
     hipStream_t       stream() const
     {
         return stream_;
@@ -337,11 +339,14 @@ public:
     // scratch staging buffers for host-pointer calls (grown on demand, reused)
     aoclsparse_status staging(int slot, size_t bytes, void **out);
     hipEvent_t        ev0 = nullptr, ev1 = nullptr;
+    // per-iteration timing: a ring of events recorded by aoclsparse_mi355_timer_mark (runtime.cpp)
+    std::vector<hipEvent_t> marks;
+    size_t                  marks_used = 0;
     std::mutex        lock;
     std::recursive_mutex stage_lock; // serialises calls that stage host buffers
 
 private:
-    bool         inited_ = false;
+    std::atomic<bool> inited_{false}; // set (release) after init_status_ / device / events are written
     aoclsparse_status init_status_ = aoclsparse_status_success;
     hipStream_t  stream_ = nullptr;
     DeviceBuffer stage_[16]; // 0-7: csrmv / mv / trsv / dotmv, 8-15: ELL family and BLKCSR (ell_api.cpp, blk_api.cpp)

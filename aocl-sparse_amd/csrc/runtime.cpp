@@ -75,12 +75,18 @@ Runtime &Runtime::get()
     return r;
 }
 
+thread_local int tl_bound_device = -1;
+
 aoclsparse_status Runtime::init()
 {
-    if(inited_)
+    // double-checked: the flag is an atomic stored with release order after everything it guards
+    if(inited_.load(std::memory_order_acquire))
+    {
+        bind_thread();
         return init_status_;
+    }
     std::lock_guard<std::mutex> g(lock);
-    if(inited_)
+    if(inited_.load(std::memory_order_relaxed))
         return init_status_;
     int        count = 0;
     hipError_t e     = hipGetDeviceCount(&count);
@@ -93,7 +99,7 @@ aoclsparse_status Runtime::init()
                      "fallback\n",
                      e == hipSuccess ? "device count 0" : hipGetErrorString(e));
         init_status_ = aoclsparse_status_internal_error;
-        inited_      = true;
+        inited_.store(true, std::memory_order_release);
         return init_status_;
     }
     // one process per GPU: honour an explicit ordinal, else keep the caller's current device
@@ -112,8 +118,21 @@ aoclsparse_status Runtime::init()
     }
     if(hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess)
         init_status_ = aoclsparse_status_internal_error;
-    inited_ = true;
+    tl_bound_device = device;
+    inited_.store(true, std::memory_order_release);
     return init_status_;
+}
+
+// The HIP current device is per THREAD: a thread other than the initialising one would launch on device 0 while
+// every buffer of the library lives on `device`.  Every ABI entry point passes through init(), which binds the calling
+// thread once.
+void Runtime::bind_thread()
+{
+    if(tl_bound_device != device && device >= 0)
+    {
+        (void)hipSetDevice(device);
+        tl_bound_device = device;
+    }
 }
 
 thread_local int tl_device_scope = 0;
@@ -235,10 +254,51 @@ aoclsparse_status aoclsparse_mi355_timer_stop(float *elapsed_ms)
     return aoclsparse_status_success;
 }
 
+// Per-iteration timing (the reference harness reports min / quartiles / max of its iterations,
+// tests/include/aoclsparse_stats.hpp:41-129): mark() records one event on the library's stream; laps() waits for
+// the last one and returns the elapsed time between consecutive marks.
+aoclsparse_status aoclsparse_mi355_timer_mark(void)
+{
+    Runtime          &rt = Runtime::get();
+    aoclsparse_status st = rt.init();
+    if(st != aoclsparse_status_success)
+        return st;
+    if(rt.marks_used == rt.marks.size())
+    {
+        if(rt.marks.size() >= 65536)
+            return aoclsparse_status_invalid_size;
+        hipEvent_t e;
+        MI355_HIP_TRY(hipEventCreate(&e));
+        rt.marks.push_back(e);
+    }
+    MI355_HIP_TRY(hipEventRecord(rt.marks[rt.marks_used], rt.stream()));
+    rt.marks_used++;
+    return aoclsparse_status_success;
+}
+
+aoclsparse_status aoclsparse_mi355_timer_laps(float *laps_ms, aoclsparse_int capacity, aoclsparse_int *count)
+{
+    Runtime &rt = Runtime::get();
+    if(!count || (capacity > 0 && !laps_ms))
+        return aoclsparse_status_invalid_pointer;
+    aoclsparse_status st = rt.init();
+    if(st != aoclsparse_status_success)
+        return st;
+    const size_t used = rt.marks_used;
+    rt.marks_used     = 0; // the ring is reset whatever happens below
+    *count            = used > 0 ? (aoclsparse_int)(used - 1) : 0;
+    if(used < 2)
+        return aoclsparse_status_success;
+    MI355_HIP_TRY(hipEventSynchronize(rt.marks[used - 1]));
+    for(size_t i = 0; i + 1 < used && (aoclsparse_int)i < capacity; i++)
+        MI355_HIP_TRY(hipEventElapsedTime(&laps_ms[i], rt.marks[i], rt.marks[i + 1]));
+    return aoclsparse_status_success;
+}
+
 // ---- version / context shims (library/src/extra/aoclsparse_auxiliary.cpp:56-173, 1433) --------
 const char *aoclsparse_get_version(void)
 {
-    return "AOCL-Sparse 5.3.2 compatible; MI355X-native engine r1 (gfx950)";
+    return "AOCL-Sparse 5.3.2 compatible; MI355X-native engine r2 (gfx950)";
 }
 
 // The ISA preference selects CPU kernels in the reference; here it is accepted and recorded so

@@ -1,0 +1,243 @@
+"""Column-sharded csrmm, one process per GPU (BASELINE.json configs[3]).
+
+C = alpha * A * B + beta * C with a tall dense B: column j of C depends on A and on column j of B only, so B and C are
+split into `world` column slabs by the reference's own rule (it splits B's columns over its worker threads,
+library/src/level3/aoclsparse_csrmm_kt.cpp:68-82 -- here a rank takes the place of a thread;
+`aoclsparse_mi355_column_shard`), every rank holds A, and the data path has NO collective.  Communication happens
+twice, outside the product: A is broadcast once from rank 0 (RCCL over xGMI when the backend is "nccl"), and a caller
+that wants all of C everywhere can all-gather the slabs afterwards (`gather_C`, reported separately).
+
+The arithmetic is the library's (`aoclsparse_dcsrmm` through the C ABI); this module is host-side orchestration only and
+holds no compute.  Works with backend "nccl" (one rank per GPU: the driver's 2/4/8-GPU runs) and with "gloo" (CPU
+tensors on the wire: lets two processes share ONE GPU so the whole control flow is testable on a 1-GPU box).
+"""
+import time
+
+import numpy as np
+
+
+def _backend(dist):
+    return dist.get_backend() if dist is not None and dist.is_initialized() else None
+
+
+def reduce_scalar(value, op, dist=None, device="cpu"):
+    """max / sum / min of a python float over all ranks (identity when not distributed)."""
+    if dist is None or not dist.is_initialized():
+        return float(value)
+    import torch
+
+    dev = "cpu" if _backend(dist) == "gloo" else device
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op={"max": dist.ReduceOp.MAX, "sum": dist.ReduceOp.SUM, "min": dist.ReduceOp.MIN}[op])
+    return float(t.item())
+
+
+def barrier(dist, torch):
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    if dist is not None and dist.is_initialized():
+        dist.barrier()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+def broadcast_csr(dist, torch, device, rank, csr):
+    """csr = (m, n, row_ptr, col_ind, val) numpy arrays on rank 0 (anything on the others) -> the same five on every
+    rank (host numpy arrays, which is what aoclsparse_create_dcsr aliases) + the broadcast time in ms.  With "nccl" the
+    three arrays travel GPU to GPU (RCCL); with "gloo" as CPU tensors."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return csr, 0.0
+    wire = "cpu" if _backend(dist) == "gloo" else device
+    meta = torch.zeros(3, dtype=torch.int64, device=wire)
+    if rank == 0:
+        m, n, rp, ci, v = csr
+        meta = torch.tensor([m, n, len(v)], dtype=torch.int64, device=wire)
+    dist.broadcast(meta, 0)
+    m, n, nnz = (int(t) for t in meta.tolist())
+    if rank == 0:
+        t_rp = torch.from_numpy(np.ascontiguousarray(rp, dtype=np.int32)).to(wire)
+        t_ci = torch.from_numpy(np.ascontiguousarray(ci, dtype=np.int32)).to(wire)
+        t_v = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64)).to(wire)
+    else:
+        t_rp = torch.empty(m + 1, dtype=torch.int32, device=wire)
+        t_ci = torch.empty(nnz, dtype=torch.int32, device=wire)
+        t_v = torch.empty(nnz, dtype=torch.float64, device=wire)
+    barrier(dist, torch)
+    t0 = time.perf_counter()
+    for t in (t_rp, t_ci, t_v):
+        dist.broadcast(t, 0)
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    if rank == 0:
+        return (m, n, rp, ci, v), ms
+    return (m, n, t_rp.cpu().numpy(), t_ci.cpu().numpy(), t_v.cpu().numpy()), ms
+
+
+def make_B_slab(torch, device, m, j0, j1, layout, seed=777):
+    """Columns [j0, j1) of the job's B: column j is U(-1, 1) from a generator seeded seed + j, so any sharding of the
+    same job sees the same matrix.  layout "col": slab stored column-major with ld = m; "row": m x (j1-j0), ld = j1-j0."""
+    nloc = j1 - j0
+    cols = torch.empty((nloc, m), dtype=torch.float64, device=device)
+    gen = torch.Generator(device=device)
+    for jl in range(nloc):
+        gen.manual_seed(seed + j0 + jl)
+        cols[jl].copy_(torch.rand(m, dtype=torch.float64, device=device, generator=gen) * 2.0 - 1.0)
+    if layout == "col":
+        return cols.reshape(-1)
+    return cols.t().contiguous().reshape(-1)
+
+
+class ShardedCsrmm:
+    """One rank's share of C = alpha*A*B + beta*C.  Every rank builds the same handle from the broadcast CSR arrays
+    (mm hint + aoclsparse_optimize), owns columns [j0, j1) and calls the ordinary aoclsparse_dcsrmm on its slab."""
+
+    def __init__(self, pkg, torch, dist, device, rank, world, csr, ncols, layout="col"):
+        assert layout in ("col", "row")
+        self.pkg, self.torch, self.dist, self.device = pkg, torch, dist, device
+        self.rank, self.world, self.ncols, self.layout = rank, world, ncols, layout
+        (self.m, self.n, rp, ci, v), self.a_broadcast_ms = broadcast_csr(dist, torch, device, rank, csr)
+        self.nnz = int(len(v))
+        self.A = pkg.Matrix(0, self.m, self.n, rp, ci, v)
+        assert self.A.status == 0, pkg.STATUS[self.A.status]
+        self.descr = pkg.Descr()
+        L = pkg.lib()
+        st = L.aoclsparse_set_mm_hint(self.A.h, pkg.OP_NONE, self.descr.h, 100)
+        assert st == 0, pkg.STATUS[st]
+        st = L.aoclsparse_optimize(self.A.h)
+        assert st == 0, pkg.STATUS[st]
+        self.j0, self.j1 = pkg.column_shard(ncols, world, rank)
+        self.nloc = self.j1 - self.j0
+
+    def slab_ld(self, rows, nloc=None):
+        nloc = self.nloc if nloc is None else nloc
+        return rows if self.layout == "col" else max(nloc, 1)
+
+    def make_B(self, seed=777, j0=None, j1=None):
+        j0 = self.j0 if j0 is None else j0
+        j1 = self.j1 if j1 is None else j1
+        return make_B_slab(self.torch, self.device, self.n, j0, j1, self.layout, seed)
+
+    def run(self, B, C, alpha=1.0, beta=0.0, nloc=None):
+        """B, C: this rank's slabs (device tensors, layout as constructed)."""
+        pkg = self.pkg
+        nloc = self.nloc if nloc is None else nloc
+        if nloc == 0:
+            return 0
+        order = pkg.ORDER_COLUMN if self.layout == "col" else pkg.ORDER_ROW
+        return pkg.dcsrmm(pkg.OP_NONE, alpha, self.A, self.descr, order, B, nloc, self.slab_ld(self.n, nloc), beta, C,
+                          self.slab_ld(self.m, nloc))
+
+    def gather_C(self, C):
+        """All slabs on every rank -> (full C as an (ncols, m) tensor of columns, ms).  Optional: the product itself
+        never needs it."""
+        cols = C.reshape(self.nloc, self.m) if self.layout == "col" else C.reshape(self.m, self.nloc).t().contiguous()
+        shards = [self.pkg.column_shard(self.ncols, self.world, r) for r in range(self.world)]
+        return gather_slabs(self.torch, self.dist, self.device, self.rank, shards, cols)
+
+
+def gather_slabs(torch, dist, device, rank, shards, cols):
+    """cols: this rank's slab as a (width, m) tensor; shards: [(j0, j1)] of every rank -> ((ncols, m) tensor, ms)."""
+    if dist is None or not dist.is_initialized() or len(shards) == 1:
+        return cols, 0.0
+    m = cols.shape[1]
+    wire = "cpu" if _backend(dist) == "gloo" else device
+    parts = [torch.empty((b - a, m), dtype=cols.dtype, device=wire) for a, b in shards]
+    barrier(dist, torch)
+    t0 = time.perf_counter()
+    if len({b - a for a, b in shards}) == 1:
+        dist.all_gather(parts, cols.to(wire).contiguous())
+    else:  # slabs differ in width (n not a multiple of 4*world): broadcast each from its owner
+        for r, (a, b) in enumerate(shards):
+            if r == rank:
+                parts[r].copy_(cols)
+            if b > a:
+                dist.broadcast(parts[r], r)
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    return torch.cat([p.to(device) for p in parts], dim=0), ms
+
+
+def quartiles(ms):
+    """min / q1 / median / q3 / max of per-iteration times -- the statistics the reference harness prints
+    (tests/include/aoclsparse_stats.hpp:41-129)."""
+    a = np.sort(np.asarray(ms, dtype=np.float64))
+    if len(a) == 0:
+        return None
+    q = lambda f: float(np.quantile(a, f))
+    return {"min": float(a[0]), "q1": q(0.25), "median": q(0.5), "q3": q(0.75), "max": float(a[-1]), "n": int(len(a))}
+
+
+def csrmm_bytes(m, k, nnz, ncols, beta_nonzero=False):
+    """Dense-correct csrmm byte count."""
+    return (m + 1 + nnz) * 4 + nnz * 8 + 8 * ncols * (k + m * (2 if beta_nonzero else 1))
+
+
+def bench_sharded_csrmm(pkg, torch, dist, device, rank, world, csr, ncols, layout="col", reps=20, warm=3,
+                        full_product=True, allgather=True, peak_gbs=8000.0):
+    """The BASELINE config-4 job on `world` ranks.  Returns (on every rank) a dict with the sharded time (max over
+    ranks of the median per-iteration device time, and the barrier-bracketed wall clock), the 1-GPU time T1 of the SAME
+    job measured in the same run (every rank runs all `ncols` columns once `full_product` is set), the scaling
+    efficiency T1 / (world * Tg), the A broadcast and the optional C all-gather."""
+    sh = ShardedCsrmm(pkg, torch, dist, device, rank, world, csr, ncols, layout)
+    m, nnz = sh.m, sh.nnz
+    B = sh.make_B()
+    C = torch.zeros(max(sh.nloc, 1) * m, dtype=torch.float64, device=device)
+
+    def timed(fn, reps, warm):
+        for _ in range(warm):
+            assert fn() == 0
+        barrier(dist, torch)
+        t0 = time.perf_counter()
+        pkg.timer_mark()
+        for _ in range(reps):
+            assert fn() == 0
+            pkg.timer_mark()
+        laps = pkg.timer_laps()
+        barrier(dist, torch)
+        return laps, (time.perf_counter() - t0) / reps * 1e3
+
+    laps, wall_ms = timed(lambda: sh.run(B, C), reps, warm)
+    st_shard = quartiles(laps)
+    tg_dev = reduce_scalar(st_shard["median"], "max", dist, device)
+    tg_wall = reduce_scalar(wall_ms, "max", dist, device)
+    checksum = reduce_scalar(float(C.sum().item()) if sh.nloc else 0.0, "sum", dist, device)
+    out = {
+        "layout": "column-major" if layout == "col" else "row-major", "ncols": ncols, "world": world,
+        "cols_per_rank": sh.nloc, "m": m, "nnz": nnz,
+        "shard_ms": st_shard, "tg_ms_device_median_max_over_ranks": round(tg_dev, 5),
+        "tg_ms_wall_max_over_ranks": round(tg_wall, 5), "a_broadcast_ms": round(sh.a_broadcast_ms, 3),
+        "checksum": checksum,
+    }
+    job_bytes = csrmm_bytes(m, sh.n, nnz, ncols) + (world - 1) * ((m + 1 + nnz) * 4 + nnz * 8)
+    shard_bytes = csrmm_bytes(m, sh.n, nnz, sh.nloc)
+    out["gflops_job"] = round(2.0 * nnz * ncols / tg_dev / 1e6, 2)
+    out["roofline_shard"] = {"bound": "hbm", "achieved": round(shard_bytes / st_shard["median"] / 1e6, 2),
+                             "peak": peak_gbs, "unit": "GB/s",
+                             "frac": round(shard_bytes / st_shard["median"] / 1e6 / peak_gbs, 4), "traffic": None,
+                             "algorithmic_bytes_per_launch": shard_bytes}
+    out["gbs_job_algorithmic"] = round(job_bytes / tg_dev / 1e6, 2)
+    if allgather:
+        full, ag_ms = sh.gather_C(C)
+        out["c_allgather_ms"] = round(reduce_scalar(ag_ms, "max", dist, device), 3)
+        out["c_allgather_checksum"] = float(full.sum().item())
+        del full
+    if full_product:
+        if world == 1:
+            t1, st_full = tg_dev, st_shard
+        else:
+            Bf = sh.make_B(j0=0, j1=ncols)
+            Cf = torch.zeros(ncols * m, dtype=torch.float64, device=device)
+            laps1, _ = timed(lambda: sh.run(Bf, Cf, nloc=ncols), max(3, reps // 2), 2)
+            st_full = quartiles(laps1)
+            t1 = reduce_scalar(st_full["median"], "min", dist, device)  # the fastest GPU's 1-GPU time: strictest T1
+            del Bf, Cf
+        out["t1_ms"] = round(t1, 5)
+        out["full_ms"] = st_full
+        out["efficiency"] = round(t1 / (world * tg_dev), 4)
+        fb = csrmm_bytes(m, sh.n, nnz, ncols)
+        out["roofline_full"] = {"bound": "hbm", "achieved": round(fb / t1 / 1e6, 2), "peak": peak_gbs, "unit": "GB/s",
+                                "frac": round(fb / t1 / 1e6 / peak_gbs, 4), "traffic": None,
+                                "algorithmic_bytes_per_launch": fb}
+    return out, sh, B, C

@@ -35,6 +35,31 @@ DLL_PUBLIC aoclsparse_status aoclsparse_mi355_device_info(aoclsparse_int *device
 /* hipEvent pair on the library's stream: start, run work, stop -> elapsed milliseconds */
 DLL_PUBLIC aoclsparse_status aoclsparse_mi355_timer_start(void);
 DLL_PUBLIC aoclsparse_status aoclsparse_mi355_timer_stop(float *elapsed_ms);
+/* per-iteration timing (the reference harness reports min / quartiles / max of its iterations,
+ * tests/include/aoclsparse_stats.hpp:41-129): mark() records one event on the library's stream (at most 65536 between
+ * two laps() calls); laps() waits for the last mark, writes min(*count, capacity) elapsed times between consecutive
+ * marks (milliseconds) and resets the ring. */
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_timer_mark(void);
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_timer_laps(float *laps_ms, aoclsparse_int capacity, aoclsparse_int *count);
+
+/* ---- column shards of csrmm: one process per GPU ------------------------------------------ */
+/* The reference splits B's columns over its worker threads inside the library
+ * (library/src/level3/aoclsparse_csrmm_kt.cpp:68-82: start = n*t/T rounded up to a multiple of 4, capped at n).
+ * column_shard applies that rule with (world, rank) in place of (threads, thread id); ?csrmm_shard computes the slab
+ * C[:, j0:j1) of rank `rank` from the FULL B / C arrays (same arguments as aoclsparse_?csrmm otherwise).  There is no
+ * communication on the data path: a rank needs A and its own columns of B only. */
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_column_shard(aoclsparse_int n, aoclsparse_int world, aoclsparse_int rank,
+                                                           aoclsparse_int *j0, aoclsparse_int *j1);
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_dcsrmm_shard(aoclsparse_operation op, const double alpha,
+                                                           const aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                                           aoclsparse_order order, const double *B, aoclsparse_int n,
+                                                           aoclsparse_int ldb, const double beta, double *C,
+                                                           aoclsparse_int ldc, aoclsparse_int world, aoclsparse_int rank);
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_scsrmm_shard(aoclsparse_operation op, const float alpha,
+                                                           const aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                                           aoclsparse_order order, const float *B, aoclsparse_int n,
+                                                           aoclsparse_int ldb, const float beta, float *C,
+                                                           aoclsparse_int ldc, aoclsparse_int world, aoclsparse_int rank);
 
 /* ---- introspection of a handle --------------------------------------------------------- */
 /* idiag / iurow of the clean CSR (host arrays owned by the handle, length m, matrix base);

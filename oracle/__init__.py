@@ -78,6 +78,17 @@ def dcsrmv_inplace(kid, base, alpha, m, nnz, val, col, row, x, beta, y, nthreads
                                 _p(row), _p(x), c_dbl(beta), _p(y), c_int(nthreads))
 
 
+def dcsrmv_bench(kid, base, m, n, nnz, val, col, row, x, nthreads, passes):
+    """CPU-baseline leg: `passes` SpMVs (alpha=1, beta=0) on first-touched copies of the arrays, each pass timed on
+    its own -> (status, seconds[passes], y of the last pass)."""
+    val, col, row, x = _f64(val), _i32(col), _i32(row), _f64(x)
+    secs = np.zeros(max(passes, 1), dtype=np.float64)
+    y = np.zeros(max(m, 1), dtype=np.float64)
+    st = lib().orc_dcsrmv_bench(c_int(kid), c_int(base), c_i32(m), c_i32(n), c_i32(nnz), _p(val), _p(col), _p(row),
+                                _p(x), c_int(nthreads), c_int(passes), _p(secs), _p(y))
+    return st, secs[:passes], y[:m]
+
+
 def dcsrmv_order(order, base, alpha, m, val, col, row, x, beta, y):
     """order in {'ref','lane4','lane8'}: one specific reference kernel."""
     fn = {"ref": "orc_dcsrmv_ref", "lane4": "orc_dcsrmv_lane4", "lane8": "orc_dcsrmv_lane8"}[order]

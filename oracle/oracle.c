@@ -216,6 +216,66 @@ int orc_dcsrmv_omp(int kid, int base, double alpha, oint m, oint nnz, const doub
     return ORC_SUCCESS;
 }
 
+/* CPU-baseline leg of bench.py: the same OpenMP row split as orc_dcsrmv_omp, but on
+ * copies of the arrays that were FIRST TOUCHED by the threads that will read them (same static schedule), so that on a
+ * multi-socket host every thread streams from its own NUMA node as a tuned run of the reference would
+ * (OMP_PROC_BIND=close / OMP_PLACES=cores are set by the caller before this library is loaded).  Each pass is timed on
+ * its own; y of the last pass is returned for the parity check.  The arithmetic is orc_dcsrmv_omp's. */
+int orc_dcsrmv_bench(int kid, int base, oint m, oint n, oint nnz, const double *val, const oint *col,
+                     const oint *row, const double *x, int nthreads, int passes, double *seconds, double *y_out)
+{
+    int k = resolve_kid(kid, m, nnz);
+    if(k > 3)
+        return ORC_INVALID_KID;
+    if(nthreads < 1)
+        nthreads = 1;
+    double *v2 = (double *)malloc(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1));
+    oint   *c2 = (oint *)malloc(sizeof(oint) * (size_t)(nnz > 0 ? nnz : 1));
+    oint   *r2 = (oint *)malloc(sizeof(oint) * ((size_t)m + 1));
+    double *x2 = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    double *y2 = (double *)malloc(sizeof(double) * (size_t)(m > 0 ? m : 1));
+    if(!v2 || !c2 || !r2 || !x2 || !y2)
+    {
+        free(v2), free(c2), free(r2), free(x2), free(y2);
+        return ORC_MEMORY_ERROR;
+    }
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+#endif
+    for(oint i = 0; i < m; i++)
+    {
+        r2[i] = row[i];
+        if(i == m - 1)
+            r2[m] = row[m];
+        for(oint p = row[i] - base; p < row[i + 1] - base; p++)
+            v2[p] = val[p], c2[p] = col[p];
+        y2[i] = 0.0;
+    }
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+#endif
+    for(oint j = 0; j < n; j++)
+        x2[j] = x[j];
+    if(m == 0)
+        r2[0] = row[0];
+    for(int t = 0; t < passes; t++)
+    {
+#ifdef _OPENMP
+        const double t0 = omp_get_wtime();
+#endif
+        orc_dcsrmv_omp(k, base, 1.0, m, nnz, v2, c2, r2, x2, 0.0, y2, nthreads);
+#ifdef _OPENMP
+        seconds[t] = omp_get_wtime() - t0;
+#else
+        seconds[t] = 0.0;
+#endif
+    }
+    if(y_out)
+        memcpy(y_out, y2, sizeof(double) * (size_t)m);
+    free(v2), free(c2), free(r2), free(x2), free(y2);
+    return ORC_SUCCESS;
+}
+
 /* csrmv_kt.cpp:96-214 with one thread: scale y (beta==0 writes zeros, beta==1 untouched),
  * then row by row y[col] += val * (alpha*x[i]).  The vector body multiplies then adds
  * (kt_mul_p then +=, :184-193); the tail "y += aval*alpha*x[i]" is contracted to an fma of

@@ -94,6 +94,8 @@ int orc_dcsrmv_omp(int kid, int base, double alpha, oint m, oint nnz, const doub
                    const oint *col, const oint *row, const double *x, double beta, double *y,
                    int nthreads);
 int orc_max_threads(void);
+int orc_dcsrmv_bench(int kid, int base, oint m, oint n, oint nnz, const double *val, const oint *col,
+                     const oint *row, const double *x, int nthreads, int passes, double *seconds, double *y_out);
 
 /* ---- TRSV, level2/aoclsparse_trsv_kr.hpp:38-222 ------------------------------------- */
 /* ilend = idiag for the L kernels, iurow for the U kernels (trsv.cpp:381-400). */

@@ -1,31 +1,40 @@
-"""CPU tier: the multi-rank bookkeeping of bench.py (column shards, max-over-ranks time, whole-job
-throughput) under torch.distributed with the gloo backend, world_size 2 -- the N > 1 path the driver
-runs on 2/4/8 GPUs with RCCL."""
+"""CPU tier: the multi-rank host logic of bench.py and aocl-sparse_amd/sharded.py (column shards, CSR broadcast,
+slab generation, C all-gather, max-over-ranks time, whole-job throughput) under torch.distributed with the gloo
+backend, world_size 2 -- the N > 1 path the driver runs on 2/4/8 GPUs with RCCL.  No compute: the product has no
+CPU path (the csrmm itself is covered by the 2-process test of tests/test_gpu_parity.py on the GPU)."""
 import os
 import socket
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+import __graft_entry__ as entry  # noqa: E402
 import bench  # noqa: E402
 
 
 def test_column_shards_partition():
-    for ncols in (256, 255, 7, 1):
+    """The reference's thread split (csrmm_kt.cpp:68-82): start = n*t/T rounded up to a multiple of 4, capped at n.
+    The python rule of bench.py and the library's aoclsparse_mi355_column_shard must agree."""
+    pkg = entry.load_package()
+    for ncols in (256, 255, 64, 7, 4, 1, 0):
         for world in (1, 2, 3, 4, 8):
             cover = []
             for r in range(world):
                 j0, j1 = bench.column_shard(ncols, world, r)
+                assert (j0, j1) == pkg.column_shard(ncols, world, r)
                 assert 0 <= j0 <= j1 <= ncols
+                assert j0 % 4 == 0 or j0 == ncols  # slabs start on the reference's 4-column blocks
                 cover += list(range(j0, j1))
             assert cover == list(range(ncols))
-            sizes = [bench.column_shard(ncols, world, r)[1] - bench.column_shard(ncols, world, r)[0]
-                     for r in range(world)]
-            assert max(sizes) - min(sizes) <= 1
     assert bench.column_shard(256, 8, 3) == (96, 128)
+    assert [bench.column_shard(7, 2, r) for r in range(2)] == [(0, 4), (4, 7)]
+    assert [bench.column_shard(10, 4, r) for r in range(4)] == [(0, 4), (4, 8), (8, 8), (8, 10)]
+    with pytest.raises(ValueError):
+        pkg.column_shard(8, 2, 2)
 
 
 def test_byte_models():
@@ -34,26 +43,56 @@ def test_byte_models():
     assert bench.spmv_bytes(10000, 10000, 49600, True) == 795204 + 80000
     m, nnz = 1000000, 4996000
     assert bench.csrmm_bytes(m, m, nnz, 256) == (m + 1 + nnz) * 4 + nnz * 8 + 8 * 256 * 2 * m
+    assert bench.trsv_bytes(7, 10) == (7 + 1 + 10) * 4 + (14 + 10) * 8
+
+
+def test_quartiles_and_roofline():
+    q = bench.quartiles([5.0, 1.0, 3.0, 2.0, 4.0])
+    assert (q["min"], q["q1"], q["median"], q["q3"], q["max"], q["n"]) == (1.0, 2.0, 3.0, 4.0, 5.0, 5)
+    r = bench.roofline(8e9, 1.0)  # 8 GB in 1 ms = 8 TB/s
+    assert r["achieved"] == 8000.0 and r["frac"] == 1.0 and r["bound"] == "hbm" and r["traffic"] is None
+    model, logical, phys = bench.cpu_info()
+    assert logical >= 1 and 1 <= phys <= max(logical, phys)
 
 
 def _worker(rank, world, port, q):
+    import torch
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        pkg = entry.load_package()
+        import aocl_sparse_amd.sharded as sharded
+
         # rank r "processed" (r+1)*10 units in (r+1) seconds
         thr, tmax = bench.job_throughput((rank + 1) * 10.0, float(rank + 1), dist)
         s = bench.reduce_scalar(rank + 1.0, "sum", dist)
-        j0, j1 = bench.column_shard(256, world, rank)
-        cols = bench.reduce_scalar(j1 - j0, "sum", dist)
-        q.put((rank, thr, tmax, s, cols))
+        mn = sharded.reduce_scalar(rank + 1.0, "min", dist)
+        # A is broadcast from rank 0: every rank ends up with the same five arrays
+        csr = None
+        if rank == 0:
+            m, rp, ci, v = entry.laplace5(12)
+            csr = (m, m, rp, ci, v)
+        (m, n, rp, ci, v), ms = sharded.broadcast_csr(dist, torch, "cpu", rank, csr)
+        m0, rp0, ci0, v0 = entry.laplace5(12)
+        same = m == m0 and n == m0 and np.array_equal(rp, rp0) and np.array_equal(ci, ci0) and np.array_equal(v, v0)
+        # slabs: seeded per column, so the concatenation of the ranks' slabs is the 1-rank matrix
+        ncols = 10
+        shards = [pkg.column_shard(ncols, world, r) for r in range(world)]
+        j0, j1 = shards[rank]
+        Bc = sharded.make_B_slab(torch, "cpu", m, j0, j1, "col")
+        Br = sharded.make_B_slab(torch, "cpu", m, j0, j1, "row")
+        full = sharded.make_B_slab(torch, "cpu", m, 0, ncols, "col").reshape(ncols, m)
+        slab_ok = torch.equal(Bc.reshape(j1 - j0, m), full[j0:j1]) and torch.equal(Br.reshape(m, j1 - j0).t(), full[j0:j1])
+        gathered, _ = sharded.gather_slabs(torch, dist, "cpu", rank, shards, Bc.reshape(j1 - j0, m))
+        q.put((rank, thr, tmax, s, mn, bool(same), bool(slab_ok), bool(torch.equal(gathered, full)), shards))
     finally:
         dist.destroy_process_group()
 
 
-def test_job_throughput_world2_gloo():
+def test_sharded_host_logic_world2_gloo():
     import torch.multiprocessing as mp
 
     with socket.socket() as s:
@@ -64,23 +103,35 @@ def test_job_throughput_world2_gloo():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in range(2))
+    res = sorted(q.get(timeout=180) for _ in range(2))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, thr, tmax, ssum, cols in res:
-        assert tmax == 2.0 and thr == 30.0 / 2.0 and ssum == 3.0 and cols == 256.0
+    for rank, thr, tmax, ssum, mn, same, slab_ok, gather_ok, shards in res:
+        assert tmax == 2.0 and thr == 30.0 / 2.0 and ssum == 3.0 and mn == 1.0
+        assert same, "broadcast CSR differs from rank 0's"
+        assert slab_ok and gather_ok
+        assert shards == [(0, 8), (8, 10)]  # 10 columns over 2 ranks: 4-column blocks, remainder to the last
 
 
 def test_single_rank_is_identity():
     assert bench.reduce_scalar(3.5, "max") == 3.5
     assert bench.job_throughput(10.0, 2.0) == (5.0, 2.0)
+    import torch
+    pkg = entry.load_package()
+    import aocl_sparse_amd.sharded as sharded
+    m, rp, ci, v = entry.laplace5(5)
+    csr, ms = sharded.broadcast_csr(None, torch, "cpu", 0, (m, m, rp, ci, v))
+    assert ms == 0.0 and csr[0] == m
+    cols = torch.arange(12, dtype=torch.float64).reshape(3, 4)
+    out, ms = sharded.gather_slabs(torch, None, "cpu", 0, [(0, 3)], cols)
+    assert out is cols and ms == 0.0
+    assert sharded.quartiles([]) is None
 
 
 def test_matrix_market_reader(tmp_path):
     """tools/standins.read_mtx: coordinate real symmetric -> full sorted CSR (what the reference's harness does,
     tests/include/aoclsparse_init.hpp:452-694)."""
-    import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import standins
     p = tmp_path / "t.mtx"
@@ -92,3 +143,21 @@ def test_matrix_market_reader(tmp_path):
     q.write_text("%%MatrixMarket matrix coordinate pattern general\n2 3 2\n1 3\n2 1\n")
     m, n, rp, ci, v = standins.read_mtx(str(q))
     assert (m, n, list(rp), list(ci)) == (2, 3, [0, 1, 2], [2, 0]) and len(v) == 2
+
+
+def test_block_standins_are_sorted_duplicate_free():
+    """The block stand-ins are built directly in sorted order (tools/standins._block_csr): rows ascending and
+    duplicate-free, full diagonal, block structure as documented."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import standins
+    for gen, kw, bs in ((standins.shell_like, dict(n=5 * 37 * 9, width=37), 5), (standins.flan_like, dict(nx=5, ny=4, nz=6), 3)):
+        m, rp, ci, v = gen(**kw)
+        assert rp[0] == 0 and rp[-1] == len(ci) == len(v) and m % bs == 0
+        for i in range(m):
+            c = ci[rp[i]:rp[i + 1]]
+            assert np.all(np.diff(c) > 0) and i in c
+            assert 4.0 <= v[rp[i] + int(np.searchsorted(c, i))] <= 8.0
+        # the bs rows of a node share one column pattern (what the csrmm row groups detect)
+        for i in range(0, m, bs):
+            for a in range(1, bs):
+                assert np.array_equal(ci[rp[i]:rp[i + 1]], ci[rp[i + a]:rp[i + a + 1]])

@@ -1,0 +1,884 @@
+// csrmm_r2.hip -- diagnostic build (never shipped), round 2: what bounds C = A*B (beta = 0) for a banded A?
+//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/csrmm_r2.hip -o tools/bin/csrmm_r2
+//   csrmm_r2 [g=1000] [n=256] [band=g]     A = 5 diagonals {-band,-1,0,1,band} on m = g*g rows
+// Row-major variants:   R0 = shipped wave/(row,128 columns); RS<LANES,R,NB> = XCD <-> column slab of 2*LANES columns,
+//                       a sub-wave of LANES lanes takes R rows at once and issues R*NB B-row loads before any FMA.
+// Column-major variants: C0 = shipped lane/row, 64-column chunks; CP<U,CC,SLAB> = software-pipelined (loads of step
+//                       k+1 are issued before the stores of step k), U columns per step, CC columns per block,
+//                       SLAB: XCD <-> column slab instead of XCD <-> row eighth.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#define CHECK(x)                                                                 \
+    do                                                                           \
+    {                                                                            \
+        hipError_t e_ = (x);                                                     \
+        if(e_ != hipSuccess)                                                     \
+        {                                                                        \
+            printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); \
+            exit(1);                                                             \
+        }                                                                        \
+    } while(0)
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int xcd_row(int bx, int chunk)
+{
+    return chunk > 0 ? (bx & 7) * chunk + (bx >> 3) : bx;
+}
+
+// ---------------------------------------------------------------- R0: shipped
+__global__ __launch_bounds__(256) void r0(int m, const double *__restrict__ val, const int *__restrict__ col,
+                                          const int *__restrict__ row_ptr, const double *__restrict__ B, int n, int ldb,
+                                          double *__restrict__ C, int ldc, int chunk)
+{
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i = xcd_row(blockIdx.x, chunk) * 4 + w;
+    const int j = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
+    if(i >= m || j >= n)
+        return;
+    const int     s = row_ptr[i], e = row_ptr[i + 1];
+    double        a0 = 0, a1 = 0;
+    const double *Bj = B + j;
+    int           p  = s;
+    for(; p + 4 <= e; p += 4)
+    {
+        const double v0 = val[p], v1 = val[p + 1], v2 = val[p + 2], v3 = val[p + 3];
+        const v2d    b0 = *reinterpret_cast<const v2d *>(Bj + (size_t)col[p] * ldb);
+        const v2d    b1 = *reinterpret_cast<const v2d *>(Bj + (size_t)col[p + 1] * ldb);
+        const v2d    b2 = *reinterpret_cast<const v2d *>(Bj + (size_t)col[p + 2] * ldb);
+        const v2d    b3 = *reinterpret_cast<const v2d *>(Bj + (size_t)col[p + 3] * ldb);
+        a0 = fma(v0, b0.x, a0), a1 = fma(v0, b0.y, a1);
+        a0 = fma(v1, b1.x, a0), a1 = fma(v1, b1.y, a1);
+        a0 = fma(v2, b2.x, a0), a1 = fma(v2, b2.y, a1);
+        a0 = fma(v3, b3.x, a0), a1 = fma(v3, b3.y, a1);
+    }
+    for(; p < e; p++)
+    {
+        const double v0 = val[p];
+        const v2d    b0 = *reinterpret_cast<const v2d *>(Bj + (size_t)col[p] * ldb);
+        a0 = fma(v0, b0.x, a0), a1 = fma(v0, b0.y, a1);
+    }
+    v2d c;
+    c.x = a0, c.y = a1;
+    *reinterpret_cast<v2d *>(C + (size_t)i * ldc + j) = c;
+}
+
+// ---------------------------------------------------------------- RS: slab kernel
+// mapping (host computes): S8 slabs side by side over the XCDs, P = 8/S8 row parts, nbp row blocks per part,
+// passes = ceil(S / S8) over the remaining slabs.  SLABMAP = false: plain XCD <-> row eighth, blockIdx.y = slab.
+template <int LANES, int R, int NB, bool NT, bool SLABMAP>
+__global__ __launch_bounds__(256) void rs(int m, const double *__restrict__ val, const int *__restrict__ col,
+                                          const int *__restrict__ row_ptr, const double *__restrict__ B, int n, int ldb,
+                                          double *__restrict__ C, int ldc, int S8, int nbp, int chunk)
+{
+    constexpr int SUB = 256 / LANES; // sub-waves per workgroup
+    constexpr int RPB = SUB * R; // rows per workgroup
+    int           slab, rb;
+    if(SLABMAP)
+    {
+        const int xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
+        slab          = (xcd % S8) + S8 * (t / nbp);
+        rb            = (xcd / S8) * nbp + (t % nbp);
+    }
+    else
+    {
+        slab = blockIdx.y;
+        rb   = xcd_row(blockIdx.x, chunk);
+    }
+    int sub = (int)threadIdx.x / LANES;
+    if(LANES == 64)
+        sub = __builtin_amdgcn_readfirstlane(sub);
+    const int lane = (int)threadIdx.x % LANES;
+    const int i0   = rb * RPB + sub * R;
+    const int j    = slab * 2 * LANES + 2 * lane;
+    if(i0 >= m || j >= n)
+        return;
+    int s[R], len[R];
+#pragma unroll
+    for(int q = 0; q < R; q++)
+    {
+        const bool ok = i0 + q < m;
+        s[q]          = ok ? row_ptr[i0 + q] : 0;
+        len[q]        = ok ? row_ptr[i0 + q + 1] - s[q] : 0;
+    }
+    int    c[R][NB];
+    double v[R][NB];
+#pragma unroll
+    for(int q = 0; q < R; q++)
+#pragma unroll
+        for(int u = 0; u < NB; u++)
+        {
+            c[q][u] = -1, v[q][u] = 0;
+            if(u < len[q])
+                c[q][u] = col[s[q] + u], v[q][u] = val[s[q] + u];
+        }
+    const double *Bj = B + j;
+    v2d           b[R][NB];
+#pragma unroll
+    for(int q = 0; q < R; q++)
+#pragma unroll
+        for(int u = 0; u < NB; u++)
+            if(c[q][u] >= 0)
+                b[q][u] = *reinterpret_cast<const v2d *>(Bj + (size_t)c[q][u] * ldb);
+#pragma unroll
+    for(int q = 0; q < R; q++)
+    {
+        if(i0 + q >= m)
+            break;
+        double a0 = 0, a1 = 0;
+#pragma unroll
+        for(int u = 0; u < NB; u++)
+            if(u < len[q])
+                a0 = fma(v[q][u], b[q][u].x, a0), a1 = fma(v[q][u], b[q][u].y, a1);
+        for(int p = s[q] + NB; p < s[q] + len[q]; p++)
+        {
+            const double vv = val[p];
+            const v2d    bb = *reinterpret_cast<const v2d *>(Bj + (size_t)col[p] * ldb);
+            a0 = fma(vv, bb.x, a0), a1 = fma(vv, bb.y, a1);
+        }
+        v2d o;
+        o.x = a0, o.y = a1;
+        v2d *cp = reinterpret_cast<v2d *>(C + (size_t)(i0 + q) * ldc + j);
+        if(NT)
+            __builtin_nontemporal_store(o, cp);
+        else
+            *cp = o;
+    }
+}
+
+// ---------------------------------------------------------------- C0: shipped column-major
+constexpr int CM_K = 8;
+__global__ __launch_bounds__(256) void c0(int m, const double *__restrict__ val, const int *__restrict__ col,
+                                          const int *__restrict__ row_ptr, const double *__restrict__ B, int n, int ldb,
+                                          double *__restrict__ C, int ldc, int chunk)
+{
+    const int i = xcd_row(blockIdx.x, chunk) * blockDim.x + threadIdx.x;
+    if(i >= m)
+        return;
+    const int j0 = blockIdx.y * 64, j1 = min(n, j0 + 64);
+    const int s = row_ptr[i], e = row_ptr[i + 1];
+    double    v[CM_K];
+    int       c[CM_K];
+#pragma unroll
+    for(int k = 0; k < CM_K; k++)
+    {
+        v[k] = 0, c[k] = 0;
+        if(s + k < e)
+            v[k] = val[s + k], c[k] = col[s + k];
+    }
+    const int len = e - s;
+    for(int j = j0; j + 4 <= j1; j += 4)
+    {
+        const double *B0 = B + (size_t)j * ldb, *B1 = B0 + ldb, *B2 = B1 + ldb, *B3 = B2 + ldb;
+        double        a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+        for(int k = 0; k < CM_K; k++)
+            if(k < len)
+            {
+                a0 = fma(v[k], B0[c[k]], a0), a1 = fma(v[k], B1[c[k]], a1);
+                a2 = fma(v[k], B2[c[k]], a2), a3 = fma(v[k], B3[c[k]], a3);
+            }
+        for(int p = s + CM_K; p < e; p++)
+        {
+            const double av = val[p];
+            const int    cc = col[p];
+            a0 = fma(av, B0[cc], a0), a1 = fma(av, B1[cc], a1), a2 = fma(av, B2[cc], a2), a3 = fma(av, B3[cc], a3);
+        }
+        double *cp = C + (size_t)i + (size_t)j * ldc;
+        cp[0] = a0, cp[(size_t)ldc] = a1, cp[2 * (size_t)ldc] = a2, cp[3 * (size_t)ldc] = a3;
+    }
+}
+
+// ---------------------------------------------------------------- CP: pipelined column-major
+// a lane owns RL rows (i, i + 256, ...), keeps their first CM_K entries in registers and sweeps columns [j0, j1) in
+// steps of U; the loads of step k+1 are issued before the stores of step k.
+template <int U, int RL, bool SLAB, bool NT>
+__global__ __launch_bounds__(256) void cp(int m, const double *__restrict__ val, const int *__restrict__ col,
+                                          const int *__restrict__ row_ptr, const double *__restrict__ B, int n, int ldb,
+                                          double *__restrict__ C, int ldc, int cc, int nbp, int chunk)
+{
+    int rb, j0;
+    if(SLAB)
+    {
+        // XCD x sweeps column slab x (cc = n / 8 columns) for every row block
+        const int xcd = blockIdx.x & 7;
+        rb            = blockIdx.x >> 3;
+        j0            = xcd * cc;
+    }
+    else
+    {
+        rb = xcd_row(blockIdx.x, chunk);
+        j0 = blockIdx.y * cc;
+    }
+    const int j1 = min(n, j0 + cc);
+    double    v[RL][CM_K];
+    unsigned  c[RL][CM_K]; // byte offsets inside a column (< 4 GB), so that loads take the sgpr-base + 32-bit-offset form
+    int       len[RL], row[RL];
+#pragma unroll
+    for(int q = 0; q < RL; q++)
+    {
+        row[q]        = rb * 256 * RL + q * 256 + (int)threadIdx.x;
+        const bool ok = row[q] < m;
+        const int  s  = ok ? row_ptr[row[q]] : 0;
+        len[q]        = ok ? row_ptr[row[q] + 1] - s : 0;
+#pragma unroll
+        for(int k = 0; k < CM_K; k++)
+        {
+            v[q][k] = 0, c[q][k] = 0;
+            if(k < len[q])
+                v[q][k] = val[s + k], c[q][k] = (unsigned)col[s + k] * 8u;
+        }
+    }
+    double bv[RL][U][CM_K];
+    auto   load = [&](int j) {
+#pragma unroll
+        for(int q = 0; q < RL; q++)
+#pragma unroll
+            for(int u = 0; u < U; u++)
+            {
+                const char *Bu = reinterpret_cast<const char *>(B + (size_t)(j + u) * ldb);
+#pragma unroll
+                for(int k = 0; k < CM_K; k++)
+                    if(k < len[q])
+                        bv[q][u][k] = *reinterpret_cast<const double *>(Bu + c[q][k]);
+            }
+    };
+    if(j0 < j1)
+        load(j0);
+    for(int j = j0; j < j1; j += U)
+    {
+        double a[RL][U];
+#pragma unroll
+        for(int q = 0; q < RL; q++)
+#pragma unroll
+            for(int u = 0; u < U; u++)
+            {
+                a[q][u] = 0;
+#pragma unroll
+                for(int k = 0; k < CM_K; k++)
+                    if(k < len[q])
+                        a[q][u] = fma(v[q][k], bv[q][u][k], a[q][u]);
+            }
+        if(j + U < j1)
+            load(j + U);
+#pragma unroll
+        for(int q = 0; q < RL; q++)
+            if(row[q] < m)
+#pragma unroll
+                for(int u = 0; u < U; u++)
+                {
+                    double *cpq = C + (size_t)row[q] + (size_t)(j + u) * ldc;
+                    if(NT)
+                        __builtin_nontemporal_store(a[q][u], cpq);
+                    else
+                        *cpq = a[q][u];
+                }
+    }
+}
+
+// ---------------------------------------------------------------- diagnostics (wrong results on purpose)
+// DG<MODE>: R0's shape.  MODE 1: every entry reads B row i (no dependence on col).  MODE 2: the five B rows come from
+// closed-form indices (i-band, i-1, i, i+1, i+band), values constant: no loads of A at all, every B load issues at once.
+// MODE 3: as 2, plus row_ptr/col/val ARE loaded (scalar) but nothing depends on them before the store.
+template <int MODE>
+__global__ __launch_bounds__(256) void dg(int m, const double *__restrict__ val, const int *__restrict__ col,
+                                          const int *__restrict__ row_ptr, const double *__restrict__ B, int n, int ldb,
+                                          double *__restrict__ C, int ldc, int chunk, int band)
+{
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i = xcd_row(blockIdx.x, chunk) * 4 + w;
+    const int j = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
+    if(i >= m || j >= n)
+        return;
+    const double *Bj = B + j;
+    double        a0 = 0, a1 = 0;
+    if(MODE == 1)
+    {
+        const int s = row_ptr[i], e = row_ptr[i + 1];
+        for(int p = s; p < e; p++)
+        {
+            const double v0 = val[p];
+            const v2d    b0 = *reinterpret_cast<const v2d *>(Bj + (size_t)i * ldb);
+            a0 = fma(v0, b0.x, a0), a1 = fma(v0, b0.y, a1);
+            asm volatile("" ::: "memory");
+        }
+    }
+    else
+    {
+        const int r0 = max(i - band, 0), r1 = max(i - 1, 0), r3 = min(i + 1, m - 1), r4 = min(i + band, m - 1);
+        const v2d b0 = *reinterpret_cast<const v2d *>(Bj + (size_t)r0 * ldb);
+        const v2d b1 = *reinterpret_cast<const v2d *>(Bj + (size_t)r1 * ldb);
+        const v2d b2 = *reinterpret_cast<const v2d *>(Bj + (size_t)i * ldb);
+        const v2d b3 = *reinterpret_cast<const v2d *>(Bj + (size_t)r3 * ldb);
+        const v2d b4 = *reinterpret_cast<const v2d *>(Bj + (size_t)r4 * ldb);
+        double    v0 = -1.0, v1 = -1.0, v2 = 4.0, v3 = -1.0, v4 = -1.0;
+        if(MODE == 3)
+        {
+            const int s = row_ptr[i], e = row_ptr[i + 1];
+            v0 = val[s], v1 = val[s + 1], v2 = val[min(s + 2, e - 1)], v3 = val[min(s + 3, e - 1)], v4 = val[e - 1];
+            v0 += (double)(col[s] & 1);
+        }
+        a0 = fma(v0, b0.x, a0), a1 = fma(v0, b0.y, a1);
+        a0 = fma(v1, b1.x, a0), a1 = fma(v1, b1.y, a1);
+        a0 = fma(v2, b2.x, a0), a1 = fma(v2, b2.y, a1);
+        a0 = fma(v3, b3.x, a0), a1 = fma(v3, b3.y, a1);
+        a0 = fma(v4, b4.x, a0), a1 = fma(v4, b4.y, a1);
+    }
+    v2d c;
+    c.x = a0, c.y = a1;
+    *reinterpret_cast<v2d *>(C + (size_t)i * ldc + j) = c;
+}
+
+__global__ __launch_bounds__(256) void kcopy(size_t n2, const v2d *__restrict__ B, v2d *__restrict__ C)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if(i < n2)
+        C[i] = B[i];
+}
+
+// ---------------------------------------------------------------- TL: row-block kernel, A staged in LDS
+// One workgroup per CSR-Adaptive row block (consecutive rows, <= TILE entries, <= MAXR rows): row_ptr / col / val of
+// the block are fetched with coalesced loads into LDS (two round trips per BLOCK instead of per row), then a sub-wave
+// of LANES lanes walks rows; UR rows are in flight per sub-wave, NB B-row loads per row and step.
+// COLLOOP: the workgroup loops over the column chunks itself (A staged once); else blockIdx.y = chunk.
+template <int LANES, int TILE, int UR, int NB, bool COLLOOP, bool NT>
+__global__ __launch_bounds__(256) void tl(int m, const double *__restrict__ val, const int *__restrict__ col,
+                                          const int *__restrict__ row_ptr, const int2 *__restrict__ blocks, int nblocks,
+                                          const double *__restrict__ B, int n, int ldb, double *__restrict__ C, int ldc,
+                                          int chunk)
+{
+    constexpr int MAXR = 512;
+    constexpr int NSUB = 256 / LANES;
+    __shared__ int    s_ptr[MAXR + 1];
+    __shared__ int    s_col[TILE];
+    __shared__ double s_val[TILE];
+    const int bx = xcd_row(blockIdx.x, chunk);
+    if(bx >= nblocks)
+        return;
+    const int2 b0 = blocks[bx], b1 = blocks[bx + 1];
+    const int  r0 = b0.x, nrows = b1.x - b0.x, s0 = b0.y, cnt = b1.y - b0.y;
+    const int  tid = threadIdx.x;
+    for(int t = tid; t <= nrows; t += 256)
+        s_ptr[t] = row_ptr[r0 + t] - s0;
+    for(int t = tid; t < cnt; t += 256)
+        s_col[t] = col[s0 + t], s_val[t] = val[s0 + t];
+    __syncthreads();
+    const int sub = tid / LANES, lane = tid % LANES;
+    const int jstep = 2 * LANES;
+    int       j     = 2 * lane + (COLLOOP ? 0 : jstep * (int)blockIdx.y);
+    do
+    {
+        if(j < n)
+        {
+            const double *Bj = B + j;
+            for(int r = sub; r < nrows; r += NSUB * UR)
+            {
+                int    p0[UR], p1[UR];
+                double a0[UR], a1[UR];
+#pragma unroll
+                for(int q = 0; q < UR; q++)
+                {
+                    const int rr = r + q * NSUB;
+                    p0[q] = rr < nrows ? s_ptr[rr] : 0, p1[q] = rr < nrows ? s_ptr[rr + 1] : 0;
+                    a0[q] = 0, a1[q] = 0;
+                }
+                bool more = true;
+                while(more)
+                {
+                    v2d    b[UR][NB];
+                    double v[UR][NB];
+#pragma unroll
+                    for(int q = 0; q < UR; q++)
+#pragma unroll
+                        for(int u = 0; u < NB; u++)
+                            if(p0[q] + u < p1[q])
+                            {
+                                v[q][u] = s_val[p0[q] + u];
+                                b[q][u] = *reinterpret_cast<const v2d *>(Bj + (size_t)s_col[p0[q] + u] * ldb);
+                            }
+                    more = false;
+#pragma unroll
+                    for(int q = 0; q < UR; q++)
+                    {
+#pragma unroll
+                        for(int u = 0; u < NB; u++)
+                            if(p0[q] + u < p1[q])
+                                a0[q] = fma(v[q][u], b[q][u].x, a0[q]), a1[q] = fma(v[q][u], b[q][u].y, a1[q]);
+                        p0[q] += NB;
+                        more |= p0[q] < p1[q];
+                    }
+                }
+#pragma unroll
+                for(int q = 0; q < UR; q++)
+                {
+                    const int rr = r + q * NSUB;
+                    if(rr < nrows)
+                    {
+                        v2d o;
+                        o.x = a0[q], o.y = a1[q];
+                        v2d *cp = reinterpret_cast<v2d *>(C + (size_t)(r0 + rr) * ldc + j);
+                        if(NT)
+                            __builtin_nontemporal_store(o, cp);
+                        else
+                            *cp = o;
+                    }
+                }
+            }
+        }
+        j += jstep;
+    } while(COLLOOP && j - 2 * lane < n);
+}
+
+// ---------------------------------------------------------------- RT: strided 2-D tile of rows per workgroup
+// workgroup = TA x TB waves, wave (a, b) takes row base + a + stride*b: for a matrix whose far off-diagonals sit at
+// +-stride the waves of a workgroup share B rows in both directions (L1 hits instead of L2 requests).
+template <int TA, int TB>
+__global__ __launch_bounds__(64 * TA * TB) void rt(int m, const double *__restrict__ val, const int *__restrict__ col,
+                                                   const int *__restrict__ row_ptr, const double *__restrict__ B, int n,
+                                                   int ldb, double *__restrict__ C, int ldc, int stride, int wg_per_super,
+                                                   int chunk)
+{
+    const int w  = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int a  = w % TA, b = w / TA;
+    const int bx = xcd_row(blockIdx.x, chunk);
+    // super-block = TB lines of `stride` rows; inside it workgroup q covers offsets [TA*q, TA*q + TA) of every line
+    const int sb = bx / wg_per_super, q = bx % wg_per_super;
+    const int off = q * TA + a;
+    const int i   = sb * TB * stride + b * stride + off;
+    const int j   = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
+    if(off >= stride || i >= m || j >= n)
+        return;
+    const int     s = row_ptr[i], e = row_ptr[i + 1];
+    double        a0 = 0, a1 = 0;
+    const double *Bj = B + j;
+    int           p  = s;
+    for(; p + 4 <= e; p += 4)
+    {
+        const double v0 = val[p], v1 = val[p + 1], v2 = val[p + 2], v3 = val[p + 3];
+        const v2d    b0 = *reinterpret_cast<const v2d *>(Bj + (size_t)col[p] * ldb);
+        const v2d    b1 = *reinterpret_cast<const v2d *>(Bj + (size_t)col[p + 1] * ldb);
+        const v2d    b2 = *reinterpret_cast<const v2d *>(Bj + (size_t)col[p + 2] * ldb);
+        const v2d    b3 = *reinterpret_cast<const v2d *>(Bj + (size_t)col[p + 3] * ldb);
+        a0 = fma(v0, b0.x, a0), a1 = fma(v0, b0.y, a1);
+        a0 = fma(v1, b1.x, a0), a1 = fma(v1, b1.y, a1);
+        a0 = fma(v2, b2.x, a0), a1 = fma(v2, b2.y, a1);
+        a0 = fma(v3, b3.x, a0), a1 = fma(v3, b3.y, a1);
+    }
+    for(; p < e; p++)
+    {
+        const double v0 = val[p];
+        const v2d    b0 = *reinterpret_cast<const v2d *>(Bj + (size_t)col[p] * ldb);
+        a0 = fma(v0, b0.x, a0), a1 = fma(v0, b0.y, a1);
+    }
+    v2d c;
+    c.x = a0, c.y = a1;
+    *reinterpret_cast<v2d *>(C + (size_t)i * ldc + j) = c;
+}
+
+// ---------------------------------------------------------------- CPAIR: column-major, a lane owns the row pair (2r, 2r+1)
+// When row 2r+1 has row 2r's pattern shifted by one column (scalar stencils, banded matrices), entry k of both rows
+// reads B[c_k], B[c_k + 1] of a column: ONE 16-byte load (8-byte aligned) feeds both rows, and the two results are one
+// 16-byte store.  Per output element the FMA chain is unchanged.  Pairs that do not match take the scalar path.
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void cpair(int m, const double *__restrict__ val, const int *__restrict__ col,
+                                             const int *__restrict__ row_ptr, const double *__restrict__ B, int n, int ldb,
+                                             double *__restrict__ C, int ldc, int cc, int chunk)
+{
+    const int pr = xcd_row(blockIdx.x, chunk) * 256 + (int)threadIdx.x; // pair index
+    const int i  = 2 * pr;
+    if(i >= m)
+        return;
+    const int j0 = blockIdx.y * cc, j1 = min(n, j0 + cc);
+    const int s = row_ptr[i], e = row_ptr[i + 1], e2 = i + 1 < m ? row_ptr[i + 2] : e;
+    const int len = e - s;
+    bool      pair = (i + 1 < m) && (e2 - e == len) && len <= CM_K && len > 0;
+    double    v0[CM_K], v1[CM_K];
+    unsigned  c[CM_K];
+#pragma unroll
+    for(int k = 0; k < CM_K; k++)
+    {
+        v0[k] = 0, v1[k] = 0, c[k] = 0;
+        if(k < len)
+        {
+            const int ca = col[s + k];
+            v0[k] = val[s + k], c[k] = (unsigned)ca * 8u;
+            if(pair)
+            {
+                v1[k] = val[e + k];
+                pair  = pair && (col[e + k] == ca + 1);
+            }
+        }
+    }
+    if(pair)
+    {
+        for(int j = j0; j < j1; j += U)
+        {
+            v2d b[U][CM_K];
+#pragma unroll
+            for(int u = 0; u < U; u++)
+            {
+                const char *Bu = reinterpret_cast<const char *>(B + (size_t)(j + u) * ldb);
+#pragma unroll
+                for(int k = 0; k < CM_K; k++)
+                    if(k < len)
+                        __builtin_memcpy(&b[u][k], Bu + c[k], 16); // 8-byte aligned 16-byte load
+            }
+#pragma unroll
+            for(int u = 0; u < U; u++)
+            {
+                double a0 = 0, a1 = 0;
+#pragma unroll
+                for(int k = 0; k < CM_K; k++)
+                    if(k < len)
+                        a0 = fma(v0[k], b[u][k].x, a0), a1 = fma(v1[k], b[u][k].y, a1);
+                v2d o;
+                o.x = a0, o.y = a1;
+                v2d *cp = reinterpret_cast<v2d *>(C + (size_t)i + (size_t)(j + u) * ldc);
+                if(NT)
+                    __builtin_nontemporal_store(o, cp);
+                else
+                    *cp = o;
+            }
+        }
+    }
+    else
+    {
+        for(int q = 0; q < 2 && i + q < m; q++)
+        {
+            const int ss = row_ptr[i + q], ee = row_ptr[i + q + 1];
+            for(int j = j0; j < j1; j++)
+            {
+                const double *Bj = B + (size_t)j * ldb;
+                double        a  = 0;
+                for(int p = ss; p < ee; p++)
+                    a = fma(val[p], Bj[col[p]], a);
+                C[(size_t)(i + q) + (size_t)j * ldc] = a;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- helpers
+__global__ void copy_kernel(const v2d *__restrict__ a, v2d *__restrict__ b, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for(; i < n; i += (size_t)gridDim.x * blockDim.x)
+        b[i] = a[i];
+}
+
+__global__ void sample_rows(const double *C, long rs, long cs, int n, const int *rows, int nrows, double *out)
+{
+    const int r = blockIdx.x, j = threadIdx.x + blockIdx.y * blockDim.x;
+    if(r < nrows && j < n)
+        out[(size_t)r * n + j] = C[(size_t)rows[r] * rs + (size_t)j * cs];
+}
+
+int main(int argc, char **argv)
+{
+    const int  g    = argc > 1 ? atoi(argv[1]) : 1000;
+    const int  n    = argc > 2 ? atoi(argv[2]) : 256;
+    const int  band = argc > 3 ? atoi(argv[3]) : g;
+    const char *only = argc > 4 ? argv[4] : "";
+    const long m    = (long)g * g;
+    std::vector<int>    rp(m + 1), ci;
+    std::vector<double> v;
+    rp[0] = 0;
+    for(long r = 0; r < m; r++)
+    {
+        if(r - band >= 0) ci.push_back((int)(r - band)), v.push_back(-1.0 - 1e-3 * (r % 7));
+        if(r - 1 >= 0) ci.push_back((int)(r - 1)), v.push_back(-1.0);
+        ci.push_back((int)r), v.push_back(4.0 + 1e-3 * (r % 5));
+        if(r + 1 < m) ci.push_back((int)(r + 1)), v.push_back(-1.0);
+        if(r + band < m) ci.push_back((int)(r + band)), v.push_back(-1.0 + 1e-3 * (r % 3));
+        rp[r + 1] = (int)ci.size();
+    }
+    const long          nnz = ci.size();
+    std::vector<double> B((size_t)m * n);
+    for(size_t q = 0; q < B.size(); q++)
+        B[q] = sin(0.001 * (double)(q % 100003)) + 1e-7 * (double)(q % 1013);
+    int    *d_rp, *d_ci, *d_rows;
+    double *d_v, *d_B, *d_C, *d_s;
+    CHECK(hipMalloc(&d_rp, (m + 1) * 4));
+    CHECK(hipMalloc(&d_ci, nnz * 4));
+    CHECK(hipMalloc(&d_v, nnz * 8));
+    CHECK(hipMalloc(&d_B, B.size() * 8));
+    CHECK(hipMalloc(&d_C, B.size() * 8));
+    CHECK(hipMemcpy(d_rp, rp.data(), (m + 1) * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_ci, ci.data(), nnz * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_v, v.data(), nnz * 8, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_B, B.data(), B.size() * 8, hipMemcpyHostToDevice));
+    // sampled rows for the bitwise check (B is read as row-major [m][n] or column-major [n][m] from the same buffer)
+    std::vector<int> rows;
+    for(long r = 0; r < m; r += 997)
+        rows.push_back((int)r);
+    rows.push_back((int)m - 1);
+    const int nrows = (int)rows.size();
+    CHECK(hipMalloc(&d_rows, nrows * 4));
+    CHECK(hipMalloc(&d_s, (size_t)nrows * n * 8));
+    CHECK(hipMemcpy(d_rows, rows.data(), nrows * 4, hipMemcpyHostToDevice));
+    std::vector<double> ref_r((size_t)nrows * n), ref_c((size_t)nrows * n), got((size_t)nrows * n);
+    for(int q = 0; q < nrows; q++)
+        for(int j = 0; j < n; j++)
+        {
+            double ar = 0, ac = 0;
+            for(int p = rp[rows[q]]; p < rp[rows[q] + 1]; p++)
+            {
+                ar = fma(v[p], B[(size_t)ci[p] * n + j], ar);
+                ac = fma(v[p], B[(size_t)ci[p] + (size_t)j * m], ac);
+            }
+            ref_r[(size_t)q * n + j] = ar, ref_c[(size_t)q * n + j] = ac;
+        }
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    const double abytes = (double)(m + 1 + nnz) * 4 + (double)nnz * 8 + 8.0 * n * 2.0 * m;
+
+    struct Var
+    {
+        std::string name;
+        bool        colmajor;
+        std::function<void()> run;
+    };
+    std::vector<Var> vars;
+    auto rowgrid = [&](int rows_per_wg, int &chunk) {
+        const int nbx = (int)((m + rows_per_wg - 1) / rows_per_wg);
+        chunk         = (nbx + 7) / 8;
+        return chunk * 8;
+    };
+    const int im = (int)m;
+    vars.push_back({"R0 shipped wave/(row,128c)", false, [&] {
+                        if(n < 128) return;
+                        int ch; int gx = rowgrid(4, ch);
+                        r0<<<dim3(gx, (n + 127) / 128), 256>>>(im, d_v, d_ci, d_rp, d_B, n, n, d_C, n, ch);
+                    }});
+#define RSVAR(LANES, R, NB, NT, SLABMAP, label)                                                                     \
+    vars.push_back({label, false, [&] {                                                                              \
+                        constexpr int RPB = (256 / LANES) * R;                                                       \
+                        const int     W = 2 * LANES, S = (n + W - 1) / W;                                            \
+                        if(SLABMAP)                                                                                  \
+                        {                                                                                            \
+                            int S8 = 1;                                                                              \
+                            while(S8 * 2 <= std::min(S, 8)) S8 *= 2;                                                 \
+                            const int P = 8 / S8, nb = (int)((m + RPB - 1) / RPB), nbp = (nb + P - 1) / P;           \
+                            const int passes = (S + S8 - 1) / S8;                                                    \
+                            rs<LANES, R, NB, NT, true><<<dim3(8 * nbp * passes), 256>>>(im, d_v, d_ci, d_rp, d_B, n, n, d_C, n, S8, nbp, 0); \
+                        }                                                                                            \
+                        else                                                                                         \
+                        {                                                                                            \
+                            int ch; int gx = rowgrid(RPB, ch);                                                       \
+                            rs<LANES, R, NB, NT, false><<<dim3(gx, S), 256>>>(im, d_v, d_ci, d_rp, d_B, n, n, d_C, n, 0, 0, ch); \
+                        }                                                                                            \
+                    }});
+    RSVAR(64, 1, 8, false, false, "RS L64 R1 NB8 rowmap")
+    RSVAR(64, 2, 8, false, false, "RS L64 R2 NB8 rowmap")
+    RSVAR(64, 4, 8, false, false, "RS L64 R4 NB8 rowmap")
+    RSVAR(64, 2, 8, true, false, "RS L64 R2 NB8 rowmap nt")
+    RSVAR(64, 1, 8, false, true, "RS L64 R1 NB8 SLAB")
+    RSVAR(64, 2, 8, false, true, "RS L64 R2 NB8 SLAB")
+    RSVAR(32, 1, 8, false, false, "RS L32 R1 NB8 rowmap")
+    RSVAR(32, 2, 8, false, false, "RS L32 R2 NB8 rowmap")
+    RSVAR(32, 1, 8, false, true, "RS L32 R1 NB8 SLAB")
+    RSVAR(32, 2, 8, false, true, "RS L32 R2 NB8 SLAB")
+    RSVAR(32, 4, 8, false, true, "RS L32 R4 NB8 SLAB")
+    RSVAR(32, 2, 8, true, true, "RS L32 R2 NB8 SLAB nt")
+    RSVAR(16, 1, 8, false, false, "RS L16 R1 NB8 rowmap")
+    RSVAR(16, 2, 8, false, false, "RS L16 R2 NB8 rowmap")
+    RSVAR(16, 1, 8, false, true, "RS L16 R1 NB8 SLAB")
+    RSVAR(16, 2, 8, false, true, "RS L16 R2 NB8 SLAB")
+    RSVAR(16, 4, 8, false, true, "RS L16 R4 NB8 SLAB")
+    RSVAR(16, 2, 8, true, true, "RS L16 R2 NB8 SLAB nt")
+    // CSR-Adaptive row blocks (as csrc/matrix.cpp builds them): consecutive rows, <= TILE entries, <= TILE/2 rows
+    auto make_blocks = [&](int tile, std::vector<int2> &blk) {
+        blk.clear();
+        long r = 0;
+        while(r < m)
+        {
+            blk.push_back(make_int2((int)r, rp[r]));
+            long e = r + 1;
+            while(e < m && e - r < std::min(512, tile / 2) && rp[e + 1] - rp[r] <= tile)
+                e++;
+            r = e;
+        }
+        blk.push_back(make_int2((int)m, rp[m]));
+    };
+    std::vector<int2> blk512, blk1024, blk256;
+    make_blocks(512, blk512), make_blocks(1024, blk1024), make_blocks(256, blk256);
+    int2 *d_b512, *d_b1024, *d_b256;
+    CHECK(hipMalloc(&d_b512, blk512.size() * 8));
+    CHECK(hipMalloc(&d_b1024, blk1024.size() * 8));
+    CHECK(hipMalloc(&d_b256, blk256.size() * 8));
+    CHECK(hipMemcpy(d_b512, blk512.data(), blk512.size() * 8, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_b1024, blk1024.data(), blk1024.size() * 8, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_b256, blk256.data(), blk256.size() * 8, hipMemcpyHostToDevice));
+#define TLVAR(LANES, TILE, UR, NB, COLLOOP, NT, label)                                                              \
+    vars.push_back({label, false, [&] {                                                                              \
+                        const int nb = (int)blk##TILE.size() - 1;                                                    \
+                        const int ch = (nb + 7) / 8;                                                                 \
+                        const int gy = COLLOOP ? 1 : (n + 2 * LANES - 1) / (2 * LANES);                              \
+                        tl<LANES, TILE, UR, NB, COLLOOP, NT><<<dim3(ch * 8, gy), 256>>>(im, d_v, d_ci, d_rp, d_b##TILE, nb, d_B, n, n, d_C, n, ch); \
+                    }});
+    TLVAR(64, 1024, 1, 8, false, false, "TL L64 T1024 UR1 NB8 ychunk")
+    TLVAR(64, 1024, 2, 8, false, false, "TL L64 T1024 UR2 NB8 ychunk")
+    TLVAR(64, 1024, 1, 8, true, false, "TL L64 T1024 UR1 NB8 colloop")
+    TLVAR(64, 1024, 2, 8, true, false, "TL L64 T1024 UR2 NB8 colloop")
+    TLVAR(64, 512, 1, 8, false, false, "TL L64 T512 UR1 NB8 ychunk")
+    TLVAR(64, 512, 2, 8, false, false, "TL L64 T512 UR2 NB8 ychunk")
+    TLVAR(64, 512, 2, 4, false, false, "TL L64 T512 UR2 NB4 ychunk")
+    TLVAR(64, 512, 2, 8, true, false, "TL L64 T512 UR2 NB8 colloop")
+    TLVAR(64, 512, 2, 8, false, true, "TL L64 T512 UR2 NB8 ychunk nt")
+    TLVAR(64, 256, 1, 8, false, false, "TL L64 T256 UR1 NB8 ychunk")
+    TLVAR(64, 256, 2, 8, false, false, "TL L64 T256 UR2 NB8 ychunk")
+    TLVAR(64, 256, 2, 8, true, false, "TL L64 T256 UR2 NB8 colloop")
+    TLVAR(32, 512, 2, 8, false, false, "TL L32 T512 UR2 NB8 ychunk")
+    TLVAR(32, 1024, 2, 8, false, false, "TL L32 T1024 UR2 NB8 ychunk")
+    TLVAR(16, 512, 1, 8, false, false, "TL L16 T512 UR1 NB8 ychunk")
+    TLVAR(16, 512, 2, 8, false, false, "TL L16 T512 UR2 NB8 ychunk")
+    TLVAR(16, 512, 4, 8, false, false, "TL L16 T512 UR4 NB8 ychunk")
+    TLVAR(16, 1024, 2, 8, false, false, "TL L16 T1024 UR2 NB8 ychunk")
+    TLVAR(16, 1024, 4, 8, false, false, "TL L16 T1024 UR4 NB8 ychunk")
+    TLVAR(16, 1024, 2, 8, false, true, "TL L16 T1024 UR2 NB8 ychunk nt")
+    TLVAR(16, 256, 2, 8, false, false, "TL L16 T256 UR2 NB8 ychunk")
+#define RTVAR(TA, TB, label)                                                                                         \
+    vars.push_back({label, false, [&] {                                                                              \
+                        if(n < 128) return;                                                                          \
+                        const int stride = band, wps = (stride + TA - 1) / TA;                                       \
+                        const int nsuper = (int)((m + (long)TB * stride - 1) / ((long)TB * stride));                 \
+                        const int nbx = nsuper * wps, ch = (nbx + 7) / 8;                                            \
+                        rt<TA, TB><<<dim3(ch * 8, (n + 127) / 128), 64 * TA * TB>>>(im, d_v, d_ci, d_rp, d_B, n, n, d_C, n, stride, wps, ch); \
+                    }});
+    RTVAR(4, 1, "RT 4x1 (= R0 shape)")
+    RTVAR(4, 2, "RT 4x2 strided tile")
+    RTVAR(4, 4, "RT 4x4 strided tile")
+    RTVAR(8, 2, "RT 8x2 strided tile")
+    RTVAR(2, 4, "RT 2x4 strided tile")
+    RTVAR(2, 8, "RT 2x8 strided tile")
+    vars.push_back({"C0 shipped lane/row 64c chunks", true, [&] {
+                        int ch; int gx = rowgrid(256, ch);
+                        c0<<<dim3(gx, (n + 63) / 64), 256>>>(im, d_v, d_ci, d_rp, d_B, n, im, d_C, im, ch);
+                    }});
+#define CPVAR(U, RL, SLAB, NT, CC, label)                                                                            \
+    vars.push_back({label, true, [&] {                                                                               \
+                        const int ccv = SLAB ? (n + 7) / 8 : std::min(n, CC);                                        \
+                        if(ccv % U) return;                                                                          \
+                        if(SLAB)                                                                                     \
+                        {                                                                                            \
+                            const int nb = (int)((m + 256 * RL - 1) / (256 * RL));                                   \
+                            cp<U, RL, true, NT><<<dim3(8 * nb), 256>>>(im, d_v, d_ci, d_rp, d_B, n, im, d_C, im, ccv, nb, 0); \
+                        }                                                                                            \
+                        else                                                                                         \
+                        {                                                                                            \
+                            int ch; int gx = rowgrid(256 * RL, ch);                                                  \
+                            cp<U, RL, false, NT><<<dim3(gx, (n + ccv - 1) / ccv), 256>>>(im, d_v, d_ci, d_rp, d_B, n, im, d_C, im, ccv, 0, ch); \
+                        }                                                                                            \
+                    }});
+    CPVAR(4, 1, false, false, 64, "CP U4 RL1 rowmap cc64")
+    CPVAR(4, 1, false, false, 32, "CP U4 RL1 rowmap cc32")
+    CPVAR(4, 1, false, false, 256, "CP U4 RL1 rowmap cc256")
+    CPVAR(2, 1, false, false, 64, "CP U2 RL1 rowmap cc64")
+    CPVAR(8, 1, false, false, 64, "CP U8 RL1 rowmap cc64")
+    CPVAR(2, 2, false, false, 64, "CP U2 RL2 rowmap cc64")
+    CPVAR(4, 2, false, false, 64, "CP U4 RL2 rowmap cc64")
+    CPVAR(1, 4, false, false, 64, "CP U1 RL4 rowmap cc64")
+    CPVAR(4, 1, false, true, 64, "CP U4 RL1 rowmap cc64 nt")
+    CPVAR(4, 1, true, false, 0, "CP U4 RL1 SLAB")
+    CPVAR(2, 2, true, false, 0, "CP U2 RL2 SLAB")
+    CPVAR(4, 2, true, false, 0, "CP U4 RL2 SLAB")
+    CPVAR(1, 4, true, false, 0, "CP U1 RL4 SLAB")
+    CPVAR(4, 1, true, true, 0, "CP U4 RL1 SLAB nt")
+#define DGVAR(MODE, label)                                                                                       \
+    vars.push_back({label, false, [&] {                                                                              \
+                        if(n < 128) return;                                                                          \
+                        int ch; int gx = rowgrid(4, ch);                                                             \
+                        dg<MODE><<<dim3(gx, (n + 127) / 128), 256>>>(im, d_v, d_ci, d_rp, d_B, n, n, d_C, n, ch, band); \
+                    }});
+    DGVAR(1, "diag D1 own B row x5")
+    DGVAR(2, "diag D2 closed-form rows, no A loads")
+    DGVAR(3, "diag D3 closed-form rows + A loads off the chain")
+#define CPAIRVAR(U, NT, CC, label)                                                                                  \
+    vars.push_back({label, true, [&] {                                                                               \
+                        const int ccv = std::min(n, CC);                                                             \
+                        if(ccv % U) return;                                                                          \
+                        int ch; int gx = rowgrid(512, ch);                                                           \
+                        cpair<U, NT><<<dim3(gx, (n + ccv - 1) / ccv), 256>>>(im, d_v, d_ci, d_rp, d_B, n, im, d_C, im, ccv, ch); \
+                    }});
+    CPAIRVAR(1, false, 64, "CPAIR U1 cc64")
+    CPAIRVAR(2, false, 64, "CPAIR U2 cc64")
+    CPAIRVAR(4, false, 64, "CPAIR U4 cc64")
+    CPAIRVAR(2, false, 32, "CPAIR U2 cc32")
+    CPAIRVAR(2, false, 256, "CPAIR U2 cc256")
+    CPAIRVAR(2, true, 64, "CPAIR U2 cc64 nt")
+    CPAIRVAR(4, true, 64, "CPAIR U4 cc64 nt")
+    vars.push_back({"copy simple (1 elem/thread)", false, [&] {
+                        kcopy<<<dim3((unsigned)((B.size() / 2 + 255) / 256)), 256>>>(B.size() / 2, reinterpret_cast<const v2d *>(d_B),
+                                                                                   reinterpret_cast<v2d *>(d_C));
+                    }});
+    vars.push_back({"copy floor (same bytes)", false, [&] {
+                        copy_kernel<<<dim3(256 * 16), 256>>>(reinterpret_cast<const v2d *>(d_B), reinterpret_cast<v2d *>(d_C),
+                                                            B.size() / 2);
+                    }});
+
+    printf("# g=%d m=%ld nnz=%ld n=%d band=%d  algorithmic bytes %.3f GB\n", g, m, nnz, n, band, abytes / 1e9);
+    const int NV = (int)vars.size();
+    std::vector<std::vector<float>> t(NV);
+    std::vector<int>                okv(NV, -1);
+    const int nrep = argc > 5 ? atoi(argv[5]) : 5;
+    for(int rep = 0; rep < nrep; rep++)
+        for(int q = 0; q < NV; q++)
+        {
+            if(only[0])
+            {
+                bool        hit = false;
+                std::string f(only);
+                size_t      a = 0;
+                while(a <= f.size())
+                {
+                    size_t b = f.find(',', a);
+                    if(b == std::string::npos) b = f.size();
+                    if(b > a && vars[q].name.find(f.substr(a, b - a)) != std::string::npos) hit = true;
+                    a = b + 1;
+                }
+                if(!hit) continue;
+            }
+            if(rep == 0)
+            {
+                CHECK(hipMemset(d_C, 0xff, B.size() * 8));
+                vars[q].run();
+                CHECK(hipGetLastError());
+                CHECK(hipDeviceSynchronize());
+                if(vars[q].name.find("copy") == std::string::npos && vars[q].name.find("diag") == std::string::npos)
+                {
+                    sample_rows<<<dim3(nrows, (n + 255) / 256), 256>>>(d_C, vars[q].colmajor ? 1 : n, vars[q].colmajor ? m : 1, n,
+                                                                      d_rows, nrows, d_s);
+                    CHECK(hipMemcpy(got.data(), d_s, got.size() * 8, hipMemcpyDeviceToHost));
+                    okv[q] = !memcmp(got.data(), (vars[q].colmajor ? ref_c : ref_r).data(), got.size() * 8);
+                }
+            }
+            CHECK(hipEventRecord(e0));
+            for(int k = 0; k < 5; k++)
+                vars[q].run();
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            float ms;
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            t[q].push_back(ms / 5);
+        }
+    for(int q = 0; q < NV; q++)
+    {
+        if(t[q].empty())
+            continue;
+        std::sort(t[q].begin(), t[q].end());
+        const double med = t[q][t[q].size() / 2];
+        printf("%-34s %s  min %.4f med %.4f ms  %.2f TB/s  frac %.3f\n", vars[q].name.c_str(),
+               okv[q] < 0 ? "     " : (okv[q] ? "exact" : "WRONG"), t[q][0], med, abytes / med / 1e9, abytes / med / 1e9 / 8.0);
+    }
+    return 0;
+}

@@ -52,12 +52,31 @@ def web_like(n=1000005, seed=202):
     return _to_csr(n, rows, cols, seed + 1)
 
 
+def _block_csr(nb, bs, bcol, ok, seed):
+    """CSR of a block matrix with dense bs x bs blocks, built directly in sorted order: block row i couples to the block
+    columns bcol[i, k] (ascending in k) where ok[i, k]; scalar row bs*i + a holds bs*bcol + b for b = 0..bs-1.
+    Values as _to_csr draws them (same generator calls in the same order, so the matrices are those of the original
+    sort-based construction, bit for bit)."""
+    n = nb * bs
+    cnt = ok.sum(axis=1).astype(np.int64) * bs  # entries per scalar row of block row i
+    row_ptr = np.zeros(n + 1, dtype=np.int64)
+    row_ptr[1:] = np.cumsum(np.repeat(cnt, bs))
+    sel = np.broadcast_to(ok[:, None, :, None], (nb, bs, ok.shape[1], bs))
+    cols = (bcol.astype(np.int32)[:, None, :, None] * np.int32(bs) + np.arange(bs, dtype=np.int32)[None, None, None, :])
+    cols = np.broadcast_to(cols, sel.shape)[sel]
+    rows = np.repeat(np.arange(n, dtype=np.int32), np.diff(row_ptr))
+    rng = np.random.default_rng(seed)
+    val = rng.uniform(-1.0, 1.0, size=len(cols))
+    diag = cols == rows
+    val[diag] = rng.uniform(4.0, 8.0, size=int(diag.sum()))
+    return n, row_ptr.astype(np.int32), cols, val
+
+
 def shell_like(n=1508065, seed=303, width=600):
     """af_shell10-like: n=1,508,065, 5 dofs per node of a structured shell mesh `width` nodes wide; node
     (i, j) couples to (i, j+-1), (i+-1, j) and the (i-1, j-1) / (i+1, j+1) diagonal: 7 dense 5x5 blocks,
     ~35 nnz/row, very uniform.  No coupling across the ends of a mesh row."""
     nb = n // 5
-    n = nb * 5
     bi = np.arange(nb, dtype=np.int64)
     j = bi % width
     offs = np.array([-width - 1, -width, -1, 0, 1, width, width + 1], dtype=np.int64)
@@ -65,11 +84,7 @@ def shell_like(n=1508065, seed=303, width=600):
     bc = bi[:, None] + offs[None, :]
     jj = j[:, None] + dj[None, :]
     ok = (bc >= 0) & (bc < nb) & (jj >= 0) & (jj < width)
-    brow = np.repeat(bi, ok.sum(axis=1))
-    bcol = bc[ok]
-    rows = (brow[:, None, None] * 5 + np.arange(5)[None, :, None] + np.zeros((1, 1, 5), np.int64)).ravel()
-    cols = (bcol[:, None, None] * 5 + np.zeros((1, 5, 1), np.int64) + np.arange(5)[None, None, :]).ravel()
-    return _to_csr(n, rows, cols, seed)
+    return _block_csr(nb, 5, bc, ok, seed)
 
 
 def flan_like(nx=81, ny=80, nz=80, seed=404):
@@ -77,20 +92,17 @@ def flan_like(nx=81, ny=80, nz=80, seed=404):
     nodes = nx * ny * nz
     idx = np.arange(nodes, dtype=np.int64)
     ix, iy, iz = idx // (ny * nz), (idx // nz) % ny, idx % nz
-    rows_l, cols_l = [], []
-    for dx in (-1, 0, 1):
+    bc = np.empty((nodes, 27), dtype=np.int64)
+    ok = np.empty((nodes, 27), dtype=bool)
+    k = 0
+    for dx in (-1, 0, 1):  # ascending neighbour index: dx, then dy, then dz
         for dy in (-1, 0, 1):
             for dz in (-1, 0, 1):
-                ok = ((ix + dx >= 0) & (ix + dx < nx) & (iy + dy >= 0) & (iy + dy < ny)
-                      & (iz + dz >= 0) & (iz + dz < nz))
-                nb = (ix + dx) * (ny * nz) + (iy + dy) * nz + (iz + dz)
-                rows_l.append(idx[ok])
-                cols_l.append(nb[ok])
-    nr = np.concatenate(rows_l)
-    nc = np.concatenate(cols_l)
-    rows = (nr[:, None, None] * 3 + np.arange(3)[None, :, None] + np.zeros((1, 1, 3), np.int64)).ravel()
-    cols = (nc[:, None, None] * 3 + np.zeros((1, 3, 1), np.int64) + np.arange(3)[None, None, :]).ravel()
-    return _to_csr(3 * nodes, rows, cols, seed)
+                ok[:, k] = ((ix + dx >= 0) & (ix + dx < nx) & (iy + dy >= 0) & (iy + dy < ny)
+                            & (iz + dz >= 0) & (iz + dz < nz))
+                bc[:, k] = (ix + dx) * (ny * nz) + (iy + dy) * nz + (iz + dz)
+                k += 1
+    return _block_csr(nodes, 3, bc, ok, seed)
 
 
 ALL = {"circuit-like": circuit_like, "web-like": web_like, "shell-like": shell_like, "flan-like": flan_like}
