@@ -77,19 +77,9 @@ aoclsparse_int count_blocks(aoclsparse_int rows, aoclsparse_int m, aoclsparse_in
     return blocks;
 }
 
-// Block value offsets for DEVICE-resident block arrays are cached on (masks, blk_row_ptr, m, nnz, rows, base),
-// like the row-block plans of the raw csrmv (spmv_api.cpp): the one-shot API has no handle to keep them on.
-// A caller that rewrites the masks in place must use other storage.  Guarded by Runtime::stage_lock.
-struct BlkPlan
-{
-    const void    *masks = nullptr, *ptr = nullptr;
-    aoclsparse_int m = -1, nnz = -1, rows = -1, base = -1, nblk = 0;
-    DeviceBuffer   valoff, part;
-};
-constexpr int BLK_CACHE = 4;
-BlkPlan       g_blk[BLK_CACHE];
-int           g_blk_next = 0;
-
+// The value offset of every block (a running popcount of the masks) is recomputed on every call by three small
+// launches into scratch: a cache keyed on the arrays' device addresses (round 1) could be served stale after the
+// caller freed and re-allocated its arrays, and the raw-array API has no handle to tie an analysis to.
 } // namespace
 
 extern "C" {
@@ -202,31 +192,18 @@ aoclsparse_status aoclsparse_dblkcsrmv(aoclsparse_operation trans, const double 
     MI355_TRY(rt.init());
     std::lock_guard<std::recursive_mutex> sl(rt.stage_lock);
     const aoclsparse_int last = (m - 1) / nRowsblk * nRowsblk; // the last row block's first sub-row holds its range
-    const bool           resident = rt.is_device_pointer(masks) && rt.is_device_pointer(blk_row_ptr);
     aoclsparse_int       nblk = 0;
     const void          *valoff = nullptr;
-    BlkPlan             *hit = nullptr;
-    if(resident)
+    if(rt.is_device_pointer(blk_row_ptr))
     {
-        for(auto &p : g_blk)
-            if(p.masks == masks && p.ptr == blk_row_ptr && p.m == m && p.nnz == nnz && p.rows == nRowsblk && p.base == descr->base)
-                hit = &p;
-        if(hit)
-            nblk = hit->nblk, valoff = hit->valoff.ptr;
+        MI355_HIP_TRY(hipMemcpyAsync(&nblk, blk_row_ptr + last + 1, sizeof(nblk), hipMemcpyDeviceToHost, rt.stream()));
+        MI355_HIP_TRY(hipStreamSynchronize(rt.stream()));
     }
-    if(!hit)
-    {
-        if(rt.is_device_pointer(blk_row_ptr))
-        {
-            MI355_HIP_TRY(hipMemcpyAsync(&nblk, blk_row_ptr + last + 1, sizeof(nblk), hipMemcpyDeviceToHost, rt.stream()));
-            MI355_HIP_TRY(hipStreamSynchronize(rt.stream()));
-        }
-        else
-            nblk = blk_row_ptr[last + 1];
-        nblk -= descr->base;
-        if(nblk < 0)
-            return aoclsparse_status_invalid_value;
-    }
+    else
+        nblk = blk_row_ptr[last + 1];
+    nblk -= descr->base;
+    if(nblk < 0)
+        return aoclsparse_status_invalid_value;
     StagedArg am, av, ac, ap, ax, ay;
     MI355_TRY(am.in(rt, 8, masks, (size_t)nblk * nRowsblk, true));
     MI355_TRY(av.in(rt, 9, blk_csr_val, sizeof(double) * (size_t)nnz, true));
@@ -234,27 +211,13 @@ aoclsparse_status aoclsparse_dblkcsrmv(aoclsparse_operation trans, const double 
     MI355_TRY(ap.in(rt, 11, blk_row_ptr, sizeof(aoclsparse_int) * ((size_t)m + 1), true));
     MI355_TRY(ax.in(rt, 3, x, sizeof(double) * (size_t)n, true));
     MI355_TRY(ay.in(rt, 4, y, sizeof(double) * (size_t)m, *beta != 0.0));
-    if(!hit)
     {
         const size_t nparts = ((size_t)nblk + (1u << BLK_PART_SHIFT) - 1) >> BLK_PART_SHIFT;
         const size_t vbytes = sizeof(aoclsparse_int) * std::max<size_t>(1, (size_t)nblk);
         const size_t pbytes = sizeof(aoclsparse_int) * std::max<size_t>(1, nparts);
         void        *vo = nullptr, *pt = nullptr;
-        if(resident)
-        {
-            BlkPlan &p = g_blk[g_blk_next];
-            g_blk_next = (g_blk_next + 1) % BLK_CACHE;
-            p.masks    = nullptr; // not a valid entry until its buffers are filled
-            MI355_TRY(p.valoff.alloc(vbytes));
-            MI355_TRY(p.part.alloc(pbytes));
-            p.masks = masks, p.ptr = blk_row_ptr, p.m = m, p.nnz = nnz, p.rows = nRowsblk, p.base = descr->base, p.nblk = nblk;
-            vo = p.valoff.ptr, pt = p.part.ptr;
-        }
-        else
-        {
-            MI355_TRY(rt.staging(14, vbytes, &vo));
-            MI355_TRY(rt.staging(15, pbytes, &pt));
-        }
+        MI355_TRY(rt.staging(14, vbytes, &vo));
+        MI355_TRY(rt.staging(15, pbytes, &pt));
         MI355_TRY(launch_blk_valoff(rt.stream(), nblk, (int)nRowsblk, static_cast<const uint8_t *>(am.dev),
                                     static_cast<aoclsparse_int *>(vo), static_cast<aoclsparse_int *>(pt)));
         valoff = vo;

@@ -77,6 +77,61 @@ aoclsparse_status build_mm_groups(const HostCsr &h, SpmvPlan &plan)
     return aoclsparse_status_success;
 }
 
+// Column-major pairs: consecutive rows (i, i+1) of equal length <= the register cache where row i+1's columns are row
+// i's + 1, chosen greedily front to back; every other row is a "single".  The pair kernel is used when at least 80 %
+// of the rows found a partner (singles go through the generic kernel with a row list).  One pass over the host CSR,
+// once per handle.
+aoclsparse_status detect_pairs(const HostCsr &h, SpmvPlan &plan)
+{
+    MmGroups &g = plan.mm;
+    if(g.pairs_tried)
+        return aoclsparse_status_success;
+    g.pairs_tried = true;
+    static const bool off = [] {
+        const char *e = getenv("AOCLSPARSE_MI355_CSRMM_PAIRS");
+        return e && atoi(e) == 0;
+    }();
+    if(off || h.m < 2)
+        return aoclsparse_status_success;
+    std::vector<aoclsparse_int> pf, sg;
+    try
+    {
+        pf.reserve((size_t)h.m / 2 + 1);
+        aoclsparse_int i = 0;
+        while(i < h.m)
+        {
+            bool ok = false;
+            if(i + 1 < h.m)
+            {
+                const aoclsparse_int s = h.ptr[i] - h.base, e = h.ptr[i + 1] - h.base, e2 = h.ptr[i + 2] - h.base;
+                const aoclsparse_int len = e - s;
+                ok = len > 0 && len <= CM_DETOUR_NNZ_PER_ROW && e2 - e == len;
+                for(aoclsparse_int k = 0; k < len && ok; k++)
+                    ok = h.ind[e + k] == h.ind[s + k] + 1;
+            }
+            if(ok)
+                pf.push_back(i), i += 2;
+            else
+                sg.push_back(i), i += 1;
+        }
+    }
+    catch(const std::bad_alloc &)
+    {
+        return aoclsparse_status_memory_error;
+    }
+    if((long long)pf.size() * 2 * 10 < (long long)h.m * 8)
+        return aoclsparse_status_success;
+    hipStream_t       st = Runtime::get().stream();
+    aoclsparse_status rc = g.pair_first.upload(pf.data(), sizeof(aoclsparse_int) * pf.size(), st);
+    if(rc == aoclsparse_status_success && !sg.empty())
+        rc = g.single_rows.upload(sg.data(), sizeof(aoclsparse_int) * sg.size(), st);
+    if(rc != aoclsparse_status_success)
+        return rc;
+    g.npairs = (aoclsparse_int)pf.size(), g.nsingles = (aoclsparse_int)sg.size();
+    g.pairs  = true;
+    return aoclsparse_status_success;
+}
+
 template <typename T>
 aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclsparse_matrix A,
                           const aoclsparse_mat_descr descr, aoclsparse_order order, const T *B,
@@ -200,6 +255,13 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
         if(st != aoclsparse_status_success)
             return st;
     }
+    if(p && colmaj && !detour && !p->mm.pairs_tried)
+    {
+        std::unique_lock<std::shared_mutex> w(A->guard);
+        st = detect_pairs(tr ? *A->trans : A->user, *p);
+        if(st != aoclsparse_status_success)
+            return st;
+    }
     if(detour && !sl.owns_lock())
         sl.lock(); // the scratch slots are shared; taken before the handle's guard, as everywhere else
     {
@@ -224,6 +286,19 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
             if(st == aoclsparse_status_success)
                 st = launch_relayout<T>(rt.stream(), false, static_cast<const T *>(ct), static_cast<T *>(dC), m_c, n, ldc);
         }
+        else if(!colmaj && !grouped && p && p->valid && p->nblocks > 0
+                && csrmm_tiled_applies<T>(n, ldb, ldc, static_cast<const T *>(dB), static_cast<const T *>(dC)))
+            // narrow row-major operands (a multi-GPU column slab): row blocks of the SpMV plan, A staged in LDS
+            st = launch_csrmm_tiled<T>(rt.stream(), d->base, alpha, d->val.as<T>(), d->ind.as<aoclsparse_int>(),
+                                       d->ptr.as<aoclsparse_int>(), p->rowblocks.as<aoclsparse_int>(), p->nblocks, p->tile,
+                                       static_cast<const T *>(dB), n, ldb, beta, static_cast<T *>(dC), ldc);
+        else if(colmaj && p && p->mm.pairs && (long long)ldb * (long long)sizeof(T) < (1LL << 32)
+                && reinterpret_cast<uintptr_t>(dB) % sizeof(T) == 0)
+            // column-major operands, rows paired with a one-column shift: 16-byte loads / stores
+            st = launch_csrmm_colpair<T>(rt.stream(), d->base, alpha, p->mm.npairs, p->mm.pair_first.as<aoclsparse_int>(),
+                                         p->mm.nsingles, p->mm.single_rows.as<aoclsparse_int>(), d->val.as<T>(),
+                                         d->ind.as<aoclsparse_int>(), d->ptr.as<aoclsparse_int>(),
+                                         static_cast<const T *>(dB), n, ldb, beta, static_cast<T *>(dC), ldc);
         else
             st = launch_csrmm<T>(rt.stream(), order, d->base, alpha, d->m, d->n, d->val.as<T>(),
                                  d->ind.as<aoclsparse_int>(), d->ptr.as<aoclsparse_int>(), static_cast<const T *>(dB),

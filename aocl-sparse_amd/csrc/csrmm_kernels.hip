@@ -364,6 +364,126 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup_sub_kernel(int base, T alp
 }
 
 
+// row-major, NARROW B (n < 128 -- the column slab one of several GPUs owns): one workgroup per CSR-Adaptive row block
+// of the handle's SpMV plan (consecutive rows, <= TILE entries).  The block's row_ptr / col_ind / val are fetched with
+// coalesced loads into LDS -- two dependent round trips per BLOCK instead of three per row, and a tenth of the vector
+// memory instructions the row-per-sub-wave kernel spends on A -- then a sub-wave of LANES lanes (2 columns each) walks
+// rows, two rows in flight, eight B-row loads per row and step.  Per output element the FMA chain is the row in CSR
+// order, so the bits are those of every other kernel here.  beta == 0 stores are non-temporal (C is written once and
+// not read again by this launch).  32 columns of the 1000^2 Laplacian: 0.131 ms against 0.195 ms for csrmm_row_kernel
+// (tools/csrmm_r2.hip, profiles/r2/csrmm_experiments.txt).
+template <typename T, int LANES, int TILE>
+__global__ __launch_bounds__(256) void csrmm_tile_kernel(int base, T alpha, const T *__restrict__ val,
+                                                         const aoclsparse_int *__restrict__ col,
+                                                         const aoclsparse_int *__restrict__ row_ptr,
+                                                         const aoclsparse_int *__restrict__ blocks, aoclsparse_int nblocks,
+                                                         const T *__restrict__ B, aoclsparse_int n, aoclsparse_int ldb,
+                                                         T beta, T *__restrict__ C, aoclsparse_int ldc, bool readc,
+                                                         int xcd_chunk)
+{
+    using V               = typename vec2<T>::type;
+    constexpr int MAXR    = 512; // spmv_maxrows(TILE) <= 512
+    constexpr int NSUB    = 256 / LANES;
+    constexpr int UR      = 2; // rows in flight per sub-wave
+    constexpr int NB      = 8; // B-row loads per row and step
+    __shared__ int s_ptr[MAXR + 1];
+    __shared__ int s_col[TILE];
+    __shared__ T   s_val[TILE];
+    const int bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if(bx >= nblocks)
+        return;
+    const int r0 = blocks[2 * bx], s0 = blocks[2 * bx + 1];
+    const int nrows = blocks[2 * bx + 2] - r0, cnt = blocks[2 * bx + 3] - s0;
+    const int tid = threadIdx.x, sub = tid / LANES, lane = tid % LANES;
+    const int j   = 2 * lane + 2 * LANES * (int)blockIdx.y;
+    auto      put = [&](int row, T a0, T a1) {
+        V      *cp = reinterpret_cast<V *>(C + (size_t)row * ldc + j);
+        const T z0 = alpha * a0, z1 = alpha * a1;
+        V       c;
+        if(readc || z0 == T(0) || z1 == T(0))
+        {
+            c   = *cp;
+            c.x = mm_fma(beta, c.x, z0);
+            c.y = mm_fma(beta, c.y, z1);
+            *cp = c;
+        }
+        else
+        {
+            typedef T nt2 __attribute__((ext_vector_type(2))); // native vector: the non-temporal builtin takes no struct
+            nt2 o;
+            o.x = z0, o.y = z1;
+            __builtin_nontemporal_store(o, reinterpret_cast<nt2 *>(cp));
+        }
+    };
+    if(cnt > TILE)
+    {
+        // a single row longer than a tile: straight from global memory, column chunks spread over the sub-waves
+        if(sub == 0 && j < n)
+        {
+            T        a0 = T(0), a1 = T(0);
+            const T *Bj = B + j;
+            for(int p = s0; p < s0 + cnt; p++)
+            {
+                const T a = val[p];
+                const V b = *reinterpret_cast<const V *>(Bj + (size_t)(col[p] - base) * ldb);
+                a0 = mm_fma(a, b.x, a0), a1 = mm_fma(a, b.y, a1);
+            }
+            put(r0, a0, a1);
+        }
+        return;
+    }
+    for(int t = tid; t <= nrows; t += 256)
+        s_ptr[t] = row_ptr[r0 + t] - base - s0;
+    for(int t = tid; t < cnt; t += 256)
+        s_col[t] = col[s0 + t] - base, s_val[t] = val[s0 + t];
+    __syncthreads();
+    if(j >= n)
+        return;
+    const T *Bj = B + j;
+    for(int r = sub; r < nrows; r += NSUB * UR)
+    {
+        int p0[UR], p1[UR];
+        T   a0[UR], a1[UR];
+#pragma unroll
+        for(int q = 0; q < UR; q++)
+        {
+            const int rr = r + q * NSUB;
+            p0[q] = rr < nrows ? s_ptr[rr] : 0, p1[q] = rr < nrows ? s_ptr[rr + 1] : 0;
+            a0[q] = T(0), a1[q] = T(0);
+        }
+        bool more = true;
+        while(more)
+        {
+            V b[UR][NB];
+            T v[UR][NB];
+#pragma unroll
+            for(int q = 0; q < UR; q++)
+#pragma unroll
+                for(int u = 0; u < NB; u++)
+                    if(p0[q] + u < p1[q])
+                    {
+                        v[q][u] = s_val[p0[q] + u];
+                        b[q][u] = *reinterpret_cast<const V *>(Bj + (size_t)s_col[p0[q] + u] * ldb);
+                    }
+            more = false;
+#pragma unroll
+            for(int q = 0; q < UR; q++)
+            {
+#pragma unroll
+                for(int u = 0; u < NB; u++)
+                    if(p0[q] + u < p1[q])
+                        a0[q] = mm_fma(v[q][u], b[q][u].x, a0[q]), a1[q] = mm_fma(v[q][u], b[q][u].y, a1[q]);
+                p0[q] += NB;
+                more |= p0[q] < p1[q];
+            }
+        }
+#pragma unroll
+        for(int q = 0; q < UR; q++)
+            if(r + q * NSUB < nrows)
+                put(r0 + r + q * NSUB, a0[q], a1[q]);
+    }
+}
+
 // column-major: one lane owns one row; the first CM_K entries of the row are kept in registers and the
 // lane sweeps CM_COLS columns, so A is read n/CM_COLS times (once for a 32..64-column shard) and every
 // B / C access is coalesced across the 64 rows of a wavefront.
@@ -377,12 +497,15 @@ __global__ __launch_bounds__(256) void csrmm_col_kernel(int base, T alpha, aocls
                                                         const aoclsparse_int *__restrict__ row_ptr,
                                                         const T *__restrict__ B, aoclsparse_int n,
                                                         aoclsparse_int ldb, T beta, T *__restrict__ C,
-                                                        aoclsparse_int ldc, bool readc, int xcd_chunk)
+                                                        aoclsparse_int ldc, bool readc, int xcd_chunk,
+                                                        const aoclsparse_int *__restrict__ rows)
 {
+    // rows != nullptr: the m entries of `rows` are the rows to compute (the partner-less rows of the pair kernel)
     const int bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const int i  = bx * blockDim.x + threadIdx.x;
-    if(i >= m)
+    const int t  = bx * blockDim.x + threadIdx.x;
+    if(t >= m)
         return;
+    const int i  = rows ? rows[t] : t;
     const int j0 = blockIdx.y * CM_COLS;
     const int j1 = min(n, j0 + CM_COLS);
     const int s = row_ptr[i] - base, e = row_ptr[i + 1] - base;
@@ -444,6 +567,107 @@ __global__ __launch_bounds__(256) void csrmm_col_kernel(int base, T alpha, aocls
         T      *cp = C + (size_t)i + (size_t)j * ldc;
         const T z  = alpha * acc;
         *cp        = (readc || z == T(0)) ? mm_fma(beta, *cp, z) : z;
+    }
+}
+
+// column-major, PAIRED rows: a lane owns rows (i, i+1) taken from a list built once per handle (csrmm_api.cpp:
+// detect_pairs): row i+1 carries row i's pattern shifted by one column (5-point and other scalar stencils, banded
+// matrices) and both fit the register cache.  Entry k of both rows then reads B[c_k] and B[c_k + 1] of a column: ONE
+// 16-byte load (8-byte aligned, which gfx950 serves) feeds both rows and the two results leave as one 16-byte store --
+// half the vector-memory instructions of csrmm_col_kernel, which is what bounds that kernel (1.02 vs 1.30 ms at 256
+// columns of a 1M-row 5-diagonal matrix, tools/csrmm_r2.hip).  Per output element the FMA chain is unchanged.  Rows that
+// found no partner are served by csrmm_col_kernel through a row list in a second launch.
+constexpr int CP_U = 4; // columns per step
+
+template <typename T>
+__global__ __launch_bounds__(256) void csrmm_colpair_kernel(int base, T alpha, aoclsparse_int npairs,
+                                                            const aoclsparse_int *__restrict__ pair_first,
+                                                            const T *__restrict__ val,
+                                                            const aoclsparse_int *__restrict__ col,
+                                                            const aoclsparse_int *__restrict__ row_ptr,
+                                                            const T *__restrict__ B, aoclsparse_int n, aoclsparse_int ldb,
+                                                            T beta, T *__restrict__ C, aoclsparse_int ldc, bool readc,
+                                                            bool c_aligned, int xcd_chunk)
+{
+    typedef T v2 __attribute__((ext_vector_type(2)));
+    const int bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int t  = bx * 256 + (int)threadIdx.x;
+    if(t >= npairs)
+        return;
+    const int i  = pair_first[t];
+    const int j0 = blockIdx.y * CM_COLS, j1 = min(n, j0 + CM_COLS);
+    const int s = row_ptr[i] - base, e = row_ptr[i + 1] - base;
+    const int len = e - s; // 1 .. CM_K, and row i+1 has the same length (detect_pairs)
+    T         v0[CM_K], v1[CM_K];
+    unsigned  off[CM_K]; // byte offset of B[c_k] inside a column (columns < 4 GB: checked by the host)
+#pragma unroll
+    for(int k = 0; k < CM_K; k++)
+    {
+        v0[k] = T(0), v1[k] = T(0), off[k] = 0;
+        if(k < len)
+            v0[k] = val[s + k], v1[k] = val[e + k], off[k] = (unsigned)(col[s + k] - base) * (unsigned)sizeof(T);
+    }
+    const bool vec_store = c_aligned && (i % 2 == 0);
+    auto       put       = [&](T *cp, T a0, T a1) {
+        const T z0 = alpha * a0, z1 = alpha * a1;
+        if((readc || z0 == T(0) || z1 == T(0)) && vec_store)
+        {
+            v2 c = *reinterpret_cast<const v2 *>(cp);
+            c.x  = mm_fma(beta, c.x, z0);
+            c.y  = mm_fma(beta, c.y, z1);
+            *reinterpret_cast<v2 *>(cp) = c;
+        }
+        else if(readc || z0 == T(0) || z1 == T(0))
+        {
+            cp[0] = mm_fma(beta, cp[0], z0);
+            cp[1] = mm_fma(beta, cp[1], z1);
+        }
+        else if(vec_store)
+        {
+            v2 o;
+            o.x = z0, o.y = z1;
+            __builtin_nontemporal_store(o, reinterpret_cast<v2 *>(cp));
+        }
+        else
+            cp[0] = z0, cp[1] = z1;
+    };
+    int j = j0;
+    for(; j + CP_U <= j1; j += CP_U)
+    {
+        v2 b[CP_U][CM_K];
+#pragma unroll
+        for(int u = 0; u < CP_U; u++)
+        {
+            const char *Bu = reinterpret_cast<const char *>(B + (size_t)(j + u) * ldb);
+#pragma unroll
+            for(int k = 0; k < CM_K; k++)
+                if(k < len)
+                    __builtin_memcpy(&b[u][k], Bu + off[k], sizeof(v2));
+        }
+#pragma unroll
+        for(int u = 0; u < CP_U; u++)
+        {
+            T a0 = T(0), a1 = T(0);
+#pragma unroll
+            for(int k = 0; k < CM_K; k++)
+                if(k < len)
+                    a0 = mm_fma(v0[k], b[u][k].x, a0), a1 = mm_fma(v1[k], b[u][k].y, a1);
+            put(C + (size_t)i + (size_t)(j + u) * ldc, a0, a1);
+        }
+    }
+    for(; j < j1; j++)
+    {
+        const char *Bu = reinterpret_cast<const char *>(B + (size_t)j * ldb);
+        T           a0 = T(0), a1 = T(0);
+#pragma unroll
+        for(int k = 0; k < CM_K; k++)
+            if(k < len)
+            {
+                v2 b;
+                __builtin_memcpy(&b, Bu + off[k], sizeof(v2));
+                a0 = mm_fma(v0[k], b.x, a0), a1 = mm_fma(v1[k], b.y, a1);
+            }
+        put(C + (size_t)i + (size_t)j * ldc, a0, a1);
     }
 }
 
@@ -585,7 +809,7 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
         const int gx = grid_x((m + 255) / 256, chunk);
         dim3      block(256), grid(gx, (n + CM_COLS - 1) / CM_COLS);
         hipLaunchKernelGGL((csrmm_col_kernel<T>), grid, block, 0, s, base, alpha, m, val, col, row_ptr, B, n, ldb,
-                           beta, C, ldc, readc, chunk);
+                           beta, C, ldc, readc, chunk, (const aoclsparse_int *)nullptr);
     }
     MI355_HIP_TRY(hipGetLastError());
     return aoclsparse_status_success;
@@ -627,6 +851,81 @@ aoclsparse_status launch_relayout(hipStream_t s, bool to_row_major, const T *src
     return aoclsparse_status_success;
 }
 
+// Row-major product over the row blocks of an SpMV plan (csrmm_tile_kernel): vec-able operands with n < 128 only.
+template <typename T>
+bool csrmm_tiled_applies(aoclsparse_int n, aoclsparse_int ldb, aoclsparse_int ldc, const T *B, const T *C)
+{
+    static const bool off = [] {
+        const char *e = getenv("AOCLSPARSE_MI355_CSRMM_TILED");
+        return e && atoi(e) == 0;
+    }();
+    return !off && n >= 2 && n < 128 && (n % 2 == 0) && (ldb % 2 == 0) && (ldc % 2 == 0)
+           && (reinterpret_cast<uintptr_t>(B) % (2 * sizeof(T)) == 0) && (reinterpret_cast<uintptr_t>(C) % (2 * sizeof(T)) == 0);
+}
+
+template <typename T>
+aoclsparse_status launch_csrmm_tiled(hipStream_t s, int base, T alpha, const T *val, const aoclsparse_int *col,
+                                     const aoclsparse_int *row_ptr, const aoclsparse_int *blocks, aoclsparse_int nblocks,
+                                     int tile, const T *B, aoclsparse_int n, aoclsparse_int ldb, T beta, T *C,
+                                     aoclsparse_int ldc)
+{
+    if(nblocks <= 0 || n <= 0)
+        return aoclsparse_status_success;
+    static const bool strict_beta0 = [] {
+        const char *e = getenv("AOCLSPARSE_MI355_CSRMM_STRICT_BETA0");
+        return e && atoi(e) != 0;
+    }();
+    const bool readc = beta != T(0) || strict_beta0;
+    const int  chunk = (nblocks + 7) / 8; // XCD-contiguous block order, as the other csrmm kernels
+    auto       go    = [&](auto lanes_tag, auto tile_tag) {
+        constexpr int LANES = decltype(lanes_tag)::value, TILE = decltype(tile_tag)::value;
+        hipLaunchKernelGGL((csrmm_tile_kernel<T, LANES, TILE>), dim3(chunk * 8, (n + 2 * LANES - 1) / (2 * LANES)), dim3(256),
+                           0, s, base, alpha, val, col, row_ptr, blocks, nblocks, B, n, ldb, beta, C, ldc, readc, chunk);
+    };
+    using L16 = std::integral_constant<int, 16>;
+    switch(tile & ~1)
+    {
+    case 512: go(L16{}, std::integral_constant<int, 512>{}); break;
+    case 1024: go(L16{}, std::integral_constant<int, 1024>{}); break;
+    case 2048: go(L16{}, std::integral_constant<int, 2048>{}); break;
+    default: return aoclsparse_status_internal_error;
+    }
+    MI355_HIP_TRY(hipGetLastError());
+    return aoclsparse_status_success;
+}
+
+template <typename T>
+aoclsparse_status launch_csrmm_colpair(hipStream_t s, int base, T alpha, aoclsparse_int npairs,
+                                       const aoclsparse_int *pair_first, aoclsparse_int nsingles,
+                                       const aoclsparse_int *single_rows, const T *val, const aoclsparse_int *col,
+                                       const aoclsparse_int *row_ptr, const T *B, aoclsparse_int n, aoclsparse_int ldb,
+                                       T beta, T *C, aoclsparse_int ldc)
+{
+    if(n <= 0)
+        return aoclsparse_status_success;
+    static const bool strict_beta0 = [] {
+        const char *e = getenv("AOCLSPARSE_MI355_CSRMM_STRICT_BETA0");
+        return e && atoi(e) != 0;
+    }();
+    const bool readc     = beta != T(0) || strict_beta0;
+    const bool c_aligned = reinterpret_cast<uintptr_t>(C) % (2 * sizeof(T)) == 0 && ldc % 2 == 0;
+    const dim3 block(256);
+    if(npairs > 0)
+    {
+        const int nbx = (npairs + 255) / 256, chunk = (nbx + 7) / 8;
+        hipLaunchKernelGGL((csrmm_colpair_kernel<T>), dim3(chunk * 8, (n + CM_COLS - 1) / CM_COLS), block, 0, s, base, alpha,
+                           npairs, pair_first, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, c_aligned, chunk);
+    }
+    if(nsingles > 0)
+    {
+        const int nbx = (nsingles + 255) / 256, chunk = (nbx + 7) / 8;
+        hipLaunchKernelGGL((csrmm_col_kernel<T>), dim3(chunk * 8, (n + CM_COLS - 1) / CM_COLS), block, 0, s, base, alpha,
+                           nsingles, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk, single_rows);
+    }
+    MI355_HIP_TRY(hipGetLastError());
+    return aoclsparse_status_success;
+}
+
 #define MI355_INST_MM(T)                                                                                     \
     template aoclsparse_status launch_csrmm<T>(hipStream_t, aoclsparse_order, int, T, aoclsparse_int,        \
                                                aoclsparse_int, const T *, const aoclsparse_int *,             \
@@ -636,7 +935,16 @@ aoclsparse_status launch_relayout(hipStream_t s, bool to_row_major, const T *src
     template aoclsparse_status launch_scale_dense<T>(hipStream_t, aoclsparse_order, T *, aoclsparse_int,     \
                                                      aoclsparse_int, aoclsparse_int, T);                     \
     template aoclsparse_status launch_relayout<T>(hipStream_t, bool, const T *, T *, aoclsparse_int,         \
-                                                  aoclsparse_int, aoclsparse_int);
+                                                  aoclsparse_int, aoclsparse_int);                            \
+    template aoclsparse_status launch_csrmm_colpair<T>(hipStream_t, int, T, aoclsparse_int, const aoclsparse_int *, \
+                                                       aoclsparse_int, const aoclsparse_int *, const T *,      \
+                                                       const aoclsparse_int *, const aoclsparse_int *, const T *, \
+                                                       aoclsparse_int, aoclsparse_int, T, T *, aoclsparse_int); \
+    template bool csrmm_tiled_applies<T>(aoclsparse_int, aoclsparse_int, aoclsparse_int, const T *, const T *); \
+    template aoclsparse_status launch_csrmm_tiled<T>(hipStream_t, int, T, const T *, const aoclsparse_int *,   \
+                                                     const aoclsparse_int *, const aoclsparse_int *,          \
+                                                     aoclsparse_int, int, const T *, aoclsparse_int,          \
+                                                     aoclsparse_int, T, T *, aoclsparse_int);
 MI355_INST_MM(double)
 MI355_INST_MM(float)
 

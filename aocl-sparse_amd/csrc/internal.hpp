@@ -182,6 +182,11 @@ struct MmGroups
     int            max_rows = 0; // rows of the largest group
     DeviceBuffer   first; // ngroups + 1 row indices
     bool           valid = false, tried = false;
+    // column-major csrmm: row pairs (2r, 2r+1) where row 2r+1 carries row 2r's pattern shifted by one column (scalar
+    // stencils, banded matrices) and both fit the register cache -- csrmm_colpair_kernel serves them with 16-byte loads
+    bool           pairs_tried = false, pairs = false;
+    aoclsparse_int npairs = 0, nsingles = 0;
+    DeviceBuffer   pair_first, single_rows; // first row of every pair; rows without a partner
 };
 
 // merge-path tiling of a device CSR (mergepath_kernels.hip): tile w starts at {row ends, non-zeros} =
@@ -230,6 +235,10 @@ struct TrsvPlan
     std::vector<TrsvSegment>    segments; // hybrid schedule
     DeviceBuffer                rowmap, levels; // device: m rows in level order; level_ptr copy
     DeviceBuffer                pptr, pind, pval; // device: level-ordered strict triangle; pind = positions
+    // level slices for trsv_slice_kernel: slice w = positions [slices[w], slices[w+1]), <= 64 of them, never across a
+    // level boundary (so the lanes of a wavefront are independent of each other)
+    aoclsparse_int              nslices = 0;
+    DeviceBuffer                slices;
     bool                        valid = false;
 };
 
@@ -338,10 +347,24 @@ public:
     char name[256] = {0};
     // scratch staging buffers for host-pointer calls (grown on demand, reused)
     aoclsparse_status staging(int slot, size_t bytes, void **out);
+    // Host <-> device copies of PAGEABLE caller memory on the library's stream.  Large transfers are pipelined through
+    // a ring of pinned buffers: worker threads copy chunk i+1 into pinned memory while the DMA engine moves chunk i, so
+    // the link runs near its rate instead of the ~20 GB/s of a plain pageable hipMemcpy (runtime.cpp).  h2d returns once
+    // every chunk is enqueued (stream order holds for what follows); d2h returns when the bytes are in `host`.
+    aoclsparse_status h2d(void *dev, const void *host, size_t bytes);
+    aoclsparse_status d2h(void *host, const void *dev, size_t bytes);
     hipEvent_t        ev0 = nullptr, ev1 = nullptr;
     // per-iteration timing: a ring of events recorded by aoclsparse_mi355_timer_mark (runtime.cpp)
     std::vector<hipEvent_t> marks;
     size_t                  marks_used = 0;
+    // sync-free TRSV: one word of pinned, device-mapped host memory a kernel sets when a wait expires.  The host reads
+    // it without a device round trip: right after the stream sync of a host-pointer solve, and at the START of the next
+    // solve for device-pointer callers (which therefore stay asynchronous).
+    volatile unsigned int *trsv_timeout_host = nullptr;
+    unsigned int          *trsv_timeout_dev  = nullptr;
+    // second word of the same pinned line: "cached raw-csrmv plan does not match this row_ptr" (spmv_api.cpp)
+    volatile unsigned int *plan_stale_host = nullptr;
+    unsigned int          *plan_stale_dev  = nullptr;
     std::mutex        lock;
     std::recursive_mutex stage_lock; // serialises calls that stage host buffers
 
@@ -383,13 +406,13 @@ struct StagedArg
         if(st != aoclsparse_status_success)
             return st;
         if(copy && nbytes)
-            MI355_HIP_TRY(hipMemcpyAsync(dev, p, nbytes, hipMemcpyHostToDevice, rt.stream()));
+            return rt.h2d(dev, p, nbytes); // pipelined through pinned memory when large
         return aoclsparse_status_success;
     }
     aoclsparse_status out(Runtime &rt)
     {
         if(staged && bytes)
-            MI355_HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, rt.stream()));
+            return rt.d2h(host, dev, bytes);
         return aoclsparse_status_success;
     }
 };
@@ -444,6 +467,10 @@ aoclsparse_status launch_csrmv(hipStream_t s, int order, bool strict, int tile, 
                                aoclsparse_int m, const T *val, const aoclsparse_int *col,
                                const aoclsparse_int *row_ptr, const aoclsparse_int *blocks,
                                aoclsparse_int nblocks, const T *x, T beta, T *y);
+// raw-array csrmv: is a cached plan still the plan of this row_ptr?  (*stale: pinned host word, set on mismatch)
+aoclsparse_status launch_plan_check(hipStream_t s, const aoclsparse_int *blocks, aoclsparse_int nblocks,
+                                    const aoclsparse_int *row_ptr, int base, aoclsparse_int m, aoclsparse_int nnz,
+                                    unsigned int *stale);
 template <typename T>
 aoclsparse_status launch_sell_fill(hipStream_t s, int pack, aoclsparse_int m, int base, const aoclsparse_int *row_ptr,
                                    const aoclsparse_int *col, const T *val, aoclsparse_int nslices,
@@ -549,13 +576,15 @@ aoclsparse_status launch_lincomb(hipStream_t s, int sign, aoclsparse_int n, int 
                                  long long ld, T *w);
 
 // TRSV on the level-ordered layout (trsv_kernels.hip).
-// schedule 0: one launch per level; 1: hybrid (narrow level runs inside one workgroup); 2: sync-free.
+// schedule 0: one launch per level; 1: hybrid (narrow level runs inside one workgroup); 2: sync-free, a lane per
+// position; 3: sync-free, a level slice per wavefront (single right-hand side; falls back to 2 otherwise).
+// timeout_word: where a sync-free kernel reports an expired wait (pinned host memory, Runtime::trsv_timeout_dev).
 constexpr int TRSV_NARROW = 1024; // a level this narrow is solved by one workgroup (one row per lane)
 template <typename T>
 aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, aoclsparse_int m,
                               const TrsvPlan &plan, const T *diag, const T *b, T *x, T *xp,
                               unsigned int *scratch, aoclsparse_int nrhs, long long b_off, aoclsparse_int incb,
-                              long long x_off, aoclsparse_int incx);
+                              long long x_off, aoclsparse_int incx, unsigned int *timeout_word = nullptr);
 
 template <typename R>
 aoclsparse_status launch_cvec_mul(hipStream_t s, aoclsparse_int n, const cplx<R> *d, cplx<R> *y);
@@ -589,6 +618,21 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
                                aoclsparse_int n, aoclsparse_int ldb, T beta, T *C,
                                aoclsparse_int ldc, const aoclsparse_int *grp = nullptr, aoclsparse_int ngroups = 0,
                                int group_rows = 0);
+// row-major, n < 128: workgroup per row block of the handle's SpMV plan, A staged in LDS (csrmm_tile_kernel)
+template <typename T>
+bool csrmm_tiled_applies(aoclsparse_int n, aoclsparse_int ldb, aoclsparse_int ldc, const T *B, const T *C);
+template <typename T>
+aoclsparse_status launch_csrmm_tiled(hipStream_t s, int base, T alpha, const T *val, const aoclsparse_int *col,
+                                     const aoclsparse_int *row_ptr, const aoclsparse_int *blocks, aoclsparse_int nblocks,
+                                     int tile, const T *B, aoclsparse_int n, aoclsparse_int ldb, T beta, T *C,
+                                     aoclsparse_int ldc);
+// column-major: a lane owns a row PAIR; 16-byte loads where the second row is the first shifted by one column
+template <typename T>
+aoclsparse_status launch_csrmm_colpair(hipStream_t s, int base, T alpha, aoclsparse_int npairs,
+                                       const aoclsparse_int *pair_first, aoclsparse_int nsingles,
+                                       const aoclsparse_int *single_rows, const T *val, const aoclsparse_int *col,
+                                       const aoclsparse_int *row_ptr, const T *B, aoclsparse_int n, aoclsparse_int ldb,
+                                       T beta, T *C, aoclsparse_int ldc);
 template <typename T>
 aoclsparse_status launch_relayout(hipStream_t s, bool to_row_major, const T *src, T *dst, aoclsparse_int R, aoclsparse_int N,
                                   aoclsparse_int ld);

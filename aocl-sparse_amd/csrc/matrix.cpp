@@ -885,6 +885,8 @@ aoclsparse_status aoclsparse_mi355_invalidate(aoclsparse_matrix A)
     A->plan_trans.merge.valid = A->plan_trans.merge.tried = false;
     A->plan_user.mm.valid = A->plan_user.mm.tried = false;
     A->plan_trans.mm.valid = A->plan_trans.mm.tried = false;
+    A->plan_user.mm.pairs = A->plan_user.mm.pairs_tried = false;
+    A->plan_trans.mm.pairs = A->plan_trans.mm.pairs_tried = false;
     for(auto &p : A->trsv_plan)
         p.valid = false, p.nlevels = -1;
     A->trans.reset();

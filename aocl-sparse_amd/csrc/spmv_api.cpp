@@ -35,13 +35,13 @@ struct Arg
         if(st != aoclsparse_status_success)
             return st;
         if(copy && nbytes)
-            MI355_HIP_TRY(hipMemcpyAsync(dev, p, nbytes, hipMemcpyHostToDevice, rt.stream()));
+            return rt.h2d(dev, p, nbytes); // pipelined through pinned memory when large
         return aoclsparse_status_success;
     }
     aoclsparse_status out(Runtime &rt)
     {
         if(staged && bytes)
-            MI355_HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, rt.stream()));
+            return rt.d2h(host, dev, bytes);
         return aoclsparse_status_success;
     }
 };
@@ -240,12 +240,16 @@ aoclsparse_status mv_t(aoclsparse_operation op, const T *alpha, aoclsparse_matri
 
 // ---- raw-array path --------------------------------------------------------------------------------
 // Plans for device-resident raw arrays are cached on (row_ptr address, m, nnz, base): the one-shot
-// API has no handle to hang an analysis on ("raw csrmv").
+// API has no handle to hang an analysis on ("raw csrmv").  The key says nothing about the CONTENTS (a
+// caller may free its arrays and get the same address back for another matrix of the same size), so every hit is
+// validated on the device against the live row_ptr before it is used (plan_check_kernel: all block boundaries), and
+// rebuilt when it does not match.  A plan is handed out as a shared_ptr copied under the lock, so a concurrent call
+// that evicts the slot cannot free or rewrite a plan that is still in use.
 struct RawPlan
 {
-    const void    *key = nullptr;
-    aoclsparse_int m = -1, nnz = -1, base = -1;
-    SpmvPlan       plan;
+    const void               *key = nullptr;
+    aoclsparse_int            m = -1, nnz = -1, base = -1;
+    std::shared_ptr<SpmvPlan> plan;
 };
 constexpr int RAW_CACHE = 8;
 RawPlan       g_raw[RAW_CACHE];
@@ -417,31 +421,58 @@ aoclsparse_status csrmv_t(aoclsparse_operation trans, const T *alpha, aoclsparse
     if(st != aoclsparse_status_success)
         return st;
 
-    SpmvPlan  local;
-    SpmvPlan *plan = &local;
+    SpmvPlan                  local;
+    SpmvPlan                 *plan = &local;
+    std::shared_ptr<SpmvPlan> held; // keeps a cached plan alive for this call whatever other threads evict
     try
     {
         if(mdev)
         {
-            std::lock_guard<std::mutex> g(rt.lock);
-            RawPlan                    *hit = nullptr;
-            for(auto &e : g_raw)
-                if(e.key == row && e.m == m && e.nnz == nnz && e.base == descr->base && e.plan.valid)
-                    hit = &e;
-            if(!hit)
+            {
+                std::lock_guard<std::mutex> g(rt.lock);
+                for(auto &e : g_raw)
+                    if(e.key == row && e.m == m && e.nnz == nnz && e.base == descr->base && e.plan && e.plan->valid)
+                        held = e.plan;
+            }
+            if(held && rt.plan_stale_dev)
+            {
+                // is it still the plan of THIS row_ptr?  (tiny kernel + one pinned word; costs a stream round trip,
+                // which is the price of a stateless API on device-resident arrays -- handles have no such check)
+                std::lock_guard<std::recursive_mutex> sl(rt.stage_lock);
+                *rt.plan_stale_host = 0;
+                st = launch_plan_check(rt.stream(), held->rowblocks.as<aoclsparse_int>(), held->nblocks, row, descr->base, m,
+                                       nnz, rt.plan_stale_dev);
+                if(st != aoclsparse_status_success)
+                    return st;
+                MI355_HIP_TRY(hipStreamSynchronize(rt.stream()));
+                if(*rt.plan_stale_host)
+                    held.reset();
+            }
+            else if(held)
+                held.reset(); // no pinned word to validate with: never trust the cache
+            if(!held)
             {
                 std::vector<aoclsparse_int> hrow((size_t)m + 1);
                 MI355_HIP_TRY(hipMemcpy(hrow.data(), row, sizeof(aoclsparse_int) * ((size_t)m + 1),
                                         hipMemcpyDeviceToHost));
-                hit             = &g_raw[g_raw_next];
-                g_raw_next      = (g_raw_next + 1) % RAW_CACHE;
-                hit->plan.valid = false;
-                st              = build_spmv_plan(m, nnz, descr->base, hrow.data(), hit->plan);
+                held = std::make_shared<SpmvPlan>();
+                st   = build_spmv_plan(m, nnz, descr->base, hrow.data(), *held);
                 if(st != aoclsparse_status_success)
                     return st;
-                hit->key = row, hit->m = m, hit->nnz = nnz, hit->base = descr->base;
+                std::lock_guard<std::mutex> g(rt.lock);
+                RawPlan                    *slot = nullptr;
+                for(auto &e : g_raw) // replace a stale entry of the same key in place, else round robin
+                    if(e.key == row && e.m == m && e.nnz == nnz && e.base == descr->base)
+                        slot = &e;
+                if(!slot)
+                {
+                    slot       = &g_raw[g_raw_next];
+                    g_raw_next = (g_raw_next + 1) % RAW_CACHE;
+                }
+                slot->plan = held;
+                slot->key = row, slot->m = m, slot->nnz = nnz, slot->base = descr->base;
             }
-            plan = &hit->plan;
+            plan = held.get();
         }
         else
         {

@@ -475,6 +475,33 @@ aoclsparse_status launch_csrmv(hipStream_t s, int order, bool strict, int tile, 
     return aoclsparse_status_success;
 }
 
+// Validation of a cached row-block plan against the LIVE row_ptr of a raw-array call (spmv_api.cpp): the kernels rely
+// on exactly one thing from the plan -- that block b starts at row blocks[b].x with its first non-zero at blocks[b].y --
+// so checking every boundary (and the total) is a complete test.  *stale (pinned host memory) is set on any mismatch.
+__global__ void plan_check_kernel(const int2 *__restrict__ blocks, aoclsparse_int nblocks, const aoclsparse_int *__restrict__ row_ptr,
+                                  int base, aoclsparse_int m, aoclsparse_int nnz, unsigned int *stale)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if(b > nblocks)
+        return;
+    const int2 e = blocks[b];
+    bool       bad = e.x < 0 || e.x > m || row_ptr[e.x] - base != e.y;
+    if(b == nblocks)
+        bad = bad || e.x != m || e.y != nnz;
+    if(bad)
+        __hip_atomic_store(stale, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+aoclsparse_status launch_plan_check(hipStream_t s, const aoclsparse_int *blocks, aoclsparse_int nblocks,
+                                    const aoclsparse_int *row_ptr, int base, aoclsparse_int m, aoclsparse_int nnz,
+                                    unsigned int *stale)
+{
+    hipLaunchKernelGGL(plan_check_kernel, dim3((nblocks + 256) / 256), dim3(256), 0, s, reinterpret_cast<const int2 *>(blocks),
+                       nblocks, row_ptr, base, m, nnz, stale);
+    MI355_HIP_TRY(hipGetLastError());
+    return aoclsparse_status_success;
+}
+
 template <typename T>
 __global__ void waxpby_kernel(aoclsparse_int n, T a, const T *x, T b, const T *y, T *w)
 {

@@ -6,6 +6,8 @@
 // or lazily on the first solve, mirroring the reference's lazy aoclsparse_csr_csc_optimize (:128).
 #include "internal.hpp"
 
+#include <cstdlib>
+
 #include <algorithm>
 #include <cstring>
 #include <type_traits>
@@ -124,6 +126,14 @@ static aoclsparse_status build_levels(aoclsparse_int m, const Triangle<T> &t, Tr
             pind[pptr[k] + j] = pos[t.ind[t.ptr[i] + j]];
         std::copy(t.val.begin() + t.ptr[i], t.val.begin() + t.ptr[i + 1], pval.begin() + pptr[k]);
     }
+    // level slices (<= 64 positions, inside one level) for the slice-per-wavefront sync-free kernel
+    std::vector<aoclsparse_int> slices;
+    slices.reserve((size_t)m / 48 + (size_t)nlev + 2);
+    for(aoclsparse_int l = 0; l < nlev; l++)
+        for(aoclsparse_int k = plan.level_ptr[l]; k < plan.level_ptr[l + 1]; k += 64)
+            slices.push_back(k);
+    slices.push_back(m);
+    plan.nslices = (aoclsparse_int)slices.size() - 1;
     // hybrid schedule
     plan.segments.clear();
     plan.launches = 0;
@@ -148,6 +158,8 @@ static aoclsparse_status build_levels(aoclsparse_int m, const Triangle<T> &t, Tr
         rc = plan.pind.upload(pind.data(), sizeof(aoclsparse_int) * pind.size(), st);
     if(rc == aoclsparse_status_success)
         rc = plan.pval.upload(pval.data(), sizeof(T) * pval.size(), st);
+    if(rc == aoclsparse_status_success)
+        rc = plan.slices.upload(slices.data(), sizeof(aoclsparse_int) * slices.size(), st);
     return rc;
 }
 
@@ -251,7 +263,26 @@ aoclsparse_status solve_core(aoclsparse_operation trans, T alpha, aoclsparse_mat
     // levels is cheapest as plain launches; otherwise sync-free, which measured fastest on both the
     // 2-D Laplacian and the shell-like ILU(0) factors (profiles/r1).
     // (complex handles always run the hybrid schedule: their 8 / 16-byte x cannot be the one-word ready flag)
-    const int schedule = is_cplx ? 1 : kid == 0 ? 0 : (kid == 3 ? 2 : (kid > 0 ? 1 : (plan.nlevels <= 32 ? 0 : 2)));
+    // The sync-free choice is the slice-per-wavefront kernel (3) for one right-hand side -- unless the level slices
+    // would leave most lanes idle (average level narrower than 16 rows: deep chains), where the lane-per-position
+    // kernel (2) packs better; AOCLSPARSE_MI355_TRSV_SYNCFREE=2|3 forces one of them.
+    static const int sf_env = [] {
+        const char *e = getenv("AOCLSPARSE_MI355_TRSV_SYNCFREE");
+        return e ? atoi(e) : 0;
+    }();
+    // measured (profiles/r2/trsv_schedules.txt): the slice kernel wins on short rows (ILU(0) of the 2-D Laplacian:
+    // 1.69 vs 2.09 ms), the lane-per-position kernel on rows of ~17 entries (shell-like factor)
+    const int sf = (sf_env == 2 || sf_env == 3) ? sf_env
+                   : (nrhs == 1 && plan.nslices > 0 && (long long)plan.nslices * 16 <= (long long)m
+                      && (long long)plan.nnz_tri <= 10LL * m) ? 3 : 2;
+    const int schedule = is_cplx ? 1 : kid == 0 ? 0 : (kid == 3 ? sf : (kid > 0 ? 1 : (plan.nlevels <= 32 ? 0 : sf)));
+    // a wait that expired in an EARLIER asynchronous (device-pointer) solve is reported now
+    if(rt.trsv_timeout_host && *rt.trsv_timeout_host)
+    {
+        (void)hipStreamSynchronize(rt.stream());
+        *rt.trsv_timeout_host = 0;
+        return aoclsparse_status_internal_error;
+    }
 
     st = A->trsv_xp.alloc(sizeof(T) * (size_t)m * (size_t)nrhs);
     if(st == aoclsparse_status_success)
@@ -285,17 +316,20 @@ aoclsparse_status solve_core(aoclsparse_operation trans, T alpha, aoclsparse_mat
                           b_off, incb, x_off, incx);
     else
         st = launch_trsv<T>(rt.stream(), schedule, unit, alpha, m, plan, A->dev_diag.as<T>(), db, dx,
-                            A->trsv_xp.as<T>(), A->trsv_scratch.as<unsigned int>(), nrhs, b_off, incb, x_off, incx);
+                            A->trsv_xp.as<T>(), A->trsv_scratch.as<unsigned int>(), nrhs, b_off, incb, x_off, incx,
+                            rt.trsv_timeout_dev);
     if(st != aoclsparse_status_success)
         return st;
     if(!xdev)
         MI355_HIP_TRY(hipMemcpyAsync(x, dx, sizeof(T) * span_x, hipMemcpyDeviceToHost, rt.stream()));
-    const bool syncfree = !is_cplx && (schedule == 2 || (schedule == 1 && (nrhs != 1 || incb != 1 || incx != 1)));
-    if(!xdev || syncfree)
+    const bool syncfree = !is_cplx && (schedule >= 2 || (schedule == 1 && (nrhs != 1 || incb != 1 || incx != 1)));
+    const bool pinned_word = rt.trsv_timeout_dev != nullptr;
+    if(!xdev || (syncfree && !pinned_word))
     {
-        // host semantics, and the sync-free path reports a (never expected) spin timeout
+        // host semantics (the result must be in the caller's memory on return); without the pinned word the
+        // sync-free path also has to fetch its device-side timeout word
         MI355_HIP_TRY(hipStreamSynchronize(rt.stream()));
-        if(syncfree)
+        if(syncfree && !pinned_word)
         {
             unsigned int word = 0;
             MI355_HIP_TRY(hipMemcpy(&word, A->trsv_scratch.as<unsigned int>() + nrhs, sizeof(word),
@@ -303,6 +337,13 @@ aoclsparse_status solve_core(aoclsparse_operation trans, T alpha, aoclsparse_mat
             if(word)
                 return aoclsparse_status_internal_error;
         }
+    }
+    // device-pointer solves stay asynchronous: an expired wait (never expected) is seen at the next solve; a
+    // host-pointer solve has just synchronised and reports it now
+    if(syncfree && pinned_word && !xdev && *rt.trsv_timeout_host)
+    {
+        *rt.trsv_timeout_host = 0;
+        return aoclsparse_status_internal_error;
     }
     return aoclsparse_status_success;
 }

@@ -48,6 +48,20 @@ struct tag<float>
     static constexpr bits value = 0x7FC0D355u;
 };
 
+// what a result whose bits EQUAL the tag is published as (a NaN with that exact payload can only come from b or A)
+template <typename T>
+struct qnan_bits;
+template <>
+struct qnan_bits<double>
+{
+    static constexpr unsigned long long value = 0x7FF8000000000000ull;
+};
+template <>
+struct qnan_bits<float>
+{
+    static constexpr unsigned int value = 0x7FC00000u;
+};
+
 __device__ __forceinline__ double neg_fma(double a, double b, double c)
 {
     return fma(-a, b, c);
@@ -116,6 +130,7 @@ __global__ void trsv_level_kernel(aoclsparse_int first, aoclsparse_int count, ao
 // across barriers.  Dependencies older than the ring are read from xp in global memory; this workgroup
 // wrote them itself (same CU, so its L1 is coherent for them) at least TRSV_RING-TRSV_NARROW positions
 // ago, and a full vmcnt(0) drain every TRSV_DRAIN levels bounds how long such a store can be pending.
+constexpr unsigned long long TRSV_WAIT_TICKS = 500000000ull; // 5 s of s_memrealtime (100 MHz): sync-free wait budget
 constexpr int TRSV_PF    = 8;
 constexpr int TRSV_RING  = 8192; // positions kept in LDS (64 KiB fp64)
 constexpr int TRSV_DRAIN = 4; // levels between full memory drains (< (RING-NARROW)/NARROW)
@@ -300,7 +315,8 @@ __global__ __launch_bounds__(TRSV_SF_BLOCK) void trsv_syncfree_kernel(
     bool done = false;
     // every lane keeps iterating until ITS row is published: a lane may wait on a row owned by
     // another lane of the same wavefront, so the store must happen inside the loop
-    unsigned int spins = 0;
+    unsigned int       spins  = 0;
+    unsigned long long t_wait = 0;
     while(!done)
     {
         if(p != pe)
@@ -319,16 +335,27 @@ __global__ __launch_bounds__(TRSV_SF_BLOCK) void trsv_syncfree_kernel(
                 __builtin_memcpy(&xv, &bits, sizeof(T));
                 xi = neg_fma(staged ? s_ev[e][tid] : pval[p], xv, xi);
                 p++;
-                spins = 0;
+                spins = 0, t_wait = 0;
             }
-            else if(++spins > (1u << 24))
+            else
             {
-                // never expected: bail out instead of hanging the GPU, host reports internal_error
-                atomicExch(timeout_flag, 1u);
-                p = pe;
+                if((++spins & 4095u) == 0)
+                {
+                    // bounded by WALL time (s_memrealtime, 100 MHz), not by a spin count: a long serial chain, a shared
+                    // GPU or a profiler must not trip it
+                    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                    if(t_wait == 0)
+                        t_wait = now;
+                    else if(now - t_wait > TRSV_WAIT_TICKS)
+                    {
+                        // never expected: report (host returns internal_error), publish nothing, keep the caller's x
+                        __hip_atomic_store(timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        return;
+                    }
+                }
+                if(q < k0)
+                    __builtin_amdgcn_s_sleep(1);
             }
-            else if(q < k0)
-                __builtin_amdgcn_s_sleep(1);
         }
         if(p == pe)
         {
@@ -336,6 +363,8 @@ __global__ __launch_bounds__(TRSV_SF_BLOCK) void trsv_syncfree_kernel(
                 xi /= dg;
             B out;
             __builtin_memcpy(&out, &xi, sizeof(T));
+            if(out == tag<T>::value) // a NaN carrying the NOT-READY payload: publish the canonical quiet NaN instead
+                out = qnan_bits<T>::value;
             __hip_atomic_store(&s_x[tid], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_store(&xb[k], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             x[(size_t)i * g.incx] = xi;
@@ -344,12 +373,167 @@ __global__ __launch_bounds__(TRSV_SF_BLOCK) void trsv_syncfree_kernel(
     }
 }
 
+// ---- schedule 3: sync-free, one LEVEL SLICE per wavefront ------------------------------------------------------
+// The plan cuts every level into slices of <= 64 consecutive positions (TrsvPlan::slices), so the 64 lanes of a
+// wavefront never depend on each other and may advance in lockstep.  That buys what the lane-per-position kernel
+// above cannot have: a lane issues the loads of ALL its staged dependencies at once (one memory round trip for
+// everything that is already solved, instead of one per entry) and keeps entries and values in registers; only the
+// entries still tagged NOT-READY are polled again, in chain order.  A workgroup takes TRSV_WV consecutive slices
+// through an atomic ticket (about three levels of a 300-row-wide level structure): dependencies inside the workgroup
+// are exchanged through LDS, the others with agent-scope (sc1) loads of the position-ordered xp[].
+// Waits are bounded by WALL time (s_memrealtime, 100 MHz): a lane that times out raises the flag and leaves x untouched.
+// A result whose bits equal the NOT-READY tag (a NaN carrying exactly that payload: only possible when b or A holds
+// it) is published as the canonical quiet NaN, so a consumer can never mistake it for "not solved yet".
+
+template <typename T, int WV, int PF>
+__global__ __launch_bounds__(64 * WV) void trsv_slice_kernel(
+    aoclsparse_int m, aoclsparse_int nslices, const aoclsparse_int *__restrict__ slices,
+    const aoclsparse_int *__restrict__ rowmap, const aoclsparse_int *__restrict__ pptr,
+    const aoclsparse_int *__restrict__ pind, const T *__restrict__ pval, const T *__restrict__ diag,
+    const T *__restrict__ b, T *xp, T *x, T alpha, int unit, unsigned int *ticket, unsigned int *timeout_flag, int incb,
+    int incx)
+{
+    using B = typename tag<T>::bits;
+    __shared__ unsigned int s_bid;
+    __shared__ B            s_x[64 * WV];
+    const int tid = threadIdx.x;
+    if(tid == 0)
+        s_bid = atomicAdd(ticket, 1u);
+    s_x[tid] = tag<T>::value;
+    __syncthreads();
+    const int w    = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sl   = (int)s_bid * WV + w;
+    if(sl >= nslices)
+        return;
+    const int k0 = slices[(int)s_bid * WV]; // first position of this workgroup
+    const int kf = slices[sl], kl = slices[sl + 1];
+    const int k  = kf + (tid & 63);
+    if(k >= kl)
+        return;
+    const int i = rowmap[k], p0 = pptr[k], pe = pptr[k + 1];
+    const int n = pe - p0;
+    T         v[PF];
+    int       q[PF];
+    B         bits[PF];
+    B        *xb = reinterpret_cast<B *>(xp);
+#pragma unroll
+    for(int e = 0; e < PF; e++)
+    {
+        v[e] = T(0), q[e] = 0;
+        if(e < n)
+            v[e] = pval[p0 + e], q[e] = pind[p0 + e];
+    }
+    T xi = alpha * b[(size_t)i * incb];
+    T dg = T(1);
+    if(!unit)
+        dg = diag[i];
+    auto peek = [&](int qq) -> B {
+        return qq >= k0 ? __hip_atomic_load(&s_x[qq - k0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                        : __hip_atomic_load(&xb[qq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // everything that is already solved arrives in ONE round trip
+#pragma unroll
+    for(int e = 0; e < PF; e++)
+        bits[e] = e < n ? peek(q[e]) : B(0);
+    unsigned long long t0   = 0;
+    bool               dead = false;
+    auto               wait = [&](int qq, B got) -> B {
+        unsigned int spins = 0;
+        while(got == tag<T>::value && !dead)
+        {
+            if(qq < k0)
+                __builtin_amdgcn_s_sleep(1);
+            got = peek(qq);
+            if((++spins & 1023u) == 0)
+            {
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                if(t0 == 0)
+                    t0 = now;
+                else if(now - t0 > TRSV_WAIT_TICKS)
+                    dead = true;
+            }
+        }
+        return got;
+    };
+    // staged entries: consume in chain order whatever is solved; every pass re-reads ALL still-pending entries in
+    // one batch (one round trip however many there are), so that when the newest dependency arrives the older ones
+    // are long in registers -- polling entry by entry would put one round trip per entry on the critical path
+    const int ns   = n < PF ? n : PF;
+    int       next = 0;
+    unsigned  idle = 0;
+    while(next < ns && !dead)
+    {
+        const int before = next;
+#pragma unroll
+        for(int e = 0; e < PF; e++)
+            if(e == next && e < ns && bits[e] != tag<T>::value)
+            {
+                T xv;
+                __builtin_memcpy(&xv, &bits[e], sizeof(T));
+                xi = neg_fma(v[e], xv, xi);
+                next++;
+            }
+        if(next == ns)
+            break;
+        if(next == before)
+        {
+            // nothing new: back off (rows far ahead of the solve front must not flood the memory system with polls)
+            idle++;
+            if(idle < 8)
+                __builtin_amdgcn_s_sleep(1);
+            else if(idle < 64)
+                __builtin_amdgcn_s_sleep(4);
+            else
+                __builtin_amdgcn_s_sleep(16);
+            if((idle & 255u) == 0)
+            {
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                if(t0 == 0)
+                    t0 = now;
+                else if(now - t0 > TRSV_WAIT_TICKS)
+                    dead = true;
+            }
+        }
+        else
+            idle = 0, t0 = 0;
+        // rows far ahead of the front (nothing solved yet) poll their OLDEST dependency only; once the front is
+        // here (something was consumed) every pending entry is refreshed
+#pragma unroll
+        for(int e = 0; e < PF; e++)
+            if(e >= next && e < ns && bits[e] == tag<T>::value && (e == next || next > 0 || idle < 2))
+                bits[e] = peek(q[e]);
+    }
+    for(int p = p0 + PF; p < pe && !dead; p++)
+    {
+        const int qq  = pind[p];
+        const B   got = wait(qq, peek(qq));
+        T         xv;
+        __builtin_memcpy(&xv, &got, sizeof(T));
+        xi = neg_fma(pval[p], xv, xi);
+    }
+    if(dead)
+    {
+        // never expected: report, publish nothing (dependants time out the same way), keep the caller's x
+        __hip_atomic_store(timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    if(!unit)
+        xi /= dg;
+    B out;
+    __builtin_memcpy(&out, &xi, sizeof(T));
+    if(out == tag<T>::value)
+        out = qnan_bits<T>::value;
+    __hip_atomic_store(&s_x[k - k0], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(&xb[k], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    x[(size_t)i * incx] = xi;
+}
+
 // scratch: nrhs ticket words followed by one timeout word (zeroed here for the sync-free schedule)
 template <typename T>
 aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, aoclsparse_int m,
                               const TrsvPlan &plan, const T *diag, const T *b, T *x, T *xp, unsigned int *scratch,
                               aoclsparse_int nrhs, long long b_off, aoclsparse_int incb, long long x_off,
-                              aoclsparse_int incx)
+                              aoclsparse_int incx, unsigned int *timeout_word)
 {
     if(m <= 0 || nrhs <= 0)
         return aoclsparse_status_success;
@@ -360,6 +544,8 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
     RhsGeom               g{b_off, x_off, incb, incx, 0};
     if(schedule == 1 && (nrhs != 1 || incb != 1 || incx != 1))
         schedule = 2; // the single-workgroup runs of the hybrid schedule are single-RHS, unit stride
+    if(schedule == 3 && (nrhs != 1 || plan.nslices <= 0))
+        schedule = 2; // the slice kernel is single-RHS; trsm keeps the lane-per-position kernel
     auto level_launch = [&](aoclsparse_int l) {
         const aoclsparse_int first = plan.level_ptr[l], count = plan.level_ptr[l + 1] - first;
         const int            bs = count >= 256 ? 256 : 64;
@@ -389,6 +575,35 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
                     level_launch(l);
         }
     }
+    else if(schedule == 3)
+    {
+        // sync-free, one level slice per wavefront (single right-hand side)
+        MI355_HIP_TRY(hipMemsetAsync(scratch, 0, 2 * sizeof(unsigned int), s));
+        hipLaunchKernelGGL((trsv_fill_tag_kernel<T>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, xp, (long long)m);
+        static const int wv_env = [] {
+            const char *e = getenv("AOCLSPARSE_MI355_TRSV_WAVES");
+            return e ? atoi(e) : 0;
+        }();
+        const bool  wide = (long long)plan.nnz_tri > 10LL * m;
+        const int   wv   = wv_env == 4 || wv_env == 8 || wv_env == 16 ? wv_env : 16;
+        const aoclsparse_int *sl = plan.slices.as<aoclsparse_int>();
+        auto go = [&](auto wv_tag, auto pf_tag) {
+            constexpr int WV = decltype(wv_tag)::value, PF = decltype(pf_tag)::value;
+            const unsigned nblk = (unsigned)((plan.nslices + WV - 1) / WV);
+            hipLaunchKernelGGL((trsv_slice_kernel<T, WV, PF>), dim3(nblk), dim3(64 * WV), 0, s, m, plan.nslices, sl, rowmap,
+                               pptr, pind, pval, diag, b, xp, x, alpha, (int)unit, scratch, timeout_word ? timeout_word : scratch + 1,
+                               (int)incb, (int)incx);
+        };
+        using I4 = std::integral_constant<int, 4>;
+        using I8 = std::integral_constant<int, 8>;
+        using I16 = std::integral_constant<int, 16>;
+        using PW = std::integral_constant<int, 20>;
+        using PN = std::integral_constant<int, 8>;
+        if(wide)
+            wv == 4 ? go(I4{}, PW{}) : wv == 8 ? go(I8{}, PW{}) : go(I16{}, PW{});
+        else
+            wv == 4 ? go(I4{}, PN{}) : wv == 8 ? go(I8{}, PN{}) : go(I16{}, PN{});
+    }
     else
     {
         // sync-free: tag xp, reset tickets + timeout word, one launch over all right-hand sides
@@ -396,7 +611,7 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
         const long long total = (long long)m * nrhs;
         hipLaunchKernelGGL((trsv_fill_tag_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xp,
                            total);
-        unsigned int *tmo = scratch + nrhs;
+        unsigned int *tmo = timeout_word ? timeout_word : scratch + nrhs;
         for(aoclsparse_int c0 = 0; c0 < nrhs; c0 += 65535)
         {
             const int nc = nrhs - c0 < 65535 ? nrhs - c0 : 65535;
@@ -420,9 +635,11 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
 
 template aoclsparse_status launch_trsv<double>(hipStream_t, int, bool, double, aoclsparse_int, const TrsvPlan &,
                                                const double *, const double *, double *, double *, unsigned int *,
-                                               aoclsparse_int, long long, aoclsparse_int, long long, aoclsparse_int);
+                                               aoclsparse_int, long long, aoclsparse_int, long long, aoclsparse_int,
+                                               unsigned int *);
 template aoclsparse_status launch_trsv<float>(hipStream_t, int, bool, float, aoclsparse_int, const TrsvPlan &,
                                               const float *, const float *, float *, float *, unsigned int *,
-                                              aoclsparse_int, long long, aoclsparse_int, long long, aoclsparse_int);
+                                              aoclsparse_int, long long, aoclsparse_int, long long, aoclsparse_int,
+                                              unsigned int *);
 
 } // namespace mi355

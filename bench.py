@@ -177,12 +177,26 @@ def main():
     legs = set(all_legs) if args.legs == "all" else set(x for x in args.legs.split(",") if x and x != "none")
     assert legs <= set(all_legs), "unknown leg in --legs: %s" % sorted(legs - set(all_legs))
 
+    # host description BEFORE any OpenMP runtime is loaded (torch brings libgomp): with OMP_PROC_BIND set, libgomp pins
+    # the thread that loads it to its first place, after which sched_getaffinity() reports that one core only
+    cpu_model, cpu_logical, cpu_physical = cpu_info()
+    main_affinity = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+
+    def unpin():
+        """give the launching thread its original CPU mask back (after the OpenMP runtime start and oracle calls)"""
+        if main_affinity is not None:
+            try:
+                os.sched_setaffinity(0, main_affinity)
+            except OSError:
+                pass
+
     import numpy as np
     import torch
     import torch.distributed as dist
 
     import __graft_entry__ as entry
 
+    unpin()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -201,19 +215,6 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
     D = dist if use_dist else None
-
-    # host description BEFORE any OpenMP region runs: with OMP_PROC_BIND libgomp pins the calling thread to its first
-    # place at the first parallel region, after which sched_getaffinity() reports that one core only
-    cpu_model, cpu_logical, cpu_physical = cpu_info()
-    main_affinity = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
-
-    def unpin():
-        """give the launching thread its original CPU mask back after an OpenMP (oracle) call"""
-        if main_affinity is not None:
-            try:
-                os.sched_setaffinity(0, main_affinity)
-            except OSError:
-                pass
 
     pkg = entry.load_package()
     import aocl_sparse_amd.sharded as sharded

@@ -412,6 +412,14 @@ out["sorv"] = [
          x_iter1=[1.6415369036903691, -29.305197322163828, 6.9000000000000004, -19.757185084519875]),
 ]
 
+# ------------------------------------------------------------------------------------------
+# aoclsparse_?mv with a TRIANGULAR descriptor on a rectangular 5 x 4 matrix: tests/unit_tests/mv_tests.cpp:344-388
+# (test_mv_success: exp_y_l with fill = lower, exp_y_u with fill = upper; alpha = 1, beta = 0, op = none, base 0)
+# ------------------------------------------------------------------------------------------
+out["mv_tri"] = dict(src="tests/unit_tests/mv_tests.cpp:344-388", base=0, m=5, n=4, row_ptr=[0, 2, 3, 4, 7, 8],
+                     col_ind=[0, 3, 1, 2, 1, 2, 3, 1], val=[1, 2, 3, 4, 5, 6, 7, 8], x=[1.0, 2.0, 3.0, 4.0],
+                     alpha=1.0, beta=0.0, exp_y_l=[1, 6, 12, 56, 16], exp_y_u=[9, 6, 12, 28, 0])
+
 with open(n25_path, "w") as f:
     json.dump(out, f, indent=None, separators=(",", ":"))
     f.write("\n")

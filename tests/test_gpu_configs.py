@@ -1,0 +1,501 @@
+"""GPU tier (-m gpu), round 2: every BASELINE.json config at its stated size through the C ABI, the multi-rank csrmm
+control flow on ONE GPU (two fresh processes, gloo on the wire), the csrmm kernels added this round, per-iteration
+timing and the TRSV robustness cases.  Parity bars: bit-exact against the oracle wherever the reference's order is
+reproduced; the componentwise bound of SURVEY.md section 8d (constant written in the test) where the schedule
+legitimately differs (rows longer than one LDS tile in auto mode)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+from util import EPS64, ROOT, laplace5, pkg, random_csr
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+P = pkg()
+L = P.lib()
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import standins  # noqa: E402
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    assert torch.cuda.is_available(), "GPU tests need a GPU (no CPU fallback exists)"
+    st, d, cus, name = P.device_info()
+    assert st == 0 and cus > 0
+    yield
+    L.aoclsparse_mi355_set_pointer_mode(P.PTR_AUTO)
+
+
+# --------------------------------------------------------------------------------------------------
+# BASELINE configs[2]: the SuiteSparse mix at full size, kernel chosen by aoclsparse_optimize
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["circuit-like", "web-like", "shell-like", "flan-like"])
+def test_mix_full_size_dmv_after_optimize(name):
+    """aoclsparse_set_mv_hint + aoclsparse_optimize + aoclsparse_dmv on the config-3 matrices (the real .mtx files when
+    $MATRIX_DIR holds them, else the seeded stand-ins) against oracle.dcsrmv with the reference's dispatch rule
+    (nnz <= 10 m -> scalar order, else the AVX-512 8-lane order, csrmv.hpp:326-343).
+      * SELL-64 (chosen for the two uniform matrices) reproduces the dispatched order for rows of any length: bit-exact.
+      * CSR-Adaptive (the two power-law matrices): rows inside one LDS tile bit-exact; a row longer than a tile is
+        reduced by a wavefront tree in auto mode: |d| <= (2 ceil(log2 n) + 4 + n/256) eps sum|a x|."""
+    label, m, rp, ci, v = standins.load(name)
+    nnz = len(v)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    d = P.Descr()
+    assert L.aoclsparse_set_mv_hint(A.h, P.OP_NONE, d.h, 100) == 0 and L.aoclsparse_optimize(A.h) == 0
+    info = A.spmv_info()
+    uniform = name in ("shell-like", "flan-like")
+    assert info.kernel == (3 if uniform else 1), "optimize chose kernel %d for %s" % (info.kernel, label)
+    assert info.order == (2 if nnz > 10 * m else 0)  # the reference's dispatch rule
+    x = np.random.default_rng(1).uniform(-1, 1, m)
+    y0 = np.random.default_rng(2).uniform(-1, 1, m)
+    for alpha, beta in ((1.0, 0.0), (-0.75, 1.5)):
+        yd = dev(y0)
+        assert P.dmv(P.OP_NONE, alpha, A, d, dev(x), beta, yd) == 0
+        torch.cuda.synchronize()
+        got = yd.cpu().numpy()
+        so, yr = oracle.dcsrmv(-1, 0, alpha, m, nnz, v, ci, rp, x, beta, y0, nthreads=oracle.max_threads())
+        assert so == 0
+        lens = np.diff(rp)
+        if info.kernel == 3:
+            assert np.array_equal(got, yr)
+        else:
+            short = lens <= info.tile
+            assert np.array_equal(got[short], yr[short])
+            scale = np.zeros(m)
+            nz = lens > 0
+            scale[nz] = np.add.reduceat(np.abs(v * x[ci]), rp[:-1][nz])
+            bound = (2 * np.ceil(np.log2(np.maximum(lens, 2))) + 4 + lens / 256.0) * EPS64 * abs(alpha) * scale
+            assert np.all(np.abs(got - yr)[~short] <= bound[~short] + 2 * EPS64 * np.abs(beta * y0[~short]))
+            assert (~short).sum() == info.long_rows
+
+
+# --------------------------------------------------------------------------------------------------
+# BASELINE configs[4]: unit-lower ILU(0) factor of the shell-like matrix through aoclsparse_dtrsv
+# --------------------------------------------------------------------------------------------------
+def _shell_factor():
+    label, m, rp, ci, v = standins.load("shell-like")
+    st, lu, dg = oracle.dilu0(m, 0, rp, ci, v)
+    assert st == 0
+    o = oracle.dcsr_optimize(m, m, len(lu), 0, rp, ci, lu)
+    assert o["status"] == 0
+    return label, m, rp, ci, lu, o
+
+
+def test_shell_like_ilu0_trsv_full_size():
+    """config 5 as BASELINE.md section 3 states it: ILU(0) of the af_shell10-like matrix (1.5 M rows, 25.6 M strict-lower
+    entries, 5,505 dependency levels), descr {triangular, lower, unit}, alpha = 1, b = L * 1.  Every schedule returns
+    the bits of the serial reference chain (ref_trsv_l, trsv_kr.hpp:57-75); the solution is the vector of ones to a
+    few ulps and the residual ||L x - b||_inf / ||b||_inf is at rounding level."""
+    label, m, rp, ci, lu, o = _shell_factor()
+    A = P.Matrix(0, m, m, rp, ci, lu)
+    dl = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=P.FILL_LOWER, diag=P.DIAG_UNIT)
+    assert L.aoclsparse_set_sv_hint(A.h, P.OP_NONE, dl.h, 10) == 0 and L.aoclsparse_optimize(A.h) == 0
+    lv = A.trsv_levels(P.FILL_LOWER)
+    assert lv > 1000
+    ones = np.ones(m)
+    _, b = oracle.dcsrmv_special("tri", 0, 1.0, m, m, 1, 0, lu, ci, rp, o["idiag"], o["iurow"], ones, 0.0, np.zeros(m))
+    st, xr = oracle.dtrsv("l", 1.0, m, 0, lu, ci, rp, o["idiag"], b, True)
+    assert st == 0
+    bd = dev(b)
+    for kid in (None, 3, 1):  # auto, sync-free, hybrid
+        xd = torch.full((m,), np.nan, dtype=torch.float64, device="cuda")
+        assert P.dtrsv(P.OP_NONE, 1.0, A, dl, bd, xd, kid=kid) == 0
+        torch.cuda.synchronize()
+        x = xd.cpu().numpy()
+        assert np.array_equal(x, xr), "schedule kid=%s differs from the serial chain" % kid
+    assert np.max(np.abs(x - 1.0)) <= 64 * EPS64
+    _, lx = oracle.dcsrmv_special("tri", 0, 1.0, m, m, 1, 0, lu, ci, rp, o["idiag"], o["iurow"], x, 0.0, np.zeros(m))
+    assert np.max(np.abs(lx - b)) <= 16 * EPS64 * np.max(np.abs(b))
+
+
+# --------------------------------------------------------------------------------------------------
+# BASELINE configs[3], multi-rank: two fresh processes on the one GPU, gloo on the wire
+# --------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _torchrun(nproc, script, *args, timeout=600):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, script)] + list(args)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, "rc=%d\nstdout:\n%s\nstderr:\n%s" % (r.returncode, r.stdout[-3000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines, r.stdout[-2000:]
+    return json.loads(lines[-1])
+
+
+@pytest.mark.parametrize("layout,cols,beta", [("col", 40, 0.0), ("row", 64, 0.0), ("row", 42, -1.25), ("col", 10, 2.0)])
+def test_sharded_csrmm_two_processes_one_gpu(layout, cols, beta):
+    """The whole N > 1 control flow of aocl-sparse_amd/sharded.py (A broadcast from rank 0, per-rank B slab, the product,
+    the optional all-gather) in two fresh processes that share the one GPU: each rank's slab and the gathered C must
+    equal the single-rank product bit for bit, and so must the in-library aoclsparse_mi355_dcsrmm_shard entry."""
+    res = _torchrun(2, "tools/sharded_check.py", "--backend", "gloo", "--grid", "150", "--cols", str(cols), "--layout", layout,
+                    "--beta", str(beta))
+    assert res["world"] == 2 and res["backend"] == "gloo"
+    assert res["slab_bit_exact"] and res["gathered_bit_exact"] and res["abi_shard_bit_exact"] and res["all_ranks_ok"]
+    assert res["shard"] == list(P.column_shard(cols, 2, 0))
+
+
+def test_bench_two_ranks_gloo_one_gpu():
+    """bench.py as the driver starts it for N = 2 (torch.distributed.run, one process per rank), with --backend gloo so
+    that both ranks can share the one GPU: the JSON line must carry the whole-job value, the sharded csrmm object with
+    its efficiency T1 / (N TN), the A broadcast, the C all-gather and the parity verdicts."""
+    res = _torchrun(2, "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "5", "--warmup", "2", "--grid", "512",
+                    "--mm-grid", "200", "--mm-cols", "64", "--legs", "csrmm_sharded")
+    assert res["n_gpus"] == 2 and res["steps"] == 5 and res["scaling"] == "weak" and res["unit"] == "GFLOP/s"
+    assert res["parity"]["bit_exact"] is True
+    assert res["roofline"]["bound"] == "hbm" and 0 < res["roofline"]["frac"] < 1.0
+    assert res["stats"]["n"] == 5 and res["stats"]["min"] <= res["stats"]["median"] <= res["stats"]["max"]
+    mm = res["csrmm_sharded"]
+    assert "error" not in mm, mm
+    assert mm["world"] == 2 and mm["cols_per_rank"] == 32 and mm["parity"]["bit_exact"] is True
+    assert mm["efficiency"] > 0 and mm["t1_ms"] > 0 and mm["a_broadcast_ms"] > 0 and mm["c_allgather_ms"] > 0
+    assert mm["roofline_shard"]["algorithmic_bytes_per_launch"] == (40000 + 1 + mm["nnz"]) * 4 + mm["nnz"] * 8 + 8 * 32 * 2 * 40000
+
+
+def test_bench_single_process_small_legs():
+    """`python bench.py` with every leg on small inputs: one JSON line whose legs all carry a roofline object and a
+    bit-exact verdict (the driver-timed run uses the full sizes)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--grid", "512",
+                        "--mm-grid", "200", "--mm-cols", "64", "--small", "--cpu-seconds", "0.5"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["parity"]["bit_exact"] and res["cpu_baseline"]["kind"] == "port"
+    cb = res["cpu_baseline"]
+    assert cb["one_thread"]["threads"] == 1 and cb["cores"] >= 1 and cb["cpu_model"] and cb["bit_exact_vs_gpu"]
+    assert res["l100"]["bit_exact"] and res["l100"]["roofline"]["frac"] > 0
+    legs = res["legs"]
+    for k in ("dcsrmv_csr_adaptive", "mix", "csrmm", "trsv"):
+        assert k in legs and "error" not in legs[k], (k, legs.get(k))
+    assert legs["dcsrmv_csr_adaptive"]["bit_exact_vs_headline_y"] and legs["dcsrmv_csr_adaptive"]["roofline"]["frac"] > 0
+    for row in legs["mix"]["matrices"]:
+        assert row["bit_exact_rows_within_tile"] and row["long_rows_within_bound"] and row["roofline"]["frac"] > 0
+    for c in legs["csrmm"]["cases"]:
+        assert c["bit_exact_4_columns"] and c["roofline"]["frac"] > 0
+    for s in legs["trsv"]["schedules"]:
+        assert s["bit_exact_vs_cpu"] and s["residual_inf"] < 1e-13
+    assert res["csrmm_sharded"]["efficiency"] == 1.0 and res["csrmm_sharded"]["parity"]["bit_exact"]
+
+
+# --------------------------------------------------------------------------------------------------
+# csrmm kernels of this round
+# --------------------------------------------------------------------------------------------------
+def _col_reference(alpha, base, v, ci, rp, m, k, Brm, n, ldb, beta, C0, ldc):
+    """per-element reference bits for ROW-major operands: the column-major oracle on the transposed layouts"""
+    Bc = np.ascontiguousarray(Brm.reshape(k, ldb)[:, :n].T).ravel()
+    Cc = np.ascontiguousarray(C0.reshape(m, ldc)[:, :n].T).ravel()
+    so, Cref = oracle.dcsrmm("col", alpha, base, v, ci, rp, m, Bc, n, k, beta, Cc, m)
+    assert so == 0
+    return Cref.reshape(n, m).T
+
+
+@pytest.mark.parametrize("base", [0, 1])
+def test_csrmm_tiled_narrow_row_major_bit_exact(base):
+    """csrmm_tile_kernel (row-major, n < 128: workgroup per row block of the SpMV plan, A staged in LDS): empty rows,
+    rows longer than the LDS tile (a block of their own), padded leading dimensions, alpha / beta classes incl. the
+    beta = 0 store path and NaN already in C (overwritten, as documented), n from 2 to 126."""
+    m, k = 2600, 2100
+    rng = np.random.default_rng(17)
+    def rowlen(r, i):
+        if i in (5, 1300):
+            return 1500  # longer than a 512- or 1024-entry tile
+        return 0 if i % 97 == 3 else int(r.integers(1, 30))
+    rp, ci, v = random_csr(23, m, k, rowlen, base=base)
+    A = P.Matrix(base, m, k, rp, ci, v)
+    d = P.Descr(base=base)
+    assert L.aoclsparse_set_mm_hint(A.h, P.OP_NONE, d.h, 2) == 0 and L.aoclsparse_optimize(A.h) == 0
+    for n, alpha, beta in ((2, 1.0, 0.0), (32, 1.0, 0.0), (32, -0.5, 2.0), (64, 3.0, -1.0), (96, 1.0, 0.0), (126, 0.25, 1.0)):
+        ldb, ldc = n + 2, n + 4
+        Br, C0 = rng.uniform(-1, 1, k * ldb), rng.uniform(-1, 1, m * ldc)
+        Cd = dev(C0)
+        assert P.dcsrmm(P.OP_NONE, alpha, A, d, P.ORDER_ROW, dev(Br), n, ldb, beta, Cd, ldc) == 0
+        torch.cuda.synchronize()
+        got = Cd.cpu().numpy().reshape(m, ldc)
+        ref = _col_reference(alpha, base, v, ci, rp, m, k, Br, n, ldb, beta, C0, ldc)
+        assert np.array_equal(got[:, :n], ref), "n=%d" % n
+        assert np.array_equal(got[:, n:], C0.reshape(m, ldc)[:, n:])  # padding untouched
+    # beta = 0 never reads a finite-or-not C
+    n = 32
+    Br = rng.uniform(-1, 1, k * n)
+    Cd = torch.full((m * n,), float("nan"), dtype=torch.float64, device="cuda")
+    assert P.dcsrmm(P.OP_NONE, 1.0, A, d, P.ORDER_ROW, dev(Br), n, n, 0.0, Cd, n) == 0
+    torch.cuda.synchronize()
+    ref = _col_reference(1.0, base, v, ci, rp, m, k, Br, n, n, 0.0, np.zeros(m * n), n)
+    got = Cd.cpu().numpy().reshape(m, n)
+    nonempty = np.diff(rp) > 0
+    assert np.array_equal(got[nonempty], ref[nonempty])
+
+
+@pytest.mark.parametrize("base", [0, 1])
+def test_csrmm_column_major_row_pairs_bit_exact(base):
+    """csrmm_colpair_kernel: banded matrix whose odd rows carry the even rows' pattern shifted by one column (5-point
+    Laplacian with perturbed values), odd row count, boundary rows that do not pair, a few rows made irregular on
+    purpose: column-major C must equal csrmm_col_major_ref bit for bit; padded leading dimensions, beta classes."""
+    g = 61  # odd grid edge: row pairs straddle grid lines, m = 3721 is odd
+    m, rp, ci, v = laplace5(g, base=base)
+    rng = np.random.default_rng(9)
+    v = v * rng.uniform(0.5, 1.5, len(v))
+    A = P.Matrix(base, m, m, rp, ci, v)
+    d = P.Descr(base=base)
+    assert L.aoclsparse_set_mm_hint(A.h, P.OP_NONE, d.h, 2) == 0 and L.aoclsparse_optimize(A.h) == 0
+    for n, alpha, beta in ((4, 1.0, 0.0), (7, 2.0, 0.0), (70, -1.0, 0.5), (130, 1.0, 0.0)):
+        ldb, ldc = m + 3, m + 5  # odd ldc: 16-byte stores not allowed -> generic kernel; even below
+        for ldc in (m + 5, m + 6):
+            B, C0 = rng.uniform(-1, 1, ldb * n), rng.uniform(-1, 1, ldc * n)
+            Cd = dev(C0)
+            assert P.dcsrmm(P.OP_NONE, alpha, A, d, P.ORDER_COLUMN, dev(B), n, ldb, beta, Cd, ldc) == 0
+            torch.cuda.synchronize()
+            so, Cr = oracle.dcsrmm("col", alpha, base, v, ci, rp, m, B, n, ldb, beta, C0, ldc)
+            assert np.array_equal(Cd.cpu().numpy(), Cr), "n=%d ldc=%d" % (n, ldc)
+    # a matrix whose pairs do NOT match must not take the pair kernel and stays exact
+    rp2, ci2, v2 = random_csr(4, 900, 800, lambda r, i: r.integers(0, 9), base=base)
+    A2 = P.Matrix(base, 900, 800, rp2, ci2, v2)
+    B, C0 = rng.uniform(-1, 1, 800 * 12), rng.uniform(-1, 1, 900 * 12)
+    Cd = dev(C0)
+    assert P.dcsrmm(P.OP_NONE, 1.0, A2, d, P.ORDER_COLUMN, dev(B), 12, 800, -1.0, Cd, 900) == 0
+    torch.cuda.synchronize()
+    so, Cr = oracle.dcsrmm("col", 1.0, base, v2, ci2, rp2, 900, B, 12, 800, -1.0, C0, 900)
+    assert np.array_equal(Cd.cpu().numpy(), Cr)
+
+
+def test_csrmm_full_config_both_layouts_and_slab():
+    """config 4 at full size (1M x 1M Laplacian, 256 columns, beta = 0): row-major and column-major products agree
+    element for element (one FMA chain per element), the 32-column slab of an 8-rank run equals the matching columns of
+    the full product in both layouts, and 4 columns equal the oracle."""
+    g, n = 1000, 256
+    m, rp, ci, v = laplace5(g)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    d = P.Descr()
+    assert L.aoclsparse_set_mm_hint(A.h, P.OP_NONE, d.h, 2) == 0 and L.aoclsparse_optimize(A.h) == 0
+    L.aoclsparse_mi355_set_pointer_mode(P.PTR_DEVICE)
+    try:
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(777)
+        Bc = torch.rand(n * m, dtype=torch.float64, device="cuda", generator=gen) * 2 - 1  # column-major, ld = m
+        Br = Bc.reshape(n, m).t().contiguous().reshape(-1)  # the same matrix row-major, ld = n
+        Cc, Cr = torch.zeros(n * m, dtype=torch.float64, device="cuda"), torch.zeros(n * m, dtype=torch.float64, device="cuda")
+        assert P.dcsrmm(P.OP_NONE, 1.0, A, d, P.ORDER_COLUMN, Bc, n, m, 0.0, Cc, m) == 0
+        assert P.dcsrmm(P.OP_NONE, 1.0, A, d, P.ORDER_ROW, Br, n, n, 0.0, Cr, n) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(Cc.reshape(n, m), Cr.reshape(m, n).t())
+        j0, j1 = P.column_shard(n, 8, 5)
+        assert (j0, j1) == (160, 192)
+        w = j1 - j0
+        Cs = torch.zeros(w * m, dtype=torch.float64, device="cuda")
+        assert P.dcsrmm(P.OP_NONE, 1.0, A, d, P.ORDER_COLUMN, Bc[j0 * m:j1 * m], w, m, 0.0, Cs, m) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(Cs, Cc[j0 * m:j1 * m])
+        Bs = Br.reshape(m, n)[:, j0:j1].contiguous().reshape(-1)  # the slab a rank owns: m x 32, ld = 32 (tiled kernel)
+        Cs.zero_()
+        assert P.dcsrmm(P.OP_NONE, 1.0, A, d, P.ORDER_ROW, Bs, w, w, 0.0, Cs, w) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(Cs.reshape(m, w), Cr.reshape(m, n)[:, j0:j1])
+        for j in (0, 100, 161, 255):
+            so, cr = oracle.dcsrmm("col", 1.0, 0, v, ci, rp, m, Bc[j * m:(j + 1) * m].cpu().numpy(), 1, m, 0.0, np.zeros(m), m)
+            assert np.array_equal(Cc[j * m:(j + 1) * m].cpu().numpy(), cr)
+    finally:
+        L.aoclsparse_mi355_set_pointer_mode(P.PTR_AUTO)
+
+
+# --------------------------------------------------------------------------------------------------
+# per-iteration timing (aoclsparse_mi355_timer_mark / _laps)
+# --------------------------------------------------------------------------------------------------
+def test_timer_marks_give_one_lap_per_interval():
+    m, rp, ci, v = laplace5(300)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    d = P.Descr()
+    x, y = dev(np.ones(m)), dev(np.zeros(m))
+    assert P.timer_laps() == []  # nothing recorded: empty, not an error
+    P.timer_mark()
+    assert P.timer_laps() == []  # one mark, no interval
+    P.timer_mark()
+    for _ in range(7):
+        assert P.dmv(P.OP_NONE, 1.0, A, d, x, 0.0, y) == 0
+        P.timer_mark()
+    laps = P.timer_laps()
+    assert len(laps) == 7 and all(0.0 < t < 50.0 for t in laps)
+    assert P.timer_laps() == []  # the ring was reset
+
+
+# --------------------------------------------------------------------------------------------------
+# TRSV robustness: NaN / Inf in b (mv_tests.cpp:1858-2290 style extreme values, applied to the solves) and a value
+# whose bits equal the sync-free kernels' NOT-READY tag
+# --------------------------------------------------------------------------------------------------
+def _same_up_to_nan_payload(got, ref):
+    """NaN where the reference has NaN (payloads may differ between x86 and gfx950), identical bits elsewhere"""
+    gn, rn = np.isnan(got), np.isnan(ref)
+    return bool(np.array_equal(gn, rn) and np.array_equal(got[~gn], ref[~rn]))
+
+
+@pytest.mark.parametrize("fill,unit", [("lower", False), ("upper", True)])
+def test_trsv_nan_inf_and_tag_collision_every_schedule(fill, unit):
+    """NaN, +-Inf and the exact NOT-READY bit pattern (0x7FF8DEADBEEF0355, a NaN) placed in b must propagate through
+    the dependency DAG exactly as in the serial reference chain -- for the per-level launches (kid 0), the hybrid
+    schedule (kid 1), the slice-per-wavefront sync-free kernel (kid 3 / auto) and the lane-per-position sync-free kernel
+    (what trsm runs for several right-hand sides) -- and never hang or report an error: a result equal to the tag is
+    published as a plain quiet NaN."""
+    from util import triangular_system
+    m = 20000
+    rp, ci, v = triangular_system(77, m, 4, band=300)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    d = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=P.FILL_LOWER if fill == "lower" else P.FILL_UPPER,
+                diag=P.DIAG_UNIT if unit else P.DIAG_NON_UNIT)
+    rng = np.random.default_rng(3)
+    tag = np.array([0x7FF8DEADBEEF0355], dtype=np.uint64).view(np.float64)[0]
+    o = oracle.dcsr_optimize(m, m, len(v), 0, rp, ci, v)
+    kind, ilend = ("l", o["idiag"]) if fill == "lower" else ("u", o["iurow"])
+    for case in ("nan", "inf", "tag", "mixed"):
+        b = rng.uniform(-1, 1, m)
+        if case in ("nan", "mixed"):
+            b[[17, 9000]] = np.nan
+        if case in ("inf", "mixed"):
+            b[[300, 15000]] = [np.inf, -np.inf]
+        if case in ("tag", "mixed"):
+            b[[5, 12345]] = tag
+        st, xr = oracle.dtrsv(kind, 1.0, m, 0, o["val"], o["ind"], o["ptr"], ilend, b, unit)
+        assert st == 0
+        assert np.isnan(xr).sum() >= 2 or case == "inf"
+        for kid in (0, 1, 3, None):
+            xd = torch.zeros(m, dtype=torch.float64, device="cuda")
+            assert P.dtrsv(P.OP_NONE, 1.0, A, d, dev(b), xd, kid=kid) == 0, (case, kid)
+            torch.cuda.synchronize()
+            assert _same_up_to_nan_payload(xd.cpu().numpy(), xr), (case, kid)
+            xh = np.zeros(m)
+            assert P.dtrsv(P.OP_NONE, 1.0, A, d, b, xh, kid=kid) == 0  # host pointers: synchronous, status checked
+            assert _same_up_to_nan_payload(xh, xr), (case, kid)
+        # two right-hand sides through trsm: the lane-per-position sync-free kernel
+        Bm = np.stack([b, b[::-1].copy()])  # column-major, ld = m
+        Xm = np.zeros_like(Bm)
+        assert L.aoclsparse_dtrsm_kid(P.OP_NONE, 1.0, A.h, d.h, P.ORDER_COLUMN, P._ptr(Bm), 2, m, P._ptr(Xm), m, 3) == 0
+        assert _same_up_to_nan_payload(Xm[0], xr), case
+        st, xr2 = oracle.dtrsv(kind, 1.0, m, 0, o["val"], o["ind"], o["ptr"], ilend, Bm[1], unit)
+        assert _same_up_to_nan_payload(Xm[1], xr2), case
+
+
+def test_strsv_tag_collision_float():
+    from util import triangular_system
+    m = 5000
+    rp, ci, v = triangular_system(78, m, 3, band=100, dtype=np.float32)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    d = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=P.FILL_LOWER)
+    b = np.random.default_rng(4).uniform(-1, 1, m).astype(np.float32)
+    b[[3, 2500]] = np.array([0x7FC0D355], dtype=np.uint32).view(np.float32)[0]
+    for kid in (0, 3):
+        xd = torch.zeros(m, dtype=torch.float32, device="cuda")
+        assert P.strsv(P.OP_NONE, 1.0, A, d, dev(b), xd, kid=kid) == 0
+        torch.cuda.synchronize()
+        got = xd.cpu().numpy()
+        if kid == 0:
+            ref = got
+    assert _same_up_to_nan_payload(got, ref) and np.isnan(ref).sum() >= 2
+
+
+def test_trsv_sync_free_is_asynchronous_for_device_pointers():
+    """device-pointer solves return before the kernel has finished (no stream sync, no blocking read of a timeout
+    word): many solves can be queued back to back and the stream's own order keeps them correct."""
+    import time
+    from util import triangular_system
+    m = 200000
+    rp, ci, v = triangular_system(79, m, 3, band=50)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    d = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=P.FILL_LOWER)
+    b = np.random.default_rng(5).uniform(-1, 1, m)
+    bd, xd = dev(b), torch.zeros(m, dtype=torch.float64, device="cuda")
+    assert P.dtrsv(P.OP_NONE, 1.0, A, d, bd, xd, kid=3) == 0  # analysis + first solve
+    torch.cuda.synchronize()
+    lv = A.trsv_levels(P.FILL_LOWER)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        assert P.dtrsv(P.OP_NONE, 1.0, A, d, bd, xd, kid=3) == 0
+    t_enqueue = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t_total = time.perf_counter() - t0
+    o = oracle.dcsr_optimize(m, m, len(v), 0, rp, ci, v)
+    st, xr = oracle.dtrsv("l", 1.0, m, 0, o["val"], o["ind"], o["ptr"], o["idiag"], b, False)
+    assert np.array_equal(xd.cpu().numpy(), xr)
+    assert lv > 100 and t_enqueue < 0.5 * t_total, (t_enqueue, t_total)
+
+
+# --------------------------------------------------------------------------------------------------
+# raw aoclsparse_dcsrmv on device arrays: the implicit plan cache must never serve another matrix's plan
+# --------------------------------------------------------------------------------------------------
+def test_raw_dcsrmv_device_arrays_plan_cache_is_validated():
+    """Two different matrices with the same m and nnz written one after the other into the SAME device buffers (what a
+    caching allocator does after free + malloc): the second product must be the second matrix's, bit for bit -- the
+    cached row-block plan of the first is checked against the live row_ptr and rebuilt."""
+    m, n = 40000, 40000
+    rng = np.random.default_rng(12)
+    # matrix 1: every row 10 entries; matrix 2: same nnz, very different row lengths (blocks of the plan move)
+    lens1 = np.full(m, 10, np.int64)
+    lens2 = np.zeros(m, np.int64)
+    lens2[: m // 2] = 1
+    lens2[m // 2:] = 19
+    mats = []
+    for lens in (lens1, lens2):
+        rp = np.zeros(m + 1, np.int32)
+        rp[1:] = np.cumsum(lens)
+        ci = np.concatenate([np.sort(rng.choice(n, size=int(k), replace=False)) for k in lens]).astype(np.int32)
+        mats.append((rp, ci, rng.uniform(-1, 1, len(ci))))
+    assert len(mats[0][1]) == len(mats[1][1])
+    nnz = len(mats[0][1])
+    d = P.Descr()
+    x = rng.uniform(-1, 1, n)
+    xd = dev(x)
+    d_rp, d_ci, d_v = dev(mats[0][0]), dev(mats[0][1]), dev(mats[0][2])
+    L.aoclsparse_mi355_set_pointer_mode(P.PTR_DEVICE)
+    try:
+        for rep in range(2):
+            for rp, ci, v in mats:
+                d_rp.copy_(torch.from_numpy(rp)), d_ci.copy_(torch.from_numpy(ci)), d_v.copy_(torch.from_numpy(v))
+                torch.cuda.synchronize()
+                yd = torch.zeros(m, dtype=torch.float64, device="cuda")
+                for _ in range(2):  # second call: a validated cache hit
+                    assert P.dcsrmv(P.OP_NONE, 1.0, m, n, nnz, d_v, d_ci, d_rp, d, xd, 0.0, yd) == 0
+                torch.cuda.synchronize()
+                so, yr = oracle.dcsrmv(-1, 0, 1.0, m, nnz, v, ci, rp, x, 0.0, np.zeros(m))
+                assert np.array_equal(yd.cpu().numpy(), yr)
+    finally:
+        L.aoclsparse_mi355_set_pointer_mode(P.PTR_AUTO)
+
+
+# --------------------------------------------------------------------------------------------------
+# reference vector: triangular aoclsparse_?mv on a rectangular matrix (mv_tests.cpp:344-388)
+# --------------------------------------------------------------------------------------------------
+def test_mv_triangular_rectangular_reference_kat(kats):
+    k = kats["mv_tri"]
+    m, n = k["m"], k["n"]
+    for base in (0, 1):
+        rp, ci = np.array(k["row_ptr"], np.int32) + base, np.array(k["col_ind"], np.int32) + base
+        x = np.array(k["x"], np.float64)
+        for dtype, mvf in ((np.float64, P.dmv), (np.float32, P.smv)):
+            v = np.array(k["val"], dtype)
+            for fill, gold in ((P.FILL_LOWER, k["exp_y_l"]), (P.FILL_UPPER, k["exp_y_u"])):
+                A = P.Matrix(base, m, n, rp, ci, v)  # a fresh handle per fill mode, as the reference test does
+                d = P.Descr(base=base, mtype=P.TYPE_TRIANGULAR, fill=fill)
+                for on_device in (False, True):
+                    y = np.full(m, np.nan, dtype)  # beta = 0: y is overwritten, never read
+                    xx = x.astype(dtype)
+                    if on_device:
+                        yd = dev(y)
+                        assert mvf(P.OP_NONE, k["alpha"], A, d, dev(xx), k["beta"], yd) == 0
+                        torch.cuda.synchronize()
+                        y = yd.cpu().numpy()
+                    else:
+                        assert mvf(P.OP_NONE, k["alpha"], A, d, xx, k["beta"], y) == 0
+                    assert np.array_equal(y, np.array(gold, dtype)), (base, dtype, fill, on_device)

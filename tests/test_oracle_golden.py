@@ -632,3 +632,18 @@ def test_sorv_kats(kats):
             assert np.allclose(x, k["x_iter10_then_alpha0"], rtol=tol, atol=tol)
     st, _ = oracle.dsorv(2, 0, [0, 1, 2], [0, 0], [1.0, 1.0], 1.0, 1.0, np.zeros(2), np.zeros(2))
     assert st == 5  # second row has no diagonal
+
+
+def test_mv_triangular_rectangular_kat(kats):
+    """mv_tests.cpp:344-388 (test_mv_success): aoclsparse_?mv with a triangular descriptor on a 5 x 4 matrix, lower and
+    upper fill; the oracle's triangular product on the clean CSR must return the reference's exp_y_l / exp_y_u."""
+    k = kats["mv_tri"]
+    m, n = k["m"], k["n"]
+    rp, ci, v = np.array(k["row_ptr"], np.int32), np.array(k["col_ind"], np.int32), np.array(k["val"], np.float64)
+    o = oracle.dcsr_optimize(m, n, len(v), k["base"], rp, ci, v)
+    assert o["status"] == 0
+    x = np.array(k["x"], np.float64)
+    for fill, gold in ((0, k["exp_y_l"]), (1, k["exp_y_u"])):
+        st, y = oracle.dcsrmv_special("tri", k["base"], k["alpha"], m, n, 0, fill, o["val"], o["ind"], o["ptr"], o["idiag"],
+                                      o["iurow"], x, k["beta"], np.full(m, np.nan))
+        assert st == 0 and np.array_equal(y, np.array(gold, np.float64))

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""TRSV schedule timings on the config-5 factors (diagnostic; one JSON line per measurement)."""
+import json, os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import __graft_entry__ as entry, oracle, standins
+from bench import timed_laps
+pkg = entry.load_package(); L = pkg.lib()
+L.aoclsparse_mi355_set_pointer_mode(pkg.PTR_DEVICE)
+dev = torch.device("cuda", 0)
+cases = [("lap1000", lambda: entry.laplace5(1000))]
+if "--small" not in sys.argv:
+    cases.append(("shell", standins.shell_like))
+for title, gen in cases:
+    m, rp, ci, v = gen()
+    st, lu, dg = oracle.dilu0(m, 0, rp, ci, v)
+    A = pkg.Matrix(0, m, m, rp, ci, lu)
+    dl = pkg.Descr(mtype=pkg.TYPE_TRIANGULAR, fill=pkg.FILL_LOWER, diag=pkg.DIAG_UNIT)
+    assert L.aoclsparse_set_sv_hint(A.h, pkg.OP_NONE, dl.h, 100) == 0 and L.aoclsparse_optimize(A.h) == 0
+    lv = A.trsv_levels(pkg.FILL_LOWER)
+    o = oracle.dcsr_optimize(m, m, len(lu), 0, rp, ci, lu)
+    b = np.random.default_rng(2).uniform(-1, 1, m)
+    st, xr = oracle.dtrsv("l", 1.0, m, 0, lu, ci, rp, o["idiag"], b, True)
+    bd, xd = torch.from_numpy(b).to(dev), torch.zeros(m, dtype=torch.float64, device=dev)
+    for kid in (3, -1):
+        lp = timed_laps(pkg, lambda: pkg.dtrsv(pkg.OP_NONE, 1.0, A, dl, bd, xd, kid=kid), 10, 2)
+        torch.cuda.synchronize()
+        print(json.dumps({"sys": title, "levels": lv, "kid": kid, "env_sf": os.environ.get("AOCLSPARSE_MI355_TRSV_SYNCFREE"),
+                          "env_wv": os.environ.get("AOCLSPARSE_MI355_TRSV_WAVES"), "ms_median": float(np.median(lp)),
+                          "us_per_level": float(np.median(lp)) * 1e3 / lv,
+                          "bit_exact": bool(np.array_equal(xd.cpu().numpy(), xr))}), flush=True)
