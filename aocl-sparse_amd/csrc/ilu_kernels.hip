@@ -140,6 +140,14 @@ aoclsparse_status launch_ilu0_level(hipStream_t s, int base, aoclsparse_int nrow
     if(nrows <= 0)
         return aoclsparse_status_success;
     const size_t lds = (sizeof(T) + sizeof(aoclsparse_int)) * (size_t)maxlen;
+    // the row lives in LDS: beyond the 64 KB a kernel gets by default the limit has to be raised explicitly, and a row
+    // that does not fit the CU's 160 KB at all (> ~13,600 fp64 entries) cannot be factorised by this kernel
+    constexpr size_t LDS_DEFAULT = 64u << 10, LDS_MAX = 160u << 10;
+    if(lds > LDS_MAX)
+        return aoclsparse_status_not_implemented;
+    if(lds > LDS_DEFAULT)
+        MI355_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ilu0_level_kernel<T>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
     hipLaunchKernelGGL((ilu0_level_kernel<T>), dim3(nrows), dim3(64), lds, s, base, rows, row_ptr, col, val, diag,
                        maxlen, error);
     MI355_HIP_TRY(hipGetLastError());

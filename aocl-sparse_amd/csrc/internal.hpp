@@ -213,7 +213,8 @@ struct SpmvPlan
     SellPlan       sell;
     MergePlan      merge;
     MmGroups       mm;
-    int            mv_calls = 0; // products served from this plan without a SELL copy (promotion counter)
+    std::atomic<int> mv_calls{0}; // products served from this plan without a SELL copy (promotion counter;
+                                  // concurrent ?mv calls on one handle are allowed, as in the reference)
 };
 
 // TRSV plan of one (triangle, op) pair (trsv_api.cpp / trsv_kernels.hip): the strict triangle

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <thread>
 
 using namespace mi355;
 
@@ -431,15 +432,82 @@ static aoclsparse_int choose_tile(aoclsparse_int /*m*/, aoclsparse_int nnz)
     return (forced == 2048 || forced == 1024 || forced == 512 ? forced : automatic) | xcd;
 }
 
+// plan_rows on the row range [r0, r1): block entries are appended to `out` (no terminal entry)
+static void plan_rows_range(aoclsparse_int r0, aoclsparse_int r1, aoclsparse_index_base base, aoclsparse_int tile,
+                            const aoclsparse_int *row_ptr, std::vector<aoclsparse_int> &out, aoclsparse_int &lr,
+                            aoclsparse_int &mx)
+{
+    aoclsparse_int i = r0;
+    while(i < r1)
+    {
+        const aoclsparse_int start = row_ptr[i] - base;
+        aoclsparse_int       j     = i;
+        while(j < r1 && j - i < spmv_maxrows(tile) && (row_ptr[j + 1] - base) - start <= tile)
+            j++;
+        if(j == i) // single row longer than a tile
+        {
+            j = i + 1;
+            lr++;
+        }
+        for(aoclsparse_int r = i; r < j; r++)
+            mx = std::max(mx, row_ptr[r + 1] - row_ptr[r]);
+        out.push_back(i);
+        out.push_back(start);
+        i = j;
+    }
+}
+
 aoclsparse_status build_spmv_plan(aoclsparse_int m, aoclsparse_int nnz, aoclsparse_index_base base,
                                   const aoclsparse_int *row_ptr_host, SpmvPlan &plan)
 {
     try
     {
-        std::vector<aoclsparse_int> blk(2 * ((size_t)m + 2));
-        plan.tile    = choose_tile(m, nnz);
-        plan.nblocks = plan_rows(m, base, plan.tile & ~1, row_ptr_host, blk.data(), &plan.long_rows,
-                                 &plan.max_row_nnz);
+        // Big matrices: the greedy packing runs on 16 fixed row chunks in parallel (the chunking does not depend on
+        // the thread count, so the plan is reproducible; a chunk edge merely ends a block early).  The one-shot raw
+        // aoclsparse_?csrmv on host arrays builds a plan per call: a sequential pass over 16.8 M rows into a zeroed
+        // 2(m+2)-int buffer cost ~50 ms there, more than sending the matrix over PCIe (profiles/r2/h2d_probe.jsonl).
+        plan.tile                 = choose_tile(m, nnz);
+        const aoclsparse_int tile = plan.tile & ~1;
+        const int            nchunks = m >= (1 << 20) ? 16 : 1;
+        std::vector<std::vector<aoclsparse_int>> part(nchunks);
+        std::vector<aoclsparse_int>              lrs(nchunks, 0), mxs(nchunks, 0);
+        auto work = [&](int c) {
+            const aoclsparse_int r0 = (aoclsparse_int)((long long)m * c / nchunks);
+            const aoclsparse_int r1 = (aoclsparse_int)((long long)m * (c + 1) / nchunks);
+            part[c].reserve((size_t)(r1 - r0) / 64 + 16);
+            plan_rows_range(r0, r1, base, tile, row_ptr_host, part[c], lrs[c], mxs[c]);
+        };
+        if(nchunks == 1)
+            work(0);
+        else
+        {
+            const unsigned hw = std::thread::hardware_concurrency();
+            const int      nt = (int)std::min<unsigned>(8u, hw ? hw : 1u);
+            std::vector<std::thread> th;
+            std::atomic<int>         next{0};
+            for(int t = 0; t < nt; t++)
+                th.emplace_back([&] {
+                    for(int c = next.fetch_add(1); c < nchunks; c = next.fetch_add(1))
+                        work(c);
+                });
+            for(auto &t : th)
+                t.join();
+        }
+        std::vector<aoclsparse_int> blk;
+        size_t                      total = 2;
+        for(auto &p : part)
+            total += p.size();
+        blk.reserve(total);
+        plan.long_rows = 0, plan.max_row_nnz = 0;
+        for(int c = 0; c < nchunks; c++)
+        {
+            blk.insert(blk.end(), part[c].begin(), part[c].end());
+            plan.long_rows += lrs[c];
+            plan.max_row_nnz = std::max(plan.max_row_nnz, mxs[c]);
+        }
+        plan.nblocks = (aoclsparse_int)(blk.size() / 2);
+        blk.push_back(m);
+        blk.push_back(row_ptr_host[m] - base);
         aoclsparse_status st = plan.rowblocks.upload(
             blk.data(), sizeof(aoclsparse_int) * 2 * (size_t)(plan.nblocks + 1), Runtime::get().stream());
         if(st != aoclsparse_status_success)
@@ -521,6 +589,7 @@ aoclsparse_status build_sell(const aoclsparse_int *row_ptr_host, const DeviceCsr
     return aoclsparse_status_success;
 }
 
+constexpr int MERGE_AUTO_TILES = 32; // auto: merge-path once the longest row spans this many LDS tiles
 // 0 auto, 1 CSR-Adaptive always, 2 merge-path whenever it can serve the request
 // (read at plan-build time, i.e. once per handle and operator)
 static int spmv_kernel_choice()
@@ -541,9 +610,20 @@ aoclsparse_status build_merge_plan(aoclsparse_int m, aoclsparse_int nnz, aoclspa
     const int choice = spmv_kernel_choice();
     if(m <= 0 || nnz <= 0)
         return aoclsparse_status_success;
-    // auto never selects it: measured on the MI355X it loses to the row-block kernel on both power-law stand-ins
-    // (44.2 vs 29.5 us web-like, 14.3 vs 11.4 us circuit-like -- DESIGN.md section 5.2), so it is opt-in
-    if(choice != 2)
+    // Automatic choice (aoclsparse_optimize / first product, from the row-length statistics of the row-block plan):
+    // the row-block kernel gives a row longer than one LDS tile to ONE workgroup, which walks it tile by tile --
+    // fine for rows of a few tiles (web-like: longest row 2,908 = 6 tiles; merge-path loses there, 44.2 vs 29.5 us,
+    // and on circuit-like, 14.3 vs 11.4 us), a serial tail once a row spans tens of tiles.  Merge-path cuts such rows
+    // into 1,024-item pieces spread over the chip, so it is selected when the longest row exceeds
+    // MERGE_AUTO_TILES tiles (tools/exp_arrow.py, profiles/r2/merge_vs_adaptive.jsonl; AOCLSPARSE_MI355_MERGE_AUTO
+    // overrides the factor, 0 disables).
+    static const int auto_tiles = [] {
+        const char *e = getenv("AOCLSPARSE_MI355_MERGE_AUTO");
+        return e ? atoi(e) : MERGE_AUTO_TILES;
+    }();
+    const bool auto_pick = choice == 0 && auto_tiles > 0 && plan.long_rows > 0
+                           && (long long)plan.max_row_nnz >= (long long)auto_tiles * (plan.tile & ~1);
+    if(choice != 2 && !auto_pick)
         return aoclsparse_status_success;
     const long long             items  = (long long)m + nnz;
     const aoclsparse_int        ntiles = (aoclsparse_int)((items + MP_ITEMS - 1) / MP_ITEMS);

@@ -195,10 +195,10 @@ aoclsparse_status Runtime::staging(int slot, size_t bytes, void **out)
 }
 
 // ---- pipelined pageable <-> device copies -------------------------------------------------------------------------
-// A plain hipMemcpy from pageable memory stages through the runtime's own pinned buffers with ONE host thread and
-// measured ~20 GB/s here (58.8 ms for the 1.2 GB of the 4096^2 Laplacian, profiles/r1).  PCIe Gen5 x16 gives ~55 GB/s
-// when the pinned side is fed fast enough, which takes several host threads: a small pool copies chunk i+1 into a
-// pinned ring slot while the DMA engine drains chunk i.
+// Opt-in (AOCLSPARSE_MI355_PIPELINED_COPY=1).  Round 1 read the 58.8 ms of a one-shot host-array csrmv on the 4096^2
+// Laplacian as a 20 GB/s copy; the probe of round 2 (tools/h2d_probe.hip) shows the copy itself at 56 GB/s -- the time
+// was host-side plan construction (matrix.cpp: build_spmv_plan, now parallel).  The ring stays for hosts whose runtime
+// stages pageable memory with one thread: a small pool copies chunk i+1 into a pinned slot while the DMA drains chunk i.
 namespace
 {
 constexpr size_t PIPE_CHUNK = 16u << 20; // bytes per ring slot
@@ -295,6 +295,7 @@ struct PinnedRing
 {
     void      *slot[PIPE_SLOTS] = {nullptr};
     hipEvent_t done[PIPE_SLOTS] = {nullptr};
+    bool       busy[PIPE_SLOTS] = {false}; // an event was recorded for a DMA that reads / writes this slot
     bool       ok = false, tried = false;
     std::mutex lock; // one pipelined transfer at a time
     bool       ensure()
@@ -320,9 +321,13 @@ aoclsparse_status Runtime::h2d(void *dev, const void *host, size_t bytes)
 {
     if(!bytes)
         return aoclsparse_status_success;
+    // OFF by default: measured on the MI355X boxes (tools/h2d_probe.hip, profiles/r2/h2d_probe.jsonl) a plain
+    // hipMemcpy of pageable memory already runs at 56 GB/s -- the ROCm 7.2 runtime pipelines it itself -- against
+    // 51-54 GB/s for this ring with 4-8 threads; AOCLSPARSE_MI355_PIPELINED_COPY=1 enables it for hosts where the
+    // runtime's own staging is slower.
     static const bool off = [] {
         const char *e = std::getenv("AOCLSPARSE_MI355_PIPELINED_COPY");
-        return e && std::atoi(e) == 0;
+        return !(e && std::atoi(e) != 0);
     }();
     std::unique_lock<std::mutex> l(g_ring.lock, std::defer_lock);
     if(!off && bytes >= PIPE_MIN)
@@ -339,15 +344,15 @@ aoclsparse_status Runtime::h2d(void *dev, const void *host, size_t bytes)
     {
         const int    k   = i % PIPE_SLOTS;
         const size_t len = bytes - off_b < PIPE_CHUNK ? bytes - off_b : PIPE_CHUNK;
-        if(i >= PIPE_SLOTS)
-            MI355_HIP_TRY(hipEventSynchronize(g_ring.done[k])); // the DMA that last read this slot has finished
+        if(g_ring.busy[k]) // the DMA that last read this slot (this transfer's or an earlier one's) must have finished
+            MI355_HIP_TRY(hipEventSynchronize(g_ring.done[k]));
         CopyPool::get().run(g_ring.slot[k], src + off_b, len);
         MI355_HIP_TRY(hipMemcpyAsync(dst + off_b, g_ring.slot[k], len, hipMemcpyHostToDevice, stream()));
         MI355_HIP_TRY(hipEventRecord(g_ring.done[k], stream()));
+        g_ring.busy[k] = true;
         off_b += len;
     }
-    // the ring is reused by the next transfer: its first PIPE_SLOTS chunks wait on these events again, which is
-    // enough -- but a caller may free `host` right after we return, and the pinned copies are already complete
+    // `host` may be freed right after we return: every byte of it has been copied into pinned memory already
     return aoclsparse_status_success;
 }
 
@@ -357,7 +362,7 @@ aoclsparse_status Runtime::d2h(void *host, const void *dev, size_t bytes)
         return aoclsparse_status_success;
     static const bool off = [] {
         const char *e = std::getenv("AOCLSPARSE_MI355_PIPELINED_COPY");
-        return e && std::atoi(e) == 0;
+        return !(e && std::atoi(e) != 0);
     }();
     std::unique_lock<std::mutex> l(g_ring.lock, std::defer_lock);
     if(!off && bytes >= PIPE_MIN)
@@ -369,7 +374,11 @@ aoclsparse_status Runtime::d2h(void *host, const void *dev, size_t bytes)
     }
     // any earlier use of the ring slots (an h2d still draining) must be over before the DMA writes into them
     for(int k = 0; k < PIPE_SLOTS; k++)
-        MI355_HIP_TRY(hipEventSynchronize(g_ring.done[k]));
+        if(g_ring.busy[k])
+        {
+            MI355_HIP_TRY(hipEventSynchronize(g_ring.done[k]));
+            g_ring.busy[k] = false;
+        }
     const char  *src = static_cast<const char *>(dev);
     char        *dst = static_cast<char *>(host);
     const size_t nchunks = (bytes + PIPE_CHUNK - 1) / PIPE_CHUNK;

@@ -225,7 +225,7 @@ aoclsparse_status mv_t(aoclsparse_operation op, const T *alpha, aoclsparse_matri
         // aoclsparse_memory_usage_minimal and AOCLSPARSE_MI355_SELL=0 forbid it.
         const bool promote = !plan->sell.valid && !plan->sell.tried && !plan->merge.valid && !is_complex_type(A->val_type)
                              && A->mem_policy == aoclsparse_memory_usage_unrestricted
-                             && ++plan->mv_calls >= SELL_PROMOTE_CALLS;
+                             && plan->mv_calls.fetch_add(1, std::memory_order_relaxed) + 1 >= SELL_PROMOTE_CALLS;
         if(promote || (plan->sell.wanted && !plan->sell.valid)) // or: values changed since the SELL copy was built
         {
             std::unique_lock<std::shared_mutex> w(A->guard);

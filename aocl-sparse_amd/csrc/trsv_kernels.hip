@@ -455,54 +455,18 @@ __global__ __launch_bounds__(64 * WV) void trsv_slice_kernel(
         }
         return got;
     };
-    // staged entries: consume in chain order whatever is solved; every pass re-reads ALL still-pending entries in
-    // one batch (one round trip however many there are), so that when the newest dependency arrives the older ones
-    // are long in registers -- polling entry by entry would put one round trip per entry on the critical path
-    const int ns   = n < PF ? n : PF;
-    int       next = 0;
-    unsigned  idle = 0;
-    while(next < ns && !dead)
-    {
-        const int before = next;
+    // staged entries in chain order.  (Re-reading all pending entries in one batch per pass with a back-off sleep was
+    // tried and lost: 4.77 vs 1.69 ms on the Laplacian factor, 11.8 vs 13.2 ms on the shell-like one -- the sleeps put
+    // their own latency on the critical path; profiles/r2/trsv_schedules.txt.)
 #pragma unroll
-        for(int e = 0; e < PF; e++)
-            if(e == next && e < ns && bits[e] != tag<T>::value)
-            {
-                T xv;
-                __builtin_memcpy(&xv, &bits[e], sizeof(T));
-                xi = neg_fma(v[e], xv, xi);
-                next++;
-            }
-        if(next == ns)
-            break;
-        if(next == before)
+    for(int e = 0; e < PF; e++)
+        if(e < n)
         {
-            // nothing new: back off (rows far ahead of the solve front must not flood the memory system with polls)
-            idle++;
-            if(idle < 8)
-                __builtin_amdgcn_s_sleep(1);
-            else if(idle < 64)
-                __builtin_amdgcn_s_sleep(4);
-            else
-                __builtin_amdgcn_s_sleep(16);
-            if((idle & 255u) == 0)
-            {
-                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-                if(t0 == 0)
-                    t0 = now;
-                else if(now - t0 > TRSV_WAIT_TICKS)
-                    dead = true;
-            }
+            const B got = wait(q[e], bits[e]);
+            T       xv;
+            __builtin_memcpy(&xv, &got, sizeof(T));
+            xi = neg_fma(v[e], xv, xi);
         }
-        else
-            idle = 0, t0 = 0;
-        // rows far ahead of the front (nothing solved yet) poll their OLDEST dependency only; once the front is
-        // here (something was consumed) every pending entry is refreshed
-#pragma unroll
-        for(int e = 0; e < PF; e++)
-            if(e >= next && e < ns && bits[e] == tag<T>::value && (e == next || next > 0 || idle < 2))
-                bits[e] = peek(q[e]);
-    }
     for(int p = p0 + PF; p < pe && !dead; p++)
     {
         const int qq  = pind[p];

@@ -414,6 +414,11 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import standins
         rows = []
+        try:  # fabric traffic of the two power-law matrices (PMC cannot be read from inside the run)
+            with open(os.path.join(ROOT, "profiles", "r2", "irregular_traffic.json")) as f:
+                pmc_irr = json.load(f)
+        except (OSError, ValueError):
+            pmc_irr = {}
         names = ["circuit-like", "web-like"] + ([] if args.small else ["shell-like", "flan-like"])
         for name in names:
             label, mm_, rp, ci, v = standins.load(name)
@@ -436,6 +441,7 @@ def main():
             err = np.abs(got - yr)
             bound = (2 * np.ceil(np.log2(np.maximum(lens, 2))) + 4 + lens / 256.0) * np.finfo(np.float64).eps * scale
             b = spmv_bytes(mm_, mm_, nz)
+            tr = (pmc_irr.get(label) or {}).get("traffic_bytes_per_launch")
             stc, secs, _ = oracle.dcsrmv_bench(-1, 0, mm_, mm_, nz, v, ci, rp, xr,
                                                max(1, min(cpu_physical, oracle.max_threads())), 5)
             unpin()
@@ -443,15 +449,50 @@ def main():
                          "kernel": {1: "csr-adaptive", 2: "merge-path", 3: "sell-64"}.get(inf.kernel, str(inf.kernel)),
                          "summation_order": {0: "scalar (ref_csrmv_gn)", 1: "4-lane AVX2", 2: "8-lane AVX-512"}.get(inf.order),
                          "us": round(ms * 1e3, 3), "stats_ms": quartiles(lp), "gflops": round(2.0 * nz / ms / 1e6, 2),
-                         "roofline": roofline(b, ms),
+                         "roofline": roofline(b, ms, tr, traffic_source="profiles/r2/irregular_traffic.json" if tr else None,
+                                              traffic_gbs=round(tr / ms / 1e6, 1) if tr else None,
+                                              traffic_frac_of_peak=round(tr / ms / 1e6 / HBM_PEAK_GBS, 4) if tr else None),
                          "bit_exact_rows_within_tile": bool(np.array_equal(got[within], yr[within])),
                          "rows_outside_bit_exact_regime": int((~within).sum()),
                          "long_rows_within_bound": bool(np.all(err <= bound + 1e-300)),
                          "max_abs_diff": float(err.max()),
                          "cpu_all_cores_gflops": round(2.0 * nz / float(np.median(secs)) / 1e9, 2)})
             del Am, xd, ydv
+        # the third kernel aoclsparse_optimize can choose: merge-path, for matrices whose longest row spans tens of LDS
+        # tiles (none of the four above does): a tridiagonal matrix with four rows of ~170 k entries
+        n3 = 300000
+        rng = np.random.default_rng(3)
+        longs = set(int(t) for t in rng.choice(n3, size=4, replace=False))
+        parts, rp3 = [], np.zeros(n3 + 1, np.int64)
+        tri = np.stack([np.arange(n3) - 1, np.arange(n3), np.arange(n3) + 1], axis=1)
+        for i in range(n3):
+            c = np.unique(np.concatenate([rng.integers(0, n3, size=250000), [i]])) if i in longs else tri[i][(tri[i] >= 0) & (tri[i] < n3)]
+            parts.append(c)
+            rp3[i + 1] = rp3[i] + len(c)
+        ci3 = np.concatenate(parts).astype(np.int32)
+        rp3 = rp3.astype(np.int32)
+        v3 = rng.uniform(-1, 1, len(ci3))
+        A3 = pkg.Matrix(0, n3, n3, rp3, ci3, v3)
+        assert L.aoclsparse_set_mv_hint(A3.h, pkg.OP_NONE, descr.h, 1000) == 0 and L.aoclsparse_optimize(A3.h) == 0
+        x3 = rng.uniform(-1, 1, n3)
+        x3d, y3d = torch.from_numpy(x3).to(device), torch.zeros(n3, dtype=torch.float64, device=device)
+        lp = timed_laps(pkg, lambda: pkg.dmv(pkg.OP_NONE, 1.0, A3, descr, x3d, 0.0, y3d), 50, 5)
+        so, y3r = oracle.dcsrmv(0, 0, 1.0, n3, len(v3), v3, ci3, rp3, x3, 0.0, np.zeros(n3))
+        lens3 = np.diff(rp3)
+        sc3 = np.add.reduceat(np.abs(v3 * x3[ci3]), rp3[:-1])
+        e3 = np.abs(y3d.cpu().numpy() - y3r)
+        inf3 = A3.spmv_info()
+        demo = {"matrix": "tridiagonal + 4 rows of ~170 k entries (m=%d, nnz=%d)" % (n3, len(v3)),
+                "kernel": {1: "csr-adaptive", 2: "merge-path", 3: "sell-64"}.get(inf3.kernel), "us": round(float(np.mean(lp)) * 1e3, 2),
+                "roofline": roofline(spmv_bytes(n3, n3, len(v3)), float(np.mean(lp))),
+                "rows_not_bit_exact": int(np.sum(y3d.cpu().numpy() != y3r)), "merge_tiles": int((n3 + len(v3)) // 1024 + 1),
+                "note": "a row is bit-exact unless a 1,024-item tile boundary cuts it (at most one row per tile)",
+                "all_rows_within_bound": bool(np.all(e3 <= (lens3 + lens3 / 1024.0 + 8) * np.finfo(np.float64).eps * sc3 + 1e-300))}
+        unpin()
         return {"workload": "BASELINE configs[2]: aoclsparse_dmv after aoclsparse_set_mv_hint + aoclsparse_optimize "
-                            "(format / kernel chosen by optimize)", "matrices": rows}
+                            "(format / kernel chosen by optimize from the row-length statistics: SELL-64 when padding "
+                            "<= 1.15x, merge-path when the longest row spans >= 32 LDS tiles, else CSR-Adaptive)",
+                "matrices": rows, "merge_path_selection": demo}
 
     run_leg("mix", leg_mix)
 

@@ -499,3 +499,80 @@ def test_mv_triangular_rectangular_reference_kat(kats):
                     else:
                         assert mvf(P.OP_NONE, k["alpha"], A, d, xx, k["beta"], y) == 0
                     assert np.array_equal(y, np.array(gold, dtype)), (base, dtype, fill, on_device)
+
+
+# --------------------------------------------------------------------------------------------------
+# the third kernel aoclsparse_optimize can choose: merge-path for matrices with very long rows
+# --------------------------------------------------------------------------------------------------
+def test_optimize_selects_merge_path_for_very_long_rows():
+    """Row-length statistics decide the SpMV kernel: a tridiagonal matrix with two rows of ~45,000 entries (> 32 LDS
+    tiles) gets merge-path tiles, the same matrix with rows of ~4,000 entries stays on CSR-Adaptive.  Rows inside one
+    tile are bit-exact (scalar order); a row cut by tile boundaries is within (len + pieces + 8) eps sum|a x|."""
+    n = 120000
+    rng = np.random.default_rng(21)
+    tri = np.stack([np.arange(n) - 1, np.arange(n), np.arange(n) + 1], axis=1)
+    for length, want in ((60000, 2), (4000, 1)):
+        longs = {777, 90001}
+        parts, rp = [], np.zeros(n + 1, np.int64)
+        for i in range(n):
+            c = np.unique(np.concatenate([rng.integers(0, n, size=length), [i]])) if i in longs else tri[i][(tri[i] >= 0) & (tri[i] < n)]
+            parts.append(c)
+            rp[i + 1] = rp[i] + len(c)
+        ci, rp = np.concatenate(parts).astype(np.int32), rp.astype(np.int32)
+        v = rng.uniform(-1, 1, len(ci))
+        A = P.Matrix(0, n, n, rp, ci, v)
+        d = P.Descr()
+        os.environ["AOCLSPARSE_MI355_SELL"] = "0"
+        try:
+            assert L.aoclsparse_set_mv_hint(A.h, P.OP_NONE, d.h, 100) == 0 and L.aoclsparse_optimize(A.h) == 0
+        finally:
+            os.environ.pop("AOCLSPARSE_MI355_SELL", None)
+        info = A.spmv_info()
+        assert info.kernel == want, (length, info.kernel, info.max_row_nnz, info.tile)
+        x = rng.uniform(-1, 1, n)
+        yd = torch.zeros(n, dtype=torch.float64, device="cuda")
+        assert P.dmv(P.OP_NONE, 1.0, A, d, dev(x), 0.0, yd) == 0
+        torch.cuda.synchronize()
+        so, yr = oracle.dcsrmv(0, 0, 1.0, n, len(v), v, ci, rp, x, 0.0, np.zeros(n))
+        got, lens = yd.cpu().numpy(), np.diff(rp)
+        if want == 1:
+            assert np.array_equal(got[lens <= 3], yr[lens <= 3])  # row-block kernel: every row inside a tile is exact
+        else:
+            # merge-path: a row is exact unless one of the 1,024-item tile boundaries cuts it (at most one row per tile)
+            ntiles = (n + len(v)) // 1024 + 1
+            assert int(np.sum(got != yr)) <= ntiles + 2
+        scale = np.add.reduceat(np.abs(v * x[ci]), rp[:-1])
+        bound = (lens + lens / 512.0 + 8 + 2 * np.ceil(np.log2(np.maximum(lens, 2)))) * EPS64 * scale
+        assert np.all(np.abs(got - yr) <= bound + 1e-300)
+
+
+# --------------------------------------------------------------------------------------------------
+# host-pointer calls with arrays large enough for the pipelined pinned copies (>= 8 MB each, several chunks)
+# --------------------------------------------------------------------------------------------------
+def test_large_host_pointer_calls_through_the_pinned_ring():
+    """raw aoclsparse_dcsrmv with ALL arrays on the host (three transfers of 21-42 MB back to back through the same
+    ring of pinned slots), then aoclsparse_dmv with host x / y on a handle, then a host-pointer csrmm: results must be
+    the oracle's bits -- a ring slot must never be refilled while an earlier transfer's DMA still reads it."""
+    g = 1024
+    m, rp, ci, v = laplace5(g)
+    rng = np.random.default_rng(31)
+    v = v * rng.uniform(0.5, 1.5, len(v))
+    nnz = len(v)
+    x = rng.uniform(-1, 1, m)
+    d = P.Descr()
+    so, yr = oracle.dcsrmv(-1, 0, 1.0, m, nnz, v, ci, rp, x, 0.0, np.zeros(m), nthreads=4)
+    for rep in range(3):
+        y = np.full(m, np.nan)
+        assert P.dcsrmv(P.OP_NONE, 1.0, m, m, nnz, v, ci, rp, d, x, 0.0, y) == 0
+        assert np.array_equal(y, yr), "raw host-array csrmv, repetition %d" % rep
+    A = P.Matrix(0, m, m, rp, ci, v)
+    assert L.aoclsparse_set_mv_hint(A.h, P.OP_NONE, d.h, 10) == 0 and L.aoclsparse_optimize(A.h) == 0
+    y = np.full(m, np.nan)
+    assert P.dmv(P.OP_NONE, 1.0, A, d, x, 0.0, y) == 0
+    assert np.array_equal(y, yr)
+    n = 8  # csrmm, host B and C: 8.4 MB each way per operand
+    B, C0 = rng.uniform(-1, 1, m * n), rng.uniform(-1, 1, m * n)
+    C = C0.copy()
+    assert P.dcsrmm(P.OP_NONE, 2.0, A, d, P.ORDER_COLUMN, B, n, m, -1.0, C, m) == 0
+    so, Cr = oracle.dcsrmm("col", 2.0, 0, v, ci, rp, m, B, n, m, -1.0, C0, m)
+    assert np.array_equal(C, Cr)

@@ -567,6 +567,138 @@ __global__ __launch_bounds__(256) void cpair(int m, const double *__restrict__ v
     }
 }
 
+// ---------------------------------------------------------------- RE: row-major with an ELL-8 copy of A
+// ecol / eval: 8 slots per row (column -1 = padding), so a row's entries sit at an address computed from the row index
+// alone: the chain is {ecol, eval} -> {B rows} (two round trips) instead of row_ptr -> {col, val} -> {B rows}.
+template <int R, bool NT>
+__global__ __launch_bounds__(256) void re(int m, const double *__restrict__ eval, const int *__restrict__ ecol,
+                                          const double *__restrict__ B, int n, int ldb, double *__restrict__ C, int ldc,
+                                          int chunk)
+{
+    const int w  = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i0 = (xcd_row(blockIdx.x, chunk) * 4 + w) * R;
+    const int j  = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
+    if(i0 >= m || j >= n)
+        return;
+    const double *Bj = B + j;
+    int           c[R][8];
+    double        v[R][8];
+#pragma unroll
+    for(int q = 0; q < R; q++)
+#pragma unroll
+        for(int u = 0; u < 8; u++)
+        {
+            const bool ok = i0 + q < m;
+            c[q][u]       = ok ? ecol[(size_t)(i0 + q) * 8 + u] : -1;
+            v[q][u]       = ok ? eval[(size_t)(i0 + q) * 8 + u] : 0.0;
+        }
+    v2d b[R][8];
+#pragma unroll
+    for(int q = 0; q < R; q++)
+#pragma unroll
+        for(int u = 0; u < 8; u++)
+            if(c[q][u] >= 0)
+                b[q][u] = *reinterpret_cast<const v2d *>(Bj + (size_t)c[q][u] * ldb);
+#pragma unroll
+    for(int q = 0; q < R; q++)
+    {
+        if(i0 + q >= m)
+            break;
+        double a0 = 0, a1 = 0;
+#pragma unroll
+        for(int u = 0; u < 8; u++)
+            if(c[q][u] >= 0)
+                a0 = fma(v[q][u], b[q][u].x, a0), a1 = fma(v[q][u], b[q][u].y, a1);
+        v2d o;
+        o.x = a0, o.y = a1;
+        v2d *cp = reinterpret_cast<v2d *>(C + (size_t)(i0 + q) * ldc + j);
+        if(NT)
+            __builtin_nontemporal_store(o, cp);
+        else
+            *cp = o;
+    }
+}
+
+// ---------------------------------------------------------------- RP: persistent waves, ELL-W copy, software pipeline
+// Every wave walks rows base + wl, base + wl + S, ... of its XCD's row range.  ecolw / evalw hold exactly W slots per row
+// (padding: column = the row itself, value 0 -- loads stay unconditional so the compiler can count them, the FMA of a
+// padding slot is skipped).  Iteration k issues the B loads of row k+1 BEFORE it waits for those of row k, and the
+// scalar loads of row k+2's slots before that: the only wait on the critical path is the B round trip itself.
+template <int W, bool NT>
+__global__ __launch_bounds__(256) void rpipe(int m, const double *__restrict__ evalw, const int *__restrict__ ecolw,
+                                          const int *__restrict__ rlen, const double *__restrict__ B, int n, int ldb,
+                                          double *__restrict__ C, int ldc, int waves_per_xcd)
+{
+    const int w    = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int xcd  = blockIdx.x & 7;
+    const int wl   = (int)(blockIdx.x >> 3) * 4 + w; // wave index inside its XCD
+    const int per  = (m + 7) / 8;
+    const int lo   = xcd * per, hi = min(m, lo + per);
+    const int j    = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
+    if(j >= n)
+        return;
+    const double *Bj = B + j;
+    int           i  = lo + wl;
+    if(i >= hi)
+        return;
+    int    c0[W], c1[W];
+    double v0[W], v1[W];
+    v2d    b0[W], b1[W];
+    int    l0, l1;
+    auto   meta = [&](int row, int *c, double *v, int &len) {
+#pragma unroll
+        for(int u = 0; u < W; u++)
+            c[u] = ecolw[(size_t)row * W + u], v[u] = evalw[(size_t)row * W + u];
+        len = rlen[row];
+    };
+    auto issue = [&](const int *c, v2d *b) {
+#pragma unroll
+        for(int u = 0; u < W; u++)
+            b[u] = *reinterpret_cast<const v2d *>(Bj + (size_t)c[u] * ldb);
+    };
+    auto finish = [&](int row, const double *v, const v2d *b, int len) {
+        double a0 = 0, a1 = 0;
+#pragma unroll
+        for(int u = 0; u < W; u++)
+            if(u < len)
+                a0 = fma(v[u], b[u].x, a0), a1 = fma(v[u], b[u].y, a1);
+        v2d o;
+        o.x = a0, o.y = a1;
+        v2d *cp = reinterpret_cast<v2d *>(C + (size_t)row * ldc + j);
+        if(NT)
+            __builtin_nontemporal_store(o, cp);
+        else
+            *cp = o;
+    };
+    meta(i, c0, v0, l0);
+    issue(c0, b0);
+    int inext = i + waves_per_xcd;
+    if(inext < hi)
+        meta(inext, c1, v1, l1);
+    while(true)
+    {
+        // phase A: row i lives in buffer 0, row inext in buffer 1
+        if(inext < hi)
+            issue(c1, b1);
+        const int i2 = inext + waves_per_xcd;
+        finish(i, v0, b0, l0);
+        if(inext >= hi)
+            break;
+        if(i2 < hi)
+            meta(i2, c0, v0, l0);
+        // phase B: row inext lives in buffer 1, row i2 in buffer 0
+        if(i2 < hi)
+            issue(c0, b0);
+        const int i3 = i2 + waves_per_xcd;
+        finish(inext, v1, b1, l1);
+        if(i2 >= hi)
+            break;
+        if(i3 < hi)
+            meta(i3, c1, v1, l1);
+        i = i2, inext = i3;
+    }
+}
+
 // ---------------------------------------------------------------- helpers
 __global__ void copy_kernel(const v2d *__restrict__ a, v2d *__restrict__ b, size_t n)
 {
@@ -761,6 +893,57 @@ int main(int argc, char **argv)
     RTVAR(8, 2, "RT 8x2 strided tile")
     RTVAR(2, 4, "RT 2x4 strided tile")
     RTVAR(2, 8, "RT 2x8 strided tile")
+    // ELL-8 copy of A (rows here have <= 5 entries)
+    std::vector<int>    ecol((size_t)m * 8, -1);
+    std::vector<double> evalv((size_t)m * 8, 0.0);
+    for(long r = 0; r < m; r++)
+        for(int p = rp[r]; p < rp[r + 1]; p++)
+            ecol[r * 8 + (p - rp[r])] = ci[p], evalv[r * 8 + (p - rp[r])] = v[p];
+    int    *d_ecol;
+    double *d_eval;
+    CHECK(hipMalloc(&d_ecol, ecol.size() * 4));
+    CHECK(hipMalloc(&d_eval, evalv.size() * 8));
+    CHECK(hipMemcpy(d_ecol, ecol.data(), ecol.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_eval, evalv.data(), evalv.size() * 8, hipMemcpyHostToDevice));
+#define REVAR(R, NT, label)                                                                                          \
+    vars.push_back({label, false, [&] {                                                                              \
+                        if(n < 128) return;                                                                          \
+                        int ch; int gx = rowgrid(4 * R, ch);                                                         \
+                        re<R, NT><<<dim3(gx, (n + 127) / 128), 256>>>(im, d_eval, d_ecol, d_B, n, n, d_C, n, ch);    \
+                    }});
+    REVAR(1, false, "RE ell8 R1")
+    REVAR(1, true, "RE ell8 R1 nt")
+    REVAR(2, false, "RE ell8 R2")
+    REVAR(2, true, "RE ell8 R2 nt")
+    // ELL-5 copy (padding: the row's own index, value 0) + row lengths
+    std::vector<int>    ecw((size_t)m * 5), rlenv(m);
+    std::vector<double> evw((size_t)m * 5, 0.0);
+    for(long r = 0; r < m; r++)
+    {
+        rlenv[r] = rp[r + 1] - rp[r];
+        for(int u = 0; u < 5; u++)
+            ecw[r * 5 + u] = u < rlenv[r] ? ci[rp[r] + u] : (int)r, evw[r * 5 + u] = u < rlenv[r] ? v[rp[r] + u] : 0.0;
+    }
+    int    *d_ecw, *d_rlen;
+    double *d_evw;
+    CHECK(hipMalloc(&d_ecw, ecw.size() * 4));
+    CHECK(hipMalloc(&d_rlen, rlenv.size() * 4));
+    CHECK(hipMalloc(&d_evw, evw.size() * 8));
+    CHECK(hipMemcpy(d_ecw, ecw.data(), ecw.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_rlen, rlenv.data(), rlenv.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_evw, evw.data(), evw.size() * 8, hipMemcpyHostToDevice));
+#define RPVAR(NT, WGS_PER_CU, label)                                                                                 \
+    vars.push_back({label, false, [&] {                                                                              \
+                        if(n < 128) return;                                                                          \
+                        const int wgs = 256 * WGS_PER_CU, gy = (n + 127) / 128;                                      \
+                        const int wgx = std::max(8, (wgs / gy) & ~7);                                                \
+                        rpipe<5, NT><<<dim3(wgx, gy), 256>>>(im, d_evw, d_ecw, d_rlen, d_B, n, n, d_C, n, (wgx / 8) * 4); \
+                    }});
+    RPVAR(false, 8, "RP ell5 persistent 8 WG/CU")
+    RPVAR(true, 8, "RP ell5 persistent 8 WG/CU nt")
+    RPVAR(false, 4, "RP ell5 persistent 4 WG/CU")
+    RPVAR(false, 16, "RP ell5 persistent 16 WG/CU")
+    RPVAR(false, 32, "RP ell5 persistent 32 WG/CU")
     vars.push_back({"C0 shipped lane/row 64c chunks", true, [&] {
                         int ch; int gx = rowgrid(256, ch);
                         c0<<<dim3(gx, (n + 63) / 64), 256>>>(im, d_v, d_ci, d_rp, d_B, n, im, d_C, im, ch);

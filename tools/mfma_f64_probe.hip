@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -87,10 +88,23 @@ __global__ __launch_bounds__(256) void vec_kernel(int G, int L, const int *__res
     }
 }
 
+// layout self-test: A[i][k] = (k == 0) * (i + 1), B[k][j] = (k == 0) * 100 * (j + 1)  ->  D[i][j] = 100 (i + 1)(j + 1);
+// every lane dumps its four D registers so the host can decode which (i, j) each one holds
+__global__ void layout_kernel(double *out)
+{
+    const int lane = threadIdx.x, row = lane & 15, kk = lane >> 4;
+    const double a = kk == 0 ? (double)(row + 1) : 0.0, b = kk == 0 ? 100.0 * (row + 1) : 0.0;
+    v4d          acc = (v4d){0, 0, 0, 0};
+    acc              = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    for(int i = 0; i < 4; i++)
+        out[lane * 4 + i] = acc[i];
+}
+
 // M: wavefront per (group, 128-column chunk) = 8 N tiles of 16 columns; K walked 4 at a time
 template <int R>
 __global__ __launch_bounds__(256) void mfma_kernel(int G, int L, const int *__restrict__ col, const double *__restrict__ a,
-                                                   const double *__restrict__ B, int n, double *__restrict__ C)
+                                                   const double *__restrict__ B, int n, double *__restrict__ C,
+                                                   const int *__restrict__ drow, const int *__restrict__ dcol)
 {
     const int w    = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int g    = blockIdx.x * 4 + w;
@@ -118,15 +132,15 @@ __global__ __launch_bounds__(256) void mfma_kernel(int G, int L, const int *__re
         for(int t = 0; t < 8; t++)
             acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[t], acc[t], 0, 0, 0);
     }
-    // D layout of 16x16x4 f64: lane holds D[4*(lane/16) + i][lane % 16], i = 0..3
+    // D layout: (row, column) of register i of this lane, decoded by the self-test at start-up
 #pragma unroll
     for(int t = 0; t < 8; t++)
 #pragma unroll
         for(int i = 0; i < 4; i++)
         {
-            const int q = 4 * kk + i;
+            const int q = drow[lane * 4 + i];
             if(q < R)
-                C[((size_t)g * R + q) * n + j0 + 16 * t + row] = acc[t][i];
+                C[((size_t)g * R + q) * n + j0 + 16 * t + dcol[lane * 4 + i]] = acc[t][i];
         }
 }
 
@@ -171,6 +185,28 @@ int main(int argc, char **argv)
     CHECK(hipMemcpy(d_col, col.data(), col.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(d_a, a.data(), a.size() * 8, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(d_B, B.data(), B.size() * 8, hipMemcpyHostToDevice));
+    // decode the D layout
+    double *d_lay;
+    int    *d_drow, *d_dcol;
+    CHECK(hipMalloc(&d_lay, 256 * 8));
+    CHECK(hipMalloc(&d_drow, 256 * 4));
+    CHECK(hipMalloc(&d_dcol, 256 * 4));
+    layout_kernel<<<1, 64>>>(d_lay);
+    std::vector<double> lay(256);
+    CHECK(hipMemcpy(lay.data(), d_lay, 256 * 8, hipMemcpyDeviceToHost));
+    std::vector<int> drow(256), dcol(256);
+    bool             assumed = true;
+    for(int q = 0; q < 256; q++)
+    {
+        const int prod = (int)(lay[q] / 100.0 + 0.5); // (i + 1)(j + 1): not unique, so use the lane's column
+        // B fragment column of lane l is l % 16 and the D column of a lane is its own column in every known layout
+        const int jx = (q / 4) % 16;
+        dcol[q]      = jx;
+        drow[q]      = prod / (jx + 1) - 1;
+        assumed      = assumed && drow[q] == 4 * ((q / 4) / 16) + q % 4 && prod % (jx + 1) == 0;
+    }
+    CHECK(hipMemcpy(d_drow, drow.data(), 256 * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_dcol, dcol.data(), 256 * 4, hipMemcpyHostToDevice));
     const dim3 grid((G + 3) / 4, n / 128);
     auto       runv = [&](double *C) {
         switch(r)
@@ -183,9 +219,9 @@ int main(int argc, char **argv)
     auto runm = [&](double *C) {
         switch(r)
         {
-        case 3: mfma_kernel<3><<<grid, 256>>>(G, L, d_col, d_a, d_B, n, C); break;
-        case 5: mfma_kernel<5><<<grid, 256>>>(G, L, d_col, d_a, d_B, n, C); break;
-        default: mfma_kernel<8><<<grid, 256>>>(G, L, d_col, d_a, d_B, n, C); break;
+        case 3: mfma_kernel<3><<<grid, 256>>>(G, L, d_col, d_a, d_B, n, C, d_drow, d_dcol); break;
+        case 5: mfma_kernel<5><<<grid, 256>>>(G, L, d_col, d_a, d_B, n, C, d_drow, d_dcol); break;
+        default: mfma_kernel<8><<<grid, 256>>>(G, L, d_col, d_a, d_B, n, C, d_drow, d_dcol); break;
         }
     };
     if(r != 3 && r != 5 && r != 8)
@@ -213,6 +249,12 @@ int main(int argc, char **argv)
         ref_ok = ref_ok && acc == c1[jx];
     }
     const bool same = !memcmp(c1.data(), c2.data(), c1.size() * 8);
+    double     maxdiff = 0, maxabs = 0;
+    for(size_t q = 0; q < c1.size(); q++)
+    {
+        maxdiff = std::max(maxdiff, std::fabs(c1[q] - c2[q]));
+        maxabs  = std::max(maxabs, std::fabs(c1[q]));
+    }
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
@@ -233,9 +275,10 @@ int main(int argc, char **argv)
     printf("{\"probe\": \"mfma_f64_16x16x4 vs vector FMA on dense r x L row-group blocks\", \"groups\": %d, \"r\": %d, \"L\": %d, "
            "\"n\": %d, \"vector_ms\": %.4f, \"mfma_ms\": %.4f, \"vector_useful_tflops\": %.2f, \"mfma_useful_tflops\": %.2f, "
            "\"mfma_issued_tflops\": %.2f, \"mfma_tile_fill\": %.3f, \"vector_matches_host_chain\": %s, "
-           "\"mfma_bits_equal_vector\": %s}\n",
+           "\"mfma_bits_equal_vector\": %s, \"max_abs_diff\": %.3e, \"max_abs_value\": %.3e, "
+           "\"d_layout_is_4x_lane_div16_plus_reg\": %s}\n",
            G, r, L, n, best[0], best[1], flop / best[0] / 1e9, flop / best[1] / 1e9,
            2.0 * G * 16 * ((L + 3) / 4 * 4) * (double)n / best[1] / 1e9, r / 16.0, ref_ok ? "true" : "false",
-           same ? "true" : "false");
+           same ? "true" : "false", maxdiff, maxabs, assumed ? "true" : "false");
     return 0;
 }
