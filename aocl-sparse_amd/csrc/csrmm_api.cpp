@@ -73,7 +73,158 @@ aoclsparse_status build_mm_groups(const HostCsr &h, SpmvPlan &plan)
     if(st != aoclsparse_status_success)
         return st;
     g.ngroups = ng, g.max_rows = max_rows;
-    g.valid   = true;
+    g.first_host.swap(first);
+    g.valid = true;
+    return aoclsparse_status_success;
+}
+
+// Super-groups: consecutive row groups whose column lists overlap (the nodes of a mesh share most of their
+// neighbours) are merged into one block over the UNION of their columns, so that a wavefront loads every B row of the
+// union once for up to CSRMM_SUPER_ROWS output rows instead of once per group.  A group joins while the block stays
+// within CSRMM_SUPER_ROWS rows / CSRMM_SUPER_UNION columns, its own column list is strictly ascending (then walking
+// the union in ascending order visits every row's entries in that row's CSR order: the FMA chain per output element,
+// hence the bits, do not change) and at least a third of its columns are already in the union.  Values are stored
+// dense per block (rows x padded union, row-major; absent positions are masked out, never multiplied).  Used when the
+// union lists are at least 15 % shorter than the groups' lists in total.
+template <typename T>
+aoclsparse_status build_mm_super(const HostCsr &h, SpmvPlan &plan)
+{
+    MmGroups &g = plan.mm;
+    if(g.super_valid || g.super_tried)
+        return aoclsparse_status_success;
+    g.super_tried = true;
+    // OPT-IN (AOCLSPARSE_MI355_CSRMM_SUPER=1, read when a handle's csrmm plan is built).  Measured on the MI355X
+    // (profiles/r2/csrmm_super_groups.jsonl): bit-exact, 2.3-2.8 x SLOWER than the row-group kernel (shell-like 6.32 vs
+    // 2.71 ms, flan-like 13.6 vs 4.90 ms at 256 columns): the per-(row, entry) mask tests are wave-uniform BRANCHES
+    // (120 per step of 8 union entries against 65 useful FMA pairs) and the 16-row accumulator set halves the occupancy,
+    // which costs more than the 35-50 % fewer B-row loads return.  Kept as a tested, documented negative result.
+    const char *env = getenv("AOCLSPARSE_MI355_CSRMM_SUPER");
+    const bool  off = !(env && atoi(env) != 0);
+    if(off || !g.valid || g.first_host.size() < 3)
+        return aoclsparse_status_success;
+    const aoclsparse_int        ng = (aoclsparse_int)g.first_host.size() - 1, b = h.base;
+    const aoclsparse_int       *first = g.first_host.data();
+    const T                    *hv = static_cast<const T *>(h.val);
+    std::vector<aoclsparse_int> sg_row, sg_u, ucol;
+    std::vector<long long>      sg_a;
+    std::vector<unsigned int>   umask;
+    std::vector<T>              aval;
+    long long                   sum_union = 0, sum_lists = 0;
+    int                         max_rows = 1;
+    try
+    {
+        std::vector<aoclsparse_int> U, nu;
+        std::vector<unsigned int>   M, nm;
+        auto cols_of = [&](aoclsparse_int gi, aoclsparse_int &len) {
+            const aoclsparse_int r = first[gi];
+            len                    = h.ptr[r + 1] - h.ptr[r];
+            return h.ind + (h.ptr[r] - b);
+        };
+        auto ascending = [](const aoclsparse_int *c, aoclsparse_int len) {
+            for(aoclsparse_int k = 1; k < len; k++)
+                if(c[k] <= c[k - 1])
+                    return false;
+            return true;
+        };
+        aoclsparse_int i = 0;
+        while(i < ng)
+        {
+            aoclsparse_int        len0;
+            const aoclsparse_int *c0   = cols_of(i, len0);
+            int                   rows = first[i + 1] - first[i];
+            U.assign(c0, c0 + len0);
+            M.assign((size_t)len0, rows >= 32 ? 0xFFFFFFFFu : ((1u << rows) - 1u));
+            aoclsparse_int j = i + 1;
+            if(len0 > 0 && len0 <= CSRMM_SUPER_UNION && rows <= CSRMM_SUPER_ROWS && ascending(c0, len0))
+                while(j < ng)
+                {
+                    aoclsparse_int        lj;
+                    const aoclsparse_int *cj = cols_of(j, lj);
+                    const int             rj = first[j + 1] - first[j];
+                    if(rows + rj > CSRMM_SUPER_ROWS || lj == 0 || !ascending(cj, lj))
+                        break;
+                    const unsigned bits = ((1u << rj) - 1u) << rows;
+                    nu.clear(), nm.clear();
+                    size_t a = 0, c = 0, shared = 0;
+                    while(a < U.size() || c < (size_t)lj)
+                    {
+                        if(c == (size_t)lj || (a < U.size() && U[a] < cj[c]))
+                            nu.push_back(U[a]), nm.push_back(M[a]), a++;
+                        else if(a == U.size() || cj[c] < U[a])
+                            nu.push_back(cj[c]), nm.push_back(bits), c++;
+                        else
+                            nu.push_back(U[a]), nm.push_back(M[a] | bits), a++, c++, shared++;
+                    }
+                    if(nu.size() > (size_t)CSRMM_SUPER_UNION || shared * 3 < (size_t)lj)
+                        break;
+                    U.swap(nu), M.swap(nm);
+                    rows += rj;
+                    j++;
+                }
+            // emit rows [first[i], first[j]) as one block
+            const aoclsparse_int r0 = first[i], nr = first[j] - r0;
+            const size_t         upad = (U.size() + 7) & ~(size_t)7;
+            sg_row.push_back(r0);
+            sg_u.push_back((aoclsparse_int)ucol.size());
+            sg_a.push_back((long long)aval.size());
+            for(size_t k = 0; k < U.size(); k++)
+                ucol.push_back(U[k] - b), umask.push_back(M[k]);
+            const size_t a0 = aval.size();
+            aval.resize(a0 + (size_t)nr * upad, T(0));
+            for(aoclsparse_int q = 0; q < nr; q++)
+            {
+                const aoclsparse_int s = h.ptr[r0 + q] - b, e = h.ptr[r0 + q + 1] - b;
+                size_t               k = 0;
+                for(aoclsparse_int p = s; p < e; p++)
+                {
+                    // single-group blocks keep the row's own (possibly unsorted) order: position p - s
+                    if(j == i + 1)
+                        k = (size_t)(p - s);
+                    else
+                        while(U[k] != h.ind[p])
+                            k++;
+                    aval[a0 + (size_t)q * upad + k] = hv[p];
+                }
+                sum_lists += e - s;
+            }
+            sum_union += (long long)U.size() * 1; // B rows loaded per block ...
+            max_rows = std::max(max_rows, (int)nr);
+            i        = j;
+        }
+        sg_row.push_back(h.m);
+        sg_u.push_back((aoclsparse_int)ucol.size());
+        sg_a.push_back((long long)aval.size());
+        for(int k = 0; k < 8; k++) // slack: the kernel reads masks / columns in batches of 8
+            ucol.push_back(0), umask.push_back(0);
+    }
+    catch(const std::bad_alloc &)
+    {
+        return aoclsparse_status_memory_error;
+    }
+    // B-row loads: per block |union| (super-groups) against |list| per GROUP (row groups): sum over groups of their list
+    long long group_loads = 0;
+    for(aoclsparse_int gi = 0; gi < ng; gi++)
+        group_loads += h.ptr[first[gi] + 1] - h.ptr[first[gi]];
+    (void)sum_lists;
+    if(sum_union * 100 > group_loads * 85)
+        return aoclsparse_status_success; // not enough sharing between neighbouring groups
+    hipStream_t       st = Runtime::get().stream();
+    aoclsparse_status rc = g.sg_row.upload(sg_row.data(), sizeof(aoclsparse_int) * sg_row.size(), st);
+    if(rc == aoclsparse_status_success)
+        rc = g.sg_u.upload(sg_u.data(), sizeof(aoclsparse_int) * sg_u.size(), st);
+    if(rc == aoclsparse_status_success)
+        rc = g.sg_a.upload(sg_a.data(), sizeof(long long) * sg_a.size(), st);
+    if(rc == aoclsparse_status_success)
+        rc = g.ucol.upload(ucol.data(), sizeof(aoclsparse_int) * ucol.size(), st);
+    if(rc == aoclsparse_status_success)
+        rc = g.umask.upload(umask.data(), sizeof(unsigned int) * umask.size(), st);
+    if(rc == aoclsparse_status_success)
+        rc = g.aval.upload(aval.data(), sizeof(T) * std::max<size_t>(aval.size(), 1), st);
+    if(rc != aoclsparse_status_success)
+        return rc;
+    g.nsuper      = (aoclsparse_int)sg_row.size() - 1;
+    g.super_rows  = max_rows;
+    g.super_valid = true;
     return aoclsparse_status_success;
 }
 
@@ -255,6 +406,13 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
         if(st != aoclsparse_status_success)
             return st;
     }
+    if(p && (!colmaj || detour) && p->mm.valid && !p->mm.super_tried && n >= 128)
+    {
+        std::unique_lock<std::shared_mutex> w(A->guard);
+        st = build_mm_super<T>(tr ? *A->trans : A->user, *p);
+        if(st != aoclsparse_status_success)
+            return st;
+    }
     if(p && colmaj && !detour && !p->mm.pairs_tried)
     {
         std::unique_lock<std::shared_mutex> w(A->guard);
@@ -269,6 +427,17 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
         const bool                          grouped = p && p->mm.valid;
         const aoclsparse_int               *grp = grouped ? p->mm.first.as<aoclsparse_int>() : nullptr;
         const aoclsparse_int                ngrp = grouped ? p->mm.ngroups : 0;
+        // super-groups (row groups merged over the union of their columns): vectorisable row-major operands, n >= 128
+        auto use_super = [&](const T *Bp, const T *Cp, aoclsparse_int lb, aoclsparse_int lc) {
+            return grouped && p->mm.super_valid && n >= 128 && n % 2 == 0 && lb % 2 == 0 && lc % 2 == 0
+                   && reinterpret_cast<uintptr_t>(Bp) % (2 * sizeof(T)) == 0 && reinterpret_cast<uintptr_t>(Cp) % (2 * sizeof(T)) == 0;
+        };
+        auto run_super = [&](const T *Bp, aoclsparse_int lb, T *Cp, aoclsparse_int lc) {
+            const MmGroups &g = p->mm;
+            return launch_csrmm_super<T>(rt.stream(), alpha, g.nsuper, g.super_rows, g.sg_row.as<aoclsparse_int>(),
+                                         g.sg_u.as<aoclsparse_int>(), g.sg_a.as<long long>(), g.ucol.as<aoclsparse_int>(),
+                                         g.umask.as<unsigned int>(), g.aval.as<T>(), Bp, n, lb, beta, Cp, lc);
+        };
         if(detour)
         {
             void *bt = nullptr, *ct = nullptr;
@@ -279,13 +448,17 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
                 st = launch_relayout<T>(rt.stream(), true, static_cast<const T *>(dB), static_cast<T *>(bt), b_rows, n, ldb);
             if(st == aoclsparse_status_success)
                 st = launch_relayout<T>(rt.stream(), true, static_cast<const T *>(dC), static_cast<T *>(ct), m_c, n, ldc);
-            if(st == aoclsparse_status_success)
+            if(st == aoclsparse_status_success && use_super(static_cast<const T *>(bt), static_cast<const T *>(ct), n, n))
+                st = run_super(static_cast<const T *>(bt), n, static_cast<T *>(ct), n);
+            else if(st == aoclsparse_status_success)
                 st = launch_csrmm<T>(rt.stream(), aoclsparse_order_row, d->base, alpha, d->m, d->n, d->val.as<T>(),
                                      d->ind.as<aoclsparse_int>(), d->ptr.as<aoclsparse_int>(), static_cast<const T *>(bt),
                                      n, n, beta, static_cast<T *>(ct), n, grp, ngrp, grouped ? p->mm.max_rows : 0);
             if(st == aoclsparse_status_success)
                 st = launch_relayout<T>(rt.stream(), false, static_cast<const T *>(ct), static_cast<T *>(dC), m_c, n, ldc);
         }
+        else if(!colmaj && use_super(static_cast<const T *>(dB), static_cast<const T *>(dC), ldb, ldc))
+            st = run_super(static_cast<const T *>(dB), ldb, static_cast<T *>(dC), ldc);
         else if(!colmaj && !grouped && p && p->valid && p->nblocks > 0
                 && csrmm_tiled_applies<T>(n, ldb, ldc, static_cast<const T *>(dB), static_cast<const T *>(dC)))
             // narrow row-major operands (a multi-GPU column slab): row blocks of the SpMV plan, A staged in LDS

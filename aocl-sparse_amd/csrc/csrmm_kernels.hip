@@ -265,6 +265,90 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup_kernel(int base, T alpha, 
         }
 }
 
+// row-major, n >= 128, SUPER-GROUPS: a wavefront owns (block, 128-column chunk), where a block is a run of row groups
+// merged over the UNION of their column lists (csrmm_api.cpp: build_mm_super).  Every B row of the union is loaded ONCE for
+// up to GR output rows -- the neighbouring nodes of a mesh share most of their neighbours, so the L2 -> CU traffic that
+// bounds csrmm_rowgroup_kernel on matrices with tens of non-zeros per row drops again (shell-like: 7 -> ~3.5 B rows per
+// output row).  Values come from the block's dense rows x union array through the scalar cache; an entry a row does not
+// have is masked out (never multiplied, so NaN / Inf in B reach only the rows that reference them).  The union is walked
+// in ascending column order = every row's CSR order (the builder merges only groups with ascending lists), so the FMA chain
+// per output element is unchanged.
+template <typename T, int GR>
+__global__ __launch_bounds__(256) void csrmm_supergroup_kernel(T alpha, aoclsparse_int nsuper,
+                                                               const aoclsparse_int *__restrict__ sg_row,
+                                                               const aoclsparse_int *__restrict__ sg_u,
+                                                               const long long *__restrict__ sg_a,
+                                                               const aoclsparse_int *__restrict__ ucol,
+                                                               const unsigned int *__restrict__ umask,
+                                                               const T *__restrict__ aval, const T *__restrict__ B,
+                                                               aoclsparse_int n, aoclsparse_int ldb, T beta,
+                                                               T *__restrict__ C, aoclsparse_int ldc, bool readc,
+                                                               int xcd_chunk)
+{
+    using V      = typename vec2<T>::type;
+    const int w  = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int sg = bx * 4 + w;
+    const int j  = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
+    if(sg >= nsuper || j >= n)
+        return;
+    const int       i0 = sg_row[sg], r = sg_row[sg + 1] - i0; // 1 <= r <= GR
+    const int       u0 = sg_u[sg], U = sg_u[sg + 1] - u0;
+    const int       upad = (U + 7) & ~7;
+    const T        *ab = aval + sg_a[sg];
+    T               acc0[GR], acc1[GR];
+#pragma unroll
+    for(int q = 0; q < GR; q++)
+        acc0[q] = T(0), acc1[q] = T(0);
+    const T *Bj = B + j;
+    for(int k = 0; k < U; k += 8)
+    {
+        int          c[8];
+        unsigned int mk[8];
+#pragma unroll
+        for(int u = 0; u < 8; u++)
+        {
+            c[u]  = ucol[u0 + k + u]; // 8 entries of slack behind the last block
+            mk[u] = k + u < U ? umask[u0 + k + u] : 0u;
+        }
+        V b[8];
+#pragma unroll
+        for(int u = 0; u < 8; u++)
+            if(mk[u])
+                b[u] = *reinterpret_cast<const V *>(Bj + (size_t)c[u] * ldb);
+#pragma unroll
+        for(int q = 0; q < GR; q++)
+            if(q < r)
+            {
+                T a[8];
+#pragma unroll
+                for(int u = 0; u < 8; u++)
+                    a[u] = ab[(size_t)q * upad + k + u];
+#pragma unroll
+                for(int u = 0; u < 8; u++)
+                    if((mk[u] >> q) & 1u)
+                        acc0[q] = mm_fma(a[u], b[u].x, acc0[q]), acc1[q] = mm_fma(a[u], b[u].y, acc1[q]);
+            }
+    }
+#pragma unroll
+    for(int q = 0; q < GR; q++)
+        if(q < r)
+        {
+            V      *cp = reinterpret_cast<V *>(C + (size_t)(i0 + q) * ldc + j);
+            const T z0 = alpha * acc0[q], z1 = alpha * acc1[q];
+            V       cc;
+            if(readc || z0 == T(0) || z1 == T(0))
+            {
+                cc   = *cp;
+                cc.x = mm_fma(beta, cc.x, z0);
+                cc.y = mm_fma(beta, cc.y, z1);
+            }
+            else
+                cc.x = z0, cc.y = z1;
+            *cp = cc;
+        }
+}
+
 // narrower B (32 <= n < 128): LANES lanes (2 columns each) per group, 64 / LANES groups per wavefront; the group's
 // row_ptr / col / val loads are then per-lane loads of one address per sub-wave instead of scalar loads
 template <typename T, int LANES, int GR>
@@ -926,6 +1010,31 @@ aoclsparse_status launch_csrmm_colpair(hipStream_t s, int base, T alpha, aoclspa
     return aoclsparse_status_success;
 }
 
+template <typename T>
+aoclsparse_status launch_csrmm_super(hipStream_t s, T alpha, aoclsparse_int nsuper, int max_rows, const aoclsparse_int *sg_row,
+                                     const aoclsparse_int *sg_u, const long long *sg_a, const aoclsparse_int *ucol,
+                                     const unsigned int *umask, const T *aval, const T *B, aoclsparse_int n,
+                                     aoclsparse_int ldb, T beta, T *C, aoclsparse_int ldc)
+{
+    if(nsuper <= 0 || n <= 0)
+        return aoclsparse_status_success;
+    static const bool strict_beta0 = [] {
+        const char *e = getenv("AOCLSPARSE_MI355_CSRMM_STRICT_BETA0");
+        return e && atoi(e) != 0;
+    }();
+    const bool readc = beta != T(0) || strict_beta0;
+    const int  nbx = (nsuper + 3) / 4, chunk = (nbx + 7) / 8;
+    const dim3 grid(chunk * 8, (n + 127) / 128), block(256);
+    if(max_rows <= 8)
+        hipLaunchKernelGGL((csrmm_supergroup_kernel<T, 8>), grid, block, 0, s, alpha, nsuper, sg_row, sg_u, sg_a, ucol, umask,
+                           aval, B, n, ldb, beta, C, ldc, readc, chunk);
+    else
+        hipLaunchKernelGGL((csrmm_supergroup_kernel<T, CSRMM_SUPER_ROWS>), grid, block, 0, s, alpha, nsuper, sg_row, sg_u, sg_a,
+                           ucol, umask, aval, B, n, ldb, beta, C, ldc, readc, chunk);
+    MI355_HIP_TRY(hipGetLastError());
+    return aoclsparse_status_success;
+}
+
 #define MI355_INST_MM(T)                                                                                     \
     template aoclsparse_status launch_csrmm<T>(hipStream_t, aoclsparse_order, int, T, aoclsparse_int,        \
                                                aoclsparse_int, const T *, const aoclsparse_int *,             \
@@ -940,6 +1049,11 @@ aoclsparse_status launch_csrmm_colpair(hipStream_t s, int base, T alpha, aoclspa
                                                        aoclsparse_int, const aoclsparse_int *, const T *,      \
                                                        const aoclsparse_int *, const aoclsparse_int *, const T *, \
                                                        aoclsparse_int, aoclsparse_int, T, T *, aoclsparse_int); \
+    template aoclsparse_status launch_csrmm_super<T>(hipStream_t, T, aoclsparse_int, int, const aoclsparse_int *,  \
+                                                     const aoclsparse_int *, const long long *,                \
+                                                     const aoclsparse_int *, const unsigned int *, const T *,  \
+                                                     const T *, aoclsparse_int, aoclsparse_int, T, T *,        \
+                                                     aoclsparse_int);                                          \
     template bool csrmm_tiled_applies<T>(aoclsparse_int, aoclsparse_int, aoclsparse_int, const T *, const T *); \
     template aoclsparse_status launch_csrmm_tiled<T>(hipStream_t, int, T, const T *, const aoclsparse_int *,   \
                                                      const aoclsparse_int *, const aoclsparse_int *,          \

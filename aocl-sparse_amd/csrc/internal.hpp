@@ -181,13 +181,25 @@ struct MmGroups
     aoclsparse_int ngroups = 0;
     int            max_rows = 0; // rows of the largest group
     DeviceBuffer   first; // ngroups + 1 row indices
+    std::vector<aoclsparse_int> first_host; // the same on the host (input of the super-group builder)
     bool           valid = false, tried = false;
     // column-major csrmm: row pairs (2r, 2r+1) where row 2r+1 carries row 2r's pattern shifted by one column (scalar
     // stencils, banded matrices) and both fit the register cache -- csrmm_colpair_kernel serves them with 16-byte loads
     bool           pairs_tried = false, pairs = false;
     aoclsparse_int npairs = 0, nsingles = 0;
     DeviceBuffer   pair_first, single_rows; // first row of every pair; rows without a partner
+    // row-major csrmm, SUPER-GROUPS (csrmm_supergroup_kernel): runs of consecutive row groups (<= CSRMM_SUPER_ROWS rows)
+    // whose column lists overlap (neighbouring nodes of a mesh), stored as one block over the UNION of their columns:
+    // sg_row[s] first row, sg_u[s] first union entry, ucol / umask per union entry (bit q: row sg_row+q has it),
+    // sg_a[s] offset of the dense rows x union value block (row-major, absent entries never read into a result).
+    // Holds VALUES, so it is rebuilt after ?set_value / ?update_values (super_valid reset by drop_derived_state).
+    bool           super_tried = false, super_valid = false;
+    aoclsparse_int nsuper = 0;
+    int            super_rows = 0; // rows of the largest super-group
+    DeviceBuffer   sg_row, sg_u, sg_a, ucol, umask, aval;
 };
+constexpr int CSRMM_SUPER_ROWS  = 16; // rows per super-group at most (mask width, accumulator registers)
+constexpr int CSRMM_SUPER_UNION = 160; // union columns per super-group at most
 
 // merge-path tiling of a device CSR (mergepath_kernels.hip): tile w starts at {row ends, non-zeros} =
 // starts[2w], starts[2w+1]; two carry records per tile
@@ -627,6 +639,12 @@ aoclsparse_status launch_csrmm_tiled(hipStream_t s, int base, T alpha, const T *
                                      const aoclsparse_int *row_ptr, const aoclsparse_int *blocks, aoclsparse_int nblocks,
                                      int tile, const T *B, aoclsparse_int n, aoclsparse_int ldb, T beta, T *C,
                                      aoclsparse_int ldc);
+// row-major, n >= 128: one wavefront per (super-group, 128-column chunk) -- every B row of the union loaded once
+template <typename T>
+aoclsparse_status launch_csrmm_super(hipStream_t s, T alpha, aoclsparse_int nsuper, int max_rows, const aoclsparse_int *sg_row,
+                                     const aoclsparse_int *sg_u, const long long *sg_a, const aoclsparse_int *ucol,
+                                     const unsigned int *umask, const T *aval, const T *B, aoclsparse_int n,
+                                     aoclsparse_int ldb, T beta, T *C, aoclsparse_int ldc);
 // column-major: a lane owns a row PAIR; 16-byte loads where the second row is the first shifted by one column
 template <typename T>
 aoclsparse_status launch_csrmm_colpair(hipStream_t s, int base, T alpha, aoclsparse_int npairs,

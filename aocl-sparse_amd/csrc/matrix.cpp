@@ -967,6 +967,8 @@ aoclsparse_status aoclsparse_mi355_invalidate(aoclsparse_matrix A)
     A->plan_trans.mm.valid = A->plan_trans.mm.tried = false;
     A->plan_user.mm.pairs = A->plan_user.mm.pairs_tried = false;
     A->plan_trans.mm.pairs = A->plan_trans.mm.pairs_tried = false;
+    A->plan_user.mm.super_valid = A->plan_user.mm.super_tried = false;
+    A->plan_trans.mm.super_valid = A->plan_trans.mm.super_tried = false;
     for(auto &p : A->trsv_plan)
         p.valid = false, p.nlevels = -1;
     A->trans.reset();
@@ -993,6 +995,8 @@ void drop_derived_state(aoclsparse_matrix A)
     A->dev_user.valid = A->dev_trans.valid = false; // row-block plans stay valid: structure is unchanged
     A->plan_user.sell.valid = A->plan_user.sell.tried = false; // the SELL copies hold values: rebuilt on optimize
     A->plan_trans.sell.valid = A->plan_trans.sell.tried = false;
+    A->plan_user.mm.super_valid = A->plan_user.mm.super_tried = false; // csrmm super-groups hold values too
+    A->plan_trans.mm.super_valid = A->plan_trans.mm.super_tried = false;
     A->dev_diag.release();
     for(auto &p : A->trsv_plan)
         p.valid = false, p.nlevels = -1;

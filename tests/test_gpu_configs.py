@@ -576,3 +576,67 @@ def test_large_host_pointer_calls_through_the_pinned_ring():
     assert P.dcsrmm(P.OP_NONE, 2.0, A, d, P.ORDER_COLUMN, B, n, m, -1.0, C, m) == 0
     so, Cr = oracle.dcsrmm("col", 2.0, 0, v, ci, rp, m, B, n, m, -1.0, C0, m)
     assert np.array_equal(C, Cr)
+
+
+# --------------------------------------------------------------------------------------------------
+# csrmm super-groups: row groups of neighbouring mesh nodes merged over the union of their columns
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("which", ["shell", "flan"])
+def test_csrmm_super_groups_bit_exact(which):
+    """csrmm_supergroup_kernel (row-major, n >= 128): block-structured mesh matrices (5 dofs / 7 neighbours and 3 dofs /
+    27 neighbours, small instances of the config-3 stand-ins).  Per element the chain is still the row in CSR order:
+    C equals csrmm_col_major_ref's bits; a NaN / Inf in one B row reaches exactly the rows that reference that column
+    (entries a row does not have are masked out of the merged block, never multiplied by zero); values changed with
+    aoclsparse_dupdate_values are picked up (the block copy of the values is rebuilt)."""
+    if which == "shell":
+        m, rp, ci, v = standins.shell_like(n=5 * 41 * 23, width=41)
+    else:
+        m, rp, ci, v = standins.flan_like(nx=9, ny=8, nz=7)
+    rng = np.random.default_rng(33)
+    os.environ["AOCLSPARSE_MI355_CSRMM_SUPER"] = "1"  # opt-in kernel (it measured slower than the row groups)
+    try:
+        _super_group_checks(which, m, rp, ci, v, rng)
+    finally:
+        os.environ.pop("AOCLSPARSE_MI355_CSRMM_SUPER", None)
+
+
+def _super_group_checks(which, m, rp, ci, v, rng):
+    A = P.Matrix(0, m, m, rp, ci, v)
+    d = P.Descr()
+    assert L.aoclsparse_set_mm_hint(A.h, P.OP_NONE, d.h, 2) == 0 and L.aoclsparse_optimize(A.h) == 0
+    for n, alpha, beta in ((128, 1.0, 0.0), (256, -0.5, 1.5), (130, 2.0, 0.0)):
+        ldb, ldc = n + 2, n + 4
+        Br, C0 = rng.uniform(-1, 1, m * ldb), rng.uniform(-1, 1, m * ldc)
+        Cd = dev(C0)
+        assert P.dcsrmm(P.OP_NONE, alpha, A, d, P.ORDER_ROW, dev(Br), n, ldb, beta, Cd, ldc) == 0
+        torch.cuda.synchronize()
+        info = A.spmv_info()
+        assert info.mm_groups > 0 and 0 < info.mm_super_blocks < info.mm_groups, (info.mm_groups, info.mm_super_blocks)
+        got = Cd.cpu().numpy().reshape(m, ldc)
+        ref = _col_reference(alpha, 0, v, ci, rp, m, m, Br, n, ldb, beta, C0, ldc)
+        assert np.array_equal(got[:, :n], ref), (which, n)
+        assert np.array_equal(got[:, n:], C0.reshape(m, ldc)[:, n:])
+    # NaN / Inf in B rows c1, c2: only rows that have those columns may see them
+    n = 128
+    Br = rng.uniform(-1, 1, m * n)
+    c1, c2 = int(ci[rp[m // 2]]), int(ci[rp[m // 3 + 1] - 1])
+    Br.reshape(m, n)[c1, 5] = np.nan
+    Br.reshape(m, n)[c2, 77] = np.inf
+    Cd = torch.zeros(m * n, dtype=torch.float64, device="cuda")
+    assert P.dcsrmm(P.OP_NONE, 1.0, A, d, P.ORDER_ROW, dev(Br), n, n, 0.0, Cd, n) == 0
+    torch.cuda.synchronize()
+    got = Cd.cpu().numpy().reshape(m, n)
+    ref = _col_reference(1.0, 0, v, ci, rp, m, m, Br, n, n, 0.0, np.zeros(m * n), n)
+    bad_g, bad_r = ~np.isfinite(got), ~np.isfinite(ref)
+    assert np.array_equal(bad_g, bad_r) and np.array_equal(got[~bad_g], ref[~bad_r])
+    rows_with_c1 = {i for i in range(m) if c1 in ci[rp[i]:rp[i + 1]]}
+    assert set(np.nonzero(np.isnan(got[:, 5]))[0]) == rows_with_c1
+    # values updated in place: the dense block copy must follow
+    v2 = v * rng.uniform(0.5, 1.5, len(v))
+    assert L.aoclsparse_dupdate_values(A.h, len(v2), P._ptr(v2)) == 0
+    Br = rng.uniform(-1, 1, m * n)
+    Cd = torch.zeros(m * n, dtype=torch.float64, device="cuda")
+    assert P.dcsrmm(P.OP_NONE, 1.0, A, d, P.ORDER_ROW, dev(Br), n, n, 0.0, Cd, n) == 0
+    torch.cuda.synchronize()
+    ref = _col_reference(1.0, 0, v2, ci, rp, m, m, Br, n, n, 0.0, np.zeros(m * n), n)
+    assert np.array_equal(Cd.cpu().numpy().reshape(m, n), ref)
