@@ -176,15 +176,17 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup_kernel(int base, T alpha, 
                                                              const aoclsparse_int *__restrict__ row_ptr,
                                                              const T *__restrict__ B, aoclsparse_int n, aoclsparse_int ldb,
                                                              T beta, T *__restrict__ C, aoclsparse_int ldc, bool readc,
-                                                             int xcd_chunk)
+                                                             int xcd_chunk, const aoclsparse_int *__restrict__ glist)
 {
+    // glist != nullptr: the `ngroups` entries of glist are the groups to compute (those the super-group kernel left)
     using V      = typename vec2<T>::type;
     const int w  = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const int gi = bx * 4 + w;
+    const int gt = bx * 4 + w;
     const int j  = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
-    if(gi >= ngroups || j >= n)
+    if(gt >= ngroups || j >= n)
         return;
+    const int gi = glist ? glist[gt] : gt;
     const int i0 = grp[gi], r = grp[gi + 1] - i0; // 1 <= r <= GR
     const int s0 = row_ptr[i0] - base, len = row_ptr[i0 + 1] - base - s0;
     int       so[GR]; // start of every row of the group (wave-uniform)
@@ -265,15 +267,15 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup_kernel(int base, T alpha, 
         }
 }
 
-// row-major, n >= 128, SUPER-GROUPS: a wavefront owns (block, 128-column chunk), where a block is a run of row groups
-// merged over the UNION of their column lists (csrmm_api.cpp: build_mm_super).  Every B row of the union is loaded ONCE for
-// up to GR output rows -- the neighbouring nodes of a mesh share most of their neighbours, so the L2 -> CU traffic that
-// bounds csrmm_rowgroup_kernel on matrices with tens of non-zeros per row drops again (shell-like: 7 -> ~3.5 B rows per
-// output row).  Values come from the block's dense rows x union array through the scalar cache; an entry a row does not
-// have is masked out (never multiplied, so NaN / Inf in B reach only the rows that reference them).  The union is walked
-// in ascending column order = every row's CSR order (the builder merges only groups with ascending lists), so the FMA chain
-// per output element is unchanged.
-template <typename T, int GR>
+// row-major, n >= 128, SUPER-GROUPS: a wavefront owns (block, 128-column chunk), where a block is a run of up to NG row
+// groups of exactly RG rows each, merged over the UNION of their column lists (csrmm_api.cpp: build_mm_super).  Every B row
+// of the union is loaded ONCE for up to NG*RG output rows -- the neighbouring nodes of a mesh share most of their neighbours,
+// so the L2 -> CU traffic that bounds csrmm_rowgroup_kernel on matrices with tens of non-zeros per row drops again
+// (shell-like: 7 -> ~3.5 B rows per output row).  Values come from the block's dense rows x union array through the scalar
+// cache; a union entry a GROUP does not have is skipped by one wave-uniform test per (group, entry) -- never multiplied, so
+// NaN / Inf in B reach only the rows that reference them.  The union is walked in ascending column order = every row's CSR
+// order (the builder merges only groups with ascending lists), so the FMA chain per output element is unchanged.
+template <typename T, int RG, int NG>
 __global__ __launch_bounds__(256) void csrmm_supergroup_kernel(T alpha, aoclsparse_int nsuper,
                                                                const aoclsparse_int *__restrict__ sg_row,
                                                                const aoclsparse_int *__restrict__ sg_u,
@@ -292,13 +294,13 @@ __global__ __launch_bounds__(256) void csrmm_supergroup_kernel(T alpha, aoclspar
     const int j  = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
     if(sg >= nsuper || j >= n)
         return;
-    const int       i0 = sg_row[sg], r = sg_row[sg + 1] - i0; // 1 <= r <= GR
-    const int       u0 = sg_u[sg], U = sg_u[sg + 1] - u0;
-    const int       upad = (U + 7) & ~7;
-    const T        *ab = aval + sg_a[sg];
-    T               acc0[GR], acc1[GR];
+    const int i0 = sg_row[2 * sg], ngb = sg_row[2 * sg + 1] / RG; // {first row, rows}: groups in this block, 1 <= ngb <= NG
+    const int u0 = sg_u[sg], U = sg_u[sg + 1] - u0;
+    const int upad = (U + 7) & ~7;
+    const T  *ab = aval + sg_a[sg];
+    T         acc0[NG * RG], acc1[NG * RG];
 #pragma unroll
-    for(int q = 0; q < GR; q++)
+    for(int q = 0; q < NG * RG; q++)
         acc0[q] = T(0), acc1[q] = T(0);
     const T *Bj = B + j;
     for(int k = 0; k < U; k += 8)
@@ -317,22 +319,29 @@ __global__ __launch_bounds__(256) void csrmm_supergroup_kernel(T alpha, aoclspar
             if(mk[u])
                 b[u] = *reinterpret_cast<const V *>(Bj + (size_t)c[u] * ldb);
 #pragma unroll
-        for(int q = 0; q < GR; q++)
-            if(q < r)
+        for(int gi = 0; gi < NG; gi++)
+            if(gi < ngb)
             {
-                T a[8];
+                T a[RG][8];
+#pragma unroll
+                for(int qq = 0; qq < RG; qq++)
+#pragma unroll
+                    for(int u = 0; u < 8; u++)
+                        a[qq][u] = ab[(size_t)(gi * RG + qq) * upad + k + u];
 #pragma unroll
                 for(int u = 0; u < 8; u++)
-                    a[u] = ab[(size_t)q * upad + k + u];
+                    if((mk[u] >> gi) & 1u)
+                    {
 #pragma unroll
-                for(int u = 0; u < 8; u++)
-                    if((mk[u] >> q) & 1u)
-                        acc0[q] = mm_fma(a[u], b[u].x, acc0[q]), acc1[q] = mm_fma(a[u], b[u].y, acc1[q]);
+                        for(int qq = 0; qq < RG; qq++)
+                            acc0[gi * RG + qq] = mm_fma(a[qq][u], b[u].x, acc0[gi * RG + qq]),
+                                           acc1[gi * RG + qq] = mm_fma(a[qq][u], b[u].y, acc1[gi * RG + qq]);
+                    }
             }
     }
 #pragma unroll
-    for(int q = 0; q < GR; q++)
-        if(q < r)
+    for(int q = 0; q < NG * RG; q++)
+        if(q < ngb * RG)
         {
             V      *cp = reinterpret_cast<V *>(C + (size_t)(i0 + q) * ldc + j);
             const T z0 = alpha * acc0[q], z1 = alpha * acc1[q];
@@ -848,7 +857,8 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
                 {
                     const int gx = grid_x((ngroups + 3) / 4, chunk);
                     hipLaunchKernelGGL((csrmm_rowgroup_kernel<T, GR>), dim3(gx, (n + 127) / 128), dim3(256), 0, s, base, alpha,
-                                       ngroups, grp, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk);
+                                       ngroups, grp, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk,
+                                       (const aoclsparse_int *)nullptr);
                 }
                 else if(n >= 64)
                 {
@@ -1011,26 +1021,49 @@ aoclsparse_status launch_csrmm_colpair(hipStream_t s, int base, T alpha, aoclspa
 }
 
 template <typename T>
-aoclsparse_status launch_csrmm_super(hipStream_t s, T alpha, aoclsparse_int nsuper, int max_rows, const aoclsparse_int *sg_row,
-                                     const aoclsparse_int *sg_u, const long long *sg_a, const aoclsparse_int *ucol,
-                                     const unsigned int *umask, const T *aval, const T *B, aoclsparse_int n,
-                                     aoclsparse_int ldb, T beta, T *C, aoclsparse_int ldc)
+aoclsparse_status launch_csrmm_super(hipStream_t s, int base, T alpha, aoclsparse_int nsuper, int rg,
+                                     const aoclsparse_int *sg_row, const aoclsparse_int *sg_u, const long long *sg_a,
+                                     const aoclsparse_int *ucol, const unsigned int *umask, const T *aval,
+                                     aoclsparse_int nrest, const aoclsparse_int *rest, const aoclsparse_int *grp,
+                                     const T *val, const aoclsparse_int *col, const aoclsparse_int *row_ptr, const T *B,
+                                     aoclsparse_int n, aoclsparse_int ldb, T beta, T *C, aoclsparse_int ldc)
 {
-    if(nsuper <= 0 || n <= 0)
+    if(n <= 0)
         return aoclsparse_status_success;
     static const bool strict_beta0 = [] {
         const char *e = getenv("AOCLSPARSE_MI355_CSRMM_STRICT_BETA0");
         return e && atoi(e) != 0;
     }();
     const bool readc = beta != T(0) || strict_beta0;
-    const int  nbx = (nsuper + 3) / 4, chunk = (nbx + 7) / 8;
-    const dim3 grid(chunk * 8, (n + 127) / 128), block(256);
-    if(max_rows <= 8)
-        hipLaunchKernelGGL((csrmm_supergroup_kernel<T, 8>), grid, block, 0, s, alpha, nsuper, sg_row, sg_u, sg_a, ucol, umask,
-                           aval, B, n, ldb, beta, C, ldc, readc, chunk);
-    else
-        hipLaunchKernelGGL((csrmm_supergroup_kernel<T, CSRMM_SUPER_ROWS>), grid, block, 0, s, alpha, nsuper, sg_row, sg_u, sg_a,
-                           ucol, umask, aval, B, n, ldb, beta, C, ldc, readc, chunk);
+    const dim3 block(256);
+    if(nsuper > 0)
+    {
+        const int  nbx = (nsuper + 3) / 4, chunk = (nbx + 7) / 8;
+        const dim3 grid(chunk * 8, (n + 127) / 128);
+        auto       go = [&](auto rg_tag, auto ng_tag) {
+            constexpr int RG = decltype(rg_tag)::value, NG = decltype(ng_tag)::value;
+            hipLaunchKernelGGL((csrmm_supergroup_kernel<T, RG, NG>), grid, block, 0, s, alpha, nsuper, sg_row, sg_u, sg_a, ucol,
+                               umask, aval, B, n, ldb, beta, C, ldc, readc, chunk);
+        };
+        using std::integral_constant;
+        switch(rg)
+        {
+        case 2: go(integral_constant<int, 2>{}, integral_constant<int, 4>{}); break;
+        case 3: go(integral_constant<int, 3>{}, integral_constant<int, 4>{}); break;
+        case 4: go(integral_constant<int, 4>{}, integral_constant<int, 4>{}); break;
+        case 5: go(integral_constant<int, 5>{}, integral_constant<int, 3>{}); break;
+        case 6: go(integral_constant<int, 6>{}, integral_constant<int, 2>{}); break;
+        case 8: go(integral_constant<int, 8>{}, integral_constant<int, 2>{}); break;
+        default: return aoclsparse_status_internal_error;
+        }
+    }
+    if(nrest > 0)
+    {
+        // groups the builder left alone (other row counts, unsorted lists): the row-group kernel on a group list
+        const int nbx = (nrest + 3) / 4, chunk = (nbx + 7) / 8;
+        hipLaunchKernelGGL((csrmm_rowgroup_kernel<T, CSRMM_GROUP>), dim3(chunk * 8, (n + 127) / 128), block, 0, s, base, alpha,
+                           nrest, grp, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk, rest);
+    }
     MI355_HIP_TRY(hipGetLastError());
     return aoclsparse_status_success;
 }
@@ -1049,11 +1082,13 @@ aoclsparse_status launch_csrmm_super(hipStream_t s, T alpha, aoclsparse_int nsup
                                                        aoclsparse_int, const aoclsparse_int *, const T *,      \
                                                        const aoclsparse_int *, const aoclsparse_int *, const T *, \
                                                        aoclsparse_int, aoclsparse_int, T, T *, aoclsparse_int); \
-    template aoclsparse_status launch_csrmm_super<T>(hipStream_t, T, aoclsparse_int, int, const aoclsparse_int *,  \
+    template aoclsparse_status launch_csrmm_super<T>(hipStream_t, int, T, aoclsparse_int, int, const aoclsparse_int *, \
                                                      const aoclsparse_int *, const long long *,                \
                                                      const aoclsparse_int *, const unsigned int *, const T *,  \
-                                                     const T *, aoclsparse_int, aoclsparse_int, T, T *,        \
-                                                     aoclsparse_int);                                          \
+                                                     aoclsparse_int, const aoclsparse_int *,                   \
+                                                     const aoclsparse_int *, const T *, const aoclsparse_int *, \
+                                                     const aoclsparse_int *, const T *, aoclsparse_int,        \
+                                                     aoclsparse_int, T, T *, aoclsparse_int);                  \
     template bool csrmm_tiled_applies<T>(aoclsparse_int, aoclsparse_int, aoclsparse_int, const T *, const T *); \
     template aoclsparse_status launch_csrmm_tiled<T>(hipStream_t, int, T, const T *, const aoclsparse_int *,   \
                                                      const aoclsparse_int *, const aoclsparse_int *,          \

@@ -194,9 +194,10 @@ struct MmGroups
     // sg_a[s] offset of the dense rows x union value block (row-major, absent entries never read into a result).
     // Holds VALUES, so it is rebuilt after ?set_value / ?update_values (super_valid reset by drop_derived_state).
     bool           super_tried = false, super_valid = false;
-    aoclsparse_int nsuper = 0;
-    int            super_rows = 0; // rows of the largest super-group
+    aoclsparse_int nsuper = 0, nrest = 0;
+    int            super_rg = 0; // rows per group inside the blocks (the matrix's dominant group size)
     DeviceBuffer   sg_row, sg_u, sg_a, ucol, umask, aval;
+    DeviceBuffer   rest; // groups left to the row-group kernel (other row counts, unsorted column lists)
 };
 constexpr int CSRMM_SUPER_ROWS  = 16; // rows per super-group at most (mask width, accumulator registers)
 constexpr int CSRMM_SUPER_UNION = 160; // union columns per super-group at most
@@ -641,10 +642,12 @@ aoclsparse_status launch_csrmm_tiled(hipStream_t s, int base, T alpha, const T *
                                      aoclsparse_int ldc);
 // row-major, n >= 128: one wavefront per (super-group, 128-column chunk) -- every B row of the union loaded once
 template <typename T>
-aoclsparse_status launch_csrmm_super(hipStream_t s, T alpha, aoclsparse_int nsuper, int max_rows, const aoclsparse_int *sg_row,
-                                     const aoclsparse_int *sg_u, const long long *sg_a, const aoclsparse_int *ucol,
-                                     const unsigned int *umask, const T *aval, const T *B, aoclsparse_int n,
-                                     aoclsparse_int ldb, T beta, T *C, aoclsparse_int ldc);
+aoclsparse_status launch_csrmm_super(hipStream_t s, int base, T alpha, aoclsparse_int nsuper, int rg,
+                                     const aoclsparse_int *sg_row, const aoclsparse_int *sg_u, const long long *sg_a,
+                                     const aoclsparse_int *ucol, const unsigned int *umask, const T *aval,
+                                     aoclsparse_int nrest, const aoclsparse_int *rest, const aoclsparse_int *grp,
+                                     const T *val, const aoclsparse_int *col, const aoclsparse_int *row_ptr, const T *B,
+                                     aoclsparse_int n, aoclsparse_int ldb, T beta, T *C, aoclsparse_int ldc);
 // column-major: a lane owns a row PAIR; 16-byte loads where the second row is the first shifted by one column
 template <typename T>
 aoclsparse_status launch_csrmm_colpair(hipStream_t s, int base, T alpha, aoclsparse_int npairs,
