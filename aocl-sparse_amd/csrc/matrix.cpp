@@ -970,7 +970,7 @@ aoclsparse_status aoclsparse_mi355_invalidate(aoclsparse_matrix A)
     A->plan_user.mm.super_valid = A->plan_user.mm.super_tried = false;
     A->plan_trans.mm.super_valid = A->plan_trans.mm.super_tried = false;
     for(auto &p : A->trsv_plan)
-        p.valid = false, p.nlevels = -1;
+        p.valid = false, p.nlevels = -1, p.blk.valid = p.blk.tried = false;
     A->trans.reset();
     return aoclsparse_status_success;
 }
@@ -999,7 +999,7 @@ void drop_derived_state(aoclsparse_matrix A)
     A->plan_trans.mm.super_valid = A->plan_trans.mm.super_tried = false;
     A->dev_diag.release();
     for(auto &p : A->trsv_plan)
-        p.valid = false, p.nlevels = -1;
+        p.valid = false, p.nlevels = -1, p.blk.valid = p.blk.tried = false;
 }
 } // namespace mi355
 

@@ -163,12 +163,159 @@ static aoclsparse_status build_levels(aoclsparse_int m, const Triangle<T> &t, Tr
     return rc;
 }
 
+// Blocked (supernodal) plan for a LOWER, non-transposed triangle: see TrsvBlockPlan.  Row r+1 joins row r's block when
+// its dependency list is exactly row r's list followed by r itself (entry for entry: the lists are ascending), the block
+// stays within TRSV_BLK_ROWS rows, TRSV_BLK_EXT external dependencies and TRSV_BLK_NV entries.  Built only when it pays:
+// at least 1.6 rows per block on average.
+template <typename T>
+static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, TrsvBlockPlan &bp)
+{
+    bp.tried = true;
+    if(t.descending || m < 2)
+        return aoclsparse_status_success;
+    static const bool off = [] {
+        const char *e = getenv("AOCLSPARSE_MI355_TRSV_BLOCKS");
+        return e && atoi(e) == 0;
+    }();
+    if(off)
+        return aoclsparse_status_success;
+    // 1. blocks, in row order.  The kernel is compiled for blocks of up to 5 rows (all rows' chains interleaved, every
+    // value in registers) and up to TRSV_BLK_ROWS (row by row): when only a few chains run longer than 5 rows they are
+    // cut at 5, so that one long chain does not put the whole solve on the slower shape (shell-like factor: 5-dof nodes,
+    // 0.4 % of the chains reach 8 rows; 1.4 us -> 0.5 us of arithmetic per block level).
+    std::vector<aoclsparse_int> bstart;
+    bstart.reserve((size_t)m / 2 + 2);
+    for(int cap : {TRSV_BLK_ROWS, 5})
+    {
+        bstart.clear();
+        aoclsparse_int longer = 0;
+        for(aoclsparse_int i = 0; i < m;)
+        {
+            bstart.push_back(i);
+            const aoclsparse_int n0 = t.ptr[i + 1] - t.ptr[i];
+            aoclsparse_int       j = i + 1, total = n0;
+            if(n0 <= TRSV_BLK_EXT)
+                while(j < m && j - i < cap)
+                {
+                    const aoclsparse_int lq = t.ptr[j] - t.ptr[j - 1], lj = t.ptr[j + 1] - t.ptr[j];
+                    if(lj != lq + 1 || total + lj > TRSV_BLK_NV || t.ind[t.ptr[j] + lq] != j - 1
+                       || (lq && std::memcmp(&t.ind[t.ptr[j]], &t.ind[t.ptr[j - 1]], sizeof(aoclsparse_int) * (size_t)lq)))
+                        break;
+                    total += lj;
+                    j++;
+                }
+            longer += (j - i > 5);
+            i = j;
+        }
+        static const bool nocut = [] { const char *e = getenv("AOCLSPARSE_MI355_TRSV_BLK_CUT"); return e && atoi(e) == 0; }();
+        if(nocut || longer == 0 || longer * 10 >= (aoclsparse_int)bstart.size())
+            break; // nothing to cut, or long chains are the rule: keep them
+    }
+    const aoclsparse_int nb = (aoclsparse_int)bstart.size();
+    bstart.push_back(m);
+    int max_rows = 1, max_ext = 0;
+    for(aoclsparse_int bq = 0; bq < nb; bq++)
+    {
+        const int rows = bstart[bq + 1] - bstart[bq];
+        max_rows       = std::max(max_rows, rows);
+        // a single row longer than the cap is served by the kernel's tail loop: it does not widen the unrolled part
+        max_ext = std::max(max_ext, std::min<int>(t.ptr[bstart[bq] + 1] - t.ptr[bstart[bq]], TRSV_BLK_EXT));
+    }
+    if((long long)nb * 16 > (long long)m * 10)
+        return aoclsparse_status_success; // fewer than 1.6 rows per block: the row-level schedules are as good
+    // 2. block levels (a block's external dependencies are those of its first row)
+    std::vector<aoclsparse_int> bof((size_t)m), blev((size_t)nb, 0);
+    for(aoclsparse_int b = 0; b < nb; b++)
+        for(aoclsparse_int r = bstart[b]; r < bstart[b + 1]; r++)
+            bof[r] = b;
+    aoclsparse_int nlev = 0;
+    for(aoclsparse_int b = 0; b < nb; b++)
+    {
+        const aoclsparse_int r  = bstart[b];
+        aoclsparse_int       lv = 0;
+        for(aoclsparse_int p = t.ptr[r]; p < t.ptr[r + 1]; p++)
+            lv = std::max(lv, blev[bof[t.ind[p]]] + 1);
+        blev[b] = lv;
+        nlev    = std::max(nlev, lv + 1);
+    }
+    // 3. blocks in level order (stable), positions of their rows
+    std::vector<aoclsparse_int> lptr((size_t)nlev + 1, 0);
+    for(aoclsparse_int b = 0; b < nb; b++)
+        lptr[blev[b] + 1]++;
+    for(aoclsparse_int l = 0; l < nlev; l++)
+        lptr[l + 1] += lptr[l];
+    std::vector<aoclsparse_int> order((size_t)nb), next(lptr.begin(), lptr.end() - 1);
+    for(aoclsparse_int b = 0; b < nb; b++)
+        order[next[blev[b]]++] = b;
+    std::vector<aoclsparse_int> bfirst((size_t)nb + 1, 0), rowmap((size_t)m), pos((size_t)m);
+    for(aoclsparse_int k = 0; k < nb; k++)
+    {
+        const aoclsparse_int b = order[k];
+        bfirst[k + 1]          = bfirst[k] + (bstart[b + 1] - bstart[b]);
+        for(aoclsparse_int r = bstart[b], q = bfirst[k]; r < bstart[b + 1]; r++, q++)
+            rowmap[q] = r, pos[r] = q;
+    }
+    // 4. the triangle in that order, dependencies as positions
+    std::vector<aoclsparse_int> pptr((size_t)m + 1, 0), pind(t.ind.size());
+    std::vector<T>              pval(t.val.size());
+    for(aoclsparse_int k = 0; k < m; k++)
+    {
+        const aoclsparse_int i = rowmap[k], len = t.ptr[i + 1] - t.ptr[i];
+        pptr[k + 1]            = pptr[k] + len;
+        for(aoclsparse_int j = 0; j < len; j++)
+            pind[pptr[k] + j] = pos[t.ind[t.ptr[i] + j]];
+        std::copy(t.val.begin() + t.ptr[i], t.val.begin() + t.ptr[i + 1], pval.begin() + pptr[k]);
+    }
+    // 5. slices of <= 64 blocks inside one block level
+    std::vector<aoclsparse_int> slices;
+    for(aoclsparse_int l = 0; l < nlev; l++)
+        for(aoclsparse_int k = lptr[l]; k < lptr[l + 1]; k += 64)
+            slices.push_back(k);
+    slices.push_back(nb);
+    // ... followed by each slice's block level (read by the diagnostic trace only)
+    {
+        const size_t ns = slices.size() - 1;
+        for(size_t q = 0; q < ns; q++)
+            slices.push_back(blev[order[slices[q]]]);
+        // ... and the first slice of each level (nlev + 1 entries): the kernel's gate counts finished slices per level
+        aoclsparse_int first = 0;
+        for(aoclsparse_int l = 0; l < nlev; l++)
+        {
+            slices.push_back(first);
+            first += (lptr[l + 1] - lptr[l] + 63) / 64;
+        }
+        slices.push_back(first);
+    }
+    hipStream_t       st = Runtime::get().stream();
+    aoclsparse_status rc = bp.rowmap.upload(rowmap.data(), sizeof(aoclsparse_int) * (size_t)m, st);
+    if(rc == aoclsparse_status_success)
+        rc = bp.pptr.upload(pptr.data(), sizeof(aoclsparse_int) * ((size_t)m + 1), st);
+    if(rc == aoclsparse_status_success)
+        rc = bp.pind.upload(pind.data(), sizeof(aoclsparse_int) * pind.size(), st);
+    if(rc == aoclsparse_status_success)
+        rc = bp.pval.upload(pval.data(), sizeof(T) * pval.size(), st);
+    if(rc == aoclsparse_status_success)
+        rc = bp.bfirst.upload(bfirst.data(), sizeof(aoclsparse_int) * bfirst.size(), st);
+    if(rc == aoclsparse_status_success)
+        rc = bp.slices.upload(slices.data(), sizeof(aoclsparse_int) * slices.size(), st);
+    if(rc != aoclsparse_status_success)
+        return rc;
+    bp.nblocks = nb, bp.nslices = (aoclsparse_int)(slices.size() - 2 - (size_t)nlev) / 2, bp.nlevels = nlev;
+    bp.max_rows = max_rows, bp.max_ext = max_ext;
+    bp.valid = true;
+    return aoclsparse_status_success;
+}
+
 template <typename T>
 static aoclsparse_status build_plan_t(const HostCsr &c, bool upper, bool transposed, bool conj, TrsvPlan &plan)
 {
     Triangle<T> t;
     build_triangle<T>(c, upper, transposed, conj, t);
-    return build_levels<T>(c.m, t, plan);
+    aoclsparse_status st = build_levels<T>(c.m, t, plan);
+    if constexpr(std::is_floating_point<T>::value)
+        if(st == aoclsparse_status_success && !upper && !transposed && !plan.blk.tried)
+            st = build_blocked<T>(c.m, t, plan.blk);
+    return st;
 }
 
 aoclsparse_status ensure_trsv(aoclsparse_matrix A, bool upper, bool transposed, bool conj)
@@ -275,7 +422,9 @@ aoclsparse_status solve_core(aoclsparse_operation trans, T alpha, aoclsparse_mat
     const int sf = (sf_env == 2 || sf_env == 3) ? sf_env
                    : (nrhs == 1 && plan.nslices > 0 && (long long)plan.nslices * 16 <= (long long)m
                       && (long long)plan.nnz_tri <= 10LL * m) ? 3 : 2;
-    const int schedule = is_cplx ? 1 : kid == 0 ? 0 : (kid == 3 ? sf : (kid > 0 ? 1 : (plan.nlevels <= 32 ? 0 : sf)));
+    // chained rows (the dofs of a node) solved back to back by one lane: one hop per BLOCK level instead of per row level
+    const int sfb = (sf_env == 0 && nrhs == 1 && plan.blk.valid) ? 4 : sf;
+    const int schedule = is_cplx ? 1 : kid == 0 ? 0 : (kid == 3 ? sfb : (kid > 0 ? 1 : (plan.nlevels <= 32 ? 0 : sfb)));
     // a wait that expired in an EARLIER asynchronous (device-pointer) solve is reported now
     if(rt.trsv_timeout_host && *rt.trsv_timeout_host)
     {
@@ -284,9 +433,10 @@ aoclsparse_status solve_core(aoclsparse_operation trans, T alpha, aoclsparse_mat
         return aoclsparse_status_internal_error;
     }
 
-    st = A->trsv_xp.alloc(sizeof(T) * (size_t)m * (size_t)nrhs);
+    // (+ TRSV_XP_PAD elements: the block kernel parks the stores of lanes / rows that own nothing there)
+    st = A->trsv_xp.alloc(sizeof(T) * ((size_t)m * (size_t)nrhs + TRSV_XP_PAD));
     if(st == aoclsparse_status_success)
-        st = A->trsv_scratch.alloc(sizeof(unsigned int) * ((size_t)nrhs + 1));
+        st = A->trsv_scratch.alloc(sizeof(unsigned int) * std::max((size_t)nrhs + 1, (size_t)2 + (size_t)plan.blk.nlevels));
     if(st != aoclsparse_status_success)
         return st;
 

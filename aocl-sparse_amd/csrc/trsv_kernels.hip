@@ -30,6 +30,12 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
+
 namespace mi355
 {
 
@@ -72,12 +78,14 @@ __device__ __forceinline__ float neg_fma(float a, float b, float c)
 }
 
 template <typename T>
-__global__ void trsv_fill_tag_kernel(T *x, long long m)
+__global__ void trsv_fill_tag_kernel(T *x, long long m, long long zero_at = -1)
 {
     using B           = typename tag<T>::bits;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if(i < m)
         reinterpret_cast<B *>(x)[i] = tag<T>::value;
+    if(i == 0 && zero_at >= 0)
+        x[zero_at] = T(0); // the block kernel's "no dependency here" slot
 }
 
 // All kernels work in LEVEL-ORDER ("position") space: xp[k] = x[rowmap[k]], and pind[] holds the
@@ -492,6 +500,357 @@ __global__ __launch_bounds__(64 * WV) void trsv_slice_kernel(
     x[(size_t)i * incx] = xi;
 }
 
+// ---- schedule 4: sync-free, a lane per BLOCK of chained rows (supernodal; lower non-transposed) ------------------
+// plan.blk groups consecutive rows r, r+1, ... where each row depends on exactly its predecessor's dependencies plus the
+// predecessor (the dofs of one mesh node in an ILU(0) factor).  One lane solves a block: it waits ONCE for the block's
+// external dependencies (those of its first row), then runs the rows back to back -- row a's chain is [the external
+// entries in order, then rows 0..a-1 of the block], which is exactly its CSR order, so every x is bit-identical to the
+// serial reference chain.  The dependency DAG is levelled per BLOCK: the shell-like factor has 1,101 block levels
+// instead of 5,505 row levels, i.e. a fifth of the cross-CU hand-offs, and the 15 neighbour values of a node are
+// fetched once instead of five times.
+// One wavefront per workgroup = one slice of <= 64 blocks of ONE block level (lanes never depend on each other).
+// Blocks are taken through an atomic ticket, so a wavefront only ever waits on blocks of wavefronts that have started.
+//
+// What the time of a block level is made of was measured with the per-slice trace below (tools/trsv_trace.py,
+// profiles/r2/trsv_block_trace.txt) -- a single wavefront issues one instruction every ~2.6 cycles, so everything
+// between "the last dependency is in" and "my values are published" is priced by its INSTRUCTION COUNT:
+//   * everything that does not need the dependencies happens before the wait: the block's values are laid out in LDS
+//     at compile-time slots ([lane][row a][entry e], zero where the block has no entry), so that after the wait the
+//     rows are 53 ds_read_b128 at constant offsets + 90 FMAs, no address arithmetic, no selects (as first written, with
+//     clamped indices and selects, that phase was ~1,500 instructions = 1.84 us per block level);
+//   * pending dependencies are polled together, one round of loads per look;
+//   * a wavefront does not look at all before the level two below its own is complete (the gate).
+__device__ __forceinline__ void lds_read_pair_async(double (&d)[2], unsigned int addr)
+{
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2             v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    d[0] = v.x, d[1] = v.y;
+}
+__device__ __forceinline__ void lds_read_pair_async(float (&d)[2], unsigned int addr)
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2            v;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr));
+    d[0] = v.x, d[1] = v.y;
+}
+__device__ __forceinline__ void lds_read_wait()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+// orders the first use of a value read by lds_read_pair_async after lds_read_wait
+template <typename T>
+__device__ __forceinline__ void lds_read_landed(T &v)
+{
+    asm volatile("" : "+v"(v));
+}
+
+// slots per lane of the fixed layout: BS x EXT external + BS x BS internal values, padded so that a lane's stride is an
+// odd number of (2 values): the paired reads of the 64 lanes then fall on distinct LDS banks
+constexpr int trsv_blk_slots(int bs, int ext)
+{
+    const int sl = bs * ext + bs * (bs + (bs & 1)); // ext and the padded internal stride are even
+    return (sl / 2) % 2 ? sl : sl + 2;
+}
+
+template <typename T, int BS, int EXT>
+__global__ __launch_bounds__(64) void trsv_block_kernel(
+    aoclsparse_int m, aoclsparse_int nslices, const aoclsparse_int *__restrict__ slices,
+    const aoclsparse_int *__restrict__ bfirst, const aoclsparse_int *__restrict__ rowmap,
+    const aoclsparse_int *__restrict__ pptr, const aoclsparse_int *__restrict__ pind, const T *__restrict__ pval,
+    const T *__restrict__ diag, const T *__restrict__ b, T *xp, T *x, T alpha, int unit, unsigned int *ticket,
+    unsigned int *timeout_flag, int incb, int incx, unsigned long long *trace, unsigned int *level_done, int gate)
+{
+    using B = typename tag<T>::bits;
+    static_assert(EXT % 2 == 0, "paired LDS reads");
+    constexpr int BSP = BS + (BS & 1), SLOTS = trsv_blk_slots(BS, EXT), INT0 = BS * EXT; // internal values from slot INT0
+    extern __shared__ unsigned char s_raw[];
+    T            *s_mine = reinterpret_cast<T *>(s_raw) + (size_t)threadIdx.x * SLOTS;
+    const int     tid    = threadIdx.x;
+    unsigned int  tk     = 0;
+    if(tid == 0)
+        tk = atomicAdd(ticket, 1u);
+    const int sl = __builtin_amdgcn_readfirstlane((int)tk);
+    if(sl >= nslices)
+        return;
+    // (diagnostic stamps are kept in registers and stored at the very end: a store right after the wait would put its own
+    // round trip into the phase it is timing)
+    const unsigned long long t_start = trace ? __builtin_amdgcn_s_memrealtime() : 0;
+    const int lev = slices[nslices + 1 + sl]; // block level of this slice
+    const int bl  = slices[sl] + tid;
+    // lanes beyond the slice own an empty block (c = 0): they run the same straight-line code and publish nothing
+    const bool live = bl < slices[sl + 1];
+    const int  k0   = live ? bfirst[bl] : 0;
+    const int  c    = live ? bfirst[bl + 1] - k0 : 0; // positions [k0, k0 + c), c <= BS
+    const int  p0   = live ? pptr[k0] : 0;
+    const int  n0   = live ? pptr[k0 + 1] - p0 : 0; // external dependencies = the first row's entries
+    const int  nl   = n0 < EXT ? n0 : EXT; // a single row may have more: the tail loop below
+    B         *xb   = reinterpret_cast<B *>(xp);
+    int        q[EXT];
+#pragma unroll
+    for(int e = 0; e < EXT; e++)
+        q[e] = e < nl ? pind[p0 + e] : m + TRSV_XP_PAD - 1; // beyond the row: a slot that always holds 0
+    // the block's values -> their slots (zero elsewhere)
+    for(int j = 0; j < SLOTS; j++)
+        s_mine[j] = T(0);
+    {
+        int p = p0;
+        for(int a = 0; a < c; a++)
+        {
+            for(int e = 0; e < nl; e++)
+                s_mine[a * EXT + e] = pval[p + e];
+            p += n0;
+            for(int tt = 0; tt < a; tt++)
+                s_mine[INT0 + a * BSP + tt] = pval[p + tt];
+            p += a;
+        }
+    }
+    // right-hand sides, diagonals, destinations
+    T   rhs[BS], dg[BS];
+    T  *xdst[BS];
+    B  *bdst[BS]; // rows this lane does not own are parked behind the m positions (one slot per lane, never read)
+#pragma unroll
+    for(int a = 0; a < BS; a++)
+    {
+        const int row = a < c ? rowmap[k0 + a] : 0;
+        rhs[a]        = a < c ? alpha * b[(size_t)row * incb] : T(0);
+        dg[a]         = (a < c && !unit) ? diag[row] : T(1);
+        xdst[a]       = a < c ? x + (size_t)row * incx : xp + (size_t)m + 64 + tid;
+        bdst[a]       = a < c ? xb + k0 + a : xb + (size_t)m + tid;
+    }
+    unsigned long long t0   = 0;
+    bool               dead = false;
+    unsigned int       spins = 0;
+    auto               tick  = [&](unsigned int every) {
+        if((++spins & every) == 0)
+        {
+            // bounded by WALL time (s_memrealtime, 100 MHz), not by a spin count
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if(t0 == 0)
+                t0 = now;
+            else if(now - t0 > TRSV_WAIT_TICKS)
+                dead = true;
+        }
+    };
+    // The gate: a wavefront does not look at its dependencies before block level (mine - gate) is complete -- until then
+    // it polls ONE word (level_done, bumped by every finished slice).  Wavefronts are resident hundreds of levels ahead
+    // of the front; with all of them polling 15 x 64 scattered lines per look, the looks of the few wavefronts that
+    // matter queued behind ~800 k requests per round (measured: 4.07 ms without the gate, 3.64 ms with, same kernel).
+    if(gate > 0 && lev >= gate)
+    {
+        const aoclsparse_int *lsl    = slices + 2 * (size_t)nslices + 1;
+        const unsigned int    target = (unsigned int)(lsl[lev - gate + 1] - lsl[lev - gate]);
+        while(__hip_atomic_load(&level_done[lev - gate], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && !dead)
+        {
+            __builtin_amdgcn_s_sleep(4);
+            tick(255u);
+        }
+    }
+    // All pending dependencies are polled TOGETHER: one round of loads per look, whatever the number outstanding (a
+    // node's 10-15 external values are published by its neighbours at about the same time; polling them one after the
+    // other put 15 trips on every block level, "wait for the last one, then re-read the rest" still two; two looks in
+    // flight half a trip apart doubled the polling traffic and lost 0.9 ms).
+    B bits[EXT];
+#pragma unroll
+    for(int e = 0; e < EXT; e++)
+        bits[e] = __hip_atomic_load(&xb[q[e]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (entry e is re-read by the whole wavefront while ANY of its lanes still misses it: a uniform branch around an
+    // unpredicated load.  Predicated per lane, the 16 exec-masked loads and the register copies hipcc wrapped around them
+    // were ~200 instructions = 0.4 us per look on top of the trip itself; a value that has arrived never changes, so
+    // reading it again is harmless.)
+    for(;;)
+    {
+        unsigned long long miss[EXT], any = 0;
+#pragma unroll
+        for(int e = 0; e < EXT; e++)
+        {
+            miss[e] = __builtin_amdgcn_ballot_w64(bits[e] == tag<T>::value);
+            any |= miss[e];
+        }
+        if(any == 0 || __builtin_amdgcn_ballot_w64(dead) != 0)
+            break;
+        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for(int e = 0; e < EXT; e++)
+            if(miss[e] != 0)
+                bits[e] = __hip_atomic_load(&xb[q[e]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tick(127u);
+    }
+    const unsigned long long t_ready = trace ? __builtin_amdgcn_s_memrealtime() : 0;
+    // ---- from here on every instruction is on the critical path of the solve ----
+    T xe[EXT];
+#pragma unroll
+    for(int e = 0; e < EXT; e++)
+        __builtin_memcpy(&xe[e], &bits[e], sizeof(T)); // 0 beyond the row (bits = 0), times a 0 value below
+    const unsigned int base = (unsigned int)(size_t)s_mine;
+    auto               read_row = [&](int a, T(&ve)[EXT], T(&vn)[BSP]) {
+#pragma unroll
+        for(int e = 0; e < EXT; e += 2)
+        {
+            T pr[2];
+            lds_read_pair_async(pr, base + (unsigned int)((a * EXT + e) * sizeof(T)));
+            ve[e] = pr[0], ve[e + 1] = pr[1];
+        }
+#pragma unroll
+        for(int tt = 0; tt < BSP; tt += 2)
+            if(tt < a)
+            {
+                T pr[2];
+                lds_read_pair_async(pr, base + (unsigned int)((INT0 + a * BSP + tt) * sizeof(T)));
+                vn[tt] = pr[0], vn[tt + 1] = pr[1];
+            }
+    };
+    auto landed = [&](int a, T(&ve)[EXT], T(&vn)[BSP]) {
+#pragma unroll
+        for(int e = 0; e < EXT; e++)
+            lds_read_landed(ve[e]);
+#pragma unroll
+        for(int tt = 0; tt < BSP; tt++)
+            if(tt < a + (a & 1))
+                lds_read_landed(vn[tt]);
+    };
+    // a single row with more than EXT dependencies (never inside a multi-row block): the rest one by one
+    auto long_row_tail = [&](T &x0) {
+        if(n0 > EXT)
+            for(int p = p0 + EXT; p < p0 + n0 && !dead; p++)
+            {
+                const int qq  = pind[p];
+                B         got = __hip_atomic_load(&xb[qq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while(got == tag<T>::value && !dead)
+                {
+                    __builtin_amdgcn_s_sleep(1);
+                    got = __hip_atomic_load(&xb[qq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    tick(1023u);
+                }
+                T xv;
+                __builtin_memcpy(&xv, &got, sizeof(T));
+                x0 = neg_fma(pval[p], xv, x0);
+            }
+    };
+    auto publish = [&](int a, T xa) {
+        if(a < c && !dead)
+        {
+            B out;
+            __builtin_memcpy(&out, &xa, sizeof(T));
+            if(out == tag<T>::value)
+                out = qnan_bits<T>::value;
+            __hip_atomic_store(bdst[a], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *xdst[a] = xa;
+        }
+    };
+    T                  xi[BS];
+    unsigned long long t_lds = 0, t_ext = 0;
+    if constexpr(SLOTS <= 112)
+    {
+        // all values in registers at once; the external parts of the rows are BS independent chains, interleaved
+        // (x - 0 * 0 = x beyond a row's entries)
+        T ve[BS][EXT], vn[BS][BSP];
+#pragma unroll
+        for(int a = 0; a < BS; a++)
+            read_row(a, ve[a], vn[a]);
+        lds_read_wait();
+        t_lds = trace ? __builtin_amdgcn_s_memrealtime() : 0;
+#pragma unroll
+        for(int a = 0; a < BS; a++)
+            landed(a, ve[a], vn[a]);
+#pragma unroll
+        for(int a = 0; a < BS; a++)
+            xi[a] = rhs[a];
+#pragma unroll
+        for(int e = 0; e < EXT; e++)
+#pragma unroll
+            for(int a = 0; a < BS; a++)
+                xi[a] = neg_fma(ve[a][e], xe[e], xi[a]);
+        long_row_tail(xi[0]);
+        if(trace)
+        {
+            lds_read_landed(xi[BS - 1]);
+            t_ext = __builtin_amdgcn_s_memrealtime();
+        }
+        // internal part, column by column: as soon as row tt is known it is taken out of every later row, so the chain
+        // from the first row to the last is BS - 1 FMAs long, not BS (BS - 1) / 2 (each row still receives its terms in
+        // CSR order).  Straight-line code, published in one go at the end: with a predicated store after every row the
+        // compiler kept the rows in separate basic blocks (0.56 us for 10 FMAs).
+        // Every row is published the moment it is final -- without a branch: rows (and lanes) that own nothing store to
+        // a parked slot.  (Published together at the end, the last row queued behind the other nine stores: +0.3 us per
+        // block level; with a predicated store after every row the compiler kept the rows in separate basic blocks.)
+        auto put = [&](int a) {
+            B out;
+            __builtin_memcpy(&out, &xi[a], sizeof(T));
+            out = out == tag<T>::value ? qnan_bits<T>::value : out;
+            __hip_atomic_store(bdst[a], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        if(dead)
+        {
+#pragma unroll
+            for(int a = 0; a < BS; a++)
+                bdst[a] = xb + (size_t)m + tid, xdst[a] = xp + (size_t)m + 64 + tid;
+        }
+        if(unit)
+        {
+#pragma unroll
+            for(int tt = 0; tt < BS; tt++)
+            {
+                put(tt);
+#pragma unroll
+                for(int a = tt + 1; a < BS; a++)
+                    xi[a] = neg_fma(vn[a][tt], xi[tt], xi[a]);
+            }
+        }
+        else
+        {
+#pragma unroll
+            for(int tt = 0; tt < BS; tt++)
+            {
+                xi[tt] /= dg[tt];
+                put(tt);
+#pragma unroll
+                for(int a = tt + 1; a < BS; a++)
+                    xi[a] = neg_fma(vn[a][tt], xi[tt], xi[a]);
+            }
+        }
+        // the caller's x: nobody waits for these
+#pragma unroll
+        for(int a = 0; a < BS; a++)
+            *xdst[a] = xi[a];
+    }
+    else
+    {
+        // larger shapes: row by row (all rows at once would need BS x (EXT + BS) values in registers)
+#pragma unroll
+        for(int a = 0; a < BS; a++)
+        {
+            T ve[EXT], vn[BSP];
+            read_row(a, ve, vn);
+            lds_read_wait();
+            landed(a, ve, vn);
+            xi[a] = rhs[a];
+#pragma unroll
+            for(int e = 0; e < EXT; e++)
+                xi[a] = neg_fma(ve[e], xe[e], xi[a]);
+            if(a == 0)
+                long_row_tail(xi[0]);
+#pragma unroll
+            for(int tt = 0; tt < BS; tt++)
+                if(tt < a)
+                    xi[a] = neg_fma(vn[tt], xi[tt], xi[a]);
+            if(!unit)
+                xi[a] /= dg[a];
+            publish(a, xi[a]);
+        }
+    }
+    if(trace && tid == 0)
+    {
+        unsigned long long *tr = trace + 6 * (size_t)sl;
+        tr[0] = t_start, tr[1] = t_ready, tr[2] = __builtin_amdgcn_s_memrealtime(), tr[3] = (unsigned long long)lev;
+        tr[4] = t_lds, tr[5] = t_ext;
+    }
+    if(tid == 0 && !dead)
+        __hip_atomic_fetch_add(&level_done[lev], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if(dead)
+        __hip_atomic_store(timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // scratch: nrhs ticket words followed by one timeout word (zeroed here for the sync-free schedule)
 template <typename T>
 aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, aoclsparse_int m,
@@ -508,6 +867,8 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
     RhsGeom               g{b_off, x_off, incb, incx, 0};
     if(schedule == 1 && (nrhs != 1 || incb != 1 || incx != 1))
         schedule = 2; // the single-workgroup runs of the hybrid schedule are single-RHS, unit stride
+    if(schedule == 4 && (nrhs != 1 || !plan.blk.valid))
+        schedule = 3;
     if(schedule == 3 && (nrhs != 1 || plan.nslices <= 0))
         schedule = 2; // the slice kernel is single-RHS; trsm keeps the lane-per-position kernel
     auto level_launch = [&](aoclsparse_int l) {
@@ -538,6 +899,66 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
                 for(aoclsparse_int l = sg.l0; l < sg.l1; l++)
                     level_launch(l);
         }
+    }
+    else if(schedule == 4)
+    {
+        // sync-free, one lane per block of chained rows (plan.blk has its own level-ordered copy of the triangle)
+        const TrsvBlockPlan &bp = plan.blk;
+        // scratch: ticket, timeout word, then one finished-slices counter per block level
+        MI355_HIP_TRY(hipMemsetAsync(scratch, 0, (2 + (size_t)bp.nlevels) * sizeof(unsigned int), s));
+        hipLaunchKernelGGL((trsv_fill_tag_kernel<T>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, xp, (long long)m,
+                           (long long)m + TRSV_XP_PAD - 1);
+        static const int gate  = [] { const char *e = getenv("AOCLSPARSE_MI355_TRSV_GATE"); return e ? atoi(e) : 2; }();
+        // diagnostic: AOCLSPARSE_MI355_TRSV_TRACE=<file> dumps, per slice, the 100 MHz clock after the ticket, when the
+        // dependencies were all in, at the end, the slice's block level, after the LDS reads, after the external FMAs (6 x u64 per slice; tools/trsv_trace.py)
+        static const char  *trace_path = getenv("AOCLSPARSE_MI355_TRSV_TRACE");
+        unsigned long long *trace      = nullptr;
+        if(trace_path && hipMalloc(&trace, sizeof(unsigned long long) * 6 * (size_t)bp.nslices) != hipSuccess)
+            trace = nullptr;
+        auto go = [&](auto bs_tag, auto ext_tag) {
+            constexpr int    BS = decltype(bs_tag)::value, EXT = decltype(ext_tag)::value;
+            constexpr size_t need = sizeof(T) * 64 * (size_t)trsv_blk_slots(BS, EXT);
+            static_assert(need <= 160 * 1024, "LDS of one CU");
+            static const size_t floor_kb = [] { const char *e = getenv("AOCLSPARSE_MI355_TRSV_BLK_LDS"); return e ? (size_t)atoi(e) : (size_t)0; }();
+            const size_t        lds = std::min<size_t>(std::max(need, floor_kb * 1024), 160 * 1024);
+            if(lds > 64 * 1024)
+            {
+                static const hipError_t raised = hipFuncSetAttribute(
+                    reinterpret_cast<const void *>(&trsv_block_kernel<T, BS, EXT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if(raised != hipSuccess)
+                    return aoclsparse_status_internal_error;
+            }
+            hipLaunchKernelGGL((trsv_block_kernel<T, BS, EXT>), dim3((unsigned)bp.nslices), dim3(64), lds, s, m, bp.nslices,
+                               bp.slices.as<aoclsparse_int>(), bp.bfirst.as<aoclsparse_int>(), bp.rowmap.as<aoclsparse_int>(),
+                               bp.pptr.as<aoclsparse_int>(), bp.pind.as<aoclsparse_int>(), bp.pval.as<T>(), diag, b, xp, x,
+                               alpha, (int)unit, scratch, timeout_word ? timeout_word : scratch + 1, (int)incb, (int)incx,
+                               trace, scratch + 2, gate);
+            return aoclsparse_status_success;
+        };
+        using std::integral_constant;
+        // shapes by the plan's largest block / external list (the loops over rows and external entries are unrolled)
+        static const bool force_big = [] { const char *e = getenv("AOCLSPARSE_MI355_TRSV_BLK_SHAPE"); return e && atoi(e) == 8; }();
+        const bool small_ext = bp.max_ext <= 16, small_bs = bp.max_rows <= 5 && !force_big;
+        const aoclsparse_status lst = small_ext && small_bs ? go(integral_constant<int, 5>{}, integral_constant<int, 16>{})
+                                      : small_ext           ? go(integral_constant<int, TRSV_BLK_ROWS>{}, integral_constant<int, 16>{})
+                                      : small_bs ? go(integral_constant<int, 5>{}, integral_constant<int, TRSV_BLK_EXT>{})
+                                                 : go(integral_constant<int, TRSV_BLK_ROWS>{}, integral_constant<int, TRSV_BLK_EXT>{});
+        if(trace)
+        {
+            std::vector<unsigned long long> host(6 * (size_t)bp.nslices);
+            if(hipStreamSynchronize(s) == hipSuccess
+               && hipMemcpy(host.data(), trace, sizeof(unsigned long long) * host.size(), hipMemcpyDeviceToHost) == hipSuccess)
+                if(FILE *f = fopen(trace_path, "wb"))
+                {
+                    fwrite(host.data(), sizeof(unsigned long long), host.size(), f);
+                    fclose(f);
+                }
+            fprintf(stderr, "[trsv trace] blocks %d slices %d levels %d max_rows %d max_ext %d\n", (int)bp.nblocks, (int)bp.nslices,
+                    (int)bp.nlevels, bp.max_rows, bp.max_ext);
+            (void)hipFree(trace);
+        }
+        if(lst != aoclsparse_status_success)
+            return lst;
     }
     else if(schedule == 3)
     {
