@@ -239,23 +239,27 @@ struct TrsvSegment
     aoclsparse_int l0, l1; // levels [l0, l1)
     bool           narrow; // true: one single-workgroup launch loops over the levels
 };
-// Supernodal variant of the plan (lower, non-transposed solves; trsv_block_kernel): consecutive rows where row r+1
-// depends on exactly row r's dependencies plus row r itself (the dofs of a mesh node in an ILU(0) factor) form a BLOCK
-// that ONE lane solves back to back -- the block's external dependencies are waited for once, the rows inside it hand
-// their results on in registers -- so the dependency DAG is levelled per block (shell-like factor: 1,101 block levels
-// instead of 5,505 row levels).  Own level-ordered copy of the triangle (positions = rows in block-level order).
+// Supernodal variant of the plan (trsv_block_kernel; all four (fill, op) triangles of real types): rows consecutive in
+// SOLVE order where each depends on exactly its predecessor's dependencies plus the predecessor (the dofs of a mesh node
+// in an ILU(0) factor) form a BLOCK that ONE lane solves back to back -- the block's external dependencies are waited for
+// once, the rows inside it hand their results on in registers -- so the dependency DAG is levelled per block (shell-like
+// factor: 1,101 block levels instead of 5,505 row levels).  Own level-ordered copy of the triangle (positions = rows in
+// block-level order, in solve order inside a block; entries in chain order).
 constexpr int TRSV_BLK_ROWS = 8; // rows per block at most
 constexpr int TRSV_BLK_EXT  = 24; // external dependencies of a multi-row block at most
-constexpr int TRSV_BLK_NV   = 96; // entries of a multi-row block at most (staged per lane in LDS)
+constexpr int TRSV_BLK_NV   = 96; // entries of a multi-row block at most
 constexpr int TRSV_XP_PAD = 128; // spare elements behind the m x nrhs position-ordered solution buffer
 struct TrsvBlockPlan
 {
     bool           tried = false, valid = false;
+    bool           front = false; // a row's chain starts with the rows of its own block (U), instead of ending with them
     aoclsparse_int nblocks = 0, nslices = 0, nlevels = 0;
     int            max_rows = 1, max_ext = 0; // largest block / largest external list of a multi-row block
     DeviceBuffer   rowmap, pptr, pind, pval; // as TrsvPlan, in block-level order
     DeviceBuffer   bfirst; // nblocks+1: first position of every block
-    DeviceBuffer   slices; // nslices+1: first BLOCK of every slice (<= 64 blocks of one block level)
+    // nslices+1: first BLOCK of every slice (<= 64 blocks of one block level); then nslices: the slice's block level;
+    // then nlevels+1: first slice of every level (the kernel's gate counts finished slices per level)
+    DeviceBuffer   slices;
 };
 struct TrsvPlan
 {
@@ -611,7 +615,7 @@ aoclsparse_status launch_lincomb(hipStream_t s, int sign, aoclsparse_int n, int 
 // TRSV on the level-ordered layout (trsv_kernels.hip).
 // schedule 0: one launch per level; 1: hybrid (narrow level runs inside one workgroup); 2: sync-free, a lane per
 // position; 3: sync-free, a level slice per wavefront (single right-hand side; falls back to 2 otherwise);
-// 4: sync-free, a lane per BLOCK of chained rows (plan.blk, lower non-transposed; falls back to 3 / 2).
+// 4: sync-free, a lane per BLOCK of chained rows (plan.blk, real types, one right-hand side; falls back to 3 / 2).
 // timeout_word: where a sync-free kernel reports an expired wait (pinned host memory, Runtime::trsv_timeout_dev).
 constexpr int TRSV_NARROW = 1024; // a level this narrow is solved by one workgroup (one row per lane)
 template <typename T>

@@ -163,15 +163,18 @@ static aoclsparse_status build_levels(aoclsparse_int m, const Triangle<T> &t, Tr
     return rc;
 }
 
-// Blocked (supernodal) plan for a LOWER, non-transposed triangle: see TrsvBlockPlan.  Row r+1 joins row r's block when
-// its dependency list is exactly row r's list followed by r itself (entry for entry: the lists are ascending), the block
-// stays within TRSV_BLK_ROWS rows, TRSV_BLK_EXT external dependencies and TRSV_BLK_NV entries.  Built only when it pays:
-// at least 1.6 rows per block on average.
+// Blocked (supernodal) plan: see TrsvBlockPlan and trsv_block_kernel.  In SOLVE order (ascending rows, or descending for
+// U and L^T) a row joins its predecessor's block when its dependency list -- in the order the reference's chain applies it
+// -- is exactly the predecessor's list with the predecessor itself
+//   * appended at the END  (L, L^T, U^T: the chain runs over the far rows first, the nearest last), or
+//   * put at the FRONT     (U: ref_trsv_u walks the row left to right, so the row solved last comes first);
+// the block stays within TRSV_BLK_ROWS rows, TRSV_BLK_EXT external dependencies and TRSV_BLK_NV entries.  One triangle
+// uses one of the two forms (whichever groups more rows).  Built only when it pays: >= 1.6 rows per block on average.
 template <typename T>
 static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, TrsvBlockPlan &bp)
 {
     bp.tried = true;
-    if(t.descending || m < 2)
+    if(m < 2)
         return aoclsparse_status_success;
     static const bool off = [] {
         const char *e = getenv("AOCLSPARSE_MI355_TRSV_BLOCKS");
@@ -179,88 +182,106 @@ static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, T
     }();
     if(off)
         return aoclsparse_status_success;
-    // 1. blocks, in row order.  The kernel is compiled for blocks of up to 5 rows (all rows' chains interleaved, every
-    // value in registers) and up to TRSV_BLK_ROWS (row by row): when only a few chains run longer than 5 rows they are
-    // cut at 5, so that one long chain does not put the whole solve on the slower shape (shell-like factor: 5-dof nodes,
-    // 0.4 % of the chains reach 8 rows; 1.4 us -> 0.5 us of arithmetic per block level).
-    std::vector<aoclsparse_int> bstart;
+    auto row_at = [&](aoclsparse_int k) { return t.descending ? m - 1 - k : k; }; // k-th row in solve order
+    auto len_of = [&](aoclsparse_int i) { return t.ptr[i + 1] - t.ptr[i]; };
+    // does `row` (lj entries) chain onto `prev` (lq entries)?  front = the predecessor is the FIRST entry
+    auto chains = [&](aoclsparse_int row, aoclsparse_int prev, bool front) {
+        const aoclsparse_int  lq = len_of(prev), lj = len_of(row);
+        const aoclsparse_int *a = &t.ind[t.ptr[row]], *q = &t.ind[t.ptr[prev]];
+        if(lj != lq + 1 || a[front ? 0 : lq] != prev)
+            return false;
+        return lq == 0 || std::memcmp(a + (front ? 1 : 0), q, sizeof(aoclsparse_int) * (size_t)lq) == 0;
+    };
+    // 1. blocks, as ranges of the solve order.  The kernel is compiled for blocks of up to 5 rows (every value in
+    // registers across the wait) and up to TRSV_BLK_ROWS (row by row, values in LDS): when only a few chains run longer
+    // than 5 rows they are cut at 5, so that one long chain does not put the whole solve on the slower shape.
+    std::vector<aoclsparse_int> bstart, best;
+    bool                        front = false, best_front = false;
     bstart.reserve((size_t)m / 2 + 2);
-    for(int cap : {TRSV_BLK_ROWS, 5})
+    static const bool nocut = [] { const char *e = getenv("AOCLSPARSE_MI355_TRSV_BLK_CUT"); return e && atoi(e) == 0; }();
+    for(int form = 0; form < 2; form++)
     {
-        bstart.clear();
-        aoclsparse_int longer = 0;
-        for(aoclsparse_int i = 0; i < m;)
+        front = form == 1;
+        for(int cap : {TRSV_BLK_ROWS, 5})
         {
-            bstart.push_back(i);
-            const aoclsparse_int n0 = t.ptr[i + 1] - t.ptr[i];
-            aoclsparse_int       j = i + 1, total = n0;
-            if(n0 <= TRSV_BLK_EXT)
-                while(j < m && j - i < cap)
-                {
-                    const aoclsparse_int lq = t.ptr[j] - t.ptr[j - 1], lj = t.ptr[j + 1] - t.ptr[j];
-                    if(lj != lq + 1 || total + lj > TRSV_BLK_NV || t.ind[t.ptr[j] + lq] != j - 1
-                       || (lq && std::memcmp(&t.ind[t.ptr[j]], &t.ind[t.ptr[j - 1]], sizeof(aoclsparse_int) * (size_t)lq)))
-                        break;
-                    total += lj;
-                    j++;
-                }
-            longer += (j - i > 5);
-            i = j;
+            bstart.clear();
+            aoclsparse_int longer = 0;
+            for(aoclsparse_int k = 0; k < m;)
+            {
+                bstart.push_back(k);
+                const aoclsparse_int n0 = len_of(row_at(k));
+                aoclsparse_int       j = k + 1, total = n0;
+                if(n0 <= TRSV_BLK_EXT)
+                    while(j < m && j - k < cap)
+                    {
+                        const aoclsparse_int lj = len_of(row_at(j));
+                        if(total + lj > TRSV_BLK_NV || !chains(row_at(j), row_at(j - 1), front))
+                            break;
+                        total += lj;
+                        j++;
+                    }
+                longer += (j - k > 5);
+                k = j;
+            }
+            if(nocut || longer == 0 || longer * 10 >= (aoclsparse_int)bstart.size())
+                break; // nothing to cut, or long chains are the rule: keep them
         }
-        static const bool nocut = [] { const char *e = getenv("AOCLSPARSE_MI355_TRSV_BLK_CUT"); return e && atoi(e) == 0; }();
-        if(nocut || longer == 0 || longer * 10 >= (aoclsparse_int)bstart.size())
-            break; // nothing to cut, or long chains are the rule: keep them
+        if(best.empty() || bstart.size() < best.size())
+            best = bstart, best_front = front;
+        if(best.size() * 16 <= (size_t)m * 10)
+            break; // this form already groups the rows
     }
+    bstart.swap(best);
+    front = best_front;
     const aoclsparse_int nb = (aoclsparse_int)bstart.size();
     bstart.push_back(m);
+    if((long long)nb * 16 > (long long)m * 10)
+        return aoclsparse_status_success; // fewer than 1.6 rows per block: the row-level schedules are as good
     int max_rows = 1, max_ext = 0;
     for(aoclsparse_int bq = 0; bq < nb; bq++)
     {
-        const int rows = bstart[bq + 1] - bstart[bq];
-        max_rows       = std::max(max_rows, rows);
+        max_rows = std::max<int>(max_rows, bstart[bq + 1] - bstart[bq]);
         // a single row longer than the cap is served by the kernel's tail loop: it does not widen the unrolled part
-        max_ext = std::max(max_ext, std::min<int>(t.ptr[bstart[bq] + 1] - t.ptr[bstart[bq]], TRSV_BLK_EXT));
+        max_ext = std::max(max_ext, std::min<int>(len_of(row_at(bstart[bq])), TRSV_BLK_EXT));
     }
-    if((long long)nb * 16 > (long long)m * 10)
-        return aoclsparse_status_success; // fewer than 1.6 rows per block: the row-level schedules are as good
-    // 2. block levels (a block's external dependencies are those of its first row)
+    // 2. block levels (a block's external dependencies are those of its first-solved row)
     std::vector<aoclsparse_int> bof((size_t)m), blev((size_t)nb, 0);
-    for(aoclsparse_int b = 0; b < nb; b++)
-        for(aoclsparse_int r = bstart[b]; r < bstart[b + 1]; r++)
-            bof[r] = b;
+    for(aoclsparse_int bq = 0; bq < nb; bq++)
+        for(aoclsparse_int k = bstart[bq]; k < bstart[bq + 1]; k++)
+            bof[row_at(k)] = bq;
     aoclsparse_int nlev = 0;
-    for(aoclsparse_int b = 0; b < nb; b++)
+    for(aoclsparse_int bq = 0; bq < nb; bq++)
     {
-        const aoclsparse_int r  = bstart[b];
+        const aoclsparse_int r  = row_at(bstart[bq]);
         aoclsparse_int       lv = 0;
         for(aoclsparse_int p = t.ptr[r]; p < t.ptr[r + 1]; p++)
             lv = std::max(lv, blev[bof[t.ind[p]]] + 1);
-        blev[b] = lv;
-        nlev    = std::max(nlev, lv + 1);
+        blev[bq] = lv;
+        nlev     = std::max(nlev, lv + 1);
     }
-    // 3. blocks in level order (stable), positions of their rows
+    // 3. blocks in level order (stable), positions of their rows (in solve order inside a block)
     std::vector<aoclsparse_int> lptr((size_t)nlev + 1, 0);
-    for(aoclsparse_int b = 0; b < nb; b++)
-        lptr[blev[b] + 1]++;
+    for(aoclsparse_int bq = 0; bq < nb; bq++)
+        lptr[blev[bq] + 1]++;
     for(aoclsparse_int l = 0; l < nlev; l++)
         lptr[l + 1] += lptr[l];
     std::vector<aoclsparse_int> order((size_t)nb), next(lptr.begin(), lptr.end() - 1);
-    for(aoclsparse_int b = 0; b < nb; b++)
-        order[next[blev[b]]++] = b;
+    for(aoclsparse_int bq = 0; bq < nb; bq++)
+        order[next[blev[bq]]++] = bq;
     std::vector<aoclsparse_int> bfirst((size_t)nb + 1, 0), rowmap((size_t)m), pos((size_t)m);
     for(aoclsparse_int k = 0; k < nb; k++)
     {
-        const aoclsparse_int b = order[k];
-        bfirst[k + 1]          = bfirst[k] + (bstart[b + 1] - bstart[b]);
-        for(aoclsparse_int r = bstart[b], q = bfirst[k]; r < bstart[b + 1]; r++, q++)
-            rowmap[q] = r, pos[r] = q;
+        const aoclsparse_int bq = order[k];
+        bfirst[k + 1]           = bfirst[k] + (bstart[bq + 1] - bstart[bq]);
+        for(aoclsparse_int kk = bstart[bq], q = bfirst[k]; kk < bstart[bq + 1]; kk++, q++)
+            rowmap[q] = row_at(kk), pos[row_at(kk)] = q;
     }
-    // 4. the triangle in that order, dependencies as positions
+    // 4. the triangle in that order (entries in chain order), dependencies as positions
     std::vector<aoclsparse_int> pptr((size_t)m + 1, 0), pind(t.ind.size());
     std::vector<T>              pval(t.val.size());
     for(aoclsparse_int k = 0; k < m; k++)
     {
-        const aoclsparse_int i = rowmap[k], len = t.ptr[i + 1] - t.ptr[i];
+        const aoclsparse_int i = rowmap[k], len = len_of(i);
         pptr[k + 1]            = pptr[k] + len;
         for(aoclsparse_int j = 0; j < len; j++)
             pind[pptr[k] + j] = pos[t.ind[t.ptr[i] + j]];
@@ -272,12 +293,12 @@ static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, T
         for(aoclsparse_int k = lptr[l]; k < lptr[l + 1]; k += 64)
             slices.push_back(k);
     slices.push_back(nb);
-    // ... followed by each slice's block level (read by the diagnostic trace only)
     {
+        // ... followed by each slice's block level, and the first slice of each level (nlev + 1 entries): the kernel's
+        // gate counts finished slices per level
         const size_t ns = slices.size() - 1;
         for(size_t q = 0; q < ns; q++)
             slices.push_back(blev[order[slices[q]]]);
-        // ... and the first slice of each level (nlev + 1 entries): the kernel's gate counts finished slices per level
         aoclsparse_int first = 0;
         for(aoclsparse_int l = 0; l < nlev; l++)
         {
@@ -302,6 +323,7 @@ static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, T
         return rc;
     bp.nblocks = nb, bp.nslices = (aoclsparse_int)(slices.size() - 2 - (size_t)nlev) / 2, bp.nlevels = nlev;
     bp.max_rows = max_rows, bp.max_ext = max_ext;
+    bp.front = front;
     bp.valid = true;
     return aoclsparse_status_success;
 }
@@ -313,7 +335,7 @@ static aoclsparse_status build_plan_t(const HostCsr &c, bool upper, bool transpo
     build_triangle<T>(c, upper, transposed, conj, t);
     aoclsparse_status st = build_levels<T>(c.m, t, plan);
     if constexpr(std::is_floating_point<T>::value)
-        if(st == aoclsparse_status_success && !upper && !transposed && !plan.blk.tried)
+        if(st == aoclsparse_status_success && !plan.blk.tried)
             st = build_blocked<T>(c.m, t, plan.blk);
     return st;
 }
@@ -419,9 +441,12 @@ aoclsparse_status solve_core(aoclsparse_operation trans, T alpha, aoclsparse_mat
     }();
     // measured (profiles/r2/trsv_schedules.txt): the slice kernel wins on short rows (ILU(0) of the 2-D Laplacian:
     // 1.69 vs 2.09 ms), the lane-per-position kernel on rows of ~17 entries (shell-like factor)
-    const int sf = (sf_env == 2 || sf_env == 3) ? sf_env
-                   : (nrhs == 1 && plan.nslices > 0 && (long long)plan.nslices * 16 <= (long long)m
-                      && (long long)plan.nnz_tri <= 10LL * m) ? 3 : 2;
+    // -- except when a row's chain STARTS with the row solved last (U, upper && !transposed): there every entry behind
+    // the first would be polled one round trip at a time (45 ms), and the slice kernel's batch re-read wins (17.9 ms)
+    const bool packed = nrhs == 1 && plan.nslices > 0 && (long long)plan.nslices * 16 <= (long long)m;
+    const int  sf     = (sf_env == 2 || sf_env == 3)                                                ? sf_env
+                        : (packed && ((long long)plan.nnz_tri <= 10LL * m || (upper && !tr && !conj))) ? 3
+                                                                                                    : 2;
     // chained rows (the dofs of a node) solved back to back by one lane: one hop per BLOCK level instead of per row level
     const int sfb = (sf_env == 0 && nrhs == 1 && plan.blk.valid) ? 4 : sf;
     const int schedule = is_cplx ? 1 : kid == 0 ? 0 : (kid == 3 ? sfb : (kid > 0 ? 1 : (plan.nlevels <= 32 ? 0 : sfb)));

@@ -466,8 +466,14 @@ __global__ __launch_bounds__(64 * WV) void trsv_slice_kernel(
     // staged entries in chain order.  (Re-reading all pending entries in one batch per pass with a back-off sleep was
     // tried and lost: 4.77 vs 1.69 ms on the Laplacian factor, 11.8 vs 13.2 ms on the shell-like one -- the sleeps put
     // their own latency on the critical path; profiles/r2/trsv_schedules.txt.)
+    // ... but whenever a wait of this wavefront actually had to spin, the entries still pending behind it are re-read
+    // in ONE batch: when the chain STARTS with the row solved last (U: ref_trsv_u walks a row left to right, nearest
+    // first) every later entry has long been solved by then, and polling them one after the other cost a round trip
+    // each -- 45 ms instead of 7.7 for the shell-like factor's U against its L.
 #pragma unroll
     for(int e = 0; e < PF; e++)
+    {
+        const bool spun = e < n && bits[e] == tag<T>::value;
         if(e < n)
         {
             const B got = wait(q[e], bits[e]);
@@ -475,6 +481,14 @@ __global__ __launch_bounds__(64 * WV) void trsv_slice_kernel(
             __builtin_memcpy(&xv, &got, sizeof(T));
             xi = neg_fma(v[e], xv, xi);
         }
+        if(PF > 8 && __builtin_amdgcn_ballot_w64(spun) != 0) // (short rows: nothing to batch, and the Laplacian factor lost 40 %)
+        {
+#pragma unroll
+            for(int e2 = e + 1; e2 < PF; e2++)
+                if(e2 < n && bits[e2] == tag<T>::value)
+                    bits[e2] = peek(q[e2]);
+        }
+    }
     for(int p = p0 + PF; p < pe && !dead; p++)
     {
         const int qq  = pind[p];
@@ -553,7 +567,7 @@ constexpr int trsv_blk_slots(int bs, int ext)
     return (sl / 2) % 2 ? sl : sl + 2;
 }
 
-template <typename T, int BS, int EXT>
+template <typename T, int BS, int EXT, bool FRONT>
 __global__ __launch_bounds__(64) void trsv_block_kernel(
     aoclsparse_int m, aoclsparse_int nslices, const aoclsparse_int *__restrict__ slices,
     const aoclsparse_int *__restrict__ bfirst, const aoclsparse_int *__restrict__ rowmap,
@@ -590,19 +604,19 @@ __global__ __launch_bounds__(64) void trsv_block_kernel(
 #pragma unroll
     for(int e = 0; e < EXT; e++)
         q[e] = e < nl ? pind[p0 + e] : m + TRSV_XP_PAD - 1; // beyond the row: a slot that always holds 0
-    // the block's values -> their slots (zero elsewhere)
-    for(int j = 0; j < SLOTS; j++)
-        s_mine[j] = T(0);
+    // larger shapes: the block's values -> their LDS slots (zero elsewhere)
+    if constexpr(SLOTS > 112)
     {
+        for(int j = 0; j < SLOTS; j++)
+            s_mine[j] = T(0);
         int p = p0;
         for(int a = 0; a < c; a++)
         {
             for(int e = 0; e < nl; e++)
-                s_mine[a * EXT + e] = pval[p + e];
-            p += n0;
+                s_mine[a * EXT + e] = pval[p + (FRONT ? a : 0) + e];
             for(int tt = 0; tt < a; tt++)
-                s_mine[INT0 + a * BSP + tt] = pval[p + tt];
-            p += a;
+                s_mine[INT0 + a * BSP + tt] = pval[p + (FRONT ? a - 1 - tt : n0 + tt)];
+            p += n0 + a;
         }
     }
     // right-hand sides, diagonals, destinations
@@ -632,6 +646,26 @@ __global__ __launch_bounds__(64) void trsv_block_kernel(
                 dead = true;
         }
     };
+    // Small shapes keep every value of the block in REGISTERS across the wait (read straight from the plan; the LDS copy
+    // is then not needed at all): after the wait there is nothing left but FMAs and stores.
+    constexpr bool IN_REGS = SLOTS <= 112;
+    T              ve[IN_REGS ? BS : 1][EXT], vn[IN_REGS ? BS : 1][BSP];
+    if constexpr(IN_REGS)
+    {
+#pragma unroll
+        for(int a = 0; a < BS; a++)
+        {
+            // row a = its n0 external entries and a internal ones: [external, rows 0..a-1], or, FRONT, [rows a-1..0,
+            // external]; vn[a][tt] is the coefficient of block row tt either way
+            const int off = p0 + a * n0 + (a * (a - 1)) / 2; // first entry of row a
+#pragma unroll
+            for(int e = 0; e < EXT; e++)
+                ve[a][e] = (a < c && e < nl) ? pval[off + (FRONT ? a : 0) + e] : T(0);
+#pragma unroll
+            for(int tt = 0; tt < BSP; tt++)
+                vn[a][tt] = (a < c && tt < a) ? pval[off + (FRONT ? a - 1 - tt : n0 + tt)] : T(0);
+        }
+    }
     // The gate: a wavefront does not look at its dependencies before block level (mine - gate) is complete -- until then
     // it polls ONE word (level_done, bumped by every finished slice).  Wavefronts are resident hundreds of levels ahead
     // of the front; with all of them polling 15 x 64 scattered lines per look, the looks of the few wavefronts that
@@ -740,40 +774,9 @@ __global__ __launch_bounds__(64) void trsv_block_kernel(
     };
     T                  xi[BS];
     unsigned long long t_lds = 0, t_ext = 0;
-    if constexpr(SLOTS <= 112)
+    if constexpr(IN_REGS)
     {
-        // all values in registers at once; the external parts of the rows are BS independent chains, interleaved
-        // (x - 0 * 0 = x beyond a row's entries)
-        T ve[BS][EXT], vn[BS][BSP];
-#pragma unroll
-        for(int a = 0; a < BS; a++)
-            read_row(a, ve[a], vn[a]);
-        lds_read_wait();
         t_lds = trace ? __builtin_amdgcn_s_memrealtime() : 0;
-#pragma unroll
-        for(int a = 0; a < BS; a++)
-            landed(a, ve[a], vn[a]);
-#pragma unroll
-        for(int a = 0; a < BS; a++)
-            xi[a] = rhs[a];
-#pragma unroll
-        for(int e = 0; e < EXT; e++)
-#pragma unroll
-            for(int a = 0; a < BS; a++)
-                xi[a] = neg_fma(ve[a][e], xe[e], xi[a]);
-        long_row_tail(xi[0]);
-        if(trace)
-        {
-            lds_read_landed(xi[BS - 1]);
-            t_ext = __builtin_amdgcn_s_memrealtime();
-        }
-        // internal part, column by column: as soon as row tt is known it is taken out of every later row, so the chain
-        // from the first row to the last is BS - 1 FMAs long, not BS (BS - 1) / 2 (each row still receives its terms in
-        // CSR order).  Straight-line code, published in one go at the end: with a predicated store after every row the
-        // compiler kept the rows in separate basic blocks (0.56 us for 10 FMAs).
-        // Every row is published the moment it is final -- without a branch: rows (and lanes) that own nothing store to
-        // a parked slot.  (Published together at the end, the last row queued behind the other nine stores: +0.3 us per
-        // block level; with a predicated store after every row the compiler kept the rows in separate basic blocks.)
         auto put = [&](int a) {
             B out;
             __builtin_memcpy(&out, &xi[a], sizeof(T));
@@ -786,27 +789,74 @@ __global__ __launch_bounds__(64) void trsv_block_kernel(
             for(int a = 0; a < BS; a++)
                 bdst[a] = xb + (size_t)m + tid, xdst[a] = xp + (size_t)m + 64 + tid;
         }
-        if(unit)
+        if constexpr(FRONT)
         {
+            // U: a row's chain STARTS with the rows of its own block (nearest first), then the external entries: one
+            // chain per row, each starting when the row before is final
 #pragma unroll
-            for(int tt = 0; tt < BS; tt++)
+            for(int a = 0; a < BS; a++)
             {
-                put(tt);
+                T xa = rhs[a];
 #pragma unroll
-                for(int a = tt + 1; a < BS; a++)
-                    xi[a] = neg_fma(vn[a][tt], xi[tt], xi[a]);
+                for(int tt = BS - 1; tt >= 0; tt--)
+                    if(tt < a)
+                        xa = neg_fma(vn[a][tt], xi[tt], xa);
+#pragma unroll
+                for(int e = 0; e < EXT; e++)
+                    xa = neg_fma(ve[a][e], xe[e], xa);
+                if(a == 0)
+                    long_row_tail(xa);
+                if(!unit)
+                    xa /= dg[a];
+                xi[a] = xa;
+                put(a);
             }
         }
         else
         {
+            // the external parts of the rows are BS independent chains, interleaved (x - 0 * 0 = x beyond a row's entries)
 #pragma unroll
-            for(int tt = 0; tt < BS; tt++)
+            for(int a = 0; a < BS; a++)
+                xi[a] = rhs[a];
+#pragma unroll
+            for(int e = 0; e < EXT; e++)
+#pragma unroll
+                for(int a = 0; a < BS; a++)
+                    xi[a] = neg_fma(ve[a][e], xe[e], xi[a]);
+            long_row_tail(xi[0]);
+            if(trace)
             {
-                xi[tt] /= dg[tt];
-                put(tt);
+                lds_read_landed(xi[BS - 1]);
+                t_ext = __builtin_amdgcn_s_memrealtime();
+            }
+            // internal part, column by column: as soon as row tt is known it is taken out of every later row, so the
+            // chain from the first row to the last is BS - 1 FMAs long, not BS (BS - 1) / 2 (each row still receives its
+            // terms in CSR order).  Every row is published the moment it is final -- without a branch: rows (and lanes)
+            // that own nothing store to a parked slot.  (Published together at the end, the last row queued behind the
+            // other nine stores: +0.3 us per block level; with a predicated store after every row the compiler kept the
+            // rows in separate basic blocks: 0.56 us for 10 FMAs.)
+            if(unit)
+            {
 #pragma unroll
-                for(int a = tt + 1; a < BS; a++)
-                    xi[a] = neg_fma(vn[a][tt], xi[tt], xi[a]);
+                for(int tt = 0; tt < BS; tt++)
+                {
+                    put(tt);
+#pragma unroll
+                    for(int a = tt + 1; a < BS; a++)
+                        xi[a] = neg_fma(vn[a][tt], xi[tt], xi[a]);
+                }
+            }
+            else
+            {
+#pragma unroll
+                for(int tt = 0; tt < BS; tt++)
+                {
+                    xi[tt] /= dg[tt];
+                    put(tt);
+#pragma unroll
+                    for(int a = tt + 1; a < BS; a++)
+                        xi[a] = neg_fma(vn[a][tt], xi[tt], xi[a]);
+                }
             }
         }
         // the caller's x: nobody waits for these
@@ -825,15 +875,25 @@ __global__ __launch_bounds__(64) void trsv_block_kernel(
             lds_read_wait();
             landed(a, ve, vn);
             xi[a] = rhs[a];
+            if constexpr(FRONT)
+            {
+#pragma unroll
+                for(int tt = BS - 1; tt >= 0; tt--)
+                    if(tt < a)
+                        xi[a] = neg_fma(vn[tt], xi[tt], xi[a]);
+            }
 #pragma unroll
             for(int e = 0; e < EXT; e++)
                 xi[a] = neg_fma(ve[e], xe[e], xi[a]);
             if(a == 0)
                 long_row_tail(xi[0]);
+            if constexpr(!FRONT)
+            {
 #pragma unroll
-            for(int tt = 0; tt < BS; tt++)
-                if(tt < a)
-                    xi[a] = neg_fma(vn[tt], xi[tt], xi[a]);
+                for(int tt = 0; tt < BS; tt++)
+                    if(tt < a)
+                        xi[a] = neg_fma(vn[tt], xi[tt], xi[a]);
+            }
             if(!unit)
                 xi[a] /= dg[a];
             publish(a, xi[a]);
@@ -915,25 +975,30 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
         unsigned long long *trace      = nullptr;
         if(trace_path && hipMalloc(&trace, sizeof(unsigned long long) * 6 * (size_t)bp.nslices) != hipSuccess)
             trace = nullptr;
-        auto go = [&](auto bs_tag, auto ext_tag) {
+        auto go_form = [&](auto bs_tag, auto ext_tag, auto front_tag) {
             constexpr int    BS = decltype(bs_tag)::value, EXT = decltype(ext_tag)::value;
-            constexpr size_t need = sizeof(T) * 64 * (size_t)trsv_blk_slots(BS, EXT);
+            constexpr bool   FRONT = decltype(front_tag)::value;
+            // (the small shapes hold the block in registers and use no LDS)
+            constexpr size_t need = trsv_blk_slots(BS, EXT) <= 112 ? 0 : sizeof(T) * 64 * (size_t)trsv_blk_slots(BS, EXT);
             static_assert(need <= 160 * 1024, "LDS of one CU");
             static const size_t floor_kb = [] { const char *e = getenv("AOCLSPARSE_MI355_TRSV_BLK_LDS"); return e ? (size_t)atoi(e) : (size_t)0; }();
             const size_t        lds = std::min<size_t>(std::max(need, floor_kb * 1024), 160 * 1024);
             if(lds > 64 * 1024)
             {
                 static const hipError_t raised = hipFuncSetAttribute(
-                    reinterpret_cast<const void *>(&trsv_block_kernel<T, BS, EXT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    reinterpret_cast<const void *>(&trsv_block_kernel<T, BS, EXT, FRONT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 if(raised != hipSuccess)
                     return aoclsparse_status_internal_error;
             }
-            hipLaunchKernelGGL((trsv_block_kernel<T, BS, EXT>), dim3((unsigned)bp.nslices), dim3(64), lds, s, m, bp.nslices,
+            hipLaunchKernelGGL((trsv_block_kernel<T, BS, EXT, FRONT>), dim3((unsigned)bp.nslices), dim3(64), lds, s, m, bp.nslices,
                                bp.slices.as<aoclsparse_int>(), bp.bfirst.as<aoclsparse_int>(), bp.rowmap.as<aoclsparse_int>(),
                                bp.pptr.as<aoclsparse_int>(), bp.pind.as<aoclsparse_int>(), bp.pval.as<T>(), diag, b, xp, x,
                                alpha, (int)unit, scratch, timeout_word ? timeout_word : scratch + 1, (int)incb, (int)incx,
                                trace, scratch + 2, gate);
             return aoclsparse_status_success;
+        };
+        auto go = [&](auto bs_tag, auto ext_tag) {
+            return bp.front ? go_form(bs_tag, ext_tag, std::true_type{}) : go_form(bs_tag, ext_tag, std::false_type{});
         };
         using std::integral_constant;
         // shapes by the plan's largest block / external list (the loops over rows and external entries are unrolled)

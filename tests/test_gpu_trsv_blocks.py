@@ -1,0 +1,192 @@
+"""GPU tier (-m gpu): the supernodal TRSV schedule (one lane per block of chained rows, csrc/trsv_kernels.hip
+trsv_block_kernel) against the serial reference chain of the oracle -- all four (fill, op) triangles, both diagonal
+types, both real precisions, every compiled shape (blocks of <= 5 rows with <= 16 external dependencies: values in
+registers; larger: row by row from LDS), blocks of mixed sizes, rows too long for a block (the kernel's tail loop),
+NaN / Inf / NOT-READY-tag propagation.  Bar: bit-exact (same chain order per row).  That the block schedule is the one
+that ran is checked through its diagnostic trace in a subprocess (the C ABI is frozen: there is no query for it)."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+from util import ROOT, pkg
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+P = pkg()
+L = P.lib()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def node_mesh(seed, nodes, width, dofs, keep=0.9, far=0):
+    """Sorted CSR of a mesh matrix with dense node-to-node blocks: node i has dofs[i] unknowns and couples to the nodes
+    i-1, i-width, i-width-1 (and symmetrically i+1, i+width, i+width+1), each kept with probability `keep`, plus `far`
+    random extra neighbours for every 50th node (rows too long for a block).  Strong diagonal, small off-diagonals."""
+    rng = np.random.default_rng(seed)
+    dofs = np.asarray(dofs, dtype=np.int64)
+    first = np.concatenate([[0], np.cumsum(dofs)])
+    m = int(first[-1])
+    nbr = [set() for _ in range(nodes)]
+    for i in range(nodes):
+        for d in (1, width, width + 1):
+            j = i - d
+            if j >= 0 and (d != 1 or i % width) and (d != width + 1 or i % width) and rng.random() < keep:
+                nbr[i].add(j), nbr[j].add(i)
+        if far and i % 50 == 25:
+            for j in rng.integers(0, nodes, size=far):
+                if j != i:
+                    nbr[i].add(int(j)), nbr[int(j)].add(i)
+    rp, ci = [0], []
+    for i in range(nodes):
+        cols = np.concatenate([np.arange(first[j], first[j + 1]) for j in sorted(nbr[i] | {i})])
+        for _ in range(dofs[i]):
+            ci.append(cols)
+            rp.append(rp[-1] + len(cols))
+    ci = np.concatenate(ci)
+    rid = np.repeat(np.arange(m), np.diff(rp))
+    val = rng.uniform(-1.0, 1.0, size=len(ci)) / 8.0
+    val[ci == rid] = rng.uniform(2.0, 4.0, size=m) * rng.choice([-1.0, 1.0], size=m)
+    return m, np.asarray(rp, dtype=np.int32), ci.astype(np.int32), val
+
+
+def fixed(n):
+    return lambda rng, nodes: np.full(nodes, n)
+
+
+def mixed(rng, nodes):
+    return rng.integers(1, 9, size=nodes)
+
+
+VARIANTS = [("l", "FILL_LOWER", "OP_NONE"), ("u", "FILL_UPPER", "OP_NONE"), ("lt", "FILL_LOWER", "OP_TRANSPOSE"),
+            ("ut", "FILL_UPPER", "OP_TRANSPOSE")]
+
+
+def solve_all(m, rp, ci, v, check):
+    o = oracle.dcsr_optimize(m, m, len(v), 0, rp, ci, v)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    rng = np.random.default_rng(11)
+    for kind, fill, op in VARIANTS:
+        for unit in (True, False):
+            d = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=getattr(P, fill), diag=P.DIAG_UNIT if unit else P.DIAG_NON_UNIT)
+            b = rng.uniform(-1, 1, m)
+            st, xr = oracle.dtrsv(kind, 0.75, m, 0, o["val"], o["ind"], o["ptr"], o["idiag"] if kind[0] == "l" else o["iurow"],
+                                  b, unit)
+            assert st == 0
+            for kid in (None, 3):
+                xd = torch.full((m,), 7.0, dtype=torch.float64, device="cuda")
+                assert P.dtrsv(getattr(P, op), 0.75, A, d, dev(b), xd, kid=kid) == 0
+                torch.cuda.synchronize()
+                check(xd.cpu().numpy(), xr, (kind, unit, kid))
+    return A
+
+
+@pytest.mark.parametrize("name,dofs,width,far", [("five", fixed(5), 37, 0), ("two", fixed(2), 50, 0), ("eight", fixed(8), 29, 0),
+                                                 ("three+long", fixed(3), 41, 12), ("mixed", mixed, 33, 0),
+                                                 ("mixed+long", mixed, 64, 9)])
+def test_block_trsv_bit_exact_every_triangle(name, dofs, width, far):
+    nodes = 3000
+    m, rp, ci, v = node_mesh(500 + len(name), nodes, width, dofs(np.random.default_rng(1), nodes), far=far)
+
+    def same(got, ref, what):
+        assert np.array_equal(got, ref), (name, what, int((got != ref).sum()))
+
+    solve_all(m, rp, ci, v, same)
+
+
+def test_block_trsv_strided_and_host_pointers():
+    nodes = 1500
+    m, rp, ci, v = node_mesh(7, nodes, 30, np.full(nodes, 5))
+    o = oracle.dcsr_optimize(m, m, len(v), 0, rp, ci, v)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    d = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=P.FILL_UPPER)
+    rng = np.random.default_rng(5)
+    incb, incx = 2, 3
+    b = rng.uniform(-1, 1, m * incb)
+    st, xr = oracle.dtrsv("u", 1.5, m, 0, o["val"], o["ind"], o["ptr"], o["iurow"], b[::incb].copy(), False)
+    x = np.full(m * incx, 7.0)
+    assert P.dtrsv(P.OP_NONE, 1.5, A, d, b, x, incb=incb, incx=incx) == 0
+    assert np.array_equal(x[::incx], xr) and np.all(x[1::incx] == 7.0) and np.all(x[2::incx] == 7.0)
+    xd = dev(np.full(m * incx, 7.0))
+    assert P.dtrsv(P.OP_NONE, 1.5, A, d, dev(b), xd, incb=incb, incx=incx) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(xd.cpu().numpy(), x)
+
+
+def test_block_strsv_float_bit_exact():
+    nodes = 3000
+    m, rp, ci, v = node_mesh(21, nodes, 45, np.full(nodes, 5))
+    vf = v.astype(np.float32)
+    o = oracle.dcsr_optimize(m, m, len(v), 0, rp, ci, v)
+    A = P.Matrix(0, m, m, rp, ci, vf)
+    bf = np.random.default_rng(6).uniform(-1, 1, m).astype(np.float32)
+    for fill, fn, iend in ((P.FILL_LOWER, "orc_strsv_l", o["idiag"]), (P.FILL_UPPER, "orc_strsv_u", o["iurow"])):
+        for unit in (True, False):
+            d = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=fill, diag=P.DIAG_UNIT if unit else P.DIAG_NON_UNIT)
+            xo = np.zeros(m, np.float32)
+            st = getattr(oracle.lib(), fn)(ctypes.c_float(1.0), m, 0, P._ptr(vf), P._ptr(ci), P._ptr(rp), P._ptr(iend),
+                                           P._ptr(bf), 1, P._ptr(xo), 1, 1 if unit else 0)
+            assert st == 0
+            xd = torch.zeros(m, dtype=torch.float32, device="cuda")
+            assert P.strsv(P.OP_NONE, 1.0, A, d, dev(bf), xd) == 0
+            torch.cuda.synchronize()
+            assert np.array_equal(xd.cpu().numpy(), xo), (fill, unit)
+
+
+def test_block_trsv_nan_inf_and_tag_propagate():
+    """NaN, +-Inf and the exact NOT-READY bit pattern in b: same propagation as the serial chain (a value that is absent
+    from a row's chain must not poison it: the kernel multiplies absent entries as 0 * 0, never 0 * x)."""
+    nodes = 2000
+    m, rp, ci, v = node_mesh(33, nodes, 40, mixed(np.random.default_rng(2), nodes))
+    o = oracle.dcsr_optimize(m, m, len(v), 0, rp, ci, v)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    tag = np.array([0x7FF8DEADBEEF0355], dtype=np.uint64).view(np.float64)[0]
+    rng = np.random.default_rng(8)
+    for kind, fill, iend in (("l", P.FILL_LOWER, o["idiag"]), ("u", P.FILL_UPPER, o["iurow"])):
+        d = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=fill)
+        b = rng.uniform(-1, 1, m)
+        b[[0, 40, m // 2]] = [np.nan, np.inf, tag]
+        b[[m - 1, m - 77]] = [-np.inf, np.nan]
+        st, xr = oracle.dtrsv(kind, 1.0, m, 0, o["val"], o["ind"], o["ptr"], iend, b, False)
+        xd = torch.zeros(m, dtype=torch.float64, device="cuda")
+        assert P.dtrsv(P.OP_NONE, 1.0, A, d, dev(b), xd) == 0
+        torch.cuda.synchronize()
+        got = xd.cpu().numpy()
+        gn, rn = np.isnan(got), np.isnan(xr)
+        assert np.array_equal(gn, rn) and np.array_equal(got[~gn], xr[~rn]) and 2 <= rn.sum() < m
+
+
+_TRACE_SCRIPT = r"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from test_gpu_trsv_blocks import node_mesh, P, VARIANTS
+nodes = 2000
+m, rp, ci, v = node_mesh(3, nodes, 40, np.full(nodes, 5))
+A = P.Matrix(0, m, m, rp, ci, v)
+b = torch.ones(m, dtype=torch.float64, device="cuda"); x = torch.zeros_like(b)
+for kind, fill, op in VARIANTS:
+    d = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=getattr(P, fill))
+    assert P.dtrsv(getattr(P, op), 1.0, A, d, b, x) == 0
+    torch.cuda.synchronize()
+    print("solved", kind, flush=True)
+"""
+
+
+def test_block_schedule_is_the_one_that_runs(tmp_path):
+    """every (fill, op) triangle of a 5-dof mesh is solved by the block kernel in auto mode: its diagnostic trace is
+    written once per solve, and reports blocks of 5 rows"""
+    trace = tmp_path / "trace.bin"
+    env = dict(os.environ, AOCLSPARSE_MI355_TRSV_TRACE=str(trace))
+    r = subprocess.run([sys.executable, "-c", _TRACE_SCRIPT, ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stderr.splitlines() if ln.startswith("[trsv trace]")]
+    assert len(lines) == 4 and all("max_rows 5" in ln for ln in lines), r.stderr[-2000:]
+    assert trace.stat().st_size > 0 and trace.stat().st_size % 48 == 0

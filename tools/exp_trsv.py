@@ -16,17 +16,22 @@ for title, gen in cases:
     m, rp, ci, v = gen()
     st, lu, dg = oracle.dilu0(m, 0, rp, ci, v)
     A = pkg.Matrix(0, m, m, rp, ci, lu)
-    dl = pkg.Descr(mtype=pkg.TYPE_TRIANGULAR, fill=pkg.FILL_LOWER, diag=pkg.DIAG_UNIT)
-    assert L.aoclsparse_set_sv_hint(A.h, pkg.OP_NONE, dl.h, 100) == 0 and L.aoclsparse_optimize(A.h) == 0
-    lv = A.trsv_levels(pkg.FILL_LOWER)
     o = oracle.dcsr_optimize(m, m, len(lu), 0, rp, ci, lu)
+    lv = A.trsv_levels(pkg.FILL_LOWER)
     b = np.random.default_rng(2).uniform(-1, 1, m)
-    st, xr = oracle.dtrsv("l", 1.0, m, 0, lu, ci, rp, o["idiag"], b, True)
     bd, xd = torch.from_numpy(b).to(dev), torch.zeros(m, dtype=torch.float64, device=dev)
-    for kid in (3, -1):
-        lp = timed_laps(pkg, lambda: pkg.dtrsv(pkg.OP_NONE, 1.0, A, dl, bd, xd, kid=kid), 10, 2)
-        torch.cuda.synchronize()
-        print(json.dumps({"sys": title, "levels": lv, "kid": kid, "env_sf": os.environ.get("AOCLSPARSE_MI355_TRSV_SYNCFREE"),
-                          "env_wv": os.environ.get("AOCLSPARSE_MI355_TRSV_WAVES"), "ms_median": float(np.median(lp)),
-                          "us_per_level": float(np.median(lp)) * 1e3 / lv,
-                          "bit_exact": bool(np.array_equal(xd.cpu().numpy(), xr))}), flush=True)
+    variants = [("l", pkg.FILL_LOWER, pkg.OP_NONE, True, o["idiag"])]
+    if "--all" in sys.argv:
+        variants += [("u", pkg.FILL_UPPER, pkg.OP_NONE, False, o["iurow"]), ("lt", pkg.FILL_LOWER, pkg.OP_TRANSPOSE, True, o["idiag"]),
+                     ("ut", pkg.FILL_UPPER, pkg.OP_TRANSPOSE, False, o["iurow"])]
+    for kind, fill, op, unit, iend in variants:
+        dl = pkg.Descr(mtype=pkg.TYPE_TRIANGULAR, fill=fill, diag=pkg.DIAG_UNIT if unit else pkg.DIAG_NON_UNIT)
+        assert L.aoclsparse_set_sv_hint(A.h, op, dl.h, 100) == 0 and L.aoclsparse_optimize(A.h) == 0
+        st, xr = oracle.dtrsv(kind, 1.0, m, 0, lu, ci, rp, iend, b, unit)
+        for kid in (3, -1):
+            lp = timed_laps(pkg, lambda: pkg.dtrsv(op, 1.0, A, dl, bd, xd, kid=kid), 10, 2)
+            torch.cuda.synchronize()
+            print(json.dumps({"sys": title, "kind": kind, "levels": lv, "kid": kid, "env_sf": os.environ.get("AOCLSPARSE_MI355_TRSV_SYNCFREE"),
+                              "env_blocks": os.environ.get("AOCLSPARSE_MI355_TRSV_BLOCKS"), "ms_median": float(np.median(lp)),
+                              "us_per_level": float(np.median(lp)) * 1e3 / lv,
+                              "bit_exact": bool(np.array_equal(xd.cpu().numpy(), xr, equal_nan=True))}), flush=True)

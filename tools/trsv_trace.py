@@ -41,8 +41,9 @@ print(json.dumps({"what": "trsv block-kernel trace (shell-like factor)", "slices
                   "per_level_us": float(us(done.max() - t0)) / nlev,
                   "hop_us_q (level l all ready - level l-1 all done)": q(hop),
                   "work_us_q (slice: ready -> done)": q(work),
-                  "lds_us_q (ready -> values in registers)": q(us(t[:, 4] - ready)),
-                  "ext_us_q (-> external FMAs done)": q(us(t[:, 5] - t[:, 4])),
-                  "int_us_q (-> rows chained + published)": q(us(done - t[:, 5])),
+                  # (the row-by-row shapes do not stamp the phases: null)
+                  "lds_us_q (ready -> values in registers)": q(us(t[:, 4] - ready)) if t[:, 4].min() > 0 else None,
+                  "ext_us_q (-> external FMAs done)": q(us(t[:, 5] - t[:, 4])) if t[:, 4].min() > 0 else None,
+                  "int_us_q (-> rows chained + published)": q(us(done - t[:, 5])) if t[:, 5].min() > 0 else None,
                   "ready_spread_us_q (level: last ready - first ready)": q(us(rd - rdmin)),
                   "lead_us_q (slice: ticket -> ready)": q(lead)}))
