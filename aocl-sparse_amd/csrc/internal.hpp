@@ -222,6 +222,11 @@ struct SpmvPlan
     aoclsparse_int max_row_nnz = 0;
     aoclsparse_int tile        = 0; // LDS tile (non-zeros per row block): 1024 or 2048
     DeviceBuffer   rowblocks; // nblocks+1 entries {first row, first non-zero (0-based)}
+    // the same blocks as {first row, first non-zero, rows, non-zeros}, blocks holding a long row FIRST (a row is one
+    // lane's serial chain: a block with a 300-entry row runs twice as long as the others, and started last it is the
+    // kernel's tail); empty when no block is heavy.  Only csr_adaptive_kernel reads it.
+    DeviceBuffer   rowblocks4;
+    bool           heavy_first = false;
     bool           valid = false;
     SellPlan       sell;
     MergePlan      merge;
@@ -503,7 +508,7 @@ template <typename T>
 aoclsparse_status launch_csrmv(hipStream_t s, int order, bool strict, int tile, int base, T alpha,
                                aoclsparse_int m, const T *val, const aoclsparse_int *col,
                                const aoclsparse_int *row_ptr, const aoclsparse_int *blocks,
-                               aoclsparse_int nblocks, const T *x, T beta, T *y);
+                               aoclsparse_int nblocks, const T *x, T beta, T *y, const aoclsparse_int *blocks4 = nullptr);
 // raw-array csrmv: is a cached plan still the plan of this row_ptr?  (*stale: pinned host word, set on mismatch)
 aoclsparse_status launch_plan_check(hipStream_t s, const aoclsparse_int *blocks, aoclsparse_int nblocks,
                                     const aoclsparse_int *row_ptr, int base, aoclsparse_int m, aoclsparse_int nnz,

@@ -512,6 +512,42 @@ aoclsparse_status build_spmv_plan(aoclsparse_int m, aoclsparse_int nnz, aoclspar
             blk.data(), sizeof(aoclsparse_int) * 2 * (size_t)(plan.nblocks + 1), Runtime::get().stream());
         if(st != aoclsparse_status_success)
             return st;
+        // Heavy blocks first.  A row is ONE lane's serial chain (scalar order), so a block that holds a row of a few
+        // hundred entries -- or is a single row longer than a tile -- runs 2-4 x as long as the others; workgroups start
+        // over 2.5-4.5 us (circuit-like: 1,900 of them), and a heavy block started last is the kernel's tail
+        // (tools/spmv_trace.py).  Same blocks, same rows, same chains: only the workgroup that takes them changes.
+        plan.heavy_first = false;
+        static const bool hf_off = [] { const char *e = std::getenv("AOCLSPARSE_MI355_SPMV_HEAVY_FIRST"); return e && std::atoi(e) == 0; }();
+        if(!hf_off && plan.nblocks >= 512 && plan.max_row_nnz >= 64)
+        {
+            const aoclsparse_int        nb = plan.nblocks;
+            std::vector<aoclsparse_int> weight((size_t)nb), order((size_t)nb);
+            aoclsparse_int              heavy = 0;
+            for(aoclsparse_int b = 0; b < nb; b++)
+            {
+                aoclsparse_int w = 0;
+                for(aoclsparse_int r = blk[2 * b]; r < blk[2 * b + 2]; r++)
+                    w = std::max(w, row_ptr_host[r + 1] - row_ptr_host[r]);
+                weight[b] = w >= 64 ? w : 0;
+                heavy += w >= 64;
+                order[b] = b;
+            }
+            if(heavy > 0) // (circuit-like: most blocks hold a row >= 64; the 300-entry ones still have to go first)
+            {
+                std::stable_sort(order.begin(), order.end(), [&](aoclsparse_int a, aoclsparse_int c) { return weight[a] > weight[c]; });
+                std::vector<aoclsparse_int> b4(4 * (size_t)nb);
+                for(aoclsparse_int k = 0; k < nb; k++)
+                {
+                    const aoclsparse_int b = order[k];
+                    b4[4 * k] = blk[2 * b], b4[4 * k + 1] = blk[2 * b + 1];
+                    b4[4 * k + 2] = blk[2 * b + 2] - blk[2 * b], b4[4 * k + 3] = blk[2 * b + 3] - blk[2 * b + 1];
+                }
+                st = plan.rowblocks4.upload(b4.data(), sizeof(aoclsparse_int) * b4.size(), Runtime::get().stream());
+                if(st != aoclsparse_status_success)
+                    return st;
+                plan.heavy_first = true;
+            }
+        }
         plan.valid = true;
     }
     catch(const std::bad_alloc &)

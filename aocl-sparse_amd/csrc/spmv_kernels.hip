@@ -24,6 +24,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
 #include <algorithm>
 
 namespace mi355
@@ -133,9 +137,16 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restr
                                                                   int base,
                                                                   int nblocks,
                                                                   int chunk,
-                                                                  int flags)
+                                                                  int flags,
+                                                                  unsigned long long *trace,
+                                                                  const int4 *__restrict__ blocks4)
 {
     constexpr int MAXROWS = spmv_maxrows(TILE); // planner guarantees rows <= MAXROWS
+    // diagnostic (AOCLSPARSE_MI355_SPMV_TRACE, tools/spmv_trace.py): 100 MHz stamps per workgroup, kept in registers and
+    // stored by thread 0 at the very end -- start / block table read / tile in LDS / after the barrier / rows reduced
+    unsigned long long t_st[4] = {0, 0, 0, 0};
+    if(trace)
+        t_st[0] = __builtin_amdgcn_s_memrealtime();
     __shared__ T              s_val[TILE + 4];
     __shared__ T              s_x[TILE + 4];
     __shared__ aoclsparse_int s_row[MAXROWS + 1];
@@ -147,10 +158,19 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restr
     const int b = (flags & 4) ? (blockIdx.x & 7) * chunk + (blockIdx.x >> 3) : (int)blockIdx.x;
     if(b >= nblocks)
         return;
-    const int2 e0 = blocks[b], e1 = blocks[b + 1];
-    const int  r0 = e0.x, p0 = e0.y;
-    const int  nrows = e1.x - r0;
-    const int  cnt   = e1.y - p0;
+    int r0, p0, nrows, cnt;
+    if(blocks4) // heavy-first order (SpmvPlan::rowblocks4): one 16-byte entry per block
+    {
+        const int4 e = blocks4[b];
+        r0 = e.x, p0 = e.y, nrows = e.z, cnt = e.w;
+    }
+    else
+    {
+        const int2 e0 = blocks[b], e1 = blocks[b + 1];
+        r0 = e0.x, p0 = e0.y, nrows = e1.x - r0, cnt = e1.y - p0;
+    }
+    if(trace)
+        t_st[1] = __builtin_amdgcn_readfirstlane(cnt) >= 0 ? __builtin_amdgcn_s_memrealtime() : 0;
 
     if(cnt <= TILE)
     {
@@ -221,7 +241,11 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restr
                 }
             }
         }
+        if(trace)
+            t_st[2] = __builtin_amdgcn_s_memrealtime();
         __syncthreads();
+        if(trace)
+            t_st[3] = __builtin_amdgcn_s_memrealtime();
         // ---- phase 2: per-row reduction in the reference order -----------------------------------------
         const int grp  = tid / L;
         const int lane = tid % L;
@@ -233,25 +257,54 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restr
             T         acc = T(0);
             if constexpr(L == 1)
             {
-                // same left-to-right chain, but the LDS reads of 8 entries are issued together so that a
-                // long row pays the LDS latency once per 8 entries instead of once per entry
+                // same left-to-right chain, but the LDS reads of 8 entries are issued together (indices clamped to the
+                // row, FMAs beyond it predicated off), so that a row pays the LDS latency once per 8 entries instead of
+                // once per entry: traced on the circuit-like stand-in (tools/spmv_trace.py), the entry-by-entry loop
+                // was 1.8 us of a workgroup's 5.4 us (rows of 1-15 entries: ~100 cycles of LDS latency per FMA)
                 int j = s;
-                if(e - s >= 16) // short rows (the common case) skip the batched path entirely
-                    for(; j + 8 <= e; j += 8)
+                if(j + 8 <= e) // full batches: no clamps, no predicates on the chain; the reads of batch k + 1 are
+                {              // issued before the FMAs of batch k (a 337-entry row is 42 batches in a row)
+                    T a[8], b[8];
+#pragma unroll
+                    for(int q = 0; q < 8; q++)
                     {
-                        T a[8], b[8];
+                        a[q] = s_val[j + q];
+                        b[q] = s_x[j + q];
+                    }
+                    for(j += 8; j + 8 <= e; j += 8)
+                    {
+                        T an[8], bn[8];
 #pragma unroll
                         for(int q = 0; q < 8; q++)
                         {
-                            a[q] = s_val[j + q];
-                            b[q] = s_x[j + q];
+                            an[q] = s_val[j + q];
+                            bn[q] = s_x[j + q];
                         }
 #pragma unroll
                         for(int q = 0; q < 8; q++)
                             acc = dev_fma(a[q], b[q], acc);
+#pragma unroll
+                        for(int q = 0; q < 8; q++)
+                            a[q] = an[q], b[q] = bn[q];
                     }
-                for(; j < e; j++)
-                    acc = dev_fma(s_val[j], s_x[j], acc);
+#pragma unroll
+                    for(int q = 0; q < 8; q++)
+                        acc = dev_fma(a[q], b[q], acc);
+                }
+                if(j < e) // the last 1..7 entries: one clamped batch
+                {
+                    T a[7], b[7];
+#pragma unroll
+                    for(int q = 0; q < 7; q++)
+                    {
+                        const int jj = min(j + q, e - 1);
+                        a[q]         = s_val[jj];
+                        b[q]         = s_x[jj];
+                    }
+#pragma unroll
+                    for(int q = 0; q < 7; q++)
+                        acc = j + q < e ? dev_fma(a[q], b[q], acc) : acc;
+                }
                 store_y(&y[r], finish(acc, alpha, beta, &y[r]), flags);
             }
             else
@@ -341,6 +394,13 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restr
                 y[r0] = finish(res, alpha, beta, &y[r0]);
         }
     }
+    if(trace && tid == 0)
+    {
+        unsigned long long *tr = trace + 8 * (size_t)b;
+        tr[0] = t_st[0], tr[1] = t_st[1], tr[2] = t_st[2], tr[3] = t_st[3], tr[4] = __builtin_amdgcn_s_memrealtime();
+        tr[5] = ((unsigned long long)(unsigned)nrows << 32) | (unsigned)cnt;
+        tr[6] = (unsigned long long)r0, tr[7] = 0;
+    }
 }
 
 template <typename T>
@@ -416,13 +476,30 @@ aoclsparse_status launch_dot(hipStream_t s, aoclsparse_int n, const T *x, const 
 template <typename T, int ORDER, int TILE, int BLOCK>
 static void launch_inst(hipStream_t s, int flags, int base, T alpha, const T *val, const aoclsparse_int *col,
                         const aoclsparse_int *row_ptr, const aoclsparse_int *blocks, aoclsparse_int nblocks,
-                        const T *x, T beta, T *y)
+                        const T *x, T beta, T *y, const aoclsparse_int *blocks4)
 {
     const int chunk = (nblocks + 7) / 8;
     const int grid  = (flags & 4) ? chunk * 8 : (int)nblocks;
+    // diagnostic: AOCLSPARSE_MI355_SPMV_TRACE=<file> dumps 8 x u64 per row block of the LAST launch (synchronises)
+    static const char  *trace_path = getenv("AOCLSPARSE_MI355_SPMV_TRACE");
+    unsigned long long *trace      = nullptr;
+    if(trace_path && hipMalloc(&trace, sizeof(unsigned long long) * 8 * (size_t)nblocks) != hipSuccess)
+        trace = nullptr;
     hipLaunchKernelGGL((csr_adaptive_kernel<T, ORDER, TILE, BLOCK>), dim3(grid), dim3(BLOCK), 0, s,
                        reinterpret_cast<const int2 *>(blocks), row_ptr, col, val, x, y, alpha, beta, base,
-                       (int)nblocks, chunk, flags);
+                       (int)nblocks, chunk, flags, trace, reinterpret_cast<const int4 *>(blocks4));
+    if(trace)
+    {
+        std::vector<unsigned long long> host(8 * (size_t)nblocks);
+        if(hipStreamSynchronize(s) == hipSuccess
+           && hipMemcpy(host.data(), trace, sizeof(unsigned long long) * host.size(), hipMemcpyDeviceToHost) == hipSuccess)
+            if(FILE *f = fopen(trace_path, "wb"))
+            {
+                fwrite(host.data(), sizeof(unsigned long long), host.size(), f);
+                fclose(f);
+            }
+        (void)hipFree(trace);
+    }
 }
 
 // tile: 512 (128-thread workgroups), 1024 or 2048 (256 threads); bit0 set = XCD-contiguous block order
@@ -430,7 +507,7 @@ template <typename T>
 aoclsparse_status launch_csrmv(hipStream_t s, int order, bool strict, int tile, int base, T alpha,
                                aoclsparse_int m, const T *val, const aoclsparse_int *col,
                                const aoclsparse_int *row_ptr, const aoclsparse_int *blocks,
-                               aoclsparse_int nblocks, const T *x, T beta, T *y)
+                               aoclsparse_int nblocks, const T *x, T beta, T *y, const aoclsparse_int *blocks4)
 {
     if(m <= 0 || nblocks <= 0)
         return aoclsparse_status_success;
@@ -447,7 +524,7 @@ aoclsparse_status launch_csrmv(hipStream_t s, int order, bool strict, int tile, 
     if(tsel < 0 || order < 0 || order > 2)
         return aoclsparse_status_invalid_kid;
 #define MI355_CASE(O, TL, BL)                                                                                 \
-    launch_inst<T, O, TL, BL>(s, flags, base, alpha, val, col, row_ptr, blocks, nblocks, x, beta, y);         \
+    launch_inst<T, O, TL, BL>(s, flags, base, alpha, val, col, row_ptr, blocks, nblocks, x, beta, y, blocks4); \
     break
     switch(order * 3 + tsel)
     {
@@ -555,7 +632,8 @@ aoclsparse_status launch_strided_scatter(hipStream_t s, const T *src, aoclsparse
 #define MI355_INSTANTIATE(T)                                                                                   \
     template aoclsparse_status launch_csrmv<T>(hipStream_t, int, bool, int, int, T, aoclsparse_int, const T *, \
                                                const aoclsparse_int *, const aoclsparse_int *,                  \
-                                               const aoclsparse_int *, aoclsparse_int, const T *, T, T *);      \
+                                               const aoclsparse_int *, aoclsparse_int, const T *, T, T *,       \
+                                               const aoclsparse_int *);                                         \
     template aoclsparse_status launch_scale<T>(hipStream_t, T *, aoclsparse_int, T);                           \
     template aoclsparse_status launch_waxpby<T>(hipStream_t, aoclsparse_int, T, const T *, T, const T *, T *); \
     template aoclsparse_status launch_dot<T>(hipStream_t, aoclsparse_int, const T *, const T *, T *, T *);     \

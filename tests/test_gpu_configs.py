@@ -504,6 +504,32 @@ def test_mv_triangular_rectangular_reference_kat(kats):
 # --------------------------------------------------------------------------------------------------
 # the third kernel aoclsparse_optimize can choose: merge-path for matrices with very long rows
 # --------------------------------------------------------------------------------------------------
+def test_heavy_first_block_order_is_bit_identical():
+    """row blocks that hold a long row are handed to the first workgroups (SpmvPlan::rowblocks4): same blocks, same
+    per-row chains -- the product must stay bit-identical to the serial scalar-order reference, through a handle and
+    through the raw-array entry, for base 0 and 1"""
+    from util import powerlaw_rows
+    m = 120000
+    for base in (0, 1):
+        rp, ci, v = random_csr(91 + base, m, m, powerlaw_rows(6, 400), base=base)
+        assert len(v) > 512 * 600 and np.diff(rp).max() >= 64  # enough blocks, heavy rows present
+        x = np.random.default_rng(5).uniform(-1, 1, m)
+        y0 = np.random.default_rng(6).uniform(-1, 1, m)
+        st, yr = oracle.dcsrmv(0, base, 1.5, m, len(v), v, ci, rp, x, -0.5, y0)
+        assert st == 0
+        A = P.Matrix(base, m, m, rp, ci, v)
+        d = P.Descr(base=base)
+        assert L.aoclsparse_set_mv_hint(A.h, P.OP_NONE, d.h, 100) == 0 and L.aoclsparse_optimize(A.h) == 0
+        assert A.spmv_info().kernel == 1  # csr-adaptive (not SELL, not merge-path)
+        yd = dev(y0)
+        assert P.dmv(P.OP_NONE, 1.5, A, d, dev(x), -0.5, yd) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(yd.cpu().numpy(), yr), base
+        yh = y0.copy()
+        assert P.dcsrmv(P.OP_NONE, 1.5, m, m, len(v), v, ci, rp, d, x, -0.5, yh) == 0
+        assert np.array_equal(yh, yr), base
+
+
 def test_optimize_selects_merge_path_for_very_long_rows():
     """Row-length statistics decide the SpMV kernel: a tridiagonal matrix with two rows of ~45,000 entries (> 32 LDS
     tiles) gets merge-path tiles, the same matrix with rows of ~4,000 entries stays on CSR-Adaptive.  Rows inside one
