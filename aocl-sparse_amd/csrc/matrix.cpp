@@ -535,6 +535,10 @@ aoclsparse_status build_spmv_plan(aoclsparse_int m, aoclsparse_int nnz, aoclspar
             if(heavy > 0) // (circuit-like: most blocks hold a row >= 64; the 300-entry ones still have to go first)
             {
                 std::stable_sort(order.begin(), order.end(), [&](aoclsparse_int a, aoclsparse_int c) { return weight[a] > weight[c]; });
+                // (Tried: the heaviest eighth on the XCD a lone launch reaches first -- workgroup i runs on XCD i % 8 and a
+                // synchronous launch reaches the XCDs staggered by up to 4.5 us, tools/spmv_trace.py -- the traced span fell
+                // 13.8 -> 11.0 us, but back-to-back calls got SLOWER (14.8 vs 13.6 us, web-like 37 vs 28 us): in a stream of
+                // launches the stagger is not there and one XCD ends up with all the long chains.)
                 std::vector<aoclsparse_int> b4(4 * (size_t)nb);
                 for(aoclsparse_int k = 0; k < nb; k++)
                 {

@@ -147,8 +147,8 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restr
     unsigned long long t_st[4] = {0, 0, 0, 0};
     if(trace)
         t_st[0] = __builtin_amdgcn_s_memrealtime();
-    __shared__ T              s_val[TILE + 4];
-    __shared__ T              s_x[TILE + 4];
+    __shared__ __attribute__((aligned(16))) T s_val[TILE + 4];
+    __shared__ __attribute__((aligned(16))) T s_x[TILE + 4];
     __shared__ aoclsparse_int s_row[MAXROWS + 1];
     using P2          = typename pair_of<T>::type;
     constexpr int L   = lanes_of<ORDER>::value;
@@ -262,34 +262,66 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restr
                 // once per entry: traced on the circuit-like stand-in (tools/spmv_trace.py), the entry-by-entry loop
                 // was 1.8 us of a workgroup's 5.4 us (rows of 1-15 entries: ~100 cycles of LDS latency per FMA)
                 int j = s;
-                if(j + 8 <= e) // full batches: no clamps, no predicates on the chain; the reads of batch k + 1 are
-                {              // issued before the FMAs of batch k (a 337-entry row is 42 batches in a row)
-                    T a[8], b[8];
-#pragma unroll
-                    for(int q = 0; q < 8; q++)
+                if(e - j >= 9) // full batches: no clamps, no predicates on the chain.  Values and x's are read in PAIRS
+                {              // (one LDS instruction per entry instead of two: a lone wavefront issues an instruction
+                               // every ~3.5 ns, so a 330-entry row was 6-7 us of reads + FMAs) and the reads of batch
+                               // k + 1 are issued before the FMAs of batch k
+                    if(j & 1) // pairs start at even LDS indices
                     {
-                        a[q] = s_val[j + q];
-                        b[q] = s_x[j + q];
+                        acc = dev_fma(s_val[j], s_x[j], acc);
+                        j++;
                     }
-                    for(j += 8; j + 8 <= e; j += 8)
-                    {
-                        T an[8], bn[8];
+                    // two register sets, used alternately (a rotating copy doubled the loop's instruction count)
+                    P2   a[4], b[4], an[4], bn[4];
+                    auto rd = [&](P2(&va)[4], P2(&vb)[4], int at) {
 #pragma unroll
-                        for(int q = 0; q < 8; q++)
+                        for(int q = 0; q < 4; q++)
                         {
-                            an[q] = s_val[j + q];
-                            bn[q] = s_x[j + q];
+                            va[q] = *reinterpret_cast<const P2 *>(&s_val[at + 2 * q]);
+                            vb[q] = *reinterpret_cast<const P2 *>(&s_x[at + 2 * q]);
                         }
+                    };
+                    auto mac = [&](const P2(&va)[4], const P2(&vb)[4]) {
 #pragma unroll
-                        for(int q = 0; q < 8; q++)
-                            acc = dev_fma(a[q], b[q], acc);
+                        for(int q = 0; q < 4; q++)
+                        {
+                            acc = dev_fma(va[q].x, vb[q].x, acc);
+                            acc = dev_fma(va[q].y, vb[q].y, acc);
+                        }
+                    };
+                    rd(a, b, j);
+                    j += 8;
+                    while(j + 16 <= e)
+                    {
+                        rd(an, bn, j);
+                        mac(a, b);
+                        rd(a, b, j + 8);
+                        mac(an, bn);
+                        j += 16;
+                    }
+                    if(j + 8 <= e)
+                    {
+                        rd(an, bn, j);
+                        mac(a, b);
+                        mac(an, bn);
+                        j += 8;
+                    }
+                    else
+                        mac(a, b);
+                }
+                if(e - j >= 8) // (a row of exactly 8, or 8 left after an odd start)
+                {
+                    T a8[8], b8[8];
 #pragma unroll
-                        for(int q = 0; q < 8; q++)
-                            a[q] = an[q], b[q] = bn[q];
+                    for(int q = 0; q < 8; q++)
+                    {
+                        a8[q] = s_val[j + q];
+                        b8[q] = s_x[j + q];
                     }
 #pragma unroll
                     for(int q = 0; q < 8; q++)
-                        acc = dev_fma(a[q], b[q], acc);
+                        acc = dev_fma(a8[q], b8[q], acc);
+                    j += 8;
                 }
                 if(j < e) // the last 1..7 entries: one clamped batch
                 {

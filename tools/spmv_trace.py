@@ -37,6 +37,8 @@ for name, gen in (("circuit-like", standins.circuit_like), ("web-like", standins
                       "long_row_block_us_q": q(us(te - tb)[~short]) if (~short).any() else None,
                       "rows_per_block_q": q((t[:, 5] >> np.uint64(32)).astype(np.int64)),
                       "quartiles": "[5, 25, 50, 75, 95, 100] %",
+                      "start_us_median_by_block_index_mod_8 (= XCD)": [round(float(np.median(us(st - t0)[k::8])), 2) for k in range(8)],
+                      "first_start_us_by_block_index_mod_8": [round(float(us(st - t0)[k::8].min()), 2) for k in range(8)],
                       "last_to_end (block index, start, table, tile, barrier, reduce, rows, nnz, longest row)":
                           [[int(b), float(us(st[b] - t0)), float(us(tb[b] - st[b])), float(us(tl[b] - tb[b])), float(us(ts[b] - tl[b])),
                             float(us(te[b] - max(ts[b], tb[b]))), int(t[b, 5] >> np.uint64(32)), int(t[b, 5] & np.uint64(0xffffffff)),
