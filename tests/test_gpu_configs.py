@@ -504,6 +504,48 @@ def test_mv_triangular_rectangular_reference_kat(kats):
 # --------------------------------------------------------------------------------------------------
 # the third kernel aoclsparse_optimize can choose: merge-path for matrices with very long rows
 # --------------------------------------------------------------------------------------------------
+def test_device_pointer_calls_can_be_captured_in_a_hip_graph():
+    """device-pointer ?mv / ?trsv calls enqueue kernels and memsets only (no allocation, no synchronisation, no host
+    read-back once their workspaces exist), so a solver loop can be captured on the stream handed to
+    aoclsparse_mi355_set_stream and replayed as one HIP graph; results are those of the eager calls, bit for bit"""
+    import ctypes
+    from test_gpu_trsv_blocks import node_mesh
+    nodes = 2000
+    m, rp, ci, v = node_mesh(9, nodes, 40, np.full(nodes, 5))
+    A = P.Matrix(0, m, m, rp, ci, v)
+    dg = P.Descr()
+    dl = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=P.FILL_LOWER)
+    du = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=P.FILL_UPPER)
+    L.aoclsparse_mi355_set_pointer_mode(P.PTR_DEVICE)
+    s = torch.cuda.Stream()
+    assert L.aoclsparse_mi355_set_stream(ctypes.c_void_p(s.cuda_stream)) == 0
+    try:
+        with torch.cuda.stream(s):
+            x = dev(np.random.default_rng(3).uniform(-1, 1, m))
+            y, z, w = (torch.zeros(m, dtype=torch.float64, device="cuda") for _ in range(3))
+
+            def step():
+                assert P.dmv(P.OP_NONE, 1.0, A, dg, x, 0.0, y) == 0          # y = A x
+                assert P.dtrsv(P.OP_NONE, 1.0, A, dl, y, z) == 0            # z = L^-1 y
+                assert P.dtrsv(P.OP_NONE, 1.0, A, du, z, w) == 0            # w = U^-1 z
+
+            for _ in range(2):  # workspaces, plans
+                step()
+            s.synchronize()
+            ref = w.clone()
+            w.zero_(), z.zero_(), y.zero_()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                step()
+            for _ in range(3):
+                g.replay()
+            s.synchronize()
+            assert torch.equal(w, ref)
+    finally:
+        assert L.aoclsparse_mi355_set_stream(None) == 0
+        L.aoclsparse_mi355_set_pointer_mode(P.PTR_AUTO)
+
+
 def test_heavy_first_block_order_is_bit_identical():
     """row blocks that hold a long row are handed to the first workgroups (SpmvPlan::rowblocks4): same blocks, same
     per-row chains -- the product must stay bit-identical to the serial scalar-order reference, through a handle and
