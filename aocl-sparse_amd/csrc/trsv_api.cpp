@@ -448,7 +448,7 @@ aoclsparse_status solve_core(aoclsparse_operation trans, T alpha, aoclsparse_mat
                         : (packed && ((long long)plan.nnz_tri <= 10LL * m || (upper && !tr && !conj))) ? 3
                                                                                                     : 2;
     // chained rows (the dofs of a node) solved back to back by one lane: one hop per BLOCK level instead of per row level
-    const int sfb = (sf_env == 0 && nrhs == 1 && plan.blk.valid) ? 4 : sf;
+    const int sfb = (sf_env == 0 && plan.blk.valid) ? 4 : sf; // (trsm too: one grid column per right-hand side)
     const int schedule = is_cplx ? 1 : kid == 0 ? 0 : (kid == 3 ? sfb : (kid > 0 ? 1 : (plan.nlevels <= 32 ? 0 : sfb)));
     // a wait that expired in an EARLIER asynchronous (device-pointer) solve is reported now
     if(rt.trsv_timeout_host && *rt.trsv_timeout_host)
@@ -461,7 +461,7 @@ aoclsparse_status solve_core(aoclsparse_operation trans, T alpha, aoclsparse_mat
     // (+ TRSV_XP_PAD elements: the block kernel parks the stores of lanes / rows that own nothing there)
     st = A->trsv_xp.alloc(sizeof(T) * ((size_t)m * (size_t)nrhs + TRSV_XP_PAD));
     if(st == aoclsparse_status_success)
-        st = A->trsv_scratch.alloc(sizeof(unsigned int) * std::max((size_t)nrhs + 1, (size_t)2 + (size_t)plan.blk.nlevels));
+        st = A->trsv_scratch.alloc(sizeof(unsigned int) * ((size_t)nrhs + 1 + (size_t)nrhs * (size_t)std::max<aoclsparse_int>(plan.blk.nlevels, 0)));
     if(st != aoclsparse_status_success)
         return st;
 

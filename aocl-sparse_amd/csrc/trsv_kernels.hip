@@ -573,10 +573,20 @@ __global__ __launch_bounds__(64) void trsv_block_kernel(
     const aoclsparse_int *__restrict__ bfirst, const aoclsparse_int *__restrict__ rowmap,
     const aoclsparse_int *__restrict__ pptr, const aoclsparse_int *__restrict__ pind, const T *__restrict__ pval,
     const T *__restrict__ diag, const T *__restrict__ b, T *xp, T *x, T alpha, int unit, unsigned int *ticket,
-    unsigned int *timeout_flag, int incb, int incx, unsigned long long *trace, unsigned int *level_done, int gate)
+    unsigned int *timeout_flag, int incb, int incx, unsigned long long *trace, unsigned int *level_done, int gate,
+    int nrhs, long long b_off, long long x_off, int nlevels)
 {
     using B = typename tag<T>::bits;
     static_assert(EXT % 2 == 0, "paired LDS reads");
+    // several right-hand sides (trsm): the column is the FAST grid dimension, so the resident workgroups are the next
+    // slices of EVERY column rather than all of one column's; each column has its own ticket, level counters and xp slab.
+    // `spare` = elements from this column's xp slab to the spare slots behind the m x nrhs solution buffer.
+    const int col   = nrhs > 1 ? (int)blockIdx.x : 0;
+    const int spare = m * (nrhs - col);
+    ticket += col, level_done += (size_t)col * nlevels;
+    b += col * b_off, x += col * x_off, xp += (size_t)col * m;
+    if(col)
+        trace = nullptr;
     constexpr int BSP = BS + (BS & 1), SLOTS = trsv_blk_slots(BS, EXT), INT0 = BS * EXT; // internal values from slot INT0
     extern __shared__ unsigned char s_raw[];
     T            *s_mine = reinterpret_cast<T *>(s_raw) + (size_t)threadIdx.x * SLOTS;
@@ -603,7 +613,7 @@ __global__ __launch_bounds__(64) void trsv_block_kernel(
     int        q[EXT];
 #pragma unroll
     for(int e = 0; e < EXT; e++)
-        q[e] = e < nl ? pind[p0 + e] : m + TRSV_XP_PAD - 1; // beyond the row: a slot that always holds 0
+        q[e] = e < nl ? pind[p0 + e] : spare + TRSV_XP_PAD - 1; // beyond the row: a slot that always holds 0
     // larger shapes: the block's values -> their LDS slots (zero elsewhere)
     if constexpr(SLOTS > 112)
     {
@@ -629,8 +639,8 @@ __global__ __launch_bounds__(64) void trsv_block_kernel(
         const int row = a < c ? rowmap[k0 + a] : 0;
         rhs[a]        = a < c ? alpha * b[(size_t)row * incb] : T(0);
         dg[a]         = (a < c && !unit) ? diag[row] : T(1);
-        xdst[a]       = a < c ? x + (size_t)row * incx : xp + (size_t)m + 64 + tid;
-        bdst[a]       = a < c ? xb + k0 + a : xb + (size_t)m + tid;
+        xdst[a]       = a < c ? x + (size_t)row * incx : xp + (size_t)spare + 64 + tid;
+        bdst[a]       = a < c ? xb + k0 + a : xb + (size_t)spare + tid;
     }
     unsigned long long t0   = 0;
     bool               dead = false;
@@ -787,7 +797,7 @@ __global__ __launch_bounds__(64) void trsv_block_kernel(
         {
 #pragma unroll
             for(int a = 0; a < BS; a++)
-                bdst[a] = xb + (size_t)m + tid, xdst[a] = xp + (size_t)m + 64 + tid;
+                bdst[a] = xb + (size_t)spare + tid, xdst[a] = xp + (size_t)spare + 64 + tid;
         }
         if constexpr(FRONT)
         {
@@ -927,7 +937,9 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
     RhsGeom               g{b_off, x_off, incb, incx, 0};
     if(schedule == 1 && (nrhs != 1 || incb != 1 || incx != 1))
         schedule = 2; // the single-workgroup runs of the hybrid schedule are single-RHS, unit stride
-    if(schedule == 4 && (nrhs != 1 || !plan.blk.valid))
+    // (several right-hand sides: the column is grid dimension x, the slice y <= 65,535; index arithmetic in int)
+    if(schedule == 4
+       && (!plan.blk.valid || (nrhs > 1 && (plan.blk.nslices > 65535 || (long long)m * nrhs + TRSV_XP_PAD >= (1LL << 31)))))
         schedule = 3;
     if(schedule == 3 && (nrhs != 1 || plan.nslices <= 0))
         schedule = 2; // the slice kernel is single-RHS; trsm keeps the lane-per-position kernel
@@ -964,10 +976,11 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
     {
         // sync-free, one lane per block of chained rows (plan.blk has its own level-ordered copy of the triangle)
         const TrsvBlockPlan &bp = plan.blk;
-        // scratch: ticket, timeout word, then one finished-slices counter per block level
-        MI355_HIP_TRY(hipMemsetAsync(scratch, 0, (2 + (size_t)bp.nlevels) * sizeof(unsigned int), s));
-        hipLaunchKernelGGL((trsv_fill_tag_kernel<T>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, xp, (long long)m,
-                           (long long)m + TRSV_XP_PAD - 1);
+        // scratch: one ticket per column, the timeout word, then one finished-slices counter per (column, block level)
+        const long long total = (long long)m * nrhs;
+        MI355_HIP_TRY(hipMemsetAsync(scratch, 0, ((size_t)nrhs + 1 + (size_t)nrhs * bp.nlevels) * sizeof(unsigned int), s));
+        hipLaunchKernelGGL((trsv_fill_tag_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xp, total,
+                           total + TRSV_XP_PAD - 1);
         static const int gate  = [] { const char *e = getenv("AOCLSPARSE_MI355_TRSV_GATE"); return e ? atoi(e) : 2; }();
         // diagnostic: AOCLSPARSE_MI355_TRSV_TRACE=<file> dumps, per slice, the 100 MHz clock after the ticket, when the
         // dependencies were all in, at the end, the slice's block level, after the LDS reads, after the external FMAs (6 x u64 per slice; tools/trsv_trace.py)
@@ -990,11 +1003,12 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
                 if(raised != hipSuccess)
                     return aoclsparse_status_internal_error;
             }
-            hipLaunchKernelGGL((trsv_block_kernel<T, BS, EXT, FRONT>), dim3((unsigned)bp.nslices), dim3(64), lds, s, m, bp.nslices,
+            const dim3 grid = nrhs > 1 ? dim3((unsigned)nrhs, (unsigned)bp.nslices) : dim3((unsigned)bp.nslices);
+            hipLaunchKernelGGL((trsv_block_kernel<T, BS, EXT, FRONT>), grid, dim3(64), lds, s, m, bp.nslices,
                                bp.slices.as<aoclsparse_int>(), bp.bfirst.as<aoclsparse_int>(), bp.rowmap.as<aoclsparse_int>(),
                                bp.pptr.as<aoclsparse_int>(), bp.pind.as<aoclsparse_int>(), bp.pval.as<T>(), diag, b, xp, x,
-                               alpha, (int)unit, scratch, timeout_word ? timeout_word : scratch + 1, (int)incb, (int)incx,
-                               trace, scratch + 2, gate);
+                               alpha, (int)unit, scratch, timeout_word ? timeout_word : scratch + nrhs, (int)incb, (int)incx,
+                               trace, scratch + nrhs + 1, gate, (int)nrhs, b_off, x_off, (int)bp.nlevels);
             return aoclsparse_status_success;
         };
         auto go = [&](auto bs_tag, auto ext_tag) {

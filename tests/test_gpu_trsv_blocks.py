@@ -163,6 +163,44 @@ def test_block_trsv_nan_inf_and_tag_propagate():
         assert np.array_equal(gn, rn) and np.array_equal(got[~gn], xr[~rn]) and 2 <= rn.sum() < m
 
 
+@pytest.mark.parametrize("order", ["column", "row"])
+def test_block_trsm_every_column_bit_exact(order):
+    """several right-hand sides: one grid column per right-hand side of the block kernel (own ticket, level counters and
+    solution slab); every column equals the serial chain, both dense layouts, padded leading dimensions untouched"""
+    nodes = 2500
+    m, rp, ci, v = node_mesh(61, nodes, 50, mixed(np.random.default_rng(4), nodes), far=7)
+    o = oracle.dcsr_optimize(m, m, len(v), 0, rp, ci, v)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    n = 7
+    rng = np.random.default_rng(12)
+    for kind, fill, op, unit in (("l", P.FILL_LOWER, P.OP_NONE, True), ("u", P.FILL_UPPER, P.OP_NONE, False),
+                                 ("lt", P.FILL_LOWER, P.OP_TRANSPOSE, False), ("ut", P.FILL_UPPER, P.OP_TRANSPOSE, True)):
+        d = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=fill, diag=P.DIAG_UNIT if unit else P.DIAG_NON_UNIT)
+        iend = o["idiag"] if kind[0] == "l" else o["iurow"]
+        if order == "column":
+            ld = m + 3
+            Bm = rng.uniform(-1, 1, (n, ld)); Xm = np.full((n, ld), 7.0)
+            cols = lambda M, j: M[j, :m]
+            pad_ok = lambda M: np.all(M[:, m:] == 7.0)
+            lay = P.ORDER_COLUMN
+        else:
+            ld = n + 2
+            Bm = rng.uniform(-1, 1, (m, ld)); Xm = np.full((m, ld), 7.0)
+            cols = lambda M, j: M[:, j]
+            pad_ok = lambda M: np.all(M[:, n:] == 7.0)
+            lay = P.ORDER_ROW
+        for ptr_dev in (False, True):
+            Bd, Xd = (dev(Bm), dev(Xm)) if ptr_dev else (Bm, Xm.copy())
+            assert L.aoclsparse_dtrsm(op, 0.5, A.h, d.h, lay, P._ptr(Bd), n, ld, P._ptr(Xd), ld) == 0
+            if ptr_dev:
+                torch.cuda.synchronize()
+            X = Xd.cpu().numpy() if ptr_dev else Xd
+            assert pad_ok(X)
+            for j in range(n):
+                st, xr = oracle.dtrsv(kind, 0.5, m, 0, o["val"], o["ind"], o["ptr"], iend, np.ascontiguousarray(cols(Bm, j)), unit)
+                assert st == 0 and np.array_equal(cols(X, j), xr), (kind, order, ptr_dev, j)
+
+
 _TRACE_SCRIPT = r"""
 import os, sys
 import numpy as np, torch
