@@ -11,6 +11,11 @@
 #include <hip/hip_runtime_api.h>
 
 #include <atomic>
+#include <algorithm>
+#include <thread>
+#include <cstdlib>
+#include <cstdio>
+#include <chrono>
 #include <cstddef>
 #include <cstdint>
 #include <memory>
@@ -130,6 +135,59 @@ struct Hint
     aoclsparse_int         nop;
     aoclsparse_int         kid;
     bool                   optimized = false;
+};
+
+
+// Host-side analysis loops over rows / blocks that are independent of each other: fixed chunking (results do not depend on
+// the thread count), at most 16 threads, inline below `grain` items.  fn(begin, end).
+template <typename F>
+inline void parallel_for(long long n, long long grain, F fn)
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int      nt = (int)std::min<long long>(std::min<unsigned>(16u, hw ? hw : 1u), (n + grain - 1) / std::max<long long>(grain, 1));
+    if(nt <= 1)
+    {
+        fn(0LL, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    th.reserve((size_t)nt);
+    for(int t = 0; t < nt; t++)
+        th.emplace_back([=] { fn(n * t / nt, n * (t + 1) / nt); });
+    for(auto &t : th)
+        t.join();
+}
+
+// Diagnostic: AOCLSPARSE_MI355_TIMING=1 prints the wall time of the analysis phases it brackets to stderr.
+struct PhaseTimer
+{
+    const char                           *name;
+    std::chrono::steady_clock::time_point t0;
+    static bool                           on()
+    {
+        static const bool v = [] { const char *e = std::getenv("AOCLSPARSE_MI355_TIMING"); return e && std::atoi(e) != 0; }();
+        return v;
+    }
+    explicit PhaseTimer(const char *n) : name(n), t0(std::chrono::steady_clock::now()) {}
+    ~PhaseTimer()
+    {
+        if(on())
+            std::fprintf(stderr, "[mi355 timing] %-34s %8.1f ms\n", name,
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
+
+struct LapTimer // same switch: lap("what") prints the time since the previous lap
+{
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void                                  lap(const char *what)
+    {
+        if(!PhaseTimer::on())
+            return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[mi355 timing]     %-30s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
 };
 
 // ---- device memory -------------------------------------------------------------------------

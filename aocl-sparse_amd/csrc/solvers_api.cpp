@@ -453,7 +453,10 @@ aoclsparse_status ilu_smoother_t(aoclsparse_operation op, aoclsparse_matrix A, c
         return aoclsparse_status_invalid_size;
     if(A->m == 0 || A->n == 0)
         return aoclsparse_status_success;
-    MI355_TRY(ilu_prepare(A));
+    {
+        PhaseTimer pt("ilu: prepare");
+        MI355_TRY(ilu_prepare(A));
+    }
 
     Runtime &rt = Runtime::get();
     MI355_TRY(rt.init());
@@ -461,7 +464,11 @@ aoclsparse_status ilu_smoother_t(aoclsparse_operation op, aoclsparse_matrix A, c
     *precond_csr_val = nullptr;
     if(!A->ilu_factorized)
     {
-        MI355_TRY(ilu0_factorize<T>(A, static_cast<T *>(A->ilu_val)));
+        {
+            PhaseTimer pt("ilu: factorise on the GPU");
+            MI355_TRY(ilu0_factorize<T>(A, static_cast<T *>(A->ilu_val)));
+        }
+        PhaseTimer pt("ilu: factor handle");
         // the factors as a matrix of their own: its level-scheduled TRSV plans are the smoother's solves
         MI355_TRY(create_csr(&A->ilu_factor, A->base, A->m, A->n, A->nnz, A->user.ptr, A->user.ind,
                              static_cast<T *>(A->ilu_val)));

@@ -19,11 +19,37 @@ namespace mi355
 
 // Host view of the strict triangle one (fill, op) variant walks: row i depends on the rows listed in
 // [ptr[i], ptr[i+1]) of ind (0-based), val in the order the reference's chain applies them.
+// nnz-sized scratch that every element of is written before it is read: NOT zero-filled (a std::vector of 25 M entries costs
+// ~30 ms of single-threaded zeroing and page faults per array; here the first touch happens in the parallel fill loops)
+template <typename U>
+struct RawArray
+{
+    std::unique_ptr<U[]> p;
+    size_t               n = 0;
+    RawArray()             = default;
+    explicit RawArray(size_t count) { resize(count); }
+    void resize(size_t count)
+    {
+        p.reset(new U[count]); // default-initialised: no fill for arithmetic types
+        n = count;
+    }
+    U       *data() { return p.get(); }
+    const U *data() const { return p.get(); }
+    U       *begin() { return p.get(); }
+    const U *begin() const { return p.get(); }
+    U       *end() { return p.get() + n; }
+    const U *end() const { return p.get() + n; }
+    size_t   size() const { return n; }
+    U       &operator[](size_t i) { return p[i]; }
+    const U &operator[](size_t i) const { return p[i]; }
+};
+
 template <typename T>
 struct Triangle
 {
-    std::vector<aoclsparse_int> ptr, ind;
-    std::vector<T>              val;
+    std::vector<aoclsparse_int> ptr;
+    RawArray<aoclsparse_int>    ind;
+    RawArray<T>                 val;
     bool                        descending = false; // solve order m-1..0 (dependencies point to larger rows)
 };
 
@@ -42,12 +68,14 @@ static void build_triangle(const HostCsr &c, bool upper, bool transposed, bool c
             t.ptr[i + 1] = t.ptr[i] + (e[i] - s[i]);
         t.ind.resize((size_t)std::max(t.ptr[m], 1));
         t.val.resize((size_t)std::max(t.ptr[m], 1));
-        for(aoclsparse_int i = 0; i < m; i++)
-            for(aoclsparse_int p = s[i] - b, q = t.ptr[i]; p < e[i] - b; p++, q++)
-            {
-                t.ind[q] = c.ind[p] - b;
-                t.val[q] = v[p];
-            }
+        parallel_for(m, 1 << 16, [&](long long i0, long long i1) {
+            for(aoclsparse_int i = (aoclsparse_int)i0; i < (aoclsparse_int)i1; i++)
+                for(aoclsparse_int p = s[i] - b, q = t.ptr[i]; p < e[i] - b; p++, q++)
+                {
+                    t.ind[q] = c.ind[p] - b;
+                    t.val[q] = v[p];
+                }
+        });
         t.descending = upper;
         return;
     }
@@ -85,6 +113,7 @@ static void build_triangle(const HostCsr &c, bool upper, bool transposed, bool c
 template <typename T>
 static aoclsparse_status build_levels(aoclsparse_int m, const Triangle<T> &t, TrsvPlan &plan)
 {
+    LapTimer                    lt;
     std::vector<aoclsparse_int> level((size_t)m, 0);
     aoclsparse_int              nlev = 0;
     for(aoclsparse_int k = 0; k < m; k++)
@@ -112,20 +141,26 @@ static aoclsparse_status build_levels(aoclsparse_int m, const Triangle<T> &t, Tr
     plan.nlevels = nlev;
     plan.nnz_tri = t.ptr[m];
 
+    lt.lap("levels: level pass + buckets");
     // level-ordered copy of the triangle; dependencies are rewritten as POSITIONS in that order
     std::vector<aoclsparse_int> pos((size_t)m);
     for(aoclsparse_int k = 0; k < m; k++)
         pos[rowmap[k]] = k;
-    std::vector<aoclsparse_int> pptr((size_t)m + 1, 0), pind(t.ind.size());
-    std::vector<T>              pval(t.val.size());
+    std::vector<aoclsparse_int> pptr((size_t)m + 1, 0);
+    RawArray<aoclsparse_int>    pind(t.ind.size());
+    RawArray<T>                 pval(t.val.size());
     for(aoclsparse_int k = 0; k < m; k++)
-    {
-        const aoclsparse_int i = rowmap[k], len = t.ptr[i + 1] - t.ptr[i];
-        pptr[k + 1]            = pptr[k] + len;
-        for(aoclsparse_int j = 0; j < len; j++)
-            pind[pptr[k] + j] = pos[t.ind[t.ptr[i] + j]];
-        std::copy(t.val.begin() + t.ptr[i], t.val.begin() + t.ptr[i + 1], pval.begin() + pptr[k]);
-    }
+        pptr[k + 1] = pptr[k] + (t.ptr[rowmap[k] + 1] - t.ptr[rowmap[k]]);
+    parallel_for(m, 1 << 16, [&](long long k0, long long k1) {
+        for(aoclsparse_int k = (aoclsparse_int)k0; k < (aoclsparse_int)k1; k++)
+        {
+            const aoclsparse_int i = rowmap[k], len = t.ptr[i + 1] - t.ptr[i];
+            for(aoclsparse_int j = 0; j < len; j++)
+                pind[pptr[k] + j] = pos[t.ind[t.ptr[i] + j]];
+            std::copy(t.val.begin() + t.ptr[i], t.val.begin() + t.ptr[i + 1], pval.begin() + pptr[k]);
+        }
+    });
+    lt.lap("levels: layout");
     // level slices (<= 64 positions, inside one level) for the slice-per-wavefront sync-free kernel
     std::vector<aoclsparse_int> slices;
     slices.reserve((size_t)m / 48 + (size_t)nlev + 2);
@@ -148,6 +183,7 @@ static aoclsparse_status build_levels(aoclsparse_int m, const Triangle<T> &t, Tr
         plan.launches += (narrow && e - l > 1) ? 1 : e - l;
         l = e;
     }
+    lt.lap("levels: slices + segments");
     hipStream_t       st = Runtime::get().stream();
     aoclsparse_status rc = plan.rowmap.upload(rowmap.data(), sizeof(aoclsparse_int) * (size_t)m, st);
     if(rc == aoclsparse_status_success)
@@ -160,6 +196,7 @@ static aoclsparse_status build_levels(aoclsparse_int m, const Triangle<T> &t, Tr
         rc = plan.pval.upload(pval.data(), sizeof(T) * pval.size(), st);
     if(rc == aoclsparse_status_success)
         rc = plan.slices.upload(slices.data(), sizeof(aoclsparse_int) * slices.size(), st);
+    lt.lap("levels: upload");
     return rc;
 }
 
@@ -182,7 +219,8 @@ static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, T
     }();
     if(off)
         return aoclsparse_status_success;
-    auto row_at = [&](aoclsparse_int k) { return t.descending ? m - 1 - k : k; }; // k-th row in solve order
+    LapTimer lt;
+    auto     row_at = [&](aoclsparse_int k) { return t.descending ? m - 1 - k : k; }; // k-th row in solve order
     auto len_of = [&](aoclsparse_int i) { return t.ptr[i + 1] - t.ptr[i]; };
     // does `row` (lj entries) chain onto `prev` (lq entries)?  front = the predecessor is the FIRST entry
     auto chains = [&](aoclsparse_int row, aoclsparse_int prev, bool front) {
@@ -233,6 +271,7 @@ static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, T
     }
     bstart.swap(best);
     front = best_front;
+    lt.lap("blocks: chains");
     const aoclsparse_int nb = (aoclsparse_int)bstart.size();
     bstart.push_back(m);
     if((long long)nb * 16 > (long long)m * 10)
@@ -259,6 +298,7 @@ static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, T
         blev[bq] = lv;
         nlev     = std::max(nlev, lv + 1);
     }
+    lt.lap("blocks: levels");
     // 3. blocks in level order (stable), positions of their rows (in solve order inside a block)
     std::vector<aoclsparse_int> lptr((size_t)nlev + 1, 0);
     for(aoclsparse_int bq = 0; bq < nb; bq++)
@@ -277,16 +317,21 @@ static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, T
             rowmap[q] = row_at(kk), pos[row_at(kk)] = q;
     }
     // 4. the triangle in that order (entries in chain order), dependencies as positions
-    std::vector<aoclsparse_int> pptr((size_t)m + 1, 0), pind(t.ind.size());
-    std::vector<T>              pval(t.val.size());
+    std::vector<aoclsparse_int> pptr((size_t)m + 1, 0);
+    RawArray<aoclsparse_int>    pind(t.ind.size());
+    RawArray<T>                 pval(t.val.size());
     for(aoclsparse_int k = 0; k < m; k++)
-    {
-        const aoclsparse_int i = rowmap[k], len = len_of(i);
-        pptr[k + 1]            = pptr[k] + len;
-        for(aoclsparse_int j = 0; j < len; j++)
-            pind[pptr[k] + j] = pos[t.ind[t.ptr[i] + j]];
-        std::copy(t.val.begin() + t.ptr[i], t.val.begin() + t.ptr[i + 1], pval.begin() + pptr[k]);
-    }
+        pptr[k + 1] = pptr[k] + len_of(rowmap[k]);
+    parallel_for(m, 1 << 16, [&](long long k0, long long k1) {
+        for(aoclsparse_int k = (aoclsparse_int)k0; k < (aoclsparse_int)k1; k++)
+        {
+            const aoclsparse_int i = rowmap[k], len = len_of(i);
+            for(aoclsparse_int j = 0; j < len; j++)
+                pind[pptr[k] + j] = pos[t.ind[t.ptr[i] + j]];
+            std::copy(t.val.begin() + t.ptr[i], t.val.begin() + t.ptr[i + 1], pval.begin() + pptr[k]);
+        }
+    });
+    lt.lap("blocks: order + layout");
     // 5. slices of <= 64 blocks inside one block level
     std::vector<aoclsparse_int> slices;
     for(aoclsparse_int l = 0; l < nlev; l++)
@@ -321,6 +366,7 @@ static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, T
         rc = bp.slices.upload(slices.data(), sizeof(aoclsparse_int) * slices.size(), st);
     if(rc != aoclsparse_status_success)
         return rc;
+    lt.lap("blocks: upload");
     bp.nblocks = nb, bp.nslices = (aoclsparse_int)(slices.size() - 2 - (size_t)nlev) / 2, bp.nlevels = nlev;
     bp.max_rows = max_rows, bp.max_ext = max_ext;
     bp.front = front;
@@ -332,18 +378,32 @@ template <typename T>
 static aoclsparse_status build_plan_t(const HostCsr &c, bool upper, bool transposed, bool conj, TrsvPlan &plan)
 {
     Triangle<T> t;
-    build_triangle<T>(c, upper, transposed, conj, t);
-    aoclsparse_status st = build_levels<T>(c.m, t, plan);
+    {
+        PhaseTimer pt("trsv plan: triangle");
+        build_triangle<T>(c, upper, transposed, conj, t);
+    }
+    aoclsparse_status st;
+    {
+        PhaseTimer pt("trsv plan: levels + layout + upload");
+        st = build_levels<T>(c.m, t, plan);
+    }
     if constexpr(std::is_floating_point<T>::value)
         if(st == aoclsparse_status_success && !plan.blk.tried)
+        {
+            PhaseTimer pt("trsv plan: blocks + layout + upload");
             st = build_blocked<T>(c.m, t, plan.blk);
+        }
     return st;
 }
 
 aoclsparse_status ensure_trsv(aoclsparse_matrix A, bool upper, bool transposed, bool conj)
 {
     conj = conj && transposed && is_complex_type(A->val_type);
-    aoclsparse_status st = csr_optimize(A);
+    aoclsparse_status st;
+    {
+        PhaseTimer pt("trsv plan: csr_optimize (if needed)");
+        st = csr_optimize(A);
+    }
     if(st != aoclsparse_status_success)
         return st;
     TrsvPlan &plan = A->trsv_plan[conj ? 4 + (upper ? 1 : 0) : (upper ? 2 : 0) + (transposed ? 1 : 0)];

@@ -1,0 +1,2 @@
+#!/bin/bash
+timeout 2400 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -6
