@@ -267,6 +267,111 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup_kernel(int base, T alpha, 
         }
 }
 
+// Second version of the row-group kernel (n >= 128), written after reading the first one's ISA: there, every 8-entry step
+// was SIX scalar-load round trips one after the other (the column indices, then -- inside a wave-uniform branch per row --
+// each row's eight values, waited for before that row's FMAs) and the B-row loads of step k + 1 were not issued before
+// the FMAs of step k were done.  Here a step is 4 entries: the values of ALL rows of the group are loaded together
+// (GR x 4 doubles through the scalar cache, unconditionally -- rows the group does not have re-read row 0's), the B rows
+// of the NEXT step are requested before the FMAs of this one (two register sets, used alternately), and only the FMAs sit
+// behind the per-row branch.  GR is the matrix's largest group size exactly (2, 3, 4, 5, 6 or 8), not rounded up to 8.
+template <typename T, int GR>
+__global__ __launch_bounds__(256) void csrmm_rowgroup2_kernel(int base, T alpha, aoclsparse_int ngroups,
+                                                              const aoclsparse_int *__restrict__ grp,
+                                                              const T *__restrict__ val,
+                                                              const aoclsparse_int *__restrict__ col,
+                                                              const aoclsparse_int *__restrict__ row_ptr,
+                                                              const T *__restrict__ B, aoclsparse_int n, aoclsparse_int ldb,
+                                                              T beta, T *__restrict__ C, aoclsparse_int ldc, bool readc,
+                                                              int xcd_chunk, const aoclsparse_int *__restrict__ glist)
+{
+    using V         = typename vec2<T>::type;
+    constexpr int U = 4;
+    const int     w  = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int     bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int     gt = bx * 4 + w;
+    const int     j  = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
+    if(gt >= ngroups || j >= n)
+        return;
+    const int gi = glist ? glist[gt] : gt;
+    const int i0 = grp[gi], r = grp[gi + 1] - i0; // 1 <= r <= GR
+    const int s0 = row_ptr[i0] - base, len = row_ptr[i0 + 1] - base - s0;
+    int       so[GR]; // start of every row of the group (wave-uniform); rows beyond the group alias row 0
+#pragma unroll
+    for(int q = 0; q < GR; q++)
+        so[q] = q < r ? row_ptr[i0 + q] - base : s0;
+    T acc0[GR], acc1[GR];
+#pragma unroll
+    for(int q = 0; q < GR; q++)
+        acc0[q] = T(0), acc1[q] = T(0);
+    const T  *Bj    = B + j;
+    const int nstep = len / U;
+    // (no branch on q < r around the FMAs: rows the group does not have accumulate row 0's products into accumulators
+    // that are never stored -- with the branch the compiler sinks each row's value loads behind it again)
+#define MM_FETCH(b, k)                                                                         \
+    {                                                                                          \
+        int c_[U];                                                                             \
+        _Pragma("unroll") for(int u = 0; u < U; u++) c_[u] = col[s0 + (k) + u] - base;         \
+        _Pragma("unroll") for(int u = 0; u < U; u++)                                           \
+            b[u] = *reinterpret_cast<const V *>(Bj + (size_t)c_[u] * ldb);                     \
+    }
+#define MM_MAC(b, k)                                                                           \
+    {                                                                                          \
+        T a_[GR][U];                                                                           \
+        _Pragma("unroll") for(int q = 0; q < GR; q++)                                          \
+            _Pragma("unroll") for(int u = 0; u < U; u++) a_[q][u] = val[so[q] + (k) + u];      \
+        _Pragma("unroll") for(int q = 0; q < GR; q++)                                          \
+            _Pragma("unroll") for(int u = 0; u < U; u++)                                       \
+            {                                                                                  \
+                acc0[q] = mm_fma(a_[q][u], b[u].x, acc0[q]);                                   \
+                acc1[q] = mm_fma(a_[q][u], b[u].y, acc1[q]);                                   \
+            }                                                                                  \
+    }
+    V   b0[U], b1[U];
+    int st = 0;
+    if(nstep > 0)
+        MM_FETCH(b0, 0)
+    for(; st + 2 <= nstep; st += 2)
+    {
+        MM_FETCH(b1, (st + 1) * U)
+        MM_MAC(b0, st * U)
+        if(st + 2 < nstep)
+            MM_FETCH(b0, (st + 2) * U)
+        MM_MAC(b1, (st + 1) * U)
+    }
+    if(st < nstep)
+        MM_MAC(b0, st * U)
+#undef MM_FETCH
+#undef MM_MAC
+    for(int k = nstep * U; k < len; k++)
+    {
+        const V bb = *reinterpret_cast<const V *>(Bj + (size_t)(col[s0 + k] - base) * ldb);
+#pragma unroll
+        for(int q = 0; q < GR; q++)
+            if(q < r)
+            {
+                const T a0 = val[so[q] + k];
+                acc0[q] = mm_fma(a0, bb.x, acc0[q]), acc1[q] = mm_fma(a0, bb.y, acc1[q]);
+            }
+    }
+#pragma unroll
+    for(int q = 0; q < GR; q++)
+        if(q < r)
+        {
+            V      *cp = reinterpret_cast<V *>(C + (size_t)(i0 + q) * ldc + j);
+            const T z0 = alpha * acc0[q], z1 = alpha * acc1[q];
+            V       c;
+            if(readc || z0 == T(0) || z1 == T(0))
+            {
+                c   = *cp;
+                c.x = mm_fma(beta, c.x, z0);
+                c.y = mm_fma(beta, c.y, z1);
+            }
+            else
+                c.x = z0, c.y = z1;
+            *cp = c;
+        }
+}
+
 // row-major, n >= 128, SUPER-GROUPS: a wavefront owns (block, 128-column chunk), where a block is a run of up to NG row
 // groups of exactly RG rows each, merged over the UNION of their column lists (csrmm_api.cpp: build_mm_super).  Every B row
 // of the union is loaded ONCE for up to NG*RG output rows -- the neighbouring nodes of a mesh share most of their neighbours,
@@ -873,7 +978,31 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
                                        alpha, ngroups, grp, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk);
                 }
             };
-            if(group_rows <= 2)
+            static const bool rg2 = [] {
+                const char *e = getenv("AOCLSPARSE_MI355_CSRMM_RG2");
+                return e ? atoi(e) != 0 : true;
+            }();
+            auto go2 = [&](auto gr_tag) {
+                constexpr int GR = decltype(gr_tag)::value;
+                const int     gx = grid_x((ngroups + 3) / 4, chunk);
+                hipLaunchKernelGGL((csrmm_rowgroup2_kernel<T, GR>), dim3(gx, (n + 127) / 128), dim3(256), 0, s, base, alpha,
+                                   ngroups, grp, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk,
+                                   (const aoclsparse_int *)nullptr);
+            };
+            if(rg2 && n >= 128)
+            {
+                switch(group_rows)
+                {
+                case 1:
+                case 2: go2(std::integral_constant<int, 2>{}); break;
+                case 3: go2(std::integral_constant<int, 3>{}); break;
+                case 4: go2(std::integral_constant<int, 4>{}); break;
+                case 5: go2(std::integral_constant<int, 5>{}); break;
+                case 6: go2(std::integral_constant<int, 6>{}); break;
+                default: go2(std::integral_constant<int, CSRMM_GROUP>{}); break;
+                }
+            }
+            else if(group_rows <= 2)
                 go(std::integral_constant<int, 2>{});
             else if(group_rows <= 4)
                 go(std::integral_constant<int, 4>{});
