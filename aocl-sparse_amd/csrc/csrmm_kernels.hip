@@ -342,16 +342,47 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup2_kernel(int base, T alpha,
         MM_MAC(b0, st * U)
 #undef MM_FETCH
 #undef MM_MAC
-    for(int k = nstep * U; k < len; k++)
+    // the last 1..3 entries as ONE more batch: indices clamped to the row, every load issued (and pinned: the compiler would
+    // sink them behind the branches below), then the FMAs of the entries that exist -- entry by entry this tail was three
+    // dependent index -> B row -> values chains, as long as the whole main loop of a 35-entry row
     {
-        const V bb = *reinterpret_cast<const V *>(Bj + (size_t)(col[s0 + k] - base) * ldb);
+        const int k = nstep * U;
+        if(k < len)
+        {
+            int c_[U - 1];
+            V   bt[U - 1];
+            T   a_[GR][U - 1];
 #pragma unroll
-        for(int q = 0; q < GR; q++)
-            if(q < r)
-            {
-                const T a0 = val[so[q] + k];
-                acc0[q] = mm_fma(a0, bb.x, acc0[q]), acc1[q] = mm_fma(a0, bb.y, acc1[q]);
-            }
+            for(int u = 0; u < U - 1; u++)
+                c_[u] = col[s0 + min(k + u, len - 1)] - base;
+#pragma unroll
+            for(int u = 0; u < U - 1; u++)
+                bt[u] = *reinterpret_cast<const V *>(Bj + (size_t)c_[u] * ldb);
+#pragma unroll
+            for(int q = 0; q < GR; q++)
+#pragma unroll
+                for(int u = 0; u < U - 1; u++)
+                    a_[q][u] = val[so[q] + min(k + u, len - 1)];
+#pragma unroll
+            for(int q = 0; q < GR; q++)
+#pragma unroll
+                for(int u = 0; u < U - 1; u++)
+                    asm volatile("" : "+s"(a_[q][u]));
+#pragma unroll
+            for(int u = 0; u < U - 1; u++)
+                asm volatile("" : "+v"(bt[u].x), "+v"(bt[u].y));
+#pragma unroll
+            for(int u = 0; u < U - 1; u++)
+                if(k + u < len)
+                {
+#pragma unroll
+                    for(int q = 0; q < GR; q++)
+                    {
+                        acc0[q] = mm_fma(a_[q][u], bt[u].x, acc0[q]);
+                        acc1[q] = mm_fma(a_[q][u], bt[u].y, acc1[q]);
+                    }
+                }
+        }
     }
 #pragma unroll
     for(int q = 0; q < GR; q++)
@@ -365,10 +396,17 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup2_kernel(int base, T alpha,
                 c   = *cp;
                 c.x = mm_fma(beta, c.x, z0);
                 c.y = mm_fma(beta, c.y, z1);
+                *cp = c;
             }
             else
-                c.x = z0, c.y = z1;
-            *cp = c;
+            {
+                // C is written once and never read: keep it out of the L2 the B rows live in (shell-like: the B window of
+                // a 128-column pass is ~9 MB per XCD against 4 MB of L2, HBM-side reads were 2.2 x B)
+                typedef T nt2 __attribute__((ext_vector_type(2)));
+                nt2 o;
+                o.x = z0, o.y = z1;
+                __builtin_nontemporal_store(o, reinterpret_cast<nt2 *>(cp));
+            }
         }
 }
 

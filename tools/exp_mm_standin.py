@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""One stand-in, row-major csrmm with n columns, a few calls (for rocprofv3 passes).  usage: exp_mm_standin.py shell-like|flan-like [n]"""
+import json, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import __graft_entry__ as entry, standins
+pkg = entry.load_package(); L = pkg.lib()
+L.aoclsparse_mi355_set_pointer_mode(pkg.PTR_DEVICE)
+dev = torch.device("cuda", 0)
+name = sys.argv[1] if len(sys.argv) > 1 else "shell-like"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+label, m, rp, ci, v = standins.load(name)
+A = pkg.Matrix(0, m, m, rp, ci, v); d = pkg.Descr()
+assert L.aoclsparse_set_mm_hint(A.h, pkg.OP_NONE, d.h, 100) == 0 and L.aoclsparse_optimize(A.h) == 0
+B = torch.from_numpy(np.random.default_rng(1).uniform(-1, 1, (m, n))).to(dev)
+C = torch.zeros((m, n), dtype=torch.float64, device=dev)
+call = lambda: L.aoclsparse_dcsrmm(pkg.OP_NONE, 1.0, A.h, d.h, pkg.ORDER_ROW, pkg._ptr(B), n, n, 0.0, pkg._ptr(C), n)
+for _ in range(3):
+    assert call() == 0
+torch.cuda.synchronize()
+pkg.timer_start()
+for _ in range(10):
+    call()
+print(json.dumps({"A": label, "n": n, "ms": round(pkg.timer_stop() / 10, 4)}))
