@@ -73,6 +73,56 @@ __global__ __launch_bounds__(256) void r0(int m, const double *__restrict__ val,
 }
 
 
+
+// ---------------------------------------------------------------- R0B: R0 with ONE batch for rows of <= 8 entries
+// column indices and values of up to 8 entries loaded together (indices clamped to the row), the B rows that exist requested
+// together, FMAs behind wave-uniform tests: kernarg -> row_ptr -> {col, val} -> B -> store, no separate tail chain
+template <bool NT>
+__global__ __launch_bounds__(256) void r0b(int m, const double *__restrict__ val, const int *__restrict__ col,
+                                           const int *__restrict__ row_ptr, const double *__restrict__ B, int n, int ldb,
+                                           double *__restrict__ C, int ldc, int chunk)
+{
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i = xcd_row(blockIdx.x, chunk) * 4 + w;
+    const int j = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
+    if(i >= m || j >= n)
+        return;
+    const int     s = row_ptr[i], e = row_ptr[i + 1];
+    double        a0 = 0, a1 = 0;
+    const double *Bj = B + j;
+    for(int p = s; p < e; p += 8)
+    {
+        const int len = e - p; // >= 1
+        int       c[8];
+        double    v[8];
+        v2d       b[8];
+#pragma unroll
+        for(int u = 0; u < 8; u++)
+        {
+            const int q = p + (u < len ? u : len - 1);
+            c[u]        = col[q];
+            v[u]        = val[q];
+        }
+#pragma unroll
+        for(int u = 0; u < 8; u++)
+            if(u < len)
+                b[u] = *reinterpret_cast<const v2d *>(Bj + (size_t)c[u] * ldb);
+#pragma unroll
+        for(int u = 0; u < 8; u++)
+            asm volatile("" : "+s"(v[u]));
+#pragma unroll
+        for(int u = 0; u < 8; u++)
+            if(u < len)
+                a0 = fma(v[u], b[u].x, a0), a1 = fma(v[u], b[u].y, a1);
+    }
+    v2d cc;
+    cc.x = a0, cc.y = a1;
+    if(NT)
+        __builtin_nontemporal_store(cc, reinterpret_cast<v2d *>(C + (size_t)i * ldc + j));
+    else
+        *reinterpret_cast<v2d *>(C + (size_t)i * ldc + j) = cc;
+}
+
 // ---------------------------------------------------------------- RW: row block with the union of its B rows in LDS
 // Experiment (banded A only: the union of a block's columns is computed from `band`): a workgroup takes R consecutive
 // rows x CW columns, stages the 3R+2 distinct B rows the block touches ({i0-band..}, {i0-1..i0+R}, {i0+band..}) in LDS
@@ -975,6 +1025,16 @@ int main(int argc, char **argv)
     CHECK(hipMalloc(&d_eval, evalv.size() * 8));
     CHECK(hipMemcpy(d_ecol, ecol.data(), ecol.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(d_eval, evalv.data(), evalv.size() * 8, hipMemcpyHostToDevice));
+    vars.push_back({"R0B one batch per <= 8 entries", false, [&] {
+                        if(n < 128) return;
+                        int ch; int gx = rowgrid(4, ch);
+                        r0b<false><<<dim3(gx, (n + 127) / 128), 256>>>(im, d_v, d_ci, d_rp, d_B, n, n, d_C, n, ch);
+                    }});
+    vars.push_back({"R0B one batch per <= 8 entries nt", false, [&] {
+                        if(n < 128) return;
+                        int ch; int gx = rowgrid(4, ch);
+                        r0b<true><<<dim3(gx, (n + 127) / 128), 256>>>(im, d_v, d_ci, d_rp, d_B, n, n, d_C, n, ch);
+                    }});
 #define RWVAR(R, CW, label)                                                                                         \
     vars.push_back({label, false, [&] {                                                                              \
                         if(n % 128 || band <= R + 2) return;                                                         \
