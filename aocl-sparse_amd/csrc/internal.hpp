@@ -228,6 +228,11 @@ struct SellPlan
     DeviceBuffer   slice_ptr; // nslices+1 cell offsets (long long)
     DeviceBuffer   val, col; // cells values / 0-based columns (-1 = padding)
     DeviceBuffer   rowlen; // m row lengths (read by the 4- and 8-lane orders only)
+    // shared column lists (sell_kernels.hip): col holds one list per leader lane of a slice, ccells entries in all;
+    // cptr = nslices+1 offsets into it, lead = m bytes (leader index of a row inside its slice)
+    bool           shared = false;
+    long long      ccells = 0;
+    DeviceBuffer   cptr, lead;
     bool           valid = false, tried = false;
     bool           wanted = false; // optimize chose SELL: rebuilt lazily after the values change
 };
@@ -574,11 +579,15 @@ aoclsparse_status launch_plan_check(hipStream_t s, const aoclsparse_int *blocks,
 template <typename T>
 aoclsparse_status launch_sell_fill(hipStream_t s, int pack, aoclsparse_int m, int base, const aoclsparse_int *row_ptr,
                                    const aoclsparse_int *col, const T *val, aoclsparse_int nslices,
-                                   const long long *slice_ptr, T *sval, aoclsparse_int *scol, aoclsparse_int *rowlen);
+                                   const long long *slice_ptr, T *sval, aoclsparse_int *scol, aoclsparse_int *rowlen,
+                                   const long long *cptr = nullptr, const unsigned char *lead = nullptr);
+aoclsparse_status launch_sell_leaders(hipStream_t s, aoclsparse_int m, const aoclsparse_int *row_ptr, const aoclsparse_int *col,
+                                      aoclsparse_int nslices, unsigned char *lead, aoclsparse_int *nl);
 template <typename T>
 aoclsparse_status launch_sellmv(hipStream_t s, int order, int pack, T alpha, aoclsparse_int m, aoclsparse_int nslices,
                                 const long long *slice_ptr, const T *sval, const aoclsparse_int *scol,
-                                const aoclsparse_int *rowlen, const T *x, T beta, T *y);
+                                const aoclsparse_int *rowlen, const T *x, T beta, T *y, const long long *cptr = nullptr,
+                                const unsigned char *lead = nullptr);
 // BLKCSR (blk_kernels.hip): value offset of every block (three small launches: per-chunk popcount scan, scan of
 // the chunk totals in part[], add), then the product
 constexpr int     BLK_PART_SHIFT = 10;

@@ -606,25 +606,64 @@ aoclsparse_status build_sell(const aoclsparse_int *row_ptr_host, const DeviceCsr
         return aoclsparse_status_success;
     Runtime          &rt = Runtime::get();
     aoclsparse_status st = sp.slice_ptr.upload(sptr.data(), sizeof(long long) * sptr.size(), rt.stream());
+    // Shared column lists: rows that repeat the list of the row before them (the dofs of a mesh node) keep ONE copy per
+    // slice.  Leaders are found on the device (one compare pass over the CSR arrays); used when the column stream shrinks
+    // to <= 70 % and rows are long enough for the software-pipelined kernel.  AOCLSPARSE_MI355_SELL_SHARED=0 disables.
+    static const bool shared_off = [] {
+        const char *e = getenv("AOCLSPARSE_MI355_SELL_SHARED");
+        return e && atoi(e) == 0;
+    }();
+    sp.shared = false, sp.ccells = cells;
+    std::vector<long long> cptr;
+    if(st == aoclsparse_status_success && !shared_off && (long long)d.nnz >= 8LL * m)
+    {
+        DeviceBuffer nl;
+        st = sp.lead.alloc((size_t)m);
+        if(st == aoclsparse_status_success)
+            st = nl.alloc(sizeof(aoclsparse_int) * (size_t)nslices);
+        if(st == aoclsparse_status_success)
+            st = launch_sell_leaders(rt.stream(), m, d.ptr.as<aoclsparse_int>(), d.ind.as<aoclsparse_int>(), nslices,
+                                     sp.lead.as<unsigned char>(), nl.as<aoclsparse_int>());
+        if(st != aoclsparse_status_success)
+            return st;
+        std::vector<aoclsparse_int> nlh((size_t)nslices);
+        MI355_HIP_TRY(hipMemcpyAsync(nlh.data(), nl.ptr, sizeof(aoclsparse_int) * (size_t)nslices, hipMemcpyDeviceToHost, rt.stream()));
+        MI355_HIP_TRY(hipStreamSynchronize(rt.stream()));
+        cptr.resize((size_t)nslices + 1);
+        cptr[0] = 0;
+        for(aoclsparse_int s = 0; s < nslices; s++)
+            cptr[s + 1] = cptr[s] + (long long)nlh[s] * ((sptr[s + 1] - sptr[s]) >> 6);
+        if(PhaseTimer::on())
+            std::fprintf(stderr, "[mi355 timing] sell: %lld cells, %lld column cells with shared lists (%d slices)\n", cells, cptr[nslices], (int)nslices);
+        if((double)cptr[nslices] <= 0.7 * (double)cells)
+        {
+            sp.shared = true, sp.ccells = cptr[nslices];
+            st        = sp.cptr.upload(cptr.data(), sizeof(long long) * cptr.size(), rt.stream());
+        }
+        else
+            sp.lead.release();
+    }
     if(st == aoclsparse_status_success)
         st = sp.val.alloc(vsize * (size_t)std::max<long long>(cells, 1));
     if(st == aoclsparse_status_success)
-        st = sp.col.alloc(sizeof(aoclsparse_int) * (size_t)std::max<long long>(cells, 1));
+        st = sp.col.alloc(sizeof(aoclsparse_int) * (size_t)std::max<long long>(sp.ccells, 1));
     if(st == aoclsparse_status_success)
         st = sp.rowlen.alloc(sizeof(aoclsparse_int) * (size_t)m);
     if(st != aoclsparse_status_success)
         return st;
+    const long long     *cp = sp.shared ? sp.cptr.as<long long>() : nullptr;
+    const unsigned char *ld = sp.shared ? sp.lead.as<unsigned char>() : nullptr;
     if(vsize == sizeof(float))
         st = launch_sell_fill<float>(rt.stream(), pack, m, d.base, d.ptr.as<aoclsparse_int>(), d.ind.as<aoclsparse_int>(),
                                      d.val.as<float>(), nslices, sp.slice_ptr.as<long long>(), sp.val.as<float>(),
-                                     sp.col.as<aoclsparse_int>(), sp.rowlen.as<aoclsparse_int>());
+                                     sp.col.as<aoclsparse_int>(), sp.rowlen.as<aoclsparse_int>(), cp, ld);
     else
         st = launch_sell_fill<double>(rt.stream(), pack, m, d.base, d.ptr.as<aoclsparse_int>(), d.ind.as<aoclsparse_int>(),
                                       d.val.as<double>(), nslices, sp.slice_ptr.as<long long>(), sp.val.as<double>(),
-                                      sp.col.as<aoclsparse_int>(), sp.rowlen.as<aoclsparse_int>());
+                                      sp.col.as<aoclsparse_int>(), sp.rowlen.as<aoclsparse_int>(), cp, ld);
     if(st != aoclsparse_status_success)
         return st;
-    MI355_HIP_TRY(hipStreamSynchronize(rt.stream())); // sptr (host) is read by the upload until here
+    MI355_HIP_TRY(hipStreamSynchronize(rt.stream())); // sptr / cptr (host) are read by the uploads until here
     sp.nslices = nslices, sp.cells = cells, sp.pack = pack, sp.valid = sp.wanted = true;
     return aoclsparse_status_success;
 }

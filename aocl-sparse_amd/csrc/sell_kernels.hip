@@ -105,6 +105,79 @@ __global__ __launch_bounds__(256) void sell_fill_kernel(aoclsparse_int m, int ba
     }
 }
 
+// ---- shared column lists (SELL-64 with one column list per run of rows that have the same one) -----------------------
+// In a matrix with several dofs per mesh node the rows of a node carry the SAME column list.  A slice then stores its
+// columns once per "leader" (the first lane of the slice, and every lane whose list differs from the lane before): cell
+// (p, leader k) of slice s at cptr[s] + nl_s p + k (PACK 4: cptr[s] + 4 nl_s (p / 4) + 4 k + p % 4), and lead[i] = the
+// leader index of row i inside its slice.  Values stay where they are.  The column stream shrinks from 4 B per cell to
+// 4 B / (rows per list): 12 -> 8.8 B per cell for 5-dof nodes; the lanes of a group read one address.
+// One wavefront per slice: leader flags by comparing each row with its predecessor, indices by ballot + popcount.
+__global__ __launch_bounds__(256) void sell_leaders_kernel(aoclsparse_int m, const aoclsparse_int *__restrict__ row_ptr,
+                                                           const aoclsparse_int *__restrict__ col, aoclsparse_int nslices,
+                                                           unsigned char *__restrict__ lead, aoclsparse_int *__restrict__ nl)
+{
+    const int s    = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if(s >= nslices)
+        return;
+    const int i      = s * 64 + lane;
+    bool      leader = false;
+    if(i < m)
+    {
+        leader = lane == 0;
+        if(!leader)
+        {
+            const int b = row_ptr[i], len = row_ptr[i + 1] - b, bp = row_ptr[i - 1];
+            leader = len != b - bp; // the base cancels: only differences are used
+            for(int k = 0; k < len && !leader; k++)
+                leader = col[b + k] != col[bp + k];
+        }
+    }
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(leader);
+    if(i < m)
+        lead[i] = (unsigned char)(__builtin_popcountll(bal & ((2ull << lane) - 1ull)) - 1);
+    if(lane == 0)
+        nl[s] = (aoclsparse_int)__builtin_popcountll(bal);
+}
+
+template <typename T, int PACK>
+__global__ __launch_bounds__(256) void sell_fill_shared_kernel(aoclsparse_int m, int base,
+                                                               const aoclsparse_int *__restrict__ row_ptr,
+                                                               const aoclsparse_int *__restrict__ col,
+                                                               const T *__restrict__ val, aoclsparse_int nslices,
+                                                               const long long *__restrict__ slice_ptr,
+                                                               const long long *__restrict__ cptr,
+                                                               const unsigned char *__restrict__ lead, T *__restrict__ sval,
+                                                               aoclsparse_int *__restrict__ scol,
+                                                               aoclsparse_int *__restrict__ rowlen)
+{
+    const int s    = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if(s >= nslices)
+        return;
+    const int       i  = s * 64 + lane;
+    const long long o0 = slice_ptr[s], c0 = cptr[s];
+    const int       w  = (int)((slice_ptr[s + 1] - o0) >> 6);
+    const int       nl = w > 0 ? (int)((cptr[s + 1] - c0) / w) : 0;
+    int             b = 0, len = 0, k = 0;
+    bool            leader = false;
+    if(i < m)
+    {
+        b   = row_ptr[i] - base;
+        len = row_ptr[i + 1] - base - b;
+        rowlen[i] = len;
+        k         = lead[i];
+        leader    = lane == 0 || lead[i - 1] != k;
+    }
+    for(int p = 0; p < w; p++)
+    {
+        const bool in = p < len;
+        sval[o0 + cell_of<PACK>(p, lane)] = in ? val[b + p] : T(0);
+        if(leader)
+            scol[c0 + (PACK == 1 ? (long long)p * nl + k : (long long)(p >> 2) * 4 * nl + 4 * k + (p & 3))] = in ? col[b + p] - base : -1;
+    }
+}
+
 // four adjacent cells of one lane as vector loads (PACK 4): 32 B of values (16 B for float), 16 B of columns
 __device__ __forceinline__ void load4(const double *p, double (&o)[4])
 {
@@ -123,8 +196,10 @@ __device__ __forceinline__ void load4(const aoclsparse_int *p, int (&o)[4])
 }
 
 // loads the G cells p0 .. p0+G-1 of this lane (wave-uniform guards against the slice width w)
+// cs = lanes per column row: 64, or the slice's number of leaders when the column lists are shared
 template <typename T, int PACK, int G>
-__device__ __forceinline__ void load_step(const T *v, const aoclsparse_int *c, int p0, int w, T (&vv)[G], int (&cc)[G])
+__device__ __forceinline__ void load_step(const T *v, const aoclsparse_int *c, int p0, int w, T (&vv)[G], int (&cc)[G],
+                                          int cs = 64)
 {
     if constexpr(PACK == 1)
     {
@@ -133,7 +208,7 @@ __device__ __forceinline__ void load_step(const T *v, const aoclsparse_int *c, i
         {
             const bool ok = p0 + q < w;
             vv[q]         = ok ? v[(p0 + q) * 64] : T(0);
-            cc[q]         = ok ? c[(p0 + q) * 64] : -1;
+            cc[q]         = ok ? c[(p0 + q) * cs] : -1;
         }
     }
     else
@@ -147,7 +222,7 @@ __device__ __forceinline__ void load_step(const T *v, const aoclsparse_int *c, i
             {
                 const long long o = (long long)((p0 >> 2) + k) * 256;
                 load4(v + o, tv);
-                load4(c + o, tc);
+                load4(c + (long long)((p0 >> 2) + k) * (4 * cs), tc);
             }
 #pragma unroll
             for(int q = 0; q < 4; q++)
@@ -157,14 +232,15 @@ __device__ __forceinline__ void load_step(const T *v, const aoclsparse_int *c, i
 }
 
 // WAVES slices per workgroup (1 for small matrices so that every slice gets its own CU)
-template <typename T, int ORDER, int WAVES, int PACK>
+template <typename T, int ORDER, int WAVES, int PACK, bool SHARED = false>
 __global__ __launch_bounds__(64 * WAVES) void sell_mv_kernel(aoclsparse_int m, aoclsparse_int nslices,
                                                              const long long *__restrict__ slice_ptr,
                                                              const T *__restrict__ sval,
                                                              const aoclsparse_int *__restrict__ scol,
                                                              const aoclsparse_int *__restrict__ rowlen, T alpha,
                                                              const T *__restrict__ x, T beta, T *__restrict__ y,
-                                                             bool nt)
+                                                             bool nt, const long long *__restrict__ cptr = nullptr,
+                                                             const unsigned char *__restrict__ lead = nullptr)
 {
     const int s    = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + (threadIdx.x >> 6)));
     const int lane = threadIdx.x & 63;
@@ -173,10 +249,18 @@ __global__ __launch_bounds__(64 * WAVES) void sell_mv_kernel(aoclsparse_int m, a
     const long long       o0 = slice_ptr[s];
     const int             w  = (int)((slice_ptr[s + 1] - o0) >> 6);
     const T              *v  = sval + o0 + lane * PACK;
-    const aoclsparse_int *c  = scol + o0 + lane * PACK;
     const int             i  = s * 64 + lane;
-    T                     r  = T(0);
-    if constexpr(ORDER == 0 && PACK == 1)
+    const aoclsparse_int *c  = scol + o0 + lane * PACK;
+    int                   cs = 64;
+    if constexpr(SHARED)
+    {
+        // one column list per leader: cs leaders in this slice, this lane reads its leader's
+        const long long c0 = cptr[s];
+        cs                 = w > 0 ? (int)((cptr[s + 1] - c0) / w) : 1;
+        c                  = scol + c0 + (i < m ? lead[i] : 0) * PACK;
+    }
+    T r = T(0);
+    if constexpr(ORDER == 0 && PACK == 1 && !SHARED)
     {
         // short rows (this is the layout of matrices with < 16 non-zeros per row): four independent line loads
         // per step, then the gathers, then the chain.  Measured on the 4096^2 Laplacian (w = 5): 0.218 ms;
@@ -215,7 +299,7 @@ __global__ __launch_bounds__(64 * WAVES) void sell_mv_kernel(aoclsparse_int m, a
         bool reduced = false;
         T    vn[G];
         int  cn[G];
-        load_step<T, PACK, G>(v, c, 0, w, vn, cn);
+        load_step<T, PACK, G>(v, c, 0, w, vn, cn, cs);
         for(int p0 = 0; p0 < w; p0 += G)
         {
             T   vv[G], xx[G];
@@ -224,7 +308,7 @@ __global__ __launch_bounds__(64 * WAVES) void sell_mv_kernel(aoclsparse_int m, a
             for(int q = 0; q < G; q++)
                 vv[q] = vn[q], cc[q] = cn[q];
             if(p0 + G < w)
-                load_step<T, PACK, G>(v, c, p0 + G, w, vn, cn);
+                load_step<T, PACK, G>(v, c, p0 + G, w, vn, cn, cs);
 #pragma unroll
             for(int q = 0; q < G; q++)
                 xx[q] = x[max(cc[q], 0)];
@@ -259,17 +343,28 @@ __global__ __launch_bounds__(64 * WAVES) void sell_mv_kernel(aoclsparse_int m, a
 
 template <typename T, int ORDER, int PACK>
 void sell_launch(hipStream_t s, aoclsparse_int m, aoclsparse_int nslices, const long long *slice_ptr, const T *sval,
-                 const aoclsparse_int *scol, const aoclsparse_int *rowlen, T alpha, const T *x, T beta, T *y)
+                 const aoclsparse_int *scol, const aoclsparse_int *rowlen, T alpha, const T *x, T beta, T *y,
+                 const long long *cptr, const unsigned char *lead)
 {
     // one slice per workgroup while the launch is small (every slice its own CU), two otherwise
     // (swept on the headline workload: 1 / 2 / 4 / 8 slices per workgroup = 0.221 / 0.218 / 0.221 / 0.222 ms)
     const bool nt = (size_t)m * sizeof(T) > ((size_t)32 << 20);
-    if(nslices < 2048)
+    if(cptr)
+    {
+        if(nslices < 2048)
+            hipLaunchKernelGGL((sell_mv_kernel<T, ORDER, 1, PACK, true>), dim3(nslices), dim3(64), 0, s, m, nslices, slice_ptr,
+                               sval, scol, rowlen, alpha, x, beta, y, nt, cptr, lead);
+        else
+            hipLaunchKernelGGL((sell_mv_kernel<T, ORDER, 2, PACK, true>), dim3((nslices + 1) / 2), dim3(128), 0, s, m, nslices,
+                               slice_ptr, sval, scol, rowlen, alpha, x, beta, y, nt, cptr, lead);
+    }
+    else if(nslices < 2048)
         hipLaunchKernelGGL((sell_mv_kernel<T, ORDER, 1, PACK>), dim3(nslices), dim3(64), 0, s, m, nslices, slice_ptr,
-                           sval, scol, rowlen, alpha, x, beta, y, nt);
+                           sval, scol, rowlen, alpha, x, beta, y, nt, (const long long *)nullptr, (const unsigned char *)nullptr);
     else
         hipLaunchKernelGGL((sell_mv_kernel<T, ORDER, 2, PACK>), dim3((nslices + 1) / 2), dim3(128), 0, s, m, nslices,
-                           slice_ptr, sval, scol, rowlen, alpha, x, beta, y, nt);
+                           slice_ptr, sval, scol, rowlen, alpha, x, beta, y, nt, (const long long *)nullptr,
+                           (const unsigned char *)nullptr);
 }
 
 } // namespace
@@ -277,11 +372,21 @@ void sell_launch(hipStream_t s, aoclsparse_int m, aoclsparse_int nslices, const 
 template <typename T>
 aoclsparse_status launch_sell_fill(hipStream_t s, int pack, aoclsparse_int m, int base, const aoclsparse_int *row_ptr,
                                    const aoclsparse_int *col, const T *val, aoclsparse_int nslices,
-                                   const long long *slice_ptr, T *sval, aoclsparse_int *scol, aoclsparse_int *rowlen)
+                                   const long long *slice_ptr, T *sval, aoclsparse_int *scol, aoclsparse_int *rowlen,
+                                   const long long *cptr, const unsigned char *lead)
 {
     if(nslices <= 0)
         return aoclsparse_status_success;
-    if(pack == 4)
+    if(cptr)
+    {
+        if(pack == 4)
+            hipLaunchKernelGGL((sell_fill_shared_kernel<T, 4>), dim3((nslices + 3) / 4), dim3(256), 0, s, m, base, row_ptr,
+                               col, val, nslices, slice_ptr, cptr, lead, sval, scol, rowlen);
+        else
+            hipLaunchKernelGGL((sell_fill_shared_kernel<T, 1>), dim3((nslices + 3) / 4), dim3(256), 0, s, m, base, row_ptr,
+                               col, val, nslices, slice_ptr, cptr, lead, sval, scol, rowlen);
+    }
+    else if(pack == 4)
         hipLaunchKernelGGL((sell_fill_kernel<T, 4>), dim3((nslices + 3) / 4), dim3(256), 0, s, m, base, row_ptr, col,
                            val, nslices, slice_ptr, sval, scol, rowlen);
     else
@@ -294,14 +399,15 @@ aoclsparse_status launch_sell_fill(hipStream_t s, int pack, aoclsparse_int m, in
 template <typename T>
 aoclsparse_status launch_sellmv(hipStream_t s, int order, int pack, T alpha, aoclsparse_int m, aoclsparse_int nslices,
                                 const long long *slice_ptr, const T *sval, const aoclsparse_int *scol,
-                                const aoclsparse_int *rowlen, const T *x, T beta, T *y)
+                                const aoclsparse_int *rowlen, const T *x, T beta, T *y, const long long *cptr,
+                                const unsigned char *lead)
 {
     if(m <= 0 || nslices <= 0)
         return aoclsparse_status_success;
     if(order < 0 || order > 2 || (pack != 1 && pack != 4))
         return aoclsparse_status_invalid_kid;
 #define SELL_CASE(O, P)                                                                        \
-    sell_launch<T, O, P>(s, m, nslices, slice_ptr, sval, scol, rowlen, alpha, x, beta, y);   \
+    sell_launch<T, O, P>(s, m, nslices, slice_ptr, sval, scol, rowlen, alpha, x, beta, y, cptr, lead); \
     break
     switch(order * 2 + (pack == 4 ? 1 : 0))
     {
@@ -323,13 +429,25 @@ aoclsparse_status launch_sellmv(hipStream_t s, int order, int pack, T alpha, aoc
     return aoclsparse_status_success;
 }
 
+aoclsparse_status launch_sell_leaders(hipStream_t s, aoclsparse_int m, const aoclsparse_int *row_ptr, const aoclsparse_int *col,
+                                      aoclsparse_int nslices, unsigned char *lead, aoclsparse_int *nl)
+{
+    if(nslices <= 0)
+        return aoclsparse_status_success;
+    hipLaunchKernelGGL(sell_leaders_kernel, dim3((nslices + 3) / 4), dim3(256), 0, s, m, row_ptr, col, nslices, lead, nl);
+    MI355_HIP_TRY(hipGetLastError());
+    return aoclsparse_status_success;
+}
+
 #define MI355_SELL_INSTANTIATE(T)                                                                                     \
     template aoclsparse_status launch_sell_fill<T>(hipStream_t, int, aoclsparse_int, int, const aoclsparse_int *,     \
                                                    const aoclsparse_int *, const T *, aoclsparse_int,                 \
-                                                   const long long *, T *, aoclsparse_int *, aoclsparse_int *);       \
+                                                   const long long *, T *, aoclsparse_int *, aoclsparse_int *,        \
+                                                   const long long *, const unsigned char *);                          \
     template aoclsparse_status launch_sellmv<T>(hipStream_t, int, int, T, aoclsparse_int, aoclsparse_int,             \
                                                 const long long *, const T *, const aoclsparse_int *,                 \
-                                                const aoclsparse_int *, const T *, T, T *);
+                                                const aoclsparse_int *, const T *, T, T *, const long long *,          \
+                                                const unsigned char *);
 MI355_SELL_INSTANTIATE(double)
 MI355_SELL_INSTANTIATE(float)
 

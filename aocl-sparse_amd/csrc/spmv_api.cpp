@@ -125,7 +125,8 @@ aoclsparse_status run_on_device_csr(Runtime &rt, aoclsparse_int kid, const Devic
         st = launch_sellmv<T>(rt.stream(), order, plan.sell.pack, alpha, d.m, plan.sell.nslices, plan.sell.slice_ptr.as<long long>(),
                               plan.sell.val.as<T>(), plan.sell.col.as<aoclsparse_int>(),
                               plan.sell.rowlen.as<aoclsparse_int>(), static_cast<const T *>(ax.dev), beta,
-                              static_cast<T *>(ay.dev));
+                              static_cast<T *>(ay.dev), plan.sell.shared ? plan.sell.cptr.as<long long>() : nullptr,
+                              plan.sell.shared ? plan.sell.lead.as<unsigned char>() : nullptr);
     else if(plan.merge.valid && order == 0 && !strict) // balanced tiles for irregular rows (scalar order, no pinned kid)
         st = launch_mergepath<T>(rt.stream(), d.base, alpha, plan.merge.ntiles, plan.merge.starts.as<aoclsparse_int>(),
                                  d.val.as<T>(), d.ind.as<aoclsparse_int>(), d.ptr.as<aoclsparse_int>(),
@@ -612,7 +613,7 @@ aoclsparse_status aoclsparse_mi355_get_spmv_info(const aoclsparse_matrix A, aocl
     info->device_resident = d.valid;
     if(!p.valid)
         return aoclsparse_status_success;
-    info->kernel      = p.sell.valid ? 3 : (p.merge.valid ? 2 : 1);
+    info->kernel      = p.sell.valid ? (p.sell.shared ? 4 : 3) : (p.merge.valid ? 2 : 1);
     info->row_blocks  = p.sell.valid ? (p.sell.nslices < 2048 ? p.sell.nslices : (p.sell.nslices + 1) / 2) : p.nblocks;
     info->tile        = p.tile & ~1;
     info->sell_slices  = p.sell.valid ? p.sell.nslices : 0;

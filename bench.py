@@ -298,7 +298,7 @@ def main():
             "kernel": ("SELL-64 built by aoclsparse_optimize for the mv hint (%d slices, %d cells = %.3f x nnz), "
                        "order %d (reference ref_csrmv_gn order)"
                        % (info.sell_slices, info.stored_cells, info.stored_cells / max(nnz, 1), info.order))
-                      if info.kernel == 3 else
+                      if info.kernel in (3, 4) else
                       ("csr-adaptive stream, order %d (reference ref_csrmv_gn order), %d row blocks"
                        % (info.order, info.row_blocks)),
             "parallelism": "replicas x%d" % world,
@@ -306,7 +306,7 @@ def main():
             "backend": args.backend if use_dist else "none",
         },
         "roofline": roofline(abytes, kernel_ms, traffic, traffic_source=traffic_src,
-                             stored_format_bytes_per_launch=(info.stored_cells * 12 + 16 * m) if info.kernel == 3 else abytes,
+                             stored_format_bytes_per_launch=(info.stored_cells * 12 + 16 * m) if info.kernel in (3, 4) else abytes,
                              achieved_at_median=round(abytes / (stats["median"] * 1e-3) / 1e9, 2)),
         "stats": dict(stats, unit="ms per step (device, hipEvent between consecutive launches)"),
     }
@@ -441,7 +441,7 @@ def main():
             so, yr = oracle.dcsrmv(-1, 0, 1.0, mm_, nz, v, ci, rp, xr, 0.0, np.zeros(mm_), nthreads=oracle.max_threads())
             got = ydv.cpu().numpy()
             lens = np.diff(rp)
-            within = lens <= max(inf.tile, 1) if inf.kernel != 3 else np.ones(mm_, bool)
+            within = lens <= max(inf.tile, 1) if inf.kernel not in (3, 4) else np.ones(mm_, bool)
             scale = np.zeros(mm_)
             nzr = lens > 0
             scale[nzr] = np.add.reduceat(np.abs(v * xr[ci]), rp[:-1][nzr])
@@ -453,7 +453,7 @@ def main():
                                                max(1, min(cpu_physical, oracle.max_threads())), 5)
             unpin()
             rows.append({"matrix": label, "m": mm_, "nnz": nz, "max_row": int(lens.max()),
-                         "kernel": {1: "csr-adaptive", 2: "merge-path", 3: "sell-64"}.get(inf.kernel, str(inf.kernel)),
+                         "kernel": {1: "csr-adaptive", 2: "merge-path", 3: "sell-64", 4: "sell-64, shared column lists"}.get(inf.kernel, str(inf.kernel)),
                          "summation_order": {0: "scalar (ref_csrmv_gn)", 1: "4-lane AVX2", 2: "8-lane AVX-512"}.get(inf.order),
                          "us": round(ms * 1e3, 3), "us_timing": "200 calls back to back between two events",
                          "us_per_call_with_an_event_each": round(ms_lap * 1e3, 3), "stats_ms": quartiles(lp),

@@ -71,7 +71,7 @@ DLL_PUBLIC aoclsparse_status aoclsparse_mi355_export_diag(const aoclsparse_matri
                                                           aoclsparse_int         *is_internal);
 typedef struct aoclsparse_mi355_spmv_info_
 {
-    aoclsparse_int kernel; /* 0 none yet, 1 csr-adaptive stream, 2 merge-path (scalar order, no pinned kid; else 1), 3 SELL-64 (mv hint + optimize) */
+    aoclsparse_int kernel; /* 0 none yet, 1 csr-adaptive stream, 2 merge-path (scalar order, no pinned kid; else 1), 3 SELL-64 (mv hint + optimize), 4 SELL-64 with one column list per run of rows that share it */
     aoclsparse_int order; /* 0 scalar chain (kid 0), 1 4-lane (kid 1/2), 2 8-lane (kid 3) */
     aoclsparse_int row_blocks; /* workgroups per launch */
     aoclsparse_int tile; /* non-zeros staged in LDS per workgroup */
@@ -79,7 +79,7 @@ typedef struct aoclsparse_mi355_spmv_info_
     aoclsparse_int max_row_nnz;
     aoclsparse_int device_resident; /* 1 once the CSR arrays are in HBM */
     aoclsparse_int sell_slices; /* SELL-64: 64-row slices (0 otherwise) */
-    long long      stored_cells; /* SELL-64: value/column cells stored, padding included */
+    long long      stored_cells; /* SELL-64: value cells stored, padding included (kernel 4 stores fewer column cells) */
     aoclsparse_int mm_groups; /* row-major csrmm: row groups (runs of rows with one column pattern) in use, else 0 */
     aoclsparse_int mm_super_blocks; /* row-major csrmm, n >= 128: super-groups (row groups merged over the union of their columns) in use, else 0 */
 } aoclsparse_mi355_spmv_info;

@@ -1339,6 +1339,70 @@ def test_sell_chosen_for_uniform_rows_and_bit_exact_scalar_order():
     assert np.array_equal(np.isnan(y), np.isnan(yr)) and np.array_equal(y[~np.isnan(yr)], yr[~np.isnan(yr)])
 
 
+def _mesh(seed, nodes, width, dofs):
+    from test_gpu_trsv_blocks import node_mesh
+    return node_mesh(seed, nodes, width, dofs, keep=1.0)  # every coupling kept: row lengths uniform enough for SELL
+
+
+@pytest.mark.parametrize("kid,order", [(None, None), (1, "lane4"), (3, "lane8"), (0, "ref")])
+@pytest.mark.parametrize("which", ["five", "four", "mixed"])
+def test_sell_shared_column_lists_bit_exact(which, kid, order):
+    """mesh matrices (several dofs per node: the rows of a node repeat one column list) are stored as SELL-64 with ONE
+    column list per run of rows that share it (kernel 4): groups that straddle a slice boundary, nodes of 2 / 5 / 7 dofs,
+    a partial last slice, every summation order, base 1, alpha / beta, NaN / Inf in x, the transposed operator"""
+    nodes = 2311
+    rng = np.random.default_rng(70)
+    dofs = {"five": np.full(nodes, 5), "four": np.full(nodes, 4),
+            "mixed": np.repeat([2, 5, 7], [770, 770, 771])}[which]  # three regions: lists of 2, 5 and 7 rows
+    m, rp, ci, v = _mesh(71, nodes, 43, dofs)
+    assert len(v) >= 8 * m
+    x, y0 = rng.uniform(-1, 1, m), rng.uniform(-1, 1, m)
+    for base in (0, 1):
+        A, d = _hinted(base, m, m, rp + base, ci + base, v, kid=kid)
+        assert A.spmv_info().kernel == 4, (which, A.spmv_info().kernel)
+        for alpha, beta in ((1.0, 0.0), (-1.3, 0.7)):
+            st, y = run_dmv(A, d, x, y0, alpha, beta)
+            if order is None:
+                so, yr = oracle.dcsrmv(-1, 0, alpha, m, len(v), v, ci, rp, x, beta, y0)
+            else:
+                so, yr = oracle.dcsrmv_order(order, 0, alpha, m, v, ci, rp, x, beta, y0)
+            assert st == 0 and so == 0 and np.array_equal(y, yr), (which, base, kid, alpha)
+    xb = x.copy()
+    xb[11], xb[m // 2] = np.nan, -np.inf
+    st, y = run_dmv(A, d, xb, np.zeros(m), 1.0, 0.0)
+    if order is None:
+        so, yr = oracle.dcsrmv(-1, 0, 1.0, m, len(v), v, ci, rp, xb, 0.0, np.zeros(m))
+    else:
+        so, yr = oracle.dcsrmv_order(order, 0, 1.0, m, v, ci, rp, xb, 0.0, np.zeros(m))
+    assert np.array_equal(np.isnan(y), np.isnan(yr)) and np.array_equal(y[~np.isnan(yr)], yr[~np.isnan(yr)])
+
+
+def test_sell_shared_lists_float_and_transposed():
+    nodes = 1500
+    m, rp, ci, v = _mesh(72, nodes, 31, np.full(nodes, 4))
+    vf = v.astype(np.float32)
+    Af = P.Matrix(0, m, m, rp, ci, vf)
+    d = P.Descr()
+    assert L.aoclsparse_set_mv_hint(Af.h, P.OP_NONE, d.h, 100) == 0 and L.aoclsparse_optimize(Af.h) == 0
+    assert Af.spmv_info().kernel == 4
+    rng = np.random.default_rng(73)
+    xf = rng.uniform(-1, 1, m).astype(np.float32)
+    yf = torch.zeros(m, dtype=torch.float32, device="cuda")
+    assert P.smv(P.OP_NONE, 1.0, Af, d, dev(xf), 0.0, yf) == 0
+    torch.cuda.synchronize()
+    # float: the reference runs its 8-lane kernel when nnz > 10 m, the scalar chain otherwise (csrmv.hpp:326-343)
+    so, yr = oracle.scsrmv("lane8" if len(v) > 10 * m else "ref", 0, 1.0, m, vf, ci, rp, xf, 0.0, np.zeros(m, np.float32))
+    assert so == 0 and np.array_equal(yf.cpu().numpy(), yr)
+    # the transposed operator gets its own SELL copy (the mesh pattern is symmetric, so its lists are shared as well)
+    B, d2 = _hinted(0, m, m, rp, ci, v, op=P.OP_TRANSPOSE)
+    x, y0 = rng.uniform(-1, 1, m), rng.uniform(-1, 1, m)
+    st, y = run_dmv(B, d2, x, y0, 0.9, -0.4, op=P.OP_TRANSPOSE)
+    so, cp, ri, cv = oracle.dcsr2csc(m, m, len(v), 0, 0, rp, ci, v)
+    so, yr = oracle.dcsrmv(-1, 0, 0.9, m, len(v), cv, ri, cp, x, -0.4, y0)
+    assert st == 0 and so == 0 and B.spmv_info(P.OP_TRANSPOSE).kernel in (3, 4)
+    assert np.max(np.abs(y - yr)) <= 64 * EPS64 * np.max(np.abs(yr))
+
+
 @pytest.mark.parametrize("kid,order", [(None, "lane8"), (1, "lane4"), (3, "lane8"), (0, "ref")])
 @pytest.mark.parametrize("base", [0, 1])
 def test_sell_lane_orders_bit_exact(kid, order, base):
