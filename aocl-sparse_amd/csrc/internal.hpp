@@ -229,7 +229,7 @@ struct SellPlan
     DeviceBuffer   val, col; // cells values / 0-based columns (-1 = padding)
     DeviceBuffer   rowlen; // m row lengths (read by the 4- and 8-lane orders only)
     // shared column lists (sell_kernels.hip): col holds one list per leader lane of a slice, ccells entries in all;
-    // cptr = nslices+1 offsets into it, lead = m bytes (leader index of a row inside its slice)
+    // cptr = nslices+1 offsets into it, lead = m x 16 bits (leader index of a row inside its slice | column shift << 8)
     bool           shared = false;
     long long      ccells = 0;
     DeviceBuffer   cptr, lead;
@@ -580,14 +580,14 @@ template <typename T>
 aoclsparse_status launch_sell_fill(hipStream_t s, int pack, aoclsparse_int m, int base, const aoclsparse_int *row_ptr,
                                    const aoclsparse_int *col, const T *val, aoclsparse_int nslices,
                                    const long long *slice_ptr, T *sval, aoclsparse_int *scol, aoclsparse_int *rowlen,
-                                   const long long *cptr = nullptr, const unsigned char *lead = nullptr);
+                                   const long long *cptr = nullptr, const unsigned short *lead = nullptr);
 aoclsparse_status launch_sell_leaders(hipStream_t s, aoclsparse_int m, const aoclsparse_int *row_ptr, const aoclsparse_int *col,
-                                      aoclsparse_int nslices, unsigned char *lead, aoclsparse_int *nl);
+                                      aoclsparse_int nslices, unsigned short *lead, aoclsparse_int *nl);
 template <typename T>
 aoclsparse_status launch_sellmv(hipStream_t s, int order, int pack, T alpha, aoclsparse_int m, aoclsparse_int nslices,
                                 const long long *slice_ptr, const T *sval, const aoclsparse_int *scol,
                                 const aoclsparse_int *rowlen, const T *x, T beta, T *y, const long long *cptr = nullptr,
-                                const unsigned char *lead = nullptr);
+                                const unsigned short *lead = nullptr);
 // BLKCSR (blk_kernels.hip): value offset of every block (three small launches: per-chunk popcount scan, scan of
 // the chunk totals in part[], add), then the product
 constexpr int     BLK_PART_SHIFT = 10;

@@ -606,24 +606,24 @@ aoclsparse_status build_sell(const aoclsparse_int *row_ptr_host, const DeviceCsr
         return aoclsparse_status_success;
     Runtime          &rt = Runtime::get();
     aoclsparse_status st = sp.slice_ptr.upload(sptr.data(), sizeof(long long) * sptr.size(), rt.stream());
-    // Shared column lists: rows that repeat the list of the row before them (the dofs of a mesh node) keep ONE copy per
-    // slice.  Leaders are found on the device (one compare pass over the CSR arrays); used when the column stream shrinks
-    // to <= 70 % and rows are long enough for the software-pipelined kernel.  AOCLSPARSE_MI355_SELL_SHARED=0 disables.
+    // Shared column lists: rows that repeat the list of the row before them -- as it is (the dofs of a mesh node) or
+    // shifted by one (the rows of a stencil) -- keep ONE copy per slice.  Leaders are found on the device (one compare
+    // pass over the CSR arrays); used when the column stream shrinks to <= 70 %.  AOCLSPARSE_MI355_SELL_SHARED=0 disables.
     static const bool shared_off = [] {
         const char *e = getenv("AOCLSPARSE_MI355_SELL_SHARED");
         return e && atoi(e) == 0;
     }();
     sp.shared = false, sp.ccells = cells;
     std::vector<long long> cptr;
-    if(st == aoclsparse_status_success && !shared_off && (long long)d.nnz >= 8LL * m)
+    if(st == aoclsparse_status_success && !shared_off)
     {
         DeviceBuffer nl;
-        st = sp.lead.alloc((size_t)m);
+        st = sp.lead.alloc(sizeof(unsigned short) * (size_t)m);
         if(st == aoclsparse_status_success)
             st = nl.alloc(sizeof(aoclsparse_int) * (size_t)nslices);
         if(st == aoclsparse_status_success)
             st = launch_sell_leaders(rt.stream(), m, d.ptr.as<aoclsparse_int>(), d.ind.as<aoclsparse_int>(), nslices,
-                                     sp.lead.as<unsigned char>(), nl.as<aoclsparse_int>());
+                                     sp.lead.as<unsigned short>(), nl.as<aoclsparse_int>());
         if(st != aoclsparse_status_success)
             return st;
         std::vector<aoclsparse_int> nlh((size_t)nslices);
@@ -652,7 +652,7 @@ aoclsparse_status build_sell(const aoclsparse_int *row_ptr_host, const DeviceCsr
     if(st != aoclsparse_status_success)
         return st;
     const long long     *cp = sp.shared ? sp.cptr.as<long long>() : nullptr;
-    const unsigned char *ld = sp.shared ? sp.lead.as<unsigned char>() : nullptr;
+    const unsigned short *ld = sp.shared ? sp.lead.as<unsigned short>() : nullptr;
     if(vsize == sizeof(float))
         st = launch_sell_fill<float>(rt.stream(), pack, m, d.base, d.ptr.as<aoclsparse_int>(), d.ind.as<aoclsparse_int>(),
                                      d.val.as<float>(), nslices, sp.slice_ptr.as<long long>(), sp.val.as<float>(),

@@ -105,37 +105,53 @@ __global__ __launch_bounds__(256) void sell_fill_kernel(aoclsparse_int m, int ba
     }
 }
 
-// ---- shared column lists (SELL-64 with one column list per run of rows that have the same one) -----------------------
-// In a matrix with several dofs per mesh node the rows of a node carry the SAME column list.  A slice then stores its
-// columns once per "leader" (the first lane of the slice, and every lane whose list differs from the lane before): cell
-// (p, leader k) of slice s at cptr[s] + nl_s p + k (PACK 4: cptr[s] + 4 nl_s (p / 4) + 4 k + p % 4), and lead[i] = the
-// leader index of row i inside its slice.  Values stay where they are.  The column stream shrinks from 4 B per cell to
-// 4 B / (rows per list): 12 -> 8.8 B per cell for 5-dof nodes; the lanes of a group read one address.
-// One wavefront per slice: leader flags by comparing each row with its predecessor, indices by ballot + popcount.
+// ---- shared column lists (SELL-64 with one column list per run of rows that repeat it) --------------------------------
+// Two kinds of repetition, found the same way: the rows of a mesh node (several dofs) carry the SAME column list, and the
+// rows of a stencil carry the list of the row before SHIFTED BY ONE (row i of a 5-point Laplacian: i-g, i-1, i, i+1, i+g).
+// A slice stores its columns once per "leader" (lane 0, and every lane whose list is neither the previous lane's nor the
+// previous lane's plus one): cell (p, leader k) of slice s at cptr[s] + nl_s p + k (PACK 4: cptr[s] + 4 nl_s (p / 4) + 4 k
+// + p % 4).  follow[i] (16 bits per row) = leader index inside the slice | shift << 8, where shift = how many of the rows
+// between the leader and row i were "plus one" steps: a lane's column is its leader's + shift.  Values stay where they are.
+// The column stream shrinks from 4 B per cell to 4 B / (rows per list): 12 -> 8.8 B per cell for 5-dof nodes, 12 -> ~8.1 B for
+// the Laplacian (one list per 64 rows, broken at the grid edges).
+// One wavefront per slice: each lane compares its row with its predecessor, indices and shifts by ballot + popcount.
 __global__ __launch_bounds__(256) void sell_leaders_kernel(aoclsparse_int m, const aoclsparse_int *__restrict__ row_ptr,
                                                            const aoclsparse_int *__restrict__ col, aoclsparse_int nslices,
-                                                           unsigned char *__restrict__ lead, aoclsparse_int *__restrict__ nl)
+                                                           unsigned short *__restrict__ follow, aoclsparse_int *__restrict__ nl)
 {
     const int s    = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if(s >= nslices)
         return;
     const int i      = s * 64 + lane;
-    bool      leader = false;
+    bool      leader = false, plus1 = false;
     if(i < m)
     {
         leader = lane == 0;
         if(!leader)
         {
             const int b = row_ptr[i], len = row_ptr[i + 1] - b, bp = row_ptr[i - 1];
-            leader = len != b - bp; // the base cancels: only differences are used
-            for(int k = 0; k < len && !leader; k++)
-                leader = col[b + k] != col[bp + k];
+            bool      same = len == b - bp, shifted = same && len > 0; // the base cancels: only differences are used
+            for(int k = 0; k < len && (same || shifted); k++)
+            {
+                const int dcol = col[b + k] - col[bp + k];
+                same           = same && dcol == 0;
+                shifted        = shifted && dcol == 1;
+            }
+            leader = !same && !shifted;
+            plus1  = shifted;
         }
     }
-    const unsigned long long bal = __builtin_amdgcn_ballot_w64(leader);
+    const unsigned long long upto = (2ull << lane) - 1ull; // lanes 0 .. lane
+    const unsigned long long bal  = __builtin_amdgcn_ballot_w64(leader);
+    const unsigned long long p1   = __builtin_amdgcn_ballot_w64(plus1);
     if(i < m)
-        lead[i] = (unsigned char)(__builtin_popcountll(bal & ((2ull << lane) - 1ull)) - 1);
+    {
+        const unsigned long long mine = bal & upto; // never 0: lane 0 is a leader
+        const int                ll   = 63 - __builtin_clzll(mine); // my leader's lane
+        const unsigned long long span = upto & ~((2ull << ll) - 1ull); // lanes ll + 1 .. lane
+        follow[i] = (unsigned short)((__builtin_popcountll(mine) - 1) | (__builtin_popcountll(p1 & span) << 8));
+    }
     if(lane == 0)
         nl[s] = (aoclsparse_int)__builtin_popcountll(bal);
 }
@@ -147,7 +163,7 @@ __global__ __launch_bounds__(256) void sell_fill_shared_kernel(aoclsparse_int m,
                                                                const T *__restrict__ val, aoclsparse_int nslices,
                                                                const long long *__restrict__ slice_ptr,
                                                                const long long *__restrict__ cptr,
-                                                               const unsigned char *__restrict__ lead, T *__restrict__ sval,
+                                                               const unsigned short *__restrict__ follow, T *__restrict__ sval,
                                                                aoclsparse_int *__restrict__ scol,
                                                                aoclsparse_int *__restrict__ rowlen)
 {
@@ -166,8 +182,8 @@ __global__ __launch_bounds__(256) void sell_fill_shared_kernel(aoclsparse_int m,
         b   = row_ptr[i] - base;
         len = row_ptr[i + 1] - base - b;
         rowlen[i] = len;
-        k         = lead[i];
-        leader    = lane == 0 || lead[i - 1] != k;
+        k         = follow[i] & 0xff;
+        leader    = lane == 0 || (follow[i - 1] & 0xff) != k;
     }
     for(int p = 0; p < w; p++)
     {
@@ -240,7 +256,7 @@ __global__ __launch_bounds__(64 * WAVES) void sell_mv_kernel(aoclsparse_int m, a
                                                              const aoclsparse_int *__restrict__ rowlen, T alpha,
                                                              const T *__restrict__ x, T beta, T *__restrict__ y,
                                                              bool nt, const long long *__restrict__ cptr = nullptr,
-                                                             const unsigned char *__restrict__ lead = nullptr)
+                                                             const unsigned short *__restrict__ follow = nullptr)
 {
     const int s    = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + (threadIdx.x >> 6)));
     const int lane = threadIdx.x & 63;
@@ -251,16 +267,18 @@ __global__ __launch_bounds__(64 * WAVES) void sell_mv_kernel(aoclsparse_int m, a
     const T              *v  = sval + o0 + lane * PACK;
     const int             i  = s * 64 + lane;
     const aoclsparse_int *c  = scol + o0 + lane * PACK;
-    int                   cs = 64;
+    int                   cs = 64, dl = 0;
     if constexpr(SHARED)
     {
-        // one column list per leader: cs leaders in this slice, this lane reads its leader's
+        // one column list per leader: cs leaders in this slice; this lane reads its leader's and adds its shift
         const long long c0 = cptr[s];
+        const int       f  = i < m ? follow[i] : 0;
         cs                 = w > 0 ? (int)((cptr[s + 1] - c0) / w) : 1;
-        c                  = scol + c0 + (i < m ? lead[i] : 0) * PACK;
+        c                  = scol + c0 + (f & 0xff) * PACK;
+        dl                 = f >> 8;
     }
     T r = T(0);
-    if constexpr(ORDER == 0 && PACK == 1 && !SHARED)
+    if constexpr(ORDER == 0 && PACK == 1)
     {
         // short rows (this is the layout of matrices with < 16 non-zeros per row): four independent line loads
         // per step, then the gathers, then the chain.  Measured on the 4096^2 Laplacian (w = 5): 0.218 ms;
@@ -269,8 +287,10 @@ __global__ __launch_bounds__(64 * WAVES) void sell_mv_kernel(aoclsparse_int m, a
         for(; p + 4 <= w; p += 4)
         {
             const T   v0 = v[(p + 0) * 64], v1 = v[(p + 1) * 64], v2 = v[(p + 2) * 64], v3 = v[(p + 3) * 64];
-            const int c0 = c[(p + 0) * 64], c1 = c[(p + 1) * 64], c2 = c[(p + 2) * 64], c3 = c[(p + 3) * 64];
-            const T   x0 = x[max(c0, 0)], x1 = x[max(c1, 0)], x2 = x[max(c2, 0)], x3 = x[max(c3, 0)];
+            const int c0 = c[(p + 0) * cs], c1 = c[(p + 1) * cs], c2 = c[(p + 2) * cs], c3 = c[(p + 3) * cs];
+            // (a padding cell, -1, is never used, but its gather must stay inside x: index 0)
+            const T   x0 = x[c0 >= 0 ? c0 + dl : 0], x1 = x[c1 >= 0 ? c1 + dl : 0], x2 = x[c2 >= 0 ? c2 + dl : 0],
+                      x3 = x[c3 >= 0 ? c3 + dl : 0];
             r = c0 >= 0 ? s_fma(v0, x0, r) : r;
             r = c1 >= 0 ? s_fma(v1, x1, r) : r;
             r = c2 >= 0 ? s_fma(v2, x2, r) : r;
@@ -279,8 +299,8 @@ __global__ __launch_bounds__(64 * WAVES) void sell_mv_kernel(aoclsparse_int m, a
         for(; p < w; p++)
         {
             const T   v0 = v[p * 64];
-            const int c0 = c[p * 64];
-            const T   x0 = x[max(c0, 0)];
+            const int c0 = c[p * cs];
+            const T   x0 = x[c0 >= 0 ? c0 + dl : 0];
             r = c0 >= 0 ? s_fma(v0, x0, r) : r;
         }
     }
@@ -311,7 +331,7 @@ __global__ __launch_bounds__(64 * WAVES) void sell_mv_kernel(aoclsparse_int m, a
                 load_step<T, PACK, G>(v, c, p0 + G, w, vn, cn, cs);
 #pragma unroll
             for(int q = 0; q < G; q++)
-                xx[q] = x[max(cc[q], 0)];
+                xx[q] = x[cc[q] >= 0 ? cc[q] + dl : 0]; // (a padding cell, -1, is never used; its gather stays inside x)
             if constexpr(ORDER == 0)
             {
 #pragma unroll
@@ -344,7 +364,7 @@ __global__ __launch_bounds__(64 * WAVES) void sell_mv_kernel(aoclsparse_int m, a
 template <typename T, int ORDER, int PACK>
 void sell_launch(hipStream_t s, aoclsparse_int m, aoclsparse_int nslices, const long long *slice_ptr, const T *sval,
                  const aoclsparse_int *scol, const aoclsparse_int *rowlen, T alpha, const T *x, T beta, T *y,
-                 const long long *cptr, const unsigned char *lead)
+                 const long long *cptr, const unsigned short *lead)
 {
     // one slice per workgroup while the launch is small (every slice its own CU), two otherwise
     // (swept on the headline workload: 1 / 2 / 4 / 8 slices per workgroup = 0.221 / 0.218 / 0.221 / 0.222 ms)
@@ -360,11 +380,11 @@ void sell_launch(hipStream_t s, aoclsparse_int m, aoclsparse_int nslices, const 
     }
     else if(nslices < 2048)
         hipLaunchKernelGGL((sell_mv_kernel<T, ORDER, 1, PACK>), dim3(nslices), dim3(64), 0, s, m, nslices, slice_ptr,
-                           sval, scol, rowlen, alpha, x, beta, y, nt, (const long long *)nullptr, (const unsigned char *)nullptr);
+                           sval, scol, rowlen, alpha, x, beta, y, nt, (const long long *)nullptr, (const unsigned short *)nullptr);
     else
         hipLaunchKernelGGL((sell_mv_kernel<T, ORDER, 2, PACK>), dim3((nslices + 1) / 2), dim3(128), 0, s, m, nslices,
                            slice_ptr, sval, scol, rowlen, alpha, x, beta, y, nt, (const long long *)nullptr,
-                           (const unsigned char *)nullptr);
+                           (const unsigned short *)nullptr);
 }
 
 } // namespace
@@ -373,7 +393,7 @@ template <typename T>
 aoclsparse_status launch_sell_fill(hipStream_t s, int pack, aoclsparse_int m, int base, const aoclsparse_int *row_ptr,
                                    const aoclsparse_int *col, const T *val, aoclsparse_int nslices,
                                    const long long *slice_ptr, T *sval, aoclsparse_int *scol, aoclsparse_int *rowlen,
-                                   const long long *cptr, const unsigned char *lead)
+                                   const long long *cptr, const unsigned short *lead)
 {
     if(nslices <= 0)
         return aoclsparse_status_success;
@@ -400,7 +420,7 @@ template <typename T>
 aoclsparse_status launch_sellmv(hipStream_t s, int order, int pack, T alpha, aoclsparse_int m, aoclsparse_int nslices,
                                 const long long *slice_ptr, const T *sval, const aoclsparse_int *scol,
                                 const aoclsparse_int *rowlen, const T *x, T beta, T *y, const long long *cptr,
-                                const unsigned char *lead)
+                                const unsigned short *lead)
 {
     if(m <= 0 || nslices <= 0)
         return aoclsparse_status_success;
@@ -430,7 +450,7 @@ aoclsparse_status launch_sellmv(hipStream_t s, int order, int pack, T alpha, aoc
 }
 
 aoclsparse_status launch_sell_leaders(hipStream_t s, aoclsparse_int m, const aoclsparse_int *row_ptr, const aoclsparse_int *col,
-                                      aoclsparse_int nslices, unsigned char *lead, aoclsparse_int *nl)
+                                      aoclsparse_int nslices, unsigned short *lead, aoclsparse_int *nl)
 {
     if(nslices <= 0)
         return aoclsparse_status_success;
@@ -443,11 +463,11 @@ aoclsparse_status launch_sell_leaders(hipStream_t s, aoclsparse_int m, const aoc
     template aoclsparse_status launch_sell_fill<T>(hipStream_t, int, aoclsparse_int, int, const aoclsparse_int *,     \
                                                    const aoclsparse_int *, const T *, aoclsparse_int,                 \
                                                    const long long *, T *, aoclsparse_int *, aoclsparse_int *,        \
-                                                   const long long *, const unsigned char *);                          \
+                                                   const long long *, const unsigned short *);                         \
     template aoclsparse_status launch_sellmv<T>(hipStream_t, int, int, T, aoclsparse_int, aoclsparse_int,             \
                                                 const long long *, const T *, const aoclsparse_int *,                 \
                                                 const aoclsparse_int *, const T *, T, T *, const long long *,          \
-                                                const unsigned char *);
+                                                const unsigned short *);
 MI355_SELL_INSTANTIATE(double)
 MI355_SELL_INSTANTIATE(float)
 

@@ -295,9 +295,11 @@ def main():
         "config": {
             "workload": "aoclsparse_dmv, 5-pt Laplacian grid %dx%d (m=%d, nnz=%d), alpha=1 beta=0; "
                         "BASELINE configs[1] scaled past the 256 MiB Infinity Cache" % (g, g, m, nnz),
-            "kernel": ("SELL-64 built by aoclsparse_optimize for the mv hint (%d slices, %d cells = %.3f x nnz), "
+            "kernel": ("SELL-64 built by aoclsparse_optimize for the mv hint (%d slices, %d cells = %.3f x nnz)%s, "
                        "order %d (reference ref_csrmv_gn order)"
-                       % (info.sell_slices, info.stored_cells, info.stored_cells / max(nnz, 1), info.order))
+                       % (info.sell_slices, info.stored_cells, info.stored_cells / max(nnz, 1),
+                          ", ONE column list per run of rows that repeat it (as it is or shifted by one: a stencil's rows) "
+                          "instead of one per row" if info.kernel == 4 else "", info.order))
                       if info.kernel in (3, 4) else
                       ("csr-adaptive stream, order %d (reference ref_csrmv_gn order), %d row blocks"
                        % (info.order, info.row_blocks)),
@@ -306,7 +308,8 @@ def main():
             "backend": args.backend if use_dist else "none",
         },
         "roofline": roofline(abytes, kernel_ms, traffic, traffic_source=traffic_src,
-                             stored_format_bytes_per_launch=(info.stored_cells * 12 + 16 * m) if info.kernel in (3, 4) else abytes,
+                             stored_format_bytes_per_launch=(info.stored_cells * 12 + 16 * m) if info.kernel == 3
+                             else (None if info.kernel == 4 else abytes),  # kernel 4: see roofline.traffic (PMC)
                              achieved_at_median=round(abytes / (stats["median"] * 1e-3) / 1e9, 2)),
         "stats": dict(stats, unit="ms per step (device, hipEvent between consecutive launches)"),
     }
