@@ -632,12 +632,15 @@ aoclsparse_status build_sell(const aoclsparse_int *row_ptr_host, const DeviceCsr
         cptr.resize((size_t)nslices + 1);
         cptr[0] = 0;
         for(aoclsparse_int s = 0; s < nslices; s++)
-            cptr[s + 1] = cptr[s] + (long long)nlh[s] * ((sptr[s + 1] - sptr[s]) >> 6);
+            cptr[s + 1] = cptr[s] + (long long)(nlh[s] & 0xff) * ((sptr[s + 1] - sptr[s]) >> 6);
+        const long long ctotal = cptr[nslices];
         if(PhaseTimer::on())
-            std::fprintf(stderr, "[mi355 timing] sell: %lld cells, %lld column cells with shared lists (%d slices)\n", cells, cptr[nslices], (int)nslices);
-        if((double)cptr[nslices] <= 0.7 * (double)cells)
+            std::fprintf(stderr, "[mi355 timing] sell: %lld cells, %lld column cells with shared lists (%d slices)\n", cells, ctotal, (int)nslices);
+        if((double)ctotal <= 0.7 * (double)cells)
         {
-            sp.shared = true, sp.ccells = cptr[nslices];
+            for(aoclsparse_int s = 0; s < nslices; s++) // the slice's mode (sell_kernels.hip) rides in the top byte
+                cptr[s] |= (long long)(nlh[s] >> 8) << 56;
+            sp.shared = true, sp.ccells = ctotal;
             st        = sp.cptr.upload(cptr.data(), sizeof(long long) * cptr.size(), rt.stream());
         }
         else

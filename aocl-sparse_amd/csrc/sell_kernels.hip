@@ -115,6 +115,9 @@ __global__ __launch_bounds__(256) void sell_fill_kernel(aoclsparse_int m, int ba
 // The column stream shrinks from 4 B per cell to 4 B / (rows per list): 12 -> 8.8 B per cell for 5-dof nodes, 12 -> ~8.1 B for
 // the Laplacian (one list per 64 rows, broken at the grid edges).
 // One wavefront per slice: each lane compares its row with its predecessor, indices and shifts by ballot + popcount.
+constexpr int       SELL_CPTR_MODE_SHIFT = 56;
+constexpr long long SELL_CPTR_MASK       = (1LL << SELL_CPTR_MODE_SHIFT) - 1;
+
 __global__ __launch_bounds__(256) void sell_leaders_kernel(aoclsparse_int m, const aoclsparse_int *__restrict__ row_ptr,
                                                            const aoclsparse_int *__restrict__ col, aoclsparse_int nslices,
                                                            unsigned short *__restrict__ follow, aoclsparse_int *__restrict__ nl)
@@ -152,8 +155,14 @@ __global__ __launch_bounds__(256) void sell_leaders_kernel(aoclsparse_int m, con
         const unsigned long long span = upto & ~((2ull << ll) - 1ull); // lanes ll + 1 .. lane
         follow[i] = (unsigned short)((__builtin_popcountll(mine) - 1) | (__builtin_popcountll(p1 & span) << 8));
     }
+    // a FULL slice with one leader whose followers are all "plus one" (the interior of a stencil) or all "same" needs no
+    // follow[] at run time: mode 1 -> shift = lane, mode 2 -> shift = 0 (bits 8.. of nl[s]; the host moves them into cptr)
     if(lane == 0)
-        nl[s] = (aoclsparse_int)__builtin_popcountll(bal);
+    {
+        const bool full = s * 64 + 63 < m;
+        const int  mode = (full && bal == 1ull) ? (p1 == ~1ull ? 1 : (p1 == 0ull ? 2 : 0)) : 0;
+        nl[s]           = (aoclsparse_int)__builtin_popcountll(bal) | (mode << 8);
+    }
 }
 
 template <typename T, int PACK>
@@ -172,9 +181,9 @@ __global__ __launch_bounds__(256) void sell_fill_shared_kernel(aoclsparse_int m,
     if(s >= nslices)
         return;
     const int       i  = s * 64 + lane;
-    const long long o0 = slice_ptr[s], c0 = cptr[s];
+    const long long o0 = slice_ptr[s], c0 = cptr[s] & SELL_CPTR_MASK;
     const int       w  = (int)((slice_ptr[s + 1] - o0) >> 6);
-    const int       nl = w > 0 ? (int)((cptr[s + 1] - c0) / w) : 0;
+    const int       nl = w > 0 ? (int)(((cptr[s + 1] & SELL_CPTR_MASK) - c0) / w) : 0;
     int             b = 0, len = 0, k = 0;
     bool            leader = false;
     if(i < m)
@@ -271,11 +280,18 @@ __global__ __launch_bounds__(64 * WAVES) void sell_mv_kernel(aoclsparse_int m, a
     if constexpr(SHARED)
     {
         // one column list per leader: cs leaders in this slice; this lane reads its leader's and adds its shift
-        const long long c0 = cptr[s];
-        const int       f  = i < m ? follow[i] : 0;
-        cs                 = w > 0 ? (int)((cptr[s + 1] - c0) / w) : 1;
-        c                  = scol + c0 + (f & 0xff) * PACK;
-        dl                 = f >> 8;
+        // (cptr's top bits carry the slice's mode: 1 = one leader, shift = lane; 2 = one leader, no shift; else follow[])
+        const long long cw   = cptr[s];
+        const long long c0   = cw & SELL_CPTR_MASK;
+        const int       mode = (int)(cw >> SELL_CPTR_MODE_SHIFT);
+        int             f    = 0;
+        if(mode == 0)
+            f = i < m ? follow[i] : 0;
+        else if(mode == 1)
+            f = lane << 8;
+        cs = w > 0 ? (int)(((cptr[s + 1] & SELL_CPTR_MASK) - c0) / w) : 1;
+        c  = scol + c0 + (f & 0xff) * PACK;
+        dl = f >> 8;
     }
     T r = T(0);
     if constexpr(ORDER == 0 && PACK == 1)
