@@ -255,6 +255,37 @@ aoclsparse_status build_mm_super(const HostCsr &h, SpmvPlan &plan)
 // i's + 1, chosen greedily front to back; every other row is a "single".  The pair kernel is used when at least 80 %
 // of the rows found a partner (singles go through the generic kernel with a row list).  One pass over the host CSR,
 // once per handle.
+// Stencil-like matrices (row-major csrmm, n >= 128): when most rows repeat the list of the row before shifted by one and have
+// <= 8 entries, the row-run kernel pays off (entry k of a row reuses the B row that entry k + 1 of the previous row loaded).
+aoclsparse_status detect_row_runs(const HostCsr &h, SpmvPlan &plan)
+{
+    MmGroups &g = plan.mm;
+    if(g.runs_tried)
+        return aoclsparse_status_success;
+    g.runs_tried = true;
+    static const bool off = [] {
+        const char *e = getenv("AOCLSPARSE_MI355_CSRMM_RUNS");
+        return e && atoi(e) == 0;
+    }();
+    if(off || h.m < 64)
+        return aoclsparse_status_success;
+    long long      followers = 0;
+    aoclsparse_int longest = 0;
+    for(aoclsparse_int i = 1; i < h.m; i++)
+    {
+        const aoclsparse_int s = h.ptr[i] - h.base, len = h.ptr[i + 1] - h.base - s, sp = h.ptr[i - 1] - h.base;
+        longest                = std::max(longest, len);
+        if(len == 0 || len > 8 || s - sp != len)
+            continue;
+        bool ok = true;
+        for(aoclsparse_int k = 0; k < len && ok; k++)
+            ok = h.ind[s + k] == h.ind[sp + k] + 1;
+        followers += ok;
+    }
+    g.row_runs = followers * 2 >= (long long)h.m && longest <= 64;
+    return aoclsparse_status_success;
+}
+
 aoclsparse_status detect_pairs(const HostCsr &h, SpmvPlan &plan)
 {
     MmGroups &g = plan.mm;
@@ -436,6 +467,13 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
         if(st != aoclsparse_status_success)
             return st;
     }
+    if(p && !colmaj && !p->mm.valid && !p->mm.runs_tried && n >= 128)
+    {
+        std::unique_lock<std::shared_mutex> w(A->guard);
+        st = detect_row_runs(tr ? *A->trans : A->user, *p);
+        if(st != aoclsparse_status_success)
+            return st;
+    }
     if(p && colmaj && !detour && !p->mm.pairs_tried)
     {
         std::unique_lock<std::shared_mutex> w(A->guard);
@@ -501,7 +539,7 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
             st = launch_csrmm<T>(rt.stream(), order, d->base, alpha, d->m, d->n, d->val.as<T>(),
                                  d->ind.as<aoclsparse_int>(), d->ptr.as<aoclsparse_int>(), static_cast<const T *>(dB),
                                  n, ldb, beta, static_cast<T *>(dC), ldc, colmaj ? nullptr : grp, colmaj ? 0 : ngrp,
-                                 grouped ? p->mm.max_rows : 0);
+                                 grouped ? p->mm.max_rows : 0, !colmaj && p && p->mm.row_runs);
     }
     return st == aoclsparse_status_success ? finish() : st;
 }

@@ -19,6 +19,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <climits>
+#include <cstddef>
+
 #include <type_traits>
 
 namespace mi355
@@ -158,6 +161,114 @@ __global__ __launch_bounds__(256) void csrmm_row_wave_kernel(int base, T alpha, 
     else
         c.x = z0, c.y = z1;
     *cp = c;
+}
+
+// row-major, n >= 128, ROW RUNS (stencil-like matrices, csrmm_api.cpp: detect_row_runs): a wavefront walks R consecutive rows
+// for one 128-column chunk and keeps the previous row's B rows in registers.  A stencil's rows repeat the previous row's
+// column list shifted by one (i-1, i, i+1 -> i, i+1, i+2), so entry k of the new row needs exactly the B row that entry
+// k + 1 of the previous row loaded: a 5-point row costs 3 new B-row loads instead of 5.  The test is made on the live
+// column indices (wave-uniform compares), so a row that does not follow the pattern simply loads everything; rows of more
+// than 8 entries take the plain loop.  Per output element the FMA chain is the row in CSR order: same bits as the other
+// kernels.  C is stored non-temporally when it is not read.  Measured in tools/csrmm_r2.hip ("RR reuse R8 nt", 1000^2
+// Laplacian, 256 columns): 0.878 vs 0.967 ms for the row-per-wave kernel on the same box; R = 2 / 4 / 6 0.90, R >= 12 worse.
+template <typename T, int R>
+__global__ __launch_bounds__(256) void csrmm_row_run_kernel(int base, T alpha, aoclsparse_int m,
+                                                            const T *__restrict__ val,
+                                                            const aoclsparse_int *__restrict__ col,
+                                                            const aoclsparse_int *__restrict__ row_ptr,
+                                                            const T *__restrict__ B, aoclsparse_int n,
+                                                            aoclsparse_int ldb, T beta, T *__restrict__ C,
+                                                            aoclsparse_int ldc, bool readc, int xcd_chunk)
+{
+    using V      = typename vec2<T>::type;
+    const int w  = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int i0 = (bx * 4 + w) * R;
+    const int j  = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
+    if(i0 >= m || j >= n)
+        return;
+    // The index base is folded into the pointers once (col / val are indexed with the raw row_ptr values, B rows with the raw
+    // column values): with "- base" inside the loop this kernel lost 13 % (0.957 vs 0.842 ms in tools/csrmm_r2.hip, RR1 vs RR).
+    col -= base, val -= base;
+    const T *Bj = B + j - (ptrdiff_t)base * ldb;
+    int      pc[8]; // previous row's (raw) columns (INT_MIN = none) and the B rows loaded for them
+    V        pb[8];
+#pragma unroll
+    for(int k = 0; k < 8; k++)
+        pc[k] = INT_MIN, pb[k].x = T(0), pb[k].y = T(0);
+    // (fully unrolled on purpose: the scalar loads of row r + 1 -- row_ptr, columns, values -- can then be issued while row r's
+    // B rows are in flight; as a rolled loop this kernel was SLOWER than the row-per-wave one, 1.07 vs 0.985 ms)
+#pragma clang loop unroll(full)
+    for(int r = 0; r < R; r++)
+    {
+        const int  i    = i0 + r;
+        const bool live = i < m; // wave-uniform
+        const int  ic   = live ? i : m - 1;
+        const int  s = row_ptr[ic], len = live ? row_ptr[ic + 1] - s : 0;
+        T         a0 = T(0), a1 = T(0);
+        if(len <= 8)
+        {
+            int c[8];
+            T   v[8];
+            V   b[8];
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+            {
+                const int q = s + (k < len ? k : len - 1); // clamped: all eight loads go out together
+                c[k]        = len > 0 ? col[q] : INT_MIN + 1;
+                v[k]        = len > 0 ? val[q] : T(0);
+            }
+            // (Tried: request every entry that cannot reuse a register first, copy the reused ones afterwards, so that a row's
+            // loads are all in flight together -- the compiler waits behind each conditional load as written here.  It was
+            // SLOWER, 1.156 vs 0.855 ms in tools/csrmm_r2.hip: three register sets per row instead of two.)
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                if(k < len)
+                {
+                    if(k + 1 < 8 && c[k] == pc[k + 1])
+                        b[k] = pb[k + 1];
+                    else
+                        b[k] = *reinterpret_cast<const V *>(Bj + (ptrdiff_t)c[k] * ldb);
+                }
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                if(k < len)
+                    a0 = mm_fma(v[k], b[k].x, a0), a1 = mm_fma(v[k], b[k].y, a1);
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                pc[k] = k < len ? c[k] : INT_MIN, pb[k] = b[k];
+        }
+        else
+        {
+            for(int p = s; p < s + len; p++)
+            {
+                const T v0 = val[p];
+                const V b0 = *reinterpret_cast<const V *>(Bj + (ptrdiff_t)col[p] * ldb);
+                a0 = mm_fma(v0, b0.x, a0), a1 = mm_fma(v0, b0.y, a1);
+            }
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                pc[k] = INT_MIN;
+        }
+        if(!live)
+            continue;
+        V      *cp = reinterpret_cast<V *>(C + (size_t)i * ldc + j);
+        const T z0 = alpha * a0, z1 = alpha * a1;
+        // C is read only where the reference's beta * C + z can differ from z (beta != 0, or a zero z whose sign beta * C
+        // decides); ONE wave-uniform test, so that the common path is a straight non-temporal store
+        const bool need = readc || z0 == T(0) || z1 == T(0);
+        typedef T  nt2 __attribute__((ext_vector_type(2)));
+        nt2        o;
+        o.x = z0, o.y = z1;
+        if(__builtin_amdgcn_ballot_w64(need) != 0)
+        {
+            const V c2 = *cp;
+            o.x        = need ? mm_fma(beta, c2.x, z0) : z0;
+            o.y        = need ? mm_fma(beta, c2.y, z1) : z1;
+        }
+        // non-temporal on both paths (with a plain store on one of them the compiler merged the two into ONE plain store)
+        __builtin_nontemporal_store(o, reinterpret_cast<nt2 *>(cp));
+    }
 }
 
 // row-major, n >= 128, ROW GROUPS: consecutive rows with the SAME column pattern (the dof rows of one node of a
@@ -963,7 +1074,7 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
                                aoclsparse_int /*k*/, const T *val, const aoclsparse_int *col,
                                const aoclsparse_int *row_ptr, const T *B, aoclsparse_int n,
                                aoclsparse_int ldb, T beta, T *C, aoclsparse_int ldc, const aoclsparse_int *grp,
-                               aoclsparse_int ngroups, int group_rows)
+                               aoclsparse_int ngroups, int group_rows, bool row_runs)
 {
     if(m <= 0 || n <= 0)
         return aoclsparse_status_success;
@@ -1046,6 +1157,13 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
                 go(std::integral_constant<int, 4>{});
             else
                 go(std::integral_constant<int, CSRMM_GROUP>{});
+        }
+        else if(vec && n >= 128 && row_runs)
+        {
+            constexpr int RUN = 8;
+            const int     gx  = grid_x((m + 4 * RUN - 1) / (4 * RUN), chunk);
+            hipLaunchKernelGGL((csrmm_row_run_kernel<T, RUN>), dim3(gx, (n + 127) / 128), dim3(256), 0, s, base, alpha,
+                               m, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk);
         }
         else if(vec && n >= 128)
         {
@@ -1240,7 +1358,7 @@ aoclsparse_status launch_csrmm_super(hipStream_t s, int base, T alpha, aoclspars
                                                aoclsparse_int, const T *, const aoclsparse_int *,             \
                                                const aoclsparse_int *, const T *, aoclsparse_int,             \
                                                aoclsparse_int, T, T *, aoclsparse_int, const aoclsparse_int *, \
-                                               aoclsparse_int, int);                                          \
+                                               aoclsparse_int, int, bool);                                    \
     template aoclsparse_status launch_scale_dense<T>(hipStream_t, aoclsparse_order, T *, aoclsparse_int,     \
                                                      aoclsparse_int, aoclsparse_int, T);                     \
     template aoclsparse_status launch_relayout<T>(hipStream_t, bool, const T *, T *, aoclsparse_int,         \

@@ -241,6 +241,9 @@ struct SellPlan
 constexpr int CSRMM_GROUP = 8; // rows per group at most
 struct MmGroups
 {
+    // row-major, n >= 128, no groups: most rows repeat the previous row's column list shifted by one (a stencil) and have
+    // <= 8 entries -> csrmm_row_run_kernel (a wave walks 8 rows and keeps the previous row's B rows in registers)
+    bool           runs_tried = false, row_runs = false;
     aoclsparse_int ngroups = 0;
     int            max_rows = 0; // rows of the largest group
     DeviceBuffer   first; // ngroups + 1 row indices
@@ -727,7 +730,7 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
                                const aoclsparse_int *col, const aoclsparse_int *row_ptr, const T *B,
                                aoclsparse_int n, aoclsparse_int ldb, T beta, T *C,
                                aoclsparse_int ldc, const aoclsparse_int *grp = nullptr, aoclsparse_int ngroups = 0,
-                               int group_rows = 0);
+                               int group_rows = 0, bool row_runs = false);
 // row-major, n < 128: workgroup per row block of the handle's SpMV plan, A staged in LDS (csrmm_tile_kernel)
 template <typename T>
 bool csrmm_tiled_applies(aoclsparse_int n, aoclsparse_int ldb, aoclsparse_int ldc, const T *B, const T *C);

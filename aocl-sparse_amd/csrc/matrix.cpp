@@ -1049,6 +1049,8 @@ aoclsparse_status aoclsparse_mi355_invalidate(aoclsparse_matrix A)
     A->plan_trans.mm.valid = A->plan_trans.mm.tried = false;
     A->plan_user.mm.pairs = A->plan_user.mm.pairs_tried = false;
     A->plan_trans.mm.pairs = A->plan_trans.mm.pairs_tried = false;
+    A->plan_user.mm.row_runs = A->plan_user.mm.runs_tried = false;
+    A->plan_trans.mm.row_runs = A->plan_trans.mm.runs_tried = false;
     A->plan_user.mm.super_valid = A->plan_user.mm.super_tried = false;
     A->plan_trans.mm.super_valid = A->plan_trans.mm.super_tried = false;
     for(auto &p : A->trsv_plan)

@@ -207,6 +207,66 @@ def _col_reference(alpha, base, v, ci, rp, m, k, Brm, n, ldb, beta, C0, ldc):
 
 
 @pytest.mark.parametrize("base", [0, 1])
+def test_csrmm_row_runs_stencil_bit_exact(base):
+    """csrmm_row_run_kernel (row-major, n >= 128, chosen when most rows repeat the previous row's column list shifted by
+    one): a 7-point 3-D stencil with empty rows, a few rows of 9-40 entries (the plain loop), rows that break the pattern,
+    a last partial run, padded leading dimensions, alpha / beta classes, NaN in C with beta = 0 (overwritten, as
+    documented), float."""
+    g = 22
+    m = g * g * g
+    rng = np.random.default_rng(31)
+    rows = []
+    for i in range(m):
+        c = [i + o for o in (-g * g, -g, -1, 0, 1, g, g * g) if 0 <= i + o < m]
+        if i % 311 == 7:
+            c = []                                         # empty row
+        elif i % 523 == 11:
+            c = sorted(set(c) | set(int(t) for t in rng.integers(0, m, size=int(rng.integers(3, 34)))))  # long row
+        elif i % 97 == 5:
+            c = c[:-1]                                     # breaks the shifted pattern
+        rows.append(np.array(c, dtype=np.int64))
+    lens = np.array([len(c) for c in rows])
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32) + base
+    ci = (np.concatenate(rows) + base).astype(np.int32)
+    v = rng.uniform(-1, 1, len(ci))
+    A = P.Matrix(base, m, m, rp, ci, v)
+    d = P.Descr(base=base)
+    for n, alpha, beta in ((128, 1.0, 0.0), (256, -0.5, 2.0), (130, 3.0, -1.0), (200, 1.0, 0.0)):
+        ldb, ldc = n + 2, n + 4
+        Br, C0 = rng.uniform(-1, 1, m * ldb), rng.uniform(-1, 1, m * ldc)
+        Cd = dev(C0)
+        assert P.dcsrmm(P.OP_NONE, alpha, A, d, P.ORDER_ROW, dev(Br), n, ldb, beta, Cd, ldc) == 0
+        torch.cuda.synchronize()
+        got = Cd.cpu().numpy().reshape(m, ldc)
+        ref = _col_reference(alpha, base, v, ci, rp, m, m, Br, n, ldb, beta, C0, ldc)
+        assert np.array_equal(got[:, :n], ref), "n=%d" % n
+        assert np.array_equal(got[:, n:], C0.reshape(m, ldc)[:, n:])  # padding untouched
+    n = 128
+    Br = rng.uniform(-1, 1, m * n)
+    Cd = torch.full((m * n,), float("nan"), dtype=torch.float64, device="cuda")
+    assert P.dcsrmm(P.OP_NONE, 1.0, A, d, P.ORDER_ROW, dev(Br), n, n, 0.0, Cd, n) == 0
+    torch.cuda.synchronize()
+    ref = _col_reference(1.0, base, v, ci, rp, m, m, Br, n, n, 0.0, np.zeros(m * n), n)
+    got = Cd.cpu().numpy().reshape(m, n)
+    nonempty = lens > 0
+    assert np.array_equal(got[nonempty], ref[nonempty])
+    # float, same matrix
+    vf = v.astype(np.float32)
+    Af = P.Matrix(base, m, m, rp, ci, vf)
+    Bf = rng.uniform(-1, 1, m * n).astype(np.float32)
+    Cf = torch.zeros(m * n, dtype=torch.float32, device="cuda")
+    assert L.aoclsparse_scsrmm(P.OP_NONE, 1.0, Af.h, d.h, P.ORDER_ROW, P._ptr(dev(Bf)), n, n, 0.0, P._ptr(Cf), n) == 0
+    torch.cuda.synchronize()
+    reff = np.zeros((m, n), np.float32)
+    Bm = Bf.reshape(m, n)
+    for i in range(0, m, 97):  # sampled rows: the serial fp32 FMA chain of csrmm_row_major_ref
+        acc = np.zeros(n, np.float32)
+        for p in range(rp[i] - base, rp[i + 1] - base):
+            acc = (np.float64(vf[p]) * Bm[ci[p] - base].astype(np.float64) + acc.astype(np.float64)).astype(np.float32)
+        assert np.array_equal(Cf.cpu().numpy().reshape(m, n)[i], acc), i
+
+
+@pytest.mark.parametrize("base", [0, 1])
 def test_csrmm_tiled_narrow_row_major_bit_exact(base):
     """csrmm_tile_kernel (row-major, n < 128: workgroup per row block of the SpMV plan, A staged in LDS): empty rows,
     rows longer than the LDS tile (a block of their own), padded leading dimensions, alpha / beta classes incl. the

@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
+#include <cstddef>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -122,6 +124,711 @@ __global__ __launch_bounds__(256) void r0b(int m, const double *__restrict__ val
     else
         *reinterpret_cast<v2d *>(C + (size_t)i * ldc + j) = cc;
 }
+
+
+// ---------------------------------------------------------------- RR: a wave walks R consecutive rows and keeps the previous
+// row's B rows in registers: entry k of the new row reuses the register of entry k+1 of the previous row when the column
+// matches (a stencil's rows repeat the previous row's list shifted by one: i-1, i, i+1 -> i, i+1, i+2), so a 5-point row
+// costs 3 new B-row loads instead of 5.  Rows longer than 8 entries fall back to plain loads.
+template <int R, bool NT>
+__global__ __launch_bounds__(256) void rr(int m, const double *__restrict__ val, const int *__restrict__ col,
+                                          const int *__restrict__ row_ptr, const double *__restrict__ B, int n, int ldb,
+                                          double *__restrict__ C, int ldc, int chunk)
+{
+    const int w  = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i0 = (xcd_row(blockIdx.x, chunk) * 4 + w) * R;
+    const int j  = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
+    if(i0 >= m || j >= n)
+        return;
+    const double *Bj = B + j;
+    int           pc[8];
+    v2d           pb[8];
+#pragma unroll
+    for(int k = 0; k < 8; k++)
+        pc[k] = -2, pb[k] = v2d{0.0, 0.0};
+#pragma unroll
+    for(int r = 0; r < R; r++)
+    {
+        const int i = i0 + r;
+        if(i >= m)
+            break;
+        const int s = row_ptr[i], e = row_ptr[i + 1], len = e - s;
+        double    a0 = 0, a1 = 0;
+        if(len <= 8)
+        {
+            int    c[8];
+            double v[8];
+            v2d    b[8];
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+            {
+                const int q = s + (k < len ? k : len - 1);
+                c[k]        = len > 0 ? col[q] : -3;
+                v[k]        = len > 0 ? val[q] : 0.0;
+            }
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                if(k < len)
+                {
+                    if(k + 1 < 8 && c[k] == pc[k + 1])
+                        b[k] = pb[k + 1];
+                    else
+                        b[k] = *reinterpret_cast<const v2d *>(Bj + (size_t)c[k] * ldb);
+                }
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                if(k < len)
+                    a0 = fma(v[k], b[k].x, a0), a1 = fma(v[k], b[k].y, a1);
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                pc[k] = k < len ? c[k] : -2, pb[k] = b[k];
+        }
+        else
+        {
+            for(int p = s; p < e; p++)
+            {
+                const double v0 = val[p];
+                const v2d    b0 = *reinterpret_cast<const v2d *>(Bj + (size_t)col[p] * ldb);
+                a0 = fma(v0, b0.x, a0), a1 = fma(v0, b0.y, a1);
+            }
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                pc[k] = -2;
+        }
+        v2d cc;
+        cc.x = a0, cc.y = a1;
+        if(NT)
+            __builtin_nontemporal_store(cc, reinterpret_cast<v2d *>(C + (size_t)i * ldc + j));
+        else
+            *reinterpret_cast<v2d *>(C + (size_t)i * ldc + j) = cc;
+    }
+}
+
+template <int R, bool NT>
+__global__ __launch_bounds__(256) void rr1(int base, double alpha, double beta, bool readc, int m, const double *__restrict__ val, const int *__restrict__ col,
+                                          const int *__restrict__ row_ptr, const double *__restrict__ B, int n, int ldb,
+                                          double *__restrict__ C, int ldc, int chunk)
+{
+    const int w  = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i0 = (xcd_row(blockIdx.x, chunk) * 4 + w) * R;
+    const int j  = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
+    if(i0 >= m || j >= n)
+        return;
+    const double *Bj = B + j;
+    int           pc[8];
+    v2d           pb[8];
+#pragma unroll
+    for(int k = 0; k < 8; k++)
+        pc[k] = -2, pb[k] = v2d{0.0, 0.0};
+#pragma unroll
+    for(int r = 0; r < R; r++)
+    {
+        const int i = i0 + r;
+        if(i >= m)
+            break;
+        const int s = row_ptr[i] - base, e = row_ptr[i + 1] - base, len = e - s;
+        double    a0 = 0, a1 = 0;
+        if(len <= 8)
+        {
+            int    c[8];
+            double v[8];
+            v2d    b[8];
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+            {
+                const int q = s + (k < len ? k : len - 1);
+                c[k]        = len > 0 ? col[q] - base : -3;
+                v[k]        = len > 0 ? val[q] : 0.0;
+            }
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                if(k < len)
+                {
+                    if(k + 1 < 8 && c[k] == pc[k + 1])
+                        b[k] = pb[k + 1];
+                    else
+                        b[k] = *reinterpret_cast<const v2d *>(Bj + (size_t)c[k] * ldb);
+                }
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                if(k < len)
+                    a0 = fma(v[k], b[k].x, a0), a1 = fma(v[k], b[k].y, a1);
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                pc[k] = k < len ? c[k] : -2, pb[k] = b[k];
+        }
+        else
+        {
+            for(int p = s; p < e; p++)
+            {
+                const double v0 = val[p];
+                const v2d    b0 = *reinterpret_cast<const v2d *>(Bj + (size_t)(col[p] - base) * ldb);
+                a0 = fma(v0, b0.x, a0), a1 = fma(v0, b0.y, a1);
+            }
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                pc[k] = -2;
+        }
+        v2d cc;
+        cc.x = a0, cc.y = a1;
+        if(NT)
+            __builtin_nontemporal_store(cc, reinterpret_cast<v2d *>(C + (size_t)i * ldc + j));
+        else
+            *reinterpret_cast<v2d *>(C + (size_t)i * ldc + j) = cc;
+    }
+}
+
+
+template <int R, bool NT>
+__global__ __launch_bounds__(256) void rr2(int base, double alpha, double beta, bool readc, int m, const double *__restrict__ val, const int *__restrict__ col,
+                                          const int *__restrict__ row_ptr, const double *__restrict__ B, int n, int ldb,
+                                          double *__restrict__ C, int ldc, int chunk)
+{
+    const int w  = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i0 = (xcd_row(blockIdx.x, chunk) * 4 + w) * R;
+    const int j  = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
+    if(i0 >= m || j >= n)
+        return;
+    const double *Bj = B + j;
+    int           pc[8];
+    v2d           pb[8];
+#pragma unroll
+    for(int k = 0; k < 8; k++)
+        pc[k] = -2, pb[k] = v2d{0.0, 0.0};
+#pragma unroll
+    for(int r = 0; r < R; r++)
+    {
+        const int i = i0 + r;
+        if(i >= m)
+            break;
+        const int s = row_ptr[i] - base, e = row_ptr[i + 1] - base, len = e - s;
+        double    a0 = 0, a1 = 0;
+        if(len <= 8)
+        {
+            int    c[8];
+            double v[8];
+            v2d    b[8];
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+            {
+                const int q = s + (k < len ? k : len - 1);
+                c[k]        = len > 0 ? col[q] - base : -3;
+                v[k]        = len > 0 ? val[q] : 0.0;
+            }
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                if(k < len)
+                {
+                    if(k + 1 < 8 && c[k] == pc[k + 1])
+                        b[k] = pb[k + 1];
+                    else
+                        b[k] = *reinterpret_cast<const v2d *>(Bj + (size_t)c[k] * ldb);
+                }
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                if(k < len)
+                    a0 = fma(v[k], b[k].x, a0), a1 = fma(v[k], b[k].y, a1);
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                pc[k] = k < len ? c[k] : -2, pb[k] = b[k];
+        }
+        else
+        {
+            for(int p = s; p < e; p++)
+            {
+                const double v0 = val[p];
+                const v2d    b0 = *reinterpret_cast<const v2d *>(Bj + (size_t)(col[p] - base) * ldb);
+                a0 = fma(v0, b0.x, a0), a1 = fma(v0, b0.y, a1);
+            }
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                pc[k] = -2;
+        }
+        v2d         *cp = reinterpret_cast<v2d *>(C + (size_t)i * ldc + j);
+        const double z0 = alpha * a0, z1 = alpha * a1;
+        if(readc || z0 == 0.0 || z1 == 0.0)
+        {
+            v2d c2 = *cp;
+            c2.x   = fma(beta, c2.x, z0);
+            c2.y   = fma(beta, c2.y, z1);
+            *cp    = c2;
+        }
+        else
+        {
+            v2d cc;
+            cc.x = z0, cc.y = z1;
+            __builtin_nontemporal_store(cc, cp);
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------- RPROD: the product's csrmm_row_run_kernel, verbatim
+template <typename T, int R>
+__global__ __launch_bounds__(256) void rprod(int base, T alpha, int m,
+                                                            const T *__restrict__ val,
+                                                            const int *__restrict__ col,
+                                                            const int *__restrict__ row_ptr,
+                                                            const T *__restrict__ B, int n,
+                                                            int ldb, T beta, T *__restrict__ C,
+                                                            int ldc, bool readc, int xcd_chunk)
+{
+    using V      = v2d;
+    const int w  = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int i0 = (bx * 4 + w) * R;
+    const int j  = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
+    if(i0 >= m || j >= n)
+        return;
+    // The index base is folded into the pointers once (col / val are indexed with the raw row_ptr values, B rows with the raw
+    // column values): with "- base" inside the loop this kernel lost 13 % (0.957 vs 0.842 ms in tools/csrmm_r2.hip, RR1 vs RR).
+    col -= base, val -= base;
+    const T *Bj = B + j - (ptrdiff_t)base * ldb;
+    int      pc[8]; // previous row's (raw) columns (INT_MIN = none) and the B rows loaded for them
+    V        pb[8];
+#pragma unroll
+    for(int k = 0; k < 8; k++)
+        pc[k] = INT_MIN, pb[k].x = T(0), pb[k].y = T(0);
+    // (fully unrolled on purpose: the scalar loads of row r + 1 -- row_ptr, columns, values -- can then be issued while row r's
+    // B rows are in flight; as a rolled loop this kernel was SLOWER than the row-per-wave one, 1.07 vs 0.985 ms)
+#pragma clang loop unroll(full)
+    for(int r = 0; r < R; r++)
+    {
+        const int  i    = i0 + r;
+        const bool live = i < m; // wave-uniform
+        const int  ic   = live ? i : m - 1;
+        const int  s = row_ptr[ic], len = live ? row_ptr[ic + 1] - s : 0;
+        T         a0 = T(0), a1 = T(0);
+        if(len <= 8)
+        {
+            int c[8];
+            T   v[8];
+            V   b[8];
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+            {
+                const int q = s + (k < len ? k : len - 1); // clamped: all eight loads go out together
+                c[k]        = len > 0 ? col[q] : INT_MIN + 1;
+                v[k]        = len > 0 ? val[q] : T(0);
+            }
+            // two passes, so that the loads of a row are all in flight together: first every entry that cannot reuse a
+            // register is requested (into nb[], which nothing else writes), then the reused ones are copied.  Written as
+            // "b[k] = reuse ? pb[k + 1] : load" the compiler waited for every load right behind it (8 serial trips per row).
+            bool reuse[8];
+            V    nb[8];
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+            {
+                reuse[k] = k + 1 < 8 && c[k] == pc[k + 1];
+                if(k < len && !reuse[k])
+                    nb[k] = *reinterpret_cast<const V *>(Bj + (ptrdiff_t)c[k] * ldb);
+            }
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                if(k < len)
+                    b[k] = reuse[k] ? pb[k < 7 ? k + 1 : 7] : nb[k];
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                if(k < len)
+                    a0 = fma(v[k], b[k].x, a0), a1 = fma(v[k], b[k].y, a1);
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                pc[k] = k < len ? c[k] : INT_MIN, pb[k] = b[k];
+        }
+        else
+        {
+            for(int p = s; p < s + len; p++)
+            {
+                const T v0 = val[p];
+                const V b0 = *reinterpret_cast<const V *>(Bj + (ptrdiff_t)col[p] * ldb);
+                a0 = fma(v0, b0.x, a0), a1 = fma(v0, b0.y, a1);
+            }
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                pc[k] = INT_MIN;
+        }
+        if(!live)
+            continue;
+        V      *cp = reinterpret_cast<V *>(C + (size_t)i * ldc + j);
+        const T z0 = alpha * a0, z1 = alpha * a1;
+        // C is read only where the reference's beta * C + z can differ from z (beta != 0, or a zero z whose sign beta * C
+        // decides); ONE wave-uniform test, so that the common path is a straight non-temporal store
+        const bool need = readc || z0 == T(0) || z1 == T(0);
+        typedef T  nt2 __attribute__((ext_vector_type(2)));
+        nt2        o;
+        o.x = z0, o.y = z1;
+        if(__builtin_amdgcn_ballot_w64(need) != 0)
+        {
+            const V c2 = *cp;
+            o.x        = need ? fma(beta, c2.x, z0) : z0;
+            o.y        = need ? fma(beta, c2.y, z1) : z1;
+        }
+        // non-temporal on both paths (with a plain store on one of them the compiler merged the two into ONE plain store)
+        __builtin_nontemporal_store(o, reinterpret_cast<nt2 *>(cp));
+    }
+}
+
+
+// ---------------------------------------------------------------- RPRODA: simple epilogue
+template <typename T, int R>
+__global__ __launch_bounds__(256) void rprodA(int base, T alpha, int m,
+                                                            const T *__restrict__ val,
+                                                            const int *__restrict__ col,
+                                                            const int *__restrict__ row_ptr,
+                                                            const T *__restrict__ B, int n,
+                                                            int ldb, T beta, T *__restrict__ C,
+                                                            int ldc, bool readc, int xcd_chunk)
+{
+    using V      = v2d;
+    const int w  = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int i0 = (bx * 4 + w) * R;
+    const int j  = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
+    if(i0 >= m || j >= n)
+        return;
+    const T *Bj = B + j;
+    int      pc[8]; // previous row's columns (-2 = none) and the B rows loaded for them
+    V        pb[8];
+#pragma unroll
+    for(int k = 0; k < 8; k++)
+        pc[k] = -2, pb[k].x = T(0), pb[k].y = T(0);
+    // (fully unrolled on purpose: the scalar loads of row r + 1 -- row_ptr, columns, values -- can then be issued while row r's
+    // B rows are in flight; as a rolled loop this kernel was SLOWER than the row-per-wave one, 1.07 vs 0.985 ms)
+#pragma clang loop unroll(full)
+    for(int r = 0; r < R; r++)
+    {
+        const int  i    = i0 + r;
+        const bool live = i < m; // wave-uniform
+        const int  ic   = live ? i : m - 1;
+        const int  s = row_ptr[ic] - base, len = live ? row_ptr[ic + 1] - base - s : 0;
+        T         a0 = T(0), a1 = T(0);
+        if(len <= 8)
+        {
+            int c[8];
+            T   v[8];
+            V   b[8];
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+            {
+                const int q = s + (k < len ? k : len - 1); // clamped: all eight loads go out together
+                c[k]        = len > 0 ? col[q] - base : -3;
+                v[k]        = len > 0 ? val[q] : T(0);
+                b[k].x = T(0), b[k].y = T(0);
+            }
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                if(k < len)
+                {
+                    if(k + 1 < 8 && c[k] == pc[k + 1])
+                        b[k] = pb[k + 1];
+                    else
+                        b[k] = *reinterpret_cast<const V *>(Bj + (size_t)c[k] * ldb);
+                }
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                if(k < len)
+                    a0 = fma(v[k], b[k].x, a0), a1 = fma(v[k], b[k].y, a1);
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                pc[k] = k < len ? c[k] : -2, pb[k] = b[k];
+        }
+        else
+        {
+            for(int p = s; p < s + len; p++)
+            {
+                const T v0 = val[p];
+                const V b0 = *reinterpret_cast<const V *>(Bj + (size_t)(col[p] - base) * ldb);
+                a0 = fma(v0, b0.x, a0), a1 = fma(v0, b0.y, a1);
+            }
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                pc[k] = -2;
+        }
+        if(!live)
+            continue;
+        {
+            typedef T nt2 __attribute__((ext_vector_type(2)));
+            nt2 o;
+            o.x = alpha * a0, o.y = alpha * a1;
+            __builtin_nontemporal_store(o, reinterpret_cast<nt2 *>(C + (size_t)i * ldc + j));
+        }
+    }
+}
+
+
+
+// ---------------------------------------------------------------- RPRODD: A without zero init
+template <typename T, int R>
+__global__ __launch_bounds__(256) void rprodD(int base, T alpha, int m,
+                                                            const T *__restrict__ val,
+                                                            const int *__restrict__ col,
+                                                            const int *__restrict__ row_ptr,
+                                                            const T *__restrict__ B, int n,
+                                                            int ldb, T beta, T *__restrict__ C,
+                                                            int ldc, bool readc, int xcd_chunk)
+{
+    using V      = v2d;
+    const int w  = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int i0 = (bx * 4 + w) * R;
+    const int j  = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
+    if(i0 >= m || j >= n)
+        return;
+    const T *Bj = B + j;
+    int      pc[8]; // previous row's columns (-2 = none) and the B rows loaded for them
+    V        pb[8];
+#pragma unroll
+    for(int k = 0; k < 8; k++)
+        pc[k] = -2, pb[k].x = T(0), pb[k].y = T(0);
+    // (fully unrolled on purpose: the scalar loads of row r + 1 -- row_ptr, columns, values -- can then be issued while row r's
+    // B rows are in flight; as a rolled loop this kernel was SLOWER than the row-per-wave one, 1.07 vs 0.985 ms)
+#pragma clang loop unroll(full)
+    for(int r = 0; r < R; r++)
+    {
+        const int  i    = i0 + r;
+        const bool live = i < m; // wave-uniform
+        const int  ic   = live ? i : m - 1;
+        const int  s = row_ptr[ic] - base, len = live ? row_ptr[ic + 1] - base - s : 0;
+        T         a0 = T(0), a1 = T(0);
+        if(len <= 8)
+        {
+            int c[8];
+            T   v[8];
+            V   b[8];
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+            {
+                const int q = s + (k < len ? k : len - 1); // clamped: all eight loads go out together
+                c[k]        = len > 0 ? col[q] - base : -3;
+                v[k]        = len > 0 ? val[q] : T(0);
+            }
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                if(k < len)
+                {
+                    if(k + 1 < 8 && c[k] == pc[k + 1])
+                        b[k] = pb[k + 1];
+                    else
+                        b[k] = *reinterpret_cast<const V *>(Bj + (size_t)c[k] * ldb);
+                }
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                if(k < len)
+                    a0 = fma(v[k], b[k].x, a0), a1 = fma(v[k], b[k].y, a1);
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                pc[k] = k < len ? c[k] : -2, pb[k] = b[k];
+        }
+        else
+        {
+            for(int p = s; p < s + len; p++)
+            {
+                const T v0 = val[p];
+                const V b0 = *reinterpret_cast<const V *>(Bj + (size_t)(col[p] - base) * ldb);
+                a0 = fma(v0, b0.x, a0), a1 = fma(v0, b0.y, a1);
+            }
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                pc[k] = -2;
+        }
+        if(!live)
+            continue;
+        {
+            typedef T nt2 __attribute__((ext_vector_type(2)));
+            nt2 o;
+            o.x = alpha * a0, o.y = alpha * a1;
+            __builtin_nontemporal_store(o, reinterpret_cast<nt2 *>(C + (size_t)i * ldc + j));
+        }
+    }
+}
+
+
+
+
+// ---------------------------------------------------------------- RPRODE: A with break
+template <typename T, int R>
+__global__ __launch_bounds__(256) void rprodE(int base, T alpha, int m,
+                                                            const T *__restrict__ val,
+                                                            const int *__restrict__ col,
+                                                            const int *__restrict__ row_ptr,
+                                                            const T *__restrict__ B, int n,
+                                                            int ldb, T beta, T *__restrict__ C,
+                                                            int ldc, bool readc, int xcd_chunk)
+{
+    using V      = v2d;
+    const int w  = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int i0 = (bx * 4 + w) * R;
+    const int j  = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
+    if(i0 >= m || j >= n)
+        return;
+    const T *Bj = B + j;
+    int      pc[8]; // previous row's columns (-2 = none) and the B rows loaded for them
+    V        pb[8];
+#pragma unroll
+    for(int k = 0; k < 8; k++)
+        pc[k] = -2, pb[k].x = T(0), pb[k].y = T(0);
+    // (fully unrolled on purpose: the scalar loads of row r + 1 -- row_ptr, columns, values -- can then be issued while row r's
+    // B rows are in flight; as a rolled loop this kernel was SLOWER than the row-per-wave one, 1.07 vs 0.985 ms)
+#pragma clang loop unroll(full)
+    for(int r = 0; r < R; r++)
+    {
+        const int i = i0 + r;
+        if(i >= m)
+            break;
+        const int s = row_ptr[i] - base, len = row_ptr[i + 1] - base - s;
+        T         a0 = T(0), a1 = T(0);
+        if(len <= 8)
+        {
+            int c[8];
+            T   v[8];
+            V   b[8];
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+            {
+                const int q = s + (k < len ? k : len - 1); // clamped: all eight loads go out together
+                c[k]        = len > 0 ? col[q] - base : -3;
+                v[k]        = len > 0 ? val[q] : T(0);
+                b[k].x = T(0), b[k].y = T(0);
+            }
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                if(k < len)
+                {
+                    if(k + 1 < 8 && c[k] == pc[k + 1])
+                        b[k] = pb[k + 1];
+                    else
+                        b[k] = *reinterpret_cast<const V *>(Bj + (size_t)c[k] * ldb);
+                }
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                if(k < len)
+                    a0 = fma(v[k], b[k].x, a0), a1 = fma(v[k], b[k].y, a1);
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                pc[k] = k < len ? c[k] : -2, pb[k] = b[k];
+        }
+        else
+        {
+            for(int p = s; p < s + len; p++)
+            {
+                const T v0 = val[p];
+                const V b0 = *reinterpret_cast<const V *>(Bj + (size_t)(col[p] - base) * ldb);
+                a0 = fma(v0, b0.x, a0), a1 = fma(v0, b0.y, a1);
+            }
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                pc[k] = -2;
+        }
+        {
+            typedef T nt2 __attribute__((ext_vector_type(2)));
+            nt2 o;
+            o.x = alpha * a0, o.y = alpha * a1;
+            __builtin_nontemporal_store(o, reinterpret_cast<nt2 *>(C + (size_t)i * ldc + j));
+        }
+    }
+}
+
+
+
+
+// ---------------------------------------------------------------- RPRODB: uniform readc only
+template <typename T, int R>
+__global__ __launch_bounds__(256) void rprodB(int base, T alpha, int m,
+                                                            const T *__restrict__ val,
+                                                            const int *__restrict__ col,
+                                                            const int *__restrict__ row_ptr,
+                                                            const T *__restrict__ B, int n,
+                                                            int ldb, T beta, T *__restrict__ C,
+                                                            int ldc, bool readc, int xcd_chunk)
+{
+    using V      = v2d;
+    const int w  = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int i0 = (bx * 4 + w) * R;
+    const int j  = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
+    if(i0 >= m || j >= n)
+        return;
+    const T *Bj = B + j;
+    int      pc[8]; // previous row's columns (-2 = none) and the B rows loaded for them
+    V        pb[8];
+#pragma unroll
+    for(int k = 0; k < 8; k++)
+        pc[k] = -2, pb[k].x = T(0), pb[k].y = T(0);
+    // (fully unrolled on purpose: the scalar loads of row r + 1 -- row_ptr, columns, values -- can then be issued while row r's
+    // B rows are in flight; as a rolled loop this kernel was SLOWER than the row-per-wave one, 1.07 vs 0.985 ms)
+#pragma clang loop unroll(full)
+    for(int r = 0; r < R; r++)
+    {
+        const int  i    = i0 + r;
+        const bool live = i < m; // wave-uniform
+        const int  ic   = live ? i : m - 1;
+        const int  s = row_ptr[ic] - base, len = live ? row_ptr[ic + 1] - base - s : 0;
+        T         a0 = T(0), a1 = T(0);
+        if(len <= 8)
+        {
+            int c[8];
+            T   v[8];
+            V   b[8];
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+            {
+                const int q = s + (k < len ? k : len - 1); // clamped: all eight loads go out together
+                c[k]        = len > 0 ? col[q] - base : -3;
+                v[k]        = len > 0 ? val[q] : T(0);
+                b[k].x = T(0), b[k].y = T(0);
+            }
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                if(k < len)
+                {
+                    if(k + 1 < 8 && c[k] == pc[k + 1])
+                        b[k] = pb[k + 1];
+                    else
+                        b[k] = *reinterpret_cast<const V *>(Bj + (size_t)c[k] * ldb);
+                }
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                if(k < len)
+                    a0 = fma(v[k], b[k].x, a0), a1 = fma(v[k], b[k].y, a1);
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                pc[k] = k < len ? c[k] : -2, pb[k] = b[k];
+        }
+        else
+        {
+            for(int p = s; p < s + len; p++)
+            {
+                const T v0 = val[p];
+                const V b0 = *reinterpret_cast<const V *>(Bj + (size_t)(col[p] - base) * ldb);
+                a0 = fma(v0, b0.x, a0), a1 = fma(v0, b0.y, a1);
+            }
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                pc[k] = -2;
+        }
+        if(!live)
+            continue;
+        V      *cp = reinterpret_cast<V *>(C + (size_t)i * ldc + j);
+        const T z0 = alpha * a0, z1 = alpha * a1;
+        if(readc)
+        {
+            V c2 = *cp;
+            c2.x = fma(beta, c2.x, z0);
+            c2.y = fma(beta, c2.y, z1);
+            *cp  = c2;
+        }
+        else
+        {
+            typedef T nt2 __attribute__((ext_vector_type(2)));
+            nt2 o;
+            o.x = z0, o.y = z1;
+            __builtin_nontemporal_store(o, reinterpret_cast<nt2 *>(cp));
+        }
+    }
+}
+
+
 
 // ---------------------------------------------------------------- RW: row block with the union of its B rows in LDS
 // Experiment (banded A only: the union of a block's columns is computed from `band`): a workgroup takes R consecutive
@@ -1035,6 +1742,53 @@ int main(int argc, char **argv)
                         int ch; int gx = rowgrid(4, ch);
                         r0b<true><<<dim3(gx, (n + 127) / 128), 256>>>(im, d_v, d_ci, d_rp, d_B, n, n, d_C, n, ch);
                     }});
+    vars.push_back({"RPROD product row-run kernel", false, [&] {
+                        if(n < 128) return;
+                        int ch; int gx = rowgrid(32, ch);
+                        rprod<double, 8><<<dim3(gx, (n + 127) / 128), 256>>>(0, 1.0, im, d_v, d_ci, d_rp, d_B, n, n, 0.0, d_C, n, false, ch);
+                    }});
+    vars.push_back({"RPRODA simple epilogue", false, [&] {
+                        int ch; int gx = rowgrid(32, ch);
+                        rprodA<double, 8><<<dim3(gx, (n + 127) / 128), 256>>>(0, 1.0, im, d_v, d_ci, d_rp, d_B, n, n, 0.0, d_C, n, false, ch);
+                    }});
+    vars.push_back({"RPRODB uniform readc only", false, [&] {
+                        int ch; int gx = rowgrid(32, ch);
+                        rprodB<double, 8><<<dim3(gx, (n + 127) / 128), 256>>>(0, 1.0, im, d_v, d_ci, d_rp, d_B, n, n, 0.0, d_C, n, false, ch);
+                    }});
+    vars.push_back({"RPRODD A without zero init", false, [&] {
+                        int ch; int gx = rowgrid(32, ch);
+                        rprodD<double, 8><<<dim3(gx, (n + 127) / 128), 256>>>(0, 1.0, im, d_v, d_ci, d_rp, d_B, n, n, 0.0, d_C, n, false, ch);
+                    }});
+    vars.push_back({"RPRODE A with break", false, [&] {
+                        int ch; int gx = rowgrid(32, ch);
+                        rprodE<double, 8><<<dim3(gx, (n + 127) / 128), 256>>>(0, 1.0, im, d_v, d_ci, d_rp, d_B, n, n, 0.0, d_C, n, false, ch);
+                    }});
+    vars.push_back({"RR1 = RR R8 nt + base", false, [&] {
+                        int ch; int gx = rowgrid(32, ch);
+                        rr1<8, true><<<dim3(gx, (n + 127) / 128), 256>>>(0, 1.0, 0.0, false, im, d_v, d_ci, d_rp, d_B, n, n, d_C, n, ch);
+                    }});
+    vars.push_back({"RR2 = RR1 + product epilogue", false, [&] {
+                        int ch; int gx = rowgrid(32, ch);
+                        rr2<8, true><<<dim3(gx, (n + 127) / 128), 256>>>(0, 1.0, 0.0, false, im, d_v, d_ci, d_rp, d_B, n, n, d_C, n, ch);
+                    }});
+#define RRVAR(R, NT, label)                                                                                         \
+    vars.push_back({label, false, [&] {                                                                              \
+                        if(n < 128) return;                                                                          \
+                        int ch; int gx = rowgrid(4 * R, ch);                                                         \
+                        rr<R, NT><<<dim3(gx, (n + 127) / 128), 256>>>(im, d_v, d_ci, d_rp, d_B, n, n, d_C, n, ch);   \
+                    }});
+    RRVAR(2, false, "RR reuse R2")
+    RRVAR(4, false, "RR reuse R4")
+    RRVAR(8, false, "RR reuse R8")
+    RRVAR(16, false, "RR reuse R16")
+    RRVAR(8, true, "RR reuse R8 nt")
+    RRVAR(32, true, "RR reuse R32 nt")
+    RRVAR(2, true, "RR reuse R2 nt")
+    RRVAR(4, true, "RR reuse R4 nt")
+    RRVAR(6, true, "RR reuse R6 nt")
+    RRVAR(12, true, "RR reuse R12 nt")
+    RRVAR(16, true, "RR reuse R16 nt")
+    RRVAR(1, true, "RR reuse R1 nt (= R0 + nt)")
 #define RWVAR(R, CW, label)                                                                                         \
     vars.push_back({label, false, [&] {                                                                              \
                         if(n % 128 || band <= R + 2) return;                                                         \

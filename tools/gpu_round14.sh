@@ -4,6 +4,6 @@ B=tools/bin/csrmm_r2
 {
 for cfg in "1000 256 1000" "1000 128 1000"; do
   echo "=== $cfg"
-  timeout 300 $B $cfg "R0 shipped,R0B,RE ell8 R1,diag D2,copy simple"
+  timeout 300 $B $cfg "R0 shipped,RR reuse,diag D2,copy simple"
 done
-} 2>&1 | tee gpurun_out/csrmm_r2_exp8.txt
+} 2>&1 | tee gpurun_out/csrmm_r2_exp9.txt
