@@ -127,17 +127,18 @@ __global__ __launch_bounds__(256) void csrmm_row_wave_kernel(int base, T alpha, 
     const int j   = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
     if(i >= m || j >= n)
         return;
-    const int s = row_ptr[i] - base, e = row_ptr[i + 1] - base;
+    col -= base, val -= base; // the index base, folded into the pointers once
+    const int s = row_ptr[i], e = row_ptr[i + 1];
     T         a0 = T(0), a1 = T(0);
-    const T  *Bj = B + j;
+    const T  *Bj = B + j - (ptrdiff_t)base * ldb;
     int       p  = s;
     for(; p + 4 <= e; p += 4)
     {
         const T v0 = val[p], v1 = val[p + 1], v2 = val[p + 2], v3 = val[p + 3];
-        const V b0 = *reinterpret_cast<const V *>(Bj + (size_t)(col[p] - base) * ldb);
-        const V b1 = *reinterpret_cast<const V *>(Bj + (size_t)(col[p + 1] - base) * ldb);
-        const V b2 = *reinterpret_cast<const V *>(Bj + (size_t)(col[p + 2] - base) * ldb);
-        const V b3 = *reinterpret_cast<const V *>(Bj + (size_t)(col[p + 3] - base) * ldb);
+        const V b0 = *reinterpret_cast<const V *>(Bj + (ptrdiff_t)col[p] * ldb);
+        const V b1 = *reinterpret_cast<const V *>(Bj + (ptrdiff_t)col[p + 1] * ldb);
+        const V b2 = *reinterpret_cast<const V *>(Bj + (ptrdiff_t)col[p + 2] * ldb);
+        const V b3 = *reinterpret_cast<const V *>(Bj + (ptrdiff_t)col[p + 3] * ldb);
         a0 = mm_fma(v0, b0.x, a0), a1 = mm_fma(v0, b0.y, a1);
         a0 = mm_fma(v1, b1.x, a0), a1 = mm_fma(v1, b1.y, a1);
         a0 = mm_fma(v2, b2.x, a0), a1 = mm_fma(v2, b2.y, a1);
@@ -146,21 +147,22 @@ __global__ __launch_bounds__(256) void csrmm_row_wave_kernel(int base, T alpha, 
     for(; p < e; p++)
     {
         const T v0 = val[p];
-        const V b0 = *reinterpret_cast<const V *>(Bj + (size_t)(col[p] - base) * ldb);
+        const V b0 = *reinterpret_cast<const V *>(Bj + (ptrdiff_t)col[p] * ldb);
         a0 = mm_fma(v0, b0.x, a0), a1 = mm_fma(v0, b0.y, a1);
     }
     V      *cp = reinterpret_cast<V *>(C + (size_t)i * ldc + j);
     const T z0 = alpha * a0, z1 = alpha * a1;
-    V       c;
-    if(readc || z0 == T(0) || z1 == T(0))
+    const bool need = readc || z0 == T(0) || z1 == T(0); // (see csrmm_rowgroup2_kernel)
+    typedef T  nt2 __attribute__((ext_vector_type(2)));
+    nt2        o;
+    o.x = z0, o.y = z1;
+    if(__builtin_amdgcn_ballot_w64(need) != 0)
     {
-        c   = *cp;
-        c.x = mm_fma(beta, c.x, z0);
-        c.y = mm_fma(beta, c.y, z1);
+        const V c = *cp;
+        o.x       = need ? mm_fma(beta, c.x, z0) : z0;
+        o.y       = need ? mm_fma(beta, c.y, z1) : z1;
     }
-    else
-        c.x = z0, c.y = z1;
-    *cp = c;
+    __builtin_nontemporal_store(o, reinterpret_cast<nt2 *>(cp));
 }
 
 // row-major, n >= 128, ROW RUNS (stencil-like matrices, csrmm_api.cpp: detect_row_runs): a wavefront walks R consecutive rows
@@ -405,25 +407,28 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup2_kernel(int base, T alpha,
         return;
     const int gi = glist ? glist[gt] : gt;
     const int i0 = grp[gi], r = grp[gi + 1] - i0; // 1 <= r <= GR
-    const int s0 = row_ptr[i0] - base, len = row_ptr[i0 + 1] - base - s0;
+    // (the index base is folded into the pointers once: col / val take raw row_ptr values, B rows raw column values --
+    // subtracting it per index cost the row-run kernel 13 %)
+    col -= base, val -= base;
+    const int s0 = row_ptr[i0], len = row_ptr[i0 + 1] - s0;
     int       so[GR]; // start of every row of the group (wave-uniform); rows beyond the group alias row 0
 #pragma unroll
     for(int q = 0; q < GR; q++)
-        so[q] = q < r ? row_ptr[i0 + q] - base : s0;
+        so[q] = q < r ? row_ptr[i0 + q] : s0;
     T acc0[GR], acc1[GR];
 #pragma unroll
     for(int q = 0; q < GR; q++)
         acc0[q] = T(0), acc1[q] = T(0);
-    const T  *Bj    = B + j;
+    const T  *Bj    = B + j - (ptrdiff_t)base * ldb;
     const int nstep = len / U;
     // (no branch on q < r around the FMAs: rows the group does not have accumulate row 0's products into accumulators
     // that are never stored -- with the branch the compiler sinks each row's value loads behind it again)
 #define MM_FETCH(b, k)                                                                         \
     {                                                                                          \
         int c_[U];                                                                             \
-        _Pragma("unroll") for(int u = 0; u < U; u++) c_[u] = col[s0 + (k) + u] - base;         \
+        _Pragma("unroll") for(int u = 0; u < U; u++) c_[u] = col[s0 + (k) + u];                \
         _Pragma("unroll") for(int u = 0; u < U; u++)                                           \
-            b[u] = *reinterpret_cast<const V *>(Bj + (size_t)c_[u] * ldb);                     \
+            b[u] = *reinterpret_cast<const V *>(Bj + (ptrdiff_t)c_[u] * ldb);                  \
     }
 #define MM_MAC(b, k)                                                                           \
     {                                                                                          \
@@ -465,10 +470,10 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup2_kernel(int base, T alpha,
             T   a_[GR][U - 1];
 #pragma unroll
             for(int u = 0; u < U - 1; u++)
-                c_[u] = col[s0 + min(k + u, len - 1)] - base;
+                c_[u] = col[s0 + min(k + u, len - 1)];
 #pragma unroll
             for(int u = 0; u < U - 1; u++)
-                bt[u] = *reinterpret_cast<const V *>(Bj + (size_t)c_[u] * ldb);
+                bt[u] = *reinterpret_cast<const V *>(Bj + (ptrdiff_t)c_[u] * ldb);
 #pragma unroll
             for(int q = 0; q < GR; q++)
 #pragma unroll
@@ -501,23 +506,19 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup2_kernel(int base, T alpha,
         {
             V      *cp = reinterpret_cast<V *>(C + (size_t)(i0 + q) * ldc + j);
             const T z0 = alpha * acc0[q], z1 = alpha * acc1[q];
-            V       c;
-            if(readc || z0 == T(0) || z1 == T(0))
+            // C is read only where beta * C + z can differ from z: one wave-uniform test, non-temporal store on both paths
+            // (C is written once and never read again: it stays out of the L2 the B rows live in)
+            const bool need = readc || z0 == T(0) || z1 == T(0);
+            typedef T  nt2 __attribute__((ext_vector_type(2)));
+            nt2        o;
+            o.x = z0, o.y = z1;
+            if(__builtin_amdgcn_ballot_w64(need) != 0)
             {
-                c   = *cp;
-                c.x = mm_fma(beta, c.x, z0);
-                c.y = mm_fma(beta, c.y, z1);
-                *cp = c;
+                const V c = *cp;
+                o.x       = need ? mm_fma(beta, c.x, z0) : z0;
+                o.y       = need ? mm_fma(beta, c.y, z1) : z1;
             }
-            else
-            {
-                // C is written once and never read: keep it out of the L2 the B rows live in (shell-like: the B window of
-                // a 128-column pass is ~9 MB per XCD against 4 MB of L2, HBM-side reads were 2.2 x B)
-                typedef T nt2 __attribute__((ext_vector_type(2)));
-                nt2 o;
-                o.x = z0, o.y = z1;
-                __builtin_nontemporal_store(o, reinterpret_cast<nt2 *>(cp));
-            }
+            __builtin_nontemporal_store(o, reinterpret_cast<nt2 *>(cp));
         }
 }
 

@@ -1,2 +1,4 @@
 #!/bin/bash
-timeout 900 python -m pytest tests/test_gpu_configs.py -x -q -m gpu -k "row_runs" 2>&1 | tail -12
+for r in 0 0; do AOCLSPARSE_MI355_CSRMM_RUNS=$r python3 tools/exp_mm_lap.py 256 2>/dev/null; done
+python3 tools/exp_mm_standin.py shell-like 256 2>/dev/null; python3 tools/exp_mm_standin.py flan-like 256 2>/dev/null
+timeout 900 python -m pytest tests/ -x -q -m gpu -k "csrmm" 2>&1 | tail -3
