@@ -574,7 +574,8 @@ template <typename T>
 aoclsparse_status launch_csrmv(hipStream_t s, int order, bool strict, int tile, int base, T alpha,
                                aoclsparse_int m, const T *val, const aoclsparse_int *col,
                                const aoclsparse_int *row_ptr, const aoclsparse_int *blocks,
-                               aoclsparse_int nblocks, const T *x, T beta, T *y, const aoclsparse_int *blocks4 = nullptr);
+                               aoclsparse_int nblocks, const T *x, T beta, T *y, const aoclsparse_int *blocks4 = nullptr,
+                               aoclsparse_int max_row_nnz = 1 << 30);
 // raw-array csrmv: is a cached plan still the plan of this row_ptr?  (*stale: pinned host word, set on mismatch)
 aoclsparse_status launch_plan_check(hipStream_t s, const aoclsparse_int *blocks, aoclsparse_int nblocks,
                                     const aoclsparse_int *row_ptr, int base, aoclsparse_int m, aoclsparse_int nnz,

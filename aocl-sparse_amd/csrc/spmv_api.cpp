@@ -137,7 +137,8 @@ aoclsparse_status run_on_device_csr(Runtime &rt, aoclsparse_int kid, const Devic
                              d.ind.as<aoclsparse_int>(), d.ptr.as<aoclsparse_int>(),
                              plan.rowblocks.as<aoclsparse_int>(), plan.nblocks, static_cast<const T *>(ax.dev),
                              beta, static_cast<T *>(ay.dev),
-                             (plan.heavy_first && (plan.tile & 1) == 0) ? plan.rowblocks4.as<aoclsparse_int>() : nullptr);
+                             (plan.heavy_first && (plan.tile & 1) == 0) ? plan.rowblocks4.as<aoclsparse_int>() : nullptr,
+                             plan.max_row_nnz);
     if(st != aoclsparse_status_success)
         return st;
     st = ay.out(rt);

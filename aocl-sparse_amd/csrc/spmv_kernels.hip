@@ -125,7 +125,7 @@ __device__ __forceinline__ T block_sum(T v, T *scratch)
 
 // flags: bit0 strict long rows, bit1 16-byte-aligned val and col (quad loads allowed),
 //        bit2 XCD-contiguous block order, bit3 non-temporal y stores
-template <typename T, int ORDER, int TILE, int BLOCK>
+template <typename T, int ORDER, int TILE, int BLOCK, bool TRACE = false>
 __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restrict__ blocks,
                                                                   const aoclsparse_int *__restrict__ row_ptr,
                                                                   const aoclsparse_int *__restrict__ col,
@@ -144,8 +144,10 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restr
     constexpr int MAXROWS = spmv_maxrows(TILE); // planner guarantees rows <= MAXROWS
     // diagnostic (AOCLSPARSE_MI355_SPMV_TRACE, tools/spmv_trace.py): 100 MHz stamps per workgroup, kept in registers and
     // stored by thread 0 at the very end -- start / block table read / tile in LDS / after the barrier / rows reduced
+    // (a template parameter, not a run-time test: with "if(trace)" around the stamps the product kernel was 6 % slower on
+    // the 4096^2 Laplacian, 0.288 vs 0.272 ms, although no stamp was ever taken)
     unsigned long long t_st[4] = {0, 0, 0, 0};
-    if(trace)
+    if constexpr(TRACE)
         t_st[0] = __builtin_amdgcn_s_memrealtime();
     __shared__ __attribute__((aligned(16))) T s_val[TILE + 4];
     __shared__ __attribute__((aligned(16))) T s_x[TILE + 4];
@@ -153,6 +155,7 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restr
     using P2          = typename pair_of<T>::type;
     constexpr int L   = lanes_of<ORDER>::value;
     const int     tid = threadIdx.x;
+    const T      *xb  = x - base; // gathers take the raw column values (the base is folded into the pointer once)
     // XCD-aware order: workgroups with equal blockIdx%8 share an XCD (one L2); give each XCD a
     // contiguous eighth of the row blocks so its x windows stay in its own L2.
     const int b = (flags & 4) ? (blockIdx.x & 7) * chunk + (blockIdx.x >> 3) : (int)blockIdx.x;
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restr
         const int2 e0 = blocks[b], e1 = blocks[b + 1];
         r0 = e0.x, p0 = e0.y, nrows = e1.x - r0, cnt = e1.y - p0;
     }
-    if(trace)
+    if constexpr(TRACE)
         t_st[1] = __builtin_amdgcn_readfirstlane(cnt) >= 0 ? __builtin_amdgcn_s_memrealtime() : 0;
 
     if(cnt <= TILE)
@@ -207,17 +210,17 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restr
                         s_val[i + 2] = vq.z;
                         s_val[i + 3] = vq.w;
                     }
-                    s_x[i]     = x[c.x - base];
-                    s_x[i + 1] = x[c.y - base];
-                    s_x[i + 2] = x[c.z - base];
-                    s_x[i + 3] = x[c.w - base];
+                    s_x[i]     = xb[c.x];
+                    s_x[i + 1] = xb[c.y];
+                    s_x[i + 2] = xb[c.z];
+                    s_x[i + 3] = xb[c.w];
                 }
                 else
                 {
                     for(int q = i; q < cntw && q < i + 4; q++)
                     {
                         s_val[q] = val[w0 + q];
-                        s_x[q]   = x[col[w0 + q] - base];
+                        s_x[q]   = xb[col[w0 + q]];
                     }
                 }
             }
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restr
             if(tid < 3 && TILE + tid < cntw)
             {
                 s_val[TILE + tid] = val[w0 + TILE + tid];
-                s_x[TILE + tid]   = x[col[w0 + TILE + tid] - base];
+                s_x[TILE + tid]   = xb[col[w0 + TILE + tid]];
             }
         }
         else
@@ -237,14 +240,14 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restr
                 if(i < cntw)
                 {
                     s_val[i] = val[w0 + i];
-                    s_x[i]   = x[col[w0 + i] - base];
+                    s_x[i]   = xb[col[w0 + i]];
                 }
             }
         }
-        if(trace)
+        if constexpr(TRACE)
             t_st[2] = __builtin_amdgcn_s_memrealtime();
         __syncthreads();
-        if(trace)
+        if constexpr(TRACE)
             t_st[3] = __builtin_amdgcn_s_memrealtime();
         // ---- phase 2: per-row reduction in the reference order -----------------------------------------
         const int grp  = tid / L;
@@ -323,7 +326,15 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restr
                         acc = dev_fma(a8[q], b8[q], acc);
                     j += 8;
                 }
-                if(j < e) // the last 1..7 entries: one clamped batch
+                if(flags & 16)
+                {
+                    // a matrix whose rows ALL have <= 8 entries (a stencil: this kernel then streams at HBM speed and the
+                    // reduction hides behind other workgroups' loads): the plain loop; the clamped batch below reads 14 LDS
+                    // words for a 5-entry row instead of 10 and cost the 4096^2 Laplacian 6 % (0.285 vs 0.268 ms)
+                    for(; j < e; j++)
+                        acc = dev_fma(s_val[j], s_x[j], acc);
+                }
+                else if(j < e) // the last 1..7 entries: one clamped batch
                 {
                     T a[7], b[7];
 #pragma unroll
@@ -375,7 +386,7 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restr
                     if(i < tn)
                     {
                         s_val[i] = val[p0 + t0 + i];
-                        s_x[i]   = x[col[p0 + t0 + i] - base];
+                        s_x[i]   = xb[col[p0 + t0 + i]];
                     }
                 }
                 __syncthreads();
@@ -393,7 +404,7 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restr
                     if(nfull == 0)
                         res = T(0);
                     for(int j = nfull; j < n; j++)
-                        res = dev_fma(val[p0 + j], x[col[p0 + j] - base], res);
+                        res = dev_fma(val[p0 + j], xb[col[p0 + j]], res);
                     y[r0] = finish(res, alpha, beta, &y[r0]);
                 }
             }
@@ -411,22 +422,22 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restr
                 int c[8];
 #pragma unroll
                 for(int q = 0; q < 8; q++)
-                    a[q] = val[p0 + j + q * BLOCK], c[q] = col[p0 + j + q * BLOCK] - base;
+                    a[q] = val[p0 + j + q * BLOCK], c[q] = col[p0 + j + q * BLOCK];
 #pragma unroll
                 for(int q = 0; q < 8; q++)
-                    xv[q] = x[c[q]];
+                    xv[q] = xb[c[q]];
 #pragma unroll
                 for(int q = 0; q < 8; q++)
                     acc = dev_fma(a[q], xv[q], acc);
             }
             for(; j < n; j += BLOCK)
-                acc = dev_fma(val[p0 + j], x[col[p0 + j] - base], acc);
+                acc = dev_fma(val[p0 + j], xb[col[p0 + j]], acc);
             T res = block_sum<T, BLOCK>(acc, s_val);
             if(tid == 0)
                 y[r0] = finish(res, alpha, beta, &y[r0]);
         }
     }
-    if(trace && tid == 0)
+    if(TRACE && tid == 0)
     {
         unsigned long long *tr = trace + 8 * (size_t)b;
         tr[0] = t_st[0], tr[1] = t_st[1], tr[2] = t_st[2], tr[3] = t_st[3], tr[4] = __builtin_amdgcn_s_memrealtime();
@@ -517,9 +528,22 @@ static void launch_inst(hipStream_t s, int flags, int base, T alpha, const T *va
     unsigned long long *trace      = nullptr;
     if(trace_path && hipMalloc(&trace, sizeof(unsigned long long) * 8 * (size_t)nblocks) != hipSuccess)
         trace = nullptr;
-    hipLaunchKernelGGL((csr_adaptive_kernel<T, ORDER, TILE, BLOCK>), dim3(grid), dim3(BLOCK), 0, s,
-                       reinterpret_cast<const int2 *>(blocks), row_ptr, col, val, x, y, alpha, beta, base,
-                       (int)nblocks, chunk, flags, trace, reinterpret_cast<const int4 *>(blocks4));
+    if constexpr(ORDER == 0) // the traced build exists for the scalar order only
+    {
+        if(trace)
+            hipLaunchKernelGGL((csr_adaptive_kernel<T, ORDER, TILE, BLOCK, true>), dim3(grid), dim3(BLOCK), 0, s,
+                               reinterpret_cast<const int2 *>(blocks), row_ptr, col, val, x, y, alpha, beta, base,
+                               (int)nblocks, chunk, flags, trace, reinterpret_cast<const int4 *>(blocks4));
+    }
+    else if(trace)
+    {
+        (void)hipFree(trace);
+        trace = nullptr;
+    }
+    if(!(ORDER == 0 && trace))
+        hipLaunchKernelGGL((csr_adaptive_kernel<T, ORDER, TILE, BLOCK>), dim3(grid), dim3(BLOCK), 0, s,
+                           reinterpret_cast<const int2 *>(blocks), row_ptr, col, val, x, y, alpha, beta, base,
+                           (int)nblocks, chunk, flags, (unsigned long long *)nullptr, reinterpret_cast<const int4 *>(blocks4));
     if(trace)
     {
         std::vector<unsigned long long> host(8 * (size_t)nblocks);
@@ -539,7 +563,8 @@ template <typename T>
 aoclsparse_status launch_csrmv(hipStream_t s, int order, bool strict, int tile, int base, T alpha,
                                aoclsparse_int m, const T *val, const aoclsparse_int *col,
                                const aoclsparse_int *row_ptr, const aoclsparse_int *blocks,
-                               aoclsparse_int nblocks, const T *x, T beta, T *y, const aoclsparse_int *blocks4)
+                               aoclsparse_int nblocks, const T *x, T beta, T *y, const aoclsparse_int *blocks4,
+                               aoclsparse_int max_row_nnz)
 {
     if(m <= 0 || nblocks <= 0)
         return aoclsparse_status_success;
@@ -552,6 +577,8 @@ aoclsparse_status launch_csrmv(hipStream_t s, int order, bool strict, int tile, 
         flags |= 4;
     if((size_t)m * sizeof(T) > (size_t)32 << 20)
         flags |= 8;
+    if(max_row_nnz <= 8)
+        flags |= 16; // every row is short: the entry-by-entry reduction (see the kernel)
     const int tsel = tile == 512 ? 0 : (tile == 1024 ? 1 : (tile == 2048 ? 2 : -1));
     if(tsel < 0 || order < 0 || order > 2)
         return aoclsparse_status_invalid_kid;
@@ -665,7 +692,7 @@ aoclsparse_status launch_strided_scatter(hipStream_t s, const T *src, aoclsparse
     template aoclsparse_status launch_csrmv<T>(hipStream_t, int, bool, int, int, T, aoclsparse_int, const T *, \
                                                const aoclsparse_int *, const aoclsparse_int *,                  \
                                                const aoclsparse_int *, aoclsparse_int, const T *, T, T *,       \
-                                               const aoclsparse_int *);                                         \
+                                               const aoclsparse_int *, aoclsparse_int);                         \
     template aoclsparse_status launch_scale<T>(hipStream_t, T *, aoclsparse_int, T);                           \
     template aoclsparse_status launch_waxpby<T>(hipStream_t, aoclsparse_int, T, const T *, T, const T *, T *); \
     template aoclsparse_status launch_dot<T>(hipStream_t, aoclsparse_int, const T *, const T *, T *, T *);     \

@@ -567,7 +567,7 @@ constexpr int trsv_blk_slots(int bs, int ext)
     return (sl / 2) % 2 ? sl : sl + 2;
 }
 
-template <typename T, int BS, int EXT, bool FRONT>
+template <typename T, int BS, int EXT, bool FRONT, bool TRACE = false>
 __global__ __launch_bounds__(64) void trsv_block_kernel(
     aoclsparse_int m, aoclsparse_int nslices, const aoclsparse_int *__restrict__ slices,
     const aoclsparse_int *__restrict__ bfirst, const aoclsparse_int *__restrict__ rowmap,
@@ -585,8 +585,7 @@ __global__ __launch_bounds__(64) void trsv_block_kernel(
     const int spare = m * (nrhs - col);
     ticket += col, level_done += (size_t)col * nlevels;
     b += col * b_off, x += col * x_off, xp += (size_t)col * m;
-    if(col)
-        trace = nullptr;
+    const bool tracing = TRACE && col == 0; // (a template parameter: run-time tests around the stamps cost the SpMV kernel 6 %)
     constexpr int BSP = BS + (BS & 1), SLOTS = trsv_blk_slots(BS, EXT), INT0 = BS * EXT; // internal values from slot INT0
     extern __shared__ unsigned char s_raw[];
     T            *s_mine = reinterpret_cast<T *>(s_raw) + (size_t)threadIdx.x * SLOTS;
@@ -599,7 +598,7 @@ __global__ __launch_bounds__(64) void trsv_block_kernel(
         return;
     // (diagnostic stamps are kept in registers and stored at the very end: a store right after the wait would put its own
     // round trip into the phase it is timing)
-    const unsigned long long t_start = trace ? __builtin_amdgcn_s_memrealtime() : 0;
+    const unsigned long long t_start = TRACE ? __builtin_amdgcn_s_memrealtime() : 0;
     const int lev = slices[nslices + 1 + sl]; // block level of this slice
     const int bl  = slices[sl] + tid;
     // lanes beyond the slice own an empty block (c = 0): they run the same straight-line code and publish nothing
@@ -720,7 +719,7 @@ __global__ __launch_bounds__(64) void trsv_block_kernel(
                 bits[e] = __hip_atomic_load(&xb[q[e]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         tick(127u);
     }
-    const unsigned long long t_ready = trace ? __builtin_amdgcn_s_memrealtime() : 0;
+    const unsigned long long t_ready = TRACE ? __builtin_amdgcn_s_memrealtime() : 0;
     // ---- from here on every instruction is on the critical path of the solve ----
     T xe[EXT];
 #pragma unroll
@@ -786,7 +785,7 @@ __global__ __launch_bounds__(64) void trsv_block_kernel(
     unsigned long long t_lds = 0, t_ext = 0;
     if constexpr(IN_REGS)
     {
-        t_lds = trace ? __builtin_amdgcn_s_memrealtime() : 0;
+        t_lds = TRACE ? __builtin_amdgcn_s_memrealtime() : 0;
         auto put = [&](int a) {
             B out;
             __builtin_memcpy(&out, &xi[a], sizeof(T));
@@ -834,7 +833,7 @@ __global__ __launch_bounds__(64) void trsv_block_kernel(
                 for(int a = 0; a < BS; a++)
                     xi[a] = neg_fma(ve[a][e], xe[e], xi[a]);
             long_row_tail(xi[0]);
-            if(trace)
+            if constexpr(TRACE)
             {
                 lds_read_landed(xi[BS - 1]);
                 t_ext = __builtin_amdgcn_s_memrealtime();
@@ -909,7 +908,7 @@ __global__ __launch_bounds__(64) void trsv_block_kernel(
             publish(a, xi[a]);
         }
     }
-    if(trace && tid == 0)
+    if(tracing && tid == 0)
     {
         unsigned long long *tr = trace + 6 * (size_t)sl;
         tr[0] = t_start, tr[1] = t_ready, tr[2] = __builtin_amdgcn_s_memrealtime(), tr[3] = (unsigned long long)lev;
@@ -986,7 +985,8 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
         // dependencies were all in, at the end, the slice's block level, after the LDS reads, after the external FMAs (6 x u64 per slice; tools/trsv_trace.py)
         static const char  *trace_path = getenv("AOCLSPARSE_MI355_TRSV_TRACE");
         unsigned long long *trace      = nullptr;
-        if(trace_path && hipMalloc(&trace, sizeof(unsigned long long) * 6 * (size_t)bp.nslices) != hipSuccess)
+        if(trace_path && std::is_same<T, double>::value
+           && hipMalloc(&trace, sizeof(unsigned long long) * 6 * (size_t)bp.nslices) != hipSuccess)
             trace = nullptr;
         auto go_form = [&](auto bs_tag, auto ext_tag, auto front_tag) {
             constexpr int    BS = decltype(bs_tag)::value, EXT = decltype(ext_tag)::value;
@@ -1004,11 +1004,24 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
                     return aoclsparse_status_internal_error;
             }
             const dim3 grid = nrhs > 1 ? dim3((unsigned)nrhs, (unsigned)bp.nslices) : dim3((unsigned)bp.nslices);
-            hipLaunchKernelGGL((trsv_block_kernel<T, BS, EXT, FRONT>), grid, dim3(64), lds, s, m, bp.nslices,
-                               bp.slices.as<aoclsparse_int>(), bp.bfirst.as<aoclsparse_int>(), bp.rowmap.as<aoclsparse_int>(),
-                               bp.pptr.as<aoclsparse_int>(), bp.pind.as<aoclsparse_int>(), bp.pval.as<T>(), diag, b, xp, x,
-                               alpha, (int)unit, scratch, timeout_word ? timeout_word : scratch + nrhs, (int)incb, (int)incx,
-                               trace, scratch + nrhs + 1, gate, (int)nrhs, b_off, x_off, (int)bp.nlevels);
+#define MI355_BLK_ARGS                                                                                                       \
+    m, bp.nslices, bp.slices.as<aoclsparse_int>(), bp.bfirst.as<aoclsparse_int>(), bp.rowmap.as<aoclsparse_int>(),              \
+        bp.pptr.as<aoclsparse_int>(), bp.pind.as<aoclsparse_int>(), bp.pval.as<T>(), diag, b, xp, x, alpha, (int)unit, scratch,   \
+        timeout_word ? timeout_word : scratch + nrhs, (int)incb, (int)incx, trace, scratch + nrhs + 1, gate, (int)nrhs, b_off,     \
+        x_off, (int)bp.nlevels
+            if constexpr(std::is_same<T, double>::value) // the traced build exists for double only
+            {
+                if(trace)
+                {
+                    if(lds > 64 * 1024)
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&trsv_block_kernel<T, BS, EXT, FRONT, true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    hipLaunchKernelGGL((trsv_block_kernel<T, BS, EXT, FRONT, true>), grid, dim3(64), lds, s, MI355_BLK_ARGS);
+                    return aoclsparse_status_success;
+                }
+            }
+            hipLaunchKernelGGL((trsv_block_kernel<T, BS, EXT, FRONT>), grid, dim3(64), lds, s, MI355_BLK_ARGS);
+#undef MI355_BLK_ARGS
             return aoclsparse_status_success;
         };
         auto go = [&](auto bs_tag, auto ext_tag) {
