@@ -659,6 +659,10 @@ template <typename T>
 aoclsparse_status launch_ilu0_level(hipStream_t s, int base, aoclsparse_int nrows, const aoclsparse_int *rows,
                                     const aoclsparse_int *row_ptr, const aoclsparse_int *col, T *val,
                                     aoclsparse_int *diag, int maxlen, int *error);
+template <typename T>
+aoclsparse_status launch_ilu0_syncfree(hipStream_t s, int base, aoclsparse_int n, const aoclsparse_int *rows,
+                                       const aoclsparse_int *row_ptr, const aoclsparse_int *col, T *val, aoclsparse_int *diag,
+                                       int maxlen, int *error, unsigned int *ticket);
 
 // dense-vector steps of the iterative solvers (itsol_kernels.hip); `partial` holds
 // vec_reduce_scratch_elems(k) elements, reduction results land in device memory

@@ -413,10 +413,35 @@ aoclsparse_status ilu0_factorize(aoclsparse_matrix A, T *host_val)
     // the factor starts from the values captured by ilu_prepare (the matrix at hint/optimize time)
     MI355_HIP_TRY(hipMemcpyAsync(dval.ptr, host_val, sizeof(T) * (size_t)nnz, hipMemcpyHostToDevice, rt.stream()));
     MI355_HIP_TRY(hipMemsetAsync(derr.ptr, 0, sizeof(int), rt.stream()));
-    for(aoclsparse_int l = 0; l < nlev; l++)
-        MI355_TRY(launch_ilu0_level<T>(rt.stream(), base, lptr[l + 1] - lptr[l], drows.as<aoclsparse_int>() + lptr[l],
-                                       dcsr->ptr.as<aoclsparse_int>(), dcsr->ind.as<aoclsparse_int>(), dval.as<T>(),
-                                       ddiag.as<aoclsparse_int>(), (int)maxlen, derr.as<int>()));
+    // real types, deep DAGs: one sync-free launch (rows wait for the rows they need; ilu_kernels.hip) instead of one launch per
+    // level -- 5,505 launches cost 390 ms on the shell-like stand-in, the sync-free launch 139 ms; with two lower entries per row
+    // (2-D Laplacian) the launches win, 20 vs 44 ms.  AOCLSPARSE_MI355_ILU_SYNCFREE=0 keeps the launches.
+    static const bool sf_off = [] {
+        const char *e = getenv("AOCLSPARSE_MI355_ILU_SYNCFREE");
+        return e && atoi(e) == 0;
+    }();
+    bool syncfree = false;
+    if constexpr(std::is_floating_point<T>::value)
+        syncfree = !sf_off && nlev > 8 && (long long)nnz >= 16LL * n; // (short rows: a level's launch is cheaper than its hops)
+    if(syncfree)
+    {
+        if constexpr(std::is_floating_point<T>::value)
+        {
+            DeviceBuffer dticket;
+            MI355_TRY(dticket.alloc(sizeof(unsigned int)));
+            MI355_HIP_TRY(hipMemsetAsync(dticket.ptr, 0, sizeof(unsigned int), rt.stream()));
+            MI355_HIP_TRY(hipMemsetAsync(ddiag.ptr, 0xFF, sizeof(aoclsparse_int) * (size_t)n, rt.stream())); // -1: not finished
+            MI355_TRY(launch_ilu0_syncfree<T>(rt.stream(), base, n, drows.as<aoclsparse_int>(), dcsr->ptr.as<aoclsparse_int>(),
+                                              dcsr->ind.as<aoclsparse_int>(), dval.as<T>(), ddiag.as<aoclsparse_int>(),
+                                              (int)maxlen, derr.as<int>(), dticket.as<unsigned int>()));
+            MI355_HIP_TRY(hipStreamSynchronize(rt.stream())); // dticket goes out of scope
+        }
+    }
+    else
+        for(aoclsparse_int l = 0; l < nlev; l++)
+            MI355_TRY(launch_ilu0_level<T>(rt.stream(), base, lptr[l + 1] - lptr[l], drows.as<aoclsparse_int>() + lptr[l],
+                                           dcsr->ptr.as<aoclsparse_int>(), dcsr->ind.as<aoclsparse_int>(), dval.as<T>(),
+                                           ddiag.as<aoclsparse_int>(), (int)maxlen, derr.as<int>()));
     int err = 0;
     MI355_HIP_TRY(hipMemcpyAsync(&err, derr.ptr, sizeof(int), hipMemcpyDeviceToHost, rt.stream()));
     MI355_HIP_TRY(hipMemcpyAsync(host_val, dval.ptr, sizeof(T) * (size_t)nnz, hipMemcpyDeviceToHost, rt.stream()));

@@ -1147,6 +1147,62 @@ def test_ilu_smoother_matches_reference_factorisation_and_solve(base):
                                       P._ptr(x), P._ptr(b)) == 1
 
 
+@pytest.mark.parametrize("base", [0, 1])
+def test_ilu_smoother_sync_free_factorisation_long_rows(base):
+    """matrices with >= 16 entries per row are factorised in ONE sync-free launch (rows wait for the rows they need through
+    their diagonal-position word): factors bit-identical to the serial IKJ loop, both precisions; a zero pivot fails the
+    call (and every row that depends on the failed one) instead of hanging"""
+    from test_gpu_trsv_blocks import node_mesh
+    nodes = 1800
+    m, rp, ci, v = node_mesh(81, nodes, 36, np.full(nodes, 5), keep=0.95)
+    assert len(v) >= 16 * m
+    rp, ci = rp + base, ci + base
+    d = P.Descr(base=base)
+    rng = np.random.default_rng(82)
+    st, lu, diag = oracle.dilu0(m, base, rp, ci, v)
+    assert st == 0
+    A = P.Matrix(base, m, m, rp, ci, v)
+    pv = ctypes.c_void_p()
+    b, x = rng.uniform(-1, 1, m), np.zeros(m)
+    assert L.aoclsparse_dilu_smoother(P.OP_NONE, A.h, d.h, ctypes.byref(pv), None, P._ptr(x), P._ptr(b)) == 0
+    fac = np.ctypeslib.as_array(ctypes.cast(pv, ctypes.POINTER(ctypes.c_double)), (len(v),))
+    assert np.array_equal(fac, lu)
+    st, xr = oracle.dilu_solve(m, base, diag, lu, rp, ci, b)
+    assert st == 0 and np.array_equal(x, xr)
+    # float
+    vf = v.astype(np.float32)
+    Af = P.Matrix(base, m, m, rp, ci, vf)
+    pf = ctypes.c_void_p()
+    xf = np.zeros(m, np.float32)
+    assert L.aoclsparse_silu_smoother(P.OP_NONE, Af.h, d.h, ctypes.byref(pf), None, P._ptr(xf), P._ptr(b.astype(np.float32))) == 0
+    facf = np.ctypeslib.as_array(ctypes.cast(pf, ctypes.POINTER(ctypes.c_float)), (len(v),)).copy()
+    lu32 = vf.copy()  # serial IKJ in fp32 (the reference's loop, ilu0.hpp:34-111), first 400 rows
+    pos = [dict((int(c), int(p)) for p, c in zip(range(rp[i] - base, rp[i + 1] - base), ci[rp[i] - base:rp[i + 1] - base] - base)) for i in range(400)]
+    dg = {}
+    for i in range(400):
+        for p in range(rp[i] - base, rp[i + 1] - base):
+            k = int(ci[p] - base)
+            if k >= i:
+                break
+            lik = np.float32(lu32[p] / lu32[dg[k]])
+            lu32[p] = lik
+            for q in range(dg[k] + 1, rp[k + 1] - base):
+                w = pos[i].get(int(ci[q] - base))
+                if w is not None:
+                    lu32[w] = np.float32(np.float64(lu32[w]) - np.float64(lik) * np.float64(lu32[q]))  # = fmaf: exact product, one rounding
+        dg[i] = pos[i][i]
+    n400 = rp[400] - base
+    assert np.array_equal(facf[:n400], lu32[:n400])
+    # a zero pivot in row 0 (nothing updates it before it is used): numerical error, no hang
+    vz = v.copy()
+    for p in range(rp[0] - base, rp[1] - base):
+        if ci[p] - base == 0:
+            vz[p] = 0.0
+    assert oracle.dilu0(m, base, rp, ci, vz)[0] != 0
+    Az = P.Matrix(base, m, m, rp, ci, vz)
+    assert L.aoclsparse_dilu_smoother(P.OP_NONE, Az.h, d.h, ctypes.byref(pv), None, P._ptr(x), P._ptr(b)) == 11  # numerical_error
+
+
 # --------------------------------------------------------------------------------------------------
 # ELL family (SURVEY 8f rank 1)
 # --------------------------------------------------------------------------------------------------

@@ -1,5 +1,2 @@
 #!/bin/bash
-mkdir -p gpurun_out
-{
-AOCLSPARSE_MI355_TIMING=1 timeout 600 python tools/exp_ilu.py
-} 2>&1 | grep -v amdgpu.ids | tee gpurun_out/ilu_exp.txt
+timeout 900 python -m pytest tests/ -x -q -m gpu -k "ilu or itsol or smoother or gmres or cg" 2>&1 | tail -12
