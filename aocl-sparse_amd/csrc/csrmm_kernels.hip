@@ -1159,7 +1159,7 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
             else
                 go(std::integral_constant<int, CSRMM_GROUP>{});
         }
-        else if(vec && n >= 128 && row_runs)
+        else if(vec && n >= 128 && row_runs && !readc) // (beta != 0: the row-per-wave kernel is faster, 1.19 vs 1.35 ms)
         {
             constexpr int RUN = 8;
             const int     gx  = grid_x((m + 4 * RUN - 1) / (4 * RUN), chunk);
