@@ -198,21 +198,48 @@ __global__ __launch_bounds__(256) void csrmm_row_run_kernel(int base, T alpha, a
 #pragma unroll
     for(int k = 0; k < 8; k++)
         pc[k] = INT_MIN, pb[k].x = T(0), pb[k].y = T(0);
-    // (fully unrolled on purpose: the scalar loads of row r + 1 -- row_ptr, columns, values -- can then be issued while row r's
-    // B rows are in flight; as a rolled loop this kernel was SLOWER than the row-per-wave one, 1.07 vs 0.985 ms)
+    // The block's row pointers in one go, and -- when the block is whole and its last row is at least 8 entries away from the
+    // end of the arrays -- every row's 8 column indices and values as WIDE scalar loads (entries beyond the row belong to the
+    // next rows: read, never used), those of row r + 1 requested before row r's B rows.  Before: two dword loads for the row
+    // pointers, then 8 + 8 clamped single loads per row, each row's only after the previous row was stored.
+    int        rp[R + 1];
+    const int  pend = row_ptr[m];
+    const bool whole = i0 + R <= m;
+#pragma unroll
+    for(int r = 0; r <= R; r++)
+        rp[r] = whole ? row_ptr[i0 + r] : row_ptr[min(i0 + r, m)];
+    const bool fast = whole && rp[R] + 8 <= pend; // wave-uniform
+    int        cn[8]; // (the column indices run one row ahead -- they gate the B-row loads; the values are needed at the
+                      // FMAs only and are requested at the start of their own row: both a row ahead spilled 76 SGPRs)
+    if(fast)
+    {
+#pragma unroll
+        for(int k = 0; k < 8; k++)
+            cn[k] = col[rp[0] + k];
+    }
+    // (fully unrolled on purpose; as a rolled loop this kernel was SLOWER than the row-per-wave one, 1.07 vs 0.985 ms)
 #pragma clang loop unroll(full)
     for(int r = 0; r < R; r++)
     {
         const int  i    = i0 + r;
         const bool live = i < m; // wave-uniform
-        const int  ic   = live ? i : m - 1;
-        const int  s = row_ptr[ic], len = live ? row_ptr[ic + 1] - s : 0;
-        T         a0 = T(0), a1 = T(0);
-        if(len <= 8)
+        const int  s = rp[r], len = live ? rp[r + 1] - s : 0;
+        int        c[8];
+        T          v[8];
+        if(fast)
         {
-            int c[8];
-            T   v[8];
-            V   b[8];
+#pragma unroll
+            for(int k = 0; k < 8; k++)
+                c[k] = cn[k], v[k] = val[s + k];
+            if(r + 1 < R)
+            {
+#pragma unroll
+                for(int k = 0; k < 8; k++)
+                    cn[k] = col[rp[r + 1] + k];
+            }
+        }
+        else if(len <= 8)
+        {
 #pragma unroll
             for(int k = 0; k < 8; k++)
             {
@@ -220,6 +247,11 @@ __global__ __launch_bounds__(256) void csrmm_row_run_kernel(int base, T alpha, a
                 c[k]        = len > 0 ? col[q] : INT_MIN + 1;
                 v[k]        = len > 0 ? val[q] : T(0);
             }
+        }
+        T         a0 = T(0), a1 = T(0);
+        if(len <= 8)
+        {
+            V b[8];
             // (Tried: request every entry that cannot reuse a register first, copy the reused ones afterwards, so that a row's
             // loads are all in flight together -- the compiler waits behind each conditional load as written here.  It was
             // SLOWER, 1.156 vs 0.855 ms in tools/csrmm_r2.hip: three register sets per row instead of two.)
