@@ -112,6 +112,11 @@ def roofline(abytes, ms, traffic=None, **extra):
     out = {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": int(abytes),
            "kernel_ms": round(ms, 6)}
+    if traffic:
+        # bytes the kernel really moved per launch (PMC) and the rate it moved them at: a format that stores less than the
+        # CSR model counts (SELL-64 with shared column lists) has achieved > traffic_gbs, and achieved may exceed what a copy does
+        out["traffic_gbs"] = round(traffic / (ms * 1e-3) / 1e9, 2)
+        out["traffic_over_algorithmic"] = round(traffic / abytes, 4)
     out.update(extra)
     return out
 
