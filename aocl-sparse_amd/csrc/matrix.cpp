@@ -615,7 +615,9 @@ aoclsparse_status build_sell(const aoclsparse_int *row_ptr_host, const DeviceCsr
     }();
     sp.shared = false, sp.ccells = cells;
     std::vector<long long> cptr;
-    if(st == aoclsparse_status_success && !shared_off)
+    // (not for matrices that live in the caches anyway: the leader / shift words are one more dependent load, and the 10k x 10k
+    // Laplacian of BASELINE configs[0] -- 50 k non-zeros, launch-bound -- ran at 5.4 instead of 4.6 us per call with them)
+    if(st == aoclsparse_status_success && !shared_off && d.nnz >= (1 << 17))
     {
         DeviceBuffer nl;
         st = sp.lead.alloc(sizeof(unsigned short) * (size_t)m);

@@ -391,11 +391,43 @@ def main():
         us = float(np.mean(lp)) * 1e3
         b1 = spmv_bytes(m1, m1, len(v1))
         so, yr1 = oracle.dcsrmv(-1, 0, 1.0, m1, len(v1), v1, ci1, rp1, x1.cpu().numpy(), 0.0, np.zeros(m1))
-        return {"workload": "BASELINE configs[1] literal: aoclsparse_dmv, 10k x 10k 5-pt Laplacian, nnz=%d" % len(v1),
-                "us_per_call": round(us, 3), "stats_ms": quartiles(lp), "gflops": round(2.0 * len(v1) / us / 1e3, 3),
-                "roofline": roofline(b1, us * 1e-3),
-                "bit_exact": bool(np.array_equal(y1.cpu().numpy(), yr1)),
-                "note": "795 KB problem: bound by launch latency, not HBM"}
+        exact = bool(np.array_equal(y1.cpu().numpy(), yr1))
+        out = {"workload": "BASELINE configs[1] literal: aoclsparse_dmv, 10k x 10k 5-pt Laplacian, nnz=%d" % len(v1),
+               "us_per_call": round(us, 3), "stats_ms": quartiles(lp), "gflops": round(2.0 * len(v1) / us / 1e3, 3),
+               "roofline": roofline(b1, us * 1e-3), "bit_exact": exact,
+               "note": "795 KB problem: bound by launch latency, not HBM"}
+        # the same call back to back without an event per call, and 100 of them captured once into a HIP graph on the stream
+        # handed to aoclsparse_mi355_set_stream and replayed (device-pointer calls only enqueue kernels: INTEGRATION.md)
+        try:
+            import ctypes
+            torch.cuda.synchronize()
+            pkg.timer_start()
+            for _ in range(2000):
+                pkg.dmv(pkg.OP_NONE, 1.0, A1, descr, x1, 0.0, y1)
+            out["us_per_call_back_to_back"] = round(pkg.timer_stop() / 2000 * 1e3, 3)
+            sg = torch.cuda.Stream()
+            assert L.aoclsparse_mi355_set_stream(ctypes.c_void_p(sg.cuda_stream)) == 0
+            try:
+                with torch.cuda.stream(sg):
+                    pkg.dmv(pkg.OP_NONE, 1.0, A1, descr, x1, 0.0, y1)
+                    sg.synchronize()
+                    gr = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gr, stream=sg):
+                        for _ in range(100):
+                            pkg.dmv(pkg.OP_NONE, 1.0, A1, descr, x1, 0.0, y1)
+                    gr.replay()
+                    sg.synchronize()
+                    t0g = time.perf_counter()
+                    for _ in range(20):
+                        gr.replay()
+                    sg.synchronize()
+                    out["us_per_call_in_a_hip_graph_of_100"] = round((time.perf_counter() - t0g) / 2000 * 1e6, 3)
+                    out["graph_bit_exact"] = bool(np.array_equal(y1.cpu().numpy(), yr1))
+            finally:
+                assert L.aoclsparse_mi355_set_stream(None) == 0
+        except Exception as e:  # noqa: BLE001 -- the graph figure is an extra
+            out["hip_graph_error"] = repr(e)[:200]
+        return out
 
     run_leg("l100", leg_l100)
 
