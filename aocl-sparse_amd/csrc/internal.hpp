@@ -585,7 +585,7 @@ aoclsparse_status launch_sell_fill(hipStream_t s, int pack, aoclsparse_int m, in
                                    const aoclsparse_int *col, const T *val, aoclsparse_int nslices,
                                    const long long *slice_ptr, T *sval, aoclsparse_int *scol, aoclsparse_int *rowlen,
                                    const long long *cptr = nullptr, const unsigned short *lead = nullptr);
-aoclsparse_status launch_sell_leaders(hipStream_t s, aoclsparse_int m, const aoclsparse_int *row_ptr, const aoclsparse_int *col,
+aoclsparse_status launch_sell_leaders(hipStream_t s, aoclsparse_int m, int base, const aoclsparse_int *row_ptr, const aoclsparse_int *col,
                                       aoclsparse_int nslices, unsigned short *lead, aoclsparse_int *nl);
 template <typename T>
 aoclsparse_status launch_sellmv(hipStream_t s, int order, int pack, T alpha, aoclsparse_int m, aoclsparse_int nslices,

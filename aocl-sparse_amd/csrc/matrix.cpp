@@ -624,7 +624,7 @@ aoclsparse_status build_sell(const aoclsparse_int *row_ptr_host, const DeviceCsr
         if(st == aoclsparse_status_success)
             st = nl.alloc(sizeof(aoclsparse_int) * (size_t)nslices);
         if(st == aoclsparse_status_success)
-            st = launch_sell_leaders(rt.stream(), m, d.ptr.as<aoclsparse_int>(), d.ind.as<aoclsparse_int>(), nslices,
+            st = launch_sell_leaders(rt.stream(), m, d.base, d.ptr.as<aoclsparse_int>(), d.ind.as<aoclsparse_int>(), nslices,
                                      sp.lead.as<unsigned short>(), nl.as<aoclsparse_int>());
         if(st != aoclsparse_status_success)
             return st;

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void sell_fill_kernel(aoclsparse_int m, int ba
 constexpr int       SELL_CPTR_MODE_SHIFT = 56;
 constexpr long long SELL_CPTR_MASK       = (1LL << SELL_CPTR_MODE_SHIFT) - 1;
 
-__global__ __launch_bounds__(256) void sell_leaders_kernel(aoclsparse_int m, const aoclsparse_int *__restrict__ row_ptr,
+__global__ __launch_bounds__(256) void sell_leaders_kernel(aoclsparse_int m, int base, const aoclsparse_int *__restrict__ row_ptr,
                                                            const aoclsparse_int *__restrict__ col, aoclsparse_int nslices,
                                                            unsigned short *__restrict__ follow, aoclsparse_int *__restrict__ nl)
 {
@@ -133,8 +133,8 @@ __global__ __launch_bounds__(256) void sell_leaders_kernel(aoclsparse_int m, con
         leader = lane == 0;
         if(!leader)
         {
-            const int b = row_ptr[i], len = row_ptr[i + 1] - b, bp = row_ptr[i - 1];
-            bool      same = len == b - bp, shifted = same && len > 0; // the base cancels: only differences are used
+            const int b = row_ptr[i] - base, len = row_ptr[i + 1] - base - b, bp = row_ptr[i - 1] - base;
+            bool      same = len == b - bp, shifted = same && len > 0; // (column VALUES: only differences are used)
             for(int k = 0; k < len && (same || shifted); k++)
             {
                 const int dcol = col[b + k] - col[bp + k];
@@ -465,12 +465,12 @@ aoclsparse_status launch_sellmv(hipStream_t s, int order, int pack, T alpha, aoc
     return aoclsparse_status_success;
 }
 
-aoclsparse_status launch_sell_leaders(hipStream_t s, aoclsparse_int m, const aoclsparse_int *row_ptr, const aoclsparse_int *col,
+aoclsparse_status launch_sell_leaders(hipStream_t s, aoclsparse_int m, int base, const aoclsparse_int *row_ptr, const aoclsparse_int *col,
                                       aoclsparse_int nslices, unsigned short *lead, aoclsparse_int *nl)
 {
     if(nslices <= 0)
         return aoclsparse_status_success;
-    hipLaunchKernelGGL(sell_leaders_kernel, dim3((nslices + 3) / 4), dim3(256), 0, s, m, row_ptr, col, nslices, lead, nl);
+    hipLaunchKernelGGL(sell_leaders_kernel, dim3((nslices + 3) / 4), dim3(256), 0, s, m, base, row_ptr, col, nslices, lead, nl);
     MI355_HIP_TRY(hipGetLastError());
     return aoclsparse_status_success;
 }

@@ -1433,6 +1433,25 @@ def test_sell_shared_column_lists_bit_exact(which, kid, order):
     assert np.array_equal(np.isnan(y), np.isnan(yr)) and np.array_equal(y[~np.isnan(yr)], yr[~np.isnan(yr)])
 
 
+def test_sell_shared_lists_first_entry_differs_base1():
+    """rows that repeat the previous row's list everywhere but in their FIRST entry must not be taken for followers -- with
+    the index base forgotten in the leader pass (base 1) exactly that entry was never compared"""
+    rng = np.random.default_rng(75)
+    m, n, L = 64 * 40, 5000, 12
+    tail = np.sort(rng.choice(np.arange(100, n), size=L - 1, replace=False))
+    rows = [np.concatenate([[int(rng.integers(0, 100))], tail]) for _ in range(m)]  # same tail, own first entry
+    rp = (np.arange(m + 1) * L).astype(np.int32)
+    ci = np.concatenate(rows).astype(np.int32)
+    v = rng.uniform(-1, 1, len(ci))
+    x, y0 = rng.uniform(-1, 1, n), rng.uniform(-1, 1, m)
+    for base in (0, 1):
+        A, d = _hinted(base, m, n, rp + base, ci + base, v)
+        assert A.spmv_info().kernel in (3, 4)
+        st, y = run_dmv(A, d, x, y0, 1.0, 0.0)
+        so, yr = oracle.dcsrmv(-1, 0, 1.0, m, len(v), v, ci, rp, x, 0.0, y0)
+        assert st == 0 and so == 0 and np.array_equal(y, yr), base
+
+
 def test_sell_shared_lists_float_and_transposed():
     nodes = 1500
     m, rp, ci, v = _mesh(72, nodes, 31, np.full(nodes, 4))
