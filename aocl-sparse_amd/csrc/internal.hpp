@@ -319,7 +319,9 @@ struct TrsvSegment
 constexpr int TRSV_BLK_ROWS = 8; // rows per block at most
 constexpr int TRSV_BLK_EXT  = 24; // external dependencies of a multi-row block at most
 constexpr int TRSV_BLK_NV   = 96; // entries of a multi-row block at most
-constexpr int TRSV_XP_PAD = 128; // spare elements behind the m x nrhs position-ordered solution buffer
+// spare elements behind the m x nrhs position-ordered solution buffer: [0, 64) parked tag stores, [64, 128) parked x stores
+// (one slot per lane), the last one (191) the slot that always holds 0 -- apart from the parked ones: a parked NaN must not reach it
+constexpr int TRSV_XP_PAD = 192;
 struct TrsvBlockPlan
 {
     bool           tried = false, valid = false;

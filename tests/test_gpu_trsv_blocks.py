@@ -163,6 +163,38 @@ def test_block_trsv_nan_inf_and_tag_propagate():
         assert np.array_equal(gn, rn) and np.array_equal(got[~gn], xr[~rn]) and 2 <= rn.sum() < m
 
 
+@pytest.mark.parametrize("dofs", [(1, 6), (1, 9)])
+def test_block_trsv_nan_in_one_component_stays_there(dofs):
+    """Two disconnected meshes in one matrix, levels >= 64 blocks wide (every lane of a slice owns a block), NaN / Inf in
+    the first mesh only: the second one must come out finite and bit-exact.  (Rows a lane does not own are computed as
+    0 - 0 * x like the others and their stores parked behind the solution; a parked NaN landing in the slot that absent
+    entries read as 0 would poison every block of the other mesh.)"""
+    width, nodes = 160, 160 * 90
+    rng = np.random.default_rng(dofs[1])
+    m1, rp1, ci1, v1 = node_mesh(91, nodes, width, rng.integers(dofs[0], dofs[1], size=nodes), keep=1.0)
+    m = 2 * m1
+    rp = np.concatenate([rp1, rp1[1:] + rp1[-1]]).astype(np.int32)
+    ci = np.concatenate([ci1, ci1 + m1]).astype(np.int32)
+    v = np.concatenate([v1, v1[::-1]])
+    rid = np.repeat(np.arange(m), np.diff(rp))
+    v[ci == rid] = np.abs(v[ci == rid]) + 2.0
+    o = oracle.dcsr_optimize(m, m, len(v), 0, rp, ci, v)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    for kind, fill, iend, bad in (("l", P.FILL_LOWER, o["idiag"], [0, 3]), ("u", P.FILL_UPPER, o["iurow"], [m1 - 1, m1 - 4])):
+        d = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=fill)
+        b = rng.uniform(-1, 1, m)
+        b[bad] = [np.nan, np.inf]
+        st, xr = oracle.dtrsv(kind, 1.0, m, 0, o["val"], o["ind"], o["ptr"], iend, b, False)
+        assert st == 0 and np.isfinite(xr[m1:]).all() and np.isnan(xr[:m1]).sum() > m1 // 2
+        xd = torch.zeros(m, dtype=torch.float64, device="cuda")
+        assert P.dtrsv(P.OP_NONE, 1.0, A, d, dev(b), xd) == 0
+        torch.cuda.synchronize()
+        got = xd.cpu().numpy()
+        assert np.array_equal(got[m1:], xr[m1:]), (kind, int(np.isnan(got[m1:]).sum()))
+        gn, rn = np.isnan(got), np.isnan(xr)
+        assert np.array_equal(gn, rn) and np.array_equal(got[~gn], xr[~rn])
+
+
 @pytest.mark.parametrize("order", ["column", "row"])
 def test_block_trsm_every_column_bit_exact(order):
     """several right-hand sides: one grid column per right-hand side of the block kernel (own ticket, level counters and
