@@ -283,6 +283,58 @@ aoclsparse_status detect_row_runs(const HostCsr &h, SpmvPlan &plan)
         followers += ok;
     }
     g.row_runs = followers * 2 >= (long long)h.m && longest <= 64;
+    g.band     = 0;
+    static const bool strips_off = [] {
+        const char *e = getenv("AOCLSPARSE_MI355_CSRMM_STRIPS");
+        return e && atoi(e) == 0;
+    }();
+    if(!g.row_runs || strips_off)
+        return aoclsparse_status_success;
+    // the band: the distance from the diagonal to a row's last entry that most rows share (majority vote, then a count)
+    aoclsparse_int cand = 0;
+    long long      votes = 0;
+    auto           reach = [&](aoclsparse_int i) {
+        const aoclsparse_int e = h.ptr[i + 1] - h.base;
+        return e > h.ptr[i] - h.base ? h.ind[e - 1] - h.base - i : 0;
+    };
+    for(aoclsparse_int i = 0; i < h.m; i++)
+    {
+        const aoclsparse_int d = reach(i);
+        if(votes == 0)
+            cand = d, votes = 1;
+        else
+            votes += d == cand ? 1 : -1;
+    }
+    long long same = 0;
+    for(aoclsparse_int i = 0; i < h.m; i++)
+        same += reach(i) == cand;
+    if(same * 2 < (long long)h.m || cand < 256 || (long long)cand * 4 > (long long)h.m)
+        return aoclsparse_status_success;
+    constexpr aoclsparse_int RUN = 8, STRIP_MAX = 256;
+    const aoclsparse_int     band = cand;
+    const aoclsparse_int     sw   = std::min<aoclsparse_int>(((band + 7) / 8 + RUN - 1) / RUN * RUN, STRIP_MAX);
+    const aoclsparse_int     ns   = (band + sw - 1) / sw;
+    const aoclsparse_int     nb   = (h.m + RUN - 1) / RUN;
+    try
+    {
+        // blocks in (strip, row) order: a counting sort by strip keeps the row order inside a strip
+        std::vector<aoclsparse_int> first((size_t)ns + 1, 0), order((size_t)nb);
+        for(aoclsparse_int b = 0; b < nb; b++)
+            first[(size_t)((b * RUN) % band / sw) + 1]++;
+        for(aoclsparse_int k = 0; k < ns; k++)
+            first[(size_t)k + 1] += first[(size_t)k];
+        for(aoclsparse_int b = 0; b < nb; b++)
+            order[(size_t)first[(size_t)((b * RUN) % band / sw)]++] = b * RUN;
+        const aoclsparse_status st
+            = g.run_order.upload(order.data(), sizeof(aoclsparse_int) * order.size(), Runtime::get().stream());
+        if(st != aoclsparse_status_success)
+            return st;
+    }
+    catch(const std::bad_alloc &)
+    {
+        return aoclsparse_status_memory_error;
+    }
+    g.band = band;
     return aoclsparse_status_success;
 }
 
@@ -539,7 +591,8 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
             st = launch_csrmm<T>(rt.stream(), order, d->base, alpha, d->m, d->n, d->val.as<T>(),
                                  d->ind.as<aoclsparse_int>(), d->ptr.as<aoclsparse_int>(), static_cast<const T *>(dB),
                                  n, ldb, beta, static_cast<T *>(dC), ldc, colmaj ? nullptr : grp, colmaj ? 0 : ngrp,
-                                 grouped ? p->mm.max_rows : 0, !colmaj && p && p->mm.row_runs);
+                                 grouped ? p->mm.max_rows : 0, !colmaj && p && p->mm.row_runs,
+                                 !colmaj && p && p->mm.row_runs && p->mm.band > 0 ? p->mm.run_order.as<aoclsparse_int>() : nullptr);
     }
     return st == aoclsparse_status_success ? finish() : st;
 }

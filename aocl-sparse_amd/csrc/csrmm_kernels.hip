@@ -180,15 +180,18 @@ __global__ __launch_bounds__(256) void csrmm_row_run_kernel(int base, T alpha, a
                                                             const aoclsparse_int *__restrict__ row_ptr,
                                                             const T *__restrict__ B, aoclsparse_int n,
                                                             aoclsparse_int ldb, T beta, T *__restrict__ C,
-                                                            aoclsparse_int ldc, bool readc, int xcd_chunk)
+                                                            aoclsparse_int ldc, bool readc, int xcd_chunk,
+                                                            const aoclsparse_int *__restrict__ order)
 {
     using V      = typename vec2<T>::type;
     const int w  = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const int i0 = (bx * 4 + w) * R;
     const int j  = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
-    if(i0 >= m || j >= n)
+    if((bx * 4 + w) * R >= m || j >= n)
         return;
+    // `order` (optional): the R-row blocks in the order the analysis wants them walked (MmGroups::run_order: strips of a
+    // banded matrix, so that the B rows a block shares with the blocks one band above / below are still in this XCD's L2)
+    const int i0 = order ? order[bx * 4 + w] : (bx * 4 + w) * R;
     // The index base is folded into the pointers once (col / val are indexed with the raw row_ptr values, B rows with the raw
     // column values): with "- base" inside the loop this kernel lost 13 % (0.957 vs 0.842 ms in tools/csrmm_r2.hip, RR1 vs RR).
     col -= base, val -= base;
@@ -1107,7 +1110,7 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
                                aoclsparse_int /*k*/, const T *val, const aoclsparse_int *col,
                                const aoclsparse_int *row_ptr, const T *B, aoclsparse_int n,
                                aoclsparse_int ldb, T beta, T *C, aoclsparse_int ldc, const aoclsparse_int *grp,
-                               aoclsparse_int ngroups, int group_rows, bool row_runs)
+                               aoclsparse_int ngroups, int group_rows, bool row_runs, const aoclsparse_int *run_order)
 {
     if(m <= 0 || n <= 0)
         return aoclsparse_status_success;
@@ -1191,12 +1194,12 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
             else
                 go(std::integral_constant<int, CSRMM_GROUP>{});
         }
-        else if(vec && n >= 128 && row_runs && !readc) // (beta != 0: the row-per-wave kernel is faster, 1.19 vs 1.35 ms)
+        else if(vec && n >= 128 && row_runs && !readc) // (beta != 0: the row-per-wave kernel is faster, 1.17 vs 1.18 ms, 1.26 in strip order)
         {
             constexpr int RUN = 8;
             const int     gx  = grid_x((m + 4 * RUN - 1) / (4 * RUN), chunk);
             hipLaunchKernelGGL((csrmm_row_run_kernel<T, RUN>), dim3(gx, (n + 127) / 128), dim3(256), 0, s, base, alpha,
-                               m, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk);
+                               m, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk, run_order);
         }
         else if(vec && n >= 128)
         {
@@ -1391,7 +1394,7 @@ aoclsparse_status launch_csrmm_super(hipStream_t s, int base, T alpha, aoclspars
                                                aoclsparse_int, const T *, const aoclsparse_int *,             \
                                                const aoclsparse_int *, const T *, aoclsparse_int,             \
                                                aoclsparse_int, T, T *, aoclsparse_int, const aoclsparse_int *, \
-                                               aoclsparse_int, int, bool);                                    \
+                                               aoclsparse_int, int, bool, const aoclsparse_int *);            \
     template aoclsparse_status launch_scale_dense<T>(hipStream_t, aoclsparse_order, T *, aoclsparse_int,     \
                                                      aoclsparse_int, aoclsparse_int, T);                     \
     template aoclsparse_status launch_relayout<T>(hipStream_t, bool, const T *, T *, aoclsparse_int,         \

@@ -168,10 +168,22 @@ __global__ __launch_bounds__(64) void ilu0_syncfree_kernel(int base, aoclsparse_
         // relaxed polls (an acquire load invalidates the L1 on every look: with thousands of resident wavefronts polling,
         // the first version ran at 2.4 s); row k's values are read with agent-scope loads below, after the flag was seen
         int dk = __hip_atomic_load(&diag[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (rows take their tickets in level order, so the row waited for is always running or finished; the wall-clock
+        // bound -- 5 s of the 100 MHz clock -- only turns a lost device into an error instead of a hang)
+        unsigned int       spins = 0;
+        unsigned long long t0    = 0;
         while(dk == -1)
         {
             __builtin_amdgcn_s_sleep(2);
             dk = __hip_atomic_load(&diag[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if((++spins & 1023u) == 0)
+            {
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                if(t0 == 0)
+                    t0 = now;
+                else if(now - t0 > 500000000ull)
+                    dk = -2;
+            }
         }
         if(dk < 0) // row k failed
         {

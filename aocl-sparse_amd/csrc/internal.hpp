@@ -244,6 +244,14 @@ struct MmGroups
     // row-major, n >= 128, no groups: most rows repeat the previous row's column list shifted by one (a stencil) and have
     // <= 8 entries -> csrmm_row_run_kernel (a wave walks 8 rows and keeps the previous row's B rows in registers)
     bool           runs_tried = false, row_runs = false;
+    // ... and, when the matrix is BANDED (most rows end `band` columns right of the diagonal, band >= 256, a 2-D / 3-D
+    // stencil), the order in which the kernel's 8-row blocks are walked: strips of <= 256 rows of the band, every strip
+    // from the top of the matrix to the bottom (run_order[b] = first row of the b-th block).  In row order the three
+    // touches of a B row (from the band above, the row itself, the band below) are `band` rows of traffic apart --
+    // 2 and 4 MB at band 1000 and 128 columns, more than an XCD's 4 MB L2 keeps: measured 2.5 x B fetched; in strip
+    // order they are one strip apart.
+    DeviceBuffer   run_order;
+    aoclsparse_int band = 0;
     aoclsparse_int ngroups = 0;
     int            max_rows = 0; // rows of the largest group
     DeviceBuffer   first; // ngroups + 1 row indices
@@ -737,7 +745,8 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
                                const aoclsparse_int *col, const aoclsparse_int *row_ptr, const T *B,
                                aoclsparse_int n, aoclsparse_int ldb, T beta, T *C,
                                aoclsparse_int ldc, const aoclsparse_int *grp = nullptr, aoclsparse_int ngroups = 0,
-                               int group_rows = 0, bool row_runs = false);
+                               int group_rows = 0, bool row_runs = false,
+                               const aoclsparse_int *run_order = nullptr);
 // row-major, n < 128: workgroup per row block of the handle's SpMV plan, A staged in LDS (csrmm_tile_kernel)
 template <typename T>
 bool csrmm_tiled_applies(aoclsparse_int n, aoclsparse_int ldb, aoclsparse_int ldc, const T *B, const T *C);

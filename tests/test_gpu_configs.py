@@ -206,6 +206,31 @@ def _col_reference(alpha, base, v, ci, rp, m, k, Brm, n, ldb, beta, C0, ldc):
     return Cref.reshape(n, m).T
 
 
+@pytest.mark.parametrize("nx,ny", [(301, 75), (1000, 9)])
+def test_csrmm_strip_order_banded_bit_exact(nx, ny):
+    """Banded stencils (csrmm_api.cpp detect_row_runs: band >= 256, m >= 4 * band): the row-run kernel walks its 8-row
+    blocks strip by strip (MmGroups::run_order).  A band that is not a multiple of the block, a matrix that is not a
+    multiple of it either, the last strip narrower than the others: every row still comes out once, bit for bit."""
+    m = nx * ny
+    i = np.arange(m)
+    cand = np.stack([i - nx, i - 1, i, i + 1, i + nx], axis=1)
+    ok = (cand >= 0) & (cand < m)
+    rp = np.concatenate([[0], np.cumsum(ok.sum(axis=1))]).astype(np.int32)
+    ci = cand[ok].astype(np.int32)
+    rng = np.random.default_rng(nx)
+    v = rng.uniform(-1, 1, len(ci))
+    A = P.Matrix(0, m, m, rp, ci, v)
+    d = P.Descr()
+    n = 128
+    Br = rng.uniform(-1, 1, m * n)
+    Cd = dev(np.full(m * n, 7.0))
+    assert P.dcsrmm(P.OP_NONE, 1.0, A, d, P.ORDER_ROW, dev(Br), n, n, 0.0, Cd, n) == 0
+    torch.cuda.synchronize()
+    got = Cd.cpu().numpy().reshape(m, n)
+    ref = _col_reference(1.0, 0, v, ci, rp, m, m, Br, n, n, 0.0, np.full(m * n, 7.0), n)
+    assert np.array_equal(got, ref)
+
+
 @pytest.mark.parametrize("base", [0, 1])
 def test_csrmm_row_runs_stencil_bit_exact(base):
     """csrmm_row_run_kernel (row-major, n >= 128, chosen when most rows repeat the previous row's column list shifted by
