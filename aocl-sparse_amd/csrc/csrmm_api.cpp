@@ -311,20 +311,32 @@ aoclsparse_status detect_row_runs(const HostCsr &h, SpmvPlan &plan)
     if(same * 2 < (long long)h.m || cand < 256 || (long long)cand * 4 > (long long)h.m)
         return aoclsparse_status_success;
     constexpr aoclsparse_int RUN = 8, STRIP_MAX = 256;
+    static const int env_rows = [] { const char *e = getenv("AOCLSPARSE_MI355_CSRMM_STRIP_ROWS"); return e ? atoi(e) : 0; }();
+    static const int env_qg   = [] { const char *e = getenv("AOCLSPARSE_MI355_CSRMM_STRIP_QGROUP"); return e ? atoi(e) : 0; }();
     const aoclsparse_int     band = cand;
-    const aoclsparse_int     sw   = std::min<aoclsparse_int>(((band + 7) / 8 + RUN - 1) / RUN * RUN, STRIP_MAX);
-    const aoclsparse_int     ns   = (band + sw - 1) / sw;
+    const aoclsparse_int     sw   = env_rows >= RUN ? (aoclsparse_int)env_rows / RUN * RUN
+                                                     : std::min<aoclsparse_int>(((band + 7) / 8 + RUN - 1) / RUN * RUN, STRIP_MAX);
+    const aoclsparse_int     qg   = env_qg >= 1 ? env_qg : 1; // band lines per workgroup-sized group of blocks
     const aoclsparse_int     nb   = (h.m + RUN - 1) / RUN;
     try
     {
-        // blocks in (strip, row) order: a counting sort by strip keeps the row order inside a strip
-        std::vector<aoclsparse_int> first((size_t)ns + 1, 0), order((size_t)nb);
+        // blocks sorted by (strip, group of qg band lines, position inside the strip, line inside the group): the row
+        // order inside a strip when qg = 1
+        std::vector<std::pair<unsigned long long, aoclsparse_int>> keyed((size_t)nb);
+        const unsigned long long nq = (unsigned long long)(h.m / band + 1), nsb = (unsigned long long)(sw / RUN + 1);
         for(aoclsparse_int b = 0; b < nb; b++)
-            first[(size_t)((b * RUN) % band / sw) + 1]++;
-        for(aoclsparse_int k = 0; k < ns; k++)
-            first[(size_t)k + 1] += first[(size_t)k];
+        {
+            const aoclsparse_int i0 = b * RUN, q = i0 / band, sp = i0 % band;
+            const unsigned long long key
+                = ((((unsigned long long)(sp / sw) * nq + (unsigned long long)(q / qg)) * nsb + (unsigned long long)((sp % sw) / RUN))
+                   * (unsigned long long)qg)
+                  + (unsigned long long)(q % qg);
+            keyed[(size_t)b] = {key, i0};
+        }
+        std::sort(keyed.begin(), keyed.end());
+        std::vector<aoclsparse_int> order((size_t)nb);
         for(aoclsparse_int b = 0; b < nb; b++)
-            order[(size_t)first[(size_t)((b * RUN) % band / sw)]++] = b * RUN;
+            order[(size_t)b] = keyed[(size_t)b].second;
         const aoclsparse_status st
             = g.run_order.upload(order.data(), sizeof(aoclsparse_int) * order.size(), Runtime::get().stream());
         if(st != aoclsparse_status_success)

@@ -881,6 +881,21 @@ __global__ __launch_bounds__(256) void csrmm_tile_kernel(int base, T alpha, cons
 // B / C access is coalesced across the 64 rows of a wavefront.
 constexpr int CM_K    = 8;
 constexpr int CM_COLS = 64;
+// columns per workgroup = the n columns spread evenly over the grid's y dimension, in whole steps of 4 (the host picks
+// gridDim.y = ceil(n / cm_cols()))
+__device__ inline int cm_cols_per_block(int n)
+{
+    return (int)(((unsigned)n + gridDim.y - 1) / gridDim.y + 3u) & ~3;
+}
+static int cm_cols()
+{
+    static const int v = [] {
+        const char *e = getenv("AOCLSPARSE_MI355_CSRMM_CM_COLS");
+        const int   c = e ? atoi(e) : CM_COLS;
+        return c >= 4 ? c : CM_COLS;
+    }();
+    return v;
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void csrmm_col_kernel(int base, T alpha, aoclsparse_int m,
@@ -898,8 +913,9 @@ __global__ __launch_bounds__(256) void csrmm_col_kernel(int base, T alpha, aocls
     if(t >= m)
         return;
     const int i  = rows ? rows[t] : t;
-    const int j0 = blockIdx.y * CM_COLS;
-    const int j1 = min(n, j0 + CM_COLS);
+    const int cpw = cm_cols_per_block(n);
+    const int j0  = blockIdx.y * cpw;
+    const int j1  = min(n, j0 + cpw);
     const int s = row_ptr[i] - base, e = row_ptr[i + 1] - base;
     T         v[CM_K];
     int       c[CM_K];
@@ -987,7 +1003,8 @@ __global__ __launch_bounds__(256) void csrmm_colpair_kernel(int base, T alpha, a
     if(t >= npairs)
         return;
     const int i  = pair_first[t];
-    const int j0 = blockIdx.y * CM_COLS, j1 = min(n, j0 + CM_COLS);
+    const int cpw = cm_cols_per_block(n);
+    const int j0 = blockIdx.y * cpw, j1 = min(n, j0 + cpw);
     const int s = row_ptr[i] - base, e = row_ptr[i + 1] - base;
     const int len = e - s; // 1 .. CM_K, and row i+1 has the same length (detect_pairs)
     T         v0[CM_K], v1[CM_K];
@@ -1209,10 +1226,11 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
             const int     gx  = grid_x((m + 4 * RUN - 1) / (4 * RUN), chunk);
             // the 128-column chunks of a row block run together (chunk = fastest index inside an XCD) rather than one chunk
             // of every block, then the next: same time at 256 columns, 1.64 vs 1.77 ms at 512 (A is read once, the chunks
-            // of a B row come in together).  AOCLSPARSE_MI355_CSRMM_YFAST=0: the 2-D grid.
+            // of a B row come in together).  Only in strip order: in plain row order it doubles the bytes between two
+            // touches of a B row (1.08 vs 0.88 ms, FETCH 5.8 vs 3.7 GB).  AOCLSPARSE_MI355_CSRMM_YFAST=0: the 2-D grid.
             static const bool yfast = [] { const char *e = getenv("AOCLSPARSE_MI355_CSRMM_YFAST"); return !e || atoi(e) != 0; }();
             const int ny = (n + 127) / 128;
-            if(yfast && chunk > 0 && (long long)gx * ny < (1LL << 31))
+            if(yfast && run_order && chunk > 0 && (long long)gx * ny < (1LL << 31))
                 hipLaunchKernelGGL((csrmm_row_run_kernel<T, RUN>), dim3(gx * ny, 1), dim3(256), 0, s, base, alpha, m, val, col,
                                    row_ptr, B, n, ldb, beta, C, ldc, readc, chunk, run_order, ny);
             else
@@ -1240,7 +1258,7 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
     else
     {
         const int gx = grid_x((m + 255) / 256, chunk);
-        dim3      block(256), grid(gx, (n + CM_COLS - 1) / CM_COLS);
+        dim3      block(256), grid(gx, (n + cm_cols() - 1) / cm_cols());
         hipLaunchKernelGGL((csrmm_col_kernel<T>), grid, block, 0, s, base, alpha, m, val, col, row_ptr, B, n, ldb,
                            beta, C, ldc, readc, chunk, (const aoclsparse_int *)nullptr);
     }
@@ -1309,10 +1327,14 @@ aoclsparse_status launch_csrmm_tiled(hipStream_t s, int base, T alpha, const T *
         return e && atoi(e) != 0;
     }();
     const bool readc = beta != T(0) || strict_beta0;
-    const int  chunk = (nblocks + 7) / 8; // XCD-contiguous block order, as the other csrmm kernels
+    static const bool xcd = [] {
+        const char *e = getenv("AOCLSPARSE_MI355_CSRMM_XCD");
+        return e ? atoi(e) != 0 : true;
+    }();
+    const int  chunk = xcd ? (nblocks + 7) / 8 : 0; // XCD-contiguous block order, as the other csrmm kernels
     auto       go    = [&](auto lanes_tag, auto tile_tag) {
         constexpr int LANES = decltype(lanes_tag)::value, TILE = decltype(tile_tag)::value;
-        hipLaunchKernelGGL((csrmm_tile_kernel<T, LANES, TILE>), dim3(chunk * 8, (n + 2 * LANES - 1) / (2 * LANES)), dim3(256),
+        hipLaunchKernelGGL((csrmm_tile_kernel<T, LANES, TILE>), dim3(xcd ? chunk * 8 : nblocks, (n + 2 * LANES - 1) / (2 * LANES)), dim3(256),
                            0, s, base, alpha, val, col, row_ptr, blocks, nblocks, B, n, ldb, beta, C, ldc, readc, chunk);
     };
     using L16 = std::integral_constant<int, 16>;
@@ -1346,13 +1368,13 @@ aoclsparse_status launch_csrmm_colpair(hipStream_t s, int base, T alpha, aoclspa
     if(npairs > 0)
     {
         const int nbx = (npairs + 255) / 256, chunk = (nbx + 7) / 8;
-        hipLaunchKernelGGL((csrmm_colpair_kernel<T>), dim3(chunk * 8, (n + CM_COLS - 1) / CM_COLS), block, 0, s, base, alpha,
+        hipLaunchKernelGGL((csrmm_colpair_kernel<T>), dim3(chunk * 8, (n + cm_cols() - 1) / cm_cols()), block, 0, s, base, alpha,
                            npairs, pair_first, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, c_aligned, chunk);
     }
     if(nsingles > 0)
     {
         const int nbx = (nsingles + 255) / 256, chunk = (nbx + 7) / 8;
-        hipLaunchKernelGGL((csrmm_col_kernel<T>), dim3(chunk * 8, (n + CM_COLS - 1) / CM_COLS), block, 0, s, base, alpha,
+        hipLaunchKernelGGL((csrmm_col_kernel<T>), dim3(chunk * 8, (n + cm_cols() - 1) / cm_cols()), block, 0, s, base, alpha,
                            nsingles, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk, single_rows);
     }
     MI355_HIP_TRY(hipGetLastError());

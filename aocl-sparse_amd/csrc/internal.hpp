@@ -18,10 +18,12 @@
 #include <chrono>
 #include <cstddef>
 #include <cstdint>
+#include <exception>
 #include <memory>
 #include <mutex>
 #include <new>
 #include <shared_mutex>
+#include <system_error>
 #include <vector>
 
 // ---- descriptor (library/src/include/aoclsparse_descr.h:37-47) --------------------------
@@ -150,12 +152,39 @@ inline void parallel_for(long long n, long long grain, F fn)
         fn(0LL, n);
         return;
     }
+    // An exception inside a chunk (bad_alloc) is carried to the caller, and a thread that cannot be started costs nothing
+    // but its parallelism (the chunk then runs here): the C ABI above this never sees std::terminate.
     std::vector<std::thread> th;
     th.reserve((size_t)nt);
+    std::exception_ptr       err;
+    std::mutex               err_lock;
+    auto                     chunk = [&](int t) {
+        try
+        {
+            fn(n * t / nt, n * (t + 1) / nt);
+        }
+        catch(...)
+        {
+            std::lock_guard<std::mutex> g(err_lock);
+            if(!err)
+                err = std::current_exception();
+        }
+    };
     for(int t = 0; t < nt; t++)
-        th.emplace_back([=] { fn(n * t / nt, n * (t + 1) / nt); });
+    {
+        try
+        {
+            th.emplace_back(chunk, t);
+        }
+        catch(const std::system_error &)
+        {
+            chunk(t);
+        }
+    }
     for(auto &t : th)
         t.join();
+    if(err)
+        std::rethrow_exception(err);
 }
 
 // Diagnostic: AOCLSPARSE_MI355_TIMING=1 prints the wall time of the analysis phases it brackets to stderr.
