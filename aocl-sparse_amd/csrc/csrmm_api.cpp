@@ -569,6 +569,19 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
         {
             void *bt = nullptr, *ct = nullptr;
             st = rt.staging(5, sizeof(T) * (size_t)b_rows * (size_t)n, &bt);
+            // handles with row groups: only B changes layout; the row-group kernel writes (and, beta != 0, reads) the caller's
+            // column-major C in place -- two of the detour's three copy passes gone (shell-like, 256 columns: 6.6 -> see DESIGN)
+            const bool direct = st == aoclsparse_status_success && grouped && !(p->mm.super_valid && n >= 128)
+                                && csrmm_groups_ccol_applies<T>(n, n, static_cast<const T *>(bt));
+            if(direct)
+            {
+                st = launch_relayout<T>(rt.stream(), true, static_cast<const T *>(dB), static_cast<T *>(bt), b_rows, n, ldb);
+                if(st == aoclsparse_status_success)
+                    st = launch_csrmm_groups_ccol<T>(rt.stream(), d->base, alpha, d->val.as<T>(), d->ind.as<aoclsparse_int>(),
+                                                     d->ptr.as<aoclsparse_int>(), static_cast<const T *>(bt), n, n, beta,
+                                                     static_cast<T *>(dC), ldc, grp, ngrp, p->mm.max_rows);
+                return st == aoclsparse_status_success ? finish() : st;
+            }
             if(st == aoclsparse_status_success)
                 st = rt.staging(6, sizeof(T) * (size_t)m_c * (size_t)n, &ct);
             if(st == aoclsparse_status_success)

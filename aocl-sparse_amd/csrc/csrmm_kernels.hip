@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup_kernel(int base, T alpha, 
 // (GR x 4 doubles through the scalar cache, unconditionally -- rows the group does not have re-read row 0's), the B rows
 // of the NEXT step are requested before the FMAs of this one (two register sets, used alternately), and only the FMAs sit
 // behind the per-row branch.  GR is the matrix's largest group size exactly (2, 3, 4, 5, 6 or 8), not rounded up to 8.
-template <typename T, int GR>
+template <typename T, int GR, bool CCOL = false>
 __global__ __launch_bounds__(256) void csrmm_rowgroup2_kernel(int base, T alpha, aoclsparse_int ngroups,
                                                               const aoclsparse_int *__restrict__ grp,
                                                               const T *__restrict__ val,
@@ -446,15 +446,24 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup2_kernel(int base, T alpha,
     const int     w  = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int     bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int     gt = bx * 4 + w;
-    const int     j  = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
-    if(gt >= ngroups || j >= n)
+    const int     jr = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
+    const bool    have = gt < ngroups;
+    if constexpr(!CCOL)
+    {
+        if(!have || jr >= n)
+            return;
+    }
+    else if(bx * 4 >= ngroups) // a workgroup of the XCD padding: all four waves leave together
         return;
-    const int gi = glist ? glist[gt] : gt;
-    const int i0 = grp[gi], r = grp[gi + 1] - i0; // 1 <= r <= GR
+    // (CCOL: every wave stays for the workgroup's store phase; a wave without a group has no rows, a lane beyond n computes
+    // column 0 again and stores nothing)
+    const int j  = (CCOL && jr >= n) ? 0 : jr;
+    const int gi = have ? (glist ? glist[gt] : gt) : 0;
+    const int i0 = have ? grp[gi] : 0, r = have ? grp[gi + 1] - i0 : 0; // 1 <= r <= GR
     // (the index base is folded into the pointers once: col / val take raw row_ptr values, B rows raw column values --
     // subtracting it per index cost the row-run kernel 13 %)
     col -= base, val -= base;
-    const int s0 = row_ptr[i0], len = row_ptr[i0 + 1] - s0;
+    const int s0 = row_ptr[i0], len = have ? row_ptr[i0 + 1] - s0 : 0;
     int       so[GR]; // start of every row of the group (wave-uniform); rows beyond the group alias row 0
 #pragma unroll
     for(int q = 0; q < GR; q++)
@@ -543,6 +552,35 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup2_kernel(int base, T alpha,
                     }
                 }
         }
+    }
+    if constexpr(CCOL)
+    {
+        // C is COLUMN-major (the column-major detour of csrmm_api.cpp: B was copied to row-major scratch, C is written where
+        // the caller wants it): element (i, j) at C[i + j * ldc].  The workgroup's four groups are consecutive rows (R = 4..32
+        // of them): alpha * acc goes through an LDS tile and leaves column by column, R consecutive rows per run -- lane by
+        // lane (r rows x 8 bytes per lane, 64 different lines per store instruction) the kernel took twice as long.
+        // beta * C + z is applied at the store (C read only where it can matter, as everywhere).
+        __shared__ T tile[4 * GR][130];
+        const int    lane = (int)(threadIdx.x & 63);
+        const int    g0 = bx * 4, g1 = min(g0 + 4, (int)ngroups);
+        const int    ib = grp[g0], R = grp[g1] - ib; // this workgroup's rows [ib, ib + R)
+#pragma unroll
+        for(int q = 0; q < GR; q++)
+            if(q < r)
+            {
+                tile[i0 - ib + q][2 * lane]     = alpha * acc0[q];
+                tile[i0 - ib + q][2 * lane + 1] = alpha * acc1[q];
+            }
+        __syncthreads();
+        const int j0 = 128 * (int)blockIdx.y, nc = min(128, (int)n - j0);
+        for(int idx = (int)threadIdx.x; idx < nc * R; idx += 256)
+        {
+            const int cc = idx / R, q = idx - cc * R;
+            T        *cp = C + (size_t)(ib + q) + (size_t)(j0 + cc) * ldc;
+            const T   z  = tile[q][cc];
+            *cp          = (readc || z == T(0)) ? mm_fma(beta, *cp, z) : z;
+        }
+        return;
     }
 #pragma unroll
     for(int q = 0; q < GR; q++)
@@ -1266,6 +1304,52 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
     return aoclsparse_status_success;
 }
 
+// the row-group kernel with row-major B (packed scratch of the column-major detour) and COLUMN-major C: see CCOL above.
+// Applies when the handle has row groups, n >= 128 and even, B 16-byte aligned; false = the caller takes the full detour.
+template <typename T>
+bool csrmm_groups_ccol_applies(aoclsparse_int n, aoclsparse_int ldb, const T *B)
+{
+    static const bool off = [] {
+        const char *e = getenv("AOCLSPARSE_MI355_CSRMM_CCOL");
+        return e && atoi(e) == 0;
+    }();
+    return !off && n >= 128 && n % 2 == 0 && ldb % 2 == 0 && reinterpret_cast<uintptr_t>(B) % (2 * sizeof(T)) == 0;
+}
+
+template <typename T>
+aoclsparse_status launch_csrmm_groups_ccol(hipStream_t s, int base, T alpha, const T *val, const aoclsparse_int *col,
+                                           const aoclsparse_int *row_ptr, const T *B, aoclsparse_int n, aoclsparse_int ldb,
+                                           T beta, T *C, aoclsparse_int ldc, const aoclsparse_int *grp, aoclsparse_int ngroups,
+                                           int group_rows)
+{
+    if(ngroups <= 0 || n <= 0)
+        return aoclsparse_status_success;
+    static const bool strict_beta0 = [] {
+        const char *e = getenv("AOCLSPARSE_MI355_CSRMM_STRICT_BETA0");
+        return e && atoi(e) != 0;
+    }();
+    const bool readc = beta != T(0) || strict_beta0;
+    const int  nbx = (int)((ngroups + 3) / 4), chunk = (nbx + 7) / 8;
+    auto       go  = [&](auto gr_tag) {
+        constexpr int GR = decltype(gr_tag)::value;
+        hipLaunchKernelGGL((csrmm_rowgroup2_kernel<T, GR, true>), dim3(chunk * 8, (n + 127) / 128), dim3(256), 0, s, base, alpha,
+                           ngroups, grp, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk,
+                           (const aoclsparse_int *)nullptr);
+    };
+    switch(group_rows)
+    {
+    case 1:
+    case 2: go(std::integral_constant<int, 2>{}); break;
+    case 3: go(std::integral_constant<int, 3>{}); break;
+    case 4: go(std::integral_constant<int, 4>{}); break;
+    case 5: go(std::integral_constant<int, 5>{}); break;
+    case 6: go(std::integral_constant<int, 6>{}); break;
+    default: go(std::integral_constant<int, CSRMM_GROUP>{}); break;
+    }
+    MI355_HIP_TRY(hipGetLastError());
+    return aoclsparse_status_success;
+}
+
 template <typename T>
 aoclsparse_status launch_scale_dense(hipStream_t s, aoclsparse_order order, T *C, aoclsparse_int m,
                                      aoclsparse_int n, aoclsparse_int ld, T beta)
@@ -1451,6 +1535,11 @@ aoclsparse_status launch_csrmm_super(hipStream_t s, int base, T alpha, aoclspars
                                                      const aoclsparse_int *, const T *, aoclsparse_int,        \
                                                      aoclsparse_int, T, T *, aoclsparse_int);                  \
     template bool csrmm_tiled_applies<T>(aoclsparse_int, aoclsparse_int, aoclsparse_int, const T *, const T *); \
+    template bool csrmm_groups_ccol_applies<T>(aoclsparse_int, aoclsparse_int, const T *);                     \
+    template aoclsparse_status launch_csrmm_groups_ccol<T>(hipStream_t, int, T, const T *, const aoclsparse_int *, \
+                                                           const aoclsparse_int *, const T *, aoclsparse_int,  \
+                                                           aoclsparse_int, T, T *, aoclsparse_int,             \
+                                                           const aoclsparse_int *, aoclsparse_int, int);       \
     template aoclsparse_status launch_csrmm_tiled<T>(hipStream_t, int, T, const T *, const aoclsparse_int *,   \
                                                      const aoclsparse_int *, const aoclsparse_int *,          \
                                                      aoclsparse_int, int, const T *, aoclsparse_int,          \

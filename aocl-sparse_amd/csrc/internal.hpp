@@ -776,6 +776,14 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
                                aoclsparse_int ldc, const aoclsparse_int *grp = nullptr, aoclsparse_int ngroups = 0,
                                int group_rows = 0, bool row_runs = false,
                                const aoclsparse_int *run_order = nullptr);
+// column-major detour, handles with row groups: row-major B scratch in, column-major C written directly (no C copies)
+template <typename T>
+bool csrmm_groups_ccol_applies(aoclsparse_int n, aoclsparse_int ldb, const T *B);
+template <typename T>
+aoclsparse_status launch_csrmm_groups_ccol(hipStream_t s, int base, T alpha, const T *val, const aoclsparse_int *col,
+                                           const aoclsparse_int *row_ptr, const T *B, aoclsparse_int n, aoclsparse_int ldb,
+                                           T beta, T *C, aoclsparse_int ldc, const aoclsparse_int *grp, aoclsparse_int ngroups,
+                                           int group_rows);
 // row-major, n < 128: workgroup per row block of the handle's SpMV plan, A staged in LDS (csrmm_tile_kernel)
 template <typename T>
 bool csrmm_tiled_applies(aoclsparse_int n, aoclsparse_int ldb, aoclsparse_int ldc, const T *B, const T *C);

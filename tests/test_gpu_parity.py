@@ -626,6 +626,37 @@ def test_csrmm_row_groups_block_structured(base):
         assert len(v) > 8 * m and np.array_equal(C2d.cpu().numpy(), C2ref)
 
 
+@pytest.mark.parametrize("dof", [2, 3, 4, 5, 6, 8])
+def test_csrmm_column_major_groups_write_c_in_place(dof):
+    """column-major operands on a handle with row groups, n >= 128: only B goes through the row-major scratch, the row-group
+    kernel writes column-major C itself (an LDS tile per workgroup, column by column).  Every group size the kernel is
+    compiled for, a last workgroup with fewer than four groups, a partial last 128-column chunk, beta classes, padded
+    leading dimensions untouched; bits of csrmm_col_major_ref."""
+    rng = np.random.default_rng(40 + dof)
+    nodes, k = 203, 900  # 203 groups: the last workgroup holds three
+    rows_p, rows_c = [0], []
+    for nd in range(nodes):
+        cols = np.sort(rng.choice(k, size=12 + nd % 29, replace=False))
+        for r in range(dof):
+            rows_c.append(cols)
+            rows_p.append(rows_p[-1] + len(cols))
+    m = len(rows_p) - 1
+    rp = np.array(rows_p, np.int32)
+    ci = np.concatenate(rows_c).astype(np.int32)
+    v = rng.uniform(-1, 1, len(ci))
+    A = P.Matrix(0, m, k, rp, ci, v)
+    d = P.Descr()
+    for n, alpha, beta in ((128, 1.0, 0.0), (200, -0.5, 2.0), (256, 2.0, 0.0)):
+        ldb, ldc = k + 3, m + 5
+        B, C0 = rng.uniform(-1, 1, ldb * n), rng.uniform(-1, 1, ldc * n)
+        Cd = dev(C0)
+        assert P.dcsrmm(P.OP_NONE, alpha, A, d, P.ORDER_COLUMN, dev(B), n, ldb, beta, Cd, ldc) == 0
+        torch.cuda.synchronize()
+        assert A.spmv_info().mm_groups == nodes
+        so, Cr = oracle.dcsrmm("col", alpha, 0, v, ci, rp, m, B, n, ldb, beta, C0, ldc)
+        assert so == 0 and np.array_equal(Cd.cpu().numpy(), Cr), "dof=%d n=%d" % (dof, n)
+
+
 def test_csrmm_alpha_zero_and_transpose():
     m, k, n = 500, 400, 16
     rp, ci, v = random_csr(91, m, k, lambda r, i: r.integers(0, 9))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One stand-in, row-major csrmm with n columns, a few calls (for rocprofv3 passes).  usage: exp_mm_standin.py shell-like|flan-like [n]"""
+"""One stand-in, csrmm with n columns, a few calls (for rocprofv3 passes).  usage: exp_mm_standin.py shell-like|flan-like [n] [row|col]"""
 import json, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,16 +10,19 @@ L.aoclsparse_mi355_set_pointer_mode(pkg.PTR_DEVICE)
 dev = torch.device("cuda", 0)
 name = sys.argv[1] if len(sys.argv) > 1 else "shell-like"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+colmaj = len(sys.argv) > 3 and sys.argv[3] == "col"
 label, m, rp, ci, v = standins.load(name)
 A = pkg.Matrix(0, m, m, rp, ci, v); d = pkg.Descr()
 assert L.aoclsparse_set_mm_hint(A.h, pkg.OP_NONE, d.h, 100) == 0 and L.aoclsparse_optimize(A.h) == 0
 B = torch.from_numpy(np.random.default_rng(1).uniform(-1, 1, (m, n))).to(dev)
 C = torch.zeros((m, n), dtype=torch.float64, device=dev)
-call = lambda: L.aoclsparse_dcsrmm(pkg.OP_NONE, 1.0, A.h, d.h, pkg.ORDER_ROW, pkg._ptr(B), n, n, 0.0, pkg._ptr(C), n)
+call = lambda: L.aoclsparse_dcsrmm(pkg.OP_NONE, 1.0, A.h, d.h, pkg.ORDER_COLUMN if colmaj else pkg.ORDER_ROW, pkg._ptr(B), n,
+                                  m if colmaj else n, 0.0, pkg._ptr(C), m if colmaj else n)
 for _ in range(3):
     assert call() == 0
 torch.cuda.synchronize()
 pkg.timer_start()
 for _ in range(10):
     call()
-print(json.dumps({"A": label, "n": n, "ms": round(pkg.timer_stop() / 10, 4)}))
+print(json.dumps({"A": label, "n": n, "layout": "column-major" if colmaj else "row-major", "ms": round(pkg.timer_stop() / 10, 4),
+                  "checksum": float(C.double().sum().item())}))
