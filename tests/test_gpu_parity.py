@@ -655,6 +655,15 @@ def test_csrmm_column_major_groups_write_c_in_place(dof):
         assert A.spmv_info().mm_groups == nodes
         so, Cr = oracle.dcsrmm("col", alpha, 0, v, ci, rp, m, B, n, ldb, beta, C0, ldc)
         assert so == 0 and np.array_equal(Cd.cpu().numpy(), Cr), "dof=%d n=%d" % (dof, n)
+    # float: the column-major result equals the row-major one of the same handle (same chains; that path has its own tests)
+    Af = P.Matrix(0, m, k, rp, ci, v.astype(np.float32))
+    n = 130
+    Bm, C0 = rng.uniform(-1, 1, (k, n)).astype(np.float32), rng.uniform(-1, 1, (m, n)).astype(np.float32)
+    Cr_, Cc_ = dev(C0.ravel()), dev(np.ascontiguousarray(C0.T).ravel())
+    assert P.scsrmm(P.OP_NONE, 1.5, Af, d, P.ORDER_ROW, dev(Bm.ravel()), n, n, -0.5, Cr_, n) == 0
+    assert P.scsrmm(P.OP_NONE, 1.5, Af, d, P.ORDER_COLUMN, dev(np.ascontiguousarray(Bm.T).ravel()), n, k, -0.5, Cc_, m) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(Cc_.cpu().numpy().reshape(n, m).T, Cr_.cpu().numpy().reshape(m, n))
 
 
 def test_csrmm_alpha_zero_and_transpose():
