@@ -697,7 +697,7 @@ __global__ __launch_bounds__(256) void csrmm_supergroup_kernel(T alpha, aoclspar
 
 // narrower B (32 <= n < 128): LANES lanes (2 columns each) per group, 64 / LANES groups per wavefront; the group's
 // row_ptr / col / val loads are then per-lane loads of one address per sub-wave instead of scalar loads
-template <typename T, int LANES, int GR>
+template <typename T, int LANES, int GR, bool CCOL = false>
 __global__ __launch_bounds__(256) void csrmm_rowgroup_sub_kernel(int base, T alpha, aoclsparse_int ngroups,
                                                              const aoclsparse_int *__restrict__ grp,
                                                              const T *__restrict__ val,
@@ -709,12 +709,21 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup_sub_kernel(int base, T alp
 {
     using V      = typename vec2<T>::type;
     const int bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const int gi = bx * (256 / LANES) + (int)threadIdx.x / LANES;
-    const int j  = 2 * ((int)threadIdx.x % LANES) + 2 * LANES * (int)blockIdx.y;
-    if(gi >= ngroups || j >= n)
+    constexpr int NG = 256 / LANES; // groups per workgroup
+    const int     gi = bx * NG + (int)threadIdx.x / LANES;
+    const int     jr = 2 * ((int)threadIdx.x % LANES) + 2 * LANES * (int)blockIdx.y;
+    const bool    have = gi < ngroups;
+    if constexpr(!CCOL)
+    {
+        if(!have || jr >= n)
+            return;
+    }
+    else if(bx * NG >= ngroups) // a workgroup of the XCD padding
         return;
-    const int i0 = grp[gi], r = grp[gi + 1] - i0; // 1 <= r <= GR
-    const int s0 = row_ptr[i0] - base, len = row_ptr[i0 + 1] - base - s0;
+    // (CCOL: every lane stays for the workgroup's store phase, see csrmm_rowgroup2_kernel)
+    const int j  = (CCOL && jr >= n) ? 0 : jr;
+    const int i0 = have ? grp[gi] : 0, r = have ? grp[gi + 1] - i0 : 0; // 1 <= r <= GR
+    const int s0 = row_ptr[i0] - base, len = have ? row_ptr[i0 + 1] - base - s0 : 0;
     int       so[GR]; // start of every row of the group (wave-uniform)
 #pragma unroll
     for(int q = 0; q < GR; q++)
@@ -773,6 +782,31 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup_sub_kernel(int base, T alp
                 const T a0 = val[so[q] + k];
                 acc0[q] = mm_fma(a0, b0.x, acc0[q]), acc1[q] = mm_fma(a0, b0.y, acc1[q]);
             }
+    }
+    if constexpr(CCOL)
+    {
+        // column-major C through an LDS tile, as in csrmm_rowgroup2_kernel: the workgroup's NG groups are consecutive rows
+        __shared__ T tile[NG * GR][2 * LANES + 2];
+        const int    lane = (int)threadIdx.x % LANES;
+        const int    g0 = bx * NG, g1 = min(g0 + NG, (int)ngroups);
+        const int    ib = grp[g0], R = grp[g1] - ib;
+#pragma unroll
+        for(int q = 0; q < GR; q++)
+            if(q < r)
+            {
+                tile[i0 - ib + q][2 * lane]     = alpha * acc0[q];
+                tile[i0 - ib + q][2 * lane + 1] = alpha * acc1[q];
+            }
+        __syncthreads();
+        const int j0 = 2 * LANES * (int)blockIdx.y, nc = min(2 * LANES, (int)n - j0);
+        for(int idx = (int)threadIdx.x; idx < nc * R; idx += 256)
+        {
+            const int cc = idx / R, q = idx - cc * R;
+            T        *cp = C + (size_t)(ib + q) + (size_t)(j0 + cc) * ldc;
+            const T   z  = tile[q][cc];
+            *cp          = (readc || z == T(0)) ? mm_fma(beta, *cp, z) : z;
+        }
+        return;
     }
 #pragma unroll
     for(int q = 0; q < GR; q++)
@@ -1305,7 +1339,8 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
 }
 
 // the row-group kernel with row-major B (packed scratch of the column-major detour) and COLUMN-major C: see CCOL above.
-// Applies when the handle has row groups, n >= 128 and even, B 16-byte aligned; false = the caller takes the full detour.
+// Applies when the handle has row groups, n >= 32 and even, B 16-byte aligned; false = the caller takes the full detour.
+// n < 128: the sub-wave row-group kernels (a group per 32 / 16 lanes), same store phase.
 template <typename T>
 bool csrmm_groups_ccol_applies(aoclsparse_int n, aoclsparse_int ldb, const T *B)
 {
@@ -1313,7 +1348,7 @@ bool csrmm_groups_ccol_applies(aoclsparse_int n, aoclsparse_int ldb, const T *B)
         const char *e = getenv("AOCLSPARSE_MI355_CSRMM_CCOL");
         return e && atoi(e) == 0;
     }();
-    return !off && n >= 128 && n % 2 == 0 && ldb % 2 == 0 && reinterpret_cast<uintptr_t>(B) % (2 * sizeof(T)) == 0;
+    return !off && n >= 32 && n % 2 == 0 && ldb % 2 == 0 && reinterpret_cast<uintptr_t>(B) % (2 * sizeof(T)) == 0;
 }
 
 template <typename T>
@@ -1329,6 +1364,32 @@ aoclsparse_status launch_csrmm_groups_ccol(hipStream_t s, int base, T alpha, con
         return e && atoi(e) != 0;
     }();
     const bool readc = beta != T(0) || strict_beta0;
+    if(n < 128)
+    {
+        auto gosub = [&](auto gr_tag) {
+            constexpr int GR = decltype(gr_tag)::value;
+            if(n >= 64)
+            {
+                const int nbx = (int)((ngroups + 7) / 8), chunk = (nbx + 7) / 8;
+                hipLaunchKernelGGL((csrmm_rowgroup_sub_kernel<T, 32, GR, true>), dim3(chunk * 8, (n + 63) / 64), dim3(256), 0, s,
+                                   base, alpha, ngroups, grp, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk);
+            }
+            else
+            {
+                const int nbx = (int)((ngroups + 15) / 16), chunk = (nbx + 7) / 8;
+                hipLaunchKernelGGL((csrmm_rowgroup_sub_kernel<T, 16, GR, true>), dim3(chunk * 8, (n + 31) / 32), dim3(256), 0, s,
+                                   base, alpha, ngroups, grp, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk);
+            }
+        };
+        if(group_rows <= 2)
+            gosub(std::integral_constant<int, 2>{});
+        else if(group_rows <= 4)
+            gosub(std::integral_constant<int, 4>{});
+        else
+            gosub(std::integral_constant<int, CSRMM_GROUP>{});
+        MI355_HIP_TRY(hipGetLastError());
+        return aoclsparse_status_success;
+    }
     const int  nbx = (int)((ngroups + 3) / 4), chunk = (nbx + 7) / 8;
     auto       go  = [&](auto gr_tag) {
         constexpr int GR = decltype(gr_tag)::value;

@@ -646,7 +646,8 @@ def test_csrmm_column_major_groups_write_c_in_place(dof):
     v = rng.uniform(-1, 1, len(ci))
     A = P.Matrix(0, m, k, rp, ci, v)
     d = P.Descr()
-    for n, alpha, beta in ((128, 1.0, 0.0), (200, -0.5, 2.0), (256, 2.0, 0.0)):
+    # (32 <= n < 128: the sub-wave row-group kernels, a group per 16 / 32 lanes; n >= 128: a group per wavefront)
+    for n, alpha, beta in ((128, 1.0, 0.0), (200, -0.5, 2.0), (256, 2.0, 0.0), (32, 1.0, 0.0), (46, 2.0, -1.0), (64, 1.0, 0.5), (100, -1.0, 0.0)):
         ldb, ldc = k + 3, m + 5
         B, C0 = rng.uniform(-1, 1, ldb * n), rng.uniform(-1, 1, ldc * n)
         Cd = dev(C0)
