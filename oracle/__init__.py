@@ -165,6 +165,87 @@ def dcsrmm(order, alpha, base, val, col, row, m, B, n, ldb, beta, C, ldc):
     return st, C
 
 
+def set_contract(fused):
+    """True (default): the reference's scalar accumulation loops are fused multiply-adds (clang / AOCC build);
+    False: a multiplication and an addition (GCC build with the reference's own -march=znver2: oracle.c header)."""
+    lib().orc_set_contract(c_int(1 if fused else 0))
+
+
+class contract:
+    """with oracle.contract(False): ... -- scoped switch, restored on exit."""
+
+    def __init__(self, fused):
+        self.fused = fused
+
+    def __enter__(self):
+        self.prev = lib().orc_get_contract()
+        set_contract(self.fused)
+
+    def __exit__(self, *a):
+        set_contract(bool(self.prev))
+
+
+def kt_hsum(tsz, v):
+    """kt_hsum_p of one vector register (double: tsz 4 / 8, float32: 8 / 16) as restated in oracle.c."""
+    v = np.ascontiguousarray(v)
+    L = lib()
+    if v.dtype == np.float32:
+        L.orc_kt_hsum_s.restype = c_flt
+        return np.float32(L.orc_kt_hsum_s(c_int(tsz), _p(v)))
+    v = _f64(v)
+    L.orc_kt_hsum_d.restype = c_dbl
+    return L.orc_kt_hsum_d(c_int(tsz), _p(v))
+
+
+def trsv_kt(kind, tsz, alpha, m, base, a, icol, ilrow, ilend, b, unit, incb=1, incx=1, x0=None, dtype=np.float64):
+    """The KT kernels kt_trsv_{l,lt,u,ut} (trsv_kt.cpp:64-531); tsz = lanes (double 4: kid 1/2, 8: kid 3; float 8 / 16)."""
+    f = _f64 if dtype == np.float64 else _f32
+    a, icol, ilrow, ilend, b = f(a), _i32(icol), _i32(ilrow), _i32(ilend), f(b)
+    x = np.zeros(max(1, (m - 1) * incx + 1), dtype=dtype) if x0 is None else f(x0).copy()
+    fn = getattr(lib(), "orc_%strsv_kt_%s" % ("d" if dtype == np.float64 else "s", kind))
+    sc = c_dbl if dtype == np.float64 else c_flt
+    st = fn(c_int(tsz), sc(alpha), c_i32(m), c_int(base), _p(a), _p(icol), _p(ilrow), _p(ilend), _p(b),
+            c_i32(incb), _p(x), c_i32(incx), c_int(1 if unit else 0))
+    return st, x
+
+
+def dcsrmm_kt(order, psz, alpha, base, val, col, row, m, B, n, ldb, beta, C, ldc):
+    """csrmm_col_kt / csrmm_row_kt (csrmm_kt.cpp:31-363); psz = 4 (kid 1/2) or 8 (kid 3)."""
+    val, col, row, B = _f64(val), _i32(col), _i32(row), _f64(B)
+    C = _f64(C).copy()
+    fn = lib().orc_dcsrmm_row_kt if order == "row" else lib().orc_dcsrmm_col_kt
+    st = fn(c_int(psz), c_dbl(alpha), c_int(base), _p(val), _p(col), _p(row), c_i32(m), _p(B), c_i32(n),
+            c_i32(ldb), c_dbl(beta), _p(C), c_i32(ldc))
+    return st, C
+
+
+_ktref = None
+
+
+def ktref():
+    """oracle/_ref/libktref.so: the reference's own kernel-template micro-kernels behind ref_kt_driver.cpp (built by
+    `make -C oracle ktref` where /root/reference exists).  None when absent or when the host lacks AVX-512."""
+    global _ktref
+    if _ktref is None:
+        path = os.path.join(_HERE, "_ref", "libktref.so")
+        if not os.path.exists(path):
+            return None
+        try:
+            with open("/proc/cpuinfo") as f:
+                flags = f.read()
+        except OSError:
+            flags = ""
+        if not all(k in flags for k in ("avx512f", "avx512vl", "avx512dq")):
+            return None
+        L = ctypes.CDLL(path)
+        for name in ("ktref_hsum_d", "ktref_dot_d", "ktref_trsv_row_d", "ktref_csrmm_col_elem_d"):
+            getattr(L, name).restype = c_dbl
+        for name in ("ktref_hsum_s", "ktref_dot_s", "ktref_trsv_row_s"):
+            getattr(L, name).restype = c_flt
+        _ktref = L
+    return _ktref
+
+
 def dscale_dense(order, C, m, n, ld, beta):
     C = _f64(C).copy()
     st = lib().orc_dscale_dense(c_int(1 if order == "col" else 0), _p(C), c_i32(m), c_i32(n),

@@ -17,6 +17,34 @@
 #endif
 
 /* ------------------------------------------------------------------------------------ */
+/* Which build of the reference?  Found in round 3 by compiling the reference's kernel    */
+/* templates with its own flags: "-O3 -ffp-contract=fast -march=znver2" does NOT fuse a   */
+/* LOOP-CARRIED scalar accumulation under GCC (>= 9; checked with 11.4): -march=znver2    */
+/* implies -mtune=znver2, whose X86_TUNE_AVOID_128FMA_CHAINS makes tree-ssa-math-opts     */
+/* leave "acc += a*b" chains as vmulsd + vaddsd; with -mtune=generic, or with clang /     */
+/* AOCC (contraction in the front end), the same statement is one vfmadd.  Everything     */
+/* that is not such a chain (beta*y + r, C[k] += a*b*alpha, the explicit _mm*_fmadd       */
+/* intrinsics) is fused by both.  So the reference has TWO sets of bits for its scalar    */
+/* loops (ref_csrmv_gn, the tails of the AVX kernels, ref_trsv_l/u, the sum loop of       */
+/* csrmm_col_major_ref, the KT tails), one per compiler.  orc_set_contract(1) (default):  */
+/* fused = clang/AOCC build (what the GPU kernels reproduce bit for bit);                 */
+/* orc_set_contract(0): the GCC -march=znver2 build (what oracle/_ref/libktref.so, built  */
+/* here with GCC and those flags, produces: tests/golden/kt_vectors.json).                */
+/* ------------------------------------------------------------------------------------ */
+static int g_fused = 1;
+void orc_set_contract(int fused)
+{
+    g_fused = fused ? 1 : 0;
+}
+int orc_get_contract(void)
+{
+    return g_fused;
+}
+/* a loop-carried scalar accumulation acc = a*b + acc */
+#define CH_D(a, b, c) (g_fused ? fma((a), (b), (c)) : ((a) * (b) + (c)))
+#define CH_S(a, b, c) (g_fused ? fmaf((a), (b), (c)) : ((a) * (b) + (c)))
+
+/* ------------------------------------------------------------------------------------ */
 /* SpMV row kernels.  Each computes one row's dot product in the reference's order.      */
 /* ------------------------------------------------------------------------------------ */
 
@@ -26,7 +54,7 @@ static inline double row_ref_d(const double *val, const oint *col, const double 
 {
     double r = 0.0;
     for(oint j = s; j < e; j++)
-        r = fma(val[j - base], x[col[j - base] - base], r);
+        r = CH_D(val[j - base], x[col[j - base] - base], r);
     return r;
 }
 
@@ -35,7 +63,7 @@ static inline float row_ref_s(const float *val, const oint *col, const float *x,
 {
     float r = 0.0f;
     for(oint j = s; j < e; j++)
-        r = fmaf(val[j - base], x[col[j - base] - base], r);
+        r = CH_S(val[j - base], x[col[j - base] - base], r);
     return r;
 }
 
@@ -55,7 +83,7 @@ static inline double row_lane4_d(const double *val, const oint *col, const doubl
     if(n / 4)
         r = (l[0] + l[1]) + (l[2] + l[3]);
     for(j = e - krem; j < e; j++)
-        r = fma(val[j - base], x[col[j - base] - base], r);
+        r = CH_D(val[j - base], x[col[j - base] - base], r);
     return r;
 }
 
@@ -77,7 +105,7 @@ static inline double row_lane8_d(const double *val, const oint *col, const doubl
         r = (v0 + v1) + (v2 + v3);
     }
     for(j = e - krem; j < e; j++)
-        r = fma(val[j - base], x[col[j - base] - base], r);
+        r = CH_D(val[j - base], x[col[j - base] - base], r);
     return r;
 }
 
@@ -100,7 +128,7 @@ static inline float row_lane8_s(const float *val, const oint *col, const float *
         r = d0 + d1;
     }
     for(j = e - krem; j < e; j++)
-        r = fmaf(val[j - base], x[col[j - base] - base], r);
+        r = CH_S(val[j - base], x[col[j - base] - base], r);
     return r;
 }
 
@@ -400,7 +428,7 @@ int orc_dcsrmv_tri(int base, double alpha, oint m, int diag, int fill, const dou
         if(so && diag == 1)
             r += x[i];
         for(oint j = rs + so; j < re + eo; j++)
-            r = fma(val[j - base], x[col[j - base] - base], r);
+            r = CH_D(val[j - base], x[col[j - base] - base], r);
         if(eo && diag == 1)
             r += x[i];
         y[i] = fma(alpha, r, y[i]);
@@ -442,7 +470,7 @@ int orc_dcsrmv_tri_t(int base, double alpha, oint m, oint n, int diag, int fill,
 /* ------------------------------------------------------------------------------------ */
 /* TRSV reference kernels, trsv_kr.hpp:38-222.  "xi -= a*x" contracts to fma(-a, x, xi). */
 /* ------------------------------------------------------------------------------------ */
-#define DEF_TRSV(T, SUF, FMA)                                                                \
+#define DEF_TRSV(T, SUF, FMA, CH)                                                                \
     int orc_##SUF##trsv_l(T alpha, oint m, int base, const T *a, const oint *icol,           \
                           const oint *ilrow, const oint *idiag, const T *b, oint incb, T *x, \
                           oint incx, int unit)                                               \
@@ -451,7 +479,7 @@ int orc_dcsrmv_tri_t(int base, double alpha, oint m, oint n, int diag, int fill,
         {                                                                                    \
             T xi = alpha * b[(size_t)i * incb];                                              \
             for(oint idx = ilrow[i]; idx < idiag[i]; idx++)                                  \
-                xi = FMA(-a[idx - base], x[(size_t)(icol[idx - base] - base) * incx], xi);   \
+                xi = CH(-a[idx - base], x[(size_t)(icol[idx - base] - base) * incx], xi);    \
             if(!unit)                                                                        \
                 xi /= a[idiag[i] - base];                                                    \
             x[(size_t)i * incx] = xi;                                                        \
@@ -466,7 +494,7 @@ int orc_dcsrmv_tri_t(int base, double alpha, oint m, oint n, int diag, int fill,
         {                                                                                    \
             T xi = alpha * b[(size_t)i * incb];                                              \
             for(oint idx = iurow[i]; idx <= ilrow[i + 1] - 1; idx++)                         \
-                xi = FMA(-a[idx - base], x[(size_t)(icol[idx - base] - base) * incx], xi);   \
+                xi = CH(-a[idx - base], x[(size_t)(icol[idx - base] - base) * incx], xi);    \
             if(!unit)                                                                        \
                 xi /= a[iurow[i] - 1 - base];                                                \
             x[(size_t)i * incx] = xi;                                                        \
@@ -474,8 +502,8 @@ int orc_dcsrmv_tri_t(int base, double alpha, oint m, oint n, int diag, int fill,
         return ORC_SUCCESS;                                                                  \
     }
 
-DEF_TRSV(double, d, fma)
-DEF_TRSV(float, s, fmaf)
+DEF_TRSV(double, d, fma, CH_D)
+DEF_TRSV(float, s, fmaf, CH_S)
 
 /* trsv_kr.hpp:101-120: x = alpha*b; for i = m-1..0: x[i] /= d; x[col] -= a*x[i]. */
 int orc_dtrsv_lt(double alpha, oint m, int base, const double *a, const oint *icol,
@@ -520,6 +548,159 @@ int orc_dtrsv_ut(double alpha, oint m, int base, const double *a, const oint *ic
 }
 
 /* ------------------------------------------------------------------------------------ */
+/* KT ("kernel template") TRSV kernels, level2/aoclsparse_trsv_kt.cpp:64-531 -- what the  */
+/* reference dispatches for kid 1/2 (256-bit vectors) and kid 3 / auto on an AVX-512 host  */
+/* (512-bit vectors), trsv.cpp:321-353.  tsz = lanes per vector: double 4 / 8, float 8 / 16.*/
+/* ------------------------------------------------------------------------------------ */
+
+/* kt_hsum_p: horizontal sum of one vector register.
+ *  b256 double (kernel-templates/kt_l0_avx2.hpp:333-340): hadd -> (v0+v1, v2+v3), lo + hi.
+ *  b256 float  (:342-350): hadd, hadd, lo + hi = ((v0+v1)+(v2+v3)) + ((v4+v5)+(v6+v7)).
+ *  b512 (kt_l0_avx512.hpp:369-376) = _mm512_reduce_add_pd/ps, a compiler-header sequence, not an
+ *  instruction; GCC's (avx512fintrin.h __MM512_REDUCE_OP): halves added lane-wise until two lanes
+ *  are left: double ((v0+v4)+(v2+v6)) + ((v1+v5)+(v3+v7)); float 16 -> 8 -> 4 -> 2 -> 1 likewise.
+ * Pinned bit for bit against the reference's own templates compiled from /root/reference
+ * (oracle/_ref/libktref.so, tests/golden/kt_vectors.json). */
+double orc_kt_hsum_d(int tsz, const double *v)
+{
+    if(tsz == 4)
+        return (v[0] + v[1]) + (v[2] + v[3]);
+    double t3[4], t6[2];
+    for(int i = 0; i < 4; i++)
+        t3[i] = v[4 + i] + v[i];
+    for(int i = 0; i < 2; i++)
+        t6[i] = t3[2 + i] + t3[i];
+    return t6[0] + t6[1];
+}
+
+float orc_kt_hsum_s(int tsz, const float *v)
+{
+    if(tsz == 8)
+        return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    float t3[8], t6[4], t8[2];
+    for(int i = 0; i < 8; i++)
+        t3[i] = v[8 + i] + v[i];
+    for(int i = 0; i < 4; i++)
+        t6[i] = t3[4 + i] + t3[i];
+    for(int i = 0; i < 2; i++)
+        t8[i] = t6[i] + t6[i + 2];
+    return t8[0] + t8[1];
+}
+
+/* One row of kt_trsv_l / kt_trsv_u (trsv_kt.cpp:92-137, :324-371): the entries idx0 .. idx0+cnt-1 (already
+ * offset by the base) are consumed as
+ *   full groups of tsz:  pvec[l] = fma(a, x, pvec[l])            (kt_fmadd_p, :109)
+ *   if cnt >= tsz:       xi -= hsum(pvec)                        (:111-114)
+ *   rem == tsz-1:        xi -= hsum(a .* x, last lane = 0*0)     (kt_maskz_set_p + kt_dot_p = mul, hsum; :121-131)
+ *   otherwise:           xi = fma(-a, x, xi) left to right       (the contracted "xi -= a*x", :136-137)
+ */
+#define DEF_KT_TRSV(T, SUF, FMA, CH, MAXL)                                                                \
+    static T kt_row_##SUF(int tsz, T xi, oint idx0, oint cnt, const T *a, const oint *icol, int base,  \
+                          const T *x, oint incx)                                                       \
+    {                                                                                                  \
+        T    p[MAXL];                                                                                  \
+        oint rem = cnt % tsz, idx = idx0;                                                              \
+        for(int l = 0; l < tsz; l++)                                                                   \
+            p[l] = 0;                                                                                  \
+        for(; idx < idx0 + cnt - rem; idx += tsz)                                                      \
+            for(int l = 0; l < tsz; l++)                                                               \
+                p[l] = FMA(a[idx + l], x[(size_t)(icol[idx + l] - base) * incx], p[l]);                \
+        if(cnt - tsz >= 0)                                                                             \
+            xi -= orc_kt_hsum_##SUF(tsz, p);                                                           \
+        if(rem == tsz - 1)                                                                             \
+        {                                                                                              \
+            for(int l = 0; l < tsz - 1; l++)                                                           \
+                p[l] = a[idx + l] * x[(size_t)(icol[idx + l] - base) * incx];                          \
+            p[tsz - 1] = (T)0 * (T)0;                                                                  \
+            xi -= orc_kt_hsum_##SUF(tsz, p);                                                           \
+        }                                                                                              \
+        else                                                                                           \
+            for(; idx < idx0 + cnt; idx++)                                                             \
+                xi = CH(-a[idx], x[(size_t)(icol[idx] - base) * incx], xi);                            \
+        return xi;                                                                                     \
+    }                                                                                                  \
+    /* kt_trsv_l, trsv_kt.cpp:64-150: forward rows; division after the chain (:140-148) */            \
+    int orc_##SUF##trsv_kt_l(int tsz, T alpha, oint m, int base, const T *a, const oint *icol,         \
+                             const oint *ilrow, const oint *idiag, const T *b, oint incb, T *x,        \
+                             oint incx, int unit)                                                      \
+    {                                                                                                  \
+        for(oint i = 0; i < m; i++)                                                                    \
+        {                                                                                              \
+            T xi = alpha * b[(size_t)i * incb];                                                        \
+            xi   = kt_row_##SUF(tsz, xi, ilrow[i] - base, idiag[i] - ilrow[i], a, icol, base, x, incx);\
+            if(!unit)                                                                                  \
+                xi /= a[idiag[i] - base];                                                              \
+            x[(size_t)i * incx] = xi;                                                                  \
+        }                                                                                              \
+        return ORC_SUCCESS;                                                                            \
+    }                                                                                                  \
+    /* kt_trsv_u, trsv_kt.cpp:297-383: backward rows over [iurow[i], ilrow[i+1]-1] */                 \
+    int orc_##SUF##trsv_kt_u(int tsz, T alpha, oint m, int base, const T *a, const oint *icol,         \
+                             const oint *ilrow, const oint *iurow, const T *b, oint incb, T *x,        \
+                             oint incx, int unit)                                                      \
+    {                                                                                                  \
+        for(oint i = m - 1; i >= 0; i--)                                                               \
+        {                                                                                              \
+            T xi = alpha * b[(size_t)i * incb];                                                        \
+            xi   = kt_row_##SUF(tsz, xi, iurow[i] - base, ilrow[i + 1] - iurow[i], a, icol, base, x,   \
+                                incx);                                                                 \
+            if(!unit)                                                                                  \
+                xi /= a[iurow[i] - 1 - base];                                                          \
+            x[(size_t)i * incx] = xi;                                                                  \
+        }                                                                                              \
+        return ORC_SUCCESS;                                                                            \
+    }                                                                                                  \
+    /* kt_trsv_lt / kt_trsv_ut, trsv_kt.cpp:183-268, :416-503: x = alpha*b (only when alpha != 0, :208-210); per row */ \
+    /* x[i] /= d, then every entry x[col] = fma(a, -x[i], x[col]) -- vector groups (:236-238), the masked group  */   \
+    /* (:254-258) and the contracted scalar tail "x[col] -= a*xi" (:264-266) are the same per-element operation, */   \
+    /* so the tsz argument changes nothing: these two equal ref_trsv_lth / ref_trsv_uth bit for bit.             */   \
+    int orc_##SUF##trsv_kt_lt(int tsz, T alpha, oint m, int base, const T *a, const oint *icol,        \
+                              const oint *ilrow, const oint *idiag, const T *b, oint incb, T *x,       \
+                              oint incx, int unit)                                                     \
+    {                                                                                                  \
+        (void)tsz;                                                                                     \
+        if(alpha != (T)0)                                                                              \
+            for(oint i = 0; i < m; i++)                                                                \
+                x[(size_t)i * incx] = alpha * b[(size_t)i * incb];                                     \
+        for(oint i = m - 1; i >= 0; i--)                                                               \
+        {                                                                                              \
+            if(!unit)                                                                                  \
+                x[(size_t)i * incx] /= a[idiag[i] - base];                                             \
+            T mxi = -x[(size_t)i * incx];                                                              \
+            for(oint idx = ilrow[i] - base; idx < idiag[i] - base; idx++)                              \
+            {                                                                                          \
+                size_t c = (size_t)(icol[idx] - base) * incx;                                          \
+                x[c]     = FMA(a[idx], mxi, x[c]);                                                     \
+            }                                                                                          \
+        }                                                                                              \
+        return ORC_SUCCESS;                                                                            \
+    }                                                                                                  \
+    int orc_##SUF##trsv_kt_ut(int tsz, T alpha, oint m, int base, const T *a, const oint *icol,        \
+                              const oint *ilrow, const oint *iurow, const T *b, oint incb, T *x,       \
+                              oint incx, int unit)                                                     \
+    {                                                                                                  \
+        (void)tsz;                                                                                     \
+        if(alpha != (T)0)                                                                              \
+            for(oint i = 0; i < m; i++)                                                                \
+                x[(size_t)i * incx] = alpha * b[(size_t)i * incb];                                     \
+        for(oint i = 0; i < m; i++)                                                                    \
+        {                                                                                              \
+            if(!unit)                                                                                  \
+                x[(size_t)i * incx] = x[(size_t)i * incx] / a[iurow[i] - 1 - base];                    \
+            T mxi = -x[(size_t)i * incx];                                                              \
+            for(oint idx = iurow[i] - base; idx <= ilrow[i + 1] - 1 - base; idx++)                     \
+            {                                                                                          \
+                size_t c = (size_t)(icol[idx] - base) * incx;                                          \
+                x[c]     = FMA(a[idx], mxi, x[c]);                                                     \
+            }                                                                                          \
+        }                                                                                              \
+        return ORC_SUCCESS;                                                                            \
+    }
+
+DEF_KT_TRSV(double, d, fma, CH_D, 8)
+DEF_KT_TRSV(float, s, fmaf, CH_S, 16)
+
+/* ------------------------------------------------------------------------------------ */
 /* csrmm reference kernels, csrmm.hpp:36-144.                                            */
 /* ------------------------------------------------------------------------------------ */
 
@@ -534,7 +715,7 @@ int orc_dcsrmm_col(double alpha, int base, const double *val, const oint *col,
         {
             double sum = 0.0;
             for(oint k = row[i]; k < row[i + 1]; k++)
-                sum = fma(val[k - base], B[(size_t)(col[k - base] - base) + (size_t)j * ldb], sum);
+                sum = CH_D(val[k - base], B[(size_t)(col[k - base] - base) + (size_t)j * ldb], sum);
             size_t ic = (size_t)i + (size_t)j * ldc;
             C[ic]     = fma(beta, C[ic], alpha * sum);
         }
@@ -558,6 +739,73 @@ int orc_dcsrmm_row(double alpha, int base, const double *val, const oint *col,
             double        av   = val[j - base];
             for(oint k = 0; k < n; k++)
                 c[k] = fma(av * brow[k], alpha, c[k]);
+        }
+    }
+    return ORC_SUCCESS;
+}
+
+/* csrmm_col_kt, level3/aoclsparse_csrmm_kt.cpp:31-197 (kid 1/2: psz = 4 lanes, kid 3 / auto on an AVX-512 host: 8).
+ * Per element (i, j), four columns at a time share the loads but not the arithmetic:
+ *   nnz >= psz: cvec[l] = fma(a, b, cvec[l]) over the full groups (:144-147), cij = 0 + hsum(cvec) (:149-156);
+ *   tail:       cij = fma(a, b, cij) left to right (the contracted "cij += aval * b", :165-168);
+ *   cij *= alpha; C = beta*C + cij (:172-191) -- one fma, which product is fused depends on the compiler (below).
+ * C is read even when beta == 0. */
+int orc_dcsrmm_col_kt(int psz, double alpha, int base, const double *val, const oint *col,
+                      const oint *row, oint m, const double *B, oint n, oint ldb, double beta,
+                      double *C, oint ldc)
+{
+    for(oint j = 0; j < n; j++)
+        for(oint i = 0; i < m; i++)
+        {
+            const double *bc  = B + (size_t)j * ldb;
+            oint          s   = row[i] - base, e = row[i + 1] - base;
+            oint          nnz = e - s, mul = nnz / psz, rem = nnz - psz * mul;
+            double        cij = 0.0;
+            if(mul)
+            {
+                double p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for(oint k = s; k < e - rem; k += psz)
+                    for(int l = 0; l < psz; l++)
+                        p[l] = fma(val[k + l], bc[col[k + l] - base], p[l]);
+                cij += orc_kt_hsum_d(psz, p);
+            }
+            for(oint k = e - rem; k < e; k++)
+                cij = CH_D(val[k], bc[col[k] - base], cij);
+            size_t ic = (size_t)i + (size_t)j * ldc;
+            /* "cij *= alpha; C = beta*C + cij": two products feed one addition and the compiler picks which one it
+             * fuses.  Statement-wise contraction (clang -ffp-contract=on style): fma(beta, C, alpha*cij);
+             * GCC's widening_mul pass takes the first product it meets: fma(cij, alpha, beta*C) -- measured on
+             * oracle/_ref/libktref.so (tests/golden/kt_vectors.json). */
+            if(g_fused)
+                C[ic] = fma(beta, C[ic], cij * alpha);
+            else
+                C[ic] = fma(cij, alpha, beta * C[ic]);
+        }
+    return ORC_SUCCESS;
+}
+
+/* csrmm_row_kt, csrmm_kt.cpp:199-363.  C_row = C_row * beta first (:244-247, a multiplication also for beta == 0);
+ * then the row's entries in CSR order (groups of four only share loads): columns j < n - n % psz take
+ * c = fma(alpha*a_k, b_kj, c) (kt_set1_p(alpha*sv), kt_fmadd_p, :289-322), the last n % psz columns the scalar
+ * statement "C += sv * B * alpha" (:335-356) = fma(sv*b, alpha, c) after contraction. */
+int orc_dcsrmm_row_kt(int psz, double alpha, int base, const double *val, const oint *col,
+                      const oint *row, oint m, const double *B, oint n, oint ldb, double beta,
+                      double *C, oint ldc)
+{
+    oint rem = n % psz;
+    for(oint i = 0; i < m; i++)
+    {
+        double *c = C + (size_t)i * ldc;
+        for(oint j = 0; j < n; j++)
+            c[j] = c[j] * beta;
+        for(oint k = row[i] - base; k < row[i + 1] - base; k++)
+        {
+            const double *brow = B + (size_t)(col[k] - base) * ldb;
+            double        sv = val[k], av = alpha * sv;
+            for(oint j = 0; j < n - rem; j++)
+                c[j] = fma(av, brow[j], c[j]);
+            for(oint j = n - rem; j < n; j++)
+                c[j] = fma(sv * brow[j], alpha, c[j]);
         }
     }
     return ORC_SUCCESS;

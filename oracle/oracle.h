@@ -118,6 +118,27 @@ int orc_strsv_u(float alpha, oint m, int base, const float *a, const oint *icol,
                 const oint *ilrow, const oint *iurow, const float *b, oint incb, float *x,
                 oint incx, int unit);
 
+/* 1 (default): every "acc += a*b" of the reference is one fma (clang / AOCC build, or GCC without znver tuning);
+ * 0: loop-carried scalar accumulations are a multiplication and an addition (GCC build with the reference's -march=znver2). */
+void orc_set_contract(int fused);
+int  orc_get_contract(void);
+
+/* ---- KT TRSV kernels, level2/aoclsparse_trsv_kt.cpp:64-531 (kid 1/2: tsz 4 double / 8 float; kid 3: 8 / 16) ---- */
+double orc_kt_hsum_d(int tsz, const double *v);
+float  orc_kt_hsum_s(int tsz, const float *v);
+#define ORC_DECL_KT_TRSV(T, SUF, K)                                                                      \
+    int orc_##SUF##trsv_kt_##K(int tsz, T alpha, oint m, int base, const T *a, const oint *icol,         \
+                               const oint *ilrow, const oint *ilend, const T *b, oint incb, T *x,        \
+                               oint incx, int unit);
+ORC_DECL_KT_TRSV(double, d, l)
+ORC_DECL_KT_TRSV(double, d, lt)
+ORC_DECL_KT_TRSV(double, d, u)
+ORC_DECL_KT_TRSV(double, d, ut)
+ORC_DECL_KT_TRSV(float, s, l)
+ORC_DECL_KT_TRSV(float, s, lt)
+ORC_DECL_KT_TRSV(float, s, u)
+ORC_DECL_KT_TRSV(float, s, ut)
+
 /* ---- csrmm, C = alpha*A*B + beta*C, level3/aoclsparse_csrmm.hpp:36-144, 361-427 ------ */
 int orc_dcsrmm_col(double alpha, int base, const double *val, const oint *col,
                    const oint *row, oint m, const double *B, oint n, oint ldb, double beta,
@@ -125,6 +146,14 @@ int orc_dcsrmm_col(double alpha, int base, const double *val, const oint *col,
 int orc_dcsrmm_row(double alpha, int base, const double *val, const oint *col,
                    const oint *row, oint m, const double *B, oint n, oint ldb, double beta,
                    double *C, oint ldc);
+/* KT kernels (what kid 1/2/3 and the auto dispatch of an AVX host run): level3/aoclsparse_csrmm_kt.cpp:31-363;
+ * psz = lanes per vector (4: kid 1/2, 8: kid 3). */
+int orc_dcsrmm_col_kt(int psz, double alpha, int base, const double *val, const oint *col,
+                      const oint *row, oint m, const double *B, oint n, oint ldb, double beta,
+                      double *C, oint ldc);
+int orc_dcsrmm_row_kt(int psz, double alpha, int base, const double *val, const oint *col,
+                      const oint *row, oint m, const double *B, oint n, oint ldb, double beta,
+                      double *C, oint ldc);
 /* order: 0 row-major, 1 column-major (aoclsparse_types.h:289-293). */
 int orc_dscale_dense(int order, double *C, oint m, oint n, oint ld, double beta);
 
