@@ -443,6 +443,11 @@ struct _aoclsparse_matrix
     mi355::DeviceBuffer dev_diag; // diagonal values of the clean CSR (length min(m,n))
     mi355::DeviceBuffer trsv_scratch; // ticket (one per right-hand side) + timeout words of the sync-free solve
     mi355::DeviceBuffer trsv_xp; // solution(s) in level order, m x nrhs (stream-ordered reuse)
+    // one word of pinned, device-mapped host memory THIS handle's sync-free solves set when a wait expires (round 3,
+    // the process-wide word of round 2 could not say which handle had failed, and a failure surfaced on an
+    // unrelated solve).  Allocated at the handle's first sync-free solve; read without a device round trip.
+    volatile unsigned int *trsv_timeout_host = nullptr;
+    unsigned int          *trsv_timeout_dev  = nullptr;
 
     // matrices derived from the clean CSR for non-general descriptors (symmetric expansion,
     // triangular slices), built on first use: see derived.cpp

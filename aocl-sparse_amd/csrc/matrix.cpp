@@ -477,22 +477,13 @@ aoclsparse_status build_spmv_plan(aoclsparse_int m, aoclsparse_int nnz, aoclspar
             part[c].reserve((size_t)(r1 - r0) / 64 + 16);
             plan_rows_range(r0, r1, base, tile, row_ptr_host, part[c], lrs[c], mxs[c]);
         };
-        if(nchunks == 1)
-            work(0);
-        else
-        {
-            const unsigned hw = std::thread::hardware_concurrency();
-            const int      nt = (int)std::min<unsigned>(8u, hw ? hw : 1u);
-            std::vector<std::thread> th;
-            std::atomic<int>         next{0};
-            for(int t = 0; t < nt; t++)
-                th.emplace_back([&] {
-                    for(int c = next.fetch_add(1); c < nchunks; c = next.fetch_add(1))
-                        work(c);
-                });
-            for(auto &t : th)
-                t.join();
-        }
+        // parallel_for (internal.hpp) carries a worker's exception (bad_alloc inside reserve / push_back) to this thread and
+        // runs a chunk inline when a thread cannot be started, so nothing can reach std::terminate below the C ABI
+        // (ADVICE r2); the 16 chunks are fixed, so the plan does not depend on how many threads took them.
+        mi355::parallel_for(nchunks, 1, [&](long long c0, long long c1) {
+            for(long long c = c0; c < c1; c++)
+                work((int)c);
+        });
         std::vector<aoclsparse_int> blk;
         size_t                      total = 2;
         for(auto &p : part)
@@ -557,6 +548,10 @@ aoclsparse_status build_spmv_plan(aoclsparse_int m, aoclsparse_int nnz, aoclspar
     catch(const std::bad_alloc &)
     {
         return aoclsparse_status_memory_error;
+    }
+    catch(const std::exception &)
+    {
+        return aoclsparse_status_internal_error;
     }
     return aoclsparse_status_success;
 }
@@ -957,6 +952,8 @@ aoclsparse_status aoclsparse_destroy(aoclsparse_matrix *mat)
         if((*mat)->ilu_factor)
             aoclsparse_destroy(&(*mat)->ilu_factor); // aliases ptr/ind/ilu_val: frees only its own plans
         std::free((*mat)->ilu_val);
+        if((*mat)->trsv_timeout_host)
+            (void)hipHostFree(const_cast<unsigned int *>((*mat)->trsv_timeout_host));
         delete *mat;
         *mat = nullptr;
     }

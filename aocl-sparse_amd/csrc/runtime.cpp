@@ -98,7 +98,11 @@ aoclsparse_status Runtime::init()
     }
     std::lock_guard<std::mutex> g(lock);
     if(inited_.load(std::memory_order_relaxed))
+    {
+        // lost the first-init race: this thread still has to be bound to the library's device
+        bind_thread();
         return init_status_;
+    }
     int        count = 0;
     hipError_t e     = hipGetDeviceCount(&count);
     if(e != hipSuccess || count <= 0)

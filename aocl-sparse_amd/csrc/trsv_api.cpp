@@ -510,11 +510,29 @@ aoclsparse_status solve_core(aoclsparse_operation trans, T alpha, aoclsparse_mat
     // chained rows (the dofs of a node) solved back to back by one lane: one hop per BLOCK level instead of per row level
     const int sfb = (sf_env == 0 && plan.blk.valid) ? 4 : sf; // (trsm too: one grid column per right-hand side)
     const int schedule = is_cplx ? 1 : kid == 0 ? 0 : (kid == 3 ? sfb : (kid > 0 ? 1 : (plan.nlevels <= 32 ? 0 : sfb)));
-    // a wait that expired in an EARLIER asynchronous (device-pointer) solve is reported now
-    if(rt.trsv_timeout_host && *rt.trsv_timeout_host)
+    // the handle's own timeout word (pinned, device-mapped): allocated once per handle
+    if(!is_cplx && !A->trsv_timeout_dev)
+    {
+        void *tw = nullptr, *twd = nullptr;
+        if(hipHostMalloc(&tw, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&twd, tw, 0) == hipSuccess)
+        {
+            A->trsv_timeout_host  = static_cast<volatile unsigned int *>(tw);
+            *A->trsv_timeout_host = 0;
+            A->trsv_timeout_dev   = static_cast<unsigned int *>(twd);
+        }
+        else
+        {
+            (void)hipGetLastError(); // the solve then keeps its device-side word and a blocking read
+            if(tw)
+                (void)hipHostFree(tw);
+        }
+    }
+    // a wait that expired in an EARLIER asynchronous (device-pointer) solve OF THIS HANDLE is reported now; callers that
+    // never solve again ask aoclsparse_mi355_trsv_status(A) after their own stream synchronisation
+    if(A->trsv_timeout_host && *A->trsv_timeout_host)
     {
         (void)hipStreamSynchronize(rt.stream());
-        *rt.trsv_timeout_host = 0;
+        *A->trsv_timeout_host = 0;
         return aoclsparse_status_internal_error;
     }
 
@@ -552,13 +570,13 @@ aoclsparse_status solve_core(aoclsparse_operation trans, T alpha, aoclsparse_mat
     else
         st = launch_trsv<T>(rt.stream(), schedule, unit, alpha, m, plan, A->dev_diag.as<T>(), db, dx,
                             A->trsv_xp.as<T>(), A->trsv_scratch.as<unsigned int>(), nrhs, b_off, incb, x_off, incx,
-                            rt.trsv_timeout_dev);
+                            A->trsv_timeout_dev);
     if(st != aoclsparse_status_success)
         return st;
     if(!xdev)
         MI355_HIP_TRY(hipMemcpyAsync(x, dx, sizeof(T) * span_x, hipMemcpyDeviceToHost, rt.stream()));
     const bool syncfree = !is_cplx && (schedule >= 2 || (schedule == 1 && (nrhs != 1 || incb != 1 || incx != 1)));
-    const bool pinned_word = rt.trsv_timeout_dev != nullptr;
+    const bool pinned_word = A->trsv_timeout_dev != nullptr;
     if(!xdev || (syncfree && !pinned_word))
     {
         // host semantics (the result must be in the caller's memory on return); without the pinned word the
@@ -575,9 +593,9 @@ aoclsparse_status solve_core(aoclsparse_operation trans, T alpha, aoclsparse_mat
     }
     // device-pointer solves stay asynchronous: an expired wait (never expected) is seen at the next solve; a
     // host-pointer solve has just synchronised and reports it now
-    if(syncfree && pinned_word && !xdev && *rt.trsv_timeout_host)
+    if(syncfree && pinned_word && !xdev && *A->trsv_timeout_host)
     {
-        *rt.trsv_timeout_host = 0;
+        *A->trsv_timeout_host = 0;
         return aoclsparse_status_internal_error;
     }
     return aoclsparse_status_success;
@@ -933,6 +951,18 @@ aoclsparse_status aoclsparse_mi355_ztrsv_full(aoclsparse_operation trans, aoclsp
 {
     return trsv_t<cdouble>(trans, cdouble(alpha.real, alpha.imag), A, descr, reinterpret_cast<const cdouble *>(b), incb,
                            reinterpret_cast<cdouble *>(x), incx, kid, aoclsparse_zmat);
+}
+
+aoclsparse_status aoclsparse_mi355_trsv_status(aoclsparse_matrix A)
+{
+    if(!A)
+        return aoclsparse_status_invalid_pointer;
+    if(A->trsv_timeout_host && *A->trsv_timeout_host)
+    {
+        *A->trsv_timeout_host = 0;
+        return aoclsparse_status_internal_error;
+    }
+    return aoclsparse_status_success;
 }
 
 aoclsparse_status aoclsparse_mi355_get_trsv_levels(const aoclsparse_matrix A, aoclsparse_fill_mode fill,

@@ -534,25 +534,18 @@ __global__ __launch_bounds__(64 * WV) void trsv_slice_kernel(
 //     clamped indices and selects, that phase was ~1,500 instructions = 1.84 us per block level);
 //   * pending dependencies are polled together, one round of loads per look;
 //   * a wavefront does not look at all before the level two below its own is complete (the gate).
-__device__ __forceinline__ void lds_read_pair_async(double (&d)[2], unsigned int addr)
+// Paired LDS reads of the row-by-row path (larger shapes).  Ordinary vector loads: round 2 issued them from inline asm
+// without a wait in the same statement, which left their ordering against the C++ stores that fill the slots and against
+// register copies to the register allocator; the compiler now sees the loads and places the waits itself.
+template <typename T>
+__device__ __forceinline__ void lds_read_pair(T (&d)[2], const T *slot)
 {
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    d2             v;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    typedef T T2 __attribute__((ext_vector_type(2)));
+    const T2  v = *reinterpret_cast<const T2 *>(slot);
     d[0] = v.x, d[1] = v.y;
 }
-__device__ __forceinline__ void lds_read_pair_async(float (&d)[2], unsigned int addr)
-{
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    f2            v;
-    asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr));
-    d[0] = v.x, d[1] = v.y;
-}
-__device__ __forceinline__ void lds_read_wait()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
-// orders the first use of a value read by lds_read_pair_async after lds_read_wait
+
+// (trace builds) keeps the stamp that follows behind the arithmetic that produced v
 template <typename T>
 __device__ __forceinline__ void lds_read_landed(T &v)
 {
@@ -725,13 +718,12 @@ __global__ __launch_bounds__(64) void trsv_block_kernel(
 #pragma unroll
     for(int e = 0; e < EXT; e++)
         __builtin_memcpy(&xe[e], &bits[e], sizeof(T)); // 0 beyond the row (bits = 0), times a 0 value below
-    const unsigned int base = (unsigned int)(size_t)s_mine;
-    auto               read_row = [&](int a, T(&ve)[EXT], T(&vn)[BSP]) {
+    auto read_row = [&](int a, T(&ve)[EXT], T(&vn)[BSP]) {
 #pragma unroll
         for(int e = 0; e < EXT; e += 2)
         {
             T pr[2];
-            lds_read_pair_async(pr, base + (unsigned int)((a * EXT + e) * sizeof(T)));
+            lds_read_pair(pr, &s_mine[a * EXT + e]);
             ve[e] = pr[0], ve[e + 1] = pr[1];
         }
 #pragma unroll
@@ -739,18 +731,9 @@ __global__ __launch_bounds__(64) void trsv_block_kernel(
             if(tt < a)
             {
                 T pr[2];
-                lds_read_pair_async(pr, base + (unsigned int)((INT0 + a * BSP + tt) * sizeof(T)));
+                lds_read_pair(pr, &s_mine[INT0 + a * BSP + tt]);
                 vn[tt] = pr[0], vn[tt + 1] = pr[1];
             }
-    };
-    auto landed = [&](int a, T(&ve)[EXT], T(&vn)[BSP]) {
-#pragma unroll
-        for(int e = 0; e < EXT; e++)
-            lds_read_landed(ve[e]);
-#pragma unroll
-        for(int tt = 0; tt < BSP; tt++)
-            if(tt < a + (a & 1))
-                lds_read_landed(vn[tt]);
     };
     // a single row with more than EXT dependencies (never inside a multi-row block): the rest one by one
     auto long_row_tail = [&](T &x0) {
@@ -881,8 +864,6 @@ __global__ __launch_bounds__(64) void trsv_block_kernel(
         {
             T ve[EXT], vn[BSP];
             read_row(a, ve, vn);
-            lds_read_wait();
-            landed(a, ve, vn);
             xi[a] = rhs[a];
             if constexpr(FRONT)
             {

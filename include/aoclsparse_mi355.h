@@ -91,6 +91,11 @@ DLL_PUBLIC aoclsparse_status aoclsparse_mi355_get_trsv_levels(const aoclsparse_m
                                                               aoclsparse_fill_mode    fill,
                                                               aoclsparse_operation    op,
                                                               aoclsparse_int         *levels);
+/* Asynchronous (device-pointer) aoclsparse_?trsv / ?trsm calls return before the solve has run.  Should one of the
+ * sync-free kernels ever give up a wait (5 s of wall time: a lost dependency, never seen in testing), it leaves x untouched
+ * and sets a word owned by the handle.  Call this AFTER synchronising your stream: internal_error if a solve of THIS handle
+ * expired since the last query (the word is cleared), success otherwise.  Host-pointer solves report it themselves. */
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_trsv_status(aoclsparse_matrix A);
 /* drop every device-side copy/plan of the handle (call after mutating the aliased arrays) */
 DLL_PUBLIC aoclsparse_status aoclsparse_mi355_invalidate(aoclsparse_matrix A);
 
