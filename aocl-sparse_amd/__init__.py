@@ -341,11 +341,16 @@ SIGNATURES = {
     "aoclsparse_mi355_timer_laps": (c_int, [POINTER(c_float), _I, POINTER(_I)]),
     "aoclsparse_mi355_column_shard": (c_int, [_I, _I, _I, POINTER(_I), POINTER(_I)]),
     "aoclsparse_mi355_dcsrmm_shard": (c_int, [c_int, c_double, _P, _P, c_int, _P, _I, _I, c_double, _P, _I, _I, _I]),
+    "aoclsparse_mi355_dcsrmm_multi": (c_int, [c_int, c_double, _P, _P, c_int, _P, _I, _I, c_double, _P, _I, _I, _P]),
+    "aoclsparse_mi355_replica_count": (c_int, [_P]),
+    "aoclsparse_mi355_scsrmm_multi": (c_int, [c_int, c_float, _P, _P, c_int, _P, _I, _I, c_float, _P, _I, _I, _P]),
+    "aoclsparse_mi355_dcsrmm_multi_slabs": (c_int, [c_int, c_double, _P, _P, c_int, _P, _I, _I, c_double, _P, _I, _I, _P]),
     "aoclsparse_mi355_scsrmm_shard": (c_int, [c_int, c_float, _P, _P, c_int, _P, _I, _I, c_float, _P, _I, _I, _I]),
     "aoclsparse_mi355_export_diag": (c_int, [_P, POINTER(_P), POINTER(_P), POINTER(_I)]),
     "aoclsparse_mi355_get_spmv_info": (c_int, [_P, c_int, POINTER(SpmvInfo)]),
     "aoclsparse_mi355_get_trsv_levels": (c_int, [_P, c_int, c_int, POINTER(_I)]),
     "aoclsparse_mi355_trsv_status": (c_int, [_P]),
+    "aoclsparse_mi355_set_csrmm_beta0_overwrite": (c_int, [c_int]),
     "aoclsparse_mi355_invalidate": (c_int, [_P]),
     "mi355_csrmv_plan_bound": (_I, [_I, _I]),
     "mi355_csrmv_plan_host": (_I, [_I, _I, _I, _P, _P]),
@@ -572,3 +577,19 @@ def column_shard(ncols, world, rank):
 def dcsrmm_shard(op, alpha, A, descr, order, B, n, ldb, beta, C, ldc, world, rank):
     return lib().aoclsparse_mi355_dcsrmm_shard(op, alpha, A.h, descr.h, order, _ptr(B), n, ldb, beta, _ptr(C), ldc,
                                                world, rank)
+
+
+def dcsrmm_multi(op, alpha, A, descr, order, B, n, ldb, beta, C, ldc, devices):
+    """aoclsparse_mi355_dcsrmm_multi: full host operands, one worker per entry of `devices` (list of HIP ordinals)."""
+    dv = (c_int32 * len(devices))(*devices)
+    return lib().aoclsparse_mi355_dcsrmm_multi(op, alpha, A.h, descr.h, order, _ptr(B), n, ldb, beta, _ptr(C), ldc,
+                                               len(devices), ctypes.cast(dv, c_void_p))
+
+
+def dcsrmm_multi_slabs(op, alpha, A, descr, order, B_slabs, n, ldb, beta, C_slabs, ldc, devices):
+    """aoclsparse_mi355_dcsrmm_multi_slabs: B_slabs[i] / C_slabs[i] are tensors resident on devices[i]."""
+    dv = (c_int32 * len(devices))(*devices)
+    bp = (c_void_p * len(devices))(*[_ptr(b) for b in B_slabs])
+    cp = (c_void_p * len(devices))(*[_ptr(c) for c in C_slabs])
+    return lib().aoclsparse_mi355_dcsrmm_multi_slabs(op, alpha, A.h, descr.h, order, ctypes.cast(bp, c_void_p), n, ldb, beta,
+                                                     ctypes.cast(cp, c_void_p), ldc, len(devices), ctypes.cast(dv, c_void_p))

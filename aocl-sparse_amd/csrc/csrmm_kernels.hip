@@ -6,7 +6,9 @@
 // Appendix B), which costs a third of the traffic at 256 columns.  Here, for beta == 0, C is read only
 // where alpha*sum is an exact zero (the one case where fma(0, C, z) != z for finite C: the sign of the
 // zero): bit-identical to the reference for every FINITE C, while a NaN/Inf already sitting in C is
-// overwritten instead of propagated.  AOCLSPARSE_MI355_CSRMM_STRICT_BETA0=1 restores the read.
+// overwritten instead of propagated.  Round 3: that is the OPT-IN mode (aoclsparse_mi355_set_csrmm_beta0_overwrite(1) or
+// AOCLSPARSE_MI355_CSRMM_BETA0_OVERWRITE=1); by default C is read for beta == 0 too, as every reference kernel does
+// (csrmm.hpp:83,129; csrmm_kt.cpp:176-191,246), so NaN / Inf in C propagate exactly as there.
 //
 // HBM-bound (AI ~ 0.6 flop/B at 256 columns, 5 nnz/row): no MFMA -- the dense tiles a 5-point
 // stencil would give an MFMA are >90 % zeros, so reshaping to GEMM only adds traffic.
@@ -836,7 +838,7 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup_sub_kernel(int base, T alp
 // order, so the bits are those of every other kernel here.  beta == 0 stores are non-temporal (C is written once and
 // not read again by this launch).  32 columns of the 1000^2 Laplacian: 0.131 ms against 0.195 ms for csrmm_row_kernel
 // (tools/csrmm_r2.hip, profiles/r2/csrmm_experiments.txt).
-template <typename T, int LANES, int TILE>
+template <typename T, int LANES, int TILE, int UR, int NB, bool RC>
 __global__ __launch_bounds__(256) void csrmm_tile_kernel(int base, T alpha, const T *__restrict__ val,
                                                          const aoclsparse_int *__restrict__ col,
                                                          const aoclsparse_int *__restrict__ row_ptr,
@@ -848,8 +850,7 @@ __global__ __launch_bounds__(256) void csrmm_tile_kernel(int base, T alpha, cons
     using V               = typename vec2<T>::type;
     constexpr int MAXR    = 512; // spmv_maxrows(TILE) <= 512
     constexpr int NSUB    = 256 / LANES;
-    constexpr int UR      = 2; // rows in flight per sub-wave
-    constexpr int NB      = 8; // B-row loads per row and step
+    // UR rows in flight per sub-wave, NB B-row loads per row and step; RC: C is read (beta != 0, or the reference's 0 * C)
     __shared__ int s_ptr[MAXR + 1];
     __shared__ int s_col[TILE];
     __shared__ T   s_val[TILE];
@@ -908,12 +909,18 @@ __global__ __launch_bounds__(256) void csrmm_tile_kernel(int base, T alpha, cons
     {
         int p0[UR], p1[UR];
         T   a0[UR], a1[UR];
+        V   cin[UR];
 #pragma unroll
         for(int q = 0; q < UR; q++)
         {
             const int rr = r + q * NSUB;
             p0[q] = rr < nrows ? s_ptr[rr] : 0, p1[q] = rr < nrows ? s_ptr[rr + 1] : 0;
             a0[q] = T(0), a1[q] = T(0);
+            // C is read (beta != 0, or the reference's 0 * C): requested BEFORE the B rows, so that the read-modify-write
+            // at the end of the row does not add a dependent round trip (round 3)
+            if constexpr(RC)
+                if(rr < nrows)
+                    cin[q] = *reinterpret_cast<const V *>(C + (size_t)(r0 + rr) * ldc + j);
         }
         bool more = true;
         while(more)
@@ -944,7 +951,17 @@ __global__ __launch_bounds__(256) void csrmm_tile_kernel(int base, T alpha, cons
 #pragma unroll
         for(int q = 0; q < UR; q++)
             if(r + q * NSUB < nrows)
-                put(r0 + r + q * NSUB, a0[q], a1[q]);
+            {
+                if constexpr(RC)
+                {
+                    V c;
+                    c.x = mm_fma(beta, cin[q].x, alpha * a0[q]);
+                    c.y = mm_fma(beta, cin[q].y, alpha * a1[q]);
+                    *reinterpret_cast<V *>(C + (size_t)(r0 + r + q * NSUB) * ldc + j) = c;
+                }
+                else
+                    put(r0 + r + q * NSUB, a0[q], a1[q]);
+            }
     }
 }
 
@@ -1212,11 +1229,7 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
 {
     if(m <= 0 || n <= 0)
         return aoclsparse_status_success;
-    static const bool strict_beta0 = [] {
-        const char *e = getenv("AOCLSPARSE_MI355_CSRMM_STRICT_BETA0");
-        return e && atoi(e) != 0;
-    }();
-    const bool readc = beta != T(0) || strict_beta0;
+    const bool readc = csrmm_reads_c(beta != T(0));
     // XCD-contiguous row order (every kernel): each XCD's L2 then serves the B rows its rows share.
     // Row-major n=256 on the 1000^2 Laplacian: 0.96 vs 1.21 ms.  AOCLSPARSE_MI355_CSRMM_XCD=0 disables.
     static const bool xcd = [] {
@@ -1359,11 +1372,7 @@ aoclsparse_status launch_csrmm_groups_ccol(hipStream_t s, int base, T alpha, con
 {
     if(ngroups <= 0 || n <= 0)
         return aoclsparse_status_success;
-    static const bool strict_beta0 = [] {
-        const char *e = getenv("AOCLSPARSE_MI355_CSRMM_STRICT_BETA0");
-        return e && atoi(e) != 0;
-    }();
-    const bool readc = beta != T(0) || strict_beta0;
+    const bool readc = csrmm_reads_c(beta != T(0));
     if(n < 128)
     {
         auto gosub = [&](auto gr_tag) {
@@ -1467,27 +1476,45 @@ aoclsparse_status launch_csrmm_tiled(hipStream_t s, int base, T alpha, const T *
 {
     if(nblocks <= 0 || n <= 0)
         return aoclsparse_status_success;
-    static const bool strict_beta0 = [] {
-        const char *e = getenv("AOCLSPARSE_MI355_CSRMM_STRICT_BETA0");
-        return e && atoi(e) != 0;
-    }();
-    const bool readc = beta != T(0) || strict_beta0;
+    const bool readc = csrmm_reads_c(beta != T(0));
     static const bool xcd = [] {
         const char *e = getenv("AOCLSPARSE_MI355_CSRMM_XCD");
         return e ? atoi(e) != 0 : true;
     }();
     const int  chunk = xcd ? (nblocks + 7) / 8 : 0; // XCD-contiguous block order, as the other csrmm kernels
-    auto       go    = [&](auto lanes_tag, auto tile_tag) {
-        constexpr int LANES = decltype(lanes_tag)::value, TILE = decltype(tile_tag)::value;
-        hipLaunchKernelGGL((csrmm_tile_kernel<T, LANES, TILE>), dim3(xcd ? chunk * 8 : nblocks, (n + 2 * LANES - 1) / (2 * LANES)), dim3(256),
-                           0, s, base, alpha, val, col, row_ptr, blocks, nblocks, B, n, ldb, beta, C, ldc, readc, chunk);
+    // (UR, NB) = rows in flight per 16-lane sub-wave x B-row loads per row and step; experiment knob AOCLSPARSE_MI355_EXP_TILE_SHAPE=<UR><NB>
+    static const int shape = [] { const char *e = getenv("AOCLSPARSE_MI355_EXP_TILE_SHAPE"); return e ? atoi(e) : 28; }();
+    static const int pad = [] { const char *e = getenv("AOCLSPARSE_MI355_EXP_TILE_PAD"); return e ? atoi(e) : 0; }();
+    auto       go3   = [&](auto tile_tag, auto ur_tag, auto nb_tag, auto rc_tag) {
+        constexpr int  TILE = decltype(tile_tag)::value, UR = decltype(ur_tag)::value, NB = decltype(nb_tag)::value;
+        constexpr bool RC   = decltype(rc_tag)::value;
+        hipLaunchKernelGGL((csrmm_tile_kernel<T, 16, TILE, UR, NB, RC>), dim3(xcd ? chunk * 8 : nblocks, (n + 31) / 32), dim3(256),
+                           (size_t)pad, s, base, alpha, val, col, row_ptr, blocks, nblocks, B, n, ldb, beta, C, ldc, readc, chunk);
     };
-    using L16 = std::integral_constant<int, 16>;
+    auto go2 = [&](auto tile_tag, auto ur_tag, auto nb_tag) {
+        if(readc)
+            go3(tile_tag, ur_tag, nb_tag, std::true_type{});
+        else
+            go3(tile_tag, ur_tag, nb_tag, std::false_type{});
+    };
+    auto go = [&](auto tile_tag) {
+        using I = std::integral_constant<int, 0>;
+        (void)sizeof(I);
+        switch(shape)
+        {
+        case 26: go2(tile_tag, std::integral_constant<int, 2>{}, std::integral_constant<int, 6>{}); break;
+        case 36: go2(tile_tag, std::integral_constant<int, 3>{}, std::integral_constant<int, 6>{}); break;
+        case 46: go2(tile_tag, std::integral_constant<int, 4>{}, std::integral_constant<int, 6>{}); break;
+        case 48: go2(tile_tag, std::integral_constant<int, 4>{}, std::integral_constant<int, 8>{}); break;
+        case 18: go2(tile_tag, std::integral_constant<int, 1>{}, std::integral_constant<int, 8>{}); break;
+        default: go2(tile_tag, std::integral_constant<int, 2>{}, std::integral_constant<int, 8>{}); break;
+        }
+    };
     switch(tile & ~1)
     {
-    case 512: go(L16{}, std::integral_constant<int, 512>{}); break;
-    case 1024: go(L16{}, std::integral_constant<int, 1024>{}); break;
-    case 2048: go(L16{}, std::integral_constant<int, 2048>{}); break;
+    case 512: go(std::integral_constant<int, 512>{}); break;
+    case 1024: go(std::integral_constant<int, 1024>{}); break;
+    case 2048: go(std::integral_constant<int, 2048>{}); break;
     default: return aoclsparse_status_internal_error;
     }
     MI355_HIP_TRY(hipGetLastError());
@@ -1503,11 +1530,7 @@ aoclsparse_status launch_csrmm_colpair(hipStream_t s, int base, T alpha, aoclspa
 {
     if(n <= 0)
         return aoclsparse_status_success;
-    static const bool strict_beta0 = [] {
-        const char *e = getenv("AOCLSPARSE_MI355_CSRMM_STRICT_BETA0");
-        return e && atoi(e) != 0;
-    }();
-    const bool readc     = beta != T(0) || strict_beta0;
+    const bool readc     = csrmm_reads_c(beta != T(0));
     const bool c_aligned = reinterpret_cast<uintptr_t>(C) % (2 * sizeof(T)) == 0 && ldc % 2 == 0;
     const dim3 block(256);
     if(npairs > 0)
@@ -1536,11 +1559,7 @@ aoclsparse_status launch_csrmm_super(hipStream_t s, int base, T alpha, aoclspars
 {
     if(n <= 0)
         return aoclsparse_status_success;
-    static const bool strict_beta0 = [] {
-        const char *e = getenv("AOCLSPARSE_MI355_CSRMM_STRICT_BETA0");
-        return e && atoi(e) != 0;
-    }();
-    const bool readc = beta != T(0) || strict_beta0;
+    const bool readc = csrmm_reads_c(beta != T(0));
     const dim3 block(256);
     if(nsuper > 0)
     {

@@ -471,6 +471,11 @@ struct _aoclsparse_matrix
     void               *ilu_val = nullptr; // nnz values, library-owned (malloc)
     aoclsparse_matrix   ilu_factor = nullptr; // aliases user.ptr / user.ind / ilu_val
 
+    // multi-device calls (aoclsparse_mi355_?csrmm_multi): replica[i] = a handle over the SAME host arrays whose device copy
+    // and plans live on the device of runtime slot i (slot 0 is this handle itself); built on first use, dropped by
+    // aoclsparse_mi355_invalidate / ?set_value / ?update_values and by aoclsparse_destroy
+    std::vector<aoclsparse_matrix> replicas;
+
     mutable std::shared_mutex guard;
 };
 
@@ -481,7 +486,13 @@ namespace mi355
 class Runtime
 {
 public:
+    // The calling thread's runtime: the primary one (the process's GPU), unless a RuntimeScope put a secondary slot in
+    // charge (in-library multi-device calls, csrmm_api.cpp: one worker thread per device).
     static Runtime &get();
+    static Runtime &primary();
+    // secondary slot idx >= 1 bound to HIP device `dev` (created on first use; own stream, staging buffers and pinned words).
+    // Two slots may name the same device: that is how the multi-device control flow is tested on a one-GPU box.
+    static Runtime *slot(int idx, int dev);
     aoclsparse_status init(); // lazy; internal_error when no device; binds the calling thread to `device`
     void              bind_thread();
     hipStream_t       stream() const
@@ -493,6 +504,9 @@ public:
         stream_ = s;
     }
     aoclsparse_mi355_pointer_mode pointer_mode = aoclsparse_mi355_pointer_auto;
+    // csrmm with beta == 0: false (default) = C is read and multiplied by zero as in every reference kernel (NaN / Inf in C
+    // propagate); true = C is overwritten without being read (BLAS semantics, a third less traffic at 256 columns)
+    bool csrmm_beta0_overwrite = false;
     // true when p is memory the device can dereference (device or managed allocation)
     bool is_device_pointer(const void *p);
     int  device = -1, cus = 0;
@@ -520,11 +534,26 @@ public:
     std::mutex        lock;
     std::recursive_mutex stage_lock; // serialises calls that stage host buffers
 
+    int forced_device = -1; // secondary slots: the device to bind to (the primary honours AOCLSPARSE_MI355_DEVICE / the current device)
+
 private:
     std::atomic<bool> inited_{false}; // set (release) after init_status_ / device / events are written
     aoclsparse_status init_status_ = aoclsparse_status_success;
     hipStream_t  stream_ = nullptr;
     DeviceBuffer stage_[16]; // 0-7: csrmv / mv / trsv / dotmv, 8-15: ELL family and BLKCSR (ell_api.cpp, blk_api.cpp)
+};
+
+// While one of these is alive on a thread, Runtime::get() on that thread is the given slot: its device is current, its
+// stream / staging buffers are used and handles built under it live on its device.  Settings of the primary runtime
+// (pointer mode, csrmm beta = 0 policy) are inherited at entry.
+struct RuntimeScope
+{
+    explicit RuntimeScope(Runtime *r);
+    ~RuntimeScope();
+    RuntimeScope(const RuntimeScope &)            = delete;
+    RuntimeScope &operator=(const RuntimeScope &) = delete;
+    Runtime          *prev;
+    aoclsparse_status status;
 };
 
 // While one of these is alive on a thread, every pointer handed to the executors by that thread is
@@ -740,6 +769,8 @@ aoclsparse_status launch_lincomb(hipStream_t s, int sign, aoclsparse_int n, int 
 // schedule 0: one launch per level; 1: hybrid (narrow level runs inside one workgroup); 2: sync-free, a lane per
 // position; 3: sync-free, a level slice per wavefront (single right-hand side; falls back to 2 otherwise);
 // 4: sync-free, a lane per BLOCK of chained rows (plan.blk, real types, one right-hand side; falls back to 3 / 2).
+// does a csrmm kernel read C?  always for beta != 0; for beta == 0 unless the overwrite mode is on (Runtime::csrmm_beta0_overwrite)
+bool csrmm_reads_c(bool beta_nonzero);
 // timeout_word: where a sync-free kernel reports an expired wait (pinned host memory, Runtime::trsv_timeout_dev).
 constexpr int TRSV_NARROW = 1024; // a level this narrow is solved by one workgroup (one row per lane)
 template <typename T>

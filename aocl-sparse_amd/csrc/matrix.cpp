@@ -951,6 +951,9 @@ aoclsparse_status aoclsparse_destroy(aoclsparse_matrix *mat)
             (*mat)->user.owned = true; // sp2m results: the handle owns its CSR
         if((*mat)->ilu_factor)
             aoclsparse_destroy(&(*mat)->ilu_factor); // aliases ptr/ind/ilu_val: frees only its own plans
+        for(auto &r : (*mat)->replicas) // multi-device replicas alias the same host arrays: only their device side goes
+            if(r)
+                aoclsparse_destroy(&r);
         std::free((*mat)->ilu_val);
         if((*mat)->trsv_timeout_host)
             (void)hipHostFree(const_cast<unsigned int *>((*mat)->trsv_timeout_host));
@@ -1038,6 +1041,9 @@ aoclsparse_status aoclsparse_mi355_invalidate(aoclsparse_matrix A)
     if(!A)
         return aoclsparse_status_invalid_pointer;
     std::unique_lock<std::shared_mutex> w(A->guard);
+    for(auto &r : A->replicas) // the replicas on other devices mirror the same arrays: rebuilt on the next multi-device call
+        if(r)
+            aoclsparse_destroy(&r);
     A->dev_user.valid = A->dev_trans.valid = false;
     A->plan_user.valid = A->plan_trans.valid = false;
     A->plan_user.sell.valid = A->plan_user.sell.tried = false;
@@ -1075,6 +1081,9 @@ void drop_derived_state(aoclsparse_matrix A)
     }
     A->trans.reset();
     A->derived.clear();
+    for(auto &r : A->replicas) // multi-device replicas hold device copies of the old values
+        if(r)
+            aoclsparse_destroy(&r);
     A->dev_user.valid = A->dev_trans.valid = false; // row-block plans stay valid: structure is unchanged
     A->plan_user.sell.valid = A->plan_user.sell.tried = false; // the SELL copies hold values: rebuilt on optimize
     A->plan_trans.sell.valid = A->plan_trans.sell.tried = false;

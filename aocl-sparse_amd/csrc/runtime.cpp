@@ -80,10 +80,60 @@ HostCsr::~HostCsr()
     delete[] iurow;
 }
 
-Runtime &Runtime::get()
+thread_local Runtime *tl_runtime = nullptr;
+
+Runtime &Runtime::primary()
 {
     static Runtime r;
     return r;
+}
+
+Runtime &Runtime::get()
+{
+    return tl_runtime ? *tl_runtime : primary();
+}
+
+Runtime *Runtime::slot(int idx, int dev)
+{
+    // secondary runtimes live for the life of the process (like the primary one)
+    static std::mutex              m;
+    static std::vector<Runtime *> slots;
+    if(idx < 1 || idx > 63 || dev < 0)
+        return nullptr;
+    std::lock_guard<std::mutex> g(m);
+    if((int)slots.size() <= idx)
+        slots.resize((size_t)idx + 1, nullptr);
+    if(!slots[idx])
+    {
+        slots[idx] = new(std::nothrow) Runtime;
+        if(slots[idx])
+            slots[idx]->forced_device = dev;
+    }
+    else if(slots[idx]->forced_device != dev)
+        return nullptr; // a slot keeps its device: its staging buffers and the replicas built under it live there
+    return slots[idx];
+}
+
+RuntimeScope::RuntimeScope(Runtime *r) : prev(tl_runtime), status(aoclsparse_status_internal_error)
+{
+    if(!r)
+        return;
+    Runtime &pr = Runtime::primary();
+    if(r != &pr)
+    {
+        r->pointer_mode          = pr.pointer_mode;
+        r->csrmm_beta0_overwrite = pr.csrmm_beta0_overwrite;
+    }
+    tl_runtime = r;
+    status     = r->init();
+}
+
+RuntimeScope::~RuntimeScope()
+{
+    tl_runtime = prev;
+    Runtime &back = Runtime::get();
+    if(back.device >= 0)
+        back.bind_thread();
 }
 
 thread_local int tl_bound_device = -1;
@@ -117,8 +167,24 @@ aoclsparse_status Runtime::init()
         inited_.store(true, std::memory_order_release);
         return init_status_;
     }
+    if(forced_device >= 0)
+    {
+        // a secondary slot of a multi-device call: its own device and its own (non-blocking) stream
+        if(forced_device >= count || hipSetDevice(forced_device) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            init_status_ = aoclsparse_status_invalid_value;
+            inited_.store(true, std::memory_order_release);
+            return init_status_;
+        }
+        if(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            stream_ = nullptr;
+        }
+    }
     // one process per GPU: honour an explicit ordinal, else keep the caller's current device
-    if(const char *env = std::getenv("AOCLSPARSE_MI355_DEVICE"))
+    else if(const char *env = std::getenv("AOCLSPARSE_MI355_DEVICE"))
     {
         int d = std::atoi(env);
         if(d >= 0 && d < count)
@@ -170,6 +236,19 @@ DeviceScope::DeviceScope()
 DeviceScope::~DeviceScope()
 {
     --tl_device_scope;
+}
+
+bool csrmm_reads_c(bool beta_nonzero)
+{
+    // the environment switch is read once; the setter (aoclsparse_mi355_set_csrmm_beta0_overwrite) wins afterwards
+    static const bool env_once = [] {
+        const char *e = std::getenv("AOCLSPARSE_MI355_CSRMM_BETA0_OVERWRITE");
+        if(e && std::atoi(e) != 0)
+            Runtime::primary().csrmm_beta0_overwrite = true;
+        return true;
+    }();
+    (void)env_once;
+    return beta_nonzero || !Runtime::primary().csrmm_beta0_overwrite;
 }
 
 bool Runtime::is_device_pointer(const void *p)
@@ -427,6 +506,12 @@ size_t val_size(aoclsparse_matrix_data_type t)
 using namespace mi355;
 
 extern "C" {
+
+aoclsparse_status aoclsparse_mi355_set_csrmm_beta0_overwrite(int overwrite)
+{
+    Runtime::get().csrmm_beta0_overwrite = overwrite != 0;
+    return aoclsparse_status_success;
+}
 
 aoclsparse_status aoclsparse_mi355_set_pointer_mode(aoclsparse_mi355_pointer_mode mode)
 {

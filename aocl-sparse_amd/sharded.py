@@ -32,6 +32,21 @@ def reduce_scalar(value, op, dist=None, device="cpu"):
     return float(t.item())
 
 
+def communicator_info(dist, torch):
+    """What the ranks actually talk through: backend, world size and -- for "nccl" -- the RCCL version torch was built
+    against (torch.cuda.nccl.version() reports RCCL's on ROCm).  Goes into the bench line so that a multi-GPU record shows
+    that RCCL saw N ranks."""
+    if dist is None or not dist.is_initialized():
+        return {"backend": None, "world": 1}
+    info = {"backend": dist.get_backend(), "world": dist.get_world_size()}
+    if info["backend"] == "nccl":
+        try:
+            info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:  # the version query is informative only
+            info["rccl_version"] = "unavailable (%s)" % type(e).__name__
+    return info
+
+
 def barrier(dist, torch):
     if torch.cuda.is_available():
         torch.cuda.synchronize()
@@ -131,6 +146,7 @@ class ShardedCsrmm:
     def gather_C(self, C):
         """All slabs on every rank -> (full C as an (ncols, m) tensor of columns, ms).  Optional: the product itself
         never needs it."""
+        C = C[: self.nloc * self.m]  # a rank that owns no columns (more ranks than 4-column blocks) holds a dummy buffer
         cols = C.reshape(self.nloc, self.m) if self.layout == "col" else C.reshape(self.m, self.nloc).t().contiguous()
         shards = [self.pkg.column_shard(self.ncols, self.world, r) for r in range(self.world)]
         return gather_slabs(self.torch, self.dist, self.device, self.rank, shards, cols)
@@ -200,9 +216,12 @@ def bench_sharded_csrmm(pkg, torch, dist, device, rank, world, csr, ncols, layou
 
     laps, wall_ms = timed(lambda: sh.run(B, C), reps, warm)
     st_shard = quartiles(laps)
+    if sh.nloc == 0:  # nothing was launched here: this rank must not win the max with timer noise nor divide by ~0 below
+        st_shard = {k: 0.0 for k in ("min", "q1", "median", "q3", "max")}
+        st_shard["n"] = 0
     tg_dev = reduce_scalar(st_shard["median"], "max", dist, device)
     tg_wall = reduce_scalar(wall_ms, "max", dist, device)
-    checksum = reduce_scalar(float(C.sum().item()) if sh.nloc else 0.0, "sum", dist, device)
+    checksum = reduce_scalar(float(C[: sh.nloc * m].sum().item()) if sh.nloc else 0.0, "sum", dist, device)
     out = {
         "layout": "column-major" if layout == "col" else "row-major", "ncols": ncols, "world": world,
         "cols_per_rank": sh.nloc, "m": m, "nnz": nnz,
@@ -213,10 +232,10 @@ def bench_sharded_csrmm(pkg, torch, dist, device, rank, world, csr, ncols, layou
     job_bytes = csrmm_bytes(m, sh.n, nnz, ncols) + (world - 1) * ((m + 1 + nnz) * 4 + nnz * 8)
     shard_bytes = csrmm_bytes(m, sh.n, nnz, sh.nloc)
     out["gflops_job"] = round(2.0 * nnz * ncols / tg_dev / 1e6, 2)
-    out["roofline_shard"] = {"bound": "hbm", "achieved": round(shard_bytes / st_shard["median"] / 1e6, 2),
-                             "peak": peak_gbs, "unit": "GB/s",
-                             "frac": round(shard_bytes / st_shard["median"] / 1e6 / peak_gbs, 4), "traffic": None,
-                             "algorithmic_bytes_per_launch": shard_bytes}
+    shard_gbs = shard_bytes / st_shard["median"] / 1e6 if sh.nloc and st_shard["median"] > 0 else 0.0
+    out["roofline_shard"] = {"bound": "hbm", "achieved": round(shard_gbs, 2), "peak": peak_gbs, "unit": "GB/s",
+                             "frac": round(shard_gbs / peak_gbs, 4), "traffic": None,
+                             "algorithmic_bytes_per_launch": shard_bytes if sh.nloc else 0}
     out["gbs_job_algorithmic"] = round(job_bytes / tg_dev / 1e6, 2)
     if allgather:
         full, ag_ms = sh.gather_C(C)

@@ -205,9 +205,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus or world == 1, "WORLD_SIZE must match --gpus"
-    assert torch.cuda.is_available(), "bench.py needs a GPU: the product has no CPU path"
+    # fail loudly, never fall back: --gpus N is N ranks under torch.distributed.run (one process per GPU over RCCL)
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d needs WORLD_SIZE=%d (launch with python -m torch.distributed.run --nproc-per-node %d ...);"
+                 " found WORLD_SIZE=%d.  No single-process fallback." % (args.gpus, args.gpus, args.gpus, world))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the product has no CPU path")
     ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > ndev:
+        sys.exit("bench.py: %d ranks but %d visible GPU(s): RCCL needs one GPU per rank (use --backend gloo to share one GPU "
+                 "for control-flow tests)" % (world, ndev))
     dev_index = local_rank % ndev if args.backend == "gloo" else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -311,6 +318,7 @@ def main():
             "parallelism": "replicas x%d" % world,
             "device": dev_name,
             "backend": args.backend if use_dist else "none",
+            "communicator": sharded.communicator_info(D, torch),
         },
         "roofline": roofline(abytes, kernel_ms, traffic, traffic_source=traffic_src,
                              stored_format_bytes_per_launch=(info.stored_cells * 12 + 16 * m) if info.kernel == 3

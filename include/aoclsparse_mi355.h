@@ -25,6 +25,11 @@ typedef enum aoclsparse_mi355_pointer_mode_
 } aoclsparse_mi355_pointer_mode;
 
 DLL_PUBLIC aoclsparse_status aoclsparse_mi355_set_pointer_mode(aoclsparse_mi355_pointer_mode mode);
+/* aoclsparse_?csrmm with beta == 0.  Default (0): C is read and multiplied by zero, exactly as every kernel of the reference
+ * does (level3/aoclsparse_csrmm.hpp:83,129; aoclsparse_csrmm_kt.cpp:176-191,246), so a NaN / Inf already in C propagates.
+ * 1: C is overwritten without being read (BLAS convention; identical results for every finite C, including the sign of
+ * exact zeros; saves the read of C: ~15 % at 256 columns).  Also AOCLSPARSE_MI355_CSRMM_BETA0_OVERWRITE=1. */
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_set_csrmm_beta0_overwrite(int overwrite);
 DLL_PUBLIC aoclsparse_status aoclsparse_mi355_set_stream(void *hip_stream);
 DLL_PUBLIC void             *aoclsparse_mi355_get_stream(void);
 DLL_PUBLIC aoclsparse_status aoclsparse_mi355_synchronize(void);
@@ -60,6 +65,41 @@ DLL_PUBLIC aoclsparse_status aoclsparse_mi355_scsrmm_shard(aoclsparse_operation 
                                                            aoclsparse_order order, const float *B, aoclsparse_int n,
                                                            aoclsparse_int ldb, const float beta, float *C,
                                                            aoclsparse_int ldc, aoclsparse_int world, aoclsparse_int rank);
+
+/* ---- one process, several GPUs (round 3) ----------------------------------------------------
+ * C = alpha * op(A) * B + beta * C with the columns of B and C split over `ndev` devices by the rule above; the GPU takes
+ * the place of the reference's worker thread (aoclsparse_csrmm_kt.cpp:68-82).  devices[0] must be the library's own device
+ * (AOCLSPARSE_MI355_DEVICE, else the caller's current device); devices == NULL means that device and the next ndev - 1
+ * ordinals.  The first call builds a replica of the handle on every other device (same host arrays, hints copied,
+ * aoclsparse_optimize there), later calls reuse it; ?set_value / ?update_values / aoclsparse_mi355_invalidate drop the
+ * replicas.  No collective on the data path.  Returns when every device has finished.
+ *   ?csrmm_multi        B, C = the FULL operands in HOST memory (the reference's calling convention): each device stages
+ *                       and returns its own slab over its own PCIe link.  AOCLSPARSE_MI355_DEVICES=N makes plain
+ *                       aoclsparse_?csrmm take this path for host operands.
+ *   dcsrmm_multi_slabs  B_slabs[i] / C_slabs[i] = device i's slab, resident in ITS memory (column-major: columns
+ *                       [j0_i, j1_i) with leading dimension ldb / ldc; row-major: rows of j1_i - j0_i columns); n is the
+ *                       TOTAL column count.  The path for operands that already live on the GPUs. */
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_dcsrmm_multi(aoclsparse_operation op, const double alpha,
+                                                           const aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                                           aoclsparse_order order, const double *B, aoclsparse_int n,
+                                                           aoclsparse_int ldb, const double beta, double *C,
+                                                           aoclsparse_int ldc, aoclsparse_int ndev,
+                                                           const aoclsparse_int *devices);
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_scsrmm_multi(aoclsparse_operation op, const float alpha,
+                                                           const aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                                           aoclsparse_order order, const float *B, aoclsparse_int n,
+                                                           aoclsparse_int ldb, const float beta, float *C,
+                                                           aoclsparse_int ldc, aoclsparse_int ndev,
+                                                           const aoclsparse_int *devices);
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_dcsrmm_multi_slabs(aoclsparse_operation op, const double alpha,
+                                                                 const aoclsparse_matrix A, const aoclsparse_mat_descr descr,
+                                                                 aoclsparse_order order, const double *const *B_slabs,
+                                                                 aoclsparse_int n, aoclsparse_int ldb, const double beta,
+                                                                 double *const *C_slabs, aoclsparse_int ldc,
+                                                                 aoclsparse_int ndev, const aoclsparse_int *devices);
+
+/* replicas of the handle currently alive on other runtime slots (0 before the first multi-device call); -1 for NULL */
+DLL_PUBLIC aoclsparse_int aoclsparse_mi355_replica_count(const aoclsparse_matrix A);
 
 /* ---- introspection of a handle --------------------------------------------------------- */
 /* idiag / iurow of the clean CSR (host arrays owned by the handle, length m, matrix base);

@@ -87,7 +87,16 @@ def _worker(rank, world, port, q):
         full = sharded.make_B_slab(torch, "cpu", m, 0, ncols, "col").reshape(ncols, m)
         slab_ok = torch.equal(Bc.reshape(j1 - j0, m), full[j0:j1]) and torch.equal(Br.reshape(m, j1 - j0).t(), full[j0:j1])
         gathered, _ = sharded.gather_slabs(torch, dist, "cpu", rank, shards, Bc.reshape(j1 - j0, m))
-        q.put((rank, thr, tmax, s, mn, bool(same), bool(slab_ok), bool(torch.equal(gathered, full)), shards))
+        # more ranks than 4-column blocks: 4 columns over 2 ranks -> the second rank owns nothing; its slab is a
+        # (0, m) tensor, the gather still returns the whole matrix everywhere
+        shards4 = [pkg.column_shard(4, world, r) for r in range(world)]
+        a0, a1 = shards4[rank]
+        slab4 = sharded.make_B_slab(torch, "cpu", m, a0, a1, "col").reshape(a1 - a0, m)
+        g4, _ = sharded.gather_slabs(torch, dist, "cpu", rank, shards4, slab4)
+        empty_ok = shards4 == [(0, 4), (4, 4)] and torch.equal(g4, full[:4])
+        info = sharded.communicator_info(dist, torch)
+        empty_ok = empty_ok and info == {"backend": "gloo", "world": world}
+        q.put((rank, thr, tmax, s, mn, bool(same), bool(slab_ok), bool(torch.equal(gathered, full)) and bool(empty_ok), shards))
     finally:
         dist.destroy_process_group()
 

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import oracle
-from util import EPS64, ROOT, laplace5, pkg, random_csr
+from util import EPS64, ROOT, beta0_overwrite, laplace5, pkg, random_csr
 
 pytestmark = pytest.mark.gpu
 
@@ -269,12 +269,18 @@ def test_csrmm_row_runs_stencil_bit_exact(base):
     n = 128
     Br = rng.uniform(-1, 1, m * n)
     Cd = torch.full((m * n,), float("nan"), dtype=torch.float64, device="cuda")
-    assert P.dcsrmm(P.OP_NONE, 1.0, A, d, P.ORDER_ROW, dev(Br), n, n, 0.0, Cd, n) == 0
-    torch.cuda.synchronize()
+    with beta0_overwrite(P):  # opt-in: beta = 0 does not read C
+        assert P.dcsrmm(P.OP_NONE, 1.0, A, d, P.ORDER_ROW, dev(Br), n, n, 0.0, Cd, n) == 0
+        torch.cuda.synchronize()
     ref = _col_reference(1.0, base, v, ci, rp, m, m, Br, n, n, 0.0, np.zeros(m * n), n)
     got = Cd.cpu().numpy().reshape(m, n)
     nonempty = lens > 0
     assert np.array_equal(got[nonempty], ref[nonempty])
+    # default: 0 * C is computed as in the reference (csrmm.hpp:83), so the NaN stays
+    Cd = torch.full((m * n,), float("nan"), dtype=torch.float64, device="cuda")
+    assert P.dcsrmm(P.OP_NONE, 1.0, A, d, P.ORDER_ROW, dev(Br), n, n, 0.0, Cd, n) == 0
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(Cd).all())
     # float, same matrix
     vf = v.astype(np.float32)
     Af = P.Matrix(base, m, m, rp, ci, vf)
@@ -295,7 +301,7 @@ def test_csrmm_row_runs_stencil_bit_exact(base):
 def test_csrmm_tiled_narrow_row_major_bit_exact(base):
     """csrmm_tile_kernel (row-major, n < 128: workgroup per row block of the SpMV plan, A staged in LDS): empty rows,
     rows longer than the LDS tile (a block of their own), padded leading dimensions, alpha / beta classes incl. the
-    beta = 0 store path and NaN already in C (overwritten, as documented), n from 2 to 126."""
+    beta = 0 store path, NaN already in C (propagated by default as in the reference, overwritten in the opt-in mode), n from 2 to 126."""
     m, k = 2600, 2100
     rng = np.random.default_rng(17)
     def rowlen(r, i):
@@ -320,12 +326,17 @@ def test_csrmm_tiled_narrow_row_major_bit_exact(base):
     n = 32
     Br = rng.uniform(-1, 1, k * n)
     Cd = torch.full((m * n,), float("nan"), dtype=torch.float64, device="cuda")
-    assert P.dcsrmm(P.OP_NONE, 1.0, A, d, P.ORDER_ROW, dev(Br), n, n, 0.0, Cd, n) == 0
-    torch.cuda.synchronize()
+    with beta0_overwrite(P):
+        assert P.dcsrmm(P.OP_NONE, 1.0, A, d, P.ORDER_ROW, dev(Br), n, n, 0.0, Cd, n) == 0
+        torch.cuda.synchronize()
     ref = _col_reference(1.0, base, v, ci, rp, m, k, Br, n, n, 0.0, np.zeros(m * n), n)
     got = Cd.cpu().numpy().reshape(m, n)
     nonempty = np.diff(rp) > 0
     assert np.array_equal(got[nonempty], ref[nonempty])
+    Cd = torch.full((m * n,), float("nan"), dtype=torch.float64, device="cuda")   # default: the reference's 0 * NaN
+    assert P.dcsrmm(P.OP_NONE, 1.0, A, d, P.ORDER_ROW, dev(Br), n, n, 0.0, Cd, n) == 0
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(Cd).all())
 
 
 @pytest.mark.parametrize("base", [0, 1])

@@ -335,3 +335,91 @@ def test_spmv_within_bound_of_the_gcc_build_orders():
         if nnz > 10 * m or kid == 0:   # the reference overrides the kid to 0 when nnz <= 10 m (csrmv.hpp:322-355)
             assert np.array_equal(y, yf), kid
         assert np.all(np.abs(y - yg) <= (lens + 2) * EPS64 * scale + 1e-300), kid
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# in-library multi-device csrmm (one process, one worker thread + runtime slot + handle replica per device)
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("order", ["col", "row"])
+def test_csrmm_multi_device_entry_points_on_one_gpu(order):
+    """aoclsparse_mi355_dcsrmm_multi / _multi_slabs with every slot on device 0 (what a one-GPU box can run: the slots still
+    have their own streams, staging buffers and handle replicas, so the whole N-device control flow executes): the result
+    equals the single-call product bit for bit for 1, 2, 3 and 8 slots, both layouts, beta classes, a column count that
+    leaves a slot without columns; value updates reach the replicas; argument errors."""
+    m, k, n = 3000, 2600, 40
+    rp, ci, v = random_csr(303, m, k, lambda r, i: r.integers(0, 12))
+    A = P.Matrix(0, m, k, rp, ci, v)
+    d = P.Descr()
+    assert L.aoclsparse_set_mm_hint(A.h, P.OP_NONE, d.h, 10) == 0 and L.aoclsparse_optimize(A.h) == 0
+    rng = np.random.default_rng(8)
+    colmaj = order == "col"
+    o = P.ORDER_COLUMN if colmaj else P.ORDER_ROW
+    ldb, ldc = (k, m) if colmaj else (n, n)
+    B = rng.uniform(-1, 1, k * n)
+    C0 = rng.uniform(-1, 1, m * n)
+    st, dev0, _, _ = P.device_info()
+    assert st == 0
+    for alpha, beta in ((1.0, 0.0), (-0.75, 1.5)):
+        ref = C0.copy()
+        assert P.dcsrmm(P.OP_NONE, alpha, A, d, o, B, n, ldb, beta, ref, ldc) == 0
+        for ndev in (1, 2, 3, 8, 12):   # 40 columns / 12 slots: some slots own no 4-column block
+            C = C0.copy()
+            assert P.dcsrmm_multi(P.OP_NONE, alpha, A, d, o, B, n, ldb, beta, C, ldc, [dev0] * ndev) == 0, ndev
+            assert np.array_equal(C, ref), (ndev, alpha, beta)
+        # slabs resident on the device(s)
+        ndev = 3
+        shards = [P.column_shard(n, ndev, r) for r in range(ndev)]
+        Bm = B.reshape(n, k) if colmaj else B.reshape(k, n)
+        Cm = C0.reshape(n, m) if colmaj else C0.reshape(m, n)
+        Bs = [dev(np.ascontiguousarray(Bm[j0:j1] if colmaj else Bm[:, j0:j1])) for j0, j1 in shards]
+        Cs = [dev(np.ascontiguousarray(Cm[j0:j1] if colmaj else Cm[:, j0:j1])) for j0, j1 in shards]
+        lb = [ldb if colmaj else max(j1 - j0, 1) for j0, j1 in shards]
+        assert len(set(lb)) == 1 or not colmaj
+        if colmaj:
+            assert P.dcsrmm_multi_slabs(P.OP_NONE, alpha, A, d, o, Bs, n, ldb, beta, Cs, ldc, [dev0] * ndev) == 0
+            R = ref.reshape(n, m)
+            for (j0, j1), c in zip(shards, Cs):
+                assert np.array_equal(c.cpu().numpy(), R[j0:j1])
+    # the replicas follow value updates (they are dropped and rebuilt)
+    v2 = v * 1.5
+    assert L.aoclsparse_dupdate_values(A.h, len(v2), P._ptr(np.ascontiguousarray(v2))) == 0
+    ref = C0.copy()
+    assert P.dcsrmm(P.OP_NONE, 1.0, A, d, o, B, n, ldb, 0.0, ref, ldc) == 0
+    C = C0.copy()
+    assert P.dcsrmm_multi(P.OP_NONE, 1.0, A, d, o, B, n, ldb, 0.0, C, ldc, [dev0, dev0]) == 0
+    assert np.array_equal(C, ref)
+    so, Cr = oracle.dcsrmm("col", 1.0, 0, v2, ci, rp, m, B if colmaj else np.ascontiguousarray(B.reshape(k, n).T).ravel(), n, k,
+                           0.0, C0 if colmaj else np.ascontiguousarray(C0.reshape(m, n).T).ravel(), m)
+    got = C if colmaj else np.ascontiguousarray(C.reshape(m, n).T).ravel()
+    assert np.array_equal(got, Cr)
+    # argument errors
+    assert P.dcsrmm_multi(P.OP_NONE, 1.0, A, d, o, B, n, ldb, 0.0, C, ldc, [dev0 + 1]) != 0      # slot 0 must be the library's device
+    assert L.aoclsparse_mi355_dcsrmm_multi(P.OP_NONE, 1.0, A.h, d.h, o, P._ptr(B), n, ldb, 0.0, P._ptr(C), ldc, 0, None) != 0
+    assert P.dcsrmm_multi(P.OP_NONE, 1.0, A, d, o, B, n, ldb, 0.0, C, ldc, [dev0, 4096]) != 0   # no such device
+
+
+def test_csrmm_env_devices_routes_host_operands():
+    """AOCLSPARSE_MI355_DEVICES=N: plain aoclsparse_dcsrmm with host operands takes the multi-device path (here N slots on the
+    only device) and returns the same bits; device operands keep the single-device path."""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        from util import pkg, random_csr
+        import oracle
+        P = pkg()
+        m, k, n = 2000, 1800, 64
+        rp, ci, v = random_csr(5, m, k, lambda r, i: r.integers(0, 9))
+        A = P.Matrix(0, m, k, rp, ci, v); d = P.Descr()
+        rng = np.random.default_rng(1); B = rng.uniform(-1, 1, k * n); C = np.zeros(m * n)
+        assert P.dcsrmm(P.OP_NONE, 2.0, A, d, P.ORDER_COLUMN, B, n, k, 0.0, C, m) == 0
+        so, Cr = oracle.dcsrmm("col", 2.0, 0, v, ci, rp, m, B, n, k, 0.0, np.zeros(m * n), m)
+        assert np.array_equal(C, Cr)
+        print("replicas", P.lib().aoclsparse_mi355_replica_count(A.h))
+    """) % (HERE, os.path.dirname(HERE))
+    for nd, want in (("1", "replicas 0"), ("3", "replicas 2")):
+        env = dict(os.environ, AOCLSPARSE_MI355_DEVICES=nd)
+        out1 = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert out1.returncode == 0 and want in out1.stdout, (nd, out1.stdout, out1.stderr[-2000:])

@@ -95,3 +95,17 @@ def banded_rows(seed, m, n, per_row, base=0):
         rp.append(len(ci))
     v = rng.uniform(-1, 1, len(ci))
     return np.array(rp, np.int32) + base, np.array(ci, np.int32) + base, v
+
+
+class beta0_overwrite:
+    """with beta0_overwrite(P): ... -- csrmm with beta == 0 does not read C inside the block (the opt-in mode of
+    aoclsparse_mi355_set_csrmm_beta0_overwrite); the default (C read and multiplied by zero, as the reference) is restored."""
+
+    def __init__(self, P):
+        self.L = P.lib()
+
+    def __enter__(self):
+        assert self.L.aoclsparse_mi355_set_csrmm_beta0_overwrite(1) == 0
+
+    def __exit__(self, *a):
+        assert self.L.aoclsparse_mi355_set_csrmm_beta0_overwrite(0) == 0
