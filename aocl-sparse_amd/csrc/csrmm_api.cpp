@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 using namespace mi355;
@@ -16,6 +17,25 @@ namespace
 {
 
 constexpr int CM_DETOUR_NNZ_PER_ROW = 8; // = the column kernel's register cache (CM_K)
+
+// Host <-> staging copy of a strided dense operand: ONLY the `inner` elements of each of the `outer` lines move; the ld
+// padding -- which for a column shard of a row-major matrix is the other shards' columns -- is neither sent nor, on the way
+// back, written (round 3: the contiguous-span copy of round 2 rewrote it with the values it had read, which is a lost update
+// as soon as another thread -- another device's worker of ?csrmm_multi -- owns those columns, and sent 8 x the bytes a
+// 1/8 shard needs).
+template <typename T>
+aoclsparse_status copy_dense(Runtime &rt, void *dst, const void *src, aoclsparse_int outer, aoclsparse_int inner,
+                             aoclsparse_int ld, hipMemcpyKind kind)
+{
+    if(outer <= 0 || inner <= 0)
+        return aoclsparse_status_success;
+    if(ld == inner || outer == 1)
+        MI355_HIP_TRY(hipMemcpyAsync(dst, src, sizeof(T) * ((size_t)(outer - 1) * (size_t)ld + (size_t)inner), kind, rt.stream()));
+    else
+        MI355_HIP_TRY(hipMemcpy2DAsync(dst, sizeof(T) * (size_t)ld, src, sizeof(T) * (size_t)ld, sizeof(T) * (size_t)inner,
+                                       (size_t)outer, kind, rt.stream()));
+    return aoclsparse_status_success;
+}
 
 template <typename T>
 aoclsparse_status stage_dense(Runtime &rt, int slot, const T *host, aoclsparse_int outer, aoclsparse_int inner,
@@ -28,7 +48,7 @@ aoclsparse_status stage_dense(Runtime &rt, int slot, const T *host, aoclsparse_i
     if(st != aoclsparse_status_success)
         return st;
     if(copy && *bytes)
-        MI355_HIP_TRY(hipMemcpyAsync(*dev, host, *bytes, hipMemcpyHostToDevice, rt.stream()));
+        return copy_dense<T>(rt, *dev, host, outer, inner, ld, hipMemcpyHostToDevice);
     return aoclsparse_status_success;
 }
 
@@ -477,7 +497,9 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
     auto finish = [&]() -> aoclsparse_status {
         if(!cdev)
         {
-            MI355_HIP_TRY(hipMemcpyAsync(C, dC, cbytes, hipMemcpyDeviceToHost, rt.stream()));
+            const aoclsparse_status cs = copy_dense<T>(rt, C, dC, (aoclsparse_int)c_outer, colmaj ? m_c : n, ldc, hipMemcpyDeviceToHost);
+            if(cs != aoclsparse_status_success)
+                return cs;
             MI355_HIP_TRY(hipStreamSynchronize(rt.stream()));
         }
         return aoclsparse_status_success;
@@ -515,6 +537,16 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
         st = ensure_spmv(const_cast<aoclsparse_matrix>(A), tr, d, p);
     if(st != aoclsparse_status_success)
         return st;
+    if(kid >= 1 && descr->type == aoclsparse_matrix_type_general)
+    {
+        // a pinned kid 1/2/3 asks for the arithmetic of the reference's KT kernels (csrmm.hpp:779-833): reproduced bit for bit
+        // (symmetric descriptors have no KT kernel in the reference either: csrmm.hpp:667-718 runs *_sym_ref for every kid)
+        const int lanes = (std::is_same<T, double>::value ? 4 : 8) * (kid == 3 ? 2 : 1);
+        std::shared_lock<std::shared_mutex> r(A->guard);
+        st = launch_csrmm_kt<T>(rt.stream(), order, lanes, d->base, alpha, d->m, d->val.as<T>(), d->ind.as<aoclsparse_int>(),
+                                d->ptr.as<aoclsparse_int>(), static_cast<const T *>(dB), n, ldb, beta, static_cast<T *>(dC), ldc);
+        return st == aoclsparse_status_success ? finish() : st;
+    }
     // Column-major operands with many columns and rows longer than the column kernel's register cache: that kernel
     // would re-read A once per 4 columns (100 ms on the shell-like stand-in).  Detour: B and C are copied to packed
     // row-major scratch, the row-major kernels run, C is copied back -- three streaming passes (~0.5 ms each per GB)
@@ -607,13 +639,13 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
             // narrow row-major operands (a multi-GPU column slab): row blocks of the SpMV plan, A staged in LDS
             st = launch_csrmm_tiled<T>(rt.stream(), d->base, alpha, d->val.as<T>(), d->ind.as<aoclsparse_int>(),
                                        d->ptr.as<aoclsparse_int>(), p->rowblocks.as<aoclsparse_int>(), p->nblocks, p->tile,
-                                       static_cast<const T *>(dB), n, ldb, beta, static_cast<T *>(dC), ldc);
+                                       p->max_row_nnz, static_cast<const T *>(dB), n, ldb, beta, static_cast<T *>(dC), ldc);
         else if(colmaj && p && p->mm.pairs && (long long)ldb * (long long)sizeof(T) < (1LL << 32)
                 && reinterpret_cast<uintptr_t>(dB) % sizeof(T) == 0)
             // column-major operands, rows paired with a one-column shift: 16-byte loads / stores
             st = launch_csrmm_colpair<T>(rt.stream(), d->base, alpha, p->mm.npairs, p->mm.pair_first.as<aoclsparse_int>(),
                                          p->mm.nsingles, p->mm.single_rows.as<aoclsparse_int>(), d->val.as<T>(),
-                                         d->ind.as<aoclsparse_int>(), d->ptr.as<aoclsparse_int>(),
+                                         d->ind.as<aoclsparse_int>(), d->ptr.as<aoclsparse_int>(), p->max_row_nnz,
                                          static_cast<const T *>(dB), n, ldb, beta, static_cast<T *>(dC), ldc);
         else
             st = launch_csrmm<T>(rt.stream(), order, d->base, alpha, d->m, d->n, d->val.as<T>(),

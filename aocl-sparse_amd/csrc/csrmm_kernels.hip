@@ -1074,9 +1074,9 @@ __global__ __launch_bounds__(256) void csrmm_col_kernel(int base, T alpha, aocls
 // half the vector-memory instructions of csrmm_col_kernel, which is what bounds that kernel (1.02 vs 1.30 ms at 256
 // columns of a 1M-row 5-diagonal matrix, tools/csrmm_r2.hip).  Per output element the FMA chain is unchanged.  Rows that
 // found no partner are served by csrmm_col_kernel through a row list in a second launch.
-constexpr int CP_U = 4; // columns per step
-
-template <typename T>
+// K = entries of a row kept in registers (the pairs of detect_pairs have <= CM_K), U = columns per step, RC = C is read (beta != 0 or the
+// reference's 0 * C): requested together with the step's B values instead of after its FMAs.
+template <typename T, int K, int U, bool RC>
 __global__ __launch_bounds__(256) void csrmm_colpair_kernel(int base, T alpha, aoclsparse_int npairs,
                                                             const aoclsparse_int *__restrict__ pair_first,
                                                             const T *__restrict__ val,
@@ -1095,34 +1095,49 @@ __global__ __launch_bounds__(256) void csrmm_colpair_kernel(int base, T alpha, a
     const int cpw = cm_cols_per_block(n);
     const int j0 = blockIdx.y * cpw, j1 = min(n, j0 + cpw);
     const int s = row_ptr[i] - base, e = row_ptr[i + 1] - base;
-    const int len = e - s; // 1 .. CM_K, and row i+1 has the same length (detect_pairs)
-    T         v0[CM_K], v1[CM_K];
-    unsigned  off[CM_K]; // byte offset of B[c_k] inside a column (columns < 4 GB: checked by the host)
+    const int len = e - s; // 1 .. K, and row i+1 has the same length (detect_pairs)
+    T         v0[K], v1[K];
+    unsigned  off[K]; // byte offset of B[c_k] inside a column (columns < 4 GB: checked by the host)
 #pragma unroll
-    for(int k = 0; k < CM_K; k++)
+    for(int k = 0; k < K; k++)
     {
         v0[k] = T(0), v1[k] = T(0), off[k] = 0;
         if(k < len)
             v0[k] = val[s + k], v1[k] = val[e + k], off[k] = (unsigned)(col[s + k] - base) * (unsigned)sizeof(T);
     }
     const bool vec_store = c_aligned && (i % 2 == 0);
-    auto       put       = [&](T *cp, T a0, T a1) {
+    auto       getc      = [&](const T *cp) {
+        v2 c;
+        if(vec_store)
+            c = *reinterpret_cast<const v2 *>(cp);
+        else
+            c.x = cp[0], c.y = cp[1];
+        return c;
+    };
+    // cin: the pair's C values when RC (already loaded), unused otherwise
+    auto put = [&](T *cp, T a0, T a1, v2 cin) {
         const T z0 = alpha * a0, z1 = alpha * a1;
-        if((readc || z0 == T(0) || z1 == T(0)) && vec_store)
+        v2      o;
+        if constexpr(RC)
         {
-            v2 c = *reinterpret_cast<const v2 *>(cp);
-            c.x  = mm_fma(beta, c.x, z0);
-            c.y  = mm_fma(beta, c.y, z1);
-            *reinterpret_cast<v2 *>(cp) = c;
+            o.x = mm_fma(beta, cin.x, z0), o.y = mm_fma(beta, cin.y, z1);
+            if(vec_store)
+                *reinterpret_cast<v2 *>(cp) = o;
+            else
+                cp[0] = o.x, cp[1] = o.y;
+            return;
         }
-        else if(readc || z0 == T(0) || z1 == T(0))
+        if(z0 == T(0) || z1 == T(0)) // the sign of an exact zero is beta * C's (the reference computes 0 * C + z)
         {
-            cp[0] = mm_fma(beta, cp[0], z0);
-            cp[1] = mm_fma(beta, cp[1], z1);
+            const v2 c = getc(cp);
+            o.x = mm_fma(beta, c.x, z0), o.y = mm_fma(beta, c.y, z1);
+            if(vec_store)
+                *reinterpret_cast<v2 *>(cp) = o;
+            else
+                cp[0] = o.x, cp[1] = o.y;
         }
         else if(vec_store)
         {
-            v2 o;
             o.x = z0, o.y = z1;
             __builtin_nontemporal_store(o, reinterpret_cast<v2 *>(cp));
         }
@@ -1130,43 +1145,178 @@ __global__ __launch_bounds__(256) void csrmm_colpair_kernel(int base, T alpha, a
             cp[0] = z0, cp[1] = z1;
     };
     int j = j0;
-    for(; j + CP_U <= j1; j += CP_U)
+    for(; j + U <= j1; j += U)
     {
-        v2 b[CP_U][CM_K];
+        v2 b[U][K], cin[U] = {};
 #pragma unroll
-        for(int u = 0; u < CP_U; u++)
+        for(int u = 0; u < U; u++)
         {
+            if constexpr(RC)
+                cin[u] = getc(C + (size_t)i + (size_t)(j + u) * ldc);
             const char *Bu = reinterpret_cast<const char *>(B + (size_t)(j + u) * ldb);
 #pragma unroll
-            for(int k = 0; k < CM_K; k++)
+            for(int k = 0; k < K; k++)
                 if(k < len)
                     __builtin_memcpy(&b[u][k], Bu + off[k], sizeof(v2));
         }
 #pragma unroll
-        for(int u = 0; u < CP_U; u++)
+        for(int u = 0; u < U; u++)
         {
             T a0 = T(0), a1 = T(0);
 #pragma unroll
-            for(int k = 0; k < CM_K; k++)
+            for(int k = 0; k < K; k++)
                 if(k < len)
                     a0 = mm_fma(v0[k], b[u][k].x, a0), a1 = mm_fma(v1[k], b[u][k].y, a1);
-            put(C + (size_t)i + (size_t)(j + u) * ldc, a0, a1);
+            put(C + (size_t)i + (size_t)(j + u) * ldc, a0, a1, cin[u]);
         }
     }
     for(; j < j1; j++)
     {
         const char *Bu = reinterpret_cast<const char *>(B + (size_t)j * ldb);
         T           a0 = T(0), a1 = T(0);
+        v2          cin = {};
+        if constexpr(RC)
+            cin = getc(C + (size_t)i + (size_t)j * ldc);
 #pragma unroll
-        for(int k = 0; k < CM_K; k++)
+        for(int k = 0; k < K; k++)
             if(k < len)
             {
                 v2 b;
                 __builtin_memcpy(&b, Bu + off[k], sizeof(v2));
                 a0 = mm_fma(v0[k], b.x, a0), a1 = mm_fma(v1[k], b.y, a1);
             }
-        put(C + (size_t)i + (size_t)j * ldc, a0, a1);
+        put(C + (size_t)i + (size_t)j * ldc, a0, a1, cin);
     }
+}
+
+// ---- the reference's KT kernels, reproduced for aoclsparse_?csrmm_kid(kid = 1, 2, 3) (round 3) ------------------------
+// csrmm_col_kt / csrmm_row_kt (level3/aoclsparse_csrmm_kt.cpp:31-363) are what the reference's dispatcher runs for kid 1/2
+// (256-bit vectors: PSZ = 4 doubles / 8 floats) and kid 3 (512-bit: 8 / 16), csrmm.hpp:779-833.  Their per-element
+// arithmetic differs from the kid-0 kernels (vector lanes + horizontal sum; beta * C first for the row-major one), so a
+// caller that pins a kid gets that order here -- bit for bit the FUSED build of the reference (oracle.c header), which
+// tests/test_oracle_kt.py pins on the reference's own templates.  Plain kernels: a pinned kid asks for bits, not speed.
+template <typename T, int PSZ>
+__device__ __forceinline__ T kt_hsum(const T (&p)[PSZ])
+{
+    if constexpr(std::is_same<T, double>::value && PSZ == 4) // kt_l0_avx2.hpp:333-340
+        return (p[0] + p[1]) + (p[2] + p[3]);
+    else if constexpr(std::is_same<T, double>::value && PSZ == 8) // _mm512_reduce_add_pd: halves added lane-wise
+        return ((p[4] + p[0]) + (p[6] + p[2])) + ((p[5] + p[1]) + (p[7] + p[3]));
+    else if constexpr(std::is_same<T, float>::value && PSZ == 8) // kt_l0_avx2.hpp:342-350: hadd, hadd, lo + hi
+        return ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+    else // float, 16 lanes: _mm512_reduce_add_ps, 16 -> 8 -> 4 -> 2 -> 1
+    {
+        T t3[8], t6[4];
+#pragma unroll
+        for(int i = 0; i < 8; i++)
+            t3[i] = p[8 + i] + p[i];
+#pragma unroll
+        for(int i = 0; i < 4; i++)
+            t6[i] = t3[4 + i] + t3[i];
+        return (t6[0] + t6[2]) + (t6[1] + t6[3]);
+    }
+}
+
+// column-major: a lane per (row, column); csrmm_kt.cpp:127-191
+template <typename T, int PSZ>
+__global__ __launch_bounds__(256) void csrmm_col_kt_kernel(int base, T alpha, aoclsparse_int m, const T *__restrict__ val,
+                                                           const aoclsparse_int *__restrict__ col,
+                                                           const aoclsparse_int *__restrict__ row_ptr,
+                                                           const T *__restrict__ B, aoclsparse_int n, aoclsparse_int ldb,
+                                                           T beta, T *__restrict__ C, aoclsparse_int ldc)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if(i >= m)
+        return;
+    const int s = row_ptr[i] - base, e = row_ptr[i + 1] - base;
+    const int nnz = e - s, mul = nnz / PSZ, rem = nnz - PSZ * mul;
+    for(int j = blockIdx.y; j < n; j += gridDim.y)
+    {
+        const T *Bj  = B + (size_t)j * ldb;
+        T        cij = T(0);
+        if(mul)
+        {
+            T p[PSZ];
+#pragma unroll
+            for(int l = 0; l < PSZ; l++)
+                p[l] = T(0);
+            for(int k = s; k < e - rem; k += PSZ)
+#pragma unroll
+                for(int l = 0; l < PSZ; l++)
+                    p[l] = mm_fma(val[k + l], Bj[col[k + l] - base], p[l]);
+            cij = cij + kt_hsum<T, PSZ>(p); // "cij += cdot" with cij = 0 (:153-156)
+        }
+        for(int k = e - rem; k < e; k++)
+            cij = mm_fma(val[k], Bj[col[k] - base], cij);
+        cij *= alpha;
+        T *cp = C + (size_t)i + (size_t)j * ldc;
+        *cp   = mm_fma(beta, *cp, cij);
+    }
+}
+
+// row-major: a lane per (row, column); csrmm_kt.cpp:244-356.  C * beta first, then the entries in CSR order: columns
+// below n - n % PSZ take fma(alpha * a, b, c) (the vector statement), the last n % PSZ columns fma(a * b, alpha, c)
+template <typename T, int PSZ>
+__global__ __launch_bounds__(256) void csrmm_row_kt_kernel(int base, T alpha, aoclsparse_int m, const T *__restrict__ val,
+                                                           const aoclsparse_int *__restrict__ col,
+                                                           const aoclsparse_int *__restrict__ row_ptr,
+                                                           const T *__restrict__ B, aoclsparse_int n, aoclsparse_int ldb,
+                                                           T beta, T *__restrict__ C, aoclsparse_int ldc)
+{
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if(i >= m || j >= n)
+        return;
+    const bool vec = j < n - n % PSZ;
+    const int  s = row_ptr[i] - base, e = row_ptr[i + 1] - base;
+    T         *cp = C + (size_t)i * ldc + j;
+    T          c  = *cp * beta;
+    for(int k = s; k < e; k++)
+    {
+        const T a = val[k], b = B[(size_t)(col[k] - base) * ldb + j];
+        c         = vec ? mm_fma(alpha * a, b, c) : mm_fma(a * b, alpha, c);
+    }
+    *cp = c;
+}
+
+template <typename T>
+aoclsparse_status launch_csrmm_kt(hipStream_t s, aoclsparse_order order, int lanes, int base, T alpha, aoclsparse_int m,
+                                  const T *val, const aoclsparse_int *col, const aoclsparse_int *row_ptr, const T *B,
+                                  aoclsparse_int n, aoclsparse_int ldb, T beta, T *C, aoclsparse_int ldc)
+{
+    if(m <= 0 || n <= 0)
+        return aoclsparse_status_success;
+    constexpr int P256 = std::is_same<T, double>::value ? 4 : 8, P512 = 2 * P256;
+    if(lanes != P256 && lanes != P512)
+        return aoclsparse_status_internal_error;
+    if(order == aoclsparse_order_column)
+    {
+        const dim3 grid((m + 255) / 256, std::min<aoclsparse_int>(n, 1024));
+        if(lanes == P256)
+            hipLaunchKernelGGL((csrmm_col_kt_kernel<T, P256>), grid, dim3(256), 0, s, base, alpha, m, val, col, row_ptr, B, n,
+                               ldb, beta, C, ldc);
+        else
+            hipLaunchKernelGGL((csrmm_col_kt_kernel<T, P512>), grid, dim3(256), 0, s, base, alpha, m, val, col, row_ptr, B, n,
+                               ldb, beta, C, ldc);
+    }
+    else
+    {
+        // rows on grid.y in chunks (65535 limit): the kernel takes row offsets through the pointers
+        const int rows_per_launch = 65535 * 4;
+        for(aoclsparse_int r0 = 0; r0 < m; r0 += rows_per_launch)
+        {
+            const aoclsparse_int mr = std::min<aoclsparse_int>(rows_per_launch, m - r0);
+            const dim3           grid((n + 63) / 64, (mr + 3) / 4);
+            if(lanes == P256)
+                hipLaunchKernelGGL((csrmm_row_kt_kernel<T, P256>), grid, dim3(256), 0, s, base, alpha, mr, val, col, row_ptr + r0,
+                                   B, n, ldb, beta, C + (size_t)r0 * ldc, ldc);
+            else
+                hipLaunchKernelGGL((csrmm_row_kt_kernel<T, P512>), grid, dim3(256), 0, s, base, alpha, mr, val, col, row_ptr + r0,
+                                   B, n, ldb, beta, C + (size_t)r0 * ldc, ldc);
+        }
+    }
+    MI355_HIP_TRY(hipGetLastError());
+    return aoclsparse_status_success;
 }
 
 // dense layout change for the column-major detour of csrmm_api.cpp: src is R x N with element (r, c) at
@@ -1471,8 +1621,8 @@ bool csrmm_tiled_applies(aoclsparse_int n, aoclsparse_int ldb, aoclsparse_int ld
 template <typename T>
 aoclsparse_status launch_csrmm_tiled(hipStream_t s, int base, T alpha, const T *val, const aoclsparse_int *col,
                                      const aoclsparse_int *row_ptr, const aoclsparse_int *blocks, aoclsparse_int nblocks,
-                                     int tile, const T *B, aoclsparse_int n, aoclsparse_int ldb, T beta, T *C,
-                                     aoclsparse_int ldc)
+                                     int tile, aoclsparse_int max_row_nnz, const T *B, aoclsparse_int n, aoclsparse_int ldb,
+                                     T beta, T *C, aoclsparse_int ldc)
 {
     if(nblocks <= 0 || n <= 0)
         return aoclsparse_status_success;
@@ -1482,33 +1632,27 @@ aoclsparse_status launch_csrmm_tiled(hipStream_t s, int base, T alpha, const T *
         return e ? atoi(e) != 0 : true;
     }();
     const int  chunk = xcd ? (nblocks + 7) / 8 : 0; // XCD-contiguous block order, as the other csrmm kernels
-    // (UR, NB) = rows in flight per 16-lane sub-wave x B-row loads per row and step; experiment knob AOCLSPARSE_MI355_EXP_TILE_SHAPE=<UR><NB>
-    static const int shape = [] { const char *e = getenv("AOCLSPARSE_MI355_EXP_TILE_SHAPE"); return e ? atoi(e) : 28; }();
-    static const int pad = [] { const char *e = getenv("AOCLSPARSE_MI355_EXP_TILE_PAD"); return e ? atoi(e) : 0; }();
-    auto       go3   = [&](auto tile_tag, auto ur_tag, auto nb_tag, auto rc_tag) {
-        constexpr int  TILE = decltype(tile_tag)::value, UR = decltype(ur_tag)::value, NB = decltype(nb_tag)::value;
+    // (UR, NB) = rows in flight per 16-lane sub-wave x B-row loads per row and step.  Round-3 sweep on the 32-column slab of
+    // the 1000^2 Laplacian (tools/exp_r3_slab3.sh, profiles/r3/slab_shapes.txt; beta = 0 overwrite / C read): (2, 8) 0.130 /
+    // 0.174 ms, (2, 6) 0.126-0.128 / 0.166-0.168, (1, 8) 0.127-0.133 / 0.165-0.175, (3, 6) 0.133-0.137 / 0.170-0.174, (4, 6) 0.154-0.158 /
+    // 0.182-0.184, (4, 8) 0.167 / 0.193-0.198: two rows in flight, and no more load slots than the rows have entries.
+    auto       go3   = [&](auto tile_tag, auto nb_tag, auto rc_tag) {
+        constexpr int  TILE = decltype(tile_tag)::value, NB = decltype(nb_tag)::value;
         constexpr bool RC   = decltype(rc_tag)::value;
-        hipLaunchKernelGGL((csrmm_tile_kernel<T, 16, TILE, UR, NB, RC>), dim3(xcd ? chunk * 8 : nblocks, (n + 31) / 32), dim3(256),
-                           (size_t)pad, s, base, alpha, val, col, row_ptr, blocks, nblocks, B, n, ldb, beta, C, ldc, readc, chunk);
+        hipLaunchKernelGGL((csrmm_tile_kernel<T, 16, TILE, 2, NB, RC>), dim3(xcd ? chunk * 8 : nblocks, (n + 31) / 32), dim3(256),
+                           0, s, base, alpha, val, col, row_ptr, blocks, nblocks, B, n, ldb, beta, C, ldc, readc, chunk);
     };
-    auto go2 = [&](auto tile_tag, auto ur_tag, auto nb_tag) {
+    auto go2 = [&](auto tile_tag, auto nb_tag) {
         if(readc)
-            go3(tile_tag, ur_tag, nb_tag, std::true_type{});
+            go3(tile_tag, nb_tag, std::true_type{});
         else
-            go3(tile_tag, ur_tag, nb_tag, std::false_type{});
+            go3(tile_tag, nb_tag, std::false_type{});
     };
     auto go = [&](auto tile_tag) {
-        using I = std::integral_constant<int, 0>;
-        (void)sizeof(I);
-        switch(shape)
-        {
-        case 26: go2(tile_tag, std::integral_constant<int, 2>{}, std::integral_constant<int, 6>{}); break;
-        case 36: go2(tile_tag, std::integral_constant<int, 3>{}, std::integral_constant<int, 6>{}); break;
-        case 46: go2(tile_tag, std::integral_constant<int, 4>{}, std::integral_constant<int, 6>{}); break;
-        case 48: go2(tile_tag, std::integral_constant<int, 4>{}, std::integral_constant<int, 8>{}); break;
-        case 18: go2(tile_tag, std::integral_constant<int, 1>{}, std::integral_constant<int, 8>{}); break;
-        default: go2(tile_tag, std::integral_constant<int, 2>{}, std::integral_constant<int, 8>{}); break;
-        }
+        if(max_row_nnz > 0 && max_row_nnz <= 6)
+            go2(tile_tag, std::integral_constant<int, 6>{});
+        else
+            go2(tile_tag, std::integral_constant<int, 8>{});
     };
     switch(tile & ~1)
     {
@@ -1525,8 +1669,8 @@ template <typename T>
 aoclsparse_status launch_csrmm_colpair(hipStream_t s, int base, T alpha, aoclsparse_int npairs,
                                        const aoclsparse_int *pair_first, aoclsparse_int nsingles,
                                        const aoclsparse_int *single_rows, const T *val, const aoclsparse_int *col,
-                                       const aoclsparse_int *row_ptr, const T *B, aoclsparse_int n, aoclsparse_int ldb,
-                                       T beta, T *C, aoclsparse_int ldc)
+                                       const aoclsparse_int *row_ptr, aoclsparse_int max_row_nnz, const T *B, aoclsparse_int n,
+                                       aoclsparse_int ldb, T beta, T *C, aoclsparse_int ldc)
 {
     if(n <= 0)
         return aoclsparse_status_success;
@@ -1536,8 +1680,16 @@ aoclsparse_status launch_csrmm_colpair(hipStream_t s, int base, T alpha, aoclspa
     if(npairs > 0)
     {
         const int nbx = (npairs + 255) / 256, chunk = (nbx + 7) / 8;
-        hipLaunchKernelGGL((csrmm_colpair_kernel<T>), dim3(chunk * 8, (n + cm_cols() - 1) / cm_cols()), block, 0, s, base, alpha,
-                           npairs, pair_first, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, c_aligned, chunk);
+        // (K, U) = entries cached x columns per step: round-3 sweep on the 32-column slab, beta = 0 overwrite / C read
+        // (tools/exp_r3_slab4.sh, profiles/r3/slab_colmajor_shapes.txt): (8, 4) 0.190-0.192 / 0.240-0.242 ms, (8, 2) 0.177-0.187 /
+        // 0.243, (6, 4) 0.193-0.195 / 0.243-0.245, (6, 2) 0.190 / 0.242-0.244 -- flat; at 256 columns (6, 4) LOSES (1.20 vs 1.09 ms).
+        // What did help is requesting C with the step's B values when it is read: 256 columns, beta != 0: 1.58 -> 1.43 ms.
+        if(readc)
+            hipLaunchKernelGGL((csrmm_colpair_kernel<T, CM_K, 4, true>), dim3(chunk * 8, (n + cm_cols() - 1) / cm_cols()), block, 0, s,
+                               base, alpha, npairs, pair_first, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, c_aligned, chunk);
+        else
+            hipLaunchKernelGGL((csrmm_colpair_kernel<T, CM_K, 4, false>), dim3(chunk * 8, (n + cm_cols() - 1) / cm_cols()), block, 0, s,
+                               base, alpha, npairs, pair_first, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, c_aligned, chunk);
     }
     if(nsingles > 0)
     {
@@ -1605,7 +1757,7 @@ aoclsparse_status launch_csrmm_super(hipStream_t s, int base, T alpha, aoclspars
                                                   aoclsparse_int, aoclsparse_int);                            \
     template aoclsparse_status launch_csrmm_colpair<T>(hipStream_t, int, T, aoclsparse_int, const aoclsparse_int *, \
                                                        aoclsparse_int, const aoclsparse_int *, const T *,      \
-                                                       const aoclsparse_int *, const aoclsparse_int *, const T *, \
+                                                       const aoclsparse_int *, const aoclsparse_int *, aoclsparse_int, const T *, \
                                                        aoclsparse_int, aoclsparse_int, T, T *, aoclsparse_int); \
     template aoclsparse_status launch_csrmm_super<T>(hipStream_t, int, T, aoclsparse_int, int, const aoclsparse_int *, \
                                                      const aoclsparse_int *, const long long *,                \
@@ -1622,10 +1774,16 @@ aoclsparse_status launch_csrmm_super(hipStream_t s, int base, T alpha, aoclspars
                                                            const aoclsparse_int *, aoclsparse_int, int);       \
     template aoclsparse_status launch_csrmm_tiled<T>(hipStream_t, int, T, const T *, const aoclsparse_int *,   \
                                                      const aoclsparse_int *, const aoclsparse_int *,          \
-                                                     aoclsparse_int, int, const T *, aoclsparse_int,          \
+                                                     aoclsparse_int, int, aoclsparse_int, const T *, aoclsparse_int, \
                                                      aoclsparse_int, T, T *, aoclsparse_int);
 MI355_INST_MM(double)
 MI355_INST_MM(float)
+template aoclsparse_status launch_csrmm_kt<double>(hipStream_t, aoclsparse_order, int, int, double, aoclsparse_int, const double *,
+                                                   const aoclsparse_int *, const aoclsparse_int *, const double *, aoclsparse_int,
+                                                   aoclsparse_int, double, double *, aoclsparse_int);
+template aoclsparse_status launch_csrmm_kt<float>(hipStream_t, aoclsparse_order, int, int, float, aoclsparse_int, const float *,
+                                                  const aoclsparse_int *, const aoclsparse_int *, const float *, aoclsparse_int,
+                                                  aoclsparse_int, float, float *, aoclsparse_int);
 
 } // namespace mi355
 

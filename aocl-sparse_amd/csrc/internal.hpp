@@ -826,8 +826,8 @@ bool csrmm_tiled_applies(aoclsparse_int n, aoclsparse_int ldb, aoclsparse_int ld
 template <typename T>
 aoclsparse_status launch_csrmm_tiled(hipStream_t s, int base, T alpha, const T *val, const aoclsparse_int *col,
                                      const aoclsparse_int *row_ptr, const aoclsparse_int *blocks, aoclsparse_int nblocks,
-                                     int tile, const T *B, aoclsparse_int n, aoclsparse_int ldb, T beta, T *C,
-                                     aoclsparse_int ldc);
+                                     int tile, aoclsparse_int max_row_nnz, const T *B, aoclsparse_int n, aoclsparse_int ldb,
+                                     T beta, T *C, aoclsparse_int ldc);
 // row-major, n >= 128: one wavefront per (super-group, 128-column chunk) -- every B row of the union loaded once
 template <typename T>
 aoclsparse_status launch_csrmm_super(hipStream_t s, int base, T alpha, aoclsparse_int nsuper, int rg,
@@ -841,8 +841,13 @@ template <typename T>
 aoclsparse_status launch_csrmm_colpair(hipStream_t s, int base, T alpha, aoclsparse_int npairs,
                                        const aoclsparse_int *pair_first, aoclsparse_int nsingles,
                                        const aoclsparse_int *single_rows, const T *val, const aoclsparse_int *col,
-                                       const aoclsparse_int *row_ptr, const T *B, aoclsparse_int n, aoclsparse_int ldb,
-                                       T beta, T *C, aoclsparse_int ldc);
+                                       const aoclsparse_int *row_ptr, aoclsparse_int max_row_nnz, const T *B, aoclsparse_int n,
+                                       aoclsparse_int ldb, T beta, T *C, aoclsparse_int ldc);
+// aoclsparse_?csrmm_kid with kid 1/2/3: the reference's KT kernels' arithmetic (csrmm_kt.cpp:31-363), lanes = 4 / 8 (double), 8 / 16 (float)
+template <typename T>
+aoclsparse_status launch_csrmm_kt(hipStream_t s, aoclsparse_order order, int lanes, int base, T alpha, aoclsparse_int m,
+                                  const T *val, const aoclsparse_int *col, const aoclsparse_int *row_ptr, const T *B,
+                                  aoclsparse_int n, aoclsparse_int ldb, T beta, T *C, aoclsparse_int ldc);
 template <typename T>
 aoclsparse_status launch_relayout(hipStream_t s, bool to_row_major, const T *src, T *dst, aoclsparse_int R, aoclsparse_int N,
                                   aoclsparse_int ld);

@@ -282,8 +282,9 @@ def test_trsv_within_bound_of_the_kt_orders(fill, op):
 @pytest.mark.parametrize("n", [5, 8, 33])
 @pytest.mark.parametrize("alpha,beta", [(1.0, 0.0), (-2.5, 0.75)])
 def test_csrmm_within_bound_of_the_kt_orders(n, alpha, beta):
-    """aoclsparse_dcsrmm (kid 0..3, both layouts) against csrmm_col_kt / csrmm_row_kt restated for 4 and 8 lanes
-    (csrmm_kt.cpp:31-363), both builds.  Tolerance per element: (len + 4) eps |alpha| sum |a_ik b_kj| + 3 eps |beta c_ij|
+    """aoclsparse_dcsrmm_kid (kid 0..3, both layouts) against csrmm_col_kt / csrmm_row_kt restated for 4 and 8 lanes
+    (csrmm_kt.cpp:31-363), both builds: kid 1 / 2 / 3 are BIT-IDENTICAL to the KT kernel of their vector width (fused build);
+    every kid is within the tolerance of every order.  Tolerance per element: (len + 4) eps |alpha| sum |a_ik b_kj| + 3 eps |beta c_ij|
     (two summation orders of the same len products + the scaling / beta operations)."""
     m, k = 500, 420
     rp, ci, v = random_csr(77, m, k, lambda r, i: r.integers(0, 40))
@@ -310,6 +311,10 @@ def test_csrmm_within_bound_of_the_kt_orders(n, alpha, beta):
                     assert st == 0
                     ref = Ck.reshape(n, m).T if oname == "col" else Ck.reshape(m, n)
                     assert np.all(np.abs(got - ref) <= bound + 1e-300), (oname, kid, psz, fused)
+                    # a pinned kid reproduces the KT kernel the reference dispatches for it (csrmm.hpp:779-833), bit for bit
+                    # in the fused build: kid 1 / 2 -> 256-bit vectors (4 lanes), kid 3 -> 512-bit (8 lanes)
+                    if fused and psz == {1: 4, 2: 4, 3: 8}.get(kid):
+                        assert np.array_equal(got, ref), (oname, kid, psz)
 
 
 def test_spmv_within_bound_of_the_gcc_build_orders():
