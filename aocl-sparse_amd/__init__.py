@@ -350,6 +350,7 @@ SIGNATURES = {
     "aoclsparse_mi355_get_spmv_info": (c_int, [_P, c_int, POINTER(SpmvInfo)]),
     "aoclsparse_mi355_get_trsv_levels": (c_int, [_P, c_int, c_int, POINTER(_I)]),
     "aoclsparse_mi355_trsv_status": (c_int, [_P]),
+    "aoclsparse_mi355_set_trsv_schedule": (c_int, [_I]),
     "aoclsparse_mi355_set_csrmm_beta0_overwrite": (c_int, [c_int]),
     "aoclsparse_mi355_invalidate": (c_int, [_P]),
     "mi355_csrmv_plan_bound": (_I, [_I, _I]),

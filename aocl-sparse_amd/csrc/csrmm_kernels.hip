@@ -18,6 +18,7 @@
 //                columns, so A is read n/64 times and every B / C access is coalesced across rows.
 // Algorithmic bytes: (m+1+nnz)*4 + nnz*8 + 8*n*(k + m*(1+[beta!=0]))  (BASELINE.md section 2).
 #include "internal.hpp"
+#include "kt_order.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -1195,28 +1196,6 @@ __global__ __launch_bounds__(256) void csrmm_colpair_kernel(int base, T alpha, a
 // arithmetic differs from the kid-0 kernels (vector lanes + horizontal sum; beta * C first for the row-major one), so a
 // caller that pins a kid gets that order here -- bit for bit the FUSED build of the reference (oracle.c header), which
 // tests/test_oracle_kt.py pins on the reference's own templates.  Plain kernels: a pinned kid asks for bits, not speed.
-template <typename T, int PSZ>
-__device__ __forceinline__ T kt_hsum(const T (&p)[PSZ])
-{
-    if constexpr(std::is_same<T, double>::value && PSZ == 4) // kt_l0_avx2.hpp:333-340
-        return (p[0] + p[1]) + (p[2] + p[3]);
-    else if constexpr(std::is_same<T, double>::value && PSZ == 8) // _mm512_reduce_add_pd: halves added lane-wise
-        return ((p[4] + p[0]) + (p[6] + p[2])) + ((p[5] + p[1]) + (p[7] + p[3]));
-    else if constexpr(std::is_same<T, float>::value && PSZ == 8) // kt_l0_avx2.hpp:342-350: hadd, hadd, lo + hi
-        return ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-    else // float, 16 lanes: _mm512_reduce_add_ps, 16 -> 8 -> 4 -> 2 -> 1
-    {
-        T t3[8], t6[4];
-#pragma unroll
-        for(int i = 0; i < 8; i++)
-            t3[i] = p[8 + i] + p[i];
-#pragma unroll
-        for(int i = 0; i < 4; i++)
-            t6[i] = t3[4 + i] + t3[i];
-        return (t6[0] + t6[2]) + (t6[1] + t6[3]);
-    }
-}
-
 // column-major: a lane per (row, column); csrmm_kt.cpp:127-191
 template <typename T, int PSZ>
 __global__ __launch_bounds__(256) void csrmm_col_kt_kernel(int base, T alpha, aoclsparse_int m, const T *__restrict__ val,

@@ -507,6 +507,8 @@ public:
     // csrmm with beta == 0: false (default) = C is read and multiplied by zero as in every reference kernel (NaN / Inf in C
     // propagate); true = C is overwritten without being read (BLAS semantics, a third less traffic at 256 columns)
     bool csrmm_beta0_overwrite = false;
+    // TRSV schedule: -1 = chosen from the plan (default); 0..4 force one (aoclsparse_mi355_set_trsv_schedule; trsv_api.cpp)
+    int trsv_schedule = -1;
     // true when p is memory the device can dereference (device or managed allocation)
     bool is_device_pointer(const void *p);
     int  device = -1, cus = 0;
@@ -777,7 +779,7 @@ template <typename T>
 aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, aoclsparse_int m,
                               const TrsvPlan &plan, const T *diag, const T *b, T *x, T *xp,
                               unsigned int *scratch, aoclsparse_int nrhs, long long b_off, aoclsparse_int incb,
-                              long long x_off, aoclsparse_int incx, unsigned int *timeout_word = nullptr);
+                              long long x_off, aoclsparse_int incx, unsigned int *timeout_word = nullptr, int kt_bits = 0);
 
 template <typename R>
 aoclsparse_status launch_cvec_mul(hipStream_t s, aoclsparse_int n, const cplx<R> *d, cplx<R> *y);

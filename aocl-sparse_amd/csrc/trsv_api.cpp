@@ -487,10 +487,8 @@ aoclsparse_status solve_core(aoclsparse_operation trans, T alpha, aoclsparse_mat
     std::shared_lock<std::shared_mutex>   r(A->guard);
     const TrsvPlan &plan = A->trsv_plan[conj ? 4 + (upper ? 1 : 0) : (upper ? 2 : 0) + (tr ? 1 : 0)];
 
-    // schedule (all three give the same bits): kid 0 = one launch per level, kid 1/2 = hybrid (narrow
-    // level runs inside one workgroup), kid 3 = sync-free single launch.  auto: a shallow DAG of wide
-    // levels is cheapest as plain launches; otherwise sync-free, which measured fastest on both the
-    // 2-D Laplacian and the shell-like ILU(0) factors (profiles/r1).
+    // schedule: every one of the five gives the same bits.  A shallow DAG of wide levels is cheapest as plain launches;
+    // otherwise sync-free, which measured fastest on both the 2-D Laplacian and the shell-like ILU(0) factors.
     // (complex handles always run the hybrid schedule: their 8 / 16-byte x cannot be the one-word ready flag)
     // The sync-free choice is the slice-per-wavefront kernel (3) for one right-hand side -- unless the level slices
     // would leave most lanes idle (average level narrower than 16 rows: deep chains), where the lane-per-position
@@ -509,7 +507,15 @@ aoclsparse_status solve_core(aoclsparse_operation trans, T alpha, aoclsparse_mat
                                                                                                     : 2;
     // chained rows (the dofs of a node) solved back to back by one lane: one hop per BLOCK level instead of per row level
     const int sfb = (sf_env == 0 && plan.blk.valid) ? 4 : sf; // (trsm too: one grid column per right-hand side)
-    const int schedule = is_cplx ? 1 : kid == 0 ? 0 : (kid == 3 ? sfb : (kid > 0 ? 1 : (plan.nlevels <= 32 ? 0 : sfb)));
+    // Round 3: the kid selects the ARITHMETIC, as it does in the reference (trsv.cpp:321-353), not the schedule.  kid 0 and auto:
+    // the chain of ref_trsv_* -- every schedule reproduces it, so the fastest one runs; kid 1 / 2: the order of the 256-bit KT
+    // kernels, kid 3: of the 512-bit ones (kt_trsv_l / kt_trsv_u, trsv_kt.cpp:64-150, :297-383), bit for bit, served by the
+    // per-level launches and the lane-per-position sync-free kernel.  The transposed KT kernels apply the same per-element fma
+    // as the reference kernels (trsv_kt.cpp:183-268, :416-503), so for op != none every kid has the same bits.
+    // aoclsparse_mi355_set_trsv_schedule forces a schedule (tests, measurements).
+    const int kt_bits  = (!is_cplx && !tr && kid >= 1) ? (kid == 3 ? 512 : 256) : 0;
+    const int forced   = Runtime::primary().trsv_schedule;
+    const int schedule = is_cplx ? 1 : (forced >= 0 && forced <= 4) ? forced : (plan.nlevels <= 32 ? 0 : sfb);
     // the handle's own timeout word (pinned, device-mapped): allocated once per handle
     if(!is_cplx && !A->trsv_timeout_dev)
     {
@@ -570,12 +576,12 @@ aoclsparse_status solve_core(aoclsparse_operation trans, T alpha, aoclsparse_mat
     else
         st = launch_trsv<T>(rt.stream(), schedule, unit, alpha, m, plan, A->dev_diag.as<T>(), db, dx,
                             A->trsv_xp.as<T>(), A->trsv_scratch.as<unsigned int>(), nrhs, b_off, incb, x_off, incx,
-                            A->trsv_timeout_dev);
+                            A->trsv_timeout_dev, kt_bits);
     if(st != aoclsparse_status_success)
         return st;
     if(!xdev)
         MI355_HIP_TRY(hipMemcpyAsync(x, dx, sizeof(T) * span_x, hipMemcpyDeviceToHost, rt.stream()));
-    const bool syncfree = !is_cplx && (schedule >= 2 || (schedule == 1 && (nrhs != 1 || incb != 1 || incx != 1)));
+    const bool syncfree = !is_cplx && (schedule >= 2 || (schedule == 1 && (nrhs != 1 || incb != 1 || incx != 1 || kt_bits != 0)));
     const bool pinned_word = A->trsv_timeout_dev != nullptr;
     if(!xdev || (syncfree && !pinned_word))
     {
@@ -951,6 +957,14 @@ aoclsparse_status aoclsparse_mi355_ztrsv_full(aoclsparse_operation trans, aoclsp
 {
     return trsv_t<cdouble>(trans, cdouble(alpha.real, alpha.imag), A, descr, reinterpret_cast<const cdouble *>(b), incb,
                            reinterpret_cast<cdouble *>(x), incx, kid, aoclsparse_zmat);
+}
+
+aoclsparse_status aoclsparse_mi355_set_trsv_schedule(aoclsparse_int schedule)
+{
+    if(schedule < -1 || schedule > 4)
+        return aoclsparse_status_invalid_value;
+    Runtime::primary().trsv_schedule = (int)schedule;
+    return aoclsparse_status_success;
 }
 
 aoclsparse_status aoclsparse_mi355_trsv_status(aoclsparse_matrix A)

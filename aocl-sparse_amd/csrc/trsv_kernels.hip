@@ -27,6 +27,7 @@
 // Algorithmic bytes per solve: 12 B per stored entry of the triangle + (4+4+8+8+8) B per row.  Bound:
 // the dependency chain (levels x per-level latency), not HBM, unless levels are tens of thousands wide.
 #include "internal.hpp"
+#include "kt_order.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -72,6 +73,14 @@ __device__ __forceinline__ double neg_fma(double a, double b, double c)
 {
     return fma(-a, b, c);
 }
+__device__ __forceinline__ double kt_fma(double a, double b, double c)
+{
+    return fma(a, b, c);
+}
+__device__ __forceinline__ float kt_fma(float a, float b, float c)
+{
+    return fmaf(a, b, c);
+}
 __device__ __forceinline__ float neg_fma(float a, float b, float c)
 {
     return fmaf(-a, b, c);
@@ -103,7 +112,50 @@ struct RhsGeom
     int       cols_fast; // sync-free kernel only: blockIdx.x = column
 };
 
-template <typename T>
+// TSZ = 0: the chain of ref_trsv_l / ref_trsv_u (kid 0).  TSZ = 4 / 8 (double), 8 / 16 (float): the row sequence of
+// kt_trsv_l / kt_trsv_u for 256- / 512-bit vectors (level2/aoclsparse_trsv_kt.cpp:92-137, :324-371; kid 1/2 / kid 3):
+// lane l of the vector accumulates entries l, l + TSZ, ... of the full groups, xi -= hsum; a remainder of TSZ - 1 entries
+// is one zero-padded vector product (mul, hsum), any other remainder the scalar chain.
+template <typename T, int TSZ>
+__device__ __forceinline__ T trsv_row_chain(T xi, int s, int e, const aoclsparse_int *__restrict__ pind,
+                                            const T *__restrict__ pval, const T *xp)
+{
+    if constexpr(TSZ == 0)
+    {
+        for(int p = s; p < e; p++)
+            xi = neg_fma(pval[p], xp[pind[p]], xi);
+        return xi;
+    }
+    else
+    {
+        const int cnt = e - s, rem = cnt % TSZ;
+        T         acc[TSZ];
+#pragma unroll
+        for(int l = 0; l < TSZ; l++)
+            acc[l] = T(0);
+        int p = s;
+        for(; p < e - rem; p += TSZ)
+#pragma unroll
+            for(int l = 0; l < TSZ; l++)
+                acc[l] = kt_fma(pval[p + l], xp[pind[p + l]], acc[l]);
+        if(cnt >= TSZ)
+            xi -= kt_hsum<T, TSZ>(acc);
+        if(rem == TSZ - 1)
+        {
+#pragma unroll
+            for(int l = 0; l < TSZ - 1; l++)
+                acc[l] = pval[p + l] * xp[pind[p + l]];
+            acc[TSZ - 1] = T(0);
+            xi -= kt_hsum<T, TSZ>(acc);
+        }
+        else
+            for(; p < e; p++)
+                xi = neg_fma(pval[p], xp[pind[p]], xi);
+        return xi;
+    }
+}
+
+template <typename T, int TSZ>
 __global__ void trsv_level_kernel(aoclsparse_int first, aoclsparse_int count, aoclsparse_int m,
                                   const aoclsparse_int *__restrict__ rowmap,
                                   const aoclsparse_int *__restrict__ pptr,
@@ -121,9 +173,7 @@ __global__ void trsv_level_kernel(aoclsparse_int first, aoclsparse_int count, ao
     const int k  = first + t;
     const int i  = rowmap[k];
     T         xi = alpha * b[(size_t)i * g.incb];
-    const int s = pptr[k], e = pptr[k + 1];
-    for(int p = s; p < e; p++)
-        xi = neg_fma(pval[p], xp[pind[p]], xi);
+    xi = trsv_row_chain<T, TSZ>(xi, pptr[k], pptr[k + 1], pind, pval, xp);
     if(!unit)
         xi /= diag[i];
     xp[k]                  = xi;
@@ -272,7 +322,7 @@ __global__ __launch_bounds__(TRSV_NARROW) void trsv_multilevel_kernel(
 // Two shapes, chosen from the triangle's mean row length: (1024 lanes, 12 staged entries) for short rows
 // and wide levels (more dependencies stay inside the workgroup), (512, 20) when rows carry more entries
 // than 12 (ILU(0) of the shell-like matrix: 7.2 ms vs 10.5 ms; of the 2-D Laplacian: 2.1 ms vs 2.5 ms).
-template <typename T, int TRSV_SF_BLOCK, int TRSV_SF_PF>
+template <typename T, int TRSV_SF_BLOCK, int TRSV_SF_PF, int TSZ = 0>
 __global__ __launch_bounds__(TRSV_SF_BLOCK) void trsv_syncfree_kernel(
     aoclsparse_int m, const aoclsparse_int *__restrict__ rowmap, const aoclsparse_int *__restrict__ pptr,
     const aoclsparse_int *__restrict__ pind, const T *__restrict__ pval, const T *__restrict__ diag,
@@ -321,6 +371,17 @@ __global__ __launch_bounds__(TRSV_SF_BLOCK) void trsv_syncfree_kernel(
     int  p    = p0;
     B   *xb   = reinterpret_cast<B *>(xp);
     bool done = false;
+    // TSZ > 0: the KT order (trsv_kt.cpp:92-137) -- entries are still consumed one by one as their x arrives, but entry e of
+    // the full groups goes to vector lane e % TSZ, the lanes are reduced with the reference's tree when the last full group
+    // is in, a remainder of TSZ - 1 entries is a zero-padded product vector reduced the same way, any other remainder the
+    // scalar chain.  (acc[] is updated through selects: a run-time register index would go to scratch memory.)
+    constexpr int AN = TSZ > 0 ? TSZ : 1;
+    T             acc[AN];
+#pragma unroll
+    for(int l = 0; l < AN; l++)
+        acc[l] = T(0);
+    const int cnt = pe - p0, full = TSZ > 0 ? cnt - cnt % AN : 0;
+    const bool masked = TSZ > 0 && cnt % AN == AN - 1;
     // every lane keeps iterating until ITS row is published: a lane may wait on a row owned by
     // another lane of the same wavefront, so the store must happen inside the loop
     unsigned int       spins  = 0;
@@ -341,7 +402,35 @@ __global__ __launch_bounds__(TRSV_SF_BLOCK) void trsv_syncfree_kernel(
             {
                 T xv;
                 __builtin_memcpy(&xv, &bits, sizeof(T));
-                xi = neg_fma(staged ? s_ev[e][tid] : pval[p], xv, xi);
+                const T av = staged ? s_ev[e][tid] : pval[p];
+                if constexpr(TSZ == 0)
+                    xi = neg_fma(av, xv, xi);
+                else
+                {
+                    if(e < full)
+                    {
+                        const int l = e % TSZ;
+#pragma unroll
+                        for(int q2 = 0; q2 < TSZ; q2++)
+                            acc[q2] = q2 == l ? kt_fma(av, xv, acc[q2]) : acc[q2];
+                        if(e == full - 1)
+                            xi -= kt_hsum<T, AN>(acc);
+                    }
+                    else if(masked)
+                    {
+                        const int l = e - full;
+#pragma unroll
+                        for(int q2 = 0; q2 < TSZ; q2++)
+                            acc[q2] = q2 == l ? av * xv : acc[q2];
+                        if(e == cnt - 1)
+                        {
+                            acc[TSZ - 1] = T(0);
+                            xi -= kt_hsum<T, AN>(acc);
+                        }
+                    }
+                    else
+                        xi = neg_fma(av, xv, xi);
+                }
                 p++;
                 spins = 0, t_wait = 0;
             }
@@ -906,10 +995,17 @@ template <typename T>
 aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, aoclsparse_int m,
                               const TrsvPlan &plan, const T *diag, const T *b, T *x, T *xp, unsigned int *scratch,
                               aoclsparse_int nrhs, long long b_off, aoclsparse_int incb, long long x_off,
-                              aoclsparse_int incx, unsigned int *timeout_word)
+                              aoclsparse_int incx, unsigned int *timeout_word, int kt_bits)
 {
     if(m <= 0 || nrhs <= 0)
         return aoclsparse_status_success;
+    // kt_bits: 0 = the reference chain (ref_trsv_*); 256 / 512 = the KT kernels' order for that vector width (kid 1/2 / 3).
+    // Served by the per-level launches and by the lane-per-position sync-free kernel.
+    constexpr int T256 = std::is_same<T, double>::value ? 4 : 8;
+    if(kt_bits != 0 && kt_bits != 256 && kt_bits != 512)
+        return aoclsparse_status_internal_error;
+    if(kt_bits != 0 && schedule != 0)
+        schedule = 2;
     const aoclsparse_int *rowmap = plan.rowmap.as<aoclsparse_int>();
     const aoclsparse_int *pptr   = plan.pptr.as<aoclsparse_int>();
     const aoclsparse_int *pind   = plan.pind.as<aoclsparse_int>();
@@ -929,9 +1025,14 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
         for(aoclsparse_int c0 = 0; c0 < nrhs; c0 += 65535)
         {
             const int nc = nrhs - c0 < 65535 ? nrhs - c0 : 65535;
-            hipLaunchKernelGGL((trsv_level_kernel<T>), dim3((count + bs - 1) / bs, nc), dim3(bs), 0, s, first, count,
-                               m, rowmap, pptr, pind, pval, diag, b + c0 * b_off, xp + (size_t)c0 * m, x + c0 * x_off,
-                               alpha, (int)unit, g);
+#define MI355_LEVEL_ARGS first, count, m, rowmap, pptr, pind, pval, diag, b + c0 * b_off, xp + (size_t)c0 * m, x + c0 * x_off, alpha, (int)unit, g
+            if(kt_bits == 0)
+                hipLaunchKernelGGL((trsv_level_kernel<T, 0>), dim3((count + bs - 1) / bs, nc), dim3(bs), 0, s, MI355_LEVEL_ARGS);
+            else if(kt_bits == 256)
+                hipLaunchKernelGGL((trsv_level_kernel<T, T256>), dim3((count + bs - 1) / bs, nc), dim3(bs), 0, s, MI355_LEVEL_ARGS);
+            else
+                hipLaunchKernelGGL((trsv_level_kernel<T, 2 * T256>), dim3((count + bs - 1) / bs, nc), dim3(bs), 0, s, MI355_LEVEL_ARGS);
+#undef MI355_LEVEL_ARGS
         }
     };
     if(schedule == 0)
@@ -1077,14 +1178,26 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
             const unsigned nblk = (unsigned)((m + (wide ? 511 : 1023)) / (wide ? 512 : 1024));
             g.cols_fast         = nc > 1 && nblk <= 65535u;
             const dim3 grid     = g.cols_fast ? dim3(nc, nblk) : dim3(nblk, nc);
-            if(wide)
-                hipLaunchKernelGGL((trsv_syncfree_kernel<T, 512, 20>), grid, dim3(512), 0, s, m, rowmap, pptr, pind, pval,
-                                   diag, b + c0 * b_off, xp + (size_t)c0 * m, x + c0 * x_off, alpha, (int)unit, scratch + c0,
-                                   tmo, g);
+#define MI355_SF_ARGS m, rowmap, pptr, pind, pval, diag, b + c0 * b_off, xp + (size_t)c0 * m, x + c0 * x_off, alpha, (int)unit, scratch + c0, tmo, g
+            if(kt_bits == 256)
+            {
+                if(wide)
+                    hipLaunchKernelGGL((trsv_syncfree_kernel<T, 512, 20, T256>), grid, dim3(512), 0, s, MI355_SF_ARGS);
+                else
+                    hipLaunchKernelGGL((trsv_syncfree_kernel<T, 1024, 12, T256>), grid, dim3(1024), 0, s, MI355_SF_ARGS);
+            }
+            else if(kt_bits == 512)
+            {
+                if(wide)
+                    hipLaunchKernelGGL((trsv_syncfree_kernel<T, 512, 20, 2 * T256>), grid, dim3(512), 0, s, MI355_SF_ARGS);
+                else
+                    hipLaunchKernelGGL((trsv_syncfree_kernel<T, 1024, 12, 2 * T256>), grid, dim3(1024), 0, s, MI355_SF_ARGS);
+            }
+            else if(wide)
+                hipLaunchKernelGGL((trsv_syncfree_kernel<T, 512, 20>), grid, dim3(512), 0, s, MI355_SF_ARGS);
             else
-                hipLaunchKernelGGL((trsv_syncfree_kernel<T, 1024, 12>), grid, dim3(1024), 0, s, m, rowmap, pptr, pind,
-                                   pval, diag, b + c0 * b_off, xp + (size_t)c0 * m, x + c0 * x_off, alpha, (int)unit,
-                                   scratch + c0, tmo, g);
+                hipLaunchKernelGGL((trsv_syncfree_kernel<T, 1024, 12>), grid, dim3(1024), 0, s, MI355_SF_ARGS);
+#undef MI355_SF_ARGS
         }
     }
     MI355_HIP_TRY(hipGetLastError());
@@ -1094,10 +1207,10 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
 template aoclsparse_status launch_trsv<double>(hipStream_t, int, bool, double, aoclsparse_int, const TrsvPlan &,
                                                const double *, const double *, double *, double *, unsigned int *,
                                                aoclsparse_int, long long, aoclsparse_int, long long, aoclsparse_int,
-                                               unsigned int *);
+                                               unsigned int *, int);
 template aoclsparse_status launch_trsv<float>(hipStream_t, int, bool, float, aoclsparse_int, const TrsvPlan &,
                                               const float *, const float *, float *, float *, unsigned int *,
                                               aoclsparse_int, long long, aoclsparse_int, long long, aoclsparse_int,
-                                              unsigned int *);
+                                              unsigned int *, int);
 
 } // namespace mi355

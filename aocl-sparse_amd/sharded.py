@@ -191,11 +191,13 @@ def csrmm_bytes(m, k, nnz, ncols, beta_nonzero=False):
 
 
 def bench_sharded_csrmm(pkg, torch, dist, device, rank, world, csr, ncols, layout="col", reps=20, warm=3,
-                        full_product=True, allgather=True, peak_gbs=8000.0):
+                        full_product=True, allgather=True, peak_gbs=8000.0, c_is_read=True):
     """The BASELINE config-4 job on `world` ranks.  Returns (on every rank) a dict with the sharded time (max over
     ranks of the median per-iteration device time, and the barrier-bracketed wall clock), the 1-GPU time T1 of the SAME
     job measured in the same run (every rank runs all `ncols` columns once `full_product` is set), the scaling
-    efficiency T1 / (world * Tg), the A broadcast and the optional C all-gather."""
+    efficiency T1 / (world * Tg), the A broadcast and the optional C all-gather.  c_is_read: the library's default for
+    beta = 0 reads C (the reference's arithmetic), so the byte model counts that read; pass False when the overwrite mode of
+    aoclsparse_mi355_set_csrmm_beta0_overwrite is on."""
     sh = ShardedCsrmm(pkg, torch, dist, device, rank, world, csr, ncols, layout)
     m, nnz = sh.m, sh.nnz
     B = sh.make_B()
@@ -224,13 +226,13 @@ def bench_sharded_csrmm(pkg, torch, dist, device, rank, world, csr, ncols, layou
     checksum = reduce_scalar(float(C[: sh.nloc * m].sum().item()) if sh.nloc else 0.0, "sum", dist, device)
     out = {
         "layout": "column-major" if layout == "col" else "row-major", "ncols": ncols, "world": world,
-        "cols_per_rank": sh.nloc, "m": m, "nnz": nnz,
+        "cols_per_rank": sh.nloc, "m": m, "nnz": nnz, "c_is_read": bool(c_is_read),
         "shard_ms": st_shard, "tg_ms_device_median_max_over_ranks": round(tg_dev, 5),
         "tg_ms_wall_max_over_ranks": round(tg_wall, 5), "a_broadcast_ms": round(sh.a_broadcast_ms, 3),
         "checksum": checksum,
     }
-    job_bytes = csrmm_bytes(m, sh.n, nnz, ncols) + (world - 1) * ((m + 1 + nnz) * 4 + nnz * 8)
-    shard_bytes = csrmm_bytes(m, sh.n, nnz, sh.nloc)
+    job_bytes = csrmm_bytes(m, sh.n, nnz, ncols, c_is_read) + (world - 1) * ((m + 1 + nnz) * 4 + nnz * 8)
+    shard_bytes = csrmm_bytes(m, sh.n, nnz, sh.nloc, c_is_read)
     out["gflops_job"] = round(2.0 * nnz * ncols / tg_dev / 1e6, 2)
     shard_gbs = shard_bytes / st_shard["median"] / 1e6 if sh.nloc and st_shard["median"] > 0 else 0.0
     out["roofline_shard"] = {"bound": "hbm", "achieved": round(shard_gbs, 2), "peak": peak_gbs, "unit": "GB/s",
@@ -255,7 +257,7 @@ def bench_sharded_csrmm(pkg, torch, dist, device, rank, world, csr, ncols, layou
         out["t1_ms"] = round(t1, 5)
         out["full_ms"] = st_full
         out["efficiency"] = round(t1 / (world * tg_dev), 4)
-        fb = csrmm_bytes(m, sh.n, nnz, ncols)
+        fb = csrmm_bytes(m, sh.n, nnz, ncols, c_is_read)
         out["roofline_full"] = {"bound": "hbm", "achieved": round(fb / t1 / 1e6, 2), "peak": peak_gbs, "unit": "GB/s",
                                 "frac": round(fb / t1 / 1e6 / peak_gbs, 4), "traffic": None,
                                 "algorithmic_bytes_per_launch": fb}

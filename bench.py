@@ -171,14 +171,15 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: CPU tensors on the wire, ranks may share one GPU (control-flow tests on a 1-GPU box)")
     ap.add_argument("--legs", default="all",
-                    help="comma list of l100,dcsrmv_csr_adaptive,mix,csrmm,csrmm_sharded,trsv,cpu (or all / none)")
+                    help="comma list of l100,dcsrmv_csr_adaptive,mix,csrmm,csrmm_sharded,trsv,cpu,inlib_multi (or all / none)")
     ap.add_argument("--mm-grid", type=int, default=1000, help="csrmm: A = Laplacian on grid^2")
     ap.add_argument("--mm-cols", type=int, default=256)
-    ap.add_argument("--mm-layout", default="col", choices=["col", "row"], help="layout of the sharded csrmm leg")
+    ap.add_argument("--mm-layout", default="row", choices=["col", "row"],
+                    help="layout of the sharded csrmm leg (row-major slabs are the faster ones: 0.13 vs 0.19 ms per 32-column slab)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU-baseline budget per thread count")
     ap.add_argument("--small", action="store_true", help="mix / trsv legs on the two small matrices only")
     args = ap.parse_args()
-    all_legs = ["l100", "dcsrmv_csr_adaptive", "mix", "csrmm", "csrmm_sharded", "trsv", "cpu"]
+    all_legs = ["l100", "dcsrmv_csr_adaptive", "mix", "csrmm", "csrmm_sharded", "trsv", "cpu", "inlib_multi"]
     legs = set(all_legs) if args.legs == "all" else set(x for x in args.legs.split(",") if x and x != "none")
     assert legs <= set(all_legs), "unknown leg in --legs: %s" % sorted(legs - set(all_legs))
 
@@ -357,7 +358,8 @@ def main():
         res, sh, B, C = sharded.bench_sharded_csrmm(pkg, torch, D, device, rank, world, csr_mm, args.mm_cols,
                                                     layout=args.mm_layout, reps=20, warm=3, full_product=True,
                                                     allgather=world > 1, peak_gbs=HBM_PEAK_GBS)
-        res["workload"] = ("aoclsparse_dcsrmm, A = 5-pt Laplacian %dx%d grid, B %d x %d fp64 %s, beta=0, columns "
+        res["workload"] = ("aoclsparse_dcsrmm, A = 5-pt Laplacian %dx%d grid, B %d x %d fp64 %s, beta=0 (C read and multiplied "
+                           "by zero as in the reference: the default), columns "
                            "sharded over %d rank(s) by the reference's thread-split rule (csrmm_kt.cpp:68-82); A "
                            "broadcast from rank 0, no data-path collective"
                            % (args.mm_grid, args.mm_grid, sh.m, args.mm_cols, res["layout"], world))
@@ -467,7 +469,11 @@ def main():
                 pmc_irr = json.load(f)
         except (OSError, ValueError):
             pmc_irr = {}
-        names = ["circuit-like", "web-like"] + ([] if args.small else ["shell-like", "flan-like"])
+        # the four stand-ins, then (round 3) each one OFF its ideal ordering: graphs with locality, meshes with irregular
+        # valence and a windowed random node order (tools/standins.py)
+        names = (["circuit-like", "web-like"] + ([] if args.small else ["shell-like", "flan-like"])
+                 + ["circuit-like, local", "web-like, local"]
+                 + ([] if args.small else ["shell-like, unstructured", "flan-like, unstructured"]))
         for name in names:
             label, mm_, rp, ci, v = standins.load(name)
             nz = len(v)
@@ -568,13 +574,23 @@ def main():
             for ncols, tag in ((args.mm_cols, "all %d columns" % args.mm_cols), (j1 - j0, "one slab of an 8-rank run")):
                 Bs = B if ncols == args.mm_cols else sh.make_B(j0=j0, j1=j1)
                 Cs = C if ncols == args.mm_cols else torch.zeros(ncols * mm_m, dtype=torch.float64, device=device)
-                for beta in (0.0, -2.0):
+                # beta = 0 twice: the default reads C and multiplies it by zero, as every reference kernel does (NaN / Inf in C
+                # propagate: csrmm.hpp:83,129) -- its algorithmic bytes therefore include the read of C; the opt-in overwrite
+                # mode (aoclsparse_mi355_set_csrmm_beta0_overwrite) does not read C
+                for beta, overwrite in ((0.0, False), (0.0, True), (-2.0, False)):
+                    assert L.aoclsparse_mi355_set_csrmm_beta0_overwrite(1 if overwrite else 0) == 0
                     lp = timed_laps(pkg, lambda: sh.run(Bs, Cs, beta=beta, nloc=ncols), 20, 3)
+                    assert L.aoclsparse_mi355_set_csrmm_beta0_overwrite(0) == 0
                     ms = float(np.mean(lp))
-                    b = csrmm_bytes(mm_m, mm_m, nz, ncols, beta != 0.0)
+                    reads_c = beta != 0.0 or not overwrite
+                    b = csrmm_bytes(mm_m, mm_m, nz, ncols, reads_c)
                     res["cases"].append({"layout": "row-major" if layout == "row" else "column-major", "ncols": ncols,
-                                         "what": tag, "beta": beta, "ms": round(ms, 5), "stats_ms": quartiles(lp),
-                                         "gflops": round(2.0 * nz * ncols / ms / 1e6, 1), "roofline": roofline(b, ms)})
+                                         "what": tag, "beta": beta,
+                                         "c_is_read": reads_c, "mode": ("default: C read (reference arithmetic)" if beta == 0.0 and not overwrite
+                                                                        else "opt-in: C overwritten" if beta == 0.0 else "beta != 0"),
+                                         "ms": round(ms, 5), "stats_ms": quartiles(lp),
+                                         "gflops": round(2.0 * nz * ncols / ms / 1e6, 1), "roofline": roofline(b, ms),
+                                         "roofline_survey_model": roofline(csrmm_bytes(mm_m, mm_m, nz, ncols, beta != 0.0), ms)})
                 # parity: 4 columns against the oracle's column-major reference kernel (beta = 0)
                 Cs.zero_()
                 assert sh.run(Bs, Cs, beta=0.0, nloc=ncols) == 0
@@ -584,8 +600,8 @@ def main():
                 bb = Bs.reshape(ncols, mm_m)[:ns] if layout == "col" else Bs.reshape(mm_m, ncols)[:, :ns].t().contiguous()
                 _, Cr = oracle.dcsrmm("col", 1.0, 0, v, ci, rp, mm_m, bb.cpu().numpy().reshape(-1), ns, mm_m, 0.0,
                                       np.zeros(ns * mm_m), mm_m)
-                res["cases"][-1]["bit_exact_4_columns"] = bool(np.array_equal(cc.cpu().numpy().reshape(-1), Cr))
-                res["cases"][-2]["bit_exact_4_columns"] = res["cases"][-1]["bit_exact_4_columns"]
+                for q in (-1, -2, -3):
+                    res["cases"][q]["bit_exact_4_columns"] = bool(np.array_equal(cc.cpu().numpy().reshape(-1), Cr))
             del sh, B, C
         return res
 
@@ -593,14 +609,20 @@ def main():
 
     # ---- configs[4]: unit-lower ILU(0) factor of the shell-like matrix ----
     def leg_trsv():
-        import oracle
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import standins
         if args.small:
-            title, (mt, rp, ci, v) = "ILU(0) of 5-pt Laplacian grid 300^2", entry.laplace5(300)
-        else:
-            label, mt, rp, ci, v = standins.load("shell-like")
-            title = "ILU(0) factor of %s" % label
+            return trsv_system("ILU(0) of 5-pt Laplacian grid 300^2", *entry.laplace5(300))
+        label, mt, rp, ci, v = standins.load("shell-like")
+        res = trsv_system("ILU(0) factor of %s" % label, mt, rp, ci, v)
+        # round 3: the same mesh OFF its ideal ordering (10 % of the couplings dropped, nodes renumbered inside windows): how
+        # the supernodal schedule (chains of dof rows) and the level structure hold up
+        label2, mt, rp, ci, v = standins.load("shell-like, unstructured")
+        res["unstructured_variant"] = trsv_system("ILU(0) factor of %s" % label2, mt, rp, ci, v, kids=(-1,))
+        return res
+
+    def trsv_system(title, mt, rp, ci, v, kids=(-1, 3, 1)):
+        import oracle
         t = time.perf_counter()
         stf, lu, dg = oracle.dilu0(mt, 0, rp, ci, v)  # input preparation (the reference factorises on the CPU too)
         t_ilu = time.perf_counter() - t
@@ -626,23 +648,48 @@ def main():
                            "levels), descr {triangular, lower, unit}, alpha=1, b = L*1" % (title, mt, nnz_l, lv),
                "schedules": [], "cpu_serial_ms": round(t_cpu * 1e3, 3), "analysis_s": round(t_opt, 2),
                "ilu0_input_preparation_s": round(t_ilu, 2)}
-        for kid, nm in ((-1, "auto"), (3, "sync-free single launch"), (1, "hybrid")):
-            reps = 20 if kid != 1 else 5
+        # the kid selects the ARITHMETIC (as in the reference, trsv.cpp:321-353): auto / 0 = ref_trsv_l's chain on the fastest
+        # schedule; 3 = the order of the 512-bit KT kernel an AVX-512 host dispatches, 1 = the 256-bit one (both served by the
+        # lane-per-position sync-free kernel), each checked bit for bit against the oracle's restatement of THAT kernel
+        _, xk8 = oracle.trsv_kt("l", 8, 1.0, mt, 0, lu, ci, rp, o["idiag"], bh, True)
+        _, xk4 = oracle.trsv_kt("l", 4, 1.0, mt, 0, lu, ci, rp, o["idiag"], bh, True)
+        for kid, nm, xref in ((-1, "auto: ref_trsv_l order, schedule chosen from the plan", xr),
+                              (3, "kid 3: kt_trsv_l<512-bit> order (AVX-512 host), sync-free lane per position", xk8),
+                              (1, "kid 1: kt_trsv_l<256-bit> order (AVX2 host), sync-free lane per position", xk4)):
+            if kid not in kids:
+                continue
+            reps = 20 if kid < 0 else 10
             lp = timed_laps(pkg, lambda: pkg.dtrsv(pkg.OP_NONE, 1.0, At, dl, bdev, xdev, kid=kid), reps, 2)
             torch.cuda.synchronize()
             xg = xdev.cpu().numpy()
             _, lx = oracle.dcsrmv_special("tri", 0, 1.0, mt, mt, 1, 0, lu, ci, rp, o["idiag"], o["iurow"], xg, 0.0, np.zeros(mt))
             ms = float(np.median(lp))
+            xr_k = xref
             res["schedules"].append({"schedule": nm, "kid": kid, "ms": round(ms, 5), "stats_ms": quartiles(lp),
                                      "us_per_level": round(ms * 1e3 / max(lv, 1), 4),
                                      "gflops": round((2.0 * nnz_l + mt) / ms / 1e6, 2),
                                      "roofline": roofline(ab, ms, note="bound by the dependency chain, not by HBM"),
-                                     "bit_exact_vs_cpu": bool(np.array_equal(xg, xr)),
+                                     "bit_exact_vs_cpu": bool(np.array_equal(xg, xr_k)),
                                      "residual_inf": float(np.max(np.abs(lx - bh)) / np.max(np.abs(bh))),
                                      "max_componentwise_err_vs_ones": float(np.max(np.abs(xg - 1.0)))})
         return res
 
     run_leg("trsv", leg_trsv)
+
+    # ---- in-library multi-device csrmm: ONE process over every visible GPU (aoclsparse_mi355_dcsrmm_multi_slabs) ----
+    # Run as a CHILD process with a timeout: a problem on a multi-GPU node (first contact with N devices happens in the
+    # driver's runs) must not take this line down.  On a one-GPU box the same control flow runs with two slots on device 0.
+    def leg_inlib_multi():
+        import subprocess
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "multi_check.py"), "--cols", str(args.mm_cols), "--grid", str(args.mm_grid)]
+        cmd += ["--devices", str(min(ndev, 8))] if ndev > 1 else ["--devices", "2", "--same-device"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": "multi_check.py exit %d: %s" % (r.returncode, r.stderr[-400:])}
+        return json.loads(lines[-1])
+
+    run_leg("inlib_multi", leg_inlib_multi)
 
     # ---- CPU baseline: the oracle on this box's host cores, bounded sample ----
     def leg_cpu():

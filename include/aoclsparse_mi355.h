@@ -136,6 +136,13 @@ DLL_PUBLIC aoclsparse_status aoclsparse_mi355_get_trsv_levels(const aoclsparse_m
  * and sets a word owned by the handle.  Call this AFTER synchronising your stream: internal_error if a solve of THIS handle
  * expired since the last query (the word is cleared), success otherwise.  Host-pointer solves report it themselves. */
 DLL_PUBLIC aoclsparse_status aoclsparse_mi355_trsv_status(aoclsparse_matrix A);
+/* TRSV / TRSM schedule.  -1 (default): chosen from the plan -- one launch per level for <= 32 levels, else a single
+ * sync-free launch (a lane per block of chained rows where the triangle has them, else a level slice per wavefront or a
+ * lane per position).  0: one launch per level, 1: hybrid (narrow level runs inside one workgroup), 2: sync-free, lane per
+ * position, 3: sync-free, level slice per wavefront, 4: sync-free, lane per block.  Every schedule returns the same bits;
+ * the `kid` of aoclsparse_?trsv_kid selects the arithmetic (0: ref_trsv_*; 1/2: 256-bit KT kernels; 3: 512-bit KT kernels), as
+ * in the reference (library/src/level2/aoclsparse_trsv.cpp:321-353).  Process-wide; for tests and measurements. */
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_set_trsv_schedule(aoclsparse_int schedule);
 /* drop every device-side copy/plan of the handle (call after mutating the aliased arrays) */
 DLL_PUBLIC aoclsparse_status aoclsparse_mi355_invalidate(aoclsparse_matrix A);
 

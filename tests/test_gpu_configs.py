@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import oracle
-from util import EPS64, ROOT, beta0_overwrite, laplace5, pkg, random_csr
+from util import EPS64, ROOT, beta0_overwrite, laplace5, pkg, random_csr, trsv_schedule
 
 pytestmark = pytest.mark.gpu
 
@@ -109,12 +109,19 @@ def test_shell_like_ilu0_trsv_full_size():
     st, xr = oracle.dtrsv("l", 1.0, m, 0, lu, ci, rp, o["idiag"], b, True)
     assert st == 0
     bd = dev(b)
-    for kid in (None, 3, 1):  # auto, sync-free, hybrid
-        xd = torch.full((m,), np.nan, dtype=torch.float64, device="cuda")
-        assert P.dtrsv(P.OP_NONE, 1.0, A, dl, bd, xd, kid=kid) == 0
-        torch.cuda.synchronize()
-        x = xd.cpu().numpy()
-        assert np.array_equal(x, xr), "schedule kid=%s differs from the serial chain" % kid
+    for sched in (-1, 0, 1, 2, 3, 4):  # the automatic choice, then every schedule (the kid selects the ARITHMETIC: round 3)
+        with trsv_schedule(P, sched):
+            xd = torch.full((m,), np.nan, dtype=torch.float64, device="cuda")
+            assert P.dtrsv(P.OP_NONE, 1.0, A, dl, bd, xd) == 0
+            torch.cuda.synchronize()
+            x = xd.cpu().numpy()
+            assert np.array_equal(x, xr), "schedule %d differs from the serial chain" % sched
+    # kid 3 = the arithmetic of kt_trsv_l with 512-bit vectors (what an AVX-512 host runs): bit-identical to its restatement
+    st, xk = oracle.trsv_kt("l", 8, 1.0, m, 0, lu, ci, rp, o["idiag"], b, True)
+    xd = torch.full((m,), np.nan, dtype=torch.float64, device="cuda")
+    assert st == 0 and P.dtrsv(P.OP_NONE, 1.0, A, dl, bd, xd, kid=3) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(xd.cpu().numpy(), xk) and not np.array_equal(xk, xr)
     assert np.max(np.abs(x - 1.0)) <= 64 * EPS64
     _, lx = oracle.dcsrmv_special("tri", 0, 1.0, m, m, 1, 0, lu, ci, rp, o["idiag"], o["iurow"], x, 0.0, np.zeros(m))
     assert np.max(np.abs(lx - b)) <= 16 * EPS64 * np.max(np.abs(b))
@@ -443,9 +450,9 @@ def _same_up_to_nan_payload(got, ref):
 @pytest.mark.parametrize("fill,unit", [("lower", False), ("upper", True)])
 def test_trsv_nan_inf_and_tag_collision_every_schedule(fill, unit):
     """NaN, +-Inf and the exact NOT-READY bit pattern (0x7FF8DEADBEEF0355, a NaN) placed in b must propagate through
-    the dependency DAG exactly as in the serial reference chain -- for the per-level launches (kid 0), the hybrid
-    schedule (kid 1), the slice-per-wavefront sync-free kernel (kid 3 / auto) and the lane-per-position sync-free kernel
-    (what trsm runs for several right-hand sides) -- and never hang or report an error: a result equal to the tag is
+    the dependency DAG exactly as in the serial reference chain -- for the per-level launches (schedule 0), the hybrid
+    schedule (1), the sync-free kernels (2: lane per position, also what trsm runs; 3: slice per wavefront; 4: lane per block)
+    and the automatic choice -- and never hang or report an error: a result equal to the tag is
     published as a plain quiet NaN."""
     from util import triangular_system
     m = 20000
@@ -468,18 +475,25 @@ def test_trsv_nan_inf_and_tag_collision_every_schedule(fill, unit):
         st, xr = oracle.dtrsv(kind, 1.0, m, 0, o["val"], o["ind"], o["ptr"], ilend, b, unit)
         assert st == 0
         assert np.isnan(xr).sum() >= 2 or case == "inf"
-        for kid in (0, 1, 3, None):
+        for sched in (0, 1, 2, 3, 4, -1):  # every schedule, then the automatic choice
+            with trsv_schedule(P, sched):
+                xd = torch.zeros(m, dtype=torch.float64, device="cuda")
+                assert P.dtrsv(P.OP_NONE, 1.0, A, d, dev(b), xd) == 0, (case, sched)
+                torch.cuda.synchronize()
+                assert _same_up_to_nan_payload(xd.cpu().numpy(), xr), (case, sched)
+                xh = np.zeros(m)
+                assert P.dtrsv(P.OP_NONE, 1.0, A, d, b, xh) == 0  # host pointers: synchronous, status checked
+                assert _same_up_to_nan_payload(xh, xr), (case, sched)
+        # the KT orders (kid 1 / 3) propagate NaN / Inf / the tag through the same DAG: NaN exactly where the chain has NaN
+        for kid in (1, 3):
             xd = torch.zeros(m, dtype=torch.float64, device="cuda")
             assert P.dtrsv(P.OP_NONE, 1.0, A, d, dev(b), xd, kid=kid) == 0, (case, kid)
             torch.cuda.synchronize()
-            assert _same_up_to_nan_payload(xd.cpu().numpy(), xr), (case, kid)
-            xh = np.zeros(m)
-            assert P.dtrsv(P.OP_NONE, 1.0, A, d, b, xh, kid=kid) == 0  # host pointers: synchronous, status checked
-            assert _same_up_to_nan_payload(xh, xr), (case, kid)
+            assert np.array_equal(np.isnan(xd.cpu().numpy()), np.isnan(xr)), (case, kid)
         # two right-hand sides through trsm: the lane-per-position sync-free kernel
         Bm = np.stack([b, b[::-1].copy()])  # column-major, ld = m
         Xm = np.zeros_like(Bm)
-        assert L.aoclsparse_dtrsm_kid(P.OP_NONE, 1.0, A.h, d.h, P.ORDER_COLUMN, P._ptr(Bm), 2, m, P._ptr(Xm), m, 3) == 0
+        assert L.aoclsparse_dtrsm(P.OP_NONE, 1.0, A.h, d.h, P.ORDER_COLUMN, P._ptr(Bm), 2, m, P._ptr(Xm), m) == 0
         assert _same_up_to_nan_payload(Xm[0], xr), case
         st, xr2 = oracle.dtrsv(kind, 1.0, m, 0, o["val"], o["ind"], o["ptr"], ilend, Bm[1], unit)
         assert _same_up_to_nan_payload(Xm[1], xr2), case
@@ -493,13 +507,14 @@ def test_strsv_tag_collision_float():
     d = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=P.FILL_LOWER)
     b = np.random.default_rng(4).uniform(-1, 1, m).astype(np.float32)
     b[[3, 2500]] = np.array([0x7FC0D355], dtype=np.uint32).view(np.float32)[0]
-    for kid in (0, 3):
-        xd = torch.zeros(m, dtype=torch.float32, device="cuda")
-        assert P.strsv(P.OP_NONE, 1.0, A, d, dev(b), xd, kid=kid) == 0
-        torch.cuda.synchronize()
-        got = xd.cpu().numpy()
-        if kid == 0:
-            ref = got
+    for sched in (0, 2):  # per-level launches, sync-free
+        with trsv_schedule(P, sched):
+            xd = torch.zeros(m, dtype=torch.float32, device="cuda")
+            assert P.strsv(P.OP_NONE, 1.0, A, d, dev(b), xd) == 0
+            torch.cuda.synchronize()
+            got = xd.cpu().numpy()
+            if sched == 0:
+                ref = got
     assert _same_up_to_nan_payload(got, ref) and np.isnan(ref).sum() >= 2
 
 
@@ -514,12 +529,12 @@ def test_trsv_sync_free_is_asynchronous_for_device_pointers():
     d = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=P.FILL_LOWER)
     b = np.random.default_rng(5).uniform(-1, 1, m)
     bd, xd = dev(b), torch.zeros(m, dtype=torch.float64, device="cuda")
-    assert P.dtrsv(P.OP_NONE, 1.0, A, d, bd, xd, kid=3) == 0  # analysis + first solve
+    assert P.dtrsv(P.OP_NONE, 1.0, A, d, bd, xd) == 0  # analysis + first solve
     torch.cuda.synchronize()
     lv = A.trsv_levels(P.FILL_LOWER)
     t0 = time.perf_counter()
     for _ in range(20):
-        assert P.dtrsv(P.OP_NONE, 1.0, A, d, bd, xd, kid=3) == 0
+        assert P.dtrsv(P.OP_NONE, 1.0, A, d, bd, xd) == 0
     t_enqueue = time.perf_counter() - t0
     torch.cuda.synchronize()
     t_total = time.perf_counter() - t0

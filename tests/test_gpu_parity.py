@@ -10,8 +10,8 @@ import numpy as np
 import pytest
 
 import oracle
-from util import (EPS32, EPS64, abs_row_sums, banded_rows, laplace5, pkg, powerlaw_rows, random_csr,
-                  triangular_system)
+from util import (EPS32, EPS64, abs_row_sums, banded_rows, kt_lanes, laplace5, pkg, powerlaw_rows, random_csr,
+                  triangular_system, trsv_schedule)
 
 pytestmark = pytest.mark.gpu
 
@@ -384,19 +384,25 @@ def test_large_laplacian_linearity_and_checksum():
 KIND = {("lower", "n"): "l", ("lower", "t"): "lt", ("upper", "n"): "u", ("upper", "t"): "ut"}
 
 
-def oracle_trsv(base, m, rp, ci, v, fill, trans, unit, alpha, b):
+def oracle_trsv(base, m, rp, ci, v, fill, trans, unit, alpha, b, kid=None):
+    """the serial chain the reference runs for this kid: ref_trsv_* for kid 0 / auto (what every GPU schedule reproduces),
+    kt_trsv_* with 4 / 8 lanes for kid 1, 2 / 3 (trsv.cpp:321-353; the transposed KT kernels equal the reference's bits)"""
     o = oracle.dcsr_optimize(m, m, len(v), base, rp, ci, v)
     assert o["status"] == 0
     ilend = o["idiag"] if fill == "lower" else o["iurow"]
-    st, x = oracle.dtrsv(KIND[(fill, trans)], alpha, m, o["base"], o["val"], o["ind"], o["ptr"], ilend, b, unit)
+    lanes = kt_lanes(kid)
+    if lanes:
+        st, x = oracle.trsv_kt(KIND[(fill, trans)], lanes, alpha, m, o["base"], o["val"], o["ind"], o["ptr"], ilend, b, unit)
+    else:
+        st, x = oracle.dtrsv(KIND[(fill, trans)], alpha, m, o["base"], o["val"], o["ind"], o["ptr"], ilend, b, unit)
     assert st == 0
     return x
 
 
 @pytest.mark.parametrize("kid", [None, 0, 1, 3])
 def test_trsv_reference_kats(kats, kid):
-    """D7 / S7 / N25 systems of the reference's unit tests (trsv_tests.cpp:279-318), every schedule,
-    both index bases, triangular and symmetric descriptors, host and device vectors."""
+    """D7 / S7 / N25 systems of the reference's unit tests (trsv_tests.cpp:279-318), every kid (= the arithmetic of the
+    kernel the reference dispatches for it), both index bases, triangular and symmetric descriptors, host and device vectors."""
     tol = kats["trsv_abs_tol"]
     for c in kats["trsv"]:
         for base in (0, 1):
@@ -414,7 +420,7 @@ def test_trsv_reference_kats(kats, kid):
             st = P.dtrsv(op, c["alpha"], A, d, b, x, kid=kid)
             assert st == 0, (c["name"], base, kid, P.STATUS[st])
             assert np.max(np.abs(x - np.array(c["xref"]))) <= tol, (c["name"], base, kid)
-            xr = oracle_trsv(base, m, rp, ci, v, c["fill"], c["trans"], c["unit"], c["alpha"], b)
+            xr = oracle_trsv(base, m, rp, ci, v, c["fill"], c["trans"], c["unit"], c["alpha"], b, kid=kid)
             assert np.array_equal(x, xr), (c["name"], base, kid)
             bd, xd = dev(b), torch.zeros(m, dtype=torch.float64, device="cuda")
             assert P.dtrsv(op, c["alpha"], A, d, bd, xd, kid=kid) == 0
@@ -424,8 +430,10 @@ def test_trsv_reference_kats(kats, kid):
 
 @pytest.mark.parametrize("fill,trans,unit", [("lower", "n", False), ("lower", "n", True), ("lower", "t", False),
                                              ("upper", "n", False), ("upper", "t", True), ("upper", "t", False)])
-@pytest.mark.parametrize("kid", [0, 2])
+@pytest.mark.parametrize("kid", [0, 2, 3])
 def test_trsv_random_bit_exact(fill, trans, unit, kid):
+    """kid 0: ref_trsv_*; kid 2: the 256-bit KT kernel's order; kid 3: the 512-bit one -- bit for bit (rows of up to 12 entries:
+    full vector groups, masked remainders and scalar tails all occur)"""
     m = 20000
     rp, ci, v = triangular_system(51, m, 6, band=300)
     b = np.random.default_rng(5).uniform(-1, 1, m)
@@ -439,8 +447,25 @@ def test_trsv_random_bit_exact(fill, trans, unit, kid):
     bd, xd = dev(b), torch.zeros(m, dtype=torch.float64, device="cuda")
     st = P.dtrsv(op, 1.3, A, d, bd, xd, kid=kid)
     torch.cuda.synchronize()
-    xr = oracle_trsv(0, m, rp, ci, v, fill, trans, unit, 1.3, b)
+    xr = oracle_trsv(0, m, rp, ci, v, fill, trans, unit, 1.3, b, kid=kid)
     assert st == 0 and np.array_equal(xd.cpu().numpy(), xr)
+    if kid == 0:
+        # every schedule returns the chain's bits (the kid picks the arithmetic, the schedule only who computes what when)
+        for sched in (0, 1, 2, 3, 4):
+            with trsv_schedule(P, sched):
+                xd.zero_()
+                assert P.dtrsv(op, 1.3, A, d, bd, xd) == 0
+                torch.cuda.synchronize()
+                assert np.array_equal(xd.cpu().numpy(), xr), sched
+    elif trans == "n":
+        # the KT order is served by the per-level launches and by the lane-per-position sync-free kernel
+        for sched in (0, 2):
+            with trsv_schedule(P, sched):
+                xd.zero_()
+                assert P.dtrsv(op, 1.3, A, d, bd, xd, kid=kid) == 0
+                torch.cuda.synchronize()
+                assert np.array_equal(xd.cpu().numpy(), xr), sched
+        assert not np.array_equal(xr, oracle_trsv(0, m, rp, ci, v, fill, trans, unit, 1.3, b))  # a different summation
 
 
 def test_trsv_unsorted_input_with_missing_diagonals_unit():
@@ -1037,7 +1062,7 @@ def test_trsm_equals_trsv_per_column(order, kid):
         torch.cuda.synchronize()
         assert np.array_equal(Xd.cpu().numpy(), Xm)
         for j in range(n):
-            xr = oracle_trsv(0, m, rp, ci, v, fill, trans, unit, 0.7, cols_b[j])
+            xr = oracle_trsv(0, m, rp, ci, v, fill, trans, unit, 0.7, cols_b[j], kid=kid)
             got = Xm[:, j] if order == P.ORDER_ROW else Xm[j, :m]
             assert np.array_equal(got, xr), (order, kid, fill, j)
         if order == P.ORDER_ROW:
@@ -1709,8 +1734,12 @@ def test_randomised_shapes_spmv_trsv_csrmm(seed):
         for fill, kind, ends in ((P.FILL_LOWER, "l", "idiag"), (P.FILL_UPPER, "u", "iurow")):
             for unit in (False, True):
                 dt = P.Descr(base=base, mtype=P.TYPE_TRIANGULAR, fill=fill, diag=P.DIAG_UNIT if unit else P.DIAG_NON_UNIT)
-                so, xr = oracle.dtrsv(kind, 0.75, m, o["base"], o["val"], o["ind"], o["ptr"], o[ends], b, unit)
                 for kid in (-1, 0, 1, 3):
+                    lanes = kt_lanes(kid)
+                    if lanes:
+                        so, xr = oracle.trsv_kt(kind, lanes, 0.75, m, o["base"], o["val"], o["ind"], o["ptr"], o[ends], b, unit)
+                    else:
+                        so, xr = oracle.dtrsv(kind, 0.75, m, o["base"], o["val"], o["ind"], o["ptr"], o[ends], b, unit)
                     xd = dev(np.zeros(m))
                     assert P.dtrsv(P.OP_NONE, 0.75, T, dt, dev(b), xd, kid=kid) == 0
                     torch.cuda.synchronize()

@@ -109,3 +109,26 @@ class beta0_overwrite:
 
     def __exit__(self, *a):
         assert self.L.aoclsparse_mi355_set_csrmm_beta0_overwrite(0) == 0
+
+
+class trsv_schedule:
+    """with trsv_schedule(P, s): ... -- forces TRSV / TRSM schedule s (0 per-level launches, 1 hybrid, 2 sync-free lane per
+    position, 3 sync-free slice per wavefront, 4 sync-free lane per block) inside the block; -1 (automatic) is restored."""
+
+    def __init__(self, P, s):
+        self.L, self.s = P.lib(), s
+
+    def __enter__(self):
+        assert self.L.aoclsparse_mi355_set_trsv_schedule(self.s) == 0
+
+    def __exit__(self, *a):
+        assert self.L.aoclsparse_mi355_set_trsv_schedule(-1) == 0
+
+
+def kt_lanes(kid, dtype=np.float64):
+    """vector lanes of the KT kernel the reference dispatches for a pinned kid (trsv.cpp:321-353): None for kid 0 / auto"""
+    if kid in (1, 2):
+        return 4 if dtype == np.float64 else 8
+    if kid == 3:
+        return 8 if dtype == np.float64 else 16
+    return None

@@ -147,12 +147,15 @@ if "trsv" in what:
         bdev = torch.from_numpy(bh).to(dev)
         xdev = torch.zeros(m, dtype=torch.float64, device=dev)
         abytes = (m + 1 + nnz_l) * 4 + (2 * m + nnz_l) * 8
-        for kid, nm in ((0, "one launch per level"), (1, "hybrid: narrow level runs in one workgroup"),
-                        (3, "sync-free single launch"), (-1, "auto (kid -1; AOCLSPARSE_MI355_TRSV_SCHEDULE=%s)" % os.environ.get("AOCLSPARSE_MI355_TRSV_SCHEDULE", "unset"))):
-            if kid not in (1, -1) and lv > 100000:
+        for sched, nm in ((0, "one launch per level"), (1, "hybrid: narrow level runs in one workgroup"),
+                          (2, "sync-free, lane per position"), (3, "sync-free, level slice per wavefront"),
+                          (4, "sync-free, lane per block of chained rows (falls back to 3 / 2 without blocks)"), (-1, "automatic")):
+            if sched in (0, 2, 3, 4) and lv > 100000:
                 continue  # hundreds of thousands of launches / hops: minutes
-            reps = 3 if kid != 1 and lv > 500 else 10
-            ms = time_calls(lambda: pkg.dtrsv(pkg.OP_NONE, 1.0, A, dl, bdev, xdev, kid=kid), reps, 1)
+            reps = 3 if sched != 1 and lv > 500 else 10
+            assert L.aoclsparse_mi355_set_trsv_schedule(sched) == 0
+            ms = time_calls(lambda: pkg.dtrsv(pkg.OP_NONE, 1.0, A, dl, bdev, xdev), reps, 1)
+            assert L.aoclsparse_mi355_set_trsv_schedule(-1) == 0
             torch.cuda.synchronize()
             xg = xdev.cpu().numpy()
             emit(kind="trsv", system=title, m=m, nnz_strict_lower=nnz_l, levels=lv, schedule=nm, ms=round(ms, 4),

@@ -28,10 +28,12 @@ for title, gen in cases:
         dl = pkg.Descr(mtype=pkg.TYPE_TRIANGULAR, fill=fill, diag=pkg.DIAG_UNIT if unit else pkg.DIAG_NON_UNIT)
         assert L.aoclsparse_set_sv_hint(A.h, op, dl.h, 100) == 0 and L.aoclsparse_optimize(A.h) == 0
         st, xr = oracle.dtrsv(kind, 1.0, m, 0, lu, ci, rp, iend, b, unit)
-        for kid in (3, -1):
-            lp = timed_laps(pkg, lambda: pkg.dtrsv(op, 1.0, A, dl, bd, xd, kid=kid), 10, 2)
+        for kid in (2, -1):  # schedule: lane per position, automatic
+            assert L.aoclsparse_mi355_set_trsv_schedule(kid) == 0
+            lp = timed_laps(pkg, lambda: pkg.dtrsv(op, 1.0, A, dl, bd, xd), 10, 2)
+            assert L.aoclsparse_mi355_set_trsv_schedule(-1) == 0
             torch.cuda.synchronize()
-            print(json.dumps({"sys": title, "kind": kind, "levels": lv, "kid": kid, "env_sf": os.environ.get("AOCLSPARSE_MI355_TRSV_SYNCFREE"),
+            print(json.dumps({"sys": title, "kind": kind, "levels": lv, "schedule": kid, "env_sf": os.environ.get("AOCLSPARSE_MI355_TRSV_SYNCFREE"),
                               "env_blocks": os.environ.get("AOCLSPARSE_MI355_TRSV_BLOCKS"), "ms_median": float(np.median(lp)),
                               "us_per_level": float(np.median(lp)) * 1e3 / lv,
                               "bit_exact": bool(np.array_equal(xd.cpu().numpy(), xr, equal_nan=True))}), flush=True)

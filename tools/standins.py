@@ -105,7 +105,103 @@ def flan_like(nx=81, ny=80, nz=80, seed=404):
     return _block_csr(nodes, 3, bc, ok, seed)
 
 
-ALL = {"circuit-like": circuit_like, "web-like": web_like, "shell-like": shell_like, "flan-like": flan_like}
+# ---- round 3: the same four, OFF their ideal ordering ------------------------------------------------
+# The mesh stand-ins above are perfectly structured meshes in natural node order -- the best case for shared / shifted column
+# lists and for the supernodal TRSV; the graph stand-ins draw most columns uniformly at random -- harsher than a real circuit
+# or web graph, which have locality.  The variants below move each pair towards what a real SuiteSparse ordering looks like,
+# so that the mix / TRSV legs show how the format tricks degrade (mesh) and what locality buys (graphs).
+def _unstructure(bc, ok, seed, window=256, drop_permille=100):
+    """irregular valence + a random renumbering of the nodes inside windows of `window` consecutive nodes.
+    bc / ok: neighbour block ids (nb x K, any order) and their validity.  A coupling {i, j} is dropped (both directions, never
+    the diagonal) when a symmetric hash of the pair falls below drop_permille / 1000; then node i becomes perm[i], a
+    permutation that shuffles every window.  Returns (bc, ok) with each row's valid neighbours ascending and first."""
+    nb, K = bc.shape
+    i = np.arange(nb, dtype=np.int64)[:, None]
+    lo, hi = np.minimum(i, bc), np.maximum(i, bc)
+    h = (lo * 2654435761 + hi * 40503 + seed) % 1000
+    ok = ok & ((h >= drop_permille) | (bc == i))
+    rng = np.random.default_rng(seed)
+    perm = np.arange(nb, dtype=np.int64)
+    for w0 in range(0, nb, window):
+        w1 = min(nb, w0 + window)
+        perm[w0:w1] = w0 + rng.permutation(w1 - w0)
+    inv = np.argsort(perm)
+    bc2 = perm[np.clip(bc, 0, nb - 1)][inv]
+    ok2 = ok[inv]
+    bc2 = np.where(ok2, bc2, nb + np.arange(K, dtype=np.int64)[None, :])  # invalid ones last, distinct
+    order = np.argsort(bc2, axis=1, kind="stable")
+    return np.take_along_axis(bc2, order, 1), np.take_along_axis(ok2, order, 1)
+
+
+def shell_like_unstructured(n=1508065, seed=313, width=600):
+    """shell-like with ~10 % of the node couplings removed and the nodes renumbered at random inside windows of 256: rows of
+    a node still share one column list (5 dofs), but lists no longer repeat from node to node and valence varies"""
+    nb = n // 5
+    bi = np.arange(nb, dtype=np.int64)
+    j = bi % width
+    offs = np.array([-width - 1, -width, -1, 0, 1, width, width + 1], dtype=np.int64)
+    dj = np.array([-1, 0, -1, 0, 1, 0, 1], dtype=np.int64)
+    bc = bi[:, None] + offs[None, :]
+    ok = (bc >= 0) & (bc < nb) & ((j[:, None] + dj[None, :]) >= 0) & ((j[:, None] + dj[None, :]) < width)
+    bc, ok = _unstructure(bc, ok, seed)
+    return _block_csr(nb, 5, bc, ok, seed)
+
+
+def flan_like_unstructured(nx=81, ny=80, nz=80, seed=414):
+    """flan-like (27-point, 3 dofs) with ~10 % of the couplings removed and windowed random renumbering"""
+    nodes = nx * ny * nz
+    idx = np.arange(nodes, dtype=np.int64)
+    ix, iy, iz = idx // (ny * nz), (idx // nz) % ny, idx % nz
+    bc = np.empty((nodes, 27), dtype=np.int64)
+    ok = np.empty((nodes, 27), dtype=bool)
+    k = 0
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dz in (-1, 0, 1):
+                ok[:, k] = ((ix + dx >= 0) & (ix + dx < nx) & (iy + dy >= 0) & (iy + dy < ny)
+                            & (iz + dz >= 0) & (iz + dz < nz))
+                bc[:, k] = (ix + dx) * (ny * nz) + (iy + dy) * nz + (iz + dz)
+                k += 1
+    bc, ok = _unstructure(bc, ok, seed)
+    return _block_csr(nodes, 3, bc, ok, seed)
+
+
+def circuit_like_local(n=170998, seed=111):
+    """circuit-like with locality: the same power-law row lengths, 80 % of the columns within +-2,000 of the row (a circuit
+    netlist in a reasonable ordering), 20 % anywhere (global nets)"""
+    rng = np.random.default_rng(seed)
+    ln = _powerlaw_lengths(rng, n, 4.7, 353, 1.6)
+    ln[rng.integers(0, n, 3)] = 353
+    rows = np.repeat(np.arange(n), ln)
+    cols = rng.integers(0, n, len(rows))
+    near = rng.random(len(rows)) < 0.8
+    cols[near] = np.clip(rows[near] + rng.integers(-2000, 2001, int(near.sum())), 0, n - 1)
+    rows = np.concatenate([rows, np.arange(n)])
+    cols = np.concatenate([cols, np.arange(n)])
+    return _to_csr(n, rows, cols, seed + 1)
+
+
+def web_like_local(n=1000005, seed=212):
+    """web-like with locality: 70 % of the links inside the page's own "site" (a window of +-5,000 rows: a crawl orders pages
+    host by host), 20 % to Zipf-distributed hubs, 10 % anywhere; same row-length law and the same few rows of ~4,700"""
+    rng = np.random.default_rng(seed)
+    ln = _powerlaw_lengths(rng, n, 2.2, 4700, 1.3)
+    ln[rng.integers(0, n, 4)] = 4700
+    rows = np.repeat(np.arange(n), ln)
+    u = rng.random(len(rows))
+    cols = (rng.zipf(1.3, len(rows)) - 1) % n
+    far = u < 0.1
+    cols[far] = rng.integers(0, n, int(far.sum()))
+    near = u >= 0.3
+    cols[near] = np.clip(rows[near] + rng.integers(-5000, 5001, int(near.sum())), 0, n - 1)
+    rows = np.concatenate([rows, np.arange(n)])
+    cols = np.concatenate([cols, np.arange(n)])
+    return _to_csr(n, rows, cols, seed + 1)
+
+
+ALL = {"circuit-like": circuit_like, "web-like": web_like, "shell-like": shell_like, "flan-like": flan_like,
+       "circuit-like, local": circuit_like_local, "web-like, local": web_like_local,
+       "shell-like, unstructured": shell_like_unstructured, "flan-like, unstructured": flan_like_unstructured}
 
 
 # ---- MatrixMarket input (tests/include/aoclsparse_init.hpp:452-694 reads coordinate real / integer / pattern,
@@ -152,7 +248,7 @@ def load(name):
     seeded stand-in (labelled as such)."""
     import os
     d = os.environ.get("MATRIX_DIR")
-    if d and os.path.isfile(os.path.join(d, REAL_FILES[name])):
+    if d and name in REAL_FILES and os.path.isfile(os.path.join(d, REAL_FILES[name])):
         m, n, rp, ci, v = read_mtx(os.path.join(d, REAL_FILES[name]))
         assert m == n
         return REAL_FILES[name], m, rp, ci, v
