@@ -96,181 +96,7 @@ aoclsparse_status build_mm_groups(const HostCsr &h, SpmvPlan &plan)
     if(st != aoclsparse_status_success)
         return st;
     g.ngroups = ng, g.max_rows = max_rows;
-    g.first_host.swap(first);
     g.valid = true;
-    return aoclsparse_status_success;
-}
-
-// Super-groups: consecutive row groups whose column lists overlap (the nodes of a mesh share most of their
-// neighbours) are merged into one block over the UNION of their columns, so that a wavefront loads every B row of the
-// union once for the whole block instead of once per group.  Only groups of the matrix's DOMINANT size RG (the dofs per
-// node) with a strictly ascending column list are merged -- then walking the union in ascending order visits every row's
-// entries in that row's CSR order (the FMA chain per output element, hence the bits, do not change) and the kernel's
-// loops have compile-time shapes.  A group joins while the block holds fewer than NG = min(4, 16 / RG) groups and
-// CSRMM_SUPER_UNION columns and at least a third of its columns are already in the union.  Values are stored dense per
-// block (rows x padded union, row-major); a union entry a group does not have is skipped through one mask bit per group.
-// Groups of any other shape go to the row-group kernel through a list.  Used when it saves >= 15 % of the B-row loads.
-template <typename T>
-aoclsparse_status build_mm_super(const HostCsr &h, SpmvPlan &plan)
-{
-    MmGroups &g = plan.mm;
-    if(g.super_valid || g.super_tried)
-        return aoclsparse_status_success;
-    g.super_tried = true;
-    // OPT-IN: AOCLSPARSE_MI355_CSRMM_SUPER=1 (read when a handle's csrmm plan is built).  Measured on the MI355X
-    // (profiles/r2/csrmm_super_groups.jsonl), bit-exact in both versions: with one mask bit per ROW and run-time shapes
-    // 2.3-2.8 x slower than the row-group kernel (shell-like 6.32 vs 2.71 ms, flan-like 13.6 vs 4.90 ms at 256 columns: 120
-    // wave-uniform branches per step of 8 union entries against 65 useful FMA pairs); this version (one bit per group,
-    // compile-time shapes) 3.27 vs 2.66 ms and 5.59 vs 4.88 ms -- 40 % fewer B-row loads and still 15-23 % slower, so
-    // L2 -> CU traffic is not what bounds the row-group kernel.  Kept as a tested negative result.
-    const char *env = getenv("AOCLSPARSE_MI355_CSRMM_SUPER");
-    if(!(env && atoi(env) != 0) || !g.valid || g.first_host.size() < 3)
-        return aoclsparse_status_success;
-    const aoclsparse_int        ng = (aoclsparse_int)g.first_host.size() - 1, b = h.base;
-    const aoclsparse_int       *first = g.first_host.data();
-    const T                    *hv = static_cast<const T *>(h.val);
-    // dominant group size among 2, 3, 4, 5, 6, 8 rows
-    long long hist[CSRMM_GROUP + 1] = {0};
-    for(aoclsparse_int gi = 0; gi < ng; gi++)
-        hist[std::min<aoclsparse_int>(first[gi + 1] - first[gi], CSRMM_GROUP)]++;
-    int rg = 0;
-    for(int r : {2, 3, 4, 5, 6, 8})
-        if(hist[r] > (rg ? hist[rg] : 0))
-            rg = r;
-    if(!rg || hist[rg] * 2 < ng)
-        return aoclsparse_status_success;
-    const int                   NG = std::min(4, CSRMM_SUPER_ROWS / rg);
-    std::vector<aoclsparse_int> sg_row, sg_u, ucol, rest;
-    std::vector<long long>      sg_a;
-    std::vector<unsigned int>   umask;
-    std::vector<T>              aval;
-    long long                   loads_super = 0, loads_groups = 0;
-    try
-    {
-        std::vector<aoclsparse_int> U, nu;
-        std::vector<unsigned int>   M, nm;
-        auto cols_of = [&](aoclsparse_int gi, aoclsparse_int &len) {
-            const aoclsparse_int r = first[gi];
-            len                    = h.ptr[r + 1] - h.ptr[r];
-            return h.ind + (h.ptr[r] - b);
-        };
-        auto eligible = [&](aoclsparse_int gi) {
-            aoclsparse_int        len;
-            const aoclsparse_int *c = cols_of(gi, len);
-            if(first[gi + 1] - first[gi] != rg || len == 0 || len > CSRMM_SUPER_UNION)
-                return false;
-            for(aoclsparse_int k = 1; k < len; k++)
-                if(c[k] <= c[k - 1])
-                    return false;
-            return true;
-        };
-        aoclsparse_int i = 0;
-        while(i < ng)
-        {
-            aoclsparse_int        len0;
-            const aoclsparse_int *c0 = cols_of(i, len0);
-            loads_groups += len0;
-            if(!eligible(i))
-            {
-                rest.push_back(i);
-                loads_super += len0;
-                i++;
-                continue;
-            }
-            U.assign(c0, c0 + len0);
-            M.assign((size_t)len0, 1u);
-            int            ngb = 1;
-            aoclsparse_int j   = i + 1;
-            while(j < ng && ngb < NG && eligible(j))
-            {
-                aoclsparse_int        lj;
-                const aoclsparse_int *cj   = cols_of(j, lj);
-                const unsigned        bits = 1u << ngb;
-                nu.clear(), nm.clear();
-                size_t a = 0, c = 0, shared = 0;
-                while(a < U.size() || c < (size_t)lj)
-                {
-                    if(c == (size_t)lj || (a < U.size() && U[a] < cj[c]))
-                        nu.push_back(U[a]), nm.push_back(M[a]), a++;
-                    else if(a == U.size() || cj[c] < U[a])
-                        nu.push_back(cj[c]), nm.push_back(bits), c++;
-                    else
-                        nu.push_back(U[a]), nm.push_back(M[a] | bits), a++, c++, shared++;
-                }
-                if(nu.size() > (size_t)CSRMM_SUPER_UNION || shared * 3 < (size_t)lj)
-                    break;
-                U.swap(nu), M.swap(nm);
-                loads_groups += lj;
-                ngb++, j++;
-            }
-            // emit groups [i, j) = rows [first[i], first[j]) as one block
-            const aoclsparse_int r0 = first[i], nr = first[j] - r0;
-            const size_t         upad = (U.size() + 7) & ~(size_t)7;
-            sg_row.push_back(r0);
-            sg_u.push_back((aoclsparse_int)ucol.size());
-            sg_a.push_back((long long)aval.size());
-            for(size_t k = 0; k < U.size(); k++)
-                ucol.push_back(U[k] - b), umask.push_back(M[k]);
-            const size_t a0 = aval.size();
-            aval.resize(a0 + (size_t)nr * upad, T(0));
-            for(aoclsparse_int q = 0; q < nr; q++)
-            {
-                size_t k = 0;
-                for(aoclsparse_int p = h.ptr[r0 + q] - b; p < h.ptr[r0 + q + 1] - b; p++)
-                {
-                    while(U[k] != h.ind[p])
-                        k++;
-                    aval[a0 + (size_t)q * upad + k] = hv[p];
-                }
-            }
-            loads_super += (long long)U.size();
-            i = j;
-        }
-        // the kernel finds a block's row count from the next block's first row: blocks are NOT contiguous (rest groups
-        // sit between them), so every block gets an explicit end through a parallel array: sg_row holds 2 entries per block
-        // -> keep it simple: store first row and row count interleaved
-        std::vector<aoclsparse_int> rows2(2 * sg_row.size());
-        // (filled below once the per-block row counts are known)
-        for(size_t t = 0; t < sg_row.size(); t++)
-            rows2[2 * t] = sg_row[t];
-        // row counts: from the dense value offsets (rows x upad) and the union sizes
-        sg_u.push_back((aoclsparse_int)ucol.size());
-        sg_a.push_back((long long)aval.size());
-        for(size_t t = 0; t + 1 < sg_u.size(); t++)
-        {
-            const size_t upad = ((size_t)(sg_u[t + 1] - sg_u[t]) + 7) & ~(size_t)7;
-            rows2[2 * t + 1]  = (aoclsparse_int)((sg_a[t + 1] - sg_a[t]) / (long long)upad);
-        }
-        sg_row.swap(rows2);
-        for(int k = 0; k < 8; k++) // slack: the kernel reads masks / columns in batches of 8
-            ucol.push_back(0), umask.push_back(0);
-    }
-    catch(const std::bad_alloc &)
-    {
-        return aoclsparse_status_memory_error;
-    }
-    if(sg_u.size() < 2 || loads_super * 100 > loads_groups * 85)
-        return aoclsparse_status_success; // not enough sharing between neighbouring groups
-    hipStream_t       st = Runtime::get().stream();
-    aoclsparse_status rc = g.sg_row.upload(sg_row.data(), sizeof(aoclsparse_int) * sg_row.size(), st);
-    if(rc == aoclsparse_status_success)
-        rc = g.sg_u.upload(sg_u.data(), sizeof(aoclsparse_int) * sg_u.size(), st);
-    if(rc == aoclsparse_status_success)
-        rc = g.sg_a.upload(sg_a.data(), sizeof(long long) * sg_a.size(), st);
-    if(rc == aoclsparse_status_success)
-        rc = g.ucol.upload(ucol.data(), sizeof(aoclsparse_int) * ucol.size(), st);
-    if(rc == aoclsparse_status_success)
-        rc = g.umask.upload(umask.data(), sizeof(unsigned int) * umask.size(), st);
-    if(rc == aoclsparse_status_success)
-        rc = g.aval.upload(aval.data(), sizeof(T) * std::max<size_t>(aval.size(), 1), st);
-    if(rc == aoclsparse_status_success && !rest.empty())
-        rc = g.rest.upload(rest.data(), sizeof(aoclsparse_int) * rest.size(), st);
-    if(rc != aoclsparse_status_success)
-        return rc;
-    g.nsuper      = (aoclsparse_int)sg_u.size() - 1;
-    g.nrest       = (aoclsparse_int)rest.size();
-    g.super_rg    = rg;
-    g.super_valid = true;
     return aoclsparse_status_success;
 }
 
@@ -559,13 +385,6 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
         if(st != aoclsparse_status_success)
             return st;
     }
-    if(p && (!colmaj || detour) && p->mm.valid && !p->mm.super_tried && n >= 128)
-    {
-        std::unique_lock<std::shared_mutex> w(A->guard);
-        st = build_mm_super<T>(tr ? *A->trans : A->user, *p);
-        if(st != aoclsparse_status_success)
-            return st;
-    }
     if(p && !colmaj && !p->mm.valid && !p->mm.runs_tried && n >= 128)
     {
         std::unique_lock<std::shared_mutex> w(A->guard);
@@ -587,26 +406,13 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
         const bool                          grouped = p && p->mm.valid;
         const aoclsparse_int               *grp = grouped ? p->mm.first.as<aoclsparse_int>() : nullptr;
         const aoclsparse_int                ngrp = grouped ? p->mm.ngroups : 0;
-        // super-groups (row groups merged over the union of their columns): vectorisable row-major operands, n >= 128
-        auto use_super = [&](const T *Bp, const T *Cp, aoclsparse_int lb, aoclsparse_int lc) {
-            return grouped && p->mm.super_valid && n >= 128 && n % 2 == 0 && lb % 2 == 0 && lc % 2 == 0
-                   && reinterpret_cast<uintptr_t>(Bp) % (2 * sizeof(T)) == 0 && reinterpret_cast<uintptr_t>(Cp) % (2 * sizeof(T)) == 0;
-        };
-        auto run_super = [&](const T *Bp, aoclsparse_int lb, T *Cp, aoclsparse_int lc) {
-            const MmGroups &g = p->mm;
-            return launch_csrmm_super<T>(rt.stream(), d->base, alpha, g.nsuper, g.super_rg, g.sg_row.as<aoclsparse_int>(),
-                                         g.sg_u.as<aoclsparse_int>(), g.sg_a.as<long long>(), g.ucol.as<aoclsparse_int>(),
-                                         g.umask.as<unsigned int>(), g.aval.as<T>(), g.nrest, g.rest.as<aoclsparse_int>(), grp,
-                                         d->val.as<T>(), d->ind.as<aoclsparse_int>(), d->ptr.as<aoclsparse_int>(), Bp, n, lb,
-                                         beta, Cp, lc);
-        };
         if(detour)
         {
             void *bt = nullptr, *ct = nullptr;
             st = rt.staging(5, sizeof(T) * (size_t)b_rows * (size_t)n, &bt);
             // handles with row groups: only B changes layout; the row-group kernel writes (and, beta != 0, reads) the caller's
             // column-major C in place -- two of the detour's three copy passes gone (shell-like, 256 columns: 6.6 -> see DESIGN)
-            const bool direct = st == aoclsparse_status_success && grouped && !(p->mm.super_valid && n >= 128)
+            const bool direct = st == aoclsparse_status_success && grouped
                                 && csrmm_groups_ccol_applies<T>(n, n, static_cast<const T *>(bt));
             if(direct)
             {
@@ -623,17 +429,13 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
                 st = launch_relayout<T>(rt.stream(), true, static_cast<const T *>(dB), static_cast<T *>(bt), b_rows, n, ldb);
             if(st == aoclsparse_status_success)
                 st = launch_relayout<T>(rt.stream(), true, static_cast<const T *>(dC), static_cast<T *>(ct), m_c, n, ldc);
-            if(st == aoclsparse_status_success && use_super(static_cast<const T *>(bt), static_cast<const T *>(ct), n, n))
-                st = run_super(static_cast<const T *>(bt), n, static_cast<T *>(ct), n);
-            else if(st == aoclsparse_status_success)
+            if(st == aoclsparse_status_success)
                 st = launch_csrmm<T>(rt.stream(), aoclsparse_order_row, d->base, alpha, d->m, d->n, d->val.as<T>(),
                                      d->ind.as<aoclsparse_int>(), d->ptr.as<aoclsparse_int>(), static_cast<const T *>(bt),
                                      n, n, beta, static_cast<T *>(ct), n, grp, ngrp, grouped ? p->mm.max_rows : 0);
             if(st == aoclsparse_status_success)
                 st = launch_relayout<T>(rt.stream(), false, static_cast<const T *>(ct), static_cast<T *>(dC), m_c, n, ldc);
         }
-        else if(!colmaj && use_super(static_cast<const T *>(dB), static_cast<const T *>(dC), ldb, ldc))
-            st = run_super(static_cast<const T *>(dB), ldb, static_cast<T *>(dC), ldc);
         else if(!colmaj && !grouped && p && p->valid && p->nblocks > 0
                 && csrmm_tiled_applies<T>(n, ldb, ldc, static_cast<const T *>(dB), static_cast<const T *>(dC)))
             // narrow row-major operands (a multi-GPU column slab): row blocks of the SpMV plan, A staged in LDS

@@ -327,106 +327,8 @@ __global__ __launch_bounds__(256) void csrmm_row_run_kernel(int base, T alpha, a
 // idea without the padding: a group IS a dense r x L block of A, read in place from the CSR arrays (row ii's k-th
 // entry sits at row_ptr[ii] + k for every row of the group).  Per output element the FMA chain is still the row in
 // CSR order, so the result equals the other kernels' bit for bit.  Groups are found once per handle on the host
-// (csrmm_api.cpp: build_mm_groups) and capped at CSRMM_GROUP rows.
-template <typename T, int GR>
-__global__ __launch_bounds__(256) void csrmm_rowgroup_kernel(int base, T alpha, aoclsparse_int ngroups,
-                                                             const aoclsparse_int *__restrict__ grp,
-                                                             const T *__restrict__ val,
-                                                             const aoclsparse_int *__restrict__ col,
-                                                             const aoclsparse_int *__restrict__ row_ptr,
-                                                             const T *__restrict__ B, aoclsparse_int n, aoclsparse_int ldb,
-                                                             T beta, T *__restrict__ C, aoclsparse_int ldc, bool readc,
-                                                             int xcd_chunk, const aoclsparse_int *__restrict__ glist)
-{
-    // glist != nullptr: the `ngroups` entries of glist are the groups to compute (those the super-group kernel left)
-    using V      = typename vec2<T>::type;
-    const int w  = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const int gt = bx * 4 + w;
-    const int j  = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
-    if(gt >= ngroups || j >= n)
-        return;
-    const int gi = glist ? glist[gt] : gt;
-    const int i0 = grp[gi], r = grp[gi + 1] - i0; // 1 <= r <= GR
-    const int s0 = row_ptr[i0] - base, len = row_ptr[i0 + 1] - base - s0;
-    int       so[GR]; // start of every row of the group (wave-uniform)
-#pragma unroll
-    for(int q = 0; q < GR; q++)
-        so[q] = q < r ? row_ptr[i0 + q] - base : s0;
-    T acc0[GR], acc1[GR];
-#pragma unroll
-    for(int q = 0; q < GR; q++)
-        acc0[q] = T(0), acc1[q] = T(0);
-    const T *Bj = B + j;
-    int      k  = 0;
-    for(; k + 8 <= len; k += 8) // eight B rows in flight per step
-    {
-        V b[8];
-#pragma unroll
-        for(int u = 0; u < 8; u++)
-            b[u] = *reinterpret_cast<const V *>(Bj + (size_t)(col[s0 + k + u] - base) * ldb);
-#pragma unroll
-        for(int q = 0; q < GR; q++)
-            if(q < r)
-            {
-                T a[8];
-#pragma unroll
-                for(int u = 0; u < 8; u++)
-                    a[u] = val[so[q] + k + u];
-#pragma unroll
-                for(int u = 0; u < 8; u++)
-                    acc0[q] = mm_fma(a[u], b[u].x, acc0[q]), acc1[q] = mm_fma(a[u], b[u].y, acc1[q]);
-            }
-    }
-    for(; k + 4 <= len; k += 4) // four B rows in flight per step
-    {
-        V b[4];
-#pragma unroll
-        for(int u = 0; u < 4; u++)
-            b[u] = *reinterpret_cast<const V *>(Bj + (size_t)(col[s0 + k + u] - base) * ldb);
-#pragma unroll
-        for(int q = 0; q < GR; q++)
-            if(q < r)
-            {
-                T a[4];
-#pragma unroll
-                for(int u = 0; u < 4; u++)
-                    a[u] = val[so[q] + k + u];
-#pragma unroll
-                for(int u = 0; u < 4; u++)
-                    acc0[q] = mm_fma(a[u], b[u].x, acc0[q]), acc1[q] = mm_fma(a[u], b[u].y, acc1[q]);
-            }
-    }
-    for(; k < len; k++)
-    {
-        const V b0 = *reinterpret_cast<const V *>(Bj + (size_t)(col[s0 + k] - base) * ldb);
-#pragma unroll
-        for(int q = 0; q < GR; q++)
-            if(q < r)
-            {
-                const T a0 = val[so[q] + k];
-                acc0[q] = mm_fma(a0, b0.x, acc0[q]), acc1[q] = mm_fma(a0, b0.y, acc1[q]);
-            }
-    }
-#pragma unroll
-    for(int q = 0; q < GR; q++)
-        if(q < r)
-        {
-            V      *cp = reinterpret_cast<V *>(C + (size_t)(i0 + q) * ldc + j);
-            const T z0 = alpha * acc0[q], z1 = alpha * acc1[q];
-            V       c;
-            if(readc || z0 == T(0) || z1 == T(0))
-            {
-                c   = *cp;
-                c.x = mm_fma(beta, c.x, z0);
-                c.y = mm_fma(beta, c.y, z1);
-            }
-            else
-                c.x = z0, c.y = z1;
-            *cp = c;
-        }
-}
-
+// (csrmm_api.cpp: build_mm_groups) and capped at CSRMM_GROUP rows.  (The first version of this kernel, which the one below
+// replaced at 2.76 -> 2.15 ms on the shell-like stand-in, was removed in round 3: profiles/r2/csrmm_rowgroup_v2.jsonl.)
 // Second version of the row-group kernel (n >= 128), written after reading the first one's ISA: there, every 8-entry step
 // was SIX scalar-load round trips one after the other (the column indices, then -- inside a wave-uniform branch per row --
 // each row's eight values, waited for before that row's FMAs) and the B-row loads of step k + 1 were not issued before
@@ -604,97 +506,6 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup2_kernel(int base, T alpha,
                 o.y       = need ? mm_fma(beta, c.y, z1) : z1;
             }
             __builtin_nontemporal_store(o, reinterpret_cast<nt2 *>(cp));
-        }
-}
-
-// row-major, n >= 128, SUPER-GROUPS: a wavefront owns (block, 128-column chunk), where a block is a run of up to NG row
-// groups of exactly RG rows each, merged over the UNION of their column lists (csrmm_api.cpp: build_mm_super).  Every B row
-// of the union is loaded ONCE for up to NG*RG output rows -- the neighbouring nodes of a mesh share most of their neighbours,
-// so the L2 -> CU traffic that bounds csrmm_rowgroup_kernel on matrices with tens of non-zeros per row drops again
-// (shell-like: 7 -> ~3.5 B rows per output row).  Values come from the block's dense rows x union array through the scalar
-// cache; a union entry a GROUP does not have is skipped by one wave-uniform test per (group, entry) -- never multiplied, so
-// NaN / Inf in B reach only the rows that reference them.  The union is walked in ascending column order = every row's CSR
-// order (the builder merges only groups with ascending lists), so the FMA chain per output element is unchanged.
-template <typename T, int RG, int NG>
-__global__ __launch_bounds__(256) void csrmm_supergroup_kernel(T alpha, aoclsparse_int nsuper,
-                                                               const aoclsparse_int *__restrict__ sg_row,
-                                                               const aoclsparse_int *__restrict__ sg_u,
-                                                               const long long *__restrict__ sg_a,
-                                                               const aoclsparse_int *__restrict__ ucol,
-                                                               const unsigned int *__restrict__ umask,
-                                                               const T *__restrict__ aval, const T *__restrict__ B,
-                                                               aoclsparse_int n, aoclsparse_int ldb, T beta,
-                                                               T *__restrict__ C, aoclsparse_int ldc, bool readc,
-                                                               int xcd_chunk)
-{
-    using V      = typename vec2<T>::type;
-    const int w  = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const int sg = bx * 4 + w;
-    const int j  = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
-    if(sg >= nsuper || j >= n)
-        return;
-    const int i0 = sg_row[2 * sg], ngb = sg_row[2 * sg + 1] / RG; // {first row, rows}: groups in this block, 1 <= ngb <= NG
-    const int u0 = sg_u[sg], U = sg_u[sg + 1] - u0;
-    const int upad = (U + 7) & ~7;
-    const T  *ab = aval + sg_a[sg];
-    T         acc0[NG * RG], acc1[NG * RG];
-#pragma unroll
-    for(int q = 0; q < NG * RG; q++)
-        acc0[q] = T(0), acc1[q] = T(0);
-    const T *Bj = B + j;
-    for(int k = 0; k < U; k += 8)
-    {
-        int          c[8];
-        unsigned int mk[8];
-#pragma unroll
-        for(int u = 0; u < 8; u++)
-        {
-            c[u]  = ucol[u0 + k + u]; // 8 entries of slack behind the last block
-            mk[u] = k + u < U ? umask[u0 + k + u] : 0u;
-        }
-        V b[8];
-#pragma unroll
-        for(int u = 0; u < 8; u++)
-            if(mk[u])
-                b[u] = *reinterpret_cast<const V *>(Bj + (size_t)c[u] * ldb);
-#pragma unroll
-        for(int gi = 0; gi < NG; gi++)
-            if(gi < ngb)
-            {
-                T a[RG][8];
-#pragma unroll
-                for(int qq = 0; qq < RG; qq++)
-#pragma unroll
-                    for(int u = 0; u < 8; u++)
-                        a[qq][u] = ab[(size_t)(gi * RG + qq) * upad + k + u];
-#pragma unroll
-                for(int u = 0; u < 8; u++)
-                    if((mk[u] >> gi) & 1u)
-                    {
-#pragma unroll
-                        for(int qq = 0; qq < RG; qq++)
-                            acc0[gi * RG + qq] = mm_fma(a[qq][u], b[u].x, acc0[gi * RG + qq]),
-                                           acc1[gi * RG + qq] = mm_fma(a[qq][u], b[u].y, acc1[gi * RG + qq]);
-                    }
-            }
-    }
-#pragma unroll
-    for(int q = 0; q < NG * RG; q++)
-        if(q < ngb * RG)
-        {
-            V      *cp = reinterpret_cast<V *>(C + (size_t)(i0 + q) * ldc + j);
-            const T z0 = alpha * acc0[q], z1 = alpha * acc1[q];
-            V       cc;
-            if(readc || z0 == T(0) || z1 == T(0))
-            {
-                cc   = *cp;
-                cc.x = mm_fma(beta, cc.x, z0);
-                cc.y = mm_fma(beta, cc.y, z1);
-            }
-            else
-                cc.x = z0, cc.y = z1;
-            *cp = cc;
         }
 }
 
@@ -1383,14 +1194,7 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
             // accumulators are sized by the largest group the matrix actually has (2, 4 or 8 rows)
             auto go = [&](auto gr_tag) {
                 constexpr int GR = decltype(gr_tag)::value;
-                if(n >= 128)
-                {
-                    const int gx = grid_x((ngroups + 3) / 4, chunk);
-                    hipLaunchKernelGGL((csrmm_rowgroup_kernel<T, GR>), dim3(gx, (n + 127) / 128), dim3(256), 0, s, base, alpha,
-                                       ngroups, grp, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk,
-                                       (const aoclsparse_int *)nullptr);
-                }
-                else if(n >= 64)
+                if(n >= 64)
                 {
                     const int gx = grid_x((ngroups + 7) / 8, chunk);
                     hipLaunchKernelGGL((csrmm_rowgroup_sub_kernel<T, 32, GR>), dim3(gx, (n + 63) / 64), dim3(256), 0, s, base,
@@ -1403,10 +1207,6 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
                                        alpha, ngroups, grp, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk);
                 }
             };
-            static const bool rg2 = [] {
-                const char *e = getenv("AOCLSPARSE_MI355_CSRMM_RG2");
-                return e ? atoi(e) != 0 : true;
-            }();
             auto go2 = [&](auto gr_tag) {
                 constexpr int GR = decltype(gr_tag)::value;
                 const int     gx = grid_x((ngroups + 3) / 4, chunk);
@@ -1414,7 +1214,7 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
                                    ngroups, grp, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk,
                                    (const aoclsparse_int *)nullptr);
             };
-            if(rg2 && n >= 128)
+            if(n >= 128)
             {
                 switch(group_rows)
                 {
@@ -1441,10 +1241,9 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
             // the 128-column chunks of a row block run together (chunk = fastest index inside an XCD) rather than one chunk
             // of every block, then the next: same time at 256 columns, 1.64 vs 1.77 ms at 512 (A is read once, the chunks
             // of a B row come in together).  Only in strip order: in plain row order it doubles the bytes between two
-            // touches of a B row (1.08 vs 0.88 ms, FETCH 5.8 vs 3.7 GB).  AOCLSPARSE_MI355_CSRMM_YFAST=0: the 2-D grid.
-            static const bool yfast = [] { const char *e = getenv("AOCLSPARSE_MI355_CSRMM_YFAST"); return !e || atoi(e) != 0; }();
+            // touches of a B row (1.08 vs 0.88 ms, FETCH 5.8 vs 3.7 GB).
             const int ny = (n + 127) / 128;
-            if(yfast && run_order && chunk > 0 && (long long)gx * ny < (1LL << 31))
+            if(run_order && chunk > 0 && (long long)gx * ny < (1LL << 31))
                 hipLaunchKernelGGL((csrmm_row_run_kernel<T, RUN>), dim3(gx * ny, 1), dim3(256), 0, s, base, alpha, m, val, col,
                                    row_ptr, B, n, ldb, beta, C, ldc, readc, chunk, run_order, ny);
             else
@@ -1680,50 +1479,6 @@ aoclsparse_status launch_csrmm_colpair(hipStream_t s, int base, T alpha, aoclspa
     return aoclsparse_status_success;
 }
 
-template <typename T>
-aoclsparse_status launch_csrmm_super(hipStream_t s, int base, T alpha, aoclsparse_int nsuper, int rg,
-                                     const aoclsparse_int *sg_row, const aoclsparse_int *sg_u, const long long *sg_a,
-                                     const aoclsparse_int *ucol, const unsigned int *umask, const T *aval,
-                                     aoclsparse_int nrest, const aoclsparse_int *rest, const aoclsparse_int *grp,
-                                     const T *val, const aoclsparse_int *col, const aoclsparse_int *row_ptr, const T *B,
-                                     aoclsparse_int n, aoclsparse_int ldb, T beta, T *C, aoclsparse_int ldc)
-{
-    if(n <= 0)
-        return aoclsparse_status_success;
-    const bool readc = csrmm_reads_c(beta != T(0));
-    const dim3 block(256);
-    if(nsuper > 0)
-    {
-        const int  nbx = (nsuper + 3) / 4, chunk = (nbx + 7) / 8;
-        const dim3 grid(chunk * 8, (n + 127) / 128);
-        auto       go = [&](auto rg_tag, auto ng_tag) {
-            constexpr int RG = decltype(rg_tag)::value, NG = decltype(ng_tag)::value;
-            hipLaunchKernelGGL((csrmm_supergroup_kernel<T, RG, NG>), grid, block, 0, s, alpha, nsuper, sg_row, sg_u, sg_a, ucol,
-                               umask, aval, B, n, ldb, beta, C, ldc, readc, chunk);
-        };
-        using std::integral_constant;
-        switch(rg)
-        {
-        case 2: go(integral_constant<int, 2>{}, integral_constant<int, 4>{}); break;
-        case 3: go(integral_constant<int, 3>{}, integral_constant<int, 4>{}); break;
-        case 4: go(integral_constant<int, 4>{}, integral_constant<int, 4>{}); break;
-        case 5: go(integral_constant<int, 5>{}, integral_constant<int, 3>{}); break;
-        case 6: go(integral_constant<int, 6>{}, integral_constant<int, 2>{}); break;
-        case 8: go(integral_constant<int, 8>{}, integral_constant<int, 2>{}); break;
-        default: return aoclsparse_status_internal_error;
-        }
-    }
-    if(nrest > 0)
-    {
-        // groups the builder left alone (other row counts, unsorted lists): the row-group kernel on a group list
-        const int nbx = (nrest + 3) / 4, chunk = (nbx + 7) / 8;
-        hipLaunchKernelGGL((csrmm_rowgroup_kernel<T, CSRMM_GROUP>), dim3(chunk * 8, (n + 127) / 128), block, 0, s, base, alpha,
-                           nrest, grp, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk, rest);
-    }
-    MI355_HIP_TRY(hipGetLastError());
-    return aoclsparse_status_success;
-}
-
 #define MI355_INST_MM(T)                                                                                     \
     template aoclsparse_status launch_csrmm<T>(hipStream_t, aoclsparse_order, int, T, aoclsparse_int,        \
                                                aoclsparse_int, const T *, const aoclsparse_int *,             \
@@ -1738,13 +1493,6 @@ aoclsparse_status launch_csrmm_super(hipStream_t s, int base, T alpha, aoclspars
                                                        aoclsparse_int, const aoclsparse_int *, const T *,      \
                                                        const aoclsparse_int *, const aoclsparse_int *, aoclsparse_int, const T *, \
                                                        aoclsparse_int, aoclsparse_int, T, T *, aoclsparse_int); \
-    template aoclsparse_status launch_csrmm_super<T>(hipStream_t, int, T, aoclsparse_int, int, const aoclsparse_int *, \
-                                                     const aoclsparse_int *, const long long *,                \
-                                                     const aoclsparse_int *, const unsigned int *, const T *,  \
-                                                     aoclsparse_int, const aoclsparse_int *,                   \
-                                                     const aoclsparse_int *, const T *, const aoclsparse_int *, \
-                                                     const aoclsparse_int *, const T *, aoclsparse_int,        \
-                                                     aoclsparse_int, T, T *, aoclsparse_int);                  \
     template bool csrmm_tiled_applies<T>(aoclsparse_int, aoclsparse_int, aoclsparse_int, const T *, const T *); \
     template bool csrmm_groups_ccol_applies<T>(aoclsparse_int, aoclsparse_int, const T *);                     \
     template aoclsparse_status launch_csrmm_groups_ccol<T>(hipStream_t, int, T, const T *, const aoclsparse_int *, \

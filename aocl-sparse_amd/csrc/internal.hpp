@@ -284,26 +284,13 @@ struct MmGroups
     aoclsparse_int ngroups = 0;
     int            max_rows = 0; // rows of the largest group
     DeviceBuffer   first; // ngroups + 1 row indices
-    std::vector<aoclsparse_int> first_host; // the same on the host (input of the super-group builder)
     bool           valid = false, tried = false;
     // column-major csrmm: row pairs (2r, 2r+1) where row 2r+1 carries row 2r's pattern shifted by one column (scalar
     // stencils, banded matrices) and both fit the register cache -- csrmm_colpair_kernel serves them with 16-byte loads
     bool           pairs_tried = false, pairs = false;
     aoclsparse_int npairs = 0, nsingles = 0;
     DeviceBuffer   pair_first, single_rows; // first row of every pair; rows without a partner
-    // row-major csrmm, SUPER-GROUPS (csrmm_supergroup_kernel): runs of consecutive row groups (<= CSRMM_SUPER_ROWS rows)
-    // whose column lists overlap (neighbouring nodes of a mesh), stored as one block over the UNION of their columns:
-    // sg_row[s] first row, sg_u[s] first union entry, ucol / umask per union entry (bit q: row sg_row+q has it),
-    // sg_a[s] offset of the dense rows x union value block (row-major, absent entries never read into a result).
-    // Holds VALUES, so it is rebuilt after ?set_value / ?update_values (super_valid reset by drop_derived_state).
-    bool           super_tried = false, super_valid = false;
-    aoclsparse_int nsuper = 0, nrest = 0;
-    int            super_rg = 0; // rows per group inside the blocks (the matrix's dominant group size)
-    DeviceBuffer   sg_row, sg_u, sg_a, ucol, umask, aval;
-    DeviceBuffer   rest; // groups left to the row-group kernel (other row counts, unsorted column lists)
 };
-constexpr int CSRMM_SUPER_ROWS  = 16; // rows per super-group at most (mask width, accumulator registers)
-constexpr int CSRMM_SUPER_UNION = 160; // union columns per super-group at most
 
 // merge-path tiling of a device CSR (mergepath_kernels.hip): tile w starts at {row ends, non-zeros} =
 // starts[2w], starts[2w+1]; two carry records per tile
@@ -515,10 +502,8 @@ public:
     char name[256] = {0};
     // scratch staging buffers for host-pointer calls (grown on demand, reused)
     aoclsparse_status staging(int slot, size_t bytes, void **out);
-    // Host <-> device copies of PAGEABLE caller memory on the library's stream.  Large transfers are pipelined through
-    // a ring of pinned buffers: worker threads copy chunk i+1 into pinned memory while the DMA engine moves chunk i, so
-    // the link runs near its rate instead of the ~20 GB/s of a plain pageable hipMemcpy (runtime.cpp).  h2d returns once
-    // every chunk is enqueued (stream order holds for what follows); d2h returns when the bytes are in `host`.
+    // Host <-> device copies of PAGEABLE caller memory on the library's stream (plain stream-ordered copies: the runtime's own
+    // staging runs at 56 GB/s on these boxes; h2d returns once enqueued, d2h likewise -- callers synchronise the stream)
     aoclsparse_status h2d(void *dev, const void *host, size_t bytes);
     aoclsparse_status d2h(void *host, const void *dev, size_t bytes);
     hipEvent_t        ev0 = nullptr, ev1 = nullptr;
@@ -830,14 +815,6 @@ aoclsparse_status launch_csrmm_tiled(hipStream_t s, int base, T alpha, const T *
                                      const aoclsparse_int *row_ptr, const aoclsparse_int *blocks, aoclsparse_int nblocks,
                                      int tile, aoclsparse_int max_row_nnz, const T *B, aoclsparse_int n, aoclsparse_int ldb,
                                      T beta, T *C, aoclsparse_int ldc);
-// row-major, n >= 128: one wavefront per (super-group, 128-column chunk) -- every B row of the union loaded once
-template <typename T>
-aoclsparse_status launch_csrmm_super(hipStream_t s, int base, T alpha, aoclsparse_int nsuper, int rg,
-                                     const aoclsparse_int *sg_row, const aoclsparse_int *sg_u, const long long *sg_a,
-                                     const aoclsparse_int *ucol, const unsigned int *umask, const T *aval,
-                                     aoclsparse_int nrest, const aoclsparse_int *rest, const aoclsparse_int *grp,
-                                     const T *val, const aoclsparse_int *col, const aoclsparse_int *row_ptr, const T *B,
-                                     aoclsparse_int n, aoclsparse_int ldb, T beta, T *C, aoclsparse_int ldc);
 // column-major: a lane owns a row PAIR; 16-byte loads where the second row is the first shifted by one column
 template <typename T>
 aoclsparse_status launch_csrmm_colpair(hipStream_t s, int base, T alpha, aoclsparse_int npairs,

@@ -277,222 +277,20 @@ aoclsparse_status Runtime::staging(int slot, size_t bytes, void **out)
     return st;
 }
 
-// ---- pipelined pageable <-> device copies -------------------------------------------------------------------------
-// Opt-in (AOCLSPARSE_MI355_PIPELINED_COPY=1).  Round 1 read the 58.8 ms of a one-shot host-array csrmv on the 4096^2
-// Laplacian as a 20 GB/s copy; the probe of round 2 (tools/h2d_probe.hip) shows the copy itself at 56 GB/s -- the time
-// was host-side plan construction (matrix.cpp: build_spmv_plan, now parallel).  The ring stays for hosts whose runtime
-// stages pageable memory with one thread: a small pool copies chunk i+1 into a pinned slot while the DMA drains chunk i.
-namespace
-{
-constexpr size_t PIPE_CHUNK = 16u << 20; // bytes per ring slot
-constexpr int    PIPE_SLOTS = 3;
-constexpr size_t PIPE_MIN   = 8u << 20; // below this a plain copy is as fast
-
-class CopyPool
-{
-public:
-    static CopyPool &get()
-    {
-        static CopyPool p;
-        return p;
-    }
-    // dst[0, bytes) = src[0, bytes), split over the workers and the calling thread
-    void run(void *dst, const void *src, size_t bytes)
-    {
-        if(workers_.empty() || bytes < (1u << 20))
-        {
-            std::memcpy(dst, src, bytes);
-            return;
-        }
-        const int parts = (int)workers_.size() + 1;
-        {
-            std::lock_guard<std::mutex> g(mu_);
-            dst_ = static_cast<char *>(dst), src_ = static_cast<const char *>(src), bytes_ = bytes;
-            pending_ = (int)workers_.size();
-            gen_++;
-        }
-        cv_job_.notify_all();
-        slice(parts - 1, parts); // the caller takes the last slice
-        std::unique_lock<std::mutex> l(mu_);
-        cv_done_.wait(l, [&] { return pending_ == 0; });
-    }
-
-private:
-    CopyPool()
-    {
-        int       n = 1;
-        cpu_set_t set;
-        if(sched_getaffinity(0, sizeof(set), &set) == 0)
-            n = CPU_COUNT(&set);
-        if(const char *e = std::getenv("AOCLSPARSE_MI355_COPY_THREADS"))
-            n = std::atoi(e);
-        n = n > 8 ? 8 : n; // 8 threads saturate the link; more only fight the caller's own threads
-        for(int t = 0; t + 1 < n; t++)
-            workers_.emplace_back([this, t] { loop(t); });
-    }
-    ~CopyPool()
-    {
-        {
-            std::lock_guard<std::mutex> g(mu_);
-            stop_ = true;
-        }
-        cv_job_.notify_all();
-        for(auto &w : workers_)
-            w.join();
-    }
-    void slice(int part, int parts)
-    {
-        const size_t per = ((bytes_ + parts - 1) / parts + 63) & ~(size_t)63;
-        const size_t lo = per * (size_t)part, hi = lo + per < bytes_ ? lo + per : bytes_;
-        if(lo < hi)
-            std::memcpy(dst_ + lo, src_ + lo, hi - lo);
-    }
-    void loop(int id)
-    {
-        int seen = 0;
-        for(;;)
-        {
-            std::unique_lock<std::mutex> l(mu_);
-            cv_job_.wait(l, [&] { return stop_ || gen_ != seen; });
-            if(stop_)
-                return;
-            seen = gen_;
-            l.unlock();
-            slice(id, (int)workers_.size() + 1);
-            l.lock();
-            if(--pending_ == 0)
-                cv_done_.notify_one();
-        }
-    }
-    std::vector<std::thread> workers_;
-    std::mutex               mu_;
-    std::condition_variable  cv_job_, cv_done_;
-    char                    *dst_ = nullptr;
-    const char              *src_ = nullptr;
-    size_t                   bytes_ = 0;
-    int                      gen_ = 0, pending_ = 0;
-    bool                     stop_ = false;
-};
-
-struct PinnedRing
-{
-    void      *slot[PIPE_SLOTS] = {nullptr};
-    hipEvent_t done[PIPE_SLOTS] = {nullptr};
-    bool       busy[PIPE_SLOTS] = {false}; // an event was recorded for a DMA that reads / writes this slot
-    bool       ok = false, tried = false;
-    std::mutex lock; // one pipelined transfer at a time
-    bool       ensure()
-    {
-        if(tried)
-            return ok;
-        tried = true;
-        for(int i = 0; i < PIPE_SLOTS; i++)
-            if(hipHostMalloc(&slot[i], PIPE_CHUNK, hipHostMallocDefault) != hipSuccess
-               || hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess)
-            {
-                (void)hipGetLastError();
-                return false;
-            }
-        ok = true;
-        return true;
-    }
-};
-PinnedRing g_ring;
-} // namespace
-
+// ---- pageable <-> device copies -----------------------------------------------------------------------------------------
+// Plain stream-ordered copies.  A hand-made pipeline through a ring of pinned slots (round 2) measured SLOWER than the ROCm
+// runtime's own staging of pageable memory (51-54 vs 56 GB/s, profiles/r2/h2d_probe.jsonl) and was removed in round 3.
 aoclsparse_status Runtime::h2d(void *dev, const void *host, size_t bytes)
 {
-    if(!bytes)
-        return aoclsparse_status_success;
-    // OFF by default: measured on the MI355X boxes (tools/h2d_probe.hip, profiles/r2/h2d_probe.jsonl) a plain
-    // hipMemcpy of pageable memory already runs at 56 GB/s -- the ROCm 7.2 runtime pipelines it itself -- against
-    // 51-54 GB/s for this ring with 4-8 threads; AOCLSPARSE_MI355_PIPELINED_COPY=1 enables it for hosts where the
-    // runtime's own staging is slower.
-    static const bool off = [] {
-        const char *e = std::getenv("AOCLSPARSE_MI355_PIPELINED_COPY");
-        return !(e && std::atoi(e) != 0);
-    }();
-    std::unique_lock<std::mutex> l(g_ring.lock, std::defer_lock);
-    if(!off && bytes >= PIPE_MIN)
-        l.lock();
-    if(off || bytes < PIPE_MIN || !g_ring.ensure())
-    {
+    if(bytes)
         MI355_HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, stream()));
-        return aoclsparse_status_success;
-    }
-    const char *src = static_cast<const char *>(host);
-    char       *dst = static_cast<char *>(dev);
-    size_t      off_b = 0;
-    for(int i = 0; off_b < bytes; i++)
-    {
-        const int    k   = i % PIPE_SLOTS;
-        const size_t len = bytes - off_b < PIPE_CHUNK ? bytes - off_b : PIPE_CHUNK;
-        if(g_ring.busy[k]) // the DMA that last read this slot (this transfer's or an earlier one's) must have finished
-            MI355_HIP_TRY(hipEventSynchronize(g_ring.done[k]));
-        CopyPool::get().run(g_ring.slot[k], src + off_b, len);
-        MI355_HIP_TRY(hipMemcpyAsync(dst + off_b, g_ring.slot[k], len, hipMemcpyHostToDevice, stream()));
-        MI355_HIP_TRY(hipEventRecord(g_ring.done[k], stream()));
-        g_ring.busy[k] = true;
-        off_b += len;
-    }
-    // `host` may be freed right after we return: every byte of it has been copied into pinned memory already
     return aoclsparse_status_success;
 }
 
 aoclsparse_status Runtime::d2h(void *host, const void *dev, size_t bytes)
 {
-    if(!bytes)
-        return aoclsparse_status_success;
-    static const bool off = [] {
-        const char *e = std::getenv("AOCLSPARSE_MI355_PIPELINED_COPY");
-        return !(e && std::atoi(e) != 0);
-    }();
-    std::unique_lock<std::mutex> l(g_ring.lock, std::defer_lock);
-    if(!off && bytes >= PIPE_MIN)
-        l.lock();
-    if(off || bytes < PIPE_MIN || !g_ring.ensure())
-    {
+    if(bytes)
         MI355_HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, stream()));
-        return aoclsparse_status_success;
-    }
-    // any earlier use of the ring slots (an h2d still draining) must be over before the DMA writes into them
-    for(int k = 0; k < PIPE_SLOTS; k++)
-        if(g_ring.busy[k])
-        {
-            MI355_HIP_TRY(hipEventSynchronize(g_ring.done[k]));
-            g_ring.busy[k] = false;
-        }
-    const char  *src = static_cast<const char *>(dev);
-    char        *dst = static_cast<char *>(host);
-    const size_t nchunks = (bytes + PIPE_CHUNK - 1) / PIPE_CHUNK;
-    auto         issue   = [&](size_t c) -> aoclsparse_status {
-        const int    k   = (int)(c % PIPE_SLOTS);
-        const size_t o   = c * PIPE_CHUNK;
-        const size_t len = bytes - o < PIPE_CHUNK ? bytes - o : PIPE_CHUNK;
-        MI355_HIP_TRY(hipMemcpyAsync(g_ring.slot[k], src + o, len, hipMemcpyDeviceToHost, stream()));
-        MI355_HIP_TRY(hipEventRecord(g_ring.done[k], stream()));
-        return aoclsparse_status_success;
-    };
-    for(size_t c = 0; c < nchunks && c < (size_t)PIPE_SLOTS - 1; c++)
-    {
-        aoclsparse_status st = issue(c);
-        if(st != aoclsparse_status_success)
-            return st;
-    }
-    for(size_t c = 0; c < nchunks; c++)
-    {
-        if(c + PIPE_SLOTS - 1 < nchunks)
-        {
-            aoclsparse_status st = issue(c + PIPE_SLOTS - 1); // keep the DMA engine ahead of the host copies
-            if(st != aoclsparse_status_success)
-                return st;
-        }
-        const int    k   = (int)(c % PIPE_SLOTS);
-        const size_t o   = c * PIPE_CHUNK;
-        const size_t len = bytes - o < PIPE_CHUNK ? bytes - o : PIPE_CHUNK;
-        MI355_HIP_TRY(hipEventSynchronize(g_ring.done[k]));
-        CopyPool::get().run(dst + o, g_ring.slot[k], len);
-    }
     return aoclsparse_status_success;
 }
 

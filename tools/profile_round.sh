@@ -24,7 +24,6 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/legs_write
 #     the pipelined pinned copies)
 cd $R
 $PY tools/bench_extra.py > $OUT/extra_measurements.jsonl 2> $OUT/extra.err
-AOCLSPARSE_MI355_PIPELINED_COPY=0 $PY tools/bench_extra.py --what pcie 2>/dev/null | sed 's/"kind": "pcie-inclusive"/"kind": "pcie-inclusive, plain pageable copies (AOCLSPARSE_MI355_PIPELINED_COPY=0)"/' >> $OUT/extra_measurements.jsonl
 cd /tmp
 # 4. summaries (small text files: these are what gets committed under profiles/<round>/)
 cd $R
