@@ -97,7 +97,9 @@ __global__ void cscale_kernel(cplx<R> *y, aoclsparse_int n, cplx<R> beta)
 }
 
 // C = alpha op(A) B + beta C, dense B / C row- or column-major: one lane per output element, lanes of a workgroup
-// along the contiguous direction of C (columns for row-major, rows for column-major).  beta == 0 does not read C.
+// along the contiguous direction of C (columns for row-major, rows for column-major).  readc: C is read and multiplied by
+// beta (always for beta != 0; for beta == 0 unless the overwrite mode is on -- csrmm_reads_c, as for the real types: the
+// reference's kernels compute beta * C for every beta).
 template <typename R, bool COLMAJ>
 __global__ __launch_bounds__(256) void ccsrmm_kernel(int base, bool conj, cplx<R> alpha, aoclsparse_int m,
                                                      const cplx<R> *__restrict__ val,
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void ccsrmm_kernel(int base, bool conj, cplx<R
                                                      const aoclsparse_int *__restrict__ row_ptr,
                                                      const cplx<R> *__restrict__ B, aoclsparse_int n,
                                                      aoclsparse_int ldb, cplx<R> beta, cplx<R> *__restrict__ C,
-                                                     aoclsparse_int ldc)
+                                                     aoclsparse_int ldc, bool readc)
 {
     const int i = COLMAJ ? blockIdx.x * blockDim.x + threadIdx.x : blockIdx.x * blockDim.y + threadIdx.y;
     const int j = COLMAJ ? blockIdx.y * blockDim.y + threadIdx.y : blockIdx.y * blockDim.x + threadIdx.x;
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256) void ccsrmm_kernel(int base, bool conj, cplx<R
     }
     cplx<R> *cp = COLMAJ ? C + i + (size_t)j * ldc : C + (size_t)i * ldc + j;
     cplx<R>  r  = c_mul(alpha, acc);
-    if(!(beta.re == R(0) && beta.im == R(0)))
+    if(readc)
         c_mac(r, beta, *cp);
     *cp = r;
 }
@@ -322,6 +324,7 @@ aoclsparse_status launch_ccsrmm(hipStream_t s, aoclsparse_order order, int base,
 {
     if(m <= 0 || n <= 0)
         return aoclsparse_status_success;
+    const bool readc = csrmm_reads_c(!(beta.re == R(0) && beta.im == R(0)));
     if(order == aoclsparse_order_column)
     {
         // rows on grid.x (no 65535 limit), columns on grid.y in chunks of 4 -> loop over y chunks if needed
@@ -330,7 +333,7 @@ aoclsparse_status launch_ccsrmm(hipStream_t s, aoclsparse_order order, int base,
             const aoclsparse_int nj = std::min<aoclsparse_int>(n - j0, 65535 * 4);
             hipLaunchKernelGGL((ccsrmm_kernel<R, true>), dim3((m + 63) / 64, (nj + 3) / 4), dim3(64, 4), 0, s, base,
                                conj, alpha, m, val, col, row_ptr, B + (size_t)j0 * ldb, nj, ldb, beta,
-                               C + (size_t)j0 * ldc, ldc);
+                               C + (size_t)j0 * ldc, ldc, readc);
         }
     }
     else
@@ -340,7 +343,7 @@ aoclsparse_status launch_ccsrmm(hipStream_t s, aoclsparse_order order, int base,
         {
             const aoclsparse_int nj = std::min<aoclsparse_int>(n - j0, 65535 * tx);
             hipLaunchKernelGGL((ccsrmm_kernel<R, false>), dim3((m + ty - 1) / ty, (nj + tx - 1) / tx), dim3(tx, ty), 0,
-                               s, base, conj, alpha, m, val, col, row_ptr, B + j0, nj, ldb, beta, C + j0, ldc);
+                               s, base, conj, alpha, m, val, col, row_ptr, B + j0, nj, ldb, beta, C + j0, ldc, readc);
         }
     }
     MI355_HIP_TRY(hipGetLastError());

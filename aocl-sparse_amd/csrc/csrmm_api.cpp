@@ -160,12 +160,9 @@ aoclsparse_status detect_row_runs(const HostCsr &h, SpmvPlan &plan)
     if(same * 2 < (long long)h.m || cand < 256 || (long long)cand * 4 > (long long)h.m)
         return aoclsparse_status_success;
     constexpr aoclsparse_int RUN = 8, STRIP_MAX = 256;
-    static const int env_rows = [] { const char *e = getenv("AOCLSPARSE_MI355_CSRMM_STRIP_ROWS"); return e ? atoi(e) : 0; }();
-    static const int env_qg   = [] { const char *e = getenv("AOCLSPARSE_MI355_CSRMM_STRIP_QGROUP"); return e ? atoi(e) : 0; }();
     const aoclsparse_int     band = cand;
-    const aoclsparse_int     sw   = env_rows >= RUN ? (aoclsparse_int)env_rows / RUN * RUN
-                                                     : std::min<aoclsparse_int>(((band + 7) / 8 + RUN - 1) / RUN * RUN, STRIP_MAX);
-    const aoclsparse_int     qg   = env_qg >= 1 ? env_qg : 1; // band lines per workgroup-sized group of blocks
+    const aoclsparse_int     sw   = std::min<aoclsparse_int>(((band + 7) / 8 + RUN - 1) / RUN * RUN, STRIP_MAX);
+    const aoclsparse_int     qg   = 1; // band lines per workgroup-sized group of blocks
     const aoclsparse_int     nb   = (h.m + RUN - 1) / RUN;
     try
     {

@@ -788,14 +788,9 @@ __device__ inline int cm_cols_per_block(int n)
 {
     return (int)(((unsigned)n + gridDim.y - 1) / gridDim.y + 3u) & ~3;
 }
-static int cm_cols()
+static constexpr int cm_cols()
 {
-    static const int v = [] {
-        const char *e = getenv("AOCLSPARSE_MI355_CSRMM_CM_COLS");
-        const int   c = e ? atoi(e) : CM_COLS;
-        return c >= 4 ? c : CM_COLS;
-    }();
-    return v;
+    return CM_COLS; // columns per workgroup of the column-major kernels: the measured optimum (round 2)
 }
 
 template <typename T>
@@ -1171,11 +1166,8 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
         return aoclsparse_status_success;
     const bool readc = csrmm_reads_c(beta != T(0));
     // XCD-contiguous row order (every kernel): each XCD's L2 then serves the B rows its rows share.
-    // Row-major n=256 on the 1000^2 Laplacian: 0.96 vs 1.21 ms.  AOCLSPARSE_MI355_CSRMM_XCD=0 disables.
-    static const bool xcd = [] {
-        const char *e = getenv("AOCLSPARSE_MI355_CSRMM_XCD");
-        return e ? atoi(e) != 0 : true;
-    }();
+    // Row-major n=256 on the 1000^2 Laplacian: 0.96 vs 1.21 ms.
+    constexpr bool xcd = true;
     auto grid_x = [&](int nbx, int &chunk) {
         chunk = xcd ? (nbx + 7) / 8 : 0;
         return xcd ? chunk * 8 : nbx;
@@ -1405,11 +1397,8 @@ aoclsparse_status launch_csrmm_tiled(hipStream_t s, int base, T alpha, const T *
     if(nblocks <= 0 || n <= 0)
         return aoclsparse_status_success;
     const bool readc = csrmm_reads_c(beta != T(0));
-    static const bool xcd = [] {
-        const char *e = getenv("AOCLSPARSE_MI355_CSRMM_XCD");
-        return e ? atoi(e) != 0 : true;
-    }();
-    const int  chunk = xcd ? (nblocks + 7) / 8 : 0; // XCD-contiguous block order, as the other csrmm kernels
+    constexpr bool xcd = true;
+    const int  chunk = (nblocks + 7) / 8; // XCD-contiguous block order, as the other csrmm kernels
     // (UR, NB) = rows in flight per 16-lane sub-wave x B-row loads per row and step.  Round-3 sweep on the 32-column slab of
     // the 1000^2 Laplacian (tools/exp_r3_slab3.sh, profiles/r3/slab_shapes.txt; beta = 0 overwrite / C read): (2, 8) 0.130 /
     // 0.174 ms, (2, 6) 0.126-0.128 / 0.166-0.168, (1, 8) 0.127-0.133 / 0.165-0.175, (3, 6) 0.133-0.137 / 0.170-0.174, (4, 6) 0.154-0.158 /

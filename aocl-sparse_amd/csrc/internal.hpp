@@ -374,6 +374,10 @@ struct TrsvPlan
     aoclsparse_int              nslices = 0;
     DeviceBuffer                slices;
     bool                        valid = false;
+    // the level-ordered layout above (rowmap .. slices) is on the device.  Round 3: when the triangle has a block plan the
+    // automatic schedule never touches it, so it is built only when something asks for it (a forced row-level schedule, the
+    // hybrid schedule, complex types, sorv): levels / nlevels / nnz_tri are always valid once `valid` is.
+    bool rows_valid = false;
 };
 
 // host CSR view; owned==true when the library allocated the arrays (clean copy / transpose)
@@ -618,7 +622,8 @@ aoclsparse_status ensure_spmv(aoclsparse_matrix A, bool transposed, DeviceCsr *&
 aoclsparse_status ensure_derived(aoclsparse_matrix A, aoclsparse_matrix_type type, aoclsparse_fill_mode fill,
                                  aoclsparse_diag_type diag, bool transposed, Derived *&out);
 // clean CSR on the device + level sets of one triangle (trsv_api.cpp)
-aoclsparse_status ensure_trsv(aoclsparse_matrix A, bool upper, bool transposed, bool conj = false);
+// need_rows: also the level-ordered row layout (TrsvPlan::rows_valid); false = only what the automatic schedule needs
+aoclsparse_status ensure_trsv(aoclsparse_matrix A, bool upper, bool transposed, bool conj = false, bool need_rows = true);
 // SELL-64 copy of d (row_ptr_host = the host row pointer d mirrors); leaves plan.sell.valid false when the
 // padding would exceed the budget (AOCLSPARSE_MI355_SELL=0 never, =1 always)
 aoclsparse_status build_sell(const aoclsparse_int *row_ptr_host, const DeviceCsr &d, size_t vsize, SpmvPlan &plan);

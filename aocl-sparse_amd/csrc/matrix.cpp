@@ -644,11 +644,7 @@ aoclsparse_status build_sell(const aoclsparse_int *row_ptr_host, const DeviceCsr
     }
     // PACK 4 (four consecutive cells of a row adjacent, width rounded up to a multiple of 4) for long rows:
     // contiguous 2 KB wavefront loads; PACK 1 otherwise (a 5-wide slice must not be padded to 8)
-    static const int pack_env = [] {
-        const char *e = getenv("AOCLSPARSE_MI355_SELL_PACK");
-        return e ? atoi(e) : 0;
-    }();
-    const int pack = pack_env == 1 || pack_env == 4 ? pack_env : ((long long)d.nnz >= 16LL * m ? 4 : 1);
+    const int pack = (long long)d.nnz >= 16LL * m ? 4 : 1;
     sptr[0] = 0;
     for(aoclsparse_int s = 0; s < nslices; s++)
     {
@@ -1121,7 +1117,7 @@ aoclsparse_status aoclsparse_mi355_invalidate(aoclsparse_matrix A)
     A->plan_user.mm.row_runs = A->plan_user.mm.runs_tried = false;
     A->plan_trans.mm.row_runs = A->plan_trans.mm.runs_tried = false;
     for(auto &p : A->trsv_plan)
-        p.valid = false, p.nlevels = -1, p.blk.valid = p.blk.tried = false;
+        p.valid = p.rows_valid = false, p.nlevels = -1, p.blk.valid = p.blk.tried = false;
     A->trans.reset();
     return aoclsparse_status_success;
 }
@@ -1151,7 +1147,7 @@ void drop_derived_state(aoclsparse_matrix A)
     A->plan_trans.sell.valid = A->plan_trans.sell.tried = false;
     A->dev_diag.release();
     for(auto &p : A->trsv_plan)
-        p.valid = false, p.nlevels = -1, p.blk.valid = p.blk.tried = false;
+        p.valid = p.rows_valid = false, p.nlevels = -1, p.blk.valid = p.blk.tried = false;
 }
 } // namespace mi355
 

@@ -87,8 +87,9 @@ extern "C" aoclsparse_status aoclsparse_optimize(aoclsparse_matrix A)
                     && (h.type == aoclsparse_matrix_type_triangular
                         || h.type == aoclsparse_matrix_type_symmetric))
             {
+                // (what the automatic schedule needs: the level-ordered row layout is built on first use if a solve asks for it)
                 st = ensure_trsv(A, h.fill == aoclsparse_fill_mode_upper, h.trans != aoclsparse_operation_none,
-                                 h.trans == aoclsparse_operation_conjugate_transpose);
+                                 h.trans == aoclsparse_operation_conjugate_transpose, /*need_rows=*/false);
             }
             else if(h.act == action_mm || h.act == action_2m)
             {

@@ -8,6 +8,7 @@
 
 #include <system_error>
 #include <thread>
+#include <tuple>
 
 #include <cstdlib>
 
@@ -46,6 +47,25 @@ struct RawArray
     U       &operator[](size_t i) { return p[i]; }
     const U &operator[](size_t i) const { return p[i]; }
 };
+
+// Hundreds of MB of analysis scratch take tens of ms to give back to the kernel (munmap of page-faulted memory): the 25 M-entry
+// shell-like factor spent 40 of its 95 ms of block-plan time in destructors.  The arrays are moved into a box that a detached
+// thread deletes, off the caller's critical path (if no thread can be started they are freed here, as before).
+template <typename... Ts>
+static void free_later(Ts &&...xs)
+{
+    auto *box = new(std::nothrow) std::tuple<std::decay_t<Ts>...>(std::move(xs)...);
+    if(!box)
+        return; // (the arguments are destroyed by their owners)
+    try
+    {
+        std::thread([box] { delete box; }).detach();
+    }
+    catch(const std::system_error &)
+    {
+        delete box;
+    }
+}
 
 template <typename T>
 struct Triangle
@@ -114,7 +134,7 @@ static void build_triangle(const HostCsr &c, bool upper, bool transposed, bool c
 // ascending row index inside a level); then the triangle is re-laid out in that order and the hybrid
 // schedule (runs of narrow levels vs. wide levels) is derived.
 template <typename T>
-static aoclsparse_status build_levels(aoclsparse_int m, const Triangle<T> &t, TrsvPlan &plan)
+static aoclsparse_status build_levels(aoclsparse_int m, const Triangle<T> &t, TrsvPlan &plan, bool do_layout)
 {
     LapTimer                    lt;
     std::vector<aoclsparse_int> level((size_t)m, 0);
@@ -145,6 +165,8 @@ static aoclsparse_status build_levels(aoclsparse_int m, const Triangle<T> &t, Tr
     plan.nnz_tri = t.ptr[m];
 
     lt.lap("levels: level pass + buckets");
+    if(!do_layout)
+        return aoclsparse_status_success;
     // level-ordered copy of the triangle; dependencies are rewritten as POSITIONS in that order
     std::vector<aoclsparse_int> pos((size_t)m);
     for(aoclsparse_int k = 0; k < m; k++)
@@ -200,6 +222,8 @@ static aoclsparse_status build_levels(aoclsparse_int m, const Triangle<T> &t, Tr
     if(rc == aoclsparse_status_success)
         rc = plan.slices.upload(slices.data(), sizeof(aoclsparse_int) * slices.size(), st);
     lt.lap("levels: upload");
+    plan.rows_valid = rc == aoclsparse_status_success;
+    free_later(std::move(pind), std::move(pval), std::move(rowmap), std::move(pos), std::move(pptr), std::move(level));
     return rc;
 }
 
@@ -239,7 +263,6 @@ static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, T
     std::vector<aoclsparse_int> bstart, best;
     bool                        front = false, best_front = false;
     bstart.reserve((size_t)m / 2 + 2);
-    static const bool nocut = [] { const char *e = getenv("AOCLSPARSE_MI355_TRSV_BLK_CUT"); return e && atoi(e) == 0; }();
     for(int form = 0; form < 2; form++)
     {
         front = form == 1;
@@ -264,7 +287,7 @@ static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, T
                 longer += (j - k > 5);
                 k = j;
             }
-            if(nocut || longer == 0 || longer * 10 >= (aoclsparse_int)bstart.size())
+            if(longer == 0 || longer * 10 >= (aoclsparse_int)bstart.size())
                 break; // nothing to cut, or long chains are the rule: keep them
         }
         if(best.empty() || bstart.size() < best.size())
@@ -374,72 +397,46 @@ static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, T
     bp.max_rows = max_rows, bp.max_ext = max_ext;
     bp.front = front;
     bp.valid = true;
+    free_later(std::move(pind), std::move(pval), std::move(rowmap), std::move(pos), std::move(pptr), std::move(bof));
     return aoclsparse_status_success;
 }
 
 template <typename T>
-static aoclsparse_status build_plan_t(const HostCsr &c, bool upper, bool transposed, bool conj, TrsvPlan &plan)
+static aoclsparse_status build_plan_t(const HostCsr &c, bool upper, bool transposed, bool conj, TrsvPlan &plan, bool need_rows)
 {
     Triangle<T> t;
     {
         PhaseTimer pt("trsv plan: triangle");
         build_triangle<T>(c, upper, transposed, conj, t);
     }
-    aoclsparse_status st = aoclsparse_status_success, stb = aoclsparse_status_success;
-    // The row-level plan and the block plan are two independent layouts of the same triangle (each ~75-95 ms on the
-    // 25 M-entry shell-like factor: page-faulting, filling, uploading and freeing 300 MB): built side by side (round 3).
-    std::thread helper;
-    if constexpr(std::is_floating_point<T>::value)
-        if(!plan.blk.tried)
+    aoclsparse_status st = aoclsparse_status_success;
+    constexpr bool    real = std::is_floating_point<T>::value;
+    if(!plan.valid)
+    {
+        // levels first (cheap; every schedule choice needs nlevels), then the block plan, then -- only if asked for, or if
+        // the triangle has no blocks -- the level-ordered row layout.  On the 25 M-entry shell-like factor the row layout is
+        // ~75 ms of page-faulting, filling, uploading and freeing 300 MB that the automatic schedule (blocks) never reads.
         {
-            Runtime *cur = &Runtime::get();
-            try
-            {
-                helper = std::thread([&, cur] {
-                    try
-                    {
-                        RuntimeScope sc(cur); // the same runtime slot (device, stream) as the calling thread
-                        PhaseTimer   pt("trsv plan: blocks + layout + upload (helper thread)");
-                        stb = sc.status == aoclsparse_status_success ? build_blocked<T>(c.m, t, plan.blk) : sc.status;
-                    }
-                    catch(const std::bad_alloc &)
-                    {
-                        stb = aoclsparse_status_memory_error;
-                    }
-                    catch(...)
-                    {
-                        stb = aoclsparse_status_internal_error;
-                    }
-                });
-            }
-            catch(const std::system_error &)
-            {
-                // no thread to be had: one after the other, below
-            }
+            PhaseTimer pt("trsv plan: level pass");
+            st = build_levels<T>(c.m, t, plan, false);
         }
-    try
+        if constexpr(real)
+            if(st == aoclsparse_status_success && !plan.blk.tried)
+            {
+                PhaseTimer pt("trsv plan: blocks + layout + upload");
+                st = build_blocked<T>(c.m, t, plan.blk);
+            }
+    }
+    if(st == aoclsparse_status_success && !plan.rows_valid && (need_rows || !real || !plan.blk.valid))
     {
         PhaseTimer pt("trsv plan: levels + layout + upload");
-        st = build_levels<T>(c.m, t, plan);
+        st = build_levels<T>(c.m, t, plan, true);
     }
-    catch(...)
-    {
-        if(helper.joinable())
-            helper.join();
-        throw;
-    }
-    if(helper.joinable())
-        helper.join();
-    else if constexpr(std::is_floating_point<T>::value)
-        if(st == aoclsparse_status_success && !plan.blk.tried)
-        {
-            PhaseTimer pt("trsv plan: blocks + layout + upload");
-            stb = build_blocked<T>(c.m, t, plan.blk);
-        }
-    return st != aoclsparse_status_success ? st : stb;
+    free_later(std::move(t.ptr), std::move(t.ind), std::move(t.val));
+    return st;
 }
 
-aoclsparse_status ensure_trsv(aoclsparse_matrix A, bool upper, bool transposed, bool conj)
+aoclsparse_status ensure_trsv(aoclsparse_matrix A, bool upper, bool transposed, bool conj, bool need_rows)
 {
     conj = conj && transposed && is_complex_type(A->val_type);
     aoclsparse_status st;
@@ -452,11 +449,11 @@ aoclsparse_status ensure_trsv(aoclsparse_matrix A, bool upper, bool transposed, 
     TrsvPlan &plan = A->trsv_plan[conj ? 4 + (upper ? 1 : 0) : (upper ? 2 : 0) + (transposed ? 1 : 0)];
     {
         std::shared_lock<std::shared_mutex> r(A->guard);
-        if(plan.valid)
+        if(plan.valid && (plan.rows_valid || !need_rows))
             return aoclsparse_status_success;
     }
     std::unique_lock<std::shared_mutex> w(A->guard);
-    if(plan.valid)
+    if(plan.valid && (plan.rows_valid || !need_rows))
         return aoclsparse_status_success;
     const HostCsr       &c  = *A->opt;
     const size_t         vs = val_size(A->val_type);
@@ -477,7 +474,7 @@ aoclsparse_status ensure_trsv(aoclsparse_matrix A, bool upper, bool transposed, 
                 return st;
         }
         st = dispatch_value_type(A->val_type, [&](auto tag) {
-            return build_plan_t<decltype(tag)>(c, upper, transposed, conj, plan);
+            return build_plan_t<decltype(tag)>(c, upper, transposed, conj, plan, need_rows);
         });
         if(st != aoclsparse_status_success)
             return st;
@@ -522,9 +519,27 @@ aoclsparse_status solve_core(aoclsparse_operation trans, T alpha, aoclsparse_mat
     const bool unit  = descr->diag_type == aoclsparse_diag_type_unit;
     constexpr bool is_cplx = !std::is_floating_point<T>::value;
     const bool     conj    = is_cplx && trans == aoclsparse_operation_conjugate_transpose;
-    st                     = ensure_trsv(A, upper, tr, conj);
+    st                     = ensure_trsv(A, upper, tr, conj, /*need_rows=*/false);
     if(st != aoclsparse_status_success)
         return st;
+    {
+        // the level-ordered row layout is needed by the per-level, hybrid and slice schedules (and by complex types); the
+        // lane-per-position kernel runs on the block plan's layout too (any topological order of the rows will do)
+        bool rows_needed;
+        {
+            std::shared_lock<std::shared_mutex> r0(A->guard);
+            const TrsvPlan &p0 = A->trsv_plan[conj ? 4 + (upper ? 1 : 0) : (upper ? 2 : 0) + (tr ? 1 : 0)];
+            const int       f0 = Runtime::primary().trsv_schedule;
+            rows_needed = !p0.rows_valid
+                          && (is_cplx || !p0.blk.valid || f0 == 0 || f0 == 1 || f0 == 3 || (f0 < 0 && p0.nlevels <= 32));
+        }
+        if(rows_needed)
+        {
+            st = ensure_trsv(A, upper, tr, conj, true);
+            if(st != aoclsparse_status_success)
+                return st;
+        }
+    }
     // solves on one handle share its workspaces: serialise their enqueue (kernels are stream-ordered)
     std::lock_guard<std::recursive_mutex> sl(rt.stage_lock);
     std::shared_lock<std::shared_mutex>   r(A->guard);
@@ -535,21 +550,15 @@ aoclsparse_status solve_core(aoclsparse_operation trans, T alpha, aoclsparse_mat
     // (complex handles always run the hybrid schedule: their 8 / 16-byte x cannot be the one-word ready flag)
     // The sync-free choice is the slice-per-wavefront kernel (3) for one right-hand side -- unless the level slices
     // would leave most lanes idle (average level narrower than 16 rows: deep chains), where the lane-per-position
-    // kernel (2) packs better; AOCLSPARSE_MI355_TRSV_SYNCFREE=2|3 forces one of them.
-    static const int sf_env = [] {
-        const char *e = getenv("AOCLSPARSE_MI355_TRSV_SYNCFREE");
-        return e ? atoi(e) : 0;
-    }();
+    // kernel (2) packs better; aoclsparse_mi355_set_trsv_schedule forces one of them.
     // measured (profiles/r2/trsv_schedules.txt): the slice kernel wins on short rows (ILU(0) of the 2-D Laplacian:
     // 1.69 vs 2.09 ms), the lane-per-position kernel on rows of ~17 entries (shell-like factor)
     // -- except when a row's chain STARTS with the row solved last (U, upper && !transposed): there every entry behind
     // the first would be polled one round trip at a time (45 ms), and the slice kernel's batch re-read wins (17.9 ms)
     const bool packed = nrhs == 1 && plan.nslices > 0 && (long long)plan.nslices * 16 <= (long long)m;
-    const int  sf     = (sf_env == 2 || sf_env == 3)                                                ? sf_env
-                        : (packed && ((long long)plan.nnz_tri <= 10LL * m || (upper && !tr && !conj))) ? 3
-                                                                                                    : 2;
+    const int  sf     = (packed && ((long long)plan.nnz_tri <= 10LL * m || (upper && !tr && !conj))) ? 3 : 2;
     // chained rows (the dofs of a node) solved back to back by one lane: one hop per BLOCK level instead of per row level
-    const int sfb = (sf_env == 0 && plan.blk.valid) ? 4 : sf; // (trsm too: one grid column per right-hand side)
+    const int sfb = plan.blk.valid ? 4 : sf; // (trsm too: one grid column per right-hand side)
     // Round 3: the kid selects the ARITHMETIC, as it does in the reference (trsv.cpp:321-353), not the schedule.  kid 0 and auto:
     // the chain of ref_trsv_* -- every schedule reproduces it, so the fastest one runs; kid 1 / 2: the order of the 256-bit KT
     // kernels, kid 3: of the 512-bit ones (kt_trsv_l / kt_trsv_u, trsv_kt.cpp:64-150, :297-383), bit for bit, served by the

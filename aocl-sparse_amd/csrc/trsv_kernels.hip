@@ -1006,10 +1006,15 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
         return aoclsparse_status_internal_error;
     if(kt_bits != 0 && schedule != 0)
         schedule = 2;
-    const aoclsparse_int *rowmap = plan.rowmap.as<aoclsparse_int>();
-    const aoclsparse_int *pptr   = plan.pptr.as<aoclsparse_int>();
-    const aoclsparse_int *pind   = plan.pind.as<aoclsparse_int>();
-    const T              *pval   = plan.pval.as<T>();
+    // the level-ordered row layout, or -- when only the block plan was built (TrsvPlan::rows_valid == false) -- the block
+    // plan's layout: also a topological order of the rows, which is all the lane-per-position kernel (schedule 2) needs
+    const bool            rows   = plan.rows_valid;
+    const aoclsparse_int *rowmap = rows ? plan.rowmap.as<aoclsparse_int>() : plan.blk.rowmap.as<aoclsparse_int>();
+    const aoclsparse_int *pptr   = rows ? plan.pptr.as<aoclsparse_int>() : plan.blk.pptr.as<aoclsparse_int>();
+    const aoclsparse_int *pind   = rows ? plan.pind.as<aoclsparse_int>() : plan.blk.pind.as<aoclsparse_int>();
+    const T              *pval   = rows ? plan.pval.as<T>() : plan.blk.pval.as<T>();
+    if(!rows && !plan.blk.valid)
+        return aoclsparse_status_internal_error;
     RhsGeom               g{b_off, x_off, incb, incx, 0};
     if(schedule == 1 && (nrhs != 1 || incb != 1 || incx != 1))
         schedule = 2; // the single-workgroup runs of the hybrid schedule are single-RHS, unit stride
@@ -1017,8 +1022,10 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
     if(schedule == 4
        && (!plan.blk.valid || (nrhs > 1 && (plan.blk.nslices > 65535 || (long long)m * nrhs + TRSV_XP_PAD >= (1LL << 31)))))
         schedule = 3;
-    if(schedule == 3 && (nrhs != 1 || plan.nslices <= 0))
+    if(schedule == 3 && (nrhs != 1 || plan.nslices <= 0 || !rows))
         schedule = 2; // the slice kernel is single-RHS; trsm keeps the lane-per-position kernel
+    if((schedule == 0 || schedule == 1) && !rows)
+        return aoclsparse_status_internal_error; // the caller asks for the row layout before choosing these (trsv_api.cpp)
     auto level_launch = [&](aoclsparse_int l) {
         const aoclsparse_int first = plan.level_ptr[l], count = plan.level_ptr[l + 1] - first;
         const int            bs = count >= 256 ? 256 : 64;
@@ -1062,7 +1069,7 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
         MI355_HIP_TRY(hipMemsetAsync(scratch, 0, ((size_t)nrhs + 1 + (size_t)nrhs * bp.nlevels) * sizeof(unsigned int), s));
         hipLaunchKernelGGL((trsv_fill_tag_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xp, total,
                            total + TRSV_XP_PAD - 1);
-        static const int gate  = [] { const char *e = getenv("AOCLSPARSE_MI355_TRSV_GATE"); return e ? atoi(e) : 2; }();
+        constexpr int gate = 2; // a wavefront starts looking at its dependencies when the block level two below is complete
         // diagnostic: AOCLSPARSE_MI355_TRSV_TRACE=<file> dumps, per slice, the 100 MHz clock after the ticket, when the
         // dependencies were all in, at the end, the slice's block level, after the LDS reads, after the external FMAs (6 x u64 per slice; tools/trsv_trace.py)
         static const char  *trace_path = getenv("AOCLSPARSE_MI355_TRSV_TRACE");
@@ -1076,8 +1083,7 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
             // (the small shapes hold the block in registers and use no LDS)
             constexpr size_t need = trsv_blk_slots(BS, EXT) <= 112 ? 0 : sizeof(T) * 64 * (size_t)trsv_blk_slots(BS, EXT);
             static_assert(need <= 160 * 1024, "LDS of one CU");
-            static const size_t floor_kb = [] { const char *e = getenv("AOCLSPARSE_MI355_TRSV_BLK_LDS"); return e ? (size_t)atoi(e) : (size_t)0; }();
-            const size_t        lds = std::min<size_t>(std::max(need, floor_kb * 1024), 160 * 1024);
+            const size_t     lds  = std::min<size_t>(need, 160 * 1024);
             if(lds > 64 * 1024)
             {
                 static const hipError_t raised = hipFuncSetAttribute(
@@ -1111,8 +1117,7 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
         };
         using std::integral_constant;
         // shapes by the plan's largest block / external list (the loops over rows and external entries are unrolled)
-        static const bool force_big = [] { const char *e = getenv("AOCLSPARSE_MI355_TRSV_BLK_SHAPE"); return e && atoi(e) == 8; }();
-        const bool small_ext = bp.max_ext <= 16, small_bs = bp.max_rows <= 5 && !force_big;
+        const bool small_ext = bp.max_ext <= 16, small_bs = bp.max_rows <= 5;
         const aoclsparse_status lst = small_ext && small_bs ? go(integral_constant<int, 5>{}, integral_constant<int, 16>{})
                                       : small_ext           ? go(integral_constant<int, TRSV_BLK_ROWS>{}, integral_constant<int, 16>{})
                                       : small_bs ? go(integral_constant<int, 5>{}, integral_constant<int, TRSV_BLK_EXT>{})
@@ -1139,12 +1144,8 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
         // sync-free, one level slice per wavefront (single right-hand side)
         MI355_HIP_TRY(hipMemsetAsync(scratch, 0, 2 * sizeof(unsigned int), s));
         hipLaunchKernelGGL((trsv_fill_tag_kernel<T>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, xp, (long long)m);
-        static const int wv_env = [] {
-            const char *e = getenv("AOCLSPARSE_MI355_TRSV_WAVES");
-            return e ? atoi(e) : 0;
-        }();
         const bool  wide = (long long)plan.nnz_tri > 10LL * m;
-        const int   wv   = wv_env == 4 || wv_env == 8 || wv_env == 16 ? wv_env : 16;
+        constexpr int wv = 16; // slices per workgroup (4 / 8 measured slower: 2.02 / 1.90 vs 1.69 ms, round 2)
         const aoclsparse_int *sl = plan.slices.as<aoclsparse_int>();
         auto go = [&](auto wv_tag, auto pf_tag) {
             constexpr int WV = decltype(wv_tag)::value, PF = decltype(pf_tag)::value;

@@ -2714,9 +2714,18 @@ def test_complex_csrmm(prec):
                     for alpha, beta in ((0.6 - 0.8j, -0.5 + 0.25j), (1.0 + 0j, 0j), (0j, 2.0 - 1j)):
                         Bb, Cb = pack(Bm, ldb), pack(C0, ldc)
                         if beta == 0:
+                            # default: 0 * C is computed as in the reference, NaN stays; overwrite mode: never read
+                            Cn = np.full_like(Cb, np.nan + 1j * np.nan)
+                            assert mm(op, CT(alpha.real, alpha.imag), h, d.h, order, P._ptr(Bb), n, ldb, CT(0.0, 0.0),
+                                      P._ptr(Cn), ldc) == 0
+                            assert np.all(np.isnan(unpack(Cn, mc, n)))
                             Cb[...] = np.nan + 1j * np.nan
-                        assert mm(op, CT(alpha.real, alpha.imag), h, d.h, order, P._ptr(Bb), n, ldb, CT(beta.real, beta.imag),
-                                  P._ptr(Cb), ldc) == 0, (mtype, opn, colmaj)
+                            assert L.aoclsparse_mi355_set_csrmm_beta0_overwrite(1) == 0
+                        try:
+                            assert mm(op, CT(alpha.real, alpha.imag), h, d.h, order, P._ptr(Bb), n, ldb, CT(beta.real, beta.imag),
+                                      P._ptr(Cb), ldc) == 0, (mtype, opn, colmaj)
+                        finally:
+                            assert L.aoclsparse_mi355_set_csrmm_beta0_overwrite(0) == 0
                         got = unpack(Cb, mc, n)
                         ref = alpha * (Mo @ Bm.astype(np.complex128)) + (beta * C0 if beta != 0 else 0)
                         scale = abs(alpha) * (np.abs(Mo) @ np.abs(Bm)) + abs(beta) * np.abs(C0)
