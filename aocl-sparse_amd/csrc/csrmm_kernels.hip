@@ -651,7 +651,7 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup_sub_kernel(int base, T alp
 // not read again by this launch).  32 columns of the 1000^2 Laplacian: 0.131 ms against 0.195 ms for csrmm_row_kernel
 // (tools/csrmm_r2.hip, profiles/r2/csrmm_experiments.txt).
 template <typename T, int LANES, int TILE, int UR, int NB, bool RC>
-__global__ __launch_bounds__(256) void csrmm_tile_kernel(int base, T alpha, const T *__restrict__ val,
+__global__ __launch_bounds__(256, 4) void csrmm_tile_kernel(int base, T alpha, const T *__restrict__ val,
                                                          const aoclsparse_int *__restrict__ col,
                                                          const aoclsparse_int *__restrict__ row_ptr,
                                                          const aoclsparse_int *__restrict__ blocks, aoclsparse_int nblocks,
@@ -1403,11 +1403,16 @@ aoclsparse_status launch_csrmm_tiled(hipStream_t s, int base, T alpha, const T *
     // the 1000^2 Laplacian (tools/exp_r3_slab3.sh, profiles/r3/slab_shapes.txt; beta = 0 overwrite / C read): (2, 8) 0.130 /
     // 0.174 ms, (2, 6) 0.126-0.128 / 0.166-0.168, (1, 8) 0.127-0.133 / 0.165-0.175, (3, 6) 0.133-0.137 / 0.170-0.174, (4, 6) 0.154-0.158 /
     // 0.182-0.184, (4, 8) 0.167 / 0.193-0.198: two rows in flight, and no more load slots than the rows have entries.
+    // Occupancy is not the lever (tools/exp_r3_slab5.sh, profiles/r3/slab_occupancy.txt): the kernel sits at 4 waves / SIMD
+    // (98-110 VGPRs); __launch_bounds__(256, 5) without spills (NB = 5 / 6, overwrite) measures the same 0.123-0.129 ms, with
+    // spills (C read) 0.19-0.29 ms, (256, 6) 0.14-0.51 ms.  NB = 5 for rows of <= 5 entries is worth 1-2 % (0.163-0.173 vs
+    // 0.167-0.174 ms C read, 0.1225-0.126 vs 0.124-0.1285 overwrite).
     auto       go3   = [&](auto tile_tag, auto nb_tag, auto rc_tag) {
         constexpr int  TILE = decltype(tile_tag)::value, NB = decltype(nb_tag)::value;
         constexpr bool RC   = decltype(rc_tag)::value;
-        hipLaunchKernelGGL((csrmm_tile_kernel<T, 16, TILE, 2, NB, RC>), dim3(xcd ? chunk * 8 : nblocks, (n + 31) / 32), dim3(256),
-                           0, s, base, alpha, val, col, row_ptr, blocks, nblocks, B, n, ldb, beta, C, ldc, readc, chunk);
+        const dim3     grid(xcd ? chunk * 8 : nblocks, (n + 31) / 32);
+        hipLaunchKernelGGL((csrmm_tile_kernel<T, 16, TILE, 2, NB, RC>), grid, dim3(256), 0, s, base, alpha, val, col, row_ptr,
+                           blocks, nblocks, B, n, ldb, beta, C, ldc, readc, chunk);
     };
     auto go2 = [&](auto tile_tag, auto nb_tag) {
         if(readc)
@@ -1416,7 +1421,9 @@ aoclsparse_status launch_csrmm_tiled(hipStream_t s, int base, T alpha, const T *
             go3(tile_tag, nb_tag, std::false_type{});
     };
     auto go = [&](auto tile_tag) {
-        if(max_row_nnz > 0 && max_row_nnz <= 6)
+        if(max_row_nnz > 0 && max_row_nnz <= 5)
+            go2(tile_tag, std::integral_constant<int, 5>{});
+        else if(max_row_nnz > 0 && max_row_nnz <= 6)
             go2(tile_tag, std::integral_constant<int, 6>{});
         else
             go2(tile_tag, std::integral_constant<int, 8>{});

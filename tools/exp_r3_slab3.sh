@@ -1,4 +1,6 @@
 #!/bin/bash
+# HISTORICAL: the AOCLSPARSE_MI355_EXP_* / _STRIP_* switches this script sets existed only in the experiment builds whose
+# output is kept under profiles/; the library no longer reads them (the winning setting is compiled in).
 # round 3: slab kernel shape sweep (rows in flight x loads per row), both beta = 0 modes, same box, interleaved twice
 cd ${GRAFT_REPO_ROOT:-.}
 for rep in 1 2; do

@@ -1,4 +1,6 @@
 #!/bin/bash
+# HISTORICAL: the AOCLSPARSE_MI355_EXP_* / _STRIP_* switches this script sets existed only in the experiment builds whose
+# output is kept under profiles/; the library no longer reads them (the winning setting is compiled in).
 # round 3: column-major slab (csrmm_colpair_kernel): entries cached x columns per step, both beta = 0 modes; + the row-major
 # slab with its fixed shape; + 256 columns both layouts (nothing else may regress)
 cd ${GRAFT_REPO_ROOT:-.}

@@ -1,4 +1,6 @@
 #!/bin/bash
+# HISTORICAL: the AOCLSPARSE_MI355_EXP_* / _STRIP_* switches this script sets existed only in the experiment builds whose
+# output is kept under profiles/; the library no longer reads them (the winning setting is compiled in).
 # Row-major csrmm on the 1000^2 Laplacian, 256 columns: strip width / band lines per workgroup group, time and L2-miss
 # traffic (FETCH_SIZE, KB, x2 on gfx950).  CASES="rows:qgroup ..." (0:0 = strips off)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
