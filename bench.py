@@ -437,6 +437,19 @@ def main():
                 assert L.aoclsparse_mi355_set_stream(None) == 0
         except Exception as e:  # noqa: BLE001 -- the graph figure is an extra
             out["hip_graph_error"] = repr(e)[:200]
+        # The figures above are timed from Python (ctypes: ~1-2 us of interpreter per call).  What a C caller pays, next to a raw
+        # launch of an empty kernel with the same 13 arguments: tools/l100_probe.hip, run as a child process with a timeout.
+        try:
+            import subprocess
+            probe = os.path.join(ROOT, "tools", "bin", "l100_probe")
+            if os.path.exists(probe):
+                r = subprocess.run([probe, "5000"], capture_output=True, text=True, timeout=120)
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                out["c_caller"] = json.loads(line[-1]) if r.returncode == 0 and line else {"error": (r.stdout + r.stderr)[-200:]}
+            else:
+                out["c_caller"] = {"skipped": "tools/bin/l100_probe not built (python -c 'import __graft_entry__ as g; g.build()')"}
+        except Exception as e:  # noqa: BLE001 -- an extra
+            out["c_caller"] = {"error": repr(e)[:200]}
         return out
 
     run_leg("l100", leg_l100)
