@@ -567,7 +567,7 @@ def main():
         unpin()
         return {"workload": "BASELINE configs[2]: aoclsparse_dmv after aoclsparse_set_mv_hint + aoclsparse_optimize "
                             "(format / kernel chosen by optimize from the row-length statistics: SELL-64 when padding "
-                            "<= 1.15x, merge-path when the longest row spans >= 32 LDS tiles, else CSR-Adaptive)",
+                            "<= 1.35x, merge-path when the longest row spans >= 32 LDS tiles, else CSR-Adaptive)",
                 "matrices": rows, "merge_path_selection": demo}
 
     run_leg("mix", leg_mix)

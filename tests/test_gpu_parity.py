@@ -1551,7 +1551,7 @@ def test_sell_lane_orders_bit_exact(kid, order, base):
     partial sums.  Rows of every length mod 8, empty rows, a last partial slice."""
     m, n = 64 * 37 + 13, 3000
     rng = np.random.default_rng(62)
-    lens = rng.integers(36, 41, m)  # padding stays under the 1.15 budget
+    lens = rng.integers(36, 41, m)  # padding stays under the budget (1.35 cells per non-zero)
     lens[3], lens[100], lens[m - 1] = 0, 7, 25
     rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
     ci = np.concatenate([rng.choice(n, k, replace=False) for k in lens]).astype(np.int32)  # unsorted columns
