@@ -529,8 +529,10 @@ def dcsrmm(op, alpha, A, descr, order, B, n, ldb, beta, C, ldc, kid=None):
     return L.aoclsparse_dcsrmm_kid(op, alpha, A.h, descr.h, order, _ptr(B), n, ldb, beta, _ptr(C), ldc, kid)
 
 
-def scsrmm(op, alpha, A, descr, order, B, n, ldb, beta, C, ldc):
-    return lib().aoclsparse_scsrmm(op, alpha, A.h, descr.h, order, _ptr(B), n, ldb, beta, _ptr(C), ldc)
+def scsrmm(op, alpha, A, descr, order, B, n, ldb, beta, C, ldc, kid=None):
+    if kid is None:
+        return lib().aoclsparse_scsrmm(op, alpha, A.h, descr.h, order, _ptr(B), n, ldb, beta, _ptr(C), ldc)
+    return lib().aoclsparse_scsrmm_kid(op, alpha, A.h, descr.h, order, _ptr(B), n, ldb, beta, _ptr(C), ldc, kid)
 
 
 def device_info():

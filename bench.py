@@ -415,6 +415,16 @@ def main():
             for _ in range(2000):
                 pkg.dmv(pkg.OP_NONE, 1.0, A1, descr, x1, 0.0, y1)
             out["us_per_call_back_to_back"] = round(pkg.timer_stop() / 2000 * 1e3, 3)
+            # the same with the ctypes arguments converted ONCE (what is left of Python is the foreign-function call itself)
+            fn, a1, b1 = L.aoclsparse_dmv, ctypes.c_double(1.0), ctypes.c_double(0.0)
+            pa, pb = ctypes.byref(a1), ctypes.byref(b1)
+            px, py = ctypes.c_void_p(x1.data_ptr()), ctypes.c_void_p(y1.data_ptr())
+            ah, dh, opn = A1.h, descr.h, pkg.OP_NONE
+            torch.cuda.synchronize()
+            pkg.timer_start()
+            for _ in range(2000):
+                fn(opn, pa, ah, dh, px, pb, py)
+            out["us_per_call_back_to_back_prebound_arguments"] = round(pkg.timer_stop() / 2000 * 1e3, 3)
             sg = torch.cuda.Stream()
             assert L.aoclsparse_mi355_set_stream(ctypes.c_void_p(sg.cuda_stream)) == 0
             try:

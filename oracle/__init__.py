@@ -219,6 +219,16 @@ def dcsrmm_kt(order, psz, alpha, base, val, col, row, m, B, n, ldb, beta, C, ldc
     return st, C
 
 
+def scsrmm_kt(order, psz, alpha, base, val, col, row, m, B, n, ldb, beta, C, ldc):
+    """float csrmm_col_kt / csrmm_row_kt; psz = 8 (kid 1/2) or 16 (kid 3)."""
+    val, col, row, B = _f32(val), _i32(col), _i32(row), _f32(B)
+    C = _f32(C).copy()
+    fn = lib().orc_scsrmm_row_kt if order == "row" else lib().orc_scsrmm_col_kt
+    st = fn(c_int(psz), c_flt(alpha), c_int(base), _p(val), _p(col), _p(row), c_i32(m), _p(B), c_i32(n),
+            c_i32(ldb), c_flt(beta), _p(C), c_i32(ldc))
+    return st, C
+
+
 _ktref = None
 
 
@@ -240,7 +250,7 @@ def ktref():
         L = ctypes.CDLL(path)
         for name in ("ktref_hsum_d", "ktref_dot_d", "ktref_trsv_row_d", "ktref_csrmm_col_elem_d"):
             getattr(L, name).restype = c_dbl
-        for name in ("ktref_hsum_s", "ktref_dot_s", "ktref_trsv_row_s"):
+        for name in ("ktref_hsum_s", "ktref_dot_s", "ktref_trsv_row_s", "ktref_csrmm_col_elem_s"):
             getattr(L, name).restype = c_flt
         _ktref = L
     return _ktref

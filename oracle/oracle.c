@@ -750,66 +750,72 @@ int orc_dcsrmm_row(double alpha, int base, const double *val, const oint *col,
  *   tail:       cij = fma(a, b, cij) left to right (the contracted "cij += aval * b", :165-168);
  *   cij *= alpha; C = beta*C + cij (:172-191) -- one fma, which product is fused depends on the compiler (below).
  * C is read even when beta == 0. */
-int orc_dcsrmm_col_kt(int psz, double alpha, int base, const double *val, const oint *col,
-                      const oint *row, oint m, const double *B, oint n, oint ldb, double beta,
-                      double *C, oint ldc)
-{
-    for(oint j = 0; j < n; j++)
-        for(oint i = 0; i < m; i++)
-        {
-            const double *bc  = B + (size_t)j * ldb;
-            oint          s   = row[i] - base, e = row[i + 1] - base;
-            oint          nnz = e - s, mul = nnz / psz, rem = nnz - psz * mul;
-            double        cij = 0.0;
-            if(mul)
-            {
-                double p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for(oint k = s; k < e - rem; k += psz)
-                    for(int l = 0; l < psz; l++)
-                        p[l] = fma(val[k + l], bc[col[k + l] - base], p[l]);
-                cij += orc_kt_hsum_d(psz, p);
-            }
-            for(oint k = e - rem; k < e; k++)
-                cij = CH_D(val[k], bc[col[k] - base], cij);
-            size_t ic = (size_t)i + (size_t)j * ldc;
-            /* "cij *= alpha; C = beta*C + cij": two products feed one addition and the compiler picks which one it
-             * fuses.  Statement-wise contraction (clang -ffp-contract=on style): fma(beta, C, alpha*cij);
-             * GCC's widening_mul pass takes the first product it meets: fma(cij, alpha, beta*C) -- measured on
-             * oracle/_ref/libktref.so (tests/golden/kt_vectors.json). */
-            if(g_fused)
-                C[ic] = fma(beta, C[ic], cij * alpha);
-            else
-                C[ic] = fma(cij, alpha, beta * C[ic]);
-        }
-    return ORC_SUCCESS;
-}
+#define DEF_CSRMM_COL_KT(NAME, T, FMA, HSUM, CH, MAXP)                                                          \
+    int NAME(int psz, T alpha, int base, const T *val, const oint *col, const oint *row, oint m, const T *B, oint n, \
+             oint ldb, T beta, T *C, oint ldc)                                                                      \
+    {                                                                                                               \
+        for(oint j = 0; j < n; j++)                                                                                 \
+            for(oint i = 0; i < m; i++)                                                                             \
+            {                                                                                                       \
+                const T *bc  = B + (size_t)j * ldb;                                                                 \
+                oint     s   = row[i] - base, e = row[i + 1] - base;                                                \
+                oint     nnz = e - s, mul = nnz / psz, rem = nnz - psz * mul;                                       \
+                T        cij = 0;                                                                                   \
+                if(mul)                                                                                             \
+                {                                                                                                   \
+                    T p[MAXP];                                                                                      \
+                    for(int l = 0; l < MAXP; l++)                                                                   \
+                        p[l] = 0;                                                                                   \
+                    for(oint k = s; k < e - rem; k += psz)                                                          \
+                        for(int l = 0; l < psz; l++)                                                                \
+                            p[l] = FMA(val[k + l], bc[col[k + l] - base], p[l]);                                    \
+                    cij += HSUM(psz, p);                                                                            \
+                }                                                                                                   \
+                for(oint k = e - rem; k < e; k++)                                                                   \
+                    cij = CH(val[k], bc[col[k] - base], cij);                                                       \
+                size_t ic = (size_t)i + (size_t)j * ldc;                                                            \
+                /* "cij *= alpha; C = beta*C + cij": two products feed one addition and the compiler picks which    \
+                 * one it fuses.  Statement-wise contraction (clang -ffp-contract=on style):          \
+                 * fma(beta, C, alpha*cij); GCC's widening_mul pass takes the first product it meets:               \
+                 * fma(cij, alpha, beta*C) -- measured on oracle/_ref/libktref.so (tests/golden/kt_vectors.json). */ \
+                if(g_fused)                                                                                         \
+                    C[ic] = FMA(beta, C[ic], cij * alpha);                                                          \
+                else                                                                                                \
+                    C[ic] = FMA(cij, alpha, beta * C[ic]);                                                          \
+            }                                                                                                       \
+        return ORC_SUCCESS;                                                                                         \
+    }
+DEF_CSRMM_COL_KT(orc_dcsrmm_col_kt, double, fma, orc_kt_hsum_d, CH_D, 8)
+DEF_CSRMM_COL_KT(orc_scsrmm_col_kt, float, fmaf, orc_kt_hsum_s, CH_S, 16)
 
 /* csrmm_row_kt, csrmm_kt.cpp:199-363.  C_row = C_row * beta first (:244-247, a multiplication also for beta == 0);
  * then the row's entries in CSR order (groups of four only share loads): columns j < n - n % psz take
  * c = fma(alpha*a_k, b_kj, c) (kt_set1_p(alpha*sv), kt_fmadd_p, :289-322), the last n % psz columns the scalar
  * statement "C += sv * B * alpha" (:335-356) = fma(sv*b, alpha, c) after contraction. */
-int orc_dcsrmm_row_kt(int psz, double alpha, int base, const double *val, const oint *col,
-                      const oint *row, oint m, const double *B, oint n, oint ldb, double beta,
-                      double *C, oint ldc)
-{
-    oint rem = n % psz;
-    for(oint i = 0; i < m; i++)
-    {
-        double *c = C + (size_t)i * ldc;
-        for(oint j = 0; j < n; j++)
-            c[j] = c[j] * beta;
-        for(oint k = row[i] - base; k < row[i + 1] - base; k++)
-        {
-            const double *brow = B + (size_t)(col[k] - base) * ldb;
-            double        sv = val[k], av = alpha * sv;
-            for(oint j = 0; j < n - rem; j++)
-                c[j] = fma(av, brow[j], c[j]);
-            for(oint j = n - rem; j < n; j++)
-                c[j] = fma(sv * brow[j], alpha, c[j]);
-        }
+#define DEF_CSRMM_ROW_KT(NAME, T, FMA)                                                                              \
+    int NAME(int psz, T alpha, int base, const T *val, const oint *col, const oint *row, oint m, const T *B, oint n, \
+             oint ldb, T beta, T *C, oint ldc)                                                                      \
+    {                                                                                                               \
+        oint rem = n % psz;                                                                                         \
+        for(oint i = 0; i < m; i++)                                                                                 \
+        {                                                                                                           \
+            T *c = C + (size_t)i * ldc;                                                                             \
+            for(oint j = 0; j < n; j++)                                                                             \
+                c[j] = c[j] * beta;                                                                                 \
+            for(oint k = row[i] - base; k < row[i + 1] - base; k++)                                                 \
+            {                                                                                                       \
+                const T *brow = B + (size_t)(col[k] - base) * ldb;                                                  \
+                T        sv = val[k], av = alpha * sv;                                                              \
+                for(oint j = 0; j < n - rem; j++)                                                                   \
+                    c[j] = FMA(av, brow[j], c[j]);                                                                  \
+                for(oint j = n - rem; j < n; j++)                                                                   \
+                    c[j] = FMA(sv * brow[j], alpha, c[j]);                                                          \
+            }                                                                                                       \
+        }                                                                                                           \
+        return ORC_SUCCESS;                                                                                         \
     }
-    return ORC_SUCCESS;
-}
+DEF_CSRMM_ROW_KT(orc_dcsrmm_row_kt, double, fma)
+DEF_CSRMM_ROW_KT(orc_scsrmm_row_kt, float, fmaf)
 
 /* csrmm.hpp:361-427: beta==0 writes exact zeros, otherwise C *= beta. */
 int orc_dscale_dense(int order, double *C, oint m, oint n, oint ld, double beta)

@@ -154,6 +154,11 @@ int orc_dcsrmm_col_kt(int psz, double alpha, int base, const double *val, const 
 int orc_dcsrmm_row_kt(int psz, double alpha, int base, const double *val, const oint *col,
                       const oint *row, oint m, const double *B, oint n, oint ldb, double beta,
                       double *C, oint ldc);
+/* float twins: psz = 8 (256-bit, kid 1/2) or 16 (512-bit, kid 3) */
+int orc_scsrmm_col_kt(int psz, float alpha, int base, const float *val, const oint *col, const oint *row, oint m,
+                      const float *B, oint n, oint ldb, float beta, float *C, oint ldc);
+int orc_scsrmm_row_kt(int psz, float alpha, int base, const float *val, const oint *col, const oint *row, oint m,
+                      const float *B, oint n, oint ldb, float beta, float *C, oint ldc);
 /* order: 0 row-major, 1 column-major (aoclsparse_types.h:289-293). */
 int orc_dscale_dense(int order, double *C, oint m, oint n, oint ld, double beta);
 

@@ -202,4 +202,28 @@ int ktref_csrmm_row_d(int bits, int nnz, const double *a, const double *B, int l
     csrmm_row<bsz::b512, double>(nnz, a, B, ldb, icol, n, alpha, beta, c);
     return 0;
 }
+
+float ktref_csrmm_col_elem_s(int bits, int nnz, const float *a, const float *bcol, const int *icol, float alpha, float beta,
+                             float c)
+{
+    if(bits == 256)
+        return csrmm_col_elem<bsz::b256, float>(nnz, a, bcol, icol, alpha, beta, c);
+    if(!have512())
+        return std::nanf("");
+    return csrmm_col_elem<bsz::b512, float>(nnz, a, bcol, icol, alpha, beta, c);
+}
+
+int ktref_csrmm_row_s(int bits, int nnz, const float *a, const float *B, int ldb, const int *icol, int n, float alpha,
+                      float beta, float *c)
+{
+    if(bits == 256)
+    {
+        csrmm_row<bsz::b256, float>(nnz, a, B, ldb, icol, n, alpha, beta, c);
+        return 0;
+    }
+    if(!have512())
+        return 1;
+    csrmm_row<bsz::b512, float>(nnz, a, B, ldb, icol, n, alpha, beta, c);
+    return 0;
+}
 }

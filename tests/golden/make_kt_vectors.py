@@ -111,11 +111,42 @@ def main():
                 row.append(dict(psz=psz, n=n, nnz=nnz, k=k, a=hx(a[:nnz]), B=hx(B), icol=[int(v) for v in icol[:nnz]],
                                 alpha=hx([alpha])[0], beta=hx([beta])[0], c0=hx(c0), out=hx(c)))
     out["csrmm_row"] = row
+
+    # float csrmm (added later in round 3): its own generator, so that every vector above keeps the bits it was committed with
+    rngs = np.random.default_rng(20261003)
+    f32 = np.float32
+    cols = []
+    for bits, psz in ((256, 8), (512, 16)):
+        for nnz in list(range(0, 2 * psz + 3)) + [5 * psz + 5]:
+            a, b = rnd(rngs, max(nnz, 1), f32), rnd(rngs, nnz + 2, f32)
+            icol = rngs.permutation(nnz + 2)[:max(nnz, 1)].astype(np.int32)
+            for alpha, beta in ((f32(1.0), f32(0.0)), (rnd(rngs, 1, f32)[0], rnd(rngs, 1, f32)[0])):
+                c0 = rnd(rngs, 1, f32)[0]
+                r = f32(L.ktref_csrmm_col_elem_s(ci(bits), ci(nnz), p(a), p(b), p(icol), cf(alpha), cf(beta), cf(c0)))
+                cols.append(dict(psz=psz, nnz=nnz, a=hx(a[:nnz]), b=hx(b), icol=[int(c) for c in icol[:nnz]],
+                                 alpha=hx(np.array([alpha], f32))[0], beta=hx(np.array([beta], f32))[0],
+                                 c0=hx(np.array([c0], f32))[0], out=hx(np.array([r], f32))[0]))
+    out["csrmm_col_s"] = cols
+    rows_s = []
+    for bits, psz in ((256, 8), (512, 16)):
+        for n in (1, 7, 8, 9, 15, 16, 17, 35):
+            for nnz in (0, 1, 3, 4, 6, 9):
+                k = nnz + 2
+                a, B = rnd(rngs, max(nnz, 1), f32), rnd(rngs, k * n, f32)
+                icol = rngs.permutation(k)[:max(nnz, 1)].astype(np.int32)
+                alpha, beta = rnd(rngs, 2, f32)
+                c = rnd(rngs, n, f32)
+                c0 = c.copy()
+                st = L.ktref_csrmm_row_s(ci(bits), ci(nnz), p(a), p(B), ci(n), p(icol), ci(n), cf(alpha), cf(beta), p(c))
+                assert st == 0
+                rows_s.append(dict(psz=psz, n=n, nnz=nnz, k=k, a=hx(a[:nnz]), B=hx(B), icol=[int(v) for v in icol[:nnz]],
+                                   alpha=hx(np.array([alpha], f32))[0], beta=hx(np.array([beta], f32))[0], c0=hx(c0), out=hx(c)))
+    out["csrmm_row_s"] = rows_s
     path = os.path.join(HERE, "kt_vectors.json")
     with open(path, "w") as f:
         json.dump(out, f, separators=(",", ":"))
     print("wrote", path, os.path.getsize(path), "bytes;", len(hs), "hsum/dot,", len(rows), "trsv rows,", len(col),
-          "csrmm col,", len(row), "csrmm row")
+          "csrmm col,", len(row), "csrmm row,", len(cols), "float csrmm col,", len(rows_s), "float csrmm row")
 
 
 if __name__ == "__main__":

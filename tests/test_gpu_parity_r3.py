@@ -317,6 +317,43 @@ def test_csrmm_within_bound_of_the_kt_orders(n, alpha, beta):
                         assert np.array_equal(got, ref), (oname, kid, psz)
 
 
+@pytest.mark.parametrize("n", [7, 16, 35])
+def test_float_csrmm_kid_reproduces_the_kt_orders(n):
+    """aoclsparse_scsrmm_kid: kid 1 / 2 -> the 8-lane (256-bit) float KT kernels, kid 3 -> the 16-lane (512-bit) ones, both layouts,
+    bit for bit against the restatement pinned on the reference's own templates (tests/golden/kt_vectors.json: csrmm_col_s,
+    csrmm_row_s); every kid within (len + 4) eps32 |alpha| sum |a b| + 3 eps32 |beta c| of every order."""
+    f32 = np.float32
+    eps32 = float(np.finfo(f32).eps)
+    m, k = 400, 350
+    rp, ci, v = random_csr(91, m, k, lambda r, i: r.integers(0, 50))
+    v = v.astype(f32)
+    A = P.Matrix(0, m, k, rp, ci, v)  # float32 values -> aoclsparse_create_scsr
+    d = P.Descr()
+    rng = np.random.default_rng(19)
+    lens = np.diff(rp)
+    absA = dense_of(m, k, 0, rp, ci, np.abs(v).astype(np.float64))
+    for alpha, beta in ((f32(1.0), f32(0.0)), (f32(-2.5), f32(0.75))):
+        for order, oname in ((P.ORDER_COLUMN, "col"), (P.ORDER_ROW, "row")):
+            ldb, ldc = (k, m) if oname == "col" else (n, n)
+            B = rng.uniform(-1, 1, k * n).astype(f32)
+            C0 = rng.uniform(-1, 1, m * n).astype(f32)
+            Bm = B.reshape(n, k).T if oname == "col" else B.reshape(k, n)
+            Cm = C0.reshape(n, m).T if oname == "col" else C0.reshape(m, n)
+            bound = ((lens[:, None] + 4) * eps32 * abs(float(alpha)) * (absA @ np.abs(Bm.astype(np.float64)))
+                     + 3 * eps32 * np.abs(float(beta) * Cm.astype(np.float64)))
+            for kid in (0, 1, 2, 3):
+                C = C0.copy()
+                assert P.scsrmm(P.OP_NONE, float(alpha), A, d, order, B, n, ldb, float(beta), C, ldc, kid=kid) == 0
+                got = C.reshape(n, m).T if oname == "col" else C.reshape(m, n)
+                for psz in (8, 16):
+                    st, Ck = oracle.scsrmm_kt(oname, psz, float(alpha), 0, v, ci, rp, m, B, n, ldb, float(beta), C0, ldc)
+                    assert st == 0
+                    ref = Ck.reshape(n, m).T if oname == "col" else Ck.reshape(m, n)
+                    assert np.all(np.abs(got.astype(np.float64) - ref.astype(np.float64)) <= bound + 1e-30), (oname, kid, psz)
+                    if psz == {1: 8, 2: 8, 3: 16}.get(kid):
+                        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (oname, kid, psz, float(alpha))
+
+
 def test_spmv_within_bound_of_the_gcc_build_orders():
     """The GPU SpMV reproduces the FUSED build of the reference bit for bit (test_gpu_parity.py).  Against the GCC -march=znver2
     build, whose scalar loops round the product and the sum separately (oracle.c header), the stated tolerance is

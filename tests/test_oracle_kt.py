@@ -148,6 +148,37 @@ def test_kt_csrmm_rows_match_the_reference_sequence(ktv):
         assert st == 0 and bits_equal(C, unhex(c["out"])), (c["psz"], n, nnz)
 
 
+def test_kt_float_csrmm_matches_the_reference_sequence(ktv):
+    # the float instances of the same two templates: 8 lanes (256-bit) and 16 lanes (512-bit)
+    f32 = np.float32
+    seen = set()
+    for c in ktv["csrmm_col_s"]:
+        a, b = unhex(c["a"], f32), unhex(c["b"], f32)
+        alpha, beta, c0 = unhex(c["alpha"], f32)[0], unhex(c["beta"], f32)[0], unhex(c["c0"], f32)[0]
+        nnz = c["nnz"]
+        row = np.array([0, nnz], np.int32)
+        col = np.array(c["icol"] if nnz else [0], np.int32)
+        args = ("col", c["psz"], alpha, 0, a if nnz else np.zeros(1, f32), col, row, 1, b, 1, len(b), beta, np.array([c0], f32), 1)
+        with oracle.contract(False):
+            st, C = oracle.scsrmm_kt(*args)
+        assert st == 0 and bits_equal(C, unhex(c["out"], f32)), (c["psz"], nnz)
+        if nnz % c["psz"] == 0 and alpha == 1.0 and beta == 0.0:
+            st, C = oracle.scsrmm_kt(*args)
+            assert st == 0 and bits_equal(C, unhex(c["out"], f32)), (c["psz"], nnz, "fused")
+        seen.add((c["psz"], nnz >= c["psz"], nnz % c["psz"] != 0))
+    for psz in (8, 16):
+        assert {(psz, True, True), (psz, True, False), (psz, False, True)} <= seen
+    for c in ktv["csrmm_row_s"]:
+        a, B = unhex(c["a"], f32), unhex(c["B"], f32)
+        alpha, beta = unhex(c["alpha"], f32)[0], unhex(c["beta"], f32)[0]
+        n, nnz = c["n"], c["nnz"]
+        row = np.array([0, nnz], np.int32)
+        col = np.array(c["icol"] if nnz else [0], np.int32)
+        st, C = oracle.scsrmm_kt("row", c["psz"], alpha, 0, a if nnz else np.zeros(1, f32), col, row, 1, B, n, n, beta,
+                                 unhex(c["c0"], f32), n)
+        assert st == 0 and bits_equal(C, unhex(c["out"], f32)), (c["psz"], n, nnz)
+
+
 def test_kt_csrmm_reads_c_when_beta_is_zero():
     # csrmm_kt.cpp:176-191, :246: beta*C is computed even for beta == 0, so NaN / Inf in C propagate
     val, col, row = np.array([2.0]), np.array([0], np.int32), np.array([0, 1], np.int32)
