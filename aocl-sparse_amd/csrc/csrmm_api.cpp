@@ -560,6 +560,44 @@ static aoclsparse_status csrmm_shard_t(aoclsparse_operation op, const T alpha, c
 // no collective on the data path, and A reaches every device once, when its replica is built (hints are copied and
 // aoclsparse_optimize runs under the slot: the host analysis runs on `ndev` threads at the same time and every device
 // fills its copy over its own PCIe link).
+// The device state a csrmm needs (CSR arrays, row-block plan, whatever csrmm plans the primary handle has already built),
+// copied device to device onto the CURRENT slot's device: what SURVEY 8e calls "A replicated in its device format once".
+// Parts the primary has not built stay unbuilt and are made on first use on the replica's device, as on any handle.
+static aoclsparse_status clone_mm_state(const _aoclsparse_matrix &A, _aoclsparse_matrix &R, hipStream_t s)
+{
+    const DeviceCsr &a = A.dev_user;
+    DeviceCsr       &r = R.dev_user;
+    aoclsparse_status st;
+#define MI355_CLONE(dst, src)                                 \
+    if((st = (dst).clone_from((src), s)) != aoclsparse_status_success) \
+    return st
+    MI355_CLONE(r.ptr, a.ptr);
+    MI355_CLONE(r.ind, a.ind);
+    MI355_CLONE(r.val, a.val);
+    r.m = a.m, r.n = a.n, r.nnz = a.nnz, r.base = a.base;
+    const SpmvPlan &pa = A.plan_user;
+    SpmvPlan       &pr = R.plan_user;
+    pr.nblocks = pa.nblocks, pr.long_rows = pa.long_rows, pr.max_row_nnz = pa.max_row_nnz, pr.tile = pa.tile;
+    MI355_CLONE(pr.rowblocks, pa.rowblocks);
+    MI355_CLONE(pr.rowblocks4, pa.rowblocks4);
+    pr.heavy_first = pa.heavy_first;
+    // (the SELL-64 and merge-path copies serve ?mv only: not cloned, marked untried, built lazily if the replica ever needs them)
+    const MmGroups &ga = pa.mm;
+    MmGroups       &gr = pr.mm;
+    gr.runs_tried = ga.runs_tried, gr.row_runs = ga.row_runs, gr.band = ga.band;
+    MI355_CLONE(gr.run_order, ga.run_order);
+    gr.ngroups = ga.ngroups, gr.max_rows = ga.max_rows, gr.valid = ga.valid, gr.tried = ga.tried;
+    MI355_CLONE(gr.first, ga.first);
+    gr.pairs_tried = ga.pairs_tried, gr.pairs = ga.pairs, gr.npairs = ga.npairs, gr.nsingles = ga.nsingles;
+    MI355_CLONE(gr.pair_first, ga.pair_first);
+    MI355_CLONE(gr.single_rows, ga.single_rows);
+#undef MI355_CLONE
+    MI355_HIP_TRY(hipStreamSynchronize(s));
+    r.valid  = true;
+    pr.valid = true;
+    return aoclsparse_status_success;
+}
+
 static aoclsparse_status get_replica(aoclsparse_matrix A, int slot_idx, aoclsparse_matrix &out)
 {
     out = nullptr;
@@ -581,7 +619,42 @@ static aoclsparse_status get_replica(aoclsparse_matrix A, int slot_idx, aoclspar
         return st;
     R->hints      = A->hints;
     R->mem_policy = A->mem_policy;
-    st            = aoclsparse_optimize(R); // device copy + plans on the CURRENT slot's device
+    // Fast path: the primary handle already holds its device format (set_mm_hint + optimize, or an earlier product) -> peer copy.
+    // Otherwise the replica analyses its own copy (every device at the same time).
+    bool cloned = false;
+    {
+        std::shared_lock<std::shared_mutex> r(A->guard);
+        if(A->dev_user.valid && A->plan_user.valid && A->mem_policy == aoclsparse_memory_usage_unrestricted)
+        {
+            Runtime &rt = Runtime::get(), &pr = Runtime::primary();
+            if(rt.init() == aoclsparse_status_success)
+            {
+                // whatever the primary still has in flight on its stream (uploads of the plan) must have landed
+                (void)hipStreamSynchronize(pr.stream());
+                if(rt.device != pr.device)
+                {
+                    int can = 0;
+                    if(hipDeviceCanAccessPeer(&can, rt.device, pr.device) == hipSuccess && can)
+                        (void)hipDeviceEnablePeerAccess(pr.device, 0); // "already enabled" is fine
+                    (void)hipGetLastError();
+                }
+                cloned = clone_mm_state(*A, *R, rt.stream()) == aoclsparse_status_success;
+                if(!cloned)
+                {
+                    (void)hipGetLastError();
+                    R->dev_user.valid = R->plan_user.valid = false;
+                }
+            }
+        }
+    }
+    if(cloned)
+    {
+        for(Hint &h : R->hints)
+            h.optimized = true;
+        st = aoclsparse_status_success;
+    }
+    else
+        st = aoclsparse_optimize(R); // device copy + plans on the CURRENT slot's device
     if(st != aoclsparse_status_success)
     {
         aoclsparse_destroy(&R);
@@ -599,6 +672,7 @@ static aoclsparse_status get_replica(aoclsparse_matrix A, int slot_idx, aoclspar
         return aoclsparse_status_success;
     }
     A->replicas[slot_idx] = R;
+    A->replicas_cloned += cloned ? 1 : 0;
     out                   = R;
     return aoclsparse_status_success;
 }
@@ -781,6 +855,14 @@ aoclsparse_int aoclsparse_mi355_replica_count(const aoclsparse_matrix A)
     for(auto &p : A->replicas)
         c += p != nullptr;
     return c;
+}
+
+aoclsparse_int aoclsparse_mi355_replicas_cloned(const aoclsparse_matrix A)
+{
+    if(!A)
+        return -1;
+    std::shared_lock<std::shared_mutex> r(A->guard);
+    return A->replicas_cloned;
 }
 
 aoclsparse_status aoclsparse_mi355_scsrmm_shard(aoclsparse_operation op, const float alpha, const aoclsparse_matrix A,

@@ -230,6 +230,9 @@ struct DeviceBuffer
     ~DeviceBuffer();
     aoclsparse_status alloc(size_t nbytes);
     aoclsparse_status upload(const void *host, size_t nbytes, hipStream_t s); // alloc + H2D
+    // alloc on the CURRENT device + device-to-device copy of src (which may live on another device: peer copy over xGMI when
+    // peer access is enabled, staged by the runtime otherwise); enqueued on s, not waited for
+    aoclsparse_status clone_from(const DeviceBuffer &src, hipStream_t s);
     void              release();
     template <typename T>
     T *as() const
@@ -466,6 +469,7 @@ struct _aoclsparse_matrix
     // and plans live on the device of runtime slot i (slot 0 is this handle itself); built on first use, dropped by
     // aoclsparse_mi355_invalidate / ?set_value / ?update_values and by aoclsparse_destroy
     std::vector<aoclsparse_matrix> replicas;
+    int                            replicas_cloned = 0; // of them: device state copied device to device instead of re-analysed
 
     mutable std::shared_mutex guard;
 };

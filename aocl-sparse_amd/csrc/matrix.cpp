@@ -1106,6 +1106,7 @@ aoclsparse_status aoclsparse_mi355_invalidate(aoclsparse_matrix A)
     for(auto &r : A->replicas) // the replicas on other devices mirror the same arrays: rebuilt on the next multi-device call
         if(r)
             aoclsparse_destroy(&r);
+    A->replicas_cloned = 0;
     A->dev_user.valid = A->dev_trans.valid = false;
     A->plan_user.valid = A->plan_trans.valid = false;
     A->plan_user.sell.valid = A->plan_user.sell.tried = false;
@@ -1144,6 +1145,7 @@ void drop_derived_state(aoclsparse_matrix A)
     for(auto &r : A->replicas) // multi-device replicas hold device copies of the old values
         if(r)
             aoclsparse_destroy(&r);
+    A->replicas_cloned = 0;
     A->dev_user.valid = A->dev_trans.valid = false; // row-block plans stay valid: structure is unchanged
     A->plan_user.sell.valid = A->plan_user.sell.tried = false; // the SELL copies hold values: rebuilt on optimize
     A->plan_trans.sell.valid = A->plan_trans.sell.tried = false;

@@ -68,6 +68,20 @@ aoclsparse_status DeviceBuffer::upload(const void *host, size_t nbytes, hipStrea
     return aoclsparse_status_success;
 }
 
+aoclsparse_status DeviceBuffer::clone_from(const DeviceBuffer &src, hipStream_t s)
+{
+    if(!src.ptr || !src.bytes)
+    {
+        release();
+        return aoclsparse_status_success;
+    }
+    aoclsparse_status st = alloc(src.bytes);
+    if(st != aoclsparse_status_success)
+        return st;
+    MI355_HIP_TRY(hipMemcpyAsync(ptr, src.ptr, src.bytes, hipMemcpyDeviceToDevice, s));
+    return aoclsparse_status_success;
+}
+
 HostCsr::~HostCsr()
 {
     if(owned)

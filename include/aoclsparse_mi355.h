@@ -100,6 +100,9 @@ DLL_PUBLIC aoclsparse_status aoclsparse_mi355_dcsrmm_multi_slabs(aoclsparse_oper
 
 /* replicas of the handle currently alive on other runtime slots (0 before the first multi-device call); -1 for NULL */
 DLL_PUBLIC aoclsparse_int aoclsparse_mi355_replica_count(const aoclsparse_matrix A);
+/* ... of which built by copying the primary handle's device format device to device (peer copy over xGMI) instead of analysing
+ * the host arrays again: the case when the handle was optimized (or used) before its first multi-device call; -1 for NULL */
+DLL_PUBLIC aoclsparse_int aoclsparse_mi355_replicas_cloned(const aoclsparse_matrix A);
 
 /* ---- introspection of a handle --------------------------------------------------------- */
 /* idiag / iurow of the clean CSR (host arrays owned by the handle, length m, matrix base);

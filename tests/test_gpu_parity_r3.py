@@ -408,6 +408,9 @@ def test_csrmm_multi_device_entry_points_on_one_gpu(order):
             C = C0.copy()
             assert P.dcsrmm_multi(P.OP_NONE, alpha, A, d, o, B, n, ldb, beta, C, ldc, [dev0] * ndev) == 0, ndev
             assert np.array_equal(C, ref), (ndev, alpha, beta)
+        # the handle was optimized before its first multi-device call: every replica is a device-to-device copy of its device
+        # format ("A replicated in its device format once"), none re-analysed the host arrays
+        assert L.aoclsparse_mi355_replica_count(A.h) == 11 and L.aoclsparse_mi355_replicas_cloned(A.h) == 11
         # slabs resident on the device(s)
         ndev = 3
         shards = [P.column_shard(n, ndev, r) for r in range(ndev)]
@@ -434,6 +437,13 @@ def test_csrmm_multi_device_entry_points_on_one_gpu(order):
                            0.0, C0 if colmaj else np.ascontiguousarray(C0.reshape(m, n).T).ravel(), m)
     got = C if colmaj else np.ascontiguousarray(C.reshape(m, n).T).ravel()
     assert np.array_equal(got, Cr)
+    assert L.aoclsparse_mi355_replica_count(A.h) == 1  # dropped by the value update, one rebuilt by the two-slot call
+    # a handle that was never optimized nor used: its replicas are built whichever way the race with slot 0 goes (slot 0
+    # uploads the primary copy while the workers start) -- the result is the same
+    A2 = P.Matrix(0, m, k, rp, ci, v2)
+    C = C0.copy()
+    assert P.dcsrmm_multi(P.OP_NONE, 1.0, A2, d, o, B, n, ldb, 0.0, C, ldc, [dev0] * 4) == 0
+    assert np.array_equal(C, ref) and 0 <= L.aoclsparse_mi355_replicas_cloned(A2.h) <= 3
     # argument errors
     assert P.dcsrmm_multi(P.OP_NONE, 1.0, A, d, o, B, n, ldb, 0.0, C, ldc, [dev0 + 1]) != 0      # slot 0 must be the library's device
     assert L.aoclsparse_mi355_dcsrmm_multi(P.OP_NONE, 1.0, A.h, d.h, o, P._ptr(B), n, ldb, 0.0, P._ptr(C), ldc, 0, None) != 0

@@ -111,6 +111,7 @@ def main():
                       "cols_per_device": widths, "ms_wall_median": round(tn, 4), "ms_wall_min": round(min(laps), 4),
                       "ms_one_device_wall_median": round(t1, 4), "efficiency_wall": round(t1 / (n * tn), 4),
                       "first_call_ms_with_replica_build": round(t_first * 1e3, 1), "replicas": int(L.aoclsparse_mi355_replica_count(A.h)),
+                      "replicas_cloned_device_to_device": int(L.aoclsparse_mi355_replicas_cloned(A.h)),
                       "slabs_bit_identical_to_one_device": same,
                       "note": "wall clock around the call: thread start, launches and the per-device stream synchronisation "
                               "are inside; beta = 0 with C read (default)"}))
