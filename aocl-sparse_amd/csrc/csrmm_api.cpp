@@ -3,6 +3,8 @@
 #include "internal.hpp"
 
 #include <system_error>
+#include <condition_variable>
+#include <functional>
 #include <thread>
 
 #include <algorithm>
@@ -677,6 +679,97 @@ static aoclsparse_status get_replica(aoclsparse_matrix A, int slot_idx, aoclspar
     return aoclsparse_status_success;
 }
 
+// One persistent worker thread per runtime slot (>= 1): a multi-device call posts slot i's share to worker i and runs slot 0's
+// itself.  Starting a std::thread per device and call cost ~0.15 ms per call -- as much as the 32-column slab of the 8-device
+// job runs on its GPU.  A worker that has just finished a job spins for a few tens of microseconds before it sleeps, so calls
+// issued back to back (an iterative caller) hand over without a futex round trip.  Workers and their mailboxes live for the life
+// of the process (leaked on purpose: a sleeping detached thread must never see its condition variable destroyed).
+namespace
+{
+    struct SlotWorker
+    {
+        std::mutex                          m;
+        std::condition_variable             cv;
+        std::atomic<std::function<void()> *> job{nullptr};
+        std::atomic<bool>                   busy{false};
+        bool                                started = false;
+    };
+    std::mutex g_multi_call; // one multi-device call at a time (the workers are a shared resource)
+
+    void spin_pause()
+    {
+        __builtin_ia32_pause();
+    }
+
+    void slot_worker_loop(SlotWorker *w)
+    {
+        for(;;)
+        {
+            std::function<void()> *j = nullptr;
+            for(int spin = 0; spin < 20000 && !(j = w->job.load(std::memory_order_acquire)); spin++)
+                spin_pause();
+            if(!j)
+            {
+                std::unique_lock<std::mutex> l(w->m);
+                w->cv.wait(l, [&] { return w->job.load(std::memory_order_acquire) != nullptr; });
+                j = w->job.load(std::memory_order_acquire);
+            }
+            (*j)();
+            {
+                std::lock_guard<std::mutex> l(w->m);
+                w->job.store(nullptr, std::memory_order_release);
+                w->busy.store(false, std::memory_order_release);
+            }
+            w->cv.notify_all();
+        }
+    }
+
+    // worker of slot idx (1..63), started on first use; nullptr when no thread can be had
+    SlotWorker *slot_worker(int idx)
+    {
+        static std::mutex  m;
+        static SlotWorker *workers[64] = {nullptr};
+        std::lock_guard<std::mutex> g(m);
+        if(!workers[idx])
+            workers[idx] = new(std::nothrow) SlotWorker;
+        SlotWorker *w = workers[idx];
+        if(w && !w->started)
+        {
+            try
+            {
+                std::thread(slot_worker_loop, w).detach();
+                w->started = true;
+            }
+            catch(const std::system_error &)
+            {
+                return nullptr;
+            }
+        }
+        return w;
+    }
+
+    void post(SlotWorker *w, std::function<void()> *job)
+    {
+        {
+            std::lock_guard<std::mutex> l(w->m);
+            w->busy.store(true, std::memory_order_release);
+            w->job.store(job, std::memory_order_release);
+        }
+        w->cv.notify_all();
+    }
+
+    void wait_done(SlotWorker *w)
+    {
+        for(int spin = 0; spin < 20000 && w->busy.load(std::memory_order_acquire); spin++)
+            spin_pause();
+        if(w->busy.load(std::memory_order_acquire))
+        {
+            std::unique_lock<std::mutex> l(w->m);
+            w->cv.wait(l, [&] { return !w->busy.load(std::memory_order_acquire); });
+        }
+    }
+} // namespace
+
 // slabs == false: B / C are the FULL operands (host memory, or memory every device can address); device i computes columns
 // [j0_i, j1_i).  slabs == true: Bs[i] / Cs[i] are device i's own slabs (device memory there), n_i = its shard width.
 template <typename T>
@@ -770,22 +863,27 @@ static aoclsparse_status csrmm_multi_t(aoclsparse_operation op, const T alpha, c
             res[i] = aoclsparse_status_internal_error;
         }
     };
-    std::vector<std::thread> th;
-    th.reserve((size_t)ndev);
-    for(int i = 1; i < ndev; i++)
     {
-        try
+        std::lock_guard<std::mutex>        one_call(g_multi_call);
+        std::vector<std::function<void()>> jobs((size_t)ndev);
+        std::vector<SlotWorker *>          posted;
+        posted.reserve((size_t)ndev);
+        for(int i = 1; i < ndev; i++)
         {
-            th.emplace_back(work, i);
+            SlotWorker *w = slot_worker(i);
+            if(!w)
+            {
+                work(i); // no thread to be had: this device's share runs from here
+                continue;
+            }
+            jobs[(size_t)i] = [&work, i] { work(i); };
+            post(w, &jobs[(size_t)i]);
+            posted.push_back(w);
         }
-        catch(const std::system_error &)
-        {
-            work(i); // no thread to be had: this device's share runs from here, after the others were started
-        }
+        work(0);
+        for(SlotWorker *w : posted)
+            wait_done(w);
     }
-    work(0);
-    for(auto &t : th)
-        t.join();
     for(int i = 0; i < ndev; i++)
         if(res[i] != aoclsparse_status_success)
             return res[i];

@@ -3,8 +3,8 @@
 
   multi_check.py [--devices N] [--cols 256] [--grid 1000] [--layout row|col] [--reps 10] [--same-device]
 
-Prints one JSON line: per-call wall time with N devices (every call returns when all devices are done: thread start +
-launch + per-device stream synchronisation are inside it), the 1-device time of the same job, T1 / (N * TN), and whether
+Prints one JSON line: per-call wall time with N devices (every call returns when all devices are done: the hand-over to the slot
+workers, the launches and the per-device stream synchronisation are inside it), the 1-device time of the same job, T1 / (N * TN), and whether
 every device's slab equals the 1-device product bit for bit.  --same-device puts all N slots on device 0 (what a one-GPU
 box can run: the control flow, not the speed-up).  bench.py runs this as a CHILD process when it sees more than one GPU, with a
 timeout, so that a problem on a multi-GPU node cannot take the bench line down with it.
@@ -113,8 +113,8 @@ def main():
                       "first_call_ms_with_replica_build": round(t_first * 1e3, 1), "replicas": int(L.aoclsparse_mi355_replica_count(A.h)),
                       "replicas_cloned_device_to_device": int(L.aoclsparse_mi355_replicas_cloned(A.h)),
                       "slabs_bit_identical_to_one_device": same,
-                      "note": "wall clock around the call: thread start, launches and the per-device stream synchronisation "
-                              "are inside; beta = 0 with C read (default)"}))
+                      "note": "wall clock around the call: the hand-over to the persistent slot workers, launches and the per-device "
+                              "stream synchronisation are inside; beta = 0 with C read (default)"}))
 
 
 if __name__ == "__main__":
