@@ -660,7 +660,8 @@ template <typename T>
 aoclsparse_status launch_sellmv(hipStream_t s, int order, int pack, T alpha, aoclsparse_int m, aoclsparse_int nslices,
                                 const long long *slice_ptr, const T *sval, const aoclsparse_int *scol,
                                 const aoclsparse_int *rowlen, const T *x, T beta, T *y, const long long *cptr = nullptr,
-                                const unsigned short *lead = nullptr);
+                                const unsigned short *lead = nullptr,
+                                aoclsparse_int max_width = 0);
 // BLKCSR (blk_kernels.hip): value offset of every block (three small launches: per-chunk popcount scan, scan of
 // the chunk totals in part[], add), then the product
 constexpr int     BLK_PART_SHIFT = 10;

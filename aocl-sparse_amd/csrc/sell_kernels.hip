@@ -17,6 +17,8 @@
 // gathers; cells <= 1.15 nnz or the handle stays on the CSR-Adaptive kernel (matrix.cpp: build_sell).
 #include "internal.hpp"
 
+#include <type_traits>
+
 #include <hip/hip_runtime.h>
 
 namespace mi355
@@ -299,7 +301,34 @@ __global__ __launch_bounds__(64 * WAVES) void sell_mv_kernel(aoclsparse_int m, a
         // short rows (this is the layout of matrices with < 16 non-zeros per row): four independent line loads
         // per step, then the gathers, then the chain.  Measured on the 4096^2 Laplacian (w = 5): 0.218 ms;
         // 8-wide, guard-predicated or software-pipelined steps 0.223-0.26 ms (profiles/r1)
+        // Widths up to 8 (round 3): ONE batch of exactly w line loads, then the w gathers, then the chain -- the wave's life is
+        // three dependent round trips (slice words -> value / column lines -> x) whatever w is.  The 4-step loop below spent
+        // five on a 5-wide slice (4 + 1 entries: lines, gathers, lines, gathers), and the kernel is bound by wave lifetime x
+        // occupancy, not by bytes in flight (same box: 0.1845-0.186 -> 0.1786-0.1793 ms, profiles/r3/sell_width_switch.txt).
         int p = 0;
+        auto batch = [&](auto wtag) {
+            constexpr int W = decltype(wtag)::value;
+            T             vv[W], xx[W];
+            int           cc[W];
+#pragma unroll
+            for(int q = 0; q < W; q++)
+                vv[q] = v[q * 64], cc[q] = c[q * cs];
+#pragma unroll
+            for(int q = 0; q < W; q++)
+                xx[q] = x[cc[q] >= 0 ? cc[q] + dl : 0];
+#pragma unroll
+            for(int q = 0; q < W; q++)
+                r = cc[q] >= 0 ? s_fma(vv[q], xx[q], r) : r;
+            p = W;
+        };
+        switch(w) // wave-uniform
+        {
+        case 5: batch(std::integral_constant<int, 5>{}); break;
+        case 6: batch(std::integral_constant<int, 6>{}); break;
+        case 7: batch(std::integral_constant<int, 7>{}); break;
+        case 8: batch(std::integral_constant<int, 8>{}); break;
+        default: break;
+        }
         for(; p + 4 <= w; p += 4)
         {
             const T   v0 = v[(p + 0) * 64], v1 = v[(p + 1) * 64], v2 = v[(p + 2) * 64], v3 = v[(p + 3) * 64];
@@ -377,6 +406,102 @@ __global__ __launch_bounds__(64 * WAVES) void sell_mv_kernel(aoclsparse_int m, a
         s_store(y + i, s_finish(r, alpha, beta, y + i), nt);
 }
 
+// Short rows (round 3): matrices whose widest slice has WMAX <= 8 cells, scalar summation order, PACK 1, large launches.  ONE
+// batch of WMAX value / column line loads (index clamped to the slice's own width: no guard inside the batch; a narrower
+// boundary slice re-reads its last line and skips the FMA), then the WMAX gathers, then the chain: three dependent round trips
+// per slice, four slices per workgroup.  Same-box sweep on the headline workload (tools/exp_r3_short.sh,
+// profiles/r3/sell_width_switch.txt): general kernel before the width switch 0.1845-0.186 ms, with it 0.1786-0.1793, this
+// kernel with 1 / 2 / 4 slices per workgroup 0.180-0.181 / 0.180-0.181 / 0.1773-0.1779; TWO or more slices per WAVEFRONT
+// (walked together, twice the bytes in flight per wave) 0.183-0.236 ms -- more registers, fewer waves, no gain.
+template <typename T, int WMAX, int WAVES, bool SHARED>
+__global__ __launch_bounds__(64 * WAVES) void sell_mv_short_kernel(aoclsparse_int m, aoclsparse_int nslices,
+                                                                   const long long *__restrict__ slice_ptr,
+                                                                   const T *__restrict__ sval,
+                                                                   const aoclsparse_int *__restrict__ scol, T alpha,
+                                                                   const T *__restrict__ x, T beta, T *__restrict__ y, bool nt,
+                                                                   const long long *__restrict__ cptr,
+                                                                   const unsigned short *__restrict__ follow)
+{
+    const int s    = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + (threadIdx.x >> 6)));
+    const int lane = threadIdx.x & 63;
+    if(s >= nslices)
+        return;
+    const long long       o0 = slice_ptr[s];
+    const int             w  = (int)((slice_ptr[s + 1] - o0) >> 6);
+    const int             i  = s * 64 + lane;
+    const T              *v  = sval + o0 + lane;
+    const aoclsparse_int *c  = scol + o0 + lane;
+    int                   cs = 64, dl = 0;
+    if constexpr(SHARED)
+    {
+        const long long cw   = cptr[s];
+        const long long c0   = cw & SELL_CPTR_MASK;
+        const int       mode = (int)(cw >> SELL_CPTR_MODE_SHIFT);
+        int             f    = 0;
+        if(mode == 0)
+            f = i < m ? follow[i] : 0;
+        else if(mode == 1)
+            f = lane << 8;
+        cs = w > 0 ? (int)(((cptr[s + 1] & SELL_CPTR_MASK) - c0) / w) : 1;
+        c  = scol + c0 + (f & 0xff);
+        dl = f >> 8;
+    }
+    T   vv[WMAX], xx[WMAX];
+    int cc[WMAX];
+    if(w > 0) // (an empty slice has no cell to read)
+    {
+#pragma unroll
+        for(int q = 0; q < WMAX; q++)
+        {
+            const int qq = min(q, w - 1); // wave-uniform
+            vv[q]        = v[qq * 64];
+            cc[q]        = c[qq * cs];
+        }
+    }
+    else
+    {
+#pragma unroll
+        for(int q = 0; q < WMAX; q++)
+            vv[q] = T(0), cc[q] = -1;
+    }
+#pragma unroll
+    for(int q = 0; q < WMAX; q++)
+        xx[q] = x[cc[q] >= 0 ? cc[q] + dl : 0];
+    T r = T(0);
+#pragma unroll
+    for(int q = 0; q < WMAX; q++)
+        r = (q < w && cc[q] >= 0) ? s_fma(vv[q], xx[q], r) : r;
+    if(i < m)
+        s_store(y + i, s_finish(r, alpha, beta, y + i), nt);
+}
+
+template <typename T, bool SHARED>
+bool sell_launch_short(hipStream_t s, int wmax, aoclsparse_int m, aoclsparse_int nslices, const long long *slice_ptr, const T *sval,
+                       const aoclsparse_int *scol, T alpha, const T *x, T beta, T *y, bool nt, const long long *cptr,
+                       const unsigned short *lead)
+{
+    constexpr int WAVES = 4;
+    const dim3    grid((unsigned)((nslices + WAVES - 1) / WAVES)), block(64 * WAVES);
+#define MI355_SHORT(W)                                                                                                    \
+    case W:                                                                                                               \
+        hipLaunchKernelGGL((sell_mv_short_kernel<T, W, WAVES, SHARED>), grid, block, 0, s, m, nslices, slice_ptr, sval,     \
+                           scol, alpha, x, beta, y, nt, cptr, lead);                                                      \
+        return true
+    switch(wmax)
+    {
+        MI355_SHORT(1);
+        MI355_SHORT(2);
+        MI355_SHORT(3);
+        MI355_SHORT(4);
+        MI355_SHORT(5);
+        MI355_SHORT(6);
+        MI355_SHORT(7);
+        MI355_SHORT(8);
+    default: return false;
+    }
+#undef MI355_SHORT
+}
+
 template <typename T, int ORDER, int PACK>
 void sell_launch(hipStream_t s, aoclsparse_int m, aoclsparse_int nslices, const long long *slice_ptr, const T *sval,
                  const aoclsparse_int *scol, const aoclsparse_int *rowlen, T alpha, const T *x, T beta, T *y,
@@ -436,12 +561,25 @@ template <typename T>
 aoclsparse_status launch_sellmv(hipStream_t s, int order, int pack, T alpha, aoclsparse_int m, aoclsparse_int nslices,
                                 const long long *slice_ptr, const T *sval, const aoclsparse_int *scol,
                                 const aoclsparse_int *rowlen, const T *x, T beta, T *y, const long long *cptr,
-                                const unsigned short *lead)
+                                const unsigned short *lead, aoclsparse_int max_width)
 {
     if(m <= 0 || nslices <= 0)
         return aoclsparse_status_success;
     if(order < 0 || order > 2 || (pack != 1 && pack != 4))
         return aoclsparse_status_invalid_kid;
+    // widest slice <= 8 cells, scalar order, a launch large enough that four slices per workgroup still spread over every CU
+    if(order == 0 && pack == 1 && max_width >= 1 && max_width <= 8 && nslices >= 4096)
+    {
+        const bool nt   = (size_t)m * sizeof(T) > ((size_t)32 << 20);
+        const bool done = cptr ? sell_launch_short<T, true>(s, (int)max_width, m, nslices, slice_ptr, sval, scol, alpha, x, beta, y, nt, cptr, lead)
+                               : sell_launch_short<T, false>(s, (int)max_width, m, nslices, slice_ptr, sval, scol, alpha, x, beta, y, nt,
+                                                             nullptr, nullptr);
+        if(done)
+        {
+            MI355_HIP_TRY(hipGetLastError());
+            return aoclsparse_status_success;
+        }
+    }
 #define SELL_CASE(O, P)                                                                        \
     sell_launch<T, O, P>(s, m, nslices, slice_ptr, sval, scol, rowlen, alpha, x, beta, y, cptr, lead); \
     break
@@ -483,7 +621,7 @@ aoclsparse_status launch_sell_leaders(hipStream_t s, aoclsparse_int m, int base,
     template aoclsparse_status launch_sellmv<T>(hipStream_t, int, int, T, aoclsparse_int, aoclsparse_int,             \
                                                 const long long *, const T *, const aoclsparse_int *,                 \
                                                 const aoclsparse_int *, const T *, T, T *, const long long *,          \
-                                                const unsigned short *);
+                                                const unsigned short *, aoclsparse_int);
 MI355_SELL_INSTANTIATE(double)
 MI355_SELL_INSTANTIATE(float)
 

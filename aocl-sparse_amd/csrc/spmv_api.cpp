@@ -126,7 +126,7 @@ aoclsparse_status run_on_device_csr(Runtime &rt, aoclsparse_int kid, const Devic
                               plan.sell.val.as<T>(), plan.sell.col.as<aoclsparse_int>(),
                               plan.sell.rowlen.as<aoclsparse_int>(), static_cast<const T *>(ax.dev), beta,
                               static_cast<T *>(ay.dev), plan.sell.shared ? plan.sell.cptr.as<long long>() : nullptr,
-                              plan.sell.shared ? plan.sell.lead.as<unsigned short>() : nullptr);
+                              plan.sell.shared ? plan.sell.lead.as<unsigned short>() : nullptr, plan.max_row_nnz);
     else if(plan.merge.valid && order == 0 && !strict) // balanced tiles for irregular rows (scalar order, no pinned kid)
         st = launch_mergepath<T>(rt.stream(), d.base, alpha, plan.merge.ntiles, plan.merge.starts.as<aoclsparse_int>(),
                                  d.val.as<T>(), d.ind.as<aoclsparse_int>(), d.ptr.as<aoclsparse_int>(),
