@@ -990,6 +990,270 @@ __global__ __launch_bounds__(64) void trsv_block_kernel(
         __hip_atomic_store(timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ---- schedule 4 with the KT arithmetic (round 3) -----------------------------------------------------------------
+// kid 1 / 2 / 3 ask for the summation order of the reference's KT kernels (kt_trsv_l / kt_trsv_u, trsv_kt.cpp:64-150, :297-383):
+// full groups of TSZ entries into TSZ lane sums, the reference's horizontal tree, then a masked product vector for a remainder
+// of TSZ - 1 or the scalar chain.  The lane-per-position kernel serves that order but consumes a row's dependencies strictly one
+// after the other -- 15 dependent agent-scope loads per row even when all of them are published: 9-10 ms on the shell-like factor.
+// This kernel keeps the block kernel's protocol (one lane per block of chained rows, ticket, gate, ALL external dependencies
+// polled together) and replaces its fixed-shape FMA section by run-time loops over the block's entries, which sit in LDS in
+// chain order ([entry][lane]: conflict-free whatever entry each lane is at) next to the x values they multiply.
+template <typename T, int TSZ, bool FRONT>
+__global__ __launch_bounds__(64) void trsv_block_kt_kernel(
+    aoclsparse_int m, aoclsparse_int nslices, const aoclsparse_int *__restrict__ slices,
+    const aoclsparse_int *__restrict__ bfirst, const aoclsparse_int *__restrict__ rowmap,
+    const aoclsparse_int *__restrict__ pptr, const aoclsparse_int *__restrict__ pind, const T *__restrict__ pval,
+    const T *__restrict__ diag, const T *__restrict__ b, T *xp, T *x, T alpha, int unit, unsigned int *ticket,
+    unsigned int *timeout_flag, int incb, int incx, unsigned int *level_done, int gate, int nrhs, long long b_off,
+    long long x_off, int nlevels, unsigned long long *trace)
+{
+    using B = typename tag<T>::bits;
+    constexpr int BS = TRSV_BLK_ROWS, EXT = TRSV_BLK_EXT, NV = TRSV_BLK_NV;
+    __shared__ T s_val[NV][64]; // the block's entries, rows back to back, each row in chain (= CSR) order
+    // the x values a row multiplies, laid out so that row a's p-th entry meets s_xv[x0_a + p]: L (a row = [external in order,
+    // rows 0..a-1]): external e at e, row a's result at n0 + a, x0_a = 0; U (FRONT, a row = [rows a-1..0, external]): row a's
+    // result at BS - 1 - a, external e at BS + e, x0_a = BS - a.  Values and x are then walked with one induction variable.
+    __shared__ T s_xv[EXT + BS][64];
+    const int col   = nrhs > 1 ? (int)blockIdx.x : 0;
+    const int spare = m * (nrhs - col);
+    ticket += col, level_done += (size_t)col * nlevels;
+    b += col * b_off, x += col * x_off, xp += (size_t)col * m;
+    const int    tid = threadIdx.x;
+    unsigned int tk  = 0;
+    if(tid == 0)
+        tk = atomicAdd(ticket, 1u);
+    const int sl = __builtin_amdgcn_readfirstlane((int)tk);
+    if(sl >= nslices)
+        return;
+    const bool               tracing = trace != nullptr && col == 0; // (diagnostic: tools/trsv_trace.py)
+    const unsigned long long t_start = tracing ? __builtin_amdgcn_s_memrealtime() : 0;
+    const int  lev  = slices[nslices + 1 + sl];
+    const int  bl   = slices[sl] + tid;
+    const bool live = bl < slices[sl + 1];
+    const int  k0   = live ? bfirst[bl] : 0;
+    const int  c    = live ? bfirst[bl + 1] - k0 : 0;
+    const int  p0   = live ? pptr[k0] : 0;
+    const int  n0   = live ? pptr[k0 + 1] - p0 : 0; // external dependencies = the first row's entries
+    const int  nl   = n0 < EXT ? n0 : EXT;
+    const bool slow = n0 > EXT; // a single long row (never inside a multi-row block): its tail is polled entry by entry
+    B         *xb   = reinterpret_cast<B *>(xp);
+    int        q[EXT];
+#pragma unroll
+    for(int e = 0; e < EXT; e++)
+        q[e] = e < nl ? pind[p0 + e] : spare + TRSV_XP_PAD - 1; // beyond the row: a slot that always holds 0
+    // everything that does not need the dependencies: the block's values -> LDS (c n0 + c (c - 1) / 2 <= NV entries)
+    const int tot = slow ? 0 : c * n0 + (c * (c - 1)) / 2;
+    for(int j = 0; j < tot; j++)
+        s_val[j][tid] = pval[p0 + j];
+    T  rhs[BS], dg[BS];
+    T *xdst[BS];
+    B *bdst[BS];
+#pragma unroll
+    for(int a = 0; a < BS; a++)
+    {
+        const int row = a < c ? rowmap[k0 + a] : 0;
+        rhs[a]        = a < c ? alpha * b[(size_t)row * incb] : T(0);
+        dg[a]         = (a < c && !unit) ? diag[row] : T(1);
+        xdst[a]       = a < c ? x + (size_t)row * incx : xp + (size_t)spare + 64 + tid;
+        bdst[a]       = a < c ? xb + k0 + a : xb + (size_t)spare + tid;
+    }
+    unsigned long long t0    = 0;
+    bool               dead  = false;
+    unsigned int       spins = 0;
+    auto               tick  = [&](unsigned int every) {
+        if((++spins & every) == 0)
+        {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if(t0 == 0)
+                t0 = now;
+            else if(now - t0 > TRSV_WAIT_TICKS)
+                dead = true;
+        }
+    };
+    if(gate > 0 && lev >= gate)
+    {
+        const aoclsparse_int *lsl    = slices + 2 * (size_t)nslices + 1;
+        const unsigned int    target = (unsigned int)(lsl[lev - gate + 1] - lsl[lev - gate]);
+        while(__hip_atomic_load(&level_done[lev - gate], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && !dead)
+        {
+            __builtin_amdgcn_s_sleep(4);
+            tick(255u);
+        }
+    }
+    B bits[EXT];
+#pragma unroll
+    for(int e = 0; e < EXT; e++)
+        bits[e] = __hip_atomic_load(&xb[q[e]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for(;;)
+    {
+        unsigned long long miss[EXT], any = 0;
+#pragma unroll
+        for(int e = 0; e < EXT; e++)
+        {
+            miss[e] = __builtin_amdgcn_ballot_w64(bits[e] == tag<T>::value);
+            any |= miss[e];
+        }
+        if(any == 0 || __builtin_amdgcn_ballot_w64(dead) != 0)
+            break;
+        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for(int e = 0; e < EXT; e++)
+            if(miss[e] != 0)
+                bits[e] = __hip_atomic_load(&xb[q[e]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tick(127u);
+    }
+    const unsigned long long t_ready = tracing ? __builtin_amdgcn_s_memrealtime() : 0;
+    // Everything loaded so far has long arrived; saying so here (vmcnt(0) lgkmcnt(0)) keeps the compiler from putting a
+    // vmcnt(0) into the row loops below for values it can no longer track across their back edges -- on gfx9 that wait would
+    // also cover the PUBLISH stores of the row before (stores count in vmcnt): ~0.7 us per row, measured 4.0 us per slice.
+    __builtin_amdgcn_s_waitcnt(0);
+#pragma unroll
+    for(int e = 0; e < EXT; e++)
+    {
+        T xv;
+        __builtin_memcpy(&xv, &bits[e], sizeof(T));
+        s_xv[FRONT ? BS + e : e][tid] = xv;
+    }
+    // A published value keeps its register until the kernel ends (okeep[], pinned below): on gfx9 a store's data register may
+    // not be overwritten before the store has completed, and the only way the compiler can make sure is s_waitcnt vmcnt(0) --
+    // it put one into every row's loop where the allocator had recycled the register of the row before: ~0.7 us per row.
+    // The caller's x is written at the very end (nobody waits for it).
+    B okeep[BS];
+    T xkeep[BS];
+#pragma unroll
+    for(int a = 0; a < BS; a++)
+        okeep[a] = 0, xkeep[a] = T(0);
+    auto publish = [&](int a, T xa) {
+        xkeep[a] = xa;
+        __builtin_memcpy(&okeep[a], &xa, sizeof(T));
+        if(okeep[a] == tag<T>::value)
+            okeep[a] = qnan_bits<T>::value;
+        if(!dead)
+            __hip_atomic_store(bdst[a], okeep[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+#pragma unroll
+    for(int a = 0; a < BS; a++)
+        if(a < c)
+        {
+            const int cnt = n0 + a; // row a: n0 external entries and a internal ones
+            T         xa  = rhs[a];
+            T         pv[TSZ];
+#pragma unroll
+            for(int l = 0; l < TSZ; l++)
+                pv[l] = T(0);
+            if(!slow)
+            {
+                const T *vp = &s_val[a * n0 + (a * (a - 1)) / 2][tid]; // row a's p-th value at vp[64 p]
+                const T *xq = &s_xv[FRONT ? BS - a : 0][tid]; // ... and the x it multiplies at xq[64 p]
+                int      g  = 0;
+                // (a single wavefront per SIMD cannot hide an LDS round trip: two groups of 4 per trip where the width is 4)
+                if constexpr(TSZ <= 4)
+                    for(; g + 2 * TSZ <= cnt; g += 2 * TSZ)
+                    {
+                        T va[2 * TSZ], xa2[2 * TSZ];
+#pragma unroll
+                        for(int l = 0; l < 2 * TSZ; l++)
+                            va[l] = vp[64 * (g + l)], xa2[l] = xq[64 * (g + l)];
+#pragma unroll
+                        for(int l = 0; l < 2 * TSZ; l++)
+                            pv[l % TSZ] = kt_fma(va[l], xa2[l], pv[l % TSZ]);
+                    }
+                for(; g + TSZ <= cnt; g += TSZ)
+                {
+#pragma unroll
+                    for(int l = 0; l < TSZ; l++)
+                        pv[l] = kt_fma(vp[64 * (g + l)], xq[64 * (g + l)], pv[l]);
+                }
+                if(cnt >= TSZ)
+                    xa -= kt_hsum<T, TSZ>(pv);
+                if(cnt - g == TSZ - 1)
+                {
+#pragma unroll
+                    for(int l = 0; l < TSZ - 1; l++)
+                        pv[l] = vp[64 * (g + l)] * xq[64 * (g + l)];
+                    pv[TSZ - 1] = T(0);
+                    xa -= kt_hsum<T, TSZ>(pv);
+                }
+                else
+                    for(int p = g; p < cnt; p++)
+                        xa = neg_fma(vp[64 * p], xq[64 * p], xa);
+            }
+            else
+            {
+                // the long single row: the first EXT values are in, the rest arrive one by one; lane sums through selects
+                const int  full   = cnt - cnt % TSZ;
+                const bool masked = cnt % TSZ == TSZ - 1;
+                for(int e = 0; e < cnt && !dead; e++)
+                {
+                    T xv;
+                    if(e < EXT)
+                        xv = s_xv[FRONT ? BS + e : e][tid];
+                    else
+                    {
+                        const int qq  = pind[p0 + e];
+                        B         got = __hip_atomic_load(&xb[qq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        while(got == tag<T>::value && !dead)
+                        {
+                            __builtin_amdgcn_s_sleep(1);
+                            got = __hip_atomic_load(&xb[qq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            tick(1023u);
+                        }
+                        __builtin_memcpy(&xv, &got, sizeof(T));
+                    }
+                    const T av = pval[p0 + e];
+                    if(e < full)
+                    {
+                        const int l = e % TSZ;
+#pragma unroll
+                        for(int q2 = 0; q2 < TSZ; q2++)
+                            pv[q2] = q2 == l ? kt_fma(av, xv, pv[q2]) : pv[q2];
+                        if(e == full - 1)
+                            xa -= kt_hsum<T, TSZ>(pv);
+                    }
+                    else if(masked)
+                    {
+                        const int l = e - full;
+#pragma unroll
+                        for(int q2 = 0; q2 < TSZ; q2++)
+                            pv[q2] = q2 == l ? av * xv : pv[q2];
+                        if(e == cnt - 1)
+                        {
+                            pv[TSZ - 1] = T(0);
+                            xa -= kt_hsum<T, TSZ>(pv);
+                        }
+                    }
+                    else
+                        xa = neg_fma(av, xv, xa);
+                }
+                // (nothing of this branch is pending where the branches join: otherwise the rows that follow get a
+                // vmcnt(0) for registers these loads might still be writing -- and that wait covers the publish stores)
+                __builtin_amdgcn_s_waitcnt(0);
+            }
+            if(!unit)
+                xa /= dg[a];
+            if(!slow) // (the long single row has no successor inside its block, and n0 + a may lie beyond the array)
+                s_xv[FRONT ? BS - 1 - a : n0 + a][tid] = xa;
+            publish(a, xa);
+        }
+#pragma unroll
+    for(int a = 0; a < BS; a++)
+    {
+        asm volatile("" ::"v"(okeep[a]), "v"(bdst[a])); // (see publish: data AND address registers of the pending stores)
+        if(a < c && !dead)
+            *xdst[a] = xkeep[a];
+    }
+    if(tracing && tid == 0)
+    {
+        unsigned long long *tr = trace + 6 * (size_t)sl;
+        tr[0] = t_start, tr[1] = t_ready, tr[2] = __builtin_amdgcn_s_memrealtime(), tr[3] = (unsigned long long)lev;
+        tr[4] = 0, tr[5] = 0;
+    }
+    if(tid == 0 && !dead)
+        __hip_atomic_fetch_add(&level_done[lev], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if(dead)
+        __hip_atomic_store(timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // scratch: nrhs ticket words followed by one timeout word (zeroed here for the sync-free schedule)
 template <typename T>
 aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, aoclsparse_int m,
@@ -1004,7 +1268,8 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
     constexpr int T256 = std::is_same<T, double>::value ? 4 : 8;
     if(kt_bits != 0 && kt_bits != 256 && kt_bits != 512)
         return aoclsparse_status_internal_error;
-    if(kt_bits != 0 && schedule != 0)
+    // (the block plan serves the KT orders through trsv_block_kt_kernel; without it: per-level launches or lane per position)
+    if(kt_bits != 0 && schedule != 0 && !(schedule == 4 && plan.blk.valid))
         schedule = 2;
     // the level-ordered row layout, or -- when only the block plan was built (TrsvPlan::rows_valid == false) -- the block
     // plan's layout: also a topological order of the rows, which is all the lane-per-position kernel (schedule 2) needs
@@ -1077,6 +1342,36 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
         if(trace_path && std::is_same<T, double>::value
            && hipMalloc(&trace, sizeof(unsigned long long) * 6 * (size_t)bp.nslices) != hipSuccess)
             trace = nullptr;
+        aoclsparse_status lst = aoclsparse_status_success;
+        if(kt_bits != 0)
+        {
+            if(bp.max_rows > TRSV_BLK_ROWS)
+                return aoclsparse_status_internal_error; // (the plan never builds larger blocks)
+            const dim3 grid = nrhs > 1 ? dim3((unsigned)nrhs, (unsigned)bp.nslices) : dim3((unsigned)bp.nslices);
+#define MI355_BLKKT_ARGS                                                                                                      \
+    m, bp.nslices, bp.slices.as<aoclsparse_int>(), bp.bfirst.as<aoclsparse_int>(), bp.rowmap.as<aoclsparse_int>(),              \
+        bp.pptr.as<aoclsparse_int>(), bp.pind.as<aoclsparse_int>(), bp.pval.as<T>(), diag, b, xp, x, alpha, (int)unit, scratch,   \
+        timeout_word ? timeout_word : scratch + nrhs, (int)incb, (int)incx, scratch + nrhs + 1, gate, (int)nrhs, b_off, x_off,     \
+        (int)bp.nlevels, trace
+            if(kt_bits == 256)
+            {
+                if(bp.front)
+                    hipLaunchKernelGGL((trsv_block_kt_kernel<T, T256, true>), grid, dim3(64), 0, s, MI355_BLKKT_ARGS);
+                else
+                    hipLaunchKernelGGL((trsv_block_kt_kernel<T, T256, false>), grid, dim3(64), 0, s, MI355_BLKKT_ARGS);
+            }
+            else
+            {
+                if(bp.front)
+                    hipLaunchKernelGGL((trsv_block_kt_kernel<T, 2 * T256, true>), grid, dim3(64), 0, s, MI355_BLKKT_ARGS);
+                else
+                    hipLaunchKernelGGL((trsv_block_kt_kernel<T, 2 * T256, false>), grid, dim3(64), 0, s, MI355_BLKKT_ARGS);
+            }
+#undef MI355_BLKKT_ARGS
+            MI355_HIP_TRY(hipGetLastError());
+        }
+        else
+        {
         auto go_form = [&](auto bs_tag, auto ext_tag, auto front_tag) {
             constexpr int    BS = decltype(bs_tag)::value, EXT = decltype(ext_tag)::value;
             constexpr bool   FRONT = decltype(front_tag)::value;
@@ -1118,10 +1413,11 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
         using std::integral_constant;
         // shapes by the plan's largest block / external list (the loops over rows and external entries are unrolled)
         const bool small_ext = bp.max_ext <= 16, small_bs = bp.max_rows <= 5;
-        const aoclsparse_status lst = small_ext && small_bs ? go(integral_constant<int, 5>{}, integral_constant<int, 16>{})
-                                      : small_ext           ? go(integral_constant<int, TRSV_BLK_ROWS>{}, integral_constant<int, 16>{})
-                                      : small_bs ? go(integral_constant<int, 5>{}, integral_constant<int, TRSV_BLK_EXT>{})
-                                                 : go(integral_constant<int, TRSV_BLK_ROWS>{}, integral_constant<int, TRSV_BLK_EXT>{});
+        lst = small_ext && small_bs ? go(integral_constant<int, 5>{}, integral_constant<int, 16>{})
+              : small_ext           ? go(integral_constant<int, TRSV_BLK_ROWS>{}, integral_constant<int, 16>{})
+              : small_bs            ? go(integral_constant<int, 5>{}, integral_constant<int, TRSV_BLK_EXT>{})
+                                    : go(integral_constant<int, TRSV_BLK_ROWS>{}, integral_constant<int, TRSV_BLK_EXT>{});
+        }
         if(trace)
         {
             std::vector<unsigned long long> host(6 * (size_t)bp.nslices);

@@ -677,8 +677,8 @@ def main():
         _, xk8 = oracle.trsv_kt("l", 8, 1.0, mt, 0, lu, ci, rp, o["idiag"], bh, True)
         _, xk4 = oracle.trsv_kt("l", 4, 1.0, mt, 0, lu, ci, rp, o["idiag"], bh, True)
         for kid, nm, xref in ((-1, "auto: ref_trsv_l order, schedule chosen from the plan", xr),
-                              (3, "kid 3: kt_trsv_l<512-bit> order (AVX-512 host), sync-free lane per position", xk8),
-                              (1, "kid 1: kt_trsv_l<256-bit> order (AVX2 host), sync-free lane per position", xk4)):
+                              (3, "kid 3: kt_trsv_l<512-bit> order (AVX-512 host), block kernel with run-time KT loops", xk8),
+                              (1, "kid 1: kt_trsv_l<256-bit> order (AVX2 host), block kernel with run-time KT loops", xk4)):
             if kid not in kids:
                 continue
             reps = 20 if kid < 0 else 10

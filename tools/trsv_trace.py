@@ -19,8 +19,9 @@ dl = pkg.Descr(mtype=pkg.TYPE_TRIANGULAR, fill=pkg.FILL_LOWER, diag=pkg.DIAG_UNI
 assert L.aoclsparse_set_sv_hint(A.h, pkg.OP_NONE, dl.h, 100) == 0 and L.aoclsparse_optimize(A.h) == 0
 b = np.random.default_rng(2).uniform(-1, 1, m)
 bd, xd = torch.from_numpy(b).to(dev), torch.zeros(m, dtype=torch.float64, device=dev)
+KID = int(os.environ["KID"]) if "KID" in os.environ else None   # KID=1 / 3: the KT-order block kernel
 for _ in range(3):
-    pkg.dtrsv(pkg.OP_NONE, 1.0, A, dl, bd, xd)
+    pkg.dtrsv(pkg.OP_NONE, 1.0, A, dl, bd, xd, kid=KID)
 torch.cuda.synchronize()
 t = np.fromfile(TRACE, dtype=np.uint64).reshape(-1, 6).astype(np.int64)
 start, ready, done, lev = t[:, 0], t[:, 1], t[:, 2], t[:, 3]
