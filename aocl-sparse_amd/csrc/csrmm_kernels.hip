@@ -168,6 +168,67 @@ __global__ __launch_bounds__(256) void csrmm_row_wave_kernel(int base, T alpha, 
     __builtin_nontemporal_store(o, reinterpret_cast<nt2 *>(cp));
 }
 
+// The same with C READ (beta != 0, or the default beta == 0 mode that multiplies C by zero as the reference does), written for
+// the wave's lifetime (round 3): the C row is requested FIRST, a row of <= 8 entries is one batch of exactly `len` B-row loads
+// (wave-uniform switch), longer rows walk in steps of 8.  The kernel above spends five dependent round trips on a 5-entry row
+// (row pointers -> values / columns -> four B rows -> the fifth -> C); this one three.  Same chain per element: same bits.
+template <typename T>
+__global__ __launch_bounds__(256) void csrmm_row_wave_rc_kernel(int base, T alpha, aoclsparse_int m,
+                                                                const T *__restrict__ val,
+                                                                const aoclsparse_int *__restrict__ col,
+                                                                const aoclsparse_int *__restrict__ row_ptr,
+                                                                const T *__restrict__ B, aoclsparse_int n,
+                                                                aoclsparse_int ldb, T beta, T *__restrict__ C,
+                                                                aoclsparse_int ldc, int xcd_chunk)
+{
+    using V      = typename vec2<T>::type;
+    const int w  = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int i  = bx * 4 + w;
+    const int j  = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
+    if(i >= m || j >= n)
+        return;
+    col -= base, val -= base;
+    V        *cp = reinterpret_cast<V *>(C + (size_t)i * ldc + j);
+    const V   c0 = *cp; // no dependency on A: in flight while the row's pointers and entries arrive
+    const int s = row_ptr[i], e = row_ptr[i + 1], len = e - s;
+    T         a0 = T(0), a1 = T(0);
+    const T  *Bj = B + j - (ptrdiff_t)base * ldb;
+    auto      batch = [&](int p, auto wtag) {
+        constexpr int W = decltype(wtag)::value;
+        T             v[W];
+        V             b[W];
+#pragma unroll
+        for(int k = 0; k < W; k++)
+            v[k] = val[p + k];
+#pragma unroll
+        for(int k = 0; k < W; k++)
+            b[k] = *reinterpret_cast<const V *>(Bj + (ptrdiff_t)col[p + k] * ldb);
+#pragma unroll
+        for(int k = 0; k < W; k++)
+            a0 = mm_fma(v[k], b[k].x, a0), a1 = mm_fma(v[k], b[k].y, a1);
+    };
+    int p = s;
+    for(; p + 8 <= e; p += 8)
+        batch(p, std::integral_constant<int, 8>{});
+    switch(e - p) // wave-uniform
+    {
+    case 1: batch(p, std::integral_constant<int, 1>{}); break;
+    case 2: batch(p, std::integral_constant<int, 2>{}); break;
+    case 3: batch(p, std::integral_constant<int, 3>{}); break;
+    case 4: batch(p, std::integral_constant<int, 4>{}); break;
+    case 5: batch(p, std::integral_constant<int, 5>{}); break;
+    case 6: batch(p, std::integral_constant<int, 6>{}); break;
+    case 7: batch(p, std::integral_constant<int, 7>{}); break;
+    default: break;
+    }
+    (void)len;
+    typedef T nt2 __attribute__((ext_vector_type(2)));
+    nt2       o;
+    o.x = mm_fma(beta, c0.x, alpha * a0), o.y = mm_fma(beta, c0.y, alpha * a1);
+    __builtin_nontemporal_store(o, reinterpret_cast<nt2 *>(cp));
+}
+
 // row-major, n >= 128, ROW RUNS (stencil-like matrices, csrmm_api.cpp: detect_row_runs): a wavefront walks R consecutive rows
 // for one 128-column chunk and keeps the previous row's B rows in registers.  A stencil's rows repeat the previous row's
 // column list shifted by one (i-1, i, i+1 -> i, i+1, i+2), so entry k of the new row needs exactly the B row that entry
@@ -1226,7 +1287,8 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
             else
                 go(std::integral_constant<int, CSRMM_GROUP>{});
         }
-        else if(vec && n >= 128 && row_runs && !readc) // (beta != 0: the row-per-wave kernel is faster, 1.17 vs 1.18 ms, 1.26 in strip order)
+        else if(vec && n >= 128 && row_runs && !readc) // (C read: the row-per-wave kernel is faster -- 1.17 vs 1.18 ms in round 2, and in
+                                                       // round 3, both with the C row requested first, 1.10-1.16 vs 1.25-1.28 ms: profiles/r3/csrmm_row_wave_rc.txt)
         {
             constexpr int RUN = 8;
             const int     gx  = grid_x((m + 4 * RUN - 1) / (4 * RUN), chunk);
@@ -1245,8 +1307,12 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
         else if(vec && n >= 128)
         {
             const int gx = grid_x((m + 3) / 4, chunk);
-            hipLaunchKernelGGL((csrmm_row_wave_kernel<T>), dim3(gx, (n + 127) / 128), dim3(256), 0, s, base, alpha,
-                               m, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk);
+            if(readc)
+                hipLaunchKernelGGL((csrmm_row_wave_rc_kernel<T>), dim3(gx, (n + 127) / 128), dim3(256), 0, s, base, alpha,
+                                   m, val, col, row_ptr, B, n, ldb, beta, C, ldc, chunk);
+            else
+                hipLaunchKernelGGL((csrmm_row_wave_kernel<T>), dim3(gx, (n + 127) / 128), dim3(256), 0, s, base, alpha,
+                                   m, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk);
         }
         else
         {
