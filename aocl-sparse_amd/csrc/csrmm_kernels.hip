@@ -172,7 +172,9 @@ __global__ __launch_bounds__(256) void csrmm_row_wave_kernel(int base, T alpha, 
 // the wave's lifetime (round 3): the C row is requested FIRST, a row of <= 8 entries is one batch of exactly `len` B-row loads
 // (wave-uniform switch), longer rows walk in steps of 8.  The kernel above spends five dependent round trips on a 5-entry row
 // (row pointers -> values / columns -> four B rows -> the fifth -> C); this one three.  Same chain per element: same bits.
-template <typename T>
+// KT: the arithmetic of the reference's csrmm_row_kt (csrmm_kt.cpp:244-356) for column counts that are a multiple of its vector
+// width: c = c * beta first, then c = fma(alpha * a_k, b_kj, c) entry by entry -- what aoclsparse_?csrmm_kid 1/2/3 asks for.
+template <typename T, bool KT = false>
 __global__ __launch_bounds__(256) void csrmm_row_wave_rc_kernel(int base, T alpha, aoclsparse_int m,
                                                                 const T *__restrict__ val,
                                                                 const aoclsparse_int *__restrict__ col,
@@ -193,6 +195,7 @@ __global__ __launch_bounds__(256) void csrmm_row_wave_rc_kernel(int base, T alph
     const V   c0 = *cp; // no dependency on A: in flight while the row's pointers and entries arrive
     const int s = row_ptr[i], e = row_ptr[i + 1], len = e - s;
     T         a0 = T(0), a1 = T(0);
+    bool      first = true;
     const T  *Bj = B + j - (ptrdiff_t)base * ldb;
     auto      batch = [&](int p, auto wtag) {
         constexpr int W = decltype(wtag)::value;
@@ -200,10 +203,12 @@ __global__ __launch_bounds__(256) void csrmm_row_wave_rc_kernel(int base, T alph
         V             b[W];
 #pragma unroll
         for(int k = 0; k < W; k++)
-            v[k] = val[p + k];
+            v[k] = KT ? alpha * val[p + k] : val[p + k];
 #pragma unroll
         for(int k = 0; k < W; k++)
             b[k] = *reinterpret_cast<const V *>(Bj + (ptrdiff_t)col[p + k] * ldb);
+        if(KT && first) // (after the B rows are requested: the chain starts from beta * C)
+            a0 = c0.x * beta, a1 = c0.y * beta, first = false;
 #pragma unroll
         for(int k = 0; k < W; k++)
             a0 = mm_fma(v[k], b[k].x, a0), a1 = mm_fma(v[k], b[k].y, a1);
@@ -225,7 +230,14 @@ __global__ __launch_bounds__(256) void csrmm_row_wave_rc_kernel(int base, T alph
     (void)len;
     typedef T nt2 __attribute__((ext_vector_type(2)));
     nt2       o;
-    o.x = mm_fma(beta, c0.x, alpha * a0), o.y = mm_fma(beta, c0.y, alpha * a1);
+    if constexpr(KT)
+    {
+        if(first) // an empty row
+            a0 = c0.x * beta, a1 = c0.y * beta;
+        o.x = a0, o.y = a1;
+    }
+    else
+        o.x = mm_fma(beta, c0.x, alpha * a0), o.y = mm_fma(beta, c0.y, alpha * a1);
     __builtin_nontemporal_store(o, reinterpret_cast<nt2 *>(cp));
 }
 
@@ -711,7 +723,7 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup_sub_kernel(int base, T alp
 // order, so the bits are those of every other kernel here.  beta == 0 stores are non-temporal (C is written once and
 // not read again by this launch).  32 columns of the 1000^2 Laplacian: 0.131 ms against 0.195 ms for csrmm_row_kernel
 // (tools/csrmm_r2.hip, profiles/r2/csrmm_experiments.txt).
-template <typename T, int LANES, int TILE, int UR, int NB, bool RC>
+template <typename T, int LANES, int TILE, int UR, int NB, bool RC, bool KT = false>
 __global__ __launch_bounds__(256, 4) void csrmm_tile_kernel(int base, T alpha, const T *__restrict__ val,
                                                          const aoclsparse_int *__restrict__ col,
                                                          const aoclsparse_int *__restrict__ row_ptr,
@@ -760,13 +772,26 @@ __global__ __launch_bounds__(256, 4) void csrmm_tile_kernel(int base, T alpha, c
         {
             T        a0 = T(0), a1 = T(0);
             const T *Bj = B + j;
+            V       *cp = reinterpret_cast<V *>(C + (size_t)r0 * ldc + j);
+            if constexpr(KT) // (csrmm_row_kt: the chain starts from beta * C and carries alpha * a)
+            {
+                const V c = *cp;
+                a0 = c.x * beta, a1 = c.y * beta;
+            }
             for(int p = s0; p < s0 + cnt; p++)
             {
-                const T a = val[p];
+                const T a = KT ? alpha * val[p] : val[p];
                 const V b = *reinterpret_cast<const V *>(Bj + (size_t)(col[p] - base) * ldb);
                 a0 = mm_fma(a, b.x, a0), a1 = mm_fma(a, b.y, a1);
             }
-            put(r0, a0, a1);
+            if constexpr(KT)
+            {
+                V c;
+                c.x = a0, c.y = a1;
+                *cp = c;
+            }
+            else
+                put(r0, a0, a1);
         }
         return;
     }
@@ -782,7 +807,7 @@ __global__ __launch_bounds__(256, 4) void csrmm_tile_kernel(int base, T alpha, c
     {
         int p0[UR], p1[UR];
         T   a0[UR], a1[UR];
-        V   cin[UR];
+        V   cin[UR] = {};
 #pragma unroll
         for(int q = 0; q < UR; q++)
         {
@@ -795,7 +820,7 @@ __global__ __launch_bounds__(256, 4) void csrmm_tile_kernel(int base, T alpha, c
                 if(rr < nrows)
                     cin[q] = *reinterpret_cast<const V *>(C + (size_t)(r0 + rr) * ldc + j);
         }
-        bool more = true;
+        bool more = true, first = true;
         while(more)
         {
             V b[UR][NB];
@@ -806,9 +831,16 @@ __global__ __launch_bounds__(256, 4) void csrmm_tile_kernel(int base, T alpha, c
                 for(int u = 0; u < NB; u++)
                     if(p0[q] + u < p1[q])
                     {
-                        v[q][u] = s_val[p0[q] + u];
+                        v[q][u] = KT ? alpha * s_val[p0[q] + u] : s_val[p0[q] + u];
                         b[q][u] = *reinterpret_cast<const V *>(Bj + (size_t)s_col[p0[q] + u] * ldb);
                     }
+            if(KT && first) // (after the B rows are requested: the chains start from beta * C)
+            {
+#pragma unroll
+                for(int q = 0; q < UR; q++)
+                    a0[q] = cin[q].x * beta, a1[q] = cin[q].y * beta;
+                first = false;
+            }
             more = false;
 #pragma unroll
             for(int q = 0; q < UR; q++)
@@ -825,7 +857,13 @@ __global__ __launch_bounds__(256, 4) void csrmm_tile_kernel(int base, T alpha, c
         for(int q = 0; q < UR; q++)
             if(r + q * NSUB < nrows)
             {
-                if constexpr(RC)
+                if constexpr(KT)
+                {
+                    V c;
+                    c.x = first ? cin[q].x * beta : a0[q], c.y = first ? cin[q].y * beta : a1[q]; // (first: empty rows only)
+                    *reinterpret_cast<V *>(C + (size_t)(r0 + r + q * NSUB) * ldc + j) = c;
+                }
+                else if constexpr(RC)
                 {
                     V c;
                     c.x = mm_fma(beta, cin[q].x, alpha * a0[q]);
@@ -1221,10 +1259,25 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
                                aoclsparse_int /*k*/, const T *val, const aoclsparse_int *col,
                                const aoclsparse_int *row_ptr, const T *B, aoclsparse_int n,
                                aoclsparse_int ldb, T beta, T *C, aoclsparse_int ldc, const aoclsparse_int *grp,
-                               aoclsparse_int ngroups, int group_rows, bool row_runs, const aoclsparse_int *run_order)
+                               aoclsparse_int ngroups, int group_rows, bool row_runs, const aoclsparse_int *run_order, bool kt)
 {
     if(m <= 0 || n <= 0)
         return aoclsparse_status_success;
+    // kt: the arithmetic of csrmm_row_kt, offered by the row-per-wave kernel only (anything else: not_implemented, the caller
+    // runs the plain KT kernel)
+    if(kt)
+    {
+        const bool vec = order == aoclsparse_order_row && (n % 2 == 0) && (ldb % 2 == 0) && (ldc % 2 == 0)
+                         && (reinterpret_cast<uintptr_t>(B) % (2 * sizeof(T)) == 0)
+                         && (reinterpret_cast<uintptr_t>(C) % (2 * sizeof(T)) == 0);
+        if(!vec || n < 128 || (grp && ngroups > 0))
+            return aoclsparse_status_not_implemented;
+        const int chunk_kt = ((m + 3) / 4 + 7) / 8;
+        hipLaunchKernelGGL((csrmm_row_wave_rc_kernel<T, true>), dim3(chunk_kt * 8, (n + 127) / 128), dim3(256), 0, s, base, alpha, m,
+                           val, col, row_ptr, B, n, ldb, beta, C, ldc, chunk_kt);
+        MI355_HIP_TRY(hipGetLastError());
+        return aoclsparse_status_success;
+    }
     const bool readc = csrmm_reads_c(beta != T(0));
     // XCD-contiguous row order (every kernel): each XCD's L2 then serves the B rows its rows share.
     // Row-major n=256 on the 1000^2 Laplacian: 0.96 vs 1.21 ms.
@@ -1458,11 +1511,11 @@ template <typename T>
 aoclsparse_status launch_csrmm_tiled(hipStream_t s, int base, T alpha, const T *val, const aoclsparse_int *col,
                                      const aoclsparse_int *row_ptr, const aoclsparse_int *blocks, aoclsparse_int nblocks,
                                      int tile, aoclsparse_int max_row_nnz, const T *B, aoclsparse_int n, aoclsparse_int ldb,
-                                     T beta, T *C, aoclsparse_int ldc)
+                                     T beta, T *C, aoclsparse_int ldc, bool kt)
 {
     if(nblocks <= 0 || n <= 0)
         return aoclsparse_status_success;
-    const bool readc = csrmm_reads_c(beta != T(0));
+    const bool readc = kt || csrmm_reads_c(beta != T(0)); // (the KT arithmetic always reads C: c = c * beta comes first)
     constexpr bool xcd = true;
     const int  chunk = (nblocks + 7) / 8; // XCD-contiguous block order, as the other csrmm kernels
     // (UR, NB) = rows in flight per 16-lane sub-wave x B-row loads per row and step.  Round-3 sweep on the 32-column slab of
@@ -1477,6 +1530,15 @@ aoclsparse_status launch_csrmm_tiled(hipStream_t s, int base, T alpha, const T *
         constexpr int  TILE = decltype(tile_tag)::value, NB = decltype(nb_tag)::value;
         constexpr bool RC   = decltype(rc_tag)::value;
         const dim3     grid(xcd ? chunk * 8 : nblocks, (n + 31) / 32);
+        if constexpr(RC)
+        {
+            if(kt)
+            {
+                hipLaunchKernelGGL((csrmm_tile_kernel<T, 16, TILE, 2, NB, true, true>), grid, dim3(256), 0, s, base, alpha, val, col,
+                                   row_ptr, blocks, nblocks, B, n, ldb, beta, C, ldc, readc, chunk);
+                return;
+            }
+        }
         hipLaunchKernelGGL((csrmm_tile_kernel<T, 16, TILE, 2, NB, RC>), grid, dim3(256), 0, s, base, alpha, val, col, row_ptr,
                            blocks, nblocks, B, n, ldb, beta, C, ldc, readc, chunk);
     };
@@ -1546,7 +1608,7 @@ aoclsparse_status launch_csrmm_colpair(hipStream_t s, int base, T alpha, aoclspa
                                                aoclsparse_int, const T *, const aoclsparse_int *,             \
                                                const aoclsparse_int *, const T *, aoclsparse_int,             \
                                                aoclsparse_int, T, T *, aoclsparse_int, const aoclsparse_int *, \
-                                               aoclsparse_int, int, bool, const aoclsparse_int *);            \
+                                               aoclsparse_int, int, bool, const aoclsparse_int *, bool);      \
     template aoclsparse_status launch_scale_dense<T>(hipStream_t, aoclsparse_order, T *, aoclsparse_int,     \
                                                      aoclsparse_int, aoclsparse_int, T);                     \
     template aoclsparse_status launch_relayout<T>(hipStream_t, bool, const T *, T *, aoclsparse_int,         \
@@ -1564,7 +1626,7 @@ aoclsparse_status launch_csrmm_colpair(hipStream_t s, int base, T alpha, aoclspa
     template aoclsparse_status launch_csrmm_tiled<T>(hipStream_t, int, T, const T *, const aoclsparse_int *,   \
                                                      const aoclsparse_int *, const aoclsparse_int *,          \
                                                      aoclsparse_int, int, aoclsparse_int, const T *, aoclsparse_int, \
-                                                     aoclsparse_int, T, T *, aoclsparse_int);
+                                                     aoclsparse_int, T, T *, aoclsparse_int, bool);
 MI355_INST_MM(double)
 MI355_INST_MM(float)
 template aoclsparse_status launch_csrmm_kt<double>(hipStream_t, aoclsparse_order, int, int, double, aoclsparse_int, const double *,

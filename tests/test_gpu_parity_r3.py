@@ -11,7 +11,7 @@ import pytest
 
 import oracle
 from test_oracle_golden_r3 import classes_match, dense_expect, dense_of, plant, ulp_close
-from util import EPS64, pkg, random_csr, triangular_system
+from util import EPS64, kt_lanes, pkg, random_csr, triangular_system
 
 pytestmark = pytest.mark.gpu
 
@@ -315,6 +315,44 @@ def test_csrmm_within_bound_of_the_kt_orders(n, alpha, beta):
                     # in the fused build: kid 1 / 2 -> 256-bit vectors (4 lanes), kid 3 -> 512-bit (8 lanes)
                     if fused and psz == {1: 4, 2: 4, 3: 8}.get(kid):
                         assert np.array_equal(got, ref), (oname, kid, psz)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n", [32, 48, 128, 256])
+def test_csrmm_kid_row_major_on_the_tuned_kernels(n, dtype):
+    """Row-major aoclsparse_?csrmm_kid 1 / 2 / 3 with a column count that is a multiple of the KT vector width runs on the tuned
+    kernels (tile kernel below 128 columns, row-per-wave kernel from 128) in their csrmm_row_kt arithmetic: c = c * beta, then
+    c = fma(alpha * a_k, b_kj, c) (csrmm_kt.cpp:244-356) -- bit for bit against the restatement pinned on the reference's
+    templates.  Matrices: a 5-point stencil (the benchmark pattern), a random CSR with empty rows, and one with a row longer than
+    an LDS tile."""
+    import __graft_entry__ as entry
+    mats = []
+    m, rp, ci, v = entry.laplace5(60)
+    mats.append(("laplace", m, m, rp, ci, v))
+    rp, ci, v = random_csr(5, 900, 700, lambda r, i: 0 if i % 7 == 3 else r.integers(1, 30))
+    mats.append(("random", 900, 700, rp, ci, v))
+    rp, ci, v = random_csr(6, 300, 1500, lambda r, i: 1400 if i == 17 else r.integers(0, 12))
+    mats.append(("long row", 300, 1500, rp, ci, v))
+    rng = np.random.default_rng(44)
+    d = P.Descr()
+    for name, m, k, rp, ci, v in mats:
+        v = v.astype(dtype)
+        A = P.Matrix(0, m, k, rp, ci, v)
+        B = rng.uniform(-1, 1, k * n).astype(dtype)
+        C0 = rng.uniform(-1, 1, m * n).astype(dtype)
+        for alpha, beta in ((1.0, 0.0), (-1.75, 0.625)):
+            for kid in (1, 2, 3):
+                lanes = kt_lanes(kid, dtype)
+                if n % lanes:
+                    continue
+                C = C0.copy()
+                fn = P.dcsrmm if dtype == np.float64 else P.scsrmm
+                assert fn(P.OP_NONE, alpha, A, d, P.ORDER_ROW, B, n, n, beta, C, n, kid=kid) == 0
+                kt = oracle.dcsrmm_kt if dtype == np.float64 else oracle.scsrmm_kt
+                st, ref = kt("row", lanes, alpha, 0, v, ci, rp, m, B, n, n, beta, C0, n)
+                assert st == 0
+                u = np.uint64 if dtype == np.float64 else np.uint32
+                assert np.array_equal(C.view(u), ref.view(u)), (name, n, kid, alpha, beta, float(np.abs(C - ref).max()))
 
 
 @pytest.mark.parametrize("n", [7, 16, 35])
