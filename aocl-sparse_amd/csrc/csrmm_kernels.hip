@@ -739,15 +739,20 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup_sub_kernel(int base, T alp
 // order, so the bits are those of every other kernel here.  beta == 0 stores are non-temporal (C is written once and
 // not read again by this launch).  32 columns of the 1000^2 Laplacian: 0.131 ms against 0.195 ms for csrmm_row_kernel
 // (tools/csrmm_r2.hip, profiles/r2/csrmm_experiments.txt).
-template <typename T, int LANES, int TILE, int UR, int NB, bool RC, bool KT = false>
+template <typename T, int LANES, int TILE, int UR, int NB, bool RC, bool KT = false, bool TRACE = false>
 __global__ __launch_bounds__(256, 4) void csrmm_tile_kernel(int base, T alpha, const T *__restrict__ val,
                                                          const aoclsparse_int *__restrict__ col,
                                                          const aoclsparse_int *__restrict__ row_ptr,
                                                          const aoclsparse_int *__restrict__ blocks, aoclsparse_int nblocks,
                                                          const T *__restrict__ B, aoclsparse_int n, aoclsparse_int ldb,
                                                          T beta, T *__restrict__ C, aoclsparse_int ldc, bool readc,
-                                                         int xcd_chunk)
+                                                         int xcd_chunk, unsigned long long *trace = nullptr)
 {
+    // diagnostic (AOCLSPARSE_MI355_MM_TRACE=<file>, tools/mm_trace.py): 100 MHz stamps per workgroup -- start / block table
+    // read / tile loads landed / after the barrier / end -- kept in registers and stored by thread 0 at the very end
+    unsigned long long t_st[5] = {0, 0, 0, 0, 0};
+    if constexpr(TRACE)
+        t_st[0] = __builtin_amdgcn_s_memrealtime();
     using V               = typename vec2<T>::type;
     constexpr int MAXR    = 512; // spmv_maxrows(TILE) <= 512
     constexpr int NSUB    = 256 / LANES;
@@ -762,6 +767,8 @@ __global__ __launch_bounds__(256, 4) void csrmm_tile_kernel(int base, T alpha, c
     const int nrows = blocks[2 * bx + 2] - r0, cnt = blocks[2 * bx + 3] - s0;
     const int tid = threadIdx.x, sub = tid / LANES, lane = tid % LANES;
     const int j   = 2 * lane + 2 * LANES * (int)blockIdx.y;
+    if constexpr(TRACE)
+        t_st[1] = __builtin_amdgcn_readfirstlane(cnt) >= 0 ? __builtin_amdgcn_s_memrealtime() : 0;
     auto      put = [&](int row, T a0, T a1) {
         V      *cp = reinterpret_cast<V *>(C + (size_t)row * ldc + j);
         const T z0 = alpha * a0, z1 = alpha * a1;
@@ -815,7 +822,14 @@ __global__ __launch_bounds__(256, 4) void csrmm_tile_kernel(int base, T alpha, c
         s_ptr[t] = row_ptr[r0 + t] - base - s0;
     for(int t = tid; t < cnt; t += 256)
         s_col[t] = col[s0 + t] - base, s_val[t] = val[s0 + t];
+    if constexpr(TRACE)
+    {
+        __builtin_amdgcn_s_waitcnt(0);
+        t_st[2] = __builtin_amdgcn_s_memrealtime();
+    }
     __syncthreads();
+    if constexpr(TRACE)
+        t_st[3] = __builtin_amdgcn_s_memrealtime();
     if(j >= n)
         return;
     const T *Bj = B + j;
@@ -890,6 +904,13 @@ __global__ __launch_bounds__(256, 4) void csrmm_tile_kernel(int base, T alpha, c
                     put(r0 + r + q * NSUB, a0[q], a1[q]);
             }
     }
+    if constexpr(TRACE)
+        if(tid == 0 && blockIdx.y == 0 && trace)
+        {
+            unsigned long long *tr = trace + 8 * (size_t)bx;
+            tr[0] = t_st[0], tr[1] = t_st[1], tr[2] = t_st[2], tr[3] = t_st[3], tr[4] = __builtin_amdgcn_s_memrealtime();
+            tr[5] = ((unsigned long long)nrows << 32) | (unsigned)cnt, tr[6] = (unsigned long long)r0, tr[7] = 0;
+        }
 }
 
 // column-major: one lane owns one row; the first CM_K entries of the row are kept in registers and the
@@ -1552,6 +1573,27 @@ aoclsparse_status launch_csrmm_tiled(hipStream_t s, int base, T alpha, const T *
         constexpr int  TILE = decltype(tile_tag)::value, NB = decltype(nb_tag)::value;
         constexpr bool RC   = decltype(rc_tag)::value;
         const dim3     grid(xcd ? chunk * 8 : nblocks, (n + 31) / 32);
+        static const char *trace_path = getenv("AOCLSPARSE_MI355_MM_TRACE");
+        if constexpr(std::is_same<T, double>::value && TILE == 1024 && NB == 5)
+        {
+            unsigned long long *trace = nullptr;
+            if(trace_path && !kt && hipMalloc(&trace, sizeof(unsigned long long) * 8 * (size_t)(chunk * 8)) == hipSuccess)
+            {
+                (void)hipMemsetAsync(trace, 0, sizeof(unsigned long long) * 8 * (size_t)(chunk * 8), s);
+                hipLaunchKernelGGL((csrmm_tile_kernel<T, 16, TILE, 2, NB, RC, false, true>), grid, dim3(256), 0, s, base, alpha, val,
+                                   col, row_ptr, blocks, nblocks, B, n, ldb, beta, C, ldc, readc, chunk, trace);
+                std::vector<unsigned long long> host(8 * (size_t)nblocks);
+                if(hipStreamSynchronize(s) == hipSuccess
+                   && hipMemcpy(host.data(), trace, sizeof(unsigned long long) * host.size(), hipMemcpyDeviceToHost) == hipSuccess)
+                    if(FILE *f = fopen(trace_path, "wb"))
+                    {
+                        fwrite(host.data(), sizeof(unsigned long long), host.size(), f);
+                        fclose(f);
+                    }
+                (void)hipFree(trace);
+                return;
+            }
+        }
         if constexpr(RC)
         {
             if(kt)
