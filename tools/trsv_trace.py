@@ -12,7 +12,7 @@ import __graft_entry__ as entry, oracle, standins
 pkg = entry.load_package(); L = pkg.lib()
 L.aoclsparse_mi355_set_pointer_mode(pkg.PTR_DEVICE)
 dev = torch.device("cuda", 0)
-m, rp, ci, v = standins.shell_like()
+m, rp, ci, v = standins.shell_like_unstructured() if os.environ.get("VARIANT") == "unstructured" else standins.shell_like()   # VARIANT=unstructured
 st, lu, dg = oracle.dilu0(m, 0, rp, ci, v)
 A = pkg.Matrix(0, m, m, rp, ci, lu)
 dl = pkg.Descr(mtype=pkg.TYPE_TRIANGULAR, fill=pkg.FILL_LOWER, diag=pkg.DIAG_UNIT)
