@@ -101,6 +101,39 @@ def test_block_trsv_bit_exact_every_triangle(name, dofs, width, far):
     solve_all(m, rp, ci, v, same)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("name,dofs,width,far", [("five", fixed(5), 37, 0), ("eight", fixed(8), 29, 0),
+                                                 ("three+long", fixed(3), 41, 30), ("mixed+long", mixed, 64, 28)])
+def test_block_trsv_pinned_kid_kt_orders(name, dofs, width, far, dtype):
+    """aoclsparse_?trsv_kid 1 / 2 / 3 on matrices whose triangles have a block plan: trsv_block_kt_kernel (the block kernel's
+    protocol with run-time KT loops) must reproduce kt_trsv_l / kt_trsv_u (trsv_kt.cpp:64-150, :297-383) bit for bit -- L and U,
+    unit and non-unit, blocks of up to 8 rows, single rows with more dependencies than the kernel polls in one batch (its
+    one-by-one path), double and float; the transposed solves (no KT arithmetic of their own) stay on the reference chain."""
+    nodes = 2500
+    m, rp, ci, v = node_mesh(900 + len(name), nodes, width, dofs(np.random.default_rng(3), nodes), far=far)
+    o = oracle.dcsr_optimize(m, m, len(v), 0, rp, ci, v)
+    vv = v.astype(dtype)
+    ov = o["val"].astype(dtype)
+    A = P.Matrix(0, m, m, rp, ci, vv)
+    rng = np.random.default_rng(12)
+    solve = P.dtrsv if dtype == np.float64 else P.strsv
+    u = np.uint64 if dtype == np.float64 else np.uint32
+    from util import kt_lanes
+    for kind, fill, op in VARIANTS:
+        for unit in (True, False):
+            d = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=getattr(P, fill), diag=P.DIAG_UNIT if unit else P.DIAG_NON_UNIT)
+            b = rng.uniform(-1, 1, m).astype(dtype)
+            iend = o["idiag"] if kind[0] == "l" else o["iurow"]
+            for kid in (1, 2, 3):
+                st, xr = oracle.trsv_kt(kind, kt_lanes(kid, dtype), 0.75, m, 0, ov, o["ind"], o["ptr"], iend, b, unit, dtype=dtype)
+                assert st == 0
+                xd = torch.full((m,), 7.0, dtype=torch.float64 if dtype == np.float64 else torch.float32, device="cuda")
+                assert solve(getattr(P, op), 0.75, A, d, dev(b), xd, kid=kid) == 0
+                torch.cuda.synchronize()
+                got = xd.cpu().numpy()
+                assert np.array_equal(got.view(u), xr.view(u)), (name, kind, unit, kid, int((got != xr).sum()))
+
+
 def test_block_trsv_strided_and_host_pointers():
     nodes = 1500
     m, rp, ci, v = node_mesh(7, nodes, 30, np.full(nodes, 5))
@@ -231,6 +264,15 @@ def test_block_trsm_every_column_bit_exact(order):
             for j in range(n):
                 st, xr = oracle.dtrsv(kind, 0.5, m, 0, o["val"], o["ind"], o["ptr"], iend, np.ascontiguousarray(cols(Bm, j)), unit)
                 assert st == 0 and np.array_equal(cols(X, j), xr), (kind, order, ptr_dev, j)
+        # a pinned kid: every column in the KT order of that kid (one grid column of trsv_block_kt_kernel per right-hand side)
+        Xk = dev(Xm)
+        assert L.aoclsparse_dtrsm_kid(op, 0.5, A.h, d.h, lay, P._ptr(dev(Bm)), n, ld, P._ptr(Xk), ld, 3) == 0
+        torch.cuda.synchronize()
+        X = Xk.cpu().numpy()
+        assert pad_ok(X)
+        for j in range(n):
+            st, xr = oracle.trsv_kt(kind, 8, 0.5, m, 0, o["val"], o["ind"], o["ptr"], iend, np.ascontiguousarray(cols(Bm, j)), unit)
+            assert st == 0 and np.array_equal(cols(X, j), xr), (kind, order, "kid 3", j)
 
 
 _TRACE_SCRIPT = r"""
