@@ -208,6 +208,46 @@ def test_mv_empty_rows_after_optimize_reference_case(k3):
         assert np.array_equal(y, np.array(c["y_exp"], dt))
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("wmax", [1, 3, 5, 8])
+def test_sell_short_row_kernel_large_launch(wmax, dtype):
+    """sell_mv_short_kernel (round 3: widest slice <= 8 cells, >= 4,096 slices, scalar order): a random matrix of 300,000 rows
+    with <= wmax entries each -- plain SELL-64 (no two rows share a list), slices narrower than the widest one, a band of 300
+    consecutive empty rows (slices of width 0), a partial last slice -- and a stencil of the same size (shared lists, modes 0 / 1 /
+    2 of the slice words).  Bit for bit against the scalar chain, alpha / beta classes, NaN in x reaching exactly its rows."""
+    import __graft_entry__ as entry
+    m = 300000 + 37
+    # (mostly full-width rows, so that the SELL padding stays inside the budget of optimize)
+    rp, ci, v = random_csr(70 + wmax, m, m,
+                           lambda r, i: 0 if 1000 <= i < 1300 else (wmax if r.random() < 0.85 else r.integers(0, wmax + 1)))
+    mats = [("random", m, rp, ci, v)]
+    if wmax == 5:
+        ml, rpl, cil, vl = entry.laplace5(550)
+        mats.append(("stencil", ml, rpl, cil, vl))
+    rng = np.random.default_rng(3)
+    for name, mm, rp, ci, v in mats:
+        v = v.astype(dtype)
+        A = P.Matrix(0, mm, mm, rp, ci, v)
+        d = P.Descr()
+        assert L.aoclsparse_set_mv_hint(A.h, P.OP_NONE, d.h, 100) == 0 and L.aoclsparse_optimize(A.h) == 0
+        assert A.spmv_info().kernel in (3, 4), name
+        x = rng.uniform(-1, 1, mm).astype(dtype)
+        x[12345] = np.nan
+        y0 = rng.uniform(-1, 1, mm).astype(dtype)
+        for alpha, beta in ((1.0, 0.0), (-0.5, 1.25)):
+            y = y0.copy()
+            fn = P.dmv if dtype == np.float64 else P.smv
+            assert fn(P.OP_NONE, alpha, A, d, x, beta, y) == 0
+            if dtype == np.float64:
+                st, yr = oracle.dcsrmv(0, 0, alpha, mm, len(v), v, ci, rp, x, beta, y0.copy())
+            else:  # the float kernel of the reference is the 8-lane one: the scalar chain for rows of < 8 entries
+                st, yr = oracle.scsrmv("lane8", 0, alpha, mm, v, ci, rp, x, beta, y0.copy())
+            assert st == 0
+            both_nan = np.isnan(y) & np.isnan(yr)
+            assert np.array_equal(np.isnan(y), np.isnan(yr)), (name, wmax)
+            assert np.array_equal(y[~both_nan], yr[~both_nan]), (name, wmax, alpha, beta)
+
+
 def test_mv_extreme_values_reference_configurations(k3):
     """mv_tests.cpp:1858-2100 (real types): NaN * x, Inf * x, Inf * 0 and the overflow / underflow products planted in the
     5 x 5 systems of common_data_utils.h:3897-4075, :4236-4330 for general / symmetric / triangular descriptors x fill x op x
