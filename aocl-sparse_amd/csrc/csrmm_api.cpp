@@ -820,6 +820,9 @@ static aoclsparse_status csrmm_multi_t(aoclsparse_operation op, const T alpha, c
     int count = 0;
     if(hipGetDeviceCount(&count) != hipSuccess || count <= 0)
         return aoclsparse_status_internal_error;
+    // (the vectors below allocate: nothing may leave through the C ABI as an exception)
+    try
+    {
     std::vector<int> dev((size_t)ndev);
     for(int i = 0; i < ndev; i++)
     {
@@ -915,6 +918,15 @@ static aoclsparse_status csrmm_multi_t(aoclsparse_operation op, const T alpha, c
         if(res[i] != aoclsparse_status_success)
             return res[i];
     return aoclsparse_status_success;
+    }
+    catch(const std::bad_alloc &)
+    {
+        return aoclsparse_status_memory_error;
+    }
+    catch(const std::exception &)
+    {
+        return aoclsparse_status_internal_error;
+    }
 }
 
 extern "C" {
