@@ -562,7 +562,7 @@ aoclsparse_status solve_core(aoclsparse_operation trans, T alpha, aoclsparse_mat
     // Round 3: the kid selects the ARITHMETIC, as it does in the reference (trsv.cpp:321-353), not the schedule.  kid 0 and auto:
     // the chain of ref_trsv_* -- every schedule reproduces it, so the fastest one runs; kid 1 / 2: the order of the 256-bit KT
     // kernels, kid 3: of the 512-bit ones (kt_trsv_l / kt_trsv_u, trsv_kt.cpp:64-150, :297-383), bit for bit, served by the
-    // per-level launches and the lane-per-position sync-free kernel.  The transposed KT kernels apply the same per-element fma
+    // block kernel with run-time KT loops (triangles with chains), the per-level launches and the lane-per-position kernel.  The transposed KT kernels apply the same per-element fma
     // as the reference kernels (trsv_kt.cpp:183-268, :416-503), so for op != none every kid has the same bits.
     // aoclsparse_mi355_set_trsv_schedule forces a schedule (tests, measurements).
     const int kt_bits  = (!is_cplx && !tr && kid >= 1) ? (kid == 3 ? 512 : 256) : 0;

@@ -1264,7 +1264,8 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
     if(m <= 0 || nrhs <= 0)
         return aoclsparse_status_success;
     // kt_bits: 0 = the reference chain (ref_trsv_*); 256 / 512 = the KT kernels' order for that vector width (kid 1/2 / 3).
-    // Served by the per-level launches and by the lane-per-position sync-free kernel.
+    // Served by trsv_block_kt_kernel when the triangle has a block plan (schedule 4), else by the per-level launches and the
+    // lane-per-position sync-free kernel.
     constexpr int T256 = std::is_same<T, double>::value ? 4 : 8;
     if(kt_bits != 0 && kt_bits != 256 && kt_bits != 512)
         return aoclsparse_status_internal_error;
