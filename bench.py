@@ -625,6 +625,35 @@ def main():
                                       np.zeros(ns * mm_m), mm_m)
                 for q in (-1, -2, -3):
                     res["cases"][q]["bit_exact_4_columns"] = bool(np.array_equal(cc.cpu().numpy().reshape(-1), Cr))
+                # a pinned kid (row-major): the KT kernels' arithmetic (csrmm_row_kt), on the tuned kernels when the column count
+                # is a multiple of the vector width; first 8 columns checked against the KT restatement (4 / 8 lanes)
+                if layout == "row":
+                    ld = ncols
+                    for kid, lanes in ((1, 4), (3, 8)):
+                        call = lambda: L.aoclsparse_dcsrmm_kid(pkg.OP_NONE, 1.0, sh.A.h, sh.descr.h, pkg.ORDER_ROW, pkg._ptr(Bs), ncols, ld,
+                                                               0.0, pkg._ptr(Cs), ld, kid)
+                        Cs.zero_()
+                        lp = timed_laps(pkg, call, 10, 2)
+                        ms = float(np.mean(lp))
+                        b = csrmm_bytes(mm_m, mm_m, nz, ncols, True)
+                        ent = {"layout": "row-major", "ncols": ncols, "what": tag, "beta": 0.0, "c_is_read": True,
+                               "mode": "kid %d: csrmm_row_kt order, %d lanes (%s)" % (kid, lanes, "AVX2 host" if kid == 1 else "AVX-512 host"),
+                               "ms": round(ms, 5), "stats_ms": quartiles(lp), "gflops": round(2.0 * nz * ncols / ms / 1e6, 1),
+                               "roofline": roofline(b, ms)}
+                        if ncols % 8 == 0:
+                            # the kernel's arithmetic does not depend on which columns are present: compare 8 columns of a
+                            # separate 8-column product (same kernel family, kid as above) with the oracle
+                            B8 = Bs.reshape(mm_m, ncols)[:, :8].contiguous()
+                            C8 = torch.zeros(mm_m * 8, dtype=torch.float64, device=device)
+                            assert L.aoclsparse_dcsrmm_kid(pkg.OP_NONE, 1.0, sh.A.h, sh.descr.h, pkg.ORDER_ROW, pkg._ptr(B8), 8, 8, 0.0,
+                                                           pkg._ptr(C8), 8, kid) == 0
+                            torch.cuda.synchronize()
+                            _, Ck = oracle.dcsrmm_kt("row", lanes, 1.0, 0, v, ci, rp, mm_m, B8.cpu().numpy().reshape(-1), 8, 8, 0.0,
+                                                     np.zeros(8 * mm_m), 8)
+                            full8 = Cs.reshape(mm_m, ncols)[:, :8].contiguous().cpu().numpy().reshape(-1)
+                            ent["bit_exact_8_columns_vs_kt_oracle"] = bool(np.array_equal(C8.cpu().numpy(), Ck)
+                                                                           and np.array_equal(full8, Ck))
+                        res["cases"].append(ent)
             del sh, B, C
         return res
 
