@@ -362,7 +362,12 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
         st = ensure_spmv(const_cast<aoclsparse_matrix>(A), tr, d, p);
     if(st != aoclsparse_status_success)
         return st;
-    if(kid >= 1 && descr->type == aoclsparse_matrix_type_general)
+    // Column-major with every row shorter than the KT vector width: csrmm_col_kt never forms a full group, its element is the
+    // scalar chain from zero followed by fma(beta, C, alpha * cij) (csrmm_kt.cpp:158-191) -- the kid-0 arithmetic to the bit, so
+    // the tuned column-major kernels serve it (kid 3 on the 5-point Laplacian: 4.7 -> 1.45 ms at 256 columns).
+    const bool kt_is_ref = kid >= 1 && colmaj && p && p->valid && p->max_row_nnz > 0
+                           && p->max_row_nnz < (std::is_same<T, double>::value ? 4 : 8) * (kid == 3 ? 2 : 1);
+    if(kid >= 1 && descr->type == aoclsparse_matrix_type_general && !kt_is_ref)
     {
         // a pinned kid 1/2/3 asks for the arithmetic of the reference's KT kernels (csrmm.hpp:779-833): reproduced bit for bit
         // (symmetric descriptors have no KT kernel in the reference either: csrmm.hpp:667-718 runs *_sym_ref for every kid)

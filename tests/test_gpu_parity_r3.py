@@ -395,6 +395,36 @@ def test_csrmm_kid_row_major_on_the_tuned_kernels(n, dtype):
                 assert np.array_equal(C.view(u), ref.view(u)), (name, n, kid, alpha, beta, float(np.abs(C - ref).max()))
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_csrmm_kid_column_major_short_rows_use_the_tuned_kernels(dtype):
+    """Column-major aoclsparse_?csrmm_kid with every row shorter than the KT vector width (kid 3 on a 5-point stencil; kid 1 / 2
+    on rows of <= 3 entries): csrmm_col_kt then never forms a full group and its arithmetic is the kid-0 chain, so the call is
+    routed to the tuned column-major kernels -- still bit for bit the KT restatement."""
+    import __graft_entry__ as entry
+    m, rp, ci, v = entry.laplace5(70)
+    rp3, ci3, v3 = random_csr(9, 2000, 1800, lambda r, i: r.integers(0, 4))
+    rng = np.random.default_rng(2)
+    d = P.Descr()
+    u = np.uint64 if dtype == np.float64 else np.uint32
+    for name, mm, kk, rp_, ci_, v_, kids in (("stencil", m, m, rp, ci, v, (3,)), ("short", 2000, 1800, rp3, ci3, v3, (1, 2, 3))):
+        v_ = v_.astype(dtype)
+        A = P.Matrix(0, mm, kk, rp_, ci_, v_)
+        for n in (32, 256):
+            B = rng.uniform(-1, 1, kk * n).astype(dtype)
+            C0 = rng.uniform(-1, 1, mm * n).astype(dtype)
+            for alpha, beta in ((1.0, 0.0), (1.5, -0.25)):
+                for kid in kids:
+                    lanes = kt_lanes(kid, dtype)
+                    if dtype == np.float32 and name == "stencil" and lanes <= 5:
+                        continue
+                    C = C0.copy()
+                    fn = P.dcsrmm if dtype == np.float64 else P.scsrmm
+                    assert fn(P.OP_NONE, alpha, A, d, P.ORDER_COLUMN, B, n, kk, beta, C, mm, kid=kid) == 0
+                    kt = oracle.dcsrmm_kt if dtype == np.float64 else oracle.scsrmm_kt
+                    st, ref = kt("col", lanes, alpha, 0, v_, ci_, rp_, mm, B, n, kk, beta, C0, mm)
+                    assert st == 0 and np.array_equal(C.view(u), ref.view(u)), (name, n, kid, alpha)
+
+
 @pytest.mark.parametrize("n", [7, 16, 35])
 def test_float_csrmm_kid_reproduces_the_kt_orders(n):
     """aoclsparse_scsrmm_kid: kid 1 / 2 -> the 8-lane (256-bit) float KT kernels, kid 3 -> the 16-lane (512-bit) ones, both layouts,
