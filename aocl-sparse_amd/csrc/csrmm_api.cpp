@@ -372,11 +372,11 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
         // a pinned kid 1/2/3 asks for the arithmetic of the reference's KT kernels (csrmm.hpp:779-833): reproduced bit for bit
         // (symmetric descriptors have no KT kernel in the reference either: csrmm.hpp:667-718 runs *_sym_ref for every kid)
         const int lanes = (std::is_same<T, double>::value ? 4 : 8) * (kid == 3 ? 2 : 1);
-        // Row-major with a column count that is a multiple of the vector width (no scalar tail columns): csrmm_row_kt is then
-        // "c = c * beta; c = fma(alpha * a_k, b_kj, c)" for every element, which the tuned row-per-wave (n >= 128) and tile
+        // Row-major: csrmm_row_kt is "c = c * beta; c = fma(alpha * a_k, b_kj, c)" for the columns its vectors cover and
+        // "c = fma(a_k * b_kj, alpha, c)" for the last n mod width ones, which the tuned row-per-wave (n >= 128) and tile
         // (n < 128) kernels compute as a variant of their chain -- 2.8 -> 1.2 ms at 256 columns, 0.62 -> 0.17 at 32 on the
-        // 1000^2 Laplacian.  Matrices with row groups, other widths and column-major operands: the plain KT kernels.
-        if(!colmaj && n % lanes == 0 && p && p->valid)
+        // 1000^2 Laplacian.  Matrices with row groups, odd column counts and column-major operands: the plain KT kernels.
+        if(!colmaj && p && p->valid)
         {
             if(!p->mm.tried)
             {
@@ -391,11 +391,11 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
                && csrmm_tiled_applies<T>(n, ldb, ldc, static_cast<const T *>(dB), static_cast<const T *>(dC)))
                 ks = launch_csrmm_tiled<T>(rt.stream(), d->base, alpha, d->val.as<T>(), d->ind.as<aoclsparse_int>(),
                                            d->ptr.as<aoclsparse_int>(), p->rowblocks.as<aoclsparse_int>(), p->nblocks, p->tile,
-                                           p->max_row_nnz, static_cast<const T *>(dB), n, ldb, beta, static_cast<T *>(dC), ldc, true);
+                                           p->max_row_nnz, static_cast<const T *>(dB), n, ldb, beta, static_cast<T *>(dC), ldc, lanes);
             else if(!p->mm.valid)
                 ks = launch_csrmm<T>(rt.stream(), order, d->base, alpha, d->m, d->n, d->val.as<T>(), d->ind.as<aoclsparse_int>(),
                                      d->ptr.as<aoclsparse_int>(), static_cast<const T *>(dB), n, ldb, beta, static_cast<T *>(dC),
-                                     ldc, nullptr, 0, 0, false, nullptr, true);
+                                     ldc, nullptr, 0, 0, false, nullptr, lanes);
             if(ks != aoclsparse_status_not_implemented)
                 return ks == aoclsparse_status_success ? finish() : ks;
         }

@@ -174,6 +174,8 @@ __global__ __launch_bounds__(256) void csrmm_row_wave_kernel(int base, T alpha, 
 // (row pointers -> values / columns -> four B rows -> the fifth -> C); this one three.  Same chain per element: same bits.
 // KT: the arithmetic of the reference's csrmm_row_kt (csrmm_kt.cpp:244-356) for column counts that are a multiple of its vector
 // width: c = c * beta first, then c = fma(alpha * a_k, b_kj, c) entry by entry -- what aoclsparse_?csrmm_kid 1/2/3 asks for.
+// kt_tail: the last kt_tail columns (n modulo the vector width) take csrmm_row_kt's scalar statement "C += sv * B * alpha" =
+// fma(sv * b, alpha, c) (csrmm_kt.cpp:335-356) instead of fma(alpha * sv, b, c): a per-lane choice between two roundings.
 template <typename T, bool KT = false>
 __global__ __launch_bounds__(256) void csrmm_row_wave_rc_kernel(int base, T alpha, aoclsparse_int m,
                                                                 const T *__restrict__ val,
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256) void csrmm_row_wave_rc_kernel(int base, T alph
                                                                 const aoclsparse_int *__restrict__ row_ptr,
                                                                 const T *__restrict__ B, aoclsparse_int n,
                                                                 aoclsparse_int ldb, T beta, T *__restrict__ C,
-                                                                aoclsparse_int ldc, int xcd_chunk)
+                                                                aoclsparse_int ldc, int xcd_chunk, int kt_tail = 0)
 {
     using V      = typename vec2<T>::type;
     const int w  = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -209,9 +211,23 @@ __global__ __launch_bounds__(256) void csrmm_row_wave_rc_kernel(int base, T alph
             b[k] = *reinterpret_cast<const V *>(Bj + (ptrdiff_t)col[p + k] * ldb);
         if(KT && first) // (after the B rows are requested: the chain starts from beta * C)
             a0 = c0.x * beta, a1 = c0.y * beta, first = false;
+        if(KT && kt_tail > 0) // (wave-uniform: only launches with tail columns pay for the second form)
+        {
+            const bool t0 = j >= n - kt_tail, t1 = j + 1 >= n - kt_tail;
 #pragma unroll
-        for(int k = 0; k < W; k++)
-            a0 = mm_fma(v[k], b[k].x, a0), a1 = mm_fma(v[k], b[k].y, a1);
+            for(int k = 0; k < W; k++)
+            {
+                const T sv = val[p + k];
+                a0         = t0 ? mm_fma(sv * b[k].x, alpha, a0) : mm_fma(v[k], b[k].x, a0);
+                a1         = t1 ? mm_fma(sv * b[k].y, alpha, a1) : mm_fma(v[k], b[k].y, a1);
+            }
+        }
+        else
+        {
+#pragma unroll
+            for(int k = 0; k < W; k++)
+                a0 = mm_fma(v[k], b[k].x, a0), a1 = mm_fma(v[k], b[k].y, a1);
+        }
     };
     int p = s;
     for(; p + 8 <= e; p += 8)
@@ -746,7 +762,7 @@ __global__ __launch_bounds__(256, 4) void csrmm_tile_kernel(int base, T alpha, c
                                                          const aoclsparse_int *__restrict__ blocks, aoclsparse_int nblocks,
                                                          const T *__restrict__ B, aoclsparse_int n, aoclsparse_int ldb,
                                                          T beta, T *__restrict__ C, aoclsparse_int ldc, bool readc,
-                                                         int xcd_chunk, unsigned long long *trace = nullptr)
+                                                         int xcd_chunk, unsigned long long *trace = nullptr, int kt_tail = 0)
 {
     // diagnostic (AOCLSPARSE_MI355_MM_TRACE=<file>, tools/mm_trace.py): 100 MHz stamps per workgroup -- start / block table
     // read / tile loads landed / after the barrier / end -- kept in registers and stored by thread 0 at the very end
@@ -801,11 +817,14 @@ __global__ __launch_bounds__(256, 4) void csrmm_tile_kernel(int base, T alpha, c
                 const V c = *cp;
                 a0 = c.x * beta, a1 = c.y * beta;
             }
+            const bool t0 = KT && j >= n - kt_tail, t1 = KT && j + 1 >= n - kt_tail; // (csrmm_row_kt's scalar tail columns)
             for(int p = s0; p < s0 + cnt; p++)
             {
-                const T a = KT ? alpha * val[p] : val[p];
-                const V b = *reinterpret_cast<const V *>(Bj + (size_t)(col[p] - base) * ldb);
-                a0 = mm_fma(a, b.x, a0), a1 = mm_fma(a, b.y, a1);
+                const T sv = val[p];
+                const T a  = KT ? alpha * sv : sv;
+                const V b  = *reinterpret_cast<const V *>(Bj + (size_t)(col[p] - base) * ldb);
+                a0 = t0 ? mm_fma(sv * b.x, alpha, a0) : mm_fma(a, b.x, a0);
+                a1 = t1 ? mm_fma(sv * b.y, alpha, a1) : mm_fma(a, b.y, a1);
             }
             if constexpr(KT)
             {
@@ -872,6 +891,27 @@ __global__ __launch_bounds__(256, 4) void csrmm_tile_kernel(int base, T alpha, c
                 first = false;
             }
             more = false;
+            if(KT && kt_tail > 0) // (wave-uniform) csrmm_row_kt's scalar tail columns: fma(sv * b, alpha, c)
+            {
+                const bool t0 = j >= n - kt_tail, t1 = j + 1 >= n - kt_tail;
+#pragma unroll
+                for(int q = 0; q < UR; q++)
+#pragma unroll
+                    for(int u = 0; u < NB; u++)
+                        if(p0[q] + u < p1[q])
+                        {
+                            const T sv = s_val[p0[q] + u];
+                            a0[q]      = t0 ? mm_fma(sv * b[q][u].x, alpha, a0[q]) : mm_fma(v[q][u], b[q][u].x, a0[q]);
+                            a1[q]      = t1 ? mm_fma(sv * b[q][u].y, alpha, a1[q]) : mm_fma(v[q][u], b[q][u].y, a1[q]);
+                        }
+#pragma unroll
+                for(int q = 0; q < UR; q++)
+                {
+                    p0[q] += NB;
+                    more |= p0[q] < p1[q];
+                }
+            }
+            else
 #pragma unroll
             for(int q = 0; q < UR; q++)
             {
@@ -1296,8 +1336,9 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
                                aoclsparse_int /*k*/, const T *val, const aoclsparse_int *col,
                                const aoclsparse_int *row_ptr, const T *B, aoclsparse_int n,
                                aoclsparse_int ldb, T beta, T *C, aoclsparse_int ldc, const aoclsparse_int *grp,
-                               aoclsparse_int ngroups, int group_rows, bool row_runs, const aoclsparse_int *run_order, bool kt)
+                               aoclsparse_int ngroups, int group_rows, bool row_runs, const aoclsparse_int *run_order, int kt_lanes)
 {
+    const bool kt = kt_lanes > 0;
     if(m <= 0 || n <= 0)
         return aoclsparse_status_success;
     // kt: the arithmetic of csrmm_row_kt, offered by the row-per-wave kernel only (anything else: not_implemented, the caller
@@ -1311,7 +1352,7 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
             return aoclsparse_status_not_implemented;
         const int chunk_kt = ((m + 3) / 4 + 7) / 8;
         hipLaunchKernelGGL((csrmm_row_wave_rc_kernel<T, true>), dim3(chunk_kt * 8, (n + 127) / 128), dim3(256), 0, s, base, alpha, m,
-                           val, col, row_ptr, B, n, ldb, beta, C, ldc, chunk_kt);
+                           val, col, row_ptr, B, n, ldb, beta, C, ldc, chunk_kt, (int)(n % kt_lanes));
         MI355_HIP_TRY(hipGetLastError());
         return aoclsparse_status_success;
     }
@@ -1554,10 +1595,12 @@ template <typename T>
 aoclsparse_status launch_csrmm_tiled(hipStream_t s, int base, T alpha, const T *val, const aoclsparse_int *col,
                                      const aoclsparse_int *row_ptr, const aoclsparse_int *blocks, aoclsparse_int nblocks,
                                      int tile, aoclsparse_int max_row_nnz, const T *B, aoclsparse_int n, aoclsparse_int ldb,
-                                     T beta, T *C, aoclsparse_int ldc, bool kt)
+                                     T beta, T *C, aoclsparse_int ldc, int kt_lanes)
 {
     if(nblocks <= 0 || n <= 0)
         return aoclsparse_status_success;
+    const bool kt      = kt_lanes > 0;
+    const int  kt_tail = kt ? (int)(n % kt_lanes) : 0; // csrmm_row_kt's scalar tail columns
     const bool readc = kt || csrmm_reads_c(beta != T(0)); // (the KT arithmetic always reads C: c = c * beta comes first)
     constexpr bool xcd = true;
     const int  chunk = (nblocks + 7) / 8; // XCD-contiguous block order, as the other csrmm kernels
@@ -1599,7 +1642,8 @@ aoclsparse_status launch_csrmm_tiled(hipStream_t s, int base, T alpha, const T *
             if(kt)
             {
                 hipLaunchKernelGGL((csrmm_tile_kernel<T, 16, TILE, 2, NB, true, true>), grid, dim3(256), 0, s, base, alpha, val, col,
-                                   row_ptr, blocks, nblocks, B, n, ldb, beta, C, ldc, readc, chunk);
+                                   row_ptr, blocks, nblocks, B, n, ldb, beta, C, ldc, readc, chunk, (unsigned long long *)nullptr,
+                                   kt_tail);
                 return;
             }
         }
@@ -1672,7 +1716,7 @@ aoclsparse_status launch_csrmm_colpair(hipStream_t s, int base, T alpha, aoclspa
                                                aoclsparse_int, const T *, const aoclsparse_int *,             \
                                                const aoclsparse_int *, const T *, aoclsparse_int,             \
                                                aoclsparse_int, T, T *, aoclsparse_int, const aoclsparse_int *, \
-                                               aoclsparse_int, int, bool, const aoclsparse_int *, bool);      \
+                                               aoclsparse_int, int, bool, const aoclsparse_int *, int);       \
     template aoclsparse_status launch_scale_dense<T>(hipStream_t, aoclsparse_order, T *, aoclsparse_int,     \
                                                      aoclsparse_int, aoclsparse_int, T);                     \
     template aoclsparse_status launch_relayout<T>(hipStream_t, bool, const T *, T *, aoclsparse_int,         \
@@ -1690,7 +1734,7 @@ aoclsparse_status launch_csrmm_colpair(hipStream_t s, int base, T alpha, aoclspa
     template aoclsparse_status launch_csrmm_tiled<T>(hipStream_t, int, T, const T *, const aoclsparse_int *,   \
                                                      const aoclsparse_int *, const aoclsparse_int *,          \
                                                      aoclsparse_int, int, aoclsparse_int, const T *, aoclsparse_int, \
-                                                     aoclsparse_int, T, T *, aoclsparse_int, bool);
+                                                     aoclsparse_int, T, T *, aoclsparse_int, int);
 MI355_INST_MM(double)
 MI355_INST_MM(float)
 template aoclsparse_status launch_csrmm_kt<double>(hipStream_t, aoclsparse_order, int, int, double, aoclsparse_int, const double *,

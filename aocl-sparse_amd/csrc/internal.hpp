@@ -808,7 +808,7 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
                                aoclsparse_int n, aoclsparse_int ldb, T beta, T *C,
                                aoclsparse_int ldc, const aoclsparse_int *grp = nullptr, aoclsparse_int ngroups = 0,
                                int group_rows = 0, bool row_runs = false,
-                               const aoclsparse_int *run_order = nullptr, bool kt = false);
+                               const aoclsparse_int *run_order = nullptr, int kt_lanes = 0);
 // column-major detour, handles with row groups: row-major B scratch in, column-major C written directly (no C copies)
 template <typename T>
 bool csrmm_groups_ccol_applies(aoclsparse_int n, aoclsparse_int ldb, const T *B);
@@ -824,7 +824,7 @@ template <typename T>
 aoclsparse_status launch_csrmm_tiled(hipStream_t s, int base, T alpha, const T *val, const aoclsparse_int *col,
                                      const aoclsparse_int *row_ptr, const aoclsparse_int *blocks, aoclsparse_int nblocks,
                                      int tile, aoclsparse_int max_row_nnz, const T *B, aoclsparse_int n, aoclsparse_int ldb,
-                                     T beta, T *C, aoclsparse_int ldc, bool kt = false);
+                                     T beta, T *C, aoclsparse_int ldc, int kt_lanes = 0);
 // column-major: a lane owns a row PAIR; 16-byte loads where the second row is the first shifted by one column
 template <typename T>
 aoclsparse_status launch_csrmm_colpair(hipStream_t s, int base, T alpha, aoclsparse_int npairs,

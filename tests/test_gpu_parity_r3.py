@@ -358,12 +358,12 @@ def test_csrmm_within_bound_of_the_kt_orders(n, alpha, beta):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("n", [32, 48, 128, 256])
+@pytest.mark.parametrize("n", [32, 36, 48, 100, 128, 130, 256])
 def test_csrmm_kid_row_major_on_the_tuned_kernels(n, dtype):
-    """Row-major aoclsparse_?csrmm_kid 1 / 2 / 3 with a column count that is a multiple of the KT vector width runs on the tuned
-    kernels (tile kernel below 128 columns, row-per-wave kernel from 128) in their csrmm_row_kt arithmetic: c = c * beta, then
-    c = fma(alpha * a_k, b_kj, c) (csrmm_kt.cpp:244-356) -- bit for bit against the restatement pinned on the reference's
-    templates.  Matrices: a 5-point stencil (the benchmark pattern), a random CSR with empty rows, and one with a row longer than
+    """Row-major aoclsparse_?csrmm_kid 1 / 2 / 3 runs on the tuned kernels (tile kernel below 128 columns, row-per-wave kernel
+    from 128) in their csrmm_row_kt arithmetic: c = c * beta, then c = fma(alpha * a_k, b_kj, c) for the columns the vectors
+    cover and c = fma(a_k * b_kj, alpha, c) for the last n mod width ones (csrmm_kt.cpp:244-356) -- bit for bit against the
+    restatement pinned on the reference's templates.  Matrices: a 5-point stencil (the benchmark pattern), a random CSR with empty rows, and one with a row longer than
     an LDS tile."""
     import __graft_entry__ as entry
     mats = []
@@ -382,9 +382,7 @@ def test_csrmm_kid_row_major_on_the_tuned_kernels(n, dtype):
         C0 = rng.uniform(-1, 1, m * n).astype(dtype)
         for alpha, beta in ((1.0, 0.0), (-1.75, 0.625)):
             for kid in (1, 2, 3):
-                lanes = kt_lanes(kid, dtype)
-                if n % lanes:
-                    continue
+                lanes = kt_lanes(kid, dtype)  # (n % lanes != 0: the last columns take csrmm_row_kt's scalar statement)
                 C = C0.copy()
                 fn = P.dcsrmm if dtype == np.float64 else P.scsrmm
                 assert fn(P.OP_NONE, alpha, A, d, P.ORDER_ROW, B, n, n, beta, C, n, kid=kid) == 0
