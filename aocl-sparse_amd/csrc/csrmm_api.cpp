@@ -375,24 +375,17 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
         // Row-major: csrmm_row_kt is "c = c * beta; c = fma(alpha * a_k, b_kj, c)" for the columns its vectors cover and
         // "c = fma(a_k * b_kj, alpha, c)" for the last n mod width ones, which the tuned row-per-wave (n >= 128) and tile
         // (n < 128) kernels compute as a variant of their chain -- 2.8 -> 1.2 ms at 256 columns, 0.62 -> 0.17 at 32 on the
-        // 1000^2 Laplacian.  Matrices with row groups, odd column counts and column-major operands: the plain KT kernels.
+        // 1000^2 Laplacian.  Odd column counts and column-major operands: the plain KT kernels.
         if(!colmaj && p && p->valid)
         {
-            if(!p->mm.tried)
-            {
-                std::unique_lock<std::shared_mutex> w(A->guard);
-                st = build_mm_groups(tr ? *A->trans : A->user, *p);
-                if(st != aoclsparse_status_success)
-                    return st;
-            }
             std::shared_lock<std::shared_mutex> r(A->guard);
             aoclsparse_status                   ks = aoclsparse_status_not_implemented;
-            if(!p->mm.valid && p->nblocks > 0
-               && csrmm_tiled_applies<T>(n, ldb, ldc, static_cast<const T *>(dB), static_cast<const T *>(dC)))
+            // (matrices with row groups: the group kernels have no KT form; the per-row kernels below ignore the groups)
+            if(p->nblocks > 0 && csrmm_tiled_applies<T>(n, ldb, ldc, static_cast<const T *>(dB), static_cast<const T *>(dC)))
                 ks = launch_csrmm_tiled<T>(rt.stream(), d->base, alpha, d->val.as<T>(), d->ind.as<aoclsparse_int>(),
                                            d->ptr.as<aoclsparse_int>(), p->rowblocks.as<aoclsparse_int>(), p->nblocks, p->tile,
                                            p->max_row_nnz, static_cast<const T *>(dB), n, ldb, beta, static_cast<T *>(dC), ldc, lanes);
-            else if(!p->mm.valid)
+            else
                 ks = launch_csrmm<T>(rt.stream(), order, d->base, alpha, d->m, d->n, d->val.as<T>(), d->ind.as<aoclsparse_int>(),
                                      d->ptr.as<aoclsparse_int>(), static_cast<const T *>(dB), n, ldb, beta, static_cast<T *>(dC),
                                      ldc, nullptr, 0, 0, false, nullptr, lanes);

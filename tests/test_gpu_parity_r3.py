@@ -373,6 +373,10 @@ def test_csrmm_kid_row_major_on_the_tuned_kernels(n, dtype):
     mats.append(("random", 900, 700, rp, ci, v))
     rp, ci, v = random_csr(6, 300, 1500, lambda r, i: 1400 if i == 17 else r.integers(0, 12))
     mats.append(("long row", 300, 1500, rp, ci, v))
+    # a matrix WITH row groups (3 dofs per mesh node): the group kernels have no KT form, the per-row kernels serve the kid
+    from test_gpu_trsv_blocks import node_mesh
+    mg, rpg, cig, vg = node_mesh(77, 400, 20, np.full(400, 3))
+    mats.append(("row groups", mg, mg, rpg, cig, vg))
     rng = np.random.default_rng(44)
     d = P.Descr()
     for name, m, k, rp, ci, v in mats:

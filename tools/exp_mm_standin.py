@@ -16,8 +16,11 @@ A = pkg.Matrix(0, m, m, rp, ci, v); d = pkg.Descr()
 assert L.aoclsparse_set_mm_hint(A.h, pkg.OP_NONE, d.h, 100) == 0 and L.aoclsparse_optimize(A.h) == 0
 B = torch.from_numpy(np.random.default_rng(1).uniform(-1, 1, (m, n))).to(dev)
 C = torch.zeros((m, n), dtype=torch.float64, device=dev)
-call = lambda: L.aoclsparse_dcsrmm(pkg.OP_NONE, 1.0, A.h, d.h, pkg.ORDER_COLUMN if colmaj else pkg.ORDER_ROW, pkg._ptr(B), n,
-                                  m if colmaj else n, 0.0, pkg._ptr(C), m if colmaj else n)
+KID = int(os.environ["KID"]) if "KID" in os.environ else None   # KID=<0..3>: aoclsparse_dcsrmm_kid
+call = (lambda: L.aoclsparse_dcsrmm(pkg.OP_NONE, 1.0, A.h, d.h, pkg.ORDER_COLUMN if colmaj else pkg.ORDER_ROW, pkg._ptr(B), n,
+                                   m if colmaj else n, 0.0, pkg._ptr(C), m if colmaj else n)) if KID is None else (
+    lambda: L.aoclsparse_dcsrmm_kid(pkg.OP_NONE, 1.0, A.h, d.h, pkg.ORDER_COLUMN if colmaj else pkg.ORDER_ROW, pkg._ptr(B), n,
+                                    m if colmaj else n, 0.0, pkg._ptr(C), m if colmaj else n, KID))
 for _ in range(3):
     assert call() == 0
 torch.cuda.synchronize()
