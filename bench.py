@@ -27,7 +27,12 @@ driver starts it with torch.distributed.run, one rank per GPU.  Prints ONE JSON 
                                      eight ranks owns
                 csrmm_sharded        configs[3] over the N ranks (aocl-sparse_amd/sharded.py): A broadcast (RCCL), B/C
                                      column slabs, efficiency T1 / (N * TN), optional C all-gather
-                trsv                 configs[4]: unit-lower ILU(0) factor of the shell-like matrix
+                trsv                 configs[4]: unit-lower ILU(0) factor of the shell-like matrix (and of its unstructured
+                                     variant), automatic kid and the pinned KT orders (kid 1 / 3)
+                inlib_multi          configs[3] from ONE process: aoclsparse_mi355_dcsrmm_multi_slabs over every visible GPU
+                                     (tools/multi_check.py as a child process)
+              (csrmm also holds the pinned-kid cases; l100.c_caller is the per-call cost seen by a C program, tools/l100_probe.hip;
+               --grid 10000 runs the 10,000 x 10,000-grid reading of configs[1]: m = 1e8, 8 GB per product)
 """
 import argparse
 import json
