@@ -373,26 +373,62 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restr
         const int n = cnt;
         if(flags & 1)
         {
+            // Tiles through LDS, the owner lanes chain them in the reference's order.  Round 3: the NEXT tile's values and x
+            // are requested (into registers) before the owner lanes start on the current one, and the chain reads LDS in
+            // batches of 8 -- a row then costs its FMA chain (~8 cycles per entry), not a memory round trip + an LDS round trip
+            // per entry: web-like (91 rows of up to 2,908 entries) 59 -> 44.5 us with AOCLSPARSE_MI355_STRICT_LONG=8192 (28.5 us without:
+            // the longest chain, ~15 ns per entry, now IS the kernel; 16-entry steps with paired reads and two alternating register
+            // sets measured 50 us).
             const int nfull = n & ~(L - 1);
             T         acc   = T(0);
+            constexpr int EPT = TILE / BLOCK;
+            T             nv[EPT], nx[EPT];
+            auto          fetch = [&](int t0) {
+                const int tn = min(TILE, nfull - t0);
+#pragma unroll
+                for(int k = 0; k < EPT; k++)
+                {
+                    const int i = tid + k * BLOCK;
+                    nv[k] = T(0), nx[k] = T(0);
+                    if(i < tn)
+                    {
+                        nv[k] = val[p0 + t0 + i];
+                        nx[k] = xb[col[p0 + t0 + i]];
+                    }
+                }
+            };
+            if(nfull > 0)
+                fetch(0);
             for(int t0 = 0; t0 < nfull; t0 += TILE)
             {
                 const int tn = min(TILE, nfull - t0);
-                __syncthreads();
+                __syncthreads(); // the owner lanes are done with the previous tile
 #pragma unroll
-                for(int k = 0; k < TILE / BLOCK; k++)
+                for(int k = 0; k < EPT; k++)
                 {
                     const int i = tid + k * BLOCK;
                     if(i < tn)
-                    {
-                        s_val[i] = val[p0 + t0 + i];
-                        s_x[i]   = xb[col[p0 + t0 + i]];
-                    }
+                        s_val[i] = nv[k], s_x[i] = nx[k];
                 }
                 __syncthreads();
+                if(t0 + TILE < nfull)
+                    fetch(t0 + TILE); // in flight while the chain below runs
                 if(tid < L)
-                    for(int j = tid; j < tn; j += L)
+                {
+                    int j = tid;
+                    for(; j + 7 * L < tn; j += 8 * L)
+                    {
+                        T a[8], b[8];
+#pragma unroll
+                        for(int q = 0; q < 8; q++)
+                            a[q] = s_val[j + q * L], b[q] = s_x[j + q * L];
+#pragma unroll
+                        for(int q = 0; q < 8; q++)
+                            acc = dev_fma(a[q], b[q], acc);
+                    }
+                    for(; j < tn; j += L)
                         acc = dev_fma(s_val[j], s_x[j], acc);
+                }
             }
             if(tid < 64) // first wavefront: owner lanes 0..L-1 hold the chains
             {
