@@ -272,3 +272,123 @@ def bench_sharded_csrmm(pkg, torch, dist, device, rank, world, csr, ncols, layou
                                 "frac": round(fb / t1 / 1e6 / peak_gbs, 4), "traffic": None,
                                 "algorithmic_bytes_per_launch": fb}
     return out, sh, B, C
+
+
+# ---- row-sharded SpMV for iterative use ("next") ---------------------------------------------------------
+# A single product does not shard (the all-gather of x costs more than the kernel), but an ITERATION that
+# feeds y back as the next x (power iteration, Jacobi, the p of CG) can keep A split by rows: rank r owns rows [r0, r1) of A
+# (all columns) and the matching slice of y; every product needs the FULL x, so each iteration ends with ONE all-gather of the
+# slices (8 n bytes per rank pair over xGMI with "nccl").  Row-wise arithmetic does not depend on the split: every y_i has the
+# bits of the unsharded product.
+
+
+def row_shard(m, world, rank):
+    """rows [r0, r1) of rank `rank`: contiguous, balanced to within one row"""
+    return (m * rank) // world, (m * (rank + 1)) // world
+
+
+def slice_rows(csr, r0, r1):
+    """(m, n, row_ptr, col_ind, val) -> the same five for rows [r0, r1) (row pointers rebased to the slice's first entry;
+    index base kept: row_ptr[0] of a base-b matrix stays b)"""
+    m, n, rp, ci, v = csr
+    base = int(rp[0])
+    s, e = int(rp[r0]) - base, int(rp[r1]) - base
+    return r1 - r0, n, (np.asarray(rp[r0:r1 + 1]) - s).astype(np.int32), np.ascontiguousarray(ci[s:e]), np.ascontiguousarray(v[s:e])
+
+
+def allgather_rows(torch, dist, device, rank, world, m, y_loc, x_full):
+    """x_full[0:m] <- concatenation of every rank's y_loc (lengths by row_shard); returns the time in ms.  The collective wants
+    equal pieces: slices are padded to the longest one in a scratch tensor and compacted after the gather (m % world != 0)."""
+    if dist is None or not dist.is_initialized() or world == 1:
+        x_full[:m].copy_(y_loc[:m])
+        return 0.0
+    wire = "cpu" if _backend(dist) == "gloo" else device
+    mx = max(row_shard(m, world, r)[1] - row_shard(m, world, r)[0] for r in range(world))
+    r0, r1 = row_shard(m, world, rank)
+    piece = torch.zeros(mx, dtype=y_loc.dtype, device=wire)
+    piece[: r1 - r0].copy_(y_loc[: r1 - r0])
+    pieces = torch.empty(world * mx, dtype=y_loc.dtype, device=wire)
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dist.all_gather_into_tensor(pieces, piece)
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    for r in range(world):
+        a, b = row_shard(m, world, r)
+        x_full[a:b].copy_(pieces[r * mx: r * mx + (b - a)])
+    return ms
+
+
+class ShardedSpmv:
+    """One rank's rows of y = A x (square A): handle over its row slice (mv hint + optimize), the full x on the device."""
+
+    def __init__(self, pkg, torch, dist, device, rank, world, csr):
+        self.pkg, self.torch, self.dist, self.device, self.rank, self.world = pkg, torch, dist, device, rank, world
+        (self.m, self.n, rp, ci, v), self.a_broadcast_ms = broadcast_csr(dist, torch, device, rank, csr)
+        assert self.m == self.n, "the iteration feeds y back as x"
+        self.r0, self.r1 = row_shard(self.m, world, rank)
+        ml, nl, rpl, cil, vl = slice_rows((self.m, self.n, rp, ci, v), self.r0, self.r1)
+        self.nnz_loc, self.nnz = int(len(vl)), int(len(v))
+        self.A = pkg.Matrix(int(rp[0]), ml, nl, rpl, cil, vl)
+        assert self.A.status == 0, pkg.STATUS[self.A.status]
+        self.descr = pkg.Descr(base=int(rp[0]))
+        L = pkg.lib()
+        assert L.aoclsparse_set_mv_hint(self.A.h, pkg.OP_NONE, self.descr.h, 1000) == 0
+        assert L.aoclsparse_optimize(self.A.h) == 0
+
+    def product(self, x_full, y_loc, alpha=1.0, beta=0.0):
+        return self.pkg.dmv(self.pkg.OP_NONE, alpha, self.A, self.descr, x_full, beta, y_loc)
+
+    def gather(self, y_loc, x_full):
+        return allgather_rows(self.torch, self.dist, self.device, self.rank, self.world, self.m, y_loc, x_full)
+
+
+def bench_sharded_spmv(pkg, torch, dist, device, rank, world, csr, iters=20, warm=3, peak_gbs=8000.0):
+    """`iters` iterations x <- A x (each: the local product, then the all-gather of the slices) on `world` ranks; returns the
+    per-iteration times (product: max over ranks of the median device time; gather: max over ranks of the median wall time),
+    the whole-job GFLOP/s including the gathers, and the bits of rank 0's slice for the caller's parity check."""
+    sh = ShardedSpmv(pkg, torch, dist, device, rank, world, csr)
+    m = sh.m
+    x = torch.from_numpy(np.sin(0.01 * np.arange(m))).to(device)
+    x0 = x.clone()
+    y = torch.zeros(max(sh.r1 - sh.r0, 1), dtype=torch.float64, device=device)
+    # parity input: ONE product of the un-iterated x (iterating a Laplacian overflows nothing in 20 steps, but the check
+    # wants a known x)
+    assert sh.product(x0, y) == 0
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    y_first = y[: sh.r1 - sh.r0].clone()
+    prod_ms, gat_ms = [], []
+    barrier(dist, torch)
+    t_all = time.perf_counter()
+    for it in range(warm + iters):
+        if it == warm:
+            barrier(dist, torch)
+            t_all = time.perf_counter()
+        pkg.timer_start()
+        assert sh.product(x, y) == 0
+        p = pkg.timer_stop()
+        g = sh.gather(y, x)
+        if it >= warm:
+            prod_ms.append(p), gat_ms.append(g)
+        # keep the iterate bounded (a scalar scale on every rank's copy: not part of the timed pieces' meaning)
+        x.mul_(0.125)
+    barrier(dist, torch)
+    wall = (time.perf_counter() - t_all) / iters * 1e3
+    tp = reduce_scalar(float(np.median(prod_ms)), "max", dist, device)
+    tg = reduce_scalar(float(np.median(gat_ms)), "max", dist, device)
+    tw = reduce_scalar(wall, "max", dist, device)
+    loc_bytes = (sh.r1 - sh.r0 + 1 + sh.nnz_loc) * 4 + (sh.r1 - sh.r0 + m + sh.nnz_loc) * 8
+    gbs = loc_bytes / tp / 1e6 if tp > 0 else 0.0
+    return {"what": "x <- A x iterated, A split by rows over %d rank(s), one all-gather of the slices per iteration" % world,
+            "world": world, "m": m, "nnz": sh.nnz, "rows_per_rank": sh.r1 - sh.r0, "a_broadcast_ms": round(sh.a_broadcast_ms, 3),
+            "product_ms_median_max_over_ranks": round(tp, 5), "allgather_ms_median_max_over_ranks": round(tg, 5),
+            "iteration_ms_wall_max_over_ranks": round(tw, 5), "gflops_job_products_only": round(2.0 * sh.nnz / tp / 1e6, 2) if tp > 0 else 0.0,
+            "gflops_job_with_gather": round(2.0 * sh.nnz / (tp + tg) / 1e6, 2) if tp + tg > 0 else 0.0,
+            "allgather_bytes_per_rank": 8 * m,
+            "note": ("a rank's share of the matrix (%d MB) fits the 256 MiB Infinity Cache: the product can run above the HBM roofline"
+                     % (loc_bytes >> 20)) if loc_bytes < (256 << 20) * 1.5 else None,
+            "roofline_shard": {"bound": "hbm", "achieved": round(gbs, 2), "peak": peak_gbs, "unit": "GB/s",
+                               "frac": round(gbs / peak_gbs, 4), "traffic": None, "algorithmic_bytes_per_launch": loc_bytes}}, sh, y_first, x0

@@ -29,6 +29,8 @@ driver starts it with torch.distributed.run, one rank per GPU.  Prints ONE JSON 
                                      column slabs, efficiency T1 / (N * TN), optional C all-gather
                 trsv                 configs[4]: unit-lower ILU(0) factor of the shell-like matrix (and of its unstructured
                                      variant), automatic kid and the pinned KT orders (kid 1 / 3)
+                spmv_row_sharded     SURVEY 8e "next": x <- A x iterated with A split by rows over the N ranks, one all-gather of
+                                     the y slices per iteration (RCCL with nccl)
                 inlib_multi          configs[3] from ONE process: aoclsparse_mi355_dcsrmm_multi_slabs over every visible GPU
                                      (tools/multi_check.py as a child process)
               (csrmm also holds the pinned-kid cases; l100.c_caller is the per-call cost seen by a C program, tools/l100_probe.hip;
@@ -176,15 +178,16 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: CPU tensors on the wire, ranks may share one GPU (control-flow tests on a 1-GPU box)")
     ap.add_argument("--legs", default="all",
-                    help="comma list of l100,dcsrmv_csr_adaptive,mix,csrmm,csrmm_sharded,trsv,cpu,inlib_multi (or all / none)")
+                    help="comma list of l100,dcsrmv_csr_adaptive,mix,csrmm,csrmm_sharded,spmv_row_sharded,trsv,cpu,inlib_multi (or all / none)")
     ap.add_argument("--mm-grid", type=int, default=1000, help="csrmm: A = Laplacian on grid^2")
     ap.add_argument("--mm-cols", type=int, default=256)
+    ap.add_argument("--shard-grid", type=int, default=2048, help="grid of the row-sharded SpMV iteration leg")
     ap.add_argument("--mm-layout", default="row", choices=["col", "row"],
                     help="layout of the sharded csrmm leg (row-major slabs are the faster ones: 0.13 vs 0.19 ms per 32-column slab)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU-baseline budget per thread count")
     ap.add_argument("--small", action="store_true", help="mix / trsv legs on the two small matrices only")
     args = ap.parse_args()
-    all_legs = ["l100", "dcsrmv_csr_adaptive", "mix", "csrmm", "csrmm_sharded", "trsv", "cpu", "inlib_multi"]
+    all_legs = ["l100", "dcsrmv_csr_adaptive", "mix", "csrmm", "csrmm_sharded", "spmv_row_sharded", "trsv", "cpu", "inlib_multi"]
     legs = set(all_legs) if args.legs == "all" else set(x for x in args.legs.split(",") if x and x != "none")
     assert legs <= set(all_legs), "unknown leg in --legs: %s" % sorted(legs - set(all_legs))
 
@@ -381,6 +384,30 @@ def main():
         return res
 
     run_leg("csrmm_sharded", leg_csrmm_sharded, collective=True)
+
+    # ---- SURVEY 8e "next": the iteration x <- A x with A split by rows and one all-gather of the slices per iteration ----
+    def leg_spmv_row_sharded():
+        csr_s = None
+        if rank == 0:
+            ms_, rp_, ci_, v_ = entry.laplace5(args.shard_grid)
+            csr_s = (ms_, ms_, rp_, ci_, v_)
+        res, sh, y_first, x0 = sharded.bench_sharded_spmv(pkg, torch, D, device, rank, world, csr_s, iters=20, warm=3,
+                                                          peak_gbs=HBM_PEAK_GBS)
+        res["workload"] = ("aoclsparse_dmv on row slices of the 5-pt Laplacian %dx%d grid, %d rank(s); every iteration ends with an "
+                           "all-gather of the y slices (%s)" % (args.shard_grid, args.shard_grid, world,
+                                                               "RCCL" if args.backend == "nccl" and world > 1 else
+                                                               "gloo, CPU tensors" if world > 1 else "one rank: none"))
+        if rank == 0:
+            import oracle
+            ms_, rp_, ci_, v_ = csr_s[0], csr_s[2], csr_s[3], csr_s[4]
+            so, yr = oracle.dcsrmv(-1, 0, 1.0, ms_, len(v_), v_, ci_, rp_, x0.cpu().numpy(), 0.0, np.zeros(ms_),
+                                   nthreads=oracle.max_threads())
+            res["parity"] = {"vs": "oracle ref_csrmv_gn order, rank 0's rows of the UNSHARDED product",
+                             "bit_exact": bool(np.array_equal(y_first.cpu().numpy(), yr[sh.r0:sh.r1]))}
+            unpin()
+        return res
+
+    run_leg("spmv_row_sharded", leg_spmv_row_sharded, collective=True)
 
     if rank == 0:
         import oracle
@@ -788,6 +815,8 @@ def main():
         # the driver-visible aliases the round-1 line carried
         if "l100" in legs_out:
             out["l100"] = legs_out.pop("l100")
+        if "spmv_row_sharded" in legs_out:
+            out["spmv_row_sharded"] = legs_out.pop("spmv_row_sharded")
         if "csrmm_sharded" in legs_out:
             out["csrmm_sharded"] = legs_out.pop("csrmm_sharded")
         out["legs"] = legs_out

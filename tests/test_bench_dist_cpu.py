@@ -94,6 +94,13 @@ def _worker(rank, world, port, q):
         slab4 = sharded.make_B_slab(torch, "cpu", m, a0, a1, "col").reshape(a1 - a0, m)
         g4, _ = sharded.gather_slabs(torch, dist, "cpu", rank, shards4, slab4)
         empty_ok = shards4 == [(0, 4), (4, 4)] and torch.equal(g4, full[:4])
+        # row-sharded SpMV (SURVEY 8e "next"): 13 rows over 2 ranks -> 6 + 7, the slices' all-gather rebuilds the vector
+        mrow = 13
+        a, b = sharded.row_shard(mrow, world, rank)
+        yloc = torch.arange(a, b, dtype=torch.float64) * 1.5
+        xfull = torch.full((mrow,), -1.0, dtype=torch.float64)
+        gms = sharded.allgather_rows(torch, dist, "cpu", rank, world, mrow, yloc, xfull)
+        empty_ok = empty_ok and gms >= 0.0 and torch.equal(xfull, torch.arange(mrow, dtype=torch.float64) * 1.5)
         info = sharded.communicator_info(dist, torch)
         empty_ok = empty_ok and info == {"backend": "gloo", "world": world}
         q.put((rank, thr, tmax, s, mn, bool(same), bool(slab_ok), bool(torch.equal(gathered, full)) and bool(empty_ok), shards))
@@ -121,6 +128,31 @@ def test_sharded_host_logic_world2_gloo():
         assert same, "broadcast CSR differs from rank 0's"
         assert slab_ok and gather_ok
         assert shards == [(0, 8), (8, 10)]  # 10 columns over 2 ranks: 4-column blocks, remainder to the last
+
+
+def test_row_shards_and_slices():
+    """row_shard partitions the rows contiguously (balanced to one row); slice_rows keeps the index base and rebases the row
+    pointers; the slices together hold every entry once; SpMV on the slices equals the rows of the full product."""
+    pkg = entry.load_package()
+    import aocl_sparse_amd.sharded as sharded
+    import oracle
+    for base in (0, 1):
+        m, rp, ci, v = entry.laplace5(9, base=base)
+        x = np.cos(0.3 * np.arange(m))
+        so, yfull = oracle.dcsrmv(0, base, 1.0, m, len(v), v, ci, rp, x, 0.0, np.zeros(m))
+        for world in (1, 2, 3, 7, 100):
+            rows = [sharded.row_shard(m, world, r) for r in range(world)]
+            assert rows[0][0] == 0 and rows[-1][1] == m and all(rows[i][1] == rows[i + 1][0] for i in range(world - 1))
+            assert max(b - a for a, b in rows) - min(b - a for a, b in rows) <= 1
+            total = 0
+            for a, b in rows:
+                ml, nl, rpl, cil, vl = sharded.slice_rows((m, m, rp, ci, v), a, b)
+                assert ml == b - a and nl == m and rpl[0] == base and rpl[-1] - base == len(vl) == len(cil)
+                total += len(vl)
+                if ml:
+                    so, yl = oracle.dcsrmv(0, base, 1.0, ml, len(vl), vl, cil, rpl, x, 0.0, np.zeros(ml))
+                    assert np.array_equal(yl, yfull[a:b])
+            assert total == len(v)
 
 
 def test_single_rank_is_identity():

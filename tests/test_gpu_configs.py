@@ -164,7 +164,7 @@ def test_bench_two_ranks_gloo_one_gpu():
     that both ranks can share the one GPU: the JSON line must carry the whole-job value, the sharded csrmm object with
     its efficiency T1 / (N TN), the A broadcast, the C all-gather and the parity verdicts."""
     res = _torchrun(2, "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "5", "--warmup", "2", "--grid", "512",
-                    "--mm-grid", "200", "--mm-cols", "64", "--legs", "csrmm_sharded")
+                    "--mm-grid", "200", "--mm-cols", "64", "--shard-grid", "301", "--legs", "csrmm_sharded,spmv_row_sharded")
     assert res["n_gpus"] == 2 and res["steps"] == 5 and res["scaling"] == "weak" and res["unit"] == "GFLOP/s"
     assert res["parity"]["bit_exact"] is True
     assert res["roofline"]["bound"] == "hbm" and 0 < res["roofline"]["frac"] < 1.0
@@ -177,13 +177,19 @@ def test_bench_two_ranks_gloo_one_gpu():
     assert mm["c_is_read"] is True
     assert mm["roofline_shard"]["algorithmic_bytes_per_launch"] == (40000 + 1 + mm["nnz"]) * 4 + mm["nnz"] * 8 + 8 * 32 * 3 * 40000
     assert res["config"]["communicator"] == {"backend": "gloo", "world": 2}
+    # the row-sharded SpMV iteration (SURVEY 8e "next"): 301^2 = 90,601 rows over two ranks, an all-gather per iteration
+    sp = res["spmv_row_sharded"]
+    assert "error" not in sp, sp
+    assert sp["world"] == 2 and sp["m"] == 90601 and sp["rows_per_rank"] == 45300 and sp["parity"]["bit_exact"] is True
+    assert sp["product_ms_median_max_over_ranks"] > 0 and sp["allgather_ms_median_max_over_ranks"] > 0
+    assert sp["allgather_bytes_per_rank"] == 8 * 90601
 
 
 def test_bench_single_process_small_legs():
     """`python bench.py` with every leg on small inputs: one JSON line whose legs all carry a roofline object and a
     bit-exact verdict (the driver-timed run uses the full sizes)."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--grid", "512",
-                        "--mm-grid", "200", "--mm-cols", "64", "--small", "--cpu-seconds", "0.5"], cwd=ROOT,
+                        "--mm-grid", "200", "--mm-cols", "64", "--shard-grid", "300", "--small", "--cpu-seconds", "0.5"], cwd=ROOT,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
@@ -209,6 +215,7 @@ def test_bench_single_process_small_legs():
     for s in legs["trsv"]["schedules"]:
         assert s["bit_exact_vs_cpu"] and s["residual_inf"] < 1e-13
     assert res["csrmm_sharded"]["efficiency"] == 1.0 and res["csrmm_sharded"]["parity"]["bit_exact"]
+    assert res["spmv_row_sharded"]["parity"]["bit_exact"] and res["spmv_row_sharded"]["allgather_ms_median_max_over_ranks"] == 0.0
 
 
 # --------------------------------------------------------------------------------------------------
