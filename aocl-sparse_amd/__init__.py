@@ -342,6 +342,7 @@ SIGNATURES = {
     "aoclsparse_mi355_dcsrmm_shard": (c_int, [c_int, c_double, _P, _P, c_int, _P, _I, _I, c_double, _P, _I, _I, _I]),
     "aoclsparse_mi355_dcsrmm_multi": (c_int, [c_int, c_double, _P, _P, c_int, _P, _I, _I, c_double, _P, _I, _I, _P]),
     "aoclsparse_mi355_replica_count": (c_int, [_P]),
+    "aoclsparse_mi355_multi_last_ms": (c_int, [_P, c_int]),
     "aoclsparse_mi355_replicas_cloned": (c_int, [_P]),
     "aoclsparse_mi355_scsrmm_multi": (c_int, [c_int, c_float, _P, _P, c_int, _P, _I, _I, c_float, _P, _I, _I, _P]),
     "aoclsparse_mi355_dcsrmm_multi_slabs": (c_int, [c_int, c_double, _P, _P, c_int, _P, _I, _I, c_double, _P, _I, _I, _P]),

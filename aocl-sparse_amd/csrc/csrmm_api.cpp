@@ -249,12 +249,17 @@ aoclsparse_status detect_pairs(const HostCsr &h, SpmvPlan &plan)
     return aoclsparse_status_success;
 }
 
+// The reference's argument checks of ?csrmm (csrmm.hpp:429-611), on the operands AS THE CALLER PASSED THEM.  quick_return is set
+// when the call is complete without a product (an empty dimension, or alpha == 0 with beta == 1).  Kept apart from csrmm_t so
+// that the column-sharded entry points validate the WHOLE operands (n, ldb, ldc, dim * ld range) once, before they split the
+// columns: a shard's own width would let an ldb / ldc < n through that the reference rejects.
 template <typename T>
-aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclsparse_matrix A,
-                          const aoclsparse_mat_descr descr, aoclsparse_order order, const T *B,
-                          aoclsparse_int n, aoclsparse_int ldb, const T beta, T *C, aoclsparse_int ldc,
-                          aoclsparse_int kid, aoclsparse_matrix_data_type vt)
+static aoclsparse_status csrmm_validate(aoclsparse_operation op, const T alpha, const aoclsparse_matrix A,
+                                        const aoclsparse_mat_descr descr, aoclsparse_order order, const T *B, aoclsparse_int n,
+                                        aoclsparse_int ldb, const T beta, const T *C, aoclsparse_int ldc, aoclsparse_int kid,
+                                        aoclsparse_matrix_data_type vt, bool &quick_return)
 {
+    quick_return = false;
     if(!A || !B || !C || !descr)
         return aoclsparse_status_invalid_pointer;
     if(A->input_format != aoclsparse_csr_mat)
@@ -278,10 +283,12 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
     const aoclsparse_int m = A->m, k = A->n;
     if(m < 0 || n < 0 || k < 0)
         return aoclsparse_status_invalid_size;
+    quick_return = true;
     if(m == 0 || n == 0 || k == 0)
         return aoclsparse_status_success;
     if(alpha == T(0) && beta == T(1))
         return aoclsparse_status_success;
+    quick_return = false;
     if(!A->user.val || !A->user.ptr || !A->user.ind)
         return aoclsparse_status_invalid_pointer;
 
@@ -301,6 +308,25 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
         return aoclsparse_status_invalid_size;
     if(kid > 3) // KATs of csrmm.hpp:776-837 hold kernels 0..3
         return aoclsparse_status_invalid_kid;
+    return aoclsparse_status_success;
+}
+
+template <typename T>
+aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclsparse_matrix A,
+                          const aoclsparse_mat_descr descr, aoclsparse_order order, const T *B,
+                          aoclsparse_int n, aoclsparse_int ldb, const T beta, T *C, aoclsparse_int ldc,
+                          aoclsparse_int kid, aoclsparse_matrix_data_type vt)
+{
+    bool quick = false;
+    if(const aoclsparse_status vs = csrmm_validate<T>(op, alpha, A, descr, order, B, n, ldb, beta, C, ldc, kid, vt, quick);
+       vs != aoclsparse_status_success || quick)
+        return vs;
+    const aoclsparse_int m = A->m, k = A->n;
+    const bool           tr     = op != aoclsparse_operation_none;
+    const bool           colmaj = order == aoclsparse_order_column;
+    const aoclsparse_int b_rows = tr ? m : k; // rows of B
+    const aoclsparse_int m_c    = tr ? k : m; // rows of C
+    const long long      c_outer = colmaj ? n : m_c, b_outer = colmaj ? n : b_rows;
 
     Runtime          &rt = Runtime::get();
     aoclsparse_status st = rt.init();
@@ -571,6 +597,12 @@ static aoclsparse_status csrmm_shard_t(aoclsparse_operation op, const T alpha, c
         return aoclsparse_status_invalid_pointer;
     if(order != aoclsparse_order_row && order != aoclsparse_order_column)
         return aoclsparse_status_invalid_value;
+    // the reference's checks on the WHOLE operands first (its own split happens after them: csrmm.hpp:592-611 precede the
+    // threads of csrmm_kt.cpp:68-82): ldb / ldc against the full column count, the LP64 range of n * ld
+    bool quick = false;
+    if(const aoclsparse_status vs = csrmm_validate<T>(op, alpha, A, descr, order, B, n, ldb, beta, C, ldc, -1, vt, quick);
+       vs != aoclsparse_status_success || quick)
+        return vs;
     const aoclsparse_int j0 = shard_edge(n, world, rank), j1 = shard_edge(n, world, rank + 1);
     if(j1 <= j0)
         return aoclsparse_status_success; // more ranks than 4-column blocks: this rank owns nothing
@@ -644,7 +676,25 @@ static aoclsparse_status get_replica(aoclsparse_matrix A, int slot_idx, aoclspar
         st = aoclsparse_create_scsr(&R, A->base, A->m, A->n, A->nnz, A->user.ptr, A->user.ind, static_cast<float *>(A->user.val));
     if(st != aoclsparse_status_success)
         return st;
-    R->hints      = A->hints;
+    // a csrmm replica serves csrmm only: it gets the mm hints (no TRSV level plans, no SELL copies on the other devices)
+    try
+    {
+        for(const Hint &h : A->hints)
+            if(h.act == action_mm)
+                R->hints.push_back(h), R->hints.back().optimized = false;
+        if(R->hints.empty())
+        {
+            Hint h{};
+            h.act = action_mm, h.trans = aoclsparse_operation_none, h.type = aoclsparse_matrix_type_general;
+            h.fill = aoclsparse_fill_mode_lower, h.nop = 1, h.kid = -1;
+            R->hints.push_back(h);
+        }
+    }
+    catch(const std::bad_alloc &)
+    {
+        aoclsparse_destroy(&R);
+        return aoclsparse_status_memory_error;
+    }
     R->mem_policy = A->mem_policy;
     // Fast path: the primary handle already holds its device format (set_mm_hint + optimize, or an earlier product) -> peer copy.
     // Otherwise the replica analyses its own copy (every device at the same time).
@@ -720,6 +770,10 @@ namespace
         bool                                started = false;
     };
     std::mutex g_multi_call; // one multi-device call at a time (the workers are a shared resource)
+    // wall time each slot spent on its share in the LAST multi-device call (its launches + the wait for its stream): what
+    // aoclsparse_mi355_multi_last_ms reports, so that a caller can see the per-device times behind one call's wall clock
+    float g_multi_last_ms[64];
+    int   g_multi_last_n = 0;
 
     void spin_pause()
     {
@@ -812,6 +866,15 @@ static aoclsparse_status csrmm_multi_t(aoclsparse_operation op, const T alpha, c
         return aoclsparse_status_invalid_value;
     if(A->val_type != vt)
         return aoclsparse_status_wrong_type;
+    if(!slabs)
+    {
+        // full operands: the reference's status for the WHOLE call comes first, before any replica is built (a replica's
+        // creation error must not mask it, and a shard's width must not let an ldb / ldc < n through)
+        bool quick = false;
+        if(const aoclsparse_status vs = csrmm_validate<T>(op, alpha, A, descr, order, B, n, ldb, beta, C, ldc, -1, vt, quick);
+           vs != aoclsparse_status_success || quick)
+            return vs;
+    }
     Runtime          &pr = Runtime::primary();
     aoclsparse_status st = pr.init();
     if(st != aoclsparse_status_success)
@@ -850,6 +913,16 @@ static aoclsparse_status csrmm_multi_t(aoclsparse_operation op, const T alpha, c
     }
     std::vector<aoclsparse_status> res((size_t)ndev, aoclsparse_status_success);
     auto                           work = [&](int i) {
+        const auto t_begin = std::chrono::steady_clock::now();
+        struct Lap
+        {
+            int                                   i;
+            std::chrono::steady_clock::time_point t0;
+            ~Lap()
+            {
+                g_multi_last_ms[i] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            }
+        } lap{i, t_begin};
         try
         {
             RuntimeScope sc(rts[i]);
@@ -894,6 +967,7 @@ static aoclsparse_status csrmm_multi_t(aoclsparse_operation op, const T alpha, c
     };
     {
         std::lock_guard<std::mutex>        one_call(g_multi_call);
+        g_multi_last_n = ndev;
         std::vector<std::function<void()>> jobs((size_t)ndev);
         std::vector<SlotWorker *>          posted;
         posted.reserve((size_t)ndev);
@@ -980,6 +1054,14 @@ aoclsparse_status aoclsparse_mi355_dcsrmm_multi_slabs(aoclsparse_operation op, c
         return aoclsparse_status_invalid_pointer;
     return csrmm_multi_t<double>(op, alpha, A, descr, order, nullptr, B_slabs, n, ldb, beta, nullptr, C_slabs, ldc, ndev,
                                  devices, aoclsparse_dmat);
+}
+
+aoclsparse_int aoclsparse_mi355_multi_last_ms(float *ms, aoclsparse_int capacity)
+{
+    std::lock_guard<std::mutex> one_call(g_multi_call);
+    for(int i = 0; ms && i < g_multi_last_n && i < capacity; i++)
+        ms[i] = g_multi_last_ms[i];
+    return g_multi_last_n;
 }
 
 aoclsparse_int aoclsparse_mi355_replica_count(const aoclsparse_matrix A)

@@ -499,9 +499,6 @@ public:
         stream_ = s;
     }
     aoclsparse_mi355_pointer_mode pointer_mode = aoclsparse_mi355_pointer_auto;
-    // csrmm with beta == 0: false (default) = C is read and multiplied by zero as in every reference kernel (NaN / Inf in C
-    // propagate); true = C is overwritten without being read (BLAS semantics, a third less traffic at 256 columns)
-    bool csrmm_beta0_overwrite = false;
     // TRSV schedule: -1 = chosen from the plan (default); 0..4 force one (aoclsparse_mi355_set_trsv_schedule; trsv_api.cpp)
     int trsv_schedule = -1;
     // true when p is memory the device can dereference (device or managed allocation)
@@ -766,7 +763,11 @@ aoclsparse_status launch_lincomb(hipStream_t s, int sign, aoclsparse_int n, int 
 // schedule 0: one launch per level; 1: hybrid (narrow level runs inside one workgroup); 2: sync-free, a lane per
 // position; 3: sync-free, a level slice per wavefront (single right-hand side; falls back to 2 otherwise);
 // 4: sync-free, a lane per BLOCK of chained rows (plan.blk, real types, one right-hand side; falls back to 3 / 2).
-// does a csrmm kernel read C?  always for beta != 0; for beta == 0 unless the overwrite mode is on (Runtime::csrmm_beta0_overwrite)
+// csrmm with beta == 0: false (default) = C is read and multiplied by zero as in every reference kernel (NaN / Inf in C
+// propagate); true = C is overwritten without being read (BLAS semantics, a third less traffic at 256 columns).  One word for the
+// process (aoclsparse_mi355_set_csrmm_beta0_overwrite; AOCLSPARSE_MI355_CSRMM_BETA0_OVERWRITE seeds it once, on first touch).
+std::atomic<bool> &csrmm_beta0_overwrite_flag();
+// does a csrmm kernel read C?  always for beta != 0; for beta == 0 unless the overwrite mode is on
 bool csrmm_reads_c(bool beta_nonzero);
 // timeout_word: where a sync-free kernel reports an expired wait (pinned host memory, Runtime::trsv_timeout_dev).
 constexpr int TRSV_NARROW = 1024; // a level this narrow is solved by one workgroup (one row per lane)

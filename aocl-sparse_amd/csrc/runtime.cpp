@@ -135,8 +135,7 @@ RuntimeScope::RuntimeScope(Runtime *r) : prev(tl_runtime), status(aoclsparse_sta
     Runtime &pr = Runtime::primary();
     if(r != &pr)
     {
-        r->pointer_mode          = pr.pointer_mode;
-        r->csrmm_beta0_overwrite = pr.csrmm_beta0_overwrite;
+        r->pointer_mode = pr.pointer_mode;
     }
     tl_runtime = r;
     status     = r->init();
@@ -183,7 +182,9 @@ aoclsparse_status Runtime::init()
     }
     if(forced_device >= 0)
     {
-        // a secondary slot of a multi-device call: its own device and its own (non-blocking) stream
+        // a secondary slot of a multi-device call: its own device and its own BLOCKING stream -- a blocking stream is ordered
+        // against that device's null stream, where a caller that has just filled B_slabs[i] / zeroed C_slabs[i] (torch's
+        // default stream) has its work in flight; a non-blocking stream would race with it
         if(forced_device >= count || hipSetDevice(forced_device) != hipSuccess)
         {
             (void)hipGetLastError();
@@ -191,7 +192,7 @@ aoclsparse_status Runtime::init()
             inited_.store(true, std::memory_order_release);
             return init_status_;
         }
-        if(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess)
+        if(hipStreamCreateWithFlags(&stream_, hipStreamDefault) != hipSuccess)
         {
             (void)hipGetLastError();
             stream_ = nullptr;
@@ -252,17 +253,21 @@ DeviceScope::~DeviceScope()
     --tl_device_scope;
 }
 
+// Process-wide mode word.  AOCLSPARSE_MI355_CSRMM_BETA0_OVERWRITE is read exactly once, when the word is first touched -- by
+// the setter or by the first product, whichever comes first -- so an explicit aoclsparse_mi355_set_csrmm_beta0_overwrite() made
+// before the first product is never overridden by the environment afterwards.
+std::atomic<bool> &csrmm_beta0_overwrite_flag()
+{
+    static std::atomic<bool> flag{[] {
+        const char *e = std::getenv("AOCLSPARSE_MI355_CSRMM_BETA0_OVERWRITE");
+        return e && std::atoi(e) != 0;
+    }()};
+    return flag;
+}
+
 bool csrmm_reads_c(bool beta_nonzero)
 {
-    // the environment switch is read once; the setter (aoclsparse_mi355_set_csrmm_beta0_overwrite) wins afterwards
-    static const bool env_once = [] {
-        const char *e = std::getenv("AOCLSPARSE_MI355_CSRMM_BETA0_OVERWRITE");
-        if(e && std::atoi(e) != 0)
-            Runtime::primary().csrmm_beta0_overwrite = true;
-        return true;
-    }();
-    (void)env_once;
-    return beta_nonzero || !Runtime::primary().csrmm_beta0_overwrite;
+    return beta_nonzero || !csrmm_beta0_overwrite_flag().load(std::memory_order_relaxed);
 }
 
 bool Runtime::is_device_pointer(const void *p)
@@ -321,7 +326,7 @@ extern "C" {
 
 aoclsparse_status aoclsparse_mi355_set_csrmm_beta0_overwrite(int overwrite)
 {
-    Runtime::get().csrmm_beta0_overwrite = overwrite != 0;
+    csrmm_beta0_overwrite_flag().store(overwrite != 0, std::memory_order_relaxed); // process-wide: every runtime slot reads it
     return aoclsparse_status_success;
 }
 

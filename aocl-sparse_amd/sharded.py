@@ -324,16 +324,30 @@ def allgather_rows(torch, dist, device, rank, world, m, y_loc, x_full):
 class ShardedSpmv:
     """One rank's rows of y = A x (square A): handle over its row slice (mv hint + optimize), the full x on the device."""
 
-    def __init__(self, pkg, torch, dist, device, rank, world, csr):
+    def __init__(self, pkg, torch, dist, device, rank, world, csr=None, build_rows=None, m=None):
+        """csr: the whole matrix on rank 0 (broadcast, then sliced) -- or build_rows(r0, r1) -> (ml, n, row_ptr, col_ind, val):
+        every rank builds ITS rows of the m x m matrix itself and no rank ever holds all of A (the form that scales)."""
         self.pkg, self.torch, self.dist, self.device, self.rank, self.world = pkg, torch, dist, device, rank, world
-        (self.m, self.n, rp, ci, v), self.a_broadcast_ms = broadcast_csr(dist, torch, device, rank, csr)
-        assert self.m == self.n, "the iteration feeds y back as x"
-        self.r0, self.r1 = row_shard(self.m, world, rank)
-        ml, nl, rpl, cil, vl = slice_rows((self.m, self.n, rp, ci, v), self.r0, self.r1)
-        self.nnz_loc, self.nnz = int(len(vl)), int(len(v))
-        self.A = pkg.Matrix(int(rp[0]), ml, nl, rpl, cil, vl)
+        if build_rows is not None:
+            self.m = self.n = int(m)
+            self.a_broadcast_ms = 0.0
+            self.r0, self.r1 = row_shard(self.m, world, rank)
+            ml, nl, rpl, cil, vl = build_rows(self.r0, self.r1)
+            assert ml == self.r1 - self.r0 and nl == self.n
+            self.nnz_loc = int(len(vl))
+            self.nnz = int(reduce_scalar(self.nnz_loc, "sum", dist, device))
+            base = int(rpl[0])
+        else:
+            (self.m, self.n, rp, ci, v), self.a_broadcast_ms = broadcast_csr(dist, torch, device, rank, csr)
+            assert self.m == self.n, "the iteration feeds y back as x"
+            self.r0, self.r1 = row_shard(self.m, world, rank)
+            ml, nl, rpl, cil, vl = slice_rows((self.m, self.n, rp, ci, v), self.r0, self.r1)
+            self.nnz_loc, self.nnz = int(len(vl)), int(len(v))
+            base = int(rp[0])
+        self.local = (ml, nl, rpl, cil, vl)
+        self.A = pkg.Matrix(base, ml, nl, rpl, cil, vl)
         assert self.A.status == 0, pkg.STATUS[self.A.status]
-        self.descr = pkg.Descr(base=int(rp[0]))
+        self.descr = pkg.Descr(base=base)
         L = pkg.lib()
         assert L.aoclsparse_set_mv_hint(self.A.h, pkg.OP_NONE, self.descr.h, 1000) == 0
         assert L.aoclsparse_optimize(self.A.h) == 0
@@ -345,11 +359,11 @@ class ShardedSpmv:
         return allgather_rows(self.torch, self.dist, self.device, self.rank, self.world, self.m, y_loc, x_full)
 
 
-def bench_sharded_spmv(pkg, torch, dist, device, rank, world, csr, iters=20, warm=3, peak_gbs=8000.0):
+def bench_sharded_spmv(pkg, torch, dist, device, rank, world, csr, iters=20, warm=3, peak_gbs=8000.0, build_rows=None, m=None):
     """`iters` iterations x <- A x (each: the local product, then the all-gather of the slices) on `world` ranks; returns the
     per-iteration times (product: max over ranks of the median device time; gather: max over ranks of the median wall time),
     the whole-job GFLOP/s including the gathers, and the bits of rank 0's slice for the caller's parity check."""
-    sh = ShardedSpmv(pkg, torch, dist, device, rank, world, csr)
+    sh = ShardedSpmv(pkg, torch, dist, device, rank, world, csr, build_rows=build_rows, m=m)
     m = sh.m
     x = torch.from_numpy(np.sin(0.01 * np.arange(m))).to(device)
     x0 = x.clone()
@@ -382,6 +396,9 @@ def bench_sharded_spmv(pkg, torch, dist, device, rank, world, csr, iters=20, war
     tw = reduce_scalar(wall, "max", dist, device)
     loc_bytes = (sh.r1 - sh.r0 + 1 + sh.nnz_loc) * 4 + (sh.r1 - sh.r0 + m + sh.nnz_loc) * 8
     gbs = loc_bytes / tp / 1e6 if tp > 0 else 0.0
+    # a share that fits the 256 MiB Infinity Cache can run above the HBM roofline: such a figure is no evidence, so the HBM
+    # roofline object is only reported for shares of at least 512 MB
+    hbm_sized = loc_bytes >= (512 << 20)
     return {"what": "x <- A x iterated, A split by rows over %d rank(s), one all-gather of the slices per iteration" % world,
             "world": world, "m": m, "nnz": sh.nnz, "rows_per_rank": sh.r1 - sh.r0, "a_broadcast_ms": round(sh.a_broadcast_ms, 3),
             "product_ms_median_max_over_ranks": round(tp, 5), "allgather_ms_median_max_over_ranks": round(tg, 5),
@@ -390,5 +407,7 @@ def bench_sharded_spmv(pkg, torch, dist, device, rank, world, csr, iters=20, war
             "allgather_bytes_per_rank": 8 * m,
             "note": ("a rank's share of the matrix (%d MB) fits the 256 MiB Infinity Cache: the product can run above the HBM roofline"
                      % (loc_bytes >> 20)) if loc_bytes < (256 << 20) * 1.5 else None,
+            "shard_bytes": loc_bytes, "shard_gbs_algorithmic": round(gbs, 2),
             "roofline_shard": {"bound": "hbm", "achieved": round(gbs, 2), "peak": peak_gbs, "unit": "GB/s",
-                               "frac": round(gbs / peak_gbs, 4), "traffic": None, "algorithmic_bytes_per_launch": loc_bytes}}, sh, y_first, x0
+                               "frac": round(gbs / peak_gbs, 4), "traffic": None,
+                               "algorithmic_bytes_per_launch": loc_bytes} if hbm_sized else None}, sh, y_first, x0

@@ -2,7 +2,13 @@
 """bench.py -- CSR SpMV fp64 (aoclsparse_dmv through the C ABI) on N MI355X, one process per GPU.
 
 Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the
-driver starts it with torch.distributed.run, one rank per GPU.  Prints ONE JSON line on rank 0.
+driver starts it with torch.distributed.run, one rank per GPU; started WITHOUT torch.distributed.run (no WORLD_SIZE in
+the environment) and N > 1 it starts the N ranks itself as a child process (self_launch below) and relays rank 0's line.
+
+OUTPUT: the LAST stdout line is one short (<= 4 KB) strict-JSON record -- the reference harness prints one short statistics
+line per run too (tests/common/aoclsparse_stats.cpp:266-340) -- carrying the headline, `roofline`, `cpu_baseline`, `parity`
+and ONE number per leg (`legs`).  The full report (every leg with its quartiles, per-case rooflines and parity verdicts) goes
+to the file named by --record (default bench_legs.json next to this file), not to stdout.
 
   step      = one aoclsparse_dmv (alpha=1, beta=0) over the whole matrix, x and y resident in HBM.
   workload  = 5-point Laplacian, BASELINE.json configs[1] scaled from its 100x100 grid (795 KB,
@@ -168,6 +174,176 @@ def timed_laps(pkg, fn, steps, warmup):
     return pkg.timer_laps()
 
 
+COMPACT_LIMIT = 4096  # bytes: the driver keeps a bounded tail of stdout, the record must fit it with room to spare
+
+
+def _short(text, n):
+    text = "" if text is None else str(text)
+    return text if len(text) <= n else text[: n - 3] + "..."
+
+
+def _eff8(t1_ms, slab_ms):
+    """projected 8-GPU compute efficiency of the column-sharded csrmm: T1 / (8 * T_slab)"""
+    return round(t1_ms / (8.0 * slab_ms), 4) if t1_ms and slab_ms else None
+
+
+def leg_numbers(full):
+    """ONE number per leg out of the full report (None where the leg did not run)."""
+    legs = full.get("legs") or {}
+    n = {}
+    l100 = full.get("l100") or {}
+    if "us_per_call" in l100:
+        n["l100_us"] = l100["us_per_call"]
+        n["l100_latency_frac"] = (l100.get("roofline_latency") or {}).get("frac")
+    ca = legs.get("dcsrmv_csr_adaptive") or {}
+    if "roofline" in ca:
+        n["csr_adaptive_ms"] = ca["ms"]
+        n["csr_adaptive_frac"] = ca["roofline"]["frac"]
+    mix = legs.get("mix") or {}
+    rows = mix.get("matrices") or []
+    if rows:
+        primary = [r["roofline"]["frac"] for r in rows if "," not in r["matrix"]]
+        n["mix_frac_mean"] = round(sum(primary) / len(primary), 4) if primary else None
+        other = [r["roofline"]["frac"] for r in rows if "," in r["matrix"]]
+        n["mix_variants_frac_mean"] = round(sum(other) / len(other), 4) if other else None
+        n["mix_frac"] = {_short(r["matrix"].split(" (")[0], 28): r["roofline"]["frac"] for r in rows}
+        lat = {_short(r["matrix"].split(" (")[0], 28): r["roofline_latency"]["frac"] for r in rows if r.get("roofline_latency")}
+        if lat:
+            n["mix_latency_frac"] = lat
+        n["mix_parity"] = all(r["bit_exact_rows_within_tile"] and r["long_rows_within_bound"] for r in rows)
+    mm = legs.get("csrmm") or {}
+    for lay, key in (("row-major", "row"), ("column-major", "col")):
+        for mode, suffix in (("default", ""), ("opt-in", "_overwrite")):
+            cs = [c for c in mm.get("cases", []) if c["layout"] == lay and c["mode"].startswith(mode)]
+            fullc = [c for c in cs if c["what"].startswith("all")]
+            slab = [c for c in cs if c["what"].startswith("one slab")]
+            if fullc and slab:
+                n["csrmm_%s%s_ms" % (key, suffix)] = fullc[0]["ms"]
+                n["csrmm_%s%s_slab_ms" % (key, suffix)] = slab[0]["ms"]
+                n["csrmm_%s%s_eff8" % (key, suffix)] = _eff8(fullc[0]["ms"], slab[0]["ms"])
+                if not suffix:
+                    n["csrmm_%s_frac_survey_bytes" % key] = fullc[0]["roofline_survey_model"]["frac"]
+    if mm.get("cases"):
+        n["csrmm_parity"] = all(c.get("bit_exact_4_columns", True) and c.get("bit_exact_8_columns_vs_kt_oracle", True)
+                                for c in mm["cases"])
+    if (mm.get("blocked") or {}).get("cases"):
+        b = mm["blocked"]
+        n["csrmm_blocked_mfma_ms"] = b.get("mfma_ms")
+        n["csrmm_blocked_best_other_ms"] = b.get("best_other_ms")
+        n["csrmm_blocked_parity"] = b.get("parity_ok")
+    tr = legs.get("trsv") or {}
+    if tr.get("schedules"):
+        n["trsv_ms"] = tr["schedules"][0]["ms"]
+        n["trsv_parity"] = all(s["bit_exact_vs_cpu"] for s in tr["schedules"])
+        if "unstructured_variant" in tr and tr["unstructured_variant"].get("schedules"):
+            n["trsv_unstructured_ms"] = tr["unstructured_variant"]["schedules"][0]["ms"]
+    for lay in ("col", "row"):
+        sh = full.get("csrmm_sharded_" + lay) or {}
+        if "tg_ms_device_median_max_over_ranks" in sh:
+            n["csrmm_sharded_" + lay] = {"world": sh["world"], "cols_per_rank": sh["cols_per_rank"],
+                                         "tg_ms": sh["tg_ms_device_median_max_over_ranks"], "t1_ms": sh.get("t1_ms"),
+                                         "efficiency": sh.get("efficiency"), "a_broadcast_ms": sh.get("a_broadcast_ms"),
+                                         "c_allgather_ms": sh.get("c_allgather_ms"),
+                                         "parity": (sh.get("parity") or {}).get("bit_exact")}
+    sp = full.get("spmv_row_sharded") or {}
+    if "product_ms_median_max_over_ranks" in sp:
+        n["spmv_row_sharded"] = {"world": sp["world"], "m": sp["m"], "product_ms": sp["product_ms_median_max_over_ranks"],
+                                 "allgather_ms": sp["allgather_ms_median_max_over_ranks"],
+                                 "shard_frac": (sp.get("roofline_shard") or {}).get("frac"),
+                                 "parity": (sp.get("parity") or {}).get("bit_exact")}
+    im = legs.get("inlib_multi") or {}
+    if im:
+        n["inlib_multi"] = {k: im.get(k) for k in ("devices", "same_device", "slabs_bit_exact", "efficiency_wall") if k in im}
+    errors = [k for k, v in list(legs.items()) + [(k, full.get(k)) for k in ("l100", "spmv_row_sharded", "csrmm_sharded_col",
+                                                                             "csrmm_sharded_row")]
+              if isinstance(v, dict) and "error" in v]
+    if errors:
+        n["errors"] = errors
+    return n
+
+
+def compact_record(full, record_path=None):
+    """The driver-facing record: strict JSON, <= COMPACT_LIMIT bytes, the contract's keys + roofline + cpu_baseline + one
+    number per leg.  Everything else stays in the full report (`record_path`)."""
+    c = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                  "scaling", "vs_baseline", "dtype", "data")}
+    cfg = full.get("config") or {}
+    c["config"] = {"workload": _short(cfg.get("workload"), 200), "kernel": _short(cfg.get("kernel"), 160),
+                   "parallelism": cfg.get("parallelism"), "device": _short(cfg.get("device"), 40),
+                   "communicator": cfg.get("communicator")}
+    rf = full.get("roofline") or {}
+    c["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic",
+                                            "algorithmic_bytes_per_launch", "kernel_ms", "traffic_source")}
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict) and "value" in cb:
+        c["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                             "cpu_model": _short(cb.get("cpu_model"), 60), "one_thread_value": (cb.get("one_thread") or {}).get("gflops"),
+                             "bit_exact_vs_gpu": cb.get("bit_exact_vs_gpu"), "sample": _short(cb.get("sample"), 160)}
+    else:
+        c["cpu_baseline"] = cb  # None on N > 1 runs / {"error": ...}
+    c["parity"] = full.get("parity")
+    c["legs"] = leg_numbers(full)
+    if record_path:
+        c["full_report"] = record_path
+    line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    if len(line) > COMPACT_LIMIT:  # never let prose cost the record: drop the optional strings, then the per-matrix maps
+        for k in ("sample",):
+            if isinstance(c.get("cpu_baseline"), dict):
+                c["cpu_baseline"].pop(k, None)
+        c["config"]["workload"] = _short(c["config"]["workload"], 80)
+        c["config"]["kernel"] = _short(c["config"]["kernel"], 60)
+        line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    if len(line) > COMPACT_LIMIT:
+        for k in ("mix_frac", "mix_latency_frac", "inlib_multi"):
+            c["legs"].pop(k, None)
+        line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    assert len(line) <= COMPACT_LIMIT, "compact record is %d bytes" % len(line)
+    return line
+
+
+def _sanitize(o):
+    """NaN / Inf -> None so that the records are STRICT JSON"""
+    if isinstance(o, float):
+        return o if o == o and o not in (float("inf"), float("-inf")) else None
+    if isinstance(o, dict):
+        return {str(k): _sanitize(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_sanitize(v) for v in o]
+    return o
+
+
+def self_launch(argv, gpus):
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed.run around it: start the N ranks as a CHILD process (this
+    parent has made no GPU call and makes none -- it never even imports torch), pass the child's stdout through, print rank 0's
+    record again as the LAST line and return the child's exit code (non-zero on any rank's failure)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", AOCLSPARSE_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // gpus)))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    record = None
+    for line in proc.stdout:
+        line = line.rstrip("\n")
+        if line.startswith("{") and '"metric"' in line:
+            record = line  # held back: it must be the last line
+        else:
+            print(line, flush=True)
+    rc = proc.wait()
+    if record is not None:
+        print(record, flush=True)
+    if rc == 0 and record is None:
+        print("bench.py: the %d-rank child printed no record" % gpus, file=sys.stderr)
+        rc = 1
+    return rc
+
+
+
 # ---- the benchmark ------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -181,12 +357,22 @@ def main():
                     help="comma list of l100,dcsrmv_csr_adaptive,mix,csrmm,csrmm_sharded,spmv_row_sharded,trsv,cpu,inlib_multi (or all / none)")
     ap.add_argument("--mm-grid", type=int, default=1000, help="csrmm: A = Laplacian on grid^2")
     ap.add_argument("--mm-cols", type=int, default=256)
-    ap.add_argument("--shard-grid", type=int, default=2048, help="grid of the row-sharded SpMV iteration leg")
-    ap.add_argument("--mm-layout", default="row", choices=["col", "row"],
-                    help="layout of the sharded csrmm leg (row-major slabs are the faster ones: 0.13 vs 0.19 ms per 32-column slab)")
+    ap.add_argument("--shard-grid", type=int, default=0,
+                    help="grid of the row-sharded SpMV iteration leg; 0 = 4096*sqrt(N) (every rank keeps the headline's 16.8 M rows = "
+                         "1.34 GB of matrix, well past the 256 MiB Infinity Cache, whatever N is); 2048 on one rank")
+    ap.add_argument("--mm-layout", default="both", choices=["col", "row", "both"],
+                    help="layout(s) of the sharded csrmm leg: column-major slabs are the contiguous ones (SURVEY.md 8e)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launch check only: the ranks rendezvous (gloo), sum their ranks and rank 0 prints a record with "
+                         "metric 'launch-check'; no GPU is touched and nothing is measured (CPU-tier test of the launch convention)")
+    ap.add_argument("--record", default=os.path.join(ROOT, "bench_legs.json"),
+                    help="file that receives the FULL report (stdout only gets the short record); '' = do not write it")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU-baseline budget per thread count")
     ap.add_argument("--small", action="store_true", help="mix / trsv legs on the two small matrices only")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under torch.distributed.run: start the ranks ourselves (as a child; nothing here has touched the GPU)
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
     all_legs = ["l100", "dcsrmv_csr_adaptive", "mix", "csrmm", "csrmm_sharded", "spmv_row_sharded", "trsv", "cpu", "inlib_multi"]
     legs = set(all_legs) if args.legs == "all" else set(x for x in args.legs.split(",") if x and x != "none")
     assert legs <= set(all_legs), "unknown leg in --legs: %s" % sorted(legs - set(all_legs))
@@ -214,10 +400,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    # fail loudly, never fall back: --gpus N is N ranks under torch.distributed.run (one process per GPU over RCCL)
+    # fail loudly, never fall back: --gpus N is N ranks (one process per GPU over RCCL); a launcher that set WORLD_SIZE to
+    # something else is a mistake of the launch, not something to paper over
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d needs WORLD_SIZE=%d (launch with python -m torch.distributed.run --nproc-per-node %d ...);"
                  " found WORLD_SIZE=%d.  No single-process fallback." % (args.gpus, args.gpus, args.gpus, world))
+    if args.dry_launch:
+        # the launch convention alone: rendezvous, one all-reduce, rank 0's record as the last line.  NOT a measurement.
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        ssum = float(rank)
+        if world > 1 or "RANK" in os.environ:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            ssum = reduce_scalar(float(rank), "sum", dist)
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "launch-check", "value": None, "n_gpus": world, "rank_sum": ssum,
+                              "self_launched": os.environ.get("AOCLSPARSE_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+        return
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the product has no CPU path")
     ndev = torch.cuda.device_count()
@@ -358,18 +558,18 @@ def main():
             legs_out[name] = res
 
     # ---------------- collectives first: the column-sharded csrmm (every rank) ----------------
-    def leg_csrmm_sharded():
+    def leg_csrmm_sharded(layout):
         csr_mm = None
         if rank == 0:
             mm_m, rp, ci, v = entry.laplace5(args.mm_grid)
             csr_mm = (mm_m, mm_m, rp, ci, v)
         res, sh, B, C = sharded.bench_sharded_csrmm(pkg, torch, D, device, rank, world, csr_mm, args.mm_cols,
-                                                    layout=args.mm_layout, reps=20, warm=3, full_product=True,
+                                                    layout=layout, reps=20, warm=3, full_product=True,
                                                     allgather=world > 1, peak_gbs=HBM_PEAK_GBS)
         res["workload"] = ("aoclsparse_dcsrmm, A = 5-pt Laplacian %dx%d grid, B %d x %d fp64 %s, beta=0 (C read and multiplied "
                            "by zero as in the reference: the default), columns "
-                           "sharded over %d rank(s) by the reference's thread-split rule (csrmm_kt.cpp:68-82); A "
-                           "broadcast from rank 0, no data-path collective"
+                           "sharded over %d rank(s) by the reference's thread-split rule (csrmm_kt.cpp:68-82); A's analysed device "
+                           "arrays broadcast from rank 0, no data-path collective"
                            % (args.mm_grid, args.mm_grid, sh.m, args.mm_cols, res["layout"], world))
         if rank == 0:
             import oracle
@@ -377,33 +577,45 @@ def main():
             ns = min(4, sh.nloc)
             cols = C.reshape(sh.nloc, sh.m)[:ns] if sh.layout == "col" else C.reshape(sh.m, sh.nloc)[:, :ns].t().contiguous()
             bcol = B.reshape(sh.nloc, sh.m)[:ns] if sh.layout == "col" else B.reshape(sh.m, sh.nloc)[:, :ns].t().contiguous()
-            _, Cr = oracle.dcsrmm("col", 1.0, 0, sh.A.val, sh.A.col_ind, sh.A.row_ptr, sh.m, bcol.cpu().numpy().reshape(-1),
+            _, Cr = oracle.dcsrmm("col", 1.0, 0, csr_mm[4], csr_mm[3], csr_mm[2], sh.m, bcol.cpu().numpy().reshape(-1),
                                   ns, sh.m, 0.0, np.zeros(ns * sh.m), sh.m)
             res["parity"] = {"vs": "oracle csrmm_col_major_ref, %d columns of rank 0's slab" % ns,
                              "bit_exact": bool(np.array_equal(cols.cpu().numpy().reshape(-1), Cr))}
+        del sh, B, C
         return res
 
-    run_leg("csrmm_sharded", leg_csrmm_sharded, collective=True)
+    for lay in (("col", "row") if args.mm_layout == "both" else (args.mm_layout,)):
+        if "csrmm_sharded" in legs:
+            legs.add("csrmm_sharded_" + lay)
+            run_leg("csrmm_sharded_" + lay, lambda lay=lay: leg_csrmm_sharded(lay), collective=True)
 
     # ---- SURVEY 8e "next": the iteration x <- A x with A split by rows and one all-gather of the slices per iteration ----
     def leg_spmv_row_sharded():
+        import math
+        # world > 1: every rank builds its own rows of a grid sized so that its share stays the headline's 1.34 GB whatever N is
+        # (no rank ever holds all of A); one rank: a small grid through the broadcast-and-slice path (control flow only)
+        sg = args.shard_grid or (int(4096 * math.sqrt(world)) if world > 1 else 2048)
+        own_rows = world > 1 and not args.shard_grid
         csr_s = None
-        if rank == 0:
-            ms_, rp_, ci_, v_ = entry.laplace5(args.shard_grid)
+        if not own_rows and rank == 0:
+            ms_, rp_, ci_, v_ = entry.laplace5(sg)
             csr_s = (ms_, ms_, rp_, ci_, v_)
         res, sh, y_first, x0 = sharded.bench_sharded_spmv(pkg, torch, D, device, rank, world, csr_s, iters=20, warm=3,
-                                                          peak_gbs=HBM_PEAK_GBS)
-        res["workload"] = ("aoclsparse_dmv on row slices of the 5-pt Laplacian %dx%d grid, %d rank(s); every iteration ends with an "
-                           "all-gather of the y slices (%s)" % (args.shard_grid, args.shard_grid, world,
+                                                          peak_gbs=HBM_PEAK_GBS,
+                                                          build_rows=(lambda r0, r1: entry.laplace5_rows(sg, r0, r1)) if own_rows else None,
+                                                          m=sg * sg)
+        res["workload"] = ("aoclsparse_dmv on row slices of the 5-pt Laplacian %dx%d grid, %d rank(s)%s; every iteration ends with an "
+                           "all-gather of the y slices (%s)" % (sg, sg, world, ", each rank builds its own rows" if own_rows else "",
                                                                "RCCL" if args.backend == "nccl" and world > 1 else
                                                                "gloo, CPU tensors" if world > 1 else "one rank: none"))
         if rank == 0:
             import oracle
-            ms_, rp_, ci_, v_ = csr_s[0], csr_s[2], csr_s[3], csr_s[4]
-            so, yr = oracle.dcsrmv(-1, 0, 1.0, ms_, len(v_), v_, ci_, rp_, x0.cpu().numpy(), 0.0, np.zeros(ms_),
+            # rank 0's rows: a row's chain does not depend on the other rows, so the oracle on the slice IS the unsharded product
+            ml, nl, rpl, cil, vl = sh.local
+            so, yr = oracle.dcsrmv(-1, 0, 1.0, ml, len(vl), vl, cil, rpl, x0.cpu().numpy(), 0.0, np.zeros(ml),
                                    nthreads=oracle.max_threads())
             res["parity"] = {"vs": "oracle ref_csrmv_gn order, rank 0's rows of the UNSHARDED product",
-                             "bit_exact": bool(np.array_equal(y_first.cpu().numpy(), yr[sh.r0:sh.r1]))}
+                             "bit_exact": bool(np.array_equal(y_first.cpu().numpy(), yr))}
             unpin()
         return res
 
@@ -632,10 +844,20 @@ def main():
                 # beta = 0 twice: the default reads C and multiplies it by zero, as every reference kernel does (NaN / Inf in C
                 # propagate: csrmm.hpp:83,129) -- its algorithmic bytes therefore include the read of C; the opt-in overwrite
                 # mode (aoclsparse_mi355_set_csrmm_beta0_overwrite) does not read C
+                ns = min(4, ncols)
+                bb = Bs.reshape(ncols, mm_m)[:ns] if layout == "col" else Bs.reshape(mm_m, ncols)[:, :ns].t().contiguous()
+                bb_host = bb.cpu().numpy().reshape(-1)
                 for beta, overwrite in ((0.0, False), (0.0, True), (-2.0, False)):
                     assert L.aoclsparse_mi355_set_csrmm_beta0_overwrite(1 if overwrite else 0) == 0
                     lp = timed_laps(pkg, lambda: sh.run(Bs, Cs, beta=beta, nloc=ncols), 20, 3)
+                    # parity of THIS mode: C preset to 0.25, one product, 4 columns against the oracle's column-major reference
+                    # kernel with the same beta and the same C (overwrite mode: identical results for finite C)
+                    Cs.fill_(0.25)
+                    assert sh.run(Bs, Cs, beta=beta, nloc=ncols) == 0
+                    torch.cuda.synchronize()
                     assert L.aoclsparse_mi355_set_csrmm_beta0_overwrite(0) == 0
+                    cc = Cs.reshape(ncols, mm_m)[:ns] if layout == "col" else Cs.reshape(mm_m, ncols)[:, :ns].t().contiguous()
+                    _, Cr = oracle.dcsrmm("col", 1.0, 0, v, ci, rp, mm_m, bb_host, ns, mm_m, beta, np.full(ns * mm_m, 0.25), mm_m)
                     ms = float(np.mean(lp))
                     reads_c = beta != 0.0 or not overwrite
                     b = csrmm_bytes(mm_m, mm_m, nz, ncols, reads_c)
@@ -645,18 +867,8 @@ def main():
                                                                         else "opt-in: C overwritten" if beta == 0.0 else "beta != 0"),
                                          "ms": round(ms, 5), "stats_ms": quartiles(lp),
                                          "gflops": round(2.0 * nz * ncols / ms / 1e6, 1), "roofline": roofline(b, ms),
-                                         "roofline_survey_model": roofline(csrmm_bytes(mm_m, mm_m, nz, ncols, beta != 0.0), ms)})
-                # parity: 4 columns against the oracle's column-major reference kernel (beta = 0)
-                Cs.zero_()
-                assert sh.run(Bs, Cs, beta=0.0, nloc=ncols) == 0
-                torch.cuda.synchronize()
-                ns = min(4, ncols)
-                cc = Cs.reshape(ncols, mm_m)[:ns] if layout == "col" else Cs.reshape(mm_m, ncols)[:, :ns].t().contiguous()
-                bb = Bs.reshape(ncols, mm_m)[:ns] if layout == "col" else Bs.reshape(mm_m, ncols)[:, :ns].t().contiguous()
-                _, Cr = oracle.dcsrmm("col", 1.0, 0, v, ci, rp, mm_m, bb.cpu().numpy().reshape(-1), ns, mm_m, 0.0,
-                                      np.zeros(ns * mm_m), mm_m)
-                for q in (-1, -2, -3):
-                    res["cases"][q]["bit_exact_4_columns"] = bool(np.array_equal(cc.cpu().numpy().reshape(-1), Cr))
+                                         "roofline_survey_model": roofline(csrmm_bytes(mm_m, mm_m, nz, ncols, beta != 0.0), ms),
+                                         "bit_exact_4_columns": bool(np.array_equal(cc.cpu().numpy().reshape(-1), Cr))})
                 # a pinned kid (row-major): the KT kernels' arithmetic (csrmm_row_kt), on the tuned kernels when the column count
                 # is a multiple of the vector width; first 8 columns checked against the KT restatement (4 / 8 lanes)
                 if layout == "row":
@@ -812,15 +1024,21 @@ def main():
         out["cpu_baseline"] = None
 
     if rank == 0:
-        # the driver-visible aliases the round-1 line carried
-        if "l100" in legs_out:
-            out["l100"] = legs_out.pop("l100")
-        if "spmv_row_sharded" in legs_out:
-            out["spmv_row_sharded"] = legs_out.pop("spmv_row_sharded")
-        if "csrmm_sharded" in legs_out:
-            out["csrmm_sharded"] = legs_out.pop("csrmm_sharded")
+        for k in ("l100", "spmv_row_sharded", "csrmm_sharded_col", "csrmm_sharded_row"):
+            if k in legs_out:
+                out[k] = legs_out.pop(k)
         out["legs"] = legs_out
-        print(json.dumps(out))
+        out = _sanitize(out)
+        record_path = None
+        if args.record:
+            try:
+                with open(args.record, "w") as f:
+                    json.dump(out, f, allow_nan=False, indent=1)
+                record_path = os.path.relpath(args.record, ROOT)
+            except OSError as e:  # a read-only tree must not cost the record
+                print("bench.py: could not write %s: %s" % (args.record, e), file=sys.stderr)
+        sys.stdout.flush()
+        print(compact_record(out, record_path), flush=True)
     if use_dist:
         dist.destroy_process_group()
 

@@ -98,6 +98,12 @@ DLL_PUBLIC aoclsparse_status aoclsparse_mi355_dcsrmm_multi_slabs(aoclsparse_oper
                                                                  double *const *C_slabs, aoclsparse_int ldc,
                                                                  aoclsparse_int ndev, const aoclsparse_int *devices);
 
+/* Operands of the two calls above must be COMPLETE on every device before the call (work in flight on a device's null stream
+ * is ordered before the product: the slot streams are blocking streams; work on other non-blocking streams is not).
+ * multi_last_ms: wall time each device spent on its share in the last multi-device call of the process (its launches and the
+ * wait for its stream), ms[i] for i < min(returned count, capacity); returns the device count of that call (0: none yet). */
+DLL_PUBLIC aoclsparse_int aoclsparse_mi355_multi_last_ms(float *ms, aoclsparse_int capacity);
+
 /* replicas of the handle currently alive on other runtime slots (0 before the first multi-device call); -1 for NULL */
 DLL_PUBLIC aoclsparse_int aoclsparse_mi355_replica_count(const aoclsparse_matrix A);
 /* ... of which built by copying the primary handle's device format device to device (peer copy over xGMI) instead of analysing

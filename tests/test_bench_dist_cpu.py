@@ -202,3 +202,74 @@ def test_block_standins_are_sorted_duplicate_free():
         for i in range(0, m, bs):
             for a in range(1, bs):
                 assert np.array_equal(ci[rp[i]:rp[i + 1]], ci[rp[i + a]:rp[i + a + 1]])
+
+
+def test_compact_record_fits_the_drivers_tail():
+    """Round 3's 29 KB single line no longer fitted the driver's bounded tail of stdout (BENCH_r03.parsed = null).  The short
+    record built from that very report must be strict JSON of at most 4 KB and carry roofline, cpu_baseline, parity and one
+    number per leg; parsing ONLY the final 8 KB of an output that ends with it must yield them."""
+    import json
+
+    with open(os.path.join(ROOT, "profiles", "r3", "bench_default.json")) as f:
+        full = json.loads([ln for ln in f.read().splitlines() if ln.startswith("{")][-1])
+    assert len(json.dumps(full)) > 20000
+    line = bench.compact_record(full, "bench_legs.json")
+    assert len(line) <= bench.COMPACT_LIMIT and "\n" not in line
+    json.loads(line, parse_constant=lambda c: (_ for _ in ()).throw(ValueError("not strict JSON: " + c)))
+    stdout = "x" * 50000 + "\n" + json.dumps(full) + "\n" + line + "\n"
+    tail = stdout[-8192:]
+    rec = json.loads(tail[tail.rstrip("\n").rfind("\n") + 1:])
+    assert rec["metric"].startswith("CSR SpMV fp64") and rec["unit"] == "GFLOP/s" and rec["value"] == full["value"]
+    assert rec["roofline"]["frac"] == full["roofline"]["frac"] and rec["roofline"]["kernel_ms"] == full["roofline"]["kernel_ms"]
+    assert rec["roofline"]["traffic"] == full["roofline"]["traffic"] and rec["roofline"]["peak"] == 8000.0
+    cb = rec["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] == full["cpu_baseline"]["value"] and cb["cores"] == full["cpu_baseline"]["cores"]
+    assert rec["parity"]["bit_exact"] is True and rec["config"]["communicator"] == full["config"]["communicator"]
+    n = rec["legs"]
+    for k in ("l100_us", "csr_adaptive_frac", "mix_frac_mean", "csrmm_row_ms", "csrmm_row_slab_ms", "csrmm_row_eff8", "csrmm_col_ms",
+              "csrmm_col_slab_ms", "csrmm_col_eff8", "trsv_ms"):
+        assert isinstance(n[k], float) and n[k] > 0, k
+    # eff8 = T1 / (8 T_slab) from the two driver-visible numbers
+    assert n["csrmm_row_eff8"] == round(n["csrmm_row_ms"] / (8 * n["csrmm_row_slab_ms"]), 4)
+    # NaN / Inf in a leg must not break strictness; an absurdly long description must not break the size
+    bad = dict(full, parity={"bit_exact": False, "max_abs_diff": float("nan")})
+    bad["config"] = dict(full["config"], workload="w" * 5000, kernel="k" * 5000)
+    line2 = bench.compact_record(bench._sanitize(bad))
+    assert len(line2) <= bench.COMPACT_LIMIT and json.loads(line2)["parity"]["max_abs_diff"] is None
+    # a run without legs (N > 1, --legs none)
+    bare = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "config", "roofline")}
+    bare["cpu_baseline"] = None
+    assert json.loads(bench.compact_record(bare))["legs"] == {}
+
+
+def test_bench_gpus_n_starts_its_own_ranks_dry():
+    """`python bench.py --gpus 2` with no torch.distributed.run around it (the driver's command form in BENCH_r03.json.cmd): the
+    parent starts both ranks as a child process, relays rank 0's line as its last line and returns the child's code.  --dry-launch
+    stops after the rendezvous (no GPU here); a failing child (no GPU: the product has no CPU path) must give a non-zero code
+    and no record; a WRONG WORLD_SIZE from an outer launcher stays a hard failure."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"]
+    r = subprocess.run(cmd + ["--dry-launch"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads(r.stdout.splitlines()[-1])
+    assert rec == {"metric": "launch-check", "value": None, "n_gpus": 2, "rank_sum": 1.0, "self_launched": True}
+    r = subprocess.run(cmd + ["--dry-launch"], cwd=ROOT, env=dict(env, WORLD_SIZE="3"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run(cmd + ["--backend", "gloo", "--steps", "1", "--record", ""], cwd=ROOT, env=env, capture_output=True,
+                           text=True, timeout=300)
+        assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert "needs a GPU" in r.stderr
+
+
+def test_laplace5_rows_are_the_rows_of_laplace5():
+    g = 7
+    m, rp, ci, v = entry.laplace5(g)
+    for r0, r1 in ((0, 49), (0, 20), (20, 49), (13, 14), (5, 5)):
+        ml, n, rpl, cil, vl = entry.laplace5_rows(g, r0, r1)
+        assert ml == r1 - r0 and n == m and rpl[0] == 0
+        assert np.array_equal(rpl, rp[r0:r1 + 1] - rp[r0]) and np.array_equal(cil, ci[rp[r0]:rp[r1]]) and np.array_equal(vl, v[rp[r0]:rp[r1]])

@@ -22,6 +22,7 @@ P = pkg()
 L = P.lib()
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import standins  # noqa: E402
+import bench  # noqa: E402
 
 
 def dev(a):
@@ -159,43 +160,103 @@ def test_sharded_csrmm_two_processes_one_gpu(layout, cols, beta):
     assert res["shard"] == list(P.column_shard(cols, 2, 0))
 
 
-def test_bench_two_ranks_gloo_one_gpu():
+def _bench_record(stdout, record_file):
+    """bench.py's contract: the LAST stdout line is the short strict-JSON record (what the driver parses from a bounded tail of
+    the output); the full report sits in the --record file.  Returns (short, full)."""
+    lines = stdout.splitlines()
+    assert lines and lines[-1].startswith("{"), stdout[-500:]
+    assert len(lines[-1]) <= bench.COMPACT_LIMIT
+    tail = stdout[-8192:]  # what a bounded tail of the output still holds
+    short = json.loads(tail[tail.rstrip("\n").rfind("\n") + 1:])
+    assert short == json.loads(lines[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "cpu_baseline",
+              "parity", "legs"):
+        assert k in short, k
+    for k in ("achieved", "peak", "frac", "traffic", "algorithmic_bytes_per_launch", "kernel_ms"):
+        assert k in short["roofline"], k
+    with open(record_file) as f:
+        full = json.load(f)
+    assert full["value"] == short["value"] and full["roofline"]["frac"] == short["roofline"]["frac"]
+    return short, full
+
+
+def test_bench_two_ranks_gloo_one_gpu(tmp_path):
     """bench.py as the driver starts it for N = 2 (torch.distributed.run, one process per rank), with --backend gloo so
-    that both ranks can share the one GPU: the JSON line must carry the whole-job value, the sharded csrmm object with
-    its efficiency T1 / (N TN), the A broadcast, the C all-gather and the parity verdicts."""
-    res = _torchrun(2, "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "5", "--warmup", "2", "--grid", "512",
-                    "--mm-grid", "200", "--mm-cols", "64", "--shard-grid", "301", "--legs", "csrmm_sharded,spmv_row_sharded")
+    that both ranks can share the one GPU: the record must carry the whole-job value, the sharded csrmm objects (both layouts)
+    with their efficiency T1 / (N TN), the A broadcast, the C all-gather and the parity verdicts."""
+    rec = str(tmp_path / "legs.json")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "5",
+           "--warmup", "2", "--grid", "512", "--mm-grid", "200", "--mm-cols", "64", "--shard-grid", "301", "--legs",
+           "csrmm_sharded,spmv_row_sharded", "--record", rec]
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4"), capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, "rc=%d\nstdout:\n%s\nstderr:\n%s" % (r.returncode, r.stdout[-3000:], r.stderr[-3000:])
+    short, res = _bench_record(r.stdout, rec)
+    _check_two_rank_record(short, res, own_rows=False)
+
+
+def _check_two_rank_record(short, res, own_rows):
     assert res["n_gpus"] == 2 and res["steps"] == 5 and res["scaling"] == "weak" and res["unit"] == "GFLOP/s"
     assert res["parity"]["bit_exact"] is True
     assert res["roofline"]["bound"] == "hbm" and 0 < res["roofline"]["frac"] < 1.0
     assert res["stats"]["n"] == 5 and res["stats"]["min"] <= res["stats"]["median"] <= res["stats"]["max"]
-    mm = res["csrmm_sharded"]
-    assert "error" not in mm, mm
-    assert mm["world"] == 2 and mm["cols_per_rank"] == 32 and mm["parity"]["bit_exact"] is True
-    assert mm["efficiency"] > 0 and mm["t1_ms"] > 0 and mm["a_broadcast_ms"] > 0 and mm["c_allgather_ms"] > 0
-    # beta = 0 reads C by default (the reference's arithmetic), so the byte model counts B, the read of C and its write
-    assert mm["c_is_read"] is True
-    assert mm["roofline_shard"]["algorithmic_bytes_per_launch"] == (40000 + 1 + mm["nnz"]) * 4 + mm["nnz"] * 8 + 8 * 32 * 3 * 40000
-    assert res["config"]["communicator"] == {"backend": "gloo", "world": 2}
-    # the row-sharded SpMV iteration (SURVEY 8e "next"): 301^2 = 90,601 rows over two ranks, an all-gather per iteration
+    assert short["cpu_baseline"] is None  # rank 0 at N = 1 only
+    for lay, name in (("col", "column-major"), ("row", "row-major")):
+        mm = res["csrmm_sharded_" + lay]
+        assert "error" not in mm, mm
+        assert mm["layout"] == name and mm["world"] == 2 and mm["cols_per_rank"] == 32 and mm["parity"]["bit_exact"] is True
+        assert mm["efficiency"] > 0 and mm["t1_ms"] > 0 and mm["a_broadcast_ms"] > 0 and mm["c_allgather_ms"] > 0
+        # beta = 0 reads C by default (the reference's arithmetic), so the byte model counts B, the read of C and its write
+        assert mm["c_is_read"] is True
+        assert mm["roofline_shard"]["algorithmic_bytes_per_launch"] == (40000 + 1 + mm["nnz"]) * 4 + mm["nnz"] * 8 + 8 * 32 * 3 * 40000
+        assert short["legs"]["csrmm_sharded_" + lay]["efficiency"] == mm["efficiency"]
+        assert short["legs"]["csrmm_sharded_" + lay]["parity"] is True
+    assert res["config"]["communicator"] == {"backend": "gloo", "world": 2} == short["config"]["communicator"]
     sp = res["spmv_row_sharded"]
     assert "error" not in sp, sp
-    assert sp["world"] == 2 and sp["m"] == 90601 and sp["rows_per_rank"] == 45300 and sp["parity"]["bit_exact"] is True
+    assert sp["world"] == 2 and sp["parity"]["bit_exact"] is True
     assert sp["product_ms_median_max_over_ranks"] > 0 and sp["allgather_ms_median_max_over_ranks"] > 0
-    assert sp["allgather_bytes_per_rank"] == 8 * 90601
+    if not own_rows:
+        # the row-sharded SpMV iteration (SURVEY 8e "next"): 301^2 = 90,601 rows over two ranks, an all-gather per iteration
+        assert sp["m"] == 90601 and sp["rows_per_rank"] == 45300 and sp["allgather_bytes_per_rank"] == 8 * 90601
+        assert sp["roofline_shard"] is None  # a cache-resident share carries no HBM roofline claim
+    assert short["legs"]["spmv_row_sharded"]["parity"] is True
 
 
-def test_bench_single_process_small_legs():
-    """`python bench.py` with every leg on small inputs: one JSON line whose legs all carry a roofline object and a
-    bit-exact verdict (the driver-timed run uses the full sizes)."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--grid", "512",
-                        "--mm-grid", "200", "--mm-cols", "64", "--shard-grid", "300", "--small", "--cpu-seconds", "0.5"], cwd=ROOT,
+def test_bench_gpus_2_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2 ...` WITHOUT torch.distributed.run (the driver's command form): the parent starts the two ranks
+    as a child process, relays rank 0's record as its own last line and exits with the child's code."""
+    rec = str(tmp_path / "legs.json")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "5", "--warmup", "2",
+                        "--grid", "512", "--mm-grid", "200", "--mm-cols", "64", "--shard-grid", "301", "--legs",
+                        "csrmm_sharded,spmv_row_sharded", "--record", rec], cwd=ROOT, env=dict(env, OMP_NUM_THREADS="4"),
                        capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, "rc=%d\nstdout:\n%s\nstderr:\n%s" % (r.returncode, r.stdout[-3000:], r.stderr[-3000:])
+    short, res = _bench_record(r.stdout, rec)
+    _check_two_rank_record(short, res, own_rows=False)
+    # with RCCL two ranks cannot share the one GPU: the child fails and the parent must report that, not a record
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--grid", "256",
+                        "--legs", "none", "--record", ""], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_single_process_small_legs(tmp_path):
+    """`python bench.py` with every leg on small inputs: the short record as the last line, and a full report whose legs all
+    carry a roofline object and a bit-exact verdict (the driver-timed run uses the full sizes)."""
+    rec = str(tmp_path / "legs.json")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--grid", "512",
+                        "--mm-grid", "200", "--mm-cols", "64", "--shard-grid", "300", "--small", "--cpu-seconds", "0.5",
+                        "--record", rec], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    short, res = _bench_record(r.stdout, rec)
     assert res["parity"]["bit_exact"] and res["cpu_baseline"]["kind"] == "port"
     cb = res["cpu_baseline"]
     assert cb["one_thread"]["threads"] == 1 and cb["cores"] >= 1 and cb["cpu_model"] and cb["bit_exact_vs_gpu"]
+    assert short["cpu_baseline"]["kind"] == "port" and short["cpu_baseline"]["value"] == cb["value"] and short["cpu_baseline"]["cores"] == cb["cores"]
     assert res["l100"]["bit_exact"] and res["l100"]["roofline"]["frac"] > 0
     legs = res["legs"]
     for k in ("dcsrmv_csr_adaptive", "mix", "csrmm", "trsv"):
@@ -214,8 +275,16 @@ def test_bench_single_process_small_legs():
     assert kid_cases >= 2
     for s in legs["trsv"]["schedules"]:
         assert s["bit_exact_vs_cpu"] and s["residual_inf"] < 1e-13
-    assert res["csrmm_sharded"]["efficiency"] == 1.0 and res["csrmm_sharded"]["parity"]["bit_exact"]
+    for lay in ("col", "row"):
+        assert res["csrmm_sharded_" + lay]["efficiency"] == 1.0 and res["csrmm_sharded_" + lay]["parity"]["bit_exact"]
     assert res["spmv_row_sharded"]["parity"]["bit_exact"] and res["spmv_row_sharded"]["allgather_ms_median_max_over_ranks"] == 0.0
+    # one number per leg in the short record, none of them missing and no leg in error
+    n = short["legs"]
+    assert "errors" not in n, n
+    for k in ("l100_us", "csr_adaptive_frac", "mix_frac_mean", "csrmm_row_ms", "csrmm_row_slab_ms", "csrmm_row_eff8", "csrmm_col_ms",
+              "csrmm_col_slab_ms", "csrmm_col_eff8", "trsv_ms"):
+        assert n.get(k) is not None and n[k] > 0, (k, n)
+    assert n["csrmm_parity"] and n["mix_parity"] and n["trsv_parity"]
 
 
 # --------------------------------------------------------------------------------------------------

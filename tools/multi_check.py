@@ -6,7 +6,9 @@
 Prints one JSON line: per-call wall time with N devices (every call returns when all devices are done: the hand-over to the slot
 workers, the launches and the per-device stream synchronisation are inside it), the 1-device time of the same job, T1 / (N * TN), and whether
 every device's slab equals the 1-device product bit for bit.  --same-device puts all N slots on device 0 (what a one-GPU
-box can run: the control flow, not the speed-up).  bench.py runs this as a CHILD process when it sees more than one GPU, with a
+box can run: the control flow ONLY -- the line then says "same_device": true and carries NO efficiency figure, because slots that
+share one GPU say nothing about scaling).  On distinct devices the line also carries each device's own time for its slab
+(a one-device call of that slab's width on that device).  bench.py runs this as a CHILD process when it sees more than one GPU, with a
 timeout, so that a problem on a multi-GPU node cannot take the bench line down with it.
 """
 import argparse
@@ -106,15 +108,27 @@ def main():
         ref = (C1m[j0:j1] if colmaj else C1m[:, j0:j1]).contiguous().reshape(-1).cpu()
         same = same and bool(torch.equal(got, ref))
     tn, t1 = float(np.median(laps)), float(np.median(laps1))
-    print(json.dumps({"what": "aoclsparse_mi355_dcsrmm_multi_slabs, one process", "devices": devices, "visible_gpus": ndev_visible,
-                      "device0": name, "layout": "column-major" if colmaj else "row-major", "ncols": ncols, "m": m,
-                      "cols_per_device": widths, "ms_wall_median": round(tn, 4), "ms_wall_min": round(min(laps), 4),
-                      "ms_one_device_wall_median": round(t1, 4), "efficiency_wall": round(t1 / (n * tn), 4),
-                      "first_call_ms_with_replica_build": round(t_first * 1e3, 1), "replicas": int(L.aoclsparse_mi355_replica_count(A.h)),
-                      "replicas_cloned_device_to_device": int(L.aoclsparse_mi355_replicas_cloned(A.h)),
-                      "slabs_bit_identical_to_one_device": same,
-                      "note": "wall clock around the call: the hand-over to the persistent slot workers, launches and the per-device "
-                              "stream synchronisation are inside; beta = 0 with C read (default)"}))
+    same_device = len(set(devices)) < len(devices)
+    out = {"what": "aoclsparse_mi355_dcsrmm_multi_slabs, one process", "devices": devices, "same_device": same_device,
+           "visible_gpus": ndev_visible, "device0": name, "layout": "column-major" if colmaj else "row-major", "ncols": ncols, "m": m,
+           "cols_per_device": widths, "ms_wall_median": round(tn, 4), "ms_wall_min": round(min(laps), 4),
+           "ms_one_device_wall_median": round(t1, 4),
+           "first_call_ms_with_replica_build": round(t_first * 1e3, 1), "replicas": int(L.aoclsparse_mi355_replica_count(A.h)),
+           "replicas_cloned_device_to_device": int(L.aoclsparse_mi355_replicas_cloned(A.h)),
+           "slabs_bit_exact": same,
+           "note": "wall clock around the call: the hand-over to the persistent slot workers, launches and the per-device "
+                   "stream synchronisation are inside; beta = 0 with C read (default)"}
+    if same_device:
+        out["note"] += "; every slot shares ONE GPU: control flow only, no efficiency is reported"
+    else:
+        out["efficiency_wall"] = round(t1 / (n * tn), 4)
+        import ctypes
+        buf = (ctypes.c_float * 64)()
+        assert multi() == 0
+        cnt = L.aoclsparse_mi355_multi_last_ms(buf, 64)
+        out["per_device"] = [{"device": dv, "cols": j1 - j0, "ms_wall": round(float(buf[i]), 4)}
+                             for i, ((j0, j1), dv) in enumerate(zip(shards, devices)) if i < cnt]
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":
