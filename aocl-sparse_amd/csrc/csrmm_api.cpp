@@ -198,6 +198,79 @@ aoclsparse_status detect_row_runs(const HostCsr &h, SpmvPlan &plan)
     return aoclsparse_status_success;
 }
 
+// Column windows for csrmm_colwin_kernel: for every block of R consecutive rows, the stretch [lo, hi] of columns its entries
+// touch, rounded out to 16-byte granules.  The kernel applies when every stretch fits its LDS buffer and the stretches add up
+// to at most 3.2 x the rows (what is fetched per column of B: a band of half-width g and R = 2048 rows gives 1 + 2g / R; past
+// ~3 x the lane-per-row kernels' L1 / L2 reuse is as good).  O(nnz) once per handle.
+aoclsparse_status detect_windows(const HostCsr &h, SpmvPlan &plan, size_t elem)
+{
+    MmGroups &g = plan.mm;
+    if(g.win_tried)
+        return aoclsparse_status_success;
+    g.win_tried = true;
+    const int R = csrmm_window_rows(plan.max_row_nnz, elem), epp = (int)(16 / elem), maxp = csrmm_window_max_pieces();
+    if(h.m < 4 * R)
+        return aoclsparse_status_success; // small matrices: nothing to win
+    if(plan.max_row_nnz > 9)
+    {
+        // rows longer than the register cache (9 entries) finish their chain from the CSR arrays, once per column: fine for a
+        // few boundary / constraint rows, not as the rule
+        long long longer = 0;
+        for(aoclsparse_int i = 0; i < h.m; i++)
+            longer += h.ptr[i + 1] - h.ptr[i] > 9;
+        if(longer * 100 > h.m)
+            return aoclsparse_status_success;
+    }
+    const aoclsparse_int nb = (aoclsparse_int)(((long long)h.m + R - 1) / R);
+    std::vector<aoclsparse_int> win;
+    try
+    {
+        win.assign((size_t)nb * 2, 0);
+    }
+    catch(const std::bad_alloc &)
+    {
+        return aoclsparse_status_memory_error;
+    }
+    std::atomic<bool>      fits{true};
+    std::atomic<long long> total{0};
+    parallel_for(nb, 16, [&](long long b0, long long b1) {
+        long long sum = 0;
+        for(long long b = b0; b < b1 && fits.load(std::memory_order_relaxed); b++)
+        {
+            const long long ra = b * R, rb = std::min<long long>(h.m, ra + R);
+            aoclsparse_int  lo = INT32_MAX, hi = -1;
+            for(aoclsparse_int p = h.ptr[ra] - h.base; p < h.ptr[rb] - h.base; p++)
+            {
+                const aoclsparse_int c = h.ind[p] - h.base;
+                lo = std::min(lo, c), hi = std::max(hi, c);
+            }
+            if(hi < 0) // a block of empty rows
+            {
+                win[(size_t)b * 2] = 0, win[(size_t)b * 2 + 1] = 0;
+                continue;
+            }
+            lo -= lo % epp;
+            const long long pcs = ((long long)hi - lo + epp) / epp;
+            if(pcs > maxp)
+            {
+                fits.store(false, std::memory_order_relaxed);
+                break;
+            }
+            win[(size_t)b * 2] = lo, win[(size_t)b * 2 + 1] = (aoclsparse_int)pcs;
+            sum += pcs * epp;
+        }
+        total.fetch_add(sum, std::memory_order_relaxed);
+    });
+    if(!fits.load() || total.load() * 10 > (long long)h.m * 32)
+        return aoclsparse_status_success;
+    const aoclsparse_status rc = g.windows.upload(win.data(), sizeof(aoclsparse_int) * win.size(), Runtime::get().stream());
+    if(rc != aoclsparse_status_success)
+        return rc;
+    g.win_rows = R;
+    g.win      = true;
+    return aoclsparse_status_success;
+}
+
 aoclsparse_status detect_pairs(const HostCsr &h, SpmvPlan &plan)
 {
     MmGroups &g = plan.mm;
@@ -427,7 +500,17 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
     // would re-read A once per 4 columns (100 ms on the shell-like stand-in).  Detour: B and C are copied to packed
     // row-major scratch, the row-major kernels run, C is copied back -- three streaming passes (~0.5 ms each per GB)
     // instead; per element the arithmetic is the same chain, so the bits do not change.
-    const bool detour = colmaj && n >= 16 && (long long)d->nnz > (long long)CM_DETOUR_NNZ_PER_ROW * d->m;
+    // column-major, banded matrix: the LDS-window kernel (tried first: it also serves 9-entry rows, which the detour below
+    // would otherwise take)
+    if(p && colmaj && !p->mm.win_tried)
+    {
+        std::unique_lock<std::shared_mutex> w(A->guard);
+        st = detect_windows(tr ? *A->trans : A->user, *p, sizeof(T));
+        if(st != aoclsparse_status_success)
+            return st;
+    }
+    const bool windowed = colmaj && p && p->mm.win && csrmm_window_applies<T>(n, ldb, static_cast<const T *>(dB));
+    const bool detour   = colmaj && !windowed && n >= 16 && (long long)d->nnz > (long long)CM_DETOUR_NNZ_PER_ROW * d->m;
     if(p && (!colmaj || detour) && !p->mm.tried)
     {
         std::unique_lock<std::shared_mutex> w(A->guard);
@@ -442,7 +525,7 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
         if(st != aoclsparse_status_success)
             return st;
     }
-    if(p && colmaj && !detour && !p->mm.pairs_tried)
+    if(p && colmaj && !detour && !windowed && !p->mm.pairs_tried)
     {
         std::unique_lock<std::shared_mutex> w(A->guard);
         st = detect_pairs(tr ? *A->trans : A->user, *p);
@@ -492,6 +575,11 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
             st = launch_csrmm_tiled<T>(rt.stream(), d->base, alpha, d->val.as<T>(), d->ind.as<aoclsparse_int>(),
                                        d->ptr.as<aoclsparse_int>(), p->rowblocks.as<aoclsparse_int>(), p->nblocks, p->tile,
                                        p->max_row_nnz, static_cast<const T *>(dB), n, ldb, beta, static_cast<T *>(dC), ldc);
+        else if(windowed)
+            // column-major operands, banded matrix: each B column's stretch staged in LDS, rows' entries in registers
+            st = launch_csrmm_window<T>(rt.stream(), d->base, alpha, d->m, d->val.as<T>(), d->ind.as<aoclsparse_int>(),
+                                        d->ptr.as<aoclsparse_int>(), p->mm.windows.as<aoclsparse_int>(), p->mm.win_rows,
+                                        p->max_row_nnz, static_cast<const T *>(dB), n, ldb, beta, static_cast<T *>(dC), ldc);
         else if(colmaj && p && p->mm.pairs && (long long)ldb * (long long)sizeof(T) < (1LL << 32)
                 && reinterpret_cast<uintptr_t>(dB) % sizeof(T) == 0)
             // column-major operands, rows paired with a one-column shift: 16-byte loads / stores
@@ -650,6 +738,8 @@ static aoclsparse_status clone_mm_state(const _aoclsparse_matrix &A, _aoclsparse
     gr.pairs_tried = ga.pairs_tried, gr.pairs = ga.pairs, gr.npairs = ga.npairs, gr.nsingles = ga.nsingles;
     MI355_CLONE(gr.pair_first, ga.pair_first);
     MI355_CLONE(gr.single_rows, ga.single_rows);
+    gr.win_tried = ga.win_tried, gr.win = ga.win, gr.win_rows = ga.win_rows;
+    MI355_CLONE(gr.windows, ga.windows);
 #undef MI355_CLONE
     MI355_HIP_TRY(hipStreamSynchronize(s));
     r.valid  = true;

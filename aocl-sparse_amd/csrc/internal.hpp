@@ -293,6 +293,12 @@ struct MmGroups
     bool           pairs_tried = false, pairs = false;
     aoclsparse_int npairs = 0, nsingles = 0;
     DeviceBuffer   pair_first, single_rows; // first row of every pair; rows without a partner
+    // column-major csrmm, round 4: every block of win_rows consecutive rows touches one short stretch of columns (banded
+    // matrices, stencils in natural order) -- csrmm_colwin_kernel stages that stretch of each B column in LDS.
+    // windows[2b], windows[2b+1] = first column (0-based, 16-byte granule) and 16-byte pieces of block b's stretch
+    bool           win_tried = false, win = false;
+    int            win_rows  = 0;
+    DeviceBuffer   windows;
 };
 
 // merge-path tiling of a device CSR (mergepath_kernels.hip): tile w starts at {row ends, non-zeros} =
@@ -833,6 +839,16 @@ aoclsparse_status launch_csrmm_colpair(hipStream_t s, int base, T alpha, aoclspa
                                        const aoclsparse_int *single_rows, const T *val, const aoclsparse_int *col,
                                        const aoclsparse_int *row_ptr, aoclsparse_int max_row_nnz, const T *B, aoclsparse_int n,
                                        aoclsparse_int ldb, T beta, T *C, aoclsparse_int ldc);
+// column-major, banded: a workgroup stages the stretch of a B column its rows can touch in LDS (csrmm_window_kernels.hip)
+int csrmm_window_rows(aoclsparse_int max_row_nnz, size_t elem); // rows per workgroup the kernel will use
+int csrmm_window_max_pieces(); // 16-byte pieces a window may hold
+template <typename T>
+bool csrmm_window_applies(aoclsparse_int n, aoclsparse_int ldb, const T *B);
+template <typename T>
+aoclsparse_status launch_csrmm_window(hipStream_t s, int base, T alpha, aoclsparse_int m, const T *val, const aoclsparse_int *col,
+                                      const aoclsparse_int *row_ptr, const aoclsparse_int *win, int win_rows,
+                                      aoclsparse_int max_row_nnz, const T *B, aoclsparse_int n, aoclsparse_int ldb, T beta, T *C,
+                                      aoclsparse_int ldc);
 // aoclsparse_?csrmm_kid with kid 1/2/3: the reference's KT kernels' arithmetic (csrmm_kt.cpp:31-363), lanes = 4 / 8 (double), 8 / 16 (float)
 template <typename T>
 aoclsparse_status launch_csrmm_kt(hipStream_t s, aoclsparse_order order, int lanes, int base, T alpha, aoclsparse_int m,

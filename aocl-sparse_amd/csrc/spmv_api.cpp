@@ -620,6 +620,7 @@ aoclsparse_status aoclsparse_mi355_get_spmv_info(const aoclsparse_matrix A, aocl
     info->sell_slices  = p.sell.valid ? p.sell.nslices : 0;
     info->stored_cells = p.sell.valid ? p.sell.cells : 0;
     info->mm_groups    = p.mm.valid ? p.mm.ngroups : 0;
+    info->mm_window_rows = p.mm.win ? p.mm.win_rows : 0;
     info->long_rows   = p.long_rows;
     info->max_row_nnz = p.max_row_nnz;
     aoclsparse_int kid = -1;

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import oracle
-from util import EPS64, ROOT, laplace5, pkg, random_csr
+from util import EPS64, ROOT, beta0_overwrite, laplace5, pkg, random_csr
 
 pytestmark = pytest.mark.gpu
 
@@ -101,3 +101,129 @@ def test_multi_check_reports_no_efficiency_on_one_device():
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert res["same_device"] is True and "efficiency_wall" not in res and res["slabs_bit_exact"] is True
     assert res["devices"] == [res["devices"][0]] * 2 and res["replicas"] == 1
+
+
+# --------------------------------------------------------------------------------------------------
+# column-major csrmm, LDS-window kernel (csrmm_window_kernels.hip)
+# --------------------------------------------------------------------------------------------------
+def _banded(g, rows, pattern, seed, base=0, extra_long=0, empty_every=0):
+    """m = g * rows rows; row r holds the offsets of `pattern` (relative columns, clipped to [0, m)) in increasing order,
+    values U(-1, 1).  extra_long: that many rows additionally get 14 more entries inside the band (rows longer than the
+    kernel's register cache); empty_every: every such row is left empty."""
+    rng = np.random.default_rng(seed)
+    m = g * rows
+    longs = set(int(t) for t in rng.choice(m, size=extra_long, replace=False)) if extra_long else set()
+    rp = np.zeros(m + 1, np.int64)
+    cols = []
+    pat = np.array(sorted(pattern), np.int64)
+    for r in range(m):
+        c = r + pat
+        c = c[(c >= 0) & (c < m)]
+        if r in longs:
+            c = np.unique(np.concatenate([c, np.clip(r + rng.integers(-g, g, size=14), 0, m - 1)]))
+        if empty_every and r % empty_every == empty_every - 1:
+            c = c[:0]
+        cols.append(c)
+        rp[r + 1] = rp[r] + len(c)
+    ci = np.concatenate(cols)
+    v = rng.uniform(-1, 1, len(ci))
+    return m, (rp + base).astype(np.int32), (ci + base).astype(np.int32), v
+
+
+def _same_bits(a, b):
+    """bit-for-bit equality (signs of zeros included) where the values are numbers; NaN must meet NaN (its payload / sign are the
+    host FPU's or the GPU's default and are not part of the reference's arithmetic)"""
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    na, nb = np.isnan(a), np.isnan(b)
+    u = np.uint64 if a.dtype == np.float64 else np.uint32
+    return bool(np.array_equal(na, nb) and np.array_equal(a.view(u)[~na], b.view(u)[~nb]))
+
+
+@pytest.mark.parametrize("case", ["laplace5", "nine_point_base1", "long_and_empty_rows"])
+def test_csrmm_column_major_window_kernel_bit_exact(case):
+    """csrmm_colwin_kernel (column-major operands, banded A: each B column's stretch staged in LDS by LDS-DMA, the rows' entries
+    in registers) against oracle.dcsrmm (csrmm_col_major_ref, csrmm.hpp:36-90): bit for bit, for 5-point rows (8 rows per lane of 512),
+    9-point rows in base 1 (4 rows per lane), rows longer than the register cache and empty rows; column counts that are not a
+    multiple of the 64-column chunk, odd counts, padded leading dimensions, alpha / beta classes, both beta = 0 modes, Inf / NaN
+    in B next to short rows (padding entries must not pick them up), m not a multiple of the rows per workgroup."""
+    if case == "laplace5":
+        g = 150
+        m, rp, ci, v = laplace5(g)
+        base, want_rows = 0, 4096
+    elif case == "nine_point_base1":
+        g = 101
+        m, rp, ci, v = _banded(g, 97, [-g - 1, -g, -g + 1, -1, 0, 1, g - 1, g, g + 1], 5, base=1)
+        base, want_rows = 1, 2048
+    else:
+        g = 120
+        m, rp, ci, v = _banded(g, 90, [-g, -1, 0, 1, g], 6, extra_long=40, empty_every=37)
+        base, want_rows = 0, 2048
+    A = P.Matrix(base, m, m, rp, ci, v)
+    d = P.Descr(base=base)
+    rng = np.random.default_rng(12)
+    first = True
+    for n, ldb, ldc, alpha, beta in ((70, m, m, 1.0, 0.0), (5, m + 2, m + 6, -1.5, 0.75), (64, m, m + 1, 2.0, 0.0), (33, m + 4, m, 1.0, -1.0)):
+        B = rng.uniform(-1, 1, ldb * n)
+        # Inf / NaN in B: rows that reference them must produce the reference's Inf / NaN, every other row must not see them
+        Bm = B.reshape(n, ldb)
+        Bm[0, 0], Bm[1, m // 2], Bm[n - 1, m - 1] = np.inf, np.nan, -np.inf
+        C0 = rng.uniform(-1, 1, ldc * n)
+        so, Cr = oracle.dcsrmm("col", alpha, base, v, ci, rp, m, B, n, ldb, beta, C0, ldc)
+        assert so == 0
+        for overwrite in ((False, True) if beta == 0.0 else (False,)):
+            Cd = dev(C0)
+            assert L.aoclsparse_mi355_set_csrmm_beta0_overwrite(1 if overwrite else 0) == 0
+            try:
+                assert P.dcsrmm(P.OP_NONE, alpha, A, d, P.ORDER_COLUMN, dev(B), n, ldb, beta, Cd, ldc) == 0
+                torch.cuda.synchronize()
+            finally:
+                assert L.aoclsparse_mi355_set_csrmm_beta0_overwrite(0) == 0
+            assert _same_bits(Cd.cpu().numpy(), Cr), (case, n, ldb, ldc, alpha, beta, overwrite)
+        if first:
+            assert A.spmv_info().mm_window_rows == want_rows, "the window kernel was not selected"
+            first = False
+    # operands the window kernel cannot take (odd leading dimension: a column's stretch would not start on 16 bytes) fall back to
+    # the lane-per-row kernels with the same bits
+    n, ldb = 12, m + 1
+    B = rng.uniform(-1, 1, ldb * n)
+    C0 = rng.uniform(-1, 1, m * n)
+    so, Cr = oracle.dcsrmm("col", 1.0, base, v, ci, rp, m, B, n, ldb, 0.5, C0, m)
+    Cd = dev(C0)
+    assert P.dcsrmm(P.OP_NONE, 1.0, A, d, P.ORDER_COLUMN, dev(B), n, ldb, 0.5, Cd, m) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(Cd.cpu().numpy(), Cr)
+
+
+def test_csrmm_column_major_window_kernel_float_and_nan_in_c():
+    """float operands (4 elements per 16-byte piece) against the serial fp32 chain of csrmm_col_major_ref on sampled rows; NaN
+    already in C: propagated by default as in the reference (csrmm.hpp:83), overwritten in the opt-in mode."""
+    g = 160
+    m, rp, ci, v = laplace5(g)
+    vf = (v + np.random.default_rng(3).uniform(-0.1, 0.1, len(v))).astype(np.float32)
+    Af = P.Matrix(0, m, m, rp, ci, vf)
+    d = P.Descr()
+    n = 24
+    rng = np.random.default_rng(4)
+    Bf = rng.uniform(-1, 1, m * n).astype(np.float32)
+    Cf = torch.zeros(m * n, dtype=torch.float32, device="cuda")
+    assert L.aoclsparse_scsrmm(P.OP_NONE, 1.0, Af.h, d.h, P.ORDER_COLUMN, P._ptr(dev(Bf)), n, m, 0.0, P._ptr(Cf), m) == 0
+    torch.cuda.synchronize()
+    assert Af.spmv_info().mm_window_rows == 4096
+    got = Cf.cpu().numpy().reshape(n, m)
+    Bm = Bf.reshape(n, m)
+    for i in list(range(0, m, 211)) + [m - 1]:
+        acc = np.zeros(n, np.float32)
+        for p in range(rp[i], rp[i + 1]):  # fmaf chain: exact product + sum in double, one rounding to float
+            acc = (np.float64(vf[p]) * Bm[:, ci[p]].astype(np.float64) + acc.astype(np.float64)).astype(np.float32)
+        assert np.array_equal(got[:, i], acc), i
+    Ad = P.Matrix(0, m, m, rp, ci, v)
+    B = rng.uniform(-1, 1, m * n)
+    Cd = torch.full((m * n,), float("nan"), dtype=torch.float64, device="cuda")
+    assert P.dcsrmm(P.OP_NONE, 1.0, Ad, d, P.ORDER_COLUMN, dev(B), n, m, 0.0, Cd, m) == 0
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(Cd).all())
+    with beta0_overwrite(P):
+        assert P.dcsrmm(P.OP_NONE, 1.0, Ad, d, P.ORDER_COLUMN, dev(B), n, m, 0.0, Cd, m) == 0
+        torch.cuda.synchronize()
+    so, Cr = oracle.dcsrmm("col", 1.0, 0, v, ci, rp, m, B, n, m, 0.0, np.zeros(m * n), m)
+    assert np.array_equal(Cd.cpu().numpy(), Cr)
