@@ -47,7 +47,7 @@ class SpmvInfo(ctypes.Structure):
     _fields_ = [("kernel", c_int32), ("order", c_int32), ("row_blocks", c_int32), ("tile", c_int32),
                 ("long_rows", c_int32), ("max_row_nnz", c_int32), ("device_resident", c_int32),
                 ("sell_slices", c_int32), ("stored_cells", ctypes.c_longlong), ("mm_groups", c_int32),
-                ("mm_window_rows", c_int32)]
+                ("mm_window_rows", c_int32), ("mm_bell_width", c_int32), ("mm_bell_fill_permille", c_int32)]
 
 
 # every exported symbol of include/*.h: name -> (restype, argtypes)

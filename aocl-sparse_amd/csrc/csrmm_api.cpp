@@ -198,6 +198,150 @@ aoclsparse_status detect_row_runs(const HostCsr &h, SpmvPlan &plan)
     return aoclsparse_status_success;
 }
 
+// Blocked-ELL copy for the MFMA kernel (csrmm_bell_kernels.hip).  The reference chooses its blocked CSR the same way: count
+// the non-empty blocks a block size would give and keep the format when enough of their cells are real entries
+// (conversion/aoclsparse_convert.cpp:36-147 aoclsparse_opt_blksize, analysis.cpp:146-160: 40-50 % thresholds).  Here: 16 x 16
+// blocks (the MFMA tile), kept when fill = nnz / (256 * blocks) >= 0.5, the ELL padding (width * block rows over blocks) stays
+// under 1.35 and every row is sorted and duplicate-free (the tile walks k upwards: only then is the sum the CSR-order chain).
+} // namespace
+aoclsparse_status mi355::build_bell(const HostCsr &h, SpmvPlan &plan, aoclsparse_matrix_data_type vt)
+{
+    BellPlan &bp = plan.bell;
+    if(bp.tried)
+        return aoclsparse_status_success;
+    bp.tried = true;
+    constexpr int BS = BELL_BS;
+    // cheap rejections first: at least 8 entries per row on average (a half-full tile row), a matrix worth the copy
+    if(vt != aoclsparse_dmat || h.m < 64 * BS || (long long)h.nnz < 8LL * h.m)
+        return aoclsparse_status_success;
+    const aoclsparse_int nbr = (aoclsparse_int)(((long long)h.m + BS - 1) / BS);
+    std::vector<aoclsparse_int> cnt;
+    try
+    {
+        cnt.assign((size_t)nbr + 1, 0);
+    }
+    catch(const std::bad_alloc &)
+    {
+        return aoclsparse_status_memory_error;
+    }
+    std::atomic<bool> sorted{true}, nomem{false};
+    // pass 1: distinct block columns per block row
+    parallel_for(nbr, 64, [&](long long b0, long long b1) {
+        std::vector<aoclsparse_int> bc;
+        try
+        {
+            for(long long b = b0; b < b1 && sorted.load(std::memory_order_relaxed); b++)
+            {
+                bc.clear();
+                const long long ra = b * BS, rb = std::min<long long>(h.m, ra + BS);
+                for(long long i = ra; i < rb; i++)
+                {
+                    aoclsparse_int prev = -1, prevb = -1;
+                    for(aoclsparse_int p = h.ptr[i] - h.base; p < h.ptr[i + 1] - h.base; p++)
+                    {
+                        const aoclsparse_int c = h.ind[p] - h.base;
+                        if(c <= prev)
+                        {
+                            sorted.store(false, std::memory_order_relaxed);
+                            break;
+                        }
+                        prev = c;
+                        if(c / BS != prevb)
+                            bc.push_back(prevb = c / BS);
+                    }
+                }
+                std::sort(bc.begin(), bc.end());
+                cnt[(size_t)b + 1] = (aoclsparse_int)(std::unique(bc.begin(), bc.end()) - bc.begin());
+            }
+        }
+        catch(const std::bad_alloc &)
+        {
+            nomem.store(true);
+        }
+    });
+    if(nomem.load())
+        return aoclsparse_status_memory_error;
+    if(!sorted.load())
+        return aoclsparse_status_success;
+    long long      nblk = 0;
+    aoclsparse_int width = 0;
+    for(aoclsparse_int b = 0; b < nbr; b++)
+        nblk += cnt[(size_t)b + 1], width = std::max(width, cnt[(size_t)b + 1]);
+    if(nblk == 0)
+        return aoclsparse_status_success;
+    const double    fill  = (double)h.nnz / (256.0 * (double)nblk);
+    const long long slots = (long long)nbr * width;
+    if(fill < 0.5 || (double)slots > 1.35 * (double)nblk || slots * 256 > (1LL << 33) / 8 * 4) // (<= 4 GB of values)
+        return aoclsparse_status_success;
+    // pass 2: values in the A-operand order, block columns ascending, empty slots (-1) last
+    std::vector<double>         bv;
+    std::vector<aoclsparse_int> bcol;
+    try
+    {
+        bv.assign((size_t)slots * 256, 0.0);
+        bcol.assign((size_t)slots, -1);
+    }
+    catch(const std::bad_alloc &)
+    {
+        return aoclsparse_status_memory_error;
+    }
+    const double *hv = static_cast<const double *>(h.val);
+    parallel_for(nbr, 64, [&](long long b0, long long b1) {
+        std::vector<aoclsparse_int> bc;
+        try
+        {
+            for(long long b = b0; b < b1; b++)
+            {
+                bc.clear();
+                const long long ra = b * BS, rb = std::min<long long>(h.m, ra + BS);
+                for(long long i = ra; i < rb; i++)
+                {
+                    aoclsparse_int prevb = -1;
+                    for(aoclsparse_int p = h.ptr[i] - h.base; p < h.ptr[i + 1] - h.base; p++)
+                        if((h.ind[p] - h.base) / BS != prevb)
+                            bc.push_back(prevb = (h.ind[p] - h.base) / BS);
+                }
+                std::sort(bc.begin(), bc.end());
+                bc.erase(std::unique(bc.begin(), bc.end()), bc.end());
+                aoclsparse_int *slot = bcol.data() + (size_t)b * width;
+                std::copy(bc.begin(), bc.end(), slot);
+                double *vb = bv.data() + (size_t)b * width * 256;
+                for(long long i = ra; i < rb; i++)
+                {
+                    size_t s = 0; // the row's entries ascend: so do the slots they fall into
+                    for(aoclsparse_int p = h.ptr[i] - h.base; p < h.ptr[i + 1] - h.base; p++)
+                    {
+                        const aoclsparse_int c = h.ind[p] - h.base, cb = c / BS, kk = c % BS;
+                        while(slot[s] != cb)
+                            s++;
+                        // A-operand order: fragment t = kk / 4, lane = 16 * (kk % 4) + row; fragments 2p and 2p+1 of a lane adjacent
+                        const size_t t = (size_t)(kk / 4), ln = 16 * (size_t)(kk % 4) + (size_t)(i - ra);
+                        vb[s * 256 + 128 * (t / 2) + 2 * ln + (t & 1)] = hv[p];
+                    }
+                }
+            }
+        }
+        catch(const std::bad_alloc &)
+        {
+            nomem.store(true);
+        }
+    });
+    if(nomem.load())
+        return aoclsparse_status_memory_error;
+    hipStream_t       st = Runtime::get().stream();
+    aoclsparse_status rc = bp.val.upload(bv.data(), sizeof(double) * bv.size(), st);
+    if(rc == aoclsparse_status_success)
+        rc = bp.bcol.upload(bcol.data(), sizeof(aoclsparse_int) * bcol.size(), st);
+    if(rc != aoclsparse_status_success)
+        return rc;
+    MI355_HIP_TRY(hipStreamSynchronize(st)); // the host buffers above go away
+    bp.nbr = nbr, bp.width = width, bp.nblocks = nblk, bp.fill = fill;
+    bp.valid = true;
+    return aoclsparse_status_success;
+}
+namespace
+{
+
 // Column windows for csrmm_colwin_kernel: for every block of R consecutive rows, the stretch [lo, hi] of columns its entries
 // touch, rounded out to 16-byte granules.  The kernel applies when every stretch fits its LDS buffer and the stretches add up
 // to at most 3.2 x the rows (what is fetched per column of B: a band of half-width g and R = 2048 rows gives 1 + 2g / R; past
@@ -511,7 +655,15 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
     }
     const bool windowed = colmaj && p && p->mm.win && csrmm_window_applies<T>(n, ldb, static_cast<const T *>(dB));
     const bool detour   = colmaj && !windowed && n >= 16 && (long long)d->nnz > (long long)CM_DETOUR_NNZ_PER_ROW * d->m;
-    if(p && (!colmaj || detour) && !p->mm.tried)
+    // (a second copy of the matrix: not under aoclsparse_memory_usage_minimal, which forbids such copies -- analysis.cpp:446)
+    if(p && (!colmaj || detour) && !p->bell.tried && A->mem_policy == aoclsparse_memory_usage_unrestricted)
+    {
+        std::unique_lock<std::shared_mutex> w(A->guard);
+        st = build_bell(tr ? *A->trans : A->user, *p, vt);
+        if(st != aoclsparse_status_success)
+            return st;
+    }
+    if(p && (!colmaj || detour) && !p->bell.valid && !p->mm.tried)
     {
         std::unique_lock<std::shared_mutex> w(A->guard);
         st = build_mm_groups(tr ? *A->trans : A->user, *p);
@@ -562,12 +714,28 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
                 st = launch_relayout<T>(rt.stream(), true, static_cast<const T *>(dB), static_cast<T *>(bt), b_rows, n, ldb);
             if(st == aoclsparse_status_success)
                 st = launch_relayout<T>(rt.stream(), true, static_cast<const T *>(dC), static_cast<T *>(ct), m_c, n, ldc);
-            if(st == aoclsparse_status_success)
+            bool on_mfma = false;
+            if constexpr(std::is_same<T, double>::value)
+                if(st == aoclsparse_status_success && p && p->bell.valid)
+                {
+                    // block-dense matrix: the blocked-ELL copy on the matrix cores (row-major scratch operands)
+                    st = launch_csrmm_bell(rt.stream(), alpha, d->m, d->n, p->bell, static_cast<const double *>(bt), n, n, beta,
+                                           static_cast<double *>(ct), n);
+                    on_mfma = true;
+                }
+            if(st == aoclsparse_status_success && !on_mfma)
                 st = launch_csrmm<T>(rt.stream(), aoclsparse_order_row, d->base, alpha, d->m, d->n, d->val.as<T>(),
                                      d->ind.as<aoclsparse_int>(), d->ptr.as<aoclsparse_int>(), static_cast<const T *>(bt),
                                      n, n, beta, static_cast<T *>(ct), n, grp, ngrp, grouped ? p->mm.max_rows : 0);
             if(st == aoclsparse_status_success)
                 st = launch_relayout<T>(rt.stream(), false, static_cast<const T *>(ct), static_cast<T *>(dC), m_c, n, ldc);
+        }
+        else if(!colmaj && p && p->bell.valid && std::is_same<T, double>::value)
+        {
+            // block-dense matrix: the blocked-ELL copy on the matrix cores
+            if constexpr(std::is_same<T, double>::value)
+                st = launch_csrmm_bell(rt.stream(), alpha, d->m, d->n, p->bell, static_cast<const double *>(dB), n, ldb, beta,
+                                       static_cast<double *>(dC), ldc);
         }
         else if(!colmaj && !grouped && p && p->valid && p->nblocks > 0
                 && csrmm_tiled_applies<T>(n, ldb, ldc, static_cast<const T *>(dB), static_cast<const T *>(dC)))
@@ -740,6 +908,11 @@ static aoclsparse_status clone_mm_state(const _aoclsparse_matrix &A, _aoclsparse
     MI355_CLONE(gr.single_rows, ga.single_rows);
     gr.win_tried = ga.win_tried, gr.win = ga.win, gr.win_rows = ga.win_rows;
     MI355_CLONE(gr.windows, ga.windows);
+    const BellPlan &ba = pa.bell;
+    BellPlan       &bl = pr.bell;
+    bl.tried = ba.tried, bl.valid = ba.valid, bl.nbr = ba.nbr, bl.width = ba.width, bl.nblocks = ba.nblocks, bl.fill = ba.fill;
+    MI355_CLONE(bl.val, ba.val);
+    MI355_CLONE(bl.bcol, ba.bcol);
 #undef MI355_CLONE
     MI355_HIP_TRY(hipStreamSynchronize(s));
     r.valid  = true;

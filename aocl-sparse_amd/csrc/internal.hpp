@@ -313,6 +313,20 @@ struct MergePlan
     bool           valid = false, tried = false;
 };
 
+// Blocked-ELL copy of a block-dense matrix for the MFMA csrmm (csrmm_bell_kernels.hip; round 4): 16 x 16 blocks, `width` block
+// slots per block row (bcol = -1: empty slot), values dense per block in the v_mfma_f64_16x16x4 A-operand order (element
+// (i, k) of a block: fragment t = k / 4, lane = 16 * (k % 4) + i, stored at 128 * (t / 2) + 2 * lane + t % 2).  Built for double matrices whose 16 x 16 tiles are at least half full
+// (the reference picks its blocked CSR by the same kind of fill threshold: conversion/aoclsparse_convert.cpp:36-147).
+constexpr int BELL_BS = 16;
+struct BellPlan
+{
+    bool           tried = false, valid = false;
+    aoclsparse_int nbr = 0, width = 0; // block rows, block slots per block row
+    long long      nblocks = 0; // stored (non-empty) blocks
+    double         fill = 0.0; // nnz / (256 * nblocks)
+    DeviceBuffer   val, bcol; // nbr * width * 256 values; nbr * width block columns
+};
+
 // SpMV execution plan (CSR-Adaptive row blocks), see spmv_kernels.hip
 struct SpmvPlan
 {
@@ -330,6 +344,7 @@ struct SpmvPlan
     SellPlan       sell;
     MergePlan      merge;
     MmGroups       mm;
+    BellPlan       bell;
     std::atomic<int> mv_calls{0}; // products served from this plan without a SELL copy (promotion counter;
                                   // concurrent ?mv calls on one handle are allowed, as in the reference)
 };
@@ -839,6 +854,11 @@ aoclsparse_status launch_csrmm_colpair(hipStream_t s, int base, T alpha, aoclspa
                                        const aoclsparse_int *single_rows, const T *val, const aoclsparse_int *col,
                                        const aoclsparse_int *row_ptr, aoclsparse_int max_row_nnz, const T *B, aoclsparse_int n,
                                        aoclsparse_int ldb, T beta, T *C, aoclsparse_int ldc);
+// row-major, block-dense matrices: blocked-ELL copy + v_mfma_f64_16x16x4_f64 (csrmm_bell_kernels.hip)
+aoclsparse_status build_bell(const HostCsr &h, SpmvPlan &plan, aoclsparse_matrix_data_type vt);
+aoclsparse_status launch_csrmm_bell(hipStream_t s, double alpha, aoclsparse_int m, aoclsparse_int k, const BellPlan &bell,
+                                    const double *B, aoclsparse_int n, aoclsparse_int ldb, double beta, double *C,
+                                    aoclsparse_int ldc);
 // column-major, banded: a workgroup stages the stretch of a B column its rows can touch in LDS (csrmm_window_kernels.hip)
 int csrmm_window_rows(aoclsparse_int max_row_nnz, size_t elem); // rows per workgroup the kernel will use
 int csrmm_window_max_pieces(); // 16-byte pieces a window may hold

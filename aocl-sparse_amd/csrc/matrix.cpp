@@ -1117,6 +1117,8 @@ aoclsparse_status aoclsparse_mi355_invalidate(aoclsparse_matrix A)
     A->plan_trans.mm.valid = A->plan_trans.mm.tried = false;
     A->plan_user.mm.pairs = A->plan_user.mm.pairs_tried = false;
     A->plan_trans.mm.pairs = A->plan_trans.mm.pairs_tried = false;
+    A->plan_user.bell.valid = A->plan_user.bell.tried = false;
+    A->plan_trans.bell.valid = A->plan_trans.bell.tried = false;
     A->plan_user.mm.win = A->plan_user.mm.win_tried = false;
     A->plan_trans.mm.win = A->plan_trans.mm.win_tried = false;
     A->plan_user.mm.row_runs = A->plan_user.mm.runs_tried = false;

@@ -96,6 +96,14 @@ extern "C" aoclsparse_status aoclsparse_optimize(aoclsparse_matrix A)
                 DeviceCsr *d = nullptr;
                 SpmvPlan  *p = nullptr;
                 st = ensure_spmv(A, false, d, p);
+                if(st == aoclsparse_status_success && h.act == action_mm && h.trans == aoclsparse_operation_none && h.nop > 0)
+                {
+                    // the mm hint's format choice (the reference builds its blocked CSR in optimize by a fill threshold,
+                    // analysis.cpp:146-160, convert.cpp:36-147): a blocked-ELL copy for the MFMA kernel when the 16 x 16
+                    // tiles are at least half full
+                    std::unique_lock<std::shared_mutex> w(A->guard);
+                    st = build_bell(A->user, *p, A->val_type);
+                }
             }
             if(st != aoclsparse_status_success)
                 return st;

@@ -621,6 +621,8 @@ aoclsparse_status aoclsparse_mi355_get_spmv_info(const aoclsparse_matrix A, aocl
     info->stored_cells = p.sell.valid ? p.sell.cells : 0;
     info->mm_groups    = p.mm.valid ? p.mm.ngroups : 0;
     info->mm_window_rows = p.mm.win ? p.mm.win_rows : 0;
+    info->mm_bell_width  = p.bell.valid ? p.bell.width : 0;
+    info->mm_bell_fill_permille = p.bell.valid ? (aoclsparse_int)(p.bell.fill * 1000.0 + 0.5) : 0;
     info->long_rows   = p.long_rows;
     info->max_row_nnz = p.max_row_nnz;
     aoclsparse_int kid = -1;

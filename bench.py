@@ -134,6 +134,42 @@ def roofline(abytes, ms, traffic=None, **extra):
     return out
 
 
+_FLOOR_CACHE = {}
+
+
+def latency_floor(workgroups, footprint_bytes, entries, achieved_us):
+    """`roofline_latency` of a leg whose working set stays in the L2s / Infinity Cache (8 TB/s of HBM is the wrong roof there):
+    the measured floor of a kernel with the same launch shape that does the CSR kernels' minimum -- launch ramp, THREE dependent
+    memory round trips per wavefront (block table -> column indices / values -> x[col]) over the same footprint, then a coalesced
+    12-byte-per-entry stream of the same length (tools/latency_floor.hip, run as a child process) -- next to the achieved time.
+    frac = floor / achieved.  None when the probe is not built or fails."""
+    import subprocess
+
+    probe = os.path.join(ROOT, "tools", "bin", "latency_floor")
+    key = (int(workgroups), max(1, int(footprint_bytes) >> 20), int(entries))
+    if key not in _FLOOR_CACHE:
+        res = None
+        try:
+            if os.path.exists(probe):
+                r = subprocess.run([probe] + [str(k) for k in key], capture_output=True, text=True, timeout=120)
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                if r.returncode == 0 and line:
+                    res = json.loads(line[-1])
+        except Exception:  # noqa: BLE001 -- an extra
+            res = None
+        _FLOOR_CACHE[key] = res
+    res = _FLOOR_CACHE[key]
+    if not res:
+        return None
+    floor = float(res["three_hops_then_stream_us"])
+    return {"bound": "latency", "floor_us": round(floor, 3), "achieved_us": round(achieved_us, 3),
+            "frac": round(floor / achieved_us, 4) if achieved_us > 0 else None, "unit": "us",
+            "empty_kernel_us": res["empty_kernel_us"], "three_dependent_trips_us": res["three_hops_us"],
+            "workgroups": key[0], "footprint_mb": key[1], "entries": key[2],
+            "how": "tools/latency_floor.hip: launch + 3 dependent round trips per wavefront + a coalesced stream of the same "
+                   "length, same number of workgroups; the working set fits the L2s / Infinity Cache, so HBM is not the bound"}
+
+
 def cpu_info():
     """CPU model string, logical CPUs this process may use, physical cores among them."""
     model, cores = "unknown", set()
@@ -650,6 +686,8 @@ def main():
                "us_per_call": round(us, 3), "stats_ms": quartiles(lp), "gflops": round(2.0 * len(v1) / us / 1e3, 3),
                "roofline": roofline(b1, us * 1e-3), "bit_exact": exact,
                "note": "795 KB problem: bound by launch latency, not HBM"}
+        inf1 = A1.spmv_info()
+        out["roofline_latency"] = latency_floor(max(inf1.row_blocks, 1), b1, len(v1), us)
         # the same call back to back without an event per call, and 100 of them captured once into a HIP graph on the stream
         # handed to aoclsparse_mi355_set_stream and replayed (device-pointer calls only enqueue kernels: INTEGRATION.md)
         try:
@@ -787,6 +825,8 @@ def main():
                          "long_rows_within_bound": bool(np.all(err <= bound + 1e-300)),
                          "max_abs_diff": float(err.max()),
                          "cpu_all_cores_gflops": round(2.0 * nz / float(np.median(secs)) / 1e9, 2)})
+            if b < (200 << 20):  # the matrix stays in the L2s / Infinity Cache between calls: state the latency roof beside HBM
+                rows[-1]["roofline_latency"] = latency_floor(max(inf.row_blocks, 1), b, nz, ms * 1e3)
             del Am, xd, ydv
         # the third kernel aoclsparse_optimize can choose: merge-path, for matrices whose longest row spans tens of LDS
         # tiles (none of the four above does): a tridiagonal matrix with four rows of ~170 k entries
@@ -899,7 +939,59 @@ def main():
                                                                            and np.array_equal(full8, Ck))
                         res["cases"].append(ent)
             del sh, B, C
+        try:
+            res["blocked"] = leg_csrmm_blocked()
+        except Exception as e:  # noqa: BLE001 -- an extra of the csrmm leg
+            res["blocked"] = {"error": "%s: %s" % (type(e).__name__, e)}
         return res
+
+    # ---- north_star's "blocked-ELL variant that feeds MFMA where tiles are dense": a block-dense stand-in (16 unknowns per node,
+    # tile fill 1.0 and 0.75), row-major, the blocked-ELL copy on v_mfma_f64_16x16x4_f64 (what aoclsparse_optimize builds for the
+    # mm hint) against the CSR kernels on the SAME matrix (a handle under aoclsparse_memory_usage_minimal gets no second copy)
+    def leg_csrmm_blocked():
+        import oracle
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import standins
+        out = {"workload": "aoclsparse_dcsrmm row-major, %d columns, beta=0 (C read), block-dense stand-ins: 16 unknowns per node, "
+                           "7-point node stencil" % args.mm_cols, "cases": []}
+        ncols = args.mm_cols
+        for name in (("block-dense",) if args.small else ("block-dense", "block-dense, 75 % fill")):
+            if args.small:
+                label, (mb, rp, ci, v) = name + " (stand-in, 8x8x8 nodes)", standins.block_dense(8, 8, 8, keep=1.0)
+            else:
+                label, mb, rp, ci, v = standins.load(name)
+            nz = len(v)
+            Bd = sharded.make_B_slab(torch, device, mb, 0, ncols, "row")
+            Cd = torch.zeros(mb * ncols, dtype=torch.float64, device=device)
+            bcol4 = Bd.reshape(mb, ncols)[:, :4].t().contiguous().cpu().numpy().reshape(-1)
+            _, Cr = oracle.dcsrmm("col", 1.0, 0, v, ci, rp, mb, bcol4, 4, mb, 0.0, np.zeros(4 * mb), mb)
+            ent = {"matrix": label, "m": mb, "nnz": nz, "ncols": ncols}
+            for kind in ("mfma", "csr"):
+                Ab = pkg.Matrix(0, mb, mb, rp, ci, v)
+                if kind == "csr":
+                    assert L.aoclsparse_set_memory_hint(Ab.h, 0) == 0  # aoclsparse_memory_usage_minimal: no second copy
+                assert L.aoclsparse_set_mm_hint(Ab.h, pkg.OP_NONE, descr.h, 100) == 0 and L.aoclsparse_optimize(Ab.h) == 0
+                call = lambda: pkg.dcsrmm(pkg.OP_NONE, 1.0, Ab, descr, pkg.ORDER_ROW, Bd, ncols, ncols, 0.0, Cd, ncols)
+                assert call() == 0
+                lp = timed_laps(pkg, call, 10, 2)
+                torch.cuda.synchronize()
+                inf = Ab.spmv_info()
+                ms = float(np.mean(lp))
+                got = Cd.reshape(mb, ncols)[:, :4].t().contiguous().cpu().numpy().reshape(-1)
+                ent[kind] = {"ms": round(ms, 5), "tflops": round(2.0 * nz * ncols / ms / 1e9, 2),
+                             "bell_width": int(inf.mm_bell_width), "tile_fill": inf.mm_bell_fill_permille / 1000.0,
+                             "roofline": roofline(csrmm_bytes(mb, mb, nz, ncols, True), ms),
+                             "bit_exact_4_columns": bool(np.array_equal(got, Cr))}
+                del Ab
+            ent["mfma_selected_by_optimize"] = ent["mfma"]["bell_width"] > 0 and ent["csr"]["bell_width"] == 0
+            ent["speedup"] = round(ent["csr"]["ms"] / ent["mfma"]["ms"], 3)
+            out["cases"].append(ent)
+            del Bd, Cd
+        out["mfma_ms"] = out["cases"][0]["mfma"]["ms"]
+        out["best_other_ms"] = out["cases"][0]["csr"]["ms"]
+        out["parity_ok"] = all(c["mfma"]["bit_exact_4_columns"] and c["csr"]["bit_exact_4_columns"] for c in out["cases"])
+        out["fp64_mfma_peak_tflops"] = 78.6
+        return out
 
     run_leg("csrmm", leg_csrmm)
 

@@ -131,6 +131,8 @@ typedef struct aoclsparse_mi355_spmv_info_
     long long      stored_cells; /* SELL-64: value cells stored, padding included (kernel 4 stores fewer column cells) */
     aoclsparse_int mm_groups; /* row-major csrmm: row groups (runs of rows with one column pattern) in use, else 0 */
     aoclsparse_int mm_window_rows; /* column-major csrmm: rows per workgroup of the LDS-window kernel (banded matrices), else 0 */
+    aoclsparse_int mm_bell_width; /* csrmm: 16 x 16 block slots per block row of the blocked-ELL copy (MFMA kernel), else 0 */
+    aoclsparse_int mm_bell_fill_permille; /* ... and 1000 * nnz / (256 * stored blocks) */
 } aoclsparse_mi355_spmv_info;
 DLL_PUBLIC aoclsparse_status aoclsparse_mi355_get_spmv_info(const aoclsparse_matrix     A,
                                                             aoclsparse_operation        op,

@@ -227,3 +227,100 @@ def test_csrmm_column_major_window_kernel_float_and_nan_in_c():
         torch.cuda.synchronize()
     so, Cr = oracle.dcsrmm("col", 1.0, 0, v, ci, rp, m, B, n, m, 0.0, np.zeros(m * n), m)
     assert np.array_equal(Cd.cpu().numpy(), Cr)
+
+
+# --------------------------------------------------------------------------------------------------
+# blocked-ELL + MFMA csrmm (csrmm_bell_kernels.hip): block-dense matrices
+# --------------------------------------------------------------------------------------------------
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import standins  # noqa: E402
+
+
+def _submatrix(m, rp, ci, v, mm, kk):
+    """leading mm x kk part of a CSR matrix"""
+    rows = np.repeat(np.arange(m), np.diff(rp))
+    sel = (rows < mm) & (ci < kk)
+    rp2 = np.zeros(mm + 1, np.int64)
+    np.add.at(rp2, rows[sel] + 1, 1)
+    return np.cumsum(rp2).astype(np.int32), ci[sel].copy(), v[sel].copy()
+
+
+@pytest.mark.parametrize("keep", [1.0, 0.75])
+def test_csrmm_blocked_ell_mfma_bit_exact(keep):
+    """A block-dense matrix (16 unknowns per node, 7-point node stencil: 16 x 16 tiles full, or thinned to 75 %) gets a blocked-ELL
+    copy from aoclsparse_optimize (mm hint) and runs on v_mfma_f64_16x16x4_f64.  The instruction accumulates k upwards as one FMA
+    chain per element, so the result must equal oracle.dcsrmm (csrmm.hpp:36-90) BIT FOR BIT: row-major with column counts that are
+    and are not multiples of the 16-column tile, padded leading dimensions, alpha / beta classes and both beta = 0 modes, a row
+    count and a column count that are not multiples of 16, and column-major operands (through the row-major scratch copy)."""
+    m0, rp0, ci0, v0 = standins.block_dense(6, 5, 4, keep=keep, seed=9)
+    for mm, kk in ((m0, m0), (m0 - 5, m0 - 9)):
+        rp, ci, v = (rp0, ci0, v0) if mm == m0 else _submatrix(m0, rp0, ci0, v0, mm, kk)
+        A = P.Matrix(0, mm, kk, rp, ci, v)
+        d = P.Descr()
+        assert L.aoclsparse_set_mm_hint(A.h, P.OP_NONE, d.h, 10) == 0 and L.aoclsparse_optimize(A.h) == 0
+        info = A.spmv_info()
+        assert info.mm_bell_width == 7, "the blocked-ELL copy was not built"
+        assert abs(info.mm_bell_fill_permille - 1000 * len(v) / (256.0 * _blocks(mm, rp, ci))) <= 1
+        rng = np.random.default_rng(21)
+        for n, ldb, ldc, alpha, beta in ((64, 64, 64, 1.0, 0.0), (40, 44, 41, -0.5, 1.25), (16, 16, 16, 2.0, 0.0), (72, 72, 80, 1.0, -1.0),
+                                         (7, 7, 7, 1.0, 0.0)):
+            B = rng.uniform(-1, 1, kk * ldb)
+            C0 = rng.uniform(-1, 1, mm * ldc)
+            Bc = np.ascontiguousarray(B.reshape(kk, ldb)[:, :n].T).ravel()
+            Cc = np.ascontiguousarray(C0.reshape(mm, ldc)[:, :n].T).ravel()
+            so, Cr = oracle.dcsrmm("col", alpha, 0, v, ci, rp, mm, Bc, n, kk, beta, Cc, mm)
+            assert so == 0
+            ref = Cr.reshape(n, mm).T
+            for overwrite in ((False, True) if beta == 0.0 else (False,)):
+                Cd = dev(C0)
+                assert L.aoclsparse_mi355_set_csrmm_beta0_overwrite(1 if overwrite else 0) == 0
+                try:
+                    assert P.dcsrmm(P.OP_NONE, alpha, A, d, P.ORDER_ROW, dev(B), n, ldb, beta, Cd, ldc) == 0
+                    torch.cuda.synchronize()
+                finally:
+                    assert L.aoclsparse_mi355_set_csrmm_beta0_overwrite(0) == 0
+                got = Cd.cpu().numpy().reshape(mm, ldc)
+                assert _same_bits(got[:, :n], ref), (keep, mm, n, ldb, ldc, alpha, beta, overwrite)
+                assert np.array_equal(got[:, n:], C0.reshape(mm, ldc)[:, n:])  # padding untouched
+        # column-major operands: copied to row-major scratch, the same kernel, copied back
+        n = 48
+        B = rng.uniform(-1, 1, kk * n)
+        C0 = rng.uniform(-1, 1, mm * n)
+        so, Cr = oracle.dcsrmm("col", 1.5, 0, v, ci, rp, mm, B, n, kk, 0.5, C0, mm)
+        Cd = dev(C0)
+        assert P.dcsrmm(P.OP_NONE, 1.5, A, d, P.ORDER_COLUMN, dev(B), n, kk, 0.5, Cd, mm) == 0
+        torch.cuda.synchronize()
+        assert _same_bits(Cd.cpu().numpy(), Cr)
+
+
+def _blocks(m, rp, ci):
+    rows = np.repeat(np.arange(m), np.diff(rp))
+    return len(np.unique((rows // 16).astype(np.int64) * (1 << 32) + ci // 16))
+
+
+def test_csrmm_blocked_ell_is_not_chosen_below_half_fill_or_for_unsorted_rows():
+    """The format choice follows the reference's kind of rule (a fill threshold, convert.cpp:36-147): tiles less than half full, or
+    rows that are not sorted (the tile walks k upwards: only sorted rows give the CSR-order chain) keep the CSR kernels -- with
+    the same bits."""
+    m, rp, ci, v = standins.block_dense(6, 5, 4, keep=0.35, seed=10)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    d = P.Descr()
+    assert L.aoclsparse_set_mm_hint(A.h, P.OP_NONE, d.h, 10) == 0 and L.aoclsparse_optimize(A.h) == 0
+    assert A.spmv_info().mm_bell_width == 0
+    m, rp, ci, v = standins.block_dense(6, 5, 4, seed=11)
+    ci2 = ci.copy()
+    s, e = rp[100], rp[101]
+    ci2[s:e] = ci[s:e][::-1]  # one row in descending order
+    v2 = v.copy()
+    A2 = P.Matrix(0, m, m, rp, ci2, v2)
+    assert L.aoclsparse_set_mm_hint(A2.h, P.OP_NONE, d.h, 10) == 0 and L.aoclsparse_optimize(A2.h) == 0
+    n = 32
+    rng = np.random.default_rng(2)
+    B, C0 = rng.uniform(-1, 1, m * n), rng.uniform(-1, 1, m * n)
+    Cd = dev(C0)
+    assert P.dcsrmm(P.OP_NONE, 1.0, A2, d, P.ORDER_ROW, dev(B), n, n, 0.0, Cd, n) == 0
+    torch.cuda.synchronize()
+    assert A2.spmv_info().mm_bell_width == 0
+    Bc = np.ascontiguousarray(B.reshape(m, n).T).ravel()
+    so, Cr = oracle.dcsrmm("col", 1.0, 0, v2, ci2, rp, m, Bc, n, m, 0.0, np.zeros(m * n), m)
+    assert np.array_equal(Cd.cpu().numpy().reshape(m, n), Cr.reshape(n, m).T)

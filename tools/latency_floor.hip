@@ -3,7 +3,7 @@
 // algorithmic bytes, web-like: 57 MB) run for 10-30 us, where the launch and the chain of DEPENDENT memory round trips
 // every workgroup must make (block table -> row_ptr / col_ind / val -> x[col]) weigh as much as the bytes.
 //   hipcc -O3 --offload-arch=gfx950 tools/latency_floor.hip -o tools/bin/latency_floor
-//   latency_floor [workgroups=2000] [footprint_MB=64]
+//   latency_floor [workgroups=2000] [footprint_MB=64] [stream_entries=3100840]
 // Prints one JSON line: back-to-back time per launch of (a) an empty kernel, (b..d) a kernel whose every wavefront
 // makes 1, 2, 3 dependent loads from a footprint larger than the L2s (pointer chase through an index array, one
 // random 64-byte line per hop), (e) 3 dependent hops followed by a 12-byte-per-lane coalesced stream of the given size.
@@ -68,7 +68,7 @@ int main(int argc, char **argv)
     }
     int    *d_idx, *d_out, *d_c;
     double *d_v, *d_o2;
-    const long stream_entries = 3100840; // web-like: 3.1 M non-zeros
+    const long stream_entries = argc > 3 ? std::max(atol(argv[3]), (long)wgs) : 3100840; // default: web-like, 3.1 M non-zeros
     CHECK(hipMalloc(&d_idx, (size_t)n * 4));
     CHECK(hipMalloc(&d_out, (size_t)wgs * 256 * 4));
     CHECK(hipMalloc(&d_v, stream_entries * 8));
@@ -106,7 +106,7 @@ int main(int argc, char **argv)
     const float t4      = timeit([&] { chase_stream_kernel<<<wgs, 256>>>(d_idx, n, d_v, d_c, per_wg, d_o2); });
     printf("{\"probe\": \"launch + dependent-round-trip floor\", \"workgroups\": %d, \"footprint_mb\": %ld, "
            "\"empty_kernel_us\": %.3f, \"one_hop_us\": %.3f, \"two_hops_us\": %.3f, \"three_hops_us\": %.3f, "
-           "\"three_hops_then_37MB_stream_us\": %.3f, \"per_hop_us\": %.3f}\n",
-           wgs, fmb, t_empty, t1, t2, t3, t4, (t3 - t1) / 2);
+           "\"three_hops_then_stream_us\": %.3f, \"stream_entries\": %ld, \"per_hop_us\": %.3f}\n",
+           wgs, fmb, t_empty, t1, t2, t3, t4, stream_entries, (t3 - t1) / 2);
     return 0;
 }

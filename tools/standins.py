@@ -199,7 +199,39 @@ def web_like_local(n=1000005, seed=212):
     return _to_csr(n, rows, cols, seed + 1)
 
 
-ALL = {"circuit-like": circuit_like, "web-like": web_like, "shell-like": shell_like, "flan-like": flan_like,
+# ---- round 4: a BLOCK-DENSE matrix --------------------------------------------------------------------
+# The SuiteSparse four have 1 / 3 / 5 unknowns per node: cut into the 16 x 16 tiles of v_mfma_f64_16x16x4_f64 their fill is
+# 0.19-0.31 (profiles/r2/mfma_f64_probe.jsonl).  What the north star's "blocked-ELL variant that feeds MFMA only where nnz/row
+# is uniform enough to form dense tiles" is for is a multi-physics / high-order discretisation with many unknowns per node:
+# here 16 per node on a 3-D grid of nodes with the 7-point node stencil => 7 dense 16 x 16 blocks per block row, 112 entries
+# per row.  `keep` < 1 thins every block at random (the diagonal stays) to that fill.
+def block_dense(nx=32, ny=32, nz=32, dofs=16, keep=1.0, seed=505):
+    nodes = nx * ny * nz
+    idx = np.arange(nodes, dtype=np.int64)
+    ix, iy, iz = idx // (ny * nz), (idx // nz) % ny, idx % nz
+    offs = [(-1, 0, 0), (0, -1, 0), (0, 0, -1), (0, 0, 0), (0, 0, 1), (0, 1, 0), (1, 0, 0)]  # ascending node index
+    bc = np.empty((nodes, 7), dtype=np.int64)
+    ok = np.empty((nodes, 7), dtype=bool)
+    for k, (dx, dy, dz) in enumerate(offs):
+        ok[:, k] = ((ix + dx >= 0) & (ix + dx < nx) & (iy + dy >= 0) & (iy + dy < ny) & (iz + dz >= 0) & (iz + dz < nz))
+        bc[:, k] = (ix + dx) * (ny * nz) + (iy + dy) * nz + (iz + dz)
+    n, rp, ci, v = _block_csr(nodes, dofs, bc, ok, seed)
+    if keep >= 1.0:
+        return n, rp, ci, v
+    rng = np.random.default_rng(seed + 1)
+    rows = np.repeat(np.arange(n, dtype=np.int32), np.diff(rp))
+    sel = (rng.random(len(ci)) < keep) | (ci == rows)
+    rp2 = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(rp2, rows[sel].astype(np.int64) + 1, 1)
+    return n, np.cumsum(rp2).astype(np.int32), ci[sel], v[sel]
+
+
+def block_dense_75():
+    return block_dense(keep=0.75, seed=515)
+
+
+ALL = {"block-dense": block_dense, "block-dense, 75 % fill": block_dense_75,
+       "circuit-like": circuit_like, "web-like": web_like, "shell-like": shell_like, "flan-like": flan_like,
        "circuit-like, local": circuit_like_local, "web-like, local": web_like_local,
        "shell-like, unstructured": shell_like_unstructured, "flan-like, unstructured": flan_like_unstructured}
 
