@@ -50,6 +50,17 @@ class SpmvInfo(ctypes.Structure):
                 ("mm_window_rows", c_int32), ("mm_bell_width", c_int32), ("mm_bell_fill_permille", c_int32)]
 
 
+class MmState(ctypes.Structure):
+    """aoclsparse_mi355_mm_state: sizes + scalars of a handle's analysed csrmm state (a POD that travels as bytes)"""
+    _fields_ = [("scalars", ctypes.c_longlong * 40), ("bytes", ctypes.c_longlong * 12)]
+
+
+class CommId(ctypes.Structure):
+    _fields_ = [("internal", ctypes.c_char * 128)]
+
+
+MM_STATE_BUFFERS = 12
+
 # every exported symbol of include/*.h: name -> (restype, argtypes)
 _I = c_int32
 _P = c_void_p
@@ -342,6 +353,15 @@ SIGNATURES = {
     "aoclsparse_mi355_column_shard": (c_int, [_I, _I, _I, POINTER(_I), POINTER(_I)]),
     "aoclsparse_mi355_dcsrmm_shard": (c_int, [c_int, c_double, _P, _P, c_int, _P, _I, _I, c_double, _P, _I, _I, _I]),
     "aoclsparse_mi355_dcsrmm_multi": (c_int, [c_int, c_double, _P, _P, c_int, _P, _I, _I, c_double, _P, _I, _I, _P]),
+    "aoclsparse_mi355_mm_state_export": (c_int, [_P, POINTER(MmState), _P]),
+    "aoclsparse_mi355_mm_state_adopt": (c_int, [_P, POINTER(MmState), _P]),
+    "aoclsparse_mi355_comm_unique_id": (c_int, [POINTER(CommId)]),
+    "aoclsparse_mi355_comm_init": (c_int, [_I, _I, POINTER(CommId)]),
+    "aoclsparse_mi355_comm_destroy": (c_int, []),
+    "aoclsparse_mi355_comm_info": (c_int, [POINTER(_I), POINTER(_I), POINTER(_I)]),
+    "aoclsparse_mi355_comm_broadcast": (c_int, [_P, ctypes.c_size_t, _I]),
+    "aoclsparse_mi355_comm_allgather": (c_int, [_P, _P, ctypes.c_size_t]),
+    "aoclsparse_mi355_comm_broadcast_matrix": (c_int, [_P, _I]),
     "aoclsparse_mi355_replica_count": (c_int, [_P]),
     "aoclsparse_mi355_multi_last_ms": (c_int, [_P, c_int]),
     "aoclsparse_mi355_replicas_cloned": (c_int, [_P]),
@@ -432,6 +452,33 @@ class Matrix:
         self.status = fn(byref(self.h), base, m, n, self.nnz, _ptr(self.row_ptr), _ptr(self.col_ind),
                          _ptr(self.val))
 
+    @classmethod
+    def from_handle(cls, h, double=True):
+        """wrap a handle the LIBRARY created and whose arrays it owns (aoclsparse_mi355_mm_state_adopt,
+        aoclsparse_mi355_comm_broadcast_matrix); m / n / nnz / base are read back through aoclsparse_export_?csr"""
+        self = cls.__new__(cls)
+        self.h, self.double, self.status = h, double, 0
+        self.row_ptr = self.col_ind = self.val = None
+        e = self.export()
+        assert e["status"] == 0, STATUS.get(e["status"], e["status"])
+        self.m, self.n, self.nnz, self.base = e["m"], e["n"], e["nnz"], e["base"]
+        return self
+
+    def mm_state_export(self):
+        """-> (status, MmState, [12 device pointers]) : aoclsparse_mi355_mm_state_export"""
+        st = MmState()
+        ptrs = (c_void_p * MM_STATE_BUFFERS)()
+        rc = lib().aoclsparse_mi355_mm_state_export(self.h, byref(st), ctypes.cast(ptrs, c_void_p))
+        return rc, st, [ptrs[i] for i in range(MM_STATE_BUFFERS)]
+
+    @classmethod
+    def mm_state_adopt(cls, state, device_ptrs, double=True):
+        """device_ptrs: 12 device addresses (int / None) in THIS process's device memory -> (status, Matrix or None)"""
+        ptrs = (c_void_p * MM_STATE_BUFFERS)(*[c_void_p(p) if p else None for p in device_ptrs])
+        h = c_void_p()
+        rc = lib().aoclsparse_mi355_mm_state_adopt(byref(h), byref(state), ctypes.cast(ptrs, c_void_p))
+        return rc, (cls.from_handle(h, double) if rc == 0 else None)
+
     def destroy(self):
         if self.h:
             lib().aoclsparse_destroy(byref(self.h))
@@ -457,7 +504,7 @@ class Matrix:
         col = np.ctypeslib.as_array(ctypes.cast(ci, POINTER(c_int32)), (max(nnz.value, 1),))[: nnz.value].copy()
         val = np.ctypeslib.as_array(ctypes.cast(v, POINTER(ct)), (max(nnz.value, 1),))[: nnz.value].copy()
         return dict(status=0, base=base.value, m=m.value, n=n.value, nnz=nnz.value, row_ptr=row_ptr,
-                    col_ind=col, val=val, aliased=(rp.value == self.row_ptr.ctypes.data))
+                    col_ind=col, val=val, aliased=(self.row_ptr is not None and rp.value == self.row_ptr.ctypes.data))
 
     def export_diag(self):
         import numpy as np

@@ -767,6 +767,36 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
 
 } // namespace
 
+// Every csrmm plan of the untransposed matrix that a later product (either layout, any column count) could ask for, built NOW
+// from the host arrays: what a handle must carry before its device state is shipped to a process that will not have done the
+// analysis (aoclsparse_mi355_mm_state_export / aoclsparse_mi355_comm_broadcast_matrix).
+aoclsparse_status mi355::prepare_mm_plans(aoclsparse_matrix A)
+{
+    if(!A || !A->user.ptr || !A->user.ind || !A->user.val)
+        return aoclsparse_status_invalid_pointer;
+    DeviceCsr        *d = nullptr;
+    SpmvPlan         *p = nullptr;
+    aoclsparse_status st = ensure_spmv(A, false, d, p);
+    if(st != aoclsparse_status_success)
+        return st;
+    std::unique_lock<std::shared_mutex> w(A->guard);
+    const size_t                        elem = val_size(A->val_type);
+    if(A->mem_policy == aoclsparse_memory_usage_unrestricted && (st = build_bell(A->user, *p, A->val_type)) != aoclsparse_status_success)
+        return st;
+    if(!p->bell.valid && (st = build_mm_groups(A->user, *p)) != aoclsparse_status_success)
+        return st;
+    if(!p->bell.valid && !p->mm.valid && (st = detect_row_runs(A->user, *p)) != aoclsparse_status_success)
+        return st;
+    if((st = detect_windows(A->user, *p, elem)) != aoclsparse_status_success)
+        return st;
+    if(!p->mm.win && (st = detect_pairs(A->user, *p)) != aoclsparse_status_success)
+        return st;
+    // whatever was skipped above is never needed for this matrix: mark it tried, so that a handle that adopts this state (and
+    // has done no analysis of its own) never starts one
+    p->bell.tried = p->mm.tried = p->mm.runs_tried = p->mm.win_tried = p->mm.pairs_tried = true;
+    return aoclsparse_status_success;
+}
+
 // in-library multi-device product (defined below, after the column-shard rule it uses)
 template <typename T>
 static aoclsparse_status csrmm_multi_t(aoclsparse_operation op, const T alpha, const aoclsparse_matrix A,

@@ -854,6 +854,8 @@ aoclsparse_status launch_csrmm_colpair(hipStream_t s, int base, T alpha, aoclspa
                                        const aoclsparse_int *single_rows, const T *val, const aoclsparse_int *col,
                                        const aoclsparse_int *row_ptr, aoclsparse_int max_row_nnz, const T *B, aoclsparse_int n,
                                        aoclsparse_int ldb, T beta, T *C, aoclsparse_int ldc);
+// all csrmm plans of the untransposed matrix, built from the host arrays now (csrmm_api.cpp)
+aoclsparse_status prepare_mm_plans(aoclsparse_matrix A);
 // row-major, block-dense matrices: blocked-ELL copy + v_mfma_f64_16x16x4_f64 (csrmm_bell_kernels.hip)
 aoclsparse_status build_bell(const HostCsr &h, SpmvPlan &plan, aoclsparse_matrix_data_type vt);
 aoclsparse_status launch_csrmm_bell(hipStream_t s, double alpha, aoclsparse_int m, aoclsparse_int k, const BellPlan &bell,

@@ -4,7 +4,9 @@ C = alpha * A * B + beta * C with a tall dense B: column j of C depends on A and
 split into `world` column slabs by the reference's own rule (it splits B's columns over its worker threads,
 library/src/level3/aoclsparse_csrmm_kt.cpp:68-82 -- here a rank takes the place of a thread;
 `aoclsparse_mi355_column_shard`), every rank holds A, and the data path has NO collective.  Communication happens
-twice, outside the product: A is broadcast once from rank 0 (RCCL over xGMI when the backend is "nccl"), and a caller
+twice, outside the product: A travels once from rank 0 -- in its DEVICE FORMAT, i.e. the CSR arrays in HBM plus every csrmm
+plan rank 0's aoclsparse_optimize built, so that the other ranks do no analysis (`broadcast_handle`: over the library's own
+RCCL communicator when the backend is "nccl", else over torch.distributed + aoclsparse_mi355_mm_state_adopt) -- and a caller
 that wants all of C everywhere can all-gather the slabs afterwards (`gather_C`, reported separately).
 
 The arithmetic is the library's (`aoclsparse_dcsrmm` through the C ABI); this module is host-side orchestration only and
@@ -89,6 +91,110 @@ def broadcast_csr(dist, torch, device, rank, csr):
     return (m, n, t_rp.cpu().numpy(), t_ci.cpu().numpy(), t_v.cpu().numpy()), ms
 
 
+class _DeviceView:
+    """zero-copy view of `nbytes` bytes of device memory at `ptr` for torch.as_tensor (CUDA array interface, version 2)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+_LIB_COMM = {"tried": False, "ok": False}
+
+
+def library_communicator(pkg, torch, dist, device, rank, world):
+    """The library's own RCCL communicator (aoclsparse_mi355_comm_*), set up once per process for an "nccl" job: rank 0 draws
+    the unique id, torch.distributed carries its 128 bytes, every rank joins.  All ranks agree on the outcome (an all-reduce of
+    the status), so a rank on which librccl could not be loaded sends the whole job down the torch.distributed path instead of
+    leaving the others inside a collective.  -> True when the communicator is usable on EVERY rank."""
+    if _LIB_COMM["tried"]:
+        return _LIB_COMM["ok"]
+    _LIB_COMM["tried"] = True
+    if _backend(dist) != "nccl" or world < 2:
+        return False
+    L = pkg.lib()
+    cid = pkg.CommId()
+    st = L.aoclsparse_mi355_comm_unique_id(cid) if rank == 0 else 0
+    wire = torch.zeros(129, dtype=torch.uint8, device=device)
+    if rank == 0:
+        wire[:128] = torch.frombuffer(bytearray(bytes(cid)), dtype=torch.uint8).to(device)
+        wire[128] = 1 if st == 0 else 0
+    dist.broadcast(wire, 0)
+    host = wire.cpu()
+    ok = bool(host[128].item())
+    if ok:
+        import ctypes
+        ctypes.memmove(ctypes.addressof(cid), bytes(host[:128].numpy().tobytes()), 128)
+        ok = L.aoclsparse_mi355_comm_init(world, rank, cid) == 0
+    ok = reduce_scalar(1.0 if ok else 0.0, "min", dist, device) > 0.5
+    _LIB_COMM["ok"] = ok
+    return ok
+
+
+def broadcast_handle(pkg, torch, dist, device, rank, world, A):
+    """A: rank 0's handle after set_mm_hint + aoclsparse_optimize (None elsewhere) -> (handle on every rank, ms, how).
+    What travels is the analysed device state (CSR arrays in HBM + every csrmm plan); the receivers adopt it and run no
+    analysis.  Wire: the library's RCCL communicator ("nccl" jobs), else torch.distributed (RCCL tensors with "nccl" when the
+    library communicator is unavailable, CPU tensors with "gloo")."""
+    if dist is None or not dist.is_initialized() or world == 1:
+        return A, 0.0, "one rank: nothing to send"
+    L = pkg.lib()
+    barrier(dist, torch)
+    t0 = time.perf_counter()
+    if library_communicator(pkg, torch, dist, device, rank, world):
+        import ctypes
+        h = A.h if rank == 0 else ctypes.c_void_p()
+        st = L.aoclsparse_mi355_comm_broadcast_matrix(ctypes.byref(h), 0)
+        L.aoclsparse_mi355_synchronize()
+        if reduce_scalar(1.0 if st == 0 else 0.0, "min", dist, device) > 0.5:
+            out = A if rank == 0 else pkg.Matrix.from_handle(h)
+            return out, (time.perf_counter() - t0) * 1e3, "library RCCL communicator: ncclBroadcast of the analysed device state"
+        if rank != 0 and st == 0:
+            L.aoclsparse_destroy(ctypes.byref(h))
+    # torch.distributed as the wire
+    cpu_wire = _backend(dist) == "gloo"
+    wire = "cpu" if cpu_wire else device
+    hdr = torch.zeros(53, dtype=torch.int64, device=wire)
+    ptrs = [None] * pkg.MM_STATE_BUFFERS
+    if rank == 0:
+        st, state, ptrs = A.mm_state_export()
+        hdr[:40] = torch.tensor(list(state.scalars), dtype=torch.int64)
+        hdr[40:52] = torch.tensor(list(state.bytes), dtype=torch.int64)
+        hdr[52] = st
+    dist.broadcast(hdr, 0)
+    h = [int(x) for x in hdr.cpu().tolist()]
+    if h[52] != 0:
+        raise RuntimeError("aoclsparse_mi355_mm_state_export failed on rank 0: %s" % pkg.STATUS.get(h[52], h[52]))
+    held = []
+    for i in range(pkg.MM_STATE_BUFFERS):
+        nbytes = h[40 + i]
+        if nbytes == 0:
+            held.append(None)
+            continue
+        if rank == 0:
+            t = torch.as_tensor(_DeviceView(ptrs[i], nbytes), device=device)  # the library's buffer itself, no copy
+            t = t.cpu() if cpu_wire else t
+        else:
+            t = torch.empty(nbytes, dtype=torch.uint8, device=wire)
+        dist.broadcast(t, 0)
+        held.append(t if rank == 0 else t.to(device))
+    if rank == 0:
+        out = A
+    else:
+        state = pkg.MmState()
+        for i in range(40):
+            state.scalars[i] = h[i]
+        for i in range(12):
+            state.bytes[i] = h[40 + i]
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        st, out = pkg.Matrix.mm_state_adopt(state, [t.data_ptr() if t is not None else None for t in held])
+        assert st == 0, pkg.STATUS.get(st, st)
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    return out, (time.perf_counter() - t0) * 1e3, ("torch.distributed (%s): the analysed device state, adopted with "
+                                                  "aoclsparse_mi355_mm_state_adopt" % _backend(dist))
+
+
 def make_B_slab(torch, device, m, j0, j1, layout, seed=777):
     """Columns [j0, j1) of the job's B: column j is U(-1, 1) from a generator seeded seed + j, so any sharding of the
     same job sees the same matrix.  layout "col": slab stored column-major with ld = m; "row": m x (j1-j0), ld = j1-j0."""
@@ -111,25 +217,27 @@ class ShardedCsrmm:
         assert layout in ("col", "row")
         self.pkg, self.torch, self.dist, self.device = pkg, torch, dist, device
         self.rank, self.world, self.ncols, self.layout = rank, world, ncols, layout
-        (self.m, self.n, rp, ci, v), self.a_broadcast_ms = broadcast_csr(dist, torch, device, rank, csr)
-        self.nnz = int(len(v))
-        self.A = pkg.Matrix(0, self.m, self.n, rp, ci, v)
-        assert self.A.status == 0, pkg.STATUS[self.A.status]
-        self.descr = pkg.Descr()
         L = pkg.lib()
-        st = L.aoclsparse_set_mm_hint(self.A.h, pkg.OP_NONE, self.descr.h, 100)
-        assert st == 0, pkg.STATUS[st]
-        # every rank analyses its own copy AT THE SAME TIME (wall clock of one optimize, reported as setup_optimize_ms): for this
-        # job the analysis is a few ms, the same order as shipping the analysed device arrays would be, so the CSR arrays are
-        # what travels
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        st = L.aoclsparse_optimize(self.A.h)
-        assert st == 0, pkg.STATUS[st]
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
-        self.optimize_ms = (time.perf_counter() - t0) * 1e3
+        self.descr = pkg.Descr()
+        A, self.optimize_ms = None, 0.0
+        if rank == 0:
+            # rank 0 alone creates the handle and analyses it (mm hint + aoclsparse_optimize) ...
+            m, n, rp, ci, v = csr
+            A = pkg.Matrix(0, m, n, rp, ci, v)
+            assert A.status == 0, pkg.STATUS[A.status]
+            st = L.aoclsparse_set_mm_hint(A.h, pkg.OP_NONE, self.descr.h, 100)
+            assert st == 0, pkg.STATUS[st]
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            st = L.aoclsparse_optimize(A.h)
+            assert st == 0, pkg.STATUS[st]
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            self.optimize_ms = (time.perf_counter() - t0) * 1e3
+        # ... and its device format travels: the other ranks adopt it and analyse nothing
+        self.A, self.a_broadcast_ms, self.a_broadcast_how = broadcast_handle(pkg, torch, dist, device, rank, world, A)
+        self.m, self.n, self.nnz = self.A.m, self.A.n, self.A.nnz
         self.j0, self.j1 = pkg.column_shard(ncols, world, rank)
         self.nloc = self.j1 - self.j0
 
@@ -158,14 +266,28 @@ class ShardedCsrmm:
         C = C[: self.nloc * self.m]  # a rank that owns no columns (more ranks than 4-column blocks) holds a dummy buffer
         cols = C.reshape(self.nloc, self.m) if self.layout == "col" else C.reshape(self.m, self.nloc).t().contiguous()
         shards = [self.pkg.column_shard(self.ncols, self.world, r) for r in range(self.world)]
-        return gather_slabs(self.torch, self.dist, self.device, self.rank, shards, cols)
+        return gather_slabs(self.torch, self.dist, self.device, self.rank, shards, cols, pkg=self.pkg)
 
 
-def gather_slabs(torch, dist, device, rank, shards, cols):
-    """cols: this rank's slab as a (width, m) tensor; shards: [(j0, j1)] of every rank -> ((ncols, m) tensor, ms)."""
+def gather_slabs(torch, dist, device, rank, shards, cols, pkg=None):
+    """cols: this rank's slab as a (width, m) tensor; shards: [(j0, j1)] of every rank -> ((ncols, m) tensor, ms).
+    Equal slabs of an "nccl" job whose library communicator is up (library_communicator) go through
+    aoclsparse_mi355_comm_allgather (ncclAllGather on the library's stream: the slabs land in place, in rank order);
+    everything else through torch.distributed."""
     if dist is None or not dist.is_initialized() or len(shards) == 1:
         return cols, 0.0
     m = cols.shape[1]
+    if pkg is not None and _LIB_COMM["ok"] and len({b - a for a, b in shards}) == 1 and cols.is_cuda:
+        send = cols.contiguous()
+        full = torch.empty((len(shards) * send.shape[0], m), dtype=cols.dtype, device=device)
+        barrier(dist, torch)
+        t0 = time.perf_counter()
+        st = pkg.lib().aoclsparse_mi355_comm_allgather(send.data_ptr(), full.data_ptr(), send.numel() * send.element_size())
+        pkg.lib().aoclsparse_mi355_synchronize()
+        ms = (time.perf_counter() - t0) * 1e3
+        if reduce_scalar(1.0 if st == 0 else 0.0, "min", dist, device) > 0.5:
+            return full, ms
+        # (a failed collective on some rank: fall through to torch.distributed on every rank)
     wire = "cpu" if _backend(dist) == "gloo" else device
     parts = [torch.empty((b - a, m), dtype=cols.dtype, device=wire) for a, b in shards]
     barrier(dist, torch)
@@ -237,8 +359,9 @@ def bench_sharded_csrmm(pkg, torch, dist, device, rank, world, csr, ncols, layou
         "layout": "column-major" if layout == "col" else "row-major", "ncols": ncols, "world": world,
         "cols_per_rank": sh.nloc, "m": m, "nnz": nnz, "c_is_read": bool(c_is_read),
         "shard_ms": st_shard, "tg_ms_device_median_max_over_ranks": round(tg_dev, 5),
-        "tg_ms_wall_max_over_ranks": round(tg_wall, 5), "a_broadcast_ms": round(sh.a_broadcast_ms, 3),
-        "setup_optimize_ms_max_over_ranks": round(reduce_scalar(sh.optimize_ms, "max", dist, device), 3),
+        "tg_ms_wall_max_over_ranks": round(tg_wall, 5),
+        "a_broadcast_ms": round(reduce_scalar(sh.a_broadcast_ms, "max", dist, device), 3), "a_broadcast_how": sh.a_broadcast_how,
+        "setup_optimize_ms_rank0": round(reduce_scalar(sh.optimize_ms, "max", dist, device), 3),
         "checksum": checksum,
     }
     job_bytes = csrmm_bytes(m, sh.n, nnz, ncols, c_is_read) + (world - 1) * ((m + 1 + nnz) * 4 + nnz * 8)

@@ -12,6 +12,8 @@
 
 #include "aoclsparse.h"
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -109,6 +111,54 @@ DLL_PUBLIC aoclsparse_int aoclsparse_mi355_replica_count(const aoclsparse_matrix
 /* ... of which built by copying the primary handle's device format device to device (peer copy over xGMI) instead of analysing
  * the host arrays again: the case when the handle was optimized (or used) before its first multi-device call; -1 for NULL */
 DLL_PUBLIC aoclsparse_int aoclsparse_mi355_replicas_cloned(const aoclsparse_matrix A);
+
+/* ---- one process per GPU: shipping the ANALYSED device state of a handle (round 4) ----------------------------------------
+ * The column shards of csrmm need A on every rank.  What travels is the device format: the CSR arrays in HBM and every csrmm
+ * plan (row blocks, row groups, row runs, column windows, row pairs, the blocked-ELL copy), so that the receiving ranks do no
+ * analysis (the reference has nothing to ship: its column split is a thread split inside one call,
+ * library/src/level3/aoclsparse_csrmm_kt.cpp:68-82, and A is shared memory).
+ *   export  builds every csrmm plan of A that is still missing, then fills `state` (sizes + scalars, a POD that can be sent as
+ *           bytes) and buffers[i] = device pointer of buffer i (owned by A, valid until A is modified or destroyed; NULL where
+ *           state->bytes[i] == 0).
+ *   adopt   creates a NEW handle (*R, to be destroyed by the caller) from `state` and device copies of the buffers that the caller
+ *           has placed in THIS process's device memory (received over whatever wire it uses): the buffers are copied device to
+ *           device, the CSR arrays are copied back once to give the handle its host view, no analysis runs.  Every
+ *           aoclsparse_* call works on the new handle; it carries an optimized mm hint. */
+#define AOCLSPARSE_MI355_MM_STATE_BUFFERS 12
+#define AOCLSPARSE_MI355_MM_STATE_SCALARS 40
+typedef struct aoclsparse_mi355_mm_state_
+{
+    long long scalars[AOCLSPARSE_MI355_MM_STATE_SCALARS];
+    long long bytes[AOCLSPARSE_MI355_MM_STATE_BUFFERS];
+} aoclsparse_mi355_mm_state;
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_mm_state_export(aoclsparse_matrix A, aoclsparse_mi355_mm_state *state,
+                                                              const void *buffers[AOCLSPARSE_MI355_MM_STATE_BUFFERS]);
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_mm_state_adopt(aoclsparse_matrix *R, const aoclsparse_mi355_mm_state *state,
+                                                             const void *const buffers[AOCLSPARSE_MI355_MM_STATE_BUFFERS]);
+
+/* ---- the same over a communicator the LIBRARY owns: RCCL (librccl.so, loaded with dlopen at the first call) ---------------
+ * One communicator per process, on the library's device.  Rank 0 calls comm_unique_id and hands the 128 bytes to the other
+ * ranks by any means (MPI, a file, torch.distributed's store); every rank then calls comm_init -- a collective, like all calls
+ * below.  Collectives are enqueued on the library's stream (aoclsparse_mi355_get_stream) and must be issued by one thread at a
+ * time, in the same order on every rank.
+ *   comm_broadcast_matrix  rank `root` passes its handle, every other rank passes *A == NULL and receives a new handle (to be
+ *                          destroyed by the caller) holding root's device CSR and csrmm plans: ncclBroadcast of a header, then
+ *                          one grouped ncclBroadcast per buffer straight into the new handle's device buffers.
+ *   comm_allgather         bytes_per_rank bytes from `send` of every rank, concatenated in rank order in `recv` (column-major C
+ *                          slabs of equal width: the whole C, in place when send == recv + rank * bytes_per_rank).
+ *   comm_broadcast         a device buffer from `root` to everyone.
+ * status not_implemented: librccl.so could not be loaded; invalid_operation: no communicator (or a second comm_init). */
+typedef struct aoclsparse_mi355_comm_id_
+{
+    char internal[128];
+} aoclsparse_mi355_comm_id;
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_comm_unique_id(aoclsparse_mi355_comm_id *id);
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_comm_init(aoclsparse_int world, aoclsparse_int rank, const aoclsparse_mi355_comm_id *id);
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_comm_destroy(void);
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_comm_info(aoclsparse_int *world, aoclsparse_int *rank, aoclsparse_int *rccl_version);
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_comm_broadcast(void *device_buffer, size_t bytes, aoclsparse_int root);
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_comm_allgather(const void *send, void *recv, size_t bytes_per_rank);
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_comm_broadcast_matrix(aoclsparse_matrix *A, aoclsparse_int root);
 
 /* ---- introspection of a handle --------------------------------------------------------- */
 /* idiag / iurow of the clean CSR (host arrays owned by the handle, length m, matrix base);

@@ -324,3 +324,105 @@ def test_csrmm_blocked_ell_is_not_chosen_below_half_fill_or_for_unsorted_rows():
     Bc = np.ascontiguousarray(B.reshape(m, n).T).ravel()
     so, Cr = oracle.dcsrmm("col", 1.0, 0, v2, ci2, rp, m, Bc, n, m, 0.0, np.zeros(m * n), m)
     assert np.array_equal(Cd.cpu().numpy().reshape(m, n), Cr.reshape(n, m).T)
+
+
+# --------------------------------------------------------------------------------------------------
+# the analysed device state of a handle travels; the library's own RCCL communicator
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("which", ["laplace", "block_dense", "random"])
+def test_mm_state_export_adopt_round_trip(which):
+    """aoclsparse_mi355_mm_state_export -> device copies of the buffers -> aoclsparse_mi355_mm_state_adopt: the new handle has
+    done no analysis, yet every csrmm (both layouts, wide and narrow) gives the exporter's bits, its plans are the exporter's
+    (window kernel / blocked-ELL copy / row groups), and the rest of the API works on it (export, ?mv, a second export)."""
+    if which == "laplace":
+        m, rp, ci, v = laplace5(140)
+    elif which == "block_dense":
+        m, rp, ci, v = standins.block_dense(5, 4, 4, seed=3)
+    else:
+        m = 5000
+        rp, ci, v = random_csr(77, m, m, lambda r, i: r.integers(0, 14))
+    A = P.Matrix(0, m, m, rp, ci, v)
+    d = P.Descr()
+    assert L.aoclsparse_set_mm_hint(A.h, P.OP_NONE, d.h, 10) == 0 and L.aoclsparse_optimize(A.h) == 0
+    st, state, ptrs = A.mm_state_export()
+    assert st == 0 and list(state.bytes)[:3] == [4 * (m + 1), 4 * len(v), 8 * len(v)]
+    # what a receiving rank holds: its OWN device copies of the buffers (here: clones made through torch)
+    from aocl_sparse_amd.sharded import _DeviceView
+    held = [torch.as_tensor(_DeviceView(p, n), device="cuda").clone() if n else None for p, n in zip(ptrs, list(state.bytes))]
+    torch.cuda.synchronize()
+    st, R = P.Matrix.mm_state_adopt(state, [t.data_ptr() if t is not None else None for t in held])
+    assert st == 0 and (R.m, R.n, R.nnz, R.base) == (m, m, len(v), 0)
+    del held
+    ia, ir = A.spmv_info(), R.spmv_info()
+    for f in ("row_blocks", "tile", "max_row_nnz", "mm_groups", "mm_window_rows", "mm_bell_width", "mm_bell_fill_permille"):
+        assert getattr(ia, f) == getattr(ir, f), f
+    if which == "laplace":
+        assert ir.mm_window_rows == 4096
+    if which == "block_dense":
+        assert ir.mm_bell_width == 7
+    e = R.export()
+    assert e["status"] == 0 and np.array_equal(e["row_ptr"], rp) and np.array_equal(e["col_ind"], ci) and np.array_equal(e["val"], v)
+    rng = np.random.default_rng(5)
+    for order, n in ((P.ORDER_COLUMN, 24), (P.ORDER_ROW, 160), (P.ORDER_ROW, 32), (P.ORDER_COLUMN, 6)):
+        ld = m if order == P.ORDER_COLUMN else n
+        B, C0 = rng.uniform(-1, 1, m * n), rng.uniform(-1, 1, m * n)
+        Ca, Cr = dev(C0), dev(C0)
+        assert P.dcsrmm(P.OP_NONE, 1.25, A, d, order, dev(B), n, ld, -0.5, Ca, ld) == 0
+        assert P.dcsrmm(P.OP_NONE, 1.25, R, d, order, dev(B), n, ld, -0.5, Cr, ld) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(Ca, Cr), (which, order, n)
+    x = rng.uniform(-1, 1, m)
+    ya, yr = np.zeros(m), np.zeros(m)
+    assert P.dmv(P.OP_NONE, 1.0, A, d, x, 0.0, ya) == 0 and P.dmv(P.OP_NONE, 1.0, R, d, x, 0.0, yr) == 0
+    assert np.array_equal(ya, yr)
+    st2, state2, _ = R.mm_state_export()
+    assert st2 == 0 and list(state2.bytes) == list(state.bytes) and list(state2.scalars) == list(state.scalars)
+    # a corrupted header is refused
+    bad = P.MmState()
+    ctypes_copy = bytes(state)
+    import ctypes
+    ctypes.memmove(ctypes.addressof(bad), ctypes_copy, len(ctypes_copy))
+    bad.scalars[0] = 1
+    st, none = P.Matrix.mm_state_adopt(bad, [None] * 12)
+    assert st != 0 and none is None
+
+
+def test_library_rccl_communicator_one_rank():
+    """aoclsparse_mi355_comm_*: librccl.so is loaded with dlopen, a communicator of ONE rank is created on the library's device
+    (all a one-GPU box can do: RCCL refuses two ranks on one GPU), and every collective the multi-GPU job uses runs through it --
+    ncclBroadcast of a handle's analysed state (root side), ncclAllGather, ncclBroadcast of a buffer.  In a child process: the
+    communicator is process-wide."""
+    code = textwrap.dedent("""
+        import sys, ctypes, numpy as np, torch
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        from util import pkg, laplace5
+        P = pkg(); L = P.lib()
+        assert L.aoclsparse_mi355_comm_info(None, None, None) != 0          # no communicator yet
+        assert L.aoclsparse_mi355_comm_allgather(None, None, 0) != 0
+        cid = P.CommId()
+        assert L.aoclsparse_mi355_comm_unique_id(cid) == 0
+        assert L.aoclsparse_mi355_comm_init(1, 0, cid) == 0
+        assert L.aoclsparse_mi355_comm_init(1, 0, cid) != 0                 # one communicator per process
+        w, r, ver = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        assert L.aoclsparse_mi355_comm_info(w, r, ver) == 0 and (w.value, r.value) == (1, 0) and ver.value > 20000
+        m, rp, ci, v = laplace5(130)
+        A = P.Matrix(0, m, m, rp, ci, v); d = P.Descr()
+        assert L.aoclsparse_set_mm_hint(A.h, P.OP_NONE, d.h, 10) == 0 and L.aoclsparse_optimize(A.h) == 0
+        h = ctypes.c_void_p(A.h.value)
+        assert L.aoclsparse_mi355_comm_broadcast_matrix(ctypes.byref(h), 0) == 0 and h.value == A.h.value
+        none = ctypes.c_void_p()
+        assert L.aoclsparse_mi355_comm_broadcast_matrix(ctypes.byref(none), 0) != 0   # the root must pass its handle
+        assert L.aoclsparse_mi355_comm_broadcast_matrix(ctypes.byref(h), 1) != 0      # no such rank
+        src = torch.arange(4096, dtype=torch.float64, device="cuda"); dst = torch.zeros_like(src)
+        assert L.aoclsparse_mi355_comm_allgather(src.data_ptr(), dst.data_ptr(), src.numel() * 8) == 0
+        assert L.aoclsparse_mi355_comm_broadcast(src.data_ptr(), src.numel() * 8, 0) == 0
+        assert L.aoclsparse_mi355_synchronize() == 0 and torch.equal(src, dst)
+        # the handle still works after having been the root of a broadcast
+        n = 8; B = np.ones(m * n); C = np.zeros(m * n)
+        assert P.dcsrmm(P.OP_NONE, 1.0, A, d, P.ORDER_COLUMN, B, n, m, 0.0, C, m) == 0
+        assert L.aoclsparse_mi355_comm_destroy() == 0 and L.aoclsparse_mi355_comm_info(None, None, None) != 0
+        print("rccl", ver.value)
+    """) % (HERE, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "rccl" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
