@@ -26,6 +26,7 @@ ORDER_ROW, ORDER_COLUMN = 0, 1
 STAGE_NNZ_COUNT, STAGE_FINALIZE, STAGE_FULL = 0, 1, 2
 MEM_MINIMAL, MEM_UNRESTRICTED = 0, 1
 PTR_AUTO, PTR_HOST, PTR_DEVICE = 0, 1, 2
+OPTION_SPMV_KERNEL, OPTION_SELL = 0, 1  # aoclsparse_mi355_set_option
 
 STATUS = {
     0: "success", 1: "not_implemented", 2: "invalid_pointer", 3: "invalid_size", 4: "internal_error",
@@ -353,6 +354,7 @@ SIGNATURES = {
     "aoclsparse_mi355_column_shard": (c_int, [_I, _I, _I, POINTER(_I), POINTER(_I)]),
     "aoclsparse_mi355_dcsrmm_shard": (c_int, [c_int, c_double, _P, _P, c_int, _P, _I, _I, c_double, _P, _I, _I, _I]),
     "aoclsparse_mi355_dcsrmm_multi": (c_int, [c_int, c_double, _P, _P, c_int, _P, _I, _I, c_double, _P, _I, _I, _P]),
+    "aoclsparse_mi355_set_option": (c_int, [c_int, _I]),
     "aoclsparse_mi355_mm_state_export": (c_int, [_P, POINTER(MmState), _P]),
     "aoclsparse_mi355_mm_state_adopt": (c_int, [_P, POINTER(MmState), _P]),
     "aoclsparse_mi355_comm_unique_id": (c_int, [POINTER(CommId)]),

@@ -62,11 +62,7 @@ aoclsparse_status build_mm_groups(const HostCsr &h, SpmvPlan &plan)
     if(g.valid || g.tried)
         return aoclsparse_status_success;
     g.tried = true;
-    static const bool off = [] {
-        const char *e = getenv("AOCLSPARSE_MI355_CSRMM_GROUPS");
-        return e && atoi(e) == 0;
-    }();
-    if(off || h.m < 2)
+    if(h.m < 2)
         return aoclsparse_status_success;
     std::vector<aoclsparse_int> first;
     int                         max_rows = 1;
@@ -114,11 +110,7 @@ aoclsparse_status detect_row_runs(const HostCsr &h, SpmvPlan &plan)
     if(g.runs_tried)
         return aoclsparse_status_success;
     g.runs_tried = true;
-    static const bool off = [] {
-        const char *e = getenv("AOCLSPARSE_MI355_CSRMM_RUNS");
-        return e && atoi(e) == 0;
-    }();
-    if(off || h.m < 64)
+    if(h.m < 64)
         return aoclsparse_status_success;
     long long      followers = 0;
     aoclsparse_int longest = 0;
@@ -135,11 +127,7 @@ aoclsparse_status detect_row_runs(const HostCsr &h, SpmvPlan &plan)
     }
     g.row_runs = followers * 2 >= (long long)h.m && longest <= 64;
     g.band     = 0;
-    static const bool strips_off = [] {
-        const char *e = getenv("AOCLSPARSE_MI355_CSRMM_STRIPS");
-        return e && atoi(e) == 0;
-    }();
-    if(!g.row_runs || strips_off)
+    if(!g.row_runs)
         return aoclsparse_status_success;
     // the band: the distance from the diagonal to a row's last entry that most rows share (majority vote, then a count)
     aoclsparse_int cand = 0;
@@ -421,11 +409,7 @@ aoclsparse_status detect_pairs(const HostCsr &h, SpmvPlan &plan)
     if(g.pairs_tried)
         return aoclsparse_status_success;
     g.pairs_tried = true;
-    static const bool off = [] {
-        const char *e = getenv("AOCLSPARSE_MI355_CSRMM_PAIRS");
-        return e && atoi(e) == 0;
-    }();
-    if(off || h.m < 2)
+    if(h.m < 2)
         return aoclsparse_status_success;
     std::vector<aoclsparse_int> pf, sg;
     try

@@ -1480,11 +1480,7 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
 template <typename T>
 bool csrmm_groups_ccol_applies(aoclsparse_int n, aoclsparse_int ldb, const T *B)
 {
-    static const bool off = [] {
-        const char *e = getenv("AOCLSPARSE_MI355_CSRMM_CCOL");
-        return e && atoi(e) == 0;
-    }();
-    return !off && n >= 32 && n % 2 == 0 && ldb % 2 == 0 && reinterpret_cast<uintptr_t>(B) % (2 * sizeof(T)) == 0;
+    return n >= 32 && n % 2 == 0 && ldb % 2 == 0 && reinterpret_cast<uintptr_t>(B) % (2 * sizeof(T)) == 0;
 }
 
 template <typename T>
@@ -1583,11 +1579,7 @@ aoclsparse_status launch_relayout(hipStream_t s, bool to_row_major, const T *src
 template <typename T>
 bool csrmm_tiled_applies(aoclsparse_int n, aoclsparse_int ldb, aoclsparse_int ldc, const T *B, const T *C)
 {
-    static const bool off = [] {
-        const char *e = getenv("AOCLSPARSE_MI355_CSRMM_TILED");
-        return e && atoi(e) == 0;
-    }();
-    return !off && n >= 2 && n < 128 && (n % 2 == 0) && (ldb % 2 == 0) && (ldc % 2 == 0)
+    return n >= 2 && n < 128 && (n % 2 == 0) && (ldb % 2 == 0) && (ldc % 2 == 0)
            && (reinterpret_cast<uintptr_t>(B) % (2 * sizeof(T)) == 0) && (reinterpret_cast<uintptr_t>(C) % (2 * sizeof(T)) == 0);
 }
 

@@ -788,6 +788,8 @@ aoclsparse_status launch_lincomb(hipStream_t s, int sign, aoclsparse_int n, int 
 // propagate); true = C is overwritten without being read (BLAS semantics, a third less traffic at 256 columns).  One word for the
 // process (aoclsparse_mi355_set_csrmm_beta0_overwrite; AOCLSPARSE_MI355_CSRMM_BETA0_OVERWRITE seeds it once, on first touch).
 std::atomic<bool> &csrmm_beta0_overwrite_flag();
+// process-wide plan options (aoclsparse_mi355_set_option; read when a plan is built): tests and measurements only
+int plan_option(aoclsparse_mi355_option option);
 // does a csrmm kernel read C?  always for beta != 0; for beta == 0 unless the overwrite mode is on
 bool csrmm_reads_c(bool beta_nonzero);
 // timeout_word: where a sync-free kernel reports an expired wait (pinned host memory, Runtime::trsv_timeout_dev).

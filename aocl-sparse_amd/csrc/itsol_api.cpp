@@ -61,14 +61,14 @@ enum cg_task
 };
 enum gmres_task
 {
-    task_gmres_start = 0,
-    task_gmres_init_res,
-    task_gmres_init_precond,
-    task_gmres_start_iter,
-    task_gmres_end_iter,
-    task_gmres_x_update,
-    task_gmres_restart_cycle,
-    task_gmres_convergence_check
+    GM_ENTRY = 0,
+    GM_RESIDUAL,
+    GM_PRECOND_R0,
+    GM_ARNOLDI_STEP,
+    GM_AFTER_PRECOND,
+    GM_UPDATE_X,
+    GM_RESTART,
+    GM_CHECK
 };
 
 // ---- options (include/aoclsparse_itsol_options.hpp; names / bounds / defaults: list_options.hpp:92-237) ----
@@ -373,7 +373,7 @@ struct Solver
                 MI355_TRY(coef.alloc(sizeof(T) * (size_t)(m + 1), false));
                 niter = 0, j = 0;
             }
-            task    = task_gmres_start;
+            task    = GM_ENTRY;
             precond = opts.reg["gmres preconditioner"].key;
             rtol    = (T)opts.reg["gmres rel tolerance"].rval;
             atol    = (T)opts.reg["gmres abs tolerance"].rval;
@@ -523,7 +523,7 @@ struct Solver
         const aoclsparse_int m           = restart;
         const long long      ld          = n;
         T                   *V = v.as<T>(), *Z = zz.as<T>();
-        if(task != task_gmres_start && *ircomm == aoclsparse_rci_interrupt)
+        if(task != GM_ENTRY && *ircomm == aoclsparse_rci_interrupt)
         {
             *ircomm = aoclsparse_rci_stop;
             return aoclsparse_status_user_stop;
@@ -534,12 +534,12 @@ struct Solver
             loop = false;
             switch(task)
             {
-            case task_gmres_start:
+            case GM_ENTRY:
                 *io1 = x, *io2 = V;
                 *ircomm = aoclsparse_rci_mv;
-                task    = task_gmres_init_res;
+                task    = GM_RESIDUAL;
                 break;
-            case task_gmres_init_res:
+            case GM_RESIDUAL:
             {
                 MI355_TRY(nrm2(rt, b.as<T>(), bnorm2));
                 if(std::isnan(bnorm2))
@@ -566,7 +566,7 @@ struct Solver
                     break;
                 }
                 MI355_TRY(launch_scale<T>(st, V, n, T(1) / rnorm2));
-                task = task_gmres_init_precond;
+                task = GM_PRECOND_R0;
                 if(!precond)
                     loop = true;
                 else
@@ -576,14 +576,14 @@ struct Solver
                 }
                 break;
             }
-            case task_gmres_init_precond:
-            case task_gmres_end_iter:
+            case GM_PRECOND_R0:
+            case GM_AFTER_PRECOND:
                 *io1    = (precond ? Z : V) + (long long)j * ld;
                 *io2    = V + (long long)(j + 1) * ld;
                 *ircomm = aoclsparse_rci_mv;
-                task    = task_gmres_start_iter;
+                task    = GM_ARNOLDI_STEP;
                 break;
-            case task_gmres_start_iter:
+            case GM_ARNOLDI_STEP:
             {
                 T *w = V + (long long)(j + 1) * ld;
                 // classical Gram-Schmidt: all h(i,j) from the unmodified w, then one update (:1087-1113)
@@ -623,11 +623,11 @@ struct Solver
                 j++;
                 if(j >= m)
                 {
-                    task = task_gmres_x_update;
+                    task = GM_UPDATE_X;
                     loop = true;
                     break;
                 }
-                task = task_gmres_end_iter;
+                task = GM_AFTER_PRECOND;
                 if(!precond)
                     loop = true;
                 else
@@ -637,7 +637,7 @@ struct Solver
                 }
                 break;
             }
-            case task_gmres_x_update:
+            case GM_UPDATE_X:
             {
                 // back substitution with the rotated Hessenberg matrix (:885-908); the result shares the
                 // array of the rotation sines, as in the reference
@@ -669,15 +669,15 @@ struct Solver
                 if(j >= m)
                     j = 0;
                 *ircomm = aoclsparse_rci_stopping_criterion;
-                task    = (below_abs || below_rel || at_max) ? task_gmres_convergence_check : task_gmres_restart_cycle;
+                task    = (below_abs || below_rel || at_max) ? GM_CHECK : GM_RESTART;
                 break;
             }
-            case task_gmres_restart_cycle:
+            case GM_RESTART:
                 *io1 = x, *io2 = V;
                 *ircomm = aoclsparse_rci_mv;
-                task    = task_gmres_init_res;
+                task    = GM_RESIDUAL;
                 break;
-            case task_gmres_convergence_check:
+            case GM_CHECK:
                 if((T(0) < atol && rnorm2 <= atol) || (T(0) < rnorm2 && rnorm2 <= brtol))
                     *ircomm = aoclsparse_rci_stop;
                 else if(maxit > 0 && niter >= maxit)
@@ -1113,7 +1113,7 @@ struct CSolver
                 }
                 niter = 0, j = 0;
             }
-            task    = task_gmres_start;
+            task    = GM_ENTRY;
             precond = opts.reg["gmres preconditioner"].key;
             rtol = (R)opts.reg["gmres rel tolerance"].rval, atol = (R)opts.reg["gmres abs tolerance"].rval;
             maxit = (aoclsparse_int)opts.reg["gmres iteration limit"].ival;
@@ -1240,7 +1240,7 @@ struct CSolver
         const aoclsparse_int m           = restart;
         const long long      ld          = n;
         C                   *V = v.as<C>(), *Z = zz.as<C>();
-        if(task != task_gmres_start && *ircomm == aoclsparse_rci_interrupt)
+        if(task != GM_ENTRY && *ircomm == aoclsparse_rci_interrupt)
         {
             *ircomm = aoclsparse_rci_stop;
             return aoclsparse_status_user_stop;
@@ -1251,11 +1251,11 @@ struct CSolver
             loop = false;
             switch(task)
             {
-            case task_gmres_start:
+            case GM_ENTRY:
                 *io1 = x, *io2 = V;
-                *ircomm = aoclsparse_rci_mv, task = task_gmres_init_res;
+                *ircomm = aoclsparse_rci_mv, task = GM_RESIDUAL;
                 break;
-            case task_gmres_init_res:
+            case GM_RESIDUAL:
             {
                 MI355_TRY(nrm2(rt, b.as<C>(), bnorm2));
                 if(std::isnan(bnorm2))
@@ -1278,7 +1278,7 @@ struct CSolver
                     break;
                 }
                 MI355_TRY(axpby(rt, Cs(R(1) / rnorm2), V, Cs(0), nullptr, V));
-                task = task_gmres_init_precond;
+                task = GM_PRECOND_R0;
                 if(!precond)
                     loop = true;
                 else
@@ -1288,12 +1288,12 @@ struct CSolver
                 }
                 break;
             }
-            case task_gmres_init_precond:
-            case task_gmres_end_iter:
+            case GM_PRECOND_R0:
+            case GM_AFTER_PRECOND:
                 *io1 = (precond ? Z : V) + (long long)j * ld, *io2 = V + (long long)(j + 1) * ld;
-                *ircomm = aoclsparse_rci_mv, task = task_gmres_start_iter;
+                *ircomm = aoclsparse_rci_mv, task = GM_ARNOLDI_STEP;
                 break;
-            case task_gmres_start_iter:
+            case GM_ARNOLDI_STEP:
             {
                 C *w = V + (long long)(j + 1) * ld;
                 for(aoclsparse_int i = 0; i <= j; i++) // all h(i,j) = v_i^H w from the unmodified w, then the update
@@ -1325,10 +1325,10 @@ struct CSolver
                 j++;
                 if(j >= m)
                 {
-                    task = task_gmres_x_update, loop = true;
+                    task = GM_UPDATE_X, loop = true;
                     break;
                 }
-                task = task_gmres_end_iter;
+                task = GM_AFTER_PRECOND;
                 if(!precond)
                     loop = true;
                 else
@@ -1338,7 +1338,7 @@ struct CSolver
                 }
                 break;
             }
-            case task_gmres_x_update:
+            case GM_UPDATE_X:
             {
                 for(aoclsparse_int jj = j - 1; jj >= 0; jj--)
                 {
@@ -1366,14 +1366,14 @@ struct CSolver
                 if(j >= m)
                     j = 0;
                 *ircomm = aoclsparse_rci_stopping_criterion;
-                task    = (below_abs || below_rel || at_max) ? task_gmres_convergence_check : task_gmres_restart_cycle;
+                task    = (below_abs || below_rel || at_max) ? GM_CHECK : GM_RESTART;
                 break;
             }
-            case task_gmres_restart_cycle:
+            case GM_RESTART:
                 *io1 = x, *io2 = V;
-                *ircomm = aoclsparse_rci_mv, task = task_gmres_init_res;
+                *ircomm = aoclsparse_rci_mv, task = GM_RESIDUAL;
                 break;
-            case task_gmres_convergence_check:
+            case GM_CHECK:
                 if((R(0) < atol && rnorm2 <= atol) || (R(0) < rnorm2 && rnorm2 <= brtol))
                     *ircomm = aoclsparse_rci_stop;
                 else if(maxit > 0 && niter >= maxit)

@@ -485,15 +485,10 @@ static aoclsparse_int choose_tile(aoclsparse_int /*m*/, aoclsparse_int nnz)
     // load -> gather -> reduce latency chain better than 4 fatter ones (0.257 vs 0.290 ms on the 4096^2
     // Laplacian).  A matrix too small to give every CU ~16 such blocks gets 512-entry tiles and 128-lane
     // workgroups instead (web-like stand-in: 0.039 vs 0.056 ms).  profiles/r1, DESIGN.md 5.1.
-    // tuning knobs (read when a plan is built): AOCLSPARSE_MI355_SPMV_TILE=512|1024|2048,
-    // AOCLSPARSE_MI355_XCD_ORDER=1 enables the XCD-contiguous block order (encoded as tile|1;
-    // measured slower than the plain order on the Laplacian, so off by default)
-    const char *e      = std::getenv("AOCLSPARSE_MI355_SPMV_TILE");
-    const int   forced = e ? std::atoi(e) : 0;
-    const char *x      = std::getenv("AOCLSPARSE_MI355_XCD_ORDER");
-    const int   xcd    = (x && std::atoi(x) != 0) ? 1 : 0;
-    const int   automatic = (long long)nnz < 1024LL * 256 * 16 ? 512 : 1024;
-    return (forced == 2048 || forced == 1024 || forced == 512 ? forced : automatic) | xcd;
+    // (the XCD-contiguous block order -- bit 0 of the tile word, which the kernel still decodes -- measured slower than launch
+    // order on the Laplacian and 6 % faster at most on the graph stand-ins: profiles/r3/irregular_locality_pmc.txt; the round 1-3
+    // switches that forced a tile size or that order are gone, the losing sides are recorded under profiles/)
+    return (long long)nnz < 1024LL * 256 * 16 ? 512 : 1024;
 }
 
 // plan_rows on the row range [r0, r1): block entries are appended to `out` (no terminal entry)
@@ -572,8 +567,7 @@ aoclsparse_status build_spmv_plan(aoclsparse_int m, aoclsparse_int nnz, aoclspar
         // over 2.5-4.5 us (circuit-like: 1,900 of them), and a heavy block started last is the kernel's tail
         // (tools/spmv_trace.py).  Same blocks, same rows, same chains: only the workgroup that takes them changes.
         plan.heavy_first = false;
-        static const bool hf_off = [] { const char *e = std::getenv("AOCLSPARSE_MI355_SPMV_HEAVY_FIRST"); return e && std::atoi(e) == 0; }();
-        if(!hf_off && plan.nblocks >= 512 && plan.max_row_nnz >= 64)
+        if(plan.nblocks >= 512 && plan.max_row_nnz >= 64)
         {
             const aoclsparse_int        nb = plan.nblocks;
             std::vector<aoclsparse_int> weight((size_t)nb), order((size_t)nb);
@@ -626,10 +620,7 @@ aoclsparse_status build_sell(const aoclsparse_int *row_ptr_host, const DeviceCsr
     if(sp.valid || sp.tried)
         return aoclsparse_status_success;
     sp.tried = true;
-    static const int mode = [] {
-        const char *e = getenv("AOCLSPARSE_MI355_SELL");
-        return e ? atoi(e) : -1;
-    }();
+    const int mode = plan_option(aoclsparse_mi355_option_sell); // -1 automatic (default), 0 never, 1 whatever the padding
     if(mode == 0 || d.m <= 0 || d.nnz <= 0 || !d.valid)
         return aoclsparse_status_success;
     const aoclsparse_int   m = d.m, nslices = (m + 63) / 64;
@@ -665,16 +656,12 @@ aoclsparse_status build_sell(const aoclsparse_int *row_ptr_host, const DeviceCsr
     aoclsparse_status st = sp.slice_ptr.upload(sptr.data(), sizeof(long long) * sptr.size(), rt.stream());
     // Shared column lists: rows that repeat the list of the row before them -- as it is (the dofs of a mesh node) or
     // shifted by one (the rows of a stencil) -- keep ONE copy per slice.  Leaders are found on the device (one compare
-    // pass over the CSR arrays); used when the column stream shrinks to <= 70 %.  AOCLSPARSE_MI355_SELL_SHARED=0 disables.
-    static const bool shared_off = [] {
-        const char *e = getenv("AOCLSPARSE_MI355_SELL_SHARED");
-        return e && atoi(e) == 0;
-    }();
+    // pass over the CSR arrays); used when the column stream shrinks to <= 70 %.
     sp.shared = false, sp.ccells = cells;
     std::vector<long long> cptr;
     // (not for matrices that live in the caches anyway: the leader / shift words are one more dependent load, and the 10k x 10k
     // Laplacian of BASELINE configs[0] -- 50 k non-zeros, launch-bound -- ran at 5.4 instead of 4.6 us per call with them)
-    if(st == aoclsparse_status_success && !shared_off && d.nnz >= (1 << 17))
+    if(st == aoclsparse_status_success && d.nnz >= (1 << 17))
     {
         DeviceBuffer nl;
         st = sp.lead.alloc(sizeof(unsigned short) * (size_t)m);
@@ -735,10 +722,7 @@ constexpr int MERGE_AUTO_TILES = 32; // auto: merge-path once the longest row sp
 // (read at plan-build time, i.e. once per handle and operator)
 static int spmv_kernel_choice()
 {
-    const char *e = getenv("AOCLSPARSE_MI355_SPMV_KERNEL");
-    if(!e)
-        return 0;
-    return !strcmp(e, "merge") ? 2 : (!strcmp(e, "adaptive") ? 1 : 0);
+    return plan_option(aoclsparse_mi355_option_spmv_kernel);
 }
 
 aoclsparse_status build_merge_plan(aoclsparse_int m, aoclsparse_int nnz, aoclsparse_index_base base,
@@ -756,12 +740,8 @@ aoclsparse_status build_merge_plan(aoclsparse_int m, aoclsparse_int nnz, aoclspa
     // fine for rows of a few tiles (web-like: longest row 2,908 = 6 tiles; merge-path loses there, 44.2 vs 29.5 us,
     // and on circuit-like, 14.3 vs 11.4 us), a serial tail once a row spans tens of tiles.  Merge-path cuts such rows
     // into 1,024-item pieces spread over the chip, so it is selected when the longest row exceeds
-    // MERGE_AUTO_TILES tiles (tools/exp_arrow.py, profiles/r2/merge_vs_adaptive.jsonl; AOCLSPARSE_MI355_MERGE_AUTO
-    // overrides the factor, 0 disables).
-    static const int auto_tiles = [] {
-        const char *e = getenv("AOCLSPARSE_MI355_MERGE_AUTO");
-        return e ? atoi(e) : MERGE_AUTO_TILES;
-    }();
+    // MERGE_AUTO_TILES tiles (tools/exp_arrow.py, profiles/r2/merge_vs_adaptive.jsonl).
+    constexpr int auto_tiles = MERGE_AUTO_TILES;
     const bool auto_pick = choice == 0 && auto_tiles > 0 && plan.long_rows > 0
                            && (long long)plan.max_row_nnz >= (long long)auto_tiles * (plan.tile & ~1);
     if(choice != 2 && !auto_pick)

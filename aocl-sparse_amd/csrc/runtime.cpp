@@ -265,6 +265,15 @@ std::atomic<bool> &csrmm_beta0_overwrite_flag()
     return flag;
 }
 
+namespace
+{
+    std::atomic<int> g_plan_options[aoclsparse_mi355_option_count] = {{0}, {-1}};
+}
+int plan_option(aoclsparse_mi355_option option)
+{
+    return option >= 0 && option < aoclsparse_mi355_option_count ? g_plan_options[option].load(std::memory_order_relaxed) : 0;
+}
+
 bool csrmm_reads_c(bool beta_nonzero)
 {
     return beta_nonzero || !csrmm_beta0_overwrite_flag().load(std::memory_order_relaxed);
@@ -327,6 +336,18 @@ extern "C" {
 aoclsparse_status aoclsparse_mi355_set_csrmm_beta0_overwrite(int overwrite)
 {
     csrmm_beta0_overwrite_flag().store(overwrite != 0, std::memory_order_relaxed); // process-wide: every runtime slot reads it
+    return aoclsparse_status_success;
+}
+
+aoclsparse_status aoclsparse_mi355_set_option(aoclsparse_mi355_option option, aoclsparse_int value)
+{
+    if(option < 0 || option >= aoclsparse_mi355_option_count)
+        return aoclsparse_status_invalid_value;
+    if(option == aoclsparse_mi355_option_spmv_kernel && (value < 0 || value > 2))
+        return aoclsparse_status_invalid_value;
+    if(option == aoclsparse_mi355_option_sell && (value < -1 || value > 1))
+        return aoclsparse_status_invalid_value;
+    g_plan_options[option].store((int)value, std::memory_order_relaxed);
     return aoclsparse_status_success;
 }
 

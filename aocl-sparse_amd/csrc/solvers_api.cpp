@@ -415,14 +415,10 @@ aoclsparse_status ilu0_factorize(aoclsparse_matrix A, T *host_val)
     MI355_HIP_TRY(hipMemsetAsync(derr.ptr, 0, sizeof(int), rt.stream()));
     // real types, deep DAGs: one sync-free launch (rows wait for the rows they need; ilu_kernels.hip) instead of one launch per
     // level -- 5,505 launches cost 390 ms on the shell-like stand-in, the sync-free launch 139 ms; with two lower entries per row
-    // (2-D Laplacian) the launches win, 20 vs 44 ms.  AOCLSPARSE_MI355_ILU_SYNCFREE=0 keeps the launches.
-    static const bool sf_off = [] {
-        const char *e = getenv("AOCLSPARSE_MI355_ILU_SYNCFREE");
-        return e && atoi(e) == 0;
-    }();
+    // (2-D Laplacian) the launches win, 20 vs 44 ms.
     bool syncfree = false;
     if constexpr(std::is_floating_point<T>::value)
-        syncfree = !sf_off && nlev > 8 && (long long)nnz >= 16LL * n; // (short rows: a level's launch is cheaper than its hops)
+        syncfree = nlev > 8 && (long long)nnz >= 16LL * n; // (short rows: a level's launch is cheaper than its hops)
     if(syncfree)
     {
         if constexpr(std::is_floating_point<T>::value)

@@ -240,12 +240,6 @@ static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, T
     bp.tried = true;
     if(m < 2)
         return aoclsparse_status_success;
-    static const bool off = [] {
-        const char *e = getenv("AOCLSPARSE_MI355_TRSV_BLOCKS");
-        return e && atoi(e) == 0;
-    }();
-    if(off)
-        return aoclsparse_status_success;
     LapTimer lt;
     auto     row_at = [&](aoclsparse_int k) { return t.descending ? m - 1 - k : k; }; // k-th row in solve order
     auto len_of = [&](aoclsparse_int i) { return t.ptr[i + 1] - t.ptr[i]; };

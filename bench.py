@@ -137,7 +137,7 @@ def roofline(abytes, ms, traffic=None, **extra):
 _FLOOR_CACHE = {}
 
 
-def latency_floor(workgroups, footprint_bytes, entries, achieved_us):
+def latency_floor(workgroups, footprint_bytes, entries, achieved_us, lanes=256):
     """`roofline_latency` of a leg whose working set stays in the L2s / Infinity Cache (8 TB/s of HBM is the wrong roof there):
     the measured floor of a kernel with the same launch shape that does the CSR kernels' minimum -- launch ramp, THREE dependent
     memory round trips per wavefront (block table -> column indices / values -> x[col]) over the same footprint, then a coalesced
@@ -146,7 +146,7 @@ def latency_floor(workgroups, footprint_bytes, entries, achieved_us):
     import subprocess
 
     probe = os.path.join(ROOT, "tools", "bin", "latency_floor")
-    key = (int(workgroups), max(1, int(footprint_bytes) >> 20), int(entries))
+    key = (int(workgroups), max(1, int(footprint_bytes) >> 20), int(entries), 128 if lanes == 128 else 256)
     if key not in _FLOOR_CACHE:
         res = None
         try:
@@ -162,10 +162,12 @@ def latency_floor(workgroups, footprint_bytes, entries, achieved_us):
     if not res:
         return None
     floor = float(res["three_hops_then_stream_us"])
+    # (the probe is a reference kernel of the same shape, not a proof of optimality: the product may come out a few % under it)
     return {"bound": "latency", "floor_us": round(floor, 3), "achieved_us": round(achieved_us, 3),
-            "frac": round(floor / achieved_us, 4) if achieved_us > 0 else None, "unit": "us",
+            "frac": round(min(1.0, floor / achieved_us), 4) if achieved_us > 0 else None, "unit": "us",
+            "floor_over_achieved_raw": round(floor / achieved_us, 4) if achieved_us > 0 else None,
             "empty_kernel_us": res["empty_kernel_us"], "three_dependent_trips_us": res["three_hops_us"],
-            "workgroups": key[0], "footprint_mb": key[1], "entries": key[2],
+            "workgroups": key[0], "lanes_per_workgroup": key[3], "footprint_mb": key[1], "entries": key[2],
             "how": "tools/latency_floor.hip: launch + 3 dependent round trips per wavefront + a coalesced stream of the same "
                    "length, same number of workgroups; the working set fits the L2s / Infinity Cache, so HBM is not the bound"}
 
@@ -826,7 +828,8 @@ def main():
                          "max_abs_diff": float(err.max()),
                          "cpu_all_cores_gflops": round(2.0 * nz / float(np.median(secs)) / 1e9, 2)})
             if b < (200 << 20):  # the matrix stays in the L2s / Infinity Cache between calls: state the latency roof beside HBM
-                rows[-1]["roofline_latency"] = latency_floor(max(inf.row_blocks, 1), b, nz, ms * 1e3)
+                rows[-1]["roofline_latency"] = latency_floor(max(inf.row_blocks, 1), b, nz, ms * 1e3,
+                                                             lanes=128 if inf.tile == 512 else 256)
             del Am, xd, ydv
         # the third kernel aoclsparse_optimize can choose: merge-path, for matrices whose longest row spans tens of LDS
         # tiles (none of the four above does): a tridiagonal matrix with four rows of ~170 k entries

@@ -27,6 +27,20 @@ typedef enum aoclsparse_mi355_pointer_mode_
 } aoclsparse_mi355_pointer_mode;
 
 DLL_PUBLIC aoclsparse_status aoclsparse_mi355_set_pointer_mode(aoclsparse_mi355_pointer_mode mode);
+/* Plan options: ONE hook for the tests and measurements that must reach a kernel the automatic choice would not pick for
+ * their (small) input.  Process-wide, read when a handle's plan is built (so: set before aoclsparse_optimize / the first
+ * product, reset afterwards).  Everything else the library chooses by itself; the selection switches of rounds 1-3
+ * (environment variables) are gone -- their measurements are under profiles/.
+ *   spmv_kernel  0 automatic (default: CSR-Adaptive, merge-path once the longest row spans 32 LDS tiles), 1 CSR-Adaptive,
+ *                2 merge-path whenever it can serve the request
+ *   sell         -1 automatic (default: SELL-64 copy for an mv hint when its padding is <= 1.35 x), 0 never, 1 always */
+typedef enum aoclsparse_mi355_option_
+{
+    aoclsparse_mi355_option_spmv_kernel = 0,
+    aoclsparse_mi355_option_sell        = 1,
+    aoclsparse_mi355_option_count       = 2
+} aoclsparse_mi355_option;
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_set_option(aoclsparse_mi355_option option, aoclsparse_int value);
 /* aoclsparse_?csrmm with beta == 0.  Default (0): C is read and multiplied by zero, exactly as every kernel of the reference
  * does (level3/aoclsparse_csrmm.hpp:83,129; aoclsparse_csrmm_kt.cpp:176-191,246), so a NaN / Inf already in C propagates.
  * 1: C is overwritten without being read (BLAS convention; identical results for every finite C, including the sign of

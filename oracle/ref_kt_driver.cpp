@@ -11,8 +11,10 @@
  * trsv_kt.cpp:92-137 and csrmm_kt.cpp:127-191 make them, with the reference's flags: -O3 -ffp-contract=fast, so the
  * scalar tails are contracted by the compiler exactly as in the reference build.)
  *
- * Built and used only in the build container (needs /root/reference); tests/golden/make_kt_vectors.py turns its
- * outputs into the committed fixture tests/golden/kt_vectors.json, which is what travels.
+ * BUILT only in the build container (needs /root/reference); tests/golden/make_kt_vectors.py turns its outputs into the
+ * committed fixture tests/golden/kt_vectors.json.  The built oracle/_ref/libktref.so travels to the GPU box with the snapshot
+ * (git-ignored, not gpurun-ignored, as the task prescribes for oracle/_ref) and tests/test_oracle_kt.py loads it there too when
+ * present: a checker of the checker, never linked or called by the product.
  */
 #include "kernel-templates/kernel_templates.hpp"
 

@@ -788,11 +788,11 @@ def test_optimize_selects_merge_path_for_very_long_rows():
         v = rng.uniform(-1, 1, len(ci))
         A = P.Matrix(0, n, n, rp, ci, v)
         d = P.Descr()
-        os.environ["AOCLSPARSE_MI355_SELL"] = "0"
+        assert L.aoclsparse_mi355_set_option(P.OPTION_SELL, 0) == 0  # no SELL copy: the choice between the two CSR kernels
         try:
             assert L.aoclsparse_set_mv_hint(A.h, P.OP_NONE, d.h, 100) == 0 and L.aoclsparse_optimize(A.h) == 0
         finally:
-            os.environ.pop("AOCLSPARSE_MI355_SELL", None)
+            assert L.aoclsparse_mi355_set_option(P.OPTION_SELL, -1) == 0
         info = A.spmv_info()
         assert info.kernel == want, (length, info.kernel, info.max_row_nnz, info.tile)
         x = rng.uniform(-1, 1, n)

@@ -151,14 +151,14 @@ def _merge_cut_rows(rp, base, items=1024):
 
 @pytest.fixture
 def merge_kernel():
-    os.environ["AOCLSPARSE_MI355_SPMV_KERNEL"] = "merge"
+    assert L.aoclsparse_mi355_set_option(P.OPTION_SPMV_KERNEL, 2) == 0  # merge-path whenever it can serve the request
     yield
-    del os.environ["AOCLSPARSE_MI355_SPMV_KERNEL"]
+    assert L.aoclsparse_mi355_set_option(P.OPTION_SPMV_KERNEL, 0) == 0
 
 
 @pytest.mark.parametrize("base", [0, 1])
 def test_merge_path_kernel_power_law(merge_kernel, base):
-    """merge-path tiles (AOCLSPARSE_MI355_SPMV_KERNEL=merge): rows inside one tile follow the reference's scalar
+    """merge-path tiles (aoclsparse_mi355_set_option(spmv_kernel, 2)): rows inside one tile follow the reference's scalar
     order bit for bit; a row cut by tile boundaries is the ordered sum of its pieces' chains -- bound
     (pieces + len) * eps * sum|a||x|."""
     m = n = 30000

@@ -3,10 +3,10 @@
 // algorithmic bytes, web-like: 57 MB) run for 10-30 us, where the launch and the chain of DEPENDENT memory round trips
 // every workgroup must make (block table -> row_ptr / col_ind / val -> x[col]) weigh as much as the bytes.
 //   hipcc -O3 --offload-arch=gfx950 tools/latency_floor.hip -o tools/bin/latency_floor
-//   latency_floor [workgroups=2000] [footprint_MB=64] [stream_entries=3100840]
+//   latency_floor [workgroups=2000] [footprint_MB=64] [stream_entries=3100840] [lanes_per_workgroup=256]
 // Prints one JSON line: back-to-back time per launch of (a) an empty kernel, (b..d) a kernel whose every wavefront
-// makes 1, 2, 3 dependent loads from a footprint larger than the L2s (pointer chase through an index array, one
-// random 64-byte line per hop), (e) 3 dependent hops followed by a 12-byte-per-lane coalesced stream of the given size.
+// makes 1, 2, 3 DEPENDENT loads from the footprint (two coalesced ones whose address comes out of the load before -- block table
+// -> column indices -- then a per-lane gather, x[col]), (e) the three followed by a 12-byte-per-entry coalesced stream.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -31,33 +31,44 @@ __global__ void empty_kernel(int *sink)
         *sink = 1;
 }
 
-// every lane hops `hops` times through idx (each hop depends on the previous load), then writes the result
+// The round trips of a CSR SpMV workgroup, in their cheapest form: hop 1 and hop 2 are COALESCED loads whose address depends on the
+// previous load (block table -> column indices / values: one line stretch per wavefront), hop 3 is a per-lane gather (x[col]).
+// HOPS = 1: the first only, 2: both coalesced ones, 3: all three.
 template <int HOPS>
 __global__ __launch_bounds__(256) void chase_kernel(const int *__restrict__ idx, int n, int *__restrict__ out)
 {
-    int p = (int)((blockIdx.x * 256u + threadIdx.x) * 2654435761u % (unsigned)n);
-#pragma unroll
-    for(int h = 0; h < HOPS; h++)
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int p = (int)((wave * 2654435761u) % (unsigned)(n - 128)) & ~63;
+    p     = idx[p + lane];
+    if(HOPS >= 2)
+        p = idx[(__builtin_amdgcn_readfirstlane(p) % (n - 128) & ~63) + lane];
+    if(HOPS >= 3)
         p = idx[p];
-    out[blockIdx.x * 256 + threadIdx.x] = p;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = p;
 }
 
 __global__ __launch_bounds__(256) void chase_stream_kernel(const int *__restrict__ idx, int n, const double *__restrict__ v,
                                                            const int *__restrict__ c, long per_wg, double *__restrict__ out)
 {
-    int p = (int)((blockIdx.x * 256u + threadIdx.x) * 2654435761u % (unsigned)n);
-    p     = idx[idx[idx[p]]];
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int p = (int)((wave * 2654435761u) % (unsigned)(n - 128)) & ~63;
+    p     = idx[p + lane];
+    p     = idx[(__builtin_amdgcn_readfirstlane(p) % (n - 128) & ~63) + lane];
+    p     = idx[p];
     double     acc = (double)(p & 1);
     const long s   = (long)blockIdx.x * per_wg;
-    for(long q = s + threadIdx.x; q < s + per_wg; q += 256)
+    for(long q = s + threadIdx.x; q < s + per_wg; q += blockDim.x)
         acc += v[q] * (double)c[q];
-    out[blockIdx.x * 256 + threadIdx.x] = acc;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
 int main(int argc, char **argv)
 {
     const int  wgs  = argc > 1 ? atoi(argv[1]) : 2000;
     const long fmb  = argc > 2 ? atol(argv[2]) : 64;
+    const int  lanes = argc > 4 && atoi(argv[4]) == 128 ? 128 : 256;
     const int  n    = (int)(fmb * 1024 * 1024 / 4);
     std::vector<int> idx(n);
     unsigned         s = 777;
@@ -98,15 +109,15 @@ int main(int argc, char **argv)
         }
         return best;
     };
-    const float t_empty = timeit([&] { empty_kernel<<<wgs, 256>>>(nullptr); });
-    const float t1      = timeit([&] { chase_kernel<1><<<wgs, 256>>>(d_idx, n, d_out); });
-    const float t2      = timeit([&] { chase_kernel<2><<<wgs, 256>>>(d_idx, n, d_out); });
-    const float t3      = timeit([&] { chase_kernel<3><<<wgs, 256>>>(d_idx, n, d_out); });
+    const float t_empty = timeit([&] { empty_kernel<<<wgs, lanes>>>(nullptr); });
+    const float t1      = timeit([&] { chase_kernel<1><<<wgs, lanes>>>(d_idx, n, d_out); });
+    const float t2      = timeit([&] { chase_kernel<2><<<wgs, lanes>>>(d_idx, n, d_out); });
+    const float t3      = timeit([&] { chase_kernel<3><<<wgs, lanes>>>(d_idx, n, d_out); });
     const long  per_wg  = stream_entries / wgs;
-    const float t4      = timeit([&] { chase_stream_kernel<<<wgs, 256>>>(d_idx, n, d_v, d_c, per_wg, d_o2); });
-    printf("{\"probe\": \"launch + dependent-round-trip floor\", \"workgroups\": %d, \"footprint_mb\": %ld, "
+    const float t4      = timeit([&] { chase_stream_kernel<<<wgs, lanes>>>(d_idx, n, d_v, d_c, per_wg, d_o2); });
+    printf("{\"probe\": \"launch + dependent-round-trip floor\", \"workgroups\": %d, \"lanes_per_workgroup\": %d, \"footprint_mb\": %ld, "
            "\"empty_kernel_us\": %.3f, \"one_hop_us\": %.3f, \"two_hops_us\": %.3f, \"three_hops_us\": %.3f, "
            "\"three_hops_then_stream_us\": %.3f, \"stream_entries\": %ld, \"per_hop_us\": %.3f}\n",
-           wgs, fmb, t_empty, t1, t2, t3, t4, stream_entries, (t3 - t1) / 2);
+           wgs, lanes, fmb, t_empty, t1, t2, t3, t4, stream_entries, (t3 - t1) / 2);
     return 0;
 }
