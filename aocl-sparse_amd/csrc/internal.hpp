@@ -662,11 +662,9 @@ aoclsparse_status launch_csrmv(hipStream_t s, int order, bool strict, int tile, 
                                aoclsparse_int m, const T *val, const aoclsparse_int *col,
                                const aoclsparse_int *row_ptr, const aoclsparse_int *blocks,
                                aoclsparse_int nblocks, const T *x, T beta, T *y, const aoclsparse_int *blocks4 = nullptr,
-                               aoclsparse_int max_row_nnz = 1 << 30);
-// raw-array csrmv: is a cached plan still the plan of this row_ptr?  (*stale: pinned host word, set on mismatch)
-aoclsparse_status launch_plan_check(hipStream_t s, const aoclsparse_int *blocks, aoclsparse_int nblocks,
-                                    const aoclsparse_int *row_ptr, int base, aoclsparse_int m, aoclsparse_int nnz,
-                                    unsigned int *stale);
+                               aoclsparse_int max_row_nnz = 1 << 30, unsigned int *stale = nullptr);
+// (stale != nullptr: the block table is a cached plan of a raw-array call -- every workgroup validates its own entry against
+// the live row_ptr, computes its rows from the live arrays on a mismatch and sets *stale, a pinned host word)
 template <typename T>
 aoclsparse_status launch_sell_fill(hipStream_t s, int pack, aoclsparse_int m, int base, const aoclsparse_int *row_ptr,
                                    const aoclsparse_int *col, const T *val, aoclsparse_int nslices,

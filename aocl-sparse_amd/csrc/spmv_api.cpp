@@ -96,7 +96,7 @@ constexpr int STRICT_LONG_AUTO = 0; // off: see run_on_device_csr
 template <typename T>
 aoclsparse_status run_on_device_csr(Runtime &rt, aoclsparse_int kid, const DeviceCsr &d,
                                     const SpmvPlan &plan, T alpha, const T *x, T beta, T *y,
-                                    aoclsparse_int nx, aoclsparse_int ny)
+                                    aoclsparse_int nx, aoclsparse_int ny, unsigned int *stale = nullptr)
 {
     int               order;
     bool              strict;
@@ -138,7 +138,7 @@ aoclsparse_status run_on_device_csr(Runtime &rt, aoclsparse_int kid, const Devic
                              plan.rowblocks.as<aoclsparse_int>(), plan.nblocks, static_cast<const T *>(ax.dev),
                              beta, static_cast<T *>(ay.dev),
                              (plan.heavy_first && (plan.tile & 1) == 0) ? plan.rowblocks4.as<aoclsparse_int>() : nullptr,
-                             plan.max_row_nnz);
+                             plan.max_row_nnz, stale);
     if(st != aoclsparse_status_success)
         return st;
     st = ay.out(rt);
@@ -257,8 +257,10 @@ aoclsparse_status mv_t(aoclsparse_operation op, const T *alpha, aoclsparse_matri
 // Plans for device-resident raw arrays are cached on (row_ptr address, m, nnz, base): the one-shot
 // API has no handle to hang an analysis on ("raw csrmv").  The key says nothing about the CONTENTS (a
 // caller may free its arrays and get the same address back for another matrix of the same size), so every hit is
-// validated on the device against the live row_ptr before it is used (plan_check_kernel: all block boundaries), and
-// rebuilt when it does not match.  A plan is handed out as a shared_ptr copied under the lock, so a concurrent call
+// validated ON THE DEVICE, INSIDE the product: each workgroup of csr_adaptive_kernel checks its own block entry against the
+// live row_ptr values it loads anyway, computes its rows from the live arrays when the entry is stale (same chains: the
+// result is right either way) and raises a pinned word that the NEXT raw call sees -- it then drops the cache and
+// rebuilds.  No check kernel, no stream round trip per call (round 3: ~70 us of each 0.334 ms call on the 4096^2 Laplacian).  A plan is handed out as a shared_ptr copied under the lock, so a concurrent call
 // that evicts the slot cannot free or rewrite a plan that is still in use.
 struct RawPlan
 {
@@ -438,6 +440,7 @@ aoclsparse_status csrmv_t(aoclsparse_operation trans, const T *alpha, aoclsparse
 
     SpmvPlan                  local;
     SpmvPlan                 *plan = &local;
+    bool                      fresh_plan = false; // built in this call from this row_ptr
     std::shared_ptr<SpmvPlan> held; // keeps a cached plan alive for this call whatever other threads evict
     try
     {
@@ -449,24 +452,21 @@ aoclsparse_status csrmv_t(aoclsparse_operation trans, const T *alpha, aoclsparse
                     if(e.key == row && e.m == m && e.nnz == nnz && e.base == descr->base && e.plan && e.plan->valid)
                         held = e.plan;
             }
-            if(held && rt.plan_stale_dev)
+            if(rt.plan_stale_host && *rt.plan_stale_host)
             {
-                // is it still the plan of THIS row_ptr?  (tiny kernel + one pinned word; costs a stream round trip,
-                // which is the price of a stateless API on device-resident arrays -- handles have no such check)
-                std::lock_guard<std::recursive_mutex> sl(rt.stage_lock);
+                // an earlier product found a cached plan stale (it computed the right result from the live arrays): forget
+                // every cached plan, they are rebuilt from the live row_ptr as their keys come back
+                std::lock_guard<std::mutex> g(rt.lock);
                 *rt.plan_stale_host = 0;
-                st = launch_plan_check(rt.stream(), held->rowblocks.as<aoclsparse_int>(), held->nblocks, row, descr->base, m,
-                                       nnz, rt.plan_stale_dev);
-                if(st != aoclsparse_status_success)
-                    return st;
-                MI355_HIP_TRY(hipStreamSynchronize(rt.stream()));
-                if(*rt.plan_stale_host)
-                    held.reset();
+                for(auto &e : g_raw)
+                    e = RawPlan();
+                held.reset();
             }
-            else if(held)
-                held.reset(); // no pinned word to validate with: never trust the cache
+            if(held && !rt.plan_stale_dev)
+                held.reset(); // no pinned word to report a stale plan with: never trust the cache
             if(!held)
             {
+                fresh_plan = true;
                 std::vector<aoclsparse_int> hrow((size_t)m + 1);
                 MI355_HIP_TRY(hipMemcpy(hrow.data(), row, sizeof(aoclsparse_int) * ((size_t)m + 1),
                                         hipMemcpyDeviceToHost));
@@ -504,7 +504,8 @@ aoclsparse_status csrmv_t(aoclsparse_operation trans, const T *alpha, aoclsparse
     DeviceCsr view; // non-owning view for the shared launcher
     view.m = m, view.n = n, view.nnz = nnz, view.base = descr->base;
     view.ptr.ptr = arow.dev, view.ind.ptr = acol.dev, view.val.ptr = aval.dev;
-    st = run_on_device_csr<T>(rt, -1, view, *plan, *alpha, x, *beta, y, n, m);
+    // (a cached plan is validated inside the kernel; a plan built in this call from this row_ptr needs no validation)
+    st = run_on_device_csr<T>(rt, -1, view, *plan, *alpha, x, *beta, y, n, m, mdev && fresh_plan == false ? rt.plan_stale_dev : nullptr);
     view.ptr.ptr = view.ind.ptr = view.val.ptr = nullptr; // not ours to free
     if(st == aoclsparse_status_success && plan == &local)
         MI355_HIP_TRY(hipStreamSynchronize(rt.stream())); // local plan buffer is freed on return

@@ -124,7 +124,13 @@ __device__ __forceinline__ T block_sum(T v, T *scratch)
 }
 
 // flags: bit0 strict long rows, bit1 16-byte-aligned val and col (quad loads allowed),
-//        bit2 XCD-contiguous block order, bit3 non-temporal y stores
+//        bit2 XCD-contiguous block order, bit3 non-temporal y stores, bit4 every row <= 8 entries,
+//        bit5 VALIDATE: the block table may be STALE (a cached plan of a raw-array call, spmv_api.cpp: the cache key is the
+//        row_ptr address, m, nnz and the base -- not the contents).  The kernel relies on exactly one thing from a block's
+//        entry: that its rows [r0, r0 + nrows) hold the entries [p0, p0 + cnt).  The live row_ptr values of those rows are
+//        loaded anyway (s_row), so each workgroup checks its own two boundaries for free; on a mismatch it computes its rows
+//        straight from the live arrays (same chains, no LDS tile) and raises *stale for the host's next call.  No check
+//        kernel, no stream round trip per call (round 3 paid ~70 us for one: 0.334 vs 0.262 ms on the 4096^2 Laplacian).
 template <typename T, int ORDER, int TILE, int BLOCK, bool TRACE = false>
 __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restrict__ blocks,
                                                                   const aoclsparse_int *__restrict__ row_ptr,
@@ -139,7 +145,8 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restr
                                                                   int chunk,
                                                                   int flags,
                                                                   unsigned long long *trace,
-                                                                  const int4 *__restrict__ blocks4)
+                                                                  const int4 *__restrict__ blocks4,
+                                                                  unsigned int *stale)
 {
     constexpr int MAXROWS = spmv_maxrows(TILE); // planner guarantees rows <= MAXROWS
     // diagnostic (AOCLSPARSE_MI355_SPMV_TRACE, tools/spmv_trace.py): 100 MHz stamps per workgroup, kept in registers and
@@ -174,6 +181,18 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restr
     }
     if constexpr(TRACE)
         t_st[1] = __builtin_amdgcn_readfirstlane(cnt) >= 0 ? __builtin_amdgcn_s_memrealtime() : 0;
+    if((flags & 32) && cnt > TILE)
+    {
+        // VALIDATE, single-row block: the live extent of the row replaces the planned one (the long-row code below works for
+        // any length)
+        const int ls = row_ptr[r0] - base, le = row_ptr[r0 + 1] - base;
+        if(ls != p0 || le - ls != cnt)
+        {
+            if(tid == 0)
+                __hip_atomic_store(stale, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            p0 = ls, cnt = le - ls;
+        }
+    }
 
     if(cnt <= TILE)
     {
@@ -249,9 +268,43 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restr
         __syncthreads();
         if constexpr(TRACE)
             t_st[3] = __builtin_amdgcn_s_memrealtime();
-        // ---- phase 2: per-row reduction in the reference order -----------------------------------------
         const int grp  = tid / L;
         const int lane = tid % L;
+        if((flags & 32) && (s_row[0] + w0 != p0 || s_row[nrows] + w0 != p0 + cnt))
+        {
+            // VALIDATE: this block's entry does not describe the live matrix.  Its rows, straight from the live arrays, in the
+            // same order as below (scalar chain, or L strided chains + the reference's reduction + scalar tail).
+            if(tid == 0)
+                __hip_atomic_store(stale, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            for(int rr = grp; rr < nrows; rr += BLOCK / L)
+            {
+                const int s = s_row[rr] + w0, e = s_row[rr + 1] + w0, r = r0 + rr;
+                T         acc = T(0);
+                if constexpr(L == 1)
+                {
+                    for(int j = s; j < e; j++)
+                        acc = dev_fma(val[j], xb[col[j]], acc);
+                    y[r] = finish(acc, alpha, beta, &y[r]);
+                }
+                else
+                {
+                    const int nfull = (e - s) & ~(L - 1);
+                    for(int j = s + lane; j < s + nfull; j += L)
+                        acc = dev_fma(val[j], xb[col[j]], acc);
+                    T res = group_reduce<T, ORDER>(acc);
+                    if(lane == 0)
+                    {
+                        if(nfull == 0)
+                            res = T(0);
+                        for(int j = s + nfull; j < e; j++)
+                            res = dev_fma(val[j], xb[col[j]], res);
+                        y[r] = finish(res, alpha, beta, &y[r]);
+                    }
+                }
+            }
+            return;
+        }
+        // ---- phase 2: per-row reduction in the reference order -----------------------------------------
         for(int rr = grp; rr < nrows; rr += BLOCK / L)
         {
             const int s   = s_row[rr];
@@ -555,7 +608,7 @@ aoclsparse_status launch_dot(hipStream_t s, aoclsparse_int n, const T *x, const 
 template <typename T, int ORDER, int TILE, int BLOCK>
 static void launch_inst(hipStream_t s, int flags, int base, T alpha, const T *val, const aoclsparse_int *col,
                         const aoclsparse_int *row_ptr, const aoclsparse_int *blocks, aoclsparse_int nblocks,
-                        const T *x, T beta, T *y, const aoclsparse_int *blocks4)
+                        const T *x, T beta, T *y, const aoclsparse_int *blocks4, unsigned int *stale)
 {
     const int chunk = (nblocks + 7) / 8;
     const int grid  = (flags & 4) ? chunk * 8 : (int)nblocks;
@@ -569,7 +622,7 @@ static void launch_inst(hipStream_t s, int flags, int base, T alpha, const T *va
         if(trace)
             hipLaunchKernelGGL((csr_adaptive_kernel<T, ORDER, TILE, BLOCK, true>), dim3(grid), dim3(BLOCK), 0, s,
                                reinterpret_cast<const int2 *>(blocks), row_ptr, col, val, x, y, alpha, beta, base,
-                               (int)nblocks, chunk, flags, trace, reinterpret_cast<const int4 *>(blocks4));
+                               (int)nblocks, chunk, flags, trace, reinterpret_cast<const int4 *>(blocks4), stale);
     }
     else if(trace)
     {
@@ -579,7 +632,7 @@ static void launch_inst(hipStream_t s, int flags, int base, T alpha, const T *va
     if(!(ORDER == 0 && trace))
         hipLaunchKernelGGL((csr_adaptive_kernel<T, ORDER, TILE, BLOCK>), dim3(grid), dim3(BLOCK), 0, s,
                            reinterpret_cast<const int2 *>(blocks), row_ptr, col, val, x, y, alpha, beta, base,
-                           (int)nblocks, chunk, flags, (unsigned long long *)nullptr, reinterpret_cast<const int4 *>(blocks4));
+                           (int)nblocks, chunk, flags, (unsigned long long *)nullptr, reinterpret_cast<const int4 *>(blocks4), stale);
     if(trace)
     {
         std::vector<unsigned long long> host(8 * (size_t)nblocks);
@@ -600,7 +653,7 @@ aoclsparse_status launch_csrmv(hipStream_t s, int order, bool strict, int tile, 
                                aoclsparse_int m, const T *val, const aoclsparse_int *col,
                                const aoclsparse_int *row_ptr, const aoclsparse_int *blocks,
                                aoclsparse_int nblocks, const T *x, T beta, T *y, const aoclsparse_int *blocks4,
-                               aoclsparse_int max_row_nnz)
+                               aoclsparse_int max_row_nnz, unsigned int *stale)
 {
     if(m <= 0 || nblocks <= 0)
         return aoclsparse_status_success;
@@ -614,12 +667,14 @@ aoclsparse_status launch_csrmv(hipStream_t s, int order, bool strict, int tile, 
     if((size_t)m * sizeof(T) > (size_t)32 << 20)
         flags |= 8;
     if(max_row_nnz <= 8)
-        flags |= 16; // every row is short: the entry-by-entry reduction (see the kernel)
+        flags |= 16; // every row is short: the entry-by-entry reduction (see the kernel; a plain loop, right for any length)
+    if(stale)
+        flags |= 32; // the block table is a cached plan of a raw-array call: every workgroup validates its own entry
     const int tsel = tile == 512 ? 0 : (tile == 1024 ? 1 : (tile == 2048 ? 2 : -1));
     if(tsel < 0 || order < 0 || order > 2)
         return aoclsparse_status_invalid_kid;
 #define MI355_CASE(O, TL, BL)                                                                                 \
-    launch_inst<T, O, TL, BL>(s, flags, base, alpha, val, col, row_ptr, blocks, nblocks, x, beta, y, blocks4); \
+    launch_inst<T, O, TL, BL>(s, flags, base, alpha, val, col, row_ptr, blocks, nblocks, x, beta, y, blocks4, stale); \
     break
     switch(order * 3 + tsel)
     {
@@ -647,32 +702,6 @@ aoclsparse_status launch_csrmv(hipStream_t s, int order, bool strict, int tile, 
     return aoclsparse_status_success;
 }
 
-// Validation of a cached row-block plan against the LIVE row_ptr of a raw-array call (spmv_api.cpp): the kernels rely
-// on exactly one thing from the plan -- that block b starts at row blocks[b].x with its first non-zero at blocks[b].y --
-// so checking every boundary (and the total) is a complete test.  *stale (pinned host memory) is set on any mismatch.
-__global__ void plan_check_kernel(const int2 *__restrict__ blocks, aoclsparse_int nblocks, const aoclsparse_int *__restrict__ row_ptr,
-                                  int base, aoclsparse_int m, aoclsparse_int nnz, unsigned int *stale)
-{
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if(b > nblocks)
-        return;
-    const int2 e = blocks[b];
-    bool       bad = e.x < 0 || e.x > m || row_ptr[e.x] - base != e.y;
-    if(b == nblocks)
-        bad = bad || e.x != m || e.y != nnz;
-    if(bad)
-        __hip_atomic_store(stale, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-aoclsparse_status launch_plan_check(hipStream_t s, const aoclsparse_int *blocks, aoclsparse_int nblocks,
-                                    const aoclsparse_int *row_ptr, int base, aoclsparse_int m, aoclsparse_int nnz,
-                                    unsigned int *stale)
-{
-    hipLaunchKernelGGL(plan_check_kernel, dim3((nblocks + 256) / 256), dim3(256), 0, s, reinterpret_cast<const int2 *>(blocks),
-                       nblocks, row_ptr, base, m, nnz, stale);
-    MI355_HIP_TRY(hipGetLastError());
-    return aoclsparse_status_success;
-}
 
 template <typename T>
 __global__ void waxpby_kernel(aoclsparse_int n, T a, const T *x, T b, const T *y, T *w)
@@ -728,7 +757,7 @@ aoclsparse_status launch_strided_scatter(hipStream_t s, const T *src, aoclsparse
     template aoclsparse_status launch_csrmv<T>(hipStream_t, int, bool, int, int, T, aoclsparse_int, const T *, \
                                                const aoclsparse_int *, const aoclsparse_int *,                  \
                                                const aoclsparse_int *, aoclsparse_int, const T *, T, T *,       \
-                                               const aoclsparse_int *, aoclsparse_int);                         \
+                                               const aoclsparse_int *, aoclsparse_int, unsigned int *);         \
     template aoclsparse_status launch_scale<T>(hipStream_t, T *, aoclsparse_int, T);                           \
     template aoclsparse_status launch_waxpby<T>(hipStream_t, aoclsparse_int, T, const T *, T, const T *, T *); \
     template aoclsparse_status launch_dot<T>(hipStream_t, aoclsparse_int, const T *, const T *, T *, T *);     \

@@ -426,3 +426,65 @@ def test_library_rccl_communicator_one_rank():
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "rccl" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+
+
+# --------------------------------------------------------------------------------------------------
+# raw aoclsparse_dcsrmv on device arrays: the cached plan is validated INSIDE the product kernel
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("avg", [8, 12])
+def test_raw_dcsrmv_stale_plan_is_caught_inside_the_kernel(avg):
+    """Different matrices of equal m and nnz written one after the other into the SAME device buffers (a caching allocator after
+    free + malloc).  The cache key (row_ptr address, m, nnz, base) hits, the cached block table is stale: every workgroup of
+    csr_adaptive_kernel checks its own entry against the live row_ptr and, on a mismatch, computes its rows from the live arrays
+    -- the FIRST product after the switch must already be the new matrix's, bit for bit, with no stream round trip; the next call
+    sees the raised word and rebuilds.  avg = 8: scalar order (nnz <= 10 m); avg = 12: the 8-lane order (nnz > 10 m,
+    csrmv_avx512.cpp:36-134).  The stale cases include a live row far longer than the LDS tile inside a planned multi-row block
+    and planned single-row blocks whose live rows are short."""
+    m = n = 30000
+    rng = np.random.default_rng(40 + avg)
+    total = avg * m
+
+    def build(lens):
+        lens = np.asarray(lens, np.int64)
+        assert lens.sum() == total and lens.max() <= n
+        rp = np.zeros(m + 1, np.int32)
+        rp[1:] = np.cumsum(lens)
+        ci = np.concatenate([np.sort(rng.choice(n, size=int(k), replace=False)) for k in lens]).astype(np.int32)
+        return rp, ci, rng.uniform(-1, 1, len(ci))
+
+    uniform = np.full(m, avg)
+    skew = np.full(m, avg)
+    skew[: m // 2] -= avg - 2
+    skew[m // 2:] += avg - 2
+    long_rows = np.full(m, avg)
+    long_rows[[7, 12345, m - 1]] += np.array([2700, 1100, 5000])
+    take = long_rows.sum() - total
+    idx = np.arange(100, 100 + take)  # one entry less on `take` other rows
+    long_rows[idx] -= 1
+    mats = [build(uniform), build(skew), build(long_rows), build(uniform[::-1]), build(long_rows[::-1].copy())]
+    d = P.Descr()
+    x = rng.uniform(-1, 1, n)
+    xd = dev(x)
+    d_rp, d_ci, d_v = dev(mats[0][0]), dev(mats[0][1]), dev(mats[0][2])
+    L.aoclsparse_mi355_set_pointer_mode(P.PTR_DEVICE)
+    try:
+        for order in ([0, 1, 2, 3, 4], [2, 0, 4, 1, 2]):
+            for k in order:
+                rp, ci, v = mats[k]
+                d_rp.copy_(torch.from_numpy(rp)), d_ci.copy_(torch.from_numpy(ci)), d_v.copy_(torch.from_numpy(v))
+                torch.cuda.synchronize()
+                so, yr = oracle.dcsrmv(-1, 0, 1.0, m, total, v, ci, rp, x, 0.0, np.zeros(m))
+                assert so == 0
+                for call in range(3):  # 1st: stale plan caught in the kernel; 2nd: rebuilt; 3rd: validated hit
+                    yd = torch.full((m,), float("nan"), dtype=torch.float64, device="cuda")
+                    assert P.dcsrmv(P.OP_NONE, 1.0, m, n, total, d_v, d_ci, d_rp, d, xd, 0.0, yd) == 0
+                    torch.cuda.synchronize()
+                    got = yd.cpu().numpy()
+                    lens = np.diff(rp)
+                    exact = lens <= 512  # rows longer than one LDS tile: tolerance only in the automatic mode (wavefront tree)
+                    assert np.array_equal(got[exact], yr[exact]), (avg, k, call)
+                    scale = np.add.reduceat(np.abs(v * x[ci]), rp[:-1][lens > 0])
+                    err = np.abs(got - yr)[lens > 0]
+                    assert np.all(err <= (lens[lens > 0] + 16) * EPS64 * scale), (avg, k, call)
+    finally:
+        L.aoclsparse_mi355_set_pointer_mode(P.PTR_AUTO)
