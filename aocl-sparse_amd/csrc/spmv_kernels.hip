@@ -131,7 +131,12 @@ __device__ __forceinline__ T block_sum(T v, T *scratch)
 //        loaded anyway (s_row), so each workgroup checks its own two boundaries for free; on a mismatch it computes its rows
 //        straight from the live arrays (same chains, no LDS tile) and raises *stale for the host's next call.  No check
 //        kernel, no stream round trip per call (round 3 paid ~70 us for one: 0.334 vs 0.262 ms on the 4096^2 Laplacian).
-template <typename T, int ORDER, int TILE, int BLOCK, bool TRACE = false>
+// VAR: 0 general; 1 strict long rows (the tile-by-tile chain of the longest rows keeps the next tile in registers); 2 every row of the
+// plan has <= 8 entries (stencils: no batched-read code, no long-row code).  Template parameters, not run-time flags: the register
+// allocation of a kernel is the maximum over ALL its paths, and the strict path's prefetch registers and the batched reads of
+// the general path had cost the 4096^2 Laplacian -- which uses neither -- a fifth of its speed (0.250 ms in round 1, 0.266 with
+// the batched reads, 0.330 with the strict prefetch: 96 VGPRs = 5 waves per SIMD; tools/exp_bisect_adaptive.py, profiles/r4).
+template <typename T, int ORDER, int TILE, int BLOCK, bool TRACE = false, int VAR = 0>
 __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restrict__ blocks,
                                                                   const aoclsparse_int *__restrict__ row_ptr,
                                                                   const aoclsparse_int *__restrict__ col,
@@ -318,6 +323,15 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restr
                 // once per entry: traced on the circuit-like stand-in (tools/spmv_trace.py), the entry-by-entry loop
                 // was 1.8 us of a workgroup's 5.4 us (rows of 1-15 entries: ~100 cycles of LDS latency per FMA)
                 int j = s;
+                if constexpr(VAR == 2)
+                {
+                    // every row is short: the plain loop (right for any length; the batched reads below read 14 LDS words for a
+                    // 5-entry row instead of 10)
+                    for(; j < e; j++)
+                        acc = dev_fma(s_val[j], s_x[j], acc);
+                }
+                else
+                {
                 if(e - j >= 9) // full batches: no clamps, no predicates on the chain.  Values and x's are read in PAIRS
                 {              // (one LDS instruction per entry instead of two: a lone wavefront issues an instruction
                                // every ~3.5 ns, so a 330-entry row was 6-7 us of reads + FMAs) and the reads of batch
@@ -379,15 +393,7 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restr
                         acc = dev_fma(a8[q], b8[q], acc);
                     j += 8;
                 }
-                if(flags & 16)
-                {
-                    // a matrix whose rows ALL have <= 8 entries (a stencil: this kernel then streams at HBM speed and the
-                    // reduction hides behind other workgroups' loads): the plain loop; the clamped batch below reads 14 LDS
-                    // words for a 5-entry row instead of 10 and cost the 4096^2 Laplacian 6 % (0.285 vs 0.268 ms)
-                    for(; j < e; j++)
-                        acc = dev_fma(s_val[j], s_x[j], acc);
-                }
-                else if(j < e) // the last 1..7 entries: one clamped batch
+                if(j < e) // the last 1..7 entries: one clamped batch
                 {
                     T a[7], b[7];
 #pragma unroll
@@ -401,6 +407,7 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restr
                     for(int q = 0; q < 7; q++)
                         acc = j + q < e ? dev_fma(a[q], b[q], acc) : acc;
                 }
+                } // VAR != 2
                 store_y(&y[r], finish(acc, alpha, beta, &y[r]), flags);
             }
             else
@@ -420,11 +427,11 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restr
             }
         }
     }
-    else
+    else if constexpr(VAR != 2) // (a plan whose rows all have <= 8 entries holds no block of more than TILE entries)
     {
         // ---- long row: this workgroup owns the single row r0 ---------------------------------------------
         const int n = cnt;
-        if(flags & 1)
+        if constexpr(VAR == 1)
         {
             // Tiles through LDS, the owner lanes chain them in the reference's order.  Round 3: the NEXT tile's values and x
             // are requested (into registers) before the owner lanes start on the current one, and the chain reads LDS in
@@ -605,7 +612,7 @@ aoclsparse_status launch_dot(hipStream_t s, aoclsparse_int n, const T *x, const 
     return aoclsparse_status_success;
 }
 
-template <typename T, int ORDER, int TILE, int BLOCK>
+template <typename T, int ORDER, int TILE, int BLOCK, int VAR>
 static void launch_inst(hipStream_t s, int flags, int base, T alpha, const T *val, const aoclsparse_int *col,
                         const aoclsparse_int *row_ptr, const aoclsparse_int *blocks, aoclsparse_int nblocks,
                         const T *x, T beta, T *y, const aoclsparse_int *blocks4, unsigned int *stale)
@@ -620,7 +627,7 @@ static void launch_inst(hipStream_t s, int flags, int base, T alpha, const T *va
     if constexpr(ORDER == 0) // the traced build exists for the scalar order only
     {
         if(trace)
-            hipLaunchKernelGGL((csr_adaptive_kernel<T, ORDER, TILE, BLOCK, true>), dim3(grid), dim3(BLOCK), 0, s,
+            hipLaunchKernelGGL((csr_adaptive_kernel<T, ORDER, TILE, BLOCK, true, VAR>), dim3(grid), dim3(BLOCK), 0, s,
                                reinterpret_cast<const int2 *>(blocks), row_ptr, col, val, x, y, alpha, beta, base,
                                (int)nblocks, chunk, flags, trace, reinterpret_cast<const int4 *>(blocks4), stale);
     }
@@ -630,7 +637,7 @@ static void launch_inst(hipStream_t s, int flags, int base, T alpha, const T *va
         trace = nullptr;
     }
     if(!(ORDER == 0 && trace))
-        hipLaunchKernelGGL((csr_adaptive_kernel<T, ORDER, TILE, BLOCK>), dim3(grid), dim3(BLOCK), 0, s,
+        hipLaunchKernelGGL((csr_adaptive_kernel<T, ORDER, TILE, BLOCK, false, VAR>), dim3(grid), dim3(BLOCK), 0, s,
                            reinterpret_cast<const int2 *>(blocks), row_ptr, col, val, x, y, alpha, beta, base,
                            (int)nblocks, chunk, flags, (unsigned long long *)nullptr, reinterpret_cast<const int4 *>(blocks4), stale);
     if(trace)
@@ -666,15 +673,20 @@ aoclsparse_status launch_csrmv(hipStream_t s, int order, bool strict, int tile, 
         flags |= 4;
     if((size_t)m * sizeof(T) > (size_t)32 << 20)
         flags |= 8;
-    if(max_row_nnz <= 8)
-        flags |= 16; // every row is short: the entry-by-entry reduction (see the kernel; a plain loop, right for any length)
+    // kernel variant (template parameter VAR): strict long rows / every row short (stencils) / general
+    const int var = strict ? 1 : (max_row_nnz <= 8 ? 2 : 0);
     if(stale)
         flags |= 32; // the block table is a cached plan of a raw-array call: every workgroup validates its own entry
     const int tsel = tile == 512 ? 0 : (tile == 1024 ? 1 : (tile == 2048 ? 2 : -1));
     if(tsel < 0 || order < 0 || order > 2)
         return aoclsparse_status_invalid_kid;
-#define MI355_CASE(O, TL, BL)                                                                                 \
-    launch_inst<T, O, TL, BL>(s, flags, base, alpha, val, col, row_ptr, blocks, nblocks, x, beta, y, blocks4, stale); \
+#define MI355_CASE(O, TL, BL)                                                                                                \
+    if(var == 1)                                                                                                             \
+        launch_inst<T, O, TL, BL, 1>(s, flags, base, alpha, val, col, row_ptr, blocks, nblocks, x, beta, y, blocks4, stale); \
+    else if(var == 2)                                                                                                        \
+        launch_inst<T, O, TL, BL, 2>(s, flags, base, alpha, val, col, row_ptr, blocks, nblocks, x, beta, y, blocks4, stale); \
+    else                                                                                                                     \
+        launch_inst<T, O, TL, BL, 0>(s, flags, base, alpha, val, col, row_ptr, blocks, nblocks, x, beta, y, blocks4, stale); \
     break
     switch(order * 3 + tsel)
     {

@@ -10,6 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 PY=/usr/bin/python3
 # 1. the default bench line, exactly as the driver runs it
 $PY $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+cp $R/bench_legs.json $OUT/bench_legs_default.json   # the full report of the same run (stdout carries the short record only)
 # 2. headline kernel alone (same timed region; the un-timed legs are dropped): kernel trace + stats, then HBM traffic
 SPMV="--steps 100 --warmup 10 --legs none"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o spmv -- $PY $R/bench.py $SPMV > $OUT/bench_under_rocprof_trace.json 2> $OUT/trace.err
@@ -18,6 +19,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write 
 # 3. the other configs' kernels: csrmm (both layouts, 256 and 32 columns), the mix, TRSV, raw dcsrmv -- stats, then traffic
 LEGS="--steps 20 --warmup 3 --legs dcsrmv_csr_adaptive,mix,csrmm,trsv"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/legs_trace -o legs -- $PY $R/bench.py $LEGS > $OUT/bench_legs_under_rocprof.json 2> $OUT/legs_trace.err
+cp $R/bench_legs.json $OUT/bench_legs_under_rocprof_full.json
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/legs_fetch -o legs -- $PY $R/bench.py $LEGS > /dev/null 2> $OUT/legs_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/legs_write -o legs -- $PY $R/bench.py $LEGS > /dev/null 2> $OUT/legs_write.err
 # 3b. secondary measurements (stand-in csrmm, TRSV schedules, CG, section-8f rows, PCIe-inclusive rates with and without
