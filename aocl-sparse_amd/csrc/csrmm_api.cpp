@@ -638,15 +638,17 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
             return st;
     }
     const bool windowed = colmaj && p && p->mm.win && csrmm_window_applies<T>(n, ldb, static_cast<const T *>(dB));
-    const bool detour   = colmaj && !windowed && n >= 16 && (long long)d->nnz > (long long)CM_DETOUR_NNZ_PER_ROW * d->m;
+    // block-dense matrix: the blocked-ELL copy for the MFMA kernels (either layout)
     // (a second copy of the matrix: not under aoclsparse_memory_usage_minimal, which forbids such copies -- analysis.cpp:446)
-    if(p && (!colmaj || detour) && !p->bell.tried && A->mem_policy == aoclsparse_memory_usage_unrestricted)
+    if(p && !windowed && !p->bell.tried && A->mem_policy == aoclsparse_memory_usage_unrestricted)
     {
         std::unique_lock<std::shared_mutex> w(A->guard);
         st = build_bell(tr ? *A->trans : A->user, *p, vt);
         if(st != aoclsparse_status_success)
             return st;
     }
+    const bool on_mfma_col = colmaj && !windowed && p && p->bell.valid && std::is_same<T, double>::value;
+    const bool detour = colmaj && !windowed && !on_mfma_col && n >= 16 && (long long)d->nnz > (long long)CM_DETOUR_NNZ_PER_ROW * d->m;
     if(p && (!colmaj || detour) && !p->bell.valid && !p->mm.tried)
     {
         std::unique_lock<std::shared_mutex> w(A->guard);
@@ -661,7 +663,7 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
         if(st != aoclsparse_status_success)
             return st;
     }
-    if(p && colmaj && !detour && !windowed && !p->mm.pairs_tried)
+    if(p && colmaj && !detour && !windowed && !on_mfma_col && !p->mm.pairs_tried)
     {
         std::unique_lock<std::shared_mutex> w(A->guard);
         st = detect_pairs(tr ? *A->trans : A->user, *p);
@@ -698,16 +700,7 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
                 st = launch_relayout<T>(rt.stream(), true, static_cast<const T *>(dB), static_cast<T *>(bt), b_rows, n, ldb);
             if(st == aoclsparse_status_success)
                 st = launch_relayout<T>(rt.stream(), true, static_cast<const T *>(dC), static_cast<T *>(ct), m_c, n, ldc);
-            bool on_mfma = false;
-            if constexpr(std::is_same<T, double>::value)
-                if(st == aoclsparse_status_success && p && p->bell.valid)
-                {
-                    // block-dense matrix: the blocked-ELL copy on the matrix cores (row-major scratch operands)
-                    st = launch_csrmm_bell(rt.stream(), alpha, d->m, d->n, p->bell, static_cast<const double *>(bt), n, n, beta,
-                                           static_cast<double *>(ct), n);
-                    on_mfma = true;
-                }
-            if(st == aoclsparse_status_success && !on_mfma)
+            if(st == aoclsparse_status_success)
                 st = launch_csrmm<T>(rt.stream(), aoclsparse_order_row, d->base, alpha, d->m, d->n, d->val.as<T>(),
                                      d->ind.as<aoclsparse_int>(), d->ptr.as<aoclsparse_int>(), static_cast<const T *>(bt),
                                      n, n, beta, static_cast<T *>(ct), n, grp, ngrp, grouped ? p->mm.max_rows : 0);
@@ -727,6 +720,13 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
             st = launch_csrmm_tiled<T>(rt.stream(), d->base, alpha, d->val.as<T>(), d->ind.as<aoclsparse_int>(),
                                        d->ptr.as<aoclsparse_int>(), p->rowblocks.as<aoclsparse_int>(), p->nblocks, p->tile,
                                        p->max_row_nnz, static_cast<const T *>(dB), n, ldb, beta, static_cast<T *>(dC), ldc);
+        else if(on_mfma_col)
+        {
+            // block-dense matrix, column-major operands: the transposed MFMA product, C stored in 128-byte column segments
+            if constexpr(std::is_same<T, double>::value)
+                st = launch_csrmm_bell(rt.stream(), alpha, d->m, d->n, p->bell, static_cast<const double *>(dB), n, ldb, beta,
+                                       static_cast<double *>(dC), ldc, /*column_major=*/true);
+        }
         else if(windowed)
             // column-major operands, banded matrix: each B column's stretch staged in LDS, rows' entries in registers
             st = launch_csrmm_window<T>(rt.stream(), d->base, alpha, d->m, d->val.as<T>(), d->ind.as<aoclsparse_int>(),

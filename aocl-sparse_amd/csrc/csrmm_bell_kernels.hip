@@ -23,7 +23,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstddef>
+#include <cstdlib>
 #include <cstdint>
 
 namespace mi355
@@ -173,16 +175,220 @@ namespace
                 }
             }
     }
+    // 4 x 4 transpose between the four 16-lane rows of a wavefront and four registers: lane row a, register b holds M[a][b] on
+    // entry and M[b][a] on return.  Two butterfly stages of the gfx950 swap instructions: v_permlane32_swap (lanes 32..63 of the
+    // first operand <-> lanes 0..31 of the second) on registers (b, b+2), then v_permlane16_swap (odd rows of the first <-> even
+    // rows of the second) on registers (0, 1) and (2, 3).
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    template <bool HALF32>
+    __device__ __forceinline__ void swap_rows(double &x, double &y)
+    {
+        const unsigned long long xb = __builtin_bit_cast(unsigned long long, x), yb = __builtin_bit_cast(unsigned long long, y);
+        v2u lo, hi;
+        if constexpr(HALF32)
+        {
+            lo = __builtin_amdgcn_permlane32_swap((unsigned)xb, (unsigned)yb, false, false);
+            hi = __builtin_amdgcn_permlane32_swap((unsigned)(xb >> 32), (unsigned)(yb >> 32), false, false);
+        }
+        else
+        {
+            lo = __builtin_amdgcn_permlane16_swap((unsigned)xb, (unsigned)yb, false, false);
+            hi = __builtin_amdgcn_permlane16_swap((unsigned)(xb >> 32), (unsigned)(yb >> 32), false, false);
+        }
+        x = __builtin_bit_cast(double, ((unsigned long long)hi.x << 32) | lo.x);
+        y = __builtin_bit_cast(double, ((unsigned long long)hi.y << 32) | lo.y);
+    }
+    __device__ __forceinline__ void transpose_rows_regs(double (&m)[4])
+    {
+        swap_rows<true>(m[0], m[2]);
+        swap_rows<true>(m[1], m[3]);
+        swap_rows<false>(m[0], m[1]);
+        swap_rows<false>(m[2], m[3]);
+    }
+
+    // ---- column-major operands (the layout the multi-GPU column shards are contiguous in) ------------------------------------
+    // The same blocks, the same fragments, the roles of the two MFMA operands swapped: D' = (B^T tile) x (A^T block), a 16 x 16 tile
+    // of C^T whose FIRST index is the column j and whose second is the row i -- so the lanes of a result register hold 16
+    // consecutive rows of one column, contiguous in a column-major C (128-byte segments).  Element (k, j) of the B operand is
+    // B[j * ldb + k]: fragment t of lane (j, kq) is the double at k = 16 bc + 4 t + kq of column j.  Loading it that way reads 16
+    // columns x 32 bytes per instruction (2.70 ms at 256 columns, against 1.39 row-major); WIDE: lane (j, a) loads the 32
+    // CONTIGUOUS bytes k = 16 bc + 4 a .. + 3 of its column (two 16-byte loads: whole 128-byte lines per column and instruction)
+    // and the four values are transposed between lane rows and registers (transpose_rows_regs).  The chain per element is unchanged
+    // (k = 4t .. 4t+3 in order, blocks ascending): the same bits as the row-major kernel and as the reference.
+    template <int NT, bool RC, bool FULL, bool WIDE>
+    __global__ __launch_bounds__(256) void csrmm_bell_mfma_col_kernel(double alpha, aoclsparse_int m, aoclsparse_int k, aoclsparse_int nbr,
+                                                                      aoclsparse_int width, const double *__restrict__ val,
+                                                                      const aoclsparse_int *__restrict__ bcol,
+                                                                      const double *__restrict__ B, aoclsparse_int n, aoclsparse_int ldb,
+                                                                      double beta, double *__restrict__ C, aoclsparse_int ldc,
+                                                                      int waves_per_row, bool readc)
+    {
+        const int  wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const long g  = (long)blockIdx.x * 4 + wv;
+        const int  br = (int)(g / waves_per_row), cw = (int)(g % waves_per_row);
+        if(br >= nbr)
+            return;
+        const int lane = threadIdx.x & 63, jl = lane & 15, kq = lane >> 4;
+        const int j0   = cw * NT * 16;
+        v4d       acc[NT];
+#pragma unroll
+        for(int u = 0; u < NT; u++)
+            acc[u] = (v4d){0.0, 0.0, 0.0, 0.0};
+        const v4d zero4 = (v4d){0.0, 0.0, 0.0, 0.0};
+        // result register r of this lane: index of the FIRST operand's row (here: the column j) and of the second's column (the row i)
+        const v4d dfirst  = __builtin_amdgcn_mfma_f64_16x16x4f64(kq == 0 ? (double)jl : 0.0, kq == 0 ? 1.0 : 0.0, zero4, 0, 0, 0);
+        const v4d dsecond = __builtin_amdgcn_mfma_f64_16x16x4f64(kq == 0 ? 1.0 : 0.0, kq == 0 ? (double)jl : 0.0, zero4, 0, 0, 0);
+        bool      colok[NT];
+#pragma unroll
+        for(int u = 0; u < NT; u++)
+            colok[u] = j0 + 16 * u + jl < n;
+        const double         *vb = val + (size_t)br * width * 256;
+        const aoclsparse_int *cb = bcol + (size_t)br * width;
+        int                   nblk = 0;
+        while(nblk < width && cb[nblk] >= 0)
+            nblk++;
+        auto fetch_a = [&](int s, double (&a)[4]) {
+            if(s >= nblk)
+            {
+                a[0] = a[1] = a[2] = a[3] = 0.0;
+                return;
+            }
+            const double *vs  = vb + (size_t)s * 256;
+            const v2d     a01 = *reinterpret_cast<const v2d *>(vs + 2 * lane), a23 = *reinterpret_cast<const v2d *>(vs + 128 + 2 * lane);
+            a[0] = a01.x, a[1] = a01.y, a[2] = a23.x, a[3] = a23.y;
+        };
+        // this lane's column of every tile: a 64-bit offset per tile (columns are ldb apart), + a wave-uniform row offset per block
+        size_t colbase[NT];
+#pragma unroll
+        for(int u = 0; u < NT; u++)
+            colbase[u] = (size_t)(colok[u] ? j0 + 16 * u + jl : 0) * (size_t)ldb + (size_t)(WIDE ? 4 * kq : kq);
+        auto fetch_b = [&](int s, double (&b)[NT][4]) {
+            if(s >= nblk)
+                return;
+            const int     bc = __builtin_amdgcn_readfirstlane(cb[s]);
+            const double *bs = B + (size_t)bc * 16;
+            if constexpr(WIDE)
+            {
+                // (k is a multiple of 4 here -- the launcher's condition -- so a lane's four rows are in or out together)
+                const bool rok = FULL || bc * 16 + 4 * kq < k;
+#pragma unroll
+                for(int u = 0; u < NT; u++)
+                {
+                    v2d p = (v2d){0.0, 0.0}, q = (v2d){0.0, 0.0};
+                    if(FULL || (rok && colok[u]))
+                    {
+                        p = *reinterpret_cast<const v2d *>(bs + colbase[u]);
+                        q = *reinterpret_cast<const v2d *>(bs + colbase[u] + 2);
+                    }
+                    b[u][0] = p.x, b[u][1] = p.y, b[u][2] = q.x, b[u][3] = q.y;
+                }
+            }
+            else
+            {
+#pragma unroll
+                for(int t = 0; t < 4; t++)
+                {
+                    const bool rok = FULL || bc * 16 + 4 * t + kq < k;
+#pragma unroll
+                    for(int u = 0; u < NT; u++)
+                        b[u][t] = (FULL || (rok && colok[u])) ? bs[colbase[u] + 4 * t] : 0.0;
+                }
+            }
+        };
+        auto mac = [&](const double (&a)[4], double (&b)[NT][4]) {
+            if constexpr(WIDE)
+            {
+#pragma unroll
+                for(int u = 0; u < NT; u++)
+                    transpose_rows_regs(b[u]); // (lane row a, register r) k = 4a + r  ->  k = 4r + a: the MFMA fragment
+            }
+#pragma unroll
+            for(int t = 0; t < 4; t++)
+#pragma unroll
+                for(int u = 0; u < NT; u++)
+                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[u][t], a[t], acc[u], 0, 0, 0);
+        };
+        double a0[4], a1[4], b0[NT][4], b1[NT][4];
+        fetch_a(0, a0);
+        fetch_b(0, b0);
+        for(int s = 0; s < nblk; s += 2)
+        {
+            fetch_a(s + 1, a1);
+            fetch_b(s + 1, b1);
+            mac(a0, b0);
+            if(s + 1 >= nblk)
+                break;
+            fetch_a(s + 2, a0);
+            fetch_b(s + 2, b0);
+            mac(a1, b1);
+        }
+#pragma unroll
+        for(int u = 0; u < NT; u++)
+#pragma unroll
+            for(int r = 0; r < 4; r++)
+            {
+                const int cj = j0 + 16 * u + (int)dfirst[r], row = br * 16 + (int)dsecond[r];
+                if(row < m && cj < n)
+                {
+                    double      *cp = C + (size_t)cj * ldc + row;
+                    const double z  = alpha * acc[u][r];
+                    if(RC || readc || z == 0.0)
+                        *cp = fma(beta, *cp, z);
+                    else
+                        __builtin_nontemporal_store(z, cp);
+                }
+            }
+    }
 } // namespace
 
 aoclsparse_status launch_csrmm_bell(hipStream_t s, double alpha, aoclsparse_int m, aoclsparse_int k, const BellPlan &bell,
                                     const double *B, aoclsparse_int n, aoclsparse_int ldb, double beta, double *C,
-                                    aoclsparse_int ldc)
+                                    aoclsparse_int ldc, bool column_major)
 {
     if(n <= 0 || m <= 0 || !bell.valid)
         return aoclsparse_status_success;
     const bool readc = csrmm_reads_c(beta != 0.0);
     const int  tiles = (n + 15) / 16;
+    if(column_major)
+    {
+        // tiles per wavefront: 2 (32 columns).  A column of B is its own 2 MB page at these sizes, so a wavefront touches one page
+        // per column and block; 1 / 2 / 3 / 4 tiles per wavefront at 256 columns: 2.06 / 1.90 / 1.89 / 2.31 ms with C read, 1.69 /
+        // 1.58 / 1.53 / 1.69 overwriting (profiles/r4/bell_experiments.txt); the 32-column slab 0.25 / 0.23 with 1 / 2
+        const int  nt = std::min(tiles, 2), wpr = (tiles + nt - 1) / nt;
+        const long waves = (long)bell.nbr * wpr;
+        const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+        const bool full = n % (16 * nt) == 0 && k % 16 == 0;
+        // 32 contiguous bytes per lane: 16-byte aligned columns (B aligned, ldb even) and a row count of B that is a multiple of 4
+        const bool wide = reinterpret_cast<uintptr_t>(B) % 16 == 0 && ldb % 2 == 0 && k % 4 == 0;
+#define MI355_BELLC(NT, FULL) MI355_BELLC2(NT, FULL, false)
+#define MI355_BELLC2(NT, FULL, WIDE)                                                                                                 \
+    do                                                                                                                          \
+    {                                                                                                                           \
+        if(readc)                                                                                                               \
+            hipLaunchKernelGGL((csrmm_bell_mfma_col_kernel<NT, true, FULL, WIDE>), grid, block, 0, s, alpha, m, k, bell.nbr, bell.width, \
+                               bell.val.as<double>(), bell.bcol.as<aoclsparse_int>(), B, n, ldb, beta, C, ldc, wpr, readc);      \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((csrmm_bell_mfma_col_kernel<NT, false, FULL, WIDE>), grid, block, 0, s, alpha, m, k, bell.nbr, bell.width, \
+                               bell.val.as<double>(), bell.bcol.as<aoclsparse_int>(), B, n, ldb, beta, C, ldc, wpr, readc);      \
+    } while(0)
+        if(wide)
+        {
+            if(nt == 2 && full)
+                MI355_BELLC2(2, true, true);
+            else if(nt == 2)
+                MI355_BELLC2(2, false, true);
+            else
+                MI355_BELLC2(1, false, true);
+        }
+        else if(nt == 2)
+            MI355_BELLC(2, false);
+        else
+            MI355_BELLC(1, false);
+#undef MI355_BELLC
+#undef MI355_BELLC2
+        MI355_HIP_TRY(hipGetLastError());
+        return aoclsparse_status_success;
+    }
     // 16-byte operand loads feed two tiles at once: 16-byte aligned B rows, an even column count
     const bool wide = tiles >= 2 && n % 2 == 0 && ldb % 2 == 0 && reinterpret_cast<uintptr_t>(B) % 16 == 0;
     // tiles per wavefront: 4 (64 columns) when there are that many, else what the slab has (an even count in wide mode)

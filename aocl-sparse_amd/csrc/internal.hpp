@@ -860,7 +860,7 @@ aoclsparse_status prepare_mm_plans(aoclsparse_matrix A);
 aoclsparse_status build_bell(const HostCsr &h, SpmvPlan &plan, aoclsparse_matrix_data_type vt);
 aoclsparse_status launch_csrmm_bell(hipStream_t s, double alpha, aoclsparse_int m, aoclsparse_int k, const BellPlan &bell,
                                     const double *B, aoclsparse_int n, aoclsparse_int ldb, double beta, double *C,
-                                    aoclsparse_int ldc);
+                                    aoclsparse_int ldc, bool column_major = false);
 // column-major, banded: a workgroup stages the stretch of a B column its rows can touch in LDS (csrmm_window_kernels.hip)
 int csrmm_window_rows(aoclsparse_int max_row_nnz, size_t elem); // rows per workgroup the kernel will use
 int csrmm_window_max_pieces(); // 16-byte pieces a window may hold

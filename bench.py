@@ -268,6 +268,8 @@ def leg_numbers(full):
         b = mm["blocked"]
         n["csrmm_blocked_mfma_ms"] = b.get("mfma_ms")
         n["csrmm_blocked_best_other_ms"] = b.get("best_other_ms")
+        n["csrmm_blocked_mfma_col_ms"] = b.get("mfma_col_ms")
+        n["csrmm_blocked_mfma_col_eff8"] = b.get("mfma_col_eff8")
         n["csrmm_blocked_parity"] = b.get("parity_ok")
     tr = legs.get("trsv") or {}
     if tr.get("schedules"):
@@ -986,13 +988,35 @@ def main():
                              "roofline": roofline(csrmm_bytes(mb, mb, nz, ncols, True), ms),
                              "bit_exact_4_columns": bool(np.array_equal(got, Cr))}
                 del Ab
+            # the same matrix with column-major operands (the layout the column shards are contiguous in): all columns and the
+            # 32-column slab of an 8-rank run -> the projected efficiency of configs[3]'s "blocked-ELL MFMA tiles, B column-sharded"
+            Ab = pkg.Matrix(0, mb, mb, rp, ci, v)
+            assert L.aoclsparse_set_mm_hint(Ab.h, pkg.OP_NONE, descr.h, 100) == 0 and L.aoclsparse_optimize(Ab.h) == 0
+            j0, j1 = column_shard(ncols, 8, 0)
+            for nc, tag in ((ncols, "mfma_col"), (j1 - j0, "mfma_col_slab")):
+                Bc = sharded.make_B_slab(torch, device, mb, 0, nc, "col")
+                Cc = torch.zeros(mb * nc, dtype=torch.float64, device=device)
+                call = lambda: pkg.dcsrmm(pkg.OP_NONE, 1.0, Ab, descr, pkg.ORDER_COLUMN, Bc, nc, mb, 0.0, Cc, mb)
+                assert call() == 0
+                lp = timed_laps(pkg, call, 10, 2)
+                torch.cuda.synchronize()
+                ms = float(np.mean(lp))
+                got = Cc.reshape(nc, mb)[:4].cpu().numpy().reshape(-1)
+                ent[tag] = {"ms": round(ms, 5), "ncols": nc, "tflops": round(2.0 * nz * nc / ms / 1e9, 2),
+                            "bit_exact_4_columns": bool(np.array_equal(got, Cr))}
+                del Bc, Cc
+            ent["mfma_col_eff8"] = _eff8(ent["mfma_col"]["ms"], ent["mfma_col_slab"]["ms"])
+            del Ab
             ent["mfma_selected_by_optimize"] = ent["mfma"]["bell_width"] > 0 and ent["csr"]["bell_width"] == 0
             ent["speedup"] = round(ent["csr"]["ms"] / ent["mfma"]["ms"], 3)
             out["cases"].append(ent)
             del Bd, Cd
         out["mfma_ms"] = out["cases"][0]["mfma"]["ms"]
         out["best_other_ms"] = out["cases"][0]["csr"]["ms"]
-        out["parity_ok"] = all(c["mfma"]["bit_exact_4_columns"] and c["csr"]["bit_exact_4_columns"] for c in out["cases"])
+        out["mfma_col_ms"] = out["cases"][0]["mfma_col"]["ms"]
+        out["mfma_col_eff8"] = out["cases"][0]["mfma_col_eff8"]
+        out["parity_ok"] = all(c["mfma"]["bit_exact_4_columns"] and c["csr"]["bit_exact_4_columns"] and c["mfma_col"]["bit_exact_4_columns"]
+                               and c["mfma_col_slab"]["bit_exact_4_columns"] for c in out["cases"])
         out["fp64_mfma_peak_tflops"] = 78.6
         return out
 

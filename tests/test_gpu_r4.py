@@ -251,7 +251,8 @@ def test_csrmm_blocked_ell_mfma_bit_exact(keep):
     copy from aoclsparse_optimize (mm hint) and runs on v_mfma_f64_16x16x4_f64.  The instruction accumulates k upwards as one FMA
     chain per element, so the result must equal oracle.dcsrmm (csrmm.hpp:36-90) BIT FOR BIT: row-major with column counts that are
     and are not multiples of the 16-column tile, padded leading dimensions, alpha / beta classes and both beta = 0 modes, a row
-    count and a column count that are not multiples of 16, and column-major operands (through the row-major scratch copy)."""
+    count and a column count that are not multiples of 16, and column-major operands (the transposed product: D' = B^T A^T, C stored in column
+    segments)."""
     m0, rp0, ci0, v0 = standins.block_dense(6, 5, 4, keep=keep, seed=9)
     for mm, kk in ((m0, m0), (m0 - 5, m0 - 9)):
         rp, ci, v = (rp0, ci0, v0) if mm == m0 else _submatrix(m0, rp0, ci0, v0, mm, kk)
@@ -282,15 +283,21 @@ def test_csrmm_blocked_ell_mfma_bit_exact(keep):
                 got = Cd.cpu().numpy().reshape(mm, ldc)
                 assert _same_bits(got[:, :n], ref), (keep, mm, n, ldb, ldc, alpha, beta, overwrite)
                 assert np.array_equal(got[:, n:], C0.reshape(mm, ldc)[:, n:])  # padding untouched
-        # column-major operands: copied to row-major scratch, the same kernel, copied back
-        n = 48
-        B = rng.uniform(-1, 1, kk * n)
-        C0 = rng.uniform(-1, 1, mm * n)
-        so, Cr = oracle.dcsrmm("col", 1.5, 0, v, ci, rp, mm, B, n, kk, 0.5, C0, mm)
-        Cd = dev(C0)
-        assert P.dcsrmm(P.OP_NONE, 1.5, A, d, P.ORDER_COLUMN, dev(B), n, kk, 0.5, Cd, mm) == 0
-        torch.cuda.synchronize()
-        assert _same_bits(Cd.cpu().numpy(), Cr)
+        # column-major operands: the transposed MFMA product (csrmm_bell_mfma_col_kernel), C stored in column segments
+        for n, ldb, ldc, alpha, beta in ((64, kk, mm, 1.0, 0.0), (48, kk + 3, mm + 5, 1.5, 0.5), (21, kk, mm, -1.0, 0.0), (7, kk + 1, mm, 1.0, 2.0)):
+            B = rng.uniform(-1, 1, ldb * n)
+            C0 = rng.uniform(-1, 1, ldc * n)
+            so, Cr = oracle.dcsrmm("col", alpha, 0, v, ci, rp, mm, B, n, ldb, beta, C0, ldc)
+            assert so == 0
+            for overwrite in ((False, True) if beta == 0.0 else (False,)):
+                Cd = dev(C0)
+                assert L.aoclsparse_mi355_set_csrmm_beta0_overwrite(1 if overwrite else 0) == 0
+                try:
+                    assert P.dcsrmm(P.OP_NONE, alpha, A, d, P.ORDER_COLUMN, dev(B), n, ldb, beta, Cd, ldc) == 0
+                    torch.cuda.synchronize()
+                finally:
+                    assert L.aoclsparse_mi355_set_csrmm_beta0_overwrite(0) == 0
+                assert _same_bits(Cd.cpu().numpy(), Cr), (keep, mm, "col", n, ldb, ldc, alpha, beta, overwrite)
 
 
 def _blocks(m, rp, ci):
