@@ -113,18 +113,18 @@ def library_communicator(pkg, torch, dist, device, rank, world):
         return False
     L = pkg.lib()
     cid = pkg.CommId()
-    st = L.aoclsparse_mi355_comm_unique_id(cid) if rank == 0 else 0
-    wire = torch.zeros(129, dtype=torch.uint8, device=device)
+    # ncclCommInitRank blocks until EVERY rank has called it: first make sure every rank CAN (librccl loads, an id can be drawn --
+    # not a collective), and only then enter the collective
+    st = L.aoclsparse_mi355_comm_unique_id(cid)
+    if reduce_scalar(1.0 if st == 0 else 0.0, "min", dist, device) < 0.5:
+        return False
+    wire = torch.zeros(128, dtype=torch.uint8, device=device)
     if rank == 0:
-        wire[:128] = torch.frombuffer(bytearray(bytes(cid)), dtype=torch.uint8).to(device)
-        wire[128] = 1 if st == 0 else 0
-    dist.broadcast(wire, 0)
-    host = wire.cpu()
-    ok = bool(host[128].item())
-    if ok:
-        import ctypes
-        ctypes.memmove(ctypes.addressof(cid), bytes(host[:128].numpy().tobytes()), 128)
-        ok = L.aoclsparse_mi355_comm_init(world, rank, cid) == 0
+        wire.copy_(torch.frombuffer(bytearray(bytes(cid)), dtype=torch.uint8))
+    dist.broadcast(wire, 0)  # rank 0's id is the job's
+    import ctypes
+    ctypes.memmove(ctypes.addressof(cid), wire.cpu().numpy().tobytes(), 128)
+    ok = L.aoclsparse_mi355_comm_init(world, rank, cid) == 0
     ok = reduce_scalar(1.0 if ok else 0.0, "min", dist, device) > 0.5
     _LIB_COMM["ok"] = ok
     return ok

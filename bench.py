@@ -400,6 +400,9 @@ def main():
     ap.add_argument("--shard-grid", type=int, default=0,
                     help="grid of the row-sharded SpMV iteration leg; 0 = 4096*sqrt(N) (every rank keeps the headline's 16.8 M rows = "
                          "1.34 GB of matrix, well past the 256 MiB Infinity Cache, whatever N is); 2048 on one rank")
+    ap.add_argument("--shard-own-rows", action="store_true",
+                    help="row-sharded SpMV leg: every rank builds its own rows even with an explicit --shard-grid (the default for "
+                         "N > 1 without --shard-grid; lets a small test take the path the multi-GPU run takes)")
     ap.add_argument("--mm-layout", default="both", choices=["col", "row", "both"],
                     help="layout(s) of the sharded csrmm leg: column-major slabs are the contiguous ones (SURVEY.md 8e)")
     ap.add_argument("--dry-launch", action="store_true",
@@ -635,7 +638,7 @@ def main():
         # world > 1: every rank builds its own rows of a grid sized so that its share stays the headline's 1.34 GB whatever N is
         # (no rank ever holds all of A); one rank: a small grid through the broadcast-and-slice path (control flow only)
         sg = args.shard_grid or (int(4096 * math.sqrt(world)) if world > 1 else 2048)
-        own_rows = world > 1 and not args.shard_grid
+        own_rows = world > 1 and (not args.shard_grid or args.shard_own_rows)
         csr_s = None
         if not own_rows and rank == 0:
             ms_, rp_, ci_, v_ = entry.laplace5(sg)

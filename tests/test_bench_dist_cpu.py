@@ -273,3 +273,102 @@ def test_laplace5_rows_are_the_rows_of_laplace5():
         ml, n, rpl, cil, vl = entry.laplace5_rows(g, r0, r1)
         assert ml == r1 - r0 and n == m and rpl[0] == 0
         assert np.array_equal(rpl, rp[r0:r1 + 1] - rp[r0]) and np.array_equal(cil, ci[rp[r0]:rp[r1]]) and np.array_equal(vl, v[rp[r0]:rp[r1]])
+
+
+def test_library_communicator_control_flow_with_mocks():
+    """The "nccl" path of sharded.broadcast_handle (library RCCL communicator: id drawn on every rank as a loadability probe,
+    rank 0's id broadcast, collective init, broadcast_matrix, agreed fallback) cannot run with two ranks on a one-GPU box (RCCL
+    refuses two ranks on one GPU) and never runs on CPU.  Its CONTROL FLOW is executed here against mocks of torch.distributed
+    and of the library, once as rank 0 and once as rank 1, including the fallbacks: a rank that cannot load librccl must send
+    everybody down the torch.distributed path BEFORE anyone enters the blocking ncclCommInitRank."""
+    import ctypes
+    import torch
+
+    pkg = entry.load_package()
+    import aocl_sparse_amd.sharded as sharded
+
+    class FakeDist:
+        class ReduceOp:
+            MAX, SUM, MIN = "max", "sum", "min"
+
+        def __init__(self, others_ok=True):
+            self.others_ok, self.log = others_ok, []
+
+        def is_initialized(self):
+            return True
+
+        def get_backend(self):
+            return "nccl"
+
+        def get_world_size(self):
+            return 2
+
+        def barrier(self):
+            self.log.append("barrier")
+
+        def broadcast(self, t, src):
+            self.log.append(("broadcast", tuple(t.shape), src))
+
+        def all_reduce(self, t, op=None):
+            self.log.append(("all_reduce", op))
+            if op == "min" and not self.others_ok:
+                t.fill_(0.0)  # some other rank reported a failure
+
+    class FakeLib:
+        def __init__(self, load_ok=True):
+            self.load_ok, self.calls = load_ok, []
+
+        def aoclsparse_mi355_comm_unique_id(self, cid):
+            self.calls.append("unique_id")
+            return 0 if self.load_ok else 1
+
+        def aoclsparse_mi355_comm_init(self, world, rank, cid):
+            self.calls.append(("init", world, rank))
+            return 0
+
+        def aoclsparse_mi355_comm_broadcast_matrix(self, href, root):
+            self.calls.append(("broadcast_matrix", root))
+            ctypes.cast(href, ctypes.POINTER(ctypes.c_void_p))[0] = ctypes.c_void_p(0x1234)
+            return 0
+
+        def aoclsparse_mi355_synchronize(self):
+            return 0
+
+    class FakeMatrix:
+        def __init__(self, h):
+            self.h = h
+
+        @classmethod
+        def from_handle(cls, h, double=True):
+            return cls(h)
+
+    class FakePkg:
+        CommId, MM_STATE_BUFFERS, STATUS, MmState = pkg.CommId, pkg.MM_STATE_BUFFERS, pkg.STATUS, pkg.MmState
+        Matrix = FakeMatrix
+
+        def __init__(self, lib):
+            self._lib = lib
+
+        def lib(self):
+            return self._lib
+
+    for rank in (0, 1):
+        sharded._LIB_COMM.update(tried=False, ok=False)
+        lib, dist = FakeLib(), FakeDist()
+        A = FakeMatrix(ctypes.c_void_p(0x1234)) if rank == 0 else None
+        out, ms, how = sharded.broadcast_handle(FakePkg(lib), torch, dist, "cpu", rank, 2, A)
+        assert "library RCCL communicator" in how and out.h.value == 0x1234 and ms >= 0
+        assert lib.calls == ["unique_id", ("init", 2, rank), ("broadcast_matrix", 0)]
+        assert ("broadcast", (128,), 0) in dist.log
+        assert sharded._LIB_COMM == {"tried": True, "ok": True}
+        # the communicator is set up once per process
+        lib.calls.clear()
+        sharded.broadcast_handle(FakePkg(lib), torch, dist, "cpu", rank, 2, A)
+        assert lib.calls == [("broadcast_matrix", 0)]
+    # a rank that cannot load librccl: nobody calls comm_init (it would block the others forever)
+    for load_ok, others_ok in ((False, True), (True, False)):
+        sharded._LIB_COMM.update(tried=False, ok=False)
+        lib, dist = FakeLib(load_ok), FakeDist(others_ok)
+        assert sharded.library_communicator(FakePkg(lib), torch, dist, "cpu", 1, 2) is False
+        assert lib.calls == ["unique_id"] and sharded._LIB_COMM == {"tried": True, "ok": False}
+    sharded._LIB_COMM.update(tried=False, ok=False)

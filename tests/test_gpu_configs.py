@@ -236,6 +236,16 @@ def test_bench_gpus_2_starts_its_own_ranks(tmp_path):
     assert r.returncode == 0, "rc=%d\nstdout:\n%s\nstderr:\n%s" % (r.returncode, r.stdout[-3000:], r.stderr[-3000:])
     short, res = _bench_record(r.stdout, rec)
     _check_two_rank_record(short, res, own_rows=False)
+    # the row-sharded SpMV leg as the multi-GPU run takes it: every rank builds ITS rows, no rank holds the whole matrix
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "5", "--warmup", "2",
+                        "--grid", "512", "--shard-grid", "301", "--shard-own-rows", "--legs", "spmv_row_sharded", "--record", rec],
+                       cwd=ROOT, env=dict(env, OMP_NUM_THREADS="4"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, "rc=%d\nstdout:\n%s\nstderr:\n%s" % (r.returncode, r.stdout[-3000:], r.stderr[-3000:])
+    short, res = _bench_record(r.stdout, rec)
+    sp = res["spmv_row_sharded"]
+    assert "error" not in sp, sp
+    assert sp["world"] == 2 and sp["m"] == 90601 and sp["rows_per_rank"] == 45300 and sp["nnz"] == 5 * 90601 - 4 * 301
+    assert sp["parity"]["bit_exact"] is True and "each rank builds its own rows" in sp["workload"]
     # with RCCL two ranks cannot share the one GPU: the child fails and the parent must report that, not a record
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--grid", "256",
                         "--legs", "none", "--record", ""], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
