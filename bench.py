@@ -59,6 +59,8 @@ os.environ.setdefault("OMP_PROC_BIND", "close")
 os.environ.setdefault("OMP_PLACES", "cores")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_MFMA_PEAK_TFLOPS = 78.6  # dense fp64 matrix peak of the part (= its fp64 vector rate: 256 CUs x 128 flop/clk x 2.4 GHz)
+FP64_MFMA_SUSTAINED_TFLOPS = 47.7  # back-to-back v_mfma_f64_16x16x4_f64, measured (profiles/r4/mfma_f64_peak.jsonl)
 
 
 # ---- pure helpers (unit-tested on CPU with gloo, tests/test_bench_dist_cpu.py) -------------------
@@ -986,7 +988,15 @@ def main():
                 inf = Ab.spmv_info()
                 ms = float(np.mean(lp))
                 got = Cd.reshape(mb, ncols)[:, :4].t().contiguous().cpu().numpy().reshape(-1)
-                ent[kind] = {"ms": round(ms, 5), "tflops": round(2.0 * nz * ncols / ms / 1e9, 2),
+                tf = 2.0 * nz * ncols / ms / 1e9
+                ent[kind] = {"ms": round(ms, 5), "tflops": round(tf, 2),
+                             # the bound of the MFMA kernel is the matrix pipe, not HBM: dense fp64 MFMA peak of the part (spec) and
+                             # what back-to-back v_mfma_f64_16x16x4_f64 sustains on it (tools/mfma_f64_peak.hip,
+                             # profiles/r4/mfma_f64_peak.jsonl: 47.7 TFLOP/s with >= 2 wavefronts per SIMD)
+                             "roofline_mfma": {"bound": "mfma", "achieved": round(tf, 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                               "frac": round(tf / FP64_MFMA_PEAK_TFLOPS, 4),
+                                               "sustained_back_to_back": FP64_MFMA_SUSTAINED_TFLOPS,
+                                               "frac_of_sustained": round(tf / FP64_MFMA_SUSTAINED_TFLOPS, 4)} if kind == "mfma" else None,
                              "bell_width": int(inf.mm_bell_width), "tile_fill": inf.mm_bell_fill_permille / 1000.0,
                              "roofline": roofline(csrmm_bytes(mb, mb, nz, ncols, True), ms),
                              "bit_exact_4_columns": bool(np.array_equal(got, Cr))}
@@ -1020,7 +1030,8 @@ def main():
         out["mfma_col_eff8"] = out["cases"][0]["mfma_col_eff8"]
         out["parity_ok"] = all(c["mfma"]["bit_exact_4_columns"] and c["csr"]["bit_exact_4_columns"] and c["mfma_col"]["bit_exact_4_columns"]
                                and c["mfma_col_slab"]["bit_exact_4_columns"] for c in out["cases"])
-        out["fp64_mfma_peak_tflops"] = 78.6
+        out["fp64_mfma_peak_tflops"] = FP64_MFMA_PEAK_TFLOPS
+        out["fp64_mfma_sustained_tflops"] = FP64_MFMA_SUSTAINED_TFLOPS
         return out
 
     run_leg("csrmm", leg_csrmm)
