@@ -146,6 +146,20 @@ namespace
         double a0[4], a1[4], b0[NT][4], b1[NT][4];
         fetch_a(0, a0);
         fetch_b(0, b0);
+        // C is read (beta != 0, or the reference's 0 * C): requested behind the first block's operands, used after the last
+        // block's MFMAs -- the closing read-modify-write does not add a dependent round trip per block row
+        double cin[NT][4];
+        if constexpr(RC)
+        {
+#pragma unroll
+            for(int u = 0; u < NT; u++)
+#pragma unroll
+                for(int r = 0; r < 4; r++)
+                {
+                    const int row = br * 16 + (int)drow[r], cj = colof(u, (int)dcol[r]);
+                    cin[u][r]     = (row < m && cj < n) ? C[(size_t)row * ldc + cj] : 0.0;
+                }
+        }
         for(int s = 0; s < nblk; s += 2)
         {
             fetch_a(s + 1, a1);
@@ -168,7 +182,9 @@ namespace
                 {
                     double      *cp = C + (size_t)row * ldc + cj;
                     const double z  = alpha * acc[u][r];
-                    if(RC || readc || z == 0.0)
+                    if constexpr(RC)
+                        *cp = fma(beta, cin[u][r], z);
+                    else if(readc || z == 0.0)
                         *cp = fma(beta, *cp, z);
                     else
                         __builtin_nontemporal_store(z, cp);
