@@ -495,3 +495,92 @@ def test_raw_dcsrmv_stale_plan_is_caught_inside_the_kernel(avg):
                     assert np.all(err <= (lens[lens > 0] + 16) * EPS64 * scale), (avg, k, call)
     finally:
         L.aoclsparse_mi355_set_pointer_mode(P.PTR_AUTO)
+
+
+# --------------------------------------------------------------------------------------------------
+# randomized sweeps of the round-4 kernels (seeded; every case bit for bit against the oracle)
+# --------------------------------------------------------------------------------------------------
+def test_window_and_blocked_kernels_randomized_sweep():
+    """Random banded matrices (band offsets, row lengths 0..12, base 0 / 1, m off the workgroup size) with column-major operands --
+    the LDS-window kernel where the plan applies, the lane-per-row kernels where it does not -- in both operations (op = T runs
+    on the handle's A^T copy and ITS window plan), random column counts / leading dimensions / alpha / beta; and random
+    block-dense matrices (block pattern, fill 0.55..1, m and k off the tile size) in both layouts on the MFMA kernels.
+    oracle.dcsrmm (csrmm_col_major_ref) is the reference in every case."""
+    rng = np.random.default_rng(20260404)
+    used_window = used_bell = 0
+    for case in range(10):
+        m = int(rng.integers(8200, 21000))
+        g = int(rng.integers(3, 900))
+        offs = sorted(set([0, -1, 1, -g, g] + [int(o) for o in rng.integers(-g, g + 1, size=int(rng.integers(0, 5)))]))
+        base = int(rng.integers(0, 2))
+        rows, cols = [], []
+        lens = np.zeros(m, np.int64)
+        keep_p = rng.uniform(0.6, 1.0)
+        for o in offs:
+            r = np.arange(max(0, -o), min(m, m - o))
+            r = r[rng.random(len(r)) < keep_p]
+            rows.append(r), cols.append(r + o)
+        rows, cols = np.concatenate(rows), np.concatenate(cols)
+        order = np.lexsort((cols, rows))
+        rows, cols = rows[order], cols[order]
+        rp = np.zeros(m + 1, np.int64)
+        np.add.at(rp, rows + 1, 1)
+        rp = np.cumsum(rp)
+        v = rng.uniform(-1, 1, len(cols))
+        rp32, ci32 = (rp + base).astype(np.int32), (cols + base).astype(np.int32)
+        A = P.Matrix(base, m, m, rp32, ci32, v)
+        d = P.Descr(base=base)
+        for op, opname in ((P.OP_NONE, "n"), (P.OP_TRANSPOSE, "t")):
+            n = int(rng.integers(4, 90))
+            ldb, ldc = m + 2 * int(rng.integers(0, 3)), m + int(rng.integers(0, 4))
+            alpha, beta = float(rng.choice([1.0, -0.5, 2.25])), float(rng.choice([0.0, 0.0, 1.0, -1.5]))
+            B, C0 = rng.uniform(-1, 1, ldb * n), rng.uniform(-1, 1, ldc * n)
+            if op == P.OP_NONE:
+                so, Cr = oracle.dcsrmm("col", alpha, base, v, ci32, rp32, m, B, n, ldb, beta, C0, ldc)
+            else:  # the reference transposes A and runs the same kernel (csrmm.hpp:690-760): the oracle on A^T
+                import scipy.sparse as sp
+                At = sp.csr_matrix((v, cols, rp), shape=(m, m)).T.tocsr()
+                At.sort_indices()
+                so, Cr = oracle.dcsrmm("col", alpha, base, At.data, (At.indices + base).astype(np.int32),
+                                       (At.indptr + base).astype(np.int32), m, B, n, ldb, beta, C0, ldc)
+            assert so == 0
+            Cd = dev(C0)
+            assert P.dcsrmm(op, alpha, A, d, P.ORDER_COLUMN, dev(B), n, ldb, beta, Cd, ldc) == 0
+            torch.cuda.synchronize()
+            assert _same_bits(Cd.cpu().numpy(), Cr), (case, opname, m, g, offs, n, ldb, ldc, alpha, beta, base)
+        used_window += A.spmv_info().mm_window_rows > 0
+    assert used_window >= 5, used_window
+    for case in range(6):
+        nx, ny, nz = (int(t) for t in rng.integers(3, 7, size=3))
+        keep = float(rng.uniform(0.55, 1.0))
+        m0, rp0, ci0, v0 = standins.block_dense(nx, ny, nz, keep=keep, seed=100 + case)
+        mm, kk = m0 - int(rng.integers(0, 16)), m0 - int(rng.integers(0, 16))
+        rp, ci, v = _submatrix(m0, rp0, ci0, v0, mm, kk)
+        A = P.Matrix(0, mm, kk, rp, ci, v)
+        d = P.Descr()
+        assert L.aoclsparse_set_mm_hint(A.h, P.OP_NONE, d.h, 10) == 0 and L.aoclsparse_optimize(A.h) == 0
+        used_bell += A.spmv_info().mm_bell_width > 0
+        for layout in ("row", "col"):
+            n = int(rng.integers(1, 100))
+            alpha, beta = float(rng.choice([1.0, -0.5])), float(rng.choice([0.0, 1.0, -1.5]))
+            if layout == "col":
+                ldb, ldc = kk + int(rng.integers(0, 4)), mm + int(rng.integers(0, 4))
+                B, C0 = rng.uniform(-1, 1, ldb * n), rng.uniform(-1, 1, ldc * n)
+                so, Cr = oracle.dcsrmm("col", alpha, 0, v, ci, rp, mm, B, n, ldb, beta, C0, ldc)
+                Cd = dev(C0)
+                assert P.dcsrmm(P.OP_NONE, alpha, A, d, P.ORDER_COLUMN, dev(B), n, ldb, beta, Cd, ldc) == 0
+                torch.cuda.synchronize()
+                assert _same_bits(Cd.cpu().numpy(), Cr), (case, layout, mm, kk, n, ldb, ldc, alpha, beta, keep)
+            else:
+                ldb, ldc = n + int(rng.integers(0, 3)), n + int(rng.integers(0, 3))
+                B, C0 = rng.uniform(-1, 1, kk * ldb), rng.uniform(-1, 1, mm * ldc)
+                Bc = np.ascontiguousarray(B.reshape(kk, ldb)[:, :n].T).ravel()
+                Cc = np.ascontiguousarray(C0.reshape(mm, ldc)[:, :n].T).ravel()
+                so, Cr = oracle.dcsrmm("col", alpha, 0, v, ci, rp, mm, Bc, n, kk, beta, Cc, mm)
+                Cd = dev(C0)
+                assert P.dcsrmm(P.OP_NONE, alpha, A, d, P.ORDER_ROW, dev(B), n, ldb, beta, Cd, ldc) == 0
+                torch.cuda.synchronize()
+                got = Cd.cpu().numpy().reshape(mm, ldc)
+                assert _same_bits(got[:, :n], Cr.reshape(n, mm).T), (case, layout, mm, kk, n, ldb, ldc, alpha, beta, keep)
+                assert np.array_equal(got[:, n:], C0.reshape(mm, ldc)[:, n:])
+    assert used_bell >= 4, used_bell
