@@ -227,8 +227,8 @@ static aoclsparse_status build_levels(aoclsparse_int m, const Triangle<T> &t, Tr
     return rc;
 }
 
-// Blocked (supernodal) plan: see TrsvBlockPlan and trsv_block_kernel.  In SOLVE order (ascending rows, or descending for
-// U and L^T) a row joins its predecessor's block when its dependency list -- in the order the reference's chain applies it
+// Blocked (supernodal) plan: see TrsvBlockPlan and trsv_block_kernel.  A row joins the block of the row its chain applies last
+// (round 4: wherever that row is numbered; rounds 2-3: only the predecessor in solve order) when its dependency list -- in the order the reference's chain applies it
 // -- is exactly the predecessor's list with the predecessor itself
 //   * appended at the END  (L, L^T, U^T: the chain runs over the far rows first, the nearest last), or
 //   * put at the FRONT     (U: ref_trsv_u walks the row left to right, so the row solved last comes first);
@@ -251,67 +251,93 @@ static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, T
             return false;
         return lq == 0 || std::memcmp(a + (front ? 1 : 0), q, sizeof(aoclsparse_int) * (size_t)lq) == 0;
     };
-    // 1. blocks, as ranges of the solve order.  The kernel is compiled for blocks of up to 5 rows (every value in
-    // registers across the wait) and up to TRSV_BLK_ROWS (row by row, values in LDS): when only a few chains run longer
-    // than 5 rows they are cut at 5, so that one long chain does not put the whole solve on the slower shape.
-    std::vector<aoclsparse_int> bstart, best;
+    // 1. blocks = CHAINS of the dependency structure (round 4; rounds 2-3 took ranges of the solve order, which only finds the
+    // chains of a matrix whose chained rows are numbered consecutively -- the dofs of a mesh node in natural order -- and lost
+    // them all on a renumbered mesh: 7,315 row levels at 0.62 us instead of ~1,100 block levels).  Row j can continue row p's
+    // block when p is the dependency its chain applies LAST (or FIRST, form `front`) and the rest of its list is exactly p's
+    // list: then everything j waits for outside the block, p's block has already waited for.  Every row has at most one
+    // follower (the first candidate in solve order).  A block's first row is solved before every other row of it, and the
+    // blocks' dependencies point to blocks with an earlier first row only: numbered by first row they are in topological order.
+    // The kernel is compiled for blocks of up to 5 rows (every value in registers across the wait) and up to TRSV_BLK_ROWS
+    // (row by row, values in LDS): when only a few chains run longer than 5 rows they are cut at 5, so that one long chain does
+    // not put the whole solve on the slower shape.
+    std::vector<aoclsparse_int> follower((size_t)m), bptr, brows, best_ptr, best_rows;
+    std::vector<char>           taken((size_t)m);
     bool                        front = false, best_front = false;
-    bstart.reserve((size_t)m / 2 + 2);
     for(int form = 0; form < 2; form++)
     {
         front = form == 1;
+        std::fill(follower.begin(), follower.end(), (aoclsparse_int)-1);
+        {
+            std::vector<char> has_pred((size_t)m, 0);
+            for(aoclsparse_int k = 0; k < m; k++)
+            {
+                const aoclsparse_int j = row_at(k), lj = len_of(j);
+                if(lj == 0)
+                    continue;
+                const aoclsparse_int pr = t.ind[t.ptr[j] + (front ? 0 : lj - 1)];
+                if(follower[pr] < 0 && chains(j, pr, front))
+                    follower[pr] = j, has_pred[j] = 1;
+            }
+        }
         for(int cap : {TRSV_BLK_ROWS, 5})
         {
-            bstart.clear();
+            bptr.clear(), brows.clear();
+            bptr.reserve((size_t)m / 2 + 2), brows.reserve((size_t)m);
+            std::fill(taken.begin(), taken.end(), 0);
             aoclsparse_int longer = 0;
-            for(aoclsparse_int k = 0; k < m;)
+            for(aoclsparse_int k = 0; k < m; k++)
             {
-                bstart.push_back(k);
-                const aoclsparse_int n0 = len_of(row_at(k));
-                aoclsparse_int       j = k + 1, total = n0;
+                aoclsparse_int j = row_at(k);
+                if(taken[j])
+                    continue;
+                bptr.push_back((aoclsparse_int)brows.size());
+                brows.push_back(j), taken[j] = 1;
+                const aoclsparse_int n0 = len_of(j);
+                aoclsparse_int       rows = 1, total = n0;
                 if(n0 <= TRSV_BLK_EXT)
-                    while(j < m && j - k < cap)
+                    while(rows < cap)
                     {
-                        const aoclsparse_int lj = len_of(row_at(j));
-                        if(total + lj > TRSV_BLK_NV || !chains(row_at(j), row_at(j - 1), front))
+                        const aoclsparse_int f = follower[j];
+                        if(f < 0 || taken[f] || total + len_of(f) > TRSV_BLK_NV)
                             break;
-                        total += lj;
-                        j++;
+                        brows.push_back(f), taken[f] = 1;
+                        total += len_of(f), rows++, j = f;
                     }
-                longer += (j - k > 5);
-                k = j;
+                longer += (rows > 5);
             }
-            if(longer == 0 || longer * 10 >= (aoclsparse_int)bstart.size())
+            if(longer == 0 || longer * 10 >= (aoclsparse_int)bptr.size())
                 break; // nothing to cut, or long chains are the rule: keep them
         }
-        if(best.empty() || bstart.size() < best.size())
-            best = bstart, best_front = front;
-        if(best.size() * 16 <= (size_t)m * 10)
+        bptr.push_back((aoclsparse_int)brows.size());
+        if(best_ptr.empty() || bptr.size() < best_ptr.size())
+            best_ptr = bptr, best_rows = brows, best_front = front;
+        if((best_ptr.size() - 1) * 16 <= (size_t)m * 10)
             break; // this form already groups the rows
     }
-    bstart.swap(best);
+    bptr.swap(best_ptr), brows.swap(best_rows);
     front = best_front;
     lt.lap("blocks: chains");
-    const aoclsparse_int nb = (aoclsparse_int)bstart.size();
-    bstart.push_back(m);
+    const aoclsparse_int nb = (aoclsparse_int)bptr.size() - 1;
     if((long long)nb * 16 > (long long)m * 10)
         return aoclsparse_status_success; // fewer than 1.6 rows per block: the row-level schedules are as good
     int max_rows = 1, max_ext = 0;
     for(aoclsparse_int bq = 0; bq < nb; bq++)
     {
-        max_rows = std::max<int>(max_rows, bstart[bq + 1] - bstart[bq]);
+        max_rows = std::max<int>(max_rows, bptr[bq + 1] - bptr[bq]);
         // a single row longer than the cap is served by the kernel's tail loop: it does not widen the unrolled part
-        max_ext = std::max(max_ext, std::min<int>(len_of(row_at(bstart[bq])), TRSV_BLK_EXT));
+        max_ext = std::max(max_ext, std::min<int>(len_of(brows[bptr[bq]]), TRSV_BLK_EXT));
     }
-    // 2. block levels (a block's external dependencies are those of its first-solved row)
+    // 2. block levels (a block's external dependencies are those of its first-solved row; blocks are numbered by first row in
+    // solve order, so every dependency's block is already levelled)
     std::vector<aoclsparse_int> bof((size_t)m), blev((size_t)nb, 0);
     for(aoclsparse_int bq = 0; bq < nb; bq++)
-        for(aoclsparse_int k = bstart[bq]; k < bstart[bq + 1]; k++)
-            bof[row_at(k)] = bq;
+        for(aoclsparse_int k = bptr[bq]; k < bptr[bq + 1]; k++)
+            bof[brows[k]] = bq;
     aoclsparse_int nlev = 0;
     for(aoclsparse_int bq = 0; bq < nb; bq++)
     {
-        const aoclsparse_int r  = row_at(bstart[bq]);
+        const aoclsparse_int r  = brows[bptr[bq]];
         aoclsparse_int       lv = 0;
         for(aoclsparse_int p = t.ptr[r]; p < t.ptr[r + 1]; p++)
             lv = std::max(lv, blev[bof[t.ind[p]]] + 1);
@@ -332,9 +358,9 @@ static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, T
     for(aoclsparse_int k = 0; k < nb; k++)
     {
         const aoclsparse_int bq = order[k];
-        bfirst[k + 1]           = bfirst[k] + (bstart[bq + 1] - bstart[bq]);
-        for(aoclsparse_int kk = bstart[bq], q = bfirst[k]; kk < bstart[bq + 1]; kk++, q++)
-            rowmap[q] = row_at(kk), pos[row_at(kk)] = q;
+        bfirst[k + 1]           = bfirst[k] + (bptr[bq + 1] - bptr[bq]);
+        for(aoclsparse_int kk = bptr[bq], q = bfirst[k]; kk < bptr[bq + 1]; kk++, q++)
+            rowmap[q] = brows[kk], pos[brows[kk]] = q;
     }
     // 4. the triangle in that order (entries in chain order), dependencies as positions
     std::vector<aoclsparse_int> pptr((size_t)m + 1, 0);

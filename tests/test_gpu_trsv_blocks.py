@@ -302,3 +302,46 @@ def test_block_schedule_is_the_one_that_runs(tmp_path):
     lines = [ln for ln in r.stderr.splitlines() if ln.startswith("[trsv trace]")]
     assert len(lines) == 4 and all("max_rows 5" in ln for ln in lines), r.stderr[-2000:]
     assert trace.stat().st_size > 0 and trace.stat().st_size % 48 == 0
+
+
+def interleave_two(m, rp, ci, v, seed=1):
+    """two independent copies of a matrix with their rows / columns INTERLEAVED (copy c's index i becomes 2 i + c; the second copy
+    gets other values): the chained rows of a node -- consecutive in the original -- are two apart now"""
+    rng = np.random.default_rng(seed)
+    lens = np.diff(rp)
+    rp2 = np.zeros(2 * m + 1, np.int64)
+    rp2[1:] = np.cumsum(np.repeat(lens, 2))
+    ci2 = np.empty(2 * len(ci), np.int64)
+    v2 = np.empty(2 * len(ci))
+    for i in range(m):
+        s, e = rp[i], rp[i + 1]
+        for c in range(2):
+            d0 = rp2[2 * i + c]
+            ci2[d0:d0 + (e - s)] = 2 * ci[s:e].astype(np.int64) + c
+            v2[d0:d0 + (e - s)] = v[s:e] if c == 0 else v[s:e] * rng.uniform(0.5, 1.5, e - s)
+    return 2 * m, rp2.astype(np.int32), ci2.astype(np.int32), v2
+
+
+_TRACE_SCRIPT_INTERLEAVED = _TRACE_SCRIPT.replace("from test_gpu_trsv_blocks import node_mesh, P, VARIANTS",
+                                                  "from test_gpu_trsv_blocks import node_mesh, interleave_two, P, VARIANTS").replace(
+    "A = P.Matrix(0, m, m, rp, ci, v)", "m, rp, ci, v = interleave_two(m, rp, ci, v)\nA = P.Matrix(0, m, m, rp, ci, v)")
+
+
+def test_block_schedule_finds_chains_that_are_not_numbered_consecutively(tmp_path):
+    """Round 4: blocks are chains of the dependency structure (a row continues the block of the row its chain applies last when
+    the rest of its list is that row's list), wherever the rows are numbered.  Two interleaved copies of a 5-dof mesh: the dofs
+    of a node are two apart, rounds 2-3 (ranges of the solve order) found no block at all; now every triangle runs on the block
+    kernel with blocks of 5 rows, bit-exact against the oracle's serial chain."""
+    m0, rp0, ci0, v0 = node_mesh(21, 1500, 31, np.full(1500, 5))
+    m, rp, ci, v = interleave_two(m0, rp0, ci0, v0)
+
+    def same(got, ref, what):
+        assert np.array_equal(got, ref), (what, int((got != ref).sum()))
+
+    solve_all(m, rp, ci, v, same)
+    trace = tmp_path / "trace.bin"
+    env = dict(os.environ, AOCLSPARSE_MI355_TRSV_TRACE=str(trace))
+    r = subprocess.run([sys.executable, "-c", _TRACE_SCRIPT_INTERLEAVED, ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stderr.splitlines() if ln.startswith("[trsv trace]")]
+    assert len(lines) == 4 and all("max_rows 5" in ln for ln in lines), r.stderr[-2000:]
