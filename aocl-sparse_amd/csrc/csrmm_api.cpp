@@ -210,7 +210,7 @@ aoclsparse_status mi355::build_bell(const HostCsr &h, SpmvPlan &plan, aoclsparse
     }
     catch(const std::bad_alloc &)
     {
-        return aoclsparse_status_memory_error;
+        return aoclsparse_status_success; // (optional format)
     }
     std::atomic<bool> sorted{true}, nomem{false};
     // pass 1: distinct block columns per block row
@@ -248,7 +248,7 @@ aoclsparse_status mi355::build_bell(const HostCsr &h, SpmvPlan &plan, aoclsparse
         }
     });
     if(nomem.load())
-        return aoclsparse_status_memory_error;
+        return aoclsparse_status_success; // (optional format)
     if(!sorted.load())
         return aoclsparse_status_success;
     long long      nblk = 0;
@@ -259,7 +259,7 @@ aoclsparse_status mi355::build_bell(const HostCsr &h, SpmvPlan &plan, aoclsparse
         return aoclsparse_status_success;
     const double    fill  = (double)h.nnz / (256.0 * (double)nblk);
     const long long slots = (long long)nbr * width;
-    if(fill < 0.5 || (double)slots > 1.35 * (double)nblk || slots * 256 > (1LL << 33) / 8 * 4) // (<= 4 GB of values)
+    if(fill < 0.5 || (double)slots > 1.35 * (double)nblk || slots * 256 > (1LL << 30)) // (the copy stays under 8 GiB of values)
         return aoclsparse_status_success;
     // pass 2: values in the A-operand order, block columns ascending, empty slots (-1) last
     std::vector<double>         bv;
@@ -271,7 +271,7 @@ aoclsparse_status mi355::build_bell(const HostCsr &h, SpmvPlan &plan, aoclsparse
     }
     catch(const std::bad_alloc &)
     {
-        return aoclsparse_status_memory_error;
+        return aoclsparse_status_success; // the blocked copy is optional: without it the CSR kernels run
     }
     const double *hv = static_cast<const double *>(h.val);
     parallel_for(nbr, 64, [&](long long b0, long long b1) {
@@ -315,14 +315,18 @@ aoclsparse_status mi355::build_bell(const HostCsr &h, SpmvPlan &plan, aoclsparse
         }
     });
     if(nomem.load())
-        return aoclsparse_status_memory_error;
+        return aoclsparse_status_success; // (optional format)
     hipStream_t       st = Runtime::get().stream();
     aoclsparse_status rc = bp.val.upload(bv.data(), sizeof(double) * bv.size(), st);
     if(rc == aoclsparse_status_success)
         rc = bp.bcol.upload(bcol.data(), sizeof(aoclsparse_int) * bcol.size(), st);
-    if(rc != aoclsparse_status_success)
-        return rc;
-    MI355_HIP_TRY(hipStreamSynchronize(st)); // the host buffers above go away
+    if(rc != aoclsparse_status_success || hipStreamSynchronize(st) != hipSuccess) // (the host buffers above go away)
+    {
+        // no room in HBM for a second copy of the matrix: not an error, the CSR kernels serve the handle
+        (void)hipGetLastError();
+        bp.val.release(), bp.bcol.release();
+        return aoclsparse_status_success;
+    }
     bp.nbr = nbr, bp.width = width, bp.nblocks = nblk, bp.fill = fill;
     bp.valid = true;
     return aoclsparse_status_success;
