@@ -401,7 +401,11 @@ aoclsparse_status detect_windows(const HostCsr &h, SpmvPlan &plan, size_t elem)
         return aoclsparse_status_success;
     const aoclsparse_status rc = g.windows.upload(win.data(), sizeof(aoclsparse_int) * win.size(), Runtime::get().stream());
     if(rc != aoclsparse_status_success)
-        return rc;
+    {
+        (void)hipGetLastError(); // (an optional plan: the pair / lane-per-row kernels serve the handle)
+        g.windows.release();
+        return aoclsparse_status_success;
+    }
     g.win_rows = R;
     g.win      = true;
     return aoclsparse_status_success;
