@@ -49,6 +49,19 @@ def communicator_info(dist, torch):
     return info
 
 
+def broadcast_text(dist, torch, device, rank, text):
+    """a short string from rank 0 to every rank (descriptions that only rank 0 can compose)"""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return text
+    wire = "cpu" if _backend(dist) == "gloo" else device
+    buf = torch.zeros(512, dtype=torch.uint8, device=wire)
+    if rank == 0:
+        raw = text.encode()[:511]
+        buf[: len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(wire)
+    dist.broadcast(buf, 0)
+    return bytes(buf.cpu().numpy().tobytes()).split(b"\0", 1)[0].decode(errors="replace")
+
+
 def barrier(dist, torch):
     if torch.cuda.is_available():
         torch.cuda.synchronize()

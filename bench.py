@@ -279,7 +279,7 @@ def leg_numbers(full):
         n["trsv_parity"] = all(s["bit_exact_vs_cpu"] for s in tr["schedules"])
         if "unstructured_variant" in tr and tr["unstructured_variant"].get("schedules"):
             n["trsv_unstructured_ms"] = tr["unstructured_variant"]["schedules"][0]["ms"]
-    for lay in ("col", "row"):
+    for lay in ("col", "row", "bell"):
         sh = full.get("csrmm_sharded_" + lay) or {}
         if "tg_ms_device_median_max_over_ranks" in sh:
             n["csrmm_sharded_" + lay] = {"world": sh["world"], "cols_per_rank": sh["cols_per_rank"],
@@ -297,7 +297,7 @@ def leg_numbers(full):
     if im:
         n["inlib_multi"] = {k: im.get(k) for k in ("devices", "same_device", "slabs_bit_exact", "efficiency_wall") if k in im}
     errors = [k for k, v in list(legs.items()) + [(k, full.get(k)) for k in ("l100", "spmv_row_sharded", "csrmm_sharded_col",
-                                                                             "csrmm_sharded_row")]
+                                                                             "csrmm_sharded_row", "csrmm_sharded_bell")]
               if isinstance(v, dict) and "error" in v]
     if errors:
         n["errors"] = errors
@@ -402,6 +402,9 @@ def main():
     ap.add_argument("--shard-grid", type=int, default=0,
                     help="grid of the row-sharded SpMV iteration leg; 0 = 4096*sqrt(N) (every rank keeps the headline's 16.8 M rows = "
                          "1.34 GB of matrix, well past the 256 MiB Infinity Cache, whatever N is); 2048 on one rank")
+    ap.add_argument("--bell-nodes", type=int, default=40,
+                    help="sharded csrmm on the block-dense stand-in (blocked-ELL MFMA path): nodes per edge of its node grid, 16 "
+                         "unknowns each (40 -> 1,024,000 rows: configs[3]'s 1M x 1M); 0 skips it")
     ap.add_argument("--shard-own-rows", action="store_true",
                     help="row-sharded SpMV leg: every rank builds its own rows even with an explicit --shard-grid (the default for "
                          "N > 1 without --shard-grid; lets a small test take the path the multi-GPU run takes)")
@@ -603,19 +606,31 @@ def main():
             legs_out[name] = res
 
     # ---------------- collectives first: the column-sharded csrmm (every rank) ----------------
-    def leg_csrmm_sharded(layout):
+    def leg_csrmm_sharded(layout, matrix="laplace"):
         csr_mm = None
         if rank == 0:
-            mm_m, rp, ci, v = entry.laplace5(args.mm_grid)
+            if matrix == "laplace":
+                mm_m, rp, ci, v = entry.laplace5(args.mm_grid)
+                what = "5-pt Laplacian %dx%d grid" % (args.mm_grid, args.mm_grid)
+            else:
+                # configs[3] to the letter: "1M x 1M CSR x dense B with 256 columns, blocked-ELL MFMA tiles, B column-sharded":
+                # the block-dense stand-in (16 unknowns per node, 7-point node stencil; 40^3 nodes = 1,024,000 rows)
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import standins
+                e = args.bell_nodes
+                mm_m, rp, ci, v = standins.block_dense(e, e, e)
+                what = "block-dense stand-in, %d^3 nodes x 16 unknowns (blocked-ELL copy, MFMA kernel)" % e
             csr_mm = (mm_m, mm_m, rp, ci, v)
         res, sh, B, C = sharded.bench_sharded_csrmm(pkg, torch, D, device, rank, world, csr_mm, args.mm_cols,
-                                                    layout=layout, reps=20, warm=3, full_product=True,
+                                                    layout=layout, reps=20 if matrix == "laplace" else 10, warm=3, full_product=True,
                                                     allgather=world > 1, peak_gbs=HBM_PEAK_GBS)
-        res["workload"] = ("aoclsparse_dcsrmm, A = 5-pt Laplacian %dx%d grid, B %d x %d fp64 %s, beta=0 (C read and multiplied "
+        what = sharded.broadcast_text(D, torch, device, rank, what if rank == 0 else None)
+        res["bell_width"] = int(sh.A.spmv_info().mm_bell_width)
+        res["workload"] = ("aoclsparse_dcsrmm, A = %s, B %d x %d fp64 %s, beta=0 (C read and multiplied "
                            "by zero as in the reference: the default), columns "
                            "sharded over %d rank(s) by the reference's thread-split rule (csrmm_kt.cpp:68-82); A's analysed device "
                            "arrays broadcast from rank 0, no data-path collective"
-                           % (args.mm_grid, args.mm_grid, sh.m, args.mm_cols, res["layout"], world))
+                           % (what, sh.m, args.mm_cols, res["layout"], world))
         if rank == 0:
             import oracle
             # parity of rank 0's slab: first 4 columns against the oracle's column-major reference kernel
@@ -633,6 +648,9 @@ def main():
         if "csrmm_sharded" in legs:
             legs.add("csrmm_sharded_" + lay)
             run_leg("csrmm_sharded_" + lay, lambda lay=lay: leg_csrmm_sharded(lay), collective=True)
+    if "csrmm_sharded" in legs and args.bell_nodes > 0:
+        legs.add("csrmm_sharded_bell")
+        run_leg("csrmm_sharded_bell", lambda: leg_csrmm_sharded("col", "block-dense"), collective=True)
 
     # ---- SURVEY 8e "next": the iteration x <- A x with A split by rows and one all-gather of the slices per iteration ----
     def leg_spmv_row_sharded():
@@ -1157,7 +1175,7 @@ def main():
         out["cpu_baseline"] = None
 
     if rank == 0:
-        for k in ("l100", "spmv_row_sharded", "csrmm_sharded_col", "csrmm_sharded_row"):
+        for k in ("l100", "spmv_row_sharded", "csrmm_sharded_col", "csrmm_sharded_row", "csrmm_sharded_bell"):
             if k in legs_out:
                 out[k] = legs_out.pop(k)
         out["legs"] = legs_out

@@ -187,7 +187,7 @@ def test_bench_two_ranks_gloo_one_gpu(tmp_path):
     rec = str(tmp_path / "legs.json")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "5",
-           "--warmup", "2", "--grid", "512", "--mm-grid", "200", "--mm-cols", "64", "--shard-grid", "301", "--legs",
+           "--warmup", "2", "--grid", "512", "--mm-grid", "200", "--mm-cols", "64", "--shard-grid", "301", "--bell-nodes", "6", "--legs",
            "csrmm_sharded,spmv_row_sharded", "--record", rec]
     r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4"), capture_output=True,
                        text=True, timeout=900)
@@ -212,6 +212,13 @@ def _check_two_rank_record(short, res, own_rows):
         assert mm["roofline_shard"]["algorithmic_bytes_per_launch"] == (40000 + 1 + mm["nnz"]) * 4 + mm["nnz"] * 8 + 8 * 32 * 3 * 40000
         assert short["legs"]["csrmm_sharded_" + lay]["efficiency"] == mm["efficiency"]
         assert short["legs"]["csrmm_sharded_" + lay]["parity"] is True
+    # configs[3] to the letter: the block-dense stand-in on the blocked-ELL MFMA kernel, column slabs; the adopting rank runs the
+    # MFMA kernel on the state it received (bell_width is read from every rank's handle)
+    bl = res["csrmm_sharded_bell"]
+    assert "error" not in bl, bl
+    assert bl["layout"] == "column-major" and bl["world"] == 2 and bl["cols_per_rank"] == 32 and bl["bell_width"] == 7
+    assert bl["parity"]["bit_exact"] is True and bl["efficiency"] > 0 and bl["m"] == 16 * 216
+    assert short["legs"]["csrmm_sharded_bell"]["parity"] is True
     assert res["config"]["communicator"] == {"backend": "gloo", "world": 2} == short["config"]["communicator"]
     sp = res["spmv_row_sharded"]
     assert "error" not in sp, sp
@@ -230,7 +237,7 @@ def test_bench_gpus_2_starts_its_own_ranks(tmp_path):
     rec = str(tmp_path / "legs.json")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "5", "--warmup", "2",
-                        "--grid", "512", "--mm-grid", "200", "--mm-cols", "64", "--shard-grid", "301", "--legs",
+                        "--grid", "512", "--mm-grid", "200", "--mm-cols", "64", "--shard-grid", "301", "--bell-nodes", "6", "--legs",
                         "csrmm_sharded,spmv_row_sharded", "--record", rec], cwd=ROOT, env=dict(env, OMP_NUM_THREADS="4"),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, "rc=%d\nstdout:\n%s\nstderr:\n%s" % (r.returncode, r.stdout[-3000:], r.stderr[-3000:])
@@ -259,7 +266,7 @@ def test_bench_single_process_small_legs(tmp_path):
     carry a roofline object and a bit-exact verdict (the driver-timed run uses the full sizes)."""
     rec = str(tmp_path / "legs.json")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--grid", "512",
-                        "--mm-grid", "200", "--mm-cols", "64", "--shard-grid", "300", "--small", "--cpu-seconds", "0.5",
+                        "--mm-grid", "200", "--mm-cols", "64", "--shard-grid", "300", "--bell-nodes", "6", "--small", "--cpu-seconds", "0.5",
                         "--record", rec], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     short, res = _bench_record(r.stdout, rec)
@@ -285,8 +292,9 @@ def test_bench_single_process_small_legs(tmp_path):
     assert kid_cases >= 2
     for s in legs["trsv"]["schedules"]:
         assert s["bit_exact_vs_cpu"] and s["residual_inf"] < 1e-13
-    for lay in ("col", "row"):
+    for lay in ("col", "row", "bell"):
         assert res["csrmm_sharded_" + lay]["efficiency"] == 1.0 and res["csrmm_sharded_" + lay]["parity"]["bit_exact"]
+    assert res["csrmm_sharded_bell"]["bell_width"] == 7
     assert res["spmv_row_sharded"]["parity"]["bit_exact"] and res["spmv_row_sharded"]["allgather_ms_median_max_over_ranks"] == 0.0
     # one number per leg in the short record, none of them missing and no leg in error
     n = short["legs"]
