@@ -345,3 +345,39 @@ def test_block_schedule_finds_chains_that_are_not_numbered_consecutively(tmp_pat
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stderr.splitlines() if ln.startswith("[trsv trace]")]
     assert len(lines) == 4 and all("max_rows 5" in ln for ln in lines), r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_block_chains_under_random_symmetric_permutations(seed):
+    """Any symmetric permutation of a mesh matrix is a valid input whose triangles hold chains in arbitrary places (partly kept,
+    partly broken, numbered far apart).  Node-level shuffles (dofs stay together), dof-level shuffles inside windows (chains
+    scattered) and full interleaving: every triangle, both diagonal types, automatic and pinned reference kid -- bit-exact
+    against the oracle's serial chain whatever blocks the grouping finds."""
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(100 + seed)
+    nodes, dofs = 1200, int(rng.integers(2, 7))
+    m, rp, ci, v = node_mesh(40 + seed, nodes, int(rng.integers(20, 45)), np.full(nodes, dofs))
+    A0 = sp.csr_matrix((v, ci, rp), shape=(m, m))
+    if seed == 1:  # nodes shuffled inside windows of 64 nodes, dofs stay consecutive
+        pn = np.arange(nodes)
+        for w0 in range(0, nodes, 64):
+            pn[w0:w0 + 64] = w0 + rng.permutation(min(64, nodes - w0))
+        perm = (pn[:, None] * dofs + np.arange(dofs)[None, :]).ravel()
+    elif seed == 2:  # rows shuffled inside windows of 4 * dofs rows: the chains of a node are scattered among its neighbours'
+        perm = np.arange(m)
+        for w0 in range(0, m, 4 * dofs):
+            w1 = min(m, w0 + 4 * dofs)
+            perm[w0:w1] = w0 + rng.permutation(w1 - w0)
+    else:  # dof a of node i -> a * nodes-block interleave of two halves of the mesh
+        half = m // 2
+        perm = np.concatenate([np.arange(half) * 2, np.arange(m - half) * 2 + 1])
+        perm = np.argsort(np.argsort(perm))[:m]
+    P_ = sp.csr_matrix((np.ones(m), (perm, np.arange(m))), shape=(m, m))
+    Ap = (P_ @ A0 @ P_.T).tocsr()
+    Ap.sort_indices()
+
+    def same(got, ref, what):
+        assert np.array_equal(got, ref), (seed, what, int((got != ref).sum()))
+
+    solve_all(m, Ap.indptr.astype(np.int32), Ap.indices.astype(np.int32), Ap.data.copy(), same)
