@@ -108,9 +108,44 @@ namespace
             return false;
         if(s[S_VTYPE] != aoclsparse_dmat && s[S_VTYPE] != aoclsparse_smat)
             return false;
-        const size_t vs = val_size((aoclsparse_matrix_data_type)s[S_VTYPE]);
-        return st.bytes[0] == (long long)sizeof(aoclsparse_int) * (s[S_M] + 1) && st.bytes[1] == (long long)sizeof(aoclsparse_int) * s[S_NNZ]
-               && st.bytes[2] == (long long)vs * s[S_NNZ];
+        const long long vs = (long long)val_size((aoclsparse_matrix_data_type)s[S_VTYPE]), I = (long long)sizeof(aoclsparse_int);
+        if(st.bytes[0] != I * (s[S_M] + 1) || st.bytes[1] != I * s[S_NNZ] || st.bytes[2] != vs * s[S_NNZ])
+            return false;
+        // every plan the scalars announce must come with a buffer of at least the size the kernels will index (a truncated or
+        // mismatched transfer is refused here, not found by a kernel); the CONTENTS are the sender's -- a state is only ever
+        // produced by _export of this library (the magic word names the layout version)
+        const long long *b = st.bytes;
+        const long long  m = s[S_M], nb = s[S_NBLOCKS];
+        if(nb < 0 || nb > m + 1 || (nb > 0 && b[3] < 2 * I * (nb + 1)))
+            return false;
+        if(nb > 0 && (s[S_TILE] & ~1LL) != 512 && (s[S_TILE] & ~1LL) != 1024 && (s[S_TILE] & ~1LL) != 2048)
+            return false;
+        if(s[S_HEAVY_FIRST] && b[4] < 4 * I * nb)
+            return false;
+        if(s[S_RUNS] && s[S_BAND] > 0 && b[5] < I * ((m + 7) / 8))
+            return false;
+        if(s[S_BAND] < 0 || s[S_NGROUPS] < 0 || s[S_NGROUPS] > m || s[S_MAX_ROWS] < 0 || s[S_MAX_ROWS] > 64)
+            return false;
+        if(s[S_GROUPS_VALID] && b[6] < I * (s[S_NGROUPS] + 1))
+            return false;
+        if(s[S_NPAIRS] < 0 || s[S_NSINGLES] < 0 || 2 * s[S_NPAIRS] + s[S_NSINGLES] > m)
+            return false;
+        if(s[S_PAIRS] && (b[7] < I * s[S_NPAIRS] || b[8] < I * s[S_NSINGLES]))
+            return false;
+        if(s[S_WIN])
+        {
+            const long long wr = s[S_WIN_ROWS];
+            if((wr != 2048 && wr != 4096) || b[9] < 2 * I * ((m + wr - 1) / wr))
+                return false;
+        }
+        if(s[S_BELL])
+        {
+            const long long nbr = s[S_BELL_NBR], w = s[S_BELL_WIDTH];
+            if(s[S_VTYPE] != aoclsparse_dmat || nbr != (m + BELL_BS - 1) / BELL_BS || w < 1 || w > (1LL << 30) / (nbr > 0 ? nbr : 1)
+               || b[10] < nbr * w * BELL_BS * BELL_BS * vs || b[11] < nbr * w * I || s[S_BELL_NBLOCKS] < 0 || s[S_BELL_NBLOCKS] > nbr * w)
+                return false;
+        }
+        return true;
     }
 
     // a fresh handle for an adopted state: owns its host arrays (filled by the caller), no hints yet

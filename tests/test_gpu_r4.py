@@ -392,6 +392,37 @@ def test_mm_state_export_adopt_round_trip(which):
     bad.scalars[0] = 1
     st, none = P.Matrix.mm_state_adopt(bad, [None] * 12)
     assert st != 0 and none is None
+    # ... and so is a state whose buffers are smaller than the plans its scalars announce (a truncated / mismatched transfer):
+    # every announced plan, one mutation each -- the receiver refuses BEFORE any kernel could index past a buffer
+    held = [torch.as_tensor(_DeviceView(p, n), device="cuda").clone() if n else None for p, n in zip(ptrs, list(state.bytes))]
+    addrs = [t.data_ptr() if t is not None else None for t in held]
+
+    def mutated(fn):
+        b = P.MmState()
+        ctypes.memmove(ctypes.addressof(b), ctypes_copy, len(ctypes_copy))
+        fn(b)
+        return P.Matrix.mm_state_adopt(b, addrs)
+
+    S_NBLOCKS, S_TILE, S_WIN, S_WIN_ROWS, S_BELL, S_BELL_WIDTH, S_GROUPS_VALID, S_NGROUPS = 8, 11, 21, 22, 23, 25, 17, 15
+    cases = [("row blocks", lambda b: b.bytes.__setitem__(3, b.bytes[3] - 8)),
+             ("block count", lambda b: b.scalars.__setitem__(S_NBLOCKS, b.scalars[S_NBLOCKS] + 1)),
+             ("tile", lambda b: b.scalars.__setitem__(S_TILE, 768)),
+             ("CSR values", lambda b: b.bytes.__setitem__(2, b.bytes[2] - 8))]
+    if state.scalars[S_WIN]:
+        cases += [("window table", lambda b: b.bytes.__setitem__(9, b.bytes[9] - 8)),
+                  ("window rows", lambda b: b.scalars.__setitem__(S_WIN_ROWS, 1000))]
+    if state.scalars[S_BELL]:
+        cases += [("blocked-ELL width", lambda b: b.scalars.__setitem__(S_BELL_WIDTH, b.scalars[S_BELL_WIDTH] + 1)),
+                  ("blocked-ELL values", lambda b: b.bytes.__setitem__(10, b.bytes[10] // 2))]
+    if state.scalars[S_GROUPS_VALID]:
+        cases += [("row groups", lambda b: b.scalars.__setitem__(S_NGROUPS, b.scalars[S_NGROUPS] + 5))]
+    assert which != "laplace" or len(cases) >= 6
+    assert which != "block_dense" or len(cases) >= 6
+    for name, fn in cases:
+        st, none = mutated(fn)
+        assert st == 5 and none is None, (which, name, st)  # aoclsparse_status_invalid_value
+    st, ok = mutated(lambda b: None)  # (the unmutated state still adopts)
+    assert st == 0 and ok is not None
 
 
 def test_library_rccl_communicator_one_rank():
