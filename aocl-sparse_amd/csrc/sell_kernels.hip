@@ -413,7 +413,7 @@ __global__ __launch_bounds__(64 * WAVES) void sell_mv_kernel(aoclsparse_int m, a
 // profiles/r3/sell_width_switch.txt): general kernel before the width switch 0.1845-0.186 ms, with it 0.1786-0.1793, this
 // kernel with 1 / 2 / 4 slices per workgroup 0.180-0.181 / 0.180-0.181 / 0.1773-0.1779; TWO or more slices per WAVEFRONT
 // (walked together, twice the bytes in flight per wave) 0.183-0.236 ms -- more registers, fewer waves, no gain.
-template <typename T, int WMAX, int WAVES, bool SHARED>
+template <typename T, int WMAX, int WAVES, bool SHARED, int SPW = 1>
 __global__ __launch_bounds__(64 * WAVES) void sell_mv_short_kernel(aoclsparse_int m, aoclsparse_int nslices,
                                                                    const long long *__restrict__ slice_ptr,
                                                                    const T *__restrict__ sval,
@@ -422,58 +422,76 @@ __global__ __launch_bounds__(64 * WAVES) void sell_mv_short_kernel(aoclsparse_in
                                                                    const long long *__restrict__ cptr,
                                                                    const unsigned short *__restrict__ follow)
 {
-    const int s    = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + (threadIdx.x >> 6)));
+    // SPW slices per wavefront, walked TOGETHER (all value / column loads of the SPW slices, then all gathers, then the chains):
+    // SPW times the bytes in flight per wavefront.  Lost for double (two: 0.183-0.236 vs 0.177 ms, round 3); float moves half the
+    // bytes per load instruction, and large float launches run four (round 4: sell_launch_short).
+    const int sb   = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + (threadIdx.x >> 6)) * SPW);
     const int lane = threadIdx.x & 63;
-    if(s >= nslices)
+    if(sb >= nslices)
         return;
-    const long long       o0 = slice_ptr[s];
-    const int             w  = (int)((slice_ptr[s + 1] - o0) >> 6);
-    const int             i  = s * 64 + lane;
-    const T              *v  = sval + o0 + lane;
-    const aoclsparse_int *c  = scol + o0 + lane;
-    int                   cs = 64, dl = 0;
-    if constexpr(SHARED)
-    {
-        const long long cw   = cptr[s];
-        const long long c0   = cw & SELL_CPTR_MASK;
-        const int       mode = (int)(cw >> SELL_CPTR_MODE_SHIFT);
-        int             f    = 0;
-        if(mode == 0)
-            f = i < m ? follow[i] : 0;
-        else if(mode == 1)
-            f = lane << 8;
-        cs = w > 0 ? (int)(((cptr[s + 1] & SELL_CPTR_MASK) - c0) / w) : 1;
-        c  = scol + c0 + (f & 0xff);
-        dl = f >> 8;
-    }
-    T   vv[WMAX], xx[WMAX];
-    int cc[WMAX];
-    if(w > 0) // (an empty slice has no cell to read)
-    {
+    T   vv[SPW][WMAX], xx[SPW][WMAX];
+    int cc[SPW][WMAX], w[SPW], dl[SPW];
 #pragma unroll
-        for(int q = 0; q < WMAX; q++)
+    for(int u = 0; u < SPW; u++)
+    {
+        const int             s  = min(sb + u, (int)nslices - 1); // (beyond the last slice: it is walked again, nothing is stored)
+        const long long       o0 = slice_ptr[s];
+        const int             i  = s * 64 + lane;
+        const T              *v  = sval + o0 + lane;
+        const aoclsparse_int *c  = scol + o0 + lane;
+        int                   cs = 64;
+        w[u]                     = (int)((slice_ptr[s + 1] - o0) >> 6);
+        dl[u]                    = 0;
+        if constexpr(SHARED)
         {
-            const int qq = min(q, w - 1); // wave-uniform
-            vv[q]        = v[qq * 64];
-            cc[q]        = c[qq * cs];
+            const long long cw   = cptr[s];
+            const long long c0   = cw & SELL_CPTR_MASK;
+            const int       mode = (int)(cw >> SELL_CPTR_MODE_SHIFT);
+            int             f    = 0;
+            if(mode == 0)
+                f = i < m ? follow[i] : 0;
+            else if(mode == 1)
+                f = lane << 8;
+            cs    = w[u] > 0 ? (int)(((cptr[s + 1] & SELL_CPTR_MASK) - c0) / w[u]) : 1;
+            c     = scol + c0 + (f & 0xff);
+            dl[u] = f >> 8;
+        }
+        if(w[u] > 0) // (an empty slice has no cell to read)
+        {
+#pragma unroll
+            for(int q = 0; q < WMAX; q++)
+            {
+                const int qq = min(q, w[u] - 1); // wave-uniform
+                vv[u][q]     = v[qq * 64];
+                cc[u][q]     = c[qq * cs];
+            }
+        }
+        else
+        {
+#pragma unroll
+            for(int q = 0; q < WMAX; q++)
+                vv[u][q] = T(0), cc[u][q] = -1;
         }
     }
-    else
-    {
+#pragma unroll
+    for(int u = 0; u < SPW; u++)
 #pragma unroll
         for(int q = 0; q < WMAX; q++)
-            vv[q] = T(0), cc[q] = -1;
+            xx[u][q] = x[cc[u][q] >= 0 ? cc[u][q] + dl[u] : 0];
+#pragma unroll
+    for(int u = 0; u < SPW; u++)
+    {
+        T r = T(0);
+#pragma unroll
+        for(int q = 0; q < WMAX; q++)
+            r = (q < w[u] && cc[u][q] >= 0) ? s_fma(vv[u][q], xx[u][q], r) : r;
+        const int i = (sb + u) * 64 + lane;
+        if(sb + u < nslices && i < m)
+            s_store(y + i, s_finish(r, alpha, beta, y + i), nt);
     }
-#pragma unroll
-    for(int q = 0; q < WMAX; q++)
-        xx[q] = x[cc[q] >= 0 ? cc[q] + dl : 0];
-    T r = T(0);
-#pragma unroll
-    for(int q = 0; q < WMAX; q++)
-        r = (q < w && cc[q] >= 0) ? s_fma(vv[q], xx[q], r) : r;
-    if(i < m)
-        s_store(y + i, s_finish(r, alpha, beta, y + i), nt);
 }
+
+constexpr aoclsparse_int SELL_SHORT_SPW4_SLICES = 100000;
 
 template <typename T, bool SHARED>
 bool sell_launch_short(hipStream_t s, int wmax, aoclsparse_int m, aoclsparse_int nslices, const long long *slice_ptr, const T *sval,
@@ -481,11 +499,20 @@ bool sell_launch_short(hipStream_t s, int wmax, aoclsparse_int m, aoclsparse_int
                        const unsigned short *lead)
 {
     constexpr int WAVES = 4;
-    const dim3    grid((unsigned)((nslices + WAVES - 1) / WAVES)), block(64 * WAVES);
+    // float, >= 100,000 slices: four slices per wavefront (a float load instruction moves half the bytes of a double one; same box,
+    // tools/exp_float_headline.py, 1 / 4 / 8 slices per wavefront: 4096^2 0.1013 / 0.0949 / 0.1218 ms, 3000^2 0.0512 / 0.0479 /
+    // 0.0543, 2000^2 0.0229 / 0.0235 / 0.0267 -- and no change for double, which stays at one: profiles/r4/float_headline.txt)
+    const bool      four   = sizeof(T) == 4 && nslices >= SELL_SHORT_SPW4_SLICES;
+    const long long per_wg = (long long)WAVES * (four ? 4 : 1);
+    const dim3      grid((unsigned)((nslices + per_wg - 1) / per_wg)), block(64 * WAVES);
 #define MI355_SHORT(W)                                                                                                    \
     case W:                                                                                                               \
-        hipLaunchKernelGGL((sell_mv_short_kernel<T, W, WAVES, SHARED>), grid, block, 0, s, m, nslices, slice_ptr, sval,     \
-                           scol, alpha, x, beta, y, nt, cptr, lead);                                                      \
+        if(four)                                                                                                          \
+            hipLaunchKernelGGL((sell_mv_short_kernel<T, W, WAVES, SHARED, 4>), grid, block, 0, s, m, nslices, slice_ptr, sval, \
+                               scol, alpha, x, beta, y, nt, cptr, lead);                                                  \
+        else                                                                                                              \
+            hipLaunchKernelGGL((sell_mv_short_kernel<T, W, WAVES, SHARED>), grid, block, 0, s, m, nslices, slice_ptr, sval, \
+                               scol, alpha, x, beta, y, nt, cptr, lead);                                                  \
         return true
     switch(wmax)
     {

@@ -615,3 +615,49 @@ def test_window_and_blocked_kernels_randomized_sweep():
                 assert _same_bits(got[:, :n], Cr.reshape(n, mm).T), (case, layout, mm, kk, n, ldb, ldc, alpha, beta, keep)
                 assert np.array_equal(got[:, n:], C0.reshape(mm, ldc)[:, n:])
     assert used_bell >= 4, used_bell
+
+
+def test_float_short_row_kernel_four_slices_per_wavefront():
+    """sell_mv_short_kernel<float, W, 4, SHARED, 4> (round 4: float launches of >= 100,000 slices walk four slices per wavefront):
+    a 2,600^2 stencil (shared column lists; 105,625 slices, the last wavefront's group is partial) and a random matrix of 6.5 M + 21
+    rows with <= 5 entries and a band of empty rows (own lists, slices narrower than the widest, a partial last slice) -- bit for
+    bit against the reference's float order (8 lanes: the scalar chain for rows of < 8 entries), alpha / beta, NaN in x."""
+    import __graft_entry__ as entry
+    rng = np.random.default_rng(11)
+    ml, rpl, cil, vl = entry.laplace5(2600)
+    m = 6500000 + 21
+    lens = np.where(rng.random(m) < 0.85, 5, rng.integers(0, 6, m)).astype(np.int64)
+    lens[200000:200300] = 0
+    rp = np.zeros(m + 1, dtype=np.int64)
+    np.cumsum(lens, out=rp[1:])
+    nnz = int(rp[m])
+    rows = np.repeat(np.arange(m, dtype=np.int64), lens)
+    # distinct sorted columns per row: a random start + strictly increasing random steps (wrapped rows are re-sorted below)
+    steps = rng.integers(1, 40000, nnz).astype(np.int64)
+    within = np.arange(nnz, dtype=np.int64) - rp[rows]
+    cs = np.cumsum(steps)
+    first = cs[rp[:-1].clip(max=nnz - 1)][rows] - steps[rp[:-1].clip(max=nnz - 1)][rows]
+    ci = (rng.integers(0, m - 250000, m)[rows] + (cs - first - steps * (within == 0))) % m
+    ci = ci.astype(np.int32)
+    assert ci.min() >= 0 and ci.max() < m
+    key = rows * m + ci
+    assert np.all(np.diff(key) > 0)  # sorted and distinct inside every row (starts leave room for 5 steps: no wrap)
+    v = rng.uniform(-1, 1, nnz).astype(np.float32)
+    for name, mm, rpp, cii, vv in (("stencil", ml, rpl, cil, vl.astype(np.float32)), ("random", m, rp.astype(np.int32), ci, v)):
+        A = P.Matrix(0, mm, mm, rpp, cii, vv)
+        d = P.Descr()
+        assert L.aoclsparse_set_mv_hint(A.h, P.OP_NONE, d.h, 100) == 0 and L.aoclsparse_optimize(A.h) == 0
+        inf = A.spmv_info()
+        assert inf.kernel in (3, 4) and (mm + 63) // 64 >= 100000, (name, inf.kernel)
+        x = rng.uniform(-1, 1, mm).astype(np.float32)
+        x[123457] = np.nan
+        y0 = rng.uniform(-1, 1, mm).astype(np.float32)
+        for alpha, beta in ((1.0, 0.0), (-0.5, 1.25)):
+            y = y0.copy()
+            assert P.smv(P.OP_NONE, alpha, A, d, x, beta, y) == 0
+            st, yr = oracle.scsrmv("lane8", 0, alpha, mm, vv, cii, rpp, x, beta, y0.copy())
+            assert st == 0
+            assert np.array_equal(np.isnan(y), np.isnan(yr)), name
+            ok = ~np.isnan(yr)
+            assert np.array_equal(y[ok], yr[ok]), (name, alpha, beta)
+        del A
