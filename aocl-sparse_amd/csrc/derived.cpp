@@ -143,7 +143,7 @@ aoclsparse_status ensure_derived(aoclsparse_matrix A, aoclsparse_matrix_type typ
         });
         st = upload_csr(d->host, val_size(A->val_type), d->dev);
         if(st == aoclsparse_status_success)
-            st = build_spmv_plan(d->host.m, d->host.nnz, d->host.base, d->host.ptr, d->plan);
+            st = build_spmv_plan(d->host.m, d->host.nnz, d->host.base, d->host.ptr, d->plan, val_size(A->val_type));
         // a derived operator exists because products with it were asked for: give it the SELL-64 twin too
         // (when its padding is small); both kernels realise the same summation order on the derived rows
         if(st == aoclsparse_status_success && A->mem_policy == aoclsparse_memory_usage_unrestricted

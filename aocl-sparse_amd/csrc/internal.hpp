@@ -653,7 +653,7 @@ aoclsparse_status build_sell(const aoclsparse_int *row_ptr_host, const DeviceCsr
 aoclsparse_status build_merge_plan(aoclsparse_int m, aoclsparse_int nnz, aoclsparse_index_base base,
                                    const aoclsparse_int *row_ptr_host, size_t vsize, SpmvPlan &plan);
 aoclsparse_status build_spmv_plan(aoclsparse_int m, aoclsparse_int nnz, aoclsparse_index_base base,
-                                  const aoclsparse_int *row_ptr_host, SpmvPlan &plan);
+                                  const aoclsparse_int *row_ptr_host, SpmvPlan &plan, size_t vsize = 8);
 
 // ---- kernel launchers (HIP translation units) --------------------------------------------------
 // order: 0 scalar, 1 lane4, 2 lane8

@@ -479,8 +479,13 @@ static aoclsparse_int plan_rows(aoclsparse_int m, aoclsparse_index_base base, ao
     return nb;
 }
 
-static aoclsparse_int choose_tile(aoclsparse_int /*m*/, aoclsparse_int nnz)
+static aoclsparse_int choose_tile(aoclsparse_int /*m*/, aoclsparse_int nnz, size_t vsize)
 {
+    // float, large: 2048 entries per block (the LDS footprint of 1024 doubles; a float load instruction moves half the bytes, so a
+    // block needs twice the entries in flight: raw scsrmv on the 4096^2 Laplacian 0.216 / 0.202 / 0.182 ms at 512 / 1024 / 2048,
+    // double 0.267 / 0.261 / 0.284 on the same box -- profiles/r4/float_headline.txt)
+    if(vsize == 4 && (long long)nnz >= 1024LL * 256 * 16)
+        return 2048;
     // 1024: 18 KiB of LDS per workgroup -> 8 workgroups (32 wavefronts) per CU hide the
     // load -> gather -> reduce latency chain better than 4 fatter ones (0.257 vs 0.290 ms on the 4096^2
     // Laplacian).  A matrix too small to give every CU ~16 such blocks gets 512-entry tiles and 128-lane
@@ -517,7 +522,7 @@ static void plan_rows_range(aoclsparse_int r0, aoclsparse_int r1, aoclsparse_ind
 }
 
 aoclsparse_status build_spmv_plan(aoclsparse_int m, aoclsparse_int nnz, aoclsparse_index_base base,
-                                  const aoclsparse_int *row_ptr_host, SpmvPlan &plan)
+                                  const aoclsparse_int *row_ptr_host, SpmvPlan &plan, size_t vsize)
 {
     try
     {
@@ -525,7 +530,7 @@ aoclsparse_status build_spmv_plan(aoclsparse_int m, aoclsparse_int nnz, aoclspar
         // the thread count, so the plan is reproducible; a chunk edge merely ends a block early).  The one-shot raw
         // aoclsparse_?csrmv on host arrays builds a plan per call: a sequential pass over 16.8 M rows into a zeroed
         // 2(m+2)-int buffer cost ~50 ms there, more than sending the matrix over PCIe (profiles/r2/h2d_probe.jsonl).
-        plan.tile                 = choose_tile(m, nnz);
+        plan.tile                 = choose_tile(m, nnz, vsize);
         const aoclsparse_int tile = plan.tile & ~1;
         const int            nchunks = m >= (1 << 20) ? 16 : 1;
         std::vector<std::vector<aoclsparse_int>> part(nchunks);
@@ -786,6 +791,19 @@ aoclsparse_status build_merge_plan(aoclsparse_int m, aoclsparse_int nnz, aoclspa
     return aoclsparse_status_success;
 }
 
+// the value size build_spmv_plan sizes its row blocks by: a float handle plans 2,048-entry blocks for its products with vectors --
+// unless it carries an mm hint: csrmm_tile_kernel walks the same blocks, and the 32-column float slab of the 1000^2 Laplacian
+// measured 0.094-0.096 ms over 1,024-entry blocks against 0.101 over 2,048 (tools/exp_float_slab.py)
+static size_t plan_value_size(const _aoclsparse_matrix &A)
+{
+    if(A.val_type != aoclsparse_smat)
+        return 8;
+    for(const Hint &h : A.hints)
+        if(h.act == action_mm)
+            return 8;
+    return 4;
+}
+
 aoclsparse_status ensure_spmv(aoclsparse_matrix A, bool transposed, DeviceCsr *&dcsr, SpmvPlan *&plan)
 {
     dcsr = transposed ? &A->dev_trans : &A->dev_user;
@@ -811,7 +829,7 @@ aoclsparse_status ensure_spmv(aoclsparse_matrix A, bool transposed, DeviceCsr *&
     }
     if(!plan->valid)
     {
-        aoclsparse_status st = build_spmv_plan(h.m, h.ptr[h.m] - h.base, h.base, h.ptr, *plan);
+        aoclsparse_status st = build_spmv_plan(h.m, h.ptr[h.m] - h.base, h.base, h.ptr, *plan, plan_value_size(*A));
         if(st != aoclsparse_status_success)
             return st;
     }

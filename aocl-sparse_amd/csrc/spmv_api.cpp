@@ -471,7 +471,7 @@ aoclsparse_status csrmv_t(aoclsparse_operation trans, const T *alpha, aoclsparse
                 MI355_HIP_TRY(hipMemcpy(hrow.data(), row, sizeof(aoclsparse_int) * ((size_t)m + 1),
                                         hipMemcpyDeviceToHost));
                 held = std::make_shared<SpmvPlan>();
-                st   = build_spmv_plan(m, nnz, descr->base, hrow.data(), *held);
+                st   = build_spmv_plan(m, nnz, descr->base, hrow.data(), *held, sizeof(T));
                 if(st != aoclsparse_status_success)
                     return st;
                 std::lock_guard<std::mutex> g(rt.lock);
@@ -491,7 +491,7 @@ aoclsparse_status csrmv_t(aoclsparse_operation trans, const T *alpha, aoclsparse
         }
         else
         {
-            st = build_spmv_plan(m, nnz, descr->base, row, local);
+            st = build_spmv_plan(m, nnz, descr->base, row, local, sizeof(T));
             if(st != aoclsparse_status_success)
                 return st;
         }

@@ -661,3 +661,61 @@ def test_float_short_row_kernel_four_slices_per_wavefront():
             ok = ~np.isnan(yr)
             assert np.array_equal(y[ok], yr[ok]), (name, alpha, beta)
         del A
+
+
+def test_float_plans_use_2048_entry_row_blocks():
+    """Large float matrices plan 2,048-entry row blocks (round 4: matrix.cpp choose_tile).  On a 1,000^2 stencil (5 M non-zeros)
+    and a random matrix with rows of up to 700 entries (blocks of one to hundreds of rows, rows that do not fit the rest of a
+    block): raw aoclsparse_scsrmv on device arrays and aoclsparse_smv on a handle without a SELL copy, bit for bit against the
+    reference's float order; the 32-column row-major slab (csrmm_tile_kernel over the same blocks) equals the same columns of a
+    160-column product (another kernel, the same chains).  A double handle of the same matrix keeps 1,024, and so does a float
+    handle with an mm hint."""
+    import __graft_entry__ as entry
+    rng = np.random.default_rng(12)
+    ml, rpl, cil, vl = entry.laplace5(1000)
+    mr = 140000
+    rpr, cir, vr = random_csr(5, mr, mr, lambda r, i: int(r.integers(300, 700)) if i % 97 == 0 else int(r.integers(0, 60)))
+    assert len(vr) >= 1024 * 256 * 16
+    d = P.Descr()
+    assert L.aoclsparse_mi355_set_option(P.OPTION_SELL, 0) == 0
+    try:
+        for name, m, rp, ci, v in (("stencil", ml, rpl, cil, vl), ("random", mr, rpr, cir, vr)):
+            vf = v.astype(np.float32)
+            A = P.Matrix(0, m, m, rp, ci, vf)
+            assert L.aoclsparse_set_mv_hint(A.h, P.OP_NONE, d.h, 100) == 0 and L.aoclsparse_optimize(A.h) == 0
+            x = rng.uniform(-1, 1, m).astype(np.float32)
+            y0 = rng.uniform(-1, 1, m).astype(np.float32)
+            y = y0.copy()
+            assert P.smv(P.OP_NONE, -0.5, A, d, x, 1.25, y) == 0
+            inf = A.spmv_info()
+            assert inf.kernel == 1 and inf.tile == 2048, (name, inf.kernel, inf.tile)
+            st, yr = oracle.scsrmv("lane8", 0, -0.5, m, vf, ci, rp, x, 1.25, y0.copy())
+            assert st == 0 and np.array_equal(y, yr), name
+            L.aoclsparse_mi355_set_pointer_mode(P.PTR_DEVICE)
+            try:
+                yd = dev(y0)
+                assert P.scsrmv(P.OP_NONE, -0.5, m, m, len(vf), dev(vf), dev(ci), dev(rp), d, dev(x), 1.25, yd) == 0
+                torch.cuda.synchronize()
+                assert np.array_equal(yd.cpu().numpy(), yr), name
+            finally:
+                L.aoclsparse_mi355_set_pointer_mode(P.PTR_AUTO)
+            n = 160
+            B = rng.uniform(-1, 1, (m, n)).astype(np.float32)
+            C0 = rng.uniform(-1, 1, (m, n)).astype(np.float32)
+            Cw = dev(C0.ravel())
+            assert P.scsrmm(P.OP_NONE, 1.5, A, d, P.ORDER_ROW, dev(B.ravel()), n, n, -0.5, Cw, n) == 0
+            for j0 in (0, 64):
+                Bs, Cs0 = np.ascontiguousarray(B[:, j0:j0 + 32]), np.ascontiguousarray(C0[:, j0:j0 + 32])
+                Cs = dev(Cs0.ravel())
+                assert P.scsrmm(P.OP_NONE, 1.5, A, d, P.ORDER_ROW, dev(Bs.ravel()), 32, 32, -0.5, Cs, 32) == 0
+                torch.cuda.synchronize()
+                assert np.array_equal(Cs.cpu().numpy().reshape(m, 32), Cw.cpu().numpy().reshape(m, n)[:, j0:j0 + 32]), (name, j0)
+            Ad = P.Matrix(0, m, m, rp, ci, v)
+            assert L.aoclsparse_set_mv_hint(Ad.h, P.OP_NONE, d.h, 100) == 0 and L.aoclsparse_optimize(Ad.h) == 0
+            assert Ad.spmv_info().tile == 1024
+            # ... and so does a float handle that announces csrmm (the slab kernel walks the same blocks and prefers 1,024)
+            Am = P.Matrix(0, m, m, rp, ci, vf)
+            assert L.aoclsparse_set_mm_hint(Am.h, P.OP_NONE, d.h, 100) == 0 and L.aoclsparse_optimize(Am.h) == 0
+            assert Am.spmv_info().tile == 1024
+    finally:
+        assert L.aoclsparse_mi355_set_option(P.OPTION_SELL, -1) == 0
