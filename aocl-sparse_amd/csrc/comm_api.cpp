@@ -184,6 +184,8 @@ namespace
         MI355_HIP_TRY(hipMemcpyAsync(R.user.ptr, d.ptr.ptr, sizeof(aoclsparse_int) * ((size_t)R.m + 1), hipMemcpyDeviceToHost, stream));
         if(R.nnz > 0)
         {
+            host_result_touch(R.user.ind, sizeof(aoclsparse_int) * (size_t)R.nnz); // (fresh arrays: see host_result_alloc)
+            host_result_touch(R.user.val, vs * (size_t)R.nnz);
             MI355_HIP_TRY(hipMemcpyAsync(R.user.ind, d.ind.ptr, sizeof(aoclsparse_int) * (size_t)R.nnz, hipMemcpyDeviceToHost, stream));
             MI355_HIP_TRY(hipMemcpyAsync(R.user.val, d.val.ptr, vs * (size_t)R.nnz, hipMemcpyDeviceToHost, stream));
         }

@@ -234,6 +234,15 @@ struct DeviceBuffer
     // peer access is enabled, staged by the runtime otherwise); enqueued on s, not waited for
     aoclsparse_status clone_from(const DeviceBuffer &src, hipStream_t s);
     void              release();
+    // take over other's allocation (this one's own is released first)
+    void adopt(DeviceBuffer &other)
+    {
+        if(this == &other)
+            return;
+        release();
+        ptr = other.ptr, bytes = other.bytes;
+        other.ptr = nullptr, other.bytes = 0;
+    }
     template <typename T>
     T *as() const
     {
@@ -416,8 +425,15 @@ struct HostCsr
     aoclsparse_int       *iurow = nullptr;
     bool                  owned        = false;
     bool                  is_optimized = false;
+    // owned ind / val came from host_result_alloc (sp2m results: 2 MB-aligned, huge pages asked for) and are freed with free()
+    bool                  result_arrays = false;
     ~HostCsr();
 };
+// Host arrays a product hands back (sp2m): a copy out of HBM first-touches them, and on a fresh new[] that costs more than the
+// copy -- 156 MB: 11.6-27 ms in 4 KB pages whatever the number of touching threads, 1.1 ms as 2 MB pages touched by 16 threads
+// (tools/pagefault_probe.cpp on the GPU box).  2 MB-aligned + MADV_HUGEPAGE from 4 MB up, plain malloc below; released with free().
+void *host_result_alloc(size_t bytes);
+void  host_result_touch(void *p, size_t bytes); // first touch by several threads (no-op for small arrays)
 
 // A general CSR derived from the clean CSR so that the general kernels can serve a symmetric or
 // triangular descriptor: key = (type, fill, diag, transposed).
@@ -553,7 +569,7 @@ private:
     std::atomic<bool> inited_{false}; // set (release) after init_status_ / device / events are written
     aoclsparse_status init_status_ = aoclsparse_status_success;
     hipStream_t  stream_ = nullptr;
-    DeviceBuffer stage_[16]; // 0-7: csrmv / mv / trsv / dotmv, 8-15: ELL family and BLKCSR (ell_api.cpp, blk_api.cpp)
+    DeviceBuffer stage_[32]; // 0-7: csrmv / mv / trsv / dotmv, 8-15: ELL family and BLKCSR (ell_api.cpp, blk_api.cpp), 16-31: sp2m (sp2m_api.cpp)
 };
 
 // While one of these is alive on a thread, Runtime::get() on that thread is the given slot: its device is current, its
@@ -810,6 +826,10 @@ template <typename R>
 aoclsparse_status launch_caxpby(hipStream_t s, aoclsparse_int n, cplx<R> a, const cplx<R> *x, cplx<R> b, const cplx<R> *y,
                                 cplx<R> *w);
 // spgemm (spgemm_kernels.hip): list entries per wavefront kept in LDS; rows whose upper bound exceeds it use a global slab
+// row bins of spgemm_hash_kernel (list capacity 32 / 256 / 2048 / 8192; the last bin is the one-product-at-a-time kernel).  The
+// fill pass has no 8192 bin (its LDS would not fit): rows with more than 2048 entries of C go to the last bin there.
+constexpr int SPGEMM_BINS = 5;
+int           spgemm_bin_of(long long entries, bool fill);
 template <typename T>
 constexpr int spgemm_lds_cap()
 {

@@ -1,6 +1,8 @@
 // runtime.cpp -- device context, pointer classification, staging buffers, misc. entry points.
 #include "internal.hpp"
 
+#include <sys/mman.h>
+
 #include <cctype>
 #include <condition_variable>
 #include <cstdio>
@@ -87,11 +89,45 @@ HostCsr::~HostCsr()
     if(owned)
     {
         delete[] ptr;
-        delete[] ind;
-        ::operator delete(val);
+        if(result_arrays)
+        {
+            std::free(ind);
+            std::free(val);
+        }
+        else
+        {
+            delete[] ind;
+            ::operator delete(val);
+        }
     }
     delete[] idiag;
     delete[] iurow;
+}
+
+constexpr size_t HOST_RESULT_BIG = (size_t)4 << 20, HOST_RESULT_PAGE = (size_t)2 << 20;
+
+void *host_result_alloc(size_t bytes)
+{
+    if(bytes < HOST_RESULT_BIG)
+        return std::malloc(bytes ? bytes : 1);
+    void *p = nullptr;
+    if(posix_memalign(&p, HOST_RESULT_PAGE, (bytes + HOST_RESULT_PAGE - 1) / HOST_RESULT_PAGE * HOST_RESULT_PAGE) != 0)
+        return nullptr;
+    (void)madvise(p, bytes, MADV_HUGEPAGE); // (advice: without transparent huge pages the array is simply 4 KB pages)
+    return p;
+}
+
+void host_result_touch(void *p, size_t bytes)
+{
+    if(!p || bytes < HOST_RESULT_BIG)
+        return;
+    const long long pages = (long long)((bytes + HOST_RESULT_PAGE - 1) / HOST_RESULT_PAGE);
+    parallel_for(pages, 4, [&](long long p0, long long p1) {
+        volatile char *b = static_cast<volatile char *>(p);
+        for(long long pg = p0; pg < p1; pg++)
+            for(size_t o = (size_t)pg * HOST_RESULT_PAGE; o < std::min(bytes, (size_t)(pg + 1) * HOST_RESULT_PAGE); o += 4096)
+                b[o] = 0;
+    });
 }
 
 thread_local Runtime *tl_runtime = nullptr;

@@ -10,6 +10,8 @@
 #include "internal.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <type_traits>
 #include <vector>
@@ -19,12 +21,17 @@ using namespace mi355;
 namespace mi355
 {
 template <typename T>
-aoclsparse_status launch_spgemm(hipStream_t s, bool fill, aoclsparse_int m, int base_a,
+aoclsparse_status launch_spgemm(hipStream_t s, bool fill, aoclsparse_int nrows, const aoclsparse_int *rows, int base_a,
                                 const aoclsparse_int *ptr_a, const aoclsparse_int *ind_a, const T *val_a,
                                 int base_b, const aoclsparse_int *ptr_b, const aoclsparse_int *ind_b,
                                 const T *val_b, const long long *slab_off, int *slab_idx, T *slab_val,
                                 const aoclsparse_int *ptr_c, aoclsparse_int *cnt_or_ind_c, T *val_c, bool conj_a,
                                 bool conj_b);
+template <typename T>
+aoclsparse_status launch_spgemm_bin(hipStream_t s, bool fill, int bin, aoclsparse_int nrows, const aoclsparse_int *rows, int base_a,
+                                    const aoclsparse_int *ptr_a, const aoclsparse_int *ind_a, const T *val_a, int base_b,
+                                    const aoclsparse_int *ptr_b, const aoclsparse_int *ind_b, const T *val_b,
+                                    const aoclsparse_int *ptr_c, aoclsparse_int *cnt_or_ind_c, T *val_c, bool conj_a, bool conj_b);
 
 aoclsparse_status new_csr_result(aoclsparse_matrix *C, aoclsparse_int m, aoclsparse_int n, aoclsparse_int nnz,
                                  aoclsparse_matrix_data_type vt, const aoclsparse_int *row_ptr, aoclsparse_index_base base)
@@ -36,9 +43,9 @@ aoclsparse_status new_csr_result(aoclsparse_matrix *C, aoclsparse_int m, aoclspa
     c->m = m, c->n = n, c->nnz = nnz, c->base = base, c->val_type = vt;
     c->user.m = m, c->user.n = n, c->user.nnz = nnz, c->user.base = base;
     c->user.ptr = new(std::nothrow) aoclsparse_int[(size_t)m + 1];
-    c->user.ind = new(std::nothrow) aoclsparse_int[(size_t)std::max(nnz, 1)];
-    c->user.val = ::operator new(vs * (size_t)std::max(nnz, 1), std::nothrow);
-    c->user.owned = true; // freed by the handle
+    c->user.ind = static_cast<aoclsparse_int *>(host_result_alloc(sizeof(aoclsparse_int) * (size_t)std::max(nnz, 1)));
+    c->user.val = host_result_alloc(vs * (size_t)std::max(nnz, 1));
+    c->user.owned = c->user.result_arrays = true; // freed by the handle
     c->owns_user_arrays = true;
     if(!c->user.ptr || !c->user.ind || !c->user.val)
     {
@@ -100,6 +107,34 @@ void transpose_of(const Operand<T> &a, Operand<T> &t)
         t.optr[j] += b;
     t.ptr = t.optr.data(), t.ind = t.oind.data(), t.val = t.oval.data();
 }
+
+// the rows of a product grouped by the bin of spgemm_hash_kernel that serves them (device arrays: staging slots of the runtime,
+// grown on demand and reused by the next product -- a hipMalloc / hipFree pair per temporary cost more than the kernels)
+struct Binned
+{
+    aoclsparse_int        bounds[SPGEMM_BINS + 1] = {};
+    long long             slab = 0; // list entries of the rows of the last bin
+    const aoclsparse_int *d_order = nullptr; // null: one bin holds every row (no list needed)
+    const long long      *d_off = nullptr; // m + 1 slab offsets; null when the last bin is empty
+    int                  *d_slab_i = nullptr;
+};
+enum
+{
+    SLOT_XP = 16,
+    SLOT_XI,
+    SLOT_XV,
+    SLOT_YP,
+    SLOT_YI,
+    SLOT_YV,
+    SLOT_CNT,
+    SLOT_ORDER_COUNT,
+    SLOT_OFF_COUNT,
+    SLOT_SLAB_COUNT,
+    SLOT_ORDER_FILL,
+    SLOT_OFF_FILL,
+    SLOT_SLAB_FILL,
+    SLOT_SLABV_FILL
+};
 
 template <typename T>
 aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr descrA, const aoclsparse_matrix A,
@@ -184,51 +219,167 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
             }
         }
         const aoclsparse_int m = X->m, n = Y->n; // product D = X * Y is m x n
+        // diagnostic: AOCLSPARSE_MI355_SP2M_TRACE=1 prints the wall time of every phase of the call (synchronising after each)
+        static const bool trace = getenv("AOCLSPARSE_MI355_SP2M_TRACE") != nullptr;
+        auto              t_last = std::chrono::steady_clock::now();
+        auto              phase  = [&](const char *what) {
+            if(!trace)
+                return;
+            (void)hipStreamSynchronize(rt.stream());
+            const auto now = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "sp2m %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+            t_last = now;
+        };
+        phase("operands (transposes)");
 
-        // upper bound of every row's list; rows above the LDS capacity get a slice of a global slab
-        // (offset table: off[i+1]-off[i] = upper bound for such rows, 0 for rows that use LDS)
-        std::vector<long long> off((size_t)m + 1, 0);
-        for(aoclsparse_int i = 0; i < m; i++)
-        {
-            long long ub = 0;
-            for(aoclsparse_int p = X->ptr[i] - X->base; p < X->ptr[i + 1] - X->base; p++)
+        // upper bound of every row's list = the products of the row (and never more than n); the rows are binned by it for the
+        // count pass and by their exact count for the fill pass (spgemm_kernels.hip: spgemm_hash_kernel)
+        std::vector<long long> ub((size_t)m);
+        parallel_for(m, 1 << 14, [&](long long i0, long long i1) {
+            for(aoclsparse_int i = (aoclsparse_int)i0; i < (aoclsparse_int)i1; i++)
             {
-                const aoclsparse_int c = X->ind[p] - X->base;
-                ub += Y->ptr[c + 1] - Y->ptr[c];
+                long long u = 0;
+                for(aoclsparse_int p = X->ptr[i] - X->base; p < X->ptr[i + 1] - X->base; p++)
+                {
+                    const aoclsparse_int c = X->ind[p] - X->base;
+                    u += Y->ptr[c + 1] - Y->ptr[c];
+                }
+                ub[(size_t)i] = u;
             }
-            off[i + 1] = off[i] + (ub > spgemm_lds_cap<T>() ? ub : 0);
-        }
-        const long long slab_total = off[m];
-        DeviceBuffer d_xp, d_xi, d_xv, d_yp, d_yi, d_yv, d_off, d_slab_i, d_slab_v, d_cnt, d_cptr, d_ci, d_cv;
+        });
+        phase("upper bounds");
         hipStream_t  s = rt.stream();
+        // rows grouped by bin (stable inside a bin: consecutive rows stay together), and for the rows of the last bin a slab of
+        // `cap(i)` list entries each: bounds[b] .. bounds[b + 1] = bin b's stretch of `order`
+        auto bin_rows = [&](Binned &bn, bool for_fill, auto cap_of) -> aoclsparse_status {
+            std::vector<unsigned char> bin((size_t)m);
+            parallel_for(m, 1 << 16, [&](long long i0, long long i1) {
+                for(long long i = i0; i < i1; i++)
+                    bin[(size_t)i] = (unsigned char)spgemm_bin_of(cap_of((aoclsparse_int)i), for_fill);
+            });
+            aoclsparse_int cnt[SPGEMM_BINS] = {};
+            for(aoclsparse_int i = 0; i < m; i++)
+                cnt[bin[(size_t)i]]++;
+            bn.bounds[0] = 0;
+            for(int b = 0; b < SPGEMM_BINS; b++)
+                bn.bounds[b + 1] = bn.bounds[b] + cnt[b];
+            aoclsparse_status rc = aoclsparse_status_success;
+            bool              one_bin = false;
+            for(int b = 0; b < SPGEMM_BINS; b++)
+                one_bin |= cnt[b] == m;
+            if(!one_bin)
+            {
+                aoclsparse_int next[SPGEMM_BINS];
+                std::copy(bn.bounds, bn.bounds + SPGEMM_BINS, next);
+                std::vector<aoclsparse_int> order((size_t)m);
+                for(aoclsparse_int i = 0; i < m; i++)
+                    order[(size_t)next[bin[(size_t)i]]++] = i;
+                void *p = nullptr;
+                rc      = rt.staging(for_fill ? SLOT_ORDER_FILL : SLOT_ORDER_COUNT, sizeof(aoclsparse_int) * (size_t)m, &p);
+                if(rc == aoclsparse_status_success)
+                    rc = rt.h2d(p, order.data(), sizeof(aoclsparse_int) * (size_t)m);
+                if(rc != aoclsparse_status_success)
+                    return rc;
+                bn.d_order = static_cast<const aoclsparse_int *>(p);
+            }
+            if(cnt[SPGEMM_BINS - 1] > 0)
+            {
+                std::vector<long long> off((size_t)m + 1, 0);
+                for(aoclsparse_int i = 0; i < m; i++)
+                    off[(size_t)i + 1] = off[(size_t)i] + (bin[(size_t)i] == SPGEMM_BINS - 1 ? cap_of(i) : 0);
+                bn.slab = off[(size_t)m];
+                void *p = nullptr, *q = nullptr;
+                rc      = rt.staging(for_fill ? SLOT_OFF_FILL : SLOT_OFF_COUNT, sizeof(long long) * ((size_t)m + 1), &p);
+                if(rc == aoclsparse_status_success)
+                    rc = rt.h2d(p, off.data(), sizeof(long long) * ((size_t)m + 1));
+                if(rc == aoclsparse_status_success)
+                    rc = rt.staging(for_fill ? SLOT_SLAB_FILL : SLOT_SLAB_COUNT, sizeof(int) * (size_t)std::max<long long>(bn.slab, 1), &q);
+                bn.d_off = static_cast<const long long *>(p), bn.d_slab_i = static_cast<int *>(q);
+            }
+            return rc;
+        };
+        // operands on the device: a handle that already holds its CSR arrays in HBM (any product or optimize before) is used as
+        // it is; otherwise one upload per distinct operand (A * A sends A once)
+        DeviceBuffer d_cptr, d_ci, d_cv; // the result's own arrays
         const bool   count = request != aoclsparse_stage_finalize, fill = request != aoclsparse_stage_nnz_count;
-        st = d_xp.upload(X->ptr, sizeof(aoclsparse_int) * ((size_t)X->m + 1), s);
+        struct DevOp
+        {
+            const aoclsparse_int *ptr = nullptr, *ind = nullptr;
+            const void           *val = nullptr;
+        } dx, dy;
+        auto resident = [&](const Operand<T> *o, const aoclsparse_matrix H, DevOp &dv) {
+            // (only an operand that IS the handle's own arrays: transposes built above are not)
+            if(o->ptr != H->user.ptr)
+                return false;
+            std::shared_lock<std::shared_mutex> r(H->guard);
+            if(!H->dev_user.valid || H->dev_user.nnz != o->nnz)
+                return false;
+            dv.ptr = H->dev_user.ptr.as<aoclsparse_int>(), dv.ind = H->dev_user.ind.as<aoclsparse_int>(), dv.val = H->dev_user.val.ptr;
+            return true;
+        };
+        const aoclsparse_matrix HX = opflag == 3 ? B : A, HY = opflag == 3 ? A : B;
+        auto send = [&](const Operand<T> *o, const aoclsparse_matrix H, DevOp &dv, int slot) {
+            if(resident(o, H, dv))
+                return aoclsparse_status_success;
+            void             *pp = nullptr, *pi = nullptr, *pv = nullptr;
+            aoclsparse_status rc = rt.staging(slot, sizeof(aoclsparse_int) * ((size_t)o->m + 1), &pp);
+            if(rc == aoclsparse_status_success)
+                rc = rt.h2d(pp, o->ptr, sizeof(aoclsparse_int) * ((size_t)o->m + 1));
+            if(rc == aoclsparse_status_success)
+                rc = rt.staging(slot + 1, sizeof(aoclsparse_int) * (size_t)o->nnz, &pi);
+            if(rc == aoclsparse_status_success)
+                rc = rt.h2d(pi, o->ind, sizeof(aoclsparse_int) * (size_t)o->nnz);
+            if(rc == aoclsparse_status_success && fill)
+            {
+                rc = rt.staging(slot + 2, sizeof(T) * (size_t)o->nnz, &pv);
+                if(rc == aoclsparse_status_success)
+                    rc = rt.h2d(pv, o->val, sizeof(T) * (size_t)o->nnz);
+            }
+            dv.ptr = static_cast<const aoclsparse_int *>(pp), dv.ind = static_cast<const aoclsparse_int *>(pi), dv.val = pv;
+            return rc;
+        };
+        st = send(X, HX, dx, SLOT_XP);
         if(st == aoclsparse_status_success)
-            st = d_xi.upload(X->ind, sizeof(aoclsparse_int) * (size_t)X->nnz, s);
-        if(st == aoclsparse_status_success)
-            st = d_yp.upload(Y->ptr, sizeof(aoclsparse_int) * ((size_t)Y->m + 1), s);
-        if(st == aoclsparse_status_success)
-            st = d_yi.upload(Y->ind, sizeof(aoclsparse_int) * (size_t)Y->nnz, s);
-        if(st == aoclsparse_status_success)
-            st = d_off.upload(off.data(), sizeof(long long) * ((size_t)m + 1), s);
-        if(st == aoclsparse_status_success)
-            st = d_slab_i.alloc(sizeof(int) * (size_t)std::max<long long>(slab_total, 1));
+        {
+            if(Y->ptr == X->ptr && Y->ind == X->ind && Y->val == X->val)
+                dy = dx;
+            else
+                st = send(Y, HY, dy, SLOT_YP);
+        }
         if(st != aoclsparse_status_success)
             return st;
+        phase("operands to the device");
+        auto run_pass = [&](bool pass_fill, Binned &bn, T *slab_v, const aoclsparse_int *ptr_c, aoclsparse_int *out_i,
+                            T *out_v) -> aoclsparse_status {
+            aoclsparse_status rc = aoclsparse_status_success;
+            for(int b = 0; b < SPGEMM_BINS - 1 && rc == aoclsparse_status_success; b++)
+                rc = launch_spgemm_bin<T>(s, pass_fill, b, bn.bounds[b + 1] - bn.bounds[b], bn.d_order ? bn.d_order + bn.bounds[b] : nullptr,
+                                          X->base, dx.ptr, dx.ind, static_cast<const T *>(dx.val), Y->base, dy.ptr, dy.ind,
+                                          static_cast<const T *>(dy.val), ptr_c, out_i, out_v, conj_x, conj_y);
+            const aoclsparse_int nlast = bn.bounds[SPGEMM_BINS] - bn.bounds[SPGEMM_BINS - 1];
+            if(rc == aoclsparse_status_success && nlast > 0)
+                rc = launch_spgemm<T>(s, pass_fill, nlast, bn.d_order ? bn.d_order + bn.bounds[SPGEMM_BINS - 1] : nullptr, X->base, dx.ptr,
+                                      dx.ind, static_cast<const T *>(dx.val), Y->base, dy.ptr, dy.ind, static_cast<const T *>(dy.val),
+                                      bn.d_off, bn.d_slab_i, slab_v, ptr_c, out_i, out_v, conj_x, conj_y);
+            return rc;
+        };
 
         if(count)
         {
-            st = d_cnt.alloc(sizeof(aoclsparse_int) * (size_t)m);
+            void *d_cnt = nullptr;
+            st          = rt.staging(SLOT_CNT, sizeof(aoclsparse_int) * (size_t)m, &d_cnt);
             if(st != aoclsparse_status_success)
                 return st;
-            st = launch_spgemm<T>(s, false, m, X->base, d_xp.as<aoclsparse_int>(), d_xi.as<aoclsparse_int>(),
-                                  nullptr, Y->base, d_yp.as<aoclsparse_int>(), d_yi.as<aoclsparse_int>(), nullptr,
-                                  d_off.as<long long>(), d_slab_i.as<int>(), nullptr, nullptr,
-                                  d_cnt.as<aoclsparse_int>(), nullptr, false, false);
+            Binned by_bound;
+            st = bin_rows(by_bound, false, [&](aoclsparse_int i) { return std::min<long long>(ub[(size_t)i], n); });
+            phase("count: bins");
+            if(st == aoclsparse_status_success)
+                st = run_pass(false, by_bound, nullptr, nullptr, static_cast<aoclsparse_int *>(d_cnt), nullptr);
             if(st != aoclsparse_status_success)
                 return st;
+            phase("count: kernels");
             std::vector<aoclsparse_int> cptr((size_t)m + 1, 0);
-            MI355_HIP_TRY(hipMemcpyAsync(cptr.data() + 1, d_cnt.ptr, sizeof(aoclsparse_int) * (size_t)m,
+            MI355_HIP_TRY(hipMemcpyAsync(cptr.data() + 1, d_cnt, sizeof(aoclsparse_int) * (size_t)m,
                                          hipMemcpyDeviceToHost, s));
             MI355_HIP_TRY(hipStreamSynchronize(s));
             long long run = 0; // 64-bit prefix sum, overflow -> invalid_size (csr2m.cpp:221-236)
@@ -240,6 +391,7 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
             if(run > 2147483647LL)
                 return aoclsparse_status_invalid_size;
             const aoclsparse_int nnz_c = (aoclsparse_int)run;
+            phase("count: counts to host, scan");
             if(opflag == 3)
             {
                 // C is n x m; keep D's row_ptr in the handle's transposed-product scratch until finalize
@@ -261,6 +413,7 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
                     return st;
             }
         }
+        phase("result handle");
         if(fill)
         {
             if(*C == nullptr)
@@ -274,11 +427,21 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
             if(d->m != m || d->n != n)
                 return aoclsparse_status_invalid_size; // csr2m.cpp:397-399
             const aoclsparse_int nnz_c = d->ptr[m];
-            st = d_xv.upload(X->val, sizeof(T) * (size_t)X->nnz, s);
-            if(st == aoclsparse_status_success)
-                st = d_yv.upload(Y->val, sizeof(T) * (size_t)Y->nnz, s);
-            if(st == aoclsparse_status_success)
-                st = d_slab_v.alloc(sizeof(T) * (size_t)std::max<long long>(slab_total, 1));
+            // whatever the handle derived from an earlier fill (device copies, plans, SELL twin, replicas) mirrors the old values
+            // (the (B A)^T scratch of stage 1 lives in c->trans, which invalidate would drop: carried across)
+            auto keep = std::move(c->trans);
+            (void)aoclsparse_mi355_invalidate(c);
+            c->trans = std::move(keep);
+            // rows binned by their exact count (the caller's row_ptr of stage 1); a row_ptr that does not belong to this product
+            // is refused here rather than trusted by a kernel (csr2m.cpp:397-399 checks the dimensions only)
+            for(aoclsparse_int i = 0; i < m; i++)
+                if(d->ptr[i + 1] < d->ptr[i] || d->ptr[i + 1] - d->ptr[i] > std::min<long long>(ub[(size_t)i], n))
+                    return aoclsparse_status_invalid_value;
+            Binned by_count;
+            st = bin_rows(by_count, true, [&](aoclsparse_int i) { return (long long)(d->ptr[i + 1] - d->ptr[i]); });
+            void *slab_v = nullptr;
+            if(st == aoclsparse_status_success && by_count.slab > 0)
+                st = rt.staging(SLOT_SLABV_FILL, sizeof(T) * (size_t)by_count.slab, &slab_v);
             if(st == aoclsparse_status_success)
                 st = d_cptr.upload(d->ptr, sizeof(aoclsparse_int) * ((size_t)m + 1), s);
             if(st == aoclsparse_status_success)
@@ -287,16 +450,29 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
                 st = d_cv.alloc(sizeof(T) * (size_t)std::max(nnz_c, 1));
             if(st != aoclsparse_status_success)
                 return st;
-            st = launch_spgemm<T>(s, true, m, X->base, d_xp.as<aoclsparse_int>(), d_xi.as<aoclsparse_int>(),
-                                  d_xv.as<T>(), Y->base, d_yp.as<aoclsparse_int>(), d_yi.as<aoclsparse_int>(),
-                                  d_yv.as<T>(), d_off.as<long long>(), d_slab_i.as<int>(), d_slab_v.as<T>(),
-                                  d_cptr.as<aoclsparse_int>(), d_ci.as<aoclsparse_int>(), d_cv.as<T>(), conj_x, conj_y);
+            phase("fill: bins, buffers");
+            st = run_pass(true, by_count, static_cast<T *>(slab_v), d_cptr.as<aoclsparse_int>(), d_ci.as<aoclsparse_int>(), d_cv.as<T>());
             if(st != aoclsparse_status_success)
                 return st;
+            // while the kernels run: the result's host arrays are first-touched by several threads (host_result_alloc; faulted in
+            // by the copy itself they cost more than the copy: 7-13 ms for 156 MB against ~3)
+            host_result_touch(d->ind, sizeof(aoclsparse_int) * (size_t)nnz_c);
+            host_result_touch(d->val, sizeof(T) * (size_t)nnz_c);
+            phase("fill: kernels (+ host pages)");
             MI355_HIP_TRY(hipMemcpyAsync(d->ind, d_ci.ptr, sizeof(aoclsparse_int) * (size_t)nnz_c,
                                          hipMemcpyDeviceToHost, s));
             MI355_HIP_TRY(hipMemcpyAsync(d->val, d_cv.ptr, sizeof(T) * (size_t)nnz_c, hipMemcpyDeviceToHost, s));
             MI355_HIP_TRY(hipStreamSynchronize(s));
+            phase("fill: result to host");
+            if(opflag != 3)
+            {
+                // the result stays resident: a product, solve or another sp2m with this handle starts from HBM
+                std::unique_lock<std::shared_mutex> w(c->guard);
+                DeviceCsr                          &dc = c->dev_user;
+                dc.ptr.adopt(d_cptr), dc.ind.adopt(d_ci), dc.val.adopt(d_cv);
+                dc.m = m, dc.n = n, dc.nnz = nnz_c, dc.base = aoclsparse_index_base_zero;
+                dc.valid = true;
+            }
             if(opflag == 3)
             {
                 // C = D^T by the reference's counting-sort transpose (csr2m.cpp:520-538)
