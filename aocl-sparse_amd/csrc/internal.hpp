@@ -825,16 +825,17 @@ aoclsparse_status launch_cdot(hipStream_t s, aoclsparse_int n, const cplx<R> *x,
 template <typename R>
 aoclsparse_status launch_caxpby(hipStream_t s, aoclsparse_int n, cplx<R> a, const cplx<R> *x, cplx<R> b, const cplx<R> *y,
                                 cplx<R> *w);
-// spgemm (spgemm_kernels.hip): list entries per wavefront kept in LDS; rows whose upper bound exceeds it use a global slab
-// row bins of spgemm_hash_kernel (list capacity 32 / 256 / 2048 / 8192; the last bin is the one-product-at-a-time kernel).  The
-// fill pass has no 8192 bin (its LDS would not fit): rows with more than 2048 entries of C go to the last bin there.
+// row bins of spgemm_hash_kernel (spgemm_kernels.hip): list capacity 32 / 256 / 2048 / 8192 in LDS; the last bin keeps its tables
+// in a global slab.  The fill pass has no 8192 bin (values and slots would not fit the LDS): rows with more than 2048 entries of
+// C go to the last bin there.
 constexpr int SPGEMM_BINS = 5;
 int           spgemm_bin_of(long long entries, bool fill);
-template <typename T>
-constexpr int spgemm_lds_cap()
+// one row of the last bin: its hash table of 2^logh slots starts at h_off (g_key / g_pos), its list at c_off (g_list / g_acc)
+struct SpgHeavy
 {
-    return sizeof(T) > 8 ? 512 : 1024; // 4 waves x cap x (4 + sizeof(T)) bytes of static LDS <= 64 KB
-}
+    int       row, logh;
+    long long h_off, c_off;
+};
 // complex triangular solve (complex_kernels.hip): the hybrid schedule of the plan (runs of narrow levels inside one
 // workgroup, one launch per wide level); conj_diag for op = H (the plan's values are stored conjugated)
 template <typename R>

@@ -21,12 +21,11 @@ using namespace mi355;
 namespace mi355
 {
 template <typename T>
-aoclsparse_status launch_spgemm(hipStream_t s, bool fill, aoclsparse_int nrows, const aoclsparse_int *rows, int base_a,
-                                const aoclsparse_int *ptr_a, const aoclsparse_int *ind_a, const T *val_a,
-                                int base_b, const aoclsparse_int *ptr_b, const aoclsparse_int *ind_b,
-                                const T *val_b, const long long *slab_off, int *slab_idx, T *slab_val,
-                                const aoclsparse_int *ptr_c, aoclsparse_int *cnt_or_ind_c, T *val_c, bool conj_a,
-                                bool conj_b);
+aoclsparse_status launch_spgemm_heavy(hipStream_t s, bool fill, aoclsparse_int nrows, const SpgHeavy *heavy, int *g_key, int *g_pos,
+                                      int *g_list, T *g_acc, int base_a, const aoclsparse_int *ptr_a, const aoclsparse_int *ind_a,
+                                      const T *val_a, int base_b, const aoclsparse_int *ptr_b, const aoclsparse_int *ind_b,
+                                      const T *val_b, const aoclsparse_int *ptr_c, aoclsparse_int *cnt_or_ind_c, T *val_c,
+                                      bool conj_a, bool conj_b);
 template <typename T>
 aoclsparse_status launch_spgemm_bin(hipStream_t s, bool fill, int bin, aoclsparse_int nrows, const aoclsparse_int *rows, int base_a,
                                     const aoclsparse_int *ptr_a, const aoclsparse_int *ind_a, const T *val_a, int base_b,
@@ -113,11 +112,15 @@ void transpose_of(const Operand<T> &a, Operand<T> &t)
 struct Binned
 {
     aoclsparse_int        bounds[SPGEMM_BINS + 1] = {};
-    long long             slab = 0; // list entries of the rows of the last bin
     const aoclsparse_int *d_order = nullptr; // null: one bin holds every row (no list needed)
-    const long long      *d_off = nullptr; // m + 1 slab offsets; null when the last bin is empty
-    int                  *d_slab_i = nullptr;
+    // the rows of the last bin (tables in a global slab), in batches whose tables fit SPG_SLAB_SLOTS: batch b = records
+    // [batch[b], batch[b + 1]) with offsets that start at 0
+    std::vector<SpgHeavy>       heavy;
+    std::vector<aoclsparse_int> batch;
+    long long                   slots = 0, entries = 0; // of the largest batch
+    const SpgHeavy             *d_heavy = nullptr;
 };
+constexpr long long SPG_SLAB_SLOTS = 1LL << 28; // 1 GiB of keys (and of slots in the fill pass) per batch
 enum
 {
     SLOT_XP = 16,
@@ -128,12 +131,13 @@ enum
     SLOT_YV,
     SLOT_CNT,
     SLOT_ORDER_COUNT,
-    SLOT_OFF_COUNT,
-    SLOT_SLAB_COUNT,
     SLOT_ORDER_FILL,
-    SLOT_OFF_FILL,
-    SLOT_SLAB_FILL,
-    SLOT_SLABV_FILL
+    SLOT_HEAVY_COUNT,
+    SLOT_HEAVY_FILL,
+    SLOT_G_KEY,
+    SLOT_G_POS,
+    SLOT_G_LIST,
+    SLOT_G_ACC
 };
 
 template <typename T>
@@ -284,17 +288,34 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
             }
             if(cnt[SPGEMM_BINS - 1] > 0)
             {
-                std::vector<long long> off((size_t)m + 1, 0);
+                bn.heavy.reserve((size_t)cnt[SPGEMM_BINS - 1]);
+                long long hs = 0, cs = 0;
+                bn.batch.push_back(0);
                 for(aoclsparse_int i = 0; i < m; i++)
-                    off[(size_t)i + 1] = off[(size_t)i] + (bin[(size_t)i] == SPGEMM_BINS - 1 ? cap_of(i) : 0);
-                bn.slab = off[(size_t)m];
-                void *p = nullptr, *q = nullptr;
-                rc      = rt.staging(for_fill ? SLOT_OFF_FILL : SLOT_OFF_COUNT, sizeof(long long) * ((size_t)m + 1), &p);
+                {
+                    if(bin[(size_t)i] != SPGEMM_BINS - 1)
+                        continue;
+                    const long long cap = cap_of(i);
+                    if(cap > (1LL << 29))
+                        return aoclsparse_status_memory_error;
+                    int logh = 6;
+                    while((1LL << logh) < 2 * cap)
+                        logh++;
+                    if(hs + (1LL << logh) > SPG_SLAB_SLOTS && hs > 0)
+                    {
+                        bn.batch.push_back((aoclsparse_int)bn.heavy.size());
+                        hs = cs = 0;
+                    }
+                    bn.heavy.push_back(SpgHeavy{i, logh, hs, cs});
+                    hs += 1LL << logh, cs += cap;
+                    bn.slots = std::max(bn.slots, hs), bn.entries = std::max(bn.entries, cs);
+                }
+                bn.batch.push_back((aoclsparse_int)bn.heavy.size());
+                void *p = nullptr;
+                rc      = rt.staging(for_fill ? SLOT_HEAVY_FILL : SLOT_HEAVY_COUNT, sizeof(SpgHeavy) * bn.heavy.size(), &p);
                 if(rc == aoclsparse_status_success)
-                    rc = rt.h2d(p, off.data(), sizeof(long long) * ((size_t)m + 1));
-                if(rc == aoclsparse_status_success)
-                    rc = rt.staging(for_fill ? SLOT_SLAB_FILL : SLOT_SLAB_COUNT, sizeof(int) * (size_t)std::max<long long>(bn.slab, 1), &q);
-                bn.d_off = static_cast<const long long *>(p), bn.d_slab_i = static_cast<int *>(q);
+                    rc = rt.h2d(p, bn.heavy.data(), sizeof(SpgHeavy) * bn.heavy.size());
+                bn.d_heavy = static_cast<const SpgHeavy *>(p);
             }
             return rc;
         };
@@ -349,18 +370,30 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
         if(st != aoclsparse_status_success)
             return st;
         phase("operands to the device");
-        auto run_pass = [&](bool pass_fill, Binned &bn, T *slab_v, const aoclsparse_int *ptr_c, aoclsparse_int *out_i,
-                            T *out_v) -> aoclsparse_status {
+        auto run_pass = [&](bool pass_fill, Binned &bn, const aoclsparse_int *ptr_c, aoclsparse_int *out_i, T *out_v) -> aoclsparse_status {
             aoclsparse_status rc = aoclsparse_status_success;
             for(int b = 0; b < SPGEMM_BINS - 1 && rc == aoclsparse_status_success; b++)
                 rc = launch_spgemm_bin<T>(s, pass_fill, b, bn.bounds[b + 1] - bn.bounds[b], bn.d_order ? bn.d_order + bn.bounds[b] : nullptr,
                                           X->base, dx.ptr, dx.ind, static_cast<const T *>(dx.val), Y->base, dy.ptr, dy.ind,
                                           static_cast<const T *>(dy.val), ptr_c, out_i, out_v, conj_x, conj_y);
-            const aoclsparse_int nlast = bn.bounds[SPGEMM_BINS] - bn.bounds[SPGEMM_BINS - 1];
-            if(rc == aoclsparse_status_success && nlast > 0)
-                rc = launch_spgemm<T>(s, pass_fill, nlast, bn.d_order ? bn.d_order + bn.bounds[SPGEMM_BINS - 1] : nullptr, X->base, dx.ptr,
-                                      dx.ind, static_cast<const T *>(dx.val), Y->base, dy.ptr, dy.ind, static_cast<const T *>(dy.val),
-                                      bn.d_off, bn.d_slab_i, slab_v, ptr_c, out_i, out_v, conj_x, conj_y);
+            if(rc != aoclsparse_status_success || bn.heavy.empty())
+                return rc;
+            void *gk = nullptr, *gp = nullptr, *gl = nullptr, *ga = nullptr;
+            rc       = rt.staging(SLOT_G_KEY, sizeof(int) * (size_t)bn.slots, &gk);
+            if(pass_fill)
+            {
+                if(rc == aoclsparse_status_success)
+                    rc = rt.staging(SLOT_G_POS, sizeof(int) * (size_t)bn.slots, &gp);
+                if(rc == aoclsparse_status_success)
+                    rc = rt.staging(SLOT_G_LIST, sizeof(int) * (size_t)bn.entries, &gl);
+                if(rc == aoclsparse_status_success)
+                    rc = rt.staging(SLOT_G_ACC, sizeof(T) * (size_t)bn.entries, &ga);
+            }
+            for(size_t b = 0; b + 1 < bn.batch.size() && rc == aoclsparse_status_success; b++) // (stream order: a batch reuses the slab)
+                rc = launch_spgemm_heavy<T>(s, pass_fill, bn.batch[b + 1] - bn.batch[b], bn.d_heavy + bn.batch[b], static_cast<int *>(gk),
+                                            static_cast<int *>(gp), static_cast<int *>(gl), static_cast<T *>(ga), X->base, dx.ptr, dx.ind,
+                                            static_cast<const T *>(dx.val), Y->base, dy.ptr, dy.ind, static_cast<const T *>(dy.val), ptr_c,
+                                            out_i, out_v, conj_x, conj_y);
             return rc;
         };
 
@@ -374,7 +407,7 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
             st = bin_rows(by_bound, false, [&](aoclsparse_int i) { return std::min<long long>(ub[(size_t)i], n); });
             phase("count: bins");
             if(st == aoclsparse_status_success)
-                st = run_pass(false, by_bound, nullptr, nullptr, static_cast<aoclsparse_int *>(d_cnt), nullptr);
+                st = run_pass(false, by_bound, nullptr, static_cast<aoclsparse_int *>(d_cnt), nullptr);
             if(st != aoclsparse_status_success)
                 return st;
             phase("count: kernels");
@@ -439,9 +472,6 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
                     return aoclsparse_status_invalid_value;
             Binned by_count;
             st = bin_rows(by_count, true, [&](aoclsparse_int i) { return (long long)(d->ptr[i + 1] - d->ptr[i]); });
-            void *slab_v = nullptr;
-            if(st == aoclsparse_status_success && by_count.slab > 0)
-                st = rt.staging(SLOT_SLABV_FILL, sizeof(T) * (size_t)by_count.slab, &slab_v);
             if(st == aoclsparse_status_success)
                 st = d_cptr.upload(d->ptr, sizeof(aoclsparse_int) * ((size_t)m + 1), s);
             if(st == aoclsparse_status_success)
@@ -451,7 +481,7 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
             if(st != aoclsparse_status_success)
                 return st;
             phase("fill: bins, buffers");
-            st = run_pass(true, by_count, static_cast<T *>(slab_v), d_cptr.as<aoclsparse_int>(), d_ci.as<aoclsparse_int>(), d_cv.as<T>());
+            st = run_pass(true, by_count, d_cptr.as<aoclsparse_int>(), d_ci.as<aoclsparse_int>(), d_cv.as<T>());
             if(st != aoclsparse_status_success)
                 return st;
             // while the kernels run: the result's host arrays are first-touched by several threads (host_result_alloc; faulted in

@@ -7,6 +7,7 @@ import subprocess
 import sys
 import textwrap
 
+import ctypes
 import numpy as np
 import pytest
 
@@ -719,3 +720,122 @@ def test_float_plans_use_2048_entry_row_blocks():
             assert Am.spmv_info().tile == 1024
     finally:
         assert L.aoclsparse_mi355_set_option(P.OPTION_SELL, -1) == 0
+
+
+def _export_csr(h, double=True):
+    base, m, n, nnz = ctypes.c_int(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    rp, ci, v = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    fn = L.aoclsparse_export_dcsr if double else L.aoclsparse_export_scsr
+    assert fn(h, ctypes.byref(base), ctypes.byref(m), ctypes.byref(n), ctypes.byref(nnz), ctypes.byref(rp), ctypes.byref(ci),
+              ctypes.byref(v)) == 0
+    k = max(nnz.value, 1)
+    row = np.ctypeslib.as_array(ctypes.cast(rp, ctypes.POINTER(ctypes.c_int32)), (m.value + 1,)).copy()
+    col = np.ctypeslib.as_array(ctypes.cast(ci, ctypes.POINTER(ctypes.c_int32)), (k,))[: nnz.value].copy()
+    val = np.ctypeslib.as_array(ctypes.cast(v, ctypes.POINTER(ctypes.c_double if double else ctypes.c_float)), (k,))[: nnz.value].copy()
+    return m.value, n.value, nnz.value, row, col, val
+
+
+def _spgemm_operands(seed, m, k, n, heavy):
+    """A (m x k) and B (k x n) that reach every bin of spgemm_hash_kernel: rows of 0-8 entries (lists of <= 32), of 20-60 (<= 256 /
+    <= 2,048), and -- heavy -- a few rows of A with thousands of entries so that their lists exceed 2,048 entries and their upper
+    bounds 8,192 (tables in the global slab).  Some B rows are unsorted, some repeat a column (legal input: csr_util.cpp:244)."""
+    rng = np.random.default_rng(seed)
+
+    def rows(nr, nc, lens, shuffle_every, dup_every):
+        ptr, ind = [0], []
+        for i in range(nr):
+            c = np.sort(rng.choice(nc, size=min(int(lens[i]), nc), replace=False))
+            if shuffle_every and i % shuffle_every == 1 and len(c) > 2:
+                c = rng.permutation(c)
+            if dup_every and i % dup_every == 2 and len(c) > 3:
+                c = c.copy()
+                c[len(c) // 2] = c[0] if c[0] != i else c[1]  # a repeated off-diagonal column, out of order
+            ind.append(c)
+            ptr.append(ptr[-1] + len(c))
+        ind = np.concatenate(ind).astype(np.int32) if ptr[-1] else np.zeros(0, np.int32)
+        return np.array(ptr, np.int32), ind, rng.uniform(-1, 1, len(ind))
+
+    la = np.where(rng.random(m) < 0.5, rng.integers(0, 9, m), rng.integers(20, 61, m))
+    lb = np.where(rng.random(k) < 0.5, rng.integers(0, 9, k), rng.integers(20, 61, k))
+    if heavy:
+        la[[5, m // 2, m - 3]] = [2500, 4000, 900]
+        lb[[7, k - 1]] = [2900, 1500]
+    pa, ia, va = rows(m, k, la, 0, 0)
+    pb, ib, vb = rows(k, n, lb, 13, 17)
+    return (pa, ia, va), (pb, ib, vb)
+
+
+@pytest.mark.parametrize("heavy", [False, True])
+def test_spgemm_hash_kernel_every_bin_bit_exact(heavy):
+    """C = A * B through aoclsparse_sp2m: row_ptr, col_ind (first-touch order) and val bit for bit those of the reference's
+    two-stage Gustavson (oracle), with rows in every bin of spgemm_hash_kernel, unsorted B rows and repeated columns; full
+    computation and the two-stage protocol (finalize twice: the second fill replaces the first); float through ?csr2m."""
+    m, k, n = 4000, 5000, 6000
+    (pa, ia, va), (pb, ib, vb) = _spgemm_operands(31 + heavy, m, k, n, heavy)
+    A, B = P.Matrix(0, m, k, pa, ia, va), P.Matrix(0, k, n, pb, ib, vb)
+    assert A.status == 0 and B.status == 0
+    d = P.Descr()
+    so, pc, ic, vc = oracle.dcsr2m(m, n, 0, pa, ia, va, 0, pb, ib, vb)
+    assert so == 0
+    counts = np.diff(pc)
+    assert counts.min() == 0 and (counts > 32).any() and (counts > 256).any()
+    if heavy:
+        assert (counts > 2048).sum() >= 3
+    C = ctypes.c_void_p()
+    assert L.aoclsparse_sp2m(P.OP_NONE, d.h, A.h, P.OP_NONE, d.h, B.h, P.STAGE_FULL, ctypes.byref(C)) == 0
+    cm, cn, cz, row, col, val = _export_csr(C)
+    assert (cm, cn, cz) == (m, n, len(ic))
+    assert np.array_equal(row, pc) and np.array_equal(col, ic) and np.array_equal(val, vc)
+    assert L.aoclsparse_destroy(ctypes.byref(C)) == 0
+    C = ctypes.c_void_p()
+    assert L.aoclsparse_sp2m(P.OP_NONE, d.h, A.h, P.OP_NONE, d.h, B.h, P.STAGE_NNZ_COUNT, ctypes.byref(C)) == 0
+    _, _, cz, row, _, _ = _export_csr(C)
+    assert cz == len(ic) and np.array_equal(row, pc)
+    for _ in range(2):
+        assert L.aoclsparse_sp2m(P.OP_NONE, d.h, A.h, P.OP_NONE, d.h, B.h, P.STAGE_FINALIZE, ctypes.byref(C)) == 0
+        _, _, _, row, col, val = _export_csr(C)
+        assert np.array_equal(col, ic) and np.array_equal(val, vc)
+    assert L.aoclsparse_destroy(ctypes.byref(C)) == 0
+    Af, Bf = P.Matrix(0, m, k, pa, ia, va.astype(np.float32)), P.Matrix(0, k, n, pb, ib, vb.astype(np.float32))
+    C = ctypes.c_void_p()
+    assert L.aoclsparse_scsr2m(P.OP_NONE, d.h, Af.h, P.OP_NONE, d.h, Bf.h, P.STAGE_FULL, ctypes.byref(C)) == 0
+    _, _, cz, row, col, valf = _export_csr(C, double=False)
+    assert cz == len(ic) and np.array_equal(row, pc) and np.array_equal(col, ic)
+    scale = np.abs(vc) + 1e-3
+    assert np.all(np.abs(valf - vc) <= 4000 * np.finfo(np.float32).eps * np.maximum(scale, 1.0))
+    assert L.aoclsparse_destroy(ctypes.byref(C)) == 0
+
+
+def test_sp2m_result_stays_resident_and_feeds_the_next_product():
+    """The handle aoclsparse_sp2m returns holds its CSR arrays in HBM (round 4): ?mv on it and a second product with it start from
+    there -- same bits as from the exported host arrays -- and a fill into a handle that has been used drops what it derived."""
+    m = 3000
+    (pa, ia, va), (pb, ib, vb) = _spgemm_operands(77, m, m, m, False)
+    A, B = P.Matrix(0, m, m, pa, ia, va), P.Matrix(0, m, m, pb, ib, vb)
+    d = P.Descr()
+    C = ctypes.c_void_p()
+    assert L.aoclsparse_sp2m(P.OP_NONE, d.h, A.h, P.OP_NONE, d.h, B.h, P.STAGE_FULL, ctypes.byref(C)) == 0
+    _, _, cz, row, col, val = _export_csr(C)
+    rng = np.random.default_rng(1)
+    x, y = rng.uniform(-1, 1, m), np.zeros(m)
+    one, zero = ctypes.c_double(1.0), ctypes.c_double(0.0)
+    assert L.aoclsparse_dmv(P.OP_NONE, ctypes.byref(one), C, d.h, P._ptr(x), ctypes.byref(zero), P._ptr(y)) == 0
+    H = P.Matrix(0, m, m, row, col, val)  # the same matrix from its exported arrays (rows in first-touch order: unsorted)
+    y2 = np.zeros(m)
+    assert P.dmv(P.OP_NONE, 1.0, H, d, x, 0.0, y2) == 0
+    assert np.array_equal(y, y2)
+    # C * A with the resident C as the left operand, against the oracle on the exported arrays
+    E = ctypes.c_void_p()
+    assert L.aoclsparse_sp2m(P.OP_NONE, d.h, C, P.OP_NONE, d.h, A.h, P.STAGE_FULL, ctypes.byref(E)) == 0
+    _, _, _, erow, ecol, evalv = _export_csr(E)
+    so, pe, ie, ve = oracle.dcsr2m(m, m, 0, row, col, val, 0, pa, ia, va)
+    assert so == 0 and np.array_equal(erow, pe) and np.array_equal(ecol, ie) and np.array_equal(evalv, ve)
+    assert L.aoclsparse_destroy(ctypes.byref(E)) == 0
+    # a second fill of C with other values (A scaled): the products above must not survive in C's device state
+    A2 = P.Matrix(0, m, m, pa, ia, 2.0 * va)
+    assert L.aoclsparse_sp2m(P.OP_NONE, d.h, A2.h, P.OP_NONE, d.h, B.h, P.STAGE_FINALIZE, ctypes.byref(C)) == 0
+    _, _, _, _, col2, val2 = _export_csr(C)
+    assert np.array_equal(col2, col) and np.array_equal(val2, 2.0 * val)
+    assert L.aoclsparse_dmv(P.OP_NONE, ctypes.byref(one), C, d.h, P._ptr(x), ctypes.byref(zero), P._ptr(y)) == 0
+    assert np.array_equal(y, 2.0 * y2)
+    assert L.aoclsparse_destroy(ctypes.byref(C)) == 0
