@@ -319,8 +319,8 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
             }
             return rc;
         };
-        // operands on the device: a handle that already holds its CSR arrays in HBM (any product or optimize before) is used as
-        // it is; otherwise one upload per distinct operand (A * A sends A once)
+        // operands on the device: the handles' own device copies; transposed operands (built on the host above) go through staging
+        // slots; A * A sends A once
         DeviceBuffer d_cptr, d_ci, d_cv; // the result's own arrays
         const bool   count = request != aoclsparse_stage_finalize, fill = request != aoclsparse_stage_nnz_count;
         struct DevOp
@@ -328,22 +328,30 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
             const aoclsparse_int *ptr = nullptr, *ind = nullptr;
             const void           *val = nullptr;
         } dx, dy;
-        auto resident = [&](const Operand<T> *o, const aoclsparse_matrix H, DevOp &dv) {
-            // (only an operand that IS the handle's own arrays: transposes built above are not)
+        auto resident = [&](const Operand<T> *o, const aoclsparse_matrix H, DevOp &dv) -> aoclsparse_status {
+            // an operand that IS the handle's own arrays (the transposes built above are not) is used from the handle's device
+            // copy, which is made here when no product or optimize has made it yet: the next product with this handle -- a
+            // Galerkin chain multiplies the same matrices again and again -- sends nothing
             if(o->ptr != H->user.ptr)
-                return false;
-            std::shared_lock<std::shared_mutex> r(H->guard);
-            if(!H->dev_user.valid || H->dev_user.nnz != o->nnz)
-                return false;
-            dv.ptr = H->dev_user.ptr.as<aoclsparse_int>(), dv.ind = H->dev_user.ind.as<aoclsparse_int>(), dv.val = H->dev_user.val.ptr;
-            return true;
+                return aoclsparse_status_not_implemented;
+            std::unique_lock<std::shared_mutex> w(H->guard);
+            if(!H->dev_user.valid)
+            {
+                const aoclsparse_status rc = upload_csr(H->user, sizeof(T), H->dev_user);
+                if(rc != aoclsparse_status_success)
+                    return rc;
+            }
+            dv.ptr = H->dev_user.ptr.template as<aoclsparse_int>(), dv.ind = H->dev_user.ind.template as<aoclsparse_int>();
+            dv.val = H->dev_user.val.ptr;
+            return aoclsparse_status_success;
         };
         const aoclsparse_matrix HX = opflag == 3 ? B : A, HY = opflag == 3 ? A : B;
         auto send = [&](const Operand<T> *o, const aoclsparse_matrix H, DevOp &dv, int slot) {
-            if(resident(o, H, dv))
-                return aoclsparse_status_success;
-            void             *pp = nullptr, *pi = nullptr, *pv = nullptr;
-            aoclsparse_status rc = rt.staging(slot, sizeof(aoclsparse_int) * ((size_t)o->m + 1), &pp);
+            aoclsparse_status rc = resident(o, H, dv);
+            if(rc != aoclsparse_status_not_implemented)
+                return rc;
+            void *pp = nullptr, *pi = nullptr, *pv = nullptr;
+            rc       = rt.staging(slot, sizeof(aoclsparse_int) * ((size_t)o->m + 1), &pp);
             if(rc == aoclsparse_status_success)
                 rc = rt.h2d(pp, o->ptr, sizeof(aoclsparse_int) * ((size_t)o->m + 1));
             if(rc == aoclsparse_status_success)

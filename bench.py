@@ -35,6 +35,8 @@ to the file named by --record (default bench_legs.json next to this file), not t
                                      column slabs, efficiency T1 / (N * TN), optional C all-gather
                 trsv                 configs[4]: unit-lower ILU(0) factor of the shell-like matrix (and of its unstructured
                                      variant), automatic kid and the pinned KT orders (kid 1 / 3)
+                sp2m                 SURVEY 8 a15: aoclsparse_sp2m(A, A) on the 1000^2 Laplacian and a 100,000-row shell mesh, host
+                                     arrays in and out, against the CPU port of the reference's two-stage Gustavson
                 spmv_row_sharded     SURVEY 8e "next": x <- A x iterated with A split by rows over the N ranks, one all-gather of
                                      the y slices per iteration (RCCL with nccl)
                 inlib_multi          configs[3] from ONE process: aoclsparse_mi355_dcsrmm_multi_slabs over every visible GPU
@@ -279,6 +281,11 @@ def leg_numbers(full):
         n["trsv_parity"] = all(s["bit_exact_vs_cpu"] for s in tr["schedules"])
         if "unstructured_variant" in tr and tr["unstructured_variant"].get("schedules"):
             n["trsv_unstructured_ms"] = tr["unstructured_variant"]["schedules"][0]["ms"]
+    sp2 = legs.get("sp2m") or {}
+    if sp2.get("cases"):
+        n["sp2m_ms"] = sp2["cases"][0]["ms"]
+        n["sp2m_vs_cpu_port"] = sp2["cases"][0]["speedup_vs_cpu_port"]
+        n["sp2m_parity"] = all(c["bit_exact"] for c in sp2["cases"])
     for lay in ("col", "row", "bell"):
         sh = full.get("csrmm_sharded_" + lay) or {}
         if "tg_ms_device_median_max_over_ranks" in sh:
@@ -396,7 +403,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: CPU tensors on the wire, ranks may share one GPU (control-flow tests on a 1-GPU box)")
     ap.add_argument("--legs", default="all",
-                    help="comma list of l100,dcsrmv_csr_adaptive,mix,csrmm,csrmm_sharded,spmv_row_sharded,trsv,cpu,inlib_multi (or all / none)")
+                    help="comma list of l100,dcsrmv_csr_adaptive,mix,csrmm,csrmm_sharded,spmv_row_sharded,trsv,sp2m,cpu,inlib_multi (or all / none)")
     ap.add_argument("--mm-grid", type=int, default=1000, help="csrmm: A = Laplacian on grid^2")
     ap.add_argument("--mm-cols", type=int, default=256)
     ap.add_argument("--shard-grid", type=int, default=0,
@@ -421,7 +428,7 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # not under torch.distributed.run: start the ranks ourselves (as a child; nothing here has touched the GPU)
         sys.exit(self_launch(sys.argv[1:], args.gpus))
-    all_legs = ["l100", "dcsrmv_csr_adaptive", "mix", "csrmm", "csrmm_sharded", "spmv_row_sharded", "trsv", "cpu", "inlib_multi"]
+    all_legs = ["l100", "dcsrmv_csr_adaptive", "mix", "csrmm", "csrmm_sharded", "spmv_row_sharded", "trsv", "sp2m", "cpu", "inlib_multi"]
     legs = set(all_legs) if args.legs == "all" else set(x for x in args.legs.split(",") if x and x != "none")
     assert legs <= set(all_legs), "unknown leg in --legs: %s" % sorted(legs - set(all_legs))
 
@@ -1122,6 +1129,57 @@ def main():
         return res
 
     run_leg("trsv", leg_trsv)
+
+    # ---- aoclsparse_sp2m: C = A * A, full computation, host arrays in / host arrays out ----
+    # The call is the reference's: operands are handles over host arrays, the result handle owns host arrays (export reads them).
+    # ms = wall time of the whole call (analysis on the host, both kernel passes, the result over PCIe); kernels_ms = the two
+    # SpGEMM passes alone (events around a second pair of calls would need the library's internals: taken from the phase trace).
+    def leg_sp2m():
+        import ctypes
+        import oracle
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import standins
+        L = pkg.lib()
+        d = pkg.Descr()
+        cases = [("5-pt Laplacian grid %d^2" % (300 if args.small else 1000),) + tuple(entry.laplace5(300 if args.small else 1000))]
+        if not args.small:
+            cases.append(("shell-like mesh, 100,000 rows",) + tuple(standins.shell_like(n=100000)))
+        out = {"what": "aoclsparse_sp2m(A, A), full computation; host arrays in, host arrays out (PCIe inside the figure)", "cases": []}
+        for title, mt, rp, ci, v in cases:
+            A = pkg.Matrix(0, mt, mt, rp, ci, v)
+
+            def run():
+                C = ctypes.c_void_p()
+                t = time.perf_counter()
+                st = L.aoclsparse_sp2m(pkg.OP_NONE, d.h, A.h, pkg.OP_NONE, d.h, A.h, pkg.STAGE_FULL, ctypes.byref(C))
+                dt = time.perf_counter() - t
+                if st != 0:
+                    raise RuntimeError("aoclsparse_sp2m: status %d" % st)
+                return C, dt
+            C, _ = run()
+            L.aoclsparse_destroy(ctypes.byref(C))
+            ts = []
+            for k in range(5):
+                C, dt = run()
+                ts.append(dt)
+                if k < 4:
+                    L.aoclsparse_destroy(ctypes.byref(C))
+            e = pkg.Matrix.from_handle(C).export()
+            t = time.perf_counter()
+            so, pc, ic, vc = oracle.dcsr2m(mt, mt, 0, rp, ci, v, 0, rp, ci, v)
+            t_cpu = time.perf_counter() - t
+            nnz_c = int(e["nnz"])
+            by = 2 * (12 * len(v) + 4 * (mt + 1)) + 12 * nnz_c + 4 * (mt + 1)  # A read by both passes, C written once
+            ms = sorted(ts)[len(ts) // 2] * 1e3
+            out["cases"].append({"matrix": title, "m": mt, "nnz_a": int(len(v)), "nnz_c": nnz_c, "ms": round(ms, 3),
+                                 "ms_all": [round(x * 1e3, 3) for x in ts], "algorithmic_bytes": by,
+                                 "algorithmic_GBs_incl_pcie": round(by / ms / 1e6, 1),
+                                 "cpu_port_1_thread_ms": round(t_cpu * 1e3, 2), "speedup_vs_cpu_port": round(t_cpu * 1e3 / ms, 2),
+                                 "bit_exact": bool(so == 0 and np.array_equal(e["row_ptr"], pc) and np.array_equal(e["col_ind"], ic)
+                                                   and np.array_equal(e["val"], vc))})
+        return out
+
+    run_leg("sp2m", leg_sp2m)
 
     # ---- in-library multi-device csrmm: ONE process over every visible GPU (aoclsparse_mi355_dcsrmm_multi_slabs) ----
     # Run as a CHILD process with a timeout: a problem on a multi-GPU node (first contact with N devices happens in the
