@@ -256,14 +256,27 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
         // rows grouped by bin (stable inside a bin: consecutive rows stay together), and for the rows of the last bin a slab of
         // `cap(i)` list entries each: bounds[b] .. bounds[b + 1] = bin b's stretch of `order`
         auto bin_rows = [&](Binned &bn, bool for_fill, auto cap_of) -> aoclsparse_status {
+            // bin of every row and the bins' sizes: fixed chunks (the result does not depend on the thread count), one histogram each
             std::vector<unsigned char> bin((size_t)m);
-            parallel_for(m, 1 << 16, [&](long long i0, long long i1) {
-                for(long long i = i0; i < i1; i++)
-                    bin[(size_t)i] = (unsigned char)spgemm_bin_of(cap_of((aoclsparse_int)i), for_fill);
+            constexpr int              NCH = 16;
+            aoclsparse_int             hist[NCH][SPGEMM_BINS] = {};
+            parallel_for(NCH, 1, [&](long long c0, long long c1) {
+                for(long long c = c0; c < c1; c++)
+                {
+                    aoclsparse_int mine[SPGEMM_BINS] = {}; // (counted on the stack: the chunks' rows of `hist` share cache lines)
+                    for(long long i = (long long)m * c / NCH; i < (long long)m * (c + 1) / NCH; i++)
+                    {
+                        const int b    = spgemm_bin_of(cap_of((aoclsparse_int)i), for_fill);
+                        bin[(size_t)i] = (unsigned char)b;
+                        mine[b]++;
+                    }
+                    std::copy(mine, mine + SPGEMM_BINS, hist[c]);
+                }
             });
             aoclsparse_int cnt[SPGEMM_BINS] = {};
-            for(aoclsparse_int i = 0; i < m; i++)
-                cnt[bin[(size_t)i]]++;
+            for(int c = 0; c < NCH; c++)
+                for(int b = 0; b < SPGEMM_BINS; b++)
+                    cnt[b] += hist[c][b];
             bn.bounds[0] = 0;
             for(int b = 0; b < SPGEMM_BINS; b++)
                 bn.bounds[b + 1] = bn.bounds[b] + cnt[b];
@@ -273,11 +286,24 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
                 one_bin |= cnt[b] == m;
             if(!one_bin)
             {
-                aoclsparse_int next[SPGEMM_BINS];
-                std::copy(bn.bounds, bn.bounds + SPGEMM_BINS, next);
+                // (stable: chunk c's rows of bin b follow those of the chunks before it)
+                aoclsparse_int start[NCH][SPGEMM_BINS];
+                for(int b = 0; b < SPGEMM_BINS; b++)
+                {
+                    aoclsparse_int at = bn.bounds[b];
+                    for(int c = 0; c < NCH; c++)
+                        start[c][b] = at, at += hist[c][b];
+                }
                 std::vector<aoclsparse_int> order((size_t)m);
-                for(aoclsparse_int i = 0; i < m; i++)
-                    order[(size_t)next[bin[(size_t)i]]++] = i;
+                parallel_for(NCH, 1, [&](long long c0, long long c1) {
+                    for(long long c = c0; c < c1; c++)
+                    {
+                        aoclsparse_int next[SPGEMM_BINS];
+                        std::copy(start[c], start[c] + SPGEMM_BINS, next);
+                        for(long long i = (long long)m * c / NCH; i < (long long)m * (c + 1) / NCH; i++)
+                            order[(size_t)next[bin[(size_t)i]]++] = (aoclsparse_int)i;
+                    }
+                });
                 void *p = nullptr;
                 rc      = rt.staging(for_fill ? SLOT_ORDER_FILL : SLOT_ORDER_COUNT, sizeof(aoclsparse_int) * (size_t)m, &p);
                 if(rc == aoclsparse_status_success)
