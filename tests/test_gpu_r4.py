@@ -839,3 +839,45 @@ def test_sp2m_result_stays_resident_and_feeds_the_next_product():
     assert L.aoclsparse_dmv(P.OP_NONE, ctypes.byref(one), C, d.h, P._ptr(x), ctypes.byref(zero), P._ptr(y)) == 0
     assert np.array_equal(y, 2.0 * y2)
     assert L.aoclsparse_destroy(ctypes.byref(C)) == 0
+
+
+@pytest.mark.parametrize("prec", ["z", "c"])
+def test_spgemm_hash_kernel_complex_heavy_rows(prec):
+    """The same operands as above with complex values (cdouble: 16-byte partial sums, cfloat: 8): the structure -- row_ptr and
+    the first-touch column order -- is the real product's, bit for bit; the values are within (terms + 4) eps sum|a||b| of the
+    sparse product scipy forms (its own order); rows in every bin including the global-slab one, unsorted and repeated columns."""
+    import scipy.sparse as sp
+    dtype, eps = (np.complex128, EPS64) if prec == "z" else (np.complex64, np.finfo(np.float32).eps)
+    create = L.aoclsparse_create_zcsr if prec == "z" else L.aoclsparse_create_ccsr
+    exp = L.aoclsparse_export_zcsr if prec == "z" else L.aoclsparse_export_ccsr
+    m, k, n = 4000, 5000, 6000
+    (pa, ia, var), (pb, ib, vbr) = _spgemm_operands(32, m, k, n, True)
+    rng = np.random.default_rng(5)
+    va = (var + 1j * rng.uniform(-1, 1, len(var))).astype(dtype)
+    vb = (vbr + 1j * rng.uniform(-1, 1, len(vbr))).astype(dtype)
+    hA, hB, C = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    assert create(ctypes.byref(hA), 0, m, k, len(va), P._ptr(pa), P._ptr(ia), P._ptr(va)) == 0
+    assert create(ctypes.byref(hB), 0, k, n, len(vb), P._ptr(pb), P._ptr(ib), P._ptr(vb)) == 0
+    d = P.Descr()
+    assert L.aoclsparse_sp2m(P.OP_NONE, d.h, hA, P.OP_NONE, d.h, hB, P.STAGE_FULL, ctypes.byref(C)) == 0
+    b, m_, n_, z_ = ctypes.c_int(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    a1, a2, a3 = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    assert exp(C, ctypes.byref(b), ctypes.byref(m_), ctypes.byref(n_), ctypes.byref(z_), ctypes.byref(a1), ctypes.byref(a2), ctypes.byref(a3)) == 0
+    nz = z_.value
+    row = np.ctypeslib.as_array(ctypes.cast(a1, ctypes.POINTER(ctypes.c_int32)), (m + 1,)).copy()
+    col = np.ctypeslib.as_array(ctypes.cast(a2, ctypes.POINTER(ctypes.c_int32)), (nz,)).copy()
+    val = np.ctypeslib.as_array(ctypes.cast(a3, ctypes.POINTER(ctypes.c_float if prec == "c" else ctypes.c_double)), (2 * nz,)).view(dtype).copy()
+    so, pc, ic, vc = oracle.dcsr2m(m, n, 0, pa, ia, var, 0, pb, ib, vbr)
+    assert so == 0 and (np.diff(pc) > 2048).sum() >= 3
+    assert (m_.value, n_.value, nz) == (m, n, len(ic)) and np.array_equal(row, pc) and np.array_equal(col, ic)
+    A64 = sp.csr_matrix((va.astype(np.complex128), ia, pa), shape=(m, k))
+    B64 = sp.csr_matrix((vb.astype(np.complex128), ib, pb), shape=(k, n))
+    R = (A64 @ B64).tocsr()
+    S = (abs(A64) @ abs(B64)).tocsr()  # sum |a||b| per entry of C
+    rows = np.repeat(np.arange(m), np.diff(row))
+    ref = np.asarray(R[rows, col]).ravel()
+    scale = np.asarray(S[rows, col]).ravel().real
+    terms = int(np.diff(pa).max())
+    assert np.all(np.abs(val.astype(np.complex128) - ref) <= (2 * terms + 8) * eps * scale + 1e-300)
+    for h in (C, hA, hB):
+        assert L.aoclsparse_destroy(ctypes.byref(h)) == 0
