@@ -211,16 +211,36 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
         }
         else
         {
+            // op = T / H: the explicit transpose of csr2m.cpp:771-781.  A handle keeps its transpose (the same stable counting
+            // sort, 0-based: build_transpose -- ?mv with op = T uses it too) and its device copy, so that a chain of products with
+            // P^T pays for it once; handles whose `trans` slot holds something else (results of a (B A)^T product) transpose here
+            auto transposed = [&](const aoclsparse_matrix H, const Operand<T> &v, Operand<T> &t) -> aoclsparse_status {
+                if(H->owns_user_arrays)
+                {
+                    transpose_of<T>(v, t);
+                    return aoclsparse_status_success;
+                }
+                const aoclsparse_status rc = build_transpose(H);
+                if(rc != aoclsparse_status_success)
+                    return rc;
+                std::shared_lock<std::shared_mutex> r(H->guard);
+                const HostCsr &h = *H->trans;
+                t.m = h.m, t.n = h.n, t.nnz = h.nnz, t.base = h.base;
+                t.ptr = h.ptr, t.ind = h.ind, t.val = static_cast<const T *>(h.val);
+                return aoclsparse_status_success;
+            };
             if(trA)
             {
-                transpose_of<T>(va, ta);
-                X = &ta;
+                st = transposed(A, va, ta);
+                X  = &ta;
             }
-            if(trB)
+            if(trB && st == aoclsparse_status_success)
             {
-                transpose_of<T>(vb, tb);
-                Y = &tb;
+                st = transposed(B, vb, tb);
+                Y  = &tb;
             }
+            if(st != aoclsparse_status_success)
+                return st;
         }
         const aoclsparse_int m = X->m, n = Y->n; // product D = X * Y is m x n
         // diagnostic: AOCLSPARSE_MI355_SP2M_TRACE=1 prints the wall time of every phase of the call (synchronising after each)
@@ -355,20 +375,21 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
             const void           *val = nullptr;
         } dx, dy;
         auto resident = [&](const Operand<T> *o, const aoclsparse_matrix H, DevOp &dv) -> aoclsparse_status {
-            // an operand that IS the handle's own arrays (the transposes built above are not) is used from the handle's device
-            // copy, which is made here when no product or optimize has made it yet: the next product with this handle -- a
-            // Galerkin chain multiplies the same matrices again and again -- sends nothing
-            if(o->ptr != H->user.ptr)
-                return aoclsparse_status_not_implemented;
+            // an operand that IS the handle's own arrays, or the handle's kept transpose, is used from the handle's device copy,
+            // which is made here when no product or optimize has made it yet: the next product with this handle -- a Galerkin
+            // chain multiplies the same matrices again and again -- sends nothing
             std::unique_lock<std::shared_mutex> w(H->guard);
-            if(!H->dev_user.valid)
+            const bool own = o->ptr == H->user.ptr, own_t = H->trans && o->ptr == H->trans->ptr;
+            if(!own && !own_t)
+                return aoclsparse_status_not_implemented;
+            DeviceCsr &dc = own ? H->dev_user : H->dev_trans;
+            if(!dc.valid)
             {
-                const aoclsparse_status rc = upload_csr(H->user, sizeof(T), H->dev_user);
+                const aoclsparse_status rc = upload_csr(own ? H->user : *H->trans, sizeof(T), dc);
                 if(rc != aoclsparse_status_success)
                     return rc;
             }
-            dv.ptr = H->dev_user.ptr.template as<aoclsparse_int>(), dv.ind = H->dev_user.ind.template as<aoclsparse_int>();
-            dv.val = H->dev_user.val.ptr;
+            dv.ptr = dc.ptr.template as<aoclsparse_int>(), dv.ind = dc.ind.template as<aoclsparse_int>(), dv.val = dc.val.ptr;
             return aoclsparse_status_success;
         };
         const aoclsparse_matrix HX = opflag == 3 ? B : A, HY = opflag == 3 ? A : B;

@@ -881,3 +881,48 @@ def test_spgemm_hash_kernel_complex_heavy_rows(prec):
     assert np.all(np.abs(val.astype(np.complex128) - ref) <= (2 * terms + 8) * eps * scale + 1e-300)
     for h in (C, hA, hB):
         assert L.aoclsparse_destroy(ctypes.byref(h)) == 0
+
+
+def test_sp2m_transposed_operands_are_kept_by_their_handles():
+    """op = T on either side: the transpose (the reference's stable counting sort) and its device copy stay with the handle, so the
+    second product sends and transposes nothing -- same bits as the first and as the oracle (csr2csc + csr2m) -- and a value
+    change through the API (?set_value) drops them."""
+    m, k = 3000, 2600
+    (pa, ia, va), _ = _spgemm_operands(55, m, k, k, False)
+    (pb, ib, vb), _ = _spgemm_operands(56, m, k, k, False)  # B is m x k too: A^T * B is k x k
+    A, B = P.Matrix(0, m, k, pa, ia, va), P.Matrix(0, m, k, pb, ib, vb)
+    d = P.Descr()
+
+    def expect(va_):
+        st, cp, ri, cv = oracle.dcsr2csc(m, k, len(va_), 0, 0, pa, ia, va_)
+        assert st == 0
+        so, pc, ic, vc = oracle.dcsr2m(k, k, 0, cp, ri.astype(np.int32), cv, 0, pb, ib, vb)
+        assert so == 0
+        return pc, ic, vc
+
+    pc, ic, vc = expect(va)
+    for _ in range(2):
+        C = ctypes.c_void_p()
+        assert L.aoclsparse_sp2m(P.OP_TRANSPOSE, d.h, A.h, P.OP_NONE, d.h, B.h, P.STAGE_FULL, ctypes.byref(C)) == 0
+        _, _, _, row, col, val = _export_csr(C)
+        assert np.array_equal(row, pc) and np.array_equal(col, ic) and np.array_equal(val, vc)
+        assert L.aoclsparse_destroy(ctypes.byref(C)) == 0
+    # A[i, j] := 9.5 for the first stored entry of row 40 (aoclsparse_dset_value writes the caller's array and drops every copy)
+    i, j = 40, int(ia[pa[40]])
+    assert L.aoclsparse_dset_value(A.h, i, j, 9.5) == 0
+    assert A.val[pa[40]] == 9.5
+    pc2, ic2, vc2 = expect(A.val)
+    C = ctypes.c_void_p()
+    assert L.aoclsparse_sp2m(P.OP_TRANSPOSE, d.h, A.h, P.OP_NONE, d.h, B.h, P.STAGE_FULL, ctypes.byref(C)) == 0
+    _, _, _, row, col, val = _export_csr(C)
+    assert np.array_equal(row, pc2) and np.array_equal(col, ic2) and np.array_equal(val, vc2) and not np.array_equal(val, vc)
+    assert L.aoclsparse_destroy(ctypes.byref(C)) == 0
+    # B^T on the right: A * B^T is m x m
+    st, cpb, rib, cvb = oracle.dcsr2csc(m, k, len(vb), 0, 0, pb, ib, vb)
+    so, pe, ie, ve = oracle.dcsr2m(m, m, 0, pa, ia, A.val, 0, cpb, rib.astype(np.int32), cvb)
+    for _ in range(2):
+        E = ctypes.c_void_p()
+        assert L.aoclsparse_sp2m(P.OP_NONE, d.h, A.h, P.OP_TRANSPOSE, d.h, B.h, P.STAGE_FULL, ctypes.byref(E)) == 0
+        _, _, _, row, col, val = _export_csr(E)
+        assert so == 0 and np.array_equal(row, pe) and np.array_equal(col, ie) and np.array_equal(val, ve)
+        assert L.aoclsparse_destroy(ctypes.byref(E)) == 0
