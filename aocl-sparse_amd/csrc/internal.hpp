@@ -569,7 +569,7 @@ private:
     std::atomic<bool> inited_{false}; // set (release) after init_status_ / device / events are written
     aoclsparse_status init_status_ = aoclsparse_status_success;
     hipStream_t  stream_ = nullptr;
-    DeviceBuffer stage_[32]; // 0-7: csrmv / mv / trsv / dotmv, 8-15: ELL family and BLKCSR (ell_api.cpp, blk_api.cpp), 16-31: sp2m (sp2m_api.cpp)
+    DeviceBuffer stage_[40]; // 0-7: csrmv / mv / trsv / dotmv, 8-15: ELL family and BLKCSR (ell_api.cpp, blk_api.cpp), 16-39: sp2m (sp2m_api.cpp)
 };
 
 // While one of these is alive on a thread, Runtime::get() on that thread is the given slot: its device is current, its
@@ -836,6 +836,18 @@ struct SpgHeavy
     int       row, logh;
     long long h_off, c_off;
 };
+// the analysis around the two passes, on the device (spgemm_kernels.hip): upper bounds, bin histogram (+ a validity word), the
+// rows of every bin, the prefix sum of the counts
+aoclsparse_status launch_spg_bounds(hipStream_t s, aoclsparse_int m, aoclsparse_int n, int base_a, const aoclsparse_int *ptr_a,
+                                    const aoclsparse_int *ind_a, const aoclsparse_int *ptr_b, int *cap);
+aoclsparse_status launch_spg_diff(hipStream_t s, aoclsparse_int m, const aoclsparse_int *ptr, int *key);
+aoclsparse_status launch_spg_hist(hipStream_t s, aoclsparse_int m, const int *key, const int *limit, bool fill, unsigned int *hist);
+aoclsparse_status launch_spg_order(hipStream_t s, aoclsparse_int m, const int *key, bool fill, const aoclsparse_int *bounds,
+                                   unsigned int *cursor, aoclsparse_int *order);
+aoclsparse_status launch_spg_gather(hipStream_t s, aoclsparse_int count, const aoclsparse_int *ids, const int *key, int *out);
+size_t            spg_scan_scratch_bytes(aoclsparse_int m);
+aoclsparse_status launch_spg_scan(hipStream_t s, aoclsparse_int m, const int *cnt, aoclsparse_int *ptr, long long *scratch,
+                                  long long **total_dev);
 // complex triangular solve (complex_kernels.hip): the hybrid schedule of the plan (runs of narrow levels inside one
 // workgroup, one launch per wide level); conj_diag for op = H (the plan's values are stored conjugated)
 template <typename R>

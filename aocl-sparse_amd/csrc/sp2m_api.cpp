@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -137,8 +138,15 @@ enum
     SLOT_G_KEY,
     SLOT_G_POS,
     SLOT_G_LIST,
-    SLOT_G_ACC
+    SLOT_G_ACC,
+    SLOT_CAP,
+    SLOT_SMALL,
+    SLOT_SCAN,
+    SLOT_HEAVY_KEYS,
+    SLOT_END
 };
+static_assert(SLOT_END <= 40, "Runtime::stage_ is too small");
+constexpr int SLOT_KEY = SLOT_CNT; // the list size of every row: the counts themselves
 
 template <typename T>
 aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr descrA, const aoclsparse_matrix A,
@@ -256,115 +264,7 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
         };
         phase("operands (transposes)");
 
-        // upper bound of every row's list = the products of the row (and never more than n); the rows are binned by it for the
-        // count pass and by their exact count for the fill pass (spgemm_kernels.hip: spgemm_hash_kernel)
-        std::vector<long long> ub((size_t)m);
-        parallel_for(m, 1 << 14, [&](long long i0, long long i1) {
-            for(aoclsparse_int i = (aoclsparse_int)i0; i < (aoclsparse_int)i1; i++)
-            {
-                long long u = 0;
-                for(aoclsparse_int p = X->ptr[i] - X->base; p < X->ptr[i + 1] - X->base; p++)
-                {
-                    const aoclsparse_int c = X->ind[p] - X->base;
-                    u += Y->ptr[c + 1] - Y->ptr[c];
-                }
-                ub[(size_t)i] = u;
-            }
-        });
-        phase("upper bounds");
         hipStream_t  s = rt.stream();
-        // rows grouped by bin (stable inside a bin: consecutive rows stay together), and for the rows of the last bin a slab of
-        // `cap(i)` list entries each: bounds[b] .. bounds[b + 1] = bin b's stretch of `order`
-        auto bin_rows = [&](Binned &bn, bool for_fill, auto cap_of) -> aoclsparse_status {
-            // bin of every row and the bins' sizes: fixed chunks (the result does not depend on the thread count), one histogram each
-            std::vector<unsigned char> bin((size_t)m);
-            constexpr int              NCH = 16;
-            aoclsparse_int             hist[NCH][SPGEMM_BINS] = {};
-            parallel_for(NCH, 1, [&](long long c0, long long c1) {
-                for(long long c = c0; c < c1; c++)
-                {
-                    aoclsparse_int mine[SPGEMM_BINS] = {}; // (counted on the stack: the chunks' rows of `hist` share cache lines)
-                    for(long long i = (long long)m * c / NCH; i < (long long)m * (c + 1) / NCH; i++)
-                    {
-                        const int b    = spgemm_bin_of(cap_of((aoclsparse_int)i), for_fill);
-                        bin[(size_t)i] = (unsigned char)b;
-                        mine[b]++;
-                    }
-                    std::copy(mine, mine + SPGEMM_BINS, hist[c]);
-                }
-            });
-            aoclsparse_int cnt[SPGEMM_BINS] = {};
-            for(int c = 0; c < NCH; c++)
-                for(int b = 0; b < SPGEMM_BINS; b++)
-                    cnt[b] += hist[c][b];
-            bn.bounds[0] = 0;
-            for(int b = 0; b < SPGEMM_BINS; b++)
-                bn.bounds[b + 1] = bn.bounds[b] + cnt[b];
-            aoclsparse_status rc = aoclsparse_status_success;
-            bool              one_bin = false;
-            for(int b = 0; b < SPGEMM_BINS; b++)
-                one_bin |= cnt[b] == m;
-            if(!one_bin)
-            {
-                // (stable: chunk c's rows of bin b follow those of the chunks before it)
-                aoclsparse_int start[NCH][SPGEMM_BINS];
-                for(int b = 0; b < SPGEMM_BINS; b++)
-                {
-                    aoclsparse_int at = bn.bounds[b];
-                    for(int c = 0; c < NCH; c++)
-                        start[c][b] = at, at += hist[c][b];
-                }
-                std::vector<aoclsparse_int> order((size_t)m);
-                parallel_for(NCH, 1, [&](long long c0, long long c1) {
-                    for(long long c = c0; c < c1; c++)
-                    {
-                        aoclsparse_int next[SPGEMM_BINS];
-                        std::copy(start[c], start[c] + SPGEMM_BINS, next);
-                        for(long long i = (long long)m * c / NCH; i < (long long)m * (c + 1) / NCH; i++)
-                            order[(size_t)next[bin[(size_t)i]]++] = (aoclsparse_int)i;
-                    }
-                });
-                void *p = nullptr;
-                rc      = rt.staging(for_fill ? SLOT_ORDER_FILL : SLOT_ORDER_COUNT, sizeof(aoclsparse_int) * (size_t)m, &p);
-                if(rc == aoclsparse_status_success)
-                    rc = rt.h2d(p, order.data(), sizeof(aoclsparse_int) * (size_t)m);
-                if(rc != aoclsparse_status_success)
-                    return rc;
-                bn.d_order = static_cast<const aoclsparse_int *>(p);
-            }
-            if(cnt[SPGEMM_BINS - 1] > 0)
-            {
-                bn.heavy.reserve((size_t)cnt[SPGEMM_BINS - 1]);
-                long long hs = 0, cs = 0;
-                bn.batch.push_back(0);
-                for(aoclsparse_int i = 0; i < m; i++)
-                {
-                    if(bin[(size_t)i] != SPGEMM_BINS - 1)
-                        continue;
-                    const long long cap = cap_of(i);
-                    if(cap > (1LL << 29))
-                        return aoclsparse_status_memory_error;
-                    int logh = 6;
-                    while((1LL << logh) < 2 * cap)
-                        logh++;
-                    if(hs + (1LL << logh) > SPG_SLAB_SLOTS && hs > 0)
-                    {
-                        bn.batch.push_back((aoclsparse_int)bn.heavy.size());
-                        hs = cs = 0;
-                    }
-                    bn.heavy.push_back(SpgHeavy{i, logh, hs, cs});
-                    hs += 1LL << logh, cs += cap;
-                    bn.slots = std::max(bn.slots, hs), bn.entries = std::max(bn.entries, cs);
-                }
-                bn.batch.push_back((aoclsparse_int)bn.heavy.size());
-                void *p = nullptr;
-                rc      = rt.staging(for_fill ? SLOT_HEAVY_FILL : SLOT_HEAVY_COUNT, sizeof(SpgHeavy) * bn.heavy.size(), &p);
-                if(rc == aoclsparse_status_success)
-                    rc = rt.h2d(p, bn.heavy.data(), sizeof(SpgHeavy) * bn.heavy.size());
-                bn.d_heavy = static_cast<const SpgHeavy *>(p);
-            }
-            return rc;
-        };
         // operands on the device: the handles' own device copies; transposed operands (built on the host above) go through staging
         // slots; A * A sends A once
         DeviceBuffer d_cptr, d_ci, d_cv; // the result's own arrays
@@ -425,6 +325,94 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
         if(st != aoclsparse_status_success)
             return st;
         phase("operands to the device");
+        // ---- analysis on the device: the upper bound of every row's list, the bins, the rows of every bin (spgemm_kernels.hip) ----
+        void *p_cap = nullptr, *p_key = nullptr, *p_small = nullptr;
+        st          = rt.staging(SLOT_CAP, sizeof(int) * (size_t)m, &p_cap);
+        if(st == aoclsparse_status_success)
+            st = rt.staging(SLOT_KEY, sizeof(int) * (size_t)m, &p_key);
+        if(st == aoclsparse_status_success)
+            st = rt.staging(SLOT_SMALL, 256, &p_small);
+        if(st == aoclsparse_status_success)
+            st = launch_spg_bounds(s, m, n, X->base, dx.ptr, dx.ind, dy.ptr, static_cast<int *>(p_cap));
+        if(st != aoclsparse_status_success)
+            return st;
+        int          *d_cap  = static_cast<int *>(p_cap);
+        unsigned int *d_hist = static_cast<unsigned int *>(p_small), *d_cursor = d_hist + 16;
+        // key = the size of every row's list (count pass: d_cap; fill pass: the exact counts, checked against d_cap)
+        auto bin_rows = [&](Binned &bn, bool for_fill, const int *key, const int *limit) -> aoclsparse_status {
+            aoclsparse_status rc = launch_spg_hist(s, m, key, limit, for_fill, d_hist);
+            if(rc != aoclsparse_status_success)
+                return rc;
+            unsigned int hist[SPGEMM_BINS + 1];
+            MI355_HIP_TRY(hipMemcpyAsync(hist, d_hist, sizeof(hist), hipMemcpyDeviceToHost, s));
+            MI355_HIP_TRY(hipStreamSynchronize(s));
+            if(hist[SPGEMM_BINS])
+                return aoclsparse_status_invalid_value; // a row_ptr that is not this product's (csr2m.cpp:397-399 checks dimensions only)
+            bn.bounds[0] = 0;
+            bool one_bin = false;
+            for(int b = 0; b < SPGEMM_BINS; b++)
+            {
+                bn.bounds[b + 1] = bn.bounds[b] + (aoclsparse_int)hist[b];
+                one_bin |= (aoclsparse_int)hist[b] == m;
+            }
+            const aoclsparse_int nheavy = (aoclsparse_int)hist[SPGEMM_BINS - 1];
+            if(one_bin && nheavy == 0)
+                return aoclsparse_status_success; // (no list: workgroup g serves row g)
+            void *po = nullptr;
+            rc       = rt.staging(for_fill ? SLOT_ORDER_FILL : SLOT_ORDER_COUNT, sizeof(aoclsparse_int) * (size_t)m, &po);
+            if(rc == aoclsparse_status_success)
+                rc = launch_spg_order(s, m, key, for_fill, bn.bounds, d_cursor, static_cast<aoclsparse_int *>(po));
+            if(rc != aoclsparse_status_success)
+                return rc;
+            bn.d_order = static_cast<const aoclsparse_int *>(po);
+            if(nheavy == 0)
+                return rc;
+            // the rows of the last bin: ids and list sizes to the host, slab offsets back (few rows: the dense ones of a power-law matrix)
+            void *pk = nullptr;
+            rc       = rt.staging(SLOT_HEAVY_KEYS, sizeof(int) * (size_t)nheavy, &pk);
+            if(rc == aoclsparse_status_success)
+                rc = launch_spg_gather(s, nheavy, bn.d_order + bn.bounds[SPGEMM_BINS - 1], key, static_cast<int *>(pk));
+            if(rc != aoclsparse_status_success)
+                return rc;
+            std::vector<aoclsparse_int> ids((size_t)nheavy);
+            std::vector<int>            caps((size_t)nheavy);
+            MI355_HIP_TRY(hipMemcpyAsync(ids.data(), bn.d_order + bn.bounds[SPGEMM_BINS - 1], sizeof(aoclsparse_int) * (size_t)nheavy,
+                                         hipMemcpyDeviceToHost, s));
+            MI355_HIP_TRY(hipMemcpyAsync(caps.data(), pk, sizeof(int) * (size_t)nheavy, hipMemcpyDeviceToHost, s));
+            MI355_HIP_TRY(hipStreamSynchronize(s));
+            std::vector<std::pair<aoclsparse_int, int>> rows((size_t)nheavy);
+            for(aoclsparse_int j = 0; j < nheavy; j++)
+                rows[(size_t)j] = {ids[(size_t)j], caps[(size_t)j]};
+            std::sort(rows.begin(), rows.end()); // (the device appends them in arrival order)
+            bn.heavy.reserve((size_t)nheavy);
+            long long hs = 0, cs = 0;
+            bn.batch.push_back(0);
+            for(const auto &r : rows)
+            {
+                const long long cap = r.second;
+                if(cap > (1LL << 29))
+                    return aoclsparse_status_memory_error;
+                int logh = 6;
+                while((1LL << logh) < 2 * cap)
+                    logh++;
+                if(hs + (1LL << logh) > SPG_SLAB_SLOTS && hs > 0)
+                {
+                    bn.batch.push_back((aoclsparse_int)bn.heavy.size());
+                    hs = cs = 0;
+                }
+                bn.heavy.push_back(SpgHeavy{r.first, logh, hs, cs});
+                hs += 1LL << logh, cs += cap;
+                bn.slots = std::max(bn.slots, hs), bn.entries = std::max(bn.entries, cs);
+            }
+            bn.batch.push_back((aoclsparse_int)bn.heavy.size());
+            void *ph = nullptr;
+            rc       = rt.staging(for_fill ? SLOT_HEAVY_FILL : SLOT_HEAVY_COUNT, sizeof(SpgHeavy) * bn.heavy.size(), &ph);
+            if(rc == aoclsparse_status_success)
+                rc = rt.h2d(ph, bn.heavy.data(), sizeof(SpgHeavy) * bn.heavy.size());
+            bn.d_heavy = static_cast<const SpgHeavy *>(ph);
+            return rc;
+        };
+        phase("upper bounds (device)");
         auto run_pass = [&](bool pass_fill, Binned &bn, const aoclsparse_int *ptr_c, aoclsparse_int *out_i, T *out_v) -> aoclsparse_status {
             aoclsparse_status rc = aoclsparse_status_success;
             for(int b = 0; b < SPGEMM_BINS - 1 && rc == aoclsparse_status_success; b++)
@@ -452,34 +440,38 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
             return rc;
         };
 
+        bool ptr_on_device = false; // d_cptr holds D's row_ptr (a full computation goes from the count pass to the fill pass in HBM)
         if(count)
         {
-            void *d_cnt = nullptr;
-            st          = rt.staging(SLOT_CNT, sizeof(aoclsparse_int) * (size_t)m, &d_cnt);
-            if(st != aoclsparse_status_success)
-                return st;
             Binned by_bound;
-            st = bin_rows(by_bound, false, [&](aoclsparse_int i) { return std::min<long long>(ub[(size_t)i], n); });
+            st = bin_rows(by_bound, false, d_cap, nullptr);
             phase("count: bins");
             if(st == aoclsparse_status_success)
-                st = run_pass(false, by_bound, nullptr, static_cast<aoclsparse_int *>(d_cnt), nullptr);
+                st = run_pass(false, by_bound, nullptr, static_cast<aoclsparse_int *>(p_key), nullptr);
             if(st != aoclsparse_status_success)
                 return st;
             phase("count: kernels");
-            std::vector<aoclsparse_int> cptr((size_t)m + 1, 0);
-            MI355_HIP_TRY(hipMemcpyAsync(cptr.data() + 1, d_cnt, sizeof(aoclsparse_int) * (size_t)m,
-                                         hipMemcpyDeviceToHost, s));
+            // row_ptr of D = prefix sum of the counts, on the device; the host needs the total now (to allocate) and the array itself
+            // for the handle (64-bit sums: a product of more than 2^31 - 1 entries is refused, csr2m.cpp:221-236)
+            void      *p_scan = nullptr;
+            long long *d_total = nullptr, total = 0;
+            st = rt.staging(SLOT_SCAN, spg_scan_scratch_bytes(m), &p_scan);
+            if(st == aoclsparse_status_success)
+                st = d_cptr.alloc(sizeof(aoclsparse_int) * ((size_t)m + 1));
+            if(st == aoclsparse_status_success)
+                st = launch_spg_scan(s, m, static_cast<const int *>(p_key), d_cptr.as<aoclsparse_int>(), static_cast<long long *>(p_scan),
+                                     &d_total);
+            if(st != aoclsparse_status_success)
+                return st;
+            std::vector<aoclsparse_int> cptr((size_t)m + 1);
+            MI355_HIP_TRY(hipMemcpyAsync(&total, d_total, sizeof(long long), hipMemcpyDeviceToHost, s));
+            MI355_HIP_TRY(hipMemcpyAsync(cptr.data(), d_cptr.ptr, sizeof(aoclsparse_int) * ((size_t)m + 1), hipMemcpyDeviceToHost, s));
             MI355_HIP_TRY(hipStreamSynchronize(s));
-            long long run = 0; // 64-bit prefix sum, overflow -> invalid_size (csr2m.cpp:221-236)
-            for(aoclsparse_int i = 1; i <= m; i++)
-            {
-                run += cptr[i];
-                cptr[i] = (aoclsparse_int)run;
-            }
-            if(run > 2147483647LL)
+            if(total > 2147483647LL)
                 return aoclsparse_status_invalid_size;
-            const aoclsparse_int nnz_c = (aoclsparse_int)run;
-            phase("count: counts to host, scan");
+            const aoclsparse_int nnz_c = (aoclsparse_int)total;
+            ptr_on_device              = true;
+            phase("count: scan, row_ptr to host");
             if(opflag == 3)
             {
                 // C is n x m; keep D's row_ptr in the handle's transposed-product scratch until finalize
@@ -520,15 +512,18 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
             auto keep = std::move(c->trans);
             (void)aoclsparse_mi355_invalidate(c);
             c->trans = std::move(keep);
-            // rows binned by their exact count (the caller's row_ptr of stage 1); a row_ptr that does not belong to this product
-            // is refused here rather than trusted by a kernel (csr2m.cpp:397-399 checks the dimensions only)
-            for(aoclsparse_int i = 0; i < m; i++)
-                if(d->ptr[i + 1] < d->ptr[i] || d->ptr[i + 1] - d->ptr[i] > std::min<long long>(ub[(size_t)i], n))
-                    return aoclsparse_status_invalid_value;
-            Binned by_count;
-            st = bin_rows(by_count, true, [&](aoclsparse_int i) { return (long long)(d->ptr[i + 1] - d->ptr[i]); });
-            if(st == aoclsparse_status_success)
+            // rows binned by their exact count: the counts of stage 1 are still in HBM after a full computation, a finalize call
+            // sends the handle's row_ptr; either way they are checked against the upper bounds on the device (bin_rows)
+            if(!ptr_on_device)
+            {
                 st = d_cptr.upload(d->ptr, sizeof(aoclsparse_int) * ((size_t)m + 1), s);
+                if(st == aoclsparse_status_success)
+                    st = launch_spg_diff(s, m, d_cptr.as<aoclsparse_int>(), static_cast<int *>(p_key));
+                if(st != aoclsparse_status_success)
+                    return st;
+            }
+            Binned by_count;
+            st = bin_rows(by_count, true, static_cast<const int *>(p_key), d_cap);
             if(st == aoclsparse_status_success)
                 st = d_ci.alloc(sizeof(aoclsparse_int) * (size_t)std::max(nnz_c, 1));
             if(st == aoclsparse_status_success)
@@ -540,12 +535,23 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
             if(st != aoclsparse_status_success)
                 return st;
             // while the kernels run: the result's host arrays are first-touched by several threads (host_result_alloc; faulted in
-            // by the copy itself they cost more than the copy: 7-13 ms for 156 MB against ~3)
+            // by the copy itself they cost more than the copy: 7-13 ms for 156 MB against ~3); the values' pages are touched while
+            // the column indices already travel
             host_result_touch(d->ind, sizeof(aoclsparse_int) * (size_t)nnz_c);
-            host_result_touch(d->val, sizeof(T) * (size_t)nnz_c);
-            phase("fill: kernels (+ host pages)");
-            MI355_HIP_TRY(hipMemcpyAsync(d->ind, d_ci.ptr, sizeof(aoclsparse_int) * (size_t)nnz_c,
-                                         hipMemcpyDeviceToHost, s));
+            phase("fill: kernels (+ host pages of col_ind)");
+            std::thread toucher;
+            try
+            {
+                toucher = std::thread([&] { host_result_touch(d->val, sizeof(T) * (size_t)nnz_c); });
+            }
+            catch(const std::system_error &)
+            {
+                host_result_touch(d->val, sizeof(T) * (size_t)nnz_c);
+            }
+            const hipError_t e1 = hipMemcpyAsync(d->ind, d_ci.ptr, sizeof(aoclsparse_int) * (size_t)nnz_c, hipMemcpyDeviceToHost, s);
+            if(toucher.joinable())
+                toucher.join();
+            MI355_HIP_TRY(e1);
             MI355_HIP_TRY(hipMemcpyAsync(d->val, d_cv.ptr, sizeof(T) * (size_t)nnz_c, hipMemcpyDeviceToHost, s));
             MI355_HIP_TRY(hipStreamSynchronize(s));
             phase("fill: result to host");

@@ -381,6 +381,257 @@ aoclsparse_status launch_spgemm_heavy(hipStream_t s, bool fill, aoclsparse_int n
     return aoclsparse_status_success;
 }
 
+// ---- the analysis around the two passes, on the device (round 4) ---------------------------------------------------------------
+// Upper bounds, bins, the rows of every bin and the prefix sum of the counts are integer work over arrays that already sit in HBM;
+// on the host they cost 3 of the 8 ms of A * A on the 1000^2 Laplacian (thread start-up and memory traffic of 1 M-row loops).
+__device__ __forceinline__ int spg_bin_dev(int entries, bool fill)
+{
+    const int last = fill ? SPGEMM_BINS - 2 : SPGEMM_BINS - 1;
+    int       b    = SPGEMM_BINS - 1;
+    for(int k = last - 1; k >= 0; k--)
+        if(entries <= SPG_CAP[k])
+            b = k;
+    return b;
+}
+
+// cap[i] = min(sum of the lengths of the B rows that row i of A touches, n)
+__global__ __launch_bounds__(256) void spg_bound_kernel(aoclsparse_int m, aoclsparse_int n, int base_a,
+                                                        const aoclsparse_int *__restrict__ ptr_a,
+                                                        const aoclsparse_int *__restrict__ ind_a, const aoclsparse_int *__restrict__ ptr_b,
+                                                        int *__restrict__ cap)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if(i >= m)
+        return;
+    long long u = 0;
+    for(int p = ptr_a[i] - base_a; p < ptr_a[i + 1] - base_a; p++)
+    {
+        const int c = ind_a[p] - base_a;
+        u += ptr_b[c + 1] - ptr_b[c];
+    }
+    cap[i] = (int)(u < (long long)n ? u : (long long)n);
+}
+
+// key[i] = ptr[i + 1] - ptr[i] (the fill pass of a two-stage call starts from the caller's row_ptr)
+__global__ __launch_bounds__(256) void spg_diff_kernel(aoclsparse_int m, const aoclsparse_int *__restrict__ ptr, int *__restrict__ key)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if(i < m)
+        key[i] = ptr[i + 1] - ptr[i];
+}
+
+// hist[b] += rows of bin b; hist[SPGEMM_BINS] != 0: some key is negative or above its limit (a row_ptr that is not this product's)
+__global__ __launch_bounds__(256) void spg_hist_kernel(aoclsparse_int m, const int *__restrict__ key, const int *__restrict__ limit,
+                                                       bool fill, unsigned int *hist)
+{
+    const int i    = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int       b    = -1;
+    bool      bad  = false;
+    if(i < m)
+    {
+        const int k = key[i];
+        bad         = k < 0 || (limit && k > limit[i]);
+        b           = spg_bin_dev(k < 0 ? 0 : k, fill);
+    }
+#pragma unroll
+    for(int k = 0; k < SPGEMM_BINS; k++)
+    {
+        const unsigned long long mk = __ballot(b == k);
+        if(lane == 0 && mk)
+            atomicAdd(&hist[k], (unsigned)__popcll(mk));
+    }
+    if(__ballot(bad) && lane == 0)
+        atomicOr(&hist[SPGEMM_BINS], 1u);
+}
+
+struct SpgBounds
+{
+    int at[SPGEMM_BINS + 1];
+};
+
+// order[bounds[b] ...] = the rows of bin b; the rows of one wavefront keep their order (ballot rank), wavefronts arrive as they come
+__global__ __launch_bounds__(256) void spg_order_kernel(aoclsparse_int m, const int *__restrict__ key, bool fill, SpgBounds bounds,
+                                                        unsigned int *cursor, aoclsparse_int *__restrict__ order)
+{
+    const int i    = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int b    = i < m ? spg_bin_dev(key[i], fill) : -1;
+#pragma unroll
+    for(int k = 0; k < SPGEMM_BINS; k++)
+    {
+        const unsigned long long mk = __ballot(b == k);
+        if(!mk)
+            continue;
+        unsigned at = 0;
+        if(lane == 0)
+            at = atomicAdd(&cursor[k], (unsigned)__popcll(mk));
+        at = __shfl(at, 0, 64);
+        if(b == k)
+            order[bounds.at[k] + at + __popcll(mk & ((1ull << lane) - 1ull))] = i;
+    }
+}
+
+__global__ __launch_bounds__(256) void spg_gather_kernel(aoclsparse_int count, const aoclsparse_int *__restrict__ ids,
+                                                         const int *__restrict__ key, int *__restrict__ out)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if(j < count)
+        out[j] = key[ids[j]];
+}
+
+// exclusive prefix sum of cnt[0..m) into ptr[0..m], 64-bit block sums (ptr is 32-bit like the reference's row_ptr; the true total
+// goes to total[0] so that the caller can refuse a product of more than 2^31 - 1 entries: csr2m.cpp:221-236)
+constexpr int SPG_SCAN_BLOCK = 1024;
+__global__ __launch_bounds__(256) void spg_scan_sums_kernel(aoclsparse_int m, const int *__restrict__ cnt, long long *__restrict__ sums)
+{
+    __shared__ long long sh[4];
+    const int            i0 = blockIdx.x * SPG_SCAN_BLOCK + threadIdx.x * 4;
+    long long            v  = 0;
+    for(int q = 0; q < 4; q++)
+        if(i0 + q < m)
+            v += cnt[i0 + q];
+    for(int o = 32; o > 0; o >>= 1)
+        v += __shfl_down(v, o, 64);
+    if((threadIdx.x & 63) == 0)
+        sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if(threadIdx.x == 0)
+        sums[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void spg_scan_blocks_kernel(int nblocks, long long *sums, long long *total)
+{
+    __shared__ long long sh[256];
+    long long            carry = 0;
+    for(int b0 = 0; b0 < nblocks; b0 += 256)
+    {
+        const int       b = b0 + threadIdx.x;
+        const long long v = b < nblocks ? sums[b] : 0;
+        sh[threadIdx.x]   = v;
+        __syncthreads();
+        for(int o = 1; o < 256; o <<= 1) // Hillis-Steele, inclusive
+        {
+            const long long t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if(b < nblocks)
+            sums[b] = carry + sh[threadIdx.x] - v; // exclusive
+        carry += sh[255];
+        __syncthreads();
+    }
+    if(threadIdx.x == 0)
+        total[0] = carry;
+}
+
+__global__ __launch_bounds__(256) void spg_scan_apply_kernel(aoclsparse_int m, const int *__restrict__ cnt, const long long *__restrict__ sums,
+                                                             const long long *__restrict__ total, aoclsparse_int *__restrict__ ptr)
+{
+    __shared__ long long sh[256];
+    const int            i0 = blockIdx.x * SPG_SCAN_BLOCK + threadIdx.x * 4;
+    int                  c[4];
+    long long            v = 0;
+    for(int q = 0; q < 4; q++)
+    {
+        c[q] = i0 + q < m ? cnt[i0 + q] : 0;
+        v += c[q];
+    }
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for(int o = 1; o < 256; o <<= 1)
+    {
+        const long long t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    long long run = sums[blockIdx.x] + sh[threadIdx.x] - v;
+    for(int q = 0; q < 4; q++)
+    {
+        if(i0 + q < m)
+            ptr[i0 + q] = (aoclsparse_int)run;
+        run += c[q];
+    }
+    if(blockIdx.x == 0 && threadIdx.x == 0)
+        ptr[m] = (aoclsparse_int)total[0];
+}
+
+aoclsparse_status launch_spg_bounds(hipStream_t s, aoclsparse_int m, aoclsparse_int n, int base_a, const aoclsparse_int *ptr_a,
+                                    const aoclsparse_int *ind_a, const aoclsparse_int *ptr_b, int *cap)
+{
+    if(m > 0)
+        hipLaunchKernelGGL(spg_bound_kernel, dim3((m + 255) / 256), dim3(256), 0, s, m, n, base_a, ptr_a, ind_a, ptr_b, cap);
+    MI355_HIP_TRY(hipGetLastError());
+    return aoclsparse_status_success;
+}
+
+aoclsparse_status launch_spg_diff(hipStream_t s, aoclsparse_int m, const aoclsparse_int *ptr, int *key)
+{
+    if(m > 0)
+        hipLaunchKernelGGL(spg_diff_kernel, dim3((m + 255) / 256), dim3(256), 0, s, m, ptr, key);
+    MI355_HIP_TRY(hipGetLastError());
+    return aoclsparse_status_success;
+}
+
+// hist: SPGEMM_BINS + 1 words, zeroed here
+aoclsparse_status launch_spg_hist(hipStream_t s, aoclsparse_int m, const int *key, const int *limit, bool fill, unsigned int *hist)
+{
+    MI355_HIP_TRY(hipMemsetAsync(hist, 0, sizeof(unsigned int) * (SPGEMM_BINS + 1), s));
+    if(m > 0)
+        hipLaunchKernelGGL(spg_hist_kernel, dim3((m + 255) / 256), dim3(256), 0, s, m, key, limit, fill, hist);
+    MI355_HIP_TRY(hipGetLastError());
+    return aoclsparse_status_success;
+}
+
+// cursor: SPGEMM_BINS words, zeroed here; bounds[b] = first position of bin b in order
+aoclsparse_status launch_spg_order(hipStream_t s, aoclsparse_int m, const int *key, bool fill, const aoclsparse_int *bounds,
+                                   unsigned int *cursor, aoclsparse_int *order)
+{
+    SpgBounds bd;
+    for(int b = 0; b <= SPGEMM_BINS; b++)
+        bd.at[b] = bounds[b];
+    MI355_HIP_TRY(hipMemsetAsync(cursor, 0, sizeof(unsigned int) * SPGEMM_BINS, s));
+    if(m > 0)
+        hipLaunchKernelGGL(spg_order_kernel, dim3((m + 255) / 256), dim3(256), 0, s, m, key, fill, bd, cursor, order);
+    MI355_HIP_TRY(hipGetLastError());
+    return aoclsparse_status_success;
+}
+
+aoclsparse_status launch_spg_gather(hipStream_t s, aoclsparse_int count, const aoclsparse_int *ids, const int *key, int *out)
+{
+    if(count > 0)
+        hipLaunchKernelGGL(spg_gather_kernel, dim3((count + 255) / 256), dim3(256), 0, s, count, ids, key, out);
+    MI355_HIP_TRY(hipGetLastError());
+    return aoclsparse_status_success;
+}
+
+// sums: ceil(m / 1024) + 1 long longs of scratch (the last one receives the total)
+size_t spg_scan_scratch_bytes(aoclsparse_int m)
+{
+    return sizeof(long long) * ((size_t)(m + SPG_SCAN_BLOCK - 1) / SPG_SCAN_BLOCK + 2);
+}
+
+aoclsparse_status launch_spg_scan(hipStream_t s, aoclsparse_int m, const int *cnt, aoclsparse_int *ptr, long long *scratch,
+                                  long long **total_dev)
+{
+    const int nb = (int)((m + SPG_SCAN_BLOCK - 1) / SPG_SCAN_BLOCK);
+    long long *total = scratch + nb;
+    *total_dev       = total;
+    if(m <= 0)
+    {
+        MI355_HIP_TRY(hipMemsetAsync(total, 0, sizeof(long long), s));
+        MI355_HIP_TRY(hipMemsetAsync(ptr, 0, sizeof(aoclsparse_int), s));
+        return aoclsparse_status_success;
+    }
+    hipLaunchKernelGGL(spg_scan_sums_kernel, dim3(nb), dim3(256), 0, s, m, cnt, scratch);
+    hipLaunchKernelGGL(spg_scan_blocks_kernel, dim3(1), dim3(256), 0, s, nb, scratch, total);
+    hipLaunchKernelGGL(spg_scan_apply_kernel, dim3(nb), dim3(256), 0, s, m, cnt, scratch, total, ptr);
+    MI355_HIP_TRY(hipGetLastError());
+    return aoclsparse_status_success;
+}
+
 int spgemm_bin_of(long long entries, bool fill)
 {
     for(int b = 0; b < (fill ? SPGEMM_BINS - 2 : SPGEMM_BINS - 1); b++)
