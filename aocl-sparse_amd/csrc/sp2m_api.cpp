@@ -26,12 +26,13 @@ aoclsparse_status launch_spgemm_heavy(hipStream_t s, bool fill, aoclsparse_int n
                                       int *g_list, T *g_acc, int base_a, const aoclsparse_int *ptr_a, const aoclsparse_int *ind_a,
                                       const T *val_a, int base_b, const aoclsparse_int *ptr_b, const aoclsparse_int *ind_b,
                                       const T *val_b, const aoclsparse_int *ptr_c, aoclsparse_int *cnt_or_ind_c, T *val_c,
-                                      bool conj_a, bool conj_b);
+                                      bool conj_a, bool conj_b, unsigned int *bad);
 template <typename T>
 aoclsparse_status launch_spgemm_bin(hipStream_t s, bool fill, int bin, aoclsparse_int nrows, const aoclsparse_int *rows, int base_a,
                                     const aoclsparse_int *ptr_a, const aoclsparse_int *ind_a, const T *val_a, int base_b,
                                     const aoclsparse_int *ptr_b, const aoclsparse_int *ind_b, const T *val_b,
-                                    const aoclsparse_int *ptr_c, aoclsparse_int *cnt_or_ind_c, T *val_c, bool conj_a, bool conj_b);
+                                    const aoclsparse_int *ptr_c, aoclsparse_int *cnt_or_ind_c, T *val_c, bool conj_a, bool conj_b,
+                                    unsigned int *bad);
 
 aoclsparse_status new_csr_result(aoclsparse_matrix *C, aoclsparse_int m, aoclsparse_int n, aoclsparse_int nnz,
                                  aoclsparse_matrix_data_type vt, const aoclsparse_int *row_ptr, aoclsparse_index_base base)
@@ -337,7 +338,8 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
         if(st != aoclsparse_status_success)
             return st;
         int          *d_cap  = static_cast<int *>(p_cap);
-        unsigned int *d_hist = static_cast<unsigned int *>(p_small), *d_cursor = d_hist + 16;
+        unsigned int *d_hist = static_cast<unsigned int *>(p_small), *d_cursor = d_hist + 16, *d_bad = d_hist + 32;
+        MI355_HIP_TRY(hipMemsetAsync(d_bad, 0, sizeof(unsigned int), s)); // raised by a row whose list does not fit what it was given
         // key = the size of every row's list (count pass: d_cap; fill pass: the exact counts, checked against d_cap)
         auto bin_rows = [&](Binned &bn, bool for_fill, const int *key, const int *limit) -> aoclsparse_status {
             aoclsparse_status rc = launch_spg_hist(s, m, key, limit, for_fill, d_hist);
@@ -418,7 +420,7 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
             for(int b = 0; b < SPGEMM_BINS - 1 && rc == aoclsparse_status_success; b++)
                 rc = launch_spgemm_bin<T>(s, pass_fill, b, bn.bounds[b + 1] - bn.bounds[b], bn.d_order ? bn.d_order + bn.bounds[b] : nullptr,
                                           X->base, dx.ptr, dx.ind, static_cast<const T *>(dx.val), Y->base, dy.ptr, dy.ind,
-                                          static_cast<const T *>(dy.val), ptr_c, out_i, out_v, conj_x, conj_y);
+                                          static_cast<const T *>(dy.val), ptr_c, out_i, out_v, conj_x, conj_y, d_bad);
             if(rc != aoclsparse_status_success || bn.heavy.empty())
                 return rc;
             void *gk = nullptr, *gp = nullptr, *gl = nullptr, *ga = nullptr;
@@ -436,7 +438,7 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
                 rc = launch_spgemm_heavy<T>(s, pass_fill, bn.batch[b + 1] - bn.batch[b], bn.d_heavy + bn.batch[b], static_cast<int *>(gk),
                                             static_cast<int *>(gp), static_cast<int *>(gl), static_cast<T *>(ga), X->base, dx.ptr, dx.ind,
                                             static_cast<const T *>(dx.val), Y->base, dy.ptr, dy.ind, static_cast<const T *>(dy.val), ptr_c,
-                                            out_i, out_v, conj_x, conj_y);
+                                            out_i, out_v, conj_x, conj_y, d_bad);
             return rc;
         };
 
@@ -553,7 +555,11 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
                 toucher.join();
             MI355_HIP_TRY(e1);
             MI355_HIP_TRY(hipMemcpyAsync(d->val, d_cv.ptr, sizeof(T) * (size_t)nnz_c, hipMemcpyDeviceToHost, s));
+            unsigned int bad = 0;
+            MI355_HIP_TRY(hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, s));
             MI355_HIP_TRY(hipStreamSynchronize(s));
+            if(bad) // the row_ptr of *C is not the one stage 1 of THIS product returned (a row ended short of, or beyond, its segment)
+                return aoclsparse_status_invalid_value;
             phase("fill: result to host");
             if(opflag != 3)
             {

@@ -140,7 +140,8 @@ __global__ __launch_bounds__(G *NG) void spgemm_hash_kernel(aoclsparse_int nrows
                                                            const aoclsparse_int *__restrict__ ind_b,
                                                            const T *__restrict__ val_b,
                                                            const aoclsparse_int *__restrict__ ptr_c,
-                                                           aoclsparse_int *cnt_or_ind_c, T *val_c, bool conj_a, bool conj_b)
+                                                           aoclsparse_int *cnt_or_ind_c, T *val_c, bool conj_a, bool conj_b,
+                                                           unsigned int *bad)
 {
     constexpr int EMPTY = -1;
     constexpr int LH = GLOBAL ? 1 : (1 << LOGH); // (LDS arrays of the global mode: one dummy element)
@@ -172,6 +173,14 @@ __global__ __launch_bounds__(G *NG) void spgemm_hash_kernel(aoclsparse_int nrows
     }
     const int      H     = 1 << logh;
     const unsigned hmask = (unsigned)H - 1u;
+    // The list may hold `limit` entries: in the fill pass what the caller's row_ptr gives this row -- a row_ptr that is not this
+    // product's must neither run a row into its neighbour's segment nor fill the table (a full table never ends a probe) --, in the
+    // count pass half the table (never reached: the bins are chosen by the upper bound).  A row that would exceed it stops and
+    // raises *bad; so does a fill that ends short of its segment.
+    int limit = H / 2;
+    if constexpr(FILL)
+        limit = min(limit, ptr_c[i + 1] - ptr_c[i]);
+    bool dead = false;
     for(int t = gl; t < H; t += G)
         hkey[t] = EMPTY;
     spg_sync<GLOBAL>();
@@ -180,7 +189,7 @@ __global__ __launch_bounds__(G *NG) void spgemm_hash_kernel(aoclsparse_int nrows
     auto           hash   = [&](int c) { return (unsigned)c * 2654435761u >> hshift; };
     int  len = 0;
     const int ja = ptr_a[i] - base_a, je = ptr_a[i + 1] - base_a;
-    for(int j0 = ja; j0 < je; j0 += G)
+    for(int j0 = ja; j0 < je && !dead; j0 += G)
     {
         // this round's entries of A's row, one per lane: value and the extent of the matching B row
         const bool have = j0 + gl < je;
@@ -194,14 +203,14 @@ __global__ __launch_bounds__(G *NG) void spgemm_hash_kernel(aoclsparse_int nrows
                 my_va = sp_conj(val_a[j0 + gl], conj_a);
         }
         const int nj = min(G, je - j0);
-        for(int jj = 0; jj < nj; jj++)
+        for(int jj = 0; jj < nj && !dead; jj++)
         {
             const int kb = __shfl(my_kb, jj, G), ke = __shfl(my_ke, jj, G);
             T         va = T(0);
             if constexpr(FILL)
                 va = spg_shfl(my_va, jj, G);
             int carry = -1;
-            for(int k0 = kb; k0 < ke; k0 += G)
+            for(int k0 = kb; k0 < ke && !dead; k0 += G)
             {
                 const int  k     = k0 + gl;
                 const bool valid = k < ke;
@@ -235,6 +244,11 @@ __global__ __launch_bounds__(G *NG) void spgemm_hash_kernel(aoclsparse_int nrows
                         }
                     const bool               isnew = valid && pos < 0;
                     const unsigned long long nm    = spg_group_bits<G>(__ballot(isnew), wgrp);
+                    if(len + __popcll(nm) > limit) // (uniform inside the group)
+                    {
+                        dead = true;
+                        break;
+                    }
                     if(isnew)
                     {
                         const int slot = len + __popcll(nm & lt);
@@ -282,6 +296,11 @@ __global__ __launch_bounds__(G *NG) void spgemm_hash_kernel(aoclsparse_int nrows
                             }
                             h = (h + 1) & hmask;
                         }
+                        if(pos < 0 && len + 1 > limit)
+                        {
+                            dead = true;
+                            break;
+                        }
                         if(gl == 0)
                         {
                             if(pos < 0)
@@ -306,6 +325,10 @@ __global__ __launch_bounds__(G *NG) void spgemm_hash_kernel(aoclsparse_int nrows
         }
     }
     if constexpr(FILL)
+        dead |= len != limit;
+    if(dead && gl == 0)
+        atomicOr(bad, 1u);
+    if constexpr(FILL)
     {
         const int dst = ptr_c[i];
         for(int t = gl; t < len; t += G)
@@ -325,14 +348,15 @@ template <typename T>
 aoclsparse_status launch_spgemm_bin(hipStream_t s, bool fill, int bin, aoclsparse_int nrows, const aoclsparse_int *rows, int base_a,
                                     const aoclsparse_int *ptr_a, const aoclsparse_int *ind_a, const T *val_a, int base_b,
                                     const aoclsparse_int *ptr_b, const aoclsparse_int *ind_b, const T *val_b,
-                                    const aoclsparse_int *ptr_c, aoclsparse_int *cnt_or_ind_c, T *val_c, bool conj_a, bool conj_b)
+                                    const aoclsparse_int *ptr_c, aoclsparse_int *cnt_or_ind_c, T *val_c, bool conj_a, bool conj_b,
+                                    unsigned int *bad)
 {
     if(nrows <= 0)
         return aoclsparse_status_success;
 #define MI355_SPG(F, G, LOGH, NG)                                                                                               \
     hipLaunchKernelGGL((spgemm_hash_kernel<T, F, G, LOGH, NG, false>), dim3((unsigned)((nrows + NG - 1) / NG)), dim3(G * NG), 0, s, \
                        nrows, rows, (const SpgHeavy *)nullptr, (int *)nullptr, (int *)nullptr, (int *)nullptr, (T *)nullptr, base_a, \
-                       ptr_a, ind_a, val_a, base_b, ptr_b, ind_b, val_b, ptr_c, cnt_or_ind_c, val_c, conj_a, conj_b)
+                       ptr_a, ind_a, val_a, base_b, ptr_b, ind_b, val_b, ptr_c, cnt_or_ind_c, val_c, conj_a, conj_b, bad)
     if(fill)
     {
         switch(bin)
@@ -365,18 +389,18 @@ aoclsparse_status launch_spgemm_heavy(hipStream_t s, bool fill, aoclsparse_int n
                                       int *g_list, T *g_acc, int base_a, const aoclsparse_int *ptr_a, const aoclsparse_int *ind_a,
                                       const T *val_a, int base_b, const aoclsparse_int *ptr_b, const aoclsparse_int *ind_b,
                                       const T *val_b, const aoclsparse_int *ptr_c, aoclsparse_int *cnt_or_ind_c, T *val_c,
-                                      bool conj_a, bool conj_b)
+                                      bool conj_a, bool conj_b, unsigned int *bad)
 {
     if(nrows <= 0)
         return aoclsparse_status_success;
     if(fill)
         hipLaunchKernelGGL((spgemm_hash_kernel<T, true, 64, 0, 1, true>), dim3((unsigned)nrows), dim3(64), 0, s, nrows,
                            (const aoclsparse_int *)nullptr, heavy, g_key, g_pos, g_list, g_acc, base_a, ptr_a, ind_a, val_a, base_b,
-                           ptr_b, ind_b, val_b, ptr_c, cnt_or_ind_c, val_c, conj_a, conj_b);
+                           ptr_b, ind_b, val_b, ptr_c, cnt_or_ind_c, val_c, conj_a, conj_b, bad);
     else
         hipLaunchKernelGGL((spgemm_hash_kernel<T, false, 64, 0, 1, true>), dim3((unsigned)nrows), dim3(64), 0, s, nrows,
                            (const aoclsparse_int *)nullptr, heavy, g_key, g_pos, g_list, g_acc, base_a, ptr_a, ind_a, val_a, base_b,
-                           ptr_b, ind_b, val_b, ptr_c, cnt_or_ind_c, val_c, conj_a, conj_b);
+                           ptr_b, ind_b, val_b, ptr_c, cnt_or_ind_c, val_c, conj_a, conj_b, bad);
     MI355_HIP_TRY(hipGetLastError());
     return aoclsparse_status_success;
 }
@@ -644,11 +668,12 @@ int spgemm_bin_of(long long entries, bool fill)
     template aoclsparse_status launch_spgemm_bin<T>(hipStream_t, bool, int, aoclsparse_int, const aoclsparse_int *, int, \
                                                     const aoclsparse_int *, const aoclsparse_int *, const T *, int, \
                                                     const aoclsparse_int *, const aoclsparse_int *, const T *,      \
-                                                    const aoclsparse_int *, aoclsparse_int *, T *, bool, bool);     \
+                                                    const aoclsparse_int *, aoclsparse_int *, T *, bool, bool,      \
+                                                    unsigned int *);                                                \
     template aoclsparse_status launch_spgemm_heavy<T>(hipStream_t, bool, aoclsparse_int, const SpgHeavy *, int *, int *, int *, T *, \
                                                       int, const aoclsparse_int *, const aoclsparse_int *, const T *, int,          \
                                                       const aoclsparse_int *, const aoclsparse_int *, const T *,                    \
-                                                      const aoclsparse_int *, aoclsparse_int *, T *, bool, bool);
+                                                      const aoclsparse_int *, aoclsparse_int *, T *, bool, bool, unsigned int *);
 MI355_SPGEMM_INST(double)
 MI355_SPGEMM_INST(float)
 MI355_SPGEMM_INST(cdouble)

@@ -926,3 +926,23 @@ def test_sp2m_transposed_operands_are_kept_by_their_handles():
         _, _, _, row, col, val = _export_csr(E)
         assert so == 0 and np.array_equal(row, pe) and np.array_equal(col, ie) and np.array_equal(val, ve)
         assert L.aoclsparse_destroy(ctypes.byref(E)) == 0
+
+
+def test_sp2m_finalize_refuses_a_row_ptr_of_another_product():
+    """stage_finalize trusts nothing about the handle it is given beyond what it can check: a C whose row_ptr came from stage 1 of a
+    DIFFERENT product of the same dimensions (rows that would end short of, or run beyond, their segments; counts above the upper
+    bound) is refused with invalid_value -- no row writes into its neighbour's segment, no table fills up -- and the right C still
+    finalizes afterwards."""
+    m = 3000
+    (pa, ia, va), (pb, ib, vb) = _spgemm_operands(91, m, m, m, False)
+    (pa2, ia2, va2), _ = _spgemm_operands(92, m, m, m, False)  # another pattern, same shape
+    A, A2, B = P.Matrix(0, m, m, pa, ia, va), P.Matrix(0, m, m, pa2, ia2, va2), P.Matrix(0, m, m, pb, ib, vb)
+    d = P.Descr()
+    C = ctypes.c_void_p()
+    assert L.aoclsparse_sp2m(P.OP_NONE, d.h, A.h, P.OP_NONE, d.h, B.h, P.STAGE_NNZ_COUNT, ctypes.byref(C)) == 0
+    assert L.aoclsparse_sp2m(P.OP_NONE, d.h, A2.h, P.OP_NONE, d.h, B.h, P.STAGE_FINALIZE, ctypes.byref(C)) == 5  # invalid_value
+    assert L.aoclsparse_sp2m(P.OP_NONE, d.h, A.h, P.OP_NONE, d.h, B.h, P.STAGE_FINALIZE, ctypes.byref(C)) == 0
+    so, pc, ic, vc = oracle.dcsr2m(m, m, 0, pa, ia, va, 0, pb, ib, vb)
+    _, _, _, row, col, val = _export_csr(C)
+    assert so == 0 and np.array_equal(row, pc) and np.array_equal(col, ic) and np.array_equal(val, vc)
+    assert L.aoclsparse_destroy(ctypes.byref(C)) == 0
