@@ -663,9 +663,10 @@ aoclsparse_status ensure_derived(aoclsparse_matrix A, aoclsparse_matrix_type typ
 // need_rows: also the level-ordered row layout (TrsvPlan::rows_valid); false = only what the automatic schedule needs
 aoclsparse_status ensure_trsv(aoclsparse_matrix A, bool upper, bool transposed, bool conj = false, bool need_rows = true);
 // SELL-64 copy of d (row_ptr_host = the host row pointer d mirrors); leaves plan.sell.valid false when the
-// padding would exceed the budget (AOCLSPARSE_MI355_SELL=0 never, =1 always)
+// padding would exceed the budget (aoclsparse_mi355_set_option(aoclsparse_mi355_option_sell, 0 / 1): never / always)
 aoclsparse_status build_sell(const aoclsparse_int *row_ptr_host, const DeviceCsr &d, size_t vsize, SpmvPlan &plan);
-// merge-path tiling (host binary searches over row_ptr_host); built only when AOCLSPARSE_MI355_SPMV_KERNEL=merge
+// merge-path tiling (host binary searches over row_ptr_host); built when the longest row spans >= 32 LDS tiles, or when
+// aoclsparse_mi355_set_option(aoclsparse_mi355_option_spmv_kernel, ...) asks for it
 aoclsparse_status build_merge_plan(aoclsparse_int m, aoclsparse_int nnz, aoclsparse_index_base base,
                                    const aoclsparse_int *row_ptr_host, size_t vsize, SpmvPlan &plan);
 aoclsparse_status build_spmv_plan(aoclsparse_int m, aoclsparse_int nnz, aoclsparse_index_base base,

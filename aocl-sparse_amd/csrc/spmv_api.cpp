@@ -237,7 +237,7 @@ aoclsparse_status mv_t(aoclsparse_operation op, const T *alpha, aoclsparse_matri
             return st;
         // A handle that keeps being multiplied without ever having been given an mv hint is promoted to the SELL-64
         // copy an optimize would have built (same summation orders, same bits; the copy costs about three products).
-        // aoclsparse_memory_usage_minimal and AOCLSPARSE_MI355_SELL=0 forbid it.
+        // aoclsparse_memory_usage_minimal and aoclsparse_mi355_set_option(sell, 0) forbid it.
         const bool promote = !plan->sell.valid && !plan->sell.tried && !plan->merge.valid && !is_complex_type(A->val_type)
                              && A->mem_policy == aoclsparse_memory_usage_unrestricted
                              && plan->mv_calls.fetch_add(1, std::memory_order_relaxed) + 1 >= SELL_PROMOTE_CALLS;
