@@ -72,31 +72,61 @@ aoclsparse_status cmv_t(aoclsparse_operation op, const cplx<R> *alpha, aoclspars
         return aoclsparse_status_success;
     }
 
-    DeviceCsr *dcsr = nullptr;
-    bool       conj = false;
+    DeviceCsr            *dcsr = nullptr;
+    SpmvPlan             *plan = nullptr;
+    const aoclsparse_int *hptr = nullptr; // host row_ptr of the operator the product runs on
+    bool                  conj = false;
     if(descr->type == aoclsparse_matrix_type_general)
     {
-        SpmvPlan *plan = nullptr;
         MI355_TRY(ensure_spmv(A, tr, dcsr, plan));
         conj = op == aoclsparse_operation_conjugate_transpose;
+        hptr = (tr ? *A->trans : A->user).ptr;
     }
     else
     {
         Derived *dv = nullptr;
         MI355_TRY(ensure_derived(A, descr->type, descr->fill_mode, descr->diag_type, tr, dv));
         dcsr = &dv->dev;
+        plan = &dv->plan;
+        hptr = dv->host.ptr;
         conj = sym    ? op == aoclsparse_operation_conjugate_transpose
                : herm ? op == aoclsparse_operation_transpose
                       : op == aoclsparse_operation_conjugate_transpose;
+    }
+    // The SELL-64 copy the real types run on (round 4: complex ?mv was a lane group per CSR row, 0.42-0.54 of the roofline on the
+    // 2000^2 Laplacian): built for a handle that carries an mv hint, at its first product; never under
+    // aoclsparse_memory_usage_minimal.  One chain per row (left to right, c_mac), conjugation at load.  No silent promotion after
+    // N products as for the real types: there the two kernels give the same bits, here the lane-group kernel sums a row as a
+    // tree, and a result that changes in the middle of a caller's loop would be worse than a slower kernel.
+    if(plan && plan->valid && !plan->sell.valid && !plan->sell.tried && A->mem_policy == aoclsparse_memory_usage_unrestricted)
+    {
+        bool hinted = false;
+        {
+            std::shared_lock<std::shared_mutex> r(A->guard);
+            for(const Hint &h : A->hints)
+                hinted |= h.act == action_mv;
+        }
+        if(hinted)
+        {
+            std::unique_lock<std::shared_mutex> w(A->guard);
+            MI355_TRY(build_sell(hptr, *dcsr, sizeof(C), *plan, true));
+        }
     }
     std::shared_lock<std::shared_mutex> r(A->guard);
     StagedArg                           ax, ay;
     const bool                          b0 = beta->re == R(0) && beta->im == R(0);
     MI355_TRY(ax.in(rt, 3, x, sizeof(C) * (size_t)dcsr->n, true));
     MI355_TRY(ay.in(rt, 4, y, sizeof(C) * (size_t)dcsr->m, !b0));
-    MI355_TRY(launch_cspmv<R>(rt.stream(), dcsr->base, conj, *alpha, dcsr->m, dcsr->nnz, dcsr->val.as<C>(),
-                              dcsr->ind.as<aoclsparse_int>(), dcsr->ptr.as<aoclsparse_int>(),
-                              static_cast<const C *>(ax.dev), *beta, static_cast<C *>(ay.dev)));
+    if(plan && plan->sell.valid)
+        MI355_TRY(launch_sellmv_complex<R>(rt.stream(), conj, *alpha, dcsr->m, plan->sell.nslices, plan->sell.slice_ptr.as<long long>(),
+                                           plan->sell.val.as<C>(), plan->sell.col.as<aoclsparse_int>(),
+                                           plan->sell.rowlen.as<aoclsparse_int>(), static_cast<const C *>(ax.dev), *beta,
+                                           static_cast<C *>(ay.dev), plan->sell.shared ? plan->sell.cptr.as<long long>() : nullptr,
+                                           plan->sell.shared ? plan->sell.lead.as<unsigned short>() : nullptr, plan->max_row_nnz));
+    else
+        MI355_TRY(launch_cspmv<R>(rt.stream(), dcsr->base, conj, *alpha, dcsr->m, dcsr->nnz, dcsr->val.as<C>(),
+                                  dcsr->ind.as<aoclsparse_int>(), dcsr->ptr.as<aoclsparse_int>(),
+                                  static_cast<const C *>(ax.dev), *beta, static_cast<C *>(ay.dev)));
     MI355_TRY(ay.out(rt));
     if(ay.staged)
         MI355_HIP_TRY(hipStreamSynchronize(rt.stream()));

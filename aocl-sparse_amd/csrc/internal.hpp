@@ -664,7 +664,7 @@ aoclsparse_status ensure_derived(aoclsparse_matrix A, aoclsparse_matrix_type typ
 aoclsparse_status ensure_trsv(aoclsparse_matrix A, bool upper, bool transposed, bool conj = false, bool need_rows = true);
 // SELL-64 copy of d (row_ptr_host = the host row pointer d mirrors); leaves plan.sell.valid false when the
 // padding would exceed the budget (aoclsparse_mi355_set_option(aoclsparse_mi355_option_sell, 0 / 1): never / always)
-aoclsparse_status build_sell(const aoclsparse_int *row_ptr_host, const DeviceCsr &d, size_t vsize, SpmvPlan &plan);
+aoclsparse_status build_sell(const aoclsparse_int *row_ptr_host, const DeviceCsr &d, size_t vsize, SpmvPlan &plan, bool complex_values = false);
 // merge-path tiling (host binary searches over row_ptr_host); built when the longest row spans >= 32 LDS tiles, or when
 // aoclsparse_mi355_set_option(aoclsparse_mi355_option_spmv_kernel, ...) asks for it
 aoclsparse_status build_merge_plan(aoclsparse_int m, aoclsparse_int nnz, aoclsparse_index_base base,
@@ -687,6 +687,11 @@ aoclsparse_status launch_sell_fill(hipStream_t s, int pack, aoclsparse_int m, in
                                    const aoclsparse_int *col, const T *val, aoclsparse_int nslices,
                                    const long long *slice_ptr, T *sval, aoclsparse_int *scol, aoclsparse_int *rowlen,
                                    const long long *cptr = nullptr, const unsigned short *lead = nullptr);
+template <typename R>
+aoclsparse_status launch_sellmv_complex(hipStream_t s, bool conj, cplx<R> alpha, aoclsparse_int m, aoclsparse_int nslices,
+                                        const long long *slice_ptr, const cplx<R> *sval, const aoclsparse_int *scol,
+                                        const aoclsparse_int *rowlen, const cplx<R> *x, cplx<R> beta, cplx<R> *y,
+                                        const long long *cptr, const unsigned short *lead, aoclsparse_int max_width);
 aoclsparse_status launch_sell_leaders(hipStream_t s, aoclsparse_int m, int base, const aoclsparse_int *row_ptr, const aoclsparse_int *col,
                                       aoclsparse_int nslices, unsigned short *lead, aoclsparse_int *nl);
 template <typename T>

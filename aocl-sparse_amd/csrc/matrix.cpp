@@ -619,7 +619,7 @@ aoclsparse_status build_spmv_plan(aoclsparse_int m, aoclsparse_int nnz, aoclspar
     return aoclsparse_status_success;
 }
 
-aoclsparse_status build_sell(const aoclsparse_int *row_ptr_host, const DeviceCsr &d, size_t vsize, SpmvPlan &plan)
+aoclsparse_status build_sell(const aoclsparse_int *row_ptr_host, const DeviceCsr &d, size_t vsize, SpmvPlan &plan, bool complex_values)
 {
     SellPlan &sp = plan.sell;
     if(sp.valid || sp.tried)
@@ -640,7 +640,8 @@ aoclsparse_status build_sell(const aoclsparse_int *row_ptr_host, const DeviceCsr
     }
     // PACK 4 (four consecutive cells of a row adjacent, width rounded up to a multiple of 4) for long rows:
     // contiguous 2 KB wavefront loads; PACK 1 otherwise (a 5-wide slice must not be padded to 8)
-    const int pack = (long long)d.nnz >= 16LL * m ? 4 : 1;
+    // (complex values: PACK 1 only -- their kernels are the scalar-chain ones)
+    const int pack = (!complex_values && (long long)d.nnz >= 16LL * m) ? 4 : 1;
     sptr[0] = 0;
     for(aoclsparse_int s = 0; s < nslices; s++)
     {
@@ -707,7 +708,11 @@ aoclsparse_status build_sell(const aoclsparse_int *row_ptr_host, const DeviceCsr
         return st;
     const long long     *cp = sp.shared ? sp.cptr.as<long long>() : nullptr;
     const unsigned short *ld = sp.shared ? sp.lead.as<unsigned short>() : nullptr;
-    if(vsize == sizeof(float))
+    if(vsize == sizeof(cdouble))
+        st = launch_sell_fill<cdouble>(rt.stream(), pack, m, d.base, d.ptr.as<aoclsparse_int>(), d.ind.as<aoclsparse_int>(),
+                                       d.val.as<cdouble>(), nslices, sp.slice_ptr.as<long long>(), sp.val.as<cdouble>(),
+                                       sp.col.as<aoclsparse_int>(), sp.rowlen.as<aoclsparse_int>(), cp, ld);
+    else if(vsize == sizeof(float))
         st = launch_sell_fill<float>(rt.stream(), pack, m, d.base, d.ptr.as<aoclsparse_int>(), d.ind.as<aoclsparse_int>(),
                                      d.val.as<float>(), nslices, sp.slice_ptr.as<long long>(), sp.val.as<float>(),
                                      sp.col.as<aoclsparse_int>(), sp.rowlen.as<aoclsparse_int>(), cp, ld);

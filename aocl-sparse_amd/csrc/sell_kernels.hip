@@ -46,11 +46,56 @@ __device__ __forceinline__ T s_finish(T r, T alpha, T beta, const T *yi)
     return r;
 }
 
+// complex handles (aoclsparse_{c,z}mv through the same SELL-64 copy, round 4): the component-wise multiply-add of
+// complex_kernels.hip (c_mac), alpha == 1 and beta == 0 skipped exactly as there; CONJ conjugates the stored value at load
+// (op = H on a general matrix, op = T on a hermitian one: complex_api.cpp)
+template <typename R>
+__device__ __forceinline__ cplx<R> s_fma(cplx<R> a, cplx<R> b, cplx<R> c)
+{
+    c.re = s_fma(a.re, b.re, c.re);
+    c.re = s_fma(-a.im, b.im, c.re);
+    c.im = s_fma(a.re, b.im, c.im);
+    c.im = s_fma(a.im, b.re, c.im);
+    return c;
+}
+template <typename R>
+__device__ __forceinline__ cplx<R> s_finish(cplx<R> r, cplx<R> alpha, cplx<R> beta, const cplx<R> *yi)
+{
+    if(!(alpha.re == R(1) && alpha.im == R(0)))
+        r = s_fma(alpha, r, cplx<R>(R(0), R(0)));
+    if(!(beta.re == R(0) && beta.im == R(0))) // beta == 0 never reads y
+        r = s_fma(beta, *yi, r);
+    return r;
+}
+template <bool CONJ, typename T>
+__device__ __forceinline__ T s_cj(T v)
+{
+    return v;
+}
+template <bool CONJ, typename R>
+__device__ __forceinline__ cplx<R> s_cj(cplx<R> v)
+{
+    if constexpr(CONJ)
+        v.im = -v.im;
+    return v;
+}
+
 template <typename T>
 __device__ __forceinline__ void s_store(T *p, T v, bool nt)
 {
     if(nt)
         __builtin_nontemporal_store(v, p);
+    else
+        *p = v;
+}
+template <typename R>
+__device__ __forceinline__ void s_store(cplx<R> *p, cplx<R> v, bool nt)
+{
+    if(nt)
+    {
+        __builtin_nontemporal_store(v.re, &p->re);
+        __builtin_nontemporal_store(v.im, &p->im);
+    }
     else
         *p = v;
 }
@@ -259,7 +304,7 @@ __device__ __forceinline__ void load_step(const T *v, const aoclsparse_int *c, i
 }
 
 // WAVES slices per workgroup (1 for small matrices so that every slice gets its own CU)
-template <typename T, int ORDER, int WAVES, int PACK, bool SHARED = false>
+template <typename T, int ORDER, int WAVES, int PACK, bool SHARED = false, bool CONJ = false>
 __global__ __launch_bounds__(64 * WAVES) void sell_mv_kernel(aoclsparse_int m, aoclsparse_int nslices,
                                                              const long long *__restrict__ slice_ptr,
                                                              const T *__restrict__ sval,
@@ -312,7 +357,7 @@ __global__ __launch_bounds__(64 * WAVES) void sell_mv_kernel(aoclsparse_int m, a
             int           cc[W];
 #pragma unroll
             for(int q = 0; q < W; q++)
-                vv[q] = v[q * 64], cc[q] = c[q * cs];
+                vv[q] = s_cj<CONJ>(v[q * 64]), cc[q] = c[q * cs];
 #pragma unroll
             for(int q = 0; q < W; q++)
                 xx[q] = x[cc[q] >= 0 ? cc[q] + dl : 0];
@@ -331,7 +376,8 @@ __global__ __launch_bounds__(64 * WAVES) void sell_mv_kernel(aoclsparse_int m, a
         }
         for(; p + 4 <= w; p += 4)
         {
-            const T   v0 = v[(p + 0) * 64], v1 = v[(p + 1) * 64], v2 = v[(p + 2) * 64], v3 = v[(p + 3) * 64];
+            const T   v0 = s_cj<CONJ>(v[(p + 0) * 64]), v1 = s_cj<CONJ>(v[(p + 1) * 64]), v2 = s_cj<CONJ>(v[(p + 2) * 64]),
+                      v3 = s_cj<CONJ>(v[(p + 3) * 64]);
             const int c0 = c[(p + 0) * cs], c1 = c[(p + 1) * cs], c2 = c[(p + 2) * cs], c3 = c[(p + 3) * cs];
             // (a padding cell, -1, is never used, but its gather must stay inside x: index 0)
             const T   x0 = x[c0 >= 0 ? c0 + dl : 0], x1 = x[c1 >= 0 ? c1 + dl : 0], x2 = x[c2 >= 0 ? c2 + dl : 0],
@@ -343,7 +389,7 @@ __global__ __launch_bounds__(64 * WAVES) void sell_mv_kernel(aoclsparse_int m, a
         }
         for(; p < w; p++)
         {
-            const T   v0 = v[p * 64];
+            const T   v0 = s_cj<CONJ>(v[p * 64]);
             const int c0 = c[p * cs];
             const T   x0 = x[c0 >= 0 ? c0 + dl : 0];
             r = c0 >= 0 ? s_fma(v0, x0, r) : r;
@@ -413,7 +459,7 @@ __global__ __launch_bounds__(64 * WAVES) void sell_mv_kernel(aoclsparse_int m, a
 // profiles/r3/sell_width_switch.txt): general kernel before the width switch 0.1845-0.186 ms, with it 0.1786-0.1793, this
 // kernel with 1 / 2 / 4 slices per workgroup 0.180-0.181 / 0.180-0.181 / 0.1773-0.1779; TWO or more slices per WAVEFRONT
 // (walked together, twice the bytes in flight per wave) 0.183-0.236 ms -- more registers, fewer waves, no gain.
-template <typename T, int WMAX, int WAVES, bool SHARED, int SPW = 1>
+template <typename T, int WMAX, int WAVES, bool SHARED, int SPW = 1, bool CONJ = false>
 __global__ __launch_bounds__(64 * WAVES) void sell_mv_short_kernel(aoclsparse_int m, aoclsparse_int nslices,
                                                                    const long long *__restrict__ slice_ptr,
                                                                    const T *__restrict__ sval,
@@ -462,7 +508,7 @@ __global__ __launch_bounds__(64 * WAVES) void sell_mv_short_kernel(aoclsparse_in
             for(int q = 0; q < WMAX; q++)
             {
                 const int qq = min(q, w[u] - 1); // wave-uniform
-                vv[u][q]     = v[qq * 64];
+                vv[u][q]     = s_cj<CONJ>(v[qq * 64]);
                 cc[u][q]     = c[qq * cs];
             }
         }
@@ -629,6 +675,77 @@ aoclsparse_status launch_sellmv(hipStream_t s, int order, int pack, T alpha, aoc
     MI355_HIP_TRY(hipGetLastError());
     return aoclsparse_status_success;
 }
+
+// aoclsparse_{c,z}mv on the SELL-64 copy (PACK 1, the scalar chain per row): the short-row kernel for large launches whose
+// widest slice has <= 8 cells, the general kernel otherwise
+template <typename R>
+aoclsparse_status launch_sellmv_complex(hipStream_t s, bool conj, cplx<R> alpha, aoclsparse_int m, aoclsparse_int nslices,
+                                        const long long *slice_ptr, const cplx<R> *sval, const aoclsparse_int *scol,
+                                        const aoclsparse_int *rowlen, const cplx<R> *x, cplx<R> beta, cplx<R> *y,
+                                        const long long *cptr, const unsigned short *lead, aoclsparse_int max_width)
+{
+    using C = cplx<R>;
+    if(m <= 0 || nslices <= 0)
+        return aoclsparse_status_success;
+    const bool nt = (size_t)m * sizeof(C) > ((size_t)32 << 20);
+    auto       go = [&](auto shared_tag, auto conj_tag) {
+        constexpr bool SH = decltype(shared_tag)::value, CJ = decltype(conj_tag)::value;
+        const long long      *cp = SH ? cptr : nullptr;
+        const unsigned short *ld = SH ? lead : nullptr;
+        if(max_width >= 1 && max_width <= 8 && nslices >= 4096)
+        {
+            constexpr int WAVES = 4;
+            const dim3    grid((unsigned)((nslices + WAVES - 1) / WAVES)), block(64 * WAVES);
+#define MI355_CSHORT(W)                                                                                                          \
+    case W:                                                                                                                      \
+        hipLaunchKernelGGL((sell_mv_short_kernel<C, W, WAVES, SH, 1, CJ>), grid, block, 0, s, m, nslices, slice_ptr, sval, scol, \
+                           alpha, x, beta, y, nt, cp, ld);                                                                       \
+        return
+            switch((int)max_width)
+            {
+                MI355_CSHORT(1);
+                MI355_CSHORT(2);
+                MI355_CSHORT(3);
+                MI355_CSHORT(4);
+                MI355_CSHORT(5);
+                MI355_CSHORT(6);
+                MI355_CSHORT(7);
+                MI355_CSHORT(8);
+            }
+#undef MI355_CSHORT
+        }
+        if(nslices < 2048)
+            hipLaunchKernelGGL((sell_mv_kernel<C, 0, 1, 1, SH, CJ>), dim3(nslices), dim3(64), 0, s, m, nslices, slice_ptr, sval, scol,
+                               rowlen, alpha, x, beta, y, nt, cp, ld);
+        else
+            hipLaunchKernelGGL((sell_mv_kernel<C, 0, 2, 1, SH, CJ>), dim3((nslices + 1) / 2), dim3(128), 0, s, m, nslices, slice_ptr,
+                               sval, scol, rowlen, alpha, x, beta, y, nt, cp, ld);
+    };
+    if(cptr)
+    {
+        if(conj)
+            go(std::true_type{}, std::true_type{});
+        else
+            go(std::true_type{}, std::false_type{});
+    }
+    else if(conj)
+        go(std::false_type{}, std::true_type{});
+    else
+        go(std::false_type{}, std::false_type{});
+    MI355_HIP_TRY(hipGetLastError());
+    return aoclsparse_status_success;
+}
+template aoclsparse_status launch_sellmv_complex<double>(hipStream_t, bool, cdouble, aoclsparse_int, aoclsparse_int, const long long *,
+                                                         const cdouble *, const aoclsparse_int *, const aoclsparse_int *,
+                                                         const cdouble *, cdouble, cdouble *, const long long *,
+                                                         const unsigned short *, aoclsparse_int);
+template aoclsparse_status launch_sellmv_complex<float>(hipStream_t, bool, cfloat, aoclsparse_int, aoclsparse_int, const long long *,
+                                                        const cfloat *, const aoclsparse_int *, const aoclsparse_int *, const cfloat *,
+                                                        cfloat, cfloat *, const long long *, const unsigned short *, aoclsparse_int);
+// (the fill kernels only move values: cfloat cells are filled as 8-byte doubles, cdouble cells need their own instantiation)
+template aoclsparse_status launch_sell_fill<cdouble>(hipStream_t, int, aoclsparse_int, int, const aoclsparse_int *, const aoclsparse_int *,
+                                                     const cdouble *, aoclsparse_int, const long long *, cdouble *, aoclsparse_int *,
+                                                     aoclsparse_int *, const long long *, const unsigned short *);
 
 aoclsparse_status launch_sell_leaders(hipStream_t s, aoclsparse_int m, int base, const aoclsparse_int *row_ptr, const aoclsparse_int *col,
                                       aoclsparse_int nslices, unsigned short *lead, aoclsparse_int *nl)

@@ -946,3 +946,91 @@ def test_sp2m_finalize_refuses_a_row_ptr_of_another_product():
     _, _, _, row, col, val = _export_csr(C)
     assert so == 0 and np.array_equal(row, pc) and np.array_equal(col, ic) and np.array_equal(val, vc)
     assert L.aoclsparse_destroy(ctypes.byref(C)) == 0
+
+
+@pytest.mark.parametrize("prec", ["z", "c"])
+def test_complex_mv_on_the_sell_copy(prec):
+    """aoclsparse_{z,c}mv on a handle with an mv hint runs on the SELL-64 copy (round 4): general (rectangular) x N / T / H,
+    symmetric / hermitian / triangular x fill x N / T / H, both bases, alpha / beta classes, within (2 len + 16) eps of the restated
+    operator; small launches (general kernel, slices of every width incl. empty rows and rows of 40 entries) and a launch of
+    > 4,096 slices with rows of <= 8 entries (short-row kernel; a stencil with shared column lists and a random matrix without);
+    beta == 0 never reads y; host and device vectors give the same bits."""
+    import scipy.sparse as sp
+    import __graft_entry__ as entry
+    dtype, eps = (np.complex128, EPS64) if prec == "z" else (np.complex64, np.finfo(np.float32).eps)
+    create = L.aoclsparse_create_zcsr if prec == "z" else L.aoclsparse_create_ccsr
+    mv = L.aoclsparse_zmv if prec == "z" else L.aoclsparse_cmv
+    rng = np.random.default_rng(211)
+    alpha, beta = np.array([0.7 - 0.4j], dtype), np.array([-0.3 + 0.2j], dtype)
+    zero = np.zeros(1, dtype)
+    ops = {"n": P.OP_NONE, "t": P.OP_TRANSPOSE, "h": P.OP_CONJ_TRANSPOSE}
+
+    def cplx_csr(seed, m, n, lens_of):
+        r = np.random.default_rng(seed)
+        lens = np.minimum(lens_of(r, m), n)
+        rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        ci = np.concatenate([np.sort(r.choice(n, int(k), replace=False)) for k in lens] + [np.zeros(0, np.int64)]).astype(np.int32)
+        v = (r.uniform(-1, 1, len(ci)) + 1j * r.uniform(-1, 1, len(ci))).astype(dtype)
+        return rp, ci, v
+
+    # small: every descriptor (the oracle's dense restatement)
+    for base in (0, 1):
+        for (m, n, cases) in ((700, 640, [("general", "lower", "non_unit")]),
+                              (600, 600, [(t, f, "non_unit") for t in ("symmetric", "hermitian", "triangular") for f in ("lower", "upper")])):
+            rp, ci, v = cplx_csr(300 + base, m, n, lambda r, mm: np.where(r.random(mm) < 0.1, 40, r.integers(0, 12, mm)))
+            if m == n:  # a full, real diagonal (hermitian)
+                A0 = sp.csr_matrix((v, ci, rp), shape=(m, n)).tolil()
+                A0.setdiag(3.0)
+                A0 = A0.tocsr(); A0.sort_indices()
+                rp, ci, v = A0.indptr.astype(np.int32), A0.indices.astype(np.int32), A0.data.astype(dtype)
+            rpb, cib = rp + base, ci + base
+            h = ctypes.c_void_p()
+            assert create(ctypes.byref(h), base, m, n, len(v), P._ptr(rpb), P._ptr(cib), P._ptr(v)) == 0
+            lens = np.diff(rp)
+            for mtype, fill, diag in cases:
+                d = P.Descr(base=base, mtype={"general": 0, "symmetric": 1, "hermitian": 2, "triangular": 3}[mtype],
+                            fill=P.FILL_LOWER if fill == "lower" else P.FILL_UPPER)
+                for opn, op in ops.items():
+                    assert L.aoclsparse_set_mv_hint(h, op, d.h, 10) == 0
+                    nx, ny = (n, m) if opn == "n" or mtype != "general" else (m, n)
+                    x = (rng.uniform(-1, 1, nx) + 1j * rng.uniform(-1, 1, nx)).astype(dtype)
+                    y0 = (rng.uniform(-1, 1, ny) + 1j * rng.uniform(-1, 1, ny)).astype(dtype)
+                    yr, scale = oracle.zmv(opn, mtype, fill, diag, base, alpha[0], m, n, rpb, cib, v, x, beta[0], y0)
+                    y = y0.copy()
+                    assert mv(op, P._ptr(alpha), h, d.h, P._ptr(x), P._ptr(beta), P._ptr(y)) == 0, (mtype, opn)
+                    bound = (2 * max(lens.max(), 1) * (2 if mtype in ("symmetric", "hermitian") else 1) + 16) * eps * (scale + 1e-30)
+                    assert np.all(np.abs(y - yr) <= bound), (prec, base, mtype, fill, opn, float(np.max(np.abs(y - yr) / bound)))
+                    yd = dev(y0)
+                    assert mv(op, P._ptr(alpha), h, d.h, P._ptr(dev(x)), P._ptr(beta), P._ptr(yd)) == 0
+                    torch.cuda.synchronize()
+                    assert np.array_equal(yd.cpu().numpy(), y)
+            if m != n:
+                assert P.Matrix.from_handle  # (binding present)
+            ynan = np.full(m, np.nan + 1j * np.nan, dtype)
+            xx = rng.uniform(-1, 1, n).astype(dtype)
+            assert mv(P.OP_NONE, P._ptr(alpha), h, P.Descr(base=base).h, P._ptr(xx), P._ptr(zero), P._ptr(ynan)) == 0
+            assert not np.any(np.isnan(ynan))
+            L.aoclsparse_destroy(ctypes.byref(h))
+    # large launches: the short-row kernel (> 4,096 slices, widest slice <= 8), shared lists (stencil) and own lists (random)
+    ml, rpl, cil, vl = entry.laplace5(560)
+    rpr, cir, vr = cplx_csr(77, 300037, 300037, lambda r, mm: np.where(r.random(mm) < 0.85, 7, r.integers(0, 8, mm)))
+    vl = (vl * (1.0 + 0.5j) + 0.25j * np.cos(np.arange(len(vl)))).astype(dtype)
+    for name, m, rp, ci, v in (("stencil", ml, rpl, cil, vl), ("random", 300037, rpr, cir, vr)):
+        h = ctypes.c_void_p()
+        assert create(ctypes.byref(h), 0, m, m, len(v), P._ptr(rp), P._ptr(ci), P._ptr(v)) == 0
+        d = P.Descr()
+        A64 = sp.csr_matrix((v.astype(np.complex128), ci, rp), shape=(m, m))
+        Aabs = abs(A64)
+        x = (rng.uniform(-1, 1, m) + 1j * rng.uniform(-1, 1, m)).astype(dtype)
+        y0 = (rng.uniform(-1, 1, m) + 1j * rng.uniform(-1, 1, m)).astype(dtype)
+        for opn, op in ops.items():
+            assert L.aoclsparse_set_mv_hint(h, op, d.h, 10) == 0
+            Mo = {"n": A64, "t": A64.T, "h": A64.conj().T}[opn]
+            Mabs = Aabs if opn == "n" else Aabs.T
+            x64, y64 = x.astype(np.complex128), y0.astype(np.complex128)
+            yr = alpha[0] * (Mo @ x64) + beta[0] * y64
+            scale = abs(alpha[0]) * (Mabs @ np.abs(x64)) + abs(beta[0]) * np.abs(y64)
+            y = y0.copy()
+            assert mv(op, P._ptr(alpha), h, d.h, P._ptr(x), P._ptr(beta), P._ptr(y)) == 0, (name, opn)
+            assert np.all(np.abs(y - yr) <= (2 * 8 + 16) * eps * (scale + 1e-30)), (prec, name, opn)
+        L.aoclsparse_destroy(ctypes.byref(h))
