@@ -257,6 +257,66 @@ __global__ __launch_bounds__(256) void csrmm_row_wave_rc_kernel(int base, T alph
     __builtin_nontemporal_store(o, reinterpret_cast<nt2 *>(cp));
 }
 
+// float, C read, n a multiple of 4 and >= 256 (round 4): the same kernel with FOUR columns per lane -- a float load instruction
+// moves half the bytes of a double one, so the two-column form spends twice the instructions (and reads A's row twice as often)
+// per byte of B and C.  Same chain per element (same bits as the two-column form).  1000^2 Laplacian, 256 columns: 0.740 -> 0.580 ms
+// (0.53 -> 0.67 of the roofline, the double product's fraction; profiles/r4/float_headline.txt).
+__global__ __launch_bounds__(256) void csrmm_row_wave_rc4_kernel(int base, float alpha, aoclsparse_int m, const float *__restrict__ val,
+                                                                 const aoclsparse_int *__restrict__ col,
+                                                                 const aoclsparse_int *__restrict__ row_ptr,
+                                                                 const float *__restrict__ B, aoclsparse_int n, aoclsparse_int ldb,
+                                                                 float beta, float *__restrict__ C, aoclsparse_int ldc, int xcd_chunk)
+{
+    const int w  = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int i  = bx * 4 + w;
+    const int j  = 4 * (int)(threadIdx.x & 63) + 256 * (int)blockIdx.y;
+    if(i >= m || j >= n)
+        return;
+    col -= base, val -= base;
+    float4      *cp = reinterpret_cast<float4 *>(C + (size_t)i * ldc + j);
+    const float4 c0 = *cp; // no dependency on A: in flight while the row's pointers and entries arrive
+    const int    s = row_ptr[i], e = row_ptr[i + 1];
+    float        a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const float *Bj = B + j - (ptrdiff_t)base * ldb;
+    auto         batch = [&](int p, auto wtag) {
+        constexpr int W = decltype(wtag)::value;
+        float         v[W];
+        float4        b[W];
+#pragma unroll
+        for(int k = 0; k < W; k++)
+            v[k] = val[p + k];
+#pragma unroll
+        for(int k = 0; k < W; k++)
+            b[k] = *reinterpret_cast<const float4 *>(Bj + (ptrdiff_t)col[p + k] * ldb);
+#pragma unroll
+        for(int k = 0; k < W; k++)
+        {
+            a0 = mm_fma(v[k], b[k].x, a0), a1 = mm_fma(v[k], b[k].y, a1);
+            a2 = mm_fma(v[k], b[k].z, a2), a3 = mm_fma(v[k], b[k].w, a3);
+        }
+    };
+    int p = s;
+    for(; p + 8 <= e; p += 8)
+        batch(p, std::integral_constant<int, 8>{});
+    switch(e - p) // wave-uniform
+    {
+    case 1: batch(p, std::integral_constant<int, 1>{}); break;
+    case 2: batch(p, std::integral_constant<int, 2>{}); break;
+    case 3: batch(p, std::integral_constant<int, 3>{}); break;
+    case 4: batch(p, std::integral_constant<int, 4>{}); break;
+    case 5: batch(p, std::integral_constant<int, 5>{}); break;
+    case 6: batch(p, std::integral_constant<int, 6>{}); break;
+    case 7: batch(p, std::integral_constant<int, 7>{}); break;
+    default: break;
+    }
+    typedef float nt4 __attribute__((ext_vector_type(4)));
+    nt4           o;
+    o.x = mm_fma(beta, c0.x, alpha * a0), o.y = mm_fma(beta, c0.y, alpha * a1);
+    o.z = mm_fma(beta, c0.z, alpha * a2), o.w = mm_fma(beta, c0.w, alpha * a3);
+    __builtin_nontemporal_store(o, reinterpret_cast<nt4 *>(cp));
+}
+
 // row-major, n >= 128, ROW RUNS (stencil-like matrices, csrmm_api.cpp: detect_row_runs): a wavefront walks R consecutive rows
 // for one 128-column chunk and keeps the previous row's B rows in registers.  A stencil's rows repeat the previous row's
 // column list shifted by one (i-1, i, i+1 -> i, i+1, i+2), so entry k of the new row needs exactly the B row that entry
@@ -1444,7 +1504,17 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
         else if(vec && n >= 128)
         {
             const int gx = grid_x((m + 3) / 4, chunk);
-            if(readc)
+            bool      wide = false;
+            if constexpr(std::is_same<T, float>::value)
+                wide = readc && n >= 256 && n % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && reinterpret_cast<uintptr_t>(B) % 16 == 0
+                       && reinterpret_cast<uintptr_t>(C) % 16 == 0;
+            if(wide)
+            {
+                if constexpr(std::is_same<T, float>::value)
+                    hipLaunchKernelGGL(csrmm_row_wave_rc4_kernel, dim3(gx, (n + 255) / 256), dim3(256), 0, s, base, alpha, m, val, col,
+                                       row_ptr, B, n, ldb, beta, C, ldc, chunk);
+            }
+            else if(readc)
                 hipLaunchKernelGGL((csrmm_row_wave_rc_kernel<T>), dim3(gx, (n + 127) / 128), dim3(256), 0, s, base, alpha,
                                    m, val, col, row_ptr, B, n, ldb, beta, C, ldc, chunk);
             else

@@ -1034,3 +1034,37 @@ def test_complex_mv_on_the_sell_copy(prec):
             assert mv(op, P._ptr(alpha), h, d.h, P._ptr(x), P._ptr(beta), P._ptr(y)) == 0, (name, opn)
             assert np.all(np.abs(y - yr) <= (2 * 8 + 16) * eps * (scale + 1e-30)), (prec, name, opn)
         L.aoclsparse_destroy(ctypes.byref(h))
+
+
+def test_float_csrmm_four_columns_per_lane_same_bits_as_two():
+    """scsrmm row-major, C read, n >= 256 and a multiple of 4 (csrmm_row_wave_rc4_kernel, round 4): every 128-column half of the
+    result equals, bit for bit, the product of the same 128 columns through the two-column kernel (n = 128 takes it); padded
+    leading dimensions, alpha / beta classes, rows of 0 .. 40 entries, and within 2 (len + 2) eps of the double product."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(17)
+    m = k = 20000
+    rp, ci, v = random_csr(19, m, k, lambda r, i: 0 if i % 50 == 7 else (40 if i % 33 == 0 else r.integers(1, 9)))
+    vf = v.astype(np.float32)
+    A = P.Matrix(0, m, k, rp, ci, vf)
+    d = P.Descr()
+    A64 = sp.csr_matrix((vf.astype(np.float64), ci, rp), shape=(m, k))
+    lens = np.diff(rp)
+    for n, pad, alpha, beta in ((256, 0, 1.0, 0.0), (260, 4, -0.5, 1.25), (512, 8, 2.0, -1.0)):
+        ldb = ldc = n + pad
+        B = rng.uniform(-1, 1, (k, ldb)).astype(np.float32)
+        C0 = rng.uniform(-1, 1, (m, ldc)).astype(np.float32)
+        Cw = dev(C0.ravel())
+        assert P.scsrmm(P.OP_NONE, alpha, A, d, P.ORDER_ROW, dev(B.ravel()), n, ldb, beta, Cw, ldc) == 0
+        torch.cuda.synchronize()
+        W = Cw.cpu().numpy().reshape(m, ldc)
+        assert np.array_equal(W[:, n:], C0[:, n:])  # the padding columns of C are untouched
+        for j0 in range(0, n - 127, 128):
+            Bs, Cs0 = np.ascontiguousarray(B[:, j0:j0 + 128]), np.ascontiguousarray(C0[:, j0:j0 + 128])
+            Cs = dev(Cs0.ravel())
+            assert P.scsrmm(P.OP_NONE, alpha, A, d, P.ORDER_ROW, dev(Bs.ravel()), 128, 128, beta, Cs, 128) == 0
+            torch.cuda.synchronize()
+            assert np.array_equal(Cs.cpu().numpy().reshape(m, 128), W[:, j0:j0 + 128]), (n, j0)
+        ref = alpha * (A64 @ B[:, :n].astype(np.float64)) + beta * C0[:, :n].astype(np.float64)
+        scale = abs(alpha) * (abs(A64) @ np.abs(B[:, :n]).astype(np.float64)) + abs(beta) * np.abs(C0[:, :n])
+        bound = (2 * (lens.max() + 2)) * np.finfo(np.float32).eps * (scale + 1e-30)
+        assert np.all(np.abs(W[:, :n] - ref) <= bound)
