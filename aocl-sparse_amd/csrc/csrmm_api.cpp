@@ -192,7 +192,7 @@ aoclsparse_status detect_row_runs(const HostCsr &h, SpmvPlan &plan)
 // blocks (the MFMA tile), kept when fill = nnz / (256 * blocks) >= 0.5, the ELL padding (width * block rows over blocks) stays
 // under 1.35 and every row is sorted and duplicate-free (the tile walks k upwards: only then is the sum the CSR-order chain).
 } // namespace
-aoclsparse_status mi355::build_bell(const HostCsr &h, SpmvPlan &plan, aoclsparse_matrix_data_type vt)
+aoclsparse_status mi355::build_bell(const HostCsr &h, const DeviceCsr &d, SpmvPlan &plan, aoclsparse_matrix_data_type vt)
 {
     BellPlan &bp = plan.bell;
     if(bp.tried)
@@ -261,19 +261,19 @@ aoclsparse_status mi355::build_bell(const HostCsr &h, SpmvPlan &plan, aoclsparse
     const long long slots = (long long)nbr * width;
     if(fill < 0.5 || (double)slots > 1.35 * (double)nblk || slots * 256 > (1LL << 30)) // (the copy stays under 8 GiB of values)
         return aoclsparse_status_success;
-    // pass 2: values in the A-operand order, block columns ascending, empty slots (-1) last
-    std::vector<double>         bv;
+    // pass 2: the block columns of every block row, ascending, empty slots (-1) last; the VALUES are scattered on the device from
+    // the CSR arrays already in HBM (bell_fill_kernel) -- no host copy of the blocked values, nothing but bcol crosses PCIe
+    if(!d.valid || d.m != h.m)
+        return aoclsparse_status_success;
     std::vector<aoclsparse_int> bcol;
     try
     {
-        bv.assign((size_t)slots * 256, 0.0);
         bcol.assign((size_t)slots, -1);
     }
     catch(const std::bad_alloc &)
     {
         return aoclsparse_status_success; // the blocked copy is optional: without it the CSR kernels run
     }
-    const double *hv = static_cast<const double *>(h.val);
     parallel_for(nbr, 64, [&](long long b0, long long b1) {
         std::vector<aoclsparse_int> bc;
         try
@@ -291,22 +291,7 @@ aoclsparse_status mi355::build_bell(const HostCsr &h, SpmvPlan &plan, aoclsparse
                 }
                 std::sort(bc.begin(), bc.end());
                 bc.erase(std::unique(bc.begin(), bc.end()), bc.end());
-                aoclsparse_int *slot = bcol.data() + (size_t)b * width;
-                std::copy(bc.begin(), bc.end(), slot);
-                double *vb = bv.data() + (size_t)b * width * 256;
-                for(long long i = ra; i < rb; i++)
-                {
-                    size_t s = 0; // the row's entries ascend: so do the slots they fall into
-                    for(aoclsparse_int p = h.ptr[i] - h.base; p < h.ptr[i + 1] - h.base; p++)
-                    {
-                        const aoclsparse_int c = h.ind[p] - h.base, cb = c / BS, kk = c % BS;
-                        while(slot[s] != cb)
-                            s++;
-                        // A-operand order: fragment t = kk / 4, lane = 16 * (kk % 4) + row; fragments 2p and 2p+1 of a lane adjacent
-                        const size_t t = (size_t)(kk / 4), ln = 16 * (size_t)(kk % 4) + (size_t)(i - ra);
-                        vb[s * 256 + 128 * (t / 2) + 2 * ln + (t & 1)] = hv[p];
-                    }
-                }
+                std::copy(bc.begin(), bc.end(), bcol.data() + (size_t)b * width);
             }
         }
         catch(const std::bad_alloc &)
@@ -317,10 +302,13 @@ aoclsparse_status mi355::build_bell(const HostCsr &h, SpmvPlan &plan, aoclsparse
     if(nomem.load())
         return aoclsparse_status_success; // (optional format)
     hipStream_t       st = Runtime::get().stream();
-    aoclsparse_status rc = bp.val.upload(bv.data(), sizeof(double) * bv.size(), st);
+    aoclsparse_status rc = bp.bcol.upload(bcol.data(), sizeof(aoclsparse_int) * bcol.size(), st);
     if(rc == aoclsparse_status_success)
-        rc = bp.bcol.upload(bcol.data(), sizeof(aoclsparse_int) * bcol.size(), st);
-    if(rc != aoclsparse_status_success || hipStreamSynchronize(st) != hipSuccess) // (the host buffers above go away)
+        rc = bp.val.alloc(sizeof(double) * (size_t)slots * 256);
+    if(rc == aoclsparse_status_success)
+        rc = launch_bell_fill(st, h.m, d.base, d.ptr.as<aoclsparse_int>(), d.ind.as<aoclsparse_int>(), d.val.as<double>(), nbr, width,
+                              bp.bcol.as<aoclsparse_int>(), bp.val.as<double>());
+    if(rc != aoclsparse_status_success || hipStreamSynchronize(st) != hipSuccess) // (the host buffer above goes away)
     {
         // no room in HBM for a second copy of the matrix: not an error, the CSR kernels serve the handle
         (void)hipGetLastError();
@@ -651,7 +639,7 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
     if(p && !windowed && !p->bell.tried && A->mem_policy == aoclsparse_memory_usage_unrestricted)
     {
         std::unique_lock<std::shared_mutex> w(A->guard);
-        st = build_bell(tr ? *A->trans : A->user, *p, vt);
+        st = build_bell(tr ? *A->trans : A->user, *d, *p, vt);
         if(st != aoclsparse_status_success)
             return st;
     }
@@ -773,7 +761,7 @@ aoclsparse_status mi355::prepare_mm_plans(aoclsparse_matrix A)
         return st;
     std::unique_lock<std::shared_mutex> w(A->guard);
     const size_t                        elem = val_size(A->val_type);
-    if(A->mem_policy == aoclsparse_memory_usage_unrestricted && (st = build_bell(A->user, *p, A->val_type)) != aoclsparse_status_success)
+    if(A->mem_policy == aoclsparse_memory_usage_unrestricted && (st = build_bell(A->user, *d, *p, A->val_type)) != aoclsparse_status_success)
         return st;
     if(!p->bell.valid && (st = build_mm_groups(A->user, *p)) != aoclsparse_status_success)
         return st;

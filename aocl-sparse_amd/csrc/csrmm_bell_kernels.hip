@@ -452,4 +452,42 @@ aoclsparse_status launch_csrmm_bell(hipStream_t s, double alpha, aoclsparse_int 
     return aoclsparse_status_success;
 }
 
+// Values of the blocked-ELL copy, scattered from the CSR arrays in HBM (round 4: the copy used to be assembled on the host -- 0.9 GB
+// zeroed, filled and sent for the 1 M-row block-dense stand-in, 380 ms of aoclsparse_optimize).  A thread per row; the row's entries
+// ascend, so do the slots of its block row they fall into (bcol: block columns ascending, -1 = empty slot).  `out` is zeroed by
+// the caller.  Cell (i, k) of a block: fragment t = k / 4, lane = 16 * (k % 4) + i, stored at 128 * (t / 2) + 2 * lane + t % 2.
+__global__ __launch_bounds__(256) void bell_fill_kernel(aoclsparse_int m, int base, const aoclsparse_int *__restrict__ ptr,
+                                                        const aoclsparse_int *__restrict__ ind, const double *__restrict__ val,
+                                                        aoclsparse_int width, const aoclsparse_int *__restrict__ bcol,
+                                                        double *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if(i >= m)
+        return;
+    const long long       b    = i / BELL_BS;
+    const int             r    = (int)(i % BELL_BS);
+    const aoclsparse_int *slot = bcol + b * width;
+    double               *vb   = out + b * width * 256;
+    int                   s    = 0;
+    for(aoclsparse_int p = ptr[i] - base; p < ptr[i + 1] - base; p++)
+    {
+        const int c = ind[p] - base, cb = c / BELL_BS, kk = c % BELL_BS;
+        while(s < width - 1 && slot[s] != cb)
+            s++;
+        const int t = kk / 4, ln = 16 * (kk % 4) + r;
+        vb[(long long)s * 256 + 128 * (t / 2) + 2 * ln + (t & 1)] = val[p];
+    }
+}
+
+aoclsparse_status launch_bell_fill(hipStream_t s, aoclsparse_int m, int base, const aoclsparse_int *ptr, const aoclsparse_int *ind,
+                                   const double *val, aoclsparse_int nbr, aoclsparse_int width, const aoclsparse_int *bcol, double *out)
+{
+    MI355_HIP_TRY(hipMemsetAsync(out, 0, sizeof(double) * (size_t)nbr * (size_t)width * 256, s));
+    if(m > 0)
+        hipLaunchKernelGGL(bell_fill_kernel, dim3((unsigned)(((long long)m + 255) / 256)), dim3(256), 0, s, m, base, ptr, ind, val, width,
+                           bcol, out);
+    MI355_HIP_TRY(hipGetLastError());
+    return aoclsparse_status_success;
+}
+
 } // namespace mi355

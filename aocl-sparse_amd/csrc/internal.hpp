@@ -896,7 +896,9 @@ aoclsparse_status launch_csrmm_colpair(hipStream_t s, int base, T alpha, aoclspa
 // all csrmm plans of the untransposed matrix, built from the host arrays now (csrmm_api.cpp)
 aoclsparse_status prepare_mm_plans(aoclsparse_matrix A);
 // row-major, block-dense matrices: blocked-ELL copy + v_mfma_f64_16x16x4_f64 (csrmm_bell_kernels.hip)
-aoclsparse_status build_bell(const HostCsr &h, SpmvPlan &plan, aoclsparse_matrix_data_type vt);
+aoclsparse_status build_bell(const HostCsr &h, const DeviceCsr &d, SpmvPlan &plan, aoclsparse_matrix_data_type vt);
+aoclsparse_status launch_bell_fill(hipStream_t s, aoclsparse_int m, int base, const aoclsparse_int *ptr, const aoclsparse_int *ind,
+                                   const double *val, aoclsparse_int nbr, aoclsparse_int width, const aoclsparse_int *bcol, double *out);
 aoclsparse_status launch_csrmm_bell(hipStream_t s, double alpha, aoclsparse_int m, aoclsparse_int k, const BellPlan &bell,
                                     const double *B, aoclsparse_int n, aoclsparse_int ldb, double beta, double *C,
                                     aoclsparse_int ldc, bool column_major = false);

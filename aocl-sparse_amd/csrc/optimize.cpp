@@ -102,7 +102,7 @@ extern "C" aoclsparse_status aoclsparse_optimize(aoclsparse_matrix A)
                     // analysis.cpp:146-160, convert.cpp:36-147): a blocked-ELL copy for the MFMA kernel when the 16 x 16
                     // tiles are at least half full
                     std::unique_lock<std::shared_mutex> w(A->guard);
-                    st = build_bell(A->user, *p, A->val_type);
+                    st = build_bell(A->user, *d, *p, A->val_type);
                 }
             }
             if(st != aoclsparse_status_success)
