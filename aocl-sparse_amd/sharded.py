@@ -547,3 +547,77 @@ def bench_sharded_spmv(pkg, torch, dist, device, rank, world, csr, iters=20, war
             "roofline_shard": {"bound": "hbm", "achieved": round(gbs, 2), "peak": peak_gbs, "unit": "GB/s",
                                "frac": round(gbs / peak_gbs, 4), "traffic": None,
                                "algorithmic_bytes_per_launch": loc_bytes} if hbm_sized else None}, sh, y_first, x0
+
+
+class ShardedSp2m:
+    """C = A * B with A split by rows over the ranks and B on every rank.  A row of C depends on
+    its row of A and on B only, so the slices are independent products (aoclsparse_sp2m on a handle over the rank's rows of A):
+    no exchange on the data path.  What the ranks do share is the size of their slices -- one all-gather of `world` integers --
+    so that each knows where its rows start in the global row_ptr of C."""
+
+    def __init__(self, pkg, torch, dist, device, rank, world, m, build_rows, b_csr):
+        """build_rows(r0, r1) -> (ml, k, row_ptr, col_ind, val): the rank's rows of the m x k matrix A (no rank holds all of A);
+        b_csr = (k, n, row_ptr, col_ind, val): the whole of B, held by every rank."""
+        self.pkg, self.torch, self.dist, self.device, self.rank, self.world = pkg, torch, dist, device, rank, world
+        self.m = int(m)
+        self.r0, self.r1 = row_shard(self.m, world, rank)
+        ml, k, rpl, cil, vl = build_rows(self.r0, self.r1)
+        kb, self.n, rpb, cib, vb = b_csr
+        assert ml == self.r1 - self.r0 and k == kb
+        self.local = (ml, k, rpl, cil, vl)
+        self.A = pkg.Matrix(int(rpl[0]), ml, k, rpl, cil, vl)
+        self.B = pkg.Matrix(int(rpb[0]), kb, self.n, rpb, cib, vb)
+        assert self.A.status == 0 and self.B.status == 0
+        self.dA, self.dB = pkg.Descr(base=int(rpl[0])), pkg.Descr(base=int(rpb[0]))
+        self.nnz_a_loc = int(len(vl))
+
+    def product(self):
+        """-> (status, handle of this rank's rows of C); the caller destroys the handle"""
+        import ctypes
+
+        C = ctypes.c_void_p()
+        st = self.pkg.lib().aoclsparse_sp2m(self.pkg.OP_NONE, self.dA.h, self.A.h, self.pkg.OP_NONE, self.dB.h, self.B.h,
+                                            self.pkg.STAGE_FULL, ctypes.byref(C))
+        return st, C
+
+    def slice_offsets(self, nnz_loc):
+        """all-gather of the slices' sizes -> (first entry of this rank's rows in the global C, total entries of C)"""
+        if self.world == 1:
+            return 0, int(nnz_loc)
+        t = self.torch.tensor([int(nnz_loc)], dtype=self.torch.int64, device=self.device if _backend(self.dist) == "nccl" else "cpu")
+        out = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        sizes = [int(o.item()) for o in out]
+        return sum(sizes[: self.rank]), sum(sizes)
+
+
+def bench_sharded_sp2m(pkg, torch, dist, device, rank, world, m, build_rows, b_csr, reps=5, warm=1):
+    """`reps` products C_r = A_r * B on every rank (wall time of the call, host arrays out, as the single-GPU leg); returns the
+    max over ranks of the median, the job's entries of C per second, and rank 0's slice for the caller's parity check."""
+    import ctypes
+
+    sh = ShardedSp2m(pkg, torch, dist, device, rank, world, m, build_rows, b_csr)
+    L = pkg.lib()
+    ts, keep = [], None
+    barrier(dist, torch)
+    for it in range(warm + reps):
+        t = time.perf_counter()
+        st, C = sh.product()
+        dt = (time.perf_counter() - t) * 1e3
+        assert st == 0, pkg.STATUS.get(st, st)
+        if it >= warm:
+            ts.append(dt)
+        if it + 1 < warm + reps:
+            L.aoclsparse_destroy(ctypes.byref(C))
+        else:
+            keep = C
+    e = pkg.Matrix.from_handle(keep).export()
+    nnz_loc = int(e["nnz"])
+    first, total = sh.slice_offsets(nnz_loc)
+    tn = reduce_scalar(float(np.median(ts)), "max", dist, device)
+    barrier(dist, torch)
+    res = {"what": "C = A * B, A split by rows over %d rank(s), B on every rank; independent slices, one all-gather of %d sizes"
+                   % (world, world),
+           "world": world, "m": sh.m, "n": sh.n, "rows_per_rank": sh.r1 - sh.r0, "nnz_c": total, "first_entry_of_this_rank": first,
+           "product_ms_median_max_over_ranks": round(tn, 3), "entries_of_c_per_second_job": round(total / tn * 1e3, 1) if tn > 0 else 0.0}
+    return res, sh, e

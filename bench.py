@@ -39,6 +39,7 @@ to the file named by --record (default bench_legs.json next to this file), not t
                                      arrays in and out, against the CPU port of the reference's two-stage Gustavson
                 spmv_row_sharded     SURVEY 8e "next": x <- A x iterated with A split by rows over the N ranks, one all-gather of
                                      the y slices per iteration (RCCL with nccl)
+                sp2m_row_sharded     SURVEY 8e: C = A * A with A's rows split over the N ranks (independent slices, no data-path exchange)
                 inlib_multi          configs[3] from ONE process: aoclsparse_mi355_dcsrmm_multi_slabs over every visible GPU
                                      (tools/multi_check.py as a child process)
               (csrmm also holds the pinned-kid cases; l100.c_caller is the per-call cost seen by a C program, tools/l100_probe.hip;
@@ -294,6 +295,10 @@ def leg_numbers(full):
                                          "efficiency": sh.get("efficiency"), "a_broadcast_ms": sh.get("a_broadcast_ms"),
                                          "c_allgather_ms": sh.get("c_allgather_ms"),
                                          "parity": (sh.get("parity") or {}).get("bit_exact")}
+    s2 = full.get("sp2m_row_sharded") or {}
+    if "product_ms_median_max_over_ranks" in s2:
+        n["sp2m_row_sharded"] = {"world": s2["world"], "product_ms": s2["product_ms_median_max_over_ranks"], "nnz_c": s2["nnz_c"],
+                                 "parity": (s2.get("parity") or {}).get("bit_exact")}
     sp = full.get("spmv_row_sharded") or {}
     if "product_ms_median_max_over_ranks" in sp:
         n["spmv_row_sharded"] = {"world": sp["world"], "m": sp["m"], "product_ms": sp["product_ms_median_max_over_ranks"],
@@ -303,8 +308,8 @@ def leg_numbers(full):
     im = legs.get("inlib_multi") or {}
     if im:
         n["inlib_multi"] = {k: im.get(k) for k in ("devices", "same_device", "slabs_bit_exact", "efficiency_wall") if k in im}
-    errors = [k for k, v in list(legs.items()) + [(k, full.get(k)) for k in ("l100", "spmv_row_sharded", "csrmm_sharded_col",
-                                                                             "csrmm_sharded_row", "csrmm_sharded_bell")]
+    errors = [k for k, v in list(legs.items()) + [(k, full.get(k)) for k in ("l100", "spmv_row_sharded", "sp2m_row_sharded",
+                                                                             "csrmm_sharded_col", "csrmm_sharded_row", "csrmm_sharded_bell")]
               if isinstance(v, dict) and "error" in v]
     if errors:
         n["errors"] = errors
@@ -346,7 +351,12 @@ def compact_record(full, record_path=None):
         for k in ("mix_frac", "mix_latency_frac", "inlib_multi"):
             c["legs"].pop(k, None)
         line = json.dumps(c, allow_nan=False, separators=(",", ":"))
-    assert len(line) <= COMPACT_LIMIT, "compact record is %d bytes" % len(line)
+    if len(line) > COMPACT_LIMIT:  # the sharded objects next, then every leg: the headline, roofline and cpu_baseline always fit
+        c["legs"] = {k: v for k, v in c["legs"].items() if not isinstance(v, dict)}
+        line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    if len(line) > COMPACT_LIMIT:
+        c["legs"] = {"dropped": "see full_report"}
+        line = json.dumps(c, allow_nan=False, separators=(",", ":"))
     return line
 
 
@@ -403,7 +413,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: CPU tensors on the wire, ranks may share one GPU (control-flow tests on a 1-GPU box)")
     ap.add_argument("--legs", default="all",
-                    help="comma list of l100,dcsrmv_csr_adaptive,mix,csrmm,csrmm_sharded,spmv_row_sharded,trsv,sp2m,cpu,inlib_multi (or all / none)")
+                    help="comma list of l100,dcsrmv_csr_adaptive,mix,csrmm,csrmm_sharded,spmv_row_sharded,sp2m_row_sharded,trsv,sp2m,cpu,inlib_multi (or all / none)")
     ap.add_argument("--mm-grid", type=int, default=1000, help="csrmm: A = Laplacian on grid^2")
     ap.add_argument("--mm-cols", type=int, default=256)
     ap.add_argument("--shard-grid", type=int, default=0,
@@ -412,6 +422,7 @@ def main():
     ap.add_argument("--bell-nodes", type=int, default=40,
                     help="sharded csrmm on the block-dense stand-in (blocked-ELL MFMA path): nodes per edge of its node grid, 16 "
                          "unknowns each (40 -> 1,024,000 rows: configs[3]'s 1M x 1M); 0 skips it")
+    ap.add_argument("--sp2m-grid", type=int, default=1000, help="sp2m_row_sharded: A = 5-pt Laplacian on grid^2 (rows split over the ranks)")
     ap.add_argument("--shard-own-rows", action="store_true",
                     help="row-sharded SpMV leg: every rank builds its own rows even with an explicit --shard-grid (the default for "
                          "N > 1 without --shard-grid; lets a small test take the path the multi-GPU run takes)")
@@ -428,7 +439,8 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # not under torch.distributed.run: start the ranks ourselves (as a child; nothing here has touched the GPU)
         sys.exit(self_launch(sys.argv[1:], args.gpus))
-    all_legs = ["l100", "dcsrmv_csr_adaptive", "mix", "csrmm", "csrmm_sharded", "spmv_row_sharded", "trsv", "sp2m", "cpu", "inlib_multi"]
+    all_legs = ["l100", "dcsrmv_csr_adaptive", "mix", "csrmm", "csrmm_sharded", "spmv_row_sharded", "sp2m_row_sharded", "trsv", "sp2m", "cpu",
+                "inlib_multi"]
     legs = set(all_legs) if args.legs == "all" else set(x for x in args.legs.split(",") if x and x != "none")
     assert legs <= set(all_legs), "unknown leg in --legs: %s" % sorted(legs - set(all_legs))
 
@@ -690,6 +702,23 @@ def main():
         return res
 
     run_leg("spmv_row_sharded", leg_spmv_row_sharded, collective=True)
+
+    # ---- SURVEY 8e "sp2m: later": C = A * A with A's rows split over the ranks, A itself (as B) on every rank ----
+    def leg_sp2m_row_sharded():
+        sg = args.sp2m_grid
+        ms_, rp_, ci_, v_ = entry.laplace5(sg)  # B (every rank holds it) -- and the source of the parity check
+        res, sh, e = sharded.bench_sharded_sp2m(pkg, torch, D, device, rank, world, sg * sg,
+                                                lambda r0, r1: entry.laplace5_rows(sg, r0, r1), (ms_, ms_, rp_, ci_, v_))
+        res["workload"] = "aoclsparse_sp2m(A_r, A): the rank's rows of the 5-pt Laplacian %dx%d grid times the whole matrix" % (sg, sg)
+        if rank == 0:
+            import oracle
+            ml, k, rpl, cil, vl = sh.local
+            so, pc, ic, vc = oracle.dcsr2m(ml, ms_, int(rpl[0]), rpl, cil, vl, 0, rp_, ci_, v_)
+            res["parity"] = {"vs": "oracle two-stage Gustavson on rank 0's rows", "bit_exact": bool(
+                so == 0 and np.array_equal(e["row_ptr"], pc) and np.array_equal(e["col_ind"], ic) and np.array_equal(e["val"], vc))}
+        return res
+
+    run_leg("sp2m_row_sharded", leg_sp2m_row_sharded, collective=True)
 
     if rank == 0:
         import oracle
@@ -1233,7 +1262,7 @@ def main():
         out["cpu_baseline"] = None
 
     if rank == 0:
-        for k in ("l100", "spmv_row_sharded", "csrmm_sharded_col", "csrmm_sharded_row", "csrmm_sharded_bell"):
+        for k in ("l100", "spmv_row_sharded", "sp2m_row_sharded", "csrmm_sharded_col", "csrmm_sharded_row", "csrmm_sharded_bell"):
             if k in legs_out:
                 out[k] = legs_out.pop(k)
         out["legs"] = legs_out

@@ -188,12 +188,24 @@ def test_bench_two_ranks_gloo_one_gpu(tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "5",
            "--warmup", "2", "--grid", "512", "--mm-grid", "200", "--mm-cols", "64", "--shard-grid", "301", "--bell-nodes", "6", "--legs",
-           "csrmm_sharded,spmv_row_sharded", "--record", rec]
+           "csrmm_sharded,spmv_row_sharded,sp2m_row_sharded", "--sp2m-grid", "150", "--record", rec]
     r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4"), capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0, "rc=%d\nstdout:\n%s\nstderr:\n%s" % (r.returncode, r.stdout[-3000:], r.stderr[-3000:])
     short, res = _bench_record(r.stdout, rec)
     _check_two_rank_record(short, res, own_rows=False)
+    # the ranks' row slices of A * A are independent products; rank 0's slice against the oracle, the slices'
+    # sizes all-gathered (the total is the unsharded product's: 5 * g^2 - 4 g entries of A give 13 g^2 - 36 g + 20 ... checked
+    # against the oracle's count of the whole product)
+    s2 = res["sp2m_row_sharded"]
+    assert "error" not in s2, s2
+    assert s2["world"] == 2 and s2["rows_per_rank"] == 150 * 150 // 2 and s2["parity"]["bit_exact"] is True
+    import oracle
+    from util import laplace5
+    mg, rpg, cig, vg = laplace5(150)
+    so, pcg, _, _ = oracle.dcsr2m(mg, mg, 0, rpg, cig, vg, 0, rpg, cig, vg)
+    assert so == 0 and s2["nnz_c"] == int(pcg[mg]) and s2["first_entry_of_this_rank"] == 0
+    assert short["legs"]["sp2m_row_sharded"]["parity"] is True
 
 
 def _check_two_rank_record(short, res, own_rows):
