@@ -103,6 +103,15 @@ def _worker(rank, world, port, q):
         empty_ok = empty_ok and gms >= 0.0 and torch.equal(xfull, torch.arange(mrow, dtype=torch.float64) * 1.5)
         info = sharded.communicator_info(dist, torch)
         empty_ok = empty_ok and info == {"backend": "gloo", "world": world}
+        # row-sharded sp2m: handles over the rank's rows of A and the whole of B are host objects (no product here:
+        # that needs the GPU); the slices' sizes are all-gathered into the offset of the rank's rows in the global C
+        g = 9
+        mB, rpB, ciB, vB = entry.laplace5(g)
+        s2 = sharded.ShardedSp2m(pkg, torch, dist, "cpu", rank, world, g * g, lambda r0, r1: entry.laplace5_rows(g, r0, r1),
+                                 (mB, mB, rpB, ciB, vB))
+        first, total = s2.slice_offsets(100 + 11 * rank)
+        empty_ok = empty_ok and (s2.r0, s2.r1) == sharded.row_shard(g * g, world, rank) and total == sum(100 + 11 * r for r in range(world))
+        empty_ok = empty_ok and first == sum(100 + 11 * r for r in range(rank)) and s2.nnz_a_loc == int(rpB[s2.r1] - rpB[s2.r0])
         q.put((rank, thr, tmax, s, mn, bool(same), bool(slab_ok), bool(torch.equal(gathered, full)) and bool(empty_ok), shards))
     finally:
         dist.destroy_process_group()
