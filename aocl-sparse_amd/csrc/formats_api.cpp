@@ -51,6 +51,53 @@ aoclsparse_status csr2csc(aoclsparse_int m, aoclsparse_int n, aoclsparse_int nnz
         return aoclsparse_status_invalid_value;
     if(!val || !ptr || !ind || !oval || !oind || !optr)
         return aoclsparse_status_invalid_pointer;
+    // Large conversions run on the device (transpose_kernels.hip: the same stable order); the arrays cross PCIe both ways, which is
+    // still several times faster than one core's counting sort.  Declined (a column of more than 2,048 entries) or failed: the host
+    // loop below.
+    if(nnz >= (1 << 20) && ptr[m] - base_in == nnz)
+    {
+        Runtime &rt = Runtime::get();
+        if(rt.init() == aoclsparse_status_success)
+        {
+            std::lock_guard<std::recursive_mutex> sl(rt.stage_lock);
+            hipStream_t                           s = rt.stream();
+            DeviceBuffer                          ip, ii, iv, op, oi, ov;
+            aoclsparse_status                     st = ip.upload(ptr, sizeof(aoclsparse_int) * ((size_t)m + 1), s);
+            if(st == aoclsparse_status_success)
+                st = ii.upload(ind, sizeof(aoclsparse_int) * (size_t)nnz, s);
+            if(st == aoclsparse_status_success)
+                st = iv.upload(val, sizeof(T) * (size_t)nnz, s);
+            if(st == aoclsparse_status_success)
+                st = op.alloc(sizeof(aoclsparse_int) * ((size_t)n + 1));
+            if(st == aoclsparse_status_success)
+                st = oi.alloc(sizeof(aoclsparse_int) * (size_t)nnz);
+            if(st == aoclsparse_status_success)
+                st = ov.alloc(sizeof(T) * (size_t)nnz);
+            if(st == aoclsparse_status_success)
+                st = device_transpose(s, m, n, nnz, base_in, ip.as<aoclsparse_int>(), ii.as<aoclsparse_int>(), iv.ptr, sizeof(T),
+                                      op.as<aoclsparse_int>(), oi.as<aoclsparse_int>(), ov.ptr);
+            if(st == aoclsparse_status_success
+               && hipMemcpyAsync(optr, op.ptr, sizeof(aoclsparse_int) * ((size_t)n + 1), hipMemcpyDeviceToHost, s) == hipSuccess
+               && hipMemcpyAsync(oind, oi.ptr, sizeof(aoclsparse_int) * (size_t)nnz, hipMemcpyDeviceToHost, s) == hipSuccess
+               && hipMemcpyAsync(oval, ov.ptr, sizeof(T) * (size_t)nnz, hipMemcpyDeviceToHost, s) == hipSuccess
+               && hipStreamSynchronize(s) == hipSuccess)
+            {
+                if(base_out != 0)
+                {
+                    parallel_for((long long)n + 1, 1 << 16, [&](long long a, long long b) {
+                        for(long long i = a; i < b; i++)
+                            optr[i] += base_out;
+                    });
+                    parallel_for(nnz, 1 << 18, [&](long long a, long long b) {
+                        for(long long q = a; q < b; q++)
+                            oind[q] += base_out;
+                    });
+                }
+                return aoclsparse_status_success;
+            }
+            (void)hipGetLastError();
+        }
+    }
     std::fill(optr, optr + n + 1, 0);
     for(aoclsparse_int i = 0; i < nnz; i++)
         ++optr[ind[i] - base_in + 1];

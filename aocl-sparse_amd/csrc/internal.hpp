@@ -650,6 +650,11 @@ aoclsparse_status csc_refresh_csr(aoclsparse_matrix A);
 aoclsparse_status ilu_prepare(aoclsparse_matrix A);
 // builds A->trans (host transpose of the user CSR, 0-based) if absent
 aoclsparse_status build_transpose(aoclsparse_matrix A);
+// B = A^T of a device CSR in the reference's counting-sort order (transpose_kernels.hip); aoclsparse_status_not_implemented when
+// a column is too long for the device sort (the caller sorts on the host)
+aoclsparse_status device_transpose(hipStream_t s, aoclsparse_int m, aoclsparse_int n, aoclsparse_int nnz, int base,
+                                   const aoclsparse_int *d_ptr, const aoclsparse_int *d_ind, const void *d_val, size_t vsize,
+                                   aoclsparse_int *tptr, aoclsparse_int *tind, void *tval);
 
 // ---- device mirrors / plans ---------------------------------------------------------------------
 size_t            val_size(aoclsparse_matrix_data_type t);

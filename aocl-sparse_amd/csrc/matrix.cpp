@@ -395,6 +395,9 @@ static void transpose_into(const HostCsr &u, aoclsparse_int nnz, HostCsr &t)
         }
 }
 
+// from this many entries on the handles' transposes are sorted on the device
+constexpr aoclsparse_int DEVICE_TRANSPOSE_MIN_NNZ = 1 << 20;
+
 aoclsparse_status build_transpose(aoclsparse_matrix A)
 {
     {
@@ -409,15 +412,58 @@ aoclsparse_status build_transpose(aoclsparse_matrix A)
     {
         std::unique_ptr<HostCsr> t(new HostCsr);
         const size_t             vs = val_size(A->val_type);
+        const size_t             nz = (size_t)(A->nnz > 0 ? A->nnz : 1);
         t->m = A->n, t->n = A->m, t->nnz = A->nnz, t->base = aoclsparse_index_base_zero;
-        t->owned = true;
+        t->owned = t->result_arrays = true;
         t->ptr   = new aoclsparse_int[t->m + 1];
-        t->ind   = new aoclsparse_int[A->nnz > 0 ? A->nnz : 1];
-        t->val   = ::operator new(vs * (A->nnz > 0 ? A->nnz : 1));
-        dispatch_value_type(A->val_type, [&](auto tag) {
-            transpose_into<decltype(tag)>(A->user, A->nnz, *t);
-            return 0;
-        });
+        t->ind   = static_cast<aoclsparse_int *>(host_result_alloc(sizeof(aoclsparse_int) * nz));
+        t->val   = host_result_alloc(vs * nz);
+        if(!t->ind || !t->val)
+            return aoclsparse_status_memory_error;
+        // Large matrices: the sort runs on the device (transpose_kernels.hip: same order, 22 -> ~3 ms for 5 M entries) and leaves
+        // the transpose in HBM as the handle's dev_trans; the host copy every analysis reads follows over PCIe.  Small ones, and
+        // matrices with a column of more than 2,048 entries, take the host sort.
+        bool on_device = false;
+        if(A->nnz >= DEVICE_TRANSPOSE_MIN_NNZ && A->user.ptr[A->m] - A->base == A->nnz)
+        {
+            Runtime          &rt = Runtime::get();
+            aoclsparse_status st = rt.init();
+            if(st == aoclsparse_status_success && !A->dev_user.valid)
+                st = upload_csr(A->user, vs, A->dev_user);
+            DeviceCsr &dt = A->dev_trans;
+            if(st == aoclsparse_status_success)
+                st = dt.ptr.alloc(sizeof(aoclsparse_int) * ((size_t)t->m + 1));
+            if(st == aoclsparse_status_success)
+                st = dt.ind.alloc(sizeof(aoclsparse_int) * nz);
+            if(st == aoclsparse_status_success)
+                st = dt.val.alloc(vs * nz);
+            if(st == aoclsparse_status_success)
+                st = device_transpose(rt.stream(), A->m, A->n, A->nnz, A->base, A->dev_user.ptr.as<aoclsparse_int>(),
+                                      A->dev_user.ind.as<aoclsparse_int>(), A->dev_user.val.ptr, vs, dt.ptr.as<aoclsparse_int>(),
+                                      dt.ind.as<aoclsparse_int>(), dt.val.ptr);
+            if(st == aoclsparse_status_success)
+            {
+                host_result_touch(t->ind, sizeof(aoclsparse_int) * nz);
+                host_result_touch(t->val, vs * nz);
+                hipStream_t s = rt.stream();
+                if(hipMemcpyAsync(t->ptr, dt.ptr.ptr, sizeof(aoclsparse_int) * ((size_t)t->m + 1), hipMemcpyDeviceToHost, s) == hipSuccess
+                   && hipMemcpyAsync(t->ind, dt.ind.ptr, sizeof(aoclsparse_int) * (size_t)A->nnz, hipMemcpyDeviceToHost, s) == hipSuccess
+                   && hipMemcpyAsync(t->val, dt.val.ptr, vs * (size_t)A->nnz, hipMemcpyDeviceToHost, s) == hipSuccess
+                   && hipStreamSynchronize(s) == hipSuccess)
+                {
+                    dt.m = t->m, dt.n = t->n, dt.nnz = A->nnz, dt.base = aoclsparse_index_base_zero;
+                    dt.valid  = true;
+                    on_device = true;
+                }
+            }
+            if(!on_device)
+                (void)hipGetLastError(); // (declined or failed: the host sort below serves the handle)
+        }
+        if(!on_device)
+            dispatch_value_type(A->val_type, [&](auto tag) {
+                transpose_into<decltype(tag)>(A->user, A->nnz, *t);
+                return 0;
+            });
         A->trans = std::move(t);
     }
     catch(const std::bad_alloc &)

@@ -870,8 +870,8 @@ def test_spgemm_hash_kernel_complex_heavy_rows(prec):
     so, pc, ic, vc = oracle.dcsr2m(m, n, 0, pa, ia, var, 0, pb, ib, vbr)
     assert so == 0 and (np.diff(pc) > 2048).sum() >= 3
     assert (m_.value, n_.value, nz) == (m, n, len(ic)) and np.array_equal(row, pc) and np.array_equal(col, ic)
-    A64 = sp.csr_matrix((va.astype(np.complex128), ia, pa), shape=(m, k))
-    B64 = sp.csr_matrix((vb.astype(np.complex128), ib, pb), shape=(k, n))
+    A64 = sp.csr_matrix((va.astype(np.complex128), ia.copy(), pa.copy()), shape=(m, k))  # (copies: scipy sorts shared arrays in place)
+    B64 = sp.csr_matrix((vb.astype(np.complex128), ib.copy(), pb.copy()), shape=(k, n))
     R = (A64 @ B64).tocsr()
     S = (abs(A64) @ abs(B64)).tocsr()  # sum |a||b| per entry of C
     rows = np.repeat(np.arange(m), np.diff(row))
@@ -1068,3 +1068,99 @@ def test_float_csrmm_four_columns_per_lane_same_bits_as_two():
         scale = abs(alpha) * (abs(A64) @ np.abs(B[:, :n]).astype(np.float64)) + abs(beta) * np.abs(C0[:, :n])
         bound = (2 * (lens.max() + 2)) * np.finfo(np.float32).eps * (scale + 1e-30)
         assert np.all(np.abs(W[:, :n] - ref) <= bound)
+
+
+def _big_rect_csr(seed, m, n, base, kind):
+    """>= 1 M entries, vectorised: rows of 0 .. 14 entries (kind 0: sorted, distinct; 1: + unsorted rows and repeated columns;
+    2: + columns of hundreds of entries; 3: + one column of > 2,048 entries, which the device sort declines)."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(0, 15, m).astype(np.int64)
+    lens[::97] = 0
+    ptr = np.zeros(m + 1, np.int64); np.cumsum(lens, out=ptr[1:])
+    nnz = int(ptr[m])
+    rows = np.repeat(np.arange(m, dtype=np.int64), lens)
+    within = np.arange(nnz, dtype=np.int64) - ptr[rows]
+    start = rng.integers(0, n - 15 * 400, m)[rows]
+    ind = start + within * rng.integers(1, 400, m)[rows]  # distinct, ascending inside a row
+    if kind >= 2:  # hub columns: every 5th row's first entry goes to one of 40 columns -> segments of hundreds
+        first = (within == 0) & (rows % 5 == 0)
+        hub = (rows[first] // 5) % 40
+        ind[first] = np.minimum(hub, start[first])  # (stays the row's smallest column or a repeat of it)
+    if kind >= 3:
+        first = (within == 0) & (rows % 3 == 1)
+        ind[first] = 0
+    if kind >= 1:
+        sw = (within == 1) & (rows % 11 == 3)  # swap the first two entries of some rows: unsorted
+        idx = np.flatnonzero(sw)
+        ind[idx], ind[idx - 1] = ind[idx - 1].copy(), ind[idx].copy()
+        dup = (within == 2) & (rows % 13 == 5)  # repeat the row's first column (not the diagonal of a square matrix: m != n here)
+        idx = np.flatnonzero(dup)
+        ind[idx] = ind[idx - 2]
+    val = rng.uniform(-1, 1, nnz)
+    return (ptr + base).astype(np.int32), (ind + base).astype(np.int32), val
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+def test_csr2csc_large_on_the_device_bit_exact(kind):
+    """aoclsparse_dcsr2csc / scsr2csc on >= 1 M entries run the stable counting sort on the device (round 4): col_ptr, row_ind and
+    val bit for bit those of the reference's host loop (oracle), for both base pairs that differ, rectangular shapes, empty rows
+    and columns, unsorted rows, repeated columns, columns of hundreds of entries (the wavefront sort) and a column of > 2,048
+    (declined: the host loop)."""
+    m, n = 120000, 150000
+    for base_in, base_out in ((0, 1), (1, 0)):
+        rp, ci, v = _big_rect_csr(40 + kind, m, n, base_in, kind)
+        nnz = len(v)
+        assert nnz >= 1 << 19
+        while nnz < (1 << 20):  # (the generator's mean row length gives ~0.84 M: two copies stacked keep it above the threshold)
+            rp = np.concatenate([rp, rp[1:] + (rp[-1] - base_in)]).astype(np.int32)
+            ci = np.concatenate([ci, ci]); v = np.concatenate([v, 2.0 * v])
+            nnz = len(v)
+        mm = len(rp) - 1
+        d = P.Descr(base=base_in)
+        st, cp, ri, cv = oracle.dcsr2csc(mm, n, nnz, base_in, base_out, rp, ci, v)
+        assert st == 0
+        op, oi, ov = np.zeros(n + 1, np.int32), np.zeros(nnz, np.int32), np.zeros(nnz)
+        assert L.aoclsparse_dcsr2csc(mm, n, nnz, d.h, base_out, P._ptr(rp), P._ptr(ci), P._ptr(v), P._ptr(oi), P._ptr(op), P._ptr(ov)) == 0
+        assert np.array_equal(op, cp) and np.array_equal(oi, ri) and np.array_equal(ov, cv), (kind, base_in)
+        if kind == 2:
+            seg = np.diff(cp)
+            assert seg.max() > 256 and seg.max() <= 2048
+        if kind == 3:
+            assert np.diff(cp).max() > 2048
+        vf = v.astype(np.float32)
+        ovf = np.zeros(nnz, np.float32)
+        assert L.aoclsparse_scsr2csc(mm, n, nnz, d.h, base_out, P._ptr(rp), P._ptr(ci), P._ptr(vf), P._ptr(oi), P._ptr(op), P._ptr(ovf)) == 0
+        assert np.array_equal(op, cp) and np.array_equal(oi, ri) and np.array_equal(ovf, cv.astype(np.float32))
+
+
+def test_handle_transpose_built_on_the_device():
+    """The transposes handles keep (?mv / sp2m with op = T) come from the same device sort for >= 1 M entries: dmv with op = T on a
+    rectangular matrix within the bound of the restated product, and sp2m(A^T, B) bit for bit the oracle's csr2csc + csr2m."""
+    import scipy.sparse as sp
+    m, n = 120000, 150000
+    rp, ci, v = _big_rect_csr(61, m, n, 0, 2)
+    while len(v) < (1 << 20):
+        rp = np.concatenate([rp, rp[1:] + rp[-1]]).astype(np.int32); ci = np.concatenate([ci, ci]); v = np.concatenate([v, 2.0 * v])
+    mm = len(rp) - 1
+    A = P.Matrix(0, mm, n, rp, ci, v)
+    assert A.status == 0
+    d = P.Descr()
+    rng = np.random.default_rng(2)
+    x, y0 = rng.uniform(-1, 1, mm), rng.uniform(-1, 1, n)
+    y = y0.copy()
+    assert P.dmv(P.OP_TRANSPOSE, 1.5, A, d, x, -0.5, y) == 0
+    A64 = sp.csr_matrix((v.copy(), ci.copy(), rp.copy()), shape=(mm, n))  # (copies: scipy canonicalises shared arrays in place)
+    ref = 1.5 * (A64.T @ x) - 0.5 * y0
+    scale = 1.5 * (abs(A64).T @ np.abs(x)) + 0.5 * np.abs(y0)
+    colmax = int(np.bincount(ci, minlength=n).max())
+    assert np.all(np.abs(y - ref) <= (2 * colmax + 16) * EPS64 * (scale + 1e-300))
+    # sp2m with the kept transpose: A^T (n x mm) times a thin B (mm x 64 columns)
+    pb, ib, vb = random_csr(9, mm, 64, lambda r, i: r.integers(0, 3))
+    B = P.Matrix(0, mm, 64, pb, ib, vb)
+    st, cp, ri, cv = oracle.dcsr2csc(mm, n, len(v), 0, 0, rp, ci, v)
+    so, pc, ic, vc = oracle.dcsr2m(n, 64, 0, cp, ri.astype(np.int32), cv, 0, pb, ib, vb)
+    C = ctypes.c_void_p()
+    assert L.aoclsparse_sp2m(P.OP_TRANSPOSE, d.h, A.h, P.OP_NONE, d.h, B.h, P.STAGE_FULL, ctypes.byref(C)) == 0
+    _, _, _, row, col, val = _export_csr(C)
+    assert st == 0 and so == 0 and np.array_equal(row, pc) and np.array_equal(col, ic) and np.array_equal(val, vc)
+    assert L.aoclsparse_destroy(ctypes.byref(C)) == 0
