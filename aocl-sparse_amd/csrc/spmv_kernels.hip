@@ -363,10 +363,16 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restr
                     j += 8;
                     while(j + 16 <= e)
                     {
+                        // (scheduling barriers: hipcc otherwise rotates the loop so that a batch's reads are consumed in the trip
+                        // that issues them -- two to three exposed LDS round trips per 16 entries of a lone wavefront)
                         rd(an, bn, j);
+                        __builtin_amdgcn_sched_barrier(0);
                         mac(a, b);
+                        __builtin_amdgcn_sched_barrier(0);
                         rd(a, b, j + 8);
+                        __builtin_amdgcn_sched_barrier(0);
                         mac(an, bn);
+                        __builtin_amdgcn_sched_barrier(0);
                         j += 16;
                     }
                     if(j + 8 <= e)
