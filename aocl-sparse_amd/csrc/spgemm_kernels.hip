@@ -24,6 +24,8 @@
 // 12 B per entry of A and of the touched B rows + 12 B per entry of C.
 #include "internal.hpp"
 
+#include <algorithm>
+
 #include <hip/hip_runtime.h>
 
 namespace mi355
@@ -444,28 +446,43 @@ __global__ __launch_bounds__(256) void spg_diff_kernel(aoclsparse_int m, const a
         key[i] = ptr[i + 1] - ptr[i];
 }
 
-// hist[b] += rows of bin b; hist[SPGEMM_BINS] != 0: some key is negative or above its limit (a row_ptr that is not this product's)
+// hist[b] += rows of bin b; hist[SPGEMM_BINS] != 0: some key is negative or above its limit (a row_ptr that is not this product's).
+// A fixed grid walks the rows with a stride, every thread counts in registers, one atomic per bin and WORKGROUP at the end (an atomic
+// per wavefront on the same five words was 180 us for 1 M rows: rocprofv3, profiles/r4/sp2m_kernel_stats_*.csv).
+constexpr int SPG_HIST_BLOCKS = 512;
 __global__ __launch_bounds__(256) void spg_hist_kernel(aoclsparse_int m, const int *__restrict__ key, const int *__restrict__ limit,
                                                        bool fill, unsigned int *hist)
 {
-    const int i    = blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    int       b    = -1;
-    bool      bad  = false;
-    if(i < m)
+    __shared__ unsigned int sh[SPGEMM_BINS + 1];
+    if(threadIdx.x <= SPGEMM_BINS)
+        sh[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned int mine[SPGEMM_BINS] = {};
+    bool         bad               = false;
+    for(long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < m; i += (long long)gridDim.x * 256)
     {
         const int k = key[i];
-        bad         = k < 0 || (limit && k > limit[i]);
-        b           = spg_bin_dev(k < 0 ? 0 : k, fill);
+        bad |= k < 0 || (limit && k > limit[i]);
+        const int b = spg_bin_dev(k < 0 ? 0 : k, fill);
+#pragma unroll
+        for(int q = 0; q < SPGEMM_BINS; q++)
+            mine[q] += b == q;
     }
 #pragma unroll
-    for(int k = 0; k < SPGEMM_BINS; k++)
+    for(int q = 0; q < SPGEMM_BINS; q++)
     {
-        const unsigned long long mk = __ballot(b == k);
-        if(lane == 0 && mk)
-            atomicAdd(&hist[k], (unsigned)__popcll(mk));
+        unsigned int v = mine[q];
+        for(int o = 32; o > 0; o >>= 1)
+            v += __shfl_down(v, o, 64);
+        if((threadIdx.x & 63) == 0 && v)
+            atomicAdd(&sh[q], v);
     }
-    if(__ballot(bad) && lane == 0)
+    if(__ballot(bad) && (threadIdx.x & 63) == 0)
+        atomicOr(&sh[SPGEMM_BINS], 1u);
+    __syncthreads();
+    if(threadIdx.x < SPGEMM_BINS && sh[threadIdx.x])
+        atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
+    if(threadIdx.x == SPGEMM_BINS && sh[SPGEMM_BINS])
         atomicOr(&hist[SPGEMM_BINS], 1u);
 }
 
@@ -474,25 +491,38 @@ struct SpgBounds
     int at[SPGEMM_BINS + 1];
 };
 
-// order[bounds[b] ...] = the rows of bin b; the rows of one wavefront keep their order (ballot rank), wavefronts arrive as they come
+// order[bounds[b] ...] = the rows of bin b; the rows of one workgroup keep their order (ballot rank inside a wavefront, wavefronts in
+// order inside the workgroup), workgroups arrive as they come: one atomic per bin and workgroup
 __global__ __launch_bounds__(256) void spg_order_kernel(aoclsparse_int m, const int *__restrict__ key, bool fill, SpgBounds bounds,
                                                         unsigned int *cursor, aoclsparse_int *__restrict__ order)
 {
+    __shared__ unsigned int cnt[4][SPGEMM_BINS], base_of[SPGEMM_BINS];
     const int i    = blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int b    = i < m ? spg_bin_dev(key[i], fill) : -1;
+    unsigned int rank = 0;
 #pragma unroll
     for(int k = 0; k < SPGEMM_BINS; k++)
     {
         const unsigned long long mk = __ballot(b == k);
-        if(!mk)
-            continue;
-        unsigned at = 0;
         if(lane == 0)
-            at = atomicAdd(&cursor[k], (unsigned)__popcll(mk));
-        at = __shfl(at, 0, 64);
+            cnt[w][k] = (unsigned)__popcll(mk);
         if(b == k)
-            order[bounds.at[k] + at + __popcll(mk & ((1ull << lane) - 1ull))] = i;
+            rank = (unsigned)__popcll(mk & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    if(threadIdx.x < SPGEMM_BINS)
+    {
+        const unsigned total = cnt[0][threadIdx.x] + cnt[1][threadIdx.x] + cnt[2][threadIdx.x] + cnt[3][threadIdx.x];
+        base_of[threadIdx.x] = total ? atomicAdd(&cursor[threadIdx.x], total) : 0u;
+    }
+    __syncthreads();
+    if(b >= 0)
+    {
+        unsigned at = base_of[b] + rank;
+        for(int u = 0; u < w; u++)
+            at += cnt[u][b];
+        order[bounds.at[b] + at] = i;
     }
 }
 
@@ -604,7 +634,8 @@ aoclsparse_status launch_spg_hist(hipStream_t s, aoclsparse_int m, const int *ke
 {
     MI355_HIP_TRY(hipMemsetAsync(hist, 0, sizeof(unsigned int) * (SPGEMM_BINS + 1), s));
     if(m > 0)
-        hipLaunchKernelGGL(spg_hist_kernel, dim3((m + 255) / 256), dim3(256), 0, s, m, key, limit, fill, hist);
+        hipLaunchKernelGGL(spg_hist_kernel, dim3((unsigned)std::min<long long>(SPG_HIST_BLOCKS, ((long long)m + 255) / 256)), dim3(256), 0, s,
+                           m, key, limit, fill, hist);
     MI355_HIP_TRY(hipGetLastError());
     return aoclsparse_status_success;
 }
