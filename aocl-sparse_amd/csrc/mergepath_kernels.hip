@@ -121,11 +121,35 @@ __global__ void mp_fixup_kernel(int ntiles, const aoclsparse_int *__restrict__ c
     const int row = carry_row[2 * w];
     if(row < 0)
         return;
-    int f = w;
-    while(f > 0 && carry_row[2 * (f - 1) + 1] == row)
-        f--;
-    T r = T(0);
-    for(int v = f; v < w; v++)
+    // the tiles [f, w) hold the head pieces of this row: "head row == row" is false ... false, true ... true over [0, w), so f is
+    // found by bisection (8 dependent loads for a row cut into 170 pieces instead of 170), and the pieces are summed in tile
+    // order as before, their loads issued 16 at a time (round 4: the lane-by-lane walk made this kernel 39 us on a matrix with
+    // four 170 k-entry rows, more than mp_kernel itself: profiles/r4/legs_kernel_stats.csv)
+    int f = 0;
+    {
+        int b = w;
+        while(f < b)
+        {
+            const int mid = (f + b) >> 1;
+            if(carry_row[2 * mid + 1] == row)
+                b = mid;
+            else
+                f = mid + 1;
+        }
+    }
+    T   r = T(0);
+    int v = f;
+    for(; v + 16 <= w; v += 16)
+    {
+        T t[16];
+#pragma unroll
+        for(int q = 0; q < 16; q++)
+            t[q] = carry_val[2 * (v + q) + 1];
+#pragma unroll
+        for(int q = 0; q < 16; q++)
+            r += t[q];
+    }
+    for(; v < w; v++)
         r += carry_val[2 * v + 1];
     r += carry_val[2 * w];
     y[row] = mp_finish(r, alpha, beta, y + row);

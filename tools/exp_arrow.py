@@ -4,7 +4,7 @@ tile: the row-block kernel gives such a row to ONE workgroup, merge-path cuts it
 chip.  One JSON line per (matrix, kernel); the threshold of the automatic choice in csrc/matrix.cpp comes from here."""
 import json, os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, [p for p in (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))) if os.path.exists(os.path.join(p, "bench.py"))][0])
 import __graft_entry__ as entry
 import oracle
 from bench import spmv_bytes, timed_laps
@@ -49,11 +49,9 @@ for title, n, nlong, length in cases:
     x = torch.from_numpy(xh).to(dev); y = torch.zeros(m, dtype=torch.float64, device=dev)
     so, yr = oracle.dcsrmv(0, 0, 1.0, m, nnz, v, ci, rp, xh, 0.0, np.zeros(m))
     for choice in ("adaptive", "merge", "auto"):
-        if choice == "auto":
-            os.environ.pop("AOCLSPARSE_MI355_SPMV_KERNEL", None)
-        else:
-            os.environ["AOCLSPARSE_MI355_SPMV_KERNEL"] = choice
-        os.environ["AOCLSPARSE_MI355_SELL"] = "0"
+        # (round 4: the selection switches of rounds 1-3 are one option hook)
+        assert L.aoclsparse_mi355_set_option(pkg.OPTION_SPMV_KERNEL, {"auto": 0, "adaptive": 1, "merge": 2}[choice]) == 0
+        assert L.aoclsparse_mi355_set_option(pkg.OPTION_SELL, 0) == 0
         A = pkg.Matrix(0, m, m, rp, ci, v)
         assert L.aoclsparse_set_mv_hint(A.h, pkg.OP_NONE, d0.h, 100) == 0 and L.aoclsparse_optimize(A.h) == 0
         info = A.spmv_info()
