@@ -377,6 +377,7 @@ SIGNATURES = {
     "aoclsparse_mi355_set_trsv_schedule": (c_int, [_I]),
     "aoclsparse_mi355_set_csrmm_beta0_overwrite": (c_int, [c_int]),
     "aoclsparse_mi355_invalidate": (c_int, [_P]),
+    "aoclsparse_mi355_release_staging": (c_int, [POINTER(ctypes.c_size_t)]),
     "mi355_csrmv_plan_bound": (_I, [_I, _I]),
     "mi355_csrmv_plan_host": (_I, [_I, _I, _I, _P, _P]),
     "mi355_dcsrmv": (c_int, [_P, _I, _I, _I, _I, c_double, _I, _P, _P, _P, _P, _I, _P, c_double, _P]),

@@ -544,6 +544,7 @@ public:
     char name[256] = {0};
     // scratch staging buffers for host-pointer calls (grown on demand, reused)
     aoclsparse_status staging(int slot, size_t bytes, void **out);
+    size_t            release_staging(); // frees every slot (after the stream has drained); bytes freed
     // Host <-> device copies of PAGEABLE caller memory on the library's stream (plain stream-ordered copies: the runtime's own
     // staging runs at 56 GB/s on these boxes; h2d returns once enqueued, d2h likewise -- callers synchronise the stream)
     aoclsparse_status h2d(void *dev, const void *host, size_t bytes);

@@ -341,6 +341,20 @@ aoclsparse_status Runtime::staging(int slot, size_t bytes, void **out)
     return st;
 }
 
+size_t Runtime::release_staging()
+{
+    std::lock_guard<std::recursive_mutex> sl(stage_lock);
+    if(stream_)
+        (void)hipStreamSynchronize(stream_); // (a kernel of the last call may still read a slot)
+    size_t freed = 0;
+    for(DeviceBuffer &b : stage_)
+    {
+        freed += b.ptr ? b.bytes : 0;
+        b.release();
+    }
+    return freed;
+}
+
 // ---- pageable <-> device copies -----------------------------------------------------------------------------------------
 // Plain stream-ordered copies.  A hand-made pipeline through a ring of pinned slots (round 2) measured SLOWER than the ROCm
 // runtime's own staging of pageable memory (51-54 vs 56 GB/s, profiles/r2/h2d_probe.jsonl) and was removed in round 3.
@@ -372,6 +386,14 @@ extern "C" {
 aoclsparse_status aoclsparse_mi355_set_csrmm_beta0_overwrite(int overwrite)
 {
     csrmm_beta0_overwrite_flag().store(overwrite != 0, std::memory_order_relaxed); // process-wide: every runtime slot reads it
+    return aoclsparse_status_success;
+}
+
+aoclsparse_status aoclsparse_mi355_release_staging(size_t *bytes_freed)
+{
+    const size_t f = Runtime::get().release_staging();
+    if(bytes_freed)
+        *bytes_freed = f;
     return aoclsparse_status_success;
 }
 

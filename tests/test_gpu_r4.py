@@ -1164,3 +1164,33 @@ def test_handle_transpose_built_on_the_device():
     _, _, _, row, col, val = _export_csr(C)
     assert st == 0 and so == 0 and np.array_equal(row, pc) and np.array_equal(col, ic) and np.array_equal(val, vc)
     assert L.aoclsparse_destroy(ctypes.byref(C)) == 0
+
+
+def test_release_staging_frees_the_scratch_and_the_next_call_allocates_again():
+    """aoclsparse_mi355_release_staging: the grow-only scratch a product leaves in HBM (sp2m: a transposed operand of a result
+    handle goes through staging slots; dmv with host vectors stages x and y) is freed on request and the next call simply
+    allocates it again -- same bits."""
+    m, rp, ci, v = laplace5(400)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    d = P.Descr()
+    x, y = np.cos(0.1 * np.arange(m)), np.zeros(m)
+    assert P.dmv(P.OP_NONE, 1.0, A, d, x, 0.0, y) == 0  # host vectors: staged
+    C = ctypes.c_void_p()
+    assert L.aoclsparse_sp2m(P.OP_NONE, d.h, A.h, P.OP_NONE, d.h, A.h, P.STAGE_FULL, ctypes.byref(C)) == 0
+    E = ctypes.c_void_p()  # C^T * A: the transpose of a result handle is built per call and staged
+    assert L.aoclsparse_sp2m(P.OP_TRANSPOSE, d.h, C, P.OP_NONE, d.h, A.h, P.STAGE_FULL, ctypes.byref(E)) == 0
+    _, _, _, row1, col1, val1 = _export_csr(E)
+    assert L.aoclsparse_destroy(ctypes.byref(E)) == 0
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    freed = ctypes.c_size_t(0)
+    assert L.aoclsparse_mi355_release_staging(ctypes.byref(freed)) == 0
+    free1 = torch.cuda.mem_get_info()[0]
+    assert freed.value > 8 * m and free1 >= free0
+    assert L.aoclsparse_mi355_release_staging(ctypes.byref(freed)) == 0 and freed.value == 0
+    y2 = np.zeros(m)
+    assert P.dmv(P.OP_NONE, 1.0, A, d, x, 0.0, y2) == 0 and np.array_equal(y, y2)
+    assert L.aoclsparse_sp2m(P.OP_TRANSPOSE, d.h, C, P.OP_NONE, d.h, A.h, P.STAGE_FULL, ctypes.byref(E)) == 0
+    _, _, _, row2, col2, val2 = _export_csr(E)
+    assert np.array_equal(row1, row2) and np.array_equal(col1, col2) and np.array_equal(val1, val2)
+    assert L.aoclsparse_destroy(ctypes.byref(E)) == 0 and L.aoclsparse_destroy(ctypes.byref(C)) == 0
