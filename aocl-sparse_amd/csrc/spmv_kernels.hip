@@ -123,6 +123,46 @@ __device__ __forceinline__ T block_sum(T v, T *scratch)
     return r;
 }
 
+// Lane exchange inside a row of 16 lanes by DPP (no LDS crossbar): ctrl 0xB1 = quad_perm [1,0,3,2], 0x4E = quad_perm [2,3,0,1],
+// 0x141 = row_half_mirror, 0x140 = row_mirror.  Every lane is a valid source for these four, so no bound_ctrl fill is seen.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo     = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi     = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ double read_lane(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float read_lane(float v, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+// sum over the 64 lanes of a wavefront in a FIXED order (pairs, quads, halves of a row, rows of 16, then (r0 + r1) + (r2 + r3));
+// every lane returns the total
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v)
+{
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    return (read_lane(v, 0) + read_lane(v, 16)) + (read_lane(v, 32) + read_lane(v, 48));
+}
+
+// rows of an LDS tile with at least this many entries are summed by a whole wavefront (auto mode, VAR 0) instead of one lane's
+// chain: lane l takes entries l, l + 64, ... as an FMA chain, wave_sum adds the 64 partial sums
+constexpr int TREE_MIN = 32;
+
 // flags: bit0 strict long rows, bit1 16-byte-aligned val and col (quad loads allowed),
 //        bit2 XCD-contiguous block order, bit3 non-temporal y stores, bit4 every row <= 8 entries,
 //        bit5 VALIDATE: the block table may be STALE (a cached plan of a raw-array call, spmv_api.cpp: the cache key is the
@@ -309,7 +349,76 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restr
             }
             return;
         }
-        // ---- phase 2: per-row reduction in the reference order -----------------------------------------
+        // ---- phase 2: per-row reduction ------------------------------------------------------------------
+        if constexpr(L == 1 && VAR == 0)
+        {
+            // Auto mode, scalar order: a row of fewer than TREE_MIN entries is one lane's left-to-right FMA chain (the bits of
+            // ref_csrmv_gn, csrmv_kr.hpp:448-513); a longer one is summed by its WAVEFRONT -- 64 strided chains + wave_sum --
+            // because as one lane's chain a 300-entry row outlasted everything else its workgroup did (traced: 6-7.5 us of a
+            // 9.7 us kernel on the circuit-like stand-in).  Componentwise bound of such a row: (ceil(n / 64) + 7) eps sum|a||x|,
+            // inside the (2 ceil(log2 n) + 4) eps sum|a||x| the tests state; a pinned kid (VAR 1) keeps every row a chain.
+            const int lane64 = tid & 63;
+            for(int rb = 0; rb < nrows; rb += BLOCK)
+            {
+                const int  rr  = rb + tid;
+                const bool act = rr < nrows;
+                int        s = 0, e = 0;
+                if(act)
+                    s = s_row[rr], e = s_row[rr + 1];
+                const bool lng = e - s >= TREE_MIN;
+                if(act && !lng)
+                {
+                    T   acc = T(0);
+                    int j   = s;
+                    while(e - j >= 8)
+                    {
+                        T a8[8], b8[8];
+#pragma unroll
+                        for(int q = 0; q < 8; q++)
+                        {
+                            a8[q] = s_val[j + q];
+                            b8[q] = s_x[j + q];
+                        }
+#pragma unroll
+                        for(int q = 0; q < 8; q++)
+                            acc = dev_fma(a8[q], b8[q], acc);
+                        j += 8;
+                    }
+                    if(j < e) // the last 1..7 entries: one clamped batch
+                    {
+                        T a[7], b[7];
+#pragma unroll
+                        for(int q = 0; q < 7; q++)
+                        {
+                            const int jj = min(j + q, e - 1);
+                            a[q]         = s_val[jj];
+                            b[q]         = s_x[jj];
+                        }
+#pragma unroll
+                        for(int q = 0; q < 7; q++)
+                            acc = j + q < e ? dev_fma(a[q], b[q], acc) : acc;
+                    }
+                    store_y(&y[r0 + rr], finish(acc, alpha, beta, &y[r0 + rr]), flags);
+                }
+                unsigned long long mask = __ballot(lng);
+                while(mask)
+                {
+                    const int l = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const int ls = __builtin_amdgcn_readlane(s, l), le = __builtin_amdgcn_readlane(e, l);
+                    T         acc = T(0);
+                    for(int j = ls + lane64; j < le; j += 64)
+                        acc = dev_fma(s_val[j], s_x[j], acc);
+                    const T tot = wave_sum(acc);
+                    if(lane64 == 0)
+                    {
+                        const int r = r0 + rb + (tid & ~63) + l;
+                        store_y(&y[r], finish(tot, alpha, beta, &y[r]), flags);
+                    }
+                }
+            }
+        }
+        else
         for(int rr = grp; rr < nrows; rr += BLOCK / L)
         {
             const int s   = s_row[rr];

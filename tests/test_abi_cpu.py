@@ -35,9 +35,60 @@ def test_every_declared_symbol_is_exported_and_bound():
     for n in names:
         assert n in exported, "declared in include/ but not exported: " + n
         assert n in P.SIGNATURES, "no ctypes signature for " + n
-    # nothing but the C ABI leaks out (library built with -fvisibility=hidden)
-    leaked = [s for s in exported if not (s.startswith("aoclsparse_") or s.startswith("mi355_"))]
+    # nothing but the C ABI and the reference's sixteen C++ template instantiations leaks out (library built with
+    # -fvisibility=hidden); template instantiations are weak definitions ("W")
+    cxx = [ln.strip() for ln in open(os.path.join(ROOT, "tests", "golden", "cxx_symbols.txt")) if ln.strip()]
+    assert len(cxx) == 16
+    weak = {ln.split()[-1] for ln in out.splitlines() if " W " in ln}
+    for n in cxx:  # mv / trsv / sp2m / create_csr x s / d / c / z (aoclsparse_mv.cpp:351-360, trsv.cpp:419-431, csr2m.cpp:863-873,
+        assert n in weak or n in exported, "C++ entry point of the reference not exported: " + n  # create.cpp:99-110)
+    leaked = [s for s in exported | weak if not (s.startswith("aoclsparse_") or s.startswith("mi355_") or s in cxx)]
     assert not leaked, leaked
+
+
+def test_soname_and_versioned_names():
+    """library/CMakeLists.txt:144-145: SOVERSION = VERSION = 5.3.2, so a program linked against the reference asks the loader for
+    libaoclsparse.so.5.3.2; this library carries that SONAME and the directory holds the name chain .so -> .so.5 -> .so.5.3.2."""
+    dyn = subprocess.check_output(["readelf", "-d", P.LIB_PATH], text=True)
+    assert "Library soname: [libaoclsparse.so.5.3.2]" in dyn, dyn
+    d = os.path.dirname(P.LIB_PATH)
+    for name in ("libaoclsparse.so", "libaoclsparse.so.5", "libaoclsparse.so.5.3.2"):
+        assert os.path.samefile(os.path.join(d, name), P.LIB_PATH), name
+
+
+def test_declaration_only_cxx_program_links(tmp_path):
+    """A C++ program that only DECLARES aoclsparse::mv / create_csr (what the reference's header gives it) links against this
+    library through the versioned name and gets the library's status codes back without a device call (null-pointer checks)."""
+    src = tmp_path / "decl_only.cpp"
+    src.write_text("""
+#include "aoclsparse.h"
+#include <complex>
+namespace aoclsparse {
+template <typename T> aoclsparse_status mv(aoclsparse_operation, const T *, aoclsparse_matrix, const aoclsparse_mat_descr,
+                                           const T *, const T *, T *);
+template <typename T> aoclsparse_status create_csr(aoclsparse_matrix *, aoclsparse_index_base, aoclsparse_int, aoclsparse_int,
+                                                   aoclsparse_int, aoclsparse_int *, aoclsparse_int *, T *, bool = false);
+template <typename T> aoclsparse_status trsv(const aoclsparse_operation, const T, aoclsparse_matrix, const aoclsparse_mat_descr,
+                                             const T *, const aoclsparse_int, T *, const aoclsparse_int, aoclsparse_int = -1);
+}
+int main() {
+    double a = 1.0, x[1] = {1.0}, y[1] = {0.0};
+    if(aoclsparse::mv<double>(aoclsparse_operation_none, &a, nullptr, nullptr, x, &a, y) != aoclsparse_status_invalid_pointer) return 1;
+    aoclsparse_int rp[2] = {0, 1}, ci[1] = {0};
+    std::complex<float> v[1] = {{1.f, 2.f}};
+    aoclsparse_matrix A = nullptr;
+    if(aoclsparse::create_csr<std::complex<float>>(&A, aoclsparse_index_base_zero, 1, 1, 1, rp, ci, v) != aoclsparse_status_success) return 2;
+    if(aoclsparse::trsv<std::complex<float>>(aoclsparse_operation_none, v[0], A, nullptr, v, 1, v, 1) != aoclsparse_status_invalid_pointer) return 3;
+    return aoclsparse_destroy(&A) == aoclsparse_status_success ? 0 : 4;
+}
+""")
+    exe = tmp_path / "decl_only"
+    d = os.path.dirname(P.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", str(src), "-I" + os.path.join(ROOT, "include"), "-L" + d, "-laoclsparse",
+                           "-Wl,-rpath," + d, "-o", str(exe)])
+    needed = subprocess.check_output(["readelf", "-d", str(exe)], text=True)
+    assert "libaoclsparse.so.5.3.2" in needed
+    assert subprocess.call([str(exe)]) == 0
 
 
 def test_product_does_not_reference_the_oracle():
