@@ -26,7 +26,7 @@ ORDER_ROW, ORDER_COLUMN = 0, 1
 STAGE_NNZ_COUNT, STAGE_FINALIZE, STAGE_FULL = 0, 1, 2
 MEM_MINIMAL, MEM_UNRESTRICTED = 0, 1
 PTR_AUTO, PTR_HOST, PTR_DEVICE = 0, 1, 2
-OPTION_SPMV_KERNEL, OPTION_SELL = 0, 1  # aoclsparse_mi355_set_option
+OPTION_SPMV_KERNEL, OPTION_SELL, OPTION_SPMV_STRICT = 0, 1, 2  # aoclsparse_mi355_set_option
 
 STATUS = {
     0: "success", 1: "not_implemented", 2: "invalid_pointer", 3: "invalid_size", 4: "internal_error",
@@ -48,7 +48,8 @@ class SpmvInfo(ctypes.Structure):
     _fields_ = [("kernel", c_int32), ("order", c_int32), ("row_blocks", c_int32), ("tile", c_int32),
                 ("long_rows", c_int32), ("max_row_nnz", c_int32), ("device_resident", c_int32),
                 ("sell_slices", c_int32), ("stored_cells", ctypes.c_longlong), ("mm_groups", c_int32),
-                ("mm_window_rows", c_int32), ("mm_bell_width", c_int32), ("mm_bell_fill_permille", c_int32)]
+                ("mm_window_rows", c_int32), ("mm_bell_width", c_int32), ("mm_bell_fill_permille", c_int32),
+                ("tree_min", c_int32)]
 
 
 class MmState(ctypes.Structure):

@@ -975,6 +975,9 @@ aoclsparse_status launch_sorv_level(hipStream_t s, const aoclsparse_int *rows, a
 // SpMV plan constants shared by host planner and kernels
 // LDS tile = non-zeros staged per workgroup: 512 (128 threads), 1024 or 2048 (256 threads);
 // rows per stream block (their row_ptr slice is kept in LDS)
+// csr_adaptive_kernel, auto mode (scalar order, no pinned kid): rows of an LDS tile with at least this many entries are summed by a
+// whole wavefront (64 strided FMA chains + a fixed-order tree) instead of one lane's chain
+constexpr int SPMV_TREE_MIN = 32;
 constexpr int spmv_maxrows(int tile)
 {
     return tile / 2 < 512 ? tile / 2 : 512;

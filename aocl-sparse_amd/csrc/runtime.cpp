@@ -303,7 +303,7 @@ std::atomic<bool> &csrmm_beta0_overwrite_flag()
 
 namespace
 {
-    std::atomic<int> g_plan_options[aoclsparse_mi355_option_count] = {{0}, {-1}};
+    std::atomic<int> g_plan_options[aoclsparse_mi355_option_count] = {{0}, {-1}, {0}};
 }
 int plan_option(aoclsparse_mi355_option option)
 {
@@ -404,6 +404,8 @@ aoclsparse_status aoclsparse_mi355_set_option(aoclsparse_mi355_option option, ao
     if(option == aoclsparse_mi355_option_spmv_kernel && (value < 0 || value > 2))
         return aoclsparse_status_invalid_value;
     if(option == aoclsparse_mi355_option_sell && (value < -1 || value > 1))
+        return aoclsparse_status_invalid_value;
+    if(option == aoclsparse_mi355_option_spmv_strict && (value < 0 || value > 1))
         return aoclsparse_status_invalid_value;
     g_plan_options[option].store((int)value, std::memory_order_relaxed);
     return aoclsparse_status_success;

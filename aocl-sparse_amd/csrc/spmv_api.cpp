@@ -91,8 +91,6 @@ aoclsparse_status resolve_order(aoclsparse_int kid, aoclsparse_int m, aoclsparse
     return aoclsparse_status_success;
 }
 
-constexpr int STRICT_LONG_AUTO = 0; // off: see run_on_device_csr
-
 template <typename T>
 aoclsparse_status run_on_device_csr(Runtime &rt, aoclsparse_int kid, const DeviceCsr &d,
                                     const SpmvPlan &plan, T alpha, const T *x, T beta, T *y,
@@ -101,15 +99,10 @@ aoclsparse_status run_on_device_csr(Runtime &rt, aoclsparse_int kid, const Devic
     int               order;
     bool              strict;
     aoclsparse_status st = resolve_order<T>(kid, d.m, d.nnz, plan.max_row_nnz, order, strict);
-    // Auto mode CAN keep rows longer than an LDS tile in the reference's order too (AOCLSPARSE_MI355_STRICT_LONG=<longest
-    // row for which to do so>): every row is then bit-exact, at the price of the sequential chain of the longest row --
-    // web-like (91 rows of up to 2,908 entries): 64.9 vs 32.4 us (tools/exp_strict.py, profiles/r2/strict_long_rows.jsonl),
-    // which is why the default (0) leaves such rows to the wavefront tree and its stated forward-error bound.
-    static const int strict_long = [] {
-        const char *e = getenv("AOCLSPARSE_MI355_STRICT_LONG");
-        return e ? atoi(e) : STRICT_LONG_AUTO;
-    }();
-    if(!strict && plan.long_rows > 0 && plan.max_row_nnz <= strict_long)
+    // aoclsparse_mi355_set_option(spmv_strict, 1): every row in the reference's order without pinning a kid (the automatic
+    // order stays) -- bit-exact everywhere, at the price of one lane's serial chain per long row (web-like, 91 rows of up to
+    // 2,908 entries: 44.5 vs 28.5 us in round 3).  The default leaves rows of >= SPMV_TREE_MIN entries to a wavefront tree.
+    if(!strict && plan_option(aoclsparse_mi355_option_spmv_strict) == 1)
         strict = true;
     if(st != aoclsparse_status_success)
         return st;
@@ -640,6 +633,9 @@ aoclsparse_status aoclsparse_mi355_get_spmv_info(const aoclsparse_matrix A, aocl
     else
         resolve_order<double>(kid, d.m, d.nnz, p.max_row_nnz, order, strict);
     info->order = order;
+    if(plan_option(aoclsparse_mi355_option_spmv_strict) == 1)
+        strict = true;
+    info->tree_min = (info->kernel == 1 && order == 0 && !strict) ? SPMV_TREE_MIN : 0;
     return aoclsparse_status_success;
 }
 

@@ -13,9 +13,11 @@
 //     order 1: 4 lanes per row, j mod 4, (l0+l1)+(l2+l3), tail = ..._vectorized_avx2  (csrmv_kr.hpp:949-1040)
 //     order 2: 8 lanes per row, j mod 8, AVX-512 tree, tail    = ..._vectorized_avx512 (csrmv_avx512.cpp:36-134)
 //              (float: the AVX2 8-lane tree of csrmv_kr.hpp:734-831)
-// so y is bit-identical to that CPU kernel (GPU fma == x86 vfmadd).  A row longer than a tile gets a
-// workgroup of its own: `strict` keeps the reference order (tiles through LDS, owner lanes chain),
-// otherwise a wavefront tree is used (documented componentwise bound).
+// so y is bit-identical to that CPU kernel (GPU fma == x86 vfmadd).  Two exceptions, both only without a pinned kid
+// (auto mode, VAR 0) and both with a stated componentwise bound (tests): a scalar-order row of >= SPMV_TREE_MIN (32)
+// entries inside a tile is summed by its wavefront (64 strided chains + wave_sum; round 5), and a row longer than a tile gets a
+// workgroup of its own with a workgroup-wide tree.  `strict` (a pinned kid, or aoclsparse_mi355_set_option(spmv_strict, 1); VAR 1)
+// keeps the reference order for every row: tiles through LDS, owner lanes chain.
 //
 // HBM traffic per launch = the algorithmic bytes: val 8 B + col 4 B per nnz, row_ptr 4 B + y 8 B per
 // row, x 8 B per column once (re-reads are cache hits), + 8 B per row block of plan.
@@ -159,9 +161,9 @@ __device__ __forceinline__ T wave_sum(T v)
     return (read_lane(v, 0) + read_lane(v, 16)) + (read_lane(v, 32) + read_lane(v, 48));
 }
 
-// rows of an LDS tile with at least this many entries are summed by a whole wavefront (auto mode, VAR 0) instead of one lane's
-// chain: lane l takes entries l, l + 64, ... as an FMA chain, wave_sum adds the 64 partial sums
-constexpr int TREE_MIN = 32;
+// rows of an LDS tile with at least SPMV_TREE_MIN entries (internal.hpp) are summed by a whole wavefront (auto mode, VAR 0) instead
+// of one lane's chain: lane l takes entries l, l + 64, ... as an FMA chain, wave_sum adds the 64 partial sums
+constexpr int TREE_MIN = SPMV_TREE_MIN;
 
 // flags: bit0 strict long rows, bit1 16-byte-aligned val and col (quad loads allowed),
 //        bit2 XCD-contiguous block order, bit3 non-temporal y stores, bit4 every row <= 8 entries,
@@ -171,7 +173,7 @@ constexpr int TREE_MIN = 32;
 //        loaded anyway (s_row), so each workgroup checks its own two boundaries for free; on a mismatch it computes its rows
 //        straight from the live arrays (same chains, no LDS tile) and raises *stale for the host's next call.  No check
 //        kernel, no stream round trip per call (round 3 paid ~70 us for one: 0.334 vs 0.262 ms on the 4096^2 Laplacian).
-// VAR: 0 general; 1 strict long rows (the tile-by-tile chain of the longest rows keeps the next tile in registers); 2 every row of the
+// VAR: 0 general (auto mode: wavefront tree for scalar-order rows of >= 32 entries); 1 strict: every row in the reference's order (the tile-by-tile chain of the longest rows keeps the next tile in registers); 2 every row of the
 // plan has <= 8 entries (stencils: no batched-read code, no long-row code).  Template parameters, not run-time flags: the register
 // allocation of a kernel is the maximum over ALL its paths, and the strict path's prefetch registers and the batched reads of
 // the general path had cost the 4096^2 Laplacian -- which uses neither -- a fifth of its speed (0.250 ms in round 1, 0.266 with

@@ -253,7 +253,11 @@ def leg_numbers(full):
         lat = {_short(r["matrix"].split(" (")[0], 28): r["roofline_latency"]["frac"] for r in rows if r.get("roofline_latency")}
         if lat:
             n["mix_latency_frac"] = lat
-        n["mix_parity"] = all(r["bit_exact_rows_within_tile"] and r["long_rows_within_bound"] for r in rows)
+        n["mix_parity"] = all(r.get("bit_exact_rows_below_tree_min", r.get("bit_exact_rows_within_tile")) and r["long_rows_within_bound"]
+                              and (r.get("strict_mode") or {}).get("bit_exact_every_row", True) for r in rows)
+        st = {_short(r["matrix"].split(" (")[0], 28): r["strict_mode"]["roofline"]["frac"] for r in rows if r.get("strict_mode")}
+        if st:
+            n["mix_strict_frac"] = st  # spmv_strict = 1: every row in the reference's order (bit-exact), same matrices
     mm = legs.get("csrmm") or {}
     for lay, key in (("row-major", "row"), ("column-major", "col")):
         for mode, suffix in (("default", ""), ("opt-in", "_overwrite")):
@@ -863,7 +867,25 @@ def main():
             so, yr = oracle.dcsrmv(-1, 0, 1.0, mm_, nz, v, ci, rp, xr, 0.0, np.zeros(mm_), nthreads=oracle.max_threads())
             got = ydv.cpu().numpy()
             lens = np.diff(rp)
-            within = lens <= max(inf.tile, 1) if inf.kernel not in (3, 4) else np.ones(mm_, bool)
+            # rows the automatic mode keeps in the reference's order (CSR-Adaptive: fewer than tree_min entries; SELL-64: all)
+            within = lens < inf.tree_min if inf.tree_min > 0 else np.ones(mm_, bool)
+            strict = None
+            if inf.tree_min > 0:  # the same product with every row in the reference's order (spmv_strict: bit-exact everywhere)
+                assert L.aoclsparse_mi355_set_option(pkg.OPTION_SPMV_STRICT, 1) == 0
+                try:
+                    ys = torch.zeros(mm_, dtype=torch.float64, device=device)
+                    for _ in range(20):
+                        pkg.dmv(pkg.OP_NONE, 1.0, Am, descr, xd, 0.0, ys)
+                    torch.cuda.synchronize()
+                    pkg.timer_start()
+                    for _ in range(200):
+                        pkg.dmv(pkg.OP_NONE, 1.0, Am, descr, xd, 0.0, ys)
+                    ms_strict = pkg.timer_stop() / 200
+                    strict = {"us": round(ms_strict * 1e3, 3), "roofline": roofline(spmv_bytes(mm_, mm_, nz), ms_strict),
+                              "bit_exact_every_row": bool(np.array_equal(ys.cpu().numpy(), oracle.dcsrmv(
+                                  -1, 0, 1.0, mm_, nz, v, ci, rp, xr, 0.0, np.zeros(mm_), nthreads=oracle.max_threads())[1]))}
+                finally:
+                    assert L.aoclsparse_mi355_set_option(pkg.OPTION_SPMV_STRICT, 0) == 0
             scale = np.zeros(mm_)
             nzr = lens > 0
             scale[nzr] = np.add.reduceat(np.abs(v * xr[ci]), rp[:-1][nzr])
@@ -883,8 +905,8 @@ def main():
                          "roofline": roofline(b, ms, tr, traffic_source="profiles/r2/irregular_traffic.json" if tr else None,
                                               traffic_gbs=round(tr / ms / 1e6, 1) if tr else None,
                                               traffic_frac_of_peak=round(tr / ms / 1e6 / HBM_PEAK_GBS, 4) if tr else None),
-                         "bit_exact_rows_within_tile": bool(np.array_equal(got[within], yr[within])),
-                         "rows_outside_bit_exact_regime": int((~within).sum()),
+                         "bit_exact_rows_below_tree_min": bool(np.array_equal(got[within], yr[within])), "tree_min": int(inf.tree_min),
+                         "rows_outside_bit_exact_regime": int((~within).sum()), "strict_mode": strict,
                          "long_rows_within_bound": bool(np.all(err <= bound + 1e-300)),
                          "max_abs_diff": float(err.max()),
                          "cpu_all_cores_gflops": round(2.0 * nz / float(np.median(secs)) / 1e9, 2)})

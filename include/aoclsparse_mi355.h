@@ -33,12 +33,17 @@ DLL_PUBLIC aoclsparse_status aoclsparse_mi355_set_pointer_mode(aoclsparse_mi355_
  * (environment variables) are gone -- their measurements are under profiles/.
  *   spmv_kernel  0 automatic (default: CSR-Adaptive, merge-path once the longest row spans 32 LDS tiles), 1 CSR-Adaptive,
  *                2 merge-path whenever it can serve the request
- *   sell         -1 automatic (default: SELL-64 copy for an mv hint when its padding is <= 1.35 x), 0 never, 1 always */
+ *   sell         -1 automatic (default: SELL-64 copy for an mv hint when its padding is <= 1.35 x), 0 never, 1 always
+ *   spmv_strict  0 (default): without a pinned kid, CSR-Adaptive sums a row of >= spmv_info.tree_min entries with a wavefront tree
+ *                (componentwise bound (2 ceil(log2 n) + 4) eps sum|a||x|; shorter rows are the reference's chain, bit for bit);
+ *                1: every row of every product in the reference's order, as a pinned kid does -- bit-exact everywhere, at the
+ *                price of one lane's serial chain per long row.  Read at every product (not a plan option). */
 typedef enum aoclsparse_mi355_option_
 {
     aoclsparse_mi355_option_spmv_kernel = 0,
     aoclsparse_mi355_option_sell        = 1,
-    aoclsparse_mi355_option_count       = 2
+    aoclsparse_mi355_option_spmv_strict = 2,
+    aoclsparse_mi355_option_count       = 3
 } aoclsparse_mi355_option;
 DLL_PUBLIC aoclsparse_status aoclsparse_mi355_set_option(aoclsparse_mi355_option option, aoclsparse_int value);
 /* aoclsparse_?csrmm with beta == 0.  Default (0): C is read and multiplied by zero, exactly as every kernel of the reference
@@ -197,6 +202,8 @@ typedef struct aoclsparse_mi355_spmv_info_
     aoclsparse_int mm_window_rows; /* column-major csrmm: rows per workgroup of the LDS-window kernel (banded matrices), else 0 */
     aoclsparse_int mm_bell_width; /* csrmm: 16 x 16 block slots per block row of the blocked-ELL copy (MFMA kernel), else 0 */
     aoclsparse_int mm_bell_fill_permille; /* ... and 1000 * nnz / (256 * stored blocks) */
+    aoclsparse_int tree_min; /* CSR-Adaptive, scalar order, no pinned kid, spmv_strict 0: rows with at least this many entries are summed
+                                by a wavefront tree (stated bound) instead of the reference's chain; 0: every row is the reference's order */
 } aoclsparse_mi355_spmv_info;
 DLL_PUBLIC aoclsparse_status aoclsparse_mi355_get_spmv_info(const aoclsparse_matrix     A,
                                                             aoclsparse_operation        op,

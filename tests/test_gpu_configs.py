@@ -47,8 +47,10 @@ def test_mix_full_size_dmv_after_optimize(name):
     $MATRIX_DIR holds them, else the seeded stand-ins) against oracle.dcsrmv with the reference's dispatch rule
     (nnz <= 10 m -> scalar order, else the AVX-512 8-lane order, csrmv.hpp:326-343).
       * SELL-64 (chosen for the two uniform matrices) reproduces the dispatched order for rows of any length: bit-exact.
-      * CSR-Adaptive (the two power-law matrices): rows inside one LDS tile bit-exact; a row longer than a tile is
-        reduced by a wavefront tree in auto mode: |d| <= (2 ceil(log2 n) + 4 + n/256) eps sum|a x|."""
+      * CSR-Adaptive (the two power-law matrices): rows of fewer than info.tree_min (32) entries bit-exact; a longer row is
+        reduced by a wavefront tree in auto mode (round 5: inside an LDS tile too -- as one lane's chain a 300-entry row was the
+        kernel's tail): |d| <= (2 ceil(log2 n) + 4 + n/256) eps sum|a x|.  aoclsparse_mi355_set_option(spmv_strict, 1) keeps
+        every row in the reference's order: bit-exact everywhere."""
     label, m, rp, ci, v = standins.load(name)
     nnz = len(v)
     A = P.Matrix(0, m, m, rp, ci, v)
@@ -72,14 +74,25 @@ def test_mix_full_size_dmv_after_optimize(name):
         if info.kernel in (3, 4):
             assert np.array_equal(got, yr)
         else:
-            short = lens <= info.tile
+            assert info.tree_min == 32
+            short = lens < info.tree_min
             assert np.array_equal(got[short], yr[short])
             scale = np.zeros(m)
             nz = lens > 0
             scale[nz] = np.add.reduceat(np.abs(v * x[ci]), rp[:-1][nz])
             bound = (2 * np.ceil(np.log2(np.maximum(lens, 2))) + 4 + lens / 256.0) * EPS64 * abs(alpha) * scale
             assert np.all(np.abs(got - yr)[~short] <= bound[~short] + 2 * EPS64 * np.abs(beta * y0[~short]))
-            assert (~short).sum() == info.long_rows
+            assert (lens > info.tile).sum() == info.long_rows
+            # strict mode: the reference's order for every row, long ones included
+            assert L.aoclsparse_mi355_set_option(P.OPTION_SPMV_STRICT, 1) == 0
+            try:
+                assert A.spmv_info().tree_min == 0
+                ys = dev(y0)
+                assert P.dmv(P.OP_NONE, alpha, A, d, dev(x), beta, ys) == 0
+                torch.cuda.synchronize()
+                assert np.array_equal(ys.cpu().numpy(), yr)
+            finally:
+                assert L.aoclsparse_mi355_set_option(P.OPTION_SPMV_STRICT, 0) == 0
 
 
 # --------------------------------------------------------------------------------------------------
@@ -292,7 +305,7 @@ def test_bench_single_process_small_legs(tmp_path):
         assert k in legs and "error" not in legs[k], (k, legs.get(k))
     assert legs["dcsrmv_csr_adaptive"]["bit_exact_vs_headline_y"] and legs["dcsrmv_csr_adaptive"]["roofline"]["frac"] > 0
     for row in legs["mix"]["matrices"]:
-        assert row["bit_exact_rows_within_tile"] and row["long_rows_within_bound"] and row["roofline"]["frac"] > 0
+        assert row["bit_exact_rows_below_tree_min"] and row["long_rows_within_bound"] and row["roofline"]["frac"] > 0
     kid_cases = 0
     for c in legs["csrmm"]["cases"]:
         assert c["roofline"]["frac"] > 0
@@ -777,7 +790,8 @@ def test_device_pointer_calls_can_be_captured_in_a_hip_graph():
 def test_heavy_first_block_order_is_bit_identical():
     """row blocks that hold a long row are handed to the first workgroups (SpmvPlan::rowblocks4): same blocks, same
     per-row chains -- the product must stay bit-identical to the serial scalar-order reference, through a handle and
-    through the raw-array entry, for base 0 and 1"""
+    through the raw-array entry, for base 0 and 1 (strict mode: every row a chain; the automatic mode's rows of fewer than 32
+    entries are compared too)"""
     from util import powerlaw_rows
     m = 120000
     for base in (0, 1):
@@ -791,13 +805,22 @@ def test_heavy_first_block_order_is_bit_identical():
         d = P.Descr(base=base)
         assert L.aoclsparse_set_mv_hint(A.h, P.OP_NONE, d.h, 100) == 0 and L.aoclsparse_optimize(A.h) == 0
         assert A.spmv_info().kernel == 1  # csr-adaptive (not SELL, not merge-path)
+        short = np.diff(rp) < 32
         yd = dev(y0)
         assert P.dmv(P.OP_NONE, 1.5, A, d, dev(x), -0.5, yd) == 0
         torch.cuda.synchronize()
-        assert np.array_equal(yd.cpu().numpy(), yr), base
-        yh = y0.copy()
-        assert P.dcsrmv(P.OP_NONE, 1.5, m, m, len(v), v, ci, rp, d, x, -0.5, yh) == 0
-        assert np.array_equal(yh, yr), base
+        assert np.array_equal(yd.cpu().numpy()[short], yr[short]), base
+        assert L.aoclsparse_mi355_set_option(P.OPTION_SPMV_STRICT, 1) == 0
+        try:
+            yd = dev(y0)
+            assert P.dmv(P.OP_NONE, 1.5, A, d, dev(x), -0.5, yd) == 0
+            torch.cuda.synchronize()
+            assert np.array_equal(yd.cpu().numpy(), yr), base
+            yh = y0.copy()
+            assert P.dcsrmv(P.OP_NONE, 1.5, m, m, len(v), v, ci, rp, d, x, -0.5, yh) == 0
+            assert np.array_equal(yh, yr), base
+        finally:
+            assert L.aoclsparse_mi355_set_option(P.OPTION_SPMV_STRICT, 0) == 0
 
 
 def test_optimize_selects_merge_path_for_very_long_rows():

@@ -115,13 +115,14 @@ def test_power_law_rows_with_long_rows_strict_and_auto():
     x = np.random.default_rng(7).uniform(-1, 1, n)
     y0 = np.zeros(m)
     d = P.Descr()
-    # auto: rows that fit a tile are bit-exact, long rows within the componentwise bound
+    # auto: rows of fewer than tree_min (32) entries are bit-exact, longer rows within the componentwise bound
     A = P.Matrix(0, m, n, rp, ci, v)
     st, y = run_dmv(A, d, x, y0, 1.0, 0.0)
-    assert st == 0 and A.spmv_info().long_rows == 3
+    assert st == 0 and A.spmv_info().long_rows == 3 and A.spmv_info().tree_min == 32
     so, yr = oracle.dcsrmv(-1, 0, 1.0, m, len(v), v, ci, rp, x, 0.0, y0)
     lens = np.diff(rp)
-    short = lens <= A.spmv_info().tile
+    short = lens < A.spmv_info().tree_min
+    assert short.sum() > 0.9 * m and (~short).sum() > 50
     assert np.array_equal(y[short], yr[short])
     scale = abs_row_sums(rp, ci, v, x)
     c = 2 * np.ceil(np.log2(np.maximum(lens, 2))) + 4 + lens / 256.0  # tree + 256 partial chains
@@ -130,7 +131,14 @@ def test_power_law_rows_with_long_rows_strict_and_auto():
     B = P.Matrix(0, m, n, rp, ci, v)
     assert L.aoclsparse_set_mv_hint_kid(B.h, P.OP_NONE, d.h, 0, 0) == 0
     st, ys = run_dmv(B, d, x, y0, 1.0, 0.0)
-    assert st == 0 and np.array_equal(ys, yr)
+    assert st == 0 and np.array_equal(ys, yr) and B.spmv_info().tree_min == 0
+    # ... and so does the strict option on the un-pinned handle
+    assert L.aoclsparse_mi355_set_option(P.OPTION_SPMV_STRICT, 1) == 0
+    try:
+        st, ys = run_dmv(A, d, x, y0, 1.0, 0.0)
+        assert st == 0 and np.array_equal(ys, yr)
+    finally:
+        assert L.aoclsparse_mi355_set_option(P.OPTION_SPMV_STRICT, 0) == 0
 
 
 def _merge_cut_rows(rp, base, items=1024):
@@ -2979,7 +2987,11 @@ def test_add_bit_exact_vs_oracle(base_a, base_b):
         y = np.zeros(m)
         dC = P.Descr(base=base_a)
         one, zero = ctypes.c_double(1.0), ctypes.c_double(0.0)
-        assert L.aoclsparse_dmv(P.OP_NONE, ctypes.byref(one), C, dC.h, P._ptr(x), ctypes.byref(zero), P._ptr(y)) == 0
+        assert L.aoclsparse_mi355_set_option(P.OPTION_SPMV_STRICT, 1) == 0  # rows of 200-350 entries: the reference's chain
+        try:
+            assert L.aoclsparse_dmv(P.OP_NONE, ctypes.byref(one), C, dC.h, P._ptr(x), ctypes.byref(zero), P._ptr(y)) == 0
+        finally:
+            assert L.aoclsparse_mi355_set_option(P.OPTION_SPMV_STRICT, 0) == 0
         so, yr = oracle.dcsrmv(-1, base_a, 1.0, m, len(vc), vc, ic, pc, x, 0.0, np.zeros(m))
         assert np.array_equal(y, yr)
         assert L.aoclsparse_destroy(ctypes.byref(C)) == 0
