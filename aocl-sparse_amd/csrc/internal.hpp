@@ -311,15 +311,22 @@ struct MmGroups
 };
 
 // merge-path tiling of a device CSR (mergepath_kernels.hip): tile w starts at {row ends, non-zeros} =
-// starts[2w], starts[2w+1]; two carry records per tile
+// starts[2w], starts[2w+1]
 constexpr int MP_ITEMS = 1024; // rows + non-zeros per workgroup
 constexpr int SELL_PROMOTE_CALLS = 8; // an un-hinted handle gets its SELL-64 copy at this many products
 struct MergePlan
 {
     aoclsparse_int ntiles = 0;
     DeviceBuffer   starts; // (ntiles + 1) x {i, j}
-    DeviceBuffer   carry_row, carry_val; // 2 * ntiles each
+    DeviceBuffer   first; // ntiles: first tile that holds a head piece of the row whose END lies in tile w, or -1
+    DeviceBuffer   granules; // 2 * ntiles x u64: tile w's head piece as {launch epoch << 32 | half of the value} (zeroed once)
     bool           valid = false, tried = false;
+    // launch bookkeeping (mutable: products run on a const plan under the handle's shared lock): the epoch tags a launch's
+    // granules; `lock` makes {take an epoch, enqueue} one step, and a launch on another stream than the last one first waits for
+    // that one (two launches in flight at once would overwrite each other's granules)
+    mutable std::mutex launch_lock;
+    mutable unsigned   epoch       = 0;
+    mutable void      *last_stream = nullptr;
 };
 
 // Blocked-ELL copy of a block-dense matrix for the MFMA csrmm (csrmm_bell_kernels.hip; round 4): 16 x 16 blocks, `width` block
@@ -716,8 +723,9 @@ aoclsparse_status launch_blkcsrmv(hipStream_t s, int base, double alpha, aoclspa
                                   const aoclsparse_int *valoff, const double *x, double beta, double *y);
 template <typename T>
 aoclsparse_status launch_mergepath(hipStream_t s, int base, T alpha, aoclsparse_int ntiles, const aoclsparse_int *starts,
-                                   const T *val, const aoclsparse_int *col, const aoclsparse_int *row_ptr, const T *x,
-                                   T beta, T *y, aoclsparse_int *carry_row, T *carry_val);
+                                   const aoclsparse_int *first, const T *val, const aoclsparse_int *col,
+                                   const aoclsparse_int *row_ptr, const T *x, T beta, T *y, unsigned long long *granules,
+                                   unsigned epoch);
 template <typename T>
 aoclsparse_status launch_scale(hipStream_t s, T *y, aoclsparse_int n, T beta);
 // w = a*x + b*y elementwise (w may alias x or y); a == 1, b == -1 is an exact subtraction

@@ -773,7 +773,7 @@ aoclsparse_status build_sell(const aoclsparse_int *row_ptr_host, const DeviceCsr
     return aoclsparse_status_success;
 }
 
-constexpr int MERGE_AUTO_TILES = 32; // auto: merge-path once the longest row spans this many LDS tiles
+constexpr int MERGE_AUTO_TILES = 16; // auto: merge-path once the longest row spans this many LDS tiles (32 until round 5)
 // 0 auto, 1 CSR-Adaptive always, 2 merge-path whenever it can serve the request
 // (read at plan-build time, i.e. once per handle and operator)
 static int spmv_kernel_choice()
@@ -793,10 +793,12 @@ aoclsparse_status build_merge_plan(aoclsparse_int m, aoclsparse_int nnz, aoclspa
         return aoclsparse_status_success;
     // Automatic choice (aoclsparse_optimize / first product, from the row-length statistics of the row-block plan):
     // the row-block kernel gives a row longer than one LDS tile to ONE workgroup, which walks it tile by tile --
-    // fine for rows of a few tiles (web-like: longest row 2,908 = 6 tiles; merge-path loses there, 44.2 vs 29.5 us,
-    // and on circuit-like, 14.3 vs 11.4 us), a serial tail once a row spans tens of tiles.  Merge-path cuts such rows
-    // into 1,024-item pieces spread over the chip, so it is selected when the longest row exceeds
-    // MERGE_AUTO_TILES tiles (tools/exp_arrow.py, profiles/r2/merge_vs_adaptive.jsonl).
+    // fine for rows of a few tiles (web-like: longest row 2,908 = 6 tiles; merge-path loses there, 29.8 vs 25.0 us,
+    // and on circuit-like, 8.8 vs 7.3 us), a serial tail once a row spans tens of tiles.  Merge-path cuts such rows
+    // into 1,024-item pieces spread over the chip, so it is selected when the longest row exceeds MERGE_AUTO_TILES tiles.
+    // Round 5 (one launch, wavefront trees for the pieces; tools/exp_arrow.py, profiles/r5/merge_vs_adaptive.jsonl; adaptive /
+    // merge, us): 1 row of 300 k 125 / 9.8; 4 x 250 k 114 / 12.4; 16 x 64 k 48 / 14.4; 64 x 16 k 24.9 / 16.9; 256 x 4 k
+    // 15.6 / 18.8; 1,024 x 1 k 15.5 / 19.1 -- the crossover lies between rows of 8 and 32 tiles.
     constexpr int auto_tiles = MERGE_AUTO_TILES;
     const bool auto_pick = choice == 0 && auto_tiles > 0 && plan.long_rows > 0
                            && (long long)plan.max_row_nnz >= (long long)auto_tiles * (plan.tile & ~1);
@@ -829,14 +831,44 @@ aoclsparse_status build_merge_plan(aoclsparse_int m, aoclsparse_int nnz, aoclspa
         st[2 * (size_t)w]     = (aoclsparse_int)lo;
         st[2 * (size_t)w + 1] = (aoclsparse_int)(d - lo);
     }
+    // first[w]: tile w holds the END of a row that started in an earlier tile -> the first tile with a (non-empty) head piece of
+    // that row; -1 otherwise.  Tile v's head piece belongs to the row its successor starts in (st[2(v+1)]), and is non-empty
+    // when the tile ends past that row's first entry.  Each tile is visited by at most one row's walk: O(ntiles).
+    std::vector<aoclsparse_int> first;
+    try
+    {
+        first.assign((size_t)ntiles, -1);
+    }
+    catch(const std::bad_alloc &)
+    {
+        return aoclsparse_status_memory_error;
+    }
+    for(aoclsparse_int w = 1; w < ntiles; w++)
+    {
+        const aoclsparse_int i0 = st[2 * (size_t)w], j0 = st[2 * (size_t)w + 1];
+        if(st[2 * (size_t)w + 2] == i0 || i0 >= m) // no row ends in this tile
+            continue;
+        const aoclsparse_int rowstart = ptr[i0] - base;
+        if(rowstart >= j0) // row i0 starts here
+            continue;
+        aoclsparse_int f = w - 1;
+        while(f > 0 && st[2 * (size_t)f] == i0 && st[2 * (size_t)f + 1] > rowstart)
+            f--;
+        first[w] = f;
+    }
+    (void)vsize;
     Runtime          &rt = Runtime::get();
     aoclsparse_status s1 = mp.starts.upload(st.data(), sizeof(aoclsparse_int) * st.size(), rt.stream());
     if(s1 == aoclsparse_status_success)
-        s1 = mp.carry_row.alloc(sizeof(aoclsparse_int) * 2 * (size_t)ntiles);
+        s1 = mp.first.upload(first.data(), sizeof(aoclsparse_int) * first.size(), rt.stream());
     if(s1 == aoclsparse_status_success)
-        s1 = mp.carry_val.alloc(vsize * 2 * (size_t)ntiles);
+        s1 = mp.granules.alloc(sizeof(unsigned long long) * 2 * (size_t)ntiles);
     if(s1 != aoclsparse_status_success)
         return s1;
+    // epoch tags start at 1: zeroed granules match no launch.  (uploads read the host vectors until the stream has run them)
+    MI355_HIP_TRY(hipMemsetAsync(mp.granules.ptr, 0, sizeof(unsigned long long) * 2 * (size_t)ntiles, rt.stream()));
+    MI355_HIP_TRY(hipStreamSynchronize(rt.stream()));
+    mp.epoch = 0, mp.last_stream = nullptr;
     mp.ntiles = ntiles;
     mp.valid  = true;
     return aoclsparse_status_success;

@@ -121,10 +121,25 @@ aoclsparse_status run_on_device_csr(Runtime &rt, aoclsparse_int kid, const Devic
                               static_cast<T *>(ay.dev), plan.sell.shared ? plan.sell.cptr.as<long long>() : nullptr,
                               plan.sell.shared ? plan.sell.lead.as<unsigned short>() : nullptr, plan.max_row_nnz);
     else if(plan.merge.valid && order == 0 && !strict) // balanced tiles for irregular rows (scalar order, no pinned kid)
-        st = launch_mergepath<T>(rt.stream(), d.base, alpha, plan.merge.ntiles, plan.merge.starts.as<aoclsparse_int>(),
+    {
+        // one launch; its head pieces are tagged with an epoch that no earlier launch on this plan used.  Taking the epoch and
+        // enqueueing are one step, and the plan's granules serve one launch at a time: a launch on another stream than the
+        // previous one waits for that one first (same stream: stream order does it).
+        const MergePlan            &mp = plan.merge;
+        std::lock_guard<std::mutex> g(mp.launch_lock);
+        if(mp.last_stream && mp.last_stream != (void *)rt.stream())
+            MI355_HIP_TRY(hipStreamSynchronize((hipStream_t)mp.last_stream));
+        if(++mp.epoch == 0) // wrapped: forget every old tag
+        {
+            MI355_HIP_TRY(hipMemsetAsync(mp.granules.ptr, 0, sizeof(unsigned long long) * 2 * (size_t)mp.ntiles, rt.stream()));
+            mp.epoch = 1;
+        }
+        mp.last_stream = (void *)rt.stream();
+        st = launch_mergepath<T>(rt.stream(), d.base, alpha, mp.ntiles, mp.starts.as<aoclsparse_int>(), mp.first.as<aoclsparse_int>(),
                                  d.val.as<T>(), d.ind.as<aoclsparse_int>(), d.ptr.as<aoclsparse_int>(),
                                  static_cast<const T *>(ax.dev), beta, static_cast<T *>(ay.dev),
-                                 plan.merge.carry_row.as<aoclsparse_int>(), plan.merge.carry_val.as<T>());
+                                 mp.granules.as<unsigned long long>(), mp.epoch);
+    }
     else
         st = launch_csrmv<T>(rt.stream(), order, strict, plan.tile, d.base, alpha, d.m, d.val.as<T>(),
                              d.ind.as<aoclsparse_int>(), d.ptr.as<aoclsparse_int>(),
@@ -635,7 +650,7 @@ aoclsparse_status aoclsparse_mi355_get_spmv_info(const aoclsparse_matrix A, aocl
     info->order = order;
     if(plan_option(aoclsparse_mi355_option_spmv_strict) == 1)
         strict = true;
-    info->tree_min = (info->kernel == 1 && order == 0 && !strict) ? SPMV_TREE_MIN : 0;
+    info->tree_min = ((info->kernel == 1 || info->kernel == 2) && order == 0 && !strict) ? SPMV_TREE_MIN : 0;
     return aoclsparse_status_success;
 }
 

@@ -166,9 +166,9 @@ def merge_kernel():
 
 @pytest.mark.parametrize("base", [0, 1])
 def test_merge_path_kernel_power_law(merge_kernel, base):
-    """merge-path tiles (aoclsparse_mi355_set_option(spmv_kernel, 2)): rows inside one tile follow the reference's scalar
-    order bit for bit; a row cut by tile boundaries is the ordered sum of its pieces' chains -- bound
-    (pieces + len) * eps * sum|a||x|."""
+    """merge-path tiles (aoclsparse_mi355_set_option(spmv_kernel, 2)): rows of fewer than tree_min (32) entries inside one tile
+    follow the reference's scalar order bit for bit; a longer row, and a row cut by tile boundaries (the fixed-order sum of its
+    pieces, combined by the look-back of the ONE launch, round 5), stay within (pieces + len) * eps * sum|a||x|."""
     m = n = 30000
     rp, ci, v = random_csr(121, m, n, lambda r, i: 9000 if i in (0, 17, 20011) else (
         2500 if i == m - 1 else (0 if i % 7 == 3 else powerlaw_rows(6, 400)(r, i))), base=base)
@@ -183,8 +183,10 @@ def test_merge_path_kernel_power_law(merge_kernel, base):
         so, yr = oracle.dcsrmv(-1, base, alpha, m, len(v), v, ci, rp, x, beta, y0)
         cut = _merge_cut_rows(rp, base)
         assert 3 <= cut.sum() < 200
-        assert np.array_equal(y[~cut], yr[~cut])
         lens = np.diff(rp)
+        assert A.spmv_info().tree_min == 32
+        exact = ~cut & (lens < 32)
+        assert exact.sum() > 0.9 * m and np.array_equal(y[exact], yr[exact])
         scale = abs(alpha) * abs_row_sums(rp, ci, v, x, base) + abs(beta * y0)
         c = lens + lens / 1024.0 + 6
         assert np.all(np.abs(y - yr) <= c * EPS64 * scale + 1e-300)
@@ -213,7 +215,8 @@ def test_merge_path_kernel_edges(merge_kernel):
         so, yr = oracle.dcsrmv(-1, 0, 2.0, m, int(rp[-1]), v, ci, rp, x, 0.5, y0)
         assert st == 0
         cut = _merge_cut_rows(rp, 0) if rp[-1] > 0 else np.zeros(m, bool)
-        assert np.array_equal(y[~cut], yr[~cut])
+        exact = ~cut & (np.diff(rp) < 32)
+        assert np.array_equal(y[exact], yr[exact])
         scale = 2.0 * abs_row_sums(rp, ci, v, x) + abs(0.5 * y0)
         assert np.all(np.abs(y - yr) <= (np.diff(rp) + 24) * EPS64 * scale + 1e-300)
     # a wide matrix (nnz > 10 m) runs the lane orders: the row-block kernel serves it, bit-exact

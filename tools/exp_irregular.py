@@ -10,7 +10,11 @@ import __graft_entry__ as entry, standins, oracle
 pkg = entry.load_package(); L = pkg.lib()
 L.aoclsparse_mi355_set_pointer_mode(pkg.PTR_DEVICE)
 dev = torch.device("cuda", 0)
-names = sys.argv[1:] or ["circuit-like", "web-like"]
+args = sys.argv[1:]
+if args and args[0].startswith("--kernel="):  # --kernel=merge | adaptive: force one CSR kernel (default: the automatic choice)
+    assert L.aoclsparse_mi355_set_option(pkg.OPTION_SPMV_KERNEL, {"adaptive": 1, "merge": 2}[args[0].split("=")[1]]) == 0
+    args = args[1:]
+names = args or ["circuit-like", "web-like"]
 env = {k: v for k, v in os.environ.items() if k.startswith("AOCLSPARSE_MI355_")}
 for name in names:
     label, m, rp, ci, v = standins.load(name)
