@@ -67,15 +67,9 @@ aoclsparse_status csr2csc(aoclsparse_int m, aoclsparse_int n, aoclsparse_int nnz
                 st = ii.upload(ind, sizeof(aoclsparse_int) * (size_t)nnz, s);
             if(st == aoclsparse_status_success)
                 st = iv.upload(val, sizeof(T) * (size_t)nnz, s);
-            if(st == aoclsparse_status_success)
-                st = op.alloc(sizeof(aoclsparse_int) * ((size_t)n + 1));
-            if(st == aoclsparse_status_success)
-                st = oi.alloc(sizeof(aoclsparse_int) * (size_t)nnz);
-            if(st == aoclsparse_status_success)
-                st = ov.alloc(sizeof(T) * (size_t)nnz);
-            if(st == aoclsparse_status_success)
-                st = device_transpose(s, m, n, nnz, base_in, ip.as<aoclsparse_int>(), ii.as<aoclsparse_int>(), iv.ptr, sizeof(T),
-                                      op.as<aoclsparse_int>(), oi.as<aoclsparse_int>(), ov.ptr);
+            if(st == aoclsparse_status_success) // (allocates op / oi / ov once the column histogram has accepted the matrix)
+                st = device_transpose(s, m, n, nnz, base_in, ip.as<aoclsparse_int>(), ii.as<aoclsparse_int>(), iv.ptr, sizeof(T), op,
+                                      oi, ov);
             if(st == aoclsparse_status_success
                && hipMemcpyAsync(optr, op.ptr, sizeof(aoclsparse_int) * ((size_t)n + 1), hipMemcpyDeviceToHost, s) == hipSuccess
                && hipMemcpyAsync(oind, oi.ptr, sizeof(aoclsparse_int) * (size_t)nnz, hipMemcpyDeviceToHost, s) == hipSuccess

@@ -532,6 +532,7 @@ public:
     // secondary slot idx >= 1 bound to HIP device `dev` (created on first use; own stream, staging buffers and pinned words).
     // Two slots may name the same device: that is how the multi-device control flow is tested on a one-GPU box.
     static Runtime *slot(int idx, int dev);
+    static std::vector<Runtime *> secondary(); // the slots created so far
     aoclsparse_status init(); // lazy; internal_error when no device; binds the calling thread to `device`
     void              bind_thread();
     hipStream_t       stream() const
@@ -658,11 +659,12 @@ aoclsparse_status csc_refresh_csr(aoclsparse_matrix A);
 aoclsparse_status ilu_prepare(aoclsparse_matrix A);
 // builds A->trans (host transpose of the user CSR, 0-based) if absent
 aoclsparse_status build_transpose(aoclsparse_matrix A);
-// B = A^T of a device CSR in the reference's counting-sort order (transpose_kernels.hip); aoclsparse_status_not_implemented when
-// a column is too long for the device sort (the caller sorts on the host)
+// B = A^T of a device CSR in the reference's counting-sort order (transpose_kernels.hip), into buffers it allocates once the matrix
+// is accepted; aoclsparse_status_not_implemented when a column is too long for the device sort (the caller sorts on the host; the
+// three buffers are then empty)
 aoclsparse_status device_transpose(hipStream_t s, aoclsparse_int m, aoclsparse_int n, aoclsparse_int nnz, int base,
                                    const aoclsparse_int *d_ptr, const aoclsparse_int *d_ind, const void *d_val, size_t vsize,
-                                   aoclsparse_int *tptr, aoclsparse_int *tind, void *tval);
+                                   DeviceBuffer &tptr, DeviceBuffer &tind, DeviceBuffer &tval);
 
 // ---- device mirrors / plans ---------------------------------------------------------------------
 size_t            val_size(aoclsparse_matrix_data_type t);

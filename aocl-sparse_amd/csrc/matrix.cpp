@@ -431,16 +431,10 @@ aoclsparse_status build_transpose(aoclsparse_matrix A)
             if(st == aoclsparse_status_success && !A->dev_user.valid)
                 st = upload_csr(A->user, vs, A->dev_user);
             DeviceCsr &dt = A->dev_trans;
-            if(st == aoclsparse_status_success)
-                st = dt.ptr.alloc(sizeof(aoclsparse_int) * ((size_t)t->m + 1));
-            if(st == aoclsparse_status_success)
-                st = dt.ind.alloc(sizeof(aoclsparse_int) * nz);
-            if(st == aoclsparse_status_success)
-                st = dt.val.alloc(vs * nz);
-            if(st == aoclsparse_status_success)
+            if(st == aoclsparse_status_success) // (dt.ptr / ind / val are allocated by the call once the matrix is accepted, and
+                                                // released again on decline or failure: nothing is held while the host sorts)
                 st = device_transpose(rt.stream(), A->m, A->n, A->nnz, A->base, A->dev_user.ptr.as<aoclsparse_int>(),
-                                      A->dev_user.ind.as<aoclsparse_int>(), A->dev_user.val.ptr, vs, dt.ptr.as<aoclsparse_int>(),
-                                      dt.ind.as<aoclsparse_int>(), dt.val.ptr);
+                                      A->dev_user.ind.as<aoclsparse_int>(), A->dev_user.val.ptr, vs, dt.ptr, dt.ind, dt.val);
             if(st == aoclsparse_status_success)
             {
                 host_result_touch(t->ind, sizeof(aoclsparse_int) * nz);
@@ -457,7 +451,10 @@ aoclsparse_status build_transpose(aoclsparse_matrix A)
                 }
             }
             if(!on_device)
+            {
                 (void)hipGetLastError(); // (declined or failed: the host sort below serves the handle)
+                dt.ptr.release(), dt.ind.release(), dt.val.release();
+            }
         }
         if(!on_device)
             dispatch_value_type(A->val_type, [&](auto tag) {

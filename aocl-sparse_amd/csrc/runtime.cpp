@@ -143,14 +143,37 @@ Runtime &Runtime::get()
     return tl_runtime ? *tl_runtime : primary();
 }
 
-Runtime *Runtime::slot(int idx, int dev)
+namespace
 {
     // secondary runtimes live for the life of the process (like the primary one)
-    static std::mutex              m;
-    static std::vector<Runtime *> slots;
+    std::mutex &slot_mutex()
+    {
+        static std::mutex m;
+        return m;
+    }
+    std::vector<Runtime *> &slot_table()
+    {
+        static std::vector<Runtime *> slots;
+        return slots;
+    }
+}
+
+std::vector<Runtime *> Runtime::secondary()
+{
+    std::lock_guard<std::mutex> g(slot_mutex());
+    std::vector<Runtime *>      out;
+    for(Runtime *r : slot_table())
+        if(r)
+            out.push_back(r);
+    return out;
+}
+
+Runtime *Runtime::slot(int idx, int dev)
+{
+    std::vector<Runtime *> &slots = slot_table();
     if(idx < 1 || idx > 63 || dev < 0)
         return nullptr;
-    std::lock_guard<std::mutex> g(m);
+    std::lock_guard<std::mutex> g(slot_mutex());
     if((int)slots.size() <= idx)
         slots.resize((size_t)idx + 1, nullptr);
     if(!slots[idx])
@@ -391,7 +414,15 @@ aoclsparse_status aoclsparse_mi355_set_csrmm_beta0_overwrite(int overwrite)
 
 aoclsparse_status aoclsparse_mi355_release_staging(size_t *bytes_freed)
 {
-    const size_t f = Runtime::get().release_staging();
+    // process-wide: the primary runtime (every host thread stages through it, under its stage_lock) and the secondary slots of
+    // the multi-device calls, each synchronised and freed with the thread bound to its own device
+    size_t f = Runtime::primary().release_staging();
+    for(Runtime *r : Runtime::secondary())
+    {
+        RuntimeScope scope(r);
+        if(scope.status == aoclsparse_status_success)
+            f += r->release_staging();
+    }
     if(bytes_freed)
         *bytes_freed = f;
     return aoclsparse_status_success;

@@ -509,11 +509,6 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
             if(d->m != m || d->n != n)
                 return aoclsparse_status_invalid_size; // csr2m.cpp:397-399
             const aoclsparse_int nnz_c = d->ptr[m];
-            // whatever the handle derived from an earlier fill (device copies, plans, SELL twin, replicas) mirrors the old values
-            // (the (B A)^T scratch of stage 1 lives in c->trans, which invalidate would drop: carried across)
-            auto keep = std::move(c->trans);
-            (void)aoclsparse_mi355_invalidate(c);
-            c->trans = std::move(keep);
             // rows binned by their exact count: the counts of stage 1 are still in HBM after a full computation, a finalize call
             // sends the handle's row_ptr; either way they are checked against the upper bounds on the device (bin_rows)
             if(!ptr_on_device)
@@ -536,6 +531,24 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
             st = run_pass(true, by_count, d_cptr.as<aoclsparse_int>(), d_ci.as<aoclsparse_int>(), d_cv.as<T>());
             if(st != aoclsparse_status_success)
                 return st;
+            unsigned int bad = 0;
+            if(!ptr_on_device)
+            {
+                // finalize-only call: the row_ptr is whatever the caller's handle holds.  The verdict of the device checks is read
+                // BEFORE anything of *C is touched, so a refused call (the row_ptr of another product) leaves the caller's handle --
+                // its arrays, its device copy, its plans -- exactly as it was
+                MI355_HIP_TRY(hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, s));
+                MI355_HIP_TRY(hipStreamSynchronize(s));
+                if(bad)
+                    return aoclsparse_status_invalid_value;
+            }
+            // whatever the handle derived from an earlier fill (device copies, plans, SELL twin, replicas) mirrors the old values
+            // (the (B A)^T scratch of stage 1 lives in c->trans, which invalidate would drop: carried across)
+            {
+                auto keep = std::move(c->trans);
+                (void)aoclsparse_mi355_invalidate(c);
+                c->trans = std::move(keep);
+            }
             // while the kernels run: the result's host arrays are first-touched by several threads (host_result_alloc; faulted in
             // by the copy itself they cost more than the copy: 7-13 ms for 156 MB against ~3); the values' pages are touched while
             // the column indices already travel
@@ -555,8 +568,8 @@ aoclsparse_status sp2m_t(aoclsparse_operation opA, const aoclsparse_mat_descr de
                 toucher.join();
             MI355_HIP_TRY(e1);
             MI355_HIP_TRY(hipMemcpyAsync(d->val, d_cv.ptr, sizeof(T) * (size_t)nnz_c, hipMemcpyDeviceToHost, s));
-            unsigned int bad = 0;
-            MI355_HIP_TRY(hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, s));
+            if(ptr_on_device) // (full computation: the counts are this product's own, the word is read with the result)
+                MI355_HIP_TRY(hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, s));
             MI355_HIP_TRY(hipStreamSynchronize(s));
             if(bad) // the row_ptr of *C is not the one stage 1 of THIS product returned (a row ended short of, or beyond, its segment)
                 return aoclsparse_status_invalid_value;

@@ -30,21 +30,41 @@ namespace mi355
 
 namespace
 {
+    constexpr int TR_ROW_WAVE = 128; // rows longer than this are walked by a wavefront
     // (a column index outside [0, n) raises *bad and is skipped: the caller then declines -- nothing is ever written out of range)
     __global__ __launch_bounds__(256) void tr_count_kernel(aoclsparse_int m, aoclsparse_int n, int base,
                                                            const aoclsparse_int *__restrict__ ptr,
                                                            const aoclsparse_int *__restrict__ ind, int *cnt, unsigned int *bad)
     {
-        const int i = blockIdx.x * 256 + threadIdx.x;
-        if(i >= m)
-            return;
-        for(int p = ptr[i] - base; p < ptr[i + 1] - base; p++)
+        // a lane per row; a row of more than TR_ROW_WAVE entries is walked by its whole wavefront instead (as one lane's loop a
+        // 190 k-entry row of a power-law matrix was the kernel: ADVICE r4)
+        const int  i   = blockIdx.x * 256 + threadIdx.x;
+        const bool act = i < m;
+        const int  s = act ? ptr[i] - base : 0, e = act ? ptr[i + 1] - base : 0;
+        const bool lng = e - s > TR_ROW_WAVE;
+        if(!lng)
+            for(int p = s; p < e; p++)
+            {
+                const int c = ind[p] - base;
+                if((unsigned)c >= (unsigned)n)
+                    atomicOr(bad, 1u);
+                else
+                    atomicAdd(&cnt[c], 1);
+            }
+        unsigned long long mask = __ballot(lng);
+        while(mask)
         {
-            const int c = ind[p] - base;
-            if((unsigned)c >= (unsigned)n)
-                atomicOr(bad, 1u);
-            else
-                atomicAdd(&cnt[c], 1);
+            const int l = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const int ls = __builtin_amdgcn_readlane(s, l), le = __builtin_amdgcn_readlane(e, l);
+            for(int p = ls + (int)(threadIdx.x & 63); p < le; p += 64)
+            {
+                const int c = ind[p] - base;
+                if((unsigned)c >= (unsigned)n)
+                    atomicOr(bad, 1u);
+                else
+                    atomicAdd(&cnt[c], 1);
+            }
         }
     }
 
@@ -53,14 +73,30 @@ namespace
                                                              const aoclsparse_int *__restrict__ tptr, int *cursor,
                                                              int *__restrict__ tpos, aoclsparse_int *__restrict__ trow)
     {
-        const int i = blockIdx.x * 256 + threadIdx.x;
-        if(i >= m)
-            return;
-        for(int p = ptr[i] - base; p < ptr[i + 1] - base; p++)
+        const int  i   = blockIdx.x * 256 + threadIdx.x;
+        const bool act = i < m;
+        const int  s = act ? ptr[i] - base : 0, e = act ? ptr[i + 1] - base : 0;
+        const bool lng = e - s > TR_ROW_WAVE;
+        if(!lng)
+            for(int p = s; p < e; p++)
+            {
+                const int c = ind[p] - base;
+                const int q = tptr[c] + atomicAdd(&cursor[c], 1);
+                tpos[q] = p, trow[q] = i;
+            }
+        unsigned long long mask = __ballot(lng); // (long rows: the whole wavefront, as in tr_count_kernel)
+        while(mask)
         {
-            const int c = ind[p] - base;
-            const int q = tptr[c] + atomicAdd(&cursor[c], 1);
-            tpos[q] = p, trow[q] = i;
+            const int l = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const int ls = __builtin_amdgcn_readlane(s, l), le = __builtin_amdgcn_readlane(e, l);
+            const int li = __builtin_amdgcn_readlane(i, l);
+            for(int p = ls + (int)(threadIdx.x & 63); p < le; p += 64)
+            {
+                const int c = ind[p] - base;
+                const int q = tptr[c] + atomicAdd(&cursor[c], 1);
+                tpos[q] = p, trow[q] = li;
+            }
         }
     }
 
@@ -122,22 +158,20 @@ namespace
 } // namespace
 
 // d_* : the CSR arrays of an m x n matrix in HBM (index base `base`); tptr (n + 1), tind (nnz), tval (nnz values of vsize bytes):
-// the 0-based CSR of the transpose.  aoclsparse_status_not_implemented: a column has more than 2,048 entries (nothing usable was
-// written: the caller sorts on the host).
-aoclsparse_status device_transpose(hipStream_t s, aoclsparse_int m, aoclsparse_int n, aoclsparse_int nnz, int base,
-                                   const aoclsparse_int *d_ptr, const aoclsparse_int *d_ind, const void *d_val, size_t vsize,
-                                   aoclsparse_int *tptr, aoclsparse_int *tind, void *tval)
+// the 0-based CSR of the transpose, ALLOCATED HERE once the matrix is accepted -- the column histogram comes first, so a declined
+// matrix (aoclsparse_status_not_implemented: a column of more than 2,048 entries, i.e. every power-law graph; the caller sorts on
+// the host) has cost n counters, not 12-20 bytes per entry of HBM held while the host sort runs.  On any failure the
+// three output buffers are released again.
+static aoclsparse_status device_transpose_run(hipStream_t s, aoclsparse_int m, aoclsparse_int n, aoclsparse_int nnz, int base,
+                                              const aoclsparse_int *d_ptr, const aoclsparse_int *d_ind, const void *d_val,
+                                              size_t vsize, DeviceBuffer &tptr_b, DeviceBuffer &tind_b, DeviceBuffer &tval_b)
 {
     if(m <= 0 || n <= 0 || nnz <= 0)
         return aoclsparse_status_not_implemented;
     DeviceBuffer cnt, cursor, tpos, scan, small, order;
     MI355_TRY(cnt.alloc(sizeof(int) * (size_t)n));
-    MI355_TRY(cursor.alloc(sizeof(int) * (size_t)n));
-    MI355_TRY(tpos.alloc(sizeof(int) * (size_t)nnz));
-    MI355_TRY(scan.alloc(spg_scan_scratch_bytes(n)));
     MI355_TRY(small.alloc(256));
     MI355_HIP_TRY(hipMemsetAsync(cnt.ptr, 0, sizeof(int) * (size_t)n, s));
-    MI355_HIP_TRY(hipMemsetAsync(cursor.ptr, 0, sizeof(int) * (size_t)n, s));
     MI355_HIP_TRY(hipMemsetAsync(small.ptr, 0, 256, s));
     unsigned int *d_bad = small.as<unsigned int>() + 32;
     hipLaunchKernelGGL(tr_count_kernel, dim3((m + 255) / 256), dim3(256), 0, s, m, n, base, d_ptr, d_ind, cnt.as<int>(), d_bad);
@@ -151,6 +185,16 @@ aoclsparse_status device_transpose(hipStream_t s, aoclsparse_int m, aoclsparse_i
     MI355_HIP_TRY(hipStreamSynchronize(s));
     if(bad || hist[3] + hist[4] > 0)
         return aoclsparse_status_not_implemented;
+    // accepted: now the outputs and the remaining temporaries
+    MI355_TRY(tptr_b.alloc(sizeof(aoclsparse_int) * ((size_t)n + 1)));
+    MI355_TRY(tind_b.alloc(sizeof(aoclsparse_int) * (size_t)nnz));
+    MI355_TRY(tval_b.alloc(vsize * (size_t)nnz));
+    MI355_TRY(cursor.alloc(sizeof(int) * (size_t)n));
+    MI355_TRY(tpos.alloc(sizeof(int) * (size_t)nnz));
+    MI355_TRY(scan.alloc(spg_scan_scratch_bytes(n)));
+    MI355_HIP_TRY(hipMemsetAsync(cursor.ptr, 0, sizeof(int) * (size_t)n, s));
+    aoclsparse_int *tptr = tptr_b.as<aoclsparse_int>(), *tind = tind_b.as<aoclsparse_int>();
+    void           *tval = tval_b.ptr;
     long long *total = nullptr;
     MI355_TRY(launch_spg_scan(s, n, cnt.as<int>(), tptr, scan.as<long long>(), &total));
     hipLaunchKernelGGL(tr_scatter_kernel, dim3((m + 255) / 256), dim3(256), 0, s, m, base, d_ptr, d_ind, tptr, cursor.as<int>(),
@@ -183,6 +227,16 @@ aoclsparse_status device_transpose(hipStream_t s, aoclsparse_int m, aoclsparse_i
     MI355_HIP_TRY(hipGetLastError());
     MI355_HIP_TRY(hipStreamSynchronize(s)); // (the temporaries above go away)
     return aoclsparse_status_success;
+}
+
+aoclsparse_status device_transpose(hipStream_t s, aoclsparse_int m, aoclsparse_int n, aoclsparse_int nnz, int base,
+                                   const aoclsparse_int *d_ptr, const aoclsparse_int *d_ind, const void *d_val, size_t vsize,
+                                   DeviceBuffer &tptr, DeviceBuffer &tind, DeviceBuffer &tval)
+{
+    const aoclsparse_status st = device_transpose_run(s, m, n, nnz, base, d_ptr, d_ind, d_val, vsize, tptr, tind, tval);
+    if(st != aoclsparse_status_success)
+        tptr.release(), tind.release(), tval.release();
+    return st;
 }
 
 } // namespace mi355

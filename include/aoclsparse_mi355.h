@@ -227,7 +227,8 @@ DLL_PUBLIC aoclsparse_status aoclsparse_mi355_trsv_status(aoclsparse_matrix A);
 DLL_PUBLIC aoclsparse_status aoclsparse_mi355_set_trsv_schedule(aoclsparse_int schedule);
 /* drop every device-side copy/plan of the handle (call after mutating the aliased arrays) */
 DLL_PUBLIC aoclsparse_status aoclsparse_mi355_invalidate(aoclsparse_matrix A);
-/* free the calling thread's staging buffers in HBM: the grow-only scratch that host-pointer calls (?csrmv, ?mv, ?trsv, the ELL
+/* free the library's staging buffers in HBM (process-wide: the primary device's and those of every device a multi-device call has
+ * used; each device's stream is synchronised first): the grow-only scratch that host-pointer calls (?csrmv, ?mv, ?trsv, the ELL
  * family) and sp2m (operands that are not a handle's own arrays, bin lists, the global slabs of very long rows) keep between calls
  * so that the next call allocates nothing.  The next call that needs one allocates it again.  Returns the number of bytes freed
  * through *bytes_freed (may be NULL).  No reference counterpart (the reference has no device). */

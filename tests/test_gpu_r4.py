@@ -945,6 +945,17 @@ def test_sp2m_finalize_refuses_a_row_ptr_of_another_product():
     so, pc, ic, vc = oracle.dcsr2m(m, m, 0, pa, ia, va, 0, pb, ib, vb)
     _, _, _, row, col, val = _export_csr(C)
     assert so == 0 and np.array_equal(row, pc) and np.array_equal(col, ic) and np.array_equal(val, vc)
+    # a refused finalize on a COMPLETE result leaves it as it was (round 5: the device verdict is read before the handle is touched)
+    assert L.aoclsparse_sp2m(P.OP_NONE, d.h, A2.h, P.OP_NONE, d.h, B.h, P.STAGE_FINALIZE, ctypes.byref(C)) == 5
+    _, _, _, row, col, val = _export_csr(C)
+    assert np.array_equal(row, pc) and np.array_equal(col, ic) and np.array_equal(val, vc)
+    x = np.random.default_rng(5).uniform(-1, 1, m)
+    y = np.zeros(m)
+    one, zero = ctypes.c_double(1.0), ctypes.c_double(0.0)
+    assert L.aoclsparse_dmv(P.OP_NONE, ctypes.byref(one), C, d.h, P._ptr(x), ctypes.byref(zero), P._ptr(y)) == 0
+    _, yr = oracle.dcsrmv(0, 0, 1.0, m, len(vc), vc, ic, pc, x, 0.0, np.zeros(m))
+    short = np.diff(pc) < 32
+    assert np.array_equal(y[short], yr[short]) and np.allclose(y, yr, rtol=1e-12, atol=1e-12)
     assert L.aoclsparse_destroy(ctypes.byref(C)) == 0
 
 

@@ -201,6 +201,33 @@ int main(int argc, char **argv)
     RUNS(0, "col + val + gather + store, plain streams")
     RUNS(1, "col + val + gather + store, nt col / val")
     RUNS(2, "col + val + gather + store, nt col / val / store")
+    // column-range split: the same entries partitioned by x range into K groups, one launch per group (each launch gathers from
+    // 1 / K of x only): is the sum of the K launches shorter than the one launch over all of x?
+    for(int K : {2, 4, 8})
+    {
+        std::vector<std::vector<int>> part(K);
+        for(int i = 0; i < entries; i++)
+            part[(long long)idx[i] * K / n].push_back(idx[i]);
+        std::vector<int *> d_part(K);
+        std::vector<int>   cnt(K);
+        for(int k = 0; k < K; k++)
+        {
+            while(part[k].size() % 4)
+                part[k].push_back(part[k].back());
+            cnt[k] = (int)part[k].size();
+            CHECK(hipMalloc(&d_part[k], sizeof(int) * (cnt[k] + 4)));
+            CHECK(hipMemcpy(d_part[k], part[k].data(), sizeof(int) * cnt[k], hipMemcpyHostToDevice));
+        }
+        char name[96];
+        snprintf(name, sizeof(name), "plain, %d launches, one x range each", K);
+        report(name, 128, time_us([&] {
+                   for(int k = 0; k < K; k++)
+                       hipLaunchKernelGGL((gather_kernel<0, 128>), dim3((cnt[k] / 4 + 127) / 128), dim3(128), 0, 0, d_part[k], d_x,
+                                          cnt[k], d_out);
+               }));
+        for(int k = 0; k < K; k++)
+            CHECK(hipFree(d_part[k]));
+    }
     report("plain, float x", 128, time_us([&] {
                hipLaunchKernelGGL((gather_f32_kernel<128>), dim3((entries / 4 + 127) / 128), dim3(128), 0, 0, d_idx, d_xf, entries,
                                   d_outf);

@@ -17,7 +17,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o spmv -- $P
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o spmv -- $PY $R/bench.py $SPMV > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o spmv -- $PY $R/bench.py $SPMV > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.err
 # 3. the other configs' kernels: csrmm (both layouts, 256 and 32 columns), the mix, TRSV, raw dcsrmv -- stats, then traffic
-LEGS="--steps 20 --warmup 3 --legs dcsrmv_csr_adaptive,mix,csrmm,trsv"
+LEGS="--steps 20 --warmup 3 --legs dcsrmv_csr_adaptive,headline_twins,mix,csrmm,trsv"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/legs_trace -o legs -- $PY $R/bench.py $LEGS > $OUT/bench_legs_under_rocprof.json 2> $OUT/legs_trace.err
 cp $R/bench_legs.json $OUT/bench_legs_under_rocprof_full.json
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/legs_fetch -o legs -- $PY $R/bench.py $LEGS > /dev/null 2> $OUT/legs_fetch.err
