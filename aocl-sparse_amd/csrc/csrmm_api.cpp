@@ -707,8 +707,9 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
         {
             // block-dense matrix: the blocked-ELL copy on the matrix cores
             if constexpr(std::is_same<T, double>::value)
-                st = launch_csrmm_bell(rt.stream(), alpha, d->m, d->n, p->bell, static_cast<const double *>(dB), n, ldb, beta,
-                                       static_cast<double *>(dC), ldc);
+                st = launch_csrmm_bell(rt.stream(), alpha, d->m, d->n, p->bell, d->base, d->ptr.as<aoclsparse_int>(),
+                                       d->ind.as<aoclsparse_int>(), d->val.as<double>(), static_cast<const double *>(dB), n, ldb,
+                                       beta, static_cast<double *>(dC), ldc);
         }
         else if(!colmaj && !grouped && p && p->valid && p->nblocks > 0
                 && csrmm_tiled_applies<T>(n, ldb, ldc, static_cast<const T *>(dB), static_cast<const T *>(dC)))
@@ -720,8 +721,9 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
         {
             // block-dense matrix, column-major operands: the transposed MFMA product, C stored in 128-byte column segments
             if constexpr(std::is_same<T, double>::value)
-                st = launch_csrmm_bell(rt.stream(), alpha, d->m, d->n, p->bell, static_cast<const double *>(dB), n, ldb, beta,
-                                       static_cast<double *>(dC), ldc, /*column_major=*/true);
+                st = launch_csrmm_bell(rt.stream(), alpha, d->m, d->n, p->bell, d->base, d->ptr.as<aoclsparse_int>(),
+                                       d->ind.as<aoclsparse_int>(), d->val.as<double>(), static_cast<const double *>(dB), n, ldb,
+                                       beta, static_cast<double *>(dC), ldc, /*column_major=*/true);
         }
         else if(windowed)
             // column-major operands, banded matrix: each B column's stretch staged in LDS, rows' entries in registers

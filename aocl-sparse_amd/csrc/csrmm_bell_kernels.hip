@@ -17,8 +17,15 @@
 // tools/mfma_f64_probe.hip, profiles/r2/mfma_f64_probe.jsonl), blocks are walked in ascending column order, so every C element
 // is the reference's chain over its row in CSR order (csrmm.hpp:69-85) with the tile's explicit zeros interleaved:
 // fma(0, b, sum) == sum for every finite b (a sum that starts at +0 is never -0).  An Inf / NaN in B at a position the row does
-// not store would turn 0 * Inf into NaN -- the same caveat as the reference's own padded formats (BLKCSR / br4: SURVEY.md a6);
-// build_bell requires sorted rows, and the plan is used for finite alpha / beta classes exactly like the other kernels.
+// not store turns 0 * Inf into NaN inside the tile -- which the reference's CSR kernel never computes.  Round 5: an
+// element whose accumulator comes out non-finite is RECOMPUTED from the CSR arrays by its lane (the row's chain without the
+// padding, csrmm.hpp:69-85), so the result is the reference's for every B; finite products pay one v_cmp_class per element.
+// build_bell requires sorted rows.
+// beta == 0 with C read (the reference's 0 * C, the default): the C tile is requested behind the first block's operands and
+// reduced to ONE predicate per element -- "is it finite" -- as soon as it lands; a finite C contributes exactly nothing
+// (fma(0, c, z) == z for z != 0), so the closing store does not wait for memory.  Elements with a non-finite C, or z == 0 (the
+// sign of the zero depends on C), re-read C and take the reference's fma.  Rounds 3-4 read C at the end of the block row: a
+// dependent round trip per block row behind a 3 us MFMA chain (1.29 vs 0.93 ms with C overwritten).
 #include "internal.hpp"
 
 #include <hip/hip_runtime.h>
@@ -36,20 +43,47 @@ namespace
     typedef double v4d __attribute__((ext_vector_type(4)));
     typedef double v2d __attribute__((ext_vector_type(2)));
 
+    // the reference's chain of C element (row, cj) over the CSR row, no padding (csrmm.hpp:69-85): the slow path of an element whose
+    // tile accumulator is not finite
+    template <bool COLMAJ>
+    __device__ __noinline__ double bell_exact_element(int row, int cj, int base, const aoclsparse_int *__restrict__ rp,
+                                                      const aoclsparse_int *__restrict__ ci, const double *__restrict__ cv,
+                                                      const double *__restrict__ B, aoclsparse_int ldb)
+    {
+        double sum = 0.0;
+        for(int p = rp[row] - base; p < rp[row + 1] - base; p++)
+        {
+            const size_t kk = (size_t)(ci[p] - base);
+            sum             = fma(cv[p], COLMAJ ? B[(size_t)cj * ldb + kk] : B[kk * ldb + cj], sum);
+        }
+        return sum;
+    }
+    __device__ __forceinline__ bool bell_finite(double v)
+    {
+        return __builtin_isfinite(v);
+    }
+
     // Operand fragments: lane -> (i or j = lane % 16, k = lane / 16), one double per lane.  Where the 4 result registers of a
     // lane sit in the 16 x 16 tile is NOT assumed: every wavefront asks the instruction itself with two extra MFMAs
     // (D = [i] and D = [j]: A = column of row numbers x B = row of ones, and the transpose) -- 2 of ~114 per block row.
     // FULL: every tile column of every wavefront is < n and the column count of A is a multiple of 16: no masks on the B loads
-    template <int NT, bool RC, bool WIDE, bool FULL>
+    // RC: 0 C is overwritten (opt-in mode, beta == 0); 1 C is read and used (beta != 0); 2 beta == 0 with C read (the default:
+    // the reference's 0 * C) -- the tile of C becomes a finite / not-finite predicate per element early on
+    // CW (with WIDE): tiles 2w and 2w+1 hold the even and the odd columns of a 32-column stretch, so a lane's two results are
+    // ADJACENT in a row of C: one 16-byte access per pair (16-byte aligned C, even ldc) instead of two 8-byte ones that each use
+    // every other double of the lines they touch
+    template <int NT, int RC, bool WIDE, bool FULL, bool CW>
     __global__ __launch_bounds__(256) void csrmm_bell_mfma_kernel(double alpha, aoclsparse_int m, aoclsparse_int k, aoclsparse_int nbr,
                                                                   aoclsparse_int width, const double *__restrict__ val,
                                                                   const aoclsparse_int *__restrict__ bcol,
                                                                   const double *__restrict__ B, aoclsparse_int n, aoclsparse_int ldb,
                                                                   double beta, double *__restrict__ C, aoclsparse_int ldc,
-                                                                  int waves_per_row, bool readc)
+                                                                  int waves_per_row, int base, const aoclsparse_int *__restrict__ rp,
+                                                                  const aoclsparse_int *__restrict__ ci, const double *__restrict__ cv)
     {
         // (block rows in launch order: giving every XCD a contiguous eighth of them -- the rule of the HBM-bound kernels here --
-        // changed nothing, 0.93 -> 0.98 ms: this kernel is bound by the MFMA pipe, profiles/r4/bell_experiments.txt)
+        // takes a fifth of the fabric traffic away and is SLOWER: 0.93 -> 0.98 ms in round 4, 1.115 -> 1.222 (C read) / 0.922 ->
+        // 0.951 ms in round 5, profiles/r4/bell_experiments.txt, profiles/r5/bell_experiments.txt)
         const int wv   = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         const long g   = (long)blockIdx.x * 4 + wv;
         const int  br  = (int)(g / waves_per_row), cw = (int)(g % waves_per_row);
@@ -148,8 +182,127 @@ namespace
         fetch_b(0, b0);
         // C is read (beta != 0, or the reference's 0 * C): requested behind the first block's operands, used after the last
         // block's MFMAs -- the closing read-modify-write does not add a dependent round trip per block row
-        double cin[NT][4];
-        if constexpr(RC)
+        double   cin[NT][4];
+        unsigned cbad = 0; // RC 2: bit 4 u + r set when C element (u, r) is not finite
+        if constexpr(RC != 0)
+        {
+            if constexpr(CW)
+            {
+#pragma unroll
+                for(int w2 = 0; w2 < NT / 2; w2++)
+#pragma unroll
+                    for(int r = 0; r < 4; r++)
+                    {
+                        const int row = br * 16 + (int)drow[r], cj = j0 + 32 * w2 + 2 * (int)dcol[r];
+                        v2d       c   = (v2d){0.0, 0.0};
+                        if(row < m && cj < n)
+                            c = *reinterpret_cast<const v2d *>(C + (size_t)row * ldc + cj);
+                        cin[2 * w2][r] = c.x, cin[2 * w2 + 1][r] = c.y;
+                    }
+            }
+            else
+            {
+#pragma unroll
+                for(int u = 0; u < NT; u++)
+#pragma unroll
+                    for(int r = 0; r < 4; r++)
+                    {
+                        const int row = br * 16 + (int)drow[r], cj = colof(u, (int)dcol[r]);
+                        cin[u][r]     = (row < m && cj < n) ? C[(size_t)row * ldc + cj] : 0.0;
+                    }
+            }
+        }
+        auto classify = [&]() {
+            if constexpr(RC == 2)
+            {
+#pragma unroll
+                for(int u = 0; u < NT; u++)
+#pragma unroll
+                    for(int r = 0; r < 4; r++)
+                        cbad |= bell_finite(cin[u][r]) ? 0u : (1u << (4 * u + r));
+            }
+        };
+        if(nblk == 0)
+            classify();
+        for(int s = 0; s < nblk; s += 2)
+        {
+            fetch_a(s + 1, a1);
+            fetch_b(s + 1, b1);
+            mac(a0, b0);
+            if(s == 0)
+                classify(); // (behind the first block's MFMAs: the C tile has landed, its registers are free from here on)
+            if(s + 1 >= nblk)
+                break;
+            fetch_a(s + 2, a0);
+            fetch_b(s + 2, b0);
+            mac(a1, b1);
+        }
+        // ---- an element whose tile sum is not finite: the reference's chain without the padding (cold path) ---------------------
+        {
+            unsigned nf = 0;
+#pragma unroll
+            for(int u = 0; u < NT; u++)
+#pragma unroll
+                for(int r = 0; r < 4; r++)
+                    nf |= bell_finite(acc[u][r]) ? 0u : (1u << (4 * u + r));
+            if(nf)
+            {
+#pragma unroll
+                for(int u = 0; u < NT; u++)
+#pragma unroll
+                    for(int r = 0; r < 4; r++)
+                        if((nf >> (4 * u + r)) & 1u)
+                        {
+                            const int row = br * 16 + (int)drow[r], cj = colof(u, (int)dcol[r]);
+                            if(row < m && cj < n)
+                                acc[u][r] = bell_exact_element<false>(row, cj, base, rp, ci, cv, B, ldb);
+                        }
+            }
+        }
+        // ---- C = beta * C + alpha * acc, the reference's closing fma (csrmm.hpp:83) ----------------------------------------
+        if constexpr(CW)
+        {
+#pragma unroll
+            for(int w2 = 0; w2 < NT / 2; w2++)
+#pragma unroll
+                for(int r = 0; r < 4; r++)
+                {
+                    const int row = br * 16 + (int)drow[r], cj = j0 + 32 * w2 + 2 * (int)dcol[r];
+                    if(row < m && cj < n) // (n is even: the pair is in or out together)
+                    {
+                        v2d         *cp = reinterpret_cast<v2d *>(C + (size_t)row * ldc + cj);
+                        const double z0 = alpha * acc[2 * w2][r], z1 = alpha * acc[2 * w2 + 1][r];
+                        v2d          o;
+                        if constexpr(RC == 1)
+                        {
+                            o.x = fma(beta, cin[2 * w2][r], z0), o.y = fma(beta, cin[2 * w2 + 1][r], z1);
+                            *cp = o;
+                        }
+                        else
+                        {
+                            // RC 2: a finite C contributes nothing unless z == 0 (then the zero's sign depends on it); RC 0 (C
+                            // overwritten): the same rule for z == 0.  fma(0, c, z) == z for a finite c and z != 0, so taking the
+                            // reference's fma on both elements of a pair is right when either needs it.
+                            const bool slow = z0 == 0.0 || z1 == 0.0 || (RC == 2 && ((cbad >> (4 * (2 * w2) + r)) & 0x11u) != 0);
+                            if(slow)
+                            {
+                                const v2d c = *cp;
+                                o.x = fma(beta, c.x, z0), o.y = fma(beta, c.y, z1);
+                                *cp = o;
+                            }
+                            else
+                            {
+                                o.x = z0, o.y = z1;
+                                if constexpr(RC == 0)
+                                    __builtin_nontemporal_store(o, cp);
+                                else
+                                    *cp = o;
+                            }
+                        }
+                    }
+                }
+        }
+        else
         {
 #pragma unroll
             for(int u = 0; u < NT; u++)
@@ -157,39 +310,26 @@ namespace
                 for(int r = 0; r < 4; r++)
                 {
                     const int row = br * 16 + (int)drow[r], cj = colof(u, (int)dcol[r]);
-                    cin[u][r]     = (row < m && cj < n) ? C[(size_t)row * ldc + cj] : 0.0;
+                    if(row < m && cj < n)
+                    {
+                        double      *cp = C + (size_t)row * ldc + cj;
+                        const double z  = alpha * acc[u][r];
+                        if constexpr(RC == 1)
+                            *cp = fma(beta, cin[u][r], z);
+                        else if constexpr(RC == 2)
+                        {
+                            if(((cbad >> (4 * u + r)) & 1u) || z == 0.0)
+                                *cp = fma(beta, *cp, z);
+                            else
+                                *cp = z; // == fma(0, c, z) for a finite c and z != 0
+                        }
+                        else if(z == 0.0)
+                            *cp = fma(beta, *cp, z);
+                        else
+                            __builtin_nontemporal_store(z, cp);
+                    }
                 }
         }
-        for(int s = 0; s < nblk; s += 2)
-        {
-            fetch_a(s + 1, a1);
-            fetch_b(s + 1, b1);
-            mac(a0, b0);
-            if(s + 1 >= nblk)
-                break;
-            fetch_a(s + 2, a0);
-            fetch_b(s + 2, b0);
-            mac(a1, b1);
-        }
-        // ---- C = beta * C + alpha * acc, the reference's closing fma (csrmm.hpp:83) ----------------------------------------
-#pragma unroll
-        for(int u = 0; u < NT; u++)
-#pragma unroll
-            for(int r = 0; r < 4; r++)
-            {
-                const int row = br * 16 + (int)drow[r], cj = colof(u, (int)dcol[r]);
-                if(row < m && cj < n)
-                {
-                    double      *cp = C + (size_t)row * ldc + cj;
-                    const double z  = alpha * acc[u][r];
-                    if constexpr(RC)
-                        *cp = fma(beta, cin[u][r], z);
-                    else if(readc || z == 0.0)
-                        *cp = fma(beta, *cp, z);
-                    else
-                        __builtin_nontemporal_store(z, cp);
-                }
-            }
     }
     // 4 x 4 transpose between the four 16-lane rows of a wavefront and four registers: lane row a, register b holds M[a][b] on
     // entry and M[b][a] on return.  Two butterfly stages of the gfx950 swap instructions: v_permlane32_swap (lanes 32..63 of the
@@ -231,13 +371,14 @@ namespace
     // CONTIGUOUS bytes k = 16 bc + 4 a .. + 3 of its column (two 16-byte loads: whole 128-byte lines per column and instruction)
     // and the four values are transposed between lane rows and registers (transpose_rows_regs).  The chain per element is unchanged
     // (k = 4t .. 4t+3 in order, blocks ascending): the same bits as the row-major kernel and as the reference.
-    template <int NT, bool RC, bool FULL, bool WIDE>
+    template <int NT, int RC, bool FULL, bool WIDE>
     __global__ __launch_bounds__(256) void csrmm_bell_mfma_col_kernel(double alpha, aoclsparse_int m, aoclsparse_int k, aoclsparse_int nbr,
                                                                       aoclsparse_int width, const double *__restrict__ val,
                                                                       const aoclsparse_int *__restrict__ bcol,
                                                                       const double *__restrict__ B, aoclsparse_int n, aoclsparse_int ldb,
                                                                       double beta, double *__restrict__ C, aoclsparse_int ldc,
-                                                                      int waves_per_row, bool readc)
+                                                                      int waves_per_row, int base, const aoclsparse_int *__restrict__ rp,
+                                                                      const aoclsparse_int *__restrict__ ci, const double *__restrict__ cv)
     {
         const int  wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         const long g  = (long)blockIdx.x * 4 + wv;
@@ -327,16 +468,67 @@ namespace
         double a0[4], a1[4], b0[NT][4], b1[NT][4];
         fetch_a(0, a0);
         fetch_b(0, b0);
+        // beta == 0 with C read (RC 2): the C tile requested now, reduced to a finite / not-finite bit per element behind the first
+        // block's MFMAs (see the row-major kernel)
+        double   cin[NT][4];
+        unsigned cbad = 0;
+        if constexpr(RC == 2)
+        {
+#pragma unroll
+            for(int u = 0; u < NT; u++)
+#pragma unroll
+                for(int r = 0; r < 4; r++)
+                {
+                    const int cj = j0 + 16 * u + (int)dfirst[r], row = br * 16 + (int)dsecond[r];
+                    cin[u][r]    = (row < m && cj < n) ? C[(size_t)cj * ldc + row] : 0.0;
+                }
+        }
+        auto classify = [&]() {
+            if constexpr(RC == 2)
+            {
+#pragma unroll
+                for(int u = 0; u < NT; u++)
+#pragma unroll
+                    for(int r = 0; r < 4; r++)
+                        cbad |= bell_finite(cin[u][r]) ? 0u : (1u << (4 * u + r));
+            }
+        };
+        if(nblk == 0)
+            classify();
         for(int s = 0; s < nblk; s += 2)
         {
             fetch_a(s + 1, a1);
             fetch_b(s + 1, b1);
             mac(a0, b0);
+            if(s == 0)
+                classify();
             if(s + 1 >= nblk)
                 break;
             fetch_a(s + 2, a0);
             fetch_b(s + 2, b0);
             mac(a1, b1);
+        }
+        {
+            // an element whose tile sum is not finite: the reference's chain without the padding (cold path, see the row-major kernel)
+            unsigned nf = 0;
+#pragma unroll
+            for(int u = 0; u < NT; u++)
+#pragma unroll
+                for(int r = 0; r < 4; r++)
+                    nf |= bell_finite(acc[u][r]) ? 0u : (1u << (4 * u + r));
+            if(nf)
+            {
+#pragma unroll
+                for(int u = 0; u < NT; u++)
+#pragma unroll
+                    for(int r = 0; r < 4; r++)
+                        if((nf >> (4 * u + r)) & 1u)
+                        {
+                            const int cj = j0 + 16 * u + (int)dfirst[r], row = br * 16 + (int)dsecond[r];
+                            if(row < m && cj < n)
+                                acc[u][r] = bell_exact_element<true>(row, cj, base, rp, ci, cv, B, ldb);
+                        }
+            }
         }
 #pragma unroll
         for(int u = 0; u < NT; u++)
@@ -348,7 +540,16 @@ namespace
                 {
                     double      *cp = C + (size_t)cj * ldc + row;
                     const double z  = alpha * acc[u][r];
-                    if(RC || readc || z == 0.0)
+                    if constexpr(RC == 1)
+                        *cp = fma(beta, *cp, z);
+                    else if constexpr(RC == 2)
+                    {
+                        if(((cbad >> (4 * u + r)) & 1u) || z == 0.0)
+                            *cp = fma(beta, *cp, z);
+                        else
+                            *cp = z;
+                    }
+                    else if(z == 0.0)
                         *cp = fma(beta, *cp, z);
                     else
                         __builtin_nontemporal_store(z, cp);
@@ -358,12 +559,14 @@ namespace
 } // namespace
 
 aoclsparse_status launch_csrmm_bell(hipStream_t s, double alpha, aoclsparse_int m, aoclsparse_int k, const BellPlan &bell,
+                                    int base, const aoclsparse_int *rp, const aoclsparse_int *ci, const double *cv,
                                     const double *B, aoclsparse_int n, aoclsparse_int ldb, double beta, double *C,
                                     aoclsparse_int ldc, bool column_major)
 {
     if(n <= 0 || m <= 0 || !bell.valid)
         return aoclsparse_status_success;
-    const bool readc = csrmm_reads_c(beta != 0.0);
+    // 0: C overwritten (opt-in), 1: beta != 0, 2: beta == 0 with C read (the default mode)
+    const int rcmode = beta != 0.0 ? 1 : (csrmm_reads_c(false) ? 2 : 0);
     const int  tiles = (n + 15) / 16;
     if(column_major)
     {
@@ -380,12 +583,15 @@ aoclsparse_status launch_csrmm_bell(hipStream_t s, double alpha, aoclsparse_int 
 #define MI355_BELLC2(NT, FULL, WIDE)                                                                                                 \
     do                                                                                                                          \
     {                                                                                                                           \
-        if(readc)                                                                                                               \
-            hipLaunchKernelGGL((csrmm_bell_mfma_col_kernel<NT, true, FULL, WIDE>), grid, block, 0, s, alpha, m, k, bell.nbr, bell.width, \
-                               bell.val.as<double>(), bell.bcol.as<aoclsparse_int>(), B, n, ldb, beta, C, ldc, wpr, readc);      \
+        if(rcmode == 1)                                                                                                         \
+            hipLaunchKernelGGL((csrmm_bell_mfma_col_kernel<NT, 1, FULL, WIDE>), grid, block, 0, s, alpha, m, k, bell.nbr, bell.width, \
+                               bell.val.as<double>(), bell.bcol.as<aoclsparse_int>(), B, n, ldb, beta, C, ldc, wpr, base, rp, ci, cv); \
+        else if(rcmode == 2)                                                                                                    \
+            hipLaunchKernelGGL((csrmm_bell_mfma_col_kernel<NT, 2, FULL, WIDE>), grid, block, 0, s, alpha, m, k, bell.nbr, bell.width, \
+                               bell.val.as<double>(), bell.bcol.as<aoclsparse_int>(), B, n, ldb, beta, C, ldc, wpr, base, rp, ci, cv); \
         else                                                                                                                    \
-            hipLaunchKernelGGL((csrmm_bell_mfma_col_kernel<NT, false, FULL, WIDE>), grid, block, 0, s, alpha, m, k, bell.nbr, bell.width, \
-                               bell.val.as<double>(), bell.bcol.as<aoclsparse_int>(), B, n, ldb, beta, C, ldc, wpr, readc);      \
+            hipLaunchKernelGGL((csrmm_bell_mfma_col_kernel<NT, 0, FULL, WIDE>), grid, block, 0, s, alpha, m, k, bell.nbr, bell.width, \
+                               bell.val.as<double>(), bell.bcol.as<aoclsparse_int>(), B, n, ldb, beta, C, ldc, wpr, base, rp, ci, cv); \
     } while(0)
         if(wide)
         {
@@ -412,16 +618,22 @@ aoclsparse_status launch_csrmm_bell(hipStream_t s, double alpha, aoclsparse_int 
     const int wpr = (tiles + nt - 1) / nt;
     const long waves  = (long)bell.nbr * wpr;
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    // 16-byte accesses to C for the tile pairs of wide mode: 16-byte aligned rows of C
+    const bool cw = wide && ldc % 2 == 0 && reinterpret_cast<uintptr_t>(C) % 16 == 0;
 #define MI355_BELL(NT, WIDE) MI355_BELL2(NT, WIDE, false)
-#define MI355_BELL2(NT, WIDE, FULL)                                                                                                      \
+#define MI355_BELL2(NT, WIDE, FULL) do { if(cw && WIDE) MI355_BELL3(NT, WIDE, FULL, WIDE); else MI355_BELL3(NT, WIDE, FULL, false); } while(0)
+#define MI355_BELL3(NT, WIDE, FULL, CWF)                                                                                                    \
     do                                                                                                                          \
     {                                                                                                                           \
-        if(readc)                                                                                                               \
-            hipLaunchKernelGGL((csrmm_bell_mfma_kernel<NT, true, WIDE, FULL>), grid, block, 0, s, alpha, m, k, bell.nbr, bell.width,    \
-                               bell.val.as<double>(), bell.bcol.as<aoclsparse_int>(), B, n, ldb, beta, C, ldc, wpr, readc); \
+        if(rcmode == 1)                                                                                                         \
+            hipLaunchKernelGGL((csrmm_bell_mfma_kernel<NT, 1, WIDE, FULL, CWF>), grid, block, 0, s, alpha, m, k, bell.nbr, bell.width,       \
+                               bell.val.as<double>(), bell.bcol.as<aoclsparse_int>(), B, n, ldb, beta, C, ldc, wpr, base, rp, ci, cv); \
+        else if(rcmode == 2)                                                                                                    \
+            hipLaunchKernelGGL((csrmm_bell_mfma_kernel<NT, 2, WIDE, FULL, CWF>), grid, block, 0, s, alpha, m, k, bell.nbr, bell.width,       \
+                               bell.val.as<double>(), bell.bcol.as<aoclsparse_int>(), B, n, ldb, beta, C, ldc, wpr, base, rp, ci, cv); \
         else                                                                                                                    \
-            hipLaunchKernelGGL((csrmm_bell_mfma_kernel<NT, false, WIDE, FULL>), grid, block, 0, s, alpha, m, k, bell.nbr, bell.width,   \
-                               bell.val.as<double>(), bell.bcol.as<aoclsparse_int>(), B, n, ldb, beta, C, ldc, wpr, readc); \
+            hipLaunchKernelGGL((csrmm_bell_mfma_kernel<NT, 0, WIDE, FULL, CWF>), grid, block, 0, s, alpha, m, k, bell.nbr, bell.width,       \
+                               bell.val.as<double>(), bell.bcol.as<aoclsparse_int>(), B, n, ldb, beta, C, ldc, wpr, base, rp, ci, cv); \
     } while(0)
     const bool full = n % (16 * nt) == 0 && k % 16 == 0;
     if(wide && full)
@@ -448,6 +660,7 @@ aoclsparse_status launch_csrmm_bell(hipStream_t s, double alpha, aoclsparse_int 
         }
 #undef MI355_BELL
 #undef MI355_BELL2
+#undef MI355_BELL3
     MI355_HIP_TRY(hipGetLastError());
     return aoclsparse_status_success;
 }

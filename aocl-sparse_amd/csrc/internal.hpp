@@ -915,7 +915,9 @@ aoclsparse_status prepare_mm_plans(aoclsparse_matrix A);
 aoclsparse_status build_bell(const HostCsr &h, const DeviceCsr &d, SpmvPlan &plan, aoclsparse_matrix_data_type vt);
 aoclsparse_status launch_bell_fill(hipStream_t s, aoclsparse_int m, int base, const aoclsparse_int *ptr, const aoclsparse_int *ind,
                                    const double *val, aoclsparse_int nbr, aoclsparse_int width, const aoclsparse_int *bcol, double *out);
+// (base / rp / ci / cv: the device CSR the copy was built from -- an element whose tile sum is not finite is recomputed from it)
 aoclsparse_status launch_csrmm_bell(hipStream_t s, double alpha, aoclsparse_int m, aoclsparse_int k, const BellPlan &bell,
+                                    int base, const aoclsparse_int *rp, const aoclsparse_int *ci, const double *cv,
                                     const double *B, aoclsparse_int n, aoclsparse_int ldb, double beta, double *C,
                                     aoclsparse_int ldc, bool column_major = false);
 // column-major, banded: a workgroup stages the stretch of a B column its rows can touch in LDS (csrmm_window_kernels.hip)

@@ -883,8 +883,9 @@ def main():
         import oracle
         nchk = min(m, 1 << 20)  # the first 2^20 rows against the oracle's float restatement (they touch only their own neighbours)
         last = int(row_ptr[nchk])
-        so, yref = oracle.scsrmv(2 if nnz > 10 * m else 0, 0, 1.0, nchk, vf[:last], col_ind[:last], row_ptr[:nchk + 1],
-                                 xf.cpu().numpy(), 0.0, np.zeros(nchk, np.float32))
+        # (the reference's only float kernel: 8 lanes + scalar tail, csrmv.hpp:317-321)
+        so, yref = oracle.scsrmv("lane8", 0, 1.0, nchk, vf[:last], col_ind[:last], row_ptr[:nchk + 1], xf.cpu().numpy(), 0.0,
+                                 np.zeros(nchk, np.float32))
         torch.cuda.synchronize()
         res["smv"] = {"workload": "aoclsparse_smv, same %dx%d-grid Laplacian, float values" % (g, g), "ms": round(ms, 6),
                       "stats_ms": quartiles(lp), "gflops": round(flops / ms / 1e6, 2),

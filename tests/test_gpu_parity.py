@@ -116,8 +116,13 @@ def test_power_law_rows_with_long_rows_strict_and_auto():
     y0 = np.zeros(m)
     d = P.Descr()
     # auto: rows of fewer than tree_min (32) entries are bit-exact, longer rows within the componentwise bound
+    # (the row-block kernel is what this test is about: with rows of 9,000 entries the automatic choice is merge-path since round 5)
     A = P.Matrix(0, m, n, rp, ci, v)
-    st, y = run_dmv(A, d, x, y0, 1.0, 0.0)
+    assert L.aoclsparse_mi355_set_option(P.OPTION_SPMV_KERNEL, 1) == 0
+    try:
+        st, y = run_dmv(A, d, x, y0, 1.0, 0.0)
+    finally:
+        assert L.aoclsparse_mi355_set_option(P.OPTION_SPMV_KERNEL, 0) == 0
     assert st == 0 and A.spmv_info().long_rows == 3 and A.spmv_info().tree_min == 32
     so, yr = oracle.dcsrmv(-1, 0, 1.0, m, len(v), v, ci, rp, x, 0.0, y0)
     lens = np.diff(rp)
@@ -1615,7 +1620,7 @@ def test_sell_not_chosen_for_power_law_rows():
     m = 20000
     rp, ci, v = random_csr(68, m, m, powerlaw_rows(6, 9000))
     A, d = _hinted(0, m, m, rp, ci, v)
-    assert A.spmv_info().kernel == 1
+    assert A.spmv_info().kernel in (1, 2)  # a CSR kernel: CSR-Adaptive, or merge-path when the longest row spans >= 16 tiles
 
 
 def test_user_stream_ordering():

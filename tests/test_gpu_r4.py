@@ -301,6 +301,57 @@ def test_csrmm_blocked_ell_mfma_bit_exact(keep):
                 assert _same_bits(Cd.cpu().numpy(), Cr), (keep, mm, "col", n, ldb, ldc, alpha, beta, overwrite)
 
 
+def test_csrmm_blocked_ell_inf_nan_in_b_and_c_as_the_reference():
+    """The tile of the MFMA kernel multiplies its explicit zeros into the sum: an Inf / NaN in B at a column a row does NOT store
+    would give 0 * Inf = NaN where the reference's CSR kernel (csrmm.hpp:69-85) never looks.  Round 5: an element whose tile sum is
+    not finite is recomputed from the CSR arrays, so the product is the reference's for every B -- finite where the reference is
+    finite, Inf / NaN exactly where the row's own entries meet them.  With 75 % fill every row has padded positions.  Also: an
+    Inf / NaN already in C propagates through beta = 0 (the reference's 0 * C) in the default mode and is overwritten in the opt-in
+    mode; both layouts."""
+    mm, rp, ci, v = standins.block_dense(6, 5, 4, keep=0.75, seed=12)
+    A = P.Matrix(0, mm, mm, rp, ci, v)
+    d = P.Descr()
+    assert L.aoclsparse_set_mm_hint(A.h, P.OP_NONE, d.h, 10) == 0 and L.aoclsparse_optimize(A.h) == 0
+    assert A.spmv_info().mm_bell_width > 0
+    rng = np.random.default_rng(77)
+    n = 48
+    for layout in ("row", "col"):
+        B = rng.uniform(-1, 1, (mm, n))
+        bad_rows = rng.choice(mm, size=40, replace=False)
+        B[bad_rows[:20], rng.integers(0, n, 20)] = np.inf
+        B[bad_rows[20:30], rng.integers(0, n, 10)] = -np.inf
+        B[bad_rows[30:], rng.integers(0, n, 10)] = np.nan
+        C0 = rng.uniform(-1, 1, (mm, n))
+        C0[5, 3], C0[77, 40], C0[300, 0] = np.inf, np.nan, -np.inf
+        Bc, Cc = np.ascontiguousarray(B.T).ravel(), np.ascontiguousarray(C0.T).ravel()
+        for alpha, beta, overwrite in ((1.0, 0.0, False), (1.0, 0.0, True), (-2.0, 0.5, False)):
+            Cin = Cc.copy()
+            if overwrite:  # BLAS convention: whatever C held is gone -- the reference arithmetic on a finite C
+                Cin = np.where(np.isfinite(Cin), Cin, 0.25)
+            so, Cr = oracle.dcsrmm("col", alpha, 0, v, ci, rp, mm, Bc, n, mm, beta, Cin, mm)
+            assert so == 0
+            ref = Cr.reshape(n, mm).T
+            assert np.isfinite(ref).sum() > 0.5 * ref.size and (~np.isfinite(ref)).sum() > 20
+            assert L.aoclsparse_mi355_set_csrmm_beta0_overwrite(1 if overwrite else 0) == 0
+            try:
+                if layout == "row":
+                    Cd = dev(np.ascontiguousarray(C0).ravel())
+                    assert P.dcsrmm(P.OP_NONE, alpha, A, d, P.ORDER_ROW, dev(np.ascontiguousarray(B).ravel()), n, n, beta, Cd, n) == 0
+                    torch.cuda.synchronize()
+                    got = Cd.cpu().numpy().reshape(mm, n)
+                else:
+                    Cd = dev(Cc)
+                    assert P.dcsrmm(P.OP_NONE, alpha, A, d, P.ORDER_COLUMN, dev(Bc), n, mm, beta, Cd, mm) == 0
+                    torch.cuda.synchronize()
+                    got = Cd.cpu().numpy().reshape(n, mm).T
+            finally:
+                assert L.aoclsparse_mi355_set_csrmm_beta0_overwrite(0) == 0
+            fin = np.isfinite(ref)
+            assert np.array_equal(np.isfinite(got), fin), (layout, alpha, beta, overwrite, int((np.isfinite(got) != fin).sum()))
+            assert np.array_equal(got[fin], ref[fin])  # bit for bit where the reference is finite
+            assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(got[np.isinf(ref)], ref[np.isinf(ref)])
+
+
 def _blocks(m, rp, ci):
     rows = np.repeat(np.arange(m), np.diff(rp))
     return len(np.unique((rows // 16).astype(np.int64) * (1 << 32) + ci // 16))
@@ -953,7 +1004,7 @@ def test_sp2m_finalize_refuses_a_row_ptr_of_another_product():
     y = np.zeros(m)
     one, zero = ctypes.c_double(1.0), ctypes.c_double(0.0)
     assert L.aoclsparse_dmv(P.OP_NONE, ctypes.byref(one), C, d.h, P._ptr(x), ctypes.byref(zero), P._ptr(y)) == 0
-    _, yr = oracle.dcsrmv(0, 0, 1.0, m, len(vc), vc, ic, pc, x, 0.0, np.zeros(m))
+    _, yr = oracle.dcsrmv(-1, 0, 1.0, m, len(vc), vc, ic, pc, x, 0.0, np.zeros(m))  # (the reference's dispatch rule picks the order)
     short = np.diff(pc) < 32
     assert np.array_equal(y[short], yr[short]) and np.allclose(y, yr, rtol=1e-12, atol=1e-12)
     assert L.aoclsparse_destroy(ctypes.byref(C)) == 0
