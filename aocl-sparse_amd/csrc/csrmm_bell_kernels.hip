@@ -14,7 +14,7 @@
 // of block s+1 are issued before the MFMAs of block s.
 //
 // Arithmetic: the instruction accumulates k = 4t .. 4t+3 in order as one FMA chain per element (bit-identical to fma(): measured,
-// tools/mfma_f64_probe.hip, profiles/r2/mfma_f64_probe.jsonl), blocks are walked in ascending column order, so every C element
+// tools/history/mfma_f64_probe.hip, profiles/r2/mfma_f64_probe.jsonl), blocks are walked in ascending column order, so every C element
 // is the reference's chain over its row in CSR order (csrmm.hpp:69-85) with the tile's explicit zeros interleaved:
 // fma(0, b, sum) == sum for every finite b (a sum that starts at +0 is never -0).  An Inf / NaN in B at a position the row does
 // not store turns 0 * Inf into NaN inside the tile -- which the reference's CSR kernel never computes.  Round 5: an

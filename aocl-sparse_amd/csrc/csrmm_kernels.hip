@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void csrmm_row_wave_rc4_kernel(int base, float
 // k + 1 of the previous row loaded: a 5-point row costs 3 new B-row loads instead of 5.  The test is made on the live
 // column indices (wave-uniform compares), so a row that does not follow the pattern simply loads everything; rows of more
 // than 8 entries take the plain loop.  Per output element the FMA chain is the row in CSR order: same bits as the other
-// kernels.  C is stored non-temporally when it is not read.  Measured in tools/csrmm_r2.hip ("RR reuse R8 nt", 1000^2
+// kernels.  C is stored non-temporally when it is not read.  Measured in tools/history/csrmm_r2.hip ("RR reuse R8 nt", 1000^2
 // Laplacian, 256 columns): 0.878 vs 0.967 ms for the row-per-wave kernel on the same box; R = 2 / 4 / 6 0.90, R >= 12 worse.
 template <typename T, int R>
 __global__ __launch_bounds__(256) void csrmm_row_run_kernel(int base, T alpha, aoclsparse_int m,
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void csrmm_row_run_kernel(int base, T alpha, a
     // banded matrix, so that the B rows a block shares with the blocks one band above / below are still in this XCD's L2)
     const int i0 = order ? order[bx * 4 + w] : (bx * 4 + w) * R;
     // The index base is folded into the pointers once (col / val are indexed with the raw row_ptr values, B rows with the raw
-    // column values): with "- base" inside the loop this kernel lost 13 % (0.957 vs 0.842 ms in tools/csrmm_r2.hip, RR1 vs RR).
+    // column values): with "- base" inside the loop this kernel lost 13 % (0.957 vs 0.842 ms in tools/history/csrmm_r2.hip, RR1 vs RR).
     col -= base, val -= base;
     const T *Bj = B + j - (ptrdiff_t)base * ldb;
     int      pc[8]; // previous row's (raw) columns (INT_MIN = none) and the B rows loaded for them
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void csrmm_row_run_kernel(int base, T alpha, a
             V b[8];
             // (Tried: request every entry that cannot reuse a register first, copy the reused ones afterwards, so that a row's
             // loads are all in flight together -- the compiler waits behind each conditional load as written here.  It was
-            // SLOWER, 1.156 vs 0.855 ms in tools/csrmm_r2.hip: three register sets per row instead of two.)
+            // SLOWER, 1.156 vs 0.855 ms in tools/history/csrmm_r2.hip: three register sets per row instead of two.)
 #pragma unroll
             for(int k = 0; k < 8; k++)
                 if(k < len)
@@ -814,7 +814,7 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup_sub_kernel(int base, T alp
 // rows, two rows in flight, eight B-row loads per row and step.  Per output element the FMA chain is the row in CSR
 // order, so the bits are those of every other kernel here.  beta == 0 stores are non-temporal (C is written once and
 // not read again by this launch).  32 columns of the 1000^2 Laplacian: 0.131 ms against 0.195 ms for csrmm_row_kernel
-// (tools/csrmm_r2.hip, profiles/r2/csrmm_experiments.txt).
+// (tools/history/csrmm_r2.hip, profiles/r2/csrmm_experiments.txt).
 template <typename T, int LANES, int TILE, int UR, int NB, bool RC, bool KT = false, bool TRACE = false>
 __global__ __launch_bounds__(256, 4) void csrmm_tile_kernel(int base, T alpha, const T *__restrict__ val,
                                                          const aoclsparse_int *__restrict__ col,
@@ -1115,7 +1115,7 @@ __global__ __launch_bounds__(256) void csrmm_col_kernel(int base, T alpha, aocls
 // matrices) and both fit the register cache.  Entry k of both rows then reads B[c_k] and B[c_k + 1] of a column: ONE
 // 16-byte load (8-byte aligned, which gfx950 serves) feeds both rows and the two results leave as one 16-byte store --
 // half the vector-memory instructions of csrmm_col_kernel, which is what bounds that kernel (1.02 vs 1.30 ms at 256
-// columns of a 1M-row 5-diagonal matrix, tools/csrmm_r2.hip).  Per output element the FMA chain is unchanged.  Rows that
+// columns of a 1M-row 5-diagonal matrix, tools/history/csrmm_r2.hip).  Per output element the FMA chain is unchanged.  Rows that
 // found no partner are served by csrmm_col_kernel through a row list in a second launch.
 // K = entries of a row kept in registers (the pairs of detect_pairs have <= CM_K), U = columns per step, RC = C is read (beta != 0 or the
 // reference's 0 * C): requested together with the step's B values instead of after its FMAs.
@@ -1667,10 +1667,10 @@ aoclsparse_status launch_csrmm_tiled(hipStream_t s, int base, T alpha, const T *
     constexpr bool xcd = true;
     const int  chunk = (nblocks + 7) / 8; // XCD-contiguous block order, as the other csrmm kernels
     // (UR, NB) = rows in flight per 16-lane sub-wave x B-row loads per row and step.  Round-3 sweep on the 32-column slab of
-    // the 1000^2 Laplacian (tools/exp_r3_slab3.sh, profiles/r3/slab_shapes.txt; beta = 0 overwrite / C read): (2, 8) 0.130 /
+    // the 1000^2 Laplacian (tools/history/exp_r3_slab3.sh, profiles/r3/slab_shapes.txt; beta = 0 overwrite / C read): (2, 8) 0.130 /
     // 0.174 ms, (2, 6) 0.126-0.128 / 0.166-0.168, (1, 8) 0.127-0.133 / 0.165-0.175, (3, 6) 0.133-0.137 / 0.170-0.174, (4, 6) 0.154-0.158 /
     // 0.182-0.184, (4, 8) 0.167 / 0.193-0.198: two rows in flight, and no more load slots than the rows have entries.
-    // Occupancy is not the lever (tools/exp_r3_slab5.sh, profiles/r3/slab_occupancy.txt): the kernel sits at 4 waves / SIMD
+    // Occupancy is not the lever (tools/history/exp_r3_slab5.sh, profiles/r3/slab_occupancy.txt): the kernel sits at 4 waves / SIMD
     // (98-110 VGPRs); __launch_bounds__(256, 5) without spills (NB = 5 / 6, overwrite) measures the same 0.123-0.129 ms, with
     // spills (C read) 0.19-0.29 ms, (256, 6) 0.14-0.51 ms.  NB = 5 for rows of <= 5 entries is worth 1-2 % (0.163-0.173 vs
     // 0.167-0.174 ms C read, 0.1225-0.126 vs 0.124-0.1285 overwrite).
@@ -1753,7 +1753,7 @@ aoclsparse_status launch_csrmm_colpair(hipStream_t s, int base, T alpha, aoclspa
     {
         const int nbx = (npairs + 255) / 256, chunk = (nbx + 7) / 8;
         // (K, U) = entries cached x columns per step: round-3 sweep on the 32-column slab, beta = 0 overwrite / C read
-        // (tools/exp_r3_slab4.sh, profiles/r3/slab_colmajor_shapes.txt): (8, 4) 0.190-0.192 / 0.240-0.242 ms, (8, 2) 0.177-0.187 /
+        // (tools/history/exp_r3_slab4.sh, profiles/r3/slab_colmajor_shapes.txt): (8, 4) 0.190-0.192 / 0.240-0.242 ms, (8, 2) 0.177-0.187 /
         // 0.243, (6, 4) 0.193-0.195 / 0.243-0.245, (6, 2) 0.190 / 0.242-0.244 -- flat; at 256 columns (6, 4) LOSES (1.20 vs 1.09 ms).
         // What did help is requesting C with the step's B values when it is read: 256 columns, beta != 0: 1.58 -> 1.43 ms.
         if(readc)

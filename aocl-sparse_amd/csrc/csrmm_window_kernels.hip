@@ -16,7 +16,7 @@
 //     C = fma(beta, C, alpha * sum)) over ds_read_b64 operands, lanes on consecutive rows (conflict-free for a stencil).
 // B is fetched wlen / R times per column in whole lines (1.49x for the 1000^2 Laplacian at R = 4096, the halo out of L2: row
 // blocks that share it run side by side on one XCD) instead of 5 unaligned gathers per output.
-// Measured (tools/csrmm_cm_r4.hip, profiles/r4/cm_window.txt), 1000^2 Laplacian, same box as the kernels it replaces:
+// Measured (tools/history/csrmm_cm_r4.hip, profiles/r4/cm_window.txt), 1000^2 Laplacian, same box as the kernels it replaces:
 //   256 columns: 1.175 -> 0.76 ms (overwrite), 1.490 -> 1.18 ms (C read); 32-column slab: 0.179 -> 0.101, 0.229 -> 0.149 ms.
 // Shapes tried there (R = 256 .. 1024 lanes x 2 .. 8 rows, 16-128 columns per workgroup, register staging instead of LDS-DMA,
 // stores deferred by a step, three buffers with counted vmcnt): 512 lanes x 8 rows, two buffers is the best; register staging

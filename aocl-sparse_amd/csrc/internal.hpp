@@ -438,7 +438,7 @@ struct HostCsr
 };
 // Host arrays a product hands back (sp2m): a copy out of HBM first-touches them, and on a fresh new[] that costs more than the
 // copy -- 156 MB: 11.6-27 ms in 4 KB pages whatever the number of touching threads, 1.1 ms as 2 MB pages touched by 16 threads
-// (tools/pagefault_probe.cpp on the GPU box).  2 MB-aligned + MADV_HUGEPAGE from 4 MB up, plain malloc below; released with free().
+// (tools/history/pagefault_probe.cpp on the GPU box).  2 MB-aligned + MADV_HUGEPAGE from 4 MB up, plain malloc below; released with free().
 void *host_result_alloc(size_t bytes);
 void  host_result_touch(void *p, size_t bytes); // first touch by several threads (no-op for small arrays)
 

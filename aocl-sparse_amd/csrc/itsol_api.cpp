@@ -50,16 +50,16 @@ enum
     solver_cg = 1,
     solver_gmres
 };
-enum cg_task
+enum cg_stage
 {
-    task_start = 0,
-    task_init_res,
-    task_check_conv,
-    task_start_iter,
-    task_compute_beta,
-    task_take_step
+    CG_ENTRY = 0,
+    CG_RESIDUAL,
+    CG_CHECK,
+    CG_PRECOND_Z,
+    CG_DIRECTION,
+    CG_UPDATE_X
 };
-enum gmres_task
+enum gmres_stage
 {
     GM_ENTRY = 0,
     GM_RESIDUAL,
@@ -297,7 +297,7 @@ struct Solver
     VBuf           r, z, p, q, y;
     T              alpha = 0, rz = 0, beta = 0, rnorm2 = 0, bnorm2 = 0, brtol = 0, rtol = 0, atol = 0;
     T              rr_last = 0; // r.r of the current residual (what z.r is when there is no preconditioner)
-    int            task = task_start;
+    int            stage = CG_ENTRY;
     aoclsparse_int niter = 0, maxit = 0;
     int            precond = 0;
     // GMRES (gmres_data, :127-143)
@@ -310,7 +310,7 @@ struct Solver
     {
         r.release(), z.release(), p.release(), q.release(), y.release(), v.release(), zz.release();
         h.clear(), g.clear(), s.clear(), c.clear();
-        task = task_start, niter = 0, j = 0;
+        stage = CG_ENTRY, niter = 0, j = 0;
     }
 
     // ---- reductions: result read back through a pinned-free plain copy ----
@@ -341,7 +341,7 @@ struct Solver
             MI355_TRY(z.alloc(nb, pinned));
             MI355_TRY(p.alloc(nb, pinned));
             MI355_TRY(q.alloc(nb, pinned));
-            task    = task_start;
+            stage    = CG_ENTRY;
             precond = opts.reg["cg preconditioner"].key;
             rtol    = (T)opts.reg["cg rel tolerance"].rval;
             atol    = (T)opts.reg["cg abs tolerance"].rval;
@@ -373,7 +373,7 @@ struct Solver
                 MI355_TRY(coef.alloc(sizeof(T) * (size_t)(m + 1), false));
                 niter = 0, j = 0;
             }
-            task    = GM_ENTRY;
+            stage    = GM_ENTRY;
             precond = opts.reg["gmres preconditioner"].key;
             rtol    = (T)opts.reg["gmres rel tolerance"].rval;
             atol    = (T)opts.reg["gmres abs tolerance"].rval;
@@ -394,7 +394,7 @@ struct Solver
     {
         aoclsparse_status exit_status = aoclsparse_status_success;
         hipStream_t       st          = rt.stream();
-        if(task != task_start && *ircomm == aoclsparse_rci_interrupt)
+        if(stage != CG_ENTRY && *ircomm == aoclsparse_rci_interrupt)
         {
             *ircomm = aoclsparse_rci_stop;
             return aoclsparse_status_user_stop;
@@ -403,9 +403,9 @@ struct Solver
         do
         {
             loop = false;
-            switch(task)
+            switch(stage)
             {
-            case task_start:
+            case CG_ENTRY:
                 for(int i = 0; i < 100; i++)
                     rinfo[i] = T(0);
                 niter = 0;
@@ -416,10 +416,10 @@ struct Solver
                 rinfo[RINFO_RHS_NORM] = bnorm2;
                 brtol                 = rtol * bnorm2;
                 *ircomm               = aoclsparse_rci_mv;
-                task                  = task_init_res;
+                stage                  = CG_RESIDUAL;
                 *u = p.as<T>(), *vv = q.as<T>();
                 break;
-            case task_init_res:
+            case CG_RESIDUAL:
                 MI355_TRY(launch_vec_add<T>(st, n, q.as<T>(), r.as<T>()));
                 MI355_TRY(dots(rt, 1, r.as<T>(), 0, r.as<T>(), &rr_last));
                 rnorm2 = std::sqrt(rr_last);
@@ -431,9 +431,9 @@ struct Solver
                 rinfo[RINFO_RES_NORM] = rnorm2;
                 MI355_TRY(launch_vec_fill<T>(st, n, p.as<T>(), T(0)));
                 rz   = T(1);
-                task = task_check_conv;
+                stage = CG_CHECK;
                 [[fallthrough]];
-            case task_check_conv:
+            case CG_CHECK:
                 *u = r.as<T>(), *vv = nullptr;
                 if(T(0) < atol && rnorm2 <= atol)
                 {
@@ -451,13 +451,13 @@ struct Solver
                     exit_status = aoclsparse_status_maxit;
                     break;
                 }
-                task    = task_start_iter;
+                stage    = CG_PRECOND_Z;
                 *ircomm = aoclsparse_rci_stopping_criterion;
                 break;
-            case task_start_iter:
+            case CG_PRECOND_Z:
                 niter++;
                 rinfo[RINFO_ITER] = (T)niter;
-                task              = task_compute_beta;
+                stage              = CG_DIRECTION;
                 if(precond) // (without one z = r: the copy of :790-797 is skipped, r itself is used)
                 {
                     *ircomm = aoclsparse_rci_precond;
@@ -465,7 +465,7 @@ struct Solver
                     break;
                 }
                 [[fallthrough]];
-            case task_compute_beta:
+            case CG_DIRECTION:
             {
                 T rz_new = rr_last; // z = r: z.r is the r.r the previous step already reduced (same summation order)
                 if(precond)
@@ -476,11 +476,11 @@ struct Solver
                 rz   = rz_new;
                 MI355_TRY(launch_cg_direction<T>(st, n, beta, p.as<T>(), precond ? z.as<T>() : r.as<T>()));
                 *ircomm = aoclsparse_rci_mv;
-                task    = task_take_step;
+                stage    = CG_UPDATE_X;
                 *u = p.as<T>(), *vv = q.as<T>();
                 break;
             }
-            case task_take_step:
+            case CG_UPDATE_X:
             {
                 // p.q, alpha = rz / (p.q) and the step are queued back to back; the host waits once, for r.r and p.q
                 MI355_TRY(red_partial.alloc(sizeof(T) * (size_t)vec_reduce_scratch_elems(2), false));
@@ -504,7 +504,7 @@ struct Solver
                 }
                 rinfo[RINFO_RES_NORM] = rnorm2;
                 loop                  = true;
-                task                  = task_check_conv;
+                stage                  = CG_CHECK;
                 break;
             }
             default:
@@ -523,7 +523,7 @@ struct Solver
         const aoclsparse_int m           = restart;
         const long long      ld          = n;
         T                   *V = v.as<T>(), *Z = zz.as<T>();
-        if(task != GM_ENTRY && *ircomm == aoclsparse_rci_interrupt)
+        if(stage != GM_ENTRY && *ircomm == aoclsparse_rci_interrupt)
         {
             *ircomm = aoclsparse_rci_stop;
             return aoclsparse_status_user_stop;
@@ -532,12 +532,12 @@ struct Solver
         do
         {
             loop = false;
-            switch(task)
+            switch(stage)
             {
             case GM_ENTRY:
                 *io1 = x, *io2 = V;
                 *ircomm = aoclsparse_rci_mv;
-                task    = GM_RESIDUAL;
+                stage    = GM_RESIDUAL;
                 break;
             case GM_RESIDUAL:
             {
@@ -566,7 +566,7 @@ struct Solver
                     break;
                 }
                 MI355_TRY(launch_scale<T>(st, V, n, T(1) / rnorm2));
-                task = GM_PRECOND_R0;
+                stage = GM_PRECOND_R0;
                 if(!precond)
                     loop = true;
                 else
@@ -581,7 +581,7 @@ struct Solver
                 *io1    = (precond ? Z : V) + (long long)j * ld;
                 *io2    = V + (long long)(j + 1) * ld;
                 *ircomm = aoclsparse_rci_mv;
-                task    = GM_ARNOLDI_STEP;
+                stage    = GM_ARNOLDI_STEP;
                 break;
             case GM_ARNOLDI_STEP:
             {
@@ -623,11 +623,11 @@ struct Solver
                 j++;
                 if(j >= m)
                 {
-                    task = GM_UPDATE_X;
+                    stage = GM_UPDATE_X;
                     loop = true;
                     break;
                 }
-                task = GM_AFTER_PRECOND;
+                stage = GM_AFTER_PRECOND;
                 if(!precond)
                     loop = true;
                 else
@@ -669,13 +669,13 @@ struct Solver
                 if(j >= m)
                     j = 0;
                 *ircomm = aoclsparse_rci_stopping_criterion;
-                task    = (below_abs || below_rel || at_max) ? GM_CHECK : GM_RESTART;
+                stage    = (below_abs || below_rel || at_max) ? GM_CHECK : GM_RESTART;
                 break;
             }
             case GM_RESTART:
                 *io1 = x, *io2 = V;
                 *ircomm = aoclsparse_rci_mv;
-                task    = GM_RESIDUAL;
+                stage    = GM_RESIDUAL;
                 break;
             case GM_CHECK:
                 if((T(0) < atol && rnorm2 <= atol) || (T(0) < rnorm2 && rnorm2 <= brtol))
@@ -1032,7 +1032,7 @@ struct CSolver
     using Cs = std::complex<R>;
     aoclsparse_int n = 0;
     bool           have_b = false, pinned = false, solving = false, x_dirty = false;
-    int            method = solver_cg, task = task_start, precond = 0;
+    int            method = solver_cg, stage = CG_ENTRY, precond = 0;
     Options        opts;
     VBuf           b, xshadow, red_partial, red_out, r, z, p, q, v, zz, symgs_y;
     Cs             alpha = 0, rz = 0, beta = 0;
@@ -1049,7 +1049,7 @@ struct CSolver
     {
         r.release(), z.release(), p.release(), q.release(), v.release(), zz.release();
         h.clear(), g.clear(), s.clear(), c.clear();
-        task = task_start, niter = 0, j = 0;
+        stage = CG_ENTRY, niter = 0, j = 0;
     }
     aoclsparse_status dot(Runtime &rt, const C *x, const C *y, bool conj_x, Cs &out)
     {
@@ -1083,7 +1083,7 @@ struct CSolver
             MI355_TRY(z.alloc(nb, pinned));
             MI355_TRY(p.alloc(nb, pinned));
             MI355_TRY(q.alloc(nb, pinned));
-            task    = task_start;
+            stage    = CG_ENTRY;
             precond = opts.reg["cg preconditioner"].key;
             rtol = (R)opts.reg["cg rel tolerance"].rval, atol = (R)opts.reg["cg abs tolerance"].rval;
             maxit = (aoclsparse_int)opts.reg["cg iteration limit"].ival;
@@ -1113,7 +1113,7 @@ struct CSolver
                 }
                 niter = 0, j = 0;
             }
-            task    = GM_ENTRY;
+            stage    = GM_ENTRY;
             precond = opts.reg["gmres preconditioner"].key;
             rtol = (R)opts.reg["gmres rel tolerance"].rval, atol = (R)opts.reg["gmres abs tolerance"].rval;
             maxit = (aoclsparse_int)opts.reg["gmres iteration limit"].ival;
@@ -1129,7 +1129,7 @@ struct CSolver
     {
         aoclsparse_status exit_status = aoclsparse_status_success;
         C *rp = r.as<C>(), *zp = z.as<C>(), *pp = p.as<C>(), *qp = q.as<C>();
-        if(task != task_start && *ircomm == aoclsparse_rci_interrupt)
+        if(stage != CG_ENTRY && *ircomm == aoclsparse_rci_interrupt)
         {
             *ircomm = aoclsparse_rci_stop;
             return aoclsparse_status_user_stop;
@@ -1138,9 +1138,9 @@ struct CSolver
         do
         {
             loop = false;
-            switch(task)
+            switch(stage)
             {
-            case task_start:
+            case CG_ENTRY:
                 for(int i = 0; i < 100; i++)
                     rinfo[i] = R(0);
                 niter = 0;
@@ -1152,10 +1152,10 @@ struct CSolver
                     return aoclsparse_status_invalid_value;
                 rinfo[RINFO_RHS_NORM] = bnorm2;
                 brtol                 = rtol * bnorm2;
-                *ircomm = aoclsparse_rci_mv, task = task_init_res;
+                *ircomm = aoclsparse_rci_mv, stage = CG_RESIDUAL;
                 *u = pp, *vv = qp;
                 break;
-            case task_init_res:
+            case CG_RESIDUAL:
                 MI355_TRY(axpby(rt, Cs(1), rp, Cs(1), qp, rp));
                 MI355_TRY(nrm2(rt, rp, rnorm2));
                 if(rnorm2 != rnorm2)
@@ -1166,9 +1166,9 @@ struct CSolver
                 rinfo[RINFO_RES_NORM] = rnorm2;
                 MI355_TRY(axpby(rt, Cs(0), nullptr, Cs(0), nullptr, pp));
                 rz   = Cs(1, 1); // sic (:723)
-                task = task_check_conv;
+                stage = CG_CHECK;
                 [[fallthrough]];
-            case task_check_conv:
+            case CG_CHECK:
                 *u = rp, *vv = nullptr;
                 if((R(0) < atol && rnorm2 <= atol) || (R(0) < rtol && rnorm2 <= brtol))
                 {
@@ -1180,12 +1180,12 @@ struct CSolver
                     *ircomm = aoclsparse_rci_stop, exit_status = aoclsparse_status_maxit;
                     break;
                 }
-                task = task_start_iter, *ircomm = aoclsparse_rci_stopping_criterion;
+                stage = CG_PRECOND_Z, *ircomm = aoclsparse_rci_stopping_criterion;
                 break;
-            case task_start_iter:
+            case CG_PRECOND_Z:
                 niter++;
                 rinfo[RINFO_ITER] = (R)niter;
-                task              = task_compute_beta;
+                stage              = CG_DIRECTION;
                 if(precond)
                 {
                     *ircomm = aoclsparse_rci_precond;
@@ -1194,7 +1194,7 @@ struct CSolver
                 }
                 MI355_TRY(axpby(rt, Cs(1), rp, Cs(0), nullptr, zp));
                 [[fallthrough]];
-            case task_compute_beta:
+            case CG_DIRECTION:
             {
                 Cs rz_new;
                 MI355_TRY(dot(rt, rp, zp, false, rz_new));
@@ -1202,11 +1202,11 @@ struct CSolver
                     return aoclsparse_status_numerical_error;
                 beta = rz_new / rz, rz = rz_new;
                 MI355_TRY(axpby(rt, beta, pp, Cs(-1), zp, pp));
-                *ircomm = aoclsparse_rci_mv, task = task_take_step;
+                *ircomm = aoclsparse_rci_mv, stage = CG_UPDATE_X;
                 *u = pp, *vv = qp;
                 break;
             }
-            case task_take_step:
+            case CG_UPDATE_X:
             {
                 Cs pq;
                 MI355_TRY(dot(rt, pp, qp, false, pq));
@@ -1223,7 +1223,7 @@ struct CSolver
                     break;
                 }
                 rinfo[RINFO_RES_NORM] = rnorm2;
-                loop = true, task = task_check_conv;
+                loop = true, stage = CG_CHECK;
                 break;
             }
             default:
@@ -1240,7 +1240,7 @@ struct CSolver
         const aoclsparse_int m           = restart;
         const long long      ld          = n;
         C                   *V = v.as<C>(), *Z = zz.as<C>();
-        if(task != GM_ENTRY && *ircomm == aoclsparse_rci_interrupt)
+        if(stage != GM_ENTRY && *ircomm == aoclsparse_rci_interrupt)
         {
             *ircomm = aoclsparse_rci_stop;
             return aoclsparse_status_user_stop;
@@ -1249,11 +1249,11 @@ struct CSolver
         do
         {
             loop = false;
-            switch(task)
+            switch(stage)
             {
             case GM_ENTRY:
                 *io1 = x, *io2 = V;
-                *ircomm = aoclsparse_rci_mv, task = GM_RESIDUAL;
+                *ircomm = aoclsparse_rci_mv, stage = GM_RESIDUAL;
                 break;
             case GM_RESIDUAL:
             {
@@ -1278,7 +1278,7 @@ struct CSolver
                     break;
                 }
                 MI355_TRY(axpby(rt, Cs(R(1) / rnorm2), V, Cs(0), nullptr, V));
-                task = GM_PRECOND_R0;
+                stage = GM_PRECOND_R0;
                 if(!precond)
                     loop = true;
                 else
@@ -1291,7 +1291,7 @@ struct CSolver
             case GM_PRECOND_R0:
             case GM_AFTER_PRECOND:
                 *io1 = (precond ? Z : V) + (long long)j * ld, *io2 = V + (long long)(j + 1) * ld;
-                *ircomm = aoclsparse_rci_mv, task = GM_ARNOLDI_STEP;
+                *ircomm = aoclsparse_rci_mv, stage = GM_ARNOLDI_STEP;
                 break;
             case GM_ARNOLDI_STEP:
             {
@@ -1325,10 +1325,10 @@ struct CSolver
                 j++;
                 if(j >= m)
                 {
-                    task = GM_UPDATE_X, loop = true;
+                    stage = GM_UPDATE_X, loop = true;
                     break;
                 }
-                task = GM_AFTER_PRECOND;
+                stage = GM_AFTER_PRECOND;
                 if(!precond)
                     loop = true;
                 else
@@ -1366,12 +1366,12 @@ struct CSolver
                 if(j >= m)
                     j = 0;
                 *ircomm = aoclsparse_rci_stopping_criterion;
-                task    = (below_abs || below_rel || at_max) ? GM_CHECK : GM_RESTART;
+                stage    = (below_abs || below_rel || at_max) ? GM_CHECK : GM_RESTART;
                 break;
             }
             case GM_RESTART:
                 *io1 = x, *io2 = V;
-                *ircomm = aoclsparse_rci_mv, task = GM_RESIDUAL;
+                *ircomm = aoclsparse_rci_mv, stage = GM_RESIDUAL;
                 break;
             case GM_CHECK:
                 if((R(0) < atol && rnorm2 <= atol) || (R(0) < rnorm2 && rnorm2 <= brtol))

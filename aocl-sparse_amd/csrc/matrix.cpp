@@ -696,7 +696,7 @@ aoclsparse_status build_sell(const aoclsparse_int *row_ptr_host, const DeviceCsr
     }
     const long long cells = sptr[nslices];
     // Padding budget: 1.35 cells per non-zero.  Round 1 set 1.15 from the two kernels' rates then (0.78 vs 0.66 of peak); the SELL
-    // kernel has gained since.  Round-3 measurement on the unstructured flan-like variant (padding 1.21: tools/exp_r3_sellpad.sh,
+    // kernel has gained since.  Round-3 measurement on the unstructured flan-like variant (padding 1.21: tools/history/exp_r3_sellpad.sh,
     // profiles/r3/sell_padding_budget.txt): SELL-64 0.259 ms vs CSR-Adaptive 0.352 ms, i.e. break-even near 1.21 * 0.352 / 0.259 =
     // 1.64 cells per non-zero; 1.35 keeps a margin for matrices with shorter rows.
     if(mode != 1 && (double)cells > 1.35 * (double)d.nnz + 64.0)
@@ -873,7 +873,7 @@ aoclsparse_status build_merge_plan(aoclsparse_int m, aoclsparse_int nnz, aoclspa
 
 // the value size build_spmv_plan sizes its row blocks by: a float handle plans 2,048-entry blocks for its products with vectors --
 // unless it carries an mm hint: csrmm_tile_kernel walks the same blocks, and the 32-column float slab of the 1000^2 Laplacian
-// measured 0.094-0.096 ms over 1,024-entry blocks against 0.101 over 2,048 (tools/exp_float_slab.py)
+// measured 0.094-0.096 ms over 1,024-entry blocks against 0.101 over 2,048 (tools/history/exp_float_slab.py)
 static size_t plan_value_size(const _aoclsparse_matrix &A)
 {
     if(A.val_type != aoclsparse_smat)

@@ -455,7 +455,7 @@ __global__ __launch_bounds__(64 * WAVES) void sell_mv_kernel(aoclsparse_int m, a
 // Short rows (round 3): matrices whose widest slice has WMAX <= 8 cells, scalar summation order, PACK 1, large launches.  ONE
 // batch of WMAX value / column line loads (index clamped to the slice's own width: no guard inside the batch; a narrower
 // boundary slice re-reads its last line and skips the FMA), then the WMAX gathers, then the chain: three dependent round trips
-// per slice, four slices per workgroup.  Same-box sweep on the headline workload (tools/exp_r3_short.sh,
+// per slice, four slices per workgroup.  Same-box sweep on the headline workload (tools/history/exp_r3_short.sh,
 // profiles/r3/sell_width_switch.txt): general kernel before the width switch 0.1845-0.186 ms, with it 0.1786-0.1793, this
 // kernel with 1 / 2 / 4 slices per workgroup 0.180-0.181 / 0.180-0.181 / 0.1773-0.1779; TWO or more slices per WAVEFRONT
 // (walked together, twice the bytes in flight per wave) 0.183-0.236 ms -- more registers, fewer waves, no gain.
@@ -546,7 +546,7 @@ bool sell_launch_short(hipStream_t s, int wmax, aoclsparse_int m, aoclsparse_int
 {
     constexpr int WAVES = 4;
     // float, >= 100,000 slices: four slices per wavefront (a float load instruction moves half the bytes of a double one; same box,
-    // tools/exp_float_headline.py, 1 / 4 / 8 slices per wavefront: 4096^2 0.1013 / 0.0949 / 0.1218 ms, 3000^2 0.0512 / 0.0479 /
+    // tools/history/exp_float_headline.py, 1 / 4 / 8 slices per wavefront: 4096^2 0.1013 / 0.0949 / 0.1218 ms, 3000^2 0.0512 / 0.0479 /
     // 0.0543, 2000^2 0.0229 / 0.0235 / 0.0267 -- and no change for double, which stays at one: profiles/r4/float_headline.txt)
     const bool      four   = sizeof(T) == 4 && nslices >= SELL_SHORT_SPW4_SLICES;
     const long long per_wg = (long long)WAVES * (four ? 4 : 1);

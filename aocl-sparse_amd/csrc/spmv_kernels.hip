@@ -177,7 +177,7 @@ constexpr int TREE_MIN = SPMV_TREE_MIN;
 // plan has <= 8 entries (stencils: no batched-read code, no long-row code).  Template parameters, not run-time flags: the register
 // allocation of a kernel is the maximum over ALL its paths, and the strict path's prefetch registers and the batched reads of
 // the general path had cost the 4096^2 Laplacian -- which uses neither -- a fifth of its speed (0.250 ms in round 1, 0.266 with
-// the batched reads, 0.330 with the strict prefetch: 96 VGPRs = 5 waves per SIMD; tools/exp_bisect_adaptive.py, profiles/r4).
+// the batched reads, 0.330 with the strict prefetch: 96 VGPRs = 5 waves per SIMD; tools/history/exp_bisect_adaptive.py, profiles/r4).
 template <typename T, int ORDER, int TILE, int BLOCK, bool TRACE = false, int VAR = 0>
 __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restrict__ blocks,
                                                                   const aoclsparse_int *__restrict__ row_ptr,
