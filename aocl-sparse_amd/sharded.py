@@ -13,6 +13,7 @@ The arithmetic is the library's (`aoclsparse_dcsrmm` through the C ABI); this mo
 holds no compute.  Works with backend "nccl" (one rank per GPU: the driver's 2/4/8-GPU runs) and with "gloo" (CPU
 tensors on the wire: lets two processes share ONE GPU so the whole control flow is testable on a 1-GPU box).
 """
+import os
 import time
 
 import numpy as np
@@ -137,7 +138,15 @@ def library_communicator(pkg, torch, dist, device, rank, world):
     dist.broadcast(wire, 0)  # rank 0's id is the job's
     import ctypes
     ctypes.memmove(ctypes.addressof(cid), wire.cpu().numpy().tobytes(), 128)
-    ok = L.aoclsparse_mi355_comm_init(world, rank, cid) == 0
+    # ncclCommInitRank has never met N > 1 GPUs on the builder's boxes: it runs in a helper thread (ctypes releases the GIL) with a
+    # deadline, so a rank that does not come back leaves the job on the torch.distributed wire instead of hanging it (the thread
+    # is a daemon; a communicator only some ranks joined is never used)
+    import threading
+    box = {}
+    th = threading.Thread(target=lambda: box.setdefault("st", L.aoclsparse_mi355_comm_init(world, rank, cid)), daemon=True)
+    th.start()
+    th.join(float(os.environ.get("AOCLSPARSE_MI355_COMM_INIT_TIMEOUT", "120")))
+    ok = (not th.is_alive()) and box.get("st", 1) == 0
     ok = reduce_scalar(1.0 if ok else 0.0, "min", dist, device) > 0.5
     _LIB_COMM["ok"] = ok
     return ok

@@ -919,11 +919,14 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import standins
         rows = []
-        try:  # fabric traffic of the two power-law matrices (PMC cannot be read from inside the run)
-            with open(os.path.join(ROOT, "profiles", "r2", "irregular_traffic.json")) as f:
-                pmc_irr = json.load(f)
-        except (OSError, ValueError):
-            pmc_irr = {}
+        pmc_irr, pmc_irr_src = {}, None
+        for rnd in ("r5", "r2"):  # fabric traffic of the mix kernels (PMC cannot be read from inside the run): the latest committed pass
+            try:
+                with open(os.path.join(ROOT, "profiles", rnd, "irregular_traffic.json")) as f:
+                    pmc_irr, pmc_irr_src = json.load(f), "profiles/%s/irregular_traffic.json" % rnd
+                break
+            except (OSError, ValueError):
+                continue
         # the four stand-ins, then (round 3) each one OFF its ideal ordering: graphs with locality, meshes with irregular
         # valence and a windowed random node order (tools/standins.py)
         names = (["circuit-like", "web-like"] + ([] if args.small else ["shell-like", "flan-like"])
@@ -985,7 +988,7 @@ def main():
                          "us": round(ms * 1e3, 3), "us_timing": "200 calls back to back between two events",
                          "us_per_call_with_an_event_each": round(ms_lap * 1e3, 3), "stats_ms": quartiles(lp),
                          "gflops": round(2.0 * nz / ms / 1e6, 2),
-                         "roofline": roofline(b, ms, tr, traffic_source="profiles/r2/irregular_traffic.json" if tr else None,
+                         "roofline": roofline(b, ms, tr, traffic_source=pmc_irr_src if tr else None,
                                               traffic_gbs=round(tr / ms / 1e6, 1) if tr else None,
                                               traffic_frac_of_peak=round(tr / ms / 1e6 / HBM_PEAK_GBS, 4) if tr else None),
                          "bit_exact_rows_below_tree_min": bool(np.array_equal(got[within], yr[within])), "tree_min": int(inf.tree_min),
