@@ -142,3 +142,47 @@ def test_hint_sequences_and_destroy_never_leak_or_crash():
                 if L.aoclsparse_copy(A.h, d.h, ctypes.byref(c)) == 0:
                     assert L.aoclsparse_destroy(ctypes.byref(c)) == 0
         del A
+
+
+def test_create_csc_coo_fuzz_accepts_only_valid_structures():
+    """aoclsparse_create_dcsc / _dcoo on randomly damaged structures (extra/aoclsparse_auxiliary.cpp: create_csc / create_coo run
+    the same structure check as create_csr): a success status implies that every index is inside the matrix and every pointer
+    array is monotone and closes at nnz; a rejected input leaves *mat NULL; convert_csr of an accepted COO handle gives a
+    structure that create_dcsr accepts."""
+    rng = np.random.default_rng(4242)
+    outcomes = set()
+    for it in range(300):
+        m, n, base = int(rng.integers(1, 30)), int(rng.integers(1, 30)), int(rng.integers(0, 2))
+        # CSC of an m x n matrix = CSR structure of the n x m transpose
+        cp, ri, v = random_csr(7000 + it, n, m, lambda r, i: r.integers(0, min(m, 5) + 1), base=base)
+        cp, ri = _mutate(rng, n, m, base, cp, ri)
+        nnz = len(ri)
+        vv = v if nnz else np.ones(1)
+        h = ctypes.c_void_p()
+        st = L.aoclsparse_create_dcsc(ctypes.byref(h), base, m, n, nnz, P._ptr(cp), P._ptr(ri), P._ptr(vv))
+        ok = (cp[0] == base and cp[n] - base == nnz and np.all(np.diff(cp) >= 0)
+              and (nnz == 0 or (ri.min() >= base and ri.max() < m + base)))
+        if st == 0:
+            assert ok, (it, cp.tolist(), ri.tolist())
+            assert L.aoclsparse_destroy(ctypes.byref(h)) == 0
+        else:
+            assert not h.value
+        outcomes.add(st == 0)
+        # COO: coordinates with one random defect
+        k = int(rng.integers(0, 40))
+        rows = rng.integers(0, m, k).astype(np.int32) + base
+        cols = rng.integers(0, n, k).astype(np.int32) + base
+        if k and rng.random() < 0.4:
+            j = int(rng.integers(0, k))
+            (rows if rng.random() < 0.5 else cols)[j] = int(rng.choice([-3, base - 1, max(m, n) + base + 2]))
+        vals = rng.uniform(-1, 1, max(k, 1))
+        rr, cc = (rows, cols) if k else (np.zeros(1, np.int32), np.zeros(1, np.int32))
+        h = ctypes.c_void_p()
+        st = L.aoclsparse_create_dcoo(ctypes.byref(h), base, m, n, k, P._ptr(rr), P._ptr(cc), P._ptr(vals))
+        okc = k == 0 or (rows.min() >= base and rows.max() < m + base and cols.min() >= base and cols.max() < n + base)
+        if st == 0:
+            assert okc, (it, rows.tolist(), cols.tolist())
+            assert L.aoclsparse_destroy(ctypes.byref(h)) == 0
+        else:
+            assert not h.value
+    assert outcomes == {True, False}
