@@ -342,8 +342,10 @@ def compact_record(full, record_path=None):
                    "parallelism": cfg.get("parallelism"), "device": _short(cfg.get("device"), 40),
                    "communicator": cfg.get("communicator")}
     rf = full.get("roofline") or {}
-    c["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic",
+    c["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "frac_traffic", "traffic",
                                             "algorithmic_bytes_per_launch", "kernel_ms", "traffic_source")}
+    if c["roofline"].get("frac_traffic") is None and rf.get("traffic") and rf.get("kernel_ms") and rf.get("peak"):
+        c["roofline"]["frac_traffic"] = round(rf["traffic"] / (rf["kernel_ms"] * 1e-3) / 1e9 / rf["peak"], 4)  # (reports of rounds 1-4)
     cb = full.get("cpu_baseline")
     if isinstance(cb, dict) and "value" in cb:
         c["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],

@@ -231,6 +231,9 @@ def test_compact_record_fits_the_drivers_tail():
     assert rec["metric"].startswith("CSR SpMV fp64") and rec["unit"] == "GFLOP/s" and rec["value"] == full["value"]
     assert rec["roofline"]["frac"] == full["roofline"]["frac"] and rec["roofline"]["kernel_ms"] == full["roofline"]["kernel_ms"]
     assert rec["roofline"]["traffic"] == full["roofline"]["traffic"] and rec["roofline"]["peak"] == 8000.0
+    # the real-traffic twin of frac (round 5): PMC bytes per launch / hipEvent time / peak
+    assert abs(rec["roofline"]["frac_traffic"] - full["roofline"]["traffic"] / (full["roofline"]["kernel_ms"] * 1e-3) / 8e12) < 1e-3
+    assert rec["roofline"]["frac_traffic"] < rec["roofline"]["frac"]
     cb = rec["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] == full["cpu_baseline"]["value"] and cb["cores"] == full["cpu_baseline"]["cores"]
     assert rec["parity"]["bit_exact"] is True and rec["config"]["communicator"] == full["config"]["communicator"]
