@@ -34,3 +34,38 @@ def test_round5_differential_fuzz_short():
     out = _run("fuzz_r5.py", 25, 3)
     assert not any(out["mismatches"].values()), out
     assert out["checked"]["spmv"] >= 30 and out["checked"]["bell"] >= 10 and out["checked"]["csr2csc"] >= 2
+
+
+def test_release_staging_reaches_the_secondary_runtime_slots():
+    """aoclsparse_mi355_release_staging is process-wide: the slabs the slots of a multi-device call staged for their
+    share of host operands are freed too (here: four slots on device 0), counted in bytes_freed, and the next multi-device call
+    allocates them again and returns the same bits."""
+    import ctypes
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import pkg, random_csr
+    P = pkg()
+    L = P.lib()
+    m, k, n = 4000, 3000, 64
+    rp, ci, v = random_csr(77, m, k, lambda r, i: r.integers(0, 9))
+    A = P.Matrix(0, m, k, rp, ci, v)
+    d = P.Descr()
+    assert L.aoclsparse_set_mm_hint(A.h, P.OP_NONE, d.h, 10) == 0 and L.aoclsparse_optimize(A.h) == 0
+    rng = np.random.default_rng(3)
+    B, C0 = rng.uniform(-1, 1, k * n), rng.uniform(-1, 1, m * n)
+    st, dev0, _, _ = P.device_info()
+    assert st == 0
+    freed = ctypes.c_size_t(0)
+    assert L.aoclsparse_mi355_release_staging(ctypes.byref(freed)) == 0  # start from nothing staged
+    C1 = C0.copy()
+    assert P.dcsrmm_multi(P.OP_NONE, 1.5, A, d, P.ORDER_ROW, B, n, n, -0.5, C1, n, [dev0] * 4) == 0
+    torch.cuda.synchronize()
+    assert L.aoclsparse_mi355_release_staging(ctypes.byref(freed)) == 0
+    # each of the four slots staged its 16-column slab of B (k x 16) and C (m x 16): at least those bytes come back
+    assert freed.value >= 8 * 16 * (k + m) * 3, freed.value
+    assert L.aoclsparse_mi355_release_staging(ctypes.byref(freed)) == 0 and freed.value == 0
+    C2 = C0.copy()
+    assert P.dcsrmm_multi(P.OP_NONE, 1.5, A, d, P.ORDER_ROW, B, n, n, -0.5, C2, n, [dev0] * 4) == 0
+    assert np.array_equal(C1, C2)
