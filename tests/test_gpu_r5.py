@@ -69,3 +69,78 @@ def test_release_staging_reaches_the_secondary_runtime_slots():
     C2 = C0.copy()
     assert P.dcsrmm_multi(P.OP_NONE, 1.5, A, d, P.ORDER_ROW, B, n, n, -0.5, C2, n, [dev0] * 4) == 0
     assert np.array_equal(C1, C2)
+
+
+def test_exported_cxx_instantiations_compute_on_the_gpu(tmp_path):
+    """A C++ program that only DECLARES aoclsparse::create_csr / mv / trsv / sp2m (what the reference's public header gives a caller)
+    links against the library's exported instantiations through the versioned name and gets the right numbers from the GPU:
+    y = 2 A x - y on the 5-point Laplacian, the unit-lower solve of its strict lower triangle, and nnz(A A)."""
+    src = tmp_path / "cxx_abi.cpp"
+    src.write_text(r"""
+#include "aoclsparse.h"
+#include <cmath>
+#include <cstdio>
+#include <vector>
+namespace aoclsparse {
+template <typename T> aoclsparse_status mv(aoclsparse_operation, const T *, aoclsparse_matrix, const aoclsparse_mat_descr,
+                                           const T *, const T *, T *);
+template <typename T> aoclsparse_status create_csr(aoclsparse_matrix *, aoclsparse_index_base, aoclsparse_int, aoclsparse_int,
+                                                   aoclsparse_int, aoclsparse_int *, aoclsparse_int *, T *, bool = false);
+template <typename T> aoclsparse_status trsv(const aoclsparse_operation, const T, aoclsparse_matrix, const aoclsparse_mat_descr,
+                                             const T *, const aoclsparse_int, T *, const aoclsparse_int, aoclsparse_int = -1);
+template <typename T> aoclsparse_status sp2m(aoclsparse_operation, const aoclsparse_mat_descr, const aoclsparse_matrix,
+                                             aoclsparse_operation, const aoclsparse_mat_descr, const aoclsparse_matrix,
+                                             aoclsparse_request, aoclsparse_matrix *);
+}
+int main() {
+    const int g = 60, m = g * g;
+    std::vector<aoclsparse_int> rp(m + 1, 0), ci;
+    std::vector<double> v;
+    for(int r = 0; r < m; r++) {
+        const int i = r / g, j = r % g;
+        const int cand[5] = {r - g, r - 1, r, r + 1, r + g};
+        const bool ok[5] = {i > 0, j > 0, true, j < g - 1, i < g - 1};
+        for(int k = 0; k < 5; k++) if(ok[k]) { ci.push_back(cand[k]); v.push_back(k == 2 ? 4.0 : -1.0); }
+        rp[r + 1] = (aoclsparse_int)ci.size();
+    }
+    aoclsparse_matrix A = nullptr;
+    if(aoclsparse::create_csr<double>(&A, aoclsparse_index_base_zero, m, m, (aoclsparse_int)v.size(), rp.data(), ci.data(), v.data()) != aoclsparse_status_success) return 1;
+    aoclsparse_mat_descr d = nullptr;
+    if(aoclsparse_create_mat_descr(&d) != aoclsparse_status_success) return 2;
+    std::vector<double> x(m), y(m, 1.0), yr(m);
+    for(int r = 0; r < m; r++) x[r] = std::sin(0.01 * r);
+    for(int r = 0; r < m; r++) { double s = 0.0; for(int p = rp[r]; p < rp[r + 1]; p++) s = std::fma(v[p], x[ci[p]], s); yr[r] = std::fma(-1.0, 1.0, 2.0 * s); }
+    const double alpha = 2.0, beta = -1.0;
+    if(aoclsparse::mv<double>(aoclsparse_operation_none, &alpha, A, d, x.data(), &beta, y.data()) != aoclsparse_status_success) return 3;
+    for(int r = 0; r < m; r++) if(y[r] != yr[r]) { std::printf("mv row %d: %.17g vs %.17g\n", r, y[r], yr[r]); return 4; }
+    // unit-lower solve: x = L^{-1} b with L = I + strict lower triangle of A, b = L * 1
+    aoclsparse_set_mat_type(d, aoclsparse_matrix_type_triangular);
+    aoclsparse_set_mat_fill_mode(d, aoclsparse_fill_mode_lower);
+    aoclsparse_set_mat_diag_type(d, aoclsparse_diag_type_unit);
+    std::vector<double> b(m), s(m);
+    for(int r = 0; r < m; r++) { double t = 1.0; for(int p = rp[r]; p < rp[r + 1]; p++) if(ci[p] < r) t += v[p]; b[r] = t; }
+    if(aoclsparse::trsv<double>(aoclsparse_operation_none, 1.0, A, d, b.data(), 1, s.data(), 1) != aoclsparse_status_success) return 5;
+    for(int r = 0; r < m; r++) if(std::fabs(s[r] - 1.0) > 1e-9) { std::printf("trsv row %d: %.17g\n", r, s[r]); return 6; }
+    // C = A * A
+    aoclsparse_set_mat_type(d, aoclsparse_matrix_type_general);
+    aoclsparse_matrix C = nullptr;
+    if(aoclsparse::sp2m<double>(aoclsparse_operation_none, d, A, aoclsparse_operation_none, d, A, aoclsparse_stage_full_computation, &C) != aoclsparse_status_success) return 7;
+    aoclsparse_index_base cb; aoclsparse_int cm, cn, cnnz, *crp, *cci; double *cv;
+    if(aoclsparse_export_dcsr(C, &cb, &cm, &cn, &cnnz, &crp, &cci, &cv) != aoclsparse_status_success) return 8;
+    // row r of A*A touches the 13-point diamond clipped by the grid: count it directly
+    long want = 0;
+    for(int i = 0; i < g; i++) for(int j = 0; j < g; j++)
+        for(int di = -2; di <= 2; di++) for(int dj = -2; dj <= 2; dj++)
+            if(std::abs(di) + std::abs(dj) <= 2 && i + di >= 0 && i + di < g && j + dj >= 0 && j + dj < g) want++;
+    if(cm != m || cn != m || cnnz != want) { std::printf("sp2m nnz %d vs %ld\n", (int)cnnz, want); return 9; }
+    std::printf("ok %d\n", (int)cnnz);
+    return (aoclsparse_destroy(&C) == aoclsparse_status_success && aoclsparse_destroy(&A) == aoclsparse_status_success
+            && aoclsparse_destroy_mat_descr(d) == aoclsparse_status_success) ? 0 : 10;
+}
+""")
+    exe = tmp_path / "cxx_abi"
+    libdir = os.path.join(ROOT, "aocl-sparse_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", str(src), "-I" + os.path.join(ROOT, "include"), "-L" + libdir, "-laoclsparse",
+                           "-Wl,-rpath," + libdir, "-o", str(exe)])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), (r.returncode, r.stdout[-500:], r.stderr[-500:])
