@@ -578,7 +578,8 @@ private:
     std::atomic<bool> inited_{false}; // set (release) after init_status_ / device / events are written
     aoclsparse_status init_status_ = aoclsparse_status_success;
     hipStream_t  stream_ = nullptr;
-    DeviceBuffer stage_[40]; // 0-7: csrmv / mv / trsv / dotmv, 8-15: ELL family and BLKCSR (ell_api.cpp, blk_api.cpp), 16-39: sp2m (sp2m_api.cpp)
+    DeviceBuffer stage_[48]; // 0-7: csrmv / mv / trsv / dotmv, 8-15: ELL family and BLKCSR (ell_api.cpp, blk_api.cpp), 16-39: sp2m (sp2m_api.cpp),
+                             // 40-45: the temporaries of the device transpose (transpose_kernels.hip; sp2m transposes operands while its own slots are in use)
 };
 
 // While one of these is alive on a thread, Runtime::get() on that thread is the given slot: its device is current, its

@@ -405,7 +405,9 @@ aoclsparse_status build_transpose(aoclsparse_matrix A)
         if(A->trans)
             return aoclsparse_status_success;
     }
-    std::unique_lock<std::shared_mutex> w(A->guard);
+    // (the device sort takes its temporaries from the staging slots: the stage lock comes BEFORE the handle's guard, as everywhere)
+    std::lock_guard<std::recursive_mutex> sl(Runtime::get().stage_lock);
+    std::unique_lock<std::shared_mutex>   w(A->guard);
     if(A->trans)
         return aoclsparse_status_success;
     try

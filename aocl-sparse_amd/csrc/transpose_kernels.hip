@@ -168,17 +168,23 @@ static aoclsparse_status device_transpose_run(hipStream_t s, aoclsparse_int m, a
 {
     if(m <= 0 || n <= 0 || nnz <= 0)
         return aoclsparse_status_not_implemented;
-    DeviceBuffer cnt, cursor, tpos, scan, small, order;
-    MI355_TRY(cnt.alloc(sizeof(int) * (size_t)n));
-    MI355_TRY(small.alloc(256));
-    MI355_HIP_TRY(hipMemsetAsync(cnt.ptr, 0, sizeof(int) * (size_t)n, s));
-    MI355_HIP_TRY(hipMemsetAsync(small.ptr, 0, 256, s));
-    unsigned int *d_bad = small.as<unsigned int>() + 32;
-    hipLaunchKernelGGL(tr_count_kernel, dim3((m + 255) / 256), dim3(256), 0, s, m, n, base, d_ptr, d_ind, cnt.as<int>(), d_bad);
+    // temporaries: grow-only staging slots of the calling thread's runtime (round 5, ADVICE r4: five hipMalloc / hipFree per call
+    // were five implicit device synchronisations), held under the stage lock until the stream has run the kernels
+    Runtime                              &rt = Runtime::get();
+    std::lock_guard<std::recursive_mutex> sl(rt.stage_lock);
+    void *p_cnt = nullptr, *p_cursor = nullptr, *p_tpos = nullptr, *p_scan = nullptr, *p_small = nullptr, *p_order = nullptr;
+    MI355_TRY(rt.staging(40, sizeof(int) * (size_t)n, &p_cnt));
+    MI355_TRY(rt.staging(41, 256, &p_small));
+    MI355_HIP_TRY(hipMemsetAsync(p_cnt, 0, sizeof(int) * (size_t)n, s));
+    MI355_HIP_TRY(hipMemsetAsync(p_small, 0, 256, s));
+    int *const          cnt_p   = static_cast<int *>(p_cnt);
+    unsigned int *const small_p = static_cast<unsigned int *>(p_small);
+    unsigned int *d_bad = small_p + 32;
+    hipLaunchKernelGGL(tr_count_kernel, dim3((m + 255) / 256), dim3(256), 0, s, m, n, base, d_ptr, d_ind, cnt_p, d_bad);
     // the columns by segment length: <= 32 (bin 0), <= 2,048 (bins 1, 2), longer (bins 3, 4: declined) -- the bins of the SpGEMM
     // analysis (32 / 256 / 2,048 / 8,192) serve as they are
-    unsigned int *d_hist = small.as<unsigned int>(), *d_cursor = d_hist + 16;
-    MI355_TRY(launch_spg_hist(s, n, cnt.as<int>(), nullptr, false, d_hist));
+    unsigned int *d_hist = small_p, *d_cursor = d_hist + 16;
+    MI355_TRY(launch_spg_hist(s, n, cnt_p, nullptr, false, d_hist));
     unsigned int hist[SPGEMM_BINS + 1], bad = 0;
     MI355_HIP_TRY(hipMemcpyAsync(hist, d_hist, sizeof(hist), hipMemcpyDeviceToHost, s));
     MI355_HIP_TRY(hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, s));
@@ -189,17 +195,18 @@ static aoclsparse_status device_transpose_run(hipStream_t s, aoclsparse_int m, a
     MI355_TRY(tptr_b.alloc(sizeof(aoclsparse_int) * ((size_t)n + 1)));
     MI355_TRY(tind_b.alloc(sizeof(aoclsparse_int) * (size_t)nnz));
     MI355_TRY(tval_b.alloc(vsize * (size_t)nnz));
-    MI355_TRY(cursor.alloc(sizeof(int) * (size_t)n));
-    MI355_TRY(tpos.alloc(sizeof(int) * (size_t)nnz));
-    MI355_TRY(scan.alloc(spg_scan_scratch_bytes(n)));
-    MI355_HIP_TRY(hipMemsetAsync(cursor.ptr, 0, sizeof(int) * (size_t)n, s));
+    MI355_TRY(rt.staging(42, sizeof(int) * (size_t)n, &p_cursor));
+    MI355_TRY(rt.staging(43, sizeof(int) * (size_t)nnz, &p_tpos));
+    MI355_TRY(rt.staging(44, spg_scan_scratch_bytes(n), &p_scan));
+    MI355_HIP_TRY(hipMemsetAsync(p_cursor, 0, sizeof(int) * (size_t)n, s));
+    int *const cursor_p = static_cast<int *>(p_cursor), *const tpos_p = static_cast<int *>(p_tpos);
     aoclsparse_int *tptr = tptr_b.as<aoclsparse_int>(), *tind = tind_b.as<aoclsparse_int>();
     void           *tval = tval_b.ptr;
     long long *total = nullptr;
-    MI355_TRY(launch_spg_scan(s, n, cnt.as<int>(), tptr, scan.as<long long>(), &total));
-    hipLaunchKernelGGL(tr_scatter_kernel, dim3((m + 255) / 256), dim3(256), 0, s, m, base, d_ptr, d_ind, tptr, cursor.as<int>(),
-                       tpos.as<int>(), tind);
-    hipLaunchKernelGGL(tr_sort_short_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, tptr, tpos.as<int>(), tind);
+    MI355_TRY(launch_spg_scan(s, n, cnt_p, tptr, static_cast<long long *>(p_scan), &total));
+    hipLaunchKernelGGL(tr_scatter_kernel, dim3((m + 255) / 256), dim3(256), 0, s, m, base, d_ptr, d_ind, tptr, cursor_p,
+                       tpos_p, tind);
+    hipLaunchKernelGGL(tr_sort_short_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, tptr, tpos_p, tind);
     const aoclsparse_int nmid = (aoclsparse_int)(hist[1] + hist[2]);
     if(nmid > 0)
     {
@@ -207,25 +214,25 @@ static aoclsparse_status device_transpose_run(hipStream_t s, aoclsparse_int m, a
         bounds[0] = 0;
         for(int b = 0; b < SPGEMM_BINS; b++)
             bounds[b + 1] = bounds[b] + (aoclsparse_int)hist[b];
-        MI355_TRY(order.alloc(sizeof(aoclsparse_int) * (size_t)n));
-        MI355_TRY(launch_spg_order(s, n, cnt.as<int>(), false, bounds, d_cursor, order.as<aoclsparse_int>()));
-        hipLaunchKernelGGL(tr_sort_wave_kernel, dim3((unsigned)nmid), dim3(64), 0, s, nmid, order.as<aoclsparse_int>() + bounds[1], tptr,
-                           tpos.as<int>(), tind);
+        MI355_TRY(rt.staging(45, sizeof(aoclsparse_int) * (size_t)n, &p_order));
+        aoclsparse_int *const order_p = static_cast<aoclsparse_int *>(p_order);
+        MI355_TRY(launch_spg_order(s, n, cnt_p, false, bounds, d_cursor, order_p));
+        hipLaunchKernelGGL(tr_sort_wave_kernel, dim3((unsigned)nmid), dim3(64), 0, s, nmid, order_p + bounds[1], tptr, tpos_p, tind);
     }
     const unsigned gq = (unsigned)(((long long)nnz + 255) / 256);
     if(vsize == 4)
-        hipLaunchKernelGGL((tr_gather_kernel<float>), dim3(gq), dim3(256), 0, s, nnz, tpos.as<int>(), static_cast<const float *>(d_val),
+        hipLaunchKernelGGL((tr_gather_kernel<float>), dim3(gq), dim3(256), 0, s, nnz, tpos_p, static_cast<const float *>(d_val),
                            static_cast<float *>(tval));
     else if(vsize == 8)
-        hipLaunchKernelGGL((tr_gather_kernel<double>), dim3(gq), dim3(256), 0, s, nnz, tpos.as<int>(), static_cast<const double *>(d_val),
+        hipLaunchKernelGGL((tr_gather_kernel<double>), dim3(gq), dim3(256), 0, s, nnz, tpos_p, static_cast<const double *>(d_val),
                            static_cast<double *>(tval));
     else if(vsize == 16)
-        hipLaunchKernelGGL((tr_gather_kernel<double2>), dim3(gq), dim3(256), 0, s, nnz, tpos.as<int>(), static_cast<const double2 *>(d_val),
+        hipLaunchKernelGGL((tr_gather_kernel<double2>), dim3(gq), dim3(256), 0, s, nnz, tpos_p, static_cast<const double2 *>(d_val),
                            static_cast<double2 *>(tval));
     else
         return aoclsparse_status_not_implemented;
     MI355_HIP_TRY(hipGetLastError());
-    MI355_HIP_TRY(hipStreamSynchronize(s)); // (the temporaries above go away)
+    MI355_HIP_TRY(hipStreamSynchronize(s)); // (the staging slots may be handed to the next caller once the lock is released)
     return aoclsparse_status_success;
 }
 
