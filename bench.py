@@ -240,6 +240,14 @@ def leg_numbers(full):
     if "us_per_call" in l100:
         n["l100_us"] = l100["us_per_call"]
         n["l100_latency_frac"] = (l100.get("roofline_latency") or {}).get("frac")
+        # l100_us is the mean of 2,000 calls each bracketed by its own event pair, from Python; what a C caller pays per call
+        # (tools/l100_probe.hip, next to an empty launch with the same arguments) and the per-call time inside a HIP graph:
+        cc = (l100.get("c_caller") or {}).get("dmv_pointer_mode_device") or {}
+        if "total_us" in cc:
+            n["l100_c_caller_us"] = cc["total_us"]
+            n["l100_empty_launch_us"] = ((l100.get("c_caller") or {}).get("empty_kernel_13_arguments") or {}).get("total_us")
+        if "us_per_call_in_a_hip_graph_of_100" in l100:
+            n["l100_graph_us"] = l100["us_per_call_in_a_hip_graph_of_100"]
     ca = legs.get("dcsrmv_csr_adaptive") or {}
     if "roofline" in ca:
         n["csr_adaptive_ms"] = ca["ms"]

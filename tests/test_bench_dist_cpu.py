@@ -248,6 +248,16 @@ def test_compact_record_fits_the_drivers_tail():
     bad["config"] = dict(full["config"], workload="w" * 5000, kernel="k" * 5000)
     line2 = bench.compact_record(bench._sanitize(bad))
     assert len(line2) <= bench.COMPACT_LIMIT and json.loads(line2)["parity"]["max_abs_diff"] is None
+    # round 5's full report: the launch-bound configs[1] literal carries the C caller's per-call cost and the in-graph time next
+    # to the event-per-call mean, and the record still fits
+    with open(os.path.join(ROOT, "profiles", "r5", "bench_legs_default.json")) as f:
+        full5 = json.load(f)
+    line5 = bench.compact_record(full5, "bench_legs.json")
+    assert len(line5) <= bench.COMPACT_LIMIT
+    n5 = json.loads(line5)["legs"]
+    assert n5["l100_c_caller_us"] == full5["l100"]["c_caller"]["dmv_pointer_mode_device"]["total_us"] < n5["l100_us"]
+    assert n5["l100_graph_us"] == full5["l100"]["us_per_call_in_a_hip_graph_of_100"] < n5["l100_c_caller_us"]
+    assert n5["l100_empty_launch_us"] <= n5["l100_c_caller_us"]
     # a run without legs (N > 1, --legs none)
     bare = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "config", "roofline")}
     bare["cpu_baseline"] = None
