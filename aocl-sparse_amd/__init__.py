@@ -346,6 +346,7 @@ SIGNATURES = {
     "aoclsparse_mi355_set_pointer_mode": (c_int, [c_int]),
     "aoclsparse_mi355_set_stream": (c_int, [_P]),
     "aoclsparse_mi355_get_stream": (_P, []),
+    "aoclsparse_mi355_hip_runtime_path": (c_int, [c_char_p, ctypes.c_size_t]),
     "aoclsparse_mi355_synchronize": (c_int, []),
     "aoclsparse_mi355_device_info": (c_int, [POINTER(_I), POINTER(_I), c_char_p]),
     "aoclsparse_mi355_timer_start": (c_int, []),
@@ -594,6 +595,13 @@ def device_info():
     name = ctypes.create_string_buffer(256)
     st = lib().aoclsparse_mi355_device_info(byref(dev), byref(cus), name)
     return st, dev.value, cus.value, name.value.decode()
+
+
+def hip_runtime_path():
+    """path of the libamdhip64 the library is bound to (streams given to aoclsparse_mi355_set_stream must come from it)"""
+    buf = ctypes.create_string_buffer(4096)
+    st = lib().aoclsparse_mi355_hip_runtime_path(buf, 4096)
+    return st, buf.value.decode()
 
 
 def timer_start():

@@ -319,14 +319,21 @@ struct MergePlan
     aoclsparse_int ntiles = 0;
     DeviceBuffer   starts; // (ntiles + 1) x {i, j}
     DeviceBuffer   first; // ntiles: first tile that holds a head piece of the row whose END lies in tile w, or -1
-    DeviceBuffer   granules; // 2 * ntiles x u64: tile w's head piece as {launch epoch << 32 | half of the value} (zeroed once)
     bool           valid = false, tried = false;
-    // launch bookkeeping (mutable: products run on a const plan under the handle's shared lock): the epoch tags a launch's
-    // granules; `lock` makes {take an epoch, enqueue} one step, and a launch on another stream than the last one first waits for
-    // that one (two launches in flight at once would overwrite each other's granules)
-    mutable std::mutex launch_lock;
-    mutable unsigned   epoch       = 0;
-    mutable void      *last_stream = nullptr;
+    // Head pieces travel between the tiles of ONE launch through granules {launch epoch << 32 | half of the value}, 2 per tile.
+    // Two launches in flight at once must not share them, and launches on one stream never are: every stream that has run this
+    // plan owns a granule set with its own epoch counter (a set is 16 bytes per tile).  No launch ever waits for another stream --
+    // a stream that the caller has destroyed since is never touched again.  (mutable: products run on a const plan under the
+    // handle's shared lock; `launch_lock` makes {find the set, take an epoch, enqueue} one step.)
+    struct GranuleSet
+    {
+        void        *stream = nullptr;
+        DeviceBuffer granules; // 2 * ntiles x u64, zeroed at allocation and when the epoch wraps
+        unsigned     epoch = 0; // tags start at 1: zeroed granules match no launch
+    };
+    static constexpr size_t                           MAX_SETS = 16; // more streams than this: the oldest sets are recycled after a device sync
+    mutable std::mutex                               launch_lock;
+    mutable std::vector<std::unique_ptr<GranuleSet>> sets;
 };
 
 // Blocked-ELL copy of a block-dense matrix for the MFMA csrmm (csrmm_bell_kernels.hip; round 4): 16 x 16 blocks, `width` block

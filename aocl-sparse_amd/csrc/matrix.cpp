@@ -860,14 +860,13 @@ aoclsparse_status build_merge_plan(aoclsparse_int m, aoclsparse_int nnz, aoclspa
     aoclsparse_status s1 = mp.starts.upload(st.data(), sizeof(aoclsparse_int) * st.size(), rt.stream());
     if(s1 == aoclsparse_status_success)
         s1 = mp.first.upload(first.data(), sizeof(aoclsparse_int) * first.size(), rt.stream());
-    if(s1 == aoclsparse_status_success)
-        s1 = mp.granules.alloc(sizeof(unsigned long long) * 2 * (size_t)ntiles);
     if(s1 != aoclsparse_status_success)
         return s1;
-    // epoch tags start at 1: zeroed granules match no launch.  (uploads read the host vectors until the stream has run them)
-    MI355_HIP_TRY(hipMemsetAsync(mp.granules.ptr, 0, sizeof(unsigned long long) * 2 * (size_t)ntiles, rt.stream()));
-    MI355_HIP_TRY(hipStreamSynchronize(rt.stream()));
-    mp.epoch = 0, mp.last_stream = nullptr;
+    MI355_HIP_TRY(hipStreamSynchronize(rt.stream())); // (uploads read the host vectors until the stream has run them)
+    {
+        std::lock_guard<std::mutex> g(mp.launch_lock);
+        mp.sets.clear(); // granule sets are made by the first launch on each stream (spmv_api.cpp)
+    }
     mp.ntiles = ntiles;
     mp.valid  = true;
     return aoclsparse_status_success;

@@ -1,6 +1,7 @@
 // runtime.cpp -- device context, pointer classification, staging buffers, misc. entry points.
 #include "internal.hpp"
 
+#include <dlfcn.h>
 #include <sys/mman.h>
 
 #include <cctype>
@@ -463,6 +464,19 @@ aoclsparse_status aoclsparse_mi355_set_stream(void *hip_stream)
 void *aoclsparse_mi355_get_stream(void)
 {
     return Runtime::get().stream();
+}
+
+aoclsparse_status aoclsparse_mi355_hip_runtime_path(char *path, size_t capacity)
+{
+    if(!path)
+        return aoclsparse_status_invalid_pointer;
+    if(capacity == 0)
+        return aoclsparse_status_invalid_size;
+    Dl_info info;
+    if(!dladdr(reinterpret_cast<const void *>(&hipStreamCreate), &info) || !info.dli_fname)
+        return aoclsparse_status_internal_error;
+    std::snprintf(path, capacity, "%s", info.dli_fname);
+    return aoclsparse_status_success;
 }
 
 aoclsparse_status aoclsparse_mi355_synchronize(void)

@@ -122,23 +122,50 @@ aoclsparse_status run_on_device_csr(Runtime &rt, aoclsparse_int kid, const Devic
                               plan.sell.shared ? plan.sell.lead.as<unsigned short>() : nullptr, plan.max_row_nnz);
     else if(plan.merge.valid && order == 0 && !strict) // balanced tiles for irregular rows (scalar order, no pinned kid)
     {
-        // one launch; its head pieces are tagged with an epoch that no earlier launch on this plan used.  Taking the epoch and
-        // enqueueing are one step, and the plan's granules serve one launch at a time: a launch on another stream than the
-        // previous one waits for that one first (same stream: stream order does it).
+        // one launch; its head pieces are tagged with an epoch that no earlier launch on this stream's granule set used
+        // (internal.hpp, MergePlan).  Finding the set, taking the epoch and enqueueing are one step.
         const MergePlan            &mp = plan.merge;
         std::lock_guard<std::mutex> g(mp.launch_lock);
-        if(mp.last_stream && mp.last_stream != (void *)rt.stream())
-            MI355_HIP_TRY(hipStreamSynchronize((hipStream_t)mp.last_stream));
-        if(++mp.epoch == 0) // wrapped: forget every old tag
+        MergePlan::GranuleSet      *gs = nullptr;
+        for(auto &c : mp.sets)
+            if(c->stream == (void *)rt.stream())
+                gs = c.get();
+        const size_t gbytes = sizeof(unsigned long long) * 2 * (size_t)mp.ntiles;
+        if(!gs)
         {
-            MI355_HIP_TRY(hipMemsetAsync(mp.granules.ptr, 0, sizeof(unsigned long long) * 2 * (size_t)mp.ntiles, rt.stream()));
-            mp.epoch = 1;
+            if(mp.sets.size() >= MergePlan::MAX_SETS) // (a caller cycling through streams: everything enqueued so far completes first)
+            {
+                MI355_HIP_TRY(hipDeviceSynchronize());
+                mp.sets.clear();
+            }
+            try
+            {
+                mp.sets.emplace_back(new MergePlan::GranuleSet);
+            }
+            catch(const std::bad_alloc &)
+            {
+                return aoclsparse_status_memory_error;
+            }
+            gs                   = mp.sets.back().get();
+            aoclsparse_status sa = gs->granules.alloc(gbytes);
+            if(sa == aoclsparse_status_success && hipMemsetAsync(gs->granules.ptr, 0, gbytes, rt.stream()) != hipSuccess)
+                sa = aoclsparse_status_internal_error;
+            if(sa != aoclsparse_status_success)
+            {
+                mp.sets.pop_back();
+                return sa;
+            }
+            gs->stream = (void *)rt.stream();
         }
-        mp.last_stream = (void *)rt.stream();
+        if(++gs->epoch == 0) // wrapped: forget every old tag
+        {
+            MI355_HIP_TRY(hipMemsetAsync(gs->granules.ptr, 0, gbytes, rt.stream()));
+            gs->epoch = 1;
+        }
         st = launch_mergepath<T>(rt.stream(), d.base, alpha, mp.ntiles, mp.starts.as<aoclsparse_int>(), mp.first.as<aoclsparse_int>(),
                                  d.val.as<T>(), d.ind.as<aoclsparse_int>(), d.ptr.as<aoclsparse_int>(),
                                  static_cast<const T *>(ax.dev), beta, static_cast<T *>(ay.dev),
-                                 mp.granules.as<unsigned long long>(), mp.epoch);
+                                 gs->granules.as<unsigned long long>(), gs->epoch);
     }
     else
         st = launch_csrmv<T>(rt.stream(), order, strict, plan.tile, d.base, alpha, d.m, d.val.as<T>(),

@@ -58,6 +58,11 @@ DLL_PUBLIC aoclsparse_status aoclsparse_mi355_synchronize(void);
 DLL_PUBLIC aoclsparse_status aoclsparse_mi355_device_info(aoclsparse_int *device,
                                                           aoclsparse_int *compute_units,
                                                           char            name[256]);
+/* Path of the HIP runtime (libamdhip64) this library's calls are bound to, as the dynamic loader resolved them.  A process can
+ * hold two copies (a framework that ships its own next to /opt/rocm's): streams and events are objects of ONE runtime, so a
+ * stream handed to aoclsparse_mi355_set_stream must come from the copy named here.  Writes at most `capacity` bytes including
+ * the terminating zero; invalid_pointer / invalid_size for a null or empty buffer, internal_error when the loader cannot tell. */
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_hip_runtime_path(char *path, size_t capacity);
 /* hipEvent pair on the library's stream: start, run work, stop -> elapsed milliseconds */
 DLL_PUBLIC aoclsparse_status aoclsparse_mi355_timer_start(void);
 DLL_PUBLIC aoclsparse_status aoclsparse_mi355_timer_stop(float *elapsed_ms);

@@ -113,6 +113,20 @@ def test_version_and_context_shims():
     assert L.aoclsparse_enable_instructions(None) == 2
 
 
+def test_hip_runtime_path_names_the_runtime_the_library_is_bound_to():
+    """a process can hold two HIP runtimes (a framework's bundled copy next to /opt/rocm's); streams given to
+    aoclsparse_mi355_set_stream must come from the one this names.  No device is touched."""
+    import ctypes
+    st, path = P.hip_runtime_path()
+    assert st == 0 and "libamdhip64" in os.path.basename(path) and os.path.exists(path)
+    with open("/proc/self/maps") as f:
+        assert any(os.path.realpath(path) == os.path.realpath(ln.split()[-1]) for ln in f if "libamdhip64" in ln)
+    assert L.aoclsparse_mi355_hip_runtime_path(None, 10) == 2  # invalid_pointer
+    buf = ctypes.create_string_buffer(8)
+    assert L.aoclsparse_mi355_hip_runtime_path(buf, 0) == 3  # invalid_size
+    assert L.aoclsparse_mi355_hip_runtime_path(buf, 8) == 0 and len(buf.value) == 7 and path.startswith(buf.value.decode())
+
+
 def test_descriptor_api():
     # library/src/extra/aoclsparse_auxiliary.cpp:191-360
     d = ctypes.c_void_p()

@@ -203,6 +203,75 @@ def test_merge_path_kernel_power_law(merge_kernel, base):
     assert st == 0 and np.array_equal(ys, yr)
 
 
+def test_merge_path_kernel_on_many_streams_and_after_a_stream_is_destroyed(merge_kernel):
+    """The head pieces of a launch travel through a granule set owned by the STREAM the launch runs on (round 5): launches of
+    one handle interleaved on two live streams (different x) do not see each other's pieces; a stream created and destroyed
+    through the HIP runtime is never touched again (the next launch on another stream succeeds); twenty streams in turn (more
+    than the sets a plan keeps) still return the first launch's bits."""
+    # streams are objects of ONE HIP runtime: this process may hold two copies (torch ships its own); take the one the library
+    # is bound to
+    st, path = P.hip_runtime_path()
+    assert st == 0 and "libamdhip64" in path
+    hip = ctypes.CDLL(path)
+    hip.hipStreamCreate.argtypes, hip.hipStreamDestroy.argtypes = [ctypes.POINTER(ctypes.c_void_p)], [ctypes.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    m = n = 20000
+    rp, ci, v = random_csr(321, m, n, lambda r, i: 7000 if i in (5, 9000) else r.integers(0, 8))
+    d = P.Descr()
+    A = P.Matrix(0, m, n, rp, ci, v)
+    xs = [np.random.default_rng(40 + k).uniform(-1, 1, n) for k in range(2)]
+    xd = [dev(x) for x in xs]
+    ref = []
+    for k in range(2):
+        yd = dev(np.zeros(m))
+        assert P.dmv(P.OP_NONE, 1.0, A, d, xd[k], 0.0, yd) == 0
+        torch.cuda.synchronize()
+        ref.append(yd.cpu().numpy())
+        so, yr = oracle.dcsrmv(-1, 0, 1.0, m, len(v), v, ci, rp, xs[k], 0.0, np.zeros(m))
+        scale = abs_row_sums(rp, ci, v, xs[k])
+        assert np.all(np.abs(ref[k] - yr) <= (np.diff(rp) + 24) * EPS64 * scale + 1e-300)
+    assert A.spmv_info().kernel == 2
+    L.aoclsparse_mi355_set_pointer_mode(P.PTR_DEVICE)
+    streams = []
+    try:
+        for _ in range(20):
+            h = ctypes.c_void_p()
+            assert hip.hipStreamCreate(ctypes.byref(h)) == 0
+            streams.append(h)
+        ys = [dev(np.zeros(m)) for _ in range(2)]
+        torch.cuda.synchronize()
+        # two live streams, 30 launches each, interleaved, no synchronisation in between
+        for it in range(30):
+            for k in range(2):
+                assert L.aoclsparse_mi355_set_stream(streams[k]) == 0
+                assert P.dmv(P.OP_NONE, 1.0, A, d, xd[k], 0.0, ys[k]) == 0
+        for k in range(2):
+            assert hip.hipStreamSynchronize(streams[k]) == 0
+            assert np.array_equal(ys[k].cpu().numpy(), ref[k])
+        # stream 0 is destroyed; the plan's set for it is simply never used again
+        assert L.aoclsparse_mi355_set_stream(streams[1]) == 0
+        assert hip.hipStreamDestroy(streams[0]) == 0
+        streams[0] = None
+        ys[1].zero_()
+        torch.cuda.synchronize()
+        assert P.dmv(P.OP_NONE, 1.0, A, d, xd[1], 0.0, ys[1]) == 0
+        assert hip.hipStreamSynchronize(streams[1]) == 0 and np.array_equal(ys[1].cpu().numpy(), ref[1])
+        # more streams than a plan keeps granule sets for
+        for h in streams[2:]:
+            assert L.aoclsparse_mi355_set_stream(h) == 0
+            ys[0].zero_()
+            torch.cuda.synchronize()
+            assert P.dmv(P.OP_NONE, 1.0, A, d, xd[0], 0.0, ys[0]) == 0
+            assert hip.hipStreamSynchronize(h) == 0 and np.array_equal(ys[0].cpu().numpy(), ref[0])
+    finally:
+        assert L.aoclsparse_mi355_set_stream(None) == 0
+        L.aoclsparse_mi355_set_pointer_mode(P.PTR_AUTO)
+        torch.cuda.synchronize()
+        for h in streams:
+            if h is not None:
+                hip.hipStreamDestroy(h)
+
+
 def test_merge_path_kernel_edges(merge_kernel):
     d = P.Descr()
     # smaller than one tile; trailing and leading empty rows; one row spanning many tiles; rectangular
