@@ -488,6 +488,10 @@ struct _aoclsparse_matrix
     mi355::DeviceBuffer dev_diag; // diagonal values of the clean CSR (length min(m,n))
     mi355::DeviceBuffer trsv_scratch; // ticket (one per right-hand side) + timeout words of the sync-free solve
     mi355::DeviceBuffer trsv_xp; // solution(s) in level order, m x nrhs (stream-ordered reuse)
+    // the stream of the last solve that used the two workspaces above: a solve on ANOTHER stream first waits for the device
+    // (not for that stream, which the caller may have destroyed since); written under the runtime's stage lock
+    void *trsv_last_stream = nullptr;
+    bool  trsv_ran         = false;
     // one word of pinned, device-mapped host memory THIS handle's sync-free solves set when a wait expires (round 3,
     // the process-wide word of round 2 could not say which handle had failed, and a failure surfaced on an
     // unrelated solve).  Allocated at the handle's first sync-free solve; read without a device round trip.

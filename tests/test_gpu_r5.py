@@ -144,3 +144,64 @@ int main() {
                            "-Wl,-rpath," + libdir, "-o", str(exe)])
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.startswith("ok"), (r.returncode, r.stdout[-500:], r.stderr[-500:])
+
+
+def test_trsv_solves_of_one_handle_on_alternating_streams():
+    """The sync-free solve's workspaces belong to the handle and are reused in stream order; a solve on another stream than the
+    previous one must not start before that one is done (the library waits for the device then -- never for the old stream, which
+    may no longer exist).  Solves of one handle alternate between two streams with different right-hand sides and no
+    synchronisation by the caller; one of the streams is then destroyed through the HIP runtime the library is bound to and
+    the handle solves on."""
+    import ctypes
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    from util import pkg, triangular_system
+    P = pkg()
+    L = P.lib()
+    st, path = P.hip_runtime_path()
+    assert st == 0
+    hip = ctypes.CDLL(path)
+    hip.hipStreamCreate.argtypes, hip.hipStreamDestroy.argtypes = [ctypes.POINTER(ctypes.c_void_p)], [ctypes.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    m = 60000
+    rp, ci, v = triangular_system(91, m, 3, band=300)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    dl = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=P.FILL_LOWER, diag=P.DIAG_NON_UNIT)
+    assert L.aoclsparse_set_sv_hint(A.h, P.OP_NONE, dl.h, 100) == 0 and L.aoclsparse_optimize(A.h) == 0
+    o = oracle.dcsr_optimize(m, m, len(v), 0, rp, ci, v)
+    bs = [np.random.default_rng(50 + k).uniform(-1, 1, m) for k in range(2)]
+    ref = [oracle.dtrsv("l", 1.0, m, 0, o["val"], o["ind"], o["ptr"], o["idiag"], b, False)[1] for b in bs]
+    bd = [torch.from_numpy(b).cuda() for b in bs]
+    xd = [torch.zeros(m, dtype=torch.float64, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    L.aoclsparse_mi355_set_pointer_mode(P.PTR_DEVICE)
+    hs = []
+    try:
+        for _ in range(2):
+            h = ctypes.c_void_p()
+            assert hip.hipStreamCreate(ctypes.byref(h)) == 0
+            hs.append(h)
+        for it in range(6):
+            for k in range(2):
+                assert L.aoclsparse_mi355_set_stream(hs[k]) == 0
+                assert P.dtrsv(P.OP_NONE, 1.0, A, dl, bd[k], xd[k]) == 0
+        for k in range(2):
+            assert hip.hipStreamSynchronize(hs[k]) == 0
+            assert np.array_equal(xd[k].cpu().numpy(), ref[k])
+        assert L.aoclsparse_mi355_set_stream(hs[0]) == 0
+        assert hip.hipStreamDestroy(hs[1]) == 0
+        hs[1] = None
+        xd[0].zero_()
+        torch.cuda.synchronize()
+        assert P.dtrsv(P.OP_NONE, 1.0, A, dl, bd[0], xd[0]) == 0
+        assert hip.hipStreamSynchronize(hs[0]) == 0 and np.array_equal(xd[0].cpu().numpy(), ref[0])
+    finally:
+        assert L.aoclsparse_mi355_set_stream(None) == 0
+        L.aoclsparse_mi355_set_pointer_mode(P.PTR_AUTO)
+        torch.cuda.synchronize()
+        for h in hs:
+            if h is not None:
+                hip.hipStreamDestroy(h)
