@@ -488,10 +488,11 @@ struct _aoclsparse_matrix
     mi355::DeviceBuffer dev_diag; // diagonal values of the clean CSR (length min(m,n))
     mi355::DeviceBuffer trsv_scratch; // ticket (one per right-hand side) + timeout words of the sync-free solve
     mi355::DeviceBuffer trsv_xp; // solution(s) in level order, m x nrhs (stream-ordered reuse)
-    // the stream of the last solve that used the two workspaces above: a solve on ANOTHER stream first waits for the device
-    // (not for that stream, which the caller may have destroyed since); written under the runtime's stage lock
-    void *trsv_last_stream = nullptr;
-    bool  trsv_ran         = false;
+    // the stream of the last call that used the handle's workspaces (the two above, `work` below): they are reused in stream
+    // order, so a call on ANOTHER stream first waits for the device -- not for that stream, which the caller may have destroyed
+    // since (workspace_stream_guard; written under the runtime's stage lock)
+    void *ws_last_stream = nullptr;
+    bool  ws_ran         = false;
     // one word of pinned, device-mapped host memory THIS handle's sync-free solves set when a wait expires (round 3,
     // the process-wide word of round 2 could not say which handle had failed, and a failure surfaced on an
     // unrelated solve).  Allocated at the handle's first sync-free solve; read without a device round trip.
@@ -528,6 +529,18 @@ struct _aoclsparse_matrix
 
     mutable std::shared_mutex guard;
 };
+
+namespace mi355
+{
+// call with the runtime's stage lock held, before a handle's workspaces are touched on stream s
+inline aoclsparse_status workspace_stream_guard(_aoclsparse_matrix *A, hipStream_t s)
+{
+    if(A->ws_ran && A->ws_last_stream != (void *)s)
+        MI355_HIP_TRY(hipDeviceSynchronize());
+    A->ws_last_stream = (void *)s, A->ws_ran = true;
+    return aoclsparse_status_success;
+}
+} // namespace mi355
 
 namespace mi355
 {

@@ -204,6 +204,7 @@ aoclsparse_status sorv_t(aoclsparse_sor_type sor_type, const aoclsparse_mat_desc
     SpmvPlan  *p = nullptr;
     MI355_TRY(ensure_spmv(A, false, d, p));
     Vec<T> vb, vx;
+    MI355_TRY(workspace_stream_guard(A, rt.stream()));
     MI355_TRY(vb.in(rt, A->work[2], b, m, true));
     MI355_TRY(vx.in(rt, A->work[3], x, m, true));
     MI355_TRY(A->work[0].alloc(sizeof(T) * (size_t)m));
@@ -277,6 +278,7 @@ aoclsparse_status symgs_t(aoclsparse_operation trans, aoclsparse_matrix A, const
     std::lock_guard<std::recursive_mutex> sl(rt.stage_lock); // the handle's workspaces are shared
     const aoclsparse_int m = A->m;
     Vec<T>               vb, vx, vy;
+    MI355_TRY(workspace_stream_guard(A, rt.stream()));
     MI355_TRY(vb.in(rt, A->work[2], b, m, true));
     MI355_TRY(vx.in(rt, A->work[3], x, m, true)); // x carries the initial guess
     if(fuse_mv)
@@ -499,6 +501,7 @@ aoclsparse_status ilu_smoother_t(aoclsparse_operation op, aoclsparse_matrix A, c
 
     const aoclsparse_int m = A->m;
     Vec<T>               vb, vx;
+    MI355_TRY(workspace_stream_guard(A, rt.stream()));
     MI355_TRY(vb.in(rt, A->work[2], b, m, true));
     MI355_TRY(vx.in(rt, A->work[3], x, m, false));
     MI355_TRY(A->work[0].alloc(sizeof(T) * (size_t)m));

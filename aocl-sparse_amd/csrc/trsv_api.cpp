@@ -640,9 +640,9 @@ aoclsparse_status solve_core(aoclsparse_operation trans, T alpha, aoclsparse_mat
 
     // the workspaces are reused in stream order; after a change of stream (aoclsparse_mi355_set_stream) nothing orders this
     // solve behind the previous one, so everything enqueued so far completes first
-    if(A->trsv_ran && A->trsv_last_stream != (void *)rt.stream())
-        MI355_HIP_TRY(hipDeviceSynchronize());
-    A->trsv_last_stream = (void *)rt.stream(), A->trsv_ran = true;
+    st = workspace_stream_guard(A, rt.stream());
+    if(st != aoclsparse_status_success)
+        return st;
 
     const bool bdev = rt.is_device_pointer(b), xdev = rt.is_device_pointer(x);
     const T   *db   = b;
