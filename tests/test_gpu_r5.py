@@ -205,3 +205,69 @@ def test_trsv_solves_of_one_handle_on_alternating_streams():
         for h in hs:
             if h is not None:
                 hip.hipStreamDestroy(h)
+
+
+def test_extreme_value_known_answers():
+    """The reference's extreme-value vectors (tests/unit_tests/extreme_value_tests.cpp, fixture reference_kats_r5.json) through
+    the library: aoclsparse_sp2m (one and two stages), aoclsparse_dadd, aoclsparse_dcsrmm (no kid, kid 1, kid 3; host and
+    device operands) and aoclsparse_ddoti -- NaN where the reference has NaN, the same infinities, finite values within its
+    one-ulp-scale tolerance; and bit for bit what the oracle returns for the same inputs."""
+    import ctypes
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    from util import pkg
+    from test_oracle_golden_r5 import ev_array, ev_match, sorted_csr
+    from test_gpu_parity_r3 import _export
+    P = pkg()
+    L = P.lib()
+    with open(os.path.join(ROOT, "tests", "golden", "reference_kats_r5.json")) as f:
+        k5 = json.load(f)
+    I = k5["init"]
+    m = I["m"]
+    a = (np.array(I["A_row_ptr"], np.int32), np.array(I["A_col_ind"], np.int32), ev_array(I["A_val"]))
+    b = (np.array(I["B_row_ptr"], np.int32), np.array(I["B_col_ind"], np.int32), ev_array(I["B_val"]))
+    A, B, d = P.Matrix(0, m, m, *a), P.Matrix(0, m, m, *b), P.Descr()
+    same = lambda x, y: np.array_equal(np.asarray(x).view(np.uint64) if np.asarray(x).dtype == np.float64 else x,
+                                       np.asarray(y).view(np.uint64) if np.asarray(y).dtype == np.float64 else y)
+    # sp2m, one stage and two
+    so, pc, ic, vc = oracle.dcsr2m(m, m, 0, a[0], a[1], a[2], 0, b[0], b[1], b[2])
+    for stages in ((P.STAGE_FULL,), (P.STAGE_NNZ_COUNT, P.STAGE_FINALIZE)):
+        C = ctypes.c_void_p()
+        for stg in stages:
+            assert L.aoclsparse_sp2m(P.OP_NONE, d.h, A.h, P.OP_NONE, d.h, B.h, stg, ctypes.byref(C)) == 0
+        _, cm, cn, cz, row, col, val = _export(C)
+        assert (cm, cn, cz) == (m, m, 34) and np.array_equal(row, pc) and np.array_equal(col, ic)
+        assert np.array_equal(np.isnan(val), np.isnan(vc)) and same(val[~np.isnan(vc)], vc[~np.isnan(vc)])
+        ev_match(sorted_csr(row, col, val)[1], ev_array(k5["sp2m"]["C_exp_val"]))
+        assert L.aoclsparse_destroy(ctypes.byref(C)) == 0
+    # add
+    C = ctypes.c_void_p()
+    assert L.aoclsparse_dadd(P.OP_NONE, A.h, 1.0, B.h, ctypes.byref(C)) == 0
+    _, cm, cn, cz, row, col, val = _export(C)
+    assert list(row) == k5["add"]["C_exp_row_ptr"] and list(sorted_csr(row, col, val)[0]) == k5["add"]["C_exp_col_ind"]
+    ev_match(sorted_csr(row, col, val)[1], ev_array(k5["add"]["C_exp_val"]))
+    assert L.aoclsparse_destroy(ctypes.byref(C)) == 0
+    # csrmm: row-major, alpha 1, beta 0, C zero on entry (the reference resizes it) -- every kid, host and device operands
+    Bd, exp = ev_array(I["B_dense_row_major"]), ev_array(k5["csrmm"]["C_exp_val"])
+    for kid, lanes in ((None, 0), (1, 4), (3, 8), (0, 0)):
+        st, Co = (oracle.dcsrmm_kt("row", lanes, 1.0, 0, a[2], a[1], a[0], m, Bd, m, m, 0.0, np.zeros(m * m), m) if lanes
+                  else oracle.dcsrmm("row", 1.0, 0, a[2], a[1], a[0], m, Bd, m, m, 0.0, np.zeros(m * m), m))
+        for on_device in (False, True):
+            Ch = np.zeros(m * m)
+            Bx, Cx = (torch.from_numpy(Bd).cuda(), torch.from_numpy(Ch).cuda()) if on_device else (Bd, Ch)
+            assert P.dcsrmm(P.OP_NONE, 1.0, A, d, P.ORDER_ROW, Bx, m, m, 0.0, Cx, m, kid=kid) == 0
+            torch.cuda.synchronize()
+            got = Cx.cpu().numpy() if on_device else Ch
+            ev_match(got, exp)
+            assert np.array_equal(np.isnan(got), np.isnan(Co)) and same(got[~np.isnan(Co)], Co[~np.isnan(Co)]), (kid, on_device)
+    # sparse dot
+    D = k5["dot"]
+    indx, y = np.array(D["indx"], np.int32), np.array(D["y"], np.float64)
+    for case in D["cases"]:
+        x = np.array(D["x"], np.float64)
+        x[0], x[1] = ev_array([case["x0"]])[0], ev_array([case["x1"]])[0]
+        got = L.aoclsparse_ddoti(len(indx), P._ptr(x), P._ptr(indx), P._ptr(y))
+        ev_match(np.array([got]), ev_array([case["expected"]]))
