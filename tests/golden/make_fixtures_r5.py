@@ -52,6 +52,57 @@ def assigns(text, name):
     return [tokens(m.group(1)) for m in re.finditer(r"\b%s\.assign\(\s*\{(.*?)\}\)" % re.escape(name), text, re.S)]
 
 
+def extract_symm_opt():
+    """tests/unit_tests/optimize_symm_herm_tests.cpp:39-758 (generate_test_matrix, real types): four small matrices (one with
+    unsorted rows and missing diagonal entries) and, per triangle, the symmetric matrix the reference's optimize builds from it --
+    both triangles, a diagonal entry in every row -- with the values it holds for non-unit / unit / zero diagonal types.  The
+    reference compares these with its internal CSR copy after set_mv_hint + optimize (+ one mv) for every (fill, base, op, diag)
+    (:760-938); through the public interface they say what y = op(A) x must be."""
+    path = "/root/reference/tests/unit_tests/optimize_symm_herm_tests.cpp"
+    src = open(path).read().split("\n")
+    tops = [i for i, l in enumerate(src) if re.match(r"        case \d+:$", l)]
+    tops.append(next(i for i, l in enumerate(src) if "void test_opt_symm_herm_matrix" in l))
+    nums = lambda t: [float(x) for x in re.findall(r"[-+]?\d+\.?\d*(?:[eE][-+]?\d+)?", t)]
+    out = []
+    for k in range(len(tops) - 1):
+        blk = src[tops[k]:tops[k + 1]]
+        head = "\n".join(blk[:next(i for i, l in enumerate(blk) if "switch(doid)" in l)])
+        mm = re.search(r"m = (\d+), n = (\d+), nnz = (\d+);", head)
+        ent = {"id": k, "src": "tests/unit_tests/optimize_symm_herm_tests.cpp:%d-%d" % (tops[k] + 1, tops[k + 1]),
+               "m": int(mm.group(1)), "n": int(mm.group(2)), "nnz": int(mm.group(3)),
+               "col_ind": [int(x) for x in nums(re.search(r"col_ind\.assign\(\{(.*?)\}\)", head, re.S).group(1))],
+               "row_ptr": [int(x) for x in nums(re.search(r"row_ptr\.assign\(\{(.*?)\}\)", head, re.S).group(1))],
+               "val": nums(re.search(r"\bval\.assign\(\{(.*?)\}\)", head, re.S).group(1)), "expected": {}}
+        idx = [i for i, l in enumerate(blk) if re.match(r"\s*case aoclsparse::doid::\w+:", l)]
+        groups, cur = [], None
+        for i in idx:
+            name = re.search(r"doid::(\w+)", blk[i]).group(1)
+            if cur and i == cur["last"] + 1:
+                cur["names"].append(name), cur.update(last=i)
+            else:
+                cur = {"names": [name], "first": i, "last": i}
+                groups.append(cur)
+        for gi, g in enumerate(groups):
+            t = "\n".join(blk[g["last"] + 1:groups[gi + 1]["first"] if gi + 1 < len(groups) else len(blk)])
+            e = {}
+            for f in ("ptr", "ind", "idiag", "non_unit_diag_val", "unit_diag_val", "zero_diag_val", "diag_val"):
+                body = re.search(r"sol_opt_csr_t\.%s\.assign\(\s*\{(.*?)\}\);" % f, t, re.S).group(1)
+                if "{" in body:  # (a hermitian group lists the complex values first: the real branch is not needed here)
+                    e = None
+                    break
+                e[f] = nums(body) if f.endswith("val") else [int(x) for x in nums(body)]
+            if e is None:
+                continue
+            assert len(e["ind"]) == e["ptr"][-1] == len(e["non_unit_diag_val"]) == len(e["unit_diag_val"]) == len(e["zero_diag_val"])
+            assert len(e["idiag"]) == ent["m"] == len(e["diag_val"])
+            for nm in g["names"]:
+                if nm in ("sl", "su"):  # real symmetric: lower / upper triangle of the input
+                    ent["expected"]["lower" if nm == "sl" else "upper"] = e
+        assert set(ent["expected"]) == {"lower", "upper"}, (k, list(ent["expected"]))
+        out.append(ent)
+    return {"src": "tests/unit_tests/optimize_symm_herm_tests.cpp:39-938", "zero_based": True, "matrices": out}
+
+
 def main():
     lines = open(SRC).read().split("\n")
 
@@ -91,6 +142,7 @@ def main():
                    "cases": [{"x0": "nan", "x1": 0.0, "expected": "nan"}, {"x0": "inf", "x1": "-inf", "expected": "nan"},
                              {"x0": "inf", "x1": 1.0, "expected": "inf"}, {"x0": "max", "x1": "max", "expected": "inf"},
                              {"x0": "max", "x1": 1.0, "expected": "max"}]}
+    kats["symm_opt"] = extract_symm_opt()
     assert len(kats["init"]["A_val"]) == 17 and len(kats["init"]["B_val"]) == 21 and len(kats["init"]["B_dense_row_major"]) == 49
     assert len(kats["add"]["C_exp_val"]) == 26 and len(kats["sp2m"]["C_exp_val"]) == 34 and len(kats["csrmm"]["C_exp_val"]) == 49
     assert len(kats["dot"]["x"]) == 18 and len(kats["dot"]["y"]) == 21

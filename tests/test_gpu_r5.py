@@ -271,3 +271,35 @@ def test_extreme_value_known_answers():
         x[0], x[1] = ev_array([case["x0"]])[0], ev_array([case["x1"]])[0]
         got = L.aoclsparse_ddoti(len(indx), P._ptr(x), P._ptr(indx), P._ptr(y))
         ev_match(np.array([got]), ev_array([case["expected"]]))
+
+
+def test_symmetric_mv_matches_the_matrix_the_reference_optimize_builds():
+    """optimize_symm_herm_tests.cpp:39-938 through the library: for the reference's four matrices (fixture symm_opt), both
+    triangles, the three diagonal types, both bases and op = none / transpose, aoclsparse_dmv after set_mv_hint + optimize returns
+    E x -- E being the symmetric matrix the reference lists as the content of its optimized copy (small integers: exact)."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import pkg
+    from test_oracle_golden_r5 import symm_expected_y
+    P = pkg()
+    L = P.lib()
+    with open(os.path.join(ROOT, "tests", "golden", "reference_kats_r5.json")) as f:
+        k5 = json.load(f)
+    ran = 0
+    for M in k5["symm_opt"]["matrices"]:
+        m = M["m"]
+        x = np.arange(1, m + 1, dtype=np.float64) * np.array([1, -2, 3, 5][:m])
+        for base in (0, 1):
+            rp, ci, v = np.array(M["row_ptr"], np.int32) + base, np.array(M["col_ind"], np.int32) + base, np.array(M["val"])
+            for fill, tri in ((P.FILL_LOWER, "lower"), (P.FILL_UPPER, "upper")):
+                for diag in (P.DIAG_NON_UNIT, P.DIAG_UNIT, P.DIAG_ZERO):
+                    for op in (P.OP_NONE, P.OP_TRANSPOSE):
+                        A = P.Matrix(base, m, m, rp, ci, v)
+                        d = P.Descr(mtype=P.TYPE_SYMMETRIC, fill=fill, diag=diag, base=base)
+                        assert L.aoclsparse_set_mv_hint(A.h, op, d.h, 1) == 0 and L.aoclsparse_optimize(A.h) == 0
+                        y = np.full(m, 7.0)
+                        assert P.dmv(op, 1.0, A, d, x, 0.0, y) == 0
+                        assert np.array_equal(y, symm_expected_y(M["expected"][tri], diag, x)), (M["id"], base, tri, diag, op)
+                        ran += 1
+    assert ran == 4 * 2 * 2 * 3 * 2

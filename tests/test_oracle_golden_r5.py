@@ -90,3 +90,29 @@ def test_extreme_value_dot(k5):
         x = np.array(D["x"], np.float64)
         x[0], x[1] = ev_array([case["x0"]])[0], ev_array([case["x1"]])[0]
         ev_match(np.array([oracle.ddoti(x, indx, y)]), ev_array([case["expected"]]))
+
+
+def symm_expected_y(e, diag, x):
+    """y = E x for the symmetric matrix the reference's optimize holds (fixture symm_opt: ptr / ind + the values of the diagonal
+    type); small integers, so every summation order gives the same doubles"""
+    vals = np.array(e[{0: "non_unit_diag_val", 1: "unit_diag_val", 2: "zero_diag_val"}[diag]])
+    ptr, ind = e["ptr"], e["ind"]
+    return np.array([sum(vals[p] * x[ind[p]] for p in range(ptr[i], ptr[i + 1])) for i in range(len(ptr) - 1)])
+
+
+@pytest.mark.parametrize("base", [0, 1])
+def test_symmetric_mv_matches_the_matrix_the_reference_optimize_builds(k5, base):
+    """optimize_symm_herm_tests.cpp:39-938 (real types): for each of its four matrices -- one with unsorted rows and missing
+    diagonal entries -- each triangle and each diagonal type, the oracle's symmetric SpMV on the clean CSR equals E x, E being the
+    expanded matrix the reference lists as the content of its optimized copy."""
+    for M in k5["symm_opt"]["matrices"]:
+        m = M["m"]
+        rp, ci, v = np.array(M["row_ptr"], np.int32) + base, np.array(M["col_ind"], np.int32) + base, np.array(M["val"])
+        o = oracle.dcsr_optimize(m, m, M["nnz"], base, rp, ci, v)
+        assert o["status"] == 0
+        x = np.arange(1, m + 1, dtype=np.float64) * np.array([1, -2, 3, 5][:m])
+        for fill, tri in ((0, "lower"), (1, "upper")):
+            for diag in (0, 1, 2):
+                st, y = oracle.dcsrmv_special("symm", o["base"], 1.0, m, m, diag, fill, o["val"], o["ind"], o["ptr"], o["idiag"], o["iurow"],
+                                              x, 0.0, np.zeros(m))
+                assert st == 0 and np.array_equal(y, symm_expected_y(M["expected"][tri], diag, x)), (M["id"], tri, diag)
