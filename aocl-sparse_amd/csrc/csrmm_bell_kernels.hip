@@ -114,13 +114,13 @@ namespace
             nblk++;
         // Operands of block s+1 are requested before the MFMAs of block s.  (Fetching the A fragments -- a pure HBM stream --
         // three blocks ahead gained 3 % without C read and cost 100 VGPRs: profiles/r4/bell_experiments.txt.)
+        // A slot past the last block is CLAMPED to it, not skipped: the loads of the look-ahead are then issued on every path, and
+        // the waits the compiler places in front of the MFMAs count them exactly.  (With `if(s >= nblk) return;` here the number of
+        // younger loads in flight depended on the path, the MFMAs of block s waited for vmcnt(1) / vmcnt(0) -- i.e. for the
+        // operands of block s + 1 as well -- and the look-ahead hid nothing: round 5, profiles/r5/bell_experiments.txt.)  The
+        // operands of the clamped slot are never multiplied: the loop ends first.
         auto fetch_a = [&](int s, double (&a)[4]) {
-            if(s >= nblk)
-            {
-                a[0] = a[1] = a[2] = a[3] = 0.0;
-                return;
-            }
-            const double *vs = vb + (size_t)s * 256;
+            const double *vs = vb + (size_t)(s < nblk ? s : nblk - 1) * 256;
             if constexpr(WIDE)
             {
                 // A fragments of t = 2p, 2p+1 sit side by side (build_bell's layout): one 16-byte load per pair
@@ -142,9 +142,7 @@ namespace
             relb[t] = (unsigned)(4 * t + kq) * (unsigned)ldb + (unsigned)(WIDE ? 2 * jl : jl);
         const double *Bj = B + j0;
         auto fetch_b = [&](int s, double (&b)[NT][4]) {
-            if(s >= nblk)
-                return; // (never multiplied: the loop ends first)
-            const int     bc = __builtin_amdgcn_readfirstlane(cb[s]);
+            const int     bc = __builtin_amdgcn_readfirstlane(cb[s < nblk ? s : nblk - 1]);
             const double *bs = Bj + (size_t)bc * 16 * (size_t)ldb;
 #pragma unroll
             for(int t = 0; t < 4; t++)
@@ -178,8 +176,11 @@ namespace
                     acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b[u][t], acc[u], 0, 0, 0);
         };
         double a0[4], a1[4], b0[NT][4], b1[NT][4];
-        fetch_a(0, a0);
-        fetch_b(0, b0);
+        if(nblk > 0)
+        {
+            fetch_a(0, a0);
+            fetch_b(0, b0);
+        }
         // C is read (beta != 0, or the reference's 0 * C): requested behind the first block's operands, used after the last
         // block's MFMAs -- the closing read-modify-write does not add a dependent round trip per block row
         double   cin[NT][4];
@@ -404,13 +405,9 @@ namespace
         int                   nblk = 0;
         while(nblk < width && cb[nblk] >= 0)
             nblk++;
+        // (a slot past the last block is clamped to it, not skipped: see the row-major kernel)
         auto fetch_a = [&](int s, double (&a)[4]) {
-            if(s >= nblk)
-            {
-                a[0] = a[1] = a[2] = a[3] = 0.0;
-                return;
-            }
-            const double *vs  = vb + (size_t)s * 256;
+            const double *vs  = vb + (size_t)(s < nblk ? s : nblk - 1) * 256;
             const v2d     a01 = *reinterpret_cast<const v2d *>(vs + 2 * lane), a23 = *reinterpret_cast<const v2d *>(vs + 128 + 2 * lane);
             a[0] = a01.x, a[1] = a01.y, a[2] = a23.x, a[3] = a23.y;
         };
@@ -420,9 +417,7 @@ namespace
         for(int u = 0; u < NT; u++)
             colbase[u] = (size_t)(colok[u] ? j0 + 16 * u + jl : 0) * (size_t)ldb + (size_t)(WIDE ? 4 * kq : kq);
         auto fetch_b = [&](int s, double (&b)[NT][4]) {
-            if(s >= nblk)
-                return;
-            const int     bc = __builtin_amdgcn_readfirstlane(cb[s]);
+            const int     bc = __builtin_amdgcn_readfirstlane(cb[s < nblk ? s : nblk - 1]);
             const double *bs = B + (size_t)bc * 16;
             if constexpr(WIDE)
             {
@@ -466,8 +461,11 @@ namespace
                     acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[u][t], a[t], acc[u], 0, 0, 0);
         };
         double a0[4], a1[4], b0[NT][4], b1[NT][4];
-        fetch_a(0, a0);
-        fetch_b(0, b0);
+        if(nblk > 0)
+        {
+            fetch_a(0, a0);
+            fetch_b(0, b0);
+        }
         // beta == 0 with C read (RC 2): the C tile requested now, reduced to a finite / not-finite bit per element behind the first
         // block's MFMAs (see the row-major kernel)
         double   cin[NT][4];
