@@ -221,6 +221,28 @@ def test_bench_two_ranks_gloo_one_gpu(tmp_path):
     assert short["legs"]["sp2m_row_sharded"]["parity"] is True
 
 
+def test_bench_one_rank_under_the_launcher_with_the_nccl_backend(tmp_path):
+    """bench.py under torch.distributed.run with its default backend ("nccl" = RCCL), one rank: what the driver's scaling run does
+    at every N, here at the only N one GPU allows -- the process group is an RCCL communicator, the record says so (backend, world,
+    RCCL version), the collective legs run (their exchanges are identities at world 1) and return the reference's bits."""
+    rec = str(tmp_path / "legs.json")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+           "--grid", "512", "--mm-grid", "200", "--mm-cols", "64", "--shard-grid", "301", "--bell-nodes", "6", "--legs",
+           "csrmm_sharded,spmv_row_sharded,sp2m_row_sharded", "--sp2m-grid", "150", "--record", rec]
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4"), capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, "rc=%d\nstdout:\n%s\nstderr:\n%s" % (r.returncode, r.stdout[-3000:], r.stderr[-3000:])
+    short, res = _bench_record(r.stdout, rec)
+    comm = short["config"]["communicator"]
+    assert comm["backend"] == "nccl" and comm["world"] == 1 and comm["rccl_version"][0].isdigit()
+    assert res["n_gpus"] == 1 and res["parity"]["bit_exact"] is True
+    for leg in ("csrmm_sharded_col", "csrmm_sharded_row", "csrmm_sharded_bell", "spmv_row_sharded", "sp2m_row_sharded"):
+        assert "error" not in res[leg], (leg, res[leg])
+        assert res[leg]["world"] == 1 and res[leg]["parity"]["bit_exact"] is True, (leg, res[leg])
+        assert short["legs"][leg]["parity"] is True
+
+
 def _check_two_rank_record(short, res, own_rows):
     assert res["n_gpus"] == 2 and res["steps"] == 5 and res["scaling"] == "weak" and res["unit"] == "GFLOP/s"
     assert res["parity"]["bit_exact"] is True
