@@ -28,3 +28,16 @@ for rep in range(4):
         for _ in range(200): pkg.dmv(pkg.OP_NONE, 1.0, A, d, x, 0.0, y)
         res[k].append(round(pkg.timer_stop() / 200 * 1e3, 2))
 print(json.dumps({"matrix": label, "pre_alloc_mb": pre, "us_per_handle_in_creation_order": res}), flush=True)
+# the same handles with the Infinity Cache flushed before every product (a 1 GB fill between two timed calls): does the spread
+# between placements survive when nothing of the matrix can be left in the cache from the call before?
+big = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+cold = []
+for k, A in enumerate(hs):
+    t = []
+    for _ in range(30):
+        big.fill_(1)
+        torch.cuda.synchronize(); pkg.timer_start()
+        pkg.dmv(pkg.OP_NONE, 1.0, A, d, x, 0.0, y)
+        t.append(pkg.timer_stop() * 1e3)
+    cold.append(round(float(np.median(t)), 2))
+print(json.dumps({"matrix": label, "us_per_handle_cold_median_of_30": cold}), flush=True)
