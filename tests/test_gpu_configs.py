@@ -350,6 +350,13 @@ def test_bench_single_process_small_legs(tmp_path):
               "csrmm_col_slab_ms", "csrmm_col_eff8", "trsv_ms"):
         assert n.get(k) is not None and n[k] > 0, (k, n)
     assert n["csrmm_parity"] and n["mix_parity"] and n["trsv_parity"]
+    # the twins of the headline product (round 5): fp32, the literal host-pointer call (PCIe inside), the same product with the
+    # Infinity Cache flushed before every call, the launch-bound case as a C caller / inside a HIP graph sees it
+    tw = legs["headline_twins"]
+    assert "error" not in tw and tw["smv"]["bit_exact_first_2e20_rows"] and tw["host_pointer_dmv"]["bit_exact_vs_headline_y"]
+    assert n["smv_parity"] and n["smv_frac"] > 0 and n["host_ptr_dmv_ms"] > short["ms_per_step"]
+    assert n["dmv_cold_ms"] == tw["cold_dmv"]["ms"] > 0
+    assert n["l100_graph_us"] > 0 and (n.get("l100_c_caller_us") is None or n["l100_c_caller_us"] > 0)
 
 
 # --------------------------------------------------------------------------------------------------
