@@ -122,7 +122,8 @@ aoclsparse_status cmv_t(aoclsparse_operation op, const cplx<R> *alpha, aoclspars
                                            plan->sell.val.as<C>(), plan->sell.col.as<aoclsparse_int>(),
                                            plan->sell.rowlen.as<aoclsparse_int>(), static_cast<const C *>(ax.dev), *beta,
                                            static_cast<C *>(ay.dev), plan->sell.shared ? plan->sell.cptr.as<long long>() : nullptr,
-                                           plan->sell.shared ? plan->sell.lead.as<unsigned short>() : nullptr, plan->max_row_nnz));
+                                           plan->sell.shared ? plan->sell.lead.as<unsigned short>() : nullptr, plan->max_row_nnz,
+                                           plan->sell.next_direction()));
     else
         MI355_TRY(launch_cspmv<R>(rt.stream(), dcsr->base, conj, *alpha, dcsr->m, dcsr->nnz, dcsr->val.as<C>(),
                                   dcsr->ind.as<aoclsparse_int>(), dcsr->ptr.as<aoclsparse_int>(),

@@ -276,6 +276,13 @@ struct SellPlan
     DeviceBuffer   cptr, lead;
     bool           valid = false, tried = false;
     bool           wanted = false; // optimize chose SELL: rebuilt lazily after the values change
+    // products served by this copy: odd ones walk the slices in descending order, so that what one product leaves in the
+    // Infinity Cache (the END of its sweep) is where the next one starts (sell_kernels.hip); the bits do not depend on it
+    mutable std::atomic<unsigned> products{0};
+    int next_direction() const
+    {
+        return (int)(products.fetch_add(1u, std::memory_order_relaxed) & 1u);
+    }
 };
 
 // csrmm row groups (csrmm_kernels.hip: csrmm_rowgroup_kernel): runs of consecutive rows with one column pattern
@@ -370,6 +377,8 @@ struct SpmvPlan
     BellPlan       bell;
     std::atomic<int> mv_calls{0}; // products served from this plan without a SELL copy (promotion counter;
                                   // concurrent ?mv calls on one handle are allowed, as in the reference)
+    // products of the row-block kernel: odd ones walk the blocks in descending order (see SellPlan::products)
+    mutable std::atomic<unsigned> sweeps{0};
 };
 
 // TRSV plan of one (triangle, op) pair (trsv_api.cpp / trsv_kernels.hip): the strict triangle
@@ -731,7 +740,7 @@ template <typename R>
 aoclsparse_status launch_sellmv_complex(hipStream_t s, bool conj, cplx<R> alpha, aoclsparse_int m, aoclsparse_int nslices,
                                         const long long *slice_ptr, const cplx<R> *sval, const aoclsparse_int *scol,
                                         const aoclsparse_int *rowlen, const cplx<R> *x, cplx<R> beta, cplx<R> *y,
-                                        const long long *cptr, const unsigned short *lead, aoclsparse_int max_width);
+                                        const long long *cptr, const unsigned short *lead, aoclsparse_int max_width, int rev = 0);
 aoclsparse_status launch_sell_leaders(hipStream_t s, aoclsparse_int m, int base, const aoclsparse_int *row_ptr, const aoclsparse_int *col,
                                       aoclsparse_int nslices, unsigned short *lead, aoclsparse_int *nl);
 template <typename T>
@@ -739,7 +748,7 @@ aoclsparse_status launch_sellmv(hipStream_t s, int order, int pack, T alpha, aoc
                                 const long long *slice_ptr, const T *sval, const aoclsparse_int *scol,
                                 const aoclsparse_int *rowlen, const T *x, T beta, T *y, const long long *cptr = nullptr,
                                 const unsigned short *lead = nullptr,
-                                aoclsparse_int max_width = 0);
+                                aoclsparse_int max_width = 0, int rev = 0);
 // BLKCSR (blk_kernels.hip): value offset of every block (three small launches: per-chunk popcount scan, scan of
 // the chunk totals in part[], add), then the product
 constexpr int     BLK_PART_SHIFT = 10;

@@ -312,9 +312,13 @@ __global__ __launch_bounds__(64 * WAVES) void sell_mv_kernel(aoclsparse_int m, a
                                                              const aoclsparse_int *__restrict__ rowlen, T alpha,
                                                              const T *__restrict__ x, T beta, T *__restrict__ y,
                                                              bool nt, const long long *__restrict__ cptr = nullptr,
-                                                             const unsigned short *__restrict__ follow = nullptr)
+                                                             const unsigned short *__restrict__ follow = nullptr, int rev = 0)
 {
-    const int s    = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + (threadIdx.x >> 6)));
+    // rev: the slices in descending order.  Consecutive products of a handle ALTERNATE the direction (SellPlan::products): the
+    // end of the matrix, which the previous product left in the 256 MB Infinity Cache, is where this one starts -- round 5,
+    // profiles/r5/sell_placement.txt: shell-like 90-101 -> 81-87 us, the headline 0.178 -> 0.165 ms.  Same slices, same bits.
+    const unsigned bx = rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+    const int s    = __builtin_amdgcn_readfirstlane((int)(bx * WAVES + (threadIdx.x >> 6)));
     const int lane = threadIdx.x & 63;
     if(s >= nslices)
         return;
@@ -466,12 +470,13 @@ __global__ __launch_bounds__(64 * WAVES) void sell_mv_short_kernel(aoclsparse_in
                                                                    const aoclsparse_int *__restrict__ scol, T alpha,
                                                                    const T *__restrict__ x, T beta, T *__restrict__ y, bool nt,
                                                                    const long long *__restrict__ cptr,
-                                                                   const unsigned short *__restrict__ follow)
+                                                                   const unsigned short *__restrict__ follow, int rev = 0)
 {
     // SPW slices per wavefront, walked TOGETHER (all value / column loads of the SPW slices, then all gathers, then the chains):
     // SPW times the bytes in flight per wavefront.  Lost for double (two: 0.183-0.236 vs 0.177 ms, round 3); float moves half the
     // bytes per load instruction, and large float launches run four (round 4: sell_launch_short).
-    const int sb   = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + (threadIdx.x >> 6)) * SPW);
+    const unsigned bx = rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+    const int sb   = __builtin_amdgcn_readfirstlane((int)(bx * WAVES + (threadIdx.x >> 6)) * SPW);
     const int lane = threadIdx.x & 63;
     if(sb >= nslices)
         return;
@@ -542,7 +547,7 @@ constexpr aoclsparse_int SELL_SHORT_SPW4_SLICES = 100000;
 template <typename T, bool SHARED>
 bool sell_launch_short(hipStream_t s, int wmax, aoclsparse_int m, aoclsparse_int nslices, const long long *slice_ptr, const T *sval,
                        const aoclsparse_int *scol, T alpha, const T *x, T beta, T *y, bool nt, const long long *cptr,
-                       const unsigned short *lead)
+                       const unsigned short *lead, int rev = 0)
 {
     constexpr int WAVES = 4;
     // float, >= 100,000 slices: four slices per wavefront (a float load instruction moves half the bytes of a double one; same box,
@@ -555,10 +560,10 @@ bool sell_launch_short(hipStream_t s, int wmax, aoclsparse_int m, aoclsparse_int
     case W:                                                                                                               \
         if(four)                                                                                                          \
             hipLaunchKernelGGL((sell_mv_short_kernel<T, W, WAVES, SHARED, 4>), grid, block, 0, s, m, nslices, slice_ptr, sval, \
-                               scol, alpha, x, beta, y, nt, cptr, lead);                                                  \
+                               scol, alpha, x, beta, y, nt, cptr, lead, rev);                                             \
         else                                                                                                              \
             hipLaunchKernelGGL((sell_mv_short_kernel<T, W, WAVES, SHARED>), grid, block, 0, s, m, nslices, slice_ptr, sval, \
-                               scol, alpha, x, beta, y, nt, cptr, lead);                                                  \
+                               scol, alpha, x, beta, y, nt, cptr, lead, rev);                                             \
         return true
     switch(wmax)
     {
@@ -578,7 +583,7 @@ bool sell_launch_short(hipStream_t s, int wmax, aoclsparse_int m, aoclsparse_int
 template <typename T, int ORDER, int PACK>
 void sell_launch(hipStream_t s, aoclsparse_int m, aoclsparse_int nslices, const long long *slice_ptr, const T *sval,
                  const aoclsparse_int *scol, const aoclsparse_int *rowlen, T alpha, const T *x, T beta, T *y,
-                 const long long *cptr, const unsigned short *lead)
+                 const long long *cptr, const unsigned short *lead, int rev = 0)
 {
     // one slice per workgroup while the launch is small (every slice its own CU), two otherwise
     // (swept on the headline workload: 1 / 2 / 4 / 8 slices per workgroup = 0.221 / 0.218 / 0.221 / 0.222 ms)
@@ -587,18 +592,18 @@ void sell_launch(hipStream_t s, aoclsparse_int m, aoclsparse_int nslices, const 
     {
         if(nslices < 2048)
             hipLaunchKernelGGL((sell_mv_kernel<T, ORDER, 1, PACK, true>), dim3(nslices), dim3(64), 0, s, m, nslices, slice_ptr,
-                               sval, scol, rowlen, alpha, x, beta, y, nt, cptr, lead);
+                               sval, scol, rowlen, alpha, x, beta, y, nt, cptr, lead, rev);
         else
             hipLaunchKernelGGL((sell_mv_kernel<T, ORDER, 2, PACK, true>), dim3((nslices + 1) / 2), dim3(128), 0, s, m, nslices,
-                               slice_ptr, sval, scol, rowlen, alpha, x, beta, y, nt, cptr, lead);
+                               slice_ptr, sval, scol, rowlen, alpha, x, beta, y, nt, cptr, lead, rev);
     }
     else if(nslices < 2048)
         hipLaunchKernelGGL((sell_mv_kernel<T, ORDER, 1, PACK>), dim3(nslices), dim3(64), 0, s, m, nslices, slice_ptr,
-                           sval, scol, rowlen, alpha, x, beta, y, nt, (const long long *)nullptr, (const unsigned short *)nullptr);
+                           sval, scol, rowlen, alpha, x, beta, y, nt, (const long long *)nullptr, (const unsigned short *)nullptr, rev);
     else
         hipLaunchKernelGGL((sell_mv_kernel<T, ORDER, 2, PACK>), dim3((nslices + 1) / 2), dim3(128), 0, s, m, nslices,
                            slice_ptr, sval, scol, rowlen, alpha, x, beta, y, nt, (const long long *)nullptr,
-                           (const unsigned short *)nullptr);
+                           (const unsigned short *)nullptr, rev);
 }
 
 } // namespace
@@ -634,7 +639,7 @@ template <typename T>
 aoclsparse_status launch_sellmv(hipStream_t s, int order, int pack, T alpha, aoclsparse_int m, aoclsparse_int nslices,
                                 const long long *slice_ptr, const T *sval, const aoclsparse_int *scol,
                                 const aoclsparse_int *rowlen, const T *x, T beta, T *y, const long long *cptr,
-                                const unsigned short *lead, aoclsparse_int max_width)
+                                const unsigned short *lead, aoclsparse_int max_width, int rev)
 {
     if(m <= 0 || nslices <= 0)
         return aoclsparse_status_success;
@@ -644,9 +649,9 @@ aoclsparse_status launch_sellmv(hipStream_t s, int order, int pack, T alpha, aoc
     if(order == 0 && pack == 1 && max_width >= 1 && max_width <= 8 && nslices >= 4096)
     {
         const bool nt   = (size_t)m * sizeof(T) > ((size_t)32 << 20);
-        const bool done = cptr ? sell_launch_short<T, true>(s, (int)max_width, m, nslices, slice_ptr, sval, scol, alpha, x, beta, y, nt, cptr, lead)
+        const bool done = cptr ? sell_launch_short<T, true>(s, (int)max_width, m, nslices, slice_ptr, sval, scol, alpha, x, beta, y, nt, cptr, lead, rev)
                                : sell_launch_short<T, false>(s, (int)max_width, m, nslices, slice_ptr, sval, scol, alpha, x, beta, y, nt,
-                                                             nullptr, nullptr);
+                                                             nullptr, nullptr, rev);
         if(done)
         {
             MI355_HIP_TRY(hipGetLastError());
@@ -654,7 +659,7 @@ aoclsparse_status launch_sellmv(hipStream_t s, int order, int pack, T alpha, aoc
         }
     }
 #define SELL_CASE(O, P)                                                                        \
-    sell_launch<T, O, P>(s, m, nslices, slice_ptr, sval, scol, rowlen, alpha, x, beta, y, cptr, lead); \
+    sell_launch<T, O, P>(s, m, nslices, slice_ptr, sval, scol, rowlen, alpha, x, beta, y, cptr, lead, rev); \
     break
     switch(order * 2 + (pack == 4 ? 1 : 0))
     {
@@ -682,7 +687,7 @@ template <typename R>
 aoclsparse_status launch_sellmv_complex(hipStream_t s, bool conj, cplx<R> alpha, aoclsparse_int m, aoclsparse_int nslices,
                                         const long long *slice_ptr, const cplx<R> *sval, const aoclsparse_int *scol,
                                         const aoclsparse_int *rowlen, const cplx<R> *x, cplx<R> beta, cplx<R> *y,
-                                        const long long *cptr, const unsigned short *lead, aoclsparse_int max_width)
+                                        const long long *cptr, const unsigned short *lead, aoclsparse_int max_width, int rev)
 {
     using C = cplx<R>;
     if(m <= 0 || nslices <= 0)
@@ -699,7 +704,7 @@ aoclsparse_status launch_sellmv_complex(hipStream_t s, bool conj, cplx<R> alpha,
 #define MI355_CSHORT(W)                                                                                                          \
     case W:                                                                                                                      \
         hipLaunchKernelGGL((sell_mv_short_kernel<C, W, WAVES, SH, 1, CJ>), grid, block, 0, s, m, nslices, slice_ptr, sval, scol, \
-                           alpha, x, beta, y, nt, cp, ld);                                                                       \
+                           alpha, x, beta, y, nt, cp, ld, rev);                                                                  \
         return
             switch((int)max_width)
             {
@@ -716,10 +721,10 @@ aoclsparse_status launch_sellmv_complex(hipStream_t s, bool conj, cplx<R> alpha,
         }
         if(nslices < 2048)
             hipLaunchKernelGGL((sell_mv_kernel<C, 0, 1, 1, SH, CJ>), dim3(nslices), dim3(64), 0, s, m, nslices, slice_ptr, sval, scol,
-                               rowlen, alpha, x, beta, y, nt, cp, ld);
+                               rowlen, alpha, x, beta, y, nt, cp, ld, rev);
         else
             hipLaunchKernelGGL((sell_mv_kernel<C, 0, 2, 1, SH, CJ>), dim3((nslices + 1) / 2), dim3(128), 0, s, m, nslices, slice_ptr,
-                               sval, scol, rowlen, alpha, x, beta, y, nt, cp, ld);
+                               sval, scol, rowlen, alpha, x, beta, y, nt, cp, ld, rev);
     };
     if(cptr)
     {
@@ -738,10 +743,10 @@ aoclsparse_status launch_sellmv_complex(hipStream_t s, bool conj, cplx<R> alpha,
 template aoclsparse_status launch_sellmv_complex<double>(hipStream_t, bool, cdouble, aoclsparse_int, aoclsparse_int, const long long *,
                                                          const cdouble *, const aoclsparse_int *, const aoclsparse_int *,
                                                          const cdouble *, cdouble, cdouble *, const long long *,
-                                                         const unsigned short *, aoclsparse_int);
+                                                         const unsigned short *, aoclsparse_int, int);
 template aoclsparse_status launch_sellmv_complex<float>(hipStream_t, bool, cfloat, aoclsparse_int, aoclsparse_int, const long long *,
                                                         const cfloat *, const aoclsparse_int *, const aoclsparse_int *, const cfloat *,
-                                                        cfloat, cfloat *, const long long *, const unsigned short *, aoclsparse_int);
+                                                        cfloat, cfloat *, const long long *, const unsigned short *, aoclsparse_int, int);
 // (the fill kernels only move values: cfloat cells are filled as 8-byte doubles, cdouble cells need their own instantiation)
 template aoclsparse_status launch_sell_fill<cdouble>(hipStream_t, int, aoclsparse_int, int, const aoclsparse_int *, const aoclsparse_int *,
                                                      const cdouble *, aoclsparse_int, const long long *, cdouble *, aoclsparse_int *,
@@ -765,7 +770,7 @@ aoclsparse_status launch_sell_leaders(hipStream_t s, aoclsparse_int m, int base,
     template aoclsparse_status launch_sellmv<T>(hipStream_t, int, int, T, aoclsparse_int, aoclsparse_int,             \
                                                 const long long *, const T *, const aoclsparse_int *,                 \
                                                 const aoclsparse_int *, const T *, T, T *, const long long *,          \
-                                                const unsigned short *, aoclsparse_int);
+                                                const unsigned short *, aoclsparse_int, int);
 MI355_SELL_INSTANTIATE(double)
 MI355_SELL_INSTANTIATE(float)
 

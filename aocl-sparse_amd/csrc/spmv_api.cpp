@@ -119,7 +119,8 @@ aoclsparse_status run_on_device_csr(Runtime &rt, aoclsparse_int kid, const Devic
                               plan.sell.val.as<T>(), plan.sell.col.as<aoclsparse_int>(),
                               plan.sell.rowlen.as<aoclsparse_int>(), static_cast<const T *>(ax.dev), beta,
                               static_cast<T *>(ay.dev), plan.sell.shared ? plan.sell.cptr.as<long long>() : nullptr,
-                              plan.sell.shared ? plan.sell.lead.as<unsigned short>() : nullptr, plan.max_row_nnz);
+                              plan.sell.shared ? plan.sell.lead.as<unsigned short>() : nullptr, plan.max_row_nnz,
+                              plan.sell.next_direction());
     else if(plan.merge.valid && order == 0 && !strict) // balanced tiles for irregular rows (scalar order, no pinned kid)
     {
         // one launch; its head pieces are tagged with an epoch that no earlier launch on this stream's granule set used
@@ -168,12 +169,18 @@ aoclsparse_status run_on_device_csr(Runtime &rt, aoclsparse_int kid, const Devic
                                  gs->granules.as<unsigned long long>(), gs->epoch);
     }
     else
-        st = launch_csrmv<T>(rt.stream(), order, strict, plan.tile, d.base, alpha, d.m, d.val.as<T>(),
+    {
+        // (bit 1 of the tile word: blocks in descending order -- every second product of a plan whose blocks are in row order;
+        // the heavy-first order of irregular matrices is left alone)
+        const bool by_rows = !(plan.heavy_first && (plan.tile & 1) == 0);
+        const int  rev     = by_rows ? (int)(plan.sweeps.fetch_add(1u, std::memory_order_relaxed) & 1u) : 0;
+        st = launch_csrmv<T>(rt.stream(), order, strict, plan.tile | (rev ? 2 : 0), d.base, alpha, d.m, d.val.as<T>(),
                              d.ind.as<aoclsparse_int>(), d.ptr.as<aoclsparse_int>(),
                              plan.rowblocks.as<aoclsparse_int>(), plan.nblocks, static_cast<const T *>(ax.dev),
                              beta, static_cast<T *>(ay.dev),
                              (plan.heavy_first && (plan.tile & 1) == 0) ? plan.rowblocks4.as<aoclsparse_int>() : nullptr,
                              plan.max_row_nnz, stale);
+    }
     if(st != aoclsparse_status_success)
         return st;
     st = ay.out(rt);

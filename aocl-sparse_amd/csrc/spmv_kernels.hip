@@ -212,7 +212,7 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(const int2 *__restr
     const T      *xb  = x - base; // gathers take the raw column values (the base is folded into the pointer once)
     // XCD-aware order: workgroups with equal blockIdx%8 share an XCD (one L2); give each XCD a
     // contiguous eighth of the row blocks so its x windows stay in its own L2.
-    const int b = (flags & 4) ? (blockIdx.x & 7) * chunk + (blockIdx.x >> 3) : (int)blockIdx.x;
+    const int b = (flags & 4) ? (blockIdx.x & 7) * chunk + (blockIdx.x >> 3) : (flags & 64) ? nblocks - 1 - (int)blockIdx.x : (int)blockIdx.x;
     if(b >= nblocks)
         return;
     int r0, p0, nrows, cnt;
@@ -781,8 +781,8 @@ aoclsparse_status launch_csrmv(hipStream_t s, int order, bool strict, int tile, 
 {
     if(m <= 0 || nblocks <= 0)
         return aoclsparse_status_success;
-    const bool xcd = (tile & 1) != 0;
-    tile &= ~1;
+    const bool xcd = (tile & 1) != 0, rev = (tile & 2) != 0;
+    tile &= ~3;
     int flags = strict ? 1 : 0;
     if(reinterpret_cast<uintptr_t>(val) % 16 == 0 && reinterpret_cast<uintptr_t>(col) % 16 == 0)
         flags |= 2;
@@ -794,6 +794,8 @@ aoclsparse_status launch_csrmv(hipStream_t s, int order, bool strict, int tile, 
     const int var = strict ? 1 : (max_row_nnz <= 8 ? 2 : 0);
     if(stale)
         flags |= 32; // the block table is a cached plan of a raw-array call: every workgroup validates its own entry
+    if(rev && !xcd)
+        flags |= 64; // blocks in descending order (the caller alternates: the end of one sweep is still in the Infinity Cache)
     const int tsel = tile == 512 ? 0 : (tile == 1024 ? 1 : (tile == 2048 ? 2 : -1));
     if(tsel < 0 || order < 0 || order > 2)
         return aoclsparse_status_invalid_kid;

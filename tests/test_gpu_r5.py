@@ -303,3 +303,76 @@ def test_symmetric_mv_matches_the_matrix_the_reference_optimize_builds():
                         assert np.array_equal(y, symm_expected_y(M["expected"][tri], diag, x)), (M["id"], base, tri, diag, op)
                         ran += 1
     assert ran == 4 * 2 * 2 * 3 * 2
+
+
+def test_consecutive_products_alternate_the_sweep_direction_with_the_same_bits():
+    """Odd-numbered products of a handle walk the SELL-64 slices (and the row blocks of the CSR kernel) in DESCENDING order, so
+    that what one product leaves in the Infinity Cache is where the next one starts.  The direction is not allowed to show in
+    the result: six consecutive products return the oracle's bits, on the short-row SELL kernel (5,625 slices), the general
+    PACK-4 kernel (8-lane order), the CSR-Adaptive kernel of an un-hinted handle (before its promotion), float and complex."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    from util import banded_rows, laplace5, pkg
+    P = pkg()
+    L = P.lib()
+    d = P.Descr()
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+    def six(run, ref, what):
+        for it in range(6):
+            got = run()
+            assert np.array_equal(got, ref), (what, it, float(np.max(np.abs(got - ref))))
+
+    # (a) short-row SELL kernel, shared column lists
+    m, rp, ci, v = laplace5(600)
+    x = np.sin(0.01 * np.arange(m))
+    A = P.Matrix(0, m, m, rp, ci, v)
+    assert L.aoclsparse_set_mv_hint(A.h, P.OP_NONE, d.h, 100) == 0 and L.aoclsparse_optimize(A.h) == 0
+    assert A.spmv_info().kernel in (3, 4)
+    so, yr = oracle.dcsrmv(-1, 0, 1.5, m, len(v), v, ci, rp, x, 0.0, np.zeros(m))
+    xd, yd = dev(x), torch.zeros(m, dtype=torch.float64, device="cuda")
+
+    def run_a():
+        assert P.dmv(P.OP_NONE, 1.5, A, d, xd, 0.0, yd) == 0
+        torch.cuda.synchronize()
+        return yd.cpu().numpy()
+    six(run_a, yr, "short")
+    # (a') the same matrix in float
+    vf = v.astype(np.float32)
+    Af = P.Matrix(0, m, m, rp, ci, vf)
+    assert L.aoclsparse_set_mv_hint(Af.h, P.OP_NONE, d.h, 100) == 0 and L.aoclsparse_optimize(Af.h) == 0
+    xf = x.astype(np.float32)
+    so, yrf = oracle.scsrmv("lane8", 0, 1.0, m, vf, ci, rp, xf, 0.0, np.zeros(m, np.float32))
+    xfd, yfd = dev(xf), torch.zeros(m, dtype=torch.float32, device="cuda")
+
+    def run_f():
+        assert P.smv(P.OP_NONE, 1.0, Af, d, xfd, 0.0, yfd) == 0
+        torch.cuda.synchronize()
+        return yfd.cpu().numpy()
+    six(run_f, yrf, "float")
+    # (b) general kernel, PACK 4, 8-lane order (nnz > 10 m)
+    m2 = 40000
+    rp2, ci2, v2 = banded_rows(17, m2, m2, lambda r, i: r.integers(18, 26))
+    x2 = np.random.default_rng(6).uniform(-1, 1, m2)
+    B = P.Matrix(0, m2, m2, rp2, ci2, v2)
+    assert L.aoclsparse_set_mv_hint(B.h, P.OP_NONE, d.h, 100) == 0 and L.aoclsparse_optimize(B.h) == 0
+    assert B.spmv_info().kernel in (3, 4) and len(v2) > 10 * m2
+    so, yr2 = oracle.dcsrmv(-1, 0, 1.0, m2, len(v2), v2, ci2, rp2, x2, 0.0, np.zeros(m2))
+    x2d, y2d = dev(x2), torch.zeros(m2, dtype=torch.float64, device="cuda")
+
+    def run_b():
+        assert P.dmv(P.OP_NONE, 1.0, B, d, x2d, 0.0, y2d) == 0
+        torch.cuda.synchronize()
+        return y2d.cpu().numpy()
+    six(run_b, yr2, "pack4")
+    # (c) no hint: the row-block kernel (the handle is promoted to SELL-64 at its 8th product only)
+    C = P.Matrix(0, m, m, rp, ci, v)
+
+    def run_c():
+        assert P.dmv(P.OP_NONE, 1.5, C, d, xd, 0.0, yd) == 0 and C.spmv_info().kernel == 1
+        torch.cuda.synchronize()
+        return yd.cpu().numpy()
+    six(run_c, yr, "csr-adaptive")
