@@ -585,6 +585,16 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
         st = ensure_spmv(const_cast<aoclsparse_matrix>(A), tr, d, p);
     if(st != aoclsparse_status_success)
         return st;
+    // Every second product of a plan runs its blocks in descending order (mm_order.hpp): what one product leaves in the Infinity
+    // Cache -- the end of B and C -- is where the next one starts.  The word is the calling thread's, for the launches below only.
+    struct DirectionScope
+    {
+        explicit DirectionScope(const SpmvPlan *pl)
+        {
+            mm_direction_word() = (pl && (pl->mm_products.fetch_add(1u, std::memory_order_relaxed) & 1u)) ? MM_DESCENDING : 0;
+        }
+        ~DirectionScope() { mm_direction_word() = 0; }
+    } direction(p);
     // Column-major with every row shorter than the KT vector width: csrmm_col_kt never forms a full group, its element is the
     // scalar chain from zero followed by fma(beta, C, alpha * cij) (csrmm_kt.cpp:158-191) -- the kid-0 arithmetic to the bit, so
     // the tuned column-major kernels serve it (kid 3 on the 5-point Laplacian: 4.7 -> 1.45 ms at 256 columns).

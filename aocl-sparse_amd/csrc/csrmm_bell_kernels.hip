@@ -27,6 +27,7 @@
 // sign of the zero depends on C), re-read C and take the reference's fma.  Rounds 3-4 read C at the end of the block row: a
 // dependent round trip per block row behind a 3 us MFMA chain (1.29 vs 0.93 ms with C overwritten).
 #include "internal.hpp"
+#include "mm_order.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -85,8 +86,9 @@ namespace
         // takes a fifth of the fabric traffic away and is SLOWER: 0.93 -> 0.98 ms in round 4, 1.115 -> 1.222 (C read) / 0.922 ->
         // 0.951 ms in round 5, profiles/r4/bell_experiments.txt, profiles/r5/bell_experiments.txt)
         const int wv   = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-        const long g   = (long)blockIdx.x * 4 + wv;
-        const int  br  = (int)(g / waves_per_row), cw = (int)(g % waves_per_row);
+        const int  wpr = waves_per_row & ~MM_DESCENDING; // (bit 30 of the word: workgroups in descending order, mm_order.hpp)
+        const long g   = (long)mm_linear_index(waves_per_row) * 4 + wv;
+        const int  br  = (int)(g / wpr), cw = (int)(g % wpr);
         if(br >= nbr)
             return;
         const int lane = threadIdx.x & 63, jl = lane & 15, kq = lane >> 4;
@@ -382,8 +384,9 @@ namespace
                                                                       const aoclsparse_int *__restrict__ ci, const double *__restrict__ cv)
     {
         const int  wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-        const long g  = (long)blockIdx.x * 4 + wv;
-        const int  br = (int)(g / waves_per_row), cw = (int)(g % waves_per_row);
+        const int  wpr = waves_per_row & ~MM_DESCENDING;
+        const long g  = (long)mm_linear_index(waves_per_row) * 4 + wv;
+        const int  br = (int)(g / wpr), cw = (int)(g % wpr);
         if(br >= nbr)
             return;
         const int lane = threadIdx.x & 63, jl = lane & 15, kq = lane >> 4;

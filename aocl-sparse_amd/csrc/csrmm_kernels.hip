@@ -18,6 +18,7 @@
 //                columns, so A is read n/64 times and every B / C access is coalesced across rows.
 // Algorithmic bytes: (m+1+nnz)*4 + nnz*8 + 8*n*(k + m*(1+[beta!=0]))  (BASELINE.md section 2).
 #include "internal.hpp"
+#include "mm_order.hpp"
 #include "kt_order.hpp"
 
 #include <hip/hip_runtime.h>
@@ -29,6 +30,13 @@
 
 namespace mi355
 {
+
+int &mm_direction_word()
+{
+    static thread_local int word = 0;
+    return word;
+}
+
 
 template <typename T>
 struct vec2;
@@ -63,7 +71,7 @@ __global__ __launch_bounds__(256) void csrmm_row_kernel(int base, T alpha, aocls
                                                         aoclsparse_int ldc, bool readc, int xcd_chunk)
 {
     using V     = typename vec2<T>::type;
-    const int bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int bx = mm_block_index(xcd_chunk);
     const int i  = bx * blockDim.y + threadIdx.y; // rows on grid.x (no 65535 limit)
     if(i >= m)
         return;
@@ -125,7 +133,7 @@ __global__ __launch_bounds__(256) void csrmm_row_wave_kernel(int base, T alpha, 
     // XCD-contiguous row order: workgroups with equal blockIdx%8 share an XCD / L2; giving each XCD one
     // contiguous eighth of the rows lets the B rows a row shares with its neighbours (i+-1, i+-g) be L2
     // hits instead of fabric reads by up to five different XCDs
-    const int bx  = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int bx  = mm_block_index(xcd_chunk);
     const int i   = bx * 4 + w;
     const int j   = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
     if(i >= m || j >= n)
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(256) void csrmm_row_wave_rc_kernel(int base, T alph
 {
     using V      = typename vec2<T>::type;
     const int w  = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int bx = mm_block_index(xcd_chunk);
     const int i  = bx * 4 + w;
     const int j  = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
     if(i >= m || j >= n)
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(256) void csrmm_row_wave_rc4_kernel(int base, float
                                                                  float beta, float *__restrict__ C, aoclsparse_int ldc, int xcd_chunk)
 {
     const int w  = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int bx = mm_block_index(xcd_chunk);
     const int i  = bx * 4 + w;
     const int j  = 4 * (int)(threadIdx.x & 63) + 256 * (int)blockIdx.y;
     if(i >= m || j >= n)
@@ -341,12 +349,13 @@ __global__ __launch_bounds__(256) void csrmm_row_run_kernel(int base, T alpha, a
     int bx, cy = (int)blockIdx.y;
     if(ny > 0)
     {
-        const int idx = (int)(blockIdx.x >> 3);
-        cy            = idx % ny;
-        bx            = (int)(blockIdx.x & 7) * xcd_chunk + idx / ny;
+        const unsigned bi  = mm_linear_index(xcd_chunk);
+        const int      idx = (int)(bi >> 3);
+        cy                 = idx % ny;
+        bx                 = (int)(bi & 7) * (xcd_chunk & ~MM_DESCENDING) + idx / ny;
     }
     else
-        bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+        bx = mm_block_index(xcd_chunk);
     const int j = 2 * (int)(threadIdx.x & 63) + 128 * cy;
     if((bx * 4 + w) * R >= m || j >= n)
         return;
@@ -500,7 +509,7 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup2_kernel(int base, T alpha,
     using V         = typename vec2<T>::type;
     constexpr int U = 4;
     const int     w  = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int     bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int     bx = mm_block_index(xcd_chunk);
     const int     gt = bx * 4 + w;
     const int     jr = 2 * (int)(threadIdx.x & 63) + 128 * (int)blockIdx.y;
     const bool    have = gt < ngroups;
@@ -687,7 +696,7 @@ __global__ __launch_bounds__(256) void csrmm_rowgroup_sub_kernel(int base, T alp
                                                              int xcd_chunk)
 {
     using V      = typename vec2<T>::type;
-    const int bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int bx = mm_block_index(xcd_chunk);
     constexpr int NG = 256 / LANES; // groups per workgroup
     const int     gi = bx * NG + (int)threadIdx.x / LANES;
     const int     jr = 2 * ((int)threadIdx.x % LANES) + 2 * LANES * (int)blockIdx.y;
@@ -836,7 +845,7 @@ __global__ __launch_bounds__(256, 4) void csrmm_tile_kernel(int base, T alpha, c
     __shared__ int s_ptr[MAXR + 1];
     __shared__ int s_col[TILE];
     __shared__ T   s_val[TILE];
-    const int bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int bx = mm_block_index(xcd_chunk);
     if(bx >= nblocks)
         return;
     const int r0 = blocks[2 * bx], s0 = blocks[2 * bx + 1];
@@ -1040,7 +1049,7 @@ __global__ __launch_bounds__(256) void csrmm_col_kernel(int base, T alpha, aocls
                                                         const aoclsparse_int *__restrict__ rows)
 {
     // rows != nullptr: the m entries of `rows` are the rows to compute (the partner-less rows of the pair kernel)
-    const int bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int bx = mm_block_index(xcd_chunk);
     const int t  = bx * blockDim.x + threadIdx.x;
     if(t >= m)
         return;
@@ -1130,7 +1139,7 @@ __global__ __launch_bounds__(256) void csrmm_colpair_kernel(int base, T alpha, a
                                                             bool c_aligned, int xcd_chunk)
 {
     typedef T v2 __attribute__((ext_vector_type(2)));
-    const int bx = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int bx = mm_block_index(xcd_chunk);
     const int t  = bx * 256 + (int)threadIdx.x;
     if(t >= npairs)
         return;
@@ -1496,10 +1505,10 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
             const int ny = (n + 127) / 128;
             if(run_order && chunk > 0 && (long long)gx * ny < (1LL << 31))
                 hipLaunchKernelGGL((csrmm_row_run_kernel<T, RUN>), dim3(gx * ny, 1), dim3(256), 0, s, base, alpha, m, val, col,
-                                   row_ptr, B, n, ldb, beta, C, ldc, readc, chunk, run_order, ny);
+                                   row_ptr, B, n, ldb, beta, C, ldc, readc, mmw(chunk), run_order, ny);
             else
                 hipLaunchKernelGGL((csrmm_row_run_kernel<T, RUN>), dim3(gx, ny), dim3(256), 0, s, base, alpha, m, val, col,
-                                   row_ptr, B, n, ldb, beta, C, ldc, readc, chunk, run_order, 0);
+                                   row_ptr, B, n, ldb, beta, C, ldc, readc, mmw(chunk), run_order, 0);
         }
         else if(vec && n >= 128)
         {
@@ -1512,14 +1521,14 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
             {
                 if constexpr(std::is_same<T, float>::value)
                     hipLaunchKernelGGL(csrmm_row_wave_rc4_kernel, dim3(gx, (n + 255) / 256), dim3(256), 0, s, base, alpha, m, val, col,
-                                       row_ptr, B, n, ldb, beta, C, ldc, chunk);
+                                       row_ptr, B, n, ldb, beta, C, ldc, mmw(chunk));
             }
             else if(readc)
                 hipLaunchKernelGGL((csrmm_row_wave_rc_kernel<T>), dim3(gx, (n + 127) / 128), dim3(256), 0, s, base, alpha,
-                                   m, val, col, row_ptr, B, n, ldb, beta, C, ldc, chunk);
+                                   m, val, col, row_ptr, B, n, ldb, beta, C, ldc, mmw(chunk));
             else
                 hipLaunchKernelGGL((csrmm_row_wave_kernel<T>), dim3(gx, (n + 127) / 128), dim3(256), 0, s, base, alpha,
-                                   m, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk);
+                                   m, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, mmw(chunk));
         }
         else
         {
@@ -1686,7 +1695,7 @@ aoclsparse_status launch_csrmm_tiled(hipStream_t s, int base, T alpha, const T *
             {
                 (void)hipMemsetAsync(trace, 0, sizeof(unsigned long long) * 8 * (size_t)(chunk * 8), s);
                 hipLaunchKernelGGL((csrmm_tile_kernel<T, 16, TILE, 2, NB, RC, false, true>), grid, dim3(256), 0, s, base, alpha, val,
-                                   col, row_ptr, blocks, nblocks, B, n, ldb, beta, C, ldc, readc, chunk, trace);
+                                   col, row_ptr, blocks, nblocks, B, n, ldb, beta, C, ldc, readc, mmw(chunk), trace);
                 std::vector<unsigned long long> host(8 * (size_t)nblocks);
                 if(hipStreamSynchronize(s) == hipSuccess
                    && hipMemcpy(host.data(), trace, sizeof(unsigned long long) * host.size(), hipMemcpyDeviceToHost) == hipSuccess)
@@ -1704,13 +1713,13 @@ aoclsparse_status launch_csrmm_tiled(hipStream_t s, int base, T alpha, const T *
             if(kt)
             {
                 hipLaunchKernelGGL((csrmm_tile_kernel<T, 16, TILE, 2, NB, true, true>), grid, dim3(256), 0, s, base, alpha, val, col,
-                                   row_ptr, blocks, nblocks, B, n, ldb, beta, C, ldc, readc, chunk, (unsigned long long *)nullptr,
+                                   row_ptr, blocks, nblocks, B, n, ldb, beta, C, ldc, readc, mmw(chunk), (unsigned long long *)nullptr,
                                    kt_tail);
                 return;
             }
         }
         hipLaunchKernelGGL((csrmm_tile_kernel<T, 16, TILE, 2, NB, RC>), grid, dim3(256), 0, s, base, alpha, val, col, row_ptr,
-                           blocks, nblocks, B, n, ldb, beta, C, ldc, readc, chunk);
+                           blocks, nblocks, B, n, ldb, beta, C, ldc, readc, mmw(chunk));
     };
     auto go2 = [&](auto tile_tag, auto nb_tag) {
         if(readc)

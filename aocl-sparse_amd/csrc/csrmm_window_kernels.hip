@@ -29,6 +29,7 @@
 // that starts at +0 can never be -0), so no NaN / Inf of B can enter through padding.  Rows longer than K finish their chain
 // from the CSR arrays (same order).
 #include "internal.hpp"
+#include "mm_order.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -69,7 +70,7 @@ namespace
         extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
         constexpr int KP  = (K + 1) / 2;         // packed offset registers per row
         const int     tid = threadIdx.x;
-        const int     bx  = chunk > 0 ? (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+        const int     bx  = mm_block_index(chunk);
         const int     r0  = bx * CW_NT * RPT;
         if(r0 >= m)
             return;

@@ -379,7 +379,14 @@ struct SpmvPlan
                                   // concurrent ?mv calls on one handle are allowed, as in the reference)
     // products of the row-block kernel: odd ones walk the blocks in descending order (see SellPlan::products)
     mutable std::atomic<unsigned> sweeps{0};
+    // the same for csrmm: every second product of a handle runs its blocks in descending order (csrmm_kernels.hip: mm_block_index)
+    mutable std::atomic<unsigned> mm_products{0};
 };
+
+// Direction of the NEXT csrmm launches of the calling thread (set by csrmm_api.cpp right before it dispatches; the launchers put it
+// into bit 30 of the kernels' XCD-chunk word).  0: ascending.
+constexpr int MM_DESCENDING = 0x40000000;
+int  &mm_direction_word();
 
 // TRSV plan of one (triangle, op) pair (trsv_api.cpp / trsv_kernels.hip): the strict triangle
 // re-laid out in LEVEL ORDER.  Position k holds row rowmap[k]; its entries sit at

@@ -376,3 +376,43 @@ def test_consecutive_products_alternate_the_sweep_direction_with_the_same_bits()
         torch.cuda.synchronize()
         return yd.cpu().numpy()
     six(run_c, yr, "csr-adaptive")
+
+
+def test_consecutive_csrmm_products_alternate_the_block_order_with_the_same_bits():
+    """Every second row-major csrmm product of a handle runs its row blocks in descending order (mm_order.hpp).  Five consecutive
+    products -- 32 columns (the slab kernel) and 256 columns (row per wavefront; row runs in overwrite mode), C read and
+    overwritten -- return the same bits, and the first four columns are the oracle's."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    from util import beta0_overwrite, laplace5, pkg
+    P = pkg()
+    L = P.lib()
+    d = P.Descr()
+    m, rp, ci, v = laplace5(300)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    assert L.aoclsparse_set_mm_hint(A.h, P.OP_NONE, d.h, 100) == 0 and L.aoclsparse_optimize(A.h) == 0
+    rng = np.random.default_rng(9)
+    for n in (32, 256):
+        B = rng.uniform(-1, 1, m * n)
+        Bd = torch.from_numpy(B).cuda()
+        Bc = np.ascontiguousarray(B.reshape(m, n)[:, :4].T).ravel()
+        so, Cr = oracle.dcsrmm("col", 1.25, 0, v, ci, rp, m, Bc, 4, m, 0.0, np.zeros(4 * m), m)
+        for overwrite in (False, True):
+            first = None
+            for it in range(5):
+                Cd = torch.zeros(m * n, dtype=torch.float64, device="cuda")
+                if overwrite:
+                    with beta0_overwrite(P):
+                        assert P.dcsrmm(P.OP_NONE, 1.25, A, d, P.ORDER_ROW, Bd, n, n, 0.0, Cd, n) == 0
+                else:
+                    assert P.dcsrmm(P.OP_NONE, 1.25, A, d, P.ORDER_ROW, Bd, n, n, 0.0, Cd, n) == 0
+                torch.cuda.synchronize()
+                got = Cd.cpu().numpy()
+                if first is None:
+                    first = got
+                    assert np.array_equal(np.ascontiguousarray(got.reshape(m, n)[:, :4].T).ravel(), Cr), (n, overwrite)
+                else:
+                    assert np.array_equal(got, first), (n, overwrite, it)
