@@ -621,10 +621,10 @@ def main():
             "workload": "aoclsparse_dmv, 5-pt Laplacian grid %dx%d (m=%d, nnz=%d), alpha=1 beta=0; "
                         "BASELINE configs[1] scaled past the 256 MiB Infinity Cache" % (g, g, m, nnz),
             # (the first 160 characters go into the short record: what a reader of `frac` must know comes first)
-            "kernel": ("SELL-64 (%d slices, %.3f cells per nnz%s); products alternate the sweep direction, so part of a product's "
-                       "bytes comes from the 256 MB Infinity Cache (frac can pass 1; cold: legs.dmv_cold_ms); built by "
+            "kernel": ("SELL-64, %d slices%s; alternating sweep direction: part of the bytes comes from the 256 MB Infinity "
+                       "Cache, frac may pass 1 (cold: legs.dmv_cold_ms); %.3f cells per nnz, built by "
                        "aoclsparse_optimize for the mv hint, order %d (reference ref_csrmv_gn order)%s"
-                       % (info.sell_slices, info.stored_cells / max(nnz, 1), ", shared column lists" if info.kernel == 4 else "",
+                       % (info.sell_slices, ", shared column lists" if info.kernel == 4 else "", info.stored_cells / max(nnz, 1),
                           info.order, ": ONE column list per run of rows that repeat it (as it is or shifted by one: a stencil's "
                           "rows) instead of one per row" if info.kernel == 4 else ""))
                       if info.kernel in (3, 4) else
