@@ -354,6 +354,8 @@ def compact_record(full, record_path=None):
     rf = full.get("roofline") or {}
     c["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "frac_traffic", "traffic",
                                             "algorithmic_bytes_per_launch", "kernel_ms", "traffic_source")}
+    if rf.get("note"):
+        c["roofline"]["note"] = _short(rf["note"], 180)
     if c["roofline"].get("frac_traffic") is None and rf.get("traffic") and rf.get("kernel_ms") and rf.get("peak"):
         c["roofline"]["frac_traffic"] = round(rf["traffic"] / (rf["kernel_ms"] * 1e-3) / 1e9 / rf["peak"], 4)  # (reports of rounds 1-4)
     cb = full.get("cpu_baseline")
@@ -638,7 +640,10 @@ def main():
         "roofline": roofline(abytes, kernel_ms, traffic, traffic_source=traffic_src,
                              stored_format_bytes_per_launch=(info.stored_cells * 12 + 16 * m) if info.kernel == 3
                              else (None if info.kernel == 4 else abytes),  # kernel 4: see roofline.traffic (PMC)
-                             achieved_at_median=round(abytes / (stats["median"] * 1e-3) / 1e9, 2)),
+                             achieved_at_median=round(abytes / (stats["median"] * 1e-3) / 1e9, 2),
+                             note=("frac = CSR-model bytes / time / peak; the format moves `traffic` bytes (fabric side, PMC) and alternating "
+                                   "sweeps serve part of them from the 256 MB Infinity Cache, so frac may pass 1")
+                             if info.kernel in (3, 4) else None),
         "stats": dict(stats, unit="ms per step (device, hipEvent between consecutive launches)"),
     }
     if lap_bcast_ms:
