@@ -925,23 +925,23 @@ def main():
                 t.append((time.perf_counter() - t0h) * 1e3)
         finally:
             L.aoclsparse_mi355_set_pointer_mode(pkg.PTR_DEVICE)
-        # the headline product COLD: a 1 GB fill between any two timed products, so that nothing of the matrix is left in the 256 MB
-        # Infinity Cache from the call before (back-to-back products keep part of their working set there, and how much depends on
-        # where the arrays lie: profiles/r5/sell_placement.txt).  One product per event pair -- the fill's write-back and the event
-        # pair are inside the figure, so it is an upper bound of the cold time.  Never the headline value.
+        # the headline product COLD: 1 GB of other data is READ between any two timed products, so that nothing of the matrix is
+        # left in the 256 MB Infinity Cache from the call before (back-to-back products keep part of their working set there;
+        # profiles/r5/sell_placement.txt).  One product per event pair.  (A 1 GB FILL as the flush leaves dirty lines whose
+        # write-back runs into the product: 0.211 instead of 0.173 ms, tools/exp_cold.py.)  Never the headline value.
         try:
-            flush = torch.empty(1 << 30, dtype=torch.uint8, device=device)
+            flush = torch.ones(1 << 28, dtype=torch.float32, device=device)
             tc = []
             for _ in range(12):
-                flush.fill_(1)
+                flush.sum()
                 torch.cuda.synchronize()
                 pkg.timer_start()
                 assert pkg.dmv(pkg.OP_NONE, 1.0, A, descr, x, 0.0, y) == 0
                 tc.append(pkg.timer_stop())
             del flush
             cms = float(np.median(tc[2:]))
-            res["cold_dmv"] = {"workload": "the headline aoclsparse_dmv with the Infinity Cache flushed before every product (1 GB fill)",
-                               "ms": round(cms, 6), "roofline": roofline(abytes, cms)}
+            res["cold_dmv"] = {"workload": "the headline aoclsparse_dmv with the Infinity Cache flushed before every product (1 GB read)",
+                               "ms": round(cms, 6), "roofline": roofline(abytes, cms, traffic)}
         except Exception as e:  # noqa: BLE001 -- an extra
             res["cold_dmv"] = {"error": repr(e)[:200]}
         res["host_pointer_dmv"] = {"workload": "aoclsparse_dmv with host x / y (reference calling convention), same matrix",

@@ -30,14 +30,15 @@ for rep in range(4):
 print(json.dumps({"matrix": label, "pre_alloc_mb": pre, "us_per_handle_in_creation_order": res}), flush=True)
 # the same handles with the Infinity Cache flushed before every product (a 1 GB fill between two timed calls): does the spread
 # between placements survive when nothing of the matrix can be left in the cache from the call before?
-big = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
-cold = []
-for k, A in enumerate(hs):
-    t = []
-    for _ in range(30):
-        big.fill_(1)
-        torch.cuda.synchronize(); pkg.timer_start()
-        pkg.dmv(pkg.OP_NONE, 1.0, A, d, x, 0.0, y)
-        t.append(pkg.timer_stop() * 1e3)
-    cold.append(round(float(np.median(t)), 2))
-print(json.dumps({"matrix": label, "us_per_handle_cold_median_of_30": cold}), flush=True)
+big = torch.ones(1 << 28, dtype=torch.float32, device="cuda")
+for how, flush in (("1 GB fill (dirty lines: their write-back runs into the product)", lambda: big.fill_(1.0)), ("1 GB read", lambda: big.sum())):
+    cold = []
+    for k, A in enumerate(hs):
+        t = []
+        for _ in range(30):
+            flush()
+            torch.cuda.synchronize(); pkg.timer_start()
+            pkg.dmv(pkg.OP_NONE, 1.0, A, d, x, 0.0, y)
+            t.append(pkg.timer_stop() * 1e3)
+        cold.append(round(float(np.median(t)), 2))
+    print(json.dumps({"matrix": label, "flush": how, "us_per_handle_cold_median_of_30": cold}), flush=True)
