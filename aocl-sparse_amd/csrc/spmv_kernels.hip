@@ -173,6 +173,9 @@ constexpr int TREE_MIN = SPMV_TREE_MIN;
 //        loaded anyway (s_row), so each workgroup checks its own two boundaries for free; on a mismatch it computes its rows
 //        straight from the live arrays (same chains, no LDS tile) and raises *stale for the host's next call.  No check
 //        kernel, no stream round trip per call (round 3 paid ~70 us for one: 0.334 vs 0.262 ms on the 4096^2 Laplacian).
+//        bit6 the blocks in DESCENDING order: every second product of a plan whose blocks are in row order (spmv_api.cpp) -- the end
+//        of one sweep over the matrix is still in the 256 MB Infinity Cache when the next one starts there (round 5; see
+//        sell_kernels.hip, where the gain is larger); the bits do not depend on the order.
 // VAR: 0 general (auto mode: wavefront tree for scalar-order rows of >= 32 entries); 1 strict: every row in the reference's order (the tile-by-tile chain of the longest rows keeps the next tile in registers); 2 every row of the
 // plan has <= 8 entries (stencils: no batched-read code, no long-row code).  Template parameters, not run-time flags: the register
 // allocation of a kernel is the maximum over ALL its paths, and the strict path's prefetch registers and the batched reads of
