@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""round 5: the headline product back to back, one call per event pair, and COLD -- the 256 MB Infinity Cache flushed before every
+product by a 1 GB fill (leaves dirty lines: their write-back runs into the product) or by a 1 GB read (clean).
+python3 tools/exp_cold.py  ->  profiles/r5/sell_placement.txt"""
 import sys, os, numpy as np, torch
 sys.path.insert(0, os.getcwd())
 import __graft_entry__ as entry
