@@ -26,7 +26,7 @@ ORDER_ROW, ORDER_COLUMN = 0, 1
 STAGE_NNZ_COUNT, STAGE_FINALIZE, STAGE_FULL = 0, 1, 2
 MEM_MINIMAL, MEM_UNRESTRICTED = 0, 1
 PTR_AUTO, PTR_HOST, PTR_DEVICE = 0, 1, 2
-OPTION_SPMV_KERNEL, OPTION_SELL, OPTION_SPMV_STRICT = 0, 1, 2  # aoclsparse_mi355_set_option
+OPTION_SPMV_KERNEL, OPTION_SELL, OPTION_SPMV_STRICT, OPTION_ALTERNATE_SWEEPS = 0, 1, 2, 3  # aoclsparse_mi355_set_option
 
 STATUS = {
     0: "success", 1: "not_implemented", 2: "invalid_pointer", 3: "invalid_size", 4: "internal_error",

@@ -279,10 +279,7 @@ struct SellPlan
     // products served by this copy: odd ones walk the slices in descending order, so that what one product leaves in the
     // Infinity Cache (the END of its sweep) is where the next one starts (sell_kernels.hip); the bits do not depend on it
     mutable std::atomic<unsigned> products{0};
-    int next_direction() const
-    {
-        return (int)(products.fetch_add(1u, std::memory_order_relaxed) & 1u);
-    }
+    int next_direction() const;
 };
 
 // csrmm row groups (csrmm_kernels.hip: csrmm_rowgroup_kernel): runs of consecutive rows with one column pattern
@@ -325,18 +322,22 @@ struct MergePlan
 {
     aoclsparse_int ntiles = 0;
     DeviceBuffer   starts; // (ntiles + 1) x {i, j}
-    DeviceBuffer   first; // ntiles: first tile that holds a head piece of the row whose END lies in tile w, or -1
+    // 2 * ntiles: first[w] = first tile that holds a head piece of the row whose END lies in tile w, or -1; then endt[v] = the
+    // tile in which the row of tile v's head piece ends, or -1
+    DeviceBuffer   first;
     bool           valid = false, tried = false;
-    // Head pieces travel between the tiles of ONE launch through granules {launch epoch << 32 | half of the value}, 2 per tile.
-    // Two launches in flight at once must not share them, and launches on one stream never are: every stream that has run this
-    // plan owns a granule set with its own epoch counter (a set is 16 bytes per tile).  No launch ever waits for another stream --
-    // a stream that the caller has destroyed since is never touched again.  (mutable: products run on a const plan under the
-    // handle's shared lock; `launch_lock` makes {find the set, take an epoch, enqueue} one step.)
+    // Pieces of cut rows meet through a piece set: per tile a head piece, a tail piece (8 bytes each) and an arrival counter
+    // (mergepath_kernels.hip).  A launch leaves every counter at 0, so a set carries nothing from one launch to the next; two
+    // launches in flight at once must not share one, and launches on one stream never are: every stream that has run this plan
+    // owns a set.  No launch ever waits for another stream.  Streams are told apart by {address, hipStreamGetId}: an address
+    // the runtime hands out again after the caller destroyed a stream is a NEW stream, and work of the old one may still be
+    // running -- the set is taken over after a device synchronisation.  (mutable: products run on a const plan under the
+    // handle's shared lock; `launch_lock` makes {find the set, enqueue} one step.)
     struct GranuleSet
     {
-        void        *stream = nullptr;
-        DeviceBuffer granules; // 2 * ntiles x u64, zeroed at allocation and when the epoch wraps
-        unsigned     epoch = 0; // tags start at 1: zeroed granules match no launch
+        void              *stream = nullptr;
+        unsigned long long uid    = 0;
+        DeviceBuffer       granules; // 3 * ntiles x 8 bytes: head pieces, tail pieces, counters; zeroed at allocation
     };
     static constexpr size_t                           MAX_SETS = 16; // more streams than this: the oldest sets are recycled after a device sync
     mutable std::mutex                               launch_lock;
@@ -507,8 +508,9 @@ struct _aoclsparse_matrix
     // the stream of the last call that used the handle's workspaces (the two above, `work` below): they are reused in stream
     // order, so a call on ANOTHER stream first waits for the device -- not for that stream, which the caller may have destroyed
     // since (workspace_stream_guard; written under the runtime's stage lock)
-    void *ws_last_stream = nullptr;
-    bool  ws_ran         = false;
+    void              *ws_last_stream = nullptr;
+    unsigned long long ws_last_uid    = 0; // hipStreamGetId: a recycled stream address is another stream
+    bool               ws_ran         = false;
     // one word of pinned, device-mapped host memory THIS handle's sync-free solves set when a wait expires (round 3,
     // the process-wide word of round 2 could not say which handle had failed, and a failure surfaced on an
     // unrelated solve).  Allocated at the handle's first sync-free solve; read without a device round trip.
@@ -548,12 +550,24 @@ struct _aoclsparse_matrix
 
 namespace mi355
 {
+// identity of a stream beyond its address (the runtime reuses the address of a destroyed stream for a new one)
+inline unsigned long long stream_uid(hipStream_t s)
+{
+    unsigned long long id = 0;
+    if(hipStreamGetId(s, &id) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        id = 0;
+    }
+    return id;
+}
 // call with the runtime's stage lock held, before a handle's workspaces are touched on stream s
 inline aoclsparse_status workspace_stream_guard(_aoclsparse_matrix *A, hipStream_t s)
 {
-    if(A->ws_ran && A->ws_last_stream != (void *)s)
+    const unsigned long long uid = stream_uid(s);
+    if(A->ws_ran && (A->ws_last_stream != (void *)s || A->ws_last_uid != uid))
         MI355_HIP_TRY(hipDeviceSynchronize());
-    A->ws_last_stream = (void *)s, A->ws_ran = true;
+    A->ws_last_stream = (void *)s, A->ws_last_uid = uid, A->ws_ran = true;
     return aoclsparse_status_success;
 }
 } // namespace mi355
@@ -767,8 +781,7 @@ aoclsparse_status launch_blkcsrmv(hipStream_t s, int base, double alpha, aoclspa
 template <typename T>
 aoclsparse_status launch_mergepath(hipStream_t s, int base, T alpha, aoclsparse_int ntiles, const aoclsparse_int *starts,
                                    const aoclsparse_int *first, const T *val, const aoclsparse_int *col,
-                                   const aoclsparse_int *row_ptr, const T *x, T beta, T *y, unsigned long long *granules,
-                                   unsigned epoch);
+                                   const aoclsparse_int *row_ptr, const T *x, T beta, T *y, void *pieces);
 template <typename T>
 aoclsparse_status launch_scale(hipStream_t s, T *y, aoclsparse_int n, T beta);
 // w = a*x + b*y elementwise (w may alias x or y); a == 1, b == -1 is an exact subtraction
@@ -867,6 +880,12 @@ aoclsparse_status launch_lincomb(hipStream_t s, int sign, aoclsparse_int n, int 
 std::atomic<bool> &csrmm_beta0_overwrite_flag();
 // process-wide plan options (aoclsparse_mi355_set_option; read when a plan is built): tests and measurements only
 int plan_option(aoclsparse_mi355_option option);
+inline int SellPlan::next_direction() const
+{
+    if(plan_option(aoclsparse_mi355_option_alternate_sweeps) == 0)
+        return 0;
+    return (int)(products.fetch_add(1u, std::memory_order_relaxed) & 1u);
+}
 // does a csrmm kernel read C?  always for beta != 0; for beta == 0 unless the overwrite mode is on
 bool csrmm_reads_c(bool beta_nonzero);
 // timeout_word: where a sync-free kernel reports an expired wait (pinned host memory, Runtime::trsv_timeout_dev).

@@ -836,7 +836,7 @@ aoclsparse_status build_merge_plan(aoclsparse_int m, aoclsparse_int nnz, aoclspa
     std::vector<aoclsparse_int> first;
     try
     {
-        first.assign((size_t)ntiles, -1);
+        first.assign(2 * (size_t)ntiles, -1);
     }
     catch(const std::bad_alloc &)
     {
@@ -855,6 +855,18 @@ aoclsparse_status build_merge_plan(aoclsparse_int m, aoclsparse_int nnz, aoclspa
             f--;
         first[w] = f;
     }
+    // endt[v] (stored behind first[]): the tile in which the row of tile v's head piece ends -- the inverse of first[]
+    for(aoclsparse_int w = 1; w < ntiles; w++)
+        for(aoclsparse_int v = first[w]; v >= 0 && v < w; v++)
+            first[(size_t)ntiles + v] = w;
+    // (the kernel decides "tile v has a head piece" from row_ptr: every such tile must know its end tile)
+    for(aoclsparse_int v = 0; v < ntiles; v++)
+    {
+        const aoclsparse_int i1 = st[2 * (size_t)v + 2], j0 = st[2 * (size_t)v + 1], j1 = st[2 * (size_t)v + 3];
+        const bool           has_head = i1 < m && std::max<aoclsparse_int>(ptr[i1] - base, j0) < j1;
+        if(has_head != (first[(size_t)ntiles + v] >= 0))
+            return aoclsparse_status_success; // (never seen) leave the matrix to the row-block kernel
+    }
     (void)vsize;
     Runtime          &rt = Runtime::get();
     aoclsparse_status s1 = mp.starts.upload(st.data(), sizeof(aoclsparse_int) * st.size(), rt.stream());
@@ -865,7 +877,7 @@ aoclsparse_status build_merge_plan(aoclsparse_int m, aoclsparse_int nnz, aoclspa
     MI355_HIP_TRY(hipStreamSynchronize(rt.stream())); // (uploads read the host vectors until the stream has run them)
     {
         std::lock_guard<std::mutex> g(mp.launch_lock);
-        mp.sets.clear(); // granule sets are made by the first launch on each stream (spmv_api.cpp)
+        mp.sets.clear(); // piece sets are made by the first launch on each stream (spmv_api.cpp)
     }
     mp.ntiles = ntiles;
     mp.valid  = true;

@@ -11,16 +11,16 @@
 //            tile is bit-identical; a longer one is summed by its wavefront (64 strided chains + a fixed-order tree),
 //            as in csr_adaptive_kernel's auto mode.  Rounds 2-4 gave every piece to ONE lane: a tile in the middle of a
 //            170 k-entry row was a 1,024-entry serial chain, ~13 us, and that chain WAS the kernel (26 us);
-//   carries  a tile whose entries after its last row end belong to a row that ends later publishes that HEAD PIECE
-//            as two self-validating 8-byte granules {launch epoch, half of the value} (relaxed agent-scope atomics: sc1
-//            stores / loads, no fence); the tile holding the row's END waits for the head pieces of the tiles
-//            [first[w], w) -- a decoupled look-back: they have smaller block indices, so they are resident or done --
-//            adds them (lane v % 64 takes tile v, then the wavefront tree), adds its own tail piece and writes y.
-//            first[] is plan data (the host knows which tiles a row crosses).  Deterministic: the order of additions
-//            depends on the tiling only.  Rounds 2-4 ran a second kernel (mp_fixup_kernel) for this.
+//   carries  a tile whose entries after its last row end belong to a row that ends later stores that HEAD PIECE in its slot
+//            of the stream's piece set and adds 1 to the counter of the tile that holds the row's END; so does the end tile
+//            with its TAIL piece.  Whoever adds LAST sums the head pieces of the tiles [first[w], w) (lane v % 64 takes tile
+//            v, then the wavefront tree), adds the tail piece, resets the counter and writes y.  first[] / endt[] are plan
+//            data (the host knows which tiles a row crosses).  Deterministic: the order of additions depends on the tiling
+//            only.  Nobody waits for anybody (round 6; round 5's end tile polled epoch-tagged granules: correct only while
+//            workgroups start in index order, and a captured launch replayed its epoch).  Rounds 2-4: a second kernel.
 // Rows cut by a tile boundary and rows of >= SPMV_TREE_MIN entries carry the forward-error bound instead of bit-exactness.
 // Served: the scalar order only (nnz <= 10 m -- where irregular rows live) without a pinned kid.
-// HBM bytes as CSR-Adaptive + 16 B per tile of granules + 4 B per tile of first[].
+// HBM bytes as CSR-Adaptive + 20 B per tile of pieces / counters + 8 B per tile of first[] / endt[].
 #include "internal.hpp"
 
 #include <hip/hip_runtime.h>
@@ -83,48 +83,25 @@ __device__ __forceinline__ T mp_wave_sum(T v)
     return (mp_lane(v, 0) + mp_lane(v, 16)) + (mp_lane(v, 32) + mp_lane(v, 48));
 }
 
-// head piece of tile w: granule(s) {epoch << 32 | 32 bits of the value}; each is ONE 8-byte store, so a reader that sees the
-// epoch sees the bits that came with it (no fence, no flag: MI355X_MICROARCH.md, hand-off forms)
-__device__ __forceinline__ void mp_publish(unsigned long long *gran, int w, unsigned epoch, double r)
+// Pieces of a row that is cut by tile boundaries meet through three per-tile arrays of the stream's piece set:
+//   head[v]  the head piece of tile v (the part of the row that ENDS LATER, in tile endt[v]),
+//   tail[w]  the tail piece of the row that ends in tile w and started in tile first[w] < w,
+//   cnt[w]   arrivals for that row: every tile of [first[w], w] adds 1 after its piece has been written.
+// Nobody waits: the tile whose add comes LAST (it reads w - first[w] back) sums the pieces in the fixed order below, resets the
+// counter and writes y.  So the kernel needs no assumption about the order in which workgroups are dispatched, carries no state
+// from one launch to the next (a captured launch replays correctly whatever x is), and the sum does not depend on who finishes.
+// Hand-off form (MI355X_MICROARCH.md, hand-offs with sc1 loads, first row): sc1 stores of the pieces by ONE lane -> that lane's
+// s_waitcnt vmcnt(0) -> its agent-scope atomic add; the lane whose add came last loads the pieces with sc1 loads after the add
+// has returned.
+template <typename T>
+__device__ __forceinline__ void mp_store(T *p, T v)
 {
-    const unsigned long long bits = (unsigned long long)__double_as_longlong(r), tag = (unsigned long long)epoch << 32;
-    __hip_atomic_store(gran + 2 * (size_t)w, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(gran + 2 * (size_t)w + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void mp_publish(unsigned long long *gran, int w, unsigned epoch, float r)
+template <typename T>
+__device__ __forceinline__ T mp_load(const T *p)
 {
-    __hip_atomic_store(gran + 2 * (size_t)w, ((unsigned long long)epoch << 32) | (unsigned)__float_as_int(r), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-}
-constexpr int MP_SPIN_LIMIT = 1 << 21; // polls before a look-back gives up (seconds; never seen: the tiles waited for are older)
-__device__ __forceinline__ bool mp_fetch(const unsigned long long *gran, int v, unsigned epoch, double &out)
-{
-    for(int spin = 0; spin < MP_SPIN_LIMIT; spin++)
-    {
-        const unsigned long long g0 = __hip_atomic_load(gran + 2 * (size_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long g1 = __hip_atomic_load(gran + 2 * (size_t)v + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if((unsigned)(g0 >> 32) == epoch && (unsigned)(g1 >> 32) == epoch)
-        {
-            out = __longlong_as_double((long long)((g1 << 32) | (g0 & 0xffffffffull)));
-            return true;
-        }
-        __builtin_amdgcn_s_sleep(1);
-    }
-    return false;
-}
-__device__ __forceinline__ bool mp_fetch(const unsigned long long *gran, int v, unsigned epoch, float &out)
-{
-    for(int spin = 0; spin < MP_SPIN_LIMIT; spin++)
-    {
-        const unsigned long long g0 = __hip_atomic_load(gran + 2 * (size_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if((unsigned)(g0 >> 32) == epoch)
-        {
-            out = __int_as_float((int)(unsigned)g0);
-            return true;
-        }
-        __builtin_amdgcn_s_sleep(1);
-    }
-    return false;
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // tile w owns the row ends [i0, i1) and the non-zeros [j0, j1) (0-based).  Slot t of the tile, t = 0 .. nr (nr = i1 - i0):
@@ -137,12 +114,12 @@ __global__ __launch_bounds__(MP_BLOCK) void mp_kernel(const int2 *__restrict__ s
                                                       const aoclsparse_int *__restrict__ col,
                                                       const T *__restrict__ val, const T *__restrict__ x,
                                                       T *__restrict__ y, T alpha, T beta, int base,
-                                                      unsigned long long *__restrict__ gran, unsigned epoch)
+                                                      T *__restrict__ pieces, unsigned *__restrict__ cnt, int ntiles)
 {
     __shared__ T              s_val[MP_ITEMS];
     __shared__ T              s_x[MP_ITEMS];
     __shared__ aoclsparse_int s_row[MP_ITEMS + 2];
-    __shared__ T              s_tail;
+    __shared__ T              s_tail, s_head;
     const int  w   = blockIdx.x;
     const int  tid = threadIdx.x, lane64 = tid & 63;
     const int2 a = starts[w], b = starts[w + 1];
@@ -162,12 +139,12 @@ __global__ __launch_bounds__(MP_BLOCK) void mp_kernel(const int2 *__restrict__ s
         if(t < nr)
         {
             if(t == 0 && rs < j0)
-                s_tail = r; // completed by the look-back below
+                s_tail = r; // completed by the last arriver below
             else
                 y[i0 + t] = mp_finish(r, alpha, beta, y + i0 + t);
         }
         else if(nonempty)
-            mp_publish(gran, w, epoch, r);
+            s_head = r;
     };
     for(int rb = 0; rb <= nr; rb += MP_BLOCK)
     {
@@ -214,27 +191,48 @@ __global__ __launch_bounds__(MP_BLOCK) void mp_kernel(const int2 *__restrict__ s
                 emit(rb + (tid & ~63) + l, lrs, true, tot);
         }
     }
-    if(f0 >= 0) // (uniform) row i0 ends here and started in tile f0: head pieces of the tiles [f0, w), in a fixed order, + the tail
+    // (uniform) a head piece exists when the tile ends past the first entry of row i1; a tail piece when row i0 ends here and
+    // started in tile f0 < w
+    const bool has_head = max(s_row[nr], j0) < j1, has_tail = f0 >= 0;
+    if(!has_head && !has_tail)
+        return;
+    __syncthreads();
+    if(tid >= 64)
+        return;
+    T  *head = pieces, *tail = pieces + ntiles;
+    int fin_head = -1, fin_tail = -1; // end tiles whose row this workgroup completes
+    if(lane64 == 0)
     {
-        __syncthreads();
-        if(tid < 64)
+        const int we = has_head ? first[ntiles + w] : -1; // the tile in which row i1 ends
+        if(has_head)
+            mp_store(head + w, s_head);
+        if(has_tail)
+            mp_store(tail + w, s_tail);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if(has_head && __hip_atomic_fetch_add(cnt + we, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(we - first[we]))
+            fin_head = we;
+        if(has_tail && __hip_atomic_fetch_add(cnt + w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(w - f0))
+            fin_tail = w;
+    }
+    asm volatile("" ::: "memory"); // the piece loads below stay behind the adds
+    fin_head = __builtin_amdgcn_readfirstlane(fin_head);
+    fin_tail = __builtin_amdgcn_readfirstlane(fin_tail);
+#pragma unroll
+    for(int k = 0; k < 2; k++)
+    {
+        const int we = k == 0 ? fin_tail : fin_head; // (uniform)
+        if(we < 0)
+            continue;
+        const int fe  = first[we];
+        T         acc = T(0);
+        for(int v = fe + lane64; v < we; v += 64)
+            acc += mp_load(head + v);
+        const T total = mp_wave_sum(acc) + mp_load(tail + we);
+        if(lane64 == 0)
         {
-            T    acc = T(0);
-            bool ok  = true;
-            for(int v = f0 + lane64; v < w; v += 64)
-            {
-                T piece = T(0);
-                ok      = mp_fetch(gran, v, epoch, piece) && ok;
-                acc += piece;
-            }
-            const T total = mp_wave_sum(acc) + s_tail;
-            if(__ballot(!ok) != 0ull) // a look-back expired (never seen): say so in the result rather than hang or guess
-            {
-                if(lane64 == 0)
-                    y[i0] = total * T(0) + (T)__builtin_nanf("");
-            }
-            else if(lane64 == 0)
-                y[i0] = mp_finish(total, alpha, beta, y + i0);
+            __hip_atomic_store(cnt + we, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch on this stream
+            const int ie = starts[we].x;
+            y[ie]        = mp_finish(total, alpha, beta, y + ie);
         }
     }
 }
@@ -244,24 +242,22 @@ __global__ __launch_bounds__(MP_BLOCK) void mp_kernel(const int2 *__restrict__ s
 template <typename T>
 aoclsparse_status launch_mergepath(hipStream_t s, int base, T alpha, aoclsparse_int ntiles, const aoclsparse_int *starts,
                                    const aoclsparse_int *first, const T *val, const aoclsparse_int *col,
-                                   const aoclsparse_int *row_ptr, const T *x, T beta, T *y, unsigned long long *granules,
-                                   unsigned epoch)
+                                   const aoclsparse_int *row_ptr, const T *x, T beta, T *y, void *pieces)
 {
     if(ntiles <= 0)
         return aoclsparse_status_success;
     hipLaunchKernelGGL((mp_kernel<T>), dim3(ntiles), dim3(MP_BLOCK), 0, s, reinterpret_cast<const int2 *>(starts), first, row_ptr,
-                       col, val, x, y, alpha, beta, base, granules, epoch);
+                       col, val, x, y, alpha, beta, base, static_cast<T *>(pieces),
+                       reinterpret_cast<unsigned *>(static_cast<unsigned long long *>(pieces) + 2 * (size_t)ntiles), (int)ntiles);
     MI355_HIP_TRY(hipGetLastError());
     return aoclsparse_status_success;
 }
 
 template aoclsparse_status launch_mergepath<double>(hipStream_t, int, double, aoclsparse_int, const aoclsparse_int *,
                                                     const aoclsparse_int *, const double *, const aoclsparse_int *,
-                                                    const aoclsparse_int *, const double *, double, double *,
-                                                    unsigned long long *, unsigned);
+                                                    const aoclsparse_int *, const double *, double, double *, void *);
 template aoclsparse_status launch_mergepath<float>(hipStream_t, int, float, aoclsparse_int, const aoclsparse_int *,
                                                    const aoclsparse_int *, const float *, const aoclsparse_int *,
-                                                   const aoclsparse_int *, const float *, float, float *, unsigned long long *,
-                                                   unsigned);
+                                                   const aoclsparse_int *, const float *, float, float *, void *);
 
 } // namespace mi355

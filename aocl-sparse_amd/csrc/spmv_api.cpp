@@ -123,15 +123,22 @@ aoclsparse_status run_on_device_csr(Runtime &rt, aoclsparse_int kid, const Devic
                               plan.sell.next_direction());
     else if(plan.merge.valid && order == 0 && !strict) // balanced tiles for irregular rows (scalar order, no pinned kid)
     {
-        // one launch; its head pieces are tagged with an epoch that no earlier launch on this stream's granule set used
-        // (internal.hpp, MergePlan).  Finding the set, taking the epoch and enqueueing are one step.
+        // one launch; the pieces of cut rows meet in the piece set of this stream (internal.hpp, MergePlan).  Finding the set
+        // and enqueueing are one step.
         const MergePlan            &mp = plan.merge;
         std::lock_guard<std::mutex> g(mp.launch_lock);
-        MergePlan::GranuleSet      *gs = nullptr;
+        MergePlan::GranuleSet      *gs  = nullptr;
+        const unsigned long long    uid = stream_uid(rt.stream());
         for(auto &c : mp.sets)
             if(c->stream == (void *)rt.stream())
                 gs = c.get();
-        const size_t gbytes = sizeof(unsigned long long) * 2 * (size_t)mp.ntiles;
+        const size_t gbytes = sizeof(unsigned long long) * 3 * (size_t)mp.ntiles;
+        if(gs && gs->uid != uid) // the address of a stream the caller has destroyed, handed out again: its launches may still run
+        {
+            MI355_HIP_TRY(hipDeviceSynchronize());
+            MI355_HIP_TRY(hipMemsetAsync(gs->granules.ptr, 0, gbytes, rt.stream()));
+            gs->uid = uid;
+        }
         if(!gs)
         {
             if(mp.sets.size() >= MergePlan::MAX_SETS) // (a caller cycling through streams: everything enqueued so far completes first)
@@ -157,23 +164,20 @@ aoclsparse_status run_on_device_csr(Runtime &rt, aoclsparse_int kid, const Devic
                 return sa;
             }
             gs->stream = (void *)rt.stream();
-        }
-        if(++gs->epoch == 0) // wrapped: forget every old tag
-        {
-            MI355_HIP_TRY(hipMemsetAsync(gs->granules.ptr, 0, gbytes, rt.stream()));
-            gs->epoch = 1;
+            gs->uid    = uid;
         }
         st = launch_mergepath<T>(rt.stream(), d.base, alpha, mp.ntiles, mp.starts.as<aoclsparse_int>(), mp.first.as<aoclsparse_int>(),
                                  d.val.as<T>(), d.ind.as<aoclsparse_int>(), d.ptr.as<aoclsparse_int>(),
-                                 static_cast<const T *>(ax.dev), beta, static_cast<T *>(ay.dev),
-                                 gs->granules.as<unsigned long long>(), gs->epoch);
+                                 static_cast<const T *>(ax.dev), beta, static_cast<T *>(ay.dev), gs->granules.ptr);
     }
     else
     {
         // (bit 1 of the tile word: blocks in descending order -- every second product of a plan whose blocks are in row order;
         // the heavy-first order of irregular matrices is left alone)
         const bool by_rows = !(plan.heavy_first && (plan.tile & 1) == 0);
-        const int  rev     = by_rows ? (int)(plan.sweeps.fetch_add(1u, std::memory_order_relaxed) & 1u) : 0;
+        const int  rev     = by_rows && plan_option(aoclsparse_mi355_option_alternate_sweeps) != 0
+                                 ? (int)(plan.sweeps.fetch_add(1u, std::memory_order_relaxed) & 1u)
+                                 : 0;
         st = launch_csrmv<T>(rt.stream(), order, strict, plan.tile | (rev ? 2 : 0), d.base, alpha, d.m, d.val.as<T>(),
                              d.ind.as<aoclsparse_int>(), d.ptr.as<aoclsparse_int>(),
                              plan.rowblocks.as<aoclsparse_int>(), plan.nblocks, static_cast<const T *>(ax.dev),

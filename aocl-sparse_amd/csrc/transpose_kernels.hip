@@ -173,6 +173,17 @@ static aoclsparse_status device_transpose_run(hipStream_t s, aoclsparse_int m, a
     Runtime                              &rt = Runtime::get();
     std::lock_guard<std::recursive_mutex> sl(rt.stage_lock);
     void *p_cnt = nullptr, *p_cursor = nullptr, *p_tpos = nullptr, *p_scan = nullptr, *p_small = nullptr, *p_order = nullptr;
+    // every way out of this function -- an allocation that fails half way included -- first lets the stream finish what was
+    // enqueued on the slots: the next holder of the lock may grow (free) them
+    struct DrainOnExit
+    {
+        hipStream_t s;
+        ~DrainOnExit()
+        {
+            if(hipStreamSynchronize(s) != hipSuccess)
+                (void)hipGetLastError();
+        }
+    } drain{s};
     MI355_TRY(rt.staging(40, sizeof(int) * (size_t)n, &p_cnt));
     MI355_TRY(rt.staging(41, 256, &p_small));
     MI355_HIP_TRY(hipMemsetAsync(p_cnt, 0, sizeof(int) * (size_t)n, s));
@@ -233,7 +244,7 @@ static aoclsparse_status device_transpose_run(hipStream_t s, aoclsparse_int m, a
         return aoclsparse_status_not_implemented;
     MI355_HIP_TRY(hipGetLastError());
     MI355_HIP_TRY(hipStreamSynchronize(s)); // (the staging slots may be handed to the next caller once the lock is released)
-    return aoclsparse_status_success;
+    return aoclsparse_status_success; // (`drain` runs before the lock guard declared above it is released)
 }
 
 aoclsparse_status device_transpose(hipStream_t s, aoclsparse_int m, aoclsparse_int n, aoclsparse_int nnz, int base,

@@ -219,6 +219,34 @@ def timed_laps(pkg, fn, steps, warmup):
     return pkg.timer_laps()
 
 
+def timed_cold(pkg, fn, steps, flush, warmup=2):
+    """`steps` calls of fn with the Infinity Cache FLUSHED before each one: `flush` (1 GiB of other data) is read by a device kernel
+    between any two calls, so nothing of the operands is left in the 256 MiB cache from the call before (a FILL as the flush would
+    leave dirty lines whose write-back runs into the product: tools/history/exp_cold.py).  One hipEvent on the library's stream
+    on each side of every call (the flush runs on the null stream, which the library's blocking stream is ordered with)
+    -> per-call device milliseconds: the HBM-only time of the call.  The model is the reference harness's byte accounting per cold
+    call, tests/include/aoclsparse_gbyte.hpp:39-45."""
+    for _ in range(warmup):
+        flush.sum()
+        fn()
+    pkg.lib().aoclsparse_mi355_synchronize()
+    pkg.timer_laps()  # (drop marks of earlier users)
+    for _ in range(steps):
+        flush.sum()
+        pkg.timer_mark()
+        fn()
+        pkg.timer_mark()
+    return pkg.timer_laps()[0::2]  # (the odd laps are the flushes)
+
+
+def bound_of(working_set_bytes):
+    """what a back-to-back loop over a working set of this size is bound by: the 8 x 4 MiB L2s keep <= 32 MiB (launch + dependent
+    round trips: latency), the Infinity Cache <= 256 MiB, beyond that HBM (MI355X_MICROARCH.md, memory hierarchy)"""
+    if working_set_bytes <= (32 << 20):
+        return "latency"
+    return "infinity_cache" if working_set_bytes <= (256 << 20) else "hbm"
+
+
 COMPACT_LIMIT = 4096  # bytes: the driver keeps a bounded tail of stdout, the record must fit it with room to spare
 
 
@@ -271,6 +299,13 @@ def leg_numbers(full):
         other = [r["roofline"]["frac"] for r in rows if "," in r["matrix"]]
         n["mix_variants_frac_mean"] = round(sum(other) / len(other), 4) if other else None
         n["mix_frac"] = {_short(r["matrix"].split(" (")[0], 28): r["roofline"]["frac"] for r in rows}
+        if all("roofline_cold" in r for r in rows):
+            # cache flushed before every product: the HBM fractions (mix_frac above is the back-to-back loop, an HBM fraction only
+            # where mix_bound says "hbm")
+            cold = [r["roofline_cold"]["frac"] for r in rows if "," not in r["matrix"]]
+            n["mix_cold_frac_mean"] = round(sum(cold) / len(cold), 4) if cold else None
+            n["mix_cold_frac"] = {_short(r["matrix"].split(" (")[0], 28): r["roofline_cold"]["frac"] for r in rows}
+            n["mix_bound"] = {_short(r["matrix"].split(" (")[0], 28): r["bound_back_to_back"] for r in rows if "," not in r["matrix"]}
         lat = {_short(r["matrix"].split(" (")[0], 28): r["roofline_latency"]["frac"] for r in rows if r.get("roofline_latency")}
         if lat:
             n["mix_latency_frac"] = lat
@@ -288,7 +323,15 @@ def leg_numbers(full):
             if fullc and slab:
                 n["csrmm_%s%s_ms" % (key, suffix)] = fullc[0]["ms"]
                 n["csrmm_%s%s_slab_ms" % (key, suffix)] = slab[0]["ms"]
-                n["csrmm_%s%s_eff8" % (key, suffix)] = _eff8(fullc[0]["ms"], slab[0]["ms"])
+                if "roofline_cold" in fullc[0] and "roofline_cold" in slab[0]:
+                    # fractions of the HBM roof on the bytes the mode must move, cache flushed before every product; ONE projected
+                    # 8-GPU efficiency per cell from the cold times, T1 / (8 T_slab) (it RISES when the full-width kernel gets slower:
+                    # the slab fraction is the figure of merit)
+                    n["csrmm_%s%s_frac" % (key, suffix)] = fullc[0]["roofline_cold"]["frac"]
+                    n["csrmm_%s%s_slab_frac" % (key, suffix)] = slab[0]["roofline_cold"]["frac"]
+                    n["csrmm_%s%s_eff8_cold" % (key, suffix)] = _eff8(fullc[0]["cold_ms"], slab[0]["cold_ms"])
+                else:
+                    n["csrmm_%s%s_eff8" % (key, suffix)] = _eff8(fullc[0]["ms"], slab[0]["ms"])
                 if not suffix:
                     n["csrmm_%s_frac_survey_bytes" % key] = fullc[0]["roofline_survey_model"]["frac"]
     if mm.get("cases"):
@@ -347,6 +390,8 @@ def compact_record(full, record_path=None):
     number per leg.  Everything else stays in the full report (`record_path`)."""
     c = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                   "scaling", "vs_baseline", "dtype", "data")}
+    if "value_back_to_back" in full:
+        c["value_back_to_back"] = full["value_back_to_back"]
     cfg = full.get("config") or {}
     c["config"] = {"workload": _short(cfg.get("workload"), 200), "kernel": _short(cfg.get("kernel"), 160),
                    "parallelism": cfg.get("parallelism"), "device": _short(cfg.get("device"), 40),
@@ -354,6 +399,9 @@ def compact_record(full, record_path=None):
     rf = full.get("roofline") or {}
     c["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "frac_traffic", "traffic",
                                             "algorithmic_bytes_per_launch", "kernel_ms", "traffic_source")}
+    for k in ("frac_back_to_back", "kernel_ms_back_to_back"):
+        if k in rf:
+            c["roofline"][k] = rf[k]
     if rf.get("note"):
         c["roofline"]["note"] = _short(rf["note"], 180)
     if c["roofline"].get("frac_traffic") is None and rf.get("traffic") and rf.get("kernel_ms") and rf.get("peak"):
@@ -474,6 +522,9 @@ def main():
                     help="file that receives the FULL report (stdout only gets the short record); '' = do not write it")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU-baseline budget per thread count")
     ap.add_argument("--small", action="store_true", help="mix / trsv legs on the two small matrices only")
+    ap.add_argument("--cold-only", action="store_true",
+                    help="skip timed region 2 (the back-to-back products): every launch of the headline kernel in the run is then a "
+                         "cold one, so a rocprofv3 --kernel-trace --stats average of that kernel is the cold average")
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # not under torch.distributed.run: start the ranks ourselves (as a child; nothing here has touched the GPU)
@@ -579,23 +630,56 @@ def main():
         s = pkg.dmv(pkg.OP_NONE, 1.0, A, descr, x, 0.0, y)
         assert s == 0, pkg.STATUS[s]
 
+    # Timed region 1 (the headline: `value`, `ms_per_step`, `roofline`): K products, each from a COLD Infinity Cache -- 1 GiB of
+    # other data is read between any two products (timed_cold's flush), one hipEvent on the launch stream on each side of every
+    # product.  A step's time is its product's device time; the flush between steps is not part of any step.  Back-to-back
+    # products of one handle keep the end of their (alternating) sweep in the 256 MiB cache: that figure is region 2 below and
+    # carries its own names (value_back_to_back, roofline.frac_back_to_back) -- a fraction of the HBM roof has to be HBM traffic.
+    flush = torch.ones(1 << 28, dtype=torch.float32, device=device)
     for _ in range(args.warmup):
+        flush.sum()
         step()
+    L.aoclsparse_mi355_synchronize()
+    pkg.timer_laps()
     barrier()
     t0 = time.perf_counter()
-    pkg.timer_mark()
     for _ in range(args.steps):
+        flush.sum()
+        pkg.timer_mark()
         step()
         pkg.timer_mark()
-    laps = pkg.timer_laps()  # one hipEvent between consecutive launches, on the launch stream; drains it
+    all_laps = pkg.timer_laps()  # drains the stream
     barrier()
-    elapsed = time.perf_counter() - t0
+    wall_cold = time.perf_counter() - t0
+    laps = all_laps[0::2]  # per-product device ms (the odd laps are the flushes)
+    assert len(laps) == args.steps
+    elapsed = float(sum(laps)) * 1e-3  # seconds of the K cold products on this rank
+
+    # Timed region 2: the same K products back to back (what an iterative solver that does nothing else between products sees)
+    b2b = None
+    if not args.cold_only:
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t1 = time.perf_counter()
+        pkg.timer_mark()
+        for _ in range(args.steps):
+            step()
+            pkg.timer_mark()
+        laps_b2b = pkg.timer_laps()
+        barrier()
+        elapsed_b2b = time.perf_counter() - t1
+        b2b = (elapsed_b2b, laps_b2b)
+    del flush
 
     flops = 2.0 * nnz
     abytes = spmv_bytes(m, m, nnz)
     gflops, tmax = job_throughput(args.steps * flops / 1e9, elapsed, D, device)
-    kernel_ms = float(sum(laps)) / max(len(laps), 1)  # average launch duration over the timed region
+    kernel_ms = float(sum(laps)) / max(len(laps), 1)  # average launch duration over the timed region (cold products)
     stats = quartiles(laps)
+    if b2b is not None:
+        gflops_b2b, tmax_b2b = job_throughput(args.steps * flops / 1e9, b2b[0], D, device)
+        kernel_ms_b2b = float(sum(b2b[1])) / max(len(b2b[1]), 1)
 
     traffic, traffic_src = None, None
     try:  # PMC counters cannot be read from inside the run: use the committed rocprofv3 measurement
@@ -623,15 +707,15 @@ def main():
             "workload": "aoclsparse_dmv, 5-pt Laplacian grid %dx%d (m=%d, nnz=%d), alpha=1 beta=0; "
                         "BASELINE configs[1] scaled past the 256 MiB Infinity Cache" % (g, g, m, nnz),
             # (the first 160 characters go into the short record: what a reader of `frac` must know comes first)
-            "kernel": ("SELL-64, %d slices%s; alternating sweep direction: part of the bytes comes from the 256 MB Infinity "
-                       "Cache, frac may pass 1 (cold: legs.dmv_cold_ms); %.3f cells per nnz, built by "
+            "kernel": ("SELL-64, %d slices%s; every timed product starts from a flushed Infinity Cache (1 GiB read between "
+                       "products): HBM-only; %.3f cells per nnz, built by "
                        "aoclsparse_optimize for the mv hint, order %d (reference ref_csrmv_gn order)%s"
                        % (info.sell_slices, ", shared column lists" if info.kernel == 4 else "", info.stored_cells / max(nnz, 1),
                           info.order, ": ONE column list per run of rows that repeat it (as it is or shifted by one: a stencil's "
                           "rows) instead of one per row" if info.kernel == 4 else ""))
                       if info.kernel in (3, 4) else
-                      ("csr-adaptive stream, order %d (reference ref_csrmv_gn order), %d row blocks"
-                       % (info.order, info.row_blocks)),
+                      ("csr-adaptive stream, order %d (reference ref_csrmv_gn order), %d row blocks; every timed product starts from a "
+                       "flushed Infinity Cache" % (info.order, info.row_blocks)),
             "parallelism": "replicas x%d" % world,
             "device": dev_name,
             "backend": args.backend if use_dist else "none",
@@ -641,11 +725,22 @@ def main():
                              stored_format_bytes_per_launch=(info.stored_cells * 12 + 16 * m) if info.kernel == 3
                              else (None if info.kernel == 4 else abytes),  # kernel 4: see roofline.traffic (PMC)
                              achieved_at_median=round(abytes / (stats["median"] * 1e-3) / 1e9, 2),
-                             note=("frac = CSR-model bytes / time / peak; the format moves `traffic` bytes (fabric side, PMC) and alternating "
-                                   "sweeps serve part of them from the 256 MB Infinity Cache, so frac may pass 1")
+                             note=("cold products (cache flushed before each): frac = CSR-model bytes / time / peak, HBM only; the format "
+                                   "moves `traffic` bytes (PMC): frac_traffic; back-to-back figure: frac_back_to_back")
                              if info.kernel in (3, 4) else None),
-        "stats": dict(stats, unit="ms per step (device, hipEvent between consecutive launches)"),
+        "stats": dict(stats, unit="ms per cold step (device, one hipEvent on each side of every product)"),
+        "timing": {"step": "one aoclsparse_dmv from a flushed Infinity Cache; ms_per_step = max over ranks of the mean device time "
+                           "of the K products (hipEvents on the launch stream); the 1 GiB flush read between steps belongs to no step",
+                   "wall_ms_per_step_including_the_flush": round(wall_cold / args.steps * 1e3, 6)},
     }
+    if b2b is not None:
+        # the cache-assisted twin, named as such: K products back to back, wall clock between barriers (rounds 1-5's headline)
+        out["value_back_to_back"] = round(gflops_b2b, 3)
+        out["ms_per_step_back_to_back"] = round(tmax_b2b / args.steps * 1e3, 6)
+        out["roofline"]["frac_back_to_back"] = round(abytes / (kernel_ms_b2b * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        out["roofline"]["kernel_ms_back_to_back"] = round(kernel_ms_b2b, 6)
+        out["roofline"]["bound_back_to_back"] = "hbm + infinity_cache (alternating sweeps: the end of one product is the start of the next)"
+        out["stats_back_to_back"] = dict(quartiles(b2b[1]), unit="ms per step (device, hipEvent between consecutive launches)")
     if lap_bcast_ms:
         out["config"]["matrix_broadcast_ms"] = round(lap_bcast_ms, 2)
 
@@ -958,7 +1053,7 @@ def main():
         import standins
         rows = []
         pmc_irr, pmc_irr_src = {}, None
-        for rnd in ("r5", "r2"):  # fabric traffic of the mix kernels (PMC cannot be read from inside the run): the latest committed pass
+        for rnd in ("r6", "r5", "r2"):  # fabric traffic of the mix kernels (PMC cannot be read from inside the run): the latest committed pass
             try:
                 with open(os.path.join(ROOT, "profiles", rnd, "irregular_traffic.json")) as f:
                     pmc_irr, pmc_irr_src = json.load(f), "profiles/%s/irregular_traffic.json" % rnd
@@ -967,6 +1062,7 @@ def main():
                 continue
         # the four stand-ins, then (round 3) each one OFF its ideal ordering: graphs with locality, meshes with irregular
         # valence and a windowed random node order (tools/standins.py)
+        flush = torch.ones(1 << 28, dtype=torch.float32, device=device)
         names = (["circuit-like", "web-like"] + ([] if args.small else ["shell-like", "flan-like"])
                  + ["circuit-like, local", "web-like, local"]
                  + ([] if args.small else ["shell-like, unstructured", "flan-like, unstructured"]))
@@ -988,6 +1084,9 @@ def main():
                 pkg.dmv(pkg.OP_NONE, 1.0, Am, descr, xd, 0.0, ydv)
             ms = pkg.timer_stop() / 200
             ms_lap = float(np.mean(lp))
+            # the HBM-only twin: the Infinity Cache flushed before every product (an event pair per product: ~3 us of event cost
+            # inside the 10-30 us of the two small matrices)
+            cold_ms = float(np.median(timed_cold(pkg, lambda: pkg.dmv(pkg.OP_NONE, 1.0, Am, descr, xd, 0.0, ydv), 12, flush)))
             so, yr = oracle.dcsrmv(-1, 0, 1.0, mm_, nz, v, ci, rp, xr, 0.0, np.zeros(mm_), nthreads=oracle.max_threads())
             got = ydv.cpu().numpy()
             lens = np.diff(rp)
@@ -1029,6 +1128,11 @@ def main():
                          "roofline": roofline(b, ms, tr, traffic_source=pmc_irr_src if tr else None,
                                               traffic_gbs=round(tr / ms / 1e6, 1) if tr else None,
                                               traffic_frac_of_peak=round(tr / ms / 1e6 / HBM_PEAK_GBS, 4) if tr else None),
+                         # back to back the working set of the small matrices never leaves the L2s / the Infinity Cache: `roofline`
+                         # (back-to-back time over the HBM roof) is an HBM fraction only where bound_back_to_back says "hbm";
+                         # `roofline_cold` always is (every byte comes from HBM)
+                         "bound_back_to_back": bound_of(b), "cold_us": round(cold_ms * 1e3, 3),
+                         "roofline_cold": roofline(b, cold_ms, tr, traffic_source=pmc_irr_src if tr else None),
                          "bit_exact_rows_below_tree_min": bool(np.array_equal(got[within], yr[within])), "tree_min": int(inf.tree_min),
                          "rows_outside_bit_exact_regime": int((~within).sum()), "strict_mode": strict,
                          "long_rows_within_bound": bool(np.all(err <= bound + 1e-300)),
@@ -1038,6 +1142,7 @@ def main():
                 rows[-1]["roofline_latency"] = latency_floor(max(inf.row_blocks, 1), b, nz, ms * 1e3,
                                                              lanes=128 if inf.tile == 512 else 256)
             del Am, xd, ydv
+        del flush
         # the third kernel aoclsparse_optimize can choose: merge-path, for matrices whose longest row spans tens of LDS
         # tiles (none of the four above does): a tridiagonal matrix with four rows of ~170 k entries
         n3 = 300000
@@ -1083,6 +1188,7 @@ def main():
         nz = len(v)
         res = {"workload": "aoclsparse_dcsrmm, A = 5-pt Laplacian %dx%d grid (m=%d, nnz=%d), beta=0, B U(-1,1) "
                            "column j seeded 777+j" % (args.mm_grid, args.mm_grid, mm_m, nz), "cases": []}
+        flush = torch.ones(1 << 28, dtype=torch.float32, device=device)
         for layout in ("row", "col"):
             sh = sharded.ShardedCsrmm(pkg, torch, None, device, 0, 1, (mm_m, mm_m, rp, ci, v), args.mm_cols, layout)
             B = sh.make_B()
@@ -1100,6 +1206,7 @@ def main():
                 for beta, overwrite in ((0.0, False), (0.0, True), (-2.0, False)):
                     assert L.aoclsparse_mi355_set_csrmm_beta0_overwrite(1 if overwrite else 0) == 0
                     lp = timed_laps(pkg, lambda: sh.run(Bs, Cs, beta=beta, nloc=ncols), 20, 3)
+                    cold_ms = float(np.median(timed_cold(pkg, lambda: sh.run(Bs, Cs, beta=beta, nloc=ncols), 8, flush)))
                     # parity of THIS mode: C preset to 0.25, one product, 4 columns against the oracle's column-major reference
                     # kernel with the same beta and the same C (overwrite mode: identical results for finite C)
                     Cs.fill_(0.25)
@@ -1117,6 +1224,10 @@ def main():
                                                                         else "opt-in: C overwritten" if beta == 0.0 else "beta != 0"),
                                          "ms": round(ms, 5), "stats_ms": quartiles(lp),
                                          "gflops": round(2.0 * nz * ncols / ms / 1e6, 1), "roofline": roofline(b, ms),
+                                         # `roofline` is the back-to-back loop (a slab's 0.6-0.8 GB mostly stays in no cache, the
+                                         # alternating block order keeps the end of C / B in the Infinity Cache); `roofline_cold`:
+                                         # cache flushed before every product -- the HBM fraction
+                                         "bound_back_to_back": bound_of(b), "cold_ms": round(cold_ms, 5), "roofline_cold": roofline(b, cold_ms),
                                          "roofline_survey_model": roofline(csrmm_bytes(mm_m, mm_m, nz, ncols, beta != 0.0), ms),
                                          "bit_exact_4_columns": bool(np.array_equal(cc.cpu().numpy().reshape(-1), Cr))})
                 # a pinned kid (row-major): the KT kernels' arithmetic (csrmm_row_kt), on the tuned kernels when the column count
@@ -1149,6 +1260,7 @@ def main():
                                                                            and np.array_equal(full8, Ck))
                         res["cases"].append(ent)
             del sh, B, C
+        del flush
         try:
             res["blocked"] = leg_csrmm_blocked()
         except Exception as e:  # noqa: BLE001 -- an extra of the csrmm leg

@@ -31,19 +31,27 @@ DLL_PUBLIC aoclsparse_status aoclsparse_mi355_set_pointer_mode(aoclsparse_mi355_
  * their (small) input.  Process-wide, read when a handle's plan is built (so: set before aoclsparse_optimize / the first
  * product, reset afterwards).  Everything else the library chooses by itself; the selection switches of rounds 1-3
  * (environment variables) are gone -- their measurements are under profiles/.
- *   spmv_kernel  0 automatic (default: CSR-Adaptive, merge-path once the longest row spans 32 LDS tiles), 1 CSR-Adaptive,
- *                2 merge-path whenever it can serve the request
+ *   spmv_kernel  0 automatic (default: CSR-Adaptive, merge-path once the longest row spans 16 LDS tiles = 8,192 entries for
+ *                matrices below 4 M non-zeros), 1 CSR-Adaptive, 2 merge-path whenever it can serve the request.  Since round 5 both
+ *                CSR kernels sum rows of >= spmv_info.tree_min (32) entries with a wavefront tree in their automatic mode: such
+ *                rows are within the stated bound, no longer the reference's bits -- spmv_strict = 1 or a pinned kid restores them
  *   sell         -1 automatic (default: SELL-64 copy for an mv hint when its padding is <= 1.35 x), 0 never, 1 always
  *   spmv_strict  0 (default): without a pinned kid, CSR-Adaptive sums a row of >= spmv_info.tree_min entries with a wavefront tree
  *                (componentwise bound (2 ceil(log2 n) + 4) eps sum|a||x|; shorter rows are the reference's chain, bit for bit);
  *                1: every row of every product in the reference's order, as a pinned kid does -- bit-exact everywhere, at the
- *                price of one lane's serial chain per long row.  Read at every product (not a plan option). */
+ *                price of one lane's serial chain per long row.  Read at every product (not a plan option).
+ *   alternate_sweeps  1 (default): consecutive products of a handle (SpMV on the SELL-64 copy or on the row blocks, row-major
+ *                csrmm) walk the matrix in alternating directions, so the end of one sweep -- what the 256 MB Infinity Cache still
+ *                holds -- is where the next one starts; 0: always ascending.  Same bits either way (a row's chain does not depend
+ *                on when the row is visited); a measurement of HBM throughput sets 0 or flushes the cache between products.
+ *                Read at every product. */
 typedef enum aoclsparse_mi355_option_
 {
     aoclsparse_mi355_option_spmv_kernel = 0,
     aoclsparse_mi355_option_sell        = 1,
     aoclsparse_mi355_option_spmv_strict = 2,
-    aoclsparse_mi355_option_count       = 3
+    aoclsparse_mi355_option_alternate_sweeps = 3,
+    aoclsparse_mi355_option_count       = 4
 } aoclsparse_mi355_option;
 DLL_PUBLIC aoclsparse_status aoclsparse_mi355_set_option(aoclsparse_mi355_option option, aoclsparse_int value);
 /* aoclsparse_?csrmm with beta == 0.  Default (0): C is read and multiplied by zero, exactly as every kernel of the reference

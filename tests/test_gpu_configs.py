@@ -346,10 +346,16 @@ def test_bench_single_process_small_legs(tmp_path):
     # one number per leg in the short record, none of them missing and no leg in error
     n = short["legs"]
     assert "errors" not in n, n
-    for k in ("l100_us", "csr_adaptive_frac", "mix_frac_mean", "csrmm_row_ms", "csrmm_row_slab_ms", "csrmm_row_eff8", "csrmm_col_ms",
-              "csrmm_col_slab_ms", "csrmm_col_eff8", "trsv_ms"):
+    for k in ("l100_us", "csr_adaptive_frac", "mix_frac_mean", "mix_cold_frac_mean", "csrmm_row_ms", "csrmm_row_slab_ms", "csrmm_row_slab_frac",
+              "csrmm_row_frac", "csrmm_row_eff8_cold", "csrmm_col_ms", "csrmm_col_slab_ms", "csrmm_col_slab_frac", "csrmm_row_overwrite_slab_frac",
+              "csrmm_col_overwrite_slab_frac", "trsv_ms"):
         assert n.get(k) is not None and n[k] > 0, (k, n)
     assert n["csrmm_parity"] and n["mix_parity"] and n["trsv_parity"]
+    # round 6: the headline is the COLD product (cache flushed before each); the back-to-back loop keeps its own names; every mix
+    # matrix says what bounds its back-to-back loop
+    assert short["value_back_to_back"] > 0 and short["roofline"]["frac_back_to_back"] > 0
+    assert abs(short["roofline"]["kernel_ms"] - short["ms_per_step"]) < 2e-6 and res["timing"]["wall_ms_per_step_including_the_flush"] > short["ms_per_step"]
+    assert set(n["mix_bound"].values()) <= {"latency", "infinity_cache", "hbm"} and len(n["mix_cold_frac"]) == len(n["mix_frac"])
     # the twins of the headline product (round 5): fp32, the literal host-pointer call (PCIe inside), the same product with the
     # Infinity Cache flushed before every call, the launch-bound case as a C caller / inside a HIP graph sees it
     tw = legs["headline_twins"]

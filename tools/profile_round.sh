@@ -11,8 +11,10 @@ PY=/usr/bin/python3
 # 1. the default bench line, exactly as the driver runs it
 $PY $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 cp $R/bench_legs.json $OUT/bench_legs_default.json   # the full report of the same run (stdout carries the short record only)
-# 2. headline kernel alone (same timed region; the un-timed legs are dropped): kernel trace + stats, then HBM traffic
-SPMV="--steps 100 --warmup 10 --legs none"
+# 2. headline kernel alone (same timed region 1: every product from a flushed Infinity Cache; --cold-only drops the back-to-back
+#    region, so EVERY launch of the kernel in these runs is a cold one and the --stats average is the cold average): kernel trace
+#    + stats, then HBM traffic
+SPMV="--steps 100 --warmup 10 --legs none --cold-only"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o spmv -- $PY $R/bench.py $SPMV > $OUT/bench_under_rocprof_trace.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o spmv -- $PY $R/bench.py $SPMV > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o spmv -- $PY $R/bench.py $SPMV > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.err
@@ -33,6 +35,7 @@ for d in trace legs_trace; do
   f=$(ls $OUT/$d/*kernel_stats.csv 2>/dev/null | head -1)
   [ -n "$f" ] && cp $f $OUT/${d}_kernel_stats.csv
 done
+[ -f $OUT/trace_kernel_stats.csv ] && cp $OUT/trace_kernel_stats.csv $OUT/spmv_g4096_cold_kernel_stats.csv
 {
   for c in FETCH_SIZE WRITE_SIZE; do
     d=pmc_$(echo $c | cut -d_ -f1 | tr A-Z a-z)
