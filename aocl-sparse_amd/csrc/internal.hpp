@@ -550,17 +550,10 @@ struct _aoclsparse_matrix
 
 namespace mi355
 {
-// identity of a stream beyond its address (the runtime reuses the address of a destroyed stream for a new one)
-inline unsigned long long stream_uid(hipStream_t s)
-{
-    unsigned long long id = 0;
-    if(hipStreamGetId(s, &id) != hipSuccess)
-    {
-        (void)hipGetLastError();
-        id = 0;
-    }
-    return id;
-}
+// identity of a stream beyond its address (the runtime reuses the address of a destroyed stream for a new one): hipStreamGetId
+// where the loaded HIP runtime has it (ROCm >= 7.1; looked up at run time -- the process may run on the older runtime a
+// framework bundles), else 0 for every stream (the address alone decides, as in rounds 1-5)
+unsigned long long stream_uid(hipStream_t s);
 // call with the runtime's stage lock held, before a handle's workspaces are touched on stream s
 inline aoclsparse_status workspace_stream_guard(_aoclsparse_matrix *A, hipStream_t s)
 {

@@ -329,6 +329,21 @@ namespace
 {
     std::atomic<int> g_plan_options[aoclsparse_mi355_option_count] = {{0}, {-1}, {0}, {1}};
 }
+unsigned long long stream_uid(hipStream_t s)
+{
+    using get_id_t = hipError_t (*)(hipStream_t, unsigned long long *);
+    static const get_id_t get_id = reinterpret_cast<get_id_t>(dlsym(RTLD_DEFAULT, "hipStreamGetId"));
+    unsigned long long    id     = 0;
+    if(!get_id)
+        return 0;
+    if(get_id(s, &id) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        id = 0;
+    }
+    return id;
+}
+
 int plan_option(aoclsparse_mi355_option option)
 {
     return option >= 0 && option < aoclsparse_mi355_option_count ? g_plan_options[option].load(std::memory_order_relaxed) : 0;

@@ -56,6 +56,15 @@ def test_soname_and_versioned_names():
         assert os.path.samefile(os.path.join(d, name), P.LIB_PATH), name
 
 
+def test_library_loads_on_the_older_hip_runtime_a_framework_bundles():
+    """A process that imports torch first runs on torch's bundled libamdhip64 (ROCm 7.0), not /opt/rocm's 7.2: the library may
+    only bind HIP symbols that runtime has (symbol versions up to hip_6.x; newer entry points such as hipStreamGetId are looked up
+    with dlsym at run time).  Round 6 found out on the GPU box."""
+    syms = subprocess.check_output(["nm", "-D", "--with-symbol-versions", P.LIB_PATH], text=True)
+    vers = sorted({ln.rsplit("@", 1)[1] for ln in syms.splitlines() if " U " in ln and "@hip_" in ln})
+    assert vers and all(tuple(int(t) for t in v[4:].split(".")) < (7, 0) for v in vers), vers
+
+
 def test_declaration_only_cxx_program_links(tmp_path):
     """A C++ program that only DECLARES aoclsparse::mv / create_csr (what the reference's header gives it) links against this
     library through the versioned name and gets the library's status codes back without a device call (null-pointer checks)."""
