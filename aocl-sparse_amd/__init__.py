@@ -26,7 +26,7 @@ ORDER_ROW, ORDER_COLUMN = 0, 1
 STAGE_NNZ_COUNT, STAGE_FINALIZE, STAGE_FULL = 0, 1, 2
 MEM_MINIMAL, MEM_UNRESTRICTED = 0, 1
 PTR_AUTO, PTR_HOST, PTR_DEVICE = 0, 1, 2
-OPTION_SPMV_KERNEL, OPTION_SELL, OPTION_SPMV_STRICT, OPTION_ALTERNATE_SWEEPS = 0, 1, 2, 3  # aoclsparse_mi355_set_option
+OPTION_SPMV_KERNEL, OPTION_SELL, OPTION_SPMV_STRICT, OPTION_ALTERNATE_SWEEPS, OPTION_TRSV_CHUNKS = 0, 1, 2, 3, 4  # aoclsparse_mi355_set_option
 
 STATUS = {
     0: "success", 1: "not_implemented", 2: "invalid_pointer", 3: "invalid_size", 4: "internal_error",
@@ -50,6 +50,11 @@ class SpmvInfo(ctypes.Structure):
                 ("sell_slices", c_int32), ("stored_cells", ctypes.c_longlong), ("mm_groups", c_int32),
                 ("mm_window_rows", c_int32), ("mm_bell_width", c_int32), ("mm_bell_fill_permille", c_int32),
                 ("tree_min", c_int32)]
+
+
+class TrsvInfo(ctypes.Structure):
+    _fields_ = [(k, c_int32) for k in ("levels", "blocks", "block_levels", "chunks", "steps", "lds_slots", "model_chunk_us",
+                                      "model_block_us", "schedule")]
 
 
 class MmState(ctypes.Structure):
@@ -375,6 +380,7 @@ SIGNATURES = {
     "aoclsparse_mi355_export_diag": (c_int, [_P, POINTER(_P), POINTER(_P), POINTER(_I)]),
     "aoclsparse_mi355_get_spmv_info": (c_int, [_P, c_int, POINTER(SpmvInfo)]),
     "aoclsparse_mi355_get_trsv_levels": (c_int, [_P, c_int, c_int, POINTER(_I)]),
+    "aoclsparse_mi355_get_trsv_info": (c_int, [_P, c_int, c_int, POINTER(TrsvInfo)]),
     "aoclsparse_mi355_trsv_status": (c_int, [_P]),
     "aoclsparse_mi355_set_trsv_schedule": (c_int, [_I]),
     "aoclsparse_mi355_set_csrmm_beta0_overwrite": (c_int, [c_int]),
@@ -527,6 +533,11 @@ class Matrix:
         info = SpmvInfo()
         st = lib().aoclsparse_mi355_get_spmv_info(self.h, op, byref(info))
         assert st == 0
+        return info
+
+    def trsv_info(self, fill, op=OP_NONE):
+        info = TrsvInfo()
+        assert lib().aoclsparse_mi355_get_trsv_info(self.h, fill, op, byref(info)) == 0
         return info
 
     def trsv_levels(self, fill, op=OP_NONE):

@@ -410,8 +410,34 @@ constexpr int TRSV_BLK_NV   = 96; // entries of a multi-row block at most
 // spare elements behind the m x nrhs position-ordered solution buffer: [0, 64) parked tag stores, [64, 128) parked x stores
 // (one slot per lane), the last one (191) the slot that always holds 0 -- apart from the parked ones: a parked NaN must not reach it
 constexpr int TRSV_XP_PAD = 192;
+// Two-level schedule on top of the block plan (trsv_chunk_kernel; round 6; L, L^T, U^T of real types): the blocks in their
+// natural (solve) order are cut into CHUNKS of consecutive blocks, one workgroup per chunk.  A chunk walks its own blocks in
+// block-level order, a STEP (<= 64 / TRSV_CHUNK_LANES blocks of one level, TRSV_CHUNK_LANES lanes per block: a lane per row) per
+// wavefront, steps dealt round-robin to the workgroup's wavefronts.  The chunk's x lives in LDS (NaN-tagged words, as in HBM):
+// a dependency inside the chunk is polled there (~0.1 us per hand-off).  Rows of EARLIER chunks a chunk depends on are its HALO:
+// one wavefront of the workgroup polls them in xp (HBM, ~1.5-2 us) in the order of their first use and copies them into LDS
+// slots behind the chunk's own rows -- the wavefronts that solve only ever poll LDS.  The chunk plan shares the block plan's
+// level-ordered copy of the triangle; its own data:
+//   steps  nsteps x 8 words {first block (index in block-level order), position of its first row, LDS slot of that row, rows of
+//          the step's blocks as nibbles; rows in front of block j as bytes (2 words), block level, blocks}
+//   cptr   nchunks + 1 first step of every chunk, then nchunks: rows of the chunk, nchunks: first halo entry (a multiple of 4),
+//          nchunks: halo entries
+//   eptr   nblocks + 1 offsets into cind (indexed like bfirst)
+//   cind   the external dependencies of every block as LDS slots of its chunk (own rows first, halo behind them)
+//   hind   the halos: positions in xp, per chunk in the order of first use
+constexpr int TRSV_CHUNK_LANES = 8; // lanes per block = TRSV_BLK_ROWS
+constexpr int TRSV_CHUNK_WAVES = 8; // wavefronts per workgroup: 7 take steps, the last one fetches the halo
+constexpr int TRSV_CHUNK_ROWS  = 15360; // LDS slots of a chunk (own rows + halo) at most: 120 KB as double
+struct TrsvChunkPlan
+{
+    bool           tried = false, valid = false;
+    aoclsparse_int nchunks = 0, nsteps = 0, max_rows = 0; // max_rows: LDS slots (rows + halo) of the largest chunk
+    double         model_us = 0.0, model_block_us = 0.0; // plan-time estimates: this schedule / the lane-per-block one
+    DeviceBuffer   steps, cptr, eptr, cind, hind;
+};
 struct TrsvBlockPlan
 {
+    TrsvChunkPlan  chunk;
     bool           tried = false, valid = false;
     bool           front = false; // a row's chain starts with the rows of its own block (U), instead of ending with them
     aoclsparse_int nblocks = 0, nslices = 0, nlevels = 0;
@@ -591,7 +617,7 @@ public:
         stream_ = s;
     }
     aoclsparse_mi355_pointer_mode pointer_mode = aoclsparse_mi355_pointer_auto;
-    // TRSV schedule: -1 = chosen from the plan (default); 0..4 force one (aoclsparse_mi355_set_trsv_schedule; trsv_api.cpp)
+    // TRSV schedule: -1 = chosen from the plan (default); 0..5 force one (aoclsparse_mi355_set_trsv_schedule; trsv_api.cpp)
     int trsv_schedule = -1;
     // true when p is memory the device can dereference (device or managed allocation)
     bool is_device_pointer(const void *p);

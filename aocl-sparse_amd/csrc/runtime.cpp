@@ -327,7 +327,7 @@ std::atomic<bool> &csrmm_beta0_overwrite_flag()
 
 namespace
 {
-    std::atomic<int> g_plan_options[aoclsparse_mi355_option_count] = {{0}, {-1}, {0}, {1}};
+    std::atomic<int> g_plan_options[aoclsparse_mi355_option_count] = {{0}, {-1}, {0}, {1}, {-1}};
 }
 unsigned long long stream_uid(hipStream_t s)
 {
@@ -455,6 +455,8 @@ aoclsparse_status aoclsparse_mi355_set_option(aoclsparse_mi355_option option, ao
     if(option == aoclsparse_mi355_option_spmv_strict && (value < 0 || value > 1))
         return aoclsparse_status_invalid_value;
     if(option == aoclsparse_mi355_option_alternate_sweeps && (value < 0 || value > 1))
+        return aoclsparse_status_invalid_value;
+    if(option == aoclsparse_mi355_option_trsv_chunks && (value < -1 || value > 1))
         return aoclsparse_status_invalid_value;
     g_plan_options[option].store((int)value, std::memory_order_relaxed);
     return aoclsparse_status_success;

@@ -434,6 +434,201 @@ static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, T
     bp.max_rows = max_rows, bp.max_ext = max_ext;
     bp.front = front;
     bp.valid = true;
+    // 6. the two-level schedule (TrsvChunkPlan): chunks of consecutive blocks in natural order, each walked in block-level order.
+    // Not for the FRONT form (U: a row's chain starts with the rows of its own block, so nothing of a block is independent of its
+    // predecessor row) and only for shapes the kernel is compiled for.
+    bp.chunk.tried = true;
+    if(!front && max_rows <= TRSV_CHUNK_LANES && max_ext <= TRSV_BLK_EXT && nb >= 64)
+    {
+        TrsvChunkPlan &cp = bp.chunk;
+        constexpr int  NBS = 64 / TRSV_CHUNK_LANES; // blocks per step
+        constexpr int  NCW = TRSV_CHUNK_WAVES - 1; // wavefronts that take steps (the last one fetches the halo)
+        // rows per chunk: as many as the LDS holds next to the chunk's halo (the rows of EARLIER chunks it depends on, copied into
+        // LDS by the fetching wavefront), but at least ~32 chunks on large triangles (a chunk streams its part of the matrix with
+        // one workgroup)
+        static const char   *cap_env = getenv("AOCLSPARSE_MI355_TRSV_CHUNK_ROWS"); // (diagnostics: rows per chunk)
+        const aoclsparse_int cap     = cap_env ? std::min<aoclsparse_int>(TRSV_CHUNK_ROWS, std::max(64, atoi(cap_env)))
+                                               : std::min<aoclsparse_int>(TRSV_CHUNK_ROWS, std::max<aoclsparse_int>(2048, m / 32));
+        std::vector<aoclsparse_int> kof((size_t)nb), chunk_of((size_t)nb), bof2((size_t)m); // bof2: natural block index of a row
+        for(aoclsparse_int k = 0; k < nb; k++)
+            kof[order[k]] = k;
+        for(aoclsparse_int bq = 0; bq < nb; bq++)
+            for(aoclsparse_int kk = bptr[bq]; kk < bptr[bq + 1]; kk++)
+                bof2[brows[kk]] = bq;
+        std::vector<aoclsparse_int> cfirst; // first block (natural index) of every chunk
+        std::vector<aoclsparse_int> stamp((size_t)m, -1); // row counted in the halo of chunk stamp[row]
+        bool                        fits = true;
+        {
+            aoclsparse_int rows = 0, halo = 0, c = 0, bq0 = 0;
+            cfirst.push_back(0);
+            for(aoclsparse_int bq = 0; bq < nb && fits; bq++)
+            {
+                const aoclsparse_int r = bptr[bq + 1] - bptr[bq], first = brows[bptr[bq]];
+                for(;;)
+                {
+                    aoclsparse_int add = 0;
+                    for(aoclsparse_int p = t.ptr[first]; p < t.ptr[first + 1]; p++)
+                        if(bof2[t.ind[p]] < bq0 && stamp[t.ind[p]] != c)
+                            stamp[t.ind[p]] = c, add++;
+                    if(rows + r <= cap && rows + r + halo + add <= TRSV_CHUNK_ROWS)
+                    {
+                        rows += r, halo += add;
+                        break;
+                    }
+                    if(rows == 0) // a block that does not fit a chunk of its own (a row with ~15,000 dependencies)
+                    {
+                        fits = false;
+                        break;
+                    }
+                    cfirst.push_back(bq), c++, bq0 = bq, rows = 0, halo = 0; // close the chunk in front of this block; count again
+                }
+                chunk_of[bq] = c;
+            }
+            cfirst.push_back(nb);
+        }
+        const aoclsparse_int        nch = (aoclsparse_int)cfirst.size() - 1;
+        std::vector<aoclsparse_int> steps, cptr((size_t)nch + 1, 0), crows((size_t)nch, 0), hptr((size_t)nch + 1, 0), slot_of((size_t)m);
+        std::vector<aoclsparse_int> hind, ks, hslot((size_t)(fits ? m : 0)), step_of((size_t)(fits ? nb : 0)), hcount((size_t)nch, 0);
+        std::vector<std::pair<aoclsparse_int, aoclsparse_int>> hl; // (first step that needs it, position)
+        steps.reserve((size_t)nb);
+        aoclsparse_int maxslots = 0;
+        for(aoclsparse_int c = 0; c < nch && fits; c++)
+        {
+            ks.clear();
+            for(aoclsparse_int bq = cfirst[c]; bq < cfirst[c + 1]; bq++)
+                ks.push_back(kof[bq]);
+            std::sort(ks.begin(), ks.end()); // = (block level, natural index): the level order is stable
+            aoclsparse_int slot = 0;
+            hl.clear();
+            for(size_t i = 0; i < ks.size();)
+            {
+                size_t               j  = i + 1;
+                const aoclsparse_int lv = blev[order[ks[i]]];
+                while(j < ks.size() && j - i < (size_t)NBS && ks[j] == ks[j - 1] + 1 && blev[order[ks[j]]] == lv)
+                    j++;
+                // header of the step, 8 words: first block (index in block-level order), position of its first row, LDS slot of
+                // that row, rows of the (<= 8) blocks as nibbles; rows in front of block j as bytes (2 words), block level, blocks
+                unsigned cw = 0, pre[2] = {0, 0};
+                int      rows_before = 0;
+                const aoclsparse_int sidx = (aoclsparse_int)(steps.size() / 8);
+                for(size_t q = i; q < j; q++)
+                {
+                    const int rws = bfirst[ks[q] + 1] - bfirst[ks[q]];
+                    cw |= (unsigned)rws << (4 * (q - i));
+                    pre[(q - i) / 4] |= (unsigned)rows_before << (8 * ((q - i) % 4));
+                    rows_before += rws;
+                    step_of[ks[q]] = sidx;
+                    const aoclsparse_int first = rowmap[bfirst[ks[q]]];
+                    for(aoclsparse_int p = t.ptr[first]; p < t.ptr[first + 1]; p++)
+                        if(chunk_of[bof2[t.ind[p]]] != c && stamp[t.ind[p]] != -2 - c) // the halo: first use decides the order
+                            stamp[t.ind[p]] = -2 - c, hl.emplace_back(sidx, pos[t.ind[p]]);
+                }
+                steps.push_back(ks[i]), steps.push_back(bfirst[ks[i]]), steps.push_back(slot), steps.push_back((aoclsparse_int)cw);
+                steps.push_back((aoclsparse_int)pre[0]), steps.push_back((aoclsparse_int)pre[1]), steps.push_back(lv);
+                steps.push_back((aoclsparse_int)(j - i));
+                for(aoclsparse_int q = bfirst[ks[i]]; q < bfirst[ks[j - 1] + 1]; q++)
+                    slot_of[q] = slot++;
+                i = j;
+            }
+            std::sort(hl.begin(), hl.end());
+            for(size_t i = 0; i < hl.size(); i++)
+                hind.push_back(hl[i].second);
+            hcount[c] = (aoclsparse_int)hl.size();
+            while(hind.size() % 4)
+                hind.push_back(0); // (the fetching wavefront reads four positions per lane with one load)
+            crows[c]    = slot;
+            hptr[c + 1] = (aoclsparse_int)hind.size();
+            maxslots    = std::max<aoclsparse_int>(maxslots, slot + (aoclsparse_int)hl.size());
+            cptr[c + 1] = (aoclsparse_int)(steps.size() / 8);
+            // this chunk's dependency lists right away (hslot is per chunk): LDS slots of its own rows and of its halo
+        }
+        // external dependency lists (those of a block's first-solved row), indexed like bfirst; every entry an LDS slot of the
+        // block's chunk.  hslot[] of a position is valid for ONE chunk at a time, so the lists are written chunk by chunk.
+        std::vector<aoclsparse_int> eptr((size_t)nb + 1, 0);
+        for(aoclsparse_int k = 0; k < nb; k++)
+            eptr[k + 1] = eptr[k] + len_of(rowmap[bfirst[k]]);
+        std::vector<aoclsparse_int> cind((size_t)eptr[nb] + 32, 0); // (padded: the kernel may read up to EXT words past a list)
+        for(aoclsparse_int c = 0; c < nch && fits; c++)
+        {
+            for(aoclsparse_int i = hptr[c]; i < hptr[c] + hcount[c]; i++)
+                hslot[hind[i]] = crows[c] + (i - hptr[c]);
+            for(aoclsparse_int bq = cfirst[c]; bq < cfirst[c + 1]; bq++)
+            {
+                const aoclsparse_int k = kof[bq], r = rowmap[bfirst[k]];
+                for(aoclsparse_int jj = 0; jj < len_of(r); jj++)
+                {
+                    const aoclsparse_int dep = t.ind[t.ptr[r] + jj];
+                    cind[eptr[k] + jj]       = chunk_of[bof2[dep]] == c ? slot_of[pos[dep]] : hslot[pos[dep]];
+                }
+            }
+        }
+        // plan-time model of both schedules (costs in us from the traces: profiles/r5/trsv_experiments.txt, profiles/r6/): a step
+        // = the later of {its wavefront free + the latency of its values, its last dependency + the hand-off} + the work
+        // (round 6, profiles/r6/trsv_chunk_trace*.txt: a hand-off through LDS 0.45, solving a step 0.4, a wavefront's loads for a step
+        // 1.7, a value of another chunk 2.5 us after it was produced)
+        const double work = 0.4, local = 0.45, remote = 2.5, vals = 1.7;
+        double       total = 0.0;
+        if(fits)
+        {
+            std::vector<double> fin((size_t)nb, 0.0);
+            for(aoclsparse_int c = 0; c < nch; c++)
+            {
+                double wfree[NCW] = {0};
+                for(aoclsparse_int sidx = cptr[c]; sidx < cptr[c + 1]; sidx++)
+                {
+                    const int            w    = (int)((sidx - cptr[c]) % NCW);
+                    double               when = wfree[w] + vals;
+                    const aoclsparse_int kf = steps[8 * (size_t)sidx], kn = kf + steps[8 * (size_t)sidx + 7];
+                    for(aoclsparse_int k = kf; k < kn; k++)
+                    {
+                        const aoclsparse_int r = rowmap[bfirst[k]];
+                        for(aoclsparse_int jj = t.ptr[r]; jj < t.ptr[r + 1]; jj++)
+                        {
+                            const aoclsparse_int d = bof2[t.ind[jj]];
+                            when = std::max(when, fin[d] + (chunk_of[d] == c ? local : remote));
+                        }
+                    }
+                    const double f = when + work;
+                    for(aoclsparse_int k = kf; k < kn; k++)
+                        fin[order[k]] = f;
+                    wfree[w] = f;
+                    total    = std::max(total, f);
+                }
+            }
+        }
+        cp.model_us       = total;
+        cp.model_block_us = (double)nlev * (1.2 + 0.4 * std::max(1.0, (double)bp.nslices / (double)nlev));
+        lt.lap("chunks: steps + dependency lists + model");
+        // aoclsparse_mi355_set_option(trsv_chunks, ...): -1 the model decides (default), 0 never, 1 whenever the plan can be built
+        const int want = plan_option(aoclsparse_mi355_option_trsv_chunks);
+        if(fits && want != 0 && (cp.model_us < 0.8 * cp.model_block_us || want == 1))
+        {
+            // cptr: first step of every chunk (nch + 1), rows of every chunk (nch), first halo entry of every chunk (nch, each a
+            // multiple of 4), halo entries of every chunk (nch)
+            std::vector<aoclsparse_int> cp2(cptr);
+            cp2.insert(cp2.end(), crows.begin(), crows.end());
+            cp2.insert(cp2.end(), hptr.begin(), hptr.end() - 1);
+            cp2.insert(cp2.end(), hcount.begin(), hcount.end());
+            hind.resize(hind.size() + 256 * 4, 0); // (a round reads 256 positions whatever is left of the list)
+            rc = cp.steps.upload(steps.data(), sizeof(aoclsparse_int) * steps.size(), st);
+            if(rc == aoclsparse_status_success)
+                rc = cp.cptr.upload(cp2.data(), sizeof(aoclsparse_int) * cp2.size(), st);
+            if(rc == aoclsparse_status_success)
+                rc = cp.eptr.upload(eptr.data(), sizeof(aoclsparse_int) * eptr.size(), st);
+            if(rc == aoclsparse_status_success)
+                rc = cp.cind.upload(cind.data(), sizeof(aoclsparse_int) * cind.size(), st);
+            if(rc == aoclsparse_status_success)
+                rc = cp.hind.upload(hind.data(), sizeof(aoclsparse_int) * hind.size(), st);
+            if(rc == aoclsparse_status_success)
+                rc = hipStreamSynchronize(st) == hipSuccess ? rc : aoclsparse_status_internal_error; // (the host vectors die here)
+            if(rc == aoclsparse_status_success)
+            {
+                cp.nchunks = nch, cp.nsteps = (aoclsparse_int)(steps.size() / 8), cp.max_rows = maxslots;
+                cp.valid = true;
+            }
+            lt.lap("chunks: upload");
+        }
+    }
     free_later(std::move(pind), std::move(pval), std::move(rowmap), std::move(pos), std::move(pptr), std::move(G.brows));
     return aoclsparse_status_success;
 }
@@ -595,7 +790,9 @@ aoclsparse_status solve_core(aoclsparse_operation trans, T alpha, aoclsparse_mat
     const bool packed = nrhs == 1 && plan.nslices > 0 && (long long)plan.nslices * 16 <= (long long)m;
     const int  sf     = (packed && ((long long)plan.nnz_tri <= 10LL * m || (upper && !tr && !conj))) ? 3 : 2;
     // chained rows (the dofs of a node) solved back to back by one lane: one hop per BLOCK level instead of per row level
-    const int sfb = plan.blk.valid ? 4 : sf; // (trsm too: one grid column per right-hand side)
+    // ... and, where the plan-time model says it pays, the two-level schedule: chunks of consecutive blocks, hand-offs inside a
+    // chunk through LDS (schedule 5; the reference chain only)
+    const int sfb = plan.blk.valid ? (plan.blk.chunk.valid ? 5 : 4) : sf; // (trsm too: one grid column per right-hand side)
     // Round 3: the kid selects the ARITHMETIC, as it does in the reference (trsv.cpp:321-353), not the schedule.  kid 0 and auto:
     // the chain of ref_trsv_* -- every schedule reproduces it, so the fastest one runs; kid 1 / 2: the order of the 256-bit KT
     // kernels, kid 3: of the 512-bit ones (kt_trsv_l / kt_trsv_u, trsv_kt.cpp:64-150, :297-383), bit for bit, served by the
@@ -604,7 +801,7 @@ aoclsparse_status solve_core(aoclsparse_operation trans, T alpha, aoclsparse_mat
     // aoclsparse_mi355_set_trsv_schedule forces a schedule (tests, measurements).
     const int kt_bits  = (!is_cplx && !tr && kid >= 1) ? (kid == 3 ? 512 : 256) : 0;
     const int forced   = Runtime::primary().trsv_schedule;
-    const int schedule = is_cplx ? 1 : (forced >= 0 && forced <= 4) ? forced : (plan.nlevels <= 32 ? 0 : sfb);
+    const int schedule = is_cplx ? 1 : (forced >= 0 && forced <= 5) ? forced : (plan.nlevels <= 32 ? 0 : sfb);
     // the handle's own timeout word (pinned, device-mapped): allocated once per handle
     if(!is_cplx && !A->trsv_timeout_dev)
     {
@@ -1056,7 +1253,7 @@ aoclsparse_status aoclsparse_mi355_ztrsv_full(aoclsparse_operation trans, aoclsp
 
 aoclsparse_status aoclsparse_mi355_set_trsv_schedule(aoclsparse_int schedule)
 {
-    if(schedule < -1 || schedule > 4)
+    if(schedule < -1 || schedule > 5)
         return aoclsparse_status_invalid_value;
     Runtime::primary().trsv_schedule = (int)schedule;
     return aoclsparse_status_success;
@@ -1084,6 +1281,36 @@ aoclsparse_status aoclsparse_mi355_get_trsv_levels(const aoclsparse_matrix A, ao
     const bool      cj = op == aoclsparse_operation_conjugate_transpose && is_complex_type(A->val_type);
     const TrsvPlan &p  = A->trsv_plan[cj ? 4 + (up ? 1 : 0) : (up ? 2 : 0) + (op != aoclsparse_operation_none ? 1 : 0)];
     *levels = p.valid ? p.nlevels : -1;
+    return aoclsparse_status_success;
+}
+
+aoclsparse_status aoclsparse_mi355_get_trsv_info(const aoclsparse_matrix A, aoclsparse_fill_mode fill, aoclsparse_operation op,
+                                                 aoclsparse_mi355_trsv_info *info)
+{
+    if(!A || !info)
+        return aoclsparse_status_invalid_pointer;
+    std::shared_lock<std::shared_mutex> r(A->guard);
+    const bool      up = fill == aoclsparse_fill_mode_upper;
+    const bool      cj = op == aoclsparse_operation_conjugate_transpose && is_complex_type(A->val_type);
+    const TrsvPlan &p  = A->trsv_plan[cj ? 4 + (up ? 1 : 0) : (up ? 2 : 0) + (op != aoclsparse_operation_none ? 1 : 0)];
+    *info              = aoclsparse_mi355_trsv_info{};
+    if(!p.valid)
+        return aoclsparse_status_success;
+    info->levels = p.nlevels;
+    if(p.blk.valid)
+        info->blocks = p.blk.nblocks, info->block_levels = p.blk.nlevels;
+    const TrsvChunkPlan &c = p.blk.chunk;
+    info->model_chunk_us = (aoclsparse_int)c.model_us, info->model_block_us = (aoclsparse_int)c.model_block_us;
+    if(p.blk.valid && c.valid)
+        info->chunks = c.nchunks, info->steps = c.nsteps, info->lds_slots = c.max_rows;
+    const int forced = Runtime::primary().trsv_schedule;
+    const int autos  = p.nlevels <= 32 ? 0 : (p.blk.valid ? (c.valid ? 5 : 4) : 2);
+    int       sched  = is_complex_type(A->val_type) ? 1 : (forced >= 0 && forced <= 5 ? forced : autos);
+    if(sched == 5 && !(p.blk.valid && c.valid))
+        sched = 4;
+    if(sched == 4 && !p.blk.valid)
+        sched = 3;
+    info->schedule = sched;
     return aoclsparse_status_success;
 }
 

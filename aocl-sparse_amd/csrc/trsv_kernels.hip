@@ -1254,6 +1254,385 @@ __global__ __launch_bounds__(64) void trsv_block_kt_kernel(
         __hip_atomic_store(timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ---- schedule 5: two levels -- chunks of consecutive blocks, hand-offs inside a chunk through LDS (round 6) ----------------
+// The lane-per-block kernel above pays one hand-off through L2 / HBM per block level (1.2-1.7 us against 0.4 us of work: profiles/r5/
+// trsv_experiments.txt), because consecutive levels always run in different wavefronts on different CUs.  Here the blocks keep their
+// NATURAL order at the top level: a workgroup owns a CHUNK of consecutive blocks (internal.hpp: TrsvChunkPlan) and walks them in
+// block-level order, one STEP (<= 8 blocks of one level) per wavefront, steps dealt round-robin to seven of its eight wavefronts.
+// The chunk's x lives in LDS as NaN-tagged words -- exactly the protocol of the sync-free kernels, one level closer: a dependency
+// on a row of the same chunk is polled in LDS (a hand-off costs an LDS write + read).  Rows of earlier chunks the chunk depends on
+// (its HALO) are polled in xp by the EIGHTH wavefront, in the order of their first use, and copied into LDS slots behind the chunk's
+// own rows: the solving wavefronts never wait for an HBM round trip, and one wavefront per chunk polls HBM instead of all of them.
+// A mesh numbered line by line puts most of a block's dependencies a few hundred blocks back, inside its chunk: the remote
+// hand-offs that remain are one per chunk boundary along the critical path, and they are pipelined (chunk c + 1 runs one remote
+// latency behind chunk c).  Chunks are taken through a ticket in natural order and depend on earlier chunks only.
+// Inside a step a block owns 8 lanes, lane a = row a of the block: the external parts of the rows (the block's 16-24 dependencies
+// times its rows) are independent chains and run in parallel lanes; their sums are gathered into the block's first lane (DPP
+// row_shl), which eliminates the block's rows column by column in registers, exactly the order of the lane-per-block kernel -- row
+// a's chain is [external entries in CSR order, then rows 0..a-1 of the block] -- so x is bit-identical to ref_trsv_* whatever the
+// schedule.  Metadata of a wavefront's NEXT step is requested while it waits for the current one.
+template <int R>
+__device__ __forceinline__ int trsv_dpp_shl(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, 0x100 + R, 0xf, 0xf, true); // lane l <- lane l + R of its row of 16 (0 beyond it)
+}
+template <int R>
+__device__ __forceinline__ double trsv_dpp_shl(double v)
+{
+    return __hiloint2double(trsv_dpp_shl<R>(__double2hiint(v)), trsv_dpp_shl<R>(__double2loint(v)));
+}
+template <int R>
+__device__ __forceinline__ float trsv_dpp_shl(float v)
+{
+    return __int_as_float(trsv_dpp_shl<R>(__float_as_int(v)));
+}
+
+template <typename T, int EXT, int BS, bool UNIT>
+__global__ __launch_bounds__(64 * TRSV_CHUNK_WAVES) void trsv_chunk_kernel(
+    aoclsparse_int m, aoclsparse_int nnz, aoclsparse_int nchunks, const int4 *__restrict__ steps, const aoclsparse_int *__restrict__ cptr,
+    const aoclsparse_int *__restrict__ rowmap, const aoclsparse_int *__restrict__ pptr, const T *__restrict__ pval,
+    const aoclsparse_int *__restrict__ eptr, const aoclsparse_int *__restrict__ cind, const aoclsparse_int *__restrict__ hind,
+    const T *__restrict__ diag, const T *__restrict__ b, T *xp, T *x, T alpha, unsigned int *ticket,
+    unsigned int *timeout_flag, int incb, int incx, int nrhs, long long b_off, long long x_off, unsigned long long *trace, int dbg)
+{
+    using B          = typename tag<T>::bits;
+    constexpr int BL = TRSV_CHUNK_LANES; // lanes per block
+    constexpr int NW = TRSV_CHUNK_WAVES - 1; // wavefronts that take steps
+    // (16-byte aligned: behind a 4-byte static variable the dynamic array started at offset 4, and every 8-byte word of the chunk
+    // was a misaligned LDS access -- slow, and not the single access the tagged-word protocol needs)
+    // NO static LDS variable next to it: behind a 4-byte one the dynamic array started at offset 4 whatever its declared alignment)
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    int &s_chunk = *reinterpret_cast<int *>(s_raw); // the first 16 bytes: the chunk this workgroup drew
+    B   *lx      = reinterpret_cast<B *>(s_raw + 16); // [rows of the chunk][its halo]: tags / x; then one slot that holds 0; then 64 parked slots
+    const int col = nrhs > 1 ? (int)blockIdx.x : 0;
+    ticket += col;
+    b += col * b_off, x += col * x_off, xp += (size_t)col * m;
+    B        *xb  = reinterpret_cast<B *>(xp);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane / BL, a = lane % BL; // block of the step, row of the block
+    if(tid == 0)
+        s_chunk = (int)atomicAdd(ticket, 1u);
+    __syncthreads();
+    const int ch = s_chunk;
+    if(ch >= nchunks)
+        return;
+    const int s0 = cptr[ch], s1 = cptr[ch + 1], nrows = cptr[nchunks + 1 + ch];
+    const int hb = cptr[2 * nchunks + 1 + ch], nh = cptr[3 * nchunks + 1 + ch]; // this chunk's halo: hind[hb .. hb + nh)
+    for(int i = tid; i < nrows + nh; i += 64 * TRSV_CHUNK_WAVES)
+        lx[i] = tag<T>::value;
+    if(tid == 0)
+        lx[nrows + nh] = 0; // "no dependency here"
+    __syncthreads();
+    // (from here on the chunk's words are polled while other wavefronts write them: relaxed workgroup-scope atomics, so that the
+    // compiler re-reads them; one 4- / 8-byte LDS access each)
+    auto lds_get = [&](int slot) { return __hip_atomic_load(&lx[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto lds_put = [&](int slot, B v) { __hip_atomic_store(&lx[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    const int          zslot = nrows + nh, park = zslot + 1 + lane; // the slot that holds 0; this lane's parked stores
+    unsigned long long t0    = 0;
+    bool               dead  = false;
+    unsigned int       spins = 0;
+    auto               tick  = [&](unsigned int every) {
+        if((++spins & every) == 0)
+        {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if(t0 == 0)
+                t0 = now;
+            else if(now - t0 > TRSV_WAIT_TICKS)
+                dead = true;
+        }
+    };
+    if(wave == NW)
+    {
+        // the fetching wavefront: the halo in ROUNDS of 256 entries (sorted by first use), lane l takes entries 4 l .. 4 l + 3 of
+        // the round: their positions are one 16-byte load (requested a round ahead), their words four loads per look; what has
+        // arrived goes to its LDS slot at once, the round ends when all of it has.  A look costs one HBM round trip whatever the
+        // number of words still missing.  (First version: two entries per lane, each followed by the load of the next position --
+        // two dependent round trips per entry, 30-40 entries per us; an unstructured mesh needs ~3,000 per chunk.)
+        const int4 *h4    = reinterpret_cast<const int4 *>(hind); // (hb is a multiple of 4: the plan pads every chunk's list)
+        const int   nr    = (nh + 255) / 256;
+        int4        qn    = nr > 0 ? h4[hb / 4 + lane] : int4{0, 0, 0, 0};
+        int         idle  = 0;
+        for(int r = 0; r < nr && __builtin_amdgcn_ballot_w64(dead) == 0; r++)
+        {
+            const int4 q  = qn;
+            const int  i0 = 256 * r + 4 * lane;
+            if(r + 1 < nr)
+                qn = h4[hb / 4 + 64 * (r + 1) + lane];
+            unsigned need = (i0 < nh ? 1u : 0u) | (i0 + 1 < nh ? 2u : 0u) | (i0 + 2 < nh ? 4u : 0u) | (i0 + 3 < nh ? 8u : 0u);
+            while(__builtin_amdgcn_ballot_w64(need != 0) != 0 && __builtin_amdgcn_ballot_w64(dead) == 0)
+            {
+                // (all four unconditionally: entries beyond the list hold position 0, a word that exists)
+                const B v0 = __hip_atomic_load(&xb[q.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const B v1 = __hip_atomic_load(&xb[q.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const B v2 = __hip_atomic_load(&xb[q.z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const B v3 = __hip_atomic_load(&xb[q.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned got = 0;
+                if((need & 1u) && v0 != tag<T>::value)
+                    lds_put(nrows + i0, v0), got |= 1u;
+                if((need & 2u) && v1 != tag<T>::value)
+                    lds_put(nrows + i0 + 1, v1), got |= 2u;
+                if((need & 4u) && v2 != tag<T>::value)
+                    lds_put(nrows + i0 + 2, v2), got |= 4u;
+                if((need & 8u) && v3 != tag<T>::value)
+                    lds_put(nrows + i0 + 3, v3), got |= 8u;
+                need &= ~got;
+                if(__builtin_amdgcn_ballot_w64(got != 0) != 0)
+                    idle = 0;
+                else if(++idle > 8) // nothing new for a while: this chunk is far ahead of its predecessors
+                    __builtin_amdgcn_s_sleep(16);
+                tick(255u);
+            }
+        }
+        if(__builtin_amdgcn_ballot_w64(dead) != 0 && lane == 0)
+            __hip_atomic_store(timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    // per-lane metadata of a step, everything ONE load away from the step's header:
+    struct Meta
+    {
+        int  mypos, myslot, c, row, pa, p0, p1, e0; // position / LDS slot of my row, rows of my block, row index, first entry of my
+        bool live; // row, of the block's first row and of its second, offset of the block's dependency list
+    };
+    auto header = [&](int s, int4 &h0, int4 &h1) {
+        const int su = __builtin_amdgcn_readfirstlane(s); // (one step per wavefront)
+        h0 = steps[2 * (size_t)su], h1 = steps[2 * (size_t)su + 1];
+    };
+    auto level1 = [&](const int4 &h0, const int4 &h1, Meta &mt) {
+        const int c   = (int)(((unsigned)h0.w >> (4 * j)) & 15u);
+        const int pre = (int)(((unsigned)(j < 4 ? h1.x : h1.y) >> (8 * (j & 3))) & 255u);
+        mt.c          = c;
+        mt.live       = a < c;
+        const int k0  = h0.y + pre; // position of the block's first row
+        mt.mypos      = mt.live ? k0 + a : 0;
+        mt.myslot     = mt.live ? h0.z + pre + a : zslot;
+        mt.row        = mt.live ? rowmap[k0 + a] : 0;
+        mt.pa         = mt.live ? pptr[k0 + a] : 0;
+        mt.p0         = c > 0 ? pptr[k0] : 0;
+        mt.p1         = c > 0 ? pptr[k0 + 1] : 0;
+        mt.e0         = c > 0 ? eptr[h0.x + j] : 0;
+    };
+    int4 h0 = {0, 0, 0, 0}, h1 = h0, g0 = h0, g1 = h0;
+    Meta cur = {0, zslot, 0, 0, 0, 0, 0, 0, false}, nxt;
+    if(s0 + wave < s1)
+    {
+        header(s0 + wave, h0, h1);
+        level1(h0, h1, cur);
+    }
+    if(s0 + wave + NW < s1)
+        header(s0 + wave + NW, g0, g1);
+    nxt = cur;
+    // level 2 of a step: my row's external coefficients, the block's dependency list (LDS slots), right-hand side, diagonal, and --
+    // for the block's first lane -- the coefficients of the rows inside the block, vn[r][tt] = row r on block row tt.  Every load
+    // unconditional, from an address that exists, and masked when it is used (predicated loads become one basic block each, and
+    // the compiler's waits at their joins serialised the batches).  Requested for the NEXT step of this wavefront as soon as the
+    // current one has left its registers, IN FRONT of the current step's stores to HBM: vmcnt retires in order, and behind the
+    // write-through stores of x the loads waited for the stores' acknowledgements too (2 us more before every first look).
+    int       la[EXT];
+    T         ve[EXT], vn[BS][BS - 1], bb = T(0), dd = T(1);
+    const int last    = nnz - 1;
+    auto      level2 = [&](const Meta &mt) {
+        const int n0 = mt.p1 - mt.p0;
+#pragma unroll
+        for(int e = 0; e < EXT; e++)
+        {
+            la[e] = cind[mt.e0 + e]; // (cind is padded by 32 words)
+            ve[e] = pval[min(mt.pa + e, last)];
+        }
+        bb = b[(size_t)mt.row * incb];
+        if constexpr(!UNIT)
+            dd = diag[mt.row];
+#pragma unroll
+        for(int r = 1; r < BS; r++)
+#pragma unroll
+            for(int tt = 0; tt < r; tt++)
+                vn[r][tt] = pval[min(mt.p0 + r * n0 + (r * (r - 1)) / 2 + n0 + tt, last)];
+    };
+    if(s0 + wave < s1)
+        level2(cur);
+    for(int s = s0 + wave; s < s1; s += NW)
+    {
+        if(__builtin_amdgcn_ballot_w64(dead) != 0)
+            break;
+        const bool live = cur.live, base = a == 0 && cur.c > 0;
+        const int  c = cur.c, n0 = cur.p1 - cur.p0, nl = n0 < EXT ? n0 : EXT;
+        const unsigned long long t_begin = trace ? __builtin_amdgcn_s_memrealtime() : 0;
+        const unsigned long long c_begin = (trace && (dbg & 8)) ? __builtin_amdgcn_s_memtime() : 0;
+        // (masked NOW, before the wait: left to the compiler, the selects moved behind it)
+#pragma unroll
+        for(int e = 0; e < EXT; e++)
+        {
+            la[e] = (c > 0 && e < nl) ? la[e] : zslot;
+            ve[e] = (live && e < nl) ? ve[e] : T(0);
+            asm volatile("" : "+v"(ve[e]), "+v"(la[e]));
+        }
+        T rhs = live ? alpha * bb : T(0);
+        T dg  = (live && !UNIT) ? dd : T(1);
+        asm volatile("" : "+v"(rhs), "+v"(dg));
+#pragma unroll
+        for(int r = 1; r < BS; r++)
+#pragma unroll
+            for(int tt = 0; tt < r; tt++)
+            {
+                vn[r][tt] = (base && r < c) ? vn[r][tt] : T(0);
+                asm volatile("" : "+v"(vn[r][tt]));
+            }
+        // the next step of this wavefront: level-1 metadata now (its header came during the previous step), header of the one after
+        if(s + NW < s1)
+        {
+            level1(g0, g1, nxt);
+            if(s + 2 * NW < s1)
+                header(s + 2 * NW, g0, g1);
+        }
+        // One round of LDS reads for all dependencies; then, while some lane misses something (`pend`, uniform), the wavefront
+        // spins on ONE missing word and looks at the other missing ones again when that one has arrived.  Six wavefronts that
+        // re-read all their 15-24 words every ~0.1 us saturate the CU's LDS pipe (traced: a hand-off through LDS took 2.5-3.7 us,
+        // the writes of the one wavefront that works queued behind the polls); one word per look is ~100 reads per us.
+        B bits[EXT];
+#pragma unroll
+        for(int e = 0; e < EXT; e++)
+            bits[e] = lds_get(la[e]);
+        unsigned long long t_first = 0;
+        if(trace)
+        {
+            asm volatile("" : "+v"(bits[EXT - 1]));
+            t_first = __builtin_amdgcn_s_memrealtime(); // the first look has landed: values and dependency list were in
+        }
+        unsigned int pend = 0;
+#pragma unroll
+        for(int e = 0; e < EXT; e++)
+            if(__builtin_amdgcn_ballot_w64(bits[e] == tag<T>::value) != 0)
+                pend |= 1u << e;
+        while(pend != 0 && __builtin_amdgcn_ballot_w64(dead) == 0)
+        {
+            int ad = zslot; // the LAST missing entry: the block solved last is the nearest in the chain order of L
+#pragma unroll
+            for(int e = 0; e < EXT; e++)
+                if(pend & (1u << e))
+                    ad = la[e];
+            for(;;)
+            {
+                const B v = lds_get(ad);
+                if(__builtin_amdgcn_ballot_w64(v == tag<T>::value) == 0 || __builtin_amdgcn_ballot_w64(dead) != 0)
+                    break;
+                __builtin_amdgcn_s_sleep(2); // (no sleep / s_sleep 8: the same hand-off time, profiles/r6/trsv_chunk_experiments.txt)
+                tick(4095u);
+            }
+            if(trace && (dbg & 4))
+                t_first = __builtin_amdgcn_s_memrealtime(); // (diagnostics, dbg 4: when the spin word was seen)
+            // then ALL entries again, without a branch (guarded re-reads of the missing ones only became one basic block each
+            // with a wait at every join: 15 LDS round trips one after the other, ~1 us on the critical path)
+#pragma unroll
+            for(int e = 0; e < EXT; e++)
+                bits[e] = lds_get(la[e]);
+            pend = 0;
+#pragma unroll
+            for(int e = 0; e < EXT; e++)
+                pend |= __builtin_amdgcn_ballot_w64(bits[e] == tag<T>::value) != 0 ? (1u << e) : 0u;
+        }
+        const unsigned long long t_ready = trace ? __builtin_amdgcn_s_memrealtime() : 0;
+        // ---- from here on every instruction is on the critical path of the solve ----
+        T sa = rhs;
+#pragma unroll
+        for(int e = 0; e < EXT; e++)
+        {
+            T xe;
+            __builtin_memcpy(&xe, &bits[e], sizeof(T));
+            sa = neg_fma(ve[e], xe, sa);
+        }
+        // a single row with more than EXT dependencies (never inside a multi-row block): the rest one by one
+        if(__builtin_amdgcn_ballot_w64(base && n0 > EXT) != 0)
+        {
+            if(base && n0 > EXT)
+                for(int p = EXT; p < n0 && !dead; p++)
+                {
+                    const int q = cind[cur.e0 + p];
+                    B         got;
+                    for(;;)
+                    {
+                        got = lds_get(q);
+                        if(got != tag<T>::value || dead)
+                            break;
+                        __builtin_amdgcn_s_sleep(1);
+                        tick(1023u);
+                    }
+                    T xv;
+                    __builtin_memcpy(&xv, &got, sizeof(T));
+                    sa = neg_fma(pval[cur.pa + p], xv, sa);
+                }
+        }
+        unsigned long long t_ext = 0;
+        if(trace)
+        {
+            asm volatile("" : "+v"(sa));
+            t_ext = __builtin_amdgcn_s_memrealtime();
+        }
+        // the sums and the diagonals of the block's rows -> its first lane
+        T sg[8], dgs[8];
+        sg[0] = sa, dgs[0] = dg;
+        sg[1] = trsv_dpp_shl<1>(sa), sg[2] = trsv_dpp_shl<2>(sa), sg[3] = trsv_dpp_shl<3>(sa), sg[4] = trsv_dpp_shl<4>(sa);
+        if constexpr(BS > 5)
+            sg[5] = trsv_dpp_shl<5>(sa), sg[6] = trsv_dpp_shl<6>(sa), sg[7] = trsv_dpp_shl<7>(sa);
+        if constexpr(!UNIT)
+        {
+            dgs[1] = trsv_dpp_shl<1>(dg), dgs[2] = trsv_dpp_shl<2>(dg), dgs[3] = trsv_dpp_shl<3>(dg), dgs[4] = trsv_dpp_shl<4>(dg);
+            if constexpr(BS > 5)
+                dgs[5] = trsv_dpp_shl<5>(dg), dgs[6] = trsv_dpp_shl<6>(dg), dgs[7] = trsv_dpp_shl<7>(dg);
+        }
+        // column by column: as soon as block row tt is final it goes to LDS (what the chunk's other wavefronts poll) and is taken
+        // out of every later row; lanes and rows that own nothing store to their parked slot
+        const int  slot0 = cur.myslot; // (first lane: slot of block row 0)
+        const bool ok    = base && !__builtin_amdgcn_ballot_w64(dead);
+#pragma unroll
+        for(int tt = 0; tt < BS; tt++)
+        {
+            T xt = sg[tt];
+            if constexpr(!UNIT) // (a template parameter: as a run-time test the compiler computed the quotient anyway and selected)
+                xt /= dgs[tt];
+            B out;
+            __builtin_memcpy(&out, &xt, sizeof(T));
+            out = out == tag<T>::value ? qnan_bits<T>::value : out;
+            lds_put((ok && tt < c) ? slot0 + tt : park, out);
+#pragma unroll
+            for(int r = tt + 1; r < BS; r++)
+                sg[r] = neg_fma(vn[r][tt], xt, sg[r]);
+        }
+        unsigned long long t_elim = 0;
+        if(trace)
+        {
+            asm volatile("" : "+v"(sg[BS - 1]));
+            t_elim = __builtin_amdgcn_s_memrealtime();
+        }
+        // every row lane takes its own x back out of LDS: the tagged word for the other chunks, and the caller's x -- stored BEHIND
+        // the requests for the next step's data
+        const bool alive  = __builtin_amdgcn_ballot_w64(dead) == 0;
+        B          mine   = lds_get(cur.myslot);
+        const int  st_pos = cur.mypos, st_row = cur.row;
+        asm volatile("" : "+v"(mine));
+        if(s + NW < s1)
+        {
+            cur = nxt;
+            level2(cur);
+        }
+        if(alive && live)
+        {
+            __hip_atomic_store(&xb[st_pos], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            T xv;
+            __builtin_memcpy(&xv, &mine, sizeof(T));
+            x[(size_t)st_row * incx] = xv;
+        }
+        if(trace && lane == 0) // (diagnostics: AOCLSPARSE_MI355_TRSV_TRACE with schedule 5 -- 8 words per step)
+        {
+            unsigned long long *tr = trace + 8 * (size_t)s;
+            tr[0] = t_begin, tr[1] = t_first, tr[2] = t_ready, tr[3] = __builtin_amdgcn_s_memrealtime();
+            tr[4] = t_ext, tr[5] = t_elim, tr[6] = (unsigned long long)ch, tr[7] = (unsigned long long)(s - s0);
+            if(dbg & 8) // (diagnostics: the shader clock next to the 100 MHz one -> the clock the CU really runs at)
+                tr[4] = __builtin_amdgcn_s_memtime(), tr[5] = c_begin;
+        }
+    }
+    if(__builtin_amdgcn_ballot_w64(dead) != 0 && lane == 0)
+        __hip_atomic_store(timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // scratch: nrhs ticket words followed by one timeout word (zeroed here for the sync-free schedule)
 template <typename T>
 aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, aoclsparse_int m,
@@ -1270,6 +1649,8 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
     if(kt_bits != 0 && kt_bits != 256 && kt_bits != 512)
         return aoclsparse_status_internal_error;
     // (the block plan serves the KT orders through trsv_block_kt_kernel; without it: per-level launches or lane per position)
+    if(kt_bits != 0 && schedule == 5)
+        schedule = 4; // (the two-level kernel serves the reference chain only)
     if(kt_bits != 0 && schedule != 0 && !(schedule == 4 && plan.blk.valid))
         schedule = 2;
     // the level-ordered row layout, or -- when only the block plan was built (TrsvPlan::rows_valid == false) -- the block
@@ -1285,6 +1666,10 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
     if(schedule == 1 && (nrhs != 1 || incb != 1 || incx != 1))
         schedule = 2; // the single-workgroup runs of the hybrid schedule are single-RHS, unit stride
     // (several right-hand sides: the column is grid dimension x, the slice y <= 65,535; index arithmetic in int)
+    if(schedule == 5
+       && (!plan.blk.valid || !plan.blk.chunk.valid || kt_bits != 0
+           || (nrhs > 1 && (plan.blk.chunk.nchunks > 65535 || (long long)m * nrhs + TRSV_XP_PAD >= (1LL << 31)))))
+        schedule = 4;
     if(schedule == 4
        && (!plan.blk.valid || (nrhs > 1 && (plan.blk.nslices > 65535 || (long long)m * nrhs + TRSV_XP_PAD >= (1LL << 31)))))
         schedule = 3;
@@ -1432,6 +1817,69 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
             fprintf(stderr, "[trsv trace] blocks %d slices %d levels %d max_rows %d max_ext %d\n", (int)bp.nblocks, (int)bp.nslices,
                     (int)bp.nlevels, bp.max_rows, bp.max_ext);
             (void)hipFree(trace);
+        }
+        if(lst != aoclsparse_status_success)
+            return lst;
+    }
+    else if(schedule == 5)
+    {
+        // two levels: a workgroup per chunk of consecutive blocks, hand-offs inside a chunk through LDS (trsv_chunk_kernel)
+        const TrsvBlockPlan &bp = plan.blk;
+        const TrsvChunkPlan &cp = bp.chunk;
+        const long long      total = (long long)m * nrhs;
+        MI355_HIP_TRY(hipMemsetAsync(scratch, 0, ((size_t)nrhs + 1) * sizeof(unsigned int), s));
+        hipLaunchKernelGGL((trsv_fill_tag_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xp, total);
+        const size_t lds = 16 + sizeof(typename tag<T>::bits) * ((size_t)cp.max_rows + 1 + 64);
+        if(lds > 156 * 1024)
+            return aoclsparse_status_internal_error; // (the plan caps a chunk's rows)
+        // diagnostic: AOCLSPARSE_MI355_TRSV_TRACE=<file> dumps, per step, the 100 MHz clock when its wavefront took it, when its first
+        // look at the dependencies had landed, when all of them were in, at the end; then per step its chunk and block level
+        // (tools/trsv_chunk_trace.py)
+        static const int    dbg5        = getenv("AOCLSPARSE_MI355_TRSV_DBG") ? atoi(getenv("AOCLSPARSE_MI355_TRSV_DBG")) : 0;
+        static const char  *trace_path5 = getenv("AOCLSPARSE_MI355_TRSV_TRACE");
+        unsigned long long *trace5      = nullptr;
+        if(trace_path5 && nrhs == 1 && hipMalloc(&trace5, sizeof(unsigned long long) * 8 * (size_t)cp.nsteps) != hipSuccess)
+            trace5 = nullptr;
+        auto go_unit = [&](auto ext_tag, auto bs_tag, auto unit_tag) {
+            constexpr int  EXT = decltype(ext_tag)::value, BS = decltype(bs_tag)::value;
+            constexpr bool UNIT = decltype(unit_tag)::value;
+            static const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void *>(&trsv_chunk_kernel<T, EXT, BS, UNIT>),
+                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+            if(raised != hipSuccess)
+                return aoclsparse_status_internal_error;
+            const dim3 grid = nrhs > 1 ? dim3((unsigned)nrhs, (unsigned)cp.nchunks) : dim3((unsigned)cp.nchunks);
+            hipLaunchKernelGGL((trsv_chunk_kernel<T, EXT, BS, UNIT>), grid, dim3(64 * TRSV_CHUNK_WAVES), lds, s, m,
+                               std::max<aoclsparse_int>(plan.nnz_tri, 1), cp.nchunks,
+                               reinterpret_cast<const int4 *>(cp.steps.as<aoclsparse_int>()), cp.cptr.as<aoclsparse_int>(),
+                               bp.rowmap.as<aoclsparse_int>(), bp.pptr.as<aoclsparse_int>(), bp.pval.as<T>(),
+                               cp.eptr.as<aoclsparse_int>(), cp.cind.as<aoclsparse_int>(), cp.hind.as<aoclsparse_int>(), diag, b, xp, x,
+                               alpha, scratch, timeout_word ? timeout_word : scratch + nrhs, (int)incb, (int)incx, (int)nrhs, b_off,
+                               x_off, trace5, dbg5);
+            return aoclsparse_status_success;
+        };
+        auto go = [&](auto ext_tag, auto bs_tag) {
+            return unit ? go_unit(ext_tag, bs_tag, std::true_type{}) : go_unit(ext_tag, bs_tag, std::false_type{});
+        };
+        using std::integral_constant;
+        const bool              small_ext = bp.max_ext <= 16, small_bs = bp.max_rows <= 5;
+        const aoclsparse_status lst
+            = small_ext && small_bs ? go(integral_constant<int, 16>{}, integral_constant<int, 5>{})
+              : small_ext           ? go(integral_constant<int, 16>{}, integral_constant<int, TRSV_CHUNK_LANES>{})
+              : small_bs            ? go(integral_constant<int, TRSV_BLK_EXT>{}, integral_constant<int, 5>{})
+                                    : go(integral_constant<int, TRSV_BLK_EXT>{}, integral_constant<int, TRSV_CHUNK_LANES>{});
+        if(trace5)
+        {
+            std::vector<unsigned long long> host(8 * (size_t)cp.nsteps);
+            if(hipStreamSynchronize(s) == hipSuccess
+               && hipMemcpy(host.data(), trace5, sizeof(unsigned long long) * host.size(), hipMemcpyDeviceToHost) == hipSuccess)
+                if(FILE *f = fopen(trace_path5, "wb"))
+                {
+                    fwrite(host.data(), sizeof(unsigned long long), host.size(), f);
+                    fclose(f);
+                }
+            fprintf(stderr, "[trsv chunk trace] chunks %d steps %d lds slots %d model %.1f us (block schedule %.1f us)\n", (int)cp.nchunks,
+                    (int)cp.nsteps, (int)cp.max_rows, cp.model_us, cp.model_block_us);
+            (void)hipFree(trace5);
         }
         if(lst != aoclsparse_status_success)
             return lst;

@@ -44,14 +44,19 @@ DLL_PUBLIC aoclsparse_status aoclsparse_mi355_set_pointer_mode(aoclsparse_mi355_
  *                csrmm) walk the matrix in alternating directions, so the end of one sweep -- what the 256 MB Infinity Cache still
  *                holds -- is where the next one starts; 0: always ascending.  Same bits either way (a row's chain does not depend
  *                on when the row is visited); a measurement of HBM throughput sets 0 or flushes the cache between products.
- *                Read at every product. */
+ *                Read at every product.
+ *   trsv_chunks  -1 (default): the two-level TRSV schedule (chunks of consecutive blocks, hand-offs inside a chunk through LDS;
+ *                schedule 5) is built when the plan-time model of the triangle's DAG predicts a gain over the lane-per-block
+ *                schedule (deep, narrow DAGs: a mesh numbered line by line); 0 never; 1 whenever the triangle has the shape the
+ *                kernel serves.  Read when a TRSV plan is built.  Same bits on every schedule. */
 typedef enum aoclsparse_mi355_option_
 {
     aoclsparse_mi355_option_spmv_kernel = 0,
     aoclsparse_mi355_option_sell        = 1,
     aoclsparse_mi355_option_spmv_strict = 2,
     aoclsparse_mi355_option_alternate_sweeps = 3,
-    aoclsparse_mi355_option_count       = 4
+    aoclsparse_mi355_option_trsv_chunks = 4,
+    aoclsparse_mi355_option_count       = 5
 } aoclsparse_mi355_option;
 DLL_PUBLIC aoclsparse_status aoclsparse_mi355_set_option(aoclsparse_mi355_option option, aoclsparse_int value);
 /* aoclsparse_?csrmm with beta == 0.  Default (0): C is read and multiplied by zero, exactly as every kernel of the reference
@@ -226,6 +231,19 @@ DLL_PUBLIC aoclsparse_status aoclsparse_mi355_get_trsv_levels(const aoclsparse_m
                                                               aoclsparse_fill_mode    fill,
                                                               aoclsparse_operation    op,
                                                               aoclsparse_int         *levels);
+/* the TRSV plan of (fill, op) in numbers (zeros before analysis): what the automatic schedule will run and why */
+typedef struct aoclsparse_mi355_trsv_info_
+{
+    aoclsparse_int levels; /* dependency levels of the rows */
+    aoclsparse_int blocks, block_levels; /* blocks of chained rows (0: no block plan) and their dependency levels */
+    aoclsparse_int chunks, steps, lds_slots; /* two-level schedule (0: not built): chunks of consecutive blocks, steps, LDS words of the largest chunk */
+    aoclsparse_int model_chunk_us, model_block_us; /* plan-time estimates of the two-level / the lane-per-block schedule */
+    aoclsparse_int schedule; /* the schedule a solve with the reference chain runs now (set_trsv_schedule included) */
+} aoclsparse_mi355_trsv_info;
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_get_trsv_info(const aoclsparse_matrix     A,
+                                                            aoclsparse_fill_mode        fill,
+                                                            aoclsparse_operation        op,
+                                                            aoclsparse_mi355_trsv_info *info);
 /* Asynchronous (device-pointer) aoclsparse_?trsv / ?trsm calls return before the solve has run.  Should one of the
  * sync-free kernels ever give up a wait (5 s of wall time: a lost dependency, never seen in testing), it leaves x untouched
  * and sets a word owned by the handle.  Call this AFTER synchronising your stream: internal_error if a solve of THIS handle

@@ -123,13 +123,16 @@ def test_shell_like_ilu0_trsv_full_size():
     st, xr = oracle.dtrsv("l", 1.0, m, 0, lu, ci, rp, o["idiag"], b, True)
     assert st == 0
     bd = dev(b)
-    for sched in (-1, 0, 1, 2, 3, 4):  # the automatic choice, then every schedule (the kid selects the ARITHMETIC: round 3)
+    for sched in (-1, 0, 1, 2, 3, 4, 5):  # the automatic choice, then every schedule (the kid selects the ARITHMETIC: round 3)
         with trsv_schedule(P, sched):
             xd = torch.full((m,), np.nan, dtype=torch.float64, device="cuda")
             assert P.dtrsv(P.OP_NONE, 1.0, A, dl, bd, xd) == 0
             torch.cuda.synchronize()
             x = xd.cpu().numpy()
             assert np.array_equal(x, xr), "schedule %d differs from the serial chain" % sched
+            if sched in (-1, 5):  # round 6: the two-level schedule is what the plan-time model picks for this factor
+                info = A.trsv_info(P.FILL_LOWER)
+                assert info.schedule == 5 and info.chunks > 50 and info.model_chunk_us < info.model_block_us, (info.schedule, info.chunks)
     # kid 3 = the arithmetic of kt_trsv_l with 512-bit vectors (what an AVX-512 host runs): bit-identical to its restatement
     st, xk = oracle.trsv_kt("l", 8, 1.0, m, 0, lu, ci, rp, o["idiag"], b, True)
     xd = torch.full((m,), np.nan, dtype=torch.float64, device="cuda")

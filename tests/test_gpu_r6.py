@@ -113,3 +113,150 @@ def test_merge_path_float_and_base_one_through_the_arrival_counters():
     scale = np.add.reduceat(np.concatenate([np.abs(v.astype(np.float64) * x[ci0]), [0.0]]), np.minimum(rp0[:-1], len(v))) * (np.diff(rp0) > 0)
     eps32 = 2.0 ** -23
     assert np.all(np.abs(outs[0] - exact) <= (np.diff(rp0) + 24) * eps32 * (1.5 * scale + np.abs(y0)) + 1e-30)
+
+
+# --------------------------------------------------------------------------------------------------
+# the two-level TRSV schedule (schedule 5: chunks of consecutive blocks, hand-offs inside a chunk through LDS)
+# --------------------------------------------------------------------------------------------------
+from test_gpu_trsv_blocks import VARIANTS, fixed, mixed, node_mesh  # noqa: E402
+from util import trsv_schedule  # noqa: E402
+
+
+@pytest.fixture
+def forced_chunks():
+    """aoclsparse_mi355_set_option(trsv_chunks, 1): build the chunk plan whatever the plan-time model says (the meshes here are small)"""
+    assert L.aoclsparse_mi355_set_option(P.OPTION_TRSV_CHUNKS, 1) == 0
+    yield
+    assert L.aoclsparse_mi355_set_option(P.OPTION_TRSV_CHUNKS, -1) == 0
+
+
+@pytest.mark.parametrize("name,dofs,width,far", [("five", fixed(5), 37, 0), ("two", fixed(2), 50, 0), ("eight", fixed(8), 29, 0),
+                                                 ("three+long", fixed(3), 41, 30), ("mixed", mixed, 33, 0),
+                                                 ("mixed+long", mixed, 64, 28)])
+def test_two_level_trsv_bit_exact_every_triangle(forced_chunks, name, dofs, width, far):
+    """L, L^T, U^T (U keeps the lane-per-block schedule: its rows start with the rows of their own block), unit and non-unit, blocks
+    of 1-8 rows, single rows with more dependencies than a step polls in one batch, several chunks with halos: x must be the
+    serial chain of ref_trsv_* bit for bit (trsv_kr.hpp:57-75), and the schedule that ran must be the two-level one."""
+    nodes = 12000
+    m, rp, ci, v = node_mesh(900 + len(name), nodes, width, dofs(np.random.default_rng(1), nodes), far=far)
+    o = oracle.dcsr_optimize(m, m, len(v), 0, rp, ci, v)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    rng = np.random.default_rng(11)
+    ran = 0
+    for kind, fill, op in VARIANTS:
+        for unit in (True, False):
+            d = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=getattr(P, fill), diag=P.DIAG_UNIT if unit else P.DIAG_NON_UNIT)
+            b = rng.uniform(-1, 1, m)
+            st, xr = oracle.dtrsv(kind, 0.75, m, 0, o["val"], o["ind"], o["ptr"], o["idiag"] if kind[0] == "l" else o["iurow"], b, unit)
+            assert st == 0
+            with trsv_schedule(P, 5):
+                xd = torch.full((m,), 7.0, dtype=torch.float64, device="cuda")
+                assert P.dtrsv(getattr(P, op), 0.75, A, d, dev(b), xd) == 0
+                torch.cuda.synchronize()
+                info = A.trsv_info(getattr(P, fill), getattr(P, op))
+            got = xd.cpu().numpy()
+            assert np.array_equal(got, xr), (name, kind, unit, int((got != xr).sum()))
+            if kind != "u":
+                assert info.schedule == 5 and info.chunks >= 2 and info.steps > info.chunks, (name, kind, info.schedule, info.chunks)
+                ran += 1
+            else:
+                assert info.schedule == 4 and info.chunks == 0
+    assert ran == 6
+
+
+def test_two_level_trsv_float_strided_and_trsm(forced_chunks):
+    """float values (4-byte tagged words), strided b / x, and several right-hand sides (one grid column per right-hand side, own
+    ticket and solution slab) on the two-level schedule"""
+    nodes = 9000
+    m, rp, ci, v = node_mesh(77, nodes, 45, mixed(np.random.default_rng(3), nodes), far=5)
+    o = oracle.dcsr_optimize(m, m, len(v), 0, rp, ci, v)
+    # float
+    vf = v.astype(np.float32)
+    Af = P.Matrix(0, m, m, rp, ci, vf)
+    bf = np.random.default_rng(6).uniform(-1, 1, m).astype(np.float32)
+    for unit in (True, False):
+        d = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=P.FILL_LOWER, diag=P.DIAG_UNIT if unit else P.DIAG_NON_UNIT)
+        xo = np.zeros(m, np.float32)
+        assert oracle.lib().orc_strsv_l(ctypes.c_float(1.0), m, 0, P._ptr(vf), P._ptr(ci), P._ptr(rp), P._ptr(o["idiag"]), P._ptr(bf), 1,
+                                        P._ptr(xo), 1, 1 if unit else 0) == 0
+        with trsv_schedule(P, 5):
+            xd = torch.zeros(m, dtype=torch.float32, device="cuda")
+            assert P.strsv(P.OP_NONE, 1.0, Af, d, dev(bf), xd) == 0
+            torch.cuda.synchronize()
+            assert Af.trsv_info(P.FILL_LOWER).schedule == 5
+        assert np.array_equal(xd.cpu().numpy(), xo), unit
+    # strided, double
+    A = P.Matrix(0, m, m, rp, ci, v)
+    d = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=P.FILL_LOWER)
+    incb, incx = 3, 2
+    b = np.random.default_rng(9).uniform(-1, 1, m * incb)
+    st, xr = oracle.dtrsv("l", 1.5, m, 0, o["val"], o["ind"], o["ptr"], o["idiag"], b[::incb].copy(), False)
+    with trsv_schedule(P, 5):
+        xs = torch.full((m * incx,), 7.0, dtype=torch.float64, device="cuda")
+        assert P.dtrsv(P.OP_NONE, 1.5, A, d, dev(b), xs, incb=incb, incx=incx) == 0
+        torch.cuda.synchronize()
+    got = xs.cpu().numpy()
+    assert np.array_equal(got[::incx], xr) and np.all(got[1::incx] == 7.0)
+    # several right-hand sides, both layouts
+    n = 5
+    rng = np.random.default_rng(12)
+    for kind, fill, op, unit in (("l", P.FILL_LOWER, P.OP_NONE, True), ("lt", P.FILL_LOWER, P.OP_TRANSPOSE, False),
+                                 ("ut", P.FILL_UPPER, P.OP_TRANSPOSE, True)):
+        dd = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=fill, diag=P.DIAG_UNIT if unit else P.DIAG_NON_UNIT)
+        iend = o["idiag"] if kind[0] == "l" else o["iurow"]
+        for lay, shape, col in ((P.ORDER_COLUMN, (n, m + 3), lambda M, j: M[j, :m]), (P.ORDER_ROW, (m, n + 2), lambda M, j: M[:, j])):
+            Bm = rng.uniform(-1, 1, shape)
+            Xd = dev(np.full(shape, 7.0))
+            with trsv_schedule(P, 5):
+                assert L.aoclsparse_dtrsm(op, 0.5, A.h, dd.h, lay, P._ptr(dev(Bm)), n, shape[1], P._ptr(Xd), shape[1]) == 0
+                torch.cuda.synchronize()
+            X = Xd.cpu().numpy()
+            for j in range(n):
+                st, xr = oracle.dtrsv(kind, 0.5, m, 0, o["val"], o["ind"], o["ptr"], iend, np.ascontiguousarray(col(Bm, j)), unit)
+                assert st == 0 and np.array_equal(col(X, j), xr), (kind, lay, j)
+
+
+def test_two_level_trsv_nan_inf_and_tag_propagate(forced_chunks):
+    """NaN, +-Inf and the exact NOT-READY bit pattern in b on the two-level schedule: the same propagation as the serial chain"""
+    nodes = 8000
+    m, rp, ci, v = node_mesh(33, nodes, 40, mixed(np.random.default_rng(2), nodes))
+    o = oracle.dcsr_optimize(m, m, len(v), 0, rp, ci, v)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    tag = np.array([0x7FF8DEADBEEF0355], dtype=np.uint64).view(np.float64)[0]
+    d = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=P.FILL_LOWER)
+    b = np.random.default_rng(8).uniform(-1, 1, m)
+    b[[0, 40, m // 2]] = [np.nan, np.inf, tag]
+    st, xr = oracle.dtrsv("l", 1.0, m, 0, o["val"], o["ind"], o["ptr"], o["idiag"], b, False)
+    with trsv_schedule(P, 5):
+        xd = torch.zeros(m, dtype=torch.float64, device="cuda")
+        assert P.dtrsv(P.OP_NONE, 1.0, A, d, dev(b), xd) == 0
+        torch.cuda.synchronize()
+        assert A.trsv_info(P.FILL_LOWER).schedule == 5
+    got = xd.cpu().numpy()
+    gn, rn = np.isnan(got), np.isnan(xr)
+    assert np.array_equal(gn, rn) and np.array_equal(got[~gn], xr[~rn]) and 2 <= rn.sum() < m
+
+
+def test_two_level_trsv_is_chosen_by_the_model_where_the_dag_is_deep_and_narrow():
+    """The plan-time model of the triangle's DAG selects the schedule: the shell-like ILU(0) factor (a mesh numbered line by
+    line: 1,101 block levels of <= 500 blocks) gets the two-level schedule, its unstructured variant (nodes renumbered at random
+    inside windows: a shallow, wide DAG whose chunks would run one after the other) keeps the lane-per-block one.  Both at a
+    tenth of the full size here; the full size is test_shell_like_ilu0_trsv_full_size."""
+    sys_path = __import__("sys").path
+    import os
+    sys_path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import standins
+    for variant, want in (("shell", 5), ("unstructured", 4)):
+        m, rp, ci, v = standins.shell_like(n=150000) if variant == "shell" else standins.shell_like_unstructured(n=150000)
+        st, lu, dg = oracle.dilu0(m, 0, rp, ci, v)
+        o = oracle.dcsr_optimize(m, m, len(lu), 0, rp, ci, lu)
+        A = P.Matrix(0, m, m, rp, ci, lu)
+        d = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=P.FILL_LOWER, diag=P.DIAG_UNIT)
+        b = np.random.default_rng(2).uniform(-1, 1, m)
+        st, xr = oracle.dtrsv("l", 1.0, m, 0, lu, ci, rp, o["idiag"], b, True)
+        xd = torch.zeros(m, dtype=torch.float64, device="cuda")
+        assert P.dtrsv(P.OP_NONE, 1.0, A, d, dev(b), xd) == 0
+        torch.cuda.synchronize()
+        info = A.trsv_info(P.FILL_LOWER)
+        assert info.schedule == want, (variant, info.schedule, info.model_chunk_us, info.model_block_us)
+        assert np.array_equal(xd.cpu().numpy(), xr), variant
