@@ -50,6 +50,17 @@ def communicator_info(dist, torch):
     return info
 
 
+def gather_scalars(value, dist, torch, device, rank, world):
+    """one python float per rank -> the list of all of them on every rank (an all-reduce of a one-hot vector)"""
+    if dist is None or not dist.is_initialized() or world == 1:
+        return [float(value)]
+    wire = "cpu" if _backend(dist) == "gloo" else device
+    t = torch.zeros(world, dtype=torch.float64, device=wire)
+    t[rank] = float(value)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t.cpu().tolist()]
+
+
 def broadcast_text(dist, torch, device, rank, text):
     """a short string from rank 0 to every rank (descriptions that only rank 0 can compose)"""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
@@ -376,11 +387,14 @@ def bench_sharded_csrmm(pkg, torch, dist, device, rank, world, csr, ncols, layou
         st_shard["n"] = 0
     tg_dev = reduce_scalar(st_shard["median"], "max", dist, device)
     tg_wall = reduce_scalar(wall_ms, "max", dist, device)
+    # every rank's own slab time (multi-GPU reporting: the spread shows a slow GPU or an uneven split)
+    per_rank = gather_scalars(st_shard["median"], dist, torch, device, rank, world)
     checksum = reduce_scalar(float(C[: sh.nloc * m].sum().item()) if sh.nloc else 0.0, "sum", dist, device)
     out = {
         "layout": "column-major" if layout == "col" else "row-major", "ncols": ncols, "world": world,
         "cols_per_rank": sh.nloc, "m": m, "nnz": nnz, "c_is_read": bool(c_is_read),
-        "shard_ms": st_shard, "tg_ms_device_median_max_over_ranks": round(tg_dev, 5),
+        "shard_ms": st_shard, "slab_ms_per_rank": [round(v, 5) for v in per_rank],
+        "tg_ms_device_median_max_over_ranks": round(tg_dev, 5),
         "tg_ms_wall_max_over_ranks": round(tg_wall, 5),
         "a_broadcast_ms": round(reduce_scalar(sh.a_broadcast_ms, "max", dist, device), 3), "a_broadcast_how": sh.a_broadcast_how,
         "setup_optimize_ms_rank0": round(reduce_scalar(sh.optimize_ms, "max", dist, device), 3),

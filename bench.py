@@ -348,9 +348,13 @@ def leg_numbers(full):
     if tr.get("schedules"):
         n["trsv_ms"] = tr["schedules"][0]["ms"]
         n["trsv_parity"] = all(s["bit_exact_vs_cpu"] for s in tr["schedules"])
+        if tr.get("plan"):
+            n["trsv_schedule"] = tr["plan"]["automatic_schedule"]
+            n["trsv_us_per_block_level"] = round(tr["schedules"][0]["ms"] * 1e3 / max(tr["plan"]["block_levels"], 1), 4)
         if "unstructured_variant" in tr and tr["unstructured_variant"].get("schedules"):
             n["trsv_unstructured_ms"] = tr["unstructured_variant"]["schedules"][0]["ms"]
             n["trsv_unstructured_us_per_level"] = tr["unstructured_variant"]["schedules"][0].get("us_per_level")
+            n["trsv_unstructured_schedule"] = (tr["unstructured_variant"].get("plan") or {}).get("automatic_schedule")
     sp2 = legs.get("sp2m") or {}
     if sp2.get("cases"):
         n["sp2m_ms"] = sp2["cases"][0]["ms"]
@@ -361,6 +365,7 @@ def leg_numbers(full):
         if "tg_ms_device_median_max_over_ranks" in sh:
             n["csrmm_sharded_" + lay] = {"world": sh["world"], "cols_per_rank": sh["cols_per_rank"],
                                          "tg_ms": sh["tg_ms_device_median_max_over_ranks"], "t1_ms": sh.get("t1_ms"),
+                                         "slab_ms_per_rank": sh.get("slab_ms_per_rank"),
                                          "efficiency": sh.get("efficiency"), "a_broadcast_ms": sh.get("a_broadcast_ms"),
                                          "c_allgather_ms": sh.get("c_allgather_ms"),
                                          "parity": (sh.get("parity") or {}).get("bit_exact")}
@@ -593,6 +598,13 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
     D = dist if use_dist else None
+    if use_dist:
+        # the first real multi-GPU run checks itself: the communicator every collective below uses spans exactly --gpus ranks, and
+        # (RCCL) says which version it is
+        cinfo = {"backend": dist.get_backend(), "world": dist.get_world_size()}
+        assert cinfo["world"] == args.gpus == world, "communicator spans %d ranks, --gpus %d" % (cinfo["world"], args.gpus)
+        if cinfo["backend"] == "nccl":
+            assert torch.cuda.nccl.version(), "RCCL reports no version"
 
     pkg = entry.load_package()
     import aocl_sparse_amd.sharded as sharded
@@ -1023,7 +1035,7 @@ def main():
         # the headline product COLD: 1 GB of other data is READ between any two timed products, so that nothing of the matrix is
         # left in the 256 MB Infinity Cache from the call before (back-to-back products keep part of their working set there;
         # profiles/r5/sell_placement.txt).  One product per event pair.  (A 1 GB FILL as the flush leaves dirty lines whose
-        # write-back runs into the product: 0.211 instead of 0.173 ms, tools/exp_cold.py.)  Never the headline value.
+        # write-back runs into the product: 0.211 instead of 0.173 ms, tools/history/exp_cold.py.)  Never the headline value.
         try:
             flush = torch.ones(1 << 28, dtype=torch.float32, device=device)
             tc = []
@@ -1389,6 +1401,12 @@ def main():
                            "levels), descr {triangular, lower, unit}, alpha=1, b = L*1" % (title, mt, nnz_l, lv),
                "schedules": [], "cpu_serial_ms": round(t_cpu * 1e3, 3), "analysis_s": round(t_opt, 2),
                "ilu0_input_preparation_s": round(t_ilu, 2)}
+        ti = At.trsv_info(pkg.FILL_LOWER)
+        # what the plan holds and which schedule its model picked (5 = two levels: chunks of consecutive blocks, hand-offs through
+        # LDS inside a chunk; 4 = a lane per block of chained rows, every hand-off through L2 / HBM)
+        res["plan"] = {"row_levels": ti.levels, "blocks": ti.blocks, "block_levels": ti.block_levels, "chunks": ti.chunks, "steps": ti.steps,
+                       "lds_words_largest_chunk": ti.lds_slots, "model_two_level_us": ti.model_chunk_us,
+                       "model_lane_per_block_us": ti.model_block_us, "automatic_schedule": ti.schedule}
         # the kid selects the ARITHMETIC (as in the reference, trsv.cpp:321-353): auto / 0 = ref_trsv_l's chain on the fastest
         # schedule; 3 = the order of the 512-bit KT kernel an AVX-512 host dispatches, 1 = the 256-bit one (both served by the
         # lane-per-position sync-free kernel), each checked bit for bit against the oracle's restatement of THAT kernel

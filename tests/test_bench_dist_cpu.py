@@ -394,3 +394,170 @@ def test_library_communicator_control_flow_with_mocks():
         assert sharded.library_communicator(FakePkg(lib), torch, dist, "cpu", 1, 2) is False
         assert lib.calls == ["unique_id"] and sharded._LIB_COMM == {"tried": True, "ok": False}
     sharded._LIB_COMM.update(tried=False, ok=False)
+
+
+def test_sharded_csrmm_world8_column_ranges_and_state_bytes_with_mocks():
+    """Round 6, multi-GPU readiness without hardware.  (a) ShardedCsrmm on a mock world of 8: the eight column ranges for n = 256
+    and for the ragged n = 250 are the reference's thread split (level3/aoclsparse_csrmm_kt.cpp:68-82: start = n t / T rounded up
+    to a multiple of 4 and capped at n), they tile [0, n) and every rank multiplies exactly its own slab.  (b) the
+    torch.distributed wire of broadcast_handle: what rank 0 exports with aoclsparse_mi355_mm_state_export reaches
+    aoclsparse_mi355_mm_state_adopt on each of the 7 other ranks byte for byte (header scalars and every buffer)."""
+    import ctypes
+    import numpy as np
+    import torch
+
+    pkg = entry.load_package()
+    import aocl_sparse_amd.sharded as sharded
+
+    def reference_split(n, t, T, bblk=4):  # csrmm_kt.cpp:71-76, restated here (not through the library's or bench.py's rule)
+        start = n * t // T
+        start = start if start % bblk == 0 else start + bblk - start % bblk
+        start = min(start, n)
+        end = n * (t + 1) // T
+        end = end if end % bblk == 0 else end + bblk - end % bblk
+        return start, min(end, n)
+
+    class FakeLibA:
+        def aoclsparse_set_mm_hint(self, *a):
+            return 0
+
+        def aoclsparse_optimize(self, *a):
+            return 0
+
+    class FakeMatrixA:
+        status, m, n, nnz, h = 0, 1000, 1000, 4996, 1
+
+        def __init__(self, *a):
+            pass
+
+    calls = []
+
+    class FakePkgA:
+        STATUS, OP_NONE, ORDER_COLUMN, ORDER_ROW = pkg.STATUS, pkg.OP_NONE, pkg.ORDER_COLUMN, pkg.ORDER_ROW
+        Matrix = FakeMatrixA
+        column_shard = staticmethod(pkg.column_shard)
+
+        class Descr:
+            h = 2
+
+        def lib(self):
+            return FakeLibA()
+
+        def dcsrmm(self, op, alpha, A, descr, order, B, n, ldb, beta, C, ldc):
+            calls.append((n, ldb, ldc, order))
+            return 0
+
+    real_bh = sharded.broadcast_handle
+    sharded.broadcast_handle = lambda pkg_, torch_, dist_, device_, rank_, world_, A_: (FakeMatrixA(), 0.0, "mock")
+    try:
+        for ncols in (256, 250):
+            cover = []
+            for rank in range(8):
+                sh = sharded.ShardedCsrmm(FakePkgA(), torch, None, "cpu", rank, 8, (1000, 1000, None, None, None), ncols, "row")
+                assert (sh.j0, sh.j1) == reference_split(ncols, rank, 8), (ncols, rank, sh.j0, sh.j1)
+                cover += list(range(sh.j0, sh.j1))
+                calls.clear()
+                assert sh.run(None, None) == 0
+                assert calls == ([(sh.nloc, sh.nloc, sh.nloc, pkg.ORDER_ROW)] if sh.nloc else [])
+            assert cover == list(range(ncols))
+        assert [reference_split(250, t, 8) for t in range(8)] == [(0, 32), (32, 64), (64, 96), (96, 128), (128, 156), (156, 188),
+                                                                  (188, 220), (220, 250)]
+    finally:
+        sharded.broadcast_handle = real_bh
+
+    # (b) the state's bytes: rank 0 exports, ranks 1..7 adopt
+    rng = np.random.default_rng(5)
+    bufs = [np.frombuffer(rng.bytes(n), dtype=np.uint8).copy() if n else None
+            for n in (4004, 19984, 39968, 0, 512, 0, 0, 96, 0, 0, 0, 0)][: pkg.MM_STATE_BUFFERS]
+    scalars = [int(v) for v in rng.integers(0, 1 << 40, size=40)]
+    adopted = {}
+
+    class Wire:
+        """rank 0's broadcasts in order; every other rank replays them"""
+        sent = []
+
+    class FakeDistB:
+        class ReduceOp:
+            MAX, SUM, MIN = "max", "sum", "min"
+
+        def __init__(self, rank):
+            self.rank, self.k = rank, 0
+
+        def is_initialized(self):
+            return True
+
+        def get_backend(self):
+            return "gloo"
+
+        def get_world_size(self):
+            return 8
+
+        def barrier(self):
+            pass
+
+        def all_reduce(self, t, op=None):
+            pass
+
+        def broadcast(self, t, src):
+            if self.rank == 0:
+                Wire.sent.append(t.clone())
+            else:
+                t.copy_(Wire.sent[self.k])
+            self.k += 1
+
+    class FakeMatrixB:
+        def __init__(self, rank):
+            self.rank = rank
+
+        def mm_state_export(self):
+            st = pkg.MmState()
+            for i in range(40):
+                st.scalars[i] = scalars[i]
+            for i in range(12):
+                st.bytes[i] = len(bufs[i]) if i < len(bufs) and bufs[i] is not None else 0
+            return 0, st, [b.ctypes.data if b is not None else None for b in bufs]
+
+        @classmethod
+        def mm_state_adopt(cls, state, ptrs, double=True):
+            got = [bytes((ctypes.c_ubyte * state.bytes[i]).from_address(p)) if p else None for i, p in enumerate(ptrs)]
+            adopted[cls.current] = (list(state.scalars), list(state.bytes), got)
+            return 0, FakeMatrixB(cls.current)
+
+    class FakePkgB:
+        CommId, MM_STATE_BUFFERS, STATUS, MmState = pkg.CommId, pkg.MM_STATE_BUFFERS, pkg.STATUS, pkg.MmState
+        Matrix = FakeMatrixB
+
+        def lib(self):
+            return None
+
+    real_as_tensor = torch.as_tensor
+
+    def as_tensor(obj, *a, **k):  # (the zero-copy device view of the library's buffer: here the bytes live in host memory)
+        if isinstance(obj, sharded._DeviceView):
+            ptr, nbytes = obj.__cuda_array_interface__["data"][0], obj.__cuda_array_interface__["shape"][0]
+            return torch.frombuffer(bytearray((ctypes.c_ubyte * nbytes).from_address(ptr)), dtype=torch.uint8)
+        return real_as_tensor(obj, *a, **k)
+
+    torch.as_tensor = as_tensor
+    sharded._LIB_COMM.update(tried=False, ok=False)
+    try:
+        for rank in range(8):
+            FakeMatrixB.current = rank
+            out, ms, how = sharded.broadcast_handle(FakePkgB(), torch, FakeDistB(rank), "cpu", rank, 8, FakeMatrixB(0) if rank == 0 else None)
+            assert "torch.distributed (gloo)" in how and isinstance(out, FakeMatrixB)
+    finally:
+        torch.as_tensor = real_as_tensor
+        sharded._LIB_COMM.update(tried=False, ok=False)
+    assert sorted(adopted) == list(range(1, 8))
+    want = [bytes(b) if b is not None else None for b in bufs]
+    for rank in range(1, 8):
+        sc, by, got = adopted[rank]
+        assert sc == scalars and by[: len(bufs)] == [len(b) if b is not None else 0 for b in bufs]
+        assert got == want, rank
+
+
+def test_gather_scalars_identity_and_shape():
+    import torch
+    pkg = entry.load_package()
+    import aocl_sparse_amd.sharded as sharded
+    assert sharded.gather_scalars(1.5, None, torch, "cpu", 0, 1) == [1.5]
