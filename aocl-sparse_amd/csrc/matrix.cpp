@@ -538,7 +538,9 @@ static aoclsparse_int choose_tile(aoclsparse_int /*m*/, aoclsparse_int nnz, size
     // (the XCD-contiguous block order -- bit 0 of the tile word, which the kernel still decodes -- measured slower than launch
     // order on the Laplacian and 6 % faster at most on the graph stand-ins: profiles/r3/irregular_locality_pmc.txt; the round 1-3
     // switches that forced a tile size or that order are gone, the losing sides are recorded under profiles/)
-    return (long long)nnz < 1024LL * 256 * 16 ? 512 : 1024;
+    // (diagnostics, counter passes of round 6: AOCLSPARSE_MI355_SPMV_XCD_ORDER=1 sets that bit; profiles/r6/csrmv_xcd_order_pmc.txt)
+    static const bool xcd_order = getenv("AOCLSPARSE_MI355_SPMV_XCD_ORDER") && getenv("AOCLSPARSE_MI355_SPMV_XCD_ORDER")[0] == '1';
+    return ((long long)nnz < 1024LL * 256 * 16 ? 512 : 1024) | (xcd_order ? 1 : 0);
 }
 
 // plan_rows on the row range [r0, r1): block entries are appended to `out` (no terminal entry)
