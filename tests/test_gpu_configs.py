@@ -243,7 +243,7 @@ def test_bench_one_rank_under_the_launcher_with_the_nccl_backend(tmp_path):
     for leg in ("csrmm_sharded_col", "csrmm_sharded_row", "csrmm_sharded_bell", "spmv_row_sharded", "sp2m_row_sharded"):
         assert "error" not in res[leg], (leg, res[leg])
         assert res[leg]["world"] == 1 and res[leg]["parity"]["bit_exact"] is True, (leg, res[leg])
-        assert short["legs"][leg]["parity"] is True
+        assert leg not in short["legs"]  # (round 6: the short record carries the sharded objects of runs with more than one rank only)
 
 
 def _check_two_rank_record(short, res, own_rows):
@@ -350,7 +350,7 @@ def test_bench_single_process_small_legs(tmp_path):
     n = short["legs"]
     assert "errors" not in n, n
     for k in ("l100_us", "csr_adaptive_frac", "mix_frac_mean", "mix_cold_frac_mean", "csrmm_row_ms", "csrmm_row_slab_ms", "csrmm_row_slab_frac",
-              "csrmm_row_frac", "csrmm_row_eff8_cold", "csrmm_col_ms", "csrmm_col_slab_ms", "csrmm_col_slab_frac", "csrmm_row_overwrite_slab_frac",
+              "csrmm_row_frac", "csrmm_row_eff8_cold", "trsv_us_per_block_level", "csrmm_col_ms", "csrmm_col_slab_ms", "csrmm_col_slab_frac", "csrmm_row_overwrite_slab_frac",
               "csrmm_col_overwrite_slab_frac", "trsv_ms"):
         assert n.get(k) is not None and n[k] > 0, (k, n)
     assert n["csrmm_parity"] and n["mix_parity"] and n["trsv_parity"]
