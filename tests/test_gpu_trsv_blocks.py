@@ -282,6 +282,7 @@ sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "t
 from test_gpu_trsv_blocks import node_mesh, P, VARIANTS
 nodes = 2000
 m, rp, ci, v = node_mesh(3, nodes, 40, np.full(nodes, 5))
+assert P.lib().aoclsparse_mi355_set_option(P.OPTION_TRSV_CHUNKS, 0) == 0  # (round 6: this test is about the lane-per-block schedule)
 A = P.Matrix(0, m, m, rp, ci, v)
 b = torch.ones(m, dtype=torch.float64, device="cuda"); x = torch.zeros_like(b)
 for kind, fill, op in VARIANTS:
