@@ -3,7 +3,7 @@
 without a SELL copy (aoclsparse_mi355_set_option(sell, 0)); ms per product between two events, 100 calls back to back."""
 import json, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (tools/history/ -> repository root)
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry
 pkg = entry.load_package(); L = pkg.lib()

@@ -4,7 +4,7 @@
 per process; the shipped library has no such switch.)"""
 import json, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (tools/history/ -> repository root)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import __graft_entry__ as entry, standins
 pkg = entry.load_package(); L = pkg.lib()

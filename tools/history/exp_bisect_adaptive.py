@@ -3,7 +3,7 @@
 library, loaded directly with ctypes (only the reference's own ABI is used, so old builds work): ms per product."""
 import ctypes, json, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (tools/history/ -> repository root)
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry
 so = sys.argv[1]

@@ -4,7 +4,7 @@ with op = T, ?trsv / ?trsm on a triangle, ?symgs -- on the g^2 Laplacian with de
 after 12), first call separately (it holds the one-time work: transposes, derived operators, analyses)."""
 import json, os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (tools/history/ -> repository root)
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry
 pkg = entry.load_package(); L = pkg.lib(); P = pkg

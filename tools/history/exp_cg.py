@@ -3,7 +3,7 @@
 ms per iteration next to the ms of the SpMV it contains (symmetric descriptor, lower triangle stored)."""
 import ctypes, json, os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (tools/history/ -> repository root)
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry
 pkg = entry.load_package(); L = pkg.lib(); P = pkg

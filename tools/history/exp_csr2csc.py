@@ -3,7 +3,7 @@
 1 M entries on -- next to the CPU port of the reference's counting sort (oracle, one thread); bit equality of the three arrays."""
 import json, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (tools/history/ -> repository root)
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry
 import oracle

@@ -4,7 +4,7 @@ the g^2 5-point Laplacian, next to the fp64 figures of the same process; ms per 
 Bytes: the CSR model of the bench ((m + 1 + nnz) * 4 + (m + n + nnz) * sizeof(T))."""
 import json, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (tools/history/ -> repository root)
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry
 pkg = entry.load_package(); L = pkg.lib()

@@ -3,7 +3,7 @@
 ~3 us of launch/event overhead included) and bit-exactness against the oracle.  Diagnostic; one JSON line per matrix."""
 import json, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (tools/history/ -> repository root)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import __graft_entry__ as entry, oracle, standins
 from bench import timed_laps

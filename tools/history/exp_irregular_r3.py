@@ -6,7 +6,7 @@
 Run under `rocprofv3 --pmc FETCH_SIZE` (tools/exp_irregular_r3.sh) for the fabric-side bytes per launch."""
 import json, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (tools/history/ -> repository root)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import __graft_entry__ as entry, oracle, standins
 pkg = entry.load_package(); L = pkg.lib()

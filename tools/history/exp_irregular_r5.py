@@ -4,7 +4,7 @@ back to back between two events) + the parity verdicts of bench.py's mix leg.  O
 round's experiment switches, if any) is echoed so that runs of different builds / switches can sit in one file."""
 import json, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (tools/history/ -> repository root)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import __graft_entry__ as entry, standins, oracle
 pkg = entry.load_package(); L = pkg.lib()

@@ -3,7 +3,7 @@
   exp_mm_lap.py [n] [row|col]      (KID=<0..3>: through aoclsparse_dcsrmm_kid)"""
 import json, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (tools/history/ -> repository root)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import __graft_entry__ as entry
 pkg = entry.load_package(); L = pkg.lib()

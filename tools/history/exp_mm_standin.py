@@ -2,7 +2,7 @@
 """One stand-in, csrmm with n columns, a few calls (for rocprofv3 passes).  usage: exp_mm_standin.py shell-like|flan-like [n] [row|col]"""
 import json, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (tools/history/ -> repository root)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import __graft_entry__ as entry, standins
 pkg = entry.load_package(); L = pkg.lib()

@@ -9,7 +9,7 @@ permuted vector, i.e. the scattered store of a real implementation is NOT in the
 usage: AOCLSPARSE_MI355_SELL=1 exp_r3_sellsigma.py short <name> [T=32] [sigma=4096];  exp_r3_sellsigma.py long <name> [T]"""
 import json, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (tools/history/ -> repository root)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import __graft_entry__ as entry, standins
 pkg = entry.load_package(); L = pkg.lib()

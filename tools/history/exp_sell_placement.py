@@ -3,7 +3,7 @@
 (i.e. where) its arrays were allocated?  (shell-like ran at 90 us in some bench runs and 102 us in others with the same binary.)"""
 import os, sys, json
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (tools/history/ -> repository root)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import __graft_entry__ as entry, standins
 pkg = entry.load_package(); L = pkg.lib()

@@ -4,7 +4,7 @@ to the products they prepare, on the headline Laplacian (grid^2) and the csrmm /
 prints the library's own phases."""
 import json, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (tools/history/ -> repository root)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import __graft_entry__ as entry
 pkg = entry.load_package(); L = pkg.lib()

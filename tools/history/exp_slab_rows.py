@@ -3,7 +3,7 @@
 (experiment knob AOCLSPARSE_MI355_EXP_MAXROWS): ms per product, C read and overwritten, next to the 256-column product."""
 import json, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (tools/history/ -> repository root)
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry
 pkg = entry.load_package(); L = pkg.lib(); P = pkg

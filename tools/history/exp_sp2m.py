@@ -3,7 +3,7 @@
 reference's two-stage Gustavson (oracle/, one thread) -- wall time per call, and bit equality of row_ptr / col_ind / val."""
 import ctypes, json, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (tools/history/ -> repository root)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import __graft_entry__ as entry
 import oracle, standins

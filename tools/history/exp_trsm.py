@@ -3,7 +3,7 @@
 lane-per-position kernel (AOCLSPARSE_MI355_TRSV_BLOCKS=0).  Diagnostic; one JSON line per (triangle, columns)."""
 import json, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (tools/history/ -> repository root)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import __graft_entry__ as entry, oracle, standins
 from bench import timed_laps

@@ -3,7 +3,7 @@
 (AOCLSPARSE_MI355_TRSV_TRACE=<file> makes the library print the plan's block / slice / level counts)."""
 import json, os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (tools/history/ -> repository root)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import __graft_entry__ as entry, standins, oracle
 pkg = entry.load_package(); L = pkg.lib()

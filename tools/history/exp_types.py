@@ -3,7 +3,7 @@
 operands, ms per call (events, 30 calls after 12) and the fraction of 8 TB/s on CSR-model bytes."""
 import ctypes, json, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (tools/history/ -> repository root)
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry
 pkg = entry.load_package(); L = pkg.lib(); P = pkg

@@ -4,7 +4,7 @@
   (row-per-wave C-first kernel), SELL short-row kernel, KT-order TRSV on meshes.   fuzz_r3.py [iterations=40] [seed=1]"""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (tools/history/ -> repository root)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle
 from util import pkg, random_csr, kt_lanes

@@ -8,7 +8,7 @@ one-stage and two-stage requests.  row_ptr, col_ind and val must be bit-identica
   python3 tools/fuzz_sp2m.py [cases=300] [seed=1] [--heavy]"""
 import ctypes, json, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (tools/history/ -> repository root)
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry
 import oracle
