@@ -434,11 +434,10 @@ static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, T
     bp.max_rows = max_rows, bp.max_ext = max_ext;
     bp.front = front;
     bp.valid = true;
-    // 6. the two-level schedule (TrsvChunkPlan): chunks of consecutive blocks in natural order, each walked in block-level order.
-    // Not for the FRONT form (U: a row's chain starts with the rows of its own block, so nothing of a block is independent of its
-    // predecessor row) and only for shapes the kernel is compiled for.
+    // 6. the two-level schedule (TrsvChunkPlan): chunks of consecutive blocks in natural order, each walked in block-level order;
+    // only for shapes the kernel is compiled for.
     bp.chunk.tried = true;
-    if(!front && max_rows <= TRSV_CHUNK_LANES && max_ext <= TRSV_BLK_EXT && nb >= 64)
+    if(max_rows <= TRSV_CHUNK_LANES && max_ext <= TRSV_BLK_EXT && nb >= 64)
     {
         TrsvChunkPlan &cp = bp.chunk;
         constexpr int  NBS = 64 / TRSV_CHUNK_LANES; // blocks per step
@@ -570,7 +569,8 @@ static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, T
         // = the later of {its wavefront free + the latency of its values, its last dependency + the hand-off} + the work
         // (round 6, profiles/r6/trsv_chunk_trace*.txt: a hand-off through LDS 0.45, solving a step 0.4, a wavefront's loads for a step
         // 1.7, a value of another chunk 2.5 us after it was produced)
-        const double work = 0.4, local = 0.45, remote = 2.5, vals = 1.7;
+        // (FRONT: the rows of a block are phases one after the other, ~0.08 us each on top)
+        const double work = front ? 0.4 + 0.08 * max_rows : 0.4, local = 0.45, remote = 2.5, vals = 1.7;
         double       total = 0.0;
         if(fits)
         {
@@ -601,11 +601,12 @@ static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, T
             }
         }
         cp.model_us       = total;
-        cp.model_block_us = (double)nlev * (1.2 + 0.4 * std::max(1.0, (double)bp.nslices / (double)nlev));
+        // (the lane-per-block schedule, measured per block level: 1.69 us with every block in registers, 2.51 us with the larger shape)
+        cp.model_block_us = (double)nlev * (max_ext <= 16 && max_rows <= 5 ? 1.7 : 2.55);
         lt.lap("chunks: steps + dependency lists + model");
         // aoclsparse_mi355_set_option(trsv_chunks, ...): -1 the model decides (default), 0 never, 1 whenever the plan can be built
         const int want = plan_option(aoclsparse_mi355_option_trsv_chunks);
-        if(fits && want != 0 && (cp.model_us < 0.8 * cp.model_block_us || want == 1))
+        if(fits && want != 0 && (cp.model_us < 0.9 * cp.model_block_us || want == 1))
         {
             // cptr: first step of every chunk (nch + 1), rows of every chunk (nch), first halo entry of every chunk (nch, each a
             // multiple of 4), halo entries of every chunk (nch)

@@ -1287,7 +1287,23 @@ __device__ __forceinline__ float trsv_dpp_shl(float v)
     return __int_as_float(trsv_dpp_shl<R>(__float_as_int(v)));
 }
 
-template <typename T, int EXT, int BS, bool UNIT>
+// FRONT (U, not transposed): a row's chain STARTS with the rows of its own block (nearest first) and ends with the external entries,
+// so row a cannot begin before row a - 1 is final: the rows of a block are BS phases one after the other.  Lane a keeps its own
+// row's coefficients; in phase r every lane runs row r's chain shape, lane r's result is the block's x_r, broadcast to the block's
+// eight lanes (ds_swizzle) for the phases that follow.
+template <int R>
+__device__ __forceinline__ double trsv_bcast8(double v)
+{
+    constexpr int pat = (R << 5) | 0x18; // swizzle(BROADCAST, 8, R): lane R of every group of 8
+    return __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(v), pat), __builtin_amdgcn_ds_swizzle(__double2loint(v), pat));
+}
+template <int R>
+__device__ __forceinline__ float trsv_bcast8(float v)
+{
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (R << 5) | 0x18));
+}
+
+template <typename T, int EXT, int BS, bool UNIT, bool FRONT>
 __global__ __launch_bounds__(64 * TRSV_CHUNK_WAVES) void trsv_chunk_kernel(
     aoclsparse_int m, aoclsparse_int nnz, aoclsparse_int nchunks, const int4 *__restrict__ steps, const aoclsparse_int *__restrict__ cptr,
     const aoclsparse_int *__restrict__ rowmap, const aoclsparse_int *__restrict__ pptr, const T *__restrict__ pval,
@@ -1485,13 +1501,22 @@ __global__ __launch_bounds__(64 * TRSV_CHUNK_WAVES) void trsv_chunk_kernel(
             for(int e = 0; e < EXT; e++)
             {
                 la[e] = cind[cur.e0 + e];
-                ve[e] = pval[min(cur.pa + e, last)];
+                ve[e] = pval[min(cur.pa + (FRONT ? a : 0) + e, last)];
             }
+            if constexpr(FRONT)
+            {
 #pragma unroll
-            for(int r = 1; r < BS; r++)
+                for(int tt = 0; tt < BS - 1; tt++)
+                    vn[1][tt] = pval[min(max(cur.pa + a - 1 - tt, 0), last)]; // (vn[1][.]: this lane's own row on block row tt)
+            }
+            else
+            {
 #pragma unroll
-                for(int tt = 0; tt < r; tt++)
-                    vn[r][tt] = pval[min(cur.p0 + r * n0 + (r * (r - 1)) / 2 + n0 + tt, last)];
+                for(int r = 1; r < BS; r++)
+#pragma unroll
+                    for(int tt = 0; tt < r; tt++)
+                        vn[r][tt] = pval[min(cur.p0 + r * n0 + (r * (r - 1)) / 2 + n0 + tt, last)];
+            }
         }
         else // deal the step's data out: staging area -> this lane's row, this block's list, the first lane's block rows
         {
@@ -1509,13 +1534,22 @@ __global__ __launch_bounds__(64 * TRSV_CHUNK_WAVES) void trsv_chunk_kernel(
             for(int e = 0; e < EXT; e++)
             {
                 la[e] = scr_e[eo + e];
-                ve[e] = scr_p[po + e];
+                ve[e] = scr_p[po + (FRONT && live ? a : 0) + e];
             }
+            if constexpr(FRONT)
+            {
 #pragma unroll
-            for(int r = 1; r < BS; r++)
+                for(int tt = 0; tt < BS - 1; tt++)
+                    vn[1][tt] = scr_p[max(po + (live ? a : 0) - 1 - tt, 0)];
+            }
+            else
+            {
 #pragma unroll
-                for(int tt = 0; tt < r; tt++)
-                    vn[r][tt] = scr_p[bo + min(r, c > 0 ? c - 1 : 0) * n0 + (r * (r - 1)) / 2 + n0 + tt];
+                for(int r = 1; r < BS; r++)
+#pragma unroll
+                    for(int tt = 0; tt < r; tt++)
+                        vn[r][tt] = scr_p[bo + min(r, c > 0 ? c - 1 : 0) * n0 + (r * (r - 1)) / 2 + n0 + tt];
+            }
         }
         // (masked NOW, before the wait: left to the compiler, the selects moved behind it)
 #pragma unroll
@@ -1528,14 +1562,26 @@ __global__ __launch_bounds__(64 * TRSV_CHUNK_WAVES) void trsv_chunk_kernel(
         T rhs = live ? alpha * bb : T(0);
         T dg  = (live && !UNIT) ? dd : T(1);
         asm volatile("" : "+v"(rhs), "+v"(dg));
+        if constexpr(FRONT)
+        {
 #pragma unroll
-        for(int r = 1; r < BS; r++)
-#pragma unroll
-            for(int tt = 0; tt < r; tt++)
+            for(int tt = 0; tt < BS - 1; tt++)
             {
-                vn[r][tt] = (base && r < c) ? vn[r][tt] : T(0);
-                asm volatile("" : "+v"(vn[r][tt]));
+                vn[1][tt] = (live && tt < a) ? vn[1][tt] : T(0);
+                asm volatile("" : "+v"(vn[1][tt]));
             }
+        }
+        else
+        {
+#pragma unroll
+            for(int r = 1; r < BS; r++)
+#pragma unroll
+                for(int tt = 0; tt < r; tt++)
+                {
+                    vn[r][tt] = (base && r < c) ? vn[r][tt] : T(0);
+                    asm volatile("" : "+v"(vn[r][tt]));
+                }
+        }
         // the next step of this wavefront: level-1 metadata now (its header came during the previous step), header of the one after
         if(s + NW < s1)
         {
@@ -1591,14 +1637,86 @@ __global__ __launch_bounds__(64 * TRSV_CHUNK_WAVES) void trsv_chunk_kernel(
         }
         const unsigned long long t_ready = trace ? __builtin_amdgcn_s_memrealtime() : 0;
         // ---- from here on every instruction is on the critical path of the solve ----
+        T xe[EXT];
+#pragma unroll
+        for(int e = 0; e < EXT; e++)
+            __builtin_memcpy(&xe[e], &bits[e], sizeof(T));
+        unsigned long long t_ext = 0, t_elim = 0;
+        if constexpr(FRONT)
+        {
+            // phase r: row r of every block -- [its block rows r-1 .. 0, then the external entries], the order ref_trsv_u applies them
+            T          xs[BS];
+            const bool okl = live && !__builtin_amdgcn_ballot_w64(dead);
+            auto       phase = [&](auto rtag) {
+                constexpr int r   = decltype(rtag)::value;
+                T             acc = rhs;
+#pragma unroll
+                for(int tt = BS - 2; tt >= 0; tt--)
+                    if(tt < r)
+                        acc = neg_fma(vn[1][tt], xs[tt], acc);
+#pragma unroll
+                for(int e = 0; e < EXT; e++)
+                    acc = neg_fma(ve[e], xe[e], acc);
+                if constexpr(r == 0)
+                {
+                    // a single row with more than EXT dependencies (never inside a multi-row block): the rest one by one
+                    if(__builtin_amdgcn_ballot_w64(base && n0 > EXT) != 0)
+                    {
+                        if(base && n0 > EXT)
+                            for(int p = EXT; p < n0 && !dead; p++)
+                            {
+                                const int q = cind[cur.e0 + p];
+                                B         got;
+                                for(;;)
+                                {
+                                    got = lds_get(q);
+                                    if(got != tag<T>::value || dead)
+                                        break;
+                                    __builtin_amdgcn_s_sleep(1);
+                                    tick(1023u);
+                                }
+                                T xv;
+                                __builtin_memcpy(&xv, &got, sizeof(T));
+                                acc = neg_fma(pval[cur.pa + p], xv, acc);
+                            }
+                    }
+                }
+                if constexpr(!UNIT)
+                    acc /= dg;
+                B out;
+                __builtin_memcpy(&out, &acc, sizeof(T));
+                out = out == tag<T>::value ? qnan_bits<T>::value : out;
+                lds_put((okl && a == r) ? cur.myslot : park, out);
+                xs[r] = trsv_bcast8<r>(acc);
+            };
+            phase(std::integral_constant<int, 0>{});
+            if(trace)
+            {
+                asm volatile("" : "+v"(xs[0]));
+                t_ext = __builtin_amdgcn_s_memrealtime();
+            }
+            phase(std::integral_constant<int, 1>{});
+            phase(std::integral_constant<int, 2>{});
+            phase(std::integral_constant<int, 3>{});
+            phase(std::integral_constant<int, 4>{});
+            if constexpr(BS > 5)
+            {
+                phase(std::integral_constant<int, 5>{});
+                phase(std::integral_constant<int, 6>{});
+                phase(std::integral_constant<int, 7>{});
+            }
+            if(trace)
+            {
+                asm volatile("" : "+v"(xs[BS - 1]));
+                t_elim = __builtin_amdgcn_s_memrealtime();
+            }
+        }
+        else
+        {
         T sa = rhs;
 #pragma unroll
         for(int e = 0; e < EXT; e++)
-        {
-            T xe;
-            __builtin_memcpy(&xe, &bits[e], sizeof(T));
-            sa = neg_fma(ve[e], xe, sa);
-        }
+            sa = neg_fma(ve[e], xe[e], sa);
         // a single row with more than EXT dependencies (never inside a multi-row block): the rest one by one
         if(__builtin_amdgcn_ballot_w64(base && n0 > EXT) != 0)
         {
@@ -1620,7 +1738,6 @@ __global__ __launch_bounds__(64 * TRSV_CHUNK_WAVES) void trsv_chunk_kernel(
                     sa = neg_fma(pval[cur.pa + p], xv, sa);
                 }
         }
-        unsigned long long t_ext = 0;
         if(trace)
         {
             asm volatile("" : "+v"(sa));
@@ -1656,11 +1773,11 @@ __global__ __launch_bounds__(64 * TRSV_CHUNK_WAVES) void trsv_chunk_kernel(
             for(int r = tt + 1; r < BS; r++)
                 sg[r] = neg_fma(vn[r][tt], xt, sg[r]);
         }
-        unsigned long long t_elim = 0;
         if(trace)
         {
             asm volatile("" : "+v"(sg[BS - 1]));
             t_elim = __builtin_amdgcn_s_memrealtime();
+        }
         }
         // every row lane takes its own x back out of LDS: the tagged word for the other chunks, and the caller's x -- stored BEHIND
         // the requests for the next step's data
@@ -1904,15 +2021,15 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
         unsigned long long *trace5      = nullptr;
         if(trace_path5 && nrhs == 1 && hipMalloc(&trace5, sizeof(unsigned long long) * 8 * (size_t)cp.nsteps) != hipSuccess)
             trace5 = nullptr;
-        auto go_unit = [&](auto ext_tag, auto bs_tag, auto unit_tag) {
+        auto go_form = [&](auto ext_tag, auto bs_tag, auto unit_tag, auto front_tag) {
             constexpr int  EXT = decltype(ext_tag)::value, BS = decltype(bs_tag)::value;
-            constexpr bool UNIT = decltype(unit_tag)::value;
-            static const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void *>(&trsv_chunk_kernel<T, EXT, BS, UNIT>),
+            constexpr bool UNIT = decltype(unit_tag)::value, FRONT = decltype(front_tag)::value;
+            static const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void *>(&trsv_chunk_kernel<T, EXT, BS, UNIT, FRONT>),
                                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if(raised != hipSuccess)
                 return aoclsparse_status_internal_error;
             const dim3 grid = nrhs > 1 ? dim3((unsigned)nrhs, (unsigned)cp.nchunks) : dim3((unsigned)cp.nchunks);
-            hipLaunchKernelGGL((trsv_chunk_kernel<T, EXT, BS, UNIT>), grid, dim3(64 * TRSV_CHUNK_WAVES), lds, s, m,
+            hipLaunchKernelGGL((trsv_chunk_kernel<T, EXT, BS, UNIT, FRONT>), grid, dim3(64 * TRSV_CHUNK_WAVES), lds, s, m,
                                std::max<aoclsparse_int>(plan.nnz_tri, 1), cp.nchunks,
                                reinterpret_cast<const int4 *>(cp.steps.as<aoclsparse_int>()), cp.cptr.as<aoclsparse_int>(),
                                bp.rowmap.as<aoclsparse_int>(), bp.pptr.as<aoclsparse_int>(), bp.pval.as<T>(),
@@ -1922,7 +2039,11 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
             return aoclsparse_status_success;
         };
         auto go = [&](auto ext_tag, auto bs_tag) {
-            return unit ? go_unit(ext_tag, bs_tag, std::true_type{}) : go_unit(ext_tag, bs_tag, std::false_type{});
+            if(bp.front)
+                return unit ? go_form(ext_tag, bs_tag, std::true_type{}, std::true_type{})
+                            : go_form(ext_tag, bs_tag, std::false_type{}, std::true_type{});
+            return unit ? go_form(ext_tag, bs_tag, std::true_type{}, std::false_type{})
+                        : go_form(ext_tag, bs_tag, std::false_type{}, std::false_type{});
         };
         using std::integral_constant;
         const bool              small_ext = bp.max_ext <= 16, small_bs = bp.max_rows <= 5;

@@ -134,8 +134,8 @@ def forced_chunks():
                                                  ("three+long", fixed(3), 41, 30), ("mixed", mixed, 33, 0),
                                                  ("mixed+long", mixed, 64, 28)])
 def test_two_level_trsv_bit_exact_every_triangle(forced_chunks, name, dofs, width, far):
-    """L, L^T, U^T (U keeps the lane-per-block schedule: its rows start with the rows of their own block), unit and non-unit, blocks
-    of 1-8 rows, single rows with more dependencies than a step polls in one batch, several chunks with halos: x must be the
+    """L, L^T, U^T and U (whose rows START with the rows of their own block: the block's rows are phases one after the other), unit
+    and non-unit, blocks of 1-8 rows, single rows with more dependencies than a step polls in one batch, several chunks with halos: x must be the
     serial chain of ref_trsv_* bit for bit (trsv_kr.hpp:57-75), and the schedule that ran must be the two-level one."""
     nodes = 12000
     m, rp, ci, v = node_mesh(900 + len(name), nodes, width, dofs(np.random.default_rng(1), nodes), far=far)
@@ -156,12 +156,9 @@ def test_two_level_trsv_bit_exact_every_triangle(forced_chunks, name, dofs, widt
                 info = A.trsv_info(getattr(P, fill), getattr(P, op))
             got = xd.cpu().numpy()
             assert np.array_equal(got, xr), (name, kind, unit, int((got != xr).sum()))
-            if kind != "u":
-                assert info.schedule == 5 and info.chunks >= 2 and info.steps > info.chunks, (name, kind, info.schedule, info.chunks)
-                ran += 1
-            else:
-                assert info.schedule == 4 and info.chunks == 0
-    assert ran == 6
+            assert info.schedule == 5 and info.chunks >= 2 and info.steps > info.chunks, (name, kind, info.schedule, info.chunks)
+            ran += 1
+    assert ran == 8
 
 
 def test_two_level_trsv_float_strided_and_trsm(forced_chunks):
@@ -201,7 +198,7 @@ def test_two_level_trsv_float_strided_and_trsm(forced_chunks):
     n = 5
     rng = np.random.default_rng(12)
     for kind, fill, op, unit in (("l", P.FILL_LOWER, P.OP_NONE, True), ("lt", P.FILL_LOWER, P.OP_TRANSPOSE, False),
-                                 ("ut", P.FILL_UPPER, P.OP_TRANSPOSE, True)):
+                                 ("ut", P.FILL_UPPER, P.OP_TRANSPOSE, True), ("u", P.FILL_UPPER, P.OP_NONE, False)):
         dd = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=fill, diag=P.DIAG_UNIT if unit else P.DIAG_NON_UNIT)
         iend = o["idiag"] if kind[0] == "l" else o["iurow"]
         for lay, shape, col in ((P.ORDER_COLUMN, (n, m + 3), lambda M, j: M[j, :m]), (P.ORDER_ROW, (m, n + 2), lambda M, j: M[:, j])):

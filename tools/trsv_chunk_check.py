@@ -23,8 +23,6 @@ for variant in (("structured", "unstructured") if which == "both" else (which,))
         d = pkg.Descr(mtype=pkg.TYPE_TRIANGULAR, fill=fill, diag=pkg.DIAG_UNIT if unit else pkg.DIAG_NON_UNIT)
         b = np.random.default_rng(2).uniform(-1, 1, m)
         for op in (pkg.OP_NONE, pkg.OP_TRANSPOSE):
-            if fill == pkg.FILL_UPPER and op == pkg.OP_NONE and not small:
-                continue  # (the FRONT form has no chunk plan; checked in small only: falls back to schedule 4)
             key = ("l" if fill == pkg.FILL_LOWER else "u") + ("t" if op == pkg.OP_TRANSPOSE else "")
             so, xr = oracle.dtrsv(key, 1.0, m, 0, lu, ci, rp, o["idiag"] if fill == pkg.FILL_LOWER else o["iurow"], b, unit)
             assert so == 0
@@ -50,5 +48,8 @@ for variant in (("structured", "unstructured") if which == "both" else (which,))
                 out["ms_%d" % sched] = round(pkg.timer_stop() / 20, 4)
             assert L.aoclsparse_mi355_set_trsv_schedule(-1) == 0
             out["levels"] = A.trsv_levels(fill, op)
+            ti = A.trsv_info(fill, op)
+            out["plan"] = {"block_levels": ti.block_levels, "chunks": ti.chunks, "steps": ti.steps, "model_two_level_us": ti.model_chunk_us,
+                           "model_lane_per_block_us": ti.model_block_us, "automatic_schedule": ti.schedule}
             print(json.dumps(out), flush=True)
         del A
