@@ -959,8 +959,12 @@ def main():
         def call():
             s = pkg.dcsrmv(pkg.OP_NONE, 1.0, m, m, nnz, d_v, d_ci, d_rp, descr, x, 0.0, y2)
             assert s == 0, pkg.STATUS[s]
-        lp = timed_laps(pkg, call, args.steps, args.warmup)
+        # cold products, as the headline (the row-block kernel alternates its block order too); the back-to-back mean beside it
+        flush = torch.ones(1 << 28, dtype=torch.float32, device=device)
+        lp = timed_cold(pkg, call, min(args.steps, 30), flush)
+        del flush
         ms = float(np.mean(lp))
+        ms_b2b = float(np.mean(timed_laps(pkg, call, min(args.steps, 30), 3)))
         tr_ca = None
         try:  # the committed PMC measurement of this kernel on this workload
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
@@ -971,6 +975,7 @@ def main():
             pass
         return {"workload": "aoclsparse_dcsrmv (no handle), CSR arrays / x / y device-resident, same %dx%d-grid Laplacian" % (g, g),
                 "kernel": "csr-adaptive (row blocks staged in LDS)", "ms": round(ms, 6), "stats_ms": quartiles(lp),
+                "timing": "cache flushed before every product", "ms_back_to_back": round(ms_b2b, 6),
                 "gflops": round(flops / ms / 1e6, 2),
                 "roofline": roofline(abytes, ms, tr_ca, traffic_source="profiles/pmc_traffic.json" if tr_ca else None),
                 "bit_exact_vs_headline_y": bool(torch.equal(y2, y))}
@@ -993,8 +998,10 @@ def main():
         assert L.aoclsparse_set_mv_hint(Af.h, pkg.OP_NONE, descr.h, 1000) == 0 and L.aoclsparse_optimize(Af.h) == 0
         xf = x.to(torch.float32)
         yf = torch.zeros(m, dtype=torch.float32, device=device)
-        lp = timed_laps(pkg, lambda: pkg.smv(pkg.OP_NONE, 1.0, Af, descr, xf, 0.0, yf), args.steps, args.warmup)
+        flush = torch.ones(1 << 28, dtype=torch.float32, device=device)
+        lp = timed_cold(pkg, lambda: pkg.smv(pkg.OP_NONE, 1.0, Af, descr, xf, 0.0, yf), min(args.steps, 30), flush)  # cold, as the headline
         ms = float(np.mean(lp))
+        ms_b2b = float(np.mean(timed_laps(pkg, lambda: pkg.smv(pkg.OP_NONE, 1.0, Af, descr, xf, 0.0, yf), min(args.steps, 30), 3)))
         fbytes = (m + 1 + nnz) * 4 + (2 * m + nnz) * 4
         ftr = (pmc.get("float_kernel") or {}).get("traffic_bytes_per_launch") if pmc.get("grid") == g else None
         import oracle
@@ -1005,10 +1012,13 @@ def main():
                                  np.zeros(nchk, np.float32))
         torch.cuda.synchronize()
         res["smv"] = {"workload": "aoclsparse_smv, same %dx%d-grid Laplacian, float values" % (g, g), "ms": round(ms, 6),
-                      "stats_ms": quartiles(lp), "gflops": round(flops / ms / 1e6, 2),
+                      "stats_ms": quartiles(lp), "gflops": round(flops / ms / 1e6, 2), "timing": "cache flushed before every product",
+                      "ms_back_to_back": round(ms_b2b, 6),
+                      # (frac on CSR-model bytes passes 1: with float values the shared column lists are 0.36 of the model's bytes;
+                      # frac_traffic is the fraction in real bytes)
                       "roofline": roofline(fbytes, ms, ftr, traffic_source="profiles/pmc_traffic.json: float_kernel" if ftr else None),
                       "bit_exact_first_2e20_rows": bool(so == 0 and np.array_equal(yf[:nchk].cpu().numpy(), yref))}
-        del Af, xf, yf
+        del Af, xf, yf, flush
         # aoclsparse_dmv exactly as a reference user calls it: x and y are HOST arrays (staged per call: 134 MB each way), the call
         # returns when y is in host memory.  Wall clock per call; the PCIe-inclusive rate, never the headline value.
         xh2, yh2 = np.ascontiguousarray(xh), np.zeros(m)
