@@ -1217,7 +1217,7 @@ aoclsparse_status aoclsparse_mi355_invalidate(aoclsparse_matrix A)
     A->plan_user.mm.row_runs = A->plan_user.mm.runs_tried = false;
     A->plan_trans.mm.row_runs = A->plan_trans.mm.runs_tried = false;
     for(auto &p : A->trsv_plan)
-        p.valid = p.rows_valid = false, p.nlevels = -1, p.blk.valid = p.blk.tried = false;
+        p.valid = p.rows_valid = false, p.nlevels = -1, p.blk.valid = p.blk.tried = false, p.blk.chunk.valid = p.blk.chunk.tried = false;
     A->trans.reset();
     return aoclsparse_status_success;
 }
@@ -1248,7 +1248,7 @@ void drop_derived_state(aoclsparse_matrix A)
     A->plan_trans.sell.valid = A->plan_trans.sell.tried = false;
     A->dev_diag.release();
     for(auto &p : A->trsv_plan)
-        p.valid = p.rows_valid = false, p.nlevels = -1, p.blk.valid = p.blk.tried = false;
+        p.valid = p.rows_valid = false, p.nlevels = -1, p.blk.valid = p.blk.tried = false, p.blk.chunk.valid = p.blk.chunk.tried = false;
 }
 } // namespace mi355
 

@@ -238,6 +238,7 @@ template <typename T>
 static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, TrsvBlockPlan &bp)
 {
     bp.tried = true;
+    bp.chunk.valid = bp.chunk.tried = false; // (rebuilt below where it applies: never a leftover of an earlier plan)
     if(m < 2)
         return aoclsparse_status_success;
     LapTimer lt;

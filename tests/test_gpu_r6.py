@@ -257,3 +257,26 @@ def test_two_level_trsv_is_chosen_by_the_model_where_the_dag_is_deep_and_narrow(
         info = A.trsv_info(P.FILL_LOWER)
         assert info.schedule == want, (variant, info.schedule, info.model_chunk_us, info.model_block_us)
         assert np.array_equal(xd.cpu().numpy(), xr), variant
+
+
+def test_two_level_trsv_after_update_values(forced_chunks):
+    """aoclsparse_dupdate_values between two solves: the TRSV plans (block plan, chunk plan with its staged copies of the values)
+    are dropped and rebuilt from the new values -- the second solve is the serial chain on the NEW matrix, still on schedule 5"""
+    nodes = 6000
+    m, rp, ci, v = node_mesh(5, nodes, 40, np.full(nodes, 5))
+    A = P.Matrix(0, m, m, rp, ci, v)
+    d = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=P.FILL_LOWER)
+    b = np.random.default_rng(3).uniform(-1, 1, m)
+    for rnd in range(2):
+        if rnd == 1:
+            v2 = v * np.random.default_rng(9).uniform(0.9, 1.1, len(v))
+            assert L.aoclsparse_dupdate_values(A.h, len(v2), P._ptr(v2)) == 0
+            v = v2
+        o = oracle.dcsr_optimize(m, m, len(v), 0, rp, ci, v)
+        st, xr = oracle.dtrsv("l", 1.0, m, 0, o["val"], o["ind"], o["ptr"], o["idiag"], b, False)
+        with trsv_schedule(P, 5):
+            xd = torch.zeros(m, dtype=torch.float64, device="cuda")
+            assert P.dtrsv(P.OP_NONE, 1.0, A, d, dev(b), xd) == 0
+            torch.cuda.synchronize()
+            assert A.trsv_info(P.FILL_LOWER).schedule == 5
+        assert np.array_equal(xd.cpu().numpy(), xr), rnd
