@@ -332,8 +332,16 @@ namespace
 unsigned long long stream_uid(hipStream_t s)
 {
     using get_id_t = hipError_t (*)(hipStream_t, unsigned long long *);
-    static const get_id_t get_id = reinterpret_cast<get_id_t>(dlsym(RTLD_DEFAULT, "hipStreamGetId"));
-    unsigned long long    id     = 0;
+    // looked up in THE runtime this library is bound to (the one hipStreamCreate resolves to), not in whatever the process holds:
+    // a process can hold two copies of libamdhip64 (aoclsparse_mi355_hip_runtime_path), and a stream is an object of one of them
+    static const get_id_t get_id = [] {
+        Dl_info info;
+        if(!dladdr(reinterpret_cast<const void *>(&hipStreamCreate), &info) || !info.dli_fname)
+            return static_cast<get_id_t>(nullptr);
+        void *h = dlopen(info.dli_fname, RTLD_LAZY | RTLD_NOLOAD);
+        return h ? reinterpret_cast<get_id_t>(dlsym(h, "hipStreamGetId")) : static_cast<get_id_t>(nullptr);
+    }();
+    unsigned long long id = 0;
     if(!get_id)
         return 0;
     if(get_id(s, &id) != hipSuccess)
