@@ -426,16 +426,19 @@ constexpr int TRSV_XP_PAD = 192;
 //   cind   the external dependencies of every block as LDS slots of its chunk (own rows first, halo behind them)
 //   hind   the halos: positions in xp, per chunk in the order of first use
 constexpr int TRSV_CHUNK_LANES = 8; // lanes per block = TRSV_BLK_ROWS
-constexpr int TRSV_CHUNK_WAVES = 8; // wavefronts per workgroup: 7 take steps, the last one fetches the halo
+// wavefronts per workgroup: all but the last take steps, the last one fetches the halo.  (4 + 1: 1.144 ms on the shell-like factor, 5 + 1:
+// 1.103, 7 + 1: 1.102 -- the solve is paced by the dependency chain; two staging areas fewer leave LDS for 12 % more rows per chunk,
+// i.e. fewer chunk boundaries on the critical path)
+constexpr int TRSV_CHUNK_WAVES = 6;
 // a solving wavefront's staging area holds the values of one step: 8 blocks of bs rows with ext external + (bs - 1) / 2 internal entries
 constexpr int trsv_chunk_pcap(int bs, int ext)
 {
     return 8 * (bs * ext + bs * (bs - 1) / 2) + ext + 16; // (+ what a read past the last block's entries can overshoot)
 }
-// LDS slots (8 bytes as double) of a chunk -- own rows + halo -- at most: what the CU's 160 KB leave next to the seven staging areas
+// LDS slots (8 bytes as double) of a chunk -- own rows + halo -- at most: what the CU's 160 KB leave next to the staging areas
 constexpr int trsv_chunk_slots(int bs, int ext)
 {
-    return ((160 * 1024 - 16 - 7 * (trsv_chunk_pcap(bs, ext) * 8 + 9 * ext * 4) - 65 * 8) / 8) / 256 * 256;
+    return ((160 * 1024 - 16 - (TRSV_CHUNK_WAVES - 1) * (trsv_chunk_pcap(bs, ext) * 8 + 9 * ext * 4) - 65 * 8) / 8) / 256 * 256;
 }
 constexpr int TRSV_CHUNK_ROWS = trsv_chunk_slots(5, 16); // the largest of the four shapes
 struct TrsvChunkPlan
