@@ -1258,10 +1258,10 @@ __global__ __launch_bounds__(64) void trsv_block_kt_kernel(
 // The lane-per-block kernel above pays one hand-off through L2 / HBM per block level (1.2-1.7 us against 0.4 us of work: profiles/r5/
 // trsv_experiments.txt), because consecutive levels always run in different wavefronts on different CUs.  Here the blocks keep their
 // NATURAL order at the top level: a workgroup owns a CHUNK of consecutive blocks (internal.hpp: TrsvChunkPlan) and walks them in
-// block-level order, one STEP (<= 8 blocks of one level) per wavefront, steps dealt round-robin to seven of its eight wavefronts.
+// block-level order, one STEP (<= 8 blocks of one level) per wavefront, steps dealt round-robin to all but the last of its wavefronts (5 of 6).
 // The chunk's x lives in LDS as NaN-tagged words -- exactly the protocol of the sync-free kernels, one level closer: a dependency
 // on a row of the same chunk is polled in LDS (a hand-off costs an LDS write + read).  Rows of earlier chunks the chunk depends on
-// (its HALO) are polled in xp by the EIGHTH wavefront, in the order of their first use, and copied into LDS slots behind the chunk's
+// (its HALO) are polled in xp by the LAST wavefront, in the order of their first use, and copied into LDS slots behind the chunk's
 // own rows: the solving wavefronts never wait for an HBM round trip, and one wavefront per chunk polls HBM instead of all of them.
 // A mesh numbered line by line puts most of a block's dependencies a few hundred blocks back, inside its chunk: the remote
 // hand-offs that remain are one per chunk boundary along the critical path, and they are pipelined (chunk c + 1 runs one remote
@@ -1459,7 +1459,7 @@ __global__ __launch_bounds__(64 * TRSV_CHUNK_WAVES) void trsv_chunk_kernel(
     // are consecutive positions, so their values are ONE contiguous range of pval and their dependency lists one of cind -- the
     // wavefront fetches the ranges with coalesced loads (lane l takes elements l, l + 64, ...: a few cache lines per instruction)
     // and deals them out through its staging area when the step starts.  Fetched lane by lane -- lane (block, row) its own row's
-    // entries, one entry per instruction -- every instruction touched ~40 different lines, ~950 per step: seven wavefronts kept
+    // entries, one entry per instruction -- every instruction touched ~40 different lines, ~950 per step: the solving wavefronts kept
     // the CU's address path busy for ~1 us per step, which was the rate of the whole solve (profiles/r6/trsv_chunk_trace.txt).
     T         bb = T(0), dd = T(1), rv[PK];
     int       re[EK];
