@@ -49,7 +49,9 @@ class SpmvInfo(ctypes.Structure):
                 ("long_rows", c_int32), ("max_row_nnz", c_int32), ("device_resident", c_int32),
                 ("sell_slices", c_int32), ("stored_cells", ctypes.c_longlong), ("mm_groups", c_int32),
                 ("mm_window_rows", c_int32), ("mm_bell_width", c_int32), ("mm_bell_fill_permille", c_int32),
-                ("tree_min", c_int32)]
+                ("tree_min", c_int32), ("mm_bell_xcd_chunk", c_int32), ("mm_bell_model_fetches_permille", c_int32),
+                ("mm_bell_model_fetches_launch_order_permille", c_int32), ("mm_bell_lattice_line", c_int32),
+                ("mm_bell_lattice_lines", c_int32), ("mm_bell_region_a", c_int32), ("mm_bell_region_b", c_int32)]
 
 
 class TrsvInfo(ctypes.Structure):
@@ -57,16 +59,18 @@ class TrsvInfo(ctypes.Structure):
                                       "model_block_us", "schedule")]
 
 
+MM_STATE_BUFFERS = 13
+
+
 class MmState(ctypes.Structure):
     """aoclsparse_mi355_mm_state: sizes + scalars of a handle's analysed csrmm state (a POD that travels as bytes)"""
-    _fields_ = [("scalars", ctypes.c_longlong * 40), ("bytes", ctypes.c_longlong * 12)]
+    _fields_ = [("scalars", ctypes.c_longlong * 40), ("bytes", ctypes.c_longlong * MM_STATE_BUFFERS)]
 
 
 class CommId(ctypes.Structure):
     _fields_ = [("internal", ctypes.c_char * 128)]
 
 
-MM_STATE_BUFFERS = 12
 
 # every exported symbol of include/*.h: name -> (restype, argtypes)
 _I = c_int32

@@ -44,10 +44,11 @@ namespace
         case 9: return &p.mm.windows;
         case 10: return &p.bell.val;
         case 11: return &p.bell.bcol;
+        case 12: return &p.bell.order;
         default: return nullptr;
         }
     }
-    static_assert(AOCLSPARSE_MI355_MM_STATE_BUFFERS == 12, "state table and header disagree");
+    static_assert(AOCLSPARSE_MI355_MM_STATE_BUFFERS == 13, "state table and header disagree");
 
     enum
     {
@@ -79,10 +80,12 @@ namespace
         S_BELL_WIDTH,
         S_BELL_NBLOCKS,
         S_BELL_FILL_BITS,
+        S_BELL_ORDER_LEN,
+        S_BELL_XCD_CHUNK,
         S_COUNT
     };
     static_assert(S_COUNT <= AOCLSPARSE_MI355_MM_STATE_SCALARS, "scalar table too small");
-    constexpr long long STATE_MAGIC = 0x6d69333535723464LL; // "mi355r4d"
+    constexpr long long STATE_MAGIC = 0x6d69333535723664LL; // "mi355r6d"
 
     void fill_scalars(const _aoclsparse_matrix &A, aoclsparse_mi355_mm_state &st)
     {
@@ -98,6 +101,7 @@ namespace
         s[S_WIN] = p.mm.win, s[S_WIN_ROWS] = p.mm.win_rows;
         s[S_BELL] = p.bell.valid, s[S_BELL_NBR] = p.bell.nbr, s[S_BELL_WIDTH] = p.bell.width, s[S_BELL_NBLOCKS] = p.bell.nblocks;
         std::memcpy(&s[S_BELL_FILL_BITS], &p.bell.fill, sizeof(double));
+        s[S_BELL_ORDER_LEN] = p.bell.order_len, s[S_BELL_XCD_CHUNK] = p.bell.xcd_chunk;
     }
 
     bool state_ok(const aoclsparse_mi355_mm_state &st)
@@ -144,6 +148,10 @@ namespace
             if(s[S_VTYPE] != aoclsparse_dmat || nbr != (m + BELL_BS - 1) / BELL_BS || w < 1 || w > (1LL << 30) / (nbr > 0 ? nbr : 1)
                || b[10] < nbr * w * BELL_BS * BELL_BS * vs || b[11] < nbr * w * I || s[S_BELL_NBLOCKS] < 0 || s[S_BELL_NBLOCKS] > nbr * w)
                 return false;
+            // the order list: at most one entry per block row and XCD position (entries are block rows or -1: checked by the kernel's
+            // bounds on nothing -- the list is the sender's, like every other plan)
+            if(s[S_BELL_ORDER_LEN] < 0 || s[S_BELL_ORDER_LEN] > nbr || (s[S_BELL_ORDER_LEN] > 0 && b[12] < 8 * I * s[S_BELL_ORDER_LEN]))
+                return false;
         }
         return true;
     }
@@ -179,6 +187,7 @@ namespace
         b.tried = true, b.valid = s[S_BELL] != 0, b.nbr = (aoclsparse_int)s[S_BELL_NBR], b.width = (aoclsparse_int)s[S_BELL_WIDTH];
         b.nblocks = s[S_BELL_NBLOCKS];
         std::memcpy(&b.fill, &s[S_BELL_FILL_BITS], sizeof(double));
+        b.order_len = (aoclsparse_int)s[S_BELL_ORDER_LEN], b.xcd_chunk = (int)s[S_BELL_XCD_CHUNK];
         // the host view of the matrix (everything outside csrmm -- export, ?mv's SELL copy, TRSV analysis -- works on it)
         const size_t vs = val_size(R.val_type);
         MI355_HIP_TRY(hipMemcpyAsync(R.user.ptr, d.ptr.ptr, sizeof(aoclsparse_int) * ((size_t)R.m + 1), hipMemcpyDeviceToHost, stream));

@@ -1,6 +1,8 @@
 // csrmm_api.cpp -- aoclsparse_?csrmm(_kid): checks of level3/aoclsparse_csrmm.hpp:448-618, then the
 // HIP kernels of csrmm_kernels.hip on the device-resident CSR (A^T copy for op != none).
 #include "internal.hpp"
+#include <climits>
+#include <cmath>
 
 #include <system_error>
 #include <condition_variable>
@@ -191,6 +193,218 @@ aoclsparse_status detect_row_runs(const HostCsr &h, SpmvPlan &plan)
 // (conversion/aoclsparse_convert.cpp:36-147 aoclsparse_opt_blksize, analysis.cpp:146-160: 40-50 % thresholds).  Here: 16 x 16
 // blocks (the MFMA tile), kept when fill = nnz / (256 * blocks) >= 0.5, the ELL padding (width * block rows over blocks) stays
 // under 1.35 and every row is sorted and duplicate-free (the tile walks k upwards: only then is the sum the CSR-order chain).
+// Which XCD works through which block rows, and in which order (BellPlan::order).  A block row's wavefronts fetch `width` stretches of B
+// (16 rows each); the same stretch is wanted by every block row that stores that block column, and it crosses the fabric once per L2 that
+// does not hold it any more.  Model: workgroup w runs on XCD w % 8, an XCD works through its list in order, and a stretch is still in that
+// XCD's L2 when the XCD touched it at most BELL_L2_WINDOW list positions ago (about what an XCD has in flight: 32 CUs x 3 workgroups;
+// beyond that the 0.3 MB every block row moves have pushed it out).  Calibration, 7-point stand-ins of 32^3 / 40^3 nodes, FETCH_SIZE per
+// distinct stretch against the model (profiles/r6/bell_experiments.txt): launch order 5.2 vs 4.9, chunks of 4 / 5 block rows 3.5 vs 3.4.
+// Candidates:
+//  * chunks of c consecutive block rows dealt to the XCDs in turn (c = 1 is launch order).  The SMALLEST chunk within 20 % of the fewest
+//    misses is kept: small chunks keep all eight XCDs inside one neighbourhood of B, C and the values, which is worth more than the last
+//    misses (32^3: chunks of 4 / 64 model 3.4 / 2.9 fetches and take 1.00 / 1.02 ms; a contiguous eighth per XCD has the fewest of the
+//    chunked orders and measures 5-12 % slower than chunks of 4: eight distant DRAM streams).
+//  * when the block columns sit at constant offsets 1, n1, n1 n2 from the diagonal (a structured grid numbered line by line): every XCD
+//    takes regions of a x b block rows of the cross-section and follows each region through all the planes, so that the neighbours in the
+//    next plane are a x b positions away instead of a plane's worth.  Taken when the model counts under 0.8 of the best chunk's misses.
+// O(stored blocks) per candidate, once per handle.  AOCLSPARSE_MI355_BELL_XCD_CHUNK (diagnostic, read at analysis time): c >= 1 forces a
+// chunk, 0 launch order without a list, -1 the lattice sweep whenever a lattice is found.
+constexpr int BELL_L2_WINDOW = 96;
+struct BellLattice
+{
+    aoclsparse_int n1 = 0, n2 = 0, n3 = 0; // block rows per line, lines per plane (1: a 2-D grid), planes
+};
+// the offsets block column - block row that at least a quarter of the block rows store
+BellLattice detect_bell_lattice(const std::vector<aoclsparse_int> &bcol, aoclsparse_int nbr, aoclsparse_int width)
+{
+    BellLattice         L;
+    std::vector<int>    hist((size_t)nbr, 0);
+    for(aoclsparse_int b = 0; b < nbr; b++)
+        for(aoclsparse_int s = 0; s < width; s++)
+        {
+            const aoclsparse_int bc = bcol[(size_t)b * width + s];
+            if(bc < 0)
+                break;
+            if(bc > b && bc - b < nbr)
+                hist[(size_t)(bc - b)]++;
+        }
+    auto in = [&](long long o) { return o >= 1 && o < nbr && hist[(size_t)o] >= nbr / 4; };
+    if(!in(1))
+        return L;
+    // a line length / plane size is the CENTRE of a cluster of offsets (7-point: n1 alone; 27-point: n1 - 1, n1, n1 + 1)
+    auto centre = [&](long long o) { return in(o) && in(o - 1) == in(o + 1); };
+    long long n1 = 0, pl = 0;
+    for(long long o = 2; o < nbr && !n1; o++)
+        if(centre(o))
+            n1 = o;
+    if(!n1 || n1 > nbr / 4)
+        return L;
+    for(long long o = 2 * n1; o < nbr && !pl; o += n1)
+        if(centre(o) && o > n1 + 1)
+            pl = o;
+    L.n1 = (aoclsparse_int)n1;
+    if(pl && pl <= nbr / 2)
+        L.n2 = (aoclsparse_int)(pl / n1), L.n3 = (aoclsparse_int)((nbr + pl - 1) / pl);
+    else
+        L.n2 = 1, L.n3 = (aoclsparse_int)((nbr + n1 - 1) / n1);
+    return L;
+}
+// the lists of the eight XCDs: the line in nsx pieces, b lines of them = a region of the cross-section, followed through the planes of a
+// z segment (nseg of them); the regions of a segment go to the XCDs in turn (eight neighbours at a time work side by side)
+void bell_lattice_lists(const BellLattice &L, aoclsparse_int nbr, int nsx, int b, int nseg, std::vector<aoclsparse_int> (&list)[8])
+{
+    for(auto &l : list)
+        l.clear();
+    long long       r  = 0;
+    const long long pl = (long long)L.n1 * L.n2;
+    for(int sg = 0; sg < nseg; sg++)
+    {
+        const aoclsparse_int za = (aoclsparse_int)((long long)L.n3 * sg / nseg), zb = (aoclsparse_int)((long long)L.n3 * (sg + 1) / nseg);
+        for(aoclsparse_int y0 = 0; y0 < L.n2; y0 += b)
+            for(int sx = 0; sx < nsx; sx++, r++)
+            {
+                const aoclsparse_int xa = (aoclsparse_int)((long long)L.n1 * sx / nsx), xb = (aoclsparse_int)((long long)L.n1 * (sx + 1) / nsx);
+                auto                &l = list[r & 7];
+                for(aoclsparse_int z = za; z < zb; z++)
+                    for(aoclsparse_int y = y0; y < std::min<aoclsparse_int>(L.n2, y0 + b); y++)
+                        for(aoclsparse_int x = xa; x < xb; x++)
+                        {
+                            const long long br = x + (long long)L.n1 * y + pl * z;
+                            if(br < nbr)
+                                l.push_back((aoclsparse_int)br);
+                        }
+            }
+    }
+}
+void bell_chunk_lists(aoclsparse_int nbr, int ch, std::vector<aoclsparse_int> (&list)[8])
+{
+    for(auto &l : list)
+        l.clear();
+    for(aoclsparse_int b = 0; b < nbr; b++)
+        list[(b / ch) & 7].push_back(b);
+}
+void choose_bell_order(const std::vector<aoclsparse_int> &bcol, aoclsparse_int nbr, aoclsparse_int width, aoclsparse_int nbc, BellPlan &bp,
+                       std::vector<aoclsparse_int> &order)
+{
+    bp.xcd_chunk = 1, bp.order_len = 0, bp.model_fetches = bp.model_fetches_launch_order = 0.0;
+    bp.lattice[0] = bp.lattice[1] = bp.lattice[2] = 0, bp.region[0] = bp.region[1] = 0;
+    order.clear();
+    static const int cand[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20, 24, 32, 40, 48, 64};
+    if(nbr < 8 * 64 || nbc <= 0)
+        return;
+    std::vector<long long>      last((size_t)nbc);
+    std::vector<aoclsparse_int> list[8];
+    auto misses = [&]() {
+        std::fill(last.begin(), last.end(), LLONG_MIN / 2);
+        long long miss = 0, t0 = 0;
+        for(const auto &l : list) // (one L2 per XCD: the lists are independent; a jump of the clock separates them)
+        {
+            for(size_t p = 0; p < l.size(); p++)
+                for(aoclsparse_int s = 0; s < width; s++)
+                {
+                    const aoclsparse_int bc = bcol[(size_t)l[p] * width + s];
+                    if(bc < 0)
+                        break;
+                    miss += t0 + (long long)p - last[(size_t)bc] > BELL_L2_WINDOW;
+                    last[(size_t)bc] = t0 + (long long)p;
+                }
+            t0 += (long long)l.size() + 4 * BELL_L2_WINDOW;
+        }
+        return miss;
+    };
+    // every block row exactly once, and no XCD with more than 1.06 of its share (the longest list is the launch's length)
+    auto balanced = [&]() {
+        size_t total = 0, longest = 0;
+        for(const auto &l : list)
+            total += l.size(), longest = std::max(longest, l.size());
+        return total == (size_t)nbr && (double)longest <= 1.06 * (double)nbr / 8.0 + 1.0;
+    };
+    long long distinct = 0;
+    {
+        std::vector<char> seen((size_t)nbc, 0);
+        for(size_t i = 0; i < bcol.size(); i++)
+            if(bcol[i] >= 0 && !seen[(size_t)bcol[i]])
+                seen[(size_t)bcol[i]] = 1, distinct++;
+    }
+    if(distinct == 0)
+        return;
+    int forced = INT_MIN;
+    if(const char *e = std::getenv("AOCLSPARSE_MI355_BELL_XCD_CHUNK"))
+        forced = std::atoi(e);
+    bell_chunk_lists(nbr, 1, list);
+    const long long m1 = misses();
+    bp.model_fetches_launch_order = bp.model_fetches = (double)m1 / (double)distinct;
+    if(forced == 0)
+        return;
+    int       pick = 1;
+    long long mpick = m1;
+    if(forced >= 1 && forced <= nbr / 8)
+    {
+        bell_chunk_lists(nbr, pick = forced, list);
+        mpick = misses();
+    }
+    else
+    {
+        std::vector<long long> mc;
+        long long              best = m1;
+        for(int ch : cand)
+        {
+            if(ch > 1)
+                bell_chunk_lists(nbr, ch, list);
+            mc.push_back(ch == 1 ? m1 : (balanced() ? misses() : LLONG_MAX)), best = std::min(best, mc.back());
+        }
+        for(size_t i = 0; i < mc.size(); i++)
+            if((double)mc[i] <= 1.2 * (double)best)
+            {
+                pick = cand[i], mpick = mc[i];
+                break;
+            }
+        if((double)mpick > 0.9 * (double)m1) // nothing worth leaving launch order for
+            pick = 1, mpick = m1;
+        // the lattice sweep: regions of about 40 block rows (the next plane's neighbours then sit inside the window)
+        const BellLattice L = detect_bell_lattice(bcol, nbr, width);
+        if(L.n1 > 0 && L.n3 >= 4)
+        {
+            // the line in 1, 2, 4, 8, ... pieces (eight consecutive regions then cover whole lines: pieces of 5 or 6 on the 32-node line
+            // measured 6-8 % slower than pieces of 4 or 8) of about 6 block rows, b lines of them: about 40 block rows per region
+            int nsx = 1;
+            while(2 * nsx <= L.n1 && std::abs((double)L.n1 / (2 * nsx) - 6.0) <= std::abs((double)L.n1 / nsx - 6.0))
+                nsx *= 2;
+            const int a = (int)((L.n1 + nsx - 1) / nsx);
+            int       b = (int)std::max<aoclsparse_int>(1, std::min<aoclsparse_int>(L.n2, 40 / a));
+            const int ntiles = (int)((L.n2 + b - 1) / b);
+            b                = (int)((L.n2 + ntiles - 1) / ntiles); // (tiles of equal height: the XCDs' lists of equal length)
+            // z segments: as many as it takes for the regions to go round the eight XCDs evenly (segments of at least 2 planes)
+            const long long regions = (long long)nsx * ntiles;
+            int             nseg    = 1;
+            while(regions * nseg % 8 != 0 && 2 * nseg <= L.n3 / 2)
+                nseg *= 2;
+            bell_lattice_lists(L, nbr, nsx, b, nseg, list);
+            const long long ml = balanced() ? misses() : LLONG_MAX;
+            if(ml != LLONG_MAX && (forced == -1 || (double)ml < 0.8 * (double)mpick))
+            {
+                pick = 0, mpick = ml;
+                bp.lattice[0] = L.n1, bp.lattice[1] = L.n2, bp.lattice[2] = L.n3, bp.region[0] = a, bp.region[1] = b;
+                bp.region_cut[0] = nsx, bp.region_cut[1] = nseg;
+            }
+        }
+    }
+    bp.xcd_chunk = pick, bp.model_fetches = (double)mpick / (double)distinct;
+    if(pick == 1)
+        return;
+    if(pick > 1)
+        bell_chunk_lists(nbr, pick, list);
+    else
+        bell_lattice_lists(BellLattice{bp.lattice[0], bp.lattice[1], bp.lattice[2]}, nbr, bp.region_cut[0], bp.region[1], bp.region_cut[1], list);
+    size_t len = 0;
+    for(const auto &l : list)
+        len = std::max(len, l.size());
+    order.assign(8 * len, -1);
+    for(int x = 0; x < 8; x++)
+        for(size_t p = 0; p < list[x].size(); p++)
+            order[8 * p + x] = list[x][p];
+    bp.order_len = (aoclsparse_int)len;
+}
 } // namespace
 aoclsparse_status mi355::build_bell(const HostCsr &h, const DeviceCsr &d, SpmvPlan &plan, aoclsparse_matrix_data_type vt)
 {
@@ -316,6 +530,25 @@ aoclsparse_status mi355::build_bell(const HostCsr &h, const DeviceCsr &d, SpmvPl
         return aoclsparse_status_success;
     }
     bp.nbr = nbr, bp.width = width, bp.nblocks = nblk, bp.fill = fill;
+    // the order of the block rows over the XCDs: optional (without the list the kernels run in launch order)
+    try
+    {
+        std::vector<aoclsparse_int> order;
+        choose_bell_order(bcol, nbr, width, (aoclsparse_int)(((long long)h.n + BS - 1) / BS), bp, order);
+        if(bp.order_len > 0
+           && (bp.order.upload(order.data(), sizeof(aoclsparse_int) * order.size(), st) != aoclsparse_status_success
+               || hipStreamSynchronize(st) != hipSuccess))
+        {
+            (void)hipGetLastError();
+            bp.order.release();
+            bp.order_len = 0, bp.xcd_chunk = 1, bp.model_fetches = bp.model_fetches_launch_order;
+        }
+    }
+    catch(const std::bad_alloc &)
+    {
+        bp.order.release();
+        bp.order_len = 0, bp.xcd_chunk = 1, bp.model_fetches = bp.model_fetches_launch_order;
+    }
     bp.valid = true;
     return aoclsparse_status_success;
 }

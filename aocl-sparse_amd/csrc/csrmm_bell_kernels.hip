@@ -64,6 +64,25 @@ namespace
         return __builtin_isfinite(v);
     }
 
+    // Which block row and which column part a wavefront takes.  Without an order list: wavefront g of the launch takes block row g / wpr
+    // (wpr wavefronts per block row).  With BellPlan::order (build_bell's model of the eight L2s, csrmm_api.cpp): the dispatcher hands
+    // workgroup w to XCD w % 8, so the wavefronts of XCD x form a stream of their own -- wavefront 4 (w / 8) + wv of it takes position
+    // p = that / wpr of XCD x's list, order[8 p + x] (-1: the list of this XCD has ended).
+    __device__ __forceinline__ bool bell_place(unsigned w, int wv, int wpr, int nbr, const aoclsparse_int *__restrict__ order, int order_len,
+                                               int &br, int &cw)
+    {
+        if(order)
+        {
+            const long gx = (long)(w >> 3) * 4 + wv, p = gx / wpr;
+            cw            = (int)(gx % wpr);
+            br            = p < order_len ? __builtin_amdgcn_readfirstlane(order[p * 8 + (w & 7u)]) : -1;
+            return br >= 0 && br < nbr;
+        }
+        const long g = (long)w * 4 + wv;
+        br = (int)(g / wpr), cw = (int)(g % wpr);
+        return br < nbr;
+    }
+
     // Operand fragments: lane -> (i or j = lane % 16, k = lane / 16), one double per lane.  Where the 4 result registers of a
     // lane sit in the 16 x 16 tile is NOT assumed: every wavefront asks the instruction itself with two extra MFMAs
     // (D = [i] and D = [j]: A = column of row numbers x B = row of ones, and the transpose) -- 2 of ~114 per block row.
@@ -79,7 +98,7 @@ namespace
                                                                   const aoclsparse_int *__restrict__ bcol,
                                                                   const double *__restrict__ B, aoclsparse_int n, aoclsparse_int ldb,
                                                                   double beta, double *__restrict__ C, aoclsparse_int ldc,
-                                                                  int waves_per_row, int base, const aoclsparse_int *__restrict__ rp,
+                                                                  int waves_per_row, const aoclsparse_int *__restrict__ order, int order_len, int base, const aoclsparse_int *__restrict__ rp,
                                                                   const aoclsparse_int *__restrict__ ci, const double *__restrict__ cv)
     {
         // (block rows in launch order: giving every XCD a contiguous eighth of them -- the rule of the HBM-bound kernels here --
@@ -87,9 +106,8 @@ namespace
         // 0.951 ms in round 5, profiles/r4/bell_experiments.txt, profiles/r5/bell_experiments.txt)
         const int wv   = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         const int  wpr = waves_per_row & ~MM_DESCENDING; // (bit 30 of the word: workgroups in descending order, mm_order.hpp)
-        const long g   = (long)mm_linear_index(waves_per_row) * 4 + wv;
-        const int  br  = (int)(g / wpr), cw = (int)(g % wpr);
-        if(br >= nbr)
+        int br, cw;
+        if(!bell_place(mm_linear_index(waves_per_row), wv, wpr, nbr, order, order_len, br, cw))
             return;
         const int lane = threadIdx.x & 63, jl = lane & 15, kq = lane >> 4;
         const int j0   = cw * NT * 16;
@@ -380,14 +398,13 @@ namespace
                                                                       const aoclsparse_int *__restrict__ bcol,
                                                                       const double *__restrict__ B, aoclsparse_int n, aoclsparse_int ldb,
                                                                       double beta, double *__restrict__ C, aoclsparse_int ldc,
-                                                                      int waves_per_row, int base, const aoclsparse_int *__restrict__ rp,
+                                                                      int waves_per_row, const aoclsparse_int *__restrict__ order, int order_len, int base, const aoclsparse_int *__restrict__ rp,
                                                                       const aoclsparse_int *__restrict__ ci, const double *__restrict__ cv)
     {
         const int  wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         const int  wpr = waves_per_row & ~MM_DESCENDING;
-        const long g  = (long)mm_linear_index(waves_per_row) * 4 + wv;
-        const int  br = (int)(g / wpr), cw = (int)(g % wpr);
-        if(br >= nbr)
+        int br, cw;
+        if(!bell_place(mm_linear_index(waves_per_row), wv, wpr, nbr, order, order_len, br, cw))
             return;
         const int lane = threadIdx.x & 63, jl = lane & 15, kq = lane >> 4;
         const int j0   = cw * NT * 16;
@@ -575,8 +592,11 @@ aoclsparse_status launch_csrmm_bell(hipStream_t s, double alpha, aoclsparse_int 
         // per column and block; 1 / 2 / 3 / 4 tiles per wavefront at 256 columns: 2.06 / 1.90 / 1.89 / 2.31 ms with C read, 1.69 /
         // 1.58 / 1.53 / 1.69 overwriting (profiles/r4/bell_experiments.txt); the 32-column slab 0.25 / 0.23 with 1 / 2
         const int  nt = std::min(tiles, 2), wpr = (tiles + nt - 1) / nt;
-        const long waves = (long)bell.nbr * wpr;
-        const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+        // (with an order list every XCD has a stream of order_len * wpr wavefronts, 4 per workgroup, workgroups dealt to the XCDs in turn)
+        const aoclsparse_int *ord = bell.order_len > 0 ? bell.order.as<aoclsparse_int>() : nullptr;
+        const int  ordlen = ord ? bell.order_len : 0;
+        const long waves  = (long)bell.nbr * wpr;
+        const dim3 grid((unsigned)(ord ? 8 * (((long)ordlen * wpr + 3) / 4) : (waves + 3) / 4)), block(256);
         const bool full = n % (16 * nt) == 0 && k % 16 == 0;
         // 32 contiguous bytes per lane: 16-byte aligned columns (B aligned, ldb even) and a row count of B that is a multiple of 4
         const bool wide = reinterpret_cast<uintptr_t>(B) % 16 == 0 && ldb % 2 == 0 && k % 4 == 0;
@@ -586,13 +606,13 @@ aoclsparse_status launch_csrmm_bell(hipStream_t s, double alpha, aoclsparse_int 
     {                                                                                                                           \
         if(rcmode == 1)                                                                                                         \
             hipLaunchKernelGGL((csrmm_bell_mfma_col_kernel<NT, 1, FULL, WIDE>), grid, block, 0, s, alpha, m, k, bell.nbr, bell.width, \
-                               bell.val.as<double>(), bell.bcol.as<aoclsparse_int>(), B, n, ldb, beta, C, ldc, wpr, base, rp, ci, cv); \
+                               bell.val.as<double>(), bell.bcol.as<aoclsparse_int>(), B, n, ldb, beta, C, ldc, wpr, ord, ordlen, base, rp, ci, cv); \
         else if(rcmode == 2)                                                                                                    \
             hipLaunchKernelGGL((csrmm_bell_mfma_col_kernel<NT, 2, FULL, WIDE>), grid, block, 0, s, alpha, m, k, bell.nbr, bell.width, \
-                               bell.val.as<double>(), bell.bcol.as<aoclsparse_int>(), B, n, ldb, beta, C, ldc, wpr, base, rp, ci, cv); \
+                               bell.val.as<double>(), bell.bcol.as<aoclsparse_int>(), B, n, ldb, beta, C, ldc, wpr, ord, ordlen, base, rp, ci, cv); \
         else                                                                                                                    \
             hipLaunchKernelGGL((csrmm_bell_mfma_col_kernel<NT, 0, FULL, WIDE>), grid, block, 0, s, alpha, m, k, bell.nbr, bell.width, \
-                               bell.val.as<double>(), bell.bcol.as<aoclsparse_int>(), B, n, ldb, beta, C, ldc, wpr, base, rp, ci, cv); \
+                               bell.val.as<double>(), bell.bcol.as<aoclsparse_int>(), B, n, ldb, beta, C, ldc, wpr, ord, ordlen, base, rp, ci, cv); \
     } while(0)
         if(wide)
         {
@@ -617,8 +637,10 @@ aoclsparse_status launch_csrmm_bell(hipStream_t s, double alpha, aoclsparse_int 
     // tiles per wavefront: 4 (64 columns) when there are that many, else what the slab has (an even count in wide mode)
     const int nt  = tiles >= 4 ? 4 : (wide ? 2 : tiles);
     const int wpr = (tiles + nt - 1) / nt;
+    const aoclsparse_int *ord = bell.order_len > 0 ? bell.order.as<aoclsparse_int>() : nullptr;
+    const int  ordlen = ord ? bell.order_len : 0;
     const long waves  = (long)bell.nbr * wpr;
-    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    const dim3 grid((unsigned)(ord ? 8 * (((long)ordlen * wpr + 3) / 4) : (waves + 3) / 4)), block(256);
     // 16-byte accesses to C for the tile pairs of wide mode: 16-byte aligned rows of C
     const bool cw = wide && ldc % 2 == 0 && reinterpret_cast<uintptr_t>(C) % 16 == 0;
 #define MI355_BELL(NT, WIDE) MI355_BELL2(NT, WIDE, false)
@@ -628,13 +650,13 @@ aoclsparse_status launch_csrmm_bell(hipStream_t s, double alpha, aoclsparse_int 
     {                                                                                                                           \
         if(rcmode == 1)                                                                                                         \
             hipLaunchKernelGGL((csrmm_bell_mfma_kernel<NT, 1, WIDE, FULL, CWF>), grid, block, 0, s, alpha, m, k, bell.nbr, bell.width,       \
-                               bell.val.as<double>(), bell.bcol.as<aoclsparse_int>(), B, n, ldb, beta, C, ldc, wpr, base, rp, ci, cv); \
+                               bell.val.as<double>(), bell.bcol.as<aoclsparse_int>(), B, n, ldb, beta, C, ldc, wpr, ord, ordlen, base, rp, ci, cv); \
         else if(rcmode == 2)                                                                                                    \
             hipLaunchKernelGGL((csrmm_bell_mfma_kernel<NT, 2, WIDE, FULL, CWF>), grid, block, 0, s, alpha, m, k, bell.nbr, bell.width,       \
-                               bell.val.as<double>(), bell.bcol.as<aoclsparse_int>(), B, n, ldb, beta, C, ldc, wpr, base, rp, ci, cv); \
+                               bell.val.as<double>(), bell.bcol.as<aoclsparse_int>(), B, n, ldb, beta, C, ldc, wpr, ord, ordlen, base, rp, ci, cv); \
         else                                                                                                                    \
             hipLaunchKernelGGL((csrmm_bell_mfma_kernel<NT, 0, WIDE, FULL, CWF>), grid, block, 0, s, alpha, m, k, bell.nbr, bell.width,       \
-                               bell.val.as<double>(), bell.bcol.as<aoclsparse_int>(), B, n, ldb, beta, C, ldc, wpr, base, rp, ci, cv); \
+                               bell.val.as<double>(), bell.bcol.as<aoclsparse_int>(), B, n, ldb, beta, C, ldc, wpr, ord, ordlen, base, rp, ci, cv); \
     } while(0)
     const bool full = n % (16 * nt) == 0 && k % 16 == 0;
     if(wide && full)

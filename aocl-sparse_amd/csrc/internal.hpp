@@ -356,6 +356,15 @@ struct BellPlan
     long long      nblocks = 0; // stored (non-empty) blocks
     double         fill = 0.0; // nnz / (256 * nblocks)
     DeviceBuffer   val, bcol; // nbr * width * 256 values; nbr * width block columns
+    // Which XCD works through which block rows, in which order (build_bell's model of the eight L2s, csrmm_api.cpp): order[8 p + x] = the
+    // p-th block row of XCD x (-1 past the end of its list), order_len lists entries per XCD; order_len == 0: launch order.
+    DeviceBuffer   order;
+    aoclsparse_int order_len = 0;
+    int            xcd_chunk = 1; // chunked deal: consecutive block rows per XCD turn (1: launch order; 0: a lattice sweep)
+    aoclsparse_int lattice[3] = {0, 0, 0}; // lattice sweep: block rows per line, lines per plane, planes (else 0)
+    int            region[2]  = {0, 0}; // ... and the cross-section of an XCD's region (block rows along the line x lines)
+    int            region_cut[2] = {0, 0}; // ... pieces per line, segments of the plane range
+    double         model_fetches = 0.0, model_fetches_launch_order = 0.0; // modelled L2 misses per distinct B block row, chosen / launch order
 };
 
 // SpMV execution plan (CSR-Adaptive row blocks), see spmv_kernels.hip

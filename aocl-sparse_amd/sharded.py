@@ -186,17 +186,18 @@ def broadcast_handle(pkg, torch, dist, device, rank, world, A):
     # torch.distributed as the wire
     cpu_wire = _backend(dist) == "gloo"
     wire = "cpu" if cpu_wire else device
-    hdr = torch.zeros(53, dtype=torch.int64, device=wire)
+    NB = pkg.MM_STATE_BUFFERS
+    hdr = torch.zeros(40 + NB + 1, dtype=torch.int64, device=wire)
     ptrs = [None] * pkg.MM_STATE_BUFFERS
     if rank == 0:
         st, state, ptrs = A.mm_state_export()
         hdr[:40] = torch.tensor(list(state.scalars), dtype=torch.int64)
-        hdr[40:52] = torch.tensor(list(state.bytes), dtype=torch.int64)
-        hdr[52] = st
+        hdr[40:40 + NB] = torch.tensor(list(state.bytes), dtype=torch.int64)
+        hdr[40 + NB] = st
     dist.broadcast(hdr, 0)
     h = [int(x) for x in hdr.cpu().tolist()]
-    if h[52] != 0:
-        raise RuntimeError("aoclsparse_mi355_mm_state_export failed on rank 0: %s" % pkg.STATUS.get(h[52], h[52]))
+    if h[40 + NB] != 0:
+        raise RuntimeError("aoclsparse_mi355_mm_state_export failed on rank 0: %s" % pkg.STATUS.get(h[40 + NB], h[40 + NB]))
     held = []
     for i in range(pkg.MM_STATE_BUFFERS):
         nbytes = h[40 + i]
@@ -216,7 +217,7 @@ def broadcast_handle(pkg, torch, dist, device, rank, world, A):
         state = pkg.MmState()
         for i in range(40):
             state.scalars[i] = h[i]
-        for i in range(12):
+        for i in range(pkg.MM_STATE_BUFFERS):
             state.bytes[i] = h[40 + i]
         if torch.cuda.is_available():
             torch.cuda.synchronize()

@@ -161,7 +161,7 @@ DLL_PUBLIC aoclsparse_int aoclsparse_mi355_replicas_cloned(const aoclsparse_matr
  *           has placed in THIS process's device memory (received over whatever wire it uses): the buffers are copied device to
  *           device, the CSR arrays are copied back once to give the handle its host view, no analysis runs.  Every
  *           aoclsparse_* call works on the new handle; it carries an optimized mm hint. */
-#define AOCLSPARSE_MI355_MM_STATE_BUFFERS 12
+#define AOCLSPARSE_MI355_MM_STATE_BUFFERS 13
 #define AOCLSPARSE_MI355_MM_STATE_SCALARS 40
 typedef struct aoclsparse_mi355_mm_state_
 {
@@ -222,6 +222,12 @@ typedef struct aoclsparse_mi355_spmv_info_
     aoclsparse_int mm_bell_fill_permille; /* ... and 1000 * nnz / (256 * stored blocks) */
     aoclsparse_int tree_min; /* CSR-Adaptive, scalar order, no pinned kid, spmv_strict 0: rows with at least this many entries are summed
                                 by a wavefront tree (stated bound) instead of the reference's chain; 0: every row is the reference's order */
+    aoclsparse_int mm_bell_xcd_chunk; /* blocked-ELL csrmm, which XCD works through which block rows: chunks of this many consecutive block
+                                         rows dealt to the XCDs in turn (1 = launch order); 0: no copy, or the lattice sweep below */
+    aoclsparse_int mm_bell_model_fetches_permille; /* ... 1000 * modelled fabric fetches per B block row in that order ... */
+    aoclsparse_int mm_bell_model_fetches_launch_order_permille; /* ... and in launch order */
+    aoclsparse_int mm_bell_lattice_line, mm_bell_lattice_lines; /* lattice sweep (block columns at offsets 1, n1, n1 n2): n1, n2; else 0 */
+    aoclsparse_int mm_bell_region_a, mm_bell_region_b; /* ... the a x b block rows of the cross-section an XCD follows through the planes */
 } aoclsparse_mi355_spmv_info;
 DLL_PUBLIC aoclsparse_status aoclsparse_mi355_get_spmv_info(const aoclsparse_matrix     A,
                                                             aoclsparse_operation        op,

@@ -442,7 +442,7 @@ def test_mm_state_export_adopt_round_trip(which):
     import ctypes
     ctypes.memmove(ctypes.addressof(bad), ctypes_copy, len(ctypes_copy))
     bad.scalars[0] = 1
-    st, none = P.Matrix.mm_state_adopt(bad, [None] * 12)
+    st, none = P.Matrix.mm_state_adopt(bad, [None] * P.MM_STATE_BUFFERS)
     assert st != 0 and none is None
     # ... and so is a state whose buffers are smaller than the plans its scalars announce (a truncated / mismatched transfer):
     # every announced plan, one mutation each -- the receiver refuses BEFORE any kernel could index past a buffer

@@ -2,6 +2,8 @@
 (round 5's epoch tag was frozen by the capture), and the same handle under out-of-order residency (pieces meet through
 arrival counters, nobody waits)."""
 import ctypes
+import os
+import sys
 
 import numpy as np
 import pytest
@@ -10,6 +12,8 @@ import oracle
 from util import EPS64, abs_row_sums, pkg, random_csr
 
 pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+import standins  # noqa: E402
 
 torch = pytest.importorskip("torch")
 P = pkg()
@@ -280,3 +284,147 @@ def test_two_level_trsv_after_update_values(forced_chunks):
             torch.cuda.synchronize()
             assert A.trsv_info(P.FILL_LOWER).schedule == 5
         assert np.array_equal(xd.cpu().numpy(), xr), rnd
+
+
+# --------------------------------------------------------------------------------------------------
+# blocked-ELL MFMA csrmm: which XCD works through which block rows (BellPlan::order)
+# --------------------------------------------------------------------------------------------------
+def _bell_handle(rp, ci, v, m, forced):
+    """mm hint + optimize with AOCLSPARSE_MI355_BELL_XCD_CHUNK (read at analysis time) forced / unset"""
+    old = os.environ.pop("AOCLSPARSE_MI355_BELL_XCD_CHUNK", None)
+    if forced is not None:
+        os.environ["AOCLSPARSE_MI355_BELL_XCD_CHUNK"] = str(forced)
+    try:
+        A = P.Matrix(0, m, m, rp, ci, v)
+        d = P.Descr()
+        assert L.aoclsparse_set_mm_hint(A.h, P.OP_NONE, d.h, 10) == 0 and L.aoclsparse_optimize(A.h) == 0
+    finally:
+        os.environ.pop("AOCLSPARSE_MI355_BELL_XCD_CHUNK", None)
+        if old is not None:
+            os.environ["AOCLSPARSE_MI355_BELL_XCD_CHUNK"] = old
+    assert A.spmv_info().mm_bell_width > 0, "the blocked-ELL copy was not built"
+    return A, d
+
+
+def _same_bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.int64), np.ascontiguousarray(b).view(np.int64))
+
+
+@pytest.mark.parametrize("dims,keep,forced", [((12, 16, 16), 1.0, -1), ((12, 16, 16), 1.0, 3), ((12, 16, 16), 1.0, 0), ((16, 24, 20), 0.75, -1),
+                                              ((8, 16, 27), 1.0, -1), ((8, 16, 27), 0.75, 5), ((40, 1, 24), 1.0, -1), ((9, 14, 13), 1.0, None)])
+def test_blocked_ell_block_row_order_over_the_xcds_same_bits(dims, keep, forced):
+    """The order in which the XCDs work through the block rows is a plan of its own (chunks dealt in turn, or a structured grid's
+    regions followed through the planes: csrmm_api.cpp choose_bell_order).  Every block row is still computed exactly once by the same
+    chain: oracle.dcsrmm's bits (csrmm.hpp:36-90) in every order -- forced chunks that do not divide the block rows, the lattice sweep
+    with lines cut into equal and unequal pieces (16, 20: 4 / 5 block rows; 27: 6, 7, 7, 7), with the plane range cut in two
+    (16 x 24 x 20: 12 regions per segment), on a 2-D grid (one line per plane), launch order without a list, and whatever the model
+    picks for a grid too small to go round the XCDs evenly (9 x 14 x 13); both layouts, 1 / 2 / 4 / 8 wavefronts per block row and a
+    column count that is no whole tile, both beta = 0 modes and beta != 0."""
+    m, rp, ci, v = standins.block_dense(*dims, keep=keep, seed=31)
+    A, d = _bell_handle(rp, ci, v, m, forced)
+    info = A.spmv_info()
+    if forced == -1:
+        # z runs fastest in the stand-in's numbering: the line is dims[2] block rows, a plane dims[1] lines
+        assert (info.mm_bell_xcd_chunk, info.mm_bell_lattice_line) == (0, dims[2]), (info.mm_bell_xcd_chunk, info.mm_bell_lattice_line)
+        assert info.mm_bell_lattice_lines == dims[1]
+        assert info.mm_bell_region_a * info.mm_bell_region_b >= 1
+    elif forced is None:
+        assert info.mm_bell_xcd_chunk >= 0
+    elif forced == 0:
+        assert (info.mm_bell_xcd_chunk, info.mm_bell_lattice_line) == (1, 0)
+    else:
+        assert (info.mm_bell_xcd_chunk, info.mm_bell_lattice_line) == (forced, 0)
+    rng = np.random.default_rng(8)
+    L.aoclsparse_mi355_set_pointer_mode(P.PTR_DEVICE)
+    try:
+        for order, n, alpha, beta in ((P.ORDER_ROW, 256, 1.0, 0.0), (P.ORDER_ROW, 64, -0.5, 1.25), (P.ORDER_ROW, 40, 2.0, 0.0),
+                                      (P.ORDER_ROW, 130, 1.0, 0.0), (P.ORDER_COLUMN, 64, 1.0, 0.0), (P.ORDER_COLUMN, 21, 1.5, 0.5)):
+            B, C0 = rng.uniform(-1, 1, m * n), rng.uniform(-1, 1, m * n)
+            if order == P.ORDER_ROW:
+                Bc = np.ascontiguousarray(B.reshape(m, n).T).ravel()
+                Cc = np.ascontiguousarray(C0.reshape(m, n).T).ravel()
+            else:
+                Bc, Cc = B, C0
+            so, Cr = oracle.dcsrmm("col", alpha, 0, v, ci, rp, m, Bc, n, m, beta, Cc, m)
+            assert so == 0
+            ref = Cr.reshape(n, m).T if order == P.ORDER_ROW else Cr
+            ld = n if order == P.ORDER_ROW else m
+            for overwrite in ((False, True) if beta == 0.0 else (False,)):
+                Cd = dev(C0)
+                assert L.aoclsparse_mi355_set_csrmm_beta0_overwrite(1 if overwrite else 0) == 0
+                try:
+                    assert P.dcsrmm(P.OP_NONE, alpha, A, d, order, dev(B), n, ld, beta, Cd, ld) == 0
+                    torch.cuda.synchronize()
+                finally:
+                    assert L.aoclsparse_mi355_set_csrmm_beta0_overwrite(0) == 0
+                got = Cd.cpu().numpy().reshape(m, n) if order == P.ORDER_ROW else Cd.cpu().numpy()
+                assert _same_bits(got, ref), (dims, keep, forced, order, n, alpha, beta, overwrite)
+    finally:
+        L.aoclsparse_mi355_set_pointer_mode(P.PTR_AUTO)
+
+
+def test_blocked_ell_order_is_chosen_by_the_model_and_travels_with_the_state():
+    """32 x 32 nodes per plane, 8 planes (131,072 rows): a plane of 1,024 block rows is more than an XCD keeps in its L2, so launch
+    order fetches every stretch of B about five times (the model says so) and the lattice sweep -- 4 x 10 block rows of the
+    cross-section followed through the planes -- under two: optimize picks it unasked.  A matrix whose block columns sit at no
+    constant offsets (the same grid with its nodes renumbered at random) gets no lattice.  The list is part of the exported
+    state: an adopted handle has it and returns the same bits (64 columns against oracle.dcsrmm)."""
+    from aocl_sparse_amd.sharded import _DeviceView
+    m, rp, ci, v = standins.block_dense(8, 32, 32, seed=41)
+    A, d = _bell_handle(rp, ci, v, m, None)
+    info = A.spmv_info()
+    assert (info.mm_bell_xcd_chunk, info.mm_bell_lattice_line, info.mm_bell_lattice_lines) == (0, 32, 32)
+    assert info.mm_bell_model_fetches_launch_order_permille > 4000 and info.mm_bell_model_fetches_permille < 2000
+    st, state, ptrs = A.mm_state_export()
+    assert st == 0 and state.bytes[12] > 0
+    held = [torch.as_tensor(_DeviceView(p, n), device="cuda").clone() if n else None for p, n in zip(ptrs, list(state.bytes))]
+    torch.cuda.synchronize()
+    st, R = P.Matrix.mm_state_adopt(state, [t.data_ptr() if t is not None else None for t in held])
+    assert st == 0
+    del held
+    ir = R.spmv_info()
+    assert (ir.mm_bell_width, ir.mm_bell_xcd_chunk) == (info.mm_bell_width, 0)
+    # a truncated order list is refused
+    import ctypes as ct
+    bad = P.MmState()
+    ct.memmove(ct.addressof(bad), bytes(state), ct.sizeof(bad))
+    bad.bytes[12] //= 2
+    held = [torch.as_tensor(_DeviceView(p, n), device="cuda").clone() if n else None for p, n in zip(ptrs, list(state.bytes))]
+    st, none = P.Matrix.mm_state_adopt(bad, [t.data_ptr() if t is not None else None for t in held])
+    assert st == 5 and none is None
+    del held
+    n = 64
+    rng = np.random.default_rng(3)
+    B, C0 = rng.uniform(-1, 1, m * n), rng.uniform(-1, 1, m * n)
+    so, Cr = oracle.dcsrmm("col", 1.0, 0, v, ci, rp, m, np.ascontiguousarray(B.reshape(m, n).T).ravel(), n, m, 0.0,
+                           np.ascontiguousarray(C0.reshape(m, n).T).ravel(), m)
+    assert so == 0
+    for H in (A, R):
+        Cd = dev(C0)
+        assert P.dcsrmm(P.OP_NONE, 1.0, H, d, P.ORDER_ROW, dev(B), n, n, 0.0, Cd, n) == 0
+        torch.cuda.synchronize()
+        assert _same_bits(Cd.cpu().numpy().reshape(m, n), Cr.reshape(n, m).T)
+    # the same grid, nodes renumbered at random: no constant offsets, no lattice (whatever chunk the model keeps, the bits stay)
+    nodes = m // 16
+    perm = np.random.default_rng(1).permutation(nodes)
+    rowp = (perm[:, None] * 16 + np.arange(16)[None, :]).ravel()  # new index of old row i
+    inv = np.empty(m, dtype=np.int64)
+    inv[rowp] = np.arange(m)
+    lens = np.diff(rp)[inv]
+    rp2 = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ci2 = np.empty_like(ci)
+    v2 = np.empty_like(v)
+    for i in range(m):
+        a, b, o = rp[inv[i]], rp[inv[i] + 1], rp2[i]
+        c = rowp[ci[a:b]]
+        s = np.argsort(c, kind="stable")
+        ci2[o:o + b - a], v2[o:o + b - a] = c[s], v[a:b][s]
+    A2, d2 = _bell_handle(rp2, ci2, v2, m, None)
+    i2 = A2.spmv_info()
+    assert i2.mm_bell_lattice_line == 0 and i2.mm_bell_xcd_chunk >= 1
+    so, Cr2 = oracle.dcsrmm("col", 1.0, 0, v2, ci2, rp2, m, np.ascontiguousarray(B.reshape(m, n).T).ravel(), n, m, 0.0,
+                            np.ascontiguousarray(C0.reshape(m, n).T).ravel(), m)
+    Cd = dev(C0)
+    assert P.dcsrmm(P.OP_NONE, 1.0, A2, d2, P.ORDER_ROW, dev(B), n, n, 0.0, Cd, n) == 0
+    torch.cuda.synchronize()
+    assert _same_bits(Cd.cpu().numpy().reshape(m, n), Cr2.reshape(n, m).T)
