@@ -988,7 +988,8 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
                                  d->ind.as<aoclsparse_int>(), d->ptr.as<aoclsparse_int>(), static_cast<const T *>(dB),
                                  n, ldb, beta, static_cast<T *>(dC), ldc, colmaj ? nullptr : grp, colmaj ? 0 : ngrp,
                                  grouped ? p->mm.max_rows : 0, !colmaj && p && p->mm.row_runs,
-                                 !colmaj && p && p->mm.row_runs && p->mm.band > 0 ? p->mm.run_order.as<aoclsparse_int>() : nullptr);
+                                 !colmaj && p && p->mm.row_runs && p->mm.band > 0 ? p->mm.run_order.as<aoclsparse_int>() : nullptr, 0,
+                                 !colmaj && p && p->mm.row_runs ? p->mm.band : 0);
     }
     return st == aoclsparse_status_success ? finish() : st;
 }

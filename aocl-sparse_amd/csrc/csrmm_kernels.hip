@@ -1405,7 +1405,8 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
                                aoclsparse_int /*k*/, const T *val, const aoclsparse_int *col,
                                const aoclsparse_int *row_ptr, const T *B, aoclsparse_int n,
                                aoclsparse_int ldb, T beta, T *C, aoclsparse_int ldc, const aoclsparse_int *grp,
-                               aoclsparse_int ngroups, int group_rows, bool row_runs, const aoclsparse_int *run_order, int kt_lanes)
+                               aoclsparse_int ngroups, int group_rows, bool row_runs, const aoclsparse_int *run_order, int kt_lanes,
+                               aoclsparse_int band)
 {
     const bool kt = kt_lanes > 0;
     if(m <= 0 || n <= 0)
@@ -1429,7 +1430,18 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
     // XCD-contiguous row order (every kernel): each XCD's L2 then serves the B rows its rows share.
     // Row-major n=256 on the 1000^2 Laplacian: 0.96 vs 1.21 ms.
     constexpr bool xcd = true;
+    // Banded matrices (detect_row_runs: most rows reach `band` columns right of the diagonal -- a grid numbered line by line), row-per-
+    // wavefront kernels: chunks of band / 8 rows are DEALT to the XCDs in turn, so that rows i and i +- band meet in one L2 (a line is one
+    // round of the deal) while all eight XCDs stay inside the same line of B and C.  1000^2 Laplacian, C read, 256 / 128 columns, cold:
+    // a contiguous eighth per XCD 1.19 / 0.61 ms, chunks of 32 workgroups 1.085 / 0.57; chunks that put row i +- band on the NEXT XCD
+    // (10, 12, 18, 20, 24, 40 workgroups) 1.30-1.34 / 0.68-0.69 (profiles/r6/mm_deal_experiments.txt).
+    int  deal = 0; // workgroups per XCD turn (0: a contiguous eighth per XCD)
     auto grid_x = [&](int nbx, int &chunk) {
+        if(deal > 0)
+        {
+            chunk = MM_DEAL | deal;
+            return (nbx + 8 * deal - 1) / (8 * deal) * (8 * deal);
+        }
         chunk = xcd ? (nbx + 7) / 8 : 0;
         return xcd ? chunk * 8 : nbx;
     };
@@ -1512,6 +1524,13 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
         }
         else if(vec && n >= 128)
         {
+            if(band >= 256 && readc)
+            {
+                // 4 rows per workgroup; a multiple of 4 workgroups when there are that many (31.25 -> 32 measured better than 31)
+                deal = (int)((band + 16) / 32);
+                if(deal >= 8)
+                    deal = (deal + 2) / 4 * 4;
+            }
             const int gx = grid_x((m + 3) / 4, chunk);
             bool      wide = false;
             if constexpr(std::is_same<T, float>::value)
@@ -1787,7 +1806,8 @@ aoclsparse_status launch_csrmm_colpair(hipStream_t s, int base, T alpha, aoclspa
                                                aoclsparse_int, const T *, const aoclsparse_int *,             \
                                                const aoclsparse_int *, const T *, aoclsparse_int,             \
                                                aoclsparse_int, T, T *, aoclsparse_int, const aoclsparse_int *, \
-                                               aoclsparse_int, int, bool, const aoclsparse_int *, int);       \
+                                               aoclsparse_int, int, bool, const aoclsparse_int *, int,        \
+                                               aoclsparse_int);                                               \
     template aoclsparse_status launch_scale_dense<T>(hipStream_t, aoclsparse_order, T *, aoclsparse_int,     \
                                                      aoclsparse_int, aoclsparse_int, T);                     \
     template aoclsparse_status launch_relayout<T>(hipStream_t, bool, const T *, T *, aoclsparse_int,         \
@@ -1830,5 +1850,5 @@ extern "C" aoclsparse_status mi355_dcsrmm(void *stream, aoclsparse_int order, ao
     if((order != aoclsparse_order_row && order != aoclsparse_order_column) || (base != 0 && base != 1))
         return aoclsparse_status_invalid_value;
     return mi355::launch_csrmm<double>((hipStream_t)stream, (aoclsparse_order)order, base, alpha, m, k, val, col,
-                                       row_ptr, B, n, ldb, beta, C, ldc, nullptr, 0, 0);
+                                       row_ptr, B, n, ldb, beta, C, ldc, nullptr, 0, 0, false, nullptr, 0, 0);
 }

@@ -396,6 +396,7 @@ struct SpmvPlan
 // Direction of the NEXT csrmm launches of the calling thread (set by csrmm_api.cpp right before it dispatches; the launchers put it
 // into bit 30 of the kernels' XCD-chunk word).  0: ascending.
 constexpr int MM_DESCENDING = 0x40000000;
+constexpr int MM_DEAL       = 0x20000000; // the chunk of the word counts blocks per XCD TURN (chunks dealt round-robin), not per XCD
 int  &mm_direction_word();
 
 // TRSV plan of one (triangle, op) pair (trsv_api.cpp / trsv_kernels.hip): the strict triangle
@@ -986,7 +987,7 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
                                aoclsparse_int n, aoclsparse_int ldb, T beta, T *C,
                                aoclsparse_int ldc, const aoclsparse_int *grp = nullptr, aoclsparse_int ngroups = 0,
                                int group_rows = 0, bool row_runs = false,
-                               const aoclsparse_int *run_order = nullptr, int kt_lanes = 0);
+                               const aoclsparse_int *run_order = nullptr, int kt_lanes = 0, aoclsparse_int band = 0);
 // column-major detour, handles with row groups: row-major B scratch in, column-major C written directly (no C copies)
 template <typename T>
 bool csrmm_groups_ccol_applies(aoclsparse_int n, aoclsparse_int ldb, const T *B);

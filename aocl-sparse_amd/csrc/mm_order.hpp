@@ -19,8 +19,13 @@ __device__ __forceinline__ unsigned mm_linear_index(int word)
 }
 __device__ __forceinline__ int mm_block_index(int word)
 {
-    const int      chunk = word & ~MM_DESCENDING;
+    const int      chunk = word & ~(MM_DESCENDING | MM_DEAL);
     const unsigned bi    = mm_linear_index(word);
+    if(word & MM_DEAL) // chunks of `chunk` consecutive blocks dealt to the XCDs in turn (gridDim.x is a multiple of 8 * chunk)
+    {
+        const unsigned j = bi >> 3;
+        return (int)(((j / chunk) * 8u + (bi & 7u)) * chunk + j % chunk);
+    }
     return chunk > 0 ? (int)(bi & 7) * chunk + (int)(bi >> 3) : (int)bi;
 }
 
