@@ -16,19 +16,21 @@ L.aoclsparse_mi355_set_pointer_mode(pkg.PTR_DEVICE)
 B = torch.rand(m * n, dtype=torch.float64, device="cuda") * 2 - 1
 C = torch.zeros(m * n, dtype=torch.float64, device="cuda")
 flush = torch.ones(1 << 28, dtype=torch.float32, device="cuda")
+ORD = pkg.ORDER_COLUMN if len(sys.argv) > 3 and sys.argv[3] == "col" else pkg.ORDER_ROW
+LD = m if ORD == pkg.ORDER_COLUMN else n
 res = {"deal": os.environ.get("MM_DEAL_EXP"), "cols": n, "grid": g}
 for ow in (0, 1):
     L.aoclsparse_mi355_set_csrmm_beta0_overwrite(ow)
     for _ in range(3):
-        assert pkg.dcsrmm(pkg.OP_NONE, 1.0, A, d, pkg.ORDER_ROW, B, n, n, 0.0, C, n) == 0
+        assert pkg.dcsrmm(pkg.OP_NONE, 1.0, A, d, ORD, B, n, LD, 0.0, C, LD) == 0
     torch.cuda.synchronize(); pkg.timer_start()
     for _ in range(20):
-        pkg.dcsrmm(pkg.OP_NONE, 1.0, A, d, pkg.ORDER_ROW, B, n, n, 0.0, C, n)
+        pkg.dcsrmm(pkg.OP_NONE, 1.0, A, d, ORD, B, n, LD, 0.0, C, LD)
     res["overwrite_ms" if ow else "c_read_ms"] = round(pkg.timer_stop() / 20, 4)
     cold = []
     for _ in range(6):
         flush.add_(1.0); torch.cuda.synchronize(); pkg.timer_start()
-        pkg.dcsrmm(pkg.OP_NONE, 1.0, A, d, pkg.ORDER_ROW, B, n, n, 0.0, C, n)
+        pkg.dcsrmm(pkg.OP_NONE, 1.0, A, d, ORD, B, n, LD, 0.0, C, LD)
         cold.append(pkg.timer_stop())
     res["overwrite_cold_ms" if ow else "c_read_cold_ms"] = round(float(np.median(cold)), 4)
 res["checksum"] = float(C.sum().item())
