@@ -335,6 +335,8 @@ def leg_numbers(full):
         b = mm["blocked"]
         n["csrmm_blocked_mfma_ms"] = b.get("mfma_ms")
         n["csrmm_blocked_mfma_col_ms"] = b.get("mfma_col_ms")
+        n["csrmm_blocked_mfma_tflops"] = b["cases"][0]["mfma"].get("tflops")
+        n["csrmm_blocked_mfma_overwrite_tflops"] = (b["cases"][0]["mfma"].get("overwrite") or {}).get("tflops")
         n["csrmm_blocked_parity"] = b.get("parity_ok")
     tr = legs.get("trsv") or {}
     if tr.get("schedules"):
@@ -1325,6 +1327,22 @@ def main():
                              "bell_width": int(inf.mm_bell_width), "tile_fill": inf.mm_bell_fill_permille / 1000.0,
                              "roofline": roofline(csrmm_bytes(mb, mb, nz, ncols, True), ms),
                              "bit_exact_4_columns": bool(np.array_equal(got, Cr))}
+                if kind == "mfma":
+                    # which XCD works through which block rows (round 6: csrmm_api.cpp choose_bell_order) and the opt-in mode that does
+                    # not read C, where the kernel is bound by the matrix pipe rather than by the fabric
+                    ent[kind]["block_row_order"] = {
+                        "xcd_chunk": int(inf.mm_bell_xcd_chunk), "lattice": [int(inf.mm_bell_lattice_line), int(inf.mm_bell_lattice_lines)],
+                        "region": [int(inf.mm_bell_region_a), int(inf.mm_bell_region_b)],
+                        "model_fetches_per_b_block_row": inf.mm_bell_model_fetches_permille / 1000.0,
+                        "model_fetches_launch_order": inf.mm_bell_model_fetches_launch_order_permille / 1000.0}
+                    assert L.aoclsparse_mi355_set_csrmm_beta0_overwrite(1) == 0
+                    try:
+                        assert call() == 0
+                        ms_ow = float(np.mean(timed_laps(pkg, call, 10, 2)))
+                    finally:
+                        assert L.aoclsparse_mi355_set_csrmm_beta0_overwrite(0) == 0
+                    ent[kind]["overwrite"] = {"ms": round(ms_ow, 5), "tflops": round(2.0 * nz * ncols / ms_ow / 1e9, 2),
+                                              "frac_of_sustained": round(2.0 * nz * ncols / ms_ow / 1e9 / FP64_MFMA_SUSTAINED_TFLOPS, 4)}
                 del Ab
             # the same matrix with column-major operands (the layout the column shards are contiguous in): all columns and the
             # 32-column slab of an 8-rank run -> the projected efficiency of configs[3]'s "blocked-ELL MFMA tiles, B column-sharded"
