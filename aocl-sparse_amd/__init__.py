@@ -59,7 +59,7 @@ class TrsvInfo(ctypes.Structure):
                                       "model_block_us", "schedule")]
 
 
-MM_STATE_BUFFERS = 13
+MM_STATE_BUFFERS = 14
 
 
 class MmState(ctypes.Structure):
@@ -480,7 +480,7 @@ class Matrix:
         return self
 
     def mm_state_export(self):
-        """-> (status, MmState, [12 device pointers]) : aoclsparse_mi355_mm_state_export"""
+        """-> (status, MmState, [MM_STATE_BUFFERS device pointers]) : aoclsparse_mi355_mm_state_export"""
         st = MmState()
         ptrs = (c_void_p * MM_STATE_BUFFERS)()
         rc = lib().aoclsparse_mi355_mm_state_export(self.h, byref(st), ctypes.cast(ptrs, c_void_p))
@@ -488,7 +488,7 @@ class Matrix:
 
     @classmethod
     def mm_state_adopt(cls, state, device_ptrs, double=True):
-        """device_ptrs: 12 device addresses (int / None) in THIS process's device memory -> (status, Matrix or None)"""
+        """device_ptrs: MM_STATE_BUFFERS device addresses (int / None) in THIS process's device memory -> (status, Matrix or None)"""
         ptrs = (c_void_p * MM_STATE_BUFFERS)(*[c_void_p(p) if p else None for p in device_ptrs])
         h = c_void_p()
         rc = lib().aoclsparse_mi355_mm_state_adopt(byref(h), byref(state), ctypes.cast(ptrs, c_void_p))

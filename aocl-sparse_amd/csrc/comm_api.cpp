@@ -45,10 +45,11 @@ namespace
         case 10: return &p.bell.val;
         case 11: return &p.bell.bcol;
         case 12: return &p.bell.order;
+        case 13: return &p.mm.slab_blocks;
         default: return nullptr;
         }
     }
-    static_assert(AOCLSPARSE_MI355_MM_STATE_BUFFERS == 13, "state table and header disagree");
+    static_assert(AOCLSPARSE_MI355_MM_STATE_BUFFERS == 14, "state table and header disagree");
 
     enum
     {
@@ -82,6 +83,7 @@ namespace
         S_BELL_FILL_BITS,
         S_BELL_ORDER_LEN,
         S_BELL_XCD_CHUNK,
+        S_SLAB_NBLOCKS,
         S_COUNT
     };
     static_assert(S_COUNT <= AOCLSPARSE_MI355_MM_STATE_SCALARS, "scalar table too small");
@@ -102,6 +104,7 @@ namespace
         s[S_BELL] = p.bell.valid, s[S_BELL_NBR] = p.bell.nbr, s[S_BELL_WIDTH] = p.bell.width, s[S_BELL_NBLOCKS] = p.bell.nblocks;
         std::memcpy(&s[S_BELL_FILL_BITS], &p.bell.fill, sizeof(double));
         s[S_BELL_ORDER_LEN] = p.bell.order_len, s[S_BELL_XCD_CHUNK] = p.bell.xcd_chunk;
+        s[S_SLAB_NBLOCKS] = p.mm.slab_nblocks;
     }
 
     bool state_ok(const aoclsparse_mi355_mm_state &st)
@@ -127,6 +130,8 @@ namespace
         if(s[S_HEAVY_FIRST] && b[4] < 4 * I * nb)
             return false;
         if(s[S_RUNS] && s[S_BAND] > 0 && b[5] < I * ((m + 7) / 8))
+            return false;
+        if(s[S_SLAB_NBLOCKS] < 0 || s[S_SLAB_NBLOCKS] > m || (s[S_SLAB_NBLOCKS] > 0 && (!s[S_RUNS] || s[S_BAND] <= 0 || b[13] < 2 * I * (s[S_SLAB_NBLOCKS] + 1))))
             return false;
         if(s[S_BAND] < 0 || s[S_NGROUPS] < 0 || s[S_NGROUPS] > m || s[S_MAX_ROWS] < 0 || s[S_MAX_ROWS] > 64)
             return false;
@@ -183,6 +188,7 @@ namespace
         g.max_rows = (int)s[S_MAX_ROWS], g.valid = s[S_GROUPS_VALID] != 0, g.pairs = s[S_PAIRS] != 0;
         g.npairs = (aoclsparse_int)s[S_NPAIRS], g.nsingles = (aoclsparse_int)s[S_NSINGLES];
         g.win = s[S_WIN] != 0, g.win_rows = (int)s[S_WIN_ROWS];
+        g.slab_nblocks = (aoclsparse_int)s[S_SLAB_NBLOCKS];
         BellPlan &b = p.bell;
         b.tried = true, b.valid = s[S_BELL] != 0, b.nbr = (aoclsparse_int)s[S_BELL_NBR], b.width = (aoclsparse_int)s[S_BELL_WIDTH];
         b.nblocks = s[S_BELL_NBLOCKS];

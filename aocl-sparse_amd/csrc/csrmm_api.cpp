@@ -185,6 +185,35 @@ aoclsparse_status detect_row_runs(const HostCsr &h, SpmvPlan &plan)
         return aoclsparse_status_memory_error;
     }
     g.band = band;
+    // row blocks along the lines of the band for the narrow kernel: 8 per line, as long as each fits the kernel's LDS tile
+    g.slab_nblocks = 0;
+    try
+    {
+        const aoclsparse_int tile = plan.tile & ~1;
+        std::vector<aoclsparse_int> blk;
+        bool                        fits = tile >= 512;
+        for(aoclsparse_int q0 = 0; q0 < h.m && fits; q0 += band)
+            for(int k = 0; k < 8 && fits; k++)
+            {
+                const aoclsparse_int ra = q0 + (aoclsparse_int)((long long)band * k / 8), rb = q0 + (aoclsparse_int)((long long)band * (k + 1) / 8);
+                if(ra >= h.m)
+                    break;
+                const aoclsparse_int re = std::min(rb, h.m);
+                fits = h.ptr[re] - h.ptr[ra] <= tile && re - ra <= spmv_maxrows(tile);
+                blk.push_back(ra), blk.push_back(h.ptr[ra] - h.base);
+            }
+        if(fits && !blk.empty())
+        {
+            const aoclsparse_int nb = (aoclsparse_int)(blk.size() / 2);
+            blk.push_back(h.m), blk.push_back(h.ptr[h.m] - h.base);
+            if(g.slab_blocks.upload(blk.data(), sizeof(aoclsparse_int) * blk.size(), Runtime::get().stream()) == aoclsparse_status_success)
+                g.slab_nblocks = nb;
+        }
+    }
+    catch(const std::bad_alloc &)
+    {
+        g.slab_nblocks = 0; // (optional: the SpMV plan's row blocks serve the kernel)
+    }
     return aoclsparse_status_success;
 }
 
@@ -898,7 +927,7 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
         if(st != aoclsparse_status_success)
             return st;
     }
-    if(p && !colmaj && !p->mm.valid && !p->mm.runs_tried && n >= 128)
+    if(p && !colmaj && !p->mm.valid && !p->mm.runs_tried) // (n >= 128: the row-run kernel and the dealt order; narrower: the line blocks)
     {
         std::unique_lock<std::shared_mutex> w(A->guard);
         st = detect_row_runs(tr ? *A->trans : A->user, *p);
@@ -959,10 +988,17 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
         }
         else if(!colmaj && !grouped && p && p->valid && p->nblocks > 0
                 && csrmm_tiled_applies<T>(n, ldb, ldc, static_cast<const T *>(dB), static_cast<const T *>(dC)))
-            // narrow row-major operands (a multi-GPU column slab): row blocks of the SpMV plan, A staged in LDS
+        {
+            // narrow row-major operands (a multi-GPU column slab): row blocks of the SpMV plan -- or, on a banded matrix, the blocks that
+            // follow its lines -- A staged in LDS
+            // (1000^2 Laplacian, 32 columns, same box: 0.163 -> 0.151 ms with C read, 0.1255 -> 0.1172 overwritten; 64 columns unchanged)
+            const bool lines = p->mm.row_runs && p->mm.band > 0 && p->mm.slab_nblocks > 0;
             st = launch_csrmm_tiled<T>(rt.stream(), d->base, alpha, d->val.as<T>(), d->ind.as<aoclsparse_int>(),
-                                       d->ptr.as<aoclsparse_int>(), p->rowblocks.as<aoclsparse_int>(), p->nblocks, p->tile,
-                                       p->max_row_nnz, static_cast<const T *>(dB), n, ldb, beta, static_cast<T *>(dC), ldc);
+                                       d->ptr.as<aoclsparse_int>(),
+                                       lines ? p->mm.slab_blocks.as<aoclsparse_int>() : p->rowblocks.as<aoclsparse_int>(),
+                                       lines ? p->mm.slab_nblocks : p->nblocks, p->tile, p->max_row_nnz, static_cast<const T *>(dB), n, ldb,
+                                       beta, static_cast<T *>(dC), ldc, 0, lines);
+        }
         else if(on_mfma_col)
         {
             // block-dense matrix, column-major operands: the transposed MFMA product, C stored in 128-byte column segments

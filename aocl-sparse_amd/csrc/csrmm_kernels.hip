@@ -1685,15 +1685,17 @@ template <typename T>
 aoclsparse_status launch_csrmm_tiled(hipStream_t s, int base, T alpha, const T *val, const aoclsparse_int *col,
                                      const aoclsparse_int *row_ptr, const aoclsparse_int *blocks, aoclsparse_int nblocks,
                                      int tile, aoclsparse_int max_row_nnz, const T *B, aoclsparse_int n, aoclsparse_int ldb,
-                                     T beta, T *C, aoclsparse_int ldc, int kt_lanes)
+                                     T beta, T *C, aoclsparse_int ldc, int kt_lanes, bool launch_order)
 {
     if(nblocks <= 0 || n <= 0)
         return aoclsparse_status_success;
     const bool kt      = kt_lanes > 0;
     const int  kt_tail = kt ? (int)(n % kt_lanes) : 0; // csrmm_row_kt's scalar tail columns
     const bool readc = kt || csrmm_reads_c(beta != T(0)); // (the KT arithmetic always reads C: c = c * beta comes first)
-    constexpr bool xcd = true;
-    const int  chunk = (nblocks + 7) / 8; // XCD-contiguous block order, as the other csrmm kernels
+    // XCD-contiguous block order, as the other csrmm kernels -- unless the blocks follow the lines of a band (MmGroups::slab_blocks): then
+    // launch order IS the deal of the lines' eighths to the XCDs
+    const bool xcd   = !launch_order;
+    const int  chunk = xcd ? (nblocks + 7) / 8 : 0;
     // (UR, NB) = rows in flight per 16-lane sub-wave x B-row loads per row and step.  Round-3 sweep on the 32-column slab of
     // the 1000^2 Laplacian (tools/history/exp_r3_slab3.sh, profiles/r3/slab_shapes.txt; beta = 0 overwrite / C read): (2, 8) 0.130 /
     // 0.174 ms, (2, 6) 0.126-0.128 / 0.166-0.168, (1, 8) 0.127-0.133 / 0.165-0.175, (3, 6) 0.133-0.137 / 0.170-0.174, (4, 6) 0.154-0.158 /
@@ -1705,14 +1707,15 @@ aoclsparse_status launch_csrmm_tiled(hipStream_t s, int base, T alpha, const T *
     auto       go3   = [&](auto tile_tag, auto nb_tag, auto rc_tag) {
         constexpr int  TILE = decltype(tile_tag)::value, NB = decltype(nb_tag)::value;
         constexpr bool RC   = decltype(rc_tag)::value;
-        const dim3     grid(xcd ? chunk * 8 : nblocks, (n + 31) / 32);
+        const dim3     grid(xcd ? chunk * 8 : (nblocks + 7) / 8 * 8, (n + 31) / 32); // (a multiple of 8: the column parts keep the XCDs)
+        const size_t   trace_slots = (size_t)grid.x;
         static const char *trace_path = getenv("AOCLSPARSE_MI355_MM_TRACE");
         if constexpr(std::is_same<T, double>::value && TILE == 1024 && NB == 5)
         {
             unsigned long long *trace = nullptr;
-            if(trace_path && !kt && hipMalloc(&trace, sizeof(unsigned long long) * 8 * (size_t)(chunk * 8)) == hipSuccess)
+            if(trace_path && !kt && hipMalloc(&trace, sizeof(unsigned long long) * 8 * trace_slots) == hipSuccess)
             {
-                (void)hipMemsetAsync(trace, 0, sizeof(unsigned long long) * 8 * (size_t)(chunk * 8), s);
+                (void)hipMemsetAsync(trace, 0, sizeof(unsigned long long) * 8 * trace_slots, s);
                 hipLaunchKernelGGL((csrmm_tile_kernel<T, 16, TILE, 2, NB, RC, false, true>), grid, dim3(256), 0, s, base, alpha, val,
                                    col, row_ptr, blocks, nblocks, B, n, ldb, beta, C, ldc, readc, mmw(chunk), trace);
                 std::vector<unsigned long long> host(8 * (size_t)nblocks);
@@ -1825,7 +1828,7 @@ aoclsparse_status launch_csrmm_colpair(hipStream_t s, int base, T alpha, aoclspa
     template aoclsparse_status launch_csrmm_tiled<T>(hipStream_t, int, T, const T *, const aoclsparse_int *,   \
                                                      const aoclsparse_int *, const aoclsparse_int *,          \
                                                      aoclsparse_int, int, aoclsparse_int, const T *, aoclsparse_int, \
-                                                     aoclsparse_int, T, T *, aoclsparse_int, int);
+                                                     aoclsparse_int, T, T *, aoclsparse_int, int, bool);
 MI355_INST_MM(double)
 MI355_INST_MM(float)
 template aoclsparse_status launch_csrmm_kt<double>(hipStream_t, aoclsparse_order, int, int, double, aoclsparse_int, const double *,

@@ -297,6 +297,11 @@ struct MmGroups
     // order they are one strip apart.
     DeviceBuffer   run_order;
     aoclsparse_int band = 0;
+    // ... and row blocks for the narrow (n < 128) row-major kernel that follow the lines of the band: every line of `band` rows in 8
+    // blocks, {first row, first non-zero} like SpmvPlan::rowblocks (+ a terminal entry).  In launch order block b runs on XCD b % 8, so
+    // rows i and i +- band meet in one L2 and all eight XCDs work inside one line (csrmm_tile_kernel; 0 blocks: not built)
+    DeviceBuffer   slab_blocks;
+    aoclsparse_int slab_nblocks = 0;
     aoclsparse_int ngroups = 0;
     int            max_rows = 0; // rows of the largest group
     DeviceBuffer   first; // ngroups + 1 row indices
@@ -1003,7 +1008,7 @@ template <typename T>
 aoclsparse_status launch_csrmm_tiled(hipStream_t s, int base, T alpha, const T *val, const aoclsparse_int *col,
                                      const aoclsparse_int *row_ptr, const aoclsparse_int *blocks, aoclsparse_int nblocks,
                                      int tile, aoclsparse_int max_row_nnz, const T *B, aoclsparse_int n, aoclsparse_int ldb,
-                                     T beta, T *C, aoclsparse_int ldc, int kt_lanes = 0);
+                                     T beta, T *C, aoclsparse_int ldc, int kt_lanes = 0, bool launch_order = false);
 // column-major: a lane owns a row PAIR; 16-byte loads where the second row is the first shifted by one column
 template <typename T>
 aoclsparse_status launch_csrmm_colpair(hipStream_t s, int base, T alpha, aoclsparse_int npairs,

@@ -161,7 +161,7 @@ DLL_PUBLIC aoclsparse_int aoclsparse_mi355_replicas_cloned(const aoclsparse_matr
  *           has placed in THIS process's device memory (received over whatever wire it uses): the buffers are copied device to
  *           device, the CSR arrays are copied back once to give the handle its host view, no analysis runs.  Every
  *           aoclsparse_* call works on the new handle; it carries an optimized mm hint. */
-#define AOCLSPARSE_MI355_MM_STATE_BUFFERS 13
+#define AOCLSPARSE_MI355_MM_STATE_BUFFERS 14
 #define AOCLSPARSE_MI355_MM_STATE_SCALARS 40
 typedef struct aoclsparse_mi355_mm_state_
 {

@@ -468,7 +468,7 @@ def test_sharded_csrmm_world8_column_ranges_and_state_bytes_with_mocks():
     # (b) the state's bytes: rank 0 exports, ranks 1..7 adopt
     rng = np.random.default_rng(5)
     bufs = [np.frombuffer(rng.bytes(n), dtype=np.uint8).copy() if n else None
-            for n in (4004, 19984, 39968, 0, 512, 0, 0, 96, 0, 0, 0, 0, 640)][: pkg.MM_STATE_BUFFERS]
+            for n in (4004, 19984, 39968, 0, 512, 0, 0, 96, 0, 0, 0, 0, 640, 72)][: pkg.MM_STATE_BUFFERS]
     scalars = [int(v) for v in rng.integers(0, 1 << 40, size=40)]
     adopted = {}
 

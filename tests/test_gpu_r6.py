@@ -376,7 +376,7 @@ def test_blocked_ell_order_is_chosen_by_the_model_and_travels_with_the_state():
     assert (info.mm_bell_xcd_chunk, info.mm_bell_lattice_line, info.mm_bell_lattice_lines) == (0, 32, 32)
     assert info.mm_bell_model_fetches_launch_order_permille > 4000 and info.mm_bell_model_fetches_permille < 2000
     st, state, ptrs = A.mm_state_export()
-    assert st == 0 and state.bytes[12] > 0
+    assert st == 0 and state.bytes[12] > 0 and state.bytes[13] == 0
     held = [torch.as_tensor(_DeviceView(p, n), device="cuda").clone() if n else None for p, n in zip(ptrs, list(state.bytes))]
     torch.cuda.synchronize()
     st, R = P.Matrix.mm_state_adopt(state, [t.data_ptr() if t is not None else None for t in held])
@@ -428,3 +428,45 @@ def test_blocked_ell_order_is_chosen_by_the_model_and_travels_with_the_state():
     assert P.dcsrmm(P.OP_NONE, 1.0, A2, d2, P.ORDER_ROW, dev(B), n, n, 0.0, Cd, n) == 0
     torch.cuda.synchronize()
     assert _same_bits(Cd.cpu().numpy().reshape(m, n), Cr2.reshape(n, m).T)
+
+
+def test_banded_matrix_row_major_csrmm_orders_same_bits_and_travel_with_the_state():
+    """A banded matrix (5-point Laplacian, 300 rows per line): the row-per-wavefront kernel deals chunks of band / 8 rows to the XCDs
+    (n >= 128, C read) and the narrow kernel walks row blocks that follow the lines, 8 per line (n < 128) -- both only decide WHERE a
+    row is computed: oracle.dcsrmm's bits (csrmm.hpp:36-90) for 32, 48, 128 and 256 columns, both beta = 0 modes and beta != 0.  The
+    line blocks are the 14th buffer of the exported state: an adopted handle (no analysis of its own) returns the same bits."""
+    from aocl_sparse_amd.sharded import _DeviceView
+    from util import laplace5
+    g = 300
+    m, rp, ci, v = laplace5(g)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    d = P.Descr()
+    assert L.aoclsparse_set_mm_hint(A.h, P.OP_NONE, d.h, 10) == 0 and L.aoclsparse_optimize(A.h) == 0
+    st, state, ptrs = A.mm_state_export()
+    assert st == 0 and state.bytes[13] == 4 * 2 * (8 * g + 1)  # 8 blocks per line of 300 rows + the terminal entry
+    held = [torch.as_tensor(_DeviceView(p, n), device="cuda").clone() if n else None for p, n in zip(ptrs, list(state.bytes))]
+    torch.cuda.synchronize()
+    st, R = P.Matrix.mm_state_adopt(state, [t.data_ptr() if t is not None else None for t in held])
+    assert st == 0
+    del held
+    rng = np.random.default_rng(12)
+    L.aoclsparse_mi355_set_pointer_mode(P.PTR_DEVICE)
+    try:
+        for n, alpha, beta in ((32, 1.0, 0.0), (48, -0.5, 1.25), (128, 1.0, 0.0), (256, 2.0, 0.0), (256, 1.0, -1.0)):
+            B, C0 = rng.uniform(-1, 1, m * n), rng.uniform(-1, 1, m * n)
+            so, Cr = oracle.dcsrmm("col", alpha, 0, v, ci, rp, m, np.ascontiguousarray(B.reshape(m, n).T).ravel(), n, m, beta,
+                                   np.ascontiguousarray(C0.reshape(m, n).T).ravel(), m)
+            assert so == 0
+            ref = Cr.reshape(n, m).T
+            for H in (A, R):
+                for overwrite in ((False, True) if beta == 0.0 else (False,)):
+                    Cd = dev(C0)
+                    assert L.aoclsparse_mi355_set_csrmm_beta0_overwrite(1 if overwrite else 0) == 0
+                    try:
+                        assert P.dcsrmm(P.OP_NONE, alpha, H, d, P.ORDER_ROW, dev(B), n, n, beta, Cd, n) == 0
+                        torch.cuda.synchronize()
+                    finally:
+                        assert L.aoclsparse_mi355_set_csrmm_beta0_overwrite(0) == 0
+                    assert _same_bits(Cd.cpu().numpy().reshape(m, n), ref), (n, alpha, beta, overwrite, H is R)
+    finally:
+        L.aoclsparse_mi355_set_pointer_mode(P.PTR_AUTO)
