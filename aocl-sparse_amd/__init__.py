@@ -363,6 +363,7 @@ SIGNATURES = {
     "aoclsparse_mi355_timer_mark": (c_int, []),
     "aoclsparse_mi355_timer_laps": (c_int, [POINTER(c_float), _I, POINTER(_I)]),
     "aoclsparse_mi355_column_shard": (c_int, [_I, _I, _I, POINTER(_I), POINTER(_I)]),
+    "aoclsparse_mi355_plan_block_row_order": (c_int, [_I, _I, _I, c_void_p, _I, c_void_p, _I, POINTER(_I), POINTER(_I)]),
     "aoclsparse_mi355_dcsrmm_shard": (c_int, [c_int, c_double, _P, _P, c_int, _P, _I, _I, c_double, _P, _I, _I, _I]),
     "aoclsparse_mi355_dcsrmm_multi": (c_int, [c_int, c_double, _P, _P, c_int, _P, _I, _I, c_double, _P, _I, _I, _P]),
     "aoclsparse_mi355_set_option": (c_int, [c_int, _I]),

@@ -244,7 +244,7 @@ struct BellLattice
     aoclsparse_int n1 = 0, n2 = 0, n3 = 0; // block rows per line, lines per plane (1: a 2-D grid), planes
 };
 // the offsets block column - block row that at least a quarter of the block rows store
-BellLattice detect_bell_lattice(const std::vector<aoclsparse_int> &bcol, aoclsparse_int nbr, aoclsparse_int width)
+BellLattice detect_bell_lattice(const aoclsparse_int *bcol, aoclsparse_int nbr, aoclsparse_int width)
 {
     BellLattice         L;
     std::vector<int>    hist((size_t)nbr, 0);
@@ -268,8 +268,9 @@ BellLattice detect_bell_lattice(const std::vector<aoclsparse_int> &bcol, aoclspa
             n1 = o;
     if(!n1 || n1 > nbr / 4)
         return L;
+    // (the plane size is also the centre of its clusters ALONG the lines: 27-point stores n1 n2 - n1, n1 n2, n1 n2 + n1)
     for(long long o = 2 * n1; o < nbr && !pl; o += n1)
-        if(centre(o) && o > n1 + 1)
+        if(centre(o) && o > n1 + 1 && in(o - n1) == in(o + n1))
             pl = o;
     L.n1 = (aoclsparse_int)n1;
     if(pl && pl <= nbr / 2)
@@ -312,8 +313,14 @@ void bell_chunk_lists(aoclsparse_int nbr, int ch, std::vector<aoclsparse_int> (&
     for(aoclsparse_int b = 0; b < nbr; b++)
         list[(b / ch) & 7].push_back(b);
 }
-void choose_bell_order(const std::vector<aoclsparse_int> &bcol, aoclsparse_int nbr, aoclsparse_int width, aoclsparse_int nbc, BellPlan &bp,
-                       std::vector<aoclsparse_int> &order)
+constexpr int BELL_ORDER_AUTO = INT_MIN;
+int bell_order_forced()
+{
+    const char *e = std::getenv("AOCLSPARSE_MI355_BELL_XCD_CHUNK");
+    return e ? std::atoi(e) : BELL_ORDER_AUTO;
+}
+void choose_bell_order(const aoclsparse_int *bcol, size_t bcol_size, aoclsparse_int nbr, aoclsparse_int width, aoclsparse_int nbc, BellPlan &bp,
+                       std::vector<aoclsparse_int> &order, int forced)
 {
     bp.xcd_chunk = 1, bp.order_len = 0, bp.model_fetches = bp.model_fetches_launch_order = 0.0;
     bp.lattice[0] = bp.lattice[1] = bp.lattice[2] = 0, bp.region[0] = bp.region[1] = 0;
@@ -351,15 +358,12 @@ void choose_bell_order(const std::vector<aoclsparse_int> &bcol, aoclsparse_int n
     long long distinct = 0;
     {
         std::vector<char> seen((size_t)nbc, 0);
-        for(size_t i = 0; i < bcol.size(); i++)
+        for(size_t i = 0; i < bcol_size; i++)
             if(bcol[i] >= 0 && !seen[(size_t)bcol[i]])
                 seen[(size_t)bcol[i]] = 1, distinct++;
     }
     if(distinct == 0)
         return;
-    int forced = INT_MIN;
-    if(const char *e = std::getenv("AOCLSPARSE_MI355_BELL_XCD_CHUNK"))
-        forced = std::atoi(e);
     bell_chunk_lists(nbr, 1, list);
     const long long m1 = misses();
     bp.model_fetches_launch_order = bp.model_fetches = (double)m1 / (double)distinct;
@@ -563,7 +567,7 @@ aoclsparse_status mi355::build_bell(const HostCsr &h, const DeviceCsr &d, SpmvPl
     try
     {
         std::vector<aoclsparse_int> order;
-        choose_bell_order(bcol, nbr, width, (aoclsparse_int)(((long long)h.n + BS - 1) / BS), bp, order);
+        choose_bell_order(bcol.data(), bcol.size(), nbr, width, (aoclsparse_int)(((long long)h.n + BS - 1) / BS), bp, order, bell_order_forced());
         if(bp.order_len > 0
            && (bp.order.upload(order.data(), sizeof(aoclsparse_int) * order.size(), st) != aoclsparse_status_success
                || hipStreamSynchronize(st) != hipSuccess))
@@ -1561,6 +1565,37 @@ static aoclsparse_status csrmm_multi_t(aoclsparse_operation op, const T alpha, c
 }
 
 extern "C" {
+
+aoclsparse_status aoclsparse_mi355_plan_block_row_order(aoclsparse_int nbr, aoclsparse_int width, aoclsparse_int nbc, const aoclsparse_int *bcol,
+                                                        aoclsparse_int forced, aoclsparse_int *order, aoclsparse_int order_capacity,
+                                                        aoclsparse_int *order_len, aoclsparse_int info[8])
+{
+    if(!bcol || !order_len || !info || (order_capacity > 0 && !order))
+        return aoclsparse_status_invalid_pointer;
+    if(nbr < 0 || width < 1 || nbc < 1 || order_capacity < 0 || (long long)nbr * width > (1LL << 31))
+        return aoclsparse_status_invalid_size;
+    for(long long i = 0; i < (long long)nbr * width; i++)
+        if(bcol[i] < -1 || bcol[i] >= nbc)
+            return aoclsparse_status_invalid_index_value;
+    try
+    {
+        BellPlan                    bp;
+        std::vector<aoclsparse_int> ord;
+        choose_bell_order(bcol, (size_t)nbr * (size_t)width, nbr, width, nbc, bp, ord, forced == -2 ? BELL_ORDER_AUTO : (int)forced);
+        if((long long)ord.size() > (long long)order_capacity)
+            return aoclsparse_status_invalid_size;
+        std::copy(ord.begin(), ord.end(), order);
+        *order_len = bp.order_len;
+        info[0] = bp.xcd_chunk, info[1] = bp.lattice[0], info[2] = bp.lattice[1], info[3] = bp.lattice[2];
+        info[4] = bp.region[0], info[5] = bp.region[1];
+        info[6] = (aoclsparse_int)(bp.model_fetches * 1000.0 + 0.5), info[7] = (aoclsparse_int)(bp.model_fetches_launch_order * 1000.0 + 0.5);
+        return aoclsparse_status_success;
+    }
+    catch(const std::bad_alloc &)
+    {
+        return aoclsparse_status_memory_error;
+    }
+}
 
 aoclsparse_status aoclsparse_mi355_column_shard(aoclsparse_int n, aoclsparse_int world, aoclsparse_int rank,
                                                 aoclsparse_int *j0, aoclsparse_int *j1)

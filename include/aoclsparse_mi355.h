@@ -232,6 +232,16 @@ typedef struct aoclsparse_mi355_spmv_info_
 DLL_PUBLIC aoclsparse_status aoclsparse_mi355_get_spmv_info(const aoclsparse_matrix     A,
                                                             aoclsparse_operation        op,
                                                             aoclsparse_mi355_spmv_info *info);
+/* The plan behind mm_bell_xcd_chunk / the lattice sweep, computed from host arrays (no device involved; what aoclsparse_optimize runs on the
+ * blocked-ELL copy's block columns): bcol = nbr x width block columns, ascending per block row, empty slots (-1) last; nbc = block columns of
+ * the matrix.  forced: -2 automatic, -1 the lattice sweep whenever a lattice is found, 0 launch order, c >= 1 chunks of c block rows.
+ * order (room for order_capacity entries; 8 * nbr always suffices) receives order[8 p + x] = the p-th block row of XCD x, -1 past the end of
+ * its list; *order_len = list positions per XCD (0: launch order, nothing written).  info = {xcd chunk (0: lattice sweep), block rows per
+ * line, lines per plane, planes, region a, region b, 1000 * modelled fetches per B block row, the same in launch order}. */
+DLL_PUBLIC aoclsparse_status aoclsparse_mi355_plan_block_row_order(aoclsparse_int nbr, aoclsparse_int width, aoclsparse_int nbc,
+                                                                   const aoclsparse_int *bcol, aoclsparse_int forced, aoclsparse_int *order,
+                                                                   aoclsparse_int order_capacity, aoclsparse_int *order_len,
+                                                                   aoclsparse_int info[8]);
 /* number of dependency levels of the triangle a trsv with (fill, op) walks; -1 before analysis */
 DLL_PUBLIC aoclsparse_status aoclsparse_mi355_get_trsv_levels(const aoclsparse_matrix A,
                                                               aoclsparse_fill_mode    fill,
