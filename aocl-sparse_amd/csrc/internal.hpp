@@ -421,7 +421,10 @@ struct TrsvSegment
 // block-level order, in solve order inside a block; entries in chain order).
 constexpr int TRSV_BLK_ROWS = 8; // rows per block at most
 constexpr int TRSV_BLK_EXT  = 24; // external dependencies of a multi-row block at most
-constexpr int TRSV_BLK_NV   = 96; // entries of a multi-row block at most
+// entries of a multi-row block at most: 5 rows on 20 external dependencies (a mesh node of 5 unknowns below 4 neighbours: 5 x 20 + 10).
+// (96 until round 6: such a node was cut into 4 rows + 1 single row of 24 entries -- an extra block level per node, and the single rows
+// put the whole solve on the (5, 24) shape of trsv_block_kernel, whose values live in LDS: 2.5 instead of 1.7 us per block level.)
+constexpr int TRSV_BLK_NV   = 110;
 // spare elements behind the m x nrhs position-ordered solution buffer: [0, 64) parked tag stores, [64, 128) parked x stores
 // (one slot per lane), the last one (191) the slot that always holds 0 -- apart from the parked ones: a parked NaN must not reach it
 constexpr int TRSV_XP_PAD = 192;

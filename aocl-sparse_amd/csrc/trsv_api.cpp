@@ -603,7 +603,7 @@ static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, T
         }
         cp.model_us       = total;
         // (the lane-per-block schedule, measured per block level: 1.69 us with every block in registers, 2.51 us with the larger shape)
-        cp.model_block_us = (double)nlev * (max_ext <= 16 && max_rows <= 5 ? 1.7 : 2.55);
+        cp.model_block_us = (double)nlev * (max_rows <= 5 ? (max_ext <= 16 ? 1.7 : (max_ext <= 20 ? 2.35 : 2.55)) : 2.55);
         lt.lap("chunks: steps + dependency lists + model");
         // aoclsparse_mi355_set_option(trsv_chunks, ...): -1 the model decides (default), 0 never, 1 whenever the plan can be built
         const int want = plan_option(aoclsparse_mi355_option_trsv_chunks);

@@ -643,6 +643,10 @@ __device__ __forceinline__ void lds_read_landed(T &v)
 
 // slots per lane of the fixed layout: BS x EXT external + BS x BS internal values, padded so that a lane's stride is an
 // odd number of (2 values): the paired reads of the 64 lanes then fall on distinct LDS banks
+// Shapes up to (5 rows, 20 external entries) keep a block's values in registers across the wait.  (5, 20) is 130 values: 256 VGPRs + 96
+// AGPRs as their overflow, one wavefront per SIMD -- still faster than the same blocks out of LDS (unstructured shell-like factor, same box:
+// 3.42 against 3.72 ms; profiles/r6/trsv_chunk_experiments.txt).
+constexpr int TRSV_BLK_REG_SLOTS = 130;
 constexpr int trsv_blk_slots(int bs, int ext)
 {
     const int sl = bs * ext + bs * (bs + (bs & 1)); // ext and the padded internal stride are even
@@ -696,7 +700,7 @@ __global__ __launch_bounds__(64) void trsv_block_kernel(
     for(int e = 0; e < EXT; e++)
         q[e] = e < nl ? pind[p0 + e] : spare + TRSV_XP_PAD - 1; // beyond the row: a slot that always holds 0
     // larger shapes: the block's values -> their LDS slots (zero elsewhere)
-    if constexpr(SLOTS > 112)
+    if constexpr(SLOTS > TRSV_BLK_REG_SLOTS)
     {
         for(int j = 0; j < SLOTS; j++)
             s_mine[j] = T(0);
@@ -739,7 +743,7 @@ __global__ __launch_bounds__(64) void trsv_block_kernel(
     };
     // Small shapes keep every value of the block in REGISTERS across the wait (read straight from the plan; the LDS copy
     // is then not needed at all): after the wait there is nothing left but FMAs and stores.
-    constexpr bool IN_REGS = SLOTS <= 112;
+    constexpr bool IN_REGS = SLOTS <= TRSV_BLK_REG_SLOTS;
     T              ve[IN_REGS ? BS : 1][EXT], vn[IN_REGS ? BS : 1][BSP];
     if constexpr(IN_REGS)
     {
@@ -1009,11 +1013,13 @@ __global__ __launch_bounds__(64) void trsv_block_kt_kernel(
 {
     using B = typename tag<T>::bits;
     constexpr int BS = TRSV_BLK_ROWS, EXT = TRSV_BLK_EXT, NV = TRSV_BLK_NV;
-    __shared__ T s_val[NV][64]; // the block's entries, rows back to back, each row in chain (= CSR) order
+    // (dynamic LDS: 64 x (NV + EXT + BS) values = 71 KB for double, past the 64 KB a kernel gets without asking)
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_kt_raw[];
+    T(*s_val)[64] = reinterpret_cast<T(*)[64]>(s_kt_raw); // the block's entries, rows back to back, each row in chain (= CSR) order
     // the x values a row multiplies, laid out so that row a's p-th entry meets s_xv[x0_a + p]: L (a row = [external in order,
     // rows 0..a-1]): external e at e, row a's result at n0 + a, x0_a = 0; U (FRONT, a row = [rows a-1..0, external]): row a's
     // result at BS - 1 - a, external e at BS + e, x0_a = BS - a.  Values and x are then walked with one induction variable.
-    __shared__ T s_xv[EXT + BS][64];
+    T(*s_xv)[64] = reinterpret_cast<T(*)[64]>(s_kt_raw + sizeof(T) * 64 * NV);
     const int col   = nrhs > 1 ? (int)blockIdx.x : 0;
     const int spare = m * (nrhs - col);
     ticket += col, level_done += (size_t)col * nlevels;
@@ -1916,20 +1922,25 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
         bp.pptr.as<aoclsparse_int>(), bp.pind.as<aoclsparse_int>(), bp.pval.as<T>(), diag, b, xp, x, alpha, (int)unit, scratch,   \
         timeout_word ? timeout_word : scratch + nrhs, (int)incb, (int)incx, scratch + nrhs + 1, gate, (int)nrhs, b_off, x_off,     \
         (int)bp.nlevels, trace
+            constexpr size_t kt_lds = sizeof(T) * 64 * (size_t)(TRSV_BLK_NV + TRSV_BLK_EXT + TRSV_BLK_ROWS);
+            auto go_kt = [&](auto tsz_tag, auto front_tag) {
+                constexpr int  TSZ = decltype(tsz_tag)::value;
+                constexpr bool FR  = decltype(front_tag)::value;
+                static const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void *>(&trsv_block_kt_kernel<T, TSZ, FR>),
+                                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kt_lds);
+                if(raised != hipSuccess)
+                    return aoclsparse_status_internal_error;
+                hipLaunchKernelGGL((trsv_block_kt_kernel<T, TSZ, FR>), grid, dim3(64), kt_lds, s, MI355_BLKKT_ARGS);
+                return aoclsparse_status_success;
+            };
             if(kt_bits == 256)
-            {
-                if(bp.front)
-                    hipLaunchKernelGGL((trsv_block_kt_kernel<T, T256, true>), grid, dim3(64), 0, s, MI355_BLKKT_ARGS);
-                else
-                    hipLaunchKernelGGL((trsv_block_kt_kernel<T, T256, false>), grid, dim3(64), 0, s, MI355_BLKKT_ARGS);
-            }
+                lst = bp.front ? go_kt(std::integral_constant<int, T256>{}, std::true_type{})
+                               : go_kt(std::integral_constant<int, T256>{}, std::false_type{});
             else
-            {
-                if(bp.front)
-                    hipLaunchKernelGGL((trsv_block_kt_kernel<T, 2 * T256, true>), grid, dim3(64), 0, s, MI355_BLKKT_ARGS);
-                else
-                    hipLaunchKernelGGL((trsv_block_kt_kernel<T, 2 * T256, false>), grid, dim3(64), 0, s, MI355_BLKKT_ARGS);
-            }
+                lst = bp.front ? go_kt(std::integral_constant<int, 2 * T256>{}, std::true_type{})
+                               : go_kt(std::integral_constant<int, 2 * T256>{}, std::false_type{});
+            if(lst != aoclsparse_status_success)
+                return lst;
 #undef MI355_BLKKT_ARGS
             MI355_HIP_TRY(hipGetLastError());
         }
@@ -1939,7 +1950,7 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
             constexpr int    BS = decltype(bs_tag)::value, EXT = decltype(ext_tag)::value;
             constexpr bool   FRONT = decltype(front_tag)::value;
             // (the small shapes hold the block in registers and use no LDS)
-            constexpr size_t need = trsv_blk_slots(BS, EXT) <= 112 ? 0 : sizeof(T) * 64 * (size_t)trsv_blk_slots(BS, EXT);
+            constexpr size_t need = trsv_blk_slots(BS, EXT) <= TRSV_BLK_REG_SLOTS ? 0 : sizeof(T) * 64 * (size_t)trsv_blk_slots(BS, EXT);
             static_assert(need <= 160 * 1024, "LDS of one CU");
             const size_t     lds  = std::min<size_t>(need, 160 * 1024);
             if(lds > 64 * 1024)
@@ -1977,6 +1988,7 @@ aoclsparse_status launch_trsv(hipStream_t s, int schedule, bool unit, T alpha, a
         // shapes by the plan's largest block / external list (the loops over rows and external entries are unrolled)
         const bool small_ext = bp.max_ext <= 16, small_bs = bp.max_rows <= 5;
         lst = small_ext && small_bs ? go(integral_constant<int, 5>{}, integral_constant<int, 16>{})
+              : bp.max_ext <= 20 && small_bs ? go(integral_constant<int, 5>{}, integral_constant<int, 20>{})
               : small_ext           ? go(integral_constant<int, TRSV_BLK_ROWS>{}, integral_constant<int, 16>{})
               : small_bs            ? go(integral_constant<int, 5>{}, integral_constant<int, TRSV_BLK_EXT>{})
                                     : go(integral_constant<int, TRSV_BLK_ROWS>{}, integral_constant<int, TRSV_BLK_EXT>{});
