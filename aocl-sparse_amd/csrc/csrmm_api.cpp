@@ -97,6 +97,27 @@ aoclsparse_status build_mm_groups(const HostCsr &h, SpmvPlan &plan)
         return st;
     g.ngroups = ng, g.max_rows = max_rows;
     g.valid = true;
+    // the band of the groups: how far right of its first row a group's list reaches, when most groups agree (majority vote, then a
+    // count -- as detect_row_runs does for single rows): what the launcher deals to the XCDs by
+    {
+        auto reach = [&](aoclsparse_int gi) {
+            const aoclsparse_int i = first[(size_t)gi], e = h.ptr[i + 1] - h.base;
+            return e > h.ptr[i] - h.base ? h.ind[e - 1] - h.base - i : 0;
+        };
+        aoclsparse_int cand = 0;
+        long long      votes = 0, same = 0;
+        for(aoclsparse_int gi = 0; gi < ng; gi++)
+        {
+            const aoclsparse_int d = reach(gi);
+            if(votes == 0)
+                cand = d, votes = 1;
+            else
+                votes += d == cand ? 1 : -1;
+        }
+        for(aoclsparse_int gi = 0; gi < ng; gi++)
+            same += reach(gi) == cand;
+        g.band = same * 2 >= (long long)ng && cand >= 256 && (long long)cand * 4 <= (long long)h.m ? cand : 0;
+    }
     return aoclsparse_status_success;
 }
 
@@ -1029,7 +1050,7 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
                                  n, ldb, beta, static_cast<T *>(dC), ldc, colmaj ? nullptr : grp, colmaj ? 0 : ngrp,
                                  grouped ? p->mm.max_rows : 0, !colmaj && p && p->mm.row_runs,
                                  !colmaj && p && p->mm.row_runs && p->mm.band > 0 ? p->mm.run_order.as<aoclsparse_int>() : nullptr, 0,
-                                 !colmaj && p && p->mm.row_runs ? p->mm.band : 0);
+                                 !colmaj && p && (p->mm.row_runs || grouped) ? p->mm.band : 0);
     }
     return st == aoclsparse_status_success ? finish() : st;
 }

@@ -1404,9 +1404,9 @@ static int pow2_at_least(int v)
 // part of a chunk whose rows i +- band fall to ANOTHER XCD is |W - 8 c| / c: the candidate with the least of it wins, a multiple of 4
 // is preferred while it stays under 0.2 (1000 rows: 32 over 31, measured 1.085 against 1.12 ms), and above 0.4 nothing is dealt (the
 // neighbour line on the next XCD is the worst order there is: 1.30 ms against 1.19 for the contiguous eighth).
-static int mm_deal_chunk(aoclsparse_int band)
+static int mm_deal_chunk(aoclsparse_int band, double rows_per_workgroup = 4.0)
 {
-    const double W = (double)band / 4.0;
+    const double W = (double)band / rows_per_workgroup;
     const int    c0 = (int)(W / 8.0);
     int          best = 0;
     double       bs = 1e30;
@@ -1479,17 +1479,25 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
         const int ty    = 256 / tx;
         if(vec && n >= 32 && grp && ngroups > 0)
         {
+            // banded matrices with row groups (MmGroups::band of the groups: a mesh of nodes numbered line by line): the deal again -- a
+            // workgroup holds 4 / 8 / 16 groups of m / ngroups rows on average
+            // (256 columns, C read / overwritten, same box: shell-like 2.38 / 2.07 -> 2.21 / 1.97 ms, flan-like 5.27 / 4.89 -> 4.62 / 4.36; 32
+            // columns: flan-like 1.225 -> 1.173, shell-like unchanged; profiles/r6/mm_deal_experiments.txt)
+            const double rows_per_group = (double)m / (double)ngroups;
+            auto         deal_for = [&](int groups_per_wg) { deal = band >= 256 ? mm_deal_chunk(band, rows_per_group * groups_per_wg) : 0; };
             // accumulators are sized by the largest group the matrix actually has (2, 4 or 8 rows)
             auto go = [&](auto gr_tag) {
                 constexpr int GR = decltype(gr_tag)::value;
                 if(n >= 64)
                 {
+                    deal_for(8);
                     const int gx = grid_x((ngroups + 7) / 8, chunk);
                     hipLaunchKernelGGL((csrmm_rowgroup_sub_kernel<T, 32, GR>), dim3(gx, (n + 63) / 64), dim3(256), 0, s, base,
                                        alpha, ngroups, grp, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk);
                 }
                 else
                 {
+                    deal_for(16);
                     const int gx = grid_x((ngroups + 15) / 16, chunk);
                     hipLaunchKernelGGL((csrmm_rowgroup_sub_kernel<T, 16, GR>), dim3(gx, (n + 31) / 32), dim3(256), 0, s, base,
                                        alpha, ngroups, grp, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk);
@@ -1497,6 +1505,7 @@ aoclsparse_status launch_csrmm(hipStream_t s, aoclsparse_order order, int base, 
             };
             auto go2 = [&](auto gr_tag) {
                 constexpr int GR = decltype(gr_tag)::value;
+                deal_for(4);
                 const int     gx = grid_x((ngroups + 3) / 4, chunk);
                 // C read: its rows are requested up front (shell-like 2.37 -> 2.31 ms, flan-like 5.46 -> 5.19, same box, 256 columns)
                 if(readc)

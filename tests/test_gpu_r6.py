@@ -470,3 +470,38 @@ def test_banded_matrix_row_major_csrmm_orders_same_bits_and_travel_with_the_stat
                     assert _same_bits(Cd.cpu().numpy().reshape(m, n), ref), (n, alpha, beta, overwrite, H is R)
     finally:
         L.aoclsparse_mi355_set_pointer_mode(P.PTR_AUTO)
+
+
+@pytest.mark.parametrize("which", ["shell", "flan"])
+def test_row_group_csrmm_with_the_groups_band_dealt_to_the_xcds_same_bits(which):
+    """Mesh matrices with row groups whose band is wide enough to be dealt (shell: 120 nodes of 5 unknowns per line -> 609 rows;
+    flan: 12 x 12 nodes of 3 unknowns per plane -> 473 rows): csrmm_rowgroup2_kernel (n >= 128) and csrmm_rowgroup_sub_kernel
+    (64 and 32 columns) in the dealt order return oracle.dcsrmm's bits (csrmm.hpp:36-90), both beta = 0 modes and beta != 0."""
+    if which == "shell":
+        m, rp, ci, v = standins.shell_like(n=5 * 120 * 60, width=120)
+    else:
+        m, rp, ci, v = standins.flan_like(nx=12, ny=12, nz=12)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    d = P.Descr()
+    assert L.aoclsparse_set_mm_hint(A.h, P.OP_NONE, d.h, 10) == 0 and L.aoclsparse_optimize(A.h) == 0
+    rng = np.random.default_rng(17)
+    L.aoclsparse_mi355_set_pointer_mode(P.PTR_DEVICE)
+    try:
+        for n, alpha, beta in ((256, 1.0, 0.0), (130, -0.5, 1.25), (64, 2.0, 0.0), (32, 1.0, 0.0)):
+            B, C0 = rng.uniform(-1, 1, m * n), rng.uniform(-1, 1, m * n)
+            so, Cr = oracle.dcsrmm("col", alpha, 0, v, ci, rp, m, np.ascontiguousarray(B.reshape(m, n).T).ravel(), n, m, beta,
+                                   np.ascontiguousarray(C0.reshape(m, n).T).ravel(), m)
+            assert so == 0
+            ref = Cr.reshape(n, m).T
+            for overwrite in ((False, True) if beta == 0.0 else (False,)):
+                Cd = dev(C0)
+                assert L.aoclsparse_mi355_set_csrmm_beta0_overwrite(1 if overwrite else 0) == 0
+                try:
+                    assert P.dcsrmm(P.OP_NONE, alpha, A, d, P.ORDER_ROW, dev(B), n, n, beta, Cd, n) == 0
+                    torch.cuda.synchronize()
+                finally:
+                    assert L.aoclsparse_mi355_set_csrmm_beta0_overwrite(0) == 0
+                assert A.spmv_info().mm_groups > 0
+                assert _same_bits(Cd.cpu().numpy().reshape(m, n), ref), (which, n, alpha, beta, overwrite)
+    finally:
+        L.aoclsparse_mi355_set_pointer_mode(P.PTR_AUTO)
