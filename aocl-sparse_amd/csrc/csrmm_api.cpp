@@ -987,7 +987,7 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
                 if(st == aoclsparse_status_success)
                     st = launch_csrmm_groups_ccol<T>(rt.stream(), d->base, alpha, d->val.as<T>(), d->ind.as<aoclsparse_int>(),
                                                      d->ptr.as<aoclsparse_int>(), static_cast<const T *>(bt), n, n, beta,
-                                                     static_cast<T *>(dC), ldc, grp, ngrp, p->mm.max_rows);
+                                                     static_cast<T *>(dC), ldc, grp, ngrp, p->mm.max_rows, d->m, p->mm.band);
                 return st == aoclsparse_status_success ? finish() : st;
             }
             if(st == aoclsparse_status_success)
@@ -999,7 +999,8 @@ aoclsparse_status csrmm_t(aoclsparse_operation op, const T alpha, const aoclspar
             if(st == aoclsparse_status_success)
                 st = launch_csrmm<T>(rt.stream(), aoclsparse_order_row, d->base, alpha, d->m, d->n, d->val.as<T>(),
                                      d->ind.as<aoclsparse_int>(), d->ptr.as<aoclsparse_int>(), static_cast<const T *>(bt),
-                                     n, n, beta, static_cast<T *>(ct), n, grp, ngrp, grouped ? p->mm.max_rows : 0);
+                                     n, n, beta, static_cast<T *>(ct), n, grp, ngrp, grouped ? p->mm.max_rows : 0, false, nullptr, 0,
+                                     grouped ? p->mm.band : 0);
             if(st == aoclsparse_status_success)
                 st = launch_relayout<T>(rt.stream(), false, static_cast<const T *>(ct), static_cast<T *>(dC), m_c, n, ldc);
         }

@@ -1612,25 +1612,40 @@ template <typename T>
 aoclsparse_status launch_csrmm_groups_ccol(hipStream_t s, int base, T alpha, const T *val, const aoclsparse_int *col,
                                            const aoclsparse_int *row_ptr, const T *B, aoclsparse_int n, aoclsparse_int ldb,
                                            T beta, T *C, aoclsparse_int ldc, const aoclsparse_int *grp, aoclsparse_int ngroups,
-                                           int group_rows)
+                                           int group_rows, aoclsparse_int m, aoclsparse_int band)
 {
     if(ngroups <= 0 || n <= 0)
         return aoclsparse_status_success;
     const bool readc = csrmm_reads_c(beta != T(0));
+    // the order word and the grid for nbx workgroups of `groups` row groups each: the band of the groups dealt to the XCDs (launch_csrmm),
+    // else a contiguous eighth per XCD
+    auto order_of = [&](int nbx, int groups, int &gx) {
+        const int deal = band >= 256 && m > 0 ? mm_deal_chunk(band, (double)m / (double)ngroups * groups) : 0;
+        if(deal > 0)
+        {
+            gx = (nbx + 8 * deal - 1) / (8 * deal) * (8 * deal);
+            return MM_DEAL | deal;
+        }
+        const int chunk = (nbx + 7) / 8;
+        gx              = chunk * 8;
+        return chunk;
+    };
     if(n < 128)
     {
         auto gosub = [&](auto gr_tag) {
             constexpr int GR = decltype(gr_tag)::value;
             if(n >= 64)
             {
-                const int nbx = (int)((ngroups + 7) / 8), chunk = (nbx + 7) / 8;
-                hipLaunchKernelGGL((csrmm_rowgroup_sub_kernel<T, 32, GR, true>), dim3(chunk * 8, (n + 63) / 64), dim3(256), 0, s,
+                int       gx  = 0;
+                const int chunk = order_of((int)((ngroups + 7) / 8), 8, gx);
+                hipLaunchKernelGGL((csrmm_rowgroup_sub_kernel<T, 32, GR, true>), dim3(gx, (n + 63) / 64), dim3(256), 0, s,
                                    base, alpha, ngroups, grp, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk);
             }
             else
             {
-                const int nbx = (int)((ngroups + 15) / 16), chunk = (nbx + 7) / 8;
-                hipLaunchKernelGGL((csrmm_rowgroup_sub_kernel<T, 16, GR, true>), dim3(chunk * 8, (n + 31) / 32), dim3(256), 0, s,
+                int       gx  = 0;
+                const int chunk = order_of((int)((ngroups + 15) / 16), 16, gx);
+                hipLaunchKernelGGL((csrmm_rowgroup_sub_kernel<T, 16, GR, true>), dim3(gx, (n + 31) / 32), dim3(256), 0, s,
                                    base, alpha, ngroups, grp, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk);
             }
         };
@@ -1643,10 +1658,11 @@ aoclsparse_status launch_csrmm_groups_ccol(hipStream_t s, int base, T alpha, con
         MI355_HIP_TRY(hipGetLastError());
         return aoclsparse_status_success;
     }
-    const int  nbx = (int)((ngroups + 3) / 4), chunk = (nbx + 7) / 8;
+    int        gx2   = 0;
+    const int  chunk = order_of((int)((ngroups + 3) / 4), 4, gx2);
     auto       go  = [&](auto gr_tag) {
         constexpr int GR = decltype(gr_tag)::value;
-        hipLaunchKernelGGL((csrmm_rowgroup2_kernel<T, GR, true>), dim3(chunk * 8, (n + 127) / 128), dim3(256), 0, s, base, alpha,
+        hipLaunchKernelGGL((csrmm_rowgroup2_kernel<T, GR, true>), dim3(gx2, (n + 127) / 128), dim3(256), 0, s, base, alpha,
                            ngroups, grp, val, col, row_ptr, B, n, ldb, beta, C, ldc, readc, chunk,
                            (const aoclsparse_int *)nullptr);
     };
@@ -1851,7 +1867,8 @@ aoclsparse_status launch_csrmm_colpair(hipStream_t s, int base, T alpha, aoclspa
     template aoclsparse_status launch_csrmm_groups_ccol<T>(hipStream_t, int, T, const T *, const aoclsparse_int *, \
                                                            const aoclsparse_int *, const T *, aoclsparse_int,  \
                                                            aoclsparse_int, T, T *, aoclsparse_int,             \
-                                                           const aoclsparse_int *, aoclsparse_int, int);       \
+                                                           const aoclsparse_int *, aoclsparse_int, int,        \
+                                                           aoclsparse_int, aoclsparse_int);                    \
     template aoclsparse_status launch_csrmm_tiled<T>(hipStream_t, int, T, const T *, const aoclsparse_int *,   \
                                                      const aoclsparse_int *, const aoclsparse_int *,          \
                                                      aoclsparse_int, int, aoclsparse_int, const T *, aoclsparse_int, \

@@ -1003,7 +1003,7 @@ template <typename T>
 aoclsparse_status launch_csrmm_groups_ccol(hipStream_t s, int base, T alpha, const T *val, const aoclsparse_int *col,
                                            const aoclsparse_int *row_ptr, const T *B, aoclsparse_int n, aoclsparse_int ldb,
                                            T beta, T *C, aoclsparse_int ldc, const aoclsparse_int *grp, aoclsparse_int ngroups,
-                                           int group_rows);
+                                           int group_rows, aoclsparse_int m = 0, aoclsparse_int band = 0);
 // row-major, n < 128: workgroup per row block of the handle's SpMV plan, A staged in LDS (csrmm_tile_kernel)
 template <typename T>
 bool csrmm_tiled_applies(aoclsparse_int n, aoclsparse_int ldb, aoclsparse_int ldc, const T *B, const T *C);
