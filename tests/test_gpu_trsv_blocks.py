@@ -26,19 +26,21 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-def node_mesh(seed, nodes, width, dofs, keep=0.9, far=0):
+def node_mesh(seed, nodes, width, dofs, keep=0.9, far=0, fourth=False):
     """Sorted CSR of a mesh matrix with dense node-to-node blocks: node i has dofs[i] unknowns and couples to the nodes
-    i-1, i-width, i-width-1 (and symmetrically i+1, i+width, i+width+1), each kept with probability `keep`, plus `far`
-    random extra neighbours for every 50th node (rows too long for a block).  Strong diagonal, small off-diagonals."""
+    i-1, i-width, i-width-1 (and symmetrically i+1, i+width, i+width+1; `fourth`: also i-width+1 / i+width-1, a nine-point
+    stencil: FOUR lower neighbours), each kept with probability `keep`, plus `far` random extra neighbours for every 50th node
+    (rows too long for a block).  Strong diagonal, small off-diagonals."""
     rng = np.random.default_rng(seed)
     dofs = np.asarray(dofs, dtype=np.int64)
     first = np.concatenate([[0], np.cumsum(dofs)])
     m = int(first[-1])
     nbr = [set() for _ in range(nodes)]
     for i in range(nodes):
-        for d in (1, width, width + 1):
+        for d in (1, width, width + 1) + ((width - 1,) if fourth else ()):
             j = i - d
-            if j >= 0 and (d != 1 or i % width) and (d != width + 1 or i % width) and rng.random() < keep:
+            if (j >= 0 and (d != 1 or i % width) and (d != width + 1 or i % width) and (d != width - 1 or (i + 1) % width)
+                    and rng.random() < keep):
                 nbr[i].add(j), nbr[j].add(i)
         if far and i % 50 == 25:
             for j in rng.integers(0, nodes, size=far):
@@ -99,6 +101,50 @@ def test_block_trsv_bit_exact_every_triangle(name, dofs, width, far):
         assert np.array_equal(got, ref), (name, what, int((got != ref).sum()))
 
     solve_all(m, rp, ci, v, same)
+
+
+def test_block_trsv_five_rows_on_twenty_dependencies():
+    """Nodes of 5 unknowns below FOUR neighbours (a nine-point node stencil, every coupling kept): 5-row blocks on 20 external
+    dependencies = 110 entries, the largest block the plan forms (TRSV_BLK_NV) and the largest shape whose values stay in registers
+    across the wait (round 6; such nodes used to be cut into 4 rows + 1).  Every triangle, unit / non-unit, the automatic kid, the
+    pinned reference kid, the lane-per-block and the two-level schedule: ref_trsv_*'s bits; kid 1 / 2 / 3 (trsv_block_kt_kernel, whose
+    LDS for 110 entries per lane is requested dynamically): kt_trsv_*'s bits."""
+    from util import kt_lanes, trsv_schedule
+    nodes = 4000
+    m, rp, ci, v = node_mesh(4242, nodes, 40, np.full(nodes, 5), keep=1.0, fourth=True)
+
+    def same(got, ref, what):
+        assert np.array_equal(got, ref), (what, int((got != ref).sum()))
+
+    A = solve_all(m, rp, ci, v, same)
+    info = A.trsv_info(P.FILL_LOWER, P.OP_NONE)
+    # one block per node: 4,000 blocks of 5 rows (not 8,000 of 4 + 1)
+    assert info.blocks == nodes, info.blocks
+    o = oracle.dcsr_optimize(m, m, len(v), 0, rp, ci, v)
+    rng = np.random.default_rng(5)
+    assert L.aoclsparse_mi355_set_option(P.OPTION_TRSV_CHUNKS, 1) == 0
+    try:
+        for kind, fill, op in VARIANTS:
+            d = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=getattr(P, fill), diag=P.DIAG_NON_UNIT)
+            b = rng.uniform(-1, 1, m)
+            iend = o["idiag"] if kind[0] == "l" else o["iurow"]
+            st, xr = oracle.dtrsv(kind, 0.75, m, 0, o["val"], o["ind"], o["ptr"], iend, b, False)
+            assert st == 0
+            for sched in (4, 5):
+                with trsv_schedule(P, sched):
+                    xd = torch.full((m,), 7.0, dtype=torch.float64, device="cuda")
+                    assert P.dtrsv(getattr(P, op), 0.75, A, d, dev(b), xd) == 0
+                    torch.cuda.synchronize()
+                assert np.array_equal(xd.cpu().numpy(), xr), (kind, sched)
+            for kid in (1, 3):
+                st, xk = oracle.trsv_kt(kind, kt_lanes(kid, np.float64), 0.75, m, 0, o["val"], o["ind"], o["ptr"], iend, b, False)
+                assert st == 0
+                xd = torch.full((m,), 7.0, dtype=torch.float64, device="cuda")
+                assert P.dtrsv(getattr(P, op), 0.75, A, d, dev(b), xd, kid=kid) == 0
+                torch.cuda.synchronize()
+                assert np.array_equal(xd.cpu().numpy().view(np.uint64), xk.view(np.uint64)), (kind, kid)
+    finally:
+        assert L.aoclsparse_mi355_set_option(P.OPTION_TRSV_CHUNKS, -1) == 0
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
