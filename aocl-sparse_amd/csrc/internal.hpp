@@ -468,6 +468,7 @@ struct TrsvChunkPlan
 };
 struct TrsvBlockPlan
 {
+    double         slice_fan_in = 0.0; // producer slices a slice of 64 blocks waits for, on average (trsv_api.cpp: the slice width)
     TrsvChunkPlan  chunk;
     bool           tried = false, valid = false;
     bool           front = false; // a row's chain starts with the rows of its own block (U), instead of ending with them

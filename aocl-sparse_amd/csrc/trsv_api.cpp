@@ -398,8 +398,39 @@ static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, T
     lt.lap("blocks: order + layout");
     // 5. slices of <= 64 blocks inside one block level
     std::vector<aoclsparse_int> slices;
+    // How many blocks share a wavefront.  A slice starts when the LAST dependency of its 64 blocks is in; when those dependencies come from
+    // many producer slices (an irregular numbering: 15.7 on average on the unstructured shell-like factor, 3.6 on the structured one --
+    // there a slice waits for the slices at the same place one and two levels down), narrower slices wait for less: slices of 32 blocks
+    // 3.42 -> 3.14 ms on the unstructured factor (48: 3.30, 40: 3.22, 24: 3.16, 16: 3.41), and 1.86 -> 2.19 on the structured one, whose
+    // slices are full either way (profiles/r6/trsv_chunk_experiments.txt).  Fan-in above 8: 32 blocks per slice.
+    int SW = 64;
+    {
+        std::vector<aoclsparse_int> blk_of_pos((size_t)m), slice_of_blk((size_t)nb), seen;
+        for(aoclsparse_int k = 0; k < nb; k++)
+            for(aoclsparse_int q = bfirst[k]; q < bfirst[k + 1]; q++)
+                blk_of_pos[q] = k;
+        aoclsparse_int ns = 0;
+        for(aoclsparse_int l = 0; l < nlev; l++)
+            for(aoclsparse_int k = lptr[l]; k < lptr[l + 1]; k += 64, ns++)
+                for(aoclsparse_int kk = k; kk < std::min<aoclsparse_int>(k + 64, lptr[l + 1]); kk++)
+                    slice_of_blk[kk] = ns;
+        long long fan = 0;
+        for(aoclsparse_int l = 0; l < nlev; l++)
+            for(aoclsparse_int k = lptr[l]; k < lptr[l + 1]; k += 64)
+            {
+                seen.clear();
+                for(aoclsparse_int kk = k; kk < std::min<aoclsparse_int>(k + 64, lptr[l + 1]); kk++)
+                    for(aoclsparse_int p = pptr[bfirst[kk]]; p < pptr[bfirst[kk] + 1]; p++)
+                        seen.push_back(slice_of_blk[blk_of_pos[pind[p]]]);
+                std::sort(seen.begin(), seen.end());
+                fan += std::unique(seen.begin(), seen.end()) - seen.begin();
+            }
+        bp.slice_fan_in = ns > 0 ? (double)fan / (double)ns : 0.0;
+        if(bp.slice_fan_in > 8.0)
+            SW = 32;
+    }
     for(aoclsparse_int l = 0; l < nlev; l++)
-        for(aoclsparse_int k = lptr[l]; k < lptr[l + 1]; k += 64)
+        for(aoclsparse_int k = lptr[l]; k < lptr[l + 1]; k += SW)
             slices.push_back(k);
     slices.push_back(nb);
     {
@@ -412,7 +443,7 @@ static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, T
         for(aoclsparse_int l = 0; l < nlev; l++)
         {
             slices.push_back(first);
-            first += (lptr[l + 1] - lptr[l] + 63) / 64;
+            first += (lptr[l + 1] - lptr[l] + SW - 1) / SW;
         }
         slices.push_back(first);
     }
@@ -603,7 +634,7 @@ static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, T
         }
         cp.model_us       = total;
         // (the lane-per-block schedule, measured per block level: 1.69 us with every block in registers, 2.51 us with the larger shape)
-        cp.model_block_us = (double)nlev * (max_rows <= 5 ? (max_ext <= 16 ? 1.7 : (max_ext <= 20 ? 2.35 : 2.55)) : 2.55);
+        cp.model_block_us = (double)nlev * (max_rows <= 5 ? (max_ext <= 16 ? 1.7 : (max_ext <= 20 ? (bp.slice_fan_in > 8.0 ? 2.15 : 2.35) : 2.55)) : 2.55);
         lt.lap("chunks: steps + dependency lists + model");
         // aoclsparse_mi355_set_option(trsv_chunks, ...): -1 the model decides (default), 0 never, 1 whenever the plan can be built
         const int want = plan_option(aoclsparse_mi355_option_trsv_chunks);
