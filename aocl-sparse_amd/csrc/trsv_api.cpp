@@ -372,6 +372,38 @@ static aoclsparse_status build_blocked(aoclsparse_int m, const Triangle<T> &t, T
     std::vector<aoclsparse_int> order((size_t)nb), next(lptr.begin(), lptr.end() - 1);
     for(aoclsparse_int bq = 0; bq < nb; bq++)
         order[next[blev[bq]]++] = bq;
+    // ... and inside a level, by the place of a block's LAST dependency in the level below (stable: the natural order where that says
+    // nothing -- a mesh numbered line by line is left as it is).  Neighbours in a slice then wait for the same producer slices: fan-in of a
+    // slice 15.7 -> 13.5 on the unstructured shell-like factor, L 3.15 -> 3.00 ms, U 3.25 -> 3.06 (profiles/r6/trsv_chunk_experiments.txt
+    // v17; the first, the mean or two levels of dependencies as the key: the same within 1 %).  Positions change, chains do not: same bits.
+    {
+        std::vector<aoclsparse_int> bofx((size_t)m), rank((size_t)nb, 0);
+        for(aoclsparse_int bq = 0; bq < nb; bq++)
+            for(aoclsparse_int k = bptr[bq]; k < bptr[bq + 1]; k++)
+                bofx[brows[k]] = bq;
+        for(aoclsparse_int k = lptr[0]; k < lptr[1]; k++)
+            rank[order[k]] = k - lptr[0];
+        std::vector<std::pair<aoclsparse_int, aoclsparse_int>> keyed;
+        for(aoclsparse_int l = 1; l < nlev; l++)
+        {
+            keyed.clear();
+            for(aoclsparse_int k = lptr[l]; k < lptr[l + 1]; k++)
+            {
+                const aoclsparse_int bq = order[k], r = brows[bptr[bq]];
+                aoclsparse_int       key = -1;
+                for(aoclsparse_int p = t.ptr[r]; p < t.ptr[r + 1]; p++)
+                {
+                    const aoclsparse_int d = bofx[t.ind[p]];
+                    if(blev[d] == l - 1)
+                        key = std::max(key, rank[d]);
+                }
+                keyed.push_back({key, bq});
+            }
+            std::stable_sort(keyed.begin(), keyed.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+            for(size_t i = 0; i < keyed.size(); i++)
+                order[lptr[l] + (aoclsparse_int)i] = keyed[i].second, rank[keyed[i].second] = (aoclsparse_int)i;
+        }
+    }
     std::vector<aoclsparse_int> bfirst((size_t)nb + 1, 0), rowmap((size_t)m), pos((size_t)m);
     for(aoclsparse_int k = 0; k < nb; k++)
     {
