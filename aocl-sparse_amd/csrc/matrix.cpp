@@ -1246,6 +1246,10 @@ void drop_derived_state(aoclsparse_matrix A)
     A->dev_user.valid = A->dev_trans.valid = false; // row-block plans stay valid: structure is unchanged
     A->plan_user.sell.valid = A->plan_user.sell.tried = false; // the SELL copies hold values: rebuilt on optimize
     A->plan_trans.sell.valid = A->plan_trans.sell.tried = false;
+    // ... and so does the blocked-ELL copy of csrmm (round 6: it was left standing, and a product after aoclsparse_?set_value /
+    // ?update_values on a block-dense handle used the OLD values -- found by tests/test_gpu_r6.py)
+    A->plan_user.bell.valid = A->plan_user.bell.tried = false;
+    A->plan_trans.bell.valid = A->plan_trans.bell.tried = false;
     A->dev_diag.release();
     for(auto &p : A->trsv_plan)
         p.valid = p.rows_valid = false, p.nlevels = -1, p.blk.valid = p.blk.tried = false, p.blk.chunk.valid = p.blk.chunk.tried = false;

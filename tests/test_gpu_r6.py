@@ -359,6 +359,24 @@ def test_blocked_ell_block_row_order_over_the_xcds_same_bits(dims, keep, forced)
                     assert L.aoclsparse_mi355_set_csrmm_beta0_overwrite(0) == 0
                 got = Cd.cpu().numpy().reshape(m, n) if order == P.ORDER_ROW else Cd.cpu().numpy()
                 assert _same_bits(got, ref), (dims, keep, forced, order, n, alpha, beta, overwrite)
+        if forced == 3:
+            # new values in place: the blocked copy AND its order list are rebuilt (same structure, same order), the product follows
+            v2 = v * rng.uniform(0.5, 1.5, len(v))
+            assert L.aoclsparse_dupdate_values(A.h, len(v2), P._ptr(v2)) == 0
+            n = 64
+            B, C0 = rng.uniform(-1, 1, m * n), rng.uniform(-1, 1, m * n)
+            so, Cr = oracle.dcsrmm("col", 1.0, 0, v2, ci, rp, m, np.ascontiguousarray(B.reshape(m, n).T).ravel(), n, m, 0.0,
+                                   np.ascontiguousarray(C0.reshape(m, n).T).ravel(), m)
+            assert so == 0
+            Cd = dev(C0)
+            os.environ["AOCLSPARSE_MI355_BELL_XCD_CHUNK"] = "3"
+            try:
+                assert P.dcsrmm(P.OP_NONE, 1.0, A, d, P.ORDER_ROW, dev(B), n, n, 0.0, Cd, n) == 0
+                torch.cuda.synchronize()
+            finally:
+                os.environ.pop("AOCLSPARSE_MI355_BELL_XCD_CHUNK", None)
+            assert A.spmv_info().mm_bell_xcd_chunk == 3
+            assert _same_bits(Cd.cpu().numpy().reshape(m, n), Cr.reshape(n, m).T)
     finally:
         L.aoclsparse_mi355_set_pointer_mode(P.PTR_AUTO)
 
