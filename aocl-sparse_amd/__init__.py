@@ -56,7 +56,7 @@ class SpmvInfo(ctypes.Structure):
 
 class TrsvInfo(ctypes.Structure):
     _fields_ = [(k, c_int32) for k in ("levels", "blocks", "block_levels", "chunks", "steps", "lds_slots", "model_chunk_us",
-                                      "model_block_us", "schedule")]
+                                      "model_block_us", "schedule", "slices", "slice_fan_in_permille")]
 
 
 MM_STATE_BUFFERS = 14

@@ -1367,7 +1367,8 @@ aoclsparse_status aoclsparse_mi355_get_trsv_info(const aoclsparse_matrix A, aocl
         return aoclsparse_status_success;
     info->levels = p.nlevels;
     if(p.blk.valid)
-        info->blocks = p.blk.nblocks, info->block_levels = p.blk.nlevels;
+        info->blocks = p.blk.nblocks, info->block_levels = p.blk.nlevels, info->slices = p.blk.nslices,
+        info->slice_fan_in_permille = (aoclsparse_int)(p.blk.slice_fan_in * 1000.0 + 0.5);
     const TrsvChunkPlan &c = p.blk.chunk;
     info->model_chunk_us = (aoclsparse_int)c.model_us, info->model_block_us = (aoclsparse_int)c.model_block_us;
     if(p.blk.valid && c.valid)

@@ -255,6 +255,8 @@ typedef struct aoclsparse_mi355_trsv_info_
     aoclsparse_int chunks, steps, lds_slots; /* two-level schedule (0: not built): chunks of consecutive blocks, steps, LDS words of the largest chunk */
     aoclsparse_int model_chunk_us, model_block_us; /* plan-time estimates of the two-level / the lane-per-block schedule */
     aoclsparse_int schedule; /* the schedule a solve with the reference chain runs now (set_trsv_schedule included) */
+    aoclsparse_int slices, slice_fan_in_permille; /* lane-per-block schedule: wavefronts (slices of <= 64 blocks of one level; 32 where
+                                                     1000 * the producer slices a slice of 64 waits for, on average, exceeds 8000) */
 } aoclsparse_mi355_trsv_info;
 DLL_PUBLIC aoclsparse_status aoclsparse_mi355_get_trsv_info(const aoclsparse_matrix     A,
                                                             aoclsparse_fill_mode        fill,

@@ -523,3 +523,47 @@ def test_row_group_csrmm_with_the_groups_band_dealt_to_the_xcds_same_bits(which)
                 assert _same_bits(Cd.cpu().numpy().reshape(m, n), ref), (which, n, alpha, beta, overwrite)
     finally:
         L.aoclsparse_mi355_set_pointer_mode(P.PTR_AUTO)
+
+
+def test_lane_per_block_trsv_on_an_irregular_numbering_narrow_slices_and_sorted_levels():
+    """The shell-like mesh with a tenth of its couplings dropped and its nodes renumbered at random inside windows of 256 (a small
+    instance of the unstructured stand-in): 5-row blocks on up to 20 dependencies, slices that wait for many producer slices -- the plan
+    then packs 32 blocks per wavefront and orders the blocks of a level by their last dependency (trsv_api.cpp).  None of that may touch
+    a row's chain: ref_trsv_*'s bits (trsv_kr.hpp:57-75) on every triangle, unit and non-unit, on the lane-per-block schedule, on the
+    automatic one, and with a pinned KT kid."""
+    from test_gpu_trsv_blocks import VARIANTS
+    from util import kt_lanes, trsv_schedule
+    m, rp, ci, v = standins.shell_like_unstructured(n=5 * 24000, width=120)
+    # ILU(0)-like triangles: the matrix itself, diagonally dominant enough for a stable solve
+    rid = np.repeat(np.arange(m), np.diff(rp))
+    v = v.copy()
+    v[ci == rid] = np.sign(v[ci == rid]) * (np.abs(v[ci == rid]) + 40.0)
+    o = oracle.dcsr_optimize(m, m, len(v), 0, rp, ci, v)
+    A = P.Matrix(0, m, m, rp, ci, v)
+    rng = np.random.default_rng(23)
+    for kind, fill, op in VARIANTS:
+        for unit in (True, False):
+            d = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=getattr(P, fill), diag=P.DIAG_UNIT if unit else P.DIAG_NON_UNIT)
+            b = rng.uniform(-1, 1, m)
+            iend = o["idiag"] if kind[0] == "l" else o["iurow"]
+            st, xr = oracle.dtrsv(kind, 0.75, m, 0, o["val"], o["ind"], o["ptr"], iend, b, unit)
+            assert st == 0
+            for sched in (4, -1):
+                with trsv_schedule(P, sched):
+                    xd = torch.full((m,), 7.0, dtype=torch.float64, device="cuda")
+                    assert P.dtrsv(getattr(P, op), 0.75, A, d, dev(b), xd) == 0
+                    torch.cuda.synchronize()
+                assert np.array_equal(xd.cpu().numpy(), xr), (kind, unit, sched)
+        info = A.trsv_info(getattr(P, fill), getattr(P, op))
+        assert info.blocks > 0 and info.block_levels > 100, (kind, info.blocks, info.block_levels)
+        # many producers per slice -> 32 blocks per wavefront: more slices than blocks / 64 would give
+        assert info.slice_fan_in_permille > 8000 and info.slices > info.blocks / 40, (kind, info.slice_fan_in_permille, info.slices, info.blocks)
+    # kid 3 on the L solve: the KT form of the block kernel on the same plan
+    d = P.Descr(mtype=P.TYPE_TRIANGULAR, fill=P.FILL_LOWER, diag=P.DIAG_NON_UNIT)
+    b = rng.uniform(-1, 1, m)
+    st, xk = oracle.trsv_kt("l", kt_lanes(3, np.float64), 0.75, m, 0, o["val"], o["ind"], o["ptr"], o["idiag"], b, False)
+    assert st == 0
+    xd = torch.full((m,), 7.0, dtype=torch.float64, device="cuda")
+    assert P.dtrsv(P.OP_NONE, 0.75, A, d, dev(b), xd, kid=3) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(xd.cpu().numpy().view(np.uint64), xk.view(np.uint64))
