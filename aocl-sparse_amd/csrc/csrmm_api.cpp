@@ -1222,6 +1222,8 @@ static aoclsparse_status clone_mm_state(const _aoclsparse_matrix &A, _aoclsparse
     MmGroups       &gr = pr.mm;
     gr.runs_tried = ga.runs_tried, gr.row_runs = ga.row_runs, gr.band = ga.band;
     MI355_CLONE(gr.run_order, ga.run_order);
+    gr.slab_nblocks = ga.slab_nblocks;
+    MI355_CLONE(gr.slab_blocks, ga.slab_blocks);
     gr.ngroups = ga.ngroups, gr.max_rows = ga.max_rows, gr.valid = ga.valid, gr.tried = ga.tried;
     MI355_CLONE(gr.first, ga.first);
     gr.pairs_tried = ga.pairs_tried, gr.pairs = ga.pairs, gr.npairs = ga.npairs, gr.nsingles = ga.nsingles;
@@ -1234,6 +1236,13 @@ static aoclsparse_status clone_mm_state(const _aoclsparse_matrix &A, _aoclsparse
     bl.tried = ba.tried, bl.valid = ba.valid, bl.nbr = ba.nbr, bl.width = ba.width, bl.nblocks = ba.nblocks, bl.fill = ba.fill;
     MI355_CLONE(bl.val, ba.val);
     MI355_CLONE(bl.bcol, ba.bcol);
+    bl.order_len = ba.order_len, bl.xcd_chunk = ba.xcd_chunk, bl.model_fetches = ba.model_fetches;
+    bl.model_fetches_launch_order = ba.model_fetches_launch_order;
+    for(int i = 0; i < 3; i++)
+        bl.lattice[i] = ba.lattice[i];
+    for(int i = 0; i < 2; i++)
+        bl.region[i] = ba.region[i], bl.region_cut[i] = ba.region_cut[i];
+    MI355_CLONE(bl.order, ba.order);
 #undef MI355_CLONE
     MI355_HIP_TRY(hipStreamSynchronize(s));
     r.valid  = true;
