@@ -567,3 +567,37 @@ def test_lane_per_block_trsv_on_an_irregular_numbering_narrow_slices_and_sorted_
     assert P.dtrsv(P.OP_NONE, 0.75, A, d, dev(b), xd, kid=3) == 0
     torch.cuda.synchronize()
     assert np.array_equal(xd.cpu().numpy().view(np.uint64), xk.view(np.uint64))
+
+
+def test_multi_device_replicas_carry_the_order_plans():
+    """aoclsparse_mi355_dcsrmm_multi with three slots on device 0: the replicas are device-to-device clones of the primary's state --
+    including the blocked-ELL order list (forced chunks of 3 block rows) and, for a banded matrix, the row blocks along its lines
+    (13-column slabs: the narrow kernel).  Every slot's slab equals the single-call product bit for bit, also after a value update."""
+    st, dev0, _, _ = P.device_info()
+    assert st == 0
+    rng = np.random.default_rng(77)
+    m, rp, ci, v = standins.block_dense(12, 16, 16, seed=5)
+    A, d = _bell_handle(rp, ci, v, m, 3)
+    assert A.spmv_info().mm_bell_xcd_chunk == 3
+    from util import laplace5
+    ml, rpl, cil, vl = laplace5(300)
+    Al = P.Matrix(0, ml, ml, rpl, cil, vl)
+    assert L.aoclsparse_set_mm_hint(Al.h, P.OP_NONE, d.h, 10) == 0 and L.aoclsparse_optimize(Al.h) == 0
+    for H, mm, vals, n in ((A, m, v, 192), (Al, ml, vl, 40)):
+        B, C0 = rng.uniform(-1, 1, mm * n), rng.uniform(-1, 1, mm * n)
+        for rnd in range(2):
+            ref, C = C0.copy(), C0.copy()
+            assert P.dcsrmm(P.OP_NONE, 1.25, H, d, P.ORDER_ROW, B, n, n, -0.5, ref, n) == 0
+            assert P.dcsrmm_multi(P.OP_NONE, 1.25, H, d, P.ORDER_ROW, B, n, n, -0.5, C, n, [dev0] * 3) == 0
+            assert np.array_equal(C, ref), (mm, rnd)
+            if rnd == 0:
+                assert L.aoclsparse_mi355_replicas_cloned(H.h) == 2
+                v2 = np.ascontiguousarray(vals * rng.uniform(0.5, 1.5, len(vals)))
+                os.environ["AOCLSPARSE_MI355_BELL_XCD_CHUNK"] = "3"
+                try:
+                    assert L.aoclsparse_dupdate_values(H.h, len(v2), P._ptr(v2)) == 0
+                    # (the next products rebuild the value-holding copies, on the primary and on fresh replicas)
+                    chk = C0.copy()
+                    assert P.dcsrmm(P.OP_NONE, 1.25, H, d, P.ORDER_ROW, B, n, n, -0.5, chk, n) == 0
+                finally:
+                    os.environ.pop("AOCLSPARSE_MI355_BELL_XCD_CHUNK", None)
